@@ -1,0 +1,110 @@
+/* rpvg_batch.h — plain-C description of the data that crosses the inference
+ * hot path of rpvg, flattened so that it can cross a C ABI.
+ *
+ * What it replaces in the reference (paths relative to the rpvg checkout):
+ *   - input : `const vector<ReadPathProbabilities> & cluster_probs` and
+ *             `PathClusterEstimates::paths` as handed to
+ *             `PathEstimator::estimate()`            src/path_estimator.hpp:23,
+ *             filled by the caller                   src/main.cpp:846-973;
+ *             row type                               src/read_path_probabilities.hpp:39-43
+ *             path type                              src/path_cluster_estimates.hpp:15-33
+ *   - output: the remaining fields of `PathClusterEstimates`
+ *                                                    src/path_cluster_estimates.hpp:49-57
+ *   - knobs : the command-line options of this path  src/main.cpp:402-418
+ *
+ * A batch is K clusters back to back.  Everything is caller-owned host memory,
+ * read-only for the callee.  Cluster k owns rows
+ * [cluster_row_off[k], cluster_row_off[k+1]) and paths
+ * [cluster_path_off[k], cluster_path_off[k+1]); path indices inside rows are
+ * cluster-local (0 .. N_k-1), exactly as in ReadPathProbabilities::pathProbs().
+ */
+#ifndef RPVG_BATCH_H
+#define RPVG_BATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rpvg_cluster_batch {
+    uint32_t num_clusters;             /* K */
+    const uint64_t * cluster_row_off;  /* [K+1] */
+    const uint64_t * cluster_path_off; /* [K+1] */
+
+    /* rows: one per merged ReadPathProbabilities */
+    const uint32_t * row_count;        /* [R]   readCount()                         */
+    const double * row_noise;          /* [R]   noiseProb()                         */
+    const uint64_t * row_grp_off;      /* [R+1] range of (prob, path list) groups   */
+    const double * grp_prob;           /* [G]   pathProbs()[g].first, ascending     */
+    const uint64_t * grp_idx_off;      /* [G+1] range into path_idx                 */
+    const uint32_t * path_idx;         /* [NNZ] pathProbs()[g].second, cluster-local */
+
+    /* paths: the PathInfo fields the estimators read */
+    const uint32_t * path_group_id;     /* [P]   PathInfo::group_id                 */
+    const uint32_t * path_source_count; /* [P]   PathInfo::source_count             */
+    const uint64_t * path_source_off;   /* [P+1] range into source_id               */
+    const uint32_t * source_id;         /* [S]   PathInfo::source_ids (any order)   */
+    const double * path_effective_length; /* [P] PathInfo::effective_length (TPM only; may be NULL) */
+} rpvg_cluster_batch;
+
+/* Every option of src/main.cpp that reaches the estimators, same defaults
+ * (see rpvg_params_default()). */
+typedef struct rpvg_params {
+    uint32_t max_em_its;        /* --max-em-its        10000   main.cpp:416 */
+    double max_rel_em_conv;     /* --max-rel-em-conv   0.001   main.cpp:417 */
+    uint32_t num_gibbs_samples; /* -n                  0       main.cpp:415 */
+    uint32_t gibbs_thin_its;    /* --gibbs-thin-its    25      main.cpp:418 */
+    double prob_precision;      /* --prob-precision    1e-8    main.cpp:402 */
+    uint32_t ploidy;            /* -y                  2       main.cpp:407 */
+    double min_hap_prob;        /* --min-hap-prob      0.001   main.cpp:409 */
+    int32_t ind_hap_inference;  /* --ind-hap-inference 0       main.cpp:410 */
+    int32_t use_hap_gibbs;      /* --use-hap-gibbs     0       main.cpp:411 */
+    uint32_t rng_seed;          /* -r; cluster i uses mt19937(rng_seed + i)  main.cpp:976 */
+} rpvg_params;
+
+static inline rpvg_params rpvg_params_default(void) {
+    rpvg_params p;
+    p.max_em_its = 10000;
+    p.max_rel_em_conv = 0.001;
+    p.num_gibbs_samples = 0;
+    p.gibbs_thin_its = 25;
+    p.prob_precision = 1e-8;
+    p.ploidy = 2;
+    p.min_hap_prob = 0.001;
+    p.ind_hap_inference = 0;
+    p.use_hap_gibbs = 0;
+    p.rng_seed = 0;
+    return p;
+}
+
+/* Read-only view of the estimates of a batch (callee-owned until the result
+ * handle is freed).  Cluster k owns group sets [set_off[k], set_off[k+1]);
+ * set s owns members [member_off[s], member_off[s+1]) — cluster-local path
+ * indices, PathClusterEstimates::path_group_sets — and posteriors[s];
+ * cluster k owns abundances [abund_off[k], abund_off[k+1]) laid out as in
+ * PathClusterEstimates::abundances (one per set for `transcripts`/`strains`,
+ * one per set member for `haplotype-transcripts`, none for `haplotypes`).
+ * em_* is instrumentation the reference does not have: the iteration count
+ * of every EM solve and the cluster-local paths that formed its columns. */
+typedef struct rpvg_estimates_view {
+    uint32_t num_clusters;
+    const uint64_t * set_off;     /* [K+1] */
+    const uint64_t * member_off;  /* [S+1] */
+    const uint32_t * members;     /* [M]   */
+    const double * posteriors;    /* [S]   */
+    const uint64_t * abund_off;   /* [K+1] */
+    const double * abundances;    /* [A]   */
+    const double * noise_count;   /* [K]   */
+    const double * total_count;   /* [K]   */
+    const uint64_t * em_off;      /* [K+1] EM solves per cluster */
+    const uint32_t * em_iters;    /* [E]   */
+    const uint64_t * em_col_off;  /* [E+1] */
+    const uint32_t * em_cols;     /* [..]  */
+} rpvg_estimates_view;
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RPVG_BATCH_H */

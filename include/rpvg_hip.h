@@ -1,0 +1,179 @@
+/* rpvg_hip.h — C ABI of the MI355X (gfx950) engine behind rpvg's inference
+ * hot path.  extern "C", plain pointers and sizes only; implemented by
+ * rpvg_amd/csrc/librpvg_hip.so (hand-written HIP kernels).
+ *
+ * The reference (C++17, no FFI today) does all of this arithmetic inside the
+ * PathEstimator class hierarchy with Eigen; each entry point below names the
+ * reference code whose arithmetic it takes over (paths relative to the rpvg
+ * checkout).  The host-side C++ classes in rpvg_amd/host keep the reference's
+ * PathEstimator::estimate() interface and call only these functions;
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative rpvg_hip_status
+ *     otherwise; never throws, never aborts; rpvg_hip_last_error() describes
+ *     the last failure on the calling thread.
+ *   - "host" pointers are ordinary host memory owned by the caller; "device"
+ *     pointers are memory of the context's GPU (rpvg_hip_malloc).
+ *   - a context is bound to one GPU and owns one HIP stream; calls on one
+ *     context are serialised internally, different contexts are independent.
+ *   - there is NO CPU fallback: without a usable GPU rpvg_hip_create fails.
+ */
+#ifndef RPVG_HIP_H
+#define RPVG_HIP_H
+
+#include <stdint.h>
+
+#include "rpvg_batch.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rpvg_hip_status {
+    RPVG_HIP_OK = 0,
+    RPVG_HIP_ERR_NO_DEVICE = -1,  /* no gfx950-compatible GPU / HIP runtime unusable */
+    RPVG_HIP_ERR_RUNTIME = -2,    /* a HIP call failed (see last_error)              */
+    RPVG_HIP_ERR_INVALID = -3,    /* argument validation failed                      */
+    RPVG_HIP_ERR_ALLOC = -4       /* host or device allocation failed                */
+} rpvg_hip_status;
+
+typedef struct rpvg_hip_ctx rpvg_hip_ctx;
+typedef struct rpvg_hip_batch rpvg_hip_batch;   /* device-resident cluster batch          */
+typedef struct rpvg_hip_groups rpvg_hip_groups; /* device-resident group (column-set) matrices */
+
+/* ---- context ------------------------------------------------------------ */
+int rpvg_hip_device_count(int * count);
+int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out);
+void rpvg_hip_destroy(rpvg_hip_ctx * ctx);
+const char * rpvg_hip_last_error(void);
+int rpvg_hip_synchronize(rpvg_hip_ctx * ctx);
+/* name of the GPU, number of CUs, bytes of device memory */
+int rpvg_hip_device_info(rpvg_hip_ctx * ctx, char * name, uint32_t name_cap, uint32_t * num_cus, uint64_t * mem_bytes);
+
+/* device memory helpers (for callers that keep matrices resident) */
+int rpvg_hip_malloc(rpvg_hip_ctx * ctx, uint64_t bytes, void ** device_ptr_out);
+int rpvg_hip_free(rpvg_hip_ctx * ctx, void * device_ptr);
+int rpvg_hip_memcpy_h2d(rpvg_hip_ctx * ctx, void * device_dst, const void * host_src, uint64_t bytes);
+int rpvg_hip_memcpy_d2h(rpvg_hip_ctx * ctx, void * host_dst, const void * device_src, uint64_t bytes);
+
+/* ---- cluster batch ------------------------------------------------------ */
+/* Copies the sparse rows of K clusters to the GPU once; every later call
+ * refers to clusters by their index in this batch.  Replaces the per-call
+ * walk over `vector<ReadPathProbabilities>` in constructProbabilityMatrix /
+ * constructPartialProbabilityMatrix / constructGroupedProbabilityMatrix
+ * (src/path_estimator.cpp:55-154): the (probability, path list) groups are
+ * expanded to (path, probability) entries on the GPU. */
+int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * host_batch, rpvg_hip_batch ** batch_out);
+void rpvg_hip_batch_free(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch);
+
+/* ---- EM abundance solves ------------------------------------------------ */
+/* One EM problem = one cluster restricted to a strictly ascending list of its
+ * paths (all of them for `-i transcripts`, a diplotype's path subset for
+ * `-i haplotype-transcripts`), plus the noise component. */
+typedef struct rpvg_hip_em_problems {
+    uint32_t num_problems;
+    const uint32_t * cluster;  /* host [P]   index into the uploaded batch          */
+    const uint64_t * col_off;  /* host [P+1] range into col_path                    */
+    const uint32_t * col_path; /* host       cluster-local path of each column      */
+} rpvg_hip_em_problems;
+
+typedef struct rpvg_hip_em_results {
+    double * abundances;   /* host [col_off[P]]  expected read count per column, laid out like col_path */
+    double * noise_count;  /* host [P] */
+    double * total_count;  /* host [P] */
+    uint32_t * iterations; /* host [P] EM iterations executed */
+} rpvg_hip_em_results;
+
+/* For every problem: build the row-normalised probability matrix of the
+ * column subset with the noise column appended, and run the EM fixed point
+ * to the reference's stop rule; everything on the GPU.  Takes over
+ *   constructPartialProbabilityMatrix       src/path_estimator.cpp:79-113
+ *   addNoiseAndNormalizeProbabilityMatrix   src/path_estimator.cpp:156-166
+ *   EMAbundanceEstimator                    src/path_abundance_estimator.cpp:47-114
+ * (start value 1/float(C), convergence over components >= 1e-8 for 10
+ * consecutive iterations, sub-1e-8 abundances moved to noise_count).
+ * readCollapseProbabilityMatrix (src/path_estimator.cpp:219-259) is not
+ * replayed: merging rows equal within prob_precision changes no sum beyond
+ * prob_precision; rows without any selected path are folded into one exact
+ * scalar instead. */
+int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t max_em_its, double max_rel_em_conv,
+                      const rpvg_hip_em_problems * problems, rpvg_hip_em_results * results);
+
+/* Same EM on a dense matrix that is already resident on the GPU: row-major,
+ * `ld` doubles between rows (ld even), columns [0, C-1) = paths and column
+ * C-1 = noise, already normalised; counts = read count per row.  Used for
+ * clusters large enough to stream from HBM (one 1M x 2k cluster = 16 GB).
+ * abundances (host) receives C-1 values. */
+int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matrix, uint64_t num_rows, uint32_t num_cols,
+                      uint64_t ld, const double * device_counts, double total_count, uint32_t max_em_its,
+                      double max_rel_em_conv, double * abundances, double * noise_count, uint32_t * iterations);
+
+/* Builds the dense normalised matrix (layout above) of one cluster of an
+ * uploaded batch, all paths + noise (constructProbabilityMatrix +
+ * addNoiseAndNormalizeProbabilityMatrix, src/path_estimator.cpp:55-77,156-166).
+ * device_matrix needs R*ld doubles, device_counts R doubles. */
+int rpvg_hip_dense_from_cluster(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t cluster,
+                                double * device_matrix, uint64_t ld, double * device_counts, double * total_count);
+
+/* ---- group (haplotype / diplotype) log-likelihoods ---------------------- */
+/* A group matrix has one column per path group: M[i][g] = sum of the row's
+ * probabilities over the paths of group g (constructGroupedProbabilityMatrix,
+ * src/path_estimator.cpp:115-154; a group of one path gives
+ * constructProbabilityMatrix).  normalise != 0 applies
+ * addNoiseAndNormalizeProbabilityMatrix (as NestedPathAbundanceEstimator does,
+ * src/path_abundance_estimator.cpp:440-446); 0 keeps raw probabilities (as
+ * PathGroupPosteriorEstimator does, src/path_posterior_estimator.cpp:45). */
+typedef struct rpvg_hip_group_spec {
+    uint32_t num_matrices;
+    const uint32_t * cluster;         /* host [M]   */
+    const uint64_t * group_off;       /* host [M+1] columns of each matrix, range into group_path_off */
+    const uint64_t * group_path_off;  /* host [G+1] */
+    const uint32_t * group_path;      /* host       cluster-local paths of each column */
+    int32_t normalise;
+} rpvg_hip_group_spec;
+
+int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec,
+                          rpvg_hip_groups ** groups_out);
+void rpvg_hip_groups_free(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups);
+
+/* Evaluates, for every request q,
+ *   out[q] = sum_i count_i * log( noise_i + ( sum_{m < width, members[q*width+m] != UINT32_MAX}
+ *                                             M[i][members[q*width+m]]  +  (add_rowmax[q] ? max_g M[i][g] : 0) ) / divisor )
+ * on matrix[q].  This is the `read_counts * (...).array().log().matrix()`
+ * contraction of calculatePathGroupPosteriorsFull (src/path_estimator.cpp:354-361),
+ * calculatePathGroupPosteriorsBounded (:424-427 with add_rowmax, :439) and the
+ * conditional of estimatePathGroupPosteriorsGibbs (:527-545); adding log
+ * frequencies, permutation counts, pruning and log-sum-exp stay on the host. */
+int rpvg_hip_group_loglik(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, uint32_t num_requests,
+                          const uint32_t * matrix, const uint32_t * members, uint32_t width, double divisor,
+                          const uint8_t * add_rowmax, double * out);
+
+/* ---- synthetic workload (bench / tests only) ---------------------------- */
+/* Fills a dense normalised R x C matrix (layout of rpvg_hip_em_dense) and unit
+ * counts on the GPU from a counter-based generator: the "1M read pairs x 2k
+ * paths single dense cluster" configuration. */
+int rpvg_hip_synth_dense_cluster(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t num_rows, uint32_t num_paths,
+                                 double * device_matrix, uint64_t ld, double * device_counts);
+
+/* ---- instrumentation ----------------------------------------------------- */
+/* Device time (HIP events on the context's stream) and launch count of the
+ * kernels of each family since the last reset, plus the algorithmic bytes
+ * they processed (DESIGN.md defines the per-launch figure). */
+typedef struct rpvg_hip_kernel_stats {
+    double em_sparse_ms;      uint64_t em_sparse_launches;   double em_sparse_alg_bytes;
+    double em_dense_ms;       uint64_t em_dense_launches;    double em_dense_alg_bytes;
+    double loglik_ms;         uint64_t loglik_launches;      double loglik_evals;
+    double build_ms;          uint64_t build_launches;
+    double h2d_ms;            double h2d_bytes;
+    uint64_t em_iterations_total;
+} rpvg_hip_kernel_stats;
+
+int rpvg_hip_stats_get(rpvg_hip_ctx * ctx, rpvg_hip_kernel_stats * stats_out);
+int rpvg_hip_stats_reset(rpvg_hip_ctx * ctx);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RPVG_HIP_H */

@@ -1,0 +1,138 @@
+"""ctypes loader for the CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module.  The product package ``rpvg_amd`` never does.
+
+"parity unpinned" — see oracle/rpvg_oracle.hpp for what that covers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from rpvg_amd.batch import CClusterBatch, CEstimatesView, CParams, ClusterBatch, ClusterEstimates, decode_view
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "librpvg_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/_build/librpvg_oracle.so with the committed Makefile (g++ only)."""
+    srcs = [os.path.join(_HERE, f) for f in ("rpvg_oracle.cpp", "rpvg_oracle_capi.cpp", "rpvg_oracle.hpp")]
+    srcs.append(os.path.join(_HERE, "..", "include", "rpvg_batch.h"))
+    stale = force or not os.path.exists(_SO) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.rpvg_oracle_run.restype = C.c_void_p
+        L.rpvg_oracle_run.argtypes = [C.c_char_p, C.POINTER(CParams), C.POINTER(CClusterBatch), C.c_int,
+                                      C.POINTER(C.c_double)]
+        L.rpvg_oracle_view.argtypes = [C.c_void_p, C.POINTER(CEstimatesView)]
+        L.rpvg_oracle_free.argtypes = [C.c_void_p]
+        L.rpvg_oracle_em_dense.restype = C.c_uint32
+        L.rpvg_oracle_em_dense.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_double,
+                                           C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double)]
+        L.rpvg_oracle_min_path_cover.restype = C.c_uint32
+        L.rpvg_oracle_min_path_cover.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rpvg_oracle_group_posteriors.restype = C.c_uint32
+        L.rpvg_oracle_group_posteriors.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_uint32, C.c_int, C.c_double, C.c_uint32,
+                                                   C.c_void_p, C.c_void_p]
+        L.rpvg_oracle_num_permutations.restype = C.c_uint32
+        L.rpvg_oracle_num_permutations.argtypes = [C.c_void_p, C.c_uint32]
+        L.rpvg_oracle_add_log.restype = C.c_double
+        L.rpvg_oracle_add_log.argtypes = [C.c_double, C.c_double]
+        L.rpvg_oracle_double_compare.restype = C.c_int
+        L.rpvg_oracle_double_compare.argtypes = [C.c_double, C.c_double]
+        L.rpvg_oracle_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def run(model: str, params: CParams, batch: ClusterBatch, num_threads: int = 1) -> Tuple[List[ClusterEstimates], float]:
+    """estimate() over every cluster of the batch (OpenMP over clusters as src/main.cpp:829)."""
+    L = lib()
+    cb = batch.as_c()
+    secs = C.c_double(0)
+    h = L.rpvg_oracle_run(model.encode(), C.byref(params), C.byref(cb), int(num_threads), C.byref(secs))
+    try:
+        view = CEstimatesView()
+        L.rpvg_oracle_view(h, C.byref(view))
+        out = decode_view(view)
+    finally:
+        L.rpvg_oracle_free(h)
+    return out, secs.value
+
+
+def em_dense(P: np.ndarray, counts: np.ndarray, max_em_its: int = 10000, max_rel_em_conv: float = 1e-3):
+    """EMAbundanceEstimator on a normalised dense R x C matrix (last column = noise).
+
+    Returns (abundances[C-1], noise_count, total_count, iterations, seconds)."""
+    L = lib()
+    Pf = np.asfortranarray(P, dtype=np.float64)
+    R, Cn = Pf.shape
+    c = np.ascontiguousarray(counts, dtype=np.float64)
+    ab = np.zeros(Cn - 1, dtype=np.float64)
+    noise, total, secs = C.c_double(0), C.c_double(0), C.c_double(0)
+    its = L.rpvg_oracle_em_dense(Pf.ctypes.data, R, Cn, c.ctypes.data, max_em_its, max_rel_em_conv, ab.ctypes.data,
+                                 C.byref(noise), C.byref(total), C.byref(secs))
+    return ab, noise.value, total.value, int(its), secs.value
+
+
+def min_path_cover(cover: np.ndarray, read_counts, path_weights) -> List[int]:
+    L = lib()
+    cv = np.ascontiguousarray(cover, dtype=np.uint8)
+    R, N = cv.shape
+    rc = np.ascontiguousarray(read_counts, dtype=np.float64)
+    pw = np.ascontiguousarray(path_weights, dtype=np.float64)
+    out = np.zeros(N, dtype=np.uint32)
+    n = L.rpvg_oracle_min_path_cover(cv.ctypes.data, R, N, rc.ctypes.data, pw.ctypes.data, out.ctypes.data)
+    return [int(x) for x in out[:n]]
+
+
+def group_posteriors(P: np.ndarray, noise, counts, path_counts, group_size: int, bounded: bool = False,
+                     min_rel_lik: float = 1e-8):
+    """Full / Bounded group posteriors.  Returns ([members tuple...], posteriors)."""
+    L = lib()
+    Pf = np.asfortranarray(P, dtype=np.float64)
+    R, N = Pf.shape
+    nz = np.ascontiguousarray(noise, dtype=np.float64)
+    c = np.ascontiguousarray(counts, dtype=np.float64)
+    pc = np.ascontiguousarray(path_counts, dtype=np.uint32)
+    from math import comb
+    max_sets = comb(N + group_size - 1, group_size)
+    mem = np.zeros(max_sets * group_size, dtype=np.uint32)
+    post = np.zeros(max_sets, dtype=np.float64)
+    n = L.rpvg_oracle_group_posteriors(Pf.ctypes.data, R, N, nz.ctypes.data, c.ctypes.data, pc.ctypes.data, group_size,
+                                       1 if bounded else 0, min_rel_lik, max_sets, mem.ctypes.data, post.ctypes.data)
+    assert n != 0xFFFFFFFF
+    sets = [tuple(int(x) for x in mem[i * group_size:(i + 1) * group_size]) for i in range(n)]
+    return sets, post[:n].copy()
+
+
+def num_permutations(values) -> int:
+    v = np.ascontiguousarray(values, dtype=np.uint32)
+    return int(lib().rpvg_oracle_num_permutations(v.ctypes.data, len(v)))
+
+
+def add_log(x: float, y: float) -> float:
+    return float(lib().rpvg_oracle_add_log(x, y))
+
+
+def max_threads() -> int:
+    return int(lib().rpvg_oracle_max_threads())

@@ -1,0 +1,111 @@
+// Internals shared by the translation units of librpvg_hip.so (gfx950 only).
+#ifndef RPVG_HIP_COMMON_HPP
+#define RPVG_HIP_COMMON_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rpvg_hip.h"
+
+namespace rpvg_hip_detail {
+
+// ---- error reporting --------------------------------------------------------
+void setError(const char * fmt, ...);
+
+#define RPVG_HIP_CHECK(expr)                                                                                  \
+    do {                                                                                                      \
+        hipError_t err__ = (expr);                                                                            \
+        if (err__ != hipSuccess) {                                                                            \
+            rpvg_hip_detail::setError("%s failed at %s:%d: %s", #expr, __FILE__, __LINE__, hipGetErrorString(err__)); \
+            return RPVG_HIP_ERR_RUNTIME;                                                                      \
+        }                                                                                                     \
+    } while (0)
+
+#define RPVG_REQUIRE(cond, ...)                       \
+    do {                                              \
+        if (!(cond)) {                                \
+            rpvg_hip_detail::setError(__VA_ARGS__);   \
+            return RPVG_HIP_ERR_INVALID;              \
+        }                                             \
+    } while (0)
+
+// ---- device buffer (owning) -------------------------------------------------
+template <typename T>
+struct DeviceBuffer {
+    T * ptr = nullptr;
+    size_t count = 0;
+    DeviceBuffer() {}
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer & operator=(const DeviceBuffer &) = delete;
+    ~DeviceBuffer() { release(); }
+    void release() {
+        if (ptr) (void) hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        count = n;
+        if (n == 0) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T));
+    }
+    hipError_t upload(const T * host, size_t n, hipStream_t stream) {
+        hipError_t e = alloc(n);
+        if (e != hipSuccess || n == 0) return e;
+        return hipMemcpyAsync(ptr, host, n * sizeof(T), hipMemcpyHostToDevice, stream);
+    }
+    hipError_t download(T * host, hipStream_t stream) const {
+        if (count == 0) return hipSuccess;
+        return hipMemcpyAsync(host, ptr, count * sizeof(T), hipMemcpyDeviceToHost, stream);
+    }
+};
+
+// ---- kernel-family timing ---------------------------------------------------
+enum KernelFamily { FAM_EM_SPARSE = 0, FAM_EM_DENSE, FAM_LOGLIK, FAM_BUILD, FAM_H2D, FAM_COUNT };
+
+struct TimedSpan {
+    hipEvent_t start, stop;
+    int family;
+};
+
+}  // namespace rpvg_hip_detail
+
+struct rpvg_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t props;
+    std::mutex mutex;  // serialises calls on this context
+    std::vector<rpvg_hip_detail::TimedSpan> spans;
+    rpvg_hip_kernel_stats stats;
+
+    // Opens a timed span on the stream; returns its index (or -1 on failure).
+    int spanBegin(int family);
+    void spanEnd(int idx);
+    // Folds all finished spans into stats (synchronises the stream).
+    int foldSpans();
+};
+
+// Device-resident batch: the expanded CSR of every cluster.
+struct rpvg_hip_batch {
+    uint32_t num_clusters = 0;
+    uint64_t num_rows = 0, num_entries = 0, num_paths = 0;
+    // host copies of the small per-cluster offsets (needed to size problems)
+    std::vector<uint64_t> h_cluster_row_off, h_cluster_path_off, h_cluster_ent_off;
+    rpvg_hip_detail::DeviceBuffer<uint64_t> cluster_row_off;   // [K+1]
+    rpvg_hip_detail::DeviceBuffer<uint64_t> cluster_path_off;  // [K+1]
+    rpvg_hip_detail::DeviceBuffer<double> row_count;           // [R] read count as double
+    rpvg_hip_detail::DeviceBuffer<double> row_noise;           // [R]
+    rpvg_hip_detail::DeviceBuffer<uint64_t> row_ent_off;       // [R+1] entry range of each row
+    rpvg_hip_detail::DeviceBuffer<uint32_t> ent_path;          // [NNZ] cluster-local path
+    rpvg_hip_detail::DeviceBuffer<double> ent_prob;            // [NNZ]
+};
+
+#endif

@@ -1,0 +1,333 @@
+// Context, device memory helpers, cluster-batch upload and kernel timing of
+// librpvg_hip.so.  gfx950 only; no CPU fallback anywhere in this library.
+
+#include "common.hpp"
+
+namespace rpvg_hip_detail {
+
+static thread_local char g_last_error[1024] = "";
+
+void setError(const char * fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace rpvg_hip_detail
+
+using namespace rpvg_hip_detail;
+
+int rpvg_hip_ctx::spanBegin(int family) {
+    TimedSpan s;
+    s.family = family;
+    if (hipEventCreate(&s.start) != hipSuccess) return -1;
+    if (hipEventCreate(&s.stop) != hipSuccess) {
+        (void) hipEventDestroy(s.start);
+        return -1;
+    }
+    (void) hipEventRecord(s.start, stream);
+    spans.push_back(s);
+    return static_cast<int>(spans.size()) - 1;
+}
+
+void rpvg_hip_ctx::spanEnd(int idx) {
+    if (idx < 0) return;
+    (void) hipEventRecord(spans[idx].stop, stream);
+}
+
+int rpvg_hip_ctx::foldSpans() {
+    RPVG_HIP_CHECK(hipStreamSynchronize(stream));
+    for (auto & s : spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s.start, s.stop) == hipSuccess) {
+            switch (s.family) {
+                case FAM_EM_SPARSE: stats.em_sparse_ms += ms; break;
+                case FAM_EM_DENSE: stats.em_dense_ms += ms; break;
+                case FAM_LOGLIK: stats.loglik_ms += ms; break;
+                case FAM_BUILD: stats.build_ms += ms; break;
+                case FAM_H2D: stats.h2d_ms += ms; break;
+                default: break;
+            }
+        }
+        (void) hipEventDestroy(s.start);
+        (void) hipEventDestroy(s.stop);
+    }
+    spans.clear();
+    return RPVG_HIP_OK;
+}
+
+// ---- kernels: expand (probability, path list) groups to entries -------------
+
+// One thread per probability group: writes the group's probability next to
+// each of its path indices (the path indices themselves are uploaded as is).
+__global__ void expandGroupsKernel(const uint64_t num_groups, const uint64_t * __restrict__ grp_idx_off,
+                                   const double * __restrict__ grp_prob, double * __restrict__ ent_prob) {
+    const uint64_t g = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (g >= num_groups) return;
+    const double p = grp_prob[g];
+    for (uint64_t e = grp_idx_off[g]; e < grp_idx_off[g + 1]; ++e) ent_prob[e] = p;
+}
+
+// One thread per row: entry range of the row and its count as double.
+__global__ void rowMetaKernel(const uint64_t num_rows, const uint64_t * __restrict__ row_grp_off,
+                              const uint64_t * __restrict__ grp_idx_off, const uint32_t * __restrict__ row_count_u32,
+                              uint64_t * __restrict__ row_ent_off, double * __restrict__ row_count) {
+    const uint64_t r = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (r > num_rows) return;
+    row_ent_off[r] = grp_idx_off[row_grp_off[r]];
+    if (r < num_rows) row_count[r] = static_cast<double>(row_count_u32[r]);
+}
+
+extern "C" {
+
+int rpvg_hip_device_count(int * count) {
+    RPVG_REQUIRE(count != nullptr, "rpvg_hip_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        setError("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        *count = 0;
+        return RPVG_HIP_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return RPVG_HIP_OK;
+}
+
+int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) {
+    RPVG_REQUIRE(ctx_out != nullptr, "rpvg_hip_create: ctx_out is NULL");
+    *ctx_out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        setError("rpvg_hip_create: no HIP device available (%s); this engine has no CPU fallback",
+                 e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return RPVG_HIP_ERR_NO_DEVICE;
+    }
+    RPVG_REQUIRE(device >= 0 && device < n, "rpvg_hip_create: device %d out of range [0, %d)", device, n);
+    rpvg_hip_ctx * ctx = new (std::nothrow) rpvg_hip_ctx();
+    if (!ctx) {
+        setError("rpvg_hip_create: out of host memory");
+        return RPVG_HIP_ERR_ALLOC;
+    }
+    ctx->device = device;
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->props, device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        setError("rpvg_hip_create: %s", hipGetErrorString(e));
+        delete ctx;
+        return RPVG_HIP_ERR_RUNTIME;
+    }
+    if (strncmp(ctx->props.gcnArchName, "gfx950", 6) != 0) {
+        setError("rpvg_hip_create: device %d is %s; this library is built for gfx950 only", device, ctx->props.gcnArchName);
+        (void) hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return RPVG_HIP_ERR_NO_DEVICE;
+    }
+    *ctx_out = ctx;
+    return RPVG_HIP_OK;
+}
+
+void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    (void) ctx->foldSpans();
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char * rpvg_hip_last_error(void) { return g_last_error; }
+
+int rpvg_hip_synchronize(rpvg_hip_ctx * ctx) {
+    RPVG_REQUIRE(ctx != nullptr, "rpvg_hip_synchronize: ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    RPVG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RPVG_HIP_OK;
+}
+
+int rpvg_hip_device_info(rpvg_hip_ctx * ctx, char * name, uint32_t name_cap, uint32_t * num_cus, uint64_t * mem_bytes) {
+    RPVG_REQUIRE(ctx != nullptr, "rpvg_hip_device_info: ctx is NULL");
+    if (name && name_cap) {
+        snprintf(name, name_cap, "%s (%s)", ctx->props.name, ctx->props.gcnArchName);
+    }
+    if (num_cus) *num_cus = ctx->props.multiProcessorCount;
+    if (mem_bytes) *mem_bytes = ctx->props.totalGlobalMem;
+    return RPVG_HIP_OK;
+}
+
+int rpvg_hip_malloc(rpvg_hip_ctx * ctx, uint64_t bytes, void ** device_ptr_out) {
+    RPVG_REQUIRE(ctx != nullptr && device_ptr_out != nullptr, "rpvg_hip_malloc: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(device_ptr_out, bytes);
+    if (e != hipSuccess) {
+        setError("rpvg_hip_malloc: %llu bytes: %s", static_cast<unsigned long long>(bytes), hipGetErrorString(e));
+        return RPVG_HIP_ERR_ALLOC;
+    }
+    return RPVG_HIP_OK;
+}
+
+int rpvg_hip_free(rpvg_hip_ctx * ctx, void * device_ptr) {
+    RPVG_REQUIRE(ctx != nullptr, "rpvg_hip_free: ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    RPVG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    RPVG_HIP_CHECK(hipFree(device_ptr));
+    return RPVG_HIP_OK;
+}
+
+int rpvg_hip_memcpy_h2d(rpvg_hip_ctx * ctx, void * device_dst, const void * host_src, uint64_t bytes) {
+    RPVG_REQUIRE(ctx != nullptr, "rpvg_hip_memcpy_h2d: ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    RPVG_HIP_CHECK(hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RPVG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RPVG_HIP_OK;
+}
+
+int rpvg_hip_memcpy_d2h(rpvg_hip_ctx * ctx, void * host_dst, const void * device_src, uint64_t bytes) {
+    RPVG_REQUIRE(ctx != nullptr, "rpvg_hip_memcpy_d2h: ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    RPVG_HIP_CHECK(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RPVG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RPVG_HIP_OK;
+}
+
+int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_hip_batch ** batch_out) {
+    RPVG_REQUIRE(ctx != nullptr && hb != nullptr && batch_out != nullptr, "rpvg_hip_batch_upload: NULL argument");
+    *batch_out = nullptr;
+    const uint32_t K = hb->num_clusters;
+    RPVG_REQUIRE(hb->cluster_row_off && hb->cluster_path_off, "rpvg_hip_batch_upload: cluster offsets are NULL");
+    const uint64_t R = hb->cluster_row_off[K];
+    const uint64_t P = hb->cluster_path_off[K];
+    RPVG_REQUIRE(R == 0 || (hb->row_count && hb->row_noise && hb->row_grp_off && hb->grp_idx_off),
+                 "rpvg_hip_batch_upload: row arrays are NULL");
+    const uint64_t G = R ? hb->row_grp_off[R] : 0;
+    const uint64_t NNZ = G ? hb->grp_idx_off[G] : 0;
+    RPVG_REQUIRE(G == 0 || hb->grp_prob, "rpvg_hip_batch_upload: grp_prob is NULL");
+    RPVG_REQUIRE(NNZ == 0 || hb->path_idx, "rpvg_hip_batch_upload: path_idx is NULL");
+
+    // Validation of the row invariants the estimators rely on
+    // (src/main.cpp:855-887,953-973; src/read_path_probabilities.cpp:91-105,184,212-219).
+    for (uint32_t k = 0; k < K; ++k) {
+        RPVG_REQUIRE(hb->cluster_row_off[k] <= hb->cluster_row_off[k + 1] && hb->cluster_path_off[k] <= hb->cluster_path_off[k + 1],
+                     "rpvg_hip_batch_upload: cluster %u has decreasing offsets", k);
+        const uint64_t n_paths = hb->cluster_path_off[k + 1] - hb->cluster_path_off[k];
+        RPVG_REQUIRE(n_paths <= 0x7fffffffu, "rpvg_hip_batch_upload: cluster %u has too many paths", k);
+        for (uint64_t r = hb->cluster_row_off[k]; r < hb->cluster_row_off[k + 1]; ++r) {
+            const double nz = hb->row_noise[r];
+            RPVG_REQUIRE(nz > 0 && nz <= 1, "rpvg_hip_batch_upload: row %llu has noise probability %g outside (0, 1]",
+                         static_cast<unsigned long long>(r), nz);
+            for (uint64_t e = hb->grp_idx_off[hb->row_grp_off[r]]; e < hb->grp_idx_off[hb->row_grp_off[r + 1]]; ++e) {
+                RPVG_REQUIRE(hb->path_idx[e] < n_paths, "rpvg_hip_batch_upload: row %llu refers to path %u of a cluster with %llu paths",
+                             static_cast<unsigned long long>(r), hb->path_idx[e], static_cast<unsigned long long>(n_paths));
+            }
+        }
+    }
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+
+    rpvg_hip_batch * b = new (std::nothrow) rpvg_hip_batch();
+    if (!b) {
+        setError("rpvg_hip_batch_upload: out of host memory");
+        return RPVG_HIP_ERR_ALLOC;
+    }
+    b->num_clusters = K;
+    b->num_rows = R;
+    b->num_entries = NNZ;
+    b->num_paths = P;
+    b->h_cluster_row_off.assign(hb->cluster_row_off, hb->cluster_row_off + K + 1);
+    b->h_cluster_path_off.assign(hb->cluster_path_off, hb->cluster_path_off + K + 1);
+    b->h_cluster_ent_off.resize(K + 1);
+    for (uint32_t k = 0; k <= K; ++k) {
+        const uint64_t r = hb->cluster_row_off[k];
+        b->h_cluster_ent_off[k] = R ? hb->grp_idx_off[hb->row_grp_off[r]] : 0;
+    }
+
+    DeviceBuffer<uint32_t> d_row_count_u32;
+    DeviceBuffer<uint64_t> d_row_grp_off, d_grp_idx_off;
+    DeviceBuffer<double> d_grp_prob;
+
+    const int span = ctx->spanBegin(FAM_H2D);
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    ok(b->cluster_row_off.upload(hb->cluster_row_off, K + 1, ctx->stream));
+    ok(b->cluster_path_off.upload(hb->cluster_path_off, K + 1, ctx->stream));
+    ok(b->row_noise.upload(hb->row_noise, R, ctx->stream));
+    ok(d_row_count_u32.upload(hb->row_count, R, ctx->stream));
+    const uint64_t zero_off[1] = {0};
+    ok(d_row_grp_off.upload(R ? hb->row_grp_off : zero_off, R + 1, ctx->stream));
+    ok(d_grp_idx_off.upload(G ? hb->grp_idx_off : zero_off, G + 1, ctx->stream));
+    ok(d_grp_prob.upload(hb->grp_prob, G, ctx->stream));
+    ok(b->ent_path.upload(hb->path_idx, NNZ, ctx->stream));
+    ok(b->ent_prob.alloc(NNZ));
+    ok(b->row_count.alloc(R));
+    ok(b->row_ent_off.alloc(R + 1));
+    ctx->spanEnd(span);
+    ctx->stats.h2d_bytes += static_cast<double>((K + 1) * 16 + R * 12 + (R + 1) * 8 + (G + 1) * 8 + G * 8 + NNZ * 4);
+    if (e != hipSuccess) {
+        setError("rpvg_hip_batch_upload: %s", hipGetErrorString(e));
+        delete b;
+        return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
+    }
+
+    const int bspan = ctx->spanBegin(FAM_BUILD);
+    if (G > 0) {
+        const uint32_t threads = 256;
+        expandGroupsKernel<<<dim3(static_cast<uint32_t>((G + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+            G, d_grp_idx_off.ptr, d_grp_prob.ptr, b->ent_prob.ptr);
+    }
+    {
+        const uint32_t threads = 256;
+        rowMetaKernel<<<dim3(static_cast<uint32_t>((R + 1 + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+            R, d_row_grp_off.ptr, d_grp_idx_off.ptr, d_row_count_u32.ptr, b->row_ent_off.ptr, b->row_count.ptr);
+    }
+    ctx->spanEnd(bspan);
+    ctx->stats.build_launches += 2;
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // temporaries are freed on return
+    if (e != hipSuccess) {
+        setError("rpvg_hip_batch_upload: %s", hipGetErrorString(e));
+        delete b;
+        return RPVG_HIP_ERR_RUNTIME;
+    }
+    *batch_out = b;
+    return RPVG_HIP_OK;
+}
+
+void rpvg_hip_batch_free(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch) {
+    if (!batch) return;
+    if (ctx) {
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        (void) hipSetDevice(ctx->device);
+        (void) hipStreamSynchronize(ctx->stream);
+        delete batch;
+    } else {
+        delete batch;
+    }
+}
+
+int rpvg_hip_stats_get(rpvg_hip_ctx * ctx, rpvg_hip_kernel_stats * stats_out) {
+    RPVG_REQUIRE(ctx != nullptr && stats_out != nullptr, "rpvg_hip_stats_get: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = ctx->foldSpans();
+    if (rc != RPVG_HIP_OK) return rc;
+    *stats_out = ctx->stats;
+    return RPVG_HIP_OK;
+}
+
+int rpvg_hip_stats_reset(rpvg_hip_ctx * ctx) {
+    RPVG_REQUIRE(ctx != nullptr, "rpvg_hip_stats_reset: ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = ctx->foldSpans();
+    if (rc != RPVG_HIP_OK) return rc;
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    return RPVG_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,422 @@
+// EM on one large dense cluster matrix streamed from HBM (gfx950).
+//
+// Takes over EMAbundanceEstimator (src/path_abundance_estimator.cpp:47-114)
+// for a matrix that is far larger than the caches (1M x 2001 doubles = 16 GB):
+// the reference makes ~5 sweeps over R x C per iteration (temp = P.*a, row
+// sums, divide, GEMV); here one iteration is ONE read of the matrix.
+//
+// Layout (chosen by this engine, the reference is column-major): row-major,
+// `ld` doubles per row (even), so that a wave reads a row with 16-byte loads,
+// lane l owning columns {2l, 2l+1} + 128*m.  Per row the wave computes
+//   s_i = sum_j P_ij a_j   (per-lane partial + 6-step wave shuffle reduction)
+//   w_i = c_i / s_i
+//   t_j += w_i P_ij        (per-lane register accumulators, no atomics)
+// and per iteration three launches run on the stream:
+//   emDenseAccumKernel<NCHUNK>  grid-wide streaming pass, one partial t[] per block
+//   emDenseFinalizeKernel       a'_j = a_j * sum_blocks t_j / T, per-column
+//                               convergence test, OR-ed into a device flag
+//   emDenseControlKernel        the reference's stop rule (10 consecutive
+//                               converged iterations) on the device; sets `done`
+// Once `done` is set the remaining queued launches exit immediately, so the
+// host can queue iterations in chunks without a sync per iteration and the
+// loop still stops at exactly the reference's iteration.
+//
+// Deterministic: fixed row->wave assignment, fixed reduction orders.
+
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+using namespace rpvg_hip_detail;
+
+namespace {
+
+constexpr double kMinEmAbundance = 1e-8;  // src/path_abundance_estimator.cpp:11
+constexpr uint32_t kMinEmConvIts = 10;    // src/path_abundance_estimator.cpp:10
+constexpr int kAccumBlock = 256;          // 4 waves
+
+struct DenseControl {
+    uint32_t done;
+    uint32_t iterations;
+    uint32_t conv_its;
+    uint32_t viol;  // OR of per-column convergence violations of the current iteration
+};
+
+__device__ __forceinline__ double waveReduceSumD(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// One streaming pass.  NCHUNK = ceil(C / 128): the wave holds a whole row in
+// registers (2*NCHUNK doubles per lane).
+template <int NCHUNK>
+__global__ __launch_bounds__(kAccumBlock) void emDenseAccumKernel(
+    const double * __restrict__ P, const uint64_t R, const uint32_t C, const uint64_t ld,
+    const double * __restrict__ counts, const double * __restrict__ a_global, double * __restrict__ partials,
+    const uint32_t partial_ld, const DenseControl * __restrict__ ctl) {
+    if (ctl->done) return;
+    __shared__ double t_lds[kAccumBlock / 64][NCHUNK * 128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t waves_total = gridDim.x * (kAccumBlock / 64);
+    const uint32_t wave_global = blockIdx.x * (kAccumBlock / 64) + wave;
+
+    double a[NCHUNK][2], t[NCHUNK][2];
+#pragma unroll
+    for (int m = 0; m < NCHUNK; ++m) {
+        const uint32_t c0 = 2 * lane + 128 * m;
+        a[m][0] = (c0 < C) ? a_global[c0] : 0.0;
+        a[m][1] = (c0 + 1 < C) ? a_global[c0 + 1] : 0.0;
+        t[m][0] = 0.0;
+        t[m][1] = 0.0;
+    }
+
+    for (uint64_t r = wave_global; r < R; r += waves_total) {
+        const double2 * row = reinterpret_cast<const double2 *>(P + r * ld);
+        double2 v[NCHUNK];
+#pragma unroll
+        for (int m = 0; m < NCHUNK; ++m) {
+            const uint32_t c0 = 2 * lane + 128 * m;
+            if (c0 + 1 < ld) {
+                v[m] = row[lane + 64 * m];
+            } else {
+                v[m].x = (c0 < ld) ? P[r * ld + c0] : 0.0;
+                v[m].y = 0.0;
+            }
+            if (c0 >= C) v[m].x = 0.0;
+            if (c0 + 1 >= C) v[m].y = 0.0;
+        }
+        const double cnt = counts[r];
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < NCHUNK; ++m) {
+            s = fma(v[m].x, a[m][0], s);
+            s = fma(v[m].y, a[m][1], s);
+        }
+        s = waveReduceSumD(s);
+        const double w = cnt / s;
+#pragma unroll
+        for (int m = 0; m < NCHUNK; ++m) {
+            t[m][0] = fma(w, v[m].x, t[m][0]);
+            t[m][1] = fma(w, v[m].y, t[m][1]);
+        }
+    }
+
+    // combine the block's 4 waves in a fixed order, one partial vector per block
+#pragma unroll
+    for (int m = 0; m < NCHUNK; ++m) {
+        t_lds[wave][2 * lane + 128 * m] = t[m][0];
+        t_lds[wave][2 * lane + 128 * m + 1] = t[m][1];
+    }
+    __syncthreads();
+    double * out = partials + static_cast<uint64_t>(blockIdx.x) * partial_ld;
+    for (uint32_t j = threadIdx.x; j < C; j += kAccumBlock) {
+        double acc = t_lds[0][j];
+#pragma unroll
+        for (int w = 1; w < kAccumBlock / 64; ++w) acc += t_lds[w][j];
+        out[j] = acc;
+    }
+}
+
+__global__ void emDenseFinalizeKernel(const uint32_t C, const uint32_t num_partials, const uint32_t partial_ld,
+                                      const double * __restrict__ partials, double * __restrict__ a_global,
+                                      const double total_count, const double max_rel_em_conv, DenseControl * ctl) {
+    if (ctl->done) return;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    int viol = 0;
+    if (j < C) {
+        double tj = 0.0;
+        for (uint32_t b = 0; b < num_partials; ++b) tj += partials[static_cast<uint64_t>(b) * partial_ld + j];
+        const double aj = a_global[j];
+        const double an = (aj * tj) / total_count;
+        if (an >= kMinEmAbundance && fabs(an - aj) / an > max_rel_em_conv) viol = 1;
+        a_global[j] = an;
+    }
+    if (__syncthreads_or(viol) && threadIdx.x == 0) atomicOr(&ctl->viol, 1u);
+}
+
+__global__ void emDenseControlKernel(DenseControl * ctl, const uint32_t max_em_its) {
+    if (ctl->done) return;
+    ctl->iterations += 1;
+    if (ctl->viol == 0) {
+        ctl->conv_its += 1;
+        if (ctl->conv_its == kMinEmConvIts) ctl->done = 1;
+    } else {
+        ctl->conv_its = 0;
+    }
+    ctl->viol = 0;
+    if (ctl->iterations >= max_em_its) ctl->done = 1;
+}
+
+__global__ void fillConstantKernel(double * x, const uint32_t n, const double v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+
+template <int NCHUNK>
+void launchAccum(uint32_t grid, hipStream_t st, const double * P, uint64_t R, uint32_t C, uint64_t ld,
+                 const double * counts, const double * a, double * partials, uint32_t partial_ld,
+                 const DenseControl * ctl) {
+    emDenseAccumKernel<NCHUNK><<<dim3(grid), dim3(kAccumBlock), 0, st>>>(P, R, C, ld, counts, a, partials, partial_ld, ctl);
+}
+
+// ---- dense builder from the sparse rows of one cluster -----------------------
+
+__global__ void denseFromClusterKernel(const uint64_t r0, const uint64_t num_rows, const uint32_t num_paths,
+                                       const uint64_t * __restrict__ row_ent_off, const uint32_t * __restrict__ ent_path,
+                                       const double * __restrict__ ent_prob, const double * __restrict__ row_count,
+                                       const double * __restrict__ row_noise, double * __restrict__ P, const uint64_t ld,
+                                       double * __restrict__ counts, double * __restrict__ total) {
+    const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    double c = 0.0;
+    if (i < num_rows) {
+        const uint64_t r = r0 + i;
+        const uint64_t e0 = row_ent_off[r], e1 = row_ent_off[r + 1];
+        double rowsum = 0.0;
+        for (uint64_t e = e0; e < e1; ++e) rowsum += ent_prob[e];
+        const double nz = row_noise[r];
+        double * out = P + i * ld;
+        for (uint64_t e = e0; e < e1; ++e) out[ent_path[e]] = (ent_prob[e] / rowsum) * (1 - nz);
+        out[num_paths] = nz;
+        c = row_count[r];
+        counts[i] = c;
+    }
+    // read counts are integers: the sum is exact in any order
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c != 0.0) atomicAdd(total, c);
+}
+
+// ---- synthetic dense cluster -------------------------------
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ double u01(uint64_t h) { return (h >> 11) * (1.0 / 9007199254740992.0); }
+
+struct SynthTables {
+    const double * theta_cdf;   // [N] inclusive CDF of the true-path distribution
+    const double * inv_len;     // [N] 1 / effective length
+    const double * score_prob;  // [21] exp(-score_log_base * d)
+    const double * deficit_cdf; // [20] CDF of 1 + Poisson(3) capped at 20 (index d-1)
+};
+
+// one wave per row
+__global__ __launch_bounds__(256) void synthDenseKernel(const uint64_t seed, const uint64_t R, const uint32_t N,
+                                                        const SynthTables tab, double * __restrict__ P, const uint64_t ld,
+                                                        double * __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = (blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x) >> 6;
+    if (r >= R) return;
+    const uint64_t row_key = mix64(seed ^ (r * 0xD1B54A32D192ED03ull));
+    // true path: inverse CDF by binary search (uniform across the wave)
+    const double ut = u01(mix64(row_key ^ 0x1ull));
+    uint32_t lo = 0, hi = N - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tab.theta_cdf[mid] < ut) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t true_path = lo;
+    // mapq in {60: 70 %, 30: 15 %, 10: 10 %, 3: 5 %} -> noise = max(1e-4, 10^(-mapq/10))
+    const double um = u01(mix64(row_key ^ 0x2ull));
+    const double noise = (um < 0.70) ? 1e-4 : (um < 0.85) ? 1e-3 : (um < 0.95) ? 0.1 : 0.50118723362727224;
+
+    auto raw = [&](uint32_t j) -> double {
+        uint32_t d = 0;
+        if (j != true_path) {
+            const double ud = u01(mix64(row_key ^ (0x100ull + j)));
+            d = 1;
+            while (d < 20 && tab.deficit_cdf[d - 1] < ud) ++d;
+        }
+        return tab.score_prob[d] * tab.inv_len[j];
+    };
+    double partial = 0.0;
+    for (uint32_t j = lane; j < N; j += 64) partial += raw(j);
+    const double rowsum = waveReduceSumD(partial);
+    double * out = P + r * ld;
+    for (uint32_t j = lane; j < N; j += 64) out[j] = (raw(j) / rowsum) * (1 - noise);
+    for (uint64_t j = N + 1 + lane; j < ld; j += 64) out[j] = 0.0;
+    if (lane == 0) {
+        out[N] = noise;
+        counts[r] = 1.0;
+    }
+}
+
+}  // namespace
+
+extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matrix, uint64_t num_rows, uint32_t num_cols,
+                                 uint64_t ld, const double * device_counts, double total_count, uint32_t max_em_its,
+                                 double max_rel_em_conv, double * abundances, double * noise_count,
+                                 uint32_t * iterations) {
+    RPVG_REQUIRE(ctx && device_matrix && device_counts && abundances && noise_count && iterations,
+                 "rpvg_hip_em_dense: NULL argument");
+    RPVG_REQUIRE(num_rows > 0 && num_cols >= 2, "rpvg_hip_em_dense: need at least one row, one path and the noise column");
+    RPVG_REQUIRE(ld >= num_cols && (ld % 2) == 0, "rpvg_hip_em_dense: ld (%llu) must be even and >= num_cols (%u)",
+                 static_cast<unsigned long long>(ld), num_cols);
+    RPVG_REQUIRE((reinterpret_cast<uintptr_t>(device_matrix) % 16) == 0, "rpvg_hip_em_dense: matrix must be 16-byte aligned");
+    RPVG_REQUIRE(num_cols <= 2048, "rpvg_hip_em_dense: %u columns exceed the register-resident row limit (2048)", num_cols);
+    RPVG_REQUIRE(total_count > 0 && max_em_its > 0, "rpvg_hip_em_dense: total_count and max_em_its must be positive");
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t C = num_cols;
+
+    const uint32_t cus = ctx->props.multiProcessorCount;
+    // enough waves to cover HBM latency, few enough partial vectors to reduce cheaply
+    uint32_t grid = std::min<uint64_t>((num_rows + 3) / 4, static_cast<uint64_t>(cus) * 2);
+    grid = std::max<uint32_t>(grid, 1);
+    const uint32_t partial_ld = (C + 1) & ~1u;
+
+    DeviceBuffer<double> d_a, d_partials;
+    DeviceBuffer<DenseControl> d_ctl;
+    RPVG_HIP_CHECK(d_a.alloc(C));
+    RPVG_HIP_CHECK(d_partials.alloc(static_cast<size_t>(grid) * partial_ld));
+    RPVG_HIP_CHECK(d_ctl.alloc(1));
+    RPVG_HIP_CHECK(hipMemsetAsync(d_ctl.ptr, 0, sizeof(DenseControl), st));
+    // src/path_abundance_estimator.cpp:54 — 1 / float(C), widened
+    const double a0 = static_cast<double>(1.0f / static_cast<float>(C));
+    fillConstantKernel<<<dim3((C + 255) / 256), dim3(256), 0, st>>>(d_a.ptr, C, a0);
+
+    const int nchunk = (C + 127) / 128;
+    const uint32_t chunk_its = 8;  // iterations queued between looks at the control word
+    DenseControl h_ctl = {0, 0, 0, 0};
+    uint32_t queued = 0;
+    uint64_t accum_launches = 0;
+    const int span = ctx->spanBegin(FAM_EM_DENSE);
+    while (!h_ctl.done) {
+        const uint32_t n = std::min<uint32_t>(chunk_its, max_em_its - queued);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (nchunk <= 1) launchAccum<1>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
+            else if (nchunk <= 2) launchAccum<2>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
+            else if (nchunk <= 4) launchAccum<4>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
+            else if (nchunk <= 8) launchAccum<8>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
+            else launchAccum<16>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
+            emDenseFinalizeKernel<<<dim3((C + 255) / 256), dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_a.ptr,
+                                                                           total_count, max_rel_em_conv, d_ctl.ptr);
+            emDenseControlKernel<<<dim3(1), dim3(1), 0, st>>>(d_ctl.ptr, max_em_its);
+        }
+        queued += n;
+        accum_launches += n;
+        RPVG_HIP_CHECK(hipGetLastError());
+        RPVG_HIP_CHECK(hipMemcpyAsync(&h_ctl, d_ctl.ptr, sizeof(DenseControl), hipMemcpyDeviceToHost, st));
+        RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    ctx->spanEnd(span);
+
+    std::vector<double> a(C);
+    RPVG_HIP_CHECK(hipMemcpyAsync(a.data(), d_a.ptr, sizeof(double) * C, hipMemcpyDeviceToHost, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+
+    // src/path_abundance_estimator.cpp:100-113
+    double nc = 0;
+    for (uint32_t j = 0; j + 1 < C; ++j) {
+        if (a[j] < kMinEmAbundance) {
+            nc += a[j] * total_count;
+            abundances[j] = 0;
+        } else {
+            abundances[j] = a[j] * total_count;
+        }
+    }
+    nc += a[C - 1] * total_count;
+    *noise_count = nc;
+    *iterations = h_ctl.iterations;
+
+    // launches that actually streamed the matrix = iterations executed
+    ctx->stats.em_dense_launches += h_ctl.iterations;
+    ctx->stats.em_dense_alg_bytes += static_cast<double>(h_ctl.iterations) *
+                                     (8.0 * static_cast<double>(num_rows) * C + 8.0 * static_cast<double>(num_rows) + 16.0 * C);
+    ctx->stats.em_iterations_total += h_ctl.iterations;
+    (void) accum_launches;
+    return RPVG_HIP_OK;
+}
+
+extern "C" int rpvg_hip_dense_from_cluster(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t cluster,
+                                           double * device_matrix, uint64_t ld, double * device_counts,
+                                           double * total_count) {
+    RPVG_REQUIRE(ctx && batch && device_matrix && device_counts && total_count, "rpvg_hip_dense_from_cluster: NULL argument");
+    RPVG_REQUIRE(cluster < batch->num_clusters, "rpvg_hip_dense_from_cluster: cluster %u of %u", cluster, batch->num_clusters);
+    const uint64_t r0 = batch->h_cluster_row_off[cluster], r1 = batch->h_cluster_row_off[cluster + 1];
+    const uint32_t N = static_cast<uint32_t>(batch->h_cluster_path_off[cluster + 1] - batch->h_cluster_path_off[cluster]);
+    RPVG_REQUIRE(r1 > r0 && N > 0, "rpvg_hip_dense_from_cluster: cluster %u is empty", cluster);
+    RPVG_REQUIRE(ld >= N + 1 && (ld % 2) == 0, "rpvg_hip_dense_from_cluster: ld must be even and >= paths + 1");
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t R = r1 - r0;
+    DeviceBuffer<double> d_total;
+    RPVG_HIP_CHECK(d_total.alloc(1));
+    const int span = ctx->spanBegin(FAM_BUILD);
+    RPVG_HIP_CHECK(hipMemsetAsync(d_total.ptr, 0, sizeof(double), st));
+    RPVG_HIP_CHECK(hipMemsetAsync(device_matrix, 0, sizeof(double) * R * ld, st));
+    denseFromClusterKernel<<<dim3(static_cast<uint32_t>((R + 255) / 256)), dim3(256), 0, st>>>(
+        r0, R, N, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_count.ptr,
+        batch->row_noise.ptr, device_matrix, ld, device_counts, d_total.ptr);
+    ctx->spanEnd(span);
+    ctx->stats.build_launches += 1;
+    RPVG_HIP_CHECK(hipGetLastError());
+    RPVG_HIP_CHECK(hipMemcpyAsync(total_count, d_total.ptr, sizeof(double), hipMemcpyDeviceToHost, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    return RPVG_HIP_OK;
+}
+
+extern "C" int rpvg_hip_synth_dense_cluster(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t num_rows, uint32_t num_paths,
+                                            double * device_matrix, uint64_t ld, double * device_counts) {
+    RPVG_REQUIRE(ctx && device_matrix && device_counts, "rpvg_hip_synth_dense_cluster: NULL argument");
+    RPVG_REQUIRE(num_rows > 0 && num_paths > 0, "rpvg_hip_synth_dense_cluster: empty cluster");
+    RPVG_REQUIRE(ld >= num_paths + 1 && (ld % 2) == 0, "rpvg_hip_synth_dense_cluster: ld must be even and >= paths + 1");
+    const uint32_t N = num_paths;
+
+    // host-side tables (tiny): theta ~ LogNormal(0, 2) normalised, lengths ~ U[200, 5000]
+    auto hmix = [](uint64_t x) {
+        x += 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        return x ^ (x >> 31);
+    };
+    auto hu01 = [](uint64_t h) { return ((h >> 11) + 0.5) * (1.0 / 9007199254740992.0); };
+    std::vector<double> theta(N), inv_len(N), score_prob(21), deficit_cdf(20);
+    double tsum = 0;
+    for (uint32_t j = 0; j < N; ++j) {
+        const double u1 = hu01(hmix(seed ^ (0xA000000000ull + 2 * j))), u2 = hu01(hmix(seed ^ (0xA000000000ull + 2 * j + 1)));
+        const double z = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);  // Box-Muller
+        theta[j] = std::exp(2.0 * z);
+        tsum += theta[j];
+        inv_len[j] = 1.0 / (200.0 + 4800.0 * hu01(hmix(seed ^ (0xB000000000ull + j))));
+    }
+    double acc = 0;
+    for (uint32_t j = 0; j < N; ++j) {
+        acc += theta[j] / tsum;
+        theta[j] = acc;
+    }
+    theta[N - 1] = 1.0;
+    for (int d = 0; d <= 20; ++d) score_prob[d] = std::exp(-1.383325268738 * d);  // Utils::score_log_base, src/utils.hpp:83
+    double pk = std::exp(-3.0), cdf = 0;  // Poisson(3)
+    for (int k = 0; k < 20; ++k) {
+        cdf += pk;
+        deficit_cdf[k] = cdf;  // deficit d = 1 + k
+        pk *= 3.0 / (k + 1);
+    }
+    deficit_cdf[19] = 1.0;
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DeviceBuffer<double> d_theta, d_inv_len, d_score, d_def;
+    RPVG_HIP_CHECK(d_theta.upload(theta.data(), N, st));
+    RPVG_HIP_CHECK(d_inv_len.upload(inv_len.data(), N, st));
+    RPVG_HIP_CHECK(d_score.upload(score_prob.data(), 21, st));
+    RPVG_HIP_CHECK(d_def.upload(deficit_cdf.data(), 20, st));
+    SynthTables tab = {d_theta.ptr, d_inv_len.ptr, d_score.ptr, d_def.ptr};
+    const uint64_t threads = num_rows * 64;
+    synthDenseKernel<<<dim3(static_cast<uint32_t>((threads + 255) / 256)), dim3(256), 0, st>>>(seed, num_rows, N, tab,
+                                                                                            device_matrix, ld, device_counts);
+    RPVG_HIP_CHECK(hipGetLastError());
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    return RPVG_HIP_OK;
+}

@@ -1,0 +1,540 @@
+// Batched EM abundance solves on ragged, sparse cluster problems (gfx950).
+//
+// Takes over, for a whole batch of (cluster, column-subset) problems at once:
+//   constructPartialProbabilityMatrix       src/path_estimator.cpp:79-113
+//   addNoiseAndNormalizeProbabilityMatrix   src/path_estimator.cpp:156-166
+//   EMAbundanceEstimator                    src/path_abundance_estimator.cpp:47-114
+//
+// Pipeline per rpvg_hip_em_solve() call (all on the context's stream):
+//   1. scatterColumnMapKernel   path -> column (or -1) map of every problem
+//   2. countProblemKernel       rows/entries that survive the column subset,
+//                               read mass of rows that touch no selected path
+//   3. (host) prefix sums over problems, cost-descending order, size bins
+//   4. fillProblemKernel        ordered compaction into a per-problem CSR of
+//                               row-normalised entries  P_ij/rowsum_i*(1-noise_i)
+//   5. emSparseKernel<BLOCK>    ONE workgroup per problem runs the whole EM
+//                               loop on the GPU: abundance vector a[] and the
+//                               M-step accumulators t[] live in LDS, the
+//                               problem's CSR streams from L2/HBM every
+//                               iteration, convergence is decided on-device.
+//
+// EM iteration, fused to one pass over the rows:
+//   s_i = noise_i*a_noise + sum_e P_e*a[col_e] ;  w_i = count_i / s_i
+//   t[col_e] += w_i*P_e ; t_noise += w_i*noise_i
+//   a'_j = a_j*t_j/T ;  a'_noise = (a_noise*t_noise + Z)/T
+// where Z is the read mass of the rows without any selected path: such a row
+// is (0,...,0,noise_i) after normalisation, its posterior is exactly 1 on the
+// noise component for every a, so its M-step contribution is the constant
+// count_i (this also subsumes what readCollapseProbabilityMatrix,
+// src/path_estimator.cpp:219-259, would merge among those rows).
+
+#include "common.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+using namespace rpvg_hip_detail;
+
+namespace {
+
+constexpr double kMinEmAbundance = 1e-8;   // src/path_abundance_estimator.cpp:11
+constexpr uint32_t kMinEmConvIts = 10;     // src/path_abundance_estimator.cpp:10
+
+// ---- block-level primitives (wave = 64) -------------------------------------
+
+template <typename T>
+__device__ __forceinline__ T waveReduceSum(T v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Sum over the block, result in every thread.  scratch: BLOCK/64 elements.
+template <typename T, int BLOCK>
+__device__ __forceinline__ T blockReduceSum(T v, T * scratch) {
+    v = waveReduceSum(v);
+    if (BLOCK == 64) return v;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    T total = scratch[0];
+#pragma unroll
+    for (int w = 1; w < BLOCK / 64; ++w) total += scratch[w];
+    return total;
+}
+
+// Exclusive scan of the pair (a, b) over the block; totals to every thread.
+// scratch: 2*BLOCK/64 uint32.
+template <int BLOCK>
+__device__ __forceinline__ void blockExclusiveScanPair(uint32_t & a, uint32_t & b, uint32_t & total_a, uint32_t & total_b,
+                                                       uint32_t * scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64);
+        if (lane >= d) {
+            ia += ta;
+            ib += tb;
+        }
+    }
+    __syncthreads();
+    if (lane == 63) {
+        scratch[2 * wave] = ia;
+        scratch[2 * wave + 1] = ib;
+    }
+    __syncthreads();
+    uint32_t off_a = 0, off_b = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        const uint32_t xa = scratch[2 * w], xb = scratch[2 * w + 1];
+        if (w < wave) {
+            off_a += xa;
+            off_b += xb;
+        }
+        ta += xa;
+        tb += xb;
+    }
+    a = off_a + ia - a;
+    b = off_b + ib - b;
+    total_a = ta;
+    total_b = tb;
+}
+
+// ---- problem descriptors on the device --------------------------------------
+
+struct ProblemTable {
+    const uint32_t * cluster;      // [P]
+    const uint64_t * col_off;      // [P+1]
+    const uint64_t * colmap_off;   // [P+1] offset of the problem's path->column map
+    const uint64_t * row_base;     // [P]   first compacted row of the problem
+    const uint64_t * ent_base;     // [P]   first compacted entry of the problem
+    const uint32_t * kept_rows;    // [P]
+};
+
+// ---- 1. path -> column map ---------------------------------------------------
+
+__global__ void scatterColumnMapKernel(const uint32_t num_problems, const uint64_t * __restrict__ col_off,
+                                       const uint32_t * __restrict__ col_path, const uint64_t * __restrict__ colmap_off,
+                                       int32_t * __restrict__ colmap) {
+    const uint32_t p = blockIdx.x;
+    if (p >= num_problems) return;
+    const uint64_t c0 = col_off[p], c1 = col_off[p + 1];
+    int32_t * map = colmap + colmap_off[p];
+    for (uint64_t c = c0 + threadIdx.x; c < c1; c += blockDim.x) map[col_path[c]] = static_cast<int32_t>(c - c0);
+}
+
+// ---- 2. count ----------------------------------------------------------------
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void countProblemKernel(
+    const uint32_t num_problems, const uint32_t * __restrict__ prob_cluster, const uint64_t * __restrict__ colmap_off,
+    const int32_t * __restrict__ colmap, const uint64_t * __restrict__ cluster_row_off,
+    const uint64_t * __restrict__ row_ent_off, const uint32_t * __restrict__ ent_path,
+    const double * __restrict__ row_count, uint32_t * __restrict__ kept_rows, uint32_t * __restrict__ kept_entries,
+    double * __restrict__ zero_mass, double * __restrict__ total_mass) {
+    __shared__ double dscratch[BLOCK / 64];
+    __shared__ uint32_t uscratch[BLOCK / 64];
+    const uint32_t p = blockIdx.x;
+    if (p >= num_problems) return;
+    const uint32_t k = prob_cluster[p];
+    const int32_t * map = colmap + colmap_off[p];
+    const uint64_t r0 = cluster_row_off[k], r1 = cluster_row_off[k + 1];
+    uint32_t n_rows = 0, n_ent = 0;
+    double z = 0, t = 0;
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += BLOCK) {
+        uint32_t n = 0;
+        for (uint64_t e = row_ent_off[r]; e < row_ent_off[r + 1]; ++e) n += (map[ent_path[e]] >= 0);
+        const double c = row_count[r];
+        t += c;
+        if (n) {
+            ++n_rows;
+            n_ent += n;
+        } else {
+            z += c;
+        }
+    }
+    n_rows = blockReduceSum<uint32_t, BLOCK>(n_rows, uscratch);
+    n_ent = blockReduceSum<uint32_t, BLOCK>(n_ent, uscratch);
+    z = blockReduceSum<double, BLOCK>(z, dscratch);
+    t = blockReduceSum<double, BLOCK>(t, dscratch);
+    if (threadIdx.x == 0) {
+        kept_rows[p] = n_rows;
+        kept_entries[p] = n_ent;
+        zero_mass[p] = z;
+        total_mass[p] = t;
+    }
+}
+
+// ---- 4. fill: ordered compaction + row normalisation -------------------------
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fillProblemKernel(
+    const uint32_t num_problems, const uint32_t * __restrict__ prob_cluster, const uint64_t * __restrict__ colmap_off,
+    const int32_t * __restrict__ colmap, const uint64_t * __restrict__ cluster_row_off,
+    const uint64_t * __restrict__ row_ent_off, const uint32_t * __restrict__ ent_path,
+    const double * __restrict__ ent_prob, const double * __restrict__ row_count, const double * __restrict__ row_noise,
+    const uint64_t * __restrict__ row_base, const uint64_t * __restrict__ ent_base,
+    uint32_t * __restrict__ prow_off,   // [rows_total + P] per problem kept_rows+1 offsets relative to the problem's entry base
+    double * __restrict__ prow_count, double * __restrict__ prow_noise, uint32_t * __restrict__ pent_col,
+    double * __restrict__ pent_val) {
+    __shared__ uint32_t scratch[2 * (BLOCK / 64)];
+    const uint32_t p = blockIdx.x;
+    if (p >= num_problems) return;
+    const uint32_t k = prob_cluster[p];
+    const int32_t * map = colmap + colmap_off[p];
+    const uint64_t r0 = cluster_row_off[k], r1 = cluster_row_off[k + 1];
+    const uint64_t rb = row_base[p], eb = ent_base[p];
+    // the offsets array has one extra slot per problem
+    uint32_t * off = prow_off + rb + p;
+    uint32_t run_rows = 0, run_ent = 0;
+    for (uint64_t rc = r0; rc < r1; rc += BLOCK) {
+        const uint64_t r = rc + threadIdx.x;
+        uint32_t n = 0;
+        double rowsum = 0;
+        uint64_t e0 = 0, e1 = 0;
+        if (r < r1) {
+            e0 = row_ent_off[r];
+            e1 = row_ent_off[r + 1];
+            for (uint64_t e = e0; e < e1; ++e) {
+                if (map[ent_path[e]] >= 0) {
+                    ++n;
+                    rowsum += ent_prob[e];
+                }
+            }
+        }
+        uint32_t slot = n ? 1u : 0u, epos = n, tot_rows, tot_ent;
+        blockExclusiveScanPair<BLOCK>(slot, epos, tot_rows, tot_ent, scratch);
+        if (n) {
+            const uint32_t my_row = run_rows + slot;
+            uint32_t my_ent = run_ent + epos;
+            off[my_row] = my_ent;
+            const double nz = row_noise[r];
+            prow_count[rb + my_row] = row_count[r];
+            prow_noise[rb + my_row] = nz;
+            const double keep = 1 - nz;
+            for (uint64_t e = e0; e < e1; ++e) {
+                const int32_t c = map[ent_path[e]];
+                if (c >= 0) {
+                    pent_col[eb + my_ent] = static_cast<uint32_t>(c);
+                    // addNoiseAndNormalizeProbabilityMatrix: (P / rowsum) * (1 - noise), two roundings
+                    pent_val[eb + my_ent] = (ent_prob[e] / rowsum) * keep;
+                    ++my_ent;
+                }
+            }
+        }
+        run_rows += tot_rows;
+        run_ent += tot_ent;
+    }
+    if (threadIdx.x == 0) off[run_rows] = run_ent;
+}
+
+// ---- 5. the EM kernel --------------------------------------------------------
+
+struct EmLaunchArgs {
+    const uint32_t * order;        // problems of this bin, cost-descending
+    uint32_t count;
+    const uint64_t * col_off;      // [P+1]
+    const uint64_t * row_base;     // [P]
+    const uint64_t * ent_base;     // [P]
+    const uint32_t * kept_rows;    // [P]
+    const double * zero_mass;      // [P]
+    const double * total_mass;     // [P]
+    const uint32_t * prow_off;
+    const double * prow_count;
+    const double * prow_noise;
+    const uint32_t * pent_col;
+    const double * pent_val;
+    uint32_t max_em_its;
+    double max_rel_em_conv;
+    double * abundances;           // [col_off[P]]
+    double * noise_count;          // [P]
+    uint32_t * iterations;         // [P]
+};
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void emSparseKernel(const EmLaunchArgs args) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (blockIdx.x >= args.count) return;
+    const uint32_t p = args.order[blockIdx.x];
+    const uint32_t C = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]) + 1;  // + noise
+    double * a = reinterpret_cast<double *>(smem_raw);  // [C] abundances (last = noise)
+    double * t = a + C;                                 // [C] M-step accumulators
+    double * red = t + C;                               // [BLOCK/64] reduction scratch
+
+    const uint32_t n_rows = args.kept_rows[p];
+    const uint64_t rb = args.row_base[p], eb = args.ent_base[p];
+    const uint32_t * off = args.prow_off + rb + p;
+    const double * cnt = args.prow_count + rb;
+    const double * nzv = args.prow_noise + rb;
+    const uint32_t * col = args.pent_col + eb;
+    const double * val = args.pent_val + eb;
+    const double T = args.total_mass[p];
+    const double Z = args.zero_mass[p];
+    const double eps = args.max_rel_em_conv;
+    const uint32_t noise_col = C - 1;
+
+    // src/path_abundance_estimator.cpp:54 — 1 / float(C), widened
+    const double a0 = static_cast<double>(1.0f / static_cast<float>(C));
+    for (uint32_t j = threadIdx.x; j < C; j += BLOCK) a[j] = a0;
+
+    uint32_t iters = 0, conv = 0;
+    for (uint32_t it = 0; it < args.max_em_its; ++it) {
+        for (uint32_t j = threadIdx.x; j < C; j += BLOCK) t[j] = 0;
+        __syncthreads();
+        const double a_noise = a[noise_col];
+        double tn = 0;
+        for (uint32_t r = threadIdx.x; r < n_rows; r += BLOCK) {
+            const uint32_t e0 = off[r], e1 = off[r + 1];
+            const double nz = nzv[r];
+            double s = nz * a_noise;
+            for (uint32_t e = e0; e < e1; ++e) s += val[e] * a[col[e]];
+            const double w = cnt[r] / s;
+            for (uint32_t e = e0; e < e1; ++e) atomicAdd(&t[col[e]], w * val[e]);
+            tn += w * nz;
+        }
+        tn = blockReduceSum<double, BLOCK>(tn, red);
+        __syncthreads();  // all atomics to t[] done
+        int viol = 0;
+        for (uint32_t j = threadIdx.x; j < C; j += BLOCK) {
+            const double aj = a[j];
+            const double an = (j == noise_col) ? (aj * tn + Z) / T : (aj * t[j]) / T;
+            if (an >= kMinEmAbundance && fabs(an - aj) / an > eps) viol = 1;
+            a[j] = an;
+        }
+        const int any_viol = __syncthreads_or(viol);
+        ++iters;
+        if (!any_viol) {
+            if (++conv == kMinEmConvIts) break;
+        } else {
+            conv = 0;
+        }
+    }
+
+    // src/path_abundance_estimator.cpp:100-113
+    double low = 0;
+    double * out = args.abundances + args.col_off[p];
+    for (uint32_t j = threadIdx.x; j < noise_col; j += BLOCK) {
+        const double aj = a[j];
+        if (aj < kMinEmAbundance) {
+            low += aj * T;
+            out[j] = 0;
+        } else {
+            out[j] = aj * T;
+        }
+    }
+    low = blockReduceSum<double, BLOCK>(low, red);
+    if (threadIdx.x == 0) {
+        args.noise_count[p] = low + a[noise_col] * T;
+        args.iterations[p] = iters;
+    }
+}
+
+template <int BLOCK>
+hipError_t launchEm(const EmLaunchArgs & args, uint32_t max_cols, hipStream_t stream) {
+    if (args.count == 0) return hipSuccess;
+    const size_t lds = sizeof(double) * (2 * static_cast<size_t>(max_cols) + BLOCK / 64 + 2);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&emSparseKernel<BLOCK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    emSparseKernel<BLOCK><<<dim3(args.count), dim3(BLOCK), lds, stream>>>(args);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t max_em_its,
+                                 double max_rel_em_conv, const rpvg_hip_em_problems * problems,
+                                 rpvg_hip_em_results * results) {
+    RPVG_REQUIRE(ctx && batch && problems && results, "rpvg_hip_em_solve: NULL argument");
+    const uint32_t P = problems->num_problems;
+    if (P == 0) return RPVG_HIP_OK;
+    RPVG_REQUIRE(problems->cluster && problems->col_off && problems->col_path, "rpvg_hip_em_solve: NULL problem arrays");
+    RPVG_REQUIRE(results->abundances && results->noise_count && results->total_count && results->iterations,
+                 "rpvg_hip_em_solve: NULL result arrays");
+    RPVG_REQUIRE(max_em_its > 0, "rpvg_hip_em_solve: max_em_its must be positive");
+
+    // ---- validate + host-side offsets ----
+    std::vector<uint64_t> colmap_off(P + 1, 0);
+    uint32_t max_cols_all = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t k = problems->cluster[p];
+        RPVG_REQUIRE(k < batch->num_clusters, "rpvg_hip_em_solve: problem %u refers to cluster %u of %u", p, k, batch->num_clusters);
+        const uint64_t n_paths = batch->h_cluster_path_off[k + 1] - batch->h_cluster_path_off[k];
+        const uint64_t c0 = problems->col_off[p], c1 = problems->col_off[p + 1];
+        RPVG_REQUIRE(c1 > c0, "rpvg_hip_em_solve: problem %u has no columns", p);
+        RPVG_REQUIRE(batch->h_cluster_row_off[k + 1] > batch->h_cluster_row_off[k],
+                     "rpvg_hip_em_solve: problem %u is on cluster %u which has no rows", p, k);
+        for (uint64_t c = c0; c < c1; ++c) {
+            RPVG_REQUIRE(problems->col_path[c] < n_paths, "rpvg_hip_em_solve: problem %u column path %u >= %llu", p,
+                         problems->col_path[c], static_cast<unsigned long long>(n_paths));
+            RPVG_REQUIRE(c == c0 || problems->col_path[c] > problems->col_path[c - 1],
+                         "rpvg_hip_em_solve: problem %u columns are not strictly ascending", p);
+        }
+        colmap_off[p + 1] = colmap_off[p] + n_paths;
+        max_cols_all = std::max<uint32_t>(max_cols_all, static_cast<uint32_t>(c1 - c0) + 1);
+    }
+    const uint64_t n_cols_total = problems->col_off[P];
+    RPVG_REQUIRE(sizeof(double) * (2 * static_cast<size_t>(max_cols_all) + 8) <= 160 * 1024,
+                 "rpvg_hip_em_solve: a problem with %u columns does not fit the LDS-resident abundance vector", max_cols_all);
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    DeviceBuffer<uint32_t> d_cluster, d_col_path, d_kept_rows, d_kept_ent;
+    DeviceBuffer<uint64_t> d_col_off, d_colmap_off;
+    DeviceBuffer<int32_t> d_colmap;
+    DeviceBuffer<double> d_zero, d_total;
+
+    int span = ctx->spanBegin(FAM_H2D);
+    RPVG_HIP_CHECK(d_cluster.upload(problems->cluster, P, st));
+    RPVG_HIP_CHECK(d_col_off.upload(problems->col_off, P + 1, st));
+    RPVG_HIP_CHECK(d_col_path.upload(problems->col_path, n_cols_total, st));
+    RPVG_HIP_CHECK(d_colmap_off.upload(colmap_off.data(), P + 1, st));
+    ctx->spanEnd(span);
+    ctx->stats.h2d_bytes += static_cast<double>(P * 4 + (P + 1) * 16 + n_cols_total * 4);
+    RPVG_HIP_CHECK(d_colmap.alloc(colmap_off[P]));
+    RPVG_HIP_CHECK(d_kept_rows.alloc(P));
+    RPVG_HIP_CHECK(d_kept_ent.alloc(P));
+    RPVG_HIP_CHECK(d_zero.alloc(P));
+    RPVG_HIP_CHECK(d_total.alloc(P));
+
+    span = ctx->spanBegin(FAM_BUILD);
+    RPVG_HIP_CHECK(hipMemsetAsync(d_colmap.ptr, 0xFF, colmap_off[P] * sizeof(int32_t), st));
+    scatterColumnMapKernel<<<dim3(P), dim3(64), 0, st>>>(P, d_col_off.ptr, d_col_path.ptr, d_colmap_off.ptr, d_colmap.ptr);
+    countProblemKernel<256><<<dim3(P), dim3(256), 0, st>>>(P, d_cluster.ptr, d_colmap_off.ptr, d_colmap.ptr,
+                                                          batch->cluster_row_off.ptr, batch->row_ent_off.ptr,
+                                                          batch->ent_path.ptr, batch->row_count.ptr, d_kept_rows.ptr,
+                                                          d_kept_ent.ptr, d_zero.ptr, d_total.ptr);
+    ctx->spanEnd(span);
+    ctx->stats.build_launches += 2;
+    RPVG_HIP_CHECK(hipGetLastError());
+
+    std::vector<uint32_t> kept_rows(P), kept_ent(P);
+    RPVG_HIP_CHECK(d_kept_rows.download(kept_rows.data(), st));
+    RPVG_HIP_CHECK(d_kept_ent.download(kept_ent.data(), st));
+    RPVG_HIP_CHECK(d_total.download(results->total_count, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+
+    // ---- host: prefix sums, ordering, bins ----
+    std::vector<uint64_t> row_base(P), ent_base(P);
+    uint64_t rows_total = 0, ent_total = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        row_base[p] = rows_total;
+        ent_base[p] = ent_total;
+        rows_total += kept_rows[p];
+        ent_total += kept_ent[p];
+    }
+    // Size bins: a wave per problem for small problems, 256 threads for
+    // medium ones, 1024 for the few giant ones.  Inside a bin the expensive
+    // problems go first (the reference sorts clusters the same way before its
+    // dynamic OpenMP schedule, src/main.cpp:811-829).
+    std::vector<uint32_t> bins[3];
+    uint32_t bin_cols[3] = {0, 0, 0};
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t C = static_cast<uint32_t>(problems->col_off[p + 1] - problems->col_off[p]) + 1;
+        const uint64_t work = static_cast<uint64_t>(kept_ent[p]) + kept_rows[p];
+        int b;
+        if (work <= 1536 && C <= 256) {
+            b = 0;
+        } else if (work <= 262144) {
+            b = 1;
+        } else {
+            b = 2;
+        }
+        bins[b].push_back(p);
+        bin_cols[b] = std::max(bin_cols[b], C);
+    }
+    std::vector<uint32_t> order;
+    order.reserve(P);
+    uint32_t bin_start[3];
+    for (int b = 2; b >= 0; --b) {
+        std::sort(bins[b].begin(), bins[b].end(), [&](uint32_t x, uint32_t y) {
+            const uint64_t wx = static_cast<uint64_t>(kept_ent[x]) + kept_rows[x], wy = static_cast<uint64_t>(kept_ent[y]) + kept_rows[y];
+            return wx != wy ? wx > wy : x < y;
+        });
+        bin_start[b] = order.size();
+        order.insert(order.end(), bins[b].begin(), bins[b].end());
+    }
+
+    DeviceBuffer<uint64_t> d_row_base, d_ent_base;
+    DeviceBuffer<uint32_t> d_order, d_prow_off, d_pent_col, d_iters;
+    DeviceBuffer<double> d_prow_count, d_prow_noise, d_pent_val, d_abund, d_noise_count;
+    span = ctx->spanBegin(FAM_H2D);
+    RPVG_HIP_CHECK(d_row_base.upload(row_base.data(), P, st));
+    RPVG_HIP_CHECK(d_ent_base.upload(ent_base.data(), P, st));
+    RPVG_HIP_CHECK(d_order.upload(order.data(), P, st));
+    ctx->spanEnd(span);
+    ctx->stats.h2d_bytes += static_cast<double>(P * 20);
+    RPVG_HIP_CHECK(d_prow_off.alloc(rows_total + P));
+    RPVG_HIP_CHECK(d_prow_count.alloc(rows_total));
+    RPVG_HIP_CHECK(d_prow_noise.alloc(rows_total));
+    RPVG_HIP_CHECK(d_pent_col.alloc(ent_total));
+    RPVG_HIP_CHECK(d_pent_val.alloc(ent_total));
+    RPVG_HIP_CHECK(d_abund.alloc(n_cols_total));
+    RPVG_HIP_CHECK(d_noise_count.alloc(P));
+    RPVG_HIP_CHECK(d_iters.alloc(P));
+
+    span = ctx->spanBegin(FAM_BUILD);
+    fillProblemKernel<256><<<dim3(P), dim3(256), 0, st>>>(
+        P, d_cluster.ptr, d_colmap_off.ptr, d_colmap.ptr, batch->cluster_row_off.ptr, batch->row_ent_off.ptr,
+        batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_count.ptr, batch->row_noise.ptr, d_row_base.ptr,
+        d_ent_base.ptr, d_prow_off.ptr, d_prow_count.ptr, d_prow_noise.ptr, d_pent_col.ptr, d_pent_val.ptr);
+    ctx->spanEnd(span);
+    ctx->stats.build_launches += 1;
+    RPVG_HIP_CHECK(hipGetLastError());
+
+    EmLaunchArgs args;
+    args.col_off = d_col_off.ptr;
+    args.row_base = d_row_base.ptr;
+    args.ent_base = d_ent_base.ptr;
+    args.kept_rows = d_kept_rows.ptr;
+    args.zero_mass = d_zero.ptr;
+    args.total_mass = d_total.ptr;
+    args.prow_off = d_prow_off.ptr;
+    args.prow_count = d_prow_count.ptr;
+    args.prow_noise = d_prow_noise.ptr;
+    args.pent_col = d_pent_col.ptr;
+    args.pent_val = d_pent_val.ptr;
+    args.max_em_its = max_em_its;
+    args.max_rel_em_conv = max_rel_em_conv;
+    args.abundances = d_abund.ptr;
+    args.noise_count = d_noise_count.ptr;
+    args.iterations = d_iters.ptr;
+
+    span = ctx->spanBegin(FAM_EM_SPARSE);
+    // giant problems first (they are the tail), then medium, then small
+    args.order = d_order.ptr + bin_start[2];
+    args.count = bins[2].size();
+    RPVG_HIP_CHECK(launchEm<1024>(args, bin_cols[2], st));
+    args.order = d_order.ptr + bin_start[1];
+    args.count = bins[1].size();
+    RPVG_HIP_CHECK(launchEm<256>(args, bin_cols[1], st));
+    args.order = d_order.ptr + bin_start[0];
+    args.count = bins[0].size();
+    RPVG_HIP_CHECK(launchEm<64>(args, bin_cols[0], st));
+    ctx->spanEnd(span);
+    for (int b = 0; b < 3; ++b) ctx->stats.em_sparse_launches += bins[b].empty() ? 0 : 1;
+
+    RPVG_HIP_CHECK(d_abund.download(results->abundances, st));
+    RPVG_HIP_CHECK(d_noise_count.download(results->noise_count, st));
+    RPVG_HIP_CHECK(d_iters.download(results->iterations, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+
+    // algorithmic bytes: per iteration 12 B per entry (value + column), 20 B
+    // per row (count, noise, offset), 16 B per column (a read + a' write)
+    double bytes = 0;
+    uint64_t its_total = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        const double C = static_cast<double>(problems->col_off[p + 1] - problems->col_off[p]) + 1;
+        bytes += static_cast<double>(results->iterations[p]) * (12.0 * kept_ent[p] + 20.0 * kept_rows[p] + 16.0 * C);
+        its_total += results->iterations[p];
+    }
+    ctx->stats.em_sparse_alg_bytes += bytes;
+    ctx->stats.em_iterations_total += its_total;
+    return RPVG_HIP_OK;
+}

@@ -1,0 +1,316 @@
+// Group (haplotype / diplotype) matrices and their log-likelihood
+// contraction on the GPU (gfx950).
+//
+// Takes over
+//   constructGroupedProbabilityMatrix / constructProbabilityMatrix
+//                                            src/path_estimator.cpp:55-77,115-154
+//   addNoiseAndNormalizeProbabilityMatrix    src/path_estimator.cpp:156-166
+//   rowwise().maxCoeff()                     src/path_estimator.cpp:414
+//   read_counts * (noise + sum cols / g).array().log().matrix()
+//                                            src/path_estimator.cpp:354-361,424-427,439,527-545
+//
+// Layout: one column-major R_m x G_m matrix per requested (cluster, grouping),
+// so that a wave walking the rows of one or two columns reads contiguous
+// memory; counts and noise are shared with the uploaded batch.  The
+// contraction is FP64-log bound (one log per row per request), not HBM bound:
+// a cluster's matrix is re-read from L2 by every request that touches it.
+
+#include "common.hpp"
+
+#include <algorithm>
+
+using namespace rpvg_hip_detail;
+
+struct rpvg_hip_groups {
+    const rpvg_hip_batch * batch = nullptr;
+    uint32_t num_matrices = 0;
+    int32_t normalise = 0;
+    std::vector<uint32_t> h_num_cols;
+    std::vector<uint64_t> h_num_rows;
+    DeviceBuffer<double> values;         // all matrices back to back, each column-major
+    DeviceBuffer<double> rowmax;         // [sum R_m]
+    DeviceBuffer<uint64_t> mat_val_off;  // [M] offset of matrix m in values
+    DeviceBuffer<uint64_t> mat_row_off;  // [M] offset of matrix m in rowmax
+    DeviceBuffer<uint64_t> mat_row0;     // [M] first batch row of the matrix's cluster
+    DeviceBuffer<uint64_t> mat_rows;     // [M] R_m
+    DeviceBuffer<uint32_t> mat_cols;     // [M] G_m
+};
+
+namespace {
+
+constexpr uint32_t kNoMember = 0xFFFFFFFFu;
+
+// block per matrix, threads stride the rows
+__global__ __launch_bounds__(256) void groupsBuildKernel(
+    const uint32_t num_matrices, const uint64_t * __restrict__ mat_val_off, const uint64_t * __restrict__ mat_row_off,
+    const uint64_t * __restrict__ mat_row0, const uint64_t * __restrict__ mat_rows, const uint32_t * __restrict__ mat_cols,
+    const uint64_t * __restrict__ mat_inc_off,   // [M] offset of the matrix's path->groups CSR offsets
+    const uint64_t * __restrict__ path_grp_off,  // per matrix N_k+1 offsets (absolute into path_grp)
+    const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
+    const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
+    const int normalise, double * __restrict__ values, double * __restrict__ rowmax) {
+    const uint32_t m = blockIdx.x;
+    if (m >= num_matrices) return;
+    const uint64_t R = mat_rows[m], r0 = mat_row0[m];
+    const uint32_t G = mat_cols[m];
+    double * M = values + mat_val_off[m];
+    double * rm = rowmax + mat_row_off[m];
+    const uint64_t * pgo = path_grp_off + mat_inc_off[m];
+    for (uint64_t i = threadIdx.x; i < R; i += blockDim.x) {
+        const uint64_t r = r0 + i;
+        for (uint64_t e = row_ent_off[r]; e < row_ent_off[r + 1]; ++e) {
+            const uint32_t p = ent_path[e];
+            const double v = ent_prob[e];
+            for (uint64_t x = pgo[p]; x < pgo[p + 1]; ++x) M[static_cast<uint64_t>(path_grp[x]) * R + i] += v;
+        }
+        double mx = 0.0;
+        if (normalise) {
+            double rowsum = 0.0;
+            for (uint32_t g = 0; g < G; ++g) rowsum += M[static_cast<uint64_t>(g) * R + i];
+            const double keep = 1 - row_noise[r];
+            for (uint32_t g = 0; g < G; ++g) {
+                double v = (M[static_cast<uint64_t>(g) * R + i] / rowsum) * keep;
+                if (v != v) v = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
+                M[static_cast<uint64_t>(g) * R + i] = v;
+                mx = (g == 0) ? v : fmax(mx, v);
+            }
+        } else {
+            for (uint32_t g = 0; g < G; ++g) {
+                const double v = M[static_cast<uint64_t>(g) * R + i];
+                mx = (g == 0) ? v : fmax(mx, v);
+            }
+        }
+        rm[i] = mx;
+    }
+}
+
+// one wave per request
+template <int WIDTH>
+__global__ __launch_bounds__(256) void groupLoglikKernel(
+    const uint32_t num_requests, const uint32_t * __restrict__ req_matrix, const uint32_t * __restrict__ req_members,
+    const uint8_t * __restrict__ req_rowmax, const double divisor, const uint64_t * __restrict__ mat_val_off,
+    const uint64_t * __restrict__ mat_row_off, const uint64_t * __restrict__ mat_row0,
+    const uint64_t * __restrict__ mat_rows, const double * __restrict__ values, const double * __restrict__ rowmax,
+    const double * __restrict__ row_count, const double * __restrict__ row_noise, double * __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (q >= num_requests) return;
+    const uint32_t m = req_matrix[q];
+    const uint64_t R = mat_rows[m];
+    const double * M = values + mat_val_off[m];
+    const double * cnt = row_count + mat_row0[m];
+    const double * nz = row_noise + mat_row0[m];
+    const double * rm = req_rowmax && req_rowmax[q] ? rowmax + mat_row_off[m] : nullptr;
+    const double * col[WIDTH];
+#pragma unroll
+    for (int w = 0; w < WIDTH; ++w) {
+        const uint32_t g = req_members[static_cast<uint64_t>(q) * WIDTH + w];
+        col[w] = (g == kNoMember) ? nullptr : M + static_cast<uint64_t>(g) * R;
+    }
+    double acc = 0.0;
+    for (uint64_t i = lane; i < R; i += 64) {
+        double v = nz[i];
+#pragma unroll
+        for (int w = 0; w < WIDTH; ++w)
+            if (col[w]) v += col[w][i] / divisor;
+        if (rm) v += rm[i] / divisor;
+        acc = fma(cnt[i], log(v), acc);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane == 0) out[q] = acc;
+}
+
+}  // namespace
+
+extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec,
+                                     rpvg_hip_groups ** groups_out) {
+    RPVG_REQUIRE(ctx && batch && spec && groups_out, "rpvg_hip_groups_build: NULL argument");
+    *groups_out = nullptr;
+    const uint32_t M = spec->num_matrices;
+    RPVG_REQUIRE(M == 0 || (spec->cluster && spec->group_off && spec->group_path_off && spec->group_path),
+                 "rpvg_hip_groups_build: NULL spec arrays");
+
+    rpvg_hip_groups * g = new (std::nothrow) rpvg_hip_groups();
+    if (!g) {
+        setError("rpvg_hip_groups_build: out of host memory");
+        return RPVG_HIP_ERR_ALLOC;
+    }
+    g->batch = batch;
+    g->num_matrices = M;
+    g->normalise = spec->normalise;
+
+    // host: sizes, offsets and the path -> groups incidence of every matrix
+    std::vector<uint64_t> val_off(M), row_off(M), row0(M), rows(M), inc_off(M);
+    std::vector<uint32_t> cols(M);
+    std::vector<uint64_t> path_grp_off;
+    std::vector<uint32_t> path_grp;
+    uint64_t val_total = 0, row_total = 0;
+    for (uint32_t m = 0; m < M; ++m) {
+        const uint32_t k = spec->cluster[m];
+        if (k >= batch->num_clusters) {
+            setError("rpvg_hip_groups_build: matrix %u refers to cluster %u of %u", m, k, batch->num_clusters);
+            delete g;
+            return RPVG_HIP_ERR_INVALID;
+        }
+        const uint64_t R = batch->h_cluster_row_off[k + 1] - batch->h_cluster_row_off[k];
+        const uint64_t N = batch->h_cluster_path_off[k + 1] - batch->h_cluster_path_off[k];
+        const uint64_t g0 = spec->group_off[m], g1 = spec->group_off[m + 1];
+        if (R == 0 || g1 <= g0) {
+            setError("rpvg_hip_groups_build: matrix %u has no rows or no columns", m);
+            delete g;
+            return RPVG_HIP_ERR_INVALID;
+        }
+        rows[m] = R;
+        cols[m] = static_cast<uint32_t>(g1 - g0);
+        row0[m] = batch->h_cluster_row_off[k];
+        val_off[m] = val_total;
+        row_off[m] = row_total;
+        val_total += R * (g1 - g0);
+        row_total += R;
+        // invert: groups of each path, in ascending group order
+        std::vector<uint32_t> deg(N + 1, 0);
+        for (uint64_t gi = g0; gi < g1; ++gi) {
+            for (uint64_t x = spec->group_path_off[gi]; x < spec->group_path_off[gi + 1]; ++x) {
+                if (spec->group_path[x] >= N) {
+                    setError("rpvg_hip_groups_build: matrix %u group path %u >= %llu", m, spec->group_path[x],
+                             static_cast<unsigned long long>(N));
+                    delete g;
+                    return RPVG_HIP_ERR_INVALID;
+                }
+                ++deg[spec->group_path[x]];
+            }
+        }
+        inc_off[m] = path_grp_off.size();
+        const uint64_t base = path_grp.size();
+        uint64_t run = base;
+        for (uint64_t p = 0; p < N; ++p) {
+            path_grp_off.push_back(run);
+            run += deg[p];
+        }
+        path_grp_off.push_back(run);
+        path_grp.resize(run);
+        std::vector<uint64_t> cursor(path_grp_off.begin() + inc_off[m], path_grp_off.begin() + inc_off[m] + N);
+        for (uint64_t gi = g0; gi < g1; ++gi) {
+            for (uint64_t x = spec->group_path_off[gi]; x < spec->group_path_off[gi + 1]; ++x) {
+                path_grp[cursor[spec->group_path[x]]++] = static_cast<uint32_t>(gi - g0);
+            }
+        }
+    }
+    g->h_num_cols = cols;
+    g->h_num_rows = rows;
+    if (M == 0) {
+        *groups_out = g;
+        return RPVG_HIP_OK;
+    }
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    hipError_t e = hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    DeviceBuffer<uint64_t> d_inc_off, d_path_grp_off;
+    DeviceBuffer<uint32_t> d_path_grp;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    int span = ctx->spanBegin(FAM_H2D);
+    ok(g->mat_val_off.upload(val_off.data(), M, st));
+    ok(g->mat_row_off.upload(row_off.data(), M, st));
+    ok(g->mat_row0.upload(row0.data(), M, st));
+    ok(g->mat_rows.upload(rows.data(), M, st));
+    ok(g->mat_cols.upload(cols.data(), M, st));
+    ok(d_inc_off.upload(inc_off.data(), M, st));
+    ok(d_path_grp_off.upload(path_grp_off.data(), path_grp_off.size(), st));
+    ok(d_path_grp.upload(path_grp.data(), path_grp.size(), st));
+    ctx->spanEnd(span);
+    ctx->stats.h2d_bytes += static_cast<double>(M * 44 + path_grp_off.size() * 8 + path_grp.size() * 4);
+    ok(g->values.alloc(val_total));
+    ok(g->rowmax.alloc(row_total));
+    if (e == hipSuccess) {
+        span = ctx->spanBegin(FAM_BUILD);
+        ok(hipMemsetAsync(g->values.ptr, 0, val_total * sizeof(double), st));
+        groupsBuildKernel<<<dim3(M), dim3(256), 0, st>>>(M, g->mat_val_off.ptr, g->mat_row_off.ptr, g->mat_row0.ptr,
+                                                       g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
+                                                       d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr,
+                                                       batch->ent_prob.ptr, batch->row_noise.ptr, spec->normalise ? 1 : 0,
+                                                       g->values.ptr, g->rowmax.ptr);
+        ctx->spanEnd(span);
+        ctx->stats.build_launches += 1;
+        ok(hipGetLastError());
+        ok(hipStreamSynchronize(st));  // incidence temporaries are freed on return
+    }
+    if (e != hipSuccess) {
+        setError("rpvg_hip_groups_build: %s", hipGetErrorString(e));
+        delete g;
+        return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
+    }
+    *groups_out = g;
+    return RPVG_HIP_OK;
+}
+
+extern "C" void rpvg_hip_groups_free(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups) {
+    if (!groups) return;
+    if (ctx) {
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        (void) hipSetDevice(ctx->device);
+        (void) hipStreamSynchronize(ctx->stream);
+        delete groups;
+    } else {
+        delete groups;
+    }
+}
+
+extern "C" int rpvg_hip_group_loglik(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, uint32_t num_requests,
+                                     const uint32_t * matrix, const uint32_t * members, uint32_t width, double divisor,
+                                     const uint8_t * add_rowmax, double * out) {
+    RPVG_REQUIRE(ctx && groups, "rpvg_hip_group_loglik: NULL argument");
+    if (num_requests == 0) return RPVG_HIP_OK;
+    RPVG_REQUIRE(matrix && members && out, "rpvg_hip_group_loglik: NULL request arrays");
+    RPVG_REQUIRE(width >= 1 && width <= 4, "rpvg_hip_group_loglik: width %u outside [1, 4]", width);
+    RPVG_REQUIRE(divisor > 0, "rpvg_hip_group_loglik: divisor must be positive");
+    double evals = 0;
+    for (uint32_t q = 0; q < num_requests; ++q) {
+        RPVG_REQUIRE(matrix[q] < groups->num_matrices, "rpvg_hip_group_loglik: request %u refers to matrix %u of %u", q,
+                     matrix[q], groups->num_matrices);
+        for (uint32_t w = 0; w < width; ++w) {
+            const uint32_t mem = members[static_cast<uint64_t>(q) * width + w];
+            RPVG_REQUIRE(mem == kNoMember || mem < groups->h_num_cols[matrix[q]],
+                         "rpvg_hip_group_loglik: request %u member %u >= %u columns", q, mem, groups->h_num_cols[matrix[q]]);
+        }
+        evals += static_cast<double>(groups->h_num_rows[matrix[q]]);
+    }
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DeviceBuffer<uint32_t> d_matrix, d_members;
+    DeviceBuffer<uint8_t> d_flag;
+    DeviceBuffer<double> d_out;
+    int span = ctx->spanBegin(FAM_H2D);
+    RPVG_HIP_CHECK(d_matrix.upload(matrix, num_requests, st));
+    RPVG_HIP_CHECK(d_members.upload(members, static_cast<size_t>(num_requests) * width, st));
+    if (add_rowmax) RPVG_HIP_CHECK(d_flag.upload(add_rowmax, num_requests, st));
+    ctx->spanEnd(span);
+    ctx->stats.h2d_bytes += static_cast<double>(num_requests) * (4 + 4 * width + (add_rowmax ? 1 : 0));
+    RPVG_HIP_CHECK(d_out.alloc(num_requests));
+
+    const uint32_t blocks = (num_requests + 3) / 4;
+    const rpvg_hip_batch * b = groups->batch;
+    span = ctx->spanBegin(FAM_LOGLIK);
+#define RPVG_LAUNCH_LOGLIK(W)                                                                                              \
+    groupLoglikKernel<W><<<dim3(blocks), dim3(256), 0, st>>>(num_requests, d_matrix.ptr, d_members.ptr, d_flag.ptr, divisor, \
+                                                            groups->mat_val_off.ptr, groups->mat_row_off.ptr,               \
+                                                            groups->mat_row0.ptr, groups->mat_rows.ptr, groups->values.ptr, \
+                                                            groups->rowmax.ptr, b->row_count.ptr, b->row_noise.ptr, d_out.ptr)
+    switch (width) {
+        case 1: RPVG_LAUNCH_LOGLIK(1); break;
+        case 2: RPVG_LAUNCH_LOGLIK(2); break;
+        case 3: RPVG_LAUNCH_LOGLIK(3); break;
+        default: RPVG_LAUNCH_LOGLIK(4); break;
+    }
+#undef RPVG_LAUNCH_LOGLIK
+    ctx->spanEnd(span);
+    ctx->stats.loglik_launches += 1;
+    ctx->stats.loglik_evals += evals;
+    RPVG_HIP_CHECK(hipGetLastError());
+    RPVG_HIP_CHECK(d_out.download(out, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    return RPVG_HIP_OK;
+}

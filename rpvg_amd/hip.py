@@ -1,0 +1,261 @@
+"""ctypes binding of ``include/rpvg_hip.h`` (librpvg_hip.so) for tests and bench.
+
+Thin: every function maps 1:1 to a C-ABI entry point.  There is no fallback:
+if the shared library is missing or no GPU is usable, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .batch import CClusterBatch, ClusterBatch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librpvg_hip.so")
+
+# every symbol include/rpvg_hip.h declares
+EXPORTS = [
+    "rpvg_hip_device_count", "rpvg_hip_create", "rpvg_hip_destroy", "rpvg_hip_last_error", "rpvg_hip_synchronize",
+    "rpvg_hip_device_info", "rpvg_hip_malloc", "rpvg_hip_free", "rpvg_hip_memcpy_h2d", "rpvg_hip_memcpy_d2h",
+    "rpvg_hip_batch_upload", "rpvg_hip_batch_free", "rpvg_hip_em_solve", "rpvg_hip_em_dense",
+    "rpvg_hip_dense_from_cluster", "rpvg_hip_groups_build", "rpvg_hip_groups_free", "rpvg_hip_group_loglik",
+    "rpvg_hip_synth_dense_cluster", "rpvg_hip_stats_get", "rpvg_hip_stats_reset",
+]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class CEmProblems(C.Structure):
+    _fields_ = [("num_problems", C.c_uint32), ("cluster", C.c_void_p), ("col_off", C.c_void_p), ("col_path", C.c_void_p)]
+
+
+class CEmResults(C.Structure):
+    _fields_ = [("abundances", C.c_void_p), ("noise_count", C.c_void_p), ("total_count", C.c_void_p),
+                ("iterations", C.c_void_p)]
+
+
+class CGroupSpec(C.Structure):
+    _fields_ = [("num_matrices", C.c_uint32), ("cluster", C.c_void_p), ("group_off", C.c_void_p),
+                ("group_path_off", C.c_void_p), ("group_path", C.c_void_p), ("normalise", C.c_int32)]
+
+
+class CKernelStats(C.Structure):
+    _fields_ = [
+        ("em_sparse_ms", C.c_double), ("em_sparse_launches", C.c_uint64), ("em_sparse_alg_bytes", C.c_double),
+        ("em_dense_ms", C.c_double), ("em_dense_launches", C.c_uint64), ("em_dense_alg_bytes", C.c_double),
+        ("loglik_ms", C.c_double), ("loglik_launches", C.c_uint64), ("loglik_evals", C.c_double),
+        ("build_ms", C.c_double), ("build_launches", C.c_uint64),
+        ("h2d_ms", C.c_double), ("h2d_bytes", C.c_double),
+        ("em_iterations_total", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads librpvg_hip.so (built by __graft_entry__.build()); raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.rpvg_hip_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            getattr(L, name)
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise EngineError(f"{what} failed ({rc}): {lib().rpvg_hip_last_error().decode()}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().rpvg_hip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class DeviceBatch:
+    def __init__(self, ctx: "Context", host: ClusterBatch):
+        self.ctx = ctx
+        self.host = host
+        self.handle = C.c_void_p()
+        cb = host.as_c()
+        _check(lib().rpvg_hip_batch_upload(ctx.handle, C.byref(cb), C.byref(self.handle)), "rpvg_hip_batch_upload")
+
+    def free(self):
+        if self.handle:
+            lib().rpvg_hip_batch_free(self.ctx.handle, self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceGroups:
+    def __init__(self, ctx: "Context", batch: DeviceBatch, clusters: Sequence[int], groups: Sequence[Sequence[Sequence[int]]],
+                 normalise: bool):
+        """groups[m] = list of path lists (one per column) for matrix m on clusters[m]."""
+        self.ctx = ctx
+        self.batch = batch
+        cl = np.ascontiguousarray(clusters, dtype=np.uint32)
+        goff, gpoff, gp = [0], [0], []
+        for cols in groups:
+            for paths in cols:
+                gp.extend(paths)
+                gpoff.append(len(gp))
+            goff.append(len(gpoff) - 1)
+        goff = np.ascontiguousarray(goff, dtype=np.uint64)
+        gpoff = np.ascontiguousarray(gpoff, dtype=np.uint64)
+        gp = np.ascontiguousarray(gp, dtype=np.uint32)
+        spec = CGroupSpec(len(cl), cl.ctypes.data, goff.ctypes.data, gpoff.ctypes.data, gp.ctypes.data, 1 if normalise else 0)
+        self.handle = C.c_void_p()
+        _check(lib().rpvg_hip_groups_build(ctx.handle, batch.handle, C.byref(spec), C.byref(self.handle)),
+               "rpvg_hip_groups_build")
+
+    def loglik(self, matrix, members, divisor: float, add_rowmax=None) -> np.ndarray:
+        mt = np.ascontiguousarray(matrix, dtype=np.uint32)
+        mem = np.ascontiguousarray(members, dtype=np.uint32)
+        if mem.ndim == 1:
+            mem = mem.reshape(len(mt), -1)
+        width = mem.shape[1]
+        out = np.zeros(len(mt), dtype=np.float64)
+        flag = None if add_rowmax is None else np.ascontiguousarray(add_rowmax, dtype=np.uint8)
+        _check(lib().rpvg_hip_group_loglik(self.ctx.handle, self.handle, C.c_uint32(len(mt)), C.c_void_p(mt.ctypes.data),
+                                           C.c_void_p(mem.ctypes.data), C.c_uint32(width), C.c_double(divisor),
+                                           C.c_void_p(flag.ctypes.data if flag is not None else None),
+                                           C.c_void_p(out.ctypes.data)), "rpvg_hip_group_loglik")
+        return out
+
+    def free(self):
+        if self.handle:
+            lib().rpvg_hip_groups_free(self.ctx.handle, self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU + one HIP stream (rpvg_hip_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.handle = C.c_void_p()
+        _check(lib().rpvg_hip_create(C.c_int(device), C.byref(self.handle)), "rpvg_hip_create")
+
+    def close(self):
+        if self.handle:
+            lib().rpvg_hip_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> Tuple[str, int, int]:
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_uint32(0), C.c_uint64(0)
+        _check(lib().rpvg_hip_device_info(self.handle, name, 256, C.byref(cus), C.byref(mem)), "rpvg_hip_device_info")
+        return name.value.decode(), cus.value, mem.value
+
+    def synchronize(self):
+        _check(lib().rpvg_hip_synchronize(self.handle), "rpvg_hip_synchronize")
+
+    def upload(self, host: ClusterBatch) -> DeviceBatch:
+        return DeviceBatch(self, host)
+
+    def groups(self, batch: DeviceBatch, clusters, groups, normalise: bool) -> DeviceGroups:
+        return DeviceGroups(self, batch, clusters, groups, normalise)
+
+    # ---- EM -----------------------------------------------------------------
+    def em_solve(self, batch: DeviceBatch, clusters: Sequence[int], columns: Sequence[Sequence[int]],
+                 max_em_its: int = 10000, max_rel_em_conv: float = 1e-3):
+        """Returns (abundances list per problem, noise_count[P], total_count[P], iterations[P])."""
+        P = len(clusters)
+        cl = np.ascontiguousarray(clusters, dtype=np.uint32)
+        col_off = np.zeros(P + 1, dtype=np.uint64)
+        col_off[1:] = np.cumsum([len(c) for c in columns])
+        col_path = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint32) for c in columns])
+                                        if P else np.zeros(0), dtype=np.uint32)
+        abund = np.zeros(int(col_off[-1]), dtype=np.float64)
+        noise = np.zeros(P, dtype=np.float64)
+        total = np.zeros(P, dtype=np.float64)
+        iters = np.zeros(P, dtype=np.uint32)
+        probs = CEmProblems(P, cl.ctypes.data, col_off.ctypes.data, col_path.ctypes.data)
+        res = CEmResults(abund.ctypes.data, noise.ctypes.data, total.ctypes.data, iters.ctypes.data)
+        _check(lib().rpvg_hip_em_solve(self.handle, batch.handle, C.c_uint32(max_em_its), C.c_double(max_rel_em_conv),
+                                       C.byref(probs), C.byref(res)), "rpvg_hip_em_solve")
+        off = col_off.astype(np.int64)
+        return [abund[off[p]:off[p + 1]] for p in range(P)], noise, total, iters
+
+    # ---- dense ----------------------------------------------------------------
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        _check(lib().rpvg_hip_malloc(self.handle, C.c_uint64(nbytes), C.byref(p)), "rpvg_hip_malloc")
+        return p.value
+
+    def free(self, ptr: int):
+        _check(lib().rpvg_hip_free(self.handle, C.c_void_p(ptr)), "rpvg_hip_free")
+
+    def h2d(self, dst: int, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        _check(lib().rpvg_hip_memcpy_h2d(self.handle, C.c_void_p(dst), C.c_void_p(a.ctypes.data), C.c_uint64(a.nbytes)),
+               "rpvg_hip_memcpy_h2d")
+
+    def d2h(self, src: int, shape, dtype=np.float64) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        _check(lib().rpvg_hip_memcpy_d2h(self.handle, C.c_void_p(out.ctypes.data), C.c_void_p(src), C.c_uint64(out.nbytes)),
+               "rpvg_hip_memcpy_d2h")
+        return out
+
+    def em_dense(self, d_matrix: int, R: int, Cn: int, ld: int, d_counts: int, total: float, max_em_its: int = 10000,
+                 max_rel_em_conv: float = 1e-3):
+        ab = np.zeros(Cn - 1, dtype=np.float64)
+        noise = C.c_double(0)
+        its = C.c_uint32(0)
+        _check(lib().rpvg_hip_em_dense(self.handle, C.c_void_p(d_matrix), C.c_uint64(R), C.c_uint32(Cn), C.c_uint64(ld),
+                                       C.c_void_p(d_counts), C.c_double(total), C.c_uint32(max_em_its),
+                                       C.c_double(max_rel_em_conv), C.c_void_p(ab.ctypes.data), C.byref(noise),
+                                       C.byref(its)), "rpvg_hip_em_dense")
+        return ab, noise.value, its.value
+
+    def dense_from_cluster(self, batch: DeviceBatch, cluster: int, d_matrix: int, ld: int, d_counts: int) -> float:
+        total = C.c_double(0)
+        _check(lib().rpvg_hip_dense_from_cluster(self.handle, batch.handle, C.c_uint32(cluster), C.c_void_p(d_matrix),
+                                                 C.c_uint64(ld), C.c_void_p(d_counts), C.byref(total)),
+               "rpvg_hip_dense_from_cluster")
+        return total.value
+
+    def synth_dense_cluster(self, seed: int, R: int, N: int, d_matrix: int, ld: int, d_counts: int):
+        _check(lib().rpvg_hip_synth_dense_cluster(self.handle, C.c_uint64(seed), C.c_uint64(R), C.c_uint32(N),
+                                                  C.c_void_p(d_matrix), C.c_uint64(ld), C.c_void_p(d_counts)),
+               "rpvg_hip_synth_dense_cluster")
+
+    # ---- stats ----------------------------------------------------------------
+    def stats(self) -> dict:
+        s = CKernelStats()
+        _check(lib().rpvg_hip_stats_get(self.handle, C.byref(s)), "rpvg_hip_stats_get")
+        return s.as_dict()
+
+    def reset_stats(self):
+        _check(lib().rpvg_hip_stats_reset(self.handle), "rpvg_hip_stats_reset")

@@ -1,0 +1,262 @@
+"""GPU parity tests of the C-ABI kernels (include/rpvg_hip.h) against the CPU oracle.
+
+Bar (BASELINE.json north_star): integer results exact (read totals, EM
+iteration counts), abundances / log-likelihoods within 1e-4 relative with an
+absolute floor of prob_precision = 1e-8.  In practice FP64 end to end gives
+~1e-12; the tests assert 1e-7 so that a real regression is loud.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle, pyoracle
+from rpvg_amd.batch import ClusterBatch, make_params
+from tests import small_cases
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-7  # far inside the 1e-4 budget
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _golden_clusters(name):
+    with open(os.path.join(GOLDEN, f"oracle_{name}.json")) as f:
+        gold = json.load(f)
+    clusters = [dict(paths=c["paths"], rows=[(r[0], r[1], [(g[0], g[1]) for g in r[2]]) for r in c["rows"]])
+                for c in gold["clusters"]]
+    return clusters, gold
+
+
+def _nonempty(clusters):
+    return [k for k, c in enumerate(clusters) if c["rows"]]
+
+
+# ---- sparse batched EM -----------------------------------------------------------
+
+def test_em_solve_golden_transcripts(hip_ctx):
+    clusters, gold = _golden_clusters("transcripts")
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    ks = _nonempty(clusters)
+    cols = [list(range(len(clusters[k]["paths"]))) for k in ks]
+    abund, noise, total, iters = hip_ctx.em_solve(dev, ks, cols)
+    for i, k in enumerate(ks):
+        ge = gold["estimates"][k]
+        want = np.array([s[2][0] for s in sorted(ge["sets"], key=lambda s: s[0])])
+        assert total[i] == ge["total_count"]
+        assert int(iters[i]) == ge["em_iters"][0]
+        assert small_cases.rel_close(abund[i], want, rel=REL)
+        assert abs(noise[i] - ge["noise_count"]) <= REL * max(1.0, ge["total_count"])
+        assert abs(abund[i].sum() + noise[i] - total[i]) <= 1e-9 * total[i]
+
+
+@pytest.mark.parametrize("seed", [401, 402, 403])
+def test_em_solve_matches_oracle_all_columns(hip_ctx, seed):
+    clusters = small_cases.make_batch_clusters(seed, n_clusters=12)
+    batch = ClusterBatch.from_clusters(clusters)
+    est, _ = pyoracle.run("transcripts", make_params(), batch, 2)
+    dev = hip_ctx.upload(batch)
+    ks = _nonempty(clusters)
+    cols = [list(range(len(clusters[k]["paths"]))) for k in ks]
+    abund, noise, total, iters = hip_ctx.em_solve(dev, ks, cols)
+    for i, k in enumerate(ks):
+        e = est[k]
+        assert total[i] == e.total_count
+        assert [int(iters[i])] == e.em_iters
+        assert small_cases.rel_close(abund[i], e.abundances, rel=REL)
+        assert abs(noise[i] - e.noise_count) <= REL * max(1.0, e.total_count)
+
+
+@pytest.mark.parametrize("seed", [411, 412])
+def test_em_solve_column_subsets(hip_ctx, seed):
+    """Subset problems (what haplotype-transcripts issues): oracle = Partial matrix -> normalise -> collapse -> EM."""
+    rng = np.random.default_rng(seed)
+    clusters = small_cases.make_batch_clusters(seed, n_clusters=8, with_empty=False)
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    ks, cols = [], []
+    for k, cl in enumerate(clusters):
+        n = len(cl["paths"])
+        for _ in range(4):
+            size = int(rng.integers(1, n + 1))
+            ks.append(k)
+            cols.append(sorted(int(x) for x in rng.choice(n, size=size, replace=False)))
+    abund, noise, total, iters = hip_ctx.em_solve(dev, ks, cols)
+    for i, (k, c) in enumerate(zip(ks, cols)):
+        cl = clusters[k]
+        P, pn, pc = np_oracle.dense_matrix(cl["rows"], len(cl["paths"]), c)
+        Pn = np_oracle.add_noise_and_normalize(P, pn)
+        Pn, pc = np_oracle.read_collapse(Pn, pc, 1e-8)
+        ab, nc, tot, its, _ = pyoracle.em_dense(Pn, pc)
+        assert total[i] == tot
+        assert int(iters[i]) == its, (k, c)
+        assert small_cases.rel_close(abund[i], ab, rel=REL)
+        assert abs(noise[i] - nc) <= REL * max(1.0, tot)
+
+
+def test_em_solve_edge_cases(hip_ctx):
+    # SURVEY §8c known answers through the GPU path, in one ragged batch
+    n = 1e-4
+    clusters = [
+        # KAT-EM-disjoint: 12 iterations, abundances (30, 70)
+        dict(paths=[{}, {}], rows=[(30, n, [(1 - n, [0])]), (70, n, [(1 - n, [1])])]),
+        # KAT-EM-tie: one row [0.45, 0.45 | 0.1] x 7 -> (3.5, 3.5), 21 iterations
+        dict(paths=[{}, {}], rows=[(7, 0.1, [(0.45, [0, 1])])]),
+        # KAT-EM-empty: only path-less rows -> (0, 0), noise 5, 11 iterations
+        dict(paths=[{}, {}], rows=[(2, 1.0, []), (3, 1.0, [])]),
+        # KAT-EM-single: one path
+        dict(paths=[{}], rows=[(5, 0.1, [(0.9, [0])]), (5, 0.01, [(0.99, [0])])]),
+    ]
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    abund, noise, total, iters = hip_ctx.em_solve(dev, [0, 1, 2, 3], [[0, 1], [0, 1], [0, 1], [0]])
+    assert list(iters) == [12, 21, 11, 16]
+    assert list(total) == [100, 7, 5, 10]
+    assert small_cases.rel_close(abund[0], [30, 70], rel=1e-12)
+    assert small_cases.rel_close(abund[1], [3.5, 3.5], rel=1e-12)
+    assert list(abund[2]) == [0, 0] and noise[2] == 5
+    assert abs(abund[3][0] - 10) < 1e-10
+    # max_em_its is honoured exactly
+    _, _, _, it1 = hip_ctx.em_solve(dev, [0, 1], [[0, 1], [0, 1]], max_em_its=3)
+    assert list(it1) == [3, 3]
+
+
+def test_em_solve_large_block_bins(hip_ctx):
+    """A problem big enough for the 256- and 1024-thread kernels; oracle on the same rows."""
+    rng = np.random.default_rng(77)
+    n_paths = 300
+    rows = []
+    for _ in range(30000):
+        k = int(rng.integers(1, 6))
+        idx = sorted(int(x) for x in rng.choice(n_paths, size=k, replace=False))
+        lik = {p: float(rng.random()) + 0.05 for p in idx}
+        rows.append(small_cases.finish_row(int(rng.integers(1, 5)), float(rng.choice([1e-4, 1e-3, 0.1])), lik))
+    cl = dict(paths=[{} for _ in range(n_paths)], rows=rows)
+    small = dict(paths=[{} for _ in range(5)], rows=rows[:0] + [small_cases.finish_row(3, 1e-3, {0: 0.2, 3: 0.7})])
+    batch = ClusterBatch.from_clusters([cl, small])
+    est, _ = pyoracle.run("transcripts", make_params(max_em_its=200), batch, 2)
+    dev = hip_ctx.upload(batch)
+    abund, noise, total, iters = hip_ctx.em_solve(dev, [0, 1], [list(range(n_paths)), list(range(5))], max_em_its=200)
+    for i in range(2):
+        assert total[i] == est[i].total_count
+        assert [int(iters[i])] == est[i].em_iters
+        assert small_cases.rel_close(abund[i], est[i].abundances, rel=REL)
+
+
+# ---- dense streaming EM -------------------------------------------------------------
+
+def test_dense_from_cluster_and_em_dense(hip_ctx):
+    clusters, gold = _golden_clusters("transcripts")
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    for k in _nonempty(clusters):
+        cl = clusters[k]
+        R, N = len(cl["rows"]), len(cl["paths"])
+        ld = (N + 2) & ~1
+        d_P, d_c = hip_ctx.malloc(R * ld * 8), hip_ctx.malloc(R * 8)
+        try:
+            total = hip_ctx.dense_from_cluster(dev, k, d_P, ld, d_c)
+            P = hip_ctx.d2h(d_P, (R, ld))
+            Pd, pn, pc = np_oracle.dense_matrix(cl["rows"], N)
+            Pn = np_oracle.add_noise_and_normalize(Pd, pn)
+            assert np.allclose(P[:, :N + 1], Pn, rtol=1e-14, atol=0)  # same two roundings per entry; row sums may differ by an ulp
+            assert np.array_equal(P[:, :N + 1] == 0, Pn == 0)
+            assert total == pc.sum()
+            ab, noise, its = hip_ctx.em_dense(d_P, R, N + 1, ld, d_c, total)
+            ge = gold["estimates"][k]
+            want = np.array([s[2][0] for s in sorted(ge["sets"], key=lambda s: s[0])])
+            assert its == ge["em_iters"][0]
+            assert small_cases.rel_close(ab, want, rel=REL)
+            assert abs(noise - ge["noise_count"]) <= REL * max(1.0, total)
+        finally:
+            hip_ctx.free(d_P)
+            hip_ctx.free(d_c)
+
+
+@pytest.mark.parametrize("R,N", [(3000, 2000), (5000, 130), (777, 1), (4096, 257)])
+def test_synth_dense_em_matches_oracle(hip_ctx, R, N):
+    ld = (N + 2) & ~1
+    d_P, d_c = hip_ctx.malloc(R * ld * 8), hip_ctx.malloc(R * 8)
+    try:
+        hip_ctx.synth_dense_cluster(2, R, N, d_P, ld, d_c)
+        P = hip_ctx.d2h(d_P, (R, ld))[:, :N + 1].copy()
+        counts = hip_ctx.d2h(d_c, (R,))
+        assert np.all(counts == 1)
+        assert np.all(np.abs(P.sum(axis=1) - 1) < 1e-12)  # K2 invariant: paths + noise = 1
+        assert np.all(P[:, :N] > 0)  # dense: every entry non-zero
+        max_its = 40
+        ab, noise, its = hip_ctx.em_dense(d_P, R, N + 1, ld, d_c, float(R), max_em_its=max_its)
+        ab_o, noise_o, tot_o, its_o, _ = pyoracle.em_dense(P, counts, max_em_its=max_its)
+        assert its == its_o
+        assert small_cases.rel_close(ab, ab_o, rel=REL)
+        assert abs(noise - noise_o) <= REL * R
+        assert abs(ab.sum() + noise - R) <= 1e-9 * R
+    finally:
+        hip_ctx.free(d_P)
+        hip_ctx.free(d_c)
+
+
+def test_em_dense_converges_like_oracle(hip_ctx):
+    R, N = 2000, 40
+    ld = (N + 2) & ~1
+    d_P, d_c = hip_ctx.malloc(R * ld * 8), hip_ctx.malloc(R * 8)
+    try:
+        hip_ctx.synth_dense_cluster(9, R, N, d_P, ld, d_c)
+        P = hip_ctx.d2h(d_P, (R, ld))[:, :N + 1].copy()
+        ab, noise, its = hip_ctx.em_dense(d_P, R, N + 1, ld, d_c, float(R))
+        ab_o, noise_o, _, its_o, _ = pyoracle.em_dense(P, np.ones(R))
+        assert its == its_o and its < 10000
+        assert small_cases.rel_close(ab, ab_o, rel=REL)
+    finally:
+        hip_ctx.free(d_P)
+        hip_ctx.free(d_c)
+
+
+# ---- group log-likelihoods ------------------------------------------------------------
+
+@pytest.mark.parametrize("normalise", [False, True])
+def test_group_loglik_matches_numpy(hip_ctx, normalise):
+    clusters = small_cases.make_batch_clusters(501, n_clusters=6, with_empty=False)
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    mats, groups = [], []
+    for k, cl in enumerate(clusters):
+        if normalise:
+            g, _ = np_oracle.source_groups(cl["paths"])
+        else:
+            g = [[p] for p in range(len(cl["paths"]))]
+        mats.append(k)
+        groups.append(g)
+    dg = hip_ctx.groups(dev, mats, groups, normalise)
+    rng = np.random.default_rng(3)
+    for m, (k, g) in enumerate(zip(mats, groups)):
+        cl = clusters[k]
+        M, noise, counts = np_oracle.grouped_matrix(cl["rows"], g)
+        if normalise:
+            Mn = np_oracle.add_noise_and_normalize(M, noise)
+            M = Mn[:, :-1]
+        G = len(g)
+        pairs = [(a, b) for a in range(G) for b in range(a, G)]
+        want2 = np.array([np_oracle.set_loglik(M, noise, counts, p, 2) for p in pairs])
+        got2 = dg.loglik([m] * len(pairs), pairs, 2.0)
+        assert small_cases.rel_close(got2, want2, rel=1e-11, floor=1e-9)
+        want1 = np.array([np_oracle.set_loglik(M, noise, counts, (a,), 1) for a in range(G)])
+        got1 = dg.loglik([m] * G, [[a] for a in range(G)], 1.0)
+        assert small_cases.rel_close(got1, want1, rel=1e-11, floor=1e-9)
+        # optimistic bound of the diploid search: noise + M_a/2 + rowmax/2
+        rm = M.max(axis=1)
+        wantb = np.array([float(counts @ np.log(noise + M[:, a] / 2 + rm / 2)) for a in range(G)])
+        gotb = dg.loglik([m] * G, [[a, 0xFFFFFFFF] for a in range(G)], 2.0, add_rowmax=[1] * G)
+        assert small_cases.rel_close(gotb, wantb, rel=1e-11, floor=1e-9)
+
+
+def test_stats_report_kernel_time(hip_ctx):
+    clusters = small_cases.make_batch_clusters(9, n_clusters=4, with_empty=False)
+    dev = hip_ctx.upload(ClusterBatch.from_clusters(clusters))
+    hip_ctx.reset_stats()
+    hip_ctx.em_solve(dev, [0, 1], [list(range(len(clusters[0]["paths"]))), list(range(len(clusters[1]["paths"])))])
+    st = hip_ctx.stats()
+    assert st["em_sparse_launches"] >= 1 and st["em_sparse_ms"] > 0 and st["em_sparse_alg_bytes"] > 0
+    assert st["em_iterations_total"] > 0
