@@ -1,0 +1,147 @@
+"""ctypes binding of the host-side estimator runner (librpvg_amd_host.so).
+
+The work happens in C++ (``rpvg_amd/host``: PathEstimator classes over the C
+ABI of the HIP engine); this module only marshals flat batches in and
+estimates out for tests and bench.  No fallback: a missing library or GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Tuple
+
+from . import hip
+from .batch import CClusterBatch, CEstimatesView, CParams, ClusterBatch, ClusterEstimates, decode_view
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "host", "librpvg_amd_host.so")
+
+MODELS = ("transcripts", "haplotype-transcripts", "haplotypes")
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise hip.EngineError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() (there is no CPU fallback)")
+        hip.lib()  # librpvg_hip.so first (also resolved through the rpath)
+        L = C.CDLL(LIB_PATH)
+        L.rpvg_amd_last_error.restype = C.c_char_p
+        L.rpvg_amd_engine_create.restype = C.c_void_p
+        L.rpvg_amd_engine_create.argtypes = [C.c_int]
+        L.rpvg_amd_engine_destroy.argtypes = [C.c_void_p]
+        L.rpvg_amd_engine_ctx.restype = C.c_void_p
+        L.rpvg_amd_engine_ctx.argtypes = [C.c_void_p]
+        L.rpvg_amd_batch_prepare.restype = C.c_void_p
+        L.rpvg_amd_batch_prepare.argtypes = [C.c_void_p, C.POINTER(CClusterBatch), C.c_int]
+        L.rpvg_amd_batch_free.argtypes = [C.c_void_p]
+        L.rpvg_amd_run.restype = C.c_void_p
+        L.rpvg_amd_run.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double)]
+        L.rpvg_amd_result_view.argtypes = [C.c_void_p, C.POINTER(CEstimatesView)]
+        L.rpvg_amd_result_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _err() -> str:
+    return lib().rpvg_amd_last_error().decode()
+
+
+class Engine:
+    """One GPU (HipEngine) shared by the estimators created on it."""
+
+    def __init__(self, device: int = 0):
+        self.handle = lib().rpvg_amd_engine_create(device)
+        if not self.handle:
+            raise hip.EngineError(f"engine create failed: {_err()}")
+
+    def close(self):
+        if self.handle:
+            lib().rpvg_amd_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ctx(self):
+        return C.c_void_p(lib().rpvg_amd_engine_ctx(self.handle))
+
+    def stats(self) -> dict:
+        s = hip.CKernelStats()
+        hip._check(hip.lib().rpvg_hip_stats_get(self._ctx(), C.byref(s)), "rpvg_hip_stats_get")
+        return s.as_dict()
+
+    def reset_stats(self):
+        hip._check(hip.lib().rpvg_hip_stats_reset(self._ctx()), "rpvg_hip_stats_reset")
+
+    def info(self) -> Tuple[str, int, int]:
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_uint32(0), C.c_uint64(0)
+        hip._check(hip.lib().rpvg_hip_device_info(self._ctx(), name, 256, C.byref(cus), C.byref(mem)), "rpvg_hip_device_info")
+        return name.value.decode(), cus.value, mem.value
+
+    def prepare(self, batch: ClusterBatch, per_cluster: bool = False) -> "PreparedBatch":
+        return PreparedBatch(self, batch, per_cluster)
+
+    def run(self, model: str, params: CParams, prepared: "PreparedBatch") -> Tuple[List[ClusterEstimates], float]:
+        """Estimates of every cluster + wall seconds of the estimator call (inputs already on the GPU)."""
+        secs = C.c_double(0)
+        h = lib().rpvg_amd_run(self.handle, prepared.handle, model.encode(), C.byref(params), C.byref(secs))
+        if not h:
+            raise hip.EngineError(f"run({model}) failed: {_err()}")
+        try:
+            view = CEstimatesView()
+            lib().rpvg_amd_result_view(h, C.byref(view))
+            out = decode_view(view)
+        finally:
+            lib().rpvg_amd_result_free(h)
+        return out, secs.value
+
+    def run_raw(self, model: str, params: CParams, prepared: "PreparedBatch") -> float:
+        """Like run() but drops the estimates (bench inner loop: no Python decode in the way)."""
+        secs = C.c_double(0)
+        h = lib().rpvg_amd_run(self.handle, prepared.handle, model.encode(), C.byref(params), C.byref(secs))
+        if not h:
+            raise hip.EngineError(f"run({model}) failed: {_err()}")
+        lib().rpvg_amd_result_free(h)
+        return secs.value
+
+
+class PreparedBatch:
+    def __init__(self, engine: Engine, batch: ClusterBatch, per_cluster: bool):
+        self.engine = engine
+        self.batch = batch
+        cb = batch.as_c()
+        self.handle = lib().rpvg_amd_batch_prepare(engine.handle, C.byref(cb), 1 if per_cluster else 0)
+        if not self.handle:
+            raise hip.EngineError(f"batch prepare failed: {_err()}")
+
+    def free(self):
+        if self.handle:
+            lib().rpvg_amd_batch_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def run(model: str, params: CParams, batch: ClusterBatch, device: int = 0, per_cluster: bool = False) -> List[ClusterEstimates]:
+    """One-shot convenience: upload, estimate, decode."""
+    eng = Engine(device)
+    try:
+        prep = eng.prepare(batch, per_cluster)
+        try:
+            out, _ = eng.run(model, params, prep)
+        finally:
+            prep.free()
+    finally:
+        eng.close()
+    return out

@@ -1,0 +1,115 @@
+#include "hip_engine.hpp"
+
+#include <cassert>
+
+namespace rpvg_amd {
+
+HipEngine::HipEngine(const int device) : context(nullptr), device_id(device) {
+
+    check(rpvg_hip_create(device, &context), "rpvg_hip_create");
+}
+
+HipEngine::~HipEngine() {
+
+    rpvg_hip_destroy(context);
+}
+
+int HipEngine::deviceCount() {
+
+    int count = 0;
+
+    if (rpvg_hip_device_count(&count) != RPVG_HIP_OK) {
+
+        return 0;
+    }
+
+    return count;
+}
+
+void HipEngine::check(const int status, const char * what) {
+
+    if (status != RPVG_HIP_OK) {
+
+        throw EngineError(std::string(what) + " failed (" + std::to_string(status) + "): " + rpvg_hip_last_error());
+    }
+}
+
+FlatClusterRows::FlatClusterRows() : cluster_row_off(1, 0), cluster_path_off(1, 0), row_grp_off(1, 0), grp_idx_off(1, 0) {}
+
+void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & cluster_probs, const uint32_t num_paths) {
+
+    for (auto & probs: cluster_probs) {
+
+        row_count.emplace_back(probs.readCount());
+        row_noise.emplace_back(probs.noiseProb());
+
+        for (auto & path_probs: probs.pathProbs()) {
+
+            grp_prob.emplace_back(path_probs.first);
+            path_idx.insert(path_idx.end(), path_probs.second.begin(), path_probs.second.end());
+            grp_idx_off.emplace_back(path_idx.size());
+        }
+
+        row_grp_off.emplace_back(grp_prob.size());
+    }
+
+    cluster_row_off.emplace_back(row_count.size());
+    cluster_path_off.emplace_back(cluster_path_off.back() + num_paths);
+}
+
+rpvg_cluster_batch FlatClusterRows::view() const {
+
+    rpvg_cluster_batch batch;
+
+    batch.num_clusters = numClusters();
+    batch.cluster_row_off = cluster_row_off.data();
+    batch.cluster_path_off = cluster_path_off.data();
+
+    batch.row_count = row_count.data();
+    batch.row_noise = row_noise.data();
+    batch.row_grp_off = row_grp_off.data();
+    batch.grp_prob = grp_prob.data();
+    batch.grp_idx_off = grp_idx_off.data();
+    batch.path_idx = path_idx.data();
+
+    // PathInfo stays on the host side of the ABI (PathClusterEstimates::paths)
+    batch.path_group_id = nullptr;
+    batch.path_source_count = nullptr;
+    batch.path_source_off = nullptr;
+    batch.source_id = nullptr;
+    batch.path_effective_length = nullptr;
+
+    return batch;
+}
+
+DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch) : hip_engine(engine_in), batch(nullptr) {
+
+    assert(hip_engine);
+
+    HipEngine::check(rpvg_hip_batch_upload(hip_engine->ctx(), &host_batch, &batch), "rpvg_hip_batch_upload");
+
+    num_rows.reserve(host_batch.num_clusters);
+    num_paths.reserve(host_batch.num_clusters);
+
+    for (uint32_t i = 0; i < host_batch.num_clusters; ++i) {
+
+        num_rows.emplace_back(host_batch.cluster_row_off[i + 1] - host_batch.cluster_row_off[i]);
+        num_paths.emplace_back(host_batch.cluster_path_off[i + 1] - host_batch.cluster_path_off[i]);
+
+        uint64_t read_count = 0;
+
+        for (uint64_t j = host_batch.cluster_row_off[i]; j < host_batch.cluster_row_off[i + 1]; ++j) {
+
+            read_count += host_batch.row_count[j];
+        }
+
+        total_read_count.emplace_back(read_count);
+    }
+}
+
+DeviceClusterBatch::~DeviceClusterBatch() {
+
+    rpvg_hip_batch_free(hip_engine->ctx(), batch);
+}
+
+}

@@ -1,0 +1,104 @@
+// RAII handles over the C ABI of the GPU engine (include/rpvg_hip.h) for the
+// host-side estimator classes.  Nothing here computes: it flattens the
+// reference's row containers into the ABI's ragged arrays and forwards.
+#ifndef RPVG_AMD_HIP_ENGINE_HPP
+#define RPVG_AMD_HIP_ENGINE_HPP
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rpvg_hip.h"
+#include "read_path_probabilities.hpp"
+
+namespace rpvg_amd {
+
+// Thrown when a C-ABI call fails (the reference would have hit an assert).
+class EngineError : public std::runtime_error {
+
+    public:
+
+        explicit EngineError(const std::string & what_in) : std::runtime_error(what_in) {}
+};
+
+// One GPU + one HIP stream.  Shared by every estimator bound to that GPU.
+class HipEngine {
+
+    public:
+
+        explicit HipEngine(const int device);
+        ~HipEngine();
+
+        HipEngine(const HipEngine &) = delete;
+        HipEngine & operator=(const HipEngine &) = delete;
+
+        rpvg_hip_ctx * ctx() const { return context; }
+        int device() const { return device_id; }
+
+        static int deviceCount();
+
+        // Throws EngineError carrying rpvg_hip_last_error() when status != 0.
+        static void check(const int status, const char * what);
+
+    private:
+
+        rpvg_hip_ctx * context;
+        int device_id;
+};
+
+// Flat host copy of the rows of K clusters (the arrays rpvg_cluster_batch
+// points into), built from the reference's row containers.
+class FlatClusterRows {
+
+    public:
+
+        FlatClusterRows();
+
+        void addCluster(const std::vector<ReadPathProbabilities> & cluster_probs, const uint32_t num_paths);
+
+        uint32_t numClusters() const { return cluster_row_off.size() - 1; }
+        rpvg_cluster_batch view() const;
+
+    private:
+
+        std::vector<uint64_t> cluster_row_off, cluster_path_off, row_grp_off, grp_idx_off;
+        std::vector<uint32_t> row_count, path_idx;
+        std::vector<double> row_noise, grp_prob;
+};
+
+// K clusters resident on the GPU.
+class DeviceClusterBatch {
+
+    public:
+
+        DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch);
+        ~DeviceClusterBatch();
+
+        DeviceClusterBatch(const DeviceClusterBatch &) = delete;
+        DeviceClusterBatch & operator=(const DeviceClusterBatch &) = delete;
+
+        const rpvg_hip_batch * handle() const { return batch; }
+        const std::shared_ptr<HipEngine> & engine() const { return hip_engine; }
+
+        uint32_t numClusters() const { return num_rows.size(); }
+        uint64_t numRows(const uint32_t cluster) const { return num_rows.at(cluster); }
+        uint32_t numPaths(const uint32_t cluster) const { return num_paths.at(cluster); }
+
+        // Sum of the read counts of all rows of the cluster (exact: integers).
+        double totalReadCount(const uint32_t cluster) const { return total_read_count.at(cluster); }
+
+    private:
+
+        std::shared_ptr<HipEngine> hip_engine;
+        rpvg_hip_batch * batch;
+
+        std::vector<uint64_t> num_rows;
+        std::vector<uint32_t> num_paths;
+        std::vector<double> total_read_count;
+};
+
+}
+
+#endif

@@ -1,0 +1,473 @@
+#include "path_abundance_estimator.hpp"
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <numeric>
+
+#include "numeric_utils.hpp"
+
+namespace rpvg_amd {
+
+PathAbundanceEstimator::PathAbundanceEstimator(const uint32_t max_em_its_in, const double max_rel_em_conv_in, const uint32_t num_gibbs_samples_in, const uint32_t gibbs_thin_its_in, const double prob_precision, std::shared_ptr<HipEngine> engine) : PathEstimator(prob_precision, engine), max_em_its(max_em_its_in), max_rel_em_conv(max_rel_em_conv_in), num_gibbs_samples(num_gibbs_samples_in), gibbs_thin_its(gibbs_thin_its_in) {}
+
+void PathAbundanceEstimator::requireNoGibbsSamples() const {
+
+    if (num_gibbs_samples > 0) {
+
+        // gibbsReadCountSampler (src/path_abundance_estimator.cpp:116-212) is not on the GPU yet
+        throw EngineError("read-count Gibbs sampling (-n > 0) is not available in the GPU engine yet");
+    }
+}
+
+void PathAbundanceEstimator::EMAbundanceEstimator(std::vector<EMSolution> * solutions, const DeviceClusterBatch & cluster_batch, const std::vector<EMProblem> & problems) const {
+
+    solutions->assign(problems.size(), EMSolution());
+
+    if (problems.empty()) {
+
+        return;
+    }
+
+    std::vector<uint32_t> clusters;
+    std::vector<uint64_t> col_off(1, 0);
+    std::vector<uint32_t> col_path;
+
+    clusters.reserve(problems.size());
+    col_off.reserve(problems.size() + 1);
+
+    for (auto & problem: problems) {
+
+        assert(!problem.path_ids.empty());
+
+        clusters.emplace_back(problem.cluster);
+        col_path.insert(col_path.end(), problem.path_ids.begin(), problem.path_ids.end());
+        col_off.emplace_back(col_path.size());
+    }
+
+    std::vector<double> abundances(col_path.size());
+    std::vector<double> noise_counts(problems.size());
+    std::vector<double> total_counts(problems.size());
+    std::vector<uint32_t> iterations(problems.size());
+
+    rpvg_hip_em_problems em_problems;
+    em_problems.num_problems = problems.size();
+    em_problems.cluster = clusters.data();
+    em_problems.col_off = col_off.data();
+    em_problems.col_path = col_path.data();
+
+    rpvg_hip_em_results em_results;
+    em_results.abundances = abundances.data();
+    em_results.noise_count = noise_counts.data();
+    em_results.total_count = total_counts.data();
+    em_results.iterations = iterations.data();
+
+    HipEngine::check(rpvg_hip_em_solve(engine->ctx(), cluster_batch.handle(), max_em_its, max_rel_em_conv, &em_problems, &em_results), "rpvg_hip_em_solve");
+
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        auto & solution = solutions->at(i);
+
+        solution.abundances.assign(abundances.begin() + col_off.at(i), abundances.begin() + col_off.at(i + 1));
+        solution.noise_count = noise_counts.at(i);
+        solution.total_count = total_counts.at(i);
+        solution.iterations = iterations.at(i);
+    }
+}
+
+// src/path_abundance_estimator.cpp:18-45 over a batch of clusters.
+void PathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs) {
+
+    requireNoGibbsSamples();
+
+    assert(path_cluster_estimates->size() == cluster_batch.numClusters());
+
+    std::vector<EMProblem> problems;
+    problems.reserve(cluster_batch.numClusters());
+
+    for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
+
+        auto & estimates = path_cluster_estimates->at(i);
+
+        assert(estimates.paths.size() == cluster_batch.numPaths(i));
+        estimates.resetEstimates(estimates.paths.size(), 1);
+
+        if (cluster_batch.numRows(i) > 0) {
+
+            problems.emplace_back(EMProblem());
+            problems.back().cluster = i;
+
+            problems.back().path_ids.resize(estimates.paths.size());
+            std::iota(problems.back().path_ids.begin(), problems.back().path_ids.end(), 0);
+        }
+    }
+
+    std::vector<EMSolution> solutions;
+    EMAbundanceEstimator(&solutions, cluster_batch, problems);
+
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        auto & estimates = path_cluster_estimates->at(problems.at(i).cluster);
+
+        estimates.abundances = std::move(solutions.at(i).abundances);
+        estimates.noise_count = solutions.at(i).noise_count;
+        estimates.total_count = solutions.at(i).total_count;
+
+        estimates.em_iterations.emplace_back(solutions.at(i).iterations);
+        estimates.em_problem_paths.emplace_back(std::move(problems.at(i).path_ids));
+    }
+}
+
+NestedPathAbundanceEstimator::NestedPathAbundanceEstimator(const uint32_t group_size_in, const double min_hap_prob_in, const bool infer_collapsed_in, const bool use_group_post_gibbs_in, const uint32_t max_em_its, const double max_rel_em_conv, const uint32_t num_gibbs_samples, const uint32_t gibbs_thin_its, const double prob_precision, std::shared_ptr<HipEngine> engine) : PathAbundanceEstimator(max_em_its, max_rel_em_conv, num_gibbs_samples, gibbs_thin_its, prob_precision, engine), group_size(group_size_in), min_hap_prob(min_hap_prob_in), infer_collapsed(infer_collapsed_in), use_group_post_gibbs(use_group_post_gibbs_in) {}
+
+// src/path_abundance_estimator.cpp:344-471 over a batch of clusters: posteriors of
+// all clusters first (one set of GPU calls), then the EM solves of every retained
+// path subset of every cluster (one GPU call), then the weighted merge.
+void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs) {
+
+    requireNoGibbsSamples();
+
+    if (use_group_post_gibbs) {
+
+        // estimatePathGroupPosteriorsGibbs (src/path_estimator.cpp:475-589) is not on the GPU yet
+        throw EngineError("Gibbs haplotype posteriors (--use-hap-gibbs) are not available in the GPU engine yet");
+    }
+
+    assert(path_cluster_estimates->size() == cluster_batch.numClusters());
+
+    std::vector<uint32_t> clusters;
+
+    for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
+
+        assert(path_cluster_estimates->at(i).paths.size() == cluster_batch.numPaths(i));
+        path_cluster_estimates->at(i).resetEstimates(0, 0);
+
+        if (cluster_batch.numRows(i) > 0) {
+
+            clusters.emplace_back(i);
+        }
+    }
+
+    std::vector<PathSubsetWeights> path_subset_samples(clusters.size());
+
+    if (infer_collapsed) {
+
+        // inferAbundancesCollapsedGroups (:428-471)
+        std::vector<GroupPosteriorProblem> problems(clusters.size());
+
+        #pragma omp parallel for schedule(dynamic, 16)
+        for (size_t i = 0; i < clusters.size(); ++i) {
+
+            auto path_source_groups = findPathSourceGroups(path_cluster_estimates->at(clusters.at(i)).paths);
+
+            problems.at(i).cluster = clusters.at(i);
+            problems.at(i).column_paths = std::move(path_source_groups.first);
+            problems.at(i).column_counts = std::move(path_source_groups.second);
+        }
+
+        for (auto & problem: problems) {
+
+            if (problem.column_paths.empty()) {
+
+                throw EngineError("haplotype-transcripts inference needs source (haplotype) ids on the paths of every cluster");
+            }
+        }
+
+        std::vector<GroupPosteriors> group_posteriors;
+        pathGroupPosteriors(&group_posteriors, cluster_batch, problems);
+
+        #pragma omp parallel for schedule(dynamic, 16)
+        for (size_t i = 0; i < clusters.size(); ++i) {
+
+            selectPathSubsetIndices(&path_subset_samples.at(i), group_posteriors.at(i), problems.at(i).column_paths);
+        }
+
+    } else {
+
+        // inferAbundancesIndependentGroups (:356-426)
+        if (!rngs) {
+
+            throw EngineError("independent haplotype inference draws random numbers: a generator per cluster is required");
+        }
+
+        std::vector<GroupPosteriorProblem> problems;
+        std::vector<std::vector<std::vector<uint32_t> > > cluster_path_groups(clusters.size());
+        std::vector<size_t> first_problem(clusters.size() + 1, 0);
+
+        for (size_t i = 0; i < clusters.size(); ++i) {
+
+            const auto & paths = path_cluster_estimates->at(clusters.at(i)).paths;
+            cluster_path_groups.at(i) = findPathGroups(paths);
+
+            for (auto & group: cluster_path_groups.at(i)) {
+
+                problems.emplace_back(GroupPosteriorProblem());
+                problems.back().cluster = clusters.at(i);
+
+                for (auto & path: group) {
+
+                    problems.back().column_paths.emplace_back(std::vector<uint32_t>(1, path));
+                    problems.back().column_counts.emplace_back(paths.at(path).source_count);
+                }
+            }
+
+            first_problem.at(i + 1) = problems.size();
+        }
+
+        std::vector<GroupPosteriors> group_posteriors;
+        pathGroupPosteriors(&group_posteriors, cluster_batch, problems);
+
+        for (size_t i = 0; i < clusters.size(); ++i) {
+
+            std::vector<std::vector<uint32_t> > samples(std::floor(1 / min_hap_prob));
+
+            for (size_t j = 0; j < cluster_path_groups.at(i).size(); ++j) {
+
+                sampleGroupPathIndices(&samples, group_posteriors.at(first_problem.at(i) + j), cluster_path_groups.at(i).at(j), &rngs->at(clusters.at(i)));
+            }
+
+            for (auto & sample: samples) {
+
+                std::sort(sample.begin(), sample.end());
+                path_subset_samples.at(i)[sample] += 1 / static_cast<double>(samples.size());
+            }
+        }
+    }
+
+    inferPathSubsetAbundance(path_cluster_estimates, cluster_batch, clusters, path_subset_samples);
+}
+
+void NestedPathAbundanceEstimator::pathGroupPosteriors(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems) const {
+
+    if (group_size == 2) {
+
+        calculatePathGroupPosteriorsBounded(group_posteriors, cluster_batch, problems, group_size, min_hap_prob, true);
+
+    } else {
+
+        calculatePathGroupPosteriorsFull(group_posteriors, cluster_batch, problems, group_size, true);
+    }
+}
+
+// Paths grouped by group_id (transcript), groups in first-seen order
+// (src/path_abundance_estimator.cpp:473-491).
+std::vector<std::vector<uint32_t> > NestedPathAbundanceEstimator::findPathGroups(const std::vector<PathInfo> & paths) const {
+
+    std::vector<std::vector<uint32_t> > path_groups;
+    std::map<uint32_t, uint32_t> path_group_indexes;
+
+    for (size_t i = 0; i < paths.size(); ++i) {
+
+        auto path_group_indexes_it = path_group_indexes.emplace(paths.at(i).group_id, path_groups.size());
+
+        if (path_group_indexes_it.second) {
+
+            path_groups.emplace_back(std::vector<uint32_t>());
+        }
+
+        path_groups.at(path_group_indexes_it.first->second).emplace_back(i);
+    }
+
+    return path_groups;
+}
+
+// Haplotypes (source ids) carrying the identical list of paths form one column;
+// its multiplicity is the number of such haplotypes
+// (src/path_abundance_estimator.cpp:493-546).  Columns come out in ascending
+// order of their smallest source id (the reference's order is that of its hash map).
+std::pair<std::vector<std::vector<uint32_t> >, std::vector<uint32_t> > NestedPathAbundanceEstimator::findPathSourceGroups(const std::vector<PathInfo> & paths) const {
+
+    std::map<uint32_t, std::vector<uint32_t> > source_id_paths;
+
+    for (size_t i = 0; i < paths.size(); ++i) {
+
+        for (auto & id: paths.at(i).source_ids) {
+
+            source_id_paths[id].emplace_back(i);
+        }
+    }
+
+    std::pair<std::vector<std::vector<uint32_t> >, std::vector<uint32_t> > path_source_groups;
+    std::map<std::vector<uint32_t>, uint32_t> group_index;
+
+    for (auto & source_paths: source_id_paths) {
+
+        auto group_index_it = group_index.emplace(source_paths.second, path_source_groups.first.size());
+
+        if (group_index_it.second) {
+
+            path_source_groups.first.emplace_back(source_paths.second);
+            path_source_groups.second.emplace_back(1);
+
+        } else {
+
+            path_source_groups.second.at(group_index_it.first->second)++;
+        }
+    }
+
+    return path_source_groups;
+}
+
+// src/path_abundance_estimator.cpp:548-567
+void NestedPathAbundanceEstimator::sampleGroupPathIndices(std::vector<std::vector<uint32_t> > * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<uint32_t> & group, std::mt19937 * mt_rng) const {
+
+    assert(group_posteriors.posteriors.size() == group_posteriors.group_sets.size());
+    std::discrete_distribution<uint32_t> path_group_set_sampler(group_posteriors.posteriors.begin(), group_posteriors.posteriors.end());
+
+    for (auto & path_subset_sample: *path_subset_samples) {
+
+        std::vector<uint32_t> path_group_set = group_posteriors.group_sets.at(path_group_set_sampler(*mt_rng));
+        assert(path_group_set.size() == group_size);
+
+        std::sort(path_group_set.begin(), path_group_set.end());
+
+        for (auto & path_group: path_group_set) {
+
+            path_subset_sample.emplace_back(group.at(path_group));
+        }
+    }
+}
+
+// src/path_abundance_estimator.cpp:569-606
+void NestedPathAbundanceEstimator::selectPathSubsetIndices(PathSubsetWeights * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<std::vector<uint32_t> > & path_groups) const {
+
+    double sum_posterior = 0;
+
+    for (size_t i = 0; i < group_posteriors.posteriors.size(); ++i) {
+
+        if (group_posteriors.posteriors.at(i) < min_hap_prob) {
+
+            continue;
+        }
+
+        std::vector<uint32_t> path_subset;
+
+        for (auto & group: group_posteriors.group_sets.at(i)) {
+
+            path_subset.insert(path_subset.end(), path_groups.at(group).begin(), path_groups.at(group).end());
+        }
+
+        std::sort(path_subset.begin(), path_subset.end());
+
+        (*path_subset_samples)[path_subset] += group_posteriors.posteriors.at(i);
+        sum_posterior += group_posteriors.posteriors.at(i);
+    }
+
+    for (auto & subset_sample: *path_subset_samples) {
+
+        subset_sample.second /= sum_posterior;
+    }
+}
+
+// src/path_abundance_estimator.cpp:608-750 for all clusters at once.
+void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples) const {
+
+    assert(clusters.size() == path_subset_samples.size());
+
+    // one EM problem per retained subset: its distinct paths
+    std::vector<EMProblem> problems;
+    std::vector<size_t> first_problem(clusters.size() + 1, 0);
+
+    for (size_t i = 0; i < clusters.size(); ++i) {
+
+        for (auto & path_subset: path_subset_samples.at(i)) {
+
+            if (path_subset.second < min_hap_prob) {
+
+                continue;
+            }
+
+            assert(!path_subset.first.empty());
+
+            problems.emplace_back(EMProblem());
+            problems.back().cluster = clusters.at(i);
+
+            std::unique_copy(path_subset.first.begin(), path_subset.first.end(), std::back_inserter(problems.back().path_ids));
+        }
+
+        first_problem.at(i + 1) = problems.size();
+    }
+
+    std::vector<EMSolution> solutions;
+    EMAbundanceEstimator(&solutions, cluster_batch, problems);
+
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (size_t i = 0; i < clusters.size(); ++i) {
+
+        auto & estimates = path_cluster_estimates->at(clusters.at(i));
+
+        assert(estimates.noise_count == 0);
+        estimates.total_count = cluster_batch.totalReadCount(clusters.at(i));
+
+        // (paths of one transcript inside a subset) -> (probability, abundance per path)
+        std::map<std::vector<uint32_t>, std::pair<double, std::vector<double> > > path_group_estimates;
+
+        double sum_hap_prob = 0;
+        size_t problem_idx = first_problem.at(i);
+
+        for (auto & path_subset: path_subset_samples.at(i)) {
+
+            if (path_subset.second < min_hap_prob) {
+
+                continue;
+            }
+
+            sum_hap_prob += path_subset.second;
+
+            const auto & problem = problems.at(problem_idx);
+            const auto & solution = solutions.at(problem_idx);
+            ++problem_idx;
+
+            assert(solution.total_count == estimates.total_count);
+
+            estimates.em_iterations.emplace_back(solution.iterations);
+            estimates.em_problem_paths.emplace_back(problem.path_ids);
+
+            estimates.noise_count += solution.noise_count * path_subset.second;
+
+            std::map<uint32_t, std::vector<uint32_t> > subset_path_group_index;
+
+            for (auto & path: path_subset.first) {
+
+                subset_path_group_index[estimates.paths.at(path).group_id].emplace_back(path);
+            }
+
+            for (auto & path_group: subset_path_group_index) {
+
+                assert(path_group.second.size() <= group_size);
+
+                auto path_group_estimates_it = path_group_estimates.emplace(path_group.second, std::make_pair(0.0, std::vector<double>(path_group.second.size(), 0)));
+                path_group_estimates_it.first->second.first += path_subset.second;
+
+                for (size_t j = 0; j < path_group.second.size(); ++j) {
+
+                    const uint32_t path = path_group.second.at(j);
+
+                    const auto column_it = std::lower_bound(problem.path_ids.begin(), problem.path_ids.end(), path);
+                    assert(column_it != problem.path_ids.end() && *column_it == path);
+
+                    const uint32_t multiplicity = std::count(path_subset.first.begin(), path_subset.first.end(), path);
+
+                    path_group_estimates_it.first->second.second.at(j) += (solution.abundances.at(column_it - problem.path_ids.begin()) * path_subset.second / multiplicity);
+                }
+            }
+        }
+
+        assert(problem_idx == first_problem.at(i + 1));
+
+        estimates.path_group_sets.reserve(path_group_estimates.size());
+        estimates.posteriors.reserve(path_group_estimates.size());
+
+        for (auto & group_estimates: path_group_estimates) {
+
+            estimates.path_group_sets.emplace_back(group_estimates.first);
+            estimates.posteriors.emplace_back(group_estimates.second.first);
+            estimates.abundances.insert(estimates.abundances.end(), group_estimates.second.second.begin(), group_estimates.second.second.end());
+        }
+
+        assert(sum_hap_prob < 1 || numeric::doubleCompare(sum_hap_prob, 1));
+        estimates.noise_count += (1 - sum_hap_prob) * estimates.total_count;
+    }
+}
+
+}

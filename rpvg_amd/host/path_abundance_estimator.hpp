@@ -1,0 +1,91 @@
+// GPU-backed abundance estimators with the constructor parameter lists of the
+// reference's classes (src/path_abundance_estimator.hpp:18-76):
+//   PathAbundanceEstimator        `-i transcripts`
+//   NestedPathAbundanceEstimator  `-i haplotype-transcripts`
+// The EM solves of a whole batch of clusters — one per cluster for
+// `transcripts`, one per retained diplotype path subset for
+// `haplotype-transcripts` — are issued as ONE call into the GPU engine.
+#ifndef RPVG_AMD_PATH_ABUNDANCE_ESTIMATOR_HPP
+#define RPVG_AMD_PATH_ABUNDANCE_ESTIMATOR_HPP
+
+#include <map>
+#include <utility>
+#include <vector>
+
+#include "path_estimator.hpp"
+
+namespace rpvg_amd {
+
+class PathAbundanceEstimator : public PathEstimator {
+
+    public:
+
+        PathAbundanceEstimator(const uint32_t max_em_its_in, const double max_rel_em_conv_in, const uint32_t num_gibbs_samples_in, const uint32_t gibbs_thin_its_in, const double prob_precision, std::shared_ptr<HipEngine> engine);
+        virtual ~PathAbundanceEstimator() {};
+
+        void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs);
+
+    protected:
+
+        const uint32_t max_em_its;
+        const double max_rel_em_conv;
+
+        const uint32_t num_gibbs_samples;
+        const uint32_t gibbs_thin_its;
+
+        // One EM problem: a cluster restricted to an ascending list of its paths.
+        struct EMProblem {
+
+            uint32_t cluster;
+            std::vector<uint32_t> path_ids;
+        };
+
+        struct EMSolution {
+
+            std::vector<double> abundances;
+            double noise_count;
+            double total_count;
+            uint32_t iterations;
+        };
+
+        // EMAbundanceEstimator (src/path_abundance_estimator.cpp:47-114), together with
+        // the matrix construction and normalisation in front of it, for a batch of problems.
+        void EMAbundanceEstimator(std::vector<EMSolution> * solutions, const DeviceClusterBatch & cluster_batch, const std::vector<EMProblem> & problems) const;
+
+        void requireNoGibbsSamples() const;
+};
+
+class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
+
+    public:
+
+        NestedPathAbundanceEstimator(const uint32_t group_size_in, const double min_hap_prob_in, const bool infer_collapsed_in, const bool use_group_post_gibbs_in, const uint32_t max_em_its, const double max_rel_em_conv, const uint32_t num_gibbs_samples, const uint32_t gibbs_thin_its, const double prob_precision, std::shared_ptr<HipEngine> engine);
+        ~NestedPathAbundanceEstimator() {};
+
+        void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs);
+
+    private:
+
+        const uint32_t group_size;
+        const double min_hap_prob;
+
+        const bool infer_collapsed;
+        const bool use_group_post_gibbs;
+
+        // path subset (sorted, homozygous paths repeated) -> weight
+        typedef std::map<std::vector<uint32_t>, double> PathSubsetWeights;
+
+        std::vector<std::vector<uint32_t> > findPathGroups(const std::vector<PathInfo> & paths) const;
+        std::pair<std::vector<std::vector<uint32_t> >, std::vector<uint32_t> > findPathSourceGroups(const std::vector<PathInfo> & paths) const;
+
+        void pathGroupPosteriors(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems) const;
+
+        void sampleGroupPathIndices(std::vector<std::vector<uint32_t> > * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<uint32_t> & group, std::mt19937 * mt_rng) const;
+        void selectPathSubsetIndices(PathSubsetWeights * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<std::vector<uint32_t> > & path_groups) const;
+
+        void inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples) const;
+};
+
+}
+
+#endif

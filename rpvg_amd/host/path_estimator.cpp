@@ -1,0 +1,477 @@
+#include "path_estimator.hpp"
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <functional>
+#include <numeric>
+
+#include "numeric_utils.hpp"
+
+namespace rpvg_amd {
+
+namespace {
+
+const uint32_t no_member = 0xFFFFFFFFu;
+
+// Largest number of log-likelihood requests sent to the GPU in one call.
+const size_t max_requests_per_call = size_t(1) << 22;
+
+// Owning handle of the group matrices of a list of posterior problems.
+class GroupMatrices {
+
+    public:
+
+        GroupMatrices(const std::shared_ptr<HipEngine> & engine_in, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const bool normalise) : engine(engine_in), groups(nullptr) {
+
+            std::vector<uint32_t> clusters;
+            std::vector<uint64_t> group_off(1, 0);
+            std::vector<uint64_t> group_path_off(1, 0);
+            std::vector<uint32_t> group_path;
+
+            clusters.reserve(problems.size());
+
+            for (auto & problem: problems) {
+
+                clusters.emplace_back(problem.cluster);
+
+                for (auto & paths: problem.column_paths) {
+
+                    group_path.insert(group_path.end(), paths.begin(), paths.end());
+                    group_path_off.emplace_back(group_path.size());
+                }
+
+                group_off.emplace_back(group_path_off.size() - 1);
+            }
+
+            rpvg_hip_group_spec spec;
+            spec.num_matrices = problems.size();
+            spec.cluster = clusters.data();
+            spec.group_off = group_off.data();
+            spec.group_path_off = group_path_off.data();
+            spec.group_path = group_path.data();
+            spec.normalise = normalise;
+
+            HipEngine::check(rpvg_hip_groups_build(engine->ctx(), cluster_batch.handle(), &spec, &groups), "rpvg_hip_groups_build");
+        }
+
+        ~GroupMatrices() {
+
+            rpvg_hip_groups_free(engine->ctx(), groups);
+        }
+
+        GroupMatrices(const GroupMatrices &) = delete;
+        GroupMatrices & operator=(const GroupMatrices &) = delete;
+
+        // Evaluates the requests in bounded chunks.
+        void logLikelihoods(std::vector<double> * out, const std::vector<uint32_t> & matrix, const std::vector<uint32_t> & members, const uint32_t width, const double divisor, const bool add_rowmax) const {
+
+            assert(members.size() == matrix.size() * width);
+            out->assign(matrix.size(), 0);
+
+            std::vector<uint8_t> flags;
+
+            for (size_t first = 0; first < matrix.size(); first += max_requests_per_call) {
+
+                const size_t count = std::min(max_requests_per_call, matrix.size() - first);
+
+                if (add_rowmax) {
+
+                    flags.assign(count, 1);
+                }
+
+                HipEngine::check(rpvg_hip_group_loglik(engine->ctx(), groups, count, matrix.data() + first, members.data() + first * width, width, divisor, add_rowmax ? flags.data() : nullptr, out->data() + first), "rpvg_hip_group_loglik");
+            }
+        }
+
+    private:
+
+        const std::shared_ptr<HipEngine> engine;
+        rpvg_hip_groups * groups;
+};
+
+// Branch-and-bound state of one diploid posterior problem.
+struct BoundedSearch {
+
+    std::vector<double> log_freqs;
+
+    // columns in descending marginal-posterior order (ties: larger index first)
+    std::vector<uint32_t> order;
+
+    // optimistic log-likelihood of any pair starting at order[i]
+    std::vector<double> optimistic;
+
+    uint32_t cursor = 0;
+    double max_log_likelihood = numeric::log_zero;
+
+    std::vector<uint32_t> candidates;
+
+    std::vector<std::vector<uint32_t> > kept_sets;
+    std::vector<double> kept_log_likelihoods;
+};
+
+}
+
+PathEstimator::PathEstimator(const double prob_precision_in, std::shared_ptr<HipEngine> engine_in) : prob_precision(prob_precision_in), engine(engine_in) {
+
+    assert(engine);
+}
+
+void PathEstimator::estimate(PathClusterEstimates * path_cluster_estimates, const std::vector<ReadPathProbabilities> & cluster_probs, std::mt19937 * mt_rng) {
+
+    FlatClusterRows rows;
+    rows.addCluster(cluster_probs, path_cluster_estimates->paths.size());
+
+    const DeviceClusterBatch cluster_batch(engine, rows.view());
+
+    std::vector<PathClusterEstimates> batch_estimates(1);
+    batch_estimates.front() = std::move(*path_cluster_estimates);
+
+    std::vector<std::mt19937> rngs;
+
+    if (mt_rng) {
+
+        rngs.emplace_back(*mt_rng);
+    }
+
+    estimateBatch(&batch_estimates, cluster_batch, mt_rng ? &rngs : nullptr);
+
+    if (mt_rng) {
+
+        *mt_rng = rngs.front();
+    }
+
+    *path_cluster_estimates = std::move(batch_estimates.front());
+}
+
+void PathEstimator::estimateBatchSeeded(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const uint32_t rng_seed) {
+
+    std::vector<std::mt19937> rngs;
+    rngs.reserve(cluster_batch.numClusters());
+
+    for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
+
+        rngs.emplace_back(rng_seed + i);
+    }
+
+    estimateBatch(path_cluster_estimates, cluster_batch, &rngs);
+}
+
+std::vector<double> PathEstimator::calcPathLogFrequences(const std::vector<uint32_t> & path_counts) {
+
+    const uint32_t count_sum = std::accumulate(path_counts.begin(), path_counts.end(), 0u);
+    assert(count_sum > 0);
+
+    std::vector<double> path_log_freqs;
+    path_log_freqs.reserve(path_counts.size());
+
+    for (auto & count: path_counts) {
+
+        assert(count > 0);
+        path_log_freqs.emplace_back(std::log(count / static_cast<double>(count_sum)));
+    }
+
+    return path_log_freqs;
+}
+
+void PathEstimator::calculatePathGroupPosteriorsFull(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const bool normalise) const {
+
+    assert(group_size > 0);
+
+    if (group_size > 4) {
+
+        throw EngineError("calculatePathGroupPosteriorsFull: group sizes above 4 are not supported by the GPU log-likelihood kernel");
+    }
+
+    group_posteriors->assign(problems.size(), GroupPosteriors());
+
+    if (problems.empty()) {
+
+        return;
+    }
+
+    const GroupMatrices matrices(engine, cluster_batch, problems, normalise);
+
+    // every multiset of every problem is one request
+    std::vector<uint32_t> request_matrix;
+    std::vector<uint32_t> request_members;
+    std::vector<size_t> first_request(problems.size() + 1, 0);
+
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        PathClusterEstimates enumerator;
+        enumerator.generateGroups(problems.at(i).column_paths.size(), group_size);
+
+        group_posteriors->at(i).group_sets = std::move(enumerator.path_group_sets);
+
+        for (auto & group_set: group_posteriors->at(i).group_sets) {
+
+            request_matrix.emplace_back(i);
+            request_members.insert(request_members.end(), group_set.begin(), group_set.end());
+        }
+
+        first_request.at(i + 1) = request_matrix.size();
+    }
+
+    std::vector<double> log_likelihoods;
+    matrices.logLikelihoods(&log_likelihoods, request_matrix, request_members, group_size, group_size, false);
+
+    #pragma omp parallel for schedule(dynamic, 8)
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        const auto path_log_freqs = calcPathLogFrequences(problems.at(i).column_counts);
+        assert(path_log_freqs.size() == problems.at(i).column_paths.size());
+
+        auto & result = group_posteriors->at(i);
+        result.posteriors.assign(result.group_sets.size(), 0);
+
+        double sum_log_posterior = numeric::log_zero;
+
+        for (size_t j = 0; j < result.group_sets.size(); ++j) {
+
+            double log_posterior = log_likelihoods.at(first_request.at(i) + j);
+
+            for (auto & path_idx: result.group_sets.at(j)) {
+
+                log_posterior += path_log_freqs.at(path_idx);
+            }
+
+            log_posterior += std::log(numeric::numPermutations(result.group_sets.at(j)));
+
+            result.posteriors.at(j) = log_posterior;
+            sum_log_posterior = numeric::add_log(sum_log_posterior, log_posterior);
+        }
+
+        for (auto & posterior: result.posteriors) {
+
+            posterior = std::exp(posterior - sum_log_posterior);
+        }
+    }
+}
+
+void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const double min_rel_likelihood, const bool normalise) const {
+
+    assert(group_size == 2);
+
+    group_posteriors->assign(problems.size(), GroupPosteriors());
+
+    if (problems.empty()) {
+
+        return;
+    }
+
+    const double min_log_likelihood_diff = std::log(min_rel_likelihood);
+
+    const GroupMatrices matrices(engine, cluster_batch, problems, normalise);
+
+    std::vector<BoundedSearch> searches(problems.size());
+
+    // Marginal posteriors (the reference's nested Full call with group size 1,
+    // src/path_estimator.cpp:397-412) and the optimistic bound of every first
+    // path (:424-428): two requests per column.
+    {
+        std::vector<uint32_t> request_matrix;
+        std::vector<uint32_t> marginal_members;
+        std::vector<uint32_t> optimistic_members;
+        std::vector<size_t> first_request(problems.size() + 1, 0);
+
+        for (size_t i = 0; i < problems.size(); ++i) {
+
+            for (uint32_t j = 0; j < problems.at(i).column_paths.size(); ++j) {
+
+                request_matrix.emplace_back(i);
+                marginal_members.emplace_back(j);
+                optimistic_members.emplace_back(j);
+                optimistic_members.emplace_back(no_member);
+            }
+
+            first_request.at(i + 1) = request_matrix.size();
+        }
+
+        std::vector<double> marginal_log_likelihoods;
+        matrices.logLikelihoods(&marginal_log_likelihoods, request_matrix, marginal_members, 1, 1, false);
+
+        std::vector<double> optimistic_log_likelihoods;
+        matrices.logLikelihoods(&optimistic_log_likelihoods, request_matrix, optimistic_members, 2, 2, true);
+
+        #pragma omp parallel for schedule(dynamic, 8)
+        for (size_t i = 0; i < problems.size(); ++i) {
+
+            auto & search = searches.at(i);
+            const uint32_t num_columns = problems.at(i).column_paths.size();
+
+            search.log_freqs = calcPathLogFrequences(problems.at(i).column_counts);
+            assert(search.log_freqs.size() == num_columns);
+
+            std::vector<std::pair<double, uint32_t> > marginal_posteriors(num_columns);
+            double sum_log_posterior = numeric::log_zero;
+
+            for (uint32_t j = 0; j < num_columns; ++j) {
+
+                // + log(numPermutations({j})) = log(1)
+                marginal_posteriors.at(j) = std::make_pair(marginal_log_likelihoods.at(first_request.at(i) + j) + search.log_freqs.at(j) + std::log(1), j);
+                sum_log_posterior = numeric::add_log(sum_log_posterior, marginal_posteriors.at(j).first);
+            }
+
+            for (auto & marginal: marginal_posteriors) {
+
+                marginal.first = std::exp(marginal.first - sum_log_posterior);
+            }
+
+            std::sort(marginal_posteriors.begin(), marginal_posteriors.end(), std::greater<std::pair<double, uint32_t> >());
+
+            search.order.reserve(num_columns);
+            search.optimistic.reserve(num_columns);
+
+            for (auto & marginal: marginal_posteriors) {
+
+                search.order.emplace_back(marginal.second);
+
+                double optimal_log_likelihood = optimistic_log_likelihoods.at(first_request.at(i) + marginal.second);
+                optimal_log_likelihood += search.log_freqs.at(marginal.second) + std::log(2);
+
+                search.optimistic.emplace_back(optimal_log_likelihood);
+            }
+        }
+    }
+
+    // Rounds: every unfinished problem asks for the pair rows of its next
+    // first paths that still pass the bound; the sequential pruning loop of
+    // the reference (src/path_estimator.cpp:418-451) is then replayed on them.
+    // The running maximum only grows, so a first path failing the bound now
+    // fails it when the reference reaches it; one passing now may fail at
+    // replay time, in which case its fetched row is simply not used.
+    uint32_t block_size = 1;
+
+    while (true) {
+
+        std::vector<uint32_t> request_matrix;
+        std::vector<uint32_t> request_members;
+        std::vector<size_t> first_request(problems.size() + 1, 0);
+
+        bool any_candidates = false;
+
+        for (size_t i = 0; i < problems.size(); ++i) {
+
+            auto & search = searches.at(i);
+            const uint32_t num_columns = search.order.size();
+
+            search.candidates.clear();
+
+            for (uint32_t pos = search.cursor; pos < num_columns && search.candidates.size() < block_size; ++pos) {
+
+                if (search.optimistic.at(pos) - search.max_log_likelihood < min_log_likelihood_diff) {
+
+                    continue;
+                }
+
+                search.candidates.emplace_back(pos);
+
+                for (uint32_t pos2 = pos; pos2 < num_columns; ++pos2) {
+
+                    request_matrix.emplace_back(i);
+                    request_members.emplace_back(search.order.at(pos));
+                    request_members.emplace_back(search.order.at(pos2));
+                }
+            }
+
+            if (search.candidates.empty()) {
+
+                search.cursor = num_columns;
+
+            } else {
+
+                any_candidates = true;
+            }
+
+            first_request.at(i + 1) = request_matrix.size();
+        }
+
+        if (!any_candidates) {
+
+            break;
+        }
+
+        std::vector<double> pair_log_likelihoods;
+        matrices.logLikelihoods(&pair_log_likelihoods, request_matrix, request_members, 2, 2, false);
+
+        #pragma omp parallel for schedule(dynamic, 8)
+        for (size_t i = 0; i < problems.size(); ++i) {
+
+            auto & search = searches.at(i);
+
+            if (search.candidates.empty()) {
+
+                continue;
+            }
+
+            const uint32_t num_columns = search.order.size();
+            size_t request = first_request.at(i);
+
+            for (auto & pos: search.candidates) {
+
+                const size_t row_request = request;
+                request += num_columns - pos;
+
+                if (search.optimistic.at(pos) - search.max_log_likelihood < min_log_likelihood_diff) {
+
+                    continue;
+                }
+
+                const uint32_t first_path_idx = search.order.at(pos);
+
+                for (uint32_t pos2 = pos; pos2 < num_columns; ++pos2) {
+
+                    const uint32_t second_path_idx = search.order.at(pos2);
+
+                    double log_likelihood = pair_log_likelihoods.at(row_request + (pos2 - pos));
+                    log_likelihood += search.log_freqs.at(first_path_idx) + search.log_freqs.at(second_path_idx) + std::log(numeric::numPermutations(std::vector<uint32_t>({first_path_idx, second_path_idx})));
+
+                    if (log_likelihood - search.max_log_likelihood < min_log_likelihood_diff) {
+
+                        continue;
+                    }
+
+                    search.max_log_likelihood = std::max(search.max_log_likelihood, log_likelihood);
+
+                    search.kept_log_likelihoods.emplace_back(log_likelihood);
+                    search.kept_sets.emplace_back(std::vector<uint32_t>({first_path_idx, second_path_idx}));
+                }
+            }
+
+            search.cursor = search.candidates.back() + 1;
+        }
+
+        block_size = std::min<uint32_t>(block_size * 4, 1024);
+    }
+
+    // src/path_estimator.cpp:453-470
+    #pragma omp parallel for schedule(dynamic, 8)
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        auto & search = searches.at(i);
+        auto & result = group_posteriors->at(i);
+
+        double sum_log_posterior = numeric::log_zero;
+
+        for (auto & log_likelihood: search.kept_log_likelihoods) {
+
+            if (log_likelihood - search.max_log_likelihood < min_log_likelihood_diff) {
+
+                log_likelihood = numeric::log_zero;
+            }
+
+            sum_log_posterior = numeric::add_log(sum_log_posterior, log_likelihood);
+        }
+
+        result.group_sets = std::move(search.kept_sets);
+        result.posteriors.reserve(search.kept_log_likelihoods.size());
+
+        for (auto & log_likelihood: search.kept_log_likelihoods) {
+
+            result.posteriors.emplace_back(std::exp(log_likelihood - sum_log_posterior));
+        }
+    }
+}
+
+}

@@ -1,0 +1,82 @@
+// GPU-backed PathEstimator: the reference's abstract estimator interface
+// (src/path_estimator.hpp:16-49) kept as is — same constructor argument,
+// same virtual estimate() — with the per-cluster Eigen algebra replaced by
+// batched calls into the C ABI of the GPU engine (include/rpvg_hip.h).
+//
+// Two ways in:
+//   estimate()       one cluster, synchronous; signature of the reference
+//                    (src/path_estimator.hpp:23), callable from the reference's
+//                    own loop (src/main.cpp:977).  It is a batch of one.
+//   estimateBatch()  all clusters of a batch at once; what a GPU wants, and
+//                    what the reference's `omp parallel for` over clusters
+//                    (src/main.cpp:829) becomes.
+#ifndef RPVG_AMD_PATH_ESTIMATOR_HPP
+#define RPVG_AMD_PATH_ESTIMATOR_HPP
+
+#include <cstdint>
+#include <memory>
+#include <random>
+#include <vector>
+
+#include "hip_engine.hpp"
+#include "path_cluster_estimates.hpp"
+#include "read_path_probabilities.hpp"
+
+namespace rpvg_amd {
+
+// One posterior problem over the columns of a group matrix of one cluster:
+// column g is the set of cluster-local paths column_paths[g] (a single path
+// for `-i haplotypes`, a haplotype's HST set for `-i haplotype-transcripts`).
+struct GroupPosteriorProblem {
+
+    uint32_t cluster;
+    std::vector<std::vector<uint32_t> > column_paths;
+    std::vector<uint32_t> column_counts;
+};
+
+struct GroupPosteriors {
+
+    std::vector<std::vector<uint32_t> > group_sets;
+    std::vector<double> posteriors;
+};
+
+class PathEstimator {
+
+    public:
+
+        PathEstimator(const double prob_precision_in, std::shared_ptr<HipEngine> engine_in);
+        virtual ~PathEstimator() {};
+
+        // Reference interface (src/path_estimator.hpp:23).  path_cluster_estimates->paths
+        // must be filled by the caller, as src/main.cpp:855-887 does.
+        virtual void estimate(PathClusterEstimates * path_cluster_estimates, const std::vector<ReadPathProbabilities> & cluster_probs, std::mt19937 * mt_rng);
+
+        // Batched form.  path_cluster_estimates->at(i).paths must be filled for
+        // every cluster i of the device batch; cluster i draws from rngs->at(i)
+        // (rngs may be null for models that consume no random numbers).
+        virtual void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs) = 0;
+
+        // Same, seeding cluster i with mt19937(rng_seed + i) as src/main.cpp:976 does.
+        void estimateBatchSeeded(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const uint32_t rng_seed);
+
+    protected:
+
+        const double prob_precision;
+        const std::shared_ptr<HipEngine> engine;
+
+        // calculatePathGroupPosteriorsFull (src/path_estimator.cpp:332-377) for many
+        // problems at once; log-likelihood contractions on the GPU.
+        void calculatePathGroupPosteriorsFull(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const bool normalise) const;
+
+        // calculatePathGroupPosteriorsBounded (src/path_estimator.cpp:379-473) for many
+        // problems at once: same sequential branch-and-bound decisions, with the
+        // pair log-likelihoods fetched from the GPU a block of first paths at a time.
+        void calculatePathGroupPosteriorsBounded(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const double min_rel_likelihood, const bool normalise) const;
+
+        // src/path_estimator.cpp:315-330
+        static std::vector<double> calcPathLogFrequences(const std::vector<uint32_t> & path_counts);
+};
+
+}
+
+#endif

@@ -1,0 +1,111 @@
+#include "path_posterior_estimator.hpp"
+
+#include <cassert>
+
+namespace rpvg_amd {
+
+// src/path_posterior_estimator.cpp:5
+static const double min_rel_likelihood = 1e-8;
+
+PathPosteriorEstimator::PathPosteriorEstimator(const double prob_precision, std::shared_ptr<HipEngine> engine) : PathEstimator(prob_precision, engine) {}
+
+std::vector<GroupPosteriorProblem> PathPosteriorEstimator::rawPathProblems(const std::vector<PathClusterEstimates> & path_cluster_estimates, const DeviceClusterBatch & cluster_batch) const {
+
+    std::vector<GroupPosteriorProblem> problems;
+
+    for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
+
+        const auto & paths = path_cluster_estimates.at(i).paths;
+        assert(paths.size() == cluster_batch.numPaths(i));
+
+        if (cluster_batch.numRows(i) == 0) {
+
+            continue;
+        }
+
+        problems.emplace_back(GroupPosteriorProblem());
+        problems.back().cluster = i;
+
+        for (uint32_t j = 0; j < paths.size(); ++j) {
+
+            problems.back().column_paths.emplace_back(std::vector<uint32_t>(1, j));
+            problems.back().column_counts.emplace_back(paths.at(j).source_count);
+        }
+    }
+
+    return problems;
+}
+
+// src/path_posterior_estimator.cpp:9-31 over a batch of clusters.
+void PathPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs) {
+
+    assert(path_cluster_estimates->size() == cluster_batch.numClusters());
+
+    for (auto & estimates: *path_cluster_estimates) {
+
+        estimates.resetEstimates(estimates.paths.size(), 1);
+    }
+
+    const auto problems = rawPathProblems(*path_cluster_estimates, cluster_batch);
+
+    std::vector<GroupPosteriors> group_posteriors;
+    calculatePathGroupPosteriorsFull(&group_posteriors, cluster_batch, problems, 1, false);
+
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        auto & estimates = path_cluster_estimates->at(problems.at(i).cluster);
+
+        // calculatePathGroupPosteriorsFull re-creates the sets and zeroes the rest (src/path_estimator.cpp:343)
+        estimates.resetEstimates(estimates.paths.size(), 1);
+        assert(estimates.path_group_sets == group_posteriors.at(i).group_sets);
+
+        estimates.posteriors = std::move(group_posteriors.at(i).posteriors);
+    }
+}
+
+PathGroupPosteriorEstimator::PathGroupPosteriorEstimator(const uint32_t group_size_in, const bool use_group_post_gibbs_in, const double prob_precision, std::shared_ptr<HipEngine> engine) : PathPosteriorEstimator(prob_precision, engine), group_size(group_size_in), use_group_post_gibbs(use_group_post_gibbs_in) {}
+
+// src/path_posterior_estimator.cpp:35-71 over a batch of clusters.
+void PathGroupPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs) {
+
+    if (use_group_post_gibbs) {
+
+        // estimatePathGroupPosteriorsGibbs (src/path_estimator.cpp:475-589) is not on the GPU yet
+        throw EngineError("Gibbs haplotype posteriors (--use-hap-gibbs) are not available in the GPU engine yet");
+    }
+
+    assert(path_cluster_estimates->size() == cluster_batch.numClusters());
+
+    for (auto & estimates: *path_cluster_estimates) {
+
+        estimates.resetEstimates(0, 0);
+    }
+
+    const auto problems = rawPathProblems(*path_cluster_estimates, cluster_batch);
+    std::vector<GroupPosteriors> group_posteriors;
+
+    if (group_size == 2) {
+
+        calculatePathGroupPosteriorsBounded(&group_posteriors, cluster_batch, problems, group_size, min_rel_likelihood, false);
+
+    } else {
+
+        calculatePathGroupPosteriorsFull(&group_posteriors, cluster_batch, problems, group_size, false);
+    }
+
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        auto & estimates = path_cluster_estimates->at(problems.at(i).cluster);
+
+        estimates.path_group_sets = std::move(group_posteriors.at(i).group_sets);
+        estimates.posteriors = std::move(group_posteriors.at(i).posteriors);
+
+        if (group_size != 2) {
+
+            // the Full routine leaves zero-filled abundances behind (resetEstimates(n, g), src/path_estimator.cpp:343)
+            estimates.abundances.assign(estimates.path_group_sets.size() * group_size, 0);
+        }
+    }
+}
+
+}

@@ -1,0 +1,271 @@
+// C entry points over the host-side estimator classes, for harnesses that are
+// not C++ (tests and bench.py bind these with ctypes).  A run goes through the
+// same classes a C++ caller uses: PathEstimator::estimateBatch() (mode 0) or
+// the reference-shaped per-cluster PathEstimator::estimate() (mode 1).
+
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rpvg_batch.h"
+#include "estimator_factory.hpp"
+
+using namespace rpvg_amd;
+
+namespace {
+
+thread_local std::string last_error;
+
+struct Engine {
+
+    std::shared_ptr<HipEngine> hip;
+};
+
+// A batch resident on the GPU together with the host-side PathInfo of its clusters.
+struct PreparedBatch {
+
+    std::unique_ptr<DeviceClusterBatch> device;
+    std::vector<std::vector<PathInfo> > paths;
+
+    // kept for the per-cluster estimate() mode
+    std::vector<std::vector<ReadPathProbabilities> > rows;
+};
+
+struct Result {
+
+    std::vector<uint64_t> set_off, member_off, abund_off, em_off, em_col_off;
+    std::vector<uint32_t> members, em_iters, em_cols;
+    std::vector<double> posteriors, abundances, noise_count, total_count;
+};
+
+std::vector<std::vector<PathInfo> > unpackPaths(const rpvg_cluster_batch & batch) {
+
+    std::vector<std::vector<PathInfo> > paths(batch.num_clusters);
+
+    for (uint32_t i = 0; i < batch.num_clusters; ++i) {
+
+        for (uint64_t j = batch.cluster_path_off[i]; j < batch.cluster_path_off[i + 1]; ++j) {
+
+            PathInfo info;
+            info.group_id = batch.path_group_id ? batch.path_group_id[j] : 0;
+            info.source_count = batch.path_source_count ? batch.path_source_count[j] : 1;
+
+            if (batch.path_source_off) {
+
+                info.source_ids.insert(batch.source_id + batch.path_source_off[j], batch.source_id + batch.path_source_off[j + 1]);
+            }
+
+            info.effective_length = batch.path_effective_length ? batch.path_effective_length[j] : 0;
+            paths.at(i).emplace_back(std::move(info));
+        }
+    }
+
+    return paths;
+}
+
+std::vector<ReadPathProbabilities> unpackRows(const rpvg_cluster_batch & batch, const uint32_t cluster, const double prob_precision) {
+
+    std::vector<ReadPathProbabilities> rows;
+
+    for (uint64_t i = batch.cluster_row_off[cluster]; i < batch.cluster_row_off[cluster + 1]; ++i) {
+
+        ReadPathProbabilities::PathProbs path_probs;
+
+        for (uint64_t j = batch.row_grp_off[i]; j < batch.row_grp_off[i + 1]; ++j) {
+
+            path_probs.emplace_back(batch.grp_prob[j], std::vector<uint32_t>(batch.path_idx + batch.grp_idx_off[j], batch.path_idx + batch.grp_idx_off[j + 1]));
+        }
+
+        rows.emplace_back(batch.row_count[i], batch.row_noise[i], path_probs, prob_precision);
+    }
+
+    return rows;
+}
+
+Result * packResult(const std::vector<PathClusterEstimates> & estimates) {
+
+    Result * result = new Result();
+
+    result->set_off.push_back(0);
+    result->member_off.push_back(0);
+    result->abund_off.push_back(0);
+    result->em_off.push_back(0);
+    result->em_col_off.push_back(0);
+
+    for (auto & cluster_estimates: estimates) {
+
+        for (size_t i = 0; i < cluster_estimates.path_group_sets.size(); ++i) {
+
+            result->members.insert(result->members.end(), cluster_estimates.path_group_sets.at(i).begin(), cluster_estimates.path_group_sets.at(i).end());
+            result->member_off.push_back(result->members.size());
+            result->posteriors.push_back(cluster_estimates.posteriors.at(i));
+        }
+
+        result->set_off.push_back(result->posteriors.size());
+
+        result->abundances.insert(result->abundances.end(), cluster_estimates.abundances.begin(), cluster_estimates.abundances.end());
+        result->abund_off.push_back(result->abundances.size());
+
+        result->noise_count.push_back(cluster_estimates.noise_count);
+        result->total_count.push_back(cluster_estimates.total_count);
+
+        for (size_t i = 0; i < cluster_estimates.em_iterations.size(); ++i) {
+
+            result->em_iters.push_back(cluster_estimates.em_iterations.at(i));
+            result->em_cols.insert(result->em_cols.end(), cluster_estimates.em_problem_paths.at(i).begin(), cluster_estimates.em_problem_paths.at(i).end());
+            result->em_col_off.push_back(result->em_cols.size());
+        }
+
+        result->em_off.push_back(result->em_iters.size());
+    }
+
+    return result;
+}
+
+}
+
+extern "C" {
+
+const char * rpvg_amd_last_error(void) {
+
+    return last_error.c_str();
+}
+
+void * rpvg_amd_engine_create(int device) {
+
+    try {
+
+        Engine * engine = new Engine();
+        engine->hip = std::make_shared<HipEngine>(device);
+        return engine;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return nullptr;
+    }
+}
+
+void rpvg_amd_engine_destroy(void * engine) {
+
+    delete static_cast<Engine *>(engine);
+}
+
+// The rpvg_hip_ctx of the engine (to read kernel statistics through include/rpvg_hip.h).
+void * rpvg_amd_engine_ctx(void * engine) {
+
+    return static_cast<Engine *>(engine)->hip->ctx();
+}
+
+// Uploads the batch to the GPU.  keep_rows != 0 also keeps ReadPathProbabilities
+// objects of every cluster for the per-cluster estimate() mode.
+void * rpvg_amd_batch_prepare(void * engine, const rpvg_cluster_batch * batch, int keep_rows) {
+
+    try {
+
+        PreparedBatch * prepared = new PreparedBatch();
+        std::unique_ptr<PreparedBatch> guard(prepared);
+
+        prepared->paths = unpackPaths(*batch);
+
+        if (keep_rows) {
+
+            for (uint32_t i = 0; i < batch->num_clusters; ++i) {
+
+                prepared->rows.emplace_back(unpackRows(*batch, i, 1e-8));
+            }
+
+        } else {
+
+            prepared->device.reset(new DeviceClusterBatch(static_cast<Engine *>(engine)->hip, *batch));
+        }
+
+        return guard.release();
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return nullptr;
+    }
+}
+
+void rpvg_amd_batch_free(void * prepared) {
+
+    delete static_cast<PreparedBatch *>(prepared);
+}
+
+// Runs `model` on a prepared batch.  seconds_out = wall time of the estimator
+// call(s) only (inputs already resident on the GPU in batch mode).
+void * rpvg_amd_run(void * engine, void * prepared_batch, const char * model, const rpvg_params * params, double * seconds_out) {
+
+    try {
+
+        PreparedBatch * prepared = static_cast<PreparedBatch *>(prepared_batch);
+        auto estimator = makePathEstimator(model, *params, static_cast<Engine *>(engine)->hip);
+
+        std::vector<PathClusterEstimates> estimates(prepared->paths.size());
+
+        for (size_t i = 0; i < estimates.size(); ++i) {
+
+            estimates.at(i).paths = prepared->paths.at(i);
+        }
+
+        const auto start = std::chrono::steady_clock::now();
+
+        if (prepared->device) {
+
+            estimator->estimateBatchSeeded(&estimates, *prepared->device, params->rng_seed);
+
+        } else {
+
+            // the reference's loop body: one estimate() per cluster (src/main.cpp:976-977)
+            for (size_t i = 0; i < estimates.size(); ++i) {
+
+                std::mt19937 mt_rng(params->rng_seed + i);
+                estimator->estimate(&estimates.at(i), prepared->rows.at(i), &mt_rng);
+            }
+        }
+
+        const auto stop = std::chrono::steady_clock::now();
+
+        if (seconds_out) {
+
+            *seconds_out = std::chrono::duration<double>(stop - start).count();
+        }
+
+        return packResult(estimates);
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return nullptr;
+    }
+}
+
+void rpvg_amd_result_view(void * result_handle, rpvg_estimates_view * out) {
+
+    Result * result = static_cast<Result *>(result_handle);
+
+    out->num_clusters = result->noise_count.size();
+    out->set_off = result->set_off.data();
+    out->member_off = result->member_off.data();
+    out->members = result->members.data();
+    out->posteriors = result->posteriors.data();
+    out->abund_off = result->abund_off.data();
+    out->abundances = result->abundances.data();
+    out->noise_count = result->noise_count.data();
+    out->total_count = result->total_count.data();
+    out->em_off = result->em_off.data();
+    out->em_iters = result->em_iters.data();
+    out->em_col_off = result->em_col_off.data();
+    out->em_cols = result->em_cols.data();
+}
+
+void rpvg_amd_result_free(void * result_handle) {
+
+    delete static_cast<Result *>(result_handle);
+}
+
+}
