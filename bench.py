@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py — read-pairs quantified per second on the synthetic pantranscriptome.
+
+A "step" is one pass of the inference hot path over one batch of path clusters that is already resident
+in HBM: NestedPathAbundanceEstimator::estimateBatch() (`-i haplotype-transcripts`, reference defaults)
+on the "10M read pairs x 200k paths in ~5k clusters" workload (BASELINE.json configs[2]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s3|c2] [--model ...] [--scale F]
+
+One process per GPU (the driver launches N of them through torch.distributed.run); clusters are
+independent, so there is no data-path collective: every rank owns a full-size batch of its own
+(weak scaling) and the final per-path abundance vectors are gathered over RCCL after the timed region.
+Rank 0 prints ONE JSON line.
+
+--workload c2 runs the other bench-able configuration, "1M read pairs x 2k paths, one dense cluster"
+(configs[1], 16 GB FP64 streamed from HBM every EM iteration, fixed 50-iteration budget).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy kernel reaches
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="s3", choices=["s3", "c2"])
+    ap.add_argument("--model", default="haplotype-transcripts", choices=["haplotype-transcripts", "transcripts", "haplotypes"])
+    ap.add_argument("--scale", type=float, default=1.0, help="fraction of the full workload (parity/dev runs only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    return rank, local_rank, world, dist, torch
+
+
+def barrier_sync(dist, torch):
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, dist, torch):
+    if dist is None:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(x, dist, torch):
+    if dist is None:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def cpu_baseline_s3(batch, model, params, target_seconds):
+    """The CPU oracle (OpenMP over clusters, serial inside a cluster, as src/main.cpp:829) on a strided
+    sample of the same batch, sized for about target_seconds of CPU work."""
+    import numpy as np
+    from oracle import pyoracle
+    cores = os.cpu_count() or 1
+    K = batch.num_clusters
+    probe_idx = list(range(0, K, max(1, K // 40)))
+    probe = batch.select(probe_idx)
+    _, probe_secs = pyoracle.run(model, params, probe, cores)
+    est_full = probe_secs * K / max(1, len(probe_idx))
+    stride = max(1, int(round(est_full / target_seconds)))
+    idx = list(range(0, K, stride))
+    sample = batch.select(idx)
+    _, secs = pyoracle.run(model, params, sample, cores)
+    return dict(value=sample.total_reads / secs, unit="read-pairs/s", cores=cores, kind="port",
+                sample=f"every {stride}th cluster of the batch ({len(idx)} clusters, {sample.total_reads} read pairs, "
+                       f"{secs:.2f} s): oracle/ C++ restatement, OpenMP dynamic over clusters, {cores} threads")
+
+
+def run_s3(args, rank, local_rank, world, dist, torch):
+    import numpy as np
+    from rpvg_amd import engine as eng_mod, synth
+    from rpvg_amd.batch import make_params
+
+    params = make_params()
+    K = max(8, int(round(5000 * args.scale)))
+    total_paths = max(K, int(round(200000 * args.scale)))
+    total_reads = int(round(10000000 * args.scale))
+    # weak scaling: every rank owns a full-size batch (its own seed)
+    batch = synth.generate(seed=3 + rank, num_clusters=K, total_paths=total_paths, total_reads=total_reads)
+
+    eng = eng_mod.Engine(local_rank)
+    prepared = eng.prepare(batch)  # upload: inputs are resident in HBM before the timed region
+    for _ in range(args.warmup):
+        eng.run_raw(args.model, params, prepared)
+    eng.reset_stats()
+
+    barrier_sync(dist, torch)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run_raw(args.model, params, prepared)
+    barrier_sync(dist, torch)
+    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed, dist, torch)
+    stats = eng.stats()
+
+    reads_all = sum_over_ranks(float(batch.total_reads), dist, torch)
+
+    # after the timed region: gather the per-path abundances of every rank over RCCL (what a multi-GPU
+    # driver does before writing rpvg.txt); also fetch one decoded result for a sanity check
+    est, _ = eng.run(args.model, params, prepared)
+    mass_ok = all(abs(e.abundances.sum() + e.noise_count - e.total_count) <= 1e-6 * max(1.0, e.total_count) for e in est)
+    gathered = None
+    if dist is not None:
+        flat = np.concatenate([e.abundances for e in est]) if est else np.zeros(0)
+        n_local = torch.tensor([flat.size], dtype=torch.int64, device="cuda")
+        sizes = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(sizes, n_local)
+        n_max = int(max(int(s.item()) for s in sizes))
+        buf = torch.zeros(n_max, dtype=torch.float64, device="cuda")
+        buf[:flat.size] = torch.from_numpy(flat).cuda()
+        out = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(out, buf)
+        gathered = float(sum(float(o[:int(s.item())].sum().item()) for o, s in zip(out, sizes)))
+
+    if rank != 0:
+        return None
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = reads_all / (elapsed / args.steps)
+    em_ms = stats["em_sparse_ms"] / max(1, stats["em_sparse_launches"])
+    em_bytes = stats["em_sparse_alg_bytes"] / max(1, stats["em_sparse_launches"])
+    achieved = (em_bytes / 1e9) / (em_ms / 1e3) if em_ms > 0 else 0.0
+    roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                    traffic=None, kernel="emSparseKernel",
+                    note="algorithmic bytes = sum over EM problems of iterations x (12 B/entry + 20 B/row + 16 B/column); "
+                         "problems are L2/LDS-resident across iterations, so this is effective bandwidth, not HBM traffic")
+    kernels = dict(
+        em_sparse_ms_per_step=stats["em_sparse_ms"] / args.steps, loglik_ms_per_step=stats["loglik_ms"] / args.steps,
+        build_ms_per_step=stats["build_ms"] / args.steps, h2d_ms_per_step=stats["h2d_ms"] / args.steps,
+        em_iterations_per_step=stats["em_iterations_total"] / args.steps,
+        loglik_evals_per_step=stats["loglik_evals"] / args.steps)
+    line = dict(
+        metric="read-pairs quantified/sec", value=value, unit="read-pairs/s", n_gpus=world, steps=args.steps,
+        warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
+        dtype="f64", data="synthetic",
+        config=dict(workload=f"synthetic pantranscriptome: {total_reads} read pairs x {total_paths} paths in {K} clusters per GPU "
+                             f"(BASELINE.json configs[2]), -i {args.model}, reference defaults",
+                    clusters_per_gpu=K, rows_per_gpu=batch.num_rows, entries_per_gpu=int(len(batch.path_idx)),
+                    parallelism=f"clusters sharded, {world} rank(s), final abundance gather over RCCL"),
+        roofline=roofline, kernels=kernels, mass_conserved=bool(mass_ok))
+    if gathered is not None:
+        line["gathered_abundance_mass"] = gathered
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_s3(batch, args.model, params, args.cpu_seconds)
+    return line
+
+
+def run_c2(args, rank, local_rank, world, dist, torch):
+    """1M x 2k dense single cluster (BASELINE.json configs[1]); `replicas only` across GPUs."""
+    import numpy as np
+    from rpvg_amd import hip
+    R = max(1024, int(round(1000000 * args.scale)))
+    N = 2000
+    Cn = N + 1
+    ld = (Cn + 1) & ~1
+    its = 50
+    ctx = hip.Context(local_rank)
+    d_P, d_c = ctx.malloc(R * ld * 8), ctx.malloc(R * 8)
+    ctx.synth_dense_cluster(2 + rank, R, N, d_P, ld, d_c)
+    for _ in range(args.warmup):
+        ctx.em_dense(d_P, R, Cn, ld, d_c, float(R), max_em_its=its, max_rel_em_conv=0.0)
+    ctx.reset_stats()
+    barrier_sync(dist, torch)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ab, noise, done = ctx.em_dense(d_P, R, Cn, ld, d_c, float(R), max_em_its=its, max_rel_em_conv=0.0)
+    barrier_sync(dist, torch)
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, torch)
+    stats = ctx.stats()
+    reads_all = sum_over_ranks(float(R), dist, torch)
+    if rank != 0:
+        return None
+    it_ms = stats["em_dense_ms"] / max(1, stats["em_dense_launches"])
+    it_bytes = stats["em_dense_alg_bytes"] / max(1, stats["em_dense_launches"])
+    achieved = (it_bytes / 1e9) / (it_ms / 1e3)
+    line = dict(
+        metric="read-pairs quantified/sec", value=reads_all / (elapsed / args.steps), unit="read-pairs/s", n_gpus=world,
+        steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
+        scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+        config=dict(workload=f"single dense cluster {R} read pairs x {N} paths (BASELINE.json configs[1]), -i transcripts EM, "
+                             f"fixed budget of {its} EM iterations per step", parallelism=f"replicas only, {world} rank(s)"),
+        roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
+                      kernel="emDenseAccumKernel", ms_per_iteration=it_ms,
+                      note="per EM iteration: 8*R*C (matrix, read once) + 8*R (counts) + 16*C bytes; includes the finalize/control launches"),
+        em_iterations_per_step=its, mass_conserved=bool(abs(ab.sum() + noise - R) <= 1e-6 * R))
+    if not args.no_cpu_baseline:
+        # reference-shaped CPU EM on a row sample of the same matrix, one core (a single cluster is serial
+        # in the reference: SURVEY.md F4)
+        from oracle import pyoracle
+        rows = min(R, 20000)
+        P = ctx.d2h(d_P, (rows, ld))[:, :Cn].copy()
+        _, _, _, its_done, secs = pyoracle.em_dense(P, np.ones(rows), max_em_its=10, max_rel_em_conv=0.0)
+        per_row_iter = secs / (rows * its_done)
+        line["cpu_baseline"] = dict(value=1.0 / (per_row_iter * its), unit="read-pairs/s", cores=1, kind="port",
+                                    sample=f"first {rows} rows of the same matrix, {its_done} EM iterations, {secs:.2f} s on one core; "
+                                           f"scaled to {its} iterations per read pair")
+    ctx.free(d_P)
+    ctx.free(d_c)
+    return line
+
+
+def main():
+    args = parse_args()
+    rank, local_rank, world, dist, torch = dist_setup(args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    line = run_s3(args, rank, local_rank, world, dist, torch) if args.workload == "s3" else run_c2(args, rank, local_rank, world, dist, torch)
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

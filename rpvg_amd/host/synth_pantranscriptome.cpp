@@ -1,0 +1,538 @@
+// Synthetic pantranscriptome workload (bench / test harness, not part of the
+// estimators): K independent path clusters shaped like the "10M read pairs x
+// 200k paths in ~5k clusters" configuration of BASELINE.json (SURVEY.md §8d,
+// S3).  Produces exactly what the reference's per-cluster loop hands to
+// estimate() (src/main.cpp:846-973): PathInfo of the cluster's paths and the
+// sorted + merged ReadPathProbabilities rows.
+//
+// Model of one cluster
+//   - N_k paths (haplotype-specific transcripts, HSTs) in T_k transcripts
+//     (PathInfo::group_id), at most `num_haplotypes` HSTs per transcript;
+//   - `num_haplotypes` haplotype ids; every haplotype carries exactly one HST of
+//     every transcript (PathInfo::source_ids / source_count), allele
+//     frequencies skewed towards the first HSTs of a transcript;
+//   - the sample is one diplotype (two haplotypes); reads pick a transcript by
+//     expression, one of the two alleles, and are compatible with the true HST
+//     plus Geometric(1/2) sibling HSTs of the transcript, each either score-tied
+//     (probability tie_prob: the read does not cover a distinguishing variant)
+//     or at a deficit of 1 + Poisson(3) alignment-score units (capped at 20);
+//     likelihood exp(-score_log_base * deficit) / effective_length;
+//   - mapping quality in {60: 70 %, 30: 15 %, 10: 10 %, 3: 5 %} gives the noise
+//     probability max(1e-4, 10^(-mapq/10)) (src/read_path_probabilities.cpp:91);
+//   - rows are finished like addPathProbs and merged like the caller does.
+// Every cluster has its own counter-seeded generator, so the output does not
+// depend on the number of threads.  Clusters are emitted in descending order
+// of read count, the order the reference processes them in (src/main.cpp:811-827).
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/rpvg_batch.h"
+#include "path_cluster_estimates.hpp"
+#include "read_path_probabilities.hpp"
+
+using namespace rpvg_amd;
+
+extern "C" {
+
+typedef struct rpvg_synth_config {
+    uint64_t seed;
+    uint32_t num_clusters;        /* 5000 */
+    uint64_t total_paths;         /* 200000 */
+    uint64_t total_reads;         /* 10000000 */
+    uint32_t num_haplotypes;      /* 64 */
+    uint32_t max_cluster_paths;   /* 4000 */
+    double cluster_paths_sigma;   /* 1.0  log-normal sigma of paths per cluster */
+    double read_mass_sigma;       /* 1.5  log-normal sigma of reads per cluster */
+    double tie_prob;              /* 0.3 */
+    double pathless_read_frac;    /* 0.005 reads without any compatible path (noise = 1) */
+} rpvg_synth_config;
+
+}
+
+namespace {
+
+const double score_log_base = 1.383325268738;  // Utils::score_log_base, src/utils.hpp:83
+
+// xoshiro256** seeded through splitmix64
+struct Rng {
+
+    uint64_t s[4];
+
+    static uint64_t splitmix(uint64_t & x) {
+
+        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+
+    explicit Rng(uint64_t seed) {
+
+        for (auto & v: s) {
+
+            v = splitmix(seed);
+        }
+    }
+
+    static uint64_t rotl(const uint64_t x, const int k) { return (x << k) | (x >> (64 - k)); }
+
+    uint64_t next() {
+
+        const uint64_t result = rotl(s[1] * 5, 7) * 9;
+        const uint64_t t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 45);
+        return result;
+    }
+
+    double uniform() { return ((next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+    uint32_t below(const uint32_t n) { return static_cast<uint32_t>(uniform() * n) % n; }
+    double normal() { return std::sqrt(-2.0 * std::log(uniform())) * std::cos(6.283185307179586 * uniform()); }
+    double logNormal(const double sigma) { return std::exp(sigma * normal()); }
+
+    uint32_t poisson3() {
+
+        // inverse CDF, lambda = 3
+        const double u = uniform();
+        double p = std::exp(-3.0), cdf = p;
+        uint32_t k = 0;
+
+        while (u > cdf && k < 40) {
+
+            ++k;
+            p *= 3.0 / k;
+            cdf += p;
+        }
+
+        return k;
+    }
+
+    uint32_t geometricHalf() {  // number of failures before the first success, p = 1/2
+
+        uint32_t k = 0;
+
+        while (uniform() < 0.5 && k < 64) {
+
+            ++k;
+        }
+
+        return k;
+    }
+};
+
+struct SynthCluster {
+
+    std::vector<PathInfo> paths;
+    std::vector<ReadPathProbabilities> rows;
+    uint64_t num_reads;
+};
+
+// Splits `total` into weights-proportional non-negative integers summing to total.
+std::vector<uint64_t> apportion(const std::vector<double> & weights, const uint64_t total, const uint64_t minimum) {
+
+    const double weight_sum = std::accumulate(weights.begin(), weights.end(), 0.0);
+    std::vector<uint64_t> parts(weights.size());
+    std::vector<std::pair<double, size_t> > remainders(weights.size());
+
+    const uint64_t spread = total - minimum * weights.size();
+    uint64_t assigned = 0;
+
+    for (size_t i = 0; i < weights.size(); ++i) {
+
+        const double share = weights[i] / weight_sum * spread;
+        parts[i] = static_cast<uint64_t>(std::floor(share));
+        remainders[i] = std::make_pair(share - parts[i], i);
+        assigned += parts[i];
+    }
+
+    std::sort(remainders.begin(), remainders.end(), [](const std::pair<double, size_t> & a, const std::pair<double, size_t> & b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+
+    for (uint64_t i = 0; i < spread - assigned; ++i) {
+
+        parts[remainders[i % remainders.size()].second]++;
+    }
+
+    for (auto & part: parts) {
+
+        part += minimum;
+    }
+
+    return parts;
+}
+
+void generateCluster(SynthCluster * cluster, const rpvg_synth_config & config, const uint32_t cluster_idx, const uint32_t num_paths, const uint64_t num_reads) {
+
+    Rng rng(config.seed * 0x9E3779B97F4A7C15ull + cluster_idx * 0xD1B54A32D192ED03ull + 1);
+
+    const uint32_t num_haplotypes = config.num_haplotypes;
+
+    // transcripts: 1-8 for ordinary clusters, more only to keep HSTs per transcript <= haplotypes
+    uint32_t num_transcripts = std::max<uint32_t>(1, std::min<uint32_t>(8, std::lround(num_paths / (3.0 + 9.0 * rng.uniform()))));
+    num_transcripts = std::max<uint32_t>(num_transcripts, (num_paths + num_haplotypes - 1) / num_haplotypes);
+    num_transcripts = std::min(num_transcripts, num_paths);
+
+    std::vector<double> split_weights(num_transcripts);
+
+    for (auto & weight: split_weights) {
+
+        weight = 0.5 + rng.uniform();
+    }
+
+    auto hst_counts = apportion(split_weights, num_paths, 1);
+
+    // repair the rare transcript that ends above the haplotype count
+    for (size_t t = 0; t < hst_counts.size(); ++t) {
+
+        while (hst_counts[t] > num_haplotypes) {
+
+            const size_t smallest = std::min_element(hst_counts.begin(), hst_counts.end()) - hst_counts.begin();
+            hst_counts[t]--;
+            hst_counts[smallest]++;
+        }
+    }
+
+    cluster->paths.assign(num_paths, PathInfo());
+    std::vector<uint32_t> transcript_first(num_transcripts + 1, 0);
+    std::vector<std::vector<uint32_t> > haplotype_hst(num_transcripts, std::vector<uint32_t>(num_haplotypes));
+
+    for (uint32_t t = 0; t < num_transcripts; ++t) {
+
+        transcript_first[t + 1] = transcript_first[t] + hst_counts[t];
+        const uint32_t n_hst = hst_counts[t];
+
+        std::vector<uint32_t> haplotype_order(num_haplotypes);
+        std::iota(haplotype_order.begin(), haplotype_order.end(), 0);
+
+        for (uint32_t i = num_haplotypes - 1; i > 0; --i) {
+
+            std::swap(haplotype_order[i], haplotype_order[rng.below(i + 1)]);
+        }
+
+        // harmonic allele frequencies over the transcript's HSTs
+        std::vector<double> hst_cdf(n_hst);
+        double acc = 0;
+
+        for (uint32_t j = 0; j < n_hst; ++j) {
+
+            acc += 1.0 / (j + 1);
+            hst_cdf[j] = acc;
+        }
+
+        for (uint32_t i = 0; i < num_haplotypes; ++i) {
+
+            uint32_t hst = i;  // the first n_hst haplotypes make sure every HST is carried
+
+            if (i >= n_hst) {
+
+                const double u = rng.uniform() * acc;
+                hst = std::lower_bound(hst_cdf.begin(), hst_cdf.end(), u) - hst_cdf.begin();
+                hst = std::min(hst, n_hst - 1);
+            }
+
+            haplotype_hst[t][haplotype_order[i]] = transcript_first[t] + hst;
+        }
+
+        for (uint32_t j = transcript_first[t]; j < transcript_first[t + 1]; ++j) {
+
+            cluster->paths[j].group_id = t;
+            cluster->paths[j].length = 200 + rng.below(4800);
+            cluster->paths[j].effective_length = cluster->paths[j].length;
+        }
+
+        for (uint32_t h = 0; h < num_haplotypes; ++h) {
+
+            cluster->paths[haplotype_hst[t][h]].source_ids.insert(h);
+        }
+    }
+
+    for (auto & path: cluster->paths) {
+
+        path.source_count = std::max<size_t>(1, path.source_ids.size());
+    }
+
+    // the sample's diplotype, expression and allelic ratio
+    const uint32_t hap_1 = rng.below(num_haplotypes);
+    const uint32_t hap_2 = rng.below(num_haplotypes);
+
+    std::vector<double> expression_cdf(num_transcripts);
+    double expression_sum = 0;
+
+    for (uint32_t t = 0; t < num_transcripts; ++t) {
+
+        expression_sum += rng.logNormal(1.0);
+        expression_cdf[t] = expression_sum;
+    }
+
+    const double allele_ratio = 0.3 + 0.4 * rng.uniform();
+
+    static const double mapq_noise[4] = {1e-4, 1e-3, 0.1, 0.50118723362727224};
+
+    // distinct read signatures -> multiplicity; signature = mapq class, then (path, deficit) pairs sorted by path
+    std::map<std::vector<uint32_t>, uint32_t> signatures;
+    std::vector<uint32_t> signature;
+    std::vector<std::pair<uint32_t, uint32_t> > compat;
+
+    cluster->num_reads = num_reads;
+
+    for (uint64_t r = 0; r < num_reads; ++r) {
+
+        signature.clear();
+
+        if (rng.uniform() < config.pathless_read_frac) {
+
+            signature.push_back(0xFFFFFFFFu);
+            signatures[signature]++;
+            continue;
+        }
+
+        const double ue = rng.uniform() * expression_sum;
+        const uint32_t t = std::min<uint32_t>(num_transcripts - 1, std::lower_bound(expression_cdf.begin(), expression_cdf.end(), ue) - expression_cdf.begin());
+        const uint32_t true_path = haplotype_hst[t][rng.uniform() < allele_ratio ? hap_1 : hap_2];
+
+        const double um = rng.uniform();
+        const uint32_t mapq_class = (um < 0.70) ? 0 : (um < 0.85) ? 1 : (um < 0.95) ? 2 : 3;
+
+        const uint32_t n_hst = transcript_first[t + 1] - transcript_first[t];
+        const uint32_t num_siblings = std::min<uint32_t>(n_hst - 1, rng.geometricHalf());
+
+        compat.clear();
+        compat.emplace_back(true_path, 0);
+
+        while (compat.size() < num_siblings + 1) {
+
+            const uint32_t sibling = transcript_first[t] + rng.below(n_hst);
+            bool seen = false;
+
+            for (auto & c: compat) {
+
+                seen = seen || (c.first == sibling);
+            }
+
+            if (!seen) {
+
+                const uint32_t deficit = (rng.uniform() < config.tie_prob) ? 0 : std::min<uint32_t>(20, 1 + rng.poisson3());
+                compat.emplace_back(sibling, deficit);
+            }
+        }
+
+        std::sort(compat.begin(), compat.end());
+        signature.push_back(mapq_class);
+
+        for (auto & c: compat) {
+
+            signature.push_back(c.first);
+            signature.push_back(c.second);
+        }
+
+        signatures[signature]++;
+    }
+
+    cluster->rows.reserve(signatures.size());
+    std::vector<std::pair<uint32_t, double> > likelihoods;
+
+    for (auto & sig: signatures) {
+
+        if (sig.first.front() == 0xFFFFFFFFu) {
+
+            cluster->rows.emplace_back(sig.second, 1.0, ReadPathProbabilities::PathProbs(), 1e-8);
+            continue;
+        }
+
+        likelihoods.clear();
+
+        for (size_t i = 1; i < sig.first.size(); i += 2) {
+
+            likelihoods.emplace_back(sig.first[i], std::exp(-score_log_base * sig.first[i + 1]) / cluster->paths[sig.first[i]].effective_length);
+        }
+
+        cluster->rows.emplace_back(ReadPathProbabilities::fromPathLikelihoods(sig.second, mapq_noise[sig.first.front()], likelihoods, 1e-8));
+    }
+
+    sortAndMergeReadPathProbabilities(&cluster->rows);
+}
+
+struct SynthBatch {
+
+    std::vector<uint64_t> cluster_row_off, cluster_path_off, row_grp_off, grp_idx_off, path_source_off;
+    std::vector<uint32_t> row_count, path_idx, path_group_id, path_source_count, source_id;
+    std::vector<double> row_noise, grp_prob, path_effective_length;
+};
+
+}
+
+extern "C" {
+
+rpvg_synth_config rpvg_amd_synth_default_config(void) {
+
+    rpvg_synth_config config;
+    config.seed = 3;
+    config.num_clusters = 5000;
+    config.total_paths = 200000;
+    config.total_reads = 10000000;
+    config.num_haplotypes = 64;
+    config.max_cluster_paths = 4000;
+    config.cluster_paths_sigma = 1.0;
+    config.read_mass_sigma = 1.5;
+    config.tie_prob = 0.3;
+    config.pathless_read_frac = 0.005;
+    return config;
+}
+
+void * rpvg_amd_synth_generate(const rpvg_synth_config * config_in) {
+
+    const rpvg_synth_config config = *config_in;
+    const uint32_t K = config.num_clusters;
+
+    assert(K > 0 && config.total_paths >= K && config.num_haplotypes >= 2);
+
+    // sizes: paths per cluster and reads per cluster, from one global stream
+    Rng sizes_rng(config.seed ^ 0x5151515151515151ull);
+
+    std::vector<double> path_weights(K), read_weights(K);
+
+    for (uint32_t k = 0; k < K; ++k) {
+
+        path_weights[k] = sizes_rng.logNormal(config.cluster_paths_sigma);
+        read_weights[k] = sizes_rng.logNormal(config.read_mass_sigma);
+    }
+
+    // clip the path counts to [1, max_cluster_paths] while keeping the total
+    auto num_paths = apportion(path_weights, config.total_paths, 1);
+
+    for (int round = 0; round < 8; ++round) {
+
+        uint64_t excess = 0;
+
+        for (auto & n: num_paths) {
+
+            if (n > config.max_cluster_paths) {
+
+                excess += n - config.max_cluster_paths;
+                n = config.max_cluster_paths;
+            }
+        }
+
+        if (excess == 0) {
+
+            break;
+        }
+
+        std::vector<double> room(K);
+
+        for (uint32_t k = 0; k < K; ++k) {
+
+            room[k] = (num_paths[k] < config.max_cluster_paths) ? path_weights[k] : 0.0;
+        }
+
+        const auto extra = apportion(room, excess, 0);
+
+        for (uint32_t k = 0; k < K; ++k) {
+
+            num_paths[k] += extra[k];
+        }
+    }
+
+    const auto num_reads = apportion(read_weights, config.total_reads, 0);
+
+    // the reference processes clusters in descending read-count order (src/main.cpp:811-827)
+    std::vector<uint32_t> order(K);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](const uint32_t a, const uint32_t b) { return num_reads[a] != num_reads[b] ? num_reads[a] > num_reads[b] : a > b; });
+
+    std::vector<SynthCluster> clusters(K);
+
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (uint32_t i = 0; i < K; ++i) {
+
+        generateCluster(&clusters[i], config, order[i], num_paths[order[i]], num_reads[order[i]]);
+    }
+
+    SynthBatch * batch = new SynthBatch();
+
+    batch->cluster_row_off.push_back(0);
+    batch->cluster_path_off.push_back(0);
+    batch->row_grp_off.push_back(0);
+    batch->grp_idx_off.push_back(0);
+    batch->path_source_off.push_back(0);
+
+    for (auto & cluster: clusters) {
+
+        for (auto & path: cluster.paths) {
+
+            batch->path_group_id.push_back(path.group_id);
+            batch->path_source_count.push_back(path.source_count);
+            batch->source_id.insert(batch->source_id.end(), path.source_ids.begin(), path.source_ids.end());
+            batch->path_source_off.push_back(batch->source_id.size());
+            batch->path_effective_length.push_back(path.effective_length);
+        }
+
+        batch->cluster_path_off.push_back(batch->path_group_id.size());
+
+        for (auto & row: cluster.rows) {
+
+            batch->row_count.push_back(row.readCount());
+            batch->row_noise.push_back(row.noiseProb());
+
+            for (auto & path_probs: row.pathProbs()) {
+
+                batch->grp_prob.push_back(path_probs.first);
+                batch->path_idx.insert(batch->path_idx.end(), path_probs.second.begin(), path_probs.second.end());
+                batch->grp_idx_off.push_back(batch->path_idx.size());
+            }
+
+            batch->row_grp_off.push_back(batch->grp_prob.size());
+        }
+
+        batch->cluster_row_off.push_back(batch->row_count.size());
+
+        std::vector<ReadPathProbabilities>().swap(cluster.rows);
+    }
+
+    return batch;
+}
+
+void rpvg_amd_synth_view(void * handle, rpvg_cluster_batch * out) {
+
+    SynthBatch * batch = static_cast<SynthBatch *>(handle);
+
+    out->num_clusters = batch->cluster_row_off.size() - 1;
+    out->cluster_row_off = batch->cluster_row_off.data();
+    out->cluster_path_off = batch->cluster_path_off.data();
+    out->row_count = batch->row_count.data();
+    out->row_noise = batch->row_noise.data();
+    out->row_grp_off = batch->row_grp_off.data();
+    out->grp_prob = batch->grp_prob.data();
+    out->grp_idx_off = batch->grp_idx_off.data();
+    out->path_idx = batch->path_idx.data();
+    out->path_group_id = batch->path_group_id.data();
+    out->path_source_count = batch->path_source_count.data();
+    out->path_source_off = batch->path_source_off.data();
+    out->source_id = batch->source_id.data();
+    out->path_effective_length = batch->path_effective_length.data();
+}
+
+void rpvg_amd_synth_sizes(void * handle, uint64_t * rows, uint64_t * groups, uint64_t * entries, uint64_t * paths, uint64_t * sources) {
+
+    SynthBatch * batch = static_cast<SynthBatch *>(handle);
+
+    *rows = batch->row_count.size();
+    *groups = batch->grp_prob.size();
+    *entries = batch->path_idx.size();
+    *paths = batch->path_group_id.size();
+    *sources = batch->source_id.size();
+}
+
+void rpvg_amd_synth_free(void * handle) {
+
+    delete static_cast<SynthBatch *>(handle);
+}
+
+}

@@ -1,0 +1,62 @@
+"""Synthetic pantranscriptome batches (bench / tests): ctypes view of the C++ generator in
+``rpvg_amd/host/synth_pantranscriptome.cpp`` (the model is described there)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import engine as _engine
+from .batch import CClusterBatch, ClusterBatch
+
+
+class CSynthConfig(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64), ("num_clusters", C.c_uint32), ("total_paths", C.c_uint64), ("total_reads", C.c_uint64),
+        ("num_haplotypes", C.c_uint32), ("max_cluster_paths", C.c_uint32), ("cluster_paths_sigma", C.c_double),
+        ("read_mass_sigma", C.c_double), ("tie_prob", C.c_double), ("pathless_read_frac", C.c_double),
+    ]
+
+
+# BASELINE.json configs[2]: 10M read pairs x 200k paths in ~5k clusters
+FULL = dict(seed=3, num_clusters=5000, total_paths=200000, total_reads=10000000)
+
+
+def generate(seed: int = 3, num_clusters: int = 5000, total_paths: int = 200000, total_reads: int = 10000000,
+             **overrides) -> ClusterBatch:
+    L = _engine.lib()
+    L.rpvg_amd_synth_default_config.restype = CSynthConfig
+    L.rpvg_amd_synth_generate.restype = C.c_void_p
+    L.rpvg_amd_synth_generate.argtypes = [C.POINTER(CSynthConfig)]
+    L.rpvg_amd_synth_view.argtypes = [C.c_void_p, C.POINTER(CClusterBatch)]
+    L.rpvg_amd_synth_sizes.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 5
+    L.rpvg_amd_synth_free.argtypes = [C.c_void_p]
+    cfg = L.rpvg_amd_synth_default_config()
+    cfg.seed, cfg.num_clusters, cfg.total_paths, cfg.total_reads = seed, num_clusters, total_paths, total_reads
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise KeyError(k)
+        setattr(cfg, k, v)
+    h = L.rpvg_amd_synth_generate(C.byref(cfg))
+    try:
+        view = CClusterBatch()
+        L.rpvg_amd_synth_view(h, C.byref(view))
+        sizes = [C.c_uint64(0) for _ in range(5)]
+        L.rpvg_amd_synth_sizes(h, *[C.byref(s) for s in sizes])
+        R, G, NNZ, P, S = (int(s.value) for s in sizes)
+        K = view.num_clusters
+
+        def arr(ptr, n, dt):
+            if n == 0:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+
+        return ClusterBatch(
+            arr(view.cluster_row_off, K + 1, np.uint64), arr(view.cluster_path_off, K + 1, np.uint64),
+            arr(view.row_count, R, np.uint32), arr(view.row_noise, R, np.float64), arr(view.row_grp_off, R + 1, np.uint64),
+            arr(view.grp_prob, G, np.float64), arr(view.grp_idx_off, G + 1, np.uint64), arr(view.path_idx, NNZ, np.uint32),
+            arr(view.path_group_id, P, np.uint32), arr(view.path_source_count, P, np.uint32),
+            arr(view.path_source_off, P + 1, np.uint64), arr(view.source_id, S, np.uint32),
+            arr(view.path_effective_length, P, np.float64))
+    finally:
+        L.rpvg_amd_synth_free(h)
