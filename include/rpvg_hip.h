@@ -149,6 +149,30 @@ int rpvg_hip_group_loglik(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, ui
                           const uint32_t * matrix, const uint32_t * members, uint32_t width, double divisor,
                           const uint8_t * add_rowmax, double * out);
 
+/* The whole diploid branch-and-bound of calculatePathGroupPosteriorsBounded
+ * (src/path_estimator.cpp:379-473) on the GPU, one workgroup per matrix:
+ * marginal posteriors (the nested group-size-1 Full call, :397-412), the
+ * descending (posterior, index) order (:412), the optimistic bound of each
+ * first column (:414,424-433), the pair loop with its running-maximum pruning
+ * in the reference's exact sequence (:435-450), the late-loser zeroing and the
+ * log-sum-exp normalisation (:453-470).  column_counts holds `path_counts` of
+ * every column of every matrix, concatenated in matrix order.  The result
+ * lists, per matrix, the kept pairs in the order the reference keeps them. */
+typedef struct rpvg_hip_pair_posteriors rpvg_hip_pair_posteriors;
+
+typedef struct rpvg_hip_pair_posteriors_view {
+    uint32_t num_matrices;
+    const uint64_t * pair_off;   /* [M+1] kept pairs of each matrix            */
+    const uint32_t * first;      /* [pairs] column index (first path)          */
+    const uint32_t * second;     /* [pairs] column index (second path)         */
+    const double * posterior;    /* [pairs]                                    */
+} rpvg_hip_pair_posteriors_view;
+
+int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const uint32_t * column_counts,
+                                     double min_rel_likelihood, rpvg_hip_pair_posteriors ** result_out);
+int rpvg_hip_pair_posteriors_get(const rpvg_hip_pair_posteriors * result, rpvg_hip_pair_posteriors_view * view_out);
+void rpvg_hip_pair_posteriors_free(rpvg_hip_pair_posteriors * result);
+
 /* ---- synthetic workload (bench / tests only) ---------------------------- */
 /* Fills a dense normalised R x C matrix (layout of rpvg_hip_em_dense) and unit
  * counts on the GPU from a counter-based generator: the "1M read pairs x 2k
@@ -163,7 +187,7 @@ int rpvg_hip_synth_dense_cluster(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t num
 typedef struct rpvg_hip_kernel_stats {
     double em_sparse_ms;      uint64_t em_sparse_launches;   double em_sparse_alg_bytes;
     double em_dense_ms;       uint64_t em_dense_launches;    double em_dense_alg_bytes;
-    double loglik_ms;         uint64_t loglik_launches;      double loglik_evals;
+    double loglik_ms;         uint64_t loglik_launches;      double loglik_evals;   /* evals = FP64 log evaluations */
     double build_ms;          uint64_t build_launches;
     double h2d_ms;            double h2d_bytes;
     uint64_t em_iterations_total;

@@ -1,0 +1,802 @@
+// Diploid branch-and-bound posterior search entirely on the GPU (gfx950).
+//
+// Takes over calculatePathGroupPosteriorsBounded (src/path_estimator.cpp:379-473)
+// for a batch of group matrices: ONE workgroup per matrix walks the search in
+// the reference's sequential order, so the kept set is the reference's kept
+// set, and only first columns that pass the optimistic bound when they are
+// reached cost any work.  Inside a workgroup the parallelism is
+//   - waves  : the pair log-likelihoods of up to NW consecutive second columns
+//              are evaluated at once, then the running-maximum pruning rule is
+//              applied to them one after the other (uniformly by all threads);
+//   - lanes  : rows of the matrix (column-major, so lane i reads element i of
+//              a column: coalesced), FP64 log per row, wave-shuffle reduction.
+// The base vector noise_i + M[i][a]/2 of the current first column and the
+// read counts are staged in LDS and reused by every pair of that column.
+// Bound: FP64 log throughput (one log per row per pair), not HBM — a cluster's
+// matrix (mean ~0.3 MB) is re-read from L2.
+
+#include "common.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <numeric>
+
+using namespace rpvg_hip_detail;
+
+struct rpvg_hip_pair_posteriors {
+    std::vector<uint64_t> pair_off;
+    std::vector<uint32_t> first, second;
+    std::vector<double> posterior;
+};
+
+namespace {
+
+constexpr uint32_t kLdsRows = 2048;  // rows of (base, count) staged in LDS: 32 KB
+
+__device__ __forceinline__ double waveSum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Utils::add_log (src/utils.hpp:300-302)
+__device__ __forceinline__ double addLog(const double log_x, const double log_y) {
+    return log_x > log_y ? log_x + log1p(exp(log_y - log_x)) : log_y + log1p(exp(log_x - log_y));
+}
+
+struct SearchArgs {
+    const uint32_t * order;          // matrices, expensive first
+    uint32_t count;
+    const uint64_t * mat_val_off;
+    const uint64_t * mat_row_off;
+    const uint64_t * mat_row0;
+    const uint64_t * mat_rows;
+    const uint32_t * mat_cols;
+    const double * values;
+    const double * rowmax;
+    const double * row_count;
+    const double * row_noise;
+    const uint64_t * col_off;        // [M+1] prefix of columns (scratch + counts)
+    const uint32_t * col_count;      // path_counts of every column
+    const uint64_t * pair_cap_off;   // [M+1] prefix of G(G+1)/2 (output regions)
+    double min_log_likelihood_diff;
+    // per-column scratch
+    double * log_freq;
+    double * marginal;
+    double * optimistic_raw;
+    double * optimistic;             // in search order
+    uint32_t * col_order;
+    // output regions
+    uint32_t * out_first;
+    uint32_t * out_second;
+    double * out_value;              // log-likelihood, then posterior
+    uint32_t * out_count;            // [M]
+};
+
+// sum_i count_i * log(base_i + col_i / 2) over rows [lane, n) step 64, four independent chains in flight
+__device__ __forceinline__ double pairRowSum(const double * __restrict__ cnt, const double * __restrict__ base,
+                                             const double * __restrict__ col, const uint32_t n, const int lane) {
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    uint32_t i = lane;
+    for (; i + 192 < n; i += 256) {
+        const double x0 = col[i], x1 = col[i + 64], x2 = col[i + 128], x3 = col[i + 192];
+        acc0 = fma(cnt[i], log(base[i] + x0 / 2.0), acc0);
+        acc1 = fma(cnt[i + 64], log(base[i + 64] + x1 / 2.0), acc1);
+        acc2 = fma(cnt[i + 128], log(base[i + 128] + x2 / 2.0), acc2);
+        acc3 = fma(cnt[i + 192], log(base[i + 192] + x3 / 2.0), acc3);
+    }
+    for (; i < n; i += 64) acc0 = fma(cnt[i], log(base[i] + col[i] / 2.0), acc0);
+    return (acc0 + acc1) + (acc2 + acc3);
+}
+
+template <int kBlock>
+__global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs args) {
+    constexpr int kWaves = kBlock / 64;
+    __shared__ double lds_base[kLdsRows];
+    __shared__ double lds_count[kLdsRows];
+    __shared__ double lds_pair[kWaves];
+    __shared__ double lds_scalar;
+    __shared__ unsigned long long lds_sum;
+
+    if (blockIdx.x >= args.count) return;
+    const uint32_t m = args.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t R = args.mat_rows[m];
+    const uint32_t G = args.mat_cols[m];
+    const double * M = args.values + args.mat_val_off[m];
+    const double * rm = args.rowmax + args.mat_row_off[m];
+    const double * cnt = args.row_count + args.mat_row0[m];
+    const double * nz = args.row_noise + args.mat_row0[m];
+    const uint64_t c0 = args.col_off[m];
+    const uint32_t * ccount = args.col_count + c0;
+    double * lf = args.log_freq + c0;
+    double * marg = args.marginal + c0;
+    double * opt_raw = args.optimistic_raw + c0;
+    double * opt = args.optimistic + c0;
+    uint32_t * ord = args.col_order + c0;
+    const uint64_t p0 = args.pair_cap_off[m];
+    uint32_t * out_first = args.out_first + p0;
+    uint32_t * out_second = args.out_second + p0;
+    double * out_value = args.out_value + p0;
+    const double thr = args.min_log_likelihood_diff;
+    const double lowest = -1.7976931348623157e308;  // numeric_limits<double>::lowest()
+    const double log_two = log(2.0);
+
+    // calcPathLogFrequences (src/path_estimator.cpp:315-330)
+    if (threadIdx.x == 0) lds_sum = 0;
+    __syncthreads();
+    unsigned long long part = 0;
+    for (uint32_t g = threadIdx.x; g < G; g += kBlock) part += ccount[g];
+    if (part) atomicAdd(&lds_sum, part);
+    __syncthreads();
+    const double count_sum = static_cast<double>(lds_sum);
+    for (uint32_t g = threadIdx.x; g < G; g += kBlock) lf[g] = log(ccount[g] / count_sum);
+    __syncthreads();
+
+    // marginal log-posteriors (group size 1) and optimistic bounds of every column: two logs per row
+    for (uint32_t g = wave; g < G; g += kWaves) {
+        const double * col = M + static_cast<uint64_t>(g) * R;
+        double acc1 = 0.0, acc2 = 0.0;
+        for (uint64_t i = lane; i < R; i += 64) {
+            const double x = col[i], n = nz[i], c = cnt[i];
+            acc1 = fma(c, log(n + x / 1.0), acc1);
+            acc2 = fma(c, log((n + x / 2.0) + rm[i] / 2.0), acc2);
+        }
+        acc1 = waveSum(acc1);
+        acc2 = waveSum(acc2);
+        if (lane == 0) {
+            marg[g] = (acc1 + lf[g]) + 0.0;           // + log(numPermutations({g})) = log(1)
+            opt_raw[g] = acc2 + (lf[g] + log_two);    // src/path_estimator.cpp:427-428
+        }
+    }
+    __syncthreads();
+
+    // normalise the marginals (log-sum-exp fold in column order, :348,370-376)
+    if (threadIdx.x == 0) {
+        double sum_log = lowest;
+        for (uint32_t g = 0; g < G; ++g) sum_log = addLog(sum_log, marg[g]);
+        lds_scalar = sum_log;
+    }
+    __syncthreads();
+    {
+        const double sum_log = lds_scalar;
+        for (uint32_t g = threadIdx.x; g < G; g += kBlock) marg[g] = exp(marg[g] - sum_log);
+    }
+    __syncthreads();
+
+    // descending (posterior, index) order (:412): rank by counting, ties impossible (indices differ)
+    for (uint32_t g = threadIdx.x; g < G; g += kBlock) {
+        const double pg = marg[g];
+        uint32_t rank = 0;
+        for (uint32_t h = 0; h < G; ++h) {
+            const double ph = marg[h];
+            rank += (ph > pg || (ph == pg && h > g)) ? 1u : 0u;
+        }
+        ord[rank] = g;
+        opt[rank] = opt_raw[g];
+    }
+    __syncthreads();
+
+    // the search (:418-451)
+    double max_ll = lowest;
+    uint32_t kept = 0;
+    const uint32_t staged = static_cast<uint32_t>(R < kLdsRows ? R : kLdsRows);
+    for (uint32_t pos = 0; pos < G; ++pos) {
+        if (opt[pos] - max_ll < thr) continue;
+        const uint32_t a = ord[pos];
+        const double * col_a = M + static_cast<uint64_t>(a) * R;
+        __syncthreads();  // previous users of the staged vectors are done
+        for (uint32_t i = threadIdx.x; i < staged; i += kBlock) {
+            lds_base[i] = nz[i] + col_a[i] / 2.0;
+            lds_count[i] = cnt[i];
+        }
+        __syncthreads();
+        const double lf_a = lf[a];
+        for (uint32_t j0 = pos; j0 < G; j0 += kWaves) {
+            const uint32_t j = j0 + wave;
+            if (j < G) {
+                const uint32_t b = ord[j];
+                const double * col_b = M + static_cast<uint64_t>(b) * R;
+                double acc = pairRowSum(lds_count, lds_base, col_b, staged, lane);
+                {
+                    double t0 = 0.0, t1 = 0.0;
+                    uint64_t i = staged + lane;
+                    for (; i + 64 < R; i += 128) {
+                        const double xa0 = col_a[i], xa1 = col_a[i + 64], xb0 = col_b[i], xb1 = col_b[i + 64];
+                        t0 = fma(cnt[i], log((nz[i] + xa0 / 2.0) + xb0 / 2.0), t0);
+                        t1 = fma(cnt[i + 64], log((nz[i + 64] + xa1 / 2.0) + xb1 / 2.0), t1);
+                    }
+                    for (; i < R; i += 64) t0 = fma(cnt[i], log((nz[i] + col_a[i] / 2.0) + col_b[i] / 2.0), t0);
+                    acc += t0 + t1;
+                }
+                acc = waveSum(acc);
+                if (lane == 0) lds_pair[wave] = acc + ((lf_a + lf[b]) + (a == b ? 0.0 : log_two));
+            }
+            __syncthreads();
+            // the reference's pruning rule, applied to the evaluated pairs in order (uniform)
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                if (j0 + w < G) {
+                    const double ll = lds_pair[w];
+                    if (!(ll - max_ll < thr)) {
+                        max_ll = fmax(max_ll, ll);
+                        if (threadIdx.x == 0) {
+                            out_first[kept] = a;
+                            out_second[kept] = ord[j0 + w];
+                            out_value[kept] = ll;
+                        }
+                        ++kept;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // late losers -> weight zero, log-sum-exp, posteriors (:453-470)
+    if (threadIdx.x == 0) {
+        double sum_log = lowest;
+        for (uint32_t k = 0; k < kept; ++k) {
+            double ll = out_value[k];
+            if (ll - max_ll < thr) {
+                ll = lowest;
+                out_value[k] = ll;
+            }
+            sum_log = addLog(sum_log, ll);
+        }
+        lds_scalar = sum_log;
+        args.out_count[m] = kept;
+    }
+    __syncthreads();
+    {
+        const double sum_log = lds_scalar;
+        for (uint32_t k = threadIdx.x; k < kept; k += kBlock) out_value[k] = exp(out_value[k] - sum_log);
+    }
+}
+
+
+// ---- table path for big matrices ----------------------------------------------
+//
+// The sequential rule "keep pair s iff ll_s - max(kept so far) >= thr" equals
+// "keep iff ll_s - max(all pairs before s) >= thr": a dropped pair is below the
+// running maximum, so it never changes it.  A first column that the reference
+// skips on its optimistic bound only holds pairs that this filter drops (the
+// bound dominates every pair of the column).  So for a big matrix every pair
+// is evaluated in parallel by many workgroups (row chunks x first columns),
+// and one workgroup then applies an exclusive prefix-max scan in the
+// reference's pair order.
+
+constexpr uint32_t kChunkRows = 2048;
+
+struct TableWork {
+    const uint32_t * item_matrix;   // [W]
+    const uint32_t * item_col;      // [W]
+    const uint32_t * item_chunk;    // [W]
+    uint32_t count;
+    const uint64_t * mat_val_off;
+    const uint64_t * mat_row_off;
+    const uint64_t * mat_row0;
+    const uint64_t * mat_rows;
+    const uint32_t * mat_cols;
+    const double * values;
+    const double * rowmax;
+    const double * row_count;
+    const double * row_noise;
+    const uint64_t * big_col_part_off;   // [M] offset of the matrix's [chunk][G] partial column sums (0 for small ones)
+    const uint64_t * big_pair_part_off;  // [M] offset of the matrix's [chunk][G][G] partial pair sums
+    double * part_marginal;
+    double * part_optimistic;
+    double * part_pair;
+};
+
+// one workgroup per (matrix, first column a, row chunk): partial sums of the column's marginal and
+// optimistic log-likelihoods and of every pair (a, b >= a) over the rows of the chunk
+__global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
+    __shared__ double lds_base[kChunkRows];
+    __shared__ double lds_count[kChunkRows];
+    if (blockIdx.x >= w.count) return;
+    const uint32_t m = w.item_matrix[blockIdx.x], a = w.item_col[blockIdx.x], chunk = w.item_chunk[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t R = w.mat_rows[m];
+    const uint32_t G = w.mat_cols[m];
+    const uint64_t r_begin = static_cast<uint64_t>(chunk) * kChunkRows;
+    const uint32_t n = static_cast<uint32_t>((R - r_begin) < kChunkRows ? (R - r_begin) : kChunkRows);
+    const double * M = w.values + w.mat_val_off[m];
+    const double * col_a = M + static_cast<uint64_t>(a) * R + r_begin;
+    const double * cnt = w.row_count + w.mat_row0[m] + r_begin;
+    const double * nz = w.row_noise + w.mat_row0[m] + r_begin;
+    const double * rm = w.rowmax + w.mat_row_off[m] + r_begin;
+
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        lds_base[i] = nz[i] + col_a[i] / 2.0;
+        lds_count[i] = cnt[i];
+    }
+    if (wave == 0) {
+        // marginal and optimistic partial sums of column a (two logs per row)
+        double acc1 = 0.0, acc2 = 0.0;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const double x = col_a[i], nn = nz[i], c = cnt[i];
+            acc1 = fma(c, log(nn + x / 1.0), acc1);
+            acc2 = fma(c, log((nn + x / 2.0) + rm[i] / 2.0), acc2);
+        }
+        acc1 = waveSum(acc1);
+        acc2 = waveSum(acc2);
+        if (lane == 0) {
+            const uint64_t o = w.big_col_part_off[m] + static_cast<uint64_t>(chunk) * G + a;
+            w.part_marginal[o] = acc1;
+            w.part_optimistic[o] = acc2;
+        }
+    }
+    __syncthreads();
+    double * out = w.part_pair + w.big_pair_part_off[m] + (static_cast<uint64_t>(chunk) * G + a) * G;
+    for (uint32_t b = a + wave; b < G; b += 4) {
+        const double * col_b = M + static_cast<uint64_t>(b) * R + r_begin;
+        const double acc = waveSum(pairRowSum(lds_count, lds_base, col_b, n, lane));
+        if (lane == 0) out[b] = acc;
+    }
+}
+
+struct ResolveArgs {
+    const uint32_t * big_matrix;    // [B] matrices on the table path
+    uint32_t count;
+    const uint64_t * mat_rows;
+    const uint32_t * mat_cols;
+    const uint64_t * col_off;
+    const uint32_t * col_count;
+    const uint64_t * pair_cap_off;
+    const uint64_t * big_col_part_off;
+    const uint64_t * big_pair_part_off;
+    const double * part_marginal;
+    const double * part_optimistic;
+    const double * part_pair;
+    double min_log_likelihood_diff;
+    double * log_freq;
+    double * marginal;
+    uint32_t * col_order;
+    double * seq_value;     // [pair_cap] log-likelihood of every pair in the reference's sequence order
+    uint32_t * out_first;
+    uint32_t * out_second;
+    double * out_value;
+    uint32_t * out_count;
+};
+
+// one workgroup per big matrix: marginal order, pair sequence, exclusive prefix-max filter, posteriors
+__global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args) {
+    constexpr int kBlock = 256;
+    __shared__ double lds_red[kBlock / 64];
+    __shared__ uint32_t lds_cnt[kBlock / 64];
+    __shared__ double lds_scalar;
+    __shared__ unsigned long long lds_sum;
+    if (blockIdx.x >= args.count) return;
+    const uint32_t m = args.big_matrix[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t R = args.mat_rows[m];
+    const uint32_t G = args.mat_cols[m];
+    const uint32_t chunks = static_cast<uint32_t>((R + kChunkRows - 1) / kChunkRows);
+    const uint64_t c0 = args.col_off[m];
+    const uint32_t * ccount = args.col_count + c0;
+    double * lf = args.log_freq + c0;
+    double * marg = args.marginal + c0;
+    uint32_t * ord = args.col_order + c0;
+    const double * pm = args.part_marginal + args.big_col_part_off[m];
+    const double * pp = args.part_pair + args.big_pair_part_off[m];
+    const uint64_t p0 = args.pair_cap_off[m];
+    double * seq = args.seq_value + p0;
+    uint32_t * out_first = args.out_first + p0;
+    uint32_t * out_second = args.out_second + p0;
+    double * out_value = args.out_value + p0;
+    const double thr = args.min_log_likelihood_diff;
+    const double lowest = -1.7976931348623157e308;
+    const double log_two = log(2.0);
+
+    if (threadIdx.x == 0) lds_sum = 0;
+    __syncthreads();
+    unsigned long long part = 0;
+    for (uint32_t g = threadIdx.x; g < G; g += kBlock) part += ccount[g];
+    if (part) atomicAdd(&lds_sum, part);
+    __syncthreads();
+    const double count_sum = static_cast<double>(lds_sum);
+    for (uint32_t g = threadIdx.x; g < G; g += kBlock) {
+        const double f = log(ccount[g] / count_sum);
+        lf[g] = f;
+        double acc = 0.0;
+        for (uint32_t c = 0; c < chunks; ++c) acc += pm[static_cast<uint64_t>(c) * G + g];
+        marg[g] = (acc + f) + 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum_log = lowest;
+        for (uint32_t g = 0; g < G; ++g) sum_log = addLog(sum_log, marg[g]);
+        lds_scalar = sum_log;
+    }
+    __syncthreads();
+    {
+        const double sum_log = lds_scalar;
+        for (uint32_t g = threadIdx.x; g < G; g += kBlock) marg[g] = exp(marg[g] - sum_log);
+    }
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < G; g += kBlock) {
+        const double pg = marg[g];
+        uint32_t rank = 0;
+        for (uint32_t h = 0; h < G; ++h) {
+            const double ph = marg[h];
+            rank += (ph > pg || (ph == pg && h > g)) ? 1u : 0u;
+        }
+        ord[rank] = g;
+    }
+    __syncthreads();
+
+    // pair sequence: (pos, j >= pos) row by row; s = pos*G - pos*(pos-1)/2 + (j - pos)
+    const uint64_t S = static_cast<uint64_t>(G) * (G + 1) / 2;
+    for (uint32_t pos = 0; pos < G; ++pos) {
+        const uint32_t a = ord[pos];
+        const uint64_t s0 = static_cast<uint64_t>(pos) * G - (static_cast<uint64_t>(pos) * (pos > 0 ? pos - 1 : 0)) / 2;
+        for (uint32_t j = pos + threadIdx.x; j < G; j += kBlock) {
+            const uint32_t b = ord[j];
+            const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+            double acc = 0.0;
+            for (uint32_t c = 0; c < chunks; ++c) acc += pp[(static_cast<uint64_t>(c) * G + lo) * G + hi];
+            seq[s0 + (j - pos)] = acc + ((lf[a] + lf[b]) + (a == b ? 0.0 : log_two));
+        }
+    }
+    __syncthreads();
+
+    // exclusive prefix max over the sequence, keep flags, ordered compaction
+    double carry_max = lowest;
+    uint32_t kept = 0;
+    for (uint64_t base = 0; base < S; base += kBlock) {
+        const uint64_t s = base + threadIdx.x;
+        const double v = s < S ? seq[s] : lowest;
+        // inclusive max scan inside the wave
+        double inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc = fmax(inc, t);
+        }
+        if (lane == 63) lds_red[wave] = inc;
+        __syncthreads();
+        double before = carry_max, total = carry_max;
+#pragma unroll
+        for (int w2 = 0; w2 < kBlock / 64; ++w2) {
+            if (w2 < wave) before = fmax(before, lds_red[w2]);
+            total = fmax(total, lds_red[w2]);
+        }
+        double excl = __shfl_up(inc, 1, 64);
+        if (lane == 0) excl = lowest;
+        excl = fmax(excl, before);
+        const bool keep = (s < S) && !(v - excl < thr);
+        // ordered compaction
+        const unsigned long long ballot = __ballot(keep);
+        const uint32_t in_wave = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) lds_cnt[wave] = __popcll(ballot);
+        __syncthreads();
+        uint32_t off = kept, tot = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kBlock / 64; ++w2) {
+            if (w2 < wave) off += lds_cnt[w2];
+            tot += lds_cnt[w2];
+        }
+        if (keep) {
+            // decode s -> (pos, j)
+            uint32_t pos = 0;
+            {
+                // largest pos with start(pos) <= s, start(pos) = pos*G - pos*(pos-1)/2
+                uint32_t lo = 0, hi = G - 1;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1) >> 1;
+                    const uint64_t st = static_cast<uint64_t>(mid) * G - (static_cast<uint64_t>(mid) * (mid - 1)) / 2;
+                    if (st <= s) lo = mid; else hi = mid - 1;
+                }
+                pos = lo;
+            }
+            const uint64_t st = static_cast<uint64_t>(pos) * G - (static_cast<uint64_t>(pos) * (pos > 0 ? pos - 1 : 0)) / 2;
+            const uint32_t j = pos + static_cast<uint32_t>(s - st);
+            out_first[off + in_wave] = ord[pos];
+            out_second[off + in_wave] = ord[j];
+            out_value[off + in_wave] = v;
+        }
+        kept += tot;
+        carry_max = total;
+        __syncthreads();
+    }
+    const double max_ll = carry_max;
+
+    // late losers -> weight zero; log-sum-exp in kept order; posteriors
+    if (threadIdx.x == 0) {
+        double sum_log = lowest;
+        for (uint32_t k = 0; k < kept; ++k) {
+            double ll = out_value[k];
+            if (ll - max_ll < thr) {
+                ll = lowest;
+                out_value[k] = ll;
+            }
+            sum_log = addLog(sum_log, ll);
+        }
+        lds_scalar = sum_log;
+        args.out_count[m] = kept;
+    }
+    __syncthreads();
+    {
+        const double sum_log = lds_scalar;
+        for (uint32_t k = threadIdx.x; k < kept; k += kBlock) out_value[k] = exp(out_value[k] - sum_log);
+    }
+}
+
+// copies the kept pairs of every matrix into dense arrays
+__global__ void compactPairsKernel(const uint32_t num_matrices, const uint64_t * __restrict__ pair_cap_off,
+                                   const uint64_t * __restrict__ pair_off, const uint32_t * __restrict__ in_first,
+                                   const uint32_t * __restrict__ in_second, const double * __restrict__ in_value,
+                                   uint32_t * __restrict__ out_first, uint32_t * __restrict__ out_second,
+                                   double * __restrict__ out_value) {
+    const uint32_t m = blockIdx.x;
+    if (m >= num_matrices) return;
+    const uint64_t src = pair_cap_off[m], dst = pair_off[m], n = pair_off[m + 1] - pair_off[m];
+    for (uint64_t k = threadIdx.x; k < n; k += blockDim.x) {
+        out_first[dst + k] = in_first[src + k];
+        out_second[dst + k] = in_second[src + k];
+        out_value[dst + k] = in_value[src + k];
+    }
+}
+
+}  // namespace
+
+extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups,
+                                                const uint32_t * column_counts, double min_rel_likelihood,
+                                                rpvg_hip_pair_posteriors ** result_out) {
+    RPVG_REQUIRE(ctx && groups && result_out, "rpvg_hip_bounded_pair_posteriors: NULL argument");
+    *result_out = nullptr;
+    RPVG_REQUIRE(min_rel_likelihood > 0, "rpvg_hip_bounded_pair_posteriors: min_rel_likelihood must be positive");
+    const uint32_t M = groups->num_matrices;
+    rpvg_hip_pair_posteriors * res = new (std::nothrow) rpvg_hip_pair_posteriors();
+    if (!res) {
+        setError("rpvg_hip_bounded_pair_posteriors: out of host memory");
+        return RPVG_HIP_ERR_ALLOC;
+    }
+    res->pair_off.assign(M + 1, 0);
+    if (M == 0) {
+        *result_out = res;
+        return RPVG_HIP_OK;
+    }
+    if (!column_counts) {
+        delete res;
+        setError("rpvg_hip_bounded_pair_posteriors: column_counts is NULL");
+        return RPVG_HIP_ERR_INVALID;
+    }
+
+    std::vector<uint64_t> col_off(M + 1, 0), pair_cap_off(M + 1, 0);
+    double evals = 0;
+    for (uint32_t m = 0; m < M; ++m) {
+        const uint64_t G = groups->h_num_cols[m];
+        col_off[m + 1] = col_off[m] + G;
+        pair_cap_off[m + 1] = pair_cap_off[m] + G * (G + 1) / 2;
+        evals += 2.0 * G * static_cast<double>(groups->h_num_rows[m]);
+    }
+    for (uint64_t c = 0; c < col_off[M]; ++c) {
+        if (column_counts[c] == 0) {
+            delete res;
+            setError("rpvg_hip_bounded_pair_posteriors: column %llu has a zero count", static_cast<unsigned long long>(c));
+            return RPVG_HIP_ERR_INVALID;
+        }
+    }
+    // expensive matrices first
+    std::vector<uint32_t> order(M);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const double wx = static_cast<double>(groups->h_num_rows[x]) * groups->h_num_cols[x] * groups->h_num_cols[x];
+        const double wy = static_cast<double>(groups->h_num_rows[y]) * groups->h_num_cols[y] * groups->h_num_cols[y];
+        return wx != wy ? wx > wy : x < y;
+    });
+
+    // Big matrices (leading part of `order`) take the table path: every pair evaluated in parallel by
+    // (column, row chunk) workgroups, then one resolving workgroup; the rest take the in-workgroup search.
+    const uint64_t table_budget = 1ull << 28;  // doubles of partial pair sums (2 GiB)
+    // rows x columns from which a matrix takes the table path (RPVG_HIP_TABLE_MIN_WORK overrides; tests use 0)
+    double table_min_work = 65536.0;
+    if (const char * env = std::getenv("RPVG_HIP_TABLE_MIN_WORK")) table_min_work = std::atof(env);
+    uint32_t num_big = 0;
+    std::vector<uint64_t> big_col_part_off(M, 0), big_pair_part_off(M, 0);
+    std::vector<uint32_t> item_matrix, item_col, item_chunk;
+    uint64_t col_part_total = 0, pair_part_total = 0;
+    while (num_big < M) {
+        const uint32_t m = order[num_big];
+        const uint64_t R = groups->h_num_rows[m], G = groups->h_num_cols[m];
+        if (static_cast<double>(R) * G < table_min_work) break;
+        const uint64_t chunks = (R + kChunkRows - 1) / kChunkRows;
+        if (pair_part_total + chunks * G * G > table_budget) break;
+        big_col_part_off[m] = col_part_total;
+        big_pair_part_off[m] = pair_part_total;
+        col_part_total += chunks * G;
+        pair_part_total += chunks * G * G;
+        for (uint32_t c = 0; c < chunks; ++c) {
+            for (uint32_t a = 0; a < G; ++a) {
+                item_matrix.push_back(m);
+                item_col.push_back(a);
+                item_chunk.push_back(c);
+            }
+        }
+        ++num_big;
+    }
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    hipError_t e = hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+
+    DeviceBuffer<uint32_t> d_order, d_col_count, d_col_order, d_out_first, d_out_second, d_out_count, d_first, d_second;
+    DeviceBuffer<uint64_t> d_col_off, d_pair_cap_off, d_pair_off;
+    DeviceBuffer<double> d_lf, d_marg, d_opt_raw, d_opt, d_out_value, d_value;
+
+    int span = ctx->spanBegin(FAM_H2D);
+    ok(d_order.upload(order.data(), M, st));
+    ok(d_col_off.upload(col_off.data(), M + 1, st));
+    ok(d_pair_cap_off.upload(pair_cap_off.data(), M + 1, st));
+    ok(d_col_count.upload(column_counts, col_off[M], st));
+    ctx->spanEnd(span);
+    ctx->stats.h2d_bytes += static_cast<double>(M * 20 + col_off[M] * 4);
+    ok(d_lf.alloc(col_off[M]));
+    ok(d_marg.alloc(col_off[M]));
+    ok(d_opt_raw.alloc(col_off[M]));
+    ok(d_opt.alloc(col_off[M]));
+    ok(d_col_order.alloc(col_off[M]));
+    ok(d_out_first.alloc(pair_cap_off[M]));
+    ok(d_out_second.alloc(pair_cap_off[M]));
+    ok(d_out_value.alloc(pair_cap_off[M]));
+    ok(d_out_count.alloc(M));
+    if (e != hipSuccess) {
+        delete res;
+        setError("rpvg_hip_bounded_pair_posteriors: %s", hipGetErrorString(e));
+        return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
+    }
+
+    const rpvg_hip_batch * b = groups->batch;
+    SearchArgs args;
+    args.order = d_order.ptr;
+    args.count = M;
+    args.mat_val_off = groups->mat_val_off.ptr;
+    args.mat_row_off = groups->mat_row_off.ptr;
+    args.mat_row0 = groups->mat_row0.ptr;
+    args.mat_rows = groups->mat_rows.ptr;
+    args.mat_cols = groups->mat_cols.ptr;
+    args.values = groups->values.ptr;
+    args.rowmax = groups->rowmax.ptr;
+    args.row_count = b->row_count.ptr;
+    args.row_noise = b->row_noise.ptr;
+    args.col_off = d_col_off.ptr;
+    args.col_count = d_col_count.ptr;
+    args.pair_cap_off = d_pair_cap_off.ptr;
+    args.min_log_likelihood_diff = std::log(min_rel_likelihood);
+    args.log_freq = d_lf.ptr;
+    args.marginal = d_marg.ptr;
+    args.optimistic_raw = d_opt_raw.ptr;
+    args.optimistic = d_opt.ptr;
+    args.col_order = d_col_order.ptr;
+    args.out_first = d_out_first.ptr;
+    args.out_second = d_out_second.ptr;
+    args.out_value = d_out_value.ptr;
+    args.out_count = d_out_count.ptr;
+
+    DeviceBuffer<uint32_t> d_item_matrix, d_item_col, d_item_chunk;
+    DeviceBuffer<uint64_t> d_big_col_part_off, d_big_pair_part_off;
+    DeviceBuffer<double> d_part_marg, d_part_opt, d_part_pair, d_seq;
+    if (num_big > 0) {
+        ok(d_item_matrix.upload(item_matrix.data(), item_matrix.size(), st));
+        ok(d_item_col.upload(item_col.data(), item_col.size(), st));
+        ok(d_item_chunk.upload(item_chunk.data(), item_chunk.size(), st));
+        ok(d_big_col_part_off.upload(big_col_part_off.data(), M, st));
+        ok(d_big_pair_part_off.upload(big_pair_part_off.data(), M, st));
+        ok(d_part_marg.alloc(col_part_total));
+        ok(d_part_opt.alloc(col_part_total));
+        ok(d_part_pair.alloc(pair_part_total));
+        ok(d_seq.alloc(pair_cap_off[M]));
+    }
+    if (e != hipSuccess) {
+        delete res;
+        setError("rpvg_hip_bounded_pair_posteriors: %s", hipGetErrorString(e));
+        return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
+    }
+
+    span = ctx->spanBegin(FAM_LOGLIK);
+    if (num_big > 0) {
+        TableWork tw;
+        tw.item_matrix = d_item_matrix.ptr;
+        tw.item_col = d_item_col.ptr;
+        tw.item_chunk = d_item_chunk.ptr;
+        tw.count = static_cast<uint32_t>(item_matrix.size());
+        tw.mat_val_off = groups->mat_val_off.ptr;
+        tw.mat_row_off = groups->mat_row_off.ptr;
+        tw.mat_row0 = groups->mat_row0.ptr;
+        tw.mat_rows = groups->mat_rows.ptr;
+        tw.mat_cols = groups->mat_cols.ptr;
+        tw.values = groups->values.ptr;
+        tw.rowmax = groups->rowmax.ptr;
+        tw.row_count = b->row_count.ptr;
+        tw.row_noise = b->row_noise.ptr;
+        tw.big_col_part_off = d_big_col_part_off.ptr;
+        tw.big_pair_part_off = d_big_pair_part_off.ptr;
+        tw.part_marginal = d_part_marg.ptr;
+        tw.part_optimistic = d_part_opt.ptr;
+        tw.part_pair = d_part_pair.ptr;
+        pairTableKernel<<<dim3(tw.count), dim3(256), 0, st>>>(tw);
+
+        ResolveArgs ra;
+        ra.big_matrix = d_order.ptr;
+        ra.count = num_big;
+        ra.mat_rows = groups->mat_rows.ptr;
+        ra.mat_cols = groups->mat_cols.ptr;
+        ra.col_off = d_col_off.ptr;
+        ra.col_count = d_col_count.ptr;
+        ra.pair_cap_off = d_pair_cap_off.ptr;
+        ra.big_col_part_off = d_big_col_part_off.ptr;
+        ra.big_pair_part_off = d_big_pair_part_off.ptr;
+        ra.part_marginal = d_part_marg.ptr;
+        ra.part_optimistic = d_part_opt.ptr;
+        ra.part_pair = d_part_pair.ptr;
+        ra.min_log_likelihood_diff = args.min_log_likelihood_diff;
+        ra.log_freq = d_lf.ptr;
+        ra.marginal = d_marg.ptr;
+        ra.col_order = d_col_order.ptr;
+        ra.seq_value = d_seq.ptr;
+        ra.out_first = d_out_first.ptr;
+        ra.out_second = d_out_second.ptr;
+        ra.out_value = d_out_value.ptr;
+        ra.out_count = d_out_count.ptr;
+        resolveTableKernel<<<dim3(num_big), dim3(256), 0, st>>>(ra);
+    }
+    if (M > num_big) {
+        args.order = d_order.ptr + num_big;
+        args.count = M - num_big;
+        boundedSearchKernel<256><<<dim3(M - num_big), dim3(256), 0, st>>>(args);
+    }
+    ctx->spanEnd(span);
+    ctx->stats.loglik_launches += (num_big > 0 ? 2 : 0) + (M > num_big);
+    ok(hipGetLastError());
+
+    std::vector<uint32_t> counts(M);
+    ok(d_out_count.download(counts.data(), st));
+    ok(hipStreamSynchronize(st));
+    if (e == hipSuccess) {
+        for (uint32_t m = 0; m < M; ++m) res->pair_off[m + 1] = res->pair_off[m] + counts[m];
+        const uint64_t total = res->pair_off[M];
+        res->first.resize(total);
+        res->second.resize(total);
+        res->posterior.resize(total);
+        ok(d_pair_off.upload(res->pair_off.data(), M + 1, st));
+        ok(d_first.alloc(total));
+        ok(d_second.alloc(total));
+        ok(d_value.alloc(total));
+        if (e == hipSuccess && total > 0) {
+            compactPairsKernel<<<dim3(M), dim3(64), 0, st>>>(M, d_pair_cap_off.ptr, d_pair_off.ptr, d_out_first.ptr,
+                                                            d_out_second.ptr, d_out_value.ptr, d_first.ptr, d_second.ptr,
+                                                            d_value.ptr);
+            ok(hipGetLastError());
+            ok(d_first.download(res->first.data(), st));
+            ok(d_second.download(res->second.data(), st));
+            ok(d_value.download(res->posterior.data(), st));
+        }
+        ok(hipStreamSynchronize(st));
+        // marginal + bound logs, plus one log per row of every kept-or-pruned pair that was evaluated is not
+        // observable from the host; count the lower bound (marginals, bounds and kept pairs)
+        for (uint32_t m = 0; m < M; ++m) evals += static_cast<double>(counts[m]) * static_cast<double>(groups->h_num_rows[m]);
+        ctx->stats.loglik_evals += evals;
+    }
+    if (e != hipSuccess) {
+        delete res;
+        setError("rpvg_hip_bounded_pair_posteriors: %s", hipGetErrorString(e));
+        return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
+    }
+    *result_out = res;
+    return RPVG_HIP_OK;
+}
+
+extern "C" int rpvg_hip_pair_posteriors_get(const rpvg_hip_pair_posteriors * result, rpvg_hip_pair_posteriors_view * view_out) {
+    RPVG_REQUIRE(result && view_out, "rpvg_hip_pair_posteriors_get: NULL argument");
+    view_out->num_matrices = static_cast<uint32_t>(result->pair_off.size() - 1);
+    view_out->pair_off = result->pair_off.data();
+    view_out->first = result->first.data();
+    view_out->second = result->second.data();
+    view_out->posterior = result->posterior.data();
+    return RPVG_HIP_OK;
+}
+
+extern "C" void rpvg_hip_pair_posteriors_free(rpvg_hip_pair_posteriors * result) { delete result; }

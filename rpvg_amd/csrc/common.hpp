@@ -108,4 +108,20 @@ struct rpvg_hip_batch {
     rpvg_hip_detail::DeviceBuffer<double> ent_prob;            // [NNZ]
 };
 
+// Device-resident group matrices (loglik.hip builds them).
+struct rpvg_hip_groups {
+    const rpvg_hip_batch * batch = nullptr;
+    uint32_t num_matrices = 0;
+    int32_t normalise = 0;
+    std::vector<uint32_t> h_num_cols;
+    std::vector<uint64_t> h_num_rows;
+    rpvg_hip_detail::DeviceBuffer<double> values;         // all matrices back to back, each column-major
+    rpvg_hip_detail::DeviceBuffer<double> rowmax;         // [sum R_m]
+    rpvg_hip_detail::DeviceBuffer<uint64_t> mat_val_off;  // [M] offset of matrix m in values
+    rpvg_hip_detail::DeviceBuffer<uint64_t> mat_row_off;  // [M] offset of matrix m in rowmax
+    rpvg_hip_detail::DeviceBuffer<uint64_t> mat_row0;     // [M] first batch row of the matrix's cluster
+    rpvg_hip_detail::DeviceBuffer<uint64_t> mat_rows;     // [M] R_m
+    rpvg_hip_detail::DeviceBuffer<uint32_t> mat_cols;     // [M] G_m
+};
+
 #endif

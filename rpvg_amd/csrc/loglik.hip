@@ -21,20 +21,6 @@
 
 using namespace rpvg_hip_detail;
 
-struct rpvg_hip_groups {
-    const rpvg_hip_batch * batch = nullptr;
-    uint32_t num_matrices = 0;
-    int32_t normalise = 0;
-    std::vector<uint32_t> h_num_cols;
-    std::vector<uint64_t> h_num_rows;
-    DeviceBuffer<double> values;         // all matrices back to back, each column-major
-    DeviceBuffer<double> rowmax;         // [sum R_m]
-    DeviceBuffer<uint64_t> mat_val_off;  // [M] offset of matrix m in values
-    DeviceBuffer<uint64_t> mat_row_off;  // [M] offset of matrix m in rowmax
-    DeviceBuffer<uint64_t> mat_row0;     // [M] first batch row of the matrix's cluster
-    DeviceBuffer<uint64_t> mat_rows;     // [M] R_m
-    DeviceBuffer<uint32_t> mat_cols;     // [M] G_m
-};
 
 namespace {
 

@@ -23,6 +23,7 @@ EXPORTS = [
     "rpvg_hip_batch_upload", "rpvg_hip_batch_free", "rpvg_hip_em_solve", "rpvg_hip_em_dense",
     "rpvg_hip_dense_from_cluster", "rpvg_hip_groups_build", "rpvg_hip_groups_free", "rpvg_hip_group_loglik",
     "rpvg_hip_synth_dense_cluster", "rpvg_hip_stats_get", "rpvg_hip_stats_reset",
+    "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
 ]
 
 
@@ -42,6 +43,11 @@ class CEmResults(C.Structure):
 class CGroupSpec(C.Structure):
     _fields_ = [("num_matrices", C.c_uint32), ("cluster", C.c_void_p), ("group_off", C.c_void_p),
                 ("group_path_off", C.c_void_p), ("group_path", C.c_void_p), ("normalise", C.c_int32)]
+
+
+class CPairPosteriorsView(C.Structure):
+    _fields_ = [("num_matrices", C.c_uint32), ("pair_off", C.POINTER(C.c_uint64)), ("first", C.POINTER(C.c_uint32)),
+                ("second", C.POINTER(C.c_uint32)), ("posterior", C.POINTER(C.c_double))]
 
 
 class CKernelStats(C.Structure):
@@ -141,6 +147,27 @@ class DeviceGroups:
                                            C.c_void_p(flag.ctypes.data if flag is not None else None),
                                            C.c_void_p(out.ctypes.data)), "rpvg_hip_group_loglik")
         return out
+
+    def bounded_pair_posteriors(self, column_counts, min_rel_likelihood: float):
+        """Per matrix: ([(first, second)...], posteriors) of the on-device branch-and-bound."""
+        cc = np.ascontiguousarray(column_counts, dtype=np.uint32)
+        h = C.c_void_p()
+        _check(lib().rpvg_hip_bounded_pair_posteriors(self.ctx.handle, self.handle, C.c_void_p(cc.ctypes.data),
+                                                      C.c_double(min_rel_likelihood), C.byref(h)),
+               "rpvg_hip_bounded_pair_posteriors")
+        try:
+            v = CPairPosteriorsView()
+            _check(lib().rpvg_hip_pair_posteriors_get(h, C.byref(v)), "rpvg_hip_pair_posteriors_get")
+            M = v.num_matrices
+            off = np.ctypeslib.as_array(v.pair_off, shape=(M + 1,)).astype(np.int64)
+            n = int(off[-1])
+            first = np.ctypeslib.as_array(v.first, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+            second = np.ctypeslib.as_array(v.second, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+            post = np.ctypeslib.as_array(v.posterior, shape=(n,)).copy() if n else np.zeros(0)
+        finally:
+            lib().rpvg_hip_pair_posteriors_free(h)
+        return [([(int(a), int(b)) for a, b in zip(first[off[m]:off[m + 1]], second[off[m]:off[m + 1]])],
+                 post[off[m]:off[m + 1]]) for m in range(M)]
 
     def free(self):
         if self.handle:

@@ -3,9 +3,11 @@
 #include <algorithm>
 #include <cassert>
 #include <cmath>
+#include <memory>
 #include <numeric>
 
 #include "numeric_utils.hpp"
+#include "trace.hpp"
 
 namespace rpvg_amd {
 
@@ -21,6 +23,8 @@ void PathAbundanceEstimator::requireNoGibbsSamples() const {
 }
 
 void PathAbundanceEstimator::EMAbundanceEstimator(std::vector<EMSolution> * solutions, const DeviceClusterBatch & cluster_batch, const std::vector<EMProblem> & problems) const {
+
+    ScopedPhase phase("EM: flatten + rpvg_hip_em_solve + unpack");
 
     solutions->assign(problems.size(), EMSolution());
 
@@ -155,6 +159,8 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
         // inferAbundancesCollapsedGroups (:428-471)
         std::vector<GroupPosteriorProblem> problems(clusters.size());
 
+        std::unique_ptr<ScopedPhase> groups_phase(new ScopedPhase("nested: findPathSourceGroups"));
+
         #pragma omp parallel for schedule(dynamic, 16)
         for (size_t i = 0; i < clusters.size(); ++i) {
 
@@ -173,8 +179,12 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
             }
         }
 
+        groups_phase.reset();
+
         std::vector<GroupPosteriors> group_posteriors;
         pathGroupPosteriors(&group_posteriors, cluster_batch, problems);
+
+        ScopedPhase select_phase("nested: selectPathSubsetIndices");
 
         #pragma omp parallel for schedule(dynamic, 16)
         for (size_t i = 0; i < clusters.size(); ++i) {
@@ -390,6 +400,8 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
 
     std::vector<EMSolution> solutions;
     EMAbundanceEstimator(&solutions, cluster_batch, problems);
+
+    ScopedPhase merge_phase("nested: weighted merge");
 
     #pragma omp parallel for schedule(dynamic, 16)
     for (size_t i = 0; i < clusters.size(); ++i) {

@@ -3,10 +3,13 @@
 #include <algorithm>
 #include <cassert>
 #include <cmath>
+#include <cstdlib>
 #include <functional>
+#include <memory>
 #include <numeric>
 
 #include "numeric_utils.hpp"
+#include "trace.hpp"
 
 namespace rpvg_amd {
 
@@ -23,6 +26,8 @@ class GroupMatrices {
     public:
 
         GroupMatrices(const std::shared_ptr<HipEngine> & engine_in, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const bool normalise) : engine(engine_in), groups(nullptr) {
+
+            ScopedPhase phase("posteriors: group matrices build");
 
             std::vector<uint32_t> clusters;
             std::vector<uint64_t> group_off(1, 0);
@@ -63,8 +68,12 @@ class GroupMatrices {
         GroupMatrices(const GroupMatrices &) = delete;
         GroupMatrices & operator=(const GroupMatrices &) = delete;
 
+        const rpvg_hip_groups * handle() const { return groups; }
+
         // Evaluates the requests in bounded chunks.
         void logLikelihoods(std::vector<double> * out, const std::vector<uint32_t> & matrix, const std::vector<uint32_t> & members, const uint32_t width, const double divisor, const bool add_rowmax) const {
+
+            ScopedPhase phase("posteriors: loglik device calls");
 
             assert(members.size() == matrix.size() * width);
             out->assign(matrix.size(), 0);
@@ -253,6 +262,63 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
 
     assert(group_size == 2);
 
+    if (std::getenv("RPVG_AMD_HOST_BOUNDED")) {
+
+        calculatePathGroupPosteriorsBoundedHostDriven(group_posteriors, cluster_batch, problems, group_size, min_rel_likelihood, normalise);
+        return;
+    }
+
+    group_posteriors->assign(problems.size(), GroupPosteriors());
+
+    if (problems.empty()) {
+
+        return;
+    }
+
+    const GroupMatrices matrices(engine, cluster_batch, problems, normalise);
+
+    std::vector<uint32_t> column_counts;
+
+    for (auto & problem: problems) {
+
+        assert(problem.column_counts.size() == problem.column_paths.size());
+        column_counts.insert(column_counts.end(), problem.column_counts.begin(), problem.column_counts.end());
+    }
+
+    rpvg_hip_pair_posteriors * pair_posteriors = nullptr;
+
+    {
+        ScopedPhase phase("posteriors: on-device bounded search");
+        HipEngine::check(rpvg_hip_bounded_pair_posteriors(engine->ctx(), matrices.handle(), column_counts.data(), min_rel_likelihood, &pair_posteriors), "rpvg_hip_bounded_pair_posteriors");
+    }
+
+    ScopedPhase phase("posteriors: unpack pairs");
+
+    rpvg_hip_pair_posteriors_view view;
+    HipEngine::check(rpvg_hip_pair_posteriors_get(pair_posteriors, &view), "rpvg_hip_pair_posteriors_get");
+
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        auto & result = group_posteriors->at(i);
+        const uint64_t num_pairs = view.pair_off[i + 1] - view.pair_off[i];
+
+        result.group_sets.reserve(num_pairs);
+        result.posteriors.assign(view.posterior + view.pair_off[i], view.posterior + view.pair_off[i + 1]);
+
+        for (uint64_t j = view.pair_off[i]; j < view.pair_off[i + 1]; ++j) {
+
+            result.group_sets.emplace_back(std::vector<uint32_t>({view.first[j], view.second[j]}));
+        }
+    }
+
+    rpvg_hip_pair_posteriors_free(pair_posteriors);
+}
+
+void PathEstimator::calculatePathGroupPosteriorsBoundedHostDriven(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const double min_rel_likelihood, const bool normalise) const {
+
+    assert(group_size == 2);
+
     group_posteriors->assign(problems.size(), GroupPosteriors());
 
     if (problems.empty()) {
@@ -351,6 +417,8 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
 
         bool any_candidates = false;
 
+        std::unique_ptr<ScopedPhase> request_phase(new ScopedPhase("posteriors: bounded request build"));
+
         for (size_t i = 0; i < problems.size(); ++i) {
 
             auto & search = searches.at(i);
@@ -387,6 +455,8 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
             first_request.at(i + 1) = request_matrix.size();
         }
 
+        request_phase.reset();
+
         if (!any_candidates) {
 
             break;
@@ -394,6 +464,8 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
 
         std::vector<double> pair_log_likelihoods;
         matrices.logLikelihoods(&pair_log_likelihoods, request_matrix, request_members, 2, 2, false);
+
+        ScopedPhase replay_phase("posteriors: bounded replay");
 
         #pragma omp parallel for schedule(dynamic, 8)
         for (size_t i = 0; i < problems.size(); ++i) {

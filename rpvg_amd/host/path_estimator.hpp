@@ -69,9 +69,15 @@ class PathEstimator {
         void calculatePathGroupPosteriorsFull(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const bool normalise) const;
 
         // calculatePathGroupPosteriorsBounded (src/path_estimator.cpp:379-473) for many
-        // problems at once: same sequential branch-and-bound decisions, with the
-        // pair log-likelihoods fetched from the GPU a block of first paths at a time.
+        // problems at once: one GPU workgroup per problem walks the branch-and-bound in
+        // the reference's sequential order (rpvg_hip_bounded_pair_posteriors).
         void calculatePathGroupPosteriorsBounded(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const double min_rel_likelihood, const bool normalise) const;
+
+        // The same search driven from the host: pair log-likelihoods are fetched from the
+        // GPU a block of first paths at a time and the reference's sequential pruning is
+        // replayed on them here.  Kept as the cross-check of the on-device search
+        // (RPVG_AMD_HOST_BOUNDED=1 selects it).
+        void calculatePathGroupPosteriorsBoundedHostDriven(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const double min_rel_likelihood, const bool normalise) const;
 
         // src/path_estimator.cpp:315-330
         static std::vector<double> calcPathLogFrequences(const std::vector<uint32_t> & path_counts);

@@ -11,6 +11,7 @@
 
 #include "../../include/rpvg_batch.h"
 #include "estimator_factory.hpp"
+#include "trace.hpp"
 
 using namespace rpvg_amd;
 
@@ -31,6 +32,8 @@ struct PreparedBatch {
 
     // kept for the per-cluster estimate() mode
     std::vector<std::vector<ReadPathProbabilities> > rows;
+
+    std::vector<PathClusterEstimates> estimates;
 };
 
 struct Result {
@@ -205,12 +208,19 @@ void * rpvg_amd_run(void * engine, void * prepared_batch, const char * model, co
         PreparedBatch * prepared = static_cast<PreparedBatch *>(prepared_batch);
         auto estimator = makePathEstimator(model, *params, static_cast<Engine *>(engine)->hip);
 
-        std::vector<PathClusterEstimates> estimates(prepared->paths.size());
+        // the estimates containers (with PathInfo filled in, as src/main.cpp:855-887 does
+        // before estimate()) are created once per prepared batch and reused by every run
+        if (prepared->estimates.size() != prepared->paths.size()) {
 
-        for (size_t i = 0; i < estimates.size(); ++i) {
+            prepared->estimates.assign(prepared->paths.size(), PathClusterEstimates());
 
-            estimates.at(i).paths = prepared->paths.at(i);
+            for (size_t i = 0; i < prepared->estimates.size(); ++i) {
+
+                prepared->estimates.at(i).paths = prepared->paths.at(i);
+            }
         }
+
+        std::vector<PathClusterEstimates> & estimates = prepared->estimates;
 
         const auto start = std::chrono::steady_clock::now();
 
@@ -234,6 +244,9 @@ void * rpvg_amd_run(void * engine, void * prepared_batch, const char * model, co
 
             *seconds_out = std::chrono::duration<double>(stop - start).count();
         }
+
+        PhaseTrace::add("total estimate call", std::chrono::duration<double>(stop - start).count());
+        PhaseTrace::report();
 
         return packResult(estimates);
 

@@ -1,0 +1,77 @@
+// Optional wall-clock phase tracing of the host layer (RPVG_AMD_TRACE=1):
+// the reference only has stage timers around whole pipeline stages
+// (src/main.cpp:612-1091); these split the inference stage itself.
+#ifndef RPVG_AMD_TRACE_HPP
+#define RPVG_AMD_TRACE_HPP
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+
+namespace rpvg_amd {
+
+class PhaseTrace {
+
+    public:
+
+        static bool enabled() {
+
+            static const bool on = (std::getenv("RPVG_AMD_TRACE") != nullptr);
+            return on;
+        }
+
+        static void add(const std::string & phase, const double seconds) {
+
+            std::lock_guard<std::mutex> lock(mutex());
+            totals()[phase] += seconds;
+        }
+
+        static void report() {
+
+            if (!enabled()) {
+
+                return;
+            }
+
+            std::lock_guard<std::mutex> lock(mutex());
+
+            for (auto & phase: totals()) {
+
+                std::fprintf(stderr, "[rpvg_amd trace] %-40s %9.3f ms\n", phase.first.c_str(), phase.second * 1e3);
+            }
+
+            totals().clear();
+        }
+
+    private:
+
+        static std::mutex & mutex() { static std::mutex m; return m; }
+        static std::map<std::string, double> & totals() { static std::map<std::string, double> t; return t; }
+};
+
+class ScopedPhase {
+
+    public:
+
+        explicit ScopedPhase(const char * name_in) : name(name_in), start(std::chrono::steady_clock::now()) {}
+
+        ~ScopedPhase() {
+
+            if (PhaseTrace::enabled()) {
+
+                PhaseTrace::add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count());
+            }
+        }
+
+    private:
+
+        const char * name;
+        const std::chrono::steady_clock::time_point start;
+};
+
+}
+
+#endif

@@ -260,3 +260,66 @@ def test_stats_report_kernel_time(hip_ctx):
     st = hip_ctx.stats()
     assert st["em_sparse_launches"] >= 1 and st["em_sparse_ms"] > 0 and st["em_sparse_alg_bytes"] > 0
     assert st["em_iterations_total"] > 0
+
+
+# ---- on-device diploid branch-and-bound ---------------------------------------------------
+
+@pytest.mark.parametrize("normalise,thr", [(True, 1e-3), (False, 1e-8)])
+def test_bounded_search_on_device_matches_oracle(hip_ctx, normalise, thr):
+    rng = np.random.default_rng(701)
+    clusters = small_cases.make_batch_clusters(702, n_clusters=10, with_empty=False)
+    clusters.append(small_cases.make_cluster(rng, 3, [9, 7, 8], n_haps=40, n_reads=1500))
+    clusters.append(small_cases.make_cluster(rng, 1, [30], n_haps=60, n_reads=3000))
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    mats, groups, counts = [], [], []
+    for k, cl in enumerate(clusters):
+        if normalise:
+            g, mult = np_oracle.source_groups(cl["paths"])
+        else:
+            g = [[p] for p in range(len(cl["paths"]))]
+            mult = [p["source_count"] for p in cl["paths"]]
+        mats.append(k)
+        groups.append(g)
+        counts.append(mult)
+    dg = hip_ctx.groups(dev, mats, groups, normalise)
+    got = dg.bounded_pair_posteriors(np.concatenate(counts), thr)
+    for m, (k, g) in enumerate(zip(mats, groups)):
+        cl = clusters[k]
+        M, noise, cnts = np_oracle.grouped_matrix(cl["rows"], g)
+        if normalise:
+            M = np_oracle.add_noise_and_normalize(M, noise)[:, :-1]
+        sets, post = pyoracle.group_posteriors(M, noise, cnts, counts[m], 2, bounded=True, min_rel_lik=thr)
+        # same sequential search -> same kept pairs in the same order
+        assert got[m][0] == sets, (m, len(got[m][0]), len(sets))
+        assert small_cases.rel_close(got[m][1], post, rel=1e-9, floor=1e-300)
+        assert abs(got[m][1].sum() - 1) < 1e-9
+
+
+@pytest.mark.parametrize("force_table", [True, False])
+def test_bounded_search_table_path(hip_ctx, force_table):
+    """Big matrices are resolved from a parallel pair table + prefix-max filter instead of the
+    in-workgroup sequential walk; both must give the reference's kept pairs, in its order."""
+    rng = np.random.default_rng(711)
+    clusters = [small_cases.make_cluster(rng, 3, [9, 7, 8], n_haps=40, n_reads=12000),
+                small_cases.make_cluster(rng, 2, [5, 4], n_haps=16, n_reads=600)]
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    groups, counts = [], []
+    for cl in clusters:
+        g, mult = np_oracle.source_groups(cl["paths"])
+        groups.append(g)
+        counts.append(mult)
+    dg = hip_ctx.groups(dev, [0, 1], groups, True)
+    if force_table:
+        os.environ["RPVG_HIP_TABLE_MIN_WORK"] = "0"
+    try:
+        got = dg.bounded_pair_posteriors(np.concatenate(counts), 1e-3)
+    finally:
+        os.environ.pop("RPVG_HIP_TABLE_MIN_WORK", None)
+    for m, cl in enumerate(clusters):
+        M, noise, cnts = np_oracle.grouped_matrix(cl["rows"], groups[m])
+        M = np_oracle.add_noise_and_normalize(M, noise)[:, :-1]
+        sets, post = pyoracle.group_posteriors(M, noise, cnts, counts[m], 2, bounded=True, min_rel_lik=1e-3)
+        assert got[m][0] == sets
+        assert small_cases.rel_close(got[m][1], post, rel=1e-9, floor=1e-300)

@@ -156,3 +156,22 @@ def test_larger_cluster_bounded_search_matches_sequential_reference(engine):
         # posteriors below prob_precision are not reported by the reference's writers
         # (src/threaded_output_writer.cpp:260,473); compare them with an absolute floor
         _compare(got, ref)
+
+
+def test_host_driven_bounded_search_agrees_with_on_device_search(engine):
+    """Two implementations of the same sequential branch-and-bound (device kernel vs host replay of
+    GPU-computed pair log-likelihoods) must keep the same pairs."""
+    rng = np.random.default_rng(671)
+    clusters = small_cases.make_batch_clusters(672, n_clusters=10)
+    clusters.append(small_cases.make_cluster(rng, 2, [12, 9], n_haps=50, n_reads=2000))
+    batch = ClusterBatch.from_clusters(clusters)
+    for model in ("haplotype-transcripts", "haplotypes"):
+        dev, _ = engine.run(model, make_params(), engine.prepare(batch))
+        os.environ["RPVG_AMD_HOST_BOUNDED"] = "1"
+        try:
+            host, _ = engine.run(model, make_params(), engine.prepare(batch))
+        finally:
+            del os.environ["RPVG_AMD_HOST_BOUNDED"]
+        for d, h in zip(dev, host):
+            assert d.path_group_sets == h.path_group_sets
+        _compare(dev, host)
