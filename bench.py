@@ -21,6 +21,10 @@ import os
 import sys
 import time
 
+# OpenMP teams (host layer, CPU oracle) sleep instead of spinning between parallel regions, so that
+# idle workers do not compete with the thread that drives the GPU.  Must be set before libgomp loads.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

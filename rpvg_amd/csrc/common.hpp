@@ -4,9 +4,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -37,6 +39,16 @@ void setError(const char * fmt, ...);
         }                                             \
     } while (0)
 
+// ---- caching device allocator -------------------------------------------------
+// hipMalloc/hipFree cost tens of microseconds to milliseconds each (hipFree also
+// synchronises the device); a step of the hot path needs ~60 scratch arrays whose
+// sizes repeat from batch to batch, and the GPU has 288 GB.  Freed blocks are
+// therefore kept in size-class free lists per device and handed out again;
+// everything is returned to the driver when the last context of the device dies.
+hipError_t poolAlloc(void ** ptr, size_t bytes);
+void poolFree(void * ptr);
+void poolTrim(int device);
+
 // ---- device buffer (owning) -------------------------------------------------
 template <typename T>
 struct DeviceBuffer {
@@ -47,7 +59,7 @@ struct DeviceBuffer {
     DeviceBuffer & operator=(const DeviceBuffer &) = delete;
     ~DeviceBuffer() { release(); }
     void release() {
-        if (ptr) (void) hipFree(ptr);
+        if (ptr) poolFree(ptr);
         ptr = nullptr;
         count = 0;
     }
@@ -55,7 +67,7 @@ struct DeviceBuffer {
         release();
         count = n;
         if (n == 0) return hipSuccess;
-        return hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T));
+        return poolAlloc(reinterpret_cast<void **>(&ptr), n * sizeof(T));
     }
     hipError_t upload(const T * host, size_t n, hipStream_t stream) {
         hipError_t e = alloc(n);
@@ -65,6 +77,20 @@ struct DeviceBuffer {
     hipError_t download(T * host, hipStream_t stream) const {
         if (count == 0) return hipSuccess;
         return hipMemcpyAsync(host, ptr, count * sizeof(T), hipMemcpyDeviceToHost, stream);
+    }
+};
+
+// ---- host-side wall-clock tracing (RPVG_AMD_TRACE=1) --------------------------
+struct HostScope {
+    const char * name;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostScope(const char * n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~HostScope() {
+        static const bool on = std::getenv("RPVG_AMD_TRACE") != nullptr;
+        if (on) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::fprintf(stderr, "[rpvg_hip trace]   %-44s %9.3f ms\n", name, ms);
+        }
     }
 };
 

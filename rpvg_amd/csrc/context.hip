@@ -3,6 +3,8 @@
 
 #include "common.hpp"
 
+#include <map>
+
 namespace rpvg_hip_detail {
 
 static thread_local char g_last_error[1024] = "";
@@ -12,6 +14,87 @@ void setError(const char * fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
+}
+
+namespace {
+
+struct DevicePool {
+    std::map<size_t, std::vector<void *>> free_blocks;  // size class -> cached blocks
+    std::map<void *, size_t> live;                      // block -> size class
+};
+
+std::mutex g_pool_mutex;
+std::map<int, DevicePool> g_pools;
+std::map<void *, int> g_block_device;
+std::map<int, int> g_device_contexts;
+
+// power-of-two classes below 1 MiB, eight classes per octave above
+size_t sizeClass(size_t bytes) {
+    if (bytes <= 256) return 256;
+    size_t pow2 = 256;
+    while (pow2 < bytes) pow2 <<= 1;
+    if (pow2 <= (1u << 20)) return pow2;
+    const size_t step = pow2 >> 4;  // pow2/2 .. pow2 in 8 steps
+    return ((bytes + step - 1) / step) * step;
+}
+
+}  // namespace
+
+hipError_t poolAlloc(void ** ptr, size_t bytes) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    const size_t cls = sizeClass(bytes);
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        DevicePool & pool = g_pools[device];
+        auto it = pool.free_blocks.find(cls);
+        if (it != pool.free_blocks.end() && !it->second.empty()) {
+            *ptr = it->second.back();
+            it->second.pop_back();
+            pool.live[*ptr] = cls;
+            return hipSuccess;
+        }
+    }
+    e = hipMalloc(ptr, cls);
+    if (e == hipErrorOutOfMemory) {
+        // give cached blocks back to the driver and retry once
+        (void) hipGetLastError();
+        poolTrim(device);
+        e = hipMalloc(ptr, cls);
+    }
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pools[device].live[*ptr] = cls;
+    g_block_device[*ptr] = device;
+    return hipSuccess;
+}
+
+void poolFree(void * ptr) {
+    if (!ptr) return;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    auto dev_it = g_block_device.find(ptr);
+    if (dev_it == g_block_device.end()) {
+        (void) hipFree(ptr);
+        return;
+    }
+    DevicePool & pool = g_pools[dev_it->second];
+    auto it = pool.live.find(ptr);
+    if (it == pool.live.end()) return;
+    pool.free_blocks[it->second].push_back(ptr);
+    pool.live.erase(it);
+}
+
+void poolTrim(int device) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    DevicePool & pool = g_pools[device];
+    for (auto & cls : pool.free_blocks) {
+        for (void * p : cls.second) {
+            (void) hipFree(p);
+            g_block_device.erase(p);
+        }
+        cls.second.clear();
+    }
 }
 
 }  // namespace rpvg_hip_detail
@@ -124,6 +207,10 @@ int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) {
         delete ctx;
         return RPVG_HIP_ERR_NO_DEVICE;
     }
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        g_device_contexts[device]++;
+    }
     *ctx_out = ctx;
     return RPVG_HIP_OK;
 }
@@ -133,6 +220,12 @@ void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
     (void) hipSetDevice(ctx->device);
     (void) ctx->foldSpans();
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    bool last = false;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        last = (--g_device_contexts[ctx->device] <= 0);
+    }
+    if (last) poolTrim(ctx->device);
     delete ctx;
 }
 

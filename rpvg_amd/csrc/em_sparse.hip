@@ -31,6 +31,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <memory>
 #include <numeric>
 
 using namespace rpvg_hip_detail;
@@ -357,6 +358,7 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
                  "rpvg_hip_em_solve: NULL result arrays");
     RPVG_REQUIRE(max_em_its > 0, "rpvg_hip_em_solve: max_em_its must be positive");
 
+    std::unique_ptr<HostScope> scope(new HostScope("em_solve: validate"));
     // ---- validate + host-side offsets ----
     std::vector<uint64_t> colmap_off(P + 1, 0);
     uint32_t max_cols_all = 0;
@@ -381,6 +383,7 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     RPVG_REQUIRE(sizeof(double) * (2 * static_cast<size_t>(max_cols_all) + 8) <= 160 * 1024,
                  "rpvg_hip_em_solve: a problem with %u columns does not fit the LDS-resident abundance vector", max_cols_all);
 
+    scope.reset(new HostScope("em_solve: colmap + count + download"));
     std::lock_guard<std::mutex> lock(ctx->mutex);
     RPVG_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -420,6 +423,7 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     RPVG_HIP_CHECK(d_total.download(results->total_count, st));
     RPVG_HIP_CHECK(hipStreamSynchronize(st));
 
+    scope.reset(new HostScope("em_solve: host prefix/order"));
     // ---- host: prefix sums, ordering, bins ----
     std::vector<uint64_t> row_base(P), ent_base(P);
     uint64_t rows_total = 0, ent_total = 0;
@@ -461,6 +465,7 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
         order.insert(order.end(), bins[b].begin(), bins[b].end());
     }
 
+    scope.reset(new HostScope("em_solve: fill + EM kernels + download"));
     DeviceBuffer<uint64_t> d_row_base, d_ent_base;
     DeviceBuffer<uint32_t> d_order, d_prow_off, d_pent_col, d_iters;
     DeviceBuffer<double> d_prow_count, d_prow_noise, d_pent_val, d_abund, d_noise_count;

@@ -18,6 +18,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <memory>
 
 using namespace rpvg_hip_detail;
 
@@ -126,6 +127,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     g->num_matrices = M;
     g->normalise = spec->normalise;
 
+    std::unique_ptr<HostScope> scope_host(new HostScope("groups_build: host incidence"));
     // host: sizes, offsets and the path -> groups incidence of every matrix
     std::vector<uint64_t> val_off(M), row_off(M), row0(M), rows(M), inc_off(M);
     std::vector<uint32_t> cols(M);
@@ -190,6 +192,8 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         return RPVG_HIP_OK;
     }
 
+    scope_host.reset();
+    HostScope scope_dev("groups_build: upload + kernels + sync");
     std::lock_guard<std::mutex> lock(ctx->mutex);
     hipError_t e = hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;

@@ -39,6 +39,8 @@ def lib() -> C.CDLL:
         L.rpvg_amd_batch_free.argtypes = [C.c_void_p]
         L.rpvg_amd_run.restype = C.c_void_p
         L.rpvg_amd_run.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double)]
+        L.rpvg_amd_run_inplace.restype = C.c_int
+        L.rpvg_amd_run_inplace.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double)]
         L.rpvg_amd_result_view.argtypes = [C.c_void_p, C.POINTER(CEstimatesView)]
         L.rpvg_amd_result_free.argtypes = [C.c_void_p]
         _lib = L
@@ -103,12 +105,12 @@ class Engine:
         return out, secs.value
 
     def run_raw(self, model: str, params: CParams, prepared: "PreparedBatch") -> float:
-        """Like run() but drops the estimates (bench inner loop: no Python decode in the way)."""
+        """Like run() but leaves the estimates in the C++ PathClusterEstimates containers of the prepared
+        batch instead of flattening and decoding them (bench inner loop)."""
         secs = C.c_double(0)
-        h = lib().rpvg_amd_run(self.handle, prepared.handle, model.encode(), C.byref(params), C.byref(secs))
-        if not h:
+        rc = lib().rpvg_amd_run_inplace(self.handle, prepared.handle, model.encode(), C.byref(params), C.byref(secs))
+        if rc != 0:
             raise hip.EngineError(f"run({model}) failed: {_err()}")
-        lib().rpvg_amd_result_free(h)
         return secs.value
 
 

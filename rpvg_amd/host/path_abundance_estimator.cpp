@@ -139,6 +139,8 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
 
     assert(path_cluster_estimates->size() == cluster_batch.numClusters());
 
+    ScopedPhase whole_phase("nested: estimateBatch incl. teardown");
+
     std::vector<uint32_t> clusters;
 
     for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
@@ -161,19 +163,16 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
 
         std::unique_ptr<ScopedPhase> groups_phase(new ScopedPhase("nested: findPathSourceGroups"));
 
-        #pragma omp parallel for schedule(dynamic, 16)
+        #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
         for (size_t i = 0; i < clusters.size(); ++i) {
 
-            auto path_source_groups = findPathSourceGroups(path_cluster_estimates->at(clusters.at(i)).paths);
-
             problems.at(i).cluster = clusters.at(i);
-            problems.at(i).column_paths = std::move(path_source_groups.first);
-            problems.at(i).column_counts = std::move(path_source_groups.second);
+            findPathSourceGroups(&problems.at(i), path_cluster_estimates->at(clusters.at(i)).paths);
         }
 
         for (auto & problem: problems) {
 
-            if (problem.column_paths.empty()) {
+            if (problem.numColumns() == 0) {
 
                 throw EngineError("haplotype-transcripts inference needs source (haplotype) ids on the paths of every cluster");
             }
@@ -186,10 +185,10 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
 
         ScopedPhase select_phase("nested: selectPathSubsetIndices");
 
-        #pragma omp parallel for schedule(dynamic, 16)
+        #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
         for (size_t i = 0; i < clusters.size(); ++i) {
 
-            selectPathSubsetIndices(&path_subset_samples.at(i), group_posteriors.at(i), problems.at(i).column_paths);
+            selectPathSubsetIndices(&path_subset_samples.at(i), group_posteriors.at(i), problems.at(i));
         }
 
     } else {
@@ -216,8 +215,7 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
 
                 for (auto & path: group) {
 
-                    problems.back().column_paths.emplace_back(std::vector<uint32_t>(1, path));
-                    problems.back().column_counts.emplace_back(paths.at(path).source_count);
+                    problems.back().addColumn(&path, &path + 1, paths.at(path).source_count);
                 }
             }
 
@@ -285,49 +283,62 @@ std::vector<std::vector<uint32_t> > NestedPathAbundanceEstimator::findPathGroups
 // its multiplicity is the number of such haplotypes
 // (src/path_abundance_estimator.cpp:493-546).  Columns come out in ascending
 // order of their smallest source id (the reference's order is that of its hash map).
-std::pair<std::vector<std::vector<uint32_t> >, std::vector<uint32_t> > NestedPathAbundanceEstimator::findPathSourceGroups(const std::vector<PathInfo> & paths) const {
+void NestedPathAbundanceEstimator::findPathSourceGroups(GroupPosteriorProblem * problem, const std::vector<PathInfo> & paths) const {
 
-    std::map<uint32_t, std::vector<uint32_t> > source_id_paths;
+    // (source id, path) incidences, grouped by source id with paths ascending
+    std::vector<std::pair<uint32_t, uint32_t> > source_paths;
 
     for (size_t i = 0; i < paths.size(); ++i) {
 
         for (auto & id: paths.at(i).source_ids) {
 
-            source_id_paths[id].emplace_back(i);
+            source_paths.emplace_back(id, i);
         }
     }
 
-    std::pair<std::vector<std::vector<uint32_t> >, std::vector<uint32_t> > path_source_groups;
+    std::sort(source_paths.begin(), source_paths.end());
+
     std::map<std::vector<uint32_t>, uint32_t> group_index;
+    std::vector<uint32_t> path_list;
 
-    for (auto & source_paths: source_id_paths) {
+    size_t run_begin = 0;
 
-        auto group_index_it = group_index.emplace(source_paths.second, path_source_groups.first.size());
+    while (run_begin < source_paths.size()) {
+
+        size_t run_end = run_begin;
+        path_list.clear();
+
+        while (run_end < source_paths.size() && source_paths.at(run_end).first == source_paths.at(run_begin).first) {
+
+            path_list.emplace_back(source_paths.at(run_end).second);
+            ++run_end;
+        }
+
+        auto group_index_it = group_index.emplace(path_list, problem->numColumns());
 
         if (group_index_it.second) {
 
-            path_source_groups.first.emplace_back(source_paths.second);
-            path_source_groups.second.emplace_back(1);
+            problem->addColumn(path_list.data(), path_list.data() + path_list.size(), 1);
 
         } else {
 
-            path_source_groups.second.at(group_index_it.first->second)++;
+            problem->column_counts.at(group_index_it.first->second)++;
         }
-    }
 
-    return path_source_groups;
+        run_begin = run_end;
+    }
 }
 
 // src/path_abundance_estimator.cpp:548-567
 void NestedPathAbundanceEstimator::sampleGroupPathIndices(std::vector<std::vector<uint32_t> > * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<uint32_t> & group, std::mt19937 * mt_rng) const {
 
-    assert(group_posteriors.posteriors.size() == group_posteriors.group_sets.size());
+    assert(group_posteriors.group_size == group_size);
     std::discrete_distribution<uint32_t> path_group_set_sampler(group_posteriors.posteriors.begin(), group_posteriors.posteriors.end());
 
     for (auto & path_subset_sample: *path_subset_samples) {
 
-        std::vector<uint32_t> path_group_set = group_posteriors.group_sets.at(path_group_set_sampler(*mt_rng));
-        assert(path_group_set.size() == group_size);
+        const size_t sampled_set = path_group_set_sampler(*mt_rng);
+        std::vector<uint32_t> path_group_set(group_posteriors.set(sampled_set), group_posteriors.set(sampled_set) + group_size);
 
         std::sort(path_group_set.begin(), path_group_set.end());
 
@@ -339,7 +350,7 @@ void NestedPathAbundanceEstimator::sampleGroupPathIndices(std::vector<std::vecto
 }
 
 // src/path_abundance_estimator.cpp:569-606
-void NestedPathAbundanceEstimator::selectPathSubsetIndices(PathSubsetWeights * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<std::vector<uint32_t> > & path_groups) const {
+void NestedPathAbundanceEstimator::selectPathSubsetIndices(PathSubsetWeights * path_subset_samples, const GroupPosteriors & group_posteriors, const GroupPosteriorProblem & problem) const {
 
     double sum_posterior = 0;
 
@@ -352,9 +363,10 @@ void NestedPathAbundanceEstimator::selectPathSubsetIndices(PathSubsetWeights * p
 
         std::vector<uint32_t> path_subset;
 
-        for (auto & group: group_posteriors.group_sets.at(i)) {
+        for (uint32_t j = 0; j < group_posteriors.group_size; ++j) {
 
-            path_subset.insert(path_subset.end(), path_groups.at(group).begin(), path_groups.at(group).end());
+            const uint32_t group = group_posteriors.set(i)[j];
+            path_subset.insert(path_subset.end(), problem.columnBegin(group), problem.columnEnd(group));
         }
 
         std::sort(path_subset.begin(), path_subset.end());
@@ -373,6 +385,8 @@ void NestedPathAbundanceEstimator::selectPathSubsetIndices(PathSubsetWeights * p
 void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples) const {
 
     assert(clusters.size() == path_subset_samples.size());
+
+    std::unique_ptr<ScopedPhase> build_phase(new ScopedPhase("nested: EM problem list"));
 
     // one EM problem per retained subset: its distinct paths
     std::vector<EMProblem> problems;
@@ -398,12 +412,14 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
         first_problem.at(i + 1) = problems.size();
     }
 
+    build_phase.reset();
+
     std::vector<EMSolution> solutions;
     EMAbundanceEstimator(&solutions, cluster_batch, problems);
 
     ScopedPhase merge_phase("nested: weighted merge");
 
-    #pragma omp parallel for schedule(dynamic, 16)
+    #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
     for (size_t i = 0; i < clusters.size(); ++i) {
 
         auto & estimates = path_cluster_estimates->at(clusters.at(i));

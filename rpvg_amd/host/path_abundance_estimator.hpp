@@ -76,12 +76,12 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
         typedef std::map<std::vector<uint32_t>, double> PathSubsetWeights;
 
         std::vector<std::vector<uint32_t> > findPathGroups(const std::vector<PathInfo> & paths) const;
-        std::pair<std::vector<std::vector<uint32_t> >, std::vector<uint32_t> > findPathSourceGroups(const std::vector<PathInfo> & paths) const;
+        void findPathSourceGroups(GroupPosteriorProblem * problem, const std::vector<PathInfo> & paths) const;
 
         void pathGroupPosteriors(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems) const;
 
         void sampleGroupPathIndices(std::vector<std::vector<uint32_t> > * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<uint32_t> & group, std::mt19937 * mt_rng) const;
-        void selectPathSubsetIndices(PathSubsetWeights * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<std::vector<uint32_t> > & path_groups) const;
+        void selectPathSubsetIndices(PathSubsetWeights * path_subset_samples, const GroupPosteriors & group_posteriors, const GroupPosteriorProblem & problem) const;
 
         void inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples) const;
 };

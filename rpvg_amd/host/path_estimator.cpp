@@ -36,16 +36,31 @@ class GroupMatrices {
 
             clusters.reserve(problems.size());
 
+            size_t num_columns = 0;
+            size_t num_column_paths = 0;
+
+            for (auto & problem: problems) {
+
+                num_columns += problem.numColumns();
+                num_column_paths += problem.column_path.size();
+            }
+
+            group_off.reserve(problems.size() + 1);
+            group_path_off.reserve(num_columns + 1);
+            group_path.reserve(num_column_paths);
+
             for (auto & problem: problems) {
 
                 clusters.emplace_back(problem.cluster);
 
-                for (auto & paths: problem.column_paths) {
+                const uint64_t first_path = group_path.size();
 
-                    group_path.insert(group_path.end(), paths.begin(), paths.end());
-                    group_path_off.emplace_back(group_path.size());
+                for (uint32_t column = 1; column <= problem.numColumns(); ++column) {
+
+                    group_path_off.emplace_back(first_path + problem.column_path_off[column]);
                 }
 
+                group_path.insert(group_path.end(), problem.column_path.begin(), problem.column_path.end());
                 group_off.emplace_back(group_path_off.size() - 1);
             }
 
@@ -115,7 +130,7 @@ struct BoundedSearch {
 
     std::vector<uint32_t> candidates;
 
-    std::vector<std::vector<uint32_t> > kept_sets;
+    std::vector<uint32_t> kept_members;
     std::vector<double> kept_log_likelihoods;
 };
 
@@ -209,43 +224,50 @@ void PathEstimator::calculatePathGroupPosteriorsFull(std::vector<GroupPosteriors
     for (size_t i = 0; i < problems.size(); ++i) {
 
         PathClusterEstimates enumerator;
-        enumerator.generateGroups(problems.at(i).column_paths.size(), group_size);
+        enumerator.generateGroups(problems.at(i).numColumns(), group_size);
 
-        group_posteriors->at(i).group_sets = std::move(enumerator.path_group_sets);
+        auto & result = group_posteriors->at(i);
+        result.group_size = group_size;
+        result.members.reserve(enumerator.path_group_sets.size() * group_size);
 
-        for (auto & group_set: group_posteriors->at(i).group_sets) {
+        for (auto & group_set: enumerator.path_group_sets) {
 
             request_matrix.emplace_back(i);
-            request_members.insert(request_members.end(), group_set.begin(), group_set.end());
+            result.members.insert(result.members.end(), group_set.begin(), group_set.end());
         }
 
+        request_members.insert(request_members.end(), result.members.begin(), result.members.end());
         first_request.at(i + 1) = request_matrix.size();
     }
 
     std::vector<double> log_likelihoods;
     matrices.logLikelihoods(&log_likelihoods, request_matrix, request_members, group_size, group_size, false);
 
-    #pragma omp parallel for schedule(dynamic, 8)
+    #pragma omp parallel for schedule(dynamic, 8) num_threads(hostThreads())
     for (size_t i = 0; i < problems.size(); ++i) {
 
         const auto path_log_freqs = calcPathLogFrequences(problems.at(i).column_counts);
-        assert(path_log_freqs.size() == problems.at(i).column_paths.size());
+        assert(path_log_freqs.size() == problems.at(i).numColumns());
 
         auto & result = group_posteriors->at(i);
-        result.posteriors.assign(result.group_sets.size(), 0);
+
+        const size_t num_sets = first_request.at(i + 1) - first_request.at(i);
+        result.posteriors.assign(num_sets, 0);
 
         double sum_log_posterior = numeric::log_zero;
 
-        for (size_t j = 0; j < result.group_sets.size(); ++j) {
+        for (size_t j = 0; j < num_sets; ++j) {
 
             double log_posterior = log_likelihoods.at(first_request.at(i) + j);
 
-            for (auto & path_idx: result.group_sets.at(j)) {
+            const std::vector<uint32_t> group_set(result.set(j), result.set(j) + group_size);
+
+            for (auto & path_idx: group_set) {
 
                 log_posterior += path_log_freqs.at(path_idx);
             }
 
-            log_posterior += std::log(numeric::numPermutations(result.group_sets.at(j)));
+            log_posterior += std::log(numeric::numPermutations(group_set));
 
             result.posteriors.at(j) = log_posterior;
             sum_log_posterior = numeric::add_log(sum_log_posterior, log_posterior);
@@ -281,7 +303,6 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
 
     for (auto & problem: problems) {
 
-        assert(problem.column_counts.size() == problem.column_paths.size());
         column_counts.insert(column_counts.end(), problem.column_counts.begin(), problem.column_counts.end());
     }
 
@@ -297,18 +318,20 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
     rpvg_hip_pair_posteriors_view view;
     HipEngine::check(rpvg_hip_pair_posteriors_get(pair_posteriors, &view), "rpvg_hip_pair_posteriors_get");
 
-    #pragma omp parallel for schedule(static)
+    #pragma omp parallel for schedule(static) num_threads(hostThreads())
     for (size_t i = 0; i < problems.size(); ++i) {
 
         auto & result = group_posteriors->at(i);
         const uint64_t num_pairs = view.pair_off[i + 1] - view.pair_off[i];
 
-        result.group_sets.reserve(num_pairs);
+        result.group_size = 2;
+        result.members.reserve(num_pairs * 2);
         result.posteriors.assign(view.posterior + view.pair_off[i], view.posterior + view.pair_off[i + 1]);
 
         for (uint64_t j = view.pair_off[i]; j < view.pair_off[i + 1]; ++j) {
 
-            result.group_sets.emplace_back(std::vector<uint32_t>({view.first[j], view.second[j]}));
+            result.members.emplace_back(view.first[j]);
+            result.members.emplace_back(view.second[j]);
         }
     }
 
@@ -343,7 +366,7 @@ void PathEstimator::calculatePathGroupPosteriorsBoundedHostDriven(std::vector<Gr
 
         for (size_t i = 0; i < problems.size(); ++i) {
 
-            for (uint32_t j = 0; j < problems.at(i).column_paths.size(); ++j) {
+            for (uint32_t j = 0; j < problems.at(i).numColumns(); ++j) {
 
                 request_matrix.emplace_back(i);
                 marginal_members.emplace_back(j);
@@ -360,11 +383,11 @@ void PathEstimator::calculatePathGroupPosteriorsBoundedHostDriven(std::vector<Gr
         std::vector<double> optimistic_log_likelihoods;
         matrices.logLikelihoods(&optimistic_log_likelihoods, request_matrix, optimistic_members, 2, 2, true);
 
-        #pragma omp parallel for schedule(dynamic, 8)
+        #pragma omp parallel for schedule(dynamic, 8) num_threads(hostThreads())
         for (size_t i = 0; i < problems.size(); ++i) {
 
             auto & search = searches.at(i);
-            const uint32_t num_columns = problems.at(i).column_paths.size();
+            const uint32_t num_columns = problems.at(i).numColumns();
 
             search.log_freqs = calcPathLogFrequences(problems.at(i).column_counts);
             assert(search.log_freqs.size() == num_columns);
@@ -467,7 +490,7 @@ void PathEstimator::calculatePathGroupPosteriorsBoundedHostDriven(std::vector<Gr
 
         ScopedPhase replay_phase("posteriors: bounded replay");
 
-        #pragma omp parallel for schedule(dynamic, 8)
+        #pragma omp parallel for schedule(dynamic, 8) num_threads(hostThreads())
         for (size_t i = 0; i < problems.size(); ++i) {
 
             auto & search = searches.at(i);
@@ -507,7 +530,8 @@ void PathEstimator::calculatePathGroupPosteriorsBoundedHostDriven(std::vector<Gr
                     search.max_log_likelihood = std::max(search.max_log_likelihood, log_likelihood);
 
                     search.kept_log_likelihoods.emplace_back(log_likelihood);
-                    search.kept_sets.emplace_back(std::vector<uint32_t>({first_path_idx, second_path_idx}));
+                    search.kept_members.emplace_back(first_path_idx);
+                    search.kept_members.emplace_back(second_path_idx);
                 }
             }
 
@@ -518,7 +542,7 @@ void PathEstimator::calculatePathGroupPosteriorsBoundedHostDriven(std::vector<Gr
     }
 
     // src/path_estimator.cpp:453-470
-    #pragma omp parallel for schedule(dynamic, 8)
+    #pragma omp parallel for schedule(dynamic, 8) num_threads(hostThreads())
     for (size_t i = 0; i < problems.size(); ++i) {
 
         auto & search = searches.at(i);
@@ -536,7 +560,8 @@ void PathEstimator::calculatePathGroupPosteriorsBoundedHostDriven(std::vector<Gr
             sum_log_posterior = numeric::add_log(sum_log_posterior, log_likelihood);
         }
 
-        result.group_sets = std::move(search.kept_sets);
+        result.group_size = 2;
+        result.members = std::move(search.kept_members);
         result.posteriors.reserve(search.kept_log_likelihoods.size());
 
         for (auto & log_likelihood: search.kept_log_likelihoods) {

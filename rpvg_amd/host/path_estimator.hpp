@@ -27,17 +27,38 @@ namespace rpvg_amd {
 // One posterior problem over the columns of a group matrix of one cluster:
 // column g is the set of cluster-local paths column_paths[g] (a single path
 // for `-i haplotypes`, a haplotype's HST set for `-i haplotype-transcripts`).
+// Stored flat (offsets + one array): a batch holds hundreds of thousands of columns.
 struct GroupPosteriorProblem {
 
-    uint32_t cluster;
-    std::vector<std::vector<uint32_t> > column_paths;
+    uint32_t cluster = 0;
+
+    std::vector<uint32_t> column_path_off = std::vector<uint32_t>(1, 0);
+    std::vector<uint32_t> column_path;
     std::vector<uint32_t> column_counts;
+
+    uint32_t numColumns() const { return column_counts.size(); }
+
+    void addColumn(const uint32_t * first_path, const uint32_t * last_path, const uint32_t count) {
+
+        column_path.insert(column_path.end(), first_path, last_path);
+        column_path_off.emplace_back(column_path.size());
+        column_counts.emplace_back(count);
+    }
+
+    const uint32_t * columnBegin(const uint32_t column) const { return column_path.data() + column_path_off[column]; }
+    const uint32_t * columnEnd(const uint32_t column) const { return column_path.data() + column_path_off[column + 1]; }
 };
 
+// Group sets (multisets of `group_size` column indices, flat) and their posteriors.
 struct GroupPosteriors {
 
-    std::vector<std::vector<uint32_t> > group_sets;
+    uint32_t group_size = 0;
+
+    std::vector<uint32_t> members;
     std::vector<double> posteriors;
+
+    size_t size() const { return posteriors.size(); }
+    const uint32_t * set(const size_t idx) const { return members.data() + idx * group_size; }
 };
 
 class PathEstimator {

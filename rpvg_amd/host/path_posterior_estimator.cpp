@@ -28,8 +28,7 @@ std::vector<GroupPosteriorProblem> PathPosteriorEstimator::rawPathProblems(const
 
         for (uint32_t j = 0; j < paths.size(); ++j) {
 
-            problems.back().column_paths.emplace_back(std::vector<uint32_t>(1, j));
-            problems.back().column_counts.emplace_back(paths.at(j).source_count);
+            problems.back().addColumn(&j, &j + 1, paths.at(j).source_count);
         }
     }
 
@@ -57,7 +56,7 @@ void PathPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates> * p
 
         // calculatePathGroupPosteriorsFull re-creates the sets and zeroes the rest (src/path_estimator.cpp:343)
         estimates.resetEstimates(estimates.paths.size(), 1);
-        assert(estimates.path_group_sets == group_posteriors.at(i).group_sets);
+        assert(estimates.path_group_sets.size() == group_posteriors.at(i).size());
 
         estimates.posteriors = std::move(group_posteriors.at(i).posteriors);
     }
@@ -97,7 +96,15 @@ void PathGroupPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates
 
         auto & estimates = path_cluster_estimates->at(problems.at(i).cluster);
 
-        estimates.path_group_sets = std::move(group_posteriors.at(i).group_sets);
+        const auto & result = group_posteriors.at(i);
+
+        estimates.path_group_sets.reserve(result.size());
+
+        for (size_t j = 0; j < result.size(); ++j) {
+
+            estimates.path_group_sets.emplace_back(result.set(j), result.set(j) + result.group_size);
+        }
+
         estimates.posteriors = std::move(group_posteriors.at(i).posteriors);
 
         if (group_size != 2) {

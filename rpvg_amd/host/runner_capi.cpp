@@ -257,6 +257,53 @@ void * rpvg_amd_run(void * engine, void * prepared_batch, const char * model, co
     }
 }
 
+// Same run, estimates left in the prepared batch's containers and not flattened
+// (timing loops).  Returns 0 on success.
+int rpvg_amd_run_inplace(void * engine, void * prepared_batch, const char * model, const rpvg_params * params, double * seconds_out) {
+
+    try {
+
+        PreparedBatch * prepared = static_cast<PreparedBatch *>(prepared_batch);
+
+        if (!prepared->device) {
+
+            last_error = "rpvg_amd_run_inplace needs a batch prepared for estimateBatch()";
+            return -1;
+        }
+
+        auto estimator = makePathEstimator(model, *params, static_cast<Engine *>(engine)->hip);
+
+        if (prepared->estimates.size() != prepared->paths.size()) {
+
+            prepared->estimates.assign(prepared->paths.size(), PathClusterEstimates());
+
+            for (size_t i = 0; i < prepared->estimates.size(); ++i) {
+
+                prepared->estimates.at(i).paths = prepared->paths.at(i);
+            }
+        }
+
+        const auto start = std::chrono::steady_clock::now();
+        estimator->estimateBatchSeeded(&prepared->estimates, *prepared->device, params->rng_seed);
+        const auto stop = std::chrono::steady_clock::now();
+
+        if (seconds_out) {
+
+            *seconds_out = std::chrono::duration<double>(stop - start).count();
+        }
+
+        PhaseTrace::add("total estimate call", std::chrono::duration<double>(stop - start).count());
+        PhaseTrace::report();
+
+        return 0;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
 void rpvg_amd_result_view(void * result_handle, rpvg_estimates_view * out) {
 
     Result * result = static_cast<Result *>(result_handle);

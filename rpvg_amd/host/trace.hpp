@@ -4,6 +4,7 @@
 #ifndef RPVG_AMD_TRACE_HPP
 #define RPVG_AMD_TRACE_HPP
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -11,7 +12,27 @@
 #include <mutex>
 #include <string>
 
+#include <omp.h>
+
 namespace rpvg_amd {
+
+// Threads used by the host-side parallel loops (flattening, subset selection, merging).  These loops
+// are short; a modest team avoids waking (and then spinning) every hardware thread of a large host
+// between GPU calls.  RPVG_AMD_HOST_THREADS overrides.
+inline int hostThreads() {
+
+    static const int threads = []() {
+
+        if (const char * env = std::getenv("RPVG_AMD_HOST_THREADS")) {
+
+            return std::max(1, std::atoi(env));
+        }
+
+        return std::max(1, std::min(16, omp_get_max_threads()));
+    }();
+
+    return threads;
+}
 
 class PhaseTrace {
 
