@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--workload", default="s3", choices=["s3", "c2"])
     ap.add_argument("--model", default="haplotype-transcripts", choices=["haplotype-transcripts", "transcripts", "haplotypes"])
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the full workload (parity/dev runs only)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank owns a full-size batch; strong: ONE batch, clusters sharded over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -105,15 +107,23 @@ def cpu_baseline_s3(batch, model, params, target_seconds):
 
 def run_s3(args, rank, local_rank, world, dist, torch):
     import numpy as np
-    from rpvg_amd import engine as eng_mod, synth
+    from rpvg_amd import dist as rdist, engine as eng_mod, synth
     from rpvg_amd.batch import make_params
 
     params = make_params()
     K = max(8, int(round(5000 * args.scale)))
     total_paths = max(K, int(round(200000 * args.scale)))
     total_reads = int(round(10000000 * args.scale))
-    # weak scaling: every rank owns a full-size batch (its own seed)
-    batch = synth.generate(seed=3 + rank, num_clusters=K, total_paths=total_paths, total_reads=total_reads)
+    if args.scaling == "weak" or world == 1:
+        # weak scaling: every rank owns a full-size batch (its own seed)
+        batch = synth.generate(seed=3 + rank, num_clusters=K, total_paths=total_paths, total_reads=total_reads)
+        my_clusters = list(range(batch.num_clusters))
+        global_clusters = batch.num_clusters
+    else:
+        # strong scaling (BASELINE.json configs[3]): the same batch on every rank, clusters bin-packed over ranks
+        full = synth.generate(seed=3, num_clusters=K, total_paths=total_paths, total_reads=total_reads)
+        batch, my_clusters = rdist.shard_batch(full, rank, world)
+        global_clusters = full.num_clusters
 
     eng = eng_mod.Engine(local_rank)
     prepared = eng.prepare(batch)  # upload: inputs are resident in HBM before the timed region
@@ -138,16 +148,12 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     mass_ok = all(abs(e.abundances.sum() + e.noise_count - e.total_count) <= 1e-6 * max(1.0, e.total_count) for e in est)
     gathered = None
     if dist is not None:
-        flat = np.concatenate([e.abundances for e in est]) if est else np.zeros(0)
-        n_local = torch.tensor([flat.size], dtype=torch.int64, device="cuda")
-        sizes = [torch.zeros_like(n_local) for _ in range(world)]
-        dist.all_gather(sizes, n_local)
-        n_max = int(max(int(s.item()) for s in sizes))
-        buf = torch.zeros(n_max, dtype=torch.float64, device="cuda")
-        buf[:flat.size] = torch.from_numpy(flat).cuda()
-        out = [torch.zeros_like(buf) for _ in range(world)]
-        dist.all_gather(out, buf)
-        gathered = float(sum(float(o[:int(s.item())].sum().item()) for o, s in zip(out, sizes)))
+        if args.scaling == "strong":
+            per_cluster = rdist.gather_cluster_values([e.abundances for e in est], my_clusters, global_clusters, dist, "cuda")
+            gathered = float(sum(float(v.sum()) for v in per_cluster))
+        else:
+            flat = np.concatenate([e.abundances for e in est]) if est else np.zeros(0)
+            gathered = float(sum(float(v.sum()) for v in rdist.all_gather_ragged(flat, dist, "cuda")))
 
     if rank != 0:
         return None
@@ -168,7 +174,8 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         loglik_evals_per_step=stats["loglik_evals"] / args.steps)
     line = dict(
         metric="read-pairs quantified/sec", value=value, unit="read-pairs/s", n_gpus=world, steps=args.steps,
-        warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
+        warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
+        scaling=("strong" if (args.scaling == "strong" and world > 1) else "weak"), vs_baseline=None,
         dtype="f64", data="synthetic",
         config=dict(workload=f"synthetic pantranscriptome: {total_reads} read pairs x {total_paths} paths in {K} clusters per GPU "
                              f"(BASELINE.json configs[2]), -i {args.model}, reference defaults",

@@ -499,6 +499,75 @@ void * rpvg_amd_synth_generate(const rpvg_synth_config * config_in) {
     return batch;
 }
 
+// Builds ONE cluster from raw reads: read r has count read_count[r], noise read_noise[r] and the per-path
+// likelihoods (lik_path, lik_value)[lik_off[r] .. lik_off[r+1]); each read is finished like
+// ReadPathProbabilities::addPathProbs finishes a row, then the rows are sorted and merged like the
+// caller does (src/main.cpp:953-973).  Harness hook for testing the row type; same handle type as
+// rpvg_amd_synth_generate().
+void * rpvg_amd_rows_from_likelihoods(uint32_t num_paths, uint32_t num_reads, const uint32_t * read_count, const double * read_noise, const uint64_t * lik_off, const uint32_t * lik_path, const double * lik_value, double prob_precision) {
+
+    std::vector<ReadPathProbabilities> rows;
+    std::vector<std::pair<uint32_t, double> > likelihoods;
+
+    for (uint32_t r = 0; r < num_reads; ++r) {
+
+        likelihoods.clear();
+
+        for (uint64_t i = lik_off[r]; i < lik_off[r + 1]; ++i) {
+
+            likelihoods.emplace_back(lik_path[i], lik_value[i]);
+        }
+
+        if (likelihoods.empty()) {
+
+            rows.emplace_back(read_count[r], 1.0, ReadPathProbabilities::PathProbs(), prob_precision);
+
+        } else {
+
+            rows.emplace_back(ReadPathProbabilities::fromPathLikelihoods(read_count[r], read_noise[r], likelihoods, prob_precision));
+        }
+    }
+
+    sortAndMergeReadPathProbabilities(&rows);
+
+    SynthBatch * batch = new SynthBatch();
+
+    batch->cluster_row_off.push_back(0);
+    batch->cluster_path_off.push_back(0);
+    batch->row_grp_off.push_back(0);
+    batch->grp_idx_off.push_back(0);
+    batch->path_source_off.push_back(0);
+
+    for (uint32_t p = 0; p < num_paths; ++p) {
+
+        batch->path_group_id.push_back(0);
+        batch->path_source_count.push_back(1);
+        batch->path_source_off.push_back(0);
+        batch->path_effective_length.push_back(0);
+    }
+
+    batch->cluster_path_off.push_back(num_paths);
+
+    for (auto & row: rows) {
+
+        batch->row_count.push_back(row.readCount());
+        batch->row_noise.push_back(row.noiseProb());
+
+        for (auto & path_probs: row.pathProbs()) {
+
+            batch->grp_prob.push_back(path_probs.first);
+            batch->path_idx.insert(batch->path_idx.end(), path_probs.second.begin(), path_probs.second.end());
+            batch->grp_idx_off.push_back(batch->path_idx.size());
+        }
+
+        batch->row_grp_off.push_back(batch->grp_prob.size());
+    }
+
+    batch->cluster_row_off.push_back(batch->row_count.size());
+
+    return batch;
+}
+
 void rpvg_amd_synth_view(void * handle, rpvg_cluster_batch * out) {
 
     SynthBatch * batch = static_cast<SynthBatch *>(handle);

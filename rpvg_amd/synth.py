@@ -22,8 +22,7 @@ class CSynthConfig(C.Structure):
 FULL = dict(seed=3, num_clusters=5000, total_paths=200000, total_reads=10000000)
 
 
-def generate(seed: int = 3, num_clusters: int = 5000, total_paths: int = 200000, total_reads: int = 10000000,
-             **overrides) -> ClusterBatch:
+def _bind():
     L = _engine.lib()
     L.rpvg_amd_synth_default_config.restype = CSynthConfig
     L.rpvg_amd_synth_generate.restype = C.c_void_p
@@ -31,6 +30,60 @@ def generate(seed: int = 3, num_clusters: int = 5000, total_paths: int = 200000,
     L.rpvg_amd_synth_view.argtypes = [C.c_void_p, C.POINTER(CClusterBatch)]
     L.rpvg_amd_synth_sizes.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 5
     L.rpvg_amd_synth_free.argtypes = [C.c_void_p]
+    L.rpvg_amd_rows_from_likelihoods.restype = C.c_void_p
+    L.rpvg_amd_rows_from_likelihoods.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_double]
+    return L
+
+
+def _to_batch(L, h) -> ClusterBatch:
+    view = CClusterBatch()
+    L.rpvg_amd_synth_view(h, C.byref(view))
+    sizes = [C.c_uint64(0) for _ in range(5)]
+    L.rpvg_amd_synth_sizes(h, *[C.byref(s) for s in sizes])
+    R, G, NNZ, P, S = (int(s.value) for s in sizes)
+    K = view.num_clusters
+
+    def arr(ptr, n, dt):
+        if n == 0:
+            return np.zeros(0, dtype=dt)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+
+    return ClusterBatch(
+        arr(view.cluster_row_off, K + 1, np.uint64), arr(view.cluster_path_off, K + 1, np.uint64),
+        arr(view.row_count, R, np.uint32), arr(view.row_noise, R, np.float64), arr(view.row_grp_off, R + 1, np.uint64),
+        arr(view.grp_prob, G, np.float64), arr(view.grp_idx_off, G + 1, np.uint64), arr(view.path_idx, NNZ, np.uint32),
+        arr(view.path_group_id, P, np.uint32), arr(view.path_source_count, P, np.uint32),
+        arr(view.path_source_off, P + 1, np.uint64), arr(view.source_id, S, np.uint32),
+        arr(view.path_effective_length, P, np.float64))
+
+
+def rows_from_likelihoods(num_paths: int, reads, prob_precision: float = 1e-8) -> ClusterBatch:
+    """reads: [(count, noise, {path: likelihood})...] -> one cluster of finished, sorted, merged rows
+    (C++ ReadPathProbabilities::fromPathLikelihoods + sortAndMergeReadPathProbabilities)."""
+    L = _bind()
+    cnt = np.ascontiguousarray([r[0] for r in reads], dtype=np.uint32)
+    noise = np.ascontiguousarray([r[1] for r in reads], dtype=np.float64)
+    off, paths, vals = [0], [], []
+    for r in reads:
+        for p in sorted(r[2]):
+            paths.append(p)
+            vals.append(r[2][p])
+        off.append(len(paths))
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    paths = np.ascontiguousarray(paths, dtype=np.uint32)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    h = L.rpvg_amd_rows_from_likelihoods(num_paths, len(reads), cnt.ctypes.data, noise.ctypes.data, off.ctypes.data,
+                                         paths.ctypes.data, vals.ctypes.data, prob_precision)
+    try:
+        return _to_batch(L, h)
+    finally:
+        L.rpvg_amd_synth_free(h)
+
+
+def generate(seed: int = 3, num_clusters: int = 5000, total_paths: int = 200000, total_reads: int = 10000000,
+             **overrides) -> ClusterBatch:
+    L = _bind()
     cfg = L.rpvg_amd_synth_default_config()
     cfg.seed, cfg.num_clusters, cfg.total_paths, cfg.total_reads = seed, num_clusters, total_paths, total_reads
     for k, v in overrides.items():
@@ -39,24 +92,6 @@ def generate(seed: int = 3, num_clusters: int = 5000, total_paths: int = 200000,
         setattr(cfg, k, v)
     h = L.rpvg_amd_synth_generate(C.byref(cfg))
     try:
-        view = CClusterBatch()
-        L.rpvg_amd_synth_view(h, C.byref(view))
-        sizes = [C.c_uint64(0) for _ in range(5)]
-        L.rpvg_amd_synth_sizes(h, *[C.byref(s) for s in sizes])
-        R, G, NNZ, P, S = (int(s.value) for s in sizes)
-        K = view.num_clusters
-
-        def arr(ptr, n, dt):
-            if n == 0:
-                return np.zeros(0, dtype=dt)
-            return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
-
-        return ClusterBatch(
-            arr(view.cluster_row_off, K + 1, np.uint64), arr(view.cluster_path_off, K + 1, np.uint64),
-            arr(view.row_count, R, np.uint32), arr(view.row_noise, R, np.float64), arr(view.row_grp_off, R + 1, np.uint64),
-            arr(view.grp_prob, G, np.float64), arr(view.grp_idx_off, G + 1, np.uint64), arr(view.path_idx, NNZ, np.uint32),
-            arr(view.path_group_id, P, np.uint32), arr(view.path_source_count, P, np.uint32),
-            arr(view.path_source_off, P + 1, np.uint64), arr(view.source_id, S, np.uint32),
-            arr(view.path_effective_length, P, np.float64))
+        return _to_batch(L, h)
     finally:
         L.rpvg_amd_synth_free(h)
