@@ -126,7 +126,9 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         global_clusters = full.num_clusters
 
     eng = eng_mod.Engine(local_rank)
+    t_up = time.perf_counter()
     prepared = eng.prepare(batch)  # upload: inputs are resident in HBM before the timed region
+    upload_ms = (time.perf_counter() - t_up) * 1e3
     for _ in range(args.warmup):
         eng.run_raw(args.model, params, prepared)
     eng.reset_stats()
@@ -181,7 +183,8 @@ def run_s3(args, rank, local_rank, world, dist, torch):
                              f"(BASELINE.json configs[2]), -i {args.model}, reference defaults",
                     clusters_per_gpu=K, rows_per_gpu=batch.num_rows, entries_per_gpu=int(len(batch.path_idx)),
                     parallelism=f"clusters sharded, {world} rank(s), final abundance gather over RCCL"),
-        roofline=roofline, kernels=kernels, mass_conserved=bool(mass_ok))
+        roofline=roofline, kernels=kernels, mass_conserved=bool(mass_ok),
+        upload_ms=upload_ms, value_including_upload=float(batch.total_reads) / ((ms_per_step + upload_ms) / 1e3) * world)
     if gathered is not None:
         line["gathered_abundance_mass"] = gathered
     if not args.no_cpu_baseline:
