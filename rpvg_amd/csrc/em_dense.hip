@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 using namespace rpvg_hip_detail;
 
@@ -42,6 +43,14 @@ struct DenseControl {
     uint32_t conv_its;
     uint32_t viol;  // OR of per-column convergence violations of the current iteration
 };
+
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+
+// streaming 16-byte load (no reuse: keep it out of the way of the cached vectors)
+__device__ __forceinline__ double2 loadStream(const double * p) {
+    const dvec2 x = __builtin_nontemporal_load(reinterpret_cast<const dvec2 *>(p));
+    return make_double2(x.x, x.y);
+}
 
 __device__ __forceinline__ double waveReduceSumD(double v) {
 #pragma unroll
@@ -117,6 +126,111 @@ __global__ __launch_bounds__(kAccumBlock) void emDenseAccumKernel(
         for (int w = 1; w < kAccumBlock / 64; ++w) acc += t_lds[w][j];
         out[j] = acc;
     }
+}
+
+
+// ---- wide matrices: one row split across the 4 waves of a block ------------------
+//
+// For C > 256 a whole row per wave needs too many registers (223 VGPRs at C = 2001:
+// two waves per SIMD, not enough loads in flight to cover HBM latency).  Here wave w of a
+// block owns columns [512w, 512w + 512) (NCHUNK <= 4 chunks of 128 columns), the block
+// walks its rows two at a time: every wave loads its quarter of both rows, reduces its
+// partial s_i, the four partials meet in LDS behind ONE barrier, and every wave updates
+// the t_j of its own columns — so the accumulators never need a cross-wave reduction.
+template <int NCHUNK>
+__global__ __launch_bounds__(256) void emDenseAccumWideKernel(
+    const double * __restrict__ P, const uint64_t R, const uint32_t C, const uint64_t ld,
+    const double * __restrict__ counts, const double * __restrict__ a_global, double * __restrict__ partials,
+    const uint32_t partial_ld, const DenseControl * __restrict__ ctl) {
+    if (ctl->done) return;
+    constexpr int ROWS = 2;
+    __shared__ double s_part[2][ROWS][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t col_base = wave * (NCHUNK * 128) + 2 * lane;
+
+    double a[NCHUNK][2], t[NCHUNK][2];
+#pragma unroll
+    for (int m = 0; m < NCHUNK; ++m) {
+        const uint32_t c0 = col_base + 128 * m;
+        a[m][0] = (c0 < C) ? a_global[c0] : 0.0;
+        a[m][1] = (c0 + 1 < C) ? a_global[c0 + 1] : 0.0;
+        t[m][0] = 0.0;
+        t[m][1] = 0.0;
+    }
+
+    const uint64_t row_stride = static_cast<uint64_t>(gridDim.x) * ROWS;
+    int parity = 0;
+    for (uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * ROWS; r0 < R; r0 += row_stride, parity ^= 1) {
+        double2 v[ROWS][NCHUNK];
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) {
+            const uint64_t r = r0 + q;
+            const double * row = P + (r < R ? r : r0) * ld;
+#pragma unroll
+            for (int m = 0; m < NCHUNK; ++m) {
+                const uint32_t c0 = col_base + 128 * m;
+                if (c0 + 1 < ld) {
+                    v[q][m] = loadStream(row + c0);
+                } else {
+                    v[q][m].x = (c0 < ld) ? P[(r < R ? r : r0) * ld + c0] : 0.0;
+                    v[q][m].y = 0.0;
+                }
+                if (c0 >= C || r >= R) v[q][m].x = 0.0;
+                if (c0 + 1 >= C || r >= R) v[q][m].y = 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) {
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < NCHUNK; ++m) {
+                s = fma(v[q][m].x, a[m][0], s);
+                s = fma(v[q][m].y, a[m][1], s);
+            }
+            s = waveReduceSumD(s);
+            if (lane == 0) s_part[parity][q][wave] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) {
+            const uint64_t r = r0 + q;
+            if (r < R) {
+                const double s = ((s_part[parity][q][0] + s_part[parity][q][1]) + s_part[parity][q][2]) + s_part[parity][q][3];
+                const double w = counts[r] / s;
+#pragma unroll
+                for (int m = 0; m < NCHUNK; ++m) {
+                    t[m][0] = fma(w, v[q][m].x, t[m][0]);
+                    t[m][1] = fma(w, v[q][m].y, t[m][1]);
+                }
+            }
+        }
+    }
+
+    double * out = partials + static_cast<uint64_t>(blockIdx.x) * partial_ld;
+#pragma unroll
+    for (int m = 0; m < NCHUNK; ++m) {
+        const uint32_t c0 = col_base + 128 * m;
+        if (c0 + 1 < partial_ld) {
+            *reinterpret_cast<double2 *>(out + c0) = make_double2(t[m][0], t[m][1]);
+        } else if (c0 < partial_ld) {
+            out[c0] = t[m][0];
+        }
+    }
+}
+
+// first finalize stage for many partial vectors: slice y of the partials -> one vector per slice
+__global__ void emDenseReducePartialsKernel(const uint32_t C, const uint32_t num_partials, const uint32_t partial_ld,
+                                            const double * __restrict__ partials, double * __restrict__ reduced,
+                                            const DenseControl * __restrict__ ctl) {
+    if (ctl->done) return;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= C) return;
+    const uint32_t slices = gridDim.y;
+    const uint32_t b0 = static_cast<uint32_t>(static_cast<uint64_t>(num_partials) * blockIdx.y / slices);
+    const uint32_t b1 = static_cast<uint32_t>(static_cast<uint64_t>(num_partials) * (blockIdx.y + 1) / slices);
+    double acc = 0.0;
+    for (uint32_t b = b0; b < b1; ++b) acc += partials[static_cast<uint64_t>(b) * partial_ld + j];
+    reduced[static_cast<uint64_t>(blockIdx.y) * partial_ld + j] = acc;
 }
 
 __global__ void emDenseFinalizeKernel(const uint32_t C, const uint32_t num_partials, const uint32_t partial_ld,
@@ -267,12 +381,18 @@ extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matri
     const uint32_t C = num_cols;
 
     const uint32_t cus = ctx->props.multiProcessorCount;
+    const bool wide = C > 256;  // row split over the block's waves (emDenseAccumWideKernel)
     // enough waves to cover HBM latency, few enough partial vectors to reduce cheaply
-    uint32_t grid = std::min<uint64_t>((num_rows + 3) / 4, static_cast<uint64_t>(cus) * 2);
+    uint32_t blocks_per_cu = wide ? 4 : 2;
+    if (const char * env = std::getenv("RPVG_HIP_DENSE_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::atoi(env));
+    uint32_t grid = wide ? std::min<uint64_t>((num_rows + 1) / 2, static_cast<uint64_t>(cus) * blocks_per_cu)
+                         : std::min<uint64_t>((num_rows + 3) / 4, static_cast<uint64_t>(cus) * blocks_per_cu);
     grid = std::max<uint32_t>(grid, 1);
-    const uint32_t partial_ld = (C + 1) & ~1u;
+    const uint32_t partial_ld = wide ? ((C + 511) / 512) * 512 : ((C + 1) & ~1u);
+    const uint32_t reduce_slices = 16;
 
-    DeviceBuffer<double> d_a, d_partials;
+    DeviceBuffer<double> d_a, d_partials, d_reduced;
+    if (wide) RPVG_HIP_CHECK(d_reduced.alloc(static_cast<size_t>(reduce_slices) * partial_ld));
     DeviceBuffer<DenseControl> d_ctl;
     RPVG_HIP_CHECK(d_a.alloc(C));
     RPVG_HIP_CHECK(d_partials.alloc(static_cast<size_t>(grid) * partial_ld));
@@ -291,6 +411,18 @@ extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matri
     while (!h_ctl.done) {
         const uint32_t n = std::min<uint32_t>(chunk_its, max_em_its - queued);
         for (uint32_t i = 0; i < n; ++i) {
+            if (wide) {
+                const int wchunk = (C + 511) / 512;
+                if (wchunk <= 1) emDenseAccumWideKernel<1><<<dim3(grid), dim3(256), 0, st>>>(device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
+                else if (wchunk <= 2) emDenseAccumWideKernel<2><<<dim3(grid), dim3(256), 0, st>>>(device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
+                else if (wchunk <= 3) emDenseAccumWideKernel<3><<<dim3(grid), dim3(256), 0, st>>>(device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
+                else emDenseAccumWideKernel<4><<<dim3(grid), dim3(256), 0, st>>>(device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
+                emDenseReducePartialsKernel<<<dim3((C + 255) / 256, reduce_slices), dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_reduced.ptr, d_ctl.ptr);
+                emDenseFinalizeKernel<<<dim3((C + 255) / 256), dim3(256), 0, st>>>(C, reduce_slices, partial_ld, d_reduced.ptr, d_a.ptr,
+                                                                               total_count, max_rel_em_conv, d_ctl.ptr);
+                emDenseControlKernel<<<dim3(1), dim3(1), 0, st>>>(d_ctl.ptr, max_em_its);
+                continue;
+            }
             if (nchunk <= 1) launchAccum<1>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
             else if (nchunk <= 2) launchAccum<2>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
             else if (nchunk <= 4) launchAccum<4>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
