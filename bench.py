@@ -217,18 +217,25 @@ def run_c2(args, rank, local_rank, world, dist, torch):
     reads_all = sum_over_ranks(float(R), dist, torch)
     if rank != 0:
         return None
-    it_ms = stats["em_dense_ms"] / max(1, stats["em_dense_launches"])
+    it_ms = stats["em_dense_ms"] / max(1, stats["em_dense_launches"])  # HIP events around the streaming-pass launches
     it_bytes = stats["em_dense_alg_bytes"] / max(1, stats["em_dense_launches"])
     achieved = (it_bytes / 1e9) / (it_ms / 1e3)
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_c2.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        if pmc["shape"]["rows"] == R and pmc["shape"]["cols"] == Cn:
+            traffic = pmc["traffic_bytes_per_launch"]  # separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE)
     line = dict(
         metric="read-pairs quantified/sec", value=reads_all / (elapsed / args.steps), unit="read-pairs/s", n_gpus=world,
         steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
         scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
         config=dict(workload=f"single dense cluster {R} read pairs x {N} paths (BASELINE.json configs[1]), -i transcripts EM, "
                              f"fixed budget of {its} EM iterations per step", parallelism=f"replicas only, {world} rank(s)"),
-        roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
-                      kernel="emDenseAccumKernel", ms_per_iteration=it_ms,
-                      note="per EM iteration: 8*R*C (matrix, read once) + 8*R (counts) + 16*C bytes; includes the finalize/control launches"),
+        roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                      kernel="emDenseAccumWideKernel", ms_per_launch=it_ms, algorithmic_bytes_per_launch=it_bytes,
+                      note="one launch = one EM iteration's streaming pass: 8*R*C (matrix, read once) + 8*R (counts) + 16*C bytes; "
+                           "traffic = HBM bytes per launch from rocprofv3 PMC passes (profiles/pmc_traffic_c2.json)"),
         em_iterations_per_step=its, mass_conserved=bool(abs(ab.sum() + noise - R) <= 1e-6 * R))
     if not args.no_cpu_baseline:
         # reference-shaped CPU EM on a row sample of the same matrix, one core (a single cluster is serial

@@ -33,11 +33,7 @@ namespace {
 
 constexpr uint32_t kLdsRows = 2048;  // rows of (base, count) staged in LDS: 32 KB
 
-__device__ __forceinline__ double waveSum(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
+__device__ __forceinline__ double waveSum(double v) { return waveSumF64(v); }
 
 // Utils::add_log (src/utils.hpp:300-302)
 __device__ __forceinline__ double addLog(const double log_x, const double log_y) {

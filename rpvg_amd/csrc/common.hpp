@@ -94,6 +94,35 @@ struct HostScope {
     }
 };
 
+// ---- wave-level FP64 sum on the DPP network -------------------------------------
+// __shfl_xor on a double lowers to two ds_bpermute_b32 per step (LDS crossbar, ~100 cycles of dependent
+// latency each, 6 steps).  DPP moves stay in the SIMD: quad_perm x2, row_half_mirror, row_mirror give
+// every lane the sum of its row of 16; the four row sums are then read with v_readlane and added.
+// The result is uniform across the wave.  Summation order is fixed (deterministic).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL>
+__device__ __forceinline__ double dppAddF64(const double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return v + __hiloint2double(hi2, lo2);
+}
+
+__device__ __forceinline__ double readLaneF64(const double v, const int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+__device__ __forceinline__ double waveSumF64(double v) {
+    v = dppAddF64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dppAddF64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dppAddF64<0x141>(v);  // row_half_mirror
+    v = dppAddF64<0x140>(v);  // row_mirror
+    return (readLaneF64(v, 0) + readLaneF64(v, 16)) + (readLaneF64(v, 32) + readLaneF64(v, 48));
+}
+#else
+__device__ double waveSumF64(double v);  // host compilation pass: declaration only
+#endif
+
 // ---- kernel-family timing ---------------------------------------------------
 enum KernelFamily { FAM_EM_SPARSE = 0, FAM_EM_DENSE, FAM_LOGLIK, FAM_BUILD, FAM_H2D, FAM_COUNT };
 

@@ -52,11 +52,7 @@ __device__ __forceinline__ double2 loadStream(const double * p) {
     return make_double2(x.x, x.y);
 }
 
-__device__ __forceinline__ double waveReduceSumD(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
+__device__ __forceinline__ double waveReduceSumD(double v) { return waveSumF64(v); }
 
 // One streaming pass.  NCHUNK = ceil(C / 128): the wave holds a whole row in
 // registers (2*NCHUNK doubles per lane).
@@ -407,16 +403,18 @@ extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matri
     DenseControl h_ctl = {0, 0, 0, 0};
     uint32_t queued = 0;
     uint64_t accum_launches = 0;
-    const int span = ctx->spanBegin(FAM_EM_DENSE);
+    // em_dense_ms (rpvg_hip_kernel_stats) = HIP-event time of the streaming-pass launches only
     while (!h_ctl.done) {
         const uint32_t n = std::min<uint32_t>(chunk_its, max_em_its - queued);
         for (uint32_t i = 0; i < n; ++i) {
+            const int span = ctx->spanBegin(FAM_EM_DENSE);
             if (wide) {
                 const int wchunk = (C + 511) / 512;
                 if (wchunk <= 1) emDenseAccumWideKernel<1><<<dim3(grid), dim3(256), 0, st>>>(device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
                 else if (wchunk <= 2) emDenseAccumWideKernel<2><<<dim3(grid), dim3(256), 0, st>>>(device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
                 else if (wchunk <= 3) emDenseAccumWideKernel<3><<<dim3(grid), dim3(256), 0, st>>>(device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
                 else emDenseAccumWideKernel<4><<<dim3(grid), dim3(256), 0, st>>>(device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
+                ctx->spanEnd(span);
                 emDenseReducePartialsKernel<<<dim3((C + 255) / 256, reduce_slices), dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_reduced.ptr, d_ctl.ptr);
                 emDenseFinalizeKernel<<<dim3((C + 255) / 256), dim3(256), 0, st>>>(C, reduce_slices, partial_ld, d_reduced.ptr, d_a.ptr,
                                                                                total_count, max_rel_em_conv, d_ctl.ptr);
@@ -428,6 +426,7 @@ extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matri
             else if (nchunk <= 4) launchAccum<4>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
             else if (nchunk <= 8) launchAccum<8>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
             else launchAccum<16>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
+            ctx->spanEnd(span);
             emDenseFinalizeKernel<<<dim3((C + 255) / 256), dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_a.ptr,
                                                                            total_count, max_rel_em_conv, d_ctl.ptr);
             emDenseControlKernel<<<dim3(1), dim3(1), 0, st>>>(d_ctl.ptr, max_em_its);
@@ -438,7 +437,6 @@ extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matri
         RPVG_HIP_CHECK(hipMemcpyAsync(&h_ctl, d_ctl.ptr, sizeof(DenseControl), hipMemcpyDeviceToHost, st));
         RPVG_HIP_CHECK(hipStreamSynchronize(st));
     }
-    ctx->spanEnd(span);
 
     std::vector<double> a(C);
     RPVG_HIP_CHECK(hipMemcpyAsync(a.data(), d_a.ptr, sizeof(double) * C, hipMemcpyDeviceToHost, st));

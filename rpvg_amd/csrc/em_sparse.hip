@@ -50,6 +50,11 @@ __device__ __forceinline__ T waveReduceSum(T v) {
     return v;
 }
 
+template <>
+__device__ __forceinline__ double waveReduceSum<double>(double v) {
+    return waveSumF64(v);
+}
+
 // Sum over the block, result in every thread.  scratch: BLOCK/64 elements.
 template <typename T, int BLOCK>
 __device__ __forceinline__ T blockReduceSum(T v, T * scratch) {
@@ -254,7 +259,10 @@ struct EmLaunchArgs {
     uint32_t * iterations;         // [P]
 };
 
-template <int BLOCK>
+// RESIDENT: the problem's compacted CSR is copied into LDS once and every EM iteration runs out of LDS
+// (small problems need up to thousands of iterations; from L2 each costs ~1.7 us of dependent-load
+// latency, from LDS a fraction of that).
+template <int BLOCK, bool RESIDENT>
 __global__ __launch_bounds__(BLOCK) void emSparseKernel(const EmLaunchArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     if (blockIdx.x >= args.count) return;
@@ -271,6 +279,28 @@ __global__ __launch_bounds__(BLOCK) void emSparseKernel(const EmLaunchArgs args)
     const double * nzv = args.prow_noise + rb;
     const uint32_t * col = args.pent_col + eb;
     const double * val = args.pent_val + eb;
+    if (RESIDENT) {
+        const uint32_t n_ent = off[n_rows];
+        double * l_cnt = red + (BLOCK / 64 + 2);
+        double * l_nz = l_cnt + n_rows;
+        double * l_val = l_nz + n_rows;
+        uint32_t * l_off = reinterpret_cast<uint32_t *>(l_val + n_ent);
+        uint32_t * l_col = l_off + (n_rows + 1);
+        for (uint32_t r = threadIdx.x; r < n_rows; r += BLOCK) {
+            l_cnt[r] = cnt[r];
+            l_nz[r] = nzv[r];
+        }
+        for (uint32_t r = threadIdx.x; r <= n_rows; r += BLOCK) l_off[r] = off[r];
+        for (uint32_t e = threadIdx.x; e < n_ent; e += BLOCK) {
+            l_val[e] = val[e];
+            l_col[e] = col[e];
+        }
+        off = l_off;
+        cnt = l_cnt;
+        nzv = l_nz;
+        col = l_col;
+        val = l_val;
+    }
     const double T = args.total_mass[p];
     const double Z = args.zero_mass[p];
     const double eps = args.max_rel_em_conv;
@@ -280,10 +310,11 @@ __global__ __launch_bounds__(BLOCK) void emSparseKernel(const EmLaunchArgs args)
     const double a0 = static_cast<double>(1.0f / static_cast<float>(C));
     for (uint32_t j = threadIdx.x; j < C; j += BLOCK) a[j] = a0;
 
+    for (uint32_t j = threadIdx.x; j < C; j += BLOCK) t[j] = 0;
+    __syncthreads();  // a[], t[] and (when resident) the problem's CSR are in LDS
+
     uint32_t iters = 0, conv = 0;
     for (uint32_t it = 0; it < args.max_em_its; ++it) {
-        for (uint32_t j = threadIdx.x; j < C; j += BLOCK) t[j] = 0;
-        __syncthreads();
         const double a_noise = a[noise_col];
         double tn = 0;
         for (uint32_t r = threadIdx.x; r < n_rows; r += BLOCK) {
@@ -296,15 +327,23 @@ __global__ __launch_bounds__(BLOCK) void emSparseKernel(const EmLaunchArgs args)
             tn += w * nz;
         }
         tn = blockReduceSum<double, BLOCK>(tn, red);
-        __syncthreads();  // all atomics to t[] done
+        __syncthreads();  // all atomics to t[] done, all reads of a[] done
         int viol = 0;
         for (uint32_t j = threadIdx.x; j < C; j += BLOCK) {
             const double aj = a[j];
             const double an = (j == noise_col) ? (aj * tn + Z) / T : (aj * t[j]) / T;
-            if (an >= kMinEmAbundance && fabs(an - aj) / an > eps) viol = 1;
+            // |an - aj| / an > eps  (src/path_abundance_estimator.cpp:73-75), without the division
+            if (an >= kMinEmAbundance && fabs(an - aj) > eps * an) viol = 1;
             a[j] = an;
+            t[j] = 0;
         }
-        const int any_viol = __syncthreads_or(viol);
+        int any_viol;
+        if (BLOCK == 64) {
+            any_viol = __any(viol);
+            __syncthreads();
+        } else {
+            any_viol = __syncthreads_or(viol);
+        }
         ++iters;
         if (!any_viol) {
             if (++conv == kMinEmConvIts) break;
@@ -332,16 +371,22 @@ __global__ __launch_bounds__(BLOCK) void emSparseKernel(const EmLaunchArgs args)
     }
 }
 
-template <int BLOCK>
-hipError_t launchEm(const EmLaunchArgs & args, uint32_t max_cols, hipStream_t stream) {
+// LDS bytes of a problem: abundance + accumulator vectors and scratch, plus its CSR when resident
+size_t emLdsBytes(uint32_t cols, uint32_t rows, uint32_t entries, int block, bool resident) {
+    size_t bytes = sizeof(double) * (2 * static_cast<size_t>(cols) + block / 64 + 2);
+    if (resident) bytes += static_cast<size_t>(rows) * 16 + static_cast<size_t>(entries) * 8 + (static_cast<size_t>(rows) + 1 + entries) * 4 + 8;
+    return (bytes + 15) & ~static_cast<size_t>(15);
+}
+
+template <int BLOCK, bool RESIDENT>
+hipError_t launchEm(const EmLaunchArgs & args, size_t lds, hipStream_t stream) {
     if (args.count == 0) return hipSuccess;
-    const size_t lds = sizeof(double) * (2 * static_cast<size_t>(max_cols) + BLOCK / 64 + 2);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&emSparseKernel<BLOCK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&emSparseKernel<BLOCK, RESIDENT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
     }
-    emSparseKernel<BLOCK><<<dim3(args.count), dim3(BLOCK), lds, stream>>>(args);
+    emSparseKernel<BLOCK, RESIDENT><<<dim3(args.count), dim3(BLOCK), lds, stream>>>(args);
     return hipGetLastError();
 }
 
@@ -380,7 +425,7 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
         max_cols_all = std::max<uint32_t>(max_cols_all, static_cast<uint32_t>(c1 - c0) + 1);
     }
     const uint64_t n_cols_total = problems->col_off[P];
-    RPVG_REQUIRE(sizeof(double) * (2 * static_cast<size_t>(max_cols_all) + 8) <= 160 * 1024,
+    RPVG_REQUIRE(sizeof(double) * (2 * static_cast<size_t>(max_cols_all) + 24) <= 160 * 1024,
                  "rpvg_hip_em_solve: a problem with %u columns does not fit the LDS-resident abundance vector", max_cols_all);
 
     scope.reset(new HostScope("em_solve: colmap + count + download"));
@@ -433,30 +478,38 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
         rows_total += kept_rows[p];
         ent_total += kept_ent[p];
     }
-    // Size bins: a wave per problem for small problems, 256 threads for
-    // medium ones, 1024 for the few giant ones.  Inside a bin the expensive
-    // problems go first (the reference sorts clusters the same way before its
-    // dynamic OpenMP schedule, src/main.cpp:811-829).
-    std::vector<uint32_t> bins[3];
-    uint32_t bin_cols[3] = {0, 0, 0};
+    // Size bins (inside a bin the expensive problems go first, as the reference orders clusters before
+    // its dynamic OpenMP schedule, src/main.cpp:811-829):
+    //   0  LDS-resident, one wave      CSR + vectors fit 8 KB
+    //   1  LDS-resident, four waves    fit 40 KB
+    //   2  streamed from L2, 4 waves
+    //   3  streamed from L2, 16 waves  (a few giant problems)
+    constexpr int kBins = 4;
+    std::vector<uint32_t> bins[kBins];
+    size_t bin_lds[kBins] = {0, 0, 0, 0};
     for (uint32_t p = 0; p < P; ++p) {
         const uint32_t C = static_cast<uint32_t>(problems->col_off[p + 1] - problems->col_off[p]) + 1;
         const uint64_t work = static_cast<uint64_t>(kept_ent[p]) + kept_rows[p];
         int b;
-        if (work <= 1536 && C <= 256) {
+        size_t lds;
+        if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 64, true)) <= 8 * 1024) {
             b = 0;
-        } else if (work <= 262144) {
+        } else if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 256, true)) <= 40 * 1024) {
             b = 1;
-        } else {
+        } else if (work <= 262144) {
             b = 2;
+            lds = emLdsBytes(C, 0, 0, 256, false);
+        } else {
+            b = 3;
+            lds = emLdsBytes(C, 0, 0, 1024, false);
         }
         bins[b].push_back(p);
-        bin_cols[b] = std::max(bin_cols[b], C);
+        bin_lds[b] = std::max(bin_lds[b], lds);
     }
     std::vector<uint32_t> order;
     order.reserve(P);
-    uint32_t bin_start[3];
-    for (int b = 2; b >= 0; --b) {
+    uint32_t bin_start[kBins];
+    for (int b = kBins - 1; b >= 0; --b) {
         std::sort(bins[b].begin(), bins[b].end(), [&](uint32_t x, uint32_t y) {
             const uint64_t wx = static_cast<uint64_t>(kept_ent[x]) + kept_rows[x], wy = static_cast<uint64_t>(kept_ent[y]) + kept_rows[y];
             return wx != wy ? wx > wy : x < y;
@@ -465,7 +518,6 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
         order.insert(order.end(), bins[b].begin(), bins[b].end());
     }
 
-    scope.reset(new HostScope("em_solve: fill + EM kernels + download"));
     DeviceBuffer<uint64_t> d_row_base, d_ent_base;
     DeviceBuffer<uint32_t> d_order, d_prow_off, d_pent_col, d_iters;
     DeviceBuffer<double> d_prow_count, d_prow_noise, d_pent_val, d_abund, d_noise_count;
@@ -512,18 +564,21 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     args.iterations = d_iters.ptr;
 
     span = ctx->spanBegin(FAM_EM_SPARSE);
-    // giant problems first (they are the tail), then medium, then small
+    // giant problems first (they are the tail), then down to the small ones
+    args.order = d_order.ptr + bin_start[3];
+    args.count = bins[3].size();
+    RPVG_HIP_CHECK((launchEm<1024, false>(args, bin_lds[3], st)));
     args.order = d_order.ptr + bin_start[2];
     args.count = bins[2].size();
-    RPVG_HIP_CHECK(launchEm<1024>(args, bin_cols[2], st));
+    RPVG_HIP_CHECK((launchEm<256, false>(args, bin_lds[2], st)));
     args.order = d_order.ptr + bin_start[1];
     args.count = bins[1].size();
-    RPVG_HIP_CHECK(launchEm<256>(args, bin_cols[1], st));
+    RPVG_HIP_CHECK((launchEm<256, true>(args, bin_lds[1], st)));
     args.order = d_order.ptr + bin_start[0];
     args.count = bins[0].size();
-    RPVG_HIP_CHECK(launchEm<64>(args, bin_cols[0], st));
+    RPVG_HIP_CHECK((launchEm<64, true>(args, bin_lds[0], st)));
     ctx->spanEnd(span);
-    for (int b = 0; b < 3; ++b) ctx->stats.em_sparse_launches += bins[b].empty() ? 0 : 1;
+    for (int b = 0; b < kBins; ++b) ctx->stats.em_sparse_launches += bins[b].empty() ? 0 : 1;
 
     RPVG_HIP_CHECK(d_abund.download(results->abundances, st));
     RPVG_HIP_CHECK(d_noise_count.download(results->noise_count, st));

@@ -27,23 +27,25 @@ namespace {
 
 constexpr uint32_t kNoMember = 0xFFFFFFFFu;
 
-// block per matrix, threads stride the rows
+// one workgroup per (matrix, chunk of 256 rows), thread per row
 __global__ __launch_bounds__(256) void groupsBuildKernel(
-    const uint32_t num_matrices, const uint64_t * __restrict__ mat_val_off, const uint64_t * __restrict__ mat_row_off,
+    const uint32_t num_items, const uint32_t * __restrict__ item_matrix, const uint32_t * __restrict__ item_chunk,
+    const uint64_t * __restrict__ mat_val_off, const uint64_t * __restrict__ mat_row_off,
     const uint64_t * __restrict__ mat_row0, const uint64_t * __restrict__ mat_rows, const uint32_t * __restrict__ mat_cols,
     const uint64_t * __restrict__ mat_inc_off,   // [M] offset of the matrix's path->groups CSR offsets
     const uint64_t * __restrict__ path_grp_off,  // per matrix N_k+1 offsets (absolute into path_grp)
     const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
     const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
     const int normalise, double * __restrict__ values, double * __restrict__ rowmax) {
-    const uint32_t m = blockIdx.x;
-    if (m >= num_matrices) return;
+    if (blockIdx.x >= num_items) return;
+    const uint32_t m = item_matrix[blockIdx.x];
     const uint64_t R = mat_rows[m], r0 = mat_row0[m];
     const uint32_t G = mat_cols[m];
     double * M = values + mat_val_off[m];
     double * rm = rowmax + mat_row_off[m];
     const uint64_t * pgo = path_grp_off + mat_inc_off[m];
-    for (uint64_t i = threadIdx.x; i < R; i += blockDim.x) {
+    const uint64_t i = static_cast<uint64_t>(item_chunk[blockIdx.x]) * 256 + threadIdx.x;
+    if (i < R) {
         const uint64_t r = r0 + i;
         for (uint64_t e = row_ent_off[r]; e < row_ent_off[r + 1]; ++e) {
             const uint32_t p = ent_path[e];
@@ -103,8 +105,7 @@ __global__ __launch_bounds__(256) void groupLoglikKernel(
         if (rm) v += rm[i] / divisor;
         acc = fma(cnt[i], log(v), acc);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    acc = waveSumF64(acc);
     if (lane == 0) out[q] = acc;
 }
 
@@ -198,7 +199,14 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     hipError_t e = hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     DeviceBuffer<uint64_t> d_inc_off, d_path_grp_off;
-    DeviceBuffer<uint32_t> d_path_grp;
+    DeviceBuffer<uint32_t> d_path_grp, d_item_matrix, d_item_chunk;
+    std::vector<uint32_t> item_matrix, item_chunk;
+    for (uint32_t m = 0; m < M; ++m) {
+        for (uint64_t c = 0; c * 256 < rows[m]; ++c) {
+            item_matrix.push_back(m);
+            item_chunk.push_back(static_cast<uint32_t>(c));
+        }
+    }
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     int span = ctx->spanBegin(FAM_H2D);
     ok(g->mat_val_off.upload(val_off.data(), M, st));
@@ -209,6 +217,8 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     ok(d_inc_off.upload(inc_off.data(), M, st));
     ok(d_path_grp_off.upload(path_grp_off.data(), path_grp_off.size(), st));
     ok(d_path_grp.upload(path_grp.data(), path_grp.size(), st));
+    ok(d_item_matrix.upload(item_matrix.data(), item_matrix.size(), st));
+    ok(d_item_chunk.upload(item_chunk.data(), item_chunk.size(), st));
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(M * 44 + path_grp_off.size() * 8 + path_grp.size() * 4);
     ok(g->values.alloc(val_total));
@@ -216,7 +226,8 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     if (e == hipSuccess) {
         span = ctx->spanBegin(FAM_BUILD);
         ok(hipMemsetAsync(g->values.ptr, 0, val_total * sizeof(double), st));
-        groupsBuildKernel<<<dim3(M), dim3(256), 0, st>>>(M, g->mat_val_off.ptr, g->mat_row_off.ptr, g->mat_row0.ptr,
+        groupsBuildKernel<<<dim3(static_cast<uint32_t>(item_matrix.size())), dim3(256), 0, st>>>(
+            static_cast<uint32_t>(item_matrix.size()), d_item_matrix.ptr, d_item_chunk.ptr, g->mat_val_off.ptr, g->mat_row_off.ptr, g->mat_row0.ptr,
                                                        g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
                                                        d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr,
                                                        batch->ent_prob.ptr, batch->row_noise.ptr, spec->normalise ? 1 : 0,

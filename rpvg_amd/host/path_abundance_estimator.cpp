@@ -143,6 +143,8 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
 
     std::vector<uint32_t> clusters;
 
+    std::unique_ptr<ScopedPhase> reset_phase(new ScopedPhase("nested: resetEstimates"));
+
     for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
 
         assert(path_cluster_estimates->at(i).paths.size() == cluster_batch.numPaths(i));
@@ -153,6 +155,8 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
             clusters.emplace_back(i);
         }
     }
+
+    reset_phase.reset();
 
     std::vector<PathSubsetWeights> path_subset_samples(clusters.size());
 
@@ -183,13 +187,20 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
         std::vector<GroupPosteriors> group_posteriors;
         pathGroupPosteriors(&group_posteriors, cluster_batch, problems);
 
-        ScopedPhase select_phase("nested: selectPathSubsetIndices");
+        std::unique_ptr<ScopedPhase> select_phase(new ScopedPhase("nested: selectPathSubsetIndices"));
 
         #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
         for (size_t i = 0; i < clusters.size(); ++i) {
 
             selectPathSubsetIndices(&path_subset_samples.at(i), group_posteriors.at(i), problems.at(i));
         }
+
+        select_phase.reset();
+
+        ScopedPhase teardown_phase("nested: teardown posterior containers");
+
+        std::vector<GroupPosteriorProblem>().swap(problems);
+        std::vector<GroupPosteriors>().swap(group_posteriors);
 
     } else {
 
@@ -243,6 +254,9 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
     }
 
     inferPathSubsetAbundance(path_cluster_estimates, cluster_batch, clusters, path_subset_samples);
+
+    ScopedPhase teardown_phase("nested: teardown subset weights");
+    std::vector<PathSubsetWeights>().swap(path_subset_samples);
 }
 
 void NestedPathAbundanceEstimator::pathGroupPosteriors(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems) const {

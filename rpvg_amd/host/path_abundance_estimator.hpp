@@ -62,6 +62,8 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
         NestedPathAbundanceEstimator(const uint32_t group_size_in, const double min_hap_prob_in, const bool infer_collapsed_in, const bool use_group_post_gibbs_in, const uint32_t max_em_its, const double max_rel_em_conv, const uint32_t num_gibbs_samples, const uint32_t gibbs_thin_its, const double prob_precision, std::shared_ptr<HipEngine> engine);
         ~NestedPathAbundanceEstimator() {};
 
+        bool usesRandomNumbers() const { return !infer_collapsed; }
+
         void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs);
 
     private:

@@ -77,6 +77,7 @@ class GroupMatrices {
 
         ~GroupMatrices() {
 
+            ScopedPhase phase("posteriors: group matrices free");
             rpvg_hip_groups_free(engine->ctx(), groups);
         }
 
@@ -169,6 +170,12 @@ void PathEstimator::estimate(PathClusterEstimates * path_cluster_estimates, cons
 }
 
 void PathEstimator::estimateBatchSeeded(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const uint32_t rng_seed) {
+
+    if (!usesRandomNumbers()) {
+
+        estimateBatch(path_cluster_estimates, cluster_batch, nullptr);
+        return;
+    }
 
     std::vector<std::mt19937> rngs;
     rngs.reserve(cluster_batch.numClusters());
@@ -297,6 +304,8 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
         return;
     }
 
+    ScopedPhase whole_phase("posteriors: bounded total incl. teardown");
+
     const GroupMatrices matrices(engine, cluster_batch, problems, normalise);
 
     std::vector<uint32_t> column_counts;
@@ -335,6 +344,7 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
         }
     }
 
+    ScopedPhase free_phase("posteriors: pair result free");
     rpvg_hip_pair_posteriors_free(pair_posteriors);
 }
 

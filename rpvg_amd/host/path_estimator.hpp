@@ -77,6 +77,10 @@ class PathEstimator {
         // (rngs may be null for models that consume no random numbers).
         virtual void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs) = 0;
 
+        // Whether estimateBatch() draws random numbers with the current settings (the reference's default
+        // `transcripts`, `haplotype-transcripts` and `haplotypes` runs draw none: SURVEY.md F7).
+        virtual bool usesRandomNumbers() const { return false; }
+
         // Same, seeding cluster i with mt19937(rng_seed + i) as src/main.cpp:976 does.
         void estimateBatchSeeded(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const uint32_t rng_seed);
 

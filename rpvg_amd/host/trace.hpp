@@ -28,7 +28,7 @@ inline int hostThreads() {
             return std::max(1, std::atoi(env));
         }
 
-        return std::max(1, std::min(16, omp_get_max_threads()));
+        return std::max(1, std::min(48, omp_get_max_threads()));
     }();
 
     return threads;
