@@ -31,7 +31,8 @@ struct rpvg_hip_pair_posteriors {
 
 namespace {
 
-constexpr uint32_t kLdsRows = 2048;  // rows of (base, count) staged in LDS: 32 KB
+constexpr uint32_t kLdsRows = 2048;   // rows of (base, count) staged in LDS by the search kernel: 32 KB
+constexpr uint32_t kSmallRows = 512;  // ... for matrices with at most this many rows: 8 KB
 
 __device__ __forceinline__ double waveSum(double v) { return waveSumF64(v); }
 
@@ -56,6 +57,7 @@ struct SearchArgs {
     const uint32_t * col_count;      // path_counts of every column
     const uint64_t * pair_cap_off;   // [M+1] prefix of G(G+1)/2 (output regions)
     double min_log_likelihood_diff;
+    uint32_t stage_rows;             // rows of (base, count) staged in dynamic LDS (16 B each)
     // per-column scratch
     double * log_freq;
     double * marginal;
@@ -76,20 +78,21 @@ __device__ __forceinline__ double pairRowSum(const double * __restrict__ cnt, co
     uint32_t i = lane;
     for (; i + 192 < n; i += 256) {
         const double x0 = col[i], x1 = col[i + 64], x2 = col[i + 128], x3 = col[i + 192];
-        acc0 = fma(cnt[i], log(base[i] + x0 / 2.0), acc0);
-        acc1 = fma(cnt[i + 64], log(base[i + 64] + x1 / 2.0), acc1);
-        acc2 = fma(cnt[i + 128], log(base[i + 128] + x2 / 2.0), acc2);
-        acc3 = fma(cnt[i + 192], log(base[i + 192] + x3 / 2.0), acc3);
+        acc0 = fma(cnt[i], logPositive(base[i] + x0 / 2.0), acc0);
+        acc1 = fma(cnt[i + 64], logPositive(base[i + 64] + x1 / 2.0), acc1);
+        acc2 = fma(cnt[i + 128], logPositive(base[i + 128] + x2 / 2.0), acc2);
+        acc3 = fma(cnt[i + 192], logPositive(base[i + 192] + x3 / 2.0), acc3);
     }
-    for (; i < n; i += 64) acc0 = fma(cnt[i], log(base[i] + col[i] / 2.0), acc0);
+    for (; i < n; i += 64) acc0 = fma(cnt[i], logPositive(base[i] + col[i] / 2.0), acc0);
     return (acc0 + acc1) + (acc2 + acc3);
 }
 
 template <int kBlock>
 __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs args) {
     constexpr int kWaves = kBlock / 64;
-    __shared__ double lds_base[kLdsRows];
-    __shared__ double lds_count[kLdsRows];
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    double * lds_base = lds_dyn;
+    double * lds_count = lds_dyn + args.stage_rows;
     __shared__ double lds_pair[kWaves];
     __shared__ double lds_scalar;
     __shared__ unsigned long long lds_sum;
@@ -135,8 +138,8 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
         double acc1 = 0.0, acc2 = 0.0;
         for (uint64_t i = lane; i < R; i += 64) {
             const double x = col[i], n = nz[i], c = cnt[i];
-            acc1 = fma(c, log(n + x / 1.0), acc1);
-            acc2 = fma(c, log((n + x / 2.0) + rm[i] / 2.0), acc2);
+            acc1 = fma(c, logPositive(n + x / 1.0), acc1);
+            acc2 = fma(c, logPositive((n + x / 2.0) + rm[i] / 2.0), acc2);
         }
         acc1 = waveSum(acc1);
         acc2 = waveSum(acc2);
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
     // the search (:418-451)
     double max_ll = lowest;
     uint32_t kept = 0;
-    const uint32_t staged = static_cast<uint32_t>(R < kLdsRows ? R : kLdsRows);
+    const uint32_t staged = static_cast<uint32_t>(R < args.stage_rows ? R : args.stage_rows);
     for (uint32_t pos = 0; pos < G; ++pos) {
         if (opt[pos] - max_ll < thr) continue;
         const uint32_t a = ord[pos];
@@ -199,10 +202,10 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
                     uint64_t i = staged + lane;
                     for (; i + 64 < R; i += 128) {
                         const double xa0 = col_a[i], xa1 = col_a[i + 64], xb0 = col_b[i], xb1 = col_b[i + 64];
-                        t0 = fma(cnt[i], log((nz[i] + xa0 / 2.0) + xb0 / 2.0), t0);
-                        t1 = fma(cnt[i + 64], log((nz[i + 64] + xa1 / 2.0) + xb1 / 2.0), t1);
+                        t0 = fma(cnt[i], logPositive((nz[i] + xa0 / 2.0) + xb0 / 2.0), t0);
+                        t1 = fma(cnt[i + 64], logPositive((nz[i + 64] + xa1 / 2.0) + xb1 / 2.0), t1);
                     }
-                    for (; i < R; i += 64) t0 = fma(cnt[i], log((nz[i] + col_a[i] / 2.0) + col_b[i] / 2.0), t0);
+                    for (; i < R; i += 64) t0 = fma(cnt[i], logPositive((nz[i] + col_a[i] / 2.0) + col_b[i] / 2.0), t0);
                     acc += t0 + t1;
                 }
                 acc = waveSum(acc);
@@ -301,34 +304,33 @@ __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
     const double * col_a = M + static_cast<uint64_t>(a) * R + r_begin;
     const double * cnt = w.row_count + w.mat_row0[m] + r_begin;
     const double * nz = w.row_noise + w.mat_row0[m] + r_begin;
-    const double * rm = w.rowmax + w.mat_row_off[m] + r_begin;
 
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         lds_base[i] = nz[i] + col_a[i] / 2.0;
         lds_count[i] = cnt[i];
     }
-    if (wave == 0) {
-        // marginal and optimistic partial sums of column a (two logs per row)
-        double acc1 = 0.0, acc2 = 0.0;
-        for (uint32_t i = lane; i < n; i += 64) {
-            const double x = col_a[i], nn = nz[i], c = cnt[i];
-            acc1 = fma(c, log(nn + x / 1.0), acc1);
-            acc2 = fma(c, log((nn + x / 2.0) + rm[i] / 2.0), acc2);
-        }
-        acc1 = waveSum(acc1);
-        acc2 = waveSum(acc2);
-        if (lane == 0) {
-            const uint64_t o = w.big_col_part_off[m] + static_cast<uint64_t>(chunk) * G + a;
-            w.part_marginal[o] = acc1;
-            w.part_optimistic[o] = acc2;
-        }
-    }
     __syncthreads();
     double * out = w.part_pair + w.big_pair_part_off[m] + (static_cast<uint64_t>(chunk) * G + a) * G;
-    for (uint32_t b = a + wave; b < G; b += 4) {
-        const double * col_b = M + static_cast<uint64_t>(b) * R + r_begin;
-        const double acc = waveSum(pairRowSum(lds_count, lds_base, col_b, n, lane));
-        if (lane == 0) out[b] = acc;
+    // tasks of the workgroup, dealt round-robin to its 4 waves: task 0 = marginal + optimistic partial
+    // sums of column a (two logs per row), task 1 + k = pair (a, a + k)
+    for (uint32_t task = wave; task < 1 + (G - a); task += 4) {
+        if (task == 0) {
+            // (the optimistic bound of the column is not needed on this path: the prefix-max filter subsumes it)
+            double acc0 = 0.0, acc1 = 0.0;
+            uint32_t i = lane;
+            for (; i + 64 < n; i += 128) {
+                acc0 = fma(lds_count[i], logPositive(nz[i] + col_a[i] / 1.0), acc0);
+                acc1 = fma(lds_count[i + 64], logPositive(nz[i + 64] + col_a[i + 64] / 1.0), acc1);
+            }
+            for (; i < n; i += 64) acc0 = fma(lds_count[i], logPositive(nz[i] + col_a[i] / 1.0), acc0);
+            const double acc = waveSum(acc0 + acc1);
+            if (lane == 0) w.part_marginal[w.big_col_part_off[m] + static_cast<uint64_t>(chunk) * G + a] = acc;
+        } else {
+            const uint32_t b = a + (task - 1);
+            const double * col_b = M + static_cast<uint64_t>(b) * R + r_begin;
+            const double acc = waveSum(pairRowSum(lds_count, lds_base, col_b, n, lane));
+            if (lane == 0) out[b] = acc;
+        }
     }
 }
 
@@ -619,6 +621,15 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     hipStream_t st = ctx->stream;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
 
+    uint32_t num_medium = 0;
+    {
+        std::vector<uint32_t> medium, small;
+        for (uint32_t i = num_big; i < M; ++i) (groups->h_num_rows[order[i]] > kSmallRows ? medium : small).push_back(order[i]);
+        num_medium = static_cast<uint32_t>(medium.size());
+        std::copy(medium.begin(), medium.end(), order.begin() + num_big);
+        std::copy(small.begin(), small.end(), order.begin() + num_big + num_medium);
+    }
+
     DeviceBuffer<uint32_t> d_order, d_col_count, d_col_order, d_out_first, d_out_second, d_out_count, d_first, d_second;
     DeviceBuffer<uint64_t> d_col_off, d_pair_cap_off, d_pair_off;
     DeviceBuffer<double> d_lf, d_marg, d_opt_raw, d_opt, d_out_value, d_value;
@@ -739,13 +750,22 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         ra.out_count = d_out_count.ptr;
         resolveTableKernel<<<dim3(num_big), dim3(256), 0, st>>>(ra);
     }
-    if (M > num_big) {
+    // the rest walk the search inside one workgroup; matrices with few rows stage less LDS (more
+    // workgroups per CU).  `order` is [big | medium | small], each part expensive first.
+    if (num_medium > 0) {
         args.order = d_order.ptr + num_big;
-        args.count = M - num_big;
-        boundedSearchKernel<256><<<dim3(M - num_big), dim3(256), 0, st>>>(args);
+        args.count = num_medium;
+        args.stage_rows = kLdsRows;
+        boundedSearchKernel<256><<<dim3(num_medium), dim3(256), kLdsRows * 16, st>>>(args);
+    }
+    if (M > num_big + num_medium) {
+        args.order = d_order.ptr + num_big + num_medium;
+        args.count = M - num_big - num_medium;
+        args.stage_rows = kSmallRows;
+        boundedSearchKernel<256><<<dim3(args.count), dim3(256), kSmallRows * 16, st>>>(args);
     }
     ctx->spanEnd(span);
-    ctx->stats.loglik_launches += (num_big > 0 ? 2 : 0) + (M > num_big);
+    ctx->stats.loglik_launches += (num_big > 0 ? 2 : 0) + (num_medium > 0) + (M > num_big + num_medium);
     ok(hipGetLastError());
 
     std::vector<uint32_t> counts(M);

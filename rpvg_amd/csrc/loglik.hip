@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void groupLoglikKernel(
         for (int w = 0; w < WIDTH; ++w)
             if (col[w]) v += col[w][i] / divisor;
         if (rm) v += rm[i] / divisor;
-        acc = fma(cnt[i], log(v), acc);
+        acc = fma(cnt[i], logPositive(v), acc);
     }
     acc = waveSumF64(acc);
     if (lane == 0) out[q] = acc;

@@ -145,10 +145,14 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
 
     std::unique_ptr<ScopedPhase> reset_phase(new ScopedPhase("nested: resetEstimates"));
 
+    #pragma omp parallel for schedule(static) num_threads(hostThreads())
     for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
 
         assert(path_cluster_estimates->at(i).paths.size() == cluster_batch.numPaths(i));
         path_cluster_estimates->at(i).resetEstimates(0, 0);
+    }
+
+    for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
 
         if (cluster_batch.numRows(i) > 0) {
 
@@ -199,8 +203,15 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
 
         ScopedPhase teardown_phase("nested: teardown posterior containers");
 
-        std::vector<GroupPosteriorProblem>().swap(problems);
-        std::vector<GroupPosteriors>().swap(group_posteriors);
+        #pragma omp parallel for schedule(static) num_threads(hostThreads())
+        for (size_t i = 0; i < problems.size(); ++i) {
+
+            GroupPosteriorProblem().column_path.swap(problems.at(i).column_path);
+            std::vector<uint32_t>().swap(problems.at(i).column_path_off);
+            std::vector<uint32_t>().swap(problems.at(i).column_counts);
+            std::vector<uint32_t>().swap(group_posteriors.at(i).members);
+            std::vector<double>().swap(group_posteriors.at(i).posteriors);
+        }
 
     } else {
 
@@ -256,7 +267,12 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
     inferPathSubsetAbundance(path_cluster_estimates, cluster_batch, clusters, path_subset_samples);
 
     ScopedPhase teardown_phase("nested: teardown subset weights");
-    std::vector<PathSubsetWeights>().swap(path_subset_samples);
+
+    #pragma omp parallel for schedule(static) num_threads(hostThreads())
+    for (size_t i = 0; i < path_subset_samples.size(); ++i) {
+
+        PathSubsetWeights().swap(path_subset_samples.at(i));
+    }
 }
 
 void NestedPathAbundanceEstimator::pathGroupPosteriors(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems) const {
@@ -403,10 +419,26 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
     std::unique_ptr<ScopedPhase> build_phase(new ScopedPhase("nested: EM problem list"));
 
     // one EM problem per retained subset: its distinct paths
-    std::vector<EMProblem> problems;
     std::vector<size_t> first_problem(clusters.size() + 1, 0);
 
     for (size_t i = 0; i < clusters.size(); ++i) {
+
+        size_t num_retained = 0;
+
+        for (auto & path_subset: path_subset_samples.at(i)) {
+
+            num_retained += (path_subset.second >= min_hap_prob);
+        }
+
+        first_problem.at(i + 1) = first_problem.at(i) + num_retained;
+    }
+
+    std::vector<EMProblem> problems(first_problem.back());
+
+    #pragma omp parallel for schedule(static) num_threads(hostThreads())
+    for (size_t i = 0; i < clusters.size(); ++i) {
+
+        size_t problem_idx = first_problem.at(i);
 
         for (auto & path_subset: path_subset_samples.at(i)) {
 
@@ -417,13 +449,12 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
 
             assert(!path_subset.first.empty());
 
-            problems.emplace_back(EMProblem());
-            problems.back().cluster = clusters.at(i);
+            auto & problem = problems.at(problem_idx);
+            ++problem_idx;
 
-            std::unique_copy(path_subset.first.begin(), path_subset.first.end(), std::back_inserter(problems.back().path_ids));
+            problem.cluster = clusters.at(i);
+            std::unique_copy(path_subset.first.begin(), path_subset.first.end(), std::back_inserter(problem.path_ids));
         }
-
-        first_problem.at(i + 1) = problems.size();
     }
 
     build_phase.reset();
