@@ -173,7 +173,8 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         em_sparse_ms_per_step=stats["em_sparse_ms"] / args.steps, loglik_ms_per_step=stats["loglik_ms"] / args.steps,
         build_ms_per_step=stats["build_ms"] / args.steps, h2d_ms_per_step=stats["h2d_ms"] / args.steps,
         em_iterations_per_step=stats["em_iterations_total"] / args.steps,
-        loglik_evals_per_step=stats["loglik_evals"] / args.steps)
+        loglik_evals_per_step=stats["loglik_evals"] / args.steps,
+        loglik_gevals_per_s=(stats["loglik_evals"] / 1e9) / (stats["loglik_ms"] / 1e3) if stats["loglik_ms"] > 0 else 0.0)
     line = dict(
         metric="read-pairs quantified/sec", value=value, unit="read-pairs/s", n_gpus=world, steps=args.steps,
         warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,

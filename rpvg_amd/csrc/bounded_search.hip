@@ -33,12 +33,47 @@ namespace {
 
 constexpr uint32_t kLdsRows = 2048;   // rows of (base, count) staged in LDS by the search kernel: 32 KB
 constexpr uint32_t kSmallRows = 512;  // ... for matrices with at most this many rows: 8 KB
+constexpr uint32_t kRowLdsCols = 512; // pair log-likelihoods of one first column kept in LDS up to this many columns: 4 KB
 
 __device__ __forceinline__ double waveSum(double v) { return waveSumF64(v); }
 
 // Utils::add_log (src/utils.hpp:300-302)
 __device__ __forceinline__ double addLog(const double log_x, const double log_y) {
     return log_x > log_y ? log_x + log1p(exp(log_y - log_x)) : log_y + log1p(exp(log_x - log_y));
+}
+
+
+// log(sum_k exp(v_k)) of n values of a workgroup, v_k given by `value(k)` (values equal to `lowest` carry no
+// mass).  The reference folds Utils::add_log over the values one by one (src/path_estimator.cpp:348,453-463);
+// here the maximum is taken first and the exponentials are summed in parallel (same value up to rounding;
+// a single thread folding a few hundred add_log calls was the longest serial stretch of these kernels).
+// scratch: kBlock/64 doubles in LDS.  Result in every thread.
+template <int kBlock, typename ValueFn>
+__device__ __forceinline__ double blockLogSumExp(const uint32_t n, ValueFn value, double * scratch) {
+    const double lowest = -1.7976931348623157e308;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double mx = lowest;
+    for (uint32_t k = threadIdx.x; k < n; k += kBlock) mx = fmax(mx, value(k));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmax(mx, __shfl_xor(mx, d, 64));
+    __syncthreads();
+    if (lane == 0) scratch[wave] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int w2 = 0; w2 < kBlock / 64; ++w2) mx = fmax(mx, scratch[w2]);
+    double sum = 0.0;
+    for (uint32_t k = threadIdx.x; k < n; k += kBlock) {
+        const double v = value(k);
+        if (v > lowest) sum += exp(v - mx);
+    }
+    sum = waveSum(sum);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = sum;
+    __syncthreads();
+    double total = 0.0;
+#pragma unroll
+    for (int w2 = 0; w2 < kBlock / 64; ++w2) total += scratch[w2];
+    return (n == 0 || !(mx > lowest)) ? lowest : mx + log(total);
 }
 
 struct SearchArgs {
@@ -58,6 +93,7 @@ struct SearchArgs {
     const uint64_t * pair_cap_off;   // [M+1] prefix of G(G+1)/2 (output regions)
     double min_log_likelihood_diff;
     uint32_t stage_rows;             // rows of (base, count) staged in dynamic LDS (16 B each)
+    uint32_t row_lds_cols;           // a row of pair log-likelihoods is kept in LDS when G <= this
     // per-column scratch
     double * log_freq;
     double * marginal;
@@ -69,6 +105,7 @@ struct SearchArgs {
     uint32_t * out_second;
     double * out_value;              // log-likelihood, then posterior
     uint32_t * out_count;            // [M]
+    unsigned long long * log_evals;  // device counter: FP64 logs evaluated
 };
 
 // sum_i count_i * log(base_i + col_i / 2) over rows [lane, n) step 64, four independent chains in flight
@@ -93,8 +130,7 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     double * lds_base = lds_dyn;
     double * lds_count = lds_dyn + args.stage_rows;
-    __shared__ double lds_pair[kWaves];
-    __shared__ double lds_scalar;
+    __shared__ double lds_red[kBlock / 64];
     __shared__ unsigned long long lds_sum;
 
     if (blockIdx.x >= args.count) return;
@@ -150,15 +186,9 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
     }
     __syncthreads();
 
-    // normalise the marginals (log-sum-exp fold in column order, :348,370-376)
-    if (threadIdx.x == 0) {
-        double sum_log = lowest;
-        for (uint32_t g = 0; g < G; ++g) sum_log = addLog(sum_log, marg[g]);
-        lds_scalar = sum_log;
-    }
-    __syncthreads();
+    // normalise the marginals (:348,370-376)
     {
-        const double sum_log = lds_scalar;
+        const double sum_log = blockLogSumExp<kBlock>(G, [&](uint32_t g) { return marg[g]; }, lds_red);
         for (uint32_t g = threadIdx.x; g < G; g += kBlock) marg[g] = exp(marg[g] - sum_log);
     }
     __syncthreads();
@@ -176,9 +206,13 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
     }
     __syncthreads();
 
+    // pair log-likelihoods of the current first column: LDS when they fit, else the (now free) bound scratch
+    double * row_ll = (G <= args.row_lds_cols) ? (lds_dyn + 2 * args.stage_rows) : opt_raw;
+
     // the search (:418-451)
     double max_ll = lowest;
     uint32_t kept = 0;
+    unsigned long long pairs_evaluated = 0;
     const uint32_t staged = static_cast<uint32_t>(R < args.stage_rows ? R : args.stage_rows);
     for (uint32_t pos = 0; pos < G; ++pos) {
         if (opt[pos] - max_ll < thr) continue;
@@ -191,65 +225,52 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
         }
         __syncthreads();
         const double lf_a = lf[a];
-        for (uint32_t j0 = pos; j0 < G; j0 += kWaves) {
-            const uint32_t j = j0 + wave;
-            if (j < G) {
-                const uint32_t b = ord[j];
-                const double * col_b = M + static_cast<uint64_t>(b) * R;
-                double acc = pairRowSum(lds_count, lds_base, col_b, staged, lane);
-                {
-                    double t0 = 0.0, t1 = 0.0;
-                    uint64_t i = staged + lane;
-                    for (; i + 64 < R; i += 128) {
-                        const double xa0 = col_a[i], xa1 = col_a[i + 64], xb0 = col_b[i], xb1 = col_b[i + 64];
-                        t0 = fma(cnt[i], logPositive((nz[i] + xa0 / 2.0) + xb0 / 2.0), t0);
-                        t1 = fma(cnt[i + 64], logPositive((nz[i + 64] + xa1 / 2.0) + xb1 / 2.0), t1);
-                    }
-                    for (; i < R; i += 64) t0 = fma(cnt[i], logPositive((nz[i] + col_a[i] / 2.0) + col_b[i] / 2.0), t0);
-                    acc += t0 + t1;
+        pairs_evaluated += G - pos;
+        // every wave evaluates its share of the row's pairs without waiting for the others ...
+        for (uint32_t j = pos + wave; j < G; j += kWaves) {
+            const uint32_t b = ord[j];
+            const double * col_b = M + static_cast<uint64_t>(b) * R;
+            double acc = pairRowSum(lds_count, lds_base, col_b, staged, lane);
+            {
+                double t0 = 0.0, t1 = 0.0;
+                uint64_t i = staged + lane;
+                for (; i + 64 < R; i += 128) {
+                    const double xa0 = col_a[i], xa1 = col_a[i + 64], xb0 = col_b[i], xb1 = col_b[i + 64];
+                    t0 = fma(cnt[i], logPositive((nz[i] + xa0 / 2.0) + xb0 / 2.0), t0);
+                    t1 = fma(cnt[i + 64], logPositive((nz[i + 64] + xa1 / 2.0) + xb1 / 2.0), t1);
                 }
-                acc = waveSum(acc);
-                if (lane == 0) lds_pair[wave] = acc + ((lf_a + lf[b]) + (a == b ? 0.0 : log_two));
+                for (; i < R; i += 64) t0 = fma(cnt[i], logPositive((nz[i] + col_a[i] / 2.0) + col_b[i] / 2.0), t0);
+                acc += t0 + t1;
             }
-            __syncthreads();
-            // the reference's pruning rule, applied to the evaluated pairs in order (uniform)
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) {
-                if (j0 + w < G) {
-                    const double ll = lds_pair[w];
-                    if (!(ll - max_ll < thr)) {
-                        max_ll = fmax(max_ll, ll);
-                        if (threadIdx.x == 0) {
-                            out_first[kept] = a;
-                            out_second[kept] = ord[j0 + w];
-                            out_value[kept] = ll;
-                        }
-                        ++kept;
-                    }
+            acc = waveSum(acc);
+            if (lane == 0) row_ll[j - pos] = acc + ((lf_a + lf[b]) + (a == b ? 0.0 : log_two));
+        }
+        __syncthreads();
+        // ... then the reference's pruning rule runs over the row in order (uniformly in all threads)
+        for (uint32_t j = pos; j < G; ++j) {
+            const double ll = row_ll[j - pos];
+            if (!(ll - max_ll < thr)) {
+                max_ll = fmax(max_ll, ll);
+                if (threadIdx.x == 0) {
+                    out_first[kept] = a;
+                    out_second[kept] = ord[j];
+                    out_value[kept] = ll;
                 }
+                ++kept;
             }
-            __syncthreads();
         }
     }
 
     // late losers -> weight zero, log-sum-exp, posteriors (:453-470)
-    if (threadIdx.x == 0) {
-        double sum_log = lowest;
-        for (uint32_t k = 0; k < kept; ++k) {
-            double ll = out_value[k];
-            if (ll - max_ll < thr) {
-                ll = lowest;
-                out_value[k] = ll;
-            }
-            sum_log = addLog(sum_log, ll);
-        }
-        lds_scalar = sum_log;
-        args.out_count[m] = kept;
-    }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        args.out_count[m] = kept;
+        atomicAdd(args.log_evals, (2ull * G + pairs_evaluated) * R);
+    }
     {
-        const double sum_log = lds_scalar;
-        for (uint32_t k = threadIdx.x; k < kept; k += kBlock) out_value[k] = exp(out_value[k] - sum_log);
+        auto kept_value = [&](uint32_t k) { const double ll = out_value[k]; return (ll - max_ll < thr) ? lowest : ll; };
+        const double sum_log = blockLogSumExp<kBlock>(kept, kept_value, lds_red);
+        for (uint32_t k = threadIdx.x; k < kept; k += kBlock) out_value[k] = exp(kept_value(k) - sum_log);
     }
 }
 
@@ -265,7 +286,8 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
 // and one workgroup then applies an exclusive prefix-max scan in the
 // reference's pair order.
 
-constexpr uint32_t kChunkRows = 2048;
+constexpr uint32_t kChunkRows = 1024;
+constexpr int kTileA = 4;
 
 struct TableWork {
     const uint32_t * item_matrix;   // [W]
@@ -286,36 +308,50 @@ struct TableWork {
     double * part_marginal;
     double * part_optimistic;
     double * part_pair;
+    unsigned long long * log_evals;
 };
 
-// one workgroup per (matrix, first column a, row chunk): partial sums of the column's marginal and
-// optimistic log-likelihoods and of every pair (a, b >= a) over the rows of the chunk
+// One workgroup per (matrix, tile of kTileA consecutive first columns, chunk of kChunkRows rows): partial
+// sums over the chunk's rows of the tile's marginal log-likelihoods and of every pair (a, b >= a), a in
+// the tile.  The tile's base vectors noise_i + M[i][a]/2 and the read counts are staged in LDS; every
+// second column b is then read ONCE per row and feeds kTileA logs (kTileA-way ILP for free, and
+// kTileA-times less L2/HBM traffic than one first column per workgroup: that version re-read 27 GB per
+// step of the bench workload and was memory-bound).  Work items are dealt to XCDs in contiguous ranges
+// (workgroup b runs on XCD b % 8), so the tiles of one row chunk share that XCD's L2.
 __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
-    __shared__ double lds_base[kChunkRows];
+    __shared__ double lds_base[kTileA][kChunkRows];
     __shared__ double lds_count[kChunkRows];
-    if (blockIdx.x >= w.count) return;
-    const uint32_t m = w.item_matrix[blockIdx.x], a = w.item_col[blockIdx.x], chunk = w.item_chunk[blockIdx.x];
+    const uint32_t per_xcd = (w.count + 7) / 8;
+    const uint32_t item = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (item >= w.count) return;
+    const uint32_t m = w.item_matrix[item], a0 = w.item_col[item], chunk = w.item_chunk[item];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t R = w.mat_rows[m];
     const uint32_t G = w.mat_cols[m];
+    const uint32_t ta = (G - a0) < kTileA ? (G - a0) : kTileA;
     const uint64_t r_begin = static_cast<uint64_t>(chunk) * kChunkRows;
     const uint32_t n = static_cast<uint32_t>((R - r_begin) < kChunkRows ? (R - r_begin) : kChunkRows);
-    const double * M = w.values + w.mat_val_off[m];
-    const double * col_a = M + static_cast<uint64_t>(a) * R + r_begin;
+    const double * M = w.values + w.mat_val_off[m] + r_begin;
     const double * cnt = w.row_count + w.mat_row0[m] + r_begin;
     const double * nz = w.row_noise + w.mat_row0[m] + r_begin;
 
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        lds_base[i] = nz[i] + col_a[i] / 2.0;
+        const double noise = nz[i];
         lds_count[i] = cnt[i];
+#pragma unroll
+        for (int t = 0; t < kTileA; ++t) {
+            const uint32_t a = a0 + (t < static_cast<int>(ta) ? t : 0);
+            lds_base[t][i] = noise + M[static_cast<uint64_t>(a) * R + i] / 2.0;
+        }
     }
     __syncthreads();
-    double * out = w.part_pair + w.big_pair_part_off[m] + (static_cast<uint64_t>(chunk) * G + a) * G;
-    // tasks of the workgroup, dealt round-robin to its 4 waves: task 0 = marginal + optimistic partial
-    // sums of column a (two logs per row), task 1 + k = pair (a, a + k)
-    for (uint32_t task = wave; task < 1 + (G - a); task += 4) {
-        if (task == 0) {
-            // (the optimistic bound of the column is not needed on this path: the prefix-max filter subsumes it)
+    // tasks dealt round-robin to the 4 waves: task t < ta = marginal partial sum of column a0 + t,
+    // task ta + k = pairs (a0 + t, a0 + k) for every t <= k of the tile
+    const uint32_t num_tasks = ta + (G - a0);
+    for (uint32_t task = wave; task < num_tasks; task += 4) {
+        if (task < ta) {
+            const uint32_t a = a0 + task;
+            const double * col_a = M + static_cast<uint64_t>(a) * R;
             double acc0 = 0.0, acc1 = 0.0;
             uint32_t i = lane;
             for (; i + 64 < n; i += 128) {
@@ -326,12 +362,26 @@ __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
             const double acc = waveSum(acc0 + acc1);
             if (lane == 0) w.part_marginal[w.big_col_part_off[m] + static_cast<uint64_t>(chunk) * G + a] = acc;
         } else {
-            const uint32_t b = a + (task - 1);
-            const double * col_b = M + static_cast<uint64_t>(b) * R + r_begin;
-            const double acc = waveSum(pairRowSum(lds_count, lds_base, col_b, n, lane));
-            if (lane == 0) out[b] = acc;
+            const uint32_t b = a0 + (task - ta);
+            const double * col_b = M + static_cast<uint64_t>(b) * R;
+            double acc[kTileA];
+#pragma unroll
+            for (int t = 0; t < kTileA; ++t) acc[t] = 0.0;
+            for (uint32_t i = lane; i < n; i += 64) {
+                const double x = col_b[i] / 2.0, c = lds_count[i];
+#pragma unroll
+                for (int t = 0; t < kTileA; ++t) acc[t] = fma(c, logPositive(lds_base[t][i] + x), acc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < kTileA; ++t) {
+                const double total = waveSum(acc[t]);
+                if (lane == 0 && t < static_cast<int>(ta) && a0 + t <= b) {
+                    w.part_pair[w.big_pair_part_off[m] + (static_cast<uint64_t>(chunk) * G + (a0 + t)) * G + b] = total;
+                }
+            }
         }
     }
+    if (threadIdx.x == 0) atomicAdd(w.log_evals, static_cast<unsigned long long>(ta + (G - a0) * kTileA) * n);
 }
 
 struct ResolveArgs {
@@ -363,7 +413,6 @@ __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args
     constexpr int kBlock = 256;
     __shared__ double lds_red[kBlock / 64];
     __shared__ uint32_t lds_cnt[kBlock / 64];
-    __shared__ double lds_scalar;
     __shared__ unsigned long long lds_sum;
     if (blockIdx.x >= args.count) return;
     const uint32_t m = args.big_matrix[blockIdx.x];
@@ -402,14 +451,8 @@ __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args
         marg[g] = (acc + f) + 0.0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double sum_log = lowest;
-        for (uint32_t g = 0; g < G; ++g) sum_log = addLog(sum_log, marg[g]);
-        lds_scalar = sum_log;
-    }
-    __syncthreads();
     {
-        const double sum_log = lds_scalar;
+        const double sum_log = blockLogSumExp<kBlock>(G, [&](uint32_t g) { return marg[g]; }, lds_red);
         for (uint32_t g = threadIdx.x; g < G; g += kBlock) marg[g] = exp(marg[g] - sum_log);
     }
     __syncthreads();
@@ -500,24 +543,13 @@ __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args
     }
     const double max_ll = carry_max;
 
-    // late losers -> weight zero; log-sum-exp in kept order; posteriors
-    if (threadIdx.x == 0) {
-        double sum_log = lowest;
-        for (uint32_t k = 0; k < kept; ++k) {
-            double ll = out_value[k];
-            if (ll - max_ll < thr) {
-                ll = lowest;
-                out_value[k] = ll;
-            }
-            sum_log = addLog(sum_log, ll);
-        }
-        lds_scalar = sum_log;
-        args.out_count[m] = kept;
-    }
+    // late losers -> weight zero; log-sum-exp; posteriors
     __syncthreads();
+    if (threadIdx.x == 0) args.out_count[m] = kept;
     {
-        const double sum_log = lds_scalar;
-        for (uint32_t k = threadIdx.x; k < kept; k += kBlock) out_value[k] = exp(out_value[k] - sum_log);
+        auto kept_value = [&](uint32_t k) { const double ll = out_value[k]; return (ll - max_ll < thr) ? lowest : ll; };
+        const double sum_log = blockLogSumExp<kBlock>(kept, kept_value, lds_red);
+        for (uint32_t k = threadIdx.x; k < kept; k += kBlock) out_value[k] = exp(kept_value(k) - sum_log);
     }
 }
 
@@ -563,12 +595,10 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     }
 
     std::vector<uint64_t> col_off(M + 1, 0), pair_cap_off(M + 1, 0);
-    double evals = 0;
     for (uint32_t m = 0; m < M; ++m) {
         const uint64_t G = groups->h_num_cols[m];
         col_off[m + 1] = col_off[m] + G;
         pair_cap_off[m + 1] = pair_cap_off[m] + G * (G + 1) / 2;
-        evals += 2.0 * G * static_cast<double>(groups->h_num_rows[m]);
     }
     for (uint64_t c = 0; c < col_off[M]; ++c) {
         if (column_counts[c] == 0) {
@@ -607,7 +637,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         col_part_total += chunks * G;
         pair_part_total += chunks * G * G;
         for (uint32_t c = 0; c < chunks; ++c) {
-            for (uint32_t a = 0; a < G; ++a) {
+            for (uint32_t a = 0; a < G; a += kTileA) {
                 item_matrix.push_back(m);
                 item_col.push_back(a);
                 item_chunk.push_back(c);
@@ -683,6 +713,10 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     args.out_value = d_out_value.ptr;
     args.out_count = d_out_count.ptr;
 
+    DeviceBuffer<unsigned long long> d_log_evals;
+    ok(d_log_evals.alloc(1));
+    if (e == hipSuccess) ok(hipMemsetAsync(d_log_evals.ptr, 0, sizeof(unsigned long long), st));
+    args.log_evals = d_log_evals.ptr;
     DeviceBuffer<uint32_t> d_item_matrix, d_item_col, d_item_chunk;
     DeviceBuffer<uint64_t> d_big_col_part_off, d_big_pair_part_off;
     DeviceBuffer<double> d_part_marg, d_part_opt, d_part_pair, d_seq;
@@ -703,7 +737,10 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
     }
 
+    // the table path, the medium and the small matrices are independent: three streams, so that the
+    // tail of one does not idle the GPU
     span = ctx->spanBegin(FAM_LOGLIK);
+    ok(ctx->forkAux());
     if (num_big > 0) {
         TableWork tw;
         tw.item_matrix = d_item_matrix.ptr;
@@ -724,7 +761,8 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         tw.part_marginal = d_part_marg.ptr;
         tw.part_optimistic = d_part_opt.ptr;
         tw.part_pair = d_part_pair.ptr;
-        pairTableKernel<<<dim3(tw.count), dim3(256), 0, st>>>(tw);
+        tw.log_evals = d_log_evals.ptr;
+        pairTableKernel<<<dim3(((tw.count + 7) / 8) * 8), dim3(256), 0, st>>>(tw);
 
         ResolveArgs ra;
         ra.big_matrix = d_order.ptr;
@@ -752,24 +790,28 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     }
     // the rest walk the search inside one workgroup; matrices with few rows stage less LDS (more
     // workgroups per CU).  `order` is [big | medium | small], each part expensive first.
+    args.row_lds_cols = kRowLdsCols;
     if (num_medium > 0) {
         args.order = d_order.ptr + num_big;
         args.count = num_medium;
         args.stage_rows = kLdsRows;
-        boundedSearchKernel<256><<<dim3(num_medium), dim3(256), kLdsRows * 16, st>>>(args);
+        boundedSearchKernel<1024><<<dim3(num_medium), dim3(1024), kLdsRows * 16 + kRowLdsCols * 8, ctx->aux[0]>>>(args);
     }
     if (M > num_big + num_medium) {
         args.order = d_order.ptr + num_big + num_medium;
         args.count = M - num_big - num_medium;
         args.stage_rows = kSmallRows;
-        boundedSearchKernel<256><<<dim3(args.count), dim3(256), kSmallRows * 16, st>>>(args);
+        boundedSearchKernel<256><<<dim3(args.count), dim3(256), kSmallRows * 16 + kRowLdsCols * 8, ctx->aux[1]>>>(args);
     }
+    ok(ctx->joinAux());
     ctx->spanEnd(span);
     ctx->stats.loglik_launches += (num_big > 0 ? 2 : 0) + (num_medium > 0) + (M > num_big + num_medium);
     ok(hipGetLastError());
 
     std::vector<uint32_t> counts(M);
+    unsigned long long log_evals = 0;
     ok(d_out_count.download(counts.data(), st));
+    ok(hipMemcpyAsync(&log_evals, d_log_evals.ptr, sizeof(log_evals), hipMemcpyDeviceToHost, st));
     ok(hipStreamSynchronize(st));
     if (e == hipSuccess) {
         for (uint32_t m = 0; m < M; ++m) res->pair_off[m + 1] = res->pair_off[m] + counts[m];
@@ -791,10 +833,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
             ok(d_value.download(res->posterior.data(), st));
         }
         ok(hipStreamSynchronize(st));
-        // marginal + bound logs, plus one log per row of every kept-or-pruned pair that was evaluated is not
-        // observable from the host; count the lower bound (marginals, bounds and kept pairs)
-        for (uint32_t m = 0; m < M; ++m) evals += static_cast<double>(counts[m]) * static_cast<double>(groups->h_num_rows[m]);
-        ctx->stats.loglik_evals += evals;
+        ctx->stats.loglik_evals += static_cast<double>(log_evals);  // counted by the kernels
     }
     if (e != hipSuccess) {
         delete res;

@@ -101,6 +101,21 @@ void poolTrim(int device) {
 
 using namespace rpvg_hip_detail;
 
+hipError_t rpvg_hip_ctx::forkAux() {
+    hipError_t e = hipEventRecord(fork_event, stream);
+    for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamWaitEvent(aux[i], fork_event, 0);
+    return e;
+}
+
+hipError_t rpvg_hip_ctx::joinAux() {
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) {
+        e = hipEventRecord(join_event[i], aux[i]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, join_event[i], 0);
+    }
+    return e;
+}
+
 int rpvg_hip_ctx::spanBegin(int family) {
     TimedSpan s;
     s.family = family;
@@ -201,6 +216,16 @@ int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) {
         delete ctx;
         return RPVG_HIP_ERR_RUNTIME;
     }
+    for (int i = 0; i < rpvg_hip_ctx::kAuxStreams && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_event[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        setError("rpvg_hip_create: %s", hipGetErrorString(e));
+        delete ctx;
+        return RPVG_HIP_ERR_RUNTIME;
+    }
     if (strncmp(ctx->props.gcnArchName, "gfx950", 6) != 0) {
         setError("rpvg_hip_create: device %d is %s; this library is built for gfx950 only", device, ctx->props.gcnArchName);
         (void) hipStreamDestroy(ctx->stream);
@@ -220,6 +245,11 @@ void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
     (void) hipSetDevice(ctx->device);
     (void) ctx->foldSpans();
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    for (int i = 0; i < rpvg_hip_ctx::kAuxStreams; ++i) {
+        if (ctx->aux[i]) (void) hipStreamDestroy(ctx->aux[i]);
+        if (ctx->join_event[i]) (void) hipEventDestroy(ctx->join_event[i]);
+    }
+    if (ctx->fork_event) (void) hipEventDestroy(ctx->fork_event);
     bool last = false;
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);

@@ -563,20 +563,23 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     args.noise_count = d_noise_count.ptr;
     args.iterations = d_iters.ptr;
 
+    // the four bins are independent: one stream each, so a bin's tail (a tiny problem that needs
+    // thousands of iterations, a giant one with many rows) overlaps the other bins
     span = ctx->spanBegin(FAM_EM_SPARSE);
-    // giant problems first (they are the tail), then down to the small ones
+    RPVG_HIP_CHECK(ctx->forkAux());
+    args.order = d_order.ptr + bin_start[0];
+    args.count = bins[0].size();
+    RPVG_HIP_CHECK((launchEm<64, true>(args, bin_lds[0], ctx->aux[2])));
     args.order = d_order.ptr + bin_start[3];
     args.count = bins[3].size();
     RPVG_HIP_CHECK((launchEm<1024, false>(args, bin_lds[3], st)));
     args.order = d_order.ptr + bin_start[2];
     args.count = bins[2].size();
-    RPVG_HIP_CHECK((launchEm<256, false>(args, bin_lds[2], st)));
+    RPVG_HIP_CHECK((launchEm<256, false>(args, bin_lds[2], ctx->aux[0])));
     args.order = d_order.ptr + bin_start[1];
     args.count = bins[1].size();
-    RPVG_HIP_CHECK((launchEm<256, true>(args, bin_lds[1], st)));
-    args.order = d_order.ptr + bin_start[0];
-    args.count = bins[0].size();
-    RPVG_HIP_CHECK((launchEm<64, true>(args, bin_lds[0], st)));
+    RPVG_HIP_CHECK((launchEm<256, true>(args, bin_lds[1], ctx->aux[1])));
+    RPVG_HIP_CHECK(ctx->joinAux());
     ctx->spanEnd(span);
     for (int b = 0; b < kBins; ++b) ctx->stats.em_sparse_launches += bins[b].empty() ? 0 : 1;
 

@@ -175,3 +175,17 @@ def test_host_driven_bounded_search_agrees_with_on_device_search(engine):
         for d, h in zip(dev, host):
             assert d.path_group_sets == h.path_group_sets
         _compare(dev, host)
+
+
+def test_independent_haplotype_inference_matches_oracle(engine):
+    """--ind-hap-inference (src/path_abundance_estimator.cpp:356-426): per-transcript posteriors on the GPU,
+    subset sampling with the reference's mt19937(rng_seed + i) / discrete_distribution on the host."""
+    clusters = small_cases.make_batch_clusters(681, n_clusters=10)
+    batch = ClusterBatch.from_clusters(clusters)
+    params = make_params(ind_hap_inference=1, rng_seed=7)
+    ref, _ = pyoracle.run("haplotype-transcripts", params, batch, 1)
+    got, _ = engine.run("haplotype-transcripts", params, engine.prepare(batch))
+    _compare(got, ref)
+    # the drop-in estimate() consumes the caller's generator the same way
+    got1, _ = engine.run("haplotype-transcripts", params, engine.prepare(batch, per_cluster=True))
+    _compare(got1, ref)
