@@ -17,6 +17,8 @@
 
 #include "common.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <memory>
 
@@ -70,6 +72,58 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
             }
         }
         rm[i] = mx;
+    }
+}
+
+
+// ---- path -> groups incidence, inverted on the device ---------------------------------
+// The caller gives, per matrix, the paths of every column (group).  The build kernel needs the
+// opposite: the columns of every path.  One thread per column counts / scatters; the per-path lists
+// come out in arbitrary column order, which does not matter (a row adds each of its entries to every
+// column of the entry's path; the order of those columns does not change any sum).
+
+__device__ __forceinline__ uint32_t matrixOfColumn(const uint64_t * __restrict__ group_off, const uint32_t num_matrices,
+                                                   const uint64_t column) {
+    uint32_t lo = 0, hi = num_matrices - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (group_off[mid] <= column) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ void incidenceCountKernel(const uint32_t num_matrices, const uint64_t num_columns,
+                                     const uint64_t * __restrict__ group_off, const uint64_t * __restrict__ group_path_off,
+                                     const uint32_t * __restrict__ group_path, const uint64_t * __restrict__ inc_off,
+                                     const uint64_t * __restrict__ num_paths, uint32_t * __restrict__ degree,
+                                     uint32_t * __restrict__ error_flag) {
+    const uint64_t column = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (column >= num_columns) return;
+    const uint32_t m = matrixOfColumn(group_off, num_matrices, column);
+    for (uint64_t x = group_path_off[column]; x < group_path_off[column + 1]; ++x) {
+        const uint32_t p = group_path[x];
+        if (p >= num_paths[m]) {
+            *error_flag = 1;
+            continue;
+        }
+        atomicAdd(&degree[inc_off[m] + p], 1u);
+    }
+}
+
+__global__ void incidenceFillKernel(const uint32_t num_matrices, const uint64_t num_columns,
+                                    const uint64_t * __restrict__ group_off, const uint64_t * __restrict__ group_path_off,
+                                    const uint32_t * __restrict__ group_path, const uint64_t * __restrict__ inc_off,
+                                    const uint64_t * __restrict__ num_paths, const uint64_t * __restrict__ path_grp_off,
+                                    uint32_t * __restrict__ cursor, uint32_t * __restrict__ path_grp) {
+    const uint64_t column = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (column >= num_columns) return;
+    const uint32_t m = matrixOfColumn(group_off, num_matrices, column);
+    const uint32_t local = static_cast<uint32_t>(column - group_off[m]);
+    for (uint64_t x = group_path_off[column]; x < group_path_off[column + 1]; ++x) {
+        const uint32_t p = group_path[x];
+        if (p >= num_paths[m]) continue;
+        const uint64_t slot = inc_off[m] + p;
+        path_grp[path_grp_off[slot] + atomicAdd(&cursor[slot], 1u)] = local;
     }
 }
 
@@ -128,13 +182,11 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     g->num_matrices = M;
     g->normalise = spec->normalise;
 
-    std::unique_ptr<HostScope> scope_host(new HostScope("groups_build: host incidence"));
-    // host: sizes, offsets and the path -> groups incidence of every matrix
-    std::vector<uint64_t> val_off(M), row_off(M), row0(M), rows(M), inc_off(M);
-    std::vector<uint32_t> cols(M);
-    std::vector<uint64_t> path_grp_off;
-    std::vector<uint32_t> path_grp;
-    uint64_t val_total = 0, row_total = 0;
+    std::unique_ptr<HostScope> scope_host(new HostScope("groups_build: host sizes"));
+    // host: sizes and offsets only (O(M)); the path -> groups incidence is inverted on the device
+    std::vector<uint64_t> val_off(M), row_off(M), row0(M), rows(M), inc_off(M), num_paths(M);
+    std::vector<uint32_t> cols(M), item_matrix, item_chunk;
+    uint64_t val_total = 0, row_total = 0, inc_total = 0;
     for (uint32_t m = 0; m < M; ++m) {
         const uint32_t k = spec->cluster[m];
         if (k >= batch->num_clusters) {
@@ -153,37 +205,16 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         rows[m] = R;
         cols[m] = static_cast<uint32_t>(g1 - g0);
         row0[m] = batch->h_cluster_row_off[k];
+        num_paths[m] = N;
         val_off[m] = val_total;
         row_off[m] = row_total;
+        inc_off[m] = inc_total;
         val_total += R * (g1 - g0);
         row_total += R;
-        // invert: groups of each path, in ascending group order
-        std::vector<uint32_t> deg(N + 1, 0);
-        for (uint64_t gi = g0; gi < g1; ++gi) {
-            for (uint64_t x = spec->group_path_off[gi]; x < spec->group_path_off[gi + 1]; ++x) {
-                if (spec->group_path[x] >= N) {
-                    setError("rpvg_hip_groups_build: matrix %u group path %u >= %llu", m, spec->group_path[x],
-                             static_cast<unsigned long long>(N));
-                    delete g;
-                    return RPVG_HIP_ERR_INVALID;
-                }
-                ++deg[spec->group_path[x]];
-            }
-        }
-        inc_off[m] = path_grp_off.size();
-        const uint64_t base = path_grp.size();
-        uint64_t run = base;
-        for (uint64_t p = 0; p < N; ++p) {
-            path_grp_off.push_back(run);
-            run += deg[p];
-        }
-        path_grp_off.push_back(run);
-        path_grp.resize(run);
-        std::vector<uint64_t> cursor(path_grp_off.begin() + inc_off[m], path_grp_off.begin() + inc_off[m] + N);
-        for (uint64_t gi = g0; gi < g1; ++gi) {
-            for (uint64_t x = spec->group_path_off[gi]; x < spec->group_path_off[gi + 1]; ++x) {
-                path_grp[cursor[spec->group_path[x]]++] = static_cast<uint32_t>(gi - g0);
-            }
+        inc_total += N + 1;
+        for (uint64_t c = 0; c * 256 < R; ++c) {
+            item_matrix.push_back(m);
+            item_chunk.push_back(static_cast<uint32_t>(c));
         }
     }
     g->h_num_cols = cols;
@@ -192,21 +223,17 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         *groups_out = g;
         return RPVG_HIP_OK;
     }
+    const uint64_t num_columns = spec->group_off[M];
+    const uint64_t num_incidences = spec->group_path_off[num_columns];
 
     scope_host.reset();
     HostScope scope_dev("groups_build: upload + kernels + sync");
     std::lock_guard<std::mutex> lock(ctx->mutex);
     hipError_t e = hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    DeviceBuffer<uint64_t> d_inc_off, d_path_grp_off;
-    DeviceBuffer<uint32_t> d_path_grp, d_item_matrix, d_item_chunk;
-    std::vector<uint32_t> item_matrix, item_chunk;
-    for (uint32_t m = 0; m < M; ++m) {
-        for (uint64_t c = 0; c * 256 < rows[m]; ++c) {
-            item_matrix.push_back(m);
-            item_chunk.push_back(static_cast<uint32_t>(c));
-        }
-    }
+    DeviceBuffer<uint64_t> d_inc_off, d_path_grp_off, d_group_off, d_group_path_off, d_num_paths;
+    DeviceBuffer<uint32_t> d_path_grp, d_item_matrix, d_item_chunk, d_group_path, d_degree, d_cursor, d_error;
+    DeviceBuffer<unsigned char> d_scan_tmp;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     int span = ctx->spanBegin(FAM_H2D);
     ok(g->mat_val_off.upload(val_off.data(), M, st));
@@ -215,27 +242,55 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     ok(g->mat_rows.upload(rows.data(), M, st));
     ok(g->mat_cols.upload(cols.data(), M, st));
     ok(d_inc_off.upload(inc_off.data(), M, st));
-    ok(d_path_grp_off.upload(path_grp_off.data(), path_grp_off.size(), st));
-    ok(d_path_grp.upload(path_grp.data(), path_grp.size(), st));
+    ok(d_num_paths.upload(num_paths.data(), M, st));
+    ok(d_group_off.upload(spec->group_off, M + 1, st));
+    ok(d_group_path_off.upload(spec->group_path_off, num_columns + 1, st));
+    ok(d_group_path.upload(spec->group_path, num_incidences, st));
     ok(d_item_matrix.upload(item_matrix.data(), item_matrix.size(), st));
     ok(d_item_chunk.upload(item_chunk.data(), item_chunk.size(), st));
     ctx->spanEnd(span);
-    ctx->stats.h2d_bytes += static_cast<double>(M * 44 + path_grp_off.size() * 8 + path_grp.size() * 4);
+    ctx->stats.h2d_bytes += static_cast<double>(M * 60 + num_columns * 8 + num_incidences * 4 + item_matrix.size() * 8);
     ok(g->values.alloc(val_total));
     ok(g->rowmax.alloc(row_total));
+    ok(d_degree.alloc(inc_total));
+    ok(d_cursor.alloc(inc_total));
+    ok(d_path_grp_off.alloc(inc_total));
+    ok(d_path_grp.alloc(num_incidences));
+    ok(d_error.alloc(1));
+    size_t scan_bytes = 0;
+    if (e == hipSuccess) ok(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_degree.ptr, d_path_grp_off.ptr, static_cast<int>(inc_total), st));
+    ok(d_scan_tmp.alloc(scan_bytes));
+    if (e == hipSuccess && inc_total > 0x7fffffffull) e = hipErrorInvalidValue;
     if (e == hipSuccess) {
         span = ctx->spanBegin(FAM_BUILD);
+        ok(hipMemsetAsync(d_degree.ptr, 0, inc_total * sizeof(uint32_t), st));
+        ok(hipMemsetAsync(d_cursor.ptr, 0, inc_total * sizeof(uint32_t), st));
+        ok(hipMemsetAsync(d_error.ptr, 0, sizeof(uint32_t), st));
         ok(hipMemsetAsync(g->values.ptr, 0, val_total * sizeof(double), st));
+        const uint32_t col_blocks = static_cast<uint32_t>((num_columns + 255) / 256);
+        incidenceCountKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,
+                                                                   d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
+                                                                   d_degree.ptr, d_error.ptr);
+        ok(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.ptr, scan_bytes, d_degree.ptr, d_path_grp_off.ptr, static_cast<int>(inc_total), st));
+        incidenceFillKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,
+                                                                  d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
+                                                                  d_path_grp_off.ptr, d_cursor.ptr, d_path_grp.ptr);
         groupsBuildKernel<<<dim3(static_cast<uint32_t>(item_matrix.size())), dim3(256), 0, st>>>(
-            static_cast<uint32_t>(item_matrix.size()), d_item_matrix.ptr, d_item_chunk.ptr, g->mat_val_off.ptr, g->mat_row_off.ptr, g->mat_row0.ptr,
-                                                       g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
-                                                       d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr,
-                                                       batch->ent_prob.ptr, batch->row_noise.ptr, spec->normalise ? 1 : 0,
-                                                       g->values.ptr, g->rowmax.ptr);
+            static_cast<uint32_t>(item_matrix.size()), d_item_matrix.ptr, d_item_chunk.ptr, g->mat_val_off.ptr,
+            g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
+            d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
+            spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr);
         ctx->spanEnd(span);
-        ctx->stats.build_launches += 1;
+        ctx->stats.build_launches += 3;
         ok(hipGetLastError());
-        ok(hipStreamSynchronize(st));  // incidence temporaries are freed on return
+        uint32_t bad = 0;
+        ok(hipMemcpyAsync(&bad, d_error.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        ok(hipStreamSynchronize(st));  // incidence temporaries are released on return
+        if (e == hipSuccess && bad) {
+            setError("rpvg_hip_groups_build: a group refers to a path outside its cluster");
+            delete g;
+            return RPVG_HIP_ERR_INVALID;
+        }
     }
     if (e != hipSuccess) {
         setError("rpvg_hip_groups_build: %s", hipGetErrorString(e));

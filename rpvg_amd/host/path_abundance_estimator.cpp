@@ -131,10 +131,9 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
 
     requireNoGibbsSamples();
 
-    if (use_group_post_gibbs) {
+    if (use_group_post_gibbs && !rngs) {
 
-        // estimatePathGroupPosteriorsGibbs (src/path_estimator.cpp:475-589) is not on the GPU yet
-        throw EngineError("Gibbs haplotype posteriors (--use-hap-gibbs) are not available in the GPU engine yet");
+        throw EngineError("Gibbs haplotype posteriors draw random numbers: a generator per cluster is required");
     }
 
     assert(path_cluster_estimates->size() == cluster_batch.numClusters());
@@ -189,7 +188,7 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
         groups_phase.reset();
 
         std::vector<GroupPosteriors> group_posteriors;
-        pathGroupPosteriors(&group_posteriors, cluster_batch, problems);
+        pathGroupPosteriors(&group_posteriors, cluster_batch, problems, rngs);
 
         std::unique_ptr<ScopedPhase> select_phase(new ScopedPhase("nested: selectPathSubsetIndices"));
 
@@ -245,7 +244,7 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
         }
 
         std::vector<GroupPosteriors> group_posteriors;
-        pathGroupPosteriors(&group_posteriors, cluster_batch, problems);
+        pathGroupPosteriors(&group_posteriors, cluster_batch, problems, rngs);
 
         for (size_t i = 0; i < clusters.size(); ++i) {
 
@@ -275,9 +274,24 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
     }
 }
 
-void NestedPathAbundanceEstimator::pathGroupPosteriors(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems) const {
+void NestedPathAbundanceEstimator::pathGroupPosteriors(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, std::vector<std::mt19937> * rngs) const {
 
-    if (group_size == 2) {
+    if (use_group_post_gibbs) {
+
+        // With collapsed groups (one problem per cluster) every problem consumes its cluster's generator exactly
+        // as the reference does.  With independent groups the reference interleaves Gibbs draws of one
+        // transcript with the subset sampling of the previous one (src/path_abundance_estimator.cpp:380-407);
+        // here all posteriors of a batch come first, so that combination agrees statistically, not draw by draw.
+        std::vector<std::mt19937 *> problem_rngs;
+
+        for (auto & problem: problems) {
+
+            problem_rngs.emplace_back(&rngs->at(problem.cluster));
+        }
+
+        estimatePathGroupPosteriorsGibbs(group_posteriors, cluster_batch, problems, group_size, true, problem_rngs);
+
+    } else if (group_size == 2) {
 
         calculatePathGroupPosteriorsBounded(group_posteriors, cluster_batch, problems, group_size, min_hap_prob, true);
 
@@ -315,44 +329,81 @@ std::vector<std::vector<uint32_t> > NestedPathAbundanceEstimator::findPathGroups
 // order of their smallest source id (the reference's order is that of its hash map).
 void NestedPathAbundanceEstimator::findPathSourceGroups(GroupPosteriorProblem * problem, const std::vector<PathInfo> & paths) const {
 
-    // (source id, path) incidences, grouped by source id with paths ascending
-    std::vector<std::pair<uint32_t, uint32_t> > source_paths;
+    // (source id, path) incidences as one sortable key each: grouped by source id, paths ascending
+    std::vector<uint64_t> source_paths;
 
     for (size_t i = 0; i < paths.size(); ++i) {
 
         for (auto & id: paths.at(i).source_ids) {
 
-            source_paths.emplace_back(id, i);
+            source_paths.emplace_back((static_cast<uint64_t>(id) << 32) | i);
         }
     }
 
     std::sort(source_paths.begin(), source_paths.end());
 
-    std::map<std::vector<uint32_t>, uint32_t> group_index;
-    std::vector<uint32_t> path_list;
+    // every run of one source id is that haplotype's path list; identical lists are found through a
+    // small open-addressing table keyed by a hash of the list (column = first haplotype with the list)
+    size_t table_size = 16;
+
+    while (table_size < 2 * paths.size() + 16 && table_size < 4 * source_paths.size() + 16) {
+
+        table_size <<= 1;
+    }
+
+    std::vector<int32_t> table(table_size, -1);
+    std::vector<uint64_t> column_hash;
 
     size_t run_begin = 0;
 
     while (run_begin < source_paths.size()) {
 
         size_t run_end = run_begin;
-        path_list.clear();
+        uint64_t hash = 1469598103934665603ull;
 
-        while (run_end < source_paths.size() && source_paths.at(run_end).first == source_paths.at(run_begin).first) {
+        while (run_end < source_paths.size() && (source_paths[run_end] >> 32) == (source_paths[run_begin] >> 32)) {
 
-            path_list.emplace_back(source_paths.at(run_end).second);
+            hash = (hash ^ (source_paths[run_end] & 0xFFFFFFFFull)) * 1099511628211ull;
             ++run_end;
         }
 
-        auto group_index_it = group_index.emplace(path_list, problem->numColumns());
+        const size_t run_length = run_end - run_begin;
+        size_t slot = hash & (table_size - 1);
 
-        if (group_index_it.second) {
+        while (true) {
 
-            problem->addColumn(path_list.data(), path_list.data() + path_list.size(), 1);
+            const int32_t column = table[slot];
 
-        } else {
+            if (column < 0) {
 
-            problem->column_counts.at(group_index_it.first->second)++;
+                table[slot] = problem->numColumns();
+                column_hash.emplace_back(hash);
+
+                problem->column_counts.emplace_back(1);
+
+                for (size_t j = run_begin; j < run_end; ++j) {
+
+                    problem->column_path.emplace_back(static_cast<uint32_t>(source_paths[j] & 0xFFFFFFFFull));
+                }
+
+                problem->column_path_off.emplace_back(problem->column_path.size());
+                break;
+            }
+
+            bool identical = (column_hash[column] == hash) && (problem->column_path_off[column + 1] - problem->column_path_off[column] == run_length);
+
+            for (size_t j = 0; identical && j < run_length; ++j) {
+
+                identical = (problem->column_path[problem->column_path_off[column] + j] == static_cast<uint32_t>(source_paths[run_begin + j] & 0xFFFFFFFFull));
+            }
+
+            if (identical) {
+
+                problem->column_counts[column]++;
+                break;
+            }
+
+            slot = (slot + 1) & (table_size - 1);
         }
 
         run_begin = run_end;

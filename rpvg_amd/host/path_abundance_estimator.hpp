@@ -62,7 +62,7 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
         NestedPathAbundanceEstimator(const uint32_t group_size_in, const double min_hap_prob_in, const bool infer_collapsed_in, const bool use_group_post_gibbs_in, const uint32_t max_em_its, const double max_rel_em_conv, const uint32_t num_gibbs_samples, const uint32_t gibbs_thin_its, const double prob_precision, std::shared_ptr<HipEngine> engine);
         ~NestedPathAbundanceEstimator() {};
 
-        bool usesRandomNumbers() const { return !infer_collapsed; }
+        bool usesRandomNumbers() const { return !infer_collapsed || use_group_post_gibbs; }
 
         void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs);
 
@@ -80,7 +80,7 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
         std::vector<std::vector<uint32_t> > findPathGroups(const std::vector<PathInfo> & paths) const;
         void findPathSourceGroups(GroupPosteriorProblem * problem, const std::vector<PathInfo> & paths) const;
 
-        void pathGroupPosteriors(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems) const;
+        void pathGroupPosteriors(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, std::vector<std::mt19937> * rngs) const;
 
         void sampleGroupPathIndices(std::vector<std::vector<uint32_t> > * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<uint32_t> & group, std::mt19937 * mt_rng) const;
         void selectPathSubsetIndices(PathSubsetWeights * path_subset_samples, const GroupPosteriors & group_posteriors, const GroupPosteriorProblem & problem) const;

@@ -7,6 +7,7 @@
 #include <functional>
 #include <memory>
 #include <numeric>
+#include <unordered_map>
 
 #include "numeric_utils.hpp"
 #include "trace.hpp"
@@ -113,6 +114,150 @@ class GroupMatrices {
 
         const std::shared_ptr<HipEngine> engine;
         rpvg_hip_groups * groups;
+};
+
+// src/path_estimator.cpp:3-11
+const uint32_t min_gibbs_chains = 10;
+const double gibbs_chain_scaling = 0.01;
+const uint32_t min_burn_it = 50;
+const double burn_it_scaling = 0.025;
+const uint32_t min_gibbs_it = 100;
+const double gibbs_it_scaling = 0.05;
+
+struct GroupSetHash {
+
+    size_t operator()(const std::vector<uint32_t> & group_set) const {
+
+        size_t seed = 0;
+
+        for (auto & value: group_set) {
+
+            seed ^= std::hash<uint32_t>()(value) + 0x9e3779b9 + (seed << 6) + (seed >> 2);
+        }
+
+        return seed;
+    }
+};
+
+// One problem's Gibbs sampler, resumable at the point where it needs a conditional
+// distribution that has not been evaluated yet.
+struct GibbsSampler {
+
+    uint32_t num_columns = 0;
+    uint32_t group_size = 0;
+
+    std::mt19937 * mt_rng = nullptr;
+    std::vector<double> log_freqs;
+
+    uint32_t num_chains = 0;
+    uint32_t num_burn_its = 0;
+    uint32_t num_gibbs_its = 0;
+
+    uint32_t chain = 0;
+    uint32_t iteration = 0;
+    uint32_t slot = 0;
+    bool chain_started = false;
+    bool done = false;
+
+    std::vector<uint32_t> cur_sampled_group_paths;
+
+    std::unordered_map<std::vector<uint32_t>, std::discrete_distribution<uint32_t>, GroupSetHash> sampler_cache;
+    std::unordered_map<std::vector<uint32_t>, uint32_t, GroupSetHash> group_set_indices;
+
+    std::vector<uint32_t> sampled_members;
+    std::vector<uint32_t> sample_counts;
+
+    // the conditional the sampler is waiting for: the other slots' paths, in slot order
+    bool waiting = false;
+    std::vector<uint32_t> pending_key;
+    std::vector<uint32_t> pending_others;
+
+    // Runs until the sampler is done or needs a conditional that is not cached.
+    void advance() {
+
+        std::uniform_int_distribution<uint32_t> init_path_sampler(0, num_columns - 1);
+
+        while (!done) {
+
+            if (!chain_started) {
+
+                cur_sampled_group_paths.clear();
+
+                for (uint32_t i = 0; i < group_size; ++i) {
+
+                    cur_sampled_group_paths.emplace_back(init_path_sampler(*mt_rng));
+                }
+
+                chain_started = true;
+                iteration = 0;
+                slot = 0;
+            }
+
+            std::vector<uint32_t> key = cur_sampled_group_paths;
+            key.at(slot) = num_columns;
+            std::sort(key.begin(), key.end());
+
+            auto sampler_cache_it = sampler_cache.find(key);
+
+            if (sampler_cache_it == sampler_cache.end()) {
+
+                waiting = true;
+                pending_key = key;
+                pending_others.clear();
+
+                for (uint32_t k = 0; k < group_size; ++k) {
+
+                    if (k != slot) {
+
+                        pending_others.emplace_back(cur_sampled_group_paths.at(k));
+                    }
+                }
+
+                return;
+            }
+
+            cur_sampled_group_paths.at(slot) = sampler_cache_it->second(*mt_rng);
+            ++slot;
+
+            if (slot < group_size) {
+
+                continue;
+            }
+
+            slot = 0;
+
+            if (iteration >= num_burn_its) {
+
+                std::vector<uint32_t> sorted_group = cur_sampled_group_paths;
+                std::sort(sorted_group.begin(), sorted_group.end());
+
+                auto group_set_indices_it = group_set_indices.emplace(sorted_group, sample_counts.size());
+
+                if (group_set_indices_it.second) {
+
+                    sampled_members.insert(sampled_members.end(), sorted_group.begin(), sorted_group.end());
+                    sample_counts.emplace_back(1);
+
+                } else {
+
+                    sample_counts.at(group_set_indices_it.first->second)++;
+                }
+            }
+
+            ++iteration;
+
+            if (iteration == num_burn_its + num_gibbs_its) {
+
+                chain_started = false;
+                ++chain;
+
+                if (chain == num_chains) {
+
+                    done = true;
+                }
+            }
+        }
+    }
 };
 
 // Branch-and-bound state of one diploid posterior problem.
@@ -346,6 +491,144 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
 
     ScopedPhase free_phase("posteriors: pair result free");
     rpvg_hip_pair_posteriors_free(pair_posteriors);
+}
+
+void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const bool normalise, const std::vector<std::mt19937 *> & rngs) const {
+
+    assert(group_size > 0);
+    assert(rngs.size() == problems.size());
+
+    if (group_size > 4) {
+
+        throw EngineError("estimatePathGroupPosteriorsGibbs: group sizes above 4 are not supported by the GPU log-likelihood kernel");
+    }
+
+    group_posteriors->assign(problems.size(), GroupPosteriors());
+
+    if (problems.empty()) {
+
+        return;
+    }
+
+    const GroupMatrices matrices(engine, cluster_batch, problems, normalise);
+
+    std::vector<GibbsSampler> samplers(problems.size());
+
+    std::vector<std::vector<size_t> > generator_problems;
+    std::unordered_map<std::mt19937 *, size_t> generator_index;
+
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        auto generator_index_it = generator_index.emplace(rngs.at(i), generator_problems.size());
+
+        if (generator_index_it.second) {
+
+            generator_problems.emplace_back();
+        }
+
+        generator_problems.at(generator_index_it.first->second).emplace_back(i);
+    }
+
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        auto & sampler = samplers.at(i);
+
+        sampler.num_columns = problems.at(i).numColumns();
+        sampler.group_size = group_size;
+        sampler.mt_rng = rngs.at(i);
+        sampler.log_freqs = calcPathLogFrequences(problems.at(i).column_counts);
+
+        // src/path_estimator.cpp:501-503
+        sampler.num_chains = min_gibbs_chains + std::round(gibbs_chain_scaling * group_size * sampler.num_columns);
+        sampler.num_burn_its = min_burn_it + std::round(burn_it_scaling * group_size * sampler.num_columns);
+        sampler.num_gibbs_its = min_gibbs_it + std::round(gibbs_it_scaling * group_size * sampler.num_columns);
+
+        sampler.advance();
+    }
+
+    // rounds: one device call evaluates the conditional every waiting sampler asked for
+    while (true) {
+
+        std::vector<uint32_t> request_matrix;
+        std::vector<uint32_t> request_members;
+        std::vector<size_t> first_request(problems.size() + 1, 0);
+
+        for (size_t i = 0; i < problems.size(); ++i) {
+
+            auto & sampler = samplers.at(i);
+
+            if (sampler.waiting) {
+
+                for (uint32_t k = 0; k < sampler.num_columns; ++k) {
+
+                    request_matrix.emplace_back(i);
+                    request_members.insert(request_members.end(), sampler.pending_others.begin(), sampler.pending_others.end());
+                    request_members.emplace_back(k);
+                }
+            }
+
+            first_request.at(i + 1) = request_matrix.size();
+        }
+
+        if (request_matrix.empty()) {
+
+            break;
+        }
+
+        std::vector<double> log_likelihoods;
+        matrices.logLikelihoods(&log_likelihoods, request_matrix, request_members, group_size, group_size, false);
+
+        // problems that share a generator (transcripts of one cluster) are advanced one after the other
+        #pragma omp parallel for schedule(dynamic, 4) num_threads(hostThreads())
+        for (size_t generator_idx = 0; generator_idx < generator_problems.size(); ++generator_idx) {
+        for (auto & i: generator_problems.at(generator_idx)) {
+
+            auto & sampler = samplers.at(i);
+
+            if (!sampler.waiting) {
+
+                continue;
+            }
+
+            // src/path_estimator.cpp:537-555
+            std::vector<double> group_probs(sampler.num_columns);
+            double sum_log_group_probs = numeric::log_zero;
+
+            for (uint32_t k = 0; k < sampler.num_columns; ++k) {
+
+                group_probs.at(k) = log_likelihoods.at(first_request.at(i) + k) + sampler.log_freqs.at(k);
+                sum_log_group_probs = numeric::add_log(sum_log_group_probs, group_probs.at(k));
+            }
+
+            for (auto & prob: group_probs) {
+
+                prob = std::exp(prob - sum_log_group_probs);
+            }
+
+            sampler.sampler_cache.emplace(sampler.pending_key, std::discrete_distribution<uint32_t>(group_probs.begin(), group_probs.end()));
+            sampler.waiting = false;
+
+            sampler.advance();
+        }
+        }
+    }
+
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        auto & sampler = samplers.at(i);
+        auto & result = group_posteriors->at(i);
+
+        assert(sampler.done);
+
+        result.group_size = group_size;
+        result.members = std::move(sampler.sampled_members);
+        result.posteriors.reserve(sampler.sample_counts.size());
+
+        for (auto & sample_count: sampler.sample_counts) {
+
+            result.posteriors.emplace_back(sample_count / static_cast<double>(sampler.num_chains * sampler.num_gibbs_its));
+        }
+    }
 }
 
 void PathEstimator::calculatePathGroupPosteriorsBoundedHostDriven(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const double min_rel_likelihood, const bool normalise) const {

@@ -98,6 +98,13 @@ class PathEstimator {
         // the reference's sequential order (rpvg_hip_bounded_pair_posteriors).
         void calculatePathGroupPosteriorsBounded(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const double min_rel_likelihood, const bool normalise) const;
 
+        // estimatePathGroupPosteriorsGibbs (src/path_estimator.cpp:475-589) for many problems at once.  The
+        // chains run on the host with the reference's generator and distributions (so a problem consumes its
+        // generator exactly as the reference would); every conditional a chain has not seen yet — N
+        // log-likelihood contractions — is evaluated on the GPU, all problems advancing in lock-step so that
+        // one device call serves the pending conditionals of every problem.  rngs.at(i) drives problem i.
+        void estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const bool normalise, const std::vector<std::mt19937 *> & rngs) const;
+
         // The same search driven from the host: pair log-likelihoods are fetched from the
         // GPU a block of first paths at a time and the reference's sequential pruning is
         // replayed on them here.  Kept as the cross-check of the on-device search

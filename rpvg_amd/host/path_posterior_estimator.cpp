@@ -67,10 +67,9 @@ PathGroupPosteriorEstimator::PathGroupPosteriorEstimator(const uint32_t group_si
 // src/path_posterior_estimator.cpp:35-71 over a batch of clusters.
 void PathGroupPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs) {
 
-    if (use_group_post_gibbs) {
+    if (use_group_post_gibbs && !rngs) {
 
-        // estimatePathGroupPosteriorsGibbs (src/path_estimator.cpp:475-589) is not on the GPU yet
-        throw EngineError("Gibbs haplotype posteriors (--use-hap-gibbs) are not available in the GPU engine yet");
+        throw EngineError("Gibbs haplotype posteriors draw random numbers: a generator per cluster is required");
     }
 
     assert(path_cluster_estimates->size() == cluster_batch.numClusters());
@@ -83,7 +82,18 @@ void PathGroupPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates
     const auto problems = rawPathProblems(*path_cluster_estimates, cluster_batch);
     std::vector<GroupPosteriors> group_posteriors;
 
-    if (group_size == 2) {
+    if (use_group_post_gibbs) {
+
+        std::vector<std::mt19937 *> problem_rngs;
+
+        for (auto & problem: problems) {
+
+            problem_rngs.emplace_back(&rngs->at(problem.cluster));
+        }
+
+        estimatePathGroupPosteriorsGibbs(&group_posteriors, cluster_batch, problems, group_size, false, problem_rngs);
+
+    } else if (group_size == 2) {
 
         calculatePathGroupPosteriorsBounded(&group_posteriors, cluster_batch, problems, group_size, min_rel_likelihood, false);
 
@@ -107,7 +117,7 @@ void PathGroupPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates
 
         estimates.posteriors = std::move(group_posteriors.at(i).posteriors);
 
-        if (group_size != 2) {
+        if (group_size != 2 && !use_group_post_gibbs) {
 
             // the Full routine leaves zero-filled abundances behind (resetEstimates(n, g), src/path_estimator.cpp:343)
             estimates.abundances.assign(estimates.path_group_sets.size() * group_size, 0);

@@ -35,6 +35,8 @@ class PathGroupPosteriorEstimator : public PathPosteriorEstimator {
         PathGroupPosteriorEstimator(const uint32_t group_size_in, const bool use_group_post_gibbs_in, const double prob_precision, std::shared_ptr<HipEngine> engine);
         ~PathGroupPosteriorEstimator() {};
 
+        bool usesRandomNumbers() const { return use_group_post_gibbs; }
+
         void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs);
 
     private:

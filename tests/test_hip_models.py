@@ -137,8 +137,6 @@ def test_unsupported_modes_fail_loudly(engine):
     with pytest.raises(hip.EngineError):
         engine.run("transcripts", make_params(num_gibbs_samples=5), prep)
     with pytest.raises(hip.EngineError):
-        engine.run("haplotypes", make_params(use_hap_gibbs=1), prep)
-    with pytest.raises(hip.EngineError):
         engine.run("strains", make_params(), prep)
     with pytest.raises(hip.EngineError):
         engine.run("no-such-model", make_params(), prep)
@@ -189,3 +187,40 @@ def test_independent_haplotype_inference_matches_oracle(engine):
     # the drop-in estimate() consumes the caller's generator the same way
     got1, _ = engine.run("haplotype-transcripts", params, engine.prepare(batch, per_cluster=True))
     _compare(got1, ref)
+
+
+@pytest.mark.parametrize("model", ["haplotypes", "haplotype-transcripts"])
+@pytest.mark.parametrize("ploidy", [1, 2])
+def test_gibbs_haplotype_posteriors_follow_the_reference_stream(engine, model, ploidy):
+    """--use-hap-gibbs (src/path_estimator.cpp:475-589): chains on the host with the reference's mt19937 and
+    discrete_distribution, conditionals on the GPU.  Same libstdc++ streams as the oracle, so the sampled
+    group sets and their frequencies agree draw for draw (a conditional differing in the last bits could
+    flip a draw; none does on these inputs)."""
+    clusters = small_cases.make_batch_clusters(691, n_clusters=8)
+    batch = ClusterBatch.from_clusters(clusters)
+    params = make_params(use_hap_gibbs=1, ploidy=ploidy, rng_seed=11)
+    ref, _ = pyoracle.run(model, params, batch, 1)
+    got, _ = engine.run(model, params, engine.prepare(batch))
+    _compare(got, ref)
+    for g, r in zip(got, ref):
+        if model == "haplotypes":
+            assert g.path_group_sets == r.path_group_sets  # first-seen order of the sampled sets
+            assert abs(g.posteriors.sum() - (1.0 if r.path_group_sets else 0.0)) < 1e-12
+    got1, _ = engine.run(model, params, engine.prepare(batch, per_cluster=True))
+    _compare(got1, ref)
+
+
+def test_gibbs_posteriors_agree_with_exact_posteriors_statistically(engine):
+    """Size-independent property: the Gibbs frequencies of the dominant diplotypes approach the exact
+    (branch-and-bound) posteriors."""
+    rng = np.random.default_rng(693)
+    clusters = [small_cases.make_cluster(rng, 1, [4], n_haps=6, n_reads=40) for _ in range(6)]
+    batch = ClusterBatch.from_clusters(clusters)
+    exact, _ = engine.run("haplotypes", make_params(), engine.prepare(batch))
+    gibbs, _ = engine.run("haplotypes", make_params(use_hap_gibbs=1, rng_seed=3), engine.prepare(batch))
+    for e, g in zip(exact, gibbs):
+        ek = {tuple(sorted(k)): v[0] for k, v in e.keyed().items()}
+        gk = {tuple(sorted(k)): v[0] for k, v in g.keyed().items()}
+        for key, p in ek.items():
+            if p > 0.2:
+                assert abs(gk.get(key, 0.0) - p) < 0.08, (key, p, gk.get(key))
