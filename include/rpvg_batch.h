@@ -101,6 +101,17 @@ typedef struct rpvg_estimates_view {
     const uint32_t * em_iters;    /* [E]   */
     const uint64_t * em_col_off;  /* [E+1] */
     const uint32_t * em_cols;     /* [..]  */
+    /* PathClusterEstimates::gibbs_read_count_samples (-n > 0): cluster k owns CountSamples
+     * [gibbs_off[k], gibbs_off[k+1]); CountSamples g has path_ids [gibbs_path_off[g], ..+1),
+     * noise_samples [gibbs_noise_off[g], ..+1) and abundance_samples (sample-major)
+     * [gibbs_abund_off[g], ..+1)  (src/path_cluster_estimates.hpp:35-43). */
+    const uint64_t * gibbs_off;        /* [K+1] */
+    const uint64_t * gibbs_path_off;   /* [Gs+1] */
+    const uint32_t * gibbs_path;
+    const uint64_t * gibbs_noise_off;  /* [Gs+1] */
+    const double * gibbs_noise;
+    const uint64_t * gibbs_abund_off;  /* [Gs+1] */
+    const double * gibbs_abund;
 } rpvg_estimates_view;
 
 #ifdef __cplusplus

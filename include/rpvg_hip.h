@@ -100,6 +100,18 @@ typedef struct rpvg_hip_em_results {
 int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t max_em_its, double max_rel_em_conv,
                       const rpvg_hip_em_problems * problems, rpvg_hip_em_results * results);
 
+/* gibbsReadCountSampler (src/path_abundance_estimator.cpp:116-212) for a batch of EM problems, on the GPU.
+ * Problem p starts from its EM estimate (init_abundances laid out like col_path, in expected read counts,
+ * plus init_noise_count[p]) and records num_samples[p] states, one every gibbs_thin_its iterations.
+ * Random numbers come from the counter-based Philox4x32-10 generator keyed by seeds[p]: the reference's
+ * mt19937 / libstdc++ distribution streams cannot be reproduced on a GPU, parity is statistical.
+ * noise_samples: [sum num_samples]; abundance_samples: per problem num_samples[p] x columns, sample-major
+ * (the layout of CountSamples::abundance_samples, src/path_cluster_estimates.hpp:35-43). */
+int rpvg_hip_gibbs_read_counts(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_em_problems * problems,
+                               const double * init_abundances, const double * init_noise_count,
+                               const uint32_t * num_samples, const uint64_t * seeds, uint32_t gibbs_thin_its,
+                               double gamma, double * noise_samples, double * abundance_samples);
+
 /* Same EM on a dense matrix that is already resident on the GPU: row-major,
  * `ld` doubles between rows (ld even), columns [0, C-1) = paths and column
  * C-1 = noise, already normalised; counts = read count per row.  Used for

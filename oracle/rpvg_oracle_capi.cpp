@@ -25,6 +25,9 @@ struct FlatResult {
     std::vector<uint64_t> set_off, member_off, abund_off, em_off, em_col_off;
     std::vector<uint32_t> members, em_iters, em_cols;
     std::vector<double> posteriors, abundances, noise_count, total_count;
+    std::vector<uint64_t> gibbs_off, gibbs_path_off, gibbs_noise_off, gibbs_abund_off;
+    std::vector<uint32_t> gibbs_path;
+    std::vector<double> gibbs_noise, gibbs_abund;
 };
 
 std::vector<ReadRow> unpackRows(const rpvg_cluster_batch * b, uint32_t k) {
@@ -107,8 +110,21 @@ void * rpvg_oracle_run(const char * model, const rpvg_params * params, const rpv
     res->abund_off.push_back(0);
     res->em_off.push_back(0);
     res->em_col_off.push_back(0);
+    res->gibbs_off.push_back(0);
+    res->gibbs_path_off.push_back(0);
+    res->gibbs_noise_off.push_back(0);
+    res->gibbs_abund_off.push_back(0);
     for (uint32_t k = 0; k < K; ++k) {
         const Estimates & e = ests[k];
+        for (auto & cs : e.gibbs_read_count_samples) {
+            res->gibbs_path.insert(res->gibbs_path.end(), cs.path_ids.begin(), cs.path_ids.end());
+            res->gibbs_path_off.push_back(res->gibbs_path.size());
+            res->gibbs_noise.insert(res->gibbs_noise.end(), cs.noise_samples.begin(), cs.noise_samples.end());
+            res->gibbs_noise_off.push_back(res->gibbs_noise.size());
+            res->gibbs_abund.insert(res->gibbs_abund.end(), cs.abundance_samples.begin(), cs.abundance_samples.end());
+            res->gibbs_abund_off.push_back(res->gibbs_abund.size());
+        }
+        res->gibbs_off.push_back(res->gibbs_path_off.size() - 1);
         for (size_t s = 0; s < e.path_group_sets.size(); ++s) {
             res->members.insert(res->members.end(), e.path_group_sets[s].begin(), e.path_group_sets[s].end());
             res->member_off.push_back(res->members.size());
@@ -144,6 +160,13 @@ void rpvg_oracle_view(void * handle, rpvg_estimates_view * out) {
     out->em_iters = r->em_iters.data();
     out->em_col_off = r->em_col_off.data();
     out->em_cols = r->em_cols.data();
+    out->gibbs_off = r->gibbs_off.data();
+    out->gibbs_path_off = r->gibbs_path_off.data();
+    out->gibbs_path = r->gibbs_path.data();
+    out->gibbs_noise_off = r->gibbs_noise_off.data();
+    out->gibbs_noise = r->gibbs_noise.data();
+    out->gibbs_abund_off = r->gibbs_abund_off.data();
+    out->gibbs_abund = r->gibbs_abund.data();
 }
 
 void rpvg_oracle_free(void * handle) { delete static_cast<FlatResult *>(handle); }

@@ -71,6 +71,13 @@ class CEstimatesView(C.Structure):
         ("em_iters", u32p),
         ("em_col_off", u64p),
         ("em_cols", u32p),
+        ("gibbs_off", u64p),
+        ("gibbs_path_off", u64p),
+        ("gibbs_path", u32p),
+        ("gibbs_noise_off", u64p),
+        ("gibbs_noise", f64p),
+        ("gibbs_abund_off", u64p),
+        ("gibbs_abund", f64p),
     ]
 
 
@@ -227,6 +234,8 @@ class ClusterEstimates:
     total_count: float
     em_iters: List[int] = field(default_factory=list)
     em_cols: List[Tuple[int, ...]] = field(default_factory=list)
+    # CountSamples of the cluster (-n > 0): [(path_ids, noise_samples[n], abundance_samples[n, len(path_ids)])...]
+    gibbs_samples: List[Tuple[Tuple[int, ...], np.ndarray, np.ndarray]] = field(default_factory=list)
 
     def keyed(self) -> Dict[Tuple[int, ...], Tuple[float, Tuple[float, ...]]]:
         """{group set -> (posterior, abundances of its members)} — order-free view.
@@ -272,12 +281,27 @@ def decode_view(view: CEstimatesView) -> List[ClusterEstimates]:
     em_iters = arr(view.em_iters, E, np.uint32)
     em_col_off = arr(view.em_col_off, E + 1, np.uint64).astype(np.int64)
     em_cols = arr(view.em_cols, int(em_col_off[-1]), np.uint32)
+    g_off = arr(view.gibbs_off, K + 1, np.uint64).astype(np.int64)
+    Gs = int(g_off[-1])
+    gp_off = arr(view.gibbs_path_off, Gs + 1, np.uint64).astype(np.int64)
+    gn_off = arr(view.gibbs_noise_off, Gs + 1, np.uint64).astype(np.int64)
+    ga_off = arr(view.gibbs_abund_off, Gs + 1, np.uint64).astype(np.int64)
+    g_path = arr(view.gibbs_path, int(gp_off[-1]), np.uint32)
+    g_noise = arr(view.gibbs_noise, int(gn_off[-1]), np.float64)
+    g_abund = arr(view.gibbs_abund, int(ga_off[-1]), np.float64)
     out = []
     for k in range(K):
         sets = [tuple(int(x) for x in members[member_off[s]:member_off[s + 1]]) for s in range(set_off[k], set_off[k + 1])]
+        gibbs = []
+        for g in range(g_off[k], g_off[k + 1]):
+            ids = tuple(int(x) for x in g_path[gp_off[g]:gp_off[g + 1]])
+            ns = g_noise[gn_off[g]:gn_off[g + 1]].copy()
+            ab = g_abund[ga_off[g]:ga_off[g + 1]].copy().reshape(len(ns), len(ids)) if len(ids) else np.zeros((len(ns), 0))
+            gibbs.append((ids, ns, ab))
         out.append(ClusterEstimates(
             sets, post[set_off[k]:set_off[k + 1]].copy(), abund[abund_off[k]:abund_off[k + 1]].copy(),
             float(noise[k]), float(total[k]),
             [int(x) for x in em_iters[em_off[k]:em_off[k + 1]]],
-            [tuple(int(x) for x in em_cols[em_col_off[e]:em_col_off[e + 1]]) for e in range(em_off[k], em_off[k + 1])]))
+            [tuple(int(x) for x in em_cols[em_col_off[e]:em_col_off[e + 1]]) for e in range(em_off[k], em_off[k + 1])],
+            gibbs))
     return out

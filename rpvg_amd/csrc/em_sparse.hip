@@ -390,6 +390,360 @@ hipError_t launchEm(const EmLaunchArgs & args, size_t lds, hipStream_t stream) {
     return hipGetLastError();
 }
 
+
+// ---- Gibbs read-count sampler ----------------------------------------------------------
+//
+// gibbsReadCountSampler (src/path_abundance_estimator.cpp:116-212) for a batch of problems: per Gibbs
+// iteration every row's reads are split multinomially over its columns with probabilities
+// P_ij a_j / s_i (the reference draws the multinomial as a chain of binomials, :149-178), then every
+// component draws a_j ~ Gamma(count_j + gamma, 1) and the vector is renormalised (:182-190); every
+// `thin`-th state is recorded (:192-210).  ONE workgroup per problem runs all iterations.  The
+// reference's mt19937 / libstdc++ distribution streams cannot be reproduced on a GPU:
+// draws come from the counter-based Philox4x32-10 generator keyed by the problem's seed, so parity with
+// the reference is statistical.  Rows without any selected path put all their reads on the noise
+// component (their posterior there is exactly 1), as in the EM kernel.
+
+struct Philox {
+    uint32_t key[2];
+    uint32_t ctr[4];
+    uint32_t out[4];
+    int have;
+
+    __device__ __forceinline__ void init(const uint64_t seed, const uint32_t stream_hi, const uint32_t stream_lo) {
+        key[0] = static_cast<uint32_t>(seed);
+        key[1] = static_cast<uint32_t>(seed >> 32);
+        ctr[0] = 0;
+        ctr[1] = 0;
+        ctr[2] = stream_lo;
+        ctr[3] = stream_hi;
+        have = 0;
+    }
+
+    __device__ __forceinline__ void round(uint32_t (&c)[4], const uint32_t k0, const uint32_t k1) {
+        const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c[0];
+        const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c[2];
+        const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = static_cast<uint32_t>(p1);
+        const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = static_cast<uint32_t>(p0);
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+
+    __device__ __forceinline__ void refill() {
+        uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+        uint32_t k0 = key[0], k1 = key[1];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+        if (++ctr[0] == 0) ++ctr[1];
+        have = 4;
+    }
+
+    __device__ __forceinline__ uint32_t next() {
+        if (have == 0) refill();
+        return out[--have];
+    }
+
+    // uniform in (0, 1)
+    __device__ __forceinline__ double uniform() {
+        const uint64_t hi = next(), lo = next();
+        return (static_cast<double>(((hi << 32) | lo) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    }
+
+    __device__ __forceinline__ double normal() {
+        const double u1 = uniform(), u2 = uniform();
+        return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+    }
+};
+
+// Binomial(n, p) by inversion: from 0 when the mean is small, otherwise outwards from the mode (expected
+// O(sqrt(n p q)) steps; exact up to floating point).
+__device__ uint32_t sampleBinomial(Philox & rng, const uint32_t n, double p) {
+    if (n == 0 || !(p > 0.0)) return 0;
+    if (p >= 1.0) return n;
+    const bool flip = p > 0.5;
+    if (flip) p = 1.0 - p;
+    const double q = 1.0 - p, ratio = p / q;
+    uint32_t k;
+    if (n * p < 16.0) {
+        double pmf = exp(n * log(q));
+        double u = rng.uniform();
+        k = 0;
+        while (u > pmf && k < n) {
+            u -= pmf;
+            pmf *= ratio * (static_cast<double>(n - k) / (k + 1.0));
+            ++k;
+        }
+    } else {
+        const uint32_t mode = static_cast<uint32_t>((n + 1.0) * p);
+        const double log_pmf_mode = lgamma(n + 1.0) - lgamma(mode + 1.0) - lgamma(n - mode + 1.0) + mode * log(p) + (n - mode) * log(q);
+        const double pmf_mode = exp(log_pmf_mode);
+        double u = rng.uniform();
+        // walk outwards from the mode, alternating sides, until the accumulated mass passes u
+        double up = pmf_mode, down = pmf_mode;
+        uint32_t ku = mode, kd = mode;
+        k = mode;
+        if (u > pmf_mode) {
+            u -= pmf_mode;
+            while (true) {
+                bool moved = false;
+                if (ku < n) {
+                    up *= ratio * (static_cast<double>(n - ku) / (ku + 1.0));
+                    ++ku;
+                    moved = true;
+                    if (u <= up) { k = ku; break; }
+                    u -= up;
+                }
+                if (kd > 0) {
+                    down *= (static_cast<double>(kd) / (n - kd + 1.0)) / ratio;
+                    --kd;
+                    moved = true;
+                    if (u <= down) { k = kd; break; }
+                    u -= down;
+                }
+                if (!moved) { k = mode; break; }
+            }
+        }
+    }
+    return flip ? n - k : k;
+}
+
+// Gamma(shape >= 1, 1) by Marsaglia and Tsang's squeeze method.
+__device__ double sampleGamma(Philox & rng, const double shape) {
+    const double d = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    while (true) {
+        const double x = rng.normal();
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        const double u = rng.uniform();
+        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v;
+    }
+}
+
+struct GibbsLaunchArgs {
+    uint32_t count;
+    const uint64_t * col_off;
+    const uint64_t * row_base;
+    const uint64_t * ent_base;
+    const uint32_t * kept_rows;
+    const double * zero_mass;
+    const double * total_mass;
+    const uint32_t * prow_off;
+    const double * prow_count;
+    const double * prow_noise;
+    const uint32_t * pent_col;
+    const double * pent_val;
+    const double * init_abundances;   // [col_off[P]] expected counts (EM result)
+    const double * init_noise_count;  // [P]
+    const uint32_t * num_samples;     // [P]
+    const uint64_t * seed;            // [P]
+    const uint64_t * sample_off;      // [P+1]
+    const uint64_t * abund_sample_off;  // [P+1] prefix of num_samples * columns
+    uint32_t thin;
+    double gamma;
+    double * noise_samples;
+    double * abundance_samples;
+};
+
+constexpr double kMinGibbsAbundance = 1e-8;  // src/path_abundance_estimator.cpp:14
+
+__global__ __launch_bounds__(256) void gibbsReadCountKernel(const GibbsLaunchArgs args) {
+    constexpr int BLOCK = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t p = blockIdx.x;
+    if (p >= args.count) return;
+    const uint32_t n_samples = args.num_samples[p];
+    if (n_samples == 0) return;
+    const uint32_t C = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]) + 1;
+    const uint32_t noise_col = C - 1;
+    double * a = reinterpret_cast<double *>(smem_raw);          // [C]
+    double * red = a + C;                                       // [BLOCK/64 + 2]
+    unsigned long long * counts = reinterpret_cast<unsigned long long *>(red + (BLOCK / 64 + 2));  // [C]
+
+    const uint32_t n_rows = args.kept_rows[p];
+    const uint64_t rb = args.row_base[p], eb = args.ent_base[p];
+    const uint32_t * off = args.prow_off + rb + p;
+    const double * cnt = args.prow_count + rb;
+    const double * nzv = args.prow_noise + rb;
+    const uint32_t * col = args.pent_col + eb;
+    const double * val = args.pent_val + eb;
+    const double T = args.total_mass[p];
+    const unsigned long long Z = static_cast<unsigned long long>(args.zero_mass[p]);
+
+    // start from the EM estimate (:128-136)
+    for (uint32_t j = threadIdx.x; j < C; j += BLOCK) {
+        a[j] = (j == noise_col ? args.init_noise_count[p] : args.init_abundances[args.col_off[p] + j]) / T;
+    }
+    __syncthreads();
+
+    Philox rng;
+    rng.init(args.seed[p], p, threadIdx.x);
+
+    double * noise_out = args.noise_samples + args.sample_off[p];
+    double * abund_out = args.abundance_samples + args.abund_sample_off[p];
+    const uint32_t num_its = n_samples * args.thin;
+    uint32_t recorded = 0;
+
+    for (uint32_t it = 1; it <= num_its; ++it) {
+        for (uint32_t j = threadIdx.x; j < C; j += BLOCK) counts[j] = (j == noise_col) ? Z : 0ull;
+        __syncthreads();
+        const double a_noise = a[noise_col];
+        for (uint32_t r = threadIdx.x; r < n_rows; r += BLOCK) {
+            const uint32_t e0 = off[r], e1 = off[r + 1];
+            const double nz = nzv[r];
+            double s = nz * a_noise;
+            for (uint32_t e = e0; e < e1; ++e) s += val[e] * a[col[e]];
+            uint32_t remaining = static_cast<uint32_t>(cnt[r]);
+            double remaining_prob = 1.0;
+            for (uint32_t e = e0; e < e1 && remaining > 0; ++e) {
+                const double prob = val[e] * a[col[e]] / s;
+                if (prob > 0.0) {
+                    const uint32_t drawn = sampleBinomial(rng, remaining, fmin(1.0, prob / remaining_prob));
+                    if (drawn) atomicAdd(&counts[col[e]], static_cast<unsigned long long>(drawn));
+                    remaining -= drawn;
+                }
+                remaining_prob -= prob;
+            }
+            if (remaining) atomicAdd(&counts[noise_col], static_cast<unsigned long long>(remaining));
+        }
+        __syncthreads();
+        double local = 0.0;
+        for (uint32_t j = threadIdx.x; j < C; j += BLOCK) {
+            const double g = sampleGamma(rng, static_cast<double>(counts[j]) + args.gamma);
+            a[j] = g;
+            local += g;
+        }
+        const double total = blockReduceSum<double, BLOCK>(local, red);
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < C; j += BLOCK) a[j] = a[j] / total;
+        __syncthreads();
+        if (it % args.thin == 0) {
+            double low = 0.0;
+            for (uint32_t j = threadIdx.x; j < noise_col; j += BLOCK) {
+                const double aj = a[j];
+                if (aj < kMinGibbsAbundance) {
+                    low += aj * T;
+                    abund_out[static_cast<uint64_t>(recorded) * noise_col + j] = 0.0;
+                } else {
+                    abund_out[static_cast<uint64_t>(recorded) * noise_col + j] = aj * T;
+                }
+            }
+            low = blockReduceSum<double, BLOCK>(low, red);
+            if (threadIdx.x == 0) noise_out[recorded] = low + a[noise_col] * T;
+            ++recorded;
+            __syncthreads();
+        }
+    }
+}
+
+// ---- shared host part: validate problems, build their compacted CSR on the device --------------
+
+struct ProblemSet {
+    uint32_t P = 0;
+    uint64_t n_cols_total = 0, rows_total = 0, ent_total = 0;
+    uint32_t max_cols = 0;
+    std::vector<uint32_t> kept_rows, kept_ent;
+    std::vector<double> total_count;
+    DeviceBuffer<uint32_t> d_cluster, d_col_path, d_kept_rows, d_kept_ent, d_prow_off, d_pent_col;
+    DeviceBuffer<uint64_t> d_col_off, d_colmap_off, d_row_base, d_ent_base;
+    DeviceBuffer<int32_t> d_colmap;
+    DeviceBuffer<double> d_zero, d_total, d_prow_count, d_prow_noise, d_pent_val;
+};
+
+// Caller holds ctx->mutex and has set the device.
+int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_em_problems * problems,
+                    ProblemSet & ps, const char * who) {
+    const uint32_t P = problems->num_problems;
+    ps.P = P;
+    std::unique_ptr<HostScope> scope(new HostScope("problems: validate"));
+    std::vector<uint64_t> colmap_off(P + 1, 0);
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t k = problems->cluster[p];
+        RPVG_REQUIRE(k < batch->num_clusters, "%s: problem %u refers to cluster %u of %u", who, p, k, batch->num_clusters);
+        const uint64_t n_paths = batch->h_cluster_path_off[k + 1] - batch->h_cluster_path_off[k];
+        const uint64_t c0 = problems->col_off[p], c1 = problems->col_off[p + 1];
+        RPVG_REQUIRE(c1 > c0, "%s: problem %u has no columns", who, p);
+        RPVG_REQUIRE(batch->h_cluster_row_off[k + 1] > batch->h_cluster_row_off[k], "%s: problem %u is on cluster %u which has no rows", who, p, k);
+        for (uint64_t c = c0; c < c1; ++c) {
+            RPVG_REQUIRE(problems->col_path[c] < n_paths, "%s: problem %u column path %u >= %llu", who, p, problems->col_path[c],
+                         static_cast<unsigned long long>(n_paths));
+            RPVG_REQUIRE(c == c0 || problems->col_path[c] > problems->col_path[c - 1], "%s: problem %u columns are not strictly ascending", who, p);
+        }
+        colmap_off[p + 1] = colmap_off[p] + n_paths;
+        ps.max_cols = std::max<uint32_t>(ps.max_cols, static_cast<uint32_t>(c1 - c0) + 1);
+    }
+    ps.n_cols_total = problems->col_off[P];
+    RPVG_REQUIRE(sizeof(double) * (3 * static_cast<size_t>(ps.max_cols) + 24) <= 160 * 1024,
+                 "%s: a problem with %u columns does not fit the LDS-resident abundance vector", who, ps.max_cols);
+
+    scope.reset(new HostScope("problems: colmap + count + fill"));
+    hipStream_t st = ctx->stream;
+    int span = ctx->spanBegin(FAM_H2D);
+    RPVG_HIP_CHECK(ps.d_cluster.upload(problems->cluster, P, st));
+    RPVG_HIP_CHECK(ps.d_col_off.upload(problems->col_off, P + 1, st));
+    RPVG_HIP_CHECK(ps.d_col_path.upload(problems->col_path, ps.n_cols_total, st));
+    RPVG_HIP_CHECK(ps.d_colmap_off.upload(colmap_off.data(), P + 1, st));
+    ctx->spanEnd(span);
+    ctx->stats.h2d_bytes += static_cast<double>(P * 4 + (P + 1) * 16 + ps.n_cols_total * 4);
+    RPVG_HIP_CHECK(ps.d_colmap.alloc(colmap_off[P]));
+    RPVG_HIP_CHECK(ps.d_kept_rows.alloc(P));
+    RPVG_HIP_CHECK(ps.d_kept_ent.alloc(P));
+    RPVG_HIP_CHECK(ps.d_zero.alloc(P));
+    RPVG_HIP_CHECK(ps.d_total.alloc(P));
+
+    span = ctx->spanBegin(FAM_BUILD);
+    RPVG_HIP_CHECK(hipMemsetAsync(ps.d_colmap.ptr, 0xFF, colmap_off[P] * sizeof(int32_t), st));
+    scatterColumnMapKernel<<<dim3(P), dim3(64), 0, st>>>(P, ps.d_col_off.ptr, ps.d_col_path.ptr, ps.d_colmap_off.ptr, ps.d_colmap.ptr);
+    countProblemKernel<256><<<dim3(P), dim3(256), 0, st>>>(P, ps.d_cluster.ptr, ps.d_colmap_off.ptr, ps.d_colmap.ptr,
+                                                          batch->cluster_row_off.ptr, batch->row_ent_off.ptr,
+                                                          batch->ent_path.ptr, batch->row_count.ptr, ps.d_kept_rows.ptr,
+                                                          ps.d_kept_ent.ptr, ps.d_zero.ptr, ps.d_total.ptr);
+    ctx->spanEnd(span);
+    ctx->stats.build_launches += 2;
+    RPVG_HIP_CHECK(hipGetLastError());
+
+    ps.kept_rows.resize(P);
+    ps.kept_ent.resize(P);
+    ps.total_count.resize(P);
+    RPVG_HIP_CHECK(ps.d_kept_rows.download(ps.kept_rows.data(), st));
+    RPVG_HIP_CHECK(ps.d_kept_ent.download(ps.kept_ent.data(), st));
+    RPVG_HIP_CHECK(ps.d_total.download(ps.total_count.data(), st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+
+    std::vector<uint64_t> row_base(P), ent_base(P);
+    for (uint32_t p = 0; p < P; ++p) {
+        row_base[p] = ps.rows_total;
+        ent_base[p] = ps.ent_total;
+        ps.rows_total += ps.kept_rows[p];
+        ps.ent_total += ps.kept_ent[p];
+    }
+    span = ctx->spanBegin(FAM_H2D);
+    RPVG_HIP_CHECK(ps.d_row_base.upload(row_base.data(), P, st));
+    RPVG_HIP_CHECK(ps.d_ent_base.upload(ent_base.data(), P, st));
+    ctx->spanEnd(span);
+    ctx->stats.h2d_bytes += static_cast<double>(P * 16);
+    RPVG_HIP_CHECK(ps.d_prow_off.alloc(ps.rows_total + P));
+    RPVG_HIP_CHECK(ps.d_prow_count.alloc(ps.rows_total));
+    RPVG_HIP_CHECK(ps.d_prow_noise.alloc(ps.rows_total));
+    RPVG_HIP_CHECK(ps.d_pent_col.alloc(ps.ent_total));
+    RPVG_HIP_CHECK(ps.d_pent_val.alloc(ps.ent_total));
+
+    span = ctx->spanBegin(FAM_BUILD);
+    fillProblemKernel<256><<<dim3(P), dim3(256), 0, st>>>(
+        P, ps.d_cluster.ptr, ps.d_colmap_off.ptr, ps.d_colmap.ptr, batch->cluster_row_off.ptr, batch->row_ent_off.ptr,
+        batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_count.ptr, batch->row_noise.ptr, ps.d_row_base.ptr,
+        ps.d_ent_base.ptr, ps.d_prow_off.ptr, ps.d_prow_count.ptr, ps.d_prow_noise.ptr, ps.d_pent_col.ptr, ps.d_pent_val.ptr);
+    ctx->spanEnd(span);
+    ctx->stats.build_launches += 1;
+    RPVG_HIP_CHECK(hipGetLastError());
+    return RPVG_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t max_em_its,
@@ -403,81 +757,18 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
                  "rpvg_hip_em_solve: NULL result arrays");
     RPVG_REQUIRE(max_em_its > 0, "rpvg_hip_em_solve: max_em_its must be positive");
 
-    std::unique_ptr<HostScope> scope(new HostScope("em_solve: validate"));
-    // ---- validate + host-side offsets ----
-    std::vector<uint64_t> colmap_off(P + 1, 0);
-    uint32_t max_cols_all = 0;
-    for (uint32_t p = 0; p < P; ++p) {
-        const uint32_t k = problems->cluster[p];
-        RPVG_REQUIRE(k < batch->num_clusters, "rpvg_hip_em_solve: problem %u refers to cluster %u of %u", p, k, batch->num_clusters);
-        const uint64_t n_paths = batch->h_cluster_path_off[k + 1] - batch->h_cluster_path_off[k];
-        const uint64_t c0 = problems->col_off[p], c1 = problems->col_off[p + 1];
-        RPVG_REQUIRE(c1 > c0, "rpvg_hip_em_solve: problem %u has no columns", p);
-        RPVG_REQUIRE(batch->h_cluster_row_off[k + 1] > batch->h_cluster_row_off[k],
-                     "rpvg_hip_em_solve: problem %u is on cluster %u which has no rows", p, k);
-        for (uint64_t c = c0; c < c1; ++c) {
-            RPVG_REQUIRE(problems->col_path[c] < n_paths, "rpvg_hip_em_solve: problem %u column path %u >= %llu", p,
-                         problems->col_path[c], static_cast<unsigned long long>(n_paths));
-            RPVG_REQUIRE(c == c0 || problems->col_path[c] > problems->col_path[c - 1],
-                         "rpvg_hip_em_solve: problem %u columns are not strictly ascending", p);
-        }
-        colmap_off[p + 1] = colmap_off[p] + n_paths;
-        max_cols_all = std::max<uint32_t>(max_cols_all, static_cast<uint32_t>(c1 - c0) + 1);
-    }
-    const uint64_t n_cols_total = problems->col_off[P];
-    RPVG_REQUIRE(sizeof(double) * (2 * static_cast<size_t>(max_cols_all) + 24) <= 160 * 1024,
-                 "rpvg_hip_em_solve: a problem with %u columns does not fit the LDS-resident abundance vector", max_cols_all);
-
-    scope.reset(new HostScope("em_solve: colmap + count + download"));
     std::lock_guard<std::mutex> lock(ctx->mutex);
     RPVG_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
 
-    DeviceBuffer<uint32_t> d_cluster, d_col_path, d_kept_rows, d_kept_ent;
-    DeviceBuffer<uint64_t> d_col_off, d_colmap_off;
-    DeviceBuffer<int32_t> d_colmap;
-    DeviceBuffer<double> d_zero, d_total;
+    ProblemSet ps;
+    const int rc = buildProblemSet(ctx, batch, problems, ps, "rpvg_hip_em_solve");
+    if (rc != RPVG_HIP_OK) return rc;
+    for (uint32_t p = 0; p < P; ++p) results->total_count[p] = ps.total_count[p];
+    const std::vector<uint32_t> & kept_rows = ps.kept_rows;
+    const std::vector<uint32_t> & kept_ent = ps.kept_ent;
 
-    int span = ctx->spanBegin(FAM_H2D);
-    RPVG_HIP_CHECK(d_cluster.upload(problems->cluster, P, st));
-    RPVG_HIP_CHECK(d_col_off.upload(problems->col_off, P + 1, st));
-    RPVG_HIP_CHECK(d_col_path.upload(problems->col_path, n_cols_total, st));
-    RPVG_HIP_CHECK(d_colmap_off.upload(colmap_off.data(), P + 1, st));
-    ctx->spanEnd(span);
-    ctx->stats.h2d_bytes += static_cast<double>(P * 4 + (P + 1) * 16 + n_cols_total * 4);
-    RPVG_HIP_CHECK(d_colmap.alloc(colmap_off[P]));
-    RPVG_HIP_CHECK(d_kept_rows.alloc(P));
-    RPVG_HIP_CHECK(d_kept_ent.alloc(P));
-    RPVG_HIP_CHECK(d_zero.alloc(P));
-    RPVG_HIP_CHECK(d_total.alloc(P));
-
-    span = ctx->spanBegin(FAM_BUILD);
-    RPVG_HIP_CHECK(hipMemsetAsync(d_colmap.ptr, 0xFF, colmap_off[P] * sizeof(int32_t), st));
-    scatterColumnMapKernel<<<dim3(P), dim3(64), 0, st>>>(P, d_col_off.ptr, d_col_path.ptr, d_colmap_off.ptr, d_colmap.ptr);
-    countProblemKernel<256><<<dim3(P), dim3(256), 0, st>>>(P, d_cluster.ptr, d_colmap_off.ptr, d_colmap.ptr,
-                                                          batch->cluster_row_off.ptr, batch->row_ent_off.ptr,
-                                                          batch->ent_path.ptr, batch->row_count.ptr, d_kept_rows.ptr,
-                                                          d_kept_ent.ptr, d_zero.ptr, d_total.ptr);
-    ctx->spanEnd(span);
-    ctx->stats.build_launches += 2;
-    RPVG_HIP_CHECK(hipGetLastError());
-
-    std::vector<uint32_t> kept_rows(P), kept_ent(P);
-    RPVG_HIP_CHECK(d_kept_rows.download(kept_rows.data(), st));
-    RPVG_HIP_CHECK(d_kept_ent.download(kept_ent.data(), st));
-    RPVG_HIP_CHECK(d_total.download(results->total_count, st));
-    RPVG_HIP_CHECK(hipStreamSynchronize(st));
-
-    scope.reset(new HostScope("em_solve: host prefix/order"));
-    // ---- host: prefix sums, ordering, bins ----
-    std::vector<uint64_t> row_base(P), ent_base(P);
-    uint64_t rows_total = 0, ent_total = 0;
-    for (uint32_t p = 0; p < P; ++p) {
-        row_base[p] = rows_total;
-        ent_base[p] = ent_total;
-        rows_total += kept_rows[p];
-        ent_total += kept_ent[p];
-    }
+    HostScope scope("em_solve: bins + EM kernels + download");
     // Size bins (inside a bin the expensive problems go first, as the reference orders clusters before
     // its dynamic OpenMP schedule, src/main.cpp:811-829):
     //   0  LDS-resident, one wave      CSR + vectors fit 8 KB
@@ -518,45 +809,28 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
         order.insert(order.end(), bins[b].begin(), bins[b].end());
     }
 
-    DeviceBuffer<uint64_t> d_row_base, d_ent_base;
-    DeviceBuffer<uint32_t> d_order, d_prow_off, d_pent_col, d_iters;
-    DeviceBuffer<double> d_prow_count, d_prow_noise, d_pent_val, d_abund, d_noise_count;
-    span = ctx->spanBegin(FAM_H2D);
-    RPVG_HIP_CHECK(d_row_base.upload(row_base.data(), P, st));
-    RPVG_HIP_CHECK(d_ent_base.upload(ent_base.data(), P, st));
+    DeviceBuffer<uint32_t> d_order, d_iters;
+    DeviceBuffer<double> d_abund, d_noise_count;
+    int span = ctx->spanBegin(FAM_H2D);
     RPVG_HIP_CHECK(d_order.upload(order.data(), P, st));
     ctx->spanEnd(span);
-    ctx->stats.h2d_bytes += static_cast<double>(P * 20);
-    RPVG_HIP_CHECK(d_prow_off.alloc(rows_total + P));
-    RPVG_HIP_CHECK(d_prow_count.alloc(rows_total));
-    RPVG_HIP_CHECK(d_prow_noise.alloc(rows_total));
-    RPVG_HIP_CHECK(d_pent_col.alloc(ent_total));
-    RPVG_HIP_CHECK(d_pent_val.alloc(ent_total));
-    RPVG_HIP_CHECK(d_abund.alloc(n_cols_total));
+    ctx->stats.h2d_bytes += static_cast<double>(P * 4);
+    RPVG_HIP_CHECK(d_abund.alloc(ps.n_cols_total));
     RPVG_HIP_CHECK(d_noise_count.alloc(P));
     RPVG_HIP_CHECK(d_iters.alloc(P));
 
-    span = ctx->spanBegin(FAM_BUILD);
-    fillProblemKernel<256><<<dim3(P), dim3(256), 0, st>>>(
-        P, d_cluster.ptr, d_colmap_off.ptr, d_colmap.ptr, batch->cluster_row_off.ptr, batch->row_ent_off.ptr,
-        batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_count.ptr, batch->row_noise.ptr, d_row_base.ptr,
-        d_ent_base.ptr, d_prow_off.ptr, d_prow_count.ptr, d_prow_noise.ptr, d_pent_col.ptr, d_pent_val.ptr);
-    ctx->spanEnd(span);
-    ctx->stats.build_launches += 1;
-    RPVG_HIP_CHECK(hipGetLastError());
-
     EmLaunchArgs args;
-    args.col_off = d_col_off.ptr;
-    args.row_base = d_row_base.ptr;
-    args.ent_base = d_ent_base.ptr;
-    args.kept_rows = d_kept_rows.ptr;
-    args.zero_mass = d_zero.ptr;
-    args.total_mass = d_total.ptr;
-    args.prow_off = d_prow_off.ptr;
-    args.prow_count = d_prow_count.ptr;
-    args.prow_noise = d_prow_noise.ptr;
-    args.pent_col = d_pent_col.ptr;
-    args.pent_val = d_pent_val.ptr;
+    args.col_off = ps.d_col_off.ptr;
+    args.row_base = ps.d_row_base.ptr;
+    args.ent_base = ps.d_ent_base.ptr;
+    args.kept_rows = ps.d_kept_rows.ptr;
+    args.zero_mass = ps.d_zero.ptr;
+    args.total_mass = ps.d_total.ptr;
+    args.prow_off = ps.d_prow_off.ptr;
+    args.prow_count = ps.d_prow_count.ptr;
+    args.prow_noise = ps.d_prow_noise.ptr;
+    args.pent_col = ps.d_pent_col.ptr;
+    args.pent_val = ps.d_pent_val.ptr;
     args.max_em_its = max_em_its;
     args.max_rel_em_conv = max_rel_em_conv;
     args.abundances = d_abund.ptr;
@@ -599,5 +873,85 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     }
     ctx->stats.em_sparse_alg_bytes += bytes;
     ctx->stats.em_iterations_total += its_total;
+    return RPVG_HIP_OK;
+}
+
+extern "C" int rpvg_hip_gibbs_read_counts(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch,
+                                          const rpvg_hip_em_problems * problems, const double * init_abundances,
+                                          const double * init_noise_count, const uint32_t * num_samples,
+                                          const uint64_t * seeds, uint32_t gibbs_thin_its, double gamma,
+                                          double * noise_samples, double * abundance_samples) {
+    RPVG_REQUIRE(ctx && batch && problems, "rpvg_hip_gibbs_read_counts: NULL argument");
+    const uint32_t P = problems->num_problems;
+    if (P == 0) return RPVG_HIP_OK;
+    RPVG_REQUIRE(problems->cluster && problems->col_off && problems->col_path, "rpvg_hip_gibbs_read_counts: NULL problem arrays");
+    RPVG_REQUIRE(init_abundances && init_noise_count && num_samples && seeds && noise_samples && abundance_samples,
+                 "rpvg_hip_gibbs_read_counts: NULL argument");
+    RPVG_REQUIRE(gibbs_thin_its > 0, "rpvg_hip_gibbs_read_counts: gibbs_thin_its must be positive");
+    RPVG_REQUIRE(gamma >= 1.0, "rpvg_hip_gibbs_read_counts: gamma must be >= 1 (the reference uses 1)");
+
+    std::vector<uint64_t> sample_off(P + 1, 0), abund_sample_off(P + 1, 0);
+    for (uint32_t p = 0; p < P; ++p) {
+        sample_off[p + 1] = sample_off[p] + num_samples[p];
+        abund_sample_off[p + 1] = abund_sample_off[p] + static_cast<uint64_t>(num_samples[p]) * (problems->col_off[p + 1] - problems->col_off[p]);
+    }
+    if (sample_off[P] == 0) return RPVG_HIP_OK;
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    ProblemSet ps;
+    const int rc = buildProblemSet(ctx, batch, problems, ps, "rpvg_hip_gibbs_read_counts");
+    if (rc != RPVG_HIP_OK) return rc;
+
+    DeviceBuffer<double> d_init_abund, d_init_noise, d_noise_samples, d_abund_samples;
+    DeviceBuffer<uint32_t> d_num_samples;
+    DeviceBuffer<uint64_t> d_seed, d_sample_off, d_abund_sample_off;
+    RPVG_HIP_CHECK(d_init_abund.upload(init_abundances, ps.n_cols_total, st));
+    RPVG_HIP_CHECK(d_init_noise.upload(init_noise_count, P, st));
+    RPVG_HIP_CHECK(d_num_samples.upload(num_samples, P, st));
+    RPVG_HIP_CHECK(d_seed.upload(seeds, P, st));
+    RPVG_HIP_CHECK(d_sample_off.upload(sample_off.data(), P + 1, st));
+    RPVG_HIP_CHECK(d_abund_sample_off.upload(abund_sample_off.data(), P + 1, st));
+    RPVG_HIP_CHECK(d_noise_samples.alloc(sample_off[P]));
+    RPVG_HIP_CHECK(d_abund_samples.alloc(abund_sample_off[P]));
+
+    GibbsLaunchArgs args;
+    args.count = P;
+    args.col_off = ps.d_col_off.ptr;
+    args.row_base = ps.d_row_base.ptr;
+    args.ent_base = ps.d_ent_base.ptr;
+    args.kept_rows = ps.d_kept_rows.ptr;
+    args.zero_mass = ps.d_zero.ptr;
+    args.total_mass = ps.d_total.ptr;
+    args.prow_off = ps.d_prow_off.ptr;
+    args.prow_count = ps.d_prow_count.ptr;
+    args.prow_noise = ps.d_prow_noise.ptr;
+    args.pent_col = ps.d_pent_col.ptr;
+    args.pent_val = ps.d_pent_val.ptr;
+    args.init_abundances = d_init_abund.ptr;
+    args.init_noise_count = d_init_noise.ptr;
+    args.num_samples = d_num_samples.ptr;
+    args.seed = d_seed.ptr;
+    args.sample_off = d_sample_off.ptr;
+    args.abund_sample_off = d_abund_sample_off.ptr;
+    args.thin = gibbs_thin_its;
+    args.gamma = gamma;
+    args.noise_samples = d_noise_samples.ptr;
+    args.abundance_samples = d_abund_samples.ptr;
+
+    const size_t lds = (sizeof(double) * (2 * static_cast<size_t>(ps.max_cols) + 256 / 64 + 2) + 15) & ~static_cast<size_t>(15);
+    if (lds > 64 * 1024) {
+        RPVG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbsReadCountKernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    }
+    const int span = ctx->spanBegin(FAM_EM_SPARSE);
+    gibbsReadCountKernel<<<dim3(P), dim3(256), lds, st>>>(args);
+    ctx->spanEnd(span);
+    RPVG_HIP_CHECK(hipGetLastError());
+    RPVG_HIP_CHECK(d_noise_samples.download(noise_samples, st));
+    RPVG_HIP_CHECK(d_abund_samples.download(abundance_samples, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
     return RPVG_HIP_OK;
 }

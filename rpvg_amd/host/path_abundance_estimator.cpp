@@ -13,12 +13,72 @@ namespace rpvg_amd {
 
 PathAbundanceEstimator::PathAbundanceEstimator(const uint32_t max_em_its_in, const double max_rel_em_conv_in, const uint32_t num_gibbs_samples_in, const uint32_t gibbs_thin_its_in, const double prob_precision, std::shared_ptr<HipEngine> engine) : PathEstimator(prob_precision, engine), max_em_its(max_em_its_in), max_rel_em_conv(max_rel_em_conv_in), num_gibbs_samples(num_gibbs_samples_in), gibbs_thin_its(gibbs_thin_its_in) {}
 
-void PathAbundanceEstimator::requireNoGibbsSamples() const {
+// src/path_abundance_estimator.cpp:13
+static const double abundance_gibbs_gamma = 1;
 
-    if (num_gibbs_samples > 0) {
+uint64_t PathAbundanceEstimator::drawSeed(std::mt19937 * mt_rng) {
 
-        // gibbsReadCountSampler (src/path_abundance_estimator.cpp:116-212) is not on the GPU yet
-        throw EngineError("read-count Gibbs sampling (-n > 0) is not available in the GPU engine yet");
+    const uint64_t high = (*mt_rng)();
+    const uint64_t low = (*mt_rng)();
+
+    return (high << 32) | low;
+}
+
+void PathAbundanceEstimator::gibbsReadCountSampler(std::vector<CountSamples> * count_samples, const DeviceClusterBatch & cluster_batch, const std::vector<EMProblem> & problems, const std::vector<EMSolution> & solutions, const std::vector<uint32_t> & num_samples, const std::vector<uint64_t> & seeds) const {
+
+    ScopedPhase phase("Gibbs read counts: rpvg_hip_gibbs_read_counts");
+
+    assert(problems.size() == solutions.size());
+    assert(problems.size() == num_samples.size());
+    assert(problems.size() == seeds.size());
+
+    count_samples->assign(problems.size(), CountSamples());
+
+    if (problems.empty()) {
+
+        return;
+    }
+
+    std::vector<uint32_t> clusters;
+    std::vector<uint64_t> col_off(1, 0);
+    std::vector<uint32_t> col_path;
+    std::vector<double> init_abundances;
+    std::vector<double> init_noise_count;
+
+    std::vector<uint64_t> sample_off(1, 0);
+    std::vector<uint64_t> abundance_sample_off(1, 0);
+
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        clusters.emplace_back(problems.at(i).cluster);
+        col_path.insert(col_path.end(), problems.at(i).path_ids.begin(), problems.at(i).path_ids.end());
+        col_off.emplace_back(col_path.size());
+
+        init_abundances.insert(init_abundances.end(), solutions.at(i).abundances.begin(), solutions.at(i).abundances.end());
+        init_noise_count.emplace_back(solutions.at(i).noise_count);
+
+        sample_off.emplace_back(sample_off.back() + num_samples.at(i));
+        abundance_sample_off.emplace_back(abundance_sample_off.back() + static_cast<uint64_t>(num_samples.at(i)) * problems.at(i).path_ids.size());
+    }
+
+    std::vector<double> noise_samples(sample_off.back());
+    std::vector<double> abundance_samples(abundance_sample_off.back());
+
+    rpvg_hip_em_problems em_problems;
+    em_problems.num_problems = problems.size();
+    em_problems.cluster = clusters.data();
+    em_problems.col_off = col_off.data();
+    em_problems.col_path = col_path.data();
+
+    HipEngine::check(rpvg_hip_gibbs_read_counts(engine->ctx(), cluster_batch.handle(), &em_problems, init_abundances.data(), init_noise_count.data(), num_samples.data(), seeds.data(), gibbs_thin_its, abundance_gibbs_gamma, noise_samples.data(), abundance_samples.data()), "rpvg_hip_gibbs_read_counts");
+
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        auto & samples = count_samples->at(i);
+
+        samples.path_ids = problems.at(i).path_ids;
+        samples.noise_samples.assign(noise_samples.begin() + sample_off.at(i), noise_samples.begin() + sample_off.at(i + 1));
+        samples.abundance_samples.assign(abundance_samples.begin() + abundance_sample_off.at(i), abundance_samples.begin() + abundance_sample_off.at(i + 1));
     }
 }
 
@@ -82,7 +142,10 @@ void PathAbundanceEstimator::EMAbundanceEstimator(std::vector<EMSolution> * solu
 // src/path_abundance_estimator.cpp:18-45 over a batch of clusters.
 void PathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs) {
 
-    requireNoGibbsSamples();
+    if (num_gibbs_samples > 0 && !rngs) {
+
+        throw EngineError("read-count Gibbs sampling draws random numbers: a generator per cluster is required");
+    }
 
     assert(path_cluster_estimates->size() == cluster_batch.numClusters());
 
@@ -109,6 +172,26 @@ void PathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimates> * p
     std::vector<EMSolution> solutions;
     EMAbundanceEstimator(&solutions, cluster_batch, problems);
 
+    if (num_gibbs_samples > 0) {
+
+        // src/path_abundance_estimator.cpp:34-43
+        std::vector<uint32_t> num_samples(problems.size(), num_gibbs_samples);
+        std::vector<uint64_t> seeds;
+
+        for (auto & problem: problems) {
+
+            seeds.emplace_back(drawSeed(&rngs->at(problem.cluster)));
+        }
+
+        std::vector<CountSamples> count_samples;
+        gibbsReadCountSampler(&count_samples, cluster_batch, problems, solutions, num_samples, seeds);
+
+        for (size_t i = 0; i < problems.size(); ++i) {
+
+            path_cluster_estimates->at(problems.at(i).cluster).gibbs_read_count_samples.emplace_back(std::move(count_samples.at(i)));
+        }
+    }
+
     for (size_t i = 0; i < problems.size(); ++i) {
 
         auto & estimates = path_cluster_estimates->at(problems.at(i).cluster);
@@ -129,7 +212,10 @@ NestedPathAbundanceEstimator::NestedPathAbundanceEstimator(const uint32_t group_
 // path subset of every cluster (one GPU call), then the weighted merge.
 void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs) {
 
-    requireNoGibbsSamples();
+    if (num_gibbs_samples > 0 && !rngs) {
+
+        throw EngineError("read-count Gibbs sampling draws random numbers: a generator per cluster is required");
+    }
 
     if (use_group_post_gibbs && !rngs) {
 
@@ -263,7 +349,7 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
         }
     }
 
-    inferPathSubsetAbundance(path_cluster_estimates, cluster_batch, clusters, path_subset_samples);
+    inferPathSubsetAbundance(path_cluster_estimates, cluster_batch, clusters, path_subset_samples, rngs);
 
     ScopedPhase teardown_phase("nested: teardown subset weights");
 
@@ -463,7 +549,7 @@ void NestedPathAbundanceEstimator::selectPathSubsetIndices(PathSubsetWeights * p
 }
 
 // src/path_abundance_estimator.cpp:608-750 for all clusters at once.
-void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples) const {
+void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples, std::vector<std::mt19937> * rngs) const {
 
     assert(clusters.size() == path_subset_samples.size());
 
@@ -513,6 +599,52 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
     std::vector<EMSolution> solutions;
     EMAbundanceEstimator(&solutions, cluster_batch, problems);
 
+    std::vector<CountSamples> count_samples;
+
+    if (num_gibbs_samples > 0) {
+
+        // the -n samples of a cluster are split over its subsets by sequential binomials on the subset
+        // weights (src/path_abundance_estimator.cpp:675-697)
+        std::vector<uint32_t> num_samples(problems.size(), 0);
+        std::vector<uint64_t> seeds(problems.size(), 0);
+
+        for (size_t i = 0; i < clusters.size(); ++i) {
+
+            std::mt19937 * mt_rng = &rngs->at(clusters.at(i));
+
+            uint32_t subset_gibbs_samples = num_gibbs_samples;
+            double subset_gibbs_prob = 1;
+
+            size_t problem_idx = first_problem.at(i);
+
+            for (auto & path_subset: path_subset_samples.at(i)) {
+
+                if (path_subset.second < min_hap_prob) {
+
+                    continue;
+                }
+
+                if (subset_gibbs_samples > 0) {
+
+                    assert(subset_gibbs_prob > 0);
+
+                    std::binomial_distribution<uint32_t> path_read_count_sampler(subset_gibbs_samples, std::min(1.0, path_subset.second / subset_gibbs_prob));
+                    const uint32_t cur_subset_gibbs_samples = path_read_count_sampler(*mt_rng);
+
+                    subset_gibbs_samples -= cur_subset_gibbs_samples;
+                    subset_gibbs_prob -= path_subset.second;
+
+                    num_samples.at(problem_idx) = cur_subset_gibbs_samples;
+                    seeds.at(problem_idx) = drawSeed(mt_rng);
+                }
+
+                ++problem_idx;
+            }
+        }
+
+        gibbsReadCountSampler(&count_samples, cluster_batch, problems, solutions, num_samples, seeds);
+    }
+
     ScopedPhase merge_phase("nested: weighted merge");
 
     #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
@@ -546,6 +678,11 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
 
             estimates.em_iterations.emplace_back(solution.iterations);
             estimates.em_problem_paths.emplace_back(problem.path_ids);
+
+            if (!count_samples.empty() && !count_samples.at(problem_idx - 1).noise_samples.empty()) {
+
+                estimates.gibbs_read_count_samples.emplace_back(std::move(count_samples.at(problem_idx - 1)));
+            }
 
             estimates.noise_count += solution.noise_count * path_subset.second;
 

@@ -23,6 +23,8 @@ class PathAbundanceEstimator : public PathEstimator {
         PathAbundanceEstimator(const uint32_t max_em_its_in, const double max_rel_em_conv_in, const uint32_t num_gibbs_samples_in, const uint32_t gibbs_thin_its_in, const double prob_precision, std::shared_ptr<HipEngine> engine);
         virtual ~PathAbundanceEstimator() {};
 
+        bool usesRandomNumbers() const { return num_gibbs_samples > 0; }
+
         void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs);
 
     protected:
@@ -52,7 +54,12 @@ class PathAbundanceEstimator : public PathEstimator {
         // the matrix construction and normalisation in front of it, for a batch of problems.
         void EMAbundanceEstimator(std::vector<EMSolution> * solutions, const DeviceClusterBatch & cluster_batch, const std::vector<EMProblem> & problems) const;
 
-        void requireNoGibbsSamples() const;
+        // gibbsReadCountSampler (src/path_abundance_estimator.cpp:116-212) for a batch of solved problems, on the
+        // GPU (Philox generator keyed by `seeds`; statistical parity with the reference's mt19937 streams).
+        // Problems with num_samples == 0 get an empty CountSamples.
+        void gibbsReadCountSampler(std::vector<CountSamples> * count_samples, const DeviceClusterBatch & cluster_batch, const std::vector<EMProblem> & problems, const std::vector<EMSolution> & solutions, const std::vector<uint32_t> & num_samples, const std::vector<uint64_t> & seeds) const;
+
+        static uint64_t drawSeed(std::mt19937 * mt_rng);
 };
 
 class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
@@ -62,7 +69,7 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
         NestedPathAbundanceEstimator(const uint32_t group_size_in, const double min_hap_prob_in, const bool infer_collapsed_in, const bool use_group_post_gibbs_in, const uint32_t max_em_its, const double max_rel_em_conv, const uint32_t num_gibbs_samples, const uint32_t gibbs_thin_its, const double prob_precision, std::shared_ptr<HipEngine> engine);
         ~NestedPathAbundanceEstimator() {};
 
-        bool usesRandomNumbers() const { return !infer_collapsed || use_group_post_gibbs; }
+        bool usesRandomNumbers() const { return !infer_collapsed || use_group_post_gibbs || num_gibbs_samples > 0; }
 
         void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs);
 
@@ -85,7 +92,7 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
         void sampleGroupPathIndices(std::vector<std::vector<uint32_t> > * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<uint32_t> & group, std::mt19937 * mt_rng) const;
         void selectPathSubsetIndices(PathSubsetWeights * path_subset_samples, const GroupPosteriors & group_posteriors, const GroupPosteriorProblem & problem) const;
 
-        void inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples) const;
+        void inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples, std::vector<std::mt19937> * rngs) const;
 };
 
 }

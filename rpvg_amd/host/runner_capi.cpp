@@ -41,6 +41,10 @@ struct Result {
     std::vector<uint64_t> set_off, member_off, abund_off, em_off, em_col_off;
     std::vector<uint32_t> members, em_iters, em_cols;
     std::vector<double> posteriors, abundances, noise_count, total_count;
+
+    std::vector<uint64_t> gibbs_off, gibbs_path_off, gibbs_noise_off, gibbs_abund_off;
+    std::vector<uint32_t> gibbs_path;
+    std::vector<double> gibbs_noise, gibbs_abund;
 };
 
 std::vector<std::vector<PathInfo> > unpackPaths(const rpvg_cluster_batch & batch) {
@@ -97,7 +101,24 @@ Result * packResult(const std::vector<PathClusterEstimates> & estimates) {
     result->em_off.push_back(0);
     result->em_col_off.push_back(0);
 
+    result->gibbs_off.push_back(0);
+    result->gibbs_path_off.push_back(0);
+    result->gibbs_noise_off.push_back(0);
+    result->gibbs_abund_off.push_back(0);
+
     for (auto & cluster_estimates: estimates) {
+
+        for (auto & count_samples: cluster_estimates.gibbs_read_count_samples) {
+
+            result->gibbs_path.insert(result->gibbs_path.end(), count_samples.path_ids.begin(), count_samples.path_ids.end());
+            result->gibbs_path_off.push_back(result->gibbs_path.size());
+            result->gibbs_noise.insert(result->gibbs_noise.end(), count_samples.noise_samples.begin(), count_samples.noise_samples.end());
+            result->gibbs_noise_off.push_back(result->gibbs_noise.size());
+            result->gibbs_abund.insert(result->gibbs_abund.end(), count_samples.abundance_samples.begin(), count_samples.abundance_samples.end());
+            result->gibbs_abund_off.push_back(result->gibbs_abund.size());
+        }
+
+        result->gibbs_off.push_back(result->gibbs_path_off.size() - 1);
 
         for (size_t i = 0; i < cluster_estimates.path_group_sets.size(); ++i) {
 
@@ -321,6 +342,13 @@ void rpvg_amd_result_view(void * result_handle, rpvg_estimates_view * out) {
     out->em_iters = result->em_iters.data();
     out->em_col_off = result->em_col_off.data();
     out->em_cols = result->em_cols.data();
+    out->gibbs_off = result->gibbs_off.data();
+    out->gibbs_path_off = result->gibbs_path_off.data();
+    out->gibbs_path = result->gibbs_path.data();
+    out->gibbs_noise_off = result->gibbs_noise_off.data();
+    out->gibbs_noise = result->gibbs_noise.data();
+    out->gibbs_abund_off = result->gibbs_abund_off.data();
+    out->gibbs_abund = result->gibbs_abund.data();
 }
 
 void rpvg_amd_result_free(void * result_handle) {

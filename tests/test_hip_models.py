@@ -135,8 +135,6 @@ def test_unsupported_modes_fail_loudly(engine):
     clusters = small_cases.make_batch_clusters(651, n_clusters=2, with_empty=False)
     prep = engine.prepare(ClusterBatch.from_clusters(clusters))
     with pytest.raises(hip.EngineError):
-        engine.run("transcripts", make_params(num_gibbs_samples=5), prep)
-    with pytest.raises(hip.EngineError):
         engine.run("strains", make_params(), prep)
     with pytest.raises(hip.EngineError):
         engine.run("no-such-model", make_params(), prep)
@@ -224,3 +222,73 @@ def test_gibbs_posteriors_agree_with_exact_posteriors_statistically(engine):
         for key, p in ek.items():
             if p > 0.2:
                 assert abs(gk.get(key, 0.0) - p) < 0.08, (key, p, gk.get(key))
+
+
+# ---- -n > 0: Gibbs read-count samples (src/path_abundance_estimator.cpp:116-212) ---------------------
+# Parity is statistical: the reference draws from mt19937 through libstdc++ distributions, the GPU from a
+# counter-based Philox generator.
+
+def _sample_stats(est):
+    out = []
+    for e in est:
+        per = []
+        for ids, noise, ab in e.gibbs_samples:
+            per.append((ids, ab.mean(axis=0), ab.std(axis=0, ddof=1) if len(noise) > 1 else np.zeros(len(ids)), noise, ab))
+        out.append(per)
+    return out
+
+
+def test_gibbs_read_count_samples_transcripts(engine):
+    clusters = small_cases.make_batch_clusters(801, n_clusters=6, with_empty=False)
+    batch = ClusterBatch.from_clusters(clusters)
+    n, thin = 400, 5
+    params = make_params(num_gibbs_samples=n, gibbs_thin_its=thin, rng_seed=5)
+    ref, _ = pyoracle.run("transcripts", params, batch, 2)
+    got, _ = engine.run("transcripts", params, engine.prepare(batch))
+    _compare(got, ref)  # the EM part is unchanged by -n
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert len(g.gibbs_samples) == len(r.gibbs_samples) == 1
+        (gi, gn, ga), (ri, rn, ra) = g.gibbs_samples[0], r.gibbs_samples[0]
+        assert gi == ri == tuple(range(len(clusters[k]["paths"])))
+        assert ga.shape == ra.shape == (n, len(gi)) and gn.shape == rn.shape == (n,)
+        # every recorded state conserves the read mass (writers assert this on the EM result)
+        assert np.all(np.abs(ga.sum(axis=1) + gn - g.total_count) <= 1e-9 * g.total_count)
+        assert np.all(ga >= 0) and np.all(gn >= 0)
+        # means agree within Monte-Carlo error (5 sigma of the difference of two means, + a floor)
+        se = np.sqrt(ga.var(axis=0, ddof=1) / n + ra.var(axis=0, ddof=1) / n)
+        assert np.all(np.abs(ga.mean(axis=0) - ra.mean(axis=0)) <= 5 * se + 0.02 * g.total_count / max(1, len(gi)) + 0.5), k
+        # spreads agree within a factor
+        sg, sr = ga.std(axis=0, ddof=1), ra.std(axis=0, ddof=1)
+        big = sr > 1.0
+        assert np.all(sg[big] < 1.6 * sr[big]) and np.all(sg[big] > 0.6 * sr[big])
+        # and the samples scatter around the EM estimate
+        assert np.all(np.abs(ga.mean(axis=0) - g.abundances) <= 6 * sg / np.sqrt(n) + 0.05 * g.total_count + 1.0)
+
+
+def test_gibbs_read_count_samples_are_reproducible_and_seeded(engine):
+    clusters = small_cases.make_batch_clusters(811, n_clusters=3, with_empty=False)
+    batch = ClusterBatch.from_clusters(clusters)
+    a, _ = engine.run("transcripts", make_params(num_gibbs_samples=20, gibbs_thin_its=3, rng_seed=1), engine.prepare(batch))
+    b, _ = engine.run("transcripts", make_params(num_gibbs_samples=20, gibbs_thin_its=3, rng_seed=1), engine.prepare(batch))
+    c, _ = engine.run("transcripts", make_params(num_gibbs_samples=20, gibbs_thin_its=3, rng_seed=2), engine.prepare(batch))
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x.gibbs_samples[0][2], y.gibbs_samples[0][2])
+        assert not np.array_equal(x.gibbs_samples[0][2], z.gibbs_samples[0][2])
+
+
+def test_gibbs_read_count_samples_nested(engine):
+    clusters = small_cases.make_batch_clusters(821, n_clusters=6, with_empty=False)
+    batch = ClusterBatch.from_clusters(clusters)
+    n = 60
+    params = make_params(num_gibbs_samples=n, gibbs_thin_its=4, rng_seed=9)
+    ref, _ = pyoracle.run("haplotype-transcripts", params, batch, 2)
+    got, _ = engine.run("haplotype-transcripts", params, engine.prepare(batch))
+    _compare(got, ref)
+    for g, r in zip(got, ref):
+        # the -n samples of a cluster are split over its path subsets (binomially on the subset weights)
+        assert sum(len(s[1]) for s in g.gibbs_samples) == sum(len(s[1]) for s in r.gibbs_samples) <= n
+        subsets = set(g.em_cols)
+        for ids, noise, ab in g.gibbs_samples:
+            assert ids in subsets
+            assert ab.shape == (len(noise), len(ids))
+            assert np.all(np.abs(ab.sum(axis=1) + noise - g.total_count) <= 1e-9 * g.total_count)
