@@ -185,6 +185,14 @@ int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_hip_groups *
 int rpvg_hip_pair_posteriors_get(const rpvg_hip_pair_posteriors * result, rpvg_hip_pair_posteriors_view * view_out);
 void rpvg_hip_pair_posteriors_free(rpvg_hip_pair_posteriors * result);
 
+/* ---- minimum path cover (`-i strains`) ------------------------------------ */
+/* For every listed cluster: the read-path cover and path weights of MinimumPathAbundanceEstimator::estimate
+ * (src/path_abundance_estimator.cpp:233-257) and the greedy weightedMinimumPathCover (:297-340) on the GPU.
+ * cover[cover_off[i] .. cover_off[i] + cover_size[i]) receives the ascending cover of clusters[i];
+ * the range cover_off[i+1] - cover_off[i] must hold the cluster's number of paths. */
+int rpvg_hip_min_path_cover(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t num_clusters,
+                            const uint32_t * clusters, const uint64_t * cover_off, uint32_t * cover, uint32_t * cover_size);
+
 /* ---- synthetic workload (bench / tests only) ---------------------------- */
 /* Fills a dense normalised R x C matrix (layout of rpvg_hip_em_dense) and unit
  * counts on the GPU from a counter-based generator: the "1M read pairs x 2k

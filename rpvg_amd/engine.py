@@ -16,7 +16,7 @@ from .batch import CClusterBatch, CEstimatesView, CParams, ClusterBatch, Cluster
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "host", "librpvg_amd_host.so")
 
-MODELS = ("transcripts", "haplotype-transcripts", "haplotypes")
+MODELS = ("transcripts", "strains", "haplotype-transcripts", "haplotypes")
 
 _lib = None
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "rpvg_hip_batch_upload", "rpvg_hip_batch_free", "rpvg_hip_em_solve", "rpvg_hip_em_dense",
     "rpvg_hip_dense_from_cluster", "rpvg_hip_groups_build", "rpvg_hip_groups_free", "rpvg_hip_group_loglik",
     "rpvg_hip_synth_dense_cluster", "rpvg_hip_stats_get", "rpvg_hip_stats_reset",
-    "rpvg_hip_gibbs_read_counts", "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
+    "rpvg_hip_gibbs_read_counts", "rpvg_hip_min_path_cover", "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
 ]
 
 
@@ -234,6 +234,18 @@ class Context:
                                        C.byref(probs), C.byref(res)), "rpvg_hip_em_solve")
         off = col_off.astype(np.int64)
         return [abund[off[p]:off[p + 1]] for p in range(P)], noise, total, iters
+
+    def min_path_cover(self, batch: DeviceBatch, clusters: Sequence[int]) -> List[List[int]]:
+        cl = np.ascontiguousarray(clusters, dtype=np.uint32)
+        n_paths = [int(batch.host.cluster_path_off[k + 1] - batch.host.cluster_path_off[k]) for k in clusters]
+        off = np.zeros(len(cl) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(n_paths)
+        cover = np.zeros(int(off[-1]), dtype=np.uint32)
+        size = np.zeros(len(cl), dtype=np.uint32)
+        _check(lib().rpvg_hip_min_path_cover(self.handle, batch.handle, C.c_uint32(len(cl)), C.c_void_p(cl.ctypes.data),
+                                             C.c_void_p(off.ctypes.data), C.c_void_p(cover.ctypes.data),
+                                             C.c_void_p(size.ctypes.data)), "rpvg_hip_min_path_cover")
+        return [[int(x) for x in cover[int(off[i]):int(off[i]) + int(size[i])]] for i in range(len(cl))]
 
     # ---- dense ----------------------------------------------------------------
     def malloc(self, nbytes: int) -> int:

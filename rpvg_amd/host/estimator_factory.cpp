@@ -21,7 +21,7 @@ std::unique_ptr<PathEstimator> makePathEstimator(const std::string & inference_m
 
     } else if (inference_model == "strains") {
 
-        throw EngineError("inference model 'strains' (minimum path cover) is not available in the GPU engine yet");
+        return std::unique_ptr<PathEstimator>(new MinimumPathAbundanceEstimator(params.max_em_its, params.max_rel_em_conv, params.num_gibbs_samples, params.gibbs_thin_its, params.prob_precision, engine));
     }
 
     throw EngineError("unknown inference model '" + inference_model + "'");

@@ -11,8 +11,7 @@
 
 namespace rpvg_amd {
 
-// inference_model: "haplotypes" | "transcripts" | "haplotype-transcripts".
-// ("strains" — the minimum path cover model — is not on the GPU engine yet.)
+// inference_model: "haplotypes" | "transcripts" | "strains" | "haplotype-transcripts".
 std::unique_ptr<PathEstimator> makePathEstimator(const std::string & inference_model, const rpvg_params & params, std::shared_ptr<HipEngine> engine);
 
 }

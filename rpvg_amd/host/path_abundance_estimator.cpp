@@ -205,6 +205,117 @@ void PathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimates> * p
     }
 }
 
+MinimumPathAbundanceEstimator::MinimumPathAbundanceEstimator(const uint32_t max_em_its, const double max_rel_em_conv, const uint32_t num_gibbs_samples, const uint32_t gibbs_thin_its, const double prob_precision, std::shared_ptr<HipEngine> engine) : PathAbundanceEstimator(max_em_its, max_rel_em_conv, num_gibbs_samples, gibbs_thin_its, prob_precision, engine) {}
+
+std::vector<std::vector<uint32_t> > MinimumPathAbundanceEstimator::weightedMinimumPathCover(const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters) const {
+
+    std::vector<std::vector<uint32_t> > covers(clusters.size());
+
+    if (clusters.empty()) {
+
+        return covers;
+    }
+
+    std::vector<uint64_t> cover_off(1, 0);
+
+    for (auto & cluster: clusters) {
+
+        cover_off.emplace_back(cover_off.back() + cluster_batch.numPaths(cluster));
+    }
+
+    std::vector<uint32_t> cover(cover_off.back());
+    std::vector<uint32_t> cover_size(clusters.size());
+
+    HipEngine::check(rpvg_hip_min_path_cover(engine->ctx(), cluster_batch.handle(), clusters.size(), clusters.data(), cover_off.data(), cover.data(), cover_size.data()), "rpvg_hip_min_path_cover");
+
+    for (size_t i = 0; i < clusters.size(); ++i) {
+
+        covers.at(i).assign(cover.begin() + cover_off.at(i), cover.begin() + cover_off.at(i) + cover_size.at(i));
+    }
+
+    return covers;
+}
+
+// src/path_abundance_estimator.cpp:217-295 over a batch of clusters.
+void MinimumPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs) {
+
+    if (num_gibbs_samples > 0 && !rngs) {
+
+        throw EngineError("read-count Gibbs sampling draws random numbers: a generator per cluster is required");
+    }
+
+    assert(path_cluster_estimates->size() == cluster_batch.numClusters());
+
+    std::vector<uint32_t> clusters;
+
+    for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
+
+        auto & estimates = path_cluster_estimates->at(i);
+
+        assert(estimates.paths.size() == cluster_batch.numPaths(i));
+        estimates.resetEstimates(estimates.paths.size(), 1);
+
+        if (cluster_batch.numRows(i) > 0) {
+
+            clusters.emplace_back(i);
+        }
+    }
+
+    const auto covers = weightedMinimumPathCover(cluster_batch, clusters);
+
+    // EM on the covering paths of every cluster that has any (:262-293)
+    std::vector<EMProblem> problems;
+
+    for (size_t i = 0; i < clusters.size(); ++i) {
+
+        if (!covers.at(i).empty()) {
+
+            problems.emplace_back(EMProblem());
+            problems.back().cluster = clusters.at(i);
+            problems.back().path_ids = covers.at(i);
+        }
+    }
+
+    std::vector<EMSolution> solutions;
+    EMAbundanceEstimator(&solutions, cluster_batch, problems);
+
+    std::vector<CountSamples> count_samples;
+
+    if (num_gibbs_samples > 0) {
+
+        std::vector<uint32_t> num_samples(problems.size(), num_gibbs_samples);
+        std::vector<uint64_t> seeds;
+
+        for (auto & problem: problems) {
+
+            seeds.emplace_back(drawSeed(&rngs->at(problem.cluster)));
+        }
+
+        gibbsReadCountSampler(&count_samples, cluster_batch, problems, solutions, num_samples, seeds);
+    }
+
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        auto & estimates = path_cluster_estimates->at(problems.at(i).cluster);
+
+        for (size_t j = 0; j < problems.at(i).path_ids.size(); ++j) {
+
+            estimates.abundances.at(problems.at(i).path_ids.at(j)) += solutions.at(i).abundances.at(j);
+        }
+
+        estimates.noise_count = solutions.at(i).noise_count;
+        estimates.total_count = solutions.at(i).total_count;
+
+        estimates.em_iterations.emplace_back(solutions.at(i).iterations);
+        estimates.em_problem_paths.emplace_back(problems.at(i).path_ids);
+
+        if (!count_samples.empty()) {
+
+            estimates.gibbs_read_count_samples.emplace_back(std::move(count_samples.at(i)));
+        }
+    }
+}
+
 NestedPathAbundanceEstimator::NestedPathAbundanceEstimator(const uint32_t group_size_in, const double min_hap_prob_in, const bool infer_collapsed_in, const bool use_group_post_gibbs_in, const uint32_t max_em_its, const double max_rel_em_conv, const uint32_t num_gibbs_samples, const uint32_t gibbs_thin_its, const double prob_precision, std::shared_ptr<HipEngine> engine) : PathAbundanceEstimator(max_em_its, max_rel_em_conv, num_gibbs_samples, gibbs_thin_its, prob_precision, engine), group_size(group_size_in), min_hap_prob(min_hap_prob_in), infer_collapsed(infer_collapsed_in), use_group_post_gibbs(use_group_post_gibbs_in) {}
 
 // src/path_abundance_estimator.cpp:344-471 over a batch of clusters: posteriors of

@@ -62,6 +62,21 @@ class PathAbundanceEstimator : public PathEstimator {
         static uint64_t drawSeed(std::mt19937 * mt_rng);
 };
 
+// `-i strains` (src/path_abundance_estimator.hpp:39-49): greedy weighted minimum path cover of the cluster's
+// reads, then the EM on the covering paths only.
+class MinimumPathAbundanceEstimator : public PathAbundanceEstimator {
+
+    public:
+
+        MinimumPathAbundanceEstimator(const uint32_t max_em_its, const double max_rel_em_conv, const uint32_t num_gibbs_samples, const uint32_t gibbs_thin_its, const double prob_precision, std::shared_ptr<HipEngine> engine);
+        ~MinimumPathAbundanceEstimator() {};
+
+        void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs);
+
+        // weightedMinimumPathCover (src/path_abundance_estimator.cpp:297-340) of the listed clusters, on the GPU.
+        std::vector<std::vector<uint32_t> > weightedMinimumPathCover(const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters) const;
+};
+
 class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
 
     public:

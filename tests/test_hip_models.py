@@ -135,8 +135,6 @@ def test_unsupported_modes_fail_loudly(engine):
     clusters = small_cases.make_batch_clusters(651, n_clusters=2, with_empty=False)
     prep = engine.prepare(ClusterBatch.from_clusters(clusters))
     with pytest.raises(hip.EngineError):
-        engine.run("strains", make_params(), prep)
-    with pytest.raises(hip.EngineError):
         engine.run("no-such-model", make_params(), prep)
 
 
@@ -292,3 +290,39 @@ def test_gibbs_read_count_samples_nested(engine):
             assert ids in subsets
             assert ab.shape == (len(noise), len(ids))
             assert np.all(np.abs(ab.sum(axis=1) + noise - g.total_count) <= 1e-9 * g.total_count)
+
+
+# ---- -i strains: minimum path cover (src/path_abundance_estimator.cpp:217-340) -------------------------
+
+def test_min_path_cover_reference_case_on_device(hip_ctx):
+    """The reference's own test (src/tests/path_abundance_estimator_test.cpp:8-28): cover rows
+    [1,0,1],[0,1,0],[1,0,0],[0,1,1], counts [1,3,1,5]; weights [1,1,1] -> {0,1}; weight_2 = 0.01 -> {0,1,2}.
+    The device entry derives the weights from the rows (-sum count*log(prob)), so the probabilities are
+    chosen to give exactly those weights."""
+    import math
+
+    def cluster(w2):
+        x = {0: 1 / 2.0, 1: 1 / 8.0, 2: w2 / 6.0}  # sum over a path's rows of count * x = weight
+        rows = [(1, 1e-4, [(math.exp(-x[0]), [0]), (math.exp(-x[2]), [2])]),
+                (3, 1e-4, [(math.exp(-x[1]), [1])]),
+                (1, 1e-4, [(math.exp(-x[0]), [0])]),
+                (5, 1e-4, [(math.exp(-x[1]), [1]), (math.exp(-x[2]), [2])])]
+        rows = [(c, n, sorted(g)) for c, n, g in rows]
+        return dict(paths=[{}, {}, {}], rows=rows)
+
+    batch = ClusterBatch.from_clusters([cluster(1.0), cluster(0.01), dict(paths=[{}], rows=[(2, 0.1, [(0.9, [0])])])])
+    dev = hip_ctx.upload(batch)
+    assert hip_ctx.min_path_cover(dev, [0, 1, 2]) == [[0, 1], [0, 1, 2], [0]]
+
+
+@pytest.mark.parametrize("seed", [901, 902])
+def test_strains_model_matches_oracle(engine, seed):
+    clusters = small_cases.make_batch_clusters(seed, n_clusters=14)
+    batch = ClusterBatch.from_clusters(clusters)
+    ref, _ = pyoracle.run("strains", make_params(), batch, 2)
+    got, _ = engine.run("strains", make_params(), engine.prepare(batch))
+    for g, r in zip(got, ref):
+        assert g.em_cols == r.em_cols  # the cover itself: integer result, exact
+    _compare(got, ref)
+    got1, _ = engine.run("strains", make_params(), engine.prepare(batch, per_cluster=True))
+    _compare(got1, ref)
