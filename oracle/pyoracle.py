@@ -79,6 +79,30 @@ def run(model: str, params: CParams, batch: ClusterBatch, num_threads: int = 1) 
     return out, secs.value
 
 
+class RawRun:
+    """estimate() over a batch, keeping the C view alive (to hand the oracle's estimates to a writer)."""
+
+    def __init__(self, model: str, params: CParams, batch: ClusterBatch, num_threads: int = 1):
+        L = lib()
+        self._batch = batch
+        cb = batch.as_c()
+        self._h = L.rpvg_oracle_run(model.encode(), C.byref(params), C.byref(cb), int(num_threads), None)
+        self.view = CEstimatesView()
+        L.rpvg_oracle_view(self._h, C.byref(self.view))
+        self.estimates = decode_view(self.view)
+
+    def close(self):
+        if self._h:
+            lib().rpvg_oracle_free(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def em_dense(P: np.ndarray, counts: np.ndarray, max_em_its: int = 10000, max_rel_em_conv: float = 1e-3):
     """EMAbundanceEstimator on a normalised dense R x C matrix (last column = noise).
 

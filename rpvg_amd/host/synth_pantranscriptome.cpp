@@ -36,6 +36,7 @@
 #include "../../include/rpvg_batch.h"
 #include "path_cluster_estimates.hpp"
 #include "read_path_probabilities.hpp"
+#include "flat_batch.hpp"
 
 using namespace rpvg_amd;
 
@@ -359,12 +360,7 @@ void generateCluster(SynthCluster * cluster, const rpvg_synth_config & config, c
     sortAndMergeReadPathProbabilities(&cluster->rows);
 }
 
-struct SynthBatch {
-
-    std::vector<uint64_t> cluster_row_off, cluster_path_off, row_grp_off, grp_idx_off, path_source_off;
-    std::vector<uint32_t> row_count, path_idx, path_group_id, path_source_count, source_id;
-    std::vector<double> row_noise, grp_prob, path_effective_length;
-};
+typedef FlatBatchStorage SynthBatch;
 
 }
 
@@ -457,42 +453,9 @@ void * rpvg_amd_synth_generate(const rpvg_synth_config * config_in) {
 
     SynthBatch * batch = new SynthBatch();
 
-    batch->cluster_row_off.push_back(0);
-    batch->cluster_path_off.push_back(0);
-    batch->row_grp_off.push_back(0);
-    batch->grp_idx_off.push_back(0);
-    batch->path_source_off.push_back(0);
-
     for (auto & cluster: clusters) {
 
-        for (auto & path: cluster.paths) {
-
-            batch->path_group_id.push_back(path.group_id);
-            batch->path_source_count.push_back(path.source_count);
-            batch->source_id.insert(batch->source_id.end(), path.source_ids.begin(), path.source_ids.end());
-            batch->path_source_off.push_back(batch->source_id.size());
-            batch->path_effective_length.push_back(path.effective_length);
-        }
-
-        batch->cluster_path_off.push_back(batch->path_group_id.size());
-
-        for (auto & row: cluster.rows) {
-
-            batch->row_count.push_back(row.readCount());
-            batch->row_noise.push_back(row.noiseProb());
-
-            for (auto & path_probs: row.pathProbs()) {
-
-                batch->grp_prob.push_back(path_probs.first);
-                batch->path_idx.insert(batch->path_idx.end(), path_probs.second.begin(), path_probs.second.end());
-                batch->grp_idx_off.push_back(batch->path_idx.size());
-            }
-
-            batch->row_grp_off.push_back(batch->grp_prob.size());
-        }
-
-        batch->cluster_row_off.push_back(batch->row_count.size());
-
+        batch->addCluster(cluster.paths, cluster.rows);
         std::vector<ReadPathProbabilities>().swap(cluster.rows);
     }
 
@@ -531,61 +494,14 @@ void * rpvg_amd_rows_from_likelihoods(uint32_t num_paths, uint32_t num_reads, co
     sortAndMergeReadPathProbabilities(&rows);
 
     SynthBatch * batch = new SynthBatch();
-
-    batch->cluster_row_off.push_back(0);
-    batch->cluster_path_off.push_back(0);
-    batch->row_grp_off.push_back(0);
-    batch->grp_idx_off.push_back(0);
-    batch->path_source_off.push_back(0);
-
-    for (uint32_t p = 0; p < num_paths; ++p) {
-
-        batch->path_group_id.push_back(0);
-        batch->path_source_count.push_back(1);
-        batch->path_source_off.push_back(0);
-        batch->path_effective_length.push_back(0);
-    }
-
-    batch->cluster_path_off.push_back(num_paths);
-
-    for (auto & row: rows) {
-
-        batch->row_count.push_back(row.readCount());
-        batch->row_noise.push_back(row.noiseProb());
-
-        for (auto & path_probs: row.pathProbs()) {
-
-            batch->grp_prob.push_back(path_probs.first);
-            batch->path_idx.insert(batch->path_idx.end(), path_probs.second.begin(), path_probs.second.end());
-            batch->grp_idx_off.push_back(batch->path_idx.size());
-        }
-
-        batch->row_grp_off.push_back(batch->grp_prob.size());
-    }
-
-    batch->cluster_row_off.push_back(batch->row_count.size());
+    batch->addCluster(std::vector<PathInfo>(num_paths, PathInfo()), rows);
 
     return batch;
 }
 
 void rpvg_amd_synth_view(void * handle, rpvg_cluster_batch * out) {
 
-    SynthBatch * batch = static_cast<SynthBatch *>(handle);
-
-    out->num_clusters = batch->cluster_row_off.size() - 1;
-    out->cluster_row_off = batch->cluster_row_off.data();
-    out->cluster_path_off = batch->cluster_path_off.data();
-    out->row_count = batch->row_count.data();
-    out->row_noise = batch->row_noise.data();
-    out->row_grp_off = batch->row_grp_off.data();
-    out->grp_prob = batch->grp_prob.data();
-    out->grp_idx_off = batch->grp_idx_off.data();
-    out->path_idx = batch->path_idx.data();
-    out->path_group_id = batch->path_group_id.data();
-    out->path_source_count = batch->path_source_count.data();
-    out->path_source_off = batch->path_source_off.data();
-    out->source_id = batch->source_id.data();
-    out->path_effective_length = batch->path_effective_length.data();
+    static_cast<SynthBatch *>(handle)->view(out);
 }
 
 void rpvg_amd_synth_sizes(void * handle, uint64_t * rows, uint64_t * groups, uint64_t * entries, uint64_t * paths, uint64_t * sources) {

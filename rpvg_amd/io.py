@@ -1,0 +1,67 @@
+"""ctypes binding of the file formats either side of the hot path and of the replay driver
+(``rpvg_amd/host/io``): `--write-probs` dumps, `-f` path info, the reference's result TSVs."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+from . import engine as _engine, hip, synth
+from .batch import CClusterBatch, CEstimatesView, CParams, ClusterBatch
+
+
+def _lib():
+    L = _engine.lib()
+    L.rpvg_amd_io_last_error.restype = C.c_char_p
+    L.rpvg_amd_batch_write_files.restype = C.c_int
+    L.rpvg_amd_batch_write_files.argtypes = [C.POINTER(CClusterBatch), C.c_char_p, C.c_char_p, C.c_double]
+    L.rpvg_amd_batch_read_files.restype = C.c_void_p
+    L.rpvg_amd_batch_read_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double]
+    L.rpvg_amd_replay.restype = C.c_int64
+    L.rpvg_amd_replay.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(CParams), C.c_char_p, C.c_int, C.c_uint32]
+    L.rpvg_amd_write_estimates.restype = C.c_int
+    L.rpvg_amd_write_estimates.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(CParams), C.POINTER(CEstimatesView),
+                                           C.c_char_p, C.c_uint32]
+    return L
+
+
+def _fail(what):
+    raise hip.EngineError(f"{what} failed: {_lib().rpvg_amd_io_last_error().decode()}")
+
+
+def write_batch_files(batch: ClusterBatch, probs_path: str, info_path: str, prob_precision: float = 1e-8):
+    """The batch as a `--write-probs` dump plus a matching `-f` path info TSV (generated names)."""
+    cb = batch.as_c()
+    if _lib().rpvg_amd_batch_write_files(C.byref(cb), probs_path.encode(), info_path.encode(), prob_precision) != 0:
+        _fail("write_batch_files")
+
+
+def read_batch_files(probs_path: str, info_path: Optional[str], parse_haplotype_ids: bool = True,
+                     prob_precision: float = 1e-8) -> ClusterBatch:
+    """A dump (+ path info) as a flat batch, clusters ranked by read count as the replay ranks them."""
+    L = _lib()
+    synth._bind()
+    h = L.rpvg_amd_batch_read_files(probs_path.encode(), (info_path or "").encode(), 1 if parse_haplotype_ids else 0, prob_precision)
+    if not h:
+        _fail("read_batch_files")
+    try:
+        return synth._to_batch(L, h)
+    finally:
+        L.rpvg_amd_synth_free(h)
+
+
+def replay(probs_path: str, info_path: Optional[str], model: str, params: CParams, prefix: str, device: int = 0,
+           unaligned_read_count: int = 0) -> int:
+    """Dump -> GPU estimators -> the reference's result files.  Returns the number of clusters."""
+    n = _lib().rpvg_amd_replay(probs_path.encode(), (info_path or "").encode(), model.encode(), C.byref(params), prefix.encode(),
+                               device, unaligned_read_count)
+    if n < 0:
+        _fail("replay")
+    return int(n)
+
+
+def write_estimates(probs_path: str, info_path: Optional[str], model: str, params: CParams, view: CEstimatesView, prefix: str,
+                    unaligned_read_count: int = 0):
+    """The reference's result files for estimates computed elsewhere (writers only; no GPU)."""
+    if _lib().rpvg_amd_write_estimates(probs_path.encode(), (info_path or "").encode(), model.encode(), C.byref(params),
+                                       C.byref(view), prefix.encode(), unaligned_read_count) != 0:
+        _fail("write_estimates")

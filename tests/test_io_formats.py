@@ -1,0 +1,208 @@
+"""File formats either side of the hot path, CPU only:
+`--write-probs` dump reader/writer (src/threaded_output_writer.cpp:42-95), `-f` path info parser
+(src/main.cpp:239-353) and the result TSV writers (src/threaded_output_writer.cpp:98-546)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from rpvg_amd import io as rio, synth
+from rpvg_amd.batch import make_params
+
+
+def fmt(x):
+    """std::setprecision(8) with default float formatting."""
+    return "%.8g" % x
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("io")
+    batch = synth.generate(seed=31, num_clusters=25, total_paths=500, total_reads=20000)
+    probs, info = str(d / "run_probs.txt.gz"), str(d / "info.tsv")
+    rio.write_batch_files(batch, probs, info)
+    return dict(dir=d, batch=batch, probs=probs, info=info)
+
+
+def test_probs_dump_format_and_round_trip(files):
+    text = gzip.open(files["probs"], "rt").read().splitlines()
+    assert text[0] == "#"
+    first_paths = text[1].split(" ")
+    name, length, eff = first_paths[0].rsplit(",", 2)
+    assert name == "c0_p0" and int(length) > 0 and float(eff) > 0
+    cnt, noise, *groups = text[2].split(" ")
+    assert int(cnt) >= 1 and 0 < float(noise) <= 1
+    for g in groups:
+        prob, idx = g.split(":")
+        assert float(prob) > 0 and all(int(i) < len(first_paths) for i in idx.split(","))
+    assert sum(1 for line in text if line == "#") == files["batch"].num_clusters
+
+    back = rio.read_batch_files(files["probs"], files["info"])
+    orig = files["batch"]
+    assert back.num_clusters == orig.num_clusters and back.num_rows == orig.num_rows and back.num_paths == orig.num_paths
+    assert back.total_reads == orig.total_reads
+    # the generator already emits clusters by descending read count, so the ranking keeps the order
+    assert np.array_equal(back.cluster_row_off, orig.cluster_row_off)
+    assert np.array_equal(back.row_count, orig.row_count)
+    assert np.array_equal(back.path_idx, orig.path_idx)
+    # transcript ids are re-numbered densely over the whole file (first seen); per cluster the partition is the same
+    for k in range(orig.num_clusters):
+        p0, p1 = int(orig.cluster_path_off[k]), int(orig.cluster_path_off[k + 1])
+        a, b = orig.path_group_id[p0:p1], back.path_group_id[p0:p1]
+        assert len(set(zip(a.tolist(), b.tolist()))) == len(set(a.tolist())) == len(set(b.tolist()))
+    # values carry 8 significant digits in the dump
+    assert np.allclose(back.grp_prob, orig.grp_prob, rtol=1e-7, atol=0)
+    assert np.allclose(back.row_noise, orig.row_noise, rtol=1e-7, atol=0)
+    # haplotype ids are re-numbered densely in first-seen order; the grouping they induce is unchanged
+    for k in (0, 7, 24):
+        a, b = orig.cluster(k)["paths"], back.cluster(k)["paths"]
+        rel = {}
+        for pa, pb in zip(a, b):
+            assert len(pa["source_ids"]) == len(pb["source_ids"]) == pb["source_count"]
+        by_a = {s: tuple(i for i, p in enumerate(a) if s in p["source_ids"]) for p in a for s in p["source_ids"]}
+        by_b = {s: tuple(i for i, p in enumerate(b) if s in p["source_ids"]) for p in b for s in p["source_ids"]}
+        assert sorted(by_a.values()) == sorted(by_b.values())
+
+
+def test_path_info_parser_formats(tmp_path):
+    new = tmp_path / "new.tsv"
+    new.write_text("Name\tLength\tTranscript\tHaplotypes\nh1\t100\ttA\tx,y\nh2\t90\ttA\ty\nh3\t50\ttB\tz,x,w\n")
+    old = tmp_path / "old.tsv"
+    old.write_text("Name\tLength\tTranscript\tReference\tHaplotypes\nh1\t100\ttA\tref1\tx,y\nh2\t90\ttA\tref1\ty\nh3\t50\ttB\tref2\tz,x,w\n")
+    probs = tmp_path / "p.txt"
+    probs.write_text("#\nh1,100,80 h2,90,70 h3,50,30\n3 0.001 0.3:0,1 0.5:2\n")
+    for info in (new, old):
+        b = rio.read_batch_files(str(probs), str(info), parse_haplotype_ids=True)
+        cl = b.cluster(0)
+        assert [p["group_id"] for p in cl["paths"]] == [0, 0, 1]          # dense transcript ids, first seen
+        assert [p["source_ids"] for p in cl["paths"]] == [[0, 1], [1], [0, 2, 3]]  # dense haplotype ids, first seen
+        assert [p["source_count"] for p in cl["paths"]] == [2, 1, 3]
+        assert cl["rows"] == [(3, 0.001, [(0.3, [0, 1]), (0.5, [2])])]
+        b2 = rio.read_batch_files(str(probs), str(info), parse_haplotype_ids=False)
+        assert [p["source_count"] for p in b2.cluster(0)["paths"]] == [2, 1, 3] and not b2.source_id.size
+    dup = tmp_path / "dup.tsv"
+    dup.write_text("Name\tLength\tTranscript\tHaplotypes\nh1\t1\tt\tx\nh1\t1\tt\ty\n")
+    from rpvg_amd import hip
+    with pytest.raises(hip.EngineError):
+        rio.read_batch_files(str(probs), str(dup))
+    missing = tmp_path / "missing.tsv"
+    missing.write_text("Name\tLength\tTranscript\tHaplotypes\nh1\t1\tt\tx\n")
+    with pytest.raises(hip.EngineError):
+        rio.read_batch_files(str(probs), str(missing))
+
+
+def _names(batch, k):
+    return [f"c{k}_p{j}" for j in range(int(batch.cluster_path_off[k + 1] - batch.cluster_path_off[k]))]
+
+
+def test_abundance_writer_format(files):
+    batch = rio.read_batch_files(files["probs"], files["info"])
+    params = make_params()
+    prefix = str(files["dir"] / "tx")
+    with pyoracle.RawRun("transcripts", params, batch, 2) as run:
+        rio.write_estimates(files["probs"], files["info"], "transcripts", params, run.view, prefix, unaligned_read_count=17)
+        est = run.estimates
+    lines = open(prefix + ".txt").read().splitlines()
+    assert lines[0] == "Name\tClusterID\tLength\tEffectiveLength\tReadCount\tTPM"
+    eff = batch.path_effective_length
+    total_tc = sum(a / eff[int(batch.cluster_path_off[k]) + j] for k, e in enumerate(est) for j, a in enumerate(e.abundances))
+    row = 1
+    for k, e in enumerate(est):
+        for j, a in enumerate(e.abundances):
+            el = eff[int(batch.cluster_path_off[k]) + j]
+            want = [f"c{k}_p{j}", str(k + 1), str(int(el) + 50), fmt(el), fmt(a), fmt(a / el / total_tc * 1e6)]
+            assert lines[row].split("\t") == want, (row, lines[row], want)
+            row += 1
+    assert lines[row] == "Unknown\t0\t0\t0\t" + fmt(sum(e.noise_count for e in est) + 17) + "\t0"
+    assert row + 1 == len(lines)
+    tpm = sum(float(l.split("\t")[5]) for l in lines[1:-1])
+    assert abs(tpm - 1e6) < 1.0
+
+
+def test_haplotype_transcript_writers_format(files):
+    batch = rio.read_batch_files(files["probs"], files["info"])
+    params = make_params()
+    prefix = str(files["dir"] / "ht")
+    with pyoracle.RawRun("haplotype-transcripts", params, batch, 2) as run:
+        rio.write_estimates(files["probs"], files["info"], "haplotype-transcripts", params, run.view, prefix, unaligned_read_count=4)
+        est = run.estimates
+    eff = batch.path_effective_length
+    total_tc = 0.0
+    for k, e in enumerate(est):
+        a = 0
+        for s in e.path_group_sets:
+            for p in s:
+                total_tc += e.abundances[a] / eff[int(batch.cluster_path_off[k]) + p]
+                a += 1
+    # <prefix>.txt: one row per path
+    lines = open(prefix + ".txt").read().splitlines()
+    assert lines[0] == "Name\tClusterID\tLength\tEffectiveLength\tHaplotypeProbability\tReadCount\tTPM"
+    row = 1
+    for k, e in enumerate(est):
+        n = int(batch.cluster_path_off[k + 1] - batch.cluster_path_off[k])
+        prob, cnt = np.zeros(n), np.zeros(n)
+        a = 0
+        for s, post in zip(e.path_group_sets, e.posteriors):
+            for j, p in enumerate(s):
+                if j == 0 or s[j] != s[j - 1]:
+                    prob[p] += post
+                cnt[p] += e.abundances[a]
+                a += 1
+        for j in range(n):
+            el = eff[int(batch.cluster_path_off[k]) + j]
+            want = [f"c{k}_p{j}", str(k + 1), str(int(el) + 50), fmt(el), fmt(prob[j]), fmt(cnt[j]), fmt(cnt[j] / el / total_tc * 1e6)]
+            assert lines[row].split("\t") == want, (row, lines[row], want)
+            row += 1
+    assert lines[row] == "Unknown\t0\t0\t0\t0\t" + fmt(sum(e.noise_count for e in est) + 4) + "\t0"
+    # <prefix>_joint.txt: one row per group set
+    joint = open(prefix + "_joint.txt").read().splitlines()
+    assert joint[0] == "Name_1\tName_2\tClusterID\tHaplotypingProbability\tReadCount_1\tTPM_1\tReadCount_2\tTPM_2"
+    row = 1
+    for k, e in enumerate(est):
+        a = 0
+        for s, post in zip(e.path_group_sets, e.posteriors):
+            names = [f"c{k}_p{p}" for p in s] + ["."] * (2 - len(s))
+            vals = []
+            for p in s:
+                el = eff[int(batch.cluster_path_off[k]) + p]
+                vals += [fmt(e.abundances[a]), fmt(e.abundances[a] / el / total_tc * 1e6)]
+                a += 1
+            vals += ["0", "0"] * (2 - len(s))
+            assert joint[row].split("\t") == names + [str(k + 1), fmt(post)] + vals, (row, joint[row])
+            row += 1
+    half = sum(e.noise_count / 2 for e in est) + 4 / 2
+    assert joint[row] == "Unknown\tUnknown\t0\t0\t" + fmt(half) + "\t0\t" + fmt(half) + "\t0"
+
+
+def test_haplotypes_and_gibbs_writers_format(files):
+    batch = rio.read_batch_files(files["probs"], files["info"], parse_haplotype_ids=False)
+    params = make_params()
+    prefix = str(files["dir"] / "hap")
+    with pyoracle.RawRun("haplotypes", params, batch, 2) as run:
+        rio.write_estimates(files["probs"], files["info"], "haplotypes", params, run.view, prefix)
+        est = run.estimates
+    lines = open(prefix + ".txt").read().splitlines()
+    assert lines[0] == "Name_1\tName_2\tClusterID\tHaplotypingProbability"
+    want = [[f"c{k}_p{s[0]}", f"c{k}_p{s[1]}", str(k + 1), fmt(p)] for k, e in enumerate(est)
+            for s, p in zip(e.path_group_sets, e.posteriors) if p >= 1e-8]
+    assert [l.split("\t") for l in lines[1:]] == want
+
+    n = 6
+    params = make_params(num_gibbs_samples=n, gibbs_thin_its=2, rng_seed=3)
+    prefix = str(files["dir"] / "g")
+    with pyoracle.RawRun("transcripts", params, batch, 2) as run:
+        rio.write_estimates(files["probs"], files["info"], "transcripts", params, run.view, prefix, unaligned_read_count=5)
+        est = run.estimates
+    lines = gzip.open(prefix + "_gibbs.txt.gz", "rt").read().splitlines()
+    assert lines[0] == "Name\tClusterID" + "".join(f"\tReadCountSample_{i + 1}" for i in range(n))
+    row = 1
+    noise = np.zeros(n)
+    for k, e in enumerate(est):
+        (ids, ns, ab), = e.gibbs_samples
+        noise += ns
+        for j, p in enumerate(ids):
+            assert lines[row].split("\t") == [f"c{k}_p{p}", str(k + 1)] + [fmt(x) for x in ab[:, j]], row
+            row += 1
+    assert lines[row].split("\t") == ["Unknown", "0"] + [fmt(x + 5) for x in noise]
