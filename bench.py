@@ -53,7 +53,7 @@ def dist_setup(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("RPVG_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path with one rank
         import torch.distributed as dist_mod
         torch.cuda.set_device(local_rank)
         dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -188,9 +188,50 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         upload_ms=upload_ms, value_including_upload=float(batch.total_reads) / ((ms_per_step + upload_ms) / 1e3) * world)
     if gathered is not None:
         line["gathered_abundance_mass"] = gathered
+    if args.scale >= 1.0:
+        try:
+            line["roofline_dense_em"] = dense_em_roofline(local_rank)
+        except Exception as exc:  # the record is optional; the default workload's line stands on its own
+            line["roofline_dense_em"] = dict(error=str(exc))
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_s3(batch, args.model, params, args.cpu_seconds)
     return line
+
+
+def dense_em_roofline(local_rank, rows=1000000, paths=2000, its=20):
+    """Short measurement of the HBM-streaming dense EM kernel (BASELINE.json configs[1] shape) for the roofline
+    record of the default run: the batched kernels of the default workload run out of L2/LDS."""
+    from rpvg_amd import hip
+    Cn = paths + 1
+    ld = (Cn + 1) & ~1
+    ctx = hip.Context(local_rank)
+    d_P = d_c = None
+    try:
+        d_P, d_c = ctx.malloc(rows * ld * 8), ctx.malloc(rows * 8)
+        ctx.synth_dense_cluster(2, rows, paths, d_P, ld, d_c)
+        ctx.em_dense(d_P, rows, Cn, ld, d_c, float(rows), max_em_its=3, max_rel_em_conv=0.0)
+        ctx.reset_stats()
+        ctx.em_dense(d_P, rows, Cn, ld, d_c, float(rows), max_em_its=its, max_rel_em_conv=0.0)
+        st = ctx.stats()
+        ms = st["em_dense_ms"] / max(1, st["em_dense_launches"])
+        nbytes = st["em_dense_alg_bytes"] / max(1, st["em_dense_launches"])
+        achieved = (nbytes / 1e9) / (ms / 1e3)
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_c2.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc["shape"]["rows"] == rows and pmc["shape"]["cols"] == Cn:
+                traffic = pmc["traffic_bytes_per_launch"]
+        return dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                    kernel="emDenseAccumWideKernel", ms_per_launch=ms, algorithmic_bytes_per_launch=nbytes,
+                    workload=f"single dense cluster {rows} x {Cn} FP64 ({rows * Cn * 8 / 1e9:.1f} GB), {its} EM iterations; "
+                             "one launch = one iteration's streaming pass")
+    finally:
+        if d_P:
+            ctx.free(d_P)
+        if d_c:
+            ctx.free(d_c)
+        ctx.close()
 
 
 def run_c2(args, rank, local_rank, world, dist, torch):

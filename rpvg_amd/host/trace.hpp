@@ -28,7 +28,15 @@ inline int hostThreads() {
             return std::max(1, std::atoi(env));
         }
 
-        return std::max(1, std::min(48, omp_get_max_threads()));
+        int threads = std::min(48, omp_get_max_threads());
+
+        // one process per GPU: share the host's hardware threads between the local ranks
+        if (const char * local_world = std::getenv("LOCAL_WORLD_SIZE")) {
+
+            threads = std::min(threads, std::max(4, omp_get_max_threads() / std::max(1, std::atoi(local_world))));
+        }
+
+        return std::max(1, threads);
     }();
 
     return threads;
