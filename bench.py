@@ -235,24 +235,33 @@ def dense_em_roofline(local_rank, rows=1000000, paths=2000, its=20):
 
 
 def run_c2(args, rank, local_rank, world, dist, torch):
-    """1M x 2k dense single cluster (BASELINE.json configs[1]); `replicas only` across GPUs."""
+    """1M x 2k dense single cluster (BASELINE.json configs[1]).  Weak scaling (default): one replica of the
+    cluster per GPU, no collective.  --scaling strong: the rows of ONE cluster are spread over the ranks and every
+    EM iteration all-reduces its C partial column sums over RCCL (rpvg_hip_em_dense_sharded)."""
     import numpy as np
-    from rpvg_amd import hip
-    R = max(1024, int(round(1000000 * args.scale)))
+    from rpvg_amd import hip, dist as rdist
+    R_all = max(1024, int(round(1000000 * args.scale)))
     N = 2000
     Cn = N + 1
     ld = (Cn + 1) & ~1
     its = 50
+    sharded = args.scaling == "strong" and dist is not None
     ctx = hip.Context(local_rank)
+    if sharded:
+        rdist.init_engine_comm(ctx, dist, f"cuda:{local_rank}")
+        r0, r1 = rdist.row_shard(R_all, rank, world)
+        R, total = r1 - r0, float(R_all)
+    else:
+        r0, R, total = 0, R_all, float(R_all)
     d_P, d_c = ctx.malloc(R * ld * 8), ctx.malloc(R * 8)
-    ctx.synth_dense_cluster(2 + rank, R, N, d_P, ld, d_c)
+    ctx.synth_dense_rows(2 if sharded else 2 + rank, r0, R, N, d_P, ld, d_c)
     for _ in range(args.warmup):
-        ctx.em_dense(d_P, R, Cn, ld, d_c, float(R), max_em_its=its, max_rel_em_conv=0.0)
+        ctx.em_dense(d_P, R, Cn, ld, d_c, total, max_em_its=its, max_rel_em_conv=0.0, sharded=sharded)
     ctx.reset_stats()
     barrier_sync(dist, torch)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ab, noise, done = ctx.em_dense(d_P, R, Cn, ld, d_c, float(R), max_em_its=its, max_rel_em_conv=0.0)
+        ab, noise, done = ctx.em_dense(d_P, R, Cn, ld, d_c, total, max_em_its=its, max_rel_em_conv=0.0, sharded=sharded)
     barrier_sync(dist, torch)
     elapsed = max_over_ranks(time.perf_counter() - t0, dist, torch)
     stats = ctx.stats()
@@ -266,19 +275,21 @@ def run_c2(args, rank, local_rank, world, dist, torch):
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_c2.json")
     if os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
-        if pmc["shape"]["rows"] == R and pmc["shape"]["cols"] == Cn:
+        if pmc["shape"]["rows"] == R and pmc["shape"]["cols"] == Cn:  # per launch of THIS rank's shard
             traffic = pmc["traffic_bytes_per_launch"]  # separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE)
     line = dict(
         metric="read-pairs quantified/sec", value=reads_all / (elapsed / args.steps), unit="read-pairs/s", n_gpus=world,
         steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
-        scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-        config=dict(workload=f"single dense cluster {R} read pairs x {N} paths (BASELINE.json configs[1]), -i transcripts EM, "
-                             f"fixed budget of {its} EM iterations per step", parallelism=f"replicas only, {world} rank(s)"),
+        scaling="strong" if sharded else "weak", vs_baseline=None, dtype="f64", data="synthetic",
+        config=dict(workload=f"single dense cluster {R_all} read pairs x {N} paths (BASELINE.json configs[1]), -i transcripts EM, "
+                             f"fixed budget of {its} EM iterations per step",
+                    parallelism=(f"rows of one cluster spread over {world} rank(s), all-reduce of {Cn} doubles per EM iteration over RCCL"
+                                 if sharded else f"replicas only, {world} rank(s)")),
         roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                       kernel="emDenseAccumWideKernel", ms_per_launch=it_ms, algorithmic_bytes_per_launch=it_bytes,
                       note="one launch = one EM iteration's streaming pass: 8*R*C (matrix, read once) + 8*R (counts) + 16*C bytes; "
                            "traffic = HBM bytes per launch from rocprofv3 PMC passes (profiles/pmc_traffic_c2.json)"),
-        em_iterations_per_step=its, mass_conserved=bool(abs(ab.sum() + noise - R) <= 1e-6 * R))
+        em_iterations_per_step=its, mass_conserved=bool(abs(ab.sum() + noise - total) <= 1e-6 * total))
     if not args.no_cpu_baseline:
         # reference-shaped CPU EM on a row sample of the same matrix, one core (a single cluster is serial
         # in the reference: SURVEY.md F4)

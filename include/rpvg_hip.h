@@ -121,6 +121,17 @@ int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matrix, uint64_t
                       uint64_t ld, const double * device_counts, double total_count, uint32_t max_em_its,
                       double max_rel_em_conv, double * abundances, double * noise_count, uint32_t * iterations);
 
+/* Row-sharded form of rpvg_hip_em_dense for ONE cluster spread over the ranks of the context's
+ * communicator (rpvg_hip_comm_init): this rank holds num_rows of the cluster's rows; total_count is
+ * the read count of the WHOLE cluster.  Every EM iteration all-reduces the C partial column sums
+ * t_j = sum_i (c_i / s_i) P_ij over the ranks (RCCL, queued on the context's stream between the
+ * streaming pass and the update), then every rank applies the identical update and convergence test
+ * (src/path_abundance_estimator.cpp:58-97), so all ranks stop at the same iteration and return the
+ * same abundances.  With a one-rank communicator it equals rpvg_hip_em_dense. */
+int rpvg_hip_em_dense_sharded(rpvg_hip_ctx * ctx, const double * device_matrix, uint64_t num_rows, uint32_t num_cols,
+                              uint64_t ld, const double * device_counts, double total_count, uint32_t max_em_its,
+                              double max_rel_em_conv, double * abundances, double * noise_count, uint32_t * iterations);
+
 /* Builds the dense normalised matrix (layout above) of one cluster of an
  * uploaded batch, all paths + noise (constructProbabilityMatrix +
  * addNoiseAndNormalizeProbabilityMatrix, src/path_estimator.cpp:55-77,156-166).
@@ -193,12 +204,31 @@ void rpvg_hip_pair_posteriors_free(rpvg_hip_pair_posteriors * result);
 int rpvg_hip_min_path_cover(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t num_clusters,
                             const uint32_t * clusters, const uint64_t * cover_off, uint32_t * cover, uint32_t * cover_size);
 
+/* ---- communicator (RCCL over xGMI; one process per GPU) --------------------- */
+/* The reference is one process with OpenMP threads (src/main.cpp:829) and has no exchange step; the
+ * only collectives of this engine are the per-iteration all-reduce of rpvg_hip_em_dense_sharded and
+ * the sum of one double behind the TPM denominator (total_transcript_count, src/main.cpp:1029-1057)
+ * when clusters are sharded over ranks.  RCCL is opened at run time (librccl.so.1) by the first of
+ * these calls, so the rest of the library has no dependency on it.
+ * rpvg_hip_comm_unique_id: rank 0 fills id (RPVG_HIP_COMM_ID_BYTES) and hands it to the other ranks by
+ * any means (the harness broadcasts it with torch.distributed); every rank then calls
+ * rpvg_hip_comm_init(ctx, id, world, rank) — collective over the ranks. */
+#define RPVG_HIP_COMM_ID_BYTES 128
+int rpvg_hip_comm_unique_id(uint8_t * id_out);
+int rpvg_hip_comm_init(rpvg_hip_ctx * ctx, const uint8_t * id, int world_size, int rank);
+int rpvg_hip_comm_destroy(rpvg_hip_ctx * ctx);
+/* In-place sum over ranks of n doubles in device memory (stream-ordered; synchronises before returning). */
+int rpvg_hip_comm_allreduce_sum_f64(rpvg_hip_ctx * ctx, double * device_buf, uint64_t n);
+
 /* ---- synthetic workload (bench / tests only) ---------------------------- */
 /* Fills a dense normalised R x C matrix (layout of rpvg_hip_em_dense) and unit
  * counts on the GPU from a counter-based generator: the "1M read pairs x 2k
  * paths single dense cluster" configuration. */
 int rpvg_hip_synth_dense_cluster(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t num_rows, uint32_t num_paths,
                                  double * device_matrix, uint64_t ld, double * device_counts);
+/* Rows [row_begin, row_begin + num_rows) of the same cluster (a rank's shard of it). */
+int rpvg_hip_synth_dense_rows(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t row_begin, uint64_t num_rows, uint32_t num_paths,
+                              double * device_matrix, uint64_t ld, double * device_counts);
 
 /* ---- instrumentation ----------------------------------------------------- */
 /* Device time (HIP events on the context's stream) and launch count of the

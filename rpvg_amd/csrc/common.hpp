@@ -177,6 +177,12 @@ struct rpvg_hip_ctx {
     hipError_t joinAux();
     hipDeviceProp_t props;
     std::mutex mutex;  // serialises calls on this context
+    // RCCL communicator of this rank (comm.hip); null until rpvg_hip_comm_init.  Collectives are
+    // queued on `stream`, so they are ordered with the kernels around them without a host sync.
+    void * comm = nullptr;
+    int comm_world = 1, comm_rank = 0;
+    // in-place sum over ranks of n doubles, stream-ordered (comm.hip); requires comm != null
+    int allReduceSumF64(double * device_buf, uint64_t n);
     std::vector<rpvg_hip_detail::TimedSpan> spans;
     rpvg_hip_kernel_stats stats;
 

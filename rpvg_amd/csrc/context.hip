@@ -244,6 +244,7 @@ void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
     (void) ctx->foldSpans();
+    (void) rpvg_hip_comm_destroy(ctx);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     for (int i = 0; i < rpvg_hip_ctx::kAuxStreams; ++i) {
         if (ctx->aux[i]) (void) hipStreamDestroy(ctx->aux[i]);

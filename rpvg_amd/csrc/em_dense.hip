@@ -316,13 +316,13 @@ struct SynthTables {
 };
 
 // one wave per row
-__global__ __launch_bounds__(256) void synthDenseKernel(const uint64_t seed, const uint64_t R, const uint32_t N,
+__global__ __launch_bounds__(256) void synthDenseKernel(const uint64_t seed, const uint64_t row_begin, const uint64_t R, const uint32_t N,
                                                         const SynthTables tab, double * __restrict__ P, const uint64_t ld,
                                                         double * __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const uint64_t r = (blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x) >> 6;
     if (r >= R) return;
-    const uint64_t row_key = mix64(seed ^ (r * 0xD1B54A32D192ED03ull));
+    const uint64_t row_key = mix64(seed ^ ((row_begin + r) * 0xD1B54A32D192ED03ull));
     // true path: inverse CDF by binary search (uniform across the wave)
     const double ut = u01(mix64(row_key ^ 0x1ull));
     uint32_t lo = 0, hi = N - 1;
@@ -358,18 +358,22 @@ __global__ __launch_bounds__(256) void synthDenseKernel(const uint64_t seed, con
 
 }  // namespace
 
-extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matrix, uint64_t num_rows, uint32_t num_cols,
-                                 uint64_t ld, const double * device_counts, double total_count, uint32_t max_em_its,
-                                 double max_rel_em_conv, double * abundances, double * noise_count,
-                                 uint32_t * iterations) {
-    RPVG_REQUIRE(ctx && device_matrix && device_counts && abundances && noise_count && iterations,
-                 "rpvg_hip_em_dense: NULL argument");
-    RPVG_REQUIRE(num_rows > 0 && num_cols >= 2, "rpvg_hip_em_dense: need at least one row, one path and the noise column");
-    RPVG_REQUIRE(ld >= num_cols && (ld % 2) == 0, "rpvg_hip_em_dense: ld (%llu) must be even and >= num_cols (%u)",
+namespace {
+
+// Shared body of rpvg_hip_em_dense and rpvg_hip_em_dense_sharded.  `sharded`: the rows held here are one
+// rank's share of the cluster; the partial column sums are summed over the ranks of the context's
+// communicator before the update.
+int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const double * device_matrix, uint64_t num_rows,
+               uint32_t num_cols, uint64_t ld, const double * device_counts, double total_count, uint32_t max_em_its,
+               double max_rel_em_conv, double * abundances, double * noise_count, uint32_t * iterations) {
+    RPVG_REQUIRE(ctx && device_matrix && device_counts && abundances && noise_count && iterations, "%s: NULL argument", who);
+    RPVG_REQUIRE(num_rows > 0 && num_cols >= 2, "%s: need at least one row, one path and the noise column", who);
+    RPVG_REQUIRE(ld >= num_cols && (ld % 2) == 0, "%s: ld (%llu) must be even and >= num_cols (%u)", who,
                  static_cast<unsigned long long>(ld), num_cols);
-    RPVG_REQUIRE((reinterpret_cast<uintptr_t>(device_matrix) % 16) == 0, "rpvg_hip_em_dense: matrix must be 16-byte aligned");
-    RPVG_REQUIRE(num_cols <= 2048, "rpvg_hip_em_dense: %u columns exceed the register-resident row limit (2048)", num_cols);
-    RPVG_REQUIRE(total_count > 0 && max_em_its > 0, "rpvg_hip_em_dense: total_count and max_em_its must be positive");
+    RPVG_REQUIRE((reinterpret_cast<uintptr_t>(device_matrix) % 16) == 0, "%s: matrix must be 16-byte aligned", who);
+    RPVG_REQUIRE(num_cols <= 2048, "%s: %u columns exceed the register-resident row limit (2048)", who, num_cols);
+    RPVG_REQUIRE(total_count > 0 && max_em_its > 0, "%s: total_count and max_em_its must be positive", who);
+    RPVG_REQUIRE(!sharded || ctx->comm, "%s: the context has no communicator (rpvg_hip_comm_init first)", who);
 
     std::lock_guard<std::mutex> lock(ctx->mutex);
     RPVG_HIP_CHECK(hipSetDevice(ctx->device));
@@ -387,8 +391,10 @@ extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matri
     const uint32_t partial_ld = wide ? ((C + 511) / 512) * 512 : ((C + 1) & ~1u);
     const uint32_t reduce_slices = 16;
 
-    DeviceBuffer<double> d_a, d_partials, d_reduced;
+    DeviceBuffer<double> d_a, d_partials, d_reduced, d_t;
     if (wide) RPVG_HIP_CHECK(d_reduced.alloc(static_cast<size_t>(reduce_slices) * partial_ld));
+    if (sharded) RPVG_HIP_CHECK(d_t.alloc(partial_ld));
+    const dim3 col_grid((C + 255) / 256);
     DeviceBuffer<DenseControl> d_ctl;
     RPVG_HIP_CHECK(d_a.alloc(C));
     RPVG_HIP_CHECK(d_partials.alloc(static_cast<size_t>(grid) * partial_ld));
@@ -416,8 +422,16 @@ extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matri
                 else emDenseAccumWideKernel<4><<<dim3(grid), dim3(256), 0, st>>>(device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
                 ctx->spanEnd(span);
                 emDenseReducePartialsKernel<<<dim3((C + 255) / 256, reduce_slices), dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_reduced.ptr, d_ctl.ptr);
-                emDenseFinalizeKernel<<<dim3((C + 255) / 256), dim3(256), 0, st>>>(C, reduce_slices, partial_ld, d_reduced.ptr, d_a.ptr,
-                                                                               total_count, max_rel_em_conv, d_ctl.ptr);
+                if (sharded) {
+                    // this rank's column sums -> sum over ranks (same bits on every rank) -> identical update everywhere
+                    emDenseReducePartialsKernel<<<col_grid, dim3(256), 0, st>>>(C, reduce_slices, partial_ld, d_reduced.ptr, d_t.ptr, d_ctl.ptr);
+                    if (const int rc = ctx->allReduceSumF64(d_t.ptr, C)) return rc;
+                    emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, 1, partial_ld, d_t.ptr, d_a.ptr, total_count,
+                                                                      max_rel_em_conv, d_ctl.ptr);
+                } else {
+                    emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, reduce_slices, partial_ld, d_reduced.ptr, d_a.ptr,
+                                                                      total_count, max_rel_em_conv, d_ctl.ptr);
+                }
                 emDenseControlKernel<<<dim3(1), dim3(1), 0, st>>>(d_ctl.ptr, max_em_its);
                 continue;
             }
@@ -427,8 +441,15 @@ extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matri
             else if (nchunk <= 8) launchAccum<8>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
             else launchAccum<16>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
             ctx->spanEnd(span);
-            emDenseFinalizeKernel<<<dim3((C + 255) / 256), dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_a.ptr,
-                                                                           total_count, max_rel_em_conv, d_ctl.ptr);
+            if (sharded) {
+                emDenseReducePartialsKernel<<<col_grid, dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_t.ptr, d_ctl.ptr);
+                if (const int rc = ctx->allReduceSumF64(d_t.ptr, C)) return rc;
+                emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, 1, partial_ld, d_t.ptr, d_a.ptr, total_count,
+                                                                  max_rel_em_conv, d_ctl.ptr);
+            } else {
+                emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_a.ptr,
+                                                                  total_count, max_rel_em_conv, d_ctl.ptr);
+            }
             emDenseControlKernel<<<dim3(1), dim3(1), 0, st>>>(d_ctl.ptr, max_em_its);
         }
         queued += n;
@@ -465,6 +486,24 @@ extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matri
     return RPVG_HIP_OK;
 }
 
+}  // namespace
+
+extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matrix, uint64_t num_rows, uint32_t num_cols,
+                                 uint64_t ld, const double * device_counts, double total_count, uint32_t max_em_its,
+                                 double max_rel_em_conv, double * abundances, double * noise_count,
+                                 uint32_t * iterations) {
+    return emDenseRun(ctx, "rpvg_hip_em_dense", false, device_matrix, num_rows, num_cols, ld, device_counts, total_count,
+                      max_em_its, max_rel_em_conv, abundances, noise_count, iterations);
+}
+
+extern "C" int rpvg_hip_em_dense_sharded(rpvg_hip_ctx * ctx, const double * device_matrix, uint64_t num_rows,
+                                         uint32_t num_cols, uint64_t ld, const double * device_counts, double total_count,
+                                         uint32_t max_em_its, double max_rel_em_conv, double * abundances,
+                                         double * noise_count, uint32_t * iterations) {
+    return emDenseRun(ctx, "rpvg_hip_em_dense_sharded", true, device_matrix, num_rows, num_cols, ld, device_counts,
+                      total_count, max_em_its, max_rel_em_conv, abundances, noise_count, iterations);
+}
+
 extern "C" int rpvg_hip_dense_from_cluster(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t cluster,
                                            double * device_matrix, uint64_t ld, double * device_counts,
                                            double * total_count) {
@@ -497,9 +536,14 @@ extern "C" int rpvg_hip_dense_from_cluster(rpvg_hip_ctx * ctx, const rpvg_hip_ba
 
 extern "C" int rpvg_hip_synth_dense_cluster(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t num_rows, uint32_t num_paths,
                                             double * device_matrix, uint64_t ld, double * device_counts) {
-    RPVG_REQUIRE(ctx && device_matrix && device_counts, "rpvg_hip_synth_dense_cluster: NULL argument");
-    RPVG_REQUIRE(num_rows > 0 && num_paths > 0, "rpvg_hip_synth_dense_cluster: empty cluster");
-    RPVG_REQUIRE(ld >= num_paths + 1 && (ld % 2) == 0, "rpvg_hip_synth_dense_cluster: ld must be even and >= paths + 1");
+    return rpvg_hip_synth_dense_rows(ctx, seed, 0, num_rows, num_paths, device_matrix, ld, device_counts);
+}
+
+extern "C" int rpvg_hip_synth_dense_rows(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t row_begin, uint64_t num_rows,
+                                         uint32_t num_paths, double * device_matrix, uint64_t ld, double * device_counts) {
+    RPVG_REQUIRE(ctx && device_matrix && device_counts, "rpvg_hip_synth_dense_rows: NULL argument");
+    RPVG_REQUIRE(num_rows > 0 && num_paths > 0, "rpvg_hip_synth_dense_rows: empty cluster");
+    RPVG_REQUIRE(ld >= num_paths + 1 && (ld % 2) == 0, "rpvg_hip_synth_dense_rows: ld must be even and >= paths + 1");
     const uint32_t N = num_paths;
 
     // host-side tables (tiny): theta ~ LogNormal(0, 2) normalised, lengths ~ U[200, 5000]
@@ -544,7 +588,7 @@ extern "C" int rpvg_hip_synth_dense_cluster(rpvg_hip_ctx * ctx, uint64_t seed, u
     RPVG_HIP_CHECK(d_def.upload(deficit_cdf.data(), 20, st));
     SynthTables tab = {d_theta.ptr, d_inv_len.ptr, d_score.ptr, d_def.ptr};
     const uint64_t threads = num_rows * 64;
-    synthDenseKernel<<<dim3(static_cast<uint32_t>((threads + 255) / 256)), dim3(256), 0, st>>>(seed, num_rows, N, tab,
+    synthDenseKernel<<<dim3(static_cast<uint32_t>((threads + 255) / 256)), dim3(256), 0, st>>>(seed, row_begin, num_rows, N, tab,
                                                                                             device_matrix, ld, device_counts);
     RPVG_HIP_CHECK(hipGetLastError());
     RPVG_HIP_CHECK(hipStreamSynchronize(st));

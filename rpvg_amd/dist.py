@@ -78,3 +78,33 @@ def gather_cluster_values(local_values: Sequence[np.ndarray], local_clusters: Se
             out[int(k)] = flat_r[off:off + int(n)].copy()
             off += int(n)
     return out
+
+
+# ---- one giant cluster, rows spread over the ranks ---------------------------------------------------
+
+def row_shard(num_rows: int, rank: int, world_size: int):
+    """Contiguous row range [begin, end) of `rank` when the rows of ONE cluster are spread over the ranks
+    ("one giant cluster"): every EM iteration then needs the all-reduce of C partial column
+    sums that rpvg_hip_em_dense_sharded queues on its stream."""
+    return (num_rows * rank) // world_size, (num_rows * (rank + 1)) // world_size
+
+
+def broadcast_bytes(payload, nbytes: int, dist, device: str = "cpu", src: int = 0) -> bytes:
+    """Hands `payload` (bytes on rank `src`, ignored elsewhere) to every rank."""
+    import torch
+    if dist.get_rank() == src:
+        assert len(payload) == nbytes
+        t = torch.tensor(list(payload), dtype=torch.uint8, device=device)
+    else:
+        t = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=src)
+    return bytes(t.cpu().tolist())
+
+
+def init_engine_comm(ctx, dist, device: str = "cpu"):
+    """Creates the engine's own RCCL communicator on `ctx` (include/rpvg_hip.h, rpvg_hip_comm_*): rank 0 draws
+    the id, torch.distributed carries it to the other ranks, every rank joins."""
+    from . import hip
+    uid = hip.Context.comm_unique_id() if dist.get_rank() == 0 else None
+    uid = broadcast_bytes(uid, hip.COMM_ID_BYTES, dist, device)
+    ctx.comm_init(uid, dist.get_world_size(), dist.get_rank())

@@ -24,7 +24,11 @@ EXPORTS = [
     "rpvg_hip_dense_from_cluster", "rpvg_hip_groups_build", "rpvg_hip_groups_free", "rpvg_hip_group_loglik",
     "rpvg_hip_synth_dense_cluster", "rpvg_hip_stats_get", "rpvg_hip_stats_reset",
     "rpvg_hip_gibbs_read_counts", "rpvg_hip_min_path_cover", "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
+    "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
+    "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64",
 ]
+
+COMM_ID_BYTES = 128  # RPVG_HIP_COMM_ID_BYTES
 
 
 class EngineError(RuntimeError):
@@ -268,15 +272,38 @@ class Context:
         return out
 
     def em_dense(self, d_matrix: int, R: int, Cn: int, ld: int, d_counts: int, total: float, max_em_its: int = 10000,
-                 max_rel_em_conv: float = 1e-3):
+                 max_rel_em_conv: float = 1e-3, sharded: bool = False):
+        """EM on a resident dense matrix.  sharded=True: the R rows are this rank's share of one cluster spread
+        over the ranks of the context's communicator (comm_init) and `total` is the whole cluster's read count."""
         ab = np.zeros(Cn - 1, dtype=np.float64)
         noise = C.c_double(0)
         its = C.c_uint32(0)
-        _check(lib().rpvg_hip_em_dense(self.handle, C.c_void_p(d_matrix), C.c_uint64(R), C.c_uint32(Cn), C.c_uint64(ld),
-                                       C.c_void_p(d_counts), C.c_double(total), C.c_uint32(max_em_its),
-                                       C.c_double(max_rel_em_conv), C.c_void_p(ab.ctypes.data), C.byref(noise),
-                                       C.byref(its)), "rpvg_hip_em_dense")
+        fn, name = ((lib().rpvg_hip_em_dense_sharded, "rpvg_hip_em_dense_sharded") if sharded
+                    else (lib().rpvg_hip_em_dense, "rpvg_hip_em_dense"))
+        _check(fn(self.handle, C.c_void_p(d_matrix), C.c_uint64(R), C.c_uint32(Cn), C.c_uint64(ld),
+                  C.c_void_p(d_counts), C.c_double(total), C.c_uint32(max_em_its),
+                  C.c_double(max_rel_em_conv), C.c_void_p(ab.ctypes.data), C.byref(noise),
+                  C.byref(its)), name)
         return ab, noise.value, its.value
+
+    # ---- communicator (RCCL) ----------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        _check(lib().rpvg_hip_comm_unique_id(buf), "rpvg_hip_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, world_size: int, rank: int):
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib().rpvg_hip_comm_init(self.handle, buf, C.c_int(world_size), C.c_int(rank)), "rpvg_hip_comm_init")
+
+    def comm_destroy(self):
+        _check(lib().rpvg_hip_comm_destroy(self.handle), "rpvg_hip_comm_destroy")
+
+    def allreduce_sum_f64(self, d_buf: int, n: int):
+        _check(lib().rpvg_hip_comm_allreduce_sum_f64(self.handle, C.c_void_p(d_buf), C.c_uint64(n)),
+               "rpvg_hip_comm_allreduce_sum_f64")
 
     def dense_from_cluster(self, batch: DeviceBatch, cluster: int, d_matrix: int, ld: int, d_counts: int) -> float:
         total = C.c_double(0)
@@ -289,6 +316,12 @@ class Context:
         _check(lib().rpvg_hip_synth_dense_cluster(self.handle, C.c_uint64(seed), C.c_uint64(R), C.c_uint32(N),
                                                   C.c_void_p(d_matrix), C.c_uint64(ld), C.c_void_p(d_counts)),
                "rpvg_hip_synth_dense_cluster")
+
+    def synth_dense_rows(self, seed: int, row_begin: int, R: int, N: int, d_matrix: int, ld: int, d_counts: int):
+        """Rows [row_begin, row_begin + R) of the synthetic dense cluster `seed` (a rank's shard)."""
+        _check(lib().rpvg_hip_synth_dense_rows(self.handle, C.c_uint64(seed), C.c_uint64(row_begin), C.c_uint64(R),
+                                               C.c_uint32(N), C.c_void_p(d_matrix), C.c_uint64(ld), C.c_void_p(d_counts)),
+               "rpvg_hip_synth_dense_rows")
 
     # ---- stats ----------------------------------------------------------------
     def stats(self) -> dict:

@@ -61,3 +61,84 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(os.path.join(str(tmp_path), "result")).read() == "ok"
+
+
+def _row_shard_worker(rank, world, port, out_dir):
+    """Model of the row-sharded EM protocol of rpvg_hip_em_dense_sharded (em_dense.hip): every rank streams its
+    own rows, the C partial column sums are all-reduced, every rank applies the same update and convergence rule
+    (src/path_abundance_estimator.cpp:58-113).  Checks that the protocol reproduces the unsharded oracle —
+    abundances and the iteration it stops at — and exercises the helpers the GPU path uses (row_shard,
+    broadcast_bytes) over a real two-process group."""
+    import torch
+    import torch.distributed as dist
+    from oracle import pyoracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        payload = bytes(range(128)) if rank == 0 else None
+        got = rdist.broadcast_bytes(payload, 128, dist)
+        assert got == bytes(range(128))
+
+        rng = np.random.default_rng(5)  # same matrix on both ranks; each uses its shard only
+        R, N = 3001, 37
+        P = rng.random((R, N)) * (rng.random((R, N)) < 0.3)
+        P[P.sum(axis=1) == 0, 0] = 0.5
+        noise = rng.choice([1e-4, 1e-3, 0.1], size=R)
+        P = P / P.sum(axis=1, keepdims=True) * (1 - noise)[:, None]
+        P = np.concatenate([P, noise[:, None]], axis=1)
+        counts = rng.integers(1, 5, size=R).astype(np.float64)
+        total = counts.sum()
+        r0, r1 = rdist.row_shard(R, rank, world)
+        assert (r0, r1) == ((0, R // 2) if rank == 0 else (R // 2, R))
+        Pl, cl = P[r0:r1], counts[r0:r1]
+
+        C_ = N + 1
+        a = np.full(C_, np.float64(np.float32(1.0) / np.float32(C_)))
+        conv_its, its = 0, 0
+        while its < 10000:
+            s = Pl @ a
+            t = torch.from_numpy((cl / s) @ Pl)
+            dist.all_reduce(t)  # the one exchange step of the path
+            an = a * t.numpy() / total
+            its += 1
+            big = an >= 1e-8
+            viol = bool(np.any(np.abs(an[big] - a[big]) / an[big] > 1e-3))
+            a = an
+            conv_its = 0 if viol else conv_its + 1
+            if conv_its == 10:
+                break
+        ab = np.where(a[:-1] < 1e-8, 0.0, a[:-1] * total)
+
+        # every rank must hold the same bits (same stop iteration is what keeps the collective calls matched)
+        mine = torch.from_numpy(np.concatenate([a, [float(its)]]))
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert all(torch.equal(both[0], b) for b in both)
+
+        if rank == 0:
+            ref_ab, ref_noise, ref_total, ref_its, _ = pyoracle.em_dense(P, counts)
+            ok = its == ref_its and np.allclose(ab, ref_ab, rtol=1e-9, atol=1e-12)
+            ok = ok and abs(ab.sum() + (total - ab.sum()) - ref_total) < 1e-6
+            with open(os.path.join(out_dir, "result_rows"), "w") as f:
+                f.write("ok" if ok else f"mismatch its {its} vs {ref_its}")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_shard_covers_all_rows():
+    for R in (1, 7, 1000, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [rdist.row_shard(R, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == R
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gloo_row_sharded_em_protocol(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_row_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(os.path.join(str(tmp_path), "result_rows")).read() == "ok"

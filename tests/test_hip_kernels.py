@@ -214,6 +214,59 @@ def test_em_dense_converges_like_oracle(hip_ctx):
         hip_ctx.free(d_c)
 
 
+def test_synth_dense_rows_are_slices_of_the_cluster(hip_ctx):
+    R, N = 1001, 70
+    ld = (N + 2) & ~1
+    d_P, d_c = hip_ctx.malloc(R * ld * 8), hip_ctx.malloc(R * 8)
+    try:
+        hip_ctx.synth_dense_cluster(4, R, N, d_P, ld, d_c)
+        whole = hip_ctx.d2h(d_P, (R, ld)).copy()
+        for r0, r1 in [(0, 500), (500, 1001), (333, 334)]:
+            hip_ctx.synth_dense_rows(4, r0, r1 - r0, N, d_P, ld, d_c)
+            part = hip_ctx.d2h(d_P, (r1 - r0, ld))
+            assert np.array_equal(part, whole[r0:r1])
+    finally:
+        hip_ctx.free(d_P)
+        hip_ctx.free(d_c)
+
+
+@pytest.mark.parametrize("R,N", [(6000, 1500), (4000, 90)])
+def test_one_rank_communicator_row_sharded_em(hip_ctx, R, N):
+    """RCCL plumbing of the row-sharded dense EM with a one-rank communicator: unique id, init, the in-stream
+    all-reduce of every iteration; the result must equal the unsharded solve bit for bit.  (The two-rank algebra
+    is covered on CPU in tests/test_distributed_cpu.py; N > 1 GPUs are the round-end driver's to launch.)"""
+    from rpvg_amd import hip
+    ld = (N + 2) & ~1
+    ctx = hip.Context(0)
+    d_P = d_c = d_x = None
+    try:
+        d_P, d_c = ctx.malloc(R * ld * 8), ctx.malloc(R * 8)
+        ctx.synth_dense_cluster(6, R, N, d_P, ld, d_c)
+        with pytest.raises(hip.EngineError, match="communicator"):
+            ctx.em_dense(d_P, R, N + 1, ld, d_c, float(R), max_em_its=30, sharded=True)
+        ctx.comm_init(hip.Context.comm_unique_id(), 1, 0)
+        with pytest.raises(hip.EngineError, match="already"):
+            ctx.comm_init(hip.Context.comm_unique_id(), 1, 0)
+        x = np.arange(1000, dtype=np.float64) * 0.25
+        d_x = ctx.malloc(x.nbytes)
+        ctx.h2d(d_x, x)
+        ctx.allreduce_sum_f64(d_x, x.size)
+        assert np.array_equal(ctx.d2h(d_x, (x.size,)), x)
+        ab_s, noise_s, its_s = ctx.em_dense(d_P, R, N + 1, ld, d_c, float(R), max_em_its=30, sharded=True)
+        ab, noise, its = ctx.em_dense(d_P, R, N + 1, ld, d_c, float(R), max_em_its=30)
+        assert its_s == its and noise_s == noise and np.array_equal(ab_s, ab)
+        P = ctx.d2h(d_P, (R, ld))[:, :N + 1].copy()
+        ab_o, noise_o, _, its_o, _ = pyoracle.em_dense(P, np.ones(R), max_em_its=30)
+        assert its_s == its_o and small_cases.rel_close(ab_s, ab_o, rel=REL)
+        ctx.comm_destroy()
+        ctx.comm_destroy()  # idempotent
+    finally:
+        for d in (d_P, d_c, d_x):
+            if d:
+                ctx.free(d)
+        ctx.close()
+
+
 # ---- group log-likelihoods ------------------------------------------------------------
 
 @pytest.mark.parametrize("normalise", [False, True])
