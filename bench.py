@@ -37,7 +37,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="s3", choices=["s3", "c2"])
+    ap.add_argument("--workload", default="s3", choices=["s3", "c2", "s5"],
+                    help="s3: BASELINE.json configs[2]/[3] (default, the metric's configuration); c2: configs[1] single dense "
+                         "cluster; s5: configs[4] diploid haplotype Gibbs, 10M reads x 500k paths")
     ap.add_argument("--model", default="haplotype-transcripts", choices=["haplotype-transcripts", "transcripts", "haplotypes"])
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the full workload (parity/dev runs only)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -110,18 +112,26 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     from rpvg_amd import dist as rdist, engine as eng_mod, synth
     from rpvg_amd.batch import make_params
 
-    params = make_params()
+    s5 = args.workload == "s5"
+    if s5:
+        # BASELINE.json configs[4] / SURVEY.md §8d S5: -i haplotypes -y 2 --use-hap-gibbs
+        args.model = "haplotypes"
+        params = make_params(use_hap_gibbs=1)
+        base_paths, seed0, gen_kw, config_name = 500000, 5, dict(max_cluster_paths=5000), "configs[4]"
+    else:
+        params = make_params()
+        base_paths, seed0, gen_kw, config_name = 200000, 3, {}, "configs[2]"
     K = max(8, int(round(5000 * args.scale)))
-    total_paths = max(K, int(round(200000 * args.scale)))
+    total_paths = max(K, int(round(base_paths * args.scale)))
     total_reads = int(round(10000000 * args.scale))
     if args.scaling == "weak" or world == 1:
         # weak scaling: every rank owns a full-size batch (its own seed)
-        batch = synth.generate(seed=3 + rank, num_clusters=K, total_paths=total_paths, total_reads=total_reads)
+        batch = synth.generate(seed=seed0 + rank, num_clusters=K, total_paths=total_paths, total_reads=total_reads, **gen_kw)
         my_clusters = list(range(batch.num_clusters))
         global_clusters = batch.num_clusters
     else:
         # strong scaling (BASELINE.json configs[3]): the same batch on every rank, clusters bin-packed over ranks
-        full = synth.generate(seed=3, num_clusters=K, total_paths=total_paths, total_reads=total_reads)
+        full = synth.generate(seed=seed0, num_clusters=K, total_paths=total_paths, total_reads=total_reads, **gen_kw)
         batch, my_clusters = rdist.shard_batch(full, rank, world)
         global_clusters = full.num_clusters
 
@@ -147,7 +157,10 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     # after the timed region: gather the per-path abundances of every rank over RCCL (what a multi-GPU
     # driver does before writing rpvg.txt); also fetch one decoded result for a sanity check
     est, _ = eng.run(args.model, params, prepared)
-    mass_ok = all(abs(e.abundances.sum() + e.noise_count - e.total_count) <= 1e-6 * max(1.0, e.total_count) for e in est)
+    if args.model == "haplotypes":  # posteriors only: they sum to one per cluster
+        mass_ok = all(abs(e.posteriors.sum() - 1) <= 1e-6 for e in est if e.total_count > 0 and len(e.posteriors))
+    else:
+        mass_ok = all(abs(e.abundances.sum() + e.noise_count - e.total_count) <= 1e-6 * max(1.0, e.total_count) for e in est)
     gathered = None
     if dist is not None:
         if args.scaling == "strong":
@@ -181,14 +194,24 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         scaling=("strong" if (args.scaling == "strong" and world > 1) else "weak"), vs_baseline=None,
         dtype="f64", data="synthetic",
         config=dict(workload=f"synthetic pantranscriptome: {total_reads} read pairs x {total_paths} paths in {K} clusters per GPU "
-                             f"(BASELINE.json configs[2]), -i {args.model}, reference defaults",
+                             f"(BASELINE.json {config_name}), -i {args.model}"
+                             + (" -y 2 --use-hap-gibbs" if s5 else "") + ", reference defaults",
                     clusters_per_gpu=K, rows_per_gpu=batch.num_rows, entries_per_gpu=int(len(batch.path_idx)),
                     parallelism=f"clusters sharded, {world} rank(s), final abundance gather over RCCL"),
         roofline=roofline, kernels=kernels, mass_conserved=bool(mass_ok),
         upload_ms=upload_ms, value_including_upload=float(batch.total_reads) / ((ms_per_step + upload_ms) / 1e3) * world)
     if gathered is not None:
         line["gathered_abundance_mass"] = gathered
-    if args.scale >= 1.0:
+    if s5:
+        # no EM on this path: the device work is the FP64 log-likelihood contraction of the Gibbs conditionals
+        ll_ms = stats["loglik_ms"] / max(1, stats["loglik_launches"])
+        ll_bytes = 16.0 * stats["loglik_evals"] / max(1, stats["loglik_launches"])
+        ach = (ll_bytes / 1e9) / (ll_ms / 1e3) if ll_ms > 0 else 0.0
+        line["roofline"] = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                                kernel="groupLoglikKernel",
+                                note="algorithmic bytes = 16 B (two matrix columns) per row-evaluation; the kernel is FP64-log "
+                                     "bound and the matrices are L2-resident, see kernels.loglik_gevals_per_s")
+    if args.scale >= 1.0 and not s5:
         try:
             line["roofline_dense_em"] = dense_em_roofline(local_rank)
         except Exception as exc:  # the record is optional; the default workload's line stands on its own
@@ -311,7 +334,7 @@ def main():
     rank, local_rank, world, dist, torch = dist_setup(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    line = run_s3(args, rank, local_rank, world, dist, torch) if args.workload == "s3" else run_c2(args, rank, local_rank, world, dist, torch)
+    line = run_c2(args, rank, local_rank, world, dist, torch) if args.workload == "c2" else run_s3(args, rank, local_rank, world, dist, torch)
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:

@@ -172,6 +172,16 @@ int rpvg_hip_group_loglik(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, ui
                           const uint32_t * matrix, const uint32_t * members, uint32_t width, double divisor,
                           const uint8_t * add_rowmax, double * out);
 
+/* A whole conditional of estimatePathGroupPosteriorsGibbs (src/path_estimator.cpp:527-545) per request: request q
+ * fixes the other width-1 members of a group (others[q*(width-1) ..], slot order) on matrix[q] and receives, for
+ * EVERY column k of that matrix,
+ *   sum_i count_i * log( noise_i + ( sum_o M[i][others] + M[i][k] ) / divisor ).
+ * out holds the requests back to back, one value per column of the request's matrix.  Same arithmetic as
+ * rpvg_hip_group_loglik with members = (others..., k); the request list is O(1) per conditional instead of O(columns). */
+int rpvg_hip_group_conditionals(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, uint32_t num_requests,
+                                const uint32_t * matrix, const uint32_t * others, uint32_t width, double divisor,
+                                double * out);
+
 /* The whole diploid branch-and-bound of calculatePathGroupPosteriorsBounded
  * (src/path_estimator.cpp:379-473) on the GPU, one workgroup per matrix:
  * marginal posteriors (the nested group-size-1 Full call, :397-412), the

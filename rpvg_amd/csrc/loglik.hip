@@ -163,6 +163,57 @@ __global__ __launch_bounds__(256) void groupLoglikKernel(
     if (lane == 0) out[q] = acc;
 }
 
+// Conditionals of the Gibbs sampler (src/path_estimator.cpp:527-545): request q fixes the other WIDTH-1 members of a
+// group on its matrix and asks for the log-likelihood of every candidate column.  One wave per (request, 4 candidate
+// columns): the base vector noise + sum(others)/g is formed once per row and shared by the four logs (same order
+// of additions as the reference: noise, the others in slot order, then the candidate).
+template <int WIDTH>
+__global__ __launch_bounds__(256) void groupConditionalKernel(
+    const uint32_t num_requests, const uint64_t num_items, const uint64_t * __restrict__ item_off,
+    const uint64_t * __restrict__ out_off, const uint32_t * __restrict__ req_matrix,
+    const uint32_t * __restrict__ req_others, const double divisor, const uint64_t * __restrict__ mat_val_off,
+    const uint64_t * __restrict__ mat_row0, const uint64_t * __restrict__ mat_rows,
+    const uint32_t * __restrict__ mat_cols, const double * __restrict__ values, const double * __restrict__ row_count,
+    const double * __restrict__ row_noise, double * __restrict__ out) {
+    constexpr int kCand = 4;
+    const int lane = threadIdx.x & 63;
+    const uint64_t item = (blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x) >> 6;
+    if (item >= num_items) return;
+    uint32_t lo = 0, hi = num_requests - 1;  // last q with item_off[q] <= item
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (item_off[mid] <= item) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t q = lo;
+    const uint32_t m = req_matrix[q];
+    const uint64_t R = mat_rows[m];
+    const uint32_t G = mat_cols[m];
+    const uint32_t k0 = static_cast<uint32_t>(item - item_off[q]) * kCand;
+    const double * M = values + mat_val_off[m];
+    const double * cnt = row_count + mat_row0[m];
+    const double * nz = row_noise + mat_row0[m];
+    const double * other[WIDTH > 1 ? WIDTH - 1 : 1];
+#pragma unroll
+    for (int w = 0; w + 1 < WIDTH; ++w) other[w] = M + static_cast<uint64_t>(req_others[static_cast<uint64_t>(q) * (WIDTH - 1) + w]) * R;
+    const double * cand[kCand];
+#pragma unroll
+    for (int c = 0; c < kCand; ++c) cand[c] = M + static_cast<uint64_t>(min(k0 + c, G - 1)) * R;
+    double acc[kCand] = {0.0, 0.0, 0.0, 0.0};
+    for (uint64_t i = lane; i < R; i += 64) {
+        double base = nz[i];
+#pragma unroll
+        for (int w = 0; w + 1 < WIDTH; ++w) base += other[w][i] / divisor;
+        const double c_i = cnt[i];
+#pragma unroll
+        for (int c = 0; c < kCand; ++c) acc[c] = fma(c_i, logPositive(base + cand[c][i] / divisor), acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < kCand; ++c) {
+        const double total = waveSumF64(acc[c]);
+        if (lane == 0 && k0 + c < G) out[out_off[q] + k0 + c] = total;
+    }
+}
+
 }  // namespace
 
 extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec,
@@ -362,6 +413,72 @@ extern "C" int rpvg_hip_group_loglik(rpvg_hip_ctx * ctx, const rpvg_hip_groups *
         default: RPVG_LAUNCH_LOGLIK(4); break;
     }
 #undef RPVG_LAUNCH_LOGLIK
+    ctx->spanEnd(span);
+    ctx->stats.loglik_launches += 1;
+    ctx->stats.loglik_evals += evals;
+    RPVG_HIP_CHECK(hipGetLastError());
+    RPVG_HIP_CHECK(d_out.download(out, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    return RPVG_HIP_OK;
+}
+
+extern "C" int rpvg_hip_group_conditionals(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, uint32_t num_requests,
+                                           const uint32_t * matrix, const uint32_t * others, uint32_t width,
+                                           double divisor, double * out) {
+    RPVG_REQUIRE(ctx && groups, "rpvg_hip_group_conditionals: NULL argument");
+    if (num_requests == 0) return RPVG_HIP_OK;
+    RPVG_REQUIRE(matrix && out && (others || width == 1), "rpvg_hip_group_conditionals: NULL request arrays");
+    RPVG_REQUIRE(width >= 1 && width <= 4, "rpvg_hip_group_conditionals: width %u outside [1, 4]", width);
+    RPVG_REQUIRE(divisor > 0, "rpvg_hip_group_conditionals: divisor must be positive");
+    std::vector<uint64_t> item_off(num_requests + 1, 0), out_off(num_requests + 1, 0);
+    double evals = 0;
+    for (uint32_t q = 0; q < num_requests; ++q) {
+        RPVG_REQUIRE(matrix[q] < groups->num_matrices, "rpvg_hip_group_conditionals: request %u refers to matrix %u of %u",
+                     q, matrix[q], groups->num_matrices);
+        const uint32_t G = groups->h_num_cols[matrix[q]];
+        for (uint32_t w = 0; w + 1 < width; ++w) {
+            RPVG_REQUIRE(others[static_cast<uint64_t>(q) * (width - 1) + w] < G,
+                         "rpvg_hip_group_conditionals: request %u member %u >= %u columns", q,
+                         others[static_cast<uint64_t>(q) * (width - 1) + w], G);
+        }
+        item_off[q + 1] = item_off[q] + (G + 3) / 4;
+        out_off[q + 1] = out_off[q] + G;
+        evals += static_cast<double>(groups->h_num_rows[matrix[q]]) * G;
+    }
+    const uint64_t num_items = item_off[num_requests];
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DeviceBuffer<uint32_t> d_matrix, d_others;
+    DeviceBuffer<uint64_t> d_item_off, d_out_off;
+    DeviceBuffer<double> d_out;
+    int span = ctx->spanBegin(FAM_H2D);
+    RPVG_HIP_CHECK(d_matrix.upload(matrix, num_requests, st));
+    if (width > 1) RPVG_HIP_CHECK(d_others.upload(others, static_cast<size_t>(num_requests) * (width - 1), st));
+    RPVG_HIP_CHECK(d_item_off.upload(item_off.data(), item_off.size(), st));
+    RPVG_HIP_CHECK(d_out_off.upload(out_off.data(), out_off.size(), st));
+    ctx->spanEnd(span);
+    ctx->stats.h2d_bytes += static_cast<double>(num_requests) * (4 + 4 * (width - 1) + 16);
+    RPVG_HIP_CHECK(d_out.alloc(out_off[num_requests]));
+
+    const uint64_t blocks = (num_items + 3) / 4;
+    RPVG_REQUIRE(blocks <= 0x7fffffffull, "rpvg_hip_group_conditionals: %llu work items exceed one launch",
+                 static_cast<unsigned long long>(num_items));
+    const rpvg_hip_batch * b = groups->batch;
+    span = ctx->spanBegin(FAM_LOGLIK);
+#define RPVG_LAUNCH_COND(W)                                                                                                  \
+    groupConditionalKernel<W><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(                                    \
+        num_requests, num_items, d_item_off.ptr, d_out_off.ptr, d_matrix.ptr, d_others.ptr, divisor, groups->mat_val_off.ptr, \
+        groups->mat_row0.ptr, groups->mat_rows.ptr, groups->mat_cols.ptr, groups->values.ptr, b->row_count.ptr,              \
+        b->row_noise.ptr, d_out.ptr)
+    switch (width) {
+        case 1: RPVG_LAUNCH_COND(1); break;
+        case 2: RPVG_LAUNCH_COND(2); break;
+        case 3: RPVG_LAUNCH_COND(3); break;
+        default: RPVG_LAUNCH_COND(4); break;
+    }
+#undef RPVG_LAUNCH_COND
     ctx->spanEnd(span);
     ctx->stats.loglik_launches += 1;
     ctx->stats.loglik_evals += evals;

@@ -25,7 +25,7 @@ EXPORTS = [
     "rpvg_hip_synth_dense_cluster", "rpvg_hip_stats_get", "rpvg_hip_stats_reset",
     "rpvg_hip_gibbs_read_counts", "rpvg_hip_min_path_cover", "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
     "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
-    "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64",
+    "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_group_conditionals",
 ]
 
 COMM_ID_BYTES = 128  # RPVG_HIP_COMM_ID_BYTES
@@ -151,6 +151,18 @@ class DeviceGroups:
                                            C.c_void_p(flag.ctypes.data if flag is not None else None),
                                            C.c_void_p(out.ctypes.data)), "rpvg_hip_group_loglik")
         return out
+
+    def conditionals(self, matrix, others, width: int, divisor: float, num_cols) -> List[np.ndarray]:
+        """Per request: log-likelihood of every candidate column given the other width-1 members."""
+        mt = np.ascontiguousarray(matrix, dtype=np.uint32)
+        oth = np.ascontiguousarray(others, dtype=np.uint32).reshape(len(mt), max(width - 1, 0))
+        sizes = [int(num_cols[int(m)]) for m in mt]
+        out = np.zeros(sum(sizes), dtype=np.float64)
+        _check(lib().rpvg_hip_group_conditionals(self.ctx.handle, self.handle, C.c_uint32(len(mt)), C.c_void_p(mt.ctypes.data),
+                                                 C.c_void_p(oth.ctypes.data if oth.size else None), C.c_uint32(width),
+                                                 C.c_double(divisor), C.c_void_p(out.ctypes.data)),
+               "rpvg_hip_group_conditionals")
+        return np.split(out, np.cumsum(sizes)[:-1]) if sizes else []
 
     def bounded_pair_posteriors(self, column_counts, min_rel_likelihood: float):
         """Per matrix: ([(first, second)...], posteriors) of the on-device branch-and-bound."""

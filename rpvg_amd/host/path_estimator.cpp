@@ -1,6 +1,7 @@
 #include "path_estimator.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cassert>
 #include <cmath>
 #include <cstdlib>
@@ -110,6 +111,17 @@ class GroupMatrices {
             }
         }
 
+        // Whole conditionals (every candidate column given the other members), request after request.
+        void conditionals(std::vector<double> * out, const std::vector<uint32_t> & matrix, const std::vector<uint32_t> & others, const size_t num_values, const uint32_t width, const double divisor) const {
+
+            ScopedPhase phase("posteriors: loglik device calls");
+
+            assert(others.size() == matrix.size() * (width - 1));
+            out->assign(num_values, 0);
+
+            HipEngine::check(rpvg_hip_group_conditionals(engine->ctx(), groups, matrix.size(), matrix.data(), others.data(), width, divisor, out->data()), "rpvg_hip_group_conditionals");
+        }
+
     private:
 
         const std::shared_ptr<HipEngine> engine;
@@ -139,8 +151,83 @@ struct GroupSetHash {
     }
 };
 
+// Open-addressing table from a packed group set (<= 2 members, 32 bits each) to its index in
+// order of first appearance; the per-iteration bookkeeping of the Gibbs sampler without a heap
+// allocation per lookup.
+class PackedSetIndex {
+
+    public:
+
+        // Returns the index of key, inserting it as `next_index` if absent (second = inserted).
+        std::pair<uint32_t, bool> emplace(const uint64_t key, const uint32_t next_index) {
+
+            if ((size + 1) * 2 > slots.size()) {
+
+                grow();
+            }
+
+            size_t pos = hash(key) & (slots.size() - 1);
+
+            while (slots[pos].second != empty_index) {
+
+                if (slots[pos].first == key) {
+
+                    return std::make_pair(slots[pos].second, false);
+                }
+
+                pos = (pos + 1) & (slots.size() - 1);
+            }
+
+            slots[pos] = std::make_pair(key, next_index);
+            ++size;
+
+            return std::make_pair(next_index, true);
+        }
+
+    private:
+
+        static constexpr uint32_t empty_index = std::numeric_limits<uint32_t>::max();
+
+        std::vector<std::pair<uint64_t, uint32_t> > slots;
+        size_t size = 0;
+
+        static size_t hash(uint64_t x) {
+
+            x ^= x >> 33;
+            x *= 0xff51afd7ed558ccdull;
+            x ^= x >> 33;
+
+            return x;
+        }
+
+        void grow() {
+
+            std::vector<std::pair<uint64_t, uint32_t> > old_slots;
+            old_slots.swap(slots);
+
+            slots.assign(std::max<size_t>(64, old_slots.size() * 2), std::make_pair(0, empty_index));
+
+            for (auto & slot: old_slots) {
+
+                if (slot.second != empty_index) {
+
+                    size_t pos = hash(slot.first) & (slots.size() - 1);
+
+                    while (slots[pos].second != empty_index) {
+
+                        pos = (pos + 1) & (slots.size() - 1);
+                    }
+
+                    slots[pos] = slot;
+                }
+            }
+        }
+};
+
 // One problem's Gibbs sampler, resumable at the point where it needs a conditional
-// distribution that has not been evaluated yet.
+// distribution that has not been evaluated yet.  The draws follow the reference's use of the
+// generator exactly (src/path_estimator.cpp:505-575): uniform_int_distribution for the start of
+// every chain, one discrete_distribution draw per slot and iteration; caches only memoise.
 struct GibbsSampler {
 
     uint32_t num_columns = 0;
@@ -161,7 +248,13 @@ struct GibbsSampler {
 
     std::vector<uint32_t> cur_sampled_group_paths;
 
-    std::unordered_map<std::vector<uint32_t>, std::discrete_distribution<uint32_t>, GroupSetHash> sampler_cache;
+    // conditionals evaluated so far; group sizes 1 and 2 (one "other" member at most) index them
+    // directly by the other member, larger groups by the sorted others
+    std::vector<std::discrete_distribution<uint32_t> > conditionals;
+    std::vector<uint32_t> conditional_of_other;
+    std::unordered_map<std::vector<uint32_t>, uint32_t, GroupSetHash> conditional_of_others;
+
+    PackedSetIndex packed_group_set_indices;
     std::unordered_map<std::vector<uint32_t>, uint32_t, GroupSetHash> group_set_indices;
 
     std::vector<uint32_t> sampled_members;
@@ -171,6 +264,129 @@ struct GibbsSampler {
     bool waiting = false;
     std::vector<uint32_t> pending_key;
     std::vector<uint32_t> pending_others;
+
+    static constexpr uint32_t no_conditional = std::numeric_limits<uint32_t>::max();
+
+    void init() {
+
+        if (group_size <= 2) {
+
+            conditional_of_other.assign((group_size == 2) ? num_columns : 1, no_conditional);
+        }
+    }
+
+    // Stores the conditional the sampler was waiting for.
+    void supply(std::discrete_distribution<uint32_t> && conditional) {
+
+        assert(waiting);
+
+        if (group_size <= 2) {
+
+            conditional_of_other.at((group_size == 2) ? pending_others.front() : 0) = conditionals.size();
+
+        } else {
+
+            conditional_of_others.emplace(pending_key, conditionals.size());
+        }
+
+        conditionals.emplace_back(std::move(conditional));
+        waiting = false;
+    }
+
+    // Index of the cached conditional of `slot` given the other slots, or no_conditional
+    // (then pending_* describe it).
+    uint32_t findConditional() {
+
+        if (group_size <= 2) {
+
+            const uint32_t other = (group_size == 2) ? cur_sampled_group_paths[1 - slot] : 0;
+            const uint32_t idx = conditional_of_other[other];
+
+            if (idx == no_conditional) {
+
+                pending_others.clear();
+
+                if (group_size == 2) {
+
+                    pending_others.emplace_back(other);
+                }
+            }
+
+            return idx;
+        }
+
+        pending_key = cur_sampled_group_paths;
+        pending_key.at(slot) = num_columns;
+        std::sort(pending_key.begin(), pending_key.end());
+
+        auto conditional_it = conditional_of_others.find(pending_key);
+
+        if (conditional_it != conditional_of_others.end()) {
+
+            return conditional_it->second;
+        }
+
+        pending_others.clear();
+
+        for (uint32_t k = 0; k < group_size; ++k) {
+
+            if (k != slot) {
+
+                pending_others.emplace_back(cur_sampled_group_paths.at(k));
+            }
+        }
+
+        return no_conditional;
+    }
+
+    void countSample() {
+
+        if (group_size <= 2) {
+
+            uint32_t first = cur_sampled_group_paths.front();
+            uint32_t second = cur_sampled_group_paths.back();
+
+            if (first > second) {
+
+                std::swap(first, second);
+            }
+
+            const auto index = packed_group_set_indices.emplace((static_cast<uint64_t>(first) << 32) | second, sample_counts.size());
+
+            if (index.second) {
+
+                sampled_members.emplace_back(first);
+
+                if (group_size == 2) {
+
+                    sampled_members.emplace_back(second);
+                }
+
+                sample_counts.emplace_back(1);
+
+            } else {
+
+                sample_counts[index.first]++;
+            }
+
+            return;
+        }
+
+        std::vector<uint32_t> sorted_group = cur_sampled_group_paths;
+        std::sort(sorted_group.begin(), sorted_group.end());
+
+        auto group_set_indices_it = group_set_indices.emplace(sorted_group, sample_counts.size());
+
+        if (group_set_indices_it.second) {
+
+            sampled_members.insert(sampled_members.end(), sorted_group.begin(), sorted_group.end());
+            sample_counts.emplace_back(1);
+
+        } else {
+
+            sample_counts.at(group_set_indices_it.first->second)++;
+        }
+    }
 
     // Runs until the sampler is done or needs a conditional that is not cached.
     void advance() {
@@ -193,30 +409,15 @@ struct GibbsSampler {
                 slot = 0;
             }
 
-            std::vector<uint32_t> key = cur_sampled_group_paths;
-            key.at(slot) = num_columns;
-            std::sort(key.begin(), key.end());
+            const uint32_t conditional_idx = findConditional();
 
-            auto sampler_cache_it = sampler_cache.find(key);
-
-            if (sampler_cache_it == sampler_cache.end()) {
+            if (conditional_idx == no_conditional) {
 
                 waiting = true;
-                pending_key = key;
-                pending_others.clear();
-
-                for (uint32_t k = 0; k < group_size; ++k) {
-
-                    if (k != slot) {
-
-                        pending_others.emplace_back(cur_sampled_group_paths.at(k));
-                    }
-                }
-
                 return;
             }
 
-            cur_sampled_group_paths.at(slot) = sampler_cache_it->second(*mt_rng);
+            cur_sampled_group_paths[slot] = conditionals[conditional_idx](*mt_rng);
             ++slot;
 
             if (slot < group_size) {
@@ -228,20 +429,7 @@ struct GibbsSampler {
 
             if (iteration >= num_burn_its) {
 
-                std::vector<uint32_t> sorted_group = cur_sampled_group_paths;
-                std::sort(sorted_group.begin(), sorted_group.end());
-
-                auto group_set_indices_it = group_set_indices.emplace(sorted_group, sample_counts.size());
-
-                if (group_set_indices_it.second) {
-
-                    sampled_members.insert(sampled_members.end(), sorted_group.begin(), sorted_group.end());
-                    sample_counts.emplace_back(1);
-
-                } else {
-
-                    sample_counts.at(group_set_indices_it.first->second)++;
-                }
+                countSample();
             }
 
             ++iteration;
@@ -322,12 +510,13 @@ void PathEstimator::estimateBatchSeeded(std::vector<PathClusterEstimates> * path
         return;
     }
 
-    std::vector<std::mt19937> rngs;
-    rngs.reserve(cluster_batch.numClusters());
+    // src/main.cpp:976 — cluster i draws from mt19937(rng_seed + i); seeding 624 words per generator adds up over a batch
+    std::vector<std::mt19937> rngs(cluster_batch.numClusters());
 
+    #pragma omp parallel for schedule(static) num_threads(hostThreads())
     for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
 
-        rngs.emplace_back(rng_seed + i);
+        rngs[i].seed(rng_seed + i);
     }
 
     estimateBatch(path_cluster_estimates, cluster_batch, &rngs);
@@ -529,6 +718,7 @@ void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors
         generator_problems.at(generator_index_it.first->second).emplace_back(i);
     }
 
+    #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
     for (size_t i = 0; i < problems.size(); ++i) {
 
         auto & sampler = samplers.at(i);
@@ -543,31 +733,46 @@ void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors
         sampler.num_burn_its = min_burn_it + std::round(burn_it_scaling * group_size * sampler.num_columns);
         sampler.num_gibbs_its = min_gibbs_it + std::round(gibbs_it_scaling * group_size * sampler.num_columns);
 
-        sampler.advance();
+        sampler.init();
+    }
+
+    // samplers that share a generator (transcripts of one cluster) are advanced one after the other
+    {
+    ScopedPhase phase("gibbs: first advance");
+    #pragma omp parallel for schedule(dynamic, 4) num_threads(hostThreads())
+    for (size_t generator_idx = 0; generator_idx < generator_problems.size(); ++generator_idx) {
+
+        for (auto & i: generator_problems.at(generator_idx)) {
+
+            samplers.at(i).advance();
+        }
+    }
     }
 
     // rounds: one device call evaluates the conditional every waiting sampler asked for
+    size_t num_rounds = 0;
+    size_t num_conditionals = 0;
+    size_t num_tail_rounds = 0;
+
     while (true) {
 
         std::vector<uint32_t> request_matrix;
-        std::vector<uint32_t> request_members;
-        std::vector<size_t> first_request(problems.size() + 1, 0);
+        std::vector<uint32_t> request_others;
+        std::vector<size_t> first_value(problems.size() + 1, 0);
+
+        ScopedPhase request_phase("gibbs: request build");
 
         for (size_t i = 0; i < problems.size(); ++i) {
 
             auto & sampler = samplers.at(i);
+            first_value.at(i + 1) = first_value.at(i);
 
             if (sampler.waiting) {
 
-                for (uint32_t k = 0; k < sampler.num_columns; ++k) {
-
-                    request_matrix.emplace_back(i);
-                    request_members.insert(request_members.end(), sampler.pending_others.begin(), sampler.pending_others.end());
-                    request_members.emplace_back(k);
-                }
+                request_matrix.emplace_back(i);
+                request_others.insert(request_others.end(), sampler.pending_others.begin(), sampler.pending_others.end());
+                first_value.at(i + 1) += sampler.num_columns;
             }
-
-            first_request.at(i + 1) = request_matrix.size();
         }
 
         if (request_matrix.empty()) {
@@ -575,13 +780,32 @@ void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors
             break;
         }
 
-        std::vector<double> log_likelihoods;
-        matrices.logLikelihoods(&log_likelihoods, request_matrix, request_members, group_size, group_size, false);
+        ++num_rounds;
+        num_conditionals += request_matrix.size();
+        num_tail_rounds += (request_matrix.size() <= 4);
 
-        // problems that share a generator (transcripts of one cluster) are advanced one after the other
-        #pragma omp parallel for schedule(dynamic, 4) num_threads(hostThreads())
-        for (size_t generator_idx = 0; generator_idx < generator_problems.size(); ++generator_idx) {
-        for (auto & i: generator_problems.at(generator_idx)) {
+        request_phase.stop();
+
+        std::vector<double> log_likelihoods;
+        matrices.conditionals(&log_likelihoods, request_matrix, request_others, first_value.back(), group_size, group_size);
+
+        ScopedPhase advance_phase("gibbs: supply + advance");
+
+        // problems that share a generator (transcripts of one cluster) are advanced one after the other;
+        // the last rounds serve a handful of large problems: no thread team for those
+        std::vector<size_t> active_generators;
+
+        for (auto & i: request_matrix) {
+
+            active_generators.emplace_back(generator_index.at(rngs.at(i)));
+        }
+
+        std::sort(active_generators.begin(), active_generators.end());
+        active_generators.erase(std::unique(active_generators.begin(), active_generators.end()), active_generators.end());
+
+        #pragma omp parallel for schedule(dynamic, 1) num_threads(hostThreads()) if(active_generators.size() > 2)
+        for (size_t active_idx = 0; active_idx < active_generators.size(); ++active_idx) {
+        for (auto & i: generator_problems.at(active_generators[active_idx])) {
 
             auto & sampler = samplers.at(i);
 
@@ -596,7 +820,7 @@ void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors
 
             for (uint32_t k = 0; k < sampler.num_columns; ++k) {
 
-                group_probs.at(k) = log_likelihoods.at(first_request.at(i) + k) + sampler.log_freqs.at(k);
+                group_probs.at(k) = log_likelihoods.at(first_value.at(i) + k) + sampler.log_freqs.at(k);
                 sum_log_group_probs = numeric::add_log(sum_log_group_probs, group_probs.at(k));
             }
 
@@ -605,14 +829,21 @@ void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors
                 prob = std::exp(prob - sum_log_group_probs);
             }
 
-            sampler.sampler_cache.emplace(sampler.pending_key, std::discrete_distribution<uint32_t>(group_probs.begin(), group_probs.end()));
-            sampler.waiting = false;
-
+            sampler.supply(std::discrete_distribution<uint32_t>(group_probs.begin(), group_probs.end()));
             sampler.advance();
         }
         }
     }
 
+    if (PhaseTrace::enabled()) {
+
+        std::fprintf(stderr, "[rpvg_amd trace] gibbs: %zu rounds (%zu with <= 4 waiting samplers), %zu conditionals\n", num_rounds, num_tail_rounds, num_conditionals);
+    }
+
+    ScopedPhase results_phase("gibbs: results + teardown");
+
+    // the samplers hold one pair of vectors per evaluated conditional: tear them down in parallel too
+    #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
     for (size_t i = 0; i < problems.size(); ++i) {
 
         auto & sampler = samplers.at(i);
@@ -628,6 +859,8 @@ void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors
 
             result.posteriors.emplace_back(sample_count / static_cast<double>(sampler.num_chains * sampler.num_gibbs_its));
         }
+
+        sampler = GibbsSampler();
     }
 }
 

@@ -2,6 +2,8 @@
 
 #include <cassert>
 
+#include "trace.hpp"
+
 namespace rpvg_amd {
 
 // src/path_posterior_estimator.cpp:5
@@ -11,24 +13,30 @@ PathPosteriorEstimator::PathPosteriorEstimator(const double prob_precision, std:
 
 std::vector<GroupPosteriorProblem> PathPosteriorEstimator::rawPathProblems(const std::vector<PathClusterEstimates> & path_cluster_estimates, const DeviceClusterBatch & cluster_batch) const {
 
+    ScopedPhase phase("posteriors: problems");
+
     std::vector<GroupPosteriorProblem> problems;
 
     for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
 
-        const auto & paths = path_cluster_estimates.at(i).paths;
-        assert(paths.size() == cluster_batch.numPaths(i));
+        assert(path_cluster_estimates.at(i).paths.size() == cluster_batch.numPaths(i));
 
-        if (cluster_batch.numRows(i) == 0) {
+        if (cluster_batch.numRows(i) > 0) {
 
-            continue;
+            problems.emplace_back(GroupPosteriorProblem());
+            problems.back().cluster = i;
         }
+    }
 
-        problems.emplace_back(GroupPosteriorProblem());
-        problems.back().cluster = i;
+    #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
+    for (size_t p = 0; p < problems.size(); ++p) {
+
+        auto & problem = problems[p];
+        const auto & paths = path_cluster_estimates.at(problem.cluster).paths;
 
         for (uint32_t j = 0; j < paths.size(); ++j) {
 
-            problems.back().addColumn(&j, &j + 1, paths.at(j).source_count);
+            problem.addColumn(&j, &j + 1, paths.at(j).source_count);
         }
     }
 
@@ -74,9 +82,14 @@ void PathGroupPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates
 
     assert(path_cluster_estimates->size() == cluster_batch.numClusters());
 
-    for (auto & estimates: *path_cluster_estimates) {
+    {
+        ScopedPhase phase("posteriors: reset estimates");
 
-        estimates.resetEstimates(0, 0);
+        #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
+        for (size_t i = 0; i < path_cluster_estimates->size(); ++i) {
+
+            (*path_cluster_estimates)[i].resetEstimates(0, 0);
+        }
     }
 
     const auto problems = rawPathProblems(*path_cluster_estimates, cluster_batch);
@@ -102,6 +115,9 @@ void PathGroupPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates
         calculatePathGroupPosteriorsFull(&group_posteriors, cluster_batch, problems, group_size, false);
     }
 
+    ScopedPhase pack_phase("posteriors: fill estimates");
+
+    #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
     for (size_t i = 0; i < problems.size(); ++i) {
 
         auto & estimates = path_cluster_estimates->at(problems.at(i).cluster);

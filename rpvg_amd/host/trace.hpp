@@ -89,16 +89,25 @@ class ScopedPhase {
 
         ~ScopedPhase() {
 
-            if (PhaseTrace::enabled()) {
+            stop();
+        }
+
+        // Ends the phase before the end of the scope.
+        void stop() {
+
+            if (!stopped && PhaseTrace::enabled()) {
 
                 PhaseTrace::add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count());
             }
+
+            stopped = true;
         }
 
     private:
 
         const char * name;
         const std::chrono::steady_clock::time_point start;
+        bool stopped = false;
 };
 
 }

@@ -305,6 +305,33 @@ def test_group_loglik_matches_numpy(hip_ctx, normalise):
         assert small_cases.rel_close(gotb, wantb, rel=1e-11, floor=1e-9)
 
 
+@pytest.mark.parametrize("width", [1, 2, 3])
+def test_group_conditionals_equal_member_list_requests(hip_ctx, width):
+    """rpvg_hip_group_conditionals (one request per Gibbs conditional) returns, for every candidate column, exactly
+    what rpvg_hip_group_loglik returns for the member list (others..., candidate)."""
+    clusters = small_cases.make_batch_clusters(503, n_clusters=7, with_empty=False)
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    mats = list(range(len(clusters)))
+    groups = [[[p] for p in range(len(cl["paths"]))] for cl in clusters]
+    num_cols = [len(g) for g in groups]
+    dg = hip_ctx.groups(dev, mats, groups, False)
+    rng = np.random.default_rng(17)
+    req_m = [int(m) for m in rng.integers(0, len(mats), size=23)]
+    req_o = [[int(x) for x in rng.integers(0, num_cols[m], size=width - 1)] for m in req_m]
+    got = dg.conditionals(req_m, req_o, width, float(width), num_cols)
+    assert len(got) == len(req_m)
+    for m, o, g in zip(req_m, req_o, got):
+        G = num_cols[m]
+        assert g.shape == (G,)
+        want = dg.loglik([m] * G, [o + [k] for k in range(G)], float(width))
+        assert np.array_equal(g, want)
+    cl = clusters[req_m[0]]
+    M, noise, counts = np_oracle.grouped_matrix(cl["rows"], groups[req_m[0]])
+    want0 = np.array([np_oracle.set_loglik(M, noise, counts, tuple(req_o[0]) + (k,), width) for k in range(num_cols[req_m[0]])])
+    assert small_cases.rel_close(got[0], want0, rel=1e-11, floor=1e-9)
+
+
 def test_stats_report_kernel_time(hip_ctx):
     clusters = small_cases.make_batch_clusters(9, n_clusters=4, with_empty=False)
     dev = hip_ctx.upload(ClusterBatch.from_clusters(clusters))
