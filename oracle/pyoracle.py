@@ -160,3 +160,34 @@ def add_log(x: float, y: float) -> float:
 
 def max_threads() -> int:
     return int(lib().rpvg_oracle_max_threads())
+
+
+# ---- row construction -----------------------------------------------------------
+
+def frag_length_table(loc: float, scale: float, shape: float = 0.0, sd_max_multi: int = 10) -> np.ndarray:
+    """FragmentLengthDist::logProb(v) for v = 0..65535 (src/fragment_length_dist.cpp:385-427)."""
+    L = lib()
+    L.rpvg_oracle_frag_length_table.argtypes = [C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_void_p]
+    out = np.zeros(65536, dtype=np.float64)
+    L.rpvg_oracle_frag_length_table(loc, scale, shape, sd_max_multi, out.ctypes.data)
+    return out
+
+
+def build_rows(align_batch, row_params, merge: bool = True, num_threads: int = 1):
+    """addPathProbs for every read of every cluster (+ sort / quickMergeIdentical when merge) -> (ClusterBatch, seconds)."""
+    from rpvg_amd import rows as rows_mod
+    L = lib()
+    L.rpvg_oracle_build_rows.restype = C.c_void_p
+    L.rpvg_oracle_build_rows.argtypes = [C.POINTER(rows_mod.CAlignmentBatch), C.POINTER(rows_mod.CRowParams), C.c_int, C.c_int,
+                                         C.POINTER(C.c_double)]
+    L.rpvg_oracle_rows_view.argtypes = [C.c_void_p, C.POINTER(CClusterBatch)]
+    L.rpvg_oracle_rows_free.argtypes = [C.c_void_p]
+    cb, cp = align_batch.as_c(), row_params.as_c()
+    secs = C.c_double(0)
+    h = L.rpvg_oracle_build_rows(C.byref(cb), C.byref(cp), 1 if merge else 0, int(num_threads), C.byref(secs))
+    try:
+        view = CClusterBatch()
+        L.rpvg_oracle_rows_view(h, C.byref(view))
+        return rows_mod.rows_from_view(view), secs.value
+    finally:
+        L.rpvg_oracle_rows_free(h)

@@ -1124,4 +1124,192 @@ void sortAndMergeRows(vector<ReadRow> * rows, const double prob_precision) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// row construction  (src/read_path_probabilities.cpp:39-221, src/fragment_length_dist.cpp)
+// ---------------------------------------------------------------------------
+static const double score_log_base = 1.383325268738;  // src/utils.hpp:83
+static const double noise_score_log_base = 1e-6;      // src/utils.hpp:84
+static const double kPi = 3.141592653589793238462643383279;
+
+// src/utils.hpp:143-161
+static double Phi(double z) {
+    static const double root_1_2 = std::sqrt(0.5);
+    const double x = z * root_1_2;
+    const double a = std::fabs(x);
+    double y;
+    if (a < root_1_2) {
+        y = 0.5 + 0.5 * std::erf(x);
+    } else {
+        y = 0.5 * std::erfc(a);
+        if (x > 0) y = 1.0 - y;
+    }
+    return y;
+}
+
+// src/utils.hpp:165-194
+static double log_Phi(double z) {
+    if (z > 6.0) return -Phi(-z);
+    if (z > -20.0) return std::log(Phi(z));
+    double last_total = 0, right_hand_side = 1, numerator = 1, denom_factor = 1;
+    const double denom_cons = 1.0 / (z * z);
+    long sign = 1, i = 0;
+    const double log_LHS = -0.5 * z * z - std::log(-z) - 0.5 * std::log(2 * kPi);
+    while (std::fabs(last_total - right_hand_side) > std::numeric_limits<double>::epsilon()) {
+        i += 1;
+        last_total = right_hand_side;
+        sign = -sign;
+        denom_factor *= denom_cons;
+        numerator *= 2 * i - 1;
+        right_hand_side += sign * numerator * denom_factor;
+    }
+    return log_LHS + std::log(right_hand_side);
+}
+
+// src/utils.hpp:206-220
+static double log_normal_pdf(double x, double m, double s) {
+    static const double inv_sqrt_2pi = 0.3989422804014327;
+    const double z = (x - m) / s;
+    return std::log(inv_sqrt_2pi) - std::log(s) - 0.5 * z * z;
+}
+
+static double log_skew_normal_pdf(double x, double m, double s, double a) {
+    static const double log_const = std::log(2.0 / std::sqrt(2.0 * kPi));
+    const double z = (x - m) / s;
+    return log_const + log_Phi(a * z) - std::log(s) - 0.5 * z * z;
+}
+
+// src/fragment_length_dist.cpp:21-27,396-427
+FragmentLengthDist::FragmentLengthDist(const double loc_in, const double scale_in, const double shape_in,
+                                       const uint32_t sd_max_multi) : loc(loc_in), scale(scale_in), shape(shape_in) {
+    assert(loc >= 0 && scale > 0);
+    const double delta = shape / std::sqrt(1.0 + shape * shape);
+    const double sd = scale * (1.0 - 2.0 * delta * delta / kPi);
+    max_length = std::ceil(loc + sd * sd_max_multi);
+    assert(max_length > 0);
+    log_prob_buffer = vector<double>(max_length + 1);
+    for (size_t i = 0; i < log_prob_buffer.size(); ++i) {
+        log_prob_buffer[i] = doubleCompare(shape, 0.0) ? log_normal_pdf(i, loc, scale) : log_skew_normal_pdf(i, loc, scale, shape);
+    }
+}
+
+// src/fragment_length_dist.cpp:385-394
+double FragmentLengthDist::logProb(const uint32_t value) const {
+    if (value < log_prob_buffer.size()) return log_prob_buffer[value];
+    if (doubleCompare(shape, 0.0)) return log_normal_pdf(value, loc, scale);
+    return log_skew_normal_pdf(value, loc, scale, shape);
+}
+
+// src/read_path_probabilities.cpp:39-67
+vector<double> calcAlignPathLogProbs(const vector<AlignPath> & align_paths, const FragmentLengthDist & fld,
+                                     const bool is_single_end) {
+    assert(align_paths.size() > 1);
+    assert(align_paths.back().path_idx.empty());
+    assert(align_paths.back().frag_length == 0);
+    assert(align_paths.back().align_length == 0);
+    assert(align_paths.back().score_sum <= 0);
+
+    vector<double> align_paths_log_probs;
+    align_paths_log_probs.reserve(align_paths.size());
+    for (size_t i = 0; i < align_paths.size() - 1; ++i) {
+        const AlignPath & align_path = align_paths[i];
+        assert(align_paths.front().min_mapq == align_path.min_mapq);
+        align_paths_log_probs.emplace_back(align_path.score_sum * score_log_base);
+        if (!is_single_end) {
+            align_paths_log_probs.back() += fld.logProb(align_path.frag_length);
+        }
+    }
+    align_paths_log_probs.emplace_back(align_paths.back().score_sum * noise_score_log_base);
+    return align_paths_log_probs;
+}
+
+// src/read_path_probabilities.cpp:74-221
+ReadRow addPathProbs(const uint32_t read_count, const double prob_precision, const vector<AlignPath> & align_paths,
+                     const vector<PathInfo> & cluster_paths, const FragmentLengthDist & fld, const bool is_single_end,
+                     const double min_noise_prob, const bool collapse_groups, const vector<uint32_t> & path_group,
+                     const uint32_t num_groups) {
+    ReadRow row;
+    row.read_count = read_count;
+    row.noise_prob = 1;
+    assert(align_paths.size() > 1);
+
+    if (align_paths.front().min_mapq > 0) {
+        // Utils::phred_to_prob, src/utils.hpp:131-133
+        row.noise_prob = std::max(prob_precision, std::max(min_noise_prob, std::pow(10, -((double) align_paths.front().min_mapq) / 10)));
+        assert(row.noise_prob < 1 && row.noise_prob > 0);
+
+        auto align_paths_log_probs = calcAlignPathLogProbs(align_paths, fld, is_single_end);
+        row.noise_prob += (1 - row.noise_prob) * std::exp(align_paths_log_probs.back());
+
+        if (align_paths.back().score_sum == 0) {
+            assert(doubleCompare(row.noise_prob, 1));
+            return row;
+        }
+
+        vector<double> read_path_log_probs(cluster_paths.size(), kLowest);
+        vector<double> read_path_max_align_lengths(cluster_paths.size(), 0);
+
+        for (size_t i = 0; i + 1 < align_paths.size(); ++i) {
+            assert(!align_paths[i].path_idx.empty());
+            for (auto path_idx: align_paths[i].path_idx) {
+                assert(path_idx < cluster_paths.size());
+                if (doubleCompare(cluster_paths[path_idx].effective_length, 0)) {
+                    assert(doubleCompare(read_path_log_probs[path_idx], kLowest));
+                } else {
+                    const double log_prob = align_paths_log_probs[i] - std::log(cluster_paths[path_idx].effective_length);
+                    assert(align_paths[i].align_length > 0);
+                    if (align_paths[i].align_length > read_path_max_align_lengths[path_idx]) {
+                        read_path_log_probs[path_idx] = log_prob;
+                        read_path_max_align_lengths[path_idx] = align_paths[i].align_length;
+                    } else if (align_paths[i].align_length == read_path_max_align_lengths[path_idx]) {
+                        read_path_log_probs[path_idx] = std::max(read_path_log_probs[path_idx], log_prob);
+                    }
+                }
+            }
+        }
+
+        if (collapse_groups) {
+            assert(path_group.size() == cluster_paths.size());
+            assert(num_groups > 0);
+            vector<double> read_path_log_probs_groups(num_groups, kLowest);
+            for (size_t i = 0; i < read_path_log_probs.size(); ++i) {
+                double & slot = read_path_log_probs_groups.at(path_group[i]);
+                slot = add_log(slot, read_path_log_probs[i] + std::log(cluster_paths[i].source_count));
+            }
+            read_path_log_probs = read_path_log_probs_groups;
+        }
+
+        double read_path_log_probs_sum = kLowest;
+        for (auto & log_prob: read_path_log_probs) {
+            read_path_log_probs_sum = add_log(read_path_log_probs_sum, log_prob);
+        }
+        double low_prob_sum = 0;
+        assert(read_path_log_probs_sum > kLowest);
+
+        auto & path_probs = row.path_probs;
+        for (size_t i = 0; i < read_path_log_probs.size(); ++i) {
+            read_path_log_probs[i] = std::exp(read_path_log_probs[i] - read_path_log_probs_sum);
+            if (read_path_log_probs[i] >= prob_precision) {
+                auto it = path_probs.begin();
+                while (it != path_probs.end()) {
+                    if (std::abs(it->first - read_path_log_probs[i]) < prob_precision) {
+                        it->first = ((it->first * it->second.size() + read_path_log_probs[i]) / (it->second.size() + 1));
+                        it->second.emplace_back(i);
+                        break;
+                    }
+                    ++it;
+                }
+                if (it == path_probs.end()) {
+                    path_probs.emplace_back(read_path_log_probs[i], vector<uint32_t>({static_cast<uint32_t>(i)}));
+                }
+            } else {
+                low_prob_sum += read_path_log_probs[i];
+            }
+        }
+        for (auto & prob: path_probs) prob.first *= (1 - row.noise_prob);
+        row.noise_prob += low_prob_sum * (1 - row.noise_prob);
+        std::sort(path_probs.begin(), path_probs.end());
+    }
+    return row;
+}
+
 }  // namespace rpvg_oracle

@@ -10,7 +10,9 @@
 // libvgio, htslib absent — SURVEY.md F2) and its own test-suite pins nothing on
 // this path except MinimumPathAbundanceEstimator::weightedMinimumPathCover
 // (src/tests/path_abundance_estimator_test.cpp:8-28), which IS pinned here
-// (tests/test_oracle_golden.py).  The restatement is additionally cross-checked
+// (tests/test_oracle_golden.py).  PINNED as well: row construction
+// (addPathProbs + quickMergeIdentical), against every case of the reference's
+// src/tests/read_path_probabilities_test.cpp:9-205 (tests/test_row_construction.py).  The restatement is additionally cross-checked
 // against an independent numpy restatement (oracle/np_oracle.py) and the
 // hand-derivable known-answer cases of SURVEY.md §8c.
 //
@@ -146,6 +148,38 @@ void estimate(const std::string & model, const Params & prm, Estimates * est, co
 bool rowLess(const ReadRow & lhs, const ReadRow & rhs);                        // read_path_probabilities.cpp:283-322
 bool quickMergeIdentical(ReadRow * a, const ReadRow & b, double prob_precision);  // :223-250
 void sortAndMergeRows(std::vector<ReadRow> * rows, double prob_precision);
+
+// ---- row construction: the step before the path -----
+// src/fragment_length_dist.cpp:19-27,385-427 (normal / skew-normal; log-density table up to max_length).
+struct FragmentLengthDist {
+    double loc = 0, scale = 0, shape = 0;
+    uint32_t max_length = 0;
+    std::vector<double> log_prob_buffer;
+    FragmentLengthDist() {}
+    FragmentLengthDist(double mean, double sd, uint32_t sd_max_multi) : FragmentLengthDist(mean, sd, 0.0, sd_max_multi) {}
+    FragmentLengthDist(double loc_in, double scale_in, double shape_in, uint32_t sd_max_multi);
+    double logProb(uint32_t value) const;
+};
+
+// The AlignmentPath fields addPathProbs reads (src/alignment_path.hpp:22-39) with the gbwt search state replaced
+// by the path ids it locates, already mapped to cluster-local indices (align_paths_ids + clustered_path_index).
+struct AlignPath {
+    uint8_t min_mapq = 0;
+    int32_t score_sum = 0;
+    uint16_t align_length = 0;
+    uint16_t frag_length = 0;
+    std::vector<uint32_t> path_idx;
+};
+
+// src/read_path_probabilities.cpp:39-67
+std::vector<double> calcAlignPathLogProbs(const std::vector<AlignPath> & align_paths, const FragmentLengthDist & fld,
+                                          bool is_single_end);
+// src/read_path_probabilities.cpp:74-221.  align_paths.back() is the noise entry.  path_group (one cluster-local
+// group index per path) and num_groups are only read when collapse_groups is set.
+ReadRow addPathProbs(uint32_t read_count, double prob_precision, const std::vector<AlignPath> & align_paths,
+                     const std::vector<PathInfo> & cluster_paths, const FragmentLengthDist & fld, bool is_single_end,
+                     double min_noise_prob, bool collapse_groups = false,
+                     const std::vector<uint32_t> & path_group = std::vector<uint32_t>(), uint32_t num_groups = 0);
 
 }  // namespace rpvg_oracle
 

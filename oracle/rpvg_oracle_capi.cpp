@@ -15,6 +15,7 @@
 #include <omp.h>
 
 #include "../include/rpvg_batch.h"
+#include "../include/rpvg_rows.h"
 #include "rpvg_oracle.hpp"
 
 using namespace rpvg_oracle;
@@ -241,5 +242,112 @@ double rpvg_oracle_add_log(double x, double y) { return add_log(x, y); }
 int rpvg_oracle_double_compare(double a, double b) { return doubleCompare(a, b) ? 1 : 0; }
 
 int rpvg_oracle_max_threads(void) { return omp_get_max_threads(); }
+
+// ---- row construction ---------------------------------------------------------------
+
+namespace {
+
+struct FlatRows {
+    std::vector<uint64_t> cluster_row_off, cluster_path_off, row_grp_off, grp_idx_off;
+    std::vector<uint32_t> row_count, path_idx;
+    std::vector<double> row_noise, grp_prob;
+};
+
+}  // namespace
+
+// FragmentLengthDist::logProb(v) for v = 0 .. RPVG_FRAG_LENGTH_TABLE_SIZE-1 (src/fragment_length_dist.cpp:385-394).
+void rpvg_oracle_frag_length_table(double loc, double scale, double shape, uint32_t sd_max_multi, double * out) {
+    const FragmentLengthDist fld(loc, scale, shape, sd_max_multi);
+    for (uint32_t v = 0; v < RPVG_FRAG_LENGTH_TABLE_SIZE; ++v) out[v] = fld.logProb(v);
+}
+
+// The caller's loop of src/main.cpp:889-973 over every cluster of the batch: one addPathProbs per read, then (merge != 0)
+// sort + quickMergeIdentical.  OpenMP over clusters as the reference (src/main.cpp:829).
+void * rpvg_oracle_build_rows(const rpvg_alignment_batch * b, const rpvg_row_params * prm, int merge, int num_threads,
+                              double * seconds_out) {
+    const uint32_t K = b->num_clusters;
+    FragmentLengthDist fld;
+    if (!prm->is_single_end) {
+        fld.log_prob_buffer.assign(prm->frag_length_log_prob, prm->frag_length_log_prob + RPVG_FRAG_LENGTH_TABLE_SIZE);
+    }
+    const bool collapse = b->path_group != nullptr;
+    std::vector<std::vector<ReadRow>> rows(K);
+    if (num_threads < 1) num_threads = 1;
+
+    auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint64_t p0 = b->cluster_path_off[k], p1 = b->cluster_path_off[k + 1];
+        std::vector<PathInfo> paths(p1 - p0);
+        std::vector<uint32_t> path_group;
+        for (uint64_t p = p0; p < p1; ++p) {
+            paths[p - p0].effective_length = b->path_effective_length[p];
+            paths[p - p0].source_count = b->path_source_count ? b->path_source_count[p] : 1;
+            if (collapse) path_group.emplace_back(b->path_group[p]);
+        }
+        const uint32_t num_groups = collapse ? b->cluster_group_off[k + 1] - b->cluster_group_off[k] : 0;
+        rows[k].reserve(b->cluster_read_off[k + 1] - b->cluster_read_off[k]);
+        for (uint64_t r = b->cluster_read_off[k]; r < b->cluster_read_off[k + 1]; ++r) {
+            std::vector<AlignPath> align_paths;
+            for (uint64_t a = b->read_align_off[r]; a < b->read_align_off[r + 1]; ++a) {
+                AlignPath ap;
+                ap.min_mapq = b->read_min_mapq[r];
+                ap.score_sum = b->align_score_sum[a];
+                ap.align_length = b->align_length[a];
+                ap.frag_length = b->align_frag_length[a];
+                ap.path_idx.assign(b->align_path_idx + b->align_path_off[a], b->align_path_idx + b->align_path_off[a + 1]);
+                align_paths.emplace_back(std::move(ap));
+            }
+            AlignPath noise;
+            noise.min_mapq = b->read_min_mapq[r];
+            noise.score_sum = b->read_noise_score[r];
+            align_paths.emplace_back(noise);
+            rows[k].emplace_back(addPathProbs(b->read_count[r], prm->prob_precision, align_paths, paths, fld,
+                                              prm->is_single_end != 0, prm->min_noise_prob, collapse, path_group, num_groups));
+        }
+        if (merge) sortAndMergeRows(&rows[k], prm->prob_precision);
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(t1 - t0).count();
+
+    FlatRows * out = new FlatRows();
+    out->cluster_row_off.push_back(0);
+    out->cluster_path_off.push_back(0);
+    out->row_grp_off.push_back(0);
+    out->grp_idx_off.push_back(0);
+    for (uint32_t k = 0; k < K; ++k) {
+        for (auto & row : rows[k]) {
+            out->row_count.push_back(row.read_count);
+            out->row_noise.push_back(row.noise_prob);
+            for (auto & g : row.path_probs) {
+                out->grp_prob.push_back(g.first);
+                out->path_idx.insert(out->path_idx.end(), g.second.begin(), g.second.end());
+                out->grp_idx_off.push_back(out->path_idx.size());
+            }
+            out->row_grp_off.push_back(out->grp_prob.size());
+        }
+        out->cluster_row_off.push_back(out->row_count.size());
+        const uint64_t cols = collapse ? b->cluster_group_off[k + 1] - b->cluster_group_off[k]
+                                       : b->cluster_path_off[k + 1] - b->cluster_path_off[k];
+        out->cluster_path_off.push_back(out->cluster_path_off.back() + cols);
+    }
+    return out;
+}
+
+void rpvg_oracle_rows_view(void * handle, rpvg_cluster_batch * out) {
+    FlatRows * r = static_cast<FlatRows *>(handle);
+    std::memset(out, 0, sizeof(*out));
+    out->num_clusters = r->cluster_row_off.size() - 1;
+    out->cluster_row_off = r->cluster_row_off.data();
+    out->cluster_path_off = r->cluster_path_off.data();
+    out->row_count = r->row_count.data();
+    out->row_noise = r->row_noise.data();
+    out->row_grp_off = r->row_grp_off.data();
+    out->grp_prob = r->grp_prob.data();
+    out->grp_idx_off = r->grp_idx_off.data();
+    out->path_idx = r->path_idx.data();
+}
+
+void rpvg_oracle_rows_free(void * handle) { delete static_cast<FlatRows *>(handle); }
 
 }  // extern "C"
