@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "rpvg_batch.h"
+#include "rpvg_rows.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -213,6 +214,18 @@ void rpvg_hip_pair_posteriors_free(rpvg_hip_pair_posteriors * result);
  * the range cover_off[i+1] - cover_off[i] must hold the cluster's number of paths. */
 int rpvg_hip_min_path_cover(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t num_clusters,
                             const uint32_t * clusters, const uint64_t * cover_off, uint32_t * cover, uint32_t * cover_size);
+
+/* ---- row construction: the step before the path (include/rpvg_rows.h) ------- */
+/* ReadPathProbabilities::addPathProbs for every read of every cluster of the batch (src/read_path_probabilities.cpp:
+ * 39-221) and, when merge != 0, the caller's sort + quickMergeIdentical of adjacent rows (src/main.cpp:953-973,
+ * src/read_path_probabilities.cpp:223-322), on the GPU.  The result holds host arrays in the layout of
+ * rpvg_cluster_batch (row fields only; with name-group collapsing the "paths" of a cluster are its groups), ready
+ * for rpvg_hip_batch_upload.  build_ms / merge_ms (optional) = device time of the row kernels and of sort+merge+pack. */
+typedef struct rpvg_hip_read_rows rpvg_hip_read_rows;
+int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_alignment_batch * alignments, const rpvg_row_params * params,
+                             int32_t merge, rpvg_hip_read_rows ** rows_out);
+int rpvg_hip_read_rows_view(const rpvg_hip_read_rows * rows, rpvg_cluster_batch * view, double * build_ms, double * merge_ms);
+void rpvg_hip_read_rows_free(rpvg_hip_read_rows * rows);
 
 /* ---- communicator (RCCL over xGMI; one process per GPU) --------------------- */
 /* The reference is one process with OpenMP threads (src/main.cpp:829) and has no exchange step; the

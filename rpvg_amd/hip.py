@@ -26,6 +26,7 @@ EXPORTS = [
     "rpvg_hip_gibbs_read_counts", "rpvg_hip_min_path_cover", "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
     "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
     "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_group_conditionals",
+    "rpvg_hip_read_rows_build", "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_free",
 ]
 
 COMM_ID_BYTES = 128  # RPVG_HIP_COMM_ID_BYTES
@@ -334,6 +335,22 @@ class Context:
         _check(lib().rpvg_hip_synth_dense_rows(self.handle, C.c_uint64(seed), C.c_uint64(row_begin), C.c_uint64(R),
                                                C.c_uint32(N), C.c_void_p(d_matrix), C.c_uint64(ld), C.c_void_p(d_counts)),
                "rpvg_hip_synth_dense_rows")
+
+    # ---- row construction (include/rpvg_rows.h) ------------------------------------
+    def build_rows(self, align_batch, row_params, merge: bool = True):
+        """addPathProbs for every read (+ sort / merge) on the GPU -> (ClusterBatch of rows, build_ms, merge_ms)."""
+        from . import rows as rows_mod
+        cb, cp = align_batch.as_c(), row_params.as_c()
+        h = C.c_void_p()
+        _check(lib().rpvg_hip_read_rows_build(self.handle, C.byref(cb), C.byref(cp), C.c_int32(1 if merge else 0), C.byref(h)),
+               "rpvg_hip_read_rows_build")
+        try:
+            view = CClusterBatch()
+            b_ms, m_ms = C.c_double(0), C.c_double(0)
+            _check(lib().rpvg_hip_read_rows_view(h, C.byref(view), C.byref(b_ms), C.byref(m_ms)), "rpvg_hip_read_rows_view")
+            return rows_mod.rows_from_view(view), b_ms.value, m_ms.value
+        finally:
+            lib().rpvg_hip_read_rows_free(h)
 
     # ---- stats ----------------------------------------------------------------
     def stats(self) -> dict:

@@ -1,0 +1,333 @@
+"""GPU row construction (rpvg_hip_read_rows_build: addPathProbs + sort/merge on the device) against the reference's own
+test vectors (src/tests/read_path_probabilities_test.cpp:9-205, through tests/test_row_construction.py's case data)
+and against the oracle on seeded alignment batches.
+
+Bar: row structure (groups, member lists, their order) and read counts exact; noise and probabilities within 1e-9
+relative (the device normalises with one log-sum-exp where the reference folds add_log: a rounding-level difference).
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from rpvg_amd import engine as eng_mod
+from rpvg_amd.batch import make_params
+from rpvg_amd.rows import INT32_LOWEST, AlignmentBatch, RowParams
+from tests import test_row_construction as kat
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-9
+
+
+def params(precision=1e-8, min_noise=0.0, single_end=False):
+    return RowParams(prob_precision=precision, min_noise_prob=min_noise, is_single_end=single_end,
+                     frag_length_log_prob=None if single_end else kat.frag_table())
+
+
+def gpu_rows(hip_ctx, cluster, precision=1e-8, min_noise=0.0, merge=False):
+    rows, _, _ = hip_ctx.build_rows(AlignmentBatch.from_clusters([cluster]), params(precision, min_noise), merge=merge)
+    return rows.cluster(0)["rows"]
+
+
+def close(a, b):
+    return abs(a - b) <= REL * max(abs(a), abs(b)) + 1e-300
+
+
+def check_row(row, count, noise, groups):
+    assert row[0] == count
+    assert close(row[1], noise), (row[1], noise)
+    assert [g[1] for g in row[2]] == [g[1] for g in groups]
+    for (p, _), (wp, _) in zip(row[2], groups):
+        assert close(p, wp), (p, wp)
+
+
+# ---- the reference's cases on the device -----------------------------------------------------------------------------
+
+def test_reference_case_single_alignment(hip_ctx):
+    (row,) = gpu_rows(hip_ctx, kat.base_case())
+    check_row(row, 1, 0.1, [(0.45, [0, 1])])
+
+
+def test_reference_case_improbable_fragment(hip_ctx):
+    c = kat.base_case()
+    c["reads"][0]["aligns"][0] = (3, 5, 10000, [0, 1])
+    (row,) = gpu_rows(hip_ctx, c)
+    check_row(row, 1, 0.1, [(0.45, [0, 1])])
+
+
+def test_reference_case_multiple_alignments(hip_ctx):
+    (row,) = gpu_rows(hip_ctx, kat.multi_case())
+    check_row(row, 1, 0.1, [(0.233044027062125, [3]), (0.333477986468937, [0, 1])])
+
+
+def test_reference_case_precision_buckets(hip_ctx):
+    c = kat.multi_case()
+    c["paths"][-1]["effective_length"] = 2.0
+    (row,) = gpu_rows(hip_ctx, c, precision=0.1)
+    check_row(row, 1, 0.1, [(0.3, [0, 1, 3])])
+
+
+def test_reference_case_longest_alignment_wins(hip_ctx):
+    c = kat.multi_case()
+    c["reads"][0]["aligns"].append((3, 10, 10, [3]))
+    (row,) = gpu_rows(hip_ctx, c, precision=0.1)
+    check_row(row, 1, 0.1, [(0.3, [0, 1, 3])])
+
+
+def test_reference_case_highest_score_wins_at_equal_length(hip_ctx):
+    c = kat.multi_case()
+    c["reads"][0]["aligns"].append((3, 8, 15, [3]))
+    (row,) = gpu_rows(hip_ctx, c, precision=0.1)
+    check_row(row, 1, 0.1, [(0.233044027062125, [3]), (0.333477986468937, [0, 1])])
+
+
+def test_reference_case_noise_alignment(hip_ctx):
+    c = kat.base_case()
+    c["reads"][0]["noise_score"] = int(-2.302585 / kat.NOISE_SCORE_LOG_BASE)
+    (row,) = gpu_rows(hip_ctx, c)
+    check_row(row, 1, 0.190000008369464, [(0.404999995815267, [0, 1])])
+    c["reads"][0]["noise_score"] = 0
+    (row,) = gpu_rows(hip_ctx, c)
+    check_row(row, 1, 1.0, [])
+
+
+def test_reference_case_effective_lengths(hip_ctx):
+    c = kat.base_case()
+    c["paths"][-1]["effective_length"] = 2.0
+    (row,) = gpu_rows(hip_ctx, c)
+    check_row(row, 1, 0.1, [(0.36, [0]), (0.54, [1])])
+
+
+def test_reference_case_base_noise(hip_ctx):
+    c = kat.base_case()
+    c["reads"][0]["noise_score"] = int(-5.0 / kat.NOISE_SCORE_LOG_BASE)
+    (row,) = gpu_rows(hip_ctx, c, min_noise=0.3)
+    check_row(row, 1, 0.304716562899359, [(0.347641718550320, [0, 1])])
+
+
+def test_reference_case_identical_rows_merge(hip_ctx):
+    c = kat.base_case()
+    c["reads"].append(copy.deepcopy(c["reads"][0]))
+    (row,) = gpu_rows(hip_ctx, c, merge=True)
+    check_row(row, 2, 0.1, [(0.45, [0, 1])])
+
+
+# ---- seeded batches against the oracle ---------------------------------------------------------------------------------
+
+def make_alignment_clusters(seed, n_clusters=6, max_paths=40, reads_per_cluster=400, collapse=False, wide=False, chains=False):
+    """Clusters whose reads instantiate a few alignment templates with shifted scores (so that rows that are equal up
+    to rounding must merge), plus mapq-0 reads, zero-length paths, duplicate paths across alignments and, with `wide`,
+    reads touching hundreds of paths (more buckets than the LDS tier of the kernel holds).
+
+    chains=False keeps the scores of one read within 8 of each other: every probability stays above prob_precision, no
+    sub-precision mass reaches the noise term, and the values of two rows either agree up to rounding or differ by far
+    more than the reference's comparison tolerance — operator< is then a consistent order and the merged rows are
+    well defined.  chains=True lets scores differ by up to 130: noise terms then differ by arbitrary tiny amounts, the
+    tolerant operator< is no longer transitive and the reference's own result depends on std::sort's internals."""
+    rng = np.random.default_rng(seed)
+    clusters = []
+    for k in range(n_clusters):
+        P = int(rng.integers(1, max_paths + 1)) if not wide else int(rng.integers(300, 700))
+        paths = []
+        for p in range(P):
+            d = dict(effective_length=float(rng.integers(50, 4000) if chains else rng.integers(500, 1500)) if rng.random() > 0.03 else 0.0,
+                     source_count=int(rng.integers(1, 5)))
+            if collapse:
+                d["group"] = int(rng.integers(0, max(1, P // 3)))
+            paths.append(d)
+        if collapse:  # group indices must be dense 0..G-1
+            remap = {g: i for i, g in enumerate(sorted({p["group"] for p in paths}))}
+            for p in paths:
+                p["group"] = remap[p["group"]]
+        templates = []
+        for _ in range(int(rng.integers(2, 9))):
+            aligns = []
+            for _ in range(int(rng.integers(1, 5))):
+                n = int(rng.integers(1, min(P, 6 if not wide else 400) + 1))
+                idx = sorted(int(x) for x in rng.choice(P, size=n, replace=False))
+                if all(paths[i]["effective_length"] == 0.0 for i in idx):  # the reference asserts on such a read (:174)
+                    paths[idx[0]]["effective_length"] = 100.0
+                score = int(rng.integers(20, 150)) if chains else int(rng.integers(100, 109))
+                aligns.append((score, int(rng.integers(60, 151)), int(rng.integers(1, 40) if chains else rng.integers(8, 13)), idx))
+            templates.append(aligns)
+        reads = []
+        R = int(rng.integers(1, reads_per_cluster + 1)) if k else 0  # cluster 0 has no reads
+        for _ in range(R):
+            tpl = templates[int(rng.integers(0, len(templates)))]
+            shift = int(rng.integers(-5, 6))
+            aligns = [(s + shift, al, fl, list(idx)) for (s, al, fl, idx) in tpl]
+            if rng.random() < 0.1:  # one alignment gets a worse score: different row
+                s, al, fl, idx = aligns[0]
+                aligns[0] = (s - int(rng.integers(1, 30) if chains else rng.integers(1, 3)), al, fl, idx)
+            reads.append(dict(count=int(rng.integers(1, 5)), min_mapq=int(rng.choice([0, 1, 10, 30, 60], p=[.05, .05, .2, .2, .5])),
+                              noise_score=int(rng.choice([INT32_LOWEST, -4000000, -700000, 0], p=[.6, .2, .15, .05])),
+                              aligns=aligns))
+        clusters.append(dict(paths=paths, reads=reads))
+    return clusters
+
+
+def compare_unmerged(got, ref):
+    assert np.array_equal(got.cluster_row_off, ref.cluster_row_off)
+    assert np.array_equal(got.cluster_path_off, ref.cluster_path_off)
+    assert np.array_equal(got.row_count, ref.row_count)
+    assert np.array_equal(got.row_grp_off, ref.row_grp_off)
+    assert np.array_equal(got.grp_idx_off, ref.grp_idx_off)
+    assert np.array_equal(got.path_idx, ref.path_idx)
+    assert np.allclose(got.row_noise, ref.row_noise, rtol=REL, atol=0)
+    assert np.allclose(got.grp_prob, ref.grp_prob, rtol=REL, atol=0)
+
+
+def canonical_rows(batch, k):
+    """Rows of cluster k as a sorted list of (structure, count, noise, probs): order-free comparison of merged rows."""
+    out = []
+    for cnt, noise, groups in batch.cluster(k)["rows"]:
+        out.append((tuple(tuple(idx) for _, idx in groups), round(noise, 7), cnt, noise, tuple(p for p, _ in groups)))
+    return sorted(out)
+
+
+def compare_merged(got, ref):
+    assert np.array_equal(got.cluster_row_off, ref.cluster_row_off)  # same number of merged rows per cluster
+    assert got.total_reads == ref.total_reads
+    for k in range(ref.num_clusters):
+        g, r = canonical_rows(got, k), canonical_rows(ref, k)
+        assert len(g) == len(r)
+        for a, b in zip(g, r):
+            assert a[0] == b[0] and a[2] == b[2], k  # structure and merged read count exact
+            assert close(a[3], b[3]) or abs(a[3] - b[3]) < 1e-8  # the kept values are those of some member of the run
+            assert all(abs(x - y) < 1e-8 for x, y in zip(a[4], b[4]))
+
+
+def check_valid_merge(got, unmerged, ref_merged):
+    """Where operator< is not transitive the exact runs are std::sort's business; what must hold regardless: reads are
+    conserved per cluster and per row structure, every merged row is one of the input rows, and the number of rows
+    left is close to the reference's."""
+    assert got.num_clusters == unmerged.num_clusters
+    for k in range(unmerged.num_clusters):
+        per_structure_in, per_structure_out, values_in = {}, {}, {}
+        for cnt, noise, groups in unmerged.cluster(k)["rows"]:
+            key = tuple(tuple(idx) for _, idx in groups)
+            per_structure_in[key] = per_structure_in.get(key, 0) + cnt
+            values_in.setdefault(key, set()).add((noise,) + tuple(p for p, _ in groups))
+        for cnt, noise, groups in got.cluster(k)["rows"]:
+            key = tuple(tuple(idx) for _, idx in groups)
+            per_structure_out[key] = per_structure_out.get(key, 0) + cnt
+            assert (noise,) + tuple(p for p, _ in groups) in values_in[key]  # the head of a run is kept bit for bit
+        assert per_structure_in == per_structure_out
+    n_got, n_ref = got.num_rows, ref_merged.num_rows
+    assert abs(n_got - n_ref) <= max(2, 0.05 * n_ref), (n_got, n_ref)
+
+
+@pytest.mark.parametrize("seed", [801, 802, 803])
+def test_rows_with_intransitive_order_still_merge_validly(hip_ctx, seed):
+    batch = AlignmentBatch.from_clusters(make_alignment_clusters(seed, chains=True))
+    prm = params(min_noise=1e-4)
+    ref, _ = pyoracle.build_rows(batch, prm, merge=False)
+    got, _, _ = hip_ctx.build_rows(batch, prm, merge=False)
+    compare_unmerged(got, ref)
+    ref_m, _ = pyoracle.build_rows(batch, prm, merge=True)
+    got_m, _, _ = hip_ctx.build_rows(batch, prm, merge=True)
+    check_valid_merge(got_m, got, ref_m)
+
+
+@pytest.mark.parametrize("seed", [801, 802, 803, 804])
+@pytest.mark.parametrize("single_end", [False, True])
+def test_rows_match_oracle(hip_ctx, seed, single_end):
+    batch = AlignmentBatch.from_clusters(make_alignment_clusters(seed))
+    prm = params(min_noise=1e-4, single_end=single_end)
+    ref, _ = pyoracle.build_rows(batch, prm, merge=False)
+    got, _, _ = hip_ctx.build_rows(batch, prm, merge=False)
+    compare_unmerged(got, ref)
+    ref_m, _ = pyoracle.build_rows(batch, prm, merge=True)
+    got_m, _, _ = hip_ctx.build_rows(batch, prm, merge=True)
+    assert ref_m.num_rows < ref.num_rows  # the generator does produce mergeable rows
+    compare_merged(got_m, ref_m)
+
+
+@pytest.mark.parametrize("seed", [811, 812])
+def test_collapsed_name_groups_match_oracle(hip_ctx, seed):
+    batch = AlignmentBatch.from_clusters(make_alignment_clusters(seed, collapse=True))
+    prm = params(min_noise=1e-4)
+    ref, _ = pyoracle.build_rows(batch, prm, merge=False)
+    got, _, _ = hip_ctx.build_rows(batch, prm, merge=False)
+    compare_unmerged(got, ref)
+    compare_merged(hip_ctx.build_rows(batch, prm, merge=True)[0], pyoracle.build_rows(batch, prm, merge=True)[0])
+
+
+def test_reads_touching_hundreds_of_paths(hip_ctx):
+    batch = AlignmentBatch.from_clusters(make_alignment_clusters(821, n_clusters=3, reads_per_cluster=60, wide=True, chains=True))
+    prm = params(min_noise=1e-4)
+    ref, _ = pyoracle.build_rows(batch, prm, merge=False)
+    got, _, _ = hip_ctx.build_rows(batch, prm, merge=False)
+    assert int(np.diff(ref.row_grp_off.astype(np.int64)).max()) > 256  # more buckets than the LDS tier
+    compare_unmerged(got, ref)
+    check_valid_merge(hip_ctx.build_rows(batch, prm, merge=True)[0], got, pyoracle.build_rows(batch, prm, merge=True)[0])
+
+
+def test_coarse_precision_chains_follow_the_reference_order(hip_ctx):
+    """prob_precision 0.05: bucket means drift as members join (running mean), so membership depends on the order
+    in which paths are visited — the sequential part of the kernel."""
+    batch = AlignmentBatch.from_clusters(make_alignment_clusters(831, max_paths=25, chains=True))
+    prm = params(precision=0.05, min_noise=1e-4)
+    ref, _ = pyoracle.build_rows(batch, prm, merge=False)
+    got, _, _ = hip_ctx.build_rows(batch, prm, merge=False)
+    compare_unmerged(got, ref)
+
+
+def test_empty_batch_and_invalid_input(hip_ctx):
+    from rpvg_amd import hip
+    empty = AlignmentBatch.from_clusters([dict(paths=[dict(effective_length=10.0)], reads=[])])
+    rows, _, _ = hip_ctx.build_rows(empty, params(), merge=True)
+    assert rows.num_rows == 0 and rows.num_clusters == 1
+    bad = AlignmentBatch.from_clusters([kat.base_case()])
+    bad.align_path_idx[:] = [1, 0]  # not ascending
+    with pytest.raises(hip.EngineError, match="ascending"):
+        hip_ctx.build_rows(bad, params(), merge=False)
+    bad = AlignmentBatch.from_clusters([kat.base_case()])
+    bad.read_noise_score[0] = 5
+    with pytest.raises(hip.EngineError, match="noise score"):
+        hip_ctx.build_rows(bad, params(), merge=False)
+
+
+def test_large_cluster_uses_the_global_sort_stages(hip_ctx):
+    """A cluster with more rows than the LDS sort tier (2048)."""
+    clusters = make_alignment_clusters(851, n_clusters=2, max_paths=30, reads_per_cluster=1)
+    rng = np.random.default_rng(851)
+    big = clusters[1]
+    P = len(big["paths"])
+    for p in big["paths"]:
+        p["effective_length"] = float(rng.integers(500, 1500))
+    big["reads"] = []
+    for _ in range(7000):
+        n = int(rng.integers(1, min(P, 4) + 1))
+        idx = sorted(int(x) for x in rng.choice(P, size=n, replace=False))
+        big["reads"].append(dict(count=int(rng.integers(1, 4)), min_mapq=int(rng.choice([10, 30, 60])), noise_score=INT32_LOWEST,
+                                 aligns=[(int(rng.integers(100, 104)), 100, 10, idx)]))
+    batch = AlignmentBatch.from_clusters(clusters)
+    prm = params(min_noise=1e-4)
+    ref_m, _ = pyoracle.build_rows(batch, prm, merge=True)
+    got_m, _, _ = hip_ctx.build_rows(batch, prm, merge=True)
+    assert batch.num_reads > 2048 and ref_m.num_rows < batch.num_reads
+    compare_merged(got_m, ref_m)
+
+
+def test_rows_feed_the_estimators(hip_ctx):
+    """alignment paths -> rows on the GPU -> EM on the GPU == oracle rows -> oracle EM."""
+    clusters = make_alignment_clusters(841, n_clusters=8)
+    batch = AlignmentBatch.from_clusters(clusters)
+    prm = params(min_noise=1e-4)
+    got, _, _ = hip_ctx.build_rows(batch, prm, merge=True)
+    ref, _ = pyoracle.build_rows(batch, prm, merge=True)
+    for rows in (got, ref):  # row construction does not carry path metadata
+        rows.path_effective_length = batch.path_effective_length.copy()
+    e = eng_mod.Engine(0)
+    try:
+        est, _ = e.run("transcripts", make_params(), e.prepare(got))
+    finally:
+        e.close()
+    want, _ = pyoracle.run("transcripts", make_params(), ref, 1)
+    for g, w in zip(est, want):
+        assert g.total_count == w.total_count
+        assert np.allclose(g.abundances, w.abundances, rtol=1e-6, atol=1e-8)
+        assert list(g.em_iters) == list(w.em_iters)
