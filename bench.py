@@ -37,9 +37,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="s3", choices=["s3", "c2", "s5"],
+    ap.add_argument("--workload", default="s3", choices=["s3", "c2", "s5", "rows"],
                     help="s3: BASELINE.json configs[2]/[3] (default, the metric's configuration); c2: configs[1] single dense "
-                         "cluster; s5: configs[4] diploid haplotype Gibbs, 10M reads x 500k paths")
+                         "cluster; s5: configs[4] diploid haplotype Gibbs, 10M reads x 500k paths; rows: the step before the path "
+                         "(alignment paths -> merged rows, SURVEY.md 8f rank 2) on the configs[2] reads")
     ap.add_argument("--model", default="haplotype-transcripts", choices=["haplotype-transcripts", "transcripts", "haplotypes"])
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the full workload (parity/dev runs only)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -257,6 +258,86 @@ def dense_em_roofline(local_rank, rows=1000000, paths=2000, its=20):
         ctx.close()
 
 
+def run_rows(args, rank, local_rank, world, dist, torch):
+    """Row construction (ReadPathProbabilities::addPathProbs + sort/merge, include/rpvg_rows.h) for the reads of the
+    configs[2] workload: every rank builds the rows of its own batch (clusters are independent: no collective)."""
+    import numpy as np
+    from rpvg_amd import hip, synth
+    from rpvg_amd.rows import RowParams
+    K = max(8, int(round(5000 * args.scale)))
+    total_paths = max(K, int(round(200000 * args.scale)))
+    total_reads = int(round(10000000 * args.scale))
+    batch, aligns = synth.generate_with_alignments(seed=3 + rank, num_clusters=K, total_paths=total_paths, total_reads=total_reads)
+    # FragmentLengthDist(300, 50): log normal density per fragment length (src/fragment_length_dist.cpp:407-427)
+    v = np.arange(65536, dtype=np.float64)
+    frag = np.log(0.3989422804014327) - np.log(50.0) - 0.5 * ((v - 300.0) / 50.0) ** 2
+    prm = RowParams(prob_precision=1e-8, min_noise_prob=0.0, is_single_end=False, frag_length_log_prob=frag)
+    ctx = hip.Context(local_rank)
+    t_up = time.perf_counter()
+    dev = ctx.upload_alignments(aligns)  # inputs resident in HBM before the timed region (validation + H2D)
+    upload_ms = (time.perf_counter() - t_up) * 1e3
+
+    def step():
+        rows = dev.build_rows(prm, merge=True)         # resident alignment lists -> resident merged rows
+        hb = rows.to_batch_handle()                    # -> the batch the estimators take, still on the GPU
+        return rows, hb
+
+    def release(rows, hb):
+        hip.lib().rpvg_hip_batch_free(ctx.handle, hb)
+        rows.free()
+
+    for _ in range(args.warmup):
+        release(*step())
+    barrier_sync(dist, torch)
+    t0 = time.perf_counter()
+    build_ms = merge_ms = 0.0
+    for i in range(args.steps):
+        drows, hb = step()
+        if i + 1 < args.steps:
+            release(drows, hb)
+    barrier_sync(dist, torch)
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, torch)
+    t_down = time.perf_counter()
+    rows, build_ms, merge_ms = drows.download()
+    download_ms = (time.perf_counter() - t_down) * 1e3
+    release(drows, hb)
+    build_ms *= args.steps
+    merge_ms *= args.steps
+    reads_all = sum_over_ranks(float(aligns.total_reads), dist, torch)
+    if rank != 0:
+        return None
+    E = int(aligns.align_path_off[-1])
+    A = int(aligns.read_align_off[-1])
+    N = aligns.num_reads
+    # algorithmic bytes of the row kernel: every input array once (4 B path index per entry, 16 B per alignment,
+    # 17 B per read) + the padded row slices written once (12 B per group, 4 B per member, 16 B per row)
+    alg_bytes = 4.0 * E + 16.0 * A + 17.0 * N + 12.0 * len(rows.grp_prob) + 4.0 * len(rows.path_idx) + 16.0 * N
+    ach = (alg_bytes / 1e9) / (build_ms / args.steps / 1e3)
+    same_structure = bool(np.array_equal(rows.cluster_row_off, batch.cluster_row_off) and np.array_equal(rows.row_count.sum(), batch.row_count.sum()))
+    line = dict(
+        metric="read-pairs through row construction/sec", value=reads_all / (elapsed / args.steps), unit="read-pairs/s", n_gpus=world,
+        steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak",
+        vs_baseline=None, dtype="f64", data="synthetic",
+        config=dict(workload=f"row construction for {total_reads} read pairs ({N} distinct alignment-path lists, {A} alignments, {E} path "
+                             f"entries) x {total_paths} paths in {K} clusters per GPU (the reads of BASELINE.json configs[2]); alignment "
+                             "lists resident in HBM -> merged rows resident in HBM as the estimators' batch", parallelism=f"clusters sharded, {world} rank(s), no collective"),
+        roofline=dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                      kernel="readRowKernel", ms_per_launch=build_ms / args.steps,
+                      note="algorithmic bytes = inputs once + row slices once; the kernel is one wave per read and latency bound "
+                           "(binary searches, sequential precision buckets), not a streaming kernel"),
+        kernels=dict(row_kernels_ms_per_step=build_ms / args.steps, sort_merge_pack_ms_per_step=merge_ms / args.steps),
+        rows_out=int(rows.num_rows), rows_match_generator=same_structure, upload_ms=upload_ms, download_ms=download_ms,
+        value_including_upload_and_download=float(aligns.total_reads) / ((elapsed / args.steps) + (upload_ms + download_ms) / 1e3) * world)
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        cores = pyoracle.max_threads()
+        _, secs = pyoracle.build_rows(aligns, prm, merge=True, num_threads=cores)
+        line["cpu_baseline"] = dict(value=aligns.total_reads / secs, unit="read-pairs/s", cores=cores, kind="port",
+                                    sample=f"the whole batch ({aligns.total_reads} read pairs, {secs:.2f} s): oracle/ addPathProbs + sort/merge, "
+                                           f"OpenMP dynamic over clusters, {cores} threads")
+    return line
+
+
 def run_c2(args, rank, local_rank, world, dist, torch):
     """1M x 2k dense single cluster (BASELINE.json configs[1]).  Weak scaling (default): one replica of the
     cluster per GPU, no collective.  --scaling strong: the rows of ONE cluster are spread over the ranks and every
@@ -334,7 +415,8 @@ def main():
     rank, local_rank, world, dist, torch = dist_setup(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    line = run_c2(args, rank, local_rank, world, dist, torch) if args.workload == "c2" else run_s3(args, rank, local_rank, world, dist, torch)
+    runner = dict(c2=run_c2, rows=run_rows).get(args.workload, run_s3)
+    line = runner(args, rank, local_rank, world, dist, torch)
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:

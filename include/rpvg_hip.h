@@ -218,14 +218,25 @@ int rpvg_hip_min_path_cover(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, ui
 /* ---- row construction: the step before the path (include/rpvg_rows.h) ------- */
 /* ReadPathProbabilities::addPathProbs for every read of every cluster of the batch (src/read_path_probabilities.cpp:
  * 39-221) and, when merge != 0, the caller's sort + quickMergeIdentical of adjacent rows (src/main.cpp:953-973,
- * src/read_path_probabilities.cpp:223-322), on the GPU.  The result holds host arrays in the layout of
- * rpvg_cluster_batch (row fields only; with name-group collapsing the "paths" of a cluster are its groups), ready
- * for rpvg_hip_batch_upload.  build_ms / merge_ms (optional) = device time of the row kernels and of sort+merge+pack. */
+ * src/read_path_probabilities.cpp:223-322), on the GPU.
+ *   rpvg_hip_alignments_upload   validates the alignment-path lists and makes them resident in HBM;
+ *   rpvg_hip_read_rows_build     resident alignments -> resident rows (grouped layout of rpvg_cluster_batch; with
+ *                                name-group collapsing the "paths" of a cluster are its groups);
+ *   rpvg_hip_read_rows_to_batch  resident rows -> the rpvg_hip_batch the estimators take, without leaving the GPU;
+ *   rpvg_hip_read_rows_sizes     the cluster offsets of the rows only (cluster_row_off, cluster_path_off; no copy);
+ *   rpvg_hip_read_rows_view      host copy of the rows (row fields of rpvg_cluster_batch; valid until the rows are
+ *                                freed) and the device time of the row kernels / of sort + merge + pack. */
+typedef struct rpvg_hip_alignments rpvg_hip_alignments;
 typedef struct rpvg_hip_read_rows rpvg_hip_read_rows;
-int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_alignment_batch * alignments, const rpvg_row_params * params,
+int rpvg_hip_alignments_upload(rpvg_hip_ctx * ctx, const rpvg_alignment_batch * alignments, rpvg_hip_alignments ** out);
+void rpvg_hip_alignments_free(rpvg_hip_ctx * ctx, rpvg_hip_alignments * alignments);
+int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_hip_alignments * alignments, const rpvg_row_params * params,
                              int32_t merge, rpvg_hip_read_rows ** rows_out);
-int rpvg_hip_read_rows_view(const rpvg_hip_read_rows * rows, rpvg_cluster_batch * view, double * build_ms, double * merge_ms);
-void rpvg_hip_read_rows_free(rpvg_hip_read_rows * rows);
+int rpvg_hip_read_rows_to_batch(rpvg_hip_ctx * ctx, const rpvg_hip_read_rows * rows, rpvg_hip_batch ** batch_out);
+int rpvg_hip_read_rows_sizes(rpvg_hip_ctx * ctx, const rpvg_hip_read_rows * rows, rpvg_cluster_batch * view);
+int rpvg_hip_read_rows_view(rpvg_hip_ctx * ctx, rpvg_hip_read_rows * rows, rpvg_cluster_batch * view, double * build_ms,
+                            double * merge_ms);
+void rpvg_hip_read_rows_free(rpvg_hip_ctx * ctx, rpvg_hip_read_rows * rows);
 
 /* ---- communicator (RCCL over xGMI; one process per GPU) --------------------- */
 /* The reference is one process with OpenMP threads (src/main.cpp:829) and has no exchange step; the

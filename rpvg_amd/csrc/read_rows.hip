@@ -32,10 +32,34 @@
 
 using namespace rpvg_hip_detail;
 
+// Device-resident alignment batch (validated copy of a rpvg_alignment_batch).
+struct rpvg_hip_alignments {
+    uint32_t num_clusters = 0;
+    uint64_t num_reads = 0, num_aligns = 0, num_entries = 0, num_paths = 0;
+    bool collapse = false;
+    std::vector<uint64_t> h_cluster_read_off;  // [K+1]
+    std::vector<uint64_t> h_out_path_off;      // [K+1] output columns of each cluster (paths, or name groups)
+    rpvg_hip_detail::DeviceBuffer<uint32_t> read_cluster, read_count, source_count, path_group, path_idx;
+    rpvg_hip_detail::DeviceBuffer<uint64_t> cluster_path_off, cluster_read_off, read_align_off, align_path_off;
+    rpvg_hip_detail::DeviceBuffer<double> eff_len;
+    rpvg_hip_detail::DeviceBuffer<uint8_t> mapq;
+    rpvg_hip_detail::DeviceBuffer<int32_t> noise_score, score;
+    rpvg_hip_detail::DeviceBuffer<uint16_t> align_length, frag_length;
+};
+
+// Device-resident rows in the grouped layout of rpvg_cluster_batch; host copies are made on demand (view).
 struct rpvg_hip_read_rows {
-    std::vector<uint64_t> cluster_row_off, cluster_path_off, row_grp_off, grp_idx_off;
-    std::vector<uint32_t> row_count, path_idx;
-    std::vector<double> row_noise, grp_prob;
+    uint32_t num_clusters = 0;
+    uint64_t num_rows = 0, num_groups = 0, num_members = 0;
+    std::vector<uint64_t> h_cluster_row_off, h_cluster_path_off;
+    rpvg_hip_detail::DeviceBuffer<uint64_t> cluster_row_off, row_grp_off, grp_idx_off;
+    rpvg_hip_detail::DeviceBuffer<uint32_t> row_count, path_idx;
+    rpvg_hip_detail::DeviceBuffer<double> row_noise, grp_prob;
+    // host copies (rpvg_hip_read_rows_view)
+    bool downloaded = false;
+    std::vector<uint64_t> h_row_grp_off, h_grp_idx_off;
+    std::vector<uint32_t> h_row_count, h_path_idx;
+    std::vector<double> h_row_noise, h_grp_prob;
     double build_ms = 0, merge_ms = 0;
 };
 
@@ -650,6 +674,30 @@ __global__ void gatherSizesKernel(const uint64_t n, const uint32_t * __restrict_
     out_nmembers[i] = nmembers[r];
 }
 
+// rows -> the expanded entries of rpvg_hip_batch (as rpvg_hip_batch_upload does for host rows)
+__global__ void rowsExpandGroupsKernel(const uint64_t num_groups, const uint64_t * __restrict__ grp_idx_off,
+                                       const double * __restrict__ grp_prob, double * __restrict__ ent_prob) {
+    const uint64_t g = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (g >= num_groups) return;
+    const double p = grp_prob[g];
+    for (uint64_t e = grp_idx_off[g]; e < grp_idx_off[g + 1]; ++e) ent_prob[e] = p;
+}
+
+__global__ void rowsMetaKernel(const uint64_t num_rows, const uint64_t * __restrict__ row_grp_off,
+                               const uint64_t * __restrict__ grp_idx_off, const uint32_t * __restrict__ row_count_u32,
+                               uint64_t * __restrict__ row_ent_off, double * __restrict__ row_count) {
+    const uint64_t r = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (r > num_rows) return;
+    row_ent_off[r] = grp_idx_off[row_grp_off[r]];
+    if (r < num_rows) row_count[r] = static_cast<double>(row_count_u32[r]);
+}
+
+__global__ void clusterEntryOffKernel(const uint32_t num_clusters, const uint64_t * __restrict__ cluster_row_off,
+                                      const uint64_t * __restrict__ row_ent_off, uint64_t * __restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k <= num_clusters) out[k] = row_ent_off[cluster_row_off[k]];
+}
+
 struct MaxOp {
     __device__ uint32_t operator()(const uint32_t a, const uint32_t b) const { return a > b ? a : b; }
 };
@@ -671,113 +719,153 @@ inline dim3 gridFor(const uint64_t n, const uint32_t block) { return dim3(static
 
 }  // namespace
 
-extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_alignment_batch * in, const rpvg_row_params * prm,
-                                        int32_t merge, rpvg_hip_read_rows ** rows_out) {
-    RPVG_REQUIRE(ctx && in && prm && rows_out, "rpvg_hip_read_rows_build: NULL argument");
-    *rows_out = nullptr;
+extern "C" int rpvg_hip_alignments_upload(rpvg_hip_ctx * ctx, const rpvg_alignment_batch * in, rpvg_hip_alignments ** out_handle) {
+    RPVG_REQUIRE(ctx && in && out_handle, "rpvg_hip_alignments_upload: NULL argument");
+    *out_handle = nullptr;
     const uint32_t K = in->num_clusters;
-    RPVG_REQUIRE(in->cluster_read_off && in->cluster_path_off, "rpvg_hip_read_rows_build: NULL cluster offsets");
+    RPVG_REQUIRE(in->cluster_read_off && in->cluster_path_off, "rpvg_hip_alignments_upload: NULL cluster offsets");
     const uint64_t N = in->cluster_read_off[K], P = in->cluster_path_off[K];
-    RPVG_REQUIRE(N < 0xffffffffull, "rpvg_hip_read_rows_build: %llu reads exceed one call", static_cast<unsigned long long>(N));
+    RPVG_REQUIRE(N < 0xffffffffull, "rpvg_hip_alignments_upload: %llu reads exceed one call", static_cast<unsigned long long>(N));
     RPVG_REQUIRE(N == 0 || (in->read_count && in->read_min_mapq && in->read_noise_score && in->read_align_off),
-                 "rpvg_hip_read_rows_build: NULL read arrays");
-    RPVG_REQUIRE(P == 0 || in->path_effective_length, "rpvg_hip_read_rows_build: NULL path_effective_length");
-    RPVG_REQUIRE(prm->is_single_end || prm->frag_length_log_prob, "rpvg_hip_read_rows_build: paired-end rows need frag_length_log_prob");
-    RPVG_REQUIRE(prm->prob_precision > 0 && prm->min_noise_prob >= 0 && prm->min_noise_prob <= 1,
-                 "rpvg_hip_read_rows_build: prob_precision / min_noise_prob out of range");
+                 "rpvg_hip_alignments_upload: NULL read arrays");
+    RPVG_REQUIRE(P == 0 || in->path_effective_length, "rpvg_hip_alignments_upload: NULL path_effective_length");
     const bool collapse = in->path_group != nullptr;
     RPVG_REQUIRE(!collapse || (in->cluster_group_off && in->path_source_count),
-                 "rpvg_hip_read_rows_build: collapsing needs cluster_group_off and path_source_count");
+                 "rpvg_hip_alignments_upload: collapsing needs cluster_group_off and path_source_count");
     const uint64_t A = N ? in->read_align_off[N] : 0;
     RPVG_REQUIRE(A == 0 || (in->align_score_sum && in->align_length && in->align_frag_length && in->align_path_off),
-                 "rpvg_hip_read_rows_build: NULL alignment arrays");
+                 "rpvg_hip_alignments_upload: NULL alignment arrays");
     const uint64_t E = A ? in->align_path_off[A] : 0;
-    RPVG_REQUIRE(E == 0 || in->align_path_idx, "rpvg_hip_read_rows_build: NULL align_path_idx");
+    RPVG_REQUIRE(E == 0 || in->align_path_idx, "rpvg_hip_alignments_upload: NULL align_path_idx");
+    RPVG_REQUIRE(E < 0xffffffffull, "rpvg_hip_alignments_upload: %llu path entries exceed one call", static_cast<unsigned long long>(E));
 
     // validation of the invariants the kernels rely on (O(input), as rpvg_hip_batch_upload does)
     std::vector<uint32_t> read_cluster(N);
-    for (uint32_t k = 0; k < K; ++k) {
-        RPVG_REQUIRE(in->cluster_read_off[k] <= in->cluster_read_off[k + 1] && in->cluster_path_off[k] <= in->cluster_path_off[k + 1],
-                     "rpvg_hip_read_rows_build: cluster %u has descending offsets", k);
+    int bad = 0;
+    for (uint32_t k = 0; k < K && !bad; ++k) {
+        int why = 0;
+        if (in->cluster_read_off[k] > in->cluster_read_off[k + 1] || in->cluster_path_off[k] > in->cluster_path_off[k + 1]) why = 1;
         const uint64_t np = in->cluster_path_off[k + 1] - in->cluster_path_off[k];
         const uint64_t ng = collapse ? in->cluster_group_off[k + 1] - in->cluster_group_off[k] : 0;
-        for (uint64_t p = in->cluster_path_off[k]; collapse && p < in->cluster_path_off[k + 1]; ++p) {
-            RPVG_REQUIRE(in->path_group[p] < ng, "rpvg_hip_read_rows_build: path %llu has group %u of %llu",
-                         static_cast<unsigned long long>(p), in->path_group[p], static_cast<unsigned long long>(ng));
-            RPVG_REQUIRE(in->path_source_count[p] > 0, "rpvg_hip_read_rows_build: path %llu has source count 0",
-                         static_cast<unsigned long long>(p));
+        for (uint64_t p = in->cluster_path_off[k]; !why && collapse && p < in->cluster_path_off[k + 1]; ++p) {
+            if (in->path_group[p] >= ng || in->path_source_count[p] == 0) why = 2;
         }
-        for (uint64_t r = in->cluster_read_off[k]; r < in->cluster_read_off[k + 1]; ++r) {
+        for (uint64_t r = in->cluster_read_off[k]; !why && r < in->cluster_read_off[k + 1]; ++r) {
             read_cluster[r] = k;
-            RPVG_REQUIRE(in->read_align_off[r] < in->read_align_off[r + 1], "rpvg_hip_read_rows_build: read %llu has no alignment",
-                         static_cast<unsigned long long>(r));
-            RPVG_REQUIRE(in->read_noise_score[r] <= 0, "rpvg_hip_read_rows_build: read %llu has a positive noise score",
-                         static_cast<unsigned long long>(r));
-            for (uint64_t a = in->read_align_off[r]; a < in->read_align_off[r + 1]; ++a) {
-                RPVG_REQUIRE(in->align_path_off[a] < in->align_path_off[a + 1] && in->align_length[a] > 0,
-                             "rpvg_hip_read_rows_build: alignment %llu has no path or zero length", static_cast<unsigned long long>(a));
-                for (uint64_t e = in->align_path_off[a]; e < in->align_path_off[a + 1]; ++e) {
-                    RPVG_REQUIRE(in->align_path_idx[e] < np && (e == in->align_path_off[a] || in->align_path_idx[e - 1] < in->align_path_idx[e]),
-                                 "rpvg_hip_read_rows_build: alignment %llu: path indices must be ascending and < %llu",
-                                 static_cast<unsigned long long>(a), static_cast<unsigned long long>(np));
+            if (in->read_align_off[r] >= in->read_align_off[r + 1]) why = 3;
+            if (in->read_noise_score[r] > 0) why = 4;
+            for (uint64_t a = in->read_align_off[r]; !why && a < in->read_align_off[r + 1]; ++a) {
+                if (in->align_path_off[a] >= in->align_path_off[a + 1] || in->align_length[a] == 0) why = 5;
+                for (uint64_t e = in->align_path_off[a]; !why && e < in->align_path_off[a + 1]; ++e) {
+                    if (in->align_path_idx[e] >= np || (e > in->align_path_off[a] && in->align_path_idx[e - 1] >= in->align_path_idx[e])) why = 6;
                 }
             }
         }
+        if (why) bad = why;
     }
+    static const char * const reasons[] = {"", "descending cluster offsets", "a path group outside its cluster or a zero source count",
+                                           "a read without alignments", "a read with a positive noise score",
+                                           "an alignment without paths or with zero length",
+                                           "path indices of an alignment must be ascending and inside the cluster"};
+    RPVG_REQUIRE(bad == 0, "rpvg_hip_alignments_upload: %s", reasons[bad]);
+
+    std::unique_ptr<rpvg_hip_alignments> al(new (std::nothrow) rpvg_hip_alignments());
+    if (!al) {
+        setError("rpvg_hip_alignments_upload: out of host memory");
+        return RPVG_HIP_ERR_ALLOC;
+    }
+    al->num_clusters = K;
+    al->num_reads = N;
+    al->num_aligns = A;
+    al->num_entries = E;
+    al->num_paths = P;
+    al->collapse = collapse;
+    al->h_cluster_read_off.assign(in->cluster_read_off, in->cluster_read_off + K + 1);
+    al->h_out_path_off.assign(K + 1, 0);
+    for (uint32_t k = 0; k < K; ++k) {
+        al->h_out_path_off[k + 1] = al->h_out_path_off[k] + (collapse ? in->cluster_group_off[k + 1] - in->cluster_group_off[k]
+                                                                      : in->cluster_path_off[k + 1] - in->cluster_path_off[k]);
+    }
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int span = ctx->spanBegin(FAM_H2D);
+    RPVG_HIP_CHECK(al->cluster_path_off.upload(in->cluster_path_off, K + 1, st));
+    RPVG_HIP_CHECK(al->cluster_read_off.upload(in->cluster_read_off, K + 1, st));
+    RPVG_HIP_CHECK(al->eff_len.upload(in->path_effective_length, P, st));
+    if (collapse) {
+        RPVG_HIP_CHECK(al->source_count.upload(in->path_source_count, P, st));
+        RPVG_HIP_CHECK(al->path_group.upload(in->path_group, P, st));
+    }
+    if (N) {
+        RPVG_HIP_CHECK(al->read_cluster.upload(read_cluster.data(), N, st));
+        RPVG_HIP_CHECK(al->read_count.upload(in->read_count, N, st));
+        RPVG_HIP_CHECK(al->mapq.upload(in->read_min_mapq, N, st));
+        RPVG_HIP_CHECK(al->noise_score.upload(in->read_noise_score, N, st));
+        RPVG_HIP_CHECK(al->read_align_off.upload(in->read_align_off, N + 1, st));
+        RPVG_HIP_CHECK(al->score.upload(in->align_score_sum, A, st));
+        RPVG_HIP_CHECK(al->align_length.upload(in->align_length, A, st));
+        RPVG_HIP_CHECK(al->frag_length.upload(in->align_frag_length, A, st));
+        RPVG_HIP_CHECK(al->align_path_off.upload(in->align_path_off, A + 1, st));
+        RPVG_HIP_CHECK(al->path_idx.upload(in->align_path_idx, E, st));
+    }
+    ctx->spanEnd(span);
+    ctx->stats.h2d_bytes += static_cast<double>(N) * 21 + static_cast<double>(A) * 16 + static_cast<double>(E) * 4 + static_cast<double>(P) * 8;
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));  // read_cluster leaves scope
+    *out_handle = al.release();
+    return RPVG_HIP_OK;
+}
+
+extern "C" void rpvg_hip_alignments_free(rpvg_hip_ctx * ctx, rpvg_hip_alignments * alignments) {
+    if (!alignments) return;
+    if (ctx) {
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        (void) hipSetDevice(ctx->device);
+        (void) hipStreamSynchronize(ctx->stream);
+    }
+    delete alignments;
+}
+
+extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_hip_alignments * al, const rpvg_row_params * prm,
+                                        int32_t merge, rpvg_hip_read_rows ** rows_out) {
+    RPVG_REQUIRE(ctx && al && prm && rows_out, "rpvg_hip_read_rows_build: NULL argument");
+    *rows_out = nullptr;
+    RPVG_REQUIRE(prm->is_single_end || prm->frag_length_log_prob, "rpvg_hip_read_rows_build: paired-end rows need frag_length_log_prob");
+    RPVG_REQUIRE(prm->prob_precision > 0 && prm->min_noise_prob >= 0 && prm->min_noise_prob <= 1,
+                 "rpvg_hip_read_rows_build: prob_precision / min_noise_prob out of range");
+    const uint32_t K = al->num_clusters;
+    const uint64_t N = al->num_reads, A = al->num_aligns, E = al->num_entries;
+    const bool collapse = al->collapse;
 
     std::unique_ptr<rpvg_hip_read_rows> out(new (std::nothrow) rpvg_hip_read_rows());
     if (!out) {
         setError("rpvg_hip_read_rows_build: out of host memory");
         return RPVG_HIP_ERR_ALLOC;
     }
-    out->cluster_path_off.assign(K + 1, 0);
-    for (uint32_t k = 0; k < K; ++k) {
-        out->cluster_path_off[k + 1] = out->cluster_path_off[k] + (collapse ? in->cluster_group_off[k + 1] - in->cluster_group_off[k]
-                                                                            : in->cluster_path_off[k + 1] - in->cluster_path_off[k]);
-    }
+    out->num_clusters = K;
+    out->h_cluster_path_off = al->h_out_path_off;
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
     if (N == 0) {
-        out->cluster_row_off.assign(K + 1, 0);
-        out->row_grp_off.assign(1, 0);
-        out->grp_idx_off.assign(1, 0);
+        out->h_cluster_row_off.assign(K + 1, 0);
+        RPVG_HIP_CHECK(out->cluster_row_off.upload(out->h_cluster_row_off.data(), K + 1, st));
+        const uint64_t zero = 0;
+        RPVG_HIP_CHECK(out->row_grp_off.upload(&zero, 1, st));
+        RPVG_HIP_CHECK(out->grp_idx_off.upload(&zero, 1, st));
+        RPVG_HIP_CHECK(hipStreamSynchronize(st));
         *rows_out = out.release();
         return RPVG_HIP_OK;
     }
 
     std::vector<double> phred(256);
     for (int q = 0; q < 256; ++q) phred[q] = std::pow(10, -static_cast<double>(q) / 10);  // Utils::phred_to_prob, src/utils.hpp:131-133
-
-    std::lock_guard<std::mutex> lock(ctx->mutex);
-    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-
-    // ---- upload --------------------------------------------------------------------------------------------
-    DeviceBuffer<uint32_t> d_read_cluster, d_read_count, d_source_count, d_path_group, d_path_idx;
-    DeviceBuffer<uint64_t> d_cluster_path_off, d_cluster_read_off, d_read_align_off, d_align_path_off;
-    DeviceBuffer<double> d_eff_len, d_frag, d_phred;
-    DeviceBuffer<uint8_t> d_mapq;
-    DeviceBuffer<int32_t> d_noise_score, d_score;
-    DeviceBuffer<uint16_t> d_align_length, d_frag_length;
-    int span = ctx->spanBegin(FAM_H2D);
-    RPVG_HIP_CHECK(d_read_cluster.upload(read_cluster.data(), N, st));
-    RPVG_HIP_CHECK(d_read_count.upload(in->read_count, N, st));
-    RPVG_HIP_CHECK(d_cluster_path_off.upload(in->cluster_path_off, K + 1, st));
-    RPVG_HIP_CHECK(d_cluster_read_off.upload(in->cluster_read_off, K + 1, st));
-    RPVG_HIP_CHECK(d_eff_len.upload(in->path_effective_length, P, st));
-    if (collapse) {
-        RPVG_HIP_CHECK(d_source_count.upload(in->path_source_count, P, st));
-        RPVG_HIP_CHECK(d_path_group.upload(in->path_group, P, st));
-    }
-    RPVG_HIP_CHECK(d_mapq.upload(in->read_min_mapq, N, st));
-    RPVG_HIP_CHECK(d_noise_score.upload(in->read_noise_score, N, st));
-    RPVG_HIP_CHECK(d_read_align_off.upload(in->read_align_off, N + 1, st));
-    RPVG_HIP_CHECK(d_score.upload(in->align_score_sum, A, st));
-    RPVG_HIP_CHECK(d_align_length.upload(in->align_length, A, st));
-    RPVG_HIP_CHECK(d_frag_length.upload(in->align_frag_length, A, st));
-    RPVG_HIP_CHECK(d_align_path_off.upload(in->align_path_off, A + 1, st));
-    RPVG_HIP_CHECK(d_path_idx.upload(in->align_path_idx, E, st));
+    DeviceBuffer<double> d_frag, d_phred;
     if (!prm->is_single_end) RPVG_HIP_CHECK(d_frag.upload(prm->frag_length_log_prob, RPVG_FRAG_LENGTH_TABLE_SIZE, st));
     RPVG_HIP_CHECK(d_phred.upload(phred.data(), 256, st));
-    ctx->spanEnd(span);
 
     // ---- scratch -------------------------------------------------------------------------------------------
     DeviceBuffer<double> s_alp, s_unit_val, s_tmp_val, s_bucket_mean, s_row_noise, s_grp_prob;
@@ -807,19 +895,19 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_alignment
 
     RowsIn rin;
     rin.num_reads = N;
-    rin.read_cluster = d_read_cluster.ptr;
-    rin.cluster_path_off = d_cluster_path_off.ptr;
-    rin.path_eff_len = d_eff_len.ptr;
-    rin.path_source_count = d_source_count.ptr;
-    rin.path_group = collapse ? d_path_group.ptr : nullptr;
-    rin.read_min_mapq = d_mapq.ptr;
-    rin.read_noise_score = d_noise_score.ptr;
-    rin.read_align_off = d_read_align_off.ptr;
-    rin.align_score_sum = d_score.ptr;
-    rin.align_length = d_align_length.ptr;
-    rin.align_frag_length = d_frag_length.ptr;
-    rin.align_path_off = d_align_path_off.ptr;
-    rin.align_path_idx = d_path_idx.ptr;
+    rin.read_cluster = al->read_cluster.ptr;
+    rin.cluster_path_off = al->cluster_path_off.ptr;
+    rin.path_eff_len = al->eff_len.ptr;
+    rin.path_source_count = al->source_count.ptr;
+    rin.path_group = collapse ? al->path_group.ptr : nullptr;
+    rin.read_min_mapq = al->mapq.ptr;
+    rin.read_noise_score = al->noise_score.ptr;
+    rin.read_align_off = al->read_align_off.ptr;
+    rin.align_score_sum = al->score.ptr;
+    rin.align_length = al->align_length.ptr;
+    rin.align_frag_length = al->frag_length.ptr;
+    rin.align_path_off = al->align_path_off.ptr;
+    rin.align_path_idx = al->path_idx.ptr;
     rin.frag_table = prm->is_single_end ? nullptr : d_frag.ptr;
     rin.phred_prob = d_phred.ptr;
     rin.prob_precision = prm->prob_precision;
@@ -852,8 +940,8 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_alignment
     RPVG_HIP_CHECK(hipEventCreate(&ev1));
     RPVG_HIP_CHECK(hipEventCreate(&ev2));
     RPVG_HIP_CHECK(hipEventRecord(ev0, st));
-    span = ctx->spanBegin(FAM_BUILD);
-    alignLogProbKernel<<<gridFor(A, 256), dim3(256), 0, st>>>(A, d_score.ptr, d_frag_length.ptr, rin.frag_table, s_alp.ptr);
+    int span = ctx->spanBegin(FAM_BUILD);
+    alignLogProbKernel<<<gridFor(A, 256), dim3(256), 0, st>>>(A, al->score.ptr, al->frag_length.ptr, rin.frag_table, s_alp.ptr);
     readRowKernel<<<gridFor(N, kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, st>>>(rin, sc);
     ctx->spanEnd(span);
     ctx->stats.build_launches += 2;
@@ -862,17 +950,15 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_alignment
 
     // rows to pack: all reads, or the heads of the merged runs
     uint64_t num_out = N;
-    DeviceBuffer<uint32_t> d_source, d_out_count;
-    DeviceBuffer<uint64_t> d_out_cluster_row_off;
+    DeviceBuffer<uint32_t> d_source;
     const uint32_t * pack_source = nullptr;
-    const uint32_t * pack_count = d_read_count.ptr;
 
     if (merge) {
         RowView view;
-        view.read_cluster = d_read_cluster.ptr;
-        view.read_count = d_read_count.ptr;
-        view.read_align_off = d_read_align_off.ptr;
-        view.align_path_off = d_align_path_off.ptr;
+        view.read_cluster = al->read_cluster.ptr;
+        view.read_count = al->read_count.ptr;
+        view.read_align_off = al->read_align_off.ptr;
+        view.align_path_off = al->align_path_off.ptr;
         view.sc = sc;
         view.prob_precision = prm->prob_precision;
         const RowLess less{view};
@@ -891,7 +977,7 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_alignment
         std::vector<uint64_t> big_pair_off(1, 0);
         uint32_t max_padded = 0;
         for (uint32_t k = 0; k < K; ++k) {
-            const uint64_t n = in->cluster_read_off[k + 1] - in->cluster_read_off[k];
+            const uint64_t n = al->h_cluster_read_off[k + 1] - al->h_cluster_read_off[k];
             if (n < 2) continue;
             if (n <= kSmallSort) {
                 small_clusters.push_back(k);
@@ -910,7 +996,7 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_alignment
         if (!small_clusters.empty()) {
             RPVG_HIP_CHECK(d_small.upload(small_clusters.data(), small_clusters.size(), st));
             sortSmallClustersKernel<<<dim3(static_cast<uint32_t>(small_clusters.size())), dim3(256), 0, st>>>(
-                static_cast<uint32_t>(small_clusters.size()), d_small.ptr, d_cluster_read_off.ptr, less, d_sorted.ptr);
+                static_cast<uint32_t>(small_clusters.size()), d_small.ptr, al->cluster_read_off.ptr, less, d_sorted.ptr);
         }
         if (!big_clusters.empty()) {
             RPVG_HIP_CHECK(d_big.upload(big_clusters.data(), big_clusters.size(), st));
@@ -920,7 +1006,7 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_alignment
             for (uint32_t k = 2; k <= max_padded; k <<= 1) {
                 for (uint32_t j = k >> 1; j > 0; j >>= 1) {
                     bitonicStepBigKernel<<<gridFor(big_pair_off.back(), 256), dim3(256), 0, st>>>(
-                        num_big, d_big.ptr, d_big_pair_off.ptr, d_big_padded.ptr, d_cluster_read_off.ptr, less, k, j, d_sorted.ptr);
+                        num_big, d_big.ptr, d_big_pair_off.ptr, d_big_padded.ptr, al->cluster_read_off.ptr, less, k, j, d_sorted.ptr);
                 }
             }
         }
@@ -943,7 +1029,7 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_alignment
         RPVG_HIP_CHECK(hipMemcpyAsync(&any, d_any.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         RPVG_HIP_CHECK(hipStreamSynchronize(st));
         if (any) {
-            walkClustersKernel<<<gridFor(K, 64), dim3(64), 0, st>>>(K, d_cluster_read_off.ptr, view, d_sorted.ptr, d_walk.ptr, d_head.ptr);
+            walkClustersKernel<<<gridFor(K, 64), dim3(64), 0, st>>>(K, al->cluster_read_off.ptr, view, d_sorted.ptr, d_walk.ptr, d_head.ptr);
         }
         {
             size_t bytes = 0;
@@ -958,70 +1044,57 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_alignment
         RPVG_HIP_CHECK(hipStreamSynchronize(st));
         num_out = num_runs;
         RPVG_HIP_CHECK(d_source.alloc(num_out));
-        RPVG_HIP_CHECK(d_out_count.alloc(num_out));
-        RPVG_HIP_CHECK(d_out_cluster_row_off.alloc(K + 1));
-        RPVG_HIP_CHECK(hipMemsetAsync(d_out_count.ptr, 0, sizeof(uint32_t) * num_out, st));
+        RPVG_HIP_CHECK(out->row_count.alloc(num_out));
+        RPVG_HIP_CHECK(out->cluster_row_off.alloc(K + 1));
+        RPVG_HIP_CHECK(hipMemsetAsync(out->row_count.ptr, 0, sizeof(uint32_t) * num_out, st));
         mergeRunsKernel<<<gridFor(N, 256), dim3(256), 0, st>>>(N, view, d_sorted.ptr, d_head.ptr, d_run_incl.ptr, d_source.ptr,
-                                                             d_out_count.ptr);
-        clusterRowOffKernel<<<gridFor(K + 1, 256), dim3(256), 0, st>>>(K, N, num_out, d_cluster_read_off.ptr, d_run_incl.ptr,
-                                                                     d_out_cluster_row_off.ptr);
+                                                             out->row_count.ptr);
+        clusterRowOffKernel<<<gridFor(K + 1, 256), dim3(256), 0, st>>>(K, N, num_out, al->cluster_read_off.ptr, d_run_incl.ptr,
+                                                                     out->cluster_row_off.ptr);
         RPVG_HIP_CHECK(hipGetLastError());
+        out->h_cluster_row_off.resize(K + 1);
+        RPVG_HIP_CHECK(hipMemcpyAsync(out->h_cluster_row_off.data(), out->cluster_row_off.ptr, sizeof(uint64_t) * (K + 1), hipMemcpyDeviceToHost, st));
         RPVG_HIP_CHECK(hipStreamSynchronize(st));  // the sort / scan buffers above go out of scope here
         pack_source = d_source.ptr;
-        pack_count = d_out_count.ptr;
+    } else {
+        RPVG_HIP_CHECK(out->row_count.alloc(N));
+        RPVG_HIP_CHECK(hipMemcpyAsync(out->row_count.ptr, al->read_count.ptr, sizeof(uint32_t) * N, hipMemcpyDeviceToDevice, st));
+        out->h_cluster_row_off = al->h_cluster_read_off;
+        RPVG_HIP_CHECK(out->cluster_row_off.upload(out->h_cluster_row_off.data(), K + 1, st));
     }
 
     // ---- pack ----------------------------------------------------------------------------------------------
-    DeviceBuffer<uint64_t> d_ng64, d_nm64, d_row_grp_off, d_row_member_off;
+    DeviceBuffer<uint64_t> d_ng64, d_nm64, d_row_member_off;
     RPVG_HIP_CHECK(d_ng64.alloc(num_out + 1));
     RPVG_HIP_CHECK(d_nm64.alloc(num_out + 1));
-    RPVG_HIP_CHECK(d_row_grp_off.alloc(num_out + 1));
+    RPVG_HIP_CHECK(out->row_grp_off.alloc(num_out + 1));
     RPVG_HIP_CHECK(d_row_member_off.alloc(num_out + 1));
     RPVG_HIP_CHECK(hipMemsetAsync(d_ng64.ptr, 0, sizeof(uint64_t) * (num_out + 1), st));
     RPVG_HIP_CHECK(hipMemsetAsync(d_nm64.ptr, 0, sizeof(uint64_t) * (num_out + 1), st));
     gatherSizesKernel<<<gridFor(num_out, 256), dim3(256), 0, st>>>(num_out, pack_source, s_ngroups.ptr, s_nmembers.ptr, d_ng64.ptr,
                                                                  d_nm64.ptr);
-    RPVG_HIP_CHECK(exclusiveSum(d_ng64.ptr, d_row_grp_off.ptr, num_out + 1, st));
+    RPVG_HIP_CHECK(exclusiveSum(d_ng64.ptr, out->row_grp_off.ptr, num_out + 1, st));
     RPVG_HIP_CHECK(exclusiveSum(d_nm64.ptr, d_row_member_off.ptr, num_out + 1, st));
-    out->row_grp_off.resize(num_out + 1);
-    std::vector<uint64_t> row_member_off(num_out + 1);
-    RPVG_HIP_CHECK(hipMemcpyAsync(out->row_grp_off.data(), d_row_grp_off.ptr, sizeof(uint64_t) * (num_out + 1), hipMemcpyDeviceToHost, st));
-    RPVG_HIP_CHECK(hipMemcpyAsync(row_member_off.data(), d_row_member_off.ptr, sizeof(uint64_t) * (num_out + 1), hipMemcpyDeviceToHost, st));
+    uint64_t totals[2] = {0, 0};
+    RPVG_HIP_CHECK(hipMemcpyAsync(&totals[0], out->row_grp_off.ptr + num_out, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    RPVG_HIP_CHECK(hipMemcpyAsync(&totals[1], d_row_member_off.ptr + num_out, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     RPVG_HIP_CHECK(hipStreamSynchronize(st));
-    const uint64_t G = out->row_grp_off[num_out], M = row_member_off[num_out];
+    const uint64_t G = totals[0], M = totals[1];
 
-    DeviceBuffer<double> d_out_noise, d_out_prob;
-    DeviceBuffer<uint64_t> d_out_idx_off;
-    DeviceBuffer<uint32_t> d_out_path;
-    RPVG_HIP_CHECK(d_out_noise.alloc(num_out));
-    RPVG_HIP_CHECK(d_out_prob.alloc(G + 1));
-    RPVG_HIP_CHECK(d_out_idx_off.alloc(G + 1));
-    RPVG_HIP_CHECK(d_out_path.alloc(M + 1));
-    RPVG_HIP_CHECK(hipMemsetAsync(d_out_idx_off.ptr + G, 0, sizeof(uint64_t), st));  // G == 0: the terminator is written here only
-    packRowsKernel<<<gridFor(num_out * 64, 256), dim3(256), 0, st>>>(num_out, pack_source, d_read_align_off.ptr, d_align_path_off.ptr,
-                                                                    sc, d_row_grp_off.ptr, d_row_member_off.ptr, d_out_noise.ptr,
-                                                                    d_out_prob.ptr, d_out_idx_off.ptr, d_out_path.ptr);
+    RPVG_HIP_CHECK(out->row_noise.alloc(num_out));
+    RPVG_HIP_CHECK(out->grp_prob.alloc(G + 1));
+    RPVG_HIP_CHECK(out->grp_idx_off.alloc(G + 1));
+    RPVG_HIP_CHECK(out->path_idx.alloc(M + 1));
+    RPVG_HIP_CHECK(hipMemsetAsync(out->grp_idx_off.ptr + G, 0, sizeof(uint64_t), st));  // G == 0: the terminator is written here only
+    packRowsKernel<<<gridFor(num_out * 64, 256), dim3(256), 0, st>>>(num_out, pack_source, al->read_align_off.ptr, al->align_path_off.ptr,
+                                                                    sc, out->row_grp_off.ptr, d_row_member_off.ptr, out->row_noise.ptr,
+                                                                    out->grp_prob.ptr, out->grp_idx_off.ptr, out->path_idx.ptr);
     RPVG_HIP_CHECK(hipGetLastError());
     RPVG_HIP_CHECK(hipEventRecord(ev2, st));
-
-    out->row_count.resize(num_out);
-    out->row_noise.resize(num_out);
-    out->grp_prob.resize(G);
-    out->grp_idx_off.resize(G + 1);
-    out->path_idx.resize(M);
-    RPVG_HIP_CHECK(hipMemcpyAsync(out->row_count.data(), pack_count, sizeof(uint32_t) * num_out, hipMemcpyDeviceToHost, st));
-    RPVG_HIP_CHECK(hipMemcpyAsync(out->row_noise.data(), d_out_noise.ptr, sizeof(double) * num_out, hipMemcpyDeviceToHost, st));
-    if (G) RPVG_HIP_CHECK(hipMemcpyAsync(out->grp_prob.data(), d_out_prob.ptr, sizeof(double) * G, hipMemcpyDeviceToHost, st));
-    RPVG_HIP_CHECK(hipMemcpyAsync(out->grp_idx_off.data(), d_out_idx_off.ptr, sizeof(uint64_t) * (G + 1), hipMemcpyDeviceToHost, st));
-    if (M) RPVG_HIP_CHECK(hipMemcpyAsync(out->path_idx.data(), d_out_path.ptr, sizeof(uint32_t) * M, hipMemcpyDeviceToHost, st));
-    out->cluster_row_off.resize(K + 1);
-    if (merge) {
-        RPVG_HIP_CHECK(hipMemcpyAsync(out->cluster_row_off.data(), d_out_cluster_row_off.ptr, sizeof(uint64_t) * (K + 1), hipMemcpyDeviceToHost, st));
-    } else {
-        std::copy(in->cluster_read_off, in->cluster_read_off + K + 1, out->cluster_row_off.begin());
-    }
-    RPVG_HIP_CHECK(hipStreamSynchronize(st));
-    if (G == 0) out->grp_idx_off[0] = 0;
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));  // the scratch slices go out of scope
+    out->num_rows = num_out;
+    out->num_groups = G;
+    out->num_members = M;
     float ms01 = 0, ms12 = 0;
     (void) hipEventElapsedTime(&ms01, ev0, ev1);
     (void) hipEventElapsedTime(&ms12, ev1, ev2);
@@ -1034,22 +1107,107 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_alignment
     return RPVG_HIP_OK;
 }
 
-extern "C" int rpvg_hip_read_rows_view(const rpvg_hip_read_rows * rows, rpvg_cluster_batch * view, double * build_ms,
+extern "C" int rpvg_hip_read_rows_view(rpvg_hip_ctx * ctx, rpvg_hip_read_rows * rows, rpvg_cluster_batch * view, double * build_ms,
                                        double * merge_ms) {
-    RPVG_REQUIRE(rows && view, "rpvg_hip_read_rows_view: NULL argument");
+    RPVG_REQUIRE(ctx && rows && view, "rpvg_hip_read_rows_view: NULL argument");
+    if (!rows->downloaded) {
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const uint64_t R = rows->num_rows, G = rows->num_groups, M = rows->num_members;
+        rows->h_row_count.resize(R);
+        rows->h_row_noise.resize(R);
+        rows->h_row_grp_off.assign(R + 1, 0);
+        rows->h_grp_prob.resize(G);
+        rows->h_grp_idx_off.assign(G + 1, 0);
+        rows->h_path_idx.resize(M);
+        if (R) {
+            RPVG_HIP_CHECK(hipMemcpyAsync(rows->h_row_count.data(), rows->row_count.ptr, sizeof(uint32_t) * R, hipMemcpyDeviceToHost, st));
+            RPVG_HIP_CHECK(hipMemcpyAsync(rows->h_row_noise.data(), rows->row_noise.ptr, sizeof(double) * R, hipMemcpyDeviceToHost, st));
+            RPVG_HIP_CHECK(hipMemcpyAsync(rows->h_row_grp_off.data(), rows->row_grp_off.ptr, sizeof(uint64_t) * (R + 1), hipMemcpyDeviceToHost, st));
+            RPVG_HIP_CHECK(hipMemcpyAsync(rows->h_grp_idx_off.data(), rows->grp_idx_off.ptr, sizeof(uint64_t) * (G + 1), hipMemcpyDeviceToHost, st));
+        }
+        if (G) RPVG_HIP_CHECK(hipMemcpyAsync(rows->h_grp_prob.data(), rows->grp_prob.ptr, sizeof(double) * G, hipMemcpyDeviceToHost, st));
+        if (M) RPVG_HIP_CHECK(hipMemcpyAsync(rows->h_path_idx.data(), rows->path_idx.ptr, sizeof(uint32_t) * M, hipMemcpyDeviceToHost, st));
+        RPVG_HIP_CHECK(hipStreamSynchronize(st));
+        rows->downloaded = true;
+    }
     std::memset(view, 0, sizeof(*view));
-    view->num_clusters = static_cast<uint32_t>(rows->cluster_row_off.size() - 1);
-    view->cluster_row_off = rows->cluster_row_off.data();
-    view->cluster_path_off = rows->cluster_path_off.data();
-    view->row_count = rows->row_count.data();
-    view->row_noise = rows->row_noise.data();
-    view->row_grp_off = rows->row_grp_off.data();
-    view->grp_prob = rows->grp_prob.data();
-    view->grp_idx_off = rows->grp_idx_off.data();
-    view->path_idx = rows->path_idx.data();
+    view->num_clusters = rows->num_clusters;
+    view->cluster_row_off = rows->h_cluster_row_off.data();
+    view->cluster_path_off = rows->h_cluster_path_off.data();
+    view->row_count = rows->h_row_count.data();
+    view->row_noise = rows->h_row_noise.data();
+    view->row_grp_off = rows->h_row_grp_off.data();
+    view->grp_prob = rows->h_grp_prob.data();
+    view->grp_idx_off = rows->h_grp_idx_off.data();
+    view->path_idx = rows->h_path_idx.data();
     if (build_ms) *build_ms = rows->build_ms;
     if (merge_ms) *merge_ms = rows->merge_ms;
     return RPVG_HIP_OK;
 }
 
-extern "C" void rpvg_hip_read_rows_free(rpvg_hip_read_rows * rows) { delete rows; }
+extern "C" int rpvg_hip_read_rows_sizes(rpvg_hip_ctx * ctx, const rpvg_hip_read_rows * rows, rpvg_cluster_batch * view) {
+    RPVG_REQUIRE(ctx && rows && view, "rpvg_hip_read_rows_sizes: NULL argument");
+    std::memset(view, 0, sizeof(*view));
+    view->num_clusters = rows->num_clusters;
+    view->cluster_row_off = rows->h_cluster_row_off.data();
+    view->cluster_path_off = rows->h_cluster_path_off.data();
+    return RPVG_HIP_OK;
+}
+
+// rows -> the device-resident batch the estimators take, without leaving the GPU
+extern "C" int rpvg_hip_read_rows_to_batch(rpvg_hip_ctx * ctx, const rpvg_hip_read_rows * rows, rpvg_hip_batch ** batch_out) {
+    RPVG_REQUIRE(ctx && rows && batch_out, "rpvg_hip_read_rows_to_batch: NULL argument");
+    *batch_out = nullptr;
+    const uint32_t K = rows->num_clusters;
+    const uint64_t R = rows->num_rows, G = rows->num_groups, M = rows->num_members;
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<rpvg_hip_batch> b(new (std::nothrow) rpvg_hip_batch());
+    if (!b) {
+        setError("rpvg_hip_read_rows_to_batch: out of host memory");
+        return RPVG_HIP_ERR_ALLOC;
+    }
+    b->num_clusters = K;
+    b->num_rows = R;
+    b->num_entries = M;
+    b->num_paths = rows->h_cluster_path_off[K];
+    b->h_cluster_row_off = rows->h_cluster_row_off;
+    b->h_cluster_path_off = rows->h_cluster_path_off;
+    b->h_cluster_ent_off.assign(K + 1, 0);
+    RPVG_HIP_CHECK(b->cluster_row_off.upload(rows->h_cluster_row_off.data(), K + 1, st));
+    RPVG_HIP_CHECK(b->cluster_path_off.upload(rows->h_cluster_path_off.data(), K + 1, st));
+    RPVG_HIP_CHECK(b->row_noise.alloc(R));
+    RPVG_HIP_CHECK(b->row_count.alloc(R));
+    RPVG_HIP_CHECK(b->row_ent_off.alloc(R + 1));
+    RPVG_HIP_CHECK(b->ent_path.alloc(M));
+    RPVG_HIP_CHECK(b->ent_prob.alloc(M));
+    DeviceBuffer<uint64_t> d_cluster_ent_off;
+    RPVG_HIP_CHECK(d_cluster_ent_off.alloc(K + 1));
+    const int span = ctx->spanBegin(FAM_BUILD);
+    if (R) RPVG_HIP_CHECK(hipMemcpyAsync(b->row_noise.ptr, rows->row_noise.ptr, sizeof(double) * R, hipMemcpyDeviceToDevice, st));
+    if (M) RPVG_HIP_CHECK(hipMemcpyAsync(b->ent_path.ptr, rows->path_idx.ptr, sizeof(uint32_t) * M, hipMemcpyDeviceToDevice, st));
+    if (G) rowsExpandGroupsKernel<<<gridFor(G, 256), dim3(256), 0, st>>>(G, rows->grp_idx_off.ptr, rows->grp_prob.ptr, b->ent_prob.ptr);
+    rowsMetaKernel<<<gridFor(R + 1, 256), dim3(256), 0, st>>>(R, rows->row_grp_off.ptr, rows->grp_idx_off.ptr, rows->row_count.ptr,
+                                                            b->row_ent_off.ptr, b->row_count.ptr);
+    clusterEntryOffKernel<<<gridFor(K + 1, 256), dim3(256), 0, st>>>(K, b->cluster_row_off.ptr, b->row_ent_off.ptr, d_cluster_ent_off.ptr);
+    ctx->spanEnd(span);
+    ctx->stats.build_launches += 3;
+    RPVG_HIP_CHECK(hipGetLastError());
+    RPVG_HIP_CHECK(hipMemcpyAsync(b->h_cluster_ent_off.data(), d_cluster_ent_off.ptr, sizeof(uint64_t) * (K + 1), hipMemcpyDeviceToHost, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    *batch_out = b.release();
+    return RPVG_HIP_OK;
+}
+
+extern "C" void rpvg_hip_read_rows_free(rpvg_hip_ctx * ctx, rpvg_hip_read_rows * rows) {
+    if (!rows) return;
+    if (ctx) {
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        (void) hipSetDevice(ctx->device);
+        (void) hipStreamSynchronize(ctx->stream);
+    }
+    delete rows;
+}

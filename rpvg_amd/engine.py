@@ -37,6 +37,10 @@ def lib() -> C.CDLL:
         L.rpvg_amd_batch_prepare.restype = C.c_void_p
         L.rpvg_amd_batch_prepare.argtypes = [C.c_void_p, C.POINTER(CClusterBatch), C.c_int]
         L.rpvg_amd_batch_free.argtypes = [C.c_void_p]
+        L.rpvg_amd_batch_prepare_from_alignments.restype = C.c_void_p
+        L.rpvg_amd_batch_prepare_from_alignments.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CClusterBatch), C.c_double, C.c_double,
+                                                             C.c_double, C.c_uint32, C.c_int, C.c_double, C.c_double,
+                                                             C.POINTER(C.c_double)]
         L.rpvg_amd_run.restype = C.c_void_p
         L.rpvg_amd_run.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double)]
         L.rpvg_amd_run_inplace.restype = C.c_int
@@ -89,6 +93,24 @@ class Engine:
 
     def prepare(self, batch: ClusterBatch, per_cluster: bool = False) -> "PreparedBatch":
         return PreparedBatch(self, batch, per_cluster)
+
+    def prepare_from_alignments(self, alignments, path_info: ClusterBatch, frag=(300.0, 50.0, 0.0, 10), is_single_end: bool = False,
+                                min_noise_prob: float = 1e-4, prob_precision: float = 1e-8) -> "PreparedBatch":
+        """Batch whose rows are constructed on the GPU from alignment-path lists (rpvg_amd/host/read_rows.hpp):
+        alignments = rows.AlignmentBatch, path_info = a ClusterBatch whose path arrays describe the clusters' paths,
+        frag = (loc, scale, shape, sd_max_multi) of the FragmentLengthDist."""
+        prep = PreparedBatch.__new__(PreparedBatch)
+        prep.engine = self
+        prep.batch = path_info
+        ca, cb = alignments.as_c(), path_info.as_c()
+        secs = C.c_double(0)
+        prep.handle = lib().rpvg_amd_batch_prepare_from_alignments(
+            self.handle, C.byref(ca), C.byref(cb), frag[0], frag[1], frag[2], int(frag[3]), 1 if is_single_end else 0,
+            min_noise_prob, prob_precision, C.byref(secs))
+        if not prep.handle:
+            raise hip.EngineError(f"batch prepare from alignments failed: {_err()}")
+        prep.row_construction_seconds = secs.value
+        return prep
 
     def run(self, model: str, params: CParams, prepared: "PreparedBatch") -> Tuple[List[ClusterEstimates], float]:
         """Estimates of every cluster + wall seconds of the estimator call (inputs already on the GPU)."""

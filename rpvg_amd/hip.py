@@ -26,7 +26,8 @@ EXPORTS = [
     "rpvg_hip_gibbs_read_counts", "rpvg_hip_min_path_cover", "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
     "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
     "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_group_conditionals",
-    "rpvg_hip_read_rows_build", "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_free",
+    "rpvg_hip_alignments_upload", "rpvg_hip_alignments_free", "rpvg_hip_read_rows_build", "rpvg_hip_read_rows_to_batch",
+    "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_sizes", "rpvg_hip_read_rows_free",
 ]
 
 COMM_ID_BYTES = 128  # RPVG_HIP_COMM_ID_BYTES
@@ -109,6 +110,69 @@ class DeviceBatch:
     def free(self):
         if self.handle:
             lib().rpvg_hip_batch_free(self.ctx.handle, self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceRows:
+    """Rows resident on the GPU (rpvg_hip_read_rows)."""
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx = ctx
+        self.handle = handle
+
+    def download(self):
+        """(ClusterBatch of the rows, build_ms, merge_ms)"""
+        from . import rows as rows_mod
+        view = CClusterBatch()
+        b_ms, m_ms = C.c_double(0), C.c_double(0)
+        _check(lib().rpvg_hip_read_rows_view(self.ctx.handle, self.handle, C.byref(view), C.byref(b_ms), C.byref(m_ms)),
+               "rpvg_hip_read_rows_view")
+        return rows_mod.rows_from_view(view), b_ms.value, m_ms.value
+
+    def to_batch_handle(self) -> C.c_void_p:
+        """rpvg_hip_batch made on the device from the rows (caller frees with rpvg_hip_batch_free)."""
+        h = C.c_void_p()
+        _check(lib().rpvg_hip_read_rows_to_batch(self.ctx.handle, self.handle, C.byref(h)), "rpvg_hip_read_rows_to_batch")
+        return h
+
+    def free(self):
+        if self.handle:
+            lib().rpvg_hip_read_rows_free(self.ctx.handle, self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceAlignments:
+    """Alignment-path lists resident on the GPU (rpvg_hip_alignments)."""
+
+    def __init__(self, ctx: "Context", host):
+        self.ctx = ctx
+        self.host = host
+        self.handle = C.c_void_p()
+        cb = host.as_c()
+        _check(lib().rpvg_hip_alignments_upload(ctx.handle, C.byref(cb), C.byref(self.handle)), "rpvg_hip_alignments_upload")
+
+    def build_rows(self, row_params, merge: bool = True) -> DeviceRows:
+        cp = row_params.as_c()
+        h = C.c_void_p()
+        _check(lib().rpvg_hip_read_rows_build(self.ctx.handle, self.handle, C.byref(cp), C.c_int32(1 if merge else 0), C.byref(h)),
+               "rpvg_hip_read_rows_build")
+        return DeviceRows(self.ctx, h)
+
+    def free(self):
+        if self.handle:
+            lib().rpvg_hip_alignments_free(self.ctx.handle, self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):
@@ -337,20 +401,22 @@ class Context:
                "rpvg_hip_synth_dense_rows")
 
     # ---- row construction (include/rpvg_rows.h) ------------------------------------
+    def upload_alignments(self, align_batch) -> "DeviceAlignments":
+        return DeviceAlignments(self, align_batch)
+
     def build_rows(self, align_batch, row_params, merge: bool = True):
-        """addPathProbs for every read (+ sort / merge) on the GPU -> (ClusterBatch of rows, build_ms, merge_ms)."""
-        from . import rows as rows_mod
-        cb, cp = align_batch.as_c(), row_params.as_c()
-        h = C.c_void_p()
-        _check(lib().rpvg_hip_read_rows_build(self.handle, C.byref(cb), C.byref(cp), C.c_int32(1 if merge else 0), C.byref(h)),
-               "rpvg_hip_read_rows_build")
+        """addPathProbs for every read (+ sort / merge) on the GPU -> (ClusterBatch of rows, build_ms, merge_ms).
+        align_batch: an AlignmentBatch (uploaded for this call) or DeviceAlignments (already resident)."""
+        dev = align_batch if isinstance(align_batch, DeviceAlignments) else DeviceAlignments(self, align_batch)
         try:
-            view = CClusterBatch()
-            b_ms, m_ms = C.c_double(0), C.c_double(0)
-            _check(lib().rpvg_hip_read_rows_view(h, C.byref(view), C.byref(b_ms), C.byref(m_ms)), "rpvg_hip_read_rows_view")
-            return rows_mod.rows_from_view(view), b_ms.value, m_ms.value
+            rows = dev.build_rows(row_params, merge)
+            try:
+                return rows.download()
+            finally:
+                rows.free()
         finally:
-            lib().rpvg_hip_read_rows_free(h)
+            if dev is not align_batch:
+                dev.free()
 
     # ---- stats ----------------------------------------------------------------
     def stats(self) -> dict:

@@ -107,6 +107,19 @@ DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, con
     }
 }
 
+DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, rpvg_hip_batch * device_batch, const rpvg_cluster_batch & offsets, const std::vector<double> & total_read_count_in) : hip_engine(engine_in), batch(device_batch), total_read_count(total_read_count_in) {
+
+    assert(hip_engine);
+    assert(batch);
+    assert(total_read_count.size() == offsets.num_clusters);
+
+    for (uint32_t i = 0; i < offsets.num_clusters; ++i) {
+
+        num_rows.emplace_back(offsets.cluster_row_off[i + 1] - offsets.cluster_row_off[i]);
+        num_paths.emplace_back(offsets.cluster_path_off[i + 1] - offsets.cluster_path_off[i]);
+    }
+}
+
 DeviceClusterBatch::~DeviceClusterBatch() {
 
     rpvg_hip_batch_free(hip_engine->ctx(), batch);

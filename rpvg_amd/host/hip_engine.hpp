@@ -74,6 +74,11 @@ class DeviceClusterBatch {
     public:
 
         DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch);
+
+        // Adopts a batch that was built on the device (row construction, read_rows.hpp).  `offsets` carries
+        // cluster_row_off / cluster_path_off only; total_read_count_in the read count of every cluster.
+        DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, rpvg_hip_batch * device_batch, const rpvg_cluster_batch & offsets, const std::vector<double> & total_read_count_in);
+
         ~DeviceClusterBatch();
 
         DeviceClusterBatch(const DeviceClusterBatch &) = delete;

@@ -3,6 +3,7 @@
 // same classes a C++ caller uses: PathEstimator::estimateBatch() (mode 0) or
 // the reference-shaped per-cluster PathEstimator::estimate() (mode 1).
 
+#include <cassert>
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -11,6 +12,7 @@
 
 #include "../../include/rpvg_batch.h"
 #include "estimator_factory.hpp"
+#include "read_rows.hpp"
 #include "trace.hpp"
 
 using namespace rpvg_amd;
@@ -204,6 +206,69 @@ void * rpvg_amd_batch_prepare(void * engine, const rpvg_cluster_batch * batch, i
         } else {
 
             prepared->device.reset(new DeviceClusterBatch(static_cast<Engine *>(engine)->hip, *batch));
+        }
+
+        return guard.release();
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return nullptr;
+    }
+}
+
+// The same, starting one step earlier: the batch's reads arrive as alignment-path lists (include/rpvg_rows.h) and
+// the rows are constructed on the GPU (read_rows.hpp); `path_info` supplies the path arrays of rpvg_cluster_batch
+// (the PathInfo of every cluster; its row arrays are ignored).  seconds_out = wall time of the row construction
+// with the alignment lists in host memory (upload included).
+void * rpvg_amd_batch_prepare_from_alignments(void * engine, const rpvg_alignment_batch * alignments, const rpvg_cluster_batch * path_info, double frag_loc, double frag_scale, double frag_shape, uint32_t frag_sd_max_multi, int is_single_end, double min_noise_prob, double prob_precision, double * seconds_out) {
+
+    try {
+
+        PreparedBatch * prepared = new PreparedBatch();
+        std::unique_ptr<PreparedBatch> guard(prepared);
+
+        prepared->paths = unpackPaths(*path_info);
+        assert(prepared->paths.size() == alignments->num_clusters);
+
+        AlignmentBatchBuilder builder;
+        const bool collapse = alignments->path_group != nullptr;
+
+        for (uint32_t i = 0; i < alignments->num_clusters; ++i) {
+
+            std::vector<uint32_t> group_name_index;
+            uint32_t num_groups = 0;
+
+            if (collapse) {
+
+                group_name_index.assign(alignments->path_group + alignments->cluster_path_off[i], alignments->path_group + alignments->cluster_path_off[i + 1]);
+                num_groups = alignments->cluster_group_off[i + 1] - alignments->cluster_group_off[i];
+            }
+
+            builder.beginCluster(prepared->paths.at(i), group_name_index, num_groups);
+
+            for (uint64_t r = alignments->cluster_read_off[i]; r < alignments->cluster_read_off[i + 1]; ++r) {
+
+                std::vector<AlignmentPath> align_paths;
+
+                for (uint64_t a = alignments->read_align_off[r]; a < alignments->read_align_off[r + 1]; ++a) {
+
+                    align_paths.emplace_back(alignments->read_min_mapq[r], alignments->align_score_sum[a], alignments->align_length[a], alignments->align_frag_length[a], std::vector<uint32_t>(alignments->align_path_idx + alignments->align_path_off[a], alignments->align_path_idx + alignments->align_path_off[a + 1]));
+                }
+
+                align_paths.emplace_back(alignments->read_min_mapq[r], alignments->read_noise_score[r], 0, 0, std::vector<uint32_t>());
+                builder.addAlignmentPaths(align_paths, alignments->read_count[r]);
+            }
+        }
+
+        const FragmentLengthDist fragment_length_dist = is_single_end ? FragmentLengthDist() : FragmentLengthDist(frag_loc, frag_scale, frag_shape, frag_sd_max_multi);
+
+        const auto start = std::chrono::steady_clock::now();
+        prepared->device = constructReadPathProbabilities(static_cast<Engine *>(engine)->hip, builder, fragment_length_dist, is_single_end != 0, min_noise_prob, prob_precision);
+
+        if (seconds_out) {
+
+            *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
         }
 
         return guard.release();

@@ -38,6 +38,8 @@
 #include "read_path_probabilities.hpp"
 #include "flat_batch.hpp"
 
+#include "../../include/rpvg_rows.h"
+
 using namespace rpvg_amd;
 
 extern "C" {
@@ -53,6 +55,7 @@ typedef struct rpvg_synth_config {
     double read_mass_sigma;       /* 1.5  log-normal sigma of reads per cluster */
     double tie_prob;              /* 0.3 */
     double pathless_read_frac;    /* 0.005 reads without any compatible path (noise = 1) */
+    uint32_t keep_alignments;     /* 0; 1 = also keep the reads as alignment-path lists (include/rpvg_rows.h) */
 } rpvg_synth_config;
 
 }
@@ -129,12 +132,29 @@ struct Rng {
     }
 };
 
+// The distinct reads of a cluster as the alignment-path lists row construction starts from (include/rpvg_rows.h):
+// one alignment per distinct score deficit of the read, holding the paths with that deficit.
+struct SynthAlignments {
+
+    std::vector<uint32_t> read_count;
+    std::vector<uint8_t> read_min_mapq;
+    std::vector<uint64_t> read_align_off = std::vector<uint64_t>(1, 0);
+    std::vector<int32_t> align_score_sum;
+    std::vector<uint64_t> align_path_off = std::vector<uint64_t>(1, 0);
+    std::vector<uint32_t> align_path_idx;
+};
+
 struct SynthCluster {
 
     std::vector<PathInfo> paths;
     std::vector<ReadPathProbabilities> rows;
+    SynthAlignments alignments;
     uint64_t num_reads;
 };
+
+const int32_t synth_best_score = 100;
+const uint16_t synth_align_length = 100;
+const uint16_t synth_frag_length = 300;
 
 // Splits `total` into weights-proportional non-negative integers summing to total.
 std::vector<uint64_t> apportion(const std::vector<double> & weights, const uint64_t total, const uint64_t minimum) {
@@ -336,6 +356,60 @@ void generateCluster(SynthCluster * cluster, const rpvg_synth_config & config, c
         signatures[signature]++;
     }
 
+    if (config.keep_alignments) {
+
+        // mapq of the four noise classes: phred_to_prob(mapq) = mapq_noise[class] (src/utils.hpp:131-133)
+        static const uint8_t class_mapq[4] = {40, 30, 10, 3};
+
+        auto & alignments = cluster->alignments;
+        std::vector<uint32_t> deficits;
+
+        for (auto & sig: signatures) {
+
+            alignments.read_count.emplace_back(sig.second);
+
+            if (sig.first.front() == 0xFFFFFFFFu) {
+
+                // no compatible path: a read whose best alignment has mapq 0 contributes noise only
+                // (src/read_path_probabilities.cpp:89)
+                alignments.read_min_mapq.emplace_back(0);
+                alignments.align_score_sum.emplace_back(synth_best_score);
+                alignments.align_path_idx.emplace_back(0);
+                alignments.align_path_off.emplace_back(alignments.align_path_idx.size());
+                alignments.read_align_off.emplace_back(alignments.align_score_sum.size());
+                continue;
+            }
+
+            alignments.read_min_mapq.emplace_back(class_mapq[sig.first.front()]);
+            deficits.clear();
+
+            for (size_t i = 1; i < sig.first.size(); i += 2) {
+
+                deficits.emplace_back(sig.first[i + 1]);
+            }
+
+            std::sort(deficits.begin(), deficits.end());
+            deficits.erase(std::unique(deficits.begin(), deficits.end()), deficits.end());
+
+            for (auto & deficit: deficits) {
+
+                alignments.align_score_sum.emplace_back(synth_best_score - static_cast<int32_t>(deficit));
+
+                for (size_t i = 1; i < sig.first.size(); i += 2) {
+
+                    if (sig.first[i + 1] == deficit) {
+
+                        alignments.align_path_idx.emplace_back(sig.first[i]);
+                    }
+                }
+
+                alignments.align_path_off.emplace_back(alignments.align_path_idx.size());
+            }
+
+            alignments.read_align_off.emplace_back(alignments.align_score_sum.size());
+        }
+    }
+
     cluster->rows.reserve(signatures.size());
     std::vector<std::pair<uint32_t, double> > likelihoods;
 
@@ -360,7 +434,14 @@ void generateCluster(SynthCluster * cluster, const rpvg_synth_config & config, c
     sortAndMergeReadPathProbabilities(&cluster->rows);
 }
 
-typedef FlatBatchStorage SynthBatch;
+struct SynthBatch : public FlatBatchStorage {
+
+    // keep_alignments: the same reads as alignment-path lists, all clusters back to back
+    std::vector<uint64_t> cluster_read_off = std::vector<uint64_t>(1, 0);
+    SynthAlignments alignments;
+    std::vector<int32_t> read_noise_score;
+    std::vector<uint16_t> align_length, align_frag_length;
+};
 
 }
 
@@ -379,6 +460,7 @@ rpvg_synth_config rpvg_amd_synth_default_config(void) {
     config.read_mass_sigma = 1.5;
     config.tie_prob = 0.3;
     config.pathless_read_frac = 0.005;
+    config.keep_alignments = 0;
     return config;
 }
 
@@ -457,6 +539,40 @@ void * rpvg_amd_synth_generate(const rpvg_synth_config * config_in) {
 
         batch->addCluster(cluster.paths, cluster.rows);
         std::vector<ReadPathProbabilities>().swap(cluster.rows);
+
+        if (config.keep_alignments) {
+
+            auto & all = batch->alignments;
+            const auto & own = cluster.alignments;
+
+            const uint64_t first_align = all.align_score_sum.size();
+            const uint64_t first_entry = all.align_path_idx.size();
+
+            all.read_count.insert(all.read_count.end(), own.read_count.begin(), own.read_count.end());
+            all.read_min_mapq.insert(all.read_min_mapq.end(), own.read_min_mapq.begin(), own.read_min_mapq.end());
+            all.align_score_sum.insert(all.align_score_sum.end(), own.align_score_sum.begin(), own.align_score_sum.end());
+            all.align_path_idx.insert(all.align_path_idx.end(), own.align_path_idx.begin(), own.align_path_idx.end());
+
+            for (size_t i = 1; i < own.read_align_off.size(); ++i) {
+
+                all.read_align_off.emplace_back(first_align + own.read_align_off[i]);
+            }
+
+            for (size_t i = 1; i < own.align_path_off.size(); ++i) {
+
+                all.align_path_off.emplace_back(first_entry + own.align_path_off[i]);
+            }
+
+            batch->cluster_read_off.emplace_back(all.read_count.size());
+            cluster.alignments = SynthAlignments();
+        }
+    }
+
+    if (config.keep_alignments) {
+
+        batch->read_noise_score.assign(batch->alignments.read_count.size(), std::numeric_limits<int32_t>::lowest());
+        batch->align_length.assign(batch->alignments.align_score_sum.size(), synth_align_length);
+        batch->align_frag_length.assign(batch->alignments.align_score_sum.size(), synth_frag_length);
     }
 
     return batch;
@@ -513,6 +629,37 @@ void rpvg_amd_synth_sizes(void * handle, uint64_t * rows, uint64_t * groups, uin
     *entries = batch->path_idx.size();
     *paths = batch->path_group_id.size();
     *sources = batch->source_id.size();
+}
+
+// The reads of a batch generated with keep_alignments as the input of row construction.  The path arrays alias
+// the batch's own (cluster_path_off, effective lengths, source counts); no name-group collapsing.
+int rpvg_amd_synth_alignments_view(void * handle, rpvg_alignment_batch * out) {
+
+    SynthBatch * batch = static_cast<SynthBatch *>(handle);
+
+    if (batch->cluster_read_off.size() != batch->cluster_path_off.size()) {
+
+        return -1;
+    }
+
+    std::memset(out, 0, sizeof(*out));
+
+    out->num_clusters = batch->cluster_path_off.size() - 1;
+    out->cluster_read_off = batch->cluster_read_off.data();
+    out->cluster_path_off = batch->cluster_path_off.data();
+    out->path_effective_length = batch->path_effective_length.data();
+    out->path_source_count = batch->path_source_count.data();
+    out->read_count = batch->alignments.read_count.data();
+    out->read_min_mapq = batch->alignments.read_min_mapq.data();
+    out->read_noise_score = batch->read_noise_score.data();
+    out->read_align_off = batch->alignments.read_align_off.data();
+    out->align_score_sum = batch->alignments.align_score_sum.data();
+    out->align_length = batch->align_length.data();
+    out->align_frag_length = batch->align_frag_length.data();
+    out->align_path_off = batch->alignments.align_path_off.data();
+    out->align_path_idx = batch->alignments.align_path_idx.data();
+
+    return 0;
 }
 
 void rpvg_amd_synth_free(void * handle) {

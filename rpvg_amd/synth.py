@@ -15,6 +15,7 @@ class CSynthConfig(C.Structure):
         ("seed", C.c_uint64), ("num_clusters", C.c_uint32), ("total_paths", C.c_uint64), ("total_reads", C.c_uint64),
         ("num_haplotypes", C.c_uint32), ("max_cluster_paths", C.c_uint32), ("cluster_paths_sigma", C.c_double),
         ("read_mass_sigma", C.c_double), ("tie_prob", C.c_double), ("pathless_read_frac", C.c_double),
+        ("keep_alignments", C.c_uint32),
     ]
 
 
@@ -93,5 +94,53 @@ def generate(seed: int = 3, num_clusters: int = 5000, total_paths: int = 200000,
     h = L.rpvg_amd_synth_generate(C.byref(cfg))
     try:
         return _to_batch(L, h)
+    finally:
+        L.rpvg_amd_synth_free(h)
+
+
+# what the generator's reads look like as alignments: best score, alignment length, fragment length
+SYNTH_FRAG_LENGTH = 300
+
+
+def generate_with_alignments(seed: int = 3, num_clusters: int = 5000, total_paths: int = 200000, total_reads: int = 10000000,
+                             **overrides):
+    """(ClusterBatch of finished rows, AlignmentBatch of the same reads as alignment-path lists): the second is what
+    row construction (include/rpvg_rows.h) starts from; the first is the generator's own result for them."""
+    from . import rows as rows_mod
+    L = _bind()
+    L.rpvg_amd_synth_alignments_view.argtypes = [C.c_void_p, C.POINTER(rows_mod.CAlignmentBatch)]
+    cfg = L.rpvg_amd_synth_default_config()
+    cfg.seed, cfg.num_clusters, cfg.total_paths, cfg.total_reads = seed, num_clusters, total_paths, total_reads
+    cfg.keep_alignments = 1
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise KeyError(k)
+        setattr(cfg, k, v)
+    h = L.rpvg_amd_synth_generate(C.byref(cfg))
+    try:
+        batch = _to_batch(L, h)
+        view = rows_mod.CAlignmentBatch()
+        assert L.rpvg_amd_synth_alignments_view(h, C.byref(view)) == 0
+        K = view.num_clusters
+
+        def arr(ptr, n, dt):
+            if n == 0:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+
+        cro = arr(view.cluster_read_off, K + 1, np.uint64)
+        N = int(cro[-1])
+        rao = arr(view.read_align_off, N + 1, np.uint64)
+        A = int(rao[-1])
+        apo = arr(view.align_path_off, A + 1, np.uint64)
+        E = int(apo[-1])
+        P = batch.num_paths
+        aligns = rows_mod.AlignmentBatch(
+            cro, batch.cluster_path_off.copy(), batch.path_effective_length.copy(), batch.path_source_count.copy(), None, None,
+            arr(view.read_count, N, np.uint32), arr(view.read_min_mapq, N, np.uint8), arr(view.read_noise_score, N, np.int32), rao,
+            arr(view.align_score_sum, A, np.int32), arr(view.align_length, A, np.uint16), arr(view.align_frag_length, A, np.uint16),
+            apo, arr(view.align_path_idx, E, np.uint32))
+        assert len(aligns.path_effective_length) == P
+        return batch, aligns
     finally:
         L.rpvg_amd_synth_free(h)

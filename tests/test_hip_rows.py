@@ -331,3 +331,29 @@ def test_rows_feed_the_estimators(hip_ctx):
         assert g.total_count == w.total_count
         assert np.allclose(g.abundances, w.abundances, rtol=1e-6, atol=1e-8)
         assert list(g.em_iters) == list(w.em_iters)
+
+
+@pytest.mark.parametrize("model", ["transcripts", "haplotype-transcripts"])
+def test_host_classes_construct_rows_on_the_device_and_estimate(model):
+    """The C++ layer (FragmentLengthDist, AlignmentPath, AlignmentBatchBuilder, constructReadPathProbabilities): reads of
+    the synthetic pantranscriptome as alignment-path lists -> rows on the GPU -> estimates, against the oracle run on
+    the generator's own rows of the same reads."""
+    from rpvg_amd import synth
+    batch, aligns = synth.generate_with_alignments(seed=41, num_clusters=40, total_paths=1500, total_reads=60000)
+    e = eng_mod.Engine(0)
+    try:
+        prep = e.prepare_from_alignments(aligns, batch, frag=(300.0, 50.0, 0.0, 10), min_noise_prob=0.0)
+        assert prep.row_construction_seconds > 0
+        got, _ = e.run(model, make_params(), prep)
+    finally:
+        e.close()
+    want, _ = pyoracle.run(model, make_params(), batch, 2)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        gk, wk = g.keyed(), w.keyed()
+        assert set(gk) == set(wk)
+        assert g.total_count == w.total_count
+        for key, (post, ab) in wk.items():
+            assert abs(gk[key][0] - post) <= 1e-6 * max(abs(post), 1e-8) + 1e-8
+            assert np.allclose(gk[key][1], ab, rtol=1e-6, atol=1e-8)
+        assert dict(zip(g.em_cols, g.em_iters)) == dict(zip(w.em_cols, w.em_iters))
