@@ -20,6 +20,9 @@ struct FlatBatchStorage {
 
     FlatBatchStorage() : cluster_row_off(1, 0), cluster_path_off(1, 0), row_grp_off(1, 0), grp_idx_off(1, 0), path_source_off(1, 0) {}
 
+    // handles of this type cross the harness C API and may hold a derived object
+    virtual ~FlatBatchStorage() {}
+
     void addCluster(const std::vector<PathInfo> & paths, const std::vector<ReadPathProbabilities> & rows) {
 
         for (auto & path: paths) {

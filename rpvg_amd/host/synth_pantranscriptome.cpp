@@ -575,7 +575,7 @@ void * rpvg_amd_synth_generate(const rpvg_synth_config * config_in) {
         batch->align_frag_length.assign(batch->alignments.align_score_sum.size(), synth_frag_length);
     }
 
-    return batch;
+    return static_cast<FlatBatchStorage *>(batch);
 }
 
 // Builds ONE cluster from raw reads: read r has count read_count[r], noise read_noise[r] and the per-path
@@ -612,17 +612,17 @@ void * rpvg_amd_rows_from_likelihoods(uint32_t num_paths, uint32_t num_reads, co
     SynthBatch * batch = new SynthBatch();
     batch->addCluster(std::vector<PathInfo>(num_paths, PathInfo()), rows);
 
-    return batch;
+    return static_cast<FlatBatchStorage *>(batch);
 }
 
 void rpvg_amd_synth_view(void * handle, rpvg_cluster_batch * out) {
 
-    static_cast<SynthBatch *>(handle)->view(out);
+    static_cast<FlatBatchStorage *>(handle)->view(out);
 }
 
 void rpvg_amd_synth_sizes(void * handle, uint64_t * rows, uint64_t * groups, uint64_t * entries, uint64_t * paths, uint64_t * sources) {
 
-    SynthBatch * batch = static_cast<SynthBatch *>(handle);
+    FlatBatchStorage * batch = static_cast<FlatBatchStorage *>(handle);
 
     *rows = batch->row_count.size();
     *groups = batch->grp_prob.size();
@@ -635,9 +635,9 @@ void rpvg_amd_synth_sizes(void * handle, uint64_t * rows, uint64_t * groups, uin
 // the batch's own (cluster_path_off, effective lengths, source counts); no name-group collapsing.
 int rpvg_amd_synth_alignments_view(void * handle, rpvg_alignment_batch * out) {
 
-    SynthBatch * batch = static_cast<SynthBatch *>(handle);
+    SynthBatch * batch = dynamic_cast<SynthBatch *>(static_cast<FlatBatchStorage *>(handle));
 
-    if (batch->cluster_read_off.size() != batch->cluster_path_off.size()) {
+    if (!batch || batch->cluster_read_off.size() != batch->cluster_path_off.size()) {
 
         return -1;
     }
@@ -664,7 +664,7 @@ int rpvg_amd_synth_alignments_view(void * handle, rpvg_alignment_batch * out) {
 
 void rpvg_amd_synth_free(void * handle) {
 
-    delete static_cast<SynthBatch *>(handle);
+    delete static_cast<FlatBatchStorage *>(handle);
 }
 
 }
