@@ -215,6 +215,17 @@ void rpvg_hip_pair_posteriors_free(rpvg_hip_pair_posteriors * result);
 int rpvg_hip_min_path_cover(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t num_clusters,
                             const uint32_t * clusters, const uint64_t * cover_off, uint32_t * cover, uint32_t * cover_size);
 
+/* ---- path clustering ------------------------------------------------------- */
+/* PathClusters (src/path_clusters.cpp:12-86 constructor, :163-207 createPathClusters, :88-262 addNodeClusters +
+ * mergeClusters): the paths of every id set — the paths one alignment-path list locates, or the paths through one
+ * node — end up in one cluster.  Clusters are numbered by ascending smallest path id and list their members in
+ * ascending order, as the reference does (test src/tests/path_clusters_test.cpp:82-87,130-135).
+ * set s = set_path[set_off[s] .. set_off[s+1]) (non-empty; ids < num_paths).  Outputs (host): path_to_cluster
+ * [num_paths]; *num_clusters_out; cluster_off[num_clusters + 1] (capacity num_paths + 1); cluster_paths [num_paths]. */
+int rpvg_hip_path_clusters(rpvg_hip_ctx * ctx, uint32_t num_paths, uint64_t num_sets, const uint64_t * set_off,
+                           const uint32_t * set_path, uint32_t * path_to_cluster, uint32_t * num_clusters_out,
+                           uint64_t * cluster_off, uint32_t * cluster_paths);
+
 /* ---- row construction: the step before the path (include/rpvg_rows.h) ------- */
 /* ReadPathProbabilities::addPathProbs for every read of every cluster of the batch (src/read_path_probabilities.cpp:
  * 39-221) and, when merge != 0, the caller's sort + quickMergeIdentical of adjacent rows (src/main.cpp:953-973,

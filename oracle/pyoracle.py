@@ -191,3 +191,32 @@ def build_rows(align_batch, row_params, merge: bool = True, num_threads: int = 1
         return rows_mod.rows_from_view(view), secs.value
     finally:
         L.rpvg_oracle_rows_free(h)
+
+
+def path_clusters(num_paths: int, sets):
+    """PathClusters over id sets -> (path_to_cluster, [members...], seconds)."""
+    L = lib()
+    L.rpvg_oracle_path_clusters.restype = C.c_uint32
+    L.rpvg_oracle_path_clusters.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_double)]
+    off = np.zeros(len(sets) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in sets])
+    flat = np.ascontiguousarray([p for x in sets for p in x], dtype=np.uint32)
+    return path_clusters_flat(num_paths, off, flat)
+
+
+def path_clusters_flat(num_paths: int, set_off, set_path):
+    L = lib()
+    L.rpvg_oracle_path_clusters.restype = C.c_uint32
+    L.rpvg_oracle_path_clusters.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_double)]
+    set_off = np.ascontiguousarray(set_off, dtype=np.uint64)
+    set_path = np.ascontiguousarray(set_path, dtype=np.uint32)
+    p2c = np.zeros(max(num_paths, 1), dtype=np.uint32)
+    coff = np.zeros(num_paths + 1, dtype=np.uint64)
+    cpaths = np.zeros(max(num_paths, 1), dtype=np.uint32)
+    secs = C.c_double(0)
+    k = L.rpvg_oracle_path_clusters(num_paths, len(set_off) - 1, set_off.ctypes.data, set_path.ctypes.data if set_path.size else None,
+                                    p2c.ctypes.data, coff.ctypes.data, cpaths.ctypes.data, C.byref(secs))
+    members = [cpaths[int(coff[c]):int(coff[c + 1])].tolist() for c in range(k)]
+    return p2c[:num_paths].copy(), members, secs.value

@@ -15,6 +15,8 @@
 #include <cmath>
 #include <limits>
 #include <numeric>
+#include <queue>
+#include <set>
 #include <unordered_map>
 
 namespace rpvg_oracle {
@@ -1310,6 +1312,54 @@ ReadRow addPathProbs(const uint32_t read_count, const double prob_precision, con
         std::sort(path_probs.begin(), path_probs.end());
     }
     return row;
+}
+
+// ---------------------------------------------------------------------------
+// path clustering  (src/path_clusters.cpp:12-86, 163-207)
+// ---------------------------------------------------------------------------
+vector<vector<uint32_t>> createPathClusters(const uint32_t num_paths, const vector<vector<uint32_t>> & id_sets,
+                                            vector<uint32_t> * path_to_cluster_index) {
+    // constructor :12-86 — connected_paths: anchor = first id of the set, every other id is linked to it both ways
+    vector<std::set<uint32_t>> connected_paths(num_paths);
+    for (auto & ids: id_sets) {
+        assert(!ids.empty());
+        const uint32_t anchor_path_id = ids.front();
+        for (auto path_id: ids) {
+            if (anchor_path_id != path_id) {
+                if (connected_paths.at(anchor_path_id).emplace(path_id).second) {
+                    connected_paths.at(path_id).emplace(anchor_path_id);
+                }
+            }
+        }
+    }
+    // createPathClusters :163-207
+    const uint32_t unset = static_cast<uint32_t>(-1);
+    *path_to_cluster_index = vector<uint32_t>(num_paths, unset);
+    vector<vector<uint32_t>> cluster_to_paths_index;
+    for (uint32_t i = 0; i < num_paths; ++i) {
+        if (path_to_cluster_index->at(i) == unset) {
+            std::queue<uint32_t> search_queue;
+            search_queue.push(i);
+            cluster_to_paths_index.emplace_back(vector<uint32_t>());
+            while (!search_queue.empty()) {
+                auto cur_path = search_queue.front();
+                const bool is_first_visit = (path_to_cluster_index->at(cur_path) == unset);
+                assert(is_first_visit || path_to_cluster_index->at(cur_path) == cluster_to_paths_index.size() - 1);
+                path_to_cluster_index->at(cur_path) = cluster_to_paths_index.size() - 1;
+                if (is_first_visit) {
+                    cluster_to_paths_index.back().emplace_back(cur_path);
+                    for (auto & next_path: connected_paths.at(cur_path)) {
+                        if (path_to_cluster_index->at(next_path) == unset) {
+                            search_queue.push(next_path);
+                        }
+                    }
+                }
+                search_queue.pop();
+            }
+            std::sort(cluster_to_paths_index.back().begin(), cluster_to_paths_index.back().end());
+        }
+    }
+    return cluster_to_paths_index;
 }
 
 }  // namespace rpvg_oracle

@@ -181,6 +181,14 @@ ReadRow addPathProbs(uint32_t read_count, double prob_precision, const std::vect
                      double min_noise_prob, bool collapse_groups = false,
                      const std::vector<uint32_t> & path_group = std::vector<uint32_t>(), uint32_t num_groups = 0);
 
+
+// ---- path clustering --------------------------------------------------------------------
+// src/path_clusters.cpp:12-86 (every id set connects its members to its first member) + :163-207
+// (createPathClusters: BFS per unvisited path in ascending id; members sorted).  Returns cluster_to_paths_index and
+// fills path_to_cluster_index.
+std::vector<std::vector<uint32_t>> createPathClusters(uint32_t num_paths, const std::vector<std::vector<uint32_t>> & id_sets,
+                                                      std::vector<uint32_t> * path_to_cluster_index);
+
 }  // namespace rpvg_oracle
 
 #endif

@@ -350,4 +350,24 @@ void rpvg_oracle_rows_view(void * handle, rpvg_cluster_batch * out) {
 
 void rpvg_oracle_rows_free(void * handle) { delete static_cast<FlatRows *>(handle); }
 
+// createPathClusters over id sets (CSR).  cluster_off needs num_paths + 1 slots, cluster_paths num_paths.
+uint32_t rpvg_oracle_path_clusters(uint32_t num_paths, uint64_t num_sets, const uint64_t * set_off, const uint32_t * set_path,
+                                   uint32_t * path_to_cluster, uint64_t * cluster_off, uint32_t * cluster_paths, double * seconds_out) {
+    std::vector<std::vector<uint32_t>> sets(num_sets);
+    for (uint64_t s = 0; s < num_sets; ++s) sets[s].assign(set_path + set_off[s], set_path + set_off[s + 1]);
+    std::vector<uint32_t> p2c;
+    auto t0 = std::chrono::steady_clock::now();
+    auto clusters = createPathClusters(num_paths, sets, &p2c);
+    auto t1 = std::chrono::steady_clock::now();
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(t1 - t0).count();
+    cluster_off[0] = 0;
+    uint64_t n = 0;
+    for (size_t c = 0; c < clusters.size(); ++c) {
+        for (auto p : clusters[c]) cluster_paths[n++] = p;
+        cluster_off[c + 1] = n;
+    }
+    for (uint32_t i = 0; i < num_paths; ++i) path_to_cluster[i] = p2c[i];
+    return clusters.size();
+}
+
 }  // extern "C"

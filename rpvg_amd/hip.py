@@ -27,7 +27,7 @@ EXPORTS = [
     "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
     "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_group_conditionals",
     "rpvg_hip_alignments_upload", "rpvg_hip_alignments_free", "rpvg_hip_read_rows_build", "rpvg_hip_read_rows_to_batch",
-    "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_sizes", "rpvg_hip_read_rows_free",
+    "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_sizes", "rpvg_hip_read_rows_free", "rpvg_hip_path_clusters",
 ]
 
 COMM_ID_BYTES = 128  # RPVG_HIP_COMM_ID_BYTES
@@ -417,6 +417,29 @@ class Context:
         finally:
             if dev is not align_batch:
                 dev.free()
+
+    # ---- path clustering ----------------------------------------------------------
+    def path_clusters(self, num_paths: int, sets):
+        """sets: id sets (lists of path ids) -> (path_to_cluster[num_paths], [members of cluster 0, 1, ...])."""
+        off = np.zeros(len(sets) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(x) for x in sets])
+        flat = np.ascontiguousarray([p for x in sets for p in x], dtype=np.uint32)
+        return self.path_clusters_flat(num_paths, off, flat)
+
+    def path_clusters_flat(self, num_paths: int, set_off: np.ndarray, set_path: np.ndarray):
+        set_off = np.ascontiguousarray(set_off, dtype=np.uint64)
+        set_path = np.ascontiguousarray(set_path, dtype=np.uint32)
+        p2c = np.zeros(max(num_paths, 1), dtype=np.uint32)
+        coff = np.zeros(num_paths + 1, dtype=np.uint64)
+        cpaths = np.zeros(max(num_paths, 1), dtype=np.uint32)
+        nc = C.c_uint32(0)
+        _check(lib().rpvg_hip_path_clusters(self.handle, C.c_uint32(num_paths), C.c_uint64(len(set_off) - 1),
+                                            C.c_void_p(set_off.ctypes.data), C.c_void_p(set_path.ctypes.data if set_path.size else None),
+                                            C.c_void_p(p2c.ctypes.data), C.byref(nc), C.c_void_p(coff.ctypes.data),
+                                            C.c_void_p(cpaths.ctypes.data)), "rpvg_hip_path_clusters")
+        k = nc.value
+        members = [cpaths[int(coff[c]):int(coff[c + 1])].tolist() for c in range(k)]
+        return p2c[:num_paths].copy(), members
 
     # ---- stats ----------------------------------------------------------------
     def stats(self) -> dict:
