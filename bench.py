@@ -179,10 +179,16 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     em_ms = stats["em_sparse_ms"] / max(1, stats["em_sparse_launches"])
     em_bytes = stats["em_sparse_alg_bytes"] / max(1, stats["em_sparse_launches"])
     achieved = (em_bytes / 1e9) / (em_ms / 1e3) if em_ms > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_s3.json")
+    if os.path.exists(pmc_path) and args.scale == 1.0 and args.workload == "s3" and args.model == "haplotype-transcripts":
+        # separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.py); per launch like `achieved`
+        traffic = json.load(open(pmc_path))["traffic_bytes_per_step"] / max(1.0, stats["em_sparse_launches"] / args.steps)
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=None, kernel="emSparseKernel",
+                    traffic=traffic, kernel="emSparseKernel", ms_per_launch=em_ms, algorithmic_bytes_per_launch=em_bytes,
                     note="algorithmic bytes = sum over EM problems of iterations x (12 B/entry + 20 B/row + 16 B/column); "
-                         "problems are L2/LDS-resident across iterations, so this is effective bandwidth, not HBM traffic")
+                         "problems are L2/LDS-resident across iterations, so this is effective bandwidth: the HBM traffic "
+                         "(PMC) is a fraction of the algorithmic bytes")
     kernels = dict(
         em_sparse_ms_per_step=stats["em_sparse_ms"] / args.steps, loglik_ms_per_step=stats["loglik_ms"] / args.steps,
         build_ms_per_step=stats["build_ms"] / args.steps, h2d_ms_per_step=stats["h2d_ms"] / args.steps,
