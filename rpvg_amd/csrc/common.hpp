@@ -139,7 +139,13 @@ __device__ __forceinline__ double logPositive(const double x) {
     m = low ? m * 2.0 : m;
     k = low ? k - 1 : k;
     const double f = m - 1.0;
-    const double s = f / (2.0 + f);
+    // s = f / (2 + f) without the IEEE division sequence: hardware reciprocal (~24 bits) + two Newton steps.
+    // s only multiplies the O(f^2) tail below, so its last-bit error reaches the result scaled by |f| / 2.
+    const double d = 2.0 + f;
+    double y = __builtin_amdgcn_rcp(d);
+    y = fma(fma(-d, y, 1.0), y, y);
+    y = fma(fma(-d, y, 1.0), y, y);
+    const double s = f * y;
     const double z = s * s, w = z * z;
     const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
     const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));

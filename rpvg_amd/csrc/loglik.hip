@@ -76,6 +76,77 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
 }
 
 
+// Rows per LDS tile for a matrix with G columns: the tile (G x rows doubles) must fit kTileDoubles; a power of two
+// of at least 16 rows (128-byte runs per column when the tile is written out).  0 = too wide: global-memory kernel.
+constexpr uint32_t kTileDoubles = 8192;  // 64 KB
+
+__host__ __device__ inline uint32_t tileRows(const uint32_t G) {
+    if (G * 16u > kTileDoubles) return 0;
+    uint32_t rows = 256;
+    while (rows * G > kTileDoubles) rows >>= 1;
+    return rows;
+}
+
+// The same construction through an LDS tile: one workgroup per (matrix, tile of rows).  The rows of the tile are
+// accumulated, normalised and scanned for their maximum in LDS by the thread that owns the row (same order of
+// additions as groupsBuildKernel: the results are bit-identical), then the tile leaves in one coalesced write —
+// one HBM write per matrix element instead of zero-fill + read-modify-writes + two normalisation passes.
+__global__ __launch_bounds__(256) void groupsBuildTileKernel(
+    const uint32_t num_items, const uint32_t * __restrict__ item_matrix, const uint32_t * __restrict__ item_chunk,
+    const uint64_t * __restrict__ mat_val_off, const uint64_t * __restrict__ mat_row_off,
+    const uint64_t * __restrict__ mat_row0, const uint64_t * __restrict__ mat_rows, const uint32_t * __restrict__ mat_cols,
+    const uint64_t * __restrict__ mat_inc_off, const uint64_t * __restrict__ path_grp_off,
+    const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
+    const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
+    const int normalise, double * __restrict__ values, double * __restrict__ rowmax) {
+    extern __shared__ double tile[];
+    if (blockIdx.x >= num_items) return;
+    const uint32_t m = item_matrix[blockIdx.x];
+    const uint64_t R = mat_rows[m], r0 = mat_row0[m];
+    const uint32_t G = mat_cols[m];
+    const uint32_t Rc = tileRows(G);
+    const uint64_t i0 = static_cast<uint64_t>(item_chunk[blockIdx.x]) * Rc;
+    const uint32_t nrows = static_cast<uint32_t>(min(static_cast<uint64_t>(Rc), R - i0));
+    const uint32_t cells = G * Rc;
+    for (uint32_t idx = threadIdx.x; idx < cells; idx += blockDim.x) tile[idx] = 0.0;
+    __syncthreads();
+    const uint32_t t = threadIdx.x;
+    if (t < nrows) {
+        const uint64_t r = r0 + i0 + t;
+        const uint64_t * pgo = path_grp_off + mat_inc_off[m];
+        for (uint64_t e = row_ent_off[r]; e < row_ent_off[r + 1]; ++e) {
+            const uint32_t p = ent_path[e];
+            const double v = ent_prob[e];
+            for (uint64_t x = pgo[p]; x < pgo[p + 1]; ++x) tile[path_grp[x] * Rc + t] += v;
+        }
+        double mx = 0.0;
+        if (normalise) {
+            double rowsum = 0.0;
+            for (uint32_t g = 0; g < G; ++g) rowsum += tile[g * Rc + t];
+            const double keep = 1 - row_noise[r];
+            for (uint32_t g = 0; g < G; ++g) {
+                double v = (tile[g * Rc + t] / rowsum) * keep;
+                if (v != v) v = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
+                tile[g * Rc + t] = v;
+                mx = (g == 0) ? v : fmax(mx, v);
+            }
+        } else {
+            for (uint32_t g = 0; g < G; ++g) {
+                const double v = tile[g * Rc + t];
+                mx = (g == 0) ? v : fmax(mx, v);
+            }
+        }
+        rowmax[mat_row_off[m] + i0 + t] = mx;
+    }
+    __syncthreads();
+    double * M = values + mat_val_off[m];
+    const uint32_t shift = 31 - __clz(Rc);
+    for (uint32_t idx = threadIdx.x; idx < cells; idx += blockDim.x) {
+        const uint32_t g = idx >> shift, tt = idx & (Rc - 1);
+        if (tt < nrows) M[static_cast<uint64_t>(g) * R + i0 + tt] = tile[idx];
+    }
+}
+
 // ---- path -> groups incidence, inverted on the device ---------------------------------
 // The caller gives, per matrix, the paths of every column (group).  The build kernel needs the
 // opposite: the columns of every path.  One thread per column counts / scatters; the per-path lists
@@ -236,7 +307,8 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     std::unique_ptr<HostScope> scope_host(new HostScope("groups_build: host sizes"));
     // host: sizes and offsets only (O(M)); the path -> groups incidence is inverted on the device
     std::vector<uint64_t> val_off(M), row_off(M), row0(M), rows(M), inc_off(M), num_paths(M);
-    std::vector<uint32_t> cols(M), item_matrix, item_chunk;
+    std::vector<uint32_t> cols(M), item_matrix, item_chunk, tile_matrix, tile_chunk;
+    std::vector<uint32_t> wide_matrices;  // too many columns for an LDS tile: global-memory kernel on zero-filled storage
     uint64_t val_total = 0, row_total = 0, inc_total = 0;
     for (uint32_t m = 0; m < M; ++m) {
         const uint32_t k = spec->cluster[m];
@@ -263,9 +335,18 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         val_total += R * (g1 - g0);
         row_total += R;
         inc_total += N + 1;
-        for (uint64_t c = 0; c * 256 < R; ++c) {
-            item_matrix.push_back(m);
-            item_chunk.push_back(static_cast<uint32_t>(c));
+        const uint32_t tile_rows = tileRows(cols[m]);
+        if (tile_rows) {
+            for (uint64_t c = 0; c * tile_rows < R; ++c) {
+                tile_matrix.push_back(m);
+                tile_chunk.push_back(static_cast<uint32_t>(c));
+            }
+        } else {
+            wide_matrices.push_back(m);
+            for (uint64_t c = 0; c * 256 < R; ++c) {
+                item_matrix.push_back(m);
+                item_chunk.push_back(static_cast<uint32_t>(c));
+            }
         }
     }
     g->h_num_cols = cols;
@@ -283,7 +364,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     hipError_t e = hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     DeviceBuffer<uint64_t> d_inc_off, d_path_grp_off, d_group_off, d_group_path_off, d_num_paths;
-    DeviceBuffer<uint32_t> d_path_grp, d_item_matrix, d_item_chunk, d_group_path, d_degree, d_cursor, d_error;
+    DeviceBuffer<uint32_t> d_path_grp, d_item_matrix, d_item_chunk, d_tile_matrix, d_tile_chunk, d_group_path, d_degree, d_cursor, d_error;
     DeviceBuffer<unsigned char> d_scan_tmp;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     int span = ctx->spanBegin(FAM_H2D);
@@ -297,10 +378,16 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     ok(d_group_off.upload(spec->group_off, M + 1, st));
     ok(d_group_path_off.upload(spec->group_path_off, num_columns + 1, st));
     ok(d_group_path.upload(spec->group_path, num_incidences, st));
-    ok(d_item_matrix.upload(item_matrix.data(), item_matrix.size(), st));
-    ok(d_item_chunk.upload(item_chunk.data(), item_chunk.size(), st));
+    if (!item_matrix.empty()) {
+        ok(d_item_matrix.upload(item_matrix.data(), item_matrix.size(), st));
+        ok(d_item_chunk.upload(item_chunk.data(), item_chunk.size(), st));
+    }
+    if (!tile_matrix.empty()) {
+        ok(d_tile_matrix.upload(tile_matrix.data(), tile_matrix.size(), st));
+        ok(d_tile_chunk.upload(tile_chunk.data(), tile_chunk.size(), st));
+    }
     ctx->spanEnd(span);
-    ctx->stats.h2d_bytes += static_cast<double>(M * 60 + num_columns * 8 + num_incidences * 4 + item_matrix.size() * 8);
+    ctx->stats.h2d_bytes += static_cast<double>(M * 60 + num_columns * 8 + num_incidences * 4 + (item_matrix.size() + tile_matrix.size()) * 8);
     ok(g->values.alloc(val_total));
     ok(g->rowmax.alloc(row_total));
     ok(d_degree.alloc(inc_total));
@@ -317,7 +404,9 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         ok(hipMemsetAsync(d_degree.ptr, 0, inc_total * sizeof(uint32_t), st));
         ok(hipMemsetAsync(d_cursor.ptr, 0, inc_total * sizeof(uint32_t), st));
         ok(hipMemsetAsync(d_error.ptr, 0, sizeof(uint32_t), st));
-        ok(hipMemsetAsync(g->values.ptr, 0, val_total * sizeof(double), st));
+        for (auto m : wide_matrices) {
+            ok(hipMemsetAsync(g->values.ptr + val_off[m], 0, rows[m] * cols[m] * sizeof(double), st));
+        }
         const uint32_t col_blocks = static_cast<uint32_t>((num_columns + 255) / 256);
         incidenceCountKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,
                                                                    d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
@@ -326,11 +415,20 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         incidenceFillKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,
                                                                   d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
                                                                   d_path_grp_off.ptr, d_cursor.ptr, d_path_grp.ptr);
-        groupsBuildKernel<<<dim3(static_cast<uint32_t>(item_matrix.size())), dim3(256), 0, st>>>(
-            static_cast<uint32_t>(item_matrix.size()), d_item_matrix.ptr, d_item_chunk.ptr, g->mat_val_off.ptr,
-            g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
-            d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
-            spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr);
+        if (!tile_matrix.empty()) {
+            groupsBuildTileKernel<<<dim3(static_cast<uint32_t>(tile_matrix.size())), dim3(256), kTileDoubles * sizeof(double), st>>>(
+                static_cast<uint32_t>(tile_matrix.size()), d_tile_matrix.ptr, d_tile_chunk.ptr, g->mat_val_off.ptr,
+                g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
+                d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
+                spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr);
+        }
+        if (!item_matrix.empty()) {
+            groupsBuildKernel<<<dim3(static_cast<uint32_t>(item_matrix.size())), dim3(256), 0, st>>>(
+                static_cast<uint32_t>(item_matrix.size()), d_item_matrix.ptr, d_item_chunk.ptr, g->mat_val_off.ptr,
+                g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
+                d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
+                spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr);
+        }
         ctx->spanEnd(span);
         ctx->stats.build_launches += 3;
         ok(hipGetLastError());
