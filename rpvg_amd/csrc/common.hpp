@@ -170,15 +170,15 @@ struct TimedSpan {
 }  // namespace rpvg_hip_detail
 
 struct rpvg_hip_ctx {
-    static constexpr int kAuxStreams = 3;
+    static constexpr int kAuxStreams = 6;
     int device = 0;
     hipStream_t stream = nullptr;
     // Side streams for independent launches of one call (size bins of the batched kernels): their tails
     // overlap instead of adding up.  forkAux() makes them wait for the work queued on `stream` so far,
     // joinAux() makes `stream` wait for them.
-    hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr};
+    hipStream_t aux[kAuxStreams] = {};
     hipEvent_t fork_event = nullptr;
-    hipEvent_t join_event[kAuxStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t join_event[kAuxStreams] = {};
     hipError_t forkAux();
     hipError_t joinAux();
     hipDeviceProp_t props;

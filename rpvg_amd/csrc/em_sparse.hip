@@ -391,6 +391,179 @@ hipError_t launchEm(const EmLaunchArgs & args, size_t lds, hipStream_t stream) {
 }
 
 
+// ---- register-resident EM for small problems ---------------------------------------------------------------
+// A problem with at most 16 paths and 64 * RPL rows is held DENSE in the registers of one wavefront: lane l owns rows
+// l, l + 64, ... (RPL of them) as 16 doubles each.  An iteration then needs no dependent memory access for the
+// matrix: the E-step is RPL x 16 fused multiply-adds against the abundance vector, the M-step RPL x 16 more into 16
+// per-lane partial column sums, which cross the wave once through LDS (four lanes per column + two butterfly steps).
+// These problems are the ones that run for thousands of iterations (the batch's EM time is the iteration count of
+// its slowest problem times the latency of ONE iteration): ~0.35 us per iteration here against ~1.2 us for the
+// LDS-resident sparse kernel.  Zero entries add exact zeros, so the E-step sums equal the sparse kernel's bit for
+// bit; the column sums are added in a fixed order (the sparse kernels use LDS atomics).
+constexpr uint32_t kRegPaths = 16;
+
+// value of the lane whose index differs in bit 0 (D = 1) or bit 1 (D = 2) — inside a quad, through DPP
+template <int D>
+__device__ __forceinline__ double quadSwapF64(const double v) {
+    constexpr int perm = (D == 1) ? 0xB1 : 0x4E;  // quad_perm [1,0,3,2] / [2,3,0,1]
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), perm, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), perm, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int RPL>
+__global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) {
+    extern __shared__ __attribute__((aligned(16))) double reg_lds[];
+    if (blockIdx.x >= args.count) return;
+    const uint32_t p = args.order[blockIdx.x];
+    const uint32_t np = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]);  // <= kRegPaths
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_rows = args.kept_rows[p];
+    const uint64_t rb = args.row_base[p], eb = args.ent_base[p];
+    const uint32_t * off = args.prow_off + rb + p;
+    const double * cnt = args.prow_count + rb;
+    const double * nzv = args.prow_noise + rb;
+    const uint32_t * col = args.pent_col + eb;
+    const double * val = args.pent_val + eb;
+
+    // stage the dense tile through LDS (the scatter needs dynamic indexing, registers must not)
+    constexpr uint32_t kTile = 64 * RPL * kRegPaths;
+    constexpr uint32_t kPart = 64 * kRegPaths;
+    double * tile = reg_lds;
+    double * a_lds = reg_lds + (kTile > kPart ? kTile : kPart);  // [kRegPaths + 1]; the noise component sits at kRegPaths
+    for (uint32_t idx = lane; idx < kTile; idx += 64) tile[idx] = 0.0;
+    __syncthreads();
+    for (uint32_t r = lane; r < n_rows; r += 64) {
+        for (uint32_t e = off[r]; e < off[r + 1]; ++e) tile[r * kRegPaths + col[e]] += val[e];
+    }
+    __syncthreads();
+    double P[RPL][kRegPaths], nz[RPL], c[RPL];
+    bool valid[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+        const uint32_t r = q * 64 + lane;
+        valid[q] = r < n_rows;
+#pragma unroll
+        for (int j = 0; j < static_cast<int>(kRegPaths); ++j) P[q][j] = tile[r * kRegPaths + j];
+        nz[q] = valid[q] ? nzv[r] : 0.0;
+        c[q] = valid[q] ? cnt[r] : 0.0;
+    }
+    __syncthreads();
+    double * part = reg_lds;  // [kRegPaths][64] partial column sums of the lanes
+
+    const double T = args.total_mass[p];
+    const double Z = args.zero_mass[p];
+    const double eps = args.max_rel_em_conv;
+    // src/path_abundance_estimator.cpp:54 — 1 / float(C), widened
+    const double a0 = static_cast<double>(1.0f / static_cast<float>(np + 1));
+    // lane 4 j owns path column j (its quad adds that column's partials); lane 1 owns the noise component
+    const uint32_t my_col = (lane == 1) ? kRegPaths : (lane >> 2);
+    const bool owns_path = (lane & 3) == 0 && my_col < np;
+    const bool owns_noise = lane == 1;
+    double a_mine = (owns_path || owns_noise) ? a0 : 0.0;
+    if (lane <= kRegPaths) a_lds[lane] = (lane < np || lane == kRegPaths) ? a0 : 0.0;
+    __syncthreads();
+
+    const double inv_T = 1.0 / T;
+    // column j = lane >> 2: the four lanes of a quad add a quarter of the column's 64 partials each
+    const double * mine = part + (lane >> 2) * 64 + (lane & 3) * 16;
+
+    uint32_t iters = 0, conv = 0;
+    for (uint32_t it = 0; it < args.max_em_its; ++it) {
+        double av[kRegPaths];
+#pragma unroll
+        for (int j = 0; j < static_cast<int>(kRegPaths); ++j) av[j] = a_lds[j];
+        const double a_noise = a_lds[kRegPaths];
+        double w[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            // four interleaved partial sums: the latency of one iteration is what this kernel is about
+            double s0 = nz[q] * a_noise, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int j = 0; j < static_cast<int>(kRegPaths); j += 4) {
+                s0 = fma(P[q][j], av[j], s0);
+                s1 = fma(P[q][j + 1], av[j + 1], s1);
+                s2 = fma(P[q][j + 2], av[j + 2], s2);
+                s3 = fma(P[q][j + 3], av[j + 3], s3);
+            }
+            const double s = (s0 + s1) + (s2 + s3);
+            // c / s: hardware reciprocal, two Newton steps, one residual correction of the quotient
+            double y = __builtin_amdgcn_rcp(s);
+            y = fma(fma(-s, y, 1.0), y, y);
+            y = fma(fma(-s, y, 1.0), y, y);
+            const double quot = c[q] * y;
+            w[q] = valid[q] ? fma(fma(-s, quot, c[q]), y, quot) : 0.0;
+        }
+        double pn = 0.0;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) pn = fma(w[q], nz[q], pn);
+#pragma unroll
+        for (int j = 0; j < static_cast<int>(kRegPaths); ++j) {
+            double pj = 0.0;
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) pj = fma(w[q], P[q][j], pj);
+            part[j * 64 + lane] = pj;
+        }
+        const double tn = waveSumF64(pn);
+        __syncthreads();
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            t0 += mine[i];
+            t1 += mine[i + 1];
+            t2 += mine[i + 2];
+            t3 += mine[i + 3];
+        }
+        double tj = (t0 + t1) + (t2 + t3);
+        tj += quadSwapF64<1>(tj);  // lanes of a quad: DPP, no LDS round trip
+        tj += quadSwapF64<2>(tj);
+
+        int viol = 0;
+        if (owns_path || owns_noise) {
+            const double an = owns_noise ? (a_mine * tn + Z) * inv_T : (a_mine * tj) * inv_T;
+            // |an - aj| / an > eps  (src/path_abundance_estimator.cpp:73-75), without the division
+            if (an >= kMinEmAbundance && fabs(an - a_mine) > eps * an) viol = 1;
+            a_mine = an;
+            a_lds[my_col] = an;
+        }
+        const int any_viol = __any(viol);
+        __syncthreads();  // a_lds is current, part may be overwritten
+        ++iters;
+        if (!any_viol) {
+            if (++conv == kMinEmConvIts) break;
+        } else {
+            conv = 0;
+        }
+    }
+
+    // src/path_abundance_estimator.cpp:100-113
+    double low = 0.0;
+    if (owns_path) {
+        double * out = args.abundances + args.col_off[p];
+        if (a_mine < kMinEmAbundance) {
+            low = a_mine * T;
+            out[my_col] = 0;
+        } else {
+            out[my_col] = a_mine * T;
+        }
+    }
+    low = waveSumF64(low);
+    if (owns_noise) {
+        args.noise_count[p] = low + a_mine * T;
+        args.iterations[p] = iters;
+    }
+}
+
+template <int RPL>
+hipError_t launchEmRegister(const EmLaunchArgs & args, hipStream_t stream) {
+    if (args.count == 0) return hipSuccess;
+    const size_t tile = 64 * RPL * kRegPaths, part = 64 * kRegPaths;
+    const size_t lds = (std::max(tile, part) + kRegPaths + 2) * sizeof(double);
+    emRegisterKernel<RPL><<<dim3(args.count), dim3(64), lds, stream>>>(args);
+    return hipGetLastError();
+}
+
+
 // ---- Gibbs read-count sampler ----------------------------------------------------------
 //
 // gibbsReadCountSampler (src/path_abundance_estimator.cpp:116-212) for a batch of problems: per Gibbs
@@ -775,15 +948,19 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     //   1  LDS-resident, four waves    fit 40 KB
     //   2  streamed from L2, 4 waves
     //   3  streamed from L2, 16 waves  (a few giant problems)
-    constexpr int kBins = 4;
+    //   4-6 register-resident dense, one wave: at most 16 paths and 64 / 128 / 256 rows (emRegisterKernel)
+    constexpr int kBins = 7;
     std::vector<uint32_t> bins[kBins];
-    size_t bin_lds[kBins] = {0, 0, 0, 0};
+    size_t bin_lds[kBins] = {0, 0, 0, 0, 0, 0, 0};
+    static const bool use_register_kernel = std::getenv("RPVG_HIP_NO_REGISTER_EM") == nullptr;
     for (uint32_t p = 0; p < P; ++p) {
         const uint32_t C = static_cast<uint32_t>(problems->col_off[p + 1] - problems->col_off[p]) + 1;
         const uint64_t work = static_cast<uint64_t>(kept_ent[p]) + kept_rows[p];
         int b;
-        size_t lds;
-        if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 64, true)) <= 8 * 1024) {
+        size_t lds = 0;
+        if (use_register_kernel && C - 1 <= kRegPaths && kept_rows[p] <= 256) {
+            b = kept_rows[p] <= 64 ? 4 : kept_rows[p] <= 128 ? 5 : 6;
+        } else if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 64, true)) <= 8 * 1024) {
             b = 0;
         } else if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 256, true)) <= 40 * 1024) {
             b = 1;
@@ -839,20 +1016,29 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
 
     // the four bins are independent: one stream each, so a bin's tail (a tiny problem that needs
     // thousands of iterations, a giant one with many rows) overlaps the other bins
+    // The bins are independent, so their tails (a small problem that needs thousands of iterations, a giant one with
+    // many rows) should overlap — but only as many kernels run side by side as the runtime has hardware queues (4 by
+    // default): four streams, the long register-resident bins on three of them.
     span = ctx->spanBegin(FAM_EM_SPARSE);
     RPVG_HIP_CHECK(ctx->forkAux());
-    args.order = d_order.ptr + bin_start[0];
-    args.count = bins[0].size();
-    RPVG_HIP_CHECK((launchEm<64, true>(args, bin_lds[0], ctx->aux[2])));
-    args.order = d_order.ptr + bin_start[3];
-    args.count = bins[3].size();
+    auto bin = [&](const int b) {
+        args.order = d_order.ptr + bin_start[b];
+        args.count = bins[b].size();
+    };
+    bin(6);
+    RPVG_HIP_CHECK(launchEmRegister<4>(args, ctx->aux[0]));
+    bin(4);
+    RPVG_HIP_CHECK(launchEmRegister<1>(args, ctx->aux[1]));
+    bin(5);
+    RPVG_HIP_CHECK(launchEmRegister<2>(args, ctx->aux[2]));
+    bin(3);
     RPVG_HIP_CHECK((launchEm<1024, false>(args, bin_lds[3], st)));
-    args.order = d_order.ptr + bin_start[2];
-    args.count = bins[2].size();
-    RPVG_HIP_CHECK((launchEm<256, false>(args, bin_lds[2], ctx->aux[0])));
-    args.order = d_order.ptr + bin_start[1];
-    args.count = bins[1].size();
-    RPVG_HIP_CHECK((launchEm<256, true>(args, bin_lds[1], ctx->aux[1])));
+    bin(2);
+    RPVG_HIP_CHECK((launchEm<256, false>(args, bin_lds[2], st)));
+    bin(1);
+    RPVG_HIP_CHECK((launchEm<256, true>(args, bin_lds[1], ctx->aux[2])));
+    bin(0);
+    RPVG_HIP_CHECK((launchEm<64, true>(args, bin_lds[0], ctx->aux[1])));
     RPVG_HIP_CHECK(ctx->joinAux());
     ctx->spanEnd(span);
     for (int b = 0; b < kBins; ++b) ctx->stats.em_sparse_launches += bins[b].empty() ? 0 : 1;
