@@ -34,6 +34,8 @@ def lib() -> C.CDLL:
         L.rpvg_amd_engine_destroy.argtypes = [C.c_void_p]
         L.rpvg_amd_engine_ctx.restype = C.c_void_p
         L.rpvg_amd_engine_ctx.argtypes = [C.c_void_p]
+        L.rpvg_amd_engine_stats_get.argtypes = [C.c_void_p, C.c_void_p]
+        L.rpvg_amd_engine_stats_reset.argtypes = [C.c_void_p]
         L.rpvg_amd_batch_prepare.restype = C.c_void_p
         L.rpvg_amd_batch_prepare.argtypes = [C.c_void_p, C.POINTER(CClusterBatch), C.c_int]
         L.rpvg_amd_batch_free.argtypes = [C.c_void_p]
@@ -79,11 +81,13 @@ class Engine:
 
     def stats(self) -> dict:
         s = hip.CKernelStats()
-        hip._check(hip.lib().rpvg_hip_stats_get(self._ctx(), C.byref(s)), "rpvg_hip_stats_get")
+        if lib().rpvg_amd_engine_stats_get(self.handle, C.byref(s)) != 0:
+            raise hip.EngineError(f"stats failed: {_err()}")
         return s.as_dict()
 
     def reset_stats(self):
-        hip._check(hip.lib().rpvg_hip_stats_reset(self._ctx()), "rpvg_hip_stats_reset")
+        if lib().rpvg_amd_engine_stats_reset(self.handle) != 0:
+            raise hip.EngineError(f"stats reset failed: {_err()}")
 
     def info(self) -> Tuple[str, int, int]:
         name = C.create_string_buffer(256)

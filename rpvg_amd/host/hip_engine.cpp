@@ -4,14 +4,63 @@
 
 namespace rpvg_amd {
 
-HipEngine::HipEngine(const int device) : context(nullptr), device_id(device) {
+HipEngine::HipEngine(const int device) : context(nullptr), lane_context(nullptr), device_id(device) {
 
     check(rpvg_hip_create(device, &context), "rpvg_hip_create");
 }
 
 HipEngine::~HipEngine() {
 
+    second_lane.reset();
+
+    if (lane_context) {
+
+        rpvg_hip_destroy(lane_context);
+    }
+
     rpvg_hip_destroy(context);
+}
+
+int & HipEngine::currentLane() {
+
+    thread_local int lane = 0;
+    return lane;
+}
+
+void HipEngine::stats(rpvg_hip_kernel_stats * stats_out) const {
+
+    check(rpvg_hip_stats_get(context, stats_out), "rpvg_hip_stats_get");
+
+    if (lane_context) {
+
+        rpvg_hip_kernel_stats lane_stats;
+        check(rpvg_hip_stats_get(lane_context, &lane_stats), "rpvg_hip_stats_get");
+
+        stats_out->em_sparse_ms += lane_stats.em_sparse_ms;
+        stats_out->em_sparse_launches += lane_stats.em_sparse_launches;
+        stats_out->em_sparse_alg_bytes += lane_stats.em_sparse_alg_bytes;
+        stats_out->em_dense_ms += lane_stats.em_dense_ms;
+        stats_out->em_dense_launches += lane_stats.em_dense_launches;
+        stats_out->em_dense_alg_bytes += lane_stats.em_dense_alg_bytes;
+        stats_out->loglik_ms += lane_stats.loglik_ms;
+        stats_out->loglik_launches += lane_stats.loglik_launches;
+        stats_out->loglik_evals += lane_stats.loglik_evals;
+        stats_out->build_ms += lane_stats.build_ms;
+        stats_out->build_launches += lane_stats.build_launches;
+        stats_out->h2d_ms += lane_stats.h2d_ms;
+        stats_out->h2d_bytes += lane_stats.h2d_bytes;
+        stats_out->em_iterations_total += lane_stats.em_iterations_total;
+    }
+}
+
+void HipEngine::resetStats() const {
+
+    check(rpvg_hip_stats_reset(context), "rpvg_hip_stats_reset");
+
+    if (lane_context) {
+
+        check(rpvg_hip_stats_reset(lane_context), "rpvg_hip_stats_reset");
+    }
 }
 
 int HipEngine::deviceCount() {
@@ -80,6 +129,19 @@ rpvg_cluster_batch FlatClusterRows::view() const {
     batch.path_effective_length = nullptr;
 
     return batch;
+}
+
+PipelineWorker & HipEngine::secondLane() {
+
+    std::lock_guard<std::mutex> lock(lane_mutex);
+
+    if (!second_lane) {
+
+        check(rpvg_hip_create(device_id, &lane_context), "rpvg_hip_create");
+        second_lane.reset(new PipelineWorker());
+    }
+
+    return *second_lane;
 }
 
 DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch) : hip_engine(engine_in), batch(nullptr) {

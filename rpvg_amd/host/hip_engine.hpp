@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/rpvg_hip.h"
+#include "pipeline_lanes.hpp"
 #include "read_path_probabilities.hpp"
 
 namespace rpvg_amd {
@@ -34,18 +35,35 @@ class HipEngine {
         HipEngine(const HipEngine &) = delete;
         HipEngine & operator=(const HipEngine &) = delete;
 
-        rpvg_hip_ctx * ctx() const { return context; }
+        // The context of the calling host thread's lane: lane 0 (the engine's own context) unless the thread is
+        // the second lane of a pipelined batch, which has a context — streams, scratch ordering — of its own so
+        // that the kernels of the two lanes run side by side on the GPU.
+        rpvg_hip_ctx * ctx() const { return (currentLane() == 1 && lane_context) ? lane_context : context; }
         int device() const { return device_id; }
+
+        // Lane of the calling thread (thread local; 0 by default).
+        static int & currentLane();
+
+        // Kernel statistics of both lanes together (include/rpvg_hip.h, rpvg_hip_kernel_stats).
+        void stats(rpvg_hip_kernel_stats * stats_out) const;
+        void resetStats() const;
 
         static int deviceCount();
 
         // Throws EngineError carrying rpvg_hip_last_error() when status != 0.
         static void check(const int status, const char * what);
 
+        // The engine's second host lane (pipeline_lanes.hpp), started on first use.
+        PipelineWorker & secondLane();
+
     private:
 
         rpvg_hip_ctx * context;
+        rpvg_hip_ctx * lane_context;
         int device_id;
+
+        std::mutex lane_mutex;
+        std::unique_ptr<PipelineWorker> second_lane;
 };
 
 // Flat host copy of the rows of K clusters (the arrays rpvg_cluster_batch

@@ -358,6 +358,57 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
 
     reset_phase.reset();
 
+    // Two host lanes over the GPU (pipeline_lanes.hpp): the clusters arrive ordered by size, so alternating
+    // them gives two halves of equal cost; one lane's host phases run while the other waits for the device.
+    static const bool single_lane = std::getenv("RPVG_AMD_SINGLE_LANE") != nullptr;
+
+    if (single_lane || clusters.size() < 64) {
+
+        estimateClusters(path_cluster_estimates, cluster_batch, clusters, rngs);
+        return;
+    }
+
+    std::vector<uint32_t> lane_clusters[2];
+
+    for (size_t i = 0; i < clusters.size(); ++i) {
+
+        lane_clusters[i & 1].emplace_back(clusters[i]);
+    }
+
+    // several ranks on one host: the two lanes of a rank share the rank's threads
+    const char * local_world = std::getenv("LOCAL_WORLD_SIZE");
+    const int lane_threads = (local_world && std::atoi(local_world) > 1) ? std::max(4, hostThreads() / 2) : hostThreads();
+    const int outer_threads = hostThreadsOverride();
+
+    PipelineWorker & second_lane = engine->secondLane();
+
+    second_lane.submit([&]() {
+
+        hostThreadsOverride() = lane_threads;
+        HipEngine::currentLane() = 1;
+        estimateClusters(path_cluster_estimates, cluster_batch, lane_clusters[1], rngs);
+    });
+
+    hostThreadsOverride() = lane_threads;
+
+    try {
+
+        estimateClusters(path_cluster_estimates, cluster_batch, lane_clusters[0], rngs);
+
+    } catch (...) {
+
+        hostThreadsOverride() = outer_threads;
+        try { second_lane.wait(); } catch (...) {}
+        throw;
+    }
+
+    hostThreadsOverride() = outer_threads;
+    second_lane.wait();
+}
+
+// The estimator on a subset of the batch's clusters (all with at least one row).
+void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, std::vector<std::mt19937> * rngs) const {
+
     std::vector<PathSubsetWeights> path_subset_samples(clusters.size());
 
     if (infer_collapsed) {

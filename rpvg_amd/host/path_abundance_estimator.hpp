@@ -102,6 +102,8 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
         std::vector<std::vector<uint32_t> > findPathGroups(const std::vector<PathInfo> & paths) const;
         void findPathSourceGroups(GroupPosteriorProblem * problem, const std::vector<PathInfo> & paths) const;
 
+        void estimateClusters(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, std::vector<std::mt19937> * rngs) const;
+
         void pathGroupPosteriors(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, std::vector<std::mt19937> * rngs) const;
 
         void sampleGroupPathIndices(std::vector<std::vector<uint32_t> > * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<uint32_t> & group, std::mt19937 * mt_rng) const;

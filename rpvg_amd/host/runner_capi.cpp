@@ -185,6 +185,35 @@ void * rpvg_amd_engine_ctx(void * engine) {
     return static_cast<Engine *>(engine)->hip->ctx();
 }
 
+// Kernel statistics of the engine, both host lanes together.
+int rpvg_amd_engine_stats_get(void * engine, rpvg_hip_kernel_stats * stats_out) {
+
+    try {
+
+        static_cast<Engine *>(engine)->hip->stats(stats_out);
+        return 0;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
+int rpvg_amd_engine_stats_reset(void * engine) {
+
+    try {
+
+        static_cast<Engine *>(engine)->hip->resetStats();
+        return 0;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
 // Uploads the batch to the GPU.  keep_rows != 0 also keeps ReadPathProbabilities
 // objects of every cluster for the per-cluster estimate() mode.
 void * rpvg_amd_batch_prepare(void * engine, const rpvg_cluster_batch * batch, int keep_rows) {

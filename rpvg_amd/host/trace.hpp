@@ -19,7 +19,20 @@ namespace rpvg_amd {
 // Threads used by the host-side parallel loops (flattening, subset selection, merging).  These loops
 // are short; a modest team avoids waking (and then spinning) every hardware thread of a large host
 // between GPU calls.  RPVG_AMD_HOST_THREADS overrides.
+// Team size override of the calling host thread (0 = none): the two lanes of a pipelined batch
+// (pipeline_lanes.hpp) share the host's threads.
+inline int & hostThreadsOverride() {
+
+    thread_local int override_threads = 0;
+    return override_threads;
+}
+
 inline int hostThreads() {
+
+    if (hostThreadsOverride() > 0) {
+
+        return hostThreadsOverride();
+    }
 
     static const int threads = []() {
 
