@@ -4,16 +4,16 @@
 
 namespace rpvg_amd {
 
-HipEngine::HipEngine(const int device) : context(nullptr), lane_context(nullptr), device_id(device) {
+HipEngine::HipEngine(const int device) : context(nullptr), device_id(device) {
 
     check(rpvg_hip_create(device, &context), "rpvg_hip_create");
 }
 
 HipEngine::~HipEngine() {
 
-    second_lane.reset();
+    lane_workers.clear();
 
-    if (lane_context) {
+    for (auto & lane_context: lane_contexts) {
 
         rpvg_hip_destroy(lane_context);
     }
@@ -31,7 +31,7 @@ void HipEngine::stats(rpvg_hip_kernel_stats * stats_out) const {
 
     check(rpvg_hip_stats_get(context, stats_out), "rpvg_hip_stats_get");
 
-    if (lane_context) {
+    for (auto & lane_context: lane_contexts) {
 
         rpvg_hip_kernel_stats lane_stats;
         check(rpvg_hip_stats_get(lane_context, &lane_stats), "rpvg_hip_stats_get");
@@ -57,7 +57,7 @@ void HipEngine::resetStats() const {
 
     check(rpvg_hip_stats_reset(context), "rpvg_hip_stats_reset");
 
-    if (lane_context) {
+    for (auto & lane_context: lane_contexts) {
 
         check(rpvg_hip_stats_reset(lane_context), "rpvg_hip_stats_reset");
     }
@@ -131,17 +131,22 @@ rpvg_cluster_batch FlatClusterRows::view() const {
     return batch;
 }
 
-PipelineWorker & HipEngine::secondLane() {
+PipelineWorker & HipEngine::lane(const int lane) {
+
+    assert(lane >= 1 && lane < max_lanes);
 
     std::lock_guard<std::mutex> lock(lane_mutex);
 
-    if (!second_lane) {
+    while (lane_workers.size() < static_cast<size_t>(lane)) {
 
+        rpvg_hip_ctx * lane_context = nullptr;
         check(rpvg_hip_create(device_id, &lane_context), "rpvg_hip_create");
-        second_lane.reset(new PipelineWorker());
+
+        lane_contexts.emplace_back(lane_context);
+        lane_workers.emplace_back(new PipelineWorker());
     }
 
-    return *second_lane;
+    return *lane_workers.at(lane - 1);
 }
 
 DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch) : hip_engine(engine_in), batch(nullptr) {

@@ -38,7 +38,11 @@ class HipEngine {
         // The context of the calling host thread's lane: lane 0 (the engine's own context) unless the thread is
         // the second lane of a pipelined batch, which has a context — streams, scratch ordering — of its own so
         // that the kernels of the two lanes run side by side on the GPU.
-        rpvg_hip_ctx * ctx() const { return (currentLane() == 1 && lane_context) ? lane_context : context; }
+        rpvg_hip_ctx * ctx() const {
+
+            const int lane = currentLane();
+            return (lane > 0 && static_cast<size_t>(lane) <= lane_contexts.size()) ? lane_contexts[lane - 1] : context;
+        }
         int device() const { return device_id; }
 
         // Lane of the calling thread (thread local; 0 by default).
@@ -53,17 +57,20 @@ class HipEngine {
         // Throws EngineError carrying rpvg_hip_last_error() when status != 0.
         static void check(const int status, const char * what);
 
-        // The engine's second host lane (pipeline_lanes.hpp), started on first use.
-        PipelineWorker & secondLane();
+        // Host lane `lane` >= 1 of the engine (pipeline_lanes.hpp): a persistent worker thread and a device
+        // context of its own, started on first use.  Lane 0 is the calling thread with the engine's context.
+        PipelineWorker & lane(const int lane);
+
+        static constexpr int max_lanes = 4;
 
     private:
 
         rpvg_hip_ctx * context;
-        rpvg_hip_ctx * lane_context;
         int device_id;
 
         std::mutex lane_mutex;
-        std::unique_ptr<PipelineWorker> second_lane;
+        std::vector<rpvg_hip_ctx *> lane_contexts;
+        std::vector<std::unique_ptr<PipelineWorker> > lane_workers;
 };
 
 // Flat host copy of the rows of K clusters (the arrays rpvg_cluster_batch
