@@ -29,7 +29,7 @@ def counter_rows(directory):
 def total(directory, counter, kernel_substr):
     value, dispatches = 0.0, set()
     for row in counter_rows(directory):
-        if row.get("Counter_Name") != counter or kernel_substr not in row.get("Kernel_Name", ""):
+        if row.get("Counter_Name") != counter or not any(k in row.get("Kernel_Name", "") for k in kernel_substr.split(",")):
             continue
         value += float(row["Counter_Value"])
         dispatches.add(row.get("Dispatch_Id"))
@@ -40,7 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fetch-dir", required=True)
     ap.add_argument("--write-dir", required=True)
-    ap.add_argument("--kernel", required=True, help="substring of the kernel name")
+    ap.add_argument("--kernel", required=True, help="substring(s) of the kernel name, comma separated")
     ap.add_argument("--steps", type=int, required=True, help="hot-path passes (warmup + timed) the profiled command ran")
     ap.add_argument("--double-fetch", action="store_true")
     ap.add_argument("--command", default="")
