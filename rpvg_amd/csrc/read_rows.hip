@@ -40,6 +40,8 @@ struct rpvg_hip_alignments {
     std::vector<uint64_t> h_cluster_read_off;  // [K+1]
     std::vector<uint64_t> h_out_path_off;      // [K+1] output columns of each cluster (paths, or name groups)
     rpvg_hip_detail::DeviceBuffer<uint32_t> read_cluster, read_count, source_count, path_group, path_idx;
+    rpvg_hip_detail::DeviceBuffer<uint32_t> small_reads, large_reads;  // at most / more than 16 (alignment, path) entries
+    uint64_t num_small = 0, num_large = 0;
     rpvg_hip_detail::DeviceBuffer<uint64_t> cluster_path_off, cluster_read_off, read_align_off, align_path_off;
     rpvg_hip_detail::DeviceBuffer<double> eff_len;
     rpvg_hip_detail::DeviceBuffer<uint8_t> mapq;
@@ -154,13 +156,15 @@ __device__ __forceinline__ double addLogDev(const double x, const double y) {  /
     return x > y ? x + log1p(exp(y - x)) : y + log1p(exp(x - y));
 }
 
-__global__ __launch_bounds__(64 * kWavesPerBlock) void readRowKernel(const RowsIn in, const RowsScratch sc) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) void readRowKernel(const RowsIn in, const RowsScratch sc,
+                                                                    const uint64_t num_listed, const uint32_t * __restrict__ listed) {
     __shared__ double lds_mean[kWavesPerBlock][kLdsBuckets];
     __shared__ uint32_t lds_count[kWavesPerBlock][kLdsBuckets];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint64_t r = blockIdx.x * static_cast<uint64_t>(kWavesPerBlock) + wave;
-    if (r >= in.num_reads) return;
+    const uint64_t slot = blockIdx.x * static_cast<uint64_t>(kWavesPerBlock) + wave;
+    if (slot >= num_listed) return;
+    const uint64_t r = listed ? listed[slot] : slot;
     volatile double * wmean = lds_mean[wave];
     volatile uint32_t * wcount = lds_count[wave];
 
@@ -428,7 +432,168 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void readRowKernel(const RowsI
     }
 }
 
-// packs the padded per-read slices into the CSR of rpvg_cluster_batch; one wave per row.  `source` (optional)
+
+// ---- small reads: sixteen lanes per read -----------------------------------------------------------------------
+// Most reads touch a handful of paths (3.3 (alignment, path) entries on average in the configs[2] workload); a whole
+// wavefront per read then spends its time waiting on the scratch arrays between phases.  A read with at most 16 entries
+// is handled by a 16-lane group — four reads per wavefront — entirely in registers: lane = entry, then lane = unit,
+// then lane = bucket; the phases talk through width-16 shuffles and ballots.  Same arithmetic, same order of the
+// sequential bucketing, same output slices as readRowKernel (which keeps the larger reads and the collapsing mode).
+constexpr int kGroupLanes = 16;
+
+__device__ __forceinline__ uint32_t groupBallot(const bool pred, const int group_shift) {
+    return static_cast<uint32_t>((__ballot(pred) >> group_shift) & 0xffffull);
+}
+
+__global__ __launch_bounds__(256) void readRowSmallKernel(const RowsIn in, const RowsScratch sc, const uint64_t num_listed,
+                                                          const uint32_t * __restrict__ listed) {
+    const int g = threadIdx.x & (kGroupLanes - 1);                  // lane inside the group
+    const int group_shift = (threadIdx.x & 63) & ~(kGroupLanes - 1);  // first lane of the group inside the wave
+    const uint64_t slot = (blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x) / kGroupLanes;
+    const bool active = slot < num_listed;
+    const uint64_t r = active ? listed[slot] : 0;
+
+    const uint64_t a0 = in.read_align_off[r], a1 = in.read_align_off[r + 1];
+    const uint64_t e0 = in.align_path_off[a0], e1 = in.align_path_off[a1];
+    const uint32_t E = active ? static_cast<uint32_t>(e1 - e0) : 0;  // <= kGroupLanes
+    const uint8_t mapq = in.read_min_mapq[r];
+    const int32_t noise_score = in.read_noise_score[r];
+
+    // src/read_path_probabilities.cpp:89-108
+    double noise = 1.0;
+    bool has_paths = false;
+    if (active && mapq > 0) {
+        noise = fmax(in.prob_precision, fmax(in.min_noise_prob, in.phred_prob[mapq]));
+        noise += (1 - noise) * exp(noise_score * kNoiseScoreLogBase);
+        has_paths = (noise_score != 0);
+    }
+    // every lane of the wave takes part in the shuffles below: groups without work carry E = 0
+    const uint32_t n_ent = has_paths ? E : 0;
+
+    // ---- A: one entry per lane; the survivor of every path (:110-149) -------------------------------------------
+    const bool is_entry = static_cast<uint32_t>(g) < n_ent;
+    uint32_t p = kNone;
+    uint32_t al = 0;
+    double alp = 0.0, lp = 0.0;
+    uint32_t a_idx = 0;
+    bool keep = false;
+    if (is_entry) {
+        const uint64_t e = e0 + g;
+        uint64_t a = a0;
+        while (a + 1 < a1 && in.align_path_off[a + 1] <= e) ++a;
+        a_idx = static_cast<uint32_t>(a - a0);
+        p = in.align_path_idx[e];
+        al = in.align_length[a];
+        alp = sc.align_log_prob[a];
+        const double len = in.path_eff_len[in.cluster_path_off[in.read_cluster[r]] + p];
+        keep = len != 0;
+        if (keep) lp = alp - log(len);  // :126
+    }
+    for (int j = 0; j < kGroupLanes; ++j) {
+        const uint32_t pj = __shfl(p, j, kGroupLanes);
+        const uint32_t alj = __shfl(al, j, kGroupLanes);
+        const double alpj = __shfl(alp, j, kGroupLanes);
+        const uint32_t aj = __shfl(a_idx, j, kGroupLanes);
+        if (is_entry && j != g && static_cast<uint32_t>(j) < n_ent && pj == p) {
+            if (alj > al || (alj == al && (alpj > alp || (alpj == alp && aj < a_idx)))) keep = false;
+        }
+    }
+    // ---- B: ascending path order ---------------------------------------------------------------------------------
+    uint32_t rank = 0;
+    for (int j = 0; j < kGroupLanes; ++j) {
+        const uint32_t pj = __shfl(p, j, kGroupLanes);
+        const bool kj = __shfl(static_cast<int>(keep), j, kGroupLanes) != 0;
+        rank += (kj && pj < p);
+    }
+    const uint32_t T = __popc(groupBallot(keep, group_shift));
+    // unit t lives on lane t: pull (path, log prob) from the survivor whose rank is t
+    uint32_t uidx = kNone;
+    double uval = -DBL_MAX;
+    for (int j = 0; j < kGroupLanes; ++j) {
+        const bool kj = __shfl(static_cast<int>(keep), j, kGroupLanes) != 0;
+        const uint32_t rj = __shfl(rank, j, kGroupLanes);
+        const uint32_t pj = __shfl(p, j, kGroupLanes);
+        const double lpj = __shfl(lp, j, kGroupLanes);
+        if (kj && rj == static_cast<uint32_t>(g)) {
+            uidx = pj;
+            uval = lpj;
+        }
+    }
+    const bool is_unit = static_cast<uint32_t>(g) < T;
+
+    // ---- C: normalise (:170-179) ---------------------------------------------------------------------------------
+    double vmax = uval;
+    for (int d = kGroupLanes / 2; d >= 1; d >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, d, kGroupLanes));
+    double vsum = is_unit ? exp(uval - vmax) : 0.0;
+    for (int d = kGroupLanes / 2; d >= 1; d >>= 1) vsum += __shfl_xor(vsum, d, kGroupLanes);
+    const double prob = is_unit ? exp(uval - (vmax + log(vsum))) : 0.0;
+
+    // ---- D: precision buckets, sequential in unit order (:181-211); bucket b lives on lane b ----------------------
+    uint32_t nb = 0, my_bucket = kNone, b_count = 0, b_first = 0;
+    double b_mean = 0.0, low_sum = 0.0;
+    for (int t = 0; t < kGroupLanes; ++t) {
+        const double pt = __shfl(prob, t, kGroupLanes);
+        const bool exists = static_cast<uint32_t>(t) < T;  // uniform inside a group
+        const bool big = exists && pt >= in.prob_precision;
+        const bool hit = big && static_cast<uint32_t>(g) < nb && fabs(b_mean - pt) < in.prob_precision;
+        const uint32_t mask = groupBallot(hit, group_shift);
+        const uint32_t found = mask ? static_cast<uint32_t>(__ffs(mask) - 1) : nb;
+        if (big) {
+            if (static_cast<uint32_t>(g) == found) {
+                if (mask) {
+                    b_mean = (b_mean * b_count + pt) / (b_count + 1);  // running mean (:189)
+                    b_count += 1;
+                } else {
+                    b_mean = pt;
+                    b_count = 1;
+                    b_first = t;
+                }
+            }
+            if (g == t) my_bucket = found;
+            if (!mask) ++nb;
+        } else if (exists) {
+            low_sum += pt;
+        }
+    }
+
+    // ---- E: scale, order the buckets, write the read's slice (:213-219) -----------------------------------------
+    const double scale = 1 - noise;
+    const bool is_bucket = static_cast<uint32_t>(g) < nb;
+    const double m = b_mean * scale;
+    const uint32_t first_member = __shfl(uidx, static_cast<int>(b_first), kGroupLanes);
+    uint32_t brank = 0, moff = 0;
+    for (int o = 0; o < kGroupLanes; ++o) {
+        const double mo = __shfl(m, o, kGroupLanes);
+        const uint32_t fo = __shfl(first_member, o, kGroupLanes);
+        if (static_cast<uint32_t>(o) < nb && o != g && (mo < m || (mo == m && fo < first_member))) ++brank;
+    }
+    for (int o = 0; o < kGroupLanes; ++o) {
+        const uint32_t ro = __shfl(brank, o, kGroupLanes);
+        const uint32_t co = __shfl(b_count, o, kGroupLanes);
+        if (static_cast<uint32_t>(o) < nb && ro < brank) moff += co;
+    }
+    if (is_bucket) {
+        sc.grp_prob[e0 + brank] = m;
+        sc.grp_size[e0 + brank] = b_count;
+        sc.grp_moff[e0 + brank] = moff;
+    }
+    // members: unit t goes behind the earlier units of its bucket
+    const uint32_t bucket_moff = __shfl(moff, static_cast<int>(my_bucket == kNone ? 0 : my_bucket), kGroupLanes);
+    uint32_t before = 0;
+    for (int t = 0; t < kGroupLanes; ++t) {
+        const uint32_t bt = __shfl(my_bucket, t, kGroupLanes);
+        if (t < g && bt == my_bucket) ++before;
+    }
+    if (is_unit && my_bucket != kNone) sc.member[e0 + bucket_moff + before] = uidx;
+    const uint32_t n_members = __popc(groupBallot(is_unit && my_bucket != kNone, group_shift));
+    if (active && g == 0) {
+        sc.row_noise[r] = has_paths && T > 0 ? noise + low_sum * scale : noise;  // :216
+        sc.row_ngroups[r] = nb;
+        sc.row_nmembers[r] = n_members;
+    }
+}
+
+// packs the padded per-read slices into the CSR of rpvg_cluster_batch; sixteen lanes per row.  `source` (optional)
 // lists the reads to copy (the merged rows); row j of the output comes from read source[j].
 __global__ __launch_bounds__(256) void packRowsKernel(const uint64_t num_rows, const uint32_t * __restrict__ source,
                                                       const uint64_t * __restrict__ read_align_off,
@@ -437,18 +602,18 @@ __global__ __launch_bounds__(256) void packRowsKernel(const uint64_t num_rows, c
                                                       const uint64_t * __restrict__ row_member_off, double * __restrict__ row_noise,
                                                       double * __restrict__ grp_prob, uint64_t * __restrict__ grp_idx_off,
                                                       uint32_t * __restrict__ path_idx) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t j = (blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & (kGroupLanes - 1);  // sixteen lanes per row: most rows have a few groups
+    const uint64_t j = (blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x) / kGroupLanes;
     if (j >= num_rows) return;
     const uint64_t r = source ? source[j] : j;
     const uint64_t e0 = align_path_off[read_align_off[r]];
     const uint64_t g0 = row_grp_off[j], m0 = row_member_off[j];
     const uint32_t nb = sc.row_ngroups[r], nm = sc.row_nmembers[r];
-    for (uint32_t b = lane; b < nb; b += 64) {
+    for (uint32_t b = lane; b < nb; b += kGroupLanes) {
         grp_prob[g0 + b] = sc.grp_prob[e0 + b];
         grp_idx_off[g0 + b] = m0 + sc.grp_moff[e0 + b];
     }
-    for (uint32_t m = lane; m < nm; m += 64) path_idx[m0 + m] = sc.member[e0 + m];
+    for (uint32_t m = lane; m < nm; m += kGroupLanes) path_idx[m0 + m] = sc.member[e0 + m];
     if (lane == 0) {
         row_noise[j] = sc.row_noise[r];
         if (j + 1 == num_rows) grp_idx_off[g0 + nb] = m0 + nm;
@@ -568,6 +733,60 @@ __global__ __launch_bounds__(256) void sortSmallClustersKernel(const uint32_t nu
         }
     }
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) sorted[r0 + i] = ids[i];
+}
+
+// Clusters with more than kSmallSort rows: tiles of kSmallSort positions are sorted (first = true: all steps up to
+// k = kSmallSort) or finished (first = false: the steps j = kSmallSort / 2 .. 1 of the merge of width k, which stay
+// inside a tile) in LDS; only the steps that span tiles run through global memory (bitonicStepBigKernel).
+__global__ __launch_bounds__(256) void sortTilesBigKernel(const uint32_t num_tiles, const uint32_t * __restrict__ tile_cluster,
+                                                          const uint32_t * __restrict__ tile_index,
+                                                          const uint64_t * __restrict__ cluster_read_off, const RowLess less,
+                                                          const bool first, const uint32_t k_merge, uint32_t * __restrict__ sorted) {
+    __shared__ uint32_t ids[kSmallSort];
+    if (blockIdx.x >= num_tiles) return;
+    const uint32_t c = tile_cluster[blockIdx.x];
+    const uint64_t r0 = cluster_read_off[c];
+    const uint32_t n = static_cast<uint32_t>(cluster_read_off[c + 1] - r0);
+    const uint32_t base = tile_index[blockIdx.x] * kSmallSort;
+    if (base >= n) return;  // a tile of padding only
+    if (!first) {
+        uint32_t padded = kSmallSort;
+        while (padded < n) padded <<= 1;
+        if (k_merge > padded) return;  // this cluster's network is complete
+    }
+    for (uint32_t i = threadIdx.x; i < kSmallSort; i += blockDim.x) ids[i] = (base + i < n) ? sorted[r0 + base + i] : kNone;
+    __syncthreads();
+    auto exchange = [&](const uint32_t i, const uint32_t l) {
+        const uint32_t a = ids[i], b = ids[l];
+        if (b != kNone && (a == kNone || less(b, a))) {
+            ids[i] = b;
+            ids[l] = a;
+        }
+    };
+    if (first) {
+        for (uint32_t k = 2; k <= kSmallSort; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = threadIdx.x; t < (kSmallSort >> 1); t += blockDim.x) {
+                    uint32_t i, l;
+                    bitonicPair(t, k, j, &i, &l);
+                    exchange(i, l);
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        for (uint32_t j = kSmallSort >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (kSmallSort >> 1); t += blockDim.x) {
+                uint32_t i, l;
+                bitonicPair(t, k_merge, j, &i, &l);  // j < k_merge / 2: the plain (i, i + j) pairing
+                exchange(i, l);
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < kSmallSort; i += blockDim.x) {
+        if (base + i < n) sorted[r0 + base + i] = ids[i];
+    }
 }
 
 // one step (k, j) of the network for the clusters with more than kSmallSort rows: thread = (big cluster, pair)
@@ -810,8 +1029,20 @@ extern "C" int rpvg_hip_alignments_upload(rpvg_hip_ctx * ctx, const rpvg_alignme
         RPVG_HIP_CHECK(al->align_path_off.upload(in->align_path_off, A + 1, st));
         RPVG_HIP_CHECK(al->path_idx.upload(in->align_path_idx, E, st));
     }
+    {
+        std::vector<uint32_t> small_reads, large_reads;
+        for (uint64_t r = 0; r < N; ++r) {
+            const uint64_t entries = in->align_path_off[in->read_align_off[r + 1]] - in->align_path_off[in->read_align_off[r]];
+            (entries <= static_cast<uint64_t>(kGroupLanes) && !collapse ? small_reads : large_reads).push_back(static_cast<uint32_t>(r));
+        }
+        al->num_small = small_reads.size();
+        al->num_large = large_reads.size();
+        if (!small_reads.empty()) RPVG_HIP_CHECK(al->small_reads.upload(small_reads.data(), small_reads.size(), st));
+        if (!large_reads.empty()) RPVG_HIP_CHECK(al->large_reads.upload(large_reads.data(), large_reads.size(), st));
+        RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    }
     ctx->spanEnd(span);
-    ctx->stats.h2d_bytes += static_cast<double>(N) * 21 + static_cast<double>(A) * 16 + static_cast<double>(E) * 4 + static_cast<double>(P) * 8;
+    ctx->stats.h2d_bytes += static_cast<double>(N) * 25 + static_cast<double>(A) * 16 + static_cast<double>(E) * 4 + static_cast<double>(P) * 8;
     RPVG_HIP_CHECK(hipStreamSynchronize(st));  // read_cluster leaves scope
     *out_handle = al.release();
     return RPVG_HIP_OK;
@@ -942,9 +1173,20 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_hip_align
     RPVG_HIP_CHECK(hipEventRecord(ev0, st));
     int span = ctx->spanBegin(FAM_BUILD);
     alignLogProbKernel<<<gridFor(A, 256), dim3(256), 0, st>>>(A, al->score.ptr, al->frag_length.ptr, rin.frag_table, s_alp.ptr);
-    readRowKernel<<<gridFor(N, kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, st>>>(rin, sc);
+    static const bool no_small_kernel = std::getenv("RPVG_HIP_NO_SMALL_READ_KERNEL") != nullptr;
+    if (no_small_kernel) {
+        readRowKernel<<<gridFor(N, kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, st>>>(rin, sc, N, nullptr);
+    } else {
+        if (al->num_small) {
+            readRowSmallKernel<<<gridFor(al->num_small * kGroupLanes, 256), dim3(256), 0, st>>>(rin, sc, al->num_small, al->small_reads.ptr);
+        }
+        if (al->num_large) {
+            readRowKernel<<<gridFor(al->num_large, kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, st>>>(rin, sc, al->num_large,
+                                                                                                  al->large_reads.ptr);
+        }
+    }
     ctx->spanEnd(span);
-    ctx->stats.build_launches += 2;
+    ctx->stats.build_launches += 3;
     RPVG_HIP_CHECK(hipGetLastError());
     RPVG_HIP_CHECK(hipEventRecord(ev1, st));
 
@@ -998,16 +1240,31 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_hip_align
             sortSmallClustersKernel<<<dim3(static_cast<uint32_t>(small_clusters.size())), dim3(256), 0, st>>>(
                 static_cast<uint32_t>(small_clusters.size()), d_small.ptr, al->cluster_read_off.ptr, less, d_sorted.ptr);
         }
+        DeviceBuffer<uint32_t> d_tile_cluster, d_tile_index;
         if (!big_clusters.empty()) {
             RPVG_HIP_CHECK(d_big.upload(big_clusters.data(), big_clusters.size(), st));
             RPVG_HIP_CHECK(d_big_padded.upload(big_padded.data(), big_padded.size(), st));
             RPVG_HIP_CHECK(d_big_pair_off.upload(big_pair_off.data(), big_pair_off.size(), st));
             const uint32_t num_big = static_cast<uint32_t>(big_clusters.size());
-            for (uint32_t k = 2; k <= max_padded; k <<= 1) {
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            std::vector<uint32_t> tile_cluster, tile_index;
+            for (uint32_t b = 0; b < num_big; ++b) {
+                for (uint32_t t = 0; t < big_padded[b] / kSmallSort; ++t) {
+                    tile_cluster.push_back(big_clusters[b]);
+                    tile_index.push_back(t);
+                }
+            }
+            const uint32_t num_tiles = static_cast<uint32_t>(tile_cluster.size());
+            RPVG_HIP_CHECK(d_tile_cluster.upload(tile_cluster.data(), num_tiles, st));
+            RPVG_HIP_CHECK(d_tile_index.upload(tile_index.data(), num_tiles, st));
+            sortTilesBigKernel<<<dim3(num_tiles), dim3(256), 0, st>>>(num_tiles, d_tile_cluster.ptr, d_tile_index.ptr,
+                                                                     al->cluster_read_off.ptr, less, true, 0, d_sorted.ptr);
+            for (uint32_t k = 2 * kSmallSort; k <= max_padded; k <<= 1) {
+                for (uint32_t j = k >> 1; j >= kSmallSort; j >>= 1) {
                     bitonicStepBigKernel<<<gridFor(big_pair_off.back(), 256), dim3(256), 0, st>>>(
                         num_big, d_big.ptr, d_big_pair_off.ptr, d_big_padded.ptr, al->cluster_read_off.ptr, less, k, j, d_sorted.ptr);
                 }
+                sortTilesBigKernel<<<dim3(num_tiles), dim3(256), 0, st>>>(num_tiles, d_tile_cluster.ptr, d_tile_index.ptr,
+                                                                         al->cluster_read_off.ptr, less, false, k, d_sorted.ptr);
             }
         }
         RPVG_HIP_CHECK(hipGetLastError());
@@ -1086,7 +1343,7 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_hip_align
     RPVG_HIP_CHECK(out->grp_idx_off.alloc(G + 1));
     RPVG_HIP_CHECK(out->path_idx.alloc(M + 1));
     RPVG_HIP_CHECK(hipMemsetAsync(out->grp_idx_off.ptr + G, 0, sizeof(uint64_t), st));  // G == 0: the terminator is written here only
-    packRowsKernel<<<gridFor(num_out * 64, 256), dim3(256), 0, st>>>(num_out, pack_source, al->read_align_off.ptr, al->align_path_off.ptr,
+    packRowsKernel<<<gridFor(num_out * kGroupLanes, 256), dim3(256), 0, st>>>(num_out, pack_source, al->read_align_off.ptr, al->align_path_off.ptr,
                                                                     sc, out->row_grp_off.ptr, d_row_member_off.ptr, out->row_noise.ptr,
                                                                     out->grp_prob.ptr, out->grp_idx_off.ptr, out->path_idx.ptr);
     RPVG_HIP_CHECK(hipGetLastError());
