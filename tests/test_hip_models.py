@@ -326,3 +326,60 @@ def test_strains_model_matches_oracle(engine, seed):
     _compare(got, ref)
     got1, _ = engine.run("strains", make_params(), engine.prepare(batch, per_cluster=True))
     _compare(got1, ref)
+
+
+# ---- host lanes (rpvg_amd/host/pipeline_lanes.hpp) ------------------------------------------------------------------
+
+def test_batches_large_enough_for_two_lanes_match_oracle(engine):
+    """Batches of 64+ clusters are cut in two host lanes (second lane: own thread and device context); every
+    cluster must come out exactly as in the oracle's one-by-one loop, empty clusters included."""
+    clusters = small_cases.make_batch_clusters(681, n_clusters=150, max_reads=120)
+    batch = ClusterBatch.from_clusters(clusters)
+    params = make_params()
+    ref, _ = pyoracle.run("haplotype-transcripts", params, batch, 2)
+    prep = engine.prepare(batch)
+    for _ in range(3):  # the lanes are reused from call to call
+        got, _ = engine.run("haplotype-transcripts", params, prep)
+        _compare(got, ref)
+
+
+def test_an_error_in_the_second_lane_reaches_the_caller(engine):
+    from rpvg_amd import hip
+    clusters = small_cases.make_batch_clusters(682, n_clusters=100, max_reads=60, with_empty=False)
+    for p in clusters[71]["paths"]:  # an odd position: the second lane's share
+        p["source_ids"] = []
+    prep = engine.prepare(ClusterBatch.from_clusters(clusters))
+    with pytest.raises(hip.EngineError, match="source"):
+        engine.run("haplotype-transcripts", make_params(), prep)
+    # the engine and its lanes stay usable
+    good = small_cases.make_batch_clusters(683, n_clusters=80, max_reads=60)
+    batch = ClusterBatch.from_clusters(good)
+    ref, _ = pyoracle.run("haplotype-transcripts", make_params(), batch, 2)
+    got, _ = engine.run("haplotype-transcripts", make_params(), engine.prepare(batch))
+    _compare(got, ref)
+
+
+def test_lane_count_does_not_change_the_result():
+    """RPVG_AMD_LANES is read once per process: compare 1, 2 and 3 lanes in child processes."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, zlib\n"
+        "from rpvg_amd import engine as e, synth\n"
+        "from rpvg_amd.batch import make_params\n"
+        "b = synth.generate(seed=7, num_clusters=300, total_paths=9000, total_reads=300000)\n"
+        "eng = e.Engine(0)\n"
+        "est, _ = eng.run('haplotype-transcripts', make_params(), eng.prepare(b))\n"
+        "sets = sum(len(x.path_group_sets) for x in est)\n"
+        "its = sum(int(np.sum(x.em_iters)) for x in est)\n"
+        "post = np.concatenate([x.posteriors for x in est])\n"
+        "ab = np.concatenate([x.abundances for x in est])\n"
+        "print(sets, its, zlib.crc32(post.tobytes()), round(float(ab.sum()), 3))\n")
+    outs = []
+    for lanes in ("1", "2", "3"):
+        env = dict(os.environ, RPVG_AMD_LANES=lanes)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(res.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2], outs
