@@ -358,80 +358,10 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
 
     reset_phase.reset();
 
-    // Host lanes over the GPU (pipeline_lanes.hpp): the clusters arrive ordered by size, so dealing them out
-    // round robin gives parts of equal cost; one lane's host phases run while the others wait for the device.
-    static const int num_lanes = []() {
+    runInLanes(clusters, [&](const std::vector<uint32_t> & lane_clusters) {
 
-        if (std::getenv("RPVG_AMD_SINGLE_LANE")) {
-
-            return 1;
-        }
-
-        const char * env = std::getenv("RPVG_AMD_LANES");
-        return env ? std::max(1, std::min(HipEngine::max_lanes, std::atoi(env))) : 2;
-    }();
-
-    if (num_lanes == 1 || clusters.size() < 64) {
-
-        estimateClusters(path_cluster_estimates, cluster_batch, clusters, rngs);
-        return;
-    }
-
-    std::vector<std::vector<uint32_t> > lane_clusters(num_lanes);
-
-    for (size_t i = 0; i < clusters.size(); ++i) {
-
-        lane_clusters[i % num_lanes].emplace_back(clusters[i]);
-    }
-
-    // several ranks on one host: the lanes of a rank share the rank's threads
-    const char * local_world = std::getenv("LOCAL_WORLD_SIZE");
-    const int lane_threads = (local_world && std::atoi(local_world) > 1) ? std::max(4, hostThreads() / num_lanes) : hostThreads();
-    const int outer_threads = hostThreadsOverride();
-
-    for (int lane = 1; lane < num_lanes; ++lane) {
-
-        engine->lane(lane).submit([&, lane]() {
-
-            hostThreadsOverride() = lane_threads;
-            HipEngine::currentLane() = lane;
-            estimateClusters(path_cluster_estimates, cluster_batch, lane_clusters[lane], rngs);
-        });
-    }
-
-    hostThreadsOverride() = lane_threads;
-    std::exception_ptr first_error = nullptr;
-
-    try {
-
-        estimateClusters(path_cluster_estimates, cluster_batch, lane_clusters[0], rngs);
-
-    } catch (...) {
-
-        first_error = std::current_exception();
-    }
-
-    hostThreadsOverride() = outer_threads;
-
-    for (int lane = 1; lane < num_lanes; ++lane) {
-
-        try {
-
-            engine->lane(lane).wait();
-
-        } catch (...) {
-
-            if (!first_error) {
-
-                first_error = std::current_exception();
-            }
-        }
-    }
-
-    if (first_error) {
-
-        std::rethrow_exception(first_error);
-    }
+        estimateClusters(path_cluster_estimates, cluster_batch, lane_clusters, rngs);
+    });
 }
 
 // The estimator on a subset of the batch's clusters (all with at least one row).

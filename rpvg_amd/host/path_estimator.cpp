@@ -502,6 +502,85 @@ void PathEstimator::estimate(PathClusterEstimates * path_cluster_estimates, cons
     *path_cluster_estimates = std::move(batch_estimates.front());
 }
 
+// Host lanes over the GPU (pipeline_lanes.hpp): the clusters arrive ordered by size, so dealing them out round
+// robin gives parts of equal cost; one lane's host phases run while the others wait for the device, and the
+// lanes' kernels (separate device contexts) overlap each other's tails.
+void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std::function<void(const std::vector<uint32_t> &)> & work) const {
+
+    static const int num_lanes = []() {
+
+        if (std::getenv("RPVG_AMD_SINGLE_LANE")) {
+
+            return 1;
+        }
+
+        const char * env = std::getenv("RPVG_AMD_LANES");
+        return env ? std::max(1, std::min(HipEngine::max_lanes, std::atoi(env))) : 2;
+    }();
+
+    if (num_lanes == 1 || clusters.size() < 64 || HipEngine::currentLane() != 0) {
+
+        work(clusters);
+        return;
+    }
+
+    std::vector<std::vector<uint32_t> > lane_clusters(num_lanes);
+
+    for (size_t i = 0; i < clusters.size(); ++i) {
+
+        lane_clusters[i % num_lanes].emplace_back(clusters[i]);
+    }
+
+    // several ranks on one host: the lanes of a rank share the rank's threads
+    const char * local_world = std::getenv("LOCAL_WORLD_SIZE");
+    const int lane_threads = (local_world && std::atoi(local_world) > 1) ? std::max(4, hostThreads() / num_lanes) : hostThreads();
+    const int outer_threads = hostThreadsOverride();
+
+    for (int lane = 1; lane < num_lanes; ++lane) {
+
+        engine->lane(lane).submit([&, lane]() {
+
+            hostThreadsOverride() = lane_threads;
+            HipEngine::currentLane() = lane;
+            work(lane_clusters[lane]);
+        });
+    }
+
+    hostThreadsOverride() = lane_threads;
+    std::exception_ptr first_error = nullptr;
+
+    try {
+
+        work(lane_clusters[0]);
+
+    } catch (...) {
+
+        first_error = std::current_exception();
+    }
+
+    hostThreadsOverride() = outer_threads;
+
+    for (int lane = 1; lane < num_lanes; ++lane) {
+
+        try {
+
+            engine->lane(lane).wait();
+
+        } catch (...) {
+
+            if (!first_error) {
+
+                first_error = std::current_exception();
+            }
+        }
+    }
+
+    if (first_error) {
+
+        std::rethrow_exception(first_error);
+    }
+}
+
 void PathEstimator::estimateBatchSeeded(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const uint32_t rng_seed) {
 
     if (!usesRandomNumbers()) {

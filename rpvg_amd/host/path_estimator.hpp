@@ -14,6 +14,7 @@
 #define RPVG_AMD_PATH_ESTIMATOR_HPP
 
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <random>
 #include <vector>
@@ -88,6 +89,10 @@ class PathEstimator {
 
         const double prob_precision;
         const std::shared_ptr<HipEngine> engine;
+
+        // Runs `work` on `clusters` (cluster indices of a batch, ordered by size) cut into the engine's host
+        // lanes (pipeline_lanes.hpp); returns when every lane is done, rethrowing the first failure.
+        void runInLanes(const std::vector<uint32_t> & clusters, const std::function<void(const std::vector<uint32_t> &)> & work) const;
 
         // calculatePathGroupPosteriorsFull (src/path_estimator.cpp:332-377) for many
         // problems at once; log-likelihood contractions on the GPU.

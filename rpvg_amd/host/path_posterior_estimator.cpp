@@ -11,21 +11,34 @@ static const double min_rel_likelihood = 1e-8;
 
 PathPosteriorEstimator::PathPosteriorEstimator(const double prob_precision, std::shared_ptr<HipEngine> engine) : PathEstimator(prob_precision, engine) {}
 
-std::vector<GroupPosteriorProblem> PathPosteriorEstimator::rawPathProblems(const std::vector<PathClusterEstimates> & path_cluster_estimates, const DeviceClusterBatch & cluster_batch) const {
+std::vector<uint32_t> PathPosteriorEstimator::clustersWithRows(const DeviceClusterBatch & cluster_batch) {
+
+    std::vector<uint32_t> clusters;
+
+    for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
+
+        if (cluster_batch.numRows(i) > 0) {
+
+            clusters.emplace_back(i);
+        }
+    }
+
+    return clusters;
+}
+
+std::vector<GroupPosteriorProblem> PathPosteriorEstimator::rawPathProblems(const std::vector<PathClusterEstimates> & path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters) const {
 
     ScopedPhase phase("posteriors: problems");
 
     std::vector<GroupPosteriorProblem> problems;
 
-    for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
+    for (auto & i: clusters) {
 
         assert(path_cluster_estimates.at(i).paths.size() == cluster_batch.numPaths(i));
+        assert(cluster_batch.numRows(i) > 0);
 
-        if (cluster_batch.numRows(i) > 0) {
-
-            problems.emplace_back(GroupPosteriorProblem());
-            problems.back().cluster = i;
-        }
+        problems.emplace_back(GroupPosteriorProblem());
+        problems.back().cluster = i;
     }
 
     #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
@@ -53,7 +66,7 @@ void PathPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates> * p
         estimates.resetEstimates(estimates.paths.size(), 1);
     }
 
-    const auto problems = rawPathProblems(*path_cluster_estimates, cluster_batch);
+    const auto problems = rawPathProblems(*path_cluster_estimates, cluster_batch, clustersWithRows(cluster_batch));
 
     std::vector<GroupPosteriors> group_posteriors;
     calculatePathGroupPosteriorsFull(&group_posteriors, cluster_batch, problems, 1, false);
@@ -92,7 +105,16 @@ void PathGroupPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates
         }
     }
 
-    const auto problems = rawPathProblems(*path_cluster_estimates, cluster_batch);
+    runInLanes(clustersWithRows(cluster_batch), [&](const std::vector<uint32_t> & lane_clusters) {
+
+        estimateClusters(path_cluster_estimates, cluster_batch, lane_clusters, rngs);
+    });
+}
+
+// src/path_posterior_estimator.cpp:35-71 for a subset of the batch's clusters (all with at least one row).
+void PathGroupPosteriorEstimator::estimateClusters(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, std::vector<std::mt19937> * rngs) const {
+
+    const auto problems = rawPathProblems(*path_cluster_estimates, cluster_batch, clusters);
     std::vector<GroupPosteriors> group_posteriors;
 
     if (use_group_post_gibbs) {

@@ -25,7 +25,10 @@ class PathPosteriorEstimator : public PathEstimator {
         // One problem per non-empty cluster on the raw (un-normalised) probability
         // matrix: a column per path, weighted by PathInfo::source_count
         // (src/path_posterior_estimator.cpp:19-27, 45-53).
-        std::vector<GroupPosteriorProblem> rawPathProblems(const std::vector<PathClusterEstimates> & path_cluster_estimates, const DeviceClusterBatch & cluster_batch) const;
+        std::vector<GroupPosteriorProblem> rawPathProblems(const std::vector<PathClusterEstimates> & path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters) const;
+
+        // The clusters of the batch that have at least one row.
+        static std::vector<uint32_t> clustersWithRows(const DeviceClusterBatch & cluster_batch);
 };
 
 class PathGroupPosteriorEstimator : public PathPosteriorEstimator {
@@ -43,6 +46,8 @@ class PathGroupPosteriorEstimator : public PathPosteriorEstimator {
 
         const uint32_t group_size;
         const bool use_group_post_gibbs;
+
+        void estimateClusters(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, std::vector<std::mt19937> * rngs) const;
 };
 
 }
