@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cassert>
 #include <cmath>
+#include <limits>
 #include <memory>
 #include <numeric>
 
@@ -535,18 +536,65 @@ std::vector<std::vector<uint32_t> > NestedPathAbundanceEstimator::findPathGroups
 // order of their smallest source id (the reference's order is that of its hash map).
 void NestedPathAbundanceEstimator::findPathSourceGroups(GroupPosteriorProblem * problem, const std::vector<PathInfo> & paths) const {
 
-    // (source id, path) incidences as one sortable key each: grouped by source id, paths ascending
-    std::vector<uint64_t> source_paths;
+    // (source id, path) incidences as one key each, grouped by source id with the paths of an id ascending.
+    // Haplotype ids are small consecutive integers in practice: a counting sort over the id range (two passes
+    // over the incidences, which already come in ascending path order) replaces the comparison sort then.
+    size_t num_incidences = 0;
+    uint32_t min_id = std::numeric_limits<uint32_t>::max();
+    uint32_t max_id = 0;
 
-    for (size_t i = 0; i < paths.size(); ++i) {
+    for (auto & path: paths) {
 
-        for (auto & id: paths.at(i).source_ids) {
+        num_incidences += path.source_ids.size();
 
-            source_paths.emplace_back((static_cast<uint64_t>(id) << 32) | i);
+        for (auto & id: path.source_ids) {
+
+            min_id = std::min(min_id, id);
+            max_id = std::max(max_id, id);
         }
     }
 
-    std::sort(source_paths.begin(), source_paths.end());
+    std::vector<uint64_t> source_paths(num_incidences);
+
+    if (num_incidences > 0 && static_cast<uint64_t>(max_id) - min_id < 4 * static_cast<uint64_t>(num_incidences) + 1024) {
+
+        std::vector<uint32_t> first_of_id(static_cast<size_t>(max_id - min_id) + 2, 0);
+
+        for (auto & path: paths) {
+
+            for (auto & id: path.source_ids) {
+
+                first_of_id[id - min_id + 1]++;
+            }
+        }
+
+        for (size_t i = 1; i < first_of_id.size(); ++i) {
+
+            first_of_id[i] += first_of_id[i - 1];
+        }
+
+        for (size_t i = 0; i < paths.size(); ++i) {
+
+            for (auto & id: paths[i].source_ids) {
+
+                source_paths[first_of_id[id - min_id]++] = (static_cast<uint64_t>(id) << 32) | i;
+            }
+        }
+
+    } else {
+
+        size_t next = 0;
+
+        for (size_t i = 0; i < paths.size(); ++i) {
+
+            for (auto & id: paths[i].source_ids) {
+
+                source_paths[next++] = (static_cast<uint64_t>(id) << 32) | i;
+            }
+        }
+
+        std::sort(source_paths.begin(), source_paths.end());
+    }
 
     // every run of one source id is that haplotype's path list; identical lists are found through a
     // small open-addressing table keyed by a hash of the list (column = first haplotype with the list)
@@ -559,6 +607,13 @@ void NestedPathAbundanceEstimator::findPathSourceGroups(GroupPosteriorProblem * 
 
     std::vector<int32_t> table(table_size, -1);
     std::vector<uint64_t> column_hash;
+
+    // upper bounds: every haplotype its own column
+    const size_t max_columns = std::min<size_t>(num_incidences, static_cast<size_t>(max_id - min_id) + 1);
+    column_hash.reserve(max_columns);
+    problem->column_counts.reserve(max_columns);
+    problem->column_path_off.reserve(max_columns + 1);
+    problem->column_path.reserve(num_incidences);
 
     size_t run_begin = 0;
 
