@@ -340,33 +340,40 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
 
     std::vector<uint32_t> clusters;
 
-    std::unique_ptr<ScopedPhase> reset_phase(new ScopedPhase("nested: resetEstimates"));
-
-    #pragma omp parallel for schedule(static) num_threads(hostThreads())
+    // clusters without reads keep empty estimates (src/path_abundance_estimator.cpp:358-360); the others are
+    // reset by the lane that owns them, under the kernels of the lane before it
     for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
 
         assert(path_cluster_estimates->at(i).paths.size() == cluster_batch.numPaths(i));
-        path_cluster_estimates->at(i).resetEstimates(0, 0);
-    }
-
-    for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
 
         if (cluster_batch.numRows(i) > 0) {
 
             clusters.emplace_back(i);
+
+        } else {
+
+            path_cluster_estimates->at(i).resetEstimates(0, 0);
         }
     }
 
-    reset_phase.reset();
+    runInLanes(clusters, [&](const std::vector<uint32_t> & lane_clusters, const std::function<void()> & first_device_stage) {
 
-    runInLanes(clusters, [&](const std::vector<uint32_t> & lane_clusters) {
-
-        estimateClusters(path_cluster_estimates, cluster_batch, lane_clusters, rngs);
+        estimateClusters(path_cluster_estimates, cluster_batch, lane_clusters, rngs, first_device_stage);
     });
 }
 
 // The estimator on a subset of the batch's clusters (all with at least one row).
-void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, std::vector<std::mt19937> * rngs) const {
+void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, std::vector<std::mt19937> * rngs, const std::function<void()> & first_device_stage) const {
+
+    {
+        ScopedPhase reset_phase("nested: resetEstimates");
+
+        #pragma omp parallel for schedule(static) num_threads(hostThreads())
+        for (size_t i = 0; i < clusters.size(); ++i) {
+
+            path_cluster_estimates->at(clusters[i]).resetEstimates(0, 0);
+        }
+    }
 
     std::vector<PathSubsetWeights> path_subset_samples(clusters.size());
 
@@ -393,6 +400,7 @@ void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstim
         }
 
         groups_phase.reset();
+        first_device_stage();
 
         std::vector<GroupPosteriors> group_posteriors;
         pathGroupPosteriors(&group_posteriors, cluster_batch, problems, rngs);

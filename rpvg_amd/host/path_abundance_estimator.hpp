@@ -102,7 +102,7 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
         std::vector<std::vector<uint32_t> > findPathGroups(const std::vector<PathInfo> & paths) const;
         void findPathSourceGroups(GroupPosteriorProblem * problem, const std::vector<PathInfo> & paths) const;
 
-        void estimateClusters(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, std::vector<std::mt19937> * rngs) const;
+        void estimateClusters(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, std::vector<std::mt19937> * rngs, const std::function<void()> & first_device_stage) const;
 
         void pathGroupPosteriors(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, std::vector<std::mt19937> * rngs) const;
 

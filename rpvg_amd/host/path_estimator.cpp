@@ -505,7 +505,7 @@ void PathEstimator::estimate(PathClusterEstimates * path_cluster_estimates, cons
 // Host lanes over the GPU (pipeline_lanes.hpp): the clusters arrive ordered by size, so dealing them out round
 // robin gives parts of equal cost; one lane's host phases run while the others wait for the device, and the
 // lanes' kernels (separate device contexts) overlap each other's tails.
-void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std::function<void(const std::vector<uint32_t> &)> & work) const {
+void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std::function<void(const std::vector<uint32_t> &, const std::function<void()> &)> & work) const {
 
     static const int num_lanes = []() {
 
@@ -520,9 +520,11 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
 
     if (num_lanes == 1 || clusters.size() < 64 || HipEngine::currentLane() != 0) {
 
-        work(clusters);
+        work(clusters, []() {});
         return;
     }
+
+    LaneStagger stagger(num_lanes);
 
     std::vector<std::vector<uint32_t> > lane_clusters(num_lanes);
 
@@ -542,7 +544,20 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
 
             hostThreadsOverride() = lane_threads;
             HipEngine::currentLane() = lane;
-            work(lane_clusters[lane]);
+
+            stagger.waitTurn(lane);
+
+            try {
+
+                work(lane_clusters[lane], [&stagger, lane]() { stagger.passBaton(lane); });
+
+            } catch (...) {
+
+                stagger.passBaton(lane);
+                throw;
+            }
+
+            stagger.passBaton(lane);
         });
     }
 
@@ -551,12 +566,14 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
 
     try {
 
-        work(lane_clusters[0]);
+        work(lane_clusters[0], [&stagger]() { stagger.passBaton(0); });
 
     } catch (...) {
 
         first_error = std::current_exception();
     }
+
+    stagger.passBaton(0);
 
     hostThreadsOverride() = outer_threads;
 

@@ -92,7 +92,9 @@ class PathEstimator {
 
         // Runs `work` on `clusters` (cluster indices of a batch, ordered by size) cut into the engine's host
         // lanes (pipeline_lanes.hpp); returns when every lane is done, rethrowing the first failure.
-        void runInLanes(const std::vector<uint32_t> & clusters, const std::function<void(const std::vector<uint32_t> &)> & work) const;
+        // `work` receives its clusters and a callback to invoke once its first host phase is done and its first
+        // device stage is about to start: the next lane begins then (LaneStagger).
+        void runInLanes(const std::vector<uint32_t> & clusters, const std::function<void(const std::vector<uint32_t> &, const std::function<void()> &)> & work) const;
 
         // calculatePathGroupPosteriorsFull (src/path_estimator.cpp:332-377) for many
         // problems at once; log-likelihood contractions on the GPU.

@@ -105,8 +105,9 @@ void PathGroupPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates
         }
     }
 
-    runInLanes(clustersWithRows(cluster_batch), [&](const std::vector<uint32_t> & lane_clusters) {
+    runInLanes(clustersWithRows(cluster_batch), [&](const std::vector<uint32_t> & lane_clusters, const std::function<void()> & first_device_stage) {
 
+        first_device_stage();  // the host phase before the first device call is negligible here
         estimateClusters(path_cluster_estimates, cluster_batch, lane_clusters, rngs);
     });
 }

@@ -14,8 +14,52 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 namespace rpvg_amd {
+
+// Staggered start of the lanes of one batch.  Lanes that begin together stay in lock step — the same host
+// phase at the same time, then the GPU at the same time — and nothing overlaps.  Lane i therefore begins
+// only when lane i - 1 has handed its first device stage to the GPU (passBaton), which shifts the lanes by
+// one host phase against each other: from then on one lane's host work runs under the other's kernels.
+class LaneStagger {
+
+    public:
+
+        explicit LaneStagger(const int num_lanes) : released(num_lanes, false) {
+
+            released.at(0) = true;
+        }
+
+        // Blocks lane until the lane before it has passed the baton.
+        void waitTurn(const int lane) {
+
+            std::unique_lock<std::mutex> lock(mutex);
+            changed.wait(lock, [&] { return released.at(lane); });
+        }
+
+        // Lets the next lane start (idempotent; also called when a lane ends, so that a lane that fails or has
+        // nothing to hand over cannot block the others).
+        void passBaton(const int lane) {
+
+            {
+                std::lock_guard<std::mutex> lock(mutex);
+
+                if (static_cast<size_t>(lane) + 1 < released.size()) {
+
+                    released.at(lane + 1) = true;
+                }
+            }
+
+            changed.notify_all();
+        }
+
+    private:
+
+        std::mutex mutex;
+        std::condition_variable changed;
+        std::vector<bool> released;
+};
 
 class PipelineWorker {
 

@@ -5,6 +5,7 @@
 #define RPVG_AMD_TRACE_HPP
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -71,6 +72,23 @@ class PhaseTrace {
             totals()[phase] += seconds;
         }
 
+        // RPVG_AMD_TIMELINE: every phase with its start and end (ms since the first phase of the process)
+        // and the OpenMP-independent id of the host thread that ran it — who waited for whom.
+        static bool timeline() {
+
+            static const bool on = (std::getenv("RPVG_AMD_TIMELINE") != nullptr);
+            return on;
+        }
+
+        static void event(const char * phase, const std::chrono::steady_clock::time_point start, const std::chrono::steady_clock::time_point end) {
+
+            static const std::chrono::steady_clock::time_point origin = start;
+            static std::atomic<int> next_thread(0);
+            thread_local const int thread_id = next_thread++;
+
+            std::fprintf(stderr, "[timeline] thread %d %-44s %9.3f %9.3f\n", thread_id, phase, std::chrono::duration<double, std::milli>(start - origin).count(), std::chrono::duration<double, std::milli>(end - origin).count());
+        }
+
         static void report() {
 
             if (!enabled()) {
@@ -111,6 +129,11 @@ class ScopedPhase {
             if (!stopped && PhaseTrace::enabled()) {
 
                 PhaseTrace::add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count());
+            }
+
+            if (!stopped && PhaseTrace::timeline()) {
+
+                PhaseTrace::event(name, start, std::chrono::steady_clock::now());
             }
 
             stopped = true;
