@@ -152,3 +152,21 @@ def test_config1_dense_cluster_16gb():
             if d:
                 ctx.free(d)
         ctx.close()
+
+
+def test_config4_diploid_haplotype_gibbs_10m_reads_follows_the_reference_stream(engine):
+    """BASELINE.json configs[4]: -i haplotypes -y 2 --use-hap-gibbs on 10M reads x 500k paths.  The sampler keeps
+    the reference's mt19937(rng_seed + i) per cluster and libstdc++ distributions, so the sampled diplotypes and their
+    frequencies must equal the oracle's exactly, cluster by cluster."""
+    batch = synth.generate(seed=5, num_clusters=5000, total_paths=500000, total_reads=10000000, max_cluster_paths=5000)
+    assert batch.num_paths == 500000 and int(batch.row_count.sum()) == 10000000
+    params = make_params(use_hap_gibbs=1, rng_seed=11)
+    got, _ = engine.run("haplotypes", params, engine.prepare(batch))
+    ref, _ = pyoracle.run("haplotypes", params, batch, _oracle_threads())
+    assert len(got) == len(ref)
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert g.path_group_sets == r.path_group_sets, k  # same sets in the same first-visit order
+        assert np.allclose(g.posteriors, r.posteriors, rtol=0, atol=1e-12), k
+        assert g.total_count == r.total_count, k
+        if r.total_count > 0 and len(r.posteriors):
+            assert abs(g.posteriors.sum() - 1) <= 1e-9, k
