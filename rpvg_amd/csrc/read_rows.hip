@@ -936,6 +936,226 @@ hipError_t exclusiveSum(const T * in, T * out, const size_t n, hipStream_t st) {
 
 inline dim3 gridFor(const uint64_t n, const uint32_t block) { return dim3(static_cast<uint32_t>((n + block - 1) / block)); }
 
+// The per-read slices of one build (RowsScratch points into them).
+struct RowsScratchBuffers {
+    DeviceBuffer<double> alp, unit_val, tmp_val, bucket_mean, row_noise, grp_prob;
+    DeviceBuffer<uint32_t> prefix, unit_idx, tmp_idx, bucket_of, bucket_count, bucket_first, bucket_rank, bucket_cursor, ngroups,
+        nmembers, grp_size, grp_moff, member;
+
+    int alloc(const uint64_t N, const uint64_t A, const uint64_t E, const bool collapse) {
+        RPVG_HIP_CHECK(alp.alloc(A));
+        RPVG_HIP_CHECK(prefix.alloc(E + N + 1));
+        RPVG_HIP_CHECK(unit_idx.alloc(E));
+        RPVG_HIP_CHECK(unit_val.alloc(E));
+        if (collapse) {
+            RPVG_HIP_CHECK(tmp_idx.alloc(E));
+            RPVG_HIP_CHECK(tmp_val.alloc(E));
+        }
+        RPVG_HIP_CHECK(bucket_of.alloc(E));
+        RPVG_HIP_CHECK(bucket_mean.alloc(E));
+        RPVG_HIP_CHECK(bucket_count.alloc(E));
+        RPVG_HIP_CHECK(bucket_first.alloc(E));
+        RPVG_HIP_CHECK(bucket_rank.alloc(E));
+        RPVG_HIP_CHECK(bucket_cursor.alloc(E));
+        RPVG_HIP_CHECK(row_noise.alloc(N));
+        RPVG_HIP_CHECK(ngroups.alloc(N + 1));
+        RPVG_HIP_CHECK(nmembers.alloc(N + 1));
+        RPVG_HIP_CHECK(grp_prob.alloc(E));
+        RPVG_HIP_CHECK(grp_size.alloc(E));
+        RPVG_HIP_CHECK(grp_moff.alloc(E));
+        RPVG_HIP_CHECK(member.alloc(E));
+        return RPVG_HIP_OK;
+    }
+
+    RowsScratch view() const {
+        RowsScratch sc;
+        sc.align_log_prob = alp.ptr;
+        sc.surv_prefix = prefix.ptr;
+        sc.unit_idx = unit_idx.ptr;
+        sc.unit_val = unit_val.ptr;
+        sc.tmp_idx = tmp_idx.ptr;
+        sc.tmp_val = tmp_val.ptr;
+        sc.bucket_of = bucket_of.ptr;
+        sc.bucket_mean = bucket_mean.ptr;
+        sc.bucket_count = bucket_count.ptr;
+        sc.bucket_first = bucket_first.ptr;
+        sc.bucket_rank = bucket_rank.ptr;
+        sc.bucket_cursor = bucket_cursor.ptr;
+        sc.row_noise = row_noise.ptr;
+        sc.row_ngroups = ngroups.ptr;
+        sc.row_nmembers = nmembers.ptr;
+        sc.grp_prob = grp_prob.ptr;
+        sc.grp_size = grp_size.ptr;
+        sc.grp_moff = grp_moff.ptr;
+        sc.member = member.ptr;
+        return sc;
+    }
+};
+
+// The caller's sort + quickMergeIdentical (src/main.cpp:953-973) over the padded row slices: sorts the rows of every
+// cluster, finds the runs and leaves out->row_count / cluster_row_off of the merged rows; source[j] = the read whose
+// slice holds merged row j.
+int mergeRows(rpvg_hip_ctx * ctx, const rpvg_hip_alignments * al, const RowsScratch & sc, const double prob_precision,
+              rpvg_hip_read_rows * out, DeviceBuffer<uint32_t> * d_source, uint64_t * num_out) {
+    hipStream_t st = ctx->stream;
+    const uint32_t K = al->num_clusters;
+    const uint64_t N = al->num_reads;
+    RowView view;
+    view.read_cluster = al->read_cluster.ptr;
+    view.read_count = al->read_count.ptr;
+    view.read_align_off = al->read_align_off.ptr;
+    view.align_path_off = al->align_path_off.ptr;
+    view.sc = sc;
+    view.prob_precision = prob_precision;
+    const RowLess less{view};
+
+    DeviceBuffer<uint32_t> d_sorted, d_head, d_head_pos, d_run_head, d_walk, d_any, d_run_incl;
+    RPVG_HIP_CHECK(d_sorted.alloc(N));
+    RPVG_HIP_CHECK(d_head.alloc(N));
+    RPVG_HIP_CHECK(d_head_pos.alloc(N));
+    RPVG_HIP_CHECK(d_run_head.alloc(N));
+    RPVG_HIP_CHECK(d_run_incl.alloc(N));
+    RPVG_HIP_CHECK(d_walk.alloc(K));
+    RPVG_HIP_CHECK(d_any.alloc(1));
+
+    // ---- sort the rows of every cluster ------------------------------------------------------------------
+    std::vector<uint32_t> small_clusters, big_clusters, big_padded;
+    std::vector<uint64_t> big_pair_off(1, 0);
+    uint32_t max_padded = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint64_t n = al->h_cluster_read_off[k + 1] - al->h_cluster_read_off[k];
+        if (n < 2) continue;
+        if (n <= kSmallSort) {
+            small_clusters.push_back(k);
+        } else {
+            uint32_t L = kSmallSort;
+            while (L < n) L <<= 1;
+            big_clusters.push_back(k);
+            big_padded.push_back(L);
+            big_pair_off.push_back(big_pair_off.back() + L / 2);
+            max_padded = std::max(max_padded, L);
+        }
+    }
+    iotaKernel<<<gridFor(N, 256), dim3(256), 0, st>>>(N, d_sorted.ptr);
+    DeviceBuffer<uint32_t> d_small, d_big, d_big_padded;
+    DeviceBuffer<uint64_t> d_big_pair_off;
+    if (!small_clusters.empty()) {
+        RPVG_HIP_CHECK(d_small.upload(small_clusters.data(), small_clusters.size(), st));
+        sortSmallClustersKernel<<<dim3(static_cast<uint32_t>(small_clusters.size())), dim3(256), 0, st>>>(
+            static_cast<uint32_t>(small_clusters.size()), d_small.ptr, al->cluster_read_off.ptr, less, d_sorted.ptr);
+    }
+    DeviceBuffer<uint32_t> d_tile_cluster, d_tile_index;
+    if (!big_clusters.empty()) {
+        RPVG_HIP_CHECK(d_big.upload(big_clusters.data(), big_clusters.size(), st));
+        RPVG_HIP_CHECK(d_big_padded.upload(big_padded.data(), big_padded.size(), st));
+        RPVG_HIP_CHECK(d_big_pair_off.upload(big_pair_off.data(), big_pair_off.size(), st));
+        const uint32_t num_big = static_cast<uint32_t>(big_clusters.size());
+        std::vector<uint32_t> tile_cluster, tile_index;
+        for (uint32_t b = 0; b < num_big; ++b) {
+            for (uint32_t t = 0; t < big_padded[b] / kSmallSort; ++t) {
+                tile_cluster.push_back(big_clusters[b]);
+                tile_index.push_back(t);
+            }
+        }
+        const uint32_t num_tiles = static_cast<uint32_t>(tile_cluster.size());
+        RPVG_HIP_CHECK(d_tile_cluster.upload(tile_cluster.data(), num_tiles, st));
+        RPVG_HIP_CHECK(d_tile_index.upload(tile_index.data(), num_tiles, st));
+        sortTilesBigKernel<<<dim3(num_tiles), dim3(256), 0, st>>>(num_tiles, d_tile_cluster.ptr, d_tile_index.ptr,
+                                                                 al->cluster_read_off.ptr, less, true, 0, d_sorted.ptr);
+        for (uint32_t k = 2 * kSmallSort; k <= max_padded; k <<= 1) {
+            for (uint32_t j = k >> 1; j >= kSmallSort; j >>= 1) {
+                bitonicStepBigKernel<<<gridFor(big_pair_off.back(), 256), dim3(256), 0, st>>>(
+                    num_big, d_big.ptr, d_big_pair_off.ptr, d_big_padded.ptr, al->cluster_read_off.ptr, less, k, j, d_sorted.ptr);
+            }
+            sortTilesBigKernel<<<dim3(num_tiles), dim3(256), 0, st>>>(num_tiles, d_tile_cluster.ptr, d_tile_index.ptr,
+                                                                     al->cluster_read_off.ptr, less, false, k, d_sorted.ptr);
+        }
+    }
+    RPVG_HIP_CHECK(hipGetLastError());
+
+    // ---- runs ---------------------------------------------------------------------------------------------
+    adjacentHeadsKernel<<<gridFor(N, 256), dim3(256), 0, st>>>(N, view, d_sorted.ptr, d_head.ptr, d_head_pos.ptr);
+    {
+        size_t bytes = 0;
+        RPVG_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, bytes, d_head_pos.ptr, d_run_head.ptr, MaxOp(), static_cast<int>(N), st));
+        DeviceBuffer<uint8_t> tmp;
+        RPVG_HIP_CHECK(tmp.alloc(bytes ? bytes : 1));
+        RPVG_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(tmp.ptr, bytes, d_head_pos.ptr, d_run_head.ptr, MaxOp(), static_cast<int>(N), st));
+        RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    RPVG_HIP_CHECK(hipMemsetAsync(d_walk.ptr, 0, sizeof(uint32_t) * K, st));
+    RPVG_HIP_CHECK(hipMemsetAsync(d_any.ptr, 0, sizeof(uint32_t), st));
+    checkRunHeadsKernel<<<gridFor(N, 256), dim3(256), 0, st>>>(N, view, d_sorted.ptr, d_head.ptr, d_run_head.ptr, d_walk.ptr, d_any.ptr);
+    uint32_t any = 0;
+    RPVG_HIP_CHECK(hipMemcpyAsync(&any, d_any.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    if (any) {
+        walkClustersKernel<<<gridFor(K, 64), dim3(64), 0, st>>>(K, al->cluster_read_off.ptr, view, d_sorted.ptr, d_walk.ptr, d_head.ptr);
+    }
+    {
+        size_t bytes = 0;
+        RPVG_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, bytes, d_head.ptr, d_run_incl.ptr, static_cast<int>(N), st));
+        DeviceBuffer<uint8_t> tmp;
+        RPVG_HIP_CHECK(tmp.alloc(bytes ? bytes : 1));
+        RPVG_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(tmp.ptr, bytes, d_head.ptr, d_run_incl.ptr, static_cast<int>(N), st));
+        RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    uint32_t num_runs = 0;
+    RPVG_HIP_CHECK(hipMemcpyAsync(&num_runs, d_run_incl.ptr + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    *num_out = num_runs;
+    RPVG_HIP_CHECK(d_source->alloc(*num_out));
+    RPVG_HIP_CHECK(out->row_count.alloc(*num_out));
+    RPVG_HIP_CHECK(out->cluster_row_off.alloc(K + 1));
+    RPVG_HIP_CHECK(hipMemsetAsync(out->row_count.ptr, 0, sizeof(uint32_t) * *num_out, st));
+    mergeRunsKernel<<<gridFor(N, 256), dim3(256), 0, st>>>(N, view, d_sorted.ptr, d_head.ptr, d_run_incl.ptr, d_source->ptr,
+                                                         out->row_count.ptr);
+    clusterRowOffKernel<<<gridFor(K + 1, 256), dim3(256), 0, st>>>(K, N, *num_out, al->cluster_read_off.ptr, d_run_incl.ptr,
+                                                                 out->cluster_row_off.ptr);
+    RPVG_HIP_CHECK(hipGetLastError());
+    out->h_cluster_row_off.resize(K + 1);
+    RPVG_HIP_CHECK(hipMemcpyAsync(out->h_cluster_row_off.data(), out->cluster_row_off.ptr, sizeof(uint64_t) * (K + 1), hipMemcpyDeviceToHost, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));  // the sort / scan buffers above go out of scope here
+    return RPVG_HIP_OK;
+}
+
+// Packs the padded slices of the listed rows (source == nullptr: all reads in order) into the grouped CSR of `out`.
+int packRows(rpvg_hip_ctx * ctx, const rpvg_hip_alignments * al, const RowsScratch & sc, const uint32_t * pack_source,
+             const uint64_t num_rows, rpvg_hip_read_rows * out) {
+    hipStream_t st = ctx->stream;
+    DeviceBuffer<uint64_t> d_ng64, d_nm64, d_row_member_off;
+    RPVG_HIP_CHECK(d_ng64.alloc(num_rows + 1));
+    RPVG_HIP_CHECK(d_nm64.alloc(num_rows + 1));
+    RPVG_HIP_CHECK(out->row_grp_off.alloc(num_rows + 1));
+    RPVG_HIP_CHECK(d_row_member_off.alloc(num_rows + 1));
+    RPVG_HIP_CHECK(hipMemsetAsync(d_ng64.ptr, 0, sizeof(uint64_t) * (num_rows + 1), st));
+    RPVG_HIP_CHECK(hipMemsetAsync(d_nm64.ptr, 0, sizeof(uint64_t) * (num_rows + 1), st));
+    gatherSizesKernel<<<gridFor(num_rows, 256), dim3(256), 0, st>>>(num_rows, pack_source, sc.row_ngroups, sc.row_nmembers, d_ng64.ptr,
+                                                                 d_nm64.ptr);
+    RPVG_HIP_CHECK(exclusiveSum(d_ng64.ptr, out->row_grp_off.ptr, num_rows + 1, st));
+    RPVG_HIP_CHECK(exclusiveSum(d_nm64.ptr, d_row_member_off.ptr, num_rows + 1, st));
+    uint64_t totals[2] = {0, 0};
+    RPVG_HIP_CHECK(hipMemcpyAsync(&totals[0], out->row_grp_off.ptr + num_rows, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    RPVG_HIP_CHECK(hipMemcpyAsync(&totals[1], d_row_member_off.ptr + num_rows, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    const uint64_t G = totals[0], M = totals[1];
+
+    RPVG_HIP_CHECK(out->row_noise.alloc(num_rows));
+    RPVG_HIP_CHECK(out->grp_prob.alloc(G + 1));
+    RPVG_HIP_CHECK(out->grp_idx_off.alloc(G + 1));
+    RPVG_HIP_CHECK(out->path_idx.alloc(M + 1));
+    RPVG_HIP_CHECK(hipMemsetAsync(out->grp_idx_off.ptr + G, 0, sizeof(uint64_t), st));  // G == 0: the terminator is written here only
+    packRowsKernel<<<gridFor(num_rows * kGroupLanes, 256), dim3(256), 0, st>>>(num_rows, pack_source, al->read_align_off.ptr, al->align_path_off.ptr,
+                                                                    sc, out->row_grp_off.ptr, d_row_member_off.ptr, out->row_noise.ptr,
+                                                                    out->grp_prob.ptr, out->grp_idx_off.ptr, out->path_idx.ptr);
+    RPVG_HIP_CHECK(hipGetLastError());
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));  // the offset buffers above go out of scope
+    out->num_rows = num_rows;
+    out->num_groups = G;
+    out->num_members = M;
+    return RPVG_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" int rpvg_hip_alignments_upload(rpvg_hip_ctx * ctx, const rpvg_alignment_batch * in, rpvg_hip_alignments ** out_handle) {
@@ -1098,31 +1318,8 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_hip_align
     if (!prm->is_single_end) RPVG_HIP_CHECK(d_frag.upload(prm->frag_length_log_prob, RPVG_FRAG_LENGTH_TABLE_SIZE, st));
     RPVG_HIP_CHECK(d_phred.upload(phred.data(), 256, st));
 
-    // ---- scratch -------------------------------------------------------------------------------------------
-    DeviceBuffer<double> s_alp, s_unit_val, s_tmp_val, s_bucket_mean, s_row_noise, s_grp_prob;
-    DeviceBuffer<uint32_t> s_prefix, s_unit_idx, s_tmp_idx, s_bucket_of, s_bucket_count, s_bucket_first, s_bucket_rank,
-        s_bucket_cursor, s_ngroups, s_nmembers, s_grp_size, s_grp_moff, s_member;
-    RPVG_HIP_CHECK(s_alp.alloc(A));
-    RPVG_HIP_CHECK(s_prefix.alloc(E + N + 1));
-    RPVG_HIP_CHECK(s_unit_idx.alloc(E));
-    RPVG_HIP_CHECK(s_unit_val.alloc(E));
-    if (collapse) {
-        RPVG_HIP_CHECK(s_tmp_idx.alloc(E));
-        RPVG_HIP_CHECK(s_tmp_val.alloc(E));
-    }
-    RPVG_HIP_CHECK(s_bucket_of.alloc(E));
-    RPVG_HIP_CHECK(s_bucket_mean.alloc(E));
-    RPVG_HIP_CHECK(s_bucket_count.alloc(E));
-    RPVG_HIP_CHECK(s_bucket_first.alloc(E));
-    RPVG_HIP_CHECK(s_bucket_rank.alloc(E));
-    RPVG_HIP_CHECK(s_bucket_cursor.alloc(E));
-    RPVG_HIP_CHECK(s_row_noise.alloc(N));
-    RPVG_HIP_CHECK(s_ngroups.alloc(N + 1));
-    RPVG_HIP_CHECK(s_nmembers.alloc(N + 1));
-    RPVG_HIP_CHECK(s_grp_prob.alloc(E));
-    RPVG_HIP_CHECK(s_grp_size.alloc(E));
-    RPVG_HIP_CHECK(s_grp_moff.alloc(E));
-    RPVG_HIP_CHECK(s_member.alloc(E));
+    RowsScratchBuffers buffers;
+    if (const int rc = buffers.alloc(N, A, E, collapse)) return rc;
 
     RowsIn rin;
     rin.num_reads = N;
@@ -1144,26 +1341,7 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_hip_align
     rin.prob_precision = prm->prob_precision;
     rin.min_noise_prob = prm->min_noise_prob;
 
-    RowsScratch sc;
-    sc.align_log_prob = s_alp.ptr;
-    sc.surv_prefix = s_prefix.ptr;
-    sc.unit_idx = s_unit_idx.ptr;
-    sc.unit_val = s_unit_val.ptr;
-    sc.tmp_idx = s_tmp_idx.ptr;
-    sc.tmp_val = s_tmp_val.ptr;
-    sc.bucket_of = s_bucket_of.ptr;
-    sc.bucket_mean = s_bucket_mean.ptr;
-    sc.bucket_count = s_bucket_count.ptr;
-    sc.bucket_first = s_bucket_first.ptr;
-    sc.bucket_rank = s_bucket_rank.ptr;
-    sc.bucket_cursor = s_bucket_cursor.ptr;
-    sc.row_noise = s_row_noise.ptr;
-    sc.row_ngroups = s_ngroups.ptr;
-    sc.row_nmembers = s_nmembers.ptr;
-    sc.grp_prob = s_grp_prob.ptr;
-    sc.grp_size = s_grp_size.ptr;
-    sc.grp_moff = s_grp_moff.ptr;
-    sc.member = s_member.ptr;
+    const RowsScratch sc = buffers.view();
 
     // ---- rows ----------------------------------------------------------------------------------------------
     hipEvent_t ev0, ev1, ev2;
@@ -1172,7 +1350,7 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_hip_align
     RPVG_HIP_CHECK(hipEventCreate(&ev2));
     RPVG_HIP_CHECK(hipEventRecord(ev0, st));
     int span = ctx->spanBegin(FAM_BUILD);
-    alignLogProbKernel<<<gridFor(A, 256), dim3(256), 0, st>>>(A, al->score.ptr, al->frag_length.ptr, rin.frag_table, s_alp.ptr);
+    alignLogProbKernel<<<gridFor(A, 256), dim3(256), 0, st>>>(A, al->score.ptr, al->frag_length.ptr, rin.frag_table, sc.align_log_prob);
     static const bool no_small_kernel = std::getenv("RPVG_HIP_NO_SMALL_READ_KERNEL") != nullptr;
     if (no_small_kernel) {
         readRowKernel<<<gridFor(N, kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, st>>>(rin, sc, N, nullptr);
@@ -1196,122 +1374,7 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_hip_align
     const uint32_t * pack_source = nullptr;
 
     if (merge) {
-        RowView view;
-        view.read_cluster = al->read_cluster.ptr;
-        view.read_count = al->read_count.ptr;
-        view.read_align_off = al->read_align_off.ptr;
-        view.align_path_off = al->align_path_off.ptr;
-        view.sc = sc;
-        view.prob_precision = prm->prob_precision;
-        const RowLess less{view};
-
-        DeviceBuffer<uint32_t> d_sorted, d_head, d_head_pos, d_run_head, d_walk, d_any, d_run_incl;
-        RPVG_HIP_CHECK(d_sorted.alloc(N));
-        RPVG_HIP_CHECK(d_head.alloc(N));
-        RPVG_HIP_CHECK(d_head_pos.alloc(N));
-        RPVG_HIP_CHECK(d_run_head.alloc(N));
-        RPVG_HIP_CHECK(d_run_incl.alloc(N));
-        RPVG_HIP_CHECK(d_walk.alloc(K));
-        RPVG_HIP_CHECK(d_any.alloc(1));
-
-        // ---- sort the rows of every cluster ------------------------------------------------------------------
-        std::vector<uint32_t> small_clusters, big_clusters, big_padded;
-        std::vector<uint64_t> big_pair_off(1, 0);
-        uint32_t max_padded = 0;
-        for (uint32_t k = 0; k < K; ++k) {
-            const uint64_t n = al->h_cluster_read_off[k + 1] - al->h_cluster_read_off[k];
-            if (n < 2) continue;
-            if (n <= kSmallSort) {
-                small_clusters.push_back(k);
-            } else {
-                uint32_t L = kSmallSort;
-                while (L < n) L <<= 1;
-                big_clusters.push_back(k);
-                big_padded.push_back(L);
-                big_pair_off.push_back(big_pair_off.back() + L / 2);
-                max_padded = std::max(max_padded, L);
-            }
-        }
-        iotaKernel<<<gridFor(N, 256), dim3(256), 0, st>>>(N, d_sorted.ptr);
-        DeviceBuffer<uint32_t> d_small, d_big, d_big_padded;
-        DeviceBuffer<uint64_t> d_big_pair_off;
-        if (!small_clusters.empty()) {
-            RPVG_HIP_CHECK(d_small.upload(small_clusters.data(), small_clusters.size(), st));
-            sortSmallClustersKernel<<<dim3(static_cast<uint32_t>(small_clusters.size())), dim3(256), 0, st>>>(
-                static_cast<uint32_t>(small_clusters.size()), d_small.ptr, al->cluster_read_off.ptr, less, d_sorted.ptr);
-        }
-        DeviceBuffer<uint32_t> d_tile_cluster, d_tile_index;
-        if (!big_clusters.empty()) {
-            RPVG_HIP_CHECK(d_big.upload(big_clusters.data(), big_clusters.size(), st));
-            RPVG_HIP_CHECK(d_big_padded.upload(big_padded.data(), big_padded.size(), st));
-            RPVG_HIP_CHECK(d_big_pair_off.upload(big_pair_off.data(), big_pair_off.size(), st));
-            const uint32_t num_big = static_cast<uint32_t>(big_clusters.size());
-            std::vector<uint32_t> tile_cluster, tile_index;
-            for (uint32_t b = 0; b < num_big; ++b) {
-                for (uint32_t t = 0; t < big_padded[b] / kSmallSort; ++t) {
-                    tile_cluster.push_back(big_clusters[b]);
-                    tile_index.push_back(t);
-                }
-            }
-            const uint32_t num_tiles = static_cast<uint32_t>(tile_cluster.size());
-            RPVG_HIP_CHECK(d_tile_cluster.upload(tile_cluster.data(), num_tiles, st));
-            RPVG_HIP_CHECK(d_tile_index.upload(tile_index.data(), num_tiles, st));
-            sortTilesBigKernel<<<dim3(num_tiles), dim3(256), 0, st>>>(num_tiles, d_tile_cluster.ptr, d_tile_index.ptr,
-                                                                     al->cluster_read_off.ptr, less, true, 0, d_sorted.ptr);
-            for (uint32_t k = 2 * kSmallSort; k <= max_padded; k <<= 1) {
-                for (uint32_t j = k >> 1; j >= kSmallSort; j >>= 1) {
-                    bitonicStepBigKernel<<<gridFor(big_pair_off.back(), 256), dim3(256), 0, st>>>(
-                        num_big, d_big.ptr, d_big_pair_off.ptr, d_big_padded.ptr, al->cluster_read_off.ptr, less, k, j, d_sorted.ptr);
-                }
-                sortTilesBigKernel<<<dim3(num_tiles), dim3(256), 0, st>>>(num_tiles, d_tile_cluster.ptr, d_tile_index.ptr,
-                                                                         al->cluster_read_off.ptr, less, false, k, d_sorted.ptr);
-            }
-        }
-        RPVG_HIP_CHECK(hipGetLastError());
-
-        // ---- runs ---------------------------------------------------------------------------------------------
-        adjacentHeadsKernel<<<gridFor(N, 256), dim3(256), 0, st>>>(N, view, d_sorted.ptr, d_head.ptr, d_head_pos.ptr);
-        {
-            size_t bytes = 0;
-            RPVG_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, bytes, d_head_pos.ptr, d_run_head.ptr, MaxOp(), static_cast<int>(N), st));
-            DeviceBuffer<uint8_t> tmp;
-            RPVG_HIP_CHECK(tmp.alloc(bytes ? bytes : 1));
-            RPVG_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(tmp.ptr, bytes, d_head_pos.ptr, d_run_head.ptr, MaxOp(), static_cast<int>(N), st));
-            RPVG_HIP_CHECK(hipStreamSynchronize(st));
-        }
-        RPVG_HIP_CHECK(hipMemsetAsync(d_walk.ptr, 0, sizeof(uint32_t) * K, st));
-        RPVG_HIP_CHECK(hipMemsetAsync(d_any.ptr, 0, sizeof(uint32_t), st));
-        checkRunHeadsKernel<<<gridFor(N, 256), dim3(256), 0, st>>>(N, view, d_sorted.ptr, d_head.ptr, d_run_head.ptr, d_walk.ptr, d_any.ptr);
-        uint32_t any = 0;
-        RPVG_HIP_CHECK(hipMemcpyAsync(&any, d_any.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        RPVG_HIP_CHECK(hipStreamSynchronize(st));
-        if (any) {
-            walkClustersKernel<<<gridFor(K, 64), dim3(64), 0, st>>>(K, al->cluster_read_off.ptr, view, d_sorted.ptr, d_walk.ptr, d_head.ptr);
-        }
-        {
-            size_t bytes = 0;
-            RPVG_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, bytes, d_head.ptr, d_run_incl.ptr, static_cast<int>(N), st));
-            DeviceBuffer<uint8_t> tmp;
-            RPVG_HIP_CHECK(tmp.alloc(bytes ? bytes : 1));
-            RPVG_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(tmp.ptr, bytes, d_head.ptr, d_run_incl.ptr, static_cast<int>(N), st));
-            RPVG_HIP_CHECK(hipStreamSynchronize(st));
-        }
-        uint32_t num_runs = 0;
-        RPVG_HIP_CHECK(hipMemcpyAsync(&num_runs, d_run_incl.ptr + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        RPVG_HIP_CHECK(hipStreamSynchronize(st));
-        num_out = num_runs;
-        RPVG_HIP_CHECK(d_source.alloc(num_out));
-        RPVG_HIP_CHECK(out->row_count.alloc(num_out));
-        RPVG_HIP_CHECK(out->cluster_row_off.alloc(K + 1));
-        RPVG_HIP_CHECK(hipMemsetAsync(out->row_count.ptr, 0, sizeof(uint32_t) * num_out, st));
-        mergeRunsKernel<<<gridFor(N, 256), dim3(256), 0, st>>>(N, view, d_sorted.ptr, d_head.ptr, d_run_incl.ptr, d_source.ptr,
-                                                             out->row_count.ptr);
-        clusterRowOffKernel<<<gridFor(K + 1, 256), dim3(256), 0, st>>>(K, N, num_out, al->cluster_read_off.ptr, d_run_incl.ptr,
-                                                                     out->cluster_row_off.ptr);
-        RPVG_HIP_CHECK(hipGetLastError());
-        out->h_cluster_row_off.resize(K + 1);
-        RPVG_HIP_CHECK(hipMemcpyAsync(out->h_cluster_row_off.data(), out->cluster_row_off.ptr, sizeof(uint64_t) * (K + 1), hipMemcpyDeviceToHost, st));
-        RPVG_HIP_CHECK(hipStreamSynchronize(st));  // the sort / scan buffers above go out of scope here
+        if (const int rc = mergeRows(ctx, al, sc, prm->prob_precision, out.get(), &d_source, &num_out)) return rc;
         pack_source = d_source.ptr;
     } else {
         RPVG_HIP_CHECK(out->row_count.alloc(N));
@@ -1320,38 +1383,9 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_hip_align
         RPVG_HIP_CHECK(out->cluster_row_off.upload(out->h_cluster_row_off.data(), K + 1, st));
     }
 
-    // ---- pack ----------------------------------------------------------------------------------------------
-    DeviceBuffer<uint64_t> d_ng64, d_nm64, d_row_member_off;
-    RPVG_HIP_CHECK(d_ng64.alloc(num_out + 1));
-    RPVG_HIP_CHECK(d_nm64.alloc(num_out + 1));
-    RPVG_HIP_CHECK(out->row_grp_off.alloc(num_out + 1));
-    RPVG_HIP_CHECK(d_row_member_off.alloc(num_out + 1));
-    RPVG_HIP_CHECK(hipMemsetAsync(d_ng64.ptr, 0, sizeof(uint64_t) * (num_out + 1), st));
-    RPVG_HIP_CHECK(hipMemsetAsync(d_nm64.ptr, 0, sizeof(uint64_t) * (num_out + 1), st));
-    gatherSizesKernel<<<gridFor(num_out, 256), dim3(256), 0, st>>>(num_out, pack_source, s_ngroups.ptr, s_nmembers.ptr, d_ng64.ptr,
-                                                                 d_nm64.ptr);
-    RPVG_HIP_CHECK(exclusiveSum(d_ng64.ptr, out->row_grp_off.ptr, num_out + 1, st));
-    RPVG_HIP_CHECK(exclusiveSum(d_nm64.ptr, d_row_member_off.ptr, num_out + 1, st));
-    uint64_t totals[2] = {0, 0};
-    RPVG_HIP_CHECK(hipMemcpyAsync(&totals[0], out->row_grp_off.ptr + num_out, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    RPVG_HIP_CHECK(hipMemcpyAsync(&totals[1], d_row_member_off.ptr + num_out, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    RPVG_HIP_CHECK(hipStreamSynchronize(st));
-    const uint64_t G = totals[0], M = totals[1];
-
-    RPVG_HIP_CHECK(out->row_noise.alloc(num_out));
-    RPVG_HIP_CHECK(out->grp_prob.alloc(G + 1));
-    RPVG_HIP_CHECK(out->grp_idx_off.alloc(G + 1));
-    RPVG_HIP_CHECK(out->path_idx.alloc(M + 1));
-    RPVG_HIP_CHECK(hipMemsetAsync(out->grp_idx_off.ptr + G, 0, sizeof(uint64_t), st));  // G == 0: the terminator is written here only
-    packRowsKernel<<<gridFor(num_out * kGroupLanes, 256), dim3(256), 0, st>>>(num_out, pack_source, al->read_align_off.ptr, al->align_path_off.ptr,
-                                                                    sc, out->row_grp_off.ptr, d_row_member_off.ptr, out->row_noise.ptr,
-                                                                    out->grp_prob.ptr, out->grp_idx_off.ptr, out->path_idx.ptr);
-    RPVG_HIP_CHECK(hipGetLastError());
+    if (const int rc = packRows(ctx, al, sc, pack_source, num_out, out.get())) return rc;
     RPVG_HIP_CHECK(hipEventRecord(ev2, st));
     RPVG_HIP_CHECK(hipStreamSynchronize(st));  // the scratch slices go out of scope
-    out->num_rows = num_out;
-    out->num_groups = G;
-    out->num_members = M;
     float ms01 = 0, ms12 = 0;
     (void) hipEventElapsedTime(&ms01, ev0, ev1);
     (void) hipEventElapsedTime(&ms12, ev1, ev2);
