@@ -334,8 +334,8 @@ def run_rows(args, rank, local_rank, world, dist, torch):
         kernels=dict(row_kernels_ms_per_step=build_ms / args.steps, sort_merge_pack_ms_per_step=merge_ms / args.steps),
         rows_out=int(rows.num_rows), rows_match_generator=same_structure, upload_ms=upload_ms, download_ms=download_ms,
         value_including_upload_and_download=float(aligns.total_reads) / ((elapsed / args.steps) + (upload_ms + download_ms) / 1e3) * world)
-    # path clustering (PathClusters) of the same reads: every alignment's path list is one id set over
-    # global path ids; the components must refine the generator's clusters
+    # path clustering (PathClusters) of the same reads: the paths of all alignments of a read are one
+    # id set over global path ids (src/path_clusters.cpp:31-47); the components must refine the generator's clusters
     per_align = np.diff(aligns.align_path_off.astype(np.int64))
     align_read = np.repeat(np.arange(N), np.diff(aligns.read_align_off.astype(np.int64)))
     read_cluster = np.repeat(np.arange(K), np.diff(aligns.cluster_read_off.astype(np.int64)))
@@ -343,19 +343,20 @@ def run_rows(args, rank, local_rank, world, dist, torch):
     global_path = (aligns.align_path_idx.astype(np.int64) + aligns.cluster_path_off.astype(np.int64)[entry_cluster]).astype(np.uint32)
     ctx.reset_stats()
     t_cl = time.perf_counter()
-    p2c, members = ctx.path_clusters_flat(total_paths, aligns.align_path_off, global_path)
+    read_set_off = aligns.align_path_off[aligns.read_align_off.astype(np.int64)]
+    p2c, members = ctx.path_clusters_flat(total_paths, read_set_off, global_path)
     cluster_ms = (time.perf_counter() - t_cl) * 1e3
     cl_stats = ctx.stats()
     path_home = np.repeat(np.arange(K), np.diff(aligns.cluster_path_off.astype(np.int64)))
     first_home = np.full(len(members), -1, dtype=np.int64)
     first_home[p2c[::-1]] = path_home[::-1]
-    line["path_clustering"] = dict(ms=cluster_ms, union_find_kernels_ms=cl_stats["build_ms"], h2d_ms=cl_stats["h2d_ms"], paths=total_paths, id_sets=int(A), set_members=int(E), clusters_found=len(members),
+    line["path_clustering"] = dict(ms=cluster_ms, union_find_kernels_ms=cl_stats["build_ms"], h2d_ms=cl_stats["h2d_ms"], paths=total_paths, id_sets=int(N), set_members=int(E), clusters_found=len(members),
                                    refines_generator_clusters=bool(np.array_equal(first_home[p2c], path_home)),
                                    note="host arrays in / out (PCIe included): rpvg_hip_path_clusters, union-find on the GPU")
     if not args.no_cpu_baseline:
         from oracle import pyoracle
         cores = pyoracle.max_threads()
-        _, _, cl_secs = pyoracle.path_clusters_flat(total_paths, aligns.align_path_off, global_path)
+        _, _, cl_secs = pyoracle.path_clusters_flat(total_paths, read_set_off, global_path)
         line["path_clustering"]["cpu_ms"] = cl_secs * 1e3
         _, secs = pyoracle.build_rows(aligns, prm, merge=True, num_threads=cores)
         line["cpu_baseline"] = dict(value=aligns.total_reads / secs, unit="read-pairs/s", cores=cores, kind="port",

@@ -1,0 +1,91 @@
+"""The widened path end to end on the GPU: alignment-path lists over GLOBAL path ids -> path clusters
+(rpvg_hip_path_clusters) -> per-cluster alignment batch in the reference's cluster order (src/main.cpp:811-827)
+-> merged rows (rpvg_hip_read_rows_build) -> estimates, against the same pipeline on the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from rpvg_amd import engine as eng_mod, synth
+from rpvg_amd.batch import ClusterBatch, make_params
+from rpvg_amd.rows import AlignmentBatch, RowParams
+
+pytestmark = pytest.mark.gpu
+
+
+def _global_reads(batch, aligns):
+    """Every read of the generated batch as (count, mapq, noise score, [(score, align length, frag length, [global path ids])])."""
+    reads = []
+    cpo = aligns.cluster_path_off.astype(np.int64)
+    for k in range(aligns.num_clusters):
+        for r in range(int(aligns.cluster_read_off[k]), int(aligns.cluster_read_off[k + 1])):
+            al = []
+            for a in range(int(aligns.read_align_off[r]), int(aligns.read_align_off[r + 1])):
+                idx = aligns.align_path_idx[int(aligns.align_path_off[a]):int(aligns.align_path_off[a + 1])].astype(np.int64) + cpo[k]
+                al.append((int(aligns.align_score_sum[a]), int(aligns.align_length[a]), int(aligns.align_frag_length[a]), [int(x) for x in idx]))
+            reads.append((int(aligns.read_count[r]), int(aligns.read_min_mapq[r]), int(aligns.read_noise_score[r]), al))
+    return reads
+
+
+def _cluster_batches(reads, path_info, p2c, members):
+    """Reads and paths regrouped by path cluster, clusters ordered as the reference orders them (descending number of
+    alignment lists, ties by descending cluster index: src/main.cpp:811-827); returns (AlignmentBatch, path ClusterBatch)."""
+    per_cluster = [[] for _ in members]
+    for rd in reads:
+        per_cluster[int(p2c[rd[3][0][3][0]])].append(rd)
+    order = sorted(range(len(members)), key=lambda c: (-len(per_cluster[c]), -c))
+    clusters, path_clusters = [], []
+    for c in order:
+        local = {p: i for i, p in enumerate(members[c])}
+        paths = [path_info[p] for p in members[c]]
+        rds = [dict(count=cnt, min_mapq=mq, noise_score=ns,
+                    aligns=[(s, al, fl, sorted(local[p] for p in ids)) for (s, al, fl, ids) in aligns])
+               for (cnt, mq, ns, aligns) in per_cluster[c]]
+        clusters.append(dict(paths=[dict(effective_length=p["effective_length"], source_count=p["source_count"]) for p in paths], reads=rds))
+        path_clusters.append(dict(paths=paths, rows=[]))
+    return AlignmentBatch.from_clusters(clusters), ClusterBatch.from_clusters(path_clusters)
+
+
+def test_alignments_to_estimates_on_the_gpu(hip_ctx):
+    batch, aligns = synth.generate_with_alignments(seed=17, num_clusters=30, total_paths=700, total_reads=40000)
+    reads = _global_reads(batch, aligns)
+    rng = np.random.default_rng(3)
+    rng.shuffle(reads)  # the clustering must not depend on the order of the reads
+    path_info = [p for k in range(batch.num_clusters) for p in batch.cluster(k)["paths"]]
+    # one id set per read: the reference links the paths of ALL alignments of a list to the first path of its
+    # first alignment (src/path_clusters.cpp:31-47)
+    id_sets = [[p for (_, _, _, ids) in rd[3] for p in ids] for rd in reads]
+
+    p2c, members = hip_ctx.path_clusters(len(path_info), id_sets)
+    p2c_o, members_o, _ = pyoracle.path_clusters(len(path_info), id_sets)
+    assert np.array_equal(p2c, p2c_o) and members == members_o
+    home = np.repeat(np.arange(batch.num_clusters), np.diff(batch.cluster_path_off.astype(np.int64)))
+    assert all(len({int(home[p]) for p in m}) == 1 for m in members)  # components refine the generator's clusters
+
+    al_batch, path_batch = _cluster_batches(reads, path_info, p2c, members)
+    frag = pyoracle.frag_length_table(300.0, 50.0, 0.0, 10)
+    prm = RowParams(min_noise_prob=0.0, frag_length_log_prob=frag)
+
+    # CPU pipeline: oracle rows -> oracle estimates
+    rows_o, _ = pyoracle.build_rows(al_batch, prm, merge=True)
+    for name in ("path_group_id", "path_source_count", "path_source_off", "source_id", "path_effective_length"):
+        setattr(rows_o, name, getattr(path_batch, name).copy())
+    want, _ = pyoracle.run("haplotype-transcripts", make_params(), rows_o, 2)
+
+    # GPU pipeline: rows built on the device and handed to the estimators without leaving it
+    e = eng_mod.Engine(0)
+    try:
+        prep = e.prepare_from_alignments(al_batch, path_batch, frag=(300.0, 50.0, 0.0, 10), min_noise_prob=0.0)
+        got, _ = e.run("haplotype-transcripts", make_params(), prep)
+    finally:
+        e.close()
+
+    assert len(got) == len(want) == len(members)
+    assert sum(g.total_count for g in got) == 40000
+    for g, w in zip(got, want):
+        gk, wk = g.keyed(), w.keyed()
+        assert set(gk) == set(wk)
+        assert g.total_count == w.total_count
+        for key, (post, ab) in wk.items():
+            assert abs(gk[key][0] - post) <= 1e-6 * max(abs(post), 1e-8) + 1e-8
+            assert np.allclose(gk[key][1], ab, rtol=1e-6, atol=1e-8)
+        assert dict(zip(g.em_cols, g.em_iters)) == dict(zip(w.em_cols, w.em_iters))
