@@ -350,9 +350,10 @@ def run_rows(args, rank, local_rank, world, dist, torch):
     path_home = np.repeat(np.arange(K), np.diff(aligns.cluster_path_off.astype(np.int64)))
     first_home = np.full(len(members), -1, dtype=np.int64)
     first_home[p2c[::-1]] = path_home[::-1]
-    line["path_clustering"] = dict(ms=cluster_ms, union_find_kernels_ms=cl_stats["build_ms"], h2d_ms=cl_stats["h2d_ms"], paths=total_paths, id_sets=int(N), set_members=int(E), clusters_found=len(members),
+    line["path_clustering"] = dict(ms=cluster_ms, device_span_ms=cl_stats["build_ms"] + cl_stats["h2d_ms"], paths=total_paths, id_sets=int(N), set_members=int(E), clusters_found=len(members),
                                    refines_generator_clusters=bool(np.array_equal(first_home[p2c], path_home)),
-                                   note="host arrays in / out (PCIe included): rpvg_hip_path_clusters, union-find on the GPU")
+                                   note="host arrays in / out: rpvg_hip_path_clusters (union-find on the GPU); device_span_ms includes the pageable "
+                                        "H2D copies, the union-find kernel itself is ~1.5 ms (profiles/r01/rocprofv3_rows_kernel_stats.csv)")
     if not args.no_cpu_baseline:
         from oracle import pyoracle
         cores = pyoracle.max_threads()

@@ -20,7 +20,8 @@ __device__ __forceinline__ uint32_t findRoot(uint32_t * parent, uint32_t x) {
     uint32_t p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (p != x) {
         const uint32_t gp = __hip_atomic_load(parent + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gp != p) atomicMin(parent + x, gp);  // path halving; parents only ever decrease
+        // path halving with a plain store: any ancestor is a valid parent, so racing halvings cannot break the forest
+        if (gp != p) __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = p;
         p = gp;
     }
@@ -32,29 +33,28 @@ __global__ void initParentKernel(const uint32_t n, uint32_t * parent) {
     if (i < n) parent[i] = i;
 }
 
-// one thread per set member: joins it with the first member of its set (the reference's anchor, :31-47)
-__global__ void unionSetsKernel(const uint64_t num_members, const uint64_t num_sets, const uint64_t * __restrict__ set_off,
+// one thread per id set: joins every member with the first one (the reference's anchor, :31-47); sets are short
+// (the paths one read aligns to), a few hundred members at most
+__global__ void unionSetsKernel(const uint64_t num_sets, const uint64_t * __restrict__ set_off,
                                 const uint32_t * __restrict__ set_path, uint32_t * parent) {
-    const uint64_t e = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (e >= num_members) return;
-    uint64_t lo = 0, hi = num_sets - 1;  // last set whose first member is <= e
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi + 1) >> 1;
-        if (set_off[mid] <= e) lo = mid; else hi = mid - 1;
-    }
-    const uint64_t first = set_off[lo];
-    if (e == first) return;
-    uint32_t a = set_path[first], b = set_path[e];
-    while (true) {
-        a = findRoot(parent, a);
-        b = findRoot(parent, b);
-        if (a == b) return;
-        if (a > b) {
-            const uint32_t t = a;
-            a = b;
-            b = t;
+    const uint64_t s = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (s >= num_sets) return;
+    const uint64_t first = set_off[s], last = set_off[s + 1];
+    uint32_t anchor = set_path[first];
+    for (uint64_t e = first + 1; e < last; ++e) {
+        uint32_t a = anchor, b = set_path[e];
+        while (true) {
+            a = findRoot(parent, a);
+            b = findRoot(parent, b);
+            if (a == b) break;
+            if (a > b) {
+                const uint32_t t = a;
+                a = b;
+                b = t;
+            }
+            if (atomicCAS(parent + b, b, a) == b) break;  // b was still a root: hooked under the smaller root
         }
-        if (atomicCAS(parent + b, b, a) == b) return;  // b was still a root: hooked under the smaller root
+        anchor = a;  // the current root: shorter walks for the next member
     }
 }
 
@@ -122,8 +122,8 @@ extern "C" int rpvg_hip_path_clusters(rpvg_hip_ctx * ctx, uint32_t num_paths, ui
     span = ctx->spanBegin(FAM_BUILD);
     initParentKernel<<<grid_n, block, 0, st>>>(n, d_parent.ptr);
     if (num_members) {
-        unionSetsKernel<<<dim3(static_cast<uint32_t>((num_members + 255) / 256)), block, 0, st>>>(num_members, num_sets, d_set_off.ptr,
-                                                                                               d_set_path.ptr, d_parent.ptr);
+        unionSetsKernel<<<dim3(static_cast<uint32_t>((num_sets + 255) / 256)), block, 0, st>>>(num_sets, d_set_off.ptr, d_set_path.ptr,
+                                                                                            d_parent.ptr);
     }
     flattenKernel<<<grid_n, block, 0, st>>>(n, d_parent.ptr, d_is_root.ptr);
     ctx->spanEnd(span);
