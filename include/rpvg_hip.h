@@ -275,6 +275,10 @@ int rpvg_hip_synth_dense_cluster(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t num
 int rpvg_hip_synth_dense_rows(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t row_begin, uint64_t num_rows, uint32_t num_paths,
                               double * device_matrix, uint64_t ld, double * device_counts);
 
+/* Test hook: the FP64 logarithm of the log-likelihood kernels (positive normal x) evaluated on the device,
+ * with (use_table != 0) or without the LDS table — tests/test_hip_kernels.py measures its error. */
+int rpvg_hip_debug_log(rpvg_hip_ctx * ctx, uint64_t n, const double * x, double * out, int32_t use_table);
+
 /* ---- instrumentation ----------------------------------------------------- */
 /* Device time (HIP events on the context's stream) and launch count of the
  * kernels of each family since the last reset, plus the algorithmic bytes

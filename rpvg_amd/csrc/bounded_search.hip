@@ -109,18 +109,18 @@ struct SearchArgs {
 };
 
 // sum_i count_i * log(base_i + col_i / 2) over rows [lane, n) step 64, four independent chains in flight
-__device__ __forceinline__ double pairRowSum(const double * __restrict__ cnt, const double * __restrict__ base,
+__device__ __forceinline__ double pairRowSum(const LogTableEntry * lt, const double * __restrict__ cnt, const double * __restrict__ base,
                                              const double * __restrict__ col, const uint32_t n, const int lane) {
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
     uint32_t i = lane;
     for (; i + 192 < n; i += 256) {
         const double x0 = col[i], x1 = col[i + 64], x2 = col[i + 128], x3 = col[i + 192];
-        acc0 = fma(cnt[i], logPositive(base[i] + x0 / 2.0), acc0);
-        acc1 = fma(cnt[i + 64], logPositive(base[i + 64] + x1 / 2.0), acc1);
-        acc2 = fma(cnt[i + 128], logPositive(base[i + 128] + x2 / 2.0), acc2);
-        acc3 = fma(cnt[i + 192], logPositive(base[i + 192] + x3 / 2.0), acc3);
+        acc0 = fma(cnt[i], logPositive(base[i] + x0 / 2.0, lt), acc0);
+        acc1 = fma(cnt[i + 64], logPositive(base[i + 64] + x1 / 2.0, lt), acc1);
+        acc2 = fma(cnt[i + 128], logPositive(base[i + 128] + x2 / 2.0, lt), acc2);
+        acc3 = fma(cnt[i + 192], logPositive(base[i + 192] + x3 / 2.0, lt), acc3);
     }
-    for (; i < n; i += 64) acc0 = fma(cnt[i], logPositive(base[i] + col[i] / 2.0), acc0);
+    for (; i < n; i += 64) acc0 = fma(cnt[i], logPositive(base[i] + col[i] / 2.0, lt), acc0);
     return (acc0 + acc1) + (acc2 + acc3);
 }
 
@@ -132,8 +132,10 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
     double * lds_count = lds_dyn + args.stage_rows;
     __shared__ double lds_red[kBlock / 64];
     __shared__ unsigned long long lds_sum;
+    __shared__ LogTableEntry lt[kLogTableSize];
 
     if (blockIdx.x >= args.count) return;
+    loadLogTable(lt);  // visible after the first barrier below
     const uint32_t m = args.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t R = args.mat_rows[m];
@@ -174,8 +176,8 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
         double acc1 = 0.0, acc2 = 0.0;
         for (uint64_t i = lane; i < R; i += 64) {
             const double x = col[i], n = nz[i], c = cnt[i];
-            acc1 = fma(c, logPositive(n + x / 1.0), acc1);
-            acc2 = fma(c, logPositive((n + x / 2.0) + rm[i] / 2.0), acc2);
+            acc1 = fma(c, logPositive(n + x / 1.0, lt), acc1);
+            acc2 = fma(c, logPositive((n + x / 2.0) + rm[i] / 2.0, lt), acc2);
         }
         acc1 = waveSum(acc1);
         acc2 = waveSum(acc2);
@@ -230,16 +232,16 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
         for (uint32_t j = pos + wave; j < G; j += kWaves) {
             const uint32_t b = ord[j];
             const double * col_b = M + static_cast<uint64_t>(b) * R;
-            double acc = pairRowSum(lds_count, lds_base, col_b, staged, lane);
+            double acc = pairRowSum(lt, lds_count, lds_base, col_b, staged, lane);
             {
                 double t0 = 0.0, t1 = 0.0;
                 uint64_t i = staged + lane;
                 for (; i + 64 < R; i += 128) {
                     const double xa0 = col_a[i], xa1 = col_a[i + 64], xb0 = col_b[i], xb1 = col_b[i + 64];
-                    t0 = fma(cnt[i], logPositive((nz[i] + xa0 / 2.0) + xb0 / 2.0), t0);
-                    t1 = fma(cnt[i + 64], logPositive((nz[i + 64] + xa1 / 2.0) + xb1 / 2.0), t1);
+                    t0 = fma(cnt[i], logPositive((nz[i] + xa0 / 2.0) + xb0 / 2.0, lt), t0);
+                    t1 = fma(cnt[i + 64], logPositive((nz[i + 64] + xa1 / 2.0) + xb1 / 2.0, lt), t1);
                 }
-                for (; i < R; i += 64) t0 = fma(cnt[i], logPositive((nz[i] + col_a[i] / 2.0) + col_b[i] / 2.0), t0);
+                for (; i < R; i += 64) t0 = fma(cnt[i], logPositive((nz[i] + col_a[i] / 2.0) + col_b[i] / 2.0, lt), t0);
                 acc += t0 + t1;
             }
             acc = waveSum(acc);
@@ -321,9 +323,11 @@ struct TableWork {
 __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
     __shared__ double lds_base[kTileA][kChunkRows];
     __shared__ double lds_count[kChunkRows];
+    __shared__ LogTableEntry lt[kLogTableSize];
     const uint32_t per_xcd = (w.count + 7) / 8;
     const uint32_t item = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (item >= w.count) return;
+    loadLogTable(lt);  // visible after the barrier that publishes the staged rows
     const uint32_t m = w.item_matrix[item], a0 = w.item_col[item], chunk = w.item_chunk[item];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t R = w.mat_rows[m];
@@ -355,10 +359,10 @@ __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
             double acc0 = 0.0, acc1 = 0.0;
             uint32_t i = lane;
             for (; i + 64 < n; i += 128) {
-                acc0 = fma(lds_count[i], logPositive(nz[i] + col_a[i] / 1.0), acc0);
-                acc1 = fma(lds_count[i + 64], logPositive(nz[i + 64] + col_a[i + 64] / 1.0), acc1);
+                acc0 = fma(lds_count[i], logPositive(nz[i] + col_a[i] / 1.0, lt), acc0);
+                acc1 = fma(lds_count[i + 64], logPositive(nz[i + 64] + col_a[i + 64] / 1.0, lt), acc1);
             }
-            for (; i < n; i += 64) acc0 = fma(lds_count[i], logPositive(nz[i] + col_a[i] / 1.0), acc0);
+            for (; i < n; i += 64) acc0 = fma(lds_count[i], logPositive(nz[i] + col_a[i] / 1.0, lt), acc0);
             const double acc = waveSum(acc0 + acc1);
             if (lane == 0) w.part_marginal[w.big_col_part_off[m] + static_cast<uint64_t>(chunk) * G + a] = acc;
         } else {
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
             for (uint32_t i = lane; i < n; i += 64) {
                 const double x = col_b[i] / 2.0, c = lds_count[i];
 #pragma unroll
-                for (int t = 0; t < kTileA; ++t) acc[t] = fma(c, logPositive(lds_base[t][i] + x), acc[t]);
+                for (int t = 0; t < kTileA; ++t) acc[t] = fma(c, logPositive(lds_base[t][i] + x, lt), acc[t]);
             }
 #pragma unroll
             for (int t = 0; t < kTileA; ++t) {

@@ -99,6 +99,14 @@ struct HostScope {
 // latency each, 6 steps).  DPP moves stay in the SIMD: quad_perm x2, row_half_mirror, row_mirror give
 // every lane the sum of its row of 16; the four row sums are then read with v_readlane and added.
 // The result is uniform across the wave.  Summation order is fixed (deterministic).
+// entry of the logarithm table (logPositive with a table, below)
+struct LogTableEntry {
+    float rc;
+    float lo;
+    double hi;
+};
+constexpr int kLogTableSize = 129;
+
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int CTRL>
 __device__ __forceinline__ double dppAddF64(const double v) {
@@ -154,9 +162,42 @@ __device__ __forceinline__ double logPositive(const double x) {
     const double dk = static_cast<double>(k);
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
+
+// The same logarithm without the reciprocal: x = 2^k m with m in [0.5, 1); entry i = round((m - 0.5) * 256) of a
+// 129-entry table (in the workgroup's LDS) holds rc ~ 1 / (0.5 + i/256) as a float and -log(rc) as hi + lo, so that
+// log m = hi + lo + log1p(r) exactly for r = m * rc - 1, |r| <= 2^-8, and log1p is a degree-7 polynomial.
+// ~21 instructions and one 16-byte LDS read; the absolute error stays below 2e-16 and the relative error below
+// 1 ulp away from x ~ 1+ (k = 1, i = 0), where hi and k ln2 cancel and the float `lo` leaves ~1e-17 absolute.
+static __device__ const LogTableEntry kLogTable[kLogTableSize] = {
+#include "log_table.inc"
+};
+
+// Copies the table into the workgroup's LDS; every thread of the block calls it, a __syncthreads() follows.
+__device__ __forceinline__ void loadLogTable(LogTableEntry * lds_table) {
+    for (int i = threadIdx.x; i < kLogTableSize; i += blockDim.x) lds_table[i] = kLogTable[i];
+}
+
+__device__ __forceinline__ double logPositive(const double x, const LogTableEntry * lds_table) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    const int k = __builtin_amdgcn_frexp_exp(x);
+    const int i = static_cast<int>(fma(m, 256.0, -127.5));
+    const LogTableEntry e = lds_table[i];
+    const double r = fma(m, static_cast<double>(e.rc), -1.0);
+    double q = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    q = fma(r, q, 0.2);
+    q = fma(r, q, -0.25);
+    q = fma(r, q, 1.0 / 3.0);
+    q = fma(r, q, -0.5);
+    const double p = fma(r * r, q, r);
+    const double dk = static_cast<double>(k);
+    return fma(dk, ln2_hi, e.hi) + (fma(dk, ln2_lo, static_cast<double>(e.lo)) + p);
+}
 #else
 __device__ double waveSumF64(double v);  // host compilation pass: declarations only
 __device__ double logPositive(double x);
+__device__ double logPositive(double x, const LogTableEntry * lds_table);
+__device__ void loadLogTable(LogTableEntry * lds_table);
 #endif
 
 // ---- kernel-family timing ---------------------------------------------------

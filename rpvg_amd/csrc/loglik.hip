@@ -206,6 +206,9 @@ __global__ __launch_bounds__(256) void groupLoglikKernel(
     const uint64_t * __restrict__ mat_row_off, const uint64_t * __restrict__ mat_row0,
     const uint64_t * __restrict__ mat_rows, const double * __restrict__ values, const double * __restrict__ rowmax,
     const double * __restrict__ row_count, const double * __restrict__ row_noise, double * __restrict__ out) {
+    __shared__ LogTableEntry lt[kLogTableSize];
+    loadLogTable(lt);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (q >= num_requests) return;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void groupLoglikKernel(
         for (int w = 0; w < WIDTH; ++w)
             if (col[w]) v += col[w][i] / divisor;
         if (rm) v += rm[i] / divisor;
-        acc = fma(cnt[i], logPositive(v), acc);
+        acc = fma(cnt[i], logPositive(v, lt), acc);
     }
     acc = waveSumF64(acc);
     if (lane == 0) out[q] = acc;
@@ -247,6 +250,9 @@ __global__ __launch_bounds__(256) void groupConditionalKernel(
     const uint32_t * __restrict__ mat_cols, const double * __restrict__ values, const double * __restrict__ row_count,
     const double * __restrict__ row_noise, double * __restrict__ out) {
     constexpr int kCand = 4;
+    __shared__ LogTableEntry lt[kLogTableSize];
+    loadLogTable(lt);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint64_t item = (blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x) >> 6;
     if (item >= num_items) return;
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(256) void groupConditionalKernel(
         for (int w = 0; w + 1 < WIDTH; ++w) base += other[w][i] / divisor;
         const double c_i = cnt[i];
 #pragma unroll
-        for (int c = 0; c < kCand; ++c) acc[c] = fma(c_i, logPositive(base + cand[c][i] / divisor), acc[c]);
+        for (int c = 0; c < kCand; ++c) acc[c] = fma(c_i, logPositive(base + cand[c][i] / divisor, lt), acc[c]);
     }
 #pragma unroll
     for (int c = 0; c < kCand; ++c) {
@@ -285,7 +291,30 @@ __global__ __launch_bounds__(256) void groupConditionalKernel(
     }
 }
 
+__global__ void debugLogKernel(const uint64_t n, const double * __restrict__ x, double * __restrict__ out, const int use_table) {
+    __shared__ LogTableEntry lt[kLogTableSize];
+    loadLogTable(lt);
+    __syncthreads();
+    const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (i < n) out[i] = use_table ? logPositive(x[i], lt) : logPositive(x[i]);
+}
+
 }  // namespace
+
+extern "C" int rpvg_hip_debug_log(rpvg_hip_ctx * ctx, uint64_t n, const double * x, double * out, int32_t use_table) {
+    RPVG_REQUIRE(ctx && x && out, "rpvg_hip_debug_log: NULL argument");
+    if (n == 0) return RPVG_HIP_OK;
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    DeviceBuffer<double> d_x, d_out;
+    RPVG_HIP_CHECK(d_x.upload(x, n, ctx->stream));
+    RPVG_HIP_CHECK(d_out.alloc(n));
+    debugLogKernel<<<dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(n, d_x.ptr, d_out.ptr, use_table);
+    RPVG_HIP_CHECK(hipGetLastError());
+    RPVG_HIP_CHECK(d_out.download(out, ctx->stream));
+    RPVG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RPVG_HIP_OK;
+}
 
 extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec,
                                      rpvg_hip_groups ** groups_out) {

@@ -27,7 +27,7 @@ EXPORTS = [
     "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
     "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_group_conditionals",
     "rpvg_hip_alignments_upload", "rpvg_hip_alignments_free", "rpvg_hip_read_rows_build", "rpvg_hip_read_rows_to_batch",
-    "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_sizes", "rpvg_hip_read_rows_free", "rpvg_hip_path_clusters",
+    "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_sizes", "rpvg_hip_read_rows_free", "rpvg_hip_path_clusters", "rpvg_hip_debug_log",
 ]
 
 COMM_ID_BYTES = 128  # RPVG_HIP_COMM_ID_BYTES
@@ -440,6 +440,13 @@ class Context:
         k = nc.value
         members = [cpaths[int(coff[c]):int(coff[c + 1])].tolist() for c in range(k)]
         return p2c[:num_paths].copy(), members
+
+    def debug_log(self, x: np.ndarray, use_table: bool = True) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros_like(x)
+        _check(lib().rpvg_hip_debug_log(self.handle, C.c_uint64(x.size), C.c_void_p(x.ctypes.data), C.c_void_p(out.ctypes.data),
+                                        C.c_int32(1 if use_table else 0)), "rpvg_hip_debug_log")
+        return out
 
     # ---- stats ----------------------------------------------------------------
     def stats(self) -> dict:

@@ -267,6 +267,26 @@ def test_one_rank_communicator_row_sharded_em(hip_ctx, R, N):
         ctx.close()
 
 
+@pytest.mark.parametrize("use_table", [False, True])
+def test_device_logarithm_accuracy(hip_ctx, use_table):
+    """The FP64 log of the log-likelihood kernels against extended precision: at most ~1 ulp over the arguments the
+    kernels see (probabilities in (1e-8, 1], and up to 2 for the un-normalised raw matrices), and an absolute error
+    below 2e-16 right above 1 where the table version trades relative for absolute accuracy."""
+    rng = np.random.default_rng(77)
+    x = np.concatenate([10.0 ** rng.uniform(-9, 0, 200000), rng.uniform(0.4, 1.0, 200000), rng.uniform(1.0, 2.0, 100000),
+                        1 - 10.0 ** rng.uniform(-16, -3, 20000), 1 + 10.0 ** rng.uniform(-16, -3, 20000),
+                        [1.0, 0.5, 0.25, 2.0, 1e-8, 0.70710678118654752]])
+    got = hip_ctx.debug_log(x, use_table)
+    ref_ld = np.log(x.astype(np.longdouble))
+    ref = ref_ld.astype(np.float64)
+    err = np.abs(got.astype(np.longdouble) - ref_ld).astype(np.float64)
+    ulp = np.spacing(np.maximum(np.abs(ref), 1e-300))
+    away = (x < 1.0) | (x > 1.002)
+    assert float((err[away] / ulp[away]).max()) < 1.6, float((err[away] / ulp[away]).max())
+    assert float(err.max()) < 2.2e-16 * max(1.0, float(np.abs(ref).max()))
+    assert abs(got[np.where(x == 1.0)[0][0]]) < 1e-19
+
+
 # ---- group log-likelihoods ------------------------------------------------------------
 
 @pytest.mark.parametrize("normalise", [False, True])
