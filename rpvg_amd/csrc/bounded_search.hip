@@ -664,6 +664,19 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         std::copy(small.begin(), small.end(), order.begin() + num_big + num_medium);
     }
 
+    if (std::getenv("RPVG_HIP_SEARCH_CLASSES")) {
+        auto show = [&](const char * name, uint32_t first, uint32_t count) {
+            double evals = 0;
+            for (uint32_t i = first; i < first + count; ++i) evals += 0.5 * groups->h_num_rows[order[i]] * groups->h_num_cols[order[i]] * groups->h_num_cols[order[i]];
+            std::fprintf(stderr, "[search classes] %-6s %6u matrices, %.3g pair-row evaluations if nothing is skipped; largest:", name, count, evals);
+            for (uint32_t i = first; i < first + std::min<uint32_t>(count, 6); ++i) std::fprintf(stderr, " %llux%u", static_cast<unsigned long long>(groups->h_num_rows[order[i]]), groups->h_num_cols[order[i]]);
+            std::fprintf(stderr, "\n");
+        };
+        show("table", 0, num_big);
+        show("medium", num_big, num_medium);
+        show("small", num_big + num_medium, M - num_big - num_medium);
+    }
+
     DeviceBuffer<uint32_t> d_order, d_col_count, d_col_order, d_out_first, d_out_second, d_out_count, d_first, d_second;
     DeviceBuffer<uint64_t> d_col_off, d_pair_cap_off, d_pair_off;
     DeviceBuffer<double> d_lf, d_marg, d_opt_raw, d_opt, d_out_value, d_value;

@@ -179,9 +179,12 @@ __device__ __forceinline__ void loadLogTable(LogTableEntry * lds_table) {
 
 __device__ __forceinline__ double logPositive(const double x, const LogTableEntry * lds_table) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    const double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
-    const int k = __builtin_amdgcn_frexp_exp(x);
-    const int i = static_cast<int>(fma(m, 256.0, -127.5));
+    // x = 2^k m, m in [0.5, 1), through the bit pattern (positive normal x): integer instructions instead of
+    // v_frexp_*_f64 and of the float -> int conversion of the table index
+    const uint32_t hi_word = static_cast<uint32_t>(__double2hiint(x));
+    const int k = static_cast<int>(hi_word >> 20) - 1022;
+    const double m = __hiloint2double(static_cast<int>((hi_word & 0x000fffffu) | 0x3fe00000u), __double2loint(x));
+    const uint32_t i = ((hi_word & 0x000fffffu) + 0x1000u) >> 13;  // round((m - 0.5) * 256): 0 .. 128
     const LogTableEntry e = lds_table[i];
     const double r = fma(m, static_cast<double>(e.rc), -1.0);
     double q = fma(r, 1.0 / 7.0, -1.0 / 6.0);
