@@ -108,3 +108,30 @@ def init_engine_comm(ctx, dist, device: str = "cpu"):
     uid = hip.Context.comm_unique_id() if dist.get_rank() == 0 else None
     uid = broadcast_bytes(uid, hip.COMM_ID_BYTES, dist, device)
     ctx.comm_init(uid, dist.get_world_size(), dist.get_rank())
+
+
+# ---- the TPM denominator over sharded clusters ---------------------------------------------------------
+
+def local_transcript_count(estimates, batch: ClusterBatch) -> float:
+    """sum over this rank's clusters of abundance / effective length (src/main.cpp:1029-1057): the TPM denominator
+    before it is summed over ranks.  estimates[k] belongs to cluster k of `batch`."""
+    total = 0.0
+    for k, e in enumerate(estimates):
+        p0 = int(batch.cluster_path_off[k])
+        lengths = batch.path_effective_length[p0:int(batch.cluster_path_off[k + 1])]
+        members = [p for s in e.path_group_sets for p in s]
+        if len(e.abundances) != len(members):  # one abundance per set (single-path sets) or none
+            members = [s[0] for s in e.path_group_sets] if len(e.abundances) == len(e.path_group_sets) else []
+        for ab, p in zip(e.abundances, members):
+            if lengths[p] > 0:
+                total += float(ab) / float(lengths[p])
+    return total
+
+
+def total_transcript_count(local_value: float, dist, device: str = "cpu") -> float:
+    """The one scalar of the multi-GPU path that needs a collective besides the result gather: every rank needs
+    the global TPM denominator to write its share of the output (all-reduce of one double; RCCL on GPUs)."""
+    import torch
+    t = torch.tensor([local_value], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    return float(t.item())

@@ -34,8 +34,11 @@ def _worker(rank, world, port, out_dir):
         gathered = rdist.gather_cluster_values([e.abundances for e in est], mine, batch.num_clusters, dist)
         noise = rdist.gather_cluster_values([np.array([e.noise_count, e.total_count]) for e in est], mine,
                                             batch.num_clusters, dist)
+        tpm_den = rdist.total_transcript_count(rdist.local_transcript_count(est, shard), dist)
         if rank == 0:
             full, _ = pyoracle.run("transcripts", make_params(), batch, 2)
+            want_den = rdist.local_transcript_count(full, batch)
+            assert abs(tpm_den - want_den) <= 1e-9 * want_den and want_den > 0
             ok = all(np.array_equal(g, f.abundances) for g, f in zip(gathered, full))
             ok = ok and all(n[0] == f.noise_count and n[1] == f.total_count for n, f in zip(noise, full))
             with open(os.path.join(out_dir, "result"), "w") as f:
