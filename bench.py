@@ -163,6 +163,10 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     else:
         mass_ok = all(abs(e.abundances.sum() + e.noise_count - e.total_count) <= 1e-6 * max(1.0, e.total_count) for e in est)
     gathered = None
+    tpm_denominator = None
+    if dist is not None and args.model != "haplotypes":
+        # the other collective of a multi-GPU run: the TPM denominator (src/main.cpp:1029-1057) summed over ranks
+        tpm_denominator = rdist.total_transcript_count(rdist.local_transcript_count(est, batch), dist, "cuda")
     if dist is not None:
         if args.scaling == "strong":
             per_cluster = rdist.gather_cluster_values([e.abundances for e in est], my_clusters, global_clusters, dist, "cuda")
@@ -209,6 +213,8 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         upload_ms=upload_ms, value_including_upload=float(batch.total_reads) / ((ms_per_step + upload_ms) / 1e3) * world)
     if gathered is not None:
         line["gathered_abundance_mass"] = gathered
+    if tpm_denominator is not None:
+        line["tpm_denominator"] = tpm_denominator
     if s5:
         # no EM on this path: the device work is the FP64 log-likelihood contraction of the Gibbs conditionals
         ll_ms = stats["loglik_ms"] / max(1, stats["loglik_launches"])
