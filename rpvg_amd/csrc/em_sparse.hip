@@ -313,6 +313,7 @@ __global__ __launch_bounds__(BLOCK) void emSparseKernel(const EmLaunchArgs args)
     for (uint32_t j = threadIdx.x; j < C; j += BLOCK) t[j] = 0;
     __syncthreads();  // a[], t[] and (when resident) the problem's CSR are in LDS
 
+    const double inv_T = 1.0 / T;
     uint32_t iters = 0, conv = 0;
     for (uint32_t it = 0; it < args.max_em_its; ++it) {
         const double a_noise = a[noise_col];
@@ -322,16 +323,23 @@ __global__ __launch_bounds__(BLOCK) void emSparseKernel(const EmLaunchArgs args)
             const double nz = nzv[r];
             double s = nz * a_noise;
             for (uint32_t e = e0; e < e1; ++e) s += val[e] * a[col[e]];
-            const double w = cnt[r] / s;
+            // cnt / s: hardware reciprocal, two Newton steps, one residual correction of the quotient
+            double y = __builtin_amdgcn_rcp(s);
+            y = fma(fma(-s, y, 1.0), y, y);
+            y = fma(fma(-s, y, 1.0), y, y);
+            const double quot = cnt[r] * y;
+            const double w = fma(fma(-s, quot, cnt[r]), y, quot);
             for (uint32_t e = e0; e < e1; ++e) atomicAdd(&t[col[e]], w * val[e]);
             tn += w * nz;
         }
-        tn = blockReduceSum<double, BLOCK>(tn, red);
+        // the noise column has no entries: its accumulator takes the per-wave sums of w * noise
+        tn = waveSumF64(tn);
+        if ((threadIdx.x & 63) == 0 && tn != 0.0) atomicAdd(&t[noise_col], tn);
         __syncthreads();  // all atomics to t[] done, all reads of a[] done
         int viol = 0;
         for (uint32_t j = threadIdx.x; j < C; j += BLOCK) {
             const double aj = a[j];
-            const double an = (j == noise_col) ? (aj * tn + Z) / T : (aj * t[j]) / T;
+            const double an = (j == noise_col) ? (aj * t[j] + Z) * inv_T : (aj * t[j]) * inv_T;
             // |an - aj| / an > eps  (src/path_abundance_estimator.cpp:73-75), without the division
             if (an >= kMinEmAbundance && fabs(an - aj) > eps * an) viol = 1;
             a[j] = an;
@@ -400,7 +408,7 @@ hipError_t launchEm(const EmLaunchArgs & args, size_t lds, hipStream_t stream) {
 // its slowest problem times the latency of ONE iteration): ~0.35 us per iteration here against ~1.2 us for the
 // LDS-resident sparse kernel.  Zero entries add exact zeros, so the E-step sums equal the sparse kernel's bit for
 // bit; the column sums are added in a fixed order (the sparse kernels use LDS atomics).
-constexpr uint32_t kRegPaths = 16;
+constexpr uint32_t kRegPathsMax = 32;  // the widest register-resident variant
 
 // value of the lane whose index differs in bit 0 (D = 1) or bit 1 (D = 2) — inside a quad, through DPP
 template <int D>
@@ -411,8 +419,10 @@ __device__ __forceinline__ double quadSwapF64(const double v) {
     return __hiloint2double(hi, lo);
 }
 
-template <int RPL>
+template <int RPL, int PATHS>
 __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) {
+    constexpr uint32_t kRegPaths = PATHS;
+    constexpr int kLanesPerColumn = 64 / PATHS;  // 4 (16 paths) or 2 (32 paths)
     extern __shared__ __attribute__((aligned(16))) double reg_lds[];
     if (blockIdx.x >= args.count) return;
     const uint32_t p = args.order[blockIdx.x];
@@ -456,17 +466,18 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
     const double eps = args.max_rel_em_conv;
     // src/path_abundance_estimator.cpp:54 — 1 / float(C), widened
     const double a0 = static_cast<double>(1.0f / static_cast<float>(np + 1));
-    // lane 4 j owns path column j (its quad adds that column's partials); lane 1 owns the noise component
-    const uint32_t my_col = (lane == 1) ? kRegPaths : (lane >> 2);
-    const bool owns_path = (lane & 3) == 0 && my_col < np;
+    // the first of the kLanesPerColumn lanes that add column j's partials owns a_j; lane 1 owns the noise component
+    const uint32_t my_col = (lane == 1) ? kRegPaths : (lane / kLanesPerColumn);
+    const bool owns_path = (lane % kLanesPerColumn) == 0 && my_col < np;
     const bool owns_noise = lane == 1;
     double a_mine = (owns_path || owns_noise) ? a0 : 0.0;
     if (lane <= kRegPaths) a_lds[lane] = (lane < np || lane == kRegPaths) ? a0 : 0.0;
     __syncthreads();
 
     const double inv_T = 1.0 / T;
-    // column j = lane >> 2: the four lanes of a quad add a quarter of the column's 64 partials each
-    const double * mine = part + (lane >> 2) * 64 + (lane & 3) * 16;
+    // column j = lane / kLanesPerColumn: its lanes add an equal share of the column's 64 partials each
+    constexpr int kShare = 64 / kLanesPerColumn;
+    const double * mine = part + (lane / kLanesPerColumn) * 64 + (lane % kLanesPerColumn) * kShare;
 
     uint32_t iters = 0, conv = 0;
     for (uint32_t it = 0; it < args.max_em_its; ++it) {
@@ -508,15 +519,15 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
         __syncthreads();
         double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; i += 4) {
+        for (int i = 0; i < kShare; i += 4) {
             t0 += mine[i];
             t1 += mine[i + 1];
             t2 += mine[i + 2];
             t3 += mine[i + 3];
         }
         double tj = (t0 + t1) + (t2 + t3);
-        tj += quadSwapF64<1>(tj);  // lanes of a quad: DPP, no LDS round trip
-        tj += quadSwapF64<2>(tj);
+        tj += quadSwapF64<1>(tj);  // neighbouring lanes: DPP, no LDS round trip
+        if (kLanesPerColumn == 4) tj += quadSwapF64<2>(tj);
 
         int viol = 0;
         if (owns_path || owns_noise) {
@@ -554,12 +565,12 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
     }
 }
 
-template <int RPL>
+template <int RPL, int PATHS>
 hipError_t launchEmRegister(const EmLaunchArgs & args, hipStream_t stream) {
     if (args.count == 0) return hipSuccess;
-    const size_t tile = 64 * RPL * kRegPaths, part = 64 * kRegPaths;
-    const size_t lds = (std::max(tile, part) + kRegPaths + 2) * sizeof(double);
-    emRegisterKernel<RPL><<<dim3(args.count), dim3(64), lds, stream>>>(args);
+    const size_t tile = 64 * RPL * PATHS, part = 64 * PATHS;
+    const size_t lds = (std::max(tile, part) + PATHS + 2) * sizeof(double);
+    emRegisterKernel<RPL, PATHS><<<dim3(args.count), dim3(64), lds, stream>>>(args);
     return hipGetLastError();
 }
 
@@ -949,21 +960,27 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     //   2  streamed from L2, 4 waves
     //   3  streamed from L2, 16 waves  (a few giant problems)
     //   4-6 register-resident dense, one wave: at most 16 paths and 64 / 128 / 256 rows (emRegisterKernel)
-    constexpr int kBins = 7;
+    //   8-9 register-resident dense, one wave: 17 to 32 paths and 64 / 128 rows
+    //   7  LDS-resident, sixteen waves  CSR + vectors fit 152 KB (one workgroup per CU: the whole LDS)
+    constexpr int kBins = 10;
     std::vector<uint32_t> bins[kBins];
-    size_t bin_lds[kBins] = {0, 0, 0, 0, 0, 0, 0};
+    size_t bin_lds[kBins] = {};
     static const bool use_register_kernel = std::getenv("RPVG_HIP_NO_REGISTER_EM") == nullptr;
     for (uint32_t p = 0; p < P; ++p) {
         const uint32_t C = static_cast<uint32_t>(problems->col_off[p + 1] - problems->col_off[p]) + 1;
         const uint64_t work = static_cast<uint64_t>(kept_ent[p]) + kept_rows[p];
         int b;
         size_t lds = 0;
-        if (use_register_kernel && C - 1 <= kRegPaths && kept_rows[p] <= 256) {
+        if (use_register_kernel && C - 1 <= 16 && kept_rows[p] <= 256) {
             b = kept_rows[p] <= 64 ? 4 : kept_rows[p] <= 128 ? 5 : 6;
+        } else if (use_register_kernel && C - 1 <= kRegPathsMax && kept_rows[p] <= 128) {
+            b = kept_rows[p] <= 64 ? 8 : 9;
         } else if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 64, true)) <= 8 * 1024) {
             b = 0;
         } else if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 256, true)) <= 40 * 1024) {
             b = 1;
+        } else if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 1024, true)) <= 152 * 1024) {
+            b = 7;
         } else if (work <= 262144) {
             b = 2;
             lds = emLdsBytes(C, 0, 0, 256, false);
@@ -1025,20 +1042,28 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
         args.order = d_order.ptr + bin_start[b];
         args.count = bins[b].size();
     };
-    bin(6);
-    RPVG_HIP_CHECK(launchEmRegister<4>(args, ctx->aux[0]));
-    bin(4);
-    RPVG_HIP_CHECK(launchEmRegister<1>(args, ctx->aux[1]));
-    bin(5);
-    RPVG_HIP_CHECK(launchEmRegister<2>(args, ctx->aux[2]));
-    bin(3);
-    RPVG_HIP_CHECK((launchEm<1024, false>(args, bin_lds[3], st)));
+    // every stream starts with one of the four sparse kernels (the ones with the long tails: a problem that needs
+    // thousands of iterations at a microsecond or more each); the register-resident bins follow them
     bin(2);
     RPVG_HIP_CHECK((launchEm<256, false>(args, bin_lds[2], st)));
-    bin(1);
-    RPVG_HIP_CHECK((launchEm<256, true>(args, bin_lds[1], ctx->aux[2])));
+    bin(3);
+    RPVG_HIP_CHECK((launchEm<1024, false>(args, bin_lds[3], st)));
+    bin(7);
+    RPVG_HIP_CHECK((launchEm<1024, true>(args, bin_lds[7], ctx->aux[0])));
+    bin(6);
+    RPVG_HIP_CHECK((launchEmRegister<4, 16>(args, ctx->aux[0])));
+    bin(9);
+    RPVG_HIP_CHECK((launchEmRegister<2, 32>(args, ctx->aux[0])));
     bin(0);
     RPVG_HIP_CHECK((launchEm<64, true>(args, bin_lds[0], ctx->aux[1])));
+    bin(4);
+    RPVG_HIP_CHECK((launchEmRegister<1, 16>(args, ctx->aux[1])));
+    bin(8);
+    RPVG_HIP_CHECK((launchEmRegister<1, 32>(args, ctx->aux[1])));
+    bin(1);
+    RPVG_HIP_CHECK((launchEm<256, true>(args, bin_lds[1], ctx->aux[2])));
+    bin(5);
+    RPVG_HIP_CHECK((launchEmRegister<2, 16>(args, ctx->aux[2])));
     RPVG_HIP_CHECK(ctx->joinAux());
     ctx->spanEnd(span);
     for (int b = 0; b < kBins; ++b) ctx->stats.em_sparse_launches += bins[b].empty() ? 0 : 1;
