@@ -466,10 +466,13 @@ rpvg_synth_config rpvg_amd_synth_default_config(void) {
 
 void * rpvg_amd_synth_generate(const rpvg_synth_config * config_in) {
 
-    const rpvg_synth_config config = *config_in;
+    rpvg_synth_config config = *config_in;
     const uint32_t K = config.num_clusters;
 
     assert(K > 0 && config.total_paths >= K && config.num_haplotypes >= 2);
+
+    // the clip must leave room for all paths
+    config.max_cluster_paths = std::max<uint64_t>(config.max_cluster_paths, (config.total_paths + K - 1) / K);
 
     // sizes: paths per cluster and reads per cluster, from one global stream
     Rng sizes_rng(config.seed ^ 0x5151515151515151ull);

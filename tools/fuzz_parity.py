@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: GPU engine vs the CPU oracle over seeds, batch shapes, models and option values.
+Not part of the test suite (minutes of GPU time); prints every mismatch and a summary.
+
+  python tools/fuzz_parity.py [rounds] [first_seed]
+"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from oracle import pyoracle  # noqa: E402
+from rpvg_amd import engine as eng_mod, synth  # noqa: E402
+from rpvg_amd.batch import ClusterBatch, make_params  # noqa: E402
+from tests import small_cases  # noqa: E402
+
+REL = 1e-6
+
+
+def compare(got, ref, check_iters=True):
+    problems = []
+    if len(got) != len(ref):
+        return [f"cluster count {len(got)} vs {len(ref)}"]
+    for k, (g, r) in enumerate(zip(got, ref)):
+        gk, rk = g.keyed(), r.keyed()
+        if set(gk) != set(rk):
+            problems.append(f"cluster {k}: group sets differ ({len(gk)} vs {len(rk)})")
+            continue
+        for key, (post, ab) in rk.items():
+            if not small_cases.rel_close(gk[key][0], post, rel=REL, floor=1e-8):
+                problems.append(f"cluster {k} set {key}: posterior {gk[key][0]} vs {post}")
+            if not small_cases.rel_close(gk[key][1], ab, rel=REL):
+                problems.append(f"cluster {k} set {key}: abundance {gk[key][1]} vs {ab}")
+        if g.total_count != r.total_count:
+            problems.append(f"cluster {k}: total {g.total_count} vs {r.total_count}")
+        if abs(g.noise_count - r.noise_count) > REL * max(1.0, r.total_count):
+            problems.append(f"cluster {k}: noise {g.noise_count} vs {r.noise_count}")
+        if check_iters and dict(zip(g.em_cols, g.em_iters)) != dict(zip(r.em_cols, r.em_iters)):
+            problems.append(f"cluster {k}: EM iterations differ")
+    return problems
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    eng = eng_mod.Engine(0)
+    failures = 0
+    t0 = time.time()
+    for i in range(rounds):
+        seed = seed0 + i
+        rng = np.random.default_rng(seed)
+        shape = rng.integers(0, 3)
+        if shape == 0:      # hand-built small clusters incl. empty ones
+            batch = ClusterBatch.from_clusters(small_cases.make_batch_clusters(seed, n_clusters=int(rng.integers(1, 200)),
+                                                                               max_reads=int(rng.integers(25, 400))))
+        elif shape == 1:    # generator: many small clusters
+            batch = synth.generate(seed=seed, num_clusters=int(rng.integers(70, 400)), total_paths=int(rng.integers(2000, 12000)),
+                                   total_reads=int(rng.integers(20000, 400000)))
+        else:               # generator: few large clusters
+            batch = synth.generate(seed=seed, num_clusters=int(rng.integers(3, 30)), total_paths=int(rng.integers(1500, 8000)),
+                                   total_reads=int(rng.integers(50000, 600000)), max_cluster_paths=int(rng.integers(200, 4000)))
+        model = ["transcripts", "haplotype-transcripts", "haplotypes", "strains"][int(rng.integers(0, 4))]
+        if model == "strains" and shape == 2:
+            model = "transcripts"  # the oracle's greedy path cover is O(rows x paths^2) per cluster
+        kw = dict(max_em_its=int(rng.choice([3, 50, 10000])), max_rel_em_conv=float(rng.choice([1e-3, 1e-2, 1e-5])),
+                  min_hap_prob=float(rng.choice([1e-3, 1e-2, 1e-5])), rng_seed=int(rng.integers(0, 1000)))
+        if model in ("haplotype-transcripts", "haplotypes"):
+            kw["ploidy"] = int(rng.choice([1, 2, 2, 2, 3]))
+            kw["use_hap_gibbs"] = int(rng.random() < 0.25)
+        if model == "haplotype-transcripts" and not kw.get("use_hap_gibbs") and rng.random() < 0.2:
+            kw["ind_hap_inference"] = 1
+        if model == "haplotypes" and kw["ploidy"] == 3 and batch.num_paths > 3000:
+            kw["ploidy"] = 2  # full enumeration of triplets over thousands of paths is not a test case
+        params = make_params(**kw)
+        try:
+            ref, _ = pyoracle.run(model, params, batch, 8)
+            got, _ = eng.run(model, params, eng.prepare(batch))
+            # independent inference interleaves generator draws differently from the reference: statistical only
+            problems = [] if kw.get("ind_hap_inference") else compare(got, ref)
+        except Exception as exc:  # noqa: BLE001
+            problems = [f"exception: {exc}"]
+        status = "ok" if not problems else "MISMATCH"
+        print(f"{time.time() - t0:6.0f}s [{i:3d}] seed {seed} shape {shape} {model:22s} {kw} clusters {batch.num_clusters} -> {status}", flush=True)
+        for p in problems[:5]:
+            print("      ", p, flush=True)
+        failures += bool(problems)
+    print(f"{rounds} rounds, {failures} with mismatches, {time.time() - t0:.0f} s")
+    eng.close()
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()
