@@ -61,20 +61,24 @@ def main():
             batch = synth.generate(seed=seed, num_clusters=int(rng.integers(3, 30)), total_paths=int(rng.integers(1500, 8000)),
                                    total_reads=int(rng.integers(50000, 600000)), max_cluster_paths=int(rng.integers(200, 4000)))
         model = ["transcripts", "haplotype-transcripts", "haplotypes", "strains"][int(rng.integers(0, 4))]
-        if model == "strains" and shape == 2:
-            model = "transcripts"  # the oracle's greedy path cover is O(rows x paths^2) per cluster
+        rows = np.diff(batch.cluster_row_off.astype(np.float64))
+        paths = np.diff(batch.cluster_path_off.astype(np.float64))
+        if model in ("strains", "haplotypes") and float((rows * paths * paths).sum()) > 2e9:
+            model = "transcripts"  # the oracle's pair enumeration / greedy cover is O(rows x paths^2) per cluster
         kw = dict(max_em_its=int(rng.choice([3, 50, 10000])), max_rel_em_conv=float(rng.choice([1e-3, 1e-2, 1e-5])),
                   min_hap_prob=float(rng.choice([1e-3, 1e-2, 1e-5])), rng_seed=int(rng.integers(0, 1000)))
         if model in ("haplotype-transcripts", "haplotypes"):
             kw["ploidy"] = int(rng.choice([1, 2, 2, 2, 3]))
             kw["use_hap_gibbs"] = int(rng.random() < 0.25)
-        if model == "haplotype-transcripts" and not kw.get("use_hap_gibbs") and rng.random() < 0.2:
+        if model == "haplotype-transcripts" and not kw.get("use_hap_gibbs") and rng.random() < 0.2 and kw["min_hap_prob"] >= 1e-3:
+            # (with 1e-5 the reference's own assertion sum_hap_prob <= 1 fails on the rounding of 100 000 weights,
+            # src/path_abundance_estimator.cpp:748)
             kw["ind_hap_inference"] = 1
         if model == "haplotypes" and kw["ploidy"] == 3 and batch.num_paths > 3000:
             kw["ploidy"] = 2  # full enumeration of triplets over thousands of paths is not a test case
         params = make_params(**kw)
         try:
-            ref, _ = pyoracle.run(model, params, batch, 8)
+            ref, _ = pyoracle.run(model, params, batch, 32)
             got, _ = eng.run(model, params, eng.prepare(batch))
             # independent inference interleaves generator draws differently from the reference: statistical only
             problems = [] if kw.get("ind_hap_inference") else compare(got, ref)
