@@ -2,7 +2,7 @@
 """Randomised parity sweep: GPU engine vs the CPU oracle over seeds, batch shapes, models and option values.
 Not part of the test suite (minutes of GPU time); prints every mismatch and a summary.
 
-  python tools/fuzz_parity.py [rounds] [first_seed]
+  python tests/fuzz_parity.py [rounds] [first_seed]
 """
 import sys
 import time
