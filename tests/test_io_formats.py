@@ -206,3 +206,37 @@ def test_haplotypes_and_gibbs_writers_format(files):
             assert lines[row].split("\t") == [f"c{k}_p{p}", str(k + 1)] + [fmt(x) for x in ab[:, j]], row
             row += 1
     assert lines[row].split("\t") == ["Unknown", "0"] + [fmt(x + 5) for x in noise]
+
+
+def test_config0_plumbing_on_the_cpu(tmp_path):
+    """BASELINE.json configs[0] / SURVEY.md §8d S1: 100,000 read pairs x 36,120 paths in 2,177 clusters, `-i transcripts`,
+    the CPU restatement with 4 threads, no GPU — the driver's ordering, the file formats and the writers' invariants:
+    dump -> reader (clusters by descending size) -> estimates -> rpvg.txt."""
+    batch = synth.generate(seed=1, num_clusters=2177, total_paths=36120, total_reads=100000)
+    probs, info = str(tmp_path / "s1_probs.txt.gz"), str(tmp_path / "s1_info.tsv")
+    rio.write_batch_files(batch, probs, info)
+    back = rio.read_batch_files(probs, info)
+    nonempty = np.diff(batch.cluster_row_off.astype(np.int64)) > 0  # clusters without reads never reach the dump
+    num_paths = int(np.diff(batch.cluster_path_off.astype(np.int64))[nonempty].sum())
+    assert back.num_clusters == int(nonempty.sum()) and back.num_paths == num_paths and back.total_reads == 100000
+    # ClusterID = rank by size: the dump does not carry the number of alignment-path lists the reference ranks by
+    # (src/main.cpp:811-827), the reader ranks by read count
+    reads = np.add.reduceat(back.row_count.astype(np.int64), back.cluster_row_off[:-1].astype(np.int64))
+    assert np.all(reads[:-1] >= reads[1:])
+    params = make_params()
+    prefix = str(tmp_path / "s1")
+    with pyoracle.RawRun("transcripts", params, back, 4) as run:
+        rio.write_estimates(probs, info, "transcripts", params, run.view, prefix, unaligned_read_count=0)
+        est = run.estimates
+    # the invariant the reference's writers assert (src/threaded_output_writer.cpp:327-328)
+    for e in est:
+        if e.total_count > 0:
+            assert abs(e.abundances.sum() + e.noise_count - e.total_count) <= 1e-9 * e.total_count
+    assert sum(e.total_count for e in est) == 100000
+    lines = open(prefix + ".txt").read().splitlines()
+    assert lines[0] == "Name\tClusterID\tLength\tEffectiveLength\tReadCount\tTPM"
+    assert len(lines) == 1 + num_paths + 1 and lines[-1].startswith("Unknown\t0\t0\t0\t")
+    cols = [l.split("\t") for l in lines[1:-1]]
+    assert abs(sum(float(c[5]) for c in cols) - 1e6) < 1.0  # TPM
+    assert abs(sum(float(c[4]) for c in cols) + float(lines[-1].split("\t")[4]) - 100000) < 1e-2  # read counts
+    assert [int(c[1]) for c in cols] == sorted(int(c[1]) for c in cols) and int(cols[-1][1]) == back.num_clusters
