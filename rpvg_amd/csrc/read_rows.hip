@@ -127,11 +127,6 @@ __device__ __forceinline__ double waveMaxF64(double v) {
     return v;
 }
 
-__device__ __forceinline__ uint32_t waveSumU32(uint32_t v) {
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-
 // first position in [lo, hi) of the ascending list whose value is >= p
 __device__ __forceinline__ uint64_t lowerBound(const uint32_t * __restrict__ list, uint64_t lo, uint64_t hi, const uint32_t p) {
     while (lo < hi) {
