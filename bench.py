@@ -37,10 +37,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="s3", choices=["s3", "c2", "s5", "rows"],
+    ap.add_argument("--workload", default="s3", choices=["s3", "c2", "s5", "rows", "e2e"],
                     help="s3: BASELINE.json configs[2]/[3] (default, the metric's configuration); c2: configs[1] single dense "
                          "cluster; s5: configs[4] diploid haplotype Gibbs, 10M reads x 500k paths; rows: the step before the path "
-                         "(alignment paths -> merged rows, SURVEY.md 8f rank 2) on the configs[2] reads")
+                         "(alignment paths -> merged rows, SURVEY.md 8f rank 2) on the configs[2] reads; e2e: rows + estimates in one "
+                         "pass, nothing leaving the GPU in between")
     ap.add_argument("--model", default="haplotype-transcripts", choices=["haplotype-transcripts", "transcripts", "haplotypes"])
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the full workload (parity/dev runs only)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -372,6 +373,62 @@ def run_rows(args, rank, local_rank, world, dist, torch):
     return line
 
 
+def run_e2e(args, rank, local_rank, world, dist, torch):
+    """The widened path in one pass: alignment-path lists resident in HBM -> merged rows (rpvg_hip_read_rows_build) -> the
+    estimators' batch (rpvg_hip_read_rows_to_batch) -> -i haplotype-transcripts, for the reads of BASELINE.json configs[2]."""
+    import numpy as np
+    from rpvg_amd import engine as eng_mod, synth
+    from rpvg_amd.batch import make_params
+    from rpvg_amd.rows import RowParams
+    params = make_params()
+    K = max(8, int(round(5000 * args.scale)))
+    total_paths = max(K, int(round(200000 * args.scale)))
+    total_reads = int(round(10000000 * args.scale))
+    batch, aligns = synth.generate_with_alignments(seed=3 + rank, num_clusters=K, total_paths=total_paths, total_reads=total_reads)
+    eng = eng_mod.Engine(local_rank)
+    frag = (300.0, 50.0, 0.0, 10)
+    prepared = eng.prepare_from_alignments(aligns, batch, frag=frag, min_noise_prob=0.0)  # lists resident before the timed region
+    for _ in range(args.warmup):
+        eng.run_from_alignments_raw(args.model, params, prepared)
+    barrier_sync(dist, torch)
+    t0 = time.perf_counter()
+    rows_s = est_s = 0.0
+    for _ in range(args.steps):
+        r, e = eng.run_from_alignments_raw(args.model, params, prepared)
+        rows_s += r
+        est_s += e
+    barrier_sync(dist, torch)
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, torch)
+    reads_all = sum_over_ranks(float(aligns.total_reads), dist, torch)
+    est, _ = eng.run(args.model, params, prepared)
+    mass_ok = all(abs(e.abundances.sum() + e.noise_count - e.total_count) <= 1e-6 * max(1.0, e.total_count) for e in est)
+    if rank != 0:
+        return None
+    line = dict(
+        metric="read-pairs quantified/sec from alignment-path lists", value=reads_all / (elapsed / args.steps), unit="read-pairs/s",
+        n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
+        scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+        config=dict(workload=f"alignment-path lists of {total_reads} read pairs ({aligns.num_reads} distinct lists) x {total_paths} paths in "
+                             f"{K} clusters per GPU (the reads of BASELINE.json configs[2]) -> rows -> -i {args.model}, all on the GPU",
+                    parallelism=f"clusters sharded, {world} rank(s), no collective"),
+        stages=dict(row_construction_ms_per_step=rows_s / args.steps * 1e3, estimates_ms_per_step=est_s / args.steps * 1e3),
+        mass_conserved=bool(mass_ok))
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        cores = pyoracle.max_threads()
+        v = np.arange(65536, dtype=np.float64)
+        prm = RowParams(prob_precision=1e-8, min_noise_prob=0.0, is_single_end=False,
+                        frag_length_log_prob=pyoracle.frag_length_table(*frag))
+        rows_o, secs_rows = pyoracle.build_rows(aligns, prm, merge=True, num_threads=cores)
+        for name in ("path_group_id", "path_source_count", "path_source_off", "source_id", "path_effective_length"):
+            setattr(rows_o, name, getattr(batch, name).copy())
+        _, secs_est = pyoracle.run(args.model, params, rows_o, cores)
+        line["cpu_baseline"] = dict(value=aligns.total_reads / (secs_rows + secs_est), unit="read-pairs/s", cores=cores, kind="port",
+                                    sample=f"the whole batch: oracle row construction {secs_rows:.2f} s + estimates {secs_est:.2f} s, "
+                                           f"OpenMP dynamic over clusters, {cores} threads")
+    return line
+
+
 def run_c2(args, rank, local_rank, world, dist, torch):
     """1M x 2k dense single cluster (BASELINE.json configs[1]).  Weak scaling (default): one replica of the
     cluster per GPU, no collective.  --scaling strong: the rows of ONE cluster are spread over the ranks and every
@@ -449,7 +506,7 @@ def main():
     rank, local_rank, world, dist, torch = dist_setup(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    runner = dict(c2=run_c2, rows=run_rows).get(args.workload, run_s3)
+    runner = dict(c2=run_c2, rows=run_rows, e2e=run_e2e).get(args.workload, run_s3)
     line = runner(args, rank, local_rank, world, dist, torch)
     if rank == 0:
         print(json.dumps(line))

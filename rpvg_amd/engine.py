@@ -47,6 +47,9 @@ def lib() -> C.CDLL:
         L.rpvg_amd_run.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double)]
         L.rpvg_amd_run_inplace.restype = C.c_int
         L.rpvg_amd_run_inplace.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double)]
+        L.rpvg_amd_run_from_alignments_inplace.restype = C.c_int
+        L.rpvg_amd_run_from_alignments_inplace.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double),
+                                                           C.POINTER(C.c_double)]
         L.rpvg_amd_result_view.argtypes = [C.c_void_p, C.POINTER(CEstimatesView)]
         L.rpvg_amd_result_free.argtypes = [C.c_void_p]
         _lib = L
@@ -138,6 +141,17 @@ class Engine:
         if rc != 0:
             raise hip.EngineError(f"run({model}) failed: {_err()}")
         return secs.value
+
+
+    def run_from_alignments_raw(self, model: str, params: CParams, prepared: "PreparedBatch") -> Tuple[float, float]:
+        """One pass alignment-path lists (resident) -> rows -> estimates, everything on the GPU; returns the wall seconds
+        of the row construction and of the estimator call.  `prepared` comes from prepare_from_alignments()."""
+        rows_s, est_s = C.c_double(0), C.c_double(0)
+        rc = lib().rpvg_amd_run_from_alignments_inplace(self.handle, prepared.handle, model.encode(), C.byref(params),
+                                                        C.byref(rows_s), C.byref(est_s))
+        if rc != 0:
+            raise hip.EngineError(f"run_from_alignments({model}) failed: {_err()}")
+        return rows_s.value, est_s.value
 
 
 class PreparedBatch:

@@ -230,11 +230,27 @@ rpvg_alignment_batch AlignmentBatchBuilder::view() const {
     return batch;
 }
 
-std::unique_ptr<DeviceClusterBatch> constructReadPathProbabilities(std::shared_ptr<HipEngine> engine, const AlignmentBatchBuilder & alignments, const FragmentLengthDist & fragment_length_dist, const bool is_single_end, const double min_noise_prob, const double prob_precision) {
+DeviceAlignmentBatch::DeviceAlignmentBatch(std::shared_ptr<HipEngine> engine_in, const AlignmentBatchBuilder & alignments) : hip_engine(engine_in), device_alignments(nullptr) {
 
-    assert(engine);
+    assert(hip_engine);
 
     const auto alignment_batch = alignments.view();
+    HipEngine::check(rpvg_hip_alignments_upload(hip_engine->ctx(), &alignment_batch, &device_alignments), "rpvg_hip_alignments_upload");
+
+    for (uint32_t i = 0; i < alignments.numClusters(); ++i) {
+
+        total_read_count.emplace_back(alignments.totalReadCount(i));
+    }
+}
+
+DeviceAlignmentBatch::~DeviceAlignmentBatch() {
+
+    rpvg_hip_alignments_free(hip_engine->ctx(), device_alignments);
+}
+
+std::unique_ptr<DeviceClusterBatch> constructReadPathProbabilities(const DeviceAlignmentBatch & alignments, const FragmentLengthDist & fragment_length_dist, const bool is_single_end, const double min_noise_prob, const double prob_precision) {
+
+    const auto & engine = alignments.engine();
 
     std::vector<double> frag_length_table;
 
@@ -250,16 +266,11 @@ std::unique_ptr<DeviceClusterBatch> constructReadPathProbabilities(std::shared_p
         params.frag_length_log_prob = frag_length_table.data();
     }
 
-    rpvg_hip_alignments * device_alignments = nullptr;
-    HipEngine::check(rpvg_hip_alignments_upload(engine->ctx(), &alignment_batch, &device_alignments), "rpvg_hip_alignments_upload");
-
     rpvg_hip_read_rows * rows = nullptr;
-    int status = rpvg_hip_read_rows_build(engine->ctx(), device_alignments, &params, 1, &rows);
-    rpvg_hip_alignments_free(engine->ctx(), device_alignments);
-    HipEngine::check(status, "rpvg_hip_read_rows_build");
+    HipEngine::check(rpvg_hip_read_rows_build(engine->ctx(), alignments.handle(), &params, 1, &rows), "rpvg_hip_read_rows_build");
 
     rpvg_hip_batch * batch = nullptr;
-    status = rpvg_hip_read_rows_to_batch(engine->ctx(), rows, &batch);
+    const int status = rpvg_hip_read_rows_to_batch(engine->ctx(), rows, &batch);
 
     rpvg_cluster_batch rows_view;
     const int view_status = (status == 0) ? rpvg_hip_read_rows_sizes(engine->ctx(), rows, &rows_view) : 0;
@@ -268,14 +279,7 @@ std::unique_ptr<DeviceClusterBatch> constructReadPathProbabilities(std::shared_p
 
     if (status == 0 && view_status == 0) {
 
-        std::vector<double> total_read_count;
-
-        for (uint32_t i = 0; i < alignments.numClusters(); ++i) {
-
-            total_read_count.emplace_back(alignments.totalReadCount(i));
-        }
-
-        cluster_batch.reset(new DeviceClusterBatch(engine, batch, rows_view, total_read_count));
+        cluster_batch.reset(new DeviceClusterBatch(engine, batch, rows_view, alignments.totalReadCounts()));
     }
 
     rpvg_hip_read_rows_free(engine->ctx(), rows);
@@ -284,6 +288,12 @@ std::unique_ptr<DeviceClusterBatch> constructReadPathProbabilities(std::shared_p
     HipEngine::check(view_status, "rpvg_hip_read_rows_sizes");
 
     return cluster_batch;
+}
+
+std::unique_ptr<DeviceClusterBatch> constructReadPathProbabilities(std::shared_ptr<HipEngine> engine, const AlignmentBatchBuilder & alignments, const FragmentLengthDist & fragment_length_dist, const bool is_single_end, const double min_noise_prob, const double prob_precision) {
+
+    const DeviceAlignmentBatch device_alignments(engine, alignments);
+    return constructReadPathProbabilities(device_alignments, fragment_length_dist, is_single_end, min_noise_prob, prob_precision);
 }
 
 }

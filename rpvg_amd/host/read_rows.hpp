@@ -98,8 +98,33 @@ class AlignmentBatchBuilder {
         std::vector<uint64_t> cluster_total_reads;
 };
 
+// The alignment-path lists of a batch resident on the GPU (validated copy; rpvg_hip_alignments_upload).
+class DeviceAlignmentBatch {
+
+    public:
+
+        DeviceAlignmentBatch(std::shared_ptr<HipEngine> engine_in, const AlignmentBatchBuilder & alignments);
+        ~DeviceAlignmentBatch();
+
+        DeviceAlignmentBatch(const DeviceAlignmentBatch &) = delete;
+        DeviceAlignmentBatch & operator=(const DeviceAlignmentBatch &) = delete;
+
+        const rpvg_hip_alignments * handle() const { return device_alignments; }
+        const std::shared_ptr<HipEngine> & engine() const { return hip_engine; }
+        const std::vector<double> & totalReadCounts() const { return total_read_count; }
+
+    private:
+
+        std::shared_ptr<HipEngine> hip_engine;
+        rpvg_hip_alignments * device_alignments;
+        std::vector<double> total_read_count;
+};
+
 // addPathProbs for every list of the batch + the caller's sort and merge, on the GPU; the rows stay on
 // the device as the batch the estimators take.
+std::unique_ptr<DeviceClusterBatch> constructReadPathProbabilities(const DeviceAlignmentBatch & alignments, const FragmentLengthDist & fragment_length_dist, const bool is_single_end, const double min_noise_prob, const double prob_precision);
+
+// The same from host memory (uploads the lists first).
 std::unique_ptr<DeviceClusterBatch> constructReadPathProbabilities(std::shared_ptr<HipEngine> engine, const AlignmentBatchBuilder & alignments, const FragmentLengthDist & fragment_length_dist, const bool is_single_end, const double min_noise_prob, const double prob_precision);
 
 }

@@ -30,6 +30,14 @@ struct Engine {
 struct PreparedBatch {
 
     std::unique_ptr<DeviceClusterBatch> device;
+
+    // batches that start from alignment-path lists keep the lists resident: rows can be rebuilt on the device
+    std::unique_ptr<DeviceAlignmentBatch> alignments;
+    std::unique_ptr<FragmentLengthDist> fragment_length_dist;
+    bool is_single_end = false;
+    double min_noise_prob = 0;
+    double prob_precision = 1e-8;
+
     std::vector<std::vector<PathInfo> > paths;
 
     // kept for the per-cluster estimate() mode
@@ -290,10 +298,14 @@ void * rpvg_amd_batch_prepare_from_alignments(void * engine, const rpvg_alignmen
             }
         }
 
-        const FragmentLengthDist fragment_length_dist = is_single_end ? FragmentLengthDist() : FragmentLengthDist(frag_loc, frag_scale, frag_shape, frag_sd_max_multi);
+        prepared->fragment_length_dist.reset(is_single_end ? new FragmentLengthDist() : new FragmentLengthDist(frag_loc, frag_scale, frag_shape, frag_sd_max_multi));
+        prepared->is_single_end = is_single_end != 0;
+        prepared->min_noise_prob = min_noise_prob;
+        prepared->prob_precision = prob_precision;
 
         const auto start = std::chrono::steady_clock::now();
-        prepared->device = constructReadPathProbabilities(static_cast<Engine *>(engine)->hip, builder, fragment_length_dist, is_single_end != 0, min_noise_prob, prob_precision);
+        prepared->alignments.reset(new DeviceAlignmentBatch(static_cast<Engine *>(engine)->hip, builder));
+        prepared->device = constructReadPathProbabilities(*prepared->alignments, *prepared->fragment_length_dist, prepared->is_single_end, min_noise_prob, prob_precision);
 
         if (seconds_out) {
 
@@ -411,6 +423,42 @@ int rpvg_amd_run_inplace(void * engine, void * prepared_batch, const char * mode
         PhaseTrace::report();
 
         return 0;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
+// One pass of the widened path with the alignment-path lists resident on the GPU: rows are constructed and merged on
+// the device (read_rows.hpp), become the estimators' batch without leaving it, and `model` runs on them.
+// rows_seconds_out / estimate_seconds_out = wall time of the two stages.
+int rpvg_amd_run_from_alignments_inplace(void * engine, void * prepared_batch, const char * model, const rpvg_params * params, double * rows_seconds_out, double * estimate_seconds_out) {
+
+    try {
+
+        PreparedBatch * prepared = static_cast<PreparedBatch *>(prepared_batch);
+
+        if (!prepared->alignments) {
+
+            last_error = "rpvg_amd_run_from_alignments_inplace needs a batch prepared from alignment-path lists";
+            return -1;
+        }
+
+        const auto start = std::chrono::steady_clock::now();
+
+        prepared->device.reset();
+        prepared->device = constructReadPathProbabilities(*prepared->alignments, *prepared->fragment_length_dist, prepared->is_single_end, prepared->min_noise_prob, prepared->prob_precision);
+
+        const auto rows_done = std::chrono::steady_clock::now();
+
+        if (rows_seconds_out) {
+
+            *rows_seconds_out = std::chrono::duration<double>(rows_done - start).count();
+        }
+
+        return rpvg_amd_run_inplace(engine, prepared_batch, model, params, estimate_seconds_out);
 
     } catch (const std::exception & e) {
 
