@@ -141,6 +141,9 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     t_up = time.perf_counter()
     prepared = eng.prepare(batch)  # upload: inputs are resident in HBM before the timed region
     upload_ms = (time.perf_counter() - t_up) * 1e3
+    # engine start-up (second host lane and its device context, scratch pools): one pass outside the measurement,
+    # so that the W warmup steps are warmup and not initialisation
+    eng.run_raw(args.model, params, prepared)
     for _ in range(args.warmup):
         eng.run_raw(args.model, params, prepared)
     eng.reset_stats()
