@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Randomised sweep of row construction (GPU vs the oracle): seeds, cluster shapes, precision / noise options,
+single- and paired-end, name-group collapsing, reads wider than the 16-lane kernel.  Run by hand.
+
+  python tests/fuzz_rows.py [rounds] [first_seed]
+"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from oracle import pyoracle  # noqa: E402
+from rpvg_amd import hip  # noqa: E402
+from rpvg_amd.rows import AlignmentBatch, RowParams  # noqa: E402
+from tests import test_hip_rows as T  # noqa: E402
+from tests import test_row_construction as kat  # noqa: E402
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 9000
+    ctx = hip.Context(0)
+    failures = 0
+    t0 = time.time()
+    for i in range(rounds):
+        seed = seed0 + i
+        rng = np.random.default_rng(seed)
+        chains = bool(rng.random() < 0.3)
+        collapse = bool(rng.random() < 0.25)
+        wide = bool(rng.random() < 0.15)
+        single_end = bool(rng.random() < 0.3)
+        precision = float(rng.choice([1e-8, 1e-8, 1e-6, 1e-3, 0.05]))
+        min_noise = float(rng.choice([0.0, 1e-4, 1e-2]))
+        clusters = T.make_alignment_clusters(seed, n_clusters=int(rng.integers(2, 12)), max_paths=int(rng.integers(1, 120)),
+                                             reads_per_cluster=int(rng.integers(1, 3000 if not wide else 80)), collapse=collapse,
+                                             wide=wide, chains=chains)
+        batch = AlignmentBatch.from_clusters(clusters)
+        prm = RowParams(prob_precision=precision, min_noise_prob=min_noise, is_single_end=single_end,
+                        frag_length_log_prob=None if single_end else kat.frag_table())
+        problems = []
+        try:
+            ref, _ = pyoracle.build_rows(batch, prm, merge=False)
+            got, _, _ = ctx.build_rows(batch, prm, merge=False)
+            T.compare_unmerged(got, ref)
+            ref_m, _ = pyoracle.build_rows(batch, prm, merge=True)
+            got_m, _, _ = ctx.build_rows(batch, prm, merge=True)
+            if chains or precision > 1e-8:
+                T.check_valid_merge(got_m, got, ref_m, count_tolerance=0.15)  # coarse precisions chain as well; which
+                # near-equal rows end up adjacent is the sort's business on either side (seen: up to 8 % apart)
+            else:
+                T.compare_merged(got_m, ref_m)
+        except AssertionError as exc:
+            problems.append(f"assertion: {str(exc)[:300]}")
+        except Exception as exc:  # noqa: BLE001
+            problems.append(f"exception: {exc}")
+        status = "ok" if not problems else "MISMATCH"
+        print(f"{time.time() - t0:5.0f}s [{i:3d}] seed {seed} chains={chains} collapse={collapse} wide={wide} single_end={single_end} "
+              f"precision={precision} min_noise={min_noise} reads={batch.num_reads} -> {status}", flush=True)
+        for p in problems:
+            print("      ", p, flush=True)
+        failures += bool(problems)
+    print(f"{rounds} rounds, {failures} with mismatches, {time.time() - t0:.0f} s")
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()
