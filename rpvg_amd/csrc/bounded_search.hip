@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <numeric>
 
 using namespace rpvg_hip_detail;
@@ -81,12 +82,12 @@ struct SearchArgs {
     uint32_t count;
     const uint64_t * mat_val_off;
     const uint64_t * mat_row_off;
-    const uint64_t * mat_row0;
+    const uint32_t * mat_fast;       // leading rows with read count 1 (running products instead of logs)
     const uint64_t * mat_rows;
     const uint32_t * mat_cols;
     const double * values;
     const double * rowmax;
-    const double * row_count;
+    const double * row_count;        // in matrix row order (rpvg_hip_groups), like row_noise
     const double * row_noise;
     const uint64_t * col_off;        // [M+1] prefix of columns (scratch + counts)
     const uint32_t * col_count;      // path_counts of every column
@@ -108,28 +109,59 @@ struct SearchArgs {
     unsigned long long * log_evals;  // device counter: FP64 logs evaluated
 };
 
-// sum_i count_i * log(base_i + col_i / 2) over rows [lane, n) step 64, four independent chains in flight
-__device__ __forceinline__ double pairRowSum(const LogTableEntry * lt, const double * __restrict__ cnt, const double * __restrict__ base,
-                                             const double * __restrict__ col, const uint32_t n, const int lane) {
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    uint32_t i = lane;
-    for (; i + 192 < n; i += 256) {
-        const double x0 = col[i], x1 = col[i + 64], x2 = col[i + 128], x3 = col[i + 192];
-        acc0 = fma(cnt[i], logPositive(base[i] + x0 / 2.0, lt), acc0);
-        acc1 = fma(cnt[i + 64], logPositive(base[i + 64] + x1 / 2.0, lt), acc1);
-        acc2 = fma(cnt[i + 128], logPositive(base[i + 128] + x2 / 2.0, lt), acc2);
-        acc3 = fma(cnt[i + 192], logPositive(base[i + 192] + x3 / 2.0, lt), acc3);
+constexpr int kTileFirst = 4;  // first columns evaluated together by the search kernel
+
+// Pair sums of one second column b against the kTileFirst first columns of a tile, over the rows of a wave:
+// out[t] = sum_i count_i log((noise_i + col_a[t][i] / 2) + col_b[i] / 2).  Every element of b is read once and feeds
+// kTileFirst logs.  The first `staged` rows take base_t = noise + col_a[t] / 2 and the counts from LDS; rows below
+// n_fast have count 1 (running products).
+__device__ __forceinline__ void tilePairSums(const LogTableEntry * lt, const double * lds_count, const double * lds_base, const uint32_t stride,
+                                             const double * __restrict__ cnt, const double * __restrict__ nz,
+                                             const double * const (&col_a)[kTileFirst], const double * __restrict__ col_b, const uint32_t staged,
+                                             const uint64_t n_fast, const uint64_t R, const int lane, double (&out)[kTileFirst]) {
+    LogProduct pr[kTileFirst];
+    double acc[kTileFirst];
+#pragma unroll
+    for (int t = 0; t < kTileFirst; ++t) acc[t] = 0.0;
+    const uint32_t fast_staged = static_cast<uint32_t>(n_fast < staged ? n_fast : staged);
+    for (uint32_t i = lane; i < fast_staged; i += 64) {  // at most kLdsRows / 64 factors: no fold needed
+        const double x = col_b[i] / 2.0;
+#pragma unroll
+        for (int t = 0; t < kTileFirst; ++t) pr[t].mul(lds_base[t * stride + i] + x);
     }
-    for (; i < n; i += 64) acc0 = fma(cnt[i], logPositive(base[i] + col[i] / 2.0, lt), acc0);
-    return (acc0 + acc1) + (acc2 + acc3);
+    for (uint32_t i = fast_staged + lane; i < staged; i += 64) {
+        const double x = col_b[i] / 2.0, c = lds_count[i];
+#pragma unroll
+        for (int t = 0; t < kTileFirst; ++t) acc[t] = fma(c, logPositive(lds_base[t * stride + i] + x, lt), acc[t]);
+    }
+    if (staged < R) {
+        for (uint64_t seg = staged; seg < n_fast; seg += kFoldRows / 4) {
+            const uint64_t seg_end = (n_fast - seg) < kFoldRows / 4 ? n_fast : seg + kFoldRows / 4;
+            for (uint64_t i = seg + lane; i < seg_end; i += 64) {
+                const double noise = nz[i], x = col_b[i] / 2.0;
+#pragma unroll
+                for (int t = 0; t < kTileFirst; ++t) pr[t].mul((noise + col_a[t][i] / 2.0) + x);
+            }
+#pragma unroll
+            for (int t = 0; t < kTileFirst; ++t) pr[t].fold();
+        }
+        for (uint64_t i = (n_fast > staged ? n_fast : staged) + lane; i < R; i += 64) {
+            const double noise = nz[i], x = col_b[i] / 2.0, c = cnt[i];
+#pragma unroll
+            for (int t = 0; t < kTileFirst; ++t) acc[t] = fma(c, logPositive((noise + col_a[t][i] / 2.0) + x, lt), acc[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kTileFirst; ++t) out[t] = n_fast ? acc[t] + pr[t].value(lt) : acc[t];
 }
 
 template <int kBlock>
 __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs args) {
     constexpr int kWaves = kBlock / 64;
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
-    double * lds_base = lds_dyn;
-    double * lds_count = lds_dyn + args.stage_rows;
+    double * lds_base = lds_dyn;                                  // [kTileFirst][stage_rows]
+    double * lds_count = lds_dyn + kTileFirst * args.stage_rows;  // [stage_rows]
+    double * lds_rows = lds_count + args.stage_rows;              // [kTileFirst][row_lds_cols]
     __shared__ double lds_red[kBlock / 64];
     __shared__ unsigned long long lds_sum;
     __shared__ LogTableEntry lt[kLogTableSize];
@@ -142,8 +174,9 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
     const uint32_t G = args.mat_cols[m];
     const double * M = args.values + args.mat_val_off[m];
     const double * rm = args.rowmax + args.mat_row_off[m];
-    const double * cnt = args.row_count + args.mat_row0[m];
-    const double * nz = args.row_noise + args.mat_row0[m];
+    const double * cnt = args.row_count + args.mat_row_off[m];
+    const double * nz = args.row_noise + args.mat_row_off[m];
+    const uint64_t n_fast = args.mat_fast[m];
     const uint64_t c0 = args.col_off[m];
     const uint32_t * ccount = args.col_count + c0;
     double * lf = args.log_freq + c0;
@@ -173,12 +206,8 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
     // marginal log-posteriors (group size 1) and optimistic bounds of every column: two logs per row
     for (uint32_t g = wave; g < G; g += kWaves) {
         const double * col = M + static_cast<uint64_t>(g) * R;
-        double acc1 = 0.0, acc2 = 0.0;
-        for (uint64_t i = lane; i < R; i += 64) {
-            const double x = col[i], n = nz[i], c = cnt[i];
-            acc1 = fma(c, logPositive(n + x / 1.0, lt), acc1);
-            acc2 = fma(c, logPositive((n + x / 2.0) + rm[i] / 2.0, lt), acc2);
-        }
+        double acc1 = sumCountLogs<uint64_t>(lt, cnt, [&](const uint64_t i) { return nz[i] + col[i] / 1.0; }, 0, n_fast, R, lane);
+        double acc2 = sumCountLogs<uint64_t>(lt, cnt, [&](const uint64_t i) { return (nz[i] + col[i] / 2.0) + rm[i] / 2.0; }, 0, n_fast, R, lane);
         acc1 = waveSum(acc1);
         acc2 = waveSum(acc2);
         if (lane == 0) {
@@ -208,57 +237,109 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
     }
     __syncthreads();
 
-    // pair log-likelihoods of the current first column: LDS when they fit, else the (now free) bound scratch
-    double * row_ll = (G <= args.row_lds_cols) ? (lds_dyn + 2 * args.stage_rows) : opt_raw;
+    // The search (:418-451).  The reference reaches the first columns one by one, in `ord` order, and skips those
+    // whose optimistic bound is too far below the running maximum.  Here the next kTileFirst columns that pass the
+    // bound under the CURRENT maximum are evaluated together (every second column is read once for all of them);
+    // their rows are then pruned one after the other exactly as the reference does it, and a column whose bound
+    // fails by the time it is reached is dropped unseen — the kept set is the reference's.
+    // Rows of pair log-likelihoods: LDS when they fit, else (one first column at a time) the now free bound scratch.
+    const bool rows_in_lds = G <= args.row_lds_cols;
+    const uint32_t tile_max = rows_in_lds ? kTileFirst : 1;
+    const uint32_t row_stride = rows_in_lds ? args.row_lds_cols : 0;
+    double * row_ll = rows_in_lds ? lds_rows : opt_raw;
+    const uint32_t stride = args.stage_rows;
 
-    // the search (:418-451)
     double max_ll = lowest;
     uint32_t kept = 0;
     unsigned long long pairs_evaluated = 0;
     const uint32_t staged = static_cast<uint32_t>(R < args.stage_rows ? R : args.stage_rows);
-    for (uint32_t pos = 0; pos < G; ++pos) {
-        if (opt[pos] - max_ll < thr) continue;
-        const uint32_t a = ord[pos];
-        const double * col_a = M + static_cast<uint64_t>(a) * R;
-        __syncthreads();  // previous users of the staged vectors are done
+    uint32_t pos = 0;
+    while (pos < G) {
+        uint32_t tile_pos[kTileFirst];
+        uint32_t nt = 0;
+        while (pos < G && nt < tile_max) {
+            if (!(opt[pos] - max_ll < thr)) tile_pos[nt++] = pos;
+            ++pos;
+        }
+        if (nt == 0) break;
+#pragma unroll
+        for (int t = 1; t < kTileFirst; ++t)
+            if (t >= static_cast<int>(nt)) tile_pos[t] = tile_pos[0];  // unused slots repeat the first (uniform code)
+        uint32_t a[kTileFirst];
+        const double * col_a[kTileFirst];
+#pragma unroll
+        for (int t = 0; t < kTileFirst; ++t) {
+            a[t] = ord[tile_pos[t]];
+            col_a[t] = M + static_cast<uint64_t>(a[t]) * R;
+        }
+        __syncthreads();  // previous users of the staged vectors and of the rows are done
         for (uint32_t i = threadIdx.x; i < staged; i += kBlock) {
-            lds_base[i] = nz[i] + col_a[i] / 2.0;
+            const double noise = nz[i];
+#pragma unroll
+            for (int t = 0; t < kTileFirst; ++t) lds_base[t * stride + i] = noise + col_a[t][i] / 2.0;
             lds_count[i] = cnt[i];
         }
         __syncthreads();
-        const double lf_a = lf[a];
-        pairs_evaluated += G - pos;
-        // every wave evaluates its share of the row's pairs without waiting for the others ...
-        for (uint32_t j = pos + wave; j < G; j += kWaves) {
+        for (uint32_t t = 0; t < nt; ++t) pairs_evaluated += G - tile_pos[t];
+        // every wave evaluates its share of the second columns without waiting for the others ...
+        const uint32_t j0 = tile_pos[0];
+        for (uint32_t j = j0 + wave; j < G; j += kWaves) {
             const uint32_t b = ord[j];
-            const double * col_b = M + static_cast<uint64_t>(b) * R;
-            double acc = pairRowSum(lt, lds_count, lds_base, col_b, staged, lane);
-            {
-                double t0 = 0.0, t1 = 0.0;
-                uint64_t i = staged + lane;
-                for (; i + 64 < R; i += 128) {
-                    const double xa0 = col_a[i], xa1 = col_a[i + 64], xb0 = col_b[i], xb1 = col_b[i + 64];
-                    t0 = fma(cnt[i], logPositive((nz[i] + xa0 / 2.0) + xb0 / 2.0, lt), t0);
-                    t1 = fma(cnt[i + 64], logPositive((nz[i + 64] + xa1 / 2.0) + xb1 / 2.0, lt), t1);
+            double sums[kTileFirst];
+            tilePairSums(lt, lds_count, lds_base, stride, cnt, nz, col_a, M + static_cast<uint64_t>(b) * R, staged, n_fast, R, lane, sums);
+            const double lf_b = lf[b];
+#pragma unroll
+            for (int t = 0; t < kTileFirst; ++t) {
+                const double total = waveSum(sums[t]);
+                if (lane == 0 && t < static_cast<int>(nt) && j >= tile_pos[t]) {
+                    row_ll[t * row_stride + (j - tile_pos[t])] = total + ((lf[a[t]] + lf_b) + (a[t] == b ? 0.0 : log_two));
                 }
-                for (; i < R; i += 64) t0 = fma(cnt[i], logPositive((nz[i] + col_a[i] / 2.0) + col_b[i] / 2.0, lt), t0);
-                acc += t0 + t1;
             }
-            acc = waveSum(acc);
-            if (lane == 0) row_ll[j - pos] = acc + ((lf_a + lf[b]) + (a == b ? 0.0 : log_two));
         }
         __syncthreads();
-        // ... then the reference's pruning rule runs over the row in order (uniformly in all threads)
-        for (uint32_t j = pos; j < G; ++j) {
-            const double ll = row_ll[j - pos];
-            if (!(ll - max_ll < thr)) {
-                max_ll = fmax(max_ll, ll);
-                if (threadIdx.x == 0) {
-                    out_first[kept] = a;
-                    out_second[kept] = ord[j];
-                    out_value[kept] = ll;
+        // ... then the reference's pruning rule runs over the rows in order (uniformly in all threads)
+        for (uint32_t t = 0; t < nt; ++t) {
+            if (t > 0 && opt[tile_pos[t]] - max_ll < thr) continue;  // the reference skips this column when it gets there
+            const double * row = row_ll + t * row_stride;
+            const uint32_t n = G - tile_pos[t];
+            if (thr <= 0.0) {
+                // a dropped pair is below the running maximum, so "maximum of the kept pairs so far" = "maximum of
+                // all pairs so far": exclusive prefix maximum by wave scan, kept pairs compacted by ballot
+                for (uint32_t c = 0; c < n; c += 64) {
+                    const uint32_t k = c + lane;
+                    const double ll = k < n ? row[k] : lowest;
+                    double incl = ll;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const double up = __shfl_up(incl, d, 64);
+                        if (lane >= d) incl = fmax(incl, up);
+                    }
+                    double before = __shfl_up(incl, 1, 64);
+                    before = lane == 0 ? max_ll : fmax(max_ll, before);
+                    const bool keep = k < n && !(ll - before < thr);
+                    const unsigned long long ballot = __ballot(keep);
+                    if (keep && wave == 0) {
+                        const uint32_t slot = kept + __popcll(ballot & ((1ull << lane) - 1ull));
+                        out_first[slot] = a[t];
+                        out_second[slot] = ord[tile_pos[t] + k];
+                        out_value[slot] = ll;
+                    }
+                    kept += __popcll(ballot);
+                    max_ll = fmax(max_ll, __shfl(incl, 63, 64));
                 }
-                ++kept;
+            } else {
+                for (uint32_t k = 0; k < n; ++k) {
+                    const double ll = row[k];
+                    if (!(ll - max_ll < thr)) {
+                        max_ll = fmax(max_ll, ll);
+                        if (threadIdx.x == 0) {
+                            out_first[kept] = a[t];
+                            out_second[kept] = ord[tile_pos[t] + k];
+                            out_value[kept] = ll;
+                        }
+                        ++kept;
+                    }
+                }
             }
         }
     }
@@ -298,7 +379,7 @@ struct TableWork {
     uint32_t count;
     const uint64_t * mat_val_off;
     const uint64_t * mat_row_off;
-    const uint64_t * mat_row0;
+    const uint32_t * mat_fast;
     const uint64_t * mat_rows;
     const uint32_t * mat_cols;
     const double * values;
@@ -336,8 +417,10 @@ __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
     const uint64_t r_begin = static_cast<uint64_t>(chunk) * kChunkRows;
     const uint32_t n = static_cast<uint32_t>((R - r_begin) < kChunkRows ? (R - r_begin) : kChunkRows);
     const double * M = w.values + w.mat_val_off[m] + r_begin;
-    const double * cnt = w.row_count + w.mat_row0[m] + r_begin;
-    const double * nz = w.row_noise + w.mat_row0[m] + r_begin;
+    const double * cnt = w.row_count + w.mat_row_off[m] + r_begin;
+    const double * nz = w.row_noise + w.mat_row_off[m] + r_begin;
+    const uint64_t fast_rows = w.mat_fast[m];
+    const uint32_t nf = fast_rows <= r_begin ? 0u : (fast_rows - r_begin < n ? static_cast<uint32_t>(fast_rows - r_begin) : n);  // count-1 rows of the chunk
 
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const double noise = nz[i];
@@ -356,14 +439,7 @@ __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
         if (task < ta) {
             const uint32_t a = a0 + task;
             const double * col_a = M + static_cast<uint64_t>(a) * R;
-            double acc0 = 0.0, acc1 = 0.0;
-            uint32_t i = lane;
-            for (; i + 64 < n; i += 128) {
-                acc0 = fma(lds_count[i], logPositive(nz[i] + col_a[i] / 1.0, lt), acc0);
-                acc1 = fma(lds_count[i + 64], logPositive(nz[i + 64] + col_a[i + 64] / 1.0, lt), acc1);
-            }
-            for (; i < n; i += 64) acc0 = fma(lds_count[i], logPositive(nz[i] + col_a[i] / 1.0, lt), acc0);
-            const double acc = waveSum(acc0 + acc1);
+            const double acc = waveSum(sumCountLogs<uint32_t>(lt, lds_count, [&](const uint32_t i) { return nz[i] + col_a[i] / 1.0; }, 0u, nf, n, lane));
             if (lane == 0) w.part_marginal[w.big_col_part_off[m] + static_cast<uint64_t>(chunk) * G + a] = acc;
         } else {
             const uint32_t b = a0 + (task - ta);
@@ -371,7 +447,17 @@ __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
             double acc[kTileA];
 #pragma unroll
             for (int t = 0; t < kTileA; ++t) acc[t] = 0.0;
-            for (uint32_t i = lane; i < n; i += 64) {
+            if (nf) {
+                LogProduct pr[kTileA];
+                for (uint32_t i = lane; i < nf; i += 64) {  // at most kChunkRows / 64 factors each
+                    const double x = col_b[i] / 2.0;
+#pragma unroll
+                    for (int t = 0; t < kTileA; ++t) pr[t].mul(lds_base[t][i] + x);
+                }
+#pragma unroll
+                for (int t = 0; t < kTileA; ++t) acc[t] = pr[t].value(lt);
+            }
+            for (uint32_t i = nf + lane; i < n; i += 64) {
                 const double x = col_b[i] / 2.0, c = lds_count[i];
 #pragma unroll
                 for (int t = 0; t < kTileA; ++t) acc[t] = fma(c, logPositive(lds_base[t][i] + x, lt), acc[t]);
@@ -626,6 +712,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     // rows x columns from which a matrix takes the table path (RPVG_HIP_TABLE_MIN_WORK overrides; tests use 0)
     double table_min_work = 65536.0;
     if (const char * env = std::getenv("RPVG_HIP_TABLE_MIN_WORK")) table_min_work = std::atof(env);
+    if (min_rel_likelihood > 1) table_min_work = 1e300;  // positive threshold: the prefix-maximum form of the rule does not hold
     uint32_t num_big = 0;
     std::vector<uint64_t> big_col_part_off(M, 0), big_pair_part_off(M, 0);
     std::vector<uint32_t> item_matrix, item_col, item_chunk;
@@ -703,19 +790,18 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
     }
 
-    const rpvg_hip_batch * b = groups->batch;
     SearchArgs args;
     args.order = d_order.ptr;
     args.count = M;
     args.mat_val_off = groups->mat_val_off.ptr;
     args.mat_row_off = groups->mat_row_off.ptr;
-    args.mat_row0 = groups->mat_row0.ptr;
+    args.mat_fast = groups->mat_fast.ptr;
     args.mat_rows = groups->mat_rows.ptr;
     args.mat_cols = groups->mat_cols.ptr;
     args.values = groups->values.ptr;
     args.rowmax = groups->rowmax.ptr;
-    args.row_count = b->row_count.ptr;
-    args.row_noise = b->row_noise.ptr;
+    args.row_count = groups->row_count.ptr;
+    args.row_noise = groups->row_noise.ptr;
     args.col_off = d_col_off.ptr;
     args.col_count = d_col_count.ptr;
     args.pair_cap_off = d_pair_cap_off.ptr;
@@ -766,13 +852,13 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         tw.count = static_cast<uint32_t>(item_matrix.size());
         tw.mat_val_off = groups->mat_val_off.ptr;
         tw.mat_row_off = groups->mat_row_off.ptr;
-        tw.mat_row0 = groups->mat_row0.ptr;
+        tw.mat_fast = groups->mat_fast.ptr;
         tw.mat_rows = groups->mat_rows.ptr;
         tw.mat_cols = groups->mat_cols.ptr;
         tw.values = groups->values.ptr;
         tw.rowmax = groups->rowmax.ptr;
-        tw.row_count = b->row_count.ptr;
-        tw.row_noise = b->row_noise.ptr;
+        tw.row_count = groups->row_count.ptr;
+        tw.row_noise = groups->row_noise.ptr;
         tw.big_col_part_off = d_big_col_part_off.ptr;
         tw.big_pair_part_off = d_big_pair_part_off.ptr;
         tw.part_marginal = d_part_marg.ptr;
@@ -808,17 +894,25 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     // the rest walk the search inside one workgroup; matrices with few rows stage less LDS (more
     // workgroups per CU).  `order` is [big | medium | small], each part expensive first.
     args.row_lds_cols = kRowLdsCols;
+    auto search_lds_bytes = [](uint32_t stage_rows) { return static_cast<size_t>((kTileFirst + 1) * stage_rows + kTileFirst * kRowLdsCols) * sizeof(double); };
+    {
+        static std::once_flag once;  // 96 KB of dynamic LDS: above the 64 KB a kernel gets without asking
+        std::call_once(once, [&]() {
+            (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&boundedSearchKernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(search_lds_bytes(kLdsRows)));
+        });
+    }
     if (num_medium > 0) {
         args.order = d_order.ptr + num_big;
         args.count = num_medium;
         args.stage_rows = kLdsRows;
-        boundedSearchKernel<1024><<<dim3(num_medium), dim3(1024), kLdsRows * 16 + kRowLdsCols * 8, ctx->aux[0]>>>(args);
+        boundedSearchKernel<1024><<<dim3(num_medium), dim3(1024), search_lds_bytes(kLdsRows), ctx->aux[0]>>>(args);
     }
     if (M > num_big + num_medium) {
         args.order = d_order.ptr + num_big + num_medium;
         args.count = M - num_big - num_medium;
         args.stage_rows = kSmallRows;
-        boundedSearchKernel<256><<<dim3(args.count), dim3(256), kSmallRows * 16 + kRowLdsCols * 8, ctx->aux[1]>>>(args);
+        boundedSearchKernel<256><<<dim3(args.count), dim3(256), search_lds_bytes(kSmallRows), ctx->aux[1]>>>(args);
     }
     ok(ctx->joinAux());
     ctx->spanEnd(span);

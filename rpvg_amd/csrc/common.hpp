@@ -196,12 +196,88 @@ __device__ __forceinline__ double logPositive(const double x, const LogTableEntr
     const double dk = static_cast<double>(k);
     return fma(dk, ln2_hi, e.hi) + (fma(dk, ln2_lo, static_cast<double>(e.lo)) + p);
 }
+
 #else
 __device__ double waveSumF64(double v);  // host compilation pass: declarations only
 __device__ double logPositive(double x);
 __device__ double logPositive(double x, const LogTableEntry * lds_table);
 __device__ void loadLogTable(LogTableEntry * lds_table);
 #endif
+
+// ---- sum of logarithms through a running product ------------------------------------
+// sum_i log(x_i) = log(prod_i x_i): every factor is split through its bit pattern into a mantissa in [1, 2), which
+// joins an FP64 product, and an exponent, which joins an integer sum — one multiplication and three integer
+// instructions per factor instead of a logarithm; one logarithm at the end.  Factors must be positive normal doubles.
+// The product of n mantissas stays below 2^n: fold() (exponent of the product -> integer sum) at least every 1000
+// factors.  The rounding error of the product grows like n * 2^-53, the same order as that of a sum of n logarithms.
+struct LogProduct {
+    double p = 1.0;
+    int e = 0;  // sum of unbiased exponents
+    __device__ __forceinline__ void mul(const double x) {
+        const uint32_t hi_word = static_cast<uint32_t>(__double2hiint(x));
+        e += static_cast<int>(hi_word >> 20) - 1023;
+        p *= __hiloint2double(static_cast<int>((hi_word & 0x000fffffu) | 0x3ff00000u), __double2loint(x));
+    }
+    __device__ __forceinline__ void fold() {
+        const uint32_t hi_word = static_cast<uint32_t>(__double2hiint(p));
+        e += static_cast<int>(hi_word >> 20) - 1023;
+        p = __hiloint2double(static_cast<int>((hi_word & 0x000fffffu) | 0x3ff00000u), __double2loint(p));
+    }
+    // both folded (or holding few factors)
+    __device__ __forceinline__ void join(const LogProduct & other) {
+        p *= other.p;
+        e += other.e;
+    }
+    __device__ __forceinline__ double value(const LogTableEntry * lds_table) {
+        const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+        fold();
+        const double de = static_cast<double>(e);
+        return fma(de, ln2_hi, fma(de, ln2_lo, logPositive(p, lds_table)));
+    }
+};
+
+// Rows with read count 1 and a noise probability that keeps every log argument a positive normal number come first
+// in a group matrix (rpvg_hip_groups::mat_fast of them): their logs go through LogProduct.
+constexpr double kFastRowMinNoise = 1e-290;
+constexpr uint32_t kFoldRows = 64 * 4 * 200;  // rows of a wave between two fold() calls of its four product chains
+
+// sum over rows [begin, end) of a wave (lane handles begin + lane, + 64, ...) of count_i * log(x(i)); rows below
+// n_fast have count 1 and go through running products, the others through one logarithm each.
+template <typename IndexT, typename XFn>
+__device__ __forceinline__ double sumCountLogs(const LogTableEntry * lt, const double * __restrict__ cnt, XFn x, const IndexT begin,
+                                               const IndexT n_fast, const IndexT end, const int lane) {
+    double acc = 0.0;
+    if (begin < n_fast) {
+        LogProduct p0, p1, p2, p3;
+        for (IndexT seg = begin; seg < n_fast; seg += kFoldRows) {
+            const IndexT seg_end = (n_fast - seg) < kFoldRows ? n_fast : seg + kFoldRows;
+            IndexT i = seg + lane;
+            for (; i + 192 < seg_end; i += 256) {
+                p0.mul(x(i));
+                p1.mul(x(i + 64));
+                p2.mul(x(i + 128));
+                p3.mul(x(i + 192));
+            }
+            for (; i < seg_end; i += 64) p0.mul(x(i));
+            p0.fold();
+            p1.fold();
+            p2.fold();
+            p3.fold();
+        }
+        p0.join(p1);
+        p2.join(p3);
+        p0.join(p2);
+        acc = p0.value(lt);
+    }
+    double acc0 = 0.0, acc1 = 0.0;
+    IndexT i = (begin < n_fast ? n_fast : begin) + lane;
+    for (; i + 64 < end; i += 128) {
+        acc0 = fma(cnt[i], logPositive(x(i), lt), acc0);
+        acc1 = fma(cnt[i + 64], logPositive(x(i + 64), lt), acc1);
+    }
+    for (; i < end; i += 64) acc0 = fma(cnt[i], logPositive(x(i), lt), acc0);
+    return acc + (acc0 + acc1);
+}
 
 // ---- kernel-family timing ---------------------------------------------------
 enum KernelFamily { FAM_EM_SPARSE = 0, FAM_EM_DENSE, FAM_LOGLIK, FAM_BUILD, FAM_H2D, FAM_COUNT };
@@ -272,6 +348,12 @@ struct rpvg_hip_groups {
     rpvg_hip_detail::DeviceBuffer<uint64_t> mat_row0;     // [M] first batch row of the matrix's cluster
     rpvg_hip_detail::DeviceBuffer<uint64_t> mat_rows;     // [M] R_m
     rpvg_hip_detail::DeviceBuffer<uint32_t> mat_cols;     // [M] G_m
+    // Rows of a matrix are a permutation of its cluster's rows (every consumer sums over rows): count-1 rows first
+    // (LogProduct, above).  Counts and noise in matrix order, indexed like rowmax.
+    rpvg_hip_detail::DeviceBuffer<uint32_t> row_perm;     // [sum R_m] cluster-relative source row
+    rpvg_hip_detail::DeviceBuffer<double> row_count;      // [sum R_m]
+    rpvg_hip_detail::DeviceBuffer<double> row_noise;      // [sum R_m]
+    rpvg_hip_detail::DeviceBuffer<uint32_t> mat_fast;     // [M] leading rows with count 1 and noise >= kFastRowMinNoise
 };
 
 #endif

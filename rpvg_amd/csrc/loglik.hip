@@ -29,6 +29,59 @@ namespace {
 
 constexpr uint32_t kNoMember = 0xFFFFFFFFu;
 
+// Row order of every matrix: the rows of its cluster whose read count is 1 (and whose noise probability keeps the
+// log arguments normal) first, the others after them, both in cluster order (stable, deterministic).  One workgroup
+// per matrix: count, then place chunk by chunk with ballot ranks.
+__global__ __launch_bounds__(256) void partitionRowsKernel(
+    const uint32_t num_matrices, const uint64_t * __restrict__ mat_row_off, const uint64_t * __restrict__ mat_row0,
+    const uint64_t * __restrict__ mat_rows, const double * __restrict__ row_count, const double * __restrict__ row_noise,
+    uint32_t * __restrict__ row_perm, double * __restrict__ count_out, double * __restrict__ noise_out,
+    uint32_t * __restrict__ mat_fast) {
+    __shared__ uint32_t wave_fast[4];
+    __shared__ uint32_t total_fast;
+    const uint32_t m = blockIdx.x;
+    if (m >= num_matrices) return;
+    const uint32_t R = static_cast<uint32_t>(mat_rows[m]);
+    const double * cnt = row_count + mat_row0[m];
+    const double * nz = row_noise + mat_row0[m];
+    const uint64_t out0 = mat_row_off[m];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) total_fast = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < R; i += 256) mine += (cnt[i] == 1.0 && nz[i] >= kFastRowMinNoise) ? 1u : 0u;
+    if (mine) atomicAdd(&total_fast, mine);
+    __syncthreads();
+    const uint32_t n_fast = total_fast;
+    if (threadIdx.x == 0) mat_fast[m] = n_fast;
+    uint32_t fast_base = 0, slow_base = n_fast;
+    for (uint32_t c0 = 0; c0 < R; c0 += 256) {
+        const uint32_t i = c0 + threadIdx.x;
+        const bool in = i < R;
+        const double c = in ? cnt[i] : 0.0, z = in ? nz[i] : 0.0;
+        const bool fast = in && c == 1.0 && z >= kFastRowMinNoise;
+        const unsigned long long ballot = __ballot(fast);
+        const uint32_t before = __popcll(ballot & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) wave_fast[wave] = __popcll(ballot);
+        __syncthreads();
+        uint32_t fast_before = before, chunk_fast = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            fast_before += (w < wave) ? wave_fast[w] : 0u;
+            chunk_fast += wave_fast[w];
+        }
+        if (in) {
+            const uint32_t dest = fast ? fast_base + fast_before : slow_base + (threadIdx.x - fast_before);
+            row_perm[out0 + dest] = i;
+            count_out[out0 + dest] = c;
+            noise_out[out0 + dest] = z;
+        }
+        fast_base += chunk_fast;
+        slow_base += min(256u, R - c0) - chunk_fast;
+    }
+}
+
 // one workgroup per (matrix, chunk of 256 rows), thread per row
 __global__ __launch_bounds__(256) void groupsBuildKernel(
     const uint32_t num_items, const uint32_t * __restrict__ item_matrix, const uint32_t * __restrict__ item_chunk,
@@ -38,7 +91,7 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
     const uint64_t * __restrict__ path_grp_off,  // per matrix N_k+1 offsets (absolute into path_grp)
     const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
     const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
-    const int normalise, double * __restrict__ values, double * __restrict__ rowmax) {
+    const uint32_t * __restrict__ row_perm, const int normalise, double * __restrict__ values, double * __restrict__ rowmax) {
     if (blockIdx.x >= num_items) return;
     const uint32_t m = item_matrix[blockIdx.x];
     const uint64_t R = mat_rows[m], r0 = mat_row0[m];
@@ -48,7 +101,7 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
     const uint64_t * pgo = path_grp_off + mat_inc_off[m];
     const uint64_t i = static_cast<uint64_t>(item_chunk[blockIdx.x]) * 256 + threadIdx.x;
     if (i < R) {
-        const uint64_t r = r0 + i;
+        const uint64_t r = r0 + row_perm[mat_row_off[m] + i];  // matrix row i = this row of the cluster
         for (uint64_t e = row_ent_off[r]; e < row_ent_off[r + 1]; ++e) {
             const uint32_t p = ent_path[e];
             const double v = ent_prob[e];
@@ -98,7 +151,7 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
     const uint64_t * __restrict__ mat_inc_off, const uint64_t * __restrict__ path_grp_off,
     const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
     const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
-    const int normalise, double * __restrict__ values, double * __restrict__ rowmax) {
+    const uint32_t * __restrict__ row_perm, const int normalise, double * __restrict__ values, double * __restrict__ rowmax) {
     extern __shared__ double tile[];
     if (blockIdx.x >= num_items) return;
     const uint32_t m = item_matrix[blockIdx.x];
@@ -112,7 +165,7 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
     __syncthreads();
     const uint32_t t = threadIdx.x;
     if (t < nrows) {
-        const uint64_t r = r0 + i0 + t;
+        const uint64_t r = r0 + row_perm[mat_row_off[m] + i0 + t];  // matrix row i0 + t = this row of the cluster
         const uint64_t * pgo = path_grp_off + mat_inc_off[m];
         for (uint64_t e = row_ent_off[r]; e < row_ent_off[r + 1]; ++e) {
             const uint32_t p = ent_path[e];
@@ -203,7 +256,7 @@ template <int WIDTH>
 __global__ __launch_bounds__(256) void groupLoglikKernel(
     const uint32_t num_requests, const uint32_t * __restrict__ req_matrix, const uint32_t * __restrict__ req_members,
     const uint8_t * __restrict__ req_rowmax, const double divisor, const uint64_t * __restrict__ mat_val_off,
-    const uint64_t * __restrict__ mat_row_off, const uint64_t * __restrict__ mat_row0,
+    const uint64_t * __restrict__ mat_row_off, const uint32_t * __restrict__ mat_fast,
     const uint64_t * __restrict__ mat_rows, const double * __restrict__ values, const double * __restrict__ rowmax,
     const double * __restrict__ row_count, const double * __restrict__ row_noise, double * __restrict__ out) {
     __shared__ LogTableEntry lt[kLogTableSize];
@@ -215,8 +268,8 @@ __global__ __launch_bounds__(256) void groupLoglikKernel(
     const uint32_t m = req_matrix[q];
     const uint64_t R = mat_rows[m];
     const double * M = values + mat_val_off[m];
-    const double * cnt = row_count + mat_row0[m];
-    const double * nz = row_noise + mat_row0[m];
+    const double * cnt = row_count + mat_row_off[m];
+    const double * nz = row_noise + mat_row_off[m];
     const double * rm = req_rowmax && req_rowmax[q] ? rowmax + mat_row_off[m] : nullptr;
     const double * col[WIDTH];
 #pragma unroll
@@ -224,16 +277,15 @@ __global__ __launch_bounds__(256) void groupLoglikKernel(
         const uint32_t g = req_members[static_cast<uint64_t>(q) * WIDTH + w];
         col[w] = (g == kNoMember) ? nullptr : M + static_cast<uint64_t>(g) * R;
     }
-    double acc = 0.0;
-    for (uint64_t i = lane; i < R; i += 64) {
+    auto x = [&](const uint64_t i) {
         double v = nz[i];
 #pragma unroll
         for (int w = 0; w < WIDTH; ++w)
             if (col[w]) v += col[w][i] / divisor;
         if (rm) v += rm[i] / divisor;
-        acc = fma(cnt[i], logPositive(v, lt), acc);
-    }
-    acc = waveSumF64(acc);
+        return v;
+    };
+    const double acc = waveSumF64(sumCountLogs<uint64_t>(lt, cnt, x, 0, mat_fast[m], R, lane));
     if (lane == 0) out[q] = acc;
 }
 
@@ -246,7 +298,7 @@ __global__ __launch_bounds__(256) void groupConditionalKernel(
     const uint32_t num_requests, const uint64_t num_items, const uint64_t * __restrict__ item_off,
     const uint64_t * __restrict__ out_off, const uint32_t * __restrict__ req_matrix,
     const uint32_t * __restrict__ req_others, const double divisor, const uint64_t * __restrict__ mat_val_off,
-    const uint64_t * __restrict__ mat_row0, const uint64_t * __restrict__ mat_rows,
+    const uint64_t * __restrict__ mat_row_off, const uint32_t * __restrict__ mat_fast, const uint64_t * __restrict__ mat_rows,
     const uint32_t * __restrict__ mat_cols, const double * __restrict__ values, const double * __restrict__ row_count,
     const double * __restrict__ row_noise, double * __restrict__ out) {
     constexpr int kCand = 4;
@@ -267,8 +319,8 @@ __global__ __launch_bounds__(256) void groupConditionalKernel(
     const uint32_t G = mat_cols[m];
     const uint32_t k0 = static_cast<uint32_t>(item - item_off[q]) * kCand;
     const double * M = values + mat_val_off[m];
-    const double * cnt = row_count + mat_row0[m];
-    const double * nz = row_noise + mat_row0[m];
+    const double * cnt = row_count + mat_row_off[m];
+    const double * nz = row_noise + mat_row_off[m];
     const double * other[WIDTH > 1 ? WIDTH - 1 : 1];
 #pragma unroll
     for (int w = 0; w + 1 < WIDTH; ++w) other[w] = M + static_cast<uint64_t>(req_others[static_cast<uint64_t>(q) * (WIDTH - 1) + w]) * R;
@@ -276,7 +328,25 @@ __global__ __launch_bounds__(256) void groupConditionalKernel(
 #pragma unroll
     for (int c = 0; c < kCand; ++c) cand[c] = M + static_cast<uint64_t>(min(k0 + c, G - 1)) * R;
     double acc[kCand] = {0.0, 0.0, 0.0, 0.0};
-    for (uint64_t i = lane; i < R; i += 64) {
+    const uint64_t n_fast = mat_fast[m];
+    if (n_fast) {  // count-1 rows: running products
+        LogProduct pr[kCand];
+        for (uint64_t seg = 0; seg < n_fast; seg += kFoldRows / 4) {
+            const uint64_t seg_end = min(n_fast, seg + kFoldRows / 4);
+            for (uint64_t i = seg + lane; i < seg_end; i += 64) {
+                double base = nz[i];
+#pragma unroll
+                for (int w = 0; w + 1 < WIDTH; ++w) base += other[w][i] / divisor;
+#pragma unroll
+                for (int c = 0; c < kCand; ++c) pr[c].mul(base + cand[c][i] / divisor);
+            }
+#pragma unroll
+            for (int c = 0; c < kCand; ++c) pr[c].fold();
+        }
+#pragma unroll
+        for (int c = 0; c < kCand; ++c) acc[c] = pr[c].value(lt);
+    }
+    for (uint64_t i = n_fast + lane; i < R; i += 64) {
         double base = nz[i];
 #pragma unroll
         for (int w = 0; w + 1 < WIDTH; ++w) base += other[w][i] / divisor;
@@ -349,6 +419,11 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         const uint64_t R = batch->h_cluster_row_off[k + 1] - batch->h_cluster_row_off[k];
         const uint64_t N = batch->h_cluster_path_off[k + 1] - batch->h_cluster_path_off[k];
         const uint64_t g0 = spec->group_off[m], g1 = spec->group_off[m + 1];
+        if (R > 0xffffffffull) {
+            setError("rpvg_hip_groups_build: matrix %u has %llu rows (limit 2^32 - 1)", m, static_cast<unsigned long long>(R));
+            delete g;
+            return RPVG_HIP_ERR_INVALID;
+        }
         if (R == 0 || g1 <= g0) {
             setError("rpvg_hip_groups_build: matrix %u has no rows or no columns", m);
             delete g;
@@ -419,6 +494,10 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     ctx->stats.h2d_bytes += static_cast<double>(M * 60 + num_columns * 8 + num_incidences * 4 + (item_matrix.size() + tile_matrix.size()) * 8);
     ok(g->values.alloc(val_total));
     ok(g->rowmax.alloc(row_total));
+    ok(g->row_perm.alloc(row_total));
+    ok(g->row_count.alloc(row_total));
+    ok(g->row_noise.alloc(row_total));
+    ok(g->mat_fast.alloc(M));
     ok(d_degree.alloc(inc_total));
     ok(d_cursor.alloc(inc_total));
     ok(d_path_grp_off.alloc(inc_total));
@@ -436,6 +515,9 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         for (auto m : wide_matrices) {
             ok(hipMemsetAsync(g->values.ptr + val_off[m], 0, rows[m] * cols[m] * sizeof(double), st));
         }
+        partitionRowsKernel<<<dim3(M), dim3(256), 0, st>>>(M, g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, batch->row_count.ptr,
+                                                           batch->row_noise.ptr, g->row_perm.ptr, g->row_count.ptr, g->row_noise.ptr,
+                                                           g->mat_fast.ptr);
         const uint32_t col_blocks = static_cast<uint32_t>((num_columns + 255) / 256);
         incidenceCountKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,
                                                                    d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
@@ -449,14 +531,14 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
                 static_cast<uint32_t>(tile_matrix.size()), d_tile_matrix.ptr, d_tile_chunk.ptr, g->mat_val_off.ptr,
                 g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
                 d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
-                spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr);
+                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr);
         }
         if (!item_matrix.empty()) {
             groupsBuildKernel<<<dim3(static_cast<uint32_t>(item_matrix.size())), dim3(256), 0, st>>>(
                 static_cast<uint32_t>(item_matrix.size()), d_item_matrix.ptr, d_item_chunk.ptr, g->mat_val_off.ptr,
                 g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
                 d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
-                spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr);
+                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr);
         }
         ctx->spanEnd(span);
         ctx->stats.build_launches += 3;
@@ -526,13 +608,12 @@ extern "C" int rpvg_hip_group_loglik(rpvg_hip_ctx * ctx, const rpvg_hip_groups *
     RPVG_HIP_CHECK(d_out.alloc(num_requests));
 
     const uint32_t blocks = (num_requests + 3) / 4;
-    const rpvg_hip_batch * b = groups->batch;
     span = ctx->spanBegin(FAM_LOGLIK);
 #define RPVG_LAUNCH_LOGLIK(W)                                                                                              \
     groupLoglikKernel<W><<<dim3(blocks), dim3(256), 0, st>>>(num_requests, d_matrix.ptr, d_members.ptr, d_flag.ptr, divisor, \
                                                             groups->mat_val_off.ptr, groups->mat_row_off.ptr,               \
-                                                            groups->mat_row0.ptr, groups->mat_rows.ptr, groups->values.ptr, \
-                                                            groups->rowmax.ptr, b->row_count.ptr, b->row_noise.ptr, d_out.ptr)
+                                                            groups->mat_fast.ptr, groups->mat_rows.ptr, groups->values.ptr, \
+                                                            groups->rowmax.ptr, groups->row_count.ptr, groups->row_noise.ptr, d_out.ptr)
     switch (width) {
         case 1: RPVG_LAUNCH_LOGLIK(1); break;
         case 2: RPVG_LAUNCH_LOGLIK(2); break;
@@ -592,13 +673,12 @@ extern "C" int rpvg_hip_group_conditionals(rpvg_hip_ctx * ctx, const rpvg_hip_gr
     const uint64_t blocks = (num_items + 3) / 4;
     RPVG_REQUIRE(blocks <= 0x7fffffffull, "rpvg_hip_group_conditionals: %llu work items exceed one launch",
                  static_cast<unsigned long long>(num_items));
-    const rpvg_hip_batch * b = groups->batch;
     span = ctx->spanBegin(FAM_LOGLIK);
 #define RPVG_LAUNCH_COND(W)                                                                                                  \
     groupConditionalKernel<W><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(                                    \
         num_requests, num_items, d_item_off.ptr, d_out_off.ptr, d_matrix.ptr, d_others.ptr, divisor, groups->mat_val_off.ptr, \
-        groups->mat_row0.ptr, groups->mat_rows.ptr, groups->mat_cols.ptr, groups->values.ptr, b->row_count.ptr,              \
-        b->row_noise.ptr, d_out.ptr)
+        groups->mat_row_off.ptr, groups->mat_fast.ptr, groups->mat_rows.ptr, groups->mat_cols.ptr, groups->values.ptr,       \
+        groups->row_count.ptr, groups->row_noise.ptr, d_out.ptr)
     switch (width) {
         case 1: RPVG_LAUNCH_COND(1); break;
         case 2: RPVG_LAUNCH_COND(2); break;

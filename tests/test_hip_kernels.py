@@ -345,7 +345,7 @@ def test_group_conditionals_equal_member_list_requests(hip_ctx, width):
         G = num_cols[m]
         assert g.shape == (G,)
         want = dg.loglik([m] * G, [o + [k] for k in range(G)], float(width))
-        assert np.array_equal(g, want)
+        assert np.allclose(g, want, rtol=1e-13, atol=0)  # same sums, different association (product chains)
     cl = clusters[req_m[0]]
     M, noise, counts = np_oracle.grouped_matrix(cl["rows"], groups[req_m[0]])
     want0 = np.array([np_oracle.set_loglik(M, noise, counts, tuple(req_o[0]) + (k,), width) for k in range(num_cols[req_m[0]])])
