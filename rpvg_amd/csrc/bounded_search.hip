@@ -82,7 +82,8 @@ struct SearchArgs {
     uint32_t count;
     const uint64_t * mat_val_off;
     const uint64_t * mat_row_off;
-    const uint32_t * mat_fast;       // leading rows with read count 1 (running products instead of logs)
+    const uint32_t * mat_fast;       // row classes of the matrix (LogProduct, common.hpp): end of the fast rows,
+    const uint32_t * mat_mid;        // end of the mid rows
     const uint64_t * mat_rows;
     const uint32_t * mat_cols;
     const double * values;
@@ -113,51 +114,42 @@ constexpr int kTileFirst = 4;  // first columns evaluated together by the search
 
 // Pair sums of one second column b against the kTileFirst first columns of a tile, over the rows of a wave:
 // out[t] = sum_i count_i log((noise_i + col_a[t][i] / 2) + col_b[i] / 2).  Every element of b is read once and feeds
-// kTileFirst logs.  The first `staged` rows take base_t = noise + col_a[t] / 2 and the counts from LDS; rows below
-// n_fast have count 1 (running products).
+// kTileFirst logs.  The first `staged` rows take base_t = noise + col_a[t] / 2 and the counts from LDS.  The rows
+// are dealt to a group of kGroup lanes (`lane` = index within the group); the caller adds the sums up over the group.
+template <int kGroup>
 __device__ __forceinline__ void tilePairSums(const LogTableEntry * lt, const double * lds_count, const double * lds_base, const uint32_t stride,
                                              const double * __restrict__ cnt, const double * __restrict__ nz,
                                              const double * const (&col_a)[kTileFirst], const double * __restrict__ col_b, const uint32_t staged,
-                                             const uint64_t n_fast, const uint64_t R, const int lane, double (&out)[kTileFirst]) {
+                                             const uint64_t fast_end, const uint64_t mid_end, const uint64_t R, const int lane,
+                                             double (&out)[kTileFirst]) {
     LogProduct pr[kTileFirst];
     double acc[kTileFirst];
 #pragma unroll
     for (int t = 0; t < kTileFirst; ++t) acc[t] = 0.0;
-    const uint32_t fast_staged = static_cast<uint32_t>(n_fast < staged ? n_fast : staged);
-    for (uint32_t i = lane; i < fast_staged; i += 64) {  // at most kLdsRows / 64 factors: no fold needed
+    auto clip = [&](const uint64_t v) { return static_cast<uint32_t>(v < staged ? v : staged); };
+    sumCountLogsMulti<kTileFirst, kGroup, uint32_t>(lt, lds_count, [&](const uint32_t i, double (&xs)[kTileFirst]) {
         const double x = col_b[i] / 2.0;
 #pragma unroll
-        for (int t = 0; t < kTileFirst; ++t) pr[t].mul(lds_base[t * stride + i] + x);
-    }
-    for (uint32_t i = fast_staged + lane; i < staged; i += 64) {
-        const double x = col_b[i] / 2.0, c = lds_count[i];
-#pragma unroll
-        for (int t = 0; t < kTileFirst; ++t) acc[t] = fma(c, logPositive(lds_base[t * stride + i] + x, lt), acc[t]);
-    }
+        for (int t = 0; t < kTileFirst; ++t) xs[t] = lds_base[t * stride + i] + x;
+    }, 0u, clip(fast_end), clip(mid_end), staged, lane, pr, acc);
     if (staged < R) {
-        for (uint64_t seg = staged; seg < n_fast; seg += kFoldRows / 4) {
-            const uint64_t seg_end = (n_fast - seg) < kFoldRows / 4 ? n_fast : seg + kFoldRows / 4;
-            for (uint64_t i = seg + lane; i < seg_end; i += 64) {
-                const double noise = nz[i], x = col_b[i] / 2.0;
+        sumCountLogsMulti<kTileFirst, kGroup, uint64_t>(lt, cnt, [&](const uint64_t i, double (&xs)[kTileFirst]) {
+            const double noise = nz[i], x = col_b[i] / 2.0;
 #pragma unroll
-                for (int t = 0; t < kTileFirst; ++t) pr[t].mul((noise + col_a[t][i] / 2.0) + x);
-            }
-#pragma unroll
-            for (int t = 0; t < kTileFirst; ++t) pr[t].fold();
-        }
-        for (uint64_t i = (n_fast > staged ? n_fast : staged) + lane; i < R; i += 64) {
-            const double noise = nz[i], x = col_b[i] / 2.0, c = cnt[i];
-#pragma unroll
-            for (int t = 0; t < kTileFirst; ++t) acc[t] = fma(c, logPositive((noise + col_a[t][i] / 2.0) + x, lt), acc[t]);
-        }
+            for (int t = 0; t < kTileFirst; ++t) xs[t] = (noise + col_a[t][i] / 2.0) + x;
+        }, static_cast<uint64_t>(staged), fast_end, mid_end, R, lane, pr, acc);
     }
 #pragma unroll
-    for (int t = 0; t < kTileFirst; ++t) out[t] = n_fast ? acc[t] + pr[t].value(lt) : acc[t];
+    for (int t = 0; t < kTileFirst; ++t) out[t] = mid_end ? acc[t] + pr[t].value(lt) : acc[t];
 }
 
-template <int kBlock>
+// kGroup lanes work on one second column at a time: 64 (a wave per column) for matrices with many rows, 16 (four
+// columns per wave) for those with few, where the end of a column's sum — one logarithm per product, the
+// reduction over the lanes — costs as much as its rows: four columns share those instructions.
+template <int kBlock, int kGroup>
 __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs args) {
     constexpr int kWaves = kBlock / 64;
+    constexpr int kGroupsPerWave = 64 / kGroup;
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     double * lds_base = lds_dyn;                                  // [kTileFirst][stage_rows]
     double * lds_count = lds_dyn + kTileFirst * args.stage_rows;  // [stage_rows]
@@ -176,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
     const double * rm = args.rowmax + args.mat_row_off[m];
     const double * cnt = args.row_count + args.mat_row_off[m];
     const double * nz = args.row_noise + args.mat_row_off[m];
-    const uint64_t n_fast = args.mat_fast[m];
+    const uint64_t fast_end = args.mat_fast[m], mid_end = args.mat_mid[m];
     const uint64_t c0 = args.col_off[m];
     const uint32_t * ccount = args.col_count + c0;
     double * lf = args.log_freq + c0;
@@ -206,8 +198,8 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
     // marginal log-posteriors (group size 1) and optimistic bounds of every column: two logs per row
     for (uint32_t g = wave; g < G; g += kWaves) {
         const double * col = M + static_cast<uint64_t>(g) * R;
-        double acc1 = sumCountLogs<uint64_t>(lt, cnt, [&](const uint64_t i) { return nz[i] + col[i] / 1.0; }, 0, n_fast, R, lane);
-        double acc2 = sumCountLogs<uint64_t>(lt, cnt, [&](const uint64_t i) { return (nz[i] + col[i] / 2.0) + rm[i] / 2.0; }, 0, n_fast, R, lane);
+        double acc1 = sumCountLogs<uint64_t>(lt, cnt, [&](const uint64_t i) { return nz[i] + col[i] / 1.0; }, 0, fast_end, mid_end, R, lane);
+        double acc2 = sumCountLogs<uint64_t>(lt, cnt, [&](const uint64_t i) { return (nz[i] + col[i] / 2.0) + rm[i] / 2.0; }, 0, fast_end, mid_end, R, lane);
         acc1 = waveSum(acc1);
         acc2 = waveSum(acc2);
         if (lane == 0) {
@@ -283,15 +275,18 @@ __global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs a
         for (uint32_t t = 0; t < nt; ++t) pairs_evaluated += G - tile_pos[t];
         // every wave evaluates its share of the second columns without waiting for the others ...
         const uint32_t j0 = tile_pos[0];
-        for (uint32_t j = j0 + wave; j < G; j += kWaves) {
-            const uint32_t b = ord[j];
+        const int sub = lane & (kGroup - 1), grp = lane / kGroup;
+        for (uint32_t jw = j0 + wave * kGroupsPerWave; jw < G; jw += kWaves * kGroupsPerWave) {
+            const uint32_t j = jw + grp;
+            const bool valid = j < G;  // idle groups of the last pass repeat the last column (uniform code)
+            const uint32_t b = ord[valid ? j : G - 1];
             double sums[kTileFirst];
-            tilePairSums(lt, lds_count, lds_base, stride, cnt, nz, col_a, M + static_cast<uint64_t>(b) * R, staged, n_fast, R, lane, sums);
+            tilePairSums<kGroup>(lt, lds_count, lds_base, stride, cnt, nz, col_a, M + static_cast<uint64_t>(b) * R, staged, fast_end, mid_end, R, sub, sums);
             const double lf_b = lf[b];
 #pragma unroll
             for (int t = 0; t < kTileFirst; ++t) {
-                const double total = waveSum(sums[t]);
-                if (lane == 0 && t < static_cast<int>(nt) && j >= tile_pos[t]) {
+                const double total = kGroup == 64 ? waveSum(sums[t]) : rowSumF64(sums[t]);
+                if (sub == 0 && valid && t < static_cast<int>(nt) && j >= tile_pos[t]) {
                     row_ll[t * row_stride + (j - tile_pos[t])] = total + ((lf[a[t]] + lf_b) + (a[t] == b ? 0.0 : log_two));
                 }
             }
@@ -380,6 +375,7 @@ struct TableWork {
     const uint64_t * mat_val_off;
     const uint64_t * mat_row_off;
     const uint32_t * mat_fast;
+    const uint32_t * mat_mid;
     const uint64_t * mat_rows;
     const uint32_t * mat_cols;
     const double * values;
@@ -419,8 +415,8 @@ __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
     const double * M = w.values + w.mat_val_off[m] + r_begin;
     const double * cnt = w.row_count + w.mat_row_off[m] + r_begin;
     const double * nz = w.row_noise + w.mat_row_off[m] + r_begin;
-    const uint64_t fast_rows = w.mat_fast[m];
-    const uint32_t nf = fast_rows <= r_begin ? 0u : (fast_rows - r_begin < n ? static_cast<uint32_t>(fast_rows - r_begin) : n);  // count-1 rows of the chunk
+    auto local = [&](const uint64_t end_row) { return end_row <= r_begin ? 0u : (end_row - r_begin < n ? static_cast<uint32_t>(end_row - r_begin) : n); };
+    const uint32_t nf = local(w.mat_fast[m]), nm = local(w.mat_mid[m]);  // class boundaries within the chunk
 
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const double noise = nz[i];
@@ -439,28 +435,23 @@ __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
         if (task < ta) {
             const uint32_t a = a0 + task;
             const double * col_a = M + static_cast<uint64_t>(a) * R;
-            const double acc = waveSum(sumCountLogs<uint32_t>(lt, lds_count, [&](const uint32_t i) { return nz[i] + col_a[i] / 1.0; }, 0u, nf, n, lane));
+            const double acc = waveSum(sumCountLogs<uint32_t>(lt, lds_count, [&](const uint32_t i) { return nz[i] + col_a[i] / 1.0; }, 0u, nf, nm, n, lane));
             if (lane == 0) w.part_marginal[w.big_col_part_off[m] + static_cast<uint64_t>(chunk) * G + a] = acc;
         } else {
             const uint32_t b = a0 + (task - ta);
             const double * col_b = M + static_cast<uint64_t>(b) * R;
             double acc[kTileA];
+            LogProduct pr[kTileA];
 #pragma unroll
             for (int t = 0; t < kTileA; ++t) acc[t] = 0.0;
-            if (nf) {
-                LogProduct pr[kTileA];
-                for (uint32_t i = lane; i < nf; i += 64) {  // at most kChunkRows / 64 factors each
-                    const double x = col_b[i] / 2.0;
+            sumCountLogsMulti<kTileA, 64, uint32_t>(lt, lds_count, [&](const uint32_t i, double (&xs)[kTileA]) {
+                const double x = col_b[i] / 2.0;
 #pragma unroll
-                    for (int t = 0; t < kTileA; ++t) pr[t].mul(lds_base[t][i] + x);
-                }
+                for (int t = 0; t < kTileA; ++t) xs[t] = lds_base[t][i] + x;
+            }, 0u, nf, nm, n, lane, pr, acc);
+            if (nm) {
 #pragma unroll
-                for (int t = 0; t < kTileA; ++t) acc[t] = pr[t].value(lt);
-            }
-            for (uint32_t i = nf + lane; i < n; i += 64) {
-                const double x = col_b[i] / 2.0, c = lds_count[i];
-#pragma unroll
-                for (int t = 0; t < kTileA; ++t) acc[t] = fma(c, logPositive(lds_base[t][i] + x, lt), acc[t]);
+                for (int t = 0; t < kTileA; ++t) acc[t] += pr[t].value(lt);
             }
 #pragma unroll
             for (int t = 0; t < kTileA; ++t) {
@@ -796,6 +787,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     args.mat_val_off = groups->mat_val_off.ptr;
     args.mat_row_off = groups->mat_row_off.ptr;
     args.mat_fast = groups->mat_fast.ptr;
+    args.mat_mid = groups->mat_mid.ptr;
     args.mat_rows = groups->mat_rows.ptr;
     args.mat_cols = groups->mat_cols.ptr;
     args.values = groups->values.ptr;
@@ -853,6 +845,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         tw.mat_val_off = groups->mat_val_off.ptr;
         tw.mat_row_off = groups->mat_row_off.ptr;
         tw.mat_fast = groups->mat_fast.ptr;
+        tw.mat_mid = groups->mat_mid.ptr;
         tw.mat_rows = groups->mat_rows.ptr;
         tw.mat_cols = groups->mat_cols.ptr;
         tw.values = groups->values.ptr;
@@ -898,7 +891,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     {
         static std::once_flag once;  // 96 KB of dynamic LDS: above the 64 KB a kernel gets without asking
         std::call_once(once, [&]() {
-            (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&boundedSearchKernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&boundedSearchKernel<1024, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(search_lds_bytes(kLdsRows)));
         });
     }
@@ -906,13 +899,13 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         args.order = d_order.ptr + num_big;
         args.count = num_medium;
         args.stage_rows = kLdsRows;
-        boundedSearchKernel<1024><<<dim3(num_medium), dim3(1024), search_lds_bytes(kLdsRows), ctx->aux[0]>>>(args);
+        boundedSearchKernel<1024, 64><<<dim3(num_medium), dim3(1024), search_lds_bytes(kLdsRows), ctx->aux[0]>>>(args);
     }
     if (M > num_big + num_medium) {
         args.order = d_order.ptr + num_big + num_medium;
         args.count = M - num_big - num_medium;
         args.stage_rows = kSmallRows;
-        boundedSearchKernel<256><<<dim3(args.count), dim3(256), search_lds_bytes(kSmallRows), ctx->aux[1]>>>(args);
+        boundedSearchKernel<256, 16><<<dim3(args.count), dim3(256), search_lds_bytes(kSmallRows), ctx->aux[1]>>>(args);
     }
     ok(ctx->joinAux());
     ctx->spanEnd(span);

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -120,6 +121,14 @@ __device__ __forceinline__ double readLaneF64(const double v, const int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
+// sum over the lane's row of 16 lanes, in every lane of the row
+__device__ __forceinline__ double rowSumF64(double v) {
+    v = dppAddF64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dppAddF64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dppAddF64<0x141>(v);  // row_half_mirror
+    return dppAddF64<0x140>(v);  // row_mirror
+}
+
 __device__ __forceinline__ double waveSumF64(double v) {
     v = dppAddF64<0xB1>(v);   // quad_perm [1,0,3,2]
     v = dppAddF64<0x4E>(v);   // quad_perm [2,3,0,1]
@@ -199,31 +208,50 @@ __device__ __forceinline__ double logPositive(const double x, const LogTableEntr
 
 #else
 __device__ double waveSumF64(double v);  // host compilation pass: declarations only
+__device__ double rowSumF64(double v);
 __device__ double logPositive(double x);
 __device__ double logPositive(double x, const LogTableEntry * lds_table);
 __device__ void loadLogTable(LogTableEntry * lds_table);
 #endif
 
 // ---- sum of logarithms through a running product ------------------------------------
-// sum_i log(x_i) = log(prod_i x_i): every factor is split through its bit pattern into a mantissa in [1, 2), which
-// joins an FP64 product, and an exponent, which joins an integer sum — one multiplication and three integer
-// instructions per factor instead of a logarithm; one logarithm at the end.  Factors must be positive normal doubles.
-// The product of n mantissas stays below 2^n: fold() (exponent of the product -> integer sum) at least every 1000
-// factors.  The rounding error of the product grows like n * 2^-53, the same order as that of a sum of n logarithms.
+// sum_i c_i log(x_i) = log(prod_i x_i^c_i).  The rows of a group matrix are ordered by class (rpvg_hip_groups):
+//   fast  read count 1                    : the factor joins an FP64 product — one multiplication instead of a logarithm;
+//   mid   read counts 2 .. kMidMaxCount,
+//         ascending                       : the factor is multiplied in c_i times (rows of a wave have nearly equal counts);
+//   slow  everything else                 : one logarithm per row, times the count.
+// Fast and mid rows have a noise probability of at least kProductMinNoise, a lower bound of every log argument of
+// the row; arguments are sums of probabilities, far below 2^21.  A product that starts in [1, 2) therefore stays a
+// normal number over kFoldFactors fast factors or one mid factor; fold() then moves its exponent to an integer sum.
+// One logarithm at the end.  The rounding error of a product of n factors grows like n * 2^-53, the same order as
+// that of a sum of n logarithms.
+constexpr double kProductMinNoise = 9.313225746154785e-10;  // 2^-30
+constexpr int kMidMaxCount = 1;  // 1 = no mid class.  8 was measured on the bench workload: no faster for matrices of thousands of rows, slower for
+                                  // those of a few hundred, where one more ragged class boundary costs a loop pass
+constexpr uint32_t kFoldFactors = 30;  // (30 + 3 remainder factors) * 30 bits < 1022
+constexpr uint32_t kNumRowClasses = kMidMaxCount + 1;  // fast, counts 2 .. kMidMaxCount, slow
+
+__host__ __device__ inline uint32_t rowClass(const double count, const double noise) {
+    if (!(noise >= kProductMinNoise)) return kNumRowClasses - 1;
+    if (count == 1.0) return 0;
+    for (int c = 2; c <= kMidMaxCount; ++c)
+        if (count == static_cast<double>(c)) return static_cast<uint32_t>(c - 1);
+    return kNumRowClasses - 1;
+}
+
 struct LogProduct {
     double p = 1.0;
-    int e = 0;  // sum of unbiased exponents
-    __device__ __forceinline__ void mul(const double x) {
-        const uint32_t hi_word = static_cast<uint32_t>(__double2hiint(x));
-        e += static_cast<int>(hi_word >> 20) - 1023;
-        p *= __hiloint2double(static_cast<int>((hi_word & 0x000fffffu) | 0x3ff00000u), __double2loint(x));
+    int e = 0;  // exponent folded out of p so far
+    __device__ __forceinline__ void mul(const double x) { p *= x; }
+    __device__ __forceinline__ void mulPow(const double x, const int c) {
+        for (int k = 0; k < c; ++k) p *= x;
     }
     __device__ __forceinline__ void fold() {
         const uint32_t hi_word = static_cast<uint32_t>(__double2hiint(p));
         e += static_cast<int>(hi_word >> 20) - 1023;
         p = __hiloint2double(static_cast<int>((hi_word & 0x000fffffu) | 0x3ff00000u), __double2loint(p));
     }
-    // both folded (or holding few factors)
+    // both folded
     __device__ __forceinline__ void join(const LogProduct & other) {
         p *= other.p;
         e += other.e;
@@ -236,21 +264,17 @@ struct LogProduct {
     }
 };
 
-// Rows with read count 1 and a noise probability that keeps every log argument a positive normal number come first
-// in a group matrix (rpvg_hip_groups::mat_fast of them): their logs go through LogProduct.
-constexpr double kFastRowMinNoise = 1e-290;
-constexpr uint32_t kFoldRows = 64 * 4 * 200;  // rows of a wave between two fold() calls of its four product chains
-
 // sum over rows [begin, end) of a wave (lane handles begin + lane, + 64, ...) of count_i * log(x(i)); rows below
-// n_fast have count 1 and go through running products, the others through one logarithm each.
+// fast_end are fast, rows below mid_end mid (classes above).
 template <typename IndexT, typename XFn>
 __device__ __forceinline__ double sumCountLogs(const LogTableEntry * lt, const double * __restrict__ cnt, XFn x, const IndexT begin,
-                                               const IndexT n_fast, const IndexT end, const int lane) {
+                                               const IndexT fast_end, const IndexT mid_end, const IndexT end, const int lane) {
+    constexpr uint32_t kSegment = 4 * 64 * kFoldFactors;  // four chains
     double acc = 0.0;
-    if (begin < n_fast) {
+    if (begin < mid_end) {
         LogProduct p0, p1, p2, p3;
-        for (IndexT seg = begin; seg < n_fast; seg += kFoldRows) {
-            const IndexT seg_end = (n_fast - seg) < kFoldRows ? n_fast : seg + kFoldRows;
+        for (IndexT seg = begin; seg < fast_end; seg += kSegment) {
+            const IndexT seg_end = (fast_end - seg) < kSegment ? fast_end : seg + kSegment;
             IndexT i = seg + lane;
             for (; i + 192 < seg_end; i += 256) {
                 p0.mul(x(i));
@@ -264,19 +288,61 @@ __device__ __forceinline__ double sumCountLogs(const LogTableEntry * lt, const d
             p2.fold();
             p3.fold();
         }
+        for (IndexT i = (begin < fast_end ? fast_end : begin) + lane; i < mid_end; i += 64) {
+            p1.mulPow(x(i), static_cast<int>(cnt[i]));
+            p1.fold();
+        }
         p0.join(p1);
         p2.join(p3);
         p0.join(p2);
         acc = p0.value(lt);
     }
     double acc0 = 0.0, acc1 = 0.0;
-    IndexT i = (begin < n_fast ? n_fast : begin) + lane;
+    IndexT i = (begin < mid_end ? mid_end : begin) + lane;
     for (; i + 64 < end; i += 128) {
         acc0 = fma(cnt[i], logPositive(x(i), lt), acc0);
         acc1 = fma(cnt[i + 64], logPositive(x(i + 64), lt), acc1);
     }
     for (; i < end; i += 64) acc0 = fma(cnt[i], logPositive(x(i), lt), acc0);
     return acc + (acc0 + acc1);
+}
+
+// The same for kOut sums at once that share the rows: x(i, xs) fills the kOut log arguments of row i.  The rows are
+// dealt to a group of kGroup lanes (a wave, or 16 lanes of it): `lane` is the index within the group.
+template <int kOut, int kGroup, typename IndexT, typename XFn>
+__device__ __forceinline__ void sumCountLogsMulti(const LogTableEntry * lt, const double * __restrict__ cnt, XFn x, const IndexT begin,
+                                                  const IndexT fast_end, const IndexT mid_end, const IndexT end, const int lane,
+                                                  LogProduct (&pr)[kOut], double (&acc)[kOut]) {
+    constexpr uint32_t kSegment = kGroup * kFoldFactors;
+    for (IndexT seg = begin; seg < fast_end; seg += kSegment) {
+        const IndexT seg_end = (fast_end - seg) < kSegment ? fast_end : seg + kSegment;
+        for (IndexT i = seg + lane; i < seg_end; i += kGroup) {
+            double xs[kOut];
+            x(i, xs);
+#pragma unroll
+            for (int t = 0; t < kOut; ++t) pr[t].mul(xs[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < kOut; ++t) pr[t].fold();
+    }
+    for (IndexT i = (begin < fast_end ? fast_end : begin) + lane; i < mid_end; i += kGroup) {
+        double xs[kOut];
+        x(i, xs);
+        const int c = static_cast<int>(cnt[i]);
+        for (int k = 0; k < c; ++k) {
+#pragma unroll
+            for (int t = 0; t < kOut; ++t) pr[t].mul(xs[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < kOut; ++t) pr[t].fold();
+    }
+    for (IndexT i = (begin < mid_end ? mid_end : begin) + lane; i < end; i += kGroup) {
+        double xs[kOut];
+        x(i, xs);
+        const double c = cnt[i];
+#pragma unroll
+        for (int t = 0; t < kOut; ++t) acc[t] = fma(c, logPositive(xs[t], lt), acc[t]);
+    }
 }
 
 // ---- kernel-family timing ---------------------------------------------------
@@ -348,12 +414,13 @@ struct rpvg_hip_groups {
     rpvg_hip_detail::DeviceBuffer<uint64_t> mat_row0;     // [M] first batch row of the matrix's cluster
     rpvg_hip_detail::DeviceBuffer<uint64_t> mat_rows;     // [M] R_m
     rpvg_hip_detail::DeviceBuffer<uint32_t> mat_cols;     // [M] G_m
-    // Rows of a matrix are a permutation of its cluster's rows (every consumer sums over rows): count-1 rows first
+    // Rows of a matrix are a permutation of its cluster's rows (every consumer sums over rows), ordered by class
     // (LogProduct, above).  Counts and noise in matrix order, indexed like rowmax.
     rpvg_hip_detail::DeviceBuffer<uint32_t> row_perm;     // [sum R_m] cluster-relative source row
     rpvg_hip_detail::DeviceBuffer<double> row_count;      // [sum R_m]
     rpvg_hip_detail::DeviceBuffer<double> row_noise;      // [sum R_m]
-    rpvg_hip_detail::DeviceBuffer<uint32_t> mat_fast;     // [M] leading rows with count 1 and noise >= kFastRowMinNoise
+    rpvg_hip_detail::DeviceBuffer<uint32_t> mat_fast;     // [M] end of the fast rows
+    rpvg_hip_detail::DeviceBuffer<uint32_t> mat_mid;      // [M] end of the mid rows
 };
 
 #endif

@@ -29,16 +29,16 @@ namespace {
 
 constexpr uint32_t kNoMember = 0xFFFFFFFFu;
 
-// Row order of every matrix: the rows of its cluster whose read count is 1 (and whose noise probability keeps the
-// log arguments normal) first, the others after them, both in cluster order (stable, deterministic).  One workgroup
-// per matrix: count, then place chunk by chunk with ballot ranks.
+// Row order of every matrix: the rows of its cluster by class (rowClass, common.hpp) — count 1 first, then the mid
+// counts ascending, then the rest — in cluster order within a class (stable, deterministic).  One workgroup per
+// matrix: class histogram, then placement chunk by chunk with ballot ranks.
 __global__ __launch_bounds__(256) void partitionRowsKernel(
     const uint32_t num_matrices, const uint64_t * __restrict__ mat_row_off, const uint64_t * __restrict__ mat_row0,
     const uint64_t * __restrict__ mat_rows, const double * __restrict__ row_count, const double * __restrict__ row_noise,
     uint32_t * __restrict__ row_perm, double * __restrict__ count_out, double * __restrict__ noise_out,
-    uint32_t * __restrict__ mat_fast) {
-    __shared__ uint32_t wave_fast[4];
-    __shared__ uint32_t total_fast;
+    uint32_t * __restrict__ mat_fast, uint32_t * __restrict__ mat_mid) {
+    __shared__ uint32_t class_base[kNumRowClasses];       // next free slot of every class
+    __shared__ uint32_t wave_count[4][kNumRowClasses];
     const uint32_t m = blockIdx.x;
     if (m >= num_matrices) return;
     const uint32_t R = static_cast<uint32_t>(mat_rows[m]);
@@ -46,39 +46,46 @@ __global__ __launch_bounds__(256) void partitionRowsKernel(
     const double * nz = row_noise + mat_row0[m];
     const uint64_t out0 = mat_row_off[m];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) total_fast = 0;
+    if (threadIdx.x < kNumRowClasses) class_base[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t mine = 0;
-    for (uint32_t i = threadIdx.x; i < R; i += 256) mine += (cnt[i] == 1.0 && nz[i] >= kFastRowMinNoise) ? 1u : 0u;
-    if (mine) atomicAdd(&total_fast, mine);
+    for (uint32_t i = threadIdx.x; i < R; i += 256) atomicAdd(&class_base[rowClass(cnt[i], nz[i])], 1u);
     __syncthreads();
-    const uint32_t n_fast = total_fast;
-    if (threadIdx.x == 0) mat_fast[m] = n_fast;
-    uint32_t fast_base = 0, slow_base = n_fast;
+    if (threadIdx.x == 0) {
+        uint32_t running = 0;
+        for (uint32_t c = 0; c < kNumRowClasses; ++c) {
+            const uint32_t n = class_base[c];
+            class_base[c] = running;
+            running += n;
+            if (c == 0) mat_fast[m] = running;
+            if (c + 2 == kNumRowClasses) mat_mid[m] = running;
+        }
+    }
+    __syncthreads();
     for (uint32_t c0 = 0; c0 < R; c0 += 256) {
         const uint32_t i = c0 + threadIdx.x;
         const bool in = i < R;
         const double c = in ? cnt[i] : 0.0, z = in ? nz[i] : 0.0;
-        const bool fast = in && c == 1.0 && z >= kFastRowMinNoise;
-        const unsigned long long ballot = __ballot(fast);
-        const uint32_t before = __popcll(ballot & ((1ull << lane) - 1ull));
-        __syncthreads();
-        if (lane == 0) wave_fast[wave] = __popcll(ballot);
-        __syncthreads();
-        uint32_t fast_before = before, chunk_fast = 0;
+        const uint32_t mine = in ? rowClass(c, z) : kNumRowClasses;
+        uint32_t rank = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            fast_before += (w < wave) ? wave_fast[w] : 0u;
-            chunk_fast += wave_fast[w];
+        for (uint32_t k = 0; k < kNumRowClasses; ++k) {
+            const unsigned long long ballot = __ballot(mine == k);
+            if (mine == k) rank = __popcll(ballot & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_count[wave][k] = __popcll(ballot);
         }
+        __syncthreads();
         if (in) {
-            const uint32_t dest = fast ? fast_base + fast_before : slow_base + (threadIdx.x - fast_before);
+            uint32_t dest = class_base[mine] + rank;
+            for (int w = 0; w < wave; ++w) dest += wave_count[w][mine];
             row_perm[out0 + dest] = i;
             count_out[out0 + dest] = c;
             noise_out[out0 + dest] = z;
         }
-        fast_base += chunk_fast;
-        slow_base += min(256u, R - c0) - chunk_fast;
+        __syncthreads();
+        if (threadIdx.x < kNumRowClasses) {
+            class_base[threadIdx.x] += wave_count[0][threadIdx.x] + wave_count[1][threadIdx.x] + wave_count[2][threadIdx.x] + wave_count[3][threadIdx.x];
+        }
+        __syncthreads();
     }
 }
 
@@ -256,7 +263,7 @@ template <int WIDTH>
 __global__ __launch_bounds__(256) void groupLoglikKernel(
     const uint32_t num_requests, const uint32_t * __restrict__ req_matrix, const uint32_t * __restrict__ req_members,
     const uint8_t * __restrict__ req_rowmax, const double divisor, const uint64_t * __restrict__ mat_val_off,
-    const uint64_t * __restrict__ mat_row_off, const uint32_t * __restrict__ mat_fast,
+    const uint64_t * __restrict__ mat_row_off, const uint32_t * __restrict__ mat_fast, const uint32_t * __restrict__ mat_mid,
     const uint64_t * __restrict__ mat_rows, const double * __restrict__ values, const double * __restrict__ rowmax,
     const double * __restrict__ row_count, const double * __restrict__ row_noise, double * __restrict__ out) {
     __shared__ LogTableEntry lt[kLogTableSize];
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(256) void groupLoglikKernel(
         if (rm) v += rm[i] / divisor;
         return v;
     };
-    const double acc = waveSumF64(sumCountLogs<uint64_t>(lt, cnt, x, 0, mat_fast[m], R, lane));
+    const double acc = waveSumF64(sumCountLogs<uint64_t>(lt, cnt, x, 0, mat_fast[m], mat_mid[m], R, lane));
     if (lane == 0) out[q] = acc;
 }
 
@@ -298,8 +305,8 @@ __global__ __launch_bounds__(256) void groupConditionalKernel(
     const uint32_t num_requests, const uint64_t num_items, const uint64_t * __restrict__ item_off,
     const uint64_t * __restrict__ out_off, const uint32_t * __restrict__ req_matrix,
     const uint32_t * __restrict__ req_others, const double divisor, const uint64_t * __restrict__ mat_val_off,
-    const uint64_t * __restrict__ mat_row_off, const uint32_t * __restrict__ mat_fast, const uint64_t * __restrict__ mat_rows,
-    const uint32_t * __restrict__ mat_cols, const double * __restrict__ values, const double * __restrict__ row_count,
+    const uint64_t * __restrict__ mat_row_off, const uint32_t * __restrict__ mat_fast, const uint32_t * __restrict__ mat_mid,
+    const uint64_t * __restrict__ mat_rows, const uint32_t * __restrict__ mat_cols, const double * __restrict__ values, const double * __restrict__ row_count,
     const double * __restrict__ row_noise, double * __restrict__ out) {
     constexpr int kCand = 4;
     __shared__ LogTableEntry lt[kLogTableSize];
@@ -328,31 +335,19 @@ __global__ __launch_bounds__(256) void groupConditionalKernel(
 #pragma unroll
     for (int c = 0; c < kCand; ++c) cand[c] = M + static_cast<uint64_t>(min(k0 + c, G - 1)) * R;
     double acc[kCand] = {0.0, 0.0, 0.0, 0.0};
-    const uint64_t n_fast = mat_fast[m];
-    if (n_fast) {  // count-1 rows: running products
-        LogProduct pr[kCand];
-        for (uint64_t seg = 0; seg < n_fast; seg += kFoldRows / 4) {
-            const uint64_t seg_end = min(n_fast, seg + kFoldRows / 4);
-            for (uint64_t i = seg + lane; i < seg_end; i += 64) {
-                double base = nz[i];
-#pragma unroll
-                for (int w = 0; w + 1 < WIDTH; ++w) base += other[w][i] / divisor;
-#pragma unroll
-                for (int c = 0; c < kCand; ++c) pr[c].mul(base + cand[c][i] / divisor);
-            }
-#pragma unroll
-            for (int c = 0; c < kCand; ++c) pr[c].fold();
-        }
-#pragma unroll
-        for (int c = 0; c < kCand; ++c) acc[c] = pr[c].value(lt);
-    }
-    for (uint64_t i = n_fast + lane; i < R; i += 64) {
+    LogProduct pr[kCand];
+    const uint64_t fast_end = mat_fast[m], mid_end = mat_mid[m];
+    auto x = [&](const uint64_t i, double (&xs)[kCand]) {
         double base = nz[i];
 #pragma unroll
         for (int w = 0; w + 1 < WIDTH; ++w) base += other[w][i] / divisor;
-        const double c_i = cnt[i];
 #pragma unroll
-        for (int c = 0; c < kCand; ++c) acc[c] = fma(c_i, logPositive(base + cand[c][i] / divisor, lt), acc[c]);
+        for (int c = 0; c < kCand; ++c) xs[c] = base + cand[c][i] / divisor;
+    };
+    sumCountLogsMulti<kCand, 64, uint64_t>(lt, cnt, x, 0, fast_end, mid_end, R, lane, pr, acc);
+    if (mid_end) {
+#pragma unroll
+        for (int c = 0; c < kCand; ++c) acc[c] += pr[c].value(lt);
     }
 #pragma unroll
     for (int c = 0; c < kCand; ++c) {
@@ -498,6 +493,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     ok(g->row_count.alloc(row_total));
     ok(g->row_noise.alloc(row_total));
     ok(g->mat_fast.alloc(M));
+    ok(g->mat_mid.alloc(M));
     ok(d_degree.alloc(inc_total));
     ok(d_cursor.alloc(inc_total));
     ok(d_path_grp_off.alloc(inc_total));
@@ -517,7 +513,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         }
         partitionRowsKernel<<<dim3(M), dim3(256), 0, st>>>(M, g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, batch->row_count.ptr,
                                                            batch->row_noise.ptr, g->row_perm.ptr, g->row_count.ptr, g->row_noise.ptr,
-                                                           g->mat_fast.ptr);
+                                                           g->mat_fast.ptr, g->mat_mid.ptr);
         const uint32_t col_blocks = static_cast<uint32_t>((num_columns + 255) / 256);
         incidenceCountKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,
                                                                    d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
@@ -612,7 +608,7 @@ extern "C" int rpvg_hip_group_loglik(rpvg_hip_ctx * ctx, const rpvg_hip_groups *
 #define RPVG_LAUNCH_LOGLIK(W)                                                                                              \
     groupLoglikKernel<W><<<dim3(blocks), dim3(256), 0, st>>>(num_requests, d_matrix.ptr, d_members.ptr, d_flag.ptr, divisor, \
                                                             groups->mat_val_off.ptr, groups->mat_row_off.ptr,               \
-                                                            groups->mat_fast.ptr, groups->mat_rows.ptr, groups->values.ptr, \
+                                                            groups->mat_fast.ptr, groups->mat_mid.ptr, groups->mat_rows.ptr, groups->values.ptr, \
                                                             groups->rowmax.ptr, groups->row_count.ptr, groups->row_noise.ptr, d_out.ptr)
     switch (width) {
         case 1: RPVG_LAUNCH_LOGLIK(1); break;
@@ -677,7 +673,8 @@ extern "C" int rpvg_hip_group_conditionals(rpvg_hip_ctx * ctx, const rpvg_hip_gr
 #define RPVG_LAUNCH_COND(W)                                                                                                  \
     groupConditionalKernel<W><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(                                    \
         num_requests, num_items, d_item_off.ptr, d_out_off.ptr, d_matrix.ptr, d_others.ptr, divisor, groups->mat_val_off.ptr, \
-        groups->mat_row_off.ptr, groups->mat_fast.ptr, groups->mat_rows.ptr, groups->mat_cols.ptr, groups->values.ptr,       \
+        groups->mat_row_off.ptr, groups->mat_fast.ptr, groups->mat_mid.ptr, groups->mat_rows.ptr, groups->mat_cols.ptr,      \
+        groups->values.ptr,                                                                                                  \
         groups->row_count.ptr, groups->row_noise.ptr, d_out.ptr)
     switch (width) {
         case 1: RPVG_LAUNCH_COND(1); break;

@@ -828,7 +828,7 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
         gibbsReadCountSampler(&count_samples, cluster_batch, problems, solutions, num_samples, seeds);
     }
 
-    ScopedPhase merge_phase("nested: weighted merge");
+    std::unique_ptr<ScopedPhase> merge_phase(new ScopedPhase("nested: weighted merge"));
 
     #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
     for (size_t i = 0; i < clusters.size(); ++i) {
@@ -911,6 +911,18 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
 
         assert(sum_hap_prob < 1 || numeric::doubleCompare(sum_hap_prob, 1));
         estimates.noise_count += (1 - sum_hap_prob) * estimates.total_count;
+    }
+
+    merge_phase.reset();
+
+    // tens of thousands of small vectors: released by the team instead of one by one on return
+    ScopedPhase teardown_phase("nested: teardown EM problems");
+
+    #pragma omp parallel for schedule(static) num_threads(hostThreads())
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        std::vector<uint32_t>().swap(problems.at(i).path_ids);
+        std::vector<double>().swap(solutions.at(i).abundances);
     }
 }
 
