@@ -150,12 +150,15 @@ def run_s3(args, rank, local_rank, world, dist, torch):
 
     barrier_sync(dist, torch)
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
-        eng.run_raw(args.model, params, prepared)
+        step_ms.append(eng.run_raw(args.model, params, prepared) * 1e3)
     barrier_sync(dist, torch)
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, dist, torch)
     stats = eng.stats()
+    if os.environ.get("RPVG_BENCH_STEP_TIMES"):  # spread of the single steps (the JSON line reports the mean)
+        print("step ms:", " ".join(f"{t:.1f}" for t in step_ms), file=sys.stderr)
 
     reads_all = sum_over_ranks(float(batch.total_reads), dist, torch)
 

@@ -19,10 +19,40 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
 #include <numeric>
 
 using namespace rpvg_hip_detail;
+
+// ---- one search at a time per device -------------------------------------------------
+// The host lanes of a batch (two contexts of one device) overlap one lane's host work with the other's kernels.
+// Two searches side by side take longer than one after the other (their workgroups compete for whole CUs), and a
+// lane whose kernels are spread over the step finishes as late as the other: the kernels of a search therefore wait,
+// on the device, for the previous search of another context — the host has queued them by then, so the next search
+// starts without a host round trip in between.
+namespace {
+std::mutex g_search_gate_mutex;
+const rpvg_hip_ctx * g_search_gate_owner = nullptr;  // context of the last search queued
+}
+
+static void searchGateEnter(const rpvg_hip_ctx * ctx, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_search_gate_mutex);
+    if (g_search_gate_owner && g_search_gate_owner != ctx && g_search_gate_owner->device == ctx->device) {
+        (void) hipStreamWaitEvent(stream, g_search_gate_owner->search_done, 0);
+    }
+}
+
+static void searchGateLeave(const rpvg_hip_ctx * ctx, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_search_gate_mutex);
+    (void) hipEventRecord(ctx->search_done, stream);
+    g_search_gate_owner = ctx;
+}
+
+void searchGateForget(const rpvg_hip_ctx * ctx) {
+    std::lock_guard<std::mutex> lock(g_search_gate_mutex);
+    if (g_search_gate_owner == ctx) g_search_gate_owner = nullptr;
+}
 
 struct rpvg_hip_pair_posteriors {
     std::vector<uint64_t> pair_off;
@@ -34,6 +64,7 @@ namespace {
 
 constexpr uint32_t kLdsRows = 2048;   // rows of (base, count) staged in LDS by the search kernel: 32 KB
 constexpr uint32_t kSmallRows = 512;  // ... for matrices with at most this many rows: 8 KB
+constexpr uint32_t kSmallRowLdsCols = 128;  // ... by the kernel for matrices with few rows (24 KB of LDS per workgroup: six per CU)
 constexpr uint32_t kRowLdsCols = 512; // pair log-likelihoods of one first column kept in LDS up to this many columns: 4 KB
 
 __device__ __forceinline__ double waveSum(double v) { return waveSumF64(v); }
@@ -147,7 +178,7 @@ __device__ __forceinline__ void tilePairSums(const LogTableEntry * lt, const dou
 // columns per wave) for those with few, where the end of a column's sum — one logarithm per product, the
 // reduction over the lanes — costs as much as its rows: four columns share those instructions.
 template <int kBlock, int kGroup>
-__global__ __launch_bounds__(kBlock) void boundedSearchKernel(const SearchArgs args) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void boundedSearchKernel(const SearchArgs args) {
     constexpr int kWaves = kBlock / 64;
     constexpr int kGroupsPerWave = 64 / kGroup;
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
@@ -658,6 +689,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     RPVG_REQUIRE(ctx && groups && result_out, "rpvg_hip_bounded_pair_posteriors: NULL argument");
     *result_out = nullptr;
     RPVG_REQUIRE(min_rel_likelihood > 0, "rpvg_hip_bounded_pair_posteriors: min_rel_likelihood must be positive");
+    std::unique_ptr<HostScope> scope(new HostScope("bounded search: host order + work items"));
     const uint32_t M = groups->num_matrices;
     rpvg_hip_pair_posteriors * res = new (std::nothrow) rpvg_hip_pair_posteriors();
     if (!res) {
@@ -728,6 +760,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         ++num_big;
     }
 
+    scope.reset(new HostScope("bounded search: uploads + launches"));
     std::lock_guard<std::mutex> lock(ctx->mutex);
     hipError_t e = hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
@@ -835,6 +868,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     // the table path, the medium and the small matrices are independent: three streams, so that the
     // tail of one does not idle the GPU
     span = ctx->spanBegin(FAM_LOGLIK);
+    searchGateEnter(ctx, st);
     ok(ctx->forkAux());
     if (num_big > 0) {
         TableWork tw;
@@ -887,36 +921,40 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     // the rest walk the search inside one workgroup; matrices with few rows stage less LDS (more
     // workgroups per CU).  `order` is [big | medium | small], each part expensive first.
     args.row_lds_cols = kRowLdsCols;
-    auto search_lds_bytes = [](uint32_t stage_rows) { return static_cast<size_t>((kTileFirst + 1) * stage_rows + kTileFirst * kRowLdsCols) * sizeof(double); };
+    auto search_lds_bytes = [](uint32_t stage_rows, uint32_t row_cols) { return static_cast<size_t>((kTileFirst + 1) * stage_rows + kTileFirst * row_cols) * sizeof(double); };
     {
         static std::once_flag once;  // 96 KB of dynamic LDS: above the 64 KB a kernel gets without asking
         std::call_once(once, [&]() {
             (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&boundedSearchKernel<1024, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(search_lds_bytes(kLdsRows)));
+                                       static_cast<int>(search_lds_bytes(kLdsRows, kRowLdsCols)));
         });
     }
     if (num_medium > 0) {
         args.order = d_order.ptr + num_big;
         args.count = num_medium;
         args.stage_rows = kLdsRows;
-        boundedSearchKernel<1024, 64><<<dim3(num_medium), dim3(1024), search_lds_bytes(kLdsRows), ctx->aux[0]>>>(args);
+        boundedSearchKernel<1024, 64><<<dim3(num_medium), dim3(1024), search_lds_bytes(kLdsRows, kRowLdsCols), ctx->aux[0]>>>(args);
     }
     if (M > num_big + num_medium) {
         args.order = d_order.ptr + num_big + num_medium;
         args.count = M - num_big - num_medium;
         args.stage_rows = kSmallRows;
-        boundedSearchKernel<256, 16><<<dim3(args.count), dim3(256), search_lds_bytes(kSmallRows), ctx->aux[1]>>>(args);
+        args.row_lds_cols = kSmallRowLdsCols;
+        boundedSearchKernel<256, 16><<<dim3(args.count), dim3(256), search_lds_bytes(kSmallRows, kSmallRowLdsCols), ctx->aux[1]>>>(args);
     }
     ok(ctx->joinAux());
+    searchGateLeave(ctx, st);
     ctx->spanEnd(span);
     ctx->stats.loglik_launches += (num_big > 0 ? 2 : 0) + (num_medium > 0) + (M > num_big + num_medium);
     ok(hipGetLastError());
 
+    scope.reset(new HostScope("bounded search: wait for the kernels"));
     std::vector<uint32_t> counts(M);
     unsigned long long log_evals = 0;
     ok(d_out_count.download(counts.data(), st));
     ok(hipMemcpyAsync(&log_evals, d_log_evals.ptr, sizeof(log_evals), hipMemcpyDeviceToHost, st));
     ok(hipStreamSynchronize(st));
+    scope.reset(new HostScope("bounded search: compact + download pairs"));
     if (e == hipSuccess) {
         for (uint32_t m = 0; m < M; ++m) res->pair_off[m + 1] = res->pair_off[m] + counts[m];
         const uint64_t total = res->pair_off[M];

@@ -226,14 +226,16 @@ __device__ void loadLogTable(LogTableEntry * lds_table);
 // One logarithm at the end.  The rounding error of a product of n factors grows like n * 2^-53, the same order as
 // that of a sum of n logarithms.
 constexpr double kProductMinNoise = 9.313225746154785e-10;  // 2^-30
-constexpr int kMidMaxCount = 1;  // 1 = no mid class.  8 was measured on the bench workload: no faster for matrices of thousands of rows, slower for
-                                  // those of a few hundred, where one more ragged class boundary costs a loop pass
+constexpr int kMidMaxCount = 8;
+constexpr uint32_t kMidMinRows = 1024;  // matrices with fewer rows have no mid class: one more ragged class boundary would
+                                        // cost them a loop pass, more than the logarithms it saves
 constexpr uint32_t kFoldFactors = 30;  // (30 + 3 remainder factors) * 30 bits < 1022
 constexpr uint32_t kNumRowClasses = kMidMaxCount + 1;  // fast, counts 2 .. kMidMaxCount, slow
 
-__host__ __device__ inline uint32_t rowClass(const double count, const double noise) {
+__host__ __device__ inline uint32_t rowClass(const double count, const double noise, const bool with_mid) {
     if (!(noise >= kProductMinNoise)) return kNumRowClasses - 1;
     if (count == 1.0) return 0;
+    if (!with_mid) return kNumRowClasses - 1;
     for (int c = 2; c <= kMidMaxCount; ++c)
         if (count == static_cast<double>(c)) return static_cast<uint32_t>(c - 1);
     return kNumRowClasses - 1;
@@ -364,6 +366,7 @@ struct rpvg_hip_ctx {
     // joinAux() makes `stream` wait for them.
     hipStream_t aux[kAuxStreams] = {};
     hipEvent_t fork_event = nullptr;
+    hipEvent_t search_done = nullptr;  // recorded behind the kernels of this context's last pair search (bounded_search.hip)
     hipEvent_t join_event[kAuxStreams] = {};
     hipError_t forkAux();
     hipError_t joinAux();
@@ -401,6 +404,9 @@ struct rpvg_hip_batch {
 };
 
 // Device-resident group matrices (loglik.hip builds them).
+// bounded_search.hip: the searches of different contexts of one device run one after the other on the device
+void searchGateForget(const rpvg_hip_ctx * ctx);
+
 struct rpvg_hip_groups {
     const rpvg_hip_batch * batch = nullptr;
     uint32_t num_matrices = 0;

@@ -221,6 +221,7 @@ int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_event[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->search_done, hipEventDisableTiming);
     if (e != hipSuccess) {
         setError("rpvg_hip_create: %s", hipGetErrorString(e));
         delete ctx;
@@ -251,6 +252,8 @@ void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
         if (ctx->join_event[i]) (void) hipEventDestroy(ctx->join_event[i]);
     }
     if (ctx->fork_event) (void) hipEventDestroy(ctx->fork_event);
+    searchGateForget(ctx);
+    if (ctx->search_done) (void) hipEventDestroy(ctx->search_done);
     bool last = false;
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);

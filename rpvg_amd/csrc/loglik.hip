@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void partitionRowsKernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < kNumRowClasses) class_base[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < R; i += 256) atomicAdd(&class_base[rowClass(cnt[i], nz[i])], 1u);
+    for (uint32_t i = threadIdx.x; i < R; i += 256) atomicAdd(&class_base[rowClass(cnt[i], nz[i], R >= kMidMinRows)], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t running = 0;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void partitionRowsKernel(
         const uint32_t i = c0 + threadIdx.x;
         const bool in = i < R;
         const double c = in ? cnt[i] : 0.0, z = in ? nz[i] : 0.0;
-        const uint32_t mine = in ? rowClass(c, z) : kNumRowClasses;
+        const uint32_t mine = in ? rowClass(c, z, R >= kMidMinRows) : kNumRowClasses;
         uint32_t rank = 0;
 #pragma unroll
         for (uint32_t k = 0; k < kNumRowClasses; ++k) {

@@ -2,10 +2,11 @@
 # PMC passes over the S3 bench for the search kernels (each pass its own run: counter slots).
 cd /tmp; export TMPDIR=/tmp
 out=/root/repo/gpurun_out/pmc_search
+rm -rf $out; mkdir -p $out
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_VALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD"; do
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_LDS"; do
   i=$((i+1))
   RPVG_AMD_SINGLE_LANE=1 timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out.log$i 2>&1
 done
 cd /root/repo
-python tools/pmc_kernels.py $out/p1 $out/p2 $out/p3 $out/p4 --kernel Search,pairTable
+python tools/pmc_kernels.py $out/p1 $out/p2 $out/p3 --kernel Search,pairTable
