@@ -3,17 +3,20 @@
 // Takes over calculatePathGroupPosteriorsBounded (src/path_estimator.cpp:379-473)
 // for a batch of group matrices: ONE workgroup per matrix walks the search in
 // the reference's sequential order, so the kept set is the reference's kept
-// set, and only first columns that pass the optimistic bound when they are
-// reached cost any work.  Inside a workgroup the parallelism is
-//   - waves  : the pair log-likelihoods of up to NW consecutive second columns
-//              are evaluated at once, then the running-maximum pruning rule is
-//              applied to them one after the other (uniformly by all threads);
+// set.  Inside a workgroup
+//   - first columns : the next kTileFirst columns that pass the optimistic bound
+//              are evaluated together (their base vectors noise_i + M[i][a]/2 and
+//              the read counts staged in LDS), then pruned one after the other;
+//   - waves  : second columns — a wave each, or 16 lanes each for matrices with
+//              few rows; every element of a second column is read once for the
+//              kTileFirst first columns;
 //   - lanes  : rows of the matrix (column-major, so lane i reads element i of
-//              a column: coalesced), FP64 log per row, wave-shuffle reduction.
-// The base vector noise_i + M[i][a]/2 of the current first column and the
-// read counts are staged in LDS and reused by every pair of that column.
-// Bound: FP64 log throughput (one log per row per pair), not HBM — a cluster's
-// matrix (mean ~0.3 MB) is re-read from L2.
+//              a column: coalesced).
+// sum_i count_i log(x_i) runs over rows ordered by class (rpvg_hip_groups): the
+// count-1 rows as a running FP64 product with one logarithm at the end
+// (LogProduct, common.hpp), the rest one table logarithm per row.
+// Bound: FP64 issue and L2 latency, not HBM — a cluster's matrix (mean ~0.3 MB)
+// is re-read from L2.
 
 #include "common.hpp"
 

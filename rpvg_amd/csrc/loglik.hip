@@ -11,9 +11,11 @@
 //
 // Layout: one column-major R_m x G_m matrix per requested (cluster, grouping),
 // so that a wave walking the rows of one or two columns reads contiguous
-// memory; counts and noise are shared with the uploaded batch.  The
-// contraction is FP64-log bound (one log per row per request), not HBM bound:
-// a cluster's matrix is re-read from L2 by every request that touches it.
+// memory.  The rows of a matrix are its cluster's rows ordered by class (count
+// 1 first: partitionRowsKernel), with counts and noise copied in that order, so
+// that the contraction — FP64-issue bound, not HBM bound: a cluster's matrix is
+// re-read from L2 by every request that touches it — replaces most logarithms
+// by a running product (LogProduct, common.hpp).
 
 #include "common.hpp"
 
