@@ -25,6 +25,12 @@ def compare(got, ref, check_iters=True):
     for k, (g, r) in enumerate(zip(got, ref)):
         gk, rk = g.keyed(), r.keyed()
         if set(gk) != set(rk):
+            # Two columns whose marginal posteriors are equal up to rounding are visited in an order that the rounding
+            # decides, on either side (seen: seed 5109, a 12-row cluster, pair (1, 2) vs (2, 1)): the same diplotype
+            # written in the other order is not a mismatch.
+            gk = {tuple(sorted(key)): v for key, v in gk.items()}
+            rk = {tuple(sorted(key)): v for key, v in rk.items()}
+        if set(gk) != set(rk):
             problems.append(f"cluster {k}: group sets differ ({len(gk)} vs {len(rk)})")
             continue
         for key, (post, ab) in rk.items():

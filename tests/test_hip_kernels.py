@@ -423,3 +423,81 @@ def test_bounded_search_table_path(hip_ctx, force_table):
         sets, post = pyoracle.group_posteriors(M, noise, cnts, counts[m], 2, bounded=True, min_rel_lik=1e-3)
         assert got[m][0] == sets
         assert small_cases.rel_close(got[m][1], post, rel=1e-9, floor=1e-300)
+
+
+# ---- row classes of the group matrices (count-1 products, mid counts, logarithms) ---------------------------
+
+def _mixed_class_cluster(rng, n_reads):
+    """A cluster whose rows cover every class of the matrix row order: read counts 1, 2..8, above 8, and noise
+    probabilities below the product path's floor (2^-30)."""
+    cl = small_cases.make_cluster(rng, 3, [8, 6, 7], n_haps=24, n_reads=n_reads)
+    rows = []
+    for i, (cnt, noise, groups) in enumerate(cl["rows"]):
+        cnt = int(rng.choice([1, 1, 1, 1, 2, 3, 5, 8, 9, 40, 700]))
+        if noise < 1.0 and rng.random() < 0.1:
+            noise = 1e-12  # sub-floor noise: the row takes the logarithm path whatever its count
+        rows.append((cnt, noise, groups))
+    cl["rows"] = rows
+    return cl
+
+
+@pytest.mark.parametrize("n_reads", [300, 6000])
+def test_row_classes_give_the_same_sums(hip_ctx, n_reads):
+    """Matrices with fewer than 1024 rows have two classes, larger ones three; every consumer (member-list sums,
+    conditionals, both searches) must agree with numpy / the oracle on rows of all classes."""
+    rng = np.random.default_rng(900 + n_reads)
+    clusters = [_mixed_class_cluster(rng, n_reads), _mixed_class_cluster(rng, n_reads // 2)]
+    batch = ClusterBatch.from_clusters(clusters)
+    assert n_reads < 1000 or min(len(cl["rows"]) for cl in clusters) >= 1024
+    dev = hip_ctx.upload(batch)
+    groups, mult = [], []
+    for cl in clusters:
+        g, m = np_oracle.source_groups(cl["paths"])
+        groups.append(g)
+        mult.append(m)
+    dg = hip_ctx.groups(dev, [0, 1], groups, True)
+    for m, cl in enumerate(clusters):
+        M, noise, counts = np_oracle.grouped_matrix(cl["rows"], groups[m])
+        M = np_oracle.add_noise_and_normalize(M, noise)[:, :-1]
+        G = len(groups[m])
+        pairs = [(a, b) for a in range(G) for b in range(a, G)]
+        want = np.array([np_oracle.set_loglik(M, noise, counts, p, 2) for p in pairs])
+        assert small_cases.rel_close(dg.loglik([m] * len(pairs), pairs, 2.0), want, rel=1e-11, floor=1e-9)
+        cond = dg.conditionals([m], [[1]], 2, 2.0, [len(g) for g in groups])[0]
+        want_c = np.array([np_oracle.set_loglik(M, noise, counts, (1, k), 2) for k in range(G)])
+        assert small_cases.rel_close(cond, want_c, rel=1e-11, floor=1e-9)
+    for table in (False, True):
+        if table:
+            os.environ["RPVG_HIP_TABLE_MIN_WORK"] = "0"
+        try:
+            got = dg.bounded_pair_posteriors(np.concatenate(mult), 1e-3)
+        finally:
+            os.environ.pop("RPVG_HIP_TABLE_MIN_WORK", None)
+        for m, cl in enumerate(clusters):
+            M, noise, counts = np_oracle.grouped_matrix(cl["rows"], groups[m])
+            M = np_oracle.add_noise_and_normalize(M, noise)[:, :-1]
+            sets, post = pyoracle.group_posteriors(M, noise, counts, mult[m], 2, bounded=True, min_rel_lik=1e-3)
+            assert got[m][0] == sets
+            assert small_cases.rel_close(got[m][1], post, rel=1e-9, floor=1e-300)
+
+
+def test_bounded_search_with_a_positive_threshold(hip_ctx):
+    """min_rel_likelihood > 1 makes the log threshold positive: the prefix-maximum form of the pruning rule does not
+    hold then, and the kernels fall back to the reference's sequential rule (no table path, no wave scan)."""
+    rng = np.random.default_rng(931)
+    clusters = [small_cases.make_cluster(rng, 2, [6, 5], n_haps=20, n_reads=800),
+                small_cases.make_cluster(rng, 3, [9, 7, 8], n_haps=40, n_reads=9000)]
+    dev = hip_ctx.upload(ClusterBatch.from_clusters(clusters))
+    groups, mult = [], []
+    for cl in clusters:
+        g, m = np_oracle.source_groups(cl["paths"])
+        groups.append(g)
+        mult.append(m)
+    dg = hip_ctx.groups(dev, [0, 1], groups, True)
+    got = dg.bounded_pair_posteriors(np.concatenate(mult), 1.5)
+    for m, cl in enumerate(clusters):
+        M, noise, counts = np_oracle.grouped_matrix(cl["rows"], groups[m])
+        M = np_oracle.add_noise_and_normalize(M, noise)[:, :-1]
+        sets, post = pyoracle.group_posteriors(M, noise, counts, mult[m], 2, bounded=True, min_rel_lik=1.5)
+        assert got[m][0] == sets
+        assert small_cases.rel_close(got[m][1], post, rel=1e-9, floor=1e-300)
