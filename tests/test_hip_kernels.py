@@ -501,3 +501,26 @@ def test_bounded_search_with_a_positive_threshold(hip_ctx):
         sets, post = pyoracle.group_posteriors(M, noise, counts, mult[m], 2, bounded=True, min_rel_lik=1.5)
         assert got[m][0] == sets
         assert small_cases.rel_close(got[m][1], post, rel=1e-9, floor=1e-300)
+
+
+@pytest.mark.parametrize("n_paths,n_reads", [(180, 500), (560, 2500)])
+def test_bounded_search_with_more_columns_than_the_lds_rows_hold(hip_ctx, n_paths, n_reads):
+    """More columns than the kernel keeps rows of pair log-likelihoods for in LDS (128 for the small-matrix kernel,
+    512 for the other): one first column at a time, rows in global scratch.  The table path is switched off so that the
+    in-workgroup search takes the matrix."""
+    rng = np.random.default_rng(940 + n_paths)
+    cl = small_cases.make_cluster(rng, 1, [n_paths], n_haps=n_paths, n_reads=n_reads)
+    dev = hip_ctx.upload(ClusterBatch.from_clusters([cl]))
+    groups = [[p] for p in range(len(cl["paths"]))]
+    mult = [p["source_count"] for p in cl["paths"]]
+    dg = hip_ctx.groups(dev, [0], [groups], False)
+    os.environ["RPVG_HIP_TABLE_MIN_WORK"] = "1e300"
+    try:
+        got = dg.bounded_pair_posteriors(np.array(mult), 1e-3)
+    finally:
+        os.environ.pop("RPVG_HIP_TABLE_MIN_WORK", None)
+    M, noise, counts = np_oracle.grouped_matrix(cl["rows"], groups)
+    assert M.shape[1] == n_paths and (M.shape[0] <= 512) == (n_paths == 180)
+    sets, post = pyoracle.group_posteriors(M, noise, counts, mult, 2, bounded=True, min_rel_lik=1e-3)
+    assert got[0][0] == sets
+    assert small_cases.rel_close(got[0][1], post, rel=1e-9, floor=1e-300)
