@@ -533,9 +533,10 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
         lane_clusters[i % num_lanes].emplace_back(clusters[i]);
     }
 
-    // several ranks on one host: the lanes of a rank share the rank's threads
-    const char * local_world = std::getenv("LOCAL_WORLD_SIZE");
-    const int lane_threads = (local_world && std::atoi(local_world) > 1) ? std::max(4, hostThreads() / num_lanes) : hostThreads();
+    // Every lane may use the rank's whole team (hostThreads(): the host's threads divided by its ranks).  The lanes are
+    // staggered, so their parallel regions mostly alternate; when they do coincide the teams share the cores, which
+    // costs what two half-size teams would have cost all the time (idle workers sleep: OMP_WAIT_POLICY=passive).
+    const int lane_threads = hostThreads();
     const int outer_threads = hostThreadsOverride();
 
     for (int lane = 1; lane < num_lanes; ++lane) {
