@@ -89,6 +89,17 @@ def sum_over_ranks(x, dist, torch):
     return float(t.item())
 
 
+def cpu_quota_note():
+    """The CPU time the container may use, if a cgroup limits it (the threads of the baseline share that)."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return f"; cgroup cpu.max grants {float(quota) / float(period):.0f} CPUs' worth of time"
+    except (OSError, ValueError):
+        pass
+    return ""
+
+
 def cpu_baseline_s3(batch, model, params, target_seconds):
     """The CPU oracle (OpenMP over clusters, serial inside a cluster, as src/main.cpp:829) on a strided
     sample of the same batch, sized for about target_seconds of CPU work."""
@@ -106,7 +117,7 @@ def cpu_baseline_s3(batch, model, params, target_seconds):
     _, secs = pyoracle.run(model, params, sample, cores)
     return dict(value=sample.total_reads / secs, unit="read-pairs/s", cores=cores, kind="port",
                 sample=f"every {stride}th cluster of the batch ({len(idx)} clusters, {sample.total_reads} read pairs, "
-                       f"{secs:.2f} s): oracle/ C++ restatement, OpenMP dynamic over clusters, {cores} threads")
+                       f"{secs:.2f} s): oracle/ C++ restatement, OpenMP dynamic over clusters, {cores} threads" + cpu_quota_note())
 
 
 def run_s3(args, rank, local_rank, world, dist, torch):
@@ -375,7 +386,7 @@ def run_rows(args, rank, local_rank, world, dist, torch):
         _, secs = pyoracle.build_rows(aligns, prm, merge=True, num_threads=cores)
         line["cpu_baseline"] = dict(value=aligns.total_reads / secs, unit="read-pairs/s", cores=cores, kind="port",
                                     sample=f"the whole batch ({aligns.total_reads} read pairs, {secs:.2f} s): oracle/ addPathProbs + sort/merge, "
-                                           f"OpenMP dynamic over clusters, {cores} threads")
+                                           f"OpenMP dynamic over clusters, {cores} threads" + cpu_quota_note())
     return line
 
 
@@ -431,7 +442,7 @@ def run_e2e(args, rank, local_rank, world, dist, torch):
         _, secs_est = pyoracle.run(args.model, params, rows_o, cores)
         line["cpu_baseline"] = dict(value=aligns.total_reads / (secs_rows + secs_est), unit="read-pairs/s", cores=cores, kind="port",
                                     sample=f"the whole batch: oracle row construction {secs_rows:.2f} s + estimates {secs_est:.2f} s, "
-                                           f"OpenMP dynamic over clusters, {cores} threads")
+                                           f"OpenMP dynamic over clusters, {cores} threads" + cpu_quota_note())
     return line
 
 

@@ -865,7 +865,7 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
     RPVG_REQUIRE(sizeof(double) * (3 * static_cast<size_t>(ps.max_cols) + 24) <= 160 * 1024,
                  "%s: a problem with %u columns does not fit the LDS-resident abundance vector", who, ps.max_cols);
 
-    scope.reset(new HostScope("problems: colmap + count + fill"));
+    scope.reset(new HostScope("problems: uploads + colmap + count launch"));
     hipStream_t st = ctx->stream;
     int span = ctx->spanBegin(FAM_H2D);
     RPVG_HIP_CHECK(ps.d_cluster.upload(problems->cluster, P, st));
@@ -891,6 +891,7 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
     ctx->stats.build_launches += 2;
     RPVG_HIP_CHECK(hipGetLastError());
 
+    scope.reset(new HostScope("problems: wait for the counts"));
     ps.kept_rows.resize(P);
     ps.kept_ent.resize(P);
     ps.total_count.resize(P);
@@ -899,6 +900,7 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
     RPVG_HIP_CHECK(ps.d_total.download(ps.total_count.data(), st));
     RPVG_HIP_CHECK(hipStreamSynchronize(st));
 
+    scope.reset(new HostScope("problems: offsets + fill launch"));
     std::vector<uint64_t> row_base(P), ent_base(P);
     for (uint32_t p = 0; p < P; ++p) {
         row_base[p] = ps.rows_total;
@@ -952,7 +954,7 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     const std::vector<uint32_t> & kept_rows = ps.kept_rows;
     const std::vector<uint32_t> & kept_ent = ps.kept_ent;
 
-    HostScope scope("em_solve: bins + EM kernels + download");
+    std::unique_ptr<HostScope> scope(new HostScope("em_solve: bins + launches"));
     // Size bins (inside a bin the expensive problems go first, as the reference orders clusters before
     // its dynamic OpenMP schedule, src/main.cpp:811-829):
     //   0  LDS-resident, one wave      CSR + vectors fit 8 KB
@@ -1068,10 +1070,12 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     ctx->spanEnd(span);
     for (int b = 0; b < kBins; ++b) ctx->stats.em_sparse_launches += bins[b].empty() ? 0 : 1;
 
+    scope.reset(new HostScope("em_solve: wait for the kernels + download"));
     RPVG_HIP_CHECK(d_abund.download(results->abundances, st));
     RPVG_HIP_CHECK(d_noise_count.download(results->noise_count, st));
     RPVG_HIP_CHECK(d_iters.download(results->iterations, st));
     RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    scope.reset();
 
     // algorithmic bytes: per iteration 12 B per entry (value + column), 20 B
     // per row (count, noise, offset), 16 B per column (a read + a' write)

@@ -106,8 +106,15 @@ void PathAbundanceEstimator::EMAbundanceEstimator(std::vector<EMSolution> * solu
         assert(!problem.path_ids.empty());
 
         clusters.emplace_back(problem.cluster);
-        col_path.insert(col_path.end(), problem.path_ids.begin(), problem.path_ids.end());
-        col_off.emplace_back(col_path.size());
+        col_off.emplace_back(col_off.back() + problem.path_ids.size());
+    }
+
+    col_path.resize(col_off.back());
+
+    #pragma omp parallel for schedule(static) num_threads(hostThreads())
+    for (size_t i = 0; i < problems.size(); ++i) {
+
+        std::copy(problems.at(i).path_ids.begin(), problems.at(i).path_ids.end(), col_path.begin() + col_off.at(i));
     }
 
     std::vector<double> abundances(col_path.size());
@@ -129,6 +136,7 @@ void PathAbundanceEstimator::EMAbundanceEstimator(std::vector<EMSolution> * solu
 
     HipEngine::check(rpvg_hip_em_solve(engine->ctx(), cluster_batch.handle(), max_em_its, max_rel_em_conv, &em_problems, &em_results), "rpvg_hip_em_solve");
 
+    #pragma omp parallel for schedule(static) num_threads(hostThreads())
     for (size_t i = 0; i < problems.size(); ++i) {
 
         auto & solution = solutions->at(i);
