@@ -523,6 +523,20 @@ struct ResolveArgs {
     uint32_t * out_count;
 };
 
+// first slot of row `pos` in the pair sequence of a matrix with G columns, and the row of a slot
+__device__ __forceinline__ uint64_t sequenceRowStart(const uint32_t pos, const uint32_t G) {
+    return static_cast<uint64_t>(pos) * G - (static_cast<uint64_t>(pos) * (pos > 0 ? pos - 1 : 0)) / 2;
+}
+
+__device__ __forceinline__ uint32_t sequenceRow(const uint64_t slot, const uint32_t G) {
+    uint32_t lo = 0, hi = G - 1;  // largest row whose first slot is <= slot
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (sequenceRowStart(mid, G) <= slot) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 // one workgroup per big matrix: marginal order, pair sequence, exclusive prefix-max filter, posteriors
 __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args) {
     constexpr int kBlock = 256;
@@ -582,18 +596,17 @@ __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args
     }
     __syncthreads();
 
-    // pair sequence: (pos, j >= pos) row by row; s = pos*G - pos*(pos-1)/2 + (j - pos)
+    // pair sequence: (pos, j >= pos) row by row; s = pos*G - pos*(pos-1)/2 + (j - pos).  One thread per slot (the
+    // chunk partials of a slot are dependent-latency loads: every thread of the block should have some in flight)
     const uint64_t S = static_cast<uint64_t>(G) * (G + 1) / 2;
-    for (uint32_t pos = 0; pos < G; ++pos) {
-        const uint32_t a = ord[pos];
-        const uint64_t s0 = static_cast<uint64_t>(pos) * G - (static_cast<uint64_t>(pos) * (pos > 0 ? pos - 1 : 0)) / 2;
-        for (uint32_t j = pos + threadIdx.x; j < G; j += kBlock) {
-            const uint32_t b = ord[j];
-            const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-            double acc = 0.0;
-            for (uint32_t c = 0; c < chunks; ++c) acc += pp[(static_cast<uint64_t>(c) * G + lo) * G + hi];
-            seq[s0 + (j - pos)] = acc + ((lf[a] + lf[b]) + (a == b ? 0.0 : log_two));
-        }
+    for (uint64_t slot = threadIdx.x; slot < S; slot += kBlock) {
+        const uint32_t pos = sequenceRow(slot, G);
+        const uint32_t j = pos + static_cast<uint32_t>(slot - sequenceRowStart(pos, G));
+        const uint32_t a = ord[pos], b = ord[j];
+        const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+        double acc = 0.0;
+        for (uint32_t c = 0; c < chunks; ++c) acc += pp[(static_cast<uint64_t>(c) * G + lo) * G + hi];
+        seq[slot] = acc + ((lf[a] + lf[b]) + (a == b ? 0.0 : log_two));
     }
     __syncthreads();
 
@@ -634,20 +647,8 @@ __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args
             tot += lds_cnt[w2];
         }
         if (keep) {
-            // decode s -> (pos, j)
-            uint32_t pos = 0;
-            {
-                // largest pos with start(pos) <= s, start(pos) = pos*G - pos*(pos-1)/2
-                uint32_t lo = 0, hi = G - 1;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi + 1) >> 1;
-                    const uint64_t st = static_cast<uint64_t>(mid) * G - (static_cast<uint64_t>(mid) * (mid - 1)) / 2;
-                    if (st <= s) lo = mid; else hi = mid - 1;
-                }
-                pos = lo;
-            }
-            const uint64_t st = static_cast<uint64_t>(pos) * G - (static_cast<uint64_t>(pos) * (pos > 0 ? pos - 1 : 0)) / 2;
-            const uint32_t j = pos + static_cast<uint32_t>(s - st);
+            const uint32_t pos = sequenceRow(s, G);
+            const uint32_t j = pos + static_cast<uint32_t>(s - sequenceRowStart(pos, G));
             out_first[off + in_wave] = ord[pos];
             out_second[off + in_wave] = ord[j];
             out_value[off + in_wave] = v;
