@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
 
 // Rows per LDS tile for a matrix with G columns: the tile (G x rows doubles) must fit kTileDoubles; a power of two
 // of at least 16 rows (128-byte runs per column when the tile is written out).  0 = too wide: global-memory kernel.
-constexpr uint32_t kTileDoubles = 8192;  // 64 KB
+constexpr uint32_t kTileDoubles = 4096;  // 32 KB: four workgroups per CU (64 KB tiles, two per CU, were 11 % slower: the rows hang on dependent loads)
 
 __host__ __device__ inline uint32_t tileRows(const uint32_t G) {
     if (G * 16u > kTileDoubles) return 0;
@@ -176,10 +176,32 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
     if (t < nrows) {
         const uint64_t r = r0 + row_perm[mat_row_off[m] + i0 + t];  // matrix row i0 + t = this row of the cluster
         const uint64_t * pgo = path_grp_off + mat_inc_off[m];
-        for (uint64_t e = row_ent_off[r]; e < row_ent_off[r + 1]; ++e) {
-            const uint32_t p = ent_path[e];
-            const double v = ent_prob[e];
-            for (uint64_t x = pgo[p]; x < pgo[p + 1]; ++x) tile[path_grp[x] * Rc + t] += v;
+        // The row's entries hang on a chain of dependent loads (entry -> path -> its columns' offsets -> column): four
+        // entries walk it side by side, the additions stay in entry order.
+        const uint64_t e_end = row_ent_off[r + 1];
+        for (uint64_t e = row_ent_off[r]; e < e_end; e += 4) {
+            uint32_t p[4], g_first[4];
+            double v[4];
+            uint64_t x_begin[4], x_end[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = e + k < e_end;
+                p[k] = in ? ent_path[e + k] : 0u;
+                v[k] = in ? ent_prob[e + k] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = e + k < e_end;
+                x_begin[k] = in ? pgo[p[k]] : 0;
+                x_end[k] = in ? pgo[p[k] + 1] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g_first[k] = x_begin[k] < x_end[k] ? path_grp[x_begin[k]] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (x_begin[k] < x_end[k]) tile[g_first[k] * Rc + t] += v[k];
+                for (uint64_t x = x_begin[k] + 1; x < x_end[k]; ++x) tile[path_grp[x] * Rc + t] += v[k];
+            }
         }
         double mx = 0.0;
         if (normalise) {
