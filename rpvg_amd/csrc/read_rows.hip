@@ -464,6 +464,12 @@ __global__ __launch_bounds__(256) void readRowSmallKernel(const RowsIn in, const
     }
     // every lane of the wave takes part in the shuffles below: groups without work carry E = 0
     const uint32_t n_ent = has_paths ? E : 0;
+    // The loops over entries / units / buckets stop at the largest entry count of the wave's four reads (3.3 entries
+    // per read on average, 16 at most): wave-uniform trip counts, a fifth of the shuffles.
+    uint32_t n_max = n_ent;
+    n_max = max(n_max, static_cast<uint32_t>(__shfl_xor(static_cast<int>(n_max), 16, 64)));
+    n_max = max(n_max, static_cast<uint32_t>(__shfl_xor(static_cast<int>(n_max), 32, 64)));
+    const int n_loop = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<int>(n_max)));
 
     // ---- A: one entry per lane; the survivor of every path (:110-149) -------------------------------------------
     const bool is_entry = static_cast<uint32_t>(g) < n_ent;
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(256) void readRowSmallKernel(const RowsIn in, const
         keep = len != 0;
         if (keep) lp = alp - log(len);  // :126
     }
-    for (int j = 0; j < kGroupLanes; ++j) {
+    for (int j = 0; j < n_loop; ++j) {
         const uint32_t pj = __shfl(p, j, kGroupLanes);
         const uint32_t alj = __shfl(al, j, kGroupLanes);
         const double alpj = __shfl(alp, j, kGroupLanes);
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(256) void readRowSmallKernel(const RowsIn in, const
     }
     // ---- B: ascending path order ---------------------------------------------------------------------------------
     uint32_t rank = 0;
-    for (int j = 0; j < kGroupLanes; ++j) {
+    for (int j = 0; j < n_loop; ++j) {
         const uint32_t pj = __shfl(p, j, kGroupLanes);
         const bool kj = __shfl(static_cast<int>(keep), j, kGroupLanes) != 0;
         rank += (kj && pj < p);
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256) void readRowSmallKernel(const RowsIn in, const
     // unit t lives on lane t: pull (path, log prob) from the survivor whose rank is t
     uint32_t uidx = kNone;
     double uval = -DBL_MAX;
-    for (int j = 0; j < kGroupLanes; ++j) {
+    for (int j = 0; j < n_loop; ++j) {
         const bool kj = __shfl(static_cast<int>(keep), j, kGroupLanes) != 0;
         const uint32_t rj = __shfl(rank, j, kGroupLanes);
         const uint32_t pj = __shfl(p, j, kGroupLanes);
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(256) void readRowSmallKernel(const RowsIn in, const
     // ---- D: precision buckets, sequential in unit order (:181-211); bucket b lives on lane b ----------------------
     uint32_t nb = 0, my_bucket = kNone, b_count = 0, b_first = 0;
     double b_mean = 0.0, low_sum = 0.0;
-    for (int t = 0; t < kGroupLanes; ++t) {
+    for (int t = 0; t < n_loop; ++t) {
         const double pt = __shfl(prob, t, kGroupLanes);
         const bool exists = static_cast<uint32_t>(t) < T;  // uniform inside a group
         const bool big = exists && pt >= in.prob_precision;
@@ -557,12 +563,12 @@ __global__ __launch_bounds__(256) void readRowSmallKernel(const RowsIn in, const
     const double m = b_mean * scale;
     const uint32_t first_member = __shfl(uidx, static_cast<int>(b_first), kGroupLanes);
     uint32_t brank = 0, moff = 0;
-    for (int o = 0; o < kGroupLanes; ++o) {
+    for (int o = 0; o < n_loop; ++o) {
         const double mo = __shfl(m, o, kGroupLanes);
         const uint32_t fo = __shfl(first_member, o, kGroupLanes);
         if (static_cast<uint32_t>(o) < nb && o != g && (mo < m || (mo == m && fo < first_member))) ++brank;
     }
-    for (int o = 0; o < kGroupLanes; ++o) {
+    for (int o = 0; o < n_loop; ++o) {
         const uint32_t ro = __shfl(brank, o, kGroupLanes);
         const uint32_t co = __shfl(b_count, o, kGroupLanes);
         if (static_cast<uint32_t>(o) < nb && ro < brank) moff += co;
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(256) void readRowSmallKernel(const RowsIn in, const
     // members: unit t goes behind the earlier units of its bucket
     const uint32_t bucket_moff = __shfl(moff, static_cast<int>(my_bucket == kNone ? 0 : my_bucket), kGroupLanes);
     uint32_t before = 0;
-    for (int t = 0; t < kGroupLanes; ++t) {
+    for (int t = 0; t < n_loop; ++t) {
         const uint32_t bt = __shfl(my_bucket, t, kGroupLanes);
         if (t < g && bt == my_bucket) ++before;
     }
