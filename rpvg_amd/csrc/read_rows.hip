@@ -706,34 +706,86 @@ __device__ __forceinline__ void bitonicPair(const uint32_t t, const uint32_t k, 
     }
 }
 
+// The positions of a tile in LDS: row id plus the row's first sort keys (noise, number of groups, probability of the
+// first group), which travel with the id.  RowLess reads its keys from global memory through a chain of dependent
+// loads (row -> alignment offsets -> groups); most comparisons are decided by the first keys, which are the same
+// values, so the outcome is RowLess's.
+struct SortTile {
+    uint32_t * id;
+    uint32_t * ngroups;
+    double * noise;
+    double * prob0;
+
+    __device__ void load(const RowLess & less, const uint32_t pos, const uint32_t row) {
+        id[pos] = row;
+        if (row == kNone) return;
+        const uint32_t nb = less.v.sc.row_ngroups[row];
+        noise[pos] = less.v.sc.row_noise[row];
+        ngroups[pos] = nb;
+        prob0[pos] = nb ? less.v.sc.grp_prob[less.v.align_path_off[less.v.read_align_off[row]]] : 0.0;
+    }
+
+    // is the row at position l before the row at position i?
+    __device__ bool before(const RowLess & less, const uint32_t l, const uint32_t i) const {
+        const double nl = noise[l], nr = noise[i];
+        if (!doubleCompareDev(nl, nr)) return nl < nr;
+        const uint32_t bl = ngroups[l], br = ngroups[i];
+        if (bl != br) return bl < br;
+        if (bl > 0) {
+            const double pl = prob0[l], pr = prob0[i];
+            if (!doubleCompareDev(pl, pr)) return pl < pr;
+        }
+        return less(id[l], id[i]);
+    }
+
+    __device__ void exchange(const RowLess & less, const uint32_t i, const uint32_t l) {
+        const uint32_t a = id[i], b = id[l];
+        if (b != kNone && (a == kNone || before(less, l, i))) {
+            const double na = noise[i], pa = prob0[i];
+            const uint32_t ga = ngroups[i];
+            id[i] = b;
+            noise[i] = noise[l];
+            prob0[i] = prob0[l];
+            ngroups[i] = ngroups[l];
+            id[l] = a;
+            noise[l] = na;
+            prob0[l] = pa;
+            ngroups[l] = ga;
+        }
+    }
+};
+
+#define RPVG_SORT_TILE_LDS(tile)                          \
+    __shared__ uint32_t tile##_id[kSmallSort];            \
+    __shared__ uint32_t tile##_ngroups[kSmallSort];       \
+    __shared__ double tile##_noise[kSmallSort];           \
+    __shared__ double tile##_prob0[kSmallSort];           \
+    SortTile tile{tile##_id, tile##_ngroups, tile##_noise, tile##_prob0}
+
 // one workgroup per cluster with at most kSmallSort rows; positions beyond the cluster's rows behave as +infinity
 __global__ __launch_bounds__(256) void sortSmallClustersKernel(const uint32_t num_listed, const uint32_t * __restrict__ listed,
                                                                const uint64_t * __restrict__ cluster_read_off, const RowLess less,
                                                                uint32_t * __restrict__ sorted) {
-    __shared__ uint32_t ids[kSmallSort];
+    RPVG_SORT_TILE_LDS(tile);
     if (blockIdx.x >= num_listed) return;
     const uint32_t c = listed[blockIdx.x];
     const uint64_t r0 = cluster_read_off[c];
     const uint32_t n = static_cast<uint32_t>(cluster_read_off[c + 1] - r0);
     uint32_t L = 2;
     while (L < n) L <<= 1;
-    for (uint32_t i = threadIdx.x; i < L; i += blockDim.x) ids[i] = (i < n) ? static_cast<uint32_t>(r0 + i) : kNone;
+    for (uint32_t i = threadIdx.x; i < L; i += blockDim.x) tile.load(less, i, (i < n) ? static_cast<uint32_t>(r0 + i) : kNone);
     __syncthreads();
     for (uint32_t k = 2; k <= L; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = threadIdx.x; t < (L >> 1); t += blockDim.x) {
                 uint32_t i, l;
                 bitonicPair(t, k, j, &i, &l);
-                const uint32_t a = ids[i], b = ids[l];
-                if (b != kNone && (a == kNone || less(b, a))) {
-                    ids[i] = b;
-                    ids[l] = a;
-                }
+                tile.exchange(less, i, l);
             }
             __syncthreads();
         }
     }
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) sorted[r0 + i] = ids[i];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) sorted[r0 + i] = tile.id[i];
 }
 
 // Clusters with more than kSmallSort rows: tiles of kSmallSort positions are sorted (first = true: all steps up to
@@ -743,7 +795,7 @@ __global__ __launch_bounds__(256) void sortTilesBigKernel(const uint32_t num_til
                                                           const uint32_t * __restrict__ tile_index,
                                                           const uint64_t * __restrict__ cluster_read_off, const RowLess less,
                                                           const bool first, const uint32_t k_merge, uint32_t * __restrict__ sorted) {
-    __shared__ uint32_t ids[kSmallSort];
+    RPVG_SORT_TILE_LDS(tile);
     if (blockIdx.x >= num_tiles) return;
     const uint32_t c = tile_cluster[blockIdx.x];
     const uint64_t r0 = cluster_read_off[c];
@@ -755,22 +807,15 @@ __global__ __launch_bounds__(256) void sortTilesBigKernel(const uint32_t num_til
         while (padded < n) padded <<= 1;
         if (k_merge > padded) return;  // this cluster's network is complete
     }
-    for (uint32_t i = threadIdx.x; i < kSmallSort; i += blockDim.x) ids[i] = (base + i < n) ? sorted[r0 + base + i] : kNone;
+    for (uint32_t i = threadIdx.x; i < kSmallSort; i += blockDim.x) tile.load(less, i, (base + i < n) ? sorted[r0 + base + i] : kNone);
     __syncthreads();
-    auto exchange = [&](const uint32_t i, const uint32_t l) {
-        const uint32_t a = ids[i], b = ids[l];
-        if (b != kNone && (a == kNone || less(b, a))) {
-            ids[i] = b;
-            ids[l] = a;
-        }
-    };
     if (first) {
         for (uint32_t k = 2; k <= kSmallSort; k <<= 1) {
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
                 for (uint32_t t = threadIdx.x; t < (kSmallSort >> 1); t += blockDim.x) {
                     uint32_t i, l;
                     bitonicPair(t, k, j, &i, &l);
-                    exchange(i, l);
+                    tile.exchange(less, i, l);
                 }
                 __syncthreads();
             }
@@ -780,13 +825,13 @@ __global__ __launch_bounds__(256) void sortTilesBigKernel(const uint32_t num_til
             for (uint32_t t = threadIdx.x; t < (kSmallSort >> 1); t += blockDim.x) {
                 uint32_t i, l;
                 bitonicPair(t, k_merge, j, &i, &l);  // j < k_merge / 2: the plain (i, i + j) pairing
-                exchange(i, l);
+                tile.exchange(less, i, l);
             }
             __syncthreads();
         }
     }
     for (uint32_t i = threadIdx.x; i < kSmallSort; i += blockDim.x) {
-        if (base + i < n) sorted[r0 + base + i] = ids[i];
+        if (base + i < n) sorted[r0 + base + i] = tile.id[i];
     }
 }
 
