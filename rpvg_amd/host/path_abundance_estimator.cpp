@@ -8,6 +8,7 @@
 #include <numeric>
 
 #include "numeric_utils.hpp"
+#include "pipeline_lanes.hpp"
 #include "trace.hpp"
 
 namespace rpvg_amd {
@@ -345,6 +346,7 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
     assert(path_cluster_estimates->size() == cluster_batch.numClusters());
 
     ScopedPhase whole_phase("nested: estimateBatch incl. teardown");
+    std::unique_ptr<ScopedPhase> list_phase(new ScopedPhase("nested: cluster list"));
 
     std::vector<uint32_t> clusters;
 
@@ -364,10 +366,29 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
         }
     }
 
+    list_phase.reset();
+
     runInLanes(clusters, [&](const std::vector<uint32_t> & lane_clusters, const std::function<void()> & first_device_stage) {
 
         estimateClusters(path_cluster_estimates, cluster_batch, lane_clusters, rngs, first_device_stage);
     });
+}
+
+// Tens of thousands of small containers are freed by a team instead of one by one — now by the first lane (it never
+// waits, and finishes first), at the start of its next batch by any other lane (RetiredContainers, pipeline_lanes.hpp).
+static void dropNowOrLater(std::function<void(int)> drop) {
+
+    static const bool never_later = std::getenv("RPVG_AMD_NO_DEFERRED_TEARDOWN") != nullptr;
+
+    if (never_later || HipEngine::currentLane() == 0) {
+
+        drop(hostThreads());
+
+    } else {
+
+        // a small team: the lane before is in its host prologue then, and nobody waits for this
+        RetiredContainers::ofThisThread().keep([drop]() { drop(std::max(1, hostThreads() / 8)); });
+    }
 }
 
 // The estimator on a subset of the batch's clusters (all with at least one row).
@@ -383,12 +404,16 @@ void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstim
         }
     }
 
+    std::unique_ptr<ScopedPhase> containers_phase(new ScopedPhase("nested: containers"));
     std::vector<PathSubsetWeights> path_subset_samples(clusters.size());
+    containers_phase.reset();
 
     if (infer_collapsed) {
 
         // inferAbundancesCollapsedGroups (:428-471)
+        containers_phase.reset(new ScopedPhase("nested: problem containers"));
         std::vector<GroupPosteriorProblem> problems(clusters.size());
+        containers_phase.reset();
 
         std::unique_ptr<ScopedPhase> groups_phase(new ScopedPhase("nested: findPathSourceGroups"));
 
@@ -425,15 +450,21 @@ void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstim
 
         ScopedPhase teardown_phase("nested: teardown posterior containers");
 
-        #pragma omp parallel for schedule(static) num_threads(hostThreads())
-        for (size_t i = 0; i < problems.size(); ++i) {
+        auto old_problems = std::make_shared<std::vector<GroupPosteriorProblem> >(std::move(problems));
+        auto old_posteriors = std::make_shared<std::vector<GroupPosteriors> >(std::move(group_posteriors));
 
-            GroupPosteriorProblem().column_path.swap(problems.at(i).column_path);
-            std::vector<uint32_t>().swap(problems.at(i).column_path_off);
-            std::vector<uint32_t>().swap(problems.at(i).column_counts);
-            std::vector<uint32_t>().swap(group_posteriors.at(i).members);
-            std::vector<double>().swap(group_posteriors.at(i).posteriors);
-        }
+        dropNowOrLater([old_problems, old_posteriors](const int threads) {
+
+            #pragma omp parallel for schedule(static) num_threads(threads)
+            for (size_t i = 0; i < old_problems->size(); ++i) {
+
+                std::vector<uint32_t>().swap(old_problems->at(i).column_path);
+                std::vector<uint32_t>().swap(old_problems->at(i).column_path_off);
+                std::vector<uint32_t>().swap(old_problems->at(i).column_counts);
+                std::vector<uint32_t>().swap(old_posteriors->at(i).members);
+                std::vector<double>().swap(old_posteriors->at(i).posteriors);
+            }
+        });
 
     } else {
 
@@ -490,11 +521,16 @@ void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstim
 
     ScopedPhase teardown_phase("nested: teardown subset weights");
 
-    #pragma omp parallel for schedule(static) num_threads(hostThreads())
-    for (size_t i = 0; i < path_subset_samples.size(); ++i) {
+    auto old_samples = std::make_shared<std::vector<PathSubsetWeights> >(std::move(path_subset_samples));
 
-        PathSubsetWeights().swap(path_subset_samples.at(i));
-    }
+    dropNowOrLater([old_samples](const int threads) {
+
+        #pragma omp parallel for schedule(static) num_threads(threads)
+        for (size_t i = 0; i < old_samples->size(); ++i) {
+
+            PathSubsetWeights().swap(old_samples->at(i));
+        }
+    });
 }
 
 void NestedPathAbundanceEstimator::pathGroupPosteriors(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, std::vector<std::mt19937> * rngs) const {
@@ -628,7 +664,7 @@ void NestedPathAbundanceEstimator::findPathSourceGroups(GroupPosteriorProblem * 
     const size_t max_columns = std::min<size_t>(num_incidences, static_cast<size_t>(max_id - min_id) + 1);
     column_hash.reserve(max_columns);
     problem->column_counts.reserve(max_columns);
-    problem->column_path_off.reserve(max_columns + 1);
+    problem->beginColumns(max_columns);
     problem->column_path.reserve(num_incidences);
 
     size_t run_begin = 0;
@@ -926,12 +962,18 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
     // tens of thousands of small vectors: released by the team instead of one by one on return
     ScopedPhase teardown_phase("nested: teardown EM problems");
 
-    #pragma omp parallel for schedule(static) num_threads(hostThreads())
-    for (size_t i = 0; i < problems.size(); ++i) {
+    auto old_problems = std::make_shared<std::vector<EMProblem> >(std::move(problems));
+    auto old_solutions = std::make_shared<std::vector<EMSolution> >(std::move(solutions));
 
-        std::vector<uint32_t>().swap(problems.at(i).path_ids);
-        std::vector<double>().swap(solutions.at(i).abundances);
-    }
+    dropNowOrLater([old_problems, old_solutions](const int threads) {
+
+        #pragma omp parallel for schedule(static) num_threads(threads)
+        for (size_t i = 0; i < old_problems->size(); ++i) {
+
+            std::vector<uint32_t>().swap(old_problems->at(i).path_ids);
+            std::vector<double>().swap(old_solutions->at(i).abundances);
+        }
+    });
 }
 
 }

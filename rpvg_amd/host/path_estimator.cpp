@@ -546,6 +546,9 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
             hostThreadsOverride() = lane_threads;
             HipEngine::currentLane() = lane;
 
+            // the lane before works through its host prologue: time to free what the previous batch left behind
+            RetiredContainers::ofThisThread().dropAll();
+
             stagger.waitTurn(lane);
 
             try {

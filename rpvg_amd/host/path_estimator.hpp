@@ -33,14 +33,26 @@ struct GroupPosteriorProblem {
 
     uint32_t cluster = 0;
 
-    std::vector<uint32_t> column_path_off = std::vector<uint32_t>(1, 0);
+    std::vector<uint32_t> column_path_off;  // empty (no allocation: thousands are constructed at once) or [columns + 1]
     std::vector<uint32_t> column_path;
     std::vector<uint32_t> column_counts;
 
     uint32_t numColumns() const { return column_counts.size(); }
 
+    // the leading offset, before the first column is added through column_path_off directly
+    void beginColumns(const size_t expected_columns = 0) {
+
+        column_path_off.reserve(expected_columns + 1);
+
+        if (column_path_off.empty()) {
+
+            column_path_off.emplace_back(0);
+        }
+    }
+
     void addColumn(const uint32_t * first_path, const uint32_t * last_path, const uint32_t count) {
 
+        beginColumns();
         column_path.insert(column_path.end(), first_path, last_path);
         column_path_off.emplace_back(column_path.size());
         column_counts.emplace_back(count);
