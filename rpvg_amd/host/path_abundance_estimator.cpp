@@ -394,7 +394,12 @@ static void dropNowOrLater(std::function<void(int)> drop) {
 // The estimator on a subset of the batch's clusters (all with at least one row).
 void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, std::vector<std::mt19937> * rngs, const std::function<void()> & first_device_stage) const {
 
-    {
+    // The previous estimates of a cluster are dropped before the new ones are written.  The first lane's prologue is
+    // the batch's (the GPU waits for it): that lane drops them in its merge loop, which nobody waits for.
+    const bool reset_in_merge = (HipEngine::currentLane() == 0);
+
+    if (!reset_in_merge) {
+
         ScopedPhase reset_phase("nested: resetEstimates");
 
         #pragma omp parallel for schedule(static) num_threads(hostThreads())
@@ -517,7 +522,7 @@ void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstim
         }
     }
 
-    inferPathSubsetAbundance(path_cluster_estimates, cluster_batch, clusters, path_subset_samples, rngs);
+    inferPathSubsetAbundance(path_cluster_estimates, cluster_batch, clusters, path_subset_samples, rngs, reset_in_merge);
 
     ScopedPhase teardown_phase("nested: teardown subset weights");
 
@@ -776,7 +781,7 @@ void NestedPathAbundanceEstimator::selectPathSubsetIndices(PathSubsetWeights * p
 }
 
 // src/path_abundance_estimator.cpp:608-750 for all clusters at once.
-void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples, std::vector<std::mt19937> * rngs) const {
+void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples, std::vector<std::mt19937> * rngs, const bool reset_first) const {
 
     assert(clusters.size() == path_subset_samples.size());
 
@@ -878,6 +883,11 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
     for (size_t i = 0; i < clusters.size(); ++i) {
 
         auto & estimates = path_cluster_estimates->at(clusters.at(i));
+
+        if (reset_first) {
+
+            estimates.resetEstimates(0, 0);
+        }
 
         assert(estimates.noise_count == 0);
         estimates.total_count = cluster_batch.totalReadCount(clusters.at(i));

@@ -109,7 +109,7 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
         void sampleGroupPathIndices(std::vector<std::vector<uint32_t> > * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<uint32_t> & group, std::mt19937 * mt_rng) const;
         void selectPathSubsetIndices(PathSubsetWeights * path_subset_samples, const GroupPosteriors & group_posteriors, const GroupPosteriorProblem & problem) const;
 
-        void inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples, std::vector<std::mt19937> * rngs) const;
+        void inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples, std::vector<std::mt19937> * rngs, bool reset_first) const;
 };
 
 }
