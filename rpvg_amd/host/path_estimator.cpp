@@ -31,39 +31,33 @@ class GroupMatrices {
 
             ScopedPhase phase("posteriors: group matrices build");
 
-            std::vector<uint32_t> clusters;
-            std::vector<uint64_t> group_off(1, 0);
-            std::vector<uint64_t> group_path_off(1, 0);
-            std::vector<uint32_t> group_path;
+            // flat spec arrays: offsets per problem first (cheap, serial), then every problem copies its columns (the
+            // incidences of a batch are megabytes, and the GPU waits for this on the first lane)
+            std::vector<uint32_t> clusters(problems.size());
+            std::vector<uint64_t> group_off(problems.size() + 1, 0);
+            std::vector<uint64_t> first_path(problems.size() + 1, 0);
 
-            clusters.reserve(problems.size());
+            for (size_t i = 0; i < problems.size(); ++i) {
 
-            size_t num_columns = 0;
-            size_t num_column_paths = 0;
-
-            for (auto & problem: problems) {
-
-                num_columns += problem.numColumns();
-                num_column_paths += problem.column_path.size();
+                group_off[i + 1] = group_off[i] + problems[i].numColumns();
+                first_path[i + 1] = first_path[i] + problems[i].column_path.size();
             }
 
-            group_off.reserve(problems.size() + 1);
-            group_path_off.reserve(num_columns + 1);
-            group_path.reserve(num_column_paths);
+            std::vector<uint64_t> group_path_off(group_off.back() + 1, 0);
+            std::vector<uint32_t> group_path(first_path.back());
 
-            for (auto & problem: problems) {
+            #pragma omp parallel for schedule(static) num_threads(hostThreads())
+            for (size_t i = 0; i < problems.size(); ++i) {
 
-                clusters.emplace_back(problem.cluster);
-
-                const uint64_t first_path = group_path.size();
+                const auto & problem = problems[i];
+                clusters[i] = problem.cluster;
 
                 for (uint32_t column = 1; column <= problem.numColumns(); ++column) {
 
-                    group_path_off.emplace_back(first_path + problem.column_path_off[column]);
+                    group_path_off[group_off[i] + column] = first_path[i] + problem.column_path_off[column];
                 }
 
-                group_path.insert(group_path.end(), problem.column_path.begin(), problem.column_path.end());
-                group_off.emplace_back(group_path_off.size() - 1);
+                std::copy(problem.column_path.begin(), problem.column_path.end(), group_path.begin() + first_path[i]);
             }
 
             rpvg_hip_group_spec spec;
