@@ -386,8 +386,9 @@ static void dropNowOrLater(std::function<void(int)> drop) {
 
     } else {
 
-        // a small team: the lane before is in its host prologue then, and nobody waits for this
-        RetiredContainers::ofThisThread().keep([drop]() { drop(std::max(1, hostThreads() / 8)); });
+        // (the lane's usual team size: libgomp lets the threads of a team go when the next team is smaller, and creating
+        // them again cost the lane's next parallel region 1.5 ms)
+        RetiredContainers::ofThisThread().keep([drop]() { drop(hostThreads()); });
     }
 }
 

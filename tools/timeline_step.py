@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Prints the phases of the last step of a RPVG_AMD_TIMELINE=1 run (stderr log given as argument)."""
+"""Prints the phases of one step of a RPVG_AMD_TIMELINE=1 run: stderr log, then the step counted from the end
+(default 1 = the last one; bench.py's last call is the decoded run after the timed steps, so 3 is a timed step)."""
 import sys
 ev = []
 for line in open(sys.argv[1]):
@@ -13,7 +14,9 @@ for line in open(sys.argv[1]):
 ev.sort()
 # last step = from the last "estimateBatch incl. teardown" start
 starts = [e for e in ev if "estimateBatch" in e[3]]
-t0 = starts[-1][0]
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t0 = starts[-back][0]
+t1 = starts[-back + 1][0] if back > 1 else float("inf")
 for s, e, t, n in ev:
-    if s >= t0 - 0.01:
+    if t0 - 0.01 <= s < t1 - 0.01:
         print(f"{s - t0:7.2f} {e - t0:7.2f} {e - s:6.2f} T{t} {n}")
