@@ -21,6 +21,9 @@ import os
 import sys
 import time
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import rpvg_amd  # noqa: E402,F401  before torch touches the GPU: runtime settings (hardware queues, heap top pad)
+
 # OpenMP teams (host layer, CPU oracle) sleep instead of spinning between parallel regions, so that
 # idle workers do not compete with the thread that drives the GPU.  Must be set before libgomp loads.
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")

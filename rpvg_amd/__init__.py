@@ -25,3 +25,14 @@ def _keep_heap_top():
 
 
 _keep_heap_top()
+
+
+def _ask_for_hardware_queues():
+    """Eight hardware queues instead of the HIP runtime's four (two host lanes x four busy streams; see
+    rpvg_amd/csrc/common.hpp).  The runtime reads the variable when it starts, so this has to run before the process
+    touches the GPU: import rpvg_amd first.  A value already in the environment is kept."""
+    import os
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+_ask_for_hardware_queues()

@@ -40,6 +40,15 @@ void setError(const char * fmt, ...);
         }                                             \
     } while (0)
 
+// ---- hardware queues ---------------------------------------------------------------
+// The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment says otherwise, read
+// when the runtime starts); work of streams that share a queue runs in order.  Two host lanes with four busy streams
+// each want eight — with four, the uploads and build kernels of the second lane queue behind the search kernels of
+// the first (0.7 ms per batch).  The library asks for eight when it is loaded (before the first HIP call of a C++
+// host; a Python harness must import rpvg_amd before it touches the GPU).  hardwareQueues() is what the environment
+// said when the library was loaded, i.e. what the runtime got if it had not been started yet.
+int hardwareQueues();
+
 // ---- caching device allocator -------------------------------------------------
 // hipMalloc/hipFree cost tens of microseconds to milliseconds each (hipFree also
 // synchronises the device); a step of the hot path needs ~60 scratch arrays whose

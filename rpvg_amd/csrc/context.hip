@@ -97,6 +97,20 @@ void poolTrim(int device) {
     }
 }
 
+namespace {
+
+int g_hardware_queues = 4;
+
+__attribute__((constructor)) void askForHardwareQueues() {
+    (void) setenv("GPU_MAX_HW_QUEUES", "8", 0);  // keeps a value the user has set
+    const char * env = std::getenv("GPU_MAX_HW_QUEUES");
+    g_hardware_queues = env ? std::max(1, std::atoi(env)) : 4;
+}
+
+}  // namespace
+
+int hardwareQueues() { return g_hardware_queues; }
+
 }  // namespace rpvg_hip_detail
 
 using namespace rpvg_hip_detail;

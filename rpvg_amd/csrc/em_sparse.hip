@@ -1033,39 +1033,39 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     args.noise_count = d_noise_count.ptr;
     args.iterations = d_iters.ptr;
 
-    // the four bins are independent: one stream each, so a bin's tail (a tiny problem that needs
-    // thousands of iterations, a giant one with many rows) overlaps the other bins
     // The bins are independent, so their tails (a small problem that needs thousands of iterations, a giant one with
-    // many rows) should overlap — but only as many kernels run side by side as the runtime has hardware queues (4 by
-    // default): four streams, the long register-resident bins on three of them.
+    // many rows) should overlap — but only as many kernels run side by side as the runtime has hardware queues.
     span = ctx->spanBegin(FAM_EM_SPARSE);
     RPVG_HIP_CHECK(ctx->forkAux());
     auto bin = [&](const int b) {
         args.order = d_order.ptr + bin_start[b];
         args.count = bins[b].size();
     };
-    // every stream starts with one of the four sparse kernels (the ones with the long tails: a problem that needs
-    // thousands of iterations at a microsecond or more each); the register-resident bins follow them
+    // The register-resident bins are the long ones: they start first.  With eight hardware queues
+    // (hardwareQueues(), context.hip) they get streams of their own; with four, streams beyond the fourth would only
+    // queue behind the others, and a bin that waits there ends later than one that shares a stream knowingly.
+    const bool wide = hardwareQueues() >= 8;
+    hipStream_t s_reg4 = wide ? ctx->aux[3] : ctx->aux[0], s_reg1 = wide ? ctx->aux[4] : ctx->aux[1], s_reg2 = wide ? ctx->aux[5] : ctx->aux[2];
+    bin(6);
+    RPVG_HIP_CHECK((launchEmRegister<4, 16>(args, s_reg4)));
+    bin(4);
+    RPVG_HIP_CHECK((launchEmRegister<1, 16>(args, s_reg1)));
+    bin(5);
+    RPVG_HIP_CHECK((launchEmRegister<2, 16>(args, s_reg2)));
     bin(2);
     RPVG_HIP_CHECK((launchEm<256, false>(args, bin_lds[2], st)));
     bin(3);
     RPVG_HIP_CHECK((launchEm<1024, false>(args, bin_lds[3], st)));
     bin(7);
     RPVG_HIP_CHECK((launchEm<1024, true>(args, bin_lds[7], ctx->aux[0])));
-    bin(6);
-    RPVG_HIP_CHECK((launchEmRegister<4, 16>(args, ctx->aux[0])));
     bin(9);
     RPVG_HIP_CHECK((launchEmRegister<2, 32>(args, ctx->aux[0])));
     bin(0);
     RPVG_HIP_CHECK((launchEm<64, true>(args, bin_lds[0], ctx->aux[1])));
-    bin(4);
-    RPVG_HIP_CHECK((launchEmRegister<1, 16>(args, ctx->aux[1])));
     bin(8);
     RPVG_HIP_CHECK((launchEmRegister<1, 32>(args, ctx->aux[1])));
     bin(1);
     RPVG_HIP_CHECK((launchEm<256, true>(args, bin_lds[1], ctx->aux[2])));
-    bin(5);
-    RPVG_HIP_CHECK((launchEmRegister<2, 16>(args, ctx->aux[2])));
     RPVG_HIP_CHECK(ctx->joinAux());
     ctx->spanEnd(span);
     for (int b = 0; b < kBins; ++b) ctx->stats.em_sparse_launches += bins[b].empty() ? 0 : 1;
