@@ -40,6 +40,8 @@ const rpvg_hip_ctx * g_search_gate_owner = nullptr;  // context of the last sear
 }
 
 static void searchGateEnter(const rpvg_hip_ctx * ctx, hipStream_t stream) {
+    static const bool open_gate = std::getenv("RPVG_HIP_NO_SEARCH_GATE") != nullptr;  // A/B knob
+    if (open_gate) return;
     std::lock_guard<std::mutex> lock(g_search_gate_mutex);
     if (g_search_gate_owner && g_search_gate_owner != ctx && g_search_gate_owner->device == ctx->device) {
         (void) hipStreamWaitEvent(stream, g_search_gate_owner->search_done, 0);
