@@ -157,6 +157,9 @@ typedef struct rpvg_hip_group_spec {
     int32_t normalise;
 } rpvg_hip_group_spec;
 
+/* Returns once the build is queued on the context's stream (the spec arrays have been consumed by then); a group that
+ * refers to a path outside its cluster is reported by the first call that uses the matrices
+ * (RPVG_HIP_ERR_INVALID from rpvg_hip_group_loglik / _conditionals / rpvg_hip_bounded_pair_posteriors). */
 int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec,
                           rpvg_hip_groups ** groups_out);
 void rpvg_hip_groups_free(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups);

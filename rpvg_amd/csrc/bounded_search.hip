@@ -960,6 +960,13 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     ok(d_out_count.download(counts.data(), st));
     ok(hipMemcpyAsync(&log_evals, d_log_evals.ptr, sizeof(log_evals), hipMemcpyDeviceToHost, st));
     ok(hipStreamSynchronize(st));
+    if (e == hipSuccess) {
+        const int build_status = groups->buildError(st);  // the matrices were built without a host sync
+        if (build_status != RPVG_HIP_OK) {
+            delete res;
+            return build_status;
+        }
+    }
     scope.reset(new HostScope("bounded search: compact + download pairs"));
     if (e == hipSuccess) {
         for (uint32_t m = 0; m < M; ++m) res->pair_off[m + 1] = res->pair_off[m] + counts[m];

@@ -436,6 +436,14 @@ struct rpvg_hip_groups {
     rpvg_hip_detail::DeviceBuffer<double> row_noise;      // [sum R_m]
     rpvg_hip_detail::DeviceBuffer<uint32_t> mat_fast;     // [M] end of the fast rows
     rpvg_hip_detail::DeviceBuffer<uint32_t> mat_mid;      // [M] end of the mid rows
+    // rpvg_hip_groups_build returns with its kernels still queued (no host sync: the caller's next call goes on the
+    // same stream and prepares its own launches meanwhile): the temporaries of the build live until the matrices
+    // are freed, and the validity flag the kernels set is read by the first consumer (buildError()).
+    std::vector<std::shared_ptr<void> > build_temporaries;
+    rpvg_hip_detail::DeviceBuffer<uint32_t> build_error_flag;
+    mutable bool build_checked = false;
+    // RPVG_HIP_OK, or the error of the build (after a sync of `stream`); consumers call it before trusting results
+    int buildError(hipStream_t stream) const;
 };
 
 #endif

@@ -486,9 +486,20 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     std::lock_guard<std::mutex> lock(ctx->mutex);
     hipError_t e = hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    DeviceBuffer<uint64_t> d_inc_off, d_path_grp_off, d_group_off, d_group_path_off, d_num_paths;
-    DeviceBuffer<uint32_t> d_path_grp, d_item_matrix, d_item_chunk, d_tile_matrix, d_tile_chunk, d_group_path, d_degree, d_cursor, d_error;
-    DeviceBuffer<unsigned char> d_scan_tmp;
+    // temporaries: owned by the matrices object (the kernels that use them may still be queued on return)
+    struct BuildTemporaries {
+        DeviceBuffer<uint64_t> inc_off, path_grp_off, group_off, group_path_off, num_paths;
+        DeviceBuffer<uint32_t> path_grp, item_matrix, item_chunk, tile_matrix, tile_chunk, group_path, degree, cursor;
+        DeviceBuffer<unsigned char> scan_tmp;
+    };
+    std::shared_ptr<BuildTemporaries> tmp = std::make_shared<BuildTemporaries>();
+    g->build_temporaries.emplace_back(tmp);
+    auto & d_inc_off = tmp->inc_off; auto & d_path_grp_off = tmp->path_grp_off; auto & d_group_off = tmp->group_off;
+    auto & d_group_path_off = tmp->group_path_off; auto & d_num_paths = tmp->num_paths; auto & d_path_grp = tmp->path_grp;
+    auto & d_item_matrix = tmp->item_matrix; auto & d_item_chunk = tmp->item_chunk; auto & d_tile_matrix = tmp->tile_matrix;
+    auto & d_tile_chunk = tmp->tile_chunk; auto & d_group_path = tmp->group_path; auto & d_degree = tmp->degree;
+    auto & d_cursor = tmp->cursor; auto & d_scan_tmp = tmp->scan_tmp;
+    auto & d_error = g->build_error_flag;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     int span = ctx->spanBegin(FAM_H2D);
     ok(g->mat_val_off.upload(val_off.data(), M, st));
@@ -563,14 +574,8 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         ctx->spanEnd(span);
         ctx->stats.build_launches += 3;
         ok(hipGetLastError());
-        uint32_t bad = 0;
-        ok(hipMemcpyAsync(&bad, d_error.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        ok(hipStreamSynchronize(st));  // incidence temporaries are released on return
-        if (e == hipSuccess && bad) {
-            setError("rpvg_hip_groups_build: a group refers to a path outside its cluster");
-            delete g;
-            return RPVG_HIP_ERR_INVALID;
-        }
+        static const bool wait_here = std::getenv("RPVG_HIP_BUILD_SYNC") != nullptr;  // A/B knob: host sync before returning
+        if (wait_here) ok(hipStreamSynchronize(st));
     }
     if (e != hipSuccess) {
         setError("rpvg_hip_groups_build: %s", hipGetErrorString(e));
@@ -578,6 +583,23 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
     }
     *groups_out = g;
+    return RPVG_HIP_OK;
+}
+
+int rpvg_hip_groups::buildError(hipStream_t stream) const {
+    if (build_checked || !build_error_flag.ptr) return RPVG_HIP_OK;
+    uint32_t bad = 0;
+    hipError_t e = hipMemcpyAsync(&bad, build_error_flag.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        setError("rpvg_hip_groups_build: %s", hipGetErrorString(e));
+        return RPVG_HIP_ERR_RUNTIME;
+    }
+    if (bad) {
+        setError("rpvg_hip_groups_build: a group refers to a path outside its cluster");
+        return RPVG_HIP_ERR_INVALID;
+    }
+    build_checked = true;
     return RPVG_HIP_OK;
 }
 
@@ -647,7 +669,7 @@ extern "C" int rpvg_hip_group_loglik(rpvg_hip_ctx * ctx, const rpvg_hip_groups *
     RPVG_HIP_CHECK(hipGetLastError());
     RPVG_HIP_CHECK(d_out.download(out, st));
     RPVG_HIP_CHECK(hipStreamSynchronize(st));
-    return RPVG_HIP_OK;
+    return groups->buildError(st);  // the matrices were built without a host sync
 }
 
 extern "C" int rpvg_hip_group_conditionals(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, uint32_t num_requests,
@@ -713,5 +735,5 @@ extern "C" int rpvg_hip_group_conditionals(rpvg_hip_ctx * ctx, const rpvg_hip_gr
     RPVG_HIP_CHECK(hipGetLastError());
     RPVG_HIP_CHECK(d_out.download(out, st));
     RPVG_HIP_CHECK(hipStreamSynchronize(st));
-    return RPVG_HIP_OK;
+    return groups->buildError(st);  // the matrices were built without a host sync
 }

@@ -524,3 +524,14 @@ def test_bounded_search_with_more_columns_than_the_lds_rows_hold(hip_ctx, n_path
     sets, post = pyoracle.group_posteriors(M, noise, counts, mult, 2, bounded=True, min_rel_lik=1e-3)
     assert got[0][0] == sets
     assert small_cases.rel_close(got[0][1], post, rel=1e-9, floor=1e-300)
+
+
+def test_groups_with_a_path_outside_the_cluster_are_reported_by_the_first_consumer(hip_ctx):
+    """rpvg_hip_groups_build returns with its kernels queued; the validity flag they set surfaces at the first use."""
+    from rpvg_amd import hip
+    clusters = small_cases.make_batch_clusters(951, n_clusters=2, with_empty=False)
+    dev = hip_ctx.upload(ClusterBatch.from_clusters(clusters))
+    bad_path = len(clusters[0]["paths"]) + 3
+    dg = hip_ctx.groups(dev, [0], [[[0], [bad_path]]], False)
+    with pytest.raises(hip.EngineError, match="outside its cluster"):
+        dg.loglik([0], [[0]], 1.0)
