@@ -217,6 +217,7 @@ __device__ __forceinline__ double logPositive(const double x, const LogTableEntr
 
 #else
 __device__ double waveSumF64(double v);  // host compilation pass: declarations only
+__device__ double readLaneF64(double v, int lane);
 __device__ double rowSumF64(double v);
 __device__ double logPositive(double x);
 __device__ double logPositive(double x, const LogTableEntry * lds_table);

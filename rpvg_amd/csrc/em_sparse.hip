@@ -438,9 +438,7 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
 
     // stage the dense tile through LDS (the scatter needs dynamic indexing, registers must not)
     constexpr uint32_t kTile = 64 * RPL * kRegPaths;
-    constexpr uint32_t kPart = 64 * kRegPaths;
     double * tile = reg_lds;
-    double * a_lds = reg_lds + (kTile > kPart ? kTile : kPart);  // [kRegPaths + 1]; the noise component sits at kRegPaths
     for (uint32_t idx = lane; idx < kTile; idx += 64) tile[idx] = 0.0;
     __syncthreads();
     for (uint32_t r = lane; r < n_rows; r += 64) {
@@ -471,7 +469,6 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
     const bool owns_path = (lane % kLanesPerColumn) == 0 && my_col < np;
     const bool owns_noise = lane == 1;
     double a_mine = (owns_path || owns_noise) ? a0 : 0.0;
-    if (lane <= kRegPaths) a_lds[lane] = (lane < np || lane == kRegPaths) ? a0 : 0.0;
     __syncthreads();
 
     const double inv_T = 1.0 / T;
@@ -481,10 +478,12 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
 
     uint32_t iters = 0, conv = 0;
     for (uint32_t it = 0; it < args.max_em_its; ++it) {
+        // the abundance vector lives in its owner lanes (a_mine): read straight from them (scalar broadcast) instead of a
+        // round trip through LDS — two of the iteration's four LDS latencies
         double av[kRegPaths];
 #pragma unroll
-        for (int j = 0; j < static_cast<int>(kRegPaths); ++j) av[j] = a_lds[j];
-        const double a_noise = a_lds[kRegPaths];
+        for (int j = 0; j < static_cast<int>(kRegPaths); ++j) av[j] = readLaneF64(a_mine, j * kLanesPerColumn);
+        const double a_noise = readLaneF64(a_mine, 1);
         double w[RPL];
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
@@ -535,10 +534,9 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
             // |an - aj| / an > eps  (src/path_abundance_estimator.cpp:73-75), without the division
             if (an >= kMinEmAbundance && fabs(an - a_mine) > eps * an) viol = 1;
             a_mine = an;
-            a_lds[my_col] = an;
         }
         const int any_viol = __any(viol);
-        __syncthreads();  // a_lds is current, part may be overwritten
+        __syncthreads();  // part may be overwritten
         ++iters;
         if (!any_viol) {
             if (++conv == kMinEmConvIts) break;
