@@ -936,8 +936,9 @@ void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors
 
     ScopedPhase results_phase("gibbs: results + teardown");
 
-    // the samplers hold one pair of vectors per evaluated conditional: tear them down in parallel too
-    #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
+    // the samplers hold one pair of vectors per evaluated conditional: tear them down in parallel too (one at a time:
+    // the problems come ordered by size, and the largest sampler alone takes milliseconds)
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(hostThreads())
     for (size_t i = 0; i < problems.size(); ++i) {
 
         auto & sampler = samplers.at(i);
