@@ -522,9 +522,45 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
 
     std::vector<std::vector<uint32_t> > lane_clusters(num_lanes);
 
+    // shares of the lanes (RPVG_AMD_LANE_SHARES="40,60": A/B knob; default equal): the clusters, ordered by size, go
+    // one by one to the lane that is furthest behind its share
+    std::vector<double> share(num_lanes, 1.0);
+
+    if (const char * env = std::getenv("RPVG_AMD_LANE_SHARES")) {
+
+        const char * cursor = env;
+
+        for (int lane = 0; lane < num_lanes && *cursor; ++lane) {
+
+            char * end = nullptr;
+            const double value = std::strtod(cursor, &end);
+
+            if (end == cursor) {
+
+                break;
+            }
+
+            share[lane] = std::max(1e-3, value);
+            cursor = (*end == ',') ? end + 1 : end;
+        }
+    }
+
+    std::vector<double> dealt(num_lanes, 0.0);
+
     for (size_t i = 0; i < clusters.size(); ++i) {
 
-        lane_clusters[i % num_lanes].emplace_back(clusters[i]);
+        int lane = 0;
+
+        for (int other = 1; other < num_lanes; ++other) {
+
+            if ((dealt[other] + 1) / share[other] < (dealt[lane] + 1) / share[lane]) {
+
+                lane = other;
+            }
+        }
+
+        dealt[lane] += 1;
+        lane_clusters[lane].emplace_back(clusters[i]);
     }
 
     // Every lane may use the rank's whole team (hostThreads(): the host's threads divided by its ranks).  The lanes are
