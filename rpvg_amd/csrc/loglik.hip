@@ -579,6 +579,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     }
     if (e != hipSuccess) {
         setError("rpvg_hip_groups_build: %s", hipGetErrorString(e));
+        (void) hipStreamSynchronize(st);  // whatever was queued before the failure still uses the buffers
         delete g;
         return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
     }
