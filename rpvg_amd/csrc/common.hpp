@@ -46,7 +46,8 @@ void setError(const char * fmt, ...);
 // each want eight — with four, the uploads and build kernels of the second lane queue behind the search kernels of
 // the first (0.7 ms per batch).  The library asks for eight when it is loaded (before the first HIP call of a C++
 // host; a Python harness must import rpvg_amd before it touches the GPU).  hardwareQueues() is what the environment
-// said when the library was loaded, i.e. what the runtime got if it had not been started yet.
+// said when the library was loaded, i.e. what the runtime got if it had not been started yet.  (12 and 16 queues
+// measured slower than 8: 13.8-14.5 against 12.6 ms per bench batch — more of the lanes' kernels side by side.)
 int hardwareQueues();
 
 // ---- caching device allocator -------------------------------------------------
