@@ -873,6 +873,14 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
 
     // the table path, the medium and the small matrices are independent: three streams, so that the
     // tail of one does not idle the GPU
+    // streams of the medium / small kernels next to the table path on `st` (RPVG_HIP_SEARCH_STREAMS: A/B knob, 3 = one
+    // stream each, 2 = medium and small share one, 1 = everything on st)
+    static const int search_streams = []() {
+        const char * env = std::getenv("RPVG_HIP_SEARCH_STREAMS");
+        return env ? std::max(1, std::min(3, std::atoi(env))) : 3;
+    }();
+    hipStream_t s_medium = search_streams == 1 ? st : ctx->aux[0];
+    hipStream_t s_small = search_streams == 1 ? st : (search_streams == 2 ? ctx->aux[0] : ctx->aux[1]);
     span = ctx->spanBegin(FAM_LOGLIK);
     searchGateEnter(ctx, st);
     ok(ctx->forkAux());
@@ -939,14 +947,14 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         args.order = d_order.ptr + num_big;
         args.count = num_medium;
         args.stage_rows = kLdsRows;
-        boundedSearchKernel<1024, 64><<<dim3(num_medium), dim3(1024), search_lds_bytes(kLdsRows, kRowLdsCols), ctx->aux[0]>>>(args);
+        boundedSearchKernel<1024, 64><<<dim3(num_medium), dim3(1024), search_lds_bytes(kLdsRows, kRowLdsCols), s_medium>>>(args);
     }
     if (M > num_big + num_medium) {
         args.order = d_order.ptr + num_big + num_medium;
         args.count = M - num_big - num_medium;
         args.stage_rows = kSmallRows;
         args.row_lds_cols = kSmallRowLdsCols;
-        boundedSearchKernel<256, 16><<<dim3(args.count), dim3(256), search_lds_bytes(kSmallRows, kSmallRowLdsCols), ctx->aux[1]>>>(args);
+        boundedSearchKernel<256, 16><<<dim3(args.count), dim3(256), search_lds_bytes(kSmallRows, kSmallRowLdsCols), s_small>>>(args);
     }
     ok(ctx->joinAux());
     searchGateLeave(ctx, st);
