@@ -49,6 +49,10 @@ def parse_args():
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the full workload (parity/dev runs only)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank owns a full-size batch; strong: ONE batch, clusters sharded over the ranks")
+    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
+                    help="s3/s5: batches in flight per GPU.  1 = a step returns before the next one starts (default); 2 = two "
+                         "engines on the GPU, each on its own resident copy of the batch, driven by two host threads: the K steps "
+                         "overlap (one batch's host prologue and epilogue run under the other's kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -160,17 +164,49 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     eng.run_raw(args.model, params, prepared)
     for _ in range(args.warmup):
         eng.run_raw(args.model, params, prepared)
+    others = []  # --in-flight 2: a second engine with its own resident copy of the batch
+    for _ in range(args.in_flight - 1):
+        other = eng_mod.Engine(local_rank)
+        other_prepared = other.prepare(batch)
+        for _ in range(args.warmup + 1):
+            other.run_raw(args.model, params, other_prepared)
+        other.reset_stats()
+        others.append((other, other_prepared))
     eng.reset_stats()
 
     barrier_sync(dist, torch)
     t0 = time.perf_counter()
     step_ms = []
-    for _ in range(args.steps):
-        step_ms.append(eng.run_raw(args.model, params, prepared) * 1e3)
+    if not others:
+        for _ in range(args.steps):
+            step_ms.append(eng.run_raw(args.model, params, prepared) * 1e3)
+    else:
+        import threading
+        lanes = [(eng, prepared)] + others
+        share = [args.steps // len(lanes) + (1 if k < args.steps % len(lanes) else 0) for k in range(len(lanes))]
+        errors = []
+
+        def drive(k):
+            try:
+                for _ in range(share[k]):
+                    lanes[k][0].run_raw(args.model, params, lanes[k][1])  # ctypes releases the GIL during the call
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+
+        threads = [threading.Thread(target=drive, args=(k,)) for k in range(len(lanes))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
     barrier_sync(dist, torch)
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, dist, torch)
     stats = eng.stats()
+    for other, _ in others:
+        for key, value in other.stats().items():
+            stats[key] += value
     if os.environ.get("RPVG_BENCH_STEP_TIMES"):  # spread of the single steps (the JSON line reports the mean)
         print("step ms:", " ".join(f"{t:.1f}" for t in step_ms), file=sys.stderr)
 
@@ -229,7 +265,8 @@ def run_s3(args, rank, local_rank, world, dist, torch):
                              f"(BASELINE.json {config_name}), -i {args.model}"
                              + (" -y 2 --use-hap-gibbs" if s5 else "") + ", reference defaults",
                     clusters_per_gpu=K, rows_per_gpu=batch.num_rows, entries_per_gpu=int(len(batch.path_idx)),
-                    parallelism=f"clusters sharded, {world} rank(s), final abundance gather over RCCL"),
+                    parallelism=f"clusters sharded, {world} rank(s), final abundance gather over RCCL",
+                    batches_in_flight=args.in_flight),
         roofline=roofline, kernels=kernels, mass_conserved=bool(mass_ok),
         upload_ms=upload_ms, value_including_upload=float(batch.total_reads) / ((ms_per_step + upload_ms) / 1e3) * world)
     if gathered is not None:
