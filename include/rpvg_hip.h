@@ -155,6 +155,10 @@ typedef struct rpvg_hip_group_spec {
     const uint64_t * group_path_off;  /* host [G+1] */
     const uint32_t * group_path;      /* host       cluster-local paths of each column */
     int32_t normalise;
+    /* > 0 (normalised matrices only): replay readCollapseProbabilityMatrix (src/path_estimator.cpp:197-259, called
+     * on every normalised group matrix, src/path_abundance_estimator.cpp:380,443) with this prob_precision — every
+     * row takes the values of the head of its run in the reference's tolerant row order; 0: rows stay as built. */
+    double collapse_precision;
 } rpvg_hip_group_spec;
 
 /* Returns once the build is queued on the context's stream (the spec arrays have been consumed by then); a group that
@@ -163,6 +167,11 @@ typedef struct rpvg_hip_group_spec {
 int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec,
                           rpvg_hip_groups ** groups_out);
 void rpvg_hip_groups_free(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups);
+/* What the row collapse of these matrices did (waits for their build): matrices that held rows within
+ * collapse_precision of each other but not equal up to rounding, and were therefore sorted and collapsed as the
+ * reference does; rows that took the values of their run head. */
+int rpvg_hip_groups_collapse_info(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, uint32_t * matrices_replayed,
+                                  uint32_t * rows_replaced);
 
 /* Evaluates, for every request q,
  *   out[q] = sum_i count_i * log( noise_i + ( sum_{m < width, members[q*width+m] != UINT32_MAX}

@@ -358,6 +358,22 @@ __device__ __forceinline__ void sumCountLogsMulti(const LogTableEntry * lt, cons
     }
 }
 
+// ---- row collapse of the group matrices (row_collapse.hip) ---------------------------------------
+// Every row of a normalised matrix carries a projection key: the sum of its values (noise last) with fixed weights
+// in [1, 2).  Rows within prob_precision of each other in every column have keys within 2 (G + 1) prob_precision;
+// rows of a normalised matrix sum to at most 1, so keys lie in [0, 4).  The sort key is (matrix, fixed-point key).
+constexpr int kCollapseKeyFractionBits = 38;
+constexpr int kCollapseKeyBits = kCollapseKeyFractionBits + 2;
+
+__host__ __device__ inline double collapseWeight(const uint32_t column) {
+    return 1.0 + static_cast<double>(((column * 0x9E3779B1u) >> 8) & 0xFFFFu) * (1.0 / 65536.0);
+}
+
+__host__ __device__ inline uint64_t collapseSortKey(const uint32_t matrix, const double key) {
+    const double k = key < 0.0 ? 0.0 : (key > 3.999999 ? 3.999999 : key);
+    return (static_cast<uint64_t>(matrix) << kCollapseKeyBits) | static_cast<uint64_t>(k * static_cast<double>(1ull << kCollapseKeyFractionBits));
+}
+
 // ---- kernel-family timing ---------------------------------------------------
 enum KernelFamily { FAM_EM_SPARSE = 0, FAM_EM_DENSE, FAM_LOGLIK, FAM_BUILD, FAM_H2D, FAM_COUNT };
 
@@ -443,9 +459,19 @@ struct rpvg_hip_groups {
     // are freed, and the validity flag the kernels set is read by the first consumer (buildError()).
     std::vector<std::shared_ptr<void> > build_temporaries;
     rpvg_hip_detail::DeviceBuffer<uint32_t> build_error_flag;
+    // row collapse (row_collapse.hip): sort keys and row ids written by the build kernels; [0] matrices replayed,
+    // [1] rows that took the values of a run head
+    rpvg_hip_detail::DeviceBuffer<uint64_t> collapse_key;  // [sum R_m]
+    rpvg_hip_detail::DeviceBuffer<uint32_t> collapse_row;  // [sum R_m]
+    rpvg_hip_detail::DeviceBuffer<uint32_t> collapse_info;
     mutable bool build_checked = false;
     // RPVG_HIP_OK, or the error of the build (after a sync of `stream`); consumers call it before trusting results
     int buildError(hipStream_t stream) const;
 };
+
+namespace rpvg_hip_detail {
+// queues the replay of readCollapseProbabilityMatrix on the matrices of `groups` behind their build (row_collapse.hip)
+hipError_t queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups, uint64_t total_rows, double precision, hipStream_t stream);
+}
 
 #endif

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
     const uint64_t * __restrict__ path_grp_off,  // per matrix N_k+1 offsets (absolute into path_grp)
     const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
     const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
-    const uint32_t * __restrict__ row_perm, const int normalise, double * __restrict__ values, double * __restrict__ rowmax) {
+    const uint32_t * __restrict__ row_perm, const int normalise, double * __restrict__ values, double * __restrict__ rowmax,
+    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row) {  // null: no row collapse
     if (blockIdx.x >= num_items) return;
     const uint32_t m = item_matrix[blockIdx.x];
     const uint64_t R = mat_rows[m], r0 = mat_row0[m];
@@ -121,11 +122,17 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
             double rowsum = 0.0;
             for (uint32_t g = 0; g < G; ++g) rowsum += M[static_cast<uint64_t>(g) * R + i];
             const double keep = 1 - row_noise[r];
+            double key = collapseWeight(G) * row_noise[r];
             for (uint32_t g = 0; g < G; ++g) {
                 double v = (M[static_cast<uint64_t>(g) * R + i] / rowsum) * keep;
                 if (v != v) v = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
                 M[static_cast<uint64_t>(g) * R + i] = v;
                 mx = (g == 0) ? v : fmax(mx, v);
+                key = fma(collapseWeight(g), v, key);
+            }
+            if (collapse_key) {
+                collapse_key[mat_row_off[m] + i] = collapseSortKey(m, key);
+                collapse_row[mat_row_off[m] + i] = static_cast<uint32_t>(mat_row_off[m] + i);
             }
         } else {
             for (uint32_t g = 0; g < G; ++g) {
@@ -160,7 +167,8 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
     const uint64_t * __restrict__ mat_inc_off, const uint64_t * __restrict__ path_grp_off,
     const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
     const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
-    const uint32_t * __restrict__ row_perm, const int normalise, double * __restrict__ values, double * __restrict__ rowmax) {
+    const uint32_t * __restrict__ row_perm, const int normalise, double * __restrict__ values, double * __restrict__ rowmax,
+    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row) {  // null: no row collapse
     extern __shared__ double tile[];
     if (blockIdx.x >= num_items) return;
     const uint32_t m = item_matrix[blockIdx.x];
@@ -208,11 +216,17 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
             double rowsum = 0.0;
             for (uint32_t g = 0; g < G; ++g) rowsum += tile[g * Rc + t];
             const double keep = 1 - row_noise[r];
+            double key = collapseWeight(G) * row_noise[r];
             for (uint32_t g = 0; g < G; ++g) {
                 double v = (tile[g * Rc + t] / rowsum) * keep;
                 if (v != v) v = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
                 tile[g * Rc + t] = v;
                 mx = (g == 0) ? v : fmax(mx, v);
+                key = fma(collapseWeight(g), v, key);
+            }
+            if (collapse_key) {
+                collapse_key[mat_row_off[m] + i0 + t] = collapseSortKey(m, key);
+                collapse_row[mat_row_off[m] + i0 + t] = static_cast<uint32_t>(mat_row_off[m] + i0 + t);
             }
         } else {
             for (uint32_t g = 0; g < G; ++g) {
@@ -412,6 +426,10 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     const uint32_t M = spec->num_matrices;
     RPVG_REQUIRE(M == 0 || (spec->cluster && spec->group_off && spec->group_path_off && spec->group_path),
                  "rpvg_hip_groups_build: NULL spec arrays");
+    RPVG_REQUIRE(spec->collapse_precision >= 0 && spec->collapse_precision < 1, "rpvg_hip_groups_build: collapse_precision outside [0, 1)");
+    RPVG_REQUIRE(spec->collapse_precision == 0 || spec->normalise,
+                 "rpvg_hip_groups_build: the row collapse applies to normalised matrices (src/path_abundance_estimator.cpp:379-380,442-443)");
+    const bool collapse = spec->collapse_precision > 0;
 
     rpvg_hip_groups * g = new (std::nothrow) rpvg_hip_groups();
     if (!g) {
@@ -529,6 +547,10 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     ok(g->row_noise.alloc(row_total));
     ok(g->mat_fast.alloc(M));
     ok(g->mat_mid.alloc(M));
+    if (collapse) {
+        ok(g->collapse_key.alloc(row_total));
+        ok(g->collapse_row.alloc(row_total));
+    }
     ok(d_degree.alloc(inc_total));
     ok(d_cursor.alloc(inc_total));
     ok(d_path_grp_off.alloc(inc_total));
@@ -562,15 +584,16 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
                 static_cast<uint32_t>(tile_matrix.size()), d_tile_matrix.ptr, d_tile_chunk.ptr, g->mat_val_off.ptr,
                 g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
                 d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
-                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr);
+                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr);
         }
         if (!item_matrix.empty()) {
             groupsBuildKernel<<<dim3(static_cast<uint32_t>(item_matrix.size())), dim3(256), 0, st>>>(
                 static_cast<uint32_t>(item_matrix.size()), d_item_matrix.ptr, d_item_chunk.ptr, g->mat_val_off.ptr,
                 g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
                 d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
-                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr);
+                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr);
         }
+        if (collapse && e == hipSuccess) ok(queueRowCollapse(ctx, g, row_total, spec->collapse_precision, st));
         ctx->spanEnd(span);
         ctx->stats.build_launches += 3;
         ok(hipGetLastError());

@@ -21,7 +21,7 @@ EXPORTS = [
     "rpvg_hip_device_count", "rpvg_hip_create", "rpvg_hip_destroy", "rpvg_hip_last_error", "rpvg_hip_synchronize",
     "rpvg_hip_device_info", "rpvg_hip_malloc", "rpvg_hip_free", "rpvg_hip_memcpy_h2d", "rpvg_hip_memcpy_d2h",
     "rpvg_hip_batch_upload", "rpvg_hip_batch_free", "rpvg_hip_em_solve", "rpvg_hip_em_dense",
-    "rpvg_hip_dense_from_cluster", "rpvg_hip_groups_build", "rpvg_hip_groups_free", "rpvg_hip_group_loglik",
+    "rpvg_hip_dense_from_cluster", "rpvg_hip_groups_build", "rpvg_hip_groups_free", "rpvg_hip_groups_collapse_info", "rpvg_hip_group_loglik",
     "rpvg_hip_synth_dense_cluster", "rpvg_hip_stats_get", "rpvg_hip_stats_reset",
     "rpvg_hip_gibbs_read_counts", "rpvg_hip_min_path_cover", "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
     "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
@@ -48,7 +48,8 @@ class CEmResults(C.Structure):
 
 class CGroupSpec(C.Structure):
     _fields_ = [("num_matrices", C.c_uint32), ("cluster", C.c_void_p), ("group_off", C.c_void_p),
-                ("group_path_off", C.c_void_p), ("group_path", C.c_void_p), ("normalise", C.c_int32)]
+                ("group_path_off", C.c_void_p), ("group_path", C.c_void_p), ("normalise", C.c_int32),
+                ("collapse_precision", C.c_double)]
 
 
 class CPairPosteriorsView(C.Structure):
@@ -184,8 +185,9 @@ class DeviceAlignments:
 
 class DeviceGroups:
     def __init__(self, ctx: "Context", batch: DeviceBatch, clusters: Sequence[int], groups: Sequence[Sequence[Sequence[int]]],
-                 normalise: bool):
-        """groups[m] = list of path lists (one per column) for matrix m on clusters[m]."""
+                 normalise: bool, collapse_precision: float = 0.0):
+        """groups[m] = list of path lists (one per column) for matrix m on clusters[m]; collapse_precision > 0 replays
+        readCollapseProbabilityMatrix on the (normalised) matrices."""
         self.ctx = ctx
         self.batch = batch
         cl = np.ascontiguousarray(clusters, dtype=np.uint32)
@@ -198,10 +200,18 @@ class DeviceGroups:
         goff = np.ascontiguousarray(goff, dtype=np.uint64)
         gpoff = np.ascontiguousarray(gpoff, dtype=np.uint64)
         gp = np.ascontiguousarray(gp, dtype=np.uint32)
-        spec = CGroupSpec(len(cl), cl.ctypes.data, goff.ctypes.data, gpoff.ctypes.data, gp.ctypes.data, 1 if normalise else 0)
+        spec = CGroupSpec(len(cl), cl.ctypes.data, goff.ctypes.data, gpoff.ctypes.data, gp.ctypes.data, 1 if normalise else 0,
+                          float(collapse_precision))
         self.handle = C.c_void_p()
         _check(lib().rpvg_hip_groups_build(ctx.handle, batch.handle, C.byref(spec), C.byref(self.handle)),
                "rpvg_hip_groups_build")
+
+    def collapse_info(self):
+        """(matrices sorted and collapsed as the reference does, rows that took the values of their run head)."""
+        replayed, replaced = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().rpvg_hip_groups_collapse_info(self.ctx.handle, self.handle, C.byref(replayed), C.byref(replaced)),
+               "rpvg_hip_groups_collapse_info")
+        return int(replayed.value), int(replaced.value)
 
     def loglik(self, matrix, members, divisor: float, add_rowmax=None) -> np.ndarray:
         mt = np.ascontiguousarray(matrix, dtype=np.uint32)
@@ -292,8 +302,8 @@ class Context:
     def upload(self, host: ClusterBatch) -> DeviceBatch:
         return DeviceBatch(self, host)
 
-    def groups(self, batch: DeviceBatch, clusters, groups, normalise: bool) -> DeviceGroups:
-        return DeviceGroups(self, batch, clusters, groups, normalise)
+    def groups(self, batch: DeviceBatch, clusters, groups, normalise: bool, collapse_precision: float = 0.0) -> DeviceGroups:
+        return DeviceGroups(self, batch, clusters, groups, normalise, collapse_precision)
 
     # ---- EM -----------------------------------------------------------------
     def em_solve(self, batch: DeviceBatch, clusters: Sequence[int], columns: Sequence[Sequence[int]],

@@ -27,7 +27,7 @@ class GroupMatrices {
 
     public:
 
-        GroupMatrices(const std::shared_ptr<HipEngine> & engine_in, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const bool normalise) : engine(engine_in), groups(nullptr) {
+        GroupMatrices(const std::shared_ptr<HipEngine> & engine_in, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const bool normalise, const double prob_precision) : engine(engine_in), groups(nullptr) {
 
             ScopedPhase phase("posteriors: group matrices build");
 
@@ -67,6 +67,9 @@ class GroupMatrices {
             spec.group_path_off = group_path_off.data();
             spec.group_path = group_path.data();
             spec.normalise = normalise;
+            // the reference collapses every normalised group matrix (src/path_abundance_estimator.cpp:380,443) and none
+            // of the raw ones (src/path_posterior_estimator.cpp:45)
+            spec.collapse_precision = normalise ? prob_precision : 0.0;
 
             HipEngine::check(rpvg_hip_groups_build(engine->ctx(), cluster_batch.handle(), &spec, &groups), "rpvg_hip_groups_build");
         }
@@ -685,7 +688,7 @@ void PathEstimator::calculatePathGroupPosteriorsFull(std::vector<GroupPosteriors
         return;
     }
 
-    const GroupMatrices matrices(engine, cluster_batch, problems, normalise);
+    const GroupMatrices matrices(engine, cluster_batch, problems, normalise, prob_precision);
 
     // every multiset of every problem is one request
     std::vector<uint32_t> request_matrix;
@@ -770,7 +773,7 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
 
     ScopedPhase whole_phase("posteriors: bounded total incl. teardown");
 
-    const GroupMatrices matrices(engine, cluster_batch, problems, normalise);
+    const GroupMatrices matrices(engine, cluster_batch, problems, normalise, prob_precision);
 
     std::vector<uint32_t> column_counts;
 
@@ -829,7 +832,7 @@ void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors
         return;
     }
 
-    const GroupMatrices matrices(engine, cluster_batch, problems, normalise);
+    const GroupMatrices matrices(engine, cluster_batch, problems, normalise, prob_precision);
 
     std::vector<GibbsSampler> samplers(problems.size());
 
@@ -1008,7 +1011,7 @@ void PathEstimator::calculatePathGroupPosteriorsBoundedHostDriven(std::vector<Gr
 
     const double min_log_likelihood_diff = std::log(min_rel_likelihood);
 
-    const GroupMatrices matrices(engine, cluster_batch, problems, normalise);
+    const GroupMatrices matrices(engine, cluster_batch, problems, normalise, prob_precision);
 
     std::vector<BoundedSearch> searches(problems.size());
 

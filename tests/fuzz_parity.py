@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: GPU engine vs the CPU oracle over seeds, batch shapes, models and option values.
-Not part of the test suite (minutes of GPU time); prints every mismatch and a summary.
+The open-ended sweep is run by hand (minutes of GPU time; prints every mismatch and a summary); a fixed set of its
+seeds is collected under -m gpu (tests/test_hip_collapse.py::test_trimmed_parity_sweep).
 
   python tests/fuzz_parity.py [rounds] [first_seed]
 """
@@ -47,6 +48,47 @@ def compare(got, ref, check_iters=True):
     return problems
 
 
+def draw_case(seed):
+    """Batch, model and options of one seed of the sweep."""
+    rng = np.random.default_rng(seed)
+    shape = rng.integers(0, 3)
+    if shape == 0:      # hand-built small clusters incl. empty ones
+        batch = ClusterBatch.from_clusters(small_cases.make_batch_clusters(seed, n_clusters=int(rng.integers(1, 200)),
+                                                                           max_reads=int(rng.integers(25, 400))))
+    elif shape == 1:    # generator: many small clusters
+        batch = synth.generate(seed=seed, num_clusters=int(rng.integers(70, 400)), total_paths=int(rng.integers(2000, 12000)),
+                               total_reads=int(rng.integers(20000, 400000)))
+    else:               # generator: few large clusters
+        batch = synth.generate(seed=seed, num_clusters=int(rng.integers(3, 30)), total_paths=int(rng.integers(1500, 8000)),
+                               total_reads=int(rng.integers(50000, 600000)), max_cluster_paths=int(rng.integers(200, 4000)))
+    model = ["transcripts", "haplotype-transcripts", "haplotypes", "strains"][int(rng.integers(0, 4))]
+    rows = np.diff(batch.cluster_row_off.astype(np.float64))
+    paths = np.diff(batch.cluster_path_off.astype(np.float64))
+    if model in ("strains", "haplotypes") and float((rows * paths * paths).sum()) > 2e9:
+        model = "transcripts"  # the oracle's pair enumeration / greedy cover is O(rows x paths^2) per cluster
+    kw = dict(max_em_its=int(rng.choice([3, 50, 10000])), max_rel_em_conv=float(rng.choice([1e-3, 1e-2, 1e-5])),
+              min_hap_prob=float(rng.choice([1e-3, 1e-2, 1e-5])), rng_seed=int(rng.integers(0, 1000)))
+    if model in ("haplotype-transcripts", "haplotypes"):
+        kw["ploidy"] = int(rng.choice([1, 2, 2, 2, 3]))
+        kw["use_hap_gibbs"] = int(rng.random() < 0.25)
+    if model == "haplotype-transcripts" and not kw.get("use_hap_gibbs") and rng.random() < 0.2 and kw["min_hap_prob"] >= 1e-3:
+        # (with 1e-5 the reference's own assertion sum_hap_prob <= 1 fails on the rounding of 100 000 weights,
+        # src/path_abundance_estimator.cpp:748)
+        kw["ind_hap_inference"] = 1
+    if model == "haplotypes" and kw["ploidy"] == 3 and batch.num_paths > 3000:
+        kw["ploidy"] = 2  # full enumeration of triplets over thousands of paths is not a test case
+    return dict(seed=seed, shape=int(shape), batch=batch, model=model, kw=kw)
+
+
+def run_case(eng, case, oracle_threads=32):
+    """Mismatches between the engine and the oracle on one case (empty list: parity)."""
+    params = make_params(**case["kw"])
+    ref, _ = pyoracle.run(case["model"], params, case["batch"], oracle_threads)
+    got, _ = eng.run(case["model"], params, eng.prepare(case["batch"]))
+    # independent inference interleaves generator draws differently from the reference: statistical only
+    return [] if case["kw"].get("ind_hap_inference") else compare(got, ref)
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -55,43 +97,14 @@ def main():
     t0 = time.time()
     for i in range(rounds):
         seed = seed0 + i
-        rng = np.random.default_rng(seed)
-        shape = rng.integers(0, 3)
-        if shape == 0:      # hand-built small clusters incl. empty ones
-            batch = ClusterBatch.from_clusters(small_cases.make_batch_clusters(seed, n_clusters=int(rng.integers(1, 200)),
-                                                                               max_reads=int(rng.integers(25, 400))))
-        elif shape == 1:    # generator: many small clusters
-            batch = synth.generate(seed=seed, num_clusters=int(rng.integers(70, 400)), total_paths=int(rng.integers(2000, 12000)),
-                                   total_reads=int(rng.integers(20000, 400000)))
-        else:               # generator: few large clusters
-            batch = synth.generate(seed=seed, num_clusters=int(rng.integers(3, 30)), total_paths=int(rng.integers(1500, 8000)),
-                                   total_reads=int(rng.integers(50000, 600000)), max_cluster_paths=int(rng.integers(200, 4000)))
-        model = ["transcripts", "haplotype-transcripts", "haplotypes", "strains"][int(rng.integers(0, 4))]
-        rows = np.diff(batch.cluster_row_off.astype(np.float64))
-        paths = np.diff(batch.cluster_path_off.astype(np.float64))
-        if model in ("strains", "haplotypes") and float((rows * paths * paths).sum()) > 2e9:
-            model = "transcripts"  # the oracle's pair enumeration / greedy cover is O(rows x paths^2) per cluster
-        kw = dict(max_em_its=int(rng.choice([3, 50, 10000])), max_rel_em_conv=float(rng.choice([1e-3, 1e-2, 1e-5])),
-                  min_hap_prob=float(rng.choice([1e-3, 1e-2, 1e-5])), rng_seed=int(rng.integers(0, 1000)))
-        if model in ("haplotype-transcripts", "haplotypes"):
-            kw["ploidy"] = int(rng.choice([1, 2, 2, 2, 3]))
-            kw["use_hap_gibbs"] = int(rng.random() < 0.25)
-        if model == "haplotype-transcripts" and not kw.get("use_hap_gibbs") and rng.random() < 0.2 and kw["min_hap_prob"] >= 1e-3:
-            # (with 1e-5 the reference's own assertion sum_hap_prob <= 1 fails on the rounding of 100 000 weights,
-            # src/path_abundance_estimator.cpp:748)
-            kw["ind_hap_inference"] = 1
-        if model == "haplotypes" and kw["ploidy"] == 3 and batch.num_paths > 3000:
-            kw["ploidy"] = 2  # full enumeration of triplets over thousands of paths is not a test case
-        params = make_params(**kw)
+        case = draw_case(seed)
         try:
-            ref, _ = pyoracle.run(model, params, batch, 32)
-            got, _ = eng.run(model, params, eng.prepare(batch))
-            # independent inference interleaves generator draws differently from the reference: statistical only
-            problems = [] if kw.get("ind_hap_inference") else compare(got, ref)
+            problems = run_case(eng, case)
         except Exception as exc:  # noqa: BLE001
             problems = [f"exception: {exc}"]
         status = "ok" if not problems else "MISMATCH"
-        print(f"{time.time() - t0:6.0f}s [{i:3d}] seed {seed} shape {shape} {model:22s} {kw} clusters {batch.num_clusters} -> {status}", flush=True)
+        print(f"{time.time() - t0:6.0f}s [{i:3d}] seed {seed} shape {case['shape']} {case['model']:22s} {case['kw']} "
+              f"clusters {case['batch'].num_clusters} -> {status}", flush=True)
         for p in problems[:5]:
             print("      ", p, flush=True)
         failures += bool(problems)

@@ -257,3 +257,51 @@ def test_oracle_reproduces_golden_vectors(name):
         assert e.total_count == ge["total_count"]
         assert abs(e.noise_count - ge["noise_count"]) <= 1e-10 * max(1.0, ge["total_count"])
         assert sorted(e.em_iters) == sorted(ge["em_iters"])
+
+
+# ---- row collapse fixtures (tests/golden/make_collapse_fixture.py, tests/collapse_cases.py) ---------------------------
+
+def test_collapse_fixture_is_what_the_oracle_computes():
+    with open(os.path.join(GOLDEN, "collapse_seed7004_cluster122.json")) as f:
+        doc = json.load(f)
+    c = doc["cluster"]
+    cluster = dict(paths=c["paths"], rows=[(r[0], r[1], [(g[0], g[1]) for g in r[2]]) for r in c["rows"]])
+    batch = ClusterBatch.from_clusters([cluster])
+    for case in doc["cases"]:
+        est, _ = pyoracle.run(doc["model"], make_params(**case["params"]), batch, 1)
+        keyed = est[0].keyed()
+        want = {tuple(s[0]): (s[1], tuple(s[2])) for s in case["sets"]}
+        assert set(keyed) == set(want)
+        for key, (post, ab) in want.items():
+            assert small_cases.rel_close(keyed[key][0], post, rel=1e-12) and small_cases.rel_close(keyed[key][1], ab, rel=1e-12)
+    # the point of the fixture: without the collapse the haploid posterior of haplotype group 0 is 6.6715e-3, with it 6.6786e-3
+    g, _ = np_oracle.source_groups(cluster["paths"])
+    M, noise, counts = np_oracle.grouped_matrix(cluster["rows"], g)
+    Pn = np_oracle.add_noise_and_normalize(M, noise)
+    Pc, cc = np_oracle.read_collapse(Pn, counts, 1e-8)
+    assert Pc.shape[0] < Pn.shape[0]
+    haploid = {tuple(s[0]): s[1] for s in doc["cases"][0]["sets"]}
+    assert abs(haploid[(0,)] - 6.6786e-3) < 1e-6
+
+
+@pytest.mark.parametrize("seed", [811, 821])
+def test_planted_close_rows_change_the_collapsed_matrix_and_both_oracles_agree(seed):
+    from tests import collapse_cases
+    clusters = collapse_cases.make_collapse_clusters(seed, n_clusters=6, max_reads=150)
+    shrunk = 0
+    for cl in clusters:
+        g, _ = np_oracle.source_groups(cl["paths"])
+        M, noise, counts = np_oracle.grouped_matrix(cl["rows"], g)
+        Pn = np_oracle.add_noise_and_normalize(M, noise)
+        Pc, cc = np_oracle.read_collapse(Pn, counts, 1e-8)
+        assert cc.sum() == counts.sum()
+        shrunk += Pn.shape[0] - Pc.shape[0]
+    assert shrunk > 0
+    batch = ClusterBatch.from_clusters(clusters)
+    est, _ = pyoracle.run("haplotype-transcripts", make_params(), batch, 1)
+    for cl, e in zip(clusters, est):
+        ref = np_oracle.estimate_haplotype_transcripts(cl["paths"], cl["rows"])
+        keyed = e.keyed()
+        assert set(keyed) == set(ref["keyed"])
+        for k, (p, a) in ref["keyed"].items():
+            assert small_cases.rel_close(keyed[k][0], p, rel=1e-9) and small_cases.rel_close(keyed[k][1], a, rel=1e-8)
