@@ -167,11 +167,12 @@ typedef struct rpvg_hip_group_spec {
 int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec,
                           rpvg_hip_groups ** groups_out);
 void rpvg_hip_groups_free(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups);
-/* What the row collapse of these matrices did (waits for their build): matrices that held rows within
- * collapse_precision of each other but not equal up to rounding, and were therefore sorted and collapsed as the
- * reference does; rows that took the values of their run head. */
+/* What the row collapse of these matrices did (waits for their build; any output may be NULL): matrices that held
+ * rows within collapse_precision of each other but not equal up to rounding, whose runs were therefore replayed as
+ * the reference forms them; rows that took the values of their run head; matrices that were sorted as a whole
+ * (otherwise only the rows close to such a pair are); rows that took part in a replay. */
 int rpvg_hip_groups_collapse_info(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, uint32_t * matrices_replayed,
-                                  uint32_t * rows_replaced);
+                                  uint32_t * rows_replaced, uint32_t * matrices_sorted_whole, uint32_t * active_rows);
 
 /* Evaluates, for every request q,
  *   out[q] = sum_i count_i * log( noise_i + ( sum_{m < width, members[q*width+m] != UINT32_MAX}

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
     const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
     const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
     const uint32_t * __restrict__ row_perm, const int normalise, double * __restrict__ values, double * __restrict__ rowmax,
-    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row) {  // null: no row collapse
+    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row, uint64_t * __restrict__ collapse_mask) {  // null: no row collapse
     if (blockIdx.x >= num_items) return;
     const uint32_t m = item_matrix[blockIdx.x];
     const uint64_t R = mat_rows[m], r0 = mat_row0[m];
@@ -123,16 +123,19 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
             for (uint32_t g = 0; g < G; ++g) rowsum += M[static_cast<uint64_t>(g) * R + i];
             const double keep = 1 - row_noise[r];
             double key = collapseWeight(G) * row_noise[r];
+            uint64_t pattern = 0;
             for (uint32_t g = 0; g < G; ++g) {
                 double v = (M[static_cast<uint64_t>(g) * R + i] / rowsum) * keep;
                 if (v != v) v = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
                 M[static_cast<uint64_t>(g) * R + i] = v;
                 mx = (g == 0) ? v : fmax(mx, v);
                 key = fma(collapseWeight(g), v, key);
+                if (g < 64 && v != 0.0) pattern |= 1ull << g;
             }
             if (collapse_key) {
-                collapse_key[mat_row_off[m] + i] = collapseSortKey(m, key);
+                collapse_key[mat_row_off[m] + i] = collapseSortKey(m, key, mx);
                 collapse_row[mat_row_off[m] + i] = static_cast<uint32_t>(mat_row_off[m] + i);
+                collapse_mask[mat_row_off[m] + i] = pattern;
             }
         } else {
             for (uint32_t g = 0; g < G; ++g) {
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
     const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
     const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
     const uint32_t * __restrict__ row_perm, const int normalise, double * __restrict__ values, double * __restrict__ rowmax,
-    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row) {  // null: no row collapse
+    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row, uint64_t * __restrict__ collapse_mask) {  // null: no row collapse
     extern __shared__ double tile[];
     if (blockIdx.x >= num_items) return;
     const uint32_t m = item_matrix[blockIdx.x];
@@ -217,16 +220,19 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
             for (uint32_t g = 0; g < G; ++g) rowsum += tile[g * Rc + t];
             const double keep = 1 - row_noise[r];
             double key = collapseWeight(G) * row_noise[r];
+            uint64_t pattern = 0;
             for (uint32_t g = 0; g < G; ++g) {
                 double v = (tile[g * Rc + t] / rowsum) * keep;
                 if (v != v) v = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
                 tile[g * Rc + t] = v;
                 mx = (g == 0) ? v : fmax(mx, v);
                 key = fma(collapseWeight(g), v, key);
+                if (g < 64 && v != 0.0) pattern |= 1ull << g;
             }
             if (collapse_key) {
-                collapse_key[mat_row_off[m] + i0 + t] = collapseSortKey(m, key);
+                collapse_key[mat_row_off[m] + i0 + t] = collapseSortKey(m, key, mx);
                 collapse_row[mat_row_off[m] + i0 + t] = static_cast<uint32_t>(mat_row_off[m] + i0 + t);
+                collapse_mask[mat_row_off[m] + i0 + t] = pattern;
             }
         } else {
             for (uint32_t g = 0; g < G; ++g) {
@@ -429,7 +435,8 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     RPVG_REQUIRE(spec->collapse_precision >= 0 && spec->collapse_precision < 1, "rpvg_hip_groups_build: collapse_precision outside [0, 1)");
     RPVG_REQUIRE(spec->collapse_precision == 0 || spec->normalise,
                  "rpvg_hip_groups_build: the row collapse applies to normalised matrices (src/path_abundance_estimator.cpp:379-380,442-443)");
-    const bool collapse = spec->collapse_precision > 0;
+    static const bool no_collapse = std::getenv("RPVG_HIP_NO_COLLAPSE") != nullptr;  // A/B knob: matrices as built
+    const bool collapse = spec->collapse_precision > 0 && !no_collapse;
 
     rpvg_hip_groups * g = new (std::nothrow) rpvg_hip_groups();
     if (!g) {
@@ -550,6 +557,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     if (collapse) {
         ok(g->collapse_key.alloc(row_total));
         ok(g->collapse_row.alloc(row_total));
+        ok(g->collapse_mask.alloc(row_total));
     }
     ok(d_degree.alloc(inc_total));
     ok(d_cursor.alloc(inc_total));
@@ -584,14 +592,14 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
                 static_cast<uint32_t>(tile_matrix.size()), d_tile_matrix.ptr, d_tile_chunk.ptr, g->mat_val_off.ptr,
                 g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
                 d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
-                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr);
+                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_mask.ptr);
         }
         if (!item_matrix.empty()) {
             groupsBuildKernel<<<dim3(static_cast<uint32_t>(item_matrix.size())), dim3(256), 0, st>>>(
                 static_cast<uint32_t>(item_matrix.size()), d_item_matrix.ptr, d_item_chunk.ptr, g->mat_val_off.ptr,
                 g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
                 d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
-                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr);
+                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_mask.ptr);
         }
         if (collapse && e == hipSuccess) ok(queueRowCollapse(ctx, g, row_total, spec->collapse_precision, st));
         ctx->spanEnd(span);
@@ -633,6 +641,14 @@ extern "C" void rpvg_hip_groups_free(rpvg_hip_ctx * ctx, rpvg_hip_groups * group
         std::lock_guard<std::mutex> lock(ctx->mutex);
         (void) hipSetDevice(ctx->device);
         (void) hipStreamSynchronize(ctx->stream);
+        static const bool trace = std::getenv("RPVG_AMD_TRACE") != nullptr;
+        if (trace && groups->collapse_info.ptr) {
+            uint32_t info[4] = {0, 0, 0, 0};
+            if (hipMemcpy(info, groups->collapse_info.ptr, sizeof(info), hipMemcpyDeviceToHost) == hipSuccess) {
+                std::fprintf(stderr, "[rpvg_hip trace]   row collapse: %u of %u matrices replayed (%u sorted whole), %u active rows, %u rows took their head's values\n",
+                             info[0], groups->num_matrices, info[2], info[3], info[1]);
+            }
+        }
         delete groups;
     } else {
         delete groups;

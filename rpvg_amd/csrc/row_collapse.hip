@@ -8,16 +8,29 @@
 // "takes the values of the head" with the row's own count: the rows stay where they are (their class order,
 // LogProduct, is untouched) and only values move.
 //
-// Two stages, both queued behind the build without a host round trip:
-//   1. detection (always): every row carries a projection key (sum of its values with fixed weights in [1, 2), written
-//      by the build kernels as (matrix, fixed-point key): collapseSortKey, common.hpp).  Rows within prob_precision of each other in all columns have keys within
-//      2 (G + 1) prob_precision, so one radix sort of (matrix, key) over all matrices and a forward window scan find
-//      every such pair.  A matrix whose close pairs are all equal up to rounding (<= 1e-13 relative) is left alone:
-//      whichever row heads a run there, the values that would move are the same to 13 digits.
-//   2. replay (flagged matrices only, one workgroup each): bitonic network over the row indices with the
-//      reference's comparator, run heads found with the reference's compare-with-the-head rule, values of the
-//      head copied over its run (group columns, noise, row maximum).  The tolerant comparison is not a strict weak
-//      order; where it is inconsistent the reference's own result is whatever std::sort makes of it.
+// Such rows are not rare: a read whose worst candidate path falls below prob_precision moves that mass into its noise
+// probability (src/read_path_probabilities.cpp:181-215), the caller's sort compares the noise first
+// (:283-322) and so does not bring it next to the row without that candidate, and the two meet again here.  But they
+// are few (427 of the 3.28 M rows of the configs[2] workload), so nothing below sorts a whole matrix unless it must:
+//   1. close pairs.  Every row carries a projection key (the sum of its values with fixed weights in [0, 2), written
+//      by the build kernels as (matrix, fixed-point key): collapseSortKey, common.hpp).  Rows within prob_precision of
+//      each other in all columns have keys within 2 (G + 1) prob_precision, so one radix sort over all matrices and
+//      a forward window scan find every close pair.  A close pair that is equal up to rounding (<= 1e-13 relative) moves
+//      nothing worth moving; a pair that is not marks both rows, and a second window scan adds the rows close to a
+//      marked row: the ACTIVE rows.  A run of the reference that changes a value consists of active rows only, and an
+//      inactive row is close to no active one.
+//   2. replay, for the matrices with active rows:
+//      a. (one workgroup per matrix) the active rows are sorted with the reference's comparator, bitonic network in LDS;
+//      b. (the rows of those matrices, spread over many workgroups) an inactive row that the order places between two
+//         neighbours of that list ends the run there, as it would in the reference (it is compared with the head,
+//         fails, and becomes the head) — such a row has the zeros of both neighbours up to the first column in which
+//         they differ, and lies between them in that column;
+//      c. (one workgroup per matrix) the reference's compare-with-the-head rule, and the values of the head (group
+//         columns, noise, row maximum) are copied over its run.
+//      A matrix whose windows are too crowded to look through, or with more active rows than the LDS list holds,
+//      takes the same code with every row active (the whole matrix sorted; no rows left to lie in between).
+// The tolerant comparison is not a strict weak order; where it is inconsistent the reference's own result is
+// whatever std::sort makes of it.
 
 #include "common.hpp"
 
@@ -30,244 +43,602 @@ using namespace rpvg_hip_detail;
 namespace {
 
 constexpr int kKeyFractionBits = kCollapseKeyFractionBits;
-constexpr int kKeyBits = kCollapseKeyBits;
-constexpr uint32_t kMaxWindowCompares = 64;    // a row with more candidates than this sends its matrix to the replay
+constexpr uint32_t kMaxWindowCompares = 256;   // a row with more candidates than this sends its matrix to the full sort
 constexpr double kEquivalentRelative = 1e-13;  // close rows that differ by no more than this are interchangeable
-constexpr uint32_t kSortLdsRows = 8192;        // index arrays up to this size are sorted in LDS
+constexpr uint32_t kListLdsRows = 8192;        // row lists up to this size live (and are sorted) in LDS
+constexpr uint32_t kSortThreads = 1024;
+constexpr uint32_t kBetweenThreads = 256;
+constexpr uint32_t kBetweenRows = 2 * kBetweenThreads;  // rows of a matrix per work item of step b
+constexpr uint32_t kPairChunk = 256;           // neighbour pairs staged in LDS at a time
+constexpr uint32_t kWholeMatrixBit = 0x80000000u;
+
+enum : uint32_t { kFlagNone = 0, kFlagActiveRows = 1, kFlagWholeMatrix = 2 };
+enum : uint32_t { kInfoMatrices = 0, kInfoRowsReplaced = 1, kInfoWholeMatrices = 2, kInfoActiveRows = 3, kInfoWords = 4 };
 
 __device__ __forceinline__ bool tolerantEqual(const double a, const double b) {  // Utils::doubleCompare, src/utils.hpp:87-93
     return a == b || fabs(a - b) < fabs(fmin(a, b)) * (DBL_EPSILON * 100);
 }
 
 struct MatrixView {
-    const double * values;  // column-major R x G
+    const double * values;     // column-major R x G
     const double * noise;
     const double * count;
+    const uint64_t * pattern;  // bit c: column c (< 64) of the row is not zero
     uint64_t R;
     uint32_t G;
+    // column G = noise.  (One load behind a selected address: a load on either side of a branch would wait for the
+    // previous one, and the comparisons below live on having their loads in flight together.)
+    __device__ __forceinline__ double at(const uint32_t column, const uint32_t row) const {
+        const double * address = column < G ? values + (static_cast<uint64_t>(column) * R + row) : noise + row;
+        return __builtin_nontemporal_load(address);
+    }
 };
 
+// Rows that are compared in depth agree in most columns, and a column costs two strided loads.  The comparisons below
+// walk the columns in the reference's order but (1) skip the columns in which both rows are zero — equal for every
+// purpose here — by their zero patterns, and (2) fetch kBatch columns of both rows before they look at any of them,
+// so that the loads are in flight together.
+constexpr uint32_t kBatch = 8;
+
+template <typename Decide>  // decide(x, y) -> true: stop
+__device__ __forceinline__ void forEachColumnPair(const MatrixView & mv, const uint32_t a, const uint32_t b, uint64_t live, Decide decide) {
+    uint32_t next_wide = 64;  // columns from 64 on carry no pattern: all of them
+    bool noise_done = false;
+    while (true) {
+        uint32_t column[kBatch];
+        uint32_t filled = 0;
+        while (filled < kBatch && live) {
+            column[filled++] = static_cast<uint32_t>(__ffsll(static_cast<long long>(live)) - 1);
+            live &= live - 1;
+        }
+        while (filled < kBatch && next_wide < mv.G) column[filled++] = next_wide++;
+        if (filled < kBatch && !noise_done) {
+            column[filled++] = mv.G;
+            noise_done = true;
+        }
+        if (filled == 0) return;
+        double x[kBatch], y[kBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; ++k) {
+            const uint32_t c = column[k < filled ? k : 0];
+            x[k] = mv.at(c, a);
+            y[k] = mv.at(c, b);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; ++k) {
+            if (k < filled && decide(x[k], y[k])) return;
+        }
+    }
+}
+
 // probabilityCountRowSorter (src/path_estimator.cpp:13-31) on rows a, b of one matrix
-__device__ bool rowLess(const MatrixView & mv, const uint32_t a, const uint32_t b) {
-    for (uint32_t c = 0; c < mv.G; ++c) {
-        const double x = mv.values[static_cast<uint64_t>(c) * mv.R + a], y = mv.values[static_cast<uint64_t>(c) * mv.R + b];
-        if (!tolerantEqual(x, y)) return x < y;
-    }
-    {
-        const double x = mv.noise[a], y = mv.noise[b];
-        if (!tolerantEqual(x, y)) return x < y;
-    }
+__device__ bool rowLess(const MatrixView & mv, const uint32_t a, const uint32_t b, const uint64_t pattern_a, const uint64_t pattern_b) {
+    int result = -1;
+    forEachColumnPair(mv, a, b, pattern_a | pattern_b, [&](const double x, const double y) {
+        if (tolerantEqual(x, y)) return false;
+        result = x < y ? 1 : 0;
+        return true;
+    });
+    if (result >= 0) return result != 0;
     const double x = mv.count[a], y = mv.count[b];
     if (!tolerantEqual(x, y)) return x < y;
     return false;
 }
 
+__device__ __forceinline__ bool rowLess(const MatrixView & mv, const uint32_t a, const uint32_t b) {
+    return rowLess(mv, a, b, mv.pattern[a], mv.pattern[b]);
+}
+
 // every column (noise included) within `precision` of each other, absolutely (src/path_estimator.cpp:232-239);
 // *equivalent: additionally equal up to rounding in every column
 __device__ bool rowsClose(const MatrixView & mv, const uint32_t a, const uint32_t b, const double precision, bool * equivalent) {
-    bool eq = true;
-    for (uint32_t c = 0; c <= mv.G; ++c) {
-        const double x = c < mv.G ? mv.values[static_cast<uint64_t>(c) * mv.R + a] : mv.noise[a];
-        const double y = c < mv.G ? mv.values[static_cast<uint64_t>(c) * mv.R + b] : mv.noise[b];
+    bool eq = true, close = true;
+    forEachColumnPair(mv, a, b, mv.pattern[a] | mv.pattern[b], [&](const double x, const double y) {
         const double d = fabs(x - y);
-        if (d >= precision) return false;
+        if (d >= precision) {
+            close = false;
+            return true;
+        }
         if (d > kEquivalentRelative * fmin(fabs(x), fabs(y))) eq = false;
-    }
-    if (equivalent) *equivalent = eq;
-    return true;
+        return false;
+    });
+    if (close && equivalent) *equivalent = eq;
+    return close;
 }
 
 __device__ bool rowsIdentical(const MatrixView & mv, const uint32_t a, const uint32_t b) {
-    for (uint32_t c = 0; c < mv.G; ++c)
-        if (mv.values[static_cast<uint64_t>(c) * mv.R + a] != mv.values[static_cast<uint64_t>(c) * mv.R + b]) return false;
-    return mv.noise[a] == mv.noise[b];
+    bool same = true;
+    forEachColumnPair(mv, a, b, mv.pattern[a] | mv.pattern[b], [&](const double x, const double y) {
+        if (x == y) return false;
+        same = false;
+        return true;
+    });
+    return same;
 }
 
-__device__ __forceinline__ MatrixView viewOf(const uint32_t m, const uint64_t * __restrict__ mat_val_off, const uint64_t * __restrict__ mat_row_off,
-                                             const uint64_t * __restrict__ mat_rows, const uint32_t * __restrict__ mat_cols,
-                                             const double * __restrict__ values, const double * __restrict__ row_noise,
-                                             const double * __restrict__ row_count) {
+struct MatrixArrays {
+    const uint64_t * mat_val_off;
+    const uint64_t * mat_row_off;
+    const uint64_t * mat_rows;
+    const uint32_t * mat_cols;
+    double * values;
+    double * row_noise;
+    const double * row_count;
+    const uint64_t * zero_pattern;
+};
+
+__device__ __forceinline__ MatrixView viewOf(const uint32_t m, const MatrixArrays & g) {
     MatrixView mv;
-    mv.values = values + mat_val_off[m];
-    mv.noise = row_noise + mat_row_off[m];
-    mv.count = row_count + mat_row_off[m];
-    mv.R = mat_rows[m];
-    mv.G = mat_cols[m];
+    mv.values = g.values + g.mat_val_off[m];
+    mv.noise = g.row_noise + g.mat_row_off[m];
+    mv.count = g.row_count + g.mat_row_off[m];
+    mv.pattern = g.zero_pattern + g.mat_row_off[m];
+    mv.R = g.mat_rows[m];
+    mv.G = g.mat_cols[m];
     return mv;
 }
 
-// ---- stage 1: detection -------------------------------------------------------------------------------------
+// ---- sort key fields (collapseSortKey, common.hpp) -------------------------------------------------------------
+__device__ __forceinline__ uint32_t keyMatrix(const uint64_t key) { return static_cast<uint32_t>(key >> kCollapseMatrixShift); }
+__device__ __forceinline__ uint64_t keySorted(const uint64_t key) { return key >> kCollapseLargestBits; }  // (matrix, projection)
+__device__ __forceinline__ int64_t keyLargest(const uint64_t key) { return static_cast<int64_t>(key & ((1ull << kCollapseLargestBits) - 1)); }
 
-// same_prev[p] = the row at sorted position p is bit for bit the row at p - 1 (same matrix)
-__global__ void collapseSamePrevKernel(const uint64_t total_rows, const uint64_t * __restrict__ sort_key, const uint32_t * __restrict__ sort_row,
-                                       const uint64_t * __restrict__ mat_val_off,
-                                       const uint64_t * __restrict__ mat_row_off, const uint64_t * __restrict__ mat_rows,
-                                       const uint32_t * __restrict__ mat_cols, const double * __restrict__ values,
-                                       const double * __restrict__ row_noise, const double * __restrict__ row_count,
-                                       uint8_t * __restrict__ same_prev) {
-    const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (p >= total_rows) return;
-    uint8_t same = 0;
-    if (p > 0 && sort_key[p] == sort_key[p - 1]) {  // equal keys: nearly always the same row twice; the comparison leaves at the first difference
-        const uint32_t m = static_cast<uint32_t>(sort_key[p] >> kKeyBits);
-        const MatrixView mv = viewOf(m, mat_val_off, mat_row_off, mat_rows, mat_cols, values, row_noise, row_count);
-        const uint64_t r0 = mat_row_off[m];
-        same = rowsIdentical(mv, static_cast<uint32_t>(sort_row[p] - r0), static_cast<uint32_t>(sort_row[p - 1] - r0)) ? 1 : 0;
-    }
-    same_prev[p] = same;
+// |key_a - key_b| <= sum_c w_c |a_c - b_c| < 2 (G + 1) precision for close rows; + rounding of the keys, + 2 quanta
+__device__ __forceinline__ uint64_t windowQuanta(const uint32_t G, const double precision) {
+    const double window = 2.0001 * (G + 1) * precision + 1e-12;
+    return static_cast<uint64_t>(window * static_cast<double>(1ull << kKeyFractionBits)) + 2;
 }
 
-// every row looks at the rows after it whose keys lie within the window; a close pair that is not equal up to
-// rounding (or a window too crowded to look through) flags the matrix
-__global__ void collapseWindowKernel(const uint64_t total_rows, const double precision, const uint64_t * __restrict__ sort_key,
-                                     const uint32_t * __restrict__ sort_row, const uint8_t * __restrict__ same_prev,
-                                     const uint64_t * __restrict__ mat_val_off, const uint64_t * __restrict__ mat_row_off,
-                                     const uint64_t * __restrict__ mat_rows, const uint32_t * __restrict__ mat_cols,
-                                     const double * __restrict__ values, const double * __restrict__ row_noise,
-                                     const double * __restrict__ row_count, uint32_t * __restrict__ mat_flag,
-                                     uint32_t * __restrict__ info) {
+// the largest values of close rows lie within the precision of each other: steps of the key's low field apart
+// (the field wraps: half its range or more means "no filter")
+__device__ __forceinline__ int64_t largestSteps(const double precision) {
+    const double steps = precision * static_cast<double>(1ull << kCollapseLargestFractionBits) + 1.0;
+    return steps >= static_cast<double>(1ull << (kCollapseLargestBits - 1)) ? (1ll << kCollapseLargestBits) : static_cast<int64_t>(steps);
+}
+
+// `other` (at or behind `key` in the sorted order) can be close to `key`'s row
+__device__ __forceinline__ bool inWindow(const uint64_t key, const uint64_t other, const uint64_t window_q, const int64_t largest_steps, bool * beyond) {
+    *beyond = keyMatrix(other) != keyMatrix(key) || keySorted(other) - keySorted(key) > window_q;
+    if (*beyond) return false;
+    int64_t d = (keyLargest(other) - keyLargest(key)) & ((1ll << kCollapseLargestBits) - 1);  // modulo the field
+    if (d >= (1ll << (kCollapseLargestBits - 1))) d -= 1ll << kCollapseLargestBits;
+    return d <= largest_steps && -d <= largest_steps;
+}
+
+// ---- stage 1: close pairs ---------------------------------------------------------------------------------------
+
+struct PairScanArgs {
+    uint64_t total_rows;
+    double precision;
+    const uint64_t * sort_key;   // sorted (matrix, key, largest value)
+    const uint32_t * sort_row;   // position of the row in the row arrays (mat_row_off[m] + row)
+    MatrixArrays g;
+    uint8_t * same_prev;     // [total rows] by sorted position
+    uint32_t * marked_bits;  // [total rows / 32] by row: has a close partner that is not its equal up to rounding
+    uint32_t * marked_list;  // [total rows] sorted positions of the marked rows
+    uint32_t * marked_count;
+    uint32_t * pairs;        // [2 x pair_capacity] candidate pairs (sorted positions) of the scan that runs
+    uint32_t * pair_count;   // its number of pairs
+    uint32_t pair_capacity;
+    uint8_t * active;        // [total rows] by row: marked, or close to a marked row
+    uint32_t * mat_flag;     // [M]
+    uint32_t * info;
+};
+
+// The window scans only collect candidate pairs; the comparisons, each a few dependent rounds of strided loads, then
+// run one per thread, all at once (a thread that walked its window and compared as it went spent ~1 us per step:
+// 0.2-0.4 ms for the longest windows of the batch).
+__device__ __forceinline__ bool appendPair(const PairScanArgs & a, const uint64_t p, const uint64_t q) {
+    const uint32_t slot = atomicAdd(a.pair_count, 1u);
+    if (slot >= a.pair_capacity) return false;
+    a.pairs[2 * static_cast<uint64_t>(slot)] = static_cast<uint32_t>(p);
+    a.pairs[2 * static_cast<uint64_t>(slot) + 1] = static_cast<uint32_t>(q);
+    return true;
+}
+
+// same_prev[p] = the row at sorted position p is bit for bit the row at p - 1 (same matrix)
+__global__ void collapseSamePrevKernel(const PairScanArgs a) {
     const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (p >= total_rows) return;
-    const uint64_t key = sort_key[p];
-    const uint32_t m = static_cast<uint32_t>(key >> kKeyBits);
-    const MatrixView mv = viewOf(m, mat_val_off, mat_row_off, mat_rows, mat_cols, values, row_noise, row_count);
-    // |key_a - key_b| <= sum_c w_c |a_c - b_c| < 2 (G + 1) precision for close rows; + rounding of the keys, + 2 quanta
-    const double window = 2.0001 * (mv.G + 1) * precision + 1e-12;
-    const uint64_t window_q = static_cast<uint64_t>(window * static_cast<double>(1ull << kKeyFractionBits)) + 2;
-    const uint64_t r0 = mat_row_off[m];
-    const uint32_t a = static_cast<uint32_t>(sort_row[p] - r0);
-    uint32_t compares = 0;
-    bool flag = false;
-    for (uint64_t q = p + 1; q < total_rows; ++q) {
-        const uint64_t other = sort_key[q];
-        if ((other >> kKeyBits) != m || other - key > window_q) break;
-        if (q > p + 1 && same_prev[q]) continue;  // bit for bit the candidate before it
-        if (++compares > kMaxWindowCompares) {
-            flag = true;
-            break;
+    if (p >= a.total_rows) return;
+    uint8_t same = 0;
+    if (p > 0 && a.sort_key[p] == a.sort_key[p - 1]) {  // equal keys: nearly always the same values twice; the comparison leaves at the first difference
+        const uint32_t m = keyMatrix(a.sort_key[p]);
+        const MatrixView mv = viewOf(m, a.g);
+        const uint64_t r0 = a.g.mat_row_off[m];
+        same = rowsIdentical(mv, static_cast<uint32_t>(a.sort_row[p] - r0), static_cast<uint32_t>(a.sort_row[p - 1] - r0)) ? 1 : 0;
+    }
+    a.same_prev[p] = same;
+}
+
+// every row lists the rows after it whose keys lie within the window (a window too crowded to list sends the matrix
+// to the full sort)
+__global__ void collapseForwardPairsKernel(const PairScanArgs a) {
+    const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (p + 1 >= a.total_rows) return;
+    const uint64_t key = a.sort_key[p];
+    const uint64_t next = a.sort_key[p + 1];
+    const uint32_t m = keyMatrix(key);
+    if (keyMatrix(next) != m) return;
+    const uint64_t window_q = windowQuanta(a.g.mat_cols[m], a.precision);
+    if (keySorted(next) - keySorted(key) > window_q) return;  // nearly every row leaves here
+    const int64_t largest_steps = largestSteps(a.precision);
+    uint32_t listed = 0;
+    for (uint64_t q = p + 1; q < a.total_rows; ++q) {
+        const uint64_t other = a.sort_key[q];
+        bool beyond;
+        if (!inWindow(key, other, window_q, largest_steps, &beyond)) {
+            if (beyond) break;
+            continue;
         }
-        bool equivalent = true;
-        if (rowsClose(mv, a, static_cast<uint32_t>(sort_row[q] - r0), precision, &equivalent) && !equivalent) {
-            flag = true;
+        if (a.same_prev[q]) continue;  // bit for bit the row before it: this row itself, or a candidate already listed
+        if (++listed > kMaxWindowCompares || !appendPair(a, p, q)) {
+            atomicMax(&a.mat_flag[m], static_cast<uint32_t>(kFlagWholeMatrix));
             break;
         }
     }
-    if (flag && atomicExch(&mat_flag[m], 1u) == 0u) atomicAdd(&info[0], 1u);
+}
+
+// marks the row at sorted position p; the first marker puts it on the list
+__device__ __forceinline__ void markRow(const PairScanArgs & a, const uint64_t p) {
+    const uint32_t row = a.sort_row[p];
+    const uint32_t bit = 1u << (row & 31);
+    if ((atomicOr(&a.marked_bits[row >> 5], bit) & bit) == 0) a.marked_list[atomicAdd(a.marked_count, 1u)] = static_cast<uint32_t>(p);
+}
+
+__device__ __forceinline__ bool isMarked(const PairScanArgs & a, const uint32_t row) { return (a.marked_bits[row >> 5] >> (row & 31)) & 1u; }
+
+// both rows of a close pair that is not equal up to rounding are marked
+__global__ void collapseMarkPairsKernel(const PairScanArgs a) {
+    const uint32_t count = min(*a.pair_count, a.pair_capacity);
+    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
+        const uint64_t p = a.pairs[2 * static_cast<uint64_t>(item)], q = a.pairs[2 * static_cast<uint64_t>(item) + 1];
+        const uint32_t m = keyMatrix(a.sort_key[p]);
+        const MatrixView mv = viewOf(m, a.g);
+        const uint64_t r0 = a.g.mat_row_off[m];
+        bool equivalent = true;
+        if (rowsClose(mv, static_cast<uint32_t>(a.sort_row[p] - r0), static_cast<uint32_t>(a.sort_row[q] - r0), a.precision, &equivalent) && !equivalent) {
+            markRow(a, p);
+            markRow(a, q);
+            // the rows that are this candidate bit for bit are marked with it (a row's own copies list the candidate themselves)
+            for (uint64_t s = q + 1; s < a.total_rows && a.same_prev[s]; ++s) markRow(a, s);
+            atomicMax(&a.mat_flag[m], static_cast<uint32_t>(kFlagActiveRows));
+        }
+    }
+}
+
+// active = marked, or close to a marked row: every marked row (they are few: a list) lists its window, both ways
+__global__ void collapseAroundPairsKernel(const PairScanArgs a) {
+    const uint32_t count = *a.marked_count;
+    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
+        const uint64_t p = a.marked_list[item];
+        a.active[a.sort_row[p]] = 1;
+        const uint64_t key = a.sort_key[p];
+        const uint32_t m = keyMatrix(key);
+        const uint64_t window_q = windowQuanta(a.g.mat_cols[m], a.precision);
+        const int64_t largest_steps = largestSteps(a.precision);
+        uint32_t listed = 0;
+        bool crowded = false;
+        for (int direction = 0; direction < 2 && !crowded; ++direction) {
+            for (uint64_t step = 1; !crowded; ++step) {
+                if (direction == 0 ? p + step >= a.total_rows : step > p) break;
+                const uint64_t q = direction == 0 ? p + step : p - step;
+                const uint64_t other = a.sort_key[q];
+                bool beyond;
+                const bool candidate = direction == 0 ? inWindow(key, other, window_q, largest_steps, &beyond)
+                                                      : inWindow(other, key, window_q, largest_steps, &beyond);
+                if (beyond) break;
+                // bit for bit the position looked at before it (same_prev[] looks towards lower positions): decided with it
+                const bool repeat = direction == 0 ? a.same_prev[q] != 0 : a.same_prev[q + 1] != 0;
+                if (!candidate || repeat || isMarked(a, a.sort_row[q])) continue;
+                if (++listed > kMaxWindowCompares || !appendPair(a, p, q)) crowded = true;
+            }
+        }
+        if (crowded) atomicMax(&a.mat_flag[m], static_cast<uint32_t>(kFlagWholeMatrix));
+    }
+}
+
+__global__ void collapseActivePairsKernel(const PairScanArgs a) {
+    const uint32_t count = min(*a.pair_count, a.pair_capacity);
+    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
+        const uint64_t p = a.pairs[2 * static_cast<uint64_t>(item)], q = a.pairs[2 * static_cast<uint64_t>(item) + 1];
+        const uint32_t m = keyMatrix(a.sort_key[p]);
+        const MatrixView mv = viewOf(m, a.g);
+        const uint64_t r0 = a.g.mat_row_off[m];
+        if (!rowsClose(mv, static_cast<uint32_t>(a.sort_row[p] - r0), static_cast<uint32_t>(a.sort_row[q] - r0), a.precision, nullptr)) continue;
+        a.active[a.sort_row[q]] = 1;  // (several writers, one value)
+        // and the rows that are this one bit for bit, on either side of it
+        for (uint64_t s = q + 1; s < a.total_rows && a.same_prev[s]; ++s) a.active[a.sort_row[s]] = 1;
+        for (uint64_t s = q; s > 0 && a.same_prev[s]; --s) a.active[a.sort_row[s - 1]] = 1;
+    }
 }
 
 // ---- stage 2: replay ------------------------------------------------------------------------------------------
 
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 
-// first index in [begin, end) for which pred holds, `end` if none; block-uniform result
-template <typename Pred>
-__device__ uint64_t blockFirstTrue(const uint64_t begin, const uint64_t end, unsigned long long * shared_min, Pred pred) {
-    for (uint64_t base = begin; base < end; base += blockDim.x) {
-        if (threadIdx.x == 0) *shared_min = end;
-        __syncthreads();
-        const uint64_t q = base + threadIdx.x;
-        if (q < end && pred(q)) atomicMin(shared_min, static_cast<unsigned long long>(q));
-        __syncthreads();
-        const uint64_t found = *shared_min;
-        __syncthreads();
-        if (found < end) return found;
-    }
-    return end;
-}
+struct ReplayArgs {
+    uint32_t num_matrices;
+    double precision;
+    MatrixArrays g;
+    const uint32_t * mat_flag;
+    const uint8_t * active;      // [total rows] by row
+    double * rowmax;
+    uint32_t * mat_fast;
+    uint32_t * mat_mid;
+    uint32_t * mat_list;         // [M] size of the matrix's list (| kWholeMatrixBit: every row), 0: nothing to replay
+    uint32_t * replay_list;      // [M] the matrices with a list, [M]: their number
+    uint32_t * between_items;    // [2 x (total rows / kBetweenRows + M)] (matrix, slice of its rows) of step b
+    uint32_t * between_count;
+    uint32_t * order;            // [2 * total rows] list of matrix m at 2 * mat_row_off[m], sorted
+    uint32_t * head_of;          // [total rows] list position of the run head of every list position
+    uint8_t * close;             // [total rows] list position p is close to p - 1 and nothing lies between them
+    uint8_t * barrier;           // [total rows] an inactive row lies between list positions p - 1 and p
+    uint32_t * pair_column;      // [total rows] column that orders list positions p - 1 and p (kNoRow: not looked at)
+    double * pair_lo;            // [total rows] their values in it, smaller
+    double * pair_hi;            //              and larger
+    uint64_t * pair_pattern;     // [total rows] zero pattern they share before that column
+    uint32_t * info;
+};
 
-__global__ __launch_bounds__(1024) void collapseReplayKernel(
-    const uint32_t num_matrices, const double precision, const uint32_t * __restrict__ mat_flag,
-    const uint64_t * __restrict__ mat_val_off, const uint64_t * __restrict__ mat_row_off, const uint64_t * __restrict__ mat_rows,
-    const uint32_t * __restrict__ mat_cols, double * __restrict__ values, double * __restrict__ row_noise,
-    const double * __restrict__ row_count, double * __restrict__ rowmax, uint32_t * __restrict__ mat_fast, uint32_t * __restrict__ mat_mid,
-    uint32_t * __restrict__ order_scratch,  // [2 * total rows]: sorted row indices of matrix m at 2 * mat_row_off[m]
-    uint32_t * __restrict__ head_scratch,   // [total rows]: sorted position of the run head of every sorted position
-    uint8_t * __restrict__ close_prev,      // [total rows]: sorted position p is close to p - 1
-    uint32_t * __restrict__ info) {
-    __shared__ uint32_t lds_order[kSortLdsRows];
-    __shared__ unsigned long long shared_min;
-    __shared__ uint32_t demote;
+// a. the list of a matrix — its active rows, or all of them — sorted with the reference's comparator, and for every
+// pair of neighbours the column that orders them
+__global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayArgs a) {
+    __shared__ uint32_t lds_list[kListLdsRows];
+    __shared__ uint64_t lds_pattern[kListLdsRows];  // zero pattern of the row at each list position (LDS lists)
+    __shared__ uint32_t list_size;
     const uint32_t m = blockIdx.x;
-    if (m >= num_matrices || !mat_flag[m]) return;
-    const MatrixView mv = viewOf(m, mat_val_off, mat_row_off, mat_rows, mat_cols, values, row_noise, row_count);
+    if (m >= a.num_matrices) return;
+    const uint32_t flag = a.mat_flag[m];
+    if (flag == kFlagNone) {
+        if (threadIdx.x == 0) a.mat_list[m] = 0;
+        return;
+    }
+    const MatrixView mv = viewOf(m, a.g);
     const uint64_t R = mv.R;
-    if (R < 2) return;
-    uint64_t padded = 1;
-    while (padded < R) padded <<= 1;
-    uint32_t * order = padded <= kSortLdsRows ? lds_order : order_scratch + 2 * mat_row_off[m];
-    if (threadIdx.x == 0) demote = 0;
-    for (uint64_t i = threadIdx.x; i < padded; i += blockDim.x) order[i] = i < R ? static_cast<uint32_t>(i) : kNoRow;
+    const uint64_t r0 = a.g.mat_row_off[m];
+    const uint8_t * active = a.active + r0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, num_waves = blockDim.x >> 6;
+    if (threadIdx.x == 0) list_size = 0;
     __syncthreads();
-    // bitonic network; kNoRow sorts behind every row
+    bool whole = flag == kFlagWholeMatrix;
+    if (!whole) {
+        for (uint64_t i = threadIdx.x; i < R; i += blockDim.x) {
+            if (active[i]) {
+                const uint32_t slot = atomicAdd(&list_size, 1u);
+                if (slot < kListLdsRows) lds_list[slot] = static_cast<uint32_t>(i);
+            }
+        }
+        __syncthreads();
+        if (list_size > kListLdsRows) whole = true;
+    }
+    const uint64_t n = whole ? R : list_size;
+    if (n < 2) {
+        if (threadIdx.x == 0) a.mat_list[m] = 0;
+        return;
+    }
+    uint64_t padded = 1;
+    while (padded < n) padded <<= 1;
+    uint32_t * global_order = a.order + 2 * r0;
+    uint32_t * order = padded <= kListLdsRows ? lds_list : global_order;
+    __syncthreads();
+    if (whole) {
+        for (uint64_t i = threadIdx.x; i < padded; i += blockDim.x) order[i] = i < R ? static_cast<uint32_t>(i) : kNoRow;
+    } else {
+        for (uint64_t i = n + threadIdx.x; i < padded; i += blockDim.x) order[i] = kNoRow;
+    }
+    const bool in_lds = order == lds_list;
+    if (in_lds) {
+        for (uint64_t i = threadIdx.x; i < padded; i += blockDim.x) lds_pattern[i] = order[i] == kNoRow ? 0ull : mv.pattern[order[i]];
+    }
+    if (threadIdx.x == 0) {
+        a.mat_list[m] = static_cast<uint32_t>(n) | (whole ? kWholeMatrixBit : 0u);
+        a.replay_list[atomicAdd(&a.replay_list[a.num_matrices], 1u)] = m;
+        if (!whole) {  // work items of step b: (matrix, slice of kBetweenRows rows)
+            const uint32_t slices = static_cast<uint32_t>((R + kBetweenRows - 1) / kBetweenRows);
+            const uint32_t first = atomicAdd(a.between_count, slices);
+            for (uint32_t k = 0; k < slices; ++k) {
+                a.between_items[2 * static_cast<uint64_t>(first + k)] = m;
+                a.between_items[2 * static_cast<uint64_t>(first + k) + 1] = k;
+            }
+        }
+        atomicAdd(&a.info[kInfoMatrices], 1u);
+        atomicAdd(&a.info[kInfoActiveRows], static_cast<uint32_t>(n));
+        if (whole) atomicAdd(&a.info[kInfoWholeMatrices], 1u);
+    }
+    __syncthreads();
+    // bitonic network with the reference's comparator; kNoRow sorts behind every row
     for (uint64_t k = 2; k <= padded; k <<= 1) {
         for (uint64_t j = k >> 1; j > 0; j >>= 1) {
             for (uint64_t t = threadIdx.x; t < (padded >> 1); t += blockDim.x) {
                 const uint64_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // bit j of i is clear
                 const uint64_t l = i | j;
-                const uint32_t a = order[i], b = order[l];
+                const uint32_t x = order[i], y = order[l];
                 const bool ascending = (i & k) == 0;
                 bool swap;
-                if (a == kNoRow || b == kNoRow) {
-                    swap = ascending ? (a == kNoRow && b != kNoRow) : (b == kNoRow && a != kNoRow);
+                if (x == kNoRow || y == kNoRow) {
+                    swap = ascending ? (x == kNoRow && y != kNoRow) : (y == kNoRow && x != kNoRow);
                 } else {
-                    swap = ascending ? rowLess(mv, b, a) : rowLess(mv, a, b);
+                    const uint64_t px = in_lds ? lds_pattern[i] : mv.pattern[x], py = in_lds ? lds_pattern[l] : mv.pattern[y];
+                    swap = ascending ? rowLess(mv, y, x, py, px) : rowLess(mv, x, y, px, py);
                 }
                 if (swap) {
-                    order[i] = b;
-                    order[l] = a;
+                    order[i] = y;
+                    order[l] = x;
+                    if (in_lds) {
+                        const uint64_t px = lds_pattern[i];
+                        lds_pattern[i] = lds_pattern[l];
+                        lds_pattern[l] = px;
+                    }
                 }
             }
             __syncthreads();
         }
     }
-    uint32_t * head_of = head_scratch + mat_row_off[m];
-    uint8_t * close = close_prev + mat_row_off[m];
-    for (uint64_t p = threadIdx.x; p < R; p += blockDim.x) {
-        head_of[p] = static_cast<uint32_t>(p);
-        close[p] = (p > 0 && rowsClose(mv, order[p - 1], order[p], precision, nullptr)) ? 1 : 0;
+    if (order != global_order) {
+        for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) global_order[i] = order[i];
     }
-    __syncthreads();
-    // Runs (src/path_estimator.cpp:226-255): a row joins the run of the current head if it is close to the head,
-    // otherwise it becomes the head.  A row whose predecessor is a head of its own is decided by close[]; the rows
-    // after a join are compared with the head, a block-wide chunk at a time.
-    uint64_t p = 1;
-    while (p < R) {
-        const uint64_t joiner = blockFirstTrue(p, R, &shared_min, [&](const uint64_t q) { return close[q] != 0; });
-        if (joiner >= R) break;
-        const uint64_t head = joiner - 1;  // every row in [p, joiner) is a head; so is joiner - 1 (p - 1 is one)
-        const uint32_t head_row = order[head];
-        const uint64_t next_head = blockFirstTrue(joiner, R, &shared_min, [&](const uint64_t q) {
-            return !rowsClose(mv, head_row, order[q], precision, nullptr);
-        });
-        for (uint64_t q = joiner + threadIdx.x; q < next_head; q += blockDim.x) head_of[q] = static_cast<uint32_t>(head);
-        p = next_head + 1;  // next_head heads a run of its own; close[next_head + 1] compares with it
+    uint8_t * barrier = a.barrier + r0;
+    for (uint64_t p = threadIdx.x; p < n; p += blockDim.x) barrier[p] = 0;
+    if (whole) return;
+    // One wave per pair of neighbours: d, the first column in which they differ, and the interval between them in it.
+    // A row x with a <= x <= b in the reference's order equals both up to rounding before column d and lies between
+    // them in column d.  A row that joins a run is within prob_precision of a head its predecessor is within
+    // prob_precision of (or the predecessor is that head): only neighbours that close can be parted by a row.
+    uint32_t * pair_column = a.pair_column + r0;
+    for (uint64_t p = 1 + wave; p < n; p += num_waves) {
+        const uint32_t x = order[p - 1], y = order[p];
+        uint32_t d = mv.G + 1;
+        bool can_join = true;
+        for (uint32_t c0 = 0; c0 <= mv.G; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            const double vx = c <= mv.G ? mv.at(c, x) : 0.0, vy = c <= mv.G ? mv.at(c, y) : 0.0;
+            if (__ballot(fabs(vx - vy) >= 2 * a.precision)) can_join = false;
+            const unsigned long long differs = __ballot(c <= mv.G && !tolerantEqual(vx, vy));
+            if (differs && d > mv.G) d = c0 + static_cast<uint32_t>(__ffsll(static_cast<long long>(differs)) - 1);
+        }
+        if (lane == 0) {
+            const bool look = can_join && d <= mv.G;  // (equal in every column: whatever lies between them is their equal, too)
+            pair_column[p] = look ? d : kNoRow;
+            if (look) {
+                const double vx = mv.at(d, x), vy = mv.at(d, y);
+                a.pair_lo[r0 + p] = fmin(vx, vy);
+                a.pair_hi[r0 + p] = fmax(vx, vy);
+                a.pair_pattern[r0 + p] = mv.pattern[x] & (d >= 64 ? ~0ull : (1ull << d) - 1ull);
+            }
+        }
+    }
+}
+
+// b. inactive rows between neighbours of the lists: work item = (matrix with a list, slice of its rows)
+__global__ __launch_bounds__(kBetweenThreads) void collapseBetweenKernel(const ReplayArgs a) {
+    __shared__ uint32_t lds_column[kPairChunk];
+    __shared__ double lds_lo[kPairChunk], lds_hi[kPairChunk];
+    __shared__ uint64_t lds_pattern[kPairChunk], lds_before[kPairChunk];
+    const uint32_t num_items = *a.between_count;
+    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
+        const uint32_t m = a.between_items[2 * static_cast<uint64_t>(item)], slice = a.between_items[2 * static_cast<uint64_t>(item) + 1];
+        const uint64_t n = a.mat_list[m];  // (not a whole matrix: those have no items)
+        const MatrixView mv = viewOf(m, a.g);
+        const uint64_t r0 = a.g.mat_row_off[m];
+        const uint8_t * active = a.active + r0;
+        const uint32_t * order = a.order + 2 * r0;
+        for (uint64_t p0 = 1; p0 < n; p0 += kPairChunk) {
+            const uint32_t chunk = static_cast<uint32_t>(min(static_cast<uint64_t>(kPairChunk), n - p0));
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < chunk; k += blockDim.x) {
+                const uint32_t d = a.pair_column[r0 + p0 + k];
+                lds_column[k] = d;
+                if (d != kNoRow) {
+                    lds_lo[k] = a.pair_lo[r0 + p0 + k];
+                    lds_hi[k] = a.pair_hi[r0 + p0 + k];
+                    lds_pattern[k] = a.pair_pattern[r0 + p0 + k];
+                    lds_before[k] = d >= 64 ? ~0ull : (1ull << d) - 1ull;
+                }
+            }
+            __syncthreads();
+            const uint64_t x_end = min(mv.R, (slice + 1ull) * kBetweenRows);
+            for (uint64_t x = slice * static_cast<uint64_t>(kBetweenRows) + threadIdx.x; x < x_end; x += blockDim.x) {
+                if (active[x]) continue;
+                const uint64_t pattern_x = mv.pattern[x];
+                uint32_t loaded_column = kNoRow;
+                double vx = 0.0;
+                for (uint32_t k = 0; k < chunk; ++k) {
+                    const uint32_t d = lds_column[k];
+                    if (d == kNoRow || (pattern_x & lds_before[k]) != lds_pattern[k]) continue;
+                    if (d != loaded_column) {
+                        vx = mv.at(d, static_cast<uint32_t>(x));
+                        loaded_column = d;
+                    }
+                    const double lo = lds_lo[k], hi = lds_hi[k];
+                    if (!((vx >= lo || tolerantEqual(vx, lo)) && (vx <= hi || tolerantEqual(vx, hi)))) continue;
+                    const uint64_t p = p0 + k;
+                    if (!rowLess(mv, static_cast<uint32_t>(x), order[p - 1]) && !rowLess(mv, order[p], static_cast<uint32_t>(x))) a.barrier[r0 + p] = 1;
+                }
+            }
+        }
+    }
+}
+
+// c. runs and values: work item = matrix with a list
+__global__ __launch_bounds__(kSortThreads) void collapseRunsKernel(const ReplayArgs a) {
+    __shared__ uint32_t lds_next[kListLdsRows];
+    __shared__ uint32_t demote;
+    const uint32_t num_items = a.replay_list[a.num_matrices];
+    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
+        const uint32_t m = a.replay_list[item];
+        const uint64_t n = a.mat_list[m] & ~kWholeMatrixBit;
+        const MatrixView mv = viewOf(m, a.g);
+        const uint64_t R = mv.R;
+        const uint64_t r0 = a.g.mat_row_off[m];
+        const uint32_t * order = a.order + 2 * r0;
+        uint32_t * head_of = a.head_of + r0;
+        uint32_t * next_head = n <= kListLdsRows ? lds_next : a.pair_column + r0;  // (the pair columns are done with)
+        uint8_t * close = a.close + r0;
+        const uint8_t * barrier = a.barrier + r0;
         __syncthreads();
-    }
-    __syncthreads();
-    // the rows of a run take the values of its head
-    double * M = values + mat_val_off[m];
-    double * nz = row_noise + mat_row_off[m];
-    double * rm = rowmax + mat_row_off[m];
-    const uint32_t fast_mid_end = mat_mid[m];
-    uint32_t replaced = 0;
-    for (uint64_t q = threadIdx.x; q < R; q += blockDim.x) {
-        const uint32_t h = head_of[q];
-        if (h == q) continue;
-        const uint32_t dst = order[q], src = order[h];
-        for (uint32_t c = 0; c < mv.G; ++c) M[static_cast<uint64_t>(c) * R + dst] = M[static_cast<uint64_t>(c) * R + src];
-        const double noise = nz[src];
-        nz[dst] = noise;
-        rm[dst] = rm[src];
-        ++replaced;
-        // a product-path row (LogProduct, common.hpp) needs noise >= kProductMinNoise: if the head's is below, the
-        // whole matrix takes the logarithm path
-        if (dst < fast_mid_end && !(noise >= kProductMinNoise)) demote = 1;
-    }
-    if (replaced) atomicAdd(&info[1], replaced);
-    __syncthreads();
-    if (threadIdx.x == 0 && demote) {
-        mat_fast[m] = 0;
-        mat_mid[m] = 0;
+        if (threadIdx.x == 0) demote = 0;
+        for (uint64_t p = threadIdx.x; p < n; p += blockDim.x) {
+            head_of[p] = kNoRow;
+            close[p] = (p > 0 && !barrier[p] && rowsClose(mv, order[p - 1], order[p], a.precision, nullptr)) ? 1 : 0;
+        }
+        __syncthreads();
+        // Runs (src/path_estimator.cpp:226-255): a row joins the run of the current head if it is close to the head,
+        // otherwise it becomes the head.  Every list position answers "if I were a head, where would the next one be"
+        // on its own (the first position behind it that an inactive row parts from it or that is not close to it);
+        // one thread then walks from head to head, and every head claims its run.
+        // (a wave per position that has a follower: its lanes compare 64 positions with it at once)
+        for (uint64_t h = threadIdx.x; h < n; h += blockDim.x) {
+            if (h + 1 >= n || !close[h + 1]) next_head[h] = static_cast<uint32_t>(h + 1);
+        }
+        const int lane = threadIdx.x & 63;
+        for (uint64_t h = threadIdx.x >> 6; h + 1 < n; h += blockDim.x >> 6) {
+            if (!close[h + 1]) continue;
+            const uint32_t head_row = order[h];
+            uint64_t q0 = h + 2, found = n;
+            while (q0 < n && found == n) {
+                const uint64_t q = q0 + lane;
+                const bool stop = q < n && (barrier[q] != 0 || !rowsClose(mv, head_row, order[q], a.precision, nullptr));
+                const unsigned long long ballot = __ballot(stop);
+                if (ballot) found = q0 + static_cast<uint64_t>(__ffsll(static_cast<long long>(ballot)) - 1);
+                q0 += 64;
+            }
+            if (lane == 0) next_head[h] = static_cast<uint32_t>(found);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (uint64_t h = 0; h < n; h = next_head[h]) head_of[h] = static_cast<uint32_t>(h);
+        }
+        __syncthreads();
+        for (uint64_t h = threadIdx.x; h < n; h += blockDim.x) {
+            if (head_of[h] != h) continue;
+            for (uint64_t q = h + 1; q < next_head[h]; ++q) head_of[q] = static_cast<uint32_t>(h);
+        }
+        __syncthreads();
+        // the rows of a run take the values of its head
+        double * M = a.g.values + a.g.mat_val_off[m];
+        double * nz = a.g.row_noise + r0;
+        double * rm = a.rowmax + r0;
+        const uint32_t fast_mid_end = a.mat_mid[m];
+        uint32_t replaced = 0;
+        for (uint64_t q = threadIdx.x; q < n; q += blockDim.x) {
+            const uint32_t h = head_of[q];
+            if (h == q) continue;
+            const uint32_t dst = order[q], src = order[h];
+            for (uint32_t c = 0; c < mv.G; ++c) M[static_cast<uint64_t>(c) * R + dst] = M[static_cast<uint64_t>(c) * R + src];
+            const double noise = nz[src];
+            nz[dst] = noise;
+            rm[dst] = rm[src];
+            ++replaced;
+            // a product-path row (LogProduct, common.hpp) needs noise >= kProductMinNoise: if the head's is below, the
+            // whole matrix takes the logarithm path
+            if (dst < fast_mid_end && !(noise >= kProductMinNoise)) demote = 1;
+        }
+        if (replaced) atomicAdd(&a.info[kInfoRowsReplaced], replaced);
+        __syncthreads();
+        if (threadIdx.x == 0 && demote) {
+            a.mat_fast[m] = 0;
+            a.mat_mid[m] = 0;
+        }
     }
 }
 
@@ -279,64 +650,126 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     (void) ctx;
     const uint32_t M = g->num_matrices;
     if (M == 0 || total_rows == 0) return hipSuccess;
-    if (total_rows > 0x7fffffffull || (static_cast<uint64_t>(M) >> (64 - kKeyBits)) != 0) return hipErrorInvalidValue;
+    if (total_rows > 0x7fffffffull || M > kCollapseMaxMatrices) return hipErrorInvalidValue;
     struct CollapseTemporaries {
-        DeviceBuffer<uint64_t> key_out;
-        DeviceBuffer<uint32_t> row_out, mat_flag, order, head;
-        DeviceBuffer<uint8_t> same_prev, close_prev;
+        DeviceBuffer<uint64_t> key_out, pair_pattern;
+        DeviceBuffer<uint32_t> row_out, words, order, head, pair_column, marked_list, pairs, between_items;
+        DeviceBuffer<double> pair_bound;
+        DeviceBuffer<uint8_t> bytes;  // same_prev, active, close, barrier: total_rows each
         DeviceBuffer<unsigned char> sort_tmp;
     };
     std::shared_ptr<CollapseTemporaries> tmp = std::make_shared<CollapseTemporaries>();
     g->build_temporaries.emplace_back(tmp);
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    // zeroed words: matrix flags [M], replay list [M] + its count, marked bits + the marked list's count, the two pair counts
+    const uint64_t mark_words = (total_rows + 31) / 32;
+    const uint64_t num_words = 2 * static_cast<uint64_t>(M) + 1 + mark_words + 1 + 2 + 1;  // (+ the number of between items)
+    const uint32_t pair_capacity = static_cast<uint32_t>(total_rows / 2 + 4096);
     ok(tmp->key_out.alloc(total_rows));
     ok(tmp->row_out.alloc(total_rows));
-    ok(tmp->mat_flag.alloc(M));
+    ok(tmp->words.alloc(num_words + M));  // + list sizes [M] (written by the sort kernel)
     ok(tmp->order.alloc(2 * total_rows));
     ok(tmp->head.alloc(total_rows));
-    ok(tmp->same_prev.alloc(total_rows));
-    ok(tmp->close_prev.alloc(total_rows));
-    ok(g->collapse_info.alloc(2));
+    ok(tmp->pair_column.alloc(total_rows));
+    ok(tmp->pair_bound.alloc(2 * total_rows));
+    ok(tmp->pair_pattern.alloc(total_rows));
+    ok(tmp->marked_list.alloc(total_rows));
+    ok(tmp->pairs.alloc(2 * static_cast<size_t>(pair_capacity)));
+    ok(tmp->between_items.alloc(2 * (total_rows / kBetweenRows + M)));
+    ok(tmp->bytes.alloc(4 * total_rows));
+    ok(g->collapse_info.alloc(kInfoWords));
     int matrix_bits = 1;
     while ((1ull << matrix_bits) < M) ++matrix_bits;
-    const int end_bit = kKeyBits + matrix_bits;
+    const int begin_bit = kCollapseLargestBits, end_bit = kCollapseMatrixShift + matrix_bits;  // (matrix, projection)
     size_t sort_bytes = 0;
     if (e == hipSuccess) ok(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, g->collapse_key.ptr, tmp->key_out.ptr, g->collapse_row.ptr, tmp->row_out.ptr,
-                                                               static_cast<int>(total_rows), 0, end_bit, st));
+                                                               static_cast<int>(total_rows), begin_bit, end_bit, st));
     ok(tmp->sort_tmp.alloc(sort_bytes));
     if (e != hipSuccess) return e;
-    ok(hipMemsetAsync(tmp->mat_flag.ptr, 0, M * sizeof(uint32_t), st));
-    ok(hipMemsetAsync(g->collapse_info.ptr, 0, 2 * sizeof(uint32_t), st));
-    const uint32_t row_blocks = static_cast<uint32_t>((total_rows + 255) / 256);
+    uint32_t * mat_flag = tmp->words.ptr, * replay_list = mat_flag + M, * marked_bits = replay_list + M + 1,
+             * marked_count = marked_bits + mark_words, * pair_counts = marked_count + 1, * between_count = pair_counts + 2,
+             * mat_list = between_count + 1;
+    uint8_t * same_prev = tmp->bytes.ptr, * active = same_prev + total_rows, * close = active + total_rows, * barrier = close + total_rows;
+    ok(hipMemsetAsync(tmp->words.ptr, 0, num_words * sizeof(uint32_t), st));
+    ok(hipMemsetAsync(g->collapse_info.ptr, 0, kInfoWords * sizeof(uint32_t), st));
+    ok(hipMemsetAsync(active, 0, total_rows, st));
     ok(hipcub::DeviceRadixSort::SortPairs(tmp->sort_tmp.ptr, sort_bytes, g->collapse_key.ptr, tmp->key_out.ptr, g->collapse_row.ptr, tmp->row_out.ptr,
-                                          static_cast<int>(total_rows), 0, end_bit, st));
-    collapseSamePrevKernel<<<dim3(row_blocks), dim3(256), 0, st>>>(total_rows, tmp->key_out.ptr, tmp->row_out.ptr, g->mat_val_off.ptr,
-                                                                 g->mat_row_off.ptr, g->mat_rows.ptr, g->mat_cols.ptr, g->values.ptr,
-                                                                 g->row_noise.ptr, g->row_count.ptr, tmp->same_prev.ptr);
-    collapseWindowKernel<<<dim3(row_blocks), dim3(256), 0, st>>>(total_rows, precision, tmp->key_out.ptr, tmp->row_out.ptr, tmp->same_prev.ptr,
-                                                               g->mat_val_off.ptr, g->mat_row_off.ptr, g->mat_rows.ptr, g->mat_cols.ptr,
-                                                               g->values.ptr, g->row_noise.ptr, g->row_count.ptr, tmp->mat_flag.ptr,
-                                                               g->collapse_info.ptr);
-    collapseReplayKernel<<<dim3(M), dim3(1024), 0, st>>>(M, precision, tmp->mat_flag.ptr, g->mat_val_off.ptr, g->mat_row_off.ptr, g->mat_rows.ptr,
-                                                        g->mat_cols.ptr, g->values.ptr, g->row_noise.ptr, g->row_count.ptr, g->rowmax.ptr,
-                                                        g->mat_fast.ptr, g->mat_mid.ptr, tmp->order.ptr, tmp->head.ptr, tmp->close_prev.ptr,
-                                                        g->collapse_info.ptr);
+                                          static_cast<int>(total_rows), begin_bit, end_bit, st));
+    MatrixArrays arrays;
+    arrays.mat_val_off = g->mat_val_off.ptr;
+    arrays.mat_row_off = g->mat_row_off.ptr;
+    arrays.mat_rows = g->mat_rows.ptr;
+    arrays.mat_cols = g->mat_cols.ptr;
+    arrays.values = g->values.ptr;
+    arrays.row_noise = g->row_noise.ptr;
+    arrays.row_count = g->row_count.ptr;
+    arrays.zero_pattern = g->collapse_mask.ptr;
+    PairScanArgs a;
+    a.total_rows = total_rows;
+    a.precision = precision;
+    a.sort_key = tmp->key_out.ptr;
+    a.sort_row = tmp->row_out.ptr;
+    a.g = arrays;
+    a.same_prev = same_prev;
+    a.marked_bits = marked_bits;
+    a.marked_list = tmp->marked_list.ptr;
+    a.marked_count = marked_count;
+    a.pairs = tmp->pairs.ptr;
+    a.pair_count = pair_counts;
+    a.pair_capacity = pair_capacity;
+    a.active = active;
+    a.mat_flag = mat_flag;
+    a.info = g->collapse_info.ptr;
+    const uint32_t row_blocks = static_cast<uint32_t>((total_rows + 255) / 256);
+    collapseSamePrevKernel<<<dim3(row_blocks), dim3(256), 0, st>>>(a);
+    collapseForwardPairsKernel<<<dim3(row_blocks), dim3(256), 0, st>>>(a);
+    collapseMarkPairsKernel<<<dim3(1024), dim3(64), 0, st>>>(a);
+    a.pair_count = pair_counts + 1;  // the list is free again
+    collapseAroundPairsKernel<<<dim3(256), dim3(64), 0, st>>>(a);
+    collapseActivePairsKernel<<<dim3(1024), dim3(64), 0, st>>>(a);
+    ReplayArgs r;
+    r.num_matrices = M;
+    r.precision = precision;
+    r.g = arrays;
+    r.mat_flag = mat_flag;
+    r.active = active;
+    r.rowmax = g->rowmax.ptr;
+    r.mat_fast = g->mat_fast.ptr;
+    r.mat_mid = g->mat_mid.ptr;
+    r.mat_list = mat_list;
+    r.replay_list = replay_list;
+    r.between_items = tmp->between_items.ptr;
+    r.between_count = between_count;
+    r.order = tmp->order.ptr;
+    r.head_of = tmp->head.ptr;
+    r.close = close;
+    r.barrier = barrier;
+    r.pair_column = tmp->pair_column.ptr;
+    r.pair_lo = tmp->pair_bound.ptr;
+    r.pair_hi = tmp->pair_bound.ptr + total_rows;
+    r.pair_pattern = tmp->pair_pattern.ptr;
+    r.info = g->collapse_info.ptr;
+    collapseSortKernel<<<dim3(M), dim3(kSortThreads), 0, st>>>(r);
+    collapseBetweenKernel<<<dim3(2048), dim3(kBetweenThreads), 0, st>>>(r);
+    collapseRunsKernel<<<dim3(512), dim3(kSortThreads), 0, st>>>(r);
     ok(hipGetLastError());
     return e;
 }
 
 extern "C" int rpvg_hip_groups_collapse_info(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, uint32_t * matrices_replayed,
-                                             uint32_t * rows_replaced) {
+                                             uint32_t * rows_replaced, uint32_t * matrices_sorted_whole, uint32_t * active_rows) {
     RPVG_REQUIRE(ctx && groups, "rpvg_hip_groups_collapse_info: NULL argument");
-    uint32_t info[2] = {0, 0};
+    uint32_t info[kInfoWords] = {0};
     if (groups->collapse_info.ptr) {
         std::lock_guard<std::mutex> lock(ctx->mutex);
         RPVG_HIP_CHECK(hipSetDevice(ctx->device));
         RPVG_HIP_CHECK(hipMemcpyAsync(info, groups->collapse_info.ptr, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
         RPVG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
-    if (matrices_replayed) *matrices_replayed = info[0];
-    if (rows_replaced) *rows_replaced = info[1];
+    if (matrices_replayed) *matrices_replayed = info[kInfoMatrices];
+    if (rows_replaced) *rows_replaced = info[kInfoRowsReplaced];
+    if (matrices_sorted_whole) *matrices_sorted_whole = info[kInfoWholeMatrices];
+    if (active_rows) *active_rows = info[kInfoActiveRows];
     return RPVG_HIP_OK;
 }

@@ -207,11 +207,12 @@ class DeviceGroups:
                "rpvg_hip_groups_build")
 
     def collapse_info(self):
-        """(matrices sorted and collapsed as the reference does, rows that took the values of their run head)."""
-        replayed, replaced = C.c_uint32(0), C.c_uint32(0)
-        _check(lib().rpvg_hip_groups_collapse_info(self.ctx.handle, self.handle, C.byref(replayed), C.byref(replaced)),
+        """(matrices whose runs were replayed, rows that took the values of their run head, matrices sorted as a
+        whole, rows that took part in a replay)."""
+        out = [C.c_uint32(0) for _ in range(4)]
+        _check(lib().rpvg_hip_groups_collapse_info(self.ctx.handle, self.handle, *[C.byref(x) for x in out]),
                "rpvg_hip_groups_collapse_info")
-        return int(replayed.value), int(replaced.value)
+        return tuple(int(x.value) for x in out)
 
     def loglik(self, matrix, members, divisor: float, add_rowmax=None) -> np.ndarray:
         mt = np.ascontiguousarray(matrix, dtype=np.uint32)

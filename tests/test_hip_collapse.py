@@ -54,8 +54,8 @@ def test_collapsed_group_matrices_match_numpy(hip_ctx, seed):
     dev = hip_ctx.upload(batch)
     groups = [np_oracle.source_groups(cl["paths"])[0] for cl in clusters]
     dg = hip_ctx.groups(dev, list(range(len(clusters))), groups, True, collapse_precision=1e-8)
-    replayed, replaced = dg.collapse_info()
-    assert replayed > 0 and replaced > 0  # the planted rows reach the sorted replay
+    replayed, replaced, whole, active = dg.collapse_info()
+    assert replayed > 0 and replaced > 0 and whole == 0 and active >= replaced  # the planted rows reach the replay
     moved = 0
     for m, (cl, g) in enumerate(zip(clusters, groups)):
         (M0, n0, c0), (M1, n1, c1) = _collapsed_logliks(cl, g, 1e-8)
