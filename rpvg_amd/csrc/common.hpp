@@ -60,18 +60,43 @@ hipError_t poolAlloc(void ** ptr, size_t bytes);
 void poolFree(void * ptr);
 void poolTrim(int device);
 
+// ---- pinned staging memory -----------------------------------------------------
+// hipMemcpyAsync from pageable host memory is not asynchronous: the runtime stages it through its own pinned buffer
+// and the calling thread waits for the copy — behind whatever the GPU is busy with (a second host lane was seen
+// blocked for 1-2 ms per batch in the uploads of a few megabytes of column lists while the first lane's kernels ran).
+// Uploads therefore go through pinned blocks of the library's own (cached by size class like the device blocks,
+// hipHostMalloc costs milliseconds): memcpy into the block, hipMemcpyAsync from it, and the block lives as long as the
+// device buffer it filled.  RPVG_HIP_PAGEABLE_UPLOADS=1 restores the direct copies (A/B).
+hipError_t pinnedAlloc(void ** ptr, size_t bytes);
+void pinnedFree(void * ptr);
+void pinnedTrim();
+bool stagedUploads();
+// An upload does not depend on the kernels queued before it on its stream (it fills a fresh block with host data), but
+// queued on that stream it would wait for them: the search's inputs sat behind the build of the matrices, ~0.5-0.9 ms
+// per batch on the critical path.  Every context owns a copy stream; a staged upload "on" one of the context's streams
+// runs on the copy stream and the stream waits for it (event), so it overlaps the kernels in front of it.
+// (Blocks come from the pool only after the work that used them has been waited for — the rule the stream-unaware
+// pool rests on anyway.)  Measured slower than uploads on their own streams (see stagedCopy): RPVG_HIP_COPY_STREAM=1
+// turns it on.
+void registerCopyStream(hipStream_t stream, hipStream_t copy_stream, hipEvent_t copied);
+void forgetCopyStream(hipStream_t stream);
+hipError_t stagedCopy(void * device_dst, const void * pinned_src, size_t bytes, hipStream_t stream);
+
 // ---- device buffer (owning) -------------------------------------------------
 template <typename T>
 struct DeviceBuffer {
     T * ptr = nullptr;
     size_t count = 0;
+    void * staging = nullptr;  // pinned block the last upload went through
     DeviceBuffer() {}
     DeviceBuffer(const DeviceBuffer &) = delete;
     DeviceBuffer & operator=(const DeviceBuffer &) = delete;
     ~DeviceBuffer() { release(); }
     void release() {
         if (ptr) poolFree(ptr);
+        if (staging) pinnedFree(staging);
         ptr = nullptr;
+        staging = nullptr;
         count = 0;
     }
     hipError_t alloc(size_t n) {
@@ -83,6 +108,11 @@ struct DeviceBuffer {
     hipError_t upload(const T * host, size_t n, hipStream_t stream) {
         hipError_t e = alloc(n);
         if (e != hipSuccess || n == 0) return e;
+        if (stagedUploads() && pinnedAlloc(&staging, n * sizeof(T)) == hipSuccess) {
+            std::memcpy(staging, host, n * sizeof(T));
+            return stagedCopy(ptr, staging, n * sizeof(T), stream);
+        }
+        staging = nullptr;
         return hipMemcpyAsync(ptr, host, n * sizeof(T), hipMemcpyHostToDevice, stream);
     }
     hipError_t download(T * host, hipStream_t stream) const {
@@ -406,6 +436,8 @@ struct rpvg_hip_ctx {
     // overlap instead of adding up.  forkAux() makes them wait for the work queued on `stream` so far,
     // joinAux() makes `stream` wait for them.
     hipStream_t aux[kAuxStreams] = {};
+    hipStream_t copy_stream = nullptr;  // staged uploads (stagedCopy)
+    hipEvent_t copied = nullptr;
     hipEvent_t fork_event = nullptr;
     hipEvent_t search_done = nullptr;  // recorded behind the kernels of this context's last pair search (bounded_search.hip)
     hipEvent_t join_event[kAuxStreams] = {};
@@ -478,6 +510,7 @@ struct rpvg_hip_groups {
     rpvg_hip_detail::DeviceBuffer<uint64_t> collapse_key;  // [sum R_m]
     rpvg_hip_detail::DeviceBuffer<uint32_t> collapse_row;  // [sum R_m]
     rpvg_hip_detail::DeviceBuffer<uint64_t> collapse_mask; // [sum R_m] zero pattern of the first 64 columns
+    rpvg_hip_detail::DeviceBuffer<uint32_t> collapse_segment_off;  // [M + 1] mat_row_off as 32-bit segment offsets
     rpvg_hip_detail::DeviceBuffer<uint32_t> collapse_info;
     mutable bool build_checked = false;
     // RPVG_HIP_OK, or the error of the build (after a sync of `stream`); consumers call it before trusting results

@@ -98,6 +98,94 @@ void poolTrim(int device) {
 }
 
 namespace {
+std::mutex g_pinned_mutex;
+std::map<size_t, std::vector<void *>> g_pinned_free;  // size class -> cached blocks
+std::map<void *, size_t> g_pinned_live;
+}  // namespace
+
+hipError_t pinnedAlloc(void ** ptr, size_t bytes) {
+    const size_t cls = sizeClass(bytes);
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        auto it = g_pinned_free.find(cls);
+        if (it != g_pinned_free.end() && !it->second.empty()) {
+            *ptr = it->second.back();
+            it->second.pop_back();
+            g_pinned_live[*ptr] = cls;
+            return hipSuccess;
+        }
+    }
+    const hipError_t e = hipHostMalloc(ptr, cls, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void) hipGetLastError();
+        *ptr = nullptr;
+        return e;
+    }
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    g_pinned_live[*ptr] = cls;
+    return hipSuccess;
+}
+
+void pinnedFree(void * ptr) {
+    if (!ptr) return;
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    auto it = g_pinned_live.find(ptr);
+    if (it == g_pinned_live.end()) return;
+    g_pinned_free[it->second].push_back(ptr);
+    g_pinned_live.erase(it);
+}
+
+void pinnedTrim() {
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (auto & cls : g_pinned_free) {
+        for (void * p : cls.second) (void) hipHostFree(p);
+        cls.second.clear();
+    }
+}
+
+bool stagedUploads() {
+    static const bool staged = std::getenv("RPVG_HIP_PAGEABLE_UPLOADS") == nullptr;
+    return staged;
+}
+
+namespace {
+struct CopyLane {
+    hipStream_t copy_stream;
+    hipEvent_t copied;
+};
+std::mutex g_copy_mutex;
+std::map<hipStream_t, CopyLane> g_copy_lanes;
+}  // namespace
+
+void registerCopyStream(hipStream_t stream, hipStream_t copy_stream, hipEvent_t copied) {
+    std::lock_guard<std::mutex> lock(g_copy_mutex);
+    g_copy_lanes[stream] = CopyLane{copy_stream, copied};
+}
+
+void forgetCopyStream(hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_copy_mutex);
+    g_copy_lanes.erase(stream);
+}
+
+hipError_t stagedCopy(void * device_dst, const void * pinned_src, size_t bytes, hipStream_t stream) {
+    // (measured on the configs[2] bench: 19.1-19.9 ms per batch with the copy stream against 14.4-15.8 ms with the
+    // uploads on their own streams — the event waits between hardware queues cost more than the overlap brings; off
+    // unless RPVG_HIP_COPY_STREAM=1)
+    static const bool inline_uploads = std::getenv("RPVG_HIP_COPY_STREAM") == nullptr;
+    CopyLane lane{nullptr, nullptr};
+    if (!inline_uploads) {
+        std::lock_guard<std::mutex> lock(g_copy_mutex);
+        auto it = g_copy_lanes.find(stream);
+        if (it != g_copy_lanes.end()) lane = it->second;
+    }
+    if (!lane.copy_stream) return hipMemcpyAsync(device_dst, pinned_src, bytes, hipMemcpyHostToDevice, stream);
+    hipError_t e = hipMemcpyAsync(device_dst, pinned_src, bytes, hipMemcpyHostToDevice, lane.copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(lane.copied, lane.copy_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream, lane.copied, 0);
+    return e;
+}
+
+namespace {
 
 int g_hardware_queues = 4;
 
@@ -206,6 +294,24 @@ int rpvg_hip_device_count(int * count) {
     return RPVG_HIP_OK;
 }
 
+namespace {
+// The context's own stream carries the short kernels that stand between a host lane and its next stage (matrix build,
+// row collapse, EM problem set); the long ones — the searches, the EM bins — run on the side streams.  With a higher
+// priority the short ones of one lane get their workgroups in between those of the other lane's long kernels
+// — the idea; measured 17.4-17.8 ms per configs[2] batch against 15.1-15.9 ms with all streams alike (same box, same
+// call), so it is off unless RPVG_HIP_MAIN_PRIORITY=1.
+hipError_t createMainStream(hipStream_t * stream) {
+    static const char * env = std::getenv("RPVG_HIP_MAIN_PRIORITY");
+    if (!env || std::atoi(env) == 0) return hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
+        (void) hipGetLastError();
+        return hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
+    }
+    return hipStreamCreateWithPriority(stream, hipStreamNonBlocking, greatest);
+}
+}  // namespace
+
 int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) {
     RPVG_REQUIRE(ctx_out != nullptr, "rpvg_hip_create: ctx_out is NULL");
     *ctx_out = nullptr;
@@ -225,7 +331,7 @@ int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) {
     ctx->device = device;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->props, device)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        (e = createMainStream(&ctx->stream)) != hipSuccess) {
         setError("rpvg_hip_create: %s", hipGetErrorString(e));
         delete ctx;
         return RPVG_HIP_ERR_RUNTIME;
@@ -236,6 +342,12 @@ int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) {
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->search_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copied, hipEventDisableTiming);
+    if (e == hipSuccess) {
+        registerCopyStream(ctx->stream, ctx->copy_stream, ctx->copied);
+        for (int i = 0; i < rpvg_hip_ctx::kAuxStreams; ++i) registerCopyStream(ctx->aux[i], ctx->copy_stream, ctx->copied);
+    }
     if (e != hipSuccess) {
         setError("rpvg_hip_create: %s", hipGetErrorString(e));
         delete ctx;
@@ -260,6 +372,15 @@ void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
     (void) hipSetDevice(ctx->device);
     (void) ctx->foldSpans();
     (void) rpvg_hip_comm_destroy(ctx);
+    if (ctx->stream) forgetCopyStream(ctx->stream);
+    for (int i = 0; i < rpvg_hip_ctx::kAuxStreams; ++i) {
+        if (ctx->aux[i]) forgetCopyStream(ctx->aux[i]);
+    }
+    if (ctx->copy_stream) {
+        (void) hipStreamSynchronize(ctx->copy_stream);
+        (void) hipStreamDestroy(ctx->copy_stream);
+    }
+    if (ctx->copied) (void) hipEventDestroy(ctx->copied);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     for (int i = 0; i < rpvg_hip_ctx::kAuxStreams; ++i) {
         if (ctx->aux[i]) (void) hipStreamDestroy(ctx->aux[i]);
@@ -273,7 +394,15 @@ void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         last = (--g_device_contexts[ctx->device] <= 0);
     }
-    if (last) poolTrim(ctx->device);
+    if (last) {
+        poolTrim(ctx->device);
+        bool any = false;
+        {
+            std::lock_guard<std::mutex> lock(g_pool_mutex);
+            for (auto & kv : g_device_contexts) any = any || kv.second > 0;
+        }
+        if (!any) pinnedTrim();
+    }
     delete ctx;
 }
 

@@ -526,6 +526,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     auto & d_cursor = tmp->cursor; auto & d_scan_tmp = tmp->scan_tmp;
     auto & d_error = g->build_error_flag;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    std::unique_ptr<HostScope> sub(new HostScope("groups_build: uploads"));
     int span = ctx->spanBegin(FAM_H2D);
     ok(g->mat_val_off.upload(val_off.data(), M, st));
     ok(g->mat_row_off.upload(row_off.data(), M, st));
@@ -547,6 +548,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     }
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(M * 60 + num_columns * 8 + num_incidences * 4 + (item_matrix.size() + tile_matrix.size()) * 8);
+    sub.reset(new HostScope("groups_build: allocations"));
     ok(g->values.alloc(val_total));
     ok(g->rowmax.alloc(row_total));
     ok(g->row_perm.alloc(row_total));
@@ -555,6 +557,11 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     ok(g->mat_fast.alloc(M));
     ok(g->mat_mid.alloc(M));
     if (collapse) {
+        std::vector<uint32_t> segment_off(M + 1);
+        for (uint32_t m = 0; m < M; ++m) segment_off[m] = static_cast<uint32_t>(row_off[m]);
+        segment_off[M] = static_cast<uint32_t>(row_total);
+        if (row_total > 0x7fffffffull) e = hipErrorInvalidValue;
+        ok(g->collapse_segment_off.upload(segment_off.data(), M + 1, st));
         ok(g->collapse_key.alloc(row_total));
         ok(g->collapse_row.alloc(row_total));
         ok(g->collapse_mask.alloc(row_total));
@@ -568,6 +575,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     if (e == hipSuccess) ok(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_degree.ptr, d_path_grp_off.ptr, static_cast<int>(inc_total), st));
     ok(d_scan_tmp.alloc(scan_bytes));
     if (e == hipSuccess && inc_total > 0x7fffffffull) e = hipErrorInvalidValue;
+    sub.reset(new HostScope("groups_build: launches"));
     if (e == hipSuccess) {
         span = ctx->spanBegin(FAM_BUILD);
         ok(hipMemsetAsync(d_degree.ptr, 0, inc_total * sizeof(uint32_t), st));
@@ -601,7 +609,9 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
                 d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
                 g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_mask.ptr);
         }
+        sub.reset(new HostScope("groups_build: row collapse launches"));
         if (collapse && e == hipSuccess) ok(queueRowCollapse(ctx, g, row_total, spec->collapse_precision, st));
+        sub.reset();
         ctx->spanEnd(span);
         ctx->stats.build_launches += 3;
         ok(hipGetLastError());

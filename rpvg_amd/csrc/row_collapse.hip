@@ -50,7 +50,12 @@ constexpr uint32_t kSortThreads = 1024;
 constexpr uint32_t kBetweenThreads = 256;
 constexpr uint32_t kBetweenRows = 2 * kBetweenThreads;  // rows of a matrix per work item of step b
 constexpr uint32_t kPairChunk = 256;           // neighbour pairs staged in LDS at a time
-constexpr uint32_t kWholeMatrixBit = 0x80000000u;
+constexpr uint32_t kWholeMatrixBit = 0x80000000u;  // mat_list: every row of the matrix is listed
+constexpr uint32_t kBigListBit = 0x40000000u;      // mat_list: sorted by the bitonic kernel, compared in depth (no pair table)
+constexpr uint32_t kListSizeMask = 0x3FFFFFFFu;
+constexpr uint32_t kPairwiseRows = 1024;           // lists up to this size get a table of all their pairs
+constexpr uint64_t kPairTableBytes = 16ull << 20;
+constexpr uint8_t kPairLess = 1, kPairClose = 2;
 
 enum : uint32_t { kFlagNone = 0, kFlagActiveRows = 1, kFlagWholeMatrix = 2 };
 enum : uint32_t { kInfoMatrices = 0, kInfoRowsReplaced = 1, kInfoWholeMatrices = 2, kInfoActiveRows = 3, kInfoWords = 4 };
@@ -369,6 +374,12 @@ struct ReplayArgs {
     uint32_t * replay_list;      // [M] the matrices with a list, [M]: their number
     uint32_t * between_items;    // [2 x (total rows / kBetweenRows + M)] (matrix, slice of its rows) of step b
     uint32_t * between_count;
+    uint32_t * row_items;        // [2 x total rows] (matrix, list index) of the rows of the lists with a pair table
+    uint32_t * row_item_count;
+    uint64_t * pair_base;        // [M] offset of the matrix's n x n pair table
+    unsigned long long * pair_bytes;  // bytes of pair tables handed out
+    uint8_t * pair_table;        // [kPairTableBytes] entry i * n + j: kPairLess (row i sorts before row j), kPairClose
+    uint32_t * list_index;       // [total rows] index in the unsorted list (= in the pair table) of every sorted position
     uint32_t * order;            // [2 * total rows] list of matrix m at 2 * mat_row_off[m], sorted
     uint32_t * head_of;          // [total rows] list position of the run head of every list position
     uint8_t * close;             // [total rows] list position p is close to p - 1 and nothing lies between them
@@ -380,11 +391,8 @@ struct ReplayArgs {
     uint32_t * info;
 };
 
-// a. the list of a matrix — its active rows, or all of them — sorted with the reference's comparator, and for every
-// pair of neighbours the column that orders them
-__global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayArgs a) {
-    __shared__ uint32_t lds_list[kListLdsRows];
-    __shared__ uint64_t lds_pattern[kListLdsRows];  // zero pattern of the row at each list position (LDS lists)
+// a0. the list of a matrix: its active rows (the replay then only touches those), or all of them
+__global__ __launch_bounds__(256) void collapseListKernel(const ReplayArgs a) {
     __shared__ uint32_t list_size;
     const uint32_t m = blockIdx.x;
     if (m >= a.num_matrices) return;
@@ -393,57 +401,200 @@ __global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayA
         if (threadIdx.x == 0) a.mat_list[m] = 0;
         return;
     }
-    const MatrixView mv = viewOf(m, a.g);
-    const uint64_t R = mv.R;
+    const uint64_t R = a.g.mat_rows[m];
     const uint64_t r0 = a.g.mat_row_off[m];
     const uint8_t * active = a.active + r0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, num_waves = blockDim.x >> 6;
+    uint32_t * list = a.order + 2 * r0;
     if (threadIdx.x == 0) list_size = 0;
     __syncthreads();
-    bool whole = flag == kFlagWholeMatrix;
-    if (!whole) {
+    if (flag != kFlagWholeMatrix) {
         for (uint64_t i = threadIdx.x; i < R; i += blockDim.x) {
-            if (active[i]) {
-                const uint32_t slot = atomicAdd(&list_size, 1u);
-                if (slot < kListLdsRows) lds_list[slot] = static_cast<uint32_t>(i);
-            }
+            if (active[i]) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(i);
         }
         __syncthreads();
-        if (list_size > kListLdsRows) whole = true;
     }
+    if (threadIdx.x != 0) return;
+    const bool whole = flag == kFlagWholeMatrix;
     const uint64_t n = whole ? R : list_size;
     if (n < 2) {
-        if (threadIdx.x == 0) a.mat_list[m] = 0;
+        a.mat_list[m] = 0;
         return;
     }
+    uint32_t encoded = static_cast<uint32_t>(n);
+    if (whole) encoded |= kWholeMatrixBit | kBigListBit;
+    else if (n > kPairwiseRows) encoded |= kBigListBit;
+    else {
+        const unsigned long long base = atomicAdd(a.pair_bytes, static_cast<unsigned long long>(n * n));
+        if (base + n * n > kPairTableBytes) encoded |= kBigListBit;
+        else {
+            a.pair_base[m] = base;
+            const uint32_t first = atomicAdd(a.row_item_count, static_cast<uint32_t>(n));
+            for (uint32_t i = 0; i < n; ++i) {
+                a.row_items[2 * static_cast<uint64_t>(first + i)] = m;
+                a.row_items[2 * static_cast<uint64_t>(first + i) + 1] = i;
+            }
+        }
+    }
+    a.mat_list[m] = encoded;
+    a.replay_list[atomicAdd(&a.replay_list[a.num_matrices], 1u)] = m;
+    if (!whole) {  // work items of step b: (matrix, slice of kBetweenRows rows)
+        const uint32_t slices = static_cast<uint32_t>((R + kBetweenRows - 1) / kBetweenRows);
+        const uint32_t first = atomicAdd(a.between_count, slices);
+        for (uint32_t k = 0; k < slices; ++k) {
+            a.between_items[2 * static_cast<uint64_t>(first + k)] = m;
+            a.between_items[2 * static_cast<uint64_t>(first + k) + 1] = k;
+        }
+    }
+    atomicAdd(&a.info[kInfoMatrices], 1u);
+    atomicAdd(&a.info[kInfoActiveRows], static_cast<uint32_t>(n));
+    if (whole) atomicAdd(&a.info[kInfoWholeMatrices], 1u);
+}
+
+// a1. every pair of rows of a small list, one thread each: order and closeness in one pass over the columns.  (A
+// workgroup that sorts its list with a comparison network goes through dozens of dependent rounds of strided loads;
+// here every comparison of the batch is in flight at once, and ranks and runs are then read off the table.)
+__global__ __launch_bounds__(64) void collapsePairTableKernel(const ReplayArgs a) {
+    const uint32_t num_items = *a.row_item_count;
+    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
+        const uint32_t m = a.row_items[2 * static_cast<uint64_t>(item)], i = a.row_items[2 * static_cast<uint64_t>(item) + 1];
+        const uint32_t n = a.mat_list[m] & kListSizeMask;
+        const MatrixView mv = viewOf(m, a.g);
+        const uint32_t * list = a.order + 2 * a.g.mat_row_off[m];
+        uint8_t * table = a.pair_table + a.pair_base[m] + static_cast<uint64_t>(i) * n;
+        const uint32_t row_i = list[i];
+        const uint64_t pattern_i = mv.pattern[row_i];
+        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+            const uint32_t row_j = list[j];
+            int less = -1;
+            bool close = true;
+            forEachColumnPair(mv, row_i, row_j, pattern_i | mv.pattern[row_j], [&](const double x, const double y) {
+                if (less < 0 && !tolerantEqual(x, y)) less = x < y ? 1 : 0;
+                if (fabs(x - y) >= a.precision) close = false;
+                return less >= 0 && !close;
+            });
+            if (less < 0) {
+                const double x = mv.count[row_i], y = mv.count[row_j];
+                less = (!tolerantEqual(x, y) && x < y) ? 1 : 0;
+            }
+            table[j] = (less ? kPairLess : 0) | (close ? kPairClose : 0);
+        }
+    }
+}
+
+// a2. small lists sorted by rank: the number of rows that sort before a row (equal rows in list order).  Where the
+// tolerant comparison is inconsistent the ranks may collide; such a list is sorted by the comparison network instead.
+__global__ __launch_bounds__(256) void collapseRankKernel(const ReplayArgs a) {
+    __shared__ uint32_t lds_row[kPairwiseRows], lds_slot[kPairwiseRows];
+    __shared__ uint32_t collision;
+    const uint32_t num_items = a.replay_list[a.num_matrices];
+    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
+        const uint32_t m = a.replay_list[item];
+        const uint32_t encoded = a.mat_list[m];
+        if (encoded & kBigListBit) continue;
+        const uint32_t n = encoded;
+        const uint64_t r0 = a.g.mat_row_off[m];
+        uint32_t * list = a.order + 2 * r0;
+        uint32_t * list_index = a.list_index + r0;
+        const uint8_t * table = a.pair_table + a.pair_base[m];
+        __syncthreads();
+        if (threadIdx.x == 0) collision = 0;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            lds_row[i] = list[i];
+            lds_slot[i] = kNoRow;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) {
+                const bool before = (table[static_cast<uint64_t>(j) * n + i] & kPairLess) != 0;
+                const bool after = (table[static_cast<uint64_t>(i) * n + j] & kPairLess) != 0;
+                rank += (before || (!after && j < i)) ? 1u : 0u;
+            }
+            if (rank >= n || atomicExch(&lds_slot[rank], i) != kNoRow) collision = 1;
+        }
+        __syncthreads();
+        if (collision) {  // (never seen; kept correct rather than fast) insertion sort with the comparator itself
+            if (threadIdx.x == 0) {
+                const MatrixView mv = viewOf(m, a.g);
+                for (uint32_t i = 0; i < n; ++i) lds_slot[i] = i;
+                for (uint32_t i = 1; i < n; ++i) {
+                    const uint32_t moving = lds_slot[i];
+                    uint32_t k = i;
+                    while (k > 0 && rowLess(mv, lds_row[moving], lds_row[lds_slot[k - 1]])) {
+                        lds_slot[k] = lds_slot[k - 1];
+                        --k;
+                    }
+                    lds_slot[k] = moving;
+                }
+            }
+            __syncthreads();
+        }
+        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) {
+            list[p] = lds_row[lds_slot[p]];
+            list_index[p] = lds_slot[p];
+            a.barrier[r0 + p] = 0;
+        }
+        __syncthreads();
+        // the column that orders every pair of neighbours, and the interval between them in it (collapseSortKernel)
+        const MatrixView mv = viewOf(m, a.g);
+        for (uint32_t p = 1 + threadIdx.x; p < n; p += blockDim.x) {
+            const uint32_t x = lds_row[lds_slot[p - 1]], y = lds_row[lds_slot[p]];
+            uint32_t d = kNoRow;
+            bool can_join = true;
+            // (forEachColumnPair visits the columns in order but skips those in which both rows are zero: the column
+            // index is recovered from the patterns)
+            const uint64_t live = mv.pattern[x] | mv.pattern[y];
+            uint64_t remaining = live;
+            uint32_t wide = 64;
+            forEachColumnPair(mv, x, y, live, [&](const double vx, const double vy) {
+                uint32_t column;
+                if (remaining) {
+                    column = static_cast<uint32_t>(__ffsll(static_cast<long long>(remaining)) - 1);
+                    remaining &= remaining - 1;
+                } else if (wide < mv.G) {
+                    column = wide++;
+                } else {
+                    column = mv.G;
+                }
+                if (fabs(vx - vy) >= 2 * a.precision) can_join = false;
+                if (d == kNoRow && !tolerantEqual(vx, vy)) d = column;
+                return !can_join;
+            });
+            const bool look = can_join && d != kNoRow;
+            a.pair_column[r0 + p] = look ? d : kNoRow;
+            if (look) {
+                const double vx = mv.at(d, x), vy = mv.at(d, y);
+                a.pair_lo[r0 + p] = fmin(vx, vy);
+                a.pair_hi[r0 + p] = fmax(vx, vy);
+                a.pair_pattern[r0 + p] = mv.pattern[x] & (d >= 64 ? ~0ull : (1ull << d) - 1ull);
+            }
+        }
+    }
+}
+
+// a3. big lists (more than kPairwiseRows rows, whole matrices): sorted with the reference's comparator in a
+// comparison network, and for every pair of neighbours the column that orders them
+__global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayArgs a) {
+    __shared__ uint32_t lds_list[kListLdsRows];
+    __shared__ uint64_t lds_pattern[kListLdsRows];  // zero pattern of the row at each list position (LDS lists)
+    const uint32_t m = blockIdx.x;
+    if (m >= a.num_matrices) return;
+    const uint32_t encoded = a.mat_list[m];
+    if (!(encoded & kBigListBit)) return;  // no list, or a small one (pair table, collapseRankKernel)
+    const bool whole = (encoded & kWholeMatrixBit) != 0;
+    const uint64_t n = encoded & kListSizeMask;
+    const MatrixView mv = viewOf(m, a.g);
+    const uint64_t r0 = a.g.mat_row_off[m];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, num_waves = blockDim.x >> 6;
     uint64_t padded = 1;
     while (padded < n) padded <<= 1;
     uint32_t * global_order = a.order + 2 * r0;
     uint32_t * order = padded <= kListLdsRows ? lds_list : global_order;
+    for (uint64_t i = threadIdx.x; i < padded; i += blockDim.x) order[i] = i < n ? (whole ? static_cast<uint32_t>(i) : global_order[i]) : kNoRow;
     __syncthreads();
-    if (whole) {
-        for (uint64_t i = threadIdx.x; i < padded; i += blockDim.x) order[i] = i < R ? static_cast<uint32_t>(i) : kNoRow;
-    } else {
-        for (uint64_t i = n + threadIdx.x; i < padded; i += blockDim.x) order[i] = kNoRow;
-    }
     const bool in_lds = order == lds_list;
     if (in_lds) {
         for (uint64_t i = threadIdx.x; i < padded; i += blockDim.x) lds_pattern[i] = order[i] == kNoRow ? 0ull : mv.pattern[order[i]];
-    }
-    if (threadIdx.x == 0) {
-        a.mat_list[m] = static_cast<uint32_t>(n) | (whole ? kWholeMatrixBit : 0u);
-        a.replay_list[atomicAdd(&a.replay_list[a.num_matrices], 1u)] = m;
-        if (!whole) {  // work items of step b: (matrix, slice of kBetweenRows rows)
-            const uint32_t slices = static_cast<uint32_t>((R + kBetweenRows - 1) / kBetweenRows);
-            const uint32_t first = atomicAdd(a.between_count, slices);
-            for (uint32_t k = 0; k < slices; ++k) {
-                a.between_items[2 * static_cast<uint64_t>(first + k)] = m;
-                a.between_items[2 * static_cast<uint64_t>(first + k) + 1] = k;
-            }
-        }
-        atomicAdd(&a.info[kInfoMatrices], 1u);
-        atomicAdd(&a.info[kInfoActiveRows], static_cast<uint32_t>(n));
-        if (whole) atomicAdd(&a.info[kInfoWholeMatrices], 1u);
     }
     __syncthreads();
     // bitonic network with the reference's comparator; kNoRow sorts behind every row
@@ -517,7 +668,7 @@ __global__ __launch_bounds__(kBetweenThreads) void collapseBetweenKernel(const R
     const uint32_t num_items = *a.between_count;
     for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
         const uint32_t m = a.between_items[2 * static_cast<uint64_t>(item)], slice = a.between_items[2 * static_cast<uint64_t>(item) + 1];
-        const uint64_t n = a.mat_list[m];  // (not a whole matrix: those have no items)
+        const uint64_t n = a.mat_list[m] & kListSizeMask;  // (not a whole matrix: those have no items)
         const MatrixView mv = viewOf(m, a.g);
         const uint64_t r0 = a.g.mat_row_off[m];
         const uint8_t * active = a.active + r0;
@@ -560,44 +711,52 @@ __global__ __launch_bounds__(kBetweenThreads) void collapseBetweenKernel(const R
 }
 
 // c. runs and values: work item = matrix with a list
-__global__ __launch_bounds__(kSortThreads) void collapseRunsKernel(const ReplayArgs a) {
+__global__ __launch_bounds__(256) void collapseRunsKernel(const ReplayArgs a) {
     __shared__ uint32_t lds_next[kListLdsRows];
     __shared__ uint32_t demote;
+    const int lane = threadIdx.x & 63;
     const uint32_t num_items = a.replay_list[a.num_matrices];
     for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
         const uint32_t m = a.replay_list[item];
-        const uint64_t n = a.mat_list[m] & ~kWholeMatrixBit;
+        const uint32_t encoded = a.mat_list[m];
+        const uint64_t n = encoded & kListSizeMask;
+        const bool tabled = !(encoded & kBigListBit);
         const MatrixView mv = viewOf(m, a.g);
         const uint64_t R = mv.R;
         const uint64_t r0 = a.g.mat_row_off[m];
         const uint32_t * order = a.order + 2 * r0;
+        const uint32_t * list_index = a.list_index + r0;
+        const uint8_t * table = a.pair_table + (tabled ? a.pair_base[m] : 0);
         uint32_t * head_of = a.head_of + r0;
         uint32_t * next_head = n <= kListLdsRows ? lds_next : a.pair_column + r0;  // (the pair columns are done with)
         uint8_t * close = a.close + r0;
         const uint8_t * barrier = a.barrier + r0;
+        // list positions p, q hold rows within prob_precision of each other: read off the pair table, or compared
+        auto closeRows = [&](const uint64_t p, const uint64_t q) {
+            if (tabled) return (table[static_cast<uint64_t>(list_index[p]) * n + list_index[q]] & kPairClose) != 0;
+            return rowsClose(mv, order[p], order[q], a.precision, nullptr);
+        };
         __syncthreads();
         if (threadIdx.x == 0) demote = 0;
         for (uint64_t p = threadIdx.x; p < n; p += blockDim.x) {
             head_of[p] = kNoRow;
-            close[p] = (p > 0 && !barrier[p] && rowsClose(mv, order[p - 1], order[p], a.precision, nullptr)) ? 1 : 0;
+            close[p] = (p > 0 && !barrier[p] && closeRows(p - 1, p)) ? 1 : 0;
         }
         __syncthreads();
         // Runs (src/path_estimator.cpp:226-255): a row joins the run of the current head if it is close to the head,
         // otherwise it becomes the head.  Every list position answers "if I were a head, where would the next one be"
-        // on its own (the first position behind it that an inactive row parts from it or that is not close to it);
-        // one thread then walks from head to head, and every head claims its run.
-        // (a wave per position that has a follower: its lanes compare 64 positions with it at once)
+        // on its own (the first position behind it that an inactive row parts from it or that is not close to it: a
+        // wave per position that has a follower, 64 candidates at a time); one thread then walks from head to head,
+        // and every head claims its run.
         for (uint64_t h = threadIdx.x; h < n; h += blockDim.x) {
             if (h + 1 >= n || !close[h + 1]) next_head[h] = static_cast<uint32_t>(h + 1);
         }
-        const int lane = threadIdx.x & 63;
         for (uint64_t h = threadIdx.x >> 6; h + 1 < n; h += blockDim.x >> 6) {
             if (!close[h + 1]) continue;
-            const uint32_t head_row = order[h];
             uint64_t q0 = h + 2, found = n;
             while (q0 < n && found == n) {
                 const uint64_t q = q0 + lane;
-                const bool stop = q < n && (barrier[q] != 0 || !rowsClose(mv, head_row, order[q], a.precision, nullptr));
+                const bool stop = q < n && (barrier[q] != 0 || !closeRows(h, q));
                 const unsigned long long ballot = __ballot(stop);
                 if (ballot) found = q0 + static_cast<uint64_t>(__ffsll(static_cast<long long>(ballot)) - 1);
                 q0 += 64;
@@ -614,24 +773,26 @@ __global__ __launch_bounds__(kSortThreads) void collapseRunsKernel(const ReplayA
             for (uint64_t q = h + 1; q < next_head[h]; ++q) head_of[q] = static_cast<uint32_t>(h);
         }
         __syncthreads();
-        // the rows of a run take the values of its head
+        // the rows of a run take the values of its head: a wave per row, its lanes over the columns
         double * M = a.g.values + a.g.mat_val_off[m];
         double * nz = a.g.row_noise + r0;
         double * rm = a.rowmax + r0;
         const uint32_t fast_mid_end = a.mat_mid[m];
         uint32_t replaced = 0;
-        for (uint64_t q = threadIdx.x; q < n; q += blockDim.x) {
+        for (uint64_t q = threadIdx.x >> 6; q < n; q += blockDim.x >> 6) {
             const uint32_t h = head_of[q];
             if (h == q) continue;
             const uint32_t dst = order[q], src = order[h];
-            for (uint32_t c = 0; c < mv.G; ++c) M[static_cast<uint64_t>(c) * R + dst] = M[static_cast<uint64_t>(c) * R + src];
-            const double noise = nz[src];
-            nz[dst] = noise;
-            rm[dst] = rm[src];
-            ++replaced;
-            // a product-path row (LogProduct, common.hpp) needs noise >= kProductMinNoise: if the head's is below, the
-            // whole matrix takes the logarithm path
-            if (dst < fast_mid_end && !(noise >= kProductMinNoise)) demote = 1;
+            for (uint32_t c = lane; c < mv.G; c += 64) M[static_cast<uint64_t>(c) * R + dst] = M[static_cast<uint64_t>(c) * R + src];
+            if (lane == 0) {
+                const double noise = nz[src];
+                nz[dst] = noise;
+                rm[dst] = rm[src];
+                ++replaced;
+                // a product-path row (LogProduct, common.hpp) needs noise >= kProductMinNoise: if the head's is below,
+                // the whole matrix takes the logarithm path
+                if (dst < fast_mid_end && !(noise >= kProductMinNoise)) demote = 1;
+            }
         }
         if (replaced) atomicAdd(&a.info[kInfoRowsReplaced], replaced);
         __syncthreads();
@@ -653,22 +814,27 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     if (total_rows > 0x7fffffffull || M > kCollapseMaxMatrices) return hipErrorInvalidValue;
     struct CollapseTemporaries {
         DeviceBuffer<uint64_t> key_out, pair_pattern;
-        DeviceBuffer<uint32_t> row_out, words, order, head, pair_column, marked_list, pairs, between_items;
+        DeviceBuffer<uint32_t> row_out, order, head, pair_column, marked_list, pairs, between_items, row_items, list_index;
+        DeviceBuffer<uint64_t> pair_base;
+        DeviceBuffer<uint8_t> pair_table;
         DeviceBuffer<double> pair_bound;
-        DeviceBuffer<uint8_t> bytes;  // same_prev, active, close, barrier: total_rows each
+        DeviceBuffer<uint8_t> bytes;  // same_prev, close, barrier: total_rows each
         DeviceBuffer<unsigned char> sort_tmp;
     };
     std::shared_ptr<CollapseTemporaries> tmp = std::make_shared<CollapseTemporaries>();
     g->build_temporaries.emplace_back(tmp);
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
-    // zeroed words: matrix flags [M], replay list [M] + its count, marked bits + the marked list's count, the two pair counts
+    // zeroed words: the pair table's byte counter (8 bytes, first: aligned), matrix flags [M], replay list [M] + its
+    // count, marked bits, then the counters of the marked list, the two pair lists, the between items, the row items
     const uint64_t mark_words = (total_rows + 31) / 32;
-    const uint64_t num_words = 2 * static_cast<uint64_t>(M) + 1 + mark_words + 1 + 2 + 1;  // (+ the number of between items)
+    const uint64_t num_words = 2 + 2 * static_cast<uint64_t>(M) + 1 + mark_words + 5;
     const uint32_t pair_capacity = static_cast<uint32_t>(total_rows / 2 + 4096);
     ok(tmp->key_out.alloc(total_rows));
     ok(tmp->row_out.alloc(total_rows));
-    ok(tmp->words.alloc(num_words + M));  // + list sizes [M] (written by the sort kernel)
+    // one block, one memset: [info | the zeroed words | active bytes] + list sizes [M] (written by the list kernel)
+    const uint64_t active_words = (total_rows + 3) / 4;
+    ok(g->collapse_info.alloc(kInfoWords + num_words + active_words + M));
     ok(tmp->order.alloc(2 * total_rows));
     ok(tmp->head.alloc(total_rows));
     ok(tmp->pair_column.alloc(total_rows));
@@ -677,25 +843,29 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     ok(tmp->marked_list.alloc(total_rows));
     ok(tmp->pairs.alloc(2 * static_cast<size_t>(pair_capacity)));
     ok(tmp->between_items.alloc(2 * (total_rows / kBetweenRows + M)));
-    ok(tmp->bytes.alloc(4 * total_rows));
-    ok(g->collapse_info.alloc(kInfoWords));
-    int matrix_bits = 1;
-    while ((1ull << matrix_bits) < M) ++matrix_bits;
-    const int begin_bit = kCollapseLargestBits, end_bit = kCollapseMatrixShift + matrix_bits;  // (matrix, projection)
+    ok(tmp->row_items.alloc(2 * total_rows));
+    ok(tmp->list_index.alloc(total_rows));
+    ok(tmp->pair_base.alloc(M));
+    ok(tmp->pair_table.alloc(kPairTableBytes));
+    ok(tmp->bytes.alloc(3 * total_rows));
+    // the rows of a matrix are a segment of the key array: sorted segment by segment on the projection bits
+    const int begin_bit = kCollapseLargestBits, end_bit = kCollapseMatrixShift;
+    const uint32_t * segment_off = g->collapse_segment_off.ptr;
     size_t sort_bytes = 0;
-    if (e == hipSuccess) ok(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, g->collapse_key.ptr, tmp->key_out.ptr, g->collapse_row.ptr, tmp->row_out.ptr,
-                                                               static_cast<int>(total_rows), begin_bit, end_bit, st));
+    if (e == hipSuccess) ok(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, sort_bytes, g->collapse_key.ptr, tmp->key_out.ptr, g->collapse_row.ptr,
+                                                                        tmp->row_out.ptr, static_cast<int>(total_rows), static_cast<int>(M),
+                                                                        segment_off, segment_off + 1, begin_bit, end_bit, st));
     ok(tmp->sort_tmp.alloc(sort_bytes));
     if (e != hipSuccess) return e;
-    uint32_t * mat_flag = tmp->words.ptr, * replay_list = mat_flag + M, * marked_bits = replay_list + M + 1,
+    uint32_t * pair_bytes = g->collapse_info.ptr + kInfoWords, * mat_flag = pair_bytes + 2, * replay_list = mat_flag + M, * marked_bits = replay_list + M + 1,
              * marked_count = marked_bits + mark_words, * pair_counts = marked_count + 1, * between_count = pair_counts + 2,
-             * mat_list = between_count + 1;
-    uint8_t * same_prev = tmp->bytes.ptr, * active = same_prev + total_rows, * close = active + total_rows, * barrier = close + total_rows;
-    ok(hipMemsetAsync(tmp->words.ptr, 0, num_words * sizeof(uint32_t), st));
-    ok(hipMemsetAsync(g->collapse_info.ptr, 0, kInfoWords * sizeof(uint32_t), st));
-    ok(hipMemsetAsync(active, 0, total_rows, st));
-    ok(hipcub::DeviceRadixSort::SortPairs(tmp->sort_tmp.ptr, sort_bytes, g->collapse_key.ptr, tmp->key_out.ptr, g->collapse_row.ptr, tmp->row_out.ptr,
-                                          static_cast<int>(total_rows), begin_bit, end_bit, st));
+             * row_item_count = between_count + 1, * mat_list = pair_bytes + num_words + active_words;
+    uint8_t * same_prev = tmp->bytes.ptr, * close = same_prev + total_rows, * barrier = close + total_rows;
+    uint8_t * active = reinterpret_cast<uint8_t *>(pair_bytes + num_words);
+    ok(hipMemsetAsync(g->collapse_info.ptr, 0, (kInfoWords + num_words + active_words) * sizeof(uint32_t), st));
+    ok(hipcub::DeviceSegmentedRadixSort::SortPairs(tmp->sort_tmp.ptr, sort_bytes, g->collapse_key.ptr, tmp->key_out.ptr, g->collapse_row.ptr,
+                                                   tmp->row_out.ptr, static_cast<int>(total_rows), static_cast<int>(M), segment_off, segment_off + 1,
+                                                   begin_bit, end_bit, st));
     MatrixArrays arrays;
     arrays.mat_val_off = g->mat_val_off.ptr;
     arrays.mat_row_off = g->mat_row_off.ptr;
@@ -741,6 +911,12 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     r.replay_list = replay_list;
     r.between_items = tmp->between_items.ptr;
     r.between_count = between_count;
+    r.row_items = tmp->row_items.ptr;
+    r.row_item_count = row_item_count;
+    r.pair_base = tmp->pair_base.ptr;
+    r.pair_bytes = reinterpret_cast<unsigned long long *>(pair_bytes);
+    r.pair_table = tmp->pair_table.ptr;
+    r.list_index = tmp->list_index.ptr;
     r.order = tmp->order.ptr;
     r.head_of = tmp->head.ptr;
     r.close = close;
@@ -750,9 +926,12 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     r.pair_hi = tmp->pair_bound.ptr + total_rows;
     r.pair_pattern = tmp->pair_pattern.ptr;
     r.info = g->collapse_info.ptr;
+    collapseListKernel<<<dim3(M), dim3(256), 0, st>>>(r);
+    collapsePairTableKernel<<<dim3(4096), dim3(64), 0, st>>>(r);
+    collapseRankKernel<<<dim3(1024), dim3(256), 0, st>>>(r);
     collapseSortKernel<<<dim3(M), dim3(kSortThreads), 0, st>>>(r);
     collapseBetweenKernel<<<dim3(2048), dim3(kBetweenThreads), 0, st>>>(r);
-    collapseRunsKernel<<<dim3(512), dim3(kSortThreads), 0, st>>>(r);
+    collapseRunsKernel<<<dim3(1024), dim3(256), 0, st>>>(r);
     ok(hipGetLastError());
     return e;
 }
