@@ -7,10 +7,12 @@ on the "10M read pairs x 200k paths in ~5k clusters" workload (BASELINE.json con
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s3|c2] [--model ...] [--scale F]
 
-One process per GPU (the driver launches N of them through torch.distributed.run); clusters are
-independent, so there is no data-path collective: every rank owns a full-size batch of its own
-(weak scaling) and the final per-path abundance vectors are gathered over RCCL after the timed region.
-Rank 0 prints ONE JSON line.
+One process per GPU: started under torch.distributed.run (WORLD_SIZE in the environment) this process is one
+rank; started plainly with --gpus N > 1 it launches the N ranks itself (torch.distributed.run, rendezvous on
+127.0.0.1) and passes their output through.  Clusters are independent, so there is no data-path collective:
+every rank owns a full-size batch of its own (weak scaling) and the final per-path abundance vectors are
+gathered over RCCL after the timed region.  Rank 0 prints ONE JSON line; its n_gpus is the number of ranks
+that ran and must equal --gpus.
 
 --workload c2 runs the other bench-able configuration, "1M read pairs x 2k paths, one dense cluster"
 (configs[1], 16 GB FP64 streamed from HBM every EM iteration, fixed 50-iteration budget).
@@ -58,16 +60,43 @@ def parse_args():
     return ap.parse_args()
 
 
+# Test seams (tests/test_distributed_cpu.py drives the launcher and the rank protocol without a GPU): the collective
+# backend and the module that provides Engine.  The defaults are the product: RCCL and the HIP engine, which fails
+# loudly without a GPU.  Nothing in this file imports the oracle except the cpu_baseline leg.
+DIST_BACKEND = os.environ.get("RPVG_BENCH_DIST_BACKEND", "nccl")
+ENGINE_MODULE = os.environ.get("RPVG_BENCH_ENGINE", "rpvg_amd.engine")
+DEVICE = "cuda" if DIST_BACKEND == "nccl" else "cpu"
+
+
+def launch_ranks(n_gpus):
+    """--gpus N > 1 without a torch.distributed.run environment: start the N ranks of this node and wait for them."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:  # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between the ranks of this node
+    return subprocess.call(cmd, env=env)
+
+
 def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != n_gpus:
+        raise SystemExit(f"bench.py: --gpus {n_gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     import torch
     dist = None
     if world > 1 or os.environ.get("RPVG_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path with one rank
         import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if DEVICE == "cuda":
+            torch.cuda.set_device(local_rank)
+            dist_mod.init_process_group(backend=DIST_BACKEND, device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend=DIST_BACKEND)
         dist = dist_mod
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
@@ -77,13 +106,14 @@ def dist_setup(n_gpus):
 def barrier_sync(dist, torch):
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    if DEVICE == "cuda":
+        torch.cuda.synchronize()
 
 
 def max_over_ranks(x, dist, torch):
     if dist is None:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    t = torch.tensor([x], dtype=torch.float64, device=DEVICE)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -91,7 +121,7 @@ def max_over_ranks(x, dist, torch):
 def sum_over_ranks(x, dist, torch):
     if dist is None:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    t = torch.tensor([x], dtype=torch.float64, device=DEVICE)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -129,8 +159,10 @@ def cpu_baseline_s3(batch, model, params, target_seconds):
 
 def run_s3(args, rank, local_rank, world, dist, torch):
     import numpy as np
-    from rpvg_amd import dist as rdist, engine as eng_mod, synth
+    import importlib
+    from rpvg_amd import dist as rdist, synth
     from rpvg_amd.batch import make_params
+    eng_mod = importlib.import_module(ENGINE_MODULE)
 
     s5 = args.workload == "s5"
     if s5:
@@ -223,14 +255,14 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     tpm_denominator = None
     if dist is not None and args.model != "haplotypes":
         # the other collective of a multi-GPU run: the TPM denominator (src/main.cpp:1029-1057) summed over ranks
-        tpm_denominator = rdist.total_transcript_count(rdist.local_transcript_count(est, batch), dist, "cuda")
+        tpm_denominator = rdist.total_transcript_count(rdist.local_transcript_count(est, batch), dist, DEVICE)
     if dist is not None:
         if args.scaling == "strong":
-            per_cluster = rdist.gather_cluster_values([e.abundances for e in est], my_clusters, global_clusters, dist, "cuda")
+            per_cluster = rdist.gather_cluster_values([e.abundances for e in est], my_clusters, global_clusters, dist, DEVICE)
             gathered = float(sum(float(v.sum()) for v in per_cluster))
         else:
             flat = np.concatenate([e.abundances for e in est]) if est else np.zeros(0)
-            gathered = float(sum(float(v.sum()) for v in rdist.all_gather_ragged(flat, dist, "cuda")))
+            gathered = float(sum(float(v.sum()) for v in rdist.all_gather_ragged(flat, dist, DEVICE)))
 
     if rank != 0:
         return None
@@ -282,7 +314,7 @@ def run_s3(args, rank, local_rank, world, dist, torch):
                                 kernel="groupLoglikKernel",
                                 note="algorithmic bytes = 16 B (two matrix columns) per row-evaluation; the kernel is FP64-log "
                                      "bound and the matrices are L2-resident, see kernels.loglik_gevals_per_s")
-    if args.scale >= 1.0 and not s5:
+    if args.scale >= 1.0 and not s5 and DEVICE == "cuda":
         try:
             line["roofline_dense_em"] = dense_em_roofline(local_rank)
         except Exception as exc:  # the record is optional; the default workload's line stands on its own
@@ -560,13 +592,16 @@ def run_c2(args, rank, local_rank, world, dist, torch):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     rank, local_rank, world, dist, torch = dist_setup(args.gpus)
-    if not torch.cuda.is_available():
+    if DEVICE == "cuda" and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     runner = dict(c2=run_c2, rows=run_rows, e2e=run_e2e).get(args.workload, run_s3)
     line = runner(args, rank, local_rank, world, dist, torch)
     if rank == 0:
-        print(json.dumps(line))
+        assert line["n_gpus"] == args.gpus, (line["n_gpus"], args.gpus)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -145,3 +145,53 @@ def test_two_rank_gloo_row_sharded_em_protocol(tmp_path):
     port = _free_port()
     mp.spawn(_row_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(os.path.join(str(tmp_path), "result_rows")).read() == "ok"
+
+
+def _run_bench(extra_args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    # the collectives over gloo and the per-rank compute by the oracle: what is under test is bench.py's launcher,
+    # its rank protocol (barrier, max over ranks, sums, gathers) and the line it prints
+    env.update(RPVG_BENCH_DIST_BACKEND="gloo", RPVG_BENCH_ENGINE="tests.oracle_engine_stub", PYTHONPATH=root, OMP_NUM_THREADS="1")
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--scale", "0.01",
+                          "--no-cpu-baseline"] + extra_args, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a torch.distributed.run environment starts two ranks itself."""
+    one = _run_bench(["--gpus", "1"])
+    two = _run_bench(["--gpus", "2"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["scaling"] == "weak" and two["config"]["clusters_per_gpu"] == one["config"]["clusters_per_gpu"]
+    assert two["mass_conserved"] and two["value"] > 0
+    # weak scaling: every rank owns a batch of its own, the gathered mass is that of both
+    assert two["gathered_abundance_mass"] > 1.5 * 0.9 * 10000000 * 0.01
+    assert two["tpm_denominator"] > 0
+
+
+def test_bench_strong_scaling_shards_one_batch():
+    two = _run_bench(["--gpus", "2", "--scaling", "strong"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["mass_conserved"]
+    reads = 10000000 * 0.01  # ONE batch, its clusters sharded over the ranks: the gathered abundances are those of one batch
+    assert 0.9 * reads < two["gathered_abundance_mass"] <= reads
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", RPVG_BENCH_DIST_BACKEND="gloo",
+               RPVG_BENCH_ENGINE="tests.oracle_engine_stub", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--scale", "0.01"], env=env,
+                         capture_output=True, text=True, timeout=120, cwd=root)
+    assert out.returncode != 0 and "--gpus 2" in (out.stderr + out.stdout)
