@@ -275,8 +275,18 @@ void rpvg_hip_read_rows_free(rpvg_hip_ctx * ctx, rpvg_hip_read_rows * rows);
 int rpvg_hip_comm_unique_id(uint8_t * id_out);
 int rpvg_hip_comm_init(rpvg_hip_ctx * ctx, const uint8_t * id, int world_size, int rank);
 int rpvg_hip_comm_destroy(rpvg_hip_ctx * ctx);
+/* The same for the contexts of ONE process — one host thread per GPU instead of one process per GPU, the shape of
+ * the reference's own parallelism (one process, `#pragma omp parallel for` over clusters, src/main.cpp:829):
+ * context i becomes rank i of num_contexts; the contexts must sit on different GPUs. */
+int rpvg_hip_comm_init_all(rpvg_hip_ctx * const * ctxs, int num_contexts);
 /* In-place sum over ranks of n doubles in device memory (stream-ordered; synchronises before returning). */
 int rpvg_hip_comm_allreduce_sum_f64(rpvg_hip_ctx * ctx, double * device_buf, uint64_t n);
+/* The one collective of a run whose clusters are sharded over GPUs: the final gather of per-path abundances
+ * (what the writers need in one place: src/main.cpp:1020-1083).  Collective over the ranks of the context's
+ * communicator (every rank calls it, from its own host thread or process): rank r brings counts[r] host values,
+ * every rank receives all of them in rank order (all_values: sum of counts; ncclAllGather over xGMI, ragged
+ * lengths padded to the longest).  A context without a communicator is a world of one. */
+int rpvg_hip_gather(rpvg_hip_ctx * ctx, const double * local_values, uint64_t local_count, const uint64_t * counts, double * all_values);
 
 /* ---- synthetic workload (bench / tests only) ---------------------------- */
 /* Fills a dense normalised R x C matrix (layout of rpvg_hip_em_dense) and unit

@@ -7,7 +7,10 @@
 //   * the TPM denominator, total_transcript_count = sum abundance / effective_length
 //     (src/main.cpp:1029-1057): one double.
 // Both are ncclAllReduce calls queued on the context's stream, so they are ordered with the kernels
-// around them and cost no host synchronisation.
+// around them and cost no host synchronisation.  The one collective of the sharded-clusters case is the
+// final gather of the per-path abundances (rpvg_hip_gather: ncclAllGather, once per run, latency bound).
+// The ranks are one process per GPU (ids handed around by the harness) or the contexts of one process, one
+// host thread per GPU (rpvg_hip_comm_init_all; rpvg_amd/host/device_group.hpp).
 //
 // RCCL is opened with dlopen at the first comm call: processes that never shard a cluster (and the
 // CPU-side ABI tests) do not need the library, and a process that already has an RCCL mapped (the
@@ -15,7 +18,9 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include <rccl/rccl.h>
 
@@ -29,6 +34,9 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char * (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -43,7 +51,8 @@ RcclApi & rccl() {
             if (api.handle) break;
         }
         if (!api.handle) {
-            api.error = std::string("cannot open librccl: ") + (dlerror() ? dlerror() : "unknown");
+            const char * why = dlerror();  // (one call: it clears the error it returns)
+            api.error = std::string("cannot open librccl: ") + (why ? why : "unknown");
             return;
         }
         auto sym = [&](const char * n) -> void * {
@@ -55,6 +64,9 @@ RcclApi & rccl() {
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
     });
     return api;
@@ -136,5 +148,69 @@ extern "C" int rpvg_hip_comm_allreduce_sum_f64(rpvg_hip_ctx * ctx, double * devi
     RPVG_HIP_CHECK(hipSetDevice(ctx->device));
     if (const int rc = ctx->allReduceSumF64(device_buf, n)) return rc;
     RPVG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RPVG_HIP_OK;
+}
+
+extern "C" int rpvg_hip_comm_init_all(rpvg_hip_ctx * const * ctxs, int num_contexts) {
+    RPVG_REQUIRE(ctxs && num_contexts >= 1, "rpvg_hip_comm_init_all: no contexts");
+    for (int i = 0; i < num_contexts; ++i) {
+        RPVG_REQUIRE(ctxs[i] && !ctxs[i]->comm, "rpvg_hip_comm_init_all: context %d is NULL or already has a communicator", i);
+        for (int j = 0; j < i; ++j) {
+            RPVG_REQUIRE(ctxs[i]->device != ctxs[j]->device, "rpvg_hip_comm_init_all: contexts %d and %d share GPU %d (one rank per GPU)", j, i,
+                         ctxs[i]->device);
+        }
+    }
+    if (const int rc = requireRccl()) return rc;
+    ncclUniqueId uid;
+    RPVG_RCCL_CHECK(rccl().GetUniqueId(&uid));
+    std::vector<ncclComm_t> comms(num_contexts, nullptr);
+    RPVG_RCCL_CHECK(rccl().GroupStart());
+    for (int i = 0; i < num_contexts; ++i) {
+        RPVG_HIP_CHECK(hipSetDevice(ctxs[i]->device));
+        const ncclResult_t rc = rccl().CommInitRank(&comms[i], num_contexts, uid, i);
+        if (rc != ncclSuccess) {
+            (void) rccl().GroupEnd();
+            rpvg_hip_detail::setError("ncclCommInitRank(rank %d of %d) failed: %s", i, num_contexts, rccl().GetErrorString(rc));
+            return RPVG_HIP_ERR_RUNTIME;
+        }
+    }
+    RPVG_RCCL_CHECK(rccl().GroupEnd());
+    for (int i = 0; i < num_contexts; ++i) {
+        ctxs[i]->comm = comms[i];
+        ctxs[i]->comm_world = num_contexts;
+        ctxs[i]->comm_rank = i;
+    }
+    return RPVG_HIP_OK;
+}
+
+extern "C" int rpvg_hip_gather(rpvg_hip_ctx * ctx, const double * local_values, uint64_t local_count, const uint64_t * counts, double * all_values) {
+    RPVG_REQUIRE(ctx && counts && all_values && (local_values || local_count == 0), "rpvg_hip_gather: NULL argument");
+    const int world = ctx->comm ? ctx->comm_world : 1, rank = ctx->comm ? ctx->comm_rank : 0;
+    RPVG_REQUIRE(counts[rank] == local_count, "rpvg_hip_gather: counts[%d] = %llu but this rank brings %llu values", rank,
+                 static_cast<unsigned long long>(counts[rank]), static_cast<unsigned long long>(local_count));
+    uint64_t widest = 0;
+    for (int r = 0; r < world; ++r) widest = std::max<uint64_t>(widest, counts[r]);
+    if (widest == 0) return RPVG_HIP_OK;
+    if (world == 1) {
+        std::memcpy(all_values, local_values, local_count * sizeof(double));
+        return RPVG_HIP_OK;
+    }
+    // ragged lengths: every rank sends `widest` values (its own, zero padded), the receiver drops the padding
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    rpvg_hip_detail::DeviceBuffer<double> send, recv;
+    std::vector<double> padded(widest, 0.0);
+    std::memcpy(padded.data(), local_values, local_count * sizeof(double));
+    RPVG_HIP_CHECK(send.upload(padded.data(), widest, ctx->stream));
+    RPVG_HIP_CHECK(recv.alloc(widest * world));
+    RPVG_RCCL_CHECK(rccl().AllGather(send.ptr, recv.ptr, widest, ncclDouble, static_cast<ncclComm_t>(ctx->comm), ctx->stream));
+    std::vector<double> gathered(widest * world);
+    RPVG_HIP_CHECK(recv.download(gathered.data(), ctx->stream));
+    RPVG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    uint64_t out = 0;
+    for (int r = 0; r < world; ++r) {
+        std::memcpy(all_values + out, gathered.data() + static_cast<uint64_t>(r) * widest, counts[r] * sizeof(double));
+        out += counts[r];
+    }
     return RPVG_HIP_OK;
 }

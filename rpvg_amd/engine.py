@@ -1,4 +1,5 @@
-"""ctypes binding of the host-side estimator runner (librpvg_amd_host.so).
+"""ctypes binding of the harness entry points (librpvg_amd_harness.so) over the host-side estimator classes
+(librpvg_amd_host.so).
 
 The work happens in C++ (``rpvg_amd/host``: PathEstimator classes over the C
 ABI of the HIP engine); this module only marshals flat batches in and
@@ -14,7 +15,7 @@ from . import hip
 from .batch import CClusterBatch, CEstimatesView, CParams, ClusterBatch, ClusterEstimates, decode_view
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "host", "librpvg_amd_host.so")
+LIB_PATH = os.path.join(_HERE, "host", "librpvg_amd_harness.so")  # links librpvg_amd_host.so, the product
 
 MODELS = ("transcripts", "strains", "haplotype-transcripts", "haplotypes")
 
@@ -50,6 +51,14 @@ def lib() -> C.CDLL:
         L.rpvg_amd_run_from_alignments_inplace.restype = C.c_int
         L.rpvg_amd_run_from_alignments_inplace.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double),
                                                            C.POINTER(C.c_double)]
+        L.rpvg_amd_group_create.restype = C.c_void_p
+        L.rpvg_amd_group_create.argtypes = [C.POINTER(C.c_int), C.c_int]
+        L.rpvg_amd_group_destroy.argtypes = [C.c_void_p]
+        L.rpvg_amd_group_has_communicator.argtypes = [C.c_void_p]
+        L.rpvg_amd_group_run.restype = C.c_void_p
+        L.rpvg_amd_group_run.argtypes = [C.c_void_p, C.POINTER(CClusterBatch), C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double)]
+        L.rpvg_amd_group_partition.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.rpvg_amd_group_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.rpvg_amd_result_view.argtypes = [C.c_void_p, C.POINTER(CEstimatesView)]
         L.rpvg_amd_result_free.argtypes = [C.c_void_p]
         _lib = L
@@ -152,6 +161,57 @@ class Engine:
         if rc != 0:
             raise hip.EngineError(f"run_from_alignments({model}) failed: {_err()}")
         return rows_s.value, est_s.value
+
+
+class DeviceGroup:
+    """The GPUs of one node behind one call (rpvg_amd/host/device_group.hpp): one engine and one host thread per
+    entry of `devices`, clusters bin-packed over them, final abundance gather over the group's communicator."""
+
+    def __init__(self, devices):
+        arr = (C.c_int * len(devices))(*devices)
+        self.handle = lib().rpvg_amd_group_create(arr, len(devices))
+        if not self.handle:
+            raise hip.EngineError(f"device group create failed: {_err()}")
+        self.num_clusters = 0
+
+    def close(self):
+        if self.handle:
+            lib().rpvg_amd_group_destroy(self.handle)
+            self.handle = None
+
+    def has_communicator(self) -> bool:
+        return bool(lib().rpvg_amd_group_has_communicator(self.handle))
+
+    def run(self, model: str, params: CParams, batch: ClusterBatch) -> Tuple[List[ClusterEstimates], float]:
+        secs = C.c_double(0)
+        cb = batch.as_c()
+        h = lib().rpvg_amd_group_run(self.handle, C.byref(cb), model.encode(), C.byref(params), C.byref(secs))
+        if not h:
+            raise hip.EngineError(f"group run({model}) failed: {_err()}")
+        try:
+            view = CEstimatesView()
+            lib().rpvg_amd_result_view(h, C.byref(view))
+            out = decode_view(view)
+        finally:
+            lib().rpvg_amd_result_free(h)
+        self.num_clusters = batch.num_clusters
+        return out, secs.value
+
+    def partition(self):
+        import numpy as np
+        out = np.zeros(self.num_clusters, dtype=np.uint32)
+        if lib().rpvg_amd_group_partition(self.handle, C.c_void_p(out.ctypes.data), self.num_clusters) != 0:
+            raise hip.EngineError(f"group partition failed: {_err()}")
+        return out
+
+    def gather(self, capacity: int):
+        """(abundances of all clusters in cluster order, TPM denominator) after the collective of the last run."""
+        import numpy as np
+        out = np.zeros(max(1, capacity), dtype=np.float64)
+        count, total = C.c_uint64(0), C.c_double(0)
+        if lib().rpvg_amd_group_gather(self.handle, C.c_void_p(out.ctypes.data), capacity, C.byref(count), C.byref(total)) != 0:
+            raise hip.EngineError(f"group gather failed: {_err()}")
+        return out[:count.value].copy(), total.value
 
 
 class PreparedBatch:

@@ -25,7 +25,7 @@ EXPORTS = [
     "rpvg_hip_synth_dense_cluster", "rpvg_hip_stats_get", "rpvg_hip_stats_reset",
     "rpvg_hip_gibbs_read_counts", "rpvg_hip_min_path_cover", "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
     "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
-    "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_group_conditionals",
+    "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_comm_init_all", "rpvg_hip_gather", "rpvg_hip_group_conditionals",
     "rpvg_hip_alignments_upload", "rpvg_hip_alignments_free", "rpvg_hip_read_rows_build", "rpvg_hip_read_rows_to_batch",
     "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_sizes", "rpvg_hip_read_rows_free", "rpvg_hip_path_clusters", "rpvg_hip_debug_log",
 ]
@@ -388,6 +388,20 @@ class Context:
 
     def comm_destroy(self):
         _check(lib().rpvg_hip_comm_destroy(self.handle), "rpvg_hip_comm_destroy")
+
+    def comm_init_all(self):
+        """A communicator over the contexts of this process (rpvg_hip_comm_init_all) — here: this one context."""
+        arr = (C.c_void_p * 1)(self.handle)
+        _check(lib().rpvg_hip_comm_init_all(arr, C.c_int(1)), "rpvg_hip_comm_init_all")
+
+    def gather(self, local: np.ndarray, counts) -> np.ndarray:
+        """rpvg_hip_gather: this rank's values in, the values of all ranks (counts[r] each) out."""
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        cnt = np.ascontiguousarray(counts, dtype=np.uint64)
+        out = np.zeros(int(cnt.sum()), dtype=np.float64)
+        _check(lib().rpvg_hip_gather(self.handle, C.c_void_p(local.ctypes.data), C.c_uint64(local.size), C.c_void_p(cnt.ctypes.data),
+                                     C.c_void_p(out.ctypes.data)), "rpvg_hip_gather")
+        return out
 
     def allreduce_sum_f64(self, d_buf: int, n: int):
         _check(lib().rpvg_hip_comm_allreduce_sum_f64(self.handle, C.c_void_p(d_buf), C.c_uint64(n)),

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/rpvg_batch.h"
+#include "device_group.hpp"
 #include "estimator_factory.hpp"
 #include "read_rows.hpp"
 #include "trace.hpp"
@@ -459,6 +460,121 @@ int rpvg_amd_run_from_alignments_inplace(void * engine, void * prepared_batch, c
         }
 
         return rpvg_amd_run_inplace(engine, prepared_batch, model, params, estimate_seconds_out);
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
+// ---- the GPUs of a node behind one call (device_group.hpp) -------------------------------------------------------
+
+struct Group {
+
+    std::unique_ptr<DeviceGroup> devices;
+    std::vector<PathClusterEstimates> estimates;
+};
+
+void * rpvg_amd_group_create(const int * devices, int num_devices) {
+
+    try {
+
+        Group * group = new Group();
+        std::unique_ptr<Group> guard(group);
+        group->devices.reset(new DeviceGroup(std::vector<int>(devices, devices + num_devices)));
+        return guard.release();
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return nullptr;
+    }
+}
+
+void rpvg_amd_group_destroy(void * group) {
+
+    delete static_cast<Group *>(group);
+}
+
+int rpvg_amd_group_has_communicator(void * group) {
+
+    return static_cast<Group *>(group)->devices->hasCommunicator() ? 1 : 0;
+}
+
+// Estimates of every cluster of a host batch, its clusters sharded over the group's GPUs.
+void * rpvg_amd_group_run(void * group_handle, const rpvg_cluster_batch * batch, const char * model, const rpvg_params * params, double * seconds_out) {
+
+    try {
+
+        Group * group = static_cast<Group *>(group_handle);
+        const auto paths = unpackPaths(*batch);
+
+        group->estimates.assign(paths.size(), PathClusterEstimates());
+
+        for (size_t i = 0; i < paths.size(); ++i) {
+
+            group->estimates.at(i).paths = paths.at(i);
+        }
+
+        const auto start = std::chrono::steady_clock::now();
+        group->devices->estimateBatch(&group->estimates, *batch, model, *params);
+
+        if (seconds_out) {
+
+            *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+        }
+
+        return packResult(group->estimates);
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return nullptr;
+    }
+}
+
+// GPU of every cluster in the last run.
+int rpvg_amd_group_partition(void * group_handle, uint32_t * device_of_cluster, uint64_t num_clusters) {
+
+    Group * group = static_cast<Group *>(group_handle);
+    const auto & partition = group->devices->lastPartition();
+
+    for (size_t idx = 0; idx < partition.size(); ++idx) {
+
+        for (auto & cluster: partition.at(idx)) {
+
+            if (cluster >= num_clusters) {
+
+                last_error = "rpvg_amd_group_partition: output too short";
+                return -1;
+            }
+
+            device_of_cluster[cluster] = idx;
+        }
+    }
+
+    return 0;
+}
+
+// The final gather of the last run: abundances of all clusters in cluster order (capacity doubles available), their
+// number, and the TPM denominator.
+int rpvg_amd_group_gather(void * group_handle, double * abundances_out, uint64_t capacity, uint64_t * count_out, double * total_transcript_count_out) {
+
+    try {
+
+        Group * group = static_cast<Group *>(group_handle);
+        const auto gathered = group->devices->gatherAbundances(group->estimates, total_transcript_count_out);
+
+        if (gathered.size() > capacity) {
+
+            last_error = "rpvg_amd_group_gather: output too short";
+            return -1;
+        }
+
+        std::copy(gathered.begin(), gathered.end(), abundances_out);
+        *count_out = gathered.size();
+        return 0;
 
     } catch (const std::exception & e) {
 

@@ -258,8 +258,17 @@ def test_one_rank_communicator_row_sharded_em(hip_ctx, R, N):
         P = ctx.d2h(d_P, (R, ld))[:, :N + 1].copy()
         ab_o, noise_o, _, its_o, _ = pyoracle.em_dense(P, np.ones(R), max_em_its=30)
         assert its_s == its_o and small_cases.rel_close(ab_s, ab_o, rel=REL)
+        # the final gather (rpvg_hip_gather, ncclAllGather) in a world of one, and its argument checks
+        assert np.array_equal(ctx.gather(x, [x.size]), x)
+        with pytest.raises(hip.EngineError, match="counts"):
+            ctx.gather(x, [x.size + 1])
         ctx.comm_destroy()
         ctx.comm_destroy()  # idempotent
+        assert np.array_equal(ctx.gather(x, [x.size]), x)  # no communicator: a world of one
+        ctx.comm_init_all()  # the single-process form (one host thread per GPU): this context is rank 0 of 1
+        ab_a, noise_a, its_a = ctx.em_dense(d_P, R, N + 1, ld, d_c, float(R), max_em_its=30, sharded=True)
+        assert its_a == its and noise_a == noise and np.array_equal(ab_a, ab)
+        ctx.comm_destroy()
     finally:
         for d in (d_P, d_c, d_x):
             if d:

@@ -8,6 +8,7 @@ from oracle import pyoracle
 from rpvg_amd import engine as eng_mod, synth
 from rpvg_amd.batch import ClusterBatch, make_params
 from rpvg_amd.rows import AlignmentBatch, RowParams
+from tests import small_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -89,3 +90,36 @@ def test_alignments_to_estimates_on_the_gpu(hip_ctx):
             assert abs(gk[key][0] - post) <= 1e-6 * max(abs(post), 1e-8) + 1e-8
             assert np.allclose(gk[key][1], ab, rtol=1e-6, atol=1e-8)
         assert dict(zip(g.em_cols, g.em_iters)) == dict(zip(w.em_cols, w.em_iters))
+
+
+# ---- the GPUs of a node behind one call (rpvg_amd/host/device_group.hpp) ---------------------------------------------
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]], ids=["one", "two-shards", "three-shards"])
+@pytest.mark.parametrize("model", ["transcripts", "haplotype-transcripts"])
+def test_device_group_shards_clusters_and_gathers(model, devices):
+    """One engine and one host thread per entry (a one-GPU box lists its GPU more than once: shards side by side);
+    every cluster gets the result it gets alone, whichever shard it lands in, and the gather returns all of them."""
+    from rpvg_amd import dist as rdist
+    batch = synth.generate(seed=31, num_clusters=60, total_paths=2500, total_reads=60000)
+    params = make_params(rng_seed=7)
+    ref, _ = pyoracle.run(model, params, batch, 2)
+    group = eng_mod.DeviceGroup(devices)
+    try:
+        got, secs = group.run(model, params, batch)
+        assert secs > 0 and len(got) == batch.num_clusters
+        for g, r in zip(got, ref):
+            gk, rk = g.keyed(), r.keyed()
+            assert set(gk) == set(rk)
+            for key, (post, ab) in rk.items():
+                assert small_cases.rel_close(gk[key][0], post, rel=1e-6) and small_cases.rel_close(gk[key][1], ab, rel=1e-6)
+        where = group.partition()
+        assert set(where.tolist()) == set(range(len(devices)))  # every shard has work
+        costs = rdist.cluster_costs(batch)
+        assert [sorted(np.nonzero(where == d)[0].tolist()) for d in range(len(devices))] == rdist.partition_clusters(costs, len(devices))
+        flat = np.concatenate([g.abundances for g in got])
+        gathered, tpm_den = group.gather(len(flat))
+        assert np.array_equal(gathered, flat)
+        assert abs(tpm_den - rdist.local_transcript_count(got, batch)) <= 1e-9 * tpm_den
+        assert not group.has_communicator()  # one GPU: RCCL wants one rank per GPU
+    finally:
+        group.close()
