@@ -58,6 +58,11 @@ int rpvg_hip_free(rpvg_hip_ctx * ctx, void * device_ptr);
 int rpvg_hip_memcpy_h2d(rpvg_hip_ctx * ctx, void * device_dst, const void * host_src, uint64_t bytes);
 int rpvg_hip_memcpy_d2h(rpvg_hip_ctx * ctx, void * host_dst, const void * device_src, uint64_t bytes);
 
+/* Page-locks a range of the caller's host memory (hipHostRegister): uploads from inside a registered range go to the
+ * GPU straight from it; anything else is staged through pinned blocks of the library's own (one more host copy). */
+int rpvg_hip_host_register(void * host, uint64_t bytes);
+int rpvg_hip_host_unregister(void * host);
+
 /* ---- cluster batch ------------------------------------------------------ */
 /* Copies the sparse rows of K clusters to the GPU once; every later call
  * refers to clusters by their index in this batch.  Replaces the per-call

@@ -78,6 +78,10 @@ bool stagedUploads();
 // (Blocks come from the pool only after the work that used them has been waited for — the rule the stream-unaware
 // pool rests on anyway.)  Measured slower than uploads on their own streams (see stagedCopy): RPVG_HIP_COPY_STREAM=1
 // turns it on.
+// host memory the caller registered with rpvg_hip_host_register (page-locked: the copy engine reads it directly)
+bool hostIsPinned(const void * host, size_t bytes);
+// memcpy; large blocks are copied by several threads (one core moves ~10 GB/s, a batch of rows is ~230 MB)
+void copyToStaging(void * staging, const void * host, size_t bytes);
 void registerCopyStream(hipStream_t stream, hipStream_t copy_stream, hipEvent_t copied);
 void forgetCopyStream(hipStream_t stream);
 hipError_t stagedCopy(void * device_dst, const void * pinned_src, size_t bytes, hipStream_t stream);
@@ -108,8 +112,11 @@ struct DeviceBuffer {
     hipError_t upload(const T * host, size_t n, hipStream_t stream) {
         hipError_t e = alloc(n);
         if (e != hipSuccess || n == 0) return e;
+        if (hostIsPinned(host, n * sizeof(T))) {  // the caller's own pinned memory (rpvg_hip_host_register): no staging
+            return hipMemcpyAsync(ptr, host, n * sizeof(T), hipMemcpyHostToDevice, stream);
+        }
         if (stagedUploads() && pinnedAlloc(&staging, n * sizeof(T)) == hipSuccess) {
-            std::memcpy(staging, host, n * sizeof(T));
+            copyToStaging(staging, host, n * sizeof(T));
             return stagedCopy(ptr, staging, n * sizeof(T), stream);
         }
         staging = nullptr;

@@ -3,6 +3,9 @@
 
 #include "common.hpp"
 
+#include <algorithm>
+#include <thread>
+
 #include <map>
 
 namespace rpvg_hip_detail {
@@ -146,6 +149,40 @@ void pinnedTrim() {
 bool stagedUploads() {
     static const bool staged = std::getenv("RPVG_HIP_PAGEABLE_UPLOADS") == nullptr;
     return staged;
+}
+
+namespace {
+std::mutex g_registered_mutex;
+std::map<const char *, size_t> g_registered;  // start -> bytes of the ranges registered through the library
+}  // namespace
+
+bool hostIsPinned(const void * host, size_t bytes) {
+    if (!host || bytes == 0) return false;
+    std::lock_guard<std::mutex> lock(g_registered_mutex);
+    if (g_registered.empty()) return false;
+    const char * p = static_cast<const char *>(host);
+    auto it = g_registered.upper_bound(p);
+    if (it == g_registered.begin()) return false;
+    --it;
+    return p >= it->first && p + bytes <= it->first + it->second;
+}
+
+void copyToStaging(void * staging, const void * host, size_t bytes) {
+    constexpr size_t kChunk = 8u << 20;
+    if (bytes < 2 * kChunk) {
+        std::memcpy(staging, host, bytes);
+        return;
+    }
+    const size_t threads = std::min<size_t>(8, (bytes + kChunk - 1) / kChunk);
+    const size_t share = ((bytes + threads - 1) / threads + 63) & ~size_t(63);
+    std::vector<std::thread> workers;
+    for (size_t t = 1; t < threads; ++t) {
+        const size_t begin = t * share;
+        if (begin >= bytes) break;
+        workers.emplace_back([=] { std::memcpy(static_cast<char *>(staging) + begin, static_cast<const char *>(host) + begin, std::min(share, bytes - begin)); });
+    }
+    std::memcpy(staging, host, std::min(share, bytes));
+    for (auto & w : workers) w.join();
 }
 
 namespace {
@@ -465,6 +502,62 @@ int rpvg_hip_memcpy_d2h(rpvg_hip_ctx * ctx, void * host_dst, const void * device
     return RPVG_HIP_OK;
 }
 
+extern "C" int rpvg_hip_host_register(void * host, uint64_t bytes) {
+    RPVG_REQUIRE(host && bytes > 0, "rpvg_hip_host_register: NULL or empty range");
+    RPVG_HIP_CHECK(hipHostRegister(host, bytes, hipHostRegisterDefault));
+    std::lock_guard<std::mutex> lock(g_registered_mutex);
+    g_registered[static_cast<const char *>(host)] = bytes;
+    return RPVG_HIP_OK;
+}
+
+extern "C" int rpvg_hip_host_unregister(void * host) {
+    RPVG_REQUIRE(host, "rpvg_hip_host_unregister: NULL");
+    {
+        std::lock_guard<std::mutex> lock(g_registered_mutex);
+        RPVG_REQUIRE(g_registered.erase(static_cast<const char *>(host)) == 1, "rpvg_hip_host_unregister: the range was not registered here");
+    }
+    RPVG_HIP_CHECK(hipHostUnregister(host));
+    return RPVG_HIP_OK;
+}
+
+namespace {
+
+// The row invariants the estimators rely on (src/main.cpp:855-887,953-973; src/read_path_probabilities.cpp:91-105,184,
+// 212-219), clusters [k0, k1); false: `message` says what is wrong.
+constexpr size_t kProblemChars = 256;
+bool validateClusters(const rpvg_cluster_batch * hb, const uint32_t k0, const uint32_t k1, char * message) {
+    message[0] = 0;
+    for (uint32_t k = k0; k < k1; ++k) {
+        if (!(hb->cluster_row_off[k] <= hb->cluster_row_off[k + 1] && hb->cluster_path_off[k] <= hb->cluster_path_off[k + 1])) {
+            std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: cluster %u has decreasing offsets", k);
+            return false;
+        }
+        const uint64_t n_paths = hb->cluster_path_off[k + 1] - hb->cluster_path_off[k];
+        if (n_paths > 0x7fffffffu) {
+            std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: cluster %u has too many paths", k);
+            return false;
+        }
+        for (uint64_t r = hb->cluster_row_off[k]; r < hb->cluster_row_off[k + 1]; ++r) {
+            const double nz = hb->row_noise[r];
+            if (!(nz > 0 && nz <= 1)) {
+                std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: row %llu has noise probability %g outside (0, 1]",
+                              static_cast<unsigned long long>(r), nz);
+                return false;
+            }
+            for (uint64_t e = hb->grp_idx_off[hb->row_grp_off[r]]; e < hb->grp_idx_off[hb->row_grp_off[r + 1]]; ++e) {
+                if (!(hb->path_idx[e] < n_paths)) {
+                    std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: row %llu refers to path %u of a cluster with %llu paths",
+                                  static_cast<unsigned long long>(r), hb->path_idx[e], static_cast<unsigned long long>(n_paths));
+                    return false;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
 int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_hip_batch ** batch_out) {
     RPVG_REQUIRE(ctx != nullptr && hb != nullptr && batch_out != nullptr, "rpvg_hip_batch_upload: NULL argument");
     *batch_out = nullptr;
@@ -479,21 +572,20 @@ int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpv
     RPVG_REQUIRE(G == 0 || hb->grp_prob, "rpvg_hip_batch_upload: grp_prob is NULL");
     RPVG_REQUIRE(NNZ == 0 || hb->path_idx, "rpvg_hip_batch_upload: path_idx is NULL");
 
-    // Validation of the row invariants the estimators rely on
-    // (src/main.cpp:855-887,953-973; src/read_path_probabilities.cpp:91-105,184,212-219).
-    for (uint32_t k = 0; k < K; ++k) {
-        RPVG_REQUIRE(hb->cluster_row_off[k] <= hb->cluster_row_off[k + 1] && hb->cluster_path_off[k] <= hb->cluster_path_off[k + 1],
-                     "rpvg_hip_batch_upload: cluster %u has decreasing offsets", k);
-        const uint64_t n_paths = hb->cluster_path_off[k + 1] - hb->cluster_path_off[k];
-        RPVG_REQUIRE(n_paths <= 0x7fffffffu, "rpvg_hip_batch_upload: cluster %u has too many paths", k);
-        for (uint64_t r = hb->cluster_row_off[k]; r < hb->cluster_row_off[k + 1]; ++r) {
-            const double nz = hb->row_noise[r];
-            RPVG_REQUIRE(nz > 0 && nz <= 1, "rpvg_hip_batch_upload: row %llu has noise probability %g outside (0, 1]",
-                         static_cast<unsigned long long>(r), nz);
-            for (uint64_t e = hb->grp_idx_off[hb->row_grp_off[r]]; e < hb->grp_idx_off[hb->row_grp_off[r + 1]]; ++e) {
-                RPVG_REQUIRE(hb->path_idx[e] < n_paths, "rpvg_hip_batch_upload: row %llu refers to path %u of a cluster with %llu paths",
-                             static_cast<unsigned long long>(r), hb->path_idx[e], static_cast<unsigned long long>(n_paths));
-            }
+    // validation: one pass over every row and entry on the host (several threads for a batch of millions of rows)
+    {
+        const uint32_t workers = R > 200000 ? std::min<uint32_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        std::vector<char> problems(workers * kProblemChars, 0);
+        std::vector<std::thread> threads;
+        for (uint32_t w = 1; w < workers; ++w) {
+            threads.emplace_back([&, w] { (void) validateClusters(hb, static_cast<uint32_t>(static_cast<uint64_t>(K) * w / workers),
+                                                                static_cast<uint32_t>(static_cast<uint64_t>(K) * (w + 1) / workers),
+                                                                problems.data() + w * kProblemChars); });
+        }
+        (void) validateClusters(hb, 0, static_cast<uint32_t>(static_cast<uint64_t>(K) / workers), problems.data());
+        for (auto & t : threads) t.join();
+        for (uint32_t w = 0; w < workers; ++w) {
+            RPVG_REQUIRE(problems[w * kProblemChars] == 0, "%s", problems.data() + w * kProblemChars);
         }
     }
 

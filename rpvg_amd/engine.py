@@ -40,6 +40,7 @@ def lib() -> C.CDLL:
         L.rpvg_amd_batch_prepare.restype = C.c_void_p
         L.rpvg_amd_batch_prepare.argtypes = [C.c_void_p, C.POINTER(CClusterBatch), C.c_int]
         L.rpvg_amd_batch_free.argtypes = [C.c_void_p]
+        L.rpvg_amd_batch_reupload.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CClusterBatch), C.POINTER(C.c_double)]
         L.rpvg_amd_batch_prepare_from_alignments.restype = C.c_void_p
         L.rpvg_amd_batch_prepare_from_alignments.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CClusterBatch), C.c_double, C.c_double,
                                                              C.c_double, C.c_uint32, C.c_int, C.c_double, C.c_double,
@@ -222,6 +223,15 @@ class PreparedBatch:
         self.handle = lib().rpvg_amd_batch_prepare(engine.handle, C.byref(cb), 1 if per_cluster else 0)
         if not self.handle:
             raise hip.EngineError(f"batch prepare failed: {_err()}")
+
+    def reupload(self, engine: "Engine", batch: Optional[ClusterBatch] = None) -> float:
+        """Replaces the resident rows by a fresh upload of `batch` (default: the batch this was prepared from) through
+        `engine` (an uploader engine on the same GPU keeps the copy off the estimating engine's streams); seconds."""
+        cb = (batch or self.batch).as_c()
+        secs = C.c_double(0)
+        if lib().rpvg_amd_batch_reupload(engine.handle, self.handle, C.byref(cb), C.byref(secs)) != 0:
+            raise hip.EngineError(f"batch reupload failed: {_err()}")
+        return secs.value
 
     def free(self):
         if self.handle:

@@ -25,7 +25,7 @@ EXPORTS = [
     "rpvg_hip_synth_dense_cluster", "rpvg_hip_stats_get", "rpvg_hip_stats_reset",
     "rpvg_hip_gibbs_read_counts", "rpvg_hip_min_path_cover", "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
     "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
-    "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_comm_init_all", "rpvg_hip_gather", "rpvg_hip_group_conditionals",
+    "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_comm_init_all", "rpvg_hip_gather", "rpvg_hip_host_register", "rpvg_hip_host_unregister", "rpvg_hip_group_conditionals",
     "rpvg_hip_alignments_upload", "rpvg_hip_alignments_free", "rpvg_hip_read_rows_build", "rpvg_hip_read_rows_to_batch",
     "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_sizes", "rpvg_hip_read_rows_free", "rpvg_hip_path_clusters", "rpvg_hip_debug_log",
 ]
@@ -181,6 +181,17 @@ class DeviceAlignments:
             self.free()
         except Exception:
             pass
+
+
+def host_register(array: np.ndarray):
+    """Page-locks the memory of a numpy array (rpvg_hip_host_register): uploads from it skip the staging copy."""
+    if array.nbytes:
+        _check(lib().rpvg_hip_host_register(C.c_void_p(array.ctypes.data), C.c_uint64(array.nbytes)), "rpvg_hip_host_register")
+
+
+def host_unregister(array: np.ndarray):
+    if array.nbytes:
+        _check(lib().rpvg_hip_host_unregister(C.c_void_p(array.ctypes.data)), "rpvg_hip_host_unregister")
 
 
 class DeviceGroups:

@@ -322,6 +322,34 @@ void * rpvg_amd_batch_prepare_from_alignments(void * engine, const rpvg_alignmen
     }
 }
 
+// A new resident copy of the rows of a prepared batch from the same host arrays (what arrives per batch in a
+// running pipeline: the rows; the PathInfo side stays).  `engine` may be another engine on the same GPU than the one
+// that estimates — an uploader with a context and stream of its own, so that the copy of batch n + 1 runs under
+// the kernels of batch n.  seconds_out = wall time of validation + H2D + expansion on the device.
+int rpvg_amd_batch_reupload(void * engine, void * prepared_batch, const rpvg_cluster_batch * batch, double * seconds_out) {
+
+    try {
+
+        PreparedBatch * prepared = static_cast<PreparedBatch *>(prepared_batch);
+        const auto start = std::chrono::steady_clock::now();
+
+        std::unique_ptr<DeviceClusterBatch> fresh(new DeviceClusterBatch(static_cast<Engine *>(engine)->hip, *batch));
+        prepared->device = std::move(fresh);
+
+        if (seconds_out) {
+
+            *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+        }
+
+        return 0;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
 void rpvg_amd_batch_free(void * prepared) {
 
     delete static_cast<PreparedBatch *>(prepared);
