@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy kernel reaches
+FP64_VALU_PEAK_TFLOPS = 78.6  # FP64 vector rate = half the 157 TF FP32 vector rate (MI355X_MICROARCH.md)
 
 
 def parse_args():
@@ -126,35 +127,67 @@ def sum_over_ranks(x, dist, torch):
     return float(t.item())
 
 
-def cpu_quota_note():
-    """The CPU time the container may use, if a cgroup limits it (the threads of the baseline share that)."""
+def cpu_quota():
+    """CPUs' worth of time the container may use if a cgroup limits it (cpu.max), else None."""
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
-            return f"; cgroup cpu.max grants {float(quota) / float(period):.0f} CPUs' worth of time"
+            return float(quota) / float(period)
     except (OSError, ValueError):
         pass
-    return ""
+    return None
+
+
+def physical_cores():
+    """Physical cores of the host (distinct (package, core) pairs of /proc/cpuinfo); hardware threads if that fails."""
+    try:
+        pairs, package = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                package = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((package, line.split(":")[1].strip()))
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_quota_note():
+    quota = cpu_quota()
+    return f"; cgroup cpu.max grants {quota:.0f} CPUs' worth of time" if quota else ""
 
 
 def cpu_baseline_s3(batch, model, params, target_seconds):
-    """The CPU oracle (OpenMP over clusters, serial inside a cluster, as src/main.cpp:829) on a strided
-    sample of the same batch, sized for about target_seconds of CPU work."""
-    import numpy as np
+    """The CPU oracle (OpenMP over clusters, serial inside a cluster, as src/main.cpp:829) on a strided sample of the
+    same batch, sized for about target_seconds of CPU work.  Threads = the cores this process can actually use:
+    min(physical cores, cgroup quota); the line with every hardware thread (oversubscribed when a quota applies) is
+    kept next to it as `all_threads`."""
     from oracle import pyoracle
-    cores = os.cpu_count() or 1
+    hardware_threads = os.cpu_count() or 1
+    quota = cpu_quota()
+    cores = max(1, min(physical_cores(), int(quota) if quota else hardware_threads))
     K = batch.num_clusters
-    probe_idx = list(range(0, K, max(1, K // 40)))
-    probe = batch.select(probe_idx)
-    _, probe_secs = pyoracle.run(model, params, probe, cores)
-    est_full = probe_secs * K / max(1, len(probe_idx))
-    stride = max(1, int(round(est_full / target_seconds)))
-    idx = list(range(0, K, stride))
-    sample = batch.select(idx)
-    _, secs = pyoracle.run(model, params, sample, cores)
-    return dict(value=sample.total_reads / secs, unit="read-pairs/s", cores=cores, kind="port",
-                sample=f"every {stride}th cluster of the batch ({len(idx)} clusters, {sample.total_reads} read pairs, "
-                       f"{secs:.2f} s): oracle/ C++ restatement, OpenMP dynamic over clusters, {cores} threads" + cpu_quota_note())
+
+    def timed(threads):
+        probe_idx = list(range(0, K, max(1, K // 40)))
+        _, probe_secs = pyoracle.run(model, params, batch.select(probe_idx), threads)
+        est_full = probe_secs * K / max(1, len(probe_idx))
+        stride = max(1, int(round(est_full / target_seconds)))
+        idx = list(range(0, K, stride))
+        sample = batch.select(idx)
+        _, secs = pyoracle.run(model, params, sample, threads)
+        return dict(value=sample.total_reads / secs, unit="read-pairs/s", cores=threads, threads=threads, kind="port",
+                    sample=f"every {stride}th cluster of the batch ({len(idx)} clusters, {sample.total_reads} read pairs, {secs:.2f} s): "
+                           f"oracle/ C++ restatement, OpenMP dynamic over clusters, {threads} threads")
+
+    line = timed(cores)
+    line.update(physical_cores=physical_cores(), hardware_threads=hardware_threads, quota_cpus=quota)
+    if hardware_threads != cores:
+        every = timed(hardware_threads)
+        line["all_threads"] = dict(value=every["value"], threads=hardware_threads, sample=every["sample"])
+    return line
 
 
 def run_s3(args, rank, local_rank, world, dist, torch):
@@ -316,15 +349,31 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         line["gathered_abundance_mass"] = gathered
     if tpm_denominator is not None:
         line["tpm_denominator"] = tpm_denominator
+    # The log-likelihood kernels (branch-and-bound search, Gibbs conditionals) are FP64-issue bound, not HBM bound: their
+    # matrices are re-read from L2.  One evaluation = one row of one column set: an add and a multiply on the
+    # running-product path (2 flop, the figure used here), a ~22-instruction logarithm on the rest.
+    evals = stats["loglik_evals"]
+    ll_ms = stats["loglik_ms"]
+    tflops = (2.0 * evals / 1e12) / (ll_ms / 1e3) if ll_ms > 0 else 0.0
+    search = dict(bound="fp64_valu", achieved=tflops, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=tflops / FP64_VALU_PEAK_TFLOPS,
+                  traffic=None, evals_per_step=evals / args.steps, flops_per_eval=2, gevals_per_s=(evals / 1e9) / (ll_ms / 1e3) if ll_ms > 0 else 0.0,
+                  ms_per_step=ll_ms / args.steps,
+                  note="device time = HIP-event spans of the log-likelihood kernels on their streams (the spans of the two host lanes "
+                       "overlap each other and the EM kernels); VALU utilisation and instructions per evaluation: profiles/ PMC passes")
+    if stats.get("search_pairs_possible"):
+        search.update(pairs_possible_per_step=stats["search_pairs_possible"] / args.steps, pairs_kept_per_step=stats["search_pairs_kept"] / args.steps,
+                      pairs_evaluated_exhaustively_per_step=stats["search_pairs_table"] / args.steps,
+                      pairs_note="possible = G(G+1)/2 per searched matrix; the pair-table path (matrices with rows x columns >= 65536) evaluates all of "
+                                 "its pairs where the reference stops at the ones its bound prunes; kept = pairs that survive the pruning")
     if s5:
-        # no EM on this path: the device work is the FP64 log-likelihood contraction of the Gibbs conditionals
-        ll_ms = stats["loglik_ms"] / max(1, stats["loglik_launches"])
-        ll_bytes = 16.0 * stats["loglik_evals"] / max(1, stats["loglik_launches"])
-        ach = (ll_bytes / 1e9) / (ll_ms / 1e3) if ll_ms > 0 else 0.0
-        line["roofline"] = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
-                                kernel="groupLoglikKernel",
-                                note="algorithmic bytes = 16 B (two matrix columns) per row-evaluation; the kernel is FP64-log "
-                                     "bound and the matrices are L2-resident, see kernels.loglik_gevals_per_s")
+        # no EM on this path: the device work is the FP64 log-likelihood contraction of the Gibbs conditionals, the rest of a
+        # step is the host's sampler state machines (the reference's mt19937 / discrete_distribution streams, draw for draw)
+        search["kernel"] = "groupConditionalKernel"
+        line["roofline"] = search
+        line["host_sampler_ms_per_step"] = ms_per_step - (stats["loglik_ms"] + stats["build_ms"] + stats["h2d_ms"]) / args.steps
+    else:
+        search["kernel"] = "boundedSearchKernel / pairTableKernel"
+        line["roofline_search"] = search
     if args.scale >= 1.0 and not s5 and DEVICE == "cuda":
         try:
             line["roofline_dense_em"] = dense_em_roofline(local_rank)

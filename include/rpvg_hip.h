@@ -318,6 +318,10 @@ typedef struct rpvg_hip_kernel_stats {
     double build_ms;          uint64_t build_launches;
     double h2d_ms;            double h2d_bytes;
     uint64_t em_iterations_total;
+    /* diploid branch-and-bound (rpvg_hip_bounded_pair_posteriors): pairs of columns the searched matrices have
+     * (G (G + 1) / 2 each), pairs among them that belong to matrices on the pair-table path (all of them evaluated),
+     * and pairs kept — the reference evaluates the kept pairs plus the ones it prunes one by one. */
+    double search_pairs_possible; double search_pairs_table; double search_pairs_kept;
 } rpvg_hip_kernel_stats;
 
 int rpvg_hip_stats_get(rpvg_hip_ctx * ctx, rpvg_hip_kernel_stats * stats_out);

@@ -997,6 +997,12 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         }
         ok(hipStreamSynchronize(st));
         ctx->stats.loglik_evals += static_cast<double>(log_evals);  // counted by the kernels
+        for (uint32_t i = 0; i < M; ++i) {
+            const double G = groups->h_num_cols[order[i]];
+            ctx->stats.search_pairs_possible += G * (G + 1) / 2;
+            if (i < num_big) ctx->stats.search_pairs_table += G * (G + 1) / 2;
+        }
+        ctx->stats.search_pairs_kept += static_cast<double>(total);
     }
     if (e != hipSuccess) {
         delete res;

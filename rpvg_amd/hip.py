@@ -65,6 +65,7 @@ class CKernelStats(C.Structure):
         ("build_ms", C.c_double), ("build_launches", C.c_uint64),
         ("h2d_ms", C.c_double), ("h2d_bytes", C.c_double),
         ("em_iterations_total", C.c_uint64),
+        ("search_pairs_possible", C.c_double), ("search_pairs_table", C.c_double), ("search_pairs_kept", C.c_double),
     ]
 
     def as_dict(self):

@@ -74,6 +74,9 @@ void HipEngine::stats(rpvg_hip_kernel_stats * stats_out) const {
         stats_out->h2d_ms += lane_stats.h2d_ms;
         stats_out->h2d_bytes += lane_stats.h2d_bytes;
         stats_out->em_iterations_total += lane_stats.em_iterations_total;
+        stats_out->search_pairs_possible += lane_stats.search_pairs_possible;
+        stats_out->search_pairs_table += lane_stats.search_pairs_table;
+        stats_out->search_pairs_kept += lane_stats.search_pairs_kept;
     }
 }
 

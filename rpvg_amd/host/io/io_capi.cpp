@@ -1,5 +1,6 @@
 // C entry points over the file formats and the replay (harness: tests bind them with ctypes).
 
+#include <algorithm>
 #include <sstream>
 #include <string>
 
@@ -57,6 +58,51 @@ extern "C" {
 const char * rpvg_amd_io_last_error(void) {
 
     return io_last_error.c_str();
+}
+
+// What parseHaplotypeTranscriptInfo (the `-f` parser, src/main.cpp:239-353) makes of a path info file, one line per
+// path in file-independent (name) order: name <tab> group_id <tab> source_count <tab> source ids ascending, comma
+// separated.  Written to out_filename.  Returns the number of paths, -1 on failure.
+int64_t rpvg_amd_info_table(const char * info_filename, int parse_haplotype_ids, int use_transcript_names, const char * out_filename) {
+
+    try {
+
+        const auto info = parseHaplotypeTranscriptInfo(info_filename, parse_haplotype_ids != 0, use_transcript_names != 0);
+
+        std::vector<const std::pair<const std::string, PathInfo> *> rows;
+
+        for (auto & entry: info) {
+
+            rows.emplace_back(&entry);
+        }
+
+        std::sort(rows.begin(), rows.end(), [](const auto * lhs, const auto * rhs) { return lhs->first < rhs->first; });
+
+        std::stringstream out;
+
+        for (auto & row: rows) {
+
+            std::vector<uint32_t> ids(row->second.source_ids.begin(), row->second.source_ids.end());
+            std::sort(ids.begin(), ids.end());
+
+            out << row->first << "\t" << row->second.name << "\t" << row->second.group_id << "\t" << row->second.source_count << "\t";
+
+            for (size_t i = 0; i < ids.size(); ++i) {
+
+                out << (i ? "," : "") << ids[i];
+            }
+
+            out << "\n";
+        }
+
+        writeTextFile(out_filename, out.str());
+        return rows.size();
+
+    } catch (const std::exception & e) {
+
+        io_last_error = e.what();
+        return -1;
+    }
 }
 
 // Writes the batch as a `--write-probs` dump and a matching `-f` path info file.

@@ -16,6 +16,8 @@ def _lib():
     L.rpvg_amd_batch_write_files.argtypes = [C.POINTER(CClusterBatch), C.c_char_p, C.c_char_p, C.c_double]
     L.rpvg_amd_batch_read_files.restype = C.c_void_p
     L.rpvg_amd_batch_read_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double]
+    L.rpvg_amd_info_table.restype = C.c_int64
+    L.rpvg_amd_info_table.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p]
     L.rpvg_amd_replay.restype = C.c_int64
     L.rpvg_amd_replay.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(CParams), C.c_char_p, C.c_int, C.c_uint32]
     L.rpvg_amd_write_estimates.restype = C.c_int
@@ -26,6 +28,23 @@ def _lib():
 
 def _fail(what):
     raise hip.EngineError(f"{what} failed: {_lib().rpvg_amd_io_last_error().decode()}")
+
+
+def info_table(info_path: str, parse_haplotype_ids: bool = True, use_transcript_names: bool = False):
+    """The `-f` parser's view of a path info file: [(key, name, group_id, source_count, [source ids ascending])], by key."""
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "table.tsv")
+        n = _lib().rpvg_amd_info_table(info_path.encode(), 1 if parse_haplotype_ids else 0, 1 if use_transcript_names else 0, out.encode())
+        if n < 0:
+            _fail("info_table")
+        rows = []
+        for line in open(out):
+            key, name, group, count, ids = line.rstrip("\n").split("\t")
+            rows.append((key, name, int(group), int(count), [int(x) for x in ids.split(",")] if ids else []))
+    assert len(rows) == n
+    return rows
 
 
 def write_batch_files(batch: ClusterBatch, probs_path: str, info_path: str, prob_precision: float = 1e-8):

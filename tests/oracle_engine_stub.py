@@ -6,7 +6,8 @@ import time
 from oracle import pyoracle
 
 _STATS = ("em_sparse_ms", "em_sparse_launches", "em_sparse_alg_bytes", "em_dense_ms", "em_dense_launches", "em_dense_alg_bytes",
-          "loglik_ms", "loglik_launches", "loglik_evals", "build_ms", "build_launches", "h2d_ms", "h2d_bytes", "em_iterations_total")
+          "loglik_ms", "loglik_launches", "loglik_evals", "build_ms", "build_launches", "h2d_ms", "h2d_bytes", "em_iterations_total",
+          "search_pairs_possible", "search_pairs_table", "search_pairs_kept")
 
 
 class Prepared:

@@ -240,3 +240,66 @@ def test_config0_plumbing_on_the_cpu(tmp_path):
     assert abs(sum(float(c[5]) for c in cols) - 1e6) < 1.0  # TPM
     assert abs(sum(float(c[4]) for c in cols) + float(lines[-1].split("\t")[4]) - 100000) < 1e-2  # read counts
     assert [int(c[1]) for c in cols] == sorted(int(c[1]) for c in cols) and int(cols[-1][1]) == back.num_clusters
+
+
+# ---- the one data file the reference holds for this path: example/pantranscriptome.txt.gz -----------------------------
+# (tests/golden/make_info_fixture.py derives the fixture in the build container; the file itself does not travel)
+
+def _info_fixture():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "info_example_pantranscriptome.json")) as f:
+        return json.load(f)
+
+
+def test_info_fixture_has_the_shape_the_survey_quotes():
+    doc = _info_fixture()
+    assert doc["num_paths"] == 36120 and doc["num_transcripts"] == 2177
+    assert doc["hsts_per_transcript"] == dict(p50=8.0, p90=39.0, p99=124.0, max=648)
+    assert round(doc["haplotypes_per_hst"]["mean"]) == 48 and doc["haplotypes_per_hst"]["max"] == 808
+    assert len(doc["first_records"]) == 20 and len(doc["last_records"]) == 20
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/example/pantranscriptome.txt.gz"), reason="the reference checkout is not here")
+def test_info_parser_reproduces_the_fixture_of_the_reference_example():
+    from tests.golden import make_info_fixture as fx
+    doc = _info_fixture()
+    table = [tuple(r) for r in rio.info_table("/root/reference/example/pantranscriptome.txt.gz", parse_haplotype_ids=True)]
+    assert fx.table_hash(table) == doc["sha256_of_parsed_table"]
+    assert [list(r) for r in table[:20]] == doc["first_records"] and [list(r) for r in table[-20:]] == doc["last_records"]
+    # without haplotype ids (`-i transcripts`, src/main.cpp:337): counted only
+    counted = rio.info_table("/root/reference/example/pantranscriptome.txt.gz", parse_haplotype_ids=False)
+    assert [r[3] for r in counted] == [r[3] for r in table] and all(not r[4] for r in counted)
+
+
+def test_info_parser_on_records_rebuilt_from_the_fixture(tmp_path):
+    """Travels: a `-f` file written from the fixture's first records parses back to them (dense ids renumbered in
+    first-seen order, src/main.cpp:315-316,325-333)."""
+    doc = _info_fixture()
+    records = doc["first_records"]
+    path = tmp_path / "info.txt"
+    with open(path, "w") as f:
+        f.write("Name\tLength\tTranscript\tHaplotypes\n")
+        for key, name, group, count, ids in records:
+            f.write(f"{key}\t1000\tT{group}\t{','.join('h%d' % i for i in ids)}\n")
+    table = rio.info_table(str(path), parse_haplotype_ids=True)
+    assert [r[0] for r in table] == [r[0] for r in records]
+    groups, haps = {}, {}
+    for key, name, group, count, ids in records:  # file order = name order here
+        groups.setdefault(group, len(groups))
+        for i in ids:
+            haps.setdefault(i, len(haps))
+    for got, (key, name, group, count, ids) in zip(table, records):
+        assert got[2] == groups[group] and got[3] == len(ids) and got[4] == sorted(haps[i] for i in ids)
+
+
+def test_s1_generator_has_the_shape_of_the_reference_example():
+    """configs[0] / S1 restates the example with generated clusters: 36 120 paths in 2 177 groups whose sizes follow the
+    example's HSTs-per-transcript distribution (a lognormal fit: the bulk within a third, the tail within 3x)."""
+    doc = _info_fixture()
+    batch = synth.generate(seed=1, num_clusters=doc["num_transcripts"], total_paths=doc["num_paths"], total_reads=100000)
+    sizes = np.diff(batch.cluster_path_off.astype(np.int64))
+    assert sizes.sum() == doc["num_paths"] and len(sizes) == doc["num_transcripts"]
+    want = doc["hsts_per_transcript"]
+    for q, key in ((50, "p50"), (90, "p90"), (99, "p99")):
+        assert abs(np.percentile(sizes, q) - want[key]) <= 0.35 * want[key], (key, np.percentile(sizes, q), want[key])
+    assert want["max"] / 3 <= sizes.max() <= want["max"] * 3
