@@ -254,6 +254,8 @@ struct EmLaunchArgs {
     const double * pent_val;
     uint32_t max_em_its;
     double max_rel_em_conv;
+    double * wide_vectors;         // problems too wide for LDS: abundance + accumulator vectors, 2 C doubles each,
+    const uint64_t * wide_off;     // [P] at this offset (emSparseKernel<..., WIDE>)
     double * abundances;           // [col_off[P]]
     double * noise_count;          // [P]
     uint32_t * iterations;         // [P]
@@ -262,15 +264,17 @@ struct EmLaunchArgs {
 // RESIDENT: the problem's compacted CSR is copied into LDS once and every EM iteration runs out of LDS
 // (small problems need up to thousands of iterations; from L2 each costs ~1.7 us of dependent-load
 // latency, from LDS a fraction of that).
-template <int BLOCK, bool RESIDENT>
+// WIDE: the abundance and accumulator vectors do not fit LDS (more than ~10 000 columns: the reference's EM has no
+// size limit, and clusters such as HLA exceed this): they live in global memory (L2), the M-step uses global FP64 atomics.
+template <int BLOCK, bool RESIDENT, bool WIDE = false>
 __global__ __launch_bounds__(BLOCK) void emSparseKernel(const EmLaunchArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     if (blockIdx.x >= args.count) return;
     const uint32_t p = args.order[blockIdx.x];
     const uint32_t C = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]) + 1;  // + noise
-    double * a = reinterpret_cast<double *>(smem_raw);  // [C] abundances (last = noise)
+    double * a = WIDE ? args.wide_vectors + args.wide_off[p] : reinterpret_cast<double *>(smem_raw);  // [C] abundances (last = noise)
     double * t = a + C;                                 // [C] M-step accumulators
-    double * red = t + C;                               // [BLOCK/64] reduction scratch
+    double * red = WIDE ? reinterpret_cast<double *>(smem_raw) : t + C;  // [BLOCK/64] reduction scratch
 
     const uint32_t n_rows = args.kept_rows[p];
     const uint64_t rb = args.row_base[p], eb = args.ent_base[p];
@@ -386,15 +390,15 @@ size_t emLdsBytes(uint32_t cols, uint32_t rows, uint32_t entries, int block, boo
     return (bytes + 15) & ~static_cast<size_t>(15);
 }
 
-template <int BLOCK, bool RESIDENT>
+template <int BLOCK, bool RESIDENT, bool WIDE = false>
 hipError_t launchEm(const EmLaunchArgs & args, size_t lds, hipStream_t stream) {
     if (args.count == 0) return hipSuccess;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&emSparseKernel<BLOCK, RESIDENT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&emSparseKernel<BLOCK, RESIDENT, WIDE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
     }
-    emSparseKernel<BLOCK, RESIDENT><<<dim3(args.count), dim3(BLOCK), lds, stream>>>(args);
+    emSparseKernel<BLOCK, RESIDENT, WIDE><<<dim3(args.count), dim3(BLOCK), lds, stream>>>(args);
     return hipGetLastError();
 }
 
@@ -860,8 +864,6 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
         ps.max_cols = std::max<uint32_t>(ps.max_cols, static_cast<uint32_t>(c1 - c0) + 1);
     }
     ps.n_cols_total = problems->col_off[P];
-    RPVG_REQUIRE(sizeof(double) * (3 * static_cast<size_t>(ps.max_cols) + 24) <= 160 * 1024,
-                 "%s: a problem with %u columns does not fit the LDS-resident abundance vector", who, ps.max_cols);
 
     scope.reset(new HostScope("problems: uploads + colmap + count launch"));
     hipStream_t st = ctx->stream;
@@ -962,7 +964,11 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     //   4-6 register-resident dense, one wave: at most 16 paths and 64 / 128 / 256 rows (emRegisterKernel)
     //   8-9 register-resident dense, one wave: 17 to 32 paths and 64 / 128 rows
     //   7  LDS-resident, sixteen waves  CSR + vectors fit 152 KB (one workgroup per CU: the whole LDS)
-    constexpr int kBins = 10;
+    //   10 too many columns for LDS-resident vectors (> ~9 700): vectors in global memory, 16 waves
+    constexpr int kBins = 11;
+    constexpr size_t kLdsLimit = 156 * 1024;
+    std::vector<uint64_t> wide_off(P, 0);
+    uint64_t wide_total = 0;
     std::vector<uint32_t> bins[kBins];
     size_t bin_lds[kBins] = {};
     static const bool use_register_kernel = std::getenv("RPVG_HIP_NO_REGISTER_EM") == nullptr;
@@ -981,6 +987,11 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
             b = 1;
         } else if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 1024, true)) <= 152 * 1024) {
             b = 7;
+        } else if (emLdsBytes(C, 0, 0, 1024, false) > kLdsLimit) {
+            b = 10;
+            lds = sizeof(double) * (1024 / 64 + 2);
+            wide_off[p] = wide_total;
+            wide_total += 2 * static_cast<uint64_t>(C);
         } else if (work <= 262144) {
             b = 2;
             lds = emLdsBytes(C, 0, 0, 256, false);
@@ -1004,9 +1015,14 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     }
 
     DeviceBuffer<uint32_t> d_order, d_iters;
-    DeviceBuffer<double> d_abund, d_noise_count;
+    DeviceBuffer<double> d_abund, d_noise_count, d_wide_vectors;
+    DeviceBuffer<uint64_t> d_wide_off;
     int span = ctx->spanBegin(FAM_H2D);
     RPVG_HIP_CHECK(d_order.upload(order.data(), P, st));
+    if (wide_total > 0) {
+        RPVG_HIP_CHECK(d_wide_off.upload(wide_off.data(), P, st));
+        RPVG_HIP_CHECK(d_wide_vectors.alloc(wide_total));
+    }
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(P * 4);
     RPVG_HIP_CHECK(d_abund.alloc(ps.n_cols_total));
@@ -1027,6 +1043,8 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     args.pent_val = ps.d_pent_val.ptr;
     args.max_em_its = max_em_its;
     args.max_rel_em_conv = max_rel_em_conv;
+    args.wide_vectors = d_wide_vectors.ptr;
+    args.wide_off = d_wide_off.ptr;
     args.abundances = d_abund.ptr;
     args.noise_count = d_noise_count.ptr;
     args.iterations = d_iters.ptr;
@@ -1054,6 +1072,8 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     RPVG_HIP_CHECK((launchEm<256, false>(args, bin_lds[2], st)));
     bin(3);
     RPVG_HIP_CHECK((launchEm<1024, false>(args, bin_lds[3], st)));
+    bin(10);
+    RPVG_HIP_CHECK((launchEm<1024, false, true>(args, bin_lds[10], st)));
     bin(7);
     RPVG_HIP_CHECK((launchEm<1024, true>(args, bin_lds[7], ctx->aux[0])));
     bin(9);
@@ -1155,6 +1175,8 @@ extern "C" int rpvg_hip_gibbs_read_counts(rpvg_hip_ctx * ctx, const rpvg_hip_bat
     args.abundance_samples = d_abund_samples.ptr;
 
     const size_t lds = (sizeof(double) * (2 * static_cast<size_t>(ps.max_cols) + 256 / 64 + 2) + 15) & ~static_cast<size_t>(15);
+    RPVG_REQUIRE(lds <= 160 * 1024, "rpvg_hip_gibbs_read_counts: a problem with %u columns does not fit the sampler's LDS-resident vectors (limit ~10 000 columns)",
+                 ps.max_cols);
     if (lds > 64 * 1024) {
         RPVG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbsReadCountKernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));

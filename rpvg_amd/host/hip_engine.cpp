@@ -45,6 +45,22 @@ HipEngine::~HipEngine() {
     rpvg_hip_destroy(context);
 }
 
+std::shared_ptr<HipEngine> HipEngine::processDefault() {
+
+    static std::mutex default_mutex;
+    static std::shared_ptr<HipEngine> default_engine;
+
+    std::lock_guard<std::mutex> lock(default_mutex);
+
+    if (!default_engine) {
+
+        const char * device = std::getenv("RPVG_AMD_DEVICE");
+        default_engine = std::make_shared<HipEngine>(device ? std::atoi(device) : 0);
+    }
+
+    return default_engine;
+}
+
 int & HipEngine::currentLane() {
 
     thread_local int lane = 0;

@@ -54,6 +54,11 @@ class HipEngine {
 
         static int deviceCount();
 
+        // The engine estimators are bound to when their constructor is called with the reference's own parameter list
+        // (src/path_abundance_estimator.hpp:22,55, src/path_posterior_estimator.hpp:22,33): one per process, on GPU
+        // RPVG_AMD_DEVICE (default 0), created on first use.  Throws EngineError without a usable GPU.
+        static std::shared_ptr<HipEngine> processDefault();
+
         // Throws EngineError carrying rpvg_hip_last_error() when status != 0.
         static void check(const int status, const char * what);
 

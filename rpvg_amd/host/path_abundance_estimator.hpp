@@ -20,7 +20,7 @@ class PathAbundanceEstimator : public PathEstimator {
 
     public:
 
-        PathAbundanceEstimator(const uint32_t max_em_its_in, const double max_rel_em_conv_in, const uint32_t num_gibbs_samples_in, const uint32_t gibbs_thin_its_in, const double prob_precision, std::shared_ptr<HipEngine> engine);
+        PathAbundanceEstimator(const uint32_t max_em_its_in, const double max_rel_em_conv_in, const uint32_t num_gibbs_samples_in, const uint32_t gibbs_thin_its_in, const double prob_precision, std::shared_ptr<HipEngine> engine = HipEngine::processDefault());
         virtual ~PathAbundanceEstimator() {};
 
         bool usesRandomNumbers() const { return num_gibbs_samples > 0; }
@@ -68,7 +68,7 @@ class MinimumPathAbundanceEstimator : public PathAbundanceEstimator {
 
     public:
 
-        MinimumPathAbundanceEstimator(const uint32_t max_em_its, const double max_rel_em_conv, const uint32_t num_gibbs_samples, const uint32_t gibbs_thin_its, const double prob_precision, std::shared_ptr<HipEngine> engine);
+        MinimumPathAbundanceEstimator(const uint32_t max_em_its, const double max_rel_em_conv, const uint32_t num_gibbs_samples, const uint32_t gibbs_thin_its, const double prob_precision, std::shared_ptr<HipEngine> engine = HipEngine::processDefault());
         ~MinimumPathAbundanceEstimator() {};
 
         void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs);
@@ -81,7 +81,7 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
 
     public:
 
-        NestedPathAbundanceEstimator(const uint32_t group_size_in, const double min_hap_prob_in, const bool infer_collapsed_in, const bool use_group_post_gibbs_in, const uint32_t max_em_its, const double max_rel_em_conv, const uint32_t num_gibbs_samples, const uint32_t gibbs_thin_its, const double prob_precision, std::shared_ptr<HipEngine> engine);
+        NestedPathAbundanceEstimator(const uint32_t group_size_in, const double min_hap_prob_in, const bool infer_collapsed_in, const bool use_group_post_gibbs_in, const uint32_t max_em_its, const double max_rel_em_conv, const uint32_t num_gibbs_samples, const uint32_t gibbs_thin_its, const double prob_precision, std::shared_ptr<HipEngine> engine = HipEngine::processDefault());
         ~NestedPathAbundanceEstimator() {};
 
         bool usesRandomNumbers() const { return !infer_collapsed || use_group_post_gibbs || num_gibbs_samples > 0; }

@@ -78,7 +78,7 @@ class PathEstimator {
 
     public:
 
-        PathEstimator(const double prob_precision_in, std::shared_ptr<HipEngine> engine_in);
+        PathEstimator(const double prob_precision_in, std::shared_ptr<HipEngine> engine_in = HipEngine::processDefault());
         virtual ~PathEstimator() {};
 
         // Reference interface (src/path_estimator.hpp:23).  path_cluster_estimates->paths

@@ -15,7 +15,7 @@ class PathPosteriorEstimator : public PathEstimator {
 
     public:
 
-        PathPosteriorEstimator(const double prob_precision, std::shared_ptr<HipEngine> engine);
+        PathPosteriorEstimator(const double prob_precision, std::shared_ptr<HipEngine> engine = HipEngine::processDefault());
         virtual ~PathPosteriorEstimator() {};
 
         void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs);
@@ -35,7 +35,7 @@ class PathGroupPosteriorEstimator : public PathPosteriorEstimator {
 
     public:
 
-        PathGroupPosteriorEstimator(const uint32_t group_size_in, const bool use_group_post_gibbs_in, const double prob_precision, std::shared_ptr<HipEngine> engine);
+        PathGroupPosteriorEstimator(const uint32_t group_size_in, const bool use_group_post_gibbs_in, const double prob_precision, std::shared_ptr<HipEngine> engine = HipEngine::processDefault());
         ~PathGroupPosteriorEstimator() {};
 
         bool usesRandomNumbers() const { return use_group_post_gibbs; }

@@ -140,3 +140,18 @@ def rel_close(a, b, rel: float = 1e-4, floor: float = 1e-8) -> bool:
     """|a-b| <= rel*max(|a|,|b|) with an absolute floor (= prob_precision): the parity bar of BASELINE.json."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return bool(np.all(np.abs(a - b) <= np.maximum(rel * np.maximum(np.abs(a), np.abs(b)), floor)))
+
+
+def build_reference_factory() -> str:
+    """Compiles tests/cpp/reference_factory.cpp — the estimator factory of src/main.cpp:766-788 with the reference's
+    constructor parameter lists — against the host library; returns the binary."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "tests", "cpp", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    binary = os.path.join(out_dir, "reference_factory")
+    host, csrc = os.path.join(root, "rpvg_amd", "host"), os.path.join(root, "rpvg_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fopenmp", "-I" + host, os.path.join(root, "tests", "cpp", "reference_factory.cpp"),
+                           "-o", binary, "-L" + host, "-lrpvg_amd_host", "-L" + csrc, "-lrpvg_hip", "-Wl,-rpath," + host, "-Wl,-rpath," + csrc])
+    return binary

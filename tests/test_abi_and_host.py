@@ -144,3 +144,16 @@ def test_batch_select_round_trips():
     for i, k in enumerate([5, 2, 9]):
         assert sub.cluster(i) == a.cluster(k)
     assert sub.total_reads == sum(sum(r[0] for r in a.cluster(k)["rows"]) for k in (5, 2, 9))
+
+
+def test_reference_factory_compiles_with_the_reference_constructor_lists():
+    """src/main.cpp:766-788 unchanged apart from the namespace: the estimators take the reference's own parameter lists
+    (the engine is a defaulted last argument); and without a GPU constructing one fails loudly."""
+    import subprocess
+    from tests import small_cases
+    binary = small_cases.build_reference_factory()
+    assert "usage" in subprocess.run([binary], capture_output=True, text=True, check=True).stdout
+    import torch
+    if not torch.cuda.is_available():
+        out = subprocess.run([binary, "transcripts"], capture_output=True, text=True)
+        assert out.returncode != 0 and "no CPU fallback" in out.stderr

@@ -69,6 +69,35 @@ def test_em_solve_matches_oracle_all_columns(hip_ctx, seed):
         assert abs(noise[i] - e.noise_count) <= REL * max(1.0, e.total_count)
 
 
+def test_em_solve_cluster_wider_than_lds(hip_ctx):
+    """A cluster with more paths than LDS-resident abundance vectors hold (~9 700 columns): the reference's EM has no
+    size limit (src/path_abundance_estimator.cpp:47-114); its vectors then live in global memory.  Next to small
+    clusters in the same call."""
+    rng = np.random.default_rng(431)
+    n_paths, n_rows = 12000, 200
+    paths = [dict(group_id=0, source_ids=[p], source_count=1, effective_length=1000.0) for p in range(n_paths)]
+    rows = []
+    for _ in range(n_rows):
+        hit = sorted(int(x) for x in rng.choice(n_paths // 20, size=int(rng.integers(1, 4)), replace=False) * 20)
+        lik = {p: float(rng.uniform(0.1, 1.0)) for p in hit}
+        rows.append(small_cases.finish_row(int(rng.integers(1, 40)), 1e-4, lik))
+    wide = dict(paths=paths, rows=small_cases.sort_and_merge(rows))
+    clusters = small_cases.make_batch_clusters(432, n_clusters=3, with_empty=False) + [wide]
+    batch = ClusterBatch.from_clusters(clusters)
+    est, _ = pyoracle.run("transcripts", make_params(max_em_its=80), batch, 2)  # (the oracle's matrix is dense: 200 x 12 001)
+    dev = hip_ctx.upload(batch)
+    ks = list(range(len(clusters)))
+    cols = [list(range(len(c["paths"]))) for c in clusters]
+    abund, noise, total, iters = hip_ctx.em_solve(dev, ks, cols, max_em_its=80)
+    for i, k in enumerate(ks):
+        e = est[k]
+        assert total[i] == e.total_count
+        assert [int(iters[i])] == e.em_iters
+        assert small_cases.rel_close(abund[i], e.abundances, rel=REL)
+        assert abs(noise[i] - e.noise_count) <= REL * max(1.0, e.total_count)
+    assert np.count_nonzero(abund[-1]) > 50 and int(iters[-1]) == 80
+
+
 @pytest.mark.parametrize("seed", [411, 412])
 def test_em_solve_column_subsets(hip_ctx, seed):
     """Subset problems (what haplotype-transcripts issues): oracle = Partial matrix -> normalise -> collapse -> EM."""

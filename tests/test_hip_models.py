@@ -383,3 +383,20 @@ def test_lane_count_does_not_change_the_result():
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(res.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] == outs[2], outs
+
+
+@pytest.mark.parametrize("model", ["transcripts", "strains", "haplotype-transcripts", "haplotypes"])
+def test_reference_shaped_factory_runs_on_the_default_engine(model):
+    """The reference's factory block (src/main.cpp:766-788) and per-cluster estimate() call (:976-977) compiled against the
+    host library: two disjoint paths with 30 and 70 reads (KAT-EM-disjoint)."""
+    import subprocess
+    binary = small_cases.build_reference_factory()
+    out = subprocess.run([binary, model], capture_output=True, text=True, check=True).stdout.split()
+    assert out[0] == model
+    if model != "haplotypes":
+        assert float(out[out.index("total") + 1]) == 100.0
+        ab = [float(x) for x in out[out.index("abundances") + 1:out.index("posteriors")]]
+        assert abs(sum(ab) - 100.0) < 1e-6 and sorted(round(a, 6) for a in ab if a > 0) == [30.0, 70.0]
+    else:
+        post = [float(x) for x in out[out.index("posteriors") + 1:]]
+        assert abs(sum(post) - 1.0) < 1e-9
