@@ -28,6 +28,8 @@ void setError(const char * fmt, ...);
         hipError_t err__ = (expr);                                                                            \
         if (err__ != hipSuccess) {                                                                            \
             rpvg_hip_detail::setError("%s failed at %s:%d: %s", #expr, __FILE__, __LINE__, hipGetErrorString(err__)); \
+            /* the buffers of this call go back to the pool on return: nothing queued may still use them */   \
+            (void) hipDeviceSynchronize();                                                                    \
             return RPVG_HIP_ERR_RUNTIME;                                                                      \
         }                                                                                                     \
     } while (0)

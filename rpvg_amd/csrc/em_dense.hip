@@ -366,8 +366,11 @@ namespace {
 int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const double * device_matrix, uint64_t num_rows,
                uint32_t num_cols, uint64_t ld, const double * device_counts, double total_count, uint32_t max_em_its,
                double max_rel_em_conv, double * abundances, double * noise_count, uint32_t * iterations) {
-    RPVG_REQUIRE(ctx && device_matrix && device_counts && abundances && noise_count && iterations, "%s: NULL argument", who);
-    RPVG_REQUIRE(num_rows > 0 && num_cols >= 2, "%s: need at least one row, one path and the noise column", who);
+    RPVG_REQUIRE(ctx && abundances && noise_count && iterations && ((device_matrix && device_counts) || (sharded && num_rows == 0)),
+                 "%s: NULL argument", who);
+    // (a rank of a row-sharded cluster may hold no rows — fewer rows than ranks —: it contributes zero column sums and
+    // takes part in every all-reduce, so that its peers do not wait for it)
+    RPVG_REQUIRE((num_rows > 0 || sharded) && num_cols >= 2, "%s: need at least one row, one path and the noise column", who);
     RPVG_REQUIRE(ld >= num_cols && (ld % 2) == 0, "%s: ld (%llu) must be even and >= num_cols (%u)", who,
                  static_cast<unsigned long long>(ld), num_cols);
     RPVG_REQUIRE((reinterpret_cast<uintptr_t>(device_matrix) % 16) == 0, "%s: matrix must be 16-byte aligned", who);
@@ -425,7 +428,10 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
                 if (sharded) {
                     // this rank's column sums -> sum over ranks (same bits on every rank) -> identical update everywhere
                     emDenseReducePartialsKernel<<<col_grid, dim3(256), 0, st>>>(C, reduce_slices, partial_ld, d_reduced.ptr, d_t.ptr, d_ctl.ptr);
-                    if (const int rc = ctx->allReduceSumF64(d_t.ptr, C)) return rc;
+                    if (const int rc = ctx->allReduceSumF64(d_t.ptr, C)) {
+                        (void) hipStreamSynchronize(st);  // the kernels queued so far use the buffers freed on return
+                        return rc;
+                    }
                     emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, 1, partial_ld, d_t.ptr, d_a.ptr, total_count,
                                                                       max_rel_em_conv, d_ctl.ptr);
                 } else {
@@ -443,7 +449,10 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
             ctx->spanEnd(span);
             if (sharded) {
                 emDenseReducePartialsKernel<<<col_grid, dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_t.ptr, d_ctl.ptr);
-                if (const int rc = ctx->allReduceSumF64(d_t.ptr, C)) return rc;
+                if (const int rc = ctx->allReduceSumF64(d_t.ptr, C)) {
+                        (void) hipStreamSynchronize(st);  // the kernels queued so far use the buffers freed on return
+                        return rc;
+                    }
                 emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, 1, partial_ld, d_t.ptr, d_a.ptr, total_count,
                                                                   max_rel_em_conv, d_ctl.ptr);
             } else {

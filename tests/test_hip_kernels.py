@@ -294,6 +294,11 @@ def test_one_rank_communicator_row_sharded_em(hip_ctx, R, N):
         ctx.comm_destroy()
         ctx.comm_destroy()  # idempotent
         assert np.array_equal(ctx.gather(x, [x.size]), x)  # no communicator: a world of one
+        ctx.comm_init(hip.Context.comm_unique_id(), 1, 0)
+        # a rank without rows (fewer rows than ranks) still joins every all-reduce with zero column sums
+        ab_e, noise_e, its_e = ctx.em_dense(d_P, 0, N + 1, ld, d_c, float(R), max_em_its=3, sharded=True)
+        assert its_e == 3 and np.all(ab_e == 0)
+        ctx.comm_destroy()
         ctx.comm_init_all()  # the single-process form (one host thread per GPU): this context is rank 0 of 1
         ab_a, noise_a, its_a = ctx.em_dense(d_P, R, N + 1, ld, d_c, float(R), max_em_its=30, sharded=True)
         assert its_a == its and noise_a == noise and np.array_equal(ab_a, ab)
