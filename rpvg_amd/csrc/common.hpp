@@ -497,6 +497,10 @@ struct rpvg_hip_groups {
     std::vector<uint64_t> h_num_rows;
     rpvg_hip_detail::DeviceBuffer<double> values;         // all matrices back to back, each column-major
     rpvg_hip_detail::DeviceBuffer<double> rowmax;         // [sum R_m]
+    // Optional second copy for the pair kernel of the diploid search (bounded_search.hip): every value halved (the
+    // search divides by the group size 2: exact), row-major, rows padded with zeros to a multiple of eight columns.
+    rpvg_hip_detail::DeviceBuffer<double> halves;         // all matrices back to back
+    rpvg_hip_detail::DeviceBuffer<uint64_t> mat_half_off; // [M] offset of matrix m in halves
     rpvg_hip_detail::DeviceBuffer<uint64_t> mat_val_off;  // [M] offset of matrix m in values
     rpvg_hip_detail::DeviceBuffer<uint64_t> mat_row_off;  // [M] offset of matrix m in rowmax
     rpvg_hip_detail::DeviceBuffer<uint64_t> mat_row0;     // [M] first batch row of the matrix's cluster

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void partitionRowsKernel(
     const uint32_t num_matrices, const uint64_t * __restrict__ mat_row_off, const uint64_t * __restrict__ mat_row0,
     const uint64_t * __restrict__ mat_rows, const double * __restrict__ row_count, const double * __restrict__ row_noise,
     uint32_t * __restrict__ row_perm, double * __restrict__ count_out, double * __restrict__ noise_out,
-    uint32_t * __restrict__ mat_fast, uint32_t * __restrict__ mat_mid) {
+    uint32_t * __restrict__ mat_fast, uint32_t * __restrict__ mat_mid, const uint32_t mid_min_rows) {
     __shared__ uint32_t class_base[kNumRowClasses];       // next free slot of every class
     __shared__ uint32_t wave_count[4][kNumRowClasses];
     const uint32_t m = blockIdx.x;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void partitionRowsKernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < kNumRowClasses) class_base[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < R; i += 256) atomicAdd(&class_base[rowClass(cnt[i], nz[i], R >= kMidMinRows)], 1u);
+    for (uint32_t i = threadIdx.x; i < R; i += 256) atomicAdd(&class_base[rowClass(cnt[i], nz[i], R >= mid_min_rows)], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t running = 0;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void partitionRowsKernel(
         const uint32_t i = c0 + threadIdx.x;
         const bool in = i < R;
         const double c = in ? cnt[i] : 0.0, z = in ? nz[i] : 0.0;
-        const uint32_t mine = in ? rowClass(c, z, R >= kMidMinRows) : kNumRowClasses;
+        const uint32_t mine = in ? rowClass(c, z, R >= mid_min_rows) : kNumRowClasses;
         uint32_t rank = 0;
 #pragma unroll
         for (uint32_t k = 0; k < kNumRowClasses; ++k) {
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
     const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
     const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
     const uint32_t * __restrict__ row_perm, const int normalise, double * __restrict__ values, double * __restrict__ rowmax,
-    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row, uint64_t * __restrict__ collapse_mask) {  // null: no row collapse
+    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row, uint64_t * __restrict__ collapse_mask,  // null: no row collapse
+    double * __restrict__ halves, const uint64_t * __restrict__ mat_half_off) {  // null: no row-major copy
     if (blockIdx.x >= num_items) return;
     const uint32_t m = item_matrix[blockIdx.x];
     const uint64_t R = mat_rows[m], r0 = mat_row0[m];
@@ -144,6 +145,11 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
             }
         }
         rm[i] = mx;
+        if (halves) {
+            const uint32_t Gp = (G + 7u) & ~7u;
+            double * H = halves + mat_half_off[m] + i * Gp;
+            for (uint32_t g = 0; g < Gp; ++g) H[g] = g < G ? M[static_cast<uint64_t>(g) * R + i] * 0.5 : 0.0;
+        }
     }
 }
 
@@ -171,7 +177,8 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
     const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
     const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
     const uint32_t * __restrict__ row_perm, const int normalise, double * __restrict__ values, double * __restrict__ rowmax,
-    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row, uint64_t * __restrict__ collapse_mask) {  // null: no row collapse
+    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row, uint64_t * __restrict__ collapse_mask,  // null: no row collapse
+    double * __restrict__ halves, const uint64_t * __restrict__ mat_half_off) {  // null: no row-major copy (pair kernel, bounded_search.hip)
     extern __shared__ double tile[];
     if (blockIdx.x >= num_items) return;
     const uint32_t m = item_matrix[blockIdx.x];
@@ -180,8 +187,9 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
     const uint32_t Rc = tileRows(G);
     const uint64_t i0 = static_cast<uint64_t>(item_chunk[blockIdx.x]) * Rc;
     const uint32_t nrows = static_cast<uint32_t>(min(static_cast<uint64_t>(Rc), R - i0));
+    const uint32_t Rs = Rc + 1;  // odd stride: a walk along a row of the tile (second loop below) meets every LDS bank
     const uint32_t cells = G * Rc;
-    for (uint32_t idx = threadIdx.x; idx < cells; idx += blockDim.x) tile[idx] = 0.0;
+    for (uint32_t idx = threadIdx.x; idx < G * Rs; idx += blockDim.x) tile[idx] = 0.0;
     __syncthreads();
     const uint32_t t = threadIdx.x;
     if (t < nrows) {
@@ -210,21 +218,21 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
             for (int k = 0; k < 4; ++k) g_first[k] = x_begin[k] < x_end[k] ? path_grp[x_begin[k]] : 0u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (x_begin[k] < x_end[k]) tile[g_first[k] * Rc + t] += v[k];
-                for (uint64_t x = x_begin[k] + 1; x < x_end[k]; ++x) tile[path_grp[x] * Rc + t] += v[k];
+                if (x_begin[k] < x_end[k]) tile[g_first[k] * Rs + t] += v[k];
+                for (uint64_t x = x_begin[k] + 1; x < x_end[k]; ++x) tile[path_grp[x] * Rs + t] += v[k];
             }
         }
         double mx = 0.0;
         if (normalise) {
             double rowsum = 0.0;
-            for (uint32_t g = 0; g < G; ++g) rowsum += tile[g * Rc + t];
+            for (uint32_t g = 0; g < G; ++g) rowsum += tile[g * Rs + t];
             const double keep = 1 - row_noise[r];
             double key = collapseWeight(G) * row_noise[r];
             uint64_t pattern = 0;
             for (uint32_t g = 0; g < G; ++g) {
-                double v = (tile[g * Rc + t] / rowsum) * keep;
+                double v = (tile[g * Rs + t] / rowsum) * keep;
                 if (v != v) v = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
-                tile[g * Rc + t] = v;
+                tile[g * Rs + t] = v;
                 mx = (g == 0) ? v : fmax(mx, v);
                 key = fma(collapseWeight(g), v, key);
                 if (g < 64 && v != 0.0) pattern |= 1ull << g;
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
             }
         } else {
             for (uint32_t g = 0; g < G; ++g) {
-                const double v = tile[g * Rc + t];
+                const double v = tile[g * Rs + t];
                 mx = (g == 0) ? v : fmax(mx, v);
             }
         }
@@ -247,7 +255,17 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
     const uint32_t shift = 31 - __clz(Rc);
     for (uint32_t idx = threadIdx.x; idx < cells; idx += blockDim.x) {
         const uint32_t g = idx >> shift, tt = idx & (Rc - 1);
-        if (tt < nrows) M[static_cast<uint64_t>(g) * R + i0 + tt] = tile[idx];
+        if (tt < nrows) M[static_cast<uint64_t>(g) * R + i0 + tt] = tile[g * Rs + tt];
+    }
+    if (halves) {
+        // the same values halved (exact), row-major with the row padded to a multiple of eight columns (zeros): lane =
+        // column in the pair kernel, the first columns of a pair come through scalar loads of eight
+        const uint32_t Gp = (G + 7u) & ~7u;
+        double * H = halves + mat_half_off[m] + i0 * Gp;
+        for (uint32_t idx = threadIdx.x; idx < nrows * Gp; idx += blockDim.x) {
+            const uint32_t tt = idx / Gp, g = idx - tt * Gp;
+            H[idx] = g < G ? tile[g * Rs + tt] * 0.5 : 0.0;
+        }
     }
 }
 
@@ -452,7 +470,8 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     std::vector<uint64_t> val_off(M), row_off(M), row0(M), rows(M), inc_off(M), num_paths(M);
     std::vector<uint32_t> cols(M), item_matrix, item_chunk, tile_matrix, tile_chunk;
     std::vector<uint32_t> wide_matrices;  // too many columns for an LDS tile: global-memory kernel on zero-filled storage
-    uint64_t val_total = 0, row_total = 0, inc_total = 0;
+    uint64_t val_total = 0, row_total = 0, inc_total = 0, half_total = 0;
+    std::vector<uint64_t> half_off(M, 0);
     for (uint32_t m = 0; m < M; ++m) {
         const uint32_t k = spec->cluster[m];
         if (k >= batch->num_clusters) {
@@ -480,6 +499,8 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         val_off[m] = val_total;
         row_off[m] = row_total;
         inc_off[m] = inc_total;
+        half_off[m] = half_total;
+        half_total += R * (((g1 - g0) + 7) & ~uint64_t(7));
         val_total += R * (g1 - g0);
         row_total += R;
         inc_total += N + 1;
@@ -556,6 +577,10 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     ok(g->row_noise.alloc(row_total));
     ok(g->mat_fast.alloc(M));
     ok(g->mat_mid.alloc(M));
+    if (spec->pair_layout) {
+        ok(g->mat_half_off.upload(half_off.data(), M, st));
+        ok(g->halves.alloc(half_total));
+    }
     if (collapse) {
         std::vector<uint32_t> segment_off(M + 1);
         for (uint32_t m = 0; m < M; ++m) segment_off[m] = static_cast<uint32_t>(row_off[m]);
@@ -586,7 +611,9 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         }
         partitionRowsKernel<<<dim3(M), dim3(256), 0, st>>>(M, g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, batch->row_count.ptr,
                                                            batch->row_noise.ptr, g->row_perm.ptr, g->row_count.ptr, g->row_noise.ptr,
-                                                           g->mat_fast.ptr, g->mat_mid.ptr);
+                                                           g->mat_fast.ptr, g->mat_mid.ptr,
+                                                           // (the pair kernel's count loop is cheap for every matrix: bounded_search.hip)
+                                                           spec->pair_layout ? 1u : kMidMinRows);
         const uint32_t col_blocks = static_cast<uint32_t>((num_columns + 255) / 256);
         incidenceCountKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,
                                                                    d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
@@ -596,18 +623,18 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
                                                                   d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
                                                                   d_path_grp_off.ptr, d_cursor.ptr, d_path_grp.ptr);
         if (!tile_matrix.empty()) {
-            groupsBuildTileKernel<<<dim3(static_cast<uint32_t>(tile_matrix.size())), dim3(256), kTileDoubles * sizeof(double), st>>>(
+            groupsBuildTileKernel<<<dim3(static_cast<uint32_t>(tile_matrix.size())), dim3(256), (kTileDoubles + 256) * sizeof(double), st>>>(
                 static_cast<uint32_t>(tile_matrix.size()), d_tile_matrix.ptr, d_tile_chunk.ptr, g->mat_val_off.ptr,
                 g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
                 d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
-                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_mask.ptr);
+                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_mask.ptr, g->halves.ptr, g->mat_half_off.ptr);
         }
         if (!item_matrix.empty()) {
             groupsBuildKernel<<<dim3(static_cast<uint32_t>(item_matrix.size())), dim3(256), 0, st>>>(
                 static_cast<uint32_t>(item_matrix.size()), d_item_matrix.ptr, d_item_chunk.ptr, g->mat_val_off.ptr,
                 g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
                 d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
-                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_mask.ptr);
+                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_mask.ptr, g->halves.ptr, g->mat_half_off.ptr);
         }
         sub.reset(new HostScope("groups_build: row collapse launches"));
         if (collapse && e == hipSuccess) ok(queueRowCollapse(ctx, g, row_total, spec->collapse_precision, st));

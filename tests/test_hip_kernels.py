@@ -407,8 +407,11 @@ def test_stats_report_kernel_time(hip_ctx):
 
 # ---- on-device diploid branch-and-bound ---------------------------------------------------
 
+@pytest.mark.parametrize("pair_layout", [False, True], ids=["sequential", "all-pairs"])
 @pytest.mark.parametrize("normalise,thr", [(True, 1e-3), (False, 1e-8)])
-def test_bounded_search_on_device_matches_oracle(hip_ctx, normalise, thr):
+def test_bounded_search_on_device_matches_oracle(hip_ctx, normalise, thr, pair_layout):
+    """pair_layout: every pair from the row-major copy (pairRowsKernel) + prefix-maximum filter instead of the sequential
+    in-workgroup walk — the kept pairs and their order are the reference's either way."""
     rng = np.random.default_rng(701)
     clusters = small_cases.make_batch_clusters(702, n_clusters=10, with_empty=False)
     clusters.append(small_cases.make_cluster(rng, 3, [9, 7, 8], n_haps=40, n_reads=1500))
@@ -425,7 +428,7 @@ def test_bounded_search_on_device_matches_oracle(hip_ctx, normalise, thr):
         mats.append(k)
         groups.append(g)
         counts.append(mult)
-    dg = hip_ctx.groups(dev, mats, groups, normalise)
+    dg = hip_ctx.groups(dev, mats, groups, normalise, pair_layout=pair_layout)
     got = dg.bounded_pair_posteriors(np.concatenate(counts), thr)
     for m, (k, g) in enumerate(zip(mats, groups)):
         cl = clusters[k]
