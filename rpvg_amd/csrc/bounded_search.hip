@@ -59,10 +59,18 @@ void searchGateForget(const rpvg_hip_ctx * ctx) {
     if (g_search_gate_owner == ctx) g_search_gate_owner = nullptr;
 }
 
+// the kept pairs of every matrix: one page-locked block [posterior: total f64 | first: total u32 | second: total u32],
+// filled by one D2H copy
 struct rpvg_hip_pair_posteriors {
     std::vector<uint64_t> pair_off;
-    std::vector<uint32_t> first, second;
-    std::vector<double> posterior;
+    void * block = nullptr;
+    bool block_pinned = false;
+    const uint32_t * first = nullptr, * second = nullptr;
+    const double * posterior = nullptr;
+    ~rpvg_hip_pair_posteriors() {
+        if (block && block_pinned) pinnedFree(block);
+        else std::free(block);
+    }
 };
 
 namespace {
@@ -869,14 +877,44 @@ __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args
     }
 }
 
-// copies the kept pairs of every matrix into dense arrays
-__global__ void compactPairsKernel(const uint32_t num_matrices, const uint64_t * __restrict__ pair_cap_off,
-                                   const uint64_t * __restrict__ pair_off, const uint32_t * __restrict__ in_first,
-                                   const uint32_t * __restrict__ in_second, const double * __restrict__ in_value,
-                                   uint32_t * __restrict__ out_first, uint32_t * __restrict__ out_second,
-                                   double * __restrict__ out_value) {
+// exclusive prefix of the kept-pair counts (one workgroup: a batch has a few thousand matrices); also fetches the
+// validity flag of the matrices' build, so that one D2H copy brings everything the host waits for
+__global__ void __launch_bounds__(1024) pairOffsetsKernel(const uint32_t num_matrices, const uint32_t * __restrict__ counts,
+                                                          uint64_t * __restrict__ pair_off, const uint32_t * __restrict__ build_error,
+                                                          uint32_t * __restrict__ build_error_out) {
+    __shared__ uint64_t sums[1024];
+    const uint32_t per = (num_matrices + 1023) / 1024;
+    const uint32_t lo = min(num_matrices, threadIdx.x * per), hi = min(num_matrices, lo + per);
+    uint64_t mine = 0;
+    for (uint32_t m = lo; m < hi; ++m) mine += counts[m];
+    sums[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t step = 1; step < 1024; step <<= 1) {
+        const uint64_t add = threadIdx.x >= step ? sums[threadIdx.x - step] : 0;
+        __syncthreads();
+        sums[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint64_t run = sums[threadIdx.x] - mine;
+    for (uint32_t m = lo; m < hi; ++m) {
+        pair_off[m] = run;
+        run += counts[m];
+    }
+    if (threadIdx.x == 1023) pair_off[num_matrices] = sums[1023];
+    if (threadIdx.x == 0 && build_error) *build_error_out = *build_error;
+}
+
+// copies the kept pairs of every matrix into one dense block [value: total f64 | first: total u32 | second: total u32]
+__global__ void compactPairsBlockKernel(const uint32_t num_matrices, const uint64_t * __restrict__ pair_cap_off,
+                                        const uint64_t * __restrict__ pair_off, const uint32_t * __restrict__ in_first,
+                                        const uint32_t * __restrict__ in_second, const double * __restrict__ in_value,
+                                        unsigned char * __restrict__ block) {
     const uint32_t m = blockIdx.x;
     if (m >= num_matrices) return;
+    const uint64_t total = pair_off[num_matrices];
+    double * out_value = reinterpret_cast<double *>(block);
+    uint32_t * out_first = reinterpret_cast<uint32_t *>(block + total * sizeof(double));
+    uint32_t * out_second = out_first + total;
     const uint64_t src = pair_cap_off[m], dst = pair_off[m], n = pair_off[m + 1] - pair_off[m];
     for (uint64_t k = threadIdx.x; k < n; k += blockDim.x) {
         out_first[dst + k] = in_first[src + k];
@@ -996,15 +1034,31 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         show("small", num_big + num_medium, M - num_big - num_medium);
     }
 
-    DeviceBuffer<uint32_t> d_order, d_col_count, d_col_order, d_out_first, d_out_second, d_out_count, d_first, d_second;
+    DeviceBuffer<uint32_t> d_order, d_col_count, d_col_order, d_out_first, d_out_second;
     DeviceBuffer<uint64_t> d_col_off, d_pair_cap_off, d_pair_off;
-    DeviceBuffer<double> d_lf, d_marg, d_opt_raw, d_opt, d_out_value, d_value;
+    DeviceBuffer<double> d_lf, d_marg, d_opt_raw, d_opt, d_out_value;
 
+    // every host array of the search in one block, one copy (UploadPack: a command per array was 1 ms per search)
+    UploadPack pack;
+    DeviceBuffer<uint32_t> d_item_matrix, d_item_col, d_item_chunk;
+    DeviceBuffer<uint64_t> d_big_col_part_off, d_big_pair_part_off;
+    pack.add(d_order, order.data(), M);
+    pack.add(d_col_off, col_off.data(), M + 1);
+    pack.add(d_pair_cap_off, pair_cap_off.data(), M + 1);
+    pack.add(d_col_count, column_counts, col_off[M]);
+    if (num_big > 0) {
+        pack.add(d_item_matrix, item_matrix.data(), item_matrix.size());
+        pack.add(d_item_col, item_col.data(), item_col.size());
+        pack.add(d_item_chunk, item_chunk.data(), item_chunk.size());
+        pack.add(d_big_col_part_off, big_col_part_off.data(), M);
+        pack.add(d_big_pair_part_off, big_pair_part_off.data(), M);
+    }
+    // [kept pairs per matrix: M words | evaluation counter: 2 words | validity flag of the build | -]: what the host reads first
+    const uint32_t evals_word = (M + 1) & ~1u, tail_words = evals_word + 4;
+    DeviceBuffer<uint32_t> d_tail;
+    pack.addZero(d_tail, tail_words);
     int span = ctx->spanBegin(FAM_H2D);
-    ok(d_order.upload(order.data(), M, st));
-    ok(d_col_off.upload(col_off.data(), M + 1, st));
-    ok(d_pair_cap_off.upload(pair_cap_off.data(), M + 1, st));
-    ok(d_col_count.upload(column_counts, col_off[M], st));
+    ok(pack.commit(st));
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(M * 20 + col_off[M] * 4);
     ok(d_lf.alloc(col_off[M]));
@@ -1015,7 +1069,6 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     ok(d_out_first.alloc(pair_cap_off[M]));
     ok(d_out_second.alloc(pair_cap_off[M]));
     ok(d_out_value.alloc(pair_cap_off[M]));
-    ok(d_out_count.alloc(M));
     if (e != hipSuccess) {
         delete res;
         setError("rpvg_hip_bounded_pair_posteriors: %s", hipGetErrorString(e));
@@ -1047,21 +1100,11 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     args.out_first = d_out_first.ptr;
     args.out_second = d_out_second.ptr;
     args.out_value = d_out_value.ptr;
-    args.out_count = d_out_count.ptr;
+    args.out_count = d_tail.ptr;
 
-    DeviceBuffer<unsigned long long> d_log_evals;
-    ok(d_log_evals.alloc(1));
-    if (e == hipSuccess) ok(hipMemsetAsync(d_log_evals.ptr, 0, sizeof(unsigned long long), st));
-    args.log_evals = d_log_evals.ptr;
-    DeviceBuffer<uint32_t> d_item_matrix, d_item_col, d_item_chunk;
-    DeviceBuffer<uint64_t> d_big_col_part_off, d_big_pair_part_off;
+    args.log_evals = reinterpret_cast<unsigned long long *>(d_tail.ptr + evals_word);
     DeviceBuffer<double> d_part_marg, d_part_opt, d_part_pair, d_seq;
     if (num_big > 0) {
-        ok(d_item_matrix.upload(item_matrix.data(), item_matrix.size(), st));
-        ok(d_item_col.upload(item_col.data(), item_col.size(), st));
-        ok(d_item_chunk.upload(item_chunk.data(), item_chunk.size(), st));
-        ok(d_big_col_part_off.upload(big_col_part_off.data(), M, st));
-        ok(d_big_pair_part_off.upload(big_pair_part_off.data(), M, st));
         ok(d_part_marg.alloc(col_part_total));
         ok(d_part_opt.alloc(col_part_total));
         ok(d_part_pair.alloc(pair_part_total));
@@ -1107,7 +1150,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         tw.part_marginal = d_part_marg.ptr;
         tw.part_optimistic = d_part_opt.ptr;
         tw.part_pair = d_part_pair.ptr;
-        tw.log_evals = d_log_evals.ptr;
+        tw.log_evals = args.log_evals;
         if (pair_rows) {
             PairRowsWork pw;
             pw.item_matrix = d_item_matrix.ptr;
@@ -1127,7 +1170,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
             pw.pair_part_off = d_big_pair_part_off.ptr;
             pw.part_marginal = d_part_marg.ptr;
             pw.part_pair = d_part_pair.ptr;
-            pw.log_evals = d_log_evals.ptr;
+            pw.log_evals = args.log_evals;
             pw.debug_skip = std::getenv("RPVG_HIP_PAIR_DEBUG") ? static_cast<uint32_t>(std::atoi(std::getenv("RPVG_HIP_PAIR_DEBUG"))) : 0u;
             pairRowsKernel<true><<<dim3(((pw.count + 7) / 8) * 8), dim3(64), 0, st>>>(pw);
             pairRowsKernel<false><<<dim3(((pw.count + 7) / 8) * 8), dim3(64), 0, st>>>(pw);
@@ -1156,7 +1199,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         ra.out_first = d_out_first.ptr;
         ra.out_second = d_out_second.ptr;
         ra.out_value = d_out_value.ptr;
-        ra.out_count = d_out_count.ptr;
+        ra.out_count = d_tail.ptr;
         resolveTableKernel<<<dim3(num_big), dim3(256), 0, st>>>(ra);
     }
     // the rest walk the search inside one workgroup; matrices with few rows stage less LDS (more
@@ -1189,40 +1232,56 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     ctx->stats.loglik_launches += (num_big > 0 ? 2 : 0) + (num_medium > 0) + (M > num_big + num_medium);
     ok(hipGetLastError());
 
+    // offsets of the kept pairs and their dense copy are queued behind the search: the host waits once for the counts
+    // (with the evaluation counter and the validity flag of the matrices' build), once for the pairs
+    DeviceBuffer<unsigned char> d_block;
+    ok(d_pair_off.alloc(M + 1));
+    ok(d_block.alloc(pair_cap_off[M] * 16));
+    void * host_tail = nullptr;
+    const size_t tail_bytes = tail_words * sizeof(uint32_t);
+    if (e == hipSuccess && pinnedAlloc(&host_tail, tail_bytes) != hipSuccess) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) {
+        const bool check_build = !groups->build_checked && groups->build_error_flag.ptr;
+        pairOffsetsKernel<<<dim3(1), dim3(1024), 0, st>>>(M, d_tail.ptr, d_pair_off.ptr, check_build ? groups->build_error_flag.ptr : nullptr,
+                                                         d_tail.ptr + evals_word + 2);
+        compactPairsBlockKernel<<<dim3(M), dim3(64), 0, st>>>(M, d_pair_cap_off.ptr, d_pair_off.ptr, d_out_first.ptr, d_out_second.ptr,
+                                                             d_out_value.ptr, d_block.ptr);
+        ok(hipGetLastError());
+        ok(hipMemcpyAsync(host_tail, d_tail.ptr, tail_bytes, hipMemcpyDeviceToHost, st));
+    }
     scope.reset(new HostScope("bounded search: wait for the kernels"));
-    std::vector<uint32_t> counts(M);
-    unsigned long long log_evals = 0;
-    ok(d_out_count.download(counts.data(), st));
-    ok(hipMemcpyAsync(&log_evals, d_log_evals.ptr, sizeof(log_evals), hipMemcpyDeviceToHost, st));
     ok(hipStreamSynchronize(st));
     if (e == hipSuccess) {
-        const int build_status = groups->buildError(st);  // the matrices were built without a host sync
-        if (build_status != RPVG_HIP_OK) {
-            delete res;
-            return build_status;
-        }
-    }
-    scope.reset(new HostScope("bounded search: compact + download pairs"));
-    if (e == hipSuccess) {
+        const uint32_t * counts = static_cast<const uint32_t *>(host_tail);
+        unsigned long long log_evals = 0;
+        std::memcpy(&log_evals, counts + evals_word, sizeof(log_evals));
+        const uint32_t build_bad = counts[evals_word + 2];
         for (uint32_t m = 0; m < M; ++m) res->pair_off[m + 1] = res->pair_off[m] + counts[m];
-        const uint64_t total = res->pair_off[M];
-        res->first.resize(total);
-        res->second.resize(total);
-        res->posterior.resize(total);
-        ok(d_pair_off.upload(res->pair_off.data(), M + 1, st));
-        ok(d_first.alloc(total));
-        ok(d_second.alloc(total));
-        ok(d_value.alloc(total));
-        if (e == hipSuccess && total > 0) {
-            compactPairsKernel<<<dim3(M), dim3(64), 0, st>>>(M, d_pair_cap_off.ptr, d_pair_off.ptr, d_out_first.ptr,
-                                                            d_out_second.ptr, d_out_value.ptr, d_first.ptr, d_second.ptr,
-                                                            d_value.ptr);
-            ok(hipGetLastError());
-            ok(d_first.download(res->first.data(), st));
-            ok(d_second.download(res->second.data(), st));
-            ok(d_value.download(res->posterior.data(), st));
+        pinnedFree(host_tail);
+        host_tail = nullptr;
+        if (build_bad) {  // the matrices were built without a host sync
+            delete res;
+            setError("rpvg_hip_groups_build: a group refers to a path outside its cluster");
+            return RPVG_HIP_ERR_INVALID;
         }
-        ok(hipStreamSynchronize(st));
+        groups->build_checked = true;
+        scope.reset(new HostScope("bounded search: download pairs"));
+        const uint64_t total = res->pair_off[M];
+        if (total > 0) {
+            if (pinnedAlloc(&res->block, total * 16) == hipSuccess) {
+                res->block_pinned = true;
+            } else {
+                res->block = std::malloc(total * 16);
+                if (!res->block) e = hipErrorOutOfMemory;
+            }
+            if (e == hipSuccess) {
+                ok(hipMemcpyAsync(res->block, d_block.ptr, total * 16, hipMemcpyDeviceToHost, st));
+                ok(hipStreamSynchronize(st));
+                res->posterior = static_cast<const double *>(res->block);
+                res->first = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(res->block) + total * sizeof(double));
+                res->second = res->first + total;
+            }
+        }
         ctx->stats.loglik_evals += static_cast<double>(log_evals);  // counted by the kernels
         for (uint32_t i = 0; i < M; ++i) {
             const double G = groups->h_num_cols[order[i]];
@@ -1231,6 +1290,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         }
         ctx->stats.search_pairs_kept += static_cast<double>(total);
     }
+    if (host_tail) pinnedFree(host_tail);
     if (e != hipSuccess) {
         delete res;
         setError("rpvg_hip_bounded_pair_posteriors: %s", hipGetErrorString(e));
@@ -1244,9 +1304,9 @@ extern "C" int rpvg_hip_pair_posteriors_get(const rpvg_hip_pair_posteriors * res
     RPVG_REQUIRE(result && view_out, "rpvg_hip_pair_posteriors_get: NULL argument");
     view_out->num_matrices = static_cast<uint32_t>(result->pair_off.size() - 1);
     view_out->pair_off = result->pair_off.data();
-    view_out->first = result->first.data();
-    view_out->second = result->second.data();
-    view_out->posterior = result->posterior.data();
+    view_out->first = result->first;
+    view_out->second = result->second;
+    view_out->posterior = result->posterior;
     return RPVG_HIP_OK;
 }
 

@@ -14,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/rpvg_hip.h"
@@ -94,22 +95,31 @@ struct DeviceBuffer {
     T * ptr = nullptr;
     size_t count = 0;
     void * staging = nullptr;  // pinned block the last upload went through
+    bool borrowed = false;     // ptr points into a block owned elsewhere
     DeviceBuffer() {}
     DeviceBuffer(const DeviceBuffer &) = delete;
     DeviceBuffer & operator=(const DeviceBuffer &) = delete;
     ~DeviceBuffer() { release(); }
     void release() {
-        if (ptr) poolFree(ptr);
+        if (ptr && !borrowed) poolFree(ptr);
         if (staging) pinnedFree(staging);
         ptr = nullptr;
         staging = nullptr;
         count = 0;
+        borrowed = false;
     }
     hipError_t alloc(size_t n) {
         release();
         count = n;
         if (n == 0) return hipSuccess;
         return poolAlloc(reinterpret_cast<void **>(&ptr), n * sizeof(T));
+    }
+    // part of a block somebody else owns (UploadPack): nothing to free
+    void borrow(T * p, size_t n) {
+        release();
+        ptr = n ? p : nullptr;
+        count = n;
+        borrowed = true;
     }
     hipError_t upload(const T * host, size_t n, hipStream_t stream) {
         hipError_t e = alloc(n);
@@ -127,6 +137,113 @@ struct DeviceBuffer {
     hipError_t download(T * host, hipStream_t stream) const {
         if (count == 0) return hipSuccess;
         return hipMemcpyAsync(host, ptr, count * sizeof(T), hipMemcpyDeviceToHost, stream);
+    }
+};
+
+// ---- several small uploads as one --------------------------------------------
+// A command queued on a stream costs the submitting thread 60-100 us when another host lane is submitting too: the ten
+// little arrays a search uploads one by one were 1 ms of every lane's critical path (rocprofv3 kernel trace, round 2).
+// The pack lays the arrays out in ONE device block (256-byte aligned pieces), fills one pinned staging block and queues
+// one H2D copy; pieces that only need zeros sit behind the copied part and take one memset.  The device buffers handed
+// to add()/addZero() become views of the block (DeviceBuffer::borrow): the pack has to outlive their use.
+struct UploadPack {
+    struct Piece {
+        const void * host;
+        size_t bytes, offset;
+        std::function<void(unsigned char *)> bind;
+    };
+    std::vector<Piece> pieces, zeros;
+    size_t copied_bytes = 0, zero_bytes = 0;
+    DeviceBuffer<unsigned char> block;
+    std::vector<unsigned char> pageable;  // RPVG_HIP_PAGEABLE_UPLOADS=1: assembled here instead of a pinned block
+    static size_t aligned(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+    template <typename T>
+    void add(DeviceBuffer<T> & target, const T * host, size_t n) {
+        DeviceBuffer<T> * t = &target;
+        pieces.push_back(Piece{host, n * sizeof(T), copied_bytes, [t, n](unsigned char * at) { t->borrow(reinterpret_cast<T *>(at), n); }});
+        copied_bytes += aligned(n * sizeof(T));
+    }
+    template <typename T>
+    void addZero(DeviceBuffer<T> & target, size_t n) {
+        DeviceBuffer<T> * t = &target;
+        zeros.push_back(Piece{nullptr, n * sizeof(T), zero_bytes, [t, n](unsigned char * at) { t->borrow(reinterpret_cast<T *>(at), n); }});
+        zero_bytes += aligned(n * sizeof(T));
+    }
+    hipError_t commit(hipStream_t stream) {
+        hipError_t e = block.alloc(copied_bytes + zero_bytes);
+        if (e != hipSuccess || block.count == 0) {
+            for (auto & p : pieces) p.bind(nullptr);
+            for (auto & p : zeros) p.bind(nullptr);
+            return e;
+        }
+        if (copied_bytes > 0) {
+            unsigned char * host_block = nullptr;
+            if (stagedUploads() && pinnedAlloc(&block.staging, copied_bytes) == hipSuccess) {
+                host_block = static_cast<unsigned char *>(block.staging);
+            } else {
+                block.staging = nullptr;
+                pageable.resize(copied_bytes);
+                host_block = pageable.data();
+            }
+            for (auto & p : pieces) {
+                if (p.bytes) copyToStaging(host_block + p.offset, p.host, p.bytes);
+            }
+            e = block.staging ? stagedCopy(block.ptr, host_block, copied_bytes, stream)
+                              : hipMemcpyAsync(block.ptr, host_block, copied_bytes, hipMemcpyHostToDevice, stream);
+            if (e != hipSuccess) return e;
+        }
+        if (zero_bytes > 0) {
+            e = hipMemsetAsync(block.ptr + copied_bytes, 0, zero_bytes, stream);
+            if (e != hipSuccess) return e;
+        }
+        for (auto & p : pieces) p.bind(block.ptr + p.offset);
+        for (auto & p : zeros) p.bind(block.ptr + copied_bytes + p.offset);
+        return hipSuccess;
+    }
+};
+
+// The same for results: the device arrays are views of one block, fetch() queues ONE D2H copy into a pinned block
+// (a copy into pageable memory is staged by the runtime and holds the calling thread), scatter() hands the pieces to
+// the caller's arrays once the stream has been waited for.
+struct DownloadPack {
+    struct Piece {
+        void * host;
+        size_t bytes, offset;
+        std::function<void(unsigned char *)> bind;
+    };
+    std::vector<Piece> pieces;
+    size_t total = 0;
+    DeviceBuffer<unsigned char> block;
+    void * pinned = nullptr;
+    std::vector<unsigned char> pageable;
+    DownloadPack() {}
+    DownloadPack(const DownloadPack &) = delete;
+    DownloadPack & operator=(const DownloadPack &) = delete;
+    ~DownloadPack() { if (pinned) pinnedFree(pinned); }
+    template <typename T>
+    void add(DeviceBuffer<T> & target, T * host, size_t n) {
+        DeviceBuffer<T> * t = &target;
+        pieces.push_back(Piece{host, n * sizeof(T), total, [t, n](unsigned char * at) { t->borrow(reinterpret_cast<T *>(at), n); }});
+        total += UploadPack::aligned(n * sizeof(T));
+    }
+    hipError_t alloc() {
+        hipError_t e = block.alloc(total);
+        for (auto & p : pieces) p.bind(block.ptr ? block.ptr + p.offset : nullptr);
+        return e;
+    }
+    hipError_t fetch(hipStream_t stream) {
+        if (total == 0) return hipSuccess;
+        if (!pinned && pinnedAlloc(&pinned, total) != hipSuccess) {
+            pinned = nullptr;
+            pageable.resize(total);
+        }
+        return hipMemcpyAsync(pinned ? pinned : pageable.data(), block.ptr, total, hipMemcpyDeviceToHost, stream);
+    }
+    void scatter() {
+        const unsigned char * from = static_cast<const unsigned char *>(pinned ? pinned : pageable.data());
+        for (auto & p : pieces) {
+            if (p.bytes) copyToStaging(p.host, from + p.offset, p.bytes);
+        }
     }
 };
 
@@ -525,6 +642,7 @@ struct rpvg_hip_groups {
     rpvg_hip_detail::DeviceBuffer<uint64_t> collapse_mask; // [sum R_m] zero pattern of the first 64 columns
     rpvg_hip_detail::DeviceBuffer<uint32_t> collapse_segment_off;  // [M + 1] mat_row_off as 32-bit segment offsets
     rpvg_hip_detail::DeviceBuffer<uint32_t> collapse_info;
+    rpvg_hip_detail::UploadPack uploads;  // the block behind the small arrays (views: mat_*, build temporaries, build_error_flag)
     mutable bool build_checked = false;
     // RPVG_HIP_OK, or the error of the build (after a sync of `stream`); consumers call it before trusting results
     int buildError(hipStream_t stream) const;

@@ -839,6 +839,8 @@ struct ProblemSet {
     DeviceBuffer<uint64_t> d_col_off, d_colmap_off, d_row_base, d_ent_base;
     DeviceBuffer<int32_t> d_colmap;
     DeviceBuffer<double> d_zero, d_total, d_prow_count, d_prow_noise, d_pent_val;
+    UploadPack uploads, base_uploads;  // d_cluster, d_col_off, d_col_path, d_colmap_off / d_row_base, d_ent_base are views of these
+    DownloadPack counts;               // d_kept_rows, d_kept_ent, d_total
 };
 
 // Caller holds ctx->mutex and has set the device.
@@ -868,17 +870,22 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
     scope.reset(new HostScope("problems: uploads + colmap + count launch"));
     hipStream_t st = ctx->stream;
     int span = ctx->spanBegin(FAM_H2D);
-    RPVG_HIP_CHECK(ps.d_cluster.upload(problems->cluster, P, st));
-    RPVG_HIP_CHECK(ps.d_col_off.upload(problems->col_off, P + 1, st));
-    RPVG_HIP_CHECK(ps.d_col_path.upload(problems->col_path, ps.n_cols_total, st));
-    RPVG_HIP_CHECK(ps.d_colmap_off.upload(colmap_off.data(), P + 1, st));
+    ps.uploads.add(ps.d_cluster, problems->cluster, P);
+    ps.uploads.add(ps.d_col_off, problems->col_off, P + 1);
+    ps.uploads.add(ps.d_col_path, problems->col_path, ps.n_cols_total);
+    ps.uploads.add(ps.d_colmap_off, colmap_off.data(), P + 1);
+    RPVG_HIP_CHECK(ps.uploads.commit(st));
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(P * 4 + (P + 1) * 16 + ps.n_cols_total * 4);
     RPVG_HIP_CHECK(ps.d_colmap.alloc(colmap_off[P]));
-    RPVG_HIP_CHECK(ps.d_kept_rows.alloc(P));
-    RPVG_HIP_CHECK(ps.d_kept_ent.alloc(P));
+    ps.kept_rows.resize(P);
+    ps.kept_ent.resize(P);
+    ps.total_count.resize(P);
+    ps.counts.add(ps.d_kept_rows, ps.kept_rows.data(), P);
+    ps.counts.add(ps.d_kept_ent, ps.kept_ent.data(), P);
+    ps.counts.add(ps.d_total, ps.total_count.data(), P);
+    RPVG_HIP_CHECK(ps.counts.alloc());
     RPVG_HIP_CHECK(ps.d_zero.alloc(P));
-    RPVG_HIP_CHECK(ps.d_total.alloc(P));
 
     span = ctx->spanBegin(FAM_BUILD);
     RPVG_HIP_CHECK(hipMemsetAsync(ps.d_colmap.ptr, 0xFF, colmap_off[P] * sizeof(int32_t), st));
@@ -892,13 +899,9 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
     RPVG_HIP_CHECK(hipGetLastError());
 
     scope.reset(new HostScope("problems: wait for the counts"));
-    ps.kept_rows.resize(P);
-    ps.kept_ent.resize(P);
-    ps.total_count.resize(P);
-    RPVG_HIP_CHECK(ps.d_kept_rows.download(ps.kept_rows.data(), st));
-    RPVG_HIP_CHECK(ps.d_kept_ent.download(ps.kept_ent.data(), st));
-    RPVG_HIP_CHECK(ps.d_total.download(ps.total_count.data(), st));
+    RPVG_HIP_CHECK(ps.counts.fetch(st));
     RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    ps.counts.scatter();
 
     scope.reset(new HostScope("problems: offsets + fill launch"));
     std::vector<uint64_t> row_base(P), ent_base(P);
@@ -909,8 +912,9 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
         ps.ent_total += ps.kept_ent[p];
     }
     span = ctx->spanBegin(FAM_H2D);
-    RPVG_HIP_CHECK(ps.d_row_base.upload(row_base.data(), P, st));
-    RPVG_HIP_CHECK(ps.d_ent_base.upload(ent_base.data(), P, st));
+    ps.base_uploads.add(ps.d_row_base, row_base.data(), P);
+    ps.base_uploads.add(ps.d_ent_base, ent_base.data(), P);
+    RPVG_HIP_CHECK(ps.base_uploads.commit(st));
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(P * 16);
     RPVG_HIP_CHECK(ps.d_prow_off.alloc(ps.rows_total + P));
@@ -1025,9 +1029,11 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     }
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(P * 4);
-    RPVG_HIP_CHECK(d_abund.alloc(ps.n_cols_total));
-    RPVG_HIP_CHECK(d_noise_count.alloc(P));
-    RPVG_HIP_CHECK(d_iters.alloc(P));
+    DownloadPack out;  // the three result arrays in one block, one copy back
+    out.add(d_abund, results->abundances, ps.n_cols_total);
+    out.add(d_noise_count, results->noise_count, P);
+    out.add(d_iters, results->iterations, P);
+    RPVG_HIP_CHECK(out.alloc());
 
     EmLaunchArgs args;
     args.col_off = ps.d_col_off.ptr;
@@ -1089,10 +1095,9 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     for (int b = 0; b < kBins; ++b) ctx->stats.em_sparse_launches += bins[b].empty() ? 0 : 1;
 
     scope.reset(new HostScope("em_solve: wait for the kernels + download"));
-    RPVG_HIP_CHECK(d_abund.download(results->abundances, st));
-    RPVG_HIP_CHECK(d_noise_count.download(results->noise_count, st));
-    RPVG_HIP_CHECK(d_iters.download(results->iterations, st));
+    RPVG_HIP_CHECK(out.fetch(st));
     RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    out.scatter();
     scope.reset();
 
     // algorithmic bytes: per iteration 12 B per entry (value + column), 20 B

@@ -549,24 +549,39 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     std::unique_ptr<HostScope> sub(new HostScope("groups_build: uploads"));
     int span = ctx->spanBegin(FAM_H2D);
-    ok(g->mat_val_off.upload(val_off.data(), M, st));
-    ok(g->mat_row_off.upload(row_off.data(), M, st));
-    ok(g->mat_row0.upload(row0.data(), M, st));
-    ok(g->mat_rows.upload(rows.data(), M, st));
-    ok(g->mat_cols.upload(cols.data(), M, st));
-    ok(d_inc_off.upload(inc_off.data(), M, st));
-    ok(d_num_paths.upload(num_paths.data(), M, st));
-    ok(d_group_off.upload(spec->group_off, M + 1, st));
-    ok(d_group_path_off.upload(spec->group_path_off, num_columns + 1, st));
-    ok(d_group_path.upload(spec->group_path, num_incidences, st));
+    // one block, one copy for the host arrays (UploadPack); the zero-initialised counters ride behind them (one memset)
+    UploadPack & pack = g->uploads;
+    pack.add(g->mat_val_off, val_off.data(), M);
+    pack.add(g->mat_row_off, row_off.data(), M);
+    pack.add(g->mat_row0, row0.data(), M);
+    pack.add(g->mat_rows, rows.data(), M);
+    pack.add(g->mat_cols, cols.data(), M);
+    pack.add(d_inc_off, inc_off.data(), M);
+    pack.add(d_num_paths, num_paths.data(), M);
+    pack.add(d_group_off, spec->group_off, M + 1);
+    pack.add(d_group_path_off, spec->group_path_off, num_columns + 1);
+    pack.add(d_group_path, spec->group_path, num_incidences);
     if (!item_matrix.empty()) {
-        ok(d_item_matrix.upload(item_matrix.data(), item_matrix.size(), st));
-        ok(d_item_chunk.upload(item_chunk.data(), item_chunk.size(), st));
+        pack.add(d_item_matrix, item_matrix.data(), item_matrix.size());
+        pack.add(d_item_chunk, item_chunk.data(), item_chunk.size());
     }
     if (!tile_matrix.empty()) {
-        ok(d_tile_matrix.upload(tile_matrix.data(), tile_matrix.size(), st));
-        ok(d_tile_chunk.upload(tile_chunk.data(), tile_chunk.size(), st));
+        pack.add(d_tile_matrix, tile_matrix.data(), tile_matrix.size());
+        pack.add(d_tile_chunk, tile_chunk.data(), tile_chunk.size());
     }
+    if (spec->pair_layout) pack.add(g->mat_half_off, half_off.data(), M);
+    std::vector<uint32_t> segment_off;
+    if (collapse) {
+        segment_off.resize(M + 1);
+        for (uint32_t m = 0; m < M; ++m) segment_off[m] = static_cast<uint32_t>(row_off[m]);
+        segment_off[M] = static_cast<uint32_t>(row_total);
+        if (row_total > 0x7fffffffull) e = hipErrorInvalidValue;
+        pack.add(g->collapse_segment_off, segment_off.data(), M + 1);
+    }
+    pack.addZero(d_degree, inc_total);
+    pack.addZero(d_cursor, inc_total);
+    pack.addZero(d_error, 1);
+    ok(pack.commit(st));
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(M * 60 + num_columns * 8 + num_incidences * 4 + (item_matrix.size() + tile_matrix.size()) * 8);
     sub.reset(new HostScope("groups_build: allocations"));
@@ -577,25 +592,14 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     ok(g->row_noise.alloc(row_total));
     ok(g->mat_fast.alloc(M));
     ok(g->mat_mid.alloc(M));
-    if (spec->pair_layout) {
-        ok(g->mat_half_off.upload(half_off.data(), M, st));
-        ok(g->halves.alloc(half_total));
-    }
+    if (spec->pair_layout) ok(g->halves.alloc(half_total));
     if (collapse) {
-        std::vector<uint32_t> segment_off(M + 1);
-        for (uint32_t m = 0; m < M; ++m) segment_off[m] = static_cast<uint32_t>(row_off[m]);
-        segment_off[M] = static_cast<uint32_t>(row_total);
-        if (row_total > 0x7fffffffull) e = hipErrorInvalidValue;
-        ok(g->collapse_segment_off.upload(segment_off.data(), M + 1, st));
         ok(g->collapse_key.alloc(row_total));
         ok(g->collapse_row.alloc(row_total));
         ok(g->collapse_mask.alloc(row_total));
     }
-    ok(d_degree.alloc(inc_total));
-    ok(d_cursor.alloc(inc_total));
     ok(d_path_grp_off.alloc(inc_total));
     ok(d_path_grp.alloc(num_incidences));
-    ok(d_error.alloc(1));
     size_t scan_bytes = 0;
     if (e == hipSuccess) ok(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_degree.ptr, d_path_grp_off.ptr, static_cast<int>(inc_total), st));
     ok(d_scan_tmp.alloc(scan_bytes));
@@ -603,9 +607,6 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     sub.reset(new HostScope("groups_build: launches"));
     if (e == hipSuccess) {
         span = ctx->spanBegin(FAM_BUILD);
-        ok(hipMemsetAsync(d_degree.ptr, 0, inc_total * sizeof(uint32_t), st));
-        ok(hipMemsetAsync(d_cursor.ptr, 0, inc_total * sizeof(uint32_t), st));
-        ok(hipMemsetAsync(d_error.ptr, 0, sizeof(uint32_t), st));
         for (auto m : wide_matrices) {
             ok(hipMemsetAsync(g->values.ptr + val_off[m], 0, rows[m] * cols[m] * sizeof(double), st));
         }

@@ -4,18 +4,101 @@
 //   PathInfo              src/path_cluster_estimates.hpp:15-33
 //   CountSamples          src/path_cluster_estimates.hpp:35-43
 //   PathClusterEstimates  src/path_cluster_estimates.hpp:45-111
-// Differences: std containers instead of sparsepp (source_ids is a sorted
-// std::set — only membership and iteration are used), no Eigen include.
+// Differences: std containers instead of sparsepp, no Eigen include; source_ids is a SourceIdSet (below): the set
+// interface the reference's code uses (insert / emplace / count / size / iteration) over ONE sorted array, because
+// the estimators walk the ids of every path of every cluster of a batch and a node-based set made that walk most of
+// a batch's host time (30 ms per 200 k paths; the GPU step is 13 ms).
 #ifndef RPVG_AMD_PATH_CLUSTER_ESTIMATES_HPP
 #define RPVG_AMD_PATH_CLUSTER_ESTIMATES_HPP
 
+#include <algorithm>
 #include <cassert>
 #include <cstdint>
-#include <set>
+#include <initializer_list>
 #include <string>
 #include <vector>
 
 namespace rpvg_amd {
+
+// Set of haplotype (source) ids: unique, ascending, contiguous.
+class SourceIdSet {
+
+    public:
+
+        typedef std::vector<uint32_t>::const_iterator const_iterator;
+        typedef std::vector<uint32_t>::const_reverse_iterator const_reverse_iterator;
+        typedef uint32_t value_type;
+
+        SourceIdSet() {}
+        SourceIdSet(std::initializer_list<uint32_t> ids_in) { insert(ids_in.begin(), ids_in.end()); }
+
+        std::pair<const_iterator, bool> insert(const uint32_t id) {
+
+            if (ids.empty() || ids.back() < id) {  // ids mostly arrive ascending
+
+                ids.push_back(id);
+                return std::make_pair(ids.end() - 1, true);
+            }
+
+            auto it = std::lower_bound(ids.begin(), ids.end(), id);
+
+            if (it != ids.end() && *it == id) {
+
+                return std::make_pair(const_iterator(it), false);
+            }
+
+            return std::make_pair(const_iterator(ids.insert(it, id)), true);
+        }
+
+        std::pair<const_iterator, bool> emplace(const uint32_t id) { return insert(id); }
+
+        template <typename Iterator>
+        void insert(Iterator first, Iterator last) {
+
+            const size_t old_size = ids.size();
+            ids.insert(ids.end(), first, last);
+
+            bool ascending = true;
+
+            for (size_t i = std::max<size_t>(old_size, 1); ascending && i < ids.size(); ++i) {
+
+                ascending = ids[i - 1] < ids[i];
+            }
+
+            if (!ascending) {
+
+                std::sort(ids.begin(), ids.end());
+                ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+            }
+        }
+
+        size_t count(const uint32_t id) const { return std::binary_search(ids.begin(), ids.end(), id) ? 1 : 0; }
+
+        const_iterator find(const uint32_t id) const {
+
+            auto it = std::lower_bound(ids.begin(), ids.end(), id);
+            return (it != ids.end() && *it == id) ? it : ids.end();
+        }
+
+        size_t size() const { return ids.size(); }
+        bool empty() const { return ids.empty(); }
+        void clear() { ids.clear(); }
+        void reserve(const size_t capacity) { ids.reserve(capacity); }
+
+        const_iterator begin() const { return ids.begin(); }
+        const_iterator end() const { return ids.end(); }
+        const_reverse_iterator rbegin() const { return ids.rbegin(); }
+        const_reverse_iterator rend() const { return ids.rend(); }
+
+        const uint32_t * data() const { return ids.data(); }
+
+        bool operator==(const SourceIdSet & other) const { return ids == other.ids; }
+        bool operator!=(const SourceIdSet & other) const { return ids != other.ids; }
+
+    private:
+
+        std::vector<uint32_t> ids;
+};
 
 struct PathInfo {
 
@@ -23,7 +106,7 @@ struct PathInfo {
     uint32_t group_id = 0;
 
     uint32_t source_count = 1;
-    std::set<uint32_t> source_ids;
+    SourceIdSet source_ids;
 
     uint32_t length = 0;
     double effective_length = 0;
