@@ -707,6 +707,290 @@ __global__ __launch_bounds__(64) void pairRowsKernel(const PairRowsWork w) {
     }
 }
 
+// ---- all pairs of a matrix from LDS, a 4 x 4 tile of pairs per lane ----------------------------------------------
+//
+// pairRowsKernel above has the minimal arithmetic in its inner loop and still only matched the sequential search: every
+// tile of eight first columns streamed the whole matrix again (G / 8 passes over it through L2: bound by that, not by
+// the multiplications), half of the lanes idled on the triangle of pairs, and a wave owned 64 second columns whether the
+// matrix had them or not.  This kernel is laid out like a matrix product whose inner dimension is the rows:
+//   * a workgroup takes (matrix, chunk of kChunkRows rows) and stages the chunk, some hundred rows at a time, in LDS —
+//     halved and transposed to row-major on the way, so the matrices need no second copy — and every pair of the
+//     matrix is evaluated from that ONE staging: the matrix is read from memory once per search;
+//   * a lane owns a 4 x 4 tile of pairs (a in 4 ta .., b in 4 tb .., ta <= tb: only the diagonal tiles carry unused
+//     slots): per row it reads 4 + 4 values and the row's noise from LDS (two 16-byte reads each) and does 16 additions
+//     and 16 multiplications into 16 running products (LogProduct) — 2 FP64 instructions per pair and row, 0.25 LDS
+//     reads;
+//   * matrices with few tiles spread the rows of the chunk over the lanes instead (slices: lane = (tile, slice), the
+//     slice takes every S-th row): the partial sums of a slice are one more part of the chunk for the resolving
+//     workgroup, which adds parts anyway.
+// Rows with read counts 2 .. kMidMaxCount multiply that many times, the others take the table logarithm, as everywhere.
+constexpr uint32_t kTileBlock = 256;
+constexpr uint32_t kTileLdsDoubles = 7 * 1024;   // staged values + noise + counts: 56 KB (two workgroups per CU and room to spare)
+constexpr uint32_t kTileMaxSubRows = 256;
+constexpr uint32_t kTileMaxColumns = 1024;       // wider matrices keep the sequential search (their pair tables would not fit either)
+
+__host__ __device__ inline uint32_t tileColumns(const uint32_t G) { return (G + 3) / 4; }
+__host__ __device__ inline uint32_t tileCount(const uint32_t G) { return tileColumns(G) * (tileColumns(G) + 1) / 2; }
+// row slices of a chunk: lanes left over by the tiles
+__host__ __device__ inline uint32_t tileSlices(const uint32_t G) { return tileCount(G) <= kTileBlock ? kTileBlock / tileCount(G) : 1u; }
+// ... for the single columns (marginals): a lane per four columns and slice — all lanes of the workgroup, so that the
+// few column sums are not a serial tail behind the pairs (26 lanes walking every second row cost 1.9 of the kernel's 6.5 ms)
+__host__ __device__ inline uint32_t marginalSlices(const uint32_t G) { return kTileBlock / tileColumns(G); }
+
+struct PairTileWork {
+    const uint32_t * item_matrix;   // [W]
+    const uint32_t * item_chunk;    // [W]
+    uint32_t count;
+    const uint64_t * mat_val_off;
+    const uint64_t * mat_row_off;
+    const uint32_t * mat_fast;
+    const uint32_t * mat_mid;
+    const uint64_t * mat_rows;
+    const uint32_t * mat_cols;
+    const double * values;
+    const double * row_count;
+    const double * row_noise;
+    const uint64_t * col_part_off;   // [M] offset of the matrix's [chunk x marginal slice][G] partial column sums
+    const uint64_t * pair_part_off;  // [M] offset of the matrix's [chunk x slice][G][G] partial pair sums
+    double * part_marginal;
+    double * part_pair;
+    unsigned long long * log_evals;
+    uint32_t debug_skip;  // timing experiments (RPVG_HIP_PAIR_DEBUG): 1 no count-1 rows, 2 no mid rows, 4 no other rows, 8 no marginals
+    unsigned long long * debug_cycles;  // [8] (RPVG_HIP_PAIR_DEBUG & 16) cycles of lane 0 of every workgroup: staging, barriers, count-1 rows, mid, rest, marginals, epilogue
+};
+
+__global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork w) {
+    extern __shared__ __attribute__((aligned(16))) double tile_lds[];
+    __shared__ LogTableEntry lt[kLogTableSize];
+    // items come expensive first and share nothing: workgroup b takes item b, which deals them round-robin to the XCDs
+    // (contiguous ranges per XCD, as the kernels above have them for their L2, gave one XCD all the large matrices)
+    const uint32_t item = blockIdx.x;
+    if (item >= w.count) return;
+    loadLogTable(lt);  // visible after the first barrier below
+    const uint32_t m = w.item_matrix[item], chunk = w.item_chunk[item];
+    const uint64_t R = w.mat_rows[m];
+    const uint32_t G = w.mat_cols[m];
+    const uint32_t T = tileColumns(G), tiles = tileCount(G), S = tileSlices(G);
+    const uint32_t passes = (tiles + kTileBlock - 1) / kTileBlock;  // 1 whenever S > 1
+    const uint32_t Gs = 4 * T + 2;  // row stride in LDS: even (16-byte reads), 2 (mod 4) doubles (consecutive rows spread over the banks)
+    const uint32_t sub_rows = min(kTileMaxSubRows, kTileLdsDoubles / (Gs + 2));
+    double * const H = tile_lds;                                   // [sub_rows][Gs] halved values, row-major
+    double * const lds_noise = H + static_cast<size_t>(sub_rows) * Gs;  // [sub_rows]
+    double * const lds_count = lds_noise + sub_rows;               // [sub_rows]
+    const uint64_t r_begin = static_cast<uint64_t>(chunk) * kChunkRows;
+    const uint32_t n = static_cast<uint32_t>((R - r_begin) < kChunkRows ? (R - r_begin) : kChunkRows);
+    const double * M = w.values + w.mat_val_off[m] + r_begin;  // column-major: M[column * R + row]
+    const double * cnt = w.row_count + w.mat_row_off[m] + r_begin;
+    const double * nz = w.row_noise + w.mat_row_off[m] + r_begin;
+    auto local = [&](const uint64_t end_row) { return end_row <= r_begin ? 0u : (end_row - r_begin < n ? static_cast<uint32_t>(end_row - r_begin) : n); };
+    const uint32_t nf = local(w.mat_fast[m]), nm = local(w.mat_mid[m]);  // class boundaries within the chunk
+
+    // the lane's column of marginals (first pass only): columns 4 tc .. 4 tc + 3, every S-th row
+    unsigned long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long cyc_mark = __builtin_readcyclecounter();
+    auto lap = [&](const int slot) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        cyc[slot] += now - cyc_mark;
+        cyc_mark = now;
+    };
+    const uint32_t SM = marginalSlices(G);
+    const uint32_t tc = threadIdx.x % T, marg_slice = threadIdx.x / T;
+    const bool marg_active = marg_slice < SM;
+
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        const uint32_t t = (S > 1 || passes == 1) ? threadIdx.x % tiles : pass * kTileBlock + threadIdx.x;
+        const uint32_t slice = (S > 1 || passes == 1) ? threadIdx.x / tiles : 0u;
+        const bool active = slice < S && t < tiles;
+        // tile t of the triangle, row by row: row ta starts at ta * T - ta (ta - 1) / 2
+        uint32_t ta = 0;
+        {
+            uint32_t lo = 0, hi = T - 1;
+            const uint32_t tt = t < tiles ? t : 0;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (mid * T - mid * (mid - 1) / 2 <= tt) lo = mid; else hi = mid - 1;
+            }
+            ta = lo;
+        }
+        const uint32_t tb = ta + ((t < tiles ? t : 0) - (ta * T - ta * (ta > 0 ? ta - 1 : 0) / 2));
+        const bool with_marginals = pass == 0 && marg_active && !(w.debug_skip & 8u);
+
+        LogProduct pr[4][4], prm[4];
+        double acc[4][4], accm[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            accm[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+        }
+        uint32_t since_fold = 0, since_fold_m = 0;
+        auto foldPairs = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pr[i][j].fold();
+            }
+            since_fold = 0;
+        };
+        auto foldMarginals = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) prm[i].fold();
+            since_fold_m = 0;
+        };
+
+        for (uint32_t s0 = 0; s0 < n; s0 += sub_rows) {
+            const uint32_t ns = (n - s0) < sub_rows ? (n - s0) : sub_rows;
+            lap(7);
+            __syncthreads();  // the rows staged before have been used
+            lap(1);
+            // lane = row (64 consecutive rows of a column: one 512-byte request), wave = column; eight requests of a
+            // thread are in flight before the first is stored (the loop is all latency otherwise: ~25 dependent round
+            // trips to memory per thread against ~5 us of arithmetic on the staged rows)
+            {
+                const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+                constexpr uint32_t kAhead = 8;
+                for (uint32_t rb = 0; rb < ns; rb += 64) {
+                    const uint32_t r = rb + lane;
+                    const bool row_ok = r < ns;
+                    const double * from = M + s0 + (row_ok ? r : 0u);
+                    for (uint32_t c0 = wave; c0 < 4 * T; c0 += 4 * kAhead) {
+                        double fetched[kAhead];
+#pragma unroll
+                        for (uint32_t k = 0; k < kAhead; ++k) {
+                            const uint32_t c = c0 + 4 * k;
+                            fetched[k] = __builtin_nontemporal_load(from + static_cast<uint64_t>(c < G ? c : 0u) * R);
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < kAhead; ++k) {
+                            const uint32_t c = c0 + 4 * k;
+                            if (row_ok && c < 4 * T) H[r * Gs + c] = c < G ? 0.5 * fetched[k] : 0.0;
+                        }
+                    }
+                }
+            }
+            for (uint32_t r = threadIdx.x; r < ns; r += kTileBlock) {
+                lds_noise[r] = nz[s0 + r];
+                lds_count[r] = cnt[s0 + r];
+            }
+            lap(0);
+            __syncthreads();
+            lap(1);
+            // class ranges inside the staged rows
+            const uint32_t f1 = nf <= s0 ? 0u : ((nf - s0) < ns ? (nf - s0) : ns);
+            const uint32_t m1 = nm <= s0 ? 0u : ((nm - s0) < ns ? (nm - s0) : ns);
+            if (active) {
+                const double * ua = H + 4 * ta, * vb = H + 4 * tb;
+                // read count 1: one multiplication per pair and row
+                for (uint32_t r = (w.debug_skip & 1u) ? f1 : slice; r < f1; r += S) {
+                    const double2 u01 = *reinterpret_cast<const double2 *>(ua + r * Gs), u23 = *reinterpret_cast<const double2 *>(ua + r * Gs + 2);
+                    const double2 v01 = *reinterpret_cast<const double2 *>(vb + r * Gs), v23 = *reinterpret_cast<const double2 *>(vb + r * Gs + 2);
+                    const double noise = lds_noise[r];
+                    const double un[4] = {u01.x + noise, u01.y + noise, u23.x + noise, u23.y + noise};
+                    const double v[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pr[i][j].mul(un[i] + v[j]);
+                    }
+                    if (++since_fold == kFoldFactors) foldPairs();
+                }
+                lap(2);
+                // read counts 2 .. kMidMaxCount: the factor that many times
+                for (uint32_t r = (w.debug_skip & 2u) ? m1 : f1 + (slice + S - f1 % S) % S; r < m1; r += S) {
+                    const double2 u01 = *reinterpret_cast<const double2 *>(ua + r * Gs), u23 = *reinterpret_cast<const double2 *>(ua + r * Gs + 2);
+                    const double2 v01 = *reinterpret_cast<const double2 *>(vb + r * Gs), v23 = *reinterpret_cast<const double2 *>(vb + r * Gs + 2);
+                    const double noise = lds_noise[r];
+                    const uint32_t c = static_cast<uint32_t>(lds_count[r]);
+                    const double un[4] = {u01.x + noise, u01.y + noise, u23.x + noise, u23.y + noise};
+                    const double v[4] = {v01.x, v01.y, v23.x, v23.y};
+                    if (since_fold + c > kFoldFactors) foldPairs();
+                    since_fold += c;
+                    double x[4][4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x[i][j] = un[i] + v[j];
+                    }
+                    for (uint32_t k = 0; k < c; ++k) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) pr[i][j].mul(x[i][j]);
+                        }
+                    }
+                }
+                lap(3);
+                // the rest: one logarithm per pair and row
+                for (uint32_t r = (w.debug_skip & 4u) ? ns : m1 + (slice + S - m1 % S) % S; r < ns; r += S) {
+                    const double2 u01 = *reinterpret_cast<const double2 *>(ua + r * Gs), u23 = *reinterpret_cast<const double2 *>(ua + r * Gs + 2);
+                    const double2 v01 = *reinterpret_cast<const double2 *>(vb + r * Gs), v23 = *reinterpret_cast<const double2 *>(vb + r * Gs + 2);
+                    const double noise = lds_noise[r], c = lds_count[r];
+                    const double un[4] = {u01.x + noise, u01.y + noise, u23.x + noise, u23.y + noise};
+                    const double v[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = fma(c, logPositive(un[i] + v[j], lt), acc[i][j]);
+                    }
+                }
+            }
+            lap(4);
+            if (with_marginals) {  // single columns: noise + the whole value = noise + 2 halves
+                const double * ua = H + 4 * tc;
+                for (uint32_t r = marg_slice; r < ns; r += SM) {
+                    const double2 u01 = *reinterpret_cast<const double2 *>(ua + r * Gs), u23 = *reinterpret_cast<const double2 *>(ua + r * Gs + 2);
+                    const double noise = lds_noise[r];
+                    const double x[4] = {fma(2.0, u01.x, noise), fma(2.0, u01.y, noise), fma(2.0, u23.x, noise), fma(2.0, u23.y, noise)};
+                    if (r < f1) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) prm[i].mul(x[i]);
+                        if (++since_fold_m == kFoldFactors) foldMarginals();
+                    } else if (r < m1) {
+                        const uint32_t c = static_cast<uint32_t>(lds_count[r]);
+                        if (since_fold_m + c > kFoldFactors) foldMarginals();
+                        since_fold_m += c;
+                        for (uint32_t k = 0; k < c; ++k) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) prm[i].mul(x[i]);
+                        }
+                    } else {
+                        const double c = lds_count[r];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) accm[i] = fma(c, logPositive(x[i], lt), accm[i]);
+                    }
+                }
+            }
+        }
+        lap(5);
+        if (active) {
+            double * out = w.part_pair + w.pair_part_off[m] + static_cast<uint64_t>(chunk * S + slice) * G * G;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = 4 * ta + i, b = 4 * tb + j;
+                    const double total = acc[i][j] + pr[i][j].value(lt);
+                    if (a <= b && b < G) out[static_cast<uint64_t>(a) * G + b] = total;
+                }
+            }
+        }
+        if (with_marginals) {
+            double * out = w.part_marginal + w.col_part_off[m] + static_cast<uint64_t>(chunk * SM + marg_slice) * G;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t a = 4 * tc + i;
+                const double total = accm[i] + prm[i].value(lt);
+                if (a < G) out[a] = total;
+            }
+        }
+    }
+    lap(6);
+    if (threadIdx.x == 0) atomicAdd(w.log_evals, static_cast<unsigned long long>(static_cast<uint64_t>(G) * (G + 1) / 2 + G) * n);
+    if (w.debug_cycles && threadIdx.x == 0) {
+        for (int k = 0; k < 8; ++k) atomicAdd(w.debug_cycles + k, cyc[k]);
+    }
+}
+
 struct ResolveArgs {
     const uint32_t * big_matrix;    // [B] matrices on the table path
     uint32_t count;
@@ -720,6 +1004,7 @@ struct ResolveArgs {
     const double * part_marginal;
     const double * part_optimistic;
     const double * part_pair;
+    uint32_t tile_parts;  // the partial sums come from pairTileKernel: tileSlices(G) parts per chunk of rows
     double min_log_likelihood_diff;
     double * log_freq;
     double * marginal;
@@ -756,7 +1041,9 @@ __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t R = args.mat_rows[m];
     const uint32_t G = args.mat_cols[m];
-    const uint32_t chunks = static_cast<uint32_t>((R + kChunkRows - 1) / kChunkRows);
+    const uint32_t row_chunks = static_cast<uint32_t>((R + kChunkRows - 1) / kChunkRows);
+    const uint32_t chunks = row_chunks * (args.tile_parts ? tileSlices(G) : 1u);  // parts to add up: pairs
+    const uint32_t col_chunks = row_chunks * (args.tile_parts ? marginalSlices(G) : 1u);  // ... single columns
     const uint64_t c0 = args.col_off[m];
     const uint32_t * ccount = args.col_count + c0;
     double * lf = args.log_freq + c0;
@@ -784,7 +1071,7 @@ __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args
         const double f = log(ccount[g] / count_sum);
         lf[g] = f;
         double acc = 0.0;
-        for (uint32_t c = 0; c < chunks; ++c) acc += pm[static_cast<uint64_t>(c) * G + g];
+        for (uint32_t c = 0; c < col_chunks; ++c) acc += pm[static_cast<uint64_t>(c) * G + g];
         marg[g] = (acc + f) + 0.0;
     }
     __syncthreads();
@@ -981,29 +1268,48 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     // matrices with the row-major copy: every one of them on the table path, its pairs by pairRowsKernel
     const bool pair_rows = groups->halves.ptr != nullptr && min_rel_likelihood <= 1;
     if (pair_rows) table_min_work = 0.0;
+    // every pair of every matrix from LDS-staged rows, a tile of pairs per lane (pairTileKernel): the default for a
+    // threshold that is a ratio <= 1; RPVG_HIP_PAIR_TILES=0 keeps the sequential search with its table path (A/B)
+    static const bool tiles_wanted = []() { const char * env = std::getenv("RPVG_HIP_PAIR_TILES"); return env ? std::atoi(env) != 0 : true; }();
+    const bool pair_tiles = tiles_wanted && !pair_rows && min_rel_likelihood <= 1;
+    if (pair_tiles) table_min_work = 0.0;
     const uint32_t tile_step = pair_rows ? kTilePairA : kTileA;
     uint32_t num_big = 0;
     std::vector<uint64_t> big_col_part_off(M, 0), big_pair_part_off(M, 0);
     std::vector<uint32_t> item_matrix, item_col, item_chunk;
     uint64_t col_part_total = 0, pair_part_total = 0;
-    while (num_big < M) {
-        const uint32_t m = order[num_big];
-        const uint64_t R = groups->h_num_rows[m], G = groups->h_num_cols[m];
-        if (static_cast<double>(R) * G < table_min_work) break;
-        const uint64_t chunks = (R + kChunkRows - 1) / kChunkRows;
-        if (pair_part_total + chunks * G * G > table_budget) break;
-        big_col_part_off[m] = col_part_total;
-        big_pair_part_off[m] = pair_part_total;
-        col_part_total += chunks * G;
-        pair_part_total += chunks * G * G;
-        for (uint32_t c = 0; c < chunks; ++c) {
-            for (uint32_t a = 0; a < G; a += tile_step) {
-                item_matrix.push_back(m);
-                item_col.push_back(a);
-                item_chunk.push_back(c);
+    {
+        std::vector<uint32_t> table_matrices, others;
+        bool table_closed = false;  // (the sequential kernels' table path: a prefix of the order, as before)
+        for (uint32_t i = 0; i < M; ++i) {
+            const uint32_t m = order[i];
+            const uint64_t R = groups->h_num_rows[m], G = groups->h_num_cols[m];
+            const uint64_t chunks = (R + kChunkRows - 1) / kChunkRows;
+            const uint64_t parts = chunks * (pair_tiles ? tileSlices(static_cast<uint32_t>(G)) : 1u);
+            const bool fits = pair_part_total + parts * G * G <= table_budget;
+            const bool takes_table = pair_tiles ? (G <= kTileMaxColumns && fits)
+                                                : (!table_closed && static_cast<double>(R) * G >= table_min_work && fits);
+            if (!takes_table) {
+                table_closed = true;
+                others.push_back(m);
+                continue;
+            }
+            table_matrices.push_back(m);
+            big_col_part_off[m] = col_part_total;
+            big_pair_part_off[m] = pair_part_total;
+            col_part_total += (pair_tiles ? chunks * marginalSlices(static_cast<uint32_t>(G)) : parts) * G;
+            pair_part_total += parts * G * G;
+            for (uint32_t c = 0; c < chunks; ++c) {
+                for (uint32_t a = 0; a < (pair_tiles ? 1u : G); a += tile_step) {
+                    item_matrix.push_back(m);
+                    item_col.push_back(a);
+                    item_chunk.push_back(c);
+                }
             }
         }
-        ++num_big;
+        num_big = static_cast<uint32_t>(table_matrices.size());
+        std::copy(table_matrices.begin(), table_matrices.end(), order.begin());
+        std::copy(others.begin(), others.end(), order.begin() + num_big);
     }
 
     scope.reset(new HostScope("bounded search: uploads + launches"));
@@ -1151,7 +1457,41 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         tw.part_optimistic = d_part_opt.ptr;
         tw.part_pair = d_part_pair.ptr;
         tw.log_evals = args.log_evals;
-        if (pair_rows) {
+        if (pair_tiles) {
+            PairTileWork pw;
+            pw.item_matrix = d_item_matrix.ptr;
+            pw.item_chunk = d_item_chunk.ptr;
+            pw.count = tw.count;
+            pw.mat_val_off = groups->mat_val_off.ptr;
+            pw.mat_row_off = groups->mat_row_off.ptr;
+            pw.mat_fast = groups->mat_fast.ptr;
+            pw.mat_mid = groups->mat_mid.ptr;
+            pw.mat_rows = groups->mat_rows.ptr;
+            pw.mat_cols = groups->mat_cols.ptr;
+            pw.values = groups->values.ptr;
+            pw.row_count = groups->row_count.ptr;
+            pw.row_noise = groups->row_noise.ptr;
+            pw.col_part_off = d_big_col_part_off.ptr;
+            pw.pair_part_off = d_big_pair_part_off.ptr;
+            pw.part_marginal = d_part_marg.ptr;
+            pw.part_pair = d_part_pair.ptr;
+            pw.log_evals = args.log_evals;
+            pw.debug_skip = std::getenv("RPVG_HIP_PAIR_DEBUG") ? static_cast<uint32_t>(std::atoi(std::getenv("RPVG_HIP_PAIR_DEBUG"))) : 0u;
+            DeviceBuffer<unsigned long long> d_debug_cycles;
+            pw.debug_cycles = nullptr;
+            if (pw.debug_skip & 16u) {
+                ok(d_debug_cycles.alloc(8));
+                ok(hipMemsetAsync(d_debug_cycles.ptr, 0, 8 * sizeof(unsigned long long), st));
+                pw.debug_cycles = d_debug_cycles.ptr;
+            }
+            pairTileKernel<<<dim3(((pw.count + 7) / 8) * 8), dim3(kTileBlock), kTileLdsDoubles * sizeof(double), st>>>(pw);
+            if (pw.debug_cycles) {
+                unsigned long long cycles[8];
+                (void) hipMemcpy(cycles, d_debug_cycles.ptr, sizeof(cycles), hipMemcpyDeviceToHost);
+                std::fprintf(stderr, "[pair tiles] %u workgroups, cycles of lane 0 summed (100 MHz counter): staging %llu barriers %llu count-1 %llu mid %llu rest %llu marginals %llu epilogue %llu other %llu\n",
+                             pw.count, cycles[0], cycles[1], cycles[2], cycles[3], cycles[4], cycles[5], cycles[6], cycles[7]);
+            }
+        } else if (pair_rows) {
             PairRowsWork pw;
             pw.item_matrix = d_item_matrix.ptr;
             pw.item_col = d_item_col.ptr;
@@ -1191,6 +1531,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         ra.part_marginal = d_part_marg.ptr;
         ra.part_optimistic = d_part_opt.ptr;
         ra.part_pair = d_part_pair.ptr;
+        ra.tile_parts = pair_tiles ? 1u : 0u;
         ra.min_log_likelihood_diff = args.min_log_likelihood_diff;
         ra.log_freq = d_lf.ptr;
         ra.marginal = d_marg.ptr;

@@ -298,22 +298,59 @@ int rpvg_hip_ctx::foldSpans() {
 
 // One thread per probability group: writes the group's probability next to
 // each of its path indices (the path indices themselves are uploaded as is).
-__global__ void expandGroupsKernel(const uint64_t num_groups, const uint64_t * __restrict__ grp_idx_off,
+__global__ void expandGroupsKernel(const uint64_t num_groups, const uint64_t num_entries, const uint64_t * __restrict__ grp_idx_off,
                                    const double * __restrict__ grp_prob, double * __restrict__ ent_prob) {
     const uint64_t g = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (g >= num_groups) return;
     const double p = grp_prob[g];
-    for (uint64_t e = grp_idx_off[g]; e < grp_idx_off[g + 1]; ++e) ent_prob[e] = p;
+    // (clamped: the offsets are checked by validateRowsKernel, whose verdict the host reads after these kernels)
+    for (uint64_t e = grp_idx_off[g]; e < min(grp_idx_off[g + 1], num_entries); ++e) ent_prob[e] = p;
 }
 
 // One thread per row: entry range of the row and its count as double.
-__global__ void rowMetaKernel(const uint64_t num_rows, const uint64_t * __restrict__ row_grp_off,
+__global__ void rowMetaKernel(const uint64_t num_rows, const uint64_t num_groups, const uint64_t * __restrict__ row_grp_off,
                               const uint64_t * __restrict__ grp_idx_off, const uint32_t * __restrict__ row_count_u32,
                               uint64_t * __restrict__ row_ent_off, double * __restrict__ row_count) {
     const uint64_t r = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (r > num_rows) return;
-    row_ent_off[r] = grp_idx_off[row_grp_off[r]];
+    row_ent_off[r] = grp_idx_off[min(row_grp_off[r], num_groups)];
     if (r < num_rows) row_count[r] = static_cast<double>(row_count_u32[r]);
+}
+
+// The row invariants the estimators rely on (src/main.cpp:855-887,953-973; src/read_path_probabilities.cpp:91-105,184,
+// 212-219), one thread per row: consistent offsets, noise probability in (0, 1], path indices inside the row's cluster.
+// first_bad_row: the smallest row that breaks one (the host words the message: validateClusters).  On the device because
+// the host pass over a batch's 280 MB cost more than their copy (8 threads: 5 ms, before the first byte moved).
+__global__ void validateRowsKernel(const uint64_t num_rows, const uint64_t num_groups, const uint64_t num_entries, const uint32_t num_clusters,
+                                   const uint64_t * __restrict__ cluster_row_off, const uint64_t * __restrict__ cluster_path_off,
+                                   const uint64_t * __restrict__ row_grp_off, const uint64_t * __restrict__ grp_idx_off,
+                                   const double * __restrict__ row_noise, const uint32_t * __restrict__ path_idx,
+                                   unsigned long long * __restrict__ first_bad_row) {
+    const uint64_t r = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (r >= num_rows) return;
+    bool good = true;
+    const uint64_t g0 = row_grp_off[r], g1 = row_grp_off[r + 1];
+    good = g0 <= g1 && g1 <= num_groups;
+    const double nz = row_noise[r];
+    good = good && nz > 0 && nz <= 1;
+    if (good) {
+        // the row's cluster: the last one that starts at or before it
+        uint32_t lo = 0, hi = num_clusters;  // cluster_row_off[lo] <= r < cluster_row_off[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (cluster_row_off[mid] <= r) lo = mid;
+            else hi = mid;
+        }
+        const uint64_t n_paths = cluster_path_off[lo + 1] - cluster_path_off[lo];
+        uint64_t e = grp_idx_off[g0];
+        good = e <= num_entries;
+        for (uint64_t g = g0; good && g < g1; ++g) {
+            const uint64_t e1 = grp_idx_off[g + 1];
+            good = e <= e1 && e1 <= num_entries;
+            for (; good && e < e1; ++e) good = path_idx[e] < n_paths;
+        }
+    }
+    if (!good) atomicMin(first_bad_row, static_cast<unsigned long long>(r));
 }
 
 extern "C" {
@@ -522,35 +559,22 @@ extern "C" int rpvg_hip_host_unregister(void * host) {
 
 namespace {
 
-// The row invariants the estimators rely on (src/main.cpp:855-887,953-973; src/read_path_probabilities.cpp:91-105,184,
-// 212-219), clusters [k0, k1); false: `message` says what is wrong.
+// Words what is wrong with row r of cluster k (validateRowsKernel found it); true: nothing is.
 constexpr size_t kProblemChars = 256;
-bool validateClusters(const rpvg_cluster_batch * hb, const uint32_t k0, const uint32_t k1, char * message) {
+bool validateRow(const rpvg_cluster_batch * hb, const uint32_t k, const uint64_t r, char * message) {
     message[0] = 0;
-    for (uint32_t k = k0; k < k1; ++k) {
-        if (!(hb->cluster_row_off[k] <= hb->cluster_row_off[k + 1] && hb->cluster_path_off[k] <= hb->cluster_path_off[k + 1])) {
-            std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: cluster %u has decreasing offsets", k);
+    const uint64_t n_paths = hb->cluster_path_off[k + 1] - hb->cluster_path_off[k];
+    const double nz = hb->row_noise[r];
+    if (!(nz > 0 && nz <= 1)) {
+        std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: row %llu has noise probability %g outside (0, 1]",
+                      static_cast<unsigned long long>(r), nz);
+        return false;
+    }
+    for (uint64_t e = hb->grp_idx_off[hb->row_grp_off[r]]; e < hb->grp_idx_off[hb->row_grp_off[r + 1]]; ++e) {
+        if (!(hb->path_idx[e] < n_paths)) {
+            std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: row %llu refers to path %u of a cluster with %llu paths",
+                          static_cast<unsigned long long>(r), hb->path_idx[e], static_cast<unsigned long long>(n_paths));
             return false;
-        }
-        const uint64_t n_paths = hb->cluster_path_off[k + 1] - hb->cluster_path_off[k];
-        if (n_paths > 0x7fffffffu) {
-            std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: cluster %u has too many paths", k);
-            return false;
-        }
-        for (uint64_t r = hb->cluster_row_off[k]; r < hb->cluster_row_off[k + 1]; ++r) {
-            const double nz = hb->row_noise[r];
-            if (!(nz > 0 && nz <= 1)) {
-                std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: row %llu has noise probability %g outside (0, 1]",
-                              static_cast<unsigned long long>(r), nz);
-                return false;
-            }
-            for (uint64_t e = hb->grp_idx_off[hb->row_grp_off[r]]; e < hb->grp_idx_off[hb->row_grp_off[r + 1]]; ++e) {
-                if (!(hb->path_idx[e] < n_paths)) {
-                    std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: row %llu refers to path %u of a cluster with %llu paths",
-                                  static_cast<unsigned long long>(r), hb->path_idx[e], static_cast<unsigned long long>(n_paths));
-                    return false;
-                }
-            }
         }
     }
     return true;
@@ -572,22 +596,14 @@ int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpv
     RPVG_REQUIRE(G == 0 || hb->grp_prob, "rpvg_hip_batch_upload: grp_prob is NULL");
     RPVG_REQUIRE(NNZ == 0 || hb->path_idx, "rpvg_hip_batch_upload: path_idx is NULL");
 
-    // validation: one pass over every row and entry on the host (several threads for a batch of millions of rows)
-    {
-        const uint32_t workers = R > 200000 ? std::min<uint32_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
-        std::vector<char> problems(workers * kProblemChars, 0);
-        std::vector<std::thread> threads;
-        for (uint32_t w = 1; w < workers; ++w) {
-            threads.emplace_back([&, w] { (void) validateClusters(hb, static_cast<uint32_t>(static_cast<uint64_t>(K) * w / workers),
-                                                                static_cast<uint32_t>(static_cast<uint64_t>(K) * (w + 1) / workers),
-                                                                problems.data() + w * kProblemChars); });
-        }
-        (void) validateClusters(hb, 0, static_cast<uint32_t>(static_cast<uint64_t>(K) / workers), problems.data());
-        for (auto & t : threads) t.join();
-        for (uint32_t w = 0; w < workers; ++w) {
-            RPVG_REQUIRE(problems[w * kProblemChars] == 0, "%s", problems.data() + w * kProblemChars);
-        }
+    std::unique_ptr<HostScope> scope(new HostScope("batch_upload: host checks + offsets"));
+    // validation: the cluster offsets here (O(K)); the rows and entries on the device, behind their copy (validateRowsKernel)
+    for (uint32_t k = 0; k < K; ++k) {
+        RPVG_REQUIRE(hb->cluster_row_off[k] <= hb->cluster_row_off[k + 1] && hb->cluster_path_off[k] <= hb->cluster_path_off[k + 1],
+                     "rpvg_hip_batch_upload: cluster %u has decreasing offsets", k);
+        RPVG_REQUIRE(hb->cluster_path_off[k + 1] - hb->cluster_path_off[k] <= 0x7fffffffu, "rpvg_hip_batch_upload: cluster %u has too many paths", k);
     }
+    RPVG_REQUIRE(hb->cluster_row_off[0] == 0, "rpvg_hip_batch_upload: the first cluster does not start at row 0");
 
     std::lock_guard<std::mutex> lock(ctx->mutex);
     RPVG_HIP_CHECK(hipSetDevice(ctx->device));
@@ -612,6 +628,7 @@ int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpv
     DeviceBuffer<uint32_t> d_row_count_u32;
     DeviceBuffer<uint64_t> d_row_grp_off, d_grp_idx_off;
     DeviceBuffer<double> d_grp_prob;
+    scope.reset(new HostScope("batch_upload: copies queued"));
 
     const int span = ctx->spanBegin(FAM_H2D);
     hipError_t e = hipSuccess;
@@ -636,25 +653,51 @@ int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpv
         return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
     }
 
+    scope.reset(new HostScope("batch_upload: kernels + wait"));
     const int bspan = ctx->spanBegin(FAM_BUILD);
     if (G > 0) {
         const uint32_t threads = 256;
         expandGroupsKernel<<<dim3(static_cast<uint32_t>((G + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            G, d_grp_idx_off.ptr, d_grp_prob.ptr, b->ent_prob.ptr);
+            G, NNZ, d_grp_idx_off.ptr, d_grp_prob.ptr, b->ent_prob.ptr);
     }
     {
         const uint32_t threads = 256;
         rowMetaKernel<<<dim3(static_cast<uint32_t>((R + 1 + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            R, d_row_grp_off.ptr, d_grp_idx_off.ptr, d_row_count_u32.ptr, b->row_ent_off.ptr, b->row_count.ptr);
+            R, G, d_row_grp_off.ptr, d_grp_idx_off.ptr, d_row_count_u32.ptr, b->row_ent_off.ptr, b->row_count.ptr);
+    }
+    unsigned long long first_bad_row = ~0ull;
+    DeviceBuffer<unsigned long long> d_first_bad_row;
+    e = d_first_bad_row.alloc(1);
+    if (e == hipSuccess) e = hipMemsetAsync(d_first_bad_row.ptr, 0xFF, sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess && R > 0) {
+        const uint32_t threads = 256;
+        validateRowsKernel<<<dim3(static_cast<uint32_t>((R + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
+            R, G, NNZ, K, b->cluster_row_off.ptr, b->cluster_path_off.ptr, d_row_grp_off.ptr, d_grp_idx_off.ptr, b->row_noise.ptr,
+            b->ent_path.ptr, d_first_bad_row.ptr);
     }
     ctx->spanEnd(bspan);
-    ctx->stats.build_launches += 2;
-    e = hipGetLastError();
+    ctx->stats.build_launches += 3;
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&first_bad_row, d_first_bad_row.ptr, sizeof(first_bad_row), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // temporaries are freed on return
     if (e != hipSuccess) {
         setError("rpvg_hip_batch_upload: %s", hipGetErrorString(e));
+        (void) hipStreamSynchronize(ctx->stream);
         delete b;
         return RPVG_HIP_ERR_RUNTIME;
+    }
+    if (first_bad_row != ~0ull) {  // the message: the host's reading of the offending row's cluster
+        delete b;
+        const uint32_t k = static_cast<uint32_t>(std::upper_bound(hb->cluster_row_off, hb->cluster_row_off + K + 1, first_bad_row) - hb->cluster_row_off) - 1;
+        char message[kProblemChars];
+        const uint64_t g0 = hb->row_grp_off[first_bad_row], g1 = hb->row_grp_off[first_bad_row + 1];
+        bool offsets_ok = g0 <= g1 && g1 <= G;
+        for (uint64_t g = g0; offsets_ok && g < g1; ++g) offsets_ok = hb->grp_idx_off[g] <= hb->grp_idx_off[g + 1] && hb->grp_idx_off[g + 1] <= NNZ;
+        if (!offsets_ok || validateRow(hb, k, first_bad_row, message)) {
+            std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: row %llu has inconsistent group or entry offsets", first_bad_row);
+        }
+        setError("%s", message);
+        return RPVG_HIP_ERR_INVALID;
     }
     *batch_out = b;
     return RPVG_HIP_OK;

@@ -682,7 +682,9 @@ extern "C" void rpvg_hip_groups_free(rpvg_hip_ctx * ctx, rpvg_hip_groups * group
         static const bool trace = std::getenv("RPVG_AMD_TRACE") != nullptr;
         if (trace && groups->collapse_info.ptr) {
             uint32_t info[4] = {0, 0, 0, 0};
-            if (hipMemcpy(info, groups->collapse_info.ptr, sizeof(info), hipMemcpyDeviceToHost) == hipSuccess) {
+            // (on the context's stream: a plain hipMemcpy waits for every stream of the device, the other lane's search included)
+            if (hipMemcpyAsync(info, groups->collapse_info.ptr, sizeof(info), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                hipStreamSynchronize(ctx->stream) == hipSuccess) {
                 std::fprintf(stderr, "[rpvg_hip trace]   row collapse: %u of %u matrices replayed (%u sorted whole), %u active rows, %u rows took their head's values\n",
                              info[0], groups->num_matrices, info[2], info[3], info[1]);
             }

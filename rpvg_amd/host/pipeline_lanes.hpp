@@ -10,6 +10,7 @@
 #define RPVG_AMD_PIPELINE_LANES_HPP
 
 #include <condition_variable>
+#include <cstdlib>
 #include <exception>
 #include <functional>
 #include <mutex>
@@ -29,6 +30,14 @@ class LaneStagger {
         explicit LaneStagger(const int num_lanes) : released(num_lanes, false) {
 
             released.at(0) = true;
+
+            // RPVG_AMD_NO_STAGGER=1 (A/B knob): every lane starts at once
+            static const bool no_stagger = std::getenv("RPVG_AMD_NO_STAGGER") != nullptr;
+
+            if (no_stagger) {
+
+                released.assign(num_lanes, true);
+            }
         }
 
         // Blocks lane until the lane before it has passed the baton.

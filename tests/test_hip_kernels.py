@@ -581,3 +581,32 @@ def test_groups_with_a_path_outside_the_cluster_are_reported_by_the_first_consum
     dg = hip_ctx.groups(dev, [0], [[[0], [bad_path]]], False)
     with pytest.raises(hip.EngineError, match="outside its cluster"):
         dg.loglik([0], [[0]], 1.0)
+
+
+def test_upload_reports_the_first_row_that_breaks_an_invariant(hip_ctx):
+    """The rows of a batch are checked on the device, behind their copy (validateRowsKernel); the host words the message."""
+    from rpvg_amd import hip
+    clusters = small_cases.make_batch_clusters(977, n_clusters=4, with_empty=False)
+    good = ClusterBatch.from_clusters(clusters)
+    hip_ctx.upload(good)  # nothing to report
+
+    bad = ClusterBatch.from_clusters(clusters)
+    last = len(bad.row_noise) - 1
+    bad.row_noise[last] = 1.5
+    bad.row_noise[last // 2] = 0.0
+    with pytest.raises(hip.EngineError, match=r"row %d has noise probability 0 outside \(0, 1\]" % (last // 2)):
+        hip_ctx.upload(bad)
+
+    bad = ClusterBatch.from_clusters(clusters)
+    row = int(bad.cluster_row_off[1])  # first row of the second cluster
+    entry = int(bad.grp_idx_off[int(bad.row_grp_off[row])])
+    n_paths = int(bad.cluster_path_off[2] - bad.cluster_path_off[1])
+    bad.path_idx[entry] = n_paths
+    with pytest.raises(hip.EngineError, match=r"row %d refers to path %d of a cluster with %d paths" % (row, n_paths, n_paths)):
+        hip_ctx.upload(bad)
+
+    bad = ClusterBatch.from_clusters(clusters)
+    bad.grp_idx_off[1] = bad.grp_idx_off[-1] + 7
+    with pytest.raises(hip.EngineError, match="inconsistent group or entry offsets"):
+        hip_ctx.upload(bad)
+    hip_ctx.upload(good)  # the context is still usable
