@@ -750,8 +750,8 @@ struct PairTileWork {
     const double * values;
     const double * row_count;
     const double * row_noise;
-    const uint64_t * col_part_off;   // [M] offset of the matrix's [chunk x marginal slice][G] partial column sums
-    const uint64_t * pair_part_off;  // [M] offset of the matrix's [chunk x slice][G][G] partial pair sums
+    const uint64_t * col_part_off;   // [M] offset of the matrix's [chunk][G] partial column sums
+    const uint64_t * pair_part_off;  // [M] offset of the matrix's [chunk][G][G] partial pair sums
     double * part_marginal;
     double * part_pair;
     unsigned long long * log_evals;
@@ -843,12 +843,12 @@ __global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork 
             lap(7);
             __syncthreads();  // the rows staged before have been used
             lap(1);
-            // lane = row (64 consecutive rows of a column: one 512-byte request), wave = column; eight requests of a
+            // lane = row (64 consecutive rows of a column: one 512-byte request), wave = column; sixteen requests of a
             // thread are in flight before the first is stored (the loop is all latency otherwise: ~25 dependent round
             // trips to memory per thread against ~5 us of arithmetic on the staged rows)
             {
                 const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-                constexpr uint32_t kAhead = 8;
+                constexpr uint32_t kAhead = 16;
                 for (uint32_t rb = 0; rb < ns; rb += 64) {
                     const uint32_t r = rb + lane;
                     const bool row_ok = r < ns;
@@ -962,25 +962,54 @@ __global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork 
             }
         }
         lap(5);
+        // The sums of a chunk: one per pair and column.  Slices add theirs up in LDS, in the order of the slices (the
+        // staged rows are done with), so that the resolving workgroup reads one part per chunk.
+        double * const out_pairs = w.part_pair + w.pair_part_off[m] + static_cast<uint64_t>(chunk) * G * G;
+        double * const out_columns = w.part_marginal + w.col_part_off[m] + static_cast<uint64_t>(chunk) * G;
+        double * const sums = tile_lds;                  // [S][tiles][16]
+        double * const column_sums = tile_lds + 16 * kTileBlock;  // [SM][T][4]
+        if (S > 1 || SM > 1) __syncthreads();
         if (active) {
-            double * out = w.part_pair + w.pair_part_off[m] + static_cast<uint64_t>(chunk * S + slice) * G * G;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t a = 4 * ta + i, b = 4 * tb + j;
                     const double total = acc[i][j] + pr[i][j].value(lt);
-                    if (a <= b && b < G) out[static_cast<uint64_t>(a) * G + b] = total;
+                    if (S > 1) sums[(slice * tiles + t) * 16 + i * 4 + j] = total;
+                    else if (a <= b && b < G) out_pairs[static_cast<uint64_t>(a) * G + b] = total;
                 }
             }
         }
         if (with_marginals) {
-            double * out = w.part_marginal + w.col_part_off[m] + static_cast<uint64_t>(chunk * SM + marg_slice) * G;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t a = 4 * tc + i;
                 const double total = accm[i] + prm[i].value(lt);
-                if (a < G) out[a] = total;
+                if (SM > 1) column_sums[(marg_slice * T + tc) * 4 + i] = total;
+                else if (a < G) out_columns[a] = total;
+            }
+        }
+        if (S > 1 || SM > 1) __syncthreads();
+        if (S > 1) {
+            for (uint32_t e = threadIdx.x; e < tiles * 16; e += kTileBlock) {
+                double total = 0.0;
+                for (uint32_t sl = 0; sl < S; ++sl) total += sums[sl * tiles * 16 + e];
+                const uint32_t te = e / 16, i = (e % 16) / 4, j = e % 4;
+                uint32_t lo = 0, hi = T - 1;  // row of tile te in the triangle
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1) >> 1;
+                    if (mid * T - mid * (mid - 1) / 2 <= te) lo = mid; else hi = mid - 1;
+                }
+                const uint32_t a = 4 * lo + i, b = 4 * (lo + (te - (lo * T - lo * (lo > 0 ? lo - 1 : 0) / 2))) + j;
+                if (a <= b && b < G) out_pairs[static_cast<uint64_t>(a) * G + b] = total;
+            }
+        }
+        if (SM > 1 && pass == 0 && !(w.debug_skip & 8u)) {
+            for (uint32_t e = threadIdx.x; e < T * 4; e += kTileBlock) {
+                double total = 0.0;
+                for (uint32_t sl = 0; sl < SM; ++sl) total += column_sums[sl * T * 4 + e];
+                if (e < G) out_columns[e] = total;
             }
         }
     }
@@ -1004,7 +1033,6 @@ struct ResolveArgs {
     const double * part_marginal;
     const double * part_optimistic;
     const double * part_pair;
-    uint32_t tile_parts;  // the partial sums come from pairTileKernel: tileSlices(G) parts per chunk of rows
     double min_log_likelihood_diff;
     double * log_freq;
     double * marginal;
@@ -1041,9 +1069,7 @@ __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t R = args.mat_rows[m];
     const uint32_t G = args.mat_cols[m];
-    const uint32_t row_chunks = static_cast<uint32_t>((R + kChunkRows - 1) / kChunkRows);
-    const uint32_t chunks = row_chunks * (args.tile_parts ? tileSlices(G) : 1u);  // parts to add up: pairs
-    const uint32_t col_chunks = row_chunks * (args.tile_parts ? marginalSlices(G) : 1u);  // ... single columns
+    const uint32_t chunks = static_cast<uint32_t>((R + kChunkRows - 1) / kChunkRows);
     const uint64_t c0 = args.col_off[m];
     const uint32_t * ccount = args.col_count + c0;
     double * lf = args.log_freq + c0;
@@ -1071,7 +1097,7 @@ __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args
         const double f = log(ccount[g] / count_sum);
         lf[g] = f;
         double acc = 0.0;
-        for (uint32_t c = 0; c < col_chunks; ++c) acc += pm[static_cast<uint64_t>(c) * G + g];
+        for (uint32_t c = 0; c < chunks; ++c) acc += pm[static_cast<uint64_t>(c) * G + g];
         marg[g] = (acc + f) + 0.0;
     }
     __syncthreads();
@@ -1285,7 +1311,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
             const uint32_t m = order[i];
             const uint64_t R = groups->h_num_rows[m], G = groups->h_num_cols[m];
             const uint64_t chunks = (R + kChunkRows - 1) / kChunkRows;
-            const uint64_t parts = chunks * (pair_tiles ? tileSlices(static_cast<uint32_t>(G)) : 1u);
+            const uint64_t parts = chunks;
             const bool fits = pair_part_total + parts * G * G <= table_budget;
             const bool takes_table = pair_tiles ? (G <= kTileMaxColumns && fits)
                                                 : (!table_closed && static_cast<double>(R) * G >= table_min_work && fits);
@@ -1297,7 +1323,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
             table_matrices.push_back(m);
             big_col_part_off[m] = col_part_total;
             big_pair_part_off[m] = pair_part_total;
-            col_part_total += (pair_tiles ? chunks * marginalSlices(static_cast<uint32_t>(G)) : parts) * G;
+            col_part_total += parts * G;
             pair_part_total += parts * G * G;
             for (uint32_t c = 0; c < chunks; ++c) {
                 for (uint32_t a = 0; a < (pair_tiles ? 1u : G); a += tile_step) {
@@ -1531,7 +1557,6 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         ra.part_marginal = d_part_marg.ptr;
         ra.part_optimistic = d_part_opt.ptr;
         ra.part_pair = d_part_pair.ptr;
-        ra.tile_parts = pair_tiles ? 1u : 0u;
         ra.min_log_likelihood_diff = args.min_log_likelihood_diff;
         ra.log_freq = d_lf.ptr;
         ra.marginal = d_marg.ptr;
