@@ -349,8 +349,8 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         line["gathered_abundance_mass"] = gathered
     if tpm_denominator is not None:
         line["tpm_denominator"] = tpm_denominator
-    # The log-likelihood kernels (branch-and-bound search, Gibbs conditionals) are FP64-issue bound, not HBM bound: their
-    # matrices are re-read from L2.  One evaluation = one row of one column set: an add and a multiply on the
+    # The log-likelihood kernels (diploid search, Gibbs conditionals) are FP64-issue bound, not HBM bound: the search reads
+    # its matrices once and works from LDS.  One evaluation = one row of one column set: an add and a multiply on the
     # running-product path (2 flop, the figure used here), a ~22-instruction logarithm on the rest.
     evals = stats["loglik_evals"]
     ll_ms = stats["loglik_ms"]
@@ -363,8 +363,10 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     if stats.get("search_pairs_possible"):
         search.update(pairs_possible_per_step=stats["search_pairs_possible"] / args.steps, pairs_kept_per_step=stats["search_pairs_kept"] / args.steps,
                       pairs_evaluated_exhaustively_per_step=stats["search_pairs_table"] / args.steps,
-                      pairs_note="possible = G(G+1)/2 per searched matrix; the pair-table path (matrices with rows x columns >= 65536) evaluates all of "
-                                 "its pairs where the reference stops at the ones its bound prunes; kept = pairs that survive the pruning")
+                      pairs_note="possible = G(G+1)/2 per searched matrix; evaluated exhaustively = pairs of the matrices whose every pair is "
+                                 "evaluated (pairTileKernel: all matrices up to 1024 columns) where the reference skips the first columns its "
+                                 "bound prunes (the sequential search reaches 4.1 of these 4.4 G row-pair evaluations anyway); kept = pairs "
+                                 "that survive the threshold")
     if s5:
         # no EM on this path: the device work is the FP64 log-likelihood contraction of the Gibbs conditionals, the rest of a
         # step is the host's sampler state machines (the reference's mt19937 / discrete_distribution streams, draw for draw)
@@ -372,7 +374,7 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         line["roofline"] = search
         line["host_sampler_ms_per_step"] = ms_per_step - (stats["loglik_ms"] + stats["build_ms"] + stats["h2d_ms"]) / args.steps
     else:
-        search["kernel"] = "boundedSearchKernel / pairTableKernel"
+        search["kernel"] = "pairTileKernel + resolveTableKernel"
         line["roofline_search"] = search
     if args.scale >= 1.0 and not s5 and DEVICE == "cuda":
         try:

@@ -725,7 +725,7 @@ __global__ __launch_bounds__(64) void pairRowsKernel(const PairRowsWork w) {
 //     workgroup, which adds parts anyway.
 // Rows with read counts 2 .. kMidMaxCount multiply that many times, the others take the table logarithm, as everywhere.
 constexpr uint32_t kTileBlock = 256;
-constexpr uint32_t kTileLdsDoubles = 7 * 1024;   // staged values + noise + counts: 56 KB (two workgroups per CU and room to spare)
+constexpr uint32_t kTileLdsDoubles = 6 * 1024;   // staged values + noise + counts: 48 KB (three workgroups per CU)
 constexpr uint32_t kTileMaxSubRows = 256;
 constexpr uint32_t kTileMaxColumns = 1024;       // wider matrices keep the sequential search (their pair tables would not fit either)
 
@@ -756,10 +756,10 @@ struct PairTileWork {
     double * part_pair;
     unsigned long long * log_evals;
     uint32_t debug_skip;  // timing experiments (RPVG_HIP_PAIR_DEBUG): 1 no count-1 rows, 2 no mid rows, 4 no other rows, 8 no marginals
-    unsigned long long * debug_cycles;  // [8] (RPVG_HIP_PAIR_DEBUG & 16) cycles of lane 0 of every workgroup: staging, barriers, count-1 rows, mid, rest, marginals, epilogue
 };
 
-__global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork w) {
+// (three waves per SIMD: what covers the LDS and staging latencies; 2.17 -> 1.61 ms per batch against two)
+__global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(3))) void pairTileKernel(const PairTileWork w) {
     extern __shared__ __attribute__((aligned(16))) double tile_lds[];
     __shared__ LogTableEntry lt[kLogTableSize];
     // items come expensive first and share nothing: workgroup b takes item b, which deals them round-robin to the XCDs
@@ -786,13 +786,6 @@ __global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork 
     const uint32_t nf = local(w.mat_fast[m]), nm = local(w.mat_mid[m]);  // class boundaries within the chunk
 
     // the lane's column of marginals (first pass only): columns 4 tc .. 4 tc + 3, every S-th row
-    unsigned long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long cyc_mark = __builtin_readcyclecounter();
-    auto lap = [&](const int slot) {
-        const unsigned long long now = __builtin_readcyclecounter();
-        cyc[slot] += now - cyc_mark;
-        cyc_mark = now;
-    };
     const uint32_t SM = marginalSlices(G);
     const uint32_t tc = threadIdx.x % T, marg_slice = threadIdx.x / T;
     const bool marg_active = marg_slice < SM;
@@ -840,15 +833,13 @@ __global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork 
 
         for (uint32_t s0 = 0; s0 < n; s0 += sub_rows) {
             const uint32_t ns = (n - s0) < sub_rows ? (n - s0) : sub_rows;
-            lap(7);
             __syncthreads();  // the rows staged before have been used
-            lap(1);
-            // lane = row (64 consecutive rows of a column: one 512-byte request), wave = column; sixteen requests of a
+            // lane = row (64 consecutive rows of a column: one 512-byte request), wave = column; eight requests of a
             // thread are in flight before the first is stored (the loop is all latency otherwise: ~25 dependent round
             // trips to memory per thread against ~5 us of arithmetic on the staged rows)
             {
                 const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-                constexpr uint32_t kAhead = 16;
+                constexpr uint32_t kAhead = 8;
                 for (uint32_t rb = 0; rb < ns; rb += 64) {
                     const uint32_t r = rb + lane;
                     const bool row_ok = r < ns;
@@ -872,9 +863,7 @@ __global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork 
                 lds_noise[r] = nz[s0 + r];
                 lds_count[r] = cnt[s0 + r];
             }
-            lap(0);
             __syncthreads();
-            lap(1);
             // class ranges inside the staged rows
             const uint32_t f1 = nf <= s0 ? 0u : ((nf - s0) < ns ? (nf - s0) : ns);
             const uint32_t m1 = nm <= s0 ? 0u : ((nm - s0) < ns ? (nm - s0) : ns);
@@ -894,7 +883,6 @@ __global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork 
                     }
                     if (++since_fold == kFoldFactors) foldPairs();
                 }
-                lap(2);
                 // read counts 2 .. kMidMaxCount: the factor that many times
                 for (uint32_t r = (w.debug_skip & 2u) ? m1 : f1 + (slice + S - f1 % S) % S; r < m1; r += S) {
                     const double2 u01 = *reinterpret_cast<const double2 *>(ua + r * Gs), u23 = *reinterpret_cast<const double2 *>(ua + r * Gs + 2);
@@ -919,7 +907,6 @@ __global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork 
                         }
                     }
                 }
-                lap(3);
                 // the rest: one logarithm per pair and row
                 for (uint32_t r = (w.debug_skip & 4u) ? ns : m1 + (slice + S - m1 % S) % S; r < ns; r += S) {
                     const double2 u01 = *reinterpret_cast<const double2 *>(ua + r * Gs), u23 = *reinterpret_cast<const double2 *>(ua + r * Gs + 2);
@@ -934,7 +921,6 @@ __global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork 
                     }
                 }
             }
-            lap(4);
             if (with_marginals) {  // single columns: noise + the whole value = noise + 2 halves
                 const double * ua = H + 4 * tc;
                 for (uint32_t r = marg_slice; r < ns; r += SM) {
@@ -961,14 +947,13 @@ __global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork 
                 }
             }
         }
-        lap(5);
         // The sums of a chunk: one per pair and column.  Slices add theirs up in LDS, in the order of the slices (the
         // staged rows are done with), so that the resolving workgroup reads one part per chunk.
         double * const out_pairs = w.part_pair + w.pair_part_off[m] + static_cast<uint64_t>(chunk) * G * G;
         double * const out_columns = w.part_marginal + w.col_part_off[m] + static_cast<uint64_t>(chunk) * G;
-        double * const sums = tile_lds;                  // [S][tiles][16]
-        double * const column_sums = tile_lds + 16 * kTileBlock;  // [SM][T][4]
-        if (S > 1 || SM > 1) __syncthreads();
+        double * const sums = tile_lds;         // [S][tiles][16], then
+        double * const column_sums = tile_lds;  // [SM][T][4]: one after the other in the same 32 KB
+        if (S > 1) __syncthreads();
         if (active) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -981,17 +966,8 @@ __global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork 
                 }
             }
         }
-        if (with_marginals) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t a = 4 * tc + i;
-                const double total = accm[i] + prm[i].value(lt);
-                if (SM > 1) column_sums[(marg_slice * T + tc) * 4 + i] = total;
-                else if (a < G) out_columns[a] = total;
-            }
-        }
-        if (S > 1 || SM > 1) __syncthreads();
         if (S > 1) {
+            __syncthreads();
             for (uint32_t e = threadIdx.x; e < tiles * 16; e += kTileBlock) {
                 double total = 0.0;
                 for (uint32_t sl = 0; sl < S; ++sl) total += sums[sl * tiles * 16 + e];
@@ -1005,19 +981,28 @@ __global__ __launch_bounds__(kTileBlock) void pairTileKernel(const PairTileWork 
                 if (a <= b && b < G) out_pairs[static_cast<uint64_t>(a) * G + b] = total;
             }
         }
-        if (SM > 1 && pass == 0 && !(w.debug_skip & 8u)) {
-            for (uint32_t e = threadIdx.x; e < T * 4; e += kTileBlock) {
-                double total = 0.0;
-                for (uint32_t sl = 0; sl < SM; ++sl) total += column_sums[sl * T * 4 + e];
-                if (e < G) out_columns[e] = total;
+        if (pass == 0 && !(w.debug_skip & 8u)) {
+            if (SM > 1) __syncthreads();
+            if (with_marginals) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t a = 4 * tc + i;
+                    const double total = accm[i] + prm[i].value(lt);
+                    if (SM > 1) column_sums[(marg_slice * T + tc) * 4 + i] = total;
+                    else if (a < G) out_columns[a] = total;
+                }
+            }
+            if (SM > 1) {
+                __syncthreads();
+                for (uint32_t e = threadIdx.x; e < T * 4; e += kTileBlock) {
+                    double total = 0.0;
+                    for (uint32_t sl = 0; sl < SM; ++sl) total += column_sums[sl * T * 4 + e];
+                    if (e < G) out_columns[e] = total;
+                }
             }
         }
     }
-    lap(6);
     if (threadIdx.x == 0) atomicAdd(w.log_evals, static_cast<unsigned long long>(static_cast<uint64_t>(G) * (G + 1) / 2 + G) * n);
-    if (w.debug_cycles && threadIdx.x == 0) {
-        for (int k = 0; k < 8; ++k) atomicAdd(w.debug_cycles + k, cyc[k]);
-    }
 }
 
 struct ResolveArgs {
@@ -1503,20 +1488,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
             pw.part_pair = d_part_pair.ptr;
             pw.log_evals = args.log_evals;
             pw.debug_skip = std::getenv("RPVG_HIP_PAIR_DEBUG") ? static_cast<uint32_t>(std::atoi(std::getenv("RPVG_HIP_PAIR_DEBUG"))) : 0u;
-            DeviceBuffer<unsigned long long> d_debug_cycles;
-            pw.debug_cycles = nullptr;
-            if (pw.debug_skip & 16u) {
-                ok(d_debug_cycles.alloc(8));
-                ok(hipMemsetAsync(d_debug_cycles.ptr, 0, 8 * sizeof(unsigned long long), st));
-                pw.debug_cycles = d_debug_cycles.ptr;
-            }
-            pairTileKernel<<<dim3(((pw.count + 7) / 8) * 8), dim3(kTileBlock), kTileLdsDoubles * sizeof(double), st>>>(pw);
-            if (pw.debug_cycles) {
-                unsigned long long cycles[8];
-                (void) hipMemcpy(cycles, d_debug_cycles.ptr, sizeof(cycles), hipMemcpyDeviceToHost);
-                std::fprintf(stderr, "[pair tiles] %u workgroups, cycles of lane 0 summed (100 MHz counter): staging %llu barriers %llu count-1 %llu mid %llu rest %llu marginals %llu epilogue %llu other %llu\n",
-                             pw.count, cycles[0], cycles[1], cycles[2], cycles[3], cycles[4], cycles[5], cycles[6], cycles[7]);
-            }
+            pairTileKernel<<<dim3(pw.count), dim3(kTileBlock), kTileLdsDoubles * sizeof(double), st>>>(pw);
         } else if (pair_rows) {
             PairRowsWork pw;
             pw.item_matrix = d_item_matrix.ptr;
