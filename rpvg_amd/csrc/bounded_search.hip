@@ -1281,7 +1281,8 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     if (pair_rows) table_min_work = 0.0;
     // every pair of every matrix from LDS-staged rows, a tile of pairs per lane (pairTileKernel): the default for a
     // threshold that is a ratio <= 1; RPVG_HIP_PAIR_TILES=0 keeps the sequential search with its table path (A/B)
-    static const bool tiles_wanted = []() { const char * env = std::getenv("RPVG_HIP_PAIR_TILES"); return env ? std::atoi(env) != 0 : true; }();
+    const char * tiles_env = std::getenv("RPVG_HIP_PAIR_TILES");  // (read per call: the tests switch between the two searches)
+    const bool tiles_wanted = tiles_env ? std::atoi(tiles_env) != 0 : true;
     const bool pair_tiles = tiles_wanted && !pair_rows && min_rel_likelihood <= 1;
     if (pair_tiles) table_min_work = 0.0;
     const uint32_t tile_step = pair_rows ? kTilePairA : kTileA;

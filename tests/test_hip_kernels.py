@@ -442,10 +442,11 @@ def test_bounded_search_on_device_matches_oracle(hip_ctx, normalise, thr, pair_l
         assert abs(got[m][1].sum() - 1) < 1e-9
 
 
-@pytest.mark.parametrize("force_table", [True, False])
+@pytest.mark.parametrize("force_table", [True, False, "tiles"])
 def test_bounded_search_table_path(hip_ctx, force_table):
     """Big matrices are resolved from a parallel pair table + prefix-max filter instead of the
-    in-workgroup sequential walk; both must give the reference's kept pairs, in its order."""
+    in-workgroup sequential walk; both must give the reference's kept pairs, in its order.  "tiles": the default search
+    (every pair of every matrix by pairTileKernel); the other two run the sequential kernels (RPVG_HIP_PAIR_TILES=0)."""
     rng = np.random.default_rng(711)
     clusters = [small_cases.make_cluster(rng, 3, [9, 7, 8], n_haps=40, n_reads=12000),
                 small_cases.make_cluster(rng, 2, [5, 4], n_haps=16, n_reads=600)]
@@ -457,12 +458,15 @@ def test_bounded_search_table_path(hip_ctx, force_table):
         groups.append(g)
         counts.append(mult)
     dg = hip_ctx.groups(dev, [0, 1], groups, True)
-    if force_table:
+    if force_table is True:
         os.environ["RPVG_HIP_TABLE_MIN_WORK"] = "0"
+    if force_table != "tiles":
+        os.environ["RPVG_HIP_PAIR_TILES"] = "0"
     try:
         got = dg.bounded_pair_posteriors(np.concatenate(counts), 1e-3)
     finally:
         os.environ.pop("RPVG_HIP_TABLE_MIN_WORK", None)
+        os.environ.pop("RPVG_HIP_PAIR_TILES", None)
     for m, cl in enumerate(clusters):
         M, noise, cnts = np_oracle.grouped_matrix(cl["rows"], groups[m])
         M = np_oracle.add_noise_and_normalize(M, noise)[:, :-1]
@@ -512,13 +516,16 @@ def test_row_classes_give_the_same_sums(hip_ctx, n_reads):
         cond = dg.conditionals([m], [[1]], 2, 2.0, [len(g) for g in groups])[0]
         want_c = np.array([np_oracle.set_loglik(M, noise, counts, (1, k), 2) for k in range(G)])
         assert small_cases.rel_close(cond, want_c, rel=1e-11, floor=1e-9)
-    for table in (False, True):
-        if table:
+    for table in (False, True, "tiles"):
+        if table is True:
             os.environ["RPVG_HIP_TABLE_MIN_WORK"] = "0"
+        if table != "tiles":
+            os.environ["RPVG_HIP_PAIR_TILES"] = "0"
         try:
             got = dg.bounded_pair_posteriors(np.concatenate(mult), 1e-3)
         finally:
             os.environ.pop("RPVG_HIP_TABLE_MIN_WORK", None)
+            os.environ.pop("RPVG_HIP_PAIR_TILES", None)
         for m, cl in enumerate(clusters):
             M, noise, counts = np_oracle.grouped_matrix(cl["rows"], groups[m])
             M = np_oracle.add_noise_and_normalize(M, noise)[:, :-1]
@@ -549,7 +556,7 @@ def test_bounded_search_with_a_positive_threshold(hip_ctx):
         assert small_cases.rel_close(got[m][1], post, rel=1e-9, floor=1e-300)
 
 
-@pytest.mark.parametrize("n_paths,n_reads", [(180, 500), (560, 2500)])
+@pytest.mark.parametrize("n_paths,n_reads", [(180, 500), (560, 2500), (1100, 700)])
 def test_bounded_search_with_more_columns_than_the_lds_rows_hold(hip_ctx, n_paths, n_reads):
     """More columns than the kernel keeps rows of pair log-likelihoods for in LDS (128 for the small-matrix kernel,
     512 for the other): one first column at a time, rows in global scratch.  The table path is switched off so that the
@@ -561,12 +568,18 @@ def test_bounded_search_with_more_columns_than_the_lds_rows_hold(hip_ctx, n_path
     mult = [p["source_count"] for p in cl["paths"]]
     dg = hip_ctx.groups(dev, [0], [groups], False)
     os.environ["RPVG_HIP_TABLE_MIN_WORK"] = "1e300"
+    os.environ["RPVG_HIP_PAIR_TILES"] = "0"
     try:
         got = dg.bounded_pair_posteriors(np.array(mult), 1e-3)
+        sequential = got
     finally:
         os.environ.pop("RPVG_HIP_TABLE_MIN_WORK", None)
+        os.environ.pop("RPVG_HIP_PAIR_TILES", None)
+    tiled = dg.bounded_pair_posteriors(np.array(mult), 1e-3)  # the default search: several passes of tiles over the staged rows
+    assert tiled[0][0] == sequential[0][0]
+    assert small_cases.rel_close(tiled[0][1], sequential[0][1], rel=1e-9, floor=1e-300)
     M, noise, counts = np_oracle.grouped_matrix(cl["rows"], groups)
-    assert M.shape[1] == n_paths and (M.shape[0] <= 512) == (n_paths == 180)
+    assert M.shape[1] == n_paths and (M.shape[0] <= 512) == (n_paths != 560)  # (1 100 columns: too wide for the tiles too)
     sets, post = pyoracle.group_posteriors(M, noise, counts, mult, 2, bounded=True, min_rel_lik=1e-3)
     assert got[0][0] == sets
     assert small_cases.rel_close(got[0][1], post, rel=1e-9, floor=1e-300)
