@@ -390,11 +390,13 @@ static int clusterChunk() {
 
 // Tens of thousands of small containers are freed by a team instead of one by one — now by the first lane (it never
 // waits, and finishes first), at the start of its next batch by any other lane (RetiredContainers, pipeline_lanes.hpp).
-static void dropNowOrLater(std::function<void(int)> drop) {
+// between_device_stages: the call sits between two GPU stages of the lane (search and EM) — the first lane keeps the
+// containers too then, until its work is done (PathEstimator::runInLanes drops them while it waits for the other lanes).
+static void dropNowOrLater(std::function<void(int)> drop, const bool between_device_stages = false) {
 
     static const bool never_later = std::getenv("RPVG_AMD_NO_DEFERRED_TEARDOWN") != nullptr;
 
-    if (never_later || HipEngine::currentLane() == 0) {
+    if (never_later || (HipEngine::currentLane() == 0 && !between_device_stages)) {
 
         drop(hostThreads());
 
@@ -484,7 +486,7 @@ void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstim
                 std::vector<uint32_t>().swap(old_posteriors->at(i).members);
                 std::vector<double>().swap(old_posteriors->at(i).posteriors);
             }
-        });
+        }, true);
 
     } else {
 
@@ -824,6 +826,8 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
     // one EM problem per retained subset: its distinct paths
     std::vector<size_t> first_problem(clusters.size() + 1, 0);
 
+    // (the subsets of a cluster sit in a node-based map: counted by the team, then one pass of additions)
+    #pragma omp parallel for schedule(static) num_threads(hostThreads())
     for (size_t i = 0; i < clusters.size(); ++i) {
 
         size_t num_retained = 0;
@@ -833,7 +837,12 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
             num_retained += (path_subset.second >= min_hap_prob);
         }
 
-        first_problem.at(i + 1) = first_problem.at(i) + num_retained;
+        first_problem.at(i + 1) = num_retained;
+    }
+
+    for (size_t i = 0; i < clusters.size(); ++i) {
+
+        first_problem.at(i + 1) += first_problem.at(i);
     }
 
     std::vector<EMProblem> problems(first_problem.back());

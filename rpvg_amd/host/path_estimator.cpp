@@ -520,6 +520,12 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
     if (num_lanes == 1 || clusters.size() < 64 || HipEngine::currentLane() != 0) {
 
         work(clusters, []() {});
+
+        if (HipEngine::currentLane() == 0) {
+
+            RetiredContainers::ofThisThread().dropAll();  // what the work kept for later
+        }
+
         return;
     }
 
@@ -613,6 +619,9 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
     }
 
     stagger.passBaton(0);
+
+    // the first lane is done before the others: time for the containers it kept between its device stages
+    RetiredContainers::ofThisThread().dropAll();
 
     hostThreadsOverride() = outer_threads;
 
