@@ -394,7 +394,7 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
               batch.grp_idx_off, batch.path_idx]
     for a in arrays:
         hip.host_register(a)
-    uploader = eng_mod.Engine(local_rank)
+    uploader = eng_mod.Engine(local_rank, uploader=True)
     slots = [prepared, eng.prepare(batch)]
     try:
         upload_s = []

@@ -46,6 +46,12 @@ typedef struct rpvg_hip_groups rpvg_hip_groups; /* device-resident group (column
 /* ---- context ------------------------------------------------------------ */
 int rpvg_hip_device_count(int * count);
 int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out);
+/* A context for rpvg_hip_batch_upload next to contexts that estimate on the same GPU (the rows of batch n + 1 copied
+ * under the kernels of batch n; the reference has no analogue: its rows never leave the host, SURVEY.md section 8d puts
+ * the copy inside the metric).  Its stream has the device's highest priority, which gives it a hardware queue of its
+ * own: the copies and expansion kernels do not queue behind the estimating contexts' kernels (measured: 10.6 -> 7.3 ms
+ * per 280 MB batch while a batch is estimated, 14.7 -> 13.7 ms per batch in steady state). */
+int rpvg_hip_create_uploader(int device, rpvg_hip_ctx ** ctx_out);
 void rpvg_hip_destroy(rpvg_hip_ctx * ctx);
 const char * rpvg_hip_last_error(void);
 int rpvg_hip_synchronize(rpvg_hip_ctx * ctx);

@@ -374,9 +374,9 @@ namespace {
 // priority the short ones of one lane get their workgroups in between those of the other lane's long kernels
 // — the idea; measured 17.4-17.8 ms per configs[2] batch against 15.1-15.9 ms with all streams alike (same box, same
 // call), so it is off unless RPVG_HIP_MAIN_PRIORITY=1.
-hipError_t createMainStream(hipStream_t * stream) {
-    static const char * env = std::getenv("RPVG_HIP_MAIN_PRIORITY");
-    if (!env || std::atoi(env) == 0) return hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
+hipError_t createMainStream(hipStream_t * stream, const bool highest_priority) {
+    const char * env = std::getenv("RPVG_HIP_MAIN_PRIORITY");  // A/B knob: every context's stream at the highest priority (slower)
+    if (!highest_priority && (!env || std::atoi(env) == 0)) return hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
         (void) hipGetLastError();
@@ -384,9 +384,16 @@ hipError_t createMainStream(hipStream_t * stream) {
     }
     return hipStreamCreateWithPriority(stream, hipStreamNonBlocking, greatest);
 }
+
+int createContext(int device, bool uploader, rpvg_hip_ctx ** ctx_out);
 }  // namespace
 
-int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) {
+int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) { return createContext(device, false, ctx_out); }
+
+int rpvg_hip_create_uploader(int device, rpvg_hip_ctx ** ctx_out) { return createContext(device, true, ctx_out); }
+
+namespace {
+int createContext(int device, const bool uploader, rpvg_hip_ctx ** ctx_out) {
     RPVG_REQUIRE(ctx_out != nullptr, "rpvg_hip_create: ctx_out is NULL");
     *ctx_out = nullptr;
     int n = 0;
@@ -405,7 +412,7 @@ int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) {
     ctx->device = device;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->props, device)) != hipSuccess ||
-        (e = createMainStream(&ctx->stream)) != hipSuccess) {
+        (e = createMainStream(&ctx->stream, uploader)) != hipSuccess) {
         setError("rpvg_hip_create: %s", hipGetErrorString(e));
         delete ctx;
         return RPVG_HIP_ERR_RUNTIME;
@@ -440,6 +447,7 @@ int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) {
     *ctx_out = ctx;
     return RPVG_HIP_OK;
 }
+}  // namespace
 
 void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
     if (!ctx) return;

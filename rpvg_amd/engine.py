@@ -32,6 +32,8 @@ def lib() -> C.CDLL:
         L.rpvg_amd_last_error.restype = C.c_char_p
         L.rpvg_amd_engine_create.restype = C.c_void_p
         L.rpvg_amd_engine_create.argtypes = [C.c_int]
+        L.rpvg_amd_engine_create_uploader.restype = C.c_void_p
+        L.rpvg_amd_engine_create_uploader.argtypes = [C.c_int]
         L.rpvg_amd_engine_destroy.argtypes = [C.c_void_p]
         L.rpvg_amd_engine_ctx.restype = C.c_void_p
         L.rpvg_amd_engine_ctx.argtypes = [C.c_void_p]
@@ -73,8 +75,9 @@ def _err() -> str:
 class Engine:
     """One GPU (HipEngine) shared by the estimators created on it."""
 
-    def __init__(self, device: int = 0):
-        self.handle = lib().rpvg_amd_engine_create(device)
+    def __init__(self, device: int = 0, uploader: bool = False):
+        """uploader: an engine that only uploads batches (PreparedBatch.reupload) next to the one that estimates."""
+        self.handle = lib().rpvg_amd_engine_create_uploader(device) if uploader else lib().rpvg_amd_engine_create(device)
         if not self.handle:
             raise hip.EngineError(f"engine create failed: {_err()}")
 

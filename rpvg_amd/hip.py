@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librpvg_hip.so")
 
 # every symbol include/rpvg_hip.h declares
 EXPORTS = [
-    "rpvg_hip_device_count", "rpvg_hip_create", "rpvg_hip_destroy", "rpvg_hip_last_error", "rpvg_hip_synchronize",
+    "rpvg_hip_device_count", "rpvg_hip_create", "rpvg_hip_create_uploader", "rpvg_hip_destroy", "rpvg_hip_last_error", "rpvg_hip_synchronize",
     "rpvg_hip_device_info", "rpvg_hip_malloc", "rpvg_hip_free", "rpvg_hip_memcpy_h2d", "rpvg_hip_memcpy_d2h",
     "rpvg_hip_batch_upload", "rpvg_hip_batch_free", "rpvg_hip_em_solve", "rpvg_hip_em_dense",
     "rpvg_hip_dense_from_cluster", "rpvg_hip_groups_build", "rpvg_hip_groups_free", "rpvg_hip_groups_collapse_info", "rpvg_hip_group_loglik",

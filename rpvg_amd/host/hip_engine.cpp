@@ -28,10 +28,10 @@ static void keepHeapTop() {
     });
 }
 
-HipEngine::HipEngine(const int device) : context(nullptr), device_id(device) {
+HipEngine::HipEngine(const int device, const bool uploader) : context(nullptr), device_id(device) {
 
     keepHeapTop();
-    check(rpvg_hip_create(device, &context), "rpvg_hip_create");
+    check(uploader ? rpvg_hip_create_uploader(device, &context) : rpvg_hip_create(device, &context), "rpvg_hip_create");
 }
 
 HipEngine::~HipEngine() {

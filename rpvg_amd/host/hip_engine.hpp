@@ -29,7 +29,9 @@ class HipEngine {
 
     public:
 
-        explicit HipEngine(const int device);
+        // uploader: an engine whose only job is DeviceClusterBatch construction next to an estimating engine on the same GPU
+        // (rpvg_hip_create_uploader: a stream, and a hardware queue, of its own)
+        explicit HipEngine(const int device, const bool uploader = false);
         ~HipEngine();
 
         HipEngine(const HipEngine &) = delete;

@@ -183,6 +183,22 @@ void * rpvg_amd_engine_create(int device) {
     }
 }
 
+// an engine for rpvg_amd_batch_reupload next to the engine that estimates (HipEngine(device, uploader = true))
+void * rpvg_amd_engine_create_uploader(int device) {
+
+    try {
+
+        Engine * engine = new Engine();
+        engine->hip = std::make_shared<HipEngine>(device, true);
+        return engine;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return nullptr;
+    }
+}
+
 void rpvg_amd_engine_destroy(void * engine) {
 
     delete static_cast<Engine *>(engine);

@@ -16,7 +16,7 @@ class Prepared:
 
 
 class Engine:
-    def __init__(self, device=0):
+    def __init__(self, device=0, uploader=False):
         self.device = device
 
     def close(self):

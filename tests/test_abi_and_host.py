@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_library_exports_runner_symbols():
     from rpvg_amd import engine
     lib = engine.lib()
-    for name in ("rpvg_amd_engine_create", "rpvg_amd_engine_destroy", "rpvg_amd_batch_prepare", "rpvg_amd_batch_free",
+    for name in ("rpvg_amd_engine_create", "rpvg_amd_engine_create_uploader", "rpvg_amd_engine_destroy", "rpvg_amd_batch_prepare", "rpvg_amd_batch_free",
                  "rpvg_amd_run", "rpvg_amd_run_inplace", "rpvg_amd_result_view", "rpvg_amd_result_free",
                  "rpvg_amd_synth_generate", "rpvg_amd_rows_from_likelihoods", "rpvg_amd_last_error"):
         assert hasattr(lib, name)
