@@ -41,8 +41,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # FP64 vector rate = half the 157 TF FP32 vector r
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="s3", choices=["s3", "c2", "s5", "rows", "e2e"],
                     help="s3: BASELINE.json configs[2]/[3] (default, the metric's configuration); c2: configs[1] single dense "
                          "cluster; s5: configs[4] diploid haplotype Gibbs, 10M reads x 500k paths; rows: the step before the path "
