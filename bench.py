@@ -677,8 +677,11 @@ def run_c2(args, rank, local_rank, world, dist, torch):
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_c2.json")
     if os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
-        if pmc["shape"]["rows"] == R and pmc["shape"]["cols"] == Cn:  # per launch of THIS rank's shard
-            traffic = pmc["traffic_bytes_per_launch"]  # separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE)
+        shape = pmc.get("shape", {})
+        if shape.get("rows") == R and shape.get("cols") == Cn:  # per launch of THIS rank's shard
+            # separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE); tools/pmc_traffic.py
+            # calls a launch a step
+            traffic = pmc.get("traffic_bytes_per_launch", pmc.get("traffic_bytes_per_step"))
     line = dict(
         metric="read-pairs quantified/sec", value=reads_all / (elapsed / args.steps), unit="read-pairs/s", n_gpus=world,
         steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,

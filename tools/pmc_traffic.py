@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--steps", type=int, required=True, help="hot-path passes (warmup + timed) the profiled command ran")
     ap.add_argument("--double-fetch", action="store_true")
     ap.add_argument("--command", default="")
+    ap.add_argument("--shape", default="", help="rows,cols,ld of the matrix the kernel streamed (recorded; bench.py checks it)")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     fetch_kb, n_fetch = total(args.fetch_dir, "FETCH_SIZE", args.kernel)
@@ -56,6 +57,9 @@ def main():
                            "none: the kernel's loads are 4 and 8 B per lane, for which the guide gives no calibration"),
                traffic_bytes_per_step=(fetch_bytes + write_bytes) / args.steps,
                fetch_bytes_per_step=fetch_bytes / args.steps, write_bytes_per_step=write_bytes / args.steps)
+    if args.shape:
+        rows, cols, ld = (int(x) for x in args.shape.split(","))
+        out["shape"] = dict(rows=rows, cols=cols, ld=ld)
     with open(args.out, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
