@@ -766,8 +766,8 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(3)))
     // (contiguous ranges per XCD, as the kernels above have them for their L2, gave one XCD all the large matrices)
     const uint32_t item = blockIdx.x;
     if (item >= w.count) return;
-    loadLogTable(lt);  // visible after the first barrier below
     const uint32_t m = w.item_matrix[item], chunk = w.item_chunk[item];
+    loadLogTable(lt);  // visible after the first barrier below
     const uint64_t R = w.mat_rows[m];
     const uint32_t G = w.mat_cols[m];
     const uint32_t T = tileColumns(G), tiles = tileCount(G), S = tileSlices(G);
@@ -1444,9 +1444,14 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     }();
     hipStream_t s_medium = search_streams == 1 ? st : ctx->aux[0];
     hipStream_t s_small = search_streams == 1 ? st : (search_streams == 2 ? ctx->aux[0] : ctx->aux[1]);
+    // The row collapse of the matrices runs on a stream of its own behind their build (rpvg_hip_groups_build): the uploads
+    // above did not wait for it, the kernels do.  (Searching the matrices as built and once more the few the collapse
+    // replayed was tried: its small kernels then wait for slots next to the search's large one, no gain.)
+    const bool side_kernels = M > num_big;  // the sequential kernels on the aux streams
+    ok(groups->waitCollapse(st));
     span = ctx->spanBegin(FAM_LOGLIK);
     searchGateEnter(ctx, st);
-    ok(ctx->forkAux());
+    if (side_kernels) ok(ctx->forkAux());
     if (num_big > 0) {
         TableWork tw;
         tw.item_matrix = d_item_matrix.ptr;
@@ -1565,7 +1570,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         args.row_lds_cols = kSmallRowLdsCols;
         boundedSearchKernel<256, 16><<<dim3(args.count), dim3(256), search_lds_bytes(kSmallRows, kSmallRowLdsCols), s_small>>>(args);
     }
-    ok(ctx->joinAux());
+    if (side_kernels) ok(ctx->joinAux());
     searchGateLeave(ctx, st);
     ctx->spanEnd(span);
     ctx->stats.loglik_launches += (num_big > 0 ? 2 : 0) + (num_medium > 0) + (M > num_big + num_medium);

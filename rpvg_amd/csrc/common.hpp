@@ -563,6 +563,7 @@ struct rpvg_hip_ctx {
     // overlap instead of adding up.  forkAux() makes them wait for the work queued on `stream` so far,
     // joinAux() makes `stream` wait for them.
     hipStream_t aux[kAuxStreams] = {};
+    hipStream_t collapse_stream = nullptr;  // row collapse of the matrices a build leaves behind (highest priority: short kernels next to a search)
     hipStream_t copy_stream = nullptr;  // staged uploads (stagedCopy)
     hipEvent_t copied = nullptr;
     hipEvent_t fork_event = nullptr;
@@ -643,6 +644,18 @@ struct rpvg_hip_groups {
     rpvg_hip_detail::DeviceBuffer<uint64_t> collapse_mask; // [sum R_m] zero pattern of the first 64 columns
     rpvg_hip_detail::DeviceBuffer<uint32_t> collapse_segment_off;  // [M + 1] mat_row_off as 32-bit segment offsets
     rpvg_hip_detail::DeviceBuffer<uint32_t> collapse_info;
+    // The row collapse runs on the building context's collapse stream behind the build; whoever reads the matrices
+    // makes its stream wait for it (waitCollapse): what a consumer queues before its kernels — uploads, allocations —
+    // does not.
+    hipEvent_t built = nullptr, collapse_done = nullptr;
+    hipError_t waitCollapse(hipStream_t stream) const { return collapse_done ? hipStreamWaitEvent(stream, collapse_done, 0) : hipSuccess; }
+    ~rpvg_hip_groups() {
+        if (collapse_done) {
+            (void) hipEventSynchronize(collapse_done);  // the collapse kernels use the buffers below
+            (void) hipEventDestroy(collapse_done);
+        }
+        if (built) (void) hipEventDestroy(built);
+    }
     rpvg_hip_detail::UploadPack uploads;  // the block behind the small arrays (views: mat_*, build temporaries, build_error_flag)
     mutable bool build_checked = false;
     // RPVG_HIP_OK, or the error of the build (after a sync of `stream`); consumers call it before trusting results

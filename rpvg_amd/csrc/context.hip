@@ -421,6 +421,7 @@ int createContext(int device, const bool uploader, rpvg_hip_ctx ** ctx_out) {
         e = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_event[i], hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = createMainStream(&ctx->collapse_stream, std::getenv("RPVG_HIP_COLLAPSE_PRIORITY") == nullptr || std::atoi(std::getenv("RPVG_HIP_COLLAPSE_PRIORITY")) != 0);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->search_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
@@ -468,6 +469,10 @@ void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
         if (ctx->aux[i]) (void) hipStreamDestroy(ctx->aux[i]);
         if (ctx->join_event[i]) (void) hipEventDestroy(ctx->join_event[i]);
     }
+    if (ctx->collapse_stream) {
+        (void) hipStreamSynchronize(ctx->collapse_stream);
+        (void) hipStreamDestroy(ctx->collapse_stream);
+    }
     if (ctx->fork_event) (void) hipEventDestroy(ctx->fork_event);
     searchGateForget(ctx);
     if (ctx->search_done) (void) hipEventDestroy(ctx->search_done);
@@ -495,6 +500,7 @@ int rpvg_hip_synchronize(rpvg_hip_ctx * ctx) {
     std::lock_guard<std::mutex> lock(ctx->mutex);
     RPVG_HIP_CHECK(hipSetDevice(ctx->device));
     RPVG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->collapse_stream) RPVG_HIP_CHECK(hipStreamSynchronize(ctx->collapse_stream));
     return RPVG_HIP_OK;
 }
 

@@ -638,7 +638,20 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
                 g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_mask.ptr, g->halves.ptr, g->mat_half_off.ptr);
         }
         sub.reset(new HostScope("groups_build: row collapse launches"));
-        if (collapse && e == hipSuccess) ok(queueRowCollapse(ctx, g, row_total, spec->collapse_precision, st));
+        if (collapse && e == hipSuccess) {
+            // on the context's collapse stream, behind the build (rpvg_hip_groups::collapse_done)
+            hipStream_t collapse_stream = ctx->collapse_stream;
+            static const bool same_stream = std::getenv("RPVG_HIP_COLLAPSE_INLINE") != nullptr;  // A/B knob: on the build's stream (11.5-12.1 vs 10.2-10.4 ms per batch)
+            if (same_stream) collapse_stream = st;
+            ok(hipEventCreateWithFlags(&g->built, hipEventDisableTiming));
+            ok(hipEventCreateWithFlags(&g->collapse_done, hipEventDisableTiming));
+            if (e == hipSuccess && collapse_stream != st) {
+                ok(hipEventRecord(g->built, st));
+                ok(hipStreamWaitEvent(collapse_stream, g->built, 0));
+            }
+            if (e == hipSuccess) ok(queueRowCollapse(ctx, g, row_total, spec->collapse_precision, collapse_stream));
+            if (e == hipSuccess) ok(hipEventRecord(g->collapse_done, collapse_stream));
+        }
         sub.reset();
         ctx->spanEnd(span);
         ctx->stats.build_launches += 3;
@@ -680,7 +693,7 @@ extern "C" void rpvg_hip_groups_free(rpvg_hip_ctx * ctx, rpvg_hip_groups * group
         (void) hipSetDevice(ctx->device);
         (void) hipStreamSynchronize(ctx->stream);
         static const bool trace = std::getenv("RPVG_AMD_TRACE") != nullptr;
-        if (trace && groups->collapse_info.ptr) {
+        if (trace && groups->collapse_info.ptr && groups->waitCollapse(ctx->stream) == hipSuccess) {
             uint32_t info[4] = {0, 0, 0, 0};
             // (on the context's stream: a plain hipMemcpy waits for every stream of the device, the other lane's search included)
             if (hipMemcpyAsync(info, groups->collapse_info.ptr, sizeof(info), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
@@ -718,6 +731,7 @@ extern "C" int rpvg_hip_group_loglik(rpvg_hip_ctx * ctx, const rpvg_hip_groups *
     std::lock_guard<std::mutex> lock(ctx->mutex);
     RPVG_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    RPVG_HIP_CHECK(groups->waitCollapse(st));
     DeviceBuffer<uint32_t> d_matrix, d_members;
     DeviceBuffer<uint8_t> d_flag;
     DeviceBuffer<double> d_out;
@@ -780,6 +794,7 @@ extern "C" int rpvg_hip_group_conditionals(rpvg_hip_ctx * ctx, const rpvg_hip_gr
     std::lock_guard<std::mutex> lock(ctx->mutex);
     RPVG_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    RPVG_HIP_CHECK(groups->waitCollapse(st));
     DeviceBuffer<uint32_t> d_matrix, d_others;
     DeviceBuffer<uint64_t> d_item_off, d_out_off;
     DeviceBuffer<double> d_out;

@@ -952,6 +952,7 @@ extern "C" int rpvg_hip_groups_collapse_info(rpvg_hip_ctx * ctx, const rpvg_hip_
     if (groups->collapse_info.ptr) {
         std::lock_guard<std::mutex> lock(ctx->mutex);
         RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+        RPVG_HIP_CHECK(groups->waitCollapse(ctx->stream));
         RPVG_HIP_CHECK(hipMemcpyAsync(info, groups->collapse_info.ptr, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
         RPVG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
