@@ -464,8 +464,9 @@ def dense_em_roofline(local_rank, rows=1000000, paths=2000, its=20):
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_c2.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            if pmc["shape"]["rows"] == rows and pmc["shape"]["cols"] == Cn:
-                traffic = pmc["traffic_bytes_per_launch"]
+            shape = pmc.get("shape", {})
+            if shape.get("rows") == rows and shape.get("cols") == Cn:
+                traffic = pmc.get("traffic_bytes_per_launch", pmc.get("traffic_bytes_per_step"))  # (tools/pmc_traffic.py calls a launch a step)
         return dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                     kernel="emDenseAccumWideKernel", ms_per_launch=ms, algorithmic_bytes_per_launch=nbytes,
                     workload=f"single dense cluster {rows} x {Cn} FP64 ({rows * Cn * 8 / 1e9:.1f} GB), {its} EM iterations; "
