@@ -157,3 +157,15 @@ def test_reference_factory_compiles_with_the_reference_constructor_lists():
     if not torch.cuda.is_available():
         out = subprocess.run([binary, "transcripts"], capture_output=True, text=True)
         assert out.returncode != 0 and "no CPU fallback" in out.stderr
+
+
+def test_source_id_set_behaves_like_the_set_it_replaces():
+    """PathInfo::source_ids: insert / emplace / count / find / iteration as the reference's code uses them, one sorted array."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "tests", "cpp", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    binary = os.path.join(out_dir, "source_id_set")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(root, "rpvg_amd", "host"),
+                           os.path.join(root, "tests", "cpp", "source_id_set.cpp"), "-o", binary])
+    assert subprocess.run([binary], capture_output=True, text=True, check=True).stdout.strip() == "ok"
