@@ -170,10 +170,6 @@ typedef struct rpvg_hip_group_spec {
      * on every normalised group matrix, src/path_abundance_estimator.cpp:380,443) with this prob_precision — every
      * row takes the values of the head of its run in the reference's tolerant row order; 0: rows stay as built. */
     double collapse_precision;
-    /* != 0: also keep the layout rpvg_hip_bounded_pair_posteriors evaluates all pairs of a matrix from at once
-     * (a row-major copy of the halved values, +1x the memory of the matrices); 0: the search walks the
-     * column-major matrices in the reference's sequential order. */
-    int32_t pair_layout;
 } rpvg_hip_group_spec;
 
 /* Returns once the build is queued on the context's stream (the spec arrays have been consumed by then); a group that

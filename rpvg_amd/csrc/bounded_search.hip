@@ -510,209 +510,16 @@ __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
 }
 
 
-// ---- all pairs of a matrix, lane = second column -----------------------------------------------------------------
-//
-// The sequential search prunes little where it matters (configs[2] bench: 4.1 of the 4.4 G row-pair evaluations of
-// "all pairs" are reached anyway), and "keep iff ll - max(all pairs before) >= thr" needs no order of evaluation
-// (above).  So every pair of every matrix is evaluated, by a kernel built around the arithmetic alone: from the
-// row-major halved copy of the matrix (rpvg_hip_group_spec::pair_layout) a wave takes kTilePairA first columns and 64
-// second columns, lane = second column b, and walks the rows of its chunk.  Per row the lane loads ONE value
-// (coalesced: the row is contiguous), adds the row's noise, and for each first column a adds H[row][a] — the same for
-// every lane, so it arrives through a scalar load and sits in an SGPR — and multiplies the sum into the pair's running
-// product (LogProduct): two FP64 instructions per pair and row, the minimum, no LDS traffic and no cross-lane
-// reduction (the lane owns its pairs).  Rows with read count 2 .. 8 multiply that many times (the count is uniform
-// over the wave), the few others take the table logarithm.  Partial sums per row chunk go to the pair table the
-// resolving workgroup reads.
-constexpr int kTilePairA = 8;
-
-struct PairRowsWork {
-    const uint32_t * item_matrix;   // [W]
-    const uint32_t * item_col;      // [W] first column of the tile (multiple of kTilePairA)
-    const uint32_t * item_chunk;    // [W]
-    uint32_t count;
-    const uint64_t * mat_half_off;
-    const uint64_t * mat_row_off;
-    const uint32_t * mat_fast;
-    const uint32_t * mat_mid;
-    const uint64_t * mat_rows;
-    const uint32_t * mat_cols;
-    const double * halves;
-    const double * row_count;
-    const double * row_noise;
-    const uint64_t * col_part_off;   // [M] offset of the matrix's [chunk][G] partial column sums
-    const uint64_t * pair_part_off;  // [M] offset of the matrix's [chunk][G][G] partial pair sums
-    double * part_marginal;
-    double * part_pair;
-    unsigned long long * log_evals;
-    uint32_t debug_skip;  // timing experiments (RPVG_HIP_PAIR_DEBUG): 1 no count-1 rows, 2 no mid rows, 4 no other rows
-};
-
-// loads through this pointer type (the constant address space: same memory, read-only by contract) become scalar
-// loads when their address is uniform — the values land in SGPRs and cost the vector unit nothing
-typedef const double __attribute__((address_space(4))) * UniformDoubles;
-
-// Two passes over the same work items: kCountOneRows — the rows with read count 1, four of five, nothing but the
-// multiply chain: few registers, eight waves per SIMD to cover the latency of the scalar loads — writes the partial
-// sums; the pass over the other rows (more registers: logarithms, count loops) adds to them.
-template <bool kCountOneRows>
-__global__ __launch_bounds__(64) void pairRowsKernel(const PairRowsWork w) {
-    __shared__ LogTableEntry lt[kLogTableSize];
-    const uint32_t per_xcd = (w.count + 7) / 8;
-    const uint32_t item = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;  // contiguous ranges of items per XCD (L2)
-    if (item >= w.count) return;
-    const int lane = threadIdx.x;
-    // everything below that does not involve `lane` is the same in all lanes of this one-wave workgroup: scalar registers
-    const uint32_t m = w.item_matrix[item], a0 = w.item_col[item], chunk = w.item_chunk[item];
-    if (!kCountOneRows) {  // nothing but count-1 rows in this chunk: the first pass has it all
-        const uint64_t chunk_end = min(w.mat_rows[m], (static_cast<uint64_t>(chunk) + 1) * kChunkRows);
-        if (w.mat_fast[m] >= chunk_end) return;
-    }
-    loadLogTable(lt);
-    __syncthreads();
-    const uint64_t R = w.mat_rows[m];
-    const uint32_t G = w.mat_cols[m];
-    const uint32_t ld = (G + 7u) & ~7u;
-    const uint64_t r_begin = static_cast<uint64_t>(chunk) * kChunkRows;
-    const uint32_t n = static_cast<uint32_t>((R - r_begin) < kChunkRows ? (R - r_begin) : kChunkRows);
-    const double * __restrict__ H = w.halves + w.mat_half_off[m] + r_begin * ld;
-    const UniformDoubles Hu = (UniformDoubles) (H + a0);  // the tile's first columns: H[row][a0 + t], uniform
-    const UniformDoubles cnt = (UniformDoubles) (w.row_count + w.mat_row_off[m] + r_begin);
-    const UniformDoubles nz = (UniformDoubles) (w.row_noise + w.mat_row_off[m] + r_begin);
-    auto local = [&](const uint64_t end_row) { return end_row <= r_begin ? 0u : (end_row - r_begin < n ? static_cast<uint32_t>(end_row - r_begin) : n); };
-    const uint32_t nf = local(w.mat_fast[m]), nm = local(w.mat_mid[m]);  // class boundaries within the chunk
-    const bool with_marginals = a0 == 0;  // the tile that starts the matrix also sums the single columns
-    double * part_pair = w.part_pair + w.pair_part_off[m] + static_cast<uint64_t>(chunk) * G * G;
-    double * part_marginal = w.part_marginal + w.col_part_off[m] + static_cast<uint64_t>(chunk) * G;
-    constexpr uint32_t kRing = 8;                                  // rows whose values a lane has requested ahead of their use
-    constexpr uint32_t kSegment = (kFoldFactors / kRing) * kRing;  // rows between folds: whole turns of the ring
-
-    for (uint32_t b0 = (a0 / 64) * 64; b0 < G; b0 += 64) {
-        const uint32_t b = b0 + lane;
-        const double * __restrict__ Hb = H + (b < G ? b : G - 1);  // this lane's second column: Hb[row * ld]
-        LogProduct pr[kTilePairA], pr_single;
-        double acc[kTilePairA], acc_single = 0.0;
-#pragma unroll
-        for (int t = 0; t < kTilePairA; ++t) acc[t] = 0.0;
-        // Read count 1: one multiplication per pair and row, the exponents fold out every kSegment rows.  A lane's own
-        // values are requested kRing rows ahead of their use (a ring of registers, each reloaded as soon as it has been
-        // used); the tile's values and the noise of a row are the same for all lanes: scalar loads, requested two rows
-        // ahead of their use.
-        auto ahead = [&](const uint32_t r) { return Hb[static_cast<uint64_t>(r < n ? r : 0) * ld]; };
-        double ring[kRing];
-#pragma unroll
-        for (uint32_t k = 0; k < kRing; ++k) ring[k] = ahead(k);
-        struct RowScalars {
-            double base[kTilePairA], noise;
-        };
-        auto fetch = [&](const uint32_t r, RowScalars & out) {
-            const uint32_t rr = r < n ? r : 0;
-            const UniformDoubles row = Hu + static_cast<uint64_t>(rr) * ld;
-#pragma unroll
-            for (int t = 0; t < kTilePairA; ++t) out.base[t] = row[t];
-            out.noise = nz[rr];
-        };
-        RowScalars s0, s1;
-        fetch(0, s0);
-        fetch(1, s1);
-        uint32_t i = (!kCountOneRows || (w.debug_skip & 1u)) ? nf : 0u;
-        while (i < nf) {
-            const uint32_t seg_end = (nf - i) < kSegment ? nf : i + kSegment;
-            for (; i + kRing <= seg_end; i += kRing) {
-#pragma unroll
-                for (uint32_t k = 0; k < kRing; k += 2) {
-                    RowScalars n0, n1;
-                    fetch(i + k + 2, n0);
-                    fetch(i + k + 3, n1);
-                    const double x0 = ring[k], x1 = ring[k + 1];
-                    ring[k] = ahead(i + kRing + k);
-                    ring[k + 1] = ahead(i + kRing + k + 1);
-                    __builtin_amdgcn_sched_barrier(0);  // the requests above stay above the arithmetic below
-                    const double y0 = x0 + s0.noise, y1 = x1 + s1.noise;
-#pragma unroll
-                    for (int t = 0; t < kTilePairA; ++t) pr[t].mul(y0 + s0.base[t]);
-#pragma unroll
-                    for (int t = 0; t < kTilePairA; ++t) pr[t].mul(y1 + s1.base[t]);
-                    if (with_marginals) {
-                        pr_single.mul(y0 + x0);
-                        pr_single.mul(y1 + x1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    s0 = n0;
-                    s1 = n1;
-                }
-            }
-            if (i + kRing > nf) {  // the last rows of the class, fewer than a turn: straight from memory
-                for (; i < nf; ++i) {
-                    RowScalars sc;
-                    fetch(i, sc);
-                    const double x = ahead(i), y = x + sc.noise;
-#pragma unroll
-                    for (int t = 0; t < kTilePairA; ++t) pr[t].mul(y + sc.base[t]);
-                    if (with_marginals) pr_single.mul(y + x);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < kTilePairA; ++t) pr[t].fold();
-            if (with_marginals) pr_single.fold();
-        }
-        // read counts 2 .. kMidMaxCount: the factor count times; four rows of them fit between folds
-        for (uint32_t i = (kCountOneRows || (w.debug_skip & 2u)) ? nm : nf; i < nm; ++i) {
-            const UniformDoubles row = Hu + static_cast<uint64_t>(i) * ld;
-            const double x = Hb[static_cast<uint64_t>(i) * ld];
-            const double y = x + nz[i];
-            const int c = static_cast<int>(cnt[i]);
-            double arg[kTilePairA];
-#pragma unroll
-            for (int t = 0; t < kTilePairA; ++t) arg[t] = y + row[t];
-            const double arg_single = y + x;
-            for (int k = 0; k < c; ++k) {
-#pragma unroll
-                for (int t = 0; t < kTilePairA; ++t) pr[t].mul(arg[t]);
-                if (with_marginals) pr_single.mul(arg_single);
-            }
-            if (((i - nf) & 3u) == 3u || i + 1 == nm) {
-#pragma unroll
-                for (int t = 0; t < kTilePairA; ++t) pr[t].fold();
-                if (with_marginals) pr_single.fold();
-            }
-        }
-        // the rest: one logarithm per pair and row
-        for (uint32_t i = (kCountOneRows || (w.debug_skip & 4u)) ? n : nm; i < n; ++i) {
-            const UniformDoubles row = Hu + static_cast<uint64_t>(i) * ld;
-            const double x = Hb[static_cast<uint64_t>(i) * ld];
-            const double y = x + nz[i];
-            const double c = cnt[i];
-#pragma unroll
-            for (int t = 0; t < kTilePairA; ++t) acc[t] = fma(c, logPositive(y + row[t], lt), acc[t]);
-            if (with_marginals) acc_single = fma(c, logPositive(y + x, lt), acc_single);
-        }
-#pragma unroll
-        for (int t = 0; t < kTilePairA; ++t) {
-            const uint32_t a = a0 + t;
-            const double total = nm ? acc[t] + pr[t].value(lt) : acc[t];
-            if (a < G && b < G && a <= b) {
-                double * out = part_pair + static_cast<uint64_t>(a) * G + b;
-                *out = kCountOneRows ? total : *out + total;
-            }
-        }
-        if (with_marginals && b < G) {
-            const double total = nm ? acc_single + pr_single.value(lt) : acc_single;
-            part_marginal[b] = kCountOneRows ? total : part_marginal[b] + total;
-        }
-    }
-    if (lane == 0 && kCountOneRows) {
-        uint64_t pairs = 0;
-        for (uint32_t t = 0; t < kTilePairA && a0 + t < G; ++t) pairs += G - (a0 + t);
-        atomicAdd(w.log_evals, static_cast<unsigned long long>((pairs + (with_marginals ? G : 0)) * n));
-    }
-}
-
 // ---- all pairs of a matrix from LDS, a 4 x 4 tile of pairs per lane ----------------------------------------------
 //
-// pairRowsKernel above has the minimal arithmetic in its inner loop and still only matched the sequential search: every
-// tile of eight first columns streamed the whole matrix again (G / 8 passes over it through L2: bound by that, not by
-// the multiplications), half of the lanes idled on the triangle of pairs, and a wave owned 64 second columns whether the
-// matrix had them or not.  This kernel is laid out like a matrix product whose inner dimension is the rows:
+// The sequential search prunes little where it matters (configs[2] bench: 4.1 of the 4.4 G row-pair evaluations of "all
+// pairs" are reached anyway), and "keep iff ll - max(all pairs before) >= thr" needs no order of evaluation (above).  So
+// every pair of every matrix is evaluated, by a kernel built around the arithmetic alone.  (A first attempt — lane =
+// second column, eight first columns through scalar loads from a row-major copy of the matrices, round 2's
+// pairRowsKernel — had the minimal arithmetic in its inner loop and only matched the sequential search: every tile of
+// first columns streamed the whole matrix again, half of the lanes idled on the triangle of pairs, a wave owned 64
+// second columns whether the matrix had them or not.)  This kernel is laid out like a matrix product whose inner
+// dimension is the rows:
 //   * a workgroup takes (matrix, chunk of kChunkRows rows) and stages the chunk, some hundred rows at a time, in LDS —
 //     halved and transposed to row-major on the way, so the matrices need no second copy — and every pair of the
 //     matrix is evaluated from that ONE staging: the matrix is read from memory once per search;
@@ -1276,16 +1083,13 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     double table_min_work = 65536.0;
     if (const char * env = std::getenv("RPVG_HIP_TABLE_MIN_WORK")) table_min_work = std::atof(env);
     if (min_rel_likelihood > 1) table_min_work = 1e300;  // positive threshold: the prefix-maximum form of the rule does not hold
-    // matrices with the row-major copy: every one of them on the table path, its pairs by pairRowsKernel
-    const bool pair_rows = groups->halves.ptr != nullptr && min_rel_likelihood <= 1;
-    if (pair_rows) table_min_work = 0.0;
     // every pair of every matrix from LDS-staged rows, a tile of pairs per lane (pairTileKernel): the default for a
     // threshold that is a ratio <= 1; RPVG_HIP_PAIR_TILES=0 keeps the sequential search with its table path (A/B)
     const char * tiles_env = std::getenv("RPVG_HIP_PAIR_TILES");  // (read per call: the tests switch between the two searches)
     const bool tiles_wanted = tiles_env ? std::atoi(tiles_env) != 0 : true;
-    const bool pair_tiles = tiles_wanted && !pair_rows && min_rel_likelihood <= 1;
+    const bool pair_tiles = tiles_wanted && min_rel_likelihood <= 1;
     if (pair_tiles) table_min_work = 0.0;
-    const uint32_t tile_step = pair_rows ? kTilePairA : kTileA;
+    const uint32_t tile_step = kTileA;
     uint32_t num_big = 0;
     std::vector<uint64_t> big_col_part_off(M, 0), big_pair_part_off(M, 0);
     std::vector<uint32_t> item_matrix, item_col, item_chunk;
@@ -1495,29 +1299,6 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
             pw.log_evals = args.log_evals;
             pw.debug_skip = std::getenv("RPVG_HIP_PAIR_DEBUG") ? static_cast<uint32_t>(std::atoi(std::getenv("RPVG_HIP_PAIR_DEBUG"))) : 0u;
             pairTileKernel<<<dim3(pw.count), dim3(kTileBlock), kTileLdsDoubles * sizeof(double), st>>>(pw);
-        } else if (pair_rows) {
-            PairRowsWork pw;
-            pw.item_matrix = d_item_matrix.ptr;
-            pw.item_col = d_item_col.ptr;
-            pw.item_chunk = d_item_chunk.ptr;
-            pw.count = tw.count;
-            pw.mat_half_off = groups->mat_half_off.ptr;
-            pw.mat_row_off = groups->mat_row_off.ptr;
-            pw.mat_fast = groups->mat_fast.ptr;
-            pw.mat_mid = groups->mat_mid.ptr;
-            pw.mat_rows = groups->mat_rows.ptr;
-            pw.mat_cols = groups->mat_cols.ptr;
-            pw.halves = groups->halves.ptr;
-            pw.row_count = groups->row_count.ptr;
-            pw.row_noise = groups->row_noise.ptr;
-            pw.col_part_off = d_big_col_part_off.ptr;
-            pw.pair_part_off = d_big_pair_part_off.ptr;
-            pw.part_marginal = d_part_marg.ptr;
-            pw.part_pair = d_part_pair.ptr;
-            pw.log_evals = args.log_evals;
-            pw.debug_skip = std::getenv("RPVG_HIP_PAIR_DEBUG") ? static_cast<uint32_t>(std::atoi(std::getenv("RPVG_HIP_PAIR_DEBUG"))) : 0u;
-            pairRowsKernel<true><<<dim3(((pw.count + 7) / 8) * 8), dim3(64), 0, st>>>(pw);
-            pairRowsKernel<false><<<dim3(((pw.count + 7) / 8) * 8), dim3(64), 0, st>>>(pw);
         } else {
             pairTableKernel<<<dim3(((tw.count + 7) / 8) * 8), dim3(256), 0, st>>>(tw);
         }

@@ -395,8 +395,8 @@ __device__ void loadLogTable(LogTableEntry * lds_table);
 // that of a sum of n logarithms.
 constexpr double kProductMinNoise = 9.313225746154785e-10;  // 2^-30
 constexpr int kMidMaxCount = 8;
-constexpr uint32_t kMidMinRows = 1024;  // matrices with fewer rows have no mid class: one more ragged class boundary would
-                                        // cost them a loop pass, more than the logarithms it saves
+constexpr uint32_t kMidMinRows = 1;     // every matrix has the mid class: the tile kernel of the diploid search pays nothing for a class
+                                        // boundary (round 1's sequential kernels did: 1 024), and half of the bench's rows sit in matrices below 1 024 rows
 constexpr uint32_t kFoldFactors = 30;  // (30 + 3 remainder factors) * 30 bits < 1022
 constexpr uint32_t kNumRowClasses = kMidMaxCount + 1;  // fast, counts 2 .. kMidMaxCount, slow
 
@@ -616,10 +616,6 @@ struct rpvg_hip_groups {
     std::vector<uint64_t> h_num_rows;
     rpvg_hip_detail::DeviceBuffer<double> values;         // all matrices back to back, each column-major
     rpvg_hip_detail::DeviceBuffer<double> rowmax;         // [sum R_m]
-    // Optional second copy for the pair kernel of the diploid search (bounded_search.hip): every value halved (the
-    // search divides by the group size 2: exact), row-major, rows padded with zeros to a multiple of eight columns.
-    rpvg_hip_detail::DeviceBuffer<double> halves;         // all matrices back to back
-    rpvg_hip_detail::DeviceBuffer<uint64_t> mat_half_off; // [M] offset of matrix m in halves
     rpvg_hip_detail::DeviceBuffer<uint64_t> mat_val_off;  // [M] offset of matrix m in values
     rpvg_hip_detail::DeviceBuffer<uint64_t> mat_row_off;  // [M] offset of matrix m in rowmax
     rpvg_hip_detail::DeviceBuffer<uint64_t> mat_row0;     // [M] first batch row of the matrix's cluster

@@ -101,8 +101,7 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
     const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
     const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
     const uint32_t * __restrict__ row_perm, const int normalise, double * __restrict__ values, double * __restrict__ rowmax,
-    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row, uint64_t * __restrict__ collapse_mask,  // null: no row collapse
-    double * __restrict__ halves, const uint64_t * __restrict__ mat_half_off) {  // null: no row-major copy
+    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row, uint64_t * __restrict__ collapse_mask) {  // null: no row collapse
     if (blockIdx.x >= num_items) return;
     const uint32_t m = item_matrix[blockIdx.x];
     const uint64_t R = mat_rows[m], r0 = mat_row0[m];
@@ -145,11 +144,6 @@ __global__ __launch_bounds__(256) void groupsBuildKernel(
             }
         }
         rm[i] = mx;
-        if (halves) {
-            const uint32_t Gp = (G + 7u) & ~7u;
-            double * H = halves + mat_half_off[m] + i * Gp;
-            for (uint32_t g = 0; g < Gp; ++g) H[g] = g < G ? M[static_cast<uint64_t>(g) * R + i] * 0.5 : 0.0;
-        }
     }
 }
 
@@ -177,8 +171,7 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
     const uint32_t * __restrict__ path_grp, const uint64_t * __restrict__ row_ent_off,
     const uint32_t * __restrict__ ent_path, const double * __restrict__ ent_prob, const double * __restrict__ row_noise,
     const uint32_t * __restrict__ row_perm, const int normalise, double * __restrict__ values, double * __restrict__ rowmax,
-    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row, uint64_t * __restrict__ collapse_mask,  // null: no row collapse
-    double * __restrict__ halves, const uint64_t * __restrict__ mat_half_off) {  // null: no row-major copy (pair kernel, bounded_search.hip)
+    uint64_t * __restrict__ collapse_key, uint32_t * __restrict__ collapse_row, uint64_t * __restrict__ collapse_mask) {  // null: no row collapse
     extern __shared__ double tile[];
     if (blockIdx.x >= num_items) return;
     const uint32_t m = item_matrix[blockIdx.x];
@@ -256,16 +249,6 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
     for (uint32_t idx = threadIdx.x; idx < cells; idx += blockDim.x) {
         const uint32_t g = idx >> shift, tt = idx & (Rc - 1);
         if (tt < nrows) M[static_cast<uint64_t>(g) * R + i0 + tt] = tile[g * Rs + tt];
-    }
-    if (halves) {
-        // the same values halved (exact), row-major with the row padded to a multiple of eight columns (zeros): lane =
-        // column in the pair kernel, the first columns of a pair come through scalar loads of eight
-        const uint32_t Gp = (G + 7u) & ~7u;
-        double * H = halves + mat_half_off[m] + i0 * Gp;
-        for (uint32_t idx = threadIdx.x; idx < nrows * Gp; idx += blockDim.x) {
-            const uint32_t tt = idx / Gp, g = idx - tt * Gp;
-            H[idx] = g < G ? tile[g * Rs + tt] * 0.5 : 0.0;
-        }
     }
 }
 
@@ -470,8 +453,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     std::vector<uint64_t> val_off(M), row_off(M), row0(M), rows(M), inc_off(M), num_paths(M);
     std::vector<uint32_t> cols(M), item_matrix, item_chunk, tile_matrix, tile_chunk;
     std::vector<uint32_t> wide_matrices;  // too many columns for an LDS tile: global-memory kernel on zero-filled storage
-    uint64_t val_total = 0, row_total = 0, inc_total = 0, half_total = 0;
-    std::vector<uint64_t> half_off(M, 0);
+    uint64_t val_total = 0, row_total = 0, inc_total = 0;
     for (uint32_t m = 0; m < M; ++m) {
         const uint32_t k = spec->cluster[m];
         if (k >= batch->num_clusters) {
@@ -499,8 +481,6 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         val_off[m] = val_total;
         row_off[m] = row_total;
         inc_off[m] = inc_total;
-        half_off[m] = half_total;
-        half_total += R * (((g1 - g0) + 7) & ~uint64_t(7));
         val_total += R * (g1 - g0);
         row_total += R;
         inc_total += N + 1;
@@ -569,7 +549,6 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         pack.add(d_tile_matrix, tile_matrix.data(), tile_matrix.size());
         pack.add(d_tile_chunk, tile_chunk.data(), tile_chunk.size());
     }
-    if (spec->pair_layout) pack.add(g->mat_half_off, half_off.data(), M);
     std::vector<uint32_t> segment_off;
     if (collapse) {
         segment_off.resize(M + 1);
@@ -592,7 +571,6 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     ok(g->row_noise.alloc(row_total));
     ok(g->mat_fast.alloc(M));
     ok(g->mat_mid.alloc(M));
-    if (spec->pair_layout) ok(g->halves.alloc(half_total));
     if (collapse) {
         ok(g->collapse_key.alloc(row_total));
         ok(g->collapse_row.alloc(row_total));
@@ -613,8 +591,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         partitionRowsKernel<<<dim3(M), dim3(256), 0, st>>>(M, g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, batch->row_count.ptr,
                                                            batch->row_noise.ptr, g->row_perm.ptr, g->row_count.ptr, g->row_noise.ptr,
                                                            g->mat_fast.ptr, g->mat_mid.ptr,
-                                                           // (the pair kernel's count loop is cheap for every matrix: bounded_search.hip)
-                                                           spec->pair_layout ? 1u : kMidMinRows);
+                                                           kMidMinRows);
         const uint32_t col_blocks = static_cast<uint32_t>((num_columns + 255) / 256);
         incidenceCountKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,
                                                                    d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
@@ -628,14 +605,14 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
                 static_cast<uint32_t>(tile_matrix.size()), d_tile_matrix.ptr, d_tile_chunk.ptr, g->mat_val_off.ptr,
                 g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
                 d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
-                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_mask.ptr, g->halves.ptr, g->mat_half_off.ptr);
+                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_mask.ptr);
         }
         if (!item_matrix.empty()) {
             groupsBuildKernel<<<dim3(static_cast<uint32_t>(item_matrix.size())), dim3(256), 0, st>>>(
                 static_cast<uint32_t>(item_matrix.size()), d_item_matrix.ptr, d_item_chunk.ptr, g->mat_val_off.ptr,
                 g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, g->mat_cols.ptr, d_inc_off.ptr, d_path_grp_off.ptr,
                 d_path_grp.ptr, batch->row_ent_off.ptr, batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_noise.ptr,
-                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_mask.ptr, g->halves.ptr, g->mat_half_off.ptr);
+                g->row_perm.ptr, spec->normalise ? 1 : 0, g->values.ptr, g->rowmax.ptr, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_mask.ptr);
         }
         sub.reset(new HostScope("groups_build: row collapse launches"));
         if (collapse && e == hipSuccess) {

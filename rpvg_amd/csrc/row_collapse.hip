@@ -368,8 +368,6 @@ struct ReplayArgs {
     const uint32_t * mat_flag;
     const uint8_t * active;      // [total rows] by row
     double * rowmax;
-    double * halves;             // row-major halved copy of the matrices (null: none), patched with the values
-    const uint64_t * mat_half_off;
     uint32_t * mat_fast;
     uint32_t * mat_mid;
     uint32_t * mat_list;         // [M] size of the matrix's list (| kWholeMatrixBit: every row), 0: nothing to replay
@@ -786,11 +784,6 @@ __global__ __launch_bounds__(256) void collapseRunsKernel(const ReplayArgs a) {
             if (h == q) continue;
             const uint32_t dst = order[q], src = order[h];
             for (uint32_t c = lane; c < mv.G; c += 64) M[static_cast<uint64_t>(c) * R + dst] = M[static_cast<uint64_t>(c) * R + src];
-            if (a.halves) {
-                const uint64_t Gp = (mv.G + 7u) & ~7u;
-                double * H = a.halves + a.mat_half_off[m];
-                for (uint32_t c = lane; c < mv.G; c += 64) H[dst * Gp + c] = H[src * Gp + c];
-            }
             if (lane == 0) {
                 const double noise = nz[src];
                 nz[dst] = noise;
@@ -912,8 +905,6 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     r.mat_flag = mat_flag;
     r.active = active;
     r.rowmax = g->rowmax.ptr;
-    r.halves = g->halves.ptr;
-    r.mat_half_off = g->mat_half_off.ptr;
     r.mat_fast = g->mat_fast.ptr;
     r.mat_mid = g->mat_mid.ptr;
     r.mat_list = mat_list;

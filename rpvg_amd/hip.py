@@ -49,7 +49,7 @@ class CEmResults(C.Structure):
 class CGroupSpec(C.Structure):
     _fields_ = [("num_matrices", C.c_uint32), ("cluster", C.c_void_p), ("group_off", C.c_void_p),
                 ("group_path_off", C.c_void_p), ("group_path", C.c_void_p), ("normalise", C.c_int32),
-                ("collapse_precision", C.c_double), ("pair_layout", C.c_int32)]
+                ("collapse_precision", C.c_double)]
 
 
 class CPairPosteriorsView(C.Structure):
@@ -197,7 +197,7 @@ def host_unregister(array: np.ndarray):
 
 class DeviceGroups:
     def __init__(self, ctx: "Context", batch: DeviceBatch, clusters: Sequence[int], groups: Sequence[Sequence[Sequence[int]]],
-                 normalise: bool, collapse_precision: float = 0.0, pair_layout: bool = False):
+                 normalise: bool, collapse_precision: float = 0.0):
         """groups[m] = list of path lists (one per column) for matrix m on clusters[m]; collapse_precision > 0 replays
         readCollapseProbabilityMatrix on the (normalised) matrices."""
         self.ctx = ctx
@@ -213,7 +213,7 @@ class DeviceGroups:
         gpoff = np.ascontiguousarray(gpoff, dtype=np.uint64)
         gp = np.ascontiguousarray(gp, dtype=np.uint32)
         spec = CGroupSpec(len(cl), cl.ctypes.data, goff.ctypes.data, gpoff.ctypes.data, gp.ctypes.data, 1 if normalise else 0,
-                          float(collapse_precision), 1 if pair_layout else 0)
+                          float(collapse_precision))
         self.handle = C.c_void_p()
         _check(lib().rpvg_hip_groups_build(ctx.handle, batch.handle, C.byref(spec), C.byref(self.handle)),
                "rpvg_hip_groups_build")
@@ -315,9 +315,8 @@ class Context:
     def upload(self, host: ClusterBatch) -> DeviceBatch:
         return DeviceBatch(self, host)
 
-    def groups(self, batch: DeviceBatch, clusters, groups, normalise: bool, collapse_precision: float = 0.0,
-               pair_layout: bool = False) -> DeviceGroups:
-        return DeviceGroups(self, batch, clusters, groups, normalise, collapse_precision, pair_layout)
+    def groups(self, batch: DeviceBatch, clusters, groups, normalise: bool, collapse_precision: float = 0.0) -> DeviceGroups:
+        return DeviceGroups(self, batch, clusters, groups, normalise, collapse_precision)
 
     # ---- EM -----------------------------------------------------------------
     def em_solve(self, batch: DeviceBatch, clusters: Sequence[int], columns: Sequence[Sequence[int]],

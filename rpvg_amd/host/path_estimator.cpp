@@ -27,7 +27,7 @@ class GroupMatrices {
 
     public:
 
-        GroupMatrices(const std::shared_ptr<HipEngine> & engine_in, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const bool normalise, const double prob_precision, const bool pair_layout = false) : engine(engine_in), groups(nullptr) {
+        GroupMatrices(const std::shared_ptr<HipEngine> & engine_in, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const bool normalise, const double prob_precision) : engine(engine_in), groups(nullptr) {
 
             ScopedPhase phase("posteriors: group matrices build");
 
@@ -71,7 +71,6 @@ class GroupMatrices {
             // of the raw ones (src/path_posterior_estimator.cpp:45)
             spec.collapse_precision = normalise ? prob_precision : 0.0;
             // the diploid search on the device evaluates all pairs of a matrix at once from a second, row-major copy
-            spec.pair_layout = pair_layout;
 
             HipEngine::check(rpvg_hip_groups_build(engine->ctx(), cluster_batch.handle(), &spec, &groups), "rpvg_hip_groups_build");
         }
@@ -784,10 +783,7 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
 
     ScopedPhase whole_phase("posteriors: bounded total incl. teardown");
 
-    // RPVG_HIP_PAIR_LAYOUT=1: every pair of every matrix from a row-major copy (pairRowsKernel, bounded_search.hip) instead
-    // of the sequential in-workgroup search; measured at par on the configs[2] bench, so not the default
-    static const bool pair_layout = std::getenv("RPVG_HIP_PAIR_LAYOUT") != nullptr;
-    const GroupMatrices matrices(engine, cluster_batch, problems, normalise, prob_precision, pair_layout && min_rel_likelihood <= 1);
+    const GroupMatrices matrices(engine, cluster_batch, problems, normalise, prob_precision);
 
     std::vector<uint32_t> column_counts;
 

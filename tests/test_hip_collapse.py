@@ -123,21 +123,17 @@ def test_planted_close_rows_match_oracle(engine, seed, kw):
     assert not fuzz_parity.compare(got, ref)
 
 
-def test_collapsed_rows_reach_the_all_pairs_layout(engine, monkeypatch):
-    """RPVG_HIP_PAIR_LAYOUT=1: the search reads a row-major copy of the matrices, which the collapse patches with them."""
-    monkeypatch.setenv("RPVG_HIP_PAIR_LAYOUT", "1")
-    import subprocess
-    import sys
-    # (the knob is read once per process: a fresh interpreter)
-    code = ("import sys; sys.path.insert(0, '.');"
-            "from tests import test_hip_collapse as T, collapse_cases, fuzz_parity;"
-            "from oracle import pyoracle; from rpvg_amd import engine as E; from rpvg_amd.batch import ClusterBatch, make_params;"
-            "cl = collapse_cases.make_collapse_clusters(823, n_clusters=12, max_reads=200); b = ClusterBatch.from_clusters(cl);"
-            "ref, _ = pyoracle.run('haplotype-transcripts', make_params(), b, 2); e = E.Engine(0);"
-            "got, _ = e.run('haplotype-transcripts', make_params(), e.prepare(b)); p = fuzz_parity.compare(got, ref); print('PROBLEMS', len(p), p[:3])")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)),
-                         env=dict(os.environ, RPVG_HIP_PAIR_LAYOUT="1"))
-    assert out.returncode == 0 and "PROBLEMS 0" in out.stdout, out.stdout[-500:] + out.stderr[-1500:]
+def test_collapsed_rows_reach_the_sequential_search(engine):
+    """RPVG_HIP_PAIR_TILES=0: the sequential kernels wait for the collapse on its stream like the tile kernel does."""
+    cl = collapse_cases.make_collapse_clusters(823, n_clusters=12, max_reads=200)
+    batch = ClusterBatch.from_clusters(cl)
+    ref, _ = pyoracle.run("haplotype-transcripts", make_params(), batch, 2)
+    os.environ["RPVG_HIP_PAIR_TILES"] = "0"
+    try:
+        got, _ = engine.run("haplotype-transcripts", make_params(), engine.prepare(batch))
+    finally:
+        os.environ.pop("RPVG_HIP_PAIR_TILES", None)
+    assert not fuzz_parity.compare(got, ref)
 
 
 # seeds of the sweep that once differed (5109: tied diplotype order; 7004: row collapse) + one of every shape / model

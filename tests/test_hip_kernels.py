@@ -407,11 +407,11 @@ def test_stats_report_kernel_time(hip_ctx):
 
 # ---- on-device diploid branch-and-bound ---------------------------------------------------
 
-@pytest.mark.parametrize("pair_layout", [False, True], ids=["sequential", "all-pairs"])
+@pytest.mark.parametrize("tiles", [False, True], ids=["sequential", "all-pairs"])
 @pytest.mark.parametrize("normalise,thr", [(True, 1e-3), (False, 1e-8)])
-def test_bounded_search_on_device_matches_oracle(hip_ctx, normalise, thr, pair_layout):
-    """pair_layout: every pair from the row-major copy (pairRowsKernel) + prefix-maximum filter instead of the sequential
-    in-workgroup walk — the kept pairs and their order are the reference's either way."""
+def test_bounded_search_on_device_matches_oracle(hip_ctx, normalise, thr, tiles):
+    """all-pairs (the default): every pair from LDS-staged rows (pairTileKernel) + prefix-maximum filter instead of the
+    sequential in-workgroup walk (RPVG_HIP_PAIR_TILES=0) — the kept pairs and their order are the reference's either way."""
     rng = np.random.default_rng(701)
     clusters = small_cases.make_batch_clusters(702, n_clusters=10, with_empty=False)
     clusters.append(small_cases.make_cluster(rng, 3, [9, 7, 8], n_haps=40, n_reads=1500))
@@ -428,8 +428,13 @@ def test_bounded_search_on_device_matches_oracle(hip_ctx, normalise, thr, pair_l
         mats.append(k)
         groups.append(g)
         counts.append(mult)
-    dg = hip_ctx.groups(dev, mats, groups, normalise, pair_layout=pair_layout)
-    got = dg.bounded_pair_posteriors(np.concatenate(counts), thr)
+    dg = hip_ctx.groups(dev, mats, groups, normalise)
+    if not tiles:
+        os.environ["RPVG_HIP_PAIR_TILES"] = "0"
+    try:
+        got = dg.bounded_pair_posteriors(np.concatenate(counts), thr)
+    finally:
+        os.environ.pop("RPVG_HIP_PAIR_TILES", None)
     for m, (k, g) in enumerate(zip(mats, groups)):
         cl = clusters[k]
         M, noise, cnts = np_oracle.grouped_matrix(cl["rows"], g)

@@ -9,4 +9,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_ACTIVE_I
   RPVG_AMD_SINGLE_LANE=1 timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out.log$i 2>&1
 done
 cd /root/repo
-python tools/pmc_kernels.py $out/p1 $out/p2 $out/p3 $out/p4 $out/p5 --kernel ${1:-Search,pairTable,pairRows}
+python tools/pmc_kernels.py $out/p1 $out/p2 $out/p3 $out/p4 $out/p5 --kernel ${1:-pairTile,resolveTable,Search,pairTable}
