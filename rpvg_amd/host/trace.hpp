@@ -48,9 +48,28 @@ inline int hostThreads() {
         int threads = std::min(32, omp_get_max_threads());
 
         // one process per GPU: share the host's hardware threads between the local ranks
+        int local_ranks = 1;
+
         if (const char * local_world = std::getenv("LOCAL_WORLD_SIZE")) {
 
-            threads = std::min(threads, std::max(4, omp_get_max_threads() / std::max(1, std::atoi(local_world))));
+            local_ranks = std::max(1, std::atoi(local_world));
+            threads = std::min(threads, std::max(4, omp_get_max_threads() / local_ranks));
+        }
+
+        // ... and the CPU time the cgroup grants (cpu.max: quota and period): a team may burst to twice its share of it
+        // (one rank on a 16-CPU quota: 32 threads, the measured optimum; eight ranks on the same quota: 4 each instead of
+        // 8 x 2 lanes x 32 threads that would spend the quota in the first millisecond of every period)
+        if (FILE * cpu_max = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+
+            long long quota = 0, period = 0;
+
+            if (std::fscanf(cpu_max, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+
+                const int share = static_cast<int>((2 * quota) / (period * local_ranks));
+                threads = std::min(threads, std::max(4, share));
+            }
+
+            std::fclose(cpu_max);
         }
 
         return std::max(1, threads);
