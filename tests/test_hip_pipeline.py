@@ -123,3 +123,35 @@ def test_device_group_shards_clusters_and_gathers(model, devices):
         assert not group.has_communicator()  # one GPU: RCCL wants one rank per GPU
     finally:
         group.close()
+
+
+def test_batches_arriving_through_an_uploader_engine():
+    """Two resident slots, an uploader engine (rpvg_hip_create_uploader: a stream and hardware queue of its own) that
+    re-uploads one slot from page-locked host arrays while the other is estimated: what bench.py's upload leg does.  The
+    estimates of every batch equal those of a plain run, whichever engine copied its rows."""
+    import threading
+    from rpvg_amd import hip
+    from tests import fuzz_parity
+    batches = [ClusterBatch.from_clusters(small_cases.make_batch_clusters(1200 + i, n_clusters=12, with_empty=(i == 1))) for i in range(2)]
+    params = make_params()
+    engine = eng_mod.Engine(0)
+    uploader = eng_mod.Engine(0, uploader=True)
+    arrays = [a for b in batches for a in (b.cluster_row_off, b.cluster_path_off, b.row_count, b.row_noise, b.row_grp_off, b.grp_prob,
+                                           b.grp_idx_off, b.path_idx)]
+    for a in arrays:
+        hip.host_register(a)
+    try:
+        want = [engine.run("haplotype-transcripts", params, engine.prepare(b))[0] for b in batches]
+        slots = [engine.prepare(b) for b in batches]  # (a slot keeps the paths of its batch: the rows are what arrives)
+        for k in range(4):
+            other = slots[(k + 1) % 2]
+            t = threading.Thread(target=other.reupload, args=(uploader,))
+            t.start()
+            got = engine.run("haplotype-transcripts", params, slots[k % 2])[0]
+            t.join()
+            assert not fuzz_parity.compare(got, want[k % 2])
+    finally:
+        for a in arrays:
+            hip.host_unregister(a)
+        uploader.close()
+        engine.close()
