@@ -75,10 +75,21 @@ class GroupMatrices {
             HipEngine::check(rpvg_hip_groups_build(engine->ctx(), cluster_batch.handle(), &spec, &groups), "rpvg_hip_groups_build");
         }
 
+        // Freeing the matrices (a stream wait, a dozen blocks back to the pool) sits between a lane's search and its EM:
+        // they are kept with the lane's retired containers (dropped when the first lane's work is done, by any other lane
+        // at the start of its next batch) — the holder frees them whichever way it goes.
         ~GroupMatrices() {
 
             ScopedPhase phase("posteriors: group matrices free");
-            rpvg_hip_groups_free(engine->ctx(), groups);
+
+            static const bool never_later = std::getenv("RPVG_AMD_NO_DEFERRED_TEARDOWN") != nullptr;
+            rpvg_hip_ctx * lane_context = engine->ctx();  // (not the engine: its lane threads own the closures, and it owns them)
+            std::shared_ptr<rpvg_hip_groups> holder(groups, [lane_context](rpvg_hip_groups * matrices) { rpvg_hip_groups_free(lane_context, matrices); });
+
+            if (!never_later) {
+
+                RetiredContainers::ofThisThread().keep([holder]() mutable { holder.reset(); });
+            }
         }
 
         GroupMatrices(const GroupMatrices &) = delete;
