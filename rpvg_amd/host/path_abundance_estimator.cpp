@@ -797,6 +797,15 @@ void NestedPathAbundanceEstimator::selectPathSubsetIndices(PathSubsetWeights * p
         }
 
         std::vector<uint32_t> path_subset;
+        size_t num_paths = 0;
+
+        for (uint32_t j = 0; j < group_posteriors.group_size; ++j) {
+
+            const uint32_t group = group_posteriors.set(i)[j];
+            num_paths += problem.columnEnd(group) - problem.columnBegin(group);
+        }
+
+        path_subset.reserve(num_paths);
 
         for (uint32_t j = 0; j < group_posteriors.group_size; ++j) {
 
@@ -806,7 +815,8 @@ void NestedPathAbundanceEstimator::selectPathSubsetIndices(PathSubsetWeights * p
 
         std::sort(path_subset.begin(), path_subset.end());
 
-        (*path_subset_samples)[path_subset] += group_posteriors.posteriors.at(i);
+        // (the key moves into the map: no second copy of the subset)
+        path_subset_samples->emplace(std::move(path_subset), 0.0).first->second += group_posteriors.posteriors.at(i);
         sum_posterior += group_posteriors.posteriors.at(i);
     }
 
@@ -865,6 +875,7 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
             ++problem_idx;
 
             problem.cluster = clusters.at(i);
+            problem.path_ids.reserve(path_subset.first.size());  // (one allocation per problem instead of one per doubling)
             std::unique_copy(path_subset.first.begin(), path_subset.first.end(), std::back_inserter(problem.path_ids));
         }
     }
