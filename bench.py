@@ -367,6 +367,12 @@ def run_s3(args, rank, local_rank, world, dist, torch):
                                  "evaluated (pairTileKernel: all matrices up to 1024 columns) where the reference skips the first columns its "
                                  "bound prunes (the sequential search reaches 4.1 of these 4.4 G row-pair evaluations anyway); kept = pairs "
                                  "that survive the threshold")
+    pmc_search_path = os.path.join(ROOT, "profiles", "pmc_search_s3.json")
+    if not s5 and os.path.exists(pmc_search_path) and args.scale == 1.0 and args.model == "haplotype-transcripts":
+        # separate rocprofv3 --pmc passes of this workload with one host lane (tools/pmc_search_summary.py)
+        pmc_search = json.load(open(pmc_search_path))
+        search.update(valu_instructions_per_eval=pmc_search["valu_instructions_per_eval"], valu_busy=pmc_search["valu_busy"],
+                      pmc_source=pmc_search["source"])
     if s5:
         # no EM on this path: the device work is the FP64 log-likelihood contraction of the Gibbs conditionals, the rest of a
         # step is the host's sampler state machines (the reference's mt19937 / discrete_distribution streams, draw for draw)
