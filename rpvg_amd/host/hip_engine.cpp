@@ -187,7 +187,7 @@ PipelineWorker & HipEngine::lane(const int lane) {
         check(rpvg_hip_create(device_id, &lane_context), "rpvg_hip_create");
 
         lane_contexts.emplace_back(lane_context);
-        lane_workers.emplace_back(new PipelineWorker());
+        lane_workers.emplace_back(new PipelineWorker([]() { RetiredContainers::ofThisThread().dropAll(); }));
     }
 
     return *lane_workers.at(lane - 1);

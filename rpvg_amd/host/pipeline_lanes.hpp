@@ -74,7 +74,9 @@ class PipelineWorker {
 
     public:
 
-        PipelineWorker() : stopping(false), has_task(false), busy(false), worker(&PipelineWorker::loop, this) {}
+        // idle_work_in: run by the worker thread after every task, once the task has been reported done (the lanes drop
+        // the containers they retired there: nobody waits for it, and nothing is left for the end of the process)
+        explicit PipelineWorker(std::function<void()> idle_work_in = nullptr) : stopping(false), has_task(false), busy(false), idle_work(std::move(idle_work_in)), worker(&PipelineWorker::loop, this) {}
 
         ~PipelineWorker() {
 
@@ -153,6 +155,20 @@ class PipelineWorker {
                 error = thrown;
                 busy = false;
                 done.notify_all();
+
+                if (idle_work) {
+
+                    lock.unlock();
+
+                    try {
+
+                        idle_work();
+
+                    } catch (...) {
+                    }
+
+                    lock.lock();
+                }
             }
         }
 
@@ -166,6 +182,7 @@ class PipelineWorker {
 
         std::function<void()> task;
         std::exception_ptr error;
+        std::function<void()> idle_work;
 
         std::thread worker;
 };

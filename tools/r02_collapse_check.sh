@@ -7,7 +7,7 @@ python -m pytest tests/test_hip_collapse.py -x -q -m gpu 2>&1 | tail -25 > $out/
 RPVG_AMD_TRACE=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep "row collapse" | tail -2 > $out/collapse_trace.log
 python bench.py --no-cpu-baseline > $out/bench_s3.json 2> $out/bench_s3.err
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>$out/prof.err | tail -1 > $out/bench_s3_profiled.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>$out/prof.err | tail -1 > $out/bench_s3_profiled.json
 cp $out/prof/*/*kernel_stats.csv $out/rocprofv3_s3_kernel_stats.csv; rm -rf $out/prof
 RPVG_AMD_SINGLE_LANE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof1 -- python /root/repo/bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>$out/prof1.err | tail -1 > $out/bench_s3_profiled_1lane.json
 cp $out/prof1/*/*kernel_stats.csv $out/rocprofv3_s3_kernel_stats_1lane.csv; rm -rf $out/prof1

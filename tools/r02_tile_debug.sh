@@ -3,7 +3,7 @@
 out=/root/repo/gpurun_out/r02/tiledbg; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 for dbg in ${DBG:-0 1 2 4 8 7 15}; do
-RPVG_HIP_PAIR_DEBUG=$dbg RPVG_AMD_SINGLE_LANE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p$dbg -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/log$dbg 2>&1
+RPVG_HIP_PAIR_DEBUG=$dbg RPVG_AMD_SINGLE_LANE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p$dbg -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/log$dbg 2>&1
 python - <<PY
 import csv,glob
 f=glob.glob("$out/p$dbg/*/*kernel_stats.csv")[0]

@@ -4,23 +4,23 @@
 out=/root/repo/gpurun_out/refresh
 rm -rf $out; mkdir -p $out
 cd /root/repo
-python bench.py --steps 20 --warmup 5 2>$out/bench_s3.err | tail -1 > $out/bench_s3_n1.json
-RPVG_HIP_PAIR_TILES=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_sequential_search.json
-RPVG_HIP_NO_COLLAPSE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_no_collapse.json
-python bench.py --workload c2 --steps 4 --warmup 1 2>$out/bench_c2.err | tail -1 > $out/bench_c2_n1.json
-python bench.py --workload s5 --steps 5 --warmup 1 2>$out/bench_s5.err | tail -1 > $out/bench_s5_n1.json
-python bench.py --workload rows --steps 10 --warmup 2 2>$out/bench_rows.err | tail -1 > $out/bench_rows_n1.json
-python bench.py --workload e2e --steps 10 --warmup 2 2>$out/bench_e2e.err | tail -1 > $out/bench_e2e_n1.json
+timeout 600 python bench.py --steps 20 --warmup 5 2>$out/bench_s3.err | tail -1 > $out/bench_s3_n1.json
+RPVG_HIP_PAIR_TILES=0 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_sequential_search.json
+RPVG_HIP_NO_COLLAPSE=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_no_collapse.json
+timeout 600 python bench.py --workload c2 --steps 4 --warmup 1 2>$out/bench_c2.err | tail -1 > $out/bench_c2_n1.json
+timeout 600 python bench.py --workload s5 --steps 5 --warmup 1 2>$out/bench_s5.err | tail -1 > $out/bench_s5_n1.json
+timeout 600 python bench.py --workload rows --steps 10 --warmup 2 2>$out/bench_rows.err | tail -1 > $out/bench_rows_n1.json
+timeout 600 python bench.py --workload e2e --steps 10 --warmup 2 2>$out/bench_e2e.err | tail -1 > $out/bench_e2e_n1.json
 cd /tmp; export TMPDIR=/tmp
 prof() {  # name, bench args...
   name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -- python /root/repo/bench.py "$@" --no-cpu-baseline 2>$out/prof_$name.err | tail -1 > $out/bench_${name}_n1_profiled.json
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -- python /root/repo/bench.py "$@" --no-cpu-baseline 2>$out/prof_$name.err | tail -1 > $out/bench_${name}_n1_profiled.json
   cp $out/prof_$name/*/*kernel_stats.csv $out/rocprofv3_${name}_kernel_stats.csv; rm -rf $out/prof_$name
 }
 prof s3 --steps 20 --warmup 5
 prof c2 --workload c2 --steps 4 --warmup 1
 prof s5 --workload s5 --steps 5 --warmup 1
-rocprofv3 --kernel-trace --output-format csv -d $out/prof_tl -- python /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/prof_tl -- python /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 python /root/repo/tools/kernel_timeline.py $out/prof_tl 30 > $out/kernel_timeline_s3_one_step.txt; rm -rf $out/prof_tl
 # PMC passes (each in its own run: counter slots; --kernel-trace only)
 pmc() {  # dir, counters, bench args...
