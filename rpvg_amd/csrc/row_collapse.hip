@@ -577,10 +577,14 @@ __global__ __launch_bounds__(256) void collapseRankKernel(const ReplayArgs a) {
 __global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayArgs a) {
     __shared__ uint32_t lds_list[kListLdsRows];
     __shared__ uint64_t lds_pattern[kListLdsRows];  // zero pattern of the row at each list position (LDS lists)
-    const uint32_t m = blockIdx.x;
-    if (m >= a.num_matrices) return;
+    // over the matrices with a list (a workgroup of this kernel takes a CU's worth of LDS: one per matrix of the batch, each
+    // only to find that its matrix has no big list, took 0.35-0.8 ms next to the other lane's kernels)
+    const uint32_t num_items = a.replay_list[a.num_matrices];
+    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
+    __syncthreads();  // the lists of the matrix before are done with
+    const uint32_t m = a.replay_list[item];
     const uint32_t encoded = a.mat_list[m];
-    if (!(encoded & kBigListBit)) return;  // no list, or a small one (pair table, collapseRankKernel)
+    if (!(encoded & kBigListBit)) continue;  // a small list (pair table, collapseRankKernel)
     const bool whole = (encoded & kWholeMatrixBit) != 0;
     const uint64_t n = encoded & kListSizeMask;
     const MatrixView mv = viewOf(m, a.g);
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayA
     }
     uint8_t * barrier = a.barrier + r0;
     for (uint64_t p = threadIdx.x; p < n; p += blockDim.x) barrier[p] = 0;
-    if (whole) return;
+    if (whole) continue;
     // One wave per pair of neighbours: d, the first column in which they differ, and the interval between them in it.
     // A row x with a <= x <= b in the reference's order equals both up to rounding before column d and lies between
     // them in column d.  A row that joins a run is within prob_precision of a head its predecessor is within
@@ -657,6 +661,7 @@ __global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayA
                 a.pair_pattern[r0 + p] = mv.pattern[x] & (d >= 64 ? ~0ull : (1ull << d) - 1ull);
             }
         }
+    }
     }
 }
 
@@ -929,7 +934,7 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     collapseListKernel<<<dim3(M), dim3(256), 0, st>>>(r);
     collapsePairTableKernel<<<dim3(4096), dim3(64), 0, st>>>(r);
     collapseRankKernel<<<dim3(1024), dim3(256), 0, st>>>(r);
-    collapseSortKernel<<<dim3(M), dim3(kSortThreads), 0, st>>>(r);
+    collapseSortKernel<<<dim3(std::min<uint32_t>(M, 128)), dim3(kSortThreads), 0, st>>>(r);
     collapseBetweenKernel<<<dim3(2048), dim3(kBetweenThreads), 0, st>>>(r);
     collapseRunsKernel<<<dim3(1024), dim3(256), 0, st>>>(r);
     ok(hipGetLastError());
