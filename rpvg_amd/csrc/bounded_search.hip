@@ -1352,7 +1352,6 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         boundedSearchKernel<256, 16><<<dim3(args.count), dim3(256), search_lds_bytes(kSmallRows, kSmallRowLdsCols), s_small>>>(args);
     }
     if (side_kernels) ok(ctx->joinAux());
-    searchGateLeave(ctx, st);
     ctx->spanEnd(span);
     ctx->stats.loglik_launches += (num_big > 0 ? 2 : 0) + (num_medium > 0) + (M > num_big + num_medium);
     ok(hipGetLastError());
@@ -1374,6 +1373,9 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         ok(hipGetLastError());
         ok(hipMemcpyAsync(host_tail, d_tail.ptr, tail_bytes, hipMemcpyDeviceToHost, st));
     }
+    // the next search (another lane's) starts behind this one's offsets and compaction, not behind its large kernel alone:
+    // two tiny kernels that would otherwise wait for slots next to that search (0.5 ms before this lane saw its results)
+    searchGateLeave(ctx, st);
     scope.reset(new HostScope("bounded search: wait for the kernels"));
     ok(hipStreamSynchronize(st));
     if (e == hipSuccess) {
