@@ -32,6 +32,12 @@ def compare(got, ref, check_iters=True):
             gk = {tuple(sorted(key)): v for key, v in gk.items()}
             rk = {tuple(sorted(key)): v for key, v in rk.items()}
         if set(gk) != set(rk):
+            # ... and the tie decides which of the two columns is visited first, whose pair with itself is then kept with
+            # posterior exactly 0 (a "late loser" of the search: seed 21204, an 11-row cluster, (0, 0) on one side and
+            # (1, 1) on the other next to the same diplotype (0, 1) with posterior 1): sets of weight zero carry nothing.
+            gk = {key: v for key, v in gk.items() if v[0] != 0.0 or len(v[1])}
+            rk = {key: v for key, v in rk.items() if v[0] != 0.0 or len(v[1])}
+        if set(gk) != set(rk):
             problems.append(f"cluster {k}: group sets differ ({len(gk)} vs {len(rk)})")
             continue
         for key, (post, ab) in rk.items():

@@ -29,6 +29,9 @@ for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 1):
         print("  gpu em", list(zip(g.em_cols, g.em_iters))[:12])
         print("  ref em", list(zip(r.em_cols, r.em_iters))[:12])
         gk, rk = g.keyed(), r.keyed()
+        if set(gk) != set(rk):
+            print("  gpu sets", sorted(gk.items())[:12])
+            print("  ref sets", sorted(rk.items())[:12])
         for key in list(rk)[:400]:
             if key in gk and (abs(gk[key][0] - rk[key][0]) > 1e-9 * max(1e-300, abs(rk[key][0])) or any(abs(a - b) > 1e-7 * max(1e-12, abs(b)) for a, b in zip(gk[key][1], rk[key][1]))):
                 print("  set", key, "post", gk[key][0], rk[key][0], "abund", gk[key][1], rk[key][1])
