@@ -1019,8 +1019,8 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
 
         // The reference asserts sum_hap_prob <= 1 up to 100 ulp here (src/path_abundance_estimator.cpp:748).  The weights are
         // posteriors normalised by a log-sum-exp over thousands of sets: they carry an ulp each, and with min_hap_prob 1e-5
-        // their sum passes that tolerance on either side's rounding (fuzz seeds 6185, 20207 trip it in the oracle, 21123
-        // here).  A library does not end its host process over that: the arithmetic is the reference's, the check keeps
+        // their sum passes that tolerance on the rounding of whoever adds them up (fuzz seeds 6185, 20207, 21123 of
+        // tests/fuzz_parity.py).  A library does not end its host process over that: the arithmetic is the reference's, the check keeps
         // the tolerance of an actual error.
         assert(sum_hap_prob < 1 + 1e-9);
         estimates.noise_count += (1 - sum_hap_prob) * estimates.total_count;
