@@ -137,7 +137,9 @@ def test_collapsed_rows_reach_the_sequential_search(engine):
 
 
 # seeds of the sweep that once differed (5109: tied diplotype order; 7004: row collapse) + one of every shape / model
-SWEEP_SEEDS = [5109, 7004, 1000, 1001, 1002, 1003, 1004, 1006, 1007, 1013, 1015, 1019, 1027, 1035, 1036, 1043, 1047]
+# ... 21123: the sum of 20 000 subset weights passes the reference's 100-ulp assertion on this side's rounding; 21204:
+# the tie of 5109 with a zero-weight pair listed for whichever column is visited first
+SWEEP_SEEDS = [5109, 7004, 21123, 21204, 1000, 1001, 1002, 1003, 1004, 1006, 1007, 1013, 1015, 1019, 1027, 1035, 1036, 1043, 1047]
 
 
 @pytest.mark.parametrize("seed", SWEEP_SEEDS)
@@ -145,3 +147,15 @@ def test_trimmed_parity_sweep(engine, seed):
     case = fuzz_parity.draw_case(seed)
     problems = fuzz_parity.run_case(engine, case)
     assert not problems, (seed, case["model"], case["kw"], problems[:5])
+
+
+def test_em_problem_rows_are_not_collapsed_and_what_that_costs(engine, monkeypatch):
+    """The reference collapses the rows of every EM problem too (src/path_abundance_estimator.cpp:266,668); this path does
+    not.  Sweep seed 20034 — one 26-path problem over 31 679 rows — is where it shows most in 1 700
+    configurations: one abundance 1.2e-6 off (relative), everything else identical incl. the EM iteration counts.  The
+    sweep's own bar (1e-6) fails on it; the project's (1e-4) holds with two orders to spare."""
+    case = fuzz_parity.draw_case(20034)
+    strict = fuzz_parity.run_case(engine, case)
+    assert all("abundance" in p for p in strict) and len(strict) <= 2, strict[:5]
+    monkeypatch.setattr(fuzz_parity, "REL", 1e-5)
+    assert not fuzz_parity.run_case(engine, case)
