@@ -7,12 +7,14 @@
 //
 // Pipeline per rpvg_hip_em_solve() call (all on the context's stream):
 //   1. scatterColumnMapKernel   path -> column (or -1) map of every problem
-//   2. countProblemKernel       rows/entries that survive the column subset,
-//                               read mass of rows that touch no selected path
-//   3. (host) prefix sums over problems, cost-descending order, size bins
-//   4. fillProblemKernel        ordered compaction into a per-problem CSR of
-//                               row-normalised entries  P_ij/rowsum_i*(1-noise_i)
-//   5. emSparseKernel<BLOCK>    ONE workgroup per problem runs the whole EM
+//   2. fillProblemKernel        ordered compaction into a per-problem CSR of
+//                               row-normalised entries  P_ij/rowsum_i*(1-noise_i),
+//                               at offsets the host knows (a problem keeps at most
+//                               the rows and entries of its cluster); counts the rows
+//                               and entries that survive the column subset and the
+//                               read mass of the rows that touch no selected path
+//   3. (host) the counts: cost-descending order, size bins
+//   4. emSparseKernel<BLOCK>    ONE workgroup per problem runs the whole EM
 //                               loop on the GPU: abundance vector a[] and the
 //                               M-step accumulators t[] live in LDS, the
 //                               problem's CSR streams from L2/HBM every
@@ -134,48 +136,6 @@ __global__ void scatterColumnMapKernel(const uint32_t num_problems, const uint64
 // ---- 2. count ----------------------------------------------------------------
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void countProblemKernel(
-    const uint32_t num_problems, const uint32_t * __restrict__ prob_cluster, const uint64_t * __restrict__ colmap_off,
-    const int32_t * __restrict__ colmap, const uint64_t * __restrict__ cluster_row_off,
-    const uint64_t * __restrict__ row_ent_off, const uint32_t * __restrict__ ent_path,
-    const double * __restrict__ row_count, uint32_t * __restrict__ kept_rows, uint32_t * __restrict__ kept_entries,
-    double * __restrict__ zero_mass, double * __restrict__ total_mass) {
-    __shared__ double dscratch[BLOCK / 64];
-    __shared__ uint32_t uscratch[BLOCK / 64];
-    const uint32_t p = blockIdx.x;
-    if (p >= num_problems) return;
-    const uint32_t k = prob_cluster[p];
-    const int32_t * map = colmap + colmap_off[p];
-    const uint64_t r0 = cluster_row_off[k], r1 = cluster_row_off[k + 1];
-    uint32_t n_rows = 0, n_ent = 0;
-    double z = 0, t = 0;
-    for (uint64_t r = r0 + threadIdx.x; r < r1; r += BLOCK) {
-        uint32_t n = 0;
-        for (uint64_t e = row_ent_off[r]; e < row_ent_off[r + 1]; ++e) n += (map[ent_path[e]] >= 0);
-        const double c = row_count[r];
-        t += c;
-        if (n) {
-            ++n_rows;
-            n_ent += n;
-        } else {
-            z += c;
-        }
-    }
-    n_rows = blockReduceSum<uint32_t, BLOCK>(n_rows, uscratch);
-    n_ent = blockReduceSum<uint32_t, BLOCK>(n_ent, uscratch);
-    z = blockReduceSum<double, BLOCK>(z, dscratch);
-    t = blockReduceSum<double, BLOCK>(t, dscratch);
-    if (threadIdx.x == 0) {
-        kept_rows[p] = n_rows;
-        kept_entries[p] = n_ent;
-        zero_mass[p] = z;
-        total_mass[p] = t;
-    }
-}
-
-// ---- 4. fill: ordered compaction + row normalisation -------------------------
-
-template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void fillProblemKernel(
     const uint32_t num_problems, const uint32_t * __restrict__ prob_cluster, const uint64_t * __restrict__ colmap_off,
     const int32_t * __restrict__ colmap, const uint64_t * __restrict__ cluster_row_off,
@@ -184,8 +144,12 @@ __global__ __launch_bounds__(BLOCK) void fillProblemKernel(
     const uint64_t * __restrict__ row_base, const uint64_t * __restrict__ ent_base,
     uint32_t * __restrict__ prow_off,   // [rows_total + P] per problem kept_rows+1 offsets relative to the problem's entry base
     double * __restrict__ prow_count, double * __restrict__ prow_noise, uint32_t * __restrict__ pent_col,
-    double * __restrict__ pent_val) {
+    double * __restrict__ pent_val,
+    // the counts of the problem
+    uint32_t * __restrict__ kept_rows, uint32_t * __restrict__ kept_entries, double * __restrict__ zero_mass,
+    double * __restrict__ total_mass) {
     __shared__ uint32_t scratch[2 * (BLOCK / 64)];
+    __shared__ double dscratch[BLOCK / 64];
     const uint32_t p = blockIdx.x;
     if (p >= num_problems) return;
     const uint32_t k = prob_cluster[p];
@@ -195,6 +159,7 @@ __global__ __launch_bounds__(BLOCK) void fillProblemKernel(
     // the offsets array has one extra slot per problem
     uint32_t * off = prow_off + rb + p;
     uint32_t run_rows = 0, run_ent = 0;
+    double z = 0, t = 0;  // read counts of the rows without a selected path / of all rows
     for (uint64_t rc = r0; rc < r1; rc += BLOCK) {
         const uint64_t r = rc + threadIdx.x;
         uint32_t n = 0;
@@ -209,6 +174,9 @@ __global__ __launch_bounds__(BLOCK) void fillProblemKernel(
                     rowsum += ent_prob[e];
                 }
             }
+            const double c = row_count[r];
+            t += c;
+            if (!n) z += c;
         }
         uint32_t slot = n ? 1u : 0u, epos = n, tot_rows, tot_ent;
         blockExclusiveScanPair<BLOCK>(slot, epos, tot_rows, tot_ent, scratch);
@@ -233,7 +201,15 @@ __global__ __launch_bounds__(BLOCK) void fillProblemKernel(
         run_rows += tot_rows;
         run_ent += tot_ent;
     }
-    if (threadIdx.x == 0) off[run_rows] = run_ent;
+    z = blockReduceSum<double, BLOCK>(z, dscratch);
+    t = blockReduceSum<double, BLOCK>(t, dscratch);
+    if (threadIdx.x == 0) {
+        off[run_rows] = run_ent;
+        kept_rows[p] = run_rows;
+        kept_entries[p] = run_ent;
+        zero_mass[p] = z;
+        total_mass[p] = t;
+    }
 }
 
 // ---- 5. the EM kernel --------------------------------------------------------
@@ -829,38 +805,6 @@ __global__ __launch_bounds__(256) void gibbsReadCountKernel(const GibbsLaunchArg
 
 // ---- shared host part: validate problems, build their compacted CSR on the device --------------
 
-// exclusive prefix sums of the kept rows and entries of the problems (one workgroup: a batch has some ten thousand)
-__global__ void __launch_bounds__(1024) problemBasesKernel(const uint32_t num_problems, const uint32_t * __restrict__ kept_rows,
-                                                           const uint32_t * __restrict__ kept_ent, uint64_t * __restrict__ row_base,
-                                                           uint64_t * __restrict__ ent_base) {
-    __shared__ uint64_t row_sums[1024], ent_sums[1024];
-    const uint32_t per = (num_problems + 1023) / 1024;
-    const uint32_t lo = min(num_problems, threadIdx.x * per), hi = min(num_problems, lo + per);
-    uint64_t my_rows = 0, my_ent = 0;
-    for (uint32_t p = lo; p < hi; ++p) {
-        my_rows += kept_rows[p];
-        my_ent += kept_ent[p];
-    }
-    row_sums[threadIdx.x] = my_rows;
-    ent_sums[threadIdx.x] = my_ent;
-    __syncthreads();
-    for (uint32_t step = 1; step < 1024; step <<= 1) {
-        const uint64_t add_rows = threadIdx.x >= step ? row_sums[threadIdx.x - step] : 0;
-        const uint64_t add_ent = threadIdx.x >= step ? ent_sums[threadIdx.x - step] : 0;
-        __syncthreads();
-        row_sums[threadIdx.x] += add_rows;
-        ent_sums[threadIdx.x] += add_ent;
-        __syncthreads();
-    }
-    uint64_t rows = row_sums[threadIdx.x] - my_rows, ent = ent_sums[threadIdx.x] - my_ent;
-    for (uint32_t p = lo; p < hi; ++p) {
-        row_base[p] = rows;
-        ent_base[p] = ent;
-        rows += kept_rows[p];
-        ent += kept_ent[p];
-    }
-}
-
 struct ProblemSet {
     uint32_t P = 0;
     uint64_t n_cols_total = 0, rows_total = 0, ent_total = 0;
@@ -882,7 +826,10 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
     ps.P = P;
     std::unique_ptr<HostScope> scope(new HostScope("problems: validate"));
     std::vector<uint64_t> colmap_off(P + 1, 0);
-    uint64_t rows_bound = 0, entries_bound = 0;  // a problem keeps at most the rows and entries of its cluster
+    // A problem keeps at most the rows and entries of its cluster: its compacted rows and entries start where those of
+    // the problems before it would end at the most — offsets the host knows, so one kernel counts and fills.
+    uint64_t rows_bound = 0, entries_bound = 0;
+    std::vector<uint64_t> row_base(P), ent_base(P);
     for (uint32_t p = 0; p < P; ++p) {
         const uint32_t k = problems->cluster[p];
         RPVG_REQUIRE(k < batch->num_clusters, "%s: problem %u refers to cluster %u of %u", who, p, k, batch->num_clusters);
@@ -897,6 +844,8 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
         }
         colmap_off[p + 1] = colmap_off[p] + n_paths;
         ps.max_cols = std::max<uint32_t>(ps.max_cols, static_cast<uint32_t>(c1 - c0) + 1);
+        row_base[p] = rows_bound;
+        ent_base[p] = entries_bound;
         rows_bound += batch->h_cluster_row_off[k + 1] - batch->h_cluster_row_off[k];
         entries_bound += batch->h_cluster_ent_off[k + 1] - batch->h_cluster_ent_off[k];
     }
@@ -909,6 +858,8 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
     ps.uploads.add(ps.d_col_off, problems->col_off, P + 1);
     ps.uploads.add(ps.d_col_path, problems->col_path, ps.n_cols_total);
     ps.uploads.add(ps.d_colmap_off, colmap_off.data(), P + 1);
+    ps.uploads.add(ps.d_row_base, row_base.data(), P);
+    ps.uploads.add(ps.d_ent_base, ent_base.data(), P);
     RPVG_HIP_CHECK(ps.uploads.commit(st));
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(P * 4 + (P + 1) * 16 + ps.n_cols_total * 4);
@@ -925,28 +876,18 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
     span = ctx->spanBegin(FAM_BUILD);
     RPVG_HIP_CHECK(hipMemsetAsync(ps.d_colmap.ptr, 0xFF, colmap_off[P] * sizeof(int32_t), st));
     scatterColumnMapKernel<<<dim3(P), dim3(64), 0, st>>>(P, ps.d_col_off.ptr, ps.d_col_path.ptr, ps.d_colmap_off.ptr, ps.d_colmap.ptr);
-    countProblemKernel<256><<<dim3(P), dim3(256), 0, st>>>(P, ps.d_cluster.ptr, ps.d_colmap_off.ptr, ps.d_colmap.ptr,
-                                                          batch->cluster_row_off.ptr, batch->row_ent_off.ptr,
-                                                          batch->ent_path.ptr, batch->row_count.ptr, ps.d_kept_rows.ptr,
-                                                          ps.d_kept_ent.ptr, ps.d_zero.ptr, ps.d_total.ptr);
-    // The compacted rows and entries of the problems lie back to back: their offsets are the prefix sums of the counts,
-    // taken on the device (one workgroup), and the storage is sized by the clusters' own rows and entries — so the
-    // fill follows the count without a round trip to the host (0.25 ms of a lane's critical path: wake-up, prefix,
-    // upload, launch); the host reads the counts once everything is queued.
-    RPVG_HIP_CHECK(ps.d_row_base.alloc(P));
-    RPVG_HIP_CHECK(ps.d_ent_base.alloc(P));
     RPVG_HIP_CHECK(ps.d_prow_off.alloc(rows_bound + P));
     RPVG_HIP_CHECK(ps.d_prow_count.alloc(rows_bound));
     RPVG_HIP_CHECK(ps.d_prow_noise.alloc(rows_bound));
     RPVG_HIP_CHECK(ps.d_pent_col.alloc(entries_bound));
     RPVG_HIP_CHECK(ps.d_pent_val.alloc(entries_bound));
-    problemBasesKernel<<<dim3(1), dim3(1024), 0, st>>>(P, ps.d_kept_rows.ptr, ps.d_kept_ent.ptr, ps.d_row_base.ptr, ps.d_ent_base.ptr);
     fillProblemKernel<256><<<dim3(P), dim3(256), 0, st>>>(
         P, ps.d_cluster.ptr, ps.d_colmap_off.ptr, ps.d_colmap.ptr, batch->cluster_row_off.ptr, batch->row_ent_off.ptr,
         batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_count.ptr, batch->row_noise.ptr, ps.d_row_base.ptr,
-        ps.d_ent_base.ptr, ps.d_prow_off.ptr, ps.d_prow_count.ptr, ps.d_prow_noise.ptr, ps.d_pent_col.ptr, ps.d_pent_val.ptr);
+        ps.d_ent_base.ptr, ps.d_prow_off.ptr, ps.d_prow_count.ptr, ps.d_prow_noise.ptr, ps.d_pent_col.ptr, ps.d_pent_val.ptr,
+        ps.d_kept_rows.ptr, ps.d_kept_ent.ptr, ps.d_zero.ptr, ps.d_total.ptr);
     ctx->spanEnd(span);
-    ctx->stats.build_launches += 4;
+    ctx->stats.build_launches += 2;
     RPVG_HIP_CHECK(hipGetLastError());
 
     scope.reset(new HostScope("problems: wait for the counts"));
