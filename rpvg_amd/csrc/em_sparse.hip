@@ -976,11 +976,22 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     std::vector<uint32_t> order;
     order.reserve(P);
     uint32_t bin_start[kBins];
+    std::vector<uint64_t> keys;  // (inverted work, problem): ascending = expensive first, ties by problem index
     for (int b = kBins - 1; b >= 0; --b) {
-        std::sort(bins[b].begin(), bins[b].end(), [&](uint32_t x, uint32_t y) {
-            const uint64_t wx = static_cast<uint64_t>(kept_ent[x]) + kept_rows[x], wy = static_cast<uint64_t>(kept_ent[y]) + kept_rows[y];
-            return wx != wy ? wx > wy : x < y;
-        });
+        keys.clear();
+        for (const uint32_t x : bins[b]) {
+            const uint64_t work = static_cast<uint64_t>(kept_ent[x]) + kept_rows[x];  // < 2^33
+            keys.push_back(((0x3ffffffffull - work) << 30) | x);
+        }
+        if (P < (1u << 30)) {
+            std::sort(keys.begin(), keys.end());
+            for (size_t i = 0; i < keys.size(); ++i) bins[b][i] = static_cast<uint32_t>(keys[i] & 0x3fffffffu);
+        } else {
+            std::sort(bins[b].begin(), bins[b].end(), [&](uint32_t x, uint32_t y) {
+                const uint64_t wx = static_cast<uint64_t>(kept_ent[x]) + kept_rows[x], wy = static_cast<uint64_t>(kept_ent[y]) + kept_rows[y];
+                return wx != wy ? wx > wy : x < y;
+            });
+        }
         bin_start[b] = order.size();
         order.insert(order.end(), bins[b].begin(), bins[b].end());
     }
