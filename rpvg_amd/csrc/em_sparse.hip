@@ -155,7 +155,8 @@ __global__ __launch_bounds__(BLOCK) void fillProblemKernel(
     const uint32_t k = prob_cluster[p];
     const int32_t * map = colmap + colmap_off[p];
     const uint64_t r0 = cluster_row_off[k], r1 = cluster_row_off[k + 1];
-    const uint64_t rb = row_base[p], eb = ent_base[p];
+    const bool count_only = prow_off == nullptr;  // first of two passes when the storage bound does not fit (buildProblemSet)
+    const uint64_t rb = count_only ? 0 : row_base[p], eb = count_only ? 0 : ent_base[p];
     // the offsets array has one extra slot per problem
     uint32_t * off = prow_off + rb + p;
     uint32_t run_rows = 0, run_ent = 0;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(BLOCK) void fillProblemKernel(
         }
         uint32_t slot = n ? 1u : 0u, epos = n, tot_rows, tot_ent;
         blockExclusiveScanPair<BLOCK>(slot, epos, tot_rows, tot_ent, scratch);
-        if (n) {
+        if (n && !count_only) {
             const uint32_t my_row = run_rows + slot;
             uint32_t my_ent = run_ent + epos;
             off[my_row] = my_ent;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(BLOCK) void fillProblemKernel(
     z = blockReduceSum<double, BLOCK>(z, dscratch);
     t = blockReduceSum<double, BLOCK>(t, dscratch);
     if (threadIdx.x == 0) {
-        off[run_rows] = run_ent;
+        if (!count_only) off[run_rows] = run_ent;
         kept_rows[p] = run_rows;
         kept_entries[p] = run_ent;
         zero_mass[p] = z;
@@ -858,8 +859,15 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
     ps.uploads.add(ps.d_col_off, problems->col_off, P + 1);
     ps.uploads.add(ps.d_col_path, problems->col_path, ps.n_cols_total);
     ps.uploads.add(ps.d_colmap_off, colmap_off.data(), P + 1);
-    ps.uploads.add(ps.d_row_base, row_base.data(), P);
-    ps.uploads.add(ps.d_ent_base, ent_base.data(), P);
+    // (storage by the bound up to a budget — RPVG_HIP_EM_BOUND_BYTES, default 32 GiB per call; beyond it two passes, the first
+    // of which only counts: what round 1 always did)
+    const char * budget_env = std::getenv("RPVG_HIP_EM_BOUND_BYTES");  // (read per call: the tests take both ways)
+    const uint64_t bound_budget = budget_env ? static_cast<uint64_t>(std::atof(budget_env)) : (32ull << 30);
+    const bool by_bound = rows_bound * 20 + entries_bound * 12 <= bound_budget;
+    if (by_bound) {
+        ps.uploads.add(ps.d_row_base, row_base.data(), P);
+        ps.uploads.add(ps.d_ent_base, ent_base.data(), P);
+    }
     RPVG_HIP_CHECK(ps.uploads.commit(st));
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(P * 4 + (P + 1) * 16 + ps.n_cols_total * 4);
@@ -876,16 +884,35 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
     span = ctx->spanBegin(FAM_BUILD);
     RPVG_HIP_CHECK(hipMemsetAsync(ps.d_colmap.ptr, 0xFF, colmap_off[P] * sizeof(int32_t), st));
     scatterColumnMapKernel<<<dim3(P), dim3(64), 0, st>>>(P, ps.d_col_off.ptr, ps.d_col_path.ptr, ps.d_colmap_off.ptr, ps.d_colmap.ptr);
+    auto fill = [&]() {
+        fillProblemKernel<256><<<dim3(P), dim3(256), 0, st>>>(
+            P, ps.d_cluster.ptr, ps.d_colmap_off.ptr, ps.d_colmap.ptr, batch->cluster_row_off.ptr, batch->row_ent_off.ptr,
+            batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_count.ptr, batch->row_noise.ptr, ps.d_row_base.ptr,
+            ps.d_ent_base.ptr, ps.d_prow_off.ptr, ps.d_prow_count.ptr, ps.d_prow_noise.ptr, ps.d_pent_col.ptr, ps.d_pent_val.ptr,
+            ps.d_kept_rows.ptr, ps.d_kept_ent.ptr, ps.d_zero.ptr, ps.d_total.ptr);
+    };
+    if (!by_bound) {
+        fill();  // no storage yet: counts only
+        RPVG_HIP_CHECK(hipGetLastError());
+        RPVG_HIP_CHECK(ps.counts.fetch(st));
+        RPVG_HIP_CHECK(hipStreamSynchronize(st));
+        ps.counts.scatter();
+        rows_bound = entries_bound = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            row_base[p] = rows_bound;
+            ent_base[p] = entries_bound;
+            rows_bound += ps.kept_rows[p];
+            entries_bound += ps.kept_ent[p];
+        }
+        RPVG_HIP_CHECK(ps.d_row_base.upload(row_base.data(), P, st));
+        RPVG_HIP_CHECK(ps.d_ent_base.upload(ent_base.data(), P, st));
+    }
     RPVG_HIP_CHECK(ps.d_prow_off.alloc(rows_bound + P));
     RPVG_HIP_CHECK(ps.d_prow_count.alloc(rows_bound));
     RPVG_HIP_CHECK(ps.d_prow_noise.alloc(rows_bound));
     RPVG_HIP_CHECK(ps.d_pent_col.alloc(entries_bound));
     RPVG_HIP_CHECK(ps.d_pent_val.alloc(entries_bound));
-    fillProblemKernel<256><<<dim3(P), dim3(256), 0, st>>>(
-        P, ps.d_cluster.ptr, ps.d_colmap_off.ptr, ps.d_colmap.ptr, batch->cluster_row_off.ptr, batch->row_ent_off.ptr,
-        batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_count.ptr, batch->row_noise.ptr, ps.d_row_base.ptr,
-        ps.d_ent_base.ptr, ps.d_prow_off.ptr, ps.d_prow_count.ptr, ps.d_prow_noise.ptr, ps.d_pent_col.ptr, ps.d_pent_val.ptr,
-        ps.d_kept_rows.ptr, ps.d_kept_ent.ptr, ps.d_zero.ptr, ps.d_total.ptr);
+    fill();
     ctx->spanEnd(span);
     ctx->stats.build_launches += 2;
     RPVG_HIP_CHECK(hipGetLastError());

@@ -628,3 +628,29 @@ def test_upload_reports_the_first_row_that_breaks_an_invariant(hip_ctx):
     with pytest.raises(hip.EngineError, match="inconsistent group or entry offsets"):
         hip_ctx.upload(bad)
     hip_ctx.upload(good)  # the context is still usable
+
+
+def test_em_problem_sets_in_two_passes_when_the_storage_bound_is_over_budget(hip_ctx):
+    """The compacted rows of the EM problems are stored by a bound (a problem keeps at most its cluster's rows and
+    entries) so that one kernel counts and fills; over a budget (RPVG_HIP_EM_BOUND_BYTES) a counting pass comes first.
+    Same solutions either way."""
+    clusters = small_cases.make_batch_clusters(991, n_clusters=9, with_empty=False)
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    problems = []
+    for k, cl in enumerate(clusters):
+        n = len(cl["paths"])
+        problems.append((k, list(range(n))))
+        if n > 2:
+            problems.append((k, list(range(0, n, 2))))
+    owners, columns = [k for k, _ in problems], [c for _, c in problems]
+    one_pass = hip_ctx.em_solve(dev, owners, columns, 10000, 1e-3)
+    os.environ["RPVG_HIP_EM_BOUND_BYTES"] = "1"
+    try:
+        two_pass = hip_ctx.em_solve(dev, owners, columns, 10000, 1e-3)
+    finally:
+        os.environ.pop("RPVG_HIP_EM_BOUND_BYTES", None)
+    assert np.array_equal(one_pass[3], two_pass[3]) and np.array_equal(one_pass[2], two_pass[2])  # iterations, totals
+    assert small_cases.rel_close(one_pass[1], two_pass[1], rel=1e-12, floor=1e-12)
+    for a, b in zip(one_pass[0], two_pass[0]):
+        assert small_cases.rel_close(a, b, rel=1e-12, floor=1e-12)  # (LDS atomics: the last bits are run-dependent)
