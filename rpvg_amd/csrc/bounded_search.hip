@@ -983,10 +983,12 @@ __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args
 }
 
 // exclusive prefix of the kept-pair counts (one workgroup: a batch has a few thousand matrices); also fetches the
-// validity flag of the matrices' build, so that one D2H copy brings everything the host waits for
+// validity flag of the matrices' build and copies the tail words in front of the dense pairs, so that one D2H copy
+// brings everything the host waits for
 __global__ void __launch_bounds__(1024) pairOffsetsKernel(const uint32_t num_matrices, const uint32_t * __restrict__ counts,
                                                           uint64_t * __restrict__ pair_off, const uint32_t * __restrict__ build_error,
-                                                          uint32_t * __restrict__ build_error_out) {
+                                                          uint32_t * __restrict__ build_error_out, uint32_t * __restrict__ tail_copy,
+                                                          const uint32_t tail_words) {
     __shared__ uint64_t sums[1024];
     const uint32_t per = (num_matrices + 1023) / 1024;
     const uint32_t lo = min(num_matrices, threadIdx.x * per), hi = min(num_matrices, lo + per);
@@ -1007,6 +1009,9 @@ __global__ void __launch_bounds__(1024) pairOffsetsKernel(const uint32_t num_mat
     }
     if (threadIdx.x == 1023) pair_off[num_matrices] = sums[1023];
     if (threadIdx.x == 0 && build_error) *build_error_out = *build_error;
+    __syncthreads();
+    // counts, evaluation counter and flag once more in front of the dense pairs: one copy brings both to the host
+    for (uint32_t i = threadIdx.x; i < tail_words; i += blockDim.x) tail_copy[i] = counts[i];
 }
 
 // copies the kept pairs of every matrix into one dense block [value: total f64 | first: total u32 | second: total u32]
@@ -1356,22 +1361,27 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     ctx->stats.loglik_launches += (num_big > 0 ? 2 : 0) + (num_medium > 0) + (M > num_big + num_medium);
     ok(hipGetLastError());
 
-    // offsets of the kept pairs and their dense copy are queued behind the search: the host waits once for the counts
-    // (with the evaluation counter and the validity flag of the matrices' build), once for the pairs
-    DeviceBuffer<unsigned char> d_block;
+    // Offsets of the kept pairs and their dense copy are queued behind the search, and ONE copy brings the host the counts
+    // (with the evaluation counter and the validity flag of the matrices' build) and the first megabyte of the dense
+    // pairs behind them — all of them, normally (20 000 pairs of a bench batch are 0.3 MB); more pairs take a second copy.
+    const char * with_counts_env = std::getenv("RPVG_HIP_PAIRS_WITH_COUNTS");  // bytes (tests: 0 = always a second copy)
+    const size_t kPairsWithTheCounts = with_counts_env ? static_cast<size_t>(std::atof(with_counts_env)) : (size_t(1) << 20);
+    const size_t tail_bytes = tail_words * sizeof(uint32_t), tail_room = (tail_bytes + 255) & ~size_t(255);
+    const size_t block_capacity = static_cast<size_t>(pair_cap_off[M]) * 16;
+    const size_t first_copy = tail_room + std::min(block_capacity, kPairsWithTheCounts);
+    DeviceBuffer<unsigned char> d_result;  // [tail words | dense pairs: value f64 x n, first u32 x n, second u32 x n]
     ok(d_pair_off.alloc(M + 1));
-    ok(d_block.alloc(pair_cap_off[M] * 16));
-    void * host_tail = nullptr;
-    const size_t tail_bytes = tail_words * sizeof(uint32_t);
-    if (e == hipSuccess && pinnedAlloc(&host_tail, tail_bytes) != hipSuccess) e = hipErrorOutOfMemory;
+    ok(d_result.alloc(tail_room + block_capacity));
+    void * host_result = nullptr;
+    if (e == hipSuccess && pinnedAlloc(&host_result, first_copy) != hipSuccess) e = hipErrorOutOfMemory;
     if (e == hipSuccess) {
         const bool check_build = !groups->build_checked && groups->build_error_flag.ptr;
         pairOffsetsKernel<<<dim3(1), dim3(1024), 0, st>>>(M, d_tail.ptr, d_pair_off.ptr, check_build ? groups->build_error_flag.ptr : nullptr,
-                                                         d_tail.ptr + evals_word + 2);
+                                                         d_tail.ptr + evals_word + 2, reinterpret_cast<uint32_t *>(d_result.ptr), tail_words);
         compactPairsBlockKernel<<<dim3(M), dim3(64), 0, st>>>(M, d_pair_cap_off.ptr, d_pair_off.ptr, d_out_first.ptr, d_out_second.ptr,
-                                                             d_out_value.ptr, d_block.ptr);
+                                                             d_out_value.ptr, d_result.ptr + tail_room);
         ok(hipGetLastError());
-        ok(hipMemcpyAsync(host_tail, d_tail.ptr, tail_bytes, hipMemcpyDeviceToHost, st));
+        ok(hipMemcpyAsync(host_result, d_result.ptr, first_copy, hipMemcpyDeviceToHost, st));
     }
     // the next search (another lane's) starts behind this one's offsets and compaction, not behind its large kernel alone:
     // two tiny kernels that would otherwise wait for slots next to that search (0.5 ms before this lane saw its results)
@@ -1379,22 +1389,27 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     scope.reset(new HostScope("bounded search: wait for the kernels"));
     ok(hipStreamSynchronize(st));
     if (e == hipSuccess) {
-        const uint32_t * counts = static_cast<const uint32_t *>(host_tail);
+        const uint32_t * counts = static_cast<const uint32_t *>(host_result);
         unsigned long long log_evals = 0;
         std::memcpy(&log_evals, counts + evals_word, sizeof(log_evals));
         const uint32_t build_bad = counts[evals_word + 2];
         for (uint32_t m = 0; m < M; ++m) res->pair_off[m + 1] = res->pair_off[m] + counts[m];
-        pinnedFree(host_tail);
-        host_tail = nullptr;
         if (build_bad) {  // the matrices were built without a host sync
+            pinnedFree(host_result);
             delete res;
             setError("rpvg_hip_groups_build: a group refers to a path outside its cluster");
             return RPVG_HIP_ERR_INVALID;
         }
         groups->build_checked = true;
-        scope.reset(new HostScope("bounded search: download pairs"));
         const uint64_t total = res->pair_off[M];
-        if (total > 0) {
+        const unsigned char * pairs = nullptr;
+        if (total * 16 <= first_copy - tail_room) {  // they came with the counts: the result keeps the block
+            res->block = host_result;
+            res->block_pinned = true;
+            host_result = nullptr;
+            pairs = static_cast<const unsigned char *>(res->block) + tail_room;
+        } else {
+            scope.reset(new HostScope("bounded search: download pairs"));
             if (pinnedAlloc(&res->block, total * 16) == hipSuccess) {
                 res->block_pinned = true;
             } else {
@@ -1402,12 +1417,15 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
                 if (!res->block) e = hipErrorOutOfMemory;
             }
             if (e == hipSuccess) {
-                ok(hipMemcpyAsync(res->block, d_block.ptr, total * 16, hipMemcpyDeviceToHost, st));
+                ok(hipMemcpyAsync(res->block, d_result.ptr + tail_room, total * 16, hipMemcpyDeviceToHost, st));
                 ok(hipStreamSynchronize(st));
-                res->posterior = static_cast<const double *>(res->block);
-                res->first = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(res->block) + total * sizeof(double));
-                res->second = res->first + total;
+                pairs = static_cast<const unsigned char *>(res->block);
             }
+        }
+        if (e == hipSuccess) {
+            res->posterior = reinterpret_cast<const double *>(pairs);
+            res->first = reinterpret_cast<const uint32_t *>(pairs + total * sizeof(double));
+            res->second = res->first + total;
         }
         ctx->stats.loglik_evals += static_cast<double>(log_evals);  // counted by the kernels
         for (uint32_t i = 0; i < M; ++i) {
@@ -1417,7 +1435,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         }
         ctx->stats.search_pairs_kept += static_cast<double>(total);
     }
-    if (host_tail) pinnedFree(host_tail);
+    if (host_result) pinnedFree(host_result);
     if (e != hipSuccess) {
         delete res;
         setError("rpvg_hip_bounded_pair_posteriors: %s", hipGetErrorString(e));

@@ -431,10 +431,12 @@ def test_bounded_search_on_device_matches_oracle(hip_ctx, normalise, thr, tiles)
     dg = hip_ctx.groups(dev, mats, groups, normalise)
     if not tiles:
         os.environ["RPVG_HIP_PAIR_TILES"] = "0"
+        os.environ["RPVG_HIP_PAIRS_WITH_COUNTS"] = "0"  # ... and the kept pairs fetched with a copy of their own
     try:
         got = dg.bounded_pair_posteriors(np.concatenate(counts), thr)
     finally:
         os.environ.pop("RPVG_HIP_PAIR_TILES", None)
+        os.environ.pop("RPVG_HIP_PAIRS_WITH_COUNTS", None)
     for m, (k, g) in enumerate(zip(mats, groups)):
         cl = clusters[k]
         M, noise, cnts = np_oracle.grouped_matrix(cl["rows"], g)
