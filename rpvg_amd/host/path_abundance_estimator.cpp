@@ -95,6 +95,8 @@ void PathAbundanceEstimator::EMAbundanceEstimator(std::vector<EMSolution> * solu
         return;
     }
 
+    std::unique_ptr<ScopedPhase> part(new ScopedPhase("EM: flatten"));
+
     std::vector<uint32_t> clusters;
     std::vector<uint64_t> col_off(1, 0);
     std::vector<uint32_t> col_path;
@@ -135,7 +137,9 @@ void PathAbundanceEstimator::EMAbundanceEstimator(std::vector<EMSolution> * solu
     em_results.total_count = total_counts.data();
     em_results.iterations = iterations.data();
 
+    part.reset();
     HipEngine::check(rpvg_hip_em_solve(engine->ctx(), cluster_batch.handle(), max_em_its, max_rel_em_conv, &em_problems, &em_results), "rpvg_hip_em_solve");
+    part.reset(new ScopedPhase("EM: unpack"));
 
     #pragma omp parallel for schedule(static) num_threads(hostThreads())
     for (size_t i = 0; i < problems.size(); ++i) {
@@ -374,6 +378,8 @@ void NestedPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimate
     });
 }
 
+// (Loops over a lane's clusters with little work per cluster use schedule(static, 1): the clusters come ordered by size, and
+// contiguous blocks would give the first thread all the large ones.)
 // Chunk of the dynamic schedules over a lane's clusters.  The clusters come ordered by size: a chunk of 16 put the 16
 // largest on one thread (weighted merge of the last lane, the end of the batch: 0.6 ms, 0.4 ms with chunks of one).
 // A/B knob RPVG_AMD_CLUSTER_CHUNK.
@@ -419,7 +425,7 @@ void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstim
 
         ScopedPhase reset_phase("nested: resetEstimates");
 
-        #pragma omp parallel for schedule(static) num_threads(hostThreads())
+        #pragma omp parallel for schedule(static, 1) num_threads(hostThreads())
         for (size_t i = 0; i < clusters.size(); ++i) {
 
             path_cluster_estimates->at(clusters[i]).resetEstimates(0, 0);
@@ -837,7 +843,7 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
     std::vector<size_t> first_problem(clusters.size() + 1, 0);
 
     // (the subsets of a cluster sit in a node-based map: counted by the team, then one pass of additions)
-    #pragma omp parallel for schedule(static) num_threads(hostThreads())
+    #pragma omp parallel for schedule(static, 1) num_threads(hostThreads())
     for (size_t i = 0; i < clusters.size(); ++i) {
 
         size_t num_retained = 0;
@@ -857,7 +863,7 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
 
     std::vector<EMProblem> problems(first_problem.back());
 
-    #pragma omp parallel for schedule(static) num_threads(hostThreads())
+    #pragma omp parallel for schedule(static, 1) num_threads(hostThreads())
     for (size_t i = 0; i < clusters.size(); ++i) {
 
         size_t problem_idx = first_problem.at(i);

@@ -46,7 +46,7 @@ class GroupMatrices {
             std::vector<uint64_t> group_path_off(group_off.back() + 1, 0);
             std::vector<uint32_t> group_path(first_path.back());
 
-            #pragma omp parallel for schedule(static) num_threads(hostThreads())
+            #pragma omp parallel for schedule(static, 1) num_threads(hostThreads())
             for (size_t i = 0; i < problems.size(); ++i) {
 
                 const auto & problem = problems[i];
@@ -815,7 +815,7 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
     rpvg_hip_pair_posteriors_view view;
     HipEngine::check(rpvg_hip_pair_posteriors_get(pair_posteriors, &view), "rpvg_hip_pair_posteriors_get");
 
-    #pragma omp parallel for schedule(static) num_threads(hostThreads())
+    #pragma omp parallel for schedule(static, 1) num_threads(hostThreads())
     for (size_t i = 0; i < problems.size(); ++i) {
 
         auto & result = group_posteriors->at(i);
