@@ -727,12 +727,19 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     runner = dict(c2=run_c2, rows=run_rows, e2e=run_e2e).get(args.workload, run_s3)
     line = runner(args, rank, local_rank, world, dist, torch)
-    if rank == 0:
-        assert line["n_gpus"] == args.gpus, (line["n_gpus"], args.gpus)
-        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes a version banner to the C library's stdout, which a pipe only sees when the buffer is flushed — at exit,
+    # behind the JSON line, if nothing is done: flushed here, so that the JSON line is the last thing on stdout
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    if rank == 0:
+        assert line["n_gpus"] == args.gpus, (line["n_gpus"], args.gpus)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
