@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — read-pairs quantified per second on the synthetic pantranscriptome.
 
-A "step" is one pass of the inference hot path over one batch of path clusters that is already resident
-in HBM: NestedPathAbundanceEstimator::estimateBatch() (`-i haplotype-transcripts`, reference defaults)
-on the "10M read pairs x 200k paths in ~5k clusters" workload (BASELINE.json configs[2]).
+A "step" is one pass of the inference hot path over one batch of path clusters:
+NestedPathAbundanceEstimator::estimateBatch() (`-i haplotype-transcripts`, reference defaults) on the "10M read pairs
+x 200k paths in ~5k clusters" workload (BASELINE.json configs[2]).  `value` is SURVEY.md section 8(d)'s metric: read pairs
+per second of wall clock with the H2D of every batch's sparse rows and the D2H of its results inside the clock (steady
+state of a double-buffered pipeline: batch n + 1 is uploaded under the kernels of batch n; the first batch is resident
+when the clock starts).  The same K steps on a batch that stays resident are reported next to it (`value_resident`).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s3|c2] [--model ...] [--scale F]
 
@@ -36,6 +39,21 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy kernel reaches
 FP64_VALU_PEAK_TFLOPS = 78.6  # FP64 vector rate = half the 157 TF FP32 vector rate (MI355X_MICROARCH.md)
+
+
+PROFILE_ROUND = "r03"
+
+
+def load_pmc(name):
+    """A PMC summary of profiles/<round>/ (separate rocprofv3 --pmc passes, tools/refresh_profiles_r03.sh): static
+    records of the tree of the refresh — the commit they were taken on is part of the record."""
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, name)
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))
+    except (OSError, ValueError):
+        return None
 
 
 def parse_args():
@@ -190,6 +208,23 @@ def cpu_baseline_s3(batch, model, params, target_seconds):
     return line
 
 
+def merge_stats(into, other):
+    for key, value in other.items():
+        if isinstance(value, dict):
+            merge_stats(into.setdefault(key, {}), value)
+        else:
+            into[key] = into.get(key, 0) + value
+
+
+def host_threads_per_lane():
+    """The OpenMP team of one host lane (rpvg_amd/host/pipeline_lanes.hpp, hostThreads()), as the library computes it."""
+    try:
+        from rpvg_amd import engine
+        return int(engine.lib().rpvg_amd_host_threads())
+    except Exception:  # noqa: BLE001  (stand-in engine of the launcher test)
+        return None
+
+
 def run_s3(args, rank, local_rank, world, dist, torch):
     import numpy as np
     import importlib
@@ -270,20 +305,20 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     elapsed = max_over_ranks(elapsed, dist, torch)
     stats = eng.stats()
     for other, _ in others:
-        for key, value in other.stats().items():
-            stats[key] += value
+        merge_stats(stats, other.stats())
     if os.environ.get("RPVG_BENCH_STEP_TIMES"):  # spread of the single steps (the JSON line reports the mean)
         print("step ms:", " ".join(f"{t:.1f}" for t in step_ms), file=sys.stderr)
 
     reads_all = sum_over_ranks(float(batch.total_reads), dist, torch)
 
-    # The same K steps with the rows of every batch arriving from host memory (SURVEY.md §8d counts the H2D of the
-    # sparse rows in): page-locked host arrays, two resident slots, an uploader engine with a stream of its own — batch
-    # n + 1 is validated, copied and expanded under the kernels of batch n.  Not `value` (that one is resident by the
-    # bench contract); reported next to it.
+    # The headline: the same K steps with the rows of every batch arriving from host memory (SURVEY.md §8d counts the H2D
+    # of the sparse rows in): page-locked host arrays, two resident slots, an uploader engine with a stream of its own —
+    # batch n + 1 is validated, copied and expanded under the kernels of batch n.  The kernel statistics of the line are
+    # those of this loop.
     h2d = None
     if not others and DEVICE == "cuda" and hasattr(prepared, "reupload"):
         h2d = measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank, dist, torch)
+        stats = h2d.pop("stats")
 
     # after the timed region: gather the per-path abundances of every rank over RCCL (what a multi-GPU
     # driver does before writing rpvg.txt); also fetch one decoded result for a sanity check
@@ -308,24 +343,51 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     if rank != 0:
         return None
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = reads_all / (elapsed / args.steps)
-    em_ms = stats["em_sparse_ms"] / max(1, stats["em_sparse_launches"])
-    em_bytes = stats["em_sparse_alg_bytes"] / max(1, stats["em_sparse_launches"])
-    achieved = (em_bytes / 1e9) / (em_ms / 1e3) if em_ms > 0 else 0.0
+    ms_resident = elapsed / args.steps * 1e3
+    ms_per_step = h2d["ms_per_step_with_h2d"] if h2d is not None else ms_resident
+    value = reads_all / (ms_per_step / 1e3)
+    # the dominant EM kernel: the variant with the most device time (its own HIP events on its own stream)
+    em_kernels = {name: ks for name, ks in stats.get("em_kernel", {}).items() if ks["launches"]}
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_s3.json")
-    if os.path.exists(pmc_path) and args.scale == 1.0 and args.workload == "s3" and args.model == "haplotype-transcripts":
-        # separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.py); per launch like `achieved`
-        traffic = json.load(open(pmc_path))["traffic_bytes_per_step"] / max(1.0, stats["em_sparse_launches"] / args.steps)
+    pmc = load_pmc("pmc_traffic_s3.json") if (args.scale == 1.0 and args.workload == "s3" and args.model == "haplotype-transcripts") else None
+    if em_kernels:
+        dominant = max(em_kernels, key=lambda name: em_kernels[name]["ms"])
+        dk = em_kernels[dominant]
+        em_ms = dk["ms"] / dk["launches"]
+        em_bytes = dk["alg_bytes"] / dk["launches"]
+    else:  # a stand-in engine without per-kernel statistics
+        dominant = "emSparseKernel"
+        em_ms = stats["em_sparse_ms"] / max(1, stats["em_sparse_launches"])
+        em_bytes = stats["em_sparse_alg_bytes"] / max(1, stats["em_sparse_launches"])
+    achieved = (em_bytes / 1e9) / (em_ms / 1e3) if em_ms > 0 else 0.0
+    if pmc is not None:
+        # separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.py), per kernel variant and launch like `achieved`
+        per_kernel = pmc.get("per_kernel", {})
+        for name, rec in per_kernel.items():
+            if name.replace(" ", "").startswith(dominant.replace(" ", "")):
+                traffic = rec["traffic_bytes_per_launch"]
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, kernel="emSparseKernel", ms_per_launch=em_ms, algorithmic_bytes_per_launch=em_bytes,
-                    note="algorithmic bytes = sum over EM problems of iterations x (12 B/entry + 20 B/row + 16 B/column); "
-                         "problems are L2/LDS-resident across iterations, so this is effective bandwidth: the HBM traffic "
-                         "(PMC) is a fraction of the algorithmic bytes")
+                    traffic=traffic, kernel=dominant, ms_per_launch=em_ms, algorithmic_bytes_per_launch=em_bytes,
+                    note="dominant EM kernel = the variant with the most device time; ms_per_launch = its own HIP-event span on the "
+                         "stream it runs on; algorithmic bytes = sum over its problems of iterations x (12 B/entry + 20 B/row + "
+                         "16 B/column); the problems are register/LDS/L2-resident across iterations, so this is effective bandwidth "
+                         "(the HBM traffic of the PMC passes is a fraction of the algorithmic bytes) and the kernel's real bound is the "
+                         "latency of one EM iteration times the iteration count of its slowest problem (em_kernels.*.us_per_iteration_of_slowest)")
+    if pmc is not None:
+        roofline.update(pmc_commit=pmc.get("commit"), pmc_source=pmc.get("source"))
+    em_kernel_lines = {}
+    for name, ks in em_kernels.items():
+        n = ks["launches"]
+        em_kernel_lines[name] = dict(
+            ms_per_launch=ks["ms"] / n, launches_per_step=n / args.steps, problems_per_launch=ks["problems"] / n,
+            iterations_per_launch=ks["iterations"] / n, slowest_problem_iterations=ks["max_iterations"] / n,
+            us_per_iteration_of_slowest=(ks["ms"] * 1e3 / ks["max_iterations"]) if ks["max_iterations"] else None,
+            algorithmic_bytes_per_launch=ks["alg_bytes"] / n,
+            effective_gb_per_s=(ks["alg_bytes"] / 1e9) / (ks["ms"] / 1e3) if ks["ms"] > 0 else 0.0)
     kernels = dict(
         em_sparse_ms_per_step=stats["em_sparse_ms"] / args.steps, loglik_ms_per_step=stats["loglik_ms"] / args.steps,
         build_ms_per_step=stats["build_ms"] / args.steps, h2d_ms_per_step=stats["h2d_ms"] / args.steps,
+        collapse_ms_per_step=stats.get("collapse_ms", 0.0) / args.steps,
         em_iterations_per_step=stats["em_iterations_total"] / args.steps,
         loglik_evals_per_step=stats["loglik_evals"] / args.steps,
         loglik_gevals_per_s=(stats["loglik_evals"] / 1e9) / (stats["loglik_ms"] / 1e3) if stats["loglik_ms"] > 0 else 0.0)
@@ -340,11 +402,22 @@ def run_s3(args, rank, local_rank, world, dist, torch):
                     clusters_per_gpu=K, rows_per_gpu=batch.num_rows, entries_per_gpu=int(len(batch.path_idx)),
                     parallelism=f"clusters sharded, {world} rank(s), final abundance gather over RCCL",
                     batches_in_flight=args.in_flight),
-        roofline=roofline, kernels=kernels, mass_conserved=bool(mass_ok),
-        upload_ms=upload_ms)
+        roofline=roofline, kernels=kernels, em_kernels=em_kernel_lines, mass_conserved=bool(mass_ok),
+        upload_ms=upload_ms, ms_per_step_resident=ms_resident, value_resident=reads_all / (ms_resident / 1e3),
+        engine_module=ENGINE_MODULE, host_threads_per_lane=host_threads_per_lane(),
+        value_note="value = read pairs / steady-state step with the H2D of every batch's rows and the D2H of its results inside the "
+                   "clock (SURVEY.md section 8d); value_resident = the same K steps on a batch that stays in HBM")
+    if stats.get("busy_ms") is not None:
+        # union of the timed spans of both host lanes' contexts over the wall time of the headline loop: an upper bound of
+        # the share of the step during which the GPU had work of this engine (a span runs from the first command of a stage
+        # to its last on the stage's stream); the rocprofv3 kernel trace under profiles/ gives the exact figure
+        line["gpu_active_frac"] = (stats["busy_ms"] / args.steps) / ms_per_step
     if h2d is not None:
         line.update(h2d)
-        line["value_including_upload"] = reads_all / (h2d["ms_per_step_with_h2d"] / 1e3)
+    if ENGINE_MODULE != "rpvg_amd.engine":
+        # a stand-in engine (the CPU test of the launcher and the rank protocol): no metric is claimed
+        line.update(metric="none: stand-in engine %s, launcher/protocol self-test only" % ENGINE_MODULE, protocol_value=value, value=None,
+                    value_resident=None)
     if gathered is not None:
         line["gathered_abundance_mass"] = gathered
     if tpm_denominator is not None:
@@ -367,12 +440,11 @@ def run_s3(args, rank, local_rank, world, dist, torch):
                                  "evaluated (pairTileKernel: all matrices up to 1024 columns) where the reference skips the first columns its "
                                  "bound prunes (the sequential search reaches 4.1 of these 4.4 G row-pair evaluations anyway); kept = pairs "
                                  "that survive the threshold")
-    pmc_search_path = os.path.join(ROOT, "profiles", "pmc_search_s3.json")
-    if not s5 and os.path.exists(pmc_search_path) and args.scale == 1.0 and args.model == "haplotype-transcripts":
+    pmc_search = load_pmc("pmc_search_s3.json") if (not s5 and args.scale == 1.0 and args.model == "haplotype-transcripts") else None
+    if pmc_search is not None:
         # separate rocprofv3 --pmc passes of this workload with one host lane (tools/pmc_search_summary.py)
-        pmc_search = json.load(open(pmc_search_path))
         search.update(valu_instructions_per_eval=pmc_search["valu_instructions_per_eval"], valu_busy=pmc_search["valu_busy"],
-                      pmc_source=pmc_search["source"])
+                      pmc_source=pmc_search["source"], pmc_commit=pmc_search.get("commit"))
     if s5:
         # no EM on this path: the device work is the FP64 log-likelihood contraction of the Gibbs conditionals, the rest of a
         # step is the host's sampler state machines (the reference's mt19937 / discrete_distribution streams, draw for draw)
@@ -424,12 +496,14 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
         for k in range(max(2, args.warmup)):
             step(k)
         upload_s.clear()
+        eng.reset_stats()
         barrier_sync(dist, torch)
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(k)
         barrier_sync(dist, torch)
         overlapped = max_over_ranks(time.perf_counter() - t0, dist, torch)
+        stats = eng.stats()
         t0 = time.perf_counter()
         for k in range(args.steps):  # no overlap: upload, then estimate
             slots[k % 2].reupload(uploader)
@@ -442,7 +516,7 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
             hip.host_unregister(a)
     bytes_per_batch = float(sum(a.nbytes for a in arrays))
     up_ms = 1e3 * sum(upload_s) / max(1, len(upload_s))
-    return dict(ms_per_step_with_h2d=overlapped / args.steps * 1e3, ms_per_step_with_h2d_serial=serial / args.steps * 1e3,
+    return dict(stats=stats, ms_per_step_with_h2d=overlapped / args.steps * 1e3, ms_per_step_with_h2d_serial=serial / args.steps * 1e3,
                 h2d_ms_per_batch=up_ms, h2d_bytes_per_batch=bytes_per_batch, h2d_gb_per_s=bytes_per_batch / 1e9 / (up_ms / 1e3),
                 h2d_note="rows of every batch uploaded from page-locked host arrays inside the clock: validation on the host, H2D, "
                          "expansion on the device; overlapped = two resident slots, uploader engine under the previous batch's kernels")
@@ -467,9 +541,8 @@ def dense_em_roofline(local_rank, rows=1000000, paths=2000, its=20):
         nbytes = st["em_dense_alg_bytes"] / max(1, st["em_dense_launches"])
         achieved = (nbytes / 1e9) / (ms / 1e3)
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_c2.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
+        pmc = load_pmc("pmc_traffic_c2.json")
+        if pmc is not None:
             shape = pmc.get("shape", {})
             if shape.get("rows") == rows and shape.get("cols") == Cn:
                 traffic = pmc.get("traffic_bytes_per_launch", pmc.get("traffic_bytes_per_step"))  # (tools/pmc_traffic.py calls a launch a step)
@@ -681,9 +754,8 @@ def run_c2(args, rank, local_rank, world, dist, torch):
     it_bytes = stats["em_dense_alg_bytes"] / max(1, stats["em_dense_launches"])
     achieved = (it_bytes / 1e9) / (it_ms / 1e3)
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_c2.json")
-    if os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path))
+    pmc = load_pmc("pmc_traffic_c2.json")
+    if pmc is not None:
         shape = pmc.get("shape", {})
         if shape.get("rows") == R and shape.get("cols") == Cn:  # per launch of THIS rank's shard
             # separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE); tools/pmc_traffic.py
@@ -700,7 +772,7 @@ def run_c2(args, rank, local_rank, world, dist, torch):
         roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                       kernel="emDenseAccumWideKernel", ms_per_launch=it_ms, algorithmic_bytes_per_launch=it_bytes,
                       note="one launch = one EM iteration's streaming pass: 8*R*C (matrix, read once) + 8*R (counts) + 16*C bytes; "
-                           "traffic = HBM bytes per launch from rocprofv3 PMC passes (profiles/pmc_traffic_c2.json)"),
+                           "traffic = HBM bytes per launch from rocprofv3 PMC passes (profiles/%s/pmc_traffic_c2.json)" % PROFILE_ROUND + ""),
         em_iterations_per_step=its, mass_conserved=bool(abs(ab.sum() + noise - total) <= 1e-6 * total))
     if not args.no_cpu_baseline:
         # reference-shaped CPU EM on a row sample of the same matrix, one core (a single cluster is serial

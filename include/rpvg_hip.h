@@ -314,7 +314,22 @@ int rpvg_hip_synth_dense_rows(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t row_be
 int rpvg_hip_debug_log(rpvg_hip_ctx * ctx, uint64_t n, const double * x, double * out, int32_t use_table);
 
 /* ---- instrumentation ----------------------------------------------------- */
-/* Device time (HIP events on the context's stream) and launch count of the
+/* The EM kernels of rpvg_hip_em_solve (rpvg_amd/csrc/em_sparse.hip): one variant per size bin of the problems; each
+ * carries its own device time (HIP events on the stream it is launched on), launches, problems, EM iterations and
+ * algorithmic bytes (per iteration of a problem 12 B/entry + 20 B/row + 16 B/column). */
+#define RPVG_HIP_EM_KERNELS 11
+typedef struct rpvg_hip_em_kernel_stats {
+    double ms;               /* sum over launches of the HIP-event span around the launch on its own stream */
+    uint64_t launches;
+    uint64_t problems;
+    uint64_t iterations;     /* EM iterations of all problems of all launches */
+    uint64_t max_iterations; /* sum over launches of the iteration count of the launch's slowest problem */
+    double alg_bytes;
+} rpvg_hip_em_kernel_stats;
+/* "emRegisterKernel<1,16>", "emSparseKernel<64,true>", ...; NULL for an index outside [0, RPVG_HIP_EM_KERNELS) */
+const char * rpvg_hip_em_kernel_name(int index);
+
+/* Device time (HIP events on the stream the kernels are launched on) and launch count of the
  * kernels of each family since the last reset, plus the algorithmic bytes
  * they processed (DESIGN.md defines the per-launch figure). */
 typedef struct rpvg_hip_kernel_stats {
@@ -328,10 +343,22 @@ typedef struct rpvg_hip_kernel_stats {
      * (G (G + 1) / 2 each), pairs among them that belong to matrices on the pair-table path (all of them evaluated),
      * and pairs kept — the reference evaluates the kept pairs plus the ones it prunes one by one. */
     double search_pairs_possible; double search_pairs_table; double search_pairs_kept;
+    /* em_sparse_* split by kernel variant (em_sparse_ms is the span of a whole rpvg_hip_em_solve's kernels, whose bins
+     * run side by side on several streams; the per-kernel spans overlap each other) */
+    rpvg_hip_em_kernel_stats em_kernel[RPVG_HIP_EM_KERNELS];
+    double collapse_ms;       /* row collapse of the group matrices (row_collapse.hip), on the collapse stream */
+    /* length of the union of all timed spans of this context (kernels and copies; a span runs from the first command of
+     * a stage to its last on the stage's stream, so this is an upper bound of the time the GPU worked for the context) */
+    double busy_ms;
 } rpvg_hip_kernel_stats;
 
 int rpvg_hip_stats_get(rpvg_hip_ctx * ctx, rpvg_hip_kernel_stats * stats_out);
 int rpvg_hip_stats_reset(rpvg_hip_ctx * ctx);
+/* The timed spans behind the statistics since the last reset, as intervals in milliseconds on a clock shared by all
+ * contexts of the GPU (so that a caller with several contexts on one GPU — the host lanes of rpvg_amd::HipEngine — can
+ * take the union over them).  Writes at most `capacity` intervals (any array may be NULL) and the number there are. */
+int rpvg_hip_stats_intervals(rpvg_hip_ctx * ctx, uint64_t capacity, double * start_ms, double * stop_ms, int32_t * family,
+                             uint64_t * count_out);
 
 #ifdef __cplusplus
 }

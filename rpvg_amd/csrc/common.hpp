@@ -546,11 +546,19 @@ __host__ __device__ inline uint64_t collapseSortKey(const uint32_t matrix, const
 }
 
 // ---- kernel-family timing ---------------------------------------------------
-enum KernelFamily { FAM_EM_SPARSE = 0, FAM_EM_DENSE, FAM_LOGLIK, FAM_BUILD, FAM_H2D, FAM_COUNT };
+enum KernelFamily { FAM_EM_SPARSE = 0, FAM_EM_DENSE, FAM_LOGLIK, FAM_BUILD, FAM_H2D, FAM_COLLAPSE, FAM_EM_KERNEL, FAM_COUNT };
 
 struct TimedSpan {
     hipEvent_t start, stop;
     int family;
+    int sub;  // FAM_EM_KERNEL: index of the kernel variant (rpvg_hip_em_kernel_name)
+};
+
+// A span folded into the statistics, on the clock of the device's base event (context.hip).
+struct TimedInterval {
+    double start_ms, stop_ms;
+    int family;
+    uint64_t clock;  // the base event it was measured against: intervals of different clocks do not compare
 };
 
 }  // namespace rpvg_hip_detail
@@ -580,10 +588,12 @@ struct rpvg_hip_ctx {
     // in-place sum over ranks of n doubles, stream-ordered (comm.hip); requires comm != null
     int allReduceSumF64(double * device_buf, uint64_t n);
     std::vector<rpvg_hip_detail::TimedSpan> spans;
+    std::vector<hipStream_t> span_streams;  // the stream of each open span
+    std::vector<rpvg_hip_detail::TimedInterval> intervals;  // folded spans since the last reset
     rpvg_hip_kernel_stats stats;
 
-    // Opens a timed span on the stream; returns its index (or -1 on failure).
-    int spanBegin(int family);
+    // Opens a timed span on `on` (the context's stream when null); returns its index (or -1 on failure).
+    int spanBegin(int family, hipStream_t on = nullptr, int sub = -1);
     void spanEnd(int idx);
     // Folds all finished spans into stats (synchronises the stream).
     int foldSpans();

@@ -255,28 +255,67 @@ hipError_t rpvg_hip_ctx::joinAux() {
     return e;
 }
 
-int rpvg_hip_ctx::spanBegin(int family) {
+namespace rpvg_hip_detail {
+namespace {
+// The clock of the timed intervals: one event per GPU that every span of every context on it is measured against
+// (hipEventElapsedTime returns a float: the base is renewed by a statistics reset once it is older than a few
+// seconds, so that the intervals of a measurement keep microsecond resolution).
+struct DeviceClock {
+    hipEvent_t base = nullptr;
+    uint64_t id = 0;
+    std::chrono::steady_clock::time_point taken;
+};
+std::mutex g_clock_mutex;
+std::map<int, DeviceClock> g_clocks;
+
+// Caller has set the device.  renew_if_old: take a new base when the present one is older than five seconds.
+DeviceClock deviceClock(const int device, hipStream_t stream, const bool renew_if_old) {
+    std::lock_guard<std::mutex> lock(g_clock_mutex);
+    DeviceClock & clock = g_clocks[device];
+    const auto now = std::chrono::steady_clock::now();
+    if (!clock.base || (renew_if_old && now - clock.taken > std::chrono::seconds(5))) {
+        hipEvent_t base = nullptr;
+        // (the previous base is not destroyed: spans of other contexts may still be folded against it)
+        if (hipEventCreate(&base) == hipSuccess && hipEventRecord(base, stream) == hipSuccess && hipEventSynchronize(base) == hipSuccess) {
+            clock.base = base;
+            clock.id++;
+            clock.taken = now;
+        }
+    }
+    return clock;
+}
+}  // namespace
+}  // namespace rpvg_hip_detail
+
+int rpvg_hip_ctx::spanBegin(int family, hipStream_t on, int sub) {
     TimedSpan s;
     s.family = family;
+    s.sub = sub;
     if (hipEventCreate(&s.start) != hipSuccess) return -1;
     if (hipEventCreate(&s.stop) != hipSuccess) {
         (void) hipEventDestroy(s.start);
         return -1;
     }
-    (void) hipEventRecord(s.start, stream);
+    if (!on) on = stream;
+    (void) hipEventRecord(s.start, on);
     spans.push_back(s);
+    span_streams.push_back(on);
     return static_cast<int>(spans.size()) - 1;
 }
 
 void rpvg_hip_ctx::spanEnd(int idx) {
     if (idx < 0) return;
-    (void) hipEventRecord(spans[idx].stop, stream);
+    (void) hipEventRecord(spans[idx].stop, span_streams[idx]);
 }
 
 int rpvg_hip_ctx::foldSpans() {
     RPVG_HIP_CHECK(hipStreamSynchronize(stream));
+    if (collapse_stream) RPVG_HIP_CHECK(hipStreamSynchronize(collapse_stream));
+    const DeviceClock clock = deviceClock(device, stream, false);
+    constexpr size_t kMaxIntervals = 1u << 20;
     for (auto & s : spans) {
         float ms = 0;
+        (void) hipEventSynchronize(s.stop);  // spans on side streams
         if (hipEventElapsedTime(&ms, s.start, s.stop) == hipSuccess) {
             switch (s.family) {
                 case FAM_EM_SPARSE: stats.em_sparse_ms += ms; break;
@@ -284,13 +323,43 @@ int rpvg_hip_ctx::foldSpans() {
                 case FAM_LOGLIK: stats.loglik_ms += ms; break;
                 case FAM_BUILD: stats.build_ms += ms; break;
                 case FAM_H2D: stats.h2d_ms += ms; break;
+                case FAM_COLLAPSE: stats.collapse_ms += ms; break;
+                case FAM_EM_KERNEL:
+                    if (s.sub >= 0 && s.sub < RPVG_HIP_EM_KERNELS) stats.em_kernel[s.sub].ms += ms;
+                    break;
                 default: break;
             }
+            float at = 0;
+            // (the per-kernel spans lie inside their call's FAM_EM_SPARSE span: not a second interval)
+            if (s.family != FAM_EM_KERNEL && clock.base && intervals.size() < kMaxIntervals &&
+                hipEventElapsedTime(&at, clock.base, s.start) == hipSuccess) {
+                intervals.push_back(TimedInterval{static_cast<double>(at), static_cast<double>(at) + ms, s.family, clock.id});
+            }
         }
+        (void) hipGetLastError();
         (void) hipEventDestroy(s.start);
         (void) hipEventDestroy(s.stop);
     }
     spans.clear();
+    span_streams.clear();
+    // union of the intervals on the present clock
+    std::vector<std::pair<double, double>> iv;
+    for (auto & t : intervals) {
+        if (t.clock == clock.id) iv.emplace_back(t.start_ms, t.stop_ms);
+    }
+    std::sort(iv.begin(), iv.end());
+    double busy = 0, cur_s = 0, cur_e = -1;
+    for (auto & x : iv) {
+        if (cur_e < cur_s || x.first > cur_e) {
+            if (cur_e >= cur_s) busy += cur_e - cur_s;
+            cur_s = x.first;
+            cur_e = x.second;
+        } else if (x.second > cur_e) {
+            cur_e = x.second;
+        }
+    }
+    if (cur_e >= cur_s) busy += cur_e - cur_s;
+    stats.busy_ms = busy;
     return RPVG_HIP_OK;
 }
 
@@ -746,6 +815,30 @@ int rpvg_hip_stats_reset(rpvg_hip_ctx * ctx) {
     int rc = ctx->foldSpans();
     if (rc != RPVG_HIP_OK) return rc;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
+    ctx->intervals.clear();
+    (void) deviceClock(ctx->device, ctx->stream, true);
+    return RPVG_HIP_OK;
+}
+
+int rpvg_hip_stats_intervals(rpvg_hip_ctx * ctx, uint64_t capacity, double * start_ms, double * stop_ms, int32_t * family,
+                             uint64_t * count_out) {
+    RPVG_REQUIRE(ctx != nullptr && count_out != nullptr, "rpvg_hip_stats_intervals: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = ctx->foldSpans();
+    if (rc != RPVG_HIP_OK) return rc;
+    const DeviceClock clock = deviceClock(ctx->device, ctx->stream, false);
+    uint64_t n = 0;
+    for (auto & t : ctx->intervals) {
+        if (t.clock != clock.id) continue;
+        if (n < capacity) {
+            if (start_ms) start_ms[n] = t.start_ms;
+            if (stop_ms) stop_ms[n] = t.stop_ms;
+            if (family) family[n] = t.family;
+        }
+        ++n;
+    }
+    *count_out = n;
     return RPVG_HIP_OK;
 }
 

@@ -930,6 +930,15 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
 
 }  // namespace
 
+extern "C" const char * rpvg_hip_em_kernel_name(int index) {
+    // (the size bins of rpvg_hip_em_solve, in bin order)
+    static const char * const names[RPVG_HIP_EM_KERNELS] = {
+        "emSparseKernel<64,true>", "emSparseKernel<256,true>", "emSparseKernel<256,false>", "emSparseKernel<1024,false>",
+        "emRegisterKernel<1,16>", "emRegisterKernel<2,16>", "emRegisterKernel<4,16>", "emSparseKernel<1024,true>",
+        "emRegisterKernel<1,32>", "emRegisterKernel<2,32>", "emSparseKernel<1024,false,WIDE>"};
+    return (index >= 0 && index < RPVG_HIP_EM_KERNELS) ? names[index] : nullptr;
+}
+
 extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t max_em_its,
                                  double max_rel_em_conv, const rpvg_hip_em_problems * problems,
                                  rpvg_hip_em_results * results) {
@@ -964,6 +973,7 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     //   7  LDS-resident, sixteen waves  CSR + vectors fit 152 KB (one workgroup per CU: the whole LDS)
     //   10 too many columns for LDS-resident vectors (> ~9 700): vectors in global memory, 16 waves
     constexpr int kBins = 11;
+    static_assert(kBins == RPVG_HIP_EM_KERNELS, "one statistics slot per EM kernel variant");
     constexpr size_t kLdsLimit = 156 * 1024;
     std::vector<uint64_t> wide_off(P, 0);
     uint64_t wide_total = 0;
@@ -1073,28 +1083,41 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     // queue behind the others, and a bin that waits there ends later than one that shares a stream knowingly.
     const bool wide = hardwareQueues() >= 8;
     hipStream_t s_reg4 = wide ? ctx->aux[3] : ctx->aux[0], s_reg1 = wide ? ctx->aux[4] : ctx->aux[1], s_reg2 = wide ? ctx->aux[5] : ctx->aux[2];
-    bin(6);
-    RPVG_HIP_CHECK((launchEmRegister<4, 16>(args, s_reg4)));
-    bin(4);
-    RPVG_HIP_CHECK((launchEmRegister<1, 16>(args, s_reg1)));
-    bin(5);
-    RPVG_HIP_CHECK((launchEmRegister<2, 16>(args, s_reg2)));
-    bin(2);
+    // every bin's launch carries its own HIP events on its own stream (rpvg_hip_kernel_stats::em_kernel)
+    int bin_span = -1;
+    auto timed = [&](const int b, hipStream_t on) {
+        bin(b);
+        bin_span = args.count ? ctx->spanBegin(FAM_EM_KERNEL, on, b) : -1;
+        return on;
+    };
+    RPVG_HIP_CHECK((launchEmRegister<4, 16>(args, timed(6, s_reg4))));
+    ctx->spanEnd(bin_span);
+    RPVG_HIP_CHECK((launchEmRegister<1, 16>(args, timed(4, s_reg1))));
+    ctx->spanEnd(bin_span);
+    RPVG_HIP_CHECK((launchEmRegister<2, 16>(args, timed(5, s_reg2))));
+    ctx->spanEnd(bin_span);
+    timed(2, st);
     RPVG_HIP_CHECK((launchEm<256, false>(args, bin_lds[2], st)));
-    bin(3);
+    ctx->spanEnd(bin_span);
+    timed(3, st);
     RPVG_HIP_CHECK((launchEm<1024, false>(args, bin_lds[3], st)));
-    bin(10);
+    ctx->spanEnd(bin_span);
+    timed(10, st);
     RPVG_HIP_CHECK((launchEm<1024, false, true>(args, bin_lds[10], st)));
-    bin(7);
+    ctx->spanEnd(bin_span);
+    timed(7, ctx->aux[0]);
     RPVG_HIP_CHECK((launchEm<1024, true>(args, bin_lds[7], ctx->aux[0])));
-    bin(9);
-    RPVG_HIP_CHECK((launchEmRegister<2, 32>(args, ctx->aux[0])));
-    bin(0);
+    ctx->spanEnd(bin_span);
+    RPVG_HIP_CHECK((launchEmRegister<2, 32>(args, timed(9, ctx->aux[0]))));
+    ctx->spanEnd(bin_span);
+    timed(0, ctx->aux[1]);
     RPVG_HIP_CHECK((launchEm<64, true>(args, bin_lds[0], ctx->aux[1])));
-    bin(8);
-    RPVG_HIP_CHECK((launchEmRegister<1, 32>(args, ctx->aux[1])));
-    bin(1);
+    ctx->spanEnd(bin_span);
+    RPVG_HIP_CHECK((launchEmRegister<1, 32>(args, timed(8, ctx->aux[1]))));
+    ctx->spanEnd(bin_span);
+    timed(1, ctx->aux[2]);
     RPVG_HIP_CHECK((launchEm<256, true>(args, bin_lds[1], ctx->aux[2])));
+    ctx->spanEnd(bin_span);
     RPVG_HIP_CHECK(ctx->joinAux());
     ctx->spanEnd(span);
     for (int b = 0; b < kBins; ++b) ctx->stats.em_sparse_launches += bins[b].empty() ? 0 : 1;
@@ -1109,10 +1132,25 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     // per row (count, noise, offset), 16 B per column (a read + a' write)
     double bytes = 0;
     uint64_t its_total = 0;
-    for (uint32_t p = 0; p < P; ++p) {
-        const double C = static_cast<double>(problems->col_off[p + 1] - problems->col_off[p]) + 1;
-        bytes += static_cast<double>(results->iterations[p]) * (12.0 * kept_ent[p] + 20.0 * kept_rows[p] + 16.0 * C);
-        its_total += results->iterations[p];
+    for (int b = 0; b < kBins; ++b) {
+        if (bins[b].empty()) continue;
+        rpvg_hip_em_kernel_stats & ks = ctx->stats.em_kernel[b];
+        uint32_t slowest = 0;
+        double bin_bytes = 0;
+        uint64_t bin_its = 0;
+        for (const uint32_t p : bins[b]) {
+            const double C = static_cast<double>(problems->col_off[p + 1] - problems->col_off[p]) + 1;
+            bin_bytes += static_cast<double>(results->iterations[p]) * (12.0 * kept_ent[p] + 20.0 * kept_rows[p] + 16.0 * C);
+            bin_its += results->iterations[p];
+            slowest = std::max(slowest, results->iterations[p]);
+        }
+        ks.launches += 1;
+        ks.problems += bins[b].size();
+        ks.iterations += bin_its;
+        ks.max_iterations += slowest;
+        ks.alg_bytes += bin_bytes;
+        bytes += bin_bytes;
+        its_total += bin_its;
     }
     ctx->stats.em_sparse_alg_bytes += bytes;
     ctx->stats.em_iterations_total += its_total;

@@ -626,7 +626,9 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
                 ok(hipEventRecord(g->built, st));
                 ok(hipStreamWaitEvent(collapse_stream, g->built, 0));
             }
+            const int collapse_span = (e == hipSuccess) ? ctx->spanBegin(FAM_COLLAPSE, collapse_stream) : -1;
             if (e == hipSuccess) ok(queueRowCollapse(ctx, g, row_total, spec->collapse_precision, collapse_stream));
+            ctx->spanEnd(collapse_span);
             if (e == hipSuccess) ok(hipEventRecord(g->collapse_done, collapse_stream));
         }
         sub.reset();

@@ -39,6 +39,7 @@ def lib() -> C.CDLL:
         L.rpvg_amd_engine_ctx.argtypes = [C.c_void_p]
         L.rpvg_amd_engine_stats_get.argtypes = [C.c_void_p, C.c_void_p]
         L.rpvg_amd_engine_stats_reset.argtypes = [C.c_void_p]
+        L.rpvg_amd_host_threads.restype = C.c_int
         L.rpvg_amd_batch_prepare.restype = C.c_void_p
         L.rpvg_amd_batch_prepare.argtypes = [C.c_void_p, C.POINTER(CClusterBatch), C.c_int]
         L.rpvg_amd_batch_free.argtypes = [C.c_void_p]

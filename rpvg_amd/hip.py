@@ -22,7 +22,7 @@ EXPORTS = [
     "rpvg_hip_device_info", "rpvg_hip_malloc", "rpvg_hip_free", "rpvg_hip_memcpy_h2d", "rpvg_hip_memcpy_d2h",
     "rpvg_hip_batch_upload", "rpvg_hip_batch_free", "rpvg_hip_em_solve", "rpvg_hip_em_dense",
     "rpvg_hip_dense_from_cluster", "rpvg_hip_groups_build", "rpvg_hip_groups_free", "rpvg_hip_groups_collapse_info", "rpvg_hip_group_loglik",
-    "rpvg_hip_synth_dense_cluster", "rpvg_hip_stats_get", "rpvg_hip_stats_reset",
+    "rpvg_hip_synth_dense_cluster", "rpvg_hip_stats_get", "rpvg_hip_stats_reset", "rpvg_hip_stats_intervals", "rpvg_hip_em_kernel_name",
     "rpvg_hip_gibbs_read_counts", "rpvg_hip_min_path_cover", "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
     "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
     "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_comm_init_all", "rpvg_hip_gather", "rpvg_hip_host_register", "rpvg_hip_host_unregister", "rpvg_hip_group_conditionals",
@@ -57,6 +57,14 @@ class CPairPosteriorsView(C.Structure):
                 ("second", C.POINTER(C.c_uint32)), ("posterior", C.POINTER(C.c_double))]
 
 
+EM_KERNELS = 11  # RPVG_HIP_EM_KERNELS
+
+
+class CEmKernelStats(C.Structure):
+    _fields_ = [("ms", C.c_double), ("launches", C.c_uint64), ("problems", C.c_uint64), ("iterations", C.c_uint64),
+                ("max_iterations", C.c_uint64), ("alg_bytes", C.c_double)]
+
+
 class CKernelStats(C.Structure):
     _fields_ = [
         ("em_sparse_ms", C.c_double), ("em_sparse_launches", C.c_uint64), ("em_sparse_alg_bytes", C.c_double),
@@ -66,10 +74,20 @@ class CKernelStats(C.Structure):
         ("h2d_ms", C.c_double), ("h2d_bytes", C.c_double),
         ("em_iterations_total", C.c_uint64),
         ("search_pairs_possible", C.c_double), ("search_pairs_table", C.c_double), ("search_pairs_kept", C.c_double),
+        ("em_kernel", CEmKernelStats * EM_KERNELS),
+        ("collapse_ms", C.c_double), ("busy_ms", C.c_double),
     ]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "em_kernel"}
+        d["em_kernel"] = {em_kernel_name(i): {n: getattr(self.em_kernel[i], n) for n, _ in CEmKernelStats._fields_} for i in range(EM_KERNELS)}
+        return d
+
+
+def em_kernel_name(index: int) -> str:
+    f = lib().rpvg_hip_em_kernel_name
+    f.restype = C.c_char_p
+    return f(index).decode()
 
 
 _lib = None

@@ -1,6 +1,7 @@
 #include "hip_engine.hpp"
 #include "trace.hpp"
 
+#include <algorithm>
 #include <cassert>
 #include <cstdlib>
 #include <mutex>
@@ -94,7 +95,73 @@ void HipEngine::stats(rpvg_hip_kernel_stats * stats_out) const {
         stats_out->search_pairs_possible += lane_stats.search_pairs_possible;
         stats_out->search_pairs_table += lane_stats.search_pairs_table;
         stats_out->search_pairs_kept += lane_stats.search_pairs_kept;
+        stats_out->collapse_ms += lane_stats.collapse_ms;
+
+        for (int i = 0; i < RPVG_HIP_EM_KERNELS; ++i) {
+
+            stats_out->em_kernel[i].ms += lane_stats.em_kernel[i].ms;
+            stats_out->em_kernel[i].launches += lane_stats.em_kernel[i].launches;
+            stats_out->em_kernel[i].problems += lane_stats.em_kernel[i].problems;
+            stats_out->em_kernel[i].iterations += lane_stats.em_kernel[i].iterations;
+            stats_out->em_kernel[i].max_iterations += lane_stats.em_kernel[i].max_iterations;
+            stats_out->em_kernel[i].alg_bytes += lane_stats.em_kernel[i].alg_bytes;
+        }
     }
+
+    // busy time: the union of the timed spans of all lanes (their contexts share the GPU's clock)
+    std::vector<std::pair<double, double> > spans;
+
+    auto collect = [&](rpvg_hip_ctx * ctx) {
+
+        uint64_t count = 0;
+        check(rpvg_hip_stats_intervals(ctx, 0, nullptr, nullptr, nullptr, &count), "rpvg_hip_stats_intervals");
+
+        std::vector<double> start(count), stop(count);
+        check(rpvg_hip_stats_intervals(ctx, count, start.data(), stop.data(), nullptr, &count), "rpvg_hip_stats_intervals");
+
+        for (size_t i = 0; i < std::min<size_t>(count, start.size()); ++i) {
+
+            spans.emplace_back(start[i], stop[i]);
+        }
+    };
+
+    collect(context);
+
+    for (auto & lane_context: lane_contexts) {
+
+        collect(lane_context);
+    }
+
+    std::sort(spans.begin(), spans.end());
+
+    double busy = 0;
+    double begin = 0;
+    double end = -1;
+
+    for (auto & span: spans) {
+
+        if (end < begin || span.first > end) {
+
+            if (end >= begin) {
+
+                busy += end - begin;
+            }
+
+            begin = span.first;
+            end = span.second;
+
+        } else {
+
+            end = std::max(end, span.second);
+        }
+    }
+
+    if (end >= begin) {
+
+        busy += end - begin;
+    }
+
+    stats_out->busy_ms = busy;
 }
 
 void HipEngine::resetStats() const {

@@ -239,6 +239,12 @@ int rpvg_amd_engine_stats_reset(void * engine) {
     }
 }
 
+// The OpenMP team of one host lane of this process (trace.hpp, hostThreads()): what bench.py prints as host_threads_per_lane.
+int rpvg_amd_host_threads() {
+
+    return rpvg_amd::hostThreads();
+}
+
 // Uploads the batch to the GPU.  keep_rows != 0 also keeps ReadPathProbabilities
 // objects of every cluster for the per-cluster estimate() mode.
 void * rpvg_amd_batch_prepare(void * engine, const rpvg_cluster_batch * batch, int keep_rows) {

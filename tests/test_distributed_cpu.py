@@ -173,7 +173,9 @@ def test_bench_launches_its_own_ranks():
     two = _run_bench(["--gpus", "2"])
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["scaling"] == "weak" and two["config"]["clusters_per_gpu"] == one["config"]["clusters_per_gpu"]
-    assert two["mass_conserved"] and two["value"] > 0
+    # a stand-in engine claims no metric: the number the protocol computed is kept under another name
+    assert two["mass_conserved"] and two["value"] is None and two["protocol_value"] > 0
+    assert two["engine_module"] == "tests.oracle_engine_stub" and two["metric"].startswith("none")
     # weak scaling: every rank owns a batch of its own, the gathered mass is that of both
     assert two["gathered_abundance_mass"] > 1.5 * 0.9 * 10000000 * 0.01
     assert two["tpm_denominator"] > 0
