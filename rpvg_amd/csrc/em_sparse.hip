@@ -381,15 +381,18 @@ hipError_t launchEm(const EmLaunchArgs & args, size_t lds, hipStream_t stream) {
 
 
 // ---- register-resident EM for small problems ---------------------------------------------------------------
-// A problem with at most 16 paths and 64 * RPL rows is held DENSE in the registers of one wavefront: lane l owns rows
-// l, l + 64, ... (RPL of them) as 16 doubles each.  An iteration then needs no dependent memory access for the
-// matrix: the E-step is RPL x 16 fused multiply-adds against the abundance vector, the M-step RPL x 16 more into 16
-// per-lane partial column sums, which cross the wave once through LDS (four lanes per column + two butterfly steps).
-// These problems are the ones that run for thousands of iterations (the batch's EM time is the iteration count of
-// its slowest problem times the latency of ONE iteration): ~0.35 us per iteration here against ~1.2 us for the
-// LDS-resident sparse kernel.  Zero entries add exact zeros, so the E-step sums equal the sparse kernel's bit for
-// bit; the column sums are added in a fixed order (the sparse kernels use LDS atomics).
-constexpr uint32_t kRegPathsMax = 32;  // the widest register-resident variant
+// A problem with at most COLS columns — its paths AND the noise component — and 64 * RPL rows is held DENSE in the
+// registers of one wavefront: lane l owns rows l, l + 64, ... (RPL of them) as COLS doubles each, the noise probability
+// of the row in the column behind the last path.  An iteration then needs no dependent memory access for the matrix:
+// the E-step is RPL x COLS fused multiply-adds against the abundance vector, the M-step RPL x COLS more into COLS
+// per-lane partial column sums, which cross the wave once through LDS (64 / COLS lanes per column + one or two DPP
+// steps inside the quad).  These problems are the ones that run for thousands of iterations (the batch's EM time is the
+// iteration count of its slowest problem times the latency of ONE iteration — a 14-path, 17-row problem with 2 494 of
+// them in the configs[2] bench).  Zero entries add exact zeros; the column sums are added in a fixed order (the sparse
+// kernels use LDS atomics).  Round 3: the noise component became a column like the others (it was a wave-wide DPP sum
+// of its own next to the transposition: 27 instructions of ~230 per iteration), the update runs in every lane of a
+// column without a branch, and the transposition is skewed (below).
+constexpr uint32_t kRegColsMax = 32;  // the widest register-resident variant
 
 // value of the lane whose index differs in bit 0 (D = 1) or bit 1 (D = 2) — inside a quad, through DPP
 template <int D>
@@ -400,14 +403,75 @@ __device__ __forceinline__ double quadSwapF64(const double v) {
     return __hiloint2double(hi, lo);
 }
 
-template <int RPL, int PATHS>
+// x of the lanes 32 .. 63 <-> y of the lanes 0 .. 31 (v_permlane32_swap_b32, new with gfx950): afterwards x + y is, in a lane
+// of the lower half, the sum of the two x of the lanes l and l + 32, in a lane of the upper half that of the two y
+__device__ __forceinline__ void swapHalvesF64(double & x, double & y) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(__double2loint(x)), static_cast<unsigned>(__double2loint(y)), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(__double2hiint(x)), static_cast<unsigned>(__double2hiint(y)), false, false);
+    x = __hiloint2double(static_cast<int>(hi[0]), static_cast<int>(lo[0]));
+    y = __hiloint2double(static_cast<int>(hi[1]), static_cast<int>(lo[1]));
+}
+
+// the same between neighbouring rows of 16 lanes: x of the odd rows <-> y of the even rows (v_permlane16_swap_b32)
+__device__ __forceinline__ void swapRowsF64(double & x, double & y) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(__double2loint(x)), static_cast<unsigned>(__double2loint(y)), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(__double2hiint(x)), static_cast<unsigned>(__double2hiint(y)), false, false);
+    x = __hiloint2double(static_cast<int>(hi[0]), static_cast<int>(lo[0]));
+    y = __hiloint2double(static_cast<int>(hi[1]), static_cast<int>(lo[1]));
+}
+
+// One halving step inside a row of 16 lanes: the DPP control CTRL pairs every lane with one whose `upper` differs; a
+// lane keeps x (upper: y) and adds the partner's copy of it.
+template <int CTRL>
+__device__ __forceinline__ double halveF64(const double x, const double y, const bool upper) {
+    const double send = upper ? x : y, keep = upper ? y : x;
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(send), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(send), CTRL, 0xF, 0xF, true);
+    return keep + __hiloint2double(hi, lo);
+}
+
+// Column sums over the wave of COLS per-lane partials v[0 .. COLS), without LDS: every step halves the number of values
+// a lane carries and doubles the lanes each value has been added over — lanes l and l + 32 (one swap per 32-bit
+// register half and one addition for TWO columns), neighbouring rows of 16 lanes, then inside the row through DPP.
+// Afterwards lane l holds, in the return value, the sum of column l / (64 / COLS) over all 64 lanes; the order of the
+// additions is fixed.  (Round 2 and the first version of round 3 transposed the partials through LDS: 16 writes and 16
+// reads per lane, 625 of an iteration's 1 180 cycles in LDS issue and waits — PMC, tools/r03_em_pmc.sh.)
+template <int COLS>
+__device__ __forceinline__ double columnSumsOverWave(double (&v)[COLS], const uint32_t lane) {
+#pragma unroll
+    for (int c = 0; c < COLS / 2; ++c) {
+        swapHalvesF64(v[c], v[c + COLS / 2]);
+        v[c] += v[c + COLS / 2];
+    }
+#pragma unroll
+    for (int c = 0; c < COLS / 4; ++c) {
+        swapRowsF64(v[c], v[c + COLS / 4]);
+        v[c] += v[c + COLS / 4];
+    }
+    const bool bit3 = (lane & 8) != 0, bit2 = (lane & 4) != 0;
+#pragma unroll
+    for (int c = 0; c < COLS / 8; ++c) v[c] = halveF64<0x128>(v[c], v[c + COLS / 8], bit3);   // row_ror:8
+#pragma unroll
+    for (int c = 0; c < COLS / 16; ++c) v[c] = halveF64<0x141>(v[c], v[c + COLS / 16], bit2);  // row_half_mirror
+    double t;
+    if (COLS == 32) {
+        t = halveF64<0x4E>(v[0], v[1], (lane & 2) != 0);  // quad_perm [2,3,0,1]
+    } else {
+        t = v[0];
+        t += quadSwapF64<2>(t);
+    }
+    t += quadSwapF64<1>(t);
+    return t;
+}
+
+template <int RPL, int COLS>
 __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) {
-    constexpr uint32_t kRegPaths = PATHS;
-    constexpr int kLanesPerColumn = 64 / PATHS;  // 4 (16 paths) or 2 (32 paths)
+    constexpr uint32_t kCols = COLS;
+    constexpr int kLanesPerColumn = 64 / COLS;  // 4 (16 columns) or 2 (32 columns)
     extern __shared__ __attribute__((aligned(16))) double reg_lds[];
     if (blockIdx.x >= args.count) return;
     const uint32_t p = args.order[blockIdx.x];
-    const uint32_t np = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]);  // <= kRegPaths
+    const uint32_t np = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]);  // < kCols; column np = noise
     const uint32_t lane = threadIdx.x;
     const uint32_t n_rows = args.kept_rows[p];
     const uint64_t rb = args.row_base[p], eb = args.ent_base[p];
@@ -418,60 +482,52 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
     const double * val = args.pent_val + eb;
 
     // stage the dense tile through LDS (the scatter needs dynamic indexing, registers must not)
-    constexpr uint32_t kTile = 64 * RPL * kRegPaths;
+    constexpr uint32_t kTile = 64 * RPL * kCols;
     double * tile = reg_lds;
     for (uint32_t idx = lane; idx < kTile; idx += 64) tile[idx] = 0.0;
     __syncthreads();
     for (uint32_t r = lane; r < n_rows; r += 64) {
-        for (uint32_t e = off[r]; e < off[r + 1]; ++e) tile[r * kRegPaths + col[e]] += val[e];
+        for (uint32_t e = off[r]; e < off[r + 1]; ++e) tile[r * kCols + col[e]] += val[e];
+        tile[r * kCols + np] = nzv[r];
     }
     __syncthreads();
-    double P[RPL][kRegPaths], nz[RPL], c[RPL];
+    double P[RPL][kCols], c[RPL];
     bool valid[RPL];
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
         const uint32_t r = q * 64 + lane;
         valid[q] = r < n_rows;
 #pragma unroll
-        for (int j = 0; j < static_cast<int>(kRegPaths); ++j) P[q][j] = tile[r * kRegPaths + j];
-        nz[q] = valid[q] ? nzv[r] : 0.0;
+        for (int j = 0; j < static_cast<int>(kCols); ++j) P[q][j] = tile[r * kCols + j];
         c[q] = valid[q] ? cnt[r] : 0.0;
     }
-    __syncthreads();
-    double * part = reg_lds;  // [kRegPaths][64] partial column sums of the lanes
-
     const double T = args.total_mass[p];
-    const double Z = args.zero_mass[p];
     const double eps = args.max_rel_em_conv;
     // src/path_abundance_estimator.cpp:54 — 1 / float(C), widened
     const double a0 = static_cast<double>(1.0f / static_cast<float>(np + 1));
-    // the first of the kLanesPerColumn lanes that add column j's partials owns a_j; lane 1 owns the noise component
-    const uint32_t my_col = (lane == 1) ? kRegPaths : (lane / kLanesPerColumn);
-    const bool owns_path = (lane % kLanesPerColumn) == 0 && my_col < np;
-    const bool owns_noise = lane == 1;
-    double a_mine = (owns_path || owns_noise) ? a0 : 0.0;
-    __syncthreads();
+    // Column j belongs to lanes kLanesPerColumn * j ...: each holds a_j and applies the update (the same arithmetic on the
+    // same values: no lane is special, nothing branches).  Columns behind the noise column are padding: their
+    // abundance starts, and therefore stays, at zero.
+    const uint32_t my_col = lane / kLanesPerColumn;
+    double a_mine = (my_col <= np) ? a0 : 0.0;
+    // Z: the read mass of the rows without any selected path, which the noise component takes whole (header of this file)
+    const double z_mine = (my_col == np) ? args.zero_mass[p] : 0.0;
 
     const double inv_T = 1.0 / T;
-    // column j = lane / kLanesPerColumn: its lanes add an equal share of the column's 64 partials each
-    constexpr int kShare = 64 / kLanesPerColumn;
-    const double * mine = part + (lane / kLanesPerColumn) * 64 + (lane % kLanesPerColumn) * kShare;
 
     uint32_t iters = 0, conv = 0;
     for (uint32_t it = 0; it < args.max_em_its; ++it) {
-        // the abundance vector lives in its owner lanes (a_mine): read straight from them (scalar broadcast) instead of a
-        // round trip through LDS — two of the iteration's four LDS latencies
-        double av[kRegPaths];
+        // the abundance vector lives in its owner lanes (a_mine): read straight from them (scalar broadcast)
+        double av[kCols];
 #pragma unroll
-        for (int j = 0; j < static_cast<int>(kRegPaths); ++j) av[j] = readLaneF64(a_mine, j * kLanesPerColumn);
-        const double a_noise = readLaneF64(a_mine, 1);
+        for (int j = 0; j < static_cast<int>(kCols); ++j) av[j] = readLaneF64(a_mine, j * kLanesPerColumn);
         double w[RPL];
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
             // four interleaved partial sums: the latency of one iteration is what this kernel is about
-            double s0 = nz[q] * a_noise, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-            for (int j = 0; j < static_cast<int>(kRegPaths); j += 4) {
+            for (int j = 0; j < static_cast<int>(kCols); j += 4) {
                 s0 = fma(P[q][j], av[j], s0);
                 s1 = fma(P[q][j + 1], av[j + 1], s1);
                 s2 = fma(P[q][j + 2], av[j + 2], s2);
@@ -485,39 +541,21 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
             const double quot = c[q] * y;
             w[q] = valid[q] ? fma(fma(-s, quot, c[q]), y, quot) : 0.0;
         }
-        double pn = 0.0;
+        double pj[kCols];
 #pragma unroll
-        for (int q = 0; q < RPL; ++q) pn = fma(w[q], nz[q], pn);
+        for (int j = 0; j < static_cast<int>(kCols); ++j) {
+            pj[j] = w[0] * P[0][j];
 #pragma unroll
-        for (int j = 0; j < static_cast<int>(kRegPaths); ++j) {
-            double pj = 0.0;
-#pragma unroll
-            for (int q = 0; q < RPL; ++q) pj = fma(w[q], P[q][j], pj);
-            part[j * 64 + lane] = pj;
+            for (int q = 1; q < RPL; ++q) pj[j] = fma(w[q], P[q][j], pj[j]);
         }
-        const double tn = waveSumF64(pn);
-        __syncthreads();
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-#pragma unroll
-        for (int i = 0; i < kShare; i += 4) {
-            t0 += mine[i];
-            t1 += mine[i + 1];
-            t2 += mine[i + 2];
-            t3 += mine[i + 3];
-        }
-        double tj = (t0 + t1) + (t2 + t3);
-        tj += quadSwapF64<1>(tj);  // neighbouring lanes: DPP, no LDS round trip
-        if (kLanesPerColumn == 4) tj += quadSwapF64<2>(tj);
+        const double tj = columnSumsOverWave<COLS>(pj, lane);
 
-        int viol = 0;
-        if (owns_path || owns_noise) {
-            const double an = owns_noise ? (a_mine * tn + Z) * inv_T : (a_mine * tj) * inv_T;
-            // |an - aj| / an > eps  (src/path_abundance_estimator.cpp:73-75), without the division
-            if (an >= kMinEmAbundance && fabs(an - a_mine) > eps * an) viol = 1;
-            a_mine = an;
-        }
+        // a'_j = a_j t_j / T;  a'_noise = (a_noise t_noise + Z) / T  (z_mine is zero off the noise column)
+        const double an = fma(a_mine, tj, z_mine) * inv_T;
+        // |an - aj| / an > eps  (src/path_abundance_estimator.cpp:73-75), without the division
+        const bool viol = (an >= kMinEmAbundance) & (fabs(an - a_mine) > eps * an);
+        a_mine = an;
         const int any_viol = __any(viol);
-        __syncthreads();  // part may be overwritten
         ++iters;
         if (!any_viol) {
             if (++conv == kMinEmConvIts) break;
@@ -528,7 +566,8 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
 
     // src/path_abundance_estimator.cpp:100-113
     double low = 0.0;
-    if (owns_path) {
+    const bool first_of_column = (lane % kLanesPerColumn) == 0;
+    if (first_of_column && my_col < np) {
         double * out = args.abundances + args.col_off[p];
         if (a_mine < kMinEmAbundance) {
             low = a_mine * T;
@@ -538,18 +577,17 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
         }
     }
     low = waveSumF64(low);
-    if (owns_noise) {
+    if (first_of_column && my_col == np) {
         args.noise_count[p] = low + a_mine * T;
         args.iterations[p] = iters;
     }
 }
 
-template <int RPL, int PATHS>
+template <int RPL, int COLS>
 hipError_t launchEmRegister(const EmLaunchArgs & args, hipStream_t stream) {
     if (args.count == 0) return hipSuccess;
-    const size_t tile = 64 * RPL * PATHS, part = 64 * PATHS;
-    const size_t lds = (std::max(tile, part) + PATHS + 2) * sizeof(double);
-    emRegisterKernel<RPL, PATHS><<<dim3(args.count), dim3(64), lds, stream>>>(args);
+    const size_t lds = (64 * RPL * COLS + 2) * sizeof(double);  // the staging tile
+    emRegisterKernel<RPL, COLS><<<dim3(args.count), dim3(64), lds, stream>>>(args);
     return hipGetLastError();
 }
 
@@ -968,13 +1006,17 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     //   1  LDS-resident, four waves    fit 40 KB
     //   2  streamed from L2, 4 waves
     //   3  streamed from L2, 16 waves  (a few giant problems)
-    //   4-6 register-resident dense, one wave: at most 16 paths and 64 / 128 / 256 rows (emRegisterKernel)
-    //   8-9 register-resident dense, one wave: 17 to 32 paths and 64 / 128 rows
+    //   4-6 register-resident dense, one wave: at most 16 columns (paths + noise) and 64 / 128 / 256 rows (emRegisterKernel)
+    //   8-9 register-resident dense, one wave: 17 to 32 columns and 64 / 128 rows
     //   7  LDS-resident, sixteen waves  CSR + vectors fit 152 KB (one workgroup per CU: the whole LDS)
     //   10 too many columns for LDS-resident vectors (> ~9 700): vectors in global memory, 16 waves
     constexpr int kBins = 11;
     static_assert(kBins == RPVG_HIP_EM_KERNELS, "one statistics slot per EM kernel variant");
     constexpr size_t kLdsLimit = 156 * 1024;
+    // A streamed problem is one workgroup: above this many rows + entries it gets 1 024 threads instead of 256 (round 2:
+    // 262 144 — a 200 000-entry problem on 256 threads took 47 us per EM iteration and, at 23 iterations, as long as the
+    // thousands of iterations of the slowest register-resident problem).
+    static const uint64_t kStreamedSmallWork = std::getenv("RPVG_HIP_EM_STREAM_SMALL") ? std::strtoull(std::getenv("RPVG_HIP_EM_STREAM_SMALL"), nullptr, 10) : 24576;
     std::vector<uint64_t> wide_off(P, 0);
     uint64_t wide_total = 0;
     std::vector<uint32_t> bins[kBins];
@@ -985,9 +1027,9 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
         const uint64_t work = static_cast<uint64_t>(kept_ent[p]) + kept_rows[p];
         int b;
         size_t lds = 0;
-        if (use_register_kernel && C - 1 <= 16 && kept_rows[p] <= 256) {
+        if (use_register_kernel && C <= 16 && kept_rows[p] <= 256) {
             b = kept_rows[p] <= 64 ? 4 : kept_rows[p] <= 128 ? 5 : 6;
-        } else if (use_register_kernel && C - 1 <= kRegPathsMax && kept_rows[p] <= 128) {
+        } else if (use_register_kernel && C <= kRegColsMax && kept_rows[p] <= 128) {
             b = kept_rows[p] <= 64 ? 8 : 9;
         } else if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 64, true)) <= 8 * 1024) {
             b = 0;
@@ -1000,7 +1042,7 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
             lds = sizeof(double) * (1024 / 64 + 2);
             wide_off[p] = wide_total;
             wide_total += 2 * static_cast<uint64_t>(C);
-        } else if (work <= 262144) {
+        } else if (work <= kStreamedSmallWork) {
             b = 2;
             lds = emLdsBytes(C, 0, 0, 256, false);
         } else {
