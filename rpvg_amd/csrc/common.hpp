@@ -669,6 +669,45 @@ struct rpvg_hip_groups {
 };
 
 namespace rpvg_hip_detail {
+// ---- EM solves on problem lists in device memory (em_sparse.hip) -------------------------------------
+// The problems may come from the host (rpvg_hip_em_solve) or be written by kernels (subset_em.hip: the path subsets the
+// diploid search retains): everything behind the list — compaction of the problems' rows, size bins, work queues, the EM
+// kernels — is decided on the device.
+struct EmProblemList {
+    uint32_t P_bound = 0;                     // number of problems, or an upper bound of it when d_num_problems is set
+    const uint32_t * d_num_problems = nullptr;
+    const uint32_t * d_cluster = nullptr;     // [P] cluster of the batch
+    const uint64_t * d_col_off = nullptr;     // [P+1]
+    const uint32_t * d_col_path = nullptr;    // strictly ascending cluster-local paths of each problem
+    const uint64_t * d_row_base = nullptr;    // [P] first compacted row / entry of the problem: a problem keeps at most the
+    const uint64_t * d_ent_base = nullptr;    //     rows and entries of its cluster, the storage is laid out by that bound
+    uint64_t rows_capacity = 0, entries_capacity = 0;
+    uint32_t max_cols = 0;                    // columns (paths + noise) of the widest problem, or a bound
+    uint32_t max_cluster_paths = 0;           // paths of the widest cluster a problem sits on, or a bound
+    unsigned long long wide_capacity = 0;     // doubles for the vectors of the problems too wide for LDS
+};
+
+struct EmOutputs {  // device arrays, [P] unless noted
+    double * d_abundances;      // [col_off[P]] laid out like col_path
+    double * d_noise_count;
+    uint32_t * d_iterations;
+    uint32_t * d_kept_rows;     // rows / entries of the problem that touch a selected path
+    uint32_t * d_kept_entries;
+    double * d_total;           // read count of the problem's cluster
+};
+
+struct EmSolveWork {  // scratch of one solve: lives until its kernels are done
+    DeviceBuffer<uint32_t> d_prow_off, d_pent_col, d_bucket, d_order;
+    DeviceBuffer<double> d_prow_count, d_prow_noise, d_pent_val, d_zero, d_wide_vectors;
+    DeviceBuffer<unsigned long long> d_wide_off;
+    DeviceBuffer<unsigned char> d_queues;
+};
+
+int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProblemList & list, uint32_t max_em_its,
+                 double max_rel_em_conv, const EmOutputs & out, EmSolveWork & work, bool fill_only);
+void accountEmSolve(rpvg_hip_ctx * ctx, uint32_t P, const uint64_t * col_off, const uint32_t * kept_rows, const uint32_t * kept_entries,
+                    const uint32_t * iterations);
+
 // queues the replay of readCollapseProbabilityMatrix on the matrices of `groups` behind their build (row_collapse.hip)
 hipError_t queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups, uint64_t total_rows, double precision, hipStream_t stream);
 }

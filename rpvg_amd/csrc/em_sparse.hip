@@ -110,55 +110,143 @@ __device__ __forceinline__ void blockExclusiveScanPair(uint32_t & a, uint32_t & 
     total_b = tb;
 }
 
-// ---- problem descriptors on the device --------------------------------------
+// ---- size bins of the EM kernels -----------------------------------------------
+// One kernel variant per bin (rpvg_hip_em_kernel_name); the bin of a problem follows from its columns (paths + noise),
+// kept rows and kept entries alone, so the device decides it (fillProblemKernel) and the host repeats the decision for
+// the statistics:
+//   0  LDS-resident, one wave      CSR + vectors fit 8 KB
+//   1  LDS-resident, four waves    fit 40 KB
+//   2  streamed from L2, 4 waves
+//   3  streamed from L2, 16 waves  (a few giant problems)
+//   4-6 register-resident dense, one wave: at most 16 columns and 64 / 128 / 256 rows (emRegisterKernel)
+//   7  LDS-resident, sixteen waves  CSR + vectors fit 152 KB (one workgroup per CU: the whole LDS)
+//   8-9 register-resident dense, one wave: 17 to 32 columns and 64 / 128 rows
+//   10 too many columns for LDS-resident vectors (> ~9 700): vectors in global memory, 16 waves
+constexpr int kEmBins = RPVG_HIP_EM_KERNELS;
+constexpr int kEmWorkBuckets = 32;   // inside a bin the problems are ordered by floor(log2(rows + entries)), large first
+constexpr size_t kEmLdsLimit = 156 * 1024;
+constexpr uint32_t kRegColsMax = 32;  // the widest register-resident variant
 
-struct ProblemTable {
-    const uint32_t * cluster;      // [P]
-    const uint64_t * col_off;      // [P+1]
-    const uint64_t * colmap_off;   // [P+1] offset of the problem's path->column map
-    const uint64_t * row_base;     // [P]   first compacted row of the problem
-    const uint64_t * ent_base;     // [P]   first compacted entry of the problem
-    const uint32_t * kept_rows;    // [P]
-};
-
-// ---- 1. path -> column map ---------------------------------------------------
-
-__global__ void scatterColumnMapKernel(const uint32_t num_problems, const uint64_t * __restrict__ col_off,
-                                       const uint32_t * __restrict__ col_path, const uint64_t * __restrict__ colmap_off,
-                                       int32_t * __restrict__ colmap) {
-    const uint32_t p = blockIdx.x;
-    if (p >= num_problems) return;
-    const uint64_t c0 = col_off[p], c1 = col_off[p + 1];
-    int32_t * map = colmap + colmap_off[p];
-    for (uint64_t c = c0 + threadIdx.x; c < c1; c += blockDim.x) map[col_path[c]] = static_cast<int32_t>(c - c0);
+// LDS bytes of a problem: abundance + accumulator vectors and scratch, plus its CSR when resident
+__host__ __device__ inline size_t emLdsBytes(uint32_t cols, uint32_t rows, uint32_t entries, int block, bool resident) {
+    size_t bytes = sizeof(double) * (2 * static_cast<size_t>(cols) + block / 64 + 2);
+    if (resident) bytes += static_cast<size_t>(rows) * 16 + static_cast<size_t>(entries) * 8 + (static_cast<size_t>(rows) + 1 + entries) * 4 + 8;
+    return (bytes + 15) & ~static_cast<size_t>(15);
 }
 
-// ---- 2. count ----------------------------------------------------------------
+struct EmBinRule {
+    uint32_t use_register_kernel;   // RPVG_HIP_NO_REGISTER_EM=1 clears it
+    uint64_t streamed_small_work;   // a streamed problem above this many rows + entries gets 1 024 threads instead of 256
+};
+
+__host__ __device__ inline int emBinOf(const EmBinRule rule, const uint32_t C, const uint32_t rows, const uint32_t entries) {
+    const uint64_t work = static_cast<uint64_t>(entries) + rows;
+    if (rule.use_register_kernel && C <= 16 && rows <= 256) return rows <= 64 ? 4 : rows <= 128 ? 5 : 6;
+    if (rule.use_register_kernel && C <= kRegColsMax && rows <= 128) return rows <= 64 ? 8 : 9;
+    if (emLdsBytes(C, rows, entries, 64, true) <= 8 * 1024) return 0;
+    if (emLdsBytes(C, rows, entries, 256, true) <= 40 * 1024) return 1;
+    if (emLdsBytes(C, rows, entries, 1024, true) <= 152 * 1024) return 7;
+    if (emLdsBytes(C, 0, 0, 1024, false) > kEmLdsLimit) return 10;
+    return work <= rule.streamed_small_work ? 2 : 3;
+}
+
+__host__ __device__ inline uint32_t emWorkBucket(const uint32_t rows, const uint32_t entries) {
+    // floor(log2(work + 1)), inverted: bucket 0 holds the largest problems
+    uint64_t work = static_cast<uint64_t>(entries) + rows + 1;
+    uint32_t lg = 0;
+    while (work > 1 && lg < static_cast<uint32_t>(kEmWorkBuckets - 1)) {
+        work >>= 1;
+        ++lg;
+    }
+    return static_cast<uint32_t>(kEmWorkBuckets - 1) - lg;
+}
+
+// Work queues of one rpvg_hip_em_solve on the device (zero-initialised): the fill kernel counts the problems of every
+// (bin, bucket); emOrderKernel turns the counts into offsets and lists the problems; the EM kernels — persistent
+// workgroups — draw problems of their bin from bin_cursor until bin_count is reached.  The host never needs the counts
+// to launch anything.
+struct EmQueues {
+    uint32_t histogram[kEmBins * kEmWorkBuckets];
+    uint32_t bucket_cursor[kEmBins * kEmWorkBuckets];
+    uint32_t bin_start[kEmBins];
+    uint32_t bin_count[kEmBins];
+    uint32_t bin_cursor[kEmBins];
+    uint32_t pad;
+    unsigned long long wide_cursor;   // doubles handed out of EmLaunchArgs::wide_vectors
+    unsigned long long wide_overflow; // set when a wide problem did not get its vectors (capacity exceeded)
+};
+
+// ---- 1 + 2. column map, count and fill ------------------------------------------
+// One workgroup per problem: the path -> column map of the problem is built in LDS from its column list (clusters of
+// up to kLdsMapPaths paths; wider ones look their paths up in the sorted list by bisection), then the rows of the
+// problem's cluster are walked in chunks of BLOCK: ordered compaction of the rows that touch a selected path by a
+// block-wide exclusive scan, P / rowsum * (1 - noise) with the reference's two roundings
+// (addNoiseAndNormalizeProbabilityMatrix, src/path_estimator.cpp:156-166).
+constexpr uint32_t kLdsMapPaths = 16384;
+
+struct FillArgs {
+    uint32_t num_problems;                 // upper bound when num_problems_dev is set
+    const uint32_t * num_problems_dev;     // null: num_problems is exact
+    const uint32_t * prob_cluster;         // [P]
+    const uint64_t * col_off;              // [P+1]
+    const uint32_t * col_path;
+    const uint64_t * cluster_row_off;
+    const uint64_t * cluster_path_off;
+    const uint64_t * row_ent_off;
+    const uint32_t * ent_path;
+    const double * ent_prob;
+    const double * row_count;
+    const double * row_noise;
+    const uint64_t * row_base;             // [P] first compacted row of the problem
+    const uint64_t * ent_base;             // [P] first compacted entry of the problem
+    uint32_t * prow_off;                   // [rows_total + P] per problem kept_rows+1 offsets relative to its entry base; null: count only
+    double * prow_count;
+    double * prow_noise;
+    uint32_t * pent_col;
+    double * pent_val;
+    uint32_t * kept_rows;                  // [P] the counts of the problem
+    uint32_t * kept_entries;
+    double * zero_mass;
+    double * total_mass;
+    uint32_t * prob_bucket;                // [P] bin * kEmWorkBuckets + bucket (with the storage only)
+    EmQueues * queues;
+    EmBinRule rule;
+    uint32_t lds_map_paths;                // capacity of the LDS map of this launch (0: bisection for every problem)
+};
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void fillProblemKernel(
-    const uint32_t num_problems, const uint32_t * __restrict__ prob_cluster, const uint64_t * __restrict__ colmap_off,
-    const int32_t * __restrict__ colmap, const uint64_t * __restrict__ cluster_row_off,
-    const uint64_t * __restrict__ row_ent_off, const uint32_t * __restrict__ ent_path,
-    const double * __restrict__ ent_prob, const double * __restrict__ row_count, const double * __restrict__ row_noise,
-    const uint64_t * __restrict__ row_base, const uint64_t * __restrict__ ent_base,
-    uint32_t * __restrict__ prow_off,   // [rows_total + P] per problem kept_rows+1 offsets relative to the problem's entry base
-    double * __restrict__ prow_count, double * __restrict__ prow_noise, uint32_t * __restrict__ pent_col,
-    double * __restrict__ pent_val,
-    // the counts of the problem
-    uint32_t * __restrict__ kept_rows, uint32_t * __restrict__ kept_entries, double * __restrict__ zero_mass,
-    double * __restrict__ total_mass) {
+__global__ __launch_bounds__(BLOCK) void fillProblemKernel(const FillArgs args) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds_map[];
     __shared__ uint32_t scratch[2 * (BLOCK / 64)];
     __shared__ double dscratch[BLOCK / 64];
     const uint32_t p = blockIdx.x;
-    if (p >= num_problems) return;
-    const uint32_t k = prob_cluster[p];
-    const int32_t * map = colmap + colmap_off[p];
-    const uint64_t r0 = cluster_row_off[k], r1 = cluster_row_off[k + 1];
-    const bool count_only = prow_off == nullptr;  // first of two passes when the storage bound does not fit (buildProblemSet)
-    const uint64_t rb = count_only ? 0 : row_base[p], eb = count_only ? 0 : ent_base[p];
+    if (p >= (args.num_problems_dev ? *args.num_problems_dev : args.num_problems)) return;
+    const uint32_t k = args.prob_cluster[p];
+    const uint32_t n_paths = static_cast<uint32_t>(args.cluster_path_off[k + 1] - args.cluster_path_off[k]);
+    const uint32_t * cols = args.col_path + args.col_off[p];
+    const uint32_t n_cols = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]);
+    const bool use_map = n_paths <= args.lds_map_paths;
+    if (use_map) {
+        for (uint32_t i = threadIdx.x; i < n_paths; i += BLOCK) lds_map[i] = -1;
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < n_cols; c += BLOCK) lds_map[cols[c]] = static_cast<int32_t>(c);
+        __syncthreads();
+    }
+    auto column_of = [&](const uint32_t path) -> int32_t {
+        if (use_map) return lds_map[path];
+        uint32_t lo = 0, hi = n_cols;  // first column whose path is not below `path`
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cols[mid] < path) lo = mid + 1;
+            else hi = mid;
+        }
+        return (lo < n_cols && cols[lo] == path) ? static_cast<int32_t>(lo) : -1;
+    };
+    const uint64_t r0 = args.cluster_row_off[k], r1 = args.cluster_row_off[k + 1];
+    const bool count_only = args.prow_off == nullptr;  // first of two passes when the storage bound does not fit (buildProblemSet)
+    const uint64_t rb = count_only ? 0 : args.row_base[p], eb = count_only ? 0 : args.ent_base[p];
     // the offsets array has one extra slot per problem
-    uint32_t * off = prow_off + rb + p;
+    uint32_t * off = args.prow_off + rb + p;
     uint32_t run_rows = 0, run_ent = 0;
     double z = 0, t = 0;  // read counts of the rows without a selected path / of all rows
     for (uint64_t rc = r0; rc < r1; rc += BLOCK) {
@@ -167,15 +255,15 @@ __global__ __launch_bounds__(BLOCK) void fillProblemKernel(
         double rowsum = 0;
         uint64_t e0 = 0, e1 = 0;
         if (r < r1) {
-            e0 = row_ent_off[r];
-            e1 = row_ent_off[r + 1];
+            e0 = args.row_ent_off[r];
+            e1 = args.row_ent_off[r + 1];
             for (uint64_t e = e0; e < e1; ++e) {
-                if (map[ent_path[e]] >= 0) {
+                if (column_of(args.ent_path[e]) >= 0) {
                     ++n;
-                    rowsum += ent_prob[e];
+                    rowsum += args.ent_prob[e];
                 }
             }
-            const double c = row_count[r];
+            const double c = args.row_count[r];
             t += c;
             if (!n) z += c;
         }
@@ -185,16 +273,16 @@ __global__ __launch_bounds__(BLOCK) void fillProblemKernel(
             const uint32_t my_row = run_rows + slot;
             uint32_t my_ent = run_ent + epos;
             off[my_row] = my_ent;
-            const double nz = row_noise[r];
-            prow_count[rb + my_row] = row_count[r];
-            prow_noise[rb + my_row] = nz;
+            const double nz = args.row_noise[r];
+            args.prow_count[rb + my_row] = args.row_count[r];
+            args.prow_noise[rb + my_row] = nz;
             const double keep = 1 - nz;
             for (uint64_t e = e0; e < e1; ++e) {
-                const int32_t c = map[ent_path[e]];
+                const int32_t c = column_of(args.ent_path[e]);
                 if (c >= 0) {
-                    pent_col[eb + my_ent] = static_cast<uint32_t>(c);
+                    args.pent_col[eb + my_ent] = static_cast<uint32_t>(c);
                     // addNoiseAndNormalizeProbabilityMatrix: (P / rowsum) * (1 - noise), two roundings
-                    pent_val[eb + my_ent] = (ent_prob[e] / rowsum) * keep;
+                    args.pent_val[eb + my_ent] = (args.ent_prob[e] / rowsum) * keep;
                     ++my_ent;
                 }
             }
@@ -205,19 +293,74 @@ __global__ __launch_bounds__(BLOCK) void fillProblemKernel(
     z = blockReduceSum<double, BLOCK>(z, dscratch);
     t = blockReduceSum<double, BLOCK>(t, dscratch);
     if (threadIdx.x == 0) {
-        if (!count_only) off[run_rows] = run_ent;
-        kept_rows[p] = run_rows;
-        kept_entries[p] = run_ent;
-        zero_mass[p] = z;
-        total_mass[p] = t;
+        if (!count_only) {
+            off[run_rows] = run_ent;
+            const uint32_t bucket = static_cast<uint32_t>(emBinOf(args.rule, n_cols + 1, run_rows, run_ent)) * kEmWorkBuckets + emWorkBucket(run_rows, run_ent);
+            args.prob_bucket[p] = bucket;
+            atomicAdd(&args.queues->histogram[bucket], 1u);
+        }
+        args.kept_rows[p] = run_rows;
+        args.kept_entries[p] = run_ent;
+        args.zero_mass[p] = z;
+        args.total_mass[p] = t;
+    }
+}
+
+// ---- 3. the work queues ------------------------------------------------------------
+// Every workgroup scans the (bin, bucket) histogram in LDS (352 counters) and lists its problems: a problem's place
+// inside its bucket is whatever the atomic hands out — the order inside a bucket only decides who starts first.
+__global__ __launch_bounds__(256) void emOrderKernel(const uint32_t num_problems, const uint32_t * __restrict__ num_problems_dev,
+                                                    const uint32_t * __restrict__ prob_bucket, const uint64_t * __restrict__ col_off,
+                                                    EmQueues * __restrict__ queues, uint32_t * __restrict__ order,
+                                                    unsigned long long * __restrict__ wide_off, const unsigned long long wide_capacity) {
+    constexpr int kCells = kEmBins * kEmWorkBuckets;
+    static_assert(kCells <= 512, "two cells per thread");
+    __shared__ uint32_t start[kCells + 1];
+    __shared__ uint32_t wave_total[4];
+    const uint32_t P = num_problems_dev ? *num_problems_dev : num_problems;
+    {
+        // exclusive prefix of the histogram: thread t owns cells 2 t and 2 t + 1
+        const uint32_t c0 = 2 * threadIdx.x, c1 = c0 + 1;
+        const uint32_t h0 = c0 < kCells ? queues->histogram[c0] : 0u, h1 = c1 < kCells ? queues->histogram[c1] : 0u;
+        uint32_t incl = h0 + h1;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_total[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += wave_total[w];
+        const uint32_t excl = before + incl - (h0 + h1);
+        if (c0 < kCells) start[c0] = excl;
+        if (c1 < kCells) start[c1] = excl + h0;
+        if (threadIdx.x == 255) start[kCells] = before + incl;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < kEmBins) {
+        queues->bin_start[threadIdx.x] = start[threadIdx.x * kEmWorkBuckets];
+        queues->bin_count[threadIdx.x] = start[(threadIdx.x + 1) * kEmWorkBuckets] - start[threadIdx.x * kEmWorkBuckets];
+    }
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const uint32_t cell = prob_bucket[p];
+    order[start[cell] + atomicAdd(&queues->bucket_cursor[cell], 1u)] = p;
+    if (cell / kEmWorkBuckets == 10) {  // abundance + accumulator vectors in global memory
+        const unsigned long long need = 2ull * (static_cast<unsigned long long>(col_off[p + 1] - col_off[p]) + 1);
+        const unsigned long long at = atomicAdd(&queues->wide_cursor, need);
+        wide_off[p] = at;
+        if (at + need > wide_capacity) atomicAdd(&queues->wide_overflow, 1ull);
     }
 }
 
 // ---- 5. the EM kernel --------------------------------------------------------
 
 struct EmLaunchArgs {
-    const uint32_t * order;        // problems of this bin, cost-descending
-    uint32_t count;
+    const uint32_t * order;        // problems, bin by bin (EmQueues::bin_start), large first
+    EmQueues * queues;
+    uint32_t bin;                  // the bin this launch serves
     const uint64_t * col_off;      // [P+1]
     const uint64_t * row_base;     // [P]
     const uint64_t * ent_base;     // [P]
@@ -232,23 +375,42 @@ struct EmLaunchArgs {
     uint32_t max_em_its;
     double max_rel_em_conv;
     double * wide_vectors;         // problems too wide for LDS: abundance + accumulator vectors, 2 C doubles each,
-    const uint64_t * wide_off;     // [P] at this offset (emSparseKernel<..., WIDE>)
+    const unsigned long long * wide_off;  // [P] at this offset (emSparseKernel<..., WIDE>)
+    unsigned long long wide_capacity;
     double * abundances;           // [col_off[P]]
     double * noise_count;          // [P]
     uint32_t * iterations;         // [P]
 };
+
+// The EM kernels are persistent: a launch has as many workgroups as the GPU holds at once (or as the bin can have
+// problems, if fewer), and every workgroup draws the next problem of its bin from the queue until the bin is empty —
+// the host launches every variant without knowing how many problems each bin got.  Returns the problem, or
+// UINT32_MAX when the bin is exhausted; uniform over the workgroup.
+template <int BLOCK>
+__device__ __forceinline__ uint32_t nextProblem(const EmLaunchArgs & args, uint32_t * slot) {
+    uint32_t i;
+    if (BLOCK == 64) {
+        i = (threadIdx.x == 0) ? atomicAdd(&args.queues->bin_cursor[args.bin], 1u) : 0u;
+        i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(i)));
+    } else {
+        __syncthreads();  // everybody is done with the previous problem (and with *slot)
+        if (threadIdx.x == 0) *slot = atomicAdd(&args.queues->bin_cursor[args.bin], 1u);
+        __syncthreads();
+        i = *slot;
+    }
+    if (i >= args.queues->bin_count[args.bin]) return UINT32_MAX;
+    return args.order[args.queues->bin_start[args.bin] + i];
+}
 
 // RESIDENT: the problem's compacted CSR is copied into LDS once and every EM iteration runs out of LDS
 // (small problems need up to thousands of iterations; from L2 each costs ~1.7 us of dependent-load
 // latency, from LDS a fraction of that).
 // WIDE: the abundance and accumulator vectors do not fit LDS (more than ~10 000 columns: the reference's EM has no
 // size limit, and clusters such as HLA exceed this): they live in global memory (L2), the M-step uses global FP64 atomics.
-template <int BLOCK, bool RESIDENT, bool WIDE = false>
-__global__ __launch_bounds__(BLOCK) void emSparseKernel(const EmLaunchArgs args) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    if (blockIdx.x >= args.count) return;
-    const uint32_t p = args.order[blockIdx.x];
+template <int BLOCK, bool RESIDENT, bool WIDE>
+__device__ __forceinline__ void emSparseProblem(const EmLaunchArgs & args, const uint32_t p, unsigned char * smem_raw) {
     const uint32_t C = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]) + 1;  // + noise
+    if (WIDE && args.wide_off[p] + 2ull * C > args.wide_capacity) return;  // (reported through EmQueues::wide_overflow)
     double * a = WIDE ? args.wide_vectors + args.wide_off[p] : reinterpret_cast<double *>(smem_raw);  // [C] abundances (last = noise)
     double * t = a + C;                                 // [C] M-step accumulators
     double * red = WIDE ? reinterpret_cast<double *>(smem_raw) : t + C;  // [BLOCK/64] reduction scratch
@@ -360,22 +522,27 @@ __global__ __launch_bounds__(BLOCK) void emSparseKernel(const EmLaunchArgs args)
     }
 }
 
-// LDS bytes of a problem: abundance + accumulator vectors and scratch, plus its CSR when resident
-size_t emLdsBytes(uint32_t cols, uint32_t rows, uint32_t entries, int block, bool resident) {
-    size_t bytes = sizeof(double) * (2 * static_cast<size_t>(cols) + block / 64 + 2);
-    if (resident) bytes += static_cast<size_t>(rows) * 16 + static_cast<size_t>(entries) * 8 + (static_cast<size_t>(rows) + 1 + entries) * 4 + 8;
-    return (bytes + 15) & ~static_cast<size_t>(15);
+template <int BLOCK, bool RESIDENT, bool WIDE = false>
+__global__ __launch_bounds__(BLOCK) void emSparseKernel(const EmLaunchArgs args) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ uint32_t next_slot;
+    if (blockIdx.x >= args.queues->bin_count[args.bin]) return;  // more workgroups than the bin has problems
+    for (uint32_t p = nextProblem<BLOCK>(args, &next_slot); p != UINT32_MAX; p = nextProblem<BLOCK>(args, &next_slot)) {
+        emSparseProblem<BLOCK, RESIDENT, WIDE>(args, p, smem_raw);
+        if (BLOCK == 64) __syncthreads();  // (the LDS is reused; wider workgroups meet in nextProblem)
+    }
 }
 
+// `grid`: workgroups of the persistent launch (the caller's bound on the problems of the bin, capped by what the GPU holds)
 template <int BLOCK, bool RESIDENT, bool WIDE = false>
-hipError_t launchEm(const EmLaunchArgs & args, size_t lds, hipStream_t stream) {
-    if (args.count == 0) return hipSuccess;
+hipError_t launchEm(const EmLaunchArgs & args, uint32_t grid, size_t lds, hipStream_t stream) {
+    if (grid == 0) return hipSuccess;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&emSparseKernel<BLOCK, RESIDENT, WIDE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
     }
-    emSparseKernel<BLOCK, RESIDENT, WIDE><<<dim3(args.count), dim3(BLOCK), lds, stream>>>(args);
+    emSparseKernel<BLOCK, RESIDENT, WIDE><<<dim3(grid), dim3(BLOCK), lds, stream>>>(args);
     return hipGetLastError();
 }
 
@@ -392,8 +559,6 @@ hipError_t launchEm(const EmLaunchArgs & args, size_t lds, hipStream_t stream) {
 // kernels use LDS atomics).  Round 3: the noise component became a column like the others (it was a wave-wide DPP sum
 // of its own next to the transposition: 27 instructions of ~230 per iteration), the update runs in every lane of a
 // column without a branch, and the transposition is skewed (below).
-constexpr uint32_t kRegColsMax = 32;  // the widest register-resident variant
-
 // value of the lane whose index differs in bit 0 (D = 1) or bit 1 (D = 2) — inside a quad, through DPP
 template <int D>
 __device__ __forceinline__ double quadSwapF64(const double v) {
@@ -465,12 +630,9 @@ __device__ __forceinline__ double columnSumsOverWave(double (&v)[COLS], const ui
 }
 
 template <int RPL, int COLS>
-__global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) {
+__device__ __forceinline__ void emRegisterProblem(const EmLaunchArgs & args, const uint32_t p, double * reg_lds) {
     constexpr uint32_t kCols = COLS;
     constexpr int kLanesPerColumn = 64 / COLS;  // 4 (16 columns) or 2 (32 columns)
-    extern __shared__ __attribute__((aligned(16))) double reg_lds[];
-    if (blockIdx.x >= args.count) return;
-    const uint32_t p = args.order[blockIdx.x];
     const uint32_t np = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]);  // < kCols; column np = noise
     const uint32_t lane = threadIdx.x;
     const uint32_t n_rows = args.kept_rows[p];
@@ -584,10 +746,20 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
 }
 
 template <int RPL, int COLS>
-hipError_t launchEmRegister(const EmLaunchArgs & args, hipStream_t stream) {
-    if (args.count == 0) return hipSuccess;
+__global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) {
+    extern __shared__ __attribute__((aligned(16))) double reg_lds[];
+    if (blockIdx.x >= args.queues->bin_count[args.bin]) return;  // more workgroups than the bin has problems
+    for (uint32_t p = nextProblem<64>(args, nullptr); p != UINT32_MAX; p = nextProblem<64>(args, nullptr)) {
+        emRegisterProblem<RPL, COLS>(args, p, reg_lds);
+        __syncthreads();  // the staging tile is reused
+    }
+}
+
+template <int RPL, int COLS>
+hipError_t launchEmRegister(const EmLaunchArgs & args, uint32_t grid, hipStream_t stream) {
+    if (grid == 0) return hipSuccess;
     const size_t lds = (64 * RPL * COLS + 2) * sizeof(double);  // the staging tile
-    emRegisterKernel<RPL, COLS><<<dim3(args.count), dim3(64), lds, stream>>>(args);
+    emRegisterKernel<RPL, COLS><<<dim3(grid), dim3(64), lds, stream>>>(args);
     return hipGetLastError();
 }
 
@@ -842,33 +1014,242 @@ __global__ __launch_bounds__(256) void gibbsReadCountKernel(const GibbsLaunchArg
     }
 }
 
-// ---- shared host part: validate problems, build their compacted CSR on the device --------------
+// ---- shared host part: the compacted CSR of a list of problems, their work queues, the EM launches -------------
 
-struct ProblemSet {
-    uint32_t P = 0;
-    uint64_t n_cols_total = 0, rows_total = 0, ent_total = 0;
-    uint32_t max_cols = 0;
-    std::vector<uint32_t> kept_rows, kept_ent;
-    std::vector<double> total_count;
-    DeviceBuffer<uint32_t> d_cluster, d_col_path, d_kept_rows, d_kept_ent, d_prow_off, d_pent_col;
-    DeviceBuffer<uint64_t> d_col_off, d_colmap_off, d_row_base, d_ent_base;
-    DeviceBuffer<int32_t> d_colmap;
-    DeviceBuffer<double> d_zero, d_total, d_prow_count, d_prow_noise, d_pent_val;
-    UploadPack uploads;                // d_cluster, d_col_off, d_col_path, d_colmap_off are views of this
-    DownloadPack counts;               // d_kept_rows, d_kept_ent, d_total
+EmBinRule emBinRule() {
+    static const bool use_register_kernel = std::getenv("RPVG_HIP_NO_REGISTER_EM") == nullptr;
+    // A streamed problem is one workgroup: above this many rows + entries it gets 1 024 threads instead of 256 (round 2:
+    // 262 144 — a 200 000-entry problem on 256 threads took 47 us per EM iteration and, at 23 iterations, as long as the
+    // thousands of iterations of the slowest register-resident problem).
+    static const uint64_t streamed_small = std::getenv("RPVG_HIP_EM_STREAM_SMALL") ? std::strtoull(std::getenv("RPVG_HIP_EM_STREAM_SMALL"), nullptr, 10) : 24576;
+    return EmBinRule{use_register_kernel ? 1u : 0u, streamed_small};
+}
+
+}  // namespace
+
+namespace rpvg_hip_detail {
+
+// Everything between a problem list in device memory and its EM results, queued on the context's streams without a host
+// synchronisation: compaction of every problem's rows (fillProblemKernel), the work queues (emOrderKernel), one
+// persistent launch per kernel variant.  Caller holds ctx->mutex and has set the device; `work` must outlive the kernels.
+int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProblemList & list, const uint32_t max_em_its,
+                 const double max_rel_em_conv, const EmOutputs & out, EmSolveWork & work, const bool fill_only) {
+    hipStream_t st = ctx->stream;
+    const uint32_t P = list.P_bound;
+    const EmBinRule rule = emBinRule();
+    RPVG_HIP_CHECK(work.d_prow_off.alloc(list.rows_capacity + P));
+    RPVG_HIP_CHECK(work.d_prow_count.alloc(list.rows_capacity));
+    RPVG_HIP_CHECK(work.d_prow_noise.alloc(list.rows_capacity));
+    RPVG_HIP_CHECK(work.d_pent_col.alloc(list.entries_capacity));
+    RPVG_HIP_CHECK(work.d_pent_val.alloc(list.entries_capacity));
+    RPVG_HIP_CHECK(work.d_zero.alloc(P));
+    RPVG_HIP_CHECK(work.d_bucket.alloc(P));
+    RPVG_HIP_CHECK(work.d_order.alloc(P));
+    RPVG_HIP_CHECK(work.d_queues.alloc(sizeof(EmQueues)));
+    if (list.wide_capacity > 0) {
+        RPVG_HIP_CHECK(work.d_wide_vectors.alloc(list.wide_capacity));
+        RPVG_HIP_CHECK(work.d_wide_off.alloc(P));
+    }
+    EmQueues * queues = reinterpret_cast<EmQueues *>(work.d_queues.ptr);
+
+    int span = ctx->spanBegin(FAM_BUILD);
+    RPVG_HIP_CHECK(hipMemsetAsync(work.d_queues.ptr, 0, sizeof(EmQueues), st));
+    FillArgs fa;
+    fa.num_problems = P;
+    fa.num_problems_dev = list.d_num_problems;
+    fa.prob_cluster = list.d_cluster;
+    fa.col_off = list.d_col_off;
+    fa.col_path = list.d_col_path;
+    fa.cluster_row_off = batch->cluster_row_off.ptr;
+    fa.cluster_path_off = batch->cluster_path_off.ptr;
+    fa.row_ent_off = batch->row_ent_off.ptr;
+    fa.ent_path = batch->ent_path.ptr;
+    fa.ent_prob = batch->ent_prob.ptr;
+    fa.row_count = batch->row_count.ptr;
+    fa.row_noise = batch->row_noise.ptr;
+    fa.row_base = list.d_row_base;
+    fa.ent_base = list.d_ent_base;
+    fa.prow_off = work.d_prow_off.ptr;
+    fa.prow_count = work.d_prow_count.ptr;
+    fa.prow_noise = work.d_prow_noise.ptr;
+    fa.pent_col = work.d_pent_col.ptr;
+    fa.pent_val = work.d_pent_val.ptr;
+    fa.kept_rows = out.d_kept_rows;
+    fa.kept_entries = out.d_kept_entries;
+    fa.zero_mass = work.d_zero.ptr;
+    fa.total_mass = out.d_total;
+    fa.prob_bucket = work.d_bucket.ptr;
+    fa.queues = queues;
+    fa.rule = rule;
+    fa.lds_map_paths = std::min<uint32_t>(list.max_cluster_paths, kLdsMapPaths);
+    fillProblemKernel<256><<<dim3(P), dim3(256), fa.lds_map_paths * sizeof(int32_t), st>>>(fa);
+    RPVG_HIP_CHECK(hipGetLastError());
+    ctx->stats.build_launches += 1;
+    if (fill_only) {
+        ctx->spanEnd(span);
+        return RPVG_HIP_OK;
+    }
+    emOrderKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(P, list.d_num_problems, work.d_bucket.ptr, list.d_col_off, queues, work.d_order.ptr,
+                                                              work.d_wide_off.ptr, list.wide_capacity);
+    RPVG_HIP_CHECK(hipGetLastError());
+    ctx->spanEnd(span);
+    ctx->stats.build_launches += 1;
+
+    EmLaunchArgs args;
+    args.order = work.d_order.ptr;
+    args.queues = queues;
+    args.bin = 0;
+    args.col_off = list.d_col_off;
+    args.row_base = list.d_row_base;
+    args.ent_base = list.d_ent_base;
+    args.kept_rows = out.d_kept_rows;
+    args.zero_mass = work.d_zero.ptr;
+    args.total_mass = out.d_total;
+    args.prow_off = work.d_prow_off.ptr;
+    args.prow_count = work.d_prow_count.ptr;
+    args.prow_noise = work.d_prow_noise.ptr;
+    args.pent_col = work.d_pent_col.ptr;
+    args.pent_val = work.d_pent_val.ptr;
+    args.max_em_its = max_em_its;
+    args.max_rel_em_conv = max_rel_em_conv;
+    args.wide_vectors = work.d_wide_vectors.ptr;
+    args.wide_off = work.d_wide_off.ptr;
+    args.wide_capacity = list.wide_capacity;
+    args.abundances = out.d_abundances;
+    args.noise_count = out.d_noise_count;
+    args.iterations = out.d_iterations;
+
+    // The bins are independent, so their tails (a small problem that needs thousands of iterations, a giant one with
+    // many rows) should overlap — but only as many kernels run side by side as the runtime has hardware queues.
+    // Workgroups of a persistent launch: what the GPU holds of the variant at once, or the bound on the problems if smaller.
+    const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
+    auto grid = [&](const uint32_t per_cu) { return std::min<uint32_t>(P, cus * per_cu); };
+    const size_t streamed_lds_256 = emLdsBytes(list.max_cols, 0, 0, 256, false), streamed_lds_1024 = emLdsBytes(list.max_cols, 0, 0, 1024, false);
+    const bool wide_possible = streamed_lds_1024 > kEmLdsLimit;
+    span = ctx->spanBegin(FAM_EM_SPARSE);
+    RPVG_HIP_CHECK(ctx->forkAux());
+    // The register-resident bins are the long ones: they start first.  With eight hardware queues
+    // (hardwareQueues(), context.hip) they get streams of their own; with four, streams beyond the fourth would only
+    // queue behind the others, and a bin that waits there ends later than one that shares a stream knowingly.
+    const bool many_queues = hardwareQueues() >= 8;
+    hipStream_t s_reg4 = many_queues ? ctx->aux[3] : ctx->aux[0], s_reg1 = many_queues ? ctx->aux[4] : ctx->aux[1], s_reg2 = many_queues ? ctx->aux[5] : ctx->aux[2];
+    // every bin's launch carries its own HIP events on its own stream (rpvg_hip_kernel_stats::em_kernel)
+    int bin_span = -1;
+    auto timed = [&](const int b, hipStream_t on) {
+        args.bin = static_cast<uint32_t>(b);
+        bin_span = ctx->spanBegin(FAM_EM_KERNEL, on, b);
+        return on;
+    };
+    // (chains of launches that share a stream run one after the other: balanced by the kernels' usual durations)
+    RPVG_HIP_CHECK((launchEmRegister<4, 16>(args, grid(4), timed(6, s_reg4))));
+    ctx->spanEnd(bin_span);
+    RPVG_HIP_CHECK((launchEmRegister<1, 16>(args, grid(16), timed(4, s_reg1))));
+    ctx->spanEnd(bin_span);
+    RPVG_HIP_CHECK((launchEmRegister<2, 16>(args, grid(8), timed(5, s_reg2))));
+    ctx->spanEnd(bin_span);
+    timed(2, st);
+    RPVG_HIP_CHECK((launchEm<256, false>(args, grid(4), std::min(streamed_lds_256, kEmLdsLimit), st)));
+    ctx->spanEnd(bin_span);
+    timed(3, ctx->aux[0]);
+    RPVG_HIP_CHECK((launchEm<1024, false>(args, grid(2), std::min(streamed_lds_1024, kEmLdsLimit), ctx->aux[0])));
+    ctx->spanEnd(bin_span);
+    timed(7, ctx->aux[0]);
+    RPVG_HIP_CHECK((launchEm<1024, true>(args, grid(1), 152 * 1024, ctx->aux[0])));
+    ctx->spanEnd(bin_span);
+    timed(0, ctx->aux[1]);
+    RPVG_HIP_CHECK((launchEm<64, true>(args, grid(16), 8 * 1024, ctx->aux[1])));
+    ctx->spanEnd(bin_span);
+    timed(1, ctx->aux[2]);
+    RPVG_HIP_CHECK((launchEm<256, true>(args, grid(4), 40 * 1024, ctx->aux[2])));
+    ctx->spanEnd(bin_span);
+    if (list.max_cols > 16) {
+        RPVG_HIP_CHECK((launchEmRegister<1, 32>(args, grid(8), timed(8, ctx->aux[2]))));
+        ctx->spanEnd(bin_span);
+        RPVG_HIP_CHECK((launchEmRegister<2, 32>(args, grid(4), timed(9, ctx->aux[2]))));
+        ctx->spanEnd(bin_span);
+    }
+    if (wide_possible) {
+        timed(10, s_reg2);
+        RPVG_HIP_CHECK((launchEm<1024, false, true>(args, grid(2), sizeof(double) * (1024 / 64 + 2), s_reg2)));
+        ctx->spanEnd(bin_span);
+    }
+    RPVG_HIP_CHECK(ctx->joinAux());
+    ctx->spanEnd(span);
+    return RPVG_HIP_OK;
+}
+
+// Folds the results of a solve into the context's statistics (after the results have reached the host): the host
+// repeats the device's bin decision per problem.  cols[p] = columns of problem p without the noise component.
+void accountEmSolve(rpvg_hip_ctx * ctx, const uint32_t P, const uint64_t * col_off, const uint32_t * kept_rows, const uint32_t * kept_entries,
+                    const uint32_t * iterations) {
+    // algorithmic bytes: per iteration 12 B per entry (value + column), 20 B per row (count, noise, offset), 16 B per
+    // column (a read + a' write)
+    const EmBinRule rule = emBinRule();
+    double bin_bytes[kEmBins] = {};
+    uint64_t bin_its[kEmBins] = {}, bin_problems[kEmBins] = {};
+    uint32_t bin_slowest[kEmBins] = {};
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t C = static_cast<uint32_t>(col_off[p + 1] - col_off[p]) + 1;
+        const int b = emBinOf(rule, C, kept_rows[p], kept_entries[p]);
+        bin_bytes[b] += static_cast<double>(iterations[p]) * (12.0 * kept_entries[p] + 20.0 * kept_rows[p] + 16.0 * C);
+        bin_its[b] += iterations[p];
+        bin_problems[b] += 1;
+        bin_slowest[b] = std::max(bin_slowest[b], iterations[p]);
+    }
+    for (int b = 0; b < kEmBins; ++b) {
+        if (!bin_problems[b]) continue;
+        rpvg_hip_em_kernel_stats & ks = ctx->stats.em_kernel[b];
+        ks.launches += 1;
+        ks.problems += bin_problems[b];
+        ks.iterations += bin_its[b];
+        ks.max_iterations += bin_slowest[b];
+        ks.alg_bytes += bin_bytes[b];
+        ctx->stats.em_sparse_launches += 1;
+        ctx->stats.em_sparse_alg_bytes += bin_bytes[b];
+        ctx->stats.em_iterations_total += bin_its[b];
+    }
+}
+
+}  // namespace rpvg_hip_detail
+
+namespace {
+
+// The problems of an rpvg_hip_em_solve / rpvg_hip_gibbs_read_counts call: validated, uploaded, and laid out.
+struct HostProblemSet {
+    EmProblemList list;
+    EmSolveWork work;
+    DeviceBuffer<uint32_t> d_cluster, d_col_path;
+    DeviceBuffer<uint64_t> d_col_off, d_row_base, d_ent_base;
+    UploadPack uploads;
+    uint64_t n_cols_total = 0;
 };
 
-// Caller holds ctx->mutex and has set the device.
-int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_em_problems * problems,
-                    ProblemSet & ps, const char * who) {
+// Free device memory a call may plan with (a share of what the driver reported when the process first asked: other lanes
+// allocate too, and hipMemGetInfo costs milliseconds — asked per call it was 3 ms of every batch's critical path).
+uint64_t deviceMemoryBudget() {
+    static const uint64_t budget = []() {
+        size_t free_bytes = 0, total_bytes = 0;
+        if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) {
+            (void) hipGetLastError();
+            return static_cast<uint64_t>(4ull << 30);
+        }
+        return static_cast<uint64_t>(free_bytes) * 2 / 5;
+    }();
+    return budget;
+}
+
+// Caller holds ctx->mutex and has set the device.  Validates the problems and uploads their description; the storage of a
+// problem starts where that of the problems before it ends at the most (a problem keeps at most the rows and entries of
+// its cluster) — offsets the host knows, so one kernel counts and fills.  When that bound does not fit the memory the
+// call may use (RPVG_HIP_EM_BOUND_BYTES, at most two fifths of the free device memory), a counting pass comes first and the
+// storage is exact.
+int prepareHostProblems(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_em_problems * problems,
+                        HostProblemSet & ps, const EmOutputs & out, const char * who) {
     const uint32_t P = problems->num_problems;
-    ps.P = P;
     std::unique_ptr<HostScope> scope(new HostScope("problems: validate"));
-    std::vector<uint64_t> colmap_off(P + 1, 0);
-    // A problem keeps at most the rows and entries of its cluster: its compacted rows and entries start where those of
-    // the problems before it would end at the most — offsets the host knows, so one kernel counts and fills.
     uint64_t rows_bound = 0, entries_bound = 0;
     std::vector<uint64_t> row_base(P), ent_base(P);
+    EmProblemList & list = ps.list;
     for (uint32_t p = 0; p < P; ++p) {
         const uint32_t k = problems->cluster[p];
         RPVG_REQUIRE(k < batch->num_clusters, "%s: problem %u refers to cluster %u of %u", who, p, k, batch->num_clusters);
@@ -881,88 +1262,84 @@ int buildProblemSet(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg
                          static_cast<unsigned long long>(n_paths));
             RPVG_REQUIRE(c == c0 || problems->col_path[c] > problems->col_path[c - 1], "%s: problem %u columns are not strictly ascending", who, p);
         }
-        colmap_off[p + 1] = colmap_off[p] + n_paths;
-        ps.max_cols = std::max<uint32_t>(ps.max_cols, static_cast<uint32_t>(c1 - c0) + 1);
+        const uint32_t C = static_cast<uint32_t>(c1 - c0) + 1;
+        list.max_cols = std::max<uint32_t>(list.max_cols, C);
+        list.max_cluster_paths = std::max<uint32_t>(list.max_cluster_paths, static_cast<uint32_t>(n_paths));
+        if (emLdsBytes(C, 0, 0, 1024, false) > kEmLdsLimit) list.wide_capacity += 2ull * C;
         row_base[p] = rows_bound;
         ent_base[p] = entries_bound;
         rows_bound += batch->h_cluster_row_off[k + 1] - batch->h_cluster_row_off[k];
         entries_bound += batch->h_cluster_ent_off[k + 1] - batch->h_cluster_ent_off[k];
     }
     ps.n_cols_total = problems->col_off[P];
+    list.P_bound = P;
 
-    scope.reset(new HostScope("problems: uploads + colmap + count launch"));
+    scope.reset(new HostScope("problems: uploads"));
     hipStream_t st = ctx->stream;
+    // (storage by the bound up to a budget — RPVG_HIP_EM_BOUND_BYTES, by default two fifths of the free device memory and at
+    // most 32 GiB; beyond it two passes, the first of which only counts)
+    const char * budget_env = std::getenv("RPVG_HIP_EM_BOUND_BYTES");  // (read per call: the tests take both ways)
+    const uint64_t bound_budget = budget_env ? static_cast<uint64_t>(std::atof(budget_env)) : std::min<uint64_t>(32ull << 30, deviceMemoryBudget());
+    const bool by_bound = rows_bound * 20 + entries_bound * 12 <= bound_budget;
     int span = ctx->spanBegin(FAM_H2D);
     ps.uploads.add(ps.d_cluster, problems->cluster, P);
     ps.uploads.add(ps.d_col_off, problems->col_off, P + 1);
     ps.uploads.add(ps.d_col_path, problems->col_path, ps.n_cols_total);
-    ps.uploads.add(ps.d_colmap_off, colmap_off.data(), P + 1);
-    // (storage by the bound up to a budget — RPVG_HIP_EM_BOUND_BYTES, default 32 GiB per call; beyond it two passes, the first
-    // of which only counts: what round 1 always did)
-    const char * budget_env = std::getenv("RPVG_HIP_EM_BOUND_BYTES");  // (read per call: the tests take both ways)
-    const uint64_t bound_budget = budget_env ? static_cast<uint64_t>(std::atof(budget_env)) : (32ull << 30);
-    const bool by_bound = rows_bound * 20 + entries_bound * 12 <= bound_budget;
     if (by_bound) {
         ps.uploads.add(ps.d_row_base, row_base.data(), P);
         ps.uploads.add(ps.d_ent_base, ent_base.data(), P);
     }
     RPVG_HIP_CHECK(ps.uploads.commit(st));
     ctx->spanEnd(span);
-    ctx->stats.h2d_bytes += static_cast<double>(P * 4 + (P + 1) * 16 + ps.n_cols_total * 4);
-    RPVG_HIP_CHECK(ps.d_colmap.alloc(colmap_off[P]));
-    ps.kept_rows.resize(P);
-    ps.kept_ent.resize(P);
-    ps.total_count.resize(P);
-    ps.counts.add(ps.d_kept_rows, ps.kept_rows.data(), P);
-    ps.counts.add(ps.d_kept_ent, ps.kept_ent.data(), P);
-    ps.counts.add(ps.d_total, ps.total_count.data(), P);
-    RPVG_HIP_CHECK(ps.counts.alloc());
-    RPVG_HIP_CHECK(ps.d_zero.alloc(P));
-
-    span = ctx->spanBegin(FAM_BUILD);
-    RPVG_HIP_CHECK(hipMemsetAsync(ps.d_colmap.ptr, 0xFF, colmap_off[P] * sizeof(int32_t), st));
-    scatterColumnMapKernel<<<dim3(P), dim3(64), 0, st>>>(P, ps.d_col_off.ptr, ps.d_col_path.ptr, ps.d_colmap_off.ptr, ps.d_colmap.ptr);
-    auto fill = [&]() {
-        fillProblemKernel<256><<<dim3(P), dim3(256), 0, st>>>(
-            P, ps.d_cluster.ptr, ps.d_colmap_off.ptr, ps.d_colmap.ptr, batch->cluster_row_off.ptr, batch->row_ent_off.ptr,
-            batch->ent_path.ptr, batch->ent_prob.ptr, batch->row_count.ptr, batch->row_noise.ptr, ps.d_row_base.ptr,
-            ps.d_ent_base.ptr, ps.d_prow_off.ptr, ps.d_prow_count.ptr, ps.d_prow_noise.ptr, ps.d_pent_col.ptr, ps.d_pent_val.ptr,
-            ps.d_kept_rows.ptr, ps.d_kept_ent.ptr, ps.d_zero.ptr, ps.d_total.ptr);
-    };
+    ctx->stats.h2d_bytes += static_cast<double>(P * 4 + (P + 1) * 24 + ps.n_cols_total * 4);
+    list.d_cluster = ps.d_cluster.ptr;
+    list.d_col_off = ps.d_col_off.ptr;
+    list.d_col_path = ps.d_col_path.ptr;
     if (!by_bound) {
-        fill();  // no storage yet: counts only
+        scope.reset(new HostScope("problems: counting pass"));
+        // counts only: no storage, no queues
+        EmProblemList count_list = list;
+        count_list.rows_capacity = count_list.entries_capacity = 0;
+        FillArgs fa{};
+        fa.num_problems = P;
+        fa.prob_cluster = list.d_cluster;
+        fa.col_off = list.d_col_off;
+        fa.col_path = list.d_col_path;
+        fa.cluster_row_off = batch->cluster_row_off.ptr;
+        fa.cluster_path_off = batch->cluster_path_off.ptr;
+        fa.row_ent_off = batch->row_ent_off.ptr;
+        fa.ent_path = batch->ent_path.ptr;
+        fa.ent_prob = batch->ent_prob.ptr;
+        fa.row_count = batch->row_count.ptr;
+        fa.row_noise = batch->row_noise.ptr;
+        DeviceBuffer<double> d_zero;
+        RPVG_HIP_CHECK(d_zero.alloc(P));
+        fa.kept_rows = out.d_kept_rows;
+        fa.kept_entries = out.d_kept_entries;
+        fa.zero_mass = d_zero.ptr;
+        fa.total_mass = out.d_total;
+        fa.rule = emBinRule();
+        fa.lds_map_paths = std::min<uint32_t>(list.max_cluster_paths, kLdsMapPaths);
+        fillProblemKernel<256><<<dim3(P), dim3(256), fa.lds_map_paths * sizeof(int32_t), st>>>(fa);
         RPVG_HIP_CHECK(hipGetLastError());
-        RPVG_HIP_CHECK(ps.counts.fetch(st));
+        std::vector<uint32_t> kept_rows(P), kept_ent(P);
+        RPVG_HIP_CHECK(hipMemcpyAsync(kept_rows.data(), out.d_kept_rows, P * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        RPVG_HIP_CHECK(hipMemcpyAsync(kept_ent.data(), out.d_kept_entries, P * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         RPVG_HIP_CHECK(hipStreamSynchronize(st));
-        ps.counts.scatter();
         rows_bound = entries_bound = 0;
         for (uint32_t p = 0; p < P; ++p) {
             row_base[p] = rows_bound;
             ent_base[p] = entries_bound;
-            rows_bound += ps.kept_rows[p];
-            entries_bound += ps.kept_ent[p];
+            rows_bound += kept_rows[p];
+            entries_bound += kept_ent[p];
         }
         RPVG_HIP_CHECK(ps.d_row_base.upload(row_base.data(), P, st));
         RPVG_HIP_CHECK(ps.d_ent_base.upload(ent_base.data(), P, st));
     }
-    RPVG_HIP_CHECK(ps.d_prow_off.alloc(rows_bound + P));
-    RPVG_HIP_CHECK(ps.d_prow_count.alloc(rows_bound));
-    RPVG_HIP_CHECK(ps.d_prow_noise.alloc(rows_bound));
-    RPVG_HIP_CHECK(ps.d_pent_col.alloc(entries_bound));
-    RPVG_HIP_CHECK(ps.d_pent_val.alloc(entries_bound));
-    fill();
-    ctx->spanEnd(span);
-    ctx->stats.build_launches += 2;
-    RPVG_HIP_CHECK(hipGetLastError());
-
-    scope.reset(new HostScope("problems: wait for the counts"));
-    RPVG_HIP_CHECK(ps.counts.fetch(st));
-    RPVG_HIP_CHECK(hipStreamSynchronize(st));
-    ps.counts.scatter();
-    for (uint32_t p = 0; p < P; ++p) {
-        ps.rows_total += ps.kept_rows[p];
-        ps.ent_total += ps.kept_ent[p];
-    }
+    list.d_row_base = ps.d_row_base.ptr;
+    list.d_ent_base = ps.d_ent_base.ptr;
+    list.rows_capacity = rows_bound;
+    list.entries_capacity = entries_bound;
     return RPVG_HIP_OK;
 }
 
@@ -992,210 +1369,33 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     RPVG_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
 
-    ProblemSet ps;
-    const int rc = buildProblemSet(ctx, batch, problems, ps, "rpvg_hip_em_solve");
+    // the results and the per-problem counts in one block, one copy back
+    std::vector<uint32_t> kept_rows(P), kept_ent(P);
+    DeviceBuffer<uint32_t> d_iters, d_kept_rows, d_kept_ent;
+    DeviceBuffer<double> d_abund, d_noise_count, d_total;
+    DownloadPack outputs;
+    outputs.add(d_abund, results->abundances, problems->col_off[P]);
+    outputs.add(d_noise_count, results->noise_count, P);
+    outputs.add(d_total, results->total_count, P);
+    outputs.add(d_iters, results->iterations, P);
+    outputs.add(d_kept_rows, kept_rows.data(), P);
+    outputs.add(d_kept_ent, kept_ent.data(), P);
+    RPVG_HIP_CHECK(outputs.alloc());
+    EmOutputs out{d_abund.ptr, d_noise_count.ptr, d_iters.ptr, d_kept_rows.ptr, d_kept_ent.ptr, d_total.ptr};
+
+    HostProblemSet ps;
+    int rc = prepareHostProblems(ctx, batch, problems, ps, out, "rpvg_hip_em_solve");
     if (rc != RPVG_HIP_OK) return rc;
-    for (uint32_t p = 0; p < P; ++p) results->total_count[p] = ps.total_count[p];
-    const std::vector<uint32_t> & kept_rows = ps.kept_rows;
-    const std::vector<uint32_t> & kept_ent = ps.kept_ent;
-
-    std::unique_ptr<HostScope> scope(new HostScope("em_solve: bins + launches"));
-    // Size bins (inside a bin the expensive problems go first, as the reference orders clusters before
-    // its dynamic OpenMP schedule, src/main.cpp:811-829):
-    //   0  LDS-resident, one wave      CSR + vectors fit 8 KB
-    //   1  LDS-resident, four waves    fit 40 KB
-    //   2  streamed from L2, 4 waves
-    //   3  streamed from L2, 16 waves  (a few giant problems)
-    //   4-6 register-resident dense, one wave: at most 16 columns (paths + noise) and 64 / 128 / 256 rows (emRegisterKernel)
-    //   8-9 register-resident dense, one wave: 17 to 32 columns and 64 / 128 rows
-    //   7  LDS-resident, sixteen waves  CSR + vectors fit 152 KB (one workgroup per CU: the whole LDS)
-    //   10 too many columns for LDS-resident vectors (> ~9 700): vectors in global memory, 16 waves
-    constexpr int kBins = 11;
-    static_assert(kBins == RPVG_HIP_EM_KERNELS, "one statistics slot per EM kernel variant");
-    constexpr size_t kLdsLimit = 156 * 1024;
-    // A streamed problem is one workgroup: above this many rows + entries it gets 1 024 threads instead of 256 (round 2:
-    // 262 144 — a 200 000-entry problem on 256 threads took 47 us per EM iteration and, at 23 iterations, as long as the
-    // thousands of iterations of the slowest register-resident problem).
-    static const uint64_t kStreamedSmallWork = std::getenv("RPVG_HIP_EM_STREAM_SMALL") ? std::strtoull(std::getenv("RPVG_HIP_EM_STREAM_SMALL"), nullptr, 10) : 24576;
-    std::vector<uint64_t> wide_off(P, 0);
-    uint64_t wide_total = 0;
-    std::vector<uint32_t> bins[kBins];
-    size_t bin_lds[kBins] = {};
-    static const bool use_register_kernel = std::getenv("RPVG_HIP_NO_REGISTER_EM") == nullptr;
-    for (uint32_t p = 0; p < P; ++p) {
-        const uint32_t C = static_cast<uint32_t>(problems->col_off[p + 1] - problems->col_off[p]) + 1;
-        const uint64_t work = static_cast<uint64_t>(kept_ent[p]) + kept_rows[p];
-        int b;
-        size_t lds = 0;
-        if (use_register_kernel && C <= 16 && kept_rows[p] <= 256) {
-            b = kept_rows[p] <= 64 ? 4 : kept_rows[p] <= 128 ? 5 : 6;
-        } else if (use_register_kernel && C <= kRegColsMax && kept_rows[p] <= 128) {
-            b = kept_rows[p] <= 64 ? 8 : 9;
-        } else if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 64, true)) <= 8 * 1024) {
-            b = 0;
-        } else if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 256, true)) <= 40 * 1024) {
-            b = 1;
-        } else if ((lds = emLdsBytes(C, kept_rows[p], kept_ent[p], 1024, true)) <= 152 * 1024) {
-            b = 7;
-        } else if (emLdsBytes(C, 0, 0, 1024, false) > kLdsLimit) {
-            b = 10;
-            lds = sizeof(double) * (1024 / 64 + 2);
-            wide_off[p] = wide_total;
-            wide_total += 2 * static_cast<uint64_t>(C);
-        } else if (work <= kStreamedSmallWork) {
-            b = 2;
-            lds = emLdsBytes(C, 0, 0, 256, false);
-        } else {
-            b = 3;
-            lds = emLdsBytes(C, 0, 0, 1024, false);
-        }
-        bins[b].push_back(p);
-        bin_lds[b] = std::max(bin_lds[b], lds);
-    }
-    std::vector<uint32_t> order;
-    order.reserve(P);
-    uint32_t bin_start[kBins];
-    std::vector<uint64_t> keys;  // (inverted work, problem): ascending = expensive first, ties by problem index
-    for (int b = kBins - 1; b >= 0; --b) {
-        keys.clear();
-        for (const uint32_t x : bins[b]) {
-            const uint64_t work = static_cast<uint64_t>(kept_ent[x]) + kept_rows[x];  // < 2^33
-            keys.push_back(((0x3ffffffffull - work) << 30) | x);
-        }
-        if (P < (1u << 30)) {
-            std::sort(keys.begin(), keys.end());
-            for (size_t i = 0; i < keys.size(); ++i) bins[b][i] = static_cast<uint32_t>(keys[i] & 0x3fffffffu);
-        } else {
-            std::sort(bins[b].begin(), bins[b].end(), [&](uint32_t x, uint32_t y) {
-                const uint64_t wx = static_cast<uint64_t>(kept_ent[x]) + kept_rows[x], wy = static_cast<uint64_t>(kept_ent[y]) + kept_rows[y];
-                return wx != wy ? wx > wy : x < y;
-            });
-        }
-        bin_start[b] = order.size();
-        order.insert(order.end(), bins[b].begin(), bins[b].end());
-    }
-
-    DeviceBuffer<uint32_t> d_order, d_iters;
-    DeviceBuffer<double> d_abund, d_noise_count, d_wide_vectors;
-    DeviceBuffer<uint64_t> d_wide_off;
-    int span = ctx->spanBegin(FAM_H2D);
-    RPVG_HIP_CHECK(d_order.upload(order.data(), P, st));
-    if (wide_total > 0) {
-        RPVG_HIP_CHECK(d_wide_off.upload(wide_off.data(), P, st));
-        RPVG_HIP_CHECK(d_wide_vectors.alloc(wide_total));
-    }
-    ctx->spanEnd(span);
-    ctx->stats.h2d_bytes += static_cast<double>(P * 4);
-    DownloadPack out;  // the three result arrays in one block, one copy back
-    out.add(d_abund, results->abundances, ps.n_cols_total);
-    out.add(d_noise_count, results->noise_count, P);
-    out.add(d_iters, results->iterations, P);
-    RPVG_HIP_CHECK(out.alloc());
-
-    EmLaunchArgs args;
-    args.col_off = ps.d_col_off.ptr;
-    args.row_base = ps.d_row_base.ptr;
-    args.ent_base = ps.d_ent_base.ptr;
-    args.kept_rows = ps.d_kept_rows.ptr;
-    args.zero_mass = ps.d_zero.ptr;
-    args.total_mass = ps.d_total.ptr;
-    args.prow_off = ps.d_prow_off.ptr;
-    args.prow_count = ps.d_prow_count.ptr;
-    args.prow_noise = ps.d_prow_noise.ptr;
-    args.pent_col = ps.d_pent_col.ptr;
-    args.pent_val = ps.d_pent_val.ptr;
-    args.max_em_its = max_em_its;
-    args.max_rel_em_conv = max_rel_em_conv;
-    args.wide_vectors = d_wide_vectors.ptr;
-    args.wide_off = d_wide_off.ptr;
-    args.abundances = d_abund.ptr;
-    args.noise_count = d_noise_count.ptr;
-    args.iterations = d_iters.ptr;
-
-    // The bins are independent, so their tails (a small problem that needs thousands of iterations, a giant one with
-    // many rows) should overlap — but only as many kernels run side by side as the runtime has hardware queues.
-    span = ctx->spanBegin(FAM_EM_SPARSE);
-    RPVG_HIP_CHECK(ctx->forkAux());
-    auto bin = [&](const int b) {
-        args.order = d_order.ptr + bin_start[b];
-        args.count = bins[b].size();
-    };
-    // The register-resident bins are the long ones: they start first.  With eight hardware queues
-    // (hardwareQueues(), context.hip) they get streams of their own; with four, streams beyond the fourth would only
-    // queue behind the others, and a bin that waits there ends later than one that shares a stream knowingly.
-    const bool wide = hardwareQueues() >= 8;
-    hipStream_t s_reg4 = wide ? ctx->aux[3] : ctx->aux[0], s_reg1 = wide ? ctx->aux[4] : ctx->aux[1], s_reg2 = wide ? ctx->aux[5] : ctx->aux[2];
-    // every bin's launch carries its own HIP events on its own stream (rpvg_hip_kernel_stats::em_kernel)
-    int bin_span = -1;
-    auto timed = [&](const int b, hipStream_t on) {
-        bin(b);
-        bin_span = args.count ? ctx->spanBegin(FAM_EM_KERNEL, on, b) : -1;
-        return on;
-    };
-    RPVG_HIP_CHECK((launchEmRegister<4, 16>(args, timed(6, s_reg4))));
-    ctx->spanEnd(bin_span);
-    RPVG_HIP_CHECK((launchEmRegister<1, 16>(args, timed(4, s_reg1))));
-    ctx->spanEnd(bin_span);
-    RPVG_HIP_CHECK((launchEmRegister<2, 16>(args, timed(5, s_reg2))));
-    ctx->spanEnd(bin_span);
-    timed(2, st);
-    RPVG_HIP_CHECK((launchEm<256, false>(args, bin_lds[2], st)));
-    ctx->spanEnd(bin_span);
-    timed(3, st);
-    RPVG_HIP_CHECK((launchEm<1024, false>(args, bin_lds[3], st)));
-    ctx->spanEnd(bin_span);
-    timed(10, st);
-    RPVG_HIP_CHECK((launchEm<1024, false, true>(args, bin_lds[10], st)));
-    ctx->spanEnd(bin_span);
-    timed(7, ctx->aux[0]);
-    RPVG_HIP_CHECK((launchEm<1024, true>(args, bin_lds[7], ctx->aux[0])));
-    ctx->spanEnd(bin_span);
-    RPVG_HIP_CHECK((launchEmRegister<2, 32>(args, timed(9, ctx->aux[0]))));
-    ctx->spanEnd(bin_span);
-    timed(0, ctx->aux[1]);
-    RPVG_HIP_CHECK((launchEm<64, true>(args, bin_lds[0], ctx->aux[1])));
-    ctx->spanEnd(bin_span);
-    RPVG_HIP_CHECK((launchEmRegister<1, 32>(args, timed(8, ctx->aux[1]))));
-    ctx->spanEnd(bin_span);
-    timed(1, ctx->aux[2]);
-    RPVG_HIP_CHECK((launchEm<256, true>(args, bin_lds[1], ctx->aux[2])));
-    ctx->spanEnd(bin_span);
-    RPVG_HIP_CHECK(ctx->joinAux());
-    ctx->spanEnd(span);
-    for (int b = 0; b < kBins; ++b) ctx->stats.em_sparse_launches += bins[b].empty() ? 0 : 1;
+    std::unique_ptr<HostScope> scope(new HostScope("em_solve: launches"));
+    rc = queueEmSolve(ctx, batch, ps.list, max_em_its, max_rel_em_conv, out, ps.work, false);
+    if (rc != RPVG_HIP_OK) return rc;
 
     scope.reset(new HostScope("em_solve: wait for the kernels + download"));
-    RPVG_HIP_CHECK(out.fetch(st));
+    RPVG_HIP_CHECK(outputs.fetch(st));
     RPVG_HIP_CHECK(hipStreamSynchronize(st));
-    out.scatter();
+    outputs.scatter();
     scope.reset();
-
-    // algorithmic bytes: per iteration 12 B per entry (value + column), 20 B
-    // per row (count, noise, offset), 16 B per column (a read + a' write)
-    double bytes = 0;
-    uint64_t its_total = 0;
-    for (int b = 0; b < kBins; ++b) {
-        if (bins[b].empty()) continue;
-        rpvg_hip_em_kernel_stats & ks = ctx->stats.em_kernel[b];
-        uint32_t slowest = 0;
-        double bin_bytes = 0;
-        uint64_t bin_its = 0;
-        for (const uint32_t p : bins[b]) {
-            const double C = static_cast<double>(problems->col_off[p + 1] - problems->col_off[p]) + 1;
-            bin_bytes += static_cast<double>(results->iterations[p]) * (12.0 * kept_ent[p] + 20.0 * kept_rows[p] + 16.0 * C);
-            bin_its += results->iterations[p];
-            slowest = std::max(slowest, results->iterations[p]);
-        }
-        ks.launches += 1;
-        ks.problems += bins[b].size();
-        ks.iterations += bin_its;
-        ks.max_iterations += slowest;
-        ks.alg_bytes += bin_bytes;
-        bytes += bin_bytes;
-        its_total += bin_its;
-    }
-    ctx->stats.em_sparse_alg_bytes += bytes;
-    ctx->stats.em_iterations_total += its_total;
+    accountEmSolve(ctx, P, problems->col_off, kept_rows.data(), kept_ent.data(), results->iterations);
     return RPVG_HIP_OK;
 }
 
@@ -1224,8 +1424,17 @@ extern "C" int rpvg_hip_gibbs_read_counts(rpvg_hip_ctx * ctx, const rpvg_hip_bat
     RPVG_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
 
-    ProblemSet ps;
-    const int rc = buildProblemSet(ctx, batch, problems, ps, "rpvg_hip_gibbs_read_counts");
+    // the compacted CSR of the problems, as for the EM (fill only: no queues, no EM kernels)
+    DeviceBuffer<uint32_t> d_iters, d_kept_rows, d_kept_ent;
+    DeviceBuffer<double> d_total;
+    RPVG_HIP_CHECK(d_kept_rows.alloc(P));
+    RPVG_HIP_CHECK(d_kept_ent.alloc(P));
+    RPVG_HIP_CHECK(d_total.alloc(P));
+    EmOutputs out{nullptr, nullptr, nullptr, d_kept_rows.ptr, d_kept_ent.ptr, d_total.ptr};
+    HostProblemSet ps;
+    int rc = prepareHostProblems(ctx, batch, problems, ps, out, "rpvg_hip_gibbs_read_counts");
+    if (rc != RPVG_HIP_OK) return rc;
+    rc = queueEmSolve(ctx, batch, ps.list, 1, 0.0, out, ps.work, true);
     if (rc != RPVG_HIP_OK) return rc;
 
     DeviceBuffer<double> d_init_abund, d_init_noise, d_noise_samples, d_abund_samples;
@@ -1245,14 +1454,14 @@ extern "C" int rpvg_hip_gibbs_read_counts(rpvg_hip_ctx * ctx, const rpvg_hip_bat
     args.col_off = ps.d_col_off.ptr;
     args.row_base = ps.d_row_base.ptr;
     args.ent_base = ps.d_ent_base.ptr;
-    args.kept_rows = ps.d_kept_rows.ptr;
-    args.zero_mass = ps.d_zero.ptr;
-    args.total_mass = ps.d_total.ptr;
-    args.prow_off = ps.d_prow_off.ptr;
-    args.prow_count = ps.d_prow_count.ptr;
-    args.prow_noise = ps.d_prow_noise.ptr;
-    args.pent_col = ps.d_pent_col.ptr;
-    args.pent_val = ps.d_pent_val.ptr;
+    args.kept_rows = d_kept_rows.ptr;
+    args.zero_mass = ps.work.d_zero.ptr;
+    args.total_mass = d_total.ptr;
+    args.prow_off = ps.work.d_prow_off.ptr;
+    args.prow_count = ps.work.d_prow_count.ptr;
+    args.prow_noise = ps.work.d_prow_noise.ptr;
+    args.pent_col = ps.work.d_pent_col.ptr;
+    args.pent_val = ps.work.d_pent_val.ptr;
     args.init_abundances = d_init_abund.ptr;
     args.init_noise_count = d_init_noise.ptr;
     args.num_samples = d_num_samples.ptr;
@@ -1264,9 +1473,9 @@ extern "C" int rpvg_hip_gibbs_read_counts(rpvg_hip_ctx * ctx, const rpvg_hip_bat
     args.noise_samples = d_noise_samples.ptr;
     args.abundance_samples = d_abund_samples.ptr;
 
-    const size_t lds = (sizeof(double) * (2 * static_cast<size_t>(ps.max_cols) + 256 / 64 + 2) + 15) & ~static_cast<size_t>(15);
+    const size_t lds = (sizeof(double) * (2 * static_cast<size_t>(ps.list.max_cols) + 256 / 64 + 2) + 15) & ~static_cast<size_t>(15);
     RPVG_REQUIRE(lds <= 160 * 1024, "rpvg_hip_gibbs_read_counts: a problem with %u columns does not fit the sampler's LDS-resident vectors (limit ~10 000 columns)",
-                 ps.max_cols);
+                 ps.list.max_cols);
     if (lds > 64 * 1024) {
         RPVG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbsReadCountKernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
