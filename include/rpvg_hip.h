@@ -36,7 +36,8 @@ typedef enum rpvg_hip_status {
     RPVG_HIP_ERR_NO_DEVICE = -1,  /* no gfx950-compatible GPU / HIP runtime unusable */
     RPVG_HIP_ERR_RUNTIME = -2,    /* a HIP call failed (see last_error)              */
     RPVG_HIP_ERR_INVALID = -3,    /* argument validation failed                      */
-    RPVG_HIP_ERR_ALLOC = -4       /* host or device allocation failed                */
+    RPVG_HIP_ERR_ALLOC = -4,      /* host or device allocation failed                */
+    RPVG_HIP_ERR_UNSUPPORTED = -5 /* the call does not take this input; the caller uses the calls it stands for (nothing was changed) */
 } rpvg_hip_status;
 
 typedef struct rpvg_hip_ctx rpvg_hip_ctx;
@@ -230,6 +231,38 @@ int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_hip_groups *
                                      double min_rel_likelihood, rpvg_hip_pair_posteriors ** result_out);
 int rpvg_hip_pair_posteriors_get(const rpvg_hip_pair_posteriors * result, rpvg_hip_pair_posteriors_view * view_out);
 void rpvg_hip_pair_posteriors_free(rpvg_hip_pair_posteriors * result);
+
+/* ---- diploid search -> retained path subsets -> EM, in one call ------------------- */
+/* NestedPathAbundanceEstimator::inferAbundancesCollapsedGroups (src/path_abundance_estimator.cpp:428-471) from the group
+ * matrices on: rpvg_hip_bounded_pair_posteriors, then selectPathSubsetIndices (:569-606: diplotypes with posterior >=
+ * min_hap_prob, each expanded to the sorted list of the paths of its two haplotype columns, identical lists merged,
+ * weights renormalised), then for every subset that keeps a weight >= min_hap_prob (:627-630) the EM of rpvg_hip_em_solve
+ * on its distinct paths (:637-671) — with nothing but a 64-byte header crossing to the host in between (round 2 made two
+ * round trips there: 1.2 ms of a lane's critical path at 32 host threads, 8 ms at 4).  The posterior-weighted merge of
+ * the solutions (:702-749) stays with the caller.
+ * Subsets of a matrix come in lexicographic order of their path lists.  Returns RPVG_HIP_ERR_UNSUPPORTED, having changed
+ * nothing, when it does not take the input (min_hap_prob below 1/1024; a cluster too wide for LDS-resident EM vectors;
+ * more subsets than the capacity it reserved — it then reserves by what it saw on the next call): the caller makes the
+ * three calls instead. */
+typedef struct rpvg_hip_subset_em rpvg_hip_subset_em;
+typedef struct rpvg_hip_subset_em_view {
+    uint32_t num_matrices;
+    const uint64_t * subset_off;   /* [M+1] retained subsets of each matrix                                        */
+    const double * weight;         /* [S]   normalised posterior mass of the subset (:602-605)                        */
+    const uint64_t * path_off;     /* [S+1]                                                                          */
+    const uint32_t * path;         /*       sorted cluster-local paths of the subset, a homozygous path twice (:583-593) */
+    const uint64_t * col_off;      /* [S+1]                                                                          */
+    const uint32_t * col_path;     /*       its distinct paths = the columns of its EM problem (:637-656)            */
+    const double * abundances;     /*       expected read counts, laid out like col_path                             */
+    const double * noise_count;    /* [S]                                                                            */
+    const double * total_count;    /* [S]                                                                            */
+    const uint32_t * iterations;   /* [S]   EM iterations executed                                                   */
+} rpvg_hip_subset_em_view;
+int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_groups * groups,
+                              const uint32_t * column_counts, double min_rel_likelihood, double min_hap_prob,
+                              uint32_t max_em_its, double max_rel_em_conv, rpvg_hip_subset_em ** result_out);
+int rpvg_hip_subset_em_get(const rpvg_hip_subset_em * result, rpvg_hip_subset_em_view * view_out);
+void rpvg_hip_subset_em_free(rpvg_hip_subset_em * result);
 
 /* ---- minimum path cover (`-i strains`) ------------------------------------ */
 /* For every listed cluster: the read-path cover and path weights of MinimumPathAbundanceEstimator::estimate

@@ -1035,31 +1035,21 @@ __global__ void compactPairsBlockKernel(const uint32_t num_matrices, const uint6
 
 }  // namespace
 
-extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups,
-                                                const uint32_t * column_counts, double min_rel_likelihood,
-                                                rpvg_hip_pair_posteriors ** result_out) {
-    RPVG_REQUIRE(ctx && groups && result_out, "rpvg_hip_bounded_pair_posteriors: NULL argument");
-    *result_out = nullptr;
-    RPVG_REQUIRE(min_rel_likelihood > 0, "rpvg_hip_bounded_pair_posteriors: min_rel_likelihood must be positive");
+namespace rpvg_hip_detail {
+
+// The diploid search of every matrix of `groups`, queued on the context's streams (no host synchronisation): afterwards
+// w.d_tail[m] holds the number of kept pairs of matrix m and w.d_out_first / second / value, at w.d_pair_cap_off[m], the
+// pairs in the order the reference keeps them.  The caller holds ctx->mutex and calls searchGateLeave when what it
+// queues behind the search may run next to another context's search.  (rpvg_hip_bounded_pair_posteriors, below, brings
+// the pairs to the host; subset_em.hip consumes them on the device.)
+int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const uint32_t * column_counts, const double min_rel_likelihood,
+                    PairSearchWork & w) {
     std::unique_ptr<HostScope> scope(new HostScope("bounded search: host order + work items"));
     const uint32_t M = groups->num_matrices;
-    rpvg_hip_pair_posteriors * res = new (std::nothrow) rpvg_hip_pair_posteriors();
-    if (!res) {
-        setError("rpvg_hip_bounded_pair_posteriors: out of host memory");
-        return RPVG_HIP_ERR_ALLOC;
-    }
-    res->pair_off.assign(M + 1, 0);
-    if (M == 0) {
-        *result_out = res;
-        return RPVG_HIP_OK;
-    }
-    if (!column_counts) {
-        delete res;
-        setError("rpvg_hip_bounded_pair_posteriors: column_counts is NULL");
-        return RPVG_HIP_ERR_INVALID;
-    }
-
-    std::vector<uint64_t> col_off(M + 1, 0), pair_cap_off(M + 1, 0);
+    w.M = M;
+    std::vector<uint64_t> & col_off = w.col_off, & pair_cap_off = w.pair_cap_off;
+    col_off.assign(M + 1, 0);
+    pair_cap_off.assign(M + 1, 0);
     for (uint32_t m = 0; m < M; ++m) {
         const uint64_t G = groups->h_num_cols[m];
         col_off[m + 1] = col_off[m] + G;
@@ -1067,13 +1057,13 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     }
     for (uint64_t c = 0; c < col_off[M]; ++c) {
         if (column_counts[c] == 0) {
-            delete res;
             setError("rpvg_hip_bounded_pair_posteriors: column %llu has a zero count", static_cast<unsigned long long>(c));
             return RPVG_HIP_ERR_INVALID;
         }
     }
     // expensive matrices first
-    std::vector<uint32_t> order(M);
+    std::vector<uint32_t> & order = w.order;
+    order.assign(M, 0);
     std::iota(order.begin(), order.end(), 0);
     std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         const double wx = static_cast<double>(groups->h_num_rows[x]) * groups->h_num_cols[x] * groups->h_num_cols[x];
@@ -1095,7 +1085,8 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     const bool pair_tiles = tiles_wanted && min_rel_likelihood <= 1;
     if (pair_tiles) table_min_work = 0.0;
     const uint32_t tile_step = kTileA;
-    uint32_t num_big = 0;
+    uint32_t & num_big = w.num_big;
+    num_big = 0;
     std::vector<uint64_t> big_col_part_off(M, 0), big_pair_part_off(M, 0);
     std::vector<uint32_t> item_matrix, item_col, item_chunk;
     uint64_t col_part_total = 0, pair_part_total = 0;
@@ -1134,7 +1125,6 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     }
 
     scope.reset(new HostScope("bounded search: uploads + launches"));
-    std::lock_guard<std::mutex> lock(ctx->mutex);
     hipError_t e = hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
@@ -1161,14 +1151,15 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         show("small", num_big + num_medium, M - num_big - num_medium);
     }
 
-    DeviceBuffer<uint32_t> d_order, d_col_count, d_col_order, d_out_first, d_out_second;
-    DeviceBuffer<uint64_t> d_col_off, d_pair_cap_off, d_pair_off;
-    DeviceBuffer<double> d_lf, d_marg, d_opt_raw, d_opt, d_out_value;
+    auto & d_order = w.d_order; auto & d_col_count = w.d_col_count; auto & d_col_order = w.d_col_order;
+    auto & d_out_first = w.d_out_first; auto & d_out_second = w.d_out_second;
+    auto & d_col_off = w.d_col_off; auto & d_pair_cap_off = w.d_pair_cap_off;
+    auto & d_lf = w.d_lf; auto & d_marg = w.d_marg; auto & d_opt_raw = w.d_opt_raw; auto & d_opt = w.d_opt; auto & d_out_value = w.d_out_value;
 
     // every host array of the search in one block, one copy (UploadPack: a command per array was 1 ms per search)
-    UploadPack pack;
-    DeviceBuffer<uint32_t> d_item_matrix, d_item_col, d_item_chunk;
-    DeviceBuffer<uint64_t> d_big_col_part_off, d_big_pair_part_off;
+    UploadPack & pack = w.pack;
+    auto & d_item_matrix = w.d_item_matrix; auto & d_item_col = w.d_item_col; auto & d_item_chunk = w.d_item_chunk;
+    auto & d_big_col_part_off = w.d_big_col_part_off; auto & d_big_pair_part_off = w.d_big_pair_part_off;
     pack.add(d_order, order.data(), M);
     pack.add(d_col_off, col_off.data(), M + 1);
     pack.add(d_pair_cap_off, pair_cap_off.data(), M + 1);
@@ -1182,8 +1173,12 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     }
     // [kept pairs per matrix: M words | evaluation counter: 2 words | validity flag of the build | -]: what the host reads first
     const uint32_t evals_word = (M + 1) & ~1u, tail_words = evals_word + 4;
-    DeviceBuffer<uint32_t> d_tail;
+    w.evals_word = evals_word;
+    w.tail_words = tail_words;
+    auto & d_tail = w.d_tail;
     pack.addZero(d_tail, tail_words);
+    if (w.extra_u64_count) pack.add(w.d_extra_u64, w.extra_u64, w.extra_u64_count);
+    if (w.extra_zero_bytes) pack.addZero(w.d_extra_zero, w.extra_zero_bytes);
     int span = ctx->spanBegin(FAM_H2D);
     ok(pack.commit(st));
     ctx->spanEnd(span);
@@ -1197,7 +1192,6 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     ok(d_out_second.alloc(pair_cap_off[M]));
     ok(d_out_value.alloc(pair_cap_off[M]));
     if (e != hipSuccess) {
-        delete res;
         setError("rpvg_hip_bounded_pair_posteriors: %s", hipGetErrorString(e));
         return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
     }
@@ -1230,7 +1224,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     args.out_count = d_tail.ptr;
 
     args.log_evals = reinterpret_cast<unsigned long long *>(d_tail.ptr + evals_word);
-    DeviceBuffer<double> d_part_marg, d_part_opt, d_part_pair, d_seq;
+    auto & d_part_marg = w.d_part_marg; auto & d_part_opt = w.d_part_opt; auto & d_part_pair = w.d_part_pair; auto & d_seq = w.d_seq;
     if (num_big > 0) {
         ok(d_part_marg.alloc(col_part_total));
         ok(d_part_opt.alloc(col_part_total));
@@ -1238,7 +1232,6 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         ok(d_seq.alloc(pair_cap_off[M]));
     }
     if (e != hipSuccess) {
-        delete res;
         setError("rpvg_hip_bounded_pair_posteriors: %s", hipGetErrorString(e));
         return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
     }
@@ -1360,6 +1353,70 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     ctx->spanEnd(span);
     ctx->stats.loglik_launches += (num_big > 0 ? 2 : 0) + (num_medium > 0) + (M > num_big + num_medium);
     ok(hipGetLastError());
+    if (e != hipSuccess) {
+        setError("rpvg_hip_bounded_pair_posteriors: %s", hipGetErrorString(e));
+        (void) hipStreamSynchronize(st);
+        return RPVG_HIP_ERR_RUNTIME;
+    }
+    return RPVG_HIP_OK;
+}
+
+void leavePairSearch(rpvg_hip_ctx * ctx) { searchGateLeave(ctx, ctx->stream); }
+
+void accountPairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const PairSearchWork & w, const unsigned long long log_evals,
+                       const uint64_t kept_pairs) {
+    ctx->stats.loglik_evals += static_cast<double>(log_evals);  // counted by the kernels
+    for (uint32_t i = 0; i < w.M; ++i) {
+        const double G = groups->h_num_cols[w.order[i]];
+        ctx->stats.search_pairs_possible += G * (G + 1) / 2;
+        if (i < w.num_big) ctx->stats.search_pairs_table += G * (G + 1) / 2;
+    }
+    ctx->stats.search_pairs_kept += static_cast<double>(kept_pairs);
+}
+
+}  // namespace rpvg_hip_detail
+
+extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups,
+                                                const uint32_t * column_counts, double min_rel_likelihood,
+                                                rpvg_hip_pair_posteriors ** result_out) {
+    RPVG_REQUIRE(ctx && groups && result_out, "rpvg_hip_bounded_pair_posteriors: NULL argument");
+    *result_out = nullptr;
+    RPVG_REQUIRE(min_rel_likelihood > 0, "rpvg_hip_bounded_pair_posteriors: min_rel_likelihood must be positive");
+    const uint32_t M = groups->num_matrices;
+    rpvg_hip_pair_posteriors * res = new (std::nothrow) rpvg_hip_pair_posteriors();
+    if (!res) {
+        setError("rpvg_hip_bounded_pair_posteriors: out of host memory");
+        return RPVG_HIP_ERR_ALLOC;
+    }
+    res->pair_off.assign(M + 1, 0);
+    if (M == 0) {
+        *result_out = res;
+        return RPVG_HIP_OK;
+    }
+    if (!column_counts) {
+        delete res;
+        setError("rpvg_hip_bounded_pair_posteriors: column_counts is NULL");
+        return RPVG_HIP_ERR_INVALID;
+    }
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    PairSearchWork w;
+    {
+        const int rc = queuePairSearch(ctx, groups, column_counts, min_rel_likelihood, w);
+        if (rc != RPVG_HIP_OK) {
+            delete res;
+            return rc;
+        }
+    }
+    hipError_t e = hipSuccess;
+    hipStream_t st = ctx->stream;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    std::unique_ptr<HostScope> scope;
+    const std::vector<uint64_t> & pair_cap_off = w.pair_cap_off;
+    const uint32_t evals_word = w.evals_word, tail_words = w.tail_words;
+    auto & d_tail = w.d_tail; auto & d_pair_cap_off = w.d_pair_cap_off; auto & d_out_first = w.d_out_first;
+    auto & d_out_second = w.d_out_second; auto & d_out_value = w.d_out_value;
+    DeviceBuffer<uint64_t> d_pair_off;
 
     // Offsets of the kept pairs and their dense copy are queued behind the search, and ONE copy brings the host the counts
     // (with the evaluation counter and the validity flag of the matrices' build) and the first megabyte of the dense
@@ -1427,13 +1484,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
             res->first = reinterpret_cast<const uint32_t *>(pairs + total * sizeof(double));
             res->second = res->first + total;
         }
-        ctx->stats.loglik_evals += static_cast<double>(log_evals);  // counted by the kernels
-        for (uint32_t i = 0; i < M; ++i) {
-            const double G = groups->h_num_cols[order[i]];
-            ctx->stats.search_pairs_possible += G * (G + 1) / 2;
-            if (i < num_big) ctx->stats.search_pairs_table += G * (G + 1) / 2;
-        }
-        ctx->stats.search_pairs_kept += static_cast<double>(total);
+        accountPairSearch(ctx, groups, w, log_evals, total);
     }
     if (host_result) pinnedFree(host_result);
     if (e != hipSuccess) {

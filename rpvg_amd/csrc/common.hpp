@@ -563,8 +563,16 @@ struct TimedInterval {
 
 }  // namespace rpvg_hip_detail
 
+namespace rpvg_hip_detail {
+// what the last rpvg_hip_nested_subset_em on a context needed: the next call reserves by it (subset_em.hip)
+struct SubsetEmHints {
+    unsigned long long subsets = 0, list_length = 0, rows = 0, entries = 0;
+};
+}  // namespace rpvg_hip_detail
+
 struct rpvg_hip_ctx {
     static constexpr int kAuxStreams = 6;
+    rpvg_hip_detail::SubsetEmHints subset_hints;
     int device = 0;
     hipStream_t stream = nullptr;
     // Side streams for independent launches of one call (size bins of the batched kernels): their tails
@@ -642,6 +650,13 @@ struct rpvg_hip_groups {
     // same stream and prepares its own launches meanwhile): the temporaries of the build live until the matrices
     // are freed, and the validity flag the kernels set is read by the first consumer (buildError()).
     std::vector<std::shared_ptr<void> > build_temporaries;
+    // the columns of the matrices as lists of cluster-local paths (the build's spec, kept on the device: subset_em.hip
+    // expands the diplotypes the search retains into path subsets): columns of matrix m = [group_off[m], group_off[m + 1])
+    const uint64_t * d_group_off = nullptr;       // [M+1]
+    const uint64_t * d_group_path_off = nullptr;  // [G+1]
+    const uint32_t * d_group_path = nullptr;
+    const uint32_t * d_cluster = nullptr;         // [M] cluster of the batch
+    std::vector<uint32_t> h_cluster, h_max_col_paths, h_num_paths;  // per matrix: cluster, longest column list, paths of the cluster
     rpvg_hip_detail::DeviceBuffer<uint32_t> build_error_flag;
     // row collapse (row_collapse.hip): sort keys and row ids written by the build kernels; [0] matrices replayed,
     // [1] rows that took the values of a run head
@@ -682,6 +697,11 @@ struct EmProblemList {
     const uint64_t * d_row_base = nullptr;    // [P] first compacted row / entry of the problem: a problem keeps at most the
     const uint64_t * d_ent_base = nullptr;    //     rows and entries of its cluster, the storage is laid out by that bound
     uint64_t rows_capacity = 0, entries_capacity = 0;
+    // the rows of every problem's cluster in segments of emFillSegmentRows(): the work items of the compaction
+    const uint64_t * d_seg_first = nullptr;   // [P+1] first item of each problem
+    const uint32_t * d_item_problem = nullptr;  // [items]
+    uint32_t items_bound = 0;                 // number of items, or an upper bound of it when d_num_items is set
+    const uint32_t * d_num_items = nullptr;
     uint32_t max_cols = 0;                    // columns (paths + noise) of the widest problem, or a bound
     uint32_t max_cluster_paths = 0;           // paths of the widest cluster a problem sits on, or a bound
     unsigned long long wide_capacity = 0;     // doubles for the vectors of the problems too wide for LDS
@@ -697,16 +717,40 @@ struct EmOutputs {  // device arrays, [P] unless noted
 };
 
 struct EmSolveWork {  // scratch of one solve: lives until its kernels are done
-    DeviceBuffer<uint32_t> d_prow_off, d_pent_col, d_bucket, d_order;
-    DeviceBuffer<double> d_prow_count, d_prow_noise, d_pent_val, d_zero, d_wide_vectors;
+    DeviceBuffer<uint32_t> d_prow_off, d_pent_col, d_bucket, d_order, d_seg_rows, d_seg_entries;
+    DeviceBuffer<double> d_prow_count, d_prow_noise, d_pent_val, d_zero, d_wide_vectors, d_seg_zero, d_seg_total;
     DeviceBuffer<unsigned long long> d_wide_off;
     DeviceBuffer<unsigned char> d_queues;
+    unsigned char * zeroed_queues = nullptr;  // set by a caller that provides the (zeroed) work queues itself: emQueuesBytes()
 };
+size_t emQueuesBytes();
+uint32_t emFillSegmentRows();
 
 int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProblemList & list, uint32_t max_em_its,
                  double max_rel_em_conv, const EmOutputs & out, EmSolveWork & work, bool fill_only);
 void accountEmSolve(rpvg_hip_ctx * ctx, uint32_t P, const uint64_t * col_off, const uint32_t * kept_rows, const uint32_t * kept_entries,
                     const uint32_t * iterations);
+
+// ---- the diploid search, queued (bounded_search.hip) -----------------------------------------------
+struct PairSearchWork {  // what one search leaves on the device (and the host arrays its statistics need)
+    uint32_t M = 0, num_big = 0, evals_word = 0, tail_words = 0;
+    std::vector<uint32_t> order;
+    std::vector<uint64_t> col_off, pair_cap_off;
+    DeviceBuffer<uint32_t> d_order, d_col_count, d_col_order, d_out_first, d_out_second, d_item_matrix, d_item_col, d_item_chunk;
+    DeviceBuffer<uint32_t> d_tail;  // [kept pairs per matrix: M words | evaluation counter: 2 words | validity flag of the build | -]
+    DeviceBuffer<uint64_t> d_col_off, d_pair_cap_off, d_big_col_part_off, d_big_pair_part_off;
+    DeviceBuffer<double> d_lf, d_marg, d_opt_raw, d_opt, d_out_value, d_part_marg, d_part_opt, d_part_pair, d_seq;
+    UploadPack pack;
+    // what the caller wants uploaded / zeroed with the search's own small arrays (one copy, one memset for everything)
+    const uint64_t * extra_u64 = nullptr;
+    size_t extra_u64_count = 0, extra_zero_bytes = 0;
+    DeviceBuffer<uint64_t> d_extra_u64;
+    DeviceBuffer<unsigned char> d_extra_zero;
+};
+int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const uint32_t * column_counts, double min_rel_likelihood,
+                    PairSearchWork & w);
+void leavePairSearch(rpvg_hip_ctx * ctx);  // the next search of another context may start behind what has been queued so far
+void accountPairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const PairSearchWork & w, unsigned long long log_evals, uint64_t kept_pairs);
 
 // queues the replay of readCollapseProbabilityMatrix on the matrices of `groups` behind their build (row_collapse.hip)
 hipError_t queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups, uint64_t total_rows, double precision, hipStream_t stream);

@@ -7,7 +7,7 @@
 //
 // Pipeline per rpvg_hip_em_solve() call (all on the context's stream):
 //   1. scatterColumnMapKernel   path -> column (or -1) map of every problem
-//   2. fillProblemKernel        ordered compaction into a per-problem CSR of
+//   2. fillSegmentsKernel       ordered compaction into a per-problem CSR of
 //                               row-normalised entries  P_ij/rowsum_i*(1-noise_i),
 //                               at offsets the host knows (a problem keeps at most
 //                               the rows and entries of its cluster); counts the rows
@@ -112,7 +112,7 @@ __device__ __forceinline__ void blockExclusiveScanPair(uint32_t & a, uint32_t & 
 
 // ---- size bins of the EM kernels -----------------------------------------------
 // One kernel variant per bin (rpvg_hip_em_kernel_name); the bin of a problem follows from its columns (paths + noise),
-// kept rows and kept entries alone, so the device decides it (fillProblemKernel) and the host repeats the decision for
+// kept rows and kept entries alone, so the device decides it (fillOffsetsKernel) and the host repeats the decision for
 // the statistics:
 //   0  LDS-resident, one wave      CSR + vectors fit 8 KB
 //   1  LDS-resident, four waves    fit 40 KB
@@ -177,16 +177,28 @@ struct EmQueues {
 };
 
 // ---- 1 + 2. column map, count and fill ------------------------------------------
-// One workgroup per problem: the path -> column map of the problem is built in LDS from its column list (clusters of
-// up to kLdsMapPaths paths; wider ones look their paths up in the sorted list by bisection), then the rows of the
-// problem's cluster are walked in chunks of BLOCK: ordered compaction of the rows that touch a selected path by a
-// block-wide exclusive scan, P / rowsum * (1 - noise) with the reference's two roundings
-// (addNoiseAndNormalizeProbabilityMatrix, src/path_estimator.cpp:156-166).
+// The rows of a problem's cluster are cut into segments of kFillSegmentRows; a work item is one segment of one problem.
+// Three launches:
+//   fillSegmentsKernel<false>  per item: the path -> column map of the problem in LDS (clusters of up to kLdsMapPaths
+//                              paths; wider ones look their paths up in the sorted column list by bisection), then the
+//                              segment's rows that touch a selected path, their entries, and the read mass — counted
+//   fillOffsetsKernel          per problem: exclusive prefix of its segments' counts, the problem's totals, its size bin
+//   fillSegmentsKernel<true>   per item: ordered compaction of the segment behind the rows of the segments before it
+//                              (block-wide exclusive scan per 256 rows), P / rowsum * (1 - noise) with the reference's two
+//                              roundings (addNoiseAndNormalizeProbabilityMatrix, src/path_estimator.cpp:156-166)
+// (Round 2 and the first version of round 3: ONE workgroup per problem walked all rows of its cluster, 256 at a time, two
+// block scans each — a 100 000-row cluster was 400 dependent steps and the kernel, 0.5-0.8 ms per lane, was as long as
+// its largest cluster.)
 constexpr uint32_t kLdsMapPaths = 16384;
+constexpr uint32_t kFillSegmentRows = 1024;
 
 struct FillArgs {
     uint32_t num_problems;                 // upper bound when num_problems_dev is set
     const uint32_t * num_problems_dev;     // null: num_problems is exact
+    uint32_t num_items;                    // segments of all problems; upper bound when num_items_dev is set
+    const uint32_t * num_items_dev;
+    const uint64_t * seg_first;            // [P+1] first item of each problem
+    const uint32_t * item_problem;         // [items]
     const uint32_t * prob_cluster;         // [P]
     const uint64_t * col_off;              // [P+1]
     const uint32_t * col_path;
@@ -204,6 +216,11 @@ struct FillArgs {
     double * prow_noise;
     uint32_t * pent_col;
     double * pent_val;
+    // per item: what the segment keeps (counted), then where it starts inside its problem (fillOffsetsKernel)
+    uint32_t * seg_rows;
+    uint32_t * seg_entries;
+    double * seg_zero_mass;
+    double * seg_total_mass;
     uint32_t * kept_rows;                  // [P] the counts of the problem
     uint32_t * kept_entries;
     double * zero_mass;
@@ -214,96 +231,129 @@ struct FillArgs {
     uint32_t lds_map_paths;                // capacity of the LDS map of this launch (0: bisection for every problem)
 };
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void fillProblemKernel(const FillArgs args) {
+template <bool WRITE>
+__global__ __launch_bounds__(256) void fillSegmentsKernel(const FillArgs args) {
+    constexpr int BLOCK = 256;
     extern __shared__ __attribute__((aligned(16))) int32_t lds_map[];
     __shared__ uint32_t scratch[2 * (BLOCK / 64)];
     __shared__ double dscratch[BLOCK / 64];
-    const uint32_t p = blockIdx.x;
+    const uint32_t num_items = args.num_items_dev ? *args.num_items_dev : args.num_items;
+    uint32_t mapped_problem = UINT32_MAX;
+    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
+        const uint32_t p = args.item_problem[item];
+        const uint32_t segment = static_cast<uint32_t>(item - args.seg_first[p]);
+        const uint32_t k = args.prob_cluster[p];
+        const uint32_t n_paths = static_cast<uint32_t>(args.cluster_path_off[k + 1] - args.cluster_path_off[k]);
+        const uint32_t * cols = args.col_path + args.col_off[p];
+        const uint32_t n_cols = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]);
+        const bool use_map = n_paths <= args.lds_map_paths;
+        __syncthreads();  // (the previous item is done with the map and the scratch)
+        if (use_map && mapped_problem != p) {
+            for (uint32_t i = threadIdx.x; i < n_paths; i += BLOCK) lds_map[i] = -1;
+            __syncthreads();
+            for (uint32_t c = threadIdx.x; c < n_cols; c += BLOCK) lds_map[cols[c]] = static_cast<int32_t>(c);
+            __syncthreads();
+            mapped_problem = p;
+        }
+        auto column_of = [&](const uint32_t path) -> int32_t {
+            if (use_map) return lds_map[path];
+            uint32_t lo = 0, hi = n_cols;  // first column whose path is not below `path`
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (cols[mid] < path) lo = mid + 1;
+                else hi = mid;
+            }
+            return (lo < n_cols && cols[lo] == path) ? static_cast<int32_t>(lo) : -1;
+        };
+        const uint64_t c0 = args.cluster_row_off[k], c1 = args.cluster_row_off[k + 1];
+        const uint64_t r0 = c0 + static_cast<uint64_t>(segment) * kFillSegmentRows, r1 = min(c1, r0 + kFillSegmentRows);
+        const uint64_t rb = WRITE ? args.row_base[p] : 0, eb = WRITE ? args.ent_base[p] : 0;
+        // the offsets array has one extra slot per problem
+        uint32_t * off = WRITE ? args.prow_off + rb + p : nullptr;
+        uint32_t run_rows = WRITE ? args.seg_rows[item] : 0, run_ent = WRITE ? args.seg_entries[item] : 0;  // (starts, by now)
+        double z = 0, t = 0;  // read counts of the rows without a selected path / of all rows
+        for (uint64_t rc = r0; rc < r1; rc += BLOCK) {
+            const uint64_t r = rc + threadIdx.x;
+            uint32_t n = 0;
+            double rowsum = 0;
+            uint64_t e0 = 0, e1 = 0;
+            if (r < r1) {
+                e0 = args.row_ent_off[r];
+                e1 = args.row_ent_off[r + 1];
+                for (uint64_t e = e0; e < e1; ++e) {
+                    if (column_of(args.ent_path[e]) >= 0) {
+                        ++n;
+                        rowsum += args.ent_prob[e];
+                    }
+                }
+                if (!WRITE) {
+                    const double c = args.row_count[r];
+                    t += c;
+                    if (!n) z += c;
+                }
+            }
+            uint32_t slot = n ? 1u : 0u, epos = n, tot_rows, tot_ent;
+            blockExclusiveScanPair<BLOCK>(slot, epos, tot_rows, tot_ent, scratch);
+            if (WRITE && n) {
+                const uint32_t my_row = run_rows + slot;
+                uint32_t my_ent = run_ent + epos;
+                off[my_row] = my_ent;
+                const double nz = args.row_noise[r];
+                args.prow_count[rb + my_row] = args.row_count[r];
+                args.prow_noise[rb + my_row] = nz;
+                const double keep = 1 - nz;
+                for (uint64_t e = e0; e < e1; ++e) {
+                    const int32_t c = column_of(args.ent_path[e]);
+                    if (c >= 0) {
+                        args.pent_col[eb + my_ent] = static_cast<uint32_t>(c);
+                        // addNoiseAndNormalizeProbabilityMatrix: (P / rowsum) * (1 - noise), two roundings
+                        args.pent_val[eb + my_ent] = (args.ent_prob[e] / rowsum) * keep;
+                        ++my_ent;
+                    }
+                }
+            }
+            run_rows += tot_rows;
+            run_ent += tot_ent;
+        }
+        if (!WRITE) {
+            z = blockReduceSum<double, BLOCK>(z, dscratch);
+            t = blockReduceSum<double, BLOCK>(t, dscratch);
+            if (threadIdx.x == 0) {
+                args.seg_rows[item] = run_rows;
+                args.seg_entries[item] = run_ent;
+                args.seg_zero_mass[item] = z;
+                args.seg_total_mass[item] = t;
+            }
+        }
+    }
+}
+
+// per problem: the counts of its segments become their starts; totals, terminal offset, size bin
+__global__ __launch_bounds__(256) void fillOffsetsKernel(const FillArgs args) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (args.num_problems_dev ? *args.num_problems_dev : args.num_problems)) return;
-    const uint32_t k = args.prob_cluster[p];
-    const uint32_t n_paths = static_cast<uint32_t>(args.cluster_path_off[k + 1] - args.cluster_path_off[k]);
-    const uint32_t * cols = args.col_path + args.col_off[p];
-    const uint32_t n_cols = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]);
-    const bool use_map = n_paths <= args.lds_map_paths;
-    if (use_map) {
-        for (uint32_t i = threadIdx.x; i < n_paths; i += BLOCK) lds_map[i] = -1;
-        __syncthreads();
-        for (uint32_t c = threadIdx.x; c < n_cols; c += BLOCK) lds_map[cols[c]] = static_cast<int32_t>(c);
-        __syncthreads();
+    uint32_t rows = 0, entries = 0;
+    double z = 0, t = 0;  // (read counts: integers, exact in any order)
+    for (uint64_t item = args.seg_first[p]; item < args.seg_first[p + 1]; ++item) {
+        const uint32_t r = args.seg_rows[item], e = args.seg_entries[item];
+        args.seg_rows[item] = rows;
+        args.seg_entries[item] = entries;
+        rows += r;
+        entries += e;
+        z += args.seg_zero_mass[item];
+        t += args.seg_total_mass[item];
     }
-    auto column_of = [&](const uint32_t path) -> int32_t {
-        if (use_map) return lds_map[path];
-        uint32_t lo = 0, hi = n_cols;  // first column whose path is not below `path`
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (cols[mid] < path) lo = mid + 1;
-            else hi = mid;
-        }
-        return (lo < n_cols && cols[lo] == path) ? static_cast<int32_t>(lo) : -1;
-    };
-    const uint64_t r0 = args.cluster_row_off[k], r1 = args.cluster_row_off[k + 1];
-    const bool count_only = args.prow_off == nullptr;  // first of two passes when the storage bound does not fit (buildProblemSet)
-    const uint64_t rb = count_only ? 0 : args.row_base[p], eb = count_only ? 0 : args.ent_base[p];
-    // the offsets array has one extra slot per problem
-    uint32_t * off = args.prow_off + rb + p;
-    uint32_t run_rows = 0, run_ent = 0;
-    double z = 0, t = 0;  // read counts of the rows without a selected path / of all rows
-    for (uint64_t rc = r0; rc < r1; rc += BLOCK) {
-        const uint64_t r = rc + threadIdx.x;
-        uint32_t n = 0;
-        double rowsum = 0;
-        uint64_t e0 = 0, e1 = 0;
-        if (r < r1) {
-            e0 = args.row_ent_off[r];
-            e1 = args.row_ent_off[r + 1];
-            for (uint64_t e = e0; e < e1; ++e) {
-                if (column_of(args.ent_path[e]) >= 0) {
-                    ++n;
-                    rowsum += args.ent_prob[e];
-                }
-            }
-            const double c = args.row_count[r];
-            t += c;
-            if (!n) z += c;
-        }
-        uint32_t slot = n ? 1u : 0u, epos = n, tot_rows, tot_ent;
-        blockExclusiveScanPair<BLOCK>(slot, epos, tot_rows, tot_ent, scratch);
-        if (n && !count_only) {
-            const uint32_t my_row = run_rows + slot;
-            uint32_t my_ent = run_ent + epos;
-            off[my_row] = my_ent;
-            const double nz = args.row_noise[r];
-            args.prow_count[rb + my_row] = args.row_count[r];
-            args.prow_noise[rb + my_row] = nz;
-            const double keep = 1 - nz;
-            for (uint64_t e = e0; e < e1; ++e) {
-                const int32_t c = column_of(args.ent_path[e]);
-                if (c >= 0) {
-                    args.pent_col[eb + my_ent] = static_cast<uint32_t>(c);
-                    // addNoiseAndNormalizeProbabilityMatrix: (P / rowsum) * (1 - noise), two roundings
-                    args.pent_val[eb + my_ent] = (args.ent_prob[e] / rowsum) * keep;
-                    ++my_ent;
-                }
-            }
-        }
-        run_rows += tot_rows;
-        run_ent += tot_ent;
+    if (args.prow_off) {
+        args.prow_off[args.row_base[p] + p + rows] = entries;
+        const uint32_t n_cols = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]);
+        const uint32_t bucket = static_cast<uint32_t>(emBinOf(args.rule, n_cols + 1, rows, entries)) * kEmWorkBuckets + emWorkBucket(rows, entries);
+        args.prob_bucket[p] = bucket;
+        atomicAdd(&args.queues->histogram[bucket], 1u);
     }
-    z = blockReduceSum<double, BLOCK>(z, dscratch);
-    t = blockReduceSum<double, BLOCK>(t, dscratch);
-    if (threadIdx.x == 0) {
-        if (!count_only) {
-            off[run_rows] = run_ent;
-            const uint32_t bucket = static_cast<uint32_t>(emBinOf(args.rule, n_cols + 1, run_rows, run_ent)) * kEmWorkBuckets + emWorkBucket(run_rows, run_ent);
-            args.prob_bucket[p] = bucket;
-            atomicAdd(&args.queues->histogram[bucket], 1u);
-        }
-        args.kept_rows[p] = run_rows;
-        args.kept_entries[p] = run_ent;
-        args.zero_mass[p] = z;
-        args.total_mass[p] = t;
-    }
+    args.kept_rows[p] = rows;
+    args.kept_entries[p] = entries;
+    args.zero_mass[p] = z;
+    args.total_mass[p] = t;
 }
 
 // ---- 3. the work queues ------------------------------------------------------------
@@ -1029,8 +1079,11 @@ EmBinRule emBinRule() {
 
 namespace rpvg_hip_detail {
 
+size_t emQueuesBytes() { return sizeof(EmQueues); }
+uint32_t emFillSegmentRows() { return kFillSegmentRows; }
+
 // Everything between a problem list in device memory and its EM results, queued on the context's streams without a host
-// synchronisation: compaction of every problem's rows (fillProblemKernel), the work queues (emOrderKernel), one
+// synchronisation: compaction of every problem's rows (fillSegmentsKernel), the work queues (emOrderKernel), one
 // persistent launch per kernel variant.  Caller holds ctx->mutex and has set the device; `work` must outlive the kernels.
 int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProblemList & list, const uint32_t max_em_its,
                  const double max_rel_em_conv, const EmOutputs & out, EmSolveWork & work, const bool fill_only) {
@@ -1045,18 +1098,26 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     RPVG_HIP_CHECK(work.d_zero.alloc(P));
     RPVG_HIP_CHECK(work.d_bucket.alloc(P));
     RPVG_HIP_CHECK(work.d_order.alloc(P));
-    RPVG_HIP_CHECK(work.d_queues.alloc(sizeof(EmQueues)));
+    if (!work.zeroed_queues) RPVG_HIP_CHECK(work.d_queues.alloc(sizeof(EmQueues)));
     if (list.wide_capacity > 0) {
         RPVG_HIP_CHECK(work.d_wide_vectors.alloc(list.wide_capacity));
         RPVG_HIP_CHECK(work.d_wide_off.alloc(P));
     }
-    EmQueues * queues = reinterpret_cast<EmQueues *>(work.d_queues.ptr);
+    EmQueues * queues = reinterpret_cast<EmQueues *>(work.zeroed_queues ? work.zeroed_queues : work.d_queues.ptr);
 
     int span = ctx->spanBegin(FAM_BUILD);
-    RPVG_HIP_CHECK(hipMemsetAsync(work.d_queues.ptr, 0, sizeof(EmQueues), st));
+    if (!work.zeroed_queues) RPVG_HIP_CHECK(hipMemsetAsync(work.d_queues.ptr, 0, sizeof(EmQueues), st));
+    RPVG_HIP_CHECK(work.d_seg_rows.alloc(list.items_bound));
+    RPVG_HIP_CHECK(work.d_seg_entries.alloc(list.items_bound));
+    RPVG_HIP_CHECK(work.d_seg_zero.alloc(list.items_bound));
+    RPVG_HIP_CHECK(work.d_seg_total.alloc(list.items_bound));
     FillArgs fa;
     fa.num_problems = P;
     fa.num_problems_dev = list.d_num_problems;
+    fa.num_items = list.items_bound;
+    fa.num_items_dev = list.d_num_items;
+    fa.seg_first = list.d_seg_first;
+    fa.item_problem = list.d_item_problem;
     fa.prob_cluster = list.d_cluster;
     fa.col_off = list.d_col_off;
     fa.col_path = list.d_col_path;
@@ -1074,6 +1135,10 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     fa.prow_noise = work.d_prow_noise.ptr;
     fa.pent_col = work.d_pent_col.ptr;
     fa.pent_val = work.d_pent_val.ptr;
+    fa.seg_rows = work.d_seg_rows.ptr;
+    fa.seg_entries = work.d_seg_entries.ptr;
+    fa.seg_zero_mass = work.d_seg_zero.ptr;
+    fa.seg_total_mass = work.d_seg_total.ptr;
     fa.kept_rows = out.d_kept_rows;
     fa.kept_entries = out.d_kept_entries;
     fa.zero_mass = work.d_zero.ptr;
@@ -1082,9 +1147,13 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     fa.queues = queues;
     fa.rule = rule;
     fa.lds_map_paths = std::min<uint32_t>(list.max_cluster_paths, kLdsMapPaths);
-    fillProblemKernel<256><<<dim3(P), dim3(256), fa.lds_map_paths * sizeof(int32_t), st>>>(fa);
+    // (the segment kernels walk the items with a grid of a few workgroups per CU: an item is at most 1 024 rows)
+    const uint32_t fill_grid = std::min<uint32_t>(list.items_bound, static_cast<uint32_t>(ctx->props.multiProcessorCount) * 8);
+    fillSegmentsKernel<false><<<dim3(fill_grid), dim3(256), fa.lds_map_paths * sizeof(int32_t), st>>>(fa);
+    fillOffsetsKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(fa);
+    fillSegmentsKernel<true><<<dim3(fill_grid), dim3(256), fa.lds_map_paths * sizeof(int32_t), st>>>(fa);
     RPVG_HIP_CHECK(hipGetLastError());
-    ctx->stats.build_launches += 1;
+    ctx->stats.build_launches += 3;
     if (fill_only) {
         ctx->spanEnd(span);
         return RPVG_HIP_OK;
@@ -1121,7 +1190,11 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
 
     // The bins are independent, so their tails (a small problem that needs thousands of iterations, a giant one with
     // many rows) should overlap — but only as many kernels run side by side as the runtime has hardware queues.
-    // Workgroups of a persistent launch: what the GPU holds of the variant at once, or the bound on the problems if smaller.
+    // Workgroups of a persistent launch: one or two per CU (or the bound on the problems if smaller) — every workgroup of a
+    // grid costs the dispatcher ~40 ns even if it finds its bin empty, and the host launches all variants blindly: grids
+    // sized by what the GPU could hold (4 096 waves for the register kernel) were 20 000 idle workgroups per call, 0.7 ms
+    // of dispatcher time next to the other lane's kernels.  A queue of 1 200 short problems drains through 512 waves in
+    // tens of microseconds; the problems that run for thousands of iterations start that much later at the most.
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
     auto grid = [&](const uint32_t per_cu) { return std::min<uint32_t>(P, cus * per_cu); };
     const size_t streamed_lds_256 = emLdsBytes(list.max_cols, 0, 0, 256, false), streamed_lds_1024 = emLdsBytes(list.max_cols, 0, 0, 1024, false);
@@ -1141,36 +1214,36 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         return on;
     };
     // (chains of launches that share a stream run one after the other: balanced by the kernels' usual durations)
-    RPVG_HIP_CHECK((launchEmRegister<4, 16>(args, grid(4), timed(6, s_reg4))));
+    RPVG_HIP_CHECK((launchEmRegister<4, 16>(args, grid(2), timed(6, s_reg4))));
     ctx->spanEnd(bin_span);
-    RPVG_HIP_CHECK((launchEmRegister<1, 16>(args, grid(16), timed(4, s_reg1))));
+    RPVG_HIP_CHECK((launchEmRegister<1, 16>(args, grid(2), timed(4, s_reg1))));
     ctx->spanEnd(bin_span);
-    RPVG_HIP_CHECK((launchEmRegister<2, 16>(args, grid(8), timed(5, s_reg2))));
+    RPVG_HIP_CHECK((launchEmRegister<2, 16>(args, grid(2), timed(5, s_reg2))));
     ctx->spanEnd(bin_span);
     timed(2, st);
-    RPVG_HIP_CHECK((launchEm<256, false>(args, grid(4), std::min(streamed_lds_256, kEmLdsLimit), st)));
+    RPVG_HIP_CHECK((launchEm<256, false>(args, grid(1), std::min(streamed_lds_256, kEmLdsLimit), st)));
     ctx->spanEnd(bin_span);
     timed(3, ctx->aux[0]);
-    RPVG_HIP_CHECK((launchEm<1024, false>(args, grid(2), std::min(streamed_lds_1024, kEmLdsLimit), ctx->aux[0])));
+    RPVG_HIP_CHECK((launchEm<1024, false>(args, grid(1), std::min(streamed_lds_1024, kEmLdsLimit), ctx->aux[0])));
     ctx->spanEnd(bin_span);
     timed(7, ctx->aux[0]);
     RPVG_HIP_CHECK((launchEm<1024, true>(args, grid(1), 152 * 1024, ctx->aux[0])));
     ctx->spanEnd(bin_span);
     timed(0, ctx->aux[1]);
-    RPVG_HIP_CHECK((launchEm<64, true>(args, grid(16), 8 * 1024, ctx->aux[1])));
+    RPVG_HIP_CHECK((launchEm<64, true>(args, grid(2), 8 * 1024, ctx->aux[1])));
     ctx->spanEnd(bin_span);
     timed(1, ctx->aux[2]);
-    RPVG_HIP_CHECK((launchEm<256, true>(args, grid(4), 40 * 1024, ctx->aux[2])));
+    RPVG_HIP_CHECK((launchEm<256, true>(args, grid(2), 40 * 1024, ctx->aux[2])));
     ctx->spanEnd(bin_span);
     if (list.max_cols > 16) {
-        RPVG_HIP_CHECK((launchEmRegister<1, 32>(args, grid(8), timed(8, ctx->aux[2]))));
+        RPVG_HIP_CHECK((launchEmRegister<1, 32>(args, grid(1), timed(8, ctx->aux[2]))));
         ctx->spanEnd(bin_span);
-        RPVG_HIP_CHECK((launchEmRegister<2, 32>(args, grid(4), timed(9, ctx->aux[2]))));
+        RPVG_HIP_CHECK((launchEmRegister<2, 32>(args, grid(1), timed(9, ctx->aux[2]))));
         ctx->spanEnd(bin_span);
     }
     if (wide_possible) {
         timed(10, s_reg2);
-        RPVG_HIP_CHECK((launchEm<1024, false, true>(args, grid(2), sizeof(double) * (1024 / 64 + 2), s_reg2)));
+        RPVG_HIP_CHECK((launchEm<1024, false, true>(args, grid(1), sizeof(double) * (1024 / 64 + 2), s_reg2)));
         ctx->spanEnd(bin_span);
     }
     RPVG_HIP_CHECK(ctx->joinAux());
@@ -1218,8 +1291,8 @@ namespace {
 struct HostProblemSet {
     EmProblemList list;
     EmSolveWork work;
-    DeviceBuffer<uint32_t> d_cluster, d_col_path;
-    DeviceBuffer<uint64_t> d_col_off, d_row_base, d_ent_base;
+    DeviceBuffer<uint32_t> d_cluster, d_col_path, d_item_problem;
+    DeviceBuffer<uint64_t> d_col_off, d_row_base, d_ent_base, d_seg_first;
     UploadPack uploads;
     uint64_t n_cols_total = 0;
 };
@@ -1273,6 +1346,19 @@ int prepareHostProblems(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const 
     }
     ps.n_cols_total = problems->col_off[P];
     list.P_bound = P;
+    // work items of the compaction: the rows of every problem's cluster in segments
+    std::vector<uint64_t> seg_first(P + 1, 0);
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t k = problems->cluster[p];
+        const uint64_t rows = batch->h_cluster_row_off[k + 1] - batch->h_cluster_row_off[k];
+        seg_first[p + 1] = seg_first[p] + (rows + kFillSegmentRows - 1) / kFillSegmentRows;
+    }
+    RPVG_REQUIRE(seg_first[P] < 0xffffffffull, "%s: too many row segments (%llu)", who, static_cast<unsigned long long>(seg_first[P]));
+    std::vector<uint32_t> item_problem(seg_first[P]);
+    for (uint32_t p = 0; p < P; ++p) {
+        for (uint64_t item = seg_first[p]; item < seg_first[p + 1]; ++item) item_problem[item] = p;
+    }
+    list.items_bound = static_cast<uint32_t>(seg_first[P]);
 
     scope.reset(new HostScope("problems: uploads"));
     hipStream_t st = ctx->stream;
@@ -1285,6 +1371,8 @@ int prepareHostProblems(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const 
     ps.uploads.add(ps.d_cluster, problems->cluster, P);
     ps.uploads.add(ps.d_col_off, problems->col_off, P + 1);
     ps.uploads.add(ps.d_col_path, problems->col_path, ps.n_cols_total);
+    ps.uploads.add(ps.d_seg_first, seg_first.data(), P + 1);
+    ps.uploads.add(ps.d_item_problem, item_problem.data(), item_problem.size());
     if (by_bound) {
         ps.uploads.add(ps.d_row_base, row_base.data(), P);
         ps.uploads.add(ps.d_ent_base, ent_base.data(), P);
@@ -1295,6 +1383,8 @@ int prepareHostProblems(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const 
     list.d_cluster = ps.d_cluster.ptr;
     list.d_col_off = ps.d_col_off.ptr;
     list.d_col_path = ps.d_col_path.ptr;
+    list.d_seg_first = ps.d_seg_first.ptr;
+    list.d_item_problem = ps.d_item_problem.ptr;
     if (!by_bound) {
         scope.reset(new HostScope("problems: counting pass"));
         // counts only: no storage, no queues
@@ -1302,6 +1392,9 @@ int prepareHostProblems(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const 
         count_list.rows_capacity = count_list.entries_capacity = 0;
         FillArgs fa{};
         fa.num_problems = P;
+        fa.num_items = list.items_bound;
+        fa.seg_first = list.d_seg_first;
+        fa.item_problem = list.d_item_problem;
         fa.prob_cluster = list.d_cluster;
         fa.col_off = list.d_col_off;
         fa.col_path = list.d_col_path;
@@ -1312,15 +1405,26 @@ int prepareHostProblems(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const 
         fa.ent_prob = batch->ent_prob.ptr;
         fa.row_count = batch->row_count.ptr;
         fa.row_noise = batch->row_noise.ptr;
-        DeviceBuffer<double> d_zero;
+        DeviceBuffer<double> d_zero, d_seg_zero, d_seg_total;
+        DeviceBuffer<uint32_t> d_seg_rows, d_seg_entries;
         RPVG_HIP_CHECK(d_zero.alloc(P));
+        RPVG_HIP_CHECK(d_seg_zero.alloc(list.items_bound));
+        RPVG_HIP_CHECK(d_seg_total.alloc(list.items_bound));
+        RPVG_HIP_CHECK(d_seg_rows.alloc(list.items_bound));
+        RPVG_HIP_CHECK(d_seg_entries.alloc(list.items_bound));
+        fa.seg_rows = d_seg_rows.ptr;
+        fa.seg_entries = d_seg_entries.ptr;
+        fa.seg_zero_mass = d_seg_zero.ptr;
+        fa.seg_total_mass = d_seg_total.ptr;
         fa.kept_rows = out.d_kept_rows;
         fa.kept_entries = out.d_kept_entries;
         fa.zero_mass = d_zero.ptr;
         fa.total_mass = out.d_total;
         fa.rule = emBinRule();
         fa.lds_map_paths = std::min<uint32_t>(list.max_cluster_paths, kLdsMapPaths);
-        fillProblemKernel<256><<<dim3(P), dim3(256), fa.lds_map_paths * sizeof(int32_t), st>>>(fa);
+        const uint32_t fill_grid = std::min<uint32_t>(list.items_bound, static_cast<uint32_t>(ctx->props.multiProcessorCount) * 8);
+        fillSegmentsKernel<false><<<dim3(fill_grid), dim3(256), fa.lds_map_paths * sizeof(int32_t), st>>>(fa);
+        fillOffsetsKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(fa);
         RPVG_HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> kept_rows(P), kept_ent(P);
         RPVG_HIP_CHECK(hipMemcpyAsync(kept_rows.data(), out.d_kept_rows, P * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

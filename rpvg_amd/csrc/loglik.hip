@@ -476,6 +476,13 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         }
         rows[m] = R;
         cols[m] = static_cast<uint32_t>(g1 - g0);
+        {
+            uint64_t longest = 0;
+            for (uint64_t c = g0; c < g1; ++c) longest = std::max<uint64_t>(longest, spec->group_path_off[c + 1] - spec->group_path_off[c]);
+            g->h_max_col_paths.push_back(static_cast<uint32_t>(std::min<uint64_t>(longest, 0xffffffffu)));
+            g->h_num_paths.push_back(static_cast<uint32_t>(N));
+            g->h_cluster.push_back(k);
+        }
         row0[m] = batch->h_cluster_row_off[k];
         num_paths[m] = N;
         val_off[m] = val_total;
@@ -515,7 +522,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     // temporaries: owned by the matrices object (the kernels that use them may still be queued on return)
     struct BuildTemporaries {
         DeviceBuffer<uint64_t> inc_off, path_grp_off, group_off, group_path_off, num_paths;
-        DeviceBuffer<uint32_t> path_grp, item_matrix, item_chunk, tile_matrix, tile_chunk, group_path, degree, cursor;
+        DeviceBuffer<uint32_t> path_grp, item_matrix, item_chunk, tile_matrix, tile_chunk, group_path, degree, cursor, cluster;
         DeviceBuffer<unsigned char> scan_tmp;
     };
     std::shared_ptr<BuildTemporaries> tmp = std::make_shared<BuildTemporaries>();
@@ -557,10 +564,16 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         if (row_total > 0x7fffffffull) e = hipErrorInvalidValue;
         pack.add(g->collapse_segment_off, segment_off.data(), M + 1);
     }
+    DeviceBuffer<uint32_t> & d_cluster = tmp->cluster;
+    pack.add(d_cluster, spec->cluster, M);
     pack.addZero(d_degree, inc_total);
     pack.addZero(d_cursor, inc_total);
     pack.addZero(d_error, 1);
     ok(pack.commit(st));
+    g->d_group_off = d_group_off.ptr;
+    g->d_group_path_off = d_group_path_off.ptr;
+    g->d_group_path = d_group_path.ptr;
+    g->d_cluster = d_cluster.ptr;
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(M * 60 + num_columns * 8 + num_incidences * 4 + (item_matrix.size() + tile_matrix.size()) * 8);
     sub.reset(new HostScope("groups_build: allocations"));

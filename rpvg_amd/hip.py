@@ -28,6 +28,7 @@ EXPORTS = [
     "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_comm_init_all", "rpvg_hip_gather", "rpvg_hip_host_register", "rpvg_hip_host_unregister", "rpvg_hip_group_conditionals",
     "rpvg_hip_alignments_upload", "rpvg_hip_alignments_free", "rpvg_hip_read_rows_build", "rpvg_hip_read_rows_to_batch",
     "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_sizes", "rpvg_hip_read_rows_free", "rpvg_hip_path_clusters", "rpvg_hip_debug_log",
+    "rpvg_hip_nested_subset_em", "rpvg_hip_subset_em_get", "rpvg_hip_subset_em_free",
 ]
 
 COMM_ID_BYTES = 128  # RPVG_HIP_COMM_ID_BYTES

@@ -463,6 +463,34 @@ void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstim
         groups_phase.reset();
         first_device_stage();
 
+        // The defaults of `-i haplotype-transcripts` — diploid, branch and bound, no read-count samples — run from the
+        // matrices to the EM solutions in one device call; the host only merges.
+        if (!use_group_post_gibbs && group_size == 2 && num_gibbs_samples == 0) {
+
+            SubsetEmResult device_result;
+
+            if (nestedSubsetAbundances(&device_result, cluster_batch, problems, min_hap_prob, min_hap_prob, max_em_its, max_rel_em_conv)) {
+
+                mergeSubsetSolutions(path_cluster_estimates, cluster_batch, clusters, device_result.view, reset_in_merge);
+
+                ScopedPhase teardown_phase("nested: teardown posterior containers");
+                auto old_problems = std::make_shared<std::vector<GroupPosteriorProblem> >(std::move(problems));
+
+                dropNowOrLater([old_problems](const int threads) {
+
+                    #pragma omp parallel for schedule(static) num_threads(threads)
+                    for (size_t i = 0; i < old_problems->size(); ++i) {
+
+                        std::vector<uint32_t>().swap(old_problems->at(i).column_path);
+                        std::vector<uint32_t>().swap(old_problems->at(i).column_path_off);
+                        std::vector<uint32_t>().swap(old_problems->at(i).column_counts);
+                    }
+                });
+
+                return;
+            }
+        }
+
         std::vector<GroupPosteriors> group_posteriors;
         pathGroupPosteriors(&group_posteriors, cluster_batch, problems, rngs);
 
@@ -832,6 +860,102 @@ void NestedPathAbundanceEstimator::selectPathSubsetIndices(PathSubsetWeights * p
     }
 }
 
+// src/path_abundance_estimator.cpp:702-749 over the subsets and EM solutions of a device call.
+void NestedPathAbundanceEstimator::mergeSubsetSolutions(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const rpvg_hip_subset_em_view & subsets, const bool reset_first) const {
+
+    assert(subsets.num_matrices == clusters.size());
+
+    ScopedPhase merge_phase("nested: weighted merge");
+
+    #pragma omp parallel for schedule(dynamic, clusterChunk()) num_threads(hostThreads())
+    for (size_t i = 0; i < clusters.size(); ++i) {
+
+        auto & estimates = path_cluster_estimates->at(clusters.at(i));
+
+        if (reset_first) {
+
+            estimates.resetEstimates(0, 0);
+        }
+
+        assert(estimates.noise_count == 0);
+        estimates.total_count = cluster_batch.totalReadCount(clusters.at(i));
+
+        // (paths of one transcript inside a subset) -> (probability, abundance per path)
+        std::map<std::vector<uint32_t>, std::pair<double, std::vector<double> > > path_group_estimates;
+
+        double sum_hap_prob = 0;
+
+        const uint64_t first_subset = subsets.subset_off[i];
+        const uint64_t last_subset = subsets.subset_off[i + 1];
+
+        estimates.em_iterations.reserve(last_subset - first_subset);
+        estimates.em_problem_paths.reserve(last_subset - first_subset);
+
+        // the subsets come in lexicographic order of their path lists: the order of the ordered map of the separate calls
+        for (uint64_t s = first_subset; s < last_subset; ++s) {
+
+            const double weight = subsets.weight[s];
+            assert(weight >= min_hap_prob);
+
+            sum_hap_prob += weight;
+
+            const uint32_t * path_begin = subsets.path + subsets.path_off[s];
+            const uint32_t * path_end = subsets.path + subsets.path_off[s + 1];
+            const uint32_t * col_begin = subsets.col_path + subsets.col_off[s];
+            const uint32_t * col_end = subsets.col_path + subsets.col_off[s + 1];
+            const double * abundances = subsets.abundances + subsets.col_off[s];
+
+            assert(subsets.total_count[s] == estimates.total_count);
+
+            estimates.em_iterations.emplace_back(subsets.iterations[s]);
+            estimates.em_problem_paths.emplace_back(col_begin, col_end);
+
+            estimates.noise_count += subsets.noise_count[s] * weight;
+
+            std::map<uint32_t, std::vector<uint32_t> > subset_path_group_index;
+
+            for (const uint32_t * path = path_begin; path != path_end; ++path) {
+
+                subset_path_group_index[estimates.paths.at(*path).group_id].emplace_back(*path);
+            }
+
+            for (auto & path_group: subset_path_group_index) {
+
+                assert(path_group.second.size() <= group_size);
+
+                auto path_group_estimates_it = path_group_estimates.emplace(path_group.second, std::make_pair(0.0, std::vector<double>(path_group.second.size(), 0)));
+                path_group_estimates_it.first->second.first += weight;
+
+                for (size_t j = 0; j < path_group.second.size(); ++j) {
+
+                    const uint32_t path = path_group.second.at(j);
+
+                    const auto column_it = std::lower_bound(col_begin, col_end, path);
+                    assert(column_it != col_end && *column_it == path);
+
+                    const uint32_t multiplicity = std::count(path_begin, path_end, path);
+
+                    path_group_estimates_it.first->second.second.at(j) += (abundances[column_it - col_begin] * weight / multiplicity);
+                }
+            }
+        }
+
+        estimates.path_group_sets.reserve(path_group_estimates.size());
+        estimates.posteriors.reserve(path_group_estimates.size());
+
+        for (auto & group_estimates: path_group_estimates) {
+
+            estimates.path_group_sets.emplace_back(group_estimates.first);
+            estimates.posteriors.emplace_back(group_estimates.second.first);
+            estimates.abundances.insert(estimates.abundances.end(), group_estimates.second.second.begin(), group_estimates.second.second.end());
+        }
+
+        // (see inferPathSubsetAbundance for the tolerance)
+        assert(sum_hap_prob < 1 + 1e-9);
+        estimates.noise_count += std::max(0.0, 1 - sum_hap_prob) * estimates.total_count;
+    }
+}
+
 // src/path_abundance_estimator.cpp:608-750 for all clusters at once.
 void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples, std::vector<std::mt19937> * rngs, const bool reset_first) const {
 
@@ -1029,7 +1153,7 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
         // tests/fuzz_parity.py).  A library does not end its host process over that: the arithmetic is the reference's, the check keeps
         // the tolerance of an actual error.
         assert(sum_hap_prob < 1 + 1e-9);
-        estimates.noise_count += (1 - sum_hap_prob) * estimates.total_count;
+        estimates.noise_count += std::max(0.0, 1 - sum_hap_prob) * estimates.total_count;
     }
 
     merge_phase.reset();

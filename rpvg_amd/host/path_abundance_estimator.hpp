@@ -109,6 +109,10 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
         void sampleGroupPathIndices(std::vector<std::vector<uint32_t> > * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<uint32_t> & group, std::mt19937 * mt_rng) const;
         void selectPathSubsetIndices(PathSubsetWeights * path_subset_samples, const GroupPosteriors & group_posteriors, const GroupPosteriorProblem & problem) const;
 
+        // The weighted merge (src/path_abundance_estimator.cpp:702-749) of the subsets and EM solutions the device left
+        // (PathEstimator::nestedSubsetAbundances): matrix i of the result belongs to clusters.at(i).
+        void mergeSubsetSolutions(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const rpvg_hip_subset_em_view & subsets, bool reset_first) const;
+
         void inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples, std::vector<std::mt19937> * rngs, bool reset_first) const;
 };
 

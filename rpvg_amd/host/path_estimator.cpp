@@ -836,6 +836,44 @@ void PathEstimator::calculatePathGroupPosteriorsBounded(std::vector<GroupPosteri
     rpvg_hip_pair_posteriors_free(pair_posteriors);
 }
 
+PathEstimator::SubsetEmResult::~SubsetEmResult() {
+
+    rpvg_hip_subset_em_free(result);
+}
+
+bool PathEstimator::nestedSubsetAbundances(SubsetEmResult * result, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const double min_rel_likelihood, const double min_hap_prob, const uint32_t max_em_its, const double max_rel_em_conv) const {
+
+    assert(!result->result);
+
+    if (problems.empty() || std::getenv("RPVG_AMD_HOST_BOUNDED")) {
+
+        return false;
+    }
+
+    ScopedPhase whole_phase("nested: search + subsets + EM on the device");
+
+    const GroupMatrices matrices(engine, cluster_batch, problems, true, prob_precision);
+
+    std::vector<uint32_t> column_counts;
+
+    for (auto & problem: problems) {
+
+        column_counts.insert(column_counts.end(), problem.column_counts.begin(), problem.column_counts.end());
+    }
+
+    const int status = rpvg_hip_nested_subset_em(engine->ctx(), cluster_batch.handle(), matrices.handle(), column_counts.data(), min_rel_likelihood, min_hap_prob, max_em_its, max_rel_em_conv, &result->result);
+
+    if (status == RPVG_HIP_ERR_UNSUPPORTED) {
+
+        return false;
+    }
+
+    HipEngine::check(status, "rpvg_hip_nested_subset_em");
+    HipEngine::check(rpvg_hip_subset_em_get(result->result, &result->view), "rpvg_hip_subset_em_get");
+
+    return true;
+}
+
 void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const bool normalise, const std::vector<std::mt19937 *> & rngs) const {
 
     assert(group_size > 0);

@@ -130,6 +130,30 @@ class PathEstimator {
         // (RPVG_AMD_HOST_BOUNDED=1 selects it).
         void calculatePathGroupPosteriorsBoundedHostDriven(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const double min_rel_likelihood, const bool normalise) const;
 
+        // The diploid search, the selection of path subsets and the EM of every retained subset in ONE device call
+        // (rpvg_hip_nested_subset_em; src/path_abundance_estimator.cpp:440-469 and :625-671): problem i of `problems`
+        // is matrix i of the result.  False when the device does not take the input (the caller runs the separate
+        // calls then); the result owns page-locked host memory.
+        class SubsetEmResult {
+
+            public:
+
+                SubsetEmResult() : result(nullptr) {}
+                ~SubsetEmResult();
+
+                SubsetEmResult(const SubsetEmResult &) = delete;
+                SubsetEmResult & operator=(const SubsetEmResult &) = delete;
+
+                rpvg_hip_subset_em_view view;
+
+            private:
+
+                friend class PathEstimator;
+                rpvg_hip_subset_em * result;
+        };
+
+        bool nestedSubsetAbundances(SubsetEmResult * result, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const double min_rel_likelihood, const double min_hap_prob, const uint32_t max_em_its, const double max_rel_em_conv) const;
+
         // src/path_estimator.cpp:315-330
         static std::vector<double> calcPathLogFrequences(const std::vector<uint32_t> & path_counts);
 };
