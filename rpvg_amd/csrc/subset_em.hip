@@ -605,7 +605,7 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
 
     // What the device path does not take (the caller runs the three calls it replaces): a subset threshold that lets a
     // matrix select more diplotypes than the select kernel holds, clusters whose EM vectors do not fit LDS, the A/B knob.
-    static const bool disabled = std::getenv("RPVG_HIP_NO_DEVICE_SUBSETS") != nullptr;
+    const bool disabled = std::getenv("RPVG_HIP_NO_DEVICE_SUBSETS") != nullptr;  // (read per call: the tests take both ways)
     if (disabled || !(min_hap_prob * kMaxSelected >= 1.0)) {
         setError("rpvg_hip_nested_subset_em: not taken (min_hap_prob %g admits more than %u subsets per cluster, or RPVG_HIP_NO_DEVICE_SUBSETS)",
                  min_hap_prob, kMaxSelected);

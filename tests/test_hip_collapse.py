@@ -118,8 +118,7 @@ def test_planted_close_rows_match_oracle(engine, seed, kw):
     params = make_params(**kw)
     ref, _ = pyoracle.run("haplotype-transcripts", params, batch, 2)
     got, _ = engine.run("haplotype-transcripts", params, engine.prepare(batch))
-    if kw.get("ind_hap_inference"):
-        return  # interleaves generator draws differently from the reference: statistical only (runs, does not compare)
+    # (only independent inference WITH Gibbs posteriors is statistical: fuzz_parity.run_case)
     assert not fuzz_parity.compare(got, ref)
 
 

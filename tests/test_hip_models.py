@@ -400,3 +400,40 @@ def test_reference_shaped_factory_runs_on_the_default_engine(model):
     else:
         post = [float(x) for x in out[out.index("posteriors") + 1:]]
         assert abs(sum(post) - 1.0) < 1e-9
+
+
+def _flat_posterior_clusters(seed, n=3):
+    """Clusters with many haplotype columns and a handful of reads: hundreds of diplotypes pass min_hap_prob."""
+    rng = np.random.default_rng(seed)
+    return ([small_cases.make_cluster(rng, 3, (12, 10, 8), n_haps=30, n_reads=int(rng.integers(3, 7)), empty_read_frac=0.0) for _ in range(n)] +
+            [small_cases.make_cluster(rng, 1, (36,), n_haps=36, n_reads=2, empty_read_frac=0.0),
+             small_cases.make_cluster(rng, 2, (20, 18), n_haps=30, n_reads=1, empty_read_frac=0.0)])
+
+
+def test_device_subset_path_equals_the_separate_calls(engine, monkeypatch):
+    """`-i haplotype-transcripts` through rpvg_hip_nested_subset_em (search -> subsets -> EM on the device) against the
+    three separate calls with the host in between (RPVG_HIP_NO_DEVICE_SUBSETS=1): the same path subsets, weights equal to
+    the bit (the same additions in the same order: src/path_abundance_estimator.cpp:595-605), the same EM iteration
+    counts; both against the oracle.  The flat-posterior clusters take the select kernel's wide variant (more than 64 kept
+    diplotypes per matrix) and give a single matrix hundreds of retained subsets."""
+    clusters = small_cases.make_batch_clusters(8801, n_clusters=40, with_empty=True) + _flat_posterior_clusters(8802)
+    batch = ClusterBatch.from_clusters(clusters)
+    prep = engine.prepare(batch)
+    params = make_params()
+    fused, _ = engine.run("haplotype-transcripts", params, prep)
+    monkeypatch.setenv("RPVG_HIP_NO_DEVICE_SUBSETS", "1")
+    separate, _ = engine.run("haplotype-transcripts", params, prep)
+    monkeypatch.delenv("RPVG_HIP_NO_DEVICE_SUBSETS")
+    most_subsets = 0
+    for k, (f, s) in enumerate(zip(fused, separate)):
+        fk, sk = f.keyed(), s.keyed()
+        assert set(fk) == set(sk), k
+        for key in sk:
+            assert fk[key][0] == sk[key][0], (k, key)  # posteriors: sums of subset weights in the same order
+            assert small_cases.rel_close(fk[key][1], sk[key][1], rel=1e-12, floor=1e-300), (k, key)
+        assert list(f.em_cols) == list(s.em_cols) and list(f.em_iters) == list(s.em_iters), k
+        assert f.total_count == s.total_count and abs(f.noise_count - s.noise_count) <= 1e-12 * max(1.0, s.total_count)
+        most_subsets = max(most_subsets, len(f.em_iters))
+    assert most_subsets > 64, most_subsets  # the wide select kernel was exercised
+    ref, _ = pyoracle.run("haplotype-transcripts", params, batch, 4)
+    _compare(fused, ref)
