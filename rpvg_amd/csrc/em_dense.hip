@@ -25,6 +25,9 @@
 
 #include "common.hpp"
 
+#include <cmath>
+#include <cstring>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -42,6 +45,7 @@ struct DenseControl {
     uint32_t iterations;
     uint32_t conv_its;
     uint32_t viol;  // OR of per-column convergence violations of the current iteration
+    uint32_t error; // row-sharded runs: some rank's column sums were not finite (the status word of the all-reduce)
 };
 
 typedef double dvec2 __attribute__((ext_vector_type(2)));
@@ -215,9 +219,12 @@ __global__ __launch_bounds__(256) void emDenseAccumWideKernel(
 }
 
 // first finalize stage for many partial vectors: slice y of the partials -> one vector per slice
+// status: row-sharded runs — the word behind the C column sums that travels through the all-reduce with them: a rank
+// whose sums are not finite raises it, and every rank stops at the same iteration instead of one of them failing alone
+// and the others waiting in the next collective.
 __global__ void emDenseReducePartialsKernel(const uint32_t C, const uint32_t num_partials, const uint32_t partial_ld,
                                             const double * __restrict__ partials, double * __restrict__ reduced,
-                                            const DenseControl * __restrict__ ctl) {
+                                            const DenseControl * __restrict__ ctl, double * __restrict__ status = nullptr) {
     if (ctl->done) return;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= C) return;
@@ -227,12 +234,18 @@ __global__ void emDenseReducePartialsKernel(const uint32_t C, const uint32_t num
     double acc = 0.0;
     for (uint32_t b = b0; b < b1; ++b) acc += partials[static_cast<uint64_t>(b) * partial_ld + j];
     reduced[static_cast<uint64_t>(blockIdx.y) * partial_ld + j] = acc;
+    if (status && !isfinite(acc)) *status = 1.0;
 }
 
 __global__ void emDenseFinalizeKernel(const uint32_t C, const uint32_t num_partials, const uint32_t partial_ld,
                                       const double * __restrict__ partials, double * __restrict__ a_global,
-                                      const double total_count, const double max_rel_em_conv, DenseControl * ctl) {
+                                      const double total_count, const double max_rel_em_conv, DenseControl * ctl,
+                                      const double * __restrict__ status = nullptr) {
     if (ctl->done) return;
+    if (status && *status != 0.0) {  // (summed over the ranks: somebody's column sums were not finite)
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctl->error = 1;
+        return;
+    }
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     int viol = 0;
     if (j < C) {
@@ -248,6 +261,10 @@ __global__ void emDenseFinalizeKernel(const uint32_t C, const uint32_t num_parti
 
 __global__ void emDenseControlKernel(DenseControl * ctl, const uint32_t max_em_its) {
     if (ctl->done) return;
+    if (ctl->error) {
+        ctl->done = 1;
+        return;
+    }
     ctl->iterations += 1;
     if (ctl->viol == 0) {
         ctl->conv_its += 1;
@@ -366,6 +383,39 @@ namespace {
 int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const double * device_matrix, uint64_t num_rows,
                uint32_t num_cols, uint64_t ld, const double * device_counts, double total_count, uint32_t max_em_its,
                double max_rel_em_conv, double * abundances, double * noise_count, uint32_t * iterations) {
+    // A row-sharded run is a collective: a rank that fails its own checks may not simply leave — its peers would wait for it
+    // in the first all-reduce.  The ranks therefore exchange a status word first (the sum over ranks of "my checks failed"),
+    // and all of them return an error if anybody's did.
+    if (sharded && ctx && ctx->comm) {
+        auto local_checks = [&]() -> int {
+            RPVG_REQUIRE(abundances && noise_count && iterations && ((device_matrix && device_counts) || num_rows == 0), "%s: NULL argument", who);
+            RPVG_REQUIRE(num_cols >= 2, "%s: need at least one path and the noise column", who);
+            RPVG_REQUIRE(ld >= num_cols && (ld % 2) == 0, "%s: ld (%llu) must be even and >= num_cols (%u)", who, static_cast<unsigned long long>(ld), num_cols);
+            RPVG_REQUIRE((reinterpret_cast<uintptr_t>(device_matrix) % 16) == 0, "%s: matrix must be 16-byte aligned", who);
+            RPVG_REQUIRE(num_cols <= 2048, "%s: %u columns exceed the register-resident row limit (2048)", who, num_cols);
+            RPVG_REQUIRE(total_count > 0 && max_em_its > 0, "%s: total_count and max_em_its must be positive", who);
+            const char * inject = std::getenv("RPVG_HIP_INJECT_SHARD_FAILURE");  // test hook: "checks" fails this rank's checks
+            RPVG_REQUIRE(!(inject && std::strcmp(inject, "checks") == 0), "%s: injected failure of the local checks (RPVG_HIP_INJECT_SHARD_FAILURE)", who);
+            return RPVG_HIP_OK;
+        };
+        const int local_rc = local_checks();
+        double peers_failed = 0;
+        {
+            std::lock_guard<std::mutex> lock(ctx->mutex);
+            RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+            DeviceBuffer<double> d_status;
+            const double mine = local_rc == RPVG_HIP_OK ? 0.0 : 1.0;
+            RPVG_HIP_CHECK(d_status.upload(&mine, 1, ctx->stream));
+            if (const int rc = ctx->allReduceSumF64(d_status.ptr, 1)) return rc;
+            RPVG_HIP_CHECK(hipMemcpyAsync(&peers_failed, d_status.ptr, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            RPVG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+        if (local_rc != RPVG_HIP_OK) return local_rc;
+        if (peers_failed != 0) {
+            setError("%s: %g rank(s) of the communicator failed their local checks; nobody entered the EM", who, peers_failed);
+            return RPVG_HIP_ERR_RUNTIME;
+        }
+    }
     RPVG_REQUIRE(ctx && abundances && noise_count && iterations && ((device_matrix && device_counts) || (sharded && num_rows == 0)),
                  "%s: NULL argument", who);
     // (a rank of a row-sharded cluster may hold no rows — fewer rows than ranks —: it contributes zero column sums and
@@ -396,7 +446,10 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
 
     DeviceBuffer<double> d_a, d_partials, d_reduced, d_t;
     if (wide) RPVG_HIP_CHECK(d_reduced.alloc(static_cast<size_t>(reduce_slices) * partial_ld));
-    if (sharded) RPVG_HIP_CHECK(d_t.alloc(partial_ld));
+    if (sharded) {
+        RPVG_HIP_CHECK(d_t.alloc(partial_ld + 2));  // [C column sums | ... | status word at C]
+        RPVG_HIP_CHECK(hipMemsetAsync(d_t.ptr, 0, (partial_ld + 2) * sizeof(double), st));
+    }
     const dim3 col_grid((C + 255) / 256);
     DeviceBuffer<DenseControl> d_ctl;
     RPVG_HIP_CHECK(d_a.alloc(C));
@@ -404,12 +457,16 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
     RPVG_HIP_CHECK(d_ctl.alloc(1));
     RPVG_HIP_CHECK(hipMemsetAsync(d_ctl.ptr, 0, sizeof(DenseControl), st));
     // src/path_abundance_estimator.cpp:54 — 1 / float(C), widened
-    const double a0 = static_cast<double>(1.0f / static_cast<float>(C));
+    double a0 = static_cast<double>(1.0f / static_cast<float>(C));
+    if (sharded) {  // test hook: "nan" poisons this rank's start vector — its column sums are not finite in the first iteration
+        const char * inject = std::getenv("RPVG_HIP_INJECT_SHARD_FAILURE");
+        if (inject && std::strcmp(inject, "nan") == 0) a0 = std::nan("");
+    }
     fillConstantKernel<<<dim3((C + 255) / 256), dim3(256), 0, st>>>(d_a.ptr, C, a0);
 
     const int nchunk = (C + 127) / 128;
     const uint32_t chunk_its = 8;  // iterations queued between looks at the control word
-    DenseControl h_ctl = {0, 0, 0, 0};
+    DenseControl h_ctl = {0, 0, 0, 0, 0};
     uint32_t queued = 0;
     uint64_t accum_launches = 0;
     // em_dense_ms (rpvg_hip_kernel_stats) = HIP-event time of the streaming-pass launches only
@@ -427,13 +484,13 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
                 emDenseReducePartialsKernel<<<dim3((C + 255) / 256, reduce_slices), dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_reduced.ptr, d_ctl.ptr);
                 if (sharded) {
                     // this rank's column sums -> sum over ranks (same bits on every rank) -> identical update everywhere
-                    emDenseReducePartialsKernel<<<col_grid, dim3(256), 0, st>>>(C, reduce_slices, partial_ld, d_reduced.ptr, d_t.ptr, d_ctl.ptr);
-                    if (const int rc = ctx->allReduceSumF64(d_t.ptr, C)) {
+                    emDenseReducePartialsKernel<<<col_grid, dim3(256), 0, st>>>(C, reduce_slices, partial_ld, d_reduced.ptr, d_t.ptr, d_ctl.ptr, d_t.ptr + C);
+                    if (const int rc = ctx->allReduceSumF64(d_t.ptr, C + 1)) {
                         (void) hipStreamSynchronize(st);  // the kernels queued so far use the buffers freed on return
                         return rc;
                     }
                     emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, 1, partial_ld, d_t.ptr, d_a.ptr, total_count,
-                                                                      max_rel_em_conv, d_ctl.ptr);
+                                                                      max_rel_em_conv, d_ctl.ptr, d_t.ptr + C);
                 } else {
                     emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, reduce_slices, partial_ld, d_reduced.ptr, d_a.ptr,
                                                                       total_count, max_rel_em_conv, d_ctl.ptr);
@@ -448,13 +505,13 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
             else launchAccum<16>(grid, st, device_matrix, num_rows, C, ld, device_counts, d_a.ptr, d_partials.ptr, partial_ld, d_ctl.ptr);
             ctx->spanEnd(span);
             if (sharded) {
-                emDenseReducePartialsKernel<<<col_grid, dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_t.ptr, d_ctl.ptr);
-                if (const int rc = ctx->allReduceSumF64(d_t.ptr, C)) {
+                emDenseReducePartialsKernel<<<col_grid, dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_t.ptr, d_ctl.ptr, d_t.ptr + C);
+                if (const int rc = ctx->allReduceSumF64(d_t.ptr, C + 1)) {
                         (void) hipStreamSynchronize(st);  // the kernels queued so far use the buffers freed on return
                         return rc;
                     }
                 emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, 1, partial_ld, d_t.ptr, d_a.ptr, total_count,
-                                                                  max_rel_em_conv, d_ctl.ptr);
+                                                                  max_rel_em_conv, d_ctl.ptr, d_t.ptr + C);
             } else {
                 emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_a.ptr,
                                                                   total_count, max_rel_em_conv, d_ctl.ptr);
@@ -468,6 +525,11 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
         RPVG_HIP_CHECK(hipStreamSynchronize(st));
     }
 
+    if (h_ctl.error) {
+        setError("%s: the column sums of some rank were not finite in EM iteration %u (status word of the all-reduce): every rank stopped there", who,
+                 h_ctl.iterations + 1);
+        return RPVG_HIP_ERR_RUNTIME;
+    }
     std::vector<double> a(C);
     RPVG_HIP_CHECK(hipMemcpyAsync(a.data(), d_a.ptr, sizeof(double) * C, hipMemcpyDeviceToHost, st));
     RPVG_HIP_CHECK(hipStreamSynchronize(st));

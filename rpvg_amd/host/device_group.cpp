@@ -1,14 +1,18 @@
 #include "device_group.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cassert>
+#include <condition_variable>
 #include <exception>
+#include <mutex>
 #include <numeric>
 #include <random>
 #include <set>
 #include <thread>
 
 #include "estimator_factory.hpp"
+#include "trace.hpp"
 
 namespace rpvg_amd {
 
@@ -163,6 +167,47 @@ void onEveryDevice(const size_t n, Work work) {
     }
 }
 
+// The ranks of a collective meet here first: everything that can fail on one rank alone (allocations, copies) happens
+// before, and a rank that failed says so — its peers then skip the collective instead of waiting in it for ever.
+class Rendezvous {
+
+    public:
+
+        explicit Rendezvous(const size_t parties_in) : parties(parties_in), arrived(0), generation(0), failed(false) {}
+
+        // Returns true when every party arrived without a failure.
+        bool arrive(const bool ok) {
+
+            std::unique_lock<std::mutex> lock(mutex);
+
+            failed = failed || !ok;
+            const size_t my_generation = generation;
+
+            if (++arrived == parties) {
+
+                arrived = 0;
+                ++generation;
+                all_here.notify_all();
+
+            } else {
+
+                all_here.wait(lock, [&] { return generation != my_generation; });
+            }
+
+            return !failed;
+        }
+
+    private:
+
+        const size_t parties;
+        size_t arrived;
+        size_t generation;
+        bool failed;
+
+        std::mutex mutex;
+        std::condition_variable all_here;
+};
+
 }
 
 DeviceGroup::DeviceGroup(const std::vector<int> & devices) : communicator(false) {
@@ -260,7 +305,12 @@ void DeviceGroup::estimateBatch(std::vector<PathClusterEstimates> * estimates, c
 
     partition = partitionClusters(clusterCosts(batch), engines.size());
 
+    // the host threads of the process are shared by the group's engines (each of which runs its own host lanes)
+    const int engine_threads = std::max(2, hostThreads() / static_cast<int>(engines.size()));
+
     onEveryDevice(engines.size(), [&](const size_t idx) {
+
+        hostThreadsOverride() = engine_threads;
 
         const auto & clusters = partition.at(idx);
 
@@ -316,19 +366,55 @@ std::vector<double> DeviceGroup::gatherAbundances(const std::vector<PathClusterE
     std::vector<std::vector<double> > gathered(engines.size(), std::vector<double>(total, 0));
     std::vector<double> transcript_counts(engines.size(), 0);
 
-    if (communicator) {
+    if (communicator && total > 0) {
+
+        // (total == 0 — a model without abundances, `-i haplotypes` — has nothing to gather and a TPM denominator of zero)
+        Rendezvous before_collectives(engines.size());
 
         onEveryDevice(engines.size(), [&](const size_t idx) {
 
             rpvg_hip_ctx * ctx = engines.at(idx)->ctx();
-            HipEngine::check(rpvg_hip_gather(ctx, local.at(idx).data(), counts.at(idx), counts.data(), gathered.at(idx).data()), "rpvg_hip_gather");
-
             double * device_sum = nullptr;
-            HipEngine::check(rpvg_hip_malloc(ctx, sizeof(double), reinterpret_cast<void **>(&device_sum)), "rpvg_hip_malloc");
-            HipEngine::check(rpvg_hip_memcpy_h2d(ctx, device_sum, &local_transcript_count.at(idx), sizeof(double)), "rpvg_hip_memcpy_h2d");
-            HipEngine::check(rpvg_hip_comm_allreduce_sum_f64(ctx, device_sum, 1), "rpvg_hip_comm_allreduce_sum_f64");
-            HipEngine::check(rpvg_hip_memcpy_d2h(ctx, &transcript_counts.at(idx), device_sum, sizeof(double)), "rpvg_hip_memcpy_d2h");
-            HipEngine::check(rpvg_hip_free(ctx, device_sum), "rpvg_hip_free");
+            std::exception_ptr failure = nullptr;
+
+            // what can fail on this rank alone comes first
+            try {
+
+                HipEngine::check(rpvg_hip_malloc(ctx, sizeof(double), reinterpret_cast<void **>(&device_sum)), "rpvg_hip_malloc");
+                HipEngine::check(rpvg_hip_memcpy_h2d(ctx, device_sum, &local_transcript_count.at(idx), sizeof(double)), "rpvg_hip_memcpy_h2d");
+
+            } catch (...) {
+
+                failure = std::current_exception();
+            }
+
+            const bool everybody_ready = before_collectives.arrive(!failure);
+
+            if (everybody_ready) {
+
+                // a rank without values still takes part (rpvg_hip_gather accepts an empty contribution)
+                static const double nothing = 0;
+                const double * mine = counts.at(idx) > 0 ? local.at(idx).data() : &nothing;
+
+                HipEngine::check(rpvg_hip_gather(ctx, mine, counts.at(idx), counts.data(), gathered.at(idx).data()), "rpvg_hip_gather");
+                HipEngine::check(rpvg_hip_comm_allreduce_sum_f64(ctx, device_sum, 1), "rpvg_hip_comm_allreduce_sum_f64");
+                HipEngine::check(rpvg_hip_memcpy_d2h(ctx, &transcript_counts.at(idx), device_sum, sizeof(double)), "rpvg_hip_memcpy_d2h");
+            }
+
+            if (device_sum) {
+
+                rpvg_hip_free(ctx, device_sum);
+            }
+
+            if (failure) {
+
+                std::rethrow_exception(failure);
+            }
+
+            if (!everybody_ready) {
+
+                throw EngineError("DeviceGroup::gatherAbundances: another rank failed before the collectives; skipped them");
+            }
         });
 
     } else {

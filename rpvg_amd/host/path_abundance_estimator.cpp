@@ -402,7 +402,7 @@ static void dropNowOrLater(std::function<void(int)> drop, const bool between_dev
 
     static const bool never_later = std::getenv("RPVG_AMD_NO_DEFERRED_TEARDOWN") != nullptr;
 
-    if (never_later || (HipEngine::currentLane() == 0 && !between_device_stages)) {
+    if (never_later || !LaneScope::active() || (HipEngine::currentLane() == 0 && !between_device_stages)) {
 
         drop(hostThreads());
 

@@ -86,7 +86,10 @@ class GroupMatrices {
             rpvg_hip_ctx * lane_context = engine->ctx();  // (not the engine: its lane threads own the closures, and it owns them)
             std::shared_ptr<rpvg_hip_groups> holder(groups, [lane_context](rpvg_hip_groups * matrices) { rpvg_hip_groups_free(lane_context, matrices); });
 
-            if (!never_later) {
+            // (only inside a lane of runInLanes does somebody drop what is kept: a caller outside of it — the posterior
+            // estimators' batches, a unit test — would pile the matrices up in device memory batch after batch, and the
+            // closure would outlive the engine)
+            if (!never_later && LaneScope::active()) {
 
                 RetiredContainers::ofThisThread().keep([holder]() mutable { holder.reset(); });
             }
@@ -529,9 +532,24 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
 
     if (num_lanes == 1 || clusters.size() < 64 || HipEngine::currentLane() != 0) {
 
-        work(clusters, []() {});
+        const bool outermost = !LaneScope::active();
 
-        if (HipEngine::currentLane() == 0) {
+        try {
+
+            LaneScope scope;
+            work(clusters, []() {});
+
+        } catch (...) {
+
+            if (outermost) {
+
+                RetiredContainers::ofThisThread().dropAll();
+            }
+
+            throw;
+        }
+
+        if (outermost) {
 
             RetiredContainers::ofThisThread().dropAll();  // what the work kept for later
         }
@@ -596,6 +614,7 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
 
             hostThreadsOverride() = lane_threads;
             HipEngine::currentLane() = lane;
+            LaneScope scope;
 
             // the lane before works through its host prologue: time to free what the previous batch left behind
             RetiredContainers::ofThisThread().dropAll();
@@ -621,6 +640,7 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
 
     try {
 
+        LaneScope scope;
         work(lane_clusters[0], [&stagger]() { stagger.passBaton(0); });
 
     } catch (...) {

@@ -187,6 +187,29 @@ class PipelineWorker {
         std::thread worker;
 };
 
+// Marks the calling thread as inside a lane of PathEstimator::runInLanes: only there is somebody who drops what
+// RetiredContainers keeps (the lane itself, once its work is done).  Outside of it, owners free on the spot.
+class LaneScope {
+
+    public:
+
+        LaneScope() { ++depth(); }
+        ~LaneScope() { --depth(); }
+
+        LaneScope(const LaneScope &) = delete;
+        LaneScope & operator=(const LaneScope &) = delete;
+
+        static bool active() { return depth() > 0; }
+
+    private:
+
+        static int & depth() {
+
+            thread_local int scopes = 0;
+            return scopes;
+        }
+};
+
 // Containers a lane is done with, kept until the lane has time to drop them.
 //
 // A batch leaves tens of thousands of small vectors and maps behind (EM problems and solutions, group posteriors,

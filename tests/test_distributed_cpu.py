@@ -97,20 +97,43 @@ def _row_shard_worker(rank, world, port, out_dir):
         Pl, cl = P[r0:r1], counts[r0:r1]
 
         C_ = N + 1
-        a = np.full(C_, np.float64(np.float32(1.0) / np.float32(C_)))
-        conv_its, its = 0, 0
-        while its < 10000:
-            s = Pl @ a
-            t = torch.from_numpy((cl / s) @ Pl)
-            dist.all_reduce(t)  # the one exchange step of the path
-            an = a * t.numpy() / total
-            its += 1
-            big = an >= 1e-8
-            viol = bool(np.any(np.abs(an[big] - a[big]) / an[big] > 1e-3))
-            a = an
-            conv_its = 0 if viol else conv_its + 1
-            if conv_its == 10:
-                break
+
+        def solve(poison_rank=None, fail_checks_rank=None):
+            """The protocol with its status words: a handshake before the EM (sum over ranks of "my local checks failed") and
+            one word behind the C column sums of every all-reduce (a rank whose sums are not finite raises it): no rank
+            leaves a collective its peers are still going to enter."""
+            hand = torch.tensor([1.0 if rank == fail_checks_rank else 0.0], dtype=torch.float64)
+            dist.all_reduce(hand)
+            if hand.item() != 0:
+                return "peer failed its checks", None, 0
+            a = np.full(C_, np.float64(np.float32(1.0) / np.float32(C_)))
+            if rank == poison_rank:
+                a[:] = np.nan
+            conv_its, its = 0, 0
+            while its < 10000:
+                with np.errstate(all="ignore"):
+                    s = Pl @ a
+                    local = (cl / s) @ Pl
+                t = torch.from_numpy(np.concatenate([local, [0.0 if np.all(np.isfinite(local)) else 1.0]]))
+                dist.all_reduce(t)  # the one exchange step of the path: C sums + the status word
+                if t[-1].item() != 0:
+                    return "not finite", None, its
+                an = a * t.numpy()[:-1] / total
+                its += 1
+                big = an >= 1e-8
+                viol = bool(np.any(np.abs(an[big] - a[big]) / an[big] > 1e-3))
+                a = an
+                conv_its = 0 if viol else conv_its + 1
+                if conv_its == 10:
+                    break
+            return "ok", a, its
+
+        # a rank that fails its checks, a rank with poisoned values: every rank returns the same verdict, nobody hangs
+        assert solve(fail_checks_rank=1)[0] == "peer failed its checks"
+        verdict, _, stopped = solve(poison_rank=1)
+        assert verdict == "not finite" and stopped == 0
+        verdict, a, its = solve()
+        assert verdict == "ok"
         ab = np.where(a[:-1] < 1e-8, 0.0, a[:-1] * total)
 
         # every rank must hold the same bits (same stop iteration is what keeps the collective calls matched)

@@ -298,6 +298,20 @@ def test_one_rank_communicator_row_sharded_em(hip_ctx, R, N):
         # a rank without rows (fewer rows than ranks) still joins every all-reduce with zero column sums
         ab_e, noise_e, its_e = ctx.em_dense(d_P, 0, N + 1, ld, d_c, float(R), max_em_its=3, sharded=True)
         assert its_e == 3 and np.all(ab_e == 0)
+        # the status words of the collective protocol: a rank that fails its local checks says so in a handshake before
+        # the EM, a rank whose column sums are not finite raises the word that travels with them — in both cases the call
+        # returns an error on every rank instead of leaving the peers in the next all-reduce
+        os.environ["RPVG_HIP_INJECT_SHARD_FAILURE"] = "checks"
+        try:
+            with pytest.raises(hip.EngineError, match="injected failure of the local checks"):
+                ctx.em_dense(d_P, R, N + 1, ld, d_c, float(R), max_em_its=30, sharded=True)
+            os.environ["RPVG_HIP_INJECT_SHARD_FAILURE"] = "nan"
+            with pytest.raises(hip.EngineError, match="not finite in EM iteration 1"):
+                ctx.em_dense(d_P, R, N + 1, ld, d_c, float(R), max_em_its=30, sharded=True)
+        finally:
+            os.environ.pop("RPVG_HIP_INJECT_SHARD_FAILURE", None)
+        ab_b, noise_b, its_b = ctx.em_dense(d_P, R, N + 1, ld, d_c, float(R), max_em_its=30, sharded=True)
+        assert its_b == its and np.array_equal(ab_b, ab)
         ctx.comm_destroy()
         ctx.comm_init_all()  # the single-process form (one host thread per GPU): this context is rank 0 of 1
         ab_a, noise_a, its_a = ctx.em_dense(d_P, R, N + 1, ld, d_c, float(R), max_em_its=30, sharded=True)

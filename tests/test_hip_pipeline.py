@@ -125,6 +125,36 @@ def test_device_group_shards_clusters_and_gathers(model, devices):
         group.close()
 
 
+@pytest.mark.parametrize("model", ["transcripts", "haplotype-transcripts", "haplotypes"])
+def test_device_group_over_distinct_gpus_uses_its_communicator(model):
+    """The first run of the RCCL collectives of a sharded batch — rpvg_hip_comm_init_all, rpvg_hip_gather
+    (ncclAllGather, ragged), the TPM all-reduce — in a world larger than one: GPUs 0 and 1 of the box.  Skipped where
+    there is one GPU (the round's test boxes): on a multi-GPU node the first multi-rank bench is then not also the
+    first multi-rank RCCL call of this code.  `haplotypes` has no abundances: the gather of nothing must not wait."""
+    from rpvg_amd import hip
+    if hip.device_count() < 2:
+        pytest.skip("one GPU: DeviceGroup over distinct GPUs needs two")
+    batch = synth.generate(seed=33, num_clusters=80, total_paths=3000, total_reads=80000)
+    params = make_params(rng_seed=7)
+    ref, _ = pyoracle.run(model, params, batch, 2)
+    group = eng_mod.DeviceGroup([0, 1])
+    try:
+        assert group.has_communicator()
+        got, _ = group.run(model, params, batch)
+        for g, r in zip(got, ref):
+            gk, rk = g.keyed(), r.keyed()
+            assert set(gk) == set(rk)
+            for key, (post, ab) in rk.items():
+                assert small_cases.rel_close(gk[key][0], post, rel=1e-6) and small_cases.rel_close(gk[key][1], ab, rel=1e-6)
+        flat = np.concatenate([g.abundances for g in got]) if got else np.zeros(0)
+        gathered, tpm_den = group.gather(len(flat))
+        assert np.array_equal(gathered, flat)
+        from rpvg_amd import dist as rdist
+        assert abs(tpm_den - rdist.local_transcript_count(got, batch)) <= 1e-9 * max(1.0, tpm_den)
+    finally:
+        group.close()
+
+
 def test_batches_arriving_through_an_uploader_engine():
     """Two resident slots, an uploader engine (rpvg_hip_create_uploader: a stream and hardware queue of its own) that
     re-uploads one slot from page-locked host arrays while the other is estimated: what bench.py's upload leg does.  The
