@@ -3,13 +3,14 @@
 tools/pmc_kernels.py (profiles/r02/pmc_s3_search_kernels.txt) and the evaluations of one launch (bench.py's
 roofline_search.evals_per_step of a one-lane run = one launch):
 
-  python tools/pmc_search_summary.py <listing> <evals per launch> <out.json> [kernel]
+  python tools/pmc_search_summary.py <listing> <evals per launch> <out.json> [commit] [kernel]
 """
 import json
 import sys
 
 listing, evals, out = sys.argv[1], float(sys.argv[2]), sys.argv[3]
-kernel = sys.argv[4] if len(sys.argv) > 4 else "pairTileKernel"
+commit = sys.argv[4] if len(sys.argv) > 4 else ""
+kernel = sys.argv[5] if len(sys.argv) > 5 else "pairTileKernel"
 counters, current = {}, None
 for line in open(listing):
     if not line.startswith(" "):
@@ -27,6 +28,6 @@ summary = dict(kernel=kernel, launches=launches, evals_per_launch=evals,
                valu_busy=counters["SQ_INSTS_VALU"] * 4 / (simds * kernel_cycles),
                lds_bank_conflict_share=counters.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, counters.get("SQ_LDS_IDX_ACTIVE", 0.0)),
                kernel_ms_at_2p4_ghz=kernel_cycles / launches / 2.4e6,
-               source=listing, note="rocprofv3 --pmc passes, one host lane (tools/refresh_profiles_r02.sh)")
+               source=listing, commit=commit, note="rocprofv3 --pmc passes, one host lane (tools/refresh_profiles_r03.sh)")
 json.dump(summary, open(out, "w"), indent=1)
 print(json.dumps(summary))
