@@ -853,13 +853,24 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     ok(tmp->pair_base.alloc(M));
     ok(tmp->pair_table.alloc(kPairTableBytes));
     ok(tmp->bytes.alloc(3 * total_rows));
-    // the rows of a matrix are a segment of the key array: sorted segment by segment on the projection bits
-    const int begin_bit = kCollapseLargestBits, end_bit = kCollapseMatrixShift;
+    // The keys carry the matrix above the projection and the rows of a matrix are contiguous: ONE (stable) radix sort of
+    // the whole array on the projection and as many matrix bits as there are matrices orders every matrix's rows by their
+    // projection.  (Round 2 sorted segment by segment, hipcub::DeviceSegmentedRadixSort: 0.33 ms per 1.6 M rows in 2 500
+    // segments, the longest kernel of the collapse; RPVG_HIP_COLLAPSE_SEGMENTED_SORT=1 keeps it for A/B.)
+    static const bool segmented = std::getenv("RPVG_HIP_COLLAPSE_SEGMENTED_SORT") != nullptr;
+    int matrix_bits = 1;
+    while ((1u << matrix_bits) < M) ++matrix_bits;
+    const int begin_bit = kCollapseLargestBits, end_bit = segmented ? kCollapseMatrixShift : kCollapseMatrixShift + matrix_bits;
     const uint32_t * segment_off = g->collapse_segment_off.ptr;
     size_t sort_bytes = 0;
-    if (e == hipSuccess) ok(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, sort_bytes, g->collapse_key.ptr, tmp->key_out.ptr, g->collapse_row.ptr,
-                                                                        tmp->row_out.ptr, static_cast<int>(total_rows), static_cast<int>(M),
-                                                                        segment_off, segment_off + 1, begin_bit, end_bit, st));
+    auto sort = [&](void * scratch) {
+        return segmented ? hipcub::DeviceSegmentedRadixSort::SortPairs(scratch, sort_bytes, g->collapse_key.ptr, tmp->key_out.ptr, g->collapse_row.ptr,
+                                                                       tmp->row_out.ptr, static_cast<int>(total_rows), static_cast<int>(M),
+                                                                       segment_off, segment_off + 1, begin_bit, end_bit, st)
+                         : hipcub::DeviceRadixSort::SortPairs(scratch, sort_bytes, g->collapse_key.ptr, tmp->key_out.ptr, g->collapse_row.ptr,
+                                                              tmp->row_out.ptr, static_cast<int>(total_rows), begin_bit, end_bit, st);
+    };
+    if (e == hipSuccess) ok(sort(nullptr));
     ok(tmp->sort_tmp.alloc(sort_bytes));
     if (e != hipSuccess) return e;
     uint32_t * pair_bytes = g->collapse_info.ptr + kInfoWords, * mat_flag = pair_bytes + 2, * replay_list = mat_flag + M, * marked_bits = replay_list + M + 1,
@@ -868,9 +879,7 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     uint8_t * same_prev = tmp->bytes.ptr, * close = same_prev + total_rows, * barrier = close + total_rows;
     uint8_t * active = reinterpret_cast<uint8_t *>(pair_bytes + num_words);
     ok(hipMemsetAsync(g->collapse_info.ptr, 0, (kInfoWords + num_words + active_words) * sizeof(uint32_t), st));
-    ok(hipcub::DeviceSegmentedRadixSort::SortPairs(tmp->sort_tmp.ptr, sort_bytes, g->collapse_key.ptr, tmp->key_out.ptr, g->collapse_row.ptr,
-                                                   tmp->row_out.ptr, static_cast<int>(total_rows), static_cast<int>(M), segment_off, segment_off + 1,
-                                                   begin_bit, end_bit, st));
+    ok(sort(tmp->sort_tmp.ptr));
     MatrixArrays arrays;
     arrays.mat_val_off = g->mat_val_off.ptr;
     arrays.mat_row_off = g->mat_row_off.ptr;
