@@ -116,10 +116,27 @@ std::vector<ProbabilityCluster> readProbabilityClusters(const std::string & file
             continue;
         }
 
-        if (line == "#") {
+        if (line == "#" || line.compare(0, 2, "# ") == 0) {
 
             clusters.emplace_back(ProbabilityCluster());
             expect_paths = true;
+
+            if (line.size() > 2) {
+
+                // "# <alignment-path lists> <cluster index>": the rank key of src/main.cpp:811-827 (an extension of this
+                // project's writer; the reference writes a bare "#")
+                const auto fields = splitString(line.substr(2), ' ');
+
+                if (fields.size() != 2) {
+
+                    throw std::runtime_error(filename + ": cluster marker \"" + line + "\" is neither \"#\" nor \"# <lists> <index>\"");
+                }
+
+                clusters.back().has_rank_key = true;
+                clusters.back().num_align_lists = std::stoull(fields.at(0));
+                clusters.back().cluster_index = std::stoull(fields.at(1));
+            }
+
             continue;
         }
 
@@ -206,7 +223,15 @@ void writeProbabilityClusters(const std::string & filename, const std::vector<Pr
             continue;
         }
 
-        out << "#" << std::endl;
+        if (cluster.has_rank_key) {
+
+            out << "# " << cluster.num_align_lists << " " << cluster.cluster_index << std::endl;
+
+        } else {
+
+            out << "#" << std::endl;
+        }
+
         out << std::setprecision(out_precision_digits);
 
         for (size_t i = 0; i < cluster.paths.size(); ++i) {

@@ -22,6 +22,14 @@ struct ProbabilityCluster {
 
     std::vector<PathInfo> paths;
     std::vector<ReadPathProbabilities> cluster_probs;
+
+    // What the reference ranks clusters by (src/main.cpp:811-827: descending (number of alignment-path lists, index of the
+    // cluster in PathClusters); the rank is the output ClusterID and the offset of the cluster's random seed, :849,976).
+    // The reference's dump does not hold them; a producer that knows them writes "# <lists> <index>" as the marker line of
+    // the block instead of "#" (has_rank_key).  Without them a replay ranks by read count.
+    bool has_rank_key = false;
+    uint64_t num_align_lists = 0;
+    uint64_t cluster_index = 0;
 };
 
 // Text file helpers (zlib): reading passes plain files through; writing gzips when the name ends in ".gz".
@@ -30,7 +38,8 @@ void writeTextFile(const std::string & filename, const std::string & text);
 
 std::vector<ProbabilityCluster> readProbabilityClusters(const std::string & filename, const double prob_precision);
 
-// Same format as the reference's writer; gzip when the name ends in ".gz".
+// Same format as the reference's writer (a block whose cluster has a rank key gets the extended marker line); gzip when the
+// name ends in ".gz".
 void writeProbabilityClusters(const std::string & filename, const std::vector<ProbabilityCluster> & clusters, const double prob_precision);
 
 // Path name -> PathInfo with group_id (dense transcript ids in first-seen order), source_count and — when

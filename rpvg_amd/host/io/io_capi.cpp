@@ -105,12 +105,32 @@ int64_t rpvg_amd_info_table(const char * info_filename, int parse_haplotype_ids,
     }
 }
 
+int rpvg_amd_batch_write_files_ranked(const rpvg_cluster_batch * batch, const char * probs_filename, const char * path_info_filename, double prob_precision, const uint64_t * num_align_lists, const uint64_t * cluster_index);
+
 // Writes the batch as a `--write-probs` dump and a matching `-f` path info file.
 int rpvg_amd_batch_write_files(const rpvg_cluster_batch * batch, const char * probs_filename, const char * path_info_filename, double prob_precision) {
 
+    return rpvg_amd_batch_write_files_ranked(batch, probs_filename, path_info_filename, prob_precision, nullptr, nullptr);
+}
+
+// The same with the rank key of the reference's cluster loop in every block's marker line ("# <lists> <index>",
+// cluster_io.hpp): num_align_lists[k], cluster_index[k] of cluster k of the batch (both NULL: the reference's bare "#").
+int rpvg_amd_batch_write_files_ranked(const rpvg_cluster_batch * batch, const char * probs_filename, const char * path_info_filename, double prob_precision, const uint64_t * num_align_lists, const uint64_t * cluster_index) {
+
     try {
 
-        const auto clusters = clustersFromBatch(*batch, prob_precision);
+        auto clusters = clustersFromBatch(*batch, prob_precision);
+
+        if (num_align_lists && cluster_index) {
+
+            for (size_t k = 0; k < clusters.size(); ++k) {
+
+                clusters[k].has_rank_key = true;
+                clusters[k].num_align_lists = num_align_lists[k];
+                clusters[k].cluster_index = cluster_index[k];
+            }
+        }
+
         writeProbabilityClusters(probs_filename, clusters, prob_precision);
 
         std::stringstream info;

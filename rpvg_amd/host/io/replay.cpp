@@ -8,11 +8,22 @@
 
 namespace rpvg_amd {
 
+// The order of the reference's cluster loop (src/main.cpp:811-827): descending (number of alignment-path lists, cluster
+// index) when every block of the dump carries that key; otherwise descending read count, dump order among equals (the
+// reference's dump holds the merged rows, not the lists).
 void rankClusters(std::vector<ProbabilityCluster> * clusters) {
 
-    std::vector<std::pair<uint64_t, size_t> > read_counts;
+    const bool by_rank_key = !clusters->empty() && std::all_of(clusters->begin(), clusters->end(), [](const ProbabilityCluster & cluster) { return cluster.has_rank_key; });
+
+    std::vector<std::pair<std::pair<uint64_t, uint64_t>, size_t> > keys;
 
     for (size_t i = 0; i < clusters->size(); ++i) {
+
+        if (by_rank_key) {
+
+            keys.emplace_back(std::make_pair(clusters->at(i).num_align_lists, clusters->at(i).cluster_index), i);
+            continue;
+        }
 
         uint64_t read_count = 0;
 
@@ -21,17 +32,17 @@ void rankClusters(std::vector<ProbabilityCluster> * clusters) {
             read_count += probs.readCount();
         }
 
-        read_counts.emplace_back(read_count, i);
+        keys.emplace_back(std::make_pair(read_count, uint64_t(0)), i);
     }
 
-    std::stable_sort(read_counts.begin(), read_counts.end(), [](const std::pair<uint64_t, size_t> & lhs, const std::pair<uint64_t, size_t> & rhs) { return lhs.first > rhs.first; });
+    std::stable_sort(keys.begin(), keys.end(), [](const std::pair<std::pair<uint64_t, uint64_t>, size_t> & lhs, const std::pair<std::pair<uint64_t, uint64_t>, size_t> & rhs) { return lhs.first > rhs.first; });
 
     std::vector<ProbabilityCluster> ranked;
     ranked.reserve(clusters->size());
 
-    for (auto & read_count: read_counts) {
+    for (auto & key: keys) {
 
-        ranked.emplace_back(std::move(clusters->at(read_count.second)));
+        ranked.emplace_back(std::move(clusters->at(key.second)));
     }
 
     clusters->swap(ranked);

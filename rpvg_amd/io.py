@@ -14,6 +14,8 @@ def _lib():
     L.rpvg_amd_io_last_error.restype = C.c_char_p
     L.rpvg_amd_batch_write_files.restype = C.c_int
     L.rpvg_amd_batch_write_files.argtypes = [C.POINTER(CClusterBatch), C.c_char_p, C.c_char_p, C.c_double]
+    L.rpvg_amd_batch_write_files_ranked.restype = C.c_int
+    L.rpvg_amd_batch_write_files_ranked.argtypes = [C.POINTER(CClusterBatch), C.c_char_p, C.c_char_p, C.c_double, C.c_void_p, C.c_void_p]
     L.rpvg_amd_batch_read_files.restype = C.c_void_p
     L.rpvg_amd_batch_read_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double]
     L.rpvg_amd_info_table.restype = C.c_int64
@@ -47,16 +49,29 @@ def info_table(info_path: str, parse_haplotype_ids: bool = True, use_transcript_
     return rows
 
 
-def write_batch_files(batch: ClusterBatch, probs_path: str, info_path: str, prob_precision: float = 1e-8):
-    """The batch as a `--write-probs` dump plus a matching `-f` path info TSV (generated names)."""
+def write_batch_files(batch: ClusterBatch, probs_path: str, info_path: str, prob_precision: float = 1e-8, num_align_lists=None,
+                      cluster_index=None):
+    """The batch as a `--write-probs` dump plus a matching `-f` path info TSV (generated names).  With num_align_lists and
+    cluster_index (one per cluster) every block carries the rank key of the reference's cluster loop (src/main.cpp:811-827)
+    in its marker line — the replay then numbers and seeds the clusters as the run that produced them did."""
+    import numpy as np
     cb = batch.as_c()
-    if _lib().rpvg_amd_batch_write_files(C.byref(cb), probs_path.encode(), info_path.encode(), prob_precision) != 0:
+    if num_align_lists is None:
+        if _lib().rpvg_amd_batch_write_files(C.byref(cb), probs_path.encode(), info_path.encode(), prob_precision) != 0:
+            _fail("write_batch_files")
+        return
+    lists = np.ascontiguousarray(num_align_lists, dtype=np.uint64)
+    index = np.ascontiguousarray(cluster_index, dtype=np.uint64)
+    assert len(lists) == batch.num_clusters == len(index)
+    if _lib().rpvg_amd_batch_write_files_ranked(C.byref(cb), probs_path.encode(), info_path.encode(), prob_precision,
+                                                C.c_void_p(lists.ctypes.data), C.c_void_p(index.ctypes.data)) != 0:
         _fail("write_batch_files")
 
 
 def read_batch_files(probs_path: str, info_path: Optional[str], parse_haplotype_ids: bool = True,
                      prob_precision: float = 1e-8) -> ClusterBatch:
-    """A dump (+ path info) as a flat batch, clusters ranked by read count as the replay ranks them."""
+    """A dump (+ path info) as a flat batch, clusters ranked as the replay ranks them: by the rank key of the blocks when every
+    block has one, else by read count."""
     L = _lib()
     synth._bind()
     h = L.rpvg_amd_batch_read_files(probs_path.encode(), (info_path or "").encode(), 1 if parse_haplotype_ids else 0, prob_precision)

@@ -9,7 +9,8 @@ import pytest
 
 from oracle import pyoracle
 from rpvg_amd import io as rio, synth
-from rpvg_amd.batch import make_params
+from rpvg_amd.batch import ClusterBatch, make_params
+from tests import small_cases
 
 
 def fmt(x):
@@ -303,3 +304,33 @@ def test_s1_generator_has_the_shape_of_the_reference_example():
     for q, key in ((50, "p50"), (90, "p90"), (99, "p99")):
         assert abs(np.percentile(sizes, q) - want[key]) <= 0.35 * want[key], (key, np.percentile(sizes, q), want[key])
     assert want["max"] / 3 <= sizes.max() <= want["max"] * 3
+
+
+def test_dump_with_rank_keys_replays_in_the_reference_order(tmp_path):
+    """The reference numbers and seeds clusters by their rank in descending (number of alignment-path lists, PathClusters
+    index) order (src/main.cpp:811-827,849,976); its dump holds neither.  A producer that knows them writes "# <lists>
+    <index>" as a block's marker line: the reader then ranks by that key instead of by read count."""
+    import gzip
+    batch = ClusterBatch.from_clusters(small_cases.make_batch_clusters(4411, n_clusters=12, with_empty=False))
+    K = batch.num_clusters
+    rng = np.random.default_rng(9)
+    lists = rng.integers(1, 50, size=K).astype(np.uint64)
+    lists[3] = lists[7]  # a tie: the larger cluster index goes first (reverse sort of (lists, index) pairs)
+    index = rng.permutation(K).astype(np.uint64)
+    probs, info = str(tmp_path / "ranked_probs.txt.gz"), str(tmp_path / "ranked_info.tsv")
+    rio.write_batch_files(batch, probs, info, num_align_lists=lists, cluster_index=index)
+    markers = [line for line in gzip.open(probs, "rt").read().splitlines() if line.startswith("#")]
+    assert markers == [f"# {int(lists[k])} {int(index[k])}" for k in range(K)]
+    back = rio.read_batch_files(probs, info)
+    expected = sorted(range(K), key=lambda k: (int(lists[k]), int(index[k])), reverse=True)
+    rows = np.diff(batch.cluster_row_off.astype(np.int64))
+    reads = np.add.reduceat(batch.row_count.astype(np.int64), batch.cluster_row_off[:-1].astype(np.int64))
+    back_rows = np.diff(back.cluster_row_off.astype(np.int64))
+    back_reads = np.add.reduceat(back.row_count.astype(np.int64), back.cluster_row_off[:-1].astype(np.int64))
+    assert back_rows.tolist() == [int(rows[k]) for k in expected] and back_reads.tolist() == [int(reads[k]) for k in expected]
+    # a dump without keys (the reference's own) still ranks by read count
+    plain = str(tmp_path / "plain_probs.txt.gz")
+    rio.write_batch_files(batch, plain, info)
+    by_reads = rio.read_batch_files(plain, info)
+    r = np.add.reduceat(by_reads.row_count.astype(np.int64), by_reads.cluster_row_off[:-1].astype(np.int64))
+    assert np.all(r[:-1] >= r[1:])
