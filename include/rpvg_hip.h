@@ -89,6 +89,10 @@ typedef struct rpvg_hip_em_problems {
     const uint32_t * cluster;  /* host [P]   index into the uploaded batch          */
     const uint64_t * col_off;  /* host [P+1] range into col_path                    */
     const uint32_t * col_path; /* host       cluster-local path of each column      */
+    /* > 0: readCollapseProbabilityMatrix (src/path_estimator.cpp:219-259) on the normalised rows of every problem, with this
+     * prob_precision, as MinimumPathAbundanceEstimator and NestedPathAbundanceEstimator do before their EM
+     * (src/path_abundance_estimator.cpp:266,668; PathAbundanceEstimator::estimate, :18-45, does not: 0). */
+    double collapse_precision;
 } rpvg_hip_em_problems;
 
 typedef struct rpvg_hip_em_results {
@@ -105,11 +109,14 @@ typedef struct rpvg_hip_em_results {
  *   addNoiseAndNormalizeProbabilityMatrix   src/path_estimator.cpp:156-166
  *   EMAbundanceEstimator                    src/path_abundance_estimator.cpp:47-114
  * (start value 1/float(C), convergence over components >= 1e-8 for 10
- * consecutive iterations, sub-1e-8 abundances moved to noise_count).
- * readCollapseProbabilityMatrix (src/path_estimator.cpp:219-259) is not
- * replayed: merging rows equal within prob_precision changes no sum beyond
- * prob_precision; rows without any selected path are folded into one exact
- * scalar instead. */
+ * consecutive iterations, sub-1e-8 abundances moved to noise_count) and, with
+ * problems->collapse_precision > 0,
+ *   readCollapseProbabilityMatrix           src/path_estimator.cpp:219-259
+ * between the normalisation and the EM: the rows of every problem are put through the reference's tolerant
+ * sort and compare-with-run-head merge (the machinery of the group matrices' collapse on the sparse rows); a
+ * merged row's read count moves to its run head.  It runs next to the EM; the problems in which it merged rows
+ * that were not equal up to rounding (rare) are solved a second time on the merged counts.  Rows without any
+ * selected path are folded into one exact scalar. */
 int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t max_em_its, double max_rel_em_conv,
                       const rpvg_hip_em_problems * problems, rpvg_hip_em_results * results);
 
@@ -237,7 +244,8 @@ void rpvg_hip_pair_posteriors_free(rpvg_hip_pair_posteriors * result);
  * matrices on: rpvg_hip_bounded_pair_posteriors, then selectPathSubsetIndices (:569-606: diplotypes with posterior >=
  * min_hap_prob, each expanded to the sorted list of the paths of its two haplotype columns, identical lists merged,
  * weights renormalised), then for every subset that keeps a weight >= min_hap_prob (:627-630) the EM of rpvg_hip_em_solve
- * on its distinct paths (:637-671) — with nothing but a 64-byte header crossing to the host in between (round 2 made two
+ * on its distinct paths (:637-671; collapse_precision as in rpvg_hip_em_problems: the subset's rows are collapsed first, :668) —
+ * with nothing but a 64-byte header crossing to the host in between (round 2 made two
  * round trips there: 1.2 ms of a lane's critical path at 32 host threads, 8 ms at 4).  The posterior-weighted merge of
  * the solutions (:702-749) stays with the caller.
  * Subsets of a matrix come in lexicographic order of their path lists.  Returns RPVG_HIP_ERR_UNSUPPORTED, having changed
@@ -260,7 +268,8 @@ typedef struct rpvg_hip_subset_em_view {
 } rpvg_hip_subset_em_view;
 int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_groups * groups,
                               const uint32_t * column_counts, double min_rel_likelihood, double min_hap_prob,
-                              uint32_t max_em_its, double max_rel_em_conv, rpvg_hip_subset_em ** result_out);
+                              uint32_t max_em_its, double max_rel_em_conv, double collapse_precision,
+                              rpvg_hip_subset_em ** result_out);
 int rpvg_hip_subset_em_get(const rpvg_hip_subset_em * result, rpvg_hip_subset_em_view * view_out);
 void rpvg_hip_subset_em_free(rpvg_hip_subset_em * result);
 

@@ -722,12 +722,21 @@ struct EmSolveWork {  // scratch of one solve: lives until its kernels are done
     DeviceBuffer<unsigned long long> d_wide_off;
     DeviceBuffer<unsigned char> d_queues;
     unsigned char * zeroed_queues = nullptr;  // set by a caller that provides the (zeroed) work queues itself: emQueuesBytes()
+    // row collapse of the problems (row_collapse.hip) and the second EM pass over the problems it merged rows in
+    std::shared_ptr<void> collapse;
+    DeviceBuffer<unsigned char> d_queues_merged;
+    hipEvent_t filled = nullptr, collapsed = nullptr;
+    ~EmSolveWork() {
+        if (filled) (void) hipEventDestroy(filled);
+        if (collapsed) (void) hipEventDestroy(collapsed);
+    }
 };
 size_t emQueuesBytes();
 uint32_t emFillSegmentRows();
 
+// collapse_precision > 0: readCollapseProbabilityMatrix on the rows of every problem (prob_precision of the reference)
 int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProblemList & list, uint32_t max_em_its,
-                 double max_rel_em_conv, const EmOutputs & out, EmSolveWork & work, bool fill_only);
+                 double max_rel_em_conv, const EmOutputs & out, EmSolveWork & work, bool fill_only, double collapse_precision = 0.0);
 void accountEmSolve(rpvg_hip_ctx * ctx, uint32_t P, const uint64_t * col_off, const uint32_t * kept_rows, const uint32_t * kept_entries,
                     const uint32_t * iterations);
 
@@ -751,6 +760,29 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
                     PairSearchWork & w);
 void leavePairSearch(rpvg_hip_ctx * ctx);  // the next search of another context may start behind what has been queued so far
 void accountPairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const PairSearchWork & w, unsigned long long log_evals, uint64_t kept_pairs);
+
+// ---- row collapse of the EM problems (row_collapse.hip) ----------------------------------------------
+struct CsrCollapseInput {  // the compacted CSR of a solve's problems (em_sparse.hip), device pointers
+    uint32_t num_problems_bound = 0;
+    const uint32_t * num_problems_dev = nullptr;
+    uint64_t rows_capacity = 0;
+    const uint64_t * row_base = nullptr;
+    const uint64_t * ent_base = nullptr;
+    const uint32_t * kept_rows = nullptr;
+    const uint64_t * col_off = nullptr;
+    const uint32_t * prow_off = nullptr;
+    const double * prow_count = nullptr;
+    const double * prow_noise = nullptr;
+    const uint32_t * pent_col = nullptr;
+    const double * pent_val = nullptr;
+};
+struct CsrCollapseWork {
+    DeviceBuffer<double> merged_count;      // [rows] read counts after the merges, for the problems with merges
+    DeviceBuffer<uint32_t> problem_merged;  // [P] flag per problem, [P]: their number
+    DeviceBuffer<uint32_t> info;
+    std::shared_ptr<void> temporaries;
+};
+hipError_t queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollapseInput & in, double precision, CsrCollapseWork & work, hipStream_t stream);
 
 // queues the replay of readCollapseProbabilityMatrix on the matrices of `groups` behind their build (row_collapse.hip)
 hipError_t queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups, uint64_t total_rows, double precision, hipStream_t stream);

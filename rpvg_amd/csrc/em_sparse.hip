@@ -359,10 +359,12 @@ __global__ __launch_bounds__(256) void fillOffsetsKernel(const FillArgs args) {
 // ---- 3. the work queues ------------------------------------------------------------
 // Every workgroup scans the (bin, bucket) histogram in LDS (352 counters) and lists its problems: a problem's place
 // inside its bucket is whatever the atomic hands out — the order inside a bucket only decides who starts first.
+// only_flagged: the second pass — the problems a row collapse merged rows in (their histogram: emMergedHistogramKernel)
 __global__ __launch_bounds__(256) void emOrderKernel(const uint32_t num_problems, const uint32_t * __restrict__ num_problems_dev,
                                                     const uint32_t * __restrict__ prob_bucket, const uint64_t * __restrict__ col_off,
                                                     EmQueues * __restrict__ queues, uint32_t * __restrict__ order,
-                                                    unsigned long long * __restrict__ wide_off, const unsigned long long wide_capacity) {
+                                                    unsigned long long * __restrict__ wide_off, const unsigned long long wide_capacity,
+                                                    const uint32_t * __restrict__ only_flagged = nullptr) {
     constexpr int kCells = kEmBins * kEmWorkBuckets;
     static_assert(kCells <= 512, "two cells per thread");
     __shared__ uint32_t start[kCells + 1];
@@ -395,9 +397,10 @@ __global__ __launch_bounds__(256) void emOrderKernel(const uint32_t num_problems
     }
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
+    if (only_flagged && !only_flagged[p]) return;
     const uint32_t cell = prob_bucket[p];
     order[start[cell] + atomicAdd(&queues->bucket_cursor[cell], 1u)] = p;
-    if (cell / kEmWorkBuckets == 10) {  // abundance + accumulator vectors in global memory
+    if (!only_flagged && cell / kEmWorkBuckets == 10) {  // abundance + accumulator vectors in global memory
         const unsigned long long need = 2ull * (static_cast<unsigned long long>(col_off[p + 1] - col_off[p]) + 1);
         const unsigned long long at = atomicAdd(&queues->wide_cursor, need);
         wide_off[p] = at;
@@ -406,6 +409,15 @@ __global__ __launch_bounds__(256) void emOrderKernel(const uint32_t num_problems
 }
 
 // ---- 5. the EM kernel --------------------------------------------------------
+
+__global__ __launch_bounds__(256) void emMergedHistogramKernel(const uint32_t num_problems, const uint32_t * __restrict__ num_problems_dev,
+                                                              const uint32_t * __restrict__ prob_bucket, const uint32_t * __restrict__ flagged,
+                                                              EmQueues * __restrict__ queues) {
+    const uint32_t P = num_problems_dev ? *num_problems_dev : num_problems;
+    if (flagged[num_problems] == 0) return;  // [num_problems]: how many problems were merged — nearly always none
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P && flagged[p]) atomicAdd(&queues->histogram[prob_bucket[p]], 1u);
+}
 
 struct EmLaunchArgs {
     const uint32_t * order;        // problems, bin by bin (EmQueues::bin_start), large first
@@ -521,7 +533,8 @@ __device__ __forceinline__ void emSparseProblem(const EmLaunchArgs & args, const
             y = fma(fma(-s, y, 1.0), y, y);
             y = fma(fma(-s, y, 1.0), y, y);
             const double quot = cnt[r] * y;
-            const double w = fma(fma(-s, quot, cnt[r]), y, quot);
+            // (a row whose count a row collapse moved to its run head takes no part: row_collapse.hip)
+            const double w = cnt[r] == 0.0 ? 0.0 : fma(fma(-s, quot, cnt[r]), y, quot);
             for (uint32_t e = e0; e < e1; ++e) atomicAdd(&t[col[e]], w * val[e]);
             tn += w * nz;
         }
@@ -708,10 +721,10 @@ __device__ __forceinline__ void emRegisterProblem(const EmLaunchArgs & args, con
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
         const uint32_t r = q * 64 + lane;
-        valid[q] = r < n_rows;
+        c[q] = r < n_rows ? cnt[r] : 0.0;
+        valid[q] = c[q] != 0.0;  // (also: a row whose count a row collapse moved to its run head, row_collapse.hip)
 #pragma unroll
         for (int j = 0; j < static_cast<int>(kCols); ++j) P[q][j] = tile[r * kCols + j];
-        c[q] = valid[q] ? cnt[r] : 0.0;
     }
     const double T = args.total_mass[p];
     const double eps = args.max_rel_em_conv;
@@ -1086,7 +1099,7 @@ uint32_t emFillSegmentRows() { return kFillSegmentRows; }
 // synchronisation: compaction of every problem's rows (fillSegmentsKernel), the work queues (emOrderKernel), one
 // persistent launch per kernel variant.  Caller holds ctx->mutex and has set the device; `work` must outlive the kernels.
 int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProblemList & list, const uint32_t max_em_its,
-                 const double max_rel_em_conv, const EmOutputs & out, EmSolveWork & work, const bool fill_only) {
+                 const double max_rel_em_conv, const EmOutputs & out, EmSolveWork & work, const bool fill_only, const double collapse_precision) {
     hipStream_t st = ctx->stream;
     const uint32_t P = list.P_bound;
     const EmBinRule rule = emBinRule();
@@ -1158,6 +1171,36 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         ctx->spanEnd(span);
         return RPVG_HIP_OK;
     }
+    // readCollapseProbabilityMatrix on the rows of every problem (src/path_abundance_estimator.cpp:266,668): on the collapse
+    // stream, next to the first EM pass (it only reads what the fill left)
+    static const bool no_em_collapse = std::getenv("RPVG_HIP_NO_EM_COLLAPSE") != nullptr;
+    const bool collapse = collapse_precision > 0 && !no_em_collapse && !std::getenv("RPVG_HIP_NO_COLLAPSE") && list.rows_capacity > 0 &&
+                          list.rows_capacity <= 0x7fffffffull && P + 1 < kCollapseMaxMatrices;
+    if (collapse) {
+        auto cw = std::make_shared<CsrCollapseWork>();
+        work.collapse = cw;
+        RPVG_HIP_CHECK(hipEventCreateWithFlags(&work.filled, hipEventDisableTiming));
+        RPVG_HIP_CHECK(hipEventCreateWithFlags(&work.collapsed, hipEventDisableTiming));
+        RPVG_HIP_CHECK(hipEventRecord(work.filled, st));
+        RPVG_HIP_CHECK(hipStreamWaitEvent(ctx->collapse_stream, work.filled, 0));
+        CsrCollapseInput in;
+        in.num_problems_bound = P;
+        in.num_problems_dev = list.d_num_problems;
+        in.rows_capacity = list.rows_capacity;
+        in.row_base = list.d_row_base;
+        in.ent_base = list.d_ent_base;
+        in.kept_rows = out.d_kept_rows;
+        in.col_off = list.d_col_off;
+        in.prow_off = work.d_prow_off.ptr;
+        in.prow_count = work.d_prow_count.ptr;
+        in.prow_noise = work.d_prow_noise.ptr;
+        in.pent_col = work.d_pent_col.ptr;
+        in.pent_val = work.d_pent_val.ptr;
+        const int collapse_span = ctx->spanBegin(FAM_COLLAPSE, ctx->collapse_stream);
+        RPVG_HIP_CHECK(queueCsrCollapse(ctx, in, collapse_precision, *cw, ctx->collapse_stream));
+        ctx->spanEnd(collapse_span);
+        RPVG_HIP_CHECK(hipEventRecord(work.collapsed, ctx->collapse_stream));
+    }
     emOrderKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(P, list.d_num_problems, work.d_bucket.ptr, list.d_col_off, queues, work.d_order.ptr,
                                                               work.d_wide_off.ptr, list.wide_capacity);
     RPVG_HIP_CHECK(hipGetLastError());
@@ -1199,55 +1242,97 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     auto grid = [&](const uint32_t per_cu) { return std::min<uint32_t>(P, cus * per_cu); };
     const size_t streamed_lds_256 = emLdsBytes(list.max_cols, 0, 0, 256, false), streamed_lds_1024 = emLdsBytes(list.max_cols, 0, 0, 1024, false);
     const bool wide_possible = streamed_lds_1024 > kEmLdsLimit;
-    span = ctx->spanBegin(FAM_EM_SPARSE);
-    RPVG_HIP_CHECK(ctx->forkAux());
-    // The register-resident bins are the long ones: they start first.  With eight hardware queues
-    // (hardwareQueues(), context.hip) they get streams of their own; with four, streams beyond the fourth would only
-    // queue behind the others, and a bin that waits there ends later than one that shares a stream knowingly.
     const bool many_queues = hardwareQueues() >= 8;
     hipStream_t s_reg4 = many_queues ? ctx->aux[3] : ctx->aux[0], s_reg1 = many_queues ? ctx->aux[4] : ctx->aux[1], s_reg2 = many_queues ? ctx->aux[5] : ctx->aux[2];
-    // every bin's launch carries its own HIP events on its own stream (rpvg_hip_kernel_stats::em_kernel)
-    int bin_span = -1;
-    auto timed = [&](const int b, hipStream_t on) {
-        args.bin = static_cast<uint32_t>(b);
-        bin_span = ctx->spanBegin(FAM_EM_KERNEL, on, b);
-        return on;
+    // One persistent launch per kernel variant (the register-resident bins are the long ones: they start first; with
+    // eight hardware queues — hardwareQueues(), context.hip — they get streams of their own; chains of launches that share
+    // a stream run one after the other: balanced by the kernels' usual durations).  with_spans: every launch carries its
+    // own HIP events on its own stream (rpvg_hip_kernel_stats::em_kernel).
+    auto launchVariants = [&](const bool with_spans) -> int {
+        RPVG_HIP_CHECK(ctx->forkAux());
+        int bin_span = -1;
+        auto timed = [&](const int b, hipStream_t on) {
+            args.bin = static_cast<uint32_t>(b);
+            bin_span = with_spans ? ctx->spanBegin(FAM_EM_KERNEL, on, b) : -1;
+            return on;
+        };
+        RPVG_HIP_CHECK((launchEmRegister<4, 16>(args, grid(2), timed(6, s_reg4))));
+        ctx->spanEnd(bin_span);
+        RPVG_HIP_CHECK((launchEmRegister<1, 16>(args, grid(2), timed(4, s_reg1))));
+        ctx->spanEnd(bin_span);
+        RPVG_HIP_CHECK((launchEmRegister<2, 16>(args, grid(2), timed(5, s_reg2))));
+        ctx->spanEnd(bin_span);
+        timed(2, st);
+        RPVG_HIP_CHECK((launchEm<256, false>(args, grid(1), std::min(streamed_lds_256, kEmLdsLimit), st)));
+        ctx->spanEnd(bin_span);
+        timed(3, ctx->aux[0]);
+        RPVG_HIP_CHECK((launchEm<1024, false>(args, grid(1), std::min(streamed_lds_1024, kEmLdsLimit), ctx->aux[0])));
+        ctx->spanEnd(bin_span);
+        timed(7, ctx->aux[0]);
+        RPVG_HIP_CHECK((launchEm<1024, true>(args, grid(1), 152 * 1024, ctx->aux[0])));
+        ctx->spanEnd(bin_span);
+        timed(0, ctx->aux[1]);
+        RPVG_HIP_CHECK((launchEm<64, true>(args, grid(2), 8 * 1024, ctx->aux[1])));
+        ctx->spanEnd(bin_span);
+        timed(1, ctx->aux[2]);
+        RPVG_HIP_CHECK((launchEm<256, true>(args, grid(2), 40 * 1024, ctx->aux[2])));
+        ctx->spanEnd(bin_span);
+        if (list.max_cols > 16) {
+            RPVG_HIP_CHECK((launchEmRegister<1, 32>(args, grid(1), timed(8, ctx->aux[2]))));
+            ctx->spanEnd(bin_span);
+            RPVG_HIP_CHECK((launchEmRegister<2, 32>(args, grid(1), timed(9, ctx->aux[2]))));
+            ctx->spanEnd(bin_span);
+        }
+        if (wide_possible) {
+            timed(10, s_reg2);
+            RPVG_HIP_CHECK((launchEm<1024, false, true>(args, grid(1), sizeof(double) * (1024 / 64 + 2), s_reg2)));
+            ctx->spanEnd(bin_span);
+        }
+        RPVG_HIP_CHECK(ctx->joinAux());
+        return RPVG_HIP_OK;
     };
-    // (chains of launches that share a stream run one after the other: balanced by the kernels' usual durations)
-    RPVG_HIP_CHECK((launchEmRegister<4, 16>(args, grid(2), timed(6, s_reg4))));
-    ctx->spanEnd(bin_span);
-    RPVG_HIP_CHECK((launchEmRegister<1, 16>(args, grid(2), timed(4, s_reg1))));
-    ctx->spanEnd(bin_span);
-    RPVG_HIP_CHECK((launchEmRegister<2, 16>(args, grid(2), timed(5, s_reg2))));
-    ctx->spanEnd(bin_span);
-    timed(2, st);
-    RPVG_HIP_CHECK((launchEm<256, false>(args, grid(1), std::min(streamed_lds_256, kEmLdsLimit), st)));
-    ctx->spanEnd(bin_span);
-    timed(3, ctx->aux[0]);
-    RPVG_HIP_CHECK((launchEm<1024, false>(args, grid(1), std::min(streamed_lds_1024, kEmLdsLimit), ctx->aux[0])));
-    ctx->spanEnd(bin_span);
-    timed(7, ctx->aux[0]);
-    RPVG_HIP_CHECK((launchEm<1024, true>(args, grid(1), 152 * 1024, ctx->aux[0])));
-    ctx->spanEnd(bin_span);
-    timed(0, ctx->aux[1]);
-    RPVG_HIP_CHECK((launchEm<64, true>(args, grid(2), 8 * 1024, ctx->aux[1])));
-    ctx->spanEnd(bin_span);
-    timed(1, ctx->aux[2]);
-    RPVG_HIP_CHECK((launchEm<256, true>(args, grid(2), 40 * 1024, ctx->aux[2])));
-    ctx->spanEnd(bin_span);
-    if (list.max_cols > 16) {
-        RPVG_HIP_CHECK((launchEmRegister<1, 32>(args, grid(1), timed(8, ctx->aux[2]))));
-        ctx->spanEnd(bin_span);
-        RPVG_HIP_CHECK((launchEmRegister<2, 32>(args, grid(1), timed(9, ctx->aux[2]))));
-        ctx->spanEnd(bin_span);
+    span = ctx->spanBegin(FAM_EM_SPARSE);
+    {
+        const int rc = launchVariants(true);
+        if (rc != RPVG_HIP_OK) return rc;
     }
-    if (wide_possible) {
-        timed(10, s_reg2);
-        RPVG_HIP_CHECK((launchEm<1024, false, true>(args, grid(1), sizeof(double) * (1024 / 64 + 2), s_reg2)));
-        ctx->spanEnd(bin_span);
-    }
-    RPVG_HIP_CHECK(ctx->joinAux());
     ctx->spanEnd(span);
+    if (collapse) {
+        // Second pass: the problems in which the row collapse — which ran next to the first pass, on the collapse stream —
+        // merged rows that were not equal up to rounding are solved again on the merged counts (a merged row's count at
+        // its run head, zero where it was) and overwrite their results.  Nearly always there is none: the launches find
+        // empty queues.
+        CsrCollapseWork * cw = static_cast<CsrCollapseWork *>(work.collapse.get());
+        RPVG_HIP_CHECK(hipStreamWaitEvent(st, work.collapsed, 0));
+        RPVG_HIP_CHECK(work.d_queues_merged.alloc(sizeof(EmQueues)));
+        EmQueues * queues2 = reinterpret_cast<EmQueues *>(work.d_queues_merged.ptr);
+        span = ctx->spanBegin(FAM_EM_SPARSE);
+        RPVG_HIP_CHECK(hipMemsetAsync(queues2, 0, sizeof(EmQueues), st));
+        emMergedHistogramKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(P, list.d_num_problems, work.d_bucket.ptr, cw->problem_merged.ptr, queues2);
+        emOrderKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(P, list.d_num_problems, work.d_bucket.ptr, list.d_col_off, queues2, work.d_order.ptr,
+                                                                  work.d_wide_off.ptr, list.wide_capacity, cw->problem_merged.ptr);
+        RPVG_HIP_CHECK(hipGetLastError());
+        args.queues = queues2;
+        args.prow_count = cw->merged_count.ptr;
+        const int rc = launchVariants(false);
+        if (rc != RPVG_HIP_OK) return rc;
+        ctx->spanEnd(span);
+        static const bool debug = std::getenv("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
+        if (debug) {  // (synchronises: a measuring aid)
+            uint32_t info[6] = {0}, merged = 0, problems = P, counts[3] = {0};
+            RPVG_HIP_CHECK(hipStreamSynchronize(st));
+            RPVG_HIP_CHECK(hipMemcpy(info, cw->info.ptr, sizeof(info), hipMemcpyDeviceToHost));
+            RPVG_HIP_CHECK(hipMemcpy(&merged, cw->problem_merged.ptr + P, sizeof(merged), hipMemcpyDeviceToHost));
+            if (list.d_num_problems) RPVG_HIP_CHECK(hipMemcpy(&problems, list.d_num_problems, sizeof(problems), hipMemcpyDeviceToHost));
+            {   // (layout of the zeroed words: queueCollapseStages)
+                const uint64_t mark_words = (list.rows_capacity + 31) / 32;
+                RPVG_HIP_CHECK(hipMemcpy(counts, cw->info.ptr + 6 + 2 + 2 * static_cast<uint64_t>(P) + 1 + mark_words, sizeof(counts), hipMemcpyDeviceToHost));
+            }
+            std::fprintf(stderr, "[em collapse] marked rows %u forward pairs %u (equal up to rounding %u, apart %u) around pairs %u\n", counts[0], counts[1], info[4], info[5], counts[2]);
+            std::fprintf(stderr, "[em collapse] problems %u (bound %u) row slots %llu: replayed %u whole %u active rows %u rows replaced %u problems merged %u\n",
+                         problems, P, static_cast<unsigned long long>(list.rows_capacity), info[0], info[2], info[3], info[1], merged);
+        }
+    }
     return RPVG_HIP_OK;
 }
 
@@ -1491,7 +1576,7 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     int rc = prepareHostProblems(ctx, batch, problems, ps, out, "rpvg_hip_em_solve");
     if (rc != RPVG_HIP_OK) return rc;
     std::unique_ptr<HostScope> scope(new HostScope("em_solve: launches"));
-    rc = queueEmSolve(ctx, batch, ps.list, max_em_its, max_rel_em_conv, out, ps.work, false);
+    rc = queueEmSolve(ctx, batch, ps.list, max_em_its, max_rel_em_conv, out, ps.work, false, problems->collapse_precision);
     if (rc != RPVG_HIP_OK) return rc;
 
     scope.reset(new HostScope("em_solve: wait for the kernels + download"));

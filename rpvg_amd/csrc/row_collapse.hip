@@ -44,6 +44,8 @@ namespace {
 
 constexpr int kKeyFractionBits = kCollapseKeyFractionBits;
 constexpr uint32_t kMaxWindowCompares = 256;   // a row with more candidates than this sends its matrix to the full sort
+enum : uint8_t { kRowListed = 1, kRowStoodFor = 2 };
+constexpr int kCsrCellHashBits = 8;  // of the sort key's low field, for the rows of EM problems (CsrArrays)
 constexpr double kEquivalentRelative = 1e-13;  // close rows that differ by no more than this are interchangeable
 constexpr uint32_t kListLdsRows = 8192;        // row lists up to this size live (and are sorted) in LDS
 constexpr uint32_t kSortThreads = 1024;
@@ -58,7 +60,7 @@ constexpr uint64_t kPairTableBytes = 16ull << 20;
 constexpr uint8_t kPairLess = 1, kPairClose = 2;
 
 enum : uint32_t { kFlagNone = 0, kFlagActiveRows = 1, kFlagWholeMatrix = 2 };
-enum : uint32_t { kInfoMatrices = 0, kInfoRowsReplaced = 1, kInfoWholeMatrices = 2, kInfoActiveRows = 3, kInfoWords = 4 };
+enum : uint32_t { kInfoMatrices = 0, kInfoRowsReplaced = 1, kInfoWholeMatrices = 2, kInfoActiveRows = 3, kInfoPairsEquivalent = 4, kInfoPairsApart = 5, kInfoWords = 6 };
 
 __device__ __forceinline__ bool tolerantEqual(const double a, const double b) {  // Utils::doubleCompare, src/utils.hpp:87-93
     return a == b || fabs(a - b) < fabs(fmin(a, b)) * (DBL_EPSILON * 100);
@@ -77,6 +79,31 @@ struct MatrixView {
         const double * address = column < G ? values + (static_cast<uint64_t>(column) * R + row) : noise + row;
         return __builtin_nontemporal_load(address);
     }
+    __device__ __forceinline__ uint64_t patternOf(const uint32_t row) const { return pattern[row]; }
+    __device__ __forceinline__ double countOf(const uint32_t row) const { return count[row]; }
+};
+
+// The rows of one EM problem (em_sparse.hip: the compacted CSR of a cluster restricted to a path subset): the same
+// interface over sparse rows.  A row holds a handful of entries, in no particular column order: at() walks them.
+struct CsrView {
+    const uint32_t * off;      // [R + 1] entry range of every row, relative to `col` / `val`
+    const uint32_t * col;
+    const double * val;
+    const double * noise;
+    const double * count;
+    const uint64_t * pattern;
+    uint64_t R;
+    uint32_t G;
+    __device__ __forceinline__ double at(const uint32_t column, const uint32_t row) const {
+        if (column >= G) return noise[row];
+        double value = 0.0;
+        for (uint32_t e = off[row]; e < off[row + 1]; ++e) {
+            if (col[e] == column) value = val[e];
+        }
+        return value;
+    }
+    __device__ __forceinline__ uint64_t patternOf(const uint32_t row) const { return pattern[row]; }
+    __device__ __forceinline__ double countOf(const uint32_t row) const { return count[row]; }
 };
 
 // Rows that are compared in depth agree in most columns, and a column costs two strided loads.  The comparisons below
@@ -85,8 +112,8 @@ struct MatrixView {
 // so that the loads are in flight together.
 constexpr uint32_t kBatch = 8;
 
-template <typename Decide>  // decide(x, y) -> true: stop
-__device__ __forceinline__ void forEachColumnPair(const MatrixView & mv, const uint32_t a, const uint32_t b, uint64_t live, Decide decide) {
+template <typename View, typename Decide>  // decide(x, y) -> true: stop
+__device__ __forceinline__ void forEachColumnPair(const View & mv, const uint32_t a, const uint32_t b, uint64_t live, Decide decide) {
     uint32_t next_wide = 64;  // columns from 64 on carry no pattern: all of them
     bool noise_done = false;
     while (true) {
@@ -117,7 +144,8 @@ __device__ __forceinline__ void forEachColumnPair(const MatrixView & mv, const u
 }
 
 // probabilityCountRowSorter (src/path_estimator.cpp:13-31) on rows a, b of one matrix
-__device__ bool rowLess(const MatrixView & mv, const uint32_t a, const uint32_t b, const uint64_t pattern_a, const uint64_t pattern_b) {
+template <typename View>
+__device__ bool rowLess(const View & mv, const uint32_t a, const uint32_t b, const uint64_t pattern_a, const uint64_t pattern_b) {
     int result = -1;
     forEachColumnPair(mv, a, b, pattern_a | pattern_b, [&](const double x, const double y) {
         if (tolerantEqual(x, y)) return false;
@@ -125,20 +153,22 @@ __device__ bool rowLess(const MatrixView & mv, const uint32_t a, const uint32_t 
         return true;
     });
     if (result >= 0) return result != 0;
-    const double x = mv.count[a], y = mv.count[b];
+    const double x = mv.countOf(a), y = mv.countOf(b);
     if (!tolerantEqual(x, y)) return x < y;
     return false;
 }
 
-__device__ __forceinline__ bool rowLess(const MatrixView & mv, const uint32_t a, const uint32_t b) {
-    return rowLess(mv, a, b, mv.pattern[a], mv.pattern[b]);
+template <typename View>
+__device__ __forceinline__ bool rowLess(const View & mv, const uint32_t a, const uint32_t b) {
+    return rowLess(mv, a, b, mv.patternOf(a), mv.patternOf(b));
 }
 
 // every column (noise included) within `precision` of each other, absolutely (src/path_estimator.cpp:232-239);
 // *equivalent: additionally equal up to rounding in every column
-__device__ bool rowsClose(const MatrixView & mv, const uint32_t a, const uint32_t b, const double precision, bool * equivalent) {
+template <typename View>
+__device__ bool rowsClose(const View & mv, const uint32_t a, const uint32_t b, const double precision, bool * equivalent) {
     bool eq = true, close = true;
-    forEachColumnPair(mv, a, b, mv.pattern[a] | mv.pattern[b], [&](const double x, const double y) {
+    forEachColumnPair(mv, a, b, mv.patternOf(a) | mv.patternOf(b), [&](const double x, const double y) {
         const double d = fabs(x - y);
         if (d >= precision) {
             close = false;
@@ -151,9 +181,28 @@ __device__ bool rowsClose(const MatrixView & mv, const uint32_t a, const uint32_
     return close;
 }
 
-__device__ bool rowsIdentical(const MatrixView & mv, const uint32_t a, const uint32_t b) {
+// The rows of an EM problem are cluster rows cut down to the problem's columns: thousands of them agree up to the rounding of
+// their last normalisation, not bit for bit.  A "cell" is a value's multiple of 2^-44 (5.7e-14, five orders below the
+// precision of the collapse): rows with the same cells in every column stand for each other in the search for close rows.
+constexpr double kCellsPerUnit = 0x1p44;
+constexpr double kCellWidth = 0x1p-44;
+__device__ __forceinline__ int64_t cellOf(const double v) { return static_cast<int64_t>(v * kCellsPerUnit); }
+
+template <typename View>
+__device__ bool rowsSameCells(const View & mv, const uint32_t a, const uint32_t b) {
     bool same = true;
-    forEachColumnPair(mv, a, b, mv.pattern[a] | mv.pattern[b], [&](const double x, const double y) {
+    forEachColumnPair(mv, a, b, mv.patternOf(a) | mv.patternOf(b), [&](const double x, const double y) {
+        if (cellOf(x) == cellOf(y)) return false;
+        same = false;
+        return true;
+    });
+    return same;
+}
+
+template <typename View>
+__device__ bool rowsIdentical(const View & mv, const uint32_t a, const uint32_t b) {
+    bool same = true;
+    forEachColumnPair(mv, a, b, mv.patternOf(a) | mv.patternOf(b), [&](const double x, const double y) {
         if (x == y) return false;
         same = false;
         return true;
@@ -170,23 +219,70 @@ struct MatrixArrays {
     double * row_noise;
     const double * row_count;
     const uint64_t * zero_pattern;
+    typedef MatrixView View;
+    static constexpr int kHashBits = 0;  // stretches: bit for bit equal rows
+    __device__ __forceinline__ uint64_t rowOffset(const uint32_t m) const { return mat_row_off[m]; }
+    __device__ __forceinline__ uint64_t numRows(const uint32_t m) const { return mat_rows[m]; }
+    __device__ __forceinline__ uint32_t numCols(const uint32_t m) const { return mat_cols[m]; }
+    __device__ __forceinline__ MatrixView view(const uint32_t m) const {
+        MatrixView mv;
+        mv.values = values + mat_val_off[m];
+        mv.noise = row_noise + mat_row_off[m];
+        mv.count = row_count + mat_row_off[m];
+        mv.pattern = zero_pattern + mat_row_off[m];
+        mv.R = mat_rows[m];
+        mv.G = mat_cols[m];
+        return mv;
+    }
 };
 
-__device__ __forceinline__ MatrixView viewOf(const uint32_t m, const MatrixArrays & g) {
-    MatrixView mv;
-    mv.values = g.values + g.mat_val_off[m];
-    mv.noise = g.row_noise + g.mat_row_off[m];
-    mv.count = g.row_count + g.mat_row_off[m];
-    mv.pattern = g.zero_pattern + g.mat_row_off[m];
-    mv.R = g.mat_rows[m];
-    mv.G = g.mat_cols[m];
-    return mv;
-}
+// the EM problems of a solve as "matrices": problem p's rows sit at row_base[p] (the layout by the bound: there are unused
+// row slots between the problems, whose sort keys carry a matrix index no problem has)
+struct CsrArrays {
+    const uint64_t * row_base;     // [P]
+    const uint64_t * ent_base;     // [P]
+    const uint32_t * kept_rows;    // [P]
+    const uint64_t * col_off;      // [P+1]
+    const uint32_t * prow_off;     // [rows + P]
+    const double * prow_count;
+    const double * prow_noise;
+    const uint32_t * pent_col;
+    const double * pent_val;
+    const uint64_t * zero_pattern; // [rows]
+    double * merged_count;         // [rows] read counts after the merges (written for the problems with a replay)
+    uint32_t * problem_merged;     // [P] 1: rows of the problem were merged
+    uint32_t * merged_problems;    // [0]: their number
+    typedef CsrView View;
+    static constexpr int kHashBits = kCsrCellHashBits;  // stretches: rows of equal cells (rowsSameCells), kept together by a hash of them in the key
+    __device__ __forceinline__ uint64_t rowOffset(const uint32_t p) const { return row_base[p]; }
+    __device__ __forceinline__ uint64_t numRows(const uint32_t p) const { return kept_rows[p]; }
+    __device__ __forceinline__ uint32_t numCols(const uint32_t p) const { return static_cast<uint32_t>(col_off[p + 1] - col_off[p]); }
+    __device__ __forceinline__ CsrView view(const uint32_t p) const {
+        CsrView mv;
+        const uint64_t rb = row_base[p], eb = ent_base[p];
+        mv.off = prow_off + rb + p;
+        mv.col = pent_col + eb;
+        mv.val = pent_val + eb;
+        mv.noise = prow_noise + rb;
+        mv.count = prow_count + rb;
+        mv.pattern = zero_pattern + rb;
+        mv.R = kept_rows[p];
+        mv.G = numCols(p);
+        return mv;
+    }
+};
+
+template <typename Arrays>
+__device__ __forceinline__ typename Arrays::View viewOf(const uint32_t m, const Arrays & g) { return g.view(m); }
 
 // ---- sort key fields (collapseSortKey, common.hpp) -------------------------------------------------------------
 __device__ __forceinline__ uint32_t keyMatrix(const uint64_t key) { return static_cast<uint32_t>(key >> kCollapseMatrixShift); }
-__device__ __forceinline__ uint64_t keySorted(const uint64_t key) { return key >> kCollapseLargestBits; }  // (matrix, projection)
-__device__ __forceinline__ int64_t keyLargest(const uint64_t key) { return static_cast<int64_t>(key & ((1ull << kCollapseLargestBits) - 1)); }
+// HASH bits at the top of the low field belong to the sorted part (EM problems: a hash of the row's cells)
+template <int HASH>
+__device__ __forceinline__ uint64_t keySorted(const uint64_t key) { return key >> (kCollapseLargestBits - HASH); }  // (matrix, projection[, hash])
+__device__ __forceinline__ uint64_t keyProjection(const uint64_t key) { return key >> kCollapseLargestBits; }  // (matrix, projection)
+template <int HASH>
+__device__ __forceinline__ int64_t keyLargest(const uint64_t key) { return static_cast<int64_t>(key & ((1ull << (kCollapseLargestBits - HASH)) - 1)); }
 
 // |key_a - key_b| <= sum_c w_c |a_c - b_c| < 2 (G + 1) precision for close rows; + rounding of the keys, + 2 quanta
 __device__ __forceinline__ uint64_t windowQuanta(const uint32_t G, const double precision) {
@@ -196,44 +292,54 @@ __device__ __forceinline__ uint64_t windowQuanta(const uint32_t G, const double 
 
 // the largest values of close rows lie within the precision of each other: steps of the key's low field apart
 // (the field wraps: half its range or more means "no filter")
+template <int HASH>
 __device__ __forceinline__ int64_t largestSteps(const double precision) {
-    const double steps = precision * static_cast<double>(1ull << kCollapseLargestFractionBits) + 1.0;
-    return steps >= static_cast<double>(1ull << (kCollapseLargestBits - 1)) ? (1ll << kCollapseLargestBits) : static_cast<int64_t>(steps);
+    const double steps = precision * static_cast<double>(1ull << kCollapseLargestFractionBits) + (HASH ? 2.0 : 1.0);  // (rows of equal cells: up to a step from their first)
+    return steps >= static_cast<double>(1ull << (kCollapseLargestBits - HASH - 1)) ? (1ll << (kCollapseLargestBits - HASH)) : static_cast<int64_t>(steps);
 }
 
 // `other` (at or behind `key` in the sorted order) can be close to `key`'s row
+template <int HASH>
 __device__ __forceinline__ bool inWindow(const uint64_t key, const uint64_t other, const uint64_t window_q, const int64_t largest_steps, bool * beyond) {
-    *beyond = keyMatrix(other) != keyMatrix(key) || keySorted(other) - keySorted(key) > window_q;
+    *beyond = keyMatrix(other) != keyMatrix(key) || keyProjection(other) - keyProjection(key) > window_q;
     if (*beyond) return false;
-    int64_t d = (keyLargest(other) - keyLargest(key)) & ((1ll << kCollapseLargestBits) - 1);  // modulo the field
-    if (d >= (1ll << (kCollapseLargestBits - 1))) d -= 1ll << kCollapseLargestBits;
+    constexpr int bits = kCollapseLargestBits - HASH;
+    int64_t d = (keyLargest<HASH>(other) - keyLargest<HASH>(key)) & ((1ll << bits) - 1);  // modulo the field
+    if (d >= (1ll << (bits - 1))) d -= 1ll << bits;
     return d <= largest_steps && -d <= largest_steps;
 }
 
 // ---- stage 1: close pairs ---------------------------------------------------------------------------------------
 
+template <typename Arrays>
 struct PairScanArgs {
+    uint32_t num_matrices;   // sort keys with a matrix index from here on belong to unused row slots (EM problems)
     uint64_t total_rows;
     double precision;
     const uint64_t * sort_key;   // sorted (matrix, key, largest value)
     const uint32_t * sort_row;   // position of the row in the row arrays (mat_row_off[m] + row)
-    MatrixArrays g;
+    Arrays g;
     uint8_t * same_prev;     // [total rows] by sorted position
+    uint32_t * stretch_first; // [total rows] by sorted position: first position of the stretch of bit-for-bit equal rows it lies in
+    uint32_t * stretch_end;   // [total rows] at the first position of a stretch: one past its last
+    uint32_t * position_of;   // [total rows] by row: its sorted position (EM problems)
     uint32_t * marked_bits;  // [total rows / 32] by row: has a close partner that is not its equal up to rounding
     uint32_t * marked_list;  // [total rows] sorted positions of the marked rows
     uint32_t * marked_count;
     uint32_t * pairs;        // [2 x pair_capacity] candidate pairs (sorted positions) of the scan that runs
     uint32_t * pair_count;   // its number of pairs
     uint32_t pair_capacity;
-    uint8_t * active;        // [total rows] by row: marked, or close to a marked row
+    uint8_t * active;        // [total rows] by row: kRowListed: marked, or close to a marked row; kRowStoodFor (EM problems): the first row of its stretch is
     uint32_t * mat_flag;     // [M]
     uint32_t * info;
+    bool count_pairs;        // measuring aid: info[] counts the candidate pairs that were equal up to rounding / not close
 };
 
 // The window scans only collect candidate pairs; the comparisons, each a few dependent rounds of strided loads, then
 // run one per thread, all at once (a thread that walked its window and compared as it went spent ~1 us per step:
 // 0.2-0.4 ms for the longest windows of the batch).
-__device__ __forceinline__ bool appendPair(const PairScanArgs & a, const uint64_t p, const uint64_t q) {
+template <typename Arrays>
+__device__ __forceinline__ bool appendPair(const PairScanArgs<Arrays> & a, const uint64_t p, const uint64_t q) {
     const uint32_t slot = atomicAdd(a.pair_count, 1u);
     if (slot >= a.pair_capacity) return false;
     a.pairs[2 * static_cast<uint64_t>(slot)] = static_cast<uint32_t>(p);
@@ -242,40 +348,61 @@ __device__ __forceinline__ bool appendPair(const PairScanArgs & a, const uint64_
 }
 
 // same_prev[p] = the row at sorted position p is bit for bit the row at p - 1 (same matrix)
-__global__ void collapseSamePrevKernel(const PairScanArgs a) {
+template <typename Arrays>
+__global__ void collapseSamePrevKernel(const PairScanArgs<Arrays> a) {
     const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (p >= a.total_rows) return;
     uint8_t same = 0;
-    if (p > 0 && a.sort_key[p] == a.sort_key[p - 1]) {  // equal keys: nearly always the same values twice; the comparison leaves at the first difference
+    constexpr int HASH = Arrays::kHashBits;
+    // equal keys (with a hash: equal sorted parts — the largest values of rows of equal cells can lie a step apart):
+    // nearly always the same values twice; the comparison leaves at the first difference
+    if (p > 0 && (HASH ? keySorted<HASH>(a.sort_key[p]) == keySorted<HASH>(a.sort_key[p - 1]) : a.sort_key[p] == a.sort_key[p - 1]) &&
+        keyMatrix(a.sort_key[p]) < a.num_matrices) {
         const uint32_t m = keyMatrix(a.sort_key[p]);
-        const MatrixView mv = viewOf(m, a.g);
-        const uint64_t r0 = a.g.mat_row_off[m];
-        same = rowsIdentical(mv, static_cast<uint32_t>(a.sort_row[p] - r0), static_cast<uint32_t>(a.sort_row[p - 1] - r0)) ? 1 : 0;
+        const typename Arrays::View mv = viewOf(m, a.g);
+        const uint64_t r0 = a.g.rowOffset(m);
+        const uint32_t row = static_cast<uint32_t>(a.sort_row[p] - r0), before = static_cast<uint32_t>(a.sort_row[p - 1] - r0);
+        same = (HASH ? rowsSameCells(mv, row, before) : rowsIdentical(mv, row, before)) ? 1 : 0;
     }
     a.same_prev[p] = same;
+    if (HASH) a.position_of[a.sort_row[p]] = static_cast<uint32_t>(p);
+    a.stretch_first[p] = same ? 0u : static_cast<uint32_t>(p);  // (the running maximum of these is the stretch's first position)
 }
 
-// every row lists the rows after it whose keys lie within the window (a window too crowded to list sends the matrix
-// to the full sort)
-__global__ void collapseForwardPairsKernel(const PairScanArgs a) {
+// stretch_end[] of every stretch, written by its last position
+template <typename Arrays>
+__global__ void collapseStretchEndKernel(const PairScanArgs<Arrays> a) {
     const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (p + 1 >= a.total_rows) return;
+    if (p >= a.total_rows) return;
+    if (p + 1 == a.total_rows || !a.same_prev[p + 1]) a.stretch_end[a.stretch_first[p]] = static_cast<uint32_t>(p + 1);
+}
+
+// The first row of every stretch of equal rows lists the stretches after it whose keys lie within the window (a window too
+// crowded to list sends the matrix to the full sort).  The scans step from stretch to stretch: the rows of an EM problem are
+// cluster rows cut down to a few columns, thousands of them bit for bit the same, and a scan that walked over every copy
+// took 3 ms on the problems of one batch.
+template <typename Arrays>
+__global__ void collapseForwardPairsKernel(const PairScanArgs<Arrays> a) {
+    const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (p + 1 >= a.total_rows || a.same_prev[p]) return;
+    const uint64_t first = a.stretch_end[p];
+    if (first >= a.total_rows) return;
     const uint64_t key = a.sort_key[p];
-    const uint64_t next = a.sort_key[p + 1];
+    const uint64_t next = a.sort_key[first];
     const uint32_t m = keyMatrix(key);
-    if (keyMatrix(next) != m) return;
-    const uint64_t window_q = windowQuanta(a.g.mat_cols[m], a.precision);
-    if (keySorted(next) - keySorted(key) > window_q) return;  // nearly every row leaves here
-    const int64_t largest_steps = largestSteps(a.precision);
+    if (keyMatrix(next) != m || m >= a.num_matrices) return;
+    const uint64_t window_q = windowQuanta(a.g.numCols(m), a.precision);
+    if (keyProjection(next) - keyProjection(key) > window_q) return;  // nearly every row leaves here
+    constexpr int HASH = Arrays::kHashBits;
+    const int64_t largest_steps = largestSteps<HASH>(a.precision);
     uint32_t listed = 0;
-    for (uint64_t q = p + 1; q < a.total_rows; ++q) {
+    for (uint64_t q = first; q < a.total_rows; q = a.stretch_end[q]) {
         const uint64_t other = a.sort_key[q];
         bool beyond;
-        if (!inWindow(key, other, window_q, largest_steps, &beyond)) {
+        if (!inWindow<HASH>(key, other, window_q, largest_steps, &beyond)) {
             if (beyond) break;
             continue;
         }
-        if (a.same_prev[q]) continue;  // bit for bit the row before it: this row itself, or a candidate already listed
         if (++listed > kMaxWindowCompares || !appendPair(a, p, q)) {
             atomicMax(&a.mat_flag[m], static_cast<uint32_t>(kFlagWholeMatrix));
             break;
@@ -284,76 +411,126 @@ __global__ void collapseForwardPairsKernel(const PairScanArgs a) {
 }
 
 // marks the row at sorted position p; the first marker puts it on the list
-__device__ __forceinline__ void markRow(const PairScanArgs & a, const uint64_t p) {
+template <typename Arrays>
+__device__ __forceinline__ void markRow(const PairScanArgs<Arrays> & a, const uint64_t p) {
     const uint32_t row = a.sort_row[p];
     const uint32_t bit = 1u << (row & 31);
     if ((atomicOr(&a.marked_bits[row >> 5], bit) & bit) == 0) a.marked_list[atomicAdd(a.marked_count, 1u)] = static_cast<uint32_t>(p);
 }
 
-__device__ __forceinline__ bool isMarked(const PairScanArgs & a, const uint32_t row) { return (a.marked_bits[row >> 5] >> (row & 31)) & 1u; }
+template <typename Arrays>
+__device__ __forceinline__ bool isMarked(const PairScanArgs<Arrays> & a, const uint32_t row) { return (a.marked_bits[row >> 5] >> (row & 31)) & 1u; }
 
-// both rows of a close pair that is not equal up to rounding are marked
-__global__ void collapseMarkPairsKernel(const PairScanArgs a) {
+// what a candidate pair of first rows has to pass for their stretches to count as close: the rows of a stretch lie within a
+// cell of its first row (bit for bit equal rows: no margin)
+template <typename Arrays>
+__device__ __forceinline__ double pairPrecision(const double precision) { return Arrays::kHashBits ? precision + 2 * kCellWidth : precision; }
+
+// the wave walks the stretches that start at the sorted positions its lanes hold in `first` (lanes with `wanted`):
+// visit(position) for every row of them
+template <typename Arrays, typename Visit>
+__device__ __forceinline__ void forEachRowOfStretches(const PairScanArgs<Arrays> & a, const bool wanted, const uint32_t first, Visit visit) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t todo = __ballot(wanted); todo; todo &= todo - 1) {
+        const int source = __ffsll(static_cast<long long>(todo)) - 1;
+        const uint32_t begin = __shfl(first, source), end = a.stretch_end[begin];
+        for (uint32_t s = begin + lane; s < end; s += 64) visit(s);
+    }
+}
+
+// first position of the stretch that sorted position s lies in
+template <typename Arrays>
+__device__ __forceinline__ uint32_t p0(const PairScanArgs<Arrays> & a, const uint32_t s) { return a.stretch_first[s]; }
+
+// both stretches of a close pair that is not equal up to rounding are marked (blocks of one wave)
+template <typename Arrays>
+__global__ void collapseMarkPairsKernel(const PairScanArgs<Arrays> a) {
     const uint32_t count = min(*a.pair_count, a.pair_capacity);
-    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
-        const uint64_t p = a.pairs[2 * static_cast<uint64_t>(item)], q = a.pairs[2 * static_cast<uint64_t>(item) + 1];
-        const uint32_t m = keyMatrix(a.sort_key[p]);
-        const MatrixView mv = viewOf(m, a.g);
-        const uint64_t r0 = a.g.mat_row_off[m];
-        bool equivalent = true;
-        if (rowsClose(mv, static_cast<uint32_t>(a.sort_row[p] - r0), static_cast<uint32_t>(a.sort_row[q] - r0), a.precision, &equivalent) && !equivalent) {
-            markRow(a, p);
-            markRow(a, q);
-            // the rows that are this candidate bit for bit are marked with it (a row's own copies list the candidate themselves)
-            for (uint64_t s = q + 1; s < a.total_rows && a.same_prev[s]; ++s) markRow(a, s);
-            atomicMax(&a.mat_flag[m], static_cast<uint32_t>(kFlagActiveRows));
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+        const uint32_t item = base + threadIdx.x;
+        uint32_t p = 0, q = 0;
+        bool mark = false;
+        if (item < count) {
+            p = a.pairs[2 * static_cast<uint64_t>(item)];
+            q = a.pairs[2 * static_cast<uint64_t>(item) + 1];
+            const uint32_t m = keyMatrix(a.sort_key[p]);
+            const typename Arrays::View mv = viewOf(m, a.g);
+            const uint64_t r0 = a.g.rowOffset(m);
+            bool equivalent = true;
+            const bool close = rowsClose(mv, static_cast<uint32_t>(a.sort_row[p] - r0), static_cast<uint32_t>(a.sort_row[q] - r0), pairPrecision<Arrays>(a.precision), &equivalent);
+            if (a.count_pairs) atomicAdd(&a.info[close ? kInfoPairsEquivalent : kInfoPairsApart], close && !equivalent ? 0u : 1u);
+            mark = close && !equivalent;
+            if (mark) atomicMax(&a.mat_flag[m], static_cast<uint32_t>(kFlagActiveRows));
+        }
+        if (Arrays::kHashBits) {
+            // EM problems: the first row of a stretch goes through the replay for all of it (finishRuns); the others only must
+            // not count as rows that part neighbours of the lists
+            if (mark) {
+                markRow(a, p);
+                markRow(a, q);
+            }
+            forEachRowOfStretches(a, mark, p, [&](const uint32_t s) { if (s != p0(a, s)) a.active[a.sort_row[s]] = kRowStoodFor; });
+            forEachRowOfStretches(a, mark, q, [&](const uint32_t s) { if (s != p0(a, s)) a.active[a.sort_row[s]] = kRowStoodFor; });
+        } else {
+            forEachRowOfStretches(a, mark, p, [&](const uint32_t s) { markRow(a, s); });
+            forEachRowOfStretches(a, mark, q, [&](const uint32_t s) { markRow(a, s); });
         }
     }
 }
 
-// active = marked, or close to a marked row: every marked row (they are few: a list) lists its window, both ways
-__global__ void collapseAroundPairsKernel(const PairScanArgs a) {
+// active = marked, or close to a marked row: the first row of every marked stretch (they are few: a list) lists its
+// window, both ways, stretch by stretch
+template <typename Arrays>
+__global__ void collapseAroundPairsKernel(const PairScanArgs<Arrays> a) {
     const uint32_t count = *a.marked_count;
     for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
         const uint64_t p = a.marked_list[item];
-        a.active[a.sort_row[p]] = 1;
+        a.active[a.sort_row[p]] = kRowListed;
+        if (a.same_prev[p]) continue;  // a copy: the first row of its stretch lists for it
         const uint64_t key = a.sort_key[p];
         const uint32_t m = keyMatrix(key);
-        const uint64_t window_q = windowQuanta(a.g.mat_cols[m], a.precision);
-        const int64_t largest_steps = largestSteps(a.precision);
+        const uint64_t window_q = windowQuanta(a.g.numCols(m), a.precision);
+        constexpr int HASH = Arrays::kHashBits;
+        const int64_t largest_steps = largestSteps<HASH>(a.precision);
         uint32_t listed = 0;
         bool crowded = false;
-        for (int direction = 0; direction < 2 && !crowded; ++direction) {
-            for (uint64_t step = 1; !crowded; ++step) {
-                if (direction == 0 ? p + step >= a.total_rows : step > p) break;
-                const uint64_t q = direction == 0 ? p + step : p - step;
-                const uint64_t other = a.sort_key[q];
-                bool beyond;
-                const bool candidate = direction == 0 ? inWindow(key, other, window_q, largest_steps, &beyond)
-                                                      : inWindow(other, key, window_q, largest_steps, &beyond);
-                if (beyond) break;
-                // bit for bit the position looked at before it (same_prev[] looks towards lower positions): decided with it
-                const bool repeat = direction == 0 ? a.same_prev[q] != 0 : a.same_prev[q + 1] != 0;
-                if (!candidate || repeat || isMarked(a, a.sort_row[q])) continue;
-                if (++listed > kMaxWindowCompares || !appendPair(a, p, q)) crowded = true;
-            }
+        for (uint64_t q = a.stretch_end[p]; q < a.total_rows && !crowded; q = a.stretch_end[q]) {
+            bool beyond;
+            const bool candidate = inWindow<HASH>(key, a.sort_key[q], window_q, largest_steps, &beyond);
+            if (beyond) break;
+            if (!candidate || isMarked(a, a.sort_row[q])) continue;
+            if (++listed > kMaxWindowCompares || !appendPair(a, p, q)) crowded = true;
+        }
+        for (uint64_t below = p; below > 0 && !crowded;) {
+            const uint64_t q = a.stretch_first[below - 1];
+            below = q;
+            bool beyond;
+            const bool candidate = inWindow<HASH>(a.sort_key[q], key, window_q, largest_steps, &beyond);
+            if (beyond) break;
+            if (!candidate || isMarked(a, a.sort_row[q])) continue;
+            if (++listed > kMaxWindowCompares || !appendPair(a, p, q)) crowded = true;
         }
         if (crowded) atomicMax(&a.mat_flag[m], static_cast<uint32_t>(kFlagWholeMatrix));
     }
 }
 
-__global__ void collapseActivePairsKernel(const PairScanArgs a) {
+template <typename Arrays>
+__global__ void collapseActivePairsKernel(const PairScanArgs<Arrays> a) {  // (blocks of one wave)
     const uint32_t count = min(*a.pair_count, a.pair_capacity);
-    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
-        const uint64_t p = a.pairs[2 * static_cast<uint64_t>(item)], q = a.pairs[2 * static_cast<uint64_t>(item) + 1];
-        const uint32_t m = keyMatrix(a.sort_key[p]);
-        const MatrixView mv = viewOf(m, a.g);
-        const uint64_t r0 = a.g.mat_row_off[m];
-        if (!rowsClose(mv, static_cast<uint32_t>(a.sort_row[p] - r0), static_cast<uint32_t>(a.sort_row[q] - r0), a.precision, nullptr)) continue;
-        a.active[a.sort_row[q]] = 1;  // (several writers, one value)
-        // and the rows that are this one bit for bit, on either side of it
-        for (uint64_t s = q + 1; s < a.total_rows && a.same_prev[s]; ++s) a.active[a.sort_row[s]] = 1;
-        for (uint64_t s = q; s > 0 && a.same_prev[s]; --s) a.active[a.sort_row[s - 1]] = 1;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+        const uint32_t item = base + threadIdx.x;
+        uint32_t q = 0;
+        bool close = false;
+        if (item < count) {
+            const uint32_t p = a.pairs[2 * static_cast<uint64_t>(item)];
+            q = a.pairs[2 * static_cast<uint64_t>(item) + 1];
+            const uint32_t m = keyMatrix(a.sort_key[p]);
+            const typename Arrays::View mv = viewOf(m, a.g);
+            const uint64_t r0 = a.g.rowOffset(m);
+            close = rowsClose(mv, static_cast<uint32_t>(a.sort_row[p] - r0), static_cast<uint32_t>(a.sort_row[q] - r0), pairPrecision<Arrays>(a.precision), nullptr);
+        }
+        // q is the first row of its stretch: the rows it stands for are active with it (several writers, one value)
+        forEachRowOfStretches(a, close, q, [&](const uint32_t s) { a.active[a.sort_row[s]] = Arrays::kHashBits && s != p0(a, s) ? kRowStoodFor : kRowListed; });
     }
 }
 
@@ -361,12 +538,16 @@ __global__ void collapseActivePairsKernel(const PairScanArgs a) {
 
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 
+template <typename Arrays>
 struct ReplayArgs {
     uint32_t num_matrices;
     double precision;
-    MatrixArrays g;
+    Arrays g;
     const uint32_t * mat_flag;
     const uint8_t * active;      // [total rows] by row
+    const uint32_t * sort_row;   // (EM problems: the stretches behind the rows of the lists)
+    const uint32_t * position_of;
+    const uint32_t * stretch_end;
     double * rowmax;
     uint32_t * mat_fast;
     uint32_t * mat_mid;
@@ -392,7 +573,8 @@ struct ReplayArgs {
 };
 
 // a0. the list of a matrix: its active rows (the replay then only touches those), or all of them
-__global__ __launch_bounds__(256) void collapseListKernel(const ReplayArgs a) {
+template <typename Arrays>
+__global__ __launch_bounds__(256) void collapseListKernel(const ReplayArgs<Arrays> a) {
     __shared__ uint32_t list_size;
     const uint32_t m = blockIdx.x;
     if (m >= a.num_matrices) return;
@@ -401,15 +583,15 @@ __global__ __launch_bounds__(256) void collapseListKernel(const ReplayArgs a) {
         if (threadIdx.x == 0) a.mat_list[m] = 0;
         return;
     }
-    const uint64_t R = a.g.mat_rows[m];
-    const uint64_t r0 = a.g.mat_row_off[m];
+    const uint64_t R = a.g.numRows(m);
+    const uint64_t r0 = a.g.rowOffset(m);
     const uint8_t * active = a.active + r0;
     uint32_t * list = a.order + 2 * r0;
     if (threadIdx.x == 0) list_size = 0;
     __syncthreads();
     if (flag != kFlagWholeMatrix) {
         for (uint64_t i = threadIdx.x; i < R; i += blockDim.x) {
-            if (active[i]) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(i);
+            if (active[i] == kRowListed) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(i);
         }
         __syncthreads();
     }
@@ -453,27 +635,28 @@ __global__ __launch_bounds__(256) void collapseListKernel(const ReplayArgs a) {
 // a1. every pair of rows of a small list, one thread each: order and closeness in one pass over the columns.  (A
 // workgroup that sorts its list with a comparison network goes through dozens of dependent rounds of strided loads;
 // here every comparison of the batch is in flight at once, and ranks and runs are then read off the table.)
-__global__ __launch_bounds__(64) void collapsePairTableKernel(const ReplayArgs a) {
+template <typename Arrays>
+__global__ __launch_bounds__(64) void collapsePairTableKernel(const ReplayArgs<Arrays> a) {
     const uint32_t num_items = *a.row_item_count;
     for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
         const uint32_t m = a.row_items[2 * static_cast<uint64_t>(item)], i = a.row_items[2 * static_cast<uint64_t>(item) + 1];
         const uint32_t n = a.mat_list[m] & kListSizeMask;
-        const MatrixView mv = viewOf(m, a.g);
-        const uint32_t * list = a.order + 2 * a.g.mat_row_off[m];
+        const typename Arrays::View mv = viewOf(m, a.g);
+        const uint32_t * list = a.order + 2 * a.g.rowOffset(m);
         uint8_t * table = a.pair_table + a.pair_base[m] + static_cast<uint64_t>(i) * n;
         const uint32_t row_i = list[i];
-        const uint64_t pattern_i = mv.pattern[row_i];
+        const uint64_t pattern_i = mv.patternOf(row_i);
         for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
             const uint32_t row_j = list[j];
             int less = -1;
             bool close = true;
-            forEachColumnPair(mv, row_i, row_j, pattern_i | mv.pattern[row_j], [&](const double x, const double y) {
+            forEachColumnPair(mv, row_i, row_j, pattern_i | mv.patternOf(row_j), [&](const double x, const double y) {
                 if (less < 0 && !tolerantEqual(x, y)) less = x < y ? 1 : 0;
                 if (fabs(x - y) >= a.precision) close = false;
                 return less >= 0 && !close;
             });
             if (less < 0) {
-                const double x = mv.count[row_i], y = mv.count[row_j];
+                const double x = mv.countOf(row_i), y = mv.countOf(row_j);
                 less = (!tolerantEqual(x, y) && x < y) ? 1 : 0;
             }
             table[j] = (less ? kPairLess : 0) | (close ? kPairClose : 0);
@@ -483,7 +666,8 @@ __global__ __launch_bounds__(64) void collapsePairTableKernel(const ReplayArgs a
 
 // a2. small lists sorted by rank: the number of rows that sort before a row (equal rows in list order).  Where the
 // tolerant comparison is inconsistent the ranks may collide; such a list is sorted by the comparison network instead.
-__global__ __launch_bounds__(256) void collapseRankKernel(const ReplayArgs a) {
+template <typename Arrays>
+__global__ __launch_bounds__(256) void collapseRankKernel(const ReplayArgs<Arrays> a) {
     __shared__ uint32_t lds_row[kPairwiseRows], lds_slot[kPairwiseRows];
     __shared__ uint32_t collision;
     const uint32_t num_items = a.replay_list[a.num_matrices];
@@ -492,7 +676,7 @@ __global__ __launch_bounds__(256) void collapseRankKernel(const ReplayArgs a) {
         const uint32_t encoded = a.mat_list[m];
         if (encoded & kBigListBit) continue;
         const uint32_t n = encoded;
-        const uint64_t r0 = a.g.mat_row_off[m];
+        const uint64_t r0 = a.g.rowOffset(m);
         uint32_t * list = a.order + 2 * r0;
         uint32_t * list_index = a.list_index + r0;
         const uint8_t * table = a.pair_table + a.pair_base[m];
@@ -515,7 +699,7 @@ __global__ __launch_bounds__(256) void collapseRankKernel(const ReplayArgs a) {
         __syncthreads();
         if (collision) {  // (never seen; kept correct rather than fast) insertion sort with the comparator itself
             if (threadIdx.x == 0) {
-                const MatrixView mv = viewOf(m, a.g);
+                const typename Arrays::View mv = viewOf(m, a.g);
                 for (uint32_t i = 0; i < n; ++i) lds_slot[i] = i;
                 for (uint32_t i = 1; i < n; ++i) {
                     const uint32_t moving = lds_slot[i];
@@ -536,14 +720,14 @@ __global__ __launch_bounds__(256) void collapseRankKernel(const ReplayArgs a) {
         }
         __syncthreads();
         // the column that orders every pair of neighbours, and the interval between them in it (collapseSortKernel)
-        const MatrixView mv = viewOf(m, a.g);
+        const typename Arrays::View mv = viewOf(m, a.g);
         for (uint32_t p = 1 + threadIdx.x; p < n; p += blockDim.x) {
             const uint32_t x = lds_row[lds_slot[p - 1]], y = lds_row[lds_slot[p]];
             uint32_t d = kNoRow;
             bool can_join = true;
             // (forEachColumnPair visits the columns in order but skips those in which both rows are zero: the column
             // index is recovered from the patterns)
-            const uint64_t live = mv.pattern[x] | mv.pattern[y];
+            const uint64_t live = mv.patternOf(x) | mv.patternOf(y);
             uint64_t remaining = live;
             uint32_t wide = 64;
             forEachColumnPair(mv, x, y, live, [&](const double vx, const double vy) {
@@ -566,7 +750,7 @@ __global__ __launch_bounds__(256) void collapseRankKernel(const ReplayArgs a) {
                 const double vx = mv.at(d, x), vy = mv.at(d, y);
                 a.pair_lo[r0 + p] = fmin(vx, vy);
                 a.pair_hi[r0 + p] = fmax(vx, vy);
-                a.pair_pattern[r0 + p] = mv.pattern[x] & (d >= 64 ? ~0ull : (1ull << d) - 1ull);
+                a.pair_pattern[r0 + p] = mv.patternOf(x) & (d >= 64 ? ~0ull : (1ull << d) - 1ull);
             }
         }
     }
@@ -574,7 +758,8 @@ __global__ __launch_bounds__(256) void collapseRankKernel(const ReplayArgs a) {
 
 // a3. big lists (more than kPairwiseRows rows, whole matrices): sorted with the reference's comparator in a
 // comparison network, and for every pair of neighbours the column that orders them
-__global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayArgs a) {
+template <typename Arrays>
+__global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayArgs<Arrays> a) {
     __shared__ uint32_t lds_list[kListLdsRows];
     __shared__ uint64_t lds_pattern[kListLdsRows];  // zero pattern of the row at each list position (LDS lists)
     // over the matrices with a list (a workgroup of this kernel takes a CU's worth of LDS: one per matrix of the batch, each
@@ -587,8 +772,8 @@ __global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayA
     if (!(encoded & kBigListBit)) continue;  // a small list (pair table, collapseRankKernel)
     const bool whole = (encoded & kWholeMatrixBit) != 0;
     const uint64_t n = encoded & kListSizeMask;
-    const MatrixView mv = viewOf(m, a.g);
-    const uint64_t r0 = a.g.mat_row_off[m];
+    const typename Arrays::View mv = viewOf(m, a.g);
+    const uint64_t r0 = a.g.rowOffset(m);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, num_waves = blockDim.x >> 6;
     uint64_t padded = 1;
     while (padded < n) padded <<= 1;
@@ -598,7 +783,7 @@ __global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayA
     __syncthreads();
     const bool in_lds = order == lds_list;
     if (in_lds) {
-        for (uint64_t i = threadIdx.x; i < padded; i += blockDim.x) lds_pattern[i] = order[i] == kNoRow ? 0ull : mv.pattern[order[i]];
+        for (uint64_t i = threadIdx.x; i < padded; i += blockDim.x) lds_pattern[i] = order[i] == kNoRow ? 0ull : mv.patternOf(order[i]);
     }
     __syncthreads();
     // bitonic network with the reference's comparator; kNoRow sorts behind every row
@@ -613,7 +798,7 @@ __global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayA
                 if (x == kNoRow || y == kNoRow) {
                     swap = ascending ? (x == kNoRow && y != kNoRow) : (y == kNoRow && x != kNoRow);
                 } else {
-                    const uint64_t px = in_lds ? lds_pattern[i] : mv.pattern[x], py = in_lds ? lds_pattern[l] : mv.pattern[y];
+                    const uint64_t px = in_lds ? lds_pattern[i] : mv.patternOf(x), py = in_lds ? lds_pattern[l] : mv.patternOf(y);
                     swap = ascending ? rowLess(mv, y, x, py, px) : rowLess(mv, x, y, px, py);
                 }
                 if (swap) {
@@ -658,7 +843,7 @@ __global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayA
                 const double vx = mv.at(d, x), vy = mv.at(d, y);
                 a.pair_lo[r0 + p] = fmin(vx, vy);
                 a.pair_hi[r0 + p] = fmax(vx, vy);
-                a.pair_pattern[r0 + p] = mv.pattern[x] & (d >= 64 ? ~0ull : (1ull << d) - 1ull);
+                a.pair_pattern[r0 + p] = mv.patternOf(x) & (d >= 64 ? ~0ull : (1ull << d) - 1ull);
             }
         }
     }
@@ -666,7 +851,8 @@ __global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayA
 }
 
 // b. inactive rows between neighbours of the lists: work item = (matrix with a list, slice of its rows)
-__global__ __launch_bounds__(kBetweenThreads) void collapseBetweenKernel(const ReplayArgs a) {
+template <typename Arrays>
+__global__ __launch_bounds__(kBetweenThreads) void collapseBetweenKernel(const ReplayArgs<Arrays> a) {
     __shared__ uint32_t lds_column[kPairChunk];
     __shared__ double lds_lo[kPairChunk], lds_hi[kPairChunk];
     __shared__ uint64_t lds_pattern[kPairChunk], lds_before[kPairChunk];
@@ -674,8 +860,8 @@ __global__ __launch_bounds__(kBetweenThreads) void collapseBetweenKernel(const R
     for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
         const uint32_t m = a.between_items[2 * static_cast<uint64_t>(item)], slice = a.between_items[2 * static_cast<uint64_t>(item) + 1];
         const uint64_t n = a.mat_list[m] & kListSizeMask;  // (not a whole matrix: those have no items)
-        const MatrixView mv = viewOf(m, a.g);
-        const uint64_t r0 = a.g.mat_row_off[m];
+        const typename Arrays::View mv = viewOf(m, a.g);
+        const uint64_t r0 = a.g.rowOffset(m);
         const uint8_t * active = a.active + r0;
         const uint32_t * order = a.order + 2 * r0;
         for (uint64_t p0 = 1; p0 < n; p0 += kPairChunk) {
@@ -695,7 +881,7 @@ __global__ __launch_bounds__(kBetweenThreads) void collapseBetweenKernel(const R
             const uint64_t x_end = min(mv.R, (slice + 1ull) * kBetweenRows);
             for (uint64_t x = slice * static_cast<uint64_t>(kBetweenRows) + threadIdx.x; x < x_end; x += blockDim.x) {
                 if (active[x]) continue;
-                const uint64_t pattern_x = mv.pattern[x];
+                const uint64_t pattern_x = mv.patternOf(x);
                 uint32_t loaded_column = kNoRow;
                 double vx = 0.0;
                 for (uint32_t k = 0; k < chunk; ++k) {
@@ -715,25 +901,124 @@ __global__ __launch_bounds__(kBetweenThreads) void collapseBetweenKernel(const R
     }
 }
 
-// c. runs and values: work item = matrix with a list
-__global__ __launch_bounds__(256) void collapseRunsKernel(const ReplayArgs a) {
-    __shared__ uint32_t lds_next[kListLdsRows];
-    __shared__ uint32_t demote;
+// What a run does to its rows.  Group matrices: the rows of a run take the values of its head — the consumers are sums over
+// rows of count * log(noise + columns), so "merged into the head" is "takes the values of the head" with the row's own
+// count; a wave per row, its lanes over the columns.
+__device__ __forceinline__ void finishRuns(const ReplayArgs<MatrixArrays> & a, const uint32_t m, const uint64_t n, const uint32_t * order,
+                                           const uint32_t * head_of, uint32_t * demote, const bool whole) {
+    (void) whole;
     const int lane = threadIdx.x & 63;
+    const MatrixView mv = viewOf(m, a.g);
+    const uint64_t R = mv.R;
+    const uint64_t r0 = a.g.rowOffset(m);
+    double * M = a.g.values + a.g.mat_val_off[m];
+    double * nz = a.g.row_noise + r0;
+    double * rm = a.rowmax + r0;
+    const uint32_t fast_mid_end = a.mat_mid[m];
+    uint32_t replaced = 0;
+    for (uint64_t q = threadIdx.x >> 6; q < n; q += blockDim.x >> 6) {
+        const uint32_t h = head_of[q];
+        if (h == q) continue;
+        const uint32_t dst = order[q], src = order[h];
+        for (uint32_t c = lane; c < mv.G; c += 64) M[static_cast<uint64_t>(c) * R + dst] = M[static_cast<uint64_t>(c) * R + src];
+        if (lane == 0) {
+            const double noise = nz[src];
+            nz[dst] = noise;
+            rm[dst] = rm[src];
+            ++replaced;
+            // a product-path row (LogProduct, common.hpp) needs noise >= kProductMinNoise: if the head's is below,
+            // the whole matrix takes the logarithm path
+            if (dst < fast_mid_end && !(noise >= kProductMinNoise)) *demote = 1;
+        }
+    }
+    if (replaced) atomicAdd(&a.info[kInfoRowsReplaced], replaced);
+    __syncthreads();
+    if (threadIdx.x == 0 && *demote) {
+        a.mat_fast[m] = 0;
+        a.mat_mid[m] = 0;
+    }
+}
+
+// EM problems (src/path_abundance_estimator.cpp:266,668 -> src/path_estimator.cpp:219-259): the head keeps its values and
+// the counts of its run add up — in CSR terms a merged row's count moves to its run head (read counts are integers: the
+// sums are exact in any order).  A row of the list stands for its stretch (rows of equal cells: all of them join the run
+// with it); in a whole-matrix list every row is there itself.  The counts after the merges go to a second array (the
+// first EM pass may still be reading the original ones); the problem is flagged for the second pass.
+__device__ __forceinline__ void finishRuns(const ReplayArgs<CsrArrays> & a, const uint32_t p, const uint64_t n, const uint32_t * order,
+                                           const uint32_t * head_of, uint32_t * demote, const bool whole) {
+    (void) demote;
+    __shared__ uint32_t any_merge, members_total;
+    const uint64_t r0 = a.g.rowOffset(p);
+    const uint64_t R = a.g.numRows(p);
+    double * merged = a.g.merged_count + r0;
+    const double * count = a.g.prow_count + r0;
+    uint8_t * joined = a.barrier + r0;  // (free again: the runs are known) by list position: 1 = a head that rows joined
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, num_waves = blockDim.x >> 6;
+    if (threadIdx.x == 0) any_merge = 0, members_total = 0;
+    for (uint64_t r = threadIdx.x; r < R; r += blockDim.x) merged[r] = count[r];
+    for (uint64_t q = threadIdx.x; q < n; q += blockDim.x) joined[q] = 0;
+    __syncthreads();
+    for (uint64_t q = threadIdx.x; q < n; q += blockDim.x) {
+        if (head_of[q] != q) joined[head_of[q]] = 1, any_merge = 1;  // (several writers, one value)
+    }
+    __syncthreads();
+    if (any_merge) {  // (uniform)
+        // the rows of the runs with more than a head, stretch by stretch (a wave each): first their counts go...
+        auto forStretchOf = [&](const uint64_t q, auto visit) {  // visit(row of the problem)
+            if (whole) {
+                if (lane == 0) visit(order[q]);
+                return;
+            }
+            const uint32_t first = a.position_of[r0 + order[q]], end = a.stretch_end[first];
+            for (uint32_t s = first + lane; s < end; s += 64) visit(static_cast<uint32_t>(a.sort_row[s] - r0));
+        };
+        for (uint64_t q = wave; q < n; q += num_waves) {
+            if (head_of[q] == q && !joined[q]) continue;
+            forStretchOf(q, [&](const uint32_t row) { merged[row] = 0.0; });
+        }
+        __syncthreads();
+        // ... then they arrive at the head
+        for (uint64_t q = wave; q < n; q += num_waves) {
+            const uint32_t h = head_of[q];
+            if (h == q && !joined[q]) continue;
+            double sum = 0.0;
+            uint32_t rows = 0;
+            forStretchOf(q, [&](const uint32_t row) { sum += count[row]; ++rows; });
+            for (int step = 32; step; step >>= 1) {
+                sum += __shfl_xor(sum, step);
+                rows += __shfl_xor(rows, step);
+            }
+            if (lane == 0) {
+                atomicAdd(&merged[order[h]], sum);
+                atomicAdd(&members_total, h == q ? rows - 1 : rows);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.g.problem_merged[p] = 1;
+            atomicAdd(a.g.merged_problems, 1u);
+            atomicAdd(&a.info[kInfoRowsReplaced], members_total);
+        }
+    }
+    __syncthreads();
+}
+
+// c. runs and values: work item = matrix with a list
+template <typename Arrays>
+__global__ __launch_bounds__(256) void collapseRunsKernel(const ReplayArgs<Arrays> a) {
+    __shared__ uint32_t demote;
     const uint32_t num_items = a.replay_list[a.num_matrices];
     for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
         const uint32_t m = a.replay_list[item];
         const uint32_t encoded = a.mat_list[m];
         const uint64_t n = encoded & kListSizeMask;
         const bool tabled = !(encoded & kBigListBit);
-        const MatrixView mv = viewOf(m, a.g);
-        const uint64_t R = mv.R;
-        const uint64_t r0 = a.g.mat_row_off[m];
+        const typename Arrays::View mv = viewOf(m, a.g);
+        const uint64_t r0 = a.g.rowOffset(m);
         const uint32_t * order = a.order + 2 * r0;
         const uint32_t * list_index = a.list_index + r0;
         const uint8_t * table = a.pair_table + (tabled ? a.pair_base[m] : 0);
         uint32_t * head_of = a.head_of + r0;
-        uint32_t * next_head = n <= kListLdsRows ? lds_next : a.pair_column + r0;  // (the pair columns are done with)
         uint8_t * close = a.close + r0;
         const uint8_t * barrier = a.barrier + r0;
         // list positions p, q hold rows within prob_precision of each other: read off the pair table, or compared
@@ -749,97 +1034,82 @@ __global__ __launch_bounds__(256) void collapseRunsKernel(const ReplayArgs a) {
         }
         __syncthreads();
         // Runs (src/path_estimator.cpp:226-255): a row joins the run of the current head if it is close to the head,
-        // otherwise it becomes the head.  Every list position answers "if I were a head, where would the next one be"
-        // on its own (the first position behind it that an inactive row parts from it or that is not close to it: a
-        // wave per position that has a follower, 64 candidates at a time); one thread then walks from head to head,
-        // and every head claims its run.
-        for (uint64_t h = threadIdx.x; h < n; h += blockDim.x) {
-            if (h + 1 >= n || !close[h + 1]) next_head[h] = static_cast<uint32_t>(h + 1);
-        }
-        for (uint64_t h = threadIdx.x >> 6; h + 1 < n; h += blockDim.x >> 6) {
-            if (!close[h + 1]) continue;
-            uint64_t q0 = h + 2, found = n;
-            while (q0 < n && found == n) {
-                const uint64_t q = q0 + lane;
-                const bool stop = q < n && (barrier[q] != 0 || !closeRows(h, q));
-                const unsigned long long ballot = __ballot(stop);
-                if (ballot) found = q0 + static_cast<uint64_t>(__ffsll(static_cast<long long>(ballot)) - 1);
-                q0 += 64;
+        // otherwise it becomes the head.  The workgroup walks from head to head: a head whose successor is not close to it
+        // (nearly every one) is a run of its own and costs one flag; a head with followers has the whole workgroup look
+        // for the end of its run, 256 candidates at a time.  (Round 2 had every list position find "where would the next
+        // head be if I were one" on its own before one thread walked the heads: with n rows all close to each other —
+        // an EM problem over 10^5 reads that differ in the ninth digit — that is n^2 / 2 comparisons for the one run.)
+        __shared__ uint32_t walk_at, run_end;
+        if (threadIdx.x == 0) walk_at = 0;
+        __syncthreads();
+        while (walk_at < n) {  // (uniform: walk_at only changes between barriers)
+            const uint64_t h = walk_at;
+            if (h + 1 >= n || !close[h + 1]) {
+                // a stretch of single-row runs: one thread runs through it
+                if (threadIdx.x == 0) {
+                    uint64_t q = h;
+                    while (q < n && (q + 1 >= n || !close[q + 1])) {
+                        head_of[q] = static_cast<uint32_t>(q);
+                        ++q;
+                    }
+                    walk_at = static_cast<uint32_t>(q);
+                }
+                __syncthreads();
+                continue;
             }
-            if (lane == 0) next_head[h] = static_cast<uint32_t>(found);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (uint64_t h = 0; h < n; h = next_head[h]) head_of[h] = static_cast<uint32_t>(h);
-        }
-        __syncthreads();
-        for (uint64_t h = threadIdx.x; h < n; h += blockDim.x) {
-            if (head_of[h] != h) continue;
-            for (uint64_t q = h + 1; q < next_head[h]; ++q) head_of[q] = static_cast<uint32_t>(h);
-        }
-        __syncthreads();
-        // the rows of a run take the values of its head: a wave per row, its lanes over the columns
-        double * M = a.g.values + a.g.mat_val_off[m];
-        double * nz = a.g.row_noise + r0;
-        double * rm = a.rowmax + r0;
-        const uint32_t fast_mid_end = a.mat_mid[m];
-        uint32_t replaced = 0;
-        for (uint64_t q = threadIdx.x >> 6; q < n; q += blockDim.x >> 6) {
-            const uint32_t h = head_of[q];
-            if (h == q) continue;
-            const uint32_t dst = order[q], src = order[h];
-            for (uint32_t c = lane; c < mv.G; c += 64) M[static_cast<uint64_t>(c) * R + dst] = M[static_cast<uint64_t>(c) * R + src];
-            if (lane == 0) {
-                const double noise = nz[src];
-                nz[dst] = noise;
-                rm[dst] = rm[src];
-                ++replaced;
-                // a product-path row (LogProduct, common.hpp) needs noise >= kProductMinNoise: if the head's is below,
-                // the whole matrix takes the logarithm path
-                if (dst < fast_mid_end && !(noise >= kProductMinNoise)) demote = 1;
+            if (threadIdx.x == 0) run_end = static_cast<uint32_t>(n);
+            __syncthreads();
+            for (uint64_t q0 = h + 2; q0 < n && run_end == n; q0 += blockDim.x) {  // (uniform: run_end read behind the barrier below)
+                const uint64_t q = q0 + threadIdx.x;
+                if (q < n && (barrier[q] != 0 || !closeRows(h, q))) atomicMin(&run_end, static_cast<uint32_t>(q));
+                __syncthreads();
             }
+            const uint64_t end = run_end;
+            for (uint64_t q = h + threadIdx.x; q < end; q += blockDim.x) head_of[q] = static_cast<uint32_t>(h);
+            __syncthreads();
+            if (threadIdx.x == 0) walk_at = static_cast<uint32_t>(end);
+            __syncthreads();
         }
-        if (replaced) atomicAdd(&a.info[kInfoRowsReplaced], replaced);
-        __syncthreads();
-        if (threadIdx.x == 0 && demote) {
-            a.mat_fast[m] = 0;
-            a.mat_mid[m] = 0;
-        }
+        finishRuns(a, m, n, order, head_of, &demote, (encoded & kWholeMatrixBit) != 0);
     }
 }
 
 }  // namespace
 
-// Queues the collapse of the matrices of `g` on `st` behind their build (rpvg_hip_groups_build).
-hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups * g, const uint64_t total_rows, const double precision,
-                                             hipStream_t st) {
-    (void) ctx;
-    const uint32_t M = g->num_matrices;
-    if (M == 0 || total_rows == 0) return hipSuccess;
-    if (total_rows > 0x7fffffffull || M > kCollapseMaxMatrices) return hipErrorInvalidValue;
-    struct CollapseTemporaries {
-        DeviceBuffer<uint64_t> key_out, pair_pattern;
-        DeviceBuffer<uint32_t> row_out, order, head, pair_column, marked_list, pairs, between_items, row_items, list_index;
-        DeviceBuffer<uint64_t> pair_base;
-        DeviceBuffer<uint8_t> pair_table;
-        DeviceBuffer<double> pair_bound;
-        DeviceBuffer<uint8_t> bytes;  // same_prev, close, barrier: total_rows each
-        DeviceBuffer<unsigned char> sort_tmp;
-    };
-    std::shared_ptr<CollapseTemporaries> tmp = std::make_shared<CollapseTemporaries>();
-    g->build_temporaries.emplace_back(tmp);
+namespace {
+
+struct CollapseTemporaries {
+    DeviceBuffer<uint64_t> key_out, pair_pattern;
+    DeviceBuffer<uint32_t> row_out, order, head, pair_column, marked_list, pairs, between_items, row_items, list_index;
+    DeviceBuffer<uint32_t> stretch;  // stretch starts by position, their running maximum, stretch ends, positions by row: total_rows each
+    DeviceBuffer<uint64_t> pair_base;
+    DeviceBuffer<uint8_t> pair_table;
+    DeviceBuffer<double> pair_bound;
+    DeviceBuffer<uint8_t> bytes;  // same_prev, close, barrier: total_rows each
+    DeviceBuffer<unsigned char> sort_tmp;
+    // EM problems only
+    DeviceBuffer<uint64_t> csr_key, csr_pattern;
+    DeviceBuffer<uint32_t> csr_row;
+};
+
+// The stages behind the keys, for group matrices and for EM problems alike: `key` / `row` hold, per row slot, the sort key
+// (matrix, projection, largest value) and the slot itself; `info` receives [counters | zeroed words | active bytes | list sizes].
+template <typename Arrays>
+hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const uint64_t total_rows, const double precision, const uint64_t * key,
+                               const uint32_t * row, const uint32_t * segment_off, DeviceBuffer<uint32_t> & info, double * rowmax, uint32_t * mat_fast,
+                               uint32_t * mat_mid, CollapseTemporaries * tmp, hipStream_t st) {
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     // zeroed words: the pair table's byte counter (8 bytes, first: aligned), matrix flags [M], replay list [M] + its
     // count, marked bits, then the counters of the marked list, the two pair lists, the between items, the row items
     const uint64_t mark_words = (total_rows + 31) / 32;
     const uint64_t num_words = 2 + 2 * static_cast<uint64_t>(M) + 1 + mark_words + 5;
-    const uint32_t pair_capacity = static_cast<uint32_t>(total_rows / 2 + 4096);
+    const uint32_t pair_capacity = static_cast<uint32_t>(std::min<uint64_t>(4 * total_rows + 4096, 0x20000000ull));
     ok(tmp->key_out.alloc(total_rows));
     ok(tmp->row_out.alloc(total_rows));
     // one block, one memset: [info | the zeroed words | active bytes] + list sizes [M] (written by the list kernel)
     const uint64_t active_words = (total_rows + 3) / 4;
-    ok(g->collapse_info.alloc(kInfoWords + num_words + active_words + M));
+    ok(info.alloc(kInfoWords + num_words + active_words + M));
     ok(tmp->order.alloc(2 * total_rows));
     ok(tmp->head.alloc(total_rows));
     ok(tmp->pair_column.alloc(total_rows));
@@ -853,49 +1123,51 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     ok(tmp->pair_base.alloc(M));
     ok(tmp->pair_table.alloc(kPairTableBytes));
     ok(tmp->bytes.alloc(3 * total_rows));
+    ok(tmp->stretch.alloc(4 * total_rows));
     // The keys carry the matrix above the projection and the rows of a matrix are contiguous: ONE (stable) radix sort of
     // the whole array on the projection and as many matrix bits as there are matrices orders every matrix's rows by their
     // projection.  (Round 2 sorted segment by segment, hipcub::DeviceSegmentedRadixSort: 0.33 ms per 1.6 M rows in 2 500
-    // segments, the longest kernel of the collapse; RPVG_HIP_COLLAPSE_SEGMENTED_SORT=1 keeps it for A/B.)
-    static const bool segmented = std::getenv("RPVG_HIP_COLLAPSE_SEGMENTED_SORT") != nullptr;
+    // segments, the longest kernel of the collapse; RPVG_HIP_COLLAPSE_SEGMENTED_SORT=1 keeps it for A/B on the group matrices.)
+    static const bool segmented_wanted = std::getenv("RPVG_HIP_COLLAPSE_SEGMENTED_SORT") != nullptr;
+    const bool segmented = segmented_wanted && segment_off != nullptr;
     int matrix_bits = 1;
-    while ((1u << matrix_bits) < M) ++matrix_bits;
-    const int begin_bit = kCollapseLargestBits, end_bit = segmented ? kCollapseMatrixShift : kCollapseMatrixShift + matrix_bits;
-    const uint32_t * segment_off = g->collapse_segment_off.ptr;
+    while ((1u << matrix_bits) < M + 1) ++matrix_bits;  // (+ 1: the index unused row slots of the EM problems carry)
+    const int begin_bit = kCollapseLargestBits - Arrays::kHashBits, end_bit = segmented ? kCollapseMatrixShift : kCollapseMatrixShift + matrix_bits;
     size_t sort_bytes = 0;
     auto sort = [&](void * scratch) {
-        return segmented ? hipcub::DeviceSegmentedRadixSort::SortPairs(scratch, sort_bytes, g->collapse_key.ptr, tmp->key_out.ptr, g->collapse_row.ptr,
+        return segmented ? hipcub::DeviceSegmentedRadixSort::SortPairs(scratch, sort_bytes, key, tmp->key_out.ptr, row,
                                                                        tmp->row_out.ptr, static_cast<int>(total_rows), static_cast<int>(M),
                                                                        segment_off, segment_off + 1, begin_bit, end_bit, st)
-                         : hipcub::DeviceRadixSort::SortPairs(scratch, sort_bytes, g->collapse_key.ptr, tmp->key_out.ptr, g->collapse_row.ptr,
+                         : hipcub::DeviceRadixSort::SortPairs(scratch, sort_bytes, key, tmp->key_out.ptr, row,
                                                               tmp->row_out.ptr, static_cast<int>(total_rows), begin_bit, end_bit, st);
     };
     if (e == hipSuccess) ok(sort(nullptr));
-    ok(tmp->sort_tmp.alloc(sort_bytes));
+    uint32_t * stretch_start = tmp->stretch.ptr, * stretch_first = stretch_start + total_rows, * stretch_end = stretch_first + total_rows,
+             * position_of = stretch_end + total_rows;
+    size_t scan_bytes = 0;
+    auto scan = [&](void * scratch) {
+        return hipcub::DeviceScan::InclusiveScan(scratch, scan_bytes, stretch_start, stretch_first, hipcub::Max(), static_cast<int>(total_rows), st);
+    };
+    if (e == hipSuccess) ok(scan(nullptr));
+    ok(tmp->sort_tmp.alloc(std::max(sort_bytes, scan_bytes)));
     if (e != hipSuccess) return e;
-    uint32_t * pair_bytes = g->collapse_info.ptr + kInfoWords, * mat_flag = pair_bytes + 2, * replay_list = mat_flag + M, * marked_bits = replay_list + M + 1,
+    uint32_t * pair_bytes = info.ptr + kInfoWords, * mat_flag = pair_bytes + 2, * replay_list = mat_flag + M, * marked_bits = replay_list + M + 1,
              * marked_count = marked_bits + mark_words, * pair_counts = marked_count + 1, * between_count = pair_counts + 2,
              * row_item_count = between_count + 1, * mat_list = pair_bytes + num_words + active_words;
     uint8_t * same_prev = tmp->bytes.ptr, * close = same_prev + total_rows, * barrier = close + total_rows;
     uint8_t * active = reinterpret_cast<uint8_t *>(pair_bytes + num_words);
-    ok(hipMemsetAsync(g->collapse_info.ptr, 0, (kInfoWords + num_words + active_words) * sizeof(uint32_t), st));
+    ok(hipMemsetAsync(info.ptr, 0, (kInfoWords + num_words + active_words) * sizeof(uint32_t), st));
     ok(sort(tmp->sort_tmp.ptr));
-    MatrixArrays arrays;
-    arrays.mat_val_off = g->mat_val_off.ptr;
-    arrays.mat_row_off = g->mat_row_off.ptr;
-    arrays.mat_rows = g->mat_rows.ptr;
-    arrays.mat_cols = g->mat_cols.ptr;
-    arrays.values = g->values.ptr;
-    arrays.row_noise = g->row_noise.ptr;
-    arrays.row_count = g->row_count.ptr;
-    arrays.zero_pattern = g->collapse_mask.ptr;
-    PairScanArgs a;
+    PairScanArgs<Arrays> a;
     a.total_rows = total_rows;
     a.precision = precision;
     a.sort_key = tmp->key_out.ptr;
     a.sort_row = tmp->row_out.ptr;
     a.g = arrays;
     a.same_prev = same_prev;
+    a.stretch_first = stretch_start;  // (the kernel in front of the scan writes the starts)
+    a.stretch_end = stretch_end;
+    a.position_of = position_of;
     a.marked_bits = marked_bits;
     a.marked_list = tmp->marked_list.ptr;
     a.marked_count = marked_count;
@@ -904,23 +1176,31 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     a.pair_capacity = pair_capacity;
     a.active = active;
     a.mat_flag = mat_flag;
-    a.info = g->collapse_info.ptr;
+    a.info = info.ptr;
+    a.num_matrices = M;
+    a.count_pairs = std::getenv("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
     const uint32_t row_blocks = static_cast<uint32_t>((total_rows + 255) / 256);
-    collapseSamePrevKernel<<<dim3(row_blocks), dim3(256), 0, st>>>(a);
-    collapseForwardPairsKernel<<<dim3(row_blocks), dim3(256), 0, st>>>(a);
-    collapseMarkPairsKernel<<<dim3(1024), dim3(64), 0, st>>>(a);
+    collapseSamePrevKernel<Arrays><<<dim3(row_blocks), dim3(256), 0, st>>>(a);
+    ok(scan(tmp->sort_tmp.ptr));
+    a.stretch_first = stretch_first;
+    collapseStretchEndKernel<Arrays><<<dim3(row_blocks), dim3(256), 0, st>>>(a);
+    collapseForwardPairsKernel<Arrays><<<dim3(row_blocks), dim3(256), 0, st>>>(a);
+    collapseMarkPairsKernel<Arrays><<<dim3(1024), dim3(64), 0, st>>>(a);
     a.pair_count = pair_counts + 1;  // the list is free again
-    collapseAroundPairsKernel<<<dim3(256), dim3(64), 0, st>>>(a);
-    collapseActivePairsKernel<<<dim3(1024), dim3(64), 0, st>>>(a);
-    ReplayArgs r;
+    collapseAroundPairsKernel<Arrays><<<dim3(256), dim3(64), 0, st>>>(a);
+    collapseActivePairsKernel<Arrays><<<dim3(1024), dim3(64), 0, st>>>(a);
+    ReplayArgs<Arrays> r;
     r.num_matrices = M;
     r.precision = precision;
     r.g = arrays;
     r.mat_flag = mat_flag;
     r.active = active;
-    r.rowmax = g->rowmax.ptr;
-    r.mat_fast = g->mat_fast.ptr;
-    r.mat_mid = g->mat_mid.ptr;
+    r.sort_row = tmp->row_out.ptr;
+    r.position_of = position_of;
+    r.stretch_end = stretch_end;
+    r.rowmax = rowmax;
+    r.mat_fast = mat_fast;
+    r.mat_mid = mat_mid;
     r.mat_list = mat_list;
     r.replay_list = replay_list;
     r.between_items = tmp->between_items.ptr;
@@ -939,15 +1219,139 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     r.pair_lo = tmp->pair_bound.ptr;
     r.pair_hi = tmp->pair_bound.ptr + total_rows;
     r.pair_pattern = tmp->pair_pattern.ptr;
-    r.info = g->collapse_info.ptr;
-    collapseListKernel<<<dim3(M), dim3(256), 0, st>>>(r);
-    collapsePairTableKernel<<<dim3(4096), dim3(64), 0, st>>>(r);
-    collapseRankKernel<<<dim3(1024), dim3(256), 0, st>>>(r);
-    collapseSortKernel<<<dim3(std::min<uint32_t>(M, 128)), dim3(kSortThreads), 0, st>>>(r);
-    collapseBetweenKernel<<<dim3(2048), dim3(kBetweenThreads), 0, st>>>(r);
-    collapseRunsKernel<<<dim3(1024), dim3(256), 0, st>>>(r);
+    r.info = info.ptr;
+    collapseListKernel<Arrays><<<dim3(M), dim3(256), 0, st>>>(r);
+    collapsePairTableKernel<Arrays><<<dim3(4096), dim3(64), 0, st>>>(r);
+    collapseRankKernel<Arrays><<<dim3(1024), dim3(256), 0, st>>>(r);
+    collapseSortKernel<Arrays><<<dim3(std::min<uint32_t>(M, 128)), dim3(kSortThreads), 0, st>>>(r);
+    collapseBetweenKernel<Arrays><<<dim3(2048), dim3(kBetweenThreads), 0, st>>>(r);
+    collapseRunsKernel<Arrays><<<dim3(1024), dim3(256), 0, st>>>(r);
     ok(hipGetLastError());
     return e;
+}
+
+// a column's share of the hash of a row's cells (summed: the entries of a row come in no particular order; an empty cell adds nothing)
+__device__ __forceinline__ uint64_t cellHashTerm(const uint32_t column, const double value) {
+    const uint64_t cell = static_cast<uint64_t>(cellOf(value));
+    uint64_t x = (cell + 0x632BE59BD9B4E019ull * (column + 1)) * 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return cell ? x * 0xC2B2AE3D27D4EB4Full : 0;
+}
+
+// sort key, slot and zero pattern of every row slot of the EM problems' storage: the slots of a problem's kept rows carry
+// (problem, projection of the normalised row, its largest value); the others the index `num_problems`, which no problem
+// has — they sort behind every row and are close to nothing
+__global__ __launch_bounds__(256) void csrCollapseKeysKernel(const CsrArrays g, const uint32_t num_problems_bound, const uint32_t * __restrict__ num_problems_dev,
+                                                           const uint64_t total_rows, uint64_t * __restrict__ key, uint32_t * __restrict__ row,
+                                                           uint64_t * __restrict__ pattern_out) {
+    // phase 1 (all slots): the unused-slot key; phase 2 (per problem, its kept rows): overwritten by the real one — two
+    // kernels' worth of work in one launch would race, so the launch is over problems and every problem also fills the
+    // gap between its rows and the next problem's
+    const uint32_t P = num_problems_dev ? *num_problems_dev : num_problems_bound;
+    const uint32_t p = blockIdx.x;
+    const uint64_t unused = collapseSortKey(num_problems_bound, 0.0, 0.0);
+    if (p >= P) {
+        if (p == P) {  // the tail behind the last problem (and everything, if there is no problem)
+            const uint64_t from = P == 0 ? 0 : g.row_base[P - 1] + g.kept_rows[P - 1];
+            for (uint64_t r = from + threadIdx.x; r < total_rows; r += blockDim.x) {
+                key[r] = unused;
+                row[r] = static_cast<uint32_t>(r);
+                pattern_out[r] = 0;
+            }
+        }
+        return;
+    }
+    const CsrView mv = g.view(p);
+    const uint64_t r0 = g.row_base[p];
+    const uint64_t gap_end = p + 1 < P ? g.row_base[p + 1] : r0 + mv.R;
+    for (uint64_t i = threadIdx.x; r0 + i < gap_end; i += blockDim.x) {
+        uint64_t k = unused, pattern = 0;
+        if (i < mv.R) {
+            const double noise = mv.noise[i];
+            double projection = collapseWeight(mv.G) * noise, largest = 0.0;
+            uint64_t cells = cellHashTerm(mv.G, noise);
+            for (uint32_t e = mv.off[i]; e < mv.off[i + 1]; ++e) {
+                const uint32_t c = mv.col[e];
+                const double v = mv.val[e];
+                projection = fma(collapseWeight(c), v, projection);
+                largest = fmax(largest, v);
+                cells += cellHashTerm(c, v);
+                if (c < 64 && v != 0.0) pattern |= 1ull << c;
+            }
+            // the top of the low field: a hash of the row's cells, sorted on (rows of equal cells end up next to each other)
+            constexpr int low_bits = kCollapseLargestBits - kCsrCellHashBits;
+            k = collapseSortKey(p, projection, largest);
+            k = (k & ~((1ull << kCollapseLargestBits) - 1)) | (((cells * 0x9E3779B97F4A7C15ull) >> (64 - kCsrCellHashBits)) << low_bits) | (k & ((1ull << low_bits) - 1));
+        }
+        key[r0 + i] = k;
+        row[r0 + i] = static_cast<uint32_t>(r0 + i);
+        pattern_out[r0 + i] = pattern;
+    }
+}
+
+}  // namespace
+
+// Queues the collapse of the matrices of `g` on `st` behind their build (rpvg_hip_groups_build).
+hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups * g, const uint64_t total_rows, const double precision,
+                                             hipStream_t st) {
+    (void) ctx;
+    const uint32_t M = g->num_matrices;
+    if (M == 0 || total_rows == 0) return hipSuccess;
+    if (total_rows > 0x7fffffffull || M >= kCollapseMaxMatrices) return hipErrorInvalidValue;
+    std::shared_ptr<CollapseTemporaries> tmp = std::make_shared<CollapseTemporaries>();
+    g->build_temporaries.emplace_back(tmp);
+    MatrixArrays arrays;
+    arrays.mat_val_off = g->mat_val_off.ptr;
+    arrays.mat_row_off = g->mat_row_off.ptr;
+    arrays.mat_rows = g->mat_rows.ptr;
+    arrays.mat_cols = g->mat_cols.ptr;
+    arrays.values = g->values.ptr;
+    arrays.row_noise = g->row_noise.ptr;
+    arrays.row_count = g->row_count.ptr;
+    arrays.zero_pattern = g->collapse_mask.ptr;
+    return queueCollapseStages(arrays, M, total_rows, precision, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_segment_off.ptr, g->collapse_info,
+                               g->rowmax.ptr, g->mat_fast.ptr, g->mat_mid.ptr, tmp.get(), st);
+}
+
+// readCollapseProbabilityMatrix on the rows of every EM problem of a solve (src/path_abundance_estimator.cpp:266,668): queued
+// on `st` behind the compaction of the problems' rows.  Afterwards work.problem_merged[p] != 0 marks the problems in which a
+// run joined rows that were not equal up to rounding, merged_count holds their read counts after the merges (a merged
+// row's count moved to its run head) and merged_problems[0] their number.
+hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollapseInput & in, const double precision, CsrCollapseWork & work, hipStream_t st) {
+    (void) ctx;
+    const uint32_t P = in.num_problems_bound;
+    const uint64_t total_rows = in.rows_capacity;
+    if (P == 0 || total_rows == 0) return hipSuccess;
+    if (total_rows > 0x7fffffffull || P + 1 >= kCollapseMaxMatrices) return hipErrorInvalidValue;
+    std::shared_ptr<CollapseTemporaries> tmp = std::make_shared<CollapseTemporaries>();
+    work.temporaries = tmp;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    ok(tmp->csr_key.alloc(total_rows));
+    ok(tmp->csr_row.alloc(total_rows));
+    ok(tmp->csr_pattern.alloc(total_rows));
+    ok(work.merged_count.alloc(total_rows));
+    ok(work.problem_merged.alloc(P + 1));  // [P]: the number of merged problems
+    if (e != hipSuccess) return e;
+    ok(hipMemsetAsync(work.problem_merged.ptr, 0, (P + 1) * sizeof(uint32_t), st));
+    CsrArrays arrays;
+    arrays.row_base = in.row_base;
+    arrays.ent_base = in.ent_base;
+    arrays.kept_rows = in.kept_rows;
+    arrays.col_off = in.col_off;
+    arrays.prow_off = in.prow_off;
+    arrays.prow_count = in.prow_count;
+    arrays.prow_noise = in.prow_noise;
+    arrays.pent_col = in.pent_col;
+    arrays.pent_val = in.pent_val;
+    arrays.zero_pattern = tmp->csr_pattern.ptr;
+    arrays.merged_count = work.merged_count.ptr;
+    arrays.problem_merged = work.problem_merged.ptr;
+    arrays.merged_problems = work.problem_merged.ptr + P;
+    csrCollapseKeysKernel<<<dim3(P + 1), dim3(256), 0, st>>>(arrays, P, in.num_problems_dev, total_rows, tmp->csr_key.ptr, tmp->csr_row.ptr, tmp->csr_pattern.ptr);
+    ok(hipGetLastError());
+    if (e != hipSuccess) return e;
+    return queueCollapseStages(arrays, P, total_rows, precision, tmp->csr_key.ptr, tmp->csr_row.ptr, nullptr, work.info, nullptr, nullptr, nullptr, tmp.get(), st);
 }
 
 extern "C" int rpvg_hip_groups_collapse_info(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, uint32_t * matrices_replayed,

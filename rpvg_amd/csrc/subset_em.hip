@@ -588,7 +588,8 @@ struct rpvg_hip_subset_em {
 
 extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_groups * groups,
                                          const uint32_t * column_counts, double min_rel_likelihood, double min_hap_prob,
-                                         uint32_t max_em_its, double max_rel_em_conv, rpvg_hip_subset_em ** result_out) {
+                                         uint32_t max_em_its, double max_rel_em_conv, double collapse_precision,
+                                         rpvg_hip_subset_em ** result_out) {
     RPVG_REQUIRE(ctx && batch && groups && result_out, "rpvg_hip_nested_subset_em: NULL argument");
     *result_out = nullptr;
     RPVG_REQUIRE(min_rel_likelihood > 0, "rpvg_hip_nested_subset_em: min_rel_likelihood must be positive");
@@ -821,7 +822,7 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
     EmSolveWork work;
     work.zeroed_queues = search.d_extra_zero.ptr + header_room;
     if (e == hipSuccess) {
-        rc = queueEmSolve(ctx, batch, list, max_em_its, max_rel_em_conv, out, work, false);
+        rc = queueEmSolve(ctx, batch, list, max_em_its, max_rel_em_conv, out, work, false, collapse_precision);
         if (rc != RPVG_HIP_OK) {
             (void) hipStreamSynchronize(st);
             (void) hipEventDestroy(header_here);

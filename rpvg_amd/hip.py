@@ -39,7 +39,8 @@ class EngineError(RuntimeError):
 
 
 class CEmProblems(C.Structure):
-    _fields_ = [("num_problems", C.c_uint32), ("cluster", C.c_void_p), ("col_off", C.c_void_p), ("col_path", C.c_void_p)]
+    _fields_ = [("num_problems", C.c_uint32), ("cluster", C.c_void_p), ("col_off", C.c_void_p), ("col_path", C.c_void_p),
+                ("collapse_precision", C.c_double)]
 
 
 class CEmResults(C.Structure):
@@ -339,7 +340,7 @@ class Context:
 
     # ---- EM -----------------------------------------------------------------
     def em_solve(self, batch: DeviceBatch, clusters: Sequence[int], columns: Sequence[Sequence[int]],
-                 max_em_its: int = 10000, max_rel_em_conv: float = 1e-3):
+                 max_em_its: int = 10000, max_rel_em_conv: float = 1e-3, collapse_precision: float = 0.0):
         """Returns (abundances list per problem, noise_count[P], total_count[P], iterations[P])."""
         P = len(clusters)
         cl = np.ascontiguousarray(clusters, dtype=np.uint32)
@@ -351,7 +352,7 @@ class Context:
         noise = np.zeros(P, dtype=np.float64)
         total = np.zeros(P, dtype=np.float64)
         iters = np.zeros(P, dtype=np.uint32)
-        probs = CEmProblems(P, cl.ctypes.data, col_off.ctypes.data, col_path.ctypes.data)
+        probs = CEmProblems(P, cl.ctypes.data, col_off.ctypes.data, col_path.ctypes.data, collapse_precision)
         res = CEmResults(abund.ctypes.data, noise.ctypes.data, total.ctypes.data, iters.ctypes.data)
         _check(lib().rpvg_hip_em_solve(self.handle, batch.handle, C.c_uint32(max_em_its), C.c_double(max_rel_em_conv),
                                        C.byref(probs), C.byref(res)), "rpvg_hip_em_solve")

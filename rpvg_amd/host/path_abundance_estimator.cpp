@@ -71,6 +71,7 @@ void PathAbundanceEstimator::gibbsReadCountSampler(std::vector<CountSamples> * c
     em_problems.cluster = clusters.data();
     em_problems.col_off = col_off.data();
     em_problems.col_path = col_path.data();
+    em_problems.collapse_precision = 0;
 
     HipEngine::check(rpvg_hip_gibbs_read_counts(engine->ctx(), cluster_batch.handle(), &em_problems, init_abundances.data(), init_noise_count.data(), num_samples.data(), seeds.data(), gibbs_thin_its, abundance_gibbs_gamma, noise_samples.data(), abundance_samples.data()), "rpvg_hip_gibbs_read_counts");
 
@@ -84,7 +85,7 @@ void PathAbundanceEstimator::gibbsReadCountSampler(std::vector<CountSamples> * c
     }
 }
 
-void PathAbundanceEstimator::EMAbundanceEstimator(std::vector<EMSolution> * solutions, const DeviceClusterBatch & cluster_batch, const std::vector<EMProblem> & problems) const {
+void PathAbundanceEstimator::EMAbundanceEstimator(std::vector<EMSolution> * solutions, const DeviceClusterBatch & cluster_batch, const std::vector<EMProblem> & problems, const bool read_collapse) const {
 
     ScopedPhase phase("EM: flatten + rpvg_hip_em_solve + unpack");
 
@@ -130,6 +131,7 @@ void PathAbundanceEstimator::EMAbundanceEstimator(std::vector<EMSolution> * solu
     em_problems.cluster = clusters.data();
     em_problems.col_off = col_off.data();
     em_problems.col_path = col_path.data();
+    em_problems.collapse_precision = read_collapse ? prob_precision : 0;
 
     rpvg_hip_em_results em_results;
     em_results.abundances = abundances.data();
@@ -184,7 +186,7 @@ void PathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimates> * p
     }
 
     std::vector<EMSolution> solutions;
-    EMAbundanceEstimator(&solutions, cluster_batch, problems);
+    EMAbundanceEstimator(&solutions, cluster_batch, problems, false);  // (src/path_abundance_estimator.cpp:18-45: no row collapse)
 
     if (num_gibbs_samples > 0) {
 
@@ -291,7 +293,7 @@ void MinimumPathAbundanceEstimator::estimateBatch(std::vector<PathClusterEstimat
     }
 
     std::vector<EMSolution> solutions;
-    EMAbundanceEstimator(&solutions, cluster_batch, problems);
+    EMAbundanceEstimator(&solutions, cluster_batch, problems, true);  // (:266)
 
     std::vector<CountSamples> count_samples;
 
@@ -1013,7 +1015,7 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
     build_phase.reset();
 
     std::vector<EMSolution> solutions;
-    EMAbundanceEstimator(&solutions, cluster_batch, problems);
+    EMAbundanceEstimator(&solutions, cluster_batch, problems, true);  // (:668)
 
     std::vector<CountSamples> count_samples;
 

@@ -52,7 +52,9 @@ class PathAbundanceEstimator : public PathEstimator {
 
         // EMAbundanceEstimator (src/path_abundance_estimator.cpp:47-114), together with
         // the matrix construction and normalisation in front of it, for a batch of problems.
-        void EMAbundanceEstimator(std::vector<EMSolution> * solutions, const DeviceClusterBatch & cluster_batch, const std::vector<EMProblem> & problems) const;
+        // read_collapse: the rows of every problem go through readCollapseProbabilityMatrix first (the callers at
+        // src/path_abundance_estimator.cpp:266,668 do that, the one at :18-45 does not)
+        void EMAbundanceEstimator(std::vector<EMSolution> * solutions, const DeviceClusterBatch & cluster_batch, const std::vector<EMProblem> & problems, const bool read_collapse) const;
 
         // gibbsReadCountSampler (src/path_abundance_estimator.cpp:116-212) for a batch of solved problems, on the
         // GPU (Philox generator keyed by `seeds`; statistical parity with the reference's mt19937 streams).

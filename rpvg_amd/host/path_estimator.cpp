@@ -881,7 +881,7 @@ bool PathEstimator::nestedSubsetAbundances(SubsetEmResult * result, const Device
         column_counts.insert(column_counts.end(), problem.column_counts.begin(), problem.column_counts.end());
     }
 
-    const int status = rpvg_hip_nested_subset_em(engine->ctx(), cluster_batch.handle(), matrices.handle(), column_counts.data(), min_rel_likelihood, min_hap_prob, max_em_its, max_rel_em_conv, &result->result);
+    const int status = rpvg_hip_nested_subset_em(engine->ctx(), cluster_batch.handle(), matrices.handle(), column_counts.data(), min_rel_likelihood, min_hap_prob, max_em_its, max_rel_em_conv, prob_precision, &result->result);
 
     if (status == RPVG_HIP_ERR_UNSUPPORTED) {
 
