@@ -775,6 +775,12 @@ struct CsrCollapseInput {  // the compacted CSR of a solve's problems (em_sparse
     const double * prow_noise = nullptr;
     const uint32_t * pent_col = nullptr;
     const double * pent_val = nullptr;
+    // the work items of the fill (EmProblemList): problem p has items seg_first[p] .. seg_first[p + 1], of segment_rows row slots each
+    uint32_t num_items_bound = 0;
+    const uint32_t * num_items_dev = nullptr;
+    const uint64_t * seg_first = nullptr;
+    const uint32_t * item_problem = nullptr;
+    uint32_t segment_rows = 0;
 };
 struct CsrCollapseWork {
     DeviceBuffer<double> merged_count;      // [rows] read counts after the merges, for the problems with merges

@@ -359,12 +359,10 @@ __global__ __launch_bounds__(256) void fillOffsetsKernel(const FillArgs args) {
 // ---- 3. the work queues ------------------------------------------------------------
 // Every workgroup scans the (bin, bucket) histogram in LDS (352 counters) and lists its problems: a problem's place
 // inside its bucket is whatever the atomic hands out — the order inside a bucket only decides who starts first.
-// only_flagged: the second pass — the problems a row collapse merged rows in (their histogram: emMergedHistogramKernel)
 __global__ __launch_bounds__(256) void emOrderKernel(const uint32_t num_problems, const uint32_t * __restrict__ num_problems_dev,
                                                     const uint32_t * __restrict__ prob_bucket, const uint64_t * __restrict__ col_off,
                                                     EmQueues * __restrict__ queues, uint32_t * __restrict__ order,
-                                                    unsigned long long * __restrict__ wide_off, const unsigned long long wide_capacity,
-                                                    const uint32_t * __restrict__ only_flagged = nullptr) {
+                                                    unsigned long long * __restrict__ wide_off, const unsigned long long wide_capacity) {
     constexpr int kCells = kEmBins * kEmWorkBuckets;
     static_assert(kCells <= 512, "two cells per thread");
     __shared__ uint32_t start[kCells + 1];
@@ -397,10 +395,9 @@ __global__ __launch_bounds__(256) void emOrderKernel(const uint32_t num_problems
     }
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    if (only_flagged && !only_flagged[p]) return;
     const uint32_t cell = prob_bucket[p];
     order[start[cell] + atomicAdd(&queues->bucket_cursor[cell], 1u)] = p;
-    if (!only_flagged && cell / kEmWorkBuckets == 10) {  // abundance + accumulator vectors in global memory
+    if (cell / kEmWorkBuckets == 10) {  // abundance + accumulator vectors in global memory
         const unsigned long long need = 2ull * (static_cast<unsigned long long>(col_off[p + 1] - col_off[p]) + 1);
         const unsigned long long at = atomicAdd(&queues->wide_cursor, need);
         wide_off[p] = at;
@@ -409,15 +406,6 @@ __global__ __launch_bounds__(256) void emOrderKernel(const uint32_t num_problems
 }
 
 // ---- 5. the EM kernel --------------------------------------------------------
-
-__global__ __launch_bounds__(256) void emMergedHistogramKernel(const uint32_t num_problems, const uint32_t * __restrict__ num_problems_dev,
-                                                              const uint32_t * __restrict__ prob_bucket, const uint32_t * __restrict__ flagged,
-                                                              EmQueues * __restrict__ queues) {
-    const uint32_t P = num_problems_dev ? *num_problems_dev : num_problems;
-    if (flagged[num_problems] == 0) return;  // [num_problems]: how many problems were merged — nearly always none
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < P && flagged[p]) atomicAdd(&queues->histogram[prob_bucket[p]], 1u);
-}
 
 struct EmLaunchArgs {
     const uint32_t * order;        // problems, bin by bin (EmQueues::bin_start), large first
@@ -431,6 +419,8 @@ struct EmLaunchArgs {
     const double * total_mass;     // [P]
     const uint32_t * prow_off;
     const double * prow_count;
+    const double * merged_count;      // read counts after the row collapse (row_collapse.hip), for the problems with ...
+    const uint32_t * problem_merged;  // ... this flag; NULL: no collapse
     const double * prow_noise;
     const uint32_t * pent_col;
     const double * pent_val;
@@ -443,6 +433,11 @@ struct EmLaunchArgs {
     double * noise_count;          // [P]
     uint32_t * iterations;         // [P]
 };
+
+// the read counts of problem p's rows: a row whose count the row collapse moved to its run head has none left and takes no part
+__device__ __forceinline__ const double * rowCounts(const EmLaunchArgs & args, const uint32_t p, const uint64_t rb) {
+    return (args.problem_merged != nullptr && args.problem_merged[p] != 0 ? args.merged_count : args.prow_count) + rb;
+}
 
 // The EM kernels are persistent: a launch has as many workgroups as the GPU holds at once (or as the bin can have
 // problems, if fewer), and every workgroup draws the next problem of its bin from the queue until the bin is empty —
@@ -480,7 +475,7 @@ __device__ __forceinline__ void emSparseProblem(const EmLaunchArgs & args, const
     const uint32_t n_rows = args.kept_rows[p];
     const uint64_t rb = args.row_base[p], eb = args.ent_base[p];
     const uint32_t * off = args.prow_off + rb + p;
-    const double * cnt = args.prow_count + rb;
+    const double * cnt = rowCounts(args, p, rb);
     const double * nzv = args.prow_noise + rb;
     const uint32_t * col = args.pent_col + eb;
     const double * val = args.pent_val + eb;
@@ -701,7 +696,7 @@ __device__ __forceinline__ void emRegisterProblem(const EmLaunchArgs & args, con
     const uint32_t n_rows = args.kept_rows[p];
     const uint64_t rb = args.row_base[p], eb = args.ent_base[p];
     const uint32_t * off = args.prow_off + rb + p;
-    const double * cnt = args.prow_count + rb;
+    const double * cnt = rowCounts(args, p, rb);
     const double * nzv = args.prow_noise + rb;
     const uint32_t * col = args.pent_col + eb;
     const double * val = args.pent_val + eb;
@@ -1083,8 +1078,10 @@ EmBinRule emBinRule() {
     static const bool use_register_kernel = std::getenv("RPVG_HIP_NO_REGISTER_EM") == nullptr;
     // A streamed problem is one workgroup: above this many rows + entries it gets 1 024 threads instead of 256 (round 2:
     // 262 144 — a 200 000-entry problem on 256 threads took 47 us per EM iteration and, at 23 iterations, as long as the
-    // thousands of iterations of the slowest register-resident problem).
-    static const uint64_t streamed_small = std::getenv("RPVG_HIP_EM_STREAM_SMALL") ? std::strtoull(std::getenv("RPVG_HIP_EM_STREAM_SMALL"), nullptr, 10) : 24576;
+    // thousands of iterations of the slowest register-resident problem; round 3: 24 576, then 0 — a batch has a few dozen
+    // streamed problems, far fewer than CUs, and on 256 threads the ones below the limit took 55 us per iteration, twice
+    // what the larger ones above it took on 1 024).
+    static const uint64_t streamed_small = std::getenv("RPVG_HIP_EM_STREAM_SMALL") ? std::strtoull(std::getenv("RPVG_HIP_EM_STREAM_SMALL"), nullptr, 10) : 0;
     return EmBinRule{use_register_kernel ? 1u : 0u, streamed_small};
 }
 
@@ -1171,17 +1168,27 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         ctx->spanEnd(span);
         return RPVG_HIP_OK;
     }
-    // readCollapseProbabilityMatrix on the rows of every problem (src/path_abundance_estimator.cpp:266,668): on the collapse
-    // stream, next to the first EM pass (it only reads what the fill left)
+    // readCollapseProbabilityMatrix on the rows of every problem (src/path_abundance_estimator.cpp:266,668), on the collapse
+    // stream; the EM kernels wait for it and read the merged counts of the problems it merged rows in (rowCounts).  (A first
+    // version solved every problem next to the collapse and the merged ones a second time: on the configs[2] batch the
+    // largest problems were the merged ones, the second pass took as long as the first, and the collapse's forty launches
+    // took 2.6 ms in between the persistent EM kernels against 1.5 ms without them.)
     static const bool no_em_collapse = std::getenv("RPVG_HIP_NO_EM_COLLAPSE") != nullptr;
     const bool collapse = collapse_precision > 0 && !no_em_collapse && !std::getenv("RPVG_HIP_NO_COLLAPSE") && list.rows_capacity > 0 &&
                           list.rows_capacity <= 0x7fffffffull && P + 1 < kCollapseMaxMatrices;
     if (collapse) {
+        RPVG_HIP_CHECK(hipEventCreateWithFlags(&work.filled, hipEventDisableTiming));
+        RPVG_HIP_CHECK(hipEventRecord(work.filled, st));
+    }
+    emOrderKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(P, list.d_num_problems, work.d_bucket.ptr, list.d_col_off, queues, work.d_order.ptr,
+                                                              work.d_wide_off.ptr, list.wide_capacity);
+    RPVG_HIP_CHECK(hipGetLastError());
+    ctx->spanEnd(span);
+    ctx->stats.build_launches += 1;
+    if (collapse) {
         auto cw = std::make_shared<CsrCollapseWork>();
         work.collapse = cw;
-        RPVG_HIP_CHECK(hipEventCreateWithFlags(&work.filled, hipEventDisableTiming));
         RPVG_HIP_CHECK(hipEventCreateWithFlags(&work.collapsed, hipEventDisableTiming));
-        RPVG_HIP_CHECK(hipEventRecord(work.filled, st));
         RPVG_HIP_CHECK(hipStreamWaitEvent(ctx->collapse_stream, work.filled, 0));
         CsrCollapseInput in;
         in.num_problems_bound = P;
@@ -1196,16 +1203,16 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         in.prow_noise = work.d_prow_noise.ptr;
         in.pent_col = work.d_pent_col.ptr;
         in.pent_val = work.d_pent_val.ptr;
+        in.num_items_bound = list.items_bound;
+        in.num_items_dev = list.d_num_items;
+        in.seg_first = list.d_seg_first;
+        in.item_problem = list.d_item_problem;
+        in.segment_rows = kFillSegmentRows;
         const int collapse_span = ctx->spanBegin(FAM_COLLAPSE, ctx->collapse_stream);
         RPVG_HIP_CHECK(queueCsrCollapse(ctx, in, collapse_precision, *cw, ctx->collapse_stream));
         ctx->spanEnd(collapse_span);
         RPVG_HIP_CHECK(hipEventRecord(work.collapsed, ctx->collapse_stream));
     }
-    emOrderKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(P, list.d_num_problems, work.d_bucket.ptr, list.d_col_off, queues, work.d_order.ptr,
-                                                              work.d_wide_off.ptr, list.wide_capacity);
-    RPVG_HIP_CHECK(hipGetLastError());
-    ctx->spanEnd(span);
-    ctx->stats.build_launches += 1;
 
     EmLaunchArgs args;
     args.order = work.d_order.ptr;
@@ -1230,6 +1237,14 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     args.abundances = out.d_abundances;
     args.noise_count = out.d_noise_count;
     args.iterations = out.d_iterations;
+    args.merged_count = nullptr;
+    args.problem_merged = nullptr;
+    if (collapse) {
+        const CsrCollapseWork * cw = static_cast<const CsrCollapseWork *>(work.collapse.get());
+        args.merged_count = cw->merged_count.ptr;
+        args.problem_merged = cw->problem_merged.ptr;
+        RPVG_HIP_CHECK(hipStreamWaitEvent(st, work.collapsed, 0));
+    }
 
     // The bins are independent, so their tails (a small problem that needs thousands of iterations, a giant one with
     // many rows) should overlap — but only as many kernels run side by side as the runtime has hardware queues.
@@ -1239,7 +1254,8 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     // of dispatcher time next to the other lane's kernels.  A queue of 1 200 short problems drains through 512 waves in
     // tens of microseconds; the problems that run for thousands of iterations start that much later at the most.
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
-    auto grid = [&](const uint32_t per_cu) { return std::min<uint32_t>(P, cus * per_cu); };
+    static const double grid_scale = std::getenv("RPVG_HIP_EM_GRID_SCALE") ? std::atof(std::getenv("RPVG_HIP_EM_GRID_SCALE")) : 1.0;  // A/B knob
+    auto grid = [&](const uint32_t per_cu) { return std::min<uint32_t>(P, std::max<uint32_t>(1, static_cast<uint32_t>(cus * per_cu * grid_scale))); };
     const size_t streamed_lds_256 = emLdsBytes(list.max_cols, 0, 0, 256, false), streamed_lds_1024 = emLdsBytes(list.max_cols, 0, 0, 1024, false);
     const bool wide_possible = streamed_lds_1024 > kEmLdsLimit;
     const bool many_queues = hardwareQueues() >= 8;
@@ -1298,25 +1314,7 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     }
     ctx->spanEnd(span);
     if (collapse) {
-        // Second pass: the problems in which the row collapse — which ran next to the first pass, on the collapse stream —
-        // merged rows that were not equal up to rounding are solved again on the merged counts (a merged row's count at
-        // its run head, zero where it was) and overwrite their results.  Nearly always there is none: the launches find
-        // empty queues.
-        CsrCollapseWork * cw = static_cast<CsrCollapseWork *>(work.collapse.get());
-        RPVG_HIP_CHECK(hipStreamWaitEvent(st, work.collapsed, 0));
-        RPVG_HIP_CHECK(work.d_queues_merged.alloc(sizeof(EmQueues)));
-        EmQueues * queues2 = reinterpret_cast<EmQueues *>(work.d_queues_merged.ptr);
-        span = ctx->spanBegin(FAM_EM_SPARSE);
-        RPVG_HIP_CHECK(hipMemsetAsync(queues2, 0, sizeof(EmQueues), st));
-        emMergedHistogramKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(P, list.d_num_problems, work.d_bucket.ptr, cw->problem_merged.ptr, queues2);
-        emOrderKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(P, list.d_num_problems, work.d_bucket.ptr, list.d_col_off, queues2, work.d_order.ptr,
-                                                                  work.d_wide_off.ptr, list.wide_capacity, cw->problem_merged.ptr);
-        RPVG_HIP_CHECK(hipGetLastError());
-        args.queues = queues2;
-        args.prow_count = cw->merged_count.ptr;
-        const int rc = launchVariants(false);
-        if (rc != RPVG_HIP_OK) return rc;
-        ctx->spanEnd(span);
+        const CsrCollapseWork * cw = static_cast<const CsrCollapseWork *>(work.collapse.get());
         static const bool debug = std::getenv("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
         if (debug) {  // (synchronises: a measuring aid)
             uint32_t info[6] = {0}, merged = 0, problems = P, counts[3] = {0};

@@ -199,6 +199,22 @@ __device__ bool rowsSameCells(const View & mv, const uint32_t a, const uint32_t 
     return same;
 }
 
+// (rows of a problem nearly always list their entries in the same column order: the entry lists are compared as they are, the
+// column walk only decides when the lists differ in shape)
+__device__ bool rowsSameCells(const CsrView & mv, const uint32_t a, const uint32_t b) {
+    const uint32_t a0 = mv.off[a], a1 = mv.off[a + 1], b0 = mv.off[b];
+    if (cellOf(mv.noise[a]) != cellOf(mv.noise[b])) return false;
+    bool same_shape = a1 - a0 == mv.off[b + 1] - b0;
+    for (uint32_t k = 0; same_shape && k < a1 - a0; ++k) same_shape = mv.col[a0 + k] == mv.col[b0 + k];
+    if (same_shape) {
+        for (uint32_t k = 0; k < a1 - a0; ++k) {
+            if (cellOf(mv.val[a0 + k]) != cellOf(mv.val[b0 + k])) return false;
+        }
+        return true;
+    }
+    return rowsSameCells<CsrView>(mv, a, b);
+}
+
 template <typename View>
 __device__ bool rowsIdentical(const View & mv, const uint32_t a, const uint32_t b) {
     bool same = true;
@@ -446,8 +462,9 @@ __device__ __forceinline__ uint32_t p0(const PairScanArgs<Arrays> & a, const uin
 template <typename Arrays>
 __global__ void collapseMarkPairsKernel(const PairScanArgs<Arrays> a) {
     const uint32_t count = min(*a.pair_count, a.pair_capacity);
-    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
-        const uint32_t item = base + threadIdx.x;
+    // (lane l of block b takes pair b + l * blocks: a short list spreads over the waves, each of which walks the stretches of its pairs)
+    for (uint32_t base = 0; base < count; base += gridDim.x * blockDim.x) {
+        const uint32_t item = base + threadIdx.x * gridDim.x + blockIdx.x;
         uint32_t p = 0, q = 0;
         bool mark = false;
         if (item < count) {
@@ -517,8 +534,8 @@ __global__ void collapseAroundPairsKernel(const PairScanArgs<Arrays> a) {
 template <typename Arrays>
 __global__ void collapseActivePairsKernel(const PairScanArgs<Arrays> a) {  // (blocks of one wave)
     const uint32_t count = min(*a.pair_count, a.pair_capacity);
-    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
-        const uint32_t item = base + threadIdx.x;
+    for (uint32_t base = 0; base < count; base += gridDim.x * blockDim.x) {
+        const uint32_t item = base + threadIdx.x * gridDim.x + blockIdx.x;
         uint32_t q = 0;
         bool close = false;
         if (item < count) {
@@ -1089,14 +1106,14 @@ struct CollapseTemporaries {
     DeviceBuffer<unsigned char> sort_tmp;
     // EM problems only
     DeviceBuffer<uint64_t> csr_key, csr_pattern;
-    DeviceBuffer<uint32_t> csr_row;
+    DeviceBuffer<uint32_t> csr_row, csr_segments;
 };
 
 // The stages behind the keys, for group matrices and for EM problems alike: `key` / `row` hold, per row slot, the sort key
 // (matrix, projection, largest value) and the slot itself; `info` receives [counters | zeroed words | active bytes | list sizes].
 template <typename Arrays>
 hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const uint64_t total_rows, const double precision, const uint64_t * key,
-                               const uint32_t * row, const uint32_t * segment_off, DeviceBuffer<uint32_t> & info, double * rowmax, uint32_t * mat_fast,
+                               const uint32_t * row, const uint32_t * segment_begin, const uint32_t * segment_end, const bool segmented, DeviceBuffer<uint32_t> & info, double * rowmax, uint32_t * mat_fast,
                                uint32_t * mat_mid, CollapseTemporaries * tmp, hipStream_t st) {
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
@@ -1105,8 +1122,8 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     const uint64_t mark_words = (total_rows + 31) / 32;
     const uint64_t num_words = 2 + 2 * static_cast<uint64_t>(M) + 1 + mark_words + 5;
     const uint32_t pair_capacity = static_cast<uint32_t>(std::min<uint64_t>(4 * total_rows + 4096, 0x20000000ull));
-    ok(tmp->key_out.alloc(total_rows));
-    ok(tmp->row_out.alloc(total_rows));
+    if (tmp->key_out.count != total_rows) ok(tmp->key_out.alloc(total_rows));  // (the EM problems' caller has them already)
+    if (tmp->row_out.count != total_rows) ok(tmp->row_out.alloc(total_rows));
     // one block, one memset: [info | the zeroed words | active bytes] + list sizes [M] (written by the list kernel)
     const uint64_t active_words = (total_rows + 3) / 4;
     ok(info.alloc(kInfoWords + num_words + active_words + M));
@@ -1128,8 +1145,6 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     // the whole array on the projection and as many matrix bits as there are matrices orders every matrix's rows by their
     // projection.  (Round 2 sorted segment by segment, hipcub::DeviceSegmentedRadixSort: 0.33 ms per 1.6 M rows in 2 500
     // segments, the longest kernel of the collapse; RPVG_HIP_COLLAPSE_SEGMENTED_SORT=1 keeps it for A/B on the group matrices.)
-    static const bool segmented_wanted = std::getenv("RPVG_HIP_COLLAPSE_SEGMENTED_SORT") != nullptr;
-    const bool segmented = segmented_wanted && segment_off != nullptr;
     int matrix_bits = 1;
     while ((1u << matrix_bits) < M + 1) ++matrix_bits;  // (+ 1: the index unused row slots of the EM problems carry)
     const int begin_bit = kCollapseLargestBits - Arrays::kHashBits, end_bit = segmented ? kCollapseMatrixShift : kCollapseMatrixShift + matrix_bits;
@@ -1137,7 +1152,7 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     auto sort = [&](void * scratch) {
         return segmented ? hipcub::DeviceSegmentedRadixSort::SortPairs(scratch, sort_bytes, key, tmp->key_out.ptr, row,
                                                                        tmp->row_out.ptr, static_cast<int>(total_rows), static_cast<int>(M),
-                                                                       segment_off, segment_off + 1, begin_bit, end_bit, st)
+                                                                       segment_begin, segment_end, begin_bit, end_bit, st)
                          : hipcub::DeviceRadixSort::SortPairs(scratch, sort_bytes, key, tmp->key_out.ptr, row,
                                                               tmp->row_out.ptr, static_cast<int>(total_rows), begin_bit, end_bit, st);
     };
@@ -1242,50 +1257,74 @@ __device__ __forceinline__ uint64_t cellHashTerm(const uint32_t column, const do
 // (problem, projection of the normalised row, its largest value); the others the index `num_problems`, which no problem
 // has — they sort behind every row and are close to nothing
 __global__ __launch_bounds__(256) void csrCollapseKeysKernel(const CsrArrays g, const uint32_t num_problems_bound, const uint32_t * __restrict__ num_problems_dev,
-                                                           const uint64_t total_rows, uint64_t * __restrict__ key, uint32_t * __restrict__ row,
-                                                           uint64_t * __restrict__ pattern_out) {
-    // phase 1 (all slots): the unused-slot key; phase 2 (per problem, its kept rows): overwritten by the real one — two
-    // kernels' worth of work in one launch would race, so the launch is over problems and every problem also fills the
-    // gap between its rows and the next problem's
+                                                           const uint32_t num_items_bound, const uint32_t * __restrict__ num_items_dev,
+                                                           const uint64_t * __restrict__ seg_first, const uint32_t * __restrict__ item_problem,
+                                                           const uint32_t segment_rows, const uint64_t total_rows, uint64_t * __restrict__ key,
+                                                           uint32_t * __restrict__ row, uint64_t * __restrict__ pattern_out, uint32_t * __restrict__ segment_begin,
+                                                           uint32_t * __restrict__ segment_end, uint64_t * __restrict__ sorted_key,
+                                                           uint32_t * __restrict__ sorted_row) {
+    // Work item = a problem's stretch of `segment_rows` row slots (the items of the fill, em_sparse.hip: a problem has at least
+    // as many as its slots need); the last item of a problem also covers the unused slots up to the next problem's.
+    // (segment_begin != NULL: the rows are sorted problem by problem, a segment each, and the unused slots — which no segment
+    // covers — keep what is written here in the sorted arrays.)
     const uint32_t P = num_problems_dev ? *num_problems_dev : num_problems_bound;
-    const uint32_t p = blockIdx.x;
+    const uint32_t items = num_items_dev ? min(*num_items_dev, num_items_bound) : num_items_bound;
     const uint64_t unused = collapseSortKey(num_problems_bound, 0.0, 0.0);
-    if (p >= P) {
-        if (p == P) {  // the tail behind the last problem (and everything, if there is no problem)
-            const uint64_t from = P == 0 ? 0 : g.row_base[P - 1] + g.kept_rows[P - 1];
-            for (uint64_t r = from + threadIdx.x; r < total_rows; r += blockDim.x) {
-                key[r] = unused;
-                row[r] = static_cast<uint32_t>(r);
-                pattern_out[r] = 0;
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const uint32_t p = item_problem[item];
+        if (p >= P) continue;
+        const uint64_t s = item - seg_first[p];
+        const bool last = item + 1 == seg_first[p + 1];
+        const CsrView mv = g.view(p);
+        const uint64_t r0 = g.row_base[p];
+        const uint64_t slots = (p + 1 < P ? g.row_base[p + 1] : r0 + mv.R) - r0;
+        if (s == 0 && threadIdx.x == 0 && segment_begin) {
+            segment_begin[p] = static_cast<uint32_t>(r0);
+            segment_end[p] = static_cast<uint32_t>(r0 + mv.R);
+        }
+        const uint64_t lo = s * segment_rows, hi = last ? slots : min(slots, (s + 1) * segment_rows);
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            uint64_t k = unused, pattern = 0;
+            if (i < mv.R) {
+                const double noise = mv.noise[i];
+                double projection = collapseWeight(mv.G) * noise, largest = 0.0;
+                uint64_t cells = cellHashTerm(mv.G, noise);
+                for (uint32_t e = mv.off[i]; e < mv.off[i + 1]; ++e) {
+                    const uint32_t c = mv.col[e];
+                    const double v = mv.val[e];
+                    projection = fma(collapseWeight(c), v, projection);
+                    largest = fmax(largest, v);
+                    cells += cellHashTerm(c, v);
+                    if (c < 64 && v != 0.0) pattern |= 1ull << c;
+                }
+                // the top of the low field: a hash of the row's cells, sorted on (rows of equal cells end up next to each other)
+                constexpr int low_bits = kCollapseLargestBits - kCsrCellHashBits;
+                k = collapseSortKey(p, projection, largest);
+                k = (k & ~((1ull << kCollapseLargestBits) - 1)) | (((cells * 0x9E3779B97F4A7C15ull) >> (64 - kCsrCellHashBits)) << low_bits) | (k & ((1ull << low_bits) - 1));
+            }
+            key[r0 + i] = k;
+            row[r0 + i] = static_cast<uint32_t>(r0 + i);
+            pattern_out[r0 + i] = pattern;
+            if (segment_begin && i >= mv.R) {
+                sorted_key[r0 + i] = unused;
+                sorted_row[r0 + i] = static_cast<uint32_t>(r0 + i);
             }
         }
-        return;
     }
-    const CsrView mv = g.view(p);
-    const uint64_t r0 = g.row_base[p];
-    const uint64_t gap_end = p + 1 < P ? g.row_base[p + 1] : r0 + mv.R;
-    for (uint64_t i = threadIdx.x; r0 + i < gap_end; i += blockDim.x) {
-        uint64_t k = unused, pattern = 0;
-        if (i < mv.R) {
-            const double noise = mv.noise[i];
-            double projection = collapseWeight(mv.G) * noise, largest = 0.0;
-            uint64_t cells = cellHashTerm(mv.G, noise);
-            for (uint32_t e = mv.off[i]; e < mv.off[i + 1]; ++e) {
-                const uint32_t c = mv.col[e];
-                const double v = mv.val[e];
-                projection = fma(collapseWeight(c), v, projection);
-                largest = fmax(largest, v);
-                cells += cellHashTerm(c, v);
-                if (c < 64 && v != 0.0) pattern |= 1ull << c;
-            }
-            // the top of the low field: a hash of the row's cells, sorted on (rows of equal cells end up next to each other)
-            constexpr int low_bits = kCollapseLargestBits - kCsrCellHashBits;
-            k = collapseSortKey(p, projection, largest);
-            k = (k & ~((1ull << kCollapseLargestBits) - 1)) | (((cells * 0x9E3779B97F4A7C15ull) >> (64 - kCsrCellHashBits)) << low_bits) | (k & ((1ull << low_bits) - 1));
+    const uint64_t thread = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x, threads = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    if (segment_begin) {  // the segments of the bound's problems that do not exist
+        for (uint64_t p = P + thread; p < num_problems_bound; p += threads) segment_begin[p] = segment_end[p] = 0;
+    }
+    // the tail behind the last problem (everything, if there is no problem)
+    const uint64_t from = P == 0 ? 0 : g.row_base[P - 1] + g.kept_rows[P - 1];
+    for (uint64_t r = from + thread; r < total_rows; r += threads) {
+        key[r] = unused;
+        row[r] = static_cast<uint32_t>(r);
+        pattern_out[r] = 0;
+        if (segment_begin) {
+            sorted_key[r] = unused;
+            sorted_row[r] = static_cast<uint32_t>(r);
         }
-        key[r0 + i] = k;
-        row[r0 + i] = static_cast<uint32_t>(r0 + i);
-        pattern_out[r0 + i] = pattern;
     }
 }
 
@@ -1309,7 +1348,9 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     arrays.row_noise = g->row_noise.ptr;
     arrays.row_count = g->row_count.ptr;
     arrays.zero_pattern = g->collapse_mask.ptr;
-    return queueCollapseStages(arrays, M, total_rows, precision, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_segment_off.ptr, g->collapse_info,
+    static const bool segmented = std::getenv("RPVG_HIP_COLLAPSE_SEGMENTED_SORT") != nullptr;  // (A/B: slower on the group matrices)
+    return queueCollapseStages(arrays, M, total_rows, precision, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_segment_off.ptr,
+                               g->collapse_segment_off.ptr + 1, segmented && g->collapse_segment_off.ptr != nullptr, g->collapse_info,
                                g->rowmax.ptr, g->mat_fast.ptr, g->mat_mid.ptr, tmp.get(), st);
 }
 
@@ -1318,7 +1359,6 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
 // run joined rows that were not equal up to rounding, merged_count holds their read counts after the merges (a merged
 // row's count moved to its run head) and merged_problems[0] their number.
 hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollapseInput & in, const double precision, CsrCollapseWork & work, hipStream_t st) {
-    (void) ctx;
     const uint32_t P = in.num_problems_bound;
     const uint64_t total_rows = in.rows_capacity;
     if (P == 0 || total_rows == 0) return hipSuccess;
@@ -1348,10 +1388,25 @@ hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollap
     arrays.merged_count = work.merged_count.ptr;
     arrays.problem_merged = work.problem_merged.ptr;
     arrays.merged_problems = work.problem_merged.ptr + P;
-    csrCollapseKeysKernel<<<dim3(P + 1), dim3(256), 0, st>>>(arrays, P, in.num_problems_dev, total_rows, tmp->csr_key.ptr, tmp->csr_row.ptr, tmp->csr_pattern.ptr);
+    // The rows of a problem are sorted as a segment: one launch for every problem that fits a workgroup and a few for the
+    // others, against the global sort's seven passes of three launches each — next to the other lane's EM kernels every
+    // launch of this chain waits 40-80 us for its turn.  RPVG_HIP_EM_COLLAPSE_GLOBAL_SORT=1: the global sort (A/B).
+    static const bool segmented = std::getenv("RPVG_HIP_EM_COLLAPSE_GLOBAL_SORT") == nullptr;
+    if (segmented) {
+        ok(tmp->csr_segments.alloc(2 * static_cast<size_t>(P)));
+        ok(tmp->key_out.alloc(total_rows));
+        ok(tmp->row_out.alloc(total_rows));
+        if (e != hipSuccess) return e;
+    }
+    uint32_t * segment_begin = segmented ? tmp->csr_segments.ptr : nullptr, * segment_end = segmented ? segment_begin + P : nullptr;
+    const uint32_t keys_grid = std::max<uint32_t>(1, std::min<uint32_t>(in.num_items_bound, static_cast<uint32_t>(ctx->props.multiProcessorCount) * 8));
+    csrCollapseKeysKernel<<<dim3(keys_grid), dim3(256), 0, st>>>(arrays, P, in.num_problems_dev, in.num_items_bound, in.num_items_dev, in.seg_first, in.item_problem,
+                                                                in.segment_rows, total_rows, tmp->csr_key.ptr, tmp->csr_row.ptr, tmp->csr_pattern.ptr, segment_begin,
+                                                                segment_end, tmp->key_out.ptr, tmp->row_out.ptr);
     ok(hipGetLastError());
     if (e != hipSuccess) return e;
-    return queueCollapseStages(arrays, P, total_rows, precision, tmp->csr_key.ptr, tmp->csr_row.ptr, nullptr, work.info, nullptr, nullptr, nullptr, tmp.get(), st);
+    return queueCollapseStages(arrays, P, total_rows, precision, tmp->csr_key.ptr, tmp->csr_row.ptr, segment_begin, segment_end, segmented, work.info, nullptr,
+                               nullptr, nullptr, tmp.get(), st);
 }
 
 extern "C" int rpvg_hip_groups_collapse_info(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, uint32_t * matrices_replayed,
