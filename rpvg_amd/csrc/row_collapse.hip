@@ -1150,6 +1150,8 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     const int begin_bit = kCollapseLargestBits - Arrays::kHashBits, end_bit = segmented ? kCollapseMatrixShift : kCollapseMatrixShift + matrix_bits;
     size_t sort_bytes = 0;
     auto sort = [&](void * scratch) {
+        // (hipcub's segmented sort partitions the segments by size and reads the partition sizes back — the lane's thread waits
+        // there for the fill; rocprim's unpartitioned configuration, one kernel and no wait, was 1 ms slower per lane all the same)
         return segmented ? hipcub::DeviceSegmentedRadixSort::SortPairs(scratch, sort_bytes, key, tmp->key_out.ptr, row,
                                                                        tmp->row_out.ptr, static_cast<int>(total_rows), static_cast<int>(M),
                                                                        segment_begin, segment_end, begin_bit, end_bit, st)
@@ -1388,9 +1390,9 @@ hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollap
     arrays.merged_count = work.merged_count.ptr;
     arrays.problem_merged = work.problem_merged.ptr;
     arrays.merged_problems = work.problem_merged.ptr + P;
-    // The rows of a problem are sorted as a segment: one launch for every problem that fits a workgroup and a few for the
-    // others, against the global sort's seven passes of three launches each — next to the other lane's EM kernels every
-    // launch of this chain waits 40-80 us for its turn.  RPVG_HIP_EM_COLLAPSE_GLOBAL_SORT=1: the global sort (A/B).
+    // The rows of a problem are sorted as a segment: a handful of launches against the global sort's seven passes of three
+    // launches each (same box, configs[2] batch: 12.0-12.5 ms per step against 14.6).  RPVG_HIP_EM_COLLAPSE_GLOBAL_SORT=1: the
+    // global sort (A/B).
     static const bool segmented = std::getenv("RPVG_HIP_EM_COLLAPSE_GLOBAL_SORT") == nullptr;
     if (segmented) {
         ok(tmp->csr_segments.alloc(2 * static_cast<size_t>(P)));
