@@ -937,7 +937,21 @@ __device__ __forceinline__ void finishRuns(const ReplayArgs<MatrixArrays> & a, c
         const uint32_t h = head_of[q];
         if (h == q) continue;
         const uint32_t dst = order[q], src = order[h];
-        for (uint32_t c = lane; c < mv.G; c += 64) M[static_cast<uint64_t>(c) * R + dst] = M[static_cast<uint64_t>(c) * R + src];
+        // (a column is a cache line of its own, in either row: eight loads in flight per lane — one at a time, a merged row of a
+        // 2 000-column matrix took a wave 60 us)
+        for (uint32_t c0 = lane; c0 < mv.G; c0 += 64 * 8) {
+            double v[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                const uint32_t c = c0 + 64 * k;
+                v[k] = c < mv.G ? __builtin_nontemporal_load(&M[static_cast<uint64_t>(c) * R + src]) : 0.0;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                const uint32_t c = c0 + 64 * k;
+                if (c < mv.G) M[static_cast<uint64_t>(c) * R + dst] = v[k];
+            }
+        }
         if (lane == 0) {
             const double noise = nz[src];
             nz[dst] = noise;
@@ -1062,15 +1076,20 @@ __global__ __launch_bounds__(256) void collapseRunsKernel(const ReplayArgs<Array
         while (walk_at < n) {  // (uniform: walk_at only changes between barriers)
             const uint64_t h = walk_at;
             if (h + 1 >= n || !close[h + 1]) {
-                // a stretch of single-row runs: one thread runs through it
-                if (threadIdx.x == 0) {
-                    uint64_t q = h;
-                    while (q < n && (q + 1 >= n || !close[q + 1])) {
-                        head_of[q] = static_cast<uint32_t>(q);
-                        ++q;
-                    }
-                    walk_at = static_cast<uint32_t>(q);
+                // a stretch of single-row runs, up to the next row with a close successor: the workgroup looks for it, 256
+                // positions at a time (one thread stepping through a list of a few hundred single rows, a dependent load per
+                // step, was most of this kernel's 0.23 ms on the group matrices)
+                if (threadIdx.x == 0) run_end = static_cast<uint32_t>(n);
+                __syncthreads();
+                for (uint64_t q0 = h + 1; q0 < n && run_end == n; q0 += blockDim.x) {  // (uniform: run_end read behind the barrier below)
+                    const uint64_t q = q0 + threadIdx.x;
+                    if (q + 1 < n && close[q + 1]) atomicMin(&run_end, static_cast<uint32_t>(q));
+                    __syncthreads();
                 }
+                const uint64_t stretch_end = run_end;
+                for (uint64_t q = h + threadIdx.x; q < stretch_end; q += blockDim.x) head_of[q] = static_cast<uint32_t>(q);
+                __syncthreads();
+                if (threadIdx.x == 0) walk_at = static_cast<uint32_t>(stretch_end);
                 __syncthreads();
                 continue;
             }
