@@ -114,9 +114,10 @@ typedef struct rpvg_hip_em_results {
  *   readCollapseProbabilityMatrix           src/path_estimator.cpp:219-259
  * between the normalisation and the EM: the rows of every problem are put through the reference's tolerant
  * sort and compare-with-run-head merge (the machinery of the group matrices' collapse on the sparse rows); a
- * merged row's read count moves to its run head.  It runs next to the EM; the problems in which it merged rows
- * that were not equal up to rounding (rare) are solved a second time on the merged counts.  Rows without any
- * selected path are folded into one exact scalar. */
+ * merged row's read count moves to its run head, and the EM kernels read the merged counts of the problems in
+ * which rows were merged.  Rows whose columns all fall into the same multiple of 2^-44 stand for each other
+ * there (and merges of rows equal to 1e-13 relative are not replayed: they move nothing).
+ * Rows without any selected path are folded into one exact scalar. */
 int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t max_em_its, double max_rel_em_conv,
                       const rpvg_hip_em_problems * problems, rpvg_hip_em_results * results);
 
