@@ -1258,7 +1258,8 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     auto grid = [&](const uint32_t per_cu) { return std::min<uint32_t>(P, std::max<uint32_t>(1, static_cast<uint32_t>(cus * per_cu * grid_scale))); };
     const size_t streamed_lds_256 = emLdsBytes(list.max_cols, 0, 0, 256, false), streamed_lds_1024 = emLdsBytes(list.max_cols, 0, 0, 1024, false);
     const bool wide_possible = streamed_lds_1024 > kEmLdsLimit;
-    const bool many_queues = hardwareQueues() >= 8;
+    static const bool few_streams = std::getenv("RPVG_HIP_EM_FEW_STREAMS") != nullptr;  // A/B knob
+    const bool many_queues = hardwareQueues() >= 8 && !few_streams;
     hipStream_t s_reg4 = many_queues ? ctx->aux[3] : ctx->aux[0], s_reg1 = many_queues ? ctx->aux[4] : ctx->aux[1], s_reg2 = many_queues ? ctx->aux[5] : ctx->aux[2];
     // One persistent launch per kernel variant (the register-resident bins are the long ones: they start first; with
     // eight hardware queues — hardwareQueues(), context.hip — they get streams of their own; chains of launches that share
