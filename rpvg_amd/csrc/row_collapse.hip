@@ -166,16 +166,15 @@ __device__ __forceinline__ bool rowLess(const View & mv, const uint32_t a, const
 // every column (noise included) within `precision` of each other, absolutely (src/path_estimator.cpp:232-239);
 // *equivalent: additionally equal up to rounding in every column
 template <typename View>
-__device__ bool rowsClose(const View & mv, const uint32_t a, const uint32_t b, const double precision, bool * equivalent) {
+__device__ __forceinline__ bool rowsClose(const View & mv, const uint32_t a, const uint32_t b, const double precision, bool * equivalent) {
     bool eq = true, close = true;
     forEachColumnPair(mv, a, b, mv.patternOf(a) | mv.patternOf(b), [&](const double x, const double y) {
+        // (both flags updated on every path: a store to whichever flag a branch picked kept them in scratch memory)
         const double d = fabs(x - y);
-        if (d >= precision) {
-            close = false;
-            return true;
-        }
-        if (d > kEquivalentRelative * fmin(fabs(x), fabs(y))) eq = false;
-        return false;
+        const bool apart = d >= precision;
+        close = close && !apart;
+        eq = eq && !(d > kEquivalentRelative * fmin(fabs(x), fabs(y)));
+        return apart;
     });
     if (close && equivalent) *equivalent = eq;
     return close;
