@@ -3,8 +3,8 @@
 cd /root/repo
 for round in 1 2 3; do
   for v in "$@"; do
-    if [ "$v" = "-" ]; then python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/b.json
-    else env $v python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/b.json; fi
+    if [ "$v" = "-" ]; then timeout 150 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/b.json
+    else env $v timeout 150 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/b.json; fi
     python - <<PY
 import json
 d=json.loads(open("/tmp/b.json").read()); k=d["kernels"]
