@@ -1296,7 +1296,16 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
             pw.part_pair = d_part_pair.ptr;
             pw.log_evals = args.log_evals;
             pw.debug_skip = std::getenv("RPVG_HIP_PAIR_DEBUG") ? static_cast<uint32_t>(std::atoi(std::getenv("RPVG_HIP_PAIR_DEBUG"))) : 0u;
-            pairTileKernel<<<dim3(pw.count), dim3(kTileBlock), kTileLdsDoubles * sizeof(double), st>>>(pw);
+            // A/B knob RPVG_HIP_PAIR_LDS_KB: more dynamic LDS than the kernel uses = fewer workgroups per CU (64: two instead of
+            // three — registers left over for the other lane's kernels while this one runs)
+            static const size_t tile_lds_bytes = []() {
+                const char * env = std::getenv("RPVG_HIP_PAIR_LDS_KB");
+                return std::max<size_t>(kTileLdsDoubles * sizeof(double), env ? static_cast<size_t>(std::atoi(env)) * 1024 : 0);
+            }();
+            if (tile_lds_bytes > 64 * 1024) {
+                RPVG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairTileKernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes)));
+            }
+            pairTileKernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
         } else {
             pairTableKernel<<<dim3(((tw.count + 7) / 8) * 8), dim3(256), 0, st>>>(tw);
         }

@@ -586,6 +586,7 @@ struct ReplayArgs {
     double * pair_hi;            //              and larger
     uint64_t * pair_pattern;     // [total rows] zero pattern they share before that column
     uint32_t * info;
+    bool debug;                  // RPVG_HIP_EM_COLLAPSE_DEBUG: slow workgroups of the runs kernel report where their time went
 };
 
 // a0. the list of a matrix: its active rows (the replay then only touches those), or all of them
@@ -1057,6 +1058,7 @@ __global__ __launch_bounds__(256) void collapseRunsKernel(const ReplayArgs<Array
             return rowsClose(mv, order[p], order[q], a.precision, nullptr);
         };
         __syncthreads();
+        const long long clock_begin = wall_clock64();
         if (threadIdx.x == 0) demote = 0;
         for (uint64_t p = threadIdx.x; p < n; p += blockDim.x) {
             head_of[p] = kNoRow;
@@ -1105,7 +1107,12 @@ __global__ __launch_bounds__(256) void collapseRunsKernel(const ReplayArgs<Array
             if (threadIdx.x == 0) walk_at = static_cast<uint32_t>(end);
             __syncthreads();
         }
+        const long long clock_walked = wall_clock64();
         finishRuns(a, m, n, order, head_of, &demote, (encoded & kWholeMatrixBit) != 0);
+        if (a.debug && threadIdx.x == 0 && wall_clock64() - clock_begin > 2000) {
+            printf("[runs] matrix %u rows %llu cols %u list %llu tabled %d: walk %lld finish %lld (10 ns)\n", m, static_cast<unsigned long long>(mv.R), mv.G,
+                   static_cast<unsigned long long>(n), tabled ? 1 : 0, clock_walked - clock_begin, wall_clock64() - clock_walked);
+        }
     }
 }
 
@@ -1255,6 +1262,7 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     r.pair_hi = tmp->pair_bound.ptr + total_rows;
     r.pair_pattern = tmp->pair_pattern.ptr;
     r.info = info.ptr;
+    r.debug = std::getenv("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
     collapseListKernel<Arrays><<<dim3(M), dim3(256), 0, st>>>(r);
     collapsePairTableKernel<Arrays><<<dim3(4096), dim3(64), 0, st>>>(r);
     collapseRankKernel<Arrays><<<dim3(1024), dim3(256), 0, st>>>(r);
