@@ -1174,8 +1174,12 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     // largest problems were the merged ones, the second pass took as long as the first, and the collapse's forty launches
     // took 2.6 ms in between the persistent EM kernels against 1.5 ms without them.)
     static const bool no_em_collapse = std::getenv("RPVG_HIP_NO_EM_COLLAPSE") != nullptr;
-    const bool collapse = collapse_precision > 0 && !no_em_collapse && !std::getenv("RPVG_HIP_NO_COLLAPSE") && list.rows_capacity > 0 &&
-                          list.rows_capacity <= 0x7fffffffull && P + 1 < kCollapseMaxMatrices;
+    const bool collapse = collapse_precision > 0 && !no_em_collapse && !std::getenv("RPVG_HIP_NO_COLLAPSE") && list.rows_capacity > 0;
+    // (the collapse indexes rows with 32 bits and matrices with 20; the callers' memory budgets keep a solve far below both —
+    // a solve that is not gets an error rather than results without the collapse)
+    RPVG_REQUIRE(!collapse || (list.rows_capacity <= 0x7fffffffull && P + 1 < kCollapseMaxMatrices),
+                 "EM solve with a row collapse: %llu row slots in %u problems exceed what one solve can collapse (2^31 - 1 rows, 2^20 - 2 problems): split the problem list",
+                 static_cast<unsigned long long>(list.rows_capacity), P);
     if (collapse) {
         RPVG_HIP_CHECK(hipEventCreateWithFlags(&work.filled, hipEventDisableTiming));
         RPVG_HIP_CHECK(hipEventRecord(work.filled, st));
