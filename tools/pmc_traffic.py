@@ -5,7 +5,7 @@ require: MI355X_MICROARCH.md, counters table) into the HBM traffic of one kernel
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <fetch_dir> -- python bench.py ...
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <write_dir> -- python bench.py ...
   python tools/pmc_traffic.py --fetch-dir <fetch_dir> --write-dir <write_dir> --kernel emSparseKernel \
-         --steps 2 --out profiles/pmc_traffic_s3.json [--double-fetch]
+         --steps 2 --out profiles/r03/pmc_traffic_s3.json [--double-fetch]
 
 --double-fetch applies the guide's gfx950 correction for wide (16 B/lane) streaming reads; other access widths are
 uncalibrated and left as reported.  FETCH_SIZE / WRITE_SIZE are in KB."""
