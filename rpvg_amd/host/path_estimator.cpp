@@ -1,6 +1,8 @@
 #include "path_estimator.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cassert>
 #include <cmath>
@@ -620,6 +622,14 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
             RetiredContainers::ofThisThread().dropAll();
 
             stagger.waitTurn(lane);
+
+            // A/B knob RPVG_AMD_LANE_DELAY_US: the lane starts this much later still
+            static const long lane_delay_us = std::getenv("RPVG_AMD_LANE_DELAY_US") ? std::atol(std::getenv("RPVG_AMD_LANE_DELAY_US")) : 0;
+
+            if (lane_delay_us > 0) {
+
+                std::this_thread::sleep_for(std::chrono::microseconds(lane_delay_us));
+            }
 
             try {
 
