@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
         // entries walk it side by side, the additions stay in entry order.
         const uint64_t e_end = row_ent_off[r + 1];
         for (uint64_t e = row_ent_off[r]; e < e_end; e += 4) {
-            uint32_t p[4], g_first[4];
+            uint32_t p[4];
             double v[4];
             uint64_t x_begin[4], x_end[4];
 #pragma unroll
@@ -207,41 +207,85 @@ __global__ __launch_bounds__(256) void groupsBuildTileKernel(
                 x_begin[k] = in ? pgo[p[k]] : 0;
                 x_end[k] = in ? pgo[p[k] + 1] : 0;
             }
+            // A path lies in as many columns as haplotype groups carry it — dozens for a common allele — and every column
+            // index is a load of its own: the first kAhead of all four entries are fetched before anything is added (32
+            // loads in flight), longer lists eight at a time.  The additions keep their order: entry after entry, column
+            // after column.
+            constexpr int kAhead = 8;
+            uint32_t columns[4][kAhead];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g_first[k] = x_begin[k] < x_end[k] ? path_grp[x_begin[k]] : 0u;
+            for (int j = 0; j < kAhead; ++j) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) columns[k][j] = x_begin[k] + j < x_end[k] ? path_grp[x_begin[k] + j] : 0u;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (x_begin[k] < x_end[k]) tile[g_first[k] * Rs + t] += v[k];
-                for (uint64_t x = x_begin[k] + 1; x < x_end[k]; ++x) tile[path_grp[x] * Rs + t] += v[k];
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) {
+                    if (x_begin[k] + j < x_end[k]) tile[columns[k][j] * Rs + t] += v[k];
+                }
+                for (uint64_t x = x_begin[k] + kAhead; x < x_end[k]; x += kAhead) {
+                    uint32_t more[kAhead];
+#pragma unroll
+                    for (int j = 0; j < kAhead; ++j) more[j] = x + j < x_end[k] ? path_grp[x + j] : 0u;
+#pragma unroll
+                    for (int j = 0; j < kAhead; ++j) {
+                        if (x + j < x_end[k]) tile[more[j] * Rs + t] += v[k];
+                    }
+                }
             }
         }
+    }
+    // The rows' second half — row sum, normalisation, maximum, sort key, zero pattern — with as many lanes per row as the
+    // workgroup has to spare (a tile of 64 columns is 64 rows: four lanes each, neighbours in a wave, every one a quarter of
+    // the columns; the owner thread alone spent 8 of the tile's 23 us here, one division and three dependent chains per
+    // column).  The row sum keeps its order (column after column, by the row's first lane); the key is a sum of the lanes'
+    // partial keys in a fixed order.
+    __syncthreads();
+    uint32_t parts = 1;
+    while (parts < 8 && 2 * parts * Rc <= blockDim.x) parts *= 2;
+    const uint32_t row = threadIdx.x / parts, part = threadIdx.x % parts;
+    if (row < Rc) {  // (whole groups of `parts` lanes: the shuffles below stay inside them)
+        const bool valid = row < nrows;
+        const uint64_t r = valid ? r0 + row_perm[mat_row_off[m] + i0 + row] : 0;
         double mx = 0.0;
         if (normalise) {
             double rowsum = 0.0;
-            for (uint32_t g = 0; g < G; ++g) rowsum += tile[g * Rs + t];
-            const double keep = 1 - row_noise[r];
-            double key = collapseWeight(G) * row_noise[r];
-            uint64_t pattern = 0;
-            for (uint32_t g = 0; g < G; ++g) {
-                double v = (tile[g * Rs + t] / rowsum) * keep;
-                if (v != v) v = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
-                tile[g * Rs + t] = v;
-                mx = (g == 0) ? v : fmax(mx, v);
-                key = fma(collapseWeight(g), v, key);
-                if (g < 64 && v != 0.0) pattern |= 1ull << g;
+            if (valid && part == 0) {
+                for (uint32_t g = 0; g < G; ++g) rowsum += tile[g * Rs + row];
             }
-            if (collapse_key) {
-                collapse_key[mat_row_off[m] + i0 + t] = collapseSortKey(m, key, mx);
-                collapse_row[mat_row_off[m] + i0 + t] = static_cast<uint32_t>(mat_row_off[m] + i0 + t);
-                collapse_mask[mat_row_off[m] + i0 + t] = pattern;
+            rowsum = __shfl(rowsum, static_cast<int>(threadIdx.x & 63u) - static_cast<int>(part));
+            const double noise = valid ? row_noise[r] : 0.0;
+            const double keep = 1 - noise;
+            double key = part == 0 ? collapseWeight(G) * noise : 0.0;
+            uint64_t pattern = 0;
+            if (valid) {
+                for (uint32_t g = part; g < G; g += parts) {
+                    double v = (tile[g * Rs + row] / rowsum) * keep;
+                    if (v != v) v = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
+                    tile[g * Rs + row] = v;
+                    mx = fmax(mx, v);
+                    key = fma(collapseWeight(g), v, key);
+                    if (g < 64 && v != 0.0) pattern |= 1ull << g;
+                }
+            }
+            for (uint32_t step = 1; step < parts; step *= 2) {
+                mx = fmax(mx, __shfl_xor(mx, static_cast<int>(step)));
+                key += __shfl_xor(key, static_cast<int>(step));
+                pattern |= __shfl_xor(pattern, static_cast<int>(step));
+            }
+            if (valid && part == 0 && collapse_key) {
+                collapse_key[mat_row_off[m] + i0 + row] = collapseSortKey(m, key, mx);
+                collapse_row[mat_row_off[m] + i0 + row] = static_cast<uint32_t>(mat_row_off[m] + i0 + row);
+                collapse_mask[mat_row_off[m] + i0 + row] = pattern;
             }
         } else {
-            for (uint32_t g = 0; g < G; ++g) {
-                const double v = tile[g * Rs + t];
-                mx = (g == 0) ? v : fmax(mx, v);
+            if (valid) {
+                for (uint32_t g = part; g < G; g += parts) mx = fmax(mx, tile[g * Rs + row]);
             }
+            for (uint32_t step = 1; step < parts; step *= 2) mx = fmax(mx, __shfl_xor(mx, static_cast<int>(step)));
         }
-        rowmax[mat_row_off[m] + i0 + t] = mx;
+        if (valid && part == 0) rowmax[mat_row_off[m] + i0 + row] = mx;
     }
     __syncthreads();
     double * M = values + mat_val_off[m];
