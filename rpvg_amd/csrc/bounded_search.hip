@@ -597,7 +597,6 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(3)))
     const uint32_t tc = threadIdx.x % T, marg_slice = threadIdx.x / T;
     const bool marg_active = marg_slice < SM;
 
-    const long long dbg_begin = wall_clock64();
     for (uint32_t pass = 0; pass < passes; ++pass) {
         const uint32_t t = (S > 1 || passes == 1) ? threadIdx.x % tiles : pass * kTileBlock + threadIdx.x;
         const uint32_t slice = (S > 1 || passes == 1) ? threadIdx.x / tiles : 0u;
@@ -639,11 +638,9 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(3)))
             since_fold_m = 0;
         };
 
-        long long dbg_stage = 0, dbg_compute = 0;
         for (uint32_t s0 = 0; s0 < n; s0 += sub_rows) {
             const uint32_t ns = (n - s0) < sub_rows ? (n - s0) : sub_rows;
             __syncthreads();  // the rows staged before have been used
-            const long long dbg_a = wall_clock64();
             // lane = row (64 consecutive rows of a column: one 512-byte request), wave = column; eight requests of a
             // thread are in flight before the first is stored (the loop is all latency otherwise: ~25 dependent round
             // trips to memory per thread against ~5 us of arithmetic on the staged rows)
@@ -674,8 +671,6 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(3)))
                 lds_count[r] = cnt[s0 + r];
             }
             __syncthreads();
-            const long long dbg_b = wall_clock64();
-            dbg_stage += dbg_b - dbg_a;
             // class ranges inside the staged rows
             const uint32_t f1 = nf <= s0 ? 0u : ((nf - s0) < ns ? (nf - s0) : ns);
             const uint32_t m1 = nm <= s0 ? 0u : ((nm - s0) < ns ? (nm - s0) : ns);
@@ -759,7 +754,6 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(3)))
                 }
             }
         }
-        if (threadIdx.x == 0 && (blockIdx.x % 997) == 3) printf("[tile] G %u rows %u sub_rows %u S %u nf %u nm %u: stage %lld total %lld (10 ns)\n", G, n, sub_rows, S, nf, nm, dbg_stage, wall_clock64() - dbg_begin);
         // The sums of a chunk: one per pair and column.  Slices add theirs up in LDS, in the order of the slices (the
         // staged rows are done with), so that the resolving workgroup reads one part per chunk.
         double * const out_pairs = w.part_pair + w.pair_part_off[m] + static_cast<uint64_t>(chunk) * G * G;
