@@ -216,6 +216,60 @@ int rpvg_hip_group_conditionals(rpvg_hip_ctx * ctx, const rpvg_hip_groups * grou
                                 const uint32_t * matrix, const uint32_t * others, uint32_t width, double divisor,
                                 double * out);
 
+/* ---- the Gibbs sampler of the group posteriors, on the device ---------------------- */
+/* estimatePathGroupPosteriorsGibbs (src/path_estimator.cpp:475-589) for group sizes 1 and 2, draw for draw: the chains
+ * of every problem (:505), their starts (uniform_int_distribution, :491,509), the conditional of a slot given the other
+ * member (:527-555: the contraction of rpvg_hip_group_conditionals, + log frequency, log-sum-exp, exp, then
+ * std::discrete_distribution's own normalisation and partial sums), one draw per slot and iteration (:556) and the
+ * counting of the sorted sets after the burn-in (:559-574).  The generators are the caller's std::mt19937s: the caller
+ * passes the NEXT 624 outputs of each (drawn from a copy) — their untempered values are the generator's state — and
+ * moves the original past the words_consumed[g] words the chains took (discard(), or the state words of the view), which
+ * leaves it where the reference's sampler would.
+ * Problems that share a generator (the transcripts of one cluster, src/path_abundance_estimator.cpp:371-412) are listed
+ * under it in the order the reference runs them.  libstdc++'s streams (GCC 11: Lemire's rejection for the starts, two
+ * words per generate_canonical<double, 53>, no draw at all from a distribution of fewer than two weights) are restated in
+ * rpvg_amd/csrc/gibbs_streams.hpp and checked against libstdc++ on the CPU (tests/cpp/gibbs_streams_check.cpp).
+ * The chain counts and lengths are the caller's (src/path_estimator.cpp:501-503).
+ * The sets of a problem come in the order the reference appends them to path_group_sets (first appearance).
+ * Returns RPVG_HIP_ERR_UNSUPPORTED, having changed nothing, for other group sizes and when the distributions outgrow the
+ * memory reserved for them (RPVG_HIP_GIBBS_BYTES; default two fifths of the free device memory): the caller then drives
+ * the sampler itself through rpvg_hip_group_conditionals. */
+typedef struct rpvg_hip_gibbs_spec {
+    uint32_t num_problems;
+    uint32_t group_size;                    /* 1 or 2                                                                  */
+    const uint32_t * matrix;                /* [P]   matrix of `groups` the problem samples on                         */
+    const uint32_t * num_chains;            /* [P]   :501                                                              */
+    const uint32_t * num_burn_its;          /* [P]   :502                                                              */
+    const uint32_t * num_gibbs_its;         /* [P]   :503                                                              */
+    const double * log_freq;                /*       calcPathLogFrequences of every column, problems back to back      */
+    uint32_t num_generators;
+    const uint32_t * generator_problem_off; /* [NG+1]                                                                  */
+    const uint32_t * generator_problem;     /* [P]   the problems of each generator, in the order it serves them       */
+    const uint32_t * generator_words;       /* [NG x 624] the next 624 outputs of each generator                       */
+} rpvg_hip_gibbs_spec;
+
+typedef struct rpvg_hip_gibbs_sets rpvg_hip_gibbs_sets;
+typedef struct rpvg_hip_gibbs_sets_view {
+    uint32_t num_problems;
+    uint32_t group_size;
+    const uint64_t * set_off;        /* [P+1] sampled sets of each problem                                             */
+    const uint32_t * first;          /* [sets] smaller member (the member, for group size 1)                           */
+    const uint32_t * second;         /* [sets] larger member                                                           */
+    const uint32_t * count;          /* [sets] samples that produced the set (:573); posterior = count / (chains x its) */
+    const uint64_t * words_consumed; /* [NG]  32-bit words the sampler took from each generator                        */
+    const uint32_t * generator_state;/* [NG x 624] for a generator that gave at least 624 words: the state words before its
+                                      * next output — seeding the std::mt19937 with a seed sequence that hands these out
+                                      * ([rand.eng.mers]: copied into the state, regenerated on the next call) continues
+                                      * the stream at output words_consumed[g]; others are moved by discard()          */
+    uint32_t rounds;                 /* rounds of (advance, conditionals) the call queued                              */
+    uint64_t conditionals;           /* conditional distributions evaluated                                            */
+} rpvg_hip_gibbs_sets_view;
+
+int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const rpvg_hip_gibbs_spec * spec,
+                         rpvg_hip_gibbs_sets ** result_out);
+int rpvg_hip_gibbs_sets_get(const rpvg_hip_gibbs_sets * result, rpvg_hip_gibbs_sets_view * view_out);
+void rpvg_hip_gibbs_sets_free(rpvg_hip_gibbs_sets * result);
+
 /* The whole diploid branch-and-bound of calculatePathGroupPosteriorsBounded
  * (src/path_estimator.cpp:379-473) on the GPU, one workgroup per matrix:
  * marginal posteriors (the nested group-size-1 Full call, :397-412), the

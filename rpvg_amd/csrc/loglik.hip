@@ -352,6 +352,19 @@ __global__ void incidenceFillKernel(const uint32_t num_matrices, const uint64_t 
     }
 }
 
+// storage of the matrices groupsBuildKernel accumulates in global memory: one work item = 256 rows of one matrix
+__global__ __launch_bounds__(256) void zeroWideMatricesKernel(const uint32_t * __restrict__ item_matrix, const uint32_t * __restrict__ item_chunk,
+                                                              const uint64_t * __restrict__ mat_val_off, const uint64_t * __restrict__ mat_rows,
+                                                              const uint32_t * __restrict__ mat_cols, double * __restrict__ values) {
+    const uint32_t m = item_matrix[blockIdx.x];
+    const uint64_t R = mat_rows[m];
+    const uint64_t row = static_cast<uint64_t>(item_chunk[blockIdx.x]) * 256 + threadIdx.x;
+    if (row >= R) return;
+    double * M = values + mat_val_off[m];
+    const uint32_t G = mat_cols[m];
+    for (uint32_t g = 0; g < G; ++g) M[static_cast<uint64_t>(g) * R + row] = 0.0;
+}
+
 // one wave per request
 template <int WIDTH>
 __global__ __launch_bounds__(256) void groupLoglikKernel(
@@ -501,7 +514,6 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     // host: sizes and offsets only (O(M)); the path -> groups incidence is inverted on the device
     std::vector<uint64_t> val_off(M), row_off(M), row0(M), rows(M), inc_off(M), num_paths(M);
     std::vector<uint32_t> cols(M), item_matrix, item_chunk, tile_matrix, tile_chunk;
-    std::vector<uint32_t> wide_matrices;  // too many columns for an LDS tile: global-memory kernel on zero-filled storage
     uint64_t val_total = 0, row_total = 0, inc_total = 0;
     for (uint32_t m = 0; m < M; ++m) {
         const uint32_t k = spec->cluster[m];
@@ -547,7 +559,6 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
                 tile_chunk.push_back(static_cast<uint32_t>(c));
             }
         } else {
-            wide_matrices.push_back(m);
             for (uint64_t c = 0; c * 256 < R; ++c) {
                 item_matrix.push_back(m);
                 item_chunk.push_back(static_cast<uint32_t>(c));
@@ -647,8 +658,10 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     sub.reset(new HostScope("groups_build: launches"));
     if (e == hipSuccess) {
         span = ctx->spanBegin(FAM_BUILD);
-        for (auto m : wide_matrices) {
-            ok(hipMemsetAsync(g->values.ptr + val_off[m], 0, rows[m] * cols[m] * sizeof(double), st));
+        if (!item_matrix.empty()) {
+            // (a hipMemsetAsync per wide matrix was up to four fill kernels each: 370 commands per lane on the configs[4] batch)
+            zeroWideMatricesKernel<<<dim3(static_cast<uint32_t>(item_matrix.size())), dim3(256), 0, st>>>(
+                d_item_matrix.ptr, d_item_chunk.ptr, g->mat_val_off.ptr, g->mat_rows.ptr, g->mat_cols.ptr, g->values.ptr);
         }
         partitionRowsKernel<1024><<<dim3(M), dim3(1024), 0, st>>>(M, g->mat_row_off.ptr, g->mat_row0.ptr, g->mat_rows.ptr, batch->row_count.ptr,
                                                            batch->row_noise.ptr, g->row_perm.ptr, g->row_count.ptr, g->row_noise.ptr,

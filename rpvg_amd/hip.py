@@ -26,6 +26,7 @@ EXPORTS = [
     "rpvg_hip_gibbs_read_counts", "rpvg_hip_min_path_cover", "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
     "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
     "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_comm_init_all", "rpvg_hip_gather", "rpvg_hip_host_register", "rpvg_hip_host_unregister", "rpvg_hip_group_conditionals",
+    "rpvg_hip_group_gibbs", "rpvg_hip_gibbs_sets_get", "rpvg_hip_gibbs_sets_free",
     "rpvg_hip_alignments_upload", "rpvg_hip_alignments_free", "rpvg_hip_read_rows_build", "rpvg_hip_read_rows_to_batch",
     "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_sizes", "rpvg_hip_read_rows_free", "rpvg_hip_path_clusters", "rpvg_hip_debug_log",
     "rpvg_hip_nested_subset_em", "rpvg_hip_subset_em_get", "rpvg_hip_subset_em_free",
@@ -52,6 +53,19 @@ class CGroupSpec(C.Structure):
     _fields_ = [("num_matrices", C.c_uint32), ("cluster", C.c_void_p), ("group_off", C.c_void_p),
                 ("group_path_off", C.c_void_p), ("group_path", C.c_void_p), ("normalise", C.c_int32),
                 ("collapse_precision", C.c_double)]
+
+
+class CGibbsSpec(C.Structure):
+    _fields_ = [("num_problems", C.c_uint32), ("group_size", C.c_uint32), ("matrix", C.c_void_p), ("num_chains", C.c_void_p),
+                ("num_burn_its", C.c_void_p), ("num_gibbs_its", C.c_void_p), ("log_freq", C.c_void_p), ("num_generators", C.c_uint32),
+                ("generator_problem_off", C.c_void_p), ("generator_problem", C.c_void_p), ("generator_words", C.c_void_p)]
+
+
+class CGibbsSetsView(C.Structure):
+    _fields_ = [("num_problems", C.c_uint32), ("group_size", C.c_uint32), ("set_off", C.POINTER(C.c_uint64)),
+                ("first", C.POINTER(C.c_uint32)), ("second", C.POINTER(C.c_uint32)), ("count", C.POINTER(C.c_uint32)),
+                ("words_consumed", C.POINTER(C.c_uint64)), ("generator_state", C.POINTER(C.c_uint32)), ("rounds", C.c_uint32),
+                ("conditionals", C.c_uint64)]
 
 
 class CPairPosteriorsView(C.Structure):
@@ -271,6 +285,40 @@ class DeviceGroups:
                                                  C.c_double(divisor), C.c_void_p(out.ctypes.data)),
                "rpvg_hip_group_conditionals")
         return np.split(out, np.cumsum(sizes)[:-1]) if sizes else []
+
+    def gibbs(self, matrix, group_size: int, num_chains, num_burn_its, num_gibbs_its, log_freq, generator_problems, generator_words):
+        """rpvg_hip_group_gibbs: per problem ([sorted member tuples in order of first appearance], counts); plus the words each
+        generator gave, the state words of the generators that gave at least 624, and (rounds, conditionals)."""
+        mt = np.ascontiguousarray(matrix, dtype=np.uint32)
+        ch = np.ascontiguousarray(num_chains, dtype=np.uint32)
+        bu = np.ascontiguousarray(num_burn_its, dtype=np.uint32)
+        it = np.ascontiguousarray(num_gibbs_its, dtype=np.uint32)
+        lf = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64) for x in log_freq]) if len(log_freq) else np.zeros(0))
+        goff = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(g) for g in generator_problems])]), dtype=np.uint32)
+        gp = np.ascontiguousarray([p for g in generator_problems for p in g], dtype=np.uint32)
+        gw = np.ascontiguousarray(generator_words, dtype=np.uint32).reshape(len(generator_problems), 624)
+        spec = CGibbsSpec(len(mt), group_size, mt.ctypes.data, ch.ctypes.data, bu.ctypes.data, it.ctypes.data, lf.ctypes.data,
+                          len(generator_problems), goff.ctypes.data, gp.ctypes.data, gw.ctypes.data)
+        h = C.c_void_p()
+        _check(lib().rpvg_hip_group_gibbs(self.ctx.handle, self.handle, C.byref(spec), C.byref(h)), "rpvg_hip_group_gibbs")
+        try:
+            v = CGibbsSetsView()
+            _check(lib().rpvg_hip_gibbs_sets_get(h, C.byref(v)), "rpvg_hip_gibbs_sets_get")
+            off = np.ctypeslib.as_array(v.set_off, shape=(len(mt) + 1,)).copy()
+            total = int(off[-1])
+            first = np.ctypeslib.as_array(v.first, shape=(total,)).copy() if total else np.zeros(0, np.uint32)
+            second = np.ctypeslib.as_array(v.second, shape=(total,)).copy() if total else np.zeros(0, np.uint32)
+            count = np.ctypeslib.as_array(v.count, shape=(total,)).copy() if total else np.zeros(0, np.uint32)
+            words = np.ctypeslib.as_array(v.words_consumed, shape=(len(generator_problems),)).copy()
+            state = np.ctypeslib.as_array(v.generator_state, shape=(len(generator_problems), 624)).copy()
+            out = []
+            for i in range(len(mt)):
+                a, b = int(off[i]), int(off[i + 1])
+                sets = [(int(x),) if group_size == 1 else (int(x), int(y)) for x, y in zip(first[a:b], second[a:b])]
+                out.append((sets, [int(c) for c in count[a:b]]))
+            return out, words, state, (int(v.rounds), int(v.conditionals))
+        finally:
+            lib().rpvg_hip_gibbs_sets_free(h)
 
     def bounded_pair_posteriors(self, column_counts, min_rel_likelihood: float):
         """Per matrix: ([(first, second)...], posteriors) of the on-device branch-and-bound."""

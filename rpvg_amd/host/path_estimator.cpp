@@ -1,6 +1,7 @@
 #include "path_estimator.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <cstdio>
@@ -904,6 +905,212 @@ bool PathEstimator::nestedSubsetAbundances(SubsetEmResult * result, const Device
     return true;
 }
 
+namespace {
+
+// A seed sequence that hands out the 624 words it was given: std::mt19937::seed(sequence) copies them into the
+// generator's state and regenerates on the next call ([rand.eng.mers]) — the standard's way of putting a generator
+// where rpvg_hip_group_gibbs left it, where discard() would generate every word the chains took once more on the host
+// (40 M words per configs[4] batch: 60 ms of CPU time).
+struct GeneratorStateWords {
+
+    typedef uint32_t result_type;
+
+    const uint32_t * words;
+
+    explicit GeneratorStateWords(const uint32_t * words_in) : words(words_in) {}
+
+    template <typename Iterator>
+    void generate(Iterator first, Iterator last) {
+
+        for (size_t i = 0; first != last; ++first, ++i) {
+
+            *first = words[i];
+        }
+    }
+};
+
+// The sampler of src/path_estimator.cpp:475-589 in one device call: the generators' next 624 outputs go in (their
+// untempered values are the generators' states), the sampled sets come out in the reference's order, and every generator
+// is moved past the words its chains took.  False when the device call does not take the input (the distributions of the
+// batch outgrow the memory set aside for them): the host-driven sampler below does.
+bool estimatePathGroupPosteriorsGibbsOnDevice(std::vector<GroupPosteriors> * group_posteriors, const std::shared_ptr<HipEngine> & engine, const rpvg_hip_groups * groups, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const std::vector<std::mt19937 *> & rngs, std::vector<double> (*log_frequencies)(const std::vector<uint32_t> &)) {
+
+    ScopedPhase phase("gibbs: device sampler");
+
+    const size_t num_problems = problems.size();
+
+    // problems by generator, in the order the reference's loop reaches them
+    std::vector<std::mt19937 *> generators;
+    std::vector<uint32_t> generator_of_problem(num_problems);
+    std::unordered_map<std::mt19937 *, uint32_t> generator_index;
+
+    for (size_t i = 0; i < num_problems; ++i) {
+
+        auto generator_index_it = generator_index.emplace(rngs.at(i), generators.size());
+
+        if (generator_index_it.second) {
+
+            generators.emplace_back(rngs.at(i));
+        }
+
+        generator_of_problem[i] = generator_index_it.first->second;
+    }
+
+    std::vector<uint32_t> generator_problem_off(generators.size() + 1, 0);
+
+    for (size_t i = 0; i < num_problems; ++i) {
+
+        generator_problem_off[generator_of_problem[i] + 1]++;
+    }
+
+    std::partial_sum(generator_problem_off.begin(), generator_problem_off.end(), generator_problem_off.begin());
+
+    std::vector<uint32_t> generator_problem(num_problems);
+    {
+        std::vector<uint32_t> cursor(generator_problem_off.begin(), generator_problem_off.end() - 1);
+
+        for (size_t i = 0; i < num_problems; ++i) {
+
+            generator_problem[cursor[generator_of_problem[i]]++] = i;
+        }
+    }
+
+    std::vector<uint32_t> matrix(num_problems);
+    std::vector<uint32_t> num_chains(num_problems);
+    std::vector<uint32_t> num_burn_its(num_problems);
+    std::vector<uint32_t> num_gibbs_its(num_problems);
+    std::vector<uint64_t> column_off(num_problems + 1, 0);
+
+    for (size_t i = 0; i < num_problems; ++i) {
+
+        column_off[i + 1] = column_off[i] + problems[i].numColumns();
+    }
+
+    std::vector<double> log_freqs(column_off.back());
+    std::vector<uint32_t> generator_words(generators.size() * std::mt19937::state_size);
+
+    ScopedPhase words_phase("gibbs: chain lengths, log frequencies, generator words");
+
+    #pragma omp parallel num_threads(hostThreads())
+    {
+        #pragma omp for schedule(dynamic, 16) nowait
+        for (size_t i = 0; i < num_problems; ++i) {
+
+            const uint32_t num_columns = problems[i].numColumns();
+
+            matrix[i] = i;
+
+            // src/path_estimator.cpp:501-503
+            num_chains[i] = min_gibbs_chains + std::round(gibbs_chain_scaling * group_size * num_columns);
+            num_burn_its[i] = min_burn_it + std::round(burn_it_scaling * group_size * num_columns);
+            num_gibbs_its[i] = min_gibbs_it + std::round(gibbs_it_scaling * group_size * num_columns);
+
+            const auto problem_log_freqs = log_frequencies(problems[i].column_counts);
+            std::copy(problem_log_freqs.begin(), problem_log_freqs.end(), log_freqs.begin() + column_off[i]);
+        }
+
+        #pragma omp for schedule(dynamic, 16)
+        for (size_t g = 0; g < generators.size(); ++g) {
+
+            std::mt19937 ahead = *generators[g];
+
+            for (size_t w = 0; w < std::mt19937::state_size; ++w) {
+
+                generator_words[g * std::mt19937::state_size + w] = ahead();
+            }
+        }
+    }
+
+    words_phase.stop();
+
+    rpvg_hip_gibbs_spec spec;
+    spec.num_problems = num_problems;
+    spec.group_size = group_size;
+    spec.matrix = matrix.data();
+    spec.num_chains = num_chains.data();
+    spec.num_burn_its = num_burn_its.data();
+    spec.num_gibbs_its = num_gibbs_its.data();
+    spec.log_freq = log_freqs.data();
+    spec.num_generators = generators.size();
+    spec.generator_problem_off = generator_problem_off.data();
+    spec.generator_problem = generator_problem.data();
+    spec.generator_words = generator_words.data();
+
+    ScopedPhase call_phase("gibbs: rpvg_hip_group_gibbs");
+
+    rpvg_hip_gibbs_sets * sets = nullptr;
+    const int status = rpvg_hip_group_gibbs(engine->ctx(), groups, &spec, &sets);
+
+    call_phase.stop();
+
+    if (status == RPVG_HIP_ERR_UNSUPPORTED) {
+
+        return false;
+    }
+
+    HipEngine::check(status, "rpvg_hip_group_gibbs");
+    std::shared_ptr<rpvg_hip_gibbs_sets> sets_holder(sets, rpvg_hip_gibbs_sets_free);
+
+    rpvg_hip_gibbs_sets_view view;
+    HipEngine::check(rpvg_hip_gibbs_sets_get(sets, &view), "rpvg_hip_gibbs_sets_get");
+
+    if (PhaseTrace::enabled()) {
+
+        std::fprintf(stderr, "[rpvg_amd trace] gibbs on the device: %u rounds, %llu conditionals, %llu sets\n", view.rounds, static_cast<unsigned long long>(view.conditionals), static_cast<unsigned long long>(view.set_off[num_problems]));
+    }
+
+    ScopedPhase results_phase("gibbs: generators moved on, posteriors");
+
+    #pragma omp parallel num_threads(hostThreads())
+    {
+        // the generators end where the reference's sampler leaves them
+        #pragma omp for schedule(dynamic, 16) nowait
+        for (size_t g = 0; g < generators.size(); ++g) {
+
+            if (view.words_consumed[g] >= std::mt19937::state_size) {
+
+                GeneratorStateWords state_words(view.generator_state + g * std::mt19937::state_size);
+                generators[g]->seed(state_words);
+
+            } else {
+
+                generators[g]->discard(view.words_consumed[g]);
+            }
+        }
+
+        #pragma omp for schedule(dynamic, 16)
+        for (size_t i = 0; i < num_problems; ++i) {
+
+            auto & result = group_posteriors->at(i);
+
+            const uint64_t first_set = view.set_off[i];
+            const uint64_t num_sets = view.set_off[i + 1] - first_set;
+            const double num_samples = static_cast<double>(num_chains[i] * num_gibbs_its[i]);
+
+            result.group_size = group_size;
+            result.members.reserve(num_sets * group_size);
+            result.posteriors.reserve(num_sets);
+
+            for (uint64_t s = first_set; s < first_set + num_sets; ++s) {
+
+                result.members.emplace_back(view.first[s]);
+
+                if (group_size == 2) {
+
+                    result.members.emplace_back(view.second[s]);
+                }
+
+                // src/path_estimator.cpp:583-586
+                result.posteriors.emplace_back(view.count[s] / num_samples);
+            }
+        }
+    }
+
+    return true;
+}
+
+}
+
 void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const bool normalise, const std::vector<std::mt19937 *> & rngs) const {
 
     assert(group_size > 0);
@@ -922,6 +1129,14 @@ void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors
     }
 
     const GroupMatrices matrices(engine, cluster_batch, problems, normalise, prob_precision);
+
+    // group sizes 1 and 2: the chains themselves run on the device (rpvg_hip_group_gibbs), draw for draw
+    static const bool host_sampler = std::getenv("RPVG_AMD_HOST_GIBBS") != nullptr;
+
+    if (group_size <= 2 && !host_sampler && estimatePathGroupPosteriorsGibbsOnDevice(group_posteriors, engine, matrices.handle(), problems, group_size, rngs, &PathEstimator::calcPathLogFrequences)) {
+
+        return;
+    }
 
     std::vector<GibbsSampler> samplers(problems.size());
 

@@ -169,3 +169,17 @@ def test_source_id_set_behaves_like_the_set_it_replaces():
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(root, "rpvg_amd", "host"),
                            os.path.join(root, "tests", "cpp", "source_id_set.cpp"), "-o", binary])
     assert subprocess.run([binary], capture_output=True, text=True, check=True).stdout.strip() == "ok"
+
+
+def test_restated_random_streams_equal_libstdcxx():
+    """rpvg_amd/csrc/gibbs_streams.hpp (mt19937 from its next 624 outputs, Lemire's uniform_int_distribution, the
+    two-word generate_canonical, lower_bound over a discrete_distribution's partial sums) against libstdc++ itself — what
+    the device sampler of --use-hap-gibbs rests on (src/path_estimator.cpp:491,509,555-556)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "tests", "cpp", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    binary = os.path.join(out_dir, "gibbs_streams_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(root, "rpvg_amd", "csrc"),
+                           os.path.join(root, "tests", "cpp", "gibbs_streams_check.cpp"), "-o", binary])
+    assert subprocess.run([binary], capture_output=True, text=True, check=True).stdout.strip() == "ok"

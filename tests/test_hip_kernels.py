@@ -670,3 +670,140 @@ def test_em_problem_sets_in_two_passes_when_the_storage_bound_is_over_budget(hip
     assert small_cases.rel_close(one_pass[1], two_pass[1], rel=1e-12, floor=1e-12)
     for a, b in zip(one_pass[0], two_pass[0]):
         assert small_cases.rel_close(a, b, rel=1e-12, floor=1e-12)  # (LDS atomics: the last bits are run-dependent)
+
+
+# ---- the Gibbs sampler of the group posteriors on the device (rpvg_hip_group_gibbs) ---------------------------------
+def _mt19937_words(seed, skip, n):
+    """Outputs skip .. skip + n of std::mt19937(seed) (numpy's legacy seeding is the reference implementation's init_genrand)."""
+    bg = np.random.MT19937()
+    bg._legacy_seeding(seed)
+    return [int(w) for w in bg.random_raw(skip + n)[skip:]]
+
+
+def _gibbs_model(G, group_size, conditional, words):
+    """estimatePathGroupPosteriorsGibbs (src/path_estimator.cpp:475-589) in plain Python over a list of generator outputs,
+    with libstdc++'s distributions restated (GCC 11: bits/uniform_int_dist.h:246-270, bits/random.tcc:2656-2713,3348-3380).
+    conditional(others) -> log-likelihood + log frequency of every candidate column.  Returns (sets in order of first
+    appearance, counts, words taken)."""
+    import bisect
+    import math
+    pos = 0
+
+    def nxt():
+        nonlocal pos
+        pos += 1
+        return words[pos - 1]
+
+    def uniform_below(rng):
+        product = nxt() * rng
+        low = product & 0xffffffff
+        if low < rng:
+            threshold = ((1 << 32) - rng) % rng
+            while low < threshold:
+                product = nxt() * rng
+                low = product & 0xffffffff
+        return product >> 32
+
+    def add_log(a, b):
+        return a + math.log1p(math.exp(b - a)) if a > b else b + math.log1p(math.exp(a - b))
+
+    chains = 10 + int(math.floor(0.01 * group_size * G + 0.5))
+    burn = 50 + int(math.floor(0.025 * group_size * G + 0.5))
+    its = 100 + int(math.floor(0.05 * group_size * G + 0.5))
+    memo, order, counts = {}, [], {}
+    for _ in range(chains):
+        cur = [uniform_below(G) for _ in range(group_size)]
+        for it in range(burn + its):
+            for slot in range(group_size):
+                others = tuple(cur[k] for k in range(group_size) if k != slot)
+                if others not in memo:
+                    ll = conditional(others)
+                    total = -1.7976931348623157e308
+                    for v in ll:
+                        total = add_log(total, v)
+                    p = [math.exp(v - total) for v in ll]
+                    s = 0.0
+                    for v in p:
+                        s += v
+                    cp, run = [], 0.0
+                    for v in p:
+                        run += v / s
+                        cp.append(run)
+                    cp[-1] = 1.0
+                    memo[others] = cp
+                if G >= 2:
+                    first, second = nxt(), nxt()
+                    u = (float(first) + float(second) * 4294967296.0) / 18446744073709551616.0
+                    if u >= 1.0:
+                        u = math.nextafter(1.0, 0.0)
+                    cur[slot] = bisect.bisect_left(memo[others], u)
+                else:
+                    cur[slot] = 0  # a distribution of fewer than two weights draws nothing
+            if it >= burn:
+                key = tuple(sorted(cur))
+                if key not in counts:
+                    order.append(key)
+                    counts[key] = 0
+                counts[key] += 1
+    return order, [counts[k] for k in order], pos, (chains, burn, its)
+
+
+def _mt_temper(y):
+    y ^= y >> 11
+    y ^= (y << 7) & 0x9d2c5680
+    y ^= (y << 15) & 0xefc60000
+    y ^= y >> 18
+    return y & 0xffffffff
+
+
+@pytest.mark.parametrize("group_size", [1, 2])
+def test_device_gibbs_sampler_follows_a_python_model_draw_for_draw(hip_ctx, group_size):
+    """rpvg_hip_group_gibbs against a sequential Python model of the reference's sampler that draws from the same
+    std::mt19937 words: same sets in the same order with the same counts, the same number of words taken from every
+    generator (one generator serves two problems, one matrix has a single column), and state words that continue the
+    stream.  The model takes its log-likelihoods from rpvg_hip_group_conditionals: this test is about the chains."""
+    import math
+    clusters = small_cases.make_batch_clusters(811, n_clusters=6, with_empty=False)
+    clusters.append(small_cases.make_batch_clusters(812, n_clusters=1, with_empty=False)[0])
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    mats = list(range(len(clusters)))
+    groups = [[[p] for p in range(len(cl["paths"]))] for cl in clusters]
+    groups[-1] = [list(range(len(clusters[-1]["paths"])))]  # one column: every path of the cluster
+    num_cols = [len(g) for g in groups]
+    dg = hip_ctx.groups(dev, mats, groups, False)
+    rng = np.random.default_rng(5)
+    log_freq = [np.log(rng.integers(1, 5, size=G) / 7.0) for G in num_cols]
+    generator_problems = [[0], [1, 2], [3], [4], [5], [6]]
+    seeds = [(11, 0), (12, 100), (13, 623), (14, 624), (15, 7), (16, 1000)]
+
+    def conditional_of(m):
+        def conditional(others):
+            got = dg.conditionals([m], [list(others)], group_size, float(group_size), num_cols)[0]
+            return [float(x) + float(y) for x, y in zip(got, log_freq[m])]
+        return conditional
+
+    want, want_words, streams, shapes = {}, [], [], {}
+    for problems, (seed, skip) in zip(generator_problems, seeds):
+        words = _mt19937_words(seed, skip, 200000)
+        taken = 0
+        for m in problems:
+            order, counts, used, shape = _gibbs_model(num_cols[m], group_size, conditional_of(m), words[taken:])
+            want[m] = (order, counts)
+            shapes[m] = shape
+            taken += used
+        want_words.append(taken)
+        streams.append(words)
+    got, words_consumed, state, (rounds, conditionals) = dg.gibbs(
+        mats, group_size, [shapes[m][0] for m in mats], [shapes[m][1] for m in mats], [shapes[m][2] for m in mats], log_freq,
+        generator_problems, [s[:624] for s in streams])
+    assert [int(w) for w in words_consumed] == want_words
+    for m in mats:
+        assert got[m][0] == want[m][0], f"sets of problem {m}"
+        assert got[m][1] == want[m][1], f"counts of problem {m}"
+        assert sum(got[m][1]) == shapes[m][0] * shapes[m][2]
+    assert got[6][0] == [(0,) * group_size]
+    assert rounds >= 1 and conditionals >= sum(1 for G in num_cols if G >= 2)  # (one column: nothing to evaluate)
+    for g, taken in enumerate(want_words):
+        if taken >= 624:
+            assert [_mt_temper(int(x)) for x in state[g]] == streams[g][taken - 624:taken]
