@@ -446,11 +446,15 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         search.update(valu_instructions_per_eval=pmc_search["valu_instructions_per_eval"], valu_busy=pmc_search["valu_busy"],
                       pmc_source=pmc_search["source"], pmc_commit=pmc_search.get("commit"))
     if s5:
-        # no EM on this path: the device work is the FP64 log-likelihood contraction of the Gibbs conditionals, the rest of a
-        # step is the host's sampler state machines (the reference's mt19937 / discrete_distribution streams, draw for draw)
-        search["kernel"] = "groupConditionalKernel"
+        # no EM on this path: the chains of the sampler run on the device (rpvg_hip_group_gibbs, round 3: mt19937 and libstdc++'s
+        # distributions restated, draw for draw); the FP64 work is the log-likelihood contraction of the conditionals they ask for
+        search["kernel"] = "gibbsConditionalKernel"
+        search["note"] = ("device time = HIP-event spans of gibbsConditionalKernel (one launch per round of the sampler: up to four requests of a problem x "
+                          "four candidate columns per wave) on the two host lanes' streams; the chains (gibbsAdvanceKernel), the distributions and the "
+                          "rest of a step are in ms_per_step only")
         line["roofline"] = search
-        line["host_sampler_ms_per_step"] = ms_per_step - (stats["loglik_ms"] + stats["build_ms"] + stats["h2d_ms"]) / args.steps
+        line["sampler"] = "device: rpvg_hip_group_gibbs (RPVG_AMD_HOST_GIBBS=1: host-driven lock-step sampler, round 2)"
+        line["ms_per_step_outside_conditionals"] = ms_per_step - (stats["loglik_ms"] + stats["build_ms"] + stats["h2d_ms"]) / args.steps
     else:
         search["kernel"] = "pairTileKernel + resolveTableKernel"
         line["roofline_search"] = search

@@ -49,7 +49,7 @@ constexpr uint32_t kErrStream = 1, kErrDistributions = 2;
 constexpr uint32_t kRankInLds = 2048;  // sets of a problem ordered by first appearance inside the collect kernel up to this many
 
 struct GibbsHeader {
-    unsigned long long num_items;  // work items of the current round's conditionals (up to 4 requests x 4 candidate columns each)
+    unsigned long long num_items;  // turns of the current round's conditionals (itemsPerTurn work items of up to 4 requests x 4 candidate columns)
     unsigned long long used;       // doubles of distribution storage handed out
     unsigned long long total_sets;
     double evals;                  // rows x columns over all requests
@@ -327,10 +327,16 @@ __global__ __launch_bounds__(256) void gibbsAdvanceKernel(const uint32_t num_cha
 // One workgroup: prefix sums over the problems with new requests — work items (up to four requests x four candidate
 // columns each), doubles of storage, requests — then the requests' own records.
 struct ActiveEntry {
-    unsigned long long item_off;  // work items before this problem's
+    unsigned long long item_off;  // turns of work before this problem's
     unsigned long long dist_off;  // storage of its first new request
     uint32_t problem, first, count, req_off;  // new requests [first, first + count) of the problem; position in the round's list
 };
+
+// A wave's turn = up to this many consecutive work items of ONE problem: finding the problem of an item is a bisection of
+// eleven dependent loads for the 2 500 problems of a lane's first round, and the matrix's description a few more — as long as
+// the rows of a small matrix take.  Matrices with many rows get one item per turn (eight of them in one wave were the
+// round's tail: 4.0 against 3.2 ms, and 1.9 against 0.6 ms for the later rounds' few items).
+__device__ __forceinline__ uint32_t itemsPerTurn(const uint64_t rows) { return rows <= 256 ? 8u : rows <= 512 ? 4u : rows <= 1024 ? 2u : 1u; }
 
 __global__ __launch_bounds__(1024) void gibbsRequestOffsetsKernel(const GibbsProblems pr, const uint32_t * __restrict__ mat_cols,
                                                                   const uint64_t * __restrict__ mat_rows, GibbsHeader * hdr,
@@ -360,7 +366,9 @@ __global__ __launch_bounds__(1024) void gibbsRequestOffsetsKernel(const GibbsPro
             first = prob_done[p];
             reqs = prob_count[p] - first;
             cols = reqs * distributionDoubles(G);
-            items = ((reqs + 3) / 4) * ((G + 3) / 4);
+            const unsigned long long work_items = ((reqs + 3) / 4) * ((G + 3) / 4);
+            const uint32_t per_turn = itemsPerTurn(mat_rows[m]);
+            items = (work_items + per_turn - 1) / per_turn;
             evals += static_cast<double>(mat_rows[m]) * static_cast<double>(reqs * G);
         }
         unsigned long long scan_items = items, scan_cols = cols, scan_reqs = reqs;
@@ -443,27 +451,87 @@ __device__ __forceinline__ void conditionalItem(const LogTableEntry * lt, const 
     const double * cand[kCand];
 #pragma unroll
     for (int c = 0; c < kCand; ++c) cand[c] = M + static_cast<uint64_t>(min(k0 + c, G - 1)) * R;
-    double acc[OTHERS * kCand];
-    LogProduct prod[OTHERS * kCand];
+    constexpr int kOut = OTHERS * kCand;
+    double acc[kOut];
+    LogProduct prod[kOut];
 #pragma unroll
-    for (int t = 0; t < OTHERS * kCand; ++t) acc[t] = 0.0;
-    auto x = [&](const uint64_t i, double (&xs)[OTHERS * kCand]) {
-        double half[kCand];
+    for (int t = 0; t < kOut; ++t) acc[t] = 0.0;
+    struct RowValues {
+        double noise, other[OTHERS], cand[kCand];
+    };
+    auto load = [&](const uint64_t i, RowValues & v) {
+        v.noise = nz[i];
 #pragma unroll
-        for (int c = 0; c < kCand; ++c) half[c] = cand[c][i] / divisor;
-        const double noise = nz[i];
+        for (int o = 0; o < OTHERS; ++o) v.other[o] = (GS == 2) ? other[o][i] : 0.0;
+#pragma unroll
+        for (int c = 0; c < kCand; ++c) v.cand[c] = cand[c][i];
+    };
+    // the log arguments of a row, in the reference's order of additions: (noise + other / g) + candidate / g
+    auto arguments = [&](const RowValues & v, double (&xs)[kOut]) {
 #pragma unroll
         for (int o = 0; o < OTHERS; ++o) {
-            double base = noise;
-            if (GS == 2) base += other[o][i] / divisor;
+            double base = v.noise;
+            if (GS == 2) base += v.other[o] / divisor;
 #pragma unroll
-            for (int c = 0; c < kCand; ++c) xs[o * kCand + c] = base + half[c];
+            for (int c = 0; c < kCand; ++c) xs[o * kCand + c] = base + v.cand[c] / divisor;
         }
     };
-    sumCountLogsMulti<OTHERS * kCand, 64, uint64_t>(lt, cnt, x, 0, fast_end, mid_end, R, lane, prod, acc);
+    // rows of read count 1 (LogProduct, common.hpp): a lane multiplies kFoldFactors factors between folds.  Two rows per
+    // step, their eighteen loads issued together: with 180 registers two waves share a SIMD, and a wave that waits for the
+    // nine loads of one row before it asks for the next is all latency (1.0 T evaluations/s: 8 waves per CU x 1 024
+    // evaluations per 2 us)
+    for (uint64_t seg = 0; seg < fast_end; seg += 64 * kFoldFactors) {
+        const uint64_t seg_end = (fast_end - seg) < 64 * kFoldFactors ? fast_end : seg + 64 * kFoldFactors;
+        uint64_t i = seg + lane;
+        for (; i + 64 < seg_end; i += 128) {
+            RowValues a, b;
+            load(i, a);
+            load(i + 64, b);
+            double xs[kOut];
+            arguments(a, xs);
+#pragma unroll
+            for (int t = 0; t < kOut; ++t) prod[t].mul(xs[t]);
+            arguments(b, xs);
+#pragma unroll
+            for (int t = 0; t < kOut; ++t) prod[t].mul(xs[t]);
+        }
+        if (i < seg_end) {
+            RowValues a;
+            load(i, a);
+            double xs[kOut];
+            arguments(a, xs);
+#pragma unroll
+            for (int t = 0; t < kOut; ++t) prod[t].mul(xs[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < kOut; ++t) prod[t].fold();
+    }
+    // read counts 2 .. kMidMaxCount: the factor that many times; the rest: a logarithm per row
+    for (uint64_t i = fast_end + lane; i < mid_end; i += 64) {
+        RowValues a;
+        load(i, a);
+        double xs[kOut];
+        arguments(a, xs);
+        const int c = static_cast<int>(cnt[i]);
+        for (int k = 0; k < c; ++k) {
+#pragma unroll
+            for (int t = 0; t < kOut; ++t) prod[t].mul(xs[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < kOut; ++t) prod[t].fold();
+    }
+    for (uint64_t i = mid_end + lane; i < R; i += 64) {
+        RowValues a;
+        load(i, a);
+        double xs[kOut];
+        arguments(a, xs);
+        const double c = cnt[i];
+#pragma unroll
+        for (int t = 0; t < kOut; ++t) acc[t] = fma(c, logPositive(xs[t], lt), acc[t]);
+    }
     if (mid_end) {
 #pragma unroll
-        for (int t = 0; t < OTHERS * kCand; ++t) acc[t] += prod[t].value(lt);
+        for (int t = 0; t < kOut; ++t) acc[t] += prod[t].value(lt);
     }
 #pragma unroll
     for (int o = 0; o < OTHERS; ++o) {
@@ -491,39 +559,47 @@ __global__ __launch_bounds__(256) void gibbsConditionalKernel(const GibbsProblem
     const int lane = threadIdx.x & 63;
     const uint32_t num_active = hdr->cur_active;
     const unsigned long long num_waves = static_cast<unsigned long long>(gridDim.x) * 4;
-    for (unsigned long long item = static_cast<unsigned long long>(blockIdx.x) * 4 + (threadIdx.x >> 6); item < num_items; item += num_waves) {
-        uint32_t lo = 0, hi = num_active - 1;  // last entry with item_off <= item
+    for (unsigned long long turn = static_cast<unsigned long long>(blockIdx.x) * 4 + (threadIdx.x >> 6); turn < num_items; turn += num_waves) {
+        uint32_t lo = 0, hi = num_active - 1;  // last entry with item_off <= turn
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo + 1) >> 1);
-            if (entries[mid].item_off <= item) lo = mid; else hi = mid - 1;
+            if (entries[mid].item_off <= turn) lo = mid; else hi = mid - 1;
         }
         const ActiveEntry e = entries[lo];
         const uint32_t p = e.problem;
         const uint32_t m = pr.matrix[p];
         const uint64_t R = mat_rows[m];
         const uint32_t G = mat_cols[m];
-        const uint32_t cand_groups = (G + 3) / 4;
-        const uint32_t local = static_cast<uint32_t>(item - e.item_off);
-        const uint32_t j0 = (local / cand_groups) * 4;  // first request of the item among the problem's new ones
-        const uint32_t k0 = (local % cand_groups) * 4;
-        const uint32_t num_others = min(4u, e.count - j0);
         const double * M = values + mat_val_off[m];
         const double * cnt = row_count + mat_row_off[m];
         const double * nz = row_noise + mat_row_off[m];
         const uint64_t col0 = pr.col_off[p];
-        uint32_t other_col[4];
-        double * out[4];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const uint32_t j = j0 + min(static_cast<uint32_t>(o), num_others - 1);
-            other_col[o] = (GS == 2) ? req_other[col0 + e.first + j] : 0;
-            out[o] = dist + e.dist_off + static_cast<unsigned long long>(j) * distributionDoubles(G);
-        }
         const double * lf = pr.log_freq + col0;
-        if (num_others == 1) {
-            conditionalItem<GS, 1>(lt, lane, M, R, G, cnt, nz, mat_fast[m], mat_mid[m], other_col, k0, 1, lf, out);
-        } else {
-            conditionalItem<GS, 4>(lt, lane, M, R, G, cnt, nz, mat_fast[m], mat_mid[m], other_col, k0, num_others, lf, out);
+        const uint64_t fast_end = mat_fast[m], mid_end = mat_mid[m];
+        // consecutive items = the same four candidate columns under the next four requests (the matrix's columns are
+        // read about once per round, the requests' own columns are a dozen and stay in L2)
+        const uint32_t other_groups = (e.count + 3) / 4;
+        const uint32_t work_items = other_groups * ((G + 3) / 4);
+        const uint32_t per_turn = itemsPerTurn(R);
+        const uint32_t local_begin = static_cast<uint32_t>(turn - e.item_off) * per_turn;
+        const uint32_t local_end = min(work_items, local_begin + per_turn);
+        for (uint32_t local = local_begin; local < local_end; ++local) {
+            const uint32_t j0 = (local % other_groups) * 4;  // first request of the item among the problem's new ones
+            const uint32_t k0 = (local / other_groups) * 4;
+            const uint32_t num_others = min(4u, e.count - j0);
+            uint32_t other_col[4];
+            double * out[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const uint32_t j = j0 + min(static_cast<uint32_t>(o), num_others - 1);
+                other_col[o] = (GS == 2) ? req_other[col0 + e.first + j] : 0;
+                out[o] = dist + e.dist_off + static_cast<unsigned long long>(j) * distributionDoubles(G);
+            }
+            if (num_others == 1) {
+                conditionalItem<GS, 1>(lt, lane, M, R, G, cnt, nz, fast_end, mid_end, other_col, k0, 1, lf, out);
+            } else {
+                conditionalItem<GS, 4>(lt, lane, M, R, G, cnt, nz, fast_end, mid_end, other_col, k0, num_others, lf, out);
+            }
         }
     }
 }
