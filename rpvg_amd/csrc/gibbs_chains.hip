@@ -46,6 +46,7 @@ constexpr uint32_t kPending = 0xffffffffu;
 constexpr uint32_t kChainDone = 0x80000000u;
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr uint32_t kErrStream = 1, kErrDistributions = 2;
+constexpr uint32_t kWordWindow = 16;  // generator words a chain keeps in LDS
 constexpr uint32_t kRankInLds = 2048;  // sets of a problem ordered by first appearance inside the collect kernel up to this many
 
 struct GibbsHeader {
@@ -192,28 +193,34 @@ __global__ __launch_bounds__(256) void gibbsStreamKernel(const uint32_t * __rest
 // What a chain does most of the time is draw the mode of one of two distributions again: the distribution of each slot
 // (its storage, and the partial sums either side of its largest weight) stays in registers while the other member does not
 // change, the generator's words are fetched ahead of the draw, and a run of equal samples is counted once.
-// Storage of one distribution: the G partial sums, then a guide of G column indices — guide[b] is (about) the first column
-// whose partial sum reaches b / G, so a draw u starts at guide[floor(u G)] and settles with a step or two instead of the
-// log2(G) dependent loads of a bisection (the chains of a flat posterior draw off the mode most of the time).
-__host__ __device__ inline unsigned long long distributionDoubles(const unsigned long long columns) { return columns + (columns + 1) / 2; }
+// Storage of one distribution: the G partial sums, then G bucket records — bucket b covers the draws u in [b / G, (b + 1) / G)
+// and holds the first column whose partial sum reaches b / G with the partial sums either side of it: a draw that falls
+// between them is settled by that one record, any other walks on from there (a step or two) instead of the log2(G) dependent
+// loads of a bisection.
+struct DrawBucket {
+    double below, upto;  // partial sums before and including the column
+    unsigned long long column;
+};
+__host__ __device__ inline unsigned long long distributionDoubles(const unsigned long long columns) { return 4 * columns; }
 
-struct RequestInfo {  // 32 bytes, written when the distribution is complete
+struct RequestInfo {  // 32 bytes per (problem, other member): the memo of the conditionals and what a draw needs first
     double mode_below, mode_upto;  // partial sums before and including the largest weight: the mode is drawn iff below < u <= upto
     unsigned long long dist_off;
     uint32_t mode;
-    uint32_t problem;
+    uint32_t state;  // 0: nobody asked; kPending: being numbered; k + 1: request k of the problem
 };
 
 template <int GS>
 __global__ __launch_bounds__(256) void gibbsAdvanceKernel(const uint32_t num_chains, const uint32_t round, const GibbsProblems pr,
                                                           const uint32_t * __restrict__ mat_cols, const GibbsChains ch,
-                                                          const uint32_t * __restrict__ stream, uint32_t * memo, uint32_t * prob_count,
+                                                          const uint32_t * __restrict__ stream, RequestInfo * records, uint32_t * prob_count,
                                                           const uint32_t * __restrict__ prob_done, GibbsHeader * hdr, uint32_t * remaining,
-                                                          uint32_t * active_problem, uint32_t * req_other, const RequestInfo * __restrict__ req_info,
+                                                          uint32_t * active_problem, uint32_t * req_other,
                                                           const double * __restrict__ dist, unsigned long long * tab_key, uint32_t * tab_count,
-                                                          uint32_t * tab_first) {
+                                                          uint32_t * tab_first, unsigned long long * debug_counts) {
     const uint32_t ci = blockIdx.x * 256 + threadIdx.x;
     if (ci >= num_chains) return;
+    uint32_t n_draws = 0, n_lookups = 0, n_off_mode = 0, n_walked = 0, n_keys = 0;  // RPVG_HIP_GIBBS_DEBUG
     uint32_t flag = ch.flag[ci];
     if (flag & kChainDone) return;
     const uint32_t p = ch.problem[ci];
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256) void gibbsAdvanceKernel(const uint32_t num_cha
     uint32_t iter = ch.iter[ci];
     uint32_t slot = flag & 1u;
     const uint64_t col0 = pr.col_off[p];
-    uint32_t * memo_p = memo + col0;
+    RequestInfo * records_p = records + col0;
     const uint64_t tab = pr.tab_off[p];
     const uint64_t tab_mask = pr.tab_off[p + 1] - tab - 1;
     const uint32_t chain_in_problem = ci - static_cast<uint32_t>(pr.chain_off[p]);
@@ -238,49 +245,64 @@ __global__ __launch_bounds__(256) void gibbsAdvanceKernel(const uint32_t num_cha
     uint32_t run_length = 0;
     uint64_t run_at = 0;
     bool waiting = false;
-    uint32_t w0 = 0, w1 = 0;
-    if (G >= 2) {
-        w0 = stream[pos];
-        w1 = stream[pos + 1];
-    }
+    // The generator's words come through a window of sixteen per thread in LDS (word j of thread t at [j][t]): one trip to
+    // memory per eight draws — the sixteen loads of a refill are in flight together — where a load per draw was a trip to L2
+    // per draw (a wave's 64 chains read 64 different lines: the lines of 16 waves do not stay in the CU's 32 KB).
+    __shared__ uint32_t word_window[kWordWindow * 256];
+    uint32_t * window = word_window + threadIdx.x;
+    unsigned long long window_pos = ~0ull;  // stream position of the window's first word
     while (true) {
         uint32_t drawn = 0;
         if (G >= 2) {
             const uint32_t other = (GS == 2) ? (slot == 0 ? cur1 : cur0) : 0;
             const uint32_t s = (GS == 2) ? slot : 0;
             if (held_other[s] != other) {
-                const uint32_t m = __atomic_load_n(memo_p + other, __ATOMIC_RELAXED);
+                const RequestInfo record = records_p[other];  // (fields behind a state below `done` were written by earlier launches)
+                const uint32_t m = record.state;
                 if (m == 0) {
-                    if (atomicCAS(memo_p + other, 0u, kPending) == 0u) {
+                    if (atomicCAS(&records_p[other].state, 0u, kPending) == 0u) {
                         const uint32_t k = atomicAdd(prob_count + p, 1u);
                         req_other[col0 + k] = other;
-                        atomicExch(memo_p + other, static_cast<uint32_t>(col0 + k) + 1);
+                        atomicExch(&records_p[other].state, k + 1);
                         if (k == done) active_problem[atomicAdd(&hdr->num_active, 1u)] = p;  // the problem's first request of this round
                     }
                     waiting = true;
                     break;
                 }
-                if (m == kPending || (m - 1) - static_cast<uint32_t>(col0) >= done) {
+                if (m == kPending || m - 1 >= done) {
                     waiting = true;
                     break;
                 }
-                held[s] = req_info[m - 1];
+                held[s] = record;
                 held_other[s] = other;
+                ++n_lookups;
             }
-            const double u = rpvg_streams::canonicalFromWords(w0, w1);
+            ++n_draws;
+            if (pos - window_pos > kWordWindow - 2) {  // (also the first draw: window_pos is all ones)
+                uint32_t fetched[kWordWindow];
+#pragma unroll
+                for (uint32_t j = 0; j < kWordWindow; ++j) fetched[j] = stream[pos + j];  // (past a slice: the next chain's words, or the slack behind the last)
+#pragma unroll
+                for (uint32_t j = 0; j < kWordWindow; ++j) window[j * 256] = fetched[j];
+                window_pos = pos;
+            }
+            const uint32_t at = static_cast<uint32_t>(pos - window_pos);
+            const double u = rpvg_streams::canonicalFromWords(window[at * 256], window[(at + 1) * 256]);
             pos += 2;
-            w0 = stream[pos];  // the next draw's words (a chain's slice is followed by the next chain's, or by the block's slack)
-            w1 = stream[pos + 1];
             if (held[s].mode_below < u && u <= held[s].mode_upto) {
                 drawn = held[s].mode;
             } else {
-                // std::lower_bound over the partial sums, from the guide's column: back while the column before reaches u
-                // too, on while this one does not (the last partial sum is 1 > u)
+                // std::lower_bound over the partial sums: the bucket's column if u lies between its partial sums, else from
+                // there back while the column before reaches u too, on while this one does not (the last partial sum is 1 > u)
                 const double * cp = dist + held[s].dist_off;
-                const uint32_t * guide = reinterpret_cast<const uint32_t *>(cp + G);
-                uint32_t k = guide[min(static_cast<uint32_t>(u * static_cast<double>(G)), G - 1)];
-                while (k > 0 && cp[k - 1] >= u) --k;
-                while (cp[k] < u) ++k;
+                const DrawBucket bucket = reinterpret_cast<const DrawBucket *>(cp + G)[min(static_cast<uint32_t>(u * static_cast<double>(G)), G - 1)];
+                uint32_t k = static_cast<uint32_t>(bucket.column);
+                ++n_off_mode;
+                if (!(bucket.below < u && u <= bucket.upto)) {
+                    ++n_walked;
+                    while (k > 0 && cp[k - 1] >= u) --k;
+                    while (cp[k] < u) ++k;
+                }
                 drawn = k;
             }
         }
@@ -305,6 +327,7 @@ __global__ __launch_bounds__(256) void gibbsAdvanceKernel(const uint32_t num_cha
                 run_key = key;
                 run_at = tab + h;
                 run_length = 1;
+                ++n_keys;
                 atomicMin(tab_first + run_at, chain_in_problem * its + (iter - burn));  // later samples of the run come later
             }
         }
@@ -321,6 +344,16 @@ __global__ __launch_bounds__(256) void gibbsAdvanceKernel(const uint32_t num_cha
     ch.iter[ci] = iter;
     ch.flag[ci] = (flag & kChainDone) | slot;
     if (waiting) atomicAdd(remaining + round, 1u);
+    if (debug_counts) {  // per round: chains that ran, draws, most draws of a chain, record lookups, draws off the mode, walks, key changes
+        unsigned long long * c = debug_counts + 8ull * round;
+        atomicAdd(c + 0, 1ull);
+        atomicAdd(c + 1, static_cast<unsigned long long>(n_draws));
+        atomicMax(c + 2, static_cast<unsigned long long>(n_draws));
+        atomicAdd(c + 3, static_cast<unsigned long long>(n_lookups));
+        atomicAdd(c + 4, static_cast<unsigned long long>(n_off_mode));
+        atomicAdd(c + 5, static_cast<unsigned long long>(n_walked));
+        atomicAdd(c + 6, static_cast<unsigned long long>(n_keys));
+    }
 }
 
 // ---- the requests of a round: work items and storage -----------------------------------------------------
@@ -342,7 +375,8 @@ __global__ __launch_bounds__(1024) void gibbsRequestOffsetsKernel(const GibbsPro
                                                                   const uint64_t * __restrict__ mat_rows, GibbsHeader * hdr,
                                                                   const uint32_t * __restrict__ active_problem, const uint32_t * __restrict__ prob_count,
                                                                   uint32_t * prob_done, ActiveEntry * entries, uint32_t * new_req,
-                                                                  RequestInfo * req_info, const unsigned long long dist_capacity) {
+                                                                  const uint32_t * __restrict__ req_other, RequestInfo * records,
+                                                                  const unsigned long long dist_capacity) {
     __shared__ unsigned long long wave_items[16], wave_cols[16], wave_reqs[16];
     __shared__ unsigned long long carry_items, carry_cols, carry_reqs;
     const uint32_t tid = threadIdx.x;
@@ -406,11 +440,11 @@ __global__ __launch_bounds__(1024) void gibbsRequestOffsetsKernel(const GibbsPro
             const uint64_t col0 = pr.col_off[p];
             for (uint32_t j = 0; j < e.count; ++j) {
                 const uint32_t id = static_cast<uint32_t>(col0) + first + j;
-                new_req[e.req_off + j] = id;
-                req_info[id].dist_off = fits ? e.dist_off + static_cast<unsigned long long>(j) * distributionDoubles(G) : 0;
-                req_info[id].problem = p;
+                const uint32_t record = static_cast<uint32_t>(col0) + req_other[id];
+                new_req[e.req_off + j] = record;
+                records[record].dist_off = fits ? e.dist_off + static_cast<unsigned long long>(j) * distributionDoubles(G) : 0;
+                records[record].mode = p;  // (the distribution kernel reads the problem here and writes the mode over it)
             }
-            prob_done[p] = first + e.count;  // complete by the time the next advance starts (stream order)
         }
         __syncthreads();
         if (tid == 1023) {
@@ -421,6 +455,11 @@ __global__ __launch_bounds__(1024) void gibbsRequestOffsetsKernel(const GibbsPro
         __syncthreads();
     }
     if (evals != 0.0) atomicAdd(&hdr->evals, evals);
+    // the round's requests are complete by the time the next advance starts (stream order) — unless the round does not fit
+    // the storage: then nothing of it is evaluated, its chains keep waiting and the host reads the error
+    if (carry_cols <= dist_capacity) {
+        for (uint32_t a = tid; a < num_active; a += 1024) prob_done[entries[a].problem] = entries[a].first + entries[a].count;
+    }
     if (tid == 0) {
         const bool fits = carry_cols <= dist_capacity;
         if (!fits) atomicOr(&hdr->error, kErrDistributions);
@@ -616,15 +655,20 @@ __device__ __forceinline__ double waveMaxF64(double v) {
 // of the largest weight go into the request's record (what the chains look at first).
 __global__ __launch_bounds__(256) void gibbsDistributionKernel(const GibbsProblems pr, const GibbsHeader * __restrict__ hdr,
                                                                const uint32_t * __restrict__ new_req,
-                                                               const uint32_t * __restrict__ mat_cols, RequestInfo * req_info,
-                                                               double * __restrict__ dist) {
+                                                               const uint32_t * __restrict__ mat_cols, RequestInfo * records,
+                                                               double * __restrict__ dist, const double ask_ahead, uint32_t * prob_count,
+                                                               const uint32_t * __restrict__ prob_done, uint32_t * active_problem,
+                                                               uint32_t * req_other, GibbsHeader * counters) {
     const int lane = threadIdx.x & 63;
     const uint32_t num_new = hdr->cur_requests;
     const uint32_t num_waves = gridDim.x * 4;
     for (uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6); q < num_new; q += num_waves) {
-        const uint32_t id = new_req[q];
-        const uint32_t G = mat_cols[pr.matrix[req_info[id].problem]];
-        double * v = dist + req_info[id].dist_off;
+        const uint32_t id = new_req[q];  // the request's record
+        const uint32_t p = records[id].mode;
+        const uint32_t G = mat_cols[pr.matrix[p]];
+        const uint64_t col0 = pr.col_off[p];
+        const uint32_t done = prob_done[p];
+        double * v = dist + records[id].dist_off;
         double largest = -INFINITY;
         uint32_t largest_at = 0;
         for (uint32_t k = lane; k < G; k += 64) {
@@ -662,28 +706,43 @@ __global__ __launch_bounds__(256) void gibbsDistributionKernel(const GibbsProble
             if (lane == l) before = through;
             through += readLaneF64(mine, l);
         }
-        uint32_t * guide = reinterpret_cast<uint32_t *>(v + G);
+        DrawBucket * buckets_of = reinterpret_cast<DrawBucket *>(v + G);
         const double buckets = static_cast<double>(G);
         double inside = 0.0;
         double below = -1.0, upto = 2.0;
         bool has_mode = false;
         uint32_t bucket = (k_begin == 0 || k_begin >= G) ? 0 : min(G, static_cast<uint32_t>(ceil(before * buckets)));  // where the stretch before ends
         for (uint32_t k = k_begin; k < k_end; ++k) {
+            const double previous = (k == 0) ? -1.0 : before + inside;
             if (k == mode) {
-                below = (k == 0) ? -1.0 : before + inside;
+                below = previous;
                 has_mode = true;
             }
-            inside += v[k] / weight_sum;
+            const double share = v[k] / weight_sum;
+            inside += share;
             const double partial = (k + 1 == G) ? 1.0 : before + inside;
             v[k] = partial;
             if (k == mode) upto = partial;
+            // RPVG_HIP_GIBBS_ASK_AHEAD=share (A/B): a column a chain is likely to draw here is the other member of its next
+            // draw — its conditional is asked for now (next round's requests) instead of when a chain gets there.  The
+            // sampler's draws do not change: the memo only fills earlier (and with conditionals nobody may ever draw from).
+            if (share >= ask_ahead) {
+                RequestInfo * ahead = records + col0 + k;
+                if (ahead->state == 0 && atomicCAS(&ahead->state, 0u, kPending) == 0u) {
+                    const uint32_t number = atomicAdd(prob_count + p, 1u);
+                    req_other[col0 + number] = k;
+                    atomicExch(&ahead->state, number + 1);
+                    if (number == done) active_problem[atomicAdd(&counters->num_active, 1u)] = p;
+                }
+            }
             const uint32_t bucket_end = (k + 1 == G) ? G : min(G, static_cast<uint32_t>(ceil(partial * buckets)));
-            for (; bucket < bucket_end; ++bucket) guide[bucket] = k;
+            for (; bucket < bucket_end; ++bucket) buckets_of[bucket] = DrawBucket{previous, partial, k};
         }
+        // (every lane has read the problem above: the wave runs in step)
         if (has_mode) {
-            req_info[id].mode_below = below;
-            req_info[id].mode_upto = upto;
-            req_info[id].mode = mode;
+            records[id].mode_below = below;
+            records[id].mode_upto = upto;
+            records[id].mode = mode;
         }
     }
 }
@@ -837,7 +896,7 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
         out_capacity += sets_bound;
         const uint64_t draws = chains * all_its * GS;
         words_needed[p] = chains * GS + (G >= 2 ? 2 * draws : 0);
-        dist_bound += static_cast<long double>(distributionDoubles(G)) * static_cast<long double>(GS == 2 ? std::min<uint64_t>(G, draws + chains * GS) : 1);
+        dist_bound += static_cast<long double>(distributionDoubles(G)) * static_cast<long double>(GS == 2 ? G : 1);  // every column as the other member once
     }
     const uint64_t num_chains = chain_off[P], num_cols = col_off[P], num_slots = tab_off[P];
     RPVG_REQUIRE(num_chains < 0x7fffffffull, "rpvg_hip_group_gibbs: %llu chains exceed one launch", static_cast<unsigned long long>(num_chains));
@@ -870,7 +929,7 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     // reports RPVG_HIP_ERR_UNSUPPORTED: the caller has the host-driven sampler)
     uint64_t dist_capacity = 0;
     {
-        static const char * env = std::getenv("RPVG_HIP_GIBBS_BYTES");
+        const char * env = std::getenv("RPVG_HIP_GIBBS_BYTES");  // (read per call: a test switches it)
         size_t free_bytes = 0, total_bytes = 0;
         RPVG_HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
         long double budget = env ? std::strtold(env, nullptr) : std::min<long double>(0.4L * free_bytes, 64.0L * (1ull << 30));
@@ -881,7 +940,8 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     DeviceBuffer<uint32_t> d_matrix, d_chains, d_burn, d_its, d_gen_prob_off, d_gen_prob, d_gen_words;
     DeviceBuffer<uint64_t> d_chain_off, d_col_off, d_tab_off, d_stream_off;
     DeviceBuffer<double> d_log_freq;
-    DeviceBuffer<uint32_t> d_memo, d_remaining, d_tab_count, d_prob_count, d_prob_done;
+    DeviceBuffer<uint32_t> d_remaining, d_tab_count, d_prob_count, d_prob_done;
+    DeviceBuffer<RequestInfo> d_records;
     DeviceBuffer<GibbsHeader> d_hdr;
     DeviceBuffer<unsigned long long> d_words, d_set_off;
     UploadPack pack;
@@ -897,7 +957,7 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     pack.add(d_tab_off, tab_off.data(), tab_off.size());
     pack.add(d_stream_off, stream_off.data(), stream_off.size());
     pack.add(d_log_freq, spec->log_freq, num_cols);
-    pack.addZero(d_memo, num_cols);
+    pack.addZero(d_records, num_cols);
     pack.addZero(d_prob_count, P);
     pack.addZero(d_prob_done, P);
     pack.addZero(d_remaining, kMaxRounds);
@@ -913,12 +973,11 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     DeviceBuffer<uint32_t> d_stream, d_chain_problem, d_chain_cur, d_chain_iter, d_chain_flag, d_active_problem, d_req_other, d_new_req, d_tab_first;
     DeviceBuffer<unsigned long long> d_chain_pos, d_tab_key;
     DeviceBuffer<ActiveEntry> d_entries;
-    DeviceBuffer<RequestInfo> d_req_info;
     DeviceBuffer<double> d_dist;
     DeviceBuffer<uint32_t> d_out;  // first | second | count | sequence, out_capacity each
     DeviceBuffer<uint32_t> d_final_state;
     RPVG_HIP_CHECK(d_final_state.alloc(static_cast<size_t>(NG) * rpvg_streams::kMtWords));
-    RPVG_HIP_CHECK(d_stream.alloc(stream_off[NG] + 2));  // (the chains fetch the words of their next draw ahead)
+    RPVG_HIP_CHECK(d_stream.alloc(stream_off[NG] + kWordWindow));  // (the chains fetch their words a window at a time)
     RPVG_HIP_CHECK(d_chain_problem.alloc(num_chains));
     RPVG_HIP_CHECK(d_chain_cur.alloc(2 * num_chains));
     RPVG_HIP_CHECK(d_chain_iter.alloc(num_chains));
@@ -928,7 +987,6 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     RPVG_HIP_CHECK(d_entries.alloc(P));
     RPVG_HIP_CHECK(d_req_other.alloc(num_cols));
     RPVG_HIP_CHECK(d_new_req.alloc(num_cols));
-    RPVG_HIP_CHECK(d_req_info.alloc(num_cols));
     RPVG_HIP_CHECK(d_tab_key.alloc(num_slots));
     RPVG_HIP_CHECK(d_tab_first.alloc(num_slots));
     RPVG_HIP_CHECK(d_dist.alloc(dist_capacity));
@@ -955,6 +1013,17 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     std::shared_ptr<void> pinned_guard(pinned, [](void * ptr) { pinnedFree(ptr); });
     Progress * progress = static_cast<Progress *>(pinned);
 
+    // share of a distribution from which a column's own conditional is asked for ahead of the chains (group size 2; above 1: never)
+    // (off by default: at 0.02 and 0.002 the fourth round has 750 / 220 chains left instead of 1 330, the dozen chains of a
+    // long-tailed posterior that make the last ten rounds are not helped, and the batch takes as long within the noise)
+    static const double ask_ahead_env = std::getenv("RPVG_HIP_GIBBS_ASK_AHEAD") ? std::atof(std::getenv("RPVG_HIP_GIBBS_ASK_AHEAD")) : 0.0;
+    const double ask_ahead = (GS == 2 && ask_ahead_env > 0) ? ask_ahead_env : 2.0;
+    static const bool debug = std::getenv("RPVG_HIP_GIBBS_DEBUG") != nullptr;
+    DeviceBuffer<unsigned long long> d_debug;
+    if (debug) {
+        RPVG_HIP_CHECK(d_debug.alloc(8ull * kMaxRounds));
+        RPVG_HIP_CHECK(hipMemsetAsync(d_debug.ptr, 0, 8ull * kMaxRounds * sizeof(unsigned long long), st));
+    }
     scope.reset(new HostScope("group_gibbs: rounds"));
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
     const uint32_t advance_blocks = static_cast<uint32_t>((num_chains + 255) / 256);
@@ -968,12 +1037,12 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
         for (uint32_t r = 0; r < chunk; ++r, ++round) {
 #define RPVG_GIBBS_ROUND(W)                                                                                                            \
     gibbsAdvanceKernel<W><<<dim3(advance_blocks), dim3(256), 0, st>>>(                                                                 \
-        static_cast<uint32_t>(num_chains), round, pr, groups->mat_cols.ptr, ch, d_stream.ptr, d_memo.ptr, d_prob_count.ptr,            \
-        d_prob_done.ptr, d_hdr.ptr, d_remaining.ptr, d_active_problem.ptr, d_req_other.ptr, d_req_info.ptr, d_dist.ptr, d_tab_key.ptr, \
-        d_tab_count.ptr, d_tab_first.ptr);                                                                                             \
+        static_cast<uint32_t>(num_chains), round, pr, groups->mat_cols.ptr, ch, d_stream.ptr, d_records.ptr, d_prob_count.ptr,         \
+        d_prob_done.ptr, d_hdr.ptr, d_remaining.ptr, d_active_problem.ptr, d_req_other.ptr, d_dist.ptr, d_tab_key.ptr,                 \
+        d_tab_count.ptr, d_tab_first.ptr, d_debug.ptr);                                                                                \
     gibbsRequestOffsetsKernel<<<dim3(1), dim3(1024), 0, st>>>(pr, groups->mat_cols.ptr, groups->mat_rows.ptr, d_hdr.ptr,               \
                                                               d_active_problem.ptr, d_prob_count.ptr, d_prob_done.ptr, d_entries.ptr,  \
-                                                              d_new_req.ptr, d_req_info.ptr, dist_capacity);                           \
+                                                              d_new_req.ptr, d_req_other.ptr, d_records.ptr, dist_capacity);           \
     span = ctx->spanBegin(FAM_LOGLIK);                                                                                                 \
     gibbsConditionalKernel<W><<<dim3(work_blocks), dim3(256), 0, st>>>(                                                                \
         pr, d_hdr.ptr, d_entries.ptr, d_req_other.ptr, groups->mat_val_off.ptr, groups->mat_row_off.ptr, groups->mat_fast.ptr,         \
@@ -986,7 +1055,8 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
                 RPVG_GIBBS_ROUND(2);
             }
 #undef RPVG_GIBBS_ROUND
-            gibbsDistributionKernel<<<dim3(work_blocks), dim3(256), 0, st>>>(pr, d_hdr.ptr, d_new_req.ptr, groups->mat_cols.ptr, d_req_info.ptr, d_dist.ptr);
+            gibbsDistributionKernel<<<dim3(work_blocks), dim3(256), 0, st>>>(pr, d_hdr.ptr, d_new_req.ptr, groups->mat_cols.ptr, d_records.ptr, d_dist.ptr,
+                                                                            ask_ahead, d_prob_count.ptr, d_prob_done.ptr, d_active_problem.ptr, d_req_other.ptr, d_hdr.ptr);
         }
         RPVG_HIP_CHECK(hipGetLastError());
         RPVG_HIP_CHECK(hipMemcpyAsync(&progress->remaining, d_remaining.ptr + (round - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1004,6 +1074,15 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
         }
         finished = progress->remaining == 0;
         chunk = 4;
+    }
+    if (debug) {
+        std::vector<unsigned long long> counts(8ull * round);
+        RPVG_HIP_CHECK(hipMemcpy(counts.data(), d_debug.ptr, counts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (uint32_t r = 0; r < round; ++r) {
+            const unsigned long long * c = counts.data() + 8ull * r;
+            std::fprintf(stderr, "[rpvg_hip gibbs] round %2u: %7llu chains ran, %9llu draws (most of one chain %6llu), %8llu record lookups, %8llu draws off the mode (%llu walked on), %8llu key changes\n",
+                         r, c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
+        }
     }
     ctx->stats.loglik_launches += round;
     ctx->stats.loglik_evals += progress->hdr.evals;

@@ -206,6 +206,25 @@ def test_gibbs_haplotype_posteriors_follow_the_reference_stream(engine, model, p
     _compare(got1, ref)
 
 
+def test_gibbs_sampler_without_room_on_the_device_falls_back_to_the_host_driven_one(engine):
+    """rpvg_hip_group_gibbs reports RPVG_HIP_ERR_UNSUPPORTED when the conditional distributions outgrow the memory set
+    aside for them; the host-driven sampler (chains on the host, conditionals from rpvg_hip_group_conditionals) then runs
+    on generators nobody has moved: the same draws, the same estimates; and ploidy 3 always takes that path."""
+    clusters = small_cases.make_batch_clusters(691, n_clusters=8)
+    batch = ClusterBatch.from_clusters(clusters)
+    for model, ploidy in (("haplotypes", 2), ("haplotype-transcripts", 2), ("haplotypes", 3)):
+        params = make_params(use_hap_gibbs=1, ploidy=ploidy, rng_seed=11)
+        ref, _ = pyoracle.run(model, params, batch, 1)
+        os.environ["RPVG_HIP_GIBBS_BYTES"] = "64"
+        try:
+            got, _ = engine.run(model, params, engine.prepare(batch))
+        finally:
+            del os.environ["RPVG_HIP_GIBBS_BYTES"]
+        _compare(got, ref)
+        again, _ = engine.run(model, params, engine.prepare(batch))
+        _compare(again, ref)
+
+
 def test_gibbs_posteriors_agree_with_exact_posteriors_statistically(engine):
     """Size-independent property: the Gibbs frequencies of the dominant diplotypes approach the exact
     (branch-and-bound) posteriors."""
