@@ -231,9 +231,10 @@ int rpvg_hip_group_conditionals(rpvg_hip_ctx * ctx, const rpvg_hip_groups * grou
  * rpvg_amd/csrc/gibbs_streams.hpp and checked against libstdc++ on the CPU (tests/cpp/gibbs_streams_check.cpp).
  * The chain counts and lengths are the caller's (src/path_estimator.cpp:501-503).
  * The sets of a problem come in the order the reference appends them to path_group_sets (first appearance).
- * Returns RPVG_HIP_ERR_UNSUPPORTED, having changed nothing, for other group sizes and when the distributions outgrow the
- * memory reserved for them (RPVG_HIP_GIBBS_BYTES; default two fifths of the free device memory): the caller then drives
- * the sampler itself through rpvg_hip_group_conditionals. */
+ * Returns RPVG_HIP_ERR_UNSUPPORTED, having changed nothing, for other group sizes, when the distributions outgrow the
+ * memory reserved for them (RPVG_HIP_GIBBS_BYTES; default: room for every column of every problem as the other member,
+ * at most two fifths of the free device memory and 64 GiB) and when the chains are not done after 8 192 rounds of requests:
+ * the caller then drives the sampler itself through rpvg_hip_group_conditionals. */
 typedef struct rpvg_hip_gibbs_spec {
     uint32_t num_problems;
     uint32_t group_size;                    /* 1 or 2                                                                  */

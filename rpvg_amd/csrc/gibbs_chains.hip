@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void gibbsAdvanceKernel(const uint32_t num_cha
     // per draw (a wave's 64 chains read 64 different lines: the lines of 16 waves do not stay in the CU's 32 KB).
     __shared__ uint32_t word_window[kWordWindow * 256];
     uint32_t * window = word_window + threadIdx.x;
-    unsigned long long window_pos = ~0ull;  // stream position of the window's first word
+    unsigned long long window_pos = 0;  // stream position of the window's first word
+    bool window_filled = false;
     while (true) {
         uint32_t drawn = 0;
         if (G >= 2) {
@@ -278,13 +279,14 @@ __global__ __launch_bounds__(256) void gibbsAdvanceKernel(const uint32_t num_cha
                 ++n_lookups;
             }
             ++n_draws;
-            if (pos - window_pos > kWordWindow - 2) {  // (also the first draw: window_pos is all ones)
+            if (!window_filled || pos - window_pos > kWordWindow - 2) {
                 uint32_t fetched[kWordWindow];
 #pragma unroll
                 for (uint32_t j = 0; j < kWordWindow; ++j) fetched[j] = stream[pos + j];  // (past a slice: the next chain's words, or the slack behind the last)
 #pragma unroll
                 for (uint32_t j = 0; j < kWordWindow; ++j) window[j * 256] = fetched[j];
                 window_pos = pos;
+                window_filled = true;
             }
             const uint32_t at = static_cast<uint32_t>(pos - window_pos);
             const double u = rpvg_streams::canonicalFromWords(window[at * 256], window[(at + 1) * 256]);
@@ -1033,7 +1035,11 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     static const uint32_t first_rounds = std::getenv("RPVG_HIP_GIBBS_FIRST_ROUNDS") ? std::max(1, std::atoi(std::getenv("RPVG_HIP_GIBBS_FIRST_ROUNDS"))) : 6;
     uint32_t chunk = first_rounds;
     while (!finished) {
-        RPVG_REQUIRE(round + chunk < kMaxRounds, "rpvg_hip_group_gibbs: the chains are not done after %u rounds", round);
+        if (round + chunk >= kMaxRounds) {  // (a round per column of a flat posterior over thousands of columns: the caller's sampler takes it)
+            RPVG_HIP_CHECK(hipStreamSynchronize(st));
+            setError("rpvg_hip_group_gibbs: the chains are not done after %u rounds", round);
+            return RPVG_HIP_ERR_UNSUPPORTED;
+        }
         for (uint32_t r = 0; r < chunk; ++r, ++round) {
 #define RPVG_GIBBS_ROUND(W)                                                                                                            \
     gibbsAdvanceKernel<W><<<dim3(advance_blocks), dim3(256), 0, st>>>(                                                                 \

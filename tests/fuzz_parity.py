@@ -3,7 +3,9 @@
 The open-ended sweep is run by hand (minutes of GPU time; prints every mismatch and a summary); a fixed set of its
 seeds is collected under -m gpu (tests/test_hip_collapse.py::test_trimmed_parity_sweep).
 
-  python tests/fuzz_parity.py [rounds] [first_seed]
+  python tests/fuzz_parity.py [rounds] [first_seed] [gibbs]
+(gibbs: every case is a haplotype model with --use-hap-gibbs — the sampler's chains on the device for ploidy 1 and 2,
+the host-driven sampler for ploidy 3)
 """
 import sys
 import time
@@ -54,7 +56,7 @@ def compare(got, ref, check_iters=True):
     return problems
 
 
-def draw_case(seed):
+def draw_case(seed, only_gibbs=False):
     """Batch, model and options of one seed of the sweep."""
     rng = np.random.default_rng(seed)
     shape = rng.integers(0, 3)
@@ -74,9 +76,11 @@ def draw_case(seed):
         model = "transcripts"  # the oracle's pair enumeration / greedy cover is O(rows x paths^2) per cluster
     kw = dict(max_em_its=int(rng.choice([3, 50, 10000])), max_rel_em_conv=float(rng.choice([1e-3, 1e-2, 1e-5])),
               min_hap_prob=float(rng.choice([1e-3, 1e-2, 1e-5])), rng_seed=int(rng.integers(0, 1000)))
+    if only_gibbs and model not in ("haplotype-transcripts", "haplotypes"):
+        model = "haplotypes" if model == "strains" else "haplotype-transcripts"
     if model in ("haplotype-transcripts", "haplotypes"):
         kw["ploidy"] = int(rng.choice([1, 2, 2, 2, 3]))
-        kw["use_hap_gibbs"] = int(rng.random() < 0.25)
+        kw["use_hap_gibbs"] = int(only_gibbs or rng.random() < 0.25)
     if model == "haplotype-transcripts" and not kw.get("use_hap_gibbs") and rng.random() < 0.2 and kw["min_hap_prob"] >= 1e-3:
         # (with 1e-5 the reference's own assertion sum_hap_prob <= 1 fails on the rounding of 100 000 weights,
         # src/path_abundance_estimator.cpp:748)
@@ -102,12 +106,13 @@ def run_case(eng, case, oracle_threads=32):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    only_gibbs = len(sys.argv) > 3 and sys.argv[3] == "gibbs"
     eng = eng_mod.Engine(0)
     failures = 0
     t0 = time.time()
     for i in range(rounds):
         seed = seed0 + i
-        case = draw_case(seed)
+        case = draw_case(seed, only_gibbs)
         try:
             problems = run_case(eng, case)
         except Exception as exc:  # noqa: BLE001

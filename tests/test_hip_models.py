@@ -225,6 +225,18 @@ def test_gibbs_sampler_without_room_on_the_device_falls_back_to_the_host_driven_
         _compare(again, ref)
 
 
+@pytest.mark.parametrize("seed", [40061, 40136, 40173, 40005, 40118])
+def test_gibbs_seeds_of_the_parity_sweep(engine, seed):
+    """Fixed seeds of `tests/fuzz_parity.py <rounds> 40000 gibbs` (every case a haplotype model with --use-hap-gibbs).  The
+    first three caught the device sampler reading its first generator words from a window in LDS it had not filled yet (the
+    first chain of a call's first generator: one subset sample in eleven came out differently in the lanes' first clusters);
+    the host-driven sampler agreed with the oracle on them."""
+    from tests import fuzz_parity
+    case = fuzz_parity.draw_case(seed, only_gibbs=True)
+    assert case["kw"]["use_hap_gibbs"] == 1
+    assert fuzz_parity.run_case(engine, case, oracle_threads=8) == []
+
+
 def test_gibbs_posteriors_agree_with_exact_posteriors_statistically(engine):
     """Size-independent property: the Gibbs frequencies of the dominant diplotypes approach the exact
     (branch-and-bound) posteriors."""

@@ -10,12 +10,12 @@ from oracle import pyoracle  # noqa: E402
 from tests import fuzz_parity  # noqa: E402
 
 seed = int(sys.argv[1])
-case = fuzz_parity.draw_case(seed)
+case = fuzz_parity.draw_case(seed, only_gibbs=("gibbs" in sys.argv))
 print(case["model"], case["kw"], "clusters", case["batch"].num_clusters, "shape", case["shape"])
 params = make_params(**case["kw"])
 eng = eng_mod.Engine(0)
 ref, _ = pyoracle.run(case["model"], params, case["batch"], 32)
-for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 1):
+for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 1):
     got, _ = eng.run(case["model"], params, eng.prepare(case["batch"]))
     problems = fuzz_parity.compare(got, ref)
     print("run", rep, "problems", len(problems))
