@@ -46,6 +46,7 @@ constexpr uint32_t kPending = 0xffffffffu;
 constexpr uint32_t kChainDone = 0x80000000u;
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr uint32_t kErrStream = 1, kErrDistributions = 2;
+constexpr uint32_t kCondCands = 64, kCondRows = 64, kCondStride = 70;  // gibbsConditionalTileKernel: doubles per staged row = 4 + 64 + noise + count
 constexpr uint32_t kWordWindow = 16;  // generator words a chain keeps in LDS
 constexpr uint32_t kRankInLds = 2048;  // sets of a problem ordered by first appearance inside the collect kernel up to this many
 
@@ -60,7 +61,8 @@ struct GibbsHeader {
     uint32_t total_requests;
     uint32_t error;
     uint32_t unsorted;             // problems whose sets left the collect kernel in table order
-    uint32_t pad[2];
+    uint32_t tiled;                // the current round's conditionals go through gibbsConditionalTileKernel
+    uint32_t pad;
 };
 
 struct GibbsProblems {  // device arrays over the problems
@@ -378,18 +380,30 @@ __global__ __launch_bounds__(1024) void gibbsRequestOffsetsKernel(const GibbsPro
                                                                   const uint32_t * __restrict__ active_problem, const uint32_t * __restrict__ prob_count,
                                                                   uint32_t * prob_done, ActiveEntry * entries, uint32_t * new_req,
                                                                   const uint32_t * __restrict__ req_other, RequestInfo * records,
-                                                                  const unsigned long long dist_capacity) {
+                                                                  const unsigned long long dist_capacity, const uint32_t tiled) {
     __shared__ unsigned long long wave_items[16], wave_cols[16], wave_reqs[16];
     __shared__ unsigned long long carry_items, carry_cols, carry_reqs;
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t num_active = hdr->num_active;
+    // A round of many requests (the first: every chain's start) goes through the workgroup-per-tile kernel, which reads
+    // less per evaluation; a round of few through the wave-per-item kernel, which makes sixteen times the work items of them
+    // (a workgroup walks ALL rows of its matrix: 1.2-1.7 against 0.6-1.0 ms for the rounds behind the first).
+    __shared__ unsigned int round_requests;
     if (tid == 0) {
         carry_items = 0;
         carry_cols = hdr->used;
         carry_reqs = 0;
+        round_requests = 0;
     }
     __syncthreads();
+    {
+        unsigned int mine = 0;
+        for (uint32_t a = tid; a < num_active; a += 1024) mine += prob_count[active_problem[a]] - prob_done[active_problem[a]];
+        if (mine) atomicAdd(&round_requests, mine);
+    }
+    __syncthreads();
+    const bool tiled_round = tiled != 0;
     double evals = 0.0;
     for (uint32_t base = 0; base < num_active; base += 1024) {
         const uint32_t a = base + tid;
@@ -402,9 +416,13 @@ __global__ __launch_bounds__(1024) void gibbsRequestOffsetsKernel(const GibbsPro
             first = prob_done[p];
             reqs = prob_count[p] - first;
             cols = reqs * distributionDoubles(G);
-            const unsigned long long work_items = ((reqs + 3) / 4) * ((G + 3) / 4);
-            const uint32_t per_turn = itemsPerTurn(mat_rows[m]);
-            items = (work_items + per_turn - 1) / per_turn;
+            if (tiled_round) {  // gibbsConditionalTileKernel: (four requests) x (64 candidate columns) per workgroup
+                items = ((reqs + 3) / 4) * ((G + kCondCands - 1) / kCondCands);
+            } else {
+                const unsigned long long work_items = ((reqs + 3) / 4) * ((G + 3) / 4);
+                const uint32_t per_turn = itemsPerTurn(mat_rows[m]);
+                items = (work_items + per_turn - 1) / per_turn;
+            }
             evals += static_cast<double>(mat_rows[m]) * static_cast<double>(reqs * G);
         }
         unsigned long long scan_items = items, scan_cols = cols, scan_reqs = reqs;
@@ -471,6 +489,7 @@ __global__ __launch_bounds__(1024) void gibbsRequestOffsetsKernel(const GibbsPro
         hdr->used = fits ? carry_cols : hdr->used;
         hdr->total_requests += static_cast<uint32_t>(carry_reqs);
         hdr->num_active = 0;
+        hdr->tiled = tiled_round ? 1u : 0u;
     }
 }
 
@@ -517,13 +536,29 @@ __device__ __forceinline__ void conditionalItem(const LogTableEntry * lt, const 
             for (int c = 0; c < kCand; ++c) xs[o * kCand + c] = base + v.cand[c] / divisor;
         }
     };
-    // rows of read count 1 (LogProduct, common.hpp): a lane multiplies kFoldFactors factors between folds.  Two rows per
-    // step, their eighteen loads issued together: with 180 registers two waves share a SIMD, and a wave that waits for the
+    // rows of read count 1 (LogProduct, common.hpp): a lane multiplies kFoldFactors factors between folds.  Three rows per
+    // step (then two, then one; four take 256 registers and the SIMD's second wave with them), their loads issued together: with 180 registers two waves share a SIMD, and a wave that waits for the
     // nine loads of one row before it asks for the next is all latency (1.0 T evaluations/s: 8 waves per CU x 1 024
     // evaluations per 2 us)
     for (uint64_t seg = 0; seg < fast_end; seg += 64 * kFoldFactors) {
         const uint64_t seg_end = (fast_end - seg) < 64 * kFoldFactors ? fast_end : seg + 64 * kFoldFactors;
         uint64_t i = seg + lane;
+        for (; i + 128 < seg_end; i += 192) {
+            RowValues a, b, c;
+            load(i, a);
+            load(i + 64, b);
+            load(i + 128, c);
+            double xs[kOut];
+            arguments(a, xs);
+#pragma unroll
+            for (int t = 0; t < kOut; ++t) prod[t].mul(xs[t]);
+            arguments(b, xs);
+#pragma unroll
+            for (int t = 0; t < kOut; ++t) prod[t].mul(xs[t]);
+            arguments(c, xs);
+#pragma unroll
+            for (int t = 0; t < kOut; ++t) prod[t].mul(xs[t]);
+        }
         for (; i + 64 < seg_end; i += 128) {
             RowValues a, b;
             load(i, a);
@@ -593,7 +628,7 @@ __global__ __launch_bounds__(256) void gibbsConditionalKernel(const GibbsProblem
                                                               const double * __restrict__ values, const double * __restrict__ row_count,
                                                               const double * __restrict__ row_noise, double * __restrict__ dist) {
     const unsigned long long num_items = hdr->num_items;
-    if (num_items == 0) return;
+    if (num_items == 0 || hdr->tiled) return;
     __shared__ LogTableEntry lt[kLogTableSize];
     loadLogTable(lt);
     __syncthreads();
@@ -640,6 +675,171 @@ __global__ __launch_bounds__(256) void gibbsConditionalKernel(const GibbsProblem
                 conditionalItem<GS, 1>(lt, lane, M, R, G, cnt, nz, fast_end, mid_end, other_col, k0, 1, lf, out);
             } else {
                 conditionalItem<GS, 4>(lt, lane, M, R, G, cnt, nz, fast_end, mid_end, other_col, k0, num_others, lf, out);
+            }
+        }
+    }
+}
+
+// ---- conditionals, the rows staged through LDS ---------------------------------------------------------------
+// A workgroup per (problem, up to four of its new requests, block of 64 candidate columns).  64 rows at a time go through
+// LDS — row-major, [4 others | 64 candidates | noise | read count] — loaded by lane = row (512-byte requests, seventeen in
+// flight per thread) where the wave-per-item kernel read nine columns per row for sixteen log arguments at two waves per
+// SIMD: 2.2 instead of 4.5 bytes per evaluation, and twice the waves.  Thread = (tile of four candidates, one of sixteen row
+// slices): per row two 16-byte LDS reads for each side and sixteen running products, as in the diploid search's tile
+// kernel; the slices are multiplied together inside the wave, the four waves' logarithms added through LDS.
+
+template <int GS>
+__global__ __launch_bounds__(256) void gibbsConditionalTileKernel(const GibbsProblems pr, const GibbsHeader * __restrict__ hdr,
+                                                                  const ActiveEntry * __restrict__ entries, const uint32_t * __restrict__ req_other,
+                                                                  const uint64_t * __restrict__ mat_val_off, const uint64_t * __restrict__ mat_row_off,
+                                                                  const uint32_t * __restrict__ mat_fast, const uint32_t * __restrict__ mat_mid,
+                                                                  const uint64_t * __restrict__ mat_rows, const uint32_t * __restrict__ mat_cols,
+                                                                  const double * __restrict__ values, const double * __restrict__ row_count,
+                                                                  const double * __restrict__ row_noise, double * __restrict__ dist) {
+    constexpr double divisor = static_cast<double>(GS);
+    const unsigned long long num_items = hdr->num_items;
+    if (num_items == 0 || !hdr->tiled) return;
+    __shared__ LogTableEntry lt[kLogTableSize];
+    __shared__ __attribute__((aligned(16))) double staged[kCondRows * kCondStride];
+    __shared__ double wave_logs[4 * 16 * 16];
+    loadLogTable(lt);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = tid & 15;   // candidates 4 tile .. 4 tile + 3 of the block
+    const uint32_t slice = tid >> 4;  // rows slice, slice + 16, ... of a staged chunk
+    const uint32_t num_active = hdr->cur_active;
+    for (unsigned long long item = blockIdx.x; item < num_items; item += gridDim.x) {
+        uint32_t lo = 0, hi = num_active - 1;  // last entry with item_off <= item
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo + 1) >> 1);
+            if (entries[mid].item_off <= item) lo = mid; else hi = mid - 1;
+        }
+        const ActiveEntry e = entries[lo];
+        const uint32_t p = e.problem;
+        const uint32_t m = pr.matrix[p];
+        const uint64_t R = mat_rows[m];
+        const uint32_t G = mat_cols[m];
+        const double * M = values + mat_val_off[m];
+        const double * cnt = row_count + mat_row_off[m];
+        const double * nz = row_noise + mat_row_off[m];
+        const uint64_t col0 = pr.col_off[p];
+        const uint64_t fast_end = mat_fast[m], mid_end = mat_mid[m];
+        const uint32_t other_groups = (e.count + 3) / 4;
+        const uint32_t local = static_cast<uint32_t>(item - e.item_off);
+        const uint32_t j0 = (local % other_groups) * 4;
+        const uint32_t k0 = (local / other_groups) * kCondCands;
+        const uint32_t num_others = min(4u, e.count - j0);
+        // the column a thread stages: 0-3 others, 4-67 candidates, 68 noise, 69 read count; columns wave, wave + 4, ...
+        LogProduct prod[16];
+        double acc[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = 0.0;
+        uint32_t factors = 0;  // fast factors since the last fold
+        const uint32_t stage_row = tid & 63, stage_col0 = tid >> 6;
+        double fetched[18];
+        auto fetch = [&](const uint64_t r0) {
+            const uint64_t i_stage = r0 + stage_row;
+            const bool row_there = i_stage < R;
+#pragma unroll
+            for (uint32_t q = 0; q < 18; ++q) {
+                const uint32_t col = stage_col0 + 4 * q;
+                double v = (col == 68) ? 1.0 : 0.0;  // a row past the end: argument 1, a factor that changes nothing
+                if (row_there && col < kCondStride) {
+                    if (col < 4) {
+                        if (GS == 2) v = M[static_cast<uint64_t>(req_other[col0 + e.first + j0 + min(col, num_others - 1)]) * R + i_stage];
+                    } else if (col < 68) {
+                        if (k0 + col - 4 < G) v = M[static_cast<uint64_t>(k0 + col - 4) * R + i_stage];
+                    } else if (col == 68) {
+                        v = nz[i_stage];
+                    } else {
+                        v = cnt[i_stage];
+                    }
+                }
+                fetched[q] = v;
+            }
+        };
+        for (uint64_t r0 = 0; r0 < R; r0 += kCondRows) {
+            fetch(r0);  // (fetching the chunk after this one under its arithmetic takes 254 registers: one wave per SIMD)
+            __syncthreads();  // the chunk before has been read
+#pragma unroll
+            for (uint32_t q = 0; q < 18; ++q) {
+                const uint32_t col = stage_col0 + 4 * q;
+                if (col < kCondStride) staged[stage_row * kCondStride + col] = fetched[q];
+            }
+            __syncthreads();
+            if (factors + 4 > kFoldFactors) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) prod[t].fold();
+                factors = 0;
+            }
+            if (k0 + 4 * tile < G) {  // (a block of fewer than 64 candidates: tiles without one)
+#pragma unroll 1
+            for (uint32_t step = 0; step < kCondRows / 16; ++step) {
+                const uint32_t row = slice + 16 * step;
+                const uint64_t i = r0 + row;
+                const double * at = staged + row * kCondStride;
+                const double2 o01 = *reinterpret_cast<const double2 *>(at), o23 = *reinterpret_cast<const double2 *>(at + 2);
+                const double2 c01 = *reinterpret_cast<const double2 *>(at + 4 + 4 * tile), c23 = *reinterpret_cast<const double2 *>(at + 6 + 4 * tile);
+                const double noise = at[68];
+                const double others[4] = {o01.x, o01.y, o23.x, o23.y};
+                const double half[4] = {c01.x / divisor, c01.y / divisor, c23.x / divisor, c23.y / divisor};
+                double xs[16];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    double base = noise;
+                    if (GS == 2) base += others[o] / divisor;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xs[o * 4 + c] = base + half[c];
+                }
+                if (i < fast_end || i >= R) {  // (past the end: factors of 1)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) prod[t].mul(xs[t]);
+                    ++factors;
+                } else if (i < mid_end) {
+                    const int count = static_cast<int>(at[69]);
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) prod[t].fold();
+                    for (int k = 0; k < count; ++k) {
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) prod[t].mul(xs[t]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) prod[t].fold();
+                    factors = 0;
+                } else {
+                    const double count = at[69];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) acc[t] = fma(count, logPositive(xs[t], lt), acc[t]);
+                }
+            }
+            }
+        }
+        // the sixteen slices: four inside every wave (lanes 16 apart), then the waves' logarithms through LDS
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            prod[t].fold();
+            for (int d = 16; d < 64; d <<= 1) {
+                LogProduct partner;
+                partner.p = __shfl_xor(prod[t].p, d);
+                partner.e = __shfl_xor(prod[t].e, d);
+                prod[t].join(partner);
+                prod[t].fold();
+                acc[t] += __shfl_xor(acc[t], d);
+            }
+        }
+        __syncthreads();  // (wave_logs of the item before have been read)
+        if ((tid & 63) < 16) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) wave_logs[((tid >> 6) * 16 + tile) * 16 + t] = acc[t] + prod[t].value(lt);
+        }
+        __syncthreads();
+        {
+            const uint32_t out_tile = tid >> 4, out_value = tid & 15;  // 16 tiles x (4 others x 4 candidates)
+            const uint32_t o = out_value >> 2, c = out_value & 3;
+            const uint32_t k = k0 + 4 * out_tile + c;
+            if (o < num_others && k < G) {
+                const double total = (wave_logs[(0 * 16 + out_tile) * 16 + out_value] + wave_logs[(1 * 16 + out_tile) * 16 + out_value]) +
+                                     (wave_logs[(2 * 16 + out_tile) * 16 + out_value] + wave_logs[(3 * 16 + out_tile) * 16 + out_value]);
+                dist[e.dist_off + static_cast<unsigned long long>(j0 + o) * distributionDoubles(G) + k] = total + pr.log_freq[col0 + k];
             }
         }
     }
@@ -1020,6 +1220,8 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     // long-tailed posterior that make the last ten rounds are not helped, and the batch takes as long within the noise)
     static const double ask_ahead_env = std::getenv("RPVG_HIP_GIBBS_ASK_AHEAD") ? std::atof(std::getenv("RPVG_HIP_GIBBS_ASK_AHEAD")) : 0.0;
     const double ask_ahead = (GS == 2 && ask_ahead_env > 0) ? ask_ahead_env : 2.0;
+    // rounds (from the first) whose conditionals go through the tile kernel (A/B)
+    static const uint32_t tiled_rounds = std::getenv("RPVG_HIP_GIBBS_TILED_ROUNDS") ? static_cast<uint32_t>(std::atoi(std::getenv("RPVG_HIP_GIBBS_TILED_ROUNDS"))) : 1u;
     static const bool debug = std::getenv("RPVG_HIP_GIBBS_DEBUG") != nullptr;
     DeviceBuffer<unsigned long long> d_debug;
     if (debug) {
@@ -1048,12 +1250,20 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
         d_tab_count.ptr, d_tab_first.ptr, d_debug.ptr);                                                                                \
     gibbsRequestOffsetsKernel<<<dim3(1), dim3(1024), 0, st>>>(pr, groups->mat_cols.ptr, groups->mat_rows.ptr, d_hdr.ptr,               \
                                                               d_active_problem.ptr, d_prob_count.ptr, d_prob_done.ptr, d_entries.ptr,  \
-                                                              d_new_req.ptr, d_req_other.ptr, d_records.ptr, dist_capacity);           \
+                                                              d_new_req.ptr, d_req_other.ptr, d_records.ptr, dist_capacity,            \
+                                                              (tiled_rounds > round) ? 1u : 0u);                                       \
     span = ctx->spanBegin(FAM_LOGLIK);                                                                                                 \
-    gibbsConditionalKernel<W><<<dim3(work_blocks), dim3(256), 0, st>>>(                                                                \
-        pr, d_hdr.ptr, d_entries.ptr, d_req_other.ptr, groups->mat_val_off.ptr, groups->mat_row_off.ptr, groups->mat_fast.ptr,         \
-        groups->mat_mid.ptr, groups->mat_rows.ptr, groups->mat_cols.ptr, groups->values.ptr, groups->row_count.ptr,                    \
-        groups->row_noise.ptr, d_dist.ptr);                                                                                            \
+    if (tiled_rounds > round) {                                                                                                        \
+        gibbsConditionalTileKernel<W><<<dim3(work_blocks), dim3(256), 0, st>>>(                                                        \
+            pr, d_hdr.ptr, d_entries.ptr, d_req_other.ptr, groups->mat_val_off.ptr, groups->mat_row_off.ptr, groups->mat_fast.ptr,     \
+            groups->mat_mid.ptr, groups->mat_rows.ptr, groups->mat_cols.ptr, groups->values.ptr, groups->row_count.ptr,                \
+            groups->row_noise.ptr, d_dist.ptr);                                                                                        \
+    } else {                                                                                                                           \
+        gibbsConditionalKernel<W><<<dim3(work_blocks), dim3(256), 0, st>>>(                                                            \
+            pr, d_hdr.ptr, d_entries.ptr, d_req_other.ptr, groups->mat_val_off.ptr, groups->mat_row_off.ptr, groups->mat_fast.ptr,     \
+            groups->mat_mid.ptr, groups->mat_rows.ptr, groups->mat_cols.ptr, groups->values.ptr, groups->row_count.ptr,                \
+            groups->row_noise.ptr, d_dist.ptr);                                                                                        \
+    }                                                                                                                                  \
     ctx->spanEnd(span)
             if (GS == 1) {
                 RPVG_GIBBS_ROUND(1);

@@ -309,8 +309,11 @@ class DeviceGroups:
             first = np.ctypeslib.as_array(v.first, shape=(total,)).copy() if total else np.zeros(0, np.uint32)
             second = np.ctypeslib.as_array(v.second, shape=(total,)).copy() if total else np.zeros(0, np.uint32)
             count = np.ctypeslib.as_array(v.count, shape=(total,)).copy() if total else np.zeros(0, np.uint32)
-            words = np.ctypeslib.as_array(v.words_consumed, shape=(len(generator_problems),)).copy()
-            state = np.ctypeslib.as_array(v.generator_state, shape=(len(generator_problems), 624)).copy()
+            if len(generator_problems):
+                words = np.ctypeslib.as_array(v.words_consumed, shape=(len(generator_problems),)).copy()
+                state = np.ctypeslib.as_array(v.generator_state, shape=(len(generator_problems), 624)).copy()
+            else:
+                words, state = np.zeros(0, np.uint64), np.zeros((0, 624), np.uint32)
             out = []
             for i in range(len(mt)):
                 a, b = int(off[i]), int(off[i + 1])

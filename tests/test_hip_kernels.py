@@ -807,3 +807,24 @@ def test_device_gibbs_sampler_follows_a_python_model_draw_for_draw(hip_ctx, grou
     for g, taken in enumerate(want_words):
         if taken >= 624:
             assert [_mt_temper(int(x)) for x in state[g]] == streams[g][taken - 624:taken]
+
+
+def test_device_gibbs_sampler_reports_what_it_does_not_take(hip_ctx):
+    """Group sizes above 2 are 'unsupported' (the caller's host-driven sampler takes them), a problem on a matrix that does
+    not exist is an invalid argument, and a call without problems is an empty result."""
+    from rpvg_amd import hip as hip_mod
+    clusters = small_cases.make_batch_clusters(813, n_clusters=3, with_empty=False)
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    groups = [[[p] for p in range(len(cl["paths"]))] for cl in clusters]
+    dg = hip_ctx.groups(dev, list(range(len(clusters))), groups, False)
+    log_freq = [np.zeros(len(g)) for g in groups]
+    words = [_mt19937_words(5, 0, 624)]
+    with pytest.raises(hip_mod.EngineError) as unsupported:
+        dg.gibbs([0], 3, [10], [50], [100], log_freq[:1], [[0]], words)
+    assert "group size 3" in str(unsupported.value)
+    with pytest.raises(hip_mod.EngineError) as invalid:
+        dg.gibbs([7], 2, [10], [50], [100], log_freq[:1], [[0]], words)
+    assert "matrix 7" in str(invalid.value)
+    got, consumed, _, (rounds, conditionals) = dg.gibbs([], 2, [], [], [], [], [], np.zeros((0, 624), np.uint32))
+    assert got == [] and len(consumed) == 0 and rounds == 0 and conditionals == 0
