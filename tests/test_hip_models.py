@@ -237,6 +237,39 @@ def test_gibbs_seeds_of_the_parity_sweep(engine, seed):
     assert fuzz_parity.run_case(engine, case, oracle_threads=8) == []
 
 
+def test_independent_inference_with_gibbs_posteriors_is_statistically_the_reference(engine):
+    """--ind-hap-inference with --use-hap-gibbs: the transcripts of a cluster share the cluster's generator (one generator,
+    several problems in rpvg_hip_group_gibbs: their chains take consecutive slices of its words).  The reference runs a
+    transcript's chains and then samples that transcript's subsets before the next transcript's chains; the batch computes
+    all posteriors first, so the comparison is statistical: reads conserved, every cluster's abundances
+    within a few percent of the oracle's where the oracle puts most of its reads, and reproducible from the seed."""
+    clusters = small_cases.make_batch_clusters(693, n_clusters=10, max_reads=300, with_empty=False)
+    batch = ClusterBatch.from_clusters(clusters)
+    params = make_params(use_hap_gibbs=1, ind_hap_inference=1, ploidy=2, rng_seed=5)
+    ref, _ = pyoracle.run("haplotype-transcripts", params, batch, 1)
+    got, _ = engine.run("haplotype-transcripts", params, engine.prepare(batch))
+    again, _ = engine.run("haplotype-transcripts", params, engine.prepare(batch))
+    close = 0
+    for g, r, a in zip(got, ref, again):
+        assert g.total_count == r.total_count
+        assert np.array_equal(g.abundances, a.abundances) and g.path_group_sets == a.path_group_sets
+        if g.total_count > 0 and len(g.abundances):
+            assert abs(g.abundances.sum() + g.noise_count - g.total_count) <= 1e-9 * g.total_count
+            assert np.all(np.isfinite(g.abundances)) and np.all(g.abundances >= 0)
+            per_path = []
+            for estimates in (g, r):
+                totals = {}
+                for group_set, (_, members) in estimates.keyed().items():
+                    for path, abundance in zip(group_set, members):
+                        totals[path] = totals.get(path, 0.0) + abundance
+                per_path.append(totals)
+            moved = sum(abs(per_path[0].get(path, 0.0) - per_path[1].get(path, 0.0)) for path in set(per_path[0]) | set(per_path[1]))
+            close += bool(moved <= 0.25 * max(1.0, r.total_count))
+        else:
+            close += 1
+    assert close >= 8, f"only {close} of {len(got)} clusters near the oracle's abundances"
+
+
 def test_gibbs_posteriors_agree_with_exact_posteriors_statistically(engine):
     """Size-independent property: the Gibbs frequencies of the dominant diplotypes approach the exact
     (branch-and-bound) posteriors."""
