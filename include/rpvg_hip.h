@@ -233,7 +233,7 @@ int rpvg_hip_group_conditionals(rpvg_hip_ctx * ctx, const rpvg_hip_groups * grou
  * The sets of a problem come in the order the reference appends them to path_group_sets (first appearance).
  * Returns RPVG_HIP_ERR_UNSUPPORTED, having changed nothing, for other group sizes, when the distributions outgrow the
  * memory reserved for them (RPVG_HIP_GIBBS_BYTES; default: room for every column of every problem as the other member,
- * at most two fifths of the free device memory and 64 GiB) and when the chains are not done after 8 192 rounds of requests:
+ * at most a quarter of the free device memory and 32 GiB) and when the chains are not done after 8 192 rounds of requests:
  * the caller then drives the sampler itself through rpvg_hip_group_conditionals. */
 typedef struct rpvg_hip_gibbs_spec {
     uint32_t num_problems;

@@ -1134,7 +1134,7 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
         const char * env = std::getenv("RPVG_HIP_GIBBS_BYTES");  // (read per call: a test switches it)
         size_t free_bytes = 0, total_bytes = 0;
         RPVG_HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
-        long double budget = env ? std::strtold(env, nullptr) : std::min<long double>(0.4L * free_bytes, 64.0L * (1ull << 30));
+        long double budget = env ? std::strtold(env, nullptr) : std::min<long double>(0.25L * free_bytes, 32.0L * (1ull << 30));  // (two host lanes ask at the same time)
         dist_capacity = static_cast<uint64_t>(std::min<long double>(dist_bound, budget / 8));
         dist_capacity = std::max<uint64_t>(dist_capacity, 1);
     }
