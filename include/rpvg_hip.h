@@ -177,7 +177,9 @@ typedef struct rpvg_hip_group_spec {
     int32_t normalise;
     /* > 0 (normalised matrices only): replay readCollapseProbabilityMatrix (src/path_estimator.cpp:197-259, called
      * on every normalised group matrix, src/path_abundance_estimator.cpp:380,443) with this prob_precision — every
-     * row takes the values of the head of its run in the reference's tolerant row order; 0: rows stay as built. */
+     * row takes the values of the head of its run in the reference's tolerant row order; 0: rows stay as built.
+     * With the collapse a call takes at most 2^20 - 1 matrices and 2^31 - 1 rows (RPVG_HIP_ERR_INVALID beyond: the
+     * matrices of a larger batch are built in several calls). */
     double collapse_precision;
 } rpvg_hip_group_spec;
 

@@ -567,6 +567,13 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     }
     g->h_num_cols = cols;
     g->h_num_rows = rows;
+    // the row collapse keeps the matrix of a row in 20 bits of its sort key and rows in 31 (row_collapse.hip)
+    if (collapse && (M >= kCollapseMaxMatrices || row_total > 0x7fffffffull)) {
+        setError("rpvg_hip_groups_build: the row collapse takes up to %u matrices and 2^31 - 1 rows per call (got %u matrices, %llu rows): "
+                 "build the matrices of a batch in several calls", kCollapseMaxMatrices - 1, M, static_cast<unsigned long long>(row_total));
+        delete g;
+        return RPVG_HIP_ERR_INVALID;
+    }
     if (M == 0) {
         *groups_out = g;
         return RPVG_HIP_OK;
