@@ -1222,6 +1222,8 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     const double ask_ahead = (GS == 2 && ask_ahead_env > 0) ? ask_ahead_env : 2.0;
     // rounds (from the first) whose conditionals go through the tile kernel (A/B)
     static const uint32_t tiled_rounds = std::getenv("RPVG_HIP_GIBBS_TILED_ROUNDS") ? static_cast<uint32_t>(std::atoi(std::getenv("RPVG_HIP_GIBBS_TILED_ROUNDS"))) : 1u;
+    static const uint32_t follow_modes = std::getenv("RPVG_HIP_GIBBS_FOLLOW_MODES") ? static_cast<uint32_t>(std::atoi(std::getenv("RPVG_HIP_GIBBS_FOLLOW_MODES"))) : 2u;
+    static const double follow_share = std::getenv("RPVG_HIP_GIBBS_FOLLOW_SHARE") ? std::atof(std::getenv("RPVG_HIP_GIBBS_FOLLOW_SHARE")) : 0.1;
     static const bool debug = std::getenv("RPVG_HIP_GIBBS_DEBUG") != nullptr;
     DeviceBuffer<unsigned long long> d_debug;
     if (debug) {
@@ -1271,8 +1273,30 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
                 RPVG_GIBBS_ROUND(2);
             }
 #undef RPVG_GIBBS_ROUND
+            const bool follows = round == 0 && GS == 2 && follow_modes > 0;
             gibbsDistributionKernel<<<dim3(work_blocks), dim3(256), 0, st>>>(pr, d_hdr.ptr, d_new_req.ptr, groups->mat_cols.ptr, d_records.ptr, d_dist.ptr,
-                                                                            ask_ahead, d_prob_count.ptr, d_prob_done.ptr, d_active_problem.ptr, d_req_other.ptr, d_hdr.ptr);
+                                                                            follows ? follow_share : ask_ahead, d_prob_count.ptr, d_prob_done.ptr,
+                                                                            d_active_problem.ptr, d_req_other.ptr, d_hdr.ptr);
+            // Behind the first round the conditionals of the columns the chains are about to draw — the columns that hold a
+            // tenth or more of a distribution just evaluated — are evaluated twice over before the chains move again: a chain
+            // from a random start needs the conditional of its first draw, then that of its second, and each was a round of all
+            // 60 000 chains of a configs[4] lane (rounds 1-3: 1.3, 6.0 and 12.6 M draws; now 19.6 M draws in the first round
+            // behind the starts and 2 500 chains left after it).  The same conditionals as before, to 0.002 % of the
+            // evaluations: they are the ones the chains ask for anyway.  (RPVG_HIP_GIBBS_FOLLOW_MODES=n, _FOLLOW_SHARE=x)
+            for (uint32_t f = 0; follows && f < follow_modes; ++f) {
+                gibbsRequestOffsetsKernel<<<dim3(1), dim3(1024), 0, st>>>(pr, groups->mat_cols.ptr, groups->mat_rows.ptr, d_hdr.ptr, d_active_problem.ptr,
+                                                                          d_prob_count.ptr, d_prob_done.ptr, d_entries.ptr, d_new_req.ptr, d_req_other.ptr,
+                                                                          d_records.ptr, dist_capacity, 0u);
+                span = ctx->spanBegin(FAM_LOGLIK);
+                gibbsConditionalKernel<2><<<dim3(work_blocks), dim3(256), 0, st>>>(
+                    pr, d_hdr.ptr, d_entries.ptr, d_req_other.ptr, groups->mat_val_off.ptr, groups->mat_row_off.ptr, groups->mat_fast.ptr,
+                    groups->mat_mid.ptr, groups->mat_rows.ptr, groups->mat_cols.ptr, groups->values.ptr, groups->row_count.ptr,
+                    groups->row_noise.ptr, d_dist.ptr);
+                ctx->spanEnd(span);
+                gibbsDistributionKernel<<<dim3(work_blocks), dim3(256), 0, st>>>(pr, d_hdr.ptr, d_new_req.ptr, groups->mat_cols.ptr, d_records.ptr, d_dist.ptr,
+                                                                                (f + 1 < follow_modes) ? follow_share : ask_ahead, d_prob_count.ptr,
+                                                                                d_prob_done.ptr, d_active_problem.ptr, d_req_other.ptr, d_hdr.ptr);
+            }
         }
         RPVG_HIP_CHECK(hipGetLastError());
         RPVG_HIP_CHECK(hipMemcpyAsync(&progress->remaining, d_remaining.ptr + (round - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
