@@ -247,13 +247,16 @@ __global__ __launch_bounds__(256) void gibbsAdvanceKernel(const uint32_t num_cha
     uint32_t run_length = 0;
     uint64_t run_at = 0;
     bool waiting = false;
-    // The generator's words come through a window of sixteen per thread in LDS (word j of thread t at [j][t]): one trip to
-    // memory per eight draws — the sixteen loads of a refill are in flight together — where a load per draw was a trip to L2
-    // per draw (a wave's 64 chains read 64 different lines: the lines of 16 waves do not stay in the CU's 32 KB).
-    __shared__ uint32_t word_window[kWordWindow * 256];
-    uint32_t * window = word_window + threadIdx.x;
-    unsigned long long window_pos = 0;  // stream position of the window's first word
-    bool window_filled = false;
+    // The generator's words of the next four draws wait in registers: every draw asks for the pair four draws ahead, the same
+    // two loads in every lane (a window of sixteen words in LDS, refilled by whichever lanes ran out, put an 80-instruction
+    // block that some lane of the wave needed at nearly every draw into the loop; a pair fetched one draw ahead arrived late).
+    constexpr int kAheadDraws = 4;
+    uint32_t ahead_first[kAheadDraws], ahead_second[kAheadDraws];
+#pragma unroll
+    for (int d = 0; d < kAheadDraws; ++d) {
+        ahead_first[d] = (G >= 2) ? stream[pos + 2 * d] : 0u;  // (past a slice: the next chain's words, or the slack behind the last)
+        ahead_second[d] = (G >= 2) ? stream[pos + 2 * d + 1] : 0u;
+    }
     while (true) {
         uint32_t drawn = 0;
         if (G >= 2) {
@@ -281,17 +284,14 @@ __global__ __launch_bounds__(256) void gibbsAdvanceKernel(const uint32_t num_cha
                 ++n_lookups;
             }
             ++n_draws;
-            if (!window_filled || pos - window_pos > kWordWindow - 2) {
-                uint32_t fetched[kWordWindow];
+            const double u = rpvg_streams::canonicalFromWords(ahead_first[0], ahead_second[0]);
 #pragma unroll
-                for (uint32_t j = 0; j < kWordWindow; ++j) fetched[j] = stream[pos + j];  // (past a slice: the next chain's words, or the slack behind the last)
-#pragma unroll
-                for (uint32_t j = 0; j < kWordWindow; ++j) window[j * 256] = fetched[j];
-                window_pos = pos;
-                window_filled = true;
+            for (int d = 0; d + 1 < kAheadDraws; ++d) {
+                ahead_first[d] = ahead_first[d + 1];
+                ahead_second[d] = ahead_second[d + 1];
             }
-            const uint32_t at = static_cast<uint32_t>(pos - window_pos);
-            const double u = rpvg_streams::canonicalFromWords(window[at * 256], window[(at + 1) * 256]);
+            ahead_first[kAheadDraws - 1] = stream[pos + 2 * kAheadDraws];
+            ahead_second[kAheadDraws - 1] = stream[pos + 2 * kAheadDraws + 1];
             pos += 2;
             if (held[s].mode_below < u && u <= held[s].mode_upto) {
                 drawn = held[s].mode;
@@ -1179,7 +1179,7 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     DeviceBuffer<uint32_t> d_out;  // first | second | count | sequence, out_capacity each
     DeviceBuffer<uint32_t> d_final_state;
     RPVG_HIP_CHECK(d_final_state.alloc(static_cast<size_t>(NG) * rpvg_streams::kMtWords));
-    RPVG_HIP_CHECK(d_stream.alloc(stream_off[NG] + kWordWindow));  // (the chains fetch their words a window at a time)
+    RPVG_HIP_CHECK(d_stream.alloc(stream_off[NG] + kWordWindow));  // (the chains fetch their words four draws ahead)
     RPVG_HIP_CHECK(d_chain_problem.alloc(num_chains));
     RPVG_HIP_CHECK(d_chain_cur.alloc(2 * num_chains));
     RPVG_HIP_CHECK(d_chain_iter.alloc(num_chains));
