@@ -219,8 +219,11 @@ __global__ __launch_bounds__(256) void gibbsAdvanceKernel(const uint32_t num_cha
                                                           const uint32_t * __restrict__ prob_done, GibbsHeader * hdr, uint32_t * remaining,
                                                           uint32_t * active_problem, uint32_t * req_other,
                                                           const double * __restrict__ dist, unsigned long long * tab_key, uint32_t * tab_count,
-                                                          uint32_t * tab_first, unsigned long long * debug_counts) {
-    const uint32_t ci = blockIdx.x * 256 + threadIdx.x;
+                                                          uint32_t * tab_first, unsigned long long * debug_counts, const uint32_t chains_per_wave) {
+    // A wave runs the union of the paths its chains take at every draw, and 60 000 chains in waves of 64 are one wave per SIMD
+    // with nothing to hide a latency behind: the first chains_per_wave lanes of a wave carry a chain, the others leave.
+    if ((threadIdx.x & 63u) >= chains_per_wave) return;
+    const uint32_t ci = ((blockIdx.x * 256 + threadIdx.x) >> 6) * chains_per_wave + (threadIdx.x & 63u);
     if (ci >= num_chains) return;
     uint32_t n_draws = 0, n_lookups = 0, n_off_mode = 0, n_walked = 0, n_keys = 0;  // RPVG_HIP_GIBBS_DEBUG
     uint32_t flag = ch.flag[ci];
@@ -1232,7 +1235,8 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     }
     scope.reset(new HostScope("group_gibbs: rounds"));
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
-    const uint32_t advance_blocks = static_cast<uint32_t>((num_chains + 255) / 256);
+    static const uint32_t chains_per_wave = std::getenv("RPVG_HIP_GIBBS_CHAINS_PER_WAVE") ? std::min(64, std::max(1, std::atoi(std::getenv("RPVG_HIP_GIBBS_CHAINS_PER_WAVE")))) : 8u;  // (64 / 16 / 8 chains per wave: 3.7 / 3.2 / 2.6 ms for the five long rounds of a configs[4] lane)
+    const uint32_t advance_blocks = static_cast<uint32_t>((num_chains + 4 * chains_per_wave - 1) / (4 * chains_per_wave));
     const uint32_t work_blocks = cus * 8;
     uint32_t round = 0;
     bool finished = false;
@@ -1249,7 +1253,7 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     gibbsAdvanceKernel<W><<<dim3(advance_blocks), dim3(256), 0, st>>>(                                                                 \
         static_cast<uint32_t>(num_chains), round, pr, groups->mat_cols.ptr, ch, d_stream.ptr, d_records.ptr, d_prob_count.ptr,         \
         d_prob_done.ptr, d_hdr.ptr, d_remaining.ptr, d_active_problem.ptr, d_req_other.ptr, d_dist.ptr, d_tab_key.ptr,                 \
-        d_tab_count.ptr, d_tab_first.ptr, d_debug.ptr);                                                                                \
+        d_tab_count.ptr, d_tab_first.ptr, d_debug.ptr, chains_per_wave);                                                               \
     gibbsRequestOffsetsKernel<<<dim3(1), dim3(1024), 0, st>>>(pr, groups->mat_cols.ptr, groups->mat_rows.ptr, d_hdr.ptr,               \
                                                               d_active_problem.ptr, d_prob_count.ptr, d_prob_done.ptr, d_entries.ptr,  \
                                                               d_new_req.ptr, d_req_other.ptr, d_records.ptr, dist_capacity,            \
