@@ -417,7 +417,7 @@ int rpvg_hip_debug_log(rpvg_hip_ctx * ctx, uint64_t n, const double * x, double 
 /* The EM kernels of rpvg_hip_em_solve (rpvg_amd/csrc/em_sparse.hip): one variant per size bin of the problems; each
  * carries its own device time (HIP events on the stream it is launched on), launches, problems, EM iterations and
  * algorithmic bytes (per iteration of a problem 12 B/entry + 20 B/row + 16 B/column). */
-#define RPVG_HIP_EM_KERNELS 11
+#define RPVG_HIP_EM_KERNELS 12
 typedef struct rpvg_hip_em_kernel_stats {
     double ms;               /* sum over launches of the HIP-event span around the launch on its own stream */
     uint64_t launches;

@@ -191,6 +191,25 @@ class ClusterBatch:
             rows.append((int(self.row_count[r]), float(self.row_noise[r]), groups))
         return dict(paths=paths, rows=rows)
 
+    @staticmethod
+    def concat(batches: Sequence["ClusterBatch"]) -> "ClusterBatch":
+        """The clusters of several batches back to back."""
+        def offs(name):
+            parts, base = [np.zeros(1, dtype=np.uint64)], 0
+            for b in batches:
+                o = getattr(b, name).astype(np.uint64)
+                parts.append(o[1:] + np.uint64(base))
+                base += int(o[-1])
+            return np.concatenate(parts)
+
+        def cat(name):
+            return np.concatenate([getattr(b, name) for b in batches])
+
+        return ClusterBatch(
+            offs("cluster_row_off"), offs("cluster_path_off"), cat("row_count"), cat("row_noise"), offs("row_grp_off"),
+            cat("grp_prob"), offs("grp_idx_off"), cat("path_idx"), cat("path_group_id"), cat("path_source_count"),
+            offs("path_source_off"), cat("source_id"), cat("path_effective_length"))
+
     def select(self, ks: Sequence[int]) -> "ClusterBatch":
         """Sub-batch holding clusters ks (in that order); used to shard a batch across ranks."""
         ks = np.asarray(ks, dtype=np.int64)

@@ -705,6 +705,9 @@ struct EmProblemList {
     uint32_t max_cols = 0;                    // columns (paths + noise) of the widest problem, or a bound
     uint32_t max_cluster_paths = 0;           // paths of the widest cluster a problem sits on, or a bound
     unsigned long long wide_capacity = 0;     // doubles for the vectors of the problems too wide for LDS
+    // rows + entries of the largest cluster a problem sits on (a bound of what a problem keeps): at or above the grid
+    // threshold (emGridMinWork()) the solve looks for problems of the grid bin and solves them over the whole GPU (em_grid.hip)
+    uint64_t max_cluster_work = 0;
 };
 
 struct EmOutputs {  // device arrays, [P] unless noted
@@ -733,6 +736,70 @@ struct EmSolveWork {  // scratch of one solve: lives until its kernels are done
 };
 size_t emQueuesBytes();
 uint32_t emFillSegmentRows();
+
+// ---- EM problems too large for one workgroup (em_grid.hip, em_dense.hip) -----------------------------
+// The stop rule of the EM on the device (src/path_abundance_estimator.cpp:67-95) for the solvers that run one iteration
+// per round of launches: the launches of an iteration exit at once when `done` is set, so the host queues iterations in
+// chunks without a synchronisation per iteration and the loop still stops at the reference's iteration.
+struct EmGridControl {
+    uint32_t done;
+    uint32_t iterations;
+    uint32_t conv_its;
+    uint32_t viol;     // OR of the per-column convergence violations of the current iteration
+    uint32_t error;    // row-sharded runs: some rank's column sums were not finite (the status word of the all-reduce)
+    uint32_t arrived;  // workgroups of the update kernel that are through (the last one applies the stop rule)
+};
+
+// One problem of the grid bin as the device describes it to the host (emGridDescribeKernel, em_sparse.hip).
+struct EmGridProblem {
+    uint32_t problem, columns;  // index in the list; paths + noise
+    uint32_t rows, entries;     // kept rows / entries (its compacted CSR)
+    uint32_t merged, pad;       // the row collapse merged rows of it: the EM reads the merged read counts
+    uint64_t row_base, ent_base, col_begin;
+    double total_mass, zero_mass;
+};
+
+// device arrays of the solve the problems belong to
+struct EmGridStorage {
+    const uint32_t * prow_off;
+    const double * prow_count;
+    const double * merged_count;  // NULL: no collapse
+    const double * prow_noise;
+    const uint32_t * pent_col;
+    const double * pent_val;
+    double * abundances;
+    double * noise_count;
+    uint32_t * iterations;
+};
+
+// rows + entries from which a problem leaves the one-workgroup kernels (RPVG_HIP_EM_GRID_MIN_WORK; 0: never)
+uint64_t emGridMinWork();
+// whether a problem of the grid bin is solved on a dense row-major copy (em_dense.hip's streaming kernels) rather than
+// on its CSR: the dense matrix is the smaller one (8 B per cell against 12 B per entry) and narrow enough for a
+// register-resident row
+bool emGridDenseRoute(uint32_t columns, uint32_t rows, uint32_t entries);
+// Solves the described problems one after the other on `st`, every launch over the whole GPU; host-driven (waits for the
+// stream).  Caller holds ctx->mutex and has set the device.
+int runEmGridProblems(rpvg_hip_ctx * ctx, hipStream_t st, const EmGridProblem * problems, uint32_t count, const EmGridStorage & storage,
+                      uint32_t max_em_its, double max_rel_em_conv);
+
+// The dense streaming EM of em_dense.hip on a resident row-major matrix, up to the stop rule; the abundance vector stays
+// on the device (d_a, C doubles).  zero_mass: read mass of the rows the matrix does not hold because they touch no
+// selected path — the noise component takes it whole (em_sparse.hip).  Caller holds ctx->mutex and has set the device.
+struct DenseEmRun {
+    const double * matrix = nullptr;
+    uint64_t num_rows = 0;
+    uint32_t num_cols = 0;
+    uint64_t ld = 0;
+    const double * counts = nullptr;
+    double total_count = 0, zero_mass = 0;
+    uint32_t max_em_its = 0;
+    double max_rel_em_conv = 0;
+    bool sharded = false;
+    DeviceBuffer<double> d_a;
+    EmGridControl control = {};
+};
+int emDenseIterate(rpvg_hip_ctx * ctx, const char * who, DenseEmRun & run);
 
 // collapse_precision > 0: readCollapseProbabilityMatrix on the rows of every problem (prob_precision of the reference)
 int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProblemList & list, uint32_t max_em_its,

@@ -40,13 +40,7 @@ constexpr double kMinEmAbundance = 1e-8;  // src/path_abundance_estimator.cpp:11
 constexpr uint32_t kMinEmConvIts = 10;    // src/path_abundance_estimator.cpp:10
 constexpr int kAccumBlock = 256;          // 4 waves
 
-struct DenseControl {
-    uint32_t done;
-    uint32_t iterations;
-    uint32_t conv_its;
-    uint32_t viol;  // OR of per-column convergence violations of the current iteration
-    uint32_t error; // row-sharded runs: some rank's column sums were not finite (the status word of the all-reduce)
-};
+typedef EmGridControl DenseControl;  // common.hpp: the stop rule's words on the device
 
 typedef double dvec2 __attribute__((ext_vector_type(2)));
 
@@ -240,7 +234,7 @@ __global__ void emDenseReducePartialsKernel(const uint32_t C, const uint32_t num
 __global__ void emDenseFinalizeKernel(const uint32_t C, const uint32_t num_partials, const uint32_t partial_ld,
                                       const double * __restrict__ partials, double * __restrict__ a_global,
                                       const double total_count, const double max_rel_em_conv, DenseControl * ctl,
-                                      const double * __restrict__ status = nullptr) {
+                                      const double * __restrict__ status = nullptr, const double zero_mass = 0.0) {
     if (ctl->done) return;
     if (status && *status != 0.0) {  // (summed over the ranks: somebody's column sums were not finite)
         if (blockIdx.x == 0 && threadIdx.x == 0) ctl->error = 1;
@@ -252,7 +246,9 @@ __global__ void emDenseFinalizeKernel(const uint32_t C, const uint32_t num_parti
         double tj = 0.0;
         for (uint32_t b = 0; b < num_partials; ++b) tj += partials[static_cast<uint64_t>(b) * partial_ld + j];
         const double aj = a_global[j];
-        const double an = (aj * tj) / total_count;
+        // (zero_mass: the rows without a selected path, which the matrix of an rpvg_hip_em_solve problem does not hold, put
+        // their whole read count on the noise component — em_sparse.hip; 0 for a matrix that holds every row)
+        const double an = (j + 1 == C ? aj * tj + zero_mass : aj * tj) / total_count;
         if (an >= kMinEmAbundance && fabs(an - aj) / an > max_rel_em_conv) viol = 1;
         a_global[j] = an;
     }
@@ -432,6 +428,54 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
     RPVG_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint32_t C = num_cols;
+    DenseEmRun run;
+    run.matrix = device_matrix;
+    run.num_rows = num_rows;
+    run.num_cols = num_cols;
+    run.ld = ld;
+    run.counts = device_counts;
+    run.total_count = total_count;
+    run.max_em_its = max_em_its;
+    run.max_rel_em_conv = max_rel_em_conv;
+    run.sharded = sharded;
+    if (const int rc = emDenseIterate(ctx, who, run)) return rc;
+
+    std::vector<double> a(C);
+    RPVG_HIP_CHECK(hipMemcpyAsync(a.data(), run.d_a.ptr, sizeof(double) * C, hipMemcpyDeviceToHost, st));
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+
+    // src/path_abundance_estimator.cpp:100-113
+    double nc = 0;
+    for (uint32_t j = 0; j + 1 < C; ++j) {
+        if (a[j] < kMinEmAbundance) {
+            nc += a[j] * total_count;
+            abundances[j] = 0;
+        } else {
+            abundances[j] = a[j] * total_count;
+        }
+    }
+    nc += a[C - 1] * total_count;
+    *noise_count = nc;
+    *iterations = run.control.iterations;
+    return RPVG_HIP_OK;
+}
+
+}  // namespace
+
+namespace rpvg_hip_detail {
+
+// The iterations of the dense EM up to the stop rule (the body of rpvg_hip_em_dense[_sharded]; also the dense route of the
+// large problems of rpvg_hip_em_solve, em_grid.hip).  Caller holds ctx->mutex, has set the device and checked the shape.
+int emDenseIterate(rpvg_hip_ctx * ctx, const char * who, DenseEmRun & run) {
+    hipStream_t st = ctx->stream;
+    const uint32_t C = run.num_cols;
+    const uint64_t num_rows = run.num_rows, ld = run.ld;
+    const double * device_matrix = run.matrix;
+    const double * device_counts = run.counts;
+    const double total_count = run.total_count, max_rel_em_conv = run.max_rel_em_conv, zero_mass = run.zero_mass;
+    const uint32_t max_em_its = run.max_em_its;
+    const bool sharded = run.sharded;
+    DeviceBuffer<double> & d_a = run.d_a;
 
     const uint32_t cus = ctx->props.multiProcessorCount;
     const bool wide = C > 256;  // row split over the block's waves (emDenseAccumWideKernel)
@@ -444,7 +488,7 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
     const uint32_t partial_ld = wide ? ((C + 511) / 512) * 512 : ((C + 1) & ~1u);
     const uint32_t reduce_slices = 16;
 
-    DeviceBuffer<double> d_a, d_partials, d_reduced, d_t;
+    DeviceBuffer<double> d_partials, d_reduced, d_t;
     if (wide) RPVG_HIP_CHECK(d_reduced.alloc(static_cast<size_t>(reduce_slices) * partial_ld));
     if (sharded) {
         RPVG_HIP_CHECK(d_t.alloc(partial_ld + 2));  // [C column sums | ... | status word at C]
@@ -466,9 +510,9 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
 
     const int nchunk = (C + 127) / 128;
     const uint32_t chunk_its = 8;  // iterations queued between looks at the control word
-    DenseControl h_ctl = {0, 0, 0, 0, 0};
+    DenseControl & h_ctl = run.control;
+    h_ctl = DenseControl{};
     uint32_t queued = 0;
-    uint64_t accum_launches = 0;
     // em_dense_ms (rpvg_hip_kernel_stats) = HIP-event time of the streaming-pass launches only
     while (!h_ctl.done) {
         const uint32_t n = std::min<uint32_t>(chunk_its, max_em_its - queued);
@@ -490,10 +534,10 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
                         return rc;
                     }
                     emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, 1, partial_ld, d_t.ptr, d_a.ptr, total_count,
-                                                                      max_rel_em_conv, d_ctl.ptr, d_t.ptr + C);
+                                                                      max_rel_em_conv, d_ctl.ptr, d_t.ptr + C, zero_mass);
                 } else {
                     emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, reduce_slices, partial_ld, d_reduced.ptr, d_a.ptr,
-                                                                      total_count, max_rel_em_conv, d_ctl.ptr);
+                                                                      total_count, max_rel_em_conv, d_ctl.ptr, nullptr, zero_mass);
                 }
                 emDenseControlKernel<<<dim3(1), dim3(1), 0, st>>>(d_ctl.ptr, max_em_its);
                 continue;
@@ -507,19 +551,18 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
             if (sharded) {
                 emDenseReducePartialsKernel<<<col_grid, dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_t.ptr, d_ctl.ptr, d_t.ptr + C);
                 if (const int rc = ctx->allReduceSumF64(d_t.ptr, C + 1)) {
-                        (void) hipStreamSynchronize(st);  // the kernels queued so far use the buffers freed on return
-                        return rc;
-                    }
+                    (void) hipStreamSynchronize(st);  // the kernels queued so far use the buffers freed on return
+                    return rc;
+                }
                 emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, 1, partial_ld, d_t.ptr, d_a.ptr, total_count,
-                                                                  max_rel_em_conv, d_ctl.ptr, d_t.ptr + C);
+                                                                  max_rel_em_conv, d_ctl.ptr, d_t.ptr + C, zero_mass);
             } else {
                 emDenseFinalizeKernel<<<col_grid, dim3(256), 0, st>>>(C, grid, partial_ld, d_partials.ptr, d_a.ptr,
-                                                                  total_count, max_rel_em_conv, d_ctl.ptr);
+                                                                  total_count, max_rel_em_conv, d_ctl.ptr, nullptr, zero_mass);
             }
             emDenseControlKernel<<<dim3(1), dim3(1), 0, st>>>(d_ctl.ptr, max_em_its);
         }
         queued += n;
-        accum_launches += n;
         RPVG_HIP_CHECK(hipGetLastError());
         RPVG_HIP_CHECK(hipMemcpyAsync(&h_ctl, d_ctl.ptr, sizeof(DenseControl), hipMemcpyDeviceToHost, st));
         RPVG_HIP_CHECK(hipStreamSynchronize(st));
@@ -530,34 +573,15 @@ int emDenseRun(rpvg_hip_ctx * ctx, const char * who, const bool sharded, const d
                  h_ctl.iterations + 1);
         return RPVG_HIP_ERR_RUNTIME;
     }
-    std::vector<double> a(C);
-    RPVG_HIP_CHECK(hipMemcpyAsync(a.data(), d_a.ptr, sizeof(double) * C, hipMemcpyDeviceToHost, st));
-    RPVG_HIP_CHECK(hipStreamSynchronize(st));
-
-    // src/path_abundance_estimator.cpp:100-113
-    double nc = 0;
-    for (uint32_t j = 0; j + 1 < C; ++j) {
-        if (a[j] < kMinEmAbundance) {
-            nc += a[j] * total_count;
-            abundances[j] = 0;
-        } else {
-            abundances[j] = a[j] * total_count;
-        }
-    }
-    nc += a[C - 1] * total_count;
-    *noise_count = nc;
-    *iterations = h_ctl.iterations;
-
     // launches that actually streamed the matrix = iterations executed
     ctx->stats.em_dense_launches += h_ctl.iterations;
     ctx->stats.em_dense_alg_bytes += static_cast<double>(h_ctl.iterations) *
                                      (8.0 * static_cast<double>(num_rows) * C + 8.0 * static_cast<double>(num_rows) + 16.0 * C);
     ctx->stats.em_iterations_total += h_ctl.iterations;
-    (void) accum_launches;
     return RPVG_HIP_OK;
 }
 
-}  // namespace
+}  // namespace rpvg_hip_detail
 
 extern "C" int rpvg_hip_em_dense(rpvg_hip_ctx * ctx, const double * device_matrix, uint64_t num_rows, uint32_t num_cols,
                                  uint64_t ld, const double * device_counts, double total_count, uint32_t max_em_its,

@@ -1,0 +1,450 @@
+// EM problems too large for one workgroup: every iteration runs over the whole GPU (gfx950).
+//
+// rpvg_hip_em_solve / rpvg_hip_nested_subset_em put every problem on ONE workgroup (em_sparse.hip): right for the
+// thousands of small problems of a batch, wrong for a cluster of 10^5 - 10^6 rows (a 200 000-row problem ran at 563 us
+// per EM iteration, 20 GB/s, on one of 256 CUs).  The reference's EMAbundanceEstimator
+// (src/path_abundance_estimator.cpp:47-114) takes a cluster of any size through the same call
+// (PathAbundanceEstimator::estimate, :18-45, src/main.cpp:977); here the size bin of a problem decides: a problem whose
+// kept rows + entries reach emGridMinWork() lands in the grid bin (emBinOf, em_sparse.hip), the device describes those
+// problems to the host (emGridDescribeKernel) and the host solves them one after the other with one round of launches
+// per EM iteration:
+//
+//   CSR route    emGridAccumKernel<LANES,UNROLL> grid-wide pass over the problem's compacted CSR; a workgroup owns a
+//                                               contiguous range of rows, abundance vector and accumulators in LDS,
+//                                               one partial column-sum vector per workgroup
+//                emGridUpdateKernel             column sums over the partials in a fixed order, the update
+//                                               a'_j = a_j t_j / T (noise: + Z), the convergence test, and — in the last
+//                                               workgroup through — the reference's stop rule
+//   dense route  a row-major copy of the problem (emGridDenseBuildKernel) and the streaming kernels of em_dense.hip,
+//                when the dense matrix is the smaller representation (8 B per cell against 12 B per entry) and a row
+//                fits the registers of a workgroup (C <= 2048): BASELINE.json configs[1], one 1M x 2k cluster, behind
+//                `-i transcripts` at the HBM roofline
+//
+// A dependent kernel boundary costs ~1.5 us on this GPU, a grid-wide barrier inside a persistent kernel 4-7 us
+// (MI355X_MICROARCH.md, price list: boundary / barrier-xcd), so the iterations are launches, not barriers; a device-side
+// `done` word makes the launches behind the last iteration return at once, the host queues iterations in chunks and
+// looks at the word between chunks (two chunks in flight), and the loop stops at exactly the reference's iteration.
+// Same arithmetic per row as emSparseProblem (em_sparse.hip): reciprocal + two Newton steps + residual correction.
+
+#include "common.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+using namespace rpvg_hip_detail;
+
+namespace {
+
+constexpr double kMinEmAbundance = 1e-8;   // src/path_abundance_estimator.cpp:11
+constexpr uint32_t kMinEmConvIts = 10;     // src/path_abundance_estimator.cpp:10
+constexpr int kGridBlock = 256;
+constexpr uint32_t kDenseMaxCols = 2048;   // em_dense.hip: a row in the registers of one workgroup
+
+struct GridAccumArgs {
+    const uint32_t * off;    // [rows + 1] entry offsets of the problem's rows (relative to col / val)
+    const double * cnt;      // [rows] read counts (after the row collapse, if it merged rows of the problem)
+    const double * nz;       // [rows] noise probabilities
+    const uint32_t * col;    // [entries]
+    const double * val;      // [entries] normalised probabilities
+    uint32_t rows, C;
+    uint32_t rows_per_block;
+    const double * a;        // [C] abundances (last = noise)
+    double * partials;       // [gridDim.x x partial_ld]
+    uint32_t partial_ld;
+    const EmGridControl * ctl;
+};
+
+// c / s as the one-workgroup kernels compute it (em_sparse.hip): hardware reciprocal, two Newton steps, one residual
+// correction of the quotient
+__device__ __forceinline__ double countOverSum(const double c, const double s) {
+    double y = __builtin_amdgcn_rcp(s);
+    y = fma(fma(-s, y, 1.0), y, y);
+    y = fma(fma(-s, y, 1.0), y, y);
+    const double quot = c * y;
+    // (a row whose count a row collapse moved to its run head takes no part: row_collapse.hip)
+    return c == 0.0 ? 0.0 : fma(fma(-s, quot, c), y, quot);
+}
+
+// sum over the LANES neighbouring lanes that share a row
+template <int LANES>
+__device__ __forceinline__ double rowLanesSum(double v) {
+    if (LANES == 64) return waveSumF64(v);
+#pragma unroll
+    for (int d = LANES / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, LANES);
+    return v;
+}
+
+// One streaming pass over the problem's CSR.  LANES lanes share a row (1: a thread per row — short rows, the entries of
+// neighbouring rows are neighbours in memory; 4 / 16 / 64: the lanes stride the row's entries, the row sum by shuffles
+// or DPP), and every row slot walks UNROLL rows at a time: their offsets, counts and noise are loaded together and their
+// entry loops follow each other without a dependent load in between — a pass is a chain of two dependent loads per row
+// (offsets, then entries), ~1 us each from L2 or memory, and with one row at a time that chain was the pass.
+template <int LANES, int UNROLL>
+__global__ __launch_bounds__(kGridBlock) void emGridAccumKernel(const GridAccumArgs args) {
+    if (args.ctl->done) return;
+    extern __shared__ __attribute__((aligned(16))) double grid_lds[];
+    const uint32_t C = args.C, noise_col = C - 1;
+    double * a = grid_lds;   // [C]
+    double * t = a + C;      // [C]
+    for (uint32_t j = threadIdx.x; j < C; j += kGridBlock) {
+        a[j] = args.a[j];
+        t[j] = 0.0;
+    }
+    __syncthreads();
+    constexpr uint32_t kSlots = kGridBlock / LANES;  // rows the workgroup holds at once
+    const uint32_t slot = threadIdx.x / LANES, sl = threadIdx.x % LANES;
+    const uint32_t r0 = blockIdx.x * args.rows_per_block;
+    const uint32_t r1 = min(args.rows, r0 + args.rows_per_block);
+    const double a_noise = a[noise_col];
+    double tn = 0.0;
+    for (uint32_t base = r0 + slot; base < r1; base += kSlots * UNROLL) {
+        uint32_t e0[UNROLL], e1[UNROLL];
+        double nz[UNROLL], c[UNROLL], s[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint32_t r = base + u * kSlots;
+            const bool ok = r < r1;
+            e0[u] = ok ? args.off[r] : 0u;
+            e1[u] = ok ? args.off[r + 1] : 0u;
+            nz[u] = ok ? args.nz[r] : 0.0;
+            c[u] = ok ? args.cnt[r] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            double x = 0.0;
+            for (uint32_t e = e0[u] + sl; e < e1[u]; e += LANES) x += args.val[e] * a[args.col[e]];
+            s[u] = x;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const double w = countOverSum(c[u], rowLanesSum<LANES>(s[u]) + nz[u] * a_noise);  // (no row: count 0, weight 0)
+            // (the columns of one row are distinct: the lanes of a row never meet on an accumulator)
+            for (uint32_t e = e0[u] + sl; e < e1[u]; e += LANES) atomicAdd(&t[args.col[e]], w * args.val[e]);
+            if (sl == 0) tn += w * nz[u];
+        }
+    }
+    // the noise column has no entries: its accumulator takes the per-wave sums of w * noise
+    tn = waveSumF64(tn);
+    if ((threadIdx.x & 63) == 0 && tn != 0.0) atomicAdd(&t[noise_col], tn);
+    __syncthreads();
+    double * out = args.partials + static_cast<uint64_t>(blockIdx.x) * args.partial_ld;
+    for (uint32_t j = threadIdx.x; j < C; j += kGridBlock) out[j] = t[j];
+}
+
+struct GridUpdateArgs {
+    uint32_t C, num_partials, partial_ld;
+    const double * partials;
+    double * a;
+    double inv_total, zero_mass, max_rel_em_conv;
+    uint32_t max_em_its;
+    EmGridControl * ctl;
+};
+
+// 64 columns per workgroup of sixteen waves: wave w adds the partials w, w + 16, ... of its columns (512-byte requests,
+// eight loads in flight: a partial comes from another XCD's L2 or from memory, ~1 us each — a first version with four
+// waves and one load at a time spent 40 us here per iteration), the sixteen slices meet in LDS in slice order — the order
+// of the additions is fixed.  The last workgroup through applies the stop rule.
+constexpr int kUpdateBlock = 1024;
+constexpr int kUpdateSlices = kUpdateBlock / 64;
+
+__global__ __launch_bounds__(kUpdateBlock) void emGridUpdateKernel(const GridUpdateArgs args) {
+    if (args.ctl->done) return;
+    __shared__ double slice_sum[kUpdateSlices][64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t j = blockIdx.x * 64 + lane;
+    double acc = 0.0;
+    if (j < args.C) {
+        const double * column = args.partials + j;
+        const uint64_t ld = args.partial_ld;
+        uint32_t b = wave;
+        for (; b + 7 * kUpdateSlices < args.num_partials; b += 8 * kUpdateSlices) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = column[static_cast<uint64_t>(b + u * kUpdateSlices) * ld];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; b < args.num_partials; b += kUpdateSlices) acc += column[static_cast<uint64_t>(b) * ld];
+    }
+    slice_sum[wave][lane] = acc;
+    __syncthreads();
+    int viol = 0;
+    if (wave == 0 && j < args.C) {
+        double tj = slice_sum[0][lane];
+#pragma unroll
+        for (int w = 1; w < kUpdateSlices; ++w) tj += slice_sum[w][lane];
+        const double aj = args.a[j];
+        // a'_j = a_j t_j / T;  a'_noise = (a_noise t_noise + Z) / T  (em_sparse.hip: the same roundings)
+        const double an = (j + 1 == args.C) ? (aj * tj + args.zero_mass) * args.inv_total : (aj * tj) * args.inv_total;
+        // |an - aj| / an > eps  (src/path_abundance_estimator.cpp:73-75), without the division
+        if (an >= kMinEmAbundance && fabs(an - aj) > args.max_rel_em_conv * an) viol = 1;
+        args.a[j] = an;
+    }
+    const int any_viol = __syncthreads_or(viol);
+    if (threadIdx.x == 0) {
+        EmGridControl * ctl = args.ctl;
+        if (any_viol) atomicOr(&ctl->viol, 1u);
+        __threadfence();
+        if (atomicAdd(&ctl->arrived, 1u) == gridDim.x - 1) {  // every workgroup's violations are in
+            const uint32_t v = atomicOr(&ctl->viol, 0u);
+            ctl->iterations += 1;
+            if (v == 0) {
+                ctl->conv_its += 1;
+                if (ctl->conv_its == kMinEmConvIts) ctl->done = 1;
+            } else {
+                ctl->conv_its = 0;
+            }
+            if (ctl->iterations >= args.max_em_its) ctl->done = 1;
+            ctl->viol = 0;
+            ctl->arrived = 0;
+        }
+    }
+}
+
+// src/path_abundance_estimator.cpp:100-113: expected read counts, sub-threshold components moved to the noise count
+__global__ __launch_bounds__(kGridBlock) void emGridFinishKernel(const uint32_t C, const double * __restrict__ a, const double T,
+                                                               const EmGridControl * __restrict__ ctl, double * __restrict__ abundances,
+                                                               double * __restrict__ noise_count, uint32_t * __restrict__ iterations) {
+    __shared__ double wave_low[kGridBlock / 64];
+    const uint32_t noise_col = C - 1;
+    double low = 0.0;
+    for (uint32_t j = threadIdx.x; j < noise_col; j += kGridBlock) {
+        const double aj = a[j];
+        if (aj < kMinEmAbundance) {
+            low += aj * T;
+            abundances[j] = 0;
+        } else {
+            abundances[j] = aj * T;
+        }
+    }
+    low = waveSumF64(low);
+    if ((threadIdx.x & 63) == 0) wave_low[threadIdx.x >> 6] = low;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total_low = wave_low[0];
+        for (int w = 1; w < kGridBlock / 64; ++w) total_low += wave_low[w];
+        *noise_count = total_low + a[noise_col] * T;
+        *iterations = ctl->iterations;
+    }
+}
+
+__global__ void gridFillKernel(double * x, const uint32_t n, const double v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+
+// dense row-major copy of a problem's CSR (zero-filled before): a wavefront per row
+__global__ __launch_bounds__(kGridBlock) void emGridDenseBuildKernel(const uint32_t rows, const uint32_t C, const uint64_t ld,
+                                                                   const uint32_t * __restrict__ off, const double * __restrict__ nz,
+                                                                   const uint32_t * __restrict__ col, const double * __restrict__ val,
+                                                                   double * __restrict__ matrix) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * (kGridBlock / 64);
+    for (uint32_t r = blockIdx.x * (kGridBlock / 64) + (threadIdx.x >> 6); r < rows; r += waves) {
+        double * out = matrix + static_cast<uint64_t>(r) * ld;
+        const uint32_t e0 = off[r], e1 = off[r + 1];
+        for (uint32_t e = e0 + lane; e < e1; e += 64) out[col[e]] = val[e];
+        if (lane == 0) out[C - 1] = nz[r];
+    }
+}
+
+template <int LANES, int UNROLL>
+hipError_t launchAccumVariant(const GridAccumArgs & args, const uint32_t grid, const size_t lds, hipStream_t st) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&emGridAccumKernel<LANES, UNROLL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    emGridAccumKernel<LANES, UNROLL><<<dim3(grid), dim3(kGridBlock), lds, st>>>(args);
+    return hipSuccess;
+}
+
+// lanes per row by the mean row length
+inline int gridRowLanes(const uint32_t rows, const uint32_t entries) {
+    if (const char * env = std::getenv("RPVG_HIP_EM_GRID_ROW_LANES")) return std::atoi(env);  // A/B knob: 1, 4, 16, 64
+    const double mean = static_cast<double>(entries) / std::max(1u, rows);
+    return mean < 6.0 ? 1 : mean < 24.0 ? 4 : mean < 96.0 ? 16 : 64;
+}
+
+hipError_t launchAccum(const int lanes, const GridAccumArgs & args, const uint32_t grid, const size_t lds, hipStream_t st) {
+    switch (lanes) {
+        case 1: return launchAccumVariant<1, 4>(args, grid, lds, st);
+        case 4: return launchAccumVariant<4, 4>(args, grid, lds, st);
+        case 16: return launchAccumVariant<16, 2>(args, grid, lds, st);
+        default: return launchAccumVariant<64, 2>(args, grid, lds, st);
+    }
+}
+
+}  // namespace
+
+namespace rpvg_hip_detail {
+
+uint64_t emGridMinWork() {
+    // (read per call: the tests take both ways)  The one-workgroup kernels stream ~1.4 work units (rows + entries) per
+    // nanosecond; an iteration over the whole GPU costs ~6 us of launches and reductions whatever the size: from ~10^5
+    // units the grid wins per iteration — but it takes its problems one after the other where the one-workgroup kernels
+    // take them side by side, so the threshold sits where ONE problem on one workgroup (>= 180 us per iteration) would
+    // outlast a batch's other work.
+    const char * env = std::getenv("RPVG_HIP_EM_GRID_MIN_WORK");
+    return env ? std::strtoull(env, nullptr, 10) : (1ull << 18);
+}
+
+bool emGridDenseRoute(const uint32_t columns, const uint32_t rows, const uint32_t entries) {
+    if (std::getenv("RPVG_HIP_EM_GRID_NO_DENSE")) return false;  // A/B knob
+    if (columns > kDenseMaxCols || columns < 2) return false;
+    const uint64_t ld = (static_cast<uint64_t>(columns) + 1) & ~1ull;
+    return 8ull * rows * ld <= 12ull * entries + 20ull * rows;
+}
+
+int runEmGridProblems(rpvg_hip_ctx * ctx, hipStream_t st, const EmGridProblem * problems, const uint32_t count, const EmGridStorage & storage,
+                      const uint32_t max_em_its, const double max_rel_em_conv) {
+    const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
+    for (uint32_t i = 0; i < count; ++i) {
+        const EmGridProblem & d = problems[i];
+        const uint32_t p = d.problem, C = d.columns, rows = d.rows;
+        const uint32_t * off = storage.prow_off + d.row_base + p;
+        const double * cnt = ((d.merged && storage.merged_count) ? storage.merged_count : storage.prow_count) + d.row_base;
+        const double * nz = storage.prow_noise + d.row_base;
+        const uint32_t * col = storage.pent_col + d.ent_base;
+        const double * val = storage.pent_val + d.ent_base;
+        double * out_abundances = storage.abundances + d.col_begin;
+
+        if (emGridDenseRoute(C, rows, d.entries)) {
+            const uint64_t ld = (static_cast<uint64_t>(C) + 1) & ~1ull;
+            DeviceBuffer<double> d_matrix;
+            RPVG_HIP_CHECK(d_matrix.alloc(static_cast<size_t>(rows) * ld));
+            const int span = ctx->spanBegin(FAM_BUILD, st);
+            RPVG_HIP_CHECK(hipMemsetAsync(d_matrix.ptr, 0, sizeof(double) * rows * ld, st));
+            const uint32_t build_grid = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(rows) + 3) / 4, static_cast<uint64_t>(cus) * 16));
+            emGridDenseBuildKernel<<<dim3(std::max(1u, build_grid)), dim3(kGridBlock), 0, st>>>(rows, C, ld, off, nz, col, val, d_matrix.ptr);
+            RPVG_HIP_CHECK(hipGetLastError());
+            ctx->spanEnd(span);
+            ctx->stats.build_launches += 1;
+            DenseEmRun run;
+            run.matrix = d_matrix.ptr;
+            run.num_rows = rows;
+            run.num_cols = C;
+            run.ld = ld;
+            run.counts = cnt;
+            run.total_count = d.total_mass;
+            run.zero_mass = d.zero_mass;
+            run.max_em_its = max_em_its;
+            run.max_rel_em_conv = max_rel_em_conv;
+            if (const int rc = emDenseIterate(ctx, "rpvg_hip_em_solve (dense route of a large problem)", run)) return rc;
+            DeviceBuffer<EmGridControl> d_ctl;
+            RPVG_HIP_CHECK(d_ctl.upload(&run.control, 1, st));
+            emGridFinishKernel<<<dim3(1), dim3(kGridBlock), 0, st>>>(C, run.d_a.ptr, d.total_mass, d_ctl.ptr, out_abundances, storage.noise_count + p,
+                                                                     storage.iterations + p);
+            RPVG_HIP_CHECK(hipGetLastError());
+            RPVG_HIP_CHECK(hipStreamSynchronize(st));  // (the buffers of this problem go back to the pool)
+            continue;
+        }
+
+        // ---- CSR route ----
+        const int row_lanes = gridRowLanes(rows, d.entries);
+        // workgroups: enough to fill the GPU, few enough that the partial vectors (written and read once per iteration,
+        // 16 B per column and workgroup) stay below the CSR's own bytes
+        const uint64_t csr_bytes = 12ull * d.entries + 20ull * rows;
+        const uint64_t slots = static_cast<uint64_t>(kGridBlock / row_lanes);
+        uint64_t blocks = (static_cast<uint64_t>(rows) + slots - 1) / slots;
+        blocks = std::min<uint64_t>(blocks, static_cast<uint64_t>(cus) * (row_lanes == 1 ? 2 : 4));
+        blocks = std::min<uint64_t>(blocks, std::max<uint64_t>(16, csr_bytes / (16ull * C)));
+        if (const char * env = std::getenv("RPVG_HIP_EM_GRID_BLOCKS")) blocks = std::max<uint64_t>(1, std::strtoull(env, nullptr, 10));  // A/B knob
+        blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, rows));
+        const uint32_t rows_per_block = static_cast<uint32_t>((static_cast<uint64_t>(rows) + blocks - 1) / blocks);
+        const uint32_t grid = (rows + rows_per_block - 1) / rows_per_block;
+        const uint32_t partial_ld = (C + 63) & ~63u;
+        const size_t lds = sizeof(double) * 2 * static_cast<size_t>(C);
+
+        DeviceBuffer<double> d_a, d_partials;
+        DeviceBuffer<EmGridControl> d_ctl;
+        RPVG_HIP_CHECK(d_a.alloc(C));
+        RPVG_HIP_CHECK(d_partials.alloc(static_cast<size_t>(grid) * partial_ld));
+        RPVG_HIP_CHECK(d_ctl.alloc(1));
+        RPVG_HIP_CHECK(hipMemsetAsync(d_ctl.ptr, 0, sizeof(EmGridControl), st));
+        // src/path_abundance_estimator.cpp:54 — 1 / float(C), widened
+        gridFillKernel<<<dim3((C + 255) / 256), dim3(256), 0, st>>>(d_a.ptr, C, static_cast<double>(1.0f / static_cast<float>(C)));
+
+        GridAccumArgs aa;
+        aa.off = off;
+        aa.cnt = cnt;
+        aa.nz = nz;
+        aa.col = col;
+        aa.val = val;
+        aa.rows = rows;
+        aa.C = C;
+        aa.rows_per_block = rows_per_block;
+        aa.a = d_a.ptr;
+        aa.partials = d_partials.ptr;
+        aa.partial_ld = partial_ld;
+        aa.ctl = d_ctl.ptr;
+        GridUpdateArgs ua;
+        ua.C = C;
+        ua.num_partials = grid;
+        ua.partial_ld = partial_ld;
+        ua.partials = d_partials.ptr;
+        ua.a = d_a.ptr;
+        ua.inv_total = 1.0 / d.total_mass;
+        ua.zero_mass = d.zero_mass;
+        ua.max_rel_em_conv = max_rel_em_conv;
+        ua.max_em_its = max_em_its;
+        ua.ctl = d_ctl.ptr;
+        const uint32_t update_grid = (C + 63) / 64;
+
+        // Iterations in chunks, two chunks in flight: the control word of chunk k is looked at while chunk k + 1 runs.
+        // A short problem's iteration is a few microseconds, a giant one's milliseconds: the chunk holds about half a
+        // millisecond of the problem's streaming time at the HBM rate, 4 to 32 iterations.
+        const double iteration_us = static_cast<double>(csr_bytes) / 4.0e6 + 8.0;
+        const uint32_t chunk_its = static_cast<uint32_t>(std::min(32.0, std::max(4.0, 500.0 / iteration_us)));
+        EmGridControl * h_ctl = nullptr;  // two pinned slots
+        if (pinnedAlloc(reinterpret_cast<void **>(&h_ctl), 2 * sizeof(EmGridControl)) != hipSuccess) {
+            setError("rpvg_hip_em_solve: out of page-locked host memory");
+            return RPVG_HIP_ERR_ALLOC;
+        }
+        hipEvent_t looked[2] = {nullptr, nullptr};
+        auto cleanup = [&]() {
+            for (hipEvent_t ev : looked) if (ev) (void) hipEventDestroy(ev);
+            pinnedFree(h_ctl);
+        };
+        hipError_t e = hipEventCreateWithFlags(&looked[0], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&looked[1], hipEventDisableTiming);
+        uint32_t queued = 0, chunk = 0;
+        bool done = false;
+        const int span = ctx->spanBegin(FAM_EM_KERNEL, st, RPVG_HIP_EM_KERNELS - 1);
+        while (e == hipSuccess && !done) {
+            const uint32_t n = std::min<uint32_t>(chunk_its, max_em_its - queued);
+            for (uint32_t it = 0; it < n && e == hipSuccess; ++it) {
+                e = launchAccum(row_lanes, aa, grid, lds, st);
+                emGridUpdateKernel<<<dim3(update_grid), dim3(kUpdateBlock), 0, st>>>(ua);
+            }
+            queued += n;
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(&h_ctl[chunk & 1], d_ctl.ptr, sizeof(EmGridControl), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipEventRecord(looked[chunk & 1], st);
+            if (e != hipSuccess) break;
+            if (chunk > 0) {  // the chunk before this one
+                e = hipEventSynchronize(looked[(chunk - 1) & 1]);
+                done = e == hipSuccess && h_ctl[(chunk - 1) & 1].done != 0;
+            }
+            if (!done && queued >= max_em_its) {  // the last chunk there can be
+                if (e == hipSuccess) e = hipEventSynchronize(looked[chunk & 1]);
+                done = true;
+            }
+            ++chunk;
+        }
+        ctx->spanEnd(span);
+        if (e == hipSuccess) {
+            emGridFinishKernel<<<dim3(1), dim3(kGridBlock), 0, st>>>(C, d_a.ptr, d.total_mass, d_ctl.ptr, out_abundances, storage.noise_count + p,
+                                                                     storage.iterations + p);
+            e = hipGetLastError();
+        }
+        const hipError_t waited = hipStreamSynchronize(st);  // (the buffers of this problem go back to the pool)
+        cleanup();
+        RPVG_HIP_CHECK(e);
+        RPVG_HIP_CHECK(waited);
+    }
+    return RPVG_HIP_OK;
+}
+
+}  // namespace rpvg_hip_detail

@@ -122,7 +122,10 @@ __device__ __forceinline__ void blockExclusiveScanPair(uint32_t & a, uint32_t & 
 //   7  LDS-resident, sixteen waves  CSR + vectors fit 152 KB (one workgroup per CU: the whole LDS)
 //   8-9 register-resident dense, one wave: 17 to 32 columns and 64 / 128 rows
 //   10 too many columns for LDS-resident vectors (> ~9 700): vectors in global memory, 16 waves
+//   11 the grid bin: rows + entries at or above EmBinRule::grid_min_work — not one workgroup but the whole GPU, one round
+//      of launches per EM iteration, driven by the host (em_grid.hip); no kernel of this file serves it
 constexpr int kEmBins = RPVG_HIP_EM_KERNELS;
+constexpr int kEmGridBin = 11;
 constexpr int kEmWorkBuckets = 32;   // inside a bin the problems are ordered by floor(log2(rows + entries)), large first
 constexpr size_t kEmLdsLimit = 156 * 1024;
 constexpr uint32_t kRegColsMax = 32;  // the widest register-resident variant
@@ -137,10 +140,13 @@ __host__ __device__ inline size_t emLdsBytes(uint32_t cols, uint32_t rows, uint3
 struct EmBinRule {
     uint32_t use_register_kernel;   // RPVG_HIP_NO_REGISTER_EM=1 clears it
     uint64_t streamed_small_work;   // a streamed problem above this many rows + entries gets 1 024 threads instead of 256
+    uint64_t grid_min_work;         // rows + entries from which a problem goes to the grid bin (0: never; emGridMinWork())
 };
 
 __host__ __device__ inline int emBinOf(const EmBinRule rule, const uint32_t C, const uint32_t rows, const uint32_t entries) {
     const uint64_t work = static_cast<uint64_t>(entries) + rows;
+    // (the grid kernels keep the vectors in LDS: the few problems too wide for that stay in bin 10)
+    if (rule.grid_min_work != 0 && work >= rule.grid_min_work && emLdsBytes(C, 0, 0, 1024, false) <= kEmLdsLimit) return kEmGridBin;
     if (rule.use_register_kernel && C <= 16 && rows <= 256) return rows <= 64 ? 4 : rows <= 128 ? 5 : 6;
     if (rule.use_register_kernel && C <= kRegColsMax && rows <= 128) return rows <= 64 ? 8 : 9;
     if (emLdsBytes(C, rows, entries, 64, true) <= 8 * 1024) return 0;
@@ -403,6 +409,43 @@ __global__ __launch_bounds__(256) void emOrderKernel(const uint32_t num_problems
         wide_off[p] = at;
         if (at + need > wide_capacity) atomicAdd(&queues->wide_overflow, 1ull);
     }
+}
+
+// ---- 4. the problems of the grid bin, described to the host ----------------------------------------
+// The grid bin has no kernel of its own here: its problems are solved over the whole GPU with one round of launches per
+// EM iteration, which the host drives (em_grid.hip).  One thread per problem of the bin writes what the host needs.
+struct GridDescribeArgs {
+    const EmQueues * queues;
+    const uint32_t * order;
+    const uint64_t * col_off;
+    const uint64_t * row_base;
+    const uint64_t * ent_base;
+    const uint32_t * kept_rows;
+    const uint32_t * kept_entries;
+    const double * zero_mass;
+    const double * total_mass;
+    const uint32_t * problem_merged;  // NULL: no collapse
+    EmGridProblem * out;
+    uint32_t capacity;
+};
+
+__global__ __launch_bounds__(256) void emGridDescribeKernel(const GridDescribeArgs args) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= args.queues->bin_count[kEmGridBin] || i >= args.capacity) return;
+    const uint32_t p = args.order[args.queues->bin_start[kEmGridBin] + i];
+    EmGridProblem d;
+    d.problem = p;
+    d.columns = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]) + 1;
+    d.rows = args.kept_rows[p];
+    d.entries = args.kept_entries[p];
+    d.merged = (args.problem_merged != nullptr && args.problem_merged[p] != 0) ? 1u : 0u;
+    d.pad = 0;
+    d.row_base = args.row_base[p];
+    d.ent_base = args.ent_base[p];
+    d.col_begin = args.col_off[p];
+    d.total_mass = args.total_mass[p];
+    d.zero_mass = args.zero_mass[p];
+    args.out[i] = d;
 }
 
 // ---- 5. the EM kernel --------------------------------------------------------
@@ -1082,7 +1125,7 @@ EmBinRule emBinRule() {
     // streamed problems, far fewer than CUs, and on 256 threads the ones below the limit took 55 us per iteration, twice
     // what the larger ones above it took on 1 024).
     static const uint64_t streamed_small = std::getenv("RPVG_HIP_EM_STREAM_SMALL") ? std::strtoull(std::getenv("RPVG_HIP_EM_STREAM_SMALL"), nullptr, 10) : 0;
-    return EmBinRule{use_register_kernel ? 1u : 0u, streamed_small};
+    return EmBinRule{use_register_kernel ? 1u : 0u, streamed_small, emGridMinWork()};
 }
 
 }  // namespace
@@ -1312,12 +1355,72 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         RPVG_HIP_CHECK(ctx->joinAux());
         return RPVG_HIP_OK;
     };
+    // The grid bin (problems too large for one workgroup, em_grid.hip): the host has to see them.  Only a solve that
+    // sits on a cluster large enough to produce one pays for the look (two small copies and their waits).
+    const bool grid_possible = rule.grid_min_work != 0 && list.max_cluster_work >= rule.grid_min_work;
+    DeviceBuffer<EmGridProblem> d_grid_problems;
+    hipEvent_t described = nullptr;
+    uint32_t * h_grid_count = nullptr;
+    struct GridLookGuard {
+        hipEvent_t & ev;
+        uint32_t *& pinned;
+        ~GridLookGuard() {
+            if (ev) (void) hipEventDestroy(ev);
+            if (pinned) pinnedFree(pinned);
+        }
+    } grid_look_guard{described, h_grid_count};
+    if (grid_possible) {
+        RPVG_HIP_CHECK(d_grid_problems.alloc(P));
+        if (pinnedAlloc(reinterpret_cast<void **>(&h_grid_count), 64) != hipSuccess) {
+            setError("rpvg_hip_em_solve: out of page-locked host memory");
+            return RPVG_HIP_ERR_ALLOC;
+        }
+        GridDescribeArgs da;
+        da.queues = queues;
+        da.order = work.d_order.ptr;
+        da.col_off = list.d_col_off;
+        da.row_base = list.d_row_base;
+        da.ent_base = list.d_ent_base;
+        da.kept_rows = out.d_kept_rows;
+        da.kept_entries = out.d_kept_entries;
+        da.zero_mass = work.d_zero.ptr;
+        da.total_mass = out.d_total;
+        da.problem_merged = args.problem_merged;
+        da.out = d_grid_problems.ptr;
+        da.capacity = P;
+        emGridDescribeKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(da);
+        RPVG_HIP_CHECK(hipGetLastError());
+        RPVG_HIP_CHECK(hipMemcpyAsync(h_grid_count, &queues->bin_count[kEmGridBin], sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        RPVG_HIP_CHECK(hipEventCreateWithFlags(&described, hipEventDisableTiming));
+        RPVG_HIP_CHECK(hipEventRecord(described, st));
+    }
     span = ctx->spanBegin(FAM_EM_SPARSE);
     {
         const int rc = launchVariants(true);
         if (rc != RPVG_HIP_OK) return rc;
     }
     ctx->spanEnd(span);
+    if (grid_possible) {
+        RPVG_HIP_CHECK(hipEventSynchronize(described));
+        const uint32_t n_grid = std::min<uint32_t>(*h_grid_count, P);
+        if (n_grid > 0) {
+            std::vector<EmGridProblem> grid_problems(n_grid);
+            RPVG_HIP_CHECK(hipMemcpyAsync(grid_problems.data(), d_grid_problems.ptr, sizeof(EmGridProblem) * n_grid, hipMemcpyDeviceToHost, st));
+            RPVG_HIP_CHECK(hipStreamSynchronize(st));
+            EmGridStorage storage;
+            storage.prow_off = work.d_prow_off.ptr;
+            storage.prow_count = work.d_prow_count.ptr;
+            storage.merged_count = args.merged_count;
+            storage.prow_noise = work.d_prow_noise.ptr;
+            storage.pent_col = work.d_pent_col.ptr;
+            storage.pent_val = work.d_pent_val.ptr;
+            storage.abundances = out.d_abundances;
+            storage.noise_count = out.d_noise_count;
+            storage.iterations = out.d_iterations;
+            const int rc = runEmGridProblems(ctx, st, grid_problems.data(), n_grid, storage, max_em_its, max_rel_em_conv);
+            if (rc != RPVG_HIP_OK) return rc;
+        }
+    }
     if (collapse) {
         const CsrCollapseWork * cw = static_cast<const CsrCollapseWork *>(work.collapse.get());
         static const bool debug = std::getenv("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
@@ -1352,6 +1455,11 @@ void accountEmSolve(rpvg_hip_ctx * ctx, const uint32_t P, const uint64_t * col_o
     for (uint32_t p = 0; p < P; ++p) {
         const uint32_t C = static_cast<uint32_t>(col_off[p + 1] - col_off[p]) + 1;
         const int b = emBinOf(rule, C, kept_rows[p], kept_entries[p]);
+        // (a problem of the grid bin on the dense route ran em_dense.hip's kernels: emDenseIterate has accounted for it)
+        if (b == kEmGridBin && emGridDenseRoute(C, kept_rows[p], kept_entries[p])) {
+            bin_problems[b] += 1;
+            continue;
+        }
         bin_bytes[b] += static_cast<double>(iterations[p]) * (12.0 * kept_entries[p] + 20.0 * kept_rows[p] + 16.0 * C);
         bin_its[b] += iterations[p];
         bin_problems[b] += 1;
@@ -1426,6 +1534,8 @@ int prepareHostProblems(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const 
         const uint32_t C = static_cast<uint32_t>(c1 - c0) + 1;
         list.max_cols = std::max<uint32_t>(list.max_cols, C);
         list.max_cluster_paths = std::max<uint32_t>(list.max_cluster_paths, static_cast<uint32_t>(n_paths));
+        list.max_cluster_work = std::max<uint64_t>(list.max_cluster_work, (batch->h_cluster_row_off[k + 1] - batch->h_cluster_row_off[k]) +
+                                                                              (batch->h_cluster_ent_off[k + 1] - batch->h_cluster_ent_off[k]));
         if (emLdsBytes(C, 0, 0, 1024, false) > kEmLdsLimit) list.wide_capacity += 2ull * C;
         row_base[p] = rows_bound;
         ent_base[p] = entries_bound;
@@ -1542,7 +1652,7 @@ extern "C" const char * rpvg_hip_em_kernel_name(int index) {
     static const char * const names[RPVG_HIP_EM_KERNELS] = {
         "emSparseKernel<64,true>", "emSparseKernel<256,true>", "emSparseKernel<256,false>", "emSparseKernel<1024,false>",
         "emRegisterKernel<1,16>", "emRegisterKernel<2,16>", "emRegisterKernel<4,16>", "emSparseKernel<1024,true>",
-        "emRegisterKernel<1,32>", "emRegisterKernel<2,32>", "emSparseKernel<1024,false,WIDE>"};
+        "emRegisterKernel<1,32>", "emRegisterKernel<2,32>", "emSparseKernel<1024,false,WIDE>", "emGridAccumKernel"};
     return (index >= 0 && index < RPVG_HIP_EM_KERNELS) ? names[index] : nullptr;
 }
 

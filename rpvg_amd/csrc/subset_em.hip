@@ -613,7 +613,7 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
         return RPVG_HIP_ERR_UNSUPPORTED;
     }
     std::unique_ptr<HostScope> scope(new HostScope("subset em: bounds"));
-    uint64_t slots = 0, lane_rows = 0, lane_entries = 0, lane_paths = 0;
+    uint64_t slots = 0, lane_rows = 0, lane_entries = 0, lane_paths = 0, max_cluster_work = 0;
     uint32_t max_paths = 0;
     std::vector<uint64_t> slot_off(M + 1, 0);
     for (uint32_t m = 0; m < M; ++m) {
@@ -624,6 +624,8 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
         lane_entries += batch->h_cluster_ent_off[k + 1] - batch->h_cluster_ent_off[k];
         lane_paths += groups->h_num_paths[m];
         max_paths = std::max(max_paths, groups->h_num_paths[m]);
+        max_cluster_work = std::max<uint64_t>(max_cluster_work, (batch->h_cluster_row_off[k + 1] - batch->h_cluster_row_off[k]) +
+                                                                    (batch->h_cluster_ent_off[k + 1] - batch->h_cluster_ent_off[k]));
     }
     slots = slot_off[M];
     if (M > 0 && 16ull * (static_cast<uint64_t>(max_paths) + 1) + 18 * 8 > 156 * 1024) {
@@ -817,6 +819,7 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
     list.d_num_items = &header->num_items;
     list.max_cols = max_paths + 1;
     list.max_cluster_paths = max_paths;
+    list.max_cluster_work = max_cluster_work;  // (a cluster large enough for the grid bin: the solve waits for its problems' descriptions)
     list.wide_capacity = 0;
     EmOutputs out{d_abund.ptr, d_noise.ptr, d_iters.ptr, d_kept_rows.ptr, d_kept_entries.ptr, d_total.ptr};
     EmSolveWork work;

@@ -73,7 +73,7 @@ class CPairPosteriorsView(C.Structure):
                 ("second", C.POINTER(C.c_uint32)), ("posterior", C.POINTER(C.c_double))]
 
 
-EM_KERNELS = 11  # RPVG_HIP_EM_KERNELS
+EM_KERNELS = 12  # RPVG_HIP_EM_KERNELS
 
 
 class CEmKernelStats(C.Structure):
