@@ -733,24 +733,48 @@ def run_c2(args, rank, local_rank, world, dist, torch):
     its = 50
     sharded = args.scaling == "strong" and dist is not None
     ctx = hip.Context(local_rank)
+    eng = prep = None
+    d_P = d_c = None
     if sharded:
+        # the rows of ONE cluster over the ranks: the raw ABI (rpvg_hip_em_dense_sharded), a matrix synthesised per rank
         rdist.init_engine_comm(ctx, dist, f"cuda:{local_rank}")
         r0, r1 = rdist.row_shard(R_all, rank, world)
         R, total = r1 - r0, float(R_all)
+        d_P, d_c = ctx.malloc(R * ld * 8), ctx.malloc(R * 8)
+        ctx.synth_dense_rows(2, r0, R, N, d_P, ld, d_c)
+
+        def step():
+            return ctx.em_dense(d_P, R, Cn, ld, d_c, total, max_em_its=its, max_rel_em_conv=0.0, sharded=True)
+        stats_of = ctx
     else:
+        # Through the estimator class: the cluster is a resident batch (its rows generated on the device), and
+        # PathAbundanceEstimator::estimateBatch -> rpvg_hip_em_solve sends its one EM problem to the dense route of the
+        # whole-GPU EM (rpvg_amd/csrc/em_grid.hip): compaction + normalisation of the rows, dense copy, `its` iterations.
+        from rpvg_amd import engine as eng_mod
+        from rpvg_amd.batch import make_params
         r0, R, total = 0, R_all, float(R_all)
-    d_P, d_c = ctx.malloc(R * ld * 8), ctx.malloc(R * 8)
-    ctx.synth_dense_rows(2 if sharded else 2 + rank, r0, R, N, d_P, ld, d_c)
+        eng = eng_mod.Engine(local_rank)
+        prep = eng.prepare_synth_dense(2 + rank, R, N)
+        params = make_params(max_em_its=its, max_rel_em_conv=0.0)
+
+        def step():
+            eng.run_raw("transcripts", params, prep)
+        stats_of = eng
     for _ in range(args.warmup):
-        ctx.em_dense(d_P, R, Cn, ld, d_c, total, max_em_its=its, max_rel_em_conv=0.0, sharded=sharded)
-    ctx.reset_stats()
+        step()
+    stats_of.reset_stats()
     barrier_sync(dist, torch)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ab, noise, done = ctx.em_dense(d_P, R, Cn, ld, d_c, total, max_em_its=its, max_rel_em_conv=0.0, sharded=sharded)
+        out = step()
     barrier_sync(dist, torch)
     elapsed = max_over_ranks(time.perf_counter() - t0, dist, torch)
-    stats = ctx.stats()
+    stats = stats_of.stats()
+    if sharded:
+        ab, noise, done = out
+    else:
+        est, _ = eng.run("transcripts", params, prep)
+        ab, noise, done = est[0].abundances, est[0].noise_count, est[0].em_iters[0]
     reads_all = sum_over_ranks(float(R), dist, torch)
     if rank != 0:
         return None
@@ -770,27 +794,44 @@ def run_c2(args, rank, local_rank, world, dist, torch):
         steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
         scaling="strong" if sharded else "weak", vs_baseline=None, dtype="f64", data="synthetic",
         config=dict(workload=f"single dense cluster {R_all} read pairs x {N} paths (BASELINE.json configs[1]), -i transcripts EM, "
-                             f"fixed budget of {its} EM iterations per step",
+                             f"fixed budget of {its} EM iterations per step"
+                             + ("" if sharded else ", through PathAbundanceEstimator::estimateBatch on a resident cluster batch"),
                     parallelism=(f"rows of one cluster spread over {world} rank(s), all-reduce of {Cn} doubles per EM iteration over RCCL"
                                  if sharded else f"replicas only, {world} rank(s)")),
         roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                       kernel="emDenseAccumWideKernel", ms_per_launch=it_ms, algorithmic_bytes_per_launch=it_bytes,
                       note="one launch = one EM iteration's streaming pass: 8*R*C (matrix, read once) + 8*R (counts) + 16*C bytes; "
                            "traffic = HBM bytes per launch from rocprofv3 PMC passes (profiles/%s/pmc_traffic_c2.json)" % PROFILE_ROUND + ""),
-        em_iterations_per_step=its, mass_conserved=bool(abs(ab.sum() + noise - total) <= 1e-6 * total))
+        em_iterations_per_step=int(done), mass_conserved=bool(abs(ab.sum() + noise - total) <= 1e-6 * total),
+        step_breakdown_ms=dict(streaming_passes=stats["em_dense_ms"] / args.steps, build_and_compaction=stats["build_ms"] / args.steps,
+                               note="streaming_passes = HIP-event spans of the iterations' streaming-pass launches; build_and_compaction = the "
+                                    "spans of the kernels in front of them (row compaction + normalisation, dense copy); the rest of a step is "
+                                    "the reduce / update / control launches and the host's waits between chunks of iterations"))
     if not args.no_cpu_baseline:
         # reference-shaped CPU EM on a row sample of the same matrix, one core (a single cluster is serial
         # in the reference: SURVEY.md F4)
         from oracle import pyoracle
         rows = min(R, 20000)
-        P = ctx.d2h(d_P, (rows, ld))[:, :Cn].copy()
+        if d_P is None:  # (the estimator route holds the cluster as a batch: the same rows as a dense matrix for the sample)
+            s_P, s_c = ctx.malloc(rows * ld * 8), ctx.malloc(rows * 8)
+            ctx.synth_dense_rows(2 + rank, 0, rows, N, s_P, ld, s_c)
+            P = ctx.d2h(s_P, (rows, ld))[:, :Cn].copy()
+            ctx.free(s_P)
+            ctx.free(s_c)
+        else:
+            P = ctx.d2h(d_P, (rows, ld))[:, :Cn].copy()
         _, _, _, its_done, secs = pyoracle.em_dense(P, np.ones(rows), max_em_its=10, max_rel_em_conv=0.0)
         per_row_iter = secs / (rows * its_done)
         line["cpu_baseline"] = dict(value=1.0 / (per_row_iter * its), unit="read-pairs/s", cores=1, kind="port",
                                     sample=f"first {rows} rows of the same matrix, {its_done} EM iterations, {secs:.2f} s on one core; "
                                            f"scaled to {its} iterations per read pair")
-    ctx.free(d_P)
-    ctx.free(d_c)
+    if d_P is not None:
+        ctx.free(d_P)
+        ctx.free(d_c)
+    if prep is not None:
+        prep.free()
+        eng.close()
+    ctx.close()
     return line
 
 

@@ -409,6 +409,12 @@ int rpvg_hip_synth_dense_cluster(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t num
 int rpvg_hip_synth_dense_rows(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t row_begin, uint64_t num_rows, uint32_t num_paths,
                               double * device_matrix, uint64_t ld, double * device_counts);
 
+/* The same cluster as a cluster batch resident on the GPU (one cluster, every row holding all num_paths paths) — what
+ * the estimator classes take: BASELINE.json configs[1] behind `-i transcripts` without 40 GB of host arrays (SURVEY.md
+ * section 8d S2 generates it on the device for the same reason).  Freed with rpvg_hip_batch_free. */
+int rpvg_hip_synth_dense_cluster_batch(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t num_rows, uint32_t num_paths,
+                                       rpvg_hip_batch ** batch_out);
+
 /* Test hook: the FP64 logarithm of the log-likelihood kernels (positive normal x) evaluated on the device,
  * with (use_table != 0) or without the LDS table — tests/test_hip_kernels.py measures its error. */
 int rpvg_hip_debug_log(rpvg_hip_ctx * ctx, uint64_t n, const double * x, double * out, int32_t use_table);

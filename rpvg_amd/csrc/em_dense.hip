@@ -369,6 +369,49 @@ __global__ __launch_bounds__(256) void synthDenseKernel(const uint64_t seed, con
     }
 }
 
+// The same cluster as the rows of a cluster batch (rpvg_hip_batch: CSR of (path, probability) entries, every row holding
+// all N paths in path order): what the estimator classes take.  One wave per row.
+__global__ __launch_bounds__(256) void synthDenseBatchKernel(const uint64_t seed, const uint64_t row_begin, const uint64_t R, const uint32_t N,
+                                                             const SynthTables tab, uint64_t * __restrict__ row_ent_off, uint32_t * __restrict__ ent_path,
+                                                             double * __restrict__ ent_prob, double * __restrict__ row_count, double * __restrict__ row_noise) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = (blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x) >> 6;
+    if (r >= R) return;
+    const uint64_t row_key = mix64(seed ^ ((row_begin + r) * 0xD1B54A32D192ED03ull));
+    const double ut = u01(mix64(row_key ^ 0x1ull));
+    uint32_t lo = 0, hi = N - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tab.theta_cdf[mid] < ut) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t true_path = lo;
+    const double um = u01(mix64(row_key ^ 0x2ull));
+    const double noise = (um < 0.70) ? 1e-4 : (um < 0.85) ? 1e-3 : (um < 0.95) ? 0.1 : 0.50118723362727224;
+    auto raw = [&](uint32_t j) -> double {
+        uint32_t d = 0;
+        if (j != true_path) {
+            const double ud = u01(mix64(row_key ^ (0x100ull + j)));
+            d = 1;
+            while (d < 20 && tab.deficit_cdf[d - 1] < ud) ++d;
+        }
+        return tab.score_prob[d] * tab.inv_len[j];
+    };
+    double partial = 0.0;
+    for (uint32_t j = lane; j < N; j += 64) partial += raw(j);
+    const double rowsum = waveReduceSumD(partial);
+    const uint64_t e0 = r * N;
+    for (uint32_t j = lane; j < N; j += 64) {
+        ent_path[e0 + j] = j;
+        ent_prob[e0 + j] = (raw(j) / rowsum) * (1 - noise);
+    }
+    if (lane == 0) {
+        row_ent_off[r] = e0;
+        if (r + 1 == R) row_ent_off[R] = R * N;
+        row_count[r] = 1.0;
+        row_noise[r] = noise;
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -634,58 +677,116 @@ extern "C" int rpvg_hip_synth_dense_cluster(rpvg_hip_ctx * ctx, uint64_t seed, u
     return rpvg_hip_synth_dense_rows(ctx, seed, 0, num_rows, num_paths, device_matrix, ld, device_counts);
 }
 
+namespace {
+
+// host-side tables of the synthetic cluster (tiny): theta ~ LogNormal(0, 2) normalised, lengths ~ U[200, 5000]
+struct SynthHostTables {
+    std::vector<double> theta, inv_len, score_prob, deficit_cdf;
+    DeviceBuffer<double> d_theta, d_inv_len, d_score, d_def;
+    explicit SynthHostTables(const uint64_t seed, const uint32_t N) : theta(N), inv_len(N), score_prob(21), deficit_cdf(20) {
+        auto hmix = [](uint64_t x) {
+            x += 0x9E3779B97F4A7C15ull;
+            x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+            x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+            return x ^ (x >> 31);
+        };
+        auto hu01 = [](uint64_t h) { return ((h >> 11) + 0.5) * (1.0 / 9007199254740992.0); };
+        double tsum = 0;
+        for (uint32_t j = 0; j < N; ++j) {
+            const double u1 = hu01(hmix(seed ^ (0xA000000000ull + 2 * j))), u2 = hu01(hmix(seed ^ (0xA000000000ull + 2 * j + 1)));
+            const double z = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);  // Box-Muller
+            theta[j] = std::exp(2.0 * z);
+            tsum += theta[j];
+            inv_len[j] = 1.0 / (200.0 + 4800.0 * hu01(hmix(seed ^ (0xB000000000ull + j))));
+        }
+        double acc = 0;
+        for (uint32_t j = 0; j < N; ++j) {
+            acc += theta[j] / tsum;
+            theta[j] = acc;
+        }
+        theta[N - 1] = 1.0;
+        for (int d = 0; d <= 20; ++d) score_prob[d] = std::exp(-1.383325268738 * d);  // Utils::score_log_base, src/utils.hpp:83
+        double pk = std::exp(-3.0), cdf = 0;  // Poisson(3)
+        for (int k = 0; k < 20; ++k) {
+            cdf += pk;
+            deficit_cdf[k] = cdf;  // deficit d = 1 + k
+            pk *= 3.0 / (k + 1);
+        }
+        deficit_cdf[19] = 1.0;
+    }
+    hipError_t upload(hipStream_t st, SynthTables * tab) {
+        hipError_t e = d_theta.upload(theta.data(), theta.size(), st);
+        if (e == hipSuccess) e = d_inv_len.upload(inv_len.data(), inv_len.size(), st);
+        if (e == hipSuccess) e = d_score.upload(score_prob.data(), 21, st);
+        if (e == hipSuccess) e = d_def.upload(deficit_cdf.data(), 20, st);
+        *tab = SynthTables{d_theta.ptr, d_inv_len.ptr, d_score.ptr, d_def.ptr};
+        return e;
+    }
+};
+
+}  // namespace
+
 extern "C" int rpvg_hip_synth_dense_rows(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t row_begin, uint64_t num_rows,
                                          uint32_t num_paths, double * device_matrix, uint64_t ld, double * device_counts) {
     RPVG_REQUIRE(ctx && device_matrix && device_counts, "rpvg_hip_synth_dense_rows: NULL argument");
     RPVG_REQUIRE(num_rows > 0 && num_paths > 0, "rpvg_hip_synth_dense_rows: empty cluster");
     RPVG_REQUIRE(ld >= num_paths + 1 && (ld % 2) == 0, "rpvg_hip_synth_dense_rows: ld must be even and >= paths + 1");
     const uint32_t N = num_paths;
-
-    // host-side tables (tiny): theta ~ LogNormal(0, 2) normalised, lengths ~ U[200, 5000]
-    auto hmix = [](uint64_t x) {
-        x += 0x9E3779B97F4A7C15ull;
-        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-        return x ^ (x >> 31);
-    };
-    auto hu01 = [](uint64_t h) { return ((h >> 11) + 0.5) * (1.0 / 9007199254740992.0); };
-    std::vector<double> theta(N), inv_len(N), score_prob(21), deficit_cdf(20);
-    double tsum = 0;
-    for (uint32_t j = 0; j < N; ++j) {
-        const double u1 = hu01(hmix(seed ^ (0xA000000000ull + 2 * j))), u2 = hu01(hmix(seed ^ (0xA000000000ull + 2 * j + 1)));
-        const double z = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);  // Box-Muller
-        theta[j] = std::exp(2.0 * z);
-        tsum += theta[j];
-        inv_len[j] = 1.0 / (200.0 + 4800.0 * hu01(hmix(seed ^ (0xB000000000ull + j))));
-    }
-    double acc = 0;
-    for (uint32_t j = 0; j < N; ++j) {
-        acc += theta[j] / tsum;
-        theta[j] = acc;
-    }
-    theta[N - 1] = 1.0;
-    for (int d = 0; d <= 20; ++d) score_prob[d] = std::exp(-1.383325268738 * d);  // Utils::score_log_base, src/utils.hpp:83
-    double pk = std::exp(-3.0), cdf = 0;  // Poisson(3)
-    for (int k = 0; k < 20; ++k) {
-        cdf += pk;
-        deficit_cdf[k] = cdf;  // deficit d = 1 + k
-        pk *= 3.0 / (k + 1);
-    }
-    deficit_cdf[19] = 1.0;
+    SynthHostTables tables(seed, N);
 
     std::lock_guard<std::mutex> lock(ctx->mutex);
     RPVG_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    DeviceBuffer<double> d_theta, d_inv_len, d_score, d_def;
-    RPVG_HIP_CHECK(d_theta.upload(theta.data(), N, st));
-    RPVG_HIP_CHECK(d_inv_len.upload(inv_len.data(), N, st));
-    RPVG_HIP_CHECK(d_score.upload(score_prob.data(), 21, st));
-    RPVG_HIP_CHECK(d_def.upload(deficit_cdf.data(), 20, st));
-    SynthTables tab = {d_theta.ptr, d_inv_len.ptr, d_score.ptr, d_def.ptr};
+    SynthTables tab;
+    RPVG_HIP_CHECK(tables.upload(st, &tab));
     const uint64_t threads = num_rows * 64;
     synthDenseKernel<<<dim3(static_cast<uint32_t>((threads + 255) / 256)), dim3(256), 0, st>>>(seed, row_begin, num_rows, N, tab,
                                                                                             device_matrix, ld, device_counts);
     RPVG_HIP_CHECK(hipGetLastError());
     RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    return RPVG_HIP_OK;
+}
+
+extern "C" int rpvg_hip_synth_dense_cluster_batch(rpvg_hip_ctx * ctx, uint64_t seed, uint64_t num_rows, uint32_t num_paths,
+                                                  rpvg_hip_batch ** batch_out) {
+    RPVG_REQUIRE(ctx && batch_out, "rpvg_hip_synth_dense_cluster_batch: NULL argument");
+    *batch_out = nullptr;
+    RPVG_REQUIRE(num_rows > 0 && num_paths > 0, "rpvg_hip_synth_dense_cluster_batch: empty cluster");
+    RPVG_REQUIRE(num_rows * num_paths < 0xffffffffull, "rpvg_hip_synth_dense_cluster_batch: %llu x %u entries exceed the 32-bit entry offsets of an EM problem",
+                 static_cast<unsigned long long>(num_rows), num_paths);
+    const uint32_t N = num_paths;
+    const uint64_t R = num_rows, M = R * N;
+    SynthHostTables tables(seed, N);
+
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<rpvg_hip_batch> b(new (std::nothrow) rpvg_hip_batch());
+    if (!b) {
+        setError("rpvg_hip_synth_dense_cluster_batch: out of host memory");
+        return RPVG_HIP_ERR_ALLOC;
+    }
+    b->num_clusters = 1;
+    b->num_rows = R;
+    b->num_entries = M;
+    b->num_paths = N;
+    b->h_cluster_row_off = {0, R};
+    b->h_cluster_path_off = {0, N};
+    b->h_cluster_ent_off = {0, M};
+    RPVG_HIP_CHECK(b->cluster_row_off.upload(b->h_cluster_row_off.data(), 2, st));
+    RPVG_HIP_CHECK(b->cluster_path_off.upload(b->h_cluster_path_off.data(), 2, st));
+    RPVG_HIP_CHECK(b->row_noise.alloc(R));
+    RPVG_HIP_CHECK(b->row_count.alloc(R));
+    RPVG_HIP_CHECK(b->row_ent_off.alloc(R + 1));
+    RPVG_HIP_CHECK(b->ent_path.alloc(M));
+    RPVG_HIP_CHECK(b->ent_prob.alloc(M));
+    SynthTables tab;
+    RPVG_HIP_CHECK(tables.upload(st, &tab));
+    const uint64_t threads = R * 64;
+    synthDenseBatchKernel<<<dim3(static_cast<uint32_t>((threads + 255) / 256)), dim3(256), 0, st>>>(seed, 0, R, N, tab, b->row_ent_off.ptr, b->ent_path.ptr,
+                                                                                                 b->ent_prob.ptr, b->row_count.ptr, b->row_noise.ptr);
+    RPVG_HIP_CHECK(hipGetLastError());
+    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    *batch_out = b.release();
     return RPVG_HIP_OK;
 }

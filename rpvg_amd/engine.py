@@ -48,6 +48,8 @@ def lib() -> C.CDLL:
         L.rpvg_amd_batch_prepare_from_alignments.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CClusterBatch), C.c_double, C.c_double,
                                                              C.c_double, C.c_uint32, C.c_int, C.c_double, C.c_double,
                                                              C.POINTER(C.c_double)]
+        L.rpvg_amd_batch_prepare_synth_dense.restype = C.c_void_p
+        L.rpvg_amd_batch_prepare_synth_dense.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32]
         L.rpvg_amd_run.restype = C.c_void_p
         L.rpvg_amd_run.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double)]
         L.rpvg_amd_run_inplace.restype = C.c_int
@@ -131,6 +133,17 @@ class Engine:
         if not prep.handle:
             raise hip.EngineError(f"batch prepare from alignments failed: {_err()}")
         prep.row_construction_seconds = secs.value
+        return prep
+
+    def prepare_synth_dense(self, seed: int, rows: int, paths: int) -> "PreparedBatch":
+        """BASELINE.json configs[1] as a resident batch for the estimator classes: one cluster of `rows` rows over all `paths`
+        paths, generated on the GPU (rpvg_hip_synth_dense_cluster_batch; every row one read pair)."""
+        prep = PreparedBatch.__new__(PreparedBatch)
+        prep.engine = self
+        prep.batch = None
+        prep.handle = lib().rpvg_amd_batch_prepare_synth_dense(self.handle, C.c_uint64(seed), C.c_uint64(rows), C.c_uint32(paths))
+        if not prep.handle:
+            raise hip.EngineError(f"synthetic dense batch failed: {_err()}")
         return prep
 
     def run(self, model: str, params: CParams, prepared: "PreparedBatch") -> Tuple[List[ClusterEstimates], float]:

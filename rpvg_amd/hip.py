@@ -24,7 +24,7 @@ EXPORTS = [
     "rpvg_hip_dense_from_cluster", "rpvg_hip_groups_build", "rpvg_hip_groups_free", "rpvg_hip_groups_collapse_info", "rpvg_hip_group_loglik",
     "rpvg_hip_synth_dense_cluster", "rpvg_hip_stats_get", "rpvg_hip_stats_reset", "rpvg_hip_stats_intervals", "rpvg_hip_em_kernel_name",
     "rpvg_hip_gibbs_read_counts", "rpvg_hip_min_path_cover", "rpvg_hip_bounded_pair_posteriors", "rpvg_hip_pair_posteriors_get", "rpvg_hip_pair_posteriors_free",
-    "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
+    "rpvg_hip_em_dense_sharded", "rpvg_hip_synth_dense_rows", "rpvg_hip_synth_dense_cluster_batch", "rpvg_hip_comm_unique_id", "rpvg_hip_comm_init",
     "rpvg_hip_comm_destroy", "rpvg_hip_comm_allreduce_sum_f64", "rpvg_hip_comm_init_all", "rpvg_hip_gather", "rpvg_hip_host_register", "rpvg_hip_host_unregister", "rpvg_hip_group_conditionals",
     "rpvg_hip_group_gibbs", "rpvg_hip_gibbs_sets_get", "rpvg_hip_gibbs_sets_free",
     "rpvg_hip_alignments_upload", "rpvg_hip_alignments_free", "rpvg_hip_read_rows_build", "rpvg_hip_read_rows_to_batch",

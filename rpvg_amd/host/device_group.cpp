@@ -310,6 +310,15 @@ void DeviceGroup::estimateBatch(std::vector<PathClusterEstimates> * estimates, c
 
     onEveryDevice(engines.size(), [&](const size_t idx) {
 
+        // (the override is thread local and engine 0 runs on the calling thread: put the caller's value back, or the next
+        // batch would divide an already divided team — 32, 16, 8, ... threads per engine, batch after batch)
+        struct OverrideGuard {
+
+            const int previous = hostThreadsOverride();
+            ~OverrideGuard() { hostThreadsOverride() = previous; }
+
+        } restore_override;
+
         hostThreadsOverride() = engine_threads;
 
         const auto & clusters = partition.at(idx);

@@ -344,6 +344,53 @@ void * rpvg_amd_batch_prepare_from_alignments(void * engine, const rpvg_alignmen
     }
 }
 
+// BASELINE.json configs[1] for the estimator classes: one cluster of `num_rows` rows that each touch all `num_paths` paths,
+// generated on the device (rpvg_hip_synth_dense_cluster_batch: the host form of 10^6 x 2 000 rows would be 40 GB) and
+// adopted as a resident batch — the caller runs `transcripts` on it like on any other batch.
+void * rpvg_amd_batch_prepare_synth_dense(void * engine, uint64_t seed, uint64_t num_rows, uint32_t num_paths) {
+
+    try {
+
+        PreparedBatch * prepared = new PreparedBatch();
+        std::unique_ptr<PreparedBatch> guard(prepared);
+
+        prepared->paths.emplace_back();
+
+        for (uint32_t j = 0; j < num_paths; ++j) {
+
+            PathInfo info;
+            info.group_id = 0;
+            info.source_count = 1;
+            info.effective_length = 1000;
+            prepared->paths.back().emplace_back(std::move(info));
+        }
+
+        auto hip = static_cast<Engine *>(engine)->hip;
+
+        rpvg_hip_batch * device_batch = nullptr;
+        HipEngine::check(rpvg_hip_synth_dense_cluster_batch(hip->ctx(), seed, num_rows, num_paths, &device_batch), "rpvg_hip_synth_dense_cluster_batch");
+
+        const uint64_t cluster_row_off[2] = {0, num_rows};
+        const uint64_t cluster_path_off[2] = {0, num_paths};
+
+        rpvg_cluster_batch offsets;
+        std::memset(&offsets, 0, sizeof(offsets));
+        offsets.num_clusters = 1;
+        offsets.cluster_row_off = cluster_row_off;
+        offsets.cluster_path_off = cluster_path_off;
+
+        // (every row of the synthetic cluster is one read pair)
+        prepared->device.reset(new DeviceClusterBatch(hip, device_batch, offsets, std::vector<double>(1, static_cast<double>(num_rows))));
+
+        return guard.release();
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return nullptr;
+    }
+}
+
 // A new resident copy of the rows of a prepared batch from the same host arrays (what arrives per batch in a
 // running pipeline: the rows; the PathInfo side stays).  `engine` may be another engine on the same GPU than the one
 // that estimates — an uploader with a context and stream of its own, so that the copy of batch n + 1 runs under

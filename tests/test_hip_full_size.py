@@ -154,6 +154,64 @@ def test_config1_dense_cluster_16gb():
         ctx.close()
 
 
+def test_config1_dense_cluster_through_the_estimator_class(engine):
+    """BASELINE.json configs[1] behind `-i transcripts`: the 1M x 2 000 cluster is a resident cluster batch (rows generated on
+    the device), PathAbundanceEstimator::estimateBatch (src/path_abundance_estimator.cpp:18-45) solves it through
+    rpvg_hip_em_solve, whose size bin sends the problem to the dense route of the whole-GPU EM.  Same property checks as the
+    raw-ABI test above: the closed form of the first iteration (against the column sums of the same cluster synthesised as
+    a dense matrix), determinism, the writers' mass invariant."""
+    R, N = 1000000, 2000
+    Cn = N + 1
+    ld = (Cn + 1) & ~1
+    prep = engine.prepare_synth_dense(2, R, N)
+    ctx = hip.Context(0)
+    d_P = d_c = None
+    try:
+        chunk = 50000
+        d_P, d_c = ctx.malloc(chunk * ld * 8), ctx.malloc(chunk * 8)
+        col_sum = np.zeros(Cn)
+        for r0 in range(0, R, chunk):
+            ctx.synth_dense_rows(2, r0, chunk, N, d_P, ld, d_c)
+            col_sum += ctx.d2h(d_P, (chunk, ld))[:, :Cn].sum(axis=0)
+
+        engine.reset_stats()
+        got1, _ = engine.run("transcripts", make_params(max_em_its=1, max_rel_em_conv=0.0), prep)
+        e1 = got1[0]
+        assert e1.em_iters == [1] and e1.total_count == R
+        keep = col_sum[:N] / R >= 1e-8  # sub-threshold components are zeroed and moved to noise (:100-113)
+        assert np.allclose(e1.abundances[keep], col_sum[:N][keep], rtol=1e-9)
+        assert np.all(e1.abundances[~keep] == 0)
+        assert abs(e1.abundances.sum() + e1.noise_count - R) <= 1e-9 * R
+        st = engine.stats()
+        assert st["em_dense_launches"] == 1 and st["em_kernel"]["emGridAccumKernel"]["problems"] == 1
+
+        params = make_params(max_em_its=12, max_rel_em_conv=0.0)
+        a, _ = engine.run("transcripts", params, prep)
+        b, _ = engine.run("transcripts", params, prep)
+        assert a[0].em_iters == [12] and b[0].em_iters == [12]
+        assert np.array_equal(a[0].abundances, b[0].abundances) and a[0].noise_count == b[0].noise_count  # fixed reduction orders
+        assert abs(a[0].abundances.sum() + a[0].noise_count - R) <= 1e-9 * R
+
+        # and the raw ABI on the dense matrix of the same cluster's first rows agrees with the batch route on those rows:
+        # (a sub-cluster through both doors)
+        sub = 20000
+        ctx.synth_dense_rows(2, 0, sub, N, d_P, ld, d_c)
+        ab_raw, noise_raw, its_raw = ctx.em_dense(d_P, sub, Cn, ld, d_c, float(sub), max_em_its=12, max_rel_em_conv=0.0)
+        prep_sub = engine.prepare_synth_dense(2, sub, N)
+        try:
+            c, _ = engine.run("transcripts", params, prep_sub)
+        finally:
+            prep_sub.free()
+        assert its_raw == 12 and c[0].em_iters == [12]
+        assert np.allclose(c[0].abundances, ab_raw, rtol=1e-9, atol=1e-9) and abs(c[0].noise_count - noise_raw) <= 1e-9 * sub
+    finally:
+        for d in (d_P, d_c):
+            if d:
+                ctx.free(d)
+        ctx.close()
+        prep.free()
+
+
 def test_config4_diploid_haplotype_gibbs_10m_reads_follows_the_reference_stream(engine):
     """BASELINE.json configs[4]: -i haplotypes -y 2 --use-hap-gibbs on 10M reads x 500k paths.  The sampler keeps
     the reference's mt19937(rng_seed + i) per cluster and libstdc++ distributions, so the sampled diplotypes and their
