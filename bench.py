@@ -502,11 +502,18 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
         upload_s.clear()
         eng.reset_stats()
         barrier_sync(dist, torch)
+        import resource
+        cpu0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
+        step_ms = []
         for k in range(args.steps):
+            ts = time.perf_counter()
             step(k)
+            step_ms.append((time.perf_counter() - ts) * 1e3)
         barrier_sync(dist, torch)
         overlapped = max_over_ranks(time.perf_counter() - t0, dist, torch)
+        cpu1 = resource.getrusage(resource.RUSAGE_SELF)
+        host_cpu_ms = ((cpu1.ru_utime - cpu0.ru_utime) + (cpu1.ru_stime - cpu0.ru_stime)) * 1e3 / args.steps
         stats = eng.stats()
         t0 = time.perf_counter()
         for k in range(args.steps):  # no overlap: upload, then estimate
@@ -520,7 +527,12 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
             hip.host_unregister(a)
     bytes_per_batch = float(sum(a.nbytes for a in arrays))
     up_ms = 1e3 * sum(upload_s) / max(1, len(upload_s))
+    ordered = sorted(step_ms)
+    spread = dict(median=ordered[len(ordered) // 2], min=ordered[0], max=ordered[-1], p10=ordered[len(ordered) // 10], p90=ordered[(9 * len(ordered)) // 10],
+                  note="wall time of the single steps of the timed region on this rank (ms_per_step is their mean between the barriers)")
     return dict(stats=stats, ms_per_step_with_h2d=overlapped / args.steps * 1e3, ms_per_step_with_h2d_serial=serial / args.steps * 1e3,
+                ms_per_step_spread=spread, host_cpu_ms_per_step=host_cpu_ms,
+                host_cpu_note="user + system CPU time of the process (every host thread: lanes, OpenMP teams, uploader) per step of the timed region, getrusage",
                 h2d_ms_per_batch=up_ms, h2d_bytes_per_batch=bytes_per_batch, h2d_gb_per_s=bytes_per_batch / 1e9 / (up_ms / 1e3),
                 h2d_note="rows of every batch uploaded from page-locked host arrays inside the clock: validation on the host, H2D, "
                          "expansion on the device; overlapped = two resident slots, uploader engine under the previous batch's kernels")

@@ -848,6 +848,7 @@ struct CsrCollapseInput {  // the compacted CSR of a solve's problems (em_sparse
     const uint64_t * seg_first = nullptr;
     const uint32_t * item_problem = nullptr;
     uint32_t segment_rows = 0;
+    uint64_t max_rows_bound = 0;  // a bound of the rows of the largest problem (its cluster's): 0 = unknown
 };
 struct CsrCollapseWork {
     DeviceBuffer<double> merged_count;      // [rows] read counts after the merges, for the problems with merges

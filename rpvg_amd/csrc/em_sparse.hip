@@ -1255,6 +1255,7 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         in.seg_first = list.d_seg_first;
         in.item_problem = list.d_item_problem;
         in.segment_rows = kFillSegmentRows;
+        in.max_rows_bound = std::min<uint64_t>(list.max_cluster_work, list.rows_capacity);  // (rows + entries of the largest cluster: a bound of its rows)
         const int collapse_span = ctx->spanBegin(FAM_COLLAPSE, ctx->collapse_stream);
         RPVG_HIP_CHECK(queueCsrCollapse(ctx, in, collapse_precision, *cw, ctx->collapse_stream));
         ctx->spanEnd(collapse_span);

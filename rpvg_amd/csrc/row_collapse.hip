@@ -589,188 +589,136 @@ struct ReplayArgs {
     bool debug;                  // RPVG_HIP_EM_COLLAPSE_DEBUG: slow workgroups of the runs kernel report where their time went
 };
 
-// a0. the list of a matrix: its active rows (the replay then only touches those), or all of them
-template <typename Arrays>
-__global__ __launch_bounds__(256) void collapseListKernel(const ReplayArgs<Arrays> a) {
-    __shared__ uint32_t list_size;
-    const uint32_t m = blockIdx.x;
-    if (m >= a.num_matrices) return;
-    const uint32_t flag = a.mat_flag[m];
-    if (flag == kFlagNone) {
-        if (threadIdx.x == 0) a.mat_list[m] = 0;
-        return;
-    }
-    const uint64_t R = a.g.numRows(m);
-    const uint64_t r0 = a.g.rowOffset(m);
-    const uint8_t * active = a.active + r0;
-    uint32_t * list = a.order + 2 * r0;
-    if (threadIdx.x == 0) list_size = 0;
-    __syncthreads();
-    if (flag != kFlagWholeMatrix) {
-        for (uint64_t i = threadIdx.x; i < R; i += blockDim.x) {
-            if (active[i] == kRowListed) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(i);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    const bool whole = flag == kFlagWholeMatrix;
-    const uint64_t n = whole ? R : list_size;
-    if (n < 2) {
-        a.mat_list[m] = 0;
-        return;
-    }
-    uint32_t encoded = static_cast<uint32_t>(n);
-    if (whole) encoded |= kWholeMatrixBit | kBigListBit;
-    else if (n > kPairwiseRows) encoded |= kBigListBit;
-    else {
-        const unsigned long long base = atomicAdd(a.pair_bytes, static_cast<unsigned long long>(n * n));
-        if (base + n * n > kPairTableBytes) encoded |= kBigListBit;
-        else {
-            a.pair_base[m] = base;
-            const uint32_t first = atomicAdd(a.row_item_count, static_cast<uint32_t>(n));
-            for (uint32_t i = 0; i < n; ++i) {
-                a.row_items[2 * static_cast<uint64_t>(first + i)] = m;
-                a.row_items[2 * static_cast<uint64_t>(first + i) + 1] = i;
-            }
-        }
-    }
-    a.mat_list[m] = encoded;
-    a.replay_list[atomicAdd(&a.replay_list[a.num_matrices], 1u)] = m;
-    if (!whole) {  // work items of step b: (matrix, slice of kBetweenRows rows)
-        const uint32_t slices = static_cast<uint32_t>((R + kBetweenRows - 1) / kBetweenRows);
-        const uint32_t first = atomicAdd(a.between_count, slices);
-        for (uint32_t k = 0; k < slices; ++k) {
-            a.between_items[2 * static_cast<uint64_t>(first + k)] = m;
-            a.between_items[2 * static_cast<uint64_t>(first + k) + 1] = k;
-        }
-    }
-    atomicAdd(&a.info[kInfoMatrices], 1u);
-    atomicAdd(&a.info[kInfoActiveRows], static_cast<uint32_t>(n));
-    if (whole) atomicAdd(&a.info[kInfoWholeMatrices], 1u);
-}
-
 // a1. every pair of rows of a small list, one thread each: order and closeness in one pass over the columns.  (A
 // workgroup that sorts its list with a comparison network goes through dozens of dependent rounds of strided loads;
 // here every comparison of the batch is in flight at once, and ranks and runs are then read off the table.)
+// row i of matrix m's pair table; the calling threads stride its columns (thread `first` of `stride`)
+template <typename Arrays>
+__device__ __forceinline__ void pairTableRow(const ReplayArgs<Arrays> & a, const uint32_t m, const uint32_t i, const uint32_t first, const uint32_t stride) {
+    const uint32_t n = a.mat_list[m] & kListSizeMask;
+    const typename Arrays::View mv = viewOf(m, a.g);
+    const uint32_t * list = a.order + 2 * a.g.rowOffset(m);
+    uint8_t * table = a.pair_table + a.pair_base[m] + static_cast<uint64_t>(i) * n;
+    const uint32_t row_i = list[i];
+    const uint64_t pattern_i = mv.patternOf(row_i);
+    for (uint32_t j = first; j < n; j += stride) {
+        const uint32_t row_j = list[j];
+        int less = -1;
+        bool close = true;
+        forEachColumnPair(mv, row_i, row_j, pattern_i | mv.patternOf(row_j), [&](const double x, const double y) {
+            if (less < 0 && !tolerantEqual(x, y)) less = x < y ? 1 : 0;
+            if (fabs(x - y) >= a.precision) close = false;
+            return less >= 0 && !close;
+        });
+        if (less < 0) {
+            const double x = mv.countOf(row_i), y = mv.countOf(row_j);
+            less = (!tolerantEqual(x, y) && x < y) ? 1 : 0;
+        }
+        table[j] = (less ? kPairLess : 0) | (close ? kPairClose : 0);
+    }
+}
+
 template <typename Arrays>
 __global__ __launch_bounds__(64) void collapsePairTableKernel(const ReplayArgs<Arrays> a) {
     const uint32_t num_items = *a.row_item_count;
     for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
-        const uint32_t m = a.row_items[2 * static_cast<uint64_t>(item)], i = a.row_items[2 * static_cast<uint64_t>(item) + 1];
-        const uint32_t n = a.mat_list[m] & kListSizeMask;
-        const typename Arrays::View mv = viewOf(m, a.g);
-        const uint32_t * list = a.order + 2 * a.g.rowOffset(m);
-        uint8_t * table = a.pair_table + a.pair_base[m] + static_cast<uint64_t>(i) * n;
-        const uint32_t row_i = list[i];
-        const uint64_t pattern_i = mv.patternOf(row_i);
-        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-            const uint32_t row_j = list[j];
-            int less = -1;
-            bool close = true;
-            forEachColumnPair(mv, row_i, row_j, pattern_i | mv.patternOf(row_j), [&](const double x, const double y) {
-                if (less < 0 && !tolerantEqual(x, y)) less = x < y ? 1 : 0;
-                if (fabs(x - y) >= a.precision) close = false;
-                return less >= 0 && !close;
-            });
-            if (less < 0) {
-                const double x = mv.countOf(row_i), y = mv.countOf(row_j);
-                less = (!tolerantEqual(x, y) && x < y) ? 1 : 0;
-            }
-            table[j] = (less ? kPairLess : 0) | (close ? kPairClose : 0);
-        }
+        pairTableRow(a, a.row_items[2 * static_cast<uint64_t>(item)], a.row_items[2 * static_cast<uint64_t>(item) + 1], threadIdx.x, blockDim.x);
     }
 }
 
 // a2. small lists sorted by rank: the number of rows that sort before a row (equal rows in list order).  Where the
 // tolerant comparison is inconsistent the ranks may collide; such a list is sorted by the comparison network instead.
+// the list of matrix m (a small one: it has a pair table) sorted by rank, and the column that orders every pair of neighbours
 template <typename Arrays>
-__global__ __launch_bounds__(256) void collapseRankKernel(const ReplayArgs<Arrays> a) {
+__device__ void rankList(const ReplayArgs<Arrays> & a, const uint32_t m) {
     __shared__ uint32_t lds_row[kPairwiseRows], lds_slot[kPairwiseRows];
     __shared__ uint32_t collision;
-    const uint32_t num_items = a.replay_list[a.num_matrices];
-    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
-        const uint32_t m = a.replay_list[item];
-        const uint32_t encoded = a.mat_list[m];
-        if (encoded & kBigListBit) continue;
-        const uint32_t n = encoded;
-        const uint64_t r0 = a.g.rowOffset(m);
-        uint32_t * list = a.order + 2 * r0;
-        uint32_t * list_index = a.list_index + r0;
-        const uint8_t * table = a.pair_table + a.pair_base[m];
-        __syncthreads();
-        if (threadIdx.x == 0) collision = 0;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            lds_row[i] = list[i];
-            lds_slot[i] = kNoRow;
+    const uint32_t encoded = a.mat_list[m];
+    if (encoded & kBigListBit) return;
+    const uint32_t n = encoded;
+    const uint64_t r0 = a.g.rowOffset(m);
+    uint32_t * list = a.order + 2 * r0;
+    uint32_t * list_index = a.list_index + r0;
+    const uint8_t * table = a.pair_table + a.pair_base[m];
+    __syncthreads();
+    if (threadIdx.x == 0) collision = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        lds_row[i] = list[i];
+        lds_slot[i] = kNoRow;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const bool before = (table[static_cast<uint64_t>(j) * n + i] & kPairLess) != 0;
+            const bool after = (table[static_cast<uint64_t>(i) * n + j] & kPairLess) != 0;
+            rank += (before || (!after && j < i)) ? 1u : 0u;
         }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < n; ++j) {
-                const bool before = (table[static_cast<uint64_t>(j) * n + i] & kPairLess) != 0;
-                const bool after = (table[static_cast<uint64_t>(i) * n + j] & kPairLess) != 0;
-                rank += (before || (!after && j < i)) ? 1u : 0u;
-            }
-            if (rank >= n || atomicExch(&lds_slot[rank], i) != kNoRow) collision = 1;
-        }
-        __syncthreads();
-        if (collision) {  // (never seen; kept correct rather than fast) insertion sort with the comparator itself
-            if (threadIdx.x == 0) {
-                const typename Arrays::View mv = viewOf(m, a.g);
-                for (uint32_t i = 0; i < n; ++i) lds_slot[i] = i;
-                for (uint32_t i = 1; i < n; ++i) {
-                    const uint32_t moving = lds_slot[i];
-                    uint32_t k = i;
-                    while (k > 0 && rowLess(mv, lds_row[moving], lds_row[lds_slot[k - 1]])) {
-                        lds_slot[k] = lds_slot[k - 1];
-                        --k;
-                    }
-                    lds_slot[k] = moving;
+        if (rank >= n || atomicExch(&lds_slot[rank], i) != kNoRow) collision = 1;
+    }
+    __syncthreads();
+    if (collision) {  // (never seen; kept correct rather than fast) insertion sort with the comparator itself
+        if (threadIdx.x == 0) {
+            const typename Arrays::View mv = viewOf(m, a.g);
+            for (uint32_t i = 0; i < n; ++i) lds_slot[i] = i;
+            for (uint32_t i = 1; i < n; ++i) {
+                const uint32_t moving = lds_slot[i];
+                uint32_t k = i;
+                while (k > 0 && rowLess(mv, lds_row[moving], lds_row[lds_slot[k - 1]])) {
+                    lds_slot[k] = lds_slot[k - 1];
+                    --k;
                 }
+                lds_slot[k] = moving;
             }
-            __syncthreads();
-        }
-        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) {
-            list[p] = lds_row[lds_slot[p]];
-            list_index[p] = lds_slot[p];
-            a.barrier[r0 + p] = 0;
         }
         __syncthreads();
-        // the column that orders every pair of neighbours, and the interval between them in it (collapseSortKernel)
-        const typename Arrays::View mv = viewOf(m, a.g);
-        for (uint32_t p = 1 + threadIdx.x; p < n; p += blockDim.x) {
-            const uint32_t x = lds_row[lds_slot[p - 1]], y = lds_row[lds_slot[p]];
-            uint32_t d = kNoRow;
-            bool can_join = true;
-            // (forEachColumnPair visits the columns in order but skips those in which both rows are zero: the column
-            // index is recovered from the patterns)
-            const uint64_t live = mv.patternOf(x) | mv.patternOf(y);
-            uint64_t remaining = live;
-            uint32_t wide = 64;
-            forEachColumnPair(mv, x, y, live, [&](const double vx, const double vy) {
-                uint32_t column;
-                if (remaining) {
-                    column = static_cast<uint32_t>(__ffsll(static_cast<long long>(remaining)) - 1);
-                    remaining &= remaining - 1;
-                } else if (wide < mv.G) {
-                    column = wide++;
-                } else {
-                    column = mv.G;
-                }
-                if (fabs(vx - vy) >= 2 * a.precision) can_join = false;
-                if (d == kNoRow && !tolerantEqual(vx, vy)) d = column;
-                return !can_join;
-            });
-            const bool look = can_join && d != kNoRow;
-            a.pair_column[r0 + p] = look ? d : kNoRow;
-            if (look) {
-                const double vx = mv.at(d, x), vy = mv.at(d, y);
-                a.pair_lo[r0 + p] = fmin(vx, vy);
-                a.pair_hi[r0 + p] = fmax(vx, vy);
-                a.pair_pattern[r0 + p] = mv.patternOf(x) & (d >= 64 ? ~0ull : (1ull << d) - 1ull);
+    }
+    for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) {
+        list[p] = lds_row[lds_slot[p]];
+        list_index[p] = lds_slot[p];
+        a.barrier[r0 + p] = 0;
+    }
+    __syncthreads();
+    // the column that orders every pair of neighbours, and the interval between them in it (collapseSortKernel)
+    const typename Arrays::View mv = viewOf(m, a.g);
+    for (uint32_t p = 1 + threadIdx.x; p < n; p += blockDim.x) {
+        const uint32_t x = lds_row[lds_slot[p - 1]], y = lds_row[lds_slot[p]];
+        uint32_t d = kNoRow;
+        bool can_join = true;
+        // (forEachColumnPair visits the columns in order but skips those in which both rows are zero: the column
+        // index is recovered from the patterns)
+        const uint64_t live = mv.patternOf(x) | mv.patternOf(y);
+        uint64_t remaining = live;
+        uint32_t wide = 64;
+        forEachColumnPair(mv, x, y, live, [&](const double vx, const double vy) {
+            uint32_t column;
+            if (remaining) {
+                column = static_cast<uint32_t>(__ffsll(static_cast<long long>(remaining)) - 1);
+                remaining &= remaining - 1;
+            } else if (wide < mv.G) {
+                column = wide++;
+            } else {
+                column = mv.G;
             }
+            if (fabs(vx - vy) >= 2 * a.precision) can_join = false;
+            if (d == kNoRow && !tolerantEqual(vx, vy)) d = column;
+            return !can_join;
+        });
+        const bool look = can_join && d != kNoRow;
+        a.pair_column[r0 + p] = look ? d : kNoRow;
+        if (look) {
+            const double vx = mv.at(d, x), vy = mv.at(d, y);
+            a.pair_lo[r0 + p] = fmin(vx, vy);
+            a.pair_hi[r0 + p] = fmax(vx, vy);
+            a.pair_pattern[r0 + p] = mv.patternOf(x) & (d >= 64 ? ~0ull : (1ull << d) - 1ull);
         }
     }
+}
+
+template <typename Arrays>
+__global__ __launch_bounds__(256) void collapseRankKernel(const ReplayArgs<Arrays> a) {
+    const uint32_t num_items = a.replay_list[a.num_matrices];
+    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) rankList(a, a.replay_list[item]);
 }
 
 // a3. big lists (more than kPairwiseRows rows, whole matrices): sorted with the reference's comparator in a
@@ -868,53 +816,58 @@ __global__ __launch_bounds__(kSortThreads) void collapseSortKernel(const ReplayA
 }
 
 // b. inactive rows between neighbours of the lists: work item = (matrix with a list, slice of its rows)
+// the rows [slice * kBetweenRows, ...) of matrix m against the neighbour pairs of its list
 template <typename Arrays>
-__global__ __launch_bounds__(kBetweenThreads) void collapseBetweenKernel(const ReplayArgs<Arrays> a) {
+__device__ void betweenSlice(const ReplayArgs<Arrays> & a, const uint32_t m, const uint32_t slice) {
     __shared__ uint32_t lds_column[kPairChunk];
     __shared__ double lds_lo[kPairChunk], lds_hi[kPairChunk];
     __shared__ uint64_t lds_pattern[kPairChunk], lds_before[kPairChunk];
-    const uint32_t num_items = *a.between_count;
-    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
-        const uint32_t m = a.between_items[2 * static_cast<uint64_t>(item)], slice = a.between_items[2 * static_cast<uint64_t>(item) + 1];
-        const uint64_t n = a.mat_list[m] & kListSizeMask;  // (not a whole matrix: those have no items)
-        const typename Arrays::View mv = viewOf(m, a.g);
-        const uint64_t r0 = a.g.rowOffset(m);
-        const uint8_t * active = a.active + r0;
-        const uint32_t * order = a.order + 2 * r0;
-        for (uint64_t p0 = 1; p0 < n; p0 += kPairChunk) {
-            const uint32_t chunk = static_cast<uint32_t>(min(static_cast<uint64_t>(kPairChunk), n - p0));
-            __syncthreads();
-            for (uint32_t k = threadIdx.x; k < chunk; k += blockDim.x) {
-                const uint32_t d = a.pair_column[r0 + p0 + k];
-                lds_column[k] = d;
-                if (d != kNoRow) {
-                    lds_lo[k] = a.pair_lo[r0 + p0 + k];
-                    lds_hi[k] = a.pair_hi[r0 + p0 + k];
-                    lds_pattern[k] = a.pair_pattern[r0 + p0 + k];
-                    lds_before[k] = d >= 64 ? ~0ull : (1ull << d) - 1ull;
-                }
-            }
-            __syncthreads();
-            const uint64_t x_end = min(mv.R, (slice + 1ull) * kBetweenRows);
-            for (uint64_t x = slice * static_cast<uint64_t>(kBetweenRows) + threadIdx.x; x < x_end; x += blockDim.x) {
-                if (active[x]) continue;
-                const uint64_t pattern_x = mv.patternOf(x);
-                uint32_t loaded_column = kNoRow;
-                double vx = 0.0;
-                for (uint32_t k = 0; k < chunk; ++k) {
-                    const uint32_t d = lds_column[k];
-                    if (d == kNoRow || (pattern_x & lds_before[k]) != lds_pattern[k]) continue;
-                    if (d != loaded_column) {
-                        vx = mv.at(d, static_cast<uint32_t>(x));
-                        loaded_column = d;
-                    }
-                    const double lo = lds_lo[k], hi = lds_hi[k];
-                    if (!((vx >= lo || tolerantEqual(vx, lo)) && (vx <= hi || tolerantEqual(vx, hi)))) continue;
-                    const uint64_t p = p0 + k;
-                    if (!rowLess(mv, static_cast<uint32_t>(x), order[p - 1]) && !rowLess(mv, order[p], static_cast<uint32_t>(x))) a.barrier[r0 + p] = 1;
-                }
+    const uint64_t n = a.mat_list[m] & kListSizeMask;  // (not a whole matrix: those have no items)
+    const typename Arrays::View mv = viewOf(m, a.g);
+    const uint64_t r0 = a.g.rowOffset(m);
+    const uint8_t * active = a.active + r0;
+    const uint32_t * order = a.order + 2 * r0;
+    for (uint64_t p0 = 1; p0 < n; p0 += kPairChunk) {
+        const uint32_t chunk = static_cast<uint32_t>(min(static_cast<uint64_t>(kPairChunk), n - p0));
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < chunk; k += blockDim.x) {
+            const uint32_t d = a.pair_column[r0 + p0 + k];
+            lds_column[k] = d;
+            if (d != kNoRow) {
+                lds_lo[k] = a.pair_lo[r0 + p0 + k];
+                lds_hi[k] = a.pair_hi[r0 + p0 + k];
+                lds_pattern[k] = a.pair_pattern[r0 + p0 + k];
+                lds_before[k] = d >= 64 ? ~0ull : (1ull << d) - 1ull;
             }
         }
+        __syncthreads();
+        const uint64_t x_end = min(mv.R, (slice + 1ull) * kBetweenRows);
+        for (uint64_t x = slice * static_cast<uint64_t>(kBetweenRows) + threadIdx.x; x < x_end; x += blockDim.x) {
+            if (active[x]) continue;
+            const uint64_t pattern_x = mv.patternOf(x);
+            uint32_t loaded_column = kNoRow;
+            double vx = 0.0;
+            for (uint32_t k = 0; k < chunk; ++k) {
+                const uint32_t d = lds_column[k];
+                if (d == kNoRow || (pattern_x & lds_before[k]) != lds_pattern[k]) continue;
+                if (d != loaded_column) {
+                    vx = mv.at(d, static_cast<uint32_t>(x));
+                    loaded_column = d;
+                }
+                const double lo = lds_lo[k], hi = lds_hi[k];
+                if (!((vx >= lo || tolerantEqual(vx, lo)) && (vx <= hi || tolerantEqual(vx, hi)))) continue;
+                const uint64_t p = p0 + k;
+                if (!rowLess(mv, static_cast<uint32_t>(x), order[p - 1]) && !rowLess(mv, order[p], static_cast<uint32_t>(x))) a.barrier[r0 + p] = 1;
+            }
+        }
+    }
+}
+
+template <typename Arrays>
+__global__ __launch_bounds__(kBetweenThreads) void collapseBetweenKernel(const ReplayArgs<Arrays> a) {
+    const uint32_t num_items = *a.between_count;
+    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
+        betweenSlice(a, a.between_items[2 * static_cast<uint64_t>(item)], a.between_items[2 * static_cast<uint64_t>(item) + 1]);
     }
 }
 
@@ -1034,84 +987,488 @@ __device__ __forceinline__ void finishRuns(const ReplayArgs<CsrArrays> & a, cons
     __syncthreads();
 }
 
-// c. runs and values: work item = matrix with a list
+// c. runs and values of matrix m (the workgroup's)
 template <typename Arrays>
-__global__ __launch_bounds__(256) void collapseRunsKernel(const ReplayArgs<Arrays> a) {
+__device__ void runsOfMatrix(const ReplayArgs<Arrays> & a, const uint32_t m) {
     __shared__ uint32_t demote;
-    const uint32_t num_items = a.replay_list[a.num_matrices];
-    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
-        const uint32_t m = a.replay_list[item];
-        const uint32_t encoded = a.mat_list[m];
-        const uint64_t n = encoded & kListSizeMask;
-        const bool tabled = !(encoded & kBigListBit);
-        const typename Arrays::View mv = viewOf(m, a.g);
-        const uint64_t r0 = a.g.rowOffset(m);
-        const uint32_t * order = a.order + 2 * r0;
-        const uint32_t * list_index = a.list_index + r0;
-        const uint8_t * table = a.pair_table + (tabled ? a.pair_base[m] : 0);
-        uint32_t * head_of = a.head_of + r0;
-        uint8_t * close = a.close + r0;
-        const uint8_t * barrier = a.barrier + r0;
-        // list positions p, q hold rows within prob_precision of each other: read off the pair table, or compared
-        auto closeRows = [&](const uint64_t p, const uint64_t q) {
-            if (tabled) return (table[static_cast<uint64_t>(list_index[p]) * n + list_index[q]] & kPairClose) != 0;
-            return rowsClose(mv, order[p], order[q], a.precision, nullptr);
-        };
-        __syncthreads();
-        const long long clock_begin = wall_clock64();
-        if (threadIdx.x == 0) demote = 0;
-        for (uint64_t p = threadIdx.x; p < n; p += blockDim.x) {
-            head_of[p] = kNoRow;
-            close[p] = (p > 0 && !barrier[p] && closeRows(p - 1, p)) ? 1 : 0;
-        }
-        __syncthreads();
-        // Runs (src/path_estimator.cpp:226-255): a row joins the run of the current head if it is close to the head,
-        // otherwise it becomes the head.  The workgroup walks from head to head: a head whose successor is not close to it
-        // (nearly every one) is a run of its own and costs one flag; a head with followers has the whole workgroup look
-        // for the end of its run, 256 candidates at a time.  (Round 2 had every list position find "where would the next
-        // head be if I were one" on its own before one thread walked the heads: with n rows all close to each other —
-        // an EM problem over 10^5 reads that differ in the ninth digit — that is n^2 / 2 comparisons for the one run.)
-        __shared__ uint32_t walk_at, run_end;
-        if (threadIdx.x == 0) walk_at = 0;
-        __syncthreads();
-        while (walk_at < n) {  // (uniform: walk_at only changes between barriers)
-            const uint64_t h = walk_at;
-            if (h + 1 >= n || !close[h + 1]) {
-                // a stretch of single-row runs, up to the next row with a close successor: the workgroup looks for it, 256
-                // positions at a time (one thread stepping through a list of a few hundred single rows, a dependent load per
-                // step, was most of this kernel's 0.23 ms on the group matrices)
-                if (threadIdx.x == 0) run_end = static_cast<uint32_t>(n);
-                __syncthreads();
-                for (uint64_t q0 = h + 1; q0 < n && run_end == n; q0 += blockDim.x) {  // (uniform: run_end read behind the barrier below)
-                    const uint64_t q = q0 + threadIdx.x;
-                    if (q + 1 < n && close[q + 1]) atomicMin(&run_end, static_cast<uint32_t>(q));
-                    __syncthreads();
-                }
-                const uint64_t stretch_end = run_end;
-                for (uint64_t q = h + threadIdx.x; q < stretch_end; q += blockDim.x) head_of[q] = static_cast<uint32_t>(q);
-                __syncthreads();
-                if (threadIdx.x == 0) walk_at = static_cast<uint32_t>(stretch_end);
-                __syncthreads();
-                continue;
-            }
+    __shared__ uint32_t walk_at, run_end;
+    const uint32_t encoded = a.mat_list[m];
+    const uint64_t n = encoded & kListSizeMask;
+    const bool tabled = !(encoded & kBigListBit);
+    const typename Arrays::View mv = viewOf(m, a.g);
+    const uint64_t r0 = a.g.rowOffset(m);
+    const uint32_t * order = a.order + 2 * r0;
+    const uint32_t * list_index = a.list_index + r0;
+    const uint8_t * table = a.pair_table + (tabled ? a.pair_base[m] : 0);
+    uint32_t * head_of = a.head_of + r0;
+    uint8_t * close = a.close + r0;
+    const uint8_t * barrier = a.barrier + r0;
+    // list positions p, q hold rows within prob_precision of each other: read off the pair table, or compared
+    auto closeRows = [&](const uint64_t p, const uint64_t q) {
+        if (tabled) return (table[static_cast<uint64_t>(list_index[p]) * n + list_index[q]] & kPairClose) != 0;
+        return rowsClose(mv, order[p], order[q], a.precision, nullptr);
+    };
+    __syncthreads();
+    const long long clock_begin = wall_clock64();
+    if (threadIdx.x == 0) demote = 0;
+    for (uint64_t p = threadIdx.x; p < n; p += blockDim.x) {
+        head_of[p] = kNoRow;
+        close[p] = (p > 0 && !barrier[p] && closeRows(p - 1, p)) ? 1 : 0;
+    }
+    __syncthreads();
+    // Runs (src/path_estimator.cpp:226-255): a row joins the run of the current head if it is close to the head,
+    // otherwise it becomes the head.  The workgroup walks from head to head: a head whose successor is not close to it
+    // (nearly every one) is a run of its own and costs one flag; a head with followers has the whole workgroup look
+    // for the end of its run, 256 candidates at a time.  (Round 2 had every list position find "where would the next
+    // head be if I were one" on its own before one thread walked the heads: with n rows all close to each other —
+    // an EM problem over 10^5 reads that differ in the ninth digit — that is n^2 / 2 comparisons for the one run.)
+    if (threadIdx.x == 0) walk_at = 0;
+    __syncthreads();
+    while (walk_at < n) {  // (uniform: walk_at only changes between barriers)
+        const uint64_t h = walk_at;
+        if (h + 1 >= n || !close[h + 1]) {
+            // a stretch of single-row runs, up to the next row with a close successor: the workgroup looks for it, 256
+            // positions at a time (one thread stepping through a list of a few hundred single rows, a dependent load per
+            // step, was most of this kernel's 0.23 ms on the group matrices)
             if (threadIdx.x == 0) run_end = static_cast<uint32_t>(n);
             __syncthreads();
-            for (uint64_t q0 = h + 2; q0 < n && run_end == n; q0 += blockDim.x) {  // (uniform: run_end read behind the barrier below)
+            for (uint64_t q0 = h + 1; q0 < n && run_end == n; q0 += blockDim.x) {  // (uniform: run_end read behind the barrier below)
                 const uint64_t q = q0 + threadIdx.x;
-                if (q < n && (barrier[q] != 0 || !closeRows(h, q))) atomicMin(&run_end, static_cast<uint32_t>(q));
+                if (q + 1 < n && close[q + 1]) atomicMin(&run_end, static_cast<uint32_t>(q));
                 __syncthreads();
             }
-            const uint64_t end = run_end;
-            for (uint64_t q = h + threadIdx.x; q < end; q += blockDim.x) head_of[q] = static_cast<uint32_t>(h);
+            const uint64_t stretch_end = run_end;
+            for (uint64_t q = h + threadIdx.x; q < stretch_end; q += blockDim.x) head_of[q] = static_cast<uint32_t>(q);
             __syncthreads();
-            if (threadIdx.x == 0) walk_at = static_cast<uint32_t>(end);
+            if (threadIdx.x == 0) walk_at = static_cast<uint32_t>(stretch_end);
+            __syncthreads();
+            continue;
+        }
+        if (threadIdx.x == 0) run_end = static_cast<uint32_t>(n);
+        __syncthreads();
+        for (uint64_t q0 = h + 2; q0 < n && run_end == n; q0 += blockDim.x) {  // (uniform: run_end read behind the barrier below)
+            const uint64_t q = q0 + threadIdx.x;
+            if (q < n && (barrier[q] != 0 || !closeRows(h, q))) atomicMin(&run_end, static_cast<uint32_t>(q));
             __syncthreads();
         }
-        const long long clock_walked = wall_clock64();
-        finishRuns(a, m, n, order, head_of, &demote, (encoded & kWholeMatrixBit) != 0);
-        if (a.debug && threadIdx.x == 0 && wall_clock64() - clock_begin > 2000) {
-            printf("[runs] matrix %u rows %llu cols %u list %llu tabled %d: walk %lld finish %lld (10 ns)\n", m, static_cast<unsigned long long>(mv.R), mv.G,
-                   static_cast<unsigned long long>(n), tabled ? 1 : 0, clock_walked - clock_begin, wall_clock64() - clock_walked);
+        const uint64_t end = run_end;
+        for (uint64_t q = h + threadIdx.x; q < end; q += blockDim.x) head_of[q] = static_cast<uint32_t>(h);
+        __syncthreads();
+        if (threadIdx.x == 0) walk_at = static_cast<uint32_t>(end);
+        __syncthreads();
+    }
+    const long long clock_walked = wall_clock64();
+    finishRuns(a, m, n, order, head_of, &demote, (encoded & kWholeMatrixBit) != 0);
+    if (a.debug && threadIdx.x == 0 && wall_clock64() - clock_begin > 2000) {
+        printf("[runs] matrix %u rows %llu cols %u list %llu tabled %d: walk %lld finish %lld (10 ns)\n", m, static_cast<unsigned long long>(mv.R), mv.G,
+               static_cast<unsigned long long>(n), tabled ? 1 : 0, clock_walked - clock_begin, wall_clock64() - clock_walked);
+    }
+}
+
+// a0. the list of a matrix: its active rows (the replay then only touches those), or all of them.
+// (Round 4 tried the whole replay of a short list right here — pair table, ranks, rows between neighbours, runs, one stage after
+// the other behind workgroup barriers instead of six dependent launches: 12.5 against 11.5 ms per configs[2] batch.  The staged
+// kernels spread a matrix's pairs and row slices over many workgroups; one workgroup walking them in turn is the longer chain.)
+template <typename Arrays>
+__global__ __launch_bounds__(256) void collapseListKernel(const ReplayArgs<Arrays> a) {
+    __shared__ uint32_t list_size;
+    const uint32_t m = blockIdx.x;
+    if (m >= a.num_matrices) return;
+    const uint32_t flag = a.mat_flag[m];
+    if (flag == kFlagNone) {
+        if (threadIdx.x == 0) a.mat_list[m] = 0;
+        return;
+    }
+    const uint64_t R = a.g.numRows(m);
+    const uint64_t r0 = a.g.rowOffset(m);
+    const uint8_t * active = a.active + r0;
+    uint32_t * list = a.order + 2 * r0;
+    if (threadIdx.x == 0) list_size = 0;
+    __syncthreads();
+    if (flag != kFlagWholeMatrix) {
+        // (eight flags per load where the alignment allows: the largest matrix of a batch has 10^5 rows, and a byte per thread
+        // and step was 50 us of this kernel)
+        const uint64_t head = min(R, static_cast<uint64_t>((8 - (reinterpret_cast<uintptr_t>(active) & 7)) & 7));
+        for (uint64_t i = threadIdx.x; i < head; i += blockDim.x) {
+            if (active[i] == kRowListed) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(i);
+        }
+        const uint64_t words = (R - head) / 8;
+        const uint64_t * active_words = reinterpret_cast<const uint64_t *>(active + head);
+        for (uint64_t w = threadIdx.x; w < words; w += blockDim.x) {
+            uint64_t flags = active_words[w];
+            for (uint32_t k = 0; flags; ++k, flags >>= 8) {
+                if ((flags & 0xFF) == kRowListed) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(head + 8 * w + k);
+            }
+        }
+        for (uint64_t i = head + 8 * words + threadIdx.x; i < R; i += blockDim.x) {
+            if (active[i] == kRowListed) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(i);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const bool whole = flag == kFlagWholeMatrix;
+    const uint64_t n = whole ? R : list_size;
+    if (n < 2) {
+        a.mat_list[m] = 0;
+        return;
+    }
+    uint32_t encoded = static_cast<uint32_t>(n);
+    if (whole) encoded |= kWholeMatrixBit | kBigListBit;
+    else if (n > kPairwiseRows) encoded |= kBigListBit;
+    else {
+        const unsigned long long base = atomicAdd(a.pair_bytes, static_cast<unsigned long long>(n * n));
+        if (base + n * n > kPairTableBytes) encoded |= kBigListBit;
+        else {
+            a.pair_base[m] = base;
+            const uint32_t first = atomicAdd(a.row_item_count, static_cast<uint32_t>(n));
+            for (uint32_t i = 0; i < n; ++i) {
+                a.row_items[2 * static_cast<uint64_t>(first + i)] = m;
+                a.row_items[2 * static_cast<uint64_t>(first + i) + 1] = i;
+            }
+        }
+    }
+    a.mat_list[m] = encoded;
+    a.replay_list[atomicAdd(&a.replay_list[a.num_matrices], 1u)] = m;
+    if (!whole) {  // work items of step b: (matrix, slice of kBetweenRows rows)
+        const uint32_t slices = static_cast<uint32_t>((R + kBetweenRows - 1) / kBetweenRows);
+        const uint32_t first = atomicAdd(a.between_count, slices);
+        for (uint32_t k = 0; k < slices; ++k) {
+            a.between_items[2 * static_cast<uint64_t>(first + k)] = m;
+            a.between_items[2 * static_cast<uint64_t>(first + k) + 1] = k;
+        }
+    }
+    atomicAdd(&a.info[kInfoMatrices], 1u);
+    atomicAdd(&a.info[kInfoActiveRows], static_cast<uint32_t>(n));
+    if (whole) atomicAdd(&a.info[kInfoWholeMatrices], 1u);
+}
+
+// work item = matrix with a list
+template <typename Arrays>
+__global__ __launch_bounds__(256) void collapseRunsKernel(const ReplayArgs<Arrays> a) {
+    const uint32_t num_items = a.replay_list[a.num_matrices];
+    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) runsOfMatrix(a, a.replay_list[item]);
+}
+
+}  // namespace
+
+namespace {
+
+// ---- stage 0: the rows of every matrix in the order of their sort keys — without a library sort ---------------------------
+// What the window scans need: the rows of a matrix ordered by (projection[, hash of the cells]), rows of equal keys in row
+// order.  The keys carry the matrix above the projection and the rows of a matrix are contiguous, so the order is one
+// segment per matrix, and nearly every segment fits LDS: a workgroup loads a chunk of up to 8 192 rows as 64-bit words
+// [projection 24 | hash H | row 20 | largest value 20 - H], sorts them with a bitonic network in LDS and — the usual case, the
+// whole matrix in one chunk — writes the sorted keys and rows, every row's sorted position, "equal to its predecessor" and
+// the stretch starts itself.  (Rounds 2-3: hipcub::DeviceRadixSort over all rows of all matrices — five passes of three
+// launches each, 0.31 ms of a lane's 1.2 ms of collapse standing alone — and DeviceSegmentedRadixSort for the EM problems,
+// 0.5 ms in one kernel behind a host wait for its partition sizes, plus a kernel for the keys and one for "equal to its
+// predecessor" that walked every row slot.)  A matrix with more rows is sorted chunk by chunk; every element then adds up,
+// over the other chunks of its matrix, how many of their elements sort before it (a binary search per chunk: the words are
+// distinct, they carry the row) — its rank is its sorted position — and is scattered there.
+constexpr uint32_t kSortChunkRows = 8192;
+constexpr uint32_t kSortThreadsPerChunk = 512;
+constexpr uint32_t kSortRowBits = 20;                       // rows of a matrix the packed word can tell apart
+constexpr uint64_t kSortMaxSegmentRows = (1ull << kSortRowBits) - 1;
+constexpr uint32_t kSortChunkItems = 8;                     // fill items (kFillSegmentRows = 1 024 row slots) per chunk
+
+template <int HASH>
+__device__ __forceinline__ uint64_t packSortWord(const uint64_t key, const uint32_t row) {
+    constexpr int low = kCollapseLargestBits - HASH;  // bits of the key that are not sorted on
+    const uint64_t sorted = (key & ((1ull << kCollapseMatrixShift) - 1)) >> low;
+    return (sorted << (kSortRowBits + low)) | (static_cast<uint64_t>(row) << low) | (key & ((1ull << low) - 1));
+}
+template <int HASH>
+__device__ __forceinline__ uint32_t sortWordRow(const uint64_t word) { return static_cast<uint32_t>(word >> (kCollapseLargestBits - HASH)) & ((1u << kSortRowBits) - 1); }
+template <int HASH>
+__device__ __forceinline__ uint64_t sortWordKey(const uint64_t word, const uint32_t matrix) {
+    constexpr int low = kCollapseLargestBits - HASH;
+    return (static_cast<uint64_t>(matrix) << kCollapseMatrixShift) | ((word >> (kSortRowBits + low)) << low) | (word & ((1ull << low) - 1));
+}
+template <int HASH>
+__device__ __forceinline__ bool sortWordsSameSortedPart(const uint64_t x, const uint64_t y) {
+    constexpr int shift = kSortRowBits + kCollapseLargestBits - HASH;
+    return HASH ? (x >> shift) == (y >> shift) : ((x >> shift) == (y >> shift) && ((x ^ y) & ((1ull << (kCollapseLargestBits - HASH)) - 1)) == 0);
+}
+
+// a column's share of the hash of a row's cells (summed: the entries of a row come in no particular order; an empty cell adds nothing)
+__device__ __forceinline__ uint64_t cellHashTerm(const uint32_t column, const double value) {
+    const uint64_t cell = static_cast<uint64_t>(cellOf(value));
+    uint64_t x = (cell + 0x632BE59BD9B4E019ull * (column + 1)) * 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return cell ? x * 0xC2B2AE3D27D4EB4Full : 0;
+}
+
+
+// the key of row i of matrix m: group matrices carry it (written by the build kernels), the rows of an EM problem get it here
+// (projection of the normalised row, its largest value, a hash of its cells) together with their zero pattern
+__device__ __forceinline__ uint64_t sortKeyOfRow(const MatrixArrays & g, const uint32_t m, const uint64_t r0, const uint32_t i, const uint64_t * key_in,
+                                                 uint64_t * pattern_out) {
+    (void) g; (void) m; (void) pattern_out;
+    return key_in[r0 + i];
+}
+__device__ __forceinline__ uint64_t sortKeyOfRow(const CsrArrays & g, const uint32_t p, const uint64_t r0, const uint32_t i, const uint64_t * key_in,
+                                                 uint64_t * pattern_out) {
+    (void) key_in;
+    const CsrView mv = g.view(p);
+    const double noise = mv.noise[i];
+    double projection = collapseWeight(mv.G) * noise, largest = 0.0;
+    uint64_t cells = cellHashTerm(mv.G, noise), pattern = 0;
+    for (uint32_t e = mv.off[i]; e < mv.off[i + 1]; ++e) {
+        const uint32_t c = mv.col[e];
+        const double v = mv.val[e];
+        projection = fma(collapseWeight(c), v, projection);
+        largest = fmax(largest, v);
+        cells += cellHashTerm(c, v);
+        if (c < 64 && v != 0.0) pattern |= 1ull << c;
+    }
+    pattern_out[r0 + i] = pattern;
+    // the top of the low field: a hash of the row's cells, sorted on (rows of equal cells end up next to each other)
+    constexpr int low_bits = kCollapseLargestBits - kCsrCellHashBits;
+    uint64_t k = collapseSortKey(p, projection, largest);
+    k = (k & ~((1ull << kCollapseLargestBits) - 1)) | (((cells * 0x9E3779B97F4A7C15ull) >> (64 - kCsrCellHashBits)) << low_bits) | (k & ((1ull << low_bits) - 1));
+    return k;
+}
+
+template <typename Arrays>
+struct ChunkSortArgs {
+    Arrays g;
+    uint32_t num_matrices;               // group matrices: their number; EM problems: the bound of their number
+    const uint32_t * num_matrices_dev;   // EM problems on a device-built list: their number
+    // who sorts what.  Group matrices: workgroup b < num_matrices takes chunk 0 of matrix b, workgroup num_matrices + k the k-th
+    // (matrix, chunk) of `extra` (the further chunks of the matrices with more than a chunk of rows: the host knows the sizes).
+    const uint32_t * extra;
+    uint32_t num_extra;
+    // EM problems: a workgroup per work item of the fill (em_sparse.hip: segment_rows row slots of a problem); the first of
+    // every kSortChunkItems items of a problem leads a chunk; every item writes the unused slots of its own range
+    uint32_t num_items_bound;
+    const uint32_t * num_items_dev;
+    const uint64_t * seg_first;
+    const uint32_t * item_problem;
+    uint32_t segment_rows;
+    uint64_t total_rows;
+    const uint64_t * key_in;             // group matrices: the keys of the build
+    uint64_t * pattern_out;              // EM problems: zero pattern of every row slot
+    uint64_t * sort_key;                 // sorted (matrix, key, largest value), by position
+    uint32_t * sort_row;
+    uint32_t * position_of;              // by row: its sorted position
+    uint8_t * same_prev;
+    uint32_t * stretch_start;
+    uint64_t * chunk_words;              // [total rows] the sorted chunks of the matrices with several
+    uint32_t * rank;                     // [total rows] by chunk slot: elements of the matrix that sort before it
+    uint32_t * multi;                    // [M] the matrix has several chunks
+    uint32_t * merge_items;              // [3 x capacity] (matrix, chunk, other chunk)
+    uint32_t * merge_count;              // [0] items, [1] chunks of multi-chunk matrices, [2] overflow
+    uint32_t merge_capacity;
+    uint32_t * multi_chunks;             // [2 x chunk capacity] (matrix, chunk) of the multi-chunk matrices
+    uint32_t multi_chunk_capacity;
+};
+
+template <typename Arrays>
+__device__ __forceinline__ void writeSortedPosition(const ChunkSortArgs<Arrays> & a, const uint32_t m, const uint64_t r0, const uint64_t position, const uint64_t word,
+                                                    const uint64_t word_before, const bool has_before) {
+    constexpr int HASH = Arrays::kHashBits;
+    const uint32_t row = sortWordRow<HASH>(word);
+    uint8_t same = 0;
+    if (has_before && sortWordsSameSortedPart<HASH>(word, word_before)) {
+        const typename Arrays::View mv = viewOf(m, a.g);
+        const uint32_t before = sortWordRow<HASH>(word_before);
+        same = (HASH ? rowsSameCells(mv, row, before) : rowsIdentical(mv, row, before)) ? 1 : 0;
+    }
+    a.sort_key[position] = sortWordKey<HASH>(word, m);
+    a.sort_row[position] = static_cast<uint32_t>(r0 + row);
+    a.position_of[r0 + row] = static_cast<uint32_t>(position);
+    a.same_prev[position] = same;
+    a.stretch_start[position] = same ? 0u : static_cast<uint32_t>(position);
+}
+
+template <typename Arrays>
+__global__ __launch_bounds__(kSortThreadsPerChunk) void collapseChunkSortKernel(const ChunkSortArgs<Arrays> a) {
+    __shared__ uint64_t words[kSortChunkRows];
+    constexpr int HASH = Arrays::kHashBits;
+    constexpr bool kCsr = HASH != 0;
+    const uint32_t M = a.num_matrices_dev ? min(*a.num_matrices_dev, a.num_matrices) : a.num_matrices;
+    uint32_t m, chunk;
+    if (!kCsr) {
+        if (blockIdx.x < a.num_matrices) {
+            m = blockIdx.x;
+            chunk = 0;
+        } else {
+            const uint32_t k = blockIdx.x - a.num_matrices;
+            if (k >= a.num_extra) return;
+            m = a.extra[2 * k];
+            chunk = a.extra[2 * k + 1];
+        }
+    } else {
+        const uint32_t items = a.num_items_dev ? min(*a.num_items_dev, a.num_items_bound) : a.num_items_bound;
+        const uint32_t item = blockIdx.x;
+        const uint64_t unused = collapseSortKey(a.num_matrices, 0.0, 0.0);
+        if (item == 0) {
+            // the row slots behind the last problem (everything, if there is none): keys that sort behind every row and are close to nothing
+            const uint64_t from = M == 0 ? 0 : a.g.rowOffset(M - 1) + a.g.numRows(M - 1);
+            // (the slots between the last problem's rows and its bound are written with its last item; the ones from its bound on, here)
+            const uint64_t tail = M == 0 ? 0 : max(from, a.g.rowOffset(M - 1) + static_cast<uint64_t>(a.seg_first[M] - a.seg_first[M - 1]) * a.segment_rows);
+            for (uint64_t r = tail + threadIdx.x; r < a.total_rows; r += blockDim.x) {
+                a.sort_key[r] = unused;
+                a.sort_row[r] = static_cast<uint32_t>(r);
+                a.position_of[r] = static_cast<uint32_t>(r);
+                a.same_prev[r] = 0;
+                a.stretch_start[r] = static_cast<uint32_t>(r);
+                a.pattern_out[r] = 0;
+            }
+        }
+        if (item >= items) return;
+        m = a.item_problem[item];
+        if (m >= M) return;
+        const uint64_t s = item - a.seg_first[m];
+        const bool last = item + 1 == a.seg_first[m + 1];
+        const uint64_t r0 = a.g.rowOffset(m), R = a.g.numRows(m);
+        // unused slots of this item's range (the last item: up to the end of the problem's items — the next problem starts there
+        // at the latest — or, behind the last problem, as far as its items reach)
+        const uint64_t lo = max(R, s * a.segment_rows);
+        const uint64_t bound = (m + 1 < M) ? a.g.rowOffset(m + 1) - r0 : static_cast<uint64_t>(a.seg_first[m + 1] - a.seg_first[m]) * a.segment_rows;
+        const uint64_t hi = last ? min(bound, a.total_rows - r0) : min(bound, (s + 1) * a.segment_rows);
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            a.sort_key[r0 + i] = unused;
+            a.sort_row[r0 + i] = static_cast<uint32_t>(r0 + i);
+            a.position_of[r0 + i] = static_cast<uint32_t>(r0 + i);
+            a.same_prev[r0 + i] = 0;
+            a.stretch_start[r0 + i] = static_cast<uint32_t>(r0 + i);
+            a.pattern_out[r0 + i] = 0;
+        }
+        if (s % kSortChunkItems != 0) return;  // (the chunk's leader sorts)
+        chunk = static_cast<uint32_t>(s / kSortChunkItems);
+    }
+    const uint64_t R = a.g.numRows(m);
+    const uint64_t r0 = a.g.rowOffset(m);
+    const uint64_t c0 = static_cast<uint64_t>(chunk) * kSortChunkRows;
+    if (c0 >= R) return;
+    const uint32_t n = static_cast<uint32_t>(min(static_cast<uint64_t>(kSortChunkRows), R - c0));
+    const uint32_t num_chunks = static_cast<uint32_t>((R + kSortChunkRows - 1) / kSortChunkRows);
+    uint32_t padded = 64;
+    while (padded < n) padded <<= 1;
+    for (uint32_t i = threadIdx.x; i < padded; i += blockDim.x) {
+        words[i] = i < n ? packSortWord<HASH>(sortKeyOfRow(a.g, m, r0, static_cast<uint32_t>(c0 + i), a.key_in, a.pattern_out), static_cast<uint32_t>(c0 + i)) : ~0ull;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= padded; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (padded >> 1); t += blockDim.x) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // bit j of i is clear
+                const uint32_t l = i | j;
+                const uint64_t x = words[i], y = words[l];
+                if (((i & k) == 0) == (x > y)) {
+                    words[i] = y;
+                    words[l] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (num_chunks == 1) {
+        if (threadIdx.x == 0) a.multi[m] = 0;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) writeSortedPosition(a, m, r0, r0 + i, words[i], i ? words[i - 1] : 0ull, i != 0);
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        a.chunk_words[r0 + c0 + i] = words[i];
+        a.rank[r0 + c0 + i] = i;
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t at = atomicAdd(&a.merge_count[1], 1u);
+        if (at < a.multi_chunk_capacity) {
+            a.multi_chunks[2 * static_cast<uint64_t>(at)] = m;
+            a.multi_chunks[2 * static_cast<uint64_t>(at) + 1] = chunk;
+        } else {
+            atomicAdd(&a.merge_count[2], 1u);
+        }
+        if (chunk == 0) {
+            a.multi[m] = 1;
+            const uint32_t pairs = num_chunks * (num_chunks - 1);
+            const uint32_t first = atomicAdd(&a.merge_count[0], pairs);
+            if (first + pairs <= a.merge_capacity) {
+                uint32_t slot = first;
+                for (uint32_t ci = 0; ci < num_chunks; ++ci) {
+                    for (uint32_t cj = 0; cj < num_chunks; ++cj) {
+                        if (ci == cj) continue;
+                        a.merge_items[3 * static_cast<uint64_t>(slot)] = m;
+                        a.merge_items[3 * static_cast<uint64_t>(slot) + 1] = ci;
+                        a.merge_items[3 * static_cast<uint64_t>(slot) + 2] = cj;
+                        ++slot;
+                    }
+                }
+            } else {
+                atomicAdd(&a.merge_count[2], 1u);
+            }
+        }
+    }
+}
+
+// every element of chunk ci adds the number of chunk cj's elements that sort before it to its rank
+template <typename Arrays>
+__global__ __launch_bounds__(256) void collapseChunkRankKernel(const ChunkSortArgs<Arrays> a) {
+    const uint32_t items = min(a.merge_count[0], a.merge_capacity);
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const uint32_t m = a.merge_items[3 * static_cast<uint64_t>(item)], ci = a.merge_items[3 * static_cast<uint64_t>(item) + 1], cj = a.merge_items[3 * static_cast<uint64_t>(item) + 2];
+        const uint64_t R = a.g.numRows(m), r0 = a.g.rowOffset(m);
+        const uint64_t i0 = static_cast<uint64_t>(ci) * kSortChunkRows, j0 = static_cast<uint64_t>(cj) * kSortChunkRows;
+        const uint32_t ni = static_cast<uint32_t>(min(static_cast<uint64_t>(kSortChunkRows), R - i0)), nj = static_cast<uint32_t>(min(static_cast<uint64_t>(kSortChunkRows), R - j0));
+        const uint64_t * other = a.chunk_words + r0 + j0;
+        for (uint32_t e = threadIdx.x; e < ni; e += blockDim.x) {
+            const uint64_t x = a.chunk_words[r0 + i0 + e];
+            uint32_t lo = 0, hi = nj;  // first element of the other chunk that is not below x
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (other[mid] < x) lo = mid + 1;
+                else hi = mid;
+            }
+            if (lo) atomicAdd(&a.rank[r0 + i0 + e], lo);
+        }
+    }
+}
+
+// ... and goes to its sorted position
+template <typename Arrays>
+__global__ __launch_bounds__(256) void collapseChunkScatterKernel(const ChunkSortArgs<Arrays> a) {
+    constexpr int HASH = Arrays::kHashBits;
+    const uint32_t chunks = min(a.merge_count[1], a.multi_chunk_capacity);
+    for (uint32_t item = blockIdx.x; item < chunks; item += gridDim.x) {
+        const uint32_t m = a.multi_chunks[2 * static_cast<uint64_t>(item)], chunk = a.multi_chunks[2 * static_cast<uint64_t>(item) + 1];
+        const uint64_t R = a.g.numRows(m), r0 = a.g.rowOffset(m);
+        const uint64_t c0 = static_cast<uint64_t>(chunk) * kSortChunkRows;
+        const uint32_t n = static_cast<uint32_t>(min(static_cast<uint64_t>(kSortChunkRows), R - c0));
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+            const uint64_t word = a.chunk_words[r0 + c0 + e];
+            const uint64_t position = r0 + a.rank[r0 + c0 + e];
+            a.sort_key[position] = sortWordKey<HASH>(word, m);
+            a.sort_row[position] = static_cast<uint32_t>(r0 + sortWordRow<HASH>(word));
+            a.position_of[r0 + sortWordRow<HASH>(word)] = static_cast<uint32_t>(position);
+        }
+    }
+}
+
+// "equal to its predecessor" and the stretch starts of the multi-chunk matrices (their neighbours are known only now)
+template <typename Arrays>
+__global__ __launch_bounds__(256) void collapseChunkSamePrevKernel(const ChunkSortArgs<Arrays> a) {
+    constexpr int HASH = Arrays::kHashBits;
+    const uint32_t chunks = min(a.merge_count[1], a.multi_chunk_capacity);
+    for (uint32_t item = blockIdx.x; item < chunks; item += gridDim.x) {
+        const uint32_t m = a.multi_chunks[2 * static_cast<uint64_t>(item)], chunk = a.multi_chunks[2 * static_cast<uint64_t>(item) + 1];
+        const uint64_t R = a.g.numRows(m), r0 = a.g.rowOffset(m);
+        const uint64_t c0 = static_cast<uint64_t>(chunk) * kSortChunkRows;  // (positions this time: any split of them will do)
+        const uint32_t n = static_cast<uint32_t>(min(static_cast<uint64_t>(kSortChunkRows), R - c0));
+        const typename Arrays::View mv = viewOf(m, a.g);
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+            const uint64_t p = r0 + c0 + e;
+            uint8_t same = 0;
+            if (c0 + e > 0) {
+                const uint64_t key = a.sort_key[p], before = a.sort_key[p - 1];
+                if (HASH ? keySorted<HASH>(key) == keySorted<HASH>(before) : key == before) {
+                    const uint32_t row = static_cast<uint32_t>(a.sort_row[p] - r0), row_before = static_cast<uint32_t>(a.sort_row[p - 1] - r0);
+                    same = (HASH ? rowsSameCells(mv, row, row_before) : rowsIdentical(mv, row, row_before)) ? 1 : 0;
+                }
+            }
+            a.same_prev[p] = same;
+            a.stretch_start[p] = same ? 0u : static_cast<uint32_t>(p);
         }
     }
 }
@@ -1132,6 +1489,23 @@ struct CollapseTemporaries {
     // EM problems only
     DeviceBuffer<uint64_t> csr_key, csr_pattern;
     DeviceBuffer<uint32_t> csr_row, csr_segments;
+    // the hand-written segment sort (stage 0)
+    DeviceBuffer<uint64_t> chunk_words;
+    DeviceBuffer<uint32_t> chunk_rank, multi, merge_items, merge_count, multi_chunks, extra_chunks;
+};
+
+// who sorts what in the hand-written segment sort (ChunkSortArgs); null: the library sort
+struct SegmentSortPlan {
+    const uint32_t * extra = nullptr;              // group matrices: (matrix, chunk) of the chunks behind the first of every matrix
+    uint32_t num_extra = 0;
+    const uint32_t * num_matrices_dev = nullptr;   // EM problems: the work items of the fill
+    uint32_t num_items_bound = 0;
+    const uint32_t * num_items_dev = nullptr;
+    const uint64_t * seg_first = nullptr;
+    const uint32_t * item_problem = nullptr;
+    uint32_t segment_rows = 0;
+    uint64_t * pattern_out = nullptr;
+    uint64_t max_segment_rows = 0;                 // a bound of the rows of the largest matrix (capacity of the merge lists)
 };
 
 // The stages behind the keys, for group matrices and for EM problems alike: `key` / `row` hold, per row slot, the sort key
@@ -1139,7 +1513,7 @@ struct CollapseTemporaries {
 template <typename Arrays>
 hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const uint64_t total_rows, const double precision, const uint64_t * key,
                                const uint32_t * row, const uint32_t * segment_begin, const uint32_t * segment_end, const bool segmented, DeviceBuffer<uint32_t> & info, double * rowmax, uint32_t * mat_fast,
-                               uint32_t * mat_mid, CollapseTemporaries * tmp, hipStream_t st) {
+                               uint32_t * mat_mid, CollapseTemporaries * tmp, hipStream_t st, const SegmentSortPlan * plan = nullptr) {
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     // zeroed words: the pair table's byte counter (8 bytes, first: aligned), matrix flags [M], replay list [M] + its
@@ -1168,7 +1542,8 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     ok(tmp->stretch.alloc(4 * total_rows));
     // The keys carry the matrix above the projection and the rows of a matrix are contiguous: ONE (stable) radix sort of
     // the whole array on the projection and as many matrix bits as there are matrices orders every matrix's rows by their
-    // projection.  (Round 2 sorted segment by segment, hipcub::DeviceSegmentedRadixSort: 0.33 ms per 1.6 M rows in 2 500
+    // projection.  (The library path: RPVG_HIP_COLLAPSE_LIBRARY_SORT=1 for A/B, and matrices of 2^20 rows or more.  Round 2
+    // sorted segment by segment, hipcub::DeviceSegmentedRadixSort: 0.33 ms per 1.6 M rows in 2 500
     // segments, the longest kernel of the collapse; RPVG_HIP_COLLAPSE_SEGMENTED_SORT=1 keeps it for A/B on the group matrices.)
     int matrix_bits = 1;
     while ((1u << matrix_bits) < M + 1) ++matrix_bits;  // (+ 1: the index unused row slots of the EM problems carry)
@@ -1183,7 +1558,7 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
                          : hipcub::DeviceRadixSort::SortPairs(scratch, sort_bytes, key, tmp->key_out.ptr, row,
                                                               tmp->row_out.ptr, static_cast<int>(total_rows), begin_bit, end_bit, st);
     };
-    if (e == hipSuccess) ok(sort(nullptr));
+    if (e == hipSuccess && !plan) ok(sort(nullptr));
     uint32_t * stretch_start = tmp->stretch.ptr, * stretch_first = stretch_start + total_rows, * stretch_end = stretch_first + total_rows,
              * position_of = stretch_end + total_rows;
     size_t scan_bytes = 0;
@@ -1192,6 +1567,19 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     };
     if (e == hipSuccess) ok(scan(nullptr));
     ok(tmp->sort_tmp.alloc(std::max(sort_bytes, scan_bytes)));
+    // the hand-written segment sort: its lists (the merge of the matrices with more than a chunk of rows)
+    uint32_t total_chunks_bound = 0, merge_capacity = 0;
+    if (plan) {
+        total_chunks_bound = static_cast<uint32_t>(std::min<uint64_t>(total_rows / kSortChunkRows + M + 1, 0x7fffffffull));
+        const uint64_t max_chunks = (plan->max_segment_rows + kSortChunkRows - 1) / kSortChunkRows;
+        merge_capacity = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(total_chunks_bound) * (max_chunks > 1 ? max_chunks - 1 : 0) + 1, 0x10000000ull));
+        ok(tmp->chunk_words.alloc(total_rows));
+        ok(tmp->chunk_rank.alloc(total_rows));
+        ok(tmp->multi.alloc(M + 1));
+        ok(tmp->merge_items.alloc(3 * static_cast<size_t>(merge_capacity)));
+        ok(tmp->merge_count.alloc(4));
+        ok(tmp->multi_chunks.alloc(2 * static_cast<size_t>(total_chunks_bound)));
+    }
     if (e != hipSuccess) return e;
     uint32_t * pair_bytes = info.ptr + kInfoWords, * mat_flag = pair_bytes + 2, * replay_list = mat_flag + M, * marked_bits = replay_list + M + 1,
              * marked_count = marked_bits + mark_words, * pair_counts = marked_count + 1, * between_count = pair_counts + 2,
@@ -1199,7 +1587,7 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     uint8_t * same_prev = tmp->bytes.ptr, * close = same_prev + total_rows, * barrier = close + total_rows;
     uint8_t * active = reinterpret_cast<uint8_t *>(pair_bytes + num_words);
     ok(hipMemsetAsync(info.ptr, 0, (kInfoWords + num_words + active_words) * sizeof(uint32_t), st));
-    ok(sort(tmp->sort_tmp.ptr));
+    if (!plan) ok(sort(tmp->sort_tmp.ptr));
     PairScanArgs<Arrays> a;
     a.total_rows = total_rows;
     a.precision = precision;
@@ -1222,15 +1610,56 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     a.num_matrices = M;
     a.count_pairs = std::getenv("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
     const uint32_t row_blocks = static_cast<uint32_t>((total_rows + 255) / 256);
-    collapseSamePrevKernel<Arrays><<<dim3(row_blocks), dim3(256), 0, st>>>(a);
+    // The kernels over pairs, lists and matrices with a list draw their (few) items from device-side counts with grid-stride
+    // loops: a workgroup per CU or two, not thousands that find nothing (a workgroup costs the dispatcher ~40 ns whatever it does:
+    // 4 096 of them were most of a 60 us kernel).  RPVG_HIP_COLLAPSE_GRID overrides (A/B).
+    static const uint32_t small_grid = std::getenv("RPVG_HIP_COLLAPSE_GRID") ? std::max(1, std::atoi(std::getenv("RPVG_HIP_COLLAPSE_GRID"))) : 256;
+    if (plan) {
+        ok(hipMemsetAsync(tmp->merge_count.ptr, 0, 4 * sizeof(uint32_t), st));
+        ChunkSortArgs<Arrays> c;
+        c.g = arrays;
+        c.num_matrices = M;
+        c.num_matrices_dev = plan->num_matrices_dev;
+        c.extra = plan->extra;
+        c.num_extra = plan->num_extra;
+        c.num_items_bound = plan->num_items_bound;
+        c.num_items_dev = plan->num_items_dev;
+        c.seg_first = plan->seg_first;
+        c.item_problem = plan->item_problem;
+        c.segment_rows = plan->segment_rows;
+        c.total_rows = total_rows;
+        c.key_in = key;
+        c.pattern_out = plan->pattern_out;
+        c.sort_key = tmp->key_out.ptr;
+        c.sort_row = tmp->row_out.ptr;
+        c.position_of = position_of;
+        c.same_prev = same_prev;
+        c.stretch_start = stretch_start;
+        c.chunk_words = tmp->chunk_words.ptr;
+        c.rank = tmp->chunk_rank.ptr;
+        c.multi = tmp->multi.ptr;
+        c.merge_items = tmp->merge_items.ptr;
+        c.merge_count = tmp->merge_count.ptr;
+        c.merge_capacity = merge_capacity;
+        c.multi_chunks = tmp->multi_chunks.ptr;
+        c.multi_chunk_capacity = total_chunks_bound;
+        const uint32_t sort_grid = Arrays::kHashBits ? std::max<uint32_t>(1, plan->num_items_bound) : M + plan->num_extra;
+        collapseChunkSortKernel<Arrays><<<dim3(sort_grid), dim3(kSortThreadsPerChunk), 0, st>>>(c);
+        // (the matrices with more than a chunk of rows: a handful per batch — the launches find their lists empty otherwise)
+        collapseChunkRankKernel<Arrays><<<dim3(2 * small_grid), dim3(256), 0, st>>>(c);
+        collapseChunkScatterKernel<Arrays><<<dim3(small_grid), dim3(256), 0, st>>>(c);
+        collapseChunkSamePrevKernel<Arrays><<<dim3(small_grid), dim3(256), 0, st>>>(c);
+    } else {
+        collapseSamePrevKernel<Arrays><<<dim3(row_blocks), dim3(256), 0, st>>>(a);
+    }
     ok(scan(tmp->sort_tmp.ptr));
     a.stretch_first = stretch_first;
     collapseStretchEndKernel<Arrays><<<dim3(row_blocks), dim3(256), 0, st>>>(a);
     collapseForwardPairsKernel<Arrays><<<dim3(row_blocks), dim3(256), 0, st>>>(a);
-    collapseMarkPairsKernel<Arrays><<<dim3(1024), dim3(64), 0, st>>>(a);
+    collapseMarkPairsKernel<Arrays><<<dim3(small_grid), dim3(64), 0, st>>>(a);
     a.pair_count = pair_counts + 1;  // the list is free again
     collapseAroundPairsKernel<Arrays><<<dim3(256), dim3(64), 0, st>>>(a);
-    collapseActivePairsKernel<Arrays><<<dim3(1024), dim3(64), 0, st>>>(a);
+    collapseActivePairsKernel<Arrays><<<dim3(small_grid), dim3(64), 0, st>>>(a);
     ReplayArgs<Arrays> r;
     r.num_matrices = M;
     r.precision = precision;
@@ -1264,21 +1693,13 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     r.info = info.ptr;
     r.debug = std::getenv("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
     collapseListKernel<Arrays><<<dim3(M), dim3(256), 0, st>>>(r);
-    collapsePairTableKernel<Arrays><<<dim3(4096), dim3(64), 0, st>>>(r);
-    collapseRankKernel<Arrays><<<dim3(1024), dim3(256), 0, st>>>(r);
+    collapsePairTableKernel<Arrays><<<dim3(2 * small_grid), dim3(64), 0, st>>>(r);
+    collapseRankKernel<Arrays><<<dim3(small_grid), dim3(256), 0, st>>>(r);
     collapseSortKernel<Arrays><<<dim3(std::min<uint32_t>(M, 128)), dim3(kSortThreads), 0, st>>>(r);
-    collapseBetweenKernel<Arrays><<<dim3(2048), dim3(kBetweenThreads), 0, st>>>(r);
-    collapseRunsKernel<Arrays><<<dim3(1024), dim3(256), 0, st>>>(r);
+    collapseBetweenKernel<Arrays><<<dim3(2 * small_grid), dim3(kBetweenThreads), 0, st>>>(r);
+    collapseRunsKernel<Arrays><<<dim3(small_grid), dim3(256), 0, st>>>(r);
     ok(hipGetLastError());
     return e;
-}
-
-// a column's share of the hash of a row's cells (summed: the entries of a row come in no particular order; an empty cell adds nothing)
-__device__ __forceinline__ uint64_t cellHashTerm(const uint32_t column, const double value) {
-    const uint64_t cell = static_cast<uint64_t>(cellOf(value));
-    uint64_t x = (cell + 0x632BE59BD9B4E019ull * (column + 1)) * 0xD6E8FEB86659FD93ull;
-    x ^= x >> 32;
-    return cell ? x * 0xC2B2AE3D27D4EB4Full : 0;
 }
 
 // sort key, slot and zero pattern of every row slot of the EM problems' storage: the slots of a problem's kept rows carry
@@ -1377,9 +1798,28 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     arrays.row_count = g->row_count.ptr;
     arrays.zero_pattern = g->collapse_mask.ptr;
     static const bool segmented = std::getenv("RPVG_HIP_COLLAPSE_SEGMENTED_SORT") != nullptr;  // (A/B: slower on the group matrices)
+    static const bool library_sort = std::getenv("RPVG_HIP_COLLAPSE_LIBRARY_SORT") != nullptr || segmented;  // A/B knob
+    // the hand-written segment sort: chunk 0 of every matrix, and the further chunks of the few matrices with more rows than a chunk
+    SegmentSortPlan plan;
+    std::vector<uint32_t> extra;
+    for (uint32_t m = 0; m < M; ++m) {
+        const uint64_t R = g->h_num_rows[m];
+        plan.max_segment_rows = std::max(plan.max_segment_rows, R);
+        for (uint64_t chunk = 1; chunk * kSortChunkRows < R; ++chunk) {
+            extra.push_back(m);
+            extra.push_back(static_cast<uint32_t>(chunk));
+        }
+    }
+    const bool use_plan = !library_sort && plan.max_segment_rows <= kSortMaxSegmentRows;
+    if (use_plan && !extra.empty()) {
+        hipError_t e = tmp->extra_chunks.upload(extra.data(), extra.size(), st);
+        if (e != hipSuccess) return e;
+        plan.extra = tmp->extra_chunks.ptr;
+        plan.num_extra = static_cast<uint32_t>(extra.size() / 2);
+    }
     return queueCollapseStages(arrays, M, total_rows, precision, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_segment_off.ptr,
                                g->collapse_segment_off.ptr + 1, segmented && g->collapse_segment_off.ptr != nullptr, g->collapse_info,
-                               g->rowmax.ptr, g->mat_fast.ptr, g->mat_mid.ptr, tmp.get(), st);
+                               g->rowmax.ptr, g->mat_fast.ptr, g->mat_mid.ptr, tmp.get(), st, use_plan ? &plan : nullptr);
 }
 
 // readCollapseProbabilityMatrix on the rows of every EM problem of a solve (src/path_abundance_estimator.cpp:266,668): queued
@@ -1395,9 +1835,16 @@ hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollap
     work.temporaries = tmp;
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
-    ok(tmp->csr_key.alloc(total_rows));
-    ok(tmp->csr_row.alloc(total_rows));
+    static const bool library_sort = std::getenv("RPVG_HIP_COLLAPSE_LIBRARY_SORT") != nullptr;  // A/B knob
+    // The hand-written segment sort works on the fill's items (chunks of kSortChunkItems of them) and computes the keys itself;
+    // problems of 2^20 rows or more (by the bound) and the A/B knob take the library sort behind csrCollapseKeysKernel.
+    const bool use_plan = !library_sort && in.max_rows_bound <= kSortMaxSegmentRows && in.max_rows_bound > 0 &&
+                          static_cast<uint64_t>(in.segment_rows) * kSortChunkItems == kSortChunkRows && in.seg_first && in.item_problem;
     ok(tmp->csr_pattern.alloc(total_rows));
+    if (!use_plan) {
+        ok(tmp->csr_key.alloc(total_rows));
+        ok(tmp->csr_row.alloc(total_rows));
+    }
     ok(work.merged_count.alloc(total_rows));
     ok(work.problem_merged.alloc(P + 1));  // [P]: the number of merged problems
     if (e != hipSuccess) return e;
@@ -1416,6 +1863,18 @@ hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollap
     arrays.merged_count = work.merged_count.ptr;
     arrays.problem_merged = work.problem_merged.ptr;
     arrays.merged_problems = work.problem_merged.ptr + P;
+    if (use_plan) {
+        SegmentSortPlan plan;
+        plan.num_matrices_dev = in.num_problems_dev;
+        plan.num_items_bound = in.num_items_bound;
+        plan.num_items_dev = in.num_items_dev;
+        plan.seg_first = in.seg_first;
+        plan.item_problem = in.item_problem;
+        plan.segment_rows = in.segment_rows;
+        plan.pattern_out = tmp->csr_pattern.ptr;
+        plan.max_segment_rows = in.max_rows_bound;
+        return queueCollapseStages(arrays, P, total_rows, precision, nullptr, nullptr, nullptr, nullptr, false, work.info, nullptr, nullptr, nullptr, tmp.get(), st, &plan);
+    }
     // The rows of a problem are sorted as a segment: a handful of launches against the global sort's seven passes of three
     // launches each (same box, configs[2] batch: 12.0-12.5 ms per step against 14.6).  RPVG_HIP_EM_COLLAPSE_GLOBAL_SORT=1: the
     // global sort (A/B).
