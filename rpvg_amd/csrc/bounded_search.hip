@@ -39,13 +39,30 @@ std::mutex g_search_gate_mutex;
 const rpvg_hip_ctx * g_search_gate_owner = nullptr;  // context of the last search queued
 }
 
+// A stream whose next command waits for an event holds its hardware queue until the event arrives — eight queues for all the
+// streams of both lanes (hardwareQueues()) — and the kernels of other streams on that queue stand behind it: a search parked
+// behind the other lane's search (0.8 ms) or behind its matrices' collapse (1 ms) stalled kernels that had nothing to do with
+// either.  The submitting thread therefore waits for a long dependency itself and queues the kernels when they can run
+// (it has nothing else to queue meanwhile); the stream wait stays, as the ordering guarantee.
+// RPVG_HIP_SEARCH_LAUNCH_EARLY=1: stream waits only (A/B).
+static bool searchLaunchesEarly() {
+    static const bool early = std::getenv("RPVG_HIP_SEARCH_LAUNCH_EARLY") != nullptr;
+    return early;
+}
+
 static void searchGateEnter(const rpvg_hip_ctx * ctx, hipStream_t stream) {
     static const bool open_gate = std::getenv("RPVG_HIP_NO_SEARCH_GATE") != nullptr;  // A/B knob
     if (open_gate) return;
-    std::lock_guard<std::mutex> lock(g_search_gate_mutex);
-    if (g_search_gate_owner && g_search_gate_owner != ctx && g_search_gate_owner->device == ctx->device) {
-        (void) hipStreamWaitEvent(stream, g_search_gate_owner->search_done, 0);
+    hipEvent_t previous = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_search_gate_mutex);
+        if (g_search_gate_owner && g_search_gate_owner != ctx && g_search_gate_owner->device == ctx->device) {
+            previous = g_search_gate_owner->search_done;
+            (void) hipStreamWaitEvent(stream, previous, 0);
+        }
     }
+    // (outside the lock: the other lane records its own event under it)
+    if (previous && !searchLaunchesEarly()) (void) hipEventSynchronize(previous);
 }
 
 static void searchGateLeave(const rpvg_hip_ctx * ctx, hipStream_t stream) {
@@ -1251,6 +1268,10 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
     // replayed was tried: its small kernels then wait for slots next to the search's large one, no gain.)
     const bool side_kernels = M > num_big;  // the sequential kernels on the aux streams
     ok(groups->waitCollapse(st));
+    if (groups->collapse_done && !searchLaunchesEarly()) {  // (see searchGateEnter: the thread waits, not the stream's queue)
+        HostScope wait_scope("search: wait for the collapse of the matrices");
+        ok(hipEventSynchronize(groups->collapse_done));
+    }
     span = ctx->spanBegin(FAM_LOGLIK);
     searchGateEnter(ctx, st);
     if (side_kernels) ok(ctx->forkAux());

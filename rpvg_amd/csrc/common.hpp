@@ -587,6 +587,7 @@ struct rpvg_hip_ctx {
     hipEvent_t join_event[kAuxStreams] = {};
     hipError_t forkAux();
     hipError_t joinAux();
+    hipError_t joinAuxOnHost();
     hipDeviceProp_t props;
     std::mutex mutex;  // serialises calls on this context
     // RCCL communicator of this rank (comm.hip); null until rpvg_hip_comm_init.  Collectives are
@@ -728,10 +729,11 @@ struct EmSolveWork {  // scratch of one solve: lives until its kernels are done
     // row collapse of the problems (row_collapse.hip) and the second EM pass over the problems it merged rows in
     std::shared_ptr<void> collapse;
     DeviceBuffer<unsigned char> d_queues_merged;
-    hipEvent_t filled = nullptr, collapsed = nullptr;
+    hipEvent_t filled = nullptr, collapsed = nullptr, collapse_sorted = nullptr;
     ~EmSolveWork() {
         if (filled) (void) hipEventDestroy(filled);
         if (collapsed) (void) hipEventDestroy(collapsed);
+        if (collapse_sorted) (void) hipEventDestroy(collapse_sorted);
     }
 };
 size_t emQueuesBytes();
@@ -856,7 +858,9 @@ struct CsrCollapseWork {
     DeviceBuffer<uint32_t> info;
     std::shared_ptr<void> temporaries;
 };
-hipError_t queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollapseInput & in, double precision, CsrCollapseWork & work, hipStream_t stream);
+// sorted: recorded behind the sort of the problems' rows (the first stages of the collapse: most of its time), if not null
+hipError_t queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollapseInput & in, double precision, CsrCollapseWork & work, hipStream_t stream,
+                            hipEvent_t sorted = nullptr);
 
 // queues the replay of readCollapseProbabilityMatrix on the matrices of `groups` behind their build (row_collapse.hip)
 hipError_t queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups, uint64_t total_rows, double precision, hipStream_t stream);

@@ -255,6 +255,17 @@ hipError_t rpvg_hip_ctx::joinAux() {
     return e;
 }
 
+// joinAux() with the submitting thread waiting for the side streams itself: `stream` is not left parked on their events (a
+// stream whose next command waits for an event holds its hardware queue until it arrives, and the kernels of other
+// streams on that queue — the other lane's — stand behind it)
+hipError_t rpvg_hip_ctx::joinAuxOnHost() {
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipEventRecord(join_event[i], aux[i]);
+    for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipEventSynchronize(join_event[i]);
+    for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamWaitEvent(stream, join_event[i], 0);  // (the ordering, for the record: they have arrived)
+    return e;
+}
+
 namespace rpvg_hip_detail {
 namespace {
 // The clock of the timed intervals: one event per GPU that every span of every context on it is measured against

@@ -1257,7 +1257,8 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         in.segment_rows = kFillSegmentRows;
         in.max_rows_bound = std::min<uint64_t>(list.max_cluster_work, list.rows_capacity);  // (rows + entries of the largest cluster: a bound of its rows)
         const int collapse_span = ctx->spanBegin(FAM_COLLAPSE, ctx->collapse_stream);
-        RPVG_HIP_CHECK(queueCsrCollapse(ctx, in, collapse_precision, *cw, ctx->collapse_stream));
+        RPVG_HIP_CHECK(hipEventCreateWithFlags(&work.collapse_sorted, hipEventDisableTiming));
+        RPVG_HIP_CHECK(queueCsrCollapse(ctx, in, collapse_precision, *cw, ctx->collapse_stream, work.collapse_sorted));
         ctx->spanEnd(collapse_span);
         RPVG_HIP_CHECK(hipEventRecord(work.collapsed, ctx->collapse_stream));
     }
@@ -1292,6 +1293,19 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         args.merged_count = cw->merged_count.ptr;
         args.problem_merged = cw->problem_merged.ptr;
         RPVG_HIP_CHECK(hipStreamWaitEvent(st, work.collapsed, 0));
+        // The EM launches go to streams of their own, and a stream whose next command waits for an event holds its hardware
+        // queue meanwhile — eight queues for every stream of both lanes (hardwareQueues()).  Queued at once, ten launches that
+        // wait for the collapse parked most of the queues for its whole millisecond and the other lane's kernels stood behind
+        // them (measured: the library's segmented sort, whose host wait for its partition sizes delayed these launches by
+        // accident, beat every sort without such a wait by 1 ms per batch).  So the submitting thread waits for the collapse
+        // itself and queues the launches then.
+        // RPVG_HIP_EM_LAUNCH_EARLY=1: queue them at once (A/B).
+        static const bool launch_early = std::getenv("RPVG_HIP_EM_LAUNCH_EARLY") != nullptr;
+        static const bool wait_whole = std::getenv("RPVG_HIP_EM_WAIT_SORT_ONLY") == nullptr;  // A/B: only the collapse's sort (11.3 against 10.2 ms per batch)
+        if (!launch_early && work.collapse_sorted) {
+            HostScope wait_scope("em_solve: wait for the collapse");
+            RPVG_HIP_CHECK(hipEventSynchronize(wait_whole ? work.collapsed : work.collapse_sorted));
+        }
     }
 
     // The bins are independent, so their tails (a small problem that needs thousands of iterations, a giant one with
@@ -1353,7 +1367,9 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
             RPVG_HIP_CHECK((launchEm<1024, false, true>(args, grid(1), sizeof(double) * (1024 / 64 + 2), s_reg2)));
             ctx->spanEnd(bin_span);
         }
-        RPVG_HIP_CHECK(ctx->joinAux());
+        // (RPVG_HIP_EM_JOIN_ON_STREAM=1: the context's stream waits for the side streams, not the thread — A/B)
+        static const bool join_on_stream = std::getenv("RPVG_HIP_EM_JOIN_ON_STREAM") != nullptr;
+        RPVG_HIP_CHECK(join_on_stream ? ctx->joinAux() : ctx->joinAuxOnHost());
         return RPVG_HIP_OK;
     };
     // The grid bin (problems too large for one workgroup, em_grid.hip): the host has to see them.  Only a solve that

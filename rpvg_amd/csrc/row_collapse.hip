@@ -1156,20 +1156,26 @@ namespace {
 // ---- stage 0: the rows of every matrix in the order of their sort keys — without a library sort ---------------------------
 // What the window scans need: the rows of a matrix ordered by (projection[, hash of the cells]), rows of equal keys in row
 // order.  The keys carry the matrix above the projection and the rows of a matrix are contiguous, so the order is one
-// segment per matrix, and nearly every segment fits LDS: a workgroup loads a chunk of up to 8 192 rows as 64-bit words
-// [projection 24 | hash H | row 20 | largest value 20 - H], sorts them with a bitonic network in LDS and — the usual case, the
-// whole matrix in one chunk — writes the sorted keys and rows, every row's sorted position, "equal to its predecessor" and
-// the stretch starts itself.  (Rounds 2-3: hipcub::DeviceRadixSort over all rows of all matrices — five passes of three
-// launches each, 0.31 ms of a lane's 1.2 ms of collapse standing alone — and DeviceSegmentedRadixSort for the EM problems,
-// 0.5 ms in one kernel behind a host wait for its partition sizes, plus a kernel for the keys and one for "equal to its
-// predecessor" that walked every row slot.)  A matrix with more rows is sorted chunk by chunk; every element then adds up,
-// over the other chunks of its matrix, how many of their elements sort before it (a binary search per chunk: the words are
-// distinct, they carry the row) — its rank is its sorted position — and is scattered there.
-constexpr uint32_t kSortChunkRows = 8192;
-constexpr uint32_t kSortThreadsPerChunk = 512;
+// segment per matrix, and nearly every segment fits a few KB of LDS: a workgroup loads up to 1 024 rows as 64-bit words
+// [projection 24 | hash H | row 20 | largest value 20 - H], sorts them with a bitonic network and — the usual case, the whole
+// matrix in one go — writes the sorted keys and rows, every row's sorted position, "equal to its predecessor" and the
+// stretch starts itself.  A larger matrix lists its chunks of 2 048 rows; they are sorted the same way into a buffer and
+// merged pairwise, round by round (merge path: every thread finds its eight output words by a binary search on its
+// diagonal), ceil(log2(chunks)) rounds for the largest matrix there can be; a last kernel writes what the one-chunk matrices
+// wrote in the sort.  (Rounds 2-3: hipcub::DeviceRadixSort over all rows of all matrices — five passes of three launches
+// each, 0.31 ms of a lane's 1.2 ms of collapse standing alone — and DeviceSegmentedRadixSort for the EM problems, 0.5 ms in
+// one kernel behind a host wait for its partition sizes, plus a kernel for the keys and one for "equal to its predecessor"
+// that walked every row slot.  A first version of this one sorted chunks of 8 192 rows on 512 threads whatever the matrix —
+// 0.28 ms for the 5 000 matrices of a configs[2] batch, two workgroups per CU — and ranked every element of a large matrix in
+// every other chunk of it: chunks squared, 0.17-0.64 ms.)
+constexpr uint32_t kSmallSortRows = 1024;
+constexpr uint32_t kSmallSortThreads = 128;
+constexpr uint32_t kSortChunkRows = 2048;
+constexpr uint32_t kSortChunkThreads = 256;
+constexpr uint32_t kMergeTile = 1024;                       // output words of a merge round per work item
+constexpr uint32_t kMergeThreads = 128;
 constexpr uint32_t kSortRowBits = 20;                       // rows of a matrix the packed word can tell apart
 constexpr uint64_t kSortMaxSegmentRows = (1ull << kSortRowBits) - 1;
-constexpr uint32_t kSortChunkItems = 8;                     // fill items (kFillSegmentRows = 1 024 row slots) per chunk
 
 template <int HASH>
 __device__ __forceinline__ uint64_t packSortWord(const uint64_t key, const uint32_t row) {
@@ -1197,7 +1203,6 @@ __device__ __forceinline__ uint64_t cellHashTerm(const uint32_t column, const do
     x ^= x >> 32;
     return cell ? x * 0xC2B2AE3D27D4EB4Full : 0;
 }
-
 
 // the key of row i of matrix m: group matrices carry it (written by the build kernels), the rows of an EM problem get it here
 // (projection of the normalised row, its largest value, a hash of its cells) together with their zero pattern
@@ -1230,16 +1235,11 @@ __device__ __forceinline__ uint64_t sortKeyOfRow(const CsrArrays & g, const uint
 }
 
 template <typename Arrays>
-struct ChunkSortArgs {
+struct SegmentSortArgs {
     Arrays g;
     uint32_t num_matrices;               // group matrices: their number; EM problems: the bound of their number
     const uint32_t * num_matrices_dev;   // EM problems on a device-built list: their number
-    // who sorts what.  Group matrices: workgroup b < num_matrices takes chunk 0 of matrix b, workgroup num_matrices + k the k-th
-    // (matrix, chunk) of `extra` (the further chunks of the matrices with more than a chunk of rows: the host knows the sizes).
-    const uint32_t * extra;
-    uint32_t num_extra;
-    // EM problems: a workgroup per work item of the fill (em_sparse.hip: segment_rows row slots of a problem); the first of
-    // every kSortChunkItems items of a problem leads a chunk; every item writes the unused slots of its own range
+    // EM problems: the work items of the fill (em_sparse.hip: segment_rows row slots of a problem) — collapseUnusedSlotsKernel
     uint32_t num_items_bound;
     const uint32_t * num_items_dev;
     const uint64_t * seg_first;
@@ -1253,18 +1253,16 @@ struct ChunkSortArgs {
     uint32_t * position_of;              // by row: its sorted position
     uint8_t * same_prev;
     uint32_t * stretch_start;
-    uint64_t * chunk_words;              // [total rows] the sorted chunks of the matrices with several
-    uint32_t * rank;                     // [total rows] by chunk slot: elements of the matrix that sort before it
-    uint32_t * multi;                    // [M] the matrix has several chunks
-    uint32_t * merge_items;              // [3 x capacity] (matrix, chunk, other chunk)
-    uint32_t * merge_count;              // [0] items, [1] chunks of multi-chunk matrices, [2] overflow
-    uint32_t merge_capacity;
-    uint32_t * multi_chunks;             // [2 x chunk capacity] (matrix, chunk) of the multi-chunk matrices
-    uint32_t multi_chunk_capacity;
+    uint64_t * words_a, * words_b;       // [total rows] each: the sorted runs of the larger matrices, source and target of a merge round in turn
+    uint32_t * chunks;                   // [2 x capacity] (matrix, chunk of kSortChunkRows rows) of the matrices beyond kSmallSortRows rows
+    uint32_t * chunk_count;
+    uint32_t chunk_capacity;
+    uint32_t round;                      // of the merge
+    uint32_t rounds;
 };
 
 template <typename Arrays>
-__device__ __forceinline__ void writeSortedPosition(const ChunkSortArgs<Arrays> & a, const uint32_t m, const uint64_t r0, const uint64_t position, const uint64_t word,
+__device__ __forceinline__ void writeSortedPosition(const SegmentSortArgs<Arrays> & a, const uint32_t m, const uint64_t r0, const uint64_t position, const uint64_t word,
                                                     const uint64_t word_before, const bool has_before) {
     constexpr int HASH = Arrays::kHashBits;
     const uint32_t row = sortWordRow<HASH>(word);
@@ -1281,71 +1279,11 @@ __device__ __forceinline__ void writeSortedPosition(const ChunkSortArgs<Arrays> 
     a.stretch_start[position] = same ? 0u : static_cast<uint32_t>(position);
 }
 
+// the rows [c0, c0 + n) of matrix m, sorted in `words` (LDS, `padded` >= n a power of two) by the calling workgroup
 template <typename Arrays>
-__global__ __launch_bounds__(kSortThreadsPerChunk) void collapseChunkSortKernel(const ChunkSortArgs<Arrays> a) {
-    __shared__ uint64_t words[kSortChunkRows];
+__device__ __forceinline__ void sortChunkInLds(const SegmentSortArgs<Arrays> & a, const uint32_t m, const uint64_t r0, const uint64_t c0, const uint32_t n,
+                                               const uint32_t padded, uint64_t * words) {
     constexpr int HASH = Arrays::kHashBits;
-    constexpr bool kCsr = HASH != 0;
-    const uint32_t M = a.num_matrices_dev ? min(*a.num_matrices_dev, a.num_matrices) : a.num_matrices;
-    uint32_t m, chunk;
-    if (!kCsr) {
-        if (blockIdx.x < a.num_matrices) {
-            m = blockIdx.x;
-            chunk = 0;
-        } else {
-            const uint32_t k = blockIdx.x - a.num_matrices;
-            if (k >= a.num_extra) return;
-            m = a.extra[2 * k];
-            chunk = a.extra[2 * k + 1];
-        }
-    } else {
-        const uint32_t items = a.num_items_dev ? min(*a.num_items_dev, a.num_items_bound) : a.num_items_bound;
-        const uint32_t item = blockIdx.x;
-        const uint64_t unused = collapseSortKey(a.num_matrices, 0.0, 0.0);
-        if (item == 0) {
-            // the row slots behind the last problem (everything, if there is none): keys that sort behind every row and are close to nothing
-            const uint64_t from = M == 0 ? 0 : a.g.rowOffset(M - 1) + a.g.numRows(M - 1);
-            // (the slots between the last problem's rows and its bound are written with its last item; the ones from its bound on, here)
-            const uint64_t tail = M == 0 ? 0 : max(from, a.g.rowOffset(M - 1) + static_cast<uint64_t>(a.seg_first[M] - a.seg_first[M - 1]) * a.segment_rows);
-            for (uint64_t r = tail + threadIdx.x; r < a.total_rows; r += blockDim.x) {
-                a.sort_key[r] = unused;
-                a.sort_row[r] = static_cast<uint32_t>(r);
-                a.position_of[r] = static_cast<uint32_t>(r);
-                a.same_prev[r] = 0;
-                a.stretch_start[r] = static_cast<uint32_t>(r);
-                a.pattern_out[r] = 0;
-            }
-        }
-        if (item >= items) return;
-        m = a.item_problem[item];
-        if (m >= M) return;
-        const uint64_t s = item - a.seg_first[m];
-        const bool last = item + 1 == a.seg_first[m + 1];
-        const uint64_t r0 = a.g.rowOffset(m), R = a.g.numRows(m);
-        // unused slots of this item's range (the last item: up to the end of the problem's items — the next problem starts there
-        // at the latest — or, behind the last problem, as far as its items reach)
-        const uint64_t lo = max(R, s * a.segment_rows);
-        const uint64_t bound = (m + 1 < M) ? a.g.rowOffset(m + 1) - r0 : static_cast<uint64_t>(a.seg_first[m + 1] - a.seg_first[m]) * a.segment_rows;
-        const uint64_t hi = last ? min(bound, a.total_rows - r0) : min(bound, (s + 1) * a.segment_rows);
-        for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-            a.sort_key[r0 + i] = unused;
-            a.sort_row[r0 + i] = static_cast<uint32_t>(r0 + i);
-            a.position_of[r0 + i] = static_cast<uint32_t>(r0 + i);
-            a.same_prev[r0 + i] = 0;
-            a.stretch_start[r0 + i] = static_cast<uint32_t>(r0 + i);
-            a.pattern_out[r0 + i] = 0;
-        }
-        if (s % kSortChunkItems != 0) return;  // (the chunk's leader sorts)
-        chunk = static_cast<uint32_t>(s / kSortChunkItems);
-    }
-    const uint64_t R = a.g.numRows(m);
-    const uint64_t r0 = a.g.rowOffset(m);
-    const uint64_t c0 = static_cast<uint64_t>(chunk) * kSortChunkRows;
-    if (c0 >= R) return;
-    const uint32_t n = static_cast<uint32_t>(min(static_cast<uint64_t>(kSortChunkRows), R - c0));
-    const uint32_t num_chunks = static_cast<uint32_t>((R + kSortChunkRows - 1) / kSortChunkRows);
-    uint32_t padded = 64;
-    while (padded < n) padded <<= 1;
     for (uint32_t i = threadIdx.x; i < padded; i += blockDim.x) {
         words[i] = i < n ? packSortWord<HASH>(sortKeyOfRow(a.g, m, r0, static_cast<uint32_t>(c0 + i), a.key_in, a.pattern_out), static_cast<uint32_t>(c0 + i)) : ~0ull;
     }
@@ -1364,113 +1302,151 @@ __global__ __launch_bounds__(kSortThreadsPerChunk) void collapseChunkSortKernel(
             __syncthreads();
         }
     }
-    if (num_chunks == 1) {
-        if (threadIdx.x == 0) a.multi[m] = 0;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) writeSortedPosition(a, m, r0, r0 + i, words[i], i ? words[i - 1] : 0ull, i != 0);
-        return;
-    }
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        a.chunk_words[r0 + c0 + i] = words[i];
-        a.rank[r0 + c0 + i] = i;
-    }
-    if (threadIdx.x == 0) {
-        const uint32_t at = atomicAdd(&a.merge_count[1], 1u);
-        if (at < a.multi_chunk_capacity) {
-            a.multi_chunks[2 * static_cast<uint64_t>(at)] = m;
-            a.multi_chunks[2 * static_cast<uint64_t>(at) + 1] = chunk;
-        } else {
-            atomicAdd(&a.merge_count[2], 1u);
-        }
-        if (chunk == 0) {
-            a.multi[m] = 1;
-            const uint32_t pairs = num_chunks * (num_chunks - 1);
-            const uint32_t first = atomicAdd(&a.merge_count[0], pairs);
-            if (first + pairs <= a.merge_capacity) {
-                uint32_t slot = first;
-                for (uint32_t ci = 0; ci < num_chunks; ++ci) {
-                    for (uint32_t cj = 0; cj < num_chunks; ++cj) {
-                        if (ci == cj) continue;
-                        a.merge_items[3 * static_cast<uint64_t>(slot)] = m;
-                        a.merge_items[3 * static_cast<uint64_t>(slot) + 1] = ci;
-                        a.merge_items[3 * static_cast<uint64_t>(slot) + 2] = cj;
-                        ++slot;
-                    }
+}
+
+// Matrices of up to kSmallSortRows rows — nearly all of a batch: sixteen workgroups of two waves per CU, each with its matrix
+// in 8 KB of LDS, drawing matrices with a grid-stride loop.  A larger matrix lists its chunks for the kernel below.
+template <typename Arrays>
+__global__ __launch_bounds__(kSmallSortThreads) void collapseSmallSortKernel(const SegmentSortArgs<Arrays> a) {
+    __shared__ uint64_t words[kSmallSortRows];
+    const uint32_t M = a.num_matrices_dev ? min(*a.num_matrices_dev, a.num_matrices) : a.num_matrices;
+    for (uint32_t m = blockIdx.x; m < M; m += gridDim.x) {
+        const uint64_t R = a.g.numRows(m);
+        if (R == 0) continue;
+        if (R > kSmallSortRows) {
+            if (threadIdx.x == 0) {
+                const uint32_t chunks = static_cast<uint32_t>((R + kSortChunkRows - 1) / kSortChunkRows);
+                const uint32_t first = atomicAdd(a.chunk_count, chunks);
+                for (uint32_t c = 0; c < chunks && first + c < a.chunk_capacity; ++c) {
+                    a.chunks[2 * static_cast<uint64_t>(first + c)] = m;
+                    a.chunks[2 * static_cast<uint64_t>(first + c) + 1] = c;
                 }
-            } else {
-                atomicAdd(&a.merge_count[2], 1u);
             }
+            continue;
         }
+        const uint64_t r0 = a.g.rowOffset(m);
+        const uint32_t n = static_cast<uint32_t>(R);
+        uint32_t padded = 2;
+        while (padded < n) padded <<= 1;
+        __syncthreads();  // (the matrix before is done with the LDS)
+        sortChunkInLds(a, m, r0, 0, n, padded, words);
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) writeSortedPosition(a, m, r0, r0 + i, words[i], i ? words[i - 1] : 0ull, i != 0);
     }
 }
 
-// every element of chunk ci adds the number of chunk cj's elements that sort before it to its rank
+// the chunks of the larger matrices: sorted runs of kSortChunkRows words in words_a
 template <typename Arrays>
-__global__ __launch_bounds__(256) void collapseChunkRankKernel(const ChunkSortArgs<Arrays> a) {
-    const uint32_t items = min(a.merge_count[0], a.merge_capacity);
-    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
-        const uint32_t m = a.merge_items[3 * static_cast<uint64_t>(item)], ci = a.merge_items[3 * static_cast<uint64_t>(item) + 1], cj = a.merge_items[3 * static_cast<uint64_t>(item) + 2];
+__global__ __launch_bounds__(kSortChunkThreads) void collapseChunkSortKernel(const SegmentSortArgs<Arrays> a) {
+    __shared__ uint64_t words[kSortChunkRows];
+    const uint32_t count = min(*a.chunk_count, a.chunk_capacity);
+    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+        const uint32_t m = a.chunks[2 * static_cast<uint64_t>(item)], chunk = a.chunks[2 * static_cast<uint64_t>(item) + 1];
         const uint64_t R = a.g.numRows(m), r0 = a.g.rowOffset(m);
-        const uint64_t i0 = static_cast<uint64_t>(ci) * kSortChunkRows, j0 = static_cast<uint64_t>(cj) * kSortChunkRows;
-        const uint32_t ni = static_cast<uint32_t>(min(static_cast<uint64_t>(kSortChunkRows), R - i0)), nj = static_cast<uint32_t>(min(static_cast<uint64_t>(kSortChunkRows), R - j0));
-        const uint64_t * other = a.chunk_words + r0 + j0;
-        for (uint32_t e = threadIdx.x; e < ni; e += blockDim.x) {
-            const uint64_t x = a.chunk_words[r0 + i0 + e];
-            uint32_t lo = 0, hi = nj;  // first element of the other chunk that is not below x
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (other[mid] < x) lo = mid + 1;
-                else hi = mid;
+        const uint64_t c0 = static_cast<uint64_t>(chunk) * kSortChunkRows;
+        const uint32_t n = static_cast<uint32_t>(min(static_cast<uint64_t>(kSortChunkRows), R - c0));
+        uint32_t padded = 64;
+        while (padded < n) padded <<= 1;
+        __syncthreads();  // (the chunk before is done with the LDS)
+        sortChunkInLds(a, m, r0, c0, n, padded, words);
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) a.words_a[r0 + c0 + i] = words[i];
+    }
+}
+
+// One round of the merge: the sorted runs of length kSortChunkRows << round of every larger matrix, two by two.  Work item =
+// kMergeTile output words of a matrix (two per chunk of the list); a thread finds where its eight outputs begin in the two
+// runs by a binary search along its diagonal (merge path; the words are distinct: they carry the row) and merges them out.
+template <typename Arrays>
+__global__ __launch_bounds__(kMergeThreads) void collapseMergeRoundKernel(const SegmentSortArgs<Arrays> a) {
+    constexpr uint32_t kPerThread = kMergeTile / kMergeThreads;
+    constexpr uint32_t kTilesPerChunk = kSortChunkRows / kMergeTile;
+    const uint32_t count = min(*a.chunk_count, a.chunk_capacity) * kTilesPerChunk;
+    const uint64_t * __restrict__ source = (a.round & 1) ? a.words_b : a.words_a;
+    uint64_t * __restrict__ target = (a.round & 1) ? a.words_a : a.words_b;
+    const uint64_t run = static_cast<uint64_t>(kSortChunkRows) << a.round;
+    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+        const uint32_t m = a.chunks[2 * static_cast<uint64_t>(item / kTilesPerChunk)];
+        const uint64_t R = a.g.numRows(m), r0 = a.g.rowOffset(m);
+        const uint64_t out0 = static_cast<uint64_t>(a.chunks[2 * static_cast<uint64_t>(item / kTilesPerChunk) + 1]) * kSortChunkRows + (item % kTilesPerChunk) * kMergeTile;
+        if (out0 >= R) continue;
+        const uint64_t pair0 = out0 / (2 * run) * (2 * run);
+        const uint64_t a1 = min(R, pair0 + run), b1 = min(R, pair0 + 2 * run);
+        const uint64_t * A = source + r0 + pair0, * B = source + r0 + a1;
+        const uint64_t nA = a1 - pair0, nB = b1 - a1;
+        const uint64_t d = (out0 - pair0) + static_cast<uint64_t>(threadIdx.x) * kPerThread;  // this thread's diagonal
+        if (d >= nA + nB) continue;
+        // i = words of A among the first d of the merged sequence: the smallest i with A[i] > B[d - i - 1]
+        uint64_t lo = d > nB ? d - nB : 0, hi = min(d, nA);
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (A[mid] < B[d - mid - 1]) lo = mid + 1;
+            else hi = mid;
+        }
+        uint64_t i = lo, j = d - lo;
+        uint64_t * out = target + r0 + pair0 + d;
+        const uint32_t outputs = static_cast<uint32_t>(min(static_cast<uint64_t>(kPerThread), nA + nB - d));
+        uint64_t x = i < nA ? A[i] : ~0ull, y = j < nB ? B[j] : ~0ull;
+        for (uint32_t k = 0; k < outputs; ++k) {
+            if (x < y) {
+                out[k] = x;
+                ++i;
+                x = i < nA ? A[i] : ~0ull;
+            } else {
+                out[k] = y;
+                ++j;
+                y = j < nB ? B[j] : ~0ull;
             }
-            if (lo) atomicAdd(&a.rank[r0 + i0 + e], lo);
         }
     }
 }
 
-// ... and goes to its sorted position
+// the larger matrices' rows at their sorted positions (what the small kernel writes itself)
 template <typename Arrays>
-__global__ __launch_bounds__(256) void collapseChunkScatterKernel(const ChunkSortArgs<Arrays> a) {
-    constexpr int HASH = Arrays::kHashBits;
-    const uint32_t chunks = min(a.merge_count[1], a.multi_chunk_capacity);
-    for (uint32_t item = blockIdx.x; item < chunks; item += gridDim.x) {
-        const uint32_t m = a.multi_chunks[2 * static_cast<uint64_t>(item)], chunk = a.multi_chunks[2 * static_cast<uint64_t>(item) + 1];
+__global__ __launch_bounds__(256) void collapseMergedPositionsKernel(const SegmentSortArgs<Arrays> a) {
+    const uint32_t count = min(*a.chunk_count, a.chunk_capacity);
+    const uint64_t * __restrict__ sorted = (a.rounds & 1) ? a.words_b : a.words_a;
+    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+        const uint32_t m = a.chunks[2 * static_cast<uint64_t>(item)], chunk = a.chunks[2 * static_cast<uint64_t>(item) + 1];
         const uint64_t R = a.g.numRows(m), r0 = a.g.rowOffset(m);
         const uint64_t c0 = static_cast<uint64_t>(chunk) * kSortChunkRows;
         const uint32_t n = static_cast<uint32_t>(min(static_cast<uint64_t>(kSortChunkRows), R - c0));
         for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-            const uint64_t word = a.chunk_words[r0 + c0 + e];
-            const uint64_t position = r0 + a.rank[r0 + c0 + e];
-            a.sort_key[position] = sortWordKey<HASH>(word, m);
-            a.sort_row[position] = static_cast<uint32_t>(r0 + sortWordRow<HASH>(word));
-            a.position_of[r0 + sortWordRow<HASH>(word)] = static_cast<uint32_t>(position);
+            const uint64_t i = c0 + e;
+            writeSortedPosition(a, m, r0, r0 + i, sorted[r0 + i], i ? sorted[r0 + i - 1] : 0ull, i != 0);
         }
     }
 }
 
-// "equal to its predecessor" and the stretch starts of the multi-chunk matrices (their neighbours are known only now)
+// EM problems: the row slots no problem's rows fill (the storage is laid out by a bound) get keys that sort behind every row
+// and are close to nothing.  A workgroup per work item of the fill (em_sparse.hip: segment_rows slots of a problem): the
+// unused slots of its own range, the last item of a problem up to the next problem's first slot; everybody shares the
+// slots behind the last problem's items.
 template <typename Arrays>
-__global__ __launch_bounds__(256) void collapseChunkSamePrevKernel(const ChunkSortArgs<Arrays> a) {
-    constexpr int HASH = Arrays::kHashBits;
-    const uint32_t chunks = min(a.merge_count[1], a.multi_chunk_capacity);
-    for (uint32_t item = blockIdx.x; item < chunks; item += gridDim.x) {
-        const uint32_t m = a.multi_chunks[2 * static_cast<uint64_t>(item)], chunk = a.multi_chunks[2 * static_cast<uint64_t>(item) + 1];
-        const uint64_t R = a.g.numRows(m), r0 = a.g.rowOffset(m);
-        const uint64_t c0 = static_cast<uint64_t>(chunk) * kSortChunkRows;  // (positions this time: any split of them will do)
-        const uint32_t n = static_cast<uint32_t>(min(static_cast<uint64_t>(kSortChunkRows), R - c0));
-        const typename Arrays::View mv = viewOf(m, a.g);
-        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-            const uint64_t p = r0 + c0 + e;
-            uint8_t same = 0;
-            if (c0 + e > 0) {
-                const uint64_t key = a.sort_key[p], before = a.sort_key[p - 1];
-                if (HASH ? keySorted<HASH>(key) == keySorted<HASH>(before) : key == before) {
-                    const uint32_t row = static_cast<uint32_t>(a.sort_row[p] - r0), row_before = static_cast<uint32_t>(a.sort_row[p - 1] - r0);
-                    same = (HASH ? rowsSameCells(mv, row, row_before) : rowsIdentical(mv, row, row_before)) ? 1 : 0;
-                }
-            }
-            a.same_prev[p] = same;
-            a.stretch_start[p] = same ? 0u : static_cast<uint32_t>(p);
-        }
+__global__ __launch_bounds__(256) void collapseUnusedSlotsKernel(const SegmentSortArgs<Arrays> a) {
+    const uint32_t M = a.num_matrices_dev ? min(*a.num_matrices_dev, a.num_matrices) : a.num_matrices;
+    const uint32_t items = a.num_items_dev ? min(*a.num_items_dev, a.num_items_bound) : a.num_items_bound;
+    const uint64_t unused = collapseSortKey(a.num_matrices, 0.0, 0.0);
+    auto fill = [&](const uint64_t r) {
+        a.sort_key[r] = unused;
+        a.sort_row[r] = static_cast<uint32_t>(r);
+        a.position_of[r] = static_cast<uint32_t>(r);
+        a.same_prev[r] = 0;
+        a.stretch_start[r] = static_cast<uint32_t>(r);
+        a.pattern_out[r] = 0;
+    };
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const uint32_t m = a.item_problem[item];
+        if (m >= M) continue;
+        const uint64_t s = item - a.seg_first[m];
+        const bool last = item + 1 == a.seg_first[m + 1];
+        const uint64_t r0 = a.g.rowOffset(m), R = a.g.numRows(m);
+        const uint64_t lo = max(R, s * a.segment_rows);
+        const uint64_t own = static_cast<uint64_t>(a.seg_first[m + 1] - a.seg_first[m]) * a.segment_rows;
+        const uint64_t bound = min((m + 1 < M) ? a.g.rowOffset(m + 1) - r0 : own, a.total_rows - r0);
+        const uint64_t hi = last ? bound : min(bound, (s + 1) * a.segment_rows);
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) fill(r0 + i);
     }
+    const uint64_t tail = M == 0 ? 0 : min(a.total_rows, a.g.rowOffset(M - 1) + static_cast<uint64_t>(a.seg_first[M] - a.seg_first[M - 1]) * a.segment_rows);
+    for (uint64_t r = tail + blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; r < a.total_rows; r += static_cast<uint64_t>(gridDim.x) * blockDim.x) fill(r);
 }
 
 }  // namespace
@@ -1490,22 +1466,20 @@ struct CollapseTemporaries {
     DeviceBuffer<uint64_t> csr_key, csr_pattern;
     DeviceBuffer<uint32_t> csr_row, csr_segments;
     // the hand-written segment sort (stage 0)
-    DeviceBuffer<uint64_t> chunk_words;
-    DeviceBuffer<uint32_t> chunk_rank, multi, merge_items, merge_count, multi_chunks, extra_chunks;
+    DeviceBuffer<uint64_t> words_a, words_b;
+    DeviceBuffer<uint32_t> chunks, chunk_count;
 };
 
-// who sorts what in the hand-written segment sort (ChunkSortArgs); null: the library sort
+// the hand-written segment sort instead of the library's (null): what it needs beyond the stages' own arguments
 struct SegmentSortPlan {
-    const uint32_t * extra = nullptr;              // group matrices: (matrix, chunk) of the chunks behind the first of every matrix
-    uint32_t num_extra = 0;
-    const uint32_t * num_matrices_dev = nullptr;   // EM problems: the work items of the fill
+    const uint32_t * num_matrices_dev = nullptr;   // EM problems: their number on the device, and the work items of the fill
     uint32_t num_items_bound = 0;
     const uint32_t * num_items_dev = nullptr;
     const uint64_t * seg_first = nullptr;
     const uint32_t * item_problem = nullptr;
     uint32_t segment_rows = 0;
     uint64_t * pattern_out = nullptr;
-    uint64_t max_segment_rows = 0;                 // a bound of the rows of the largest matrix (capacity of the merge lists)
+    uint64_t max_segment_rows = 0;                 // a bound of the rows of the largest matrix (the rounds of the merge)
 };
 
 // The stages behind the keys, for group matrices and for EM problems alike: `key` / `row` hold, per row slot, the sort key
@@ -1513,7 +1487,7 @@ struct SegmentSortPlan {
 template <typename Arrays>
 hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const uint64_t total_rows, const double precision, const uint64_t * key,
                                const uint32_t * row, const uint32_t * segment_begin, const uint32_t * segment_end, const bool segmented, DeviceBuffer<uint32_t> & info, double * rowmax, uint32_t * mat_fast,
-                               uint32_t * mat_mid, CollapseTemporaries * tmp, hipStream_t st, const SegmentSortPlan * plan = nullptr) {
+                               uint32_t * mat_mid, CollapseTemporaries * tmp, hipStream_t st, const SegmentSortPlan * plan = nullptr, hipEvent_t sorted = nullptr) {
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     // zeroed words: the pair table's byte counter (8 bytes, first: aligned), matrix flags [M], replay list [M] + its
@@ -1567,18 +1541,16 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     };
     if (e == hipSuccess) ok(scan(nullptr));
     ok(tmp->sort_tmp.alloc(std::max(sort_bytes, scan_bytes)));
-    // the hand-written segment sort: its lists (the merge of the matrices with more than a chunk of rows)
-    uint32_t total_chunks_bound = 0, merge_capacity = 0;
+    // the hand-written segment sort: the chunk list of the matrices beyond the small sort, the two buffers of their merge
+    uint32_t chunk_capacity = 0, merge_rounds = 0;
     if (plan) {
-        total_chunks_bound = static_cast<uint32_t>(std::min<uint64_t>(total_rows / kSortChunkRows + M + 1, 0x7fffffffull));
+        chunk_capacity = static_cast<uint32_t>(std::min<uint64_t>(total_rows / kSortChunkRows + M + 1, 0x7fffffffull));
         const uint64_t max_chunks = (plan->max_segment_rows + kSortChunkRows - 1) / kSortChunkRows;
-        merge_capacity = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(total_chunks_bound) * (max_chunks > 1 ? max_chunks - 1 : 0) + 1, 0x10000000ull));
-        ok(tmp->chunk_words.alloc(total_rows));
-        ok(tmp->chunk_rank.alloc(total_rows));
-        ok(tmp->multi.alloc(M + 1));
-        ok(tmp->merge_items.alloc(3 * static_cast<size_t>(merge_capacity)));
-        ok(tmp->merge_count.alloc(4));
-        ok(tmp->multi_chunks.alloc(2 * static_cast<size_t>(total_chunks_bound)));
+        while ((1ull << merge_rounds) < max_chunks) ++merge_rounds;
+        ok(tmp->words_a.alloc(total_rows));
+        ok(tmp->words_b.alloc(total_rows));
+        ok(tmp->chunks.alloc(2 * static_cast<size_t>(chunk_capacity)));
+        ok(tmp->chunk_count.alloc(1));
     }
     if (e != hipSuccess) return e;
     uint32_t * pair_bytes = info.ptr + kInfoWords, * mat_flag = pair_bytes + 2, * replay_list = mat_flag + M, * marked_bits = replay_list + M + 1,
@@ -1615,13 +1587,11 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     // 4 096 of them were most of a 60 us kernel).  RPVG_HIP_COLLAPSE_GRID overrides (A/B).
     static const uint32_t small_grid = std::getenv("RPVG_HIP_COLLAPSE_GRID") ? std::max(1, std::atoi(std::getenv("RPVG_HIP_COLLAPSE_GRID"))) : 256;
     if (plan) {
-        ok(hipMemsetAsync(tmp->merge_count.ptr, 0, 4 * sizeof(uint32_t), st));
-        ChunkSortArgs<Arrays> c;
+        ok(hipMemsetAsync(tmp->chunk_count.ptr, 0, sizeof(uint32_t), st));
+        SegmentSortArgs<Arrays> c;
         c.g = arrays;
         c.num_matrices = M;
         c.num_matrices_dev = plan->num_matrices_dev;
-        c.extra = plan->extra;
-        c.num_extra = plan->num_extra;
         c.num_items_bound = plan->num_items_bound;
         c.num_items_dev = plan->num_items_dev;
         c.seg_first = plan->seg_first;
@@ -1635,23 +1605,31 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
         c.position_of = position_of;
         c.same_prev = same_prev;
         c.stretch_start = stretch_start;
-        c.chunk_words = tmp->chunk_words.ptr;
-        c.rank = tmp->chunk_rank.ptr;
-        c.multi = tmp->multi.ptr;
-        c.merge_items = tmp->merge_items.ptr;
-        c.merge_count = tmp->merge_count.ptr;
-        c.merge_capacity = merge_capacity;
-        c.multi_chunks = tmp->multi_chunks.ptr;
-        c.multi_chunk_capacity = total_chunks_bound;
-        const uint32_t sort_grid = Arrays::kHashBits ? std::max<uint32_t>(1, plan->num_items_bound) : M + plan->num_extra;
-        collapseChunkSortKernel<Arrays><<<dim3(sort_grid), dim3(kSortThreadsPerChunk), 0, st>>>(c);
-        // (the matrices with more than a chunk of rows: a handful per batch — the launches find their lists empty otherwise)
-        collapseChunkRankKernel<Arrays><<<dim3(2 * small_grid), dim3(256), 0, st>>>(c);
-        collapseChunkScatterKernel<Arrays><<<dim3(small_grid), dim3(256), 0, st>>>(c);
-        collapseChunkSamePrevKernel<Arrays><<<dim3(small_grid), dim3(256), 0, st>>>(c);
+        c.words_a = tmp->words_a.ptr;
+        c.words_b = tmp->words_b.ptr;
+        c.chunks = tmp->chunks.ptr;
+        c.chunk_count = tmp->chunk_count.ptr;
+        c.chunk_capacity = chunk_capacity;
+        c.round = 0;
+        c.rounds = merge_rounds;
+        if (Arrays::kHashBits) {
+            collapseUnusedSlotsKernel<Arrays><<<dim3(std::max<uint32_t>(1, std::min<uint32_t>(plan->num_items_bound, 8 * small_grid))), dim3(256), 0, st>>>(c);
+        }
+        collapseSmallSortKernel<Arrays><<<dim3(std::max<uint32_t>(1, std::min<uint32_t>(M, 16 * small_grid))), dim3(kSmallSortThreads), 0, st>>>(c);
+        // (the matrices beyond the small sort — a few dozen per batch: the chunks of their list, log2(chunks of the largest) rounds
+        // of merging, their positions; with no such matrix possible, nothing)
+        if (plan->max_segment_rows > kSmallSortRows) {
+            collapseChunkSortKernel<Arrays><<<dim3(4 * small_grid), dim3(kSortChunkThreads), 0, st>>>(c);
+            for (uint32_t round = 0; round < merge_rounds; ++round) {
+                c.round = round;
+                collapseMergeRoundKernel<Arrays><<<dim3(8 * small_grid), dim3(kMergeThreads), 0, st>>>(c);
+            }
+            collapseMergedPositionsKernel<Arrays><<<dim3(4 * small_grid), dim3(256), 0, st>>>(c);
+        }
     } else {
         collapseSamePrevKernel<Arrays><<<dim3(row_blocks), dim3(256), 0, st>>>(a);
     }
+    if (sorted) ok(hipEventRecord(sorted, st));
     ok(scan(tmp->sort_tmp.ptr));
     a.stretch_first = stretch_first;
     collapseStretchEndKernel<Arrays><<<dim3(row_blocks), dim3(256), 0, st>>>(a);
@@ -1779,6 +1757,12 @@ __global__ __launch_bounds__(256) void csrCollapseKeysKernel(const CsrArrays g, 
 
 }  // namespace
 
+// RPVG_HIP_COLLAPSE_LIBRARY_SORT = 1 | matrices | problems: the library's radix sorts instead of the hand-written segment sort (A/B)
+static bool librarySortFor(const char * what) {
+    const char * env = std::getenv("RPVG_HIP_COLLAPSE_LIBRARY_SORT");
+    return env != nullptr && (std::strcmp(env, "1") == 0 || std::strcmp(env, what) == 0);
+}
+
 // Queues the collapse of the matrices of `g` on `st` behind their build (rpvg_hip_groups_build).
 hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups * g, const uint64_t total_rows, const double precision,
                                              hipStream_t st) {
@@ -1798,25 +1782,10 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     arrays.row_count = g->row_count.ptr;
     arrays.zero_pattern = g->collapse_mask.ptr;
     static const bool segmented = std::getenv("RPVG_HIP_COLLAPSE_SEGMENTED_SORT") != nullptr;  // (A/B: slower on the group matrices)
-    static const bool library_sort = std::getenv("RPVG_HIP_COLLAPSE_LIBRARY_SORT") != nullptr || segmented;  // A/B knob
-    // the hand-written segment sort: chunk 0 of every matrix, and the further chunks of the few matrices with more rows than a chunk
+    static const bool library_sort = librarySortFor("matrices") || segmented;  // A/B knob
     SegmentSortPlan plan;
-    std::vector<uint32_t> extra;
-    for (uint32_t m = 0; m < M; ++m) {
-        const uint64_t R = g->h_num_rows[m];
-        plan.max_segment_rows = std::max(plan.max_segment_rows, R);
-        for (uint64_t chunk = 1; chunk * kSortChunkRows < R; ++chunk) {
-            extra.push_back(m);
-            extra.push_back(static_cast<uint32_t>(chunk));
-        }
-    }
+    for (uint32_t m = 0; m < M; ++m) plan.max_segment_rows = std::max<uint64_t>(plan.max_segment_rows, g->h_num_rows[m]);
     const bool use_plan = !library_sort && plan.max_segment_rows <= kSortMaxSegmentRows;
-    if (use_plan && !extra.empty()) {
-        hipError_t e = tmp->extra_chunks.upload(extra.data(), extra.size(), st);
-        if (e != hipSuccess) return e;
-        plan.extra = tmp->extra_chunks.ptr;
-        plan.num_extra = static_cast<uint32_t>(extra.size() / 2);
-    }
     return queueCollapseStages(arrays, M, total_rows, precision, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_segment_off.ptr,
                                g->collapse_segment_off.ptr + 1, segmented && g->collapse_segment_off.ptr != nullptr, g->collapse_info,
                                g->rowmax.ptr, g->mat_fast.ptr, g->mat_mid.ptr, tmp.get(), st, use_plan ? &plan : nullptr);
@@ -1826,7 +1795,8 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
 // on `st` behind the compaction of the problems' rows.  Afterwards work.problem_merged[p] != 0 marks the problems in which a
 // run joined rows that were not equal up to rounding, merged_count holds their read counts after the merges (a merged
 // row's count moved to its run head) and merged_problems[0] their number.
-hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollapseInput & in, const double precision, CsrCollapseWork & work, hipStream_t st) {
+hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollapseInput & in, const double precision, CsrCollapseWork & work, hipStream_t st,
+                                             hipEvent_t sorted) {
     const uint32_t P = in.num_problems_bound;
     const uint64_t total_rows = in.rows_capacity;
     if (P == 0 || total_rows == 0) return hipSuccess;
@@ -1835,11 +1805,10 @@ hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollap
     work.temporaries = tmp;
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
-    static const bool library_sort = std::getenv("RPVG_HIP_COLLAPSE_LIBRARY_SORT") != nullptr;  // A/B knob
-    // The hand-written segment sort works on the fill's items (chunks of kSortChunkItems of them) and computes the keys itself;
-    // problems of 2^20 rows or more (by the bound) and the A/B knob take the library sort behind csrCollapseKeysKernel.
-    const bool use_plan = !library_sort && in.max_rows_bound <= kSortMaxSegmentRows && in.max_rows_bound > 0 &&
-                          static_cast<uint64_t>(in.segment_rows) * kSortChunkItems == kSortChunkRows && in.seg_first && in.item_problem;
+    static const bool library_sort = librarySortFor("problems");  // A/B knob
+    // The hand-written segment sort computes the keys itself; problems of 2^20 rows or more (by the bound) and the A/B knob take
+    // the library sort behind csrCollapseKeysKernel.
+    const bool use_plan = !library_sort && in.max_rows_bound <= kSortMaxSegmentRows && in.max_rows_bound > 0 && in.seg_first && in.item_problem;
     ok(tmp->csr_pattern.alloc(total_rows));
     if (!use_plan) {
         ok(tmp->csr_key.alloc(total_rows));
@@ -1873,7 +1842,7 @@ hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollap
         plan.segment_rows = in.segment_rows;
         plan.pattern_out = tmp->csr_pattern.ptr;
         plan.max_segment_rows = in.max_rows_bound;
-        return queueCollapseStages(arrays, P, total_rows, precision, nullptr, nullptr, nullptr, nullptr, false, work.info, nullptr, nullptr, nullptr, tmp.get(), st, &plan);
+        return queueCollapseStages(arrays, P, total_rows, precision, nullptr, nullptr, nullptr, nullptr, false, work.info, nullptr, nullptr, nullptr, tmp.get(), st, &plan, sorted);
     }
     // The rows of a problem are sorted as a segment: a handful of launches against the global sort's seven passes of three
     // launches each (same box, configs[2] batch: 12.0-12.5 ms per step against 14.6).  RPVG_HIP_EM_COLLAPSE_GLOBAL_SORT=1: the
@@ -1893,7 +1862,7 @@ hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollap
     ok(hipGetLastError());
     if (e != hipSuccess) return e;
     return queueCollapseStages(arrays, P, total_rows, precision, tmp->csr_key.ptr, tmp->csr_row.ptr, segment_begin, segment_end, segmented, work.info, nullptr,
-                               nullptr, nullptr, tmp.get(), st);
+                               nullptr, nullptr, tmp.get(), st, nullptr, sorted);
 }
 
 extern "C" int rpvg_hip_groups_collapse_info(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, uint32_t * matrices_replayed,
