@@ -513,6 +513,23 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
         barrier_sync(dist, torch)
         overlapped = max_over_ranks(time.perf_counter() - t0, dist, torch)
         cpu1 = resource.getrusage(resource.RUSAGE_SELF)
+        if os.environ.get("RPVG_BENCH_THREAD_CPU"):  # who burnt it: CPU seconds of every thread of the process so far
+            import glob
+            ticks = os.sysconf("SC_CLK_TCK")
+            rows = []
+            for stat in glob.glob("/proc/self/task/*/stat"):
+                try:
+                    text = open(stat).read()
+                    name = text[text.index("(") + 1:text.rindex(")")]
+                    fields = text[text.rindex(")") + 2:].split()
+                    rows.append(((int(fields[11]) + int(fields[12])) / ticks, int(fields[11]) / ticks, int(fields[12]) / ticks, name, stat.split("/")[4]))
+                except Exception:  # noqa: BLE001
+                    pass
+            rows.sort(reverse=True)
+            print("thread cpu (total user sys name tid):", file=sys.stderr)
+            for r in rows[:24]:
+                print(f"  {r[0]:7.2f} {r[1]:7.2f} {r[2]:7.2f} {r[3]} {r[4]}", file=sys.stderr)
+            print(f"  threads {len(rows)}  sum {sum(r[0] for r in rows):.2f} s", file=sys.stderr)
         host_cpu_ms = ((cpu1.ru_utime - cpu0.ru_utime) + (cpu1.ru_stime - cpu0.ru_stime)) * 1e3 / args.steps
         stats = eng.stats()
         t0 = time.perf_counter()

@@ -1326,6 +1326,11 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
             if (tile_lds_bytes > 64 * 1024) {
                 RPVG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairTileKernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes)));
             }
+            // (On the device's lowest stream priority — the slots its workgroups free going to the other lane's short kernels first —
+            // the batch took 11.6 against 10.5 ms: the search is itself on its lane's critical path.  Two passes around the replay of
+            // the matrices' collapse — the matrices it leaves alone as soon as its first stages have told them apart, the others when
+            // it is done — 10.4 against 9.9 ms: the second pass's grid of mostly empty workgroups, and the replay's small kernels next
+            // to the lane's own tile kernel.)
             pairTileKernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
         } else {
             pairTableKernel<<<dim3(((tw.count + 7) / 8) * 8), dim3(256), 0, st>>>(tw);

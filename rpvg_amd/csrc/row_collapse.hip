@@ -47,8 +47,10 @@ constexpr uint32_t kMaxWindowCompares = 256;   // a row with more candidates tha
 enum : uint8_t { kRowListed = 1, kRowStoodFor = 2 };
 constexpr int kCsrCellHashBits = 8;  // of the sort key's low field, for the rows of EM problems (CsrArrays)
 constexpr double kEquivalentRelative = 1e-13;  // close rows that differ by no more than this are interchangeable
-constexpr uint32_t kListLdsRows = 8192;        // row lists up to this size live (and are sorted) in LDS
-constexpr uint32_t kSortThreads = 1024;
+// (8 192 in rounds 2-3: 96 KB of static LDS and 1 024 threads, a whole CU per workgroup — on a batch without a single big list
+// the kernel still waited 0.2-0.4 ms for CUs the other lane's kernels held, on the collapse's critical path)
+constexpr uint32_t kListLdsRows = 2048;        // row lists up to this size live (and are sorted) in LDS
+constexpr uint32_t kSortThreads = 256;  // (1 024 in rounds 2-3: sixteen waves' worth of registers to find on one CU before the kernel could even see that it has no big list)
 constexpr uint32_t kBetweenThreads = 256;
 constexpr uint32_t kBetweenRows = 2 * kBetweenThreads;  // rows of a matrix per work item of step b
 constexpr uint32_t kPairChunk = 256;           // neighbour pairs staged in LDS at a time
@@ -58,6 +60,7 @@ constexpr uint32_t kListSizeMask = 0x3FFFFFFFu;
 constexpr uint32_t kPairwiseRows = 1024;           // lists up to this size get a table of all their pairs
 constexpr uint64_t kPairTableBytes = 16ull << 20;
 constexpr uint8_t kPairLess = 1, kPairClose = 2;
+constexpr uint32_t kLdsTableRows = 128;            // pair tables of lists up to this size are read from LDS (16 KB)
 
 enum : uint32_t { kFlagNone = 0, kFlagActiveRows = 1, kFlagWholeMatrix = 2 };
 enum : uint32_t { kInfoMatrices = 0, kInfoRowsReplaced = 1, kInfoWholeMatrices = 2, kInfoActiveRows = 3, kInfoPairsEquivalent = 4, kInfoPairsApart = 5, kInfoWords = 6 };
@@ -587,6 +590,7 @@ struct ReplayArgs {
     uint64_t * pair_pattern;     // [total rows] zero pattern they share before that column
     uint32_t * info;
     bool debug;                  // RPVG_HIP_EM_COLLAPSE_DEBUG: slow workgroups of the runs kernel report where their time went
+    bool no_lds_tables;          // RPVG_HIP_COLLAPSE_NO_LDS_TABLES (A/B): pair tables read from global memory as in round 3
 };
 
 // a1. every pair of rows of a small list, one thread each: order and closeness in one pass over the columns.  (A
@@ -632,6 +636,7 @@ __global__ __launch_bounds__(64) void collapsePairTableKernel(const ReplayArgs<A
 template <typename Arrays>
 __device__ void rankList(const ReplayArgs<Arrays> & a, const uint32_t m) {
     __shared__ uint32_t lds_row[kPairwiseRows], lds_slot[kPairwiseRows];
+    __shared__ uint8_t lds_table[kLdsTableRows * kLdsTableRows];
     __shared__ uint32_t collision;
     const uint32_t encoded = a.mat_list[m];
     if (encoded & kBigListBit) return;
@@ -647,12 +652,27 @@ __device__ void rankList(const ReplayArgs<Arrays> & a, const uint32_t m) {
         lds_slot[i] = kNoRow;
     }
     __syncthreads();
+    // (the table of a short list — nearly every list — moves to LDS first: a rank is 2 n dependent byte loads, and from global
+    // memory the 100-row list of a batch made this kernel 0.1-0.2 ms of the collapse's critical path)
+    const bool table_in_lds = n <= kLdsTableRows && !a.no_lds_tables;
+    if (table_in_lds) {
+        for (uint32_t k = threadIdx.x; k < n * n; k += blockDim.x) lds_table[k] = table[k];
+        __syncthreads();
+    }
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < n; ++j) {
-            const bool before = (table[static_cast<uint64_t>(j) * n + i] & kPairLess) != 0;
-            const bool after = (table[static_cast<uint64_t>(i) * n + j] & kPairLess) != 0;
-            rank += (before || (!after && j < i)) ? 1u : 0u;
+        if (table_in_lds) {
+            for (uint32_t j = 0; j < n; ++j) {
+                const bool before = (lds_table[j * n + i] & kPairLess) != 0;
+                const bool after = (lds_table[i * n + j] & kPairLess) != 0;
+                rank += (before || (!after && j < i)) ? 1u : 0u;
+            }
+        } else {
+            for (uint32_t j = 0; j < n; ++j) {
+                const bool before = (table[static_cast<uint64_t>(j) * n + i] & kPairLess) != 0;
+                const bool after = (table[static_cast<uint64_t>(i) * n + j] & kPairLess) != 0;
+                rank += (before || (!after && j < i)) ? 1u : 0u;
+            }
         }
         if (rank >= n || atomicExch(&lds_slot[rank], i) != kNoRow) collision = 1;
     }
@@ -1011,6 +1031,36 @@ __device__ void runsOfMatrix(const ReplayArgs<Arrays> & a, const uint32_t m) {
     __syncthreads();
     const long long clock_begin = wall_clock64();
     if (threadIdx.x == 0) demote = 0;
+    if (tabled && n <= kLdsTableRows && !a.no_lds_tables) {
+        // A short list with a pair table — nearly every list: table, barriers and heads in LDS, and ONE thread walks the runs
+        // (src/path_estimator.cpp:226-255: a row joins the run of the current head if nothing parts them and it is close to the
+        // head, otherwise it becomes the head).  The walk below, a workgroup stepping from head to head through barriers and
+        // global memory, took 0.1-0.3 ms for the 100-row list of a batch.
+        __shared__ uint8_t lds_table[kLdsTableRows * kLdsTableRows];
+        __shared__ uint8_t lds_barrier[kLdsTableRows];
+        __shared__ uint32_t lds_index[kLdsTableRows], lds_head[kLdsTableRows];
+        const uint32_t nn = static_cast<uint32_t>(n);
+        for (uint32_t k = threadIdx.x; k < nn * nn; k += blockDim.x) lds_table[k] = table[k];
+        for (uint32_t p = threadIdx.x; p < nn; p += blockDim.x) {
+            lds_barrier[p] = barrier[p];
+            lds_index[p] = list_index[p];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t h = 0;
+            while (h < nn) {
+                uint32_t q = h + 1;
+                while (q < nn && !lds_barrier[q] && (lds_table[lds_index[h] * nn + lds_index[q]] & kPairClose) != 0) ++q;
+                for (uint32_t r = h; r < q; ++r) lds_head[r] = h;
+                h = q;
+            }
+        }
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < nn; p += blockDim.x) head_of[p] = lds_head[p];
+        __syncthreads();
+        finishRuns(a, m, n, order, head_of, &demote, (encoded & kWholeMatrixBit) != 0);
+        return;
+    }
     for (uint64_t p = threadIdx.x; p < n; p += blockDim.x) {
         head_of[p] = kNoRow;
         close[p] = (p > 0 && !barrier[p] && closeRows(p - 1, p)) ? 1 : 0;
@@ -1065,81 +1115,86 @@ __device__ void runsOfMatrix(const ReplayArgs<Arrays> & a, const uint32_t m) {
     }
 }
 
-// a0. the list of a matrix: its active rows (the replay then only touches those), or all of them.
-// (Round 4 tried the whole replay of a short list right here — pair table, ranks, rows between neighbours, runs, one stage after
-// the other behind workgroup barriers instead of six dependent launches: 12.5 against 11.5 ms per configs[2] batch.  The staged
-// kernels spread a matrix's pairs and row slices over many workgroups; one workgroup walking them in turn is the longer chain.)
+// a0. the list of a matrix: its active rows (the replay then only touches those), or all of them.  Persistent workgroups, a
+// grid-stride loop over the matrices: most have no flag and cost a load.
+// (Round 4 tried the whole replay of a short list right here, twice — pair table, ranks, rows between neighbours, runs, one stage
+// after the other behind workgroup barriers instead of six dependent launches; first a workgroup per matrix with the tables in
+// global memory, then persistent workgroups with the tables in LDS: 12.5 against 11.5 and 11.4 against 10.3 ms per configs[2]
+// batch.  The staged kernels spread a matrix's pairs and row slices over many workgroups; one workgroup walking the stages of
+// its matrices in turn is the longer chain, and the batch waits for the longest.)
 template <typename Arrays>
 __global__ __launch_bounds__(256) void collapseListKernel(const ReplayArgs<Arrays> a) {
     __shared__ uint32_t list_size;
-    const uint32_t m = blockIdx.x;
-    if (m >= a.num_matrices) return;
-    const uint32_t flag = a.mat_flag[m];
-    if (flag == kFlagNone) {
-        if (threadIdx.x == 0) a.mat_list[m] = 0;
-        return;
-    }
-    const uint64_t R = a.g.numRows(m);
-    const uint64_t r0 = a.g.rowOffset(m);
-    const uint8_t * active = a.active + r0;
-    uint32_t * list = a.order + 2 * r0;
-    if (threadIdx.x == 0) list_size = 0;
-    __syncthreads();
-    if (flag != kFlagWholeMatrix) {
-        // (eight flags per load where the alignment allows: the largest matrix of a batch has 10^5 rows, and a byte per thread
-        // and step was 50 us of this kernel)
-        const uint64_t head = min(R, static_cast<uint64_t>((8 - (reinterpret_cast<uintptr_t>(active) & 7)) & 7));
-        for (uint64_t i = threadIdx.x; i < head; i += blockDim.x) {
-            if (active[i] == kRowListed) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(i);
+    for (uint32_t m = blockIdx.x; m < a.num_matrices; m += gridDim.x) {
+        const uint32_t flag = a.mat_flag[m];
+        if (flag == kFlagNone) {
+            if (threadIdx.x == 0) a.mat_list[m] = 0;
+            continue;
         }
-        const uint64_t words = (R - head) / 8;
-        const uint64_t * active_words = reinterpret_cast<const uint64_t *>(active + head);
-        for (uint64_t w = threadIdx.x; w < words; w += blockDim.x) {
-            uint64_t flags = active_words[w];
-            for (uint32_t k = 0; flags; ++k, flags >>= 8) {
-                if ((flags & 0xFF) == kRowListed) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(head + 8 * w + k);
-            }
-        }
-        for (uint64_t i = head + 8 * words + threadIdx.x; i < R; i += blockDim.x) {
-            if (active[i] == kRowListed) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(i);
-        }
+        const uint64_t R = a.g.numRows(m);
+        const uint64_t r0 = a.g.rowOffset(m);
+        const uint8_t * active = a.active + r0;
+        uint32_t * list = a.order + 2 * r0;
+        __syncthreads();  // (the matrix before is done with the shared words)
+        if (threadIdx.x == 0) list_size = 0;
         __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    const bool whole = flag == kFlagWholeMatrix;
-    const uint64_t n = whole ? R : list_size;
-    if (n < 2) {
-        a.mat_list[m] = 0;
-        return;
-    }
-    uint32_t encoded = static_cast<uint32_t>(n);
-    if (whole) encoded |= kWholeMatrixBit | kBigListBit;
-    else if (n > kPairwiseRows) encoded |= kBigListBit;
-    else {
-        const unsigned long long base = atomicAdd(a.pair_bytes, static_cast<unsigned long long>(n * n));
-        if (base + n * n > kPairTableBytes) encoded |= kBigListBit;
-        else {
-            a.pair_base[m] = base;
-            const uint32_t first = atomicAdd(a.row_item_count, static_cast<uint32_t>(n));
-            for (uint32_t i = 0; i < n; ++i) {
-                a.row_items[2 * static_cast<uint64_t>(first + i)] = m;
-                a.row_items[2 * static_cast<uint64_t>(first + i) + 1] = i;
+        if (flag != kFlagWholeMatrix) {
+            // (eight flags per load where the alignment allows: the largest matrix of a batch has 10^5 rows, and a byte per thread
+            // and step was 50 us of this kernel)
+            const uint64_t head = min(R, static_cast<uint64_t>((8 - (reinterpret_cast<uintptr_t>(active) & 7)) & 7));
+            for (uint64_t i = threadIdx.x; i < head; i += blockDim.x) {
+                if (active[i] == kRowListed) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(i);
+            }
+            const uint64_t words = (R - head) / 8;
+            const uint64_t * active_words = reinterpret_cast<const uint64_t *>(active + head);
+            for (uint64_t w = threadIdx.x; w < words; w += blockDim.x) {
+                uint64_t flags = active_words[w];
+                for (uint32_t k = 0; flags; ++k, flags >>= 8) {
+                    if ((flags & 0xFF) == kRowListed) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(head + 8 * w + k);
+                }
+            }
+            for (uint64_t i = head + 8 * words + threadIdx.x; i < R; i += blockDim.x) {
+                if (active[i] == kRowListed) list[atomicAdd(&list_size, 1u)] = static_cast<uint32_t>(i);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const bool whole = flag == kFlagWholeMatrix;
+            const uint64_t n = whole ? R : list_size;
+            if (n < 2) {
+                a.mat_list[m] = 0;
+            } else {
+                uint32_t encoded = static_cast<uint32_t>(n);
+                if (whole) encoded |= kWholeMatrixBit | kBigListBit;
+                else if (n > kPairwiseRows) encoded |= kBigListBit;
+                else {
+                    const unsigned long long base = atomicAdd(a.pair_bytes, static_cast<unsigned long long>(n * n));
+                    if (base + n * n > kPairTableBytes) encoded |= kBigListBit;
+                    else {
+                        a.pair_base[m] = base;
+                        const uint32_t first = atomicAdd(a.row_item_count, static_cast<uint32_t>(n));
+                        for (uint32_t i = 0; i < n; ++i) {
+                            a.row_items[2 * static_cast<uint64_t>(first + i)] = m;
+                            a.row_items[2 * static_cast<uint64_t>(first + i) + 1] = i;
+                        }
+                    }
+                }
+                a.mat_list[m] = encoded;
+                a.replay_list[atomicAdd(&a.replay_list[a.num_matrices], 1u)] = m;
+                if (!whole) {  // work items of step b: (matrix, slice of kBetweenRows rows)
+                    const uint32_t slices = static_cast<uint32_t>((R + kBetweenRows - 1) / kBetweenRows);
+                    const uint32_t first = atomicAdd(a.between_count, slices);
+                    for (uint32_t k = 0; k < slices; ++k) {
+                        a.between_items[2 * static_cast<uint64_t>(first + k)] = m;
+                        a.between_items[2 * static_cast<uint64_t>(first + k) + 1] = k;
+                    }
+                }
+                atomicAdd(&a.info[kInfoMatrices], 1u);
+                atomicAdd(&a.info[kInfoActiveRows], static_cast<uint32_t>(n));
+                if (whole) atomicAdd(&a.info[kInfoWholeMatrices], 1u);
             }
         }
     }
-    a.mat_list[m] = encoded;
-    a.replay_list[atomicAdd(&a.replay_list[a.num_matrices], 1u)] = m;
-    if (!whole) {  // work items of step b: (matrix, slice of kBetweenRows rows)
-        const uint32_t slices = static_cast<uint32_t>((R + kBetweenRows - 1) / kBetweenRows);
-        const uint32_t first = atomicAdd(a.between_count, slices);
-        for (uint32_t k = 0; k < slices; ++k) {
-            a.between_items[2 * static_cast<uint64_t>(first + k)] = m;
-            a.between_items[2 * static_cast<uint64_t>(first + k) + 1] = k;
-        }
-    }
-    atomicAdd(&a.info[kInfoMatrices], 1u);
-    atomicAdd(&a.info[kInfoActiveRows], static_cast<uint32_t>(n));
-    if (whole) atomicAdd(&a.info[kInfoWholeMatrices], 1u);
 }
 
 // work item = matrix with a list
@@ -1670,12 +1725,14 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     r.pair_pattern = tmp->pair_pattern.ptr;
     r.info = info.ptr;
     r.debug = std::getenv("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
-    collapseListKernel<Arrays><<<dim3(M), dim3(256), 0, st>>>(r);
-    collapsePairTableKernel<Arrays><<<dim3(2 * small_grid), dim3(64), 0, st>>>(r);
-    collapseRankKernel<Arrays><<<dim3(small_grid), dim3(256), 0, st>>>(r);
-    collapseSortKernel<Arrays><<<dim3(std::min<uint32_t>(M, 128)), dim3(kSortThreads), 0, st>>>(r);
-    collapseBetweenKernel<Arrays><<<dim3(2 * small_grid), dim3(kBetweenThreads), 0, st>>>(r);
-    collapseRunsKernel<Arrays><<<dim3(small_grid), dim3(256), 0, st>>>(r);
+    r.no_lds_tables = std::getenv("RPVG_HIP_COLLAPSE_NO_LDS_TABLES") != nullptr;
+    collapseListKernel<Arrays><<<dim3(std::min<uint32_t>(M, small_grid)), dim3(256), 0, st>>>(r);
+    const uint32_t staged_grid = small_grid;
+    collapsePairTableKernel<Arrays><<<dim3(staged_grid), dim3(64), 0, st>>>(r);
+    collapseRankKernel<Arrays><<<dim3(staged_grid), dim3(256), 0, st>>>(r);
+    collapseSortKernel<Arrays><<<dim3(std::min<uint32_t>(M, 32)), dim3(kSortThreads), 0, st>>>(r);
+    collapseBetweenKernel<Arrays><<<dim3(2 * staged_grid), dim3(kBetweenThreads), 0, st>>>(r);
+    collapseRunsKernel<Arrays><<<dim3(staged_grid), dim3(256), 0, st>>>(r);
     ok(hipGetLastError());
     return e;
 }
