@@ -197,6 +197,8 @@ struct EmQueues {
 // its largest cluster.)
 constexpr uint32_t kLdsMapPaths = 16384;
 constexpr uint32_t kFillSegmentRows = 1024;
+constexpr uint64_t kFillLongRowEntries = 32;   // mean entries per row from which a cluster's rows take a wavefront each
+constexpr size_t kFillLongRowLds = kFillSegmentRows * (3 * sizeof(uint32_t) + sizeof(double));
 
 struct FillArgs {
     uint32_t num_problems;                 // upper bound when num_problems_dev is set
@@ -235,6 +237,7 @@ struct FillArgs {
     EmQueues * queues;
     EmBinRule rule;
     uint32_t lds_map_paths;                // capacity of the LDS map of this launch (0: bisection for every problem)
+    uint32_t long_row_scratch;             // the launch carries kFillLongRowLds bytes of LDS behind the map: clusters of long rows take a wavefront per row
 };
 
 template <bool WRITE>
@@ -278,6 +281,101 @@ __global__ __launch_bounds__(256) void fillSegmentsKernel(const FillArgs args) {
         uint32_t * off = WRITE ? args.prow_off + rb + p : nullptr;
         uint32_t run_rows = WRITE ? args.seg_rows[item] : 0, run_ent = WRITE ? args.seg_entries[item] : 0;  // (starts, by now)
         double z = 0, t = 0;  // read counts of the rows without a selected path / of all rows
+        if (args.long_row_scratch && args.row_ent_off[c1] - args.row_ent_off[c0] >= kFillLongRowEntries * (c1 - c0)) {
+            // A cluster of long rows (the 2 000-path rows of BASELINE.json configs[1]): a wavefront per row, its lanes striding the
+            // row's entries — 512-byte requests — instead of a thread walking 2 000 entries 24 KB from its neighbour's (0.2 s for
+            // the 1 M x 2 000 cluster, as long as eighty EM iterations over it).  Kept entries of a row and, for the write, its
+            // row sum go to LDS; the rows' places come from a scan over the segment; a row's entries are compacted 64 at a time
+            // (ballot + prefix count), in order.
+            uint32_t * row_n = reinterpret_cast<uint32_t *>(lds_map + args.lds_map_paths);  // [kFillSegmentRows] kept entries
+            uint32_t * row_slot = row_n + kFillSegmentRows, * row_eoff = row_slot + kFillSegmentRows;  // exclusive prefixes of (kept ? 1 : 0), kept entries
+            double * row_sum = reinterpret_cast<double *>(row_eoff + kFillSegmentRows);
+            const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const uint32_t seg_n = static_cast<uint32_t>(r1 - r0);
+            for (uint32_t i = wave; i < seg_n; i += BLOCK / 64) {
+                const uint64_t r = r0 + i;
+                const uint64_t e0 = args.row_ent_off[r], e1 = args.row_ent_off[r + 1];
+                uint32_t n = 0;
+                double sum = 0;
+                for (uint64_t e = e0 + lane; e < e1; e += 64) {
+                    if (column_of(args.ent_path[e]) >= 0) {
+                        ++n;
+                        sum += args.ent_prob[e];
+                    }
+                }
+                for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
+                if (WRITE) sum = waveSumF64(sum);
+                if (lane == 0) {
+                    row_n[i] = n;
+                    if (WRITE) row_sum[i] = sum;
+                    if (!WRITE) {
+                        const double c = args.row_count[r];
+                        t += c;
+                        if (!n) z += c;
+                    }
+                }
+            }
+            __syncthreads();
+            // exclusive scan over the segment's rows: a thread takes kFillSegmentRows / BLOCK neighbouring rows
+            constexpr uint32_t kPer = kFillSegmentRows / BLOCK;
+            uint32_t slots = 0, ents = 0;
+            for (uint32_t j = 0; j < kPer; ++j) {
+                const uint32_t i = threadIdx.x * kPer + j;
+                const uint32_t n = i < seg_n ? row_n[i] : 0u;
+                slots += n ? 1u : 0u;
+                ents += n;
+            }
+            uint32_t slot0 = slots, ent0 = ents, tot_rows, tot_ent;
+            blockExclusiveScanPair<BLOCK>(slot0, ent0, tot_rows, tot_ent, scratch);
+            if (WRITE) {
+                for (uint32_t j = 0; j < kPer; ++j) {
+                    const uint32_t i = threadIdx.x * kPer + j;
+                    if (i >= seg_n) break;
+                    row_slot[i] = slot0;
+                    row_eoff[i] = ent0;
+                    slot0 += row_n[i] ? 1u : 0u;
+                    ent0 += row_n[i];
+                }
+                __syncthreads();
+                for (uint32_t i = wave; i < seg_n; i += BLOCK / 64) {
+                    if (!row_n[i]) continue;
+                    const uint64_t r = r0 + i;
+                    const uint32_t my_row = run_rows + row_slot[i];
+                    const uint32_t my_ent = run_ent + row_eoff[i];
+                    const double nz = args.row_noise[r];
+                    if (lane == 0) {
+                        off[my_row] = my_ent;
+                        args.prow_count[rb + my_row] = args.row_count[r];
+                        args.prow_noise[rb + my_row] = nz;
+                    }
+                    const double keep = 1 - nz, rowsum = row_sum[i];
+                    const uint64_t e0 = args.row_ent_off[r], e1 = args.row_ent_off[r + 1];
+                    uint32_t base = 0;
+                    for (uint64_t eb0 = e0; eb0 < e1; eb0 += 64) {
+                        const uint64_t e = eb0 + lane;
+                        const int32_t c = e < e1 ? column_of(args.ent_path[e]) : -1;
+                        const unsigned long long kept = __ballot(c >= 0);
+                        if (c >= 0) {
+                            const uint32_t at = my_ent + base + static_cast<uint32_t>(__popcll(kept & ((1ull << lane) - 1)));
+                            args.pent_col[eb + at] = static_cast<uint32_t>(c);
+                            // addNoiseAndNormalizeProbabilityMatrix: (P / rowsum) * (1 - noise), two roundings
+                            args.pent_val[eb + at] = (args.ent_prob[e] / rowsum) * keep;
+                        }
+                        base += static_cast<uint32_t>(__popcll(kept));
+                    }
+                }
+            } else {
+                z = blockReduceSum<double, BLOCK>(z, dscratch);
+                t = blockReduceSum<double, BLOCK>(t, dscratch);
+                if (threadIdx.x == 0) {
+                    args.seg_rows[item] = tot_rows;
+                    args.seg_entries[item] = tot_ent;
+                    args.seg_zero_mass[item] = z;
+                    args.seg_total_mass[item] = t;
+                }
+            }
+            continue;
+        }
         for (uint64_t rc = r0; rc < r1; rc += BLOCK) {
             const uint64_t r = rc + threadIdx.x;
             uint32_t n = 0;
@@ -332,6 +430,22 @@ __global__ __launch_bounds__(256) void fillSegmentsKernel(const FillArgs args) {
             }
         }
     }
+}
+
+// The wavefront-per-row path costs 20 KB of LDS per workgroup: only a solve that sits on a cluster large enough to matter
+// (the grid threshold of the EM: a batch of small clusters keeps its eight workgroups per CU) carries it.
+template <bool WRITE>
+hipError_t launchFillSegments(FillArgs & fa, const uint32_t grid, const uint64_t max_cluster_work, hipStream_t st) {
+    static const bool never = std::getenv("RPVG_HIP_FILL_THREAD_ROWS") != nullptr;  // A/B knob
+    fa.long_row_scratch = (!never && max_cluster_work >= (1ull << 18)) ? 1u : 0u;
+    fa.lds_map_paths = (fa.lds_map_paths + 1) & ~1u;  // (the scratch behind the map holds doubles)
+    const size_t lds = fa.lds_map_paths * sizeof(int32_t) + (fa.long_row_scratch ? kFillLongRowLds : 0);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fillSegmentsKernel<WRITE>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    fillSegmentsKernel<WRITE><<<dim3(grid), dim3(256), lds, st>>>(fa);
+    return hipSuccess;
 }
 
 // per problem: the counts of its segments become their starts; totals, terminal offset, size bin
@@ -1202,9 +1316,9 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     fa.lds_map_paths = std::min<uint32_t>(list.max_cluster_paths, kLdsMapPaths);
     // (the segment kernels walk the items with a grid of a few workgroups per CU: an item is at most 1 024 rows)
     const uint32_t fill_grid = std::min<uint32_t>(list.items_bound, static_cast<uint32_t>(ctx->props.multiProcessorCount) * 8);
-    fillSegmentsKernel<false><<<dim3(fill_grid), dim3(256), fa.lds_map_paths * sizeof(int32_t), st>>>(fa);
+    RPVG_HIP_CHECK(launchFillSegments<false>(fa, fill_grid, list.max_cluster_work, st));
     fillOffsetsKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(fa);
-    fillSegmentsKernel<true><<<dim3(fill_grid), dim3(256), fa.lds_map_paths * sizeof(int32_t), st>>>(fa);
+    RPVG_HIP_CHECK(launchFillSegments<true>(fa, fill_grid, list.max_cluster_work, st));
     RPVG_HIP_CHECK(hipGetLastError());
     ctx->stats.build_launches += 3;
     if (fill_only) {
@@ -1638,7 +1752,7 @@ int prepareHostProblems(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const 
         fa.rule = emBinRule();
         fa.lds_map_paths = std::min<uint32_t>(list.max_cluster_paths, kLdsMapPaths);
         const uint32_t fill_grid = std::min<uint32_t>(list.items_bound, static_cast<uint32_t>(ctx->props.multiProcessorCount) * 8);
-        fillSegmentsKernel<false><<<dim3(fill_grid), dim3(256), fa.lds_map_paths * sizeof(int32_t), st>>>(fa);
+        RPVG_HIP_CHECK(launchFillSegments<false>(fa, fill_grid, list.max_cluster_work, st));
         fillOffsetsKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(fa);
         RPVG_HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> kept_rows(P), kept_ent(P);
