@@ -132,6 +132,15 @@ std::vector<ProbabilityCluster> readProbabilityClusters(const std::string & file
                     throw std::runtime_error(filename + ": cluster marker \"" + line + "\" is neither \"#\" nor \"# <lists> <index>\"");
                 }
 
+                // (digits only: std::stoull would take "12abc", and its own exceptions name neither the file nor the line)
+                for (auto & field: fields) {
+
+                    if (field.empty() || field.size() > 19 || field.find_first_not_of("0123456789") != std::string::npos) {
+
+                        throw std::runtime_error(filename + ": cluster marker \"" + line + "\": \"" + field + "\" is not a number");
+                    }
+                }
+
                 clusters.back().has_rank_key = true;
                 clusters.back().num_align_lists = std::stoull(fields.at(0));
                 clusters.back().cluster_index = std::stoull(fields.at(1));

@@ -1,6 +1,7 @@
 #include "path_abundance_estimator.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cassert>
 #include <cmath>
 #include <limits>
@@ -658,8 +659,13 @@ void NestedPathAbundanceEstimator::findPathSourceGroups(GroupPosteriorProblem * 
         num_incidences += path.source_ids.size();
     }
 
-    std::vector<uint32_t> flat_ids(num_incidences);
-    std::vector<uint32_t> flat_end(paths.size());
+    // (scratch of the calling thread, kept from cluster to cluster: six allocations per cluster were a fifth of this function)
+    static thread_local std::vector<uint32_t> flat_ids, flat_end, first_of_id;
+    static thread_local std::vector<uint64_t> source_paths, column_hash;
+    static thread_local std::vector<int32_t> table;
+
+    flat_ids.resize(num_incidences);
+    flat_end.resize(paths.size());
     uint32_t min_id = std::numeric_limits<uint32_t>::max();
     uint32_t max_id = 0;
 
@@ -683,11 +689,11 @@ void NestedPathAbundanceEstimator::findPathSourceGroups(GroupPosteriorProblem * 
         }
     }
 
-    std::vector<uint64_t> source_paths(num_incidences);
+    source_paths.resize(num_incidences);
 
     if (num_incidences > 0 && static_cast<uint64_t>(max_id) - min_id < 4 * static_cast<uint64_t>(num_incidences) + 1024) {
 
-        std::vector<uint32_t> first_of_id(static_cast<size_t>(max_id - min_id) + 2, 0);
+        first_of_id.assign(static_cast<size_t>(max_id - min_id) + 2, 0);
 
         for (auto & id: flat_ids) {
 
@@ -734,8 +740,8 @@ void NestedPathAbundanceEstimator::findPathSourceGroups(GroupPosteriorProblem * 
         table_size <<= 1;
     }
 
-    std::vector<int32_t> table(table_size, -1);
-    std::vector<uint64_t> column_hash;
+    table.assign(table_size, -1);
+    column_hash.clear();
 
     // upper bounds: every haplotype its own column
     const size_t max_columns = std::min<size_t>(num_incidences, static_cast<size_t>(max_id - min_id) + 1);
@@ -869,6 +875,14 @@ void NestedPathAbundanceEstimator::mergeSubsetSolutions(std::vector<PathClusterE
 
     ScopedPhase merge_phase("nested: weighted merge");
 
+    // (the device path is the diploid one; the keys below hold up to four paths: ploidy <= 4, as everywhere on the device)
+    constexpr uint32_t max_group_size = 4;
+
+    if (group_size > max_group_size) {
+
+        throw EngineError("weighted merge of device-built subsets: group size above 4");
+    }
+
     #pragma omp parallel for schedule(dynamic, clusterChunk()) num_threads(hostThreads())
     for (size_t i = 0; i < clusters.size(); ++i) {
 
@@ -882,8 +896,24 @@ void NestedPathAbundanceEstimator::mergeSubsetSolutions(std::vector<PathClusterE
         assert(estimates.noise_count == 0);
         estimates.total_count = cluster_batch.totalReadCount(clusters.at(i));
 
-        // (paths of one transcript inside a subset) -> (probability, abundance per path)
-        std::map<std::vector<uint32_t>, std::pair<double, std::vector<double> > > path_group_estimates;
+        // (paths of one transcript inside a subset) -> (probability, abundance per path): the reference keeps a hash map of vectors
+        // (src/path_abundance_estimator.cpp:702-745), the separate-calls path below an ordered map of them.  Here the entries of all
+        // subsets go to one flat array — key = the paths + 1, zero-padded, which orders like the vectors do —, a stable sort brings
+        // equal keys together in subset order, and the runs are added up in that order: the sums of the ordered map, addition for
+        // addition, without a node allocation per (subset, transcript) — two maps per subset were 6.5 ms of single-thread time per
+        // 5 000-cluster batch.
+        struct Entry {
+
+            std::array<uint32_t, max_group_size> key;
+            uint32_t size;
+            double weight;
+            std::array<double, max_group_size> abundance;
+        };
+
+        static thread_local std::vector<Entry> entries;
+        static thread_local std::vector<std::pair<uint32_t, uint32_t> > grouped;  // (group id, position in the subset's list)
+
+        entries.clear();
 
         double sum_hap_prob = 0;
 
@@ -914,47 +944,88 @@ void NestedPathAbundanceEstimator::mergeSubsetSolutions(std::vector<PathClusterE
 
             estimates.noise_count += subsets.noise_count[s] * weight;
 
-            std::map<uint32_t, std::vector<uint32_t> > subset_path_group_index;
+            // the subset's paths by transcript (group id ascending, the paths of a transcript in list order)
+            grouped.clear();
 
             for (const uint32_t * path = path_begin; path != path_end; ++path) {
 
-                subset_path_group_index[estimates.paths.at(*path).group_id].emplace_back(*path);
+                grouped.emplace_back(estimates.paths.at(*path).group_id, static_cast<uint32_t>(path - path_begin));
             }
 
-            for (auto & path_group: subset_path_group_index) {
+            std::stable_sort(grouped.begin(), grouped.end(), [](const std::pair<uint32_t, uint32_t> & lhs, const std::pair<uint32_t, uint32_t> & rhs) { return lhs.first < rhs.first; });
 
-                assert(path_group.second.size() <= group_size);
+            for (size_t g0 = 0; g0 < grouped.size();) {
 
-                auto path_group_estimates_it = path_group_estimates.emplace(path_group.second, std::make_pair(0.0, std::vector<double>(path_group.second.size(), 0)));
-                path_group_estimates_it.first->second.first += weight;
+                size_t g1 = g0;
 
-                for (size_t j = 0; j < path_group.second.size(); ++j) {
+                while (g1 < grouped.size() && grouped[g1].first == grouped[g0].first) {
 
-                    const uint32_t path = path_group.second.at(j);
+                    ++g1;
+                }
+
+                assert(g1 - g0 <= group_size && g1 - g0 <= max_group_size);
+
+                Entry entry;
+                entry.key.fill(0);
+                entry.abundance.fill(0);
+                entry.size = g1 - g0;
+                entry.weight = weight;
+
+                for (size_t j = g0; j < g1; ++j) {
+
+                    const uint32_t path = path_begin[grouped[j].second];
 
                     const auto column_it = std::lower_bound(col_begin, col_end, path);
                     assert(column_it != col_end && *column_it == path);
 
                     const uint32_t multiplicity = std::count(path_begin, path_end, path);
 
-                    path_group_estimates_it.first->second.second.at(j) += (abundances[column_it - col_begin] * weight / multiplicity);
+                    entry.key[j - g0] = path + 1;
+                    entry.abundance[j - g0] = (abundances[column_it - col_begin] * weight / multiplicity);
                 }
+
+                entries.emplace_back(entry);
+                g0 = g1;
             }
         }
 
-        estimates.path_group_sets.reserve(path_group_estimates.size());
-        estimates.posteriors.reserve(path_group_estimates.size());
+        std::stable_sort(entries.begin(), entries.end(), [](const Entry & lhs, const Entry & rhs) { return lhs.key < rhs.key; });
 
-        for (auto & group_estimates: path_group_estimates) {
+        for (size_t e0 = 0; e0 < entries.size();) {
 
-            estimates.path_group_sets.emplace_back(group_estimates.first);
-            estimates.posteriors.emplace_back(group_estimates.second.first);
-            estimates.abundances.insert(estimates.abundances.end(), group_estimates.second.second.begin(), group_estimates.second.second.end());
+            size_t e1 = e0;
+            double posterior = 0;
+            std::array<double, max_group_size> sums;
+            sums.fill(0);
+
+            while (e1 < entries.size() && entries[e1].key == entries[e0].key) {
+
+                posterior += entries[e1].weight;
+
+                for (uint32_t j = 0; j < entries[e0].size; ++j) {
+
+                    sums[j] += entries[e1].abundance[j];
+                }
+
+                ++e1;
+            }
+
+            estimates.path_group_sets.emplace_back();
+
+            for (uint32_t j = 0; j < entries[e0].size; ++j) {
+
+                estimates.path_group_sets.back().emplace_back(entries[e0].key[j] - 1);
+            }
+
+            estimates.posteriors.emplace_back(posterior);
+            estimates.abundances.insert(estimates.abundances.end(), sums.begin(), sums.begin() + entries[e0].size);
+
+            e0 = e1;
         }
 
         // (see inferPathSubsetAbundance for the tolerance)
         assert(sum_hap_prob < 1 + 1e-9);
-        estimates.noise_count += std::max(0.0, 1 - sum_hap_prob) * estimates.total_count;
+        estimates.noise_count += (1 - sum_hap_prob) * estimates.total_count;  // (src/path_abundance_estimator.cpp:749: unclamped, as the reference adds it)
     }
 }
 
@@ -1155,7 +1226,7 @@ void NestedPathAbundanceEstimator::inferPathSubsetAbundance(std::vector<PathClus
         // tests/fuzz_parity.py).  A library does not end its host process over that: the arithmetic is the reference's, the check keeps
         // the tolerance of an actual error.
         assert(sum_hap_prob < 1 + 1e-9);
-        estimates.noise_count += std::max(0.0, 1 - sum_hap_prob) * estimates.total_count;
+        estimates.noise_count += (1 - sum_hap_prob) * estimates.total_count;  // (src/path_abundance_estimator.cpp:749: unclamped, as the reference adds it)
     }
 
     merge_phase.reset();

@@ -183,3 +183,11 @@ def test_restated_random_streams_equal_libstdcxx():
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(root, "rpvg_amd", "csrc"),
                            os.path.join(root, "tests", "cpp", "gibbs_streams_check.cpp"), "-o", binary])
     assert subprocess.run([binary], capture_output=True, text=True, check=True).stdout.strip() == "ok"
+
+
+@pytest.mark.gpu
+def test_restated_random_streams_equal_the_gpu_box_libstdcxx():
+    """The same check on the GPU box, against the libstdc++ the host library there is built with and runs on: the device
+    sampler's draw-for-draw equality with the reference holds for a reference built with that library (INTEGRATION.md:
+    GCC 11's uniform_int_distribution; GCC <= 10 draws different starts)."""
+    test_restated_random_streams_equal_libstdcxx()
