@@ -116,8 +116,8 @@ typedef struct rpvg_hip_em_results {
  * sort and compare-with-run-head merge (the machinery of the group matrices' collapse on the sparse rows); a
  * merged row's read count moves to its run head, and the EM kernels read the merged counts of the problems in
  * which rows were merged.  Rows whose columns all fall into the same multiple of 2^-44 stand for each other
- * there (and merges of rows equal to 1e-13 relative are not replayed: they move nothing).
- * Rows without any selected path are folded into one exact scalar. */
+ * there (and merges of rows equal to 1e-13 relative are not replayed: they move nothing; docs/design/kernels-collapse.md).
+ * Rows without any selected path are folded into one exact scalar (docs/design/kernels-em.md). */
 int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t max_em_its, double max_rel_em_conv,
                       const rpvg_hip_em_problems * problems, rpvg_hip_em_results * results);
 
@@ -219,7 +219,10 @@ int rpvg_hip_group_conditionals(rpvg_hip_ctx * ctx, const rpvg_hip_groups * grou
                                 double * out);
 
 /* ---- the Gibbs sampler of the group posteriors, on the device ---------------------- */
-/* estimatePathGroupPosteriorsGibbs (src/path_estimator.cpp:475-589) for group sizes 1 and 2, draw for draw: the chains
+/* estimatePathGroupPosteriorsGibbs (src/path_estimator.cpp:475-589) for group sizes 1 and 2, draw for draw up to the
+ * floating-point reduction order of a distribution's sums (the conditional's log-sum-exp, the weight sum and the partial sums
+ * are added wave-parallel here, one after the other in std::discrete_distribution: a last-ulp difference in a partial sum can
+ * move a draw that lands exactly on a boundary — never seen in 1 300 swept configurations, not excluded): the chains
  * of every problem (:505), their starts (uniform_int_distribution, :491,509), the conditional of a slot given the other
  * member (:527-555: the contraction of rpvg_hip_group_conditionals, + log frequency, log-sum-exp, exp, then
  * std::discrete_distribution's own normalisation and partial sums), one draw per slot and iteration (:556) and the
@@ -422,7 +425,7 @@ int rpvg_hip_debug_log(rpvg_hip_ctx * ctx, uint64_t n, const double * x, double 
 /* ---- instrumentation ----------------------------------------------------- */
 /* The EM kernels of rpvg_hip_em_solve (rpvg_amd/csrc/em_sparse.hip): one variant per size bin of the problems; each
  * carries its own device time (HIP events on the stream it is launched on), launches, problems, EM iterations and
- * algorithmic bytes (per iteration of a problem 12 B/entry + 20 B/row + 16 B/column). */
+ * algorithmic bytes (per iteration of a problem 12 B/entry + 20 B/row + 16 B/column, DESIGN.md section 3, docs/design/kernels-em.md). */
 #define RPVG_HIP_EM_KERNELS 12
 typedef struct rpvg_hip_em_kernel_stats {
     double ms;               /* sum over launches of the HIP-event span around the launch on its own stream */
