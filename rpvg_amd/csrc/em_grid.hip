@@ -141,39 +141,40 @@ struct GridUpdateArgs {
     EmGridControl * ctl;
 };
 
-// 64 columns per workgroup of sixteen waves: wave w adds the partials w, w + 16, ... of its columns (512-byte requests,
-// eight loads in flight: a partial comes from another XCD's L2 or from memory, ~1 us each — a first version with four
-// waves and one load at a time spent 40 us here per iteration), the sixteen slices meet in LDS in slice order — the order
-// of the additions is fixed.  The last workgroup through applies the stop rule.
+// 16 columns per workgroup, 64 slices of the partials (thread = (column, slice): 128-byte requests, four loads in flight per
+// thread for 256 partials — a partial comes from another XCD's L2 or from memory, ~1 us each: a first version with four waves
+// and one load at a time spent 40 us here per iteration, 64 columns x 16 slices 7.3), the slices meet in LDS in slice order —
+// the order of the additions is fixed.  The last workgroup through applies the stop rule.
 constexpr int kUpdateBlock = 1024;
-constexpr int kUpdateSlices = kUpdateBlock / 64;
+constexpr int kUpdateColumns = 16;
+constexpr int kUpdateSlices = kUpdateBlock / kUpdateColumns;
 
 __global__ __launch_bounds__(kUpdateBlock) void emGridUpdateKernel(const GridUpdateArgs args) {
     if (args.ctl->done) return;
-    __shared__ double slice_sum[kUpdateSlices][64];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t j = blockIdx.x * 64 + lane;
+    __shared__ double slice_sum[kUpdateSlices][kUpdateColumns];
+    const uint32_t column = threadIdx.x % kUpdateColumns, slice = threadIdx.x / kUpdateColumns;
+    const uint32_t j = blockIdx.x * kUpdateColumns + column;
     double acc = 0.0;
     if (j < args.C) {
-        const double * column = args.partials + j;
+        const double * partial = args.partials + j;
         const uint64_t ld = args.partial_ld;
-        uint32_t b = wave;
-        for (; b + 7 * kUpdateSlices < args.num_partials; b += 8 * kUpdateSlices) {
-            double v[8];
+        uint32_t b = slice;
+        for (; b + 3 * kUpdateSlices < args.num_partials; b += 4 * kUpdateSlices) {
+            double v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = column[static_cast<uint64_t>(b + u * kUpdateSlices) * ld];
+            for (int u = 0; u < 4; ++u) v[u] = partial[static_cast<uint64_t>(b + u * kUpdateSlices) * ld];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
+            for (int u = 0; u < 4; ++u) acc += v[u];
         }
-        for (; b < args.num_partials; b += kUpdateSlices) acc += column[static_cast<uint64_t>(b) * ld];
+        for (; b < args.num_partials; b += kUpdateSlices) acc += partial[static_cast<uint64_t>(b) * ld];
     }
-    slice_sum[wave][lane] = acc;
+    slice_sum[slice][column] = acc;
     __syncthreads();
     int viol = 0;
-    if (wave == 0 && j < args.C) {
-        double tj = slice_sum[0][lane];
-#pragma unroll
-        for (int w = 1; w < kUpdateSlices; ++w) tj += slice_sum[w][lane];
+    if (slice == 0 && j < args.C) {
+        double tj = slice_sum[0][column];
+#pragma unroll 8
+        for (int w = 1; w < kUpdateSlices; ++w) tj += slice_sum[w][column];
         const double aj = args.a[j];
         // a'_j = a_j t_j / T;  a'_noise = (a_noise t_noise + Z) / T  (em_sparse.hip: the same roundings)
         const double an = (j + 1 == args.C) ? (aj * tj + args.zero_mass) * args.inv_total : (aj * tj) * args.inv_total;
@@ -271,8 +272,8 @@ hipError_t launchAccum(const int lanes, const GridAccumArgs & args, const uint32
     switch (lanes) {
         case 1: return launchAccumVariant<1, 4>(args, grid, lds, st);
         case 4: return launchAccumVariant<4, 4>(args, grid, lds, st);
-        case 16: return launchAccumVariant<16, 2>(args, grid, lds, st);
-        default: return launchAccumVariant<64, 2>(args, grid, lds, st);
+        case 16: return launchAccumVariant<16, 4>(args, grid, lds, st);
+        default: return launchAccumVariant<64, 4>(args, grid, lds, st);
     }
 }
 
@@ -390,7 +391,7 @@ int runEmGridProblems(rpvg_hip_ctx * ctx, hipStream_t st, const EmGridProblem * 
         ua.max_rel_em_conv = max_rel_em_conv;
         ua.max_em_its = max_em_its;
         ua.ctl = d_ctl.ptr;
-        const uint32_t update_grid = (C + 63) / 64;
+        const uint32_t update_grid = (C + kUpdateColumns - 1) / kUpdateColumns;
 
         // Iterations in chunks, two chunks in flight: the control word of chunk k is looked at while chunk k + 1 runs.
         // A short problem's iteration is a few microseconds, a giant one's milliseconds: the chunk holds about half a

@@ -696,7 +696,10 @@ void PathEstimator::estimateBatchSeeded(std::vector<PathClusterEstimates> * path
     }
 
     // src/main.cpp:976 — cluster i draws from mt19937(rng_seed + i); seeding 624 words per generator adds up over a batch
-    std::vector<std::mt19937> rngs(cluster_batch.numClusters());
+    // (copies of one generator, not n default constructions: a default-constructed mt19937 seeds its 624 words too — 5 000 of
+    // them one after the other were 10 ms of a configs[4] batch before the team's seeding below even started)
+    static const std::mt19937 unseeded;
+    std::vector<std::mt19937> rngs(cluster_batch.numClusters(), unseeded);
 
     #pragma omp parallel for schedule(static) num_threads(hostThreads())
     for (uint32_t i = 0; i < cluster_batch.numClusters(); ++i) {
