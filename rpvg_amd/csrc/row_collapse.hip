@@ -1839,7 +1839,7 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     arrays.row_count = g->row_count.ptr;
     arrays.zero_pattern = g->collapse_mask.ptr;
     static const bool segmented = std::getenv("RPVG_HIP_COLLAPSE_SEGMENTED_SORT") != nullptr;  // (A/B: slower on the group matrices)
-    static const bool library_sort = librarySortFor("matrices") || segmented;  // A/B knob
+    const bool library_sort = librarySortFor("matrices") || segmented;  // A/B knob (read per call: the tests take both ways)
     SegmentSortPlan plan;
     for (uint32_t m = 0; m < M; ++m) plan.max_segment_rows = std::max<uint64_t>(plan.max_segment_rows, g->h_num_rows[m]);
     const bool use_plan = !library_sort && plan.max_segment_rows <= kSortMaxSegmentRows;
@@ -1862,7 +1862,7 @@ hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollap
     work.temporaries = tmp;
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
-    static const bool library_sort = librarySortFor("problems");  // A/B knob
+    const bool library_sort = librarySortFor("problems");  // A/B knob (read per call: the tests take both ways)
     // The hand-written segment sort computes the keys itself; problems of 2^20 rows or more (by the bound) and the A/B knob take
     // the library sort behind csrCollapseKeysKernel.
     const bool use_plan = !library_sort && in.max_rows_bound <= kSortMaxSegmentRows && in.max_rows_bound > 0 && in.seg_first && in.item_problem;

@@ -216,3 +216,24 @@ def test_em_solve_collapses_planted_near_identical_rows(n_rows):
         ctx.close()
 
 
+
+
+@pytest.mark.parametrize("sort", ["segment", "library"])
+def test_planted_close_rows_in_matrices_of_several_sort_chunks(engine, monkeypatch, sort):
+    """Clusters of a few thousand reads: their group matrices are beyond the one-workgroup sort of the collapse (1 024 rows) and
+    go through chunks of 2 048 rows merged pairwise (row_collapse.hip, stage 0) — the same planted near-equal rows must reach the
+    replay either way, and with the library's radix sort (RPVG_HIP_COLLAPSE_LIBRARY_SORT=1) in its place."""
+    if sort == "library":
+        monkeypatch.setenv("RPVG_HIP_COLLAPSE_LIBRARY_SORT", "1")
+    rng = np.random.default_rng(4100)
+    clusters = []
+    for n_reads in (20000, 40000):  # 3 400 and 5 600 distinct rows after the caller's merge: two and three sort chunks
+        base = small_cases.make_cluster(rng, 4, (4, 4, 4, 4), n_haps=8, n_reads=n_reads, tie_prob=0.1)
+        clusters.append(collapse_cases.plant_near_rows(rng, base, fraction=0.02))
+    clusters += collapse_cases.make_collapse_clusters(4101, n_clusters=4, max_reads=150)
+    assert max(len(c["rows"]) for c in clusters) > 2048
+    batch = ClusterBatch.from_clusters(clusters)
+    params = make_params()
+    ref, _ = pyoracle.run("haplotype-transcripts", params, batch, 2)
+    got, _ = engine.run("haplotype-transcripts", params, engine.prepare(batch))
+    assert not fuzz_parity.compare(got, ref)
