@@ -556,17 +556,72 @@ void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstim
             first_problem.at(i + 1) = problems.size();
         }
 
-        std::vector<GroupPosteriors> group_posteriors;
-        pathGroupPosteriors(&group_posteriors, cluster_batch, problems, rngs);
+        std::vector<std::vector<std::vector<uint32_t> > > cluster_samples(clusters.size());
+
+        for (auto & samples: cluster_samples) {
+
+            samples.resize(std::floor(1 / min_hap_prob));
+        }
+
+        if (use_group_post_gibbs) {
+
+            // The reference runs a transcript's chains and draws that transcript's subsets from the same generator before
+            // the next transcript's chains start (src/path_abundance_estimator.cpp:371-412): where the next chains start
+            // in the generator's stream depends on how many sets the chains before them found (a discrete distribution
+            // over one set draws nothing).  Round j of the batch is transcript j of every cluster that has one — one
+            // problem per generator and device call, as with collapsed groups — and its subsets are drawn before round
+            // j + 1 is queued: draw for draw the reference's order, at the price of one device call per round.
+            size_t max_groups = 0;
+
+            for (auto & path_groups: cluster_path_groups) {
+
+                max_groups = std::max(max_groups, path_groups.size());
+            }
+
+            for (size_t j = 0; j < max_groups; ++j) {
+
+                std::vector<GroupPosteriorProblem> round_problems;
+                std::vector<size_t> round_clusters;
+
+                for (size_t i = 0; i < clusters.size(); ++i) {
+
+                    if (j < cluster_path_groups.at(i).size()) {
+
+                        round_problems.emplace_back(std::move(problems.at(first_problem.at(i) + j)));
+                        round_clusters.emplace_back(i);
+                    }
+                }
+
+                std::vector<GroupPosteriors> round_posteriors;
+                pathGroupPosteriors(&round_posteriors, cluster_batch, round_problems, rngs);
+
+                #pragma omp parallel for schedule(dynamic, clusterChunk()) num_threads(hostThreads())
+                for (size_t k = 0; k < round_clusters.size(); ++k) {
+
+                    const size_t i = round_clusters.at(k);
+                    sampleGroupPathIndices(&cluster_samples.at(i), round_posteriors.at(k), cluster_path_groups.at(i).at(j), &rngs->at(clusters.at(i)));
+                }
+            }
+
+        } else {
+
+            // exact posteriors draw nothing: all transcripts of the batch in one device call, the subsets after it
+            std::vector<GroupPosteriors> group_posteriors;
+            pathGroupPosteriors(&group_posteriors, cluster_batch, problems, rngs);
+
+            #pragma omp parallel for schedule(dynamic, clusterChunk()) num_threads(hostThreads())
+            for (size_t i = 0; i < clusters.size(); ++i) {
+
+                for (size_t j = 0; j < cluster_path_groups.at(i).size(); ++j) {
+
+                    sampleGroupPathIndices(&cluster_samples.at(i), group_posteriors.at(first_problem.at(i) + j), cluster_path_groups.at(i).at(j), &rngs->at(clusters.at(i)));
+                }
+            }
+        }
 
         for (size_t i = 0; i < clusters.size(); ++i) {
 
-            std::vector<std::vector<uint32_t> > samples(std::floor(1 / min_hap_prob));
-
-            for (size_t j = 0; j < cluster_path_groups.at(i).size(); ++j) {
-
-                sampleGroupPathIndices(&samples, group_posteriors.at(first_problem.at(i) + j), cluster_path_groups.at(i).at(j), &rngs->at(clusters.at(i)));
-            }
+            auto & samples = cluster_samples.at(i);
 
             for (auto & sample: samples) {
 
@@ -596,10 +651,8 @@ void NestedPathAbundanceEstimator::pathGroupPosteriors(std::vector<GroupPosterio
 
     if (use_group_post_gibbs) {
 
-        // With collapsed groups (one problem per cluster) every problem consumes its cluster's generator exactly
-        // as the reference does.  With independent groups the reference interleaves Gibbs draws of one
-        // transcript with the subset sampling of the previous one (src/path_abundance_estimator.cpp:380-407);
-        // here all posteriors of a batch come first, so that combination agrees statistically, not draw by draw.
+        // One problem per cluster and call (collapsed groups; independent groups call this once per transcript
+        // round): every problem consumes its cluster's generator exactly as the reference does.
         std::vector<std::mt19937 *> problem_rngs;
 
         for (auto & problem: problems) {

@@ -81,7 +81,7 @@ def draw_case(seed, only_gibbs=False):
     if model in ("haplotype-transcripts", "haplotypes"):
         kw["ploidy"] = int(rng.choice([1, 2, 2, 2, 3]))
         kw["use_hap_gibbs"] = int(only_gibbs or rng.random() < 0.25)
-    if model == "haplotype-transcripts" and not kw.get("use_hap_gibbs") and rng.random() < 0.2 and kw["min_hap_prob"] >= 1e-3:
+    if model == "haplotype-transcripts" and rng.random() < 0.2 and kw["min_hap_prob"] >= 1e-3:
         # (with 1e-5 the reference's own assertion sum_hap_prob <= 1 fails on the rounding of 100 000 weights,
         # src/path_abundance_estimator.cpp:748)
         kw["ind_hap_inference"] = 1
@@ -96,11 +96,6 @@ def run_case(eng, case, oracle_threads=32):
     params = make_params(**case["kw"])
     ref, _ = pyoracle.run(case["model"], params, case["batch"], oracle_threads)
     got, _ = eng.run(case["model"], params, eng.prepare(case["batch"]))
-    # independent inference WITH Gibbs posteriors interleaves the draws of one transcript's chains with the subset
-    # sampling of the previous one (src/path_abundance_estimator.cpp:380-407); the batch draws all posteriors first:
-    # statistical only.  Independent inference alone consumes the generator as the reference does.
-    if case["kw"].get("ind_hap_inference") and case["kw"].get("use_hap_gibbs"):
-        return []
     return compare(got, ref)
 
 

@@ -118,7 +118,7 @@ def test_planted_close_rows_match_oracle(engine, seed, kw):
     params = make_params(**kw)
     ref, _ = pyoracle.run("haplotype-transcripts", params, batch, 2)
     got, _ = engine.run("haplotype-transcripts", params, engine.prepare(batch))
-    # (only independent inference WITH Gibbs posteriors is statistical: fuzz_parity.run_case)
+    # (independent inference with Gibbs posteriors: test_hip_models.py and the sweep of fuzz_parity.py)
     assert not fuzz_parity.compare(got, ref)
 
 
