@@ -437,7 +437,7 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         search.update(pairs_possible_per_step=stats["search_pairs_possible"] / args.steps, pairs_kept_per_step=stats["search_pairs_kept"] / args.steps,
                       pairs_evaluated_exhaustively_per_step=stats["search_pairs_table"] / args.steps,
                       pairs_note="possible = G(G+1)/2 per searched matrix; evaluated exhaustively = pairs of the matrices whose every pair is "
-                                 "evaluated (pairTileKernel: all matrices up to 1024 columns) where the reference skips the first columns its "
+                                 "evaluated (pairTile2Kernel: all matrices up to 1024 columns) where the reference skips the first columns its "
                                  "bound prunes (the sequential search reaches 4.1 of these 4.4 G row-pair evaluations anyway); kept = pairs "
                                  "that survive the threshold")
     pmc_search = load_pmc("pmc_search_s3.json") if (not s5 and args.scale == 1.0 and args.model == "haplotype-transcripts") else None
@@ -456,7 +456,7 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         line["sampler"] = "device: rpvg_hip_group_gibbs (RPVG_AMD_HOST_GIBBS=1: host-driven lock-step sampler, round 2)"
         line["ms_per_step_outside_conditionals"] = ms_per_step - (stats["loglik_ms"] + stats["build_ms"] + stats["h2d_ms"]) / args.steps
     else:
-        search["kernel"] = "pairTileKernel + resolveTableKernel"
+        search["kernel"] = "pairTile2Kernel + resolveTableKernel"
         line["roofline_search"] = search
     if args.scale >= 1.0 and not s5 and DEVICE == "cuda":
         try:

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -564,6 +565,8 @@ __host__ __device__ inline uint32_t marginalSlices(const uint32_t G) { return kT
 struct PairTileWork {
     const uint32_t * item_matrix;   // [W]
     const uint32_t * item_chunk;    // [W]
+    const uint32_t * item_tiles;    // [W] pairTile2Kernel: first tile | (tiles - 1) << 16
+    uint32_t chunk_rows;            // pairTile2Kernel: rows of a chunk (kChunkRows for the others)
     uint32_t count;
     const uint64_t * mat_val_off;
     const uint64_t * mat_row_off;
@@ -829,8 +832,355 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(3)))
     if (threadIdx.x == 0) atomicAdd(w.log_evals, static_cast<unsigned long long>(static_cast<uint64_t>(G) * (G + 1) / 2 + G) * n);
 }
 
+
+// ---- the same tiles, lanes balanced and the staging asynchronous (round 4) -----------------------------------------
+//
+// What pairTileKernel left on the table (configs[2] bench: 99 % of its evaluations are in matrices of 33 .. 64 columns, most
+// of them 64): 136 tiles on 256 lanes is one slice — 53 % of the lanes, a wave of 8 lanes walking every row — and its staging
+// (loads to registers, transposed stores to LDS, between two barriers) and its arithmetic added up instead of overlapping
+// (1.40 ms = 0.47 staging and fixed costs + 0.93 arithmetic; without the loads 0.93).  Here
+//   * a work item is (matrix, chunk of rows, RANGE OF TILES): the host cuts the tiles of a matrix so that tiles x slices fills
+//     the workgroup — 136 tiles = 128 tiles in two slices + 8 tiles in 32 slices, 0.53 of the rows per lane instead of all of
+//     them; an item stages only the columns its tiles touch;
+//   * the rows are staged COLUMN-MAJOR, as they lie in memory, by LDS-direct loads (global_load_lds_dwordx4: two rows per
+//     lane, no registers, no transposing stores) into one of two buffers: the loads of the next rows are in flight while the
+//     lanes work on the current ones, one barrier per staged block;
+//   * the values are staged as they are, not halved: a lane multiplies 2 x = (u + 2 noise) + v — the same roundings as
+//     (u / 2 + noise) + v / 2 scaled by two — and takes one from the product's exponent per factor.
+constexpr uint32_t kTile2BufferDoubles = 3 * 1024;  // two of them: 48 KB (three workgroups per CU)
+
+__host__ __device__ inline uint32_t tileRowOfTile(const uint32_t t, const uint32_t T) {
+    uint32_t lo = 0, hi = T - 1;  // row ta of the triangle starts at tile ta * T - ta (ta - 1) / 2
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (mid * T - mid * (mid - 1) / 2 <= t) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void ldsDirectLoad16(const double * from, double * lds_wave_base) {
+    // (destination: the wave-uniform base + 16 bytes x lane; source: the lane's own address)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)from, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// The nine values a lane takes from a staged row — noise, four first-column and four second-column values, the columns
+// kSubRows doubles apart — as nine ds_read_b64 at immediate offsets from three addresses.  Written out: the compiler pairs
+// such reads into ds_read2_b64, which the LDS serves at half the rate (8 cycles a wave for 1 KB against 2 for a ds_read_b64's
+// 512 bytes), and the reads of this loop keep the LDS as busy as its FP64 instructions keep the SIMDs (1.49 against 1.22 ms).
+template <uint32_t kSubRows>
+__device__ __forceinline__ void ldsReadRow(const uint32_t noise_at, const uint32_t u_at, const uint32_t v_at, double & noise, double (&u)[4], double (&v)[4]) {
+    // (one statement: the compiler puts its own waits before or behind it, not between the reads)
+    asm volatile("ds_read_b64 %0, %9\n\t"
+                 "ds_read_b64 %1, %10\n\t"
+                 "ds_read_b64 %2, %10 offset:%12\n\t"
+                 "ds_read_b64 %3, %10 offset:%13\n\t"
+                 "ds_read_b64 %4, %10 offset:%14\n\t"
+                 "ds_read_b64 %5, %11\n\t"
+                 "ds_read_b64 %6, %11 offset:%12\n\t"
+                 "ds_read_b64 %7, %11 offset:%13\n\t"
+                 "ds_read_b64 %8, %11 offset:%14"
+                 : "=&v"(noise), "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "v"(noise_at), "v"(u_at), "v"(v_at), "i"(kSubRows * 8), "i"(kSubRows * 16), "i"(kSubRows * 24));
+}
+
+// ... and the wait for them: the values pass through it, so that nothing that uses them moves above it
+__device__ __forceinline__ void ldsRowLanded(double & noise, double (&u)[4], double (&v)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(noise), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+
+__device__ __forceinline__ uint32_t ldsByteAddress(const double * const p) {
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));  // (a generic pointer into LDS: the offset is its low word)
+}
+
+// Rows per staged block: a compile-time constant, so that the eight values of a row sit at immediate offsets from one address
+// per side (a stride in a register cost nine address additions and nine increments per row next to the 36 FP64 instructions);
+// even (a lane loads two).  The largest of the menu whose block fits a buffer.
+__host__ __device__ inline uint32_t tileSubRows(const uint32_t ncols) {
+    const uint32_t fit = (kTile2BufferDoubles - ncols / 2) / (ncols + 2);
+    return fit >= 126 ? 126u : fit >= 94 ? 94u : fit >= 46 ? 46u : fit >= 30 ? 30u : fit >= 14 ? 14u : fit >= 6 ? 6u : 2u;
+}
+
+template <uint32_t kSubRows>
+__device__ __forceinline__ void pairTile2Item(const PairTileWork & w, double * const tile_lds, const LogTableEntry * const lt, const uint32_t m, const uint32_t chunk,
+                                              const uint32_t t0, const uint32_t tcount, const uint32_t c_lo, const uint32_t ncols) {
+    const uint64_t R = w.mat_rows[m];
+    const uint32_t G = w.mat_cols[m];
+    const uint32_t T = tileColumns(G);
+    const uint32_t S = kTileBlock / tcount;
+    constexpr uint32_t sub_rows = kSubRows;
+    // a load instruction fills 16 bytes x 64 lanes of LDS in one piece: 1, 2 or 4 columns of one group of four (the groups are
+    // two doubles apart: the lanes of a wave read the same row of up to 16 different groups, whose stride over the 64 banks is
+    // 4 (mod 8) words that way — with 8 sub_rows words they would fall on four bank positions)
+    const uint32_t lanes_per_column = sub_rows / 2, columns_per_load = lanes_per_column <= 16 ? 4u : lanes_per_column <= 32 ? 2u : 1u;
+    auto columnOffset = [&](const uint32_t c) { return static_cast<size_t>(c) * sub_rows + (c / 4) * 2; };
+    const uint64_t r_begin = static_cast<uint64_t>(chunk) * w.chunk_rows;
+    const uint32_t n = static_cast<uint32_t>((R - r_begin) < w.chunk_rows ? (R - r_begin) : w.chunk_rows);
+    const double * M = w.values + w.mat_val_off[m] + r_begin;  // column-major: M[column * R + row]
+    const double * cnt = w.row_count + w.mat_row_off[m] + r_begin;
+    const double * nz = w.row_noise + w.mat_row_off[m] + r_begin;
+    auto local = [&](const uint64_t end_row) { return end_row <= r_begin ? 0u : (end_row - r_begin < n ? static_cast<uint32_t>(end_row - r_begin) : n); };
+    const uint32_t nf = local(w.mat_fast[m]), nm = local(w.mat_mid[m]);  // class boundaries within the chunk
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+
+    // a buffer: [ncols][sub_rows] values, [sub_rows] noise, [sub_rows] counts
+    const uint32_t buffer_doubles = (ncols + 2) * sub_rows + ncols / 2;
+    auto stage = [&](const uint32_t s0, const uint32_t ns, double * const buffer) {
+        if (w.debug_skip & 16u) return;
+        const uint32_t pairs = (ns + 1) / 2;  // (a row past the block's last is read, not used)
+        const uint32_t col_in_load = lane / lanes_per_column, pair = lane % lanes_per_column;
+        const bool lane_loads = col_in_load < columns_per_load && pair < pairs;
+        for (uint32_t c0 = wave * columns_per_load; c0 < ncols; c0 += 4 * columns_per_load) {
+            const uint32_t c = c0 + col_in_load;
+            if (lane_loads && c < ncols) {
+                const uint32_t column = c_lo + c < G ? c_lo + c : G - 1;  // (columns past the matrix: slots nobody keeps)
+                ldsDirectLoad16(M + static_cast<uint64_t>(column) * R + s0 + 2 * pair, buffer + columnOffset(c0));
+            }
+        }
+        if (wave < 2 && lane < pairs) {
+            ldsDirectLoad16((wave == 0 ? nz : cnt) + s0 + 2 * lane, buffer + columnOffset(ncols) + wave * sub_rows);
+        }
+    };
+
+    // the lane's tile and slice; its column of marginals (the item with the matrix's first tiles only)
+    const uint32_t t = t0 + threadIdx.x % tcount, slice = threadIdx.x / tcount;
+    const bool active = slice < S;
+    const uint32_t ta = tileRowOfTile(t, T);
+    const uint32_t tb = ta + (t - (ta * T - ta * (ta > 0 ? ta - 1 : 0) / 2));
+    const uint32_t SM = marginalSlices(G);
+    const uint32_t tc = threadIdx.x % T, marg_slice = threadIdx.x / T;
+    const bool with_marginals = t0 == 0 && marg_slice < SM && !(w.debug_skip & 8u);
+
+    LogProduct pr[4][4], prm[4];
+    double acc[4][4], accm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accm[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    }
+    uint32_t since_fold = 0, since_fold_m = 0;
+    int doubled = 0;  // factors of the pairs' products that were 2 x
+    auto foldPairs = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pr[i][j].fold();
+        }
+        since_fold = 0;
+    };
+    auto foldMarginals = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) prm[i].fold();
+        since_fold_m = 0;
+    };
+
+    const uint32_t blocks = (n + sub_rows - 1) / sub_rows;
+    if (w.debug_skip & 16u) {  // (timing without the loads: finite values everywhere)
+        for (uint32_t i = threadIdx.x; i < 2 * kTile2BufferDoubles; i += kTileBlock) tile_lds[i] = 0.25;
+    }
+    stage(0, n < sub_rows ? n : sub_rows, tile_lds);
+    for (uint32_t blk = 0; blk < blocks; ++blk) {
+        const uint32_t s0 = blk * sub_rows;
+        const uint32_t ns = (n - s0) < sub_rows ? (n - s0) : sub_rows;
+        double * const H = tile_lds + static_cast<size_t>(blk & 1u) * buffer_doubles;
+        // this block's rows have landed (every wave waits for its own loads, the barrier for everybody's), and the other buffer
+        // has been read for the last time: the next block's loads go out before the arithmetic on this one starts
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (blk + 1 < blocks) {
+            const uint32_t s1 = s0 + sub_rows;
+            stage(s1, (n - s1) < sub_rows ? (n - s1) : sub_rows, tile_lds + static_cast<size_t>((blk + 1) & 1u) * buffer_doubles);
+        }
+        const double * const lds_noise = H + columnOffset(ncols);
+        const double * const lds_count = lds_noise + sub_rows;
+        const uint32_t f1 = nf <= s0 ? 0u : ((nf - s0) < ns ? (nf - s0) : ns);
+        const uint32_t m1 = nm <= s0 ? 0u : ((nm - s0) < ns ? (nm - s0) : ns);
+        if (active) {
+            const double * const ua = H + columnOffset(4 * ta - c_lo), * const vb = H + columnOffset(4 * tb - c_lo);
+            // read count 1: one multiplication per pair and row
+            uint32_t r = (w.debug_skip & 1u) ? f1 : slice;
+            {
+                uint32_t noise_at = ldsByteAddress(lds_noise + r), u_at = ldsByteAddress(ua + r), v_at = ldsByteAddress(vb + r);
+                for (; r < f1; r += S, noise_at += 8 * S, u_at += 8 * S, v_at += 8 * S) {
+                    double noise, u[4], v[4];
+                    ldsReadRow<kSubRows>(noise_at, u_at, v_at, noise, u, v);
+                    ldsRowLanded(noise, u, v);
+                    const double un[4] = {fma(2.0, noise, u[0]), fma(2.0, noise, u[1]), fma(2.0, noise, u[2]), fma(2.0, noise, u[3])};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pr[i][j].mul(un[i] + v[j]);
+                    }
+                    doubled += 1;
+                    if (++since_fold == kFoldFactors) foldPairs();
+                }
+            }
+            // read counts 2 .. kMidMaxCount: the factor that many times
+            for (r = (w.debug_skip & 2u) ? m1 : f1 + (slice + S - f1 % S) % S; r < m1; r += S) {
+                double noise, u[4], v[4];
+                ldsReadRow<kSubRows>(ldsByteAddress(lds_noise + r), ldsByteAddress(ua + r), ldsByteAddress(vb + r), noise, u, v);
+                ldsRowLanded(noise, u, v);
+                const uint32_t c = static_cast<uint32_t>(lds_count[r]);
+                const double un[4] = {fma(2.0, noise, u[0]), fma(2.0, noise, u[1]), fma(2.0, noise, u[2]), fma(2.0, noise, u[3])};
+                if (since_fold + c > kFoldFactors) foldPairs();
+                since_fold += c;
+                doubled += static_cast<int>(c);
+                double x[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[i][j] = un[i] + v[j];
+                }
+                for (uint32_t k = 0; k < c; ++k) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pr[i][j].mul(x[i][j]);
+                    }
+                }
+            }
+            // the rest: one logarithm per pair and row
+            for (r = (w.debug_skip & 4u) ? ns : m1 + (slice + S - m1 % S) % S; r < ns; r += S) {
+                const double noise = lds_noise[r], c = lds_count[r];
+                const double un[4] = {fma(2.0, noise, ua[r]), fma(2.0, noise, ua[sub_rows + r]), fma(2.0, noise, ua[2 * sub_rows + r]), fma(2.0, noise, ua[3 * sub_rows + r])};
+                const double v[4] = {vb[r], vb[sub_rows + r], vb[2 * sub_rows + r], vb[3 * sub_rows + r]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = fma(c, logPositive(0.5 * (un[i] + v[j]), lt), acc[i][j]);
+                }
+            }
+        }
+        if (with_marginals) {  // single columns: noise + the whole value
+            const double * const ua = H + columnOffset(4 * tc);  // (c_lo = 0 for this item)
+            for (uint32_t r = marg_slice; r < ns; r += SM) {
+                const double noise = lds_noise[r];
+                const double x[4] = {ua[r] + noise, ua[sub_rows + r] + noise, ua[2 * sub_rows + r] + noise, ua[3 * sub_rows + r] + noise};
+                if (r < f1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) prm[i].mul(x[i]);
+                    if (++since_fold_m == kFoldFactors) foldMarginals();
+                } else if (r < m1) {
+                    const uint32_t c = static_cast<uint32_t>(lds_count[r]);
+                    if (since_fold_m + c > kFoldFactors) foldMarginals();
+                    since_fold_m += c;
+                    for (uint32_t k = 0; k < c; ++k) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) prm[i].mul(x[i]);
+                    }
+                } else {
+                    const double c = lds_count[r];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) accm[i] = fma(c, logPositive(x[i], lt), accm[i]);
+                }
+            }
+        }
+    }
+    // The sums of a chunk: one per pair and column.  Slices add theirs up in LDS, in the order of the slices (the staged rows
+    // are done with, no load is in flight), so that the resolving workgroup reads one part per chunk.
+    double * const out_pairs = w.part_pair + w.pair_part_off[m] + static_cast<uint64_t>(chunk) * G * G;
+    double * const out_columns = w.part_marginal + w.col_part_off[m] + static_cast<uint64_t>(chunk) * G;
+    double * const sums = tile_lds;         // [S][tcount][16], then
+    double * const column_sums = tile_lds;  // [SM][T][4]: one after the other in the same LDS
+    if (S > 1) __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t a = 4 * ta + i, b = 4 * tb + j;
+                pr[i][j].fold();
+                pr[i][j].e -= doubled;
+                const double total = acc[i][j] + pr[i][j].value(lt);
+                if (S > 1) sums[(slice * tcount + (t - t0)) * 16 + i * 4 + j] = total;
+                else if (a <= b && b < G) out_pairs[static_cast<uint64_t>(a) * G + b] = total;
+            }
+        }
+    }
+    if (S > 1) {
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < tcount * 16; e += kTileBlock) {
+            double total = 0.0;
+            for (uint32_t sl = 0; sl < S; ++sl) total += sums[sl * tcount * 16 + e];
+            const uint32_t te = t0 + e / 16, i = (e % 16) / 4, j = e % 4;
+            const uint32_t row = tileRowOfTile(te, T);
+            const uint32_t a = 4 * row + i, b = 4 * (row + (te - (row * T - row * (row > 0 ? row - 1 : 0) / 2))) + j;
+            if (a <= b && b < G) out_pairs[static_cast<uint64_t>(a) * G + b] = total;
+        }
+    }
+    if (t0 == 0 && !(w.debug_skip & 8u)) {
+        if (SM > 1) __syncthreads();
+        if (with_marginals) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t a = 4 * tc + i;
+                const double total = accm[i] + prm[i].value(lt);
+                if (SM > 1) column_sums[(marg_slice * T + tc) * 4 + i] = total;
+                else if (a < G) out_columns[a] = total;
+            }
+        }
+        if (SM > 1) {
+            __syncthreads();
+            for (uint32_t e = threadIdx.x; e < T * 4; e += kTileBlock) {
+                double total = 0.0;
+                for (uint32_t sl = 0; sl < SM; ++sl) total += column_sums[sl * T * 4 + e];
+                if (e < G) out_columns[e] = total;
+            }
+        }
+    }
+    if (threadIdx.x == 0 && t0 == 0) atomicAdd(w.log_evals, static_cast<unsigned long long>(static_cast<uint64_t>(G) * (G + 1) / 2 + G) * n);
+}
+
+__global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(3))) void pairTile2Kernel(const PairTileWork w) {
+    extern __shared__ __attribute__((aligned(16))) double tile_lds[];
+    __shared__ LogTableEntry lt[kLogTableSize];
+    const uint32_t item = blockIdx.x;
+    if (item >= w.count) return;
+    const uint32_t m = w.item_matrix[item], chunk = w.item_chunk[item];
+    const uint32_t t0 = w.item_tiles[item] & 0xffffu, tcount = (w.item_tiles[item] >> 16) + 1;  // tiles [t0, t0 + tcount)
+    loadLogTable(lt);  // visible after the first barrier of the item
+    const uint32_t T = tileColumns(w.mat_cols[m]);
+    const uint32_t c_lo = 4 * tileRowOfTile(t0, T), ncols = 4 * T - c_lo;  // columns the item's tiles touch: [c_lo, 4 T)
+    switch (tileSubRows(ncols)) {
+        case 126: pairTile2Item<126>(w, tile_lds, lt, m, chunk, t0, tcount, c_lo, ncols); break;
+        case 94: pairTile2Item<94>(w, tile_lds, lt, m, chunk, t0, tcount, c_lo, ncols); break;
+        case 46: pairTile2Item<46>(w, tile_lds, lt, m, chunk, t0, tcount, c_lo, ncols); break;
+        case 30: pairTile2Item<30>(w, tile_lds, lt, m, chunk, t0, tcount, c_lo, ncols); break;
+        case 14: pairTile2Item<14>(w, tile_lds, lt, m, chunk, t0, tcount, c_lo, ncols); break;
+        case 6: pairTile2Item<6>(w, tile_lds, lt, m, chunk, t0, tcount, c_lo, ncols); break;
+        default: pairTile2Item<2>(w, tile_lds, lt, m, chunk, t0, tcount, c_lo, ncols); break;
+    }
+}
+
+// The tiles of a matrix cut into the ranges of its work items: 256 at a time, and what is left so that tiles x slices fills
+// the workgroup — one more slice for as many tiles as fit then, the rest of the tiles in an item of their own (its lanes walk
+// 1 / slices of the rows each) — whenever that walks at least a tenth fewer rows per lane than one item with the slices that fit.
+inline void planTileRanges(const uint32_t tiles, std::vector<std::pair<uint32_t, uint32_t> > * ranges) {
+    uint32_t t0 = 0, left = tiles;
+    while (left > 0) {
+        if (left >= kTileBlock) {
+            ranges->emplace_back(t0, kTileBlock);
+            t0 += kTileBlock;
+            left -= kTileBlock;
+            continue;
+        }
+        const uint32_t slices = kTileBlock / left;
+        const uint32_t more = kTileBlock / (slices + 1), rest = left - more;
+        const double one = 1.0 / slices, two = 1.0 / (slices + 1) + 1.0 / (kTileBlock / rest);
+        if (two < 0.9 * one) {
+            ranges->emplace_back(t0, more);
+            t0 += more;
+            left = rest;
+        } else {
+            ranges->emplace_back(t0, left);
+            left = 0;
+        }
+    }
+}
+
 struct ResolveArgs {
     const uint32_t * big_matrix;    // [B] matrices on the table path
+    uint32_t chunk_rows;            // rows of a chunk of the partial sums
     uint32_t count;
     const uint64_t * mat_rows;
     const uint32_t * mat_cols;
@@ -878,7 +1228,7 @@ __global__ __launch_bounds__(256) void resolveTableKernel(const ResolveArgs args
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t R = args.mat_rows[m];
     const uint32_t G = args.mat_cols[m];
-    const uint32_t chunks = static_cast<uint32_t>((R + kChunkRows - 1) / kChunkRows);
+    const uint32_t chunks = static_cast<uint32_t>((R + args.chunk_rows - 1) / args.chunk_rows);
     const uint64_t c0 = args.col_off[m];
     const uint32_t * ccount = args.col_count + c0;
     double * lf = args.log_freq + c0;
@@ -1098,14 +1448,18 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
     // every pair of every matrix from LDS-staged rows, a tile of pairs per lane (pairTileKernel): the default for a
     // threshold that is a ratio <= 1; RPVG_HIP_PAIR_TILES=0 keeps the sequential search with its table path (A/B)
     const char * tiles_env = std::getenv("RPVG_HIP_PAIR_TILES");  // (read per call: the tests switch between the two searches)
-    const bool tiles_wanted = tiles_env ? std::atoi(tiles_env) != 0 : true;
-    const bool pair_tiles = tiles_wanted && min_rel_likelihood <= 1;
+    const int tiles_wanted = tiles_env ? std::atoi(tiles_env) : 2;  // (1: the tile kernel of round 2, synchronous staging, one item per chunk)
+    const bool pair_tiles = tiles_wanted != 0 && min_rel_likelihood <= 1;
+    const bool tile_ranges = pair_tiles && tiles_wanted != 1;
+    // rows of a work item's chunk (RPVG_HIP_PAIR_CHUNK_ROWS with tile ranges: A/B knob)
+    const uint32_t chunk_rows = tile_ranges && std::getenv("RPVG_HIP_PAIR_CHUNK_ROWS") ? std::max(256, std::atoi(std::getenv("RPVG_HIP_PAIR_CHUNK_ROWS"))) : kChunkRows;
     if (pair_tiles) table_min_work = 0.0;
     const uint32_t tile_step = kTileA;
     uint32_t & num_big = w.num_big;
     num_big = 0;
     std::vector<uint64_t> big_col_part_off(M, 0), big_pair_part_off(M, 0);
-    std::vector<uint32_t> item_matrix, item_col, item_chunk;
+    std::vector<uint32_t> item_matrix, item_col, item_chunk;  // (item_col: with tile ranges, first tile | (tiles - 1) << 16)
+    std::vector<std::pair<uint32_t, uint32_t> > ranges;
     uint64_t col_part_total = 0, pair_part_total = 0;
     {
         std::vector<uint32_t> table_matrices, others;
@@ -1113,7 +1467,7 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
         for (uint32_t i = 0; i < M; ++i) {
             const uint32_t m = order[i];
             const uint64_t R = groups->h_num_rows[m], G = groups->h_num_cols[m];
-            const uint64_t chunks = (R + kChunkRows - 1) / kChunkRows;
+            const uint64_t chunks = (R + chunk_rows - 1) / chunk_rows;
             const uint64_t parts = chunks;
             const bool fits = pair_part_total + parts * G * G <= table_budget;
             const bool takes_table = pair_tiles ? (G <= kTileMaxColumns && fits)
@@ -1128,6 +1482,18 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
             big_pair_part_off[m] = pair_part_total;
             col_part_total += parts * G;
             pair_part_total += parts * G * G;
+            if (tile_ranges) {
+                ranges.clear();
+                planTileRanges(tileCount(static_cast<uint32_t>(G)), &ranges);
+                for (uint32_t c = 0; c < chunks; ++c) {
+                    for (auto & range: ranges) {
+                        item_matrix.push_back(m);
+                        item_col.push_back(range.first | ((range.second - 1) << 16));
+                        item_chunk.push_back(c);
+                    }
+                }
+                continue;
+            }
             for (uint32_t c = 0; c < chunks; ++c) {
                 for (uint32_t a = 0; a < (pair_tiles ? 1u : G); a += tile_step) {
                     item_matrix.push_back(m);
@@ -1164,6 +1530,28 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
             std::fprintf(stderr, "\n");
         };
         show("table", 0, num_big);
+        if (pair_tiles) {  // the tile kernel's lanes: how many of a workgroup's 256 carry a tile, how many of a tile's 16 slots a pair
+            struct Bucket { uint64_t matrices = 0; double rows = 0, evals = 0, lane_rows = 0, slot_rows = 0; };
+            std::map<uint32_t, Bucket> buckets;
+            for (uint32_t i = 0; i < num_big; ++i) {
+                const double R = static_cast<double>(groups->h_num_rows[order[i]]);
+                const uint32_t G = groups->h_num_cols[order[i]];
+                uint32_t key = 1;
+                while (key < G) key <<= 1;
+                Bucket & b = buckets[key];
+                const uint32_t tiles = tileCount(G), S = tileSlices(G), passes = (tiles + kTileBlock - 1) / kTileBlock;
+                b.matrices += 1;
+                b.rows += R;
+                b.evals += R * (0.5 * G * (G + 1));
+                b.lane_rows += R / S * passes * kTileBlock;   // rows a lane walks x lanes of the workgroup
+                b.slot_rows += R * tiles * 16;
+            }
+            for (auto & kv : buckets) {
+                const Bucket & b = kv.second;
+                std::fprintf(stderr, "[search classes]   columns <= %4u: %6llu matrices, %9.0f rows, %.3g evaluations, pairs / tile slots %.2f, tile slots / lane slots %.2f\n",
+                             kv.first, static_cast<unsigned long long>(b.matrices), b.rows, b.evals, b.evals / b.slot_rows, b.slot_rows / (16.0 * b.lane_rows));
+            }
+        }
         show("medium", num_big, num_medium);
         show("small", num_big + num_medium, M - num_big - num_medium);
     }
@@ -1301,6 +1689,8 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
             PairTileWork pw;
             pw.item_matrix = d_item_matrix.ptr;
             pw.item_chunk = d_item_chunk.ptr;
+            pw.item_tiles = d_item_col.ptr;
+            pw.chunk_rows = chunk_rows;
             pw.count = tw.count;
             pw.mat_val_off = groups->mat_val_off.ptr;
             pw.mat_row_off = groups->mat_row_off.ptr;
@@ -1331,7 +1721,13 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
             // the matrices' collapse — the matrices it leaves alone as soon as its first stages have told them apart, the others when
             // it is done — 10.4 against 9.9 ms: the second pass's grid of mostly empty workgroups, and the replay's small kernels next
             // to the lane's own tile kernel.)
-            pairTileKernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
+            if (tile_ranges) pairTile2Kernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
+            else pairTileKernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
+            // (experiment, RPVG_HIP_PAIR_REPEAT=n: the same launch n more times — what a batch pays per millisecond of this kernel)
+            for (int k = std::getenv("RPVG_HIP_PAIR_REPEAT") ? std::atoi(std::getenv("RPVG_HIP_PAIR_REPEAT")) : 0; k > 0; --k) {
+                if (tile_ranges) pairTile2Kernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
+                else pairTileKernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
+            }
         } else {
             pairTableKernel<<<dim3(((tw.count + 7) / 8) * 8), dim3(256), 0, st>>>(tw);
         }
@@ -1341,6 +1737,7 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
         ra.count = num_big;
         ra.mat_rows = groups->mat_rows.ptr;
         ra.mat_cols = groups->mat_cols.ptr;
+        ra.chunk_rows = chunk_rows;
         ra.col_off = d_col_off.ptr;
         ra.col_count = d_col_count.ptr;
         ra.pair_cap_off = d_pair_cap_off.ptr;

@@ -644,11 +644,11 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(M * 60 + num_columns * 8 + num_incidences * 4 + (item_matrix.size() + tile_matrix.size()) * 8);
     sub.reset(new HostScope("groups_build: allocations"));
-    ok(g->values.alloc(val_total));
+    ok(g->values.alloc(val_total + 2));
     ok(g->rowmax.alloc(row_total));
     ok(g->row_perm.alloc(row_total));
-    ok(g->row_count.alloc(row_total));
-    ok(g->row_noise.alloc(row_total));
+    ok(g->row_count.alloc(row_total + 2));
+    ok(g->row_noise.alloc(row_total + 2));
     ok(g->mat_fast.alloc(M));
     ok(g->mat_mid.alloc(M));
     if (collapse) {

@@ -421,11 +421,12 @@ def test_stats_report_kernel_time(hip_ctx):
 
 # ---- on-device diploid branch-and-bound ---------------------------------------------------
 
-@pytest.mark.parametrize("tiles", [False, True], ids=["sequential", "all-pairs"])
+@pytest.mark.parametrize("tiles", [0, 1, 2], ids=["sequential", "all-pairs-one-item-per-chunk", "all-pairs"])
 @pytest.mark.parametrize("normalise,thr", [(True, 1e-3), (False, 1e-8)])
 def test_bounded_search_on_device_matches_oracle(hip_ctx, normalise, thr, tiles):
-    """all-pairs (the default): every pair from LDS-staged rows (pairTileKernel) + prefix-maximum filter instead of the
-    sequential in-workgroup walk (RPVG_HIP_PAIR_TILES=0) — the kept pairs and their order are the reference's either way."""
+    """all-pairs (the default): every pair from LDS-staged rows (pairTile2Kernel: ranges of tiles, LDS-direct loads; 1: round 2's
+    pairTileKernel) + prefix-maximum filter instead of the sequential in-workgroup walk (RPVG_HIP_PAIR_TILES=0) — the kept pairs
+    and their order are the reference's either way."""
     rng = np.random.default_rng(701)
     clusters = small_cases.make_batch_clusters(702, n_clusters=10, with_empty=False)
     clusters.append(small_cases.make_cluster(rng, 3, [9, 7, 8], n_haps=40, n_reads=1500))
@@ -443,8 +444,9 @@ def test_bounded_search_on_device_matches_oracle(hip_ctx, normalise, thr, tiles)
         groups.append(g)
         counts.append(mult)
     dg = hip_ctx.groups(dev, mats, groups, normalise)
-    if not tiles:
-        os.environ["RPVG_HIP_PAIR_TILES"] = "0"
+    if tiles != 2:
+        os.environ["RPVG_HIP_PAIR_TILES"] = str(tiles)
+    if tiles == 0:
         os.environ["RPVG_HIP_PAIRS_WITH_COUNTS"] = "0"  # ... and the kept pairs fetched with a copy of their own
     try:
         got = dg.bounded_pair_posteriors(np.concatenate(counts), thr)
@@ -494,6 +496,31 @@ def test_bounded_search_table_path(hip_ctx, force_table):
         sets, post = pyoracle.group_posteriors(M, noise, cnts, counts[m], 2, bounded=True, min_rel_lik=1e-3)
         assert got[m][0] == sets
         assert small_cases.rel_close(got[m][1], post, rel=1e-9, floor=1e-300)
+
+
+@pytest.mark.parametrize("haplotypes,reads,chunk_rows", [(64, 2600, None), (52, 1500, None), (100, 2300, None), (150, 1200, None), (64, 2600, 512)])
+def test_tile_ranges_of_the_pair_search(hip_ctx, haplotypes, reads, chunk_rows):
+    """pairTile2Kernel cuts the tiles of a matrix into the ranges of its work items: 64 columns are 136 tiles = 128 in two slices +
+    8 in 32 slices, 100 columns 325 tiles = 256 + 69, ... — every item stages the columns its tiles touch, several chunks of rows,
+    blocks of 46, 30 or 14 rows by LDS-direct loads at 8-byte-aligned (odd) row offsets.  Kept pairs and order: the oracle's."""
+    rng = np.random.default_rng(7300 + haplotypes)
+    cl = small_cases.make_cluster(rng, 1, [haplotypes], n_haps=haplotypes, n_reads=reads)
+    batch = ClusterBatch.from_clusters([cl])
+    dev = hip_ctx.upload(batch)
+    g = [[p] for p in range(len(cl["paths"]))]
+    mult = [p["source_count"] for p in cl["paths"]]
+    dg = hip_ctx.groups(dev, [0], [g], False)
+    if chunk_rows:
+        os.environ["RPVG_HIP_PAIR_CHUNK_ROWS"] = str(chunk_rows)
+    try:
+        got = dg.bounded_pair_posteriors(np.asarray(mult), 1e-6)
+    finally:
+        os.environ.pop("RPVG_HIP_PAIR_CHUNK_ROWS", None)
+    M, noise, cnts = np_oracle.grouped_matrix(cl["rows"], g)
+    assert M.shape[1] == haplotypes
+    sets, post = pyoracle.group_posteriors(M, noise, cnts, mult, 2, bounded=True, min_rel_lik=1e-6)
+    assert got[0][0] == sets, (len(got[0][0]), len(sets))
+    assert small_cases.rel_close(got[0][1], post, rel=1e-9, floor=1e-300)
 
 
 # ---- row classes of the group matrices (count-1 products, mid counts, logarithms) ---------------------------

@@ -3,14 +3,18 @@
 tools/pmc_kernels.py (profiles/r02/pmc_s3_search_kernels.txt) and the evaluations of one launch (bench.py's
 roofline_search.evals_per_step of a one-lane run = one launch):
 
-  python tools/pmc_search_summary.py <listing> <evals per launch> <out.json> [commit] [kernel]
+  python tools/pmc_search_summary.py <listing> <evals per launch> <out.json> [commit] [kernel] [launches]
+
+launches: launches of the kernel in one PMC pass (the one-lane bench with --steps 2 --warmup 1 runs the search 11 times: start-up,
+warm-up, timed, the upload leg and the decoded run); without it, from SQ_WAVES and round 2's 6 621 items of four waves.
 """
 import json
 import sys
 
 listing, evals, out = sys.argv[1], float(sys.argv[2]), sys.argv[3]
 commit = sys.argv[4] if len(sys.argv) > 4 else ""
-kernel = sys.argv[5] if len(sys.argv) > 5 else "pairTileKernel"
+kernel = sys.argv[5] if len(sys.argv) > 5 else "pairTile2Kernel"
+given_launches = float(sys.argv[6]) if len(sys.argv) > 6 else None
 counters, current = {}, None
 for line in open(listing):
     if not line.startswith(" "):
@@ -19,7 +23,7 @@ for line in open(listing):
         name, value = line.split()
         counters[name] = float(value)
 waves_per_launch = 4 * 6621  # 256-thread workgroups of the S3 batch (bench.py's configs[2] workload: 6 621 (matrix, chunk) items)
-launches = counters["SQ_WAVES"] / waves_per_launch
+launches = given_launches if given_launches else counters["SQ_WAVES"] / waves_per_launch
 simds, xcds = 256 * 4, 8
 # GRBM_GUI_ACTIVE is summed over the XCDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
 kernel_cycles = counters["GRBM_GUI_ACTIVE"] / xcds

@@ -1,0 +1,15 @@
+#!/bin/bash
+# pairTile2Kernel duration for settings of the environment (each argument: "NAME=ENV1=x ENV2=y") (gpurun)
+out=/root/repo/gpurun_out/r04/tileab; mkdir -p $out
+cd /tmp; export TMPDIR=/tmp
+for v in "$@"; do
+name=${v%%=*}; envs=${v#*=}
+env $envs RPVG_AMD_SINGLE_LANE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/log_$name 2>&1
+python - <<PY
+import csv,glob
+f=glob.glob("$out/p/*/*kernel_stats.csv")[0]
+for r in csv.DictReader(open(f)):
+    if "pairTile" in r["Name"] or "resolveTable" in r["Name"]: print("$name", r["Name"].split("(")[0][-30:], "calls", r["Calls"], "avg us", round(float(r["AverageNs"])/1e3,1))
+PY
+rm -rf $out/p
+done

@@ -71,7 +71,7 @@ python tools/pmc_traffic.py --fetch-dir $out/pmc_c2_fetch --write-dir $out/pmc_c
   --command "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --workload c2 --steps 1 --warmup 1 --no-cpu-baseline (two separate passes; 3 estimator calls x 50 EM iterations = 150 launches)" \
   --out $out/pmc_traffic_c2.json > /dev/null
 python tools/pmc_kernels.py $out/pmc_search_1 $out/pmc_search_2 $out/pmc_search_3 $out/pmc_search_4 --kernel pairTile,resolveTable,Search,pairTable > $out/pmc_s3_search_kernels.txt
-(cd $out && python /root/repo/tools/pmc_search_summary.py pmc_s3_search_kernels.txt 4573105636 pmc_search_s3.json $commit > /dev/null)
+(cd $out && python /root/repo/tools/pmc_search_summary.py pmc_s3_search_kernels.txt 4573105636 pmc_search_s3.json $commit pairTile2Kernel 11 > /dev/null)
 python tools/pmc_kernels.py $out/pmc_s5_1 $out/pmc_s5_2 $out/pmc_s5_3 $out/pmc_s5_4 --kernel groupConditional,groupLoglik,gibbs > $out/pmc_s5_conditional_kernels.txt
 python tools/pmc_kernels.py $out/pmc_emlat_1 $out/pmc_emlat_2 $out/pmc_emlat_3 $out/pmc_emlat_4 --kernel emRegisterKernel,emSparseKernel > $out/pmc_em_iteration_latency.txt
 rm -rf $out/pmc_s3_fetch $out/pmc_s3_write $out/pmc_c2_fetch $out/pmc_c2_write $out/pmc_search_? $out/pmc_s5_? $out/pmc_emlat_?
