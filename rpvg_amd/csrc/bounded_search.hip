@@ -1886,7 +1886,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         if (build_bad) {  // the matrices were built without a host sync
             pinnedFree(host_result);
             delete res;
-            setError("rpvg_hip_groups_build: a group refers to a path outside its cluster");
+            setError(build_bad == 2 ? "rpvg_hip_groups_build: a group lists a path twice" : "rpvg_hip_groups_build: a group refers to a path outside its cluster");
             return RPVG_HIP_ERR_INVALID;
         }
         groups->build_checked = true;

@@ -352,6 +352,182 @@ __global__ void incidenceFillKernel(const uint32_t num_matrices, const uint64_t 
     }
 }
 
+// ---- the same matrices from the columns' path sets as bit masks (round 4) -----------------------------------------------
+//
+// groupsBuildTileKernel walks, for every entry of a row, a chain of dependent loads (entry -> path -> the path's list of
+// columns -> column) and adds into an LDS tile that holds 64 rows of 64 columns: a wave of the workgroup's four works, four
+// workgroups fit a CU, and 23 us per tile is what the chain takes (0.95 ms per configs[2] batch, a third of the HBM time of
+// the 1.5 GB it writes).  The incidence the other way round needs no lists: a column IS a set of paths, and a cluster has tens
+// of paths — one or a few 64-bit words per column.  A lane owns a row, a wave a quarter of (up to 64) columns: the lane loads
+// its row's entries once and, for each of its columns, adds the probabilities of the entries whose path is in the column's
+// set, entry after entry (the additions of groupsBuildKernel in the same order: bit-identical values).  No tile: the values
+// stay in registers until they leave, 64 consecutive rows of a column per store.  Row sum, normalisation, largest value,
+// sort key and zero pattern as before (the sum over the columns in ascending order, handed from wave to wave).
+constexpr uint32_t kMaskMaxColumns = 1024;  // (wider matrices, and sets of more than kMaskMaxWords words: the list kernels)
+constexpr uint32_t kMaskMaxWords = 16;
+constexpr uint32_t kMaskRows = 64;
+
+// one thread per column: the set of its paths
+__global__ void columnMaskKernel(const uint32_t num_matrices, const uint64_t num_columns, const uint64_t * __restrict__ group_off,
+                                 const uint64_t * __restrict__ group_path_off, const uint32_t * __restrict__ group_path,
+                                 const uint64_t * __restrict__ num_paths, const uint64_t * __restrict__ mask_off, uint64_t * __restrict__ masks,
+                                 uint32_t * __restrict__ error_flag) {
+    const uint64_t column = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (column >= num_columns) return;
+    const uint32_t m = matrixOfColumn(group_off, num_matrices, column);
+    if (mask_off[m] == ~0ull) return;  // (a matrix of the other kernels)
+    const uint32_t words = static_cast<uint32_t>((num_paths[m] + 63) / 64);
+    uint64_t * const out = masks + mask_off[m] + (column - group_off[m]) * words;
+    for (uint32_t k = 0; k < words; ++k) out[k] = 0;
+    for (uint64_t x = group_path_off[column]; x < group_path_off[column + 1]; ++x) {
+        const uint32_t p = group_path[x];
+        if (p >= num_paths[m]) {
+            *error_flag = 1;
+            continue;
+        }
+        const uint64_t bit = 1ull << (p & 63u);
+        if (out[p >> 6] & bit) *error_flag = 2;  // (the lists of the other kernels would add such a path twice)
+        out[p >> 6] |= bit;
+    }
+}
+
+struct MaskBuildArgs {
+    uint32_t num_items;
+    const uint32_t * item_matrix;
+    const uint32_t * item_chunk;
+    const uint64_t * mat_val_off;
+    const uint64_t * mat_row_off;
+    const uint64_t * mat_row0;
+    const uint64_t * mat_rows;
+    const uint32_t * mat_cols;
+    const uint64_t * num_paths;
+    const uint64_t * mask_off;
+    const uint64_t * masks;
+    const uint64_t * row_ent_off;
+    const uint32_t * ent_path;
+    const double * ent_prob;
+    const double * row_noise;
+    const uint32_t * row_perm;
+    int normalise;
+    int debug_no_long_rows;    // timing experiment (RPVG_HIP_BUILD_DEBUG=1): entries past the held ones are dropped
+    double * values;
+    double * rowmax;
+    uint64_t * collapse_key;   // null: no row collapse
+    uint32_t * collapse_row;
+    uint64_t * collapse_mask;
+};
+
+// A wave per (matrix, 64 rows) item, a lane per row, and nothing shared between lanes: the lane walks the columns of its row
+// twice — once for the row sum (column after column: the order of the other kernels), once more for the values, which it
+// computes again rather than keeping them (a cell is a handful of bit tests and additions; a tile of 64 x 64 values in LDS was
+// what limited a CU to four workgroups, and the kernel's time went with the workgroups a CU held: 0.97 ms with four, 1.31 with
+// three, 2.35 with two — latency of its loads and of its short dependent loops, not bandwidth).  No LDS, no barrier; the set of
+// a column is the same word for every lane (a scalar load).
+constexpr int kMaskHeld = 8;   // entries of a row in registers (3.3 a row on the configs[2] batch), in two halves
+
+__global__ __launch_bounds__(256) void groupsBuildMaskKernel(const MaskBuildArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (item >= a.num_items) return;
+    const uint32_t m = a.item_matrix[item];
+    const uint64_t R = a.mat_rows[m], r0 = a.mat_row0[m], row_off = a.mat_row_off[m];
+    const uint32_t G = a.mat_cols[m];
+    const uint32_t words = static_cast<uint32_t>((a.num_paths[m] + 63) / 64);
+    const uint64_t * const sets = a.masks + a.mask_off[m];
+    double * const M = a.values + a.mat_val_off[m];
+    const uint64_t i = static_cast<uint64_t>(a.item_chunk[item]) * kMaskRows + lane;
+    const bool valid = i < R;
+    const uint64_t r = valid ? r0 + a.row_perm[row_off + i] : 0;
+    const uint64_t e_begin = valid ? a.row_ent_off[r] : 0, e_end = valid ? a.row_ent_off[r + 1] : 0;
+    const double noise = valid && a.normalise ? a.row_noise[r] : 0.0;
+    uint32_t p[kMaskHeld];
+    double v[kMaskHeld];
+#pragma unroll
+    for (int k = 0; k < kMaskHeld; ++k) {
+        p[k] = 0u;
+        v[k] = 0.0;  // (an entry past the row's last adds + 0.0: nothing)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (e_begin + k < e_end) {
+            p[k] = a.ent_path[e_begin + k];
+            v[k] = a.ent_prob[e_begin + k];
+        }
+    }
+    const bool second_half = __ballot(e_begin + 4 < e_end) != 0ull;  // (of the wave: the same for every lane)
+    if (second_half) {
+#pragma unroll
+        for (int k = 4; k < kMaskHeld; ++k) {
+            if (e_begin + k < e_end) {
+                p[k] = a.ent_path[e_begin + k];
+                v[k] = a.ent_prob[e_begin + k];
+            }
+        }
+    }
+    const bool longer = !a.debug_no_long_rows && __ballot(e_begin + kMaskHeld < e_end) != 0ull;
+
+    // the row's value in column c: the probabilities of its entries whose path is in the column's set, entry after entry
+    auto cell = [&](const uint32_t c) {
+        double sum = 0.0;
+        if (words == 1) {
+            const uint64_t set = sets[c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum += ((set >> (p[k] & 63u)) & 1ull) ? v[k] : 0.0;
+            if (second_half) {
+#pragma unroll
+                for (int k = 4; k < kMaskHeld; ++k) sum += ((set >> (p[k] & 63u)) & 1ull) ? v[k] : 0.0;
+            }
+            if (longer) {
+                for (uint64_t e = e_begin + kMaskHeld; e < e_end; ++e) sum += ((set >> (a.ent_path[e] & 63u)) & 1ull) ? a.ent_prob[e] : 0.0;
+            }
+        } else {
+            const uint64_t * const set = sets + static_cast<size_t>(c) * words;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum += ((set[p[k] >> 6] >> (p[k] & 63u)) & 1ull) ? v[k] : 0.0;
+            if (second_half) {
+#pragma unroll
+                for (int k = 4; k < kMaskHeld; ++k) sum += ((set[p[k] >> 6] >> (p[k] & 63u)) & 1ull) ? v[k] : 0.0;
+            }
+            if (longer) {
+                for (uint64_t e = e_begin + kMaskHeld; e < e_end; ++e) {
+                    const uint32_t path = a.ent_path[e];
+                    sum += ((set[path >> 6] >> (path & 63u)) & 1ull) ? a.ent_prob[e] : 0.0;
+                }
+            }
+        }
+        return sum;
+    };
+
+    double rowsum = 0.0;
+    if (a.normalise) {
+#pragma unroll 4
+        for (uint32_t c = 0; c < G; ++c) rowsum += cell(c);
+    }
+    const double keep = 1 - noise;
+    double key = collapseWeight(G) * noise, mx = 0.0;
+    uint64_t pattern = 0;
+#pragma unroll 4
+    for (uint32_t c = 0; c < G; ++c) {
+        double value = cell(c);
+        if (a.normalise) {
+            value = (value / rowsum) * keep;
+            if (value != value) value = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
+            key = fma(collapseWeight(c), value, key);
+            if (c < 64 && value != 0.0) pattern |= 1ull << c;
+        }
+        mx = fmax(mx, value);
+        if (valid) M[static_cast<uint64_t>(c) * R + i] = value;
+    }
+    if (valid) {
+        a.rowmax[row_off + i] = mx;
+        if (a.normalise && a.collapse_key) {
+            a.collapse_key[row_off + i] = collapseSortKey(m, key, mx);
+            a.collapse_row[row_off + i] = static_cast<uint32_t>(row_off + i);
+            a.collapse_mask[row_off + i] = pattern;
+        }
+    }
+}
+
 // storage of the matrices groupsBuildKernel accumulates in global memory: one work item = 256 rows of one matrix
 __global__ __launch_bounds__(256) void zeroWideMatricesKernel(const uint32_t * __restrict__ item_matrix, const uint32_t * __restrict__ item_chunk,
                                                               const uint64_t * __restrict__ mat_val_off, const uint64_t * __restrict__ mat_rows,
@@ -513,8 +689,13 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     std::unique_ptr<HostScope> scope_host(new HostScope("groups_build: host sizes"));
     // host: sizes and offsets only (O(M)); the path -> groups incidence is inverted on the device
     std::vector<uint64_t> val_off(M), row_off(M), row0(M), rows(M), inc_off(M), num_paths(M);
-    std::vector<uint32_t> cols(M), item_matrix, item_chunk, tile_matrix, tile_chunk;
-    uint64_t val_total = 0, row_total = 0, inc_total = 0;
+    std::vector<uint32_t> cols(M), item_matrix, item_chunk, tile_matrix, tile_chunk, mask_matrix, mask_chunk;
+    std::vector<uint64_t> mask_off(M, ~0ull);  // (~0: a matrix of the list kernels)
+    uint64_t val_total = 0, row_total = 0, inc_total = 0, mask_total = 0;
+    bool lists_needed = false;  // the path -> columns lists of the tile / global-memory kernels
+    // RPVG_HIP_BUILD_MASKS=0: every matrix through the list kernels (A/B, tests)
+    const char * masks_env = std::getenv("RPVG_HIP_BUILD_MASKS");
+    const bool build_masks = masks_env ? std::atoi(masks_env) != 0 : true;
     for (uint32_t m = 0; m < M; ++m) {
         const uint32_t k = spec->cluster[m];
         if (k >= batch->num_clusters) {
@@ -552,6 +733,17 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         val_total += R * (g1 - g0);
         row_total += R;
         inc_total += N + 1;
+        const uint64_t mask_words = (N + 63) / 64;
+        if (build_masks && cols[m] <= kMaskMaxColumns && mask_words <= kMaskMaxWords) {
+            mask_off[m] = mask_total;
+            mask_total += cols[m] * mask_words;
+            for (uint64_t c = 0; c * kMaskRows < R; ++c) {
+                mask_matrix.push_back(m);
+                mask_chunk.push_back(static_cast<uint32_t>(c));
+            }
+            continue;
+        }
+        lists_needed = true;
         const uint32_t tile_rows = tileRows(cols[m]);
         if (tile_rows) {
             for (uint64_t c = 0; c * tile_rows < R; ++c) {
@@ -589,7 +781,8 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     // temporaries: owned by the matrices object (the kernels that use them may still be queued on return)
     struct BuildTemporaries {
         DeviceBuffer<uint64_t> inc_off, path_grp_off, group_off, group_path_off, num_paths;
-        DeviceBuffer<uint32_t> path_grp, item_matrix, item_chunk, tile_matrix, tile_chunk, group_path, degree, cursor, cluster;
+        DeviceBuffer<uint32_t> path_grp, item_matrix, item_chunk, tile_matrix, tile_chunk, group_path, degree, cursor, cluster, mask_matrix, mask_chunk;
+        DeviceBuffer<uint64_t> mask_off, masks;
         DeviceBuffer<unsigned char> scan_tmp;
     };
     std::shared_ptr<BuildTemporaries> tmp = std::make_shared<BuildTemporaries>();
@@ -623,6 +816,11 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         pack.add(d_tile_matrix, tile_matrix.data(), tile_matrix.size());
         pack.add(d_tile_chunk, tile_chunk.data(), tile_chunk.size());
     }
+    if (!mask_matrix.empty()) {
+        pack.add(tmp->mask_matrix, mask_matrix.data(), mask_matrix.size());
+        pack.add(tmp->mask_chunk, mask_chunk.data(), mask_chunk.size());
+        pack.add(tmp->mask_off, mask_off.data(), M);
+    }
     std::vector<uint32_t> segment_off;
     if (collapse) {
         segment_off.resize(M + 1);
@@ -633,8 +831,10 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     }
     DeviceBuffer<uint32_t> & d_cluster = tmp->cluster;
     pack.add(d_cluster, spec->cluster, M);
-    pack.addZero(d_degree, inc_total);
-    pack.addZero(d_cursor, inc_total);
+    if (lists_needed) {
+        pack.addZero(d_degree, inc_total);
+        pack.addZero(d_cursor, inc_total);
+    }
     pack.addZero(d_error, 1);
     ok(pack.commit(st));
     g->d_group_off = d_group_off.ptr;
@@ -656,12 +856,15 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         ok(g->collapse_row.alloc(row_total));
         ok(g->collapse_mask.alloc(row_total));
     }
-    ok(d_path_grp_off.alloc(inc_total));
-    ok(d_path_grp.alloc(num_incidences));
     size_t scan_bytes = 0;
-    if (e == hipSuccess) ok(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_degree.ptr, d_path_grp_off.ptr, static_cast<int>(inc_total), st));
-    ok(d_scan_tmp.alloc(scan_bytes));
-    if (e == hipSuccess && inc_total > 0x7fffffffull) e = hipErrorInvalidValue;
+    if (lists_needed) {
+        ok(d_path_grp_off.alloc(inc_total));
+        ok(d_path_grp.alloc(num_incidences));
+        if (e == hipSuccess) ok(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_degree.ptr, d_path_grp_off.ptr, static_cast<int>(inc_total), st));
+        ok(d_scan_tmp.alloc(scan_bytes));
+        if (e == hipSuccess && inc_total > 0x7fffffffull) e = hipErrorInvalidValue;
+    }
+    if (!mask_matrix.empty()) ok(tmp->masks.alloc(mask_total));
     sub.reset(new HostScope("groups_build: launches"));
     if (e == hipSuccess) {
         span = ctx->spanBegin(FAM_BUILD);
@@ -675,13 +878,44 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
                                                            g->mat_fast.ptr, g->mat_mid.ptr,
                                                            kMidMinRows);
         const uint32_t col_blocks = static_cast<uint32_t>((num_columns + 255) / 256);
-        incidenceCountKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,
-                                                                   d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
-                                                                   d_degree.ptr, d_error.ptr);
-        ok(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.ptr, scan_bytes, d_degree.ptr, d_path_grp_off.ptr, static_cast<int>(inc_total), st));
-        incidenceFillKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,
-                                                                  d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
-                                                                  d_path_grp_off.ptr, d_cursor.ptr, d_path_grp.ptr);
+        if (!mask_matrix.empty()) {
+            columnMaskKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr, d_group_path.ptr,
+                                                                    d_num_paths.ptr, tmp->mask_off.ptr, tmp->masks.ptr, d_error.ptr);
+            MaskBuildArgs ma;
+            ma.num_items = static_cast<uint32_t>(mask_matrix.size());
+            ma.item_matrix = tmp->mask_matrix.ptr;
+            ma.item_chunk = tmp->mask_chunk.ptr;
+            ma.mat_val_off = g->mat_val_off.ptr;
+            ma.mat_row_off = g->mat_row_off.ptr;
+            ma.mat_row0 = g->mat_row0.ptr;
+            ma.mat_rows = g->mat_rows.ptr;
+            ma.mat_cols = g->mat_cols.ptr;
+            ma.num_paths = d_num_paths.ptr;
+            ma.mask_off = tmp->mask_off.ptr;
+            ma.masks = tmp->masks.ptr;
+            ma.row_ent_off = batch->row_ent_off.ptr;
+            ma.ent_path = batch->ent_path.ptr;
+            ma.ent_prob = batch->ent_prob.ptr;
+            ma.row_noise = batch->row_noise.ptr;
+            ma.row_perm = g->row_perm.ptr;
+            ma.normalise = spec->normalise ? 1 : 0;
+            ma.debug_no_long_rows = std::getenv("RPVG_HIP_BUILD_DEBUG") ? std::atoi(std::getenv("RPVG_HIP_BUILD_DEBUG")) & 1 : 0;
+            ma.values = g->values.ptr;
+            ma.rowmax = g->rowmax.ptr;
+            ma.collapse_key = g->collapse_key.ptr;
+            ma.collapse_row = g->collapse_row.ptr;
+            ma.collapse_mask = g->collapse_mask.ptr;
+            groupsBuildMaskKernel<<<dim3((ma.num_items + 3) / 4), dim3(256), 0, st>>>(ma);
+        }
+        if (lists_needed) {
+            incidenceCountKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,
+                                                                       d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
+                                                                       d_degree.ptr, d_error.ptr);
+            ok(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.ptr, scan_bytes, d_degree.ptr, d_path_grp_off.ptr, static_cast<int>(inc_total), st));
+            incidenceFillKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,
+                                                                      d_group_path.ptr, d_inc_off.ptr, d_num_paths.ptr,
+                                                                      d_path_grp_off.ptr, d_cursor.ptr, d_path_grp.ptr);
+        }
         if (!tile_matrix.empty()) {
             groupsBuildTileKernel<<<dim3(static_cast<uint32_t>(tile_matrix.size())), dim3(256), (kTileDoubles + 256) * sizeof(double), st>>>(
                 static_cast<uint32_t>(tile_matrix.size()), d_tile_matrix.ptr, d_tile_chunk.ptr, g->mat_val_off.ptr,
@@ -740,7 +974,7 @@ int rpvg_hip_groups::buildError(hipStream_t stream) const {
         return RPVG_HIP_ERR_RUNTIME;
     }
     if (bad) {
-        setError("rpvg_hip_groups_build: a group refers to a path outside its cluster");
+        setError(bad == 2 ? "rpvg_hip_groups_build: a group lists a path twice" : "rpvg_hip_groups_build: a group refers to a path outside its cluster");
         return RPVG_HIP_ERR_INVALID;
     }
     build_checked = true;

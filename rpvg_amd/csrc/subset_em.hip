@@ -869,7 +869,7 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
     hints.entries = got.entries;
     if (got.build_bad) {
         (void) hipStreamSynchronize(st);
-        setError("rpvg_hip_groups_build: a group refers to a path outside its cluster");
+        setError(got.build_bad == 2 ? "rpvg_hip_groups_build: a group lists a path twice" : "rpvg_hip_groups_build: a group refers to a path outside its cluster");
         return RPVG_HIP_ERR_INVALID;
     }
     groups->build_checked = true;

@@ -644,6 +644,57 @@ def test_groups_with_a_path_outside_the_cluster_are_reported_by_the_first_consum
         dg.loglik([0], [[0]], 1.0)
 
 
+def test_groups_with_a_path_listed_twice_are_reported(hip_ctx):
+    """The columns of a matrix are sets of paths (bit masks on the device: groupsBuildMaskKernel)."""
+    from rpvg_amd import hip
+    clusters = small_cases.make_batch_clusters(952, n_clusters=2, with_empty=False)
+    dev = hip_ctx.upload(ClusterBatch.from_clusters(clusters))
+    dg = hip_ctx.groups(dev, [0], [[[0], [1, 1]]], False)
+    with pytest.raises(hip.EngineError, match="lists a path twice"):
+        dg.loglik([0], [[0]], 1.0)
+
+
+@pytest.mark.parametrize("normalise", [True, False])
+def test_matrices_from_path_masks_equal_the_matrices_from_path_lists(hip_ctx, normalise):
+    """groupsBuildMaskKernel (the default: a column's paths as a bit mask, a lane per row, a wave per 16 columns) adds a row's
+    entries in the order groupsBuildTileKernel / groupsBuildKernel (RPVG_HIP_BUILD_MASKS=0) do: the same values to the bit —
+    seen through the log-likelihoods of every column and of pairs.  One word per column, two words (75 paths), more than 64
+    columns (two blocks), a cluster of one row."""
+    rng = np.random.default_rng(961)
+    clusters = small_cases.make_batch_clusters(962, n_clusters=8, with_empty=False)
+    clusters.append(small_cases.make_cluster(rng, 3, [30, 25, 20], n_haps=100, n_reads=700))
+    clusters.append(small_cases.make_cluster(rng, 1, [70], n_haps=70, n_reads=300))
+    clusters.append(small_cases.make_cluster(rng, 2, [3, 2], n_haps=4, n_reads=1, empty_read_frac=0.0))
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    groups = []
+    for cl in clusters:
+        if normalise:
+            g, _ = np_oracle.source_groups(cl["paths"])
+        else:
+            g = [[p] for p in range(len(cl["paths"]))]
+        groups.append(g)
+    assert max(len(g) for g in groups) > 64 and max(len(cl["paths"]) for cl in clusters) > 64
+    mats = list(range(len(clusters)))
+    requests_m, requests_c = [], []
+    for m, g in enumerate(groups):
+        for c in range(len(g)):
+            requests_m.append(m)
+            requests_c.append([c, (c * 7 + 3) % len(g)])
+    results = []
+    for masks in ("1", "0"):
+        os.environ["RPVG_HIP_BUILD_MASKS"] = masks
+        try:
+            dg = hip_ctx.groups(dev, mats, groups, normalise)
+            single = dg.loglik(requests_m, [[c[0]] for c in requests_c], 1.0)
+            pairs = dg.loglik(requests_m, requests_c, 2.0)
+        finally:
+            os.environ.pop("RPVG_HIP_BUILD_MASKS", None)
+        results.append((single, pairs))
+    assert np.all(np.isfinite(results[0][0])) and np.all(np.isfinite(results[0][1]))
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+
+
 def test_upload_reports_the_first_row_that_breaks_an_invariant(hip_ctx):
     """The rows of a batch are checked on the device, behind their copy (validateRowsKernel); the host words the message."""
     from rpvg_amd import hip

@@ -1,0 +1,18 @@
+#!/bin/bash
+# average duration of the kernels whose names contain $1 (comma-separated) in one-lane runs of the configs[2] bench, for
+# settings of the environment (further arguments: "NAME=ENV1=x ENV2=y") (gpurun)
+out=/root/repo/gpurun_out/r04/kab; mkdir -p $out
+cd /tmp; export TMPDIR=/tmp
+want=$1; shift
+for v in "$@"; do
+name=${v%%=*}; envs=${v#*=}
+env $envs RPVG_AMD_SINGLE_LANE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/log_$name 2>&1
+python - <<PY
+import csv,glob
+f=glob.glob("$out/p/*/*kernel_stats.csv")[0]
+want="$want".split(",")
+for r in csv.DictReader(open(f)):
+    if any(w in r["Name"] for w in want): print("$name", r["Name"].split("(")[0][-40:], "calls", r["Calls"], "avg us", round(float(r["AverageNs"])/1e3,1))
+PY
+rm -rf $out/p
+done
