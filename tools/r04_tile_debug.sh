@@ -1,6 +1,7 @@
 #!/bin/bash
-# pairTileKernel: shapes of the matrices it takes (lane use) and its duration with row classes switched off
-# (RPVG_HIP_PAIR_DEBUG: results are wrong then, timing only) (gpurun)
+# pairTile2Kernel: shapes of the matrices it takes (lane use) and its duration with row classes / loads switched off
+# (RPVG_HIP_PAIR_DEBUG bits: 1 count-1 rows, 2 counts 2..8, 4 logarithm rows, 8 single columns, 16 loads; results are wrong then,
+# timing only) (gpurun; one lane, rocprofv3 --kernel-trace --stats)
 out=/root/repo/gpurun_out/r04/tiledbg; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 [ -n "$NOCLASSES" ] || RPVG_HIP_SEARCH_CLASSES=1 RPVG_AMD_SINGLE_LANE=1 timeout 300 python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep "search classes" | head -20 > $out/classes.txt
