@@ -173,7 +173,7 @@ typedef struct rpvg_hip_group_spec {
     const uint32_t * cluster;         /* host [M]   */
     const uint64_t * group_off;       /* host [M+1] columns of each matrix, range into group_path_off */
     const uint64_t * group_path_off;  /* host [G+1] */
-    const uint32_t * group_path;      /* host       cluster-local paths of each column: a set — every path at most once */
+    const uint32_t * group_path;      /* host       cluster-local paths of each column (a set: list a path once) */
     int32_t normalise;
     /* > 0 (normalised matrices only): replay readCollapseProbabilityMatrix (src/path_estimator.cpp:197-259, called
      * on every normalised group matrix, src/path_abundance_estimator.cpp:380,443) with this prob_precision — every
@@ -184,8 +184,8 @@ typedef struct rpvg_hip_group_spec {
 } rpvg_hip_group_spec;
 
 /* Returns once the build is queued on the context's stream (the spec arrays have been consumed by then); a group that
- * refers to a path outside its cluster, or lists a path twice (the columns of constructGroupedProbabilityMatrix are sets
- * of paths: src/path_abundance_estimator.cpp:493-546), is reported by the first call that uses the matrices
+ * refers to a path outside its cluster (or, with RPVG_HIP_BUILD_MASKS=1, lists a path twice: the columns of
+ * constructGroupedProbabilityMatrix are sets of paths, src/path_abundance_estimator.cpp:493-546) is reported by the first call that uses the matrices
  * (RPVG_HIP_ERR_INVALID from rpvg_hip_group_loglik / _conditionals / rpvg_hip_bounded_pair_posteriors). */
 int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec,
                           rpvg_hip_groups ** groups_out);

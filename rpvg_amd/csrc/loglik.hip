@@ -693,9 +693,11 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     std::vector<uint64_t> mask_off(M, ~0ull);  // (~0: a matrix of the list kernels)
     uint64_t val_total = 0, row_total = 0, inc_total = 0, mask_total = 0;
     bool lists_needed = false;  // the path -> columns lists of the tile / global-memory kernels
-    // RPVG_HIP_BUILD_MASKS=0: every matrix through the list kernels (A/B, tests)
+    // RPVG_HIP_BUILD_MASKS=1: matrices of up to kMaskMaxColumns columns through groupsBuildMaskKernel instead of the list kernels
+    // (0.84 against 1.05 ms per configs[2] batch standing alone, but 9.71 against 9.65 ms per batch in the two-lane bench: the
+    // list kernels wait, and the other lane's kernels run meanwhile; the mask kernel computes)
     const char * masks_env = std::getenv("RPVG_HIP_BUILD_MASKS");
-    const bool build_masks = masks_env ? std::atoi(masks_env) != 0 : true;
+    const bool build_masks = masks_env ? std::atoi(masks_env) != 0 : false;
     for (uint32_t m = 0; m < M; ++m) {
         const uint32_t k = spec->cluster[m];
         if (k >= batch->num_clusters) {

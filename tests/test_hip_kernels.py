@@ -645,19 +645,23 @@ def test_groups_with_a_path_outside_the_cluster_are_reported_by_the_first_consum
 
 
 def test_groups_with_a_path_listed_twice_are_reported(hip_ctx):
-    """The columns of a matrix are sets of paths (bit masks on the device: groupsBuildMaskKernel)."""
+    """With the columns' paths as bit masks (RPVG_HIP_BUILD_MASKS=1: groupsBuildMaskKernel) a column is a set of paths."""
     from rpvg_amd import hip
     clusters = small_cases.make_batch_clusters(952, n_clusters=2, with_empty=False)
     dev = hip_ctx.upload(ClusterBatch.from_clusters(clusters))
-    dg = hip_ctx.groups(dev, [0], [[[0], [1, 1]]], False)
-    with pytest.raises(hip.EngineError, match="lists a path twice"):
-        dg.loglik([0], [[0]], 1.0)
+    os.environ["RPVG_HIP_BUILD_MASKS"] = "1"
+    try:
+        dg = hip_ctx.groups(dev, [0], [[[0], [1, 1]]], False)
+        with pytest.raises(hip.EngineError, match="lists a path twice"):
+            dg.loglik([0], [[0]], 1.0)
+    finally:
+        os.environ.pop("RPVG_HIP_BUILD_MASKS", None)
 
 
 @pytest.mark.parametrize("normalise", [True, False])
 def test_matrices_from_path_masks_equal_the_matrices_from_path_lists(hip_ctx, normalise):
-    """groupsBuildMaskKernel (the default: a column's paths as a bit mask, a lane per row, a wave per 16 columns) adds a row's
-    entries in the order groupsBuildTileKernel / groupsBuildKernel (RPVG_HIP_BUILD_MASKS=0) do: the same values to the bit —
+    """groupsBuildMaskKernel (RPVG_HIP_BUILD_MASKS=1: a column's paths as a bit mask, a wave per 64 rows, a lane per row) adds a
+    row's entries in the order groupsBuildTileKernel / groupsBuildKernel (the default) do: the same values to the bit —
     seen through the log-likelihoods of every column and of pairs.  One word per column, two words (75 paths), more than 64
     columns (two blocks), a cluster of one row."""
     rng = np.random.default_rng(961)

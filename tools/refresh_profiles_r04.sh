@@ -32,7 +32,7 @@ timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline 2>/dev/null 
 RPVG_HIP_EM_LAUNCH_EARLY=1 RPVG_HIP_SEARCH_LAUNCH_EARLY=1 RPVG_HIP_EM_JOIN_ON_STREAM=1 timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_60_steps_parked_streams.json; stamp $out/bench_s3_n1_60_steps_parked_streams.json
 RPVG_HIP_COLLAPSE_LIBRARY_SORT=1 timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_60_steps_library_sort.json; stamp $out/bench_s3_n1_60_steps_library_sort.json
 RPVG_HIP_PAIR_TILES=1 timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_60_steps_round2_tile_kernel.json; stamp $out/bench_s3_n1_60_steps_round2_tile_kernel.json
-RPVG_HIP_BUILD_MASKS=0 timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_60_steps_list_build.json; stamp $out/bench_s3_n1_60_steps_list_build.json
+RPVG_HIP_BUILD_MASKS=1 timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_60_steps_mask_build.json; stamp $out/bench_s3_n1_60_steps_mask_build.json
 DBG="0 1 2 4 8 15 16 31" bash tools/r04_tile_debug.sh > $out/pair_tile_breakdown.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 prof() {  # name, bench args...
@@ -79,7 +79,7 @@ python tools/pmc_kernels.py $out/pmc_s5_1 $out/pmc_s5_2 $out/pmc_s5_3 $out/pmc_s
 python tools/pmc_kernels.py $out/pmc_emlat_1 $out/pmc_emlat_2 $out/pmc_emlat_3 $out/pmc_emlat_4 --kernel emRegisterKernel,emSparseKernel > $out/pmc_em_iteration_latency.txt
 rm -rf $out/pmc_s3_fetch $out/pmc_s3_write $out/pmc_c2_fetch $out/pmc_c2_write $out/pmc_search_? $out/pmc_s5_? $out/pmc_emlat_?
 echo $commit > $out/COMMIT
-for f in bench_s3_n1 bench_s3_n1_60_steps bench_s3_n1_60_steps_round2_tile_kernel bench_s3_n1_60_steps_list_build bench_s3_n1_60_steps_parked_streams bench_s3_n1_60_steps_library_sort bench_s3_n1_host_threads_4 bench_s3_n1_separate_calls bench_s3_n1_separate_calls_host_threads_4 bench_s3_n1_no_collapse bench_c2_n1 bench_s5_n1 bench_rows_n1 bench_e2e_n1 bench_s3_n1_profiled; do python - <<PY
+for f in bench_s3_n1 bench_s3_n1_60_steps bench_s3_n1_60_steps_round2_tile_kernel bench_s3_n1_60_steps_mask_build bench_s3_n1_60_steps_parked_streams bench_s3_n1_60_steps_library_sort bench_s3_n1_host_threads_4 bench_s3_n1_separate_calls bench_s3_n1_separate_calls_host_threads_4 bench_s3_n1_no_collapse bench_c2_n1 bench_s5_n1 bench_rows_n1 bench_e2e_n1 bench_s3_n1_profiled; do python - <<PY
 import json
 try:
     d=json.loads(open("$out/$f.json").read())
