@@ -503,6 +503,21 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
         eng.reset_stats()
         barrier_sync(dist, torch)
         import resource
+
+        def thread_cpu():  # CPU seconds (user, system) of every thread of the process so far
+            import glob
+            ticks = os.sysconf("SC_CLK_TCK")
+            out = {}
+            for stat in glob.glob("/proc/self/task/*/stat"):
+                try:
+                    text = open(stat).read()
+                    fields = text[text.rindex(")") + 2:].split()
+                    out[stat.split("/")[4]] = (int(fields[11]) / ticks, int(fields[12]) / ticks)
+                except Exception:  # noqa: BLE001
+                    pass
+            return out
+
+        threads0 = thread_cpu() if os.environ.get("RPVG_BENCH_THREAD_CPU") else None
         cpu0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         step_ms = []
@@ -513,23 +528,17 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
         barrier_sync(dist, torch)
         overlapped = max_over_ranks(time.perf_counter() - t0, dist, torch)
         cpu1 = resource.getrusage(resource.RUSAGE_SELF)
-        if os.environ.get("RPVG_BENCH_THREAD_CPU"):  # who burnt it: CPU seconds of every thread of the process so far
-            import glob
-            ticks = os.sysconf("SC_CLK_TCK")
-            rows = []
-            for stat in glob.glob("/proc/self/task/*/stat"):
-                try:
-                    text = open(stat).read()
-                    name = text[text.index("(") + 1:text.rindex(")")]
-                    fields = text[text.rindex(")") + 2:].split()
-                    rows.append(((int(fields[11]) + int(fields[12])) / ticks, int(fields[11]) / ticks, int(fields[12]) / ticks, name, stat.split("/")[4]))
-                except Exception:  # noqa: BLE001
-                    pass
-            rows.sort(reverse=True)
-            print("thread cpu (total user sys name tid):", file=sys.stderr)
-            for r in rows[:24]:
-                print(f"  {r[0]:7.2f} {r[1]:7.2f} {r[2]:7.2f} {r[3]} {r[4]}", file=sys.stderr)
-            print(f"  threads {len(rows)}  sum {sum(r[0] for r in rows):.2f} s", file=sys.stderr)
+        if threads0 is not None:  # who burnt it: CPU time of every thread over the timed region, per step
+            threads1 = thread_cpu()
+            rows = sorted(((sum(threads1[t]) - sum(threads0.get(t, (0.0, 0.0))), threads1[t][0] - threads0.get(t, (0.0, 0.0))[0],
+                            threads1[t][1] - threads0.get(t, (0.0, 0.0))[1], t) for t in threads1), reverse=True)
+            print("thread cpu over the timed region, ms per step (total user sys tid):", file=sys.stderr)
+            for r in rows[:16]:
+                print(f"  {r[0] * 1e3 / args.steps:7.2f} {r[1] * 1e3 / args.steps:7.2f} {r[2] * 1e3 / args.steps:7.2f} {r[3]}", file=sys.stderr)
+            busy = [r for r in rows if r[0] > 0]
+            print(f"  threads {len(rows)}, with CPU time {len(busy)}, sum {sum(r[0] for r in rows) * 1e3 / args.steps:.1f} ms per step "
+                  f"(user {sum(r[1] for r in rows) * 1e3 / args.steps:.1f}, system {sum(r[2] for r in rows) * 1e3 / args.steps:.1f}); "
+                  f"the 16 busiest {sum(r[0] for r in rows[:16]) * 1e3 / args.steps:.1f}", file=sys.stderr)
         host_cpu_ms = ((cpu1.ru_utime - cpu0.ru_utime) + (cpu1.ru_stime - cpu0.ru_stime)) * 1e3 / args.steps
         stats = eng.stats()
         t0 = time.perf_counter()
@@ -546,6 +555,7 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
     up_ms = 1e3 * sum(upload_s) / max(1, len(upload_s))
     ordered = sorted(step_ms)
     spread = dict(median=ordered[len(ordered) // 2], min=ordered[0], max=ordered[-1], p10=ordered[len(ordered) // 10], p90=ordered[(9 * len(ordered)) // 10],
+                  in_order=[round(x, 2) for x in step_ms] if len(step_ms) <= 64 else None,
                   note="wall time of the single steps of the timed region on this rank (ms_per_step is their mean between the barriers)")
     return dict(stats=stats, ms_per_step_with_h2d=overlapped / args.steps * 1e3, ms_per_step_with_h2d_serial=serial / args.steps * 1e3,
                 ms_per_step_spread=spread, host_cpu_ms_per_step=host_cpu_ms,

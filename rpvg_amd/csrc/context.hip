@@ -59,6 +59,10 @@ hipError_t poolAlloc(void ** ptr, size_t bytes) {
             return hipSuccess;
         }
     }
+    {
+        static const bool trace = std::getenv("RPVG_AMD_TRACE") != nullptr;
+        if (trace) std::fprintf(stderr, "[rpvg_hip trace] pool miss: device block of %zu bytes\n", cls);
+    }
     e = hipMalloc(ptr, cls);
     if (e == hipErrorOutOfMemory) {
         // give cached blocks back to the driver and retry once
@@ -117,6 +121,10 @@ hipError_t pinnedAlloc(void ** ptr, size_t bytes) {
             g_pinned_live[*ptr] = cls;
             return hipSuccess;
         }
+    }
+    {
+        static const bool trace = std::getenv("RPVG_AMD_TRACE") != nullptr;
+        if (trace) std::fprintf(stderr, "[rpvg_hip trace] pool miss: pinned block of %zu bytes\n", cls);
     }
     const hipError_t e = hipHostMalloc(ptr, cls, hipHostMallocDefault);
     if (e != hipSuccess) {
