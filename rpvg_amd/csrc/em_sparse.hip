@@ -582,6 +582,7 @@ struct EmLaunchArgs {
     const uint32_t * pent_col;
     const double * pent_val;
     uint32_t max_em_its;
+    uint32_t register_copies;      // emRegisterKernel<1,16>: small problems in copies (RPVG_HIP_EM_COPIES=0: never)
     double max_rel_em_conv;
     double * wide_vectors;         // problems too wide for LDS: abundance + accumulator vectors, 2 C doubles each,
     const unsigned long long * wide_off;  // [P] at this offset (emSparseKernel<..., WIDE>)
@@ -816,17 +817,24 @@ __device__ __forceinline__ double halveF64(const double x, const double y, const
 // Afterwards lane l holds, in the return value, the sum of column l / (64 / COLS) over all 64 lanes; the order of the
 // additions is fixed.  (Round 2 and the first version of round 3 transposed the partials through LDS: 16 writes and 16
 // reads per lane, 625 of an iteration's 1 180 cycles in LDS issue and waits — PMC, tools/r03_em_pmc.sh.)
-template <int COLS>
+// SKIP: the first SKIP halving steps have nothing to add (problems of at most 32 / 16 rows whose lanes 32 .. 63 / 16 .. 63 carry
+// copies of the rows, every copy the partial sums of its share of the columns in v[0 .. COLS >> SKIP): exactly where those steps
+// would have put them, the other addends being zeros).
+template <int COLS, int SKIP = 0>
 __device__ __forceinline__ double columnSumsOverWave(double (&v)[COLS], const uint32_t lane) {
+    if (SKIP < 1) {
 #pragma unroll
-    for (int c = 0; c < COLS / 2; ++c) {
-        swapHalvesF64(v[c], v[c + COLS / 2]);
-        v[c] += v[c + COLS / 2];
+        for (int c = 0; c < COLS / 2; ++c) {
+            swapHalvesF64(v[c], v[c + COLS / 2]);
+            v[c] += v[c + COLS / 2];
+        }
     }
+    if (SKIP < 2) {
 #pragma unroll
-    for (int c = 0; c < COLS / 4; ++c) {
-        swapRowsF64(v[c], v[c + COLS / 4]);
-        v[c] += v[c + COLS / 4];
+        for (int c = 0; c < COLS / 4; ++c) {
+            swapRowsF64(v[c], v[c + COLS / 4]);
+            v[c] += v[c + COLS / 4];
+        }
     }
     const bool bit3 = (lane & 8) != 0, bit2 = (lane & 4) != 0;
 #pragma unroll
@@ -844,9 +852,17 @@ __device__ __forceinline__ double columnSumsOverWave(double (&v)[COLS], const ui
     return t;
 }
 
-template <int RPL, int COLS>
+// COPIES (one row per lane, 16 columns): a problem of at most 64 / COPIES rows is held COPIES times — lane l carries row
+// l % (64 / COPIES) — and every copy takes 16 / COPIES of the columns in the M-step: 16 / COPIES multiplications instead of 16, and
+// the first log2(COPIES) steps of the column sums (eight and four swaps and additions) fall away.  The E-step, and with it every
+// value, is what it is with one copy (the steps left out add zeros).  The batch's EM time is the latency of one iteration times
+// the iterations of its slowest problems, and those are small (2 268 iterations on 17 rows in the configs[2] batch).
+template <int RPL, int COLS, int COPIES = 1>
 __device__ __forceinline__ void emRegisterProblem(const EmLaunchArgs & args, const uint32_t p, double * reg_lds) {
+    static_assert(COPIES == 1 || (RPL == 1 && COLS == 16), "copies: one row per lane, 16 columns");
     constexpr uint32_t kCols = COLS;
+    constexpr int kSkip = COPIES == 4 ? 2 : (COPIES == 2 ? 1 : 0);
+    constexpr int kShare = COLS / COPIES;  // columns of a copy in the M-step
     constexpr int kLanesPerColumn = 64 / COLS;  // 4 (16 columns) or 2 (32 columns)
     const uint32_t np = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]);  // < kCols; column np = noise
     const uint32_t lane = threadIdx.x;
@@ -869,14 +885,20 @@ __device__ __forceinline__ void emRegisterProblem(const EmLaunchArgs & args, con
     }
     __syncthreads();
     double P[RPL][kCols], c[RPL];
+    double mine[kShare];  // (COPIES > 1) the row's values in the columns of this copy
     bool valid[RPL];
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
-        const uint32_t r = q * 64 + lane;
+        const uint32_t r = COPIES > 1 ? lane % (64 / COPIES) : q * 64 + lane;
         c[q] = r < n_rows ? cnt[r] : 0.0;
         valid[q] = c[q] != 0.0;  // (also: a row whose count a row collapse moved to its run head, row_collapse.hip)
 #pragma unroll
         for (int j = 0; j < static_cast<int>(kCols); ++j) P[q][j] = tile[r * kCols + j];
+        if (COPIES > 1) {
+            const uint32_t first_column = (lane / (64 / COPIES)) * kShare;
+#pragma unroll
+            for (int j = 0; j < kShare; ++j) mine[j] = tile[r * kCols + first_column + j];
+        }
     }
     const double T = args.total_mass[p];
     const double eps = args.max_rel_em_conv;
@@ -919,13 +941,18 @@ __device__ __forceinline__ void emRegisterProblem(const EmLaunchArgs & args, con
             w[q] = valid[q] ? fma(fma(-s, quot, c[q]), y, quot) : 0.0;
         }
         double pj[kCols];
+        if (COPIES > 1) {
 #pragma unroll
-        for (int j = 0; j < static_cast<int>(kCols); ++j) {
-            pj[j] = w[0] * P[0][j];
+            for (int j = 0; j < kShare; ++j) pj[j] = w[0] * mine[j];
+        } else {
 #pragma unroll
-            for (int q = 1; q < RPL; ++q) pj[j] = fma(w[q], P[q][j], pj[j]);
+            for (int j = 0; j < static_cast<int>(kCols); ++j) {
+                pj[j] = w[0] * P[0][j];
+#pragma unroll
+                for (int q = 1; q < RPL; ++q) pj[j] = fma(w[q], P[q][j], pj[j]);
+            }
         }
-        const double tj = columnSumsOverWave<COLS>(pj, lane);
+        const double tj = columnSumsOverWave<COLS, kSkip>(pj, lane);
 
         // a'_j = a_j t_j / T;  a'_noise = (a_noise t_noise + Z) / T  (z_mine is zero off the noise column)
         const double an = fma(a_mine, tj, z_mine) * inv_T;
@@ -964,8 +991,16 @@ template <int RPL, int COLS>
 __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) {
     extern __shared__ __attribute__((aligned(16))) double reg_lds[];
     if (blockIdx.x >= args.queues->bin_count[args.bin]) return;  // more workgroups than the bin has problems
+    // (RPVG_HIP_EM_COPIES=0 in the launch arguments: every problem with one copy, A/B and tests)
     for (uint32_t p = nextProblem<64>(args, nullptr); p != UINT32_MAX; p = nextProblem<64>(args, nullptr)) {
-        emRegisterProblem<RPL, COLS>(args, p, reg_lds);
+        if (RPL == 1 && COLS == 16 && args.register_copies) {
+            const uint32_t n_rows = args.kept_rows[p];
+            if (n_rows <= 16) emRegisterProblem<1, 16, 4>(args, p, reg_lds);
+            else if (n_rows <= 32) emRegisterProblem<1, 16, 2>(args, p, reg_lds);
+            else emRegisterProblem<1, 16, 1>(args, p, reg_lds);
+        } else {
+            emRegisterProblem<RPL, COLS>(args, p, reg_lds);
+        }
         __syncthreads();  // the staging tile is reused
     }
 }
@@ -1394,6 +1429,10 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     args.pent_val = work.d_pent_val.ptr;
     args.max_em_its = max_em_its;
     args.max_rel_em_conv = max_rel_em_conv;
+    {
+        const char * env = std::getenv("RPVG_HIP_EM_COPIES");  // (read per call: the tests take both ways)
+        args.register_copies = env ? (std::atoi(env) != 0 ? 1u : 0u) : 1u;
+    }
     args.wide_vectors = work.d_wide_vectors.ptr;
     args.wide_off = work.d_wide_off.ptr;
     args.wide_capacity = list.wide_capacity;

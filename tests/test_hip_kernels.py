@@ -69,6 +69,36 @@ def test_em_solve_matches_oracle_all_columns(hip_ctx, seed):
         assert abs(noise[i] - e.noise_count) <= REL * max(1.0, e.total_count)
 
 
+def test_register_em_in_copies_equals_one_copy_to_the_bit(hip_ctx):
+    """emRegisterKernel<1,16> holds a problem of at most 16 / 32 rows four / two times and gives every copy a share of the
+    columns in the M-step (the halving steps it leaves out would add zeros): abundances, noise and iteration counts equal
+    RPVG_HIP_EM_COPIES=0 (every problem with one copy) to the bit; both equal the oracle."""
+    rng = np.random.default_rng(451)
+    clusters = []
+    for reads in (1, 3, 9, 16, 17, 25, 32, 33, 50, 64):   # merged rows are at most the reads
+        for paths in (1, 2, 7, 15):
+            clusters.append(small_cases.make_cluster(rng, 1, [paths], n_haps=max(2, paths), n_reads=reads, empty_read_frac=0.1))
+    batch = ClusterBatch.from_clusters(clusters)
+    est, _ = pyoracle.run("transcripts", make_params(), batch, 2)
+    dev = hip_ctx.upload(batch)
+    ks = _nonempty(clusters)
+    cols = [list(range(len(clusters[k]["paths"]))) for k in ks]
+    results = []
+    for copies in ("1", "0"):
+        os.environ["RPVG_HIP_EM_COPIES"] = copies
+        try:
+            results.append(hip_ctx.em_solve(dev, ks, cols))
+        finally:
+            os.environ.pop("RPVG_HIP_EM_COPIES", None)
+    (a1, n1, t1, i1), (a0, n0, t0, i0) = results
+    assert np.array_equal(i1, i0) and np.array_equal(n1, n0) and np.array_equal(t1, t0)
+    for x, y in zip(a1, a0):
+        assert np.array_equal(x, y)
+    for i, k in enumerate(ks):
+        assert [int(i1[i])] == est[k].em_iters
+        assert small_cases.rel_close(a1[i], est[k].abundances, rel=REL)
+
+
 def test_em_solve_cluster_wider_than_lds(hip_ctx):
     """A cluster with more paths than LDS-resident abundance vectors hold (~9 700 columns): the reference's EM has no
     size limit (src/path_abundance_estimator.cpp:47-114); its vectors then live in global memory.  Next to small
