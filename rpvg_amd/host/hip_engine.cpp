@@ -275,8 +275,15 @@ DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, con
     num_paths.resize(host_batch.num_clusters);
     total_read_count.resize(host_batch.num_clusters);
 
-    // (millions of rows: by the team)
-    #pragma omp parallel for schedule(static) num_threads(hostThreads())
+    // (millions of rows: by a team — a small one: this runs on the uploading thread, next to the lanes' teams and on the same CPU
+    // quota; RPVG_AMD_UPLOAD_THREADS)
+    static const int upload_threads = []() {
+
+        const char * env = std::getenv("RPVG_AMD_UPLOAD_THREADS");
+        return env ? std::max(1, std::atoi(env)) : 8;
+    }();
+
+    #pragma omp parallel for schedule(static) num_threads(std::min(upload_threads, hostThreads()))
     for (uint32_t i = 0; i < host_batch.num_clusters; ++i) {
 
         num_rows[i] = host_batch.cluster_row_off[i + 1] - host_batch.cluster_row_off[i];
