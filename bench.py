@@ -472,8 +472,10 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
     """Steady state with the H2D of every batch's rows inside the clock, overlapped (double buffered) and serial."""
     import threading
     from rpvg_amd import hip
+    # (the rows, and the path side the device reads: PathInfo::group_id and PathInfo::source_ids — the haplotype columns of every
+    # cluster are formed on the device behind the copy, every batch)
     arrays = [batch.cluster_row_off, batch.cluster_path_off, batch.row_count, batch.row_noise, batch.row_grp_off, batch.grp_prob,
-              batch.grp_idx_off, batch.path_idx]
+              batch.grp_idx_off, batch.path_idx, batch.path_group_id, batch.path_source_off, batch.source_id]
     for a in arrays:
         hip.host_register(a)
     uploader = eng_mod.Engine(local_rank, uploader=True)

@@ -79,6 +79,22 @@ int rpvg_hip_host_unregister(void * host);
  * expanded to (path, probability) entries on the GPU. */
 int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * host_batch, rpvg_hip_batch ** batch_out);
 void rpvg_hip_batch_free(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch);
+/* Read count of every cluster of an uploaded batch (the sum of its rows' read counts, exact), added up on the device behind
+ * the copy (src/path_abundance_estimator.cpp:44,291,690: `read_counts.sum()`). */
+int rpvg_hip_batch_cluster_totals(const rpvg_hip_batch * batch, double * totals_out, uint32_t num_clusters);
+/* The path side of a batch.  When host_batch carries path_group_id, path_source_off and source_id, rpvg_hip_batch_upload
+ * also copies those and runs NestedPathAbundanceEstimator::findPathSourceGroups (src/path_abundance_estimator.cpp:493-546)
+ * for every cluster on the device: haplotypes (source ids) that carry the identical list of paths form one column, its
+ * multiplicity is their number, columns in ascending order of their smallest haplotype id.  1 when the batch holds such
+ * columns (0: no ids were given, or their ranges are too wide for the device scratch — ids are expected to be small
+ * consecutive integers — and the caller groups on the host). */
+int rpvg_hip_batch_has_source_columns(const rpvg_hip_batch * batch);
+/* Inspection (tests): the columns of one cluster — sizes first, then multiplicities [columns], the end of every column's list
+ * within column_paths [columns], and the lists back to back (ascending cluster-local paths) [column paths]. */
+int rpvg_hip_batch_source_columns_sizes(const rpvg_hip_batch * batch, uint32_t cluster, uint32_t * num_columns_out,
+                                        uint32_t * num_column_paths_out);
+int rpvg_hip_batch_source_columns_get(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t cluster,
+                                      uint32_t * column_counts_out, uint32_t * column_path_end_out, uint32_t * column_paths_out);
 
 /* ---- EM abundance solves ------------------------------------------------ */
 /* One EM problem = one cluster restricted to a strictly ascending list of its
@@ -189,6 +205,17 @@ typedef struct rpvg_hip_group_spec {
  * (RPVG_HIP_ERR_INVALID from rpvg_hip_group_loglik / _conditionals / rpvg_hip_bounded_pair_posteriors). */
 int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec,
                           rpvg_hip_groups ** groups_out);
+/* The matrices of NestedPathAbundanceEstimator::inferAbundancesCollapsedGroups (src/path_abundance_estimator.cpp:428-446) for
+ * the listed clusters, their columns being the batch's own haplotype columns: findPathSourceGroups
+ * (src/path_abundance_estimator.cpp:493-546) ran on the device when the batch was uploaded with PathInfo::source_ids
+ * (rpvg_hip_batch_upload; rpvg_amd/csrc/path_sources.hip), so no column list crosses the ABI.  Column c of a matrix is the
+ * c-th distinct path list among its cluster's haplotypes in ascending order of the smallest haplotype id that carries it; the
+ * columns' multiplicities (path_counts) stay on the device with the matrices: rpvg_hip_bounded_pair_posteriors and
+ * rpvg_hip_nested_subset_em take column_counts = NULL for them.  Returns RPVG_HIP_ERR_UNSUPPORTED, having changed nothing,
+ * for a batch without device-resident columns (the caller groups on the host and calls rpvg_hip_groups_build). */
+int rpvg_hip_groups_build_from_sources(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t num_matrices,
+                                       const uint32_t * clusters, int32_t normalise, double collapse_precision,
+                                       rpvg_hip_groups ** groups_out);
 void rpvg_hip_groups_free(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups);
 /* What the row collapse of these matrices did (waits for their build; any output may be NULL): matrices that held
  * rows within collapse_precision of each other but not equal up to rounding, whose runs were therefore replayed as
@@ -327,6 +354,20 @@ typedef struct rpvg_hip_subset_em_view {
     const double * noise_count;    /* [S]                                                                            */
     const double * total_count;    /* [S]                                                                            */
     const uint32_t * iterations;   /* [S]   EM iterations executed                                                   */
+    /* The posterior-weighted merge of the solutions (src/path_abundance_estimator.cpp:702-749), done on the device when the
+     * batch was uploaded with PathInfo::group_id (rpvg_cluster_batch::path_group_id); all NULL otherwise.  The path group
+     * sets of matrix m — one per (transcript, paths of that transcript in a retained subset), in lexicographic order of their
+     * path lists — sit in the slots [path_off[subset_off[m]], + set_count[m]) of the set_* arrays: one path (set_second =
+     * UINT32_MAX) or two, the sum of the weights of the subsets that hold the set, and per path the sum over those subsets of
+     * weight x abundance / multiplicity, added in subset order with the host's roundings (bit-equal to the host merge).
+     * cluster_noise_count[m] = sum of weight x noise_count over the subsets + (1 - sum of weights) x total_count (:712,749);
+     * a matrix without retained subsets has set_count 0 and leaves its noise count (= its total count) to the caller. */
+    const uint32_t * set_count;           /* [M] */
+    const double * cluster_noise_count;   /* [M] */
+    const uint32_t * set_first;
+    const uint32_t * set_second;
+    const double * set_posterior;
+    const double * set_abundance;         /* two per set slot */
 } rpvg_hip_subset_em_view;
 int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_groups * groups,
                               const uint32_t * column_counts, double min_rel_likelihood, double min_hap_prob,

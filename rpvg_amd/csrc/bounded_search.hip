@@ -63,7 +63,7 @@ static void searchGateEnter(const rpvg_hip_ctx * ctx, hipStream_t stream) {
         }
     }
     // (outside the lock: the other lane records its own event under it)
-    if (previous && !searchLaunchesEarly()) (void) hipEventSynchronize(previous);
+    if (previous && !searchLaunchesEarly()) (void) waitEvent(previous);
 }
 
 static void searchGateLeave(const rpvg_hip_ctx * ctx, hipStream_t stream) {
@@ -1422,7 +1422,13 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
         col_off[m + 1] = col_off[m] + G;
         pair_cap_off[m + 1] = pair_cap_off[m] + G * (G + 1) / 2;
     }
-    for (uint64_t c = 0; c < col_off[M]; ++c) {
+    // (column_counts == NULL: the matrices were built from the batch's own haplotype columns, whose multiplicities — at least one
+    // haplotype each — are on the device already)
+    if (!column_counts && M > 0 && !groups->d_column_counts) {
+        setError("rpvg_hip_bounded_pair_posteriors: column_counts is NULL");
+        return RPVG_HIP_ERR_INVALID;
+    }
+    for (uint64_t c = 0; column_counts && c < col_off[M]; ++c) {
         if (column_counts[c] == 0) {
             setError("rpvg_hip_bounded_pair_posteriors: column %llu has a zero count", static_cast<unsigned long long>(c));
             return RPVG_HIP_ERR_INVALID;
@@ -1568,7 +1574,7 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
     pack.add(d_order, order.data(), M);
     pack.add(d_col_off, col_off.data(), M + 1);
     pack.add(d_pair_cap_off, pair_cap_off.data(), M + 1);
-    pack.add(d_col_count, column_counts, col_off[M]);
+    if (column_counts) pack.add(d_col_count, column_counts, col_off[M]);
     if (num_big > 0) {
         pack.add(d_item_matrix, item_matrix.data(), item_matrix.size());
         pack.add(d_item_col, item_col.data(), item_col.size());
@@ -1586,6 +1592,7 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
     if (w.extra_zero_bytes) pack.addZero(w.d_extra_zero, w.extra_zero_bytes);
     int span = ctx->spanBegin(FAM_H2D);
     ok(pack.commit(st));
+    if (!column_counts) d_col_count.borrow(const_cast<uint32_t *>(groups->d_column_counts), col_off[M]);
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(M * 20 + col_off[M] * 4);
     ok(d_lf.alloc(col_off[M]));
@@ -1658,7 +1665,7 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
     ok(groups->waitCollapse(st));
     if (groups->collapse_done && !searchLaunchesEarly()) {  // (see searchGateEnter: the thread waits, not the stream's queue)
         HostScope wait_scope("search: wait for the collapse of the matrices");
-        ok(hipEventSynchronize(groups->collapse_done));
+        ok(waitEvent(groups->collapse_done));
     }
     span = ctx->spanBegin(FAM_LOGLIK);
     searchGateEnter(ctx, st);
@@ -1825,7 +1832,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
         *result_out = res;
         return RPVG_HIP_OK;
     }
-    if (!column_counts) {
+    if (!column_counts && !groups->d_column_counts) {
         delete res;
         setError("rpvg_hip_bounded_pair_posteriors: column_counts is NULL");
         return RPVG_HIP_ERR_INVALID;

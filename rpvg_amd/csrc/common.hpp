@@ -54,6 +54,15 @@ void setError(const char * fmt, ...);
 // measured slower than 8: 13.8-14.5 against 12.6 ms per bench batch — more of the lanes' kernels side by side.)
 int hardwareQueues();
 
+// ---- waiting without burning a core ---------------------------------------------------------------
+// hipEventSynchronize / hipStreamSynchronize spin: a host lane that waits for its kernels is a core at 100 % (8.5 of the 9.3 ms
+// of a configs[2] batch per lane, the bulk of the process's CPU time once findPathSourceGroups and the merge had left the
+// host).  These poll instead — the event or stream is queried, the thread sleeps 30 us in between (timer slack of the
+// thread lowered to 1 us) after a first 20 us of plain polling for the waits that are nearly over — which costs a wait at
+// most one sleep of latency.  RPVG_HIP_SPIN_WAITS=1 restores the runtime's waits (A/B).
+hipError_t waitEvent(hipEvent_t event);
+hipError_t waitStream(hipStream_t stream);
+
 // ---- caching device allocator -------------------------------------------------
 // hipMalloc/hipFree cost tens of microseconds to milliseconds each (hipFree also
 // synchronises the device); a step of the hot path needs ~60 scratch arrays whose
@@ -545,6 +554,43 @@ __host__ __device__ inline uint64_t collapseSortKey(const uint32_t matrix, const
            (static_cast<uint64_t>(l * static_cast<double>(1ull << kCollapseLargestFractionBits)) & ((1ull << kCollapseLargestBits) - 1));
 }
 
+// ---- products and sums that stay two roundings --------------------------------------------------------
+// hipcc contracts a * b + c into a fused multiply-add by default (-ffp-contract=fast), and HIP's __dmul_rn / __dadd_rn are plain
+// operators that take part in it.  Where a kernel restates host arithmetic addition for addition (the posterior-weighted merge,
+// subset_em.hip: the host is compiled for baseline x86-64, which has no fused multiply-add), the operations go through these.
+__device__ __forceinline__ double mulRounded(const double a, const double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double addRounded(const double a, const double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+
+// ---- exclusive prefix sum over the threads of a workgroup ---------------------------------------------
+// (scratch: BLOCK / 64 words of LDS; two barriers)
+template <int BLOCK>
+__device__ __forceinline__ uint32_t blockExclusiveSum(const uint32_t v, uint32_t & total, uint32_t * scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    __syncthreads();
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        if (w < wave) before += scratch[w];
+        all += scratch[w];
+    }
+    total = all;
+    return before + incl - v;
+}
+
 // ---- kernel-family timing ---------------------------------------------------
 enum KernelFamily { FAM_EM_SPARSE = 0, FAM_EM_DENSE, FAM_LOGLIK, FAM_BUILD, FAM_H2D, FAM_COLLAPSE, FAM_EM_KERNEL, FAM_COUNT };
 
@@ -621,6 +667,21 @@ struct rpvg_hip_batch {
     rpvg_hip_detail::DeviceBuffer<uint64_t> row_ent_off;       // [R+1] entry range of each row
     rpvg_hip_detail::DeviceBuffer<uint32_t> ent_path;          // [NNZ] cluster-local path
     rpvg_hip_detail::DeviceBuffer<double> ent_prob;            // [NNZ]
+    // read count of every cluster (exact: integers), summed on the device behind the copy of the rows
+    std::vector<double> h_cluster_total;
+    // ---- the path side of the batch (path_sources.hip), present when the host batch carried PathInfo::group_id and
+    // PathInfo::source_ids: the haplotype columns of every cluster — findPathSourceGroups, src/path_abundance_estimator.cpp:493-546,
+    // done once per batch on the device behind the copy — in a layout by bounds (a cluster has at most as many columns, and its
+    // columns list at most as many paths, as it has (haplotype, path) incidences): cluster k owns the slots
+    // [h_cluster_src_off[k], h_cluster_src_off[k + 1]) of the three arrays below; the first h_src_num_cols[k] of them are used.
+    bool has_source_columns = false;
+    rpvg_hip_detail::DeviceBuffer<uint32_t> path_group_id;     // [P]  PathInfo::group_id (the transcript of a path)
+    rpvg_hip_detail::DeviceBuffer<uint64_t> cluster_src_off;   // [K+1]
+    rpvg_hip_detail::DeviceBuffer<uint32_t> src_col_count;     // haplotypes that carry the column's path list (path_counts)
+    rpvg_hip_detail::DeviceBuffer<uint32_t> src_col_end;       // end of the column's list in src_col_path, relative to the cluster's first slot
+    rpvg_hip_detail::DeviceBuffer<uint32_t> src_col_path;      // the lists, ascending cluster-local paths, columns back to back
+    std::vector<uint64_t> h_cluster_src_off;                   // [K+1]
+    std::vector<uint32_t> h_src_num_cols, h_src_col_paths, h_src_max_col_paths;  // [K] columns, sum and maximum of their list lengths
 };
 
 // Device-resident group matrices (loglik.hip builds them).
@@ -657,6 +718,9 @@ struct rpvg_hip_groups {
     const uint64_t * d_group_path_off = nullptr;  // [G+1]
     const uint32_t * d_group_path = nullptr;
     const uint32_t * d_cluster = nullptr;         // [M] cluster of the batch
+    // matrices built from the batch's own haplotype columns (rpvg_hip_groups_build_from_sources): the multiplicity of every
+    // column (path_counts of calculatePathGroupPosteriorsBounded), laid out like the columns; null for a caller's spec
+    const uint32_t * d_column_counts = nullptr;
     std::vector<uint32_t> h_cluster, h_max_col_paths, h_num_paths;  // per matrix: cluster, longest column list, paths of the cluster
     rpvg_hip_detail::DeviceBuffer<uint32_t> build_error_flag;
     // row collapse (row_collapse.hip): sort keys and row ids written by the build kernels; [0] matrices replayed,
@@ -861,6 +925,26 @@ struct CsrCollapseWork {
 // sorted: recorded behind the sort of the problems' rows (the first stages of the collapse: most of its time), if not null
 hipError_t queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollapseInput & in, double precision, CsrCollapseWork & work, hipStream_t stream,
                             hipEvent_t sorted = nullptr);
+
+// ---- the path side of a batch (path_sources.hip) -----------------------------------------------------
+// Queues, on the context's stream, the copies of PathInfo::group_id / source_ids of `hb` and the kernels that form the
+// haplotype columns of every cluster, plus the copy of their sizes back to the host; finishPathSources() reads those
+// once the stream has been waited for.  The caller holds ctx->mutex and has set the device.
+struct PathSourcesPending {
+    DeviceBuffer<uint64_t> d_path_source_off;
+    DeviceBuffer<uint32_t> d_source_id, d_sizes;
+    DeviceBuffer<unsigned long long> d_arena;
+    void * h_sizes = nullptr;  // pinned: [num_cols K | col_paths K | max_col_paths K | error, arena overflow]
+    uint32_t K = 0;
+    bool queued = false;
+    ~PathSourcesPending() { if (h_sizes) pinnedFree(h_sizes); }
+};
+// read count of every cluster (exact integer sums) from the 32-bit counts as uploaded
+hipError_t queueClusterTotals(hipStream_t stream, uint32_t num_clusters, const uint64_t * d_cluster_row_off, const uint32_t * d_row_count_u32, double * d_totals);
+hipError_t queuePathSources(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_cluster_batch * hb, PathSourcesPending & pending);
+// RPVG_HIP_OK; RPVG_HIP_ERR_INVALID for inconsistent offsets.  A batch whose id ranges outgrow the scratch set aside for them
+// simply has no source columns (has_source_columns stays false: the caller groups on the host).
+int finishPathSources(rpvg_hip_batch * b, PathSourcesPending & pending);
 
 // queues the replay of readCollapseProbabilityMatrix on the matrices of `groups` behind their build (row_collapse.hip)
 hipError_t queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups, uint64_t total_rows, double precision, hipStream_t stream);

@@ -3,6 +3,9 @@
 
 #include "common.hpp"
 
+#include <sys/prctl.h>
+#include <time.h>
+
 #include <algorithm>
 #include <thread>
 
@@ -248,6 +251,43 @@ int hardwareQueues() { return g_hardware_queues; }
 
 using namespace rpvg_hip_detail;
 
+namespace rpvg_hip_detail {
+
+namespace {
+
+template <typename Query>
+hipError_t pollUntilDone(Query query) {
+    static const bool spin = std::getenv("RPVG_HIP_SPIN_WAITS") != nullptr;
+    if (spin) return hipErrorNotSupported;  // (the caller falls back to the runtime's wait)
+    thread_local bool slack_set = false;
+    if (!slack_set) {
+        (void) prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+        slack_set = true;
+    }
+    const auto begin = std::chrono::steady_clock::now();
+    while (true) {
+        const hipError_t e = query();
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - begin < std::chrono::microseconds(20)) continue;
+        timespec nap{0, 30000};
+        (void) nanosleep(&nap, nullptr);
+    }
+}
+
+}  // namespace
+
+hipError_t waitEvent(hipEvent_t event) {
+    const hipError_t e = pollUntilDone([event]() { return hipEventQuery(event); });
+    return e == hipErrorNotSupported ? hipEventSynchronize(event) : e;
+}
+
+hipError_t waitStream(hipStream_t stream) {
+    const hipError_t e = pollUntilDone([stream]() { return hipStreamQuery(stream); });
+    return e == hipErrorNotSupported ? hipStreamSynchronize(stream) : e;
+}
+
+}  // namespace rpvg_hip_detail
+
 hipError_t rpvg_hip_ctx::forkAux() {
     hipError_t e = hipEventRecord(fork_event, stream);
     for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamWaitEvent(aux[i], fork_event, 0);
@@ -269,7 +309,7 @@ hipError_t rpvg_hip_ctx::joinAux() {
 hipError_t rpvg_hip_ctx::joinAuxOnHost() {
     hipError_t e = hipSuccess;
     for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipEventRecord(join_event[i], aux[i]);
-    for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipEventSynchronize(join_event[i]);
+    for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = rpvg_hip_detail::waitEvent(join_event[i]);
     for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamWaitEvent(stream, join_event[i], 0);  // (the ordering, for the record: they have arrived)
     return e;
 }
@@ -777,11 +817,20 @@ int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpv
             R, G, NNZ, K, b->cluster_row_off.ptr, b->cluster_path_off.ptr, d_row_grp_off.ptr, d_grp_idx_off.ptr, b->row_noise.ptr,
             b->ent_path.ptr, d_first_bad_row.ptr);
     }
+    // read counts per cluster (the host summed three million of them per batch with a team of its own)
+    DeviceBuffer<double> d_cluster_total;
+    b->h_cluster_total.assign(K, 0.0);
+    if (e == hipSuccess) e = d_cluster_total.alloc(K);
+    if (e == hipSuccess) e = queueClusterTotals(ctx->stream, K, b->cluster_row_off.ptr, d_row_count_u32.ptr, d_cluster_total.ptr);
     ctx->spanEnd(bspan);
-    ctx->stats.build_launches += 3;
+    ctx->stats.build_launches += 4;
     if (e == hipSuccess) e = hipGetLastError();
+    // the path side, when the caller handed it in: PathInfo::group_id and the haplotype columns of every cluster (path_sources.hip)
+    PathSourcesPending path_sources;
+    if (e == hipSuccess) e = queuePathSources(ctx, b, hb, path_sources);
     if (e == hipSuccess) e = hipMemcpyAsync(&first_bad_row, d_first_bad_row.ptr, sizeof(first_bad_row), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // temporaries are freed on return
+    if (e == hipSuccess && K > 0) e = hipMemcpyAsync(b->h_cluster_total.data(), d_cluster_total.ptr, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = waitStream(ctx->stream);  // temporaries are freed on return
     if (e != hipSuccess) {
         setError("rpvg_hip_batch_upload: %s", hipGetErrorString(e));
         (void) hipStreamSynchronize(ctx->stream);
@@ -800,6 +849,11 @@ int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpv
         }
         setError("%s", message);
         return RPVG_HIP_ERR_INVALID;
+    }
+    const int sources_rc = finishPathSources(b, path_sources);
+    if (sources_rc != RPVG_HIP_OK) {
+        delete b;
+        return sources_rc;
     }
     *batch_out = b;
     return RPVG_HIP_OK;

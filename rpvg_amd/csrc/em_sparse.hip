@@ -1457,7 +1457,7 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         static const bool wait_whole = std::getenv("RPVG_HIP_EM_WAIT_SORT_ONLY") == nullptr;  // A/B: only the collapse's sort (11.3 against 10.2 ms per batch)
         if (!launch_early && work.collapse_sorted) {
             HostScope wait_scope("em_solve: wait for the collapse");
-            RPVG_HIP_CHECK(hipEventSynchronize(wait_whole ? work.collapsed : work.collapse_sorted));
+            RPVG_HIP_CHECK(waitEvent(wait_whole ? work.collapsed : work.collapse_sorted));
         }
     }
 
@@ -1571,7 +1571,7 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     }
     ctx->spanEnd(span);
     if (grid_possible) {
-        RPVG_HIP_CHECK(hipEventSynchronize(described));
+        RPVG_HIP_CHECK(waitEvent(described));
         const uint32_t n_grid = std::min<uint32_t>(*h_grid_count, P);
         if (n_grid > 0) {
             std::vector<EmGridProblem> grid_problems(n_grid);

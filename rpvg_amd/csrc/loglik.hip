@@ -664,13 +664,74 @@ extern "C" int rpvg_hip_debug_log(rpvg_hip_ctx * ctx, uint64_t n, const double *
     return RPVG_HIP_OK;
 }
 
+// The haplotype columns of the batch (path_sources.hip: laid out by bounds, per cluster) for the clusters of a build, as the
+// compact lists the build kernels take.  One workgroup per matrix.
+__global__ __launch_bounds__(256) void gatherSourceColumnsKernel(const uint32_t num_matrices, const uint32_t * __restrict__ cluster,
+                                                                 const uint64_t * __restrict__ cluster_src_off, const uint32_t * __restrict__ src_col_count,
+                                                                 const uint32_t * __restrict__ src_col_end, const uint32_t * __restrict__ src_col_path,
+                                                                 const uint64_t * __restrict__ group_off, const uint64_t * __restrict__ first_path,
+                                                                 uint64_t * __restrict__ group_path_off, uint32_t * __restrict__ group_path,
+                                                                 uint32_t * __restrict__ column_counts) {
+    const uint32_t m = blockIdx.x;
+    if (m >= num_matrices) return;
+    const uint64_t slot0 = cluster_src_off[cluster[m]];
+    const uint64_t g0 = group_off[m], p0 = first_path[m];
+    const uint32_t G = static_cast<uint32_t>(group_off[m + 1] - g0), L = static_cast<uint32_t>(first_path[m + 1] - p0);
+    if (threadIdx.x == 0 && m == 0) group_path_off[0] = 0;
+    for (uint32_t c = threadIdx.x; c < G; c += 256) {
+        group_path_off[g0 + c + 1] = p0 + src_col_end[slot0 + c];
+        column_counts[g0 + c] = src_col_count[slot0 + c];
+    }
+    for (uint32_t x = threadIdx.x; x < L; x += 256) group_path[p0 + x] = src_col_path[slot0 + x];
+}
+
+static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec, bool from_sources,
+                       rpvg_hip_groups ** groups_out);
+
 extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec,
                                      rpvg_hip_groups ** groups_out) {
     RPVG_REQUIRE(ctx && batch && spec && groups_out, "rpvg_hip_groups_build: NULL argument");
     *groups_out = nullptr;
-    const uint32_t M = spec->num_matrices;
-    RPVG_REQUIRE(M == 0 || (spec->cluster && spec->group_off && spec->group_path_off && spec->group_path),
+    RPVG_REQUIRE(spec->num_matrices == 0 || (spec->cluster && spec->group_off && spec->group_path_off && spec->group_path),
                  "rpvg_hip_groups_build: NULL spec arrays");
+    return buildGroups(ctx, batch, spec, false, groups_out);
+}
+
+extern "C" int rpvg_hip_groups_build_from_sources(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t num_matrices, const uint32_t * clusters,
+                                                  int32_t normalise, double collapse_precision, rpvg_hip_groups ** groups_out) {
+    RPVG_REQUIRE(ctx && batch && groups_out && (clusters || num_matrices == 0), "rpvg_hip_groups_build_from_sources: NULL argument");
+    *groups_out = nullptr;
+    if (!batch->has_source_columns) {
+        setError("rpvg_hip_groups_build_from_sources: not taken (the batch was uploaded without PathInfo::source_ids, or their id ranges "
+                 "outgrew the device scratch)");
+        return RPVG_HIP_ERR_UNSUPPORTED;
+    }
+    for (uint32_t m = 0; m < num_matrices; ++m) {
+        RPVG_REQUIRE(clusters[m] < batch->num_clusters, "rpvg_hip_groups_build_from_sources: matrix %u refers to cluster %u of %u", m, clusters[m],
+                     batch->num_clusters);
+        RPVG_REQUIRE(batch->h_src_num_cols[clusters[m]] > 0, "rpvg_hip_groups_build_from_sources: cluster %u has no source (haplotype) ids on its paths",
+                     clusters[m]);
+    }
+    // the columns of matrix m are those of its cluster: the offsets are sums of sizes the upload brought back
+    std::vector<uint64_t> group_off(num_matrices + 1, 0), first_path(num_matrices + 1, 0);
+    for (uint32_t m = 0; m < num_matrices; ++m) {
+        group_off[m + 1] = group_off[m] + batch->h_src_num_cols[clusters[m]];
+        first_path[m + 1] = first_path[m] + batch->h_src_col_paths[clusters[m]];
+    }
+    rpvg_hip_group_spec spec;
+    spec.num_matrices = num_matrices;
+    spec.cluster = clusters;
+    spec.group_off = group_off.data();
+    spec.group_path_off = first_path.data();  // (from_sources: per MATRIX, the first list entry of its columns)
+    spec.group_path = nullptr;
+    spec.normalise = normalise;
+    spec.collapse_precision = collapse_precision;
+    return buildGroups(ctx, batch, &spec, true, groups_out);
+}
+
+static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec, const bool from_sources,
+                       rpvg_hip_groups ** groups_out) {
+    const uint32_t M = spec->num_matrices;
     RPVG_REQUIRE(spec->collapse_precision >= 0 && spec->collapse_precision < 1, "rpvg_hip_groups_build: collapse_precision outside [0, 1)");
     RPVG_REQUIRE(spec->collapse_precision == 0 || spec->normalise,
                  "rpvg_hip_groups_build: the row collapse applies to normalised matrices (src/path_abundance_estimator.cpp:379-380,442-443)");
@@ -722,7 +783,8 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         cols[m] = static_cast<uint32_t>(g1 - g0);
         {
             uint64_t longest = 0;
-            for (uint64_t c = g0; c < g1; ++c) longest = std::max<uint64_t>(longest, spec->group_path_off[c + 1] - spec->group_path_off[c]);
+            if (from_sources) longest = batch->h_src_max_col_paths[k];
+            else for (uint64_t c = g0; c < g1; ++c) longest = std::max<uint64_t>(longest, spec->group_path_off[c + 1] - spec->group_path_off[c]);
             g->h_max_col_paths.push_back(static_cast<uint32_t>(std::min<uint64_t>(longest, 0xffffffffu)));
             g->h_num_paths.push_back(static_cast<uint32_t>(N));
             g->h_cluster.push_back(k);
@@ -773,7 +835,7 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
         return RPVG_HIP_OK;
     }
     const uint64_t num_columns = spec->group_off[M];
-    const uint64_t num_incidences = spec->group_path_off[num_columns];
+    const uint64_t num_incidences = from_sources ? spec->group_path_off[M] : spec->group_path_off[num_columns];
 
     scope_host.reset();
     HostScope scope_dev("groups_build: upload + kernels + sync");
@@ -784,7 +846,8 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     struct BuildTemporaries {
         DeviceBuffer<uint64_t> inc_off, path_grp_off, group_off, group_path_off, num_paths;
         DeviceBuffer<uint32_t> path_grp, item_matrix, item_chunk, tile_matrix, tile_chunk, group_path, degree, cursor, cluster, mask_matrix, mask_chunk;
-        DeviceBuffer<uint64_t> mask_off, masks;
+        DeviceBuffer<uint64_t> mask_off, masks, first_path;
+        DeviceBuffer<uint32_t> column_counts;
         DeviceBuffer<unsigned char> scan_tmp;
     };
     std::shared_ptr<BuildTemporaries> tmp = std::make_shared<BuildTemporaries>();
@@ -808,8 +871,12 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     pack.add(d_inc_off, inc_off.data(), M);
     pack.add(d_num_paths, num_paths.data(), M);
     pack.add(d_group_off, spec->group_off, M + 1);
-    pack.add(d_group_path_off, spec->group_path_off, num_columns + 1);
-    pack.add(d_group_path, spec->group_path, num_incidences);
+    if (from_sources) {
+        pack.add(tmp->first_path, spec->group_path_off, M + 1);
+    } else {
+        pack.add(d_group_path_off, spec->group_path_off, num_columns + 1);
+        pack.add(d_group_path, spec->group_path, num_incidences);
+    }
     if (!item_matrix.empty()) {
         pack.add(d_item_matrix, item_matrix.data(), item_matrix.size());
         pack.add(d_item_chunk, item_chunk.data(), item_chunk.size());
@@ -839,6 +906,18 @@ extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * 
     }
     pack.addZero(d_error, 1);
     ok(pack.commit(st));
+    if (from_sources) {  // the lists stay on the device: gathered from the batch's columns
+        ok(d_group_path_off.alloc(num_columns + 1));
+        ok(d_group_path.alloc(num_incidences));
+        ok(tmp->column_counts.alloc(num_columns));
+        if (e == hipSuccess) {
+            gatherSourceColumnsKernel<<<dim3(M), dim3(256), 0, st>>>(M, d_cluster.ptr, batch->cluster_src_off.ptr, batch->src_col_count.ptr,
+                                                                   batch->src_col_end.ptr, batch->src_col_path.ptr, d_group_off.ptr, tmp->first_path.ptr,
+                                                                   d_group_path_off.ptr, d_group_path.ptr, tmp->column_counts.ptr);
+            ok(hipGetLastError());
+        }
+        g->d_column_counts = tmp->column_counts.ptr;
+    }
     g->d_group_off = d_group_off.ptr;
     g->d_group_path_off = d_group_path_off.ptr;
     g->d_group_path = d_group_path.ptr;

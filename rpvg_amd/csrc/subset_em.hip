@@ -90,6 +90,10 @@ struct SubsetHeader {  // device -> host, one small copy
 // every lane.)
 struct PackedLayout {
     size_t subset_off, weight, path_off, col_off, abundances, noise, total, path, col_path, iterations, kept_rows, kept_entries, bytes;
+    // the posterior-weighted merge (subsetMergeKernel): per matrix the number of path group sets and the noise count, per set (the
+    // sets of matrix m from slot path_off[subset_off[m]] on: a matrix has at most as many as its subsets list paths) its one or
+    // two paths, its posterior and the abundance of either path; flags[0]: a transcript with more than two paths in one subset
+    size_t set_count, cluster_noise, set_first, set_second, set_posterior, set_abund, merge_flags;
 };
 __host__ __device__ inline PackedLayout packedLayout(const uint64_t M, const uint64_t S, const uint64_t L, const uint64_t C) {
     PackedLayout p;
@@ -111,6 +115,13 @@ __host__ __device__ inline PackedLayout packedLayout(const uint64_t M, const uin
     p.iterations = place(S * 4);
     p.kept_rows = place(S * 4);
     p.kept_entries = place(S * 4);
+    p.set_count = place(M * 4);
+    p.cluster_noise = place(M * 8);
+    p.set_first = place(L * 4);
+    p.set_second = place(L * 4);
+    p.set_posterior = place(L * 8);
+    p.set_abund = place(L * 16);
+    p.merge_flags = place(64);
     p.bytes = at;
     return p;
 }
@@ -545,6 +556,7 @@ struct PackArgs {
     const uint32_t * iterations;
     const uint32_t * kept_rows;
     const uint32_t * kept_entries;
+    const uint32_t * merge_bad;  // null: no merge on the device
     unsigned char * packed;
 };
 
@@ -571,6 +583,185 @@ __global__ __launch_bounds__(256) void packResultsKernel(const PackArgs args) {
     copy(lay.iterations, args.iterations, S);
     copy(lay.kept_rows, args.kept_rows, S);
     copy(lay.kept_entries, args.kept_entries, S);
+    if (args.merge_bad && first == 0) *reinterpret_cast<uint32_t *>(args.packed + lay.merge_flags) = *args.merge_bad;
+}
+
+// ---- the posterior-weighted merge of the subsets' EM solutions (src/path_abundance_estimator.cpp:702-749) ----------------
+// Per cluster the reference walks its retained subsets in order and, for every transcript (PathInfo::group_id) that has paths in
+// the subset, adds the subset's weight to the posterior of that transcript's path set and weight x abundance / multiplicity to
+// the set's abundances; the sets come out in lexicographic order of their path lists (the ordered map of the host classes).
+// One workgroup per cluster does the same: every position of every subset's path list looks for the other path of its
+// transcript in the list (a diplotype's list holds at most two: its haplotypes' paths) and the first one emits a record
+//   key = [ path + 1 : 27 | other path + 1 or 0 : 27 | rank of the subset in the cluster : 10 ]
+// with the two weighted abundances; the records are sorted by key (bitonic network, in LDS up to 2 048 list entries per cluster,
+// in device memory beyond) — which puts the sets in the reference's order and the records of a set in subset order — and one
+// thread per set adds its records up one after the other: the additions of the host's merge, in its order, with
+// separately rounded multiplies and adds (mulRounded / addRounded, common.hpp: no fused multiply-add, the host has none), so the results are bit-equal.
+constexpr uint32_t kMergeLdsRecords = 2048;
+constexpr unsigned long long kMergeNoRecord = ~0ull;
+constexpr uint32_t kMergePathBits = 27, kMergeRankBits = 10;
+
+struct MergeArgs {
+    const SubsetHeader * header;
+    uint32_t num_matrices;
+    const uint64_t * subset_off;
+    const double * weight;
+    const uint64_t * path_off;
+    const uint32_t * path;
+    const uint64_t * col_off;
+    const uint32_t * col_path;
+    const double * abundances;
+    const double * noise;
+    const double * total;
+    const uint32_t * cluster;           // [M]
+    const uint64_t * cluster_path_off;  // of the batch
+    const uint32_t * path_group_id;     // of the batch
+    unsigned long long * sort_key;      // [2 x capacity of the lists] scratch of the clusters beyond LDS
+    uint32_t * sort_pos;
+    double * rec_a0;                    // [capacity of the lists]
+    double * rec_a1;
+    uint32_t * merge_bad;               // zero-initialised: set when a transcript has more than two paths in one subset
+    unsigned char * packed;
+};
+
+__global__ __launch_bounds__(256) void subsetMergeKernel(const MergeArgs args) {
+    constexpr int BLOCK = 256;
+    __shared__ unsigned long long s_key[kMergeLdsRecords];
+    __shared__ uint32_t s_pos[kMergeLdsRecords];
+    __shared__ uint32_t s_scan[BLOCK / 64];
+    const SubsetHeader h = *args.header;
+    if (h.overflow) return;
+    const uint32_t m = blockIdx.x, tid = threadIdx.x;
+    const uint64_t M = args.num_matrices;
+    if (m >= M) return;
+    const PackedLayout lay = packedLayout(M, h.subsets, h.list_length, h.columns);
+    uint32_t * set_count = reinterpret_cast<uint32_t *>(args.packed + lay.set_count);
+    double * cluster_noise = reinterpret_cast<double *>(args.packed + lay.cluster_noise);
+    uint32_t * set_first = reinterpret_cast<uint32_t *>(args.packed + lay.set_first);
+    uint32_t * set_second = reinterpret_cast<uint32_t *>(args.packed + lay.set_second);
+    double * set_posterior = reinterpret_cast<double *>(args.packed + lay.set_posterior);
+    double * set_abund = reinterpret_cast<double *>(args.packed + lay.set_abund);
+    const uint64_t s0 = args.subset_off[m];
+    const uint32_t n = static_cast<uint32_t>(args.subset_off[m + 1] - s0);
+    if (n == 0) {  // (no diplotype reached min_hap_prob: all reads are noise, src/path_abundance_estimator.cpp:749 — the host fills that in)
+        if (tid == 0) {
+            set_count[m] = 0;
+            cluster_noise[m] = 0.0;
+        }
+        return;
+    }
+    const uint64_t base = args.path_off[s0];
+    const uint32_t Lm = static_cast<uint32_t>(args.path_off[s0 + n] - base);
+    const uint32_t * gid = args.path_group_id + args.cluster_path_off[args.cluster[m]];
+    if (tid == BLOCK - 1) {  // the noise count: the subsets' noise counts by their weights, then the mass of the dropped diplotypes (:712,749)
+        double noise = 0.0, sum_hap_prob = 0.0;
+        for (uint32_t r = 0; r < n; ++r) {
+            const double w = args.weight[s0 + r];
+            sum_hap_prob = addRounded(sum_hap_prob, w);
+            noise = addRounded(noise, mulRounded(args.noise[s0 + r], w));
+        }
+        cluster_noise[m] = addRounded(noise, mulRounded(addRounded(1.0, -sum_hap_prob), args.total[s0]));
+    }
+    uint32_t P2 = 2;
+    while (P2 < Lm) P2 <<= 1;
+    unsigned long long * keys = s_key;
+    uint32_t * order = s_pos;
+    if (P2 > kMergeLdsRecords) {
+        keys = args.sort_key + 2 * base;
+        order = args.sort_pos + 2 * base;
+    }
+    for (uint32_t pos = tid; pos < P2; pos += BLOCK) {
+        unsigned long long key = kMergeNoRecord;
+        if (pos < Lm) {
+            uint32_t lo = 0, hi = n - 1;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (args.path_off[s0 + mid] - base <= pos) lo = mid; else hi = mid - 1;
+            }
+            const uint32_t r = lo;
+            const uint32_t l0 = static_cast<uint32_t>(args.path_off[s0 + r] - base), L = static_cast<uint32_t>(args.path_off[s0 + r + 1] - base) - l0;
+            const uint32_t * list = args.path + base + l0;
+            const uint32_t j = pos - l0;
+            const uint32_t g = gid[list[j]];
+            uint32_t members = 0, first = 0, second = 0;
+            for (uint32_t t = 0; t < L; ++t) {
+                if (gid[list[t]] == g) {
+                    if (members == 0) first = t;
+                    else if (members == 1) second = t;
+                    ++members;
+                }
+            }
+            if (members > 2) *args.merge_bad = 1;
+            if (first == j && members <= 2) {
+                const uint32_t p0 = list[first], p1 = (members == 2) ? list[second] : 0xffffffffu;
+                const double w = args.weight[s0 + r];
+                const uint64_t c0 = args.col_off[s0 + r];
+                const uint32_t C = static_cast<uint32_t>(args.col_off[s0 + r + 1] - c0);
+                const uint32_t * cols = args.col_path + c0;
+                auto column = [&](const uint32_t p) {
+                    uint32_t a = 0, b = C;
+                    while (a < b) {
+                        const uint32_t mid = (a + b) >> 1;
+                        if (cols[mid] < p) a = mid + 1; else b = mid;
+                    }
+                    return a;
+                };
+                const double multiplicity = (members == 2 && p0 == p1) ? 2.0 : 1.0;
+                args.rec_a0[base + pos] = mulRounded(args.abundances[c0 + column(p0)], w) / multiplicity;
+                args.rec_a1[base + pos] = (members == 2) ? mulRounded(args.abundances[c0 + column(p1)], w) / multiplicity : 0.0;
+                key = (static_cast<unsigned long long>(p0 + 1) << (kMergePathBits + kMergeRankBits)) |
+                      (static_cast<unsigned long long>(members == 2 ? p1 + 1 : 0u) << kMergeRankBits) | r;
+            }
+        }
+        keys[pos] = key;
+        order[pos] = pos;
+    }
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1) {
+        for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (uint32_t i = tid; i < P2; i += BLOCK) {
+                const uint32_t x = i ^ j2;
+                if (x > i) {
+                    const unsigned long long a = keys[i], b = keys[x];
+                    if ((a > b) == ((i & k2) == 0)) {
+                        keys[i] = b;
+                        keys[x] = a;
+                        const uint32_t oa = order[i];
+                        order[i] = order[x];
+                        order[x] = oa;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    uint32_t Q = 0;
+    for (uint32_t c0 = 0; c0 < Lm; c0 += BLOCK) {
+        const uint32_t i = c0 + tid;
+        const unsigned long long key = i < Lm ? keys[i] : kMergeNoRecord;
+        const bool start = key != kMergeNoRecord && (i == 0 || (keys[i - 1] >> kMergeRankBits) != (key >> kMergeRankBits));
+        uint32_t total;
+        const uint32_t before = blockExclusiveSum<BLOCK>(start ? 1u : 0u, total, s_scan);
+        if (start) {
+            const unsigned long long set = key >> kMergeRankBits;
+            double posterior = 0.0, a0 = 0.0, a1 = 0.0;
+            for (uint32_t e = i; e < Lm && keys[e] != kMergeNoRecord && (keys[e] >> kMergeRankBits) == set; ++e) {
+                const uint32_t r = static_cast<uint32_t>(keys[e] & ((1u << kMergeRankBits) - 1u)), pos = order[e];
+                posterior = addRounded(posterior, args.weight[s0 + r]);
+                a0 = addRounded(a0, args.rec_a0[base + pos]);
+                a1 = addRounded(a1, args.rec_a1[base + pos]);
+            }
+            const uint64_t q = base + Q + before;
+            const uint32_t second = static_cast<uint32_t>(set & ((1u << kMergePathBits) - 1u));
+            set_first[q] = static_cast<uint32_t>(set >> kMergePathBits) - 1;
+            set_second[q] = second ? second - 1 : 0xffffffffu;
+            set_posterior[q] = posterior;
+            set_abund[2 * q] = a0;
+            set_abund[2 * q + 1] = a1;
+        }
+        Q += total;
+    }
+    if (tid == 0) set_count[m] = Q;
 }
 
 }  // namespace
@@ -596,7 +787,7 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
     RPVG_REQUIRE(max_em_its > 0, "rpvg_hip_nested_subset_em: max_em_its must be positive");
     RPVG_REQUIRE(groups->batch == batch, "rpvg_hip_nested_subset_em: the matrices were built on another batch");
     const uint32_t M = groups->num_matrices;
-    RPVG_REQUIRE(M == 0 || column_counts, "rpvg_hip_nested_subset_em: column_counts is NULL");
+    RPVG_REQUIRE(M == 0 || column_counts || groups->d_column_counts, "rpvg_hip_nested_subset_em: column_counts is NULL");
     std::unique_ptr<rpvg_hip_subset_em> res(new (std::nothrow) rpvg_hip_subset_em());
     if (!res) {
         setError("rpvg_hip_nested_subset_em: out of host memory");
@@ -701,6 +892,17 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
     ok(d_kept_entries.alloc(cap_subsets));
     const size_t packed_capacity = packedLayout(M, cap_subsets, cap_length, cap_columns).bytes;
     ok(d_packed.alloc(packed_capacity));
+    // the posterior-weighted merge on the device: when the batch carries the transcripts of its paths (PathInfo::group_id)
+    const bool merge_here = batch->path_group_id.ptr != nullptr && max_paths < (1u << kMergePathBits) - 2;
+    DeviceBuffer<unsigned long long> d_merge_key;
+    DeviceBuffer<uint32_t> d_merge_pos;
+    DeviceBuffer<double> d_merge_a0, d_merge_a1;
+    if (merge_here) {
+        ok(d_merge_key.alloc(2 * cap_length + 2));
+        ok(d_merge_pos.alloc(2 * cap_length + 2));
+        ok(d_merge_a0.alloc(cap_length));
+        ok(d_merge_a1.alloc(cap_length));
+    }
     void * pinned_header = nullptr;
     if (e == hipSuccess && pinnedAlloc(&pinned_header, sizeof(SubsetHeader)) != hipSuccess) e = hipErrorOutOfMemory;
     hipEvent_t header_here = nullptr;
@@ -833,7 +1035,37 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
             return rc;
         }
     }
+    static_assert(sizeof(SubsetHeader) <= 192, "the merge's flag word sits behind the header");
+    uint32_t * d_merge_bad = reinterpret_cast<uint32_t *>(search.d_extra_zero.ptr + 192);
+    if (merge_here && e == hipSuccess) {
+        MergeArgs ma;
+        ma.header = header;
+        ma.num_matrices = M;
+        ma.subset_off = d_subset_off.ptr;
+        ma.weight = d_sub_weight.ptr;
+        ma.path_off = d_path_off.ptr;
+        ma.path = d_path.ptr;
+        ma.col_off = d_col_off.ptr;
+        ma.col_path = d_col_path.ptr;
+        ma.abundances = d_abund.ptr;
+        ma.noise = d_noise.ptr;
+        ma.total = d_total.ptr;
+        ma.cluster = groups->d_cluster;
+        ma.cluster_path_off = batch->cluster_path_off.ptr;
+        ma.path_group_id = batch->path_group_id.ptr;
+        ma.sort_key = d_merge_key.ptr;
+        ma.sort_pos = d_merge_pos.ptr;
+        ma.rec_a0 = d_merge_a0.ptr;
+        ma.rec_a1 = d_merge_a1.ptr;
+        ma.merge_bad = d_merge_bad;
+        ma.packed = d_packed.ptr;
+        const int merge_span = ctx->spanBegin(FAM_BUILD);
+        subsetMergeKernel<<<dim3(M), dim3(256), 0, st>>>(ma);
+        ctx->spanEnd(merge_span);
+        ctx->stats.build_launches += 1;
+    }
     PackArgs pa;
+    pa.merge_bad = merge_here ? d_merge_bad : nullptr;
     pa.header = header;
     pa.num_matrices = M;
     pa.subset_off = d_subset_off.ptr;
@@ -853,7 +1085,7 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
     ok(hipGetLastError());
 
     scope.reset(new HostScope("subset em: header"));
-    if (e == hipSuccess) ok(hipEventSynchronize(header_here));
+    if (e == hipSuccess) ok(waitEvent(header_here));
     (void) hipEventDestroy(header_here);
     if (e != hipSuccess) {
         setError("rpvg_hip_nested_subset_em: %s", hipGetErrorString(e));
@@ -890,7 +1122,7 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
     }
     unsigned char * host = static_cast<unsigned char *>(res->block);
     ok(hipMemcpyAsync(host, d_packed.ptr, lay.bytes, hipMemcpyDeviceToHost, st));
-    ok(hipStreamSynchronize(st));
+    ok(waitStream(st));
     if (e != hipSuccess) {
         setError("rpvg_hip_nested_subset_em: %s", hipGetErrorString(e));
         return RPVG_HIP_ERR_RUNTIME;
@@ -909,6 +1141,19 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
     v.noise_count = reinterpret_cast<const double *>(host + lay.noise);
     v.total_count = reinterpret_cast<const double *>(host + lay.total);
     v.iterations = reinterpret_cast<const uint32_t *>(host + lay.iterations);
+    if (merge_here) {
+        if (*reinterpret_cast<const uint32_t *>(host + lay.merge_flags)) {
+            setError("rpvg_hip_nested_subset_em: a diplotype's path subset holds more than two paths of one transcript (PathInfo::group_id): "
+                     "the reference asserts against it (src/path_abundance_estimator.cpp:722)");
+            return RPVG_HIP_ERR_INVALID;
+        }
+        v.set_count = reinterpret_cast<const uint32_t *>(host + lay.set_count);
+        v.cluster_noise_count = reinterpret_cast<const double *>(host + lay.cluster_noise);
+        v.set_first = reinterpret_cast<const uint32_t *>(host + lay.set_first);
+        v.set_second = reinterpret_cast<const uint32_t *>(host + lay.set_second);
+        v.set_posterior = reinterpret_cast<const double *>(host + lay.set_posterior);
+        v.set_abundance = reinterpret_cast<const double *>(host + lay.set_abund);
+    }
     res->num_subsets = S;
     accountEmSolve(ctx, static_cast<uint32_t>(S), v.col_off, reinterpret_cast<const uint32_t *>(host + lay.kept_rows),
                    reinterpret_cast<const uint32_t *>(host + lay.kept_entries), v.iterations);

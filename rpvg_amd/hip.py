@@ -30,6 +30,8 @@ EXPORTS = [
     "rpvg_hip_alignments_upload", "rpvg_hip_alignments_free", "rpvg_hip_read_rows_build", "rpvg_hip_read_rows_to_batch",
     "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_sizes", "rpvg_hip_read_rows_free", "rpvg_hip_path_clusters", "rpvg_hip_debug_log",
     "rpvg_hip_nested_subset_em", "rpvg_hip_subset_em_get", "rpvg_hip_subset_em_free",
+    "rpvg_hip_batch_cluster_totals", "rpvg_hip_batch_has_source_columns", "rpvg_hip_batch_source_columns_sizes",
+    "rpvg_hip_batch_source_columns_get", "rpvg_hip_groups_build_from_sources",
 ]
 
 COMM_ID_BYTES = 128  # RPVG_HIP_COMM_ID_BYTES
@@ -142,6 +144,30 @@ class DeviceBatch:
         self.handle = C.c_void_p()
         cb = host.as_c()
         _check(lib().rpvg_hip_batch_upload(ctx.handle, C.byref(cb), C.byref(self.handle)), "rpvg_hip_batch_upload")
+
+    def has_source_columns(self) -> bool:
+        """Whether the upload formed the haplotype columns of the clusters on the device (path_sources.hip)."""
+        return bool(lib().rpvg_hip_batch_has_source_columns(self.handle))
+
+    def cluster_totals(self) -> np.ndarray:
+        out = np.zeros(self.host.num_clusters, dtype=np.float64)
+        _check(lib().rpvg_hip_batch_cluster_totals(self.handle, C.c_void_p(out.ctypes.data), self.host.num_clusters), "rpvg_hip_batch_cluster_totals")
+        return out
+
+    def source_columns(self, cluster: int):
+        """(multiplicities, [path list of every column]) of one cluster as the device formed them."""
+        ncols, npaths = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().rpvg_hip_batch_source_columns_sizes(self.handle, cluster, C.byref(ncols), C.byref(npaths)), "rpvg_hip_batch_source_columns_sizes")
+        counts = np.zeros(max(1, ncols.value), dtype=np.uint32)
+        ends = np.zeros(max(1, ncols.value), dtype=np.uint32)
+        paths = np.zeros(max(1, npaths.value), dtype=np.uint32)
+        _check(lib().rpvg_hip_batch_source_columns_get(self.ctx.handle, self.handle, cluster, C.c_void_p(counts.ctypes.data),
+                                                       C.c_void_p(ends.ctypes.data), C.c_void_p(paths.ctypes.data)), "rpvg_hip_batch_source_columns_get")
+        lists, begin = [], 0
+        for c in range(ncols.value):
+            lists.append([int(p) for p in paths[begin:ends[c]]])
+            begin = int(ends[c])
+        return [int(x) for x in counts[:ncols.value]], lists
 
     def free(self):
         if self.handle:

@@ -194,7 +194,21 @@ void HipEngine::check(const int status, const char * what) {
     }
 }
 
-FlatClusterRows::FlatClusterRows() : cluster_row_off(1, 0), cluster_path_off(1, 0), row_grp_off(1, 0), grp_idx_off(1, 0) {}
+FlatClusterRows::FlatClusterRows() : cluster_row_off(1, 0), cluster_path_off(1, 0), row_grp_off(1, 0), grp_idx_off(1, 0), path_source_off(1, 0) {}
+
+void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & cluster_probs, const std::vector<PathInfo> & paths) {
+
+    assert(path_group_id.size() == cluster_path_off.back());
+
+    for (auto & path: paths) {
+
+        path_group_id.emplace_back(path.group_id);
+        source_id.insert(source_id.end(), path.source_ids.begin(), path.source_ids.end());
+        path_source_off.emplace_back(source_id.size());
+    }
+
+    addCluster(cluster_probs, paths.size());
+}
 
 void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & cluster_probs, const uint32_t num_paths) {
 
@@ -232,11 +246,14 @@ rpvg_cluster_batch FlatClusterRows::view() const {
     batch.grp_idx_off = grp_idx_off.data();
     batch.path_idx = path_idx.data();
 
-    // PathInfo stays on the host side of the ABI (PathClusterEstimates::paths)
-    batch.path_group_id = nullptr;
+    // the PathInfo fields the device reads, when the clusters were added with their paths; the rest of PathInfo stays on the
+    // host side of the ABI (PathClusterEstimates::paths)
+    const bool with_paths = !path_group_id.empty() && path_group_id.size() == cluster_path_off.back();
+
+    batch.path_group_id = with_paths ? path_group_id.data() : nullptr;
     batch.path_source_count = nullptr;
-    batch.path_source_off = nullptr;
-    batch.source_id = nullptr;
+    batch.path_source_off = with_paths ? path_source_off.data() : nullptr;
+    batch.source_id = with_paths ? source_id.data() : nullptr;
     batch.path_effective_length = nullptr;
 
     return batch;
@@ -269,34 +286,18 @@ DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, con
         HipEngine::check(rpvg_hip_batch_upload(hip_engine->ctx(), &host_batch, &batch), "rpvg_hip_batch_upload");
     }
 
-    ScopedPhase counts_phase("device batch: read counts per cluster");
-
+    // (the read count of every cluster comes back from the device with the upload: the sum over three million rows per batch was
+    // a team of its own on the uploading thread)
     num_rows.resize(host_batch.num_clusters);
     num_paths.resize(host_batch.num_clusters);
     total_read_count.resize(host_batch.num_clusters);
 
-    // (millions of rows: by a team — a small one: this runs on the uploading thread, next to the lanes' teams and on the same CPU
-    // quota; RPVG_AMD_UPLOAD_THREADS)
-    static const int upload_threads = []() {
+    HipEngine::check(rpvg_hip_batch_cluster_totals(batch, total_read_count.data(), host_batch.num_clusters), "rpvg_hip_batch_cluster_totals");
 
-        const char * env = std::getenv("RPVG_AMD_UPLOAD_THREADS");
-        return env ? std::max(1, std::atoi(env)) : 8;
-    }();
-
-    #pragma omp parallel for schedule(static) num_threads(std::min(upload_threads, hostThreads()))
     for (uint32_t i = 0; i < host_batch.num_clusters; ++i) {
 
         num_rows[i] = host_batch.cluster_row_off[i + 1] - host_batch.cluster_row_off[i];
         num_paths[i] = host_batch.cluster_path_off[i + 1] - host_batch.cluster_path_off[i];
-
-        uint64_t read_count = 0;
-
-        for (uint64_t j = host_batch.cluster_row_off[i]; j < host_batch.cluster_row_off[i + 1]; ++j) {
-
-            read_count += host_batch.row_count[j];
-        }
-
-        total_read_count[i] = read_count;
     }
 }
 

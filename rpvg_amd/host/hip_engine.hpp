@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/rpvg_hip.h"
+#include "path_cluster_estimates.hpp"
 #include "pipeline_lanes.hpp"
 #include "read_path_probabilities.hpp"
 
@@ -90,13 +91,17 @@ class FlatClusterRows {
 
         void addCluster(const std::vector<ReadPathProbabilities> & cluster_probs, const uint32_t num_paths);
 
+        // The same with the PathInfo fields the device reads: PathInfo::group_id and PathInfo::source_ids (the batch then
+        // carries its haplotype columns, rpvg_hip_batch_upload).  All clusters of a batch with them, or none.
+        void addCluster(const std::vector<ReadPathProbabilities> & cluster_probs, const std::vector<PathInfo> & paths);
+
         uint32_t numClusters() const { return cluster_row_off.size() - 1; }
         rpvg_cluster_batch view() const;
 
     private:
 
-        std::vector<uint64_t> cluster_row_off, cluster_path_off, row_grp_off, grp_idx_off;
-        std::vector<uint32_t> row_count, path_idx;
+        std::vector<uint64_t> cluster_row_off, cluster_path_off, row_grp_off, grp_idx_off, path_source_off;
+        std::vector<uint32_t> row_count, path_idx, path_group_id, source_id;
         std::vector<double> row_noise, grp_prob;
 };
 
@@ -125,6 +130,10 @@ class DeviceClusterBatch {
 
         // Sum of the read counts of all rows of the cluster (exact: integers).
         double totalReadCount(const uint32_t cluster) const { return total_read_count.at(cluster); }
+
+        // Whether the batch holds the haplotype columns of its clusters (findPathSourceGroups on the device: the batch was
+        // uploaded with PathInfo::group_id and PathInfo::source_ids) — rpvg_hip_groups_build_from_sources takes it then.
+        bool hasSourceColumns() const { return rpvg_hip_batch_has_source_columns(batch) != 0; }
 
     private:
 

@@ -424,6 +424,22 @@ static void dropNowOrLater(std::function<void(int)> drop, const bool between_dev
 // The estimator on a subset of the batch's clusters (all with at least one row).
 void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, std::vector<std::mt19937> * rngs, const std::function<void()> & first_device_stage) const {
 
+    // The defaults of `-i haplotype-transcripts` — collapsed groups, diploid, branch and bound, no read-count samples — on a
+    // batch that carries its haplotype columns (findPathSourceGroups ran on the device with the upload): matrices, search,
+    // subsets, EM and the weighted merge are ONE device call; the host lists the lane's clusters and copies the estimates out.
+    if (infer_collapsed && !use_group_post_gibbs && group_size == 2 && num_gibbs_samples == 0 && cluster_batch.hasSourceColumns() && !std::getenv("RPVG_AMD_HOST_SOURCE_GROUPS")) {
+
+        first_device_stage();
+
+        SubsetEmResult device_result;
+
+        if (nestedSubsetAbundances(&device_result, cluster_batch, clusters, min_hap_prob, min_hap_prob, max_em_its, max_rel_em_conv) && device_result.view.set_count) {
+
+            unpackMergedSolutions(path_cluster_estimates, cluster_batch, clusters, device_result.view);
+            return;
+        }
+    }
+
     // The previous estimates of a cluster are dropped before the new ones are written.  The first lane's prologue is
     // the batch's (the GPU waits for it): that lane drops them in its merge loop, which nobody waits for.
     const bool reset_in_merge = (HipEngine::currentLane() == 0);
@@ -1083,6 +1099,62 @@ void NestedPathAbundanceEstimator::mergeSubsetSolutions(std::vector<PathClusterE
         // (see inferPathSubsetAbundance for the tolerance)
         assert(sum_hap_prob < 1 + 1e-9);
         estimates.noise_count += (1 - sum_hap_prob) * estimates.total_count;  // (src/path_abundance_estimator.cpp:749: unclamped, as the reference adds it)
+    }
+}
+
+void NestedPathAbundanceEstimator::unpackMergedSolutions(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const rpvg_hip_subset_em_view & subsets) const {
+
+    assert(subsets.num_matrices == clusters.size());
+    assert(subsets.set_count);
+
+    ScopedPhase unpack_phase("nested: estimates out of the device block");
+
+    // Every field of the estimates is overwritten (what resetEstimates(0, 0) clears, src/path_abundance_estimator.cpp:351), the
+    // vectors of vectors element by element: their allocations survive from one batch to the next.
+    for (size_t i = 0; i < clusters.size(); ++i) {
+
+        auto & estimates = path_cluster_estimates->at(clusters[i]);
+
+        const uint64_t first_subset = subsets.subset_off[i];
+        const uint64_t num_subsets = subsets.subset_off[i + 1] - first_subset;
+        const uint64_t first_set = subsets.path_off[first_subset];
+        const uint32_t num_sets = subsets.set_count[i];
+
+        estimates.total_count = cluster_batch.totalReadCount(clusters[i]);
+        estimates.noise_count = (num_subsets > 0) ? subsets.cluster_noise_count[i] : estimates.total_count;  // (:749 with no subset kept)
+        estimates.gibbs_read_count_samples.clear();
+
+        estimates.path_group_sets.resize(num_sets);
+        estimates.posteriors.assign(subsets.set_posterior + first_set, subsets.set_posterior + first_set + num_sets);
+        estimates.abundances.clear();
+
+        for (uint32_t q = 0; q < num_sets; ++q) {
+
+            const uint64_t slot = first_set + q;
+            auto & path_group_set = estimates.path_group_sets[q];
+
+            if (subsets.set_second[slot] == 0xFFFFFFFFu) {
+
+                path_group_set.assign(1, subsets.set_first[slot]);
+                estimates.abundances.emplace_back(subsets.set_abundance[2 * slot]);
+
+            } else {
+
+                path_group_set.resize(2);
+                path_group_set[0] = subsets.set_first[slot];
+                path_group_set[1] = subsets.set_second[slot];
+                estimates.abundances.emplace_back(subsets.set_abundance[2 * slot]);
+                estimates.abundances.emplace_back(subsets.set_abundance[2 * slot + 1]);
+            }
+        }
+
+        estimates.em_iterations.assign(subsets.iterations + first_subset, subsets.iterations + first_subset + num_subsets);
+        estimates.em_problem_paths.resize(num_subsets);
+
+        for (uint64_t s = 0; s < num_subsets; ++s) {
+
+            estimates.em_problem_paths[s].assign(subsets.col_path + subsets.col_off[first_subset + s], subsets.col_path + subsets.col_off[first_subset + s + 1]);
+        }
     }
 }
 

@@ -115,6 +115,10 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
         // (PathEstimator::nestedSubsetAbundances): matrix i of the result belongs to clusters.at(i).
         void mergeSubsetSolutions(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const rpvg_hip_subset_em_view & subsets, bool reset_first) const;
 
+        // The estimates of a device call that merged on the device too (rpvg_hip_subset_em_view::set_*): copied into the
+        // clusters' containers in place — a caller that hands the same containers in again pays no allocation.
+        void unpackMergedSolutions(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const rpvg_hip_subset_em_view & subsets) const;
+
         void inferPathSubsetAbundance(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const std::vector<PathSubsetWeights> & path_subset_samples, std::vector<std::mt19937> * rngs, bool reset_first) const;
 };
 

@@ -78,6 +78,14 @@ class GroupMatrices {
             HipEngine::check(rpvg_hip_groups_build(engine->ctx(), cluster_batch.handle(), &spec, &groups), "rpvg_hip_groups_build");
         }
 
+        // The matrices of NestedPathAbundanceEstimator::inferAbundancesCollapsedGroups for the listed clusters from the haplotype
+        // columns the batch holds on the device (findPathSourceGroups ran there with the upload: no list is flattened or copied here).
+        GroupMatrices(const std::shared_ptr<HipEngine> & engine_in, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const bool normalise, const double prob_precision) : engine(engine_in), groups(nullptr) {
+
+            ScopedPhase phase("posteriors: group matrices build (device columns)");
+            HipEngine::check(rpvg_hip_groups_build_from_sources(engine->ctx(), cluster_batch.handle(), clusters.size(), clusters.data(), normalise, normalise ? prob_precision : 0.0, &groups), "rpvg_hip_groups_build_from_sources");
+        }
+
         // Freeing the matrices (a stream wait, a dozen blocks back to the pool) sits between a lane's search and its EM:
         // they are kept with the lane's retired containers (dropped when the first lane's work is done, by any other lane
         // at the start of its next batch) — the holder frees them whichever way it goes.
@@ -493,7 +501,7 @@ PathEstimator::PathEstimator(const double prob_precision_in, std::shared_ptr<Hip
 void PathEstimator::estimate(PathClusterEstimates * path_cluster_estimates, const std::vector<ReadPathProbabilities> & cluster_probs, std::mt19937 * mt_rng) {
 
     FlatClusterRows rows;
-    rows.addCluster(cluster_probs, path_cluster_estimates->paths.size());
+    rows.addCluster(cluster_probs, path_cluster_estimates->paths);  // (with PathInfo::group_id / source_ids: the device forms the haplotype columns)
 
     const DeviceClusterBatch cluster_batch(engine, rows.view());
 
@@ -896,6 +904,33 @@ bool PathEstimator::nestedSubsetAbundances(SubsetEmResult * result, const Device
     }
 
     const int status = rpvg_hip_nested_subset_em(engine->ctx(), cluster_batch.handle(), matrices.handle(), column_counts.data(), min_rel_likelihood, min_hap_prob, max_em_its, max_rel_em_conv, prob_precision, &result->result);
+
+    if (status == RPVG_HIP_ERR_UNSUPPORTED) {
+
+        return false;
+    }
+
+    HipEngine::check(status, "rpvg_hip_nested_subset_em");
+    HipEngine::check(rpvg_hip_subset_em_get(result->result, &result->view), "rpvg_hip_subset_em_get");
+
+    return true;
+}
+
+bool PathEstimator::nestedSubsetAbundances(SubsetEmResult * result, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const double min_rel_likelihood, const double min_hap_prob, const uint32_t max_em_its, const double max_rel_em_conv) const {
+
+    assert(!result->result);
+    assert(cluster_batch.hasSourceColumns());
+
+    if (clusters.empty() || std::getenv("RPVG_AMD_HOST_BOUNDED")) {
+
+        return false;
+    }
+
+    ScopedPhase whole_phase("nested: matrices + search + subsets + EM + merge on the device");
+
+    const GroupMatrices matrices(engine, cluster_batch, clusters, true, prob_precision);
+
+    const int status = rpvg_hip_nested_subset_em(engine->ctx(), cluster_batch.handle(), matrices.handle(), nullptr, min_rel_likelihood, min_hap_prob, max_em_its, max_rel_em_conv, prob_precision, &result->result);
 
     if (status == RPVG_HIP_ERR_UNSUPPORTED) {
 

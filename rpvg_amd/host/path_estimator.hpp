@@ -154,6 +154,11 @@ class PathEstimator {
 
         bool nestedSubsetAbundances(SubsetEmResult * result, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const double min_rel_likelihood, const double min_hap_prob, const uint32_t max_em_its, const double max_rel_em_conv) const;
 
+        // The same from the haplotype columns the batch holds on the device (DeviceClusterBatch::hasSourceColumns()): matrix i of
+        // the result belongs to clusters.at(i); nothing but the cluster list goes up, and the result carries the
+        // posterior-weighted merge of the solutions as well (rpvg_hip_subset_em_view::set_*).
+        bool nestedSubsetAbundances(SubsetEmResult * result, const DeviceClusterBatch & cluster_batch, const std::vector<uint32_t> & clusters, const double min_rel_likelihood, const double min_hap_prob, const uint32_t max_em_its, const double max_rel_em_conv) const;
+
         // src/path_estimator.cpp:315-330
         static std::vector<double> calcPathLogFrequences(const std::vector<uint32_t> & path_counts);
 };
