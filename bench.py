@@ -59,8 +59,8 @@ def load_pmc(name):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="s3", choices=["s3", "c2", "s5", "rows", "e2e"],
                     help="s3: BASELINE.json configs[2]/[3] (default, the metric's configuration); c2: configs[1] single dense "
                          "cluster; s5: configs[4] diploid haplotype Gibbs, 10M reads x 500k paths; rows: the step before the path "
@@ -70,10 +70,13 @@ def parse_args():
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the full workload (parity/dev runs only)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank owns a full-size batch; strong: ONE batch, clusters sharded over the ranks")
-    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
+    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2, 3, 4],
                     help="s3/s5: batches in flight per GPU.  1 = a step returns before the next one starts (default); 2 = two "
                          "engines on the GPU, each on its own resident copy of the batch, driven by two host threads: the K steps "
                          "overlap (one batch's host prologue and epilogue run under the other's kernels)")
+    ap.add_argument("--pipeline-workers", type=int, default=0,
+                    help="s3/s5 headline: estimator threads of the batch pipeline (rpvg_amd/host/batch_pipeline.hpp) = batches estimated side by "
+                         "side; 0 = the library's default (4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -317,12 +320,39 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     # those of this loop.
     h2d = None
     if not others and DEVICE == "cuda" and hasattr(prepared, "reupload"):
-        h2d = measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank, dist, torch)
-        stats = h2d.pop("stats")
+        single = measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank, dist, torch)
+        single_stats = single.pop("stats")
+        if hasattr(eng_mod, "Pipeline") and not os.environ.get("RPVG_BENCH_NO_PIPELINE"):
+            # the headline: the same K batches through the pipeline of the host library (rpvg_amd/host/batch_pipeline.hpp) — an uploader
+            # thread and several single-lane engines, several batches in flight on the GPU, every batch uploaded inside the clock
+            h2d = measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch)
+            stats = h2d.pop("stats")
+            one = {k: single[k] for k in ("ms_per_step_with_h2d", "ms_per_step_with_h2d_serial", "ms_per_step_spread", "host_cpu_ms_per_step",
+                                          "h2d_ms_per_batch", "h2d_gb_per_s")}
+            if single_stats.get("busy_ms") is not None:
+                one["gpu_active_frac"] = (single_stats["busy_ms"] / args.steps) / single["ms_per_step_with_h2d"]
+            one["note"] = ("the same steps with ONE batch in flight (the headline of rounds 2-4): estimateBatch on two host lanes, the next batch "
+                           "uploaded under it from a second resident slot")
+            h2d["one_batch_in_flight"] = one
+        else:
+            h2d, stats = single, single_stats
 
     # after the timed region: gather the per-path abundances of every rank over RCCL (what a multi-GPU
     # driver does before writing rpvg.txt); also fetch one decoded result for a sanity check
     est, _ = eng.run(args.model, params, prepared)
+    pipeline_est = h2d.pop("sample_estimates", None) if h2d is not None else None
+    if pipeline_est is not None:  # the pipeline's batches are the engine's: same estimates, to the bit
+        assert len(pipeline_est) == len(est)
+        def same(a, b):
+            return (a.path_group_sets == b.path_group_sets and np.allclose(a.posteriors, b.posteriors, rtol=1e-9, atol=1e-12)
+                    and np.allclose(a.abundances, b.abundances, rtol=1e-9, atol=1e-9) and abs(a.noise_count - b.noise_count) <= 1e-9 * max(1.0, b.total_count)
+                    and a.em_iters == b.em_iters)
+        pipeline_equal = all(same(a, b) for a, b in zip(pipeline_est, est))
+        if not pipeline_equal:
+            bad = [k for k, (a, b) in enumerate(zip(pipeline_est, est)) if not same(a, b)]
+            print(f"pipeline != single engine in {len(bad)} clusters, first {bad[:5]}", file=sys.stderr)
+    else:
+        pipeline_equal = None
     if args.model == "haplotypes":  # posteriors only: they sum to one per cluster
         mass_ok = all(abs(e.posteriors.sum() - 1) <= 1e-6 for e in est if e.total_count > 0 and len(e.posteriors))
     else:
@@ -401,7 +431,7 @@ def run_s3(args, rank, local_rank, world, dist, torch):
                              + (" -y 2 --use-hap-gibbs" if s5 else "") + ", reference defaults",
                     clusters_per_gpu=K, rows_per_gpu=batch.num_rows, entries_per_gpu=int(len(batch.path_idx)),
                     parallelism=f"clusters sharded, {world} rank(s), final abundance gather over RCCL",
-                    batches_in_flight=args.in_flight),
+                    batches_in_flight=(h2d or {}).get("pipeline", {}).get("workers", args.in_flight)),
         roofline=roofline, kernels=kernels, em_kernels=em_kernel_lines, mass_conserved=bool(mass_ok),
         upload_ms=upload_ms, ms_per_step_resident=ms_resident, value_resident=reads_all / (ms_resident / 1e3),
         engine_module=ENGINE_MODULE, host_threads_per_lane=host_threads_per_lane(),
@@ -414,6 +444,8 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         line["gpu_active_frac"] = (stats["busy_ms"] / args.steps) / ms_per_step
     if h2d is not None:
         line.update(h2d)
+    if pipeline_equal is not None:
+        line["pipeline_estimates_equal_single_engine"] = bool(pipeline_equal)
     if ENGINE_MODULE != "rpvg_amd.engine":
         # a stand-in engine (the CPU test of the launcher and the rank protocol): no metric is claimed
         line.update(metric="none: stand-in engine %s, launcher/protocol self-test only" % ENGINE_MODULE, protocol_value=value, value=None,
@@ -565,6 +597,70 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
                 h2d_ms_per_batch=up_ms, h2d_bytes_per_batch=bytes_per_batch, h2d_gb_per_s=bytes_per_batch / 1e9 / (up_ms / 1e3),
                 h2d_note="rows of every batch uploaded from page-locked host arrays inside the clock: validation on the host, H2D, "
                          "expansion on the device; overlapped = two resident slots, uploader engine under the previous batch's kernels")
+
+
+def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
+    """K batches through BatchPipeline: submit() K times, wait().  The host arrays are page-locked; every batch is validated,
+    copied and expanded on the device inside the clock (and its haplotype columns formed), several batches are in flight, the
+    estimates of every batch land in host containers (PathClusterEstimates).  The pipeline is empty when the clock starts and
+    when it stops: ramp-up and drain are inside."""
+    import resource
+    from rpvg_amd import hip
+    arrays = [batch.cluster_row_off, batch.cluster_path_off, batch.row_count, batch.row_noise, batch.row_grp_off, batch.grp_prob,
+              batch.grp_idx_off, batch.path_idx, batch.path_group_id, batch.path_source_off, batch.source_id]
+    for a in arrays:
+        hip.host_register(a)
+    pipe = eng_mod.Pipeline(args.model, params, local_rank, workers=args.pipeline_workers)
+    try:
+        slots = pipe.workers + 4
+        pipe.prepare_slots(batch, slots)
+        for k in range(max(args.warmup, 2 * slots)):
+            pipe.submit(batch, k % slots)
+        pipe.wait()
+        pipe.reset_stats()
+        barrier_sync(dist, torch)
+        cpu0 = resource.getrusage(resource.RUSAGE_SELF)
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            pipe.submit(batch, k % slots)
+        pipe.wait()
+        barrier_sync(dist, torch)
+        elapsed = max_over_ranks(time.perf_counter() - t0, dist, torch)
+        cpu1 = resource.getrusage(resource.RUSAGE_SELF)
+        stats = pipe.stats()
+        done = pipe.completions()
+        workers = pipe.workers
+        est = pipe.result((args.steps - 1) % slots)
+    finally:
+        pipe.close()
+        for a in arrays:
+            hip.host_unregister(a)
+    host_cpu_ms = ((cpu1.ru_utime - cpu0.ru_utime) + (cpu1.ru_stime - cpu0.ru_stime)) * 1e3 / args.steps
+    bytes_per_batch = float(sum(a.nbytes for a in arrays))
+    up_ms = stats.pop("upload_seconds_per_batch") * 1e3
+    up_copies_ms, up_kernels_ms = stats.pop("upload_copies_ms_per_batch", None), stats.pop("upload_kernels_ms_per_batch", None)
+    worker_ms = dict(finish_upload=stats.pop("worker_finish_ms_per_batch", None), estimate=stats.pop("worker_estimate_ms_per_batch", None),
+                     wait_for_a_batch=stats.pop("worker_idle_ms_per_batch", None),
+                     note="wall ms per batch of an estimator thread: the kernels behind the copies (rpvg_hip_batch_upload_finish), "
+                          "estimateBatch, and waiting for the uploader")
+    gaps = sorted((done[1:] - done[:-1]) * 1e3) if len(done) > 2 else []
+    spread = None
+    if gaps:
+        spread = dict(median=gaps[len(gaps) // 2], min=gaps[0], max=gaps[-1], p10=gaps[len(gaps) // 10], p90=gaps[(9 * len(gaps)) // 10],
+                      first_batch_done_ms=float(done[0]) * 1e3, last_batch_done_ms=float(done[-1]) * 1e3,
+                      note="time between the completions of consecutive batches inside the timed region (ms_per_step = wall time between the "
+                           "barriers / K, ramp-up of the first batch and drain of the last included)")
+    return dict(stats=stats, ms_per_step_with_h2d=elapsed / args.steps * 1e3, ms_per_step_spread=spread, host_cpu_ms_per_step=host_cpu_ms,
+                host_cpu_note="user + system CPU time of the process (uploader, estimator threads, this thread) per step of the timed region, getrusage",
+                pipeline=dict(workers=workers, resident_batches=workers + 1, estimates_slots=slots, worker_ms_per_batch=worker_ms,
+                              note="rpvg_amd/host/batch_pipeline.hpp: one uploader thread (context of its own), `workers` estimator threads with a "
+                                   "single-lane engine each; batches do not interact, results equal those of one call after the other "
+                                   "(tests/test_hip_pipeline.py)"),
+                h2d_ms_per_batch=up_ms, h2d_bytes_per_batch=bytes_per_batch, h2d_gb_per_s=bytes_per_batch / 1e9 / (up_ms / 1e3) if up_ms > 0 else None,
+                h2d_copies_device_ms_per_batch=up_copies_ms, h2d_kernels_device_ms_per_batch=up_kernels_ms,
+                h2d_note="rows and path side (PathInfo::group_id, source_ids) of every batch from page-locked host arrays inside the clock: offsets "
+                         "checked on the host, H2D, validation + expansion + haplotype columns on the device",
+                sample_estimates=est)
 
 
 def dense_em_roofline(local_rank, rows=1000000, paths=2000, its=20):

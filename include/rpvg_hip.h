@@ -53,6 +53,12 @@ int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out);
  * own: the copies and expansion kernels do not queue behind the estimating contexts' kernels (measured: 10.6 -> 7.3 ms
  * per 280 MB batch while a batch is estimated, 14.7 -> 13.7 ms per batch in steady state). */
 int rpvg_hip_create_uploader(int device, rpvg_hip_ctx ** ctx_out);
+/* A context with fewer side streams than rpvg_hip_create's six (1..6), for engines that run whole batches next to each other
+ * on one GPU (rpvg_amd/host/batch_pipeline.hpp): the runtime maps all streams of a process onto its hardware queues
+ * (GPU_MAX_HW_QUEUES, 16 here), commands of streams that share a queue run in order, and four engines of nine streams
+ * each put one engine's short kernels behind another's long ones.  The launches that would have had streams of their own
+ * follow one another on the streams there are; results are the same. */
+int rpvg_hip_create_with_streams(int device, int side_streams, rpvg_hip_ctx ** ctx_out);
 void rpvg_hip_destroy(rpvg_hip_ctx * ctx);
 const char * rpvg_hip_last_error(void);
 int rpvg_hip_synchronize(rpvg_hip_ctx * ctx);
@@ -79,6 +85,13 @@ int rpvg_hip_host_unregister(void * host);
  * expanded to (path, probability) entries on the GPU. */
 int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * host_batch, rpvg_hip_batch ** batch_out);
 void rpvg_hip_batch_free(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch);
+/* The same upload in two halves, for a caller that keeps a copy engine busy (rpvg_amd/host/batch_pipeline.hpp): _begin checks
+ * the offsets, queues the copies on `ctx` — an uploader's context — and returns when they are done; _finish runs the kernels
+ * behind them (expansion, validation, read totals, haplotype columns) on `ctx` — any context of the same GPU, e.g. the one
+ * that estimates the batch next — and returns the upload's verdict.  Between the two the batch takes no other call;
+ * host_batch is the same caller-owned batch both times (a batch that fails _finish is freed by it). */
+int rpvg_hip_batch_upload_begin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * host_batch, rpvg_hip_batch ** batch_out);
+int rpvg_hip_batch_upload_finish(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch, const rpvg_cluster_batch * host_batch);
 /* Read count of every cluster of an uploaded batch (the sum of its rows' read counts, exact), added up on the device behind
  * the copy (src/path_abundance_estimator.cpp:44,291,690: `read_counts.sum()`). */
 int rpvg_hip_batch_cluster_totals(const rpvg_hip_batch * batch, double * totals_out, uint32_t num_clusters);

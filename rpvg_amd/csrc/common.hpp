@@ -625,6 +625,7 @@ struct rpvg_hip_ctx {
     // overlap instead of adding up.  forkAux() makes them wait for the work queued on `stream` so far,
     // joinAux() makes `stream` wait for them.
     hipStream_t aux[kAuxStreams] = {};
+    int aux_count = kAuxStreams;  // real side streams: aux[i] for i >= aux_count aliases aux[i % aux_count] (rpvg_hip_create_with_streams)
     hipStream_t collapse_stream = nullptr;  // row collapse of the matrices a build leaves behind (highest priority: short kernels next to a search)
     hipStream_t copy_stream = nullptr;  // staged uploads (stagedCopy)
     hipEvent_t copied = nullptr;
@@ -654,6 +655,22 @@ struct rpvg_hip_ctx {
     int foldSpans();
 };
 
+namespace rpvg_hip_detail {
+// ---- the path side of a batch (path_sources.hip) -----------------------------------------------------
+// What an upload keeps between its copies and the kernels behind them: the copied PathInfo::source_ids, the scratch of the
+// kernel that forms the haplotype columns of every cluster, the sizes it brings back.
+struct PathSourcesPending {
+    DeviceBuffer<uint64_t> d_path_source_off;
+    DeviceBuffer<uint32_t> d_source_id, d_sizes;
+    DeviceBuffer<unsigned long long> d_arena;
+    unsigned long long arena_words = 0, num_sources = 0;
+    void * h_sizes = nullptr;  // pinned: [num_cols K | col_paths K | max_col_paths K | error, arena overflow]
+    uint32_t K = 0;
+    bool copied = false, queued = false;
+    ~PathSourcesPending() { if (h_sizes) pinnedFree(h_sizes); }
+};
+}  // namespace rpvg_hip_detail
+
 // Device-resident batch: the expanded CSR of every cluster.
 struct rpvg_hip_batch {
     uint32_t num_clusters = 0;
@@ -682,6 +699,15 @@ struct rpvg_hip_batch {
     rpvg_hip_detail::DeviceBuffer<uint32_t> src_col_path;      // the lists, ascending cluster-local paths, columns back to back
     std::vector<uint64_t> h_cluster_src_off;                   // [K+1]
     std::vector<uint32_t> h_src_num_cols, h_src_col_paths, h_src_max_col_paths;  // [K] columns, sum and maximum of their list lengths
+    // An upload in two halves (rpvg_hip_batch_upload_begin / _finish): what the kernels of the second half read and free.
+    struct UploadInProgress {
+        rpvg_hip_detail::DeviceBuffer<uint32_t> d_row_count_u32;
+        rpvg_hip_detail::DeviceBuffer<uint64_t> d_row_grp_off, d_grp_idx_off;
+        rpvg_hip_detail::DeviceBuffer<double> d_grp_prob;
+        uint64_t num_groups = 0;
+        rpvg_hip_detail::PathSourcesPending path_sources;
+    };
+    std::unique_ptr<UploadInProgress> upload;  // null: the batch is complete
 };
 
 // Device-resident group matrices (loglik.hip builds them).
@@ -926,22 +952,13 @@ struct CsrCollapseWork {
 hipError_t queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollapseInput & in, double precision, CsrCollapseWork & work, hipStream_t stream,
                             hipEvent_t sorted = nullptr);
 
-// ---- the path side of a batch (path_sources.hip) -----------------------------------------------------
-// Queues, on the context's stream, the copies of PathInfo::group_id / source_ids of `hb` and the kernels that form the
-// haplotype columns of every cluster, plus the copy of their sizes back to the host; finishPathSources() reads those
-// once the stream has been waited for.  The caller holds ctx->mutex and has set the device.
-struct PathSourcesPending {
-    DeviceBuffer<uint64_t> d_path_source_off;
-    DeviceBuffer<uint32_t> d_source_id, d_sizes;
-    DeviceBuffer<unsigned long long> d_arena;
-    void * h_sizes = nullptr;  // pinned: [num_cols K | col_paths K | max_col_paths K | error, arena overflow]
-    uint32_t K = 0;
-    bool queued = false;
-    ~PathSourcesPending() { if (h_sizes) pinnedFree(h_sizes); }
-};
+// The copies of PathInfo::group_id / source_ids of `hb` on the context's stream; then, on the stream of any context of the
+// device, the kernel that forms the haplotype columns of every cluster and the copy of their sizes back to the host;
+// finishPathSources() reads those once that stream has been waited for.  The caller holds ctx->mutex and has set the device.
 // read count of every cluster (exact integer sums) from the 32-bit counts as uploaded
 hipError_t queueClusterTotals(hipStream_t stream, uint32_t num_clusters, const uint64_t * d_cluster_row_off, const uint32_t * d_row_count_u32, double * d_totals);
-hipError_t queuePathSources(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_cluster_batch * hb, PathSourcesPending & pending);
+hipError_t queuePathSourceCopies(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_cluster_batch * hb, PathSourcesPending & pending);
+hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSourcesPending & pending);
 // RPVG_HIP_OK; RPVG_HIP_ERR_INVALID for inconsistent offsets.  A batch whose id ranges outgrow the scratch set aside for them
 // simply has no source columns (has_source_columns stays false: the caller groups on the host).
 int finishPathSources(rpvg_hip_batch * b, PathSourcesPending & pending);

@@ -238,7 +238,10 @@ namespace {
 int g_hardware_queues = 4;
 
 __attribute__((constructor)) void askForHardwareQueues() {
-    (void) setenv("GPU_MAX_HW_QUEUES", "8", 0);  // keeps a value the user has set
+    // (16 since round 5: several batches in flight on one GPU — rpvg_amd/host/batch_pipeline.hpp, one single-lane engine of nine
+    // streams each — run 4.5 ms per configs[2] batch on sixteen queues against 5.4 on twelve and 6.6 on eight; 24 and 32 are
+    // time-sliced and twice as slow; two lanes over one batch measure the same on 8 and 16)
+    (void) setenv("GPU_MAX_HW_QUEUES", "16", 0);  // keeps a value the user has set
     const char * env = std::getenv("GPU_MAX_HW_QUEUES");
     g_hardware_queues = env ? std::max(1, std::atoi(env)) : 4;
 }
@@ -290,13 +293,13 @@ hipError_t waitStream(hipStream_t stream) {
 
 hipError_t rpvg_hip_ctx::forkAux() {
     hipError_t e = hipEventRecord(fork_event, stream);
-    for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamWaitEvent(aux[i], fork_event, 0);
+    for (int i = 0; i < aux_count && e == hipSuccess; ++i) e = hipStreamWaitEvent(aux[i], fork_event, 0);
     return e;
 }
 
 hipError_t rpvg_hip_ctx::joinAux() {
     hipError_t e = hipSuccess;
-    for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) {
+    for (int i = 0; i < aux_count && e == hipSuccess; ++i) {
         e = hipEventRecord(join_event[i], aux[i]);
         if (e == hipSuccess) e = hipStreamWaitEvent(stream, join_event[i], 0);
     }
@@ -308,9 +311,9 @@ hipError_t rpvg_hip_ctx::joinAux() {
 // streams on that queue — the other lane's — stand behind it)
 hipError_t rpvg_hip_ctx::joinAuxOnHost() {
     hipError_t e = hipSuccess;
-    for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipEventRecord(join_event[i], aux[i]);
-    for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = rpvg_hip_detail::waitEvent(join_event[i]);
-    for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamWaitEvent(stream, join_event[i], 0);  // (the ordering, for the record: they have arrived)
+    for (int i = 0; i < aux_count && e == hipSuccess; ++i) e = hipEventRecord(join_event[i], aux[i]);
+    for (int i = 0; i < aux_count && e == hipSuccess; ++i) e = rpvg_hip_detail::waitEvent(join_event[i]);
+    for (int i = 0; i < aux_count && e == hipSuccess; ++i) e = hipStreamWaitEvent(stream, join_event[i], 0);  // (the ordering, for the record: they have arrived)
     return e;
 }
 
@@ -513,15 +516,20 @@ hipError_t createMainStream(hipStream_t * stream, const bool highest_priority) {
     return hipStreamCreateWithPriority(stream, hipStreamNonBlocking, greatest);
 }
 
-int createContext(int device, bool uploader, rpvg_hip_ctx ** ctx_out);
+int createContext(int device, bool uploader, int side_streams, rpvg_hip_ctx ** ctx_out);
 }  // namespace
 
-int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) { return createContext(device, false, ctx_out); }
+int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out) { return createContext(device, false, rpvg_hip_ctx::kAuxStreams, ctx_out); }
 
-int rpvg_hip_create_uploader(int device, rpvg_hip_ctx ** ctx_out) { return createContext(device, true, ctx_out); }
+int rpvg_hip_create_uploader(int device, rpvg_hip_ctx ** ctx_out) { return createContext(device, true, 1, ctx_out); }
+
+int rpvg_hip_create_with_streams(int device, int side_streams, rpvg_hip_ctx ** ctx_out) {
+    RPVG_REQUIRE(side_streams >= 1 && side_streams <= rpvg_hip_ctx::kAuxStreams, "rpvg_hip_create_with_streams: 1 to %d side streams", rpvg_hip_ctx::kAuxStreams);
+    return createContext(device, false, side_streams, ctx_out);
+}
 
 namespace {
-int createContext(int device, const bool uploader, rpvg_hip_ctx ** ctx_out) {
+int createContext(int device, const bool uploader, const int side_streams, rpvg_hip_ctx ** ctx_out) {
     RPVG_REQUIRE(ctx_out != nullptr, "rpvg_hip_create: ctx_out is NULL");
     *ctx_out = nullptr;
     int n = 0;
@@ -545,9 +553,16 @@ int createContext(int device, const bool uploader, rpvg_hip_ctx ** ctx_out) {
         delete ctx;
         return RPVG_HIP_ERR_RUNTIME;
     }
+    // side_streams real side streams; the other entries of aux[] are aliases of them, so that every use site keeps its index
+    // (launches that would have had streams of their own then follow one another on the stream they share)
+    ctx->aux_count = side_streams;
     for (int i = 0; i < rpvg_hip_ctx::kAuxStreams && e == hipSuccess; ++i) {
-        e = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_event[i], hipEventDisableTiming);
+        if (i < side_streams) {
+            e = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_event[i], hipEventDisableTiming);
+        } else {
+            ctx->aux[i] = ctx->aux[i % side_streams];
+        }
     }
     if (e == hipSuccess) e = createMainStream(&ctx->collapse_stream, std::getenv("RPVG_HIP_COLLAPSE_PRIORITY") == nullptr || std::atoi(std::getenv("RPVG_HIP_COLLAPSE_PRIORITY")) != 0);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming);
@@ -556,7 +571,7 @@ int createContext(int device, const bool uploader, rpvg_hip_ctx ** ctx_out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copied, hipEventDisableTiming);
     if (e == hipSuccess) {
         registerCopyStream(ctx->stream, ctx->copy_stream, ctx->copied);
-        for (int i = 0; i < rpvg_hip_ctx::kAuxStreams; ++i) registerCopyStream(ctx->aux[i], ctx->copy_stream, ctx->copied);
+        for (int i = 0; i < ctx->aux_count; ++i) registerCopyStream(ctx->aux[i], ctx->copy_stream, ctx->copied);
     }
     if (e != hipSuccess) {
         setError("rpvg_hip_create: %s", hipGetErrorString(e));
@@ -584,7 +599,7 @@ void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
     (void) ctx->foldSpans();
     (void) rpvg_hip_comm_destroy(ctx);
     if (ctx->stream) forgetCopyStream(ctx->stream);
-    for (int i = 0; i < rpvg_hip_ctx::kAuxStreams; ++i) {
+    for (int i = 0; i < ctx->aux_count; ++i) {
         if (ctx->aux[i]) forgetCopyStream(ctx->aux[i]);
     }
     if (ctx->copy_stream) {
@@ -593,7 +608,7 @@ void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
     }
     if (ctx->copied) (void) hipEventDestroy(ctx->copied);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
-    for (int i = 0; i < rpvg_hip_ctx::kAuxStreams; ++i) {
+    for (int i = 0; i < ctx->aux_count; ++i) {  // (the entries behind are aliases)
         if (ctx->aux[i]) (void) hipStreamDestroy(ctx->aux[i]);
         if (ctx->join_event[i]) (void) hipEventDestroy(ctx->join_event[i]);
     }
@@ -724,7 +739,10 @@ bool validateRow(const rpvg_cluster_batch * hb, const uint32_t k, const uint64_t
 
 }  // namespace
 
-int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_hip_batch ** batch_out) {
+// The two halves of an upload.  Begin: offsets checked, copies queued on `ctx` (an uploader's stream, usually).  Finish: the
+// kernels behind the copies — expansion of the (probability, path list) groups, row meta data, validation, read totals, the
+// haplotype columns — on any context of the device, and the small results they bring back.
+static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_hip_batch ** batch_out) {
     RPVG_REQUIRE(ctx != nullptr && hb != nullptr && batch_out != nullptr, "rpvg_hip_batch_upload: NULL argument");
     *batch_out = nullptr;
     const uint32_t K = hb->num_clusters;
@@ -766,10 +784,9 @@ int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpv
         const uint64_t r = hb->cluster_row_off[k];
         b->h_cluster_ent_off[k] = R ? hb->grp_idx_off[hb->row_grp_off[r]] : 0;
     }
-
-    DeviceBuffer<uint32_t> d_row_count_u32;
-    DeviceBuffer<uint64_t> d_row_grp_off, d_grp_idx_off;
-    DeviceBuffer<double> d_grp_prob;
+    b->upload.reset(new rpvg_hip_batch::UploadInProgress());
+    rpvg_hip_batch::UploadInProgress & up = *b->upload;
+    up.num_groups = G;
     scope.reset(new HostScope("batch_upload: copies queued"));
 
     const int span = ctx->spanBegin(FAM_H2D);
@@ -778,56 +795,68 @@ int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpv
     ok(b->cluster_row_off.upload(hb->cluster_row_off, K + 1, ctx->stream));
     ok(b->cluster_path_off.upload(hb->cluster_path_off, K + 1, ctx->stream));
     ok(b->row_noise.upload(hb->row_noise, R, ctx->stream));
-    ok(d_row_count_u32.upload(hb->row_count, R, ctx->stream));
+    ok(up.d_row_count_u32.upload(hb->row_count, R, ctx->stream));
     const uint64_t zero_off[1] = {0};
-    ok(d_row_grp_off.upload(R ? hb->row_grp_off : zero_off, R + 1, ctx->stream));
-    ok(d_grp_idx_off.upload(G ? hb->grp_idx_off : zero_off, G + 1, ctx->stream));
-    ok(d_grp_prob.upload(hb->grp_prob, G, ctx->stream));
+    ok(up.d_row_grp_off.upload(R ? hb->row_grp_off : zero_off, R + 1, ctx->stream));
+    ok(up.d_grp_idx_off.upload(G ? hb->grp_idx_off : zero_off, G + 1, ctx->stream));
+    ok(up.d_grp_prob.upload(hb->grp_prob, G, ctx->stream));
     ok(b->ent_path.upload(hb->path_idx, NNZ, ctx->stream));
     ok(b->ent_prob.alloc(NNZ));
     ok(b->row_count.alloc(R));
     ok(b->row_ent_off.alloc(R + 1));
+    // the path side, when the caller handed it in: PathInfo::group_id and source_ids (path_sources.hip)
+    if (e == hipSuccess) ok(queuePathSourceCopies(ctx, b, hb, up.path_sources));
     ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>((K + 1) * 16 + R * 12 + (R + 1) * 8 + (G + 1) * 8 + G * 8 + NNZ * 4);
     if (e != hipSuccess) {
         setError("rpvg_hip_batch_upload: %s", hipGetErrorString(e));
+        (void) hipStreamSynchronize(ctx->stream);
         delete b;
         return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
     }
+    *batch_out = b;
+    return RPVG_HIP_OK;
+}
 
-    scope.reset(new HostScope("batch_upload: kernels + wait"));
+// (the caller holds no lock; `b` is deleted on failure)
+static int uploadFinish(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_cluster_batch * hb) {
+    const uint32_t K = b->num_clusters;
+    const uint64_t R = b->num_rows, NNZ = b->num_entries;
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    hipError_t e = hipSetDevice(ctx->device);
+    rpvg_hip_batch::UploadInProgress & up = *b->upload;
+    const uint64_t G = up.num_groups;
+    HostScope scope("batch_upload: kernels + wait");
     const int bspan = ctx->spanBegin(FAM_BUILD);
-    if (G > 0) {
+    if (e == hipSuccess && G > 0) {
         const uint32_t threads = 256;
         expandGroupsKernel<<<dim3(static_cast<uint32_t>((G + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            G, NNZ, d_grp_idx_off.ptr, d_grp_prob.ptr, b->ent_prob.ptr);
+            G, NNZ, up.d_grp_idx_off.ptr, up.d_grp_prob.ptr, b->ent_prob.ptr);
     }
-    {
+    if (e == hipSuccess) {
         const uint32_t threads = 256;
         rowMetaKernel<<<dim3(static_cast<uint32_t>((R + 1 + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            R, G, d_row_grp_off.ptr, d_grp_idx_off.ptr, d_row_count_u32.ptr, b->row_ent_off.ptr, b->row_count.ptr);
+            R, G, up.d_row_grp_off.ptr, up.d_grp_idx_off.ptr, up.d_row_count_u32.ptr, b->row_ent_off.ptr, b->row_count.ptr);
     }
     unsigned long long first_bad_row = ~0ull;
     DeviceBuffer<unsigned long long> d_first_bad_row;
-    e = d_first_bad_row.alloc(1);
+    if (e == hipSuccess) e = d_first_bad_row.alloc(1);
     if (e == hipSuccess) e = hipMemsetAsync(d_first_bad_row.ptr, 0xFF, sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess && R > 0) {
         const uint32_t threads = 256;
         validateRowsKernel<<<dim3(static_cast<uint32_t>((R + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            R, G, NNZ, K, b->cluster_row_off.ptr, b->cluster_path_off.ptr, d_row_grp_off.ptr, d_grp_idx_off.ptr, b->row_noise.ptr,
+            R, G, NNZ, K, b->cluster_row_off.ptr, b->cluster_path_off.ptr, up.d_row_grp_off.ptr, up.d_grp_idx_off.ptr, b->row_noise.ptr,
             b->ent_path.ptr, d_first_bad_row.ptr);
     }
     // read counts per cluster (the host summed three million of them per batch with a team of its own)
     DeviceBuffer<double> d_cluster_total;
     b->h_cluster_total.assign(K, 0.0);
     if (e == hipSuccess) e = d_cluster_total.alloc(K);
-    if (e == hipSuccess) e = queueClusterTotals(ctx->stream, K, b->cluster_row_off.ptr, d_row_count_u32.ptr, d_cluster_total.ptr);
+    if (e == hipSuccess) e = queueClusterTotals(ctx->stream, K, b->cluster_row_off.ptr, up.d_row_count_u32.ptr, d_cluster_total.ptr);
+    if (e == hipSuccess) e = queuePathSourceKernels(ctx, b, up.path_sources);
     ctx->spanEnd(bspan);
-    ctx->stats.build_launches += 4;
+    ctx->stats.build_launches += 5;
     if (e == hipSuccess) e = hipGetLastError();
-    // the path side, when the caller handed it in: PathInfo::group_id and the haplotype columns of every cluster (path_sources.hip)
-    PathSourcesPending path_sources;
-    if (e == hipSuccess) e = queuePathSources(ctx, b, hb, path_sources);
     if (e == hipSuccess) e = hipMemcpyAsync(&first_bad_row, d_first_bad_row.ptr, sizeof(first_bad_row), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && K > 0) e = hipMemcpyAsync(b->h_cluster_total.data(), d_cluster_total.ptr, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = waitStream(ctx->stream);  // temporaries are freed on return
@@ -850,13 +879,49 @@ int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpv
         setError("%s", message);
         return RPVG_HIP_ERR_INVALID;
     }
-    const int sources_rc = finishPathSources(b, path_sources);
+    const int sources_rc = finishPathSources(b, up.path_sources);
     if (sources_rc != RPVG_HIP_OK) {
         delete b;
         return sources_rc;
     }
+    b->upload.reset();
+    return RPVG_HIP_OK;
+}
+
+int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_hip_batch ** batch_out) {
+    rpvg_hip_batch * b = nullptr;
+    int rc = uploadBegin(ctx, hb, &b);
+    if (rc != RPVG_HIP_OK) return rc;
+    rc = uploadFinish(ctx, b, hb);  // (same stream: behind the copies)
+    if (rc != RPVG_HIP_OK) return rc;
     *batch_out = b;
     return RPVG_HIP_OK;
+}
+
+int rpvg_hip_batch_upload_begin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_hip_batch ** batch_out) {
+    rpvg_hip_batch * b = nullptr;
+    const int rc = uploadBegin(ctx, hb, &b);
+    if (rc != RPVG_HIP_OK) return rc;
+    hipError_t e = hipSuccess;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        e = waitStream(ctx->stream);  // the copies are done: any context of the device may finish the batch
+    }
+    if (e != hipSuccess) {
+        setError("rpvg_hip_batch_upload_begin: %s", hipGetErrorString(e));
+        delete b;
+        return RPVG_HIP_ERR_RUNTIME;
+    }
+    *batch_out = b;
+    return RPVG_HIP_OK;
+}
+
+int rpvg_hip_batch_upload_finish(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch, const rpvg_cluster_batch * hb) {
+    RPVG_REQUIRE(ctx != nullptr && batch != nullptr && hb != nullptr, "rpvg_hip_batch_upload_finish: NULL argument");
+    RPVG_REQUIRE(batch->upload != nullptr, "rpvg_hip_batch_upload_finish: the batch is complete already");
+    RPVG_REQUIRE(hb->num_clusters == batch->num_clusters && hb->cluster_row_off && hb->cluster_row_off[hb->num_clusters] == batch->num_rows,
+                 "rpvg_hip_batch_upload_finish: not the host batch the upload began with");
+    return uploadFinish(ctx, batch, hb);
 }
 
 void rpvg_hip_batch_free(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch) {

@@ -256,7 +256,7 @@ hipError_t queueClusterTotals(hipStream_t stream, const uint32_t num_clusters, c
     return hipGetLastError();
 }
 
-hipError_t queuePathSources(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_cluster_batch * hb, PathSourcesPending & pending) {
+hipError_t queuePathSourceCopies(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_cluster_batch * hb, PathSourcesPending & pending) {
     const uint32_t K = hb->num_clusters;
     const uint64_t P = hb->cluster_path_off[K];
     pending.K = K;
@@ -268,33 +268,41 @@ hipError_t queuePathSources(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_c
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     b->h_cluster_src_off.resize(K + 1);
     for (uint32_t k = 0; k <= K; ++k) b->h_cluster_src_off[k] = hb->path_source_off[hb->cluster_path_off[k]];
-    const int span = ctx->spanBegin(FAM_H2D);
     ok(b->path_group_id.upload(hb->path_group_id, P, st));
     ok(pending.d_path_source_off.upload(hb->path_source_off, P + 1, st));
     ok(pending.d_source_id.upload(hb->source_id, S, st));
     ok(b->cluster_src_off.upload(b->h_cluster_src_off.data(), K + 1, st));
-    ctx->spanEnd(span);
     ctx->stats.h2d_bytes += static_cast<double>(P * 12 + S * 4 + K * 8);
     ok(b->src_col_count.alloc(S));
     ok(b->src_col_end.alloc(S));
     ok(b->src_col_path.alloc(S));
     // scratch of the clusters whose id range or path count outgrows LDS: eight words per incidence, at least 128 MB
-    const unsigned long long arena_words = std::max<unsigned long long>(1ull << 24, 8ull * S);
-    ok(pending.d_arena.alloc(arena_words + 1));
+    pending.arena_words = std::max<unsigned long long>(1ull << 24, 8ull * S);
+    pending.num_sources = S;
+    ok(pending.d_arena.alloc(pending.arena_words + 1));
     ok(pending.d_sizes.alloc(3 * static_cast<size_t>(K) + 2));
     if (e == hipSuccess && pinnedAlloc(&pending.h_sizes, (3 * static_cast<size_t>(K) + 2) * sizeof(uint32_t)) != hipSuccess) e = hipErrorOutOfMemory;
-    if (e != hipSuccess) return e;
-    ok(hipMemsetAsync(pending.d_arena.ptr + arena_words, 0, sizeof(unsigned long long), st));
+    pending.copied = (e == hipSuccess);
+    return e;
+}
+
+hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSourcesPending & pending) {
+    if (!pending.copied) return hipSuccess;
+    const uint32_t K = pending.K;
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    ok(hipMemsetAsync(pending.d_arena.ptr + pending.arena_words, 0, sizeof(unsigned long long), st));
     ok(hipMemsetAsync(pending.d_sizes.ptr + 3 * static_cast<size_t>(K), 0, 2 * sizeof(uint32_t), st));
     SourceArgs a;
     a.num_clusters = K;
     a.cluster_path_off = b->cluster_path_off.ptr;
     a.path_source_off = pending.d_path_source_off.ptr;
     a.source_id = pending.d_source_id.ptr;
-    a.num_sources = S;
+    a.num_sources = pending.num_sources;
     a.arena = pending.d_arena.ptr;
-    a.arena_words = arena_words;
-    a.arena_cursor = pending.d_arena.ptr + arena_words;
+    a.arena_words = pending.arena_words;
+    a.arena_cursor = pending.d_arena.ptr + pending.arena_words;
     a.col_count = b->src_col_count.ptr;
     a.col_end = b->src_col_end.ptr;
     a.col_path = b->src_col_path.ptr;
@@ -302,13 +310,10 @@ hipError_t queuePathSources(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_c
     a.num_col_paths = pending.d_sizes.ptr + K;
     a.max_col_paths = pending.d_sizes.ptr + 2 * static_cast<size_t>(K);
     a.flags = pending.d_sizes.ptr + 3 * static_cast<size_t>(K);
-    const int bspan = ctx->spanBegin(FAM_BUILD);
     if (e == hipSuccess) {
         sourceColumnsKernel<<<dim3(K), dim3(kBlock), 0, st>>>(a);
         ok(hipGetLastError());
     }
-    ctx->spanEnd(bspan);
-    ctx->stats.build_launches += 1;
     ok(hipMemcpyAsync(pending.h_sizes, pending.d_sizes.ptr, (3 * static_cast<size_t>(K) + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     pending.queued = (e == hipSuccess);
     return e;

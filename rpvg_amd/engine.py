@@ -65,6 +65,18 @@ def lib() -> C.CDLL:
         L.rpvg_amd_group_run.argtypes = [C.c_void_p, C.POINTER(CClusterBatch), C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double)]
         L.rpvg_amd_group_partition.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.rpvg_amd_group_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        L.rpvg_amd_pipeline_create.restype = C.c_void_p
+        L.rpvg_amd_pipeline_create.argtypes = [C.c_int, C.c_char_p, C.POINTER(CParams), C.c_int]
+        L.rpvg_amd_pipeline_destroy.argtypes = [C.c_void_p]
+        L.rpvg_amd_pipeline_workers.argtypes = [C.c_void_p]
+        L.rpvg_amd_pipeline_prepare_slots.argtypes = [C.c_void_p, C.POINTER(CClusterBatch), C.c_int]
+        L.rpvg_amd_pipeline_submit.argtypes = [C.c_void_p, C.POINTER(CClusterBatch), C.c_int]
+        L.rpvg_amd_pipeline_wait.argtypes = [C.c_void_p]
+        L.rpvg_amd_pipeline_result.restype = C.c_void_p
+        L.rpvg_amd_pipeline_result.argtypes = [C.c_void_p, C.c_int]
+        L.rpvg_amd_pipeline_stats_get.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.rpvg_amd_pipeline_stats_reset.argtypes = [C.c_void_p]
+        L.rpvg_amd_pipeline_completions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.rpvg_amd_result_view.argtypes = [C.c_void_p, C.POINTER(CEstimatesView)]
         L.rpvg_amd_result_free.argtypes = [C.c_void_p]
         _lib = L
@@ -230,6 +242,85 @@ class DeviceGroup:
         if lib().rpvg_amd_group_gather(self.handle, C.c_void_p(out.ctypes.data), capacity, C.byref(count), C.byref(total)) != 0:
             raise hip.EngineError(f"group gather failed: {_err()}")
         return out[:count.value].copy(), total.value
+
+
+class Pipeline:
+    """Several batches in flight on one GPU (rpvg_amd/host/batch_pipeline.hpp): an uploader thread and `workers` estimator
+    threads, each with an engine of its own; submit() returns at once, wait() when every submitted batch is done."""
+
+    def __init__(self, model: str, params: CParams, device: int = 0, workers: int = 0):
+        self.handle = lib().rpvg_amd_pipeline_create(device, model.encode(), C.byref(params), workers)
+        if not self.handle:
+            raise hip.EngineError(f"pipeline create failed: {_err()}")
+        self._keep = []  # the host batches (and their C views) of the submissions since the last wait()
+
+    @property
+    def workers(self) -> int:
+        return int(lib().rpvg_amd_pipeline_workers(self.handle))
+
+    def prepare_slots(self, batch: ClusterBatch, slots: int):
+        """`slots` sets of estimates containers for batches with the clusters (paths) of `batch`."""
+        cb = batch.as_c()
+        if lib().rpvg_amd_pipeline_prepare_slots(self.handle, C.byref(cb), slots) != 0:
+            raise hip.EngineError(f"pipeline prepare failed: {_err()}")
+
+    def submit(self, batch: ClusterBatch, slot: int):
+        cb = batch.as_c()
+        self._keep.append((batch, cb))
+        if lib().rpvg_amd_pipeline_submit(self.handle, C.byref(cb), slot) != 0:
+            raise hip.EngineError(f"pipeline submit failed: {_err()}")
+
+    def wait(self):
+        rc = lib().rpvg_amd_pipeline_wait(self.handle)
+        self._keep.clear()
+        if rc != 0:
+            raise hip.EngineError(f"pipeline batch failed: {_err()}")
+
+    def result(self, slot: int) -> List[ClusterEstimates]:
+        h = lib().rpvg_amd_pipeline_result(self.handle, slot)
+        if not h:
+            raise hip.EngineError(f"pipeline result failed: {_err()}")
+        try:
+            view = CEstimatesView()
+            lib().rpvg_amd_result_view(h, C.byref(view))
+            return decode_view(view)
+        finally:
+            lib().rpvg_amd_result_free(h)
+
+    def stats(self) -> dict:
+        s = hip.CKernelStats()
+        up = (C.c_double * 6)()
+        if lib().rpvg_amd_pipeline_stats_get(self.handle, C.byref(s), up) != 0:
+            raise hip.EngineError(f"pipeline stats failed: {_err()}")
+        out = s.as_dict()
+        out["upload_seconds_per_batch"] = up[0]
+        out["upload_copies_ms_per_batch"] = up[1]   # HIP-event span around the H2D copies of a batch
+        out["upload_kernels_ms_per_batch"] = up[2]  # ... around the kernels behind them
+        out["worker_finish_ms_per_batch"], out["worker_estimate_ms_per_batch"], out["worker_idle_ms_per_batch"] = up[3] * 1e3, up[4] * 1e3, up[5] * 1e3
+        return out
+
+    def reset_stats(self):
+        if lib().rpvg_amd_pipeline_stats_reset(self.handle) != 0:
+            raise hip.EngineError(f"pipeline stats reset failed: {_err()}")
+
+    def completions(self, capacity: int = 4096):
+        """Seconds since the last reset_stats() at which the batches since then were done, in order of completion."""
+        import numpy as np
+        out = np.zeros(capacity, dtype=np.float64)
+        count = C.c_uint64(0)
+        lib().rpvg_amd_pipeline_completions(self.handle, C.c_void_p(out.ctypes.data), capacity, C.byref(count))
+        return out[:min(capacity, count.value)].copy()
+
+    def close(self):
+        if self.handle:
+            lib().rpvg_amd_pipeline_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PreparedBatch:

@@ -31,7 +31,7 @@ EXPORTS = [
     "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_sizes", "rpvg_hip_read_rows_free", "rpvg_hip_path_clusters", "rpvg_hip_debug_log",
     "rpvg_hip_nested_subset_em", "rpvg_hip_subset_em_get", "rpvg_hip_subset_em_free",
     "rpvg_hip_batch_cluster_totals", "rpvg_hip_batch_has_source_columns", "rpvg_hip_batch_source_columns_sizes",
-    "rpvg_hip_batch_source_columns_get", "rpvg_hip_groups_build_from_sources",
+    "rpvg_hip_batch_source_columns_get", "rpvg_hip_groups_build_from_sources", "rpvg_hip_batch_upload_begin", "rpvg_hip_batch_upload_finish", "rpvg_hip_create_with_streams",
 ]
 
 COMM_ID_BYTES = 128  # RPVG_HIP_COMM_ID_BYTES

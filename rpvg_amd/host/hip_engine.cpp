@@ -29,10 +29,41 @@ static void keepHeapTop() {
     });
 }
 
-HipEngine::HipEngine(const int device, const bool uploader) : context(nullptr), device_id(device) {
+static int defaultHostLanes() {
+
+    if (std::getenv("RPVG_AMD_SINGLE_LANE")) {
+
+        return 1;
+    }
+
+    const char * env = std::getenv("RPVG_AMD_LANES");
+    return env ? std::max(1, std::min(HipEngine::max_lanes, std::atoi(env))) : 2;
+}
+
+HipEngine::HipEngine(const int device, const bool uploader, const int host_lanes_in) : context(nullptr), device_id(device), host_lanes(host_lanes_in > 0 ? std::min(host_lanes_in, max_lanes) : defaultHostLanes()) {
 
     keepHeapTop();
-    check(uploader ? rpvg_hip_create_uploader(device, &context) : rpvg_hip_create(device, &context), "rpvg_hip_create");
+
+    // an engine that runs whole batches (one lane) stands next to others like it on the GPU (BatchPipeline): few side streams,
+    // so that all of them together stay within the hardware queues (RPVG_AMD_SIDE_STREAMS: A/B)
+    static const int lean_side_streams = []() {
+
+        const char * env = std::getenv("RPVG_AMD_SIDE_STREAMS");
+        return env ? std::max(1, std::min(6, std::atoi(env))) : 3;
+    }();
+
+    if (uploader) {
+
+        check(rpvg_hip_create_uploader(device, &context), "rpvg_hip_create");
+
+    } else if (host_lanes_in == 1) {
+
+        check(rpvg_hip_create_with_streams(device, lean_side_streams, &context), "rpvg_hip_create");
+
+    } else {
+
+        check(rpvg_hip_create(device, &context), "rpvg_hip_create");
+    }
 }
 
 HipEngine::~HipEngine() {
@@ -71,12 +102,26 @@ int & HipEngine::currentLane() {
 
 void HipEngine::stats(rpvg_hip_kernel_stats * stats_out) const {
 
-    check(rpvg_hip_stats_get(context, stats_out), "rpvg_hip_stats_get");
+    stats(std::vector<const HipEngine *>(1, this), stats_out);
+}
 
-    for (auto & lane_context: lane_contexts) {
+void HipEngine::stats(const std::vector<const HipEngine *> & engines, rpvg_hip_kernel_stats * stats_out) {
+
+    std::vector<rpvg_hip_ctx *> contexts;
+
+    for (auto & engine: engines) {
+
+        contexts.emplace_back(engine->context);
+        contexts.insert(contexts.end(), engine->lane_contexts.begin(), engine->lane_contexts.end());
+    }
+
+    assert(!contexts.empty());
+    check(rpvg_hip_stats_get(contexts.front(), stats_out), "rpvg_hip_stats_get");
+
+    for (size_t c = 1; c < contexts.size(); ++c) {
 
         rpvg_hip_kernel_stats lane_stats;
-        check(rpvg_hip_stats_get(lane_context, &lane_stats), "rpvg_hip_stats_get");
+        check(rpvg_hip_stats_get(contexts[c], &lane_stats), "rpvg_hip_stats_get");
 
         stats_out->em_sparse_ms += lane_stats.em_sparse_ms;
         stats_out->em_sparse_launches += lane_stats.em_sparse_launches;
@@ -108,10 +153,10 @@ void HipEngine::stats(rpvg_hip_kernel_stats * stats_out) const {
         }
     }
 
-    // busy time: the union of the timed spans of all lanes (their contexts share the GPU's clock)
+    // busy time: the union of the timed spans of all contexts (the contexts of a GPU share its clock)
     std::vector<std::pair<double, double> > spans;
 
-    auto collect = [&](rpvg_hip_ctx * ctx) {
+    for (auto & ctx: contexts) {
 
         uint64_t count = 0;
         check(rpvg_hip_stats_intervals(ctx, 0, nullptr, nullptr, nullptr, &count), "rpvg_hip_stats_intervals");
@@ -123,13 +168,6 @@ void HipEngine::stats(rpvg_hip_kernel_stats * stats_out) const {
 
             spans.emplace_back(start[i], stop[i]);
         }
-    };
-
-    collect(context);
-
-    for (auto & lane_context: lane_contexts) {
-
-        collect(lane_context);
     }
 
     std::sort(spans.begin(), spans.end());
@@ -277,9 +315,25 @@ PipelineWorker & HipEngine::lane(const int lane) {
     return *lane_workers.at(lane - 1);
 }
 
-DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch) : hip_engine(engine_in), batch(nullptr) {
+DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch, const bool finish_later) : hip_engine(engine_in), batch(nullptr), unfinished_host_batch(host_batch), unfinished(finish_later) {
 
     assert(hip_engine);
+
+    num_rows.resize(host_batch.num_clusters);
+    num_paths.resize(host_batch.num_clusters);
+
+    for (uint32_t i = 0; i < host_batch.num_clusters; ++i) {
+
+        num_rows[i] = host_batch.cluster_row_off[i + 1] - host_batch.cluster_row_off[i];
+        num_paths[i] = host_batch.cluster_path_off[i + 1] - host_batch.cluster_path_off[i];
+    }
+
+    if (finish_later) {
+
+        ScopedPhase upload_phase("device batch: rpvg_hip_batch_upload_begin");
+        HipEngine::check(rpvg_hip_batch_upload_begin(hip_engine->ctx(), &host_batch, &batch), "rpvg_hip_batch_upload_begin");
+        return;
+    }
 
     {
         ScopedPhase upload_phase("device batch: rpvg_hip_batch_upload");
@@ -288,20 +342,29 @@ DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, con
 
     // (the read count of every cluster comes back from the device with the upload: the sum over three million rows per batch was
     // a team of its own on the uploading thread)
-    num_rows.resize(host_batch.num_clusters);
-    num_paths.resize(host_batch.num_clusters);
     total_read_count.resize(host_batch.num_clusters);
-
     HipEngine::check(rpvg_hip_batch_cluster_totals(batch, total_read_count.data(), host_batch.num_clusters), "rpvg_hip_batch_cluster_totals");
-
-    for (uint32_t i = 0; i < host_batch.num_clusters; ++i) {
-
-        num_rows[i] = host_batch.cluster_row_off[i + 1] - host_batch.cluster_row_off[i];
-        num_paths[i] = host_batch.cluster_path_off[i + 1] - host_batch.cluster_path_off[i];
-    }
 }
 
-DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, rpvg_hip_batch * device_batch, const rpvg_cluster_batch & offsets, const std::vector<double> & total_read_count_in) : hip_engine(engine_in), batch(device_batch), total_read_count(total_read_count_in) {
+void DeviceClusterBatch::finish(std::shared_ptr<HipEngine> engine_in) {
+
+    assert(unfinished && batch);
+    hip_engine = engine_in;
+
+    ScopedPhase finish_phase("device batch: rpvg_hip_batch_upload_finish");
+
+    rpvg_hip_batch * unfinished_batch = batch;
+    batch = nullptr;  // (a batch that fails its second half is freed by the call)
+    unfinished = false;
+
+    HipEngine::check(rpvg_hip_batch_upload_finish(hip_engine->ctx(), unfinished_batch, &unfinished_host_batch), "rpvg_hip_batch_upload_finish");
+    batch = unfinished_batch;
+
+    total_read_count.resize(num_rows.size());
+    HipEngine::check(rpvg_hip_batch_cluster_totals(batch, total_read_count.data(), num_rows.size()), "rpvg_hip_batch_cluster_totals");
+}
+
+DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, rpvg_hip_batch * device_batch, const rpvg_cluster_batch & offsets, const std::vector<double> & total_read_count_in) : hip_engine(engine_in), batch(device_batch), total_read_count(total_read_count_in), unfinished_host_batch(offsets), unfinished(false) {
 
     assert(hip_engine);
     assert(batch);
@@ -316,7 +379,10 @@ DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, rpv
 
 DeviceClusterBatch::~DeviceClusterBatch() {
 
-    rpvg_hip_batch_free(hip_engine->ctx(), batch);
+    if (batch) {
+
+        rpvg_hip_batch_free(hip_engine->ctx(), batch);
+    }
 }
 
 }

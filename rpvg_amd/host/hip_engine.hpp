@@ -32,7 +32,9 @@ class HipEngine {
 
         // uploader: an engine whose only job is DeviceClusterBatch construction next to an estimating engine on the same GPU
         // (rpvg_hip_create_uploader: a stream, and a hardware queue, of its own)
-        explicit HipEngine(const int device, const bool uploader = false);
+        // host_lanes: host lanes a batch is cut into (PathEstimator::runInLanes); 0 = the default (RPVG_AMD_LANES, else 2) —
+        // the engines of a BatchPipeline run whole batches side by side instead and take 1
+        explicit HipEngine(const int device, const bool uploader = false, const int host_lanes = 0);
         ~HipEngine();
 
         HipEngine(const HipEngine &) = delete;
@@ -47,6 +49,7 @@ class HipEngine {
             return (lane > 0 && static_cast<size_t>(lane) <= lane_contexts.size()) ? lane_contexts[lane - 1] : context;
         }
         int device() const { return device_id; }
+        int hostLanes() const { return host_lanes; }
 
         // Lane of the calling thread (thread local; 0 by default).
         static int & currentLane();
@@ -54,6 +57,9 @@ class HipEngine {
         // Kernel statistics of both lanes together (include/rpvg_hip.h, rpvg_hip_kernel_stats).
         void stats(rpvg_hip_kernel_stats * stats_out) const;
         void resetStats() const;
+
+        // The same over several engines of one GPU (the workers of a BatchPipeline): sums, and the union of their busy spans.
+        static void stats(const std::vector<const HipEngine *> & engines, rpvg_hip_kernel_stats * stats_out);
 
         static int deviceCount();
 
@@ -75,6 +81,7 @@ class HipEngine {
 
         rpvg_hip_ctx * context;
         int device_id;
+        int host_lanes;
 
         std::mutex lane_mutex;
         std::vector<rpvg_hip_ctx *> lane_contexts;
@@ -110,7 +117,10 @@ class DeviceClusterBatch {
 
     public:
 
-        DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch);
+        // finish_later: only the copies are made here, on engine_in's context (rpvg_hip_batch_upload_begin) — finish() runs the
+        // kernels behind them on another engine of the GPU, which owns the batch from then on; host_batch stays valid until then
+        DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch, const bool finish_later = false);
+        void finish(std::shared_ptr<HipEngine> engine_in);
 
         // Adopts a batch that was built on the device (row construction, read_rows.hpp).  `offsets` carries
         // cluster_row_off / cluster_path_off only; total_read_count_in the read count of every cluster.
@@ -120,6 +130,10 @@ class DeviceClusterBatch {
 
         DeviceClusterBatch(const DeviceClusterBatch &) = delete;
         DeviceClusterBatch & operator=(const DeviceClusterBatch &) = delete;
+
+        // Hands the batch to another engine of the same GPU (a batch is made by an uploader's context and used, and freed, by an
+        // estimator's: the free would otherwise wait for whatever the uploader is copying).
+        void rehome(std::shared_ptr<HipEngine> engine_in) { hip_engine = engine_in; }
 
         const rpvg_hip_batch * handle() const { return batch; }
         const std::shared_ptr<HipEngine> & engine() const { return hip_engine; }
@@ -143,6 +157,9 @@ class DeviceClusterBatch {
         std::vector<uint64_t> num_rows;
         std::vector<uint32_t> num_paths;
         std::vector<double> total_read_count;
+
+        rpvg_cluster_batch unfinished_host_batch;
+        bool unfinished;
 };
 
 }

@@ -530,16 +530,7 @@ void PathEstimator::estimate(PathClusterEstimates * path_cluster_estimates, cons
 // lanes' kernels (separate device contexts) overlap each other's tails.
 void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std::function<void(const std::vector<uint32_t> &, const std::function<void()> &)> & work) const {
 
-    static const int num_lanes = []() {
-
-        if (std::getenv("RPVG_AMD_SINGLE_LANE")) {
-
-            return 1;
-        }
-
-        const char * env = std::getenv("RPVG_AMD_LANES");
-        return env ? std::max(1, std::min(HipEngine::max_lanes, std::atoi(env))) : 2;
-    }();
+    const int num_lanes = engine->hostLanes();  // (RPVG_AMD_LANES, default 2; the engines of a BatchPipeline: 1)
 
     if (num_lanes == 1 || clusters.size() < 64 || HipEngine::currentLane() != 0) {
 

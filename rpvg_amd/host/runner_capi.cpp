@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/rpvg_batch.h"
+#include "batch_pipeline.hpp"
 #include "device_group.hpp"
 #include "estimator_factory.hpp"
 #include "read_rows.hpp"
@@ -671,6 +672,168 @@ int rpvg_amd_group_gather(void * group_handle, double * abundances_out, uint64_t
 
         std::copy(gathered.begin(), gathered.end(), abundances_out);
         *count_out = gathered.size();
+        return 0;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
+// ---- several batches in flight on one GPU (batch_pipeline.hpp) --------------------------------------------------------
+
+struct Pipeline {
+
+    std::unique_ptr<BatchPipeline> pipeline;
+
+    // the containers the estimates of the batches in flight go to: a harness hands the same host batch in again and again,
+    // and every batch in flight needs containers of its own
+    std::vector<std::vector<PathClusterEstimates> > slots;
+};
+
+void * rpvg_amd_pipeline_create(int device, const char * model, const rpvg_params * params, int workers) {
+
+    try {
+
+        Pipeline * pipeline = new Pipeline();
+        std::unique_ptr<Pipeline> guard(pipeline);
+        pipeline->pipeline.reset(new BatchPipeline(device, model, *params, workers));
+        return guard.release();
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return nullptr;
+    }
+}
+
+void rpvg_amd_pipeline_destroy(void * pipeline) {
+
+    delete static_cast<Pipeline *>(pipeline);
+}
+
+int rpvg_amd_pipeline_workers(void * pipeline) {
+
+    return static_cast<Pipeline *>(pipeline)->pipeline->numWorkers();
+}
+
+// `slots` sets of estimates containers with the PathInfo of the batch's clusters filled in (src/main.cpp:855-887).
+int rpvg_amd_pipeline_prepare_slots(void * pipeline_handle, const rpvg_cluster_batch * batch, int slots) {
+
+    try {
+
+        Pipeline * pipeline = static_cast<Pipeline *>(pipeline_handle);
+        pipeline->pipeline->wait();
+
+        const auto paths = unpackPaths(*batch);
+        pipeline->slots.assign(slots, std::vector<PathClusterEstimates>(paths.size()));
+
+        for (auto & slot: pipeline->slots) {
+
+            for (size_t i = 0; i < paths.size(); ++i) {
+
+                slot.at(i).paths = paths.at(i);
+            }
+        }
+
+        return 0;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
+// Queues one batch (its arrays stay the caller's until rpvg_amd_pipeline_wait returns) with the containers of `slot`.
+int rpvg_amd_pipeline_submit(void * pipeline_handle, const rpvg_cluster_batch * batch, int slot) {
+
+    try {
+
+        Pipeline * pipeline = static_cast<Pipeline *>(pipeline_handle);
+        pipeline->pipeline->submit(*batch, &pipeline->slots.at(slot));
+        return 0;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
+int rpvg_amd_pipeline_wait(void * pipeline_handle) {
+
+    try {
+
+        static_cast<Pipeline *>(pipeline_handle)->pipeline->wait();
+        return 0;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
+// The estimates a finished batch left in the containers of `slot` (call after rpvg_amd_pipeline_wait).
+void * rpvg_amd_pipeline_result(void * pipeline_handle, int slot) {
+
+    try {
+
+        return packResult(static_cast<Pipeline *>(pipeline_handle)->slots.at(slot));
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return nullptr;
+    }
+}
+
+int rpvg_amd_pipeline_stats_get(void * pipeline_handle, rpvg_hip_kernel_stats * stats_out, double * mean_upload_seconds_out) {
+
+    try {
+
+        Pipeline * pipeline = static_cast<Pipeline *>(pipeline_handle);
+        pipeline->pipeline->stats(stats_out);
+
+        if (mean_upload_seconds_out) {
+
+            uint64_t batches = 0;
+            mean_upload_seconds_out[0] = pipeline->pipeline->meanUploadSeconds(&batches);
+
+            // [1], [2]: device milliseconds per batch of the uploads' copies and of the kernels behind them
+            pipeline->pipeline->uploadDeviceMs(mean_upload_seconds_out + 1, mean_upload_seconds_out + 2);
+            mean_upload_seconds_out[1] /= std::max<uint64_t>(1, batches);
+            mean_upload_seconds_out[2] /= std::max<uint64_t>(1, batches);
+
+            // [3], [4], [5]: wall seconds per batch of a worker's upload finish, estimate, and wait for a resident batch
+            pipeline->pipeline->workerSeconds(mean_upload_seconds_out + 3, mean_upload_seconds_out + 4, mean_upload_seconds_out + 5);
+        }
+
+        return 0;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
+// Completion times of the batches since the last statistics reset (seconds since that reset, in order of completion).
+int rpvg_amd_pipeline_completions(void * pipeline_handle, double * seconds_out, uint64_t capacity, uint64_t * count_out) {
+
+    const auto completions = static_cast<Pipeline *>(pipeline_handle)->pipeline->completionSeconds();
+    *count_out = completions.size();
+    std::copy(completions.begin(), completions.begin() + std::min<size_t>(capacity, completions.size()), seconds_out);
+    return 0;
+}
+
+int rpvg_amd_pipeline_stats_reset(void * pipeline_handle) {
+
+    try {
+
+        static_cast<Pipeline *>(pipeline_handle)->pipeline->resetStats();
         return 0;
 
     } catch (const std::exception & e) {

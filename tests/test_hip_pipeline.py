@@ -185,3 +185,60 @@ def test_batches_arriving_through_an_uploader_engine():
             hip.host_unregister(a)
         uploader.close()
         engine.close()
+
+
+@pytest.mark.parametrize("model,kw", [("haplotype-transcripts", {}), ("transcripts", {}), ("haplotypes", dict(use_hap_gibbs=1, rng_seed=5)),
+                                      ("haplotype-transcripts", dict(num_gibbs_samples=3, rng_seed=9))],
+                         ids=["nested", "transcripts", "haplotype-gibbs", "nested-read-count-samples"])
+def test_batches_in_flight_equal_one_call_after_the_other(model, kw):
+    """BatchPipeline (rpvg_amd/host/batch_pipeline.hpp): different batches in flight at once — an uploader thread, three
+    estimator threads with an engine each — leave the estimates the same batches get from one engine, one call after the
+    other, bit for bit (batches do not interact; cluster i of every batch draws from mt19937(rng_seed + i),
+    src/main.cpp:976).  Also: containers handed in again (a slot reused by a later batch) hold that later batch's estimates,
+    and a batch that fails (a path index outside its cluster) is reported by wait() without wedging the pipeline."""
+    params = make_params(**kw)
+    batches = [ClusterBatch.from_clusters(small_cases.make_batch_clusters(7300 + b, n_clusters=30, with_empty=True)) for b in range(3)]
+    # (all batches of a set of containers have the same clusters: the same paths; the rows differ)
+    base = small_cases.make_batch_clusters(7400, n_clusters=25, with_empty=True)
+    rng = np.random.default_rng(7401)
+    variants = []
+    for v in range(5):
+        clusters = []
+        for cl in base:
+            rows = [(int(c) + int(rng.integers(0, 3)), z, g) for (c, z, g) in cl["rows"]]
+            clusters.append(dict(paths=cl["paths"], rows=rows))
+        variants.append(ClusterBatch.from_clusters(clusters))
+    engine = eng_mod.Engine(0)
+    try:
+        expected = [engine.run(model, params, engine.prepare(b))[0] for b in variants]
+    finally:
+        engine.close()
+    pipe = eng_mod.Pipeline(model, params, 0, workers=3)
+    try:
+        pipe.prepare_slots(variants[0], 5)
+        for round_ in range(2):  # the second round reuses every slot
+            for v, b in enumerate(variants):
+                pipe.submit(b, (v + round_) % 5)
+            pipe.wait()
+            for v in range(len(variants)):
+                got = pipe.result((v + round_) % 5)
+                for k, (g, e) in enumerate(zip(got, expected[v])):
+                    assert g.path_group_sets == e.path_group_sets, (v, k)
+                    assert np.array_equal(g.posteriors, e.posteriors) and np.array_equal(g.abundances, e.abundances), (v, k)
+                    assert g.noise_count == e.noise_count and g.total_count == e.total_count, (v, k)
+                    assert g.em_iters == e.em_iters and g.em_cols == e.em_cols, (v, k)
+                    assert len(g.gibbs_samples) == len(e.gibbs_samples), (v, k)
+        # a bad batch between good ones
+        bad_fields = {name: getattr(variants[1], name).copy() for name in ClusterBatch._DTYPES}
+        bad_fields["path_idx"][0] = 10 ** 6
+        pipe.submit(variants[0], 0)
+        pipe.submit(ClusterBatch(**bad_fields), 1)
+        with pytest.raises(eng_mod.hip.EngineError, match="refers to path"):
+            pipe.wait()
+        pipe.submit(variants[2], 2)
+        pipe.wait()
+        got = pipe.result(2)
+        assert all(np.array_equal(g.posteriors, e.posteriors) for g, e in zip(got, expected[2]))
+    finally:
+        pipe.close()
+    del batches
