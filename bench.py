@@ -61,7 +61,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="s3", choices=["s3", "c2", "s5", "rows", "e2e"],
+    ap.add_argument("--workload", default="s3", choices=["s3", "c2", "s5", "rows", "e2e", "a1"],
                     help="s3: BASELINE.json configs[2]/[3] (default, the metric's configuration); c2: configs[1] single dense "
                          "cluster; s5: configs[4] diploid haplotype Gibbs, 10M reads x 500k paths; rows: the step before the path "
                          "(alignment paths -> merged rows, SURVEY.md 8f rank 2) on the configs[2] reads; e2e: rows + estimates in one "
@@ -77,6 +77,9 @@ def parse_args():
     ap.add_argument("--pipeline-workers", type=int, default=0,
                     help="s3/s5 headline: estimator threads of the batch pipeline (rpvg_amd/host/batch_pipeline.hpp) = batches estimated side by "
                          "side; 0 = the library's default (4)")
+    ap.add_argument("--team", type=int, default=1024,
+                    help="a1: threads of the OpenMP team that calls PathEstimator::estimate() (the reference's -t; the threads sleep in the "
+                         "call combiner while their batch is on the GPU, so a team far larger than the cores is what keeps batches in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -663,6 +666,50 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
                 sample_estimates=est)
 
 
+def run_a1(args, rank, local_rank, world, dist, torch):
+    """The reference's own call pattern on the configs[2] workload: PathEstimator::estimate() once per cluster from an OpenMP team
+    (src/main.cpp:829,976-977), clusters in the reference's order (src/main.cpp:811-827: descending read count, the order the
+    generator emits).  A step = all clusters of the batch through estimate(); rows start on the host (ReadPathProbabilities
+    objects, as the reference holds them) and every call flattens and uploads its own."""
+    import numpy as np
+    from rpvg_amd import synth, engine as eng_mod
+    from rpvg_amd.batch import make_params
+    params = make_params()
+    K = max(8, int(round(5000 * args.scale)))
+    total_paths = max(K, int(round(200000 * args.scale)))
+    total_reads = int(round(10000000 * args.scale))
+    batch = synth.generate(seed=3 + rank, num_clusters=K, total_paths=total_paths, total_reads=total_reads)
+    eng = eng_mod.Engine(local_rank)
+    t0 = time.perf_counter()
+    prepared = eng.prepare(batch, per_cluster=True)  # the rows as vector<ReadPathProbabilities> per cluster, on the host
+    prepare_s = time.perf_counter() - t0
+    steps, warmup = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+    for _ in range(warmup):
+        eng.run_team(args.model, params, prepared, args.team, decode=False)
+    barrier_sync(dist, torch)
+    t0 = time.perf_counter()
+    step_s = [eng.run_team(args.model, params, prepared, args.team, decode=False)[1] for _ in range(steps)]
+    barrier_sync(dist, torch)
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, torch)
+    est, _ = eng.run_team(args.model, params, prepared, args.team)
+    whole, _ = eng.run(args.model, params, eng.prepare(batch))
+    same = all(a.path_group_sets == b.path_group_sets and np.allclose(a.posteriors, b.posteriors, rtol=1e-9, atol=1e-12)
+               and np.allclose(a.abundances, b.abundances, rtol=1e-9, atol=1e-9) and a.em_iters == b.em_iters for a, b in zip(est, whole))
+    reads_all = sum_over_ranks(float(batch.total_reads), dist, torch)
+    if rank != 0:
+        return None
+    ms = elapsed / steps * 1e3
+    return dict(metric="read-pairs quantified/sec", value=reads_all / (ms / 1e3), unit="read-pairs/s", n_gpus=world, steps=steps, warmup=warmup,
+                ms_per_step=ms, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+                config=dict(workload=f"synthetic pantranscriptome: {total_reads} read pairs x {total_paths} paths in {K} clusters per GPU (BASELINE.json "
+                                     f"configs[2]), -i {args.model}, reference defaults — through PathEstimator::estimate(), one call per cluster "
+                                     f"from an OpenMP team of {args.team} threads (the reference's loop, src/main.cpp:829,976-977)",
+                            team_threads=args.team, clusters_per_gpu=K),
+                ms_per_step_in_order=[round(x * 1e3, 2) for x in step_s], estimates_equal_estimate_batch=bool(same), prepare_seconds=prepare_s,
+                note="every call flattens its cluster on its own thread; the calls in flight are joined into batches of up to 256 clusters behind "
+                     "the interface (PathEstimator::CallCombiner), up to three batches on the GPU at once; rows start on the host, uploads inside")
+
+
 def dense_em_roofline(local_rank, rows=1000000, paths=2000, its=20):
     """Short measurement of the HBM-streaming dense EM kernel (BASELINE.json configs[1] shape) for the roofline
     record of the default run: the batched kernels of the default workload run out of L2/LDS."""
@@ -979,7 +1026,7 @@ def main():
     rank, local_rank, world, dist, torch = dist_setup(args.gpus)
     if DEVICE == "cuda" and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    runner = dict(c2=run_c2, rows=run_rows, e2e=run_e2e).get(args.workload, run_s3)
+    runner = dict(c2=run_c2, rows=run_rows, e2e=run_e2e, a1=run_a1).get(args.workload, run_s3)
     line = runner(args, rank, local_rank, world, dist, torch)
     if dist is not None:
         dist.barrier()

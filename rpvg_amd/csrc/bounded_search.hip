@@ -47,12 +47,12 @@ const rpvg_hip_ctx * g_search_gate_owner = nullptr;  // context of the last sear
 // (it has nothing else to queue meanwhile); the stream wait stays, as the ordering guarantee.
 // RPVG_HIP_SEARCH_LAUNCH_EARLY=1: stream waits only (A/B).
 static bool searchLaunchesEarly() {
-    static const bool early = std::getenv("RPVG_HIP_SEARCH_LAUNCH_EARLY") != nullptr;
+    static const bool early = RPVG_EXPERIMENT_ENV("RPVG_HIP_SEARCH_LAUNCH_EARLY") != nullptr;
     return early;
 }
 
 static void searchGateEnter(const rpvg_hip_ctx * ctx, hipStream_t stream) {
-    static const bool open_gate = std::getenv("RPVG_HIP_NO_SEARCH_GATE") != nullptr;  // A/B knob
+    static const bool open_gate = RPVG_EXPERIMENT_ENV("RPVG_HIP_NO_SEARCH_GATE") != nullptr;  // A/B knob
     if (open_gate) return;
     hipEvent_t previous = nullptr;
     {
@@ -551,7 +551,6 @@ __global__ __launch_bounds__(256) void pairTableKernel(const TableWork w) {
 // Rows with read counts 2 .. kMidMaxCount multiply that many times, the others take the table logarithm, as everywhere.
 constexpr uint32_t kTileBlock = 256;
 constexpr uint32_t kTileLdsDoubles = 6 * 1024;   // staged values + noise + counts: 48 KB (three workgroups per CU)
-constexpr uint32_t kTileMaxSubRows = 256;
 constexpr uint32_t kTileMaxColumns = 1024;       // wider matrices keep the sequential search (their pair tables would not fit either)
 
 __host__ __device__ inline uint32_t tileColumns(const uint32_t G) { return (G + 3) / 4; }
@@ -582,256 +581,17 @@ struct PairTileWork {
     double * part_marginal;
     double * part_pair;
     unsigned long long * log_evals;
+#ifdef RPVG_HIP_EXPERIMENTS
     uint32_t debug_skip;  // timing experiments (RPVG_HIP_PAIR_DEBUG): 1 no count-1 rows, 2 no mid rows, 4 no other rows, 8 no marginals
+#endif
 };
 
-// (three waves per SIMD: what covers the LDS and staging latencies; 2.17 -> 1.61 ms per batch against two)
-__global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(3))) void pairTileKernel(const PairTileWork w) {
-    extern __shared__ __attribute__((aligned(16))) double tile_lds[];
-    __shared__ LogTableEntry lt[kLogTableSize];
-    // items come expensive first and share nothing: workgroup b takes item b, which deals them round-robin to the XCDs
-    // (contiguous ranges per XCD, as the kernels above have them for their L2, gave one XCD all the large matrices)
-    const uint32_t item = blockIdx.x;
-    if (item >= w.count) return;
-    const uint32_t m = w.item_matrix[item], chunk = w.item_chunk[item];
-    loadLogTable(lt);  // visible after the first barrier below
-    const uint64_t R = w.mat_rows[m];
-    const uint32_t G = w.mat_cols[m];
-    const uint32_t T = tileColumns(G), tiles = tileCount(G), S = tileSlices(G);
-    const uint32_t passes = (tiles + kTileBlock - 1) / kTileBlock;  // 1 whenever S > 1
-    const uint32_t Gs = 4 * T + 2;  // row stride in LDS: even (16-byte reads), 2 (mod 4) doubles (consecutive rows spread over the banks)
-    const uint32_t sub_rows = min(kTileMaxSubRows, kTileLdsDoubles / (Gs + 2));
-    double * const H = tile_lds;                                   // [sub_rows][Gs] halved values, row-major
-    double * const lds_noise = H + static_cast<size_t>(sub_rows) * Gs;  // [sub_rows]
-    double * const lds_count = lds_noise + sub_rows;               // [sub_rows]
-    const uint64_t r_begin = static_cast<uint64_t>(chunk) * kChunkRows;
-    const uint32_t n = static_cast<uint32_t>((R - r_begin) < kChunkRows ? (R - r_begin) : kChunkRows);
-    const double * M = w.values + w.mat_val_off[m] + r_begin;  // column-major: M[column * R + row]
-    const double * cnt = w.row_count + w.mat_row_off[m] + r_begin;
-    const double * nz = w.row_noise + w.mat_row_off[m] + r_begin;
-    auto local = [&](const uint64_t end_row) { return end_row <= r_begin ? 0u : (end_row - r_begin < n ? static_cast<uint32_t>(end_row - r_begin) : n); };
-    const uint32_t nf = local(w.mat_fast[m]), nm = local(w.mat_mid[m]);  // class boundaries within the chunk
-
-    // the lane's column of marginals (first pass only): columns 4 tc .. 4 tc + 3, every S-th row
-    const uint32_t SM = marginalSlices(G);
-    const uint32_t tc = threadIdx.x % T, marg_slice = threadIdx.x / T;
-    const bool marg_active = marg_slice < SM;
-
-    for (uint32_t pass = 0; pass < passes; ++pass) {
-        const uint32_t t = (S > 1 || passes == 1) ? threadIdx.x % tiles : pass * kTileBlock + threadIdx.x;
-        const uint32_t slice = (S > 1 || passes == 1) ? threadIdx.x / tiles : 0u;
-        const bool active = slice < S && t < tiles;
-        // tile t of the triangle, row by row: row ta starts at ta * T - ta (ta - 1) / 2
-        uint32_t ta = 0;
-        {
-            uint32_t lo = 0, hi = T - 1;
-            const uint32_t tt = t < tiles ? t : 0;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1) >> 1;
-                if (mid * T - mid * (mid - 1) / 2 <= tt) lo = mid; else hi = mid - 1;
-            }
-            ta = lo;
-        }
-        const uint32_t tb = ta + ((t < tiles ? t : 0) - (ta * T - ta * (ta > 0 ? ta - 1 : 0) / 2));
-        const bool with_marginals = pass == 0 && marg_active && !(w.debug_skip & 8u);
-
-        LogProduct pr[4][4], prm[4];
-        double acc[4][4], accm[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            accm[i] = 0.0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-        }
-        uint32_t since_fold = 0, since_fold_m = 0;
-        auto foldPairs = [&]() {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pr[i][j].fold();
-            }
-            since_fold = 0;
-        };
-        auto foldMarginals = [&]() {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) prm[i].fold();
-            since_fold_m = 0;
-        };
-
-        for (uint32_t s0 = 0; s0 < n; s0 += sub_rows) {
-            const uint32_t ns = (n - s0) < sub_rows ? (n - s0) : sub_rows;
-            __syncthreads();  // the rows staged before have been used
-            // lane = row (64 consecutive rows of a column: one 512-byte request), wave = column; eight requests of a
-            // thread are in flight before the first is stored (the loop is all latency otherwise: ~25 dependent round
-            // trips to memory per thread against ~5 us of arithmetic on the staged rows)
-            {
-                const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-                constexpr uint32_t kAhead = 8;
-                for (uint32_t rb = 0; rb < ns; rb += 64) {
-                    const uint32_t r = rb + lane;
-                    const bool row_ok = r < ns;
-                    const double * from = M + s0 + (row_ok ? r : 0u);
-                    for (uint32_t c0 = wave; c0 < 4 * T; c0 += 4 * kAhead) {
-                        double fetched[kAhead];
-#pragma unroll
-                        for (uint32_t k = 0; k < kAhead; ++k) {
-                            const uint32_t c = c0 + 4 * k;
-                            fetched[k] = __builtin_nontemporal_load(from + static_cast<uint64_t>(c < G ? c : 0u) * R);
-                        }
-#pragma unroll
-                        for (uint32_t k = 0; k < kAhead; ++k) {
-                            const uint32_t c = c0 + 4 * k;
-                            if (row_ok && c < 4 * T) H[r * Gs + c] = c < G ? 0.5 * fetched[k] : 0.0;
-                        }
-                    }
-                }
-            }
-            for (uint32_t r = threadIdx.x; r < ns; r += kTileBlock) {
-                lds_noise[r] = nz[s0 + r];
-                lds_count[r] = cnt[s0 + r];
-            }
-            __syncthreads();
-            // class ranges inside the staged rows
-            const uint32_t f1 = nf <= s0 ? 0u : ((nf - s0) < ns ? (nf - s0) : ns);
-            const uint32_t m1 = nm <= s0 ? 0u : ((nm - s0) < ns ? (nm - s0) : ns);
-            if (active) {
-                const double * ua = H + 4 * ta, * vb = H + 4 * tb;
-                // read count 1: one multiplication per pair and row
-                for (uint32_t r = (w.debug_skip & 1u) ? f1 : slice; r < f1; r += S) {
-                    const double2 u01 = *reinterpret_cast<const double2 *>(ua + r * Gs), u23 = *reinterpret_cast<const double2 *>(ua + r * Gs + 2);
-                    const double2 v01 = *reinterpret_cast<const double2 *>(vb + r * Gs), v23 = *reinterpret_cast<const double2 *>(vb + r * Gs + 2);
-                    const double noise = lds_noise[r];
-                    const double un[4] = {u01.x + noise, u01.y + noise, u23.x + noise, u23.y + noise};
-                    const double v[4] = {v01.x, v01.y, v23.x, v23.y};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) pr[i][j].mul(un[i] + v[j]);
-                    }
-                    if (++since_fold == kFoldFactors) foldPairs();
-                }
-                // read counts 2 .. kMidMaxCount: the factor that many times
-                for (uint32_t r = (w.debug_skip & 2u) ? m1 : f1 + (slice + S - f1 % S) % S; r < m1; r += S) {
-                    const double2 u01 = *reinterpret_cast<const double2 *>(ua + r * Gs), u23 = *reinterpret_cast<const double2 *>(ua + r * Gs + 2);
-                    const double2 v01 = *reinterpret_cast<const double2 *>(vb + r * Gs), v23 = *reinterpret_cast<const double2 *>(vb + r * Gs + 2);
-                    const double noise = lds_noise[r];
-                    const uint32_t c = static_cast<uint32_t>(lds_count[r]);
-                    const double un[4] = {u01.x + noise, u01.y + noise, u23.x + noise, u23.y + noise};
-                    const double v[4] = {v01.x, v01.y, v23.x, v23.y};
-                    if (since_fold + c > kFoldFactors) foldPairs();
-                    since_fold += c;
-                    double x[4][4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) x[i][j] = un[i] + v[j];
-                    }
-                    for (uint32_t k = 0; k < c; ++k) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) pr[i][j].mul(x[i][j]);
-                        }
-                    }
-                }
-                // the rest: one logarithm per pair and row
-                for (uint32_t r = (w.debug_skip & 4u) ? ns : m1 + (slice + S - m1 % S) % S; r < ns; r += S) {
-                    const double2 u01 = *reinterpret_cast<const double2 *>(ua + r * Gs), u23 = *reinterpret_cast<const double2 *>(ua + r * Gs + 2);
-                    const double2 v01 = *reinterpret_cast<const double2 *>(vb + r * Gs), v23 = *reinterpret_cast<const double2 *>(vb + r * Gs + 2);
-                    const double noise = lds_noise[r], c = lds_count[r];
-                    const double un[4] = {u01.x + noise, u01.y + noise, u23.x + noise, u23.y + noise};
-                    const double v[4] = {v01.x, v01.y, v23.x, v23.y};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j] = fma(c, logPositive(un[i] + v[j], lt), acc[i][j]);
-                    }
-                }
-            }
-            if (with_marginals) {  // single columns: noise + the whole value = noise + 2 halves
-                const double * ua = H + 4 * tc;
-                for (uint32_t r = marg_slice; r < ns; r += SM) {
-                    const double2 u01 = *reinterpret_cast<const double2 *>(ua + r * Gs), u23 = *reinterpret_cast<const double2 *>(ua + r * Gs + 2);
-                    const double noise = lds_noise[r];
-                    const double x[4] = {fma(2.0, u01.x, noise), fma(2.0, u01.y, noise), fma(2.0, u23.x, noise), fma(2.0, u23.y, noise)};
-                    if (r < f1) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) prm[i].mul(x[i]);
-                        if (++since_fold_m == kFoldFactors) foldMarginals();
-                    } else if (r < m1) {
-                        const uint32_t c = static_cast<uint32_t>(lds_count[r]);
-                        if (since_fold_m + c > kFoldFactors) foldMarginals();
-                        since_fold_m += c;
-                        for (uint32_t k = 0; k < c; ++k) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) prm[i].mul(x[i]);
-                        }
-                    } else {
-                        const double c = lds_count[r];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) accm[i] = fma(c, logPositive(x[i], lt), accm[i]);
-                    }
-                }
-            }
-        }
-        // The sums of a chunk: one per pair and column.  Slices add theirs up in LDS, in the order of the slices (the
-        // staged rows are done with), so that the resolving workgroup reads one part per chunk.
-        double * const out_pairs = w.part_pair + w.pair_part_off[m] + static_cast<uint64_t>(chunk) * G * G;
-        double * const out_columns = w.part_marginal + w.col_part_off[m] + static_cast<uint64_t>(chunk) * G;
-        double * const sums = tile_lds;         // [S][tiles][16], then
-        double * const column_sums = tile_lds;  // [SM][T][4]: one after the other in the same 32 KB
-        if (S > 1) __syncthreads();
-        if (active) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t a = 4 * ta + i, b = 4 * tb + j;
-                    const double total = acc[i][j] + pr[i][j].value(lt);
-                    if (S > 1) sums[(slice * tiles + t) * 16 + i * 4 + j] = total;
-                    else if (a <= b && b < G) out_pairs[static_cast<uint64_t>(a) * G + b] = total;
-                }
-            }
-        }
-        if (S > 1) {
-            __syncthreads();
-            for (uint32_t e = threadIdx.x; e < tiles * 16; e += kTileBlock) {
-                double total = 0.0;
-                for (uint32_t sl = 0; sl < S; ++sl) total += sums[sl * tiles * 16 + e];
-                const uint32_t te = e / 16, i = (e % 16) / 4, j = e % 4;
-                uint32_t lo = 0, hi = T - 1;  // row of tile te in the triangle
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi + 1) >> 1;
-                    if (mid * T - mid * (mid - 1) / 2 <= te) lo = mid; else hi = mid - 1;
-                }
-                const uint32_t a = 4 * lo + i, b = 4 * (lo + (te - (lo * T - lo * (lo > 0 ? lo - 1 : 0) / 2))) + j;
-                if (a <= b && b < G) out_pairs[static_cast<uint64_t>(a) * G + b] = total;
-            }
-        }
-        if (pass == 0 && !(w.debug_skip & 8u)) {
-            if (SM > 1) __syncthreads();
-            if (with_marginals) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t a = 4 * tc + i;
-                    const double total = accm[i] + prm[i].value(lt);
-                    if (SM > 1) column_sums[(marg_slice * T + tc) * 4 + i] = total;
-                    else if (a < G) out_columns[a] = total;
-                }
-            }
-            if (SM > 1) {
-                __syncthreads();
-                for (uint32_t e = threadIdx.x; e < T * 4; e += kTileBlock) {
-                    double total = 0.0;
-                    for (uint32_t sl = 0; sl < SM; ++sl) total += column_sums[sl * T * 4 + e];
-                    if (e < G) out_columns[e] = total;
-                }
-            }
-        }
-    }
-    if (threadIdx.x == 0) atomicAdd(w.log_evals, static_cast<unsigned long long>(static_cast<uint64_t>(G) * (G + 1) / 2 + G) * n);
-}
-
+// (the experiments build times the kernel with classes of rows left out: wrong results, on purpose; not in the shipped library)
+#ifdef RPVG_HIP_EXPERIMENTS
+#define RPVG_PAIR_DEBUG_SKIP(w) ((w).debug_skip)
+#else
+#define RPVG_PAIR_DEBUG_SKIP(w) 0u
+#endif
 
 // ---- the same tiles, lanes balanced and the staging asynchronous (round 4) -----------------------------------------
 //
@@ -925,7 +685,7 @@ __device__ __forceinline__ void pairTile2Item(const PairTileWork & w, double * c
     // a buffer: [ncols][sub_rows] values, [sub_rows] noise, [sub_rows] counts
     const uint32_t buffer_doubles = (ncols + 2) * sub_rows + ncols / 2;
     auto stage = [&](const uint32_t s0, const uint32_t ns, double * const buffer) {
-        if (w.debug_skip & 16u) return;
+        if (RPVG_PAIR_DEBUG_SKIP(w) & 16u) return;
         const uint32_t pairs = (ns + 1) / 2;  // (a row past the block's last is read, not used)
         const uint32_t col_in_load = lane / lanes_per_column, pair = lane % lanes_per_column;
         const bool lane_loads = col_in_load < columns_per_load && pair < pairs;
@@ -948,7 +708,7 @@ __device__ __forceinline__ void pairTile2Item(const PairTileWork & w, double * c
     const uint32_t tb = ta + (t - (ta * T - ta * (ta > 0 ? ta - 1 : 0) / 2));
     const uint32_t SM = marginalSlices(G);
     const uint32_t tc = threadIdx.x % T, marg_slice = threadIdx.x / T;
-    const bool with_marginals = t0 == 0 && marg_slice < SM && !(w.debug_skip & 8u);
+    const bool with_marginals = t0 == 0 && marg_slice < SM && !(RPVG_PAIR_DEBUG_SKIP(w) & 8u);
 
     LogProduct pr[4][4], prm[4];
     double acc[4][4], accm[4];
@@ -975,7 +735,7 @@ __device__ __forceinline__ void pairTile2Item(const PairTileWork & w, double * c
     };
 
     const uint32_t blocks = (n + sub_rows - 1) / sub_rows;
-    if (w.debug_skip & 16u) {  // (timing without the loads: finite values everywhere)
+    if (RPVG_PAIR_DEBUG_SKIP(w) & 16u) {  // (timing without the loads: finite values everywhere)
         for (uint32_t i = threadIdx.x; i < 2 * kTile2BufferDoubles; i += kTileBlock) tile_lds[i] = 0.25;
     }
     stage(0, n < sub_rows ? n : sub_rows, tile_lds);
@@ -998,7 +758,7 @@ __device__ __forceinline__ void pairTile2Item(const PairTileWork & w, double * c
         if (active) {
             const double * const ua = H + columnOffset(4 * ta - c_lo), * const vb = H + columnOffset(4 * tb - c_lo);
             // read count 1: one multiplication per pair and row
-            uint32_t r = (w.debug_skip & 1u) ? f1 : slice;
+            uint32_t r = (RPVG_PAIR_DEBUG_SKIP(w) & 1u) ? f1 : slice;
             {
                 uint32_t noise_at = ldsByteAddress(lds_noise + r), u_at = ldsByteAddress(ua + r), v_at = ldsByteAddress(vb + r);
                 for (; r < f1; r += S, noise_at += 8 * S, u_at += 8 * S, v_at += 8 * S) {
@@ -1016,7 +776,7 @@ __device__ __forceinline__ void pairTile2Item(const PairTileWork & w, double * c
                 }
             }
             // read counts 2 .. kMidMaxCount: the factor that many times
-            for (r = (w.debug_skip & 2u) ? m1 : f1 + (slice + S - f1 % S) % S; r < m1; r += S) {
+            for (r = (RPVG_PAIR_DEBUG_SKIP(w) & 2u) ? m1 : f1 + (slice + S - f1 % S) % S; r < m1; r += S) {
                 double noise, u[4], v[4];
                 ldsReadRow<kSubRows>(ldsByteAddress(lds_noise + r), ldsByteAddress(ua + r), ldsByteAddress(vb + r), noise, u, v);
                 ldsRowLanded(noise, u, v);
@@ -1040,7 +800,7 @@ __device__ __forceinline__ void pairTile2Item(const PairTileWork & w, double * c
                 }
             }
             // the rest: one logarithm per pair and row
-            for (r = (w.debug_skip & 4u) ? ns : m1 + (slice + S - m1 % S) % S; r < ns; r += S) {
+            for (r = (RPVG_PAIR_DEBUG_SKIP(w) & 4u) ? ns : m1 + (slice + S - m1 % S) % S; r < ns; r += S) {
                 const double noise = lds_noise[r], c = lds_count[r];
                 const double un[4] = {fma(2.0, noise, ua[r]), fma(2.0, noise, ua[sub_rows + r]), fma(2.0, noise, ua[2 * sub_rows + r]), fma(2.0, noise, ua[3 * sub_rows + r])};
                 const double v[4] = {vb[r], vb[sub_rows + r], vb[2 * sub_rows + r], vb[3 * sub_rows + r]};
@@ -1108,7 +868,7 @@ __device__ __forceinline__ void pairTile2Item(const PairTileWork & w, double * c
             if (a <= b && b < G) out_pairs[static_cast<uint64_t>(a) * G + b] = total;
         }
     }
-    if (t0 == 0 && !(w.debug_skip & 8u)) {
+    if (t0 == 0 && !(RPVG_PAIR_DEBUG_SKIP(w) & 8u)) {
         if (SM > 1) __syncthreads();
         if (with_marginals) {
 #pragma unroll
@@ -1454,10 +1214,10 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
     // every pair of every matrix from LDS-staged rows, a tile of pairs per lane (pairTileKernel): the default for a
     // threshold that is a ratio <= 1; RPVG_HIP_PAIR_TILES=0 keeps the sequential search with its table path (A/B)
     const char * tiles_env = std::getenv("RPVG_HIP_PAIR_TILES");  // (read per call: the tests switch between the two searches)
-    const int tiles_wanted = tiles_env ? std::atoi(tiles_env) : 2;  // (1: the tile kernel of round 2, synchronous staging, one item per chunk)
+    const int tiles_wanted = tiles_env ? std::atoi(tiles_env) : 2;
     const bool pair_tiles = tiles_wanted != 0 && min_rel_likelihood <= 1;
-    const bool tile_ranges = pair_tiles && tiles_wanted != 1;
-    // rows of a work item's chunk (RPVG_HIP_PAIR_CHUNK_ROWS with tile ranges: A/B knob)
+    const bool tile_ranges = pair_tiles;  // (round 2's tile kernel, one item per chunk, went with round 5: pairTile2Kernel has two rounds of sweeps behind it)
+    // rows of a work item's chunk (RPVG_HIP_PAIR_CHUNK_ROWS: the tests cut small matrices into several chunks with it)
     const uint32_t chunk_rows = tile_ranges && std::getenv("RPVG_HIP_PAIR_CHUNK_ROWS") ? std::max(256, std::atoi(std::getenv("RPVG_HIP_PAIR_CHUNK_ROWS"))) : kChunkRows;
     if (pair_tiles) table_min_work = 0.0;
     const uint32_t tile_step = kTileA;
@@ -1527,7 +1287,7 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
         std::copy(small.begin(), small.end(), order.begin() + num_big + num_medium);
     }
 
-    if (std::getenv("RPVG_HIP_SEARCH_CLASSES")) {
+    if (RPVG_EXPERIMENT_ENV("RPVG_HIP_SEARCH_CLASSES")) {
         auto show = [&](const char * name, uint32_t first, uint32_t count) {
             double evals = 0;
             for (uint32_t i = first; i < first + count; ++i) evals += 0.5 * groups->h_num_rows[order[i]] * groups->h_num_cols[order[i]] * groups->h_num_cols[order[i]];
@@ -1653,7 +1413,7 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
     // streams of the medium / small kernels next to the table path on `st` (RPVG_HIP_SEARCH_STREAMS: A/B knob, 3 = one
     // stream each, 2 = medium and small share one, 1 = everything on st)
     static const int search_streams = []() {
-        const char * env = std::getenv("RPVG_HIP_SEARCH_STREAMS");
+        const char * env = RPVG_EXPERIMENT_ENV("RPVG_HIP_SEARCH_STREAMS");
         return env ? std::max(1, std::min(3, std::atoi(env))) : 3;
     }();
     hipStream_t s_medium = search_streams == 1 ? st : ctx->aux[0];
@@ -1713,28 +1473,30 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
             pw.part_marginal = d_part_marg.ptr;
             pw.part_pair = d_part_pair.ptr;
             pw.log_evals = args.log_evals;
-            pw.debug_skip = std::getenv("RPVG_HIP_PAIR_DEBUG") ? static_cast<uint32_t>(std::atoi(std::getenv("RPVG_HIP_PAIR_DEBUG"))) : 0u;
+#ifdef RPVG_HIP_EXPERIMENTS
+            pw.debug_skip = RPVG_EXPERIMENT_ENV("RPVG_HIP_PAIR_DEBUG") ? static_cast<uint32_t>(std::atoi(RPVG_EXPERIMENT_ENV("RPVG_HIP_PAIR_DEBUG"))) : 0u;
+#endif
             // A/B knob RPVG_HIP_PAIR_LDS_KB: more dynamic LDS than the kernel uses = fewer workgroups per CU (64: two instead of
             // three — registers left over for the other lane's kernels while this one runs)
             static const size_t tile_lds_bytes = []() {
-                const char * env = std::getenv("RPVG_HIP_PAIR_LDS_KB");
+                const char * env = RPVG_EXPERIMENT_ENV("RPVG_HIP_PAIR_LDS_KB");
                 return std::max<size_t>(kTileLdsDoubles * sizeof(double), env ? static_cast<size_t>(std::atoi(env)) * 1024 : 0);
             }();
             if (tile_lds_bytes > 64 * 1024) {
-                RPVG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairTileKernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes)));
+                RPVG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairTile2Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes)));
             }
             // (On the device's lowest stream priority — the slots its workgroups free going to the other lane's short kernels first —
             // the batch took 11.6 against 10.5 ms: the search is itself on its lane's critical path.  Two passes around the replay of
             // the matrices' collapse — the matrices it leaves alone as soon as its first stages have told them apart, the others when
             // it is done — 10.4 against 9.9 ms: the second pass's grid of mostly empty workgroups, and the replay's small kernels next
             // to the lane's own tile kernel.)
-            if (tile_ranges) pairTile2Kernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
-            else pairTileKernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
-            // (experiment, RPVG_HIP_PAIR_REPEAT=n: the same launch n more times — what a batch pays per millisecond of this kernel)
-            for (int k = std::getenv("RPVG_HIP_PAIR_REPEAT") ? std::atoi(std::getenv("RPVG_HIP_PAIR_REPEAT")) : 0; k > 0; --k) {
-                if (tile_ranges) pairTile2Kernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
-                else pairTileKernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
+            pairTile2Kernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
+#ifdef RPVG_HIP_EXPERIMENTS
+            // (RPVG_HIP_PAIR_REPEAT=n: the same launch n more times — what a batch pays per millisecond of this kernel)
+            for (int k = RPVG_EXPERIMENT_ENV("RPVG_HIP_PAIR_REPEAT") ? std::atoi(RPVG_EXPERIMENT_ENV("RPVG_HIP_PAIR_REPEAT")) : 0; k > 0; --k) {
+                pairTile2Kernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
             }
+#endif
         } else {
             pairTableKernel<<<dim3(((tw.count + 7) / 8) * 8), dim3(256), 0, st>>>(tw);
         }

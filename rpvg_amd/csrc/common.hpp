@@ -44,6 +44,18 @@ void setError(const char * fmt, ...);
         }                                             \
     } while (0)
 
+// ---- A/B switches and timing experiments -----------------------------------------------------------
+// Four rounds of measurements left some forty environment switches behind — alternative launch orders, stream layouts, grid
+// sizes, kernels with parts of their work skipped for timing (docs/design/knobs.md).  Several change results or skip work; none
+// belongs in a library somebody links.  The shipped build does not read them: the macro is a null pointer there and the
+// names are not in the binary.  `make -C rpvg_amd/csrc experiments` builds librpvg_hip_experiments.so, which does
+// (-DRPVG_HIP_EXPERIMENTS; RPVG_HIP_LIBRARY=<path> makes the Python harness load it: tools/).
+#ifdef RPVG_HIP_EXPERIMENTS
+#define RPVG_EXPERIMENT_ENV(name) std::getenv(name)
+#else
+#define RPVG_EXPERIMENT_ENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 // ---- hardware queues ---------------------------------------------------------------
 // The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment says otherwise, read
 // when the runtime starts); work of streams that share a queue runs in order.  Two host lanes with four busy streams

@@ -219,7 +219,7 @@ hipError_t stagedCopy(void * device_dst, const void * pinned_src, size_t bytes, 
     // (measured on the configs[2] bench: 19.1-19.9 ms per batch with the copy stream against 14.4-15.8 ms with the
     // uploads on their own streams — the event waits between hardware queues cost more than the overlap brings; off
     // unless RPVG_HIP_COPY_STREAM=1)
-    static const bool inline_uploads = std::getenv("RPVG_HIP_COPY_STREAM") == nullptr;
+    static const bool inline_uploads = RPVG_EXPERIMENT_ENV("RPVG_HIP_COPY_STREAM") == nullptr;
     CopyLane lane{nullptr, nullptr};
     if (!inline_uploads) {
         std::lock_guard<std::mutex> lock(g_copy_mutex);
@@ -506,7 +506,7 @@ namespace {
 // — the idea; measured 17.4-17.8 ms per configs[2] batch against 15.1-15.9 ms with all streams alike (same box, same
 // call), so it is off unless RPVG_HIP_MAIN_PRIORITY=1.
 hipError_t createMainStream(hipStream_t * stream, const bool highest_priority) {
-    const char * env = std::getenv("RPVG_HIP_MAIN_PRIORITY");  // A/B knob: every context's stream at the highest priority (slower)
+    const char * env = RPVG_EXPERIMENT_ENV("RPVG_HIP_MAIN_PRIORITY");  // A/B knob: every context's stream at the highest priority (slower)
     if (!highest_priority && (!env || std::atoi(env) == 0)) return hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
@@ -564,7 +564,7 @@ int createContext(int device, const bool uploader, const int side_streams, rpvg_
             ctx->aux[i] = ctx->aux[i % side_streams];
         }
     }
-    if (e == hipSuccess) e = createMainStream(&ctx->collapse_stream, std::getenv("RPVG_HIP_COLLAPSE_PRIORITY") == nullptr || std::atoi(std::getenv("RPVG_HIP_COLLAPSE_PRIORITY")) != 0);
+    if (e == hipSuccess) e = createMainStream(&ctx->collapse_stream, RPVG_EXPERIMENT_ENV("RPVG_HIP_COLLAPSE_PRIORITY") == nullptr || std::atoi(RPVG_EXPERIMENT_ENV("RPVG_HIP_COLLAPSE_PRIORITY")) != 0);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->search_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);

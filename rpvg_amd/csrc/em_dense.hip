@@ -524,7 +524,7 @@ int emDenseIterate(rpvg_hip_ctx * ctx, const char * who, DenseEmRun & run) {
     const bool wide = C > 256;  // row split over the block's waves (emDenseAccumWideKernel)
     // enough waves to cover HBM latency, few enough partial vectors to reduce cheaply
     uint32_t blocks_per_cu = wide ? 4 : 2;
-    if (const char * env = std::getenv("RPVG_HIP_DENSE_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::atoi(env));
+    if (const char * env = RPVG_EXPERIMENT_ENV("RPVG_HIP_DENSE_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::atoi(env));
     uint32_t grid = wide ? std::min<uint64_t>((num_rows + 1) / 2, static_cast<uint64_t>(cus) * blocks_per_cu)
                          : std::min<uint64_t>((num_rows + 3) / 4, static_cast<uint64_t>(cus) * blocks_per_cu);
     grid = std::max<uint32_t>(grid, 1);

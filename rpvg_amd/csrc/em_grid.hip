@@ -263,7 +263,7 @@ hipError_t launchAccumVariant(const GridAccumArgs & args, const uint32_t grid, c
 
 // lanes per row by the mean row length
 inline int gridRowLanes(const uint32_t rows, const uint32_t entries) {
-    if (const char * env = std::getenv("RPVG_HIP_EM_GRID_ROW_LANES")) return std::atoi(env);  // A/B knob: 1, 4, 16, 64
+    if (const char * env = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_GRID_ROW_LANES")) return std::atoi(env);  // A/B knob: 1, 4, 16, 64
     const double mean = static_cast<double>(entries) / std::max(1u, rows);
     return mean < 6.0 ? 1 : mean < 24.0 ? 4 : mean < 96.0 ? 16 : 64;
 }
@@ -292,7 +292,7 @@ uint64_t emGridMinWork() {
 }
 
 bool emGridDenseRoute(const uint32_t columns, const uint32_t rows, const uint32_t entries) {
-    if (std::getenv("RPVG_HIP_EM_GRID_NO_DENSE")) return false;  // A/B knob
+    if (RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_GRID_NO_DENSE")) return false;  // A/B knob
     if (columns > kDenseMaxCols || columns < 2) return false;
     const uint64_t ld = (static_cast<uint64_t>(columns) + 1) & ~1ull;
     return 8ull * rows * ld <= 12ull * entries + 20ull * rows;
@@ -351,7 +351,7 @@ int runEmGridProblems(rpvg_hip_ctx * ctx, hipStream_t st, const EmGridProblem * 
         uint64_t blocks = (static_cast<uint64_t>(rows) + slots - 1) / slots;
         blocks = std::min<uint64_t>(blocks, static_cast<uint64_t>(cus) * (row_lanes == 1 ? 2 : 4));
         blocks = std::min<uint64_t>(blocks, std::max<uint64_t>(16, csr_bytes / (16ull * C)));
-        if (const char * env = std::getenv("RPVG_HIP_EM_GRID_BLOCKS")) blocks = std::max<uint64_t>(1, std::strtoull(env, nullptr, 10));  // A/B knob
+        if (const char * env = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_GRID_BLOCKS")) blocks = std::max<uint64_t>(1, std::strtoull(env, nullptr, 10));  // A/B knob
         blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, rows));
         const uint32_t rows_per_block = static_cast<uint32_t>((static_cast<uint64_t>(rows) + blocks - 1) / blocks);
         const uint32_t grid = (rows + rows_per_block - 1) / rows_per_block;

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void fillSegmentsKernel(const FillArgs args) {
 // (the grid threshold of the EM: a batch of small clusters keeps its eight workgroups per CU) carries it.
 template <bool WRITE>
 hipError_t launchFillSegments(FillArgs & fa, const uint32_t grid, const uint64_t max_cluster_work, hipStream_t st) {
-    static const bool never = std::getenv("RPVG_HIP_FILL_THREAD_ROWS") != nullptr;  // A/B knob
+    static const bool never = RPVG_EXPERIMENT_ENV("RPVG_HIP_FILL_THREAD_ROWS") != nullptr;  // A/B knob
     fa.long_row_scratch = (!never && max_cluster_work >= (1ull << 18)) ? 1u : 0u;
     fa.lds_map_paths = (fa.lds_map_paths + 1) & ~1u;  // (the scratch behind the map holds doubles)
     const size_t lds = fa.lds_map_paths * sizeof(int32_t) + (fa.long_row_scratch ? kFillLongRowLds : 0);
@@ -1267,13 +1267,13 @@ __global__ __launch_bounds__(256) void gibbsReadCountKernel(const GibbsLaunchArg
 // ---- shared host part: the compacted CSR of a list of problems, their work queues, the EM launches -------------
 
 EmBinRule emBinRule() {
-    static const bool use_register_kernel = std::getenv("RPVG_HIP_NO_REGISTER_EM") == nullptr;
+    static const bool use_register_kernel = RPVG_EXPERIMENT_ENV("RPVG_HIP_NO_REGISTER_EM") == nullptr;
     // A streamed problem is one workgroup: above this many rows + entries it gets 1 024 threads instead of 256 (round 2:
     // 262 144 — a 200 000-entry problem on 256 threads took 47 us per EM iteration and, at 23 iterations, as long as the
     // thousands of iterations of the slowest register-resident problem; round 3: 24 576, then 0 — a batch has a few dozen
     // streamed problems, far fewer than CUs, and on 256 threads the ones below the limit took 55 us per iteration, twice
     // what the larger ones above it took on 1 024).
-    static const uint64_t streamed_small = std::getenv("RPVG_HIP_EM_STREAM_SMALL") ? std::strtoull(std::getenv("RPVG_HIP_EM_STREAM_SMALL"), nullptr, 10) : 0;
+    static const uint64_t streamed_small = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_STREAM_SMALL") ? std::strtoull(RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_STREAM_SMALL"), nullptr, 10) : 0;
     return EmBinRule{use_register_kernel ? 1u : 0u, streamed_small, emGridMinWork()};
 }
 
@@ -1365,8 +1365,8 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     // version solved every problem next to the collapse and the merged ones a second time: on the configs[2] batch the
     // largest problems were the merged ones, the second pass took as long as the first, and the collapse's forty launches
     // took 2.6 ms in between the persistent EM kernels against 1.5 ms without them.)
-    static const bool no_em_collapse = std::getenv("RPVG_HIP_NO_EM_COLLAPSE") != nullptr;
-    const bool collapse = collapse_precision > 0 && !no_em_collapse && !std::getenv("RPVG_HIP_NO_COLLAPSE") && list.rows_capacity > 0;
+    static const bool no_em_collapse = RPVG_EXPERIMENT_ENV("RPVG_HIP_NO_EM_COLLAPSE") != nullptr;
+    const bool collapse = collapse_precision > 0 && !no_em_collapse && !RPVG_EXPERIMENT_ENV("RPVG_HIP_NO_COLLAPSE") && list.rows_capacity > 0;
     // (the collapse indexes rows with 32 bits and matrices with 20; the callers' memory budgets keep a solve far below both —
     // a solve that is not gets an error rather than results without the collapse)
     RPVG_REQUIRE(!collapse || (list.rows_capacity <= 0x7fffffffull && P + 1 < kCollapseMaxMatrices),
@@ -1453,8 +1453,8 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         // accident, beat every sort without such a wait by 1 ms per batch).  So the submitting thread waits for the collapse
         // itself and queues the launches then.
         // RPVG_HIP_EM_LAUNCH_EARLY=1: queue them at once (A/B).
-        static const bool launch_early = std::getenv("RPVG_HIP_EM_LAUNCH_EARLY") != nullptr;
-        static const bool wait_whole = std::getenv("RPVG_HIP_EM_WAIT_SORT_ONLY") == nullptr;  // A/B: only the collapse's sort (11.3 against 10.2 ms per batch)
+        static const bool launch_early = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_LAUNCH_EARLY") != nullptr;
+        static const bool wait_whole = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_WAIT_SORT_ONLY") == nullptr;  // A/B: only the collapse's sort (11.3 against 10.2 ms per batch)
         if (!launch_early && work.collapse_sorted) {
             HostScope wait_scope("em_solve: wait for the collapse");
             RPVG_HIP_CHECK(waitEvent(wait_whole ? work.collapsed : work.collapse_sorted));
@@ -1469,11 +1469,11 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     // of dispatcher time next to the other lane's kernels.  A queue of 1 200 short problems drains through 512 waves in
     // tens of microseconds; the problems that run for thousands of iterations start that much later at the most.
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
-    static const double grid_scale = std::getenv("RPVG_HIP_EM_GRID_SCALE") ? std::atof(std::getenv("RPVG_HIP_EM_GRID_SCALE")) : 1.0;  // A/B knob
+    static const double grid_scale = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_GRID_SCALE") ? std::atof(RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_GRID_SCALE")) : 1.0;  // A/B knob
     auto grid = [&](const uint32_t per_cu) { return std::min<uint32_t>(P, std::max<uint32_t>(1, static_cast<uint32_t>(cus * per_cu * grid_scale))); };
     const size_t streamed_lds_256 = emLdsBytes(list.max_cols, 0, 0, 256, false), streamed_lds_1024 = emLdsBytes(list.max_cols, 0, 0, 1024, false);
     const bool wide_possible = streamed_lds_1024 > kEmLdsLimit;
-    static const bool few_streams = std::getenv("RPVG_HIP_EM_FEW_STREAMS") != nullptr;  // A/B knob
+    static const bool few_streams = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_FEW_STREAMS") != nullptr;  // A/B knob
     const bool many_queues = hardwareQueues() >= 8 && !few_streams;
     hipStream_t s_reg4 = many_queues ? ctx->aux[3] : ctx->aux[0], s_reg1 = many_queues ? ctx->aux[4] : ctx->aux[1], s_reg2 = many_queues ? ctx->aux[5] : ctx->aux[2];
     // One persistent launch per kernel variant (the register-resident bins are the long ones: they start first; with
@@ -1521,7 +1521,7 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
             ctx->spanEnd(bin_span);
         }
         // (RPVG_HIP_EM_JOIN_ON_STREAM=1: the context's stream waits for the side streams, not the thread — A/B)
-        static const bool join_on_stream = std::getenv("RPVG_HIP_EM_JOIN_ON_STREAM") != nullptr;
+        static const bool join_on_stream = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_JOIN_ON_STREAM") != nullptr;
         RPVG_HIP_CHECK(join_on_stream ? ctx->joinAux() : ctx->joinAuxOnHost());
         return RPVG_HIP_OK;
     };
@@ -1593,7 +1593,7 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     }
     if (collapse) {
         const CsrCollapseWork * cw = static_cast<const CsrCollapseWork *>(work.collapse.get());
-        static const bool debug = std::getenv("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
+        static const bool debug = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
         if (debug) {  // (synchronises: a measuring aid)
             uint32_t info[6] = {0}, merged = 0, problems = P, counts[3] = {0};
             RPVG_HIP_CHECK(hipStreamSynchronize(st));

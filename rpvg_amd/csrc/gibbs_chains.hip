@@ -1221,13 +1221,13 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     // share of a distribution from which a column's own conditional is asked for ahead of the chains (group size 2; above 1: never)
     // (off by default: at 0.02 and 0.002 the fourth round has 750 / 220 chains left instead of 1 330, the dozen chains of a
     // long-tailed posterior that make the last ten rounds are not helped, and the batch takes as long within the noise)
-    static const double ask_ahead_env = std::getenv("RPVG_HIP_GIBBS_ASK_AHEAD") ? std::atof(std::getenv("RPVG_HIP_GIBBS_ASK_AHEAD")) : 0.0;
+    static const double ask_ahead_env = RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_ASK_AHEAD") ? std::atof(RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_ASK_AHEAD")) : 0.0;
     const double ask_ahead = (GS == 2 && ask_ahead_env > 0) ? ask_ahead_env : 2.0;
     // rounds (from the first) whose conditionals go through the tile kernel (A/B)
-    static const uint32_t tiled_rounds = std::getenv("RPVG_HIP_GIBBS_TILED_ROUNDS") ? static_cast<uint32_t>(std::atoi(std::getenv("RPVG_HIP_GIBBS_TILED_ROUNDS"))) : 1u;
-    static const uint32_t follow_modes = std::getenv("RPVG_HIP_GIBBS_FOLLOW_MODES") ? static_cast<uint32_t>(std::atoi(std::getenv("RPVG_HIP_GIBBS_FOLLOW_MODES"))) : 2u;
-    static const double follow_share = std::getenv("RPVG_HIP_GIBBS_FOLLOW_SHARE") ? std::atof(std::getenv("RPVG_HIP_GIBBS_FOLLOW_SHARE")) : 0.1;
-    static const bool debug = std::getenv("RPVG_HIP_GIBBS_DEBUG") != nullptr;
+    static const uint32_t tiled_rounds = RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_TILED_ROUNDS") ? static_cast<uint32_t>(std::atoi(RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_TILED_ROUNDS"))) : 1u;
+    static const uint32_t follow_modes = RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_FOLLOW_MODES") ? static_cast<uint32_t>(std::atoi(RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_FOLLOW_MODES"))) : 2u;
+    static const double follow_share = RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_FOLLOW_SHARE") ? std::atof(RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_FOLLOW_SHARE")) : 0.1;
+    static const bool debug = RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_DEBUG") != nullptr;
     DeviceBuffer<unsigned long long> d_debug;
     if (debug) {
         RPVG_HIP_CHECK(d_debug.alloc(8ull * kMaxRounds));
@@ -1235,12 +1235,12 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     }
     scope.reset(new HostScope("group_gibbs: rounds"));
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
-    static const uint32_t chains_per_wave = std::getenv("RPVG_HIP_GIBBS_CHAINS_PER_WAVE") ? std::min(64, std::max(1, std::atoi(std::getenv("RPVG_HIP_GIBBS_CHAINS_PER_WAVE")))) : 8u;  // (64 / 16 / 8 chains per wave: 3.7 / 3.2 / 2.6 ms for the five long rounds of a configs[4] lane)
+    static const uint32_t chains_per_wave = RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_CHAINS_PER_WAVE") ? std::min(64, std::max(1, std::atoi(RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_CHAINS_PER_WAVE")))) : 8u;  // (64 / 16 / 8 chains per wave: 3.7 / 3.2 / 2.6 ms for the five long rounds of a configs[4] lane)
     const uint32_t advance_blocks = static_cast<uint32_t>((num_chains + 4 * chains_per_wave - 1) / (4 * chains_per_wave));
     const uint32_t work_blocks = cus * 8;
     uint32_t round = 0;
     bool finished = false;
-    static const uint32_t first_rounds = std::getenv("RPVG_HIP_GIBBS_FIRST_ROUNDS") ? std::max(1, std::atoi(std::getenv("RPVG_HIP_GIBBS_FIRST_ROUNDS"))) : 6;
+    static const uint32_t first_rounds = RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_FIRST_ROUNDS") ? std::max(1, std::atoi(RPVG_EXPERIMENT_ENV("RPVG_HIP_GIBBS_FIRST_ROUNDS"))) : 6;
     uint32_t chunk = first_rounds;
     while (!finished) {
         if (round + chunk >= kMaxRounds) {  // (a round per column of a flat posterior over thousands of columns: the caller's sampler takes it)

@@ -409,7 +409,9 @@ struct MaskBuildArgs {
     const double * row_noise;
     const uint32_t * row_perm;
     int normalise;
+#ifdef RPVG_HIP_EXPERIMENTS
     int debug_no_long_rows;    // timing experiment (RPVG_HIP_BUILD_DEBUG=1): entries past the held ones are dropped
+#endif
     double * values;
     double * rowmax;
     uint64_t * collapse_key;   // null: no row collapse
@@ -464,7 +466,11 @@ __global__ __launch_bounds__(256) void groupsBuildMaskKernel(const MaskBuildArgs
             }
         }
     }
+#ifdef RPVG_HIP_EXPERIMENTS
     const bool longer = !a.debug_no_long_rows && __ballot(e_begin + kMaskHeld < e_end) != 0ull;
+#else
+    const bool longer = __ballot(e_begin + kMaskHeld < e_end) != 0ull;
+#endif
 
     // the row's value in column c: the probabilities of its entries whose path is in the column's set, entry after entry
     auto cell = [&](const uint32_t c) {
@@ -735,7 +741,7 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
     RPVG_REQUIRE(spec->collapse_precision >= 0 && spec->collapse_precision < 1, "rpvg_hip_groups_build: collapse_precision outside [0, 1)");
     RPVG_REQUIRE(spec->collapse_precision == 0 || spec->normalise,
                  "rpvg_hip_groups_build: the row collapse applies to normalised matrices (src/path_abundance_estimator.cpp:379-380,442-443)");
-    static const bool no_collapse = std::getenv("RPVG_HIP_NO_COLLAPSE") != nullptr;  // A/B knob: matrices as built
+    static const bool no_collapse = RPVG_EXPERIMENT_ENV("RPVG_HIP_NO_COLLAPSE") != nullptr;  // A/B knob: matrices as built
     const bool collapse = spec->collapse_precision > 0 && !no_collapse;
 
     rpvg_hip_groups * g = new (std::nothrow) rpvg_hip_groups();
@@ -980,7 +986,9 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
             ma.row_noise = batch->row_noise.ptr;
             ma.row_perm = g->row_perm.ptr;
             ma.normalise = spec->normalise ? 1 : 0;
-            ma.debug_no_long_rows = std::getenv("RPVG_HIP_BUILD_DEBUG") ? std::atoi(std::getenv("RPVG_HIP_BUILD_DEBUG")) & 1 : 0;
+#ifdef RPVG_HIP_EXPERIMENTS
+            ma.debug_no_long_rows = RPVG_EXPERIMENT_ENV("RPVG_HIP_BUILD_DEBUG") ? std::atoi(RPVG_EXPERIMENT_ENV("RPVG_HIP_BUILD_DEBUG")) & 1 : 0;
+#endif
             ma.values = g->values.ptr;
             ma.rowmax = g->rowmax.ptr;
             ma.collapse_key = g->collapse_key.ptr;
@@ -1015,7 +1023,7 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
         if (collapse && e == hipSuccess) {
             // on the context's collapse stream, behind the build (rpvg_hip_groups::collapse_done)
             hipStream_t collapse_stream = ctx->collapse_stream;
-            static const bool same_stream = std::getenv("RPVG_HIP_COLLAPSE_INLINE") != nullptr;  // A/B knob: on the build's stream (11.5-12.1 vs 10.2-10.4 ms per batch)
+            static const bool same_stream = RPVG_EXPERIMENT_ENV("RPVG_HIP_COLLAPSE_INLINE") != nullptr;  // A/B knob: on the build's stream (11.5-12.1 vs 10.2-10.4 ms per batch)
             if (same_stream) collapse_stream = st;
             ok(hipEventCreateWithFlags(&g->built, hipEventDisableTiming));
             ok(hipEventCreateWithFlags(&g->collapse_done, hipEventDisableTiming));
@@ -1032,7 +1040,7 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
         ctx->spanEnd(span);
         ctx->stats.build_launches += 3;
         ok(hipGetLastError());
-        static const bool wait_here = std::getenv("RPVG_HIP_BUILD_SYNC") != nullptr;  // A/B knob: host sync before returning
+        static const bool wait_here = RPVG_EXPERIMENT_ENV("RPVG_HIP_BUILD_SYNC") != nullptr;  // A/B knob: host sync before returning
         if (wait_here) ok(hipStreamSynchronize(st));
     }
     if (e != hipSuccess) {

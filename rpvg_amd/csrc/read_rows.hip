@@ -1397,7 +1397,7 @@ extern "C" int rpvg_hip_read_rows_build(rpvg_hip_ctx * ctx, const rpvg_hip_align
     RPVG_HIP_CHECK(hipEventRecord(ev0, st));
     int span = ctx->spanBegin(FAM_BUILD);
     alignLogProbKernel<<<gridFor(A, 256), dim3(256), 0, st>>>(A, al->score.ptr, al->frag_length.ptr, rin.frag_table, sc.align_log_prob);
-    static const bool no_small_kernel = std::getenv("RPVG_HIP_NO_SMALL_READ_KERNEL") != nullptr;
+    static const bool no_small_kernel = RPVG_EXPERIMENT_ENV("RPVG_HIP_NO_SMALL_READ_KERNEL") != nullptr;
     if (no_small_kernel) {
         readRowKernel<<<gridFor(N, kWavesPerBlock), dim3(64 * kWavesPerBlock), 0, st>>>(rin, sc, N, nullptr);
     } else {

@@ -1635,12 +1635,12 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     a.mat_flag = mat_flag;
     a.info = info.ptr;
     a.num_matrices = M;
-    a.count_pairs = std::getenv("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
+    a.count_pairs = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
     const uint32_t row_blocks = static_cast<uint32_t>((total_rows + 255) / 256);
     // The kernels over pairs, lists and matrices with a list draw their (few) items from device-side counts with grid-stride
     // loops: a workgroup per CU or two, not thousands that find nothing (a workgroup costs the dispatcher ~40 ns whatever it does:
     // 4 096 of them were most of a 60 us kernel).  RPVG_HIP_COLLAPSE_GRID overrides (A/B).
-    static const uint32_t small_grid = std::getenv("RPVG_HIP_COLLAPSE_GRID") ? std::max(1, std::atoi(std::getenv("RPVG_HIP_COLLAPSE_GRID"))) : 256;
+    static const uint32_t small_grid = RPVG_EXPERIMENT_ENV("RPVG_HIP_COLLAPSE_GRID") ? std::max(1, std::atoi(RPVG_EXPERIMENT_ENV("RPVG_HIP_COLLAPSE_GRID"))) : 256;
     if (plan) {
         ok(hipMemsetAsync(tmp->chunk_count.ptr, 0, sizeof(uint32_t), st));
         SegmentSortArgs<Arrays> c;
@@ -1724,8 +1724,8 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     r.pair_hi = tmp->pair_bound.ptr + total_rows;
     r.pair_pattern = tmp->pair_pattern.ptr;
     r.info = info.ptr;
-    r.debug = std::getenv("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
-    r.no_lds_tables = std::getenv("RPVG_HIP_COLLAPSE_NO_LDS_TABLES") != nullptr;
+    r.debug = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
+    r.no_lds_tables = RPVG_EXPERIMENT_ENV("RPVG_HIP_COLLAPSE_NO_LDS_TABLES") != nullptr;
     collapseListKernel<Arrays><<<dim3(std::min<uint32_t>(M, small_grid)), dim3(256), 0, st>>>(r);
     const uint32_t staged_grid = small_grid;
     collapsePairTableKernel<Arrays><<<dim3(staged_grid), dim3(64), 0, st>>>(r);
@@ -1816,7 +1816,7 @@ __global__ __launch_bounds__(256) void csrCollapseKeysKernel(const CsrArrays g, 
 
 // RPVG_HIP_COLLAPSE_LIBRARY_SORT = 1 | matrices | problems: the library's radix sorts instead of the hand-written segment sort (A/B)
 static bool librarySortFor(const char * what) {
-    const char * env = std::getenv("RPVG_HIP_COLLAPSE_LIBRARY_SORT");
+    const char * env = RPVG_EXPERIMENT_ENV("RPVG_HIP_COLLAPSE_LIBRARY_SORT");
     return env != nullptr && (std::strcmp(env, "1") == 0 || std::strcmp(env, what) == 0);
 }
 
@@ -1838,7 +1838,7 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     arrays.row_noise = g->row_noise.ptr;
     arrays.row_count = g->row_count.ptr;
     arrays.zero_pattern = g->collapse_mask.ptr;
-    static const bool segmented = std::getenv("RPVG_HIP_COLLAPSE_SEGMENTED_SORT") != nullptr;  // (A/B: slower on the group matrices)
+    static const bool segmented = RPVG_EXPERIMENT_ENV("RPVG_HIP_COLLAPSE_SEGMENTED_SORT") != nullptr;  // (A/B: slower on the group matrices)
     const bool library_sort = librarySortFor("matrices") || segmented;  // A/B knob (read per call: the tests take both ways)
     SegmentSortPlan plan;
     for (uint32_t m = 0; m < M; ++m) plan.max_segment_rows = std::max<uint64_t>(plan.max_segment_rows, g->h_num_rows[m]);
@@ -1904,7 +1904,7 @@ hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollap
     // The rows of a problem are sorted as a segment: a handful of launches against the global sort's seven passes of three
     // launches each (same box, configs[2] batch: 12.0-12.5 ms per step against 14.6).  RPVG_HIP_EM_COLLAPSE_GLOBAL_SORT=1: the
     // global sort (A/B).
-    static const bool segmented = std::getenv("RPVG_HIP_EM_COLLAPSE_GLOBAL_SORT") == nullptr;
+    static const bool segmented = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_COLLAPSE_GLOBAL_SORT") == nullptr;
     if (segmented) {
         ok(tmp->csr_segments.alloc(2 * static_cast<size_t>(P)));
         ok(tmp->key_out.alloc(total_rows));

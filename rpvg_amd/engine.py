@@ -52,6 +52,10 @@ def lib() -> C.CDLL:
         L.rpvg_amd_batch_prepare_synth_dense.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32]
         L.rpvg_amd_run.restype = C.c_void_p
         L.rpvg_amd_run.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double)]
+        L.rpvg_amd_run_team.restype = C.c_int
+        L.rpvg_amd_run_team.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(CParams), C.c_int, C.POINTER(C.c_double)]
+        L.rpvg_amd_run_team_result.restype = C.c_void_p
+        L.rpvg_amd_run_team_result.argtypes = [C.c_void_p]
         L.rpvg_amd_run_inplace.restype = C.c_int
         L.rpvg_amd_run_inplace.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(CParams), C.POINTER(C.c_double)]
         L.rpvg_amd_run_from_alignments_inplace.restype = C.c_int
@@ -164,6 +168,25 @@ class Engine:
         h = lib().rpvg_amd_run(self.handle, prepared.handle, model.encode(), C.byref(params), C.byref(secs))
         if not h:
             raise hip.EngineError(f"run({model}) failed: {_err()}")
+        try:
+            view = CEstimatesView()
+            lib().rpvg_amd_result_view(h, C.byref(view))
+            out = decode_view(view)
+        finally:
+            lib().rpvg_amd_result_free(h)
+        return out, secs.value
+
+    def run_team(self, model: str, params: CParams, prepared: "PreparedBatch", threads: int, decode: bool = True):
+        """The reference's cluster loop (src/main.cpp:829,976-977): PathEstimator::estimate() once per cluster from an OpenMP team
+        of `threads`; `prepared` was made with per_cluster=True.  Returns (estimates or None, wall seconds)."""
+        secs = C.c_double(0)
+        if lib().rpvg_amd_run_team(self.handle, prepared.handle, model.encode(), C.byref(params), threads, C.byref(secs)) != 0:
+            raise hip.EngineError(f"run_team({model}) failed: {_err()}")
+        if not decode:
+            return None, secs.value
+        h = lib().rpvg_amd_run_team_result(prepared.handle)
+        if not h:
+            raise hip.EngineError(f"run_team({model}) result failed: {_err()}")
         try:
             view = CEstimatesView()
             lib().rpvg_amd_result_view(h, C.byref(view))

@@ -269,6 +269,32 @@ void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & clus
     cluster_path_off.emplace_back(cluster_path_off.back() + num_paths);
 }
 
+void FlatClusterRows::append(const FlatClusterRows & other) {
+
+    auto appendOffsets = [](std::vector<uint64_t> & to, const std::vector<uint64_t> & from) {
+
+        const uint64_t base = to.back();
+
+        for (size_t i = 1; i < from.size(); ++i) {
+
+            to.emplace_back(base + from[i]);
+        }
+    };
+
+    appendOffsets(cluster_row_off, other.cluster_row_off);
+    appendOffsets(cluster_path_off, other.cluster_path_off);
+    appendOffsets(row_grp_off, other.row_grp_off);
+    appendOffsets(grp_idx_off, other.grp_idx_off);
+    appendOffsets(path_source_off, other.path_source_off);
+
+    row_count.insert(row_count.end(), other.row_count.begin(), other.row_count.end());
+    row_noise.insert(row_noise.end(), other.row_noise.begin(), other.row_noise.end());
+    grp_prob.insert(grp_prob.end(), other.grp_prob.begin(), other.grp_prob.end());
+    path_idx.insert(path_idx.end(), other.path_idx.begin(), other.path_idx.end());
+    path_group_id.insert(path_group_id.end(), other.path_group_id.begin(), other.path_group_id.end());
+    source_id.insert(source_id.end(), other.source_id.begin(), other.source_id.end());
+}
+
 rpvg_cluster_batch FlatClusterRows::view() const {
 
     rpvg_cluster_batch batch;

@@ -102,6 +102,10 @@ class FlatClusterRows {
         // carries its haplotype columns, rpvg_hip_batch_upload).  All clusters of a batch with them, or none.
         void addCluster(const std::vector<ReadPathProbabilities> & cluster_probs, const std::vector<PathInfo> & paths);
 
+        // The clusters of `other` behind this one's (the call combiner of PathEstimator::estimate() joins the clusters its
+        // callers flattened).  Both with paths, or both without.
+        void append(const FlatClusterRows & other);
+
         uint32_t numClusters() const { return cluster_row_off.size() - 1; }
         rpvg_cluster_batch view() const;
 

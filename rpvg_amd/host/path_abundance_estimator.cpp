@@ -394,7 +394,7 @@ static int clusterChunk() {
 
     static const int chunk = []() {
 
-        const char * env = std::getenv("RPVG_AMD_CLUSTER_CHUNK");
+        const char * env = RPVG_AMD_EXPERIMENT_ENV("RPVG_AMD_CLUSTER_CHUNK");
         return env ? std::max(1, std::atoi(env)) : 1;
     }();
 
@@ -407,7 +407,7 @@ static int clusterChunk() {
 // containers too then, until its work is done (PathEstimator::runInLanes drops them while it waits for the other lanes).
 static void dropNowOrLater(std::function<void(int)> drop, const bool between_device_stages = false) {
 
-    static const bool never_later = std::getenv("RPVG_AMD_NO_DEFERRED_TEARDOWN") != nullptr;
+    static const bool never_later = RPVG_AMD_EXPERIMENT_ENV("RPVG_AMD_NO_DEFERRED_TEARDOWN") != nullptr;
 
     if (never_later || !LaneScope::active() || (HipEngine::currentLane() == 0 && !between_device_stages)) {
 

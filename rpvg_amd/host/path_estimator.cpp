@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cassert>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <functional>
 #include <memory>
@@ -93,7 +94,7 @@ class GroupMatrices {
 
             ScopedPhase phase("posteriors: group matrices free");
 
-            static const bool never_later = std::getenv("RPVG_AMD_NO_DEFERRED_TEARDOWN") != nullptr;
+            static const bool never_later = RPVG_AMD_EXPERIMENT_ENV("RPVG_AMD_NO_DEFERRED_TEARDOWN") != nullptr;
             rpvg_hip_ctx * lane_context = engine->ctx();  // (not the engine: its lane threads own the closures, and it owns them)
             std::shared_ptr<rpvg_hip_groups> holder(groups, [lane_context](rpvg_hip_groups * matrices) { rpvg_hip_groups_free(lane_context, matrices); });
 
@@ -498,7 +499,7 @@ PathEstimator::PathEstimator(const double prob_precision_in, std::shared_ptr<Hip
     assert(engine);
 }
 
-void PathEstimator::estimate(PathClusterEstimates * path_cluster_estimates, const std::vector<ReadPathProbabilities> & cluster_probs, std::mt19937 * mt_rng) {
+void PathEstimator::estimateAlone(PathClusterEstimates * path_cluster_estimates, const std::vector<ReadPathProbabilities> & cluster_probs, std::mt19937 * mt_rng) {
 
     FlatClusterRows rows;
     rows.addCluster(cluster_probs, path_cluster_estimates->paths);  // (with PathInfo::group_id / source_ids: the device forms the haplotype columns)
@@ -523,6 +524,262 @@ void PathEstimator::estimate(PathClusterEstimates * path_cluster_estimates, cons
     }
 
     *path_cluster_estimates = std::move(batch_estimates.front());
+}
+
+// The reference calls estimate() once per cluster from every thread of an OpenMP team (src/main.cpp:829,976-977:
+// `schedule(dynamic, 1)`).  One cluster is a poor unit of work for a GPU — a chain of some sixty dependent launches whatever
+// its size — so the calls that are in flight at the same time are joined: a caller flattens its cluster (its own work, on
+// its own thread), parks it and sleeps; the first to park leads — it waits for one of three device contexts of the engine
+// to be free and then until 256 clusters are parked, or nobody has arrived for 50 us, or 500 us have passed, takes what is
+// parked as ONE batch through estimateBatch() on that context (up to three batches of a large team are on the GPU at
+// once; while all three are busy the next batch grows), hands every caller its estimates and its advanced generator, and
+// wakes them.
+// Cluster i of a batch is estimated exactly as estimateBatch() estimates it: the results do not depend on who shared the batch.
+// RPVG_AMD_NO_COMBINER=1: every call a batch of one (estimateAlone).  RPVG_AMD_COMBINE_MAX / _QUIET_US / _LINGER_US: the three bounds.
+class PathEstimator::CallCombiner {
+
+    public:
+
+        CallCombiner() : leader_present(false), busy_slots(0) {
+
+            auto setting = [](const char * name, const long fallback) {
+
+                const char * env = std::getenv(name);
+                return env ? std::max(1L, std::atol(env)) : fallback;
+            };
+
+            max_clusters = setting("RPVG_AMD_COMBINE_MAX", 256);
+            quiet = std::chrono::microseconds(setting("RPVG_AMD_COMBINE_QUIET_US", 50));
+            linger = std::chrono::microseconds(setting("RPVG_AMD_COMBINE_LINGER_US", 500));
+        }
+
+        void call(PathEstimator * owner, PathClusterEstimates * path_cluster_estimates, const std::vector<ReadPathProbabilities> & cluster_probs, std::mt19937 * mt_rng) {
+
+            Parked me;
+
+            {
+                ScopedPhase phase("combiner: flatten the cluster (callers, summed)");
+                me.rows.addCluster(cluster_probs, path_cluster_estimates->paths);
+            }
+
+            me.estimates = path_cluster_estimates;
+            me.rng = mt_rng;
+
+            std::unique_lock<std::mutex> lock(mutex);
+
+            const auto now = std::chrono::steady_clock::now();
+
+            if (staging.empty()) {
+
+                first_arrival = now;
+            }
+
+            last_arrival = now;
+            staging.emplace_back(&me);
+
+            if (leader_present) {
+
+                arrived.notify_all();
+                finished.wait(lock, [&] { return me.done; });
+
+            } else {
+
+                leader_present = true;
+
+                // a batch leaves when a device context is free for it — while all three are busy the parked clusters simply pile up,
+                // so the batches grow with the load — and, a context being free, when enough clusters are parked or nobody has
+                // arrived for a while
+                while (true) {
+
+                    const bool slot_free = busy_slots != 7;
+                    const auto deadline = std::min(first_arrival + linger, last_arrival + quiet);
+
+                    if (slot_free && (staging.size() >= static_cast<size_t>(max_clusters) || std::chrono::steady_clock::now() >= deadline)) {
+
+                        break;
+                    }
+
+                    if (slot_free) {
+
+                        arrived.wait_until(lock, deadline);
+
+                    } else {
+
+                        arrived.wait(lock);  // (a freed context notifies too)
+                    }
+                }
+
+                std::vector<Parked *> batch;
+                batch.swap(staging);
+                leader_present = false;  // (whoever parks next leads the next batch, while this one runs)
+
+                // one of the three device contexts of the engine that are not the calling threads' own (lanes 1 to 3)
+                int slot = 1;
+
+                while (busy_slots & (1 << (slot - 1))) {
+
+                    ++slot;
+                }
+
+                busy_slots |= 1 << (slot - 1);
+                lock.unlock();
+
+                std::exception_ptr error = nullptr;
+
+                try {
+
+                    flush(owner, batch, slot);
+
+                } catch (...) {
+
+                    error = std::current_exception();
+                }
+
+                lock.lock();
+                busy_slots &= ~(1 << (slot - 1));
+
+                for (auto & parked: batch) {
+
+                    parked->error = error;
+                    parked->done = true;
+                }
+
+                lock.unlock();
+                arrived.notify_all();
+                finished.notify_all();
+            }
+
+            if (me.error) {
+
+                std::rethrow_exception(me.error);
+            }
+        }
+
+    private:
+
+        struct Parked {
+
+            FlatClusterRows rows;
+            PathClusterEstimates * estimates = nullptr;
+            std::mt19937 * rng = nullptr;
+            bool done = false;
+            std::exception_ptr error = nullptr;
+        };
+
+        static void flush(PathEstimator * owner, const std::vector<Parked *> & batch, const int slot) {
+
+            ScopedPhase flush_phase("combiner: batches (leaders, summed)");
+            PhaseTrace::add("combiner: number of batches", 1e-3);
+            PhaseTrace::add("combiner: clusters in batches", 1e-3 * batch.size());
+
+            std::unique_ptr<ScopedPhase> phase(new ScopedPhase("combiner: join the clusters"));
+
+            FlatClusterRows rows;
+            bool all_have_generators = true;
+
+            for (auto & parked: batch) {
+
+                rows.append(parked->rows);
+                all_have_generators = all_have_generators && parked->rng;
+            }
+
+            phase.reset(new ScopedPhase("combiner: upload"));
+
+            // the engine's context for this thread while the batch runs: lane `slot` (a thread that is not in lane 0 runs its
+            // batch on that lane's context, whole: PathEstimator::runInLanes)
+            owner->engine->lane(slot);  // (creates the lane's context on first use)
+
+            struct LaneGuard {
+
+                int previous;
+                explicit LaneGuard(const int lane) : previous(HipEngine::currentLane()) { HipEngine::currentLane() = lane; }
+                ~LaneGuard() { HipEngine::currentLane() = previous; }
+
+            } lane_guard(slot);
+
+            const DeviceClusterBatch cluster_batch(owner->engine, rows.view());
+
+            phase.reset(new ScopedPhase("combiner: containers in"));
+
+            std::vector<PathClusterEstimates> batch_estimates(batch.size());
+            std::vector<std::mt19937> rngs;
+
+            for (size_t i = 0; i < batch.size(); ++i) {
+
+                batch_estimates[i] = std::move(*batch[i]->estimates);
+
+                if (all_have_generators) {
+
+                    rngs.emplace_back(*batch[i]->rng);
+                }
+            }
+
+            phase.reset(new ScopedPhase("combiner: estimateBatch"));
+            std::exception_ptr error = nullptr;
+
+            try {
+
+                owner->estimateBatch(&batch_estimates, cluster_batch, all_have_generators ? &rngs : nullptr);
+
+            } catch (...) {
+
+                error = std::current_exception();
+            }
+
+            phase.reset(new ScopedPhase("combiner: containers out"));
+
+            for (size_t i = 0; i < batch.size(); ++i) {  // (the callers' containers go back whatever happened: their paths are in them)
+
+                *batch[i]->estimates = std::move(batch_estimates[i]);
+
+                if (all_have_generators && !error) {
+
+                    *batch[i]->rng = rngs[i];
+                }
+            }
+
+            if (error) {
+
+                std::rethrow_exception(error);
+            }
+        }
+
+        std::mutex mutex;
+        std::condition_variable arrived, finished;
+
+        std::vector<Parked *> staging;
+        std::chrono::steady_clock::time_point first_arrival, last_arrival;
+        bool leader_present;
+        int busy_slots;
+
+        long max_clusters;
+        std::chrono::microseconds quiet, linger;
+};
+
+void PathEstimator::estimate(PathClusterEstimates * path_cluster_estimates, const std::vector<ReadPathProbabilities> & cluster_probs, std::mt19937 * mt_rng) {
+
+    static const bool alone = std::getenv("RPVG_AMD_NO_COMBINER") != nullptr;
+
+    if (alone) {
+
+        estimateAlone(path_cluster_estimates, cluster_probs, mt_rng);
+        return;
+    }
+
+    std::shared_ptr<CallCombiner> combiner;
+
+    {
+        std::lock_guard<std::mutex> lock(call_combiner_mutex);
+
+        if (!call_combiner) {
+
+            call_combiner = std::make_shared<CallCombiner>();
+        }
+
+        combiner = call_combiner;
+    }
+
+    combiner->call(this, path_cluster_estimates, cluster_probs, mt_rng);
 }
 
 // Host lanes over the GPU (pipeline_lanes.hpp): the clusters arrive ordered by size, so dealing them out round
@@ -567,7 +824,7 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
     // one by one to the lane that is furthest behind its share
     std::vector<double> share(num_lanes, 1.0);
 
-    if (const char * env = std::getenv("RPVG_AMD_LANE_SHARES")) {
+    if (const char * env = RPVG_AMD_EXPERIMENT_ENV("RPVG_AMD_LANE_SHARES")) {
 
         const char * cursor = env;
 
@@ -623,6 +880,7 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
 
             stagger.waitTurn(lane);
 
+#ifdef RPVG_AMD_EXPERIMENTS
             // A/B knob RPVG_AMD_LANE_DELAY_US: the lane starts this much later still
             static const long lane_delay_us = std::getenv("RPVG_AMD_LANE_DELAY_US") ? std::atol(std::getenv("RPVG_AMD_LANE_DELAY_US")) : 0;
 
@@ -630,6 +888,7 @@ void PathEstimator::runInLanes(const std::vector<uint32_t> & clusters, const std
 
                 std::this_thread::sleep_for(std::chrono::microseconds(lane_delay_us));
             }
+#endif
 
             try {
 

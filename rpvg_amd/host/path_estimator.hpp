@@ -6,7 +6,12 @@
 // Two ways in:
 //   estimate()       one cluster, synchronous; signature of the reference
 //                    (src/path_estimator.hpp:23), callable from the reference's
-//                    own loop (src/main.cpp:977).  It is a batch of one.
+//                    own loop (src/main.cpp:977) — from all threads of its OpenMP
+//                    team at once: the calls that are in flight together are
+//                    joined into batches (CallCombiner, path_estimator.cpp), up to
+//                    three of them on the GPU at a time; every caller returns
+//                    with its own cluster's estimates and its own generator
+//                    advanced.  A lone caller gets a batch of one.
 //   estimateBatch()  all clusters of a batch at once; what a GPU wants, and
 //                    what the reference's `omp parallel for` over clusters
 //                    (src/main.cpp:829) becomes.
@@ -16,6 +21,7 @@
 #include <cstdint>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <vector>
 
@@ -97,6 +103,9 @@ class PathEstimator {
         // Same, seeding cluster i with mt19937(rng_seed + i) as src/main.cpp:976 does.
         void estimateBatchSeeded(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const uint32_t rng_seed);
 
+        // estimate() without the call combiner: the cluster as a batch of one, on the calling thread.
+        void estimateAlone(PathClusterEstimates * path_cluster_estimates, const std::vector<ReadPathProbabilities> & cluster_probs, std::mt19937 * mt_rng);
+
     protected:
 
         const double prob_precision;
@@ -161,6 +170,13 @@ class PathEstimator {
 
         // src/path_estimator.cpp:315-330
         static std::vector<double> calcPathLogFrequences(const std::vector<uint32_t> & path_counts);
+
+    private:
+
+        // Joins the estimate() calls of concurrent threads into batches (path_estimator.cpp).
+        class CallCombiner;
+        std::shared_ptr<CallCombiner> call_combiner;
+        std::mutex call_combiner_mutex;
 };
 
 }

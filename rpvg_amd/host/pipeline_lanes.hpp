@@ -17,6 +17,8 @@
 #include <thread>
 #include <vector>
 
+#include "experiments.hpp"
+
 namespace rpvg_amd {
 
 // Staggered start of the lanes of one batch.  Lanes that begin together stay in lock step — the same host
@@ -32,7 +34,7 @@ class LaneStagger {
             released.at(0) = true;
 
             // RPVG_AMD_NO_STAGGER=1 (A/B knob): every lane starts at once
-            static const bool no_stagger = std::getenv("RPVG_AMD_NO_STAGGER") != nullptr;
+            static const bool no_stagger = RPVG_AMD_EXPERIMENT_ENV("RPVG_AMD_NO_STAGGER") != nullptr;
 
             if (no_stagger) {
 

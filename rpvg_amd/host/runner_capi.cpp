@@ -483,6 +483,91 @@ void * rpvg_amd_run(void * engine, void * prepared_batch, const char * model, co
     }
 }
 
+// The reference's cluster loop (src/main.cpp:829,976-977) on a batch prepared with keep_rows: estimate() once per cluster
+// from an OpenMP team of `threads` (schedule(dynamic, 1), clusters in the batch's order), cluster i with mt19937(rng_seed + i).
+// The estimates stay in the prepared batch's containers (rpvg_amd_run_team_result flattens them).
+int rpvg_amd_run_team(void * engine, void * prepared_batch, const char * model, const rpvg_params * params, int threads, double * seconds_out) {
+
+    try {
+
+        PreparedBatch * prepared = static_cast<PreparedBatch *>(prepared_batch);
+
+        if (prepared->rows.size() != prepared->paths.size()) {
+
+            last_error = "rpvg_amd_run_team needs a batch prepared with keep_rows";
+            return -1;
+        }
+
+        auto estimator = makePathEstimator(model, *params, static_cast<Engine *>(engine)->hip);
+
+        if (prepared->estimates.size() != prepared->paths.size()) {
+
+            prepared->estimates.assign(prepared->paths.size(), PathClusterEstimates());
+
+            for (size_t i = 0; i < prepared->estimates.size(); ++i) {
+
+                prepared->estimates.at(i).paths = prepared->paths.at(i);
+            }
+        }
+
+        std::vector<PathClusterEstimates> & estimates = prepared->estimates;
+        std::string first_failure;
+
+        const auto start = std::chrono::steady_clock::now();
+
+        #pragma omp parallel for schedule(dynamic, 1) num_threads(std::max(1, threads))
+        for (size_t i = 0; i < estimates.size(); ++i) {
+
+            try {
+
+                std::mt19937 mt_rng(params->rng_seed + i);
+                estimator->estimate(&estimates.at(i), prepared->rows.at(i), &mt_rng);
+
+            } catch (const std::exception & e) {
+
+                #pragma omp critical
+                if (first_failure.empty()) {
+
+                    first_failure = e.what();
+                }
+            }
+        }
+
+        if (seconds_out) {
+
+            *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+        }
+
+        PhaseTrace::report();
+
+        if (!first_failure.empty()) {
+
+            last_error = first_failure;
+            return -1;
+        }
+
+        return 0;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
+void * rpvg_amd_run_team_result(void * prepared_batch) {
+
+    try {
+
+        return packResult(static_cast<PreparedBatch *>(prepared_batch)->estimates);
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return nullptr;
+    }
+}
+
 // Same run, estimates left in the prepared batch's containers and not flattened
 // (timing loops).  Returns 0 on success.
 int rpvg_amd_run_inplace(void * engine, void * prepared_batch, const char * model, const rpvg_params * params, double * seconds_out) {

@@ -15,6 +15,8 @@
 
 #include <omp.h>
 
+#include "experiments.hpp"
+
 namespace rpvg_amd {
 
 // Threads used by the host-side parallel loops (flattening, subset selection, merging).  These loops

@@ -218,13 +218,10 @@ def test_em_solve_collapses_planted_near_identical_rows(n_rows):
 
 
 
-@pytest.mark.parametrize("sort", ["segment", "library"])
-def test_planted_close_rows_in_matrices_of_several_sort_chunks(engine, monkeypatch, sort):
+def test_planted_close_rows_in_matrices_of_several_sort_chunks(engine):
     """Clusters of a few thousand reads: their group matrices are beyond the one-workgroup sort of the collapse (1 024 rows) and
     go through chunks of 2 048 rows merged pairwise (row_collapse.hip, stage 0) — the same planted near-equal rows must reach the
-    replay either way, and with the library's radix sort (RPVG_HIP_COLLAPSE_LIBRARY_SORT=1) in its place."""
-    if sort == "library":
-        monkeypatch.setenv("RPVG_HIP_COLLAPSE_LIBRARY_SORT", "1")
+    replay either way."""
     rng = np.random.default_rng(4100)
     clusters = []
     for n_reads in (20000, 40000):  # 3 400 and 5 600 distinct rows after the caller's merge: two and three sort chunks

@@ -483,3 +483,29 @@ def test_device_subset_path_equals_the_separate_calls(engine, monkeypatch):
     assert most_subsets > 64, most_subsets  # the wide select kernel was exercised
     ref, _ = pyoracle.run("haplotype-transcripts", params, batch, 4)
     _compare(fused, ref)
+
+
+@pytest.mark.parametrize("model,kw", [("haplotype-transcripts", {}), ("transcripts", {}), ("haplotypes", dict(use_hap_gibbs=1, rng_seed=21)),
+                                      ("haplotype-transcripts", dict(ind_hap_inference=1, rng_seed=4)), ("strains", {})],
+                         ids=["nested", "transcripts", "haplotype-gibbs", "nested-independent", "strains"])
+@pytest.mark.parametrize("threads", [64, 5])
+def test_team_of_threads_calling_estimate_equals_the_batch(engine, model, kw, threads):
+    """The reference's cluster loop (src/main.cpp:829,976-977): estimate() once per cluster from every thread of an OpenMP
+    team, cluster i with mt19937(rng_seed + i).  The calls in flight are joined into batches behind the interface
+    (PathEstimator::CallCombiner) — which clusters share a batch depends on the scheduler, the estimates of a cluster must
+    not: they equal those of estimateBatch() on all clusters at once, and the oracle's."""
+    clusters = small_cases.make_batch_clusters(6400, n_clusters=150, with_empty=True)
+    batch = ClusterBatch.from_clusters(clusters)
+    params = make_params(**kw)
+    whole, _ = engine.run(model, params, engine.prepare(batch))
+    for repeat in range(2):  # (different batch compositions)
+        team, secs = engine.run_team(model, params, engine.prepare(batch, per_cluster=True), threads)
+        assert secs > 0
+        for k, (t, w) in enumerate(zip(team, whole)):
+            assert t.path_group_sets == w.path_group_sets, k
+            assert np.allclose(t.posteriors, w.posteriors, rtol=1e-12, atol=0) and np.allclose(t.abundances, w.abundances, rtol=1e-9, atol=1e-12), k
+            assert abs(t.noise_count - w.noise_count) <= 1e-9 * max(1.0, w.total_count) and t.total_count == w.total_count, k
+            assert t.em_iters == w.em_iters and t.em_cols == w.em_cols, k
+    if not kw:
+        ref, _ = pyoracle.run(model, params, batch, 4)
+        _compare(team, ref)
