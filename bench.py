@@ -609,8 +609,10 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
     when it stops: ramp-up and drain are inside."""
     import resource
     from rpvg_amd import hip
-    arrays = [batch.cluster_row_off, batch.cluster_path_off, batch.row_count, batch.row_noise, batch.row_grp_off, batch.grp_prob,
-              batch.grp_idx_off, batch.path_idx, batch.path_group_id, batch.path_source_off, batch.source_id]
+    # (the two long offset arrays in their 32-bit form, include/rpvg_batch.h: what a caller that flattens rows for the GPU writes)
+    row_grp_off32, grp_idx_off32 = batch.offsets32()
+    arrays = [batch.cluster_row_off, batch.cluster_path_off, batch.row_count, batch.row_noise, row_grp_off32, batch.grp_prob,
+              grp_idx_off32, batch.path_idx, batch.path_group_id, batch.path_source_off, batch.source_id]
     for a in arrays:
         hip.host_register(a)
     pipe = eng_mod.Pipeline(args.model, params, local_rank, workers=args.pipeline_workers)
@@ -618,14 +620,14 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
         slots = pipe.workers + 4
         pipe.prepare_slots(batch, slots)
         for k in range(max(args.warmup, 2 * slots)):
-            pipe.submit(batch, k % slots)
+            pipe.submit(batch, k % slots, compact=True)
         pipe.wait()
         pipe.reset_stats()
         barrier_sync(dist, torch)
         cpu0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         for k in range(args.steps):
-            pipe.submit(batch, k % slots)
+            pipe.submit(batch, k % slots, compact=True)
         pipe.wait()
         barrier_sync(dist, torch)
         elapsed = max_over_ranks(time.perf_counter() - t0, dist, torch)

@@ -46,7 +46,21 @@ typedef struct rpvg_cluster_batch {
     const uint64_t * path_source_off;   /* [P+1] range into source_id               */
     const uint32_t * source_id;         /* [S]   PathInfo::source_ids (any order)   */
     const double * path_effective_length; /* [P] PathInfo::effective_length (TPM only; may be NULL) */
+
+    /* The two long offset arrays in 32 bits, for a batch of fewer than 2^32 groups and entries: used INSTEAD of row_grp_off /
+     * grp_idx_off when not NULL (those may then be NULL).  A third of a batch's bytes are offsets, and the copy to the GPU is
+     * what paces a pipeline of batches (rpvg_amd/host/batch_pipeline.hpp): whoever flattens rows writes these. */
+    const uint32_t * row_grp_off32;    /* [R+1] */
+    const uint32_t * grp_idx_off32;    /* [G+1] */
 } rpvg_cluster_batch;
+
+/* The two long offset arrays of a batch in whichever width its owner wrote them. */
+static inline uint64_t rpvg_batch_row_group_offset(const rpvg_cluster_batch * batch, uint64_t row) {
+    return batch->row_grp_off32 ? batch->row_grp_off32[row] : batch->row_grp_off[row];
+}
+static inline uint64_t rpvg_batch_group_entry_offset(const rpvg_cluster_batch * batch, uint64_t group) {
+    return batch->grp_idx_off32 ? batch->grp_idx_off32[group] : batch->grp_idx_off[group];
+}
 
 /* Every option of src/main.cpp that reaches the estimators, same defaults
  * (see rpvg_params_default()). */

@@ -38,6 +38,8 @@ class CClusterBatch(C.Structure):
         ("path_source_off", u64p),
         ("source_id", u32p),
         ("path_effective_length", f64p),
+        ("row_grp_off32", u32p),
+        ("grp_idx_off32", u32p),
     ]
 
 
@@ -139,14 +141,32 @@ class ClusterBatch:
     def total_reads(self) -> int:
         return int(self.row_count.astype(np.uint64).sum())
 
-    def as_c(self) -> CClusterBatch:
+    def offsets32(self):
+        """The two long offset arrays in 32 bits (rpvg_cluster_batch::row_grp_off32 / grp_idx_off32), made once and kept."""
+        cached = getattr(self, "_offsets32", None)
+        if cached is None:
+            assert int(self.grp_idx_off[-1]) < 2 ** 32 and int(self.row_grp_off[-1]) < 2 ** 32
+            cached = (np.ascontiguousarray(self.row_grp_off, dtype=np.uint32), np.ascontiguousarray(self.grp_idx_off, dtype=np.uint32))
+            self._offsets32 = cached
+        return cached
+
+    def as_c(self, compact: bool = False) -> CClusterBatch:
+        """compact: the 32-bit forms of the two long offset arrays instead of the 64-bit ones (a sixth fewer bytes to copy)."""
         # the returned struct borrows the arrays: keep `self` alive while it is in use
+        if compact:
+            row32, grp32 = self.offsets32()
+            return CClusterBatch(
+                self.num_clusters, _ptr(self.cluster_row_off, u64p), _ptr(self.cluster_path_off, u64p),
+                _ptr(self.row_count, u32p), _ptr(self.row_noise, f64p), None,
+                _ptr(self.grp_prob, f64p), None, _ptr(self.path_idx, u32p),
+                _ptr(self.path_group_id, u32p), _ptr(self.path_source_count, u32p), _ptr(self.path_source_off, u64p),
+                _ptr(self.source_id, u32p), _ptr(self.path_effective_length, f64p), _ptr(row32, u32p), _ptr(grp32, u32p))
         return CClusterBatch(
             self.num_clusters, _ptr(self.cluster_row_off, u64p), _ptr(self.cluster_path_off, u64p),
             _ptr(self.row_count, u32p), _ptr(self.row_noise, f64p), _ptr(self.row_grp_off, u64p),
             _ptr(self.grp_prob, f64p), _ptr(self.grp_idx_off, u64p), _ptr(self.path_idx, u32p),
             _ptr(self.path_group_id, u32p), _ptr(self.path_source_count, u32p), _ptr(self.path_source_off, u64p),
-            _ptr(self.source_id, u32p), _ptr(self.path_effective_length, f64p))
+            _ptr(self.source_id, u32p), _ptr(self.path_effective_length, f64p), None, None)
 
     # ---- construction from nested python data (tests, fixtures) -------------
     @staticmethod

@@ -713,7 +713,7 @@ struct rpvg_hip_batch {
     std::vector<uint32_t> h_src_num_cols, h_src_col_paths, h_src_max_col_paths;  // [K] columns, sum and maximum of their list lengths
     // An upload in two halves (rpvg_hip_batch_upload_begin / _finish): what the kernels of the second half read and free.
     struct UploadInProgress {
-        rpvg_hip_detail::DeviceBuffer<uint32_t> d_row_count_u32;
+        rpvg_hip_detail::DeviceBuffer<uint32_t> d_row_count_u32, d_row_grp_off32, d_grp_idx_off32;
         rpvg_hip_detail::DeviceBuffer<uint64_t> d_row_grp_off, d_grp_idx_off;
         rpvg_hip_detail::DeviceBuffer<double> d_grp_prob;
         uint64_t num_groups = 0;

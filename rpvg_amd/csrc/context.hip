@@ -716,6 +716,15 @@ extern "C" int rpvg_hip_host_unregister(void * host) {
 
 namespace {
 
+// the two long offset arrays of a host batch, in whichever width the caller wrote them (include/rpvg_batch.h)
+inline uint64_t rowGroupOffset(const rpvg_cluster_batch * hb, const uint64_t r) { return hb->row_grp_off32 ? hb->row_grp_off32[r] : hb->row_grp_off[r]; }
+inline uint64_t groupEntryOffset(const rpvg_cluster_batch * hb, const uint64_t g) { return hb->grp_idx_off32 ? hb->grp_idx_off32[g] : hb->grp_idx_off[g]; }
+
+__global__ void widenOffsetsKernel(const uint64_t n, const uint32_t * __restrict__ narrow, uint64_t * __restrict__ wide) {
+    const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (i < n) wide[i] = narrow[i];
+}
+
 // Words what is wrong with row r of cluster k (validateRowsKernel found it); true: nothing is.
 constexpr size_t kProblemChars = 256;
 bool validateRow(const rpvg_cluster_batch * hb, const uint32_t k, const uint64_t r, char * message) {
@@ -727,7 +736,7 @@ bool validateRow(const rpvg_cluster_batch * hb, const uint32_t k, const uint64_t
                       static_cast<unsigned long long>(r), nz);
         return false;
     }
-    for (uint64_t e = hb->grp_idx_off[hb->row_grp_off[r]]; e < hb->grp_idx_off[hb->row_grp_off[r + 1]]; ++e) {
+    for (uint64_t e = groupEntryOffset(hb, rowGroupOffset(hb, r)); e < groupEntryOffset(hb, rowGroupOffset(hb, r + 1)); ++e) {
         if (!(hb->path_idx[e] < n_paths)) {
             std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: row %llu refers to path %u of a cluster with %llu paths",
                           static_cast<unsigned long long>(r), hb->path_idx[e], static_cast<unsigned long long>(n_paths));
@@ -749,10 +758,10 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
     RPVG_REQUIRE(hb->cluster_row_off && hb->cluster_path_off, "rpvg_hip_batch_upload: cluster offsets are NULL");
     const uint64_t R = hb->cluster_row_off[K];
     const uint64_t P = hb->cluster_path_off[K];
-    RPVG_REQUIRE(R == 0 || (hb->row_count && hb->row_noise && hb->row_grp_off && hb->grp_idx_off),
+    RPVG_REQUIRE(R == 0 || (hb->row_count && hb->row_noise && (hb->row_grp_off || hb->row_grp_off32) && (hb->grp_idx_off || hb->grp_idx_off32)),
                  "rpvg_hip_batch_upload: row arrays are NULL");
-    const uint64_t G = R ? hb->row_grp_off[R] : 0;
-    const uint64_t NNZ = G ? hb->grp_idx_off[G] : 0;
+    const uint64_t G = R ? rowGroupOffset(hb, R) : 0;
+    const uint64_t NNZ = G ? groupEntryOffset(hb, G) : 0;
     RPVG_REQUIRE(G == 0 || hb->grp_prob, "rpvg_hip_batch_upload: grp_prob is NULL");
     RPVG_REQUIRE(NNZ == 0 || hb->path_idx, "rpvg_hip_batch_upload: path_idx is NULL");
 
@@ -782,7 +791,7 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
     b->h_cluster_ent_off.resize(K + 1);
     for (uint32_t k = 0; k <= K; ++k) {
         const uint64_t r = hb->cluster_row_off[k];
-        b->h_cluster_ent_off[k] = R ? hb->grp_idx_off[hb->row_grp_off[r]] : 0;
+        b->h_cluster_ent_off[k] = R ? groupEntryOffset(hb, rowGroupOffset(hb, r)) : 0;
     }
     b->upload.reset(new rpvg_hip_batch::UploadInProgress());
     rpvg_hip_batch::UploadInProgress & up = *b->upload;
@@ -797,8 +806,19 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
     ok(b->row_noise.upload(hb->row_noise, R, ctx->stream));
     ok(up.d_row_count_u32.upload(hb->row_count, R, ctx->stream));
     const uint64_t zero_off[1] = {0};
-    ok(up.d_row_grp_off.upload(R ? hb->row_grp_off : zero_off, R + 1, ctx->stream));
-    ok(up.d_grp_idx_off.upload(G ? hb->grp_idx_off : zero_off, G + 1, ctx->stream));
+    // (the 32-bit forms travel as they are and are widened on the device, behind the copy)
+    if (R && hb->row_grp_off32) {
+        ok(up.d_row_grp_off32.upload(hb->row_grp_off32, R + 1, ctx->stream));
+        ok(up.d_row_grp_off.alloc(R + 1));
+    } else {
+        ok(up.d_row_grp_off.upload(R ? hb->row_grp_off : zero_off, R + 1, ctx->stream));
+    }
+    if (G && hb->grp_idx_off32) {
+        ok(up.d_grp_idx_off32.upload(hb->grp_idx_off32, G + 1, ctx->stream));
+        ok(up.d_grp_idx_off.alloc(G + 1));
+    } else {
+        ok(up.d_grp_idx_off.upload(G ? hb->grp_idx_off : zero_off, G + 1, ctx->stream));
+    }
     ok(up.d_grp_prob.upload(hb->grp_prob, G, ctx->stream));
     ok(b->ent_path.upload(hb->path_idx, NNZ, ctx->stream));
     ok(b->ent_prob.alloc(NNZ));
@@ -807,7 +827,7 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
     // the path side, when the caller handed it in: PathInfo::group_id and source_ids (path_sources.hip)
     if (e == hipSuccess) ok(queuePathSourceCopies(ctx, b, hb, up.path_sources));
     ctx->spanEnd(span);
-    ctx->stats.h2d_bytes += static_cast<double>((K + 1) * 16 + R * 12 + (R + 1) * 8 + (G + 1) * 8 + G * 8 + NNZ * 4);
+    ctx->stats.h2d_bytes += static_cast<double>((K + 1) * 16 + R * 12 + (R + 1) * (hb->row_grp_off32 ? 4 : 8) + (G + 1) * (hb->grp_idx_off32 ? 4 : 8) + G * 8 + NNZ * 4);
     if (e != hipSuccess) {
         setError("rpvg_hip_batch_upload: %s", hipGetErrorString(e));
         (void) hipStreamSynchronize(ctx->stream);
@@ -828,6 +848,12 @@ static int uploadFinish(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_clust
     const uint64_t G = up.num_groups;
     HostScope scope("batch_upload: kernels + wait");
     const int bspan = ctx->spanBegin(FAM_BUILD);
+    if (e == hipSuccess && up.d_row_grp_off32.ptr) {
+        widenOffsetsKernel<<<dim3(static_cast<uint32_t>((R + 1 + 255) / 256)), dim3(256), 0, ctx->stream>>>(R + 1, up.d_row_grp_off32.ptr, up.d_row_grp_off.ptr);
+    }
+    if (e == hipSuccess && up.d_grp_idx_off32.ptr) {
+        widenOffsetsKernel<<<dim3(static_cast<uint32_t>((G + 1 + 255) / 256)), dim3(256), 0, ctx->stream>>>(G + 1, up.d_grp_idx_off32.ptr, up.d_grp_idx_off.ptr);
+    }
     if (e == hipSuccess && G > 0) {
         const uint32_t threads = 256;
         expandGroupsKernel<<<dim3(static_cast<uint32_t>((G + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
@@ -870,9 +896,9 @@ static int uploadFinish(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_clust
         delete b;
         const uint32_t k = static_cast<uint32_t>(std::upper_bound(hb->cluster_row_off, hb->cluster_row_off + K + 1, first_bad_row) - hb->cluster_row_off) - 1;
         char message[kProblemChars];
-        const uint64_t g0 = hb->row_grp_off[first_bad_row], g1 = hb->row_grp_off[first_bad_row + 1];
+        const uint64_t g0 = rowGroupOffset(hb, first_bad_row), g1 = rowGroupOffset(hb, first_bad_row + 1);
         bool offsets_ok = g0 <= g1 && g1 <= G;
-        for (uint64_t g = g0; offsets_ok && g < g1; ++g) offsets_ok = hb->grp_idx_off[g] <= hb->grp_idx_off[g + 1] && hb->grp_idx_off[g + 1] <= NNZ;
+        for (uint64_t g = g0; offsets_ok && g < g1; ++g) offsets_ok = groupEntryOffset(hb, g) <= groupEntryOffset(hb, g + 1) && groupEntryOffset(hb, g + 1) <= NNZ;
         if (!offsets_ok || validateRow(hb, k, first_bad_row, message)) {
             std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: row %llu has inconsistent group or entry offsets", first_bad_row);
         }

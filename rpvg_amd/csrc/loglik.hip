@@ -764,7 +764,7 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
     // (0.84 against 1.05 ms per configs[2] batch standing alone, but 9.71 against 9.65 ms per batch in the two-lane bench: the
     // list kernels wait, and the other lane's kernels run meanwhile; the mask kernel computes)
     const char * masks_env = std::getenv("RPVG_HIP_BUILD_MASKS");
-    const bool build_masks = masks_env ? std::atoi(masks_env) != 0 : false;
+    const bool build_masks = masks_env ? std::atoi(masks_env) != 0 : true;
     for (uint32_t m = 0; m < M; ++m) {
         const uint32_t k = spec->cluster[m];
         if (k >= batch->num_clusters) {

@@ -287,8 +287,9 @@ class Pipeline:
         if lib().rpvg_amd_pipeline_prepare_slots(self.handle, C.byref(cb), slots) != 0:
             raise hip.EngineError(f"pipeline prepare failed: {_err()}")
 
-    def submit(self, batch: ClusterBatch, slot: int):
-        cb = batch.as_c()
+    def submit(self, batch: ClusterBatch, slot: int, compact: bool = False):
+        """compact: hand the batch over with 32-bit offset arrays (ClusterBatch.as_c)."""
+        cb = batch.as_c(compact)
         self._keep.append((batch, cb))
         if lib().rpvg_amd_pipeline_submit(self.handle, C.byref(cb), slot) != 0:
             raise hip.EngineError(f"pipeline submit failed: {_err()}")
@@ -355,10 +356,10 @@ class PreparedBatch:
         if not self.handle:
             raise hip.EngineError(f"batch prepare failed: {_err()}")
 
-    def reupload(self, engine: "Engine", batch: Optional[ClusterBatch] = None) -> float:
+    def reupload(self, engine: "Engine", batch: Optional[ClusterBatch] = None, compact: bool = False) -> float:
         """Replaces the resident rows by a fresh upload of `batch` (default: the batch this was prepared from) through
         `engine` (an uploader engine on the same GPU keeps the copy off the estimating engine's streams); seconds."""
-        cb = (batch or self.batch).as_c()
+        cb = (batch or self.batch).as_c(compact)
         secs = C.c_double(0)
         if lib().rpvg_amd_batch_reupload(engine.handle, self.handle, C.byref(cb), C.byref(secs)) != 0:
             raise hip.EngineError(f"batch reupload failed: {_err()}")

@@ -38,10 +38,10 @@ class BatchShard {
                     row_count.push_back(batch.row_count[row]);
                     row_noise.push_back(batch.row_noise[row]);
 
-                    for (uint64_t grp = batch.row_grp_off[row]; grp < batch.row_grp_off[row + 1]; ++grp) {
+                    for (uint64_t grp = rpvg_batch_row_group_offset(&batch, row); grp < rpvg_batch_row_group_offset(&batch, row + 1); ++grp) {
 
                         grp_prob.push_back(batch.grp_prob[grp]);
-                        path_idx.insert(path_idx.end(), batch.path_idx + batch.grp_idx_off[grp], batch.path_idx + batch.grp_idx_off[grp + 1]);
+                        path_idx.insert(path_idx.end(), batch.path_idx + rpvg_batch_group_entry_offset(&batch, grp), batch.path_idx + rpvg_batch_group_entry_offset(&batch, grp + 1));
                         grp_idx_off.push_back(path_idx.size());
                     }
 
@@ -70,7 +70,7 @@ class BatchShard {
 
         rpvg_cluster_batch view() const {
 
-            rpvg_cluster_batch out;
+            rpvg_cluster_batch out = {};
             out.num_clusters = cluster_row_off.size() - 1;
             out.cluster_row_off = cluster_row_off.data();
             out.cluster_path_off = cluster_path_off.data();
@@ -260,7 +260,7 @@ std::vector<double> DeviceGroup::clusterCosts(const rpvg_cluster_batch & batch) 
 
         const double num_rows = last_row - first_row;
         const double num_paths = batch.cluster_path_off[i + 1] - batch.cluster_path_off[i];
-        const double num_entries = batch.grp_idx_off[batch.row_grp_off[last_row]] - batch.grp_idx_off[batch.row_grp_off[first_row]];
+        const double num_entries = rpvg_batch_group_entry_offset(&batch, rpvg_batch_row_group_offset(&batch, last_row)) - rpvg_batch_group_entry_offset(&batch, rpvg_batch_row_group_offset(&batch, first_row));
 
         costs.at(i) = num_entries + num_rows * (num_paths + 1);
     }

@@ -56,6 +56,7 @@ struct FlatBatchStorage {
 
     void view(rpvg_cluster_batch * out) const {
 
+        *out = rpvg_cluster_batch();
         out->num_clusters = cluster_row_off.size() - 1;
         out->cluster_row_off = cluster_row_off.data();
         out->cluster_path_off = cluster_path_off.data();

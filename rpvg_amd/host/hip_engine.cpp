@@ -232,7 +232,7 @@ void HipEngine::check(const int status, const char * what) {
     }
 }
 
-FlatClusterRows::FlatClusterRows() : cluster_row_off(1, 0), cluster_path_off(1, 0), row_grp_off(1, 0), grp_idx_off(1, 0), path_source_off(1, 0) {}
+FlatClusterRows::FlatClusterRows() : cluster_row_off(1, 0), cluster_path_off(1, 0), path_source_off(1, 0), row_grp_off(1, 0), grp_idx_off(1, 0) {}
 
 void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & cluster_probs, const std::vector<PathInfo> & paths) {
 
@@ -251,6 +251,11 @@ void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & clus
 void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & cluster_probs, const uint32_t num_paths) {
 
     for (auto & probs: cluster_probs) {
+
+        if (path_idx.size() > 0xF0000000ull) {
+
+            throw EngineError("FlatClusterRows: a batch of more than 2^32 - 1 entries");
+        }
 
         row_count.emplace_back(probs.readCount());
         row_noise.emplace_back(probs.noiseProb());
@@ -271,9 +276,14 @@ void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & clus
 
 void FlatClusterRows::append(const FlatClusterRows & other) {
 
-    auto appendOffsets = [](std::vector<uint64_t> & to, const std::vector<uint64_t> & from) {
+    if (static_cast<uint64_t>(grp_prob.size()) + other.grp_prob.size() > 0xFFFFFFFFull || static_cast<uint64_t>(path_idx.size()) + other.path_idx.size() > 0xFFFFFFFFull) {
 
-        const uint64_t base = to.back();
+        throw EngineError("FlatClusterRows: a batch of more than 2^32 - 1 (probability, path list) groups or entries");
+    }
+
+    auto appendOffsets = [](auto & to, const auto & from) {
+
+        const auto base = to.back();
 
         for (size_t i = 1; i < from.size(); ++i) {
 
@@ -297,7 +307,7 @@ void FlatClusterRows::append(const FlatClusterRows & other) {
 
 rpvg_cluster_batch FlatClusterRows::view() const {
 
-    rpvg_cluster_batch batch;
+    rpvg_cluster_batch batch = {};
 
     batch.num_clusters = numClusters();
     batch.cluster_row_off = cluster_row_off.data();
@@ -305,9 +315,11 @@ rpvg_cluster_batch FlatClusterRows::view() const {
 
     batch.row_count = row_count.data();
     batch.row_noise = row_noise.data();
-    batch.row_grp_off = row_grp_off.data();
+    batch.row_grp_off = nullptr;
+    batch.row_grp_off32 = row_grp_off.data();
     batch.grp_prob = grp_prob.data();
-    batch.grp_idx_off = grp_idx_off.data();
+    batch.grp_idx_off = nullptr;
+    batch.grp_idx_off32 = grp_idx_off.data();
     batch.path_idx = path_idx.data();
 
     // the PathInfo fields the device reads, when the clusters were added with their paths; the rest of PathInfo stays on the

@@ -111,7 +111,9 @@ class FlatClusterRows {
 
     private:
 
-        std::vector<uint64_t> cluster_row_off, cluster_path_off, row_grp_off, grp_idx_off, path_source_off;
+        // (the two long offset arrays in 32 bits: rpvg_cluster_batch::row_grp_off32 / grp_idx_off32 — fewer bytes to copy)
+        std::vector<uint64_t> cluster_row_off, cluster_path_off, path_source_off;
+        std::vector<uint32_t> row_grp_off, grp_idx_off;
         std::vector<uint32_t> row_count, path_idx, path_group_id, source_id;
         std::vector<double> row_noise, grp_prob;
 };

@@ -39,9 +39,9 @@ std::vector<ProbabilityCluster> clustersFromBatch(const rpvg_cluster_batch & bat
 
             ReadPathProbabilities::PathProbs path_probs;
 
-            for (uint64_t g = batch.row_grp_off[r]; g < batch.row_grp_off[r + 1]; ++g) {
+            for (uint64_t g = rpvg_batch_row_group_offset(&batch, r); g < rpvg_batch_row_group_offset(&batch, r + 1); ++g) {
 
-                path_probs.emplace_back(batch.grp_prob[g], std::vector<uint32_t>(batch.path_idx + batch.grp_idx_off[g], batch.path_idx + batch.grp_idx_off[g + 1]));
+                path_probs.emplace_back(batch.grp_prob[g], std::vector<uint32_t>(batch.path_idx + rpvg_batch_group_entry_offset(&batch, g), batch.path_idx + rpvg_batch_group_entry_offset(&batch, g + 1)));
             }
 
             clusters[k].cluster_probs.emplace_back(batch.row_count[r], batch.row_noise[r], path_probs, prob_precision);

@@ -92,9 +92,9 @@ std::vector<ReadPathProbabilities> unpackRows(const rpvg_cluster_batch & batch, 
 
         ReadPathProbabilities::PathProbs path_probs;
 
-        for (uint64_t j = batch.row_grp_off[i]; j < batch.row_grp_off[i + 1]; ++j) {
+        for (uint64_t j = rpvg_batch_row_group_offset(&batch, i); j < rpvg_batch_row_group_offset(&batch, i + 1); ++j) {
 
-            path_probs.emplace_back(batch.grp_prob[j], std::vector<uint32_t>(batch.path_idx + batch.grp_idx_off[j], batch.path_idx + batch.grp_idx_off[j + 1]));
+            path_probs.emplace_back(batch.grp_prob[j], std::vector<uint32_t>(batch.path_idx + rpvg_batch_group_entry_offset(&batch, j), batch.path_idx + rpvg_batch_group_entry_offset(&batch, j + 1)));
         }
 
         rows.emplace_back(batch.row_count[i], batch.row_noise[i], path_probs, prob_precision);

@@ -218,7 +218,7 @@ def test_batches_in_flight_equal_one_call_after_the_other(model, kw):
         pipe.prepare_slots(variants[0], 5)
         for round_ in range(2):  # the second round reuses every slot
             for v, b in enumerate(variants):
-                pipe.submit(b, (v + round_) % 5)
+                pipe.submit(b, (v + round_) % 5, compact=(round_ == 1))  # (the second round with 32-bit offset arrays)
             pipe.wait()
             for v in range(len(variants)):
                 got = pipe.result((v + round_) % 5)
