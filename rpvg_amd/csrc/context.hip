@@ -429,22 +429,25 @@ int rpvg_hip_ctx::foldSpans() {
 
 // One thread per probability group: writes the group's probability next to
 // each of its path indices (the path indices themselves are uploaded as is).
-__global__ void expandGroupsKernel(const uint64_t num_groups, const uint64_t num_entries, const uint64_t * __restrict__ grp_idx_off,
+// (RowOff / GrpOff: the width the caller wrote the two long offset arrays in, include/rpvg_batch.h)
+template <typename GrpOff>
+__global__ void expandGroupsKernel(const uint64_t num_groups, const uint64_t num_entries, const GrpOff * __restrict__ grp_idx_off,
                                    const double * __restrict__ grp_prob, double * __restrict__ ent_prob) {
     const uint64_t g = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (g >= num_groups) return;
     const double p = grp_prob[g];
     // (clamped: the offsets are checked by validateRowsKernel, whose verdict the host reads after these kernels)
-    for (uint64_t e = grp_idx_off[g]; e < min(grp_idx_off[g + 1], num_entries); ++e) ent_prob[e] = p;
+    for (uint64_t e = grp_idx_off[g]; e < min(static_cast<uint64_t>(grp_idx_off[g + 1]), num_entries); ++e) ent_prob[e] = p;
 }
 
 // One thread per row: entry range of the row and its count as double.
-__global__ void rowMetaKernel(const uint64_t num_rows, const uint64_t num_groups, const uint64_t * __restrict__ row_grp_off,
-                              const uint64_t * __restrict__ grp_idx_off, const uint32_t * __restrict__ row_count_u32,
+template <typename RowOff, typename GrpOff>
+__global__ void rowMetaKernel(const uint64_t num_rows, const uint64_t num_groups, const RowOff * __restrict__ row_grp_off,
+                              const GrpOff * __restrict__ grp_idx_off, const uint32_t * __restrict__ row_count_u32,
                               uint64_t * __restrict__ row_ent_off, double * __restrict__ row_count) {
     const uint64_t r = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (r > num_rows) return;
-    row_ent_off[r] = grp_idx_off[min(row_grp_off[r], num_groups)];
+    row_ent_off[r] = grp_idx_off[min(static_cast<uint64_t>(row_grp_off[r]), num_groups)];
     if (r < num_rows) row_count[r] = static_cast<double>(row_count_u32[r]);
 }
 
@@ -452,9 +455,10 @@ __global__ void rowMetaKernel(const uint64_t num_rows, const uint64_t num_groups
 // 212-219), one thread per row: consistent offsets, noise probability in (0, 1], path indices inside the row's cluster.
 // first_bad_row: the smallest row that breaks one (the host words the message: validateClusters).  On the device because
 // the host pass over a batch's 280 MB cost more than their copy (8 threads: 5 ms, before the first byte moved).
+template <typename RowOff, typename GrpOff>
 __global__ void validateRowsKernel(const uint64_t num_rows, const uint64_t num_groups, const uint64_t num_entries, const uint32_t num_clusters,
                                    const uint64_t * __restrict__ cluster_row_off, const uint64_t * __restrict__ cluster_path_off,
-                                   const uint64_t * __restrict__ row_grp_off, const uint64_t * __restrict__ grp_idx_off,
+                                   const RowOff * __restrict__ row_grp_off, const GrpOff * __restrict__ grp_idx_off,
                                    const double * __restrict__ row_noise, const uint32_t * __restrict__ path_idx,
                                    unsigned long long * __restrict__ first_bad_row) {
     const uint64_t r = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
@@ -807,15 +811,16 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
     ok(up.d_row_count_u32.upload(hb->row_count, R, ctx->stream));
     const uint64_t zero_off[1] = {0};
     // (the 32-bit forms travel as they are and are widened on the device, behind the copy)
+    const bool narrow_offsets = R && G && hb->row_grp_off32 && hb->grp_idx_off32;
     if (R && hb->row_grp_off32) {
         ok(up.d_row_grp_off32.upload(hb->row_grp_off32, R + 1, ctx->stream));
-        ok(up.d_row_grp_off.alloc(R + 1));
+        if (!narrow_offsets) ok(up.d_row_grp_off.alloc(R + 1));
     } else {
         ok(up.d_row_grp_off.upload(R ? hb->row_grp_off : zero_off, R + 1, ctx->stream));
     }
     if (G && hb->grp_idx_off32) {
         ok(up.d_grp_idx_off32.upload(hb->grp_idx_off32, G + 1, ctx->stream));
-        ok(up.d_grp_idx_off.alloc(G + 1));
+        if (!narrow_offsets) ok(up.d_grp_idx_off.alloc(G + 1));
     } else {
         ok(up.d_grp_idx_off.upload(G ? hb->grp_idx_off : zero_off, G + 1, ctx->stream));
     }
@@ -848,31 +853,36 @@ static int uploadFinish(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_clust
     const uint64_t G = up.num_groups;
     HostScope scope("batch_upload: kernels + wait");
     const int bspan = ctx->spanBegin(FAM_BUILD);
-    if (e == hipSuccess && up.d_row_grp_off32.ptr) {
+    // both long offset arrays in 32 bits (what a caller that flattens rows for the GPU writes): the kernels read them as they are;
+    // one of them only: that one is widened first
+    const bool narrow = up.d_row_grp_off32.ptr && up.d_grp_idx_off32.ptr;
+    if (e == hipSuccess && !narrow && up.d_row_grp_off32.ptr) {
         widenOffsetsKernel<<<dim3(static_cast<uint32_t>((R + 1 + 255) / 256)), dim3(256), 0, ctx->stream>>>(R + 1, up.d_row_grp_off32.ptr, up.d_row_grp_off.ptr);
     }
-    if (e == hipSuccess && up.d_grp_idx_off32.ptr) {
+    if (e == hipSuccess && !narrow && up.d_grp_idx_off32.ptr) {
         widenOffsetsKernel<<<dim3(static_cast<uint32_t>((G + 1 + 255) / 256)), dim3(256), 0, ctx->stream>>>(G + 1, up.d_grp_idx_off32.ptr, up.d_grp_idx_off.ptr);
     }
-    if (e == hipSuccess && G > 0) {
-        const uint32_t threads = 256;
-        expandGroupsKernel<<<dim3(static_cast<uint32_t>((G + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            G, NNZ, up.d_grp_idx_off.ptr, up.d_grp_prob.ptr, b->ent_prob.ptr);
-    }
-    if (e == hipSuccess) {
-        const uint32_t threads = 256;
-        rowMetaKernel<<<dim3(static_cast<uint32_t>((R + 1 + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            R, G, up.d_row_grp_off.ptr, up.d_grp_idx_off.ptr, up.d_row_count_u32.ptr, b->row_ent_off.ptr, b->row_count.ptr);
-    }
+    const uint32_t threads = 256;
+    const dim3 group_grid(static_cast<uint32_t>((G + threads - 1) / threads)), meta_grid(static_cast<uint32_t>((R + 1 + threads - 1) / threads)),
+        row_grid(static_cast<uint32_t>((R + threads - 1) / threads));
     unsigned long long first_bad_row = ~0ull;
     DeviceBuffer<unsigned long long> d_first_bad_row;
     if (e == hipSuccess) e = d_first_bad_row.alloc(1);
     if (e == hipSuccess) e = hipMemsetAsync(d_first_bad_row.ptr, 0xFF, sizeof(unsigned long long), ctx->stream);
-    if (e == hipSuccess && R > 0) {
-        const uint32_t threads = 256;
-        validateRowsKernel<<<dim3(static_cast<uint32_t>((R + threads - 1) / threads)), dim3(threads), 0, ctx->stream>>>(
-            R, G, NNZ, K, b->cluster_row_off.ptr, b->cluster_path_off.ptr, up.d_row_grp_off.ptr, up.d_grp_idx_off.ptr, b->row_noise.ptr,
-            b->ent_path.ptr, d_first_bad_row.ptr);
+    if (e == hipSuccess && narrow) {
+        if (G > 0) expandGroupsKernel<uint32_t><<<group_grid, dim3(threads), 0, ctx->stream>>>(G, NNZ, up.d_grp_idx_off32.ptr, up.d_grp_prob.ptr, b->ent_prob.ptr);
+        rowMetaKernel<uint32_t, uint32_t><<<meta_grid, dim3(threads), 0, ctx->stream>>>(R, G, up.d_row_grp_off32.ptr, up.d_grp_idx_off32.ptr, up.d_row_count_u32.ptr,
+                                                                                         b->row_ent_off.ptr, b->row_count.ptr);
+        if (R > 0) validateRowsKernel<uint32_t, uint32_t><<<row_grid, dim3(threads), 0, ctx->stream>>>(
+            R, G, NNZ, K, b->cluster_row_off.ptr, b->cluster_path_off.ptr, up.d_row_grp_off32.ptr, up.d_grp_idx_off32.ptr, b->row_noise.ptr, b->ent_path.ptr,
+            d_first_bad_row.ptr);
+    } else if (e == hipSuccess) {
+        if (G > 0) expandGroupsKernel<uint64_t><<<group_grid, dim3(threads), 0, ctx->stream>>>(G, NNZ, up.d_grp_idx_off.ptr, up.d_grp_prob.ptr, b->ent_prob.ptr);
+        rowMetaKernel<uint64_t, uint64_t><<<meta_grid, dim3(threads), 0, ctx->stream>>>(R, G, up.d_row_grp_off.ptr, up.d_grp_idx_off.ptr, up.d_row_count_u32.ptr,
+                                                                                         b->row_ent_off.ptr, b->row_count.ptr);
+        if (R > 0) validateRowsKernel<uint64_t, uint64_t><<<row_grid, dim3(threads), 0, ctx->stream>>>(
+            R, G, NNZ, K, b->cluster_row_off.ptr, b->cluster_path_off.ptr, up.d_row_grp_off.ptr, up.d_grp_idx_off.ptr, b->row_noise.ptr, b->ent_path.ptr,
+            d_first_bad_row.ptr);
     }
     // read counts per cluster (the host summed three million of them per batch with a team of its own)
     DeviceBuffer<double> d_cluster_total;

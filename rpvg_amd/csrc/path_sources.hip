@@ -31,8 +31,11 @@ namespace {
 constexpr uint32_t kEmptySlot = 0xffffffffu;
 constexpr uint32_t kLdsWords = 3072;        // 64-bit words of bit vectors a workgroup keeps in LDS (24 KB; 56 KB with the tables)
 constexpr uint32_t kLdsHaplotypes = 1024;   // id range up to which the tables stay in LDS
-constexpr uint32_t kLdsTable = 2 * kLdsHaplotypes;
 constexpr int kBlock = 256;
+// Most clusters are small — tens of paths, tens of haplotypes: a wavefront each, 6 KB of LDS, many per CU (5 000 workgroups of
+// 256 threads and 56 KB took 0.41 ms per configs[2] batch); what does not fit goes on a list for the launch of large workgroups.
+constexpr uint32_t kSmallLdsWords = 256, kSmallLdsHaplotypes = 128;
+constexpr int kSmallBlock = 64;
 
 struct SourceArgs {
     uint32_t num_clusters;
@@ -50,6 +53,7 @@ struct SourceArgs {
     uint32_t * num_col_paths;            // [K]
     uint32_t * max_col_paths;            // [K]
     uint32_t * flags;                    // [0] inconsistent offsets, [1] clusters the arena had no room for
+    uint32_t * big_list;                 // [K] clusters the small workgroups left to the large ones, [K]: their number
 };
 
 __device__ __forceinline__ unsigned long long mixHash(unsigned long long h) {
@@ -59,13 +63,24 @@ __device__ __forceinline__ unsigned long long mixHash(unsigned long long h) {
     return h;
 }
 
-__global__ __launch_bounds__(kBlock) void sourceColumnsKernel(const SourceArgs a) {
+// SMALL: the first launch, over all clusters — a cluster that does not fit its LDS is put on the list; otherwise the launch over the
+// list (a workgroup whose index is beyond the list's length has nothing to do), with the arena for what does not fit LDS either.
+template <int BLOCK, uint32_t LDS_WORDS, uint32_t LDS_HAPLOTYPES, bool SMALL>
+__global__ __launch_bounds__(BLOCK) void sourceColumnsKernel(const SourceArgs a) {
+    constexpr int kBlock = BLOCK;
+    constexpr int kWaves = BLOCK / 64;
+    constexpr uint32_t kLdsWords = LDS_WORDS, kLdsHaplotypes = LDS_HAPLOTYPES, kLdsTable = 2 * LDS_HAPLOTYPES;
     __shared__ unsigned long long s_bits[kLdsWords];
     __shared__ uint32_t s_owner[kLdsTable], s_min[kLdsTable], s_cnt[kLdsTable];
     __shared__ uint32_t s_group[kLdsHaplotypes], s_rep[kLdsHaplotypes];
-    __shared__ uint32_t s_scan[kBlock / 64], s_lo[kBlock / 64], s_hi[kBlock / 64];
+    __shared__ uint32_t s_scan[kWaves], s_lo[kWaves], s_hi[kWaves];
     __shared__ unsigned long long s_base;
-    const uint32_t k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t k = blockIdx.x;
+    if (!SMALL) {
+        if (k >= a.big_list[a.num_clusters]) return;
+        k = a.big_list[k];
+    }
     if (k >= a.num_clusters) return;
     const uint64_t p0 = a.cluster_path_off[k], p1 = a.cluster_path_off[k + 1];
     const uint32_t N = static_cast<uint32_t>(p1 - p0);
@@ -103,8 +118,13 @@ __global__ __launch_bounds__(kBlock) void sourceColumnsKernel(const SourceArgs a
         s_hi[wave] = hi;
     }
     __syncthreads();
-    lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
-    hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+    lo = s_lo[0];
+    hi = s_hi[0];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) {
+        lo = min(lo, s_lo[w]);
+        hi = max(hi, s_hi[w]);
+    }
     const unsigned long long H = static_cast<unsigned long long>(hi - lo) + 1;
     const uint32_t W = (N + 63) / 64;
     const unsigned long long words = H * W;
@@ -112,6 +132,10 @@ __global__ __launch_bounds__(kBlock) void sourceColumnsKernel(const SourceArgs a
     while (T < 2 * H) T <<= 1;
     unsigned long long * bits = s_bits;
     uint32_t * owner = s_owner, * smin = s_min, * scnt = s_cnt, * group = s_group, * rep = s_rep;
+    if (SMALL && !(words <= kLdsWords && H <= kLdsHaplotypes)) {  // (for a large workgroup)
+        if (tid == 0) a.big_list[atomicAdd(&a.big_list[a.num_clusters], 1u)] = k;
+        return;
+    }
     if (!(words <= kLdsWords && H <= kLdsHaplotypes)) {
         const unsigned long long need = words + (3 * T + 2 * H + 1) / 2;
         if (tid == 0) s_base = (need <= a.arena_words) ? atomicAdd(a.arena_cursor, need) : a.arena_words;
@@ -137,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void sourceColumnsKernel(const SourceArgs a
     __syncthreads();
     // 2. the path set of every haplotype: a wave per path, its lanes over the path's ids
     bool bad = false;
-    for (uint32_t p = wave; p < N; p += kBlock / 64) {
+    for (uint32_t p = wave; p < N; p += kWaves) {
         const uint64_t b = a.path_source_off[p0 + p], e = a.path_source_off[p0 + p + 1];
         if (b > e || b < i0 || e > i1) {
             bad = true;
@@ -213,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void sourceColumnsKernel(const SourceArgs a
     __syncthreads();  // (col_end of the whole cluster is written; s_hi is free again)
     if (lane == 0) s_hi[wave] = longest;
     __syncthreads();
-    for (uint32_t c = wave; c < G; c += kBlock / 64) {
+    for (uint32_t c = wave; c < G; c += kWaves) {
         const unsigned long long * row = bits + static_cast<unsigned long long>(rep[c]) * W;
         uint32_t * out = a.col_path + i0 + (c ? a.col_end[i0 + c - 1] : 0u);
         uint32_t written = 0;
@@ -226,7 +250,9 @@ __global__ __launch_bounds__(kBlock) void sourceColumnsKernel(const SourceArgs a
     if (tid == 0) {
         a.num_cols[k] = G;
         a.num_col_paths[k] = run;
-        a.max_col_paths[k] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        uint32_t longest_of_all = s_hi[0];
+        for (int w = 1; w < kWaves; ++w) longest_of_all = max(longest_of_all, s_hi[w]);
+        a.max_col_paths[k] = longest_of_all;
     }
 }
 
@@ -280,7 +306,7 @@ hipError_t queuePathSourceCopies(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const r
     pending.arena_words = std::max<unsigned long long>(1ull << 24, 8ull * S);
     pending.num_sources = S;
     ok(pending.d_arena.alloc(pending.arena_words + 1));
-    ok(pending.d_sizes.alloc(3 * static_cast<size_t>(K) + 2));
+    ok(pending.d_sizes.alloc(4 * static_cast<size_t>(K) + 3));  // [sizes 3K | flags 2 | list of the large workgroups K | its length]
     if (e == hipSuccess && pinnedAlloc(&pending.h_sizes, (3 * static_cast<size_t>(K) + 2) * sizeof(uint32_t)) != hipSuccess) e = hipErrorOutOfMemory;
     pending.copied = (e == hipSuccess);
     return e;
@@ -294,6 +320,7 @@ hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSo
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     ok(hipMemsetAsync(pending.d_arena.ptr + pending.arena_words, 0, sizeof(unsigned long long), st));
     ok(hipMemsetAsync(pending.d_sizes.ptr + 3 * static_cast<size_t>(K), 0, 2 * sizeof(uint32_t), st));
+    ok(hipMemsetAsync(pending.d_sizes.ptr + 4 * static_cast<size_t>(K) + 2, 0, sizeof(uint32_t), st));  // (the length of the large workgroups' list)
     SourceArgs a;
     a.num_clusters = K;
     a.cluster_path_off = b->cluster_path_off.ptr;
@@ -310,8 +337,10 @@ hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSo
     a.num_col_paths = pending.d_sizes.ptr + K;
     a.max_col_paths = pending.d_sizes.ptr + 2 * static_cast<size_t>(K);
     a.flags = pending.d_sizes.ptr + 3 * static_cast<size_t>(K);
+    a.big_list = pending.d_sizes.ptr + 3 * static_cast<size_t>(K) + 2;
     if (e == hipSuccess) {
-        sourceColumnsKernel<<<dim3(K), dim3(kBlock), 0, st>>>(a);
+        sourceColumnsKernel<kSmallBlock, kSmallLdsWords, kSmallLdsHaplotypes, true><<<dim3(K), dim3(kSmallBlock), 0, st>>>(a);
+        sourceColumnsKernel<kBlock, kLdsWords, kLdsHaplotypes, false><<<dim3(K), dim3(kBlock), 0, st>>>(a);
         ok(hipGetLastError());
     }
     ok(hipMemcpyAsync(pending.h_sizes, pending.d_sizes.ptr, (3 * static_cast<size_t>(K) + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
