@@ -323,9 +323,13 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     # those of this loop.
     h2d = None
     if not others and DEVICE == "cuda" and hasattr(prepared, "reupload"):
-        single = measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank, dist, torch)
-        single_stats = single.pop("stats")
-        if hasattr(eng_mod, "Pipeline") and not os.environ.get("RPVG_BENCH_NO_PIPELINE"):
+        quick = bool(os.environ.get("RPVG_BENCH_NO_SINGLE")) and hasattr(eng_mod, "Pipeline")  # (the pipeline only: profiling runs, the s5 line inside the default run)
+        single = None if quick else measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank, dist, torch)
+        single_stats = single.pop("stats") if single else {}
+        if quick:
+            h2d = measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch)
+            stats = h2d.pop("stats")
+        elif hasattr(eng_mod, "Pipeline") and not os.environ.get("RPVG_BENCH_NO_PIPELINE"):
             # the headline: the same K batches through the pipeline of the host library (rpvg_amd/host/batch_pipeline.hpp) — an uploader
             # thread and several single-lane engines, several batches in flight on the GPU, every batch uploaded inside the clock
             h2d = measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch)
@@ -337,6 +341,13 @@ def run_s3(args, rank, local_rank, world, dist, torch):
             one["note"] = ("the same steps with ONE batch in flight (the headline of rounds 2-4): estimateBatch on two host lanes, the next batch "
                            "uploaded under it from a second resident slot")
             h2d["one_batch_in_flight"] = one
+            if world == 1 and args.scale >= 1.0 and not os.environ.get("RPVG_BENCH_NO_HOST_BOUND"):
+                try:
+                    bound = host_bound_line(args, eng_mod, batch, params, local_rank)
+                    bound["efficiency_bound"] = min(1.0, h2d["ms_per_step_with_h2d"] / bound["ms_per_step"])
+                    h2d["predicted_host_bound_8_ranks"] = bound
+                except Exception as exc:  # noqa: BLE001
+                    h2d["predicted_host_bound_8_ranks"] = dict(error=str(exc))
         else:
             h2d, stats = single, single_stats
 
@@ -483,10 +494,19 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     if s5:
         # no EM on this path: the chains of the sampler run on the device (rpvg_hip_group_gibbs, round 3: mt19937 and libstdc++'s
         # distributions restated, draw for draw); the FP64 work is the log-likelihood contraction of the conditionals they ask for
-        search["kernel"] = "gibbsConditionalKernel"
-        search["note"] = ("device time = HIP-event spans of gibbsConditionalKernel (one launch per round of the sampler: up to four requests of a problem x "
-                          "four candidate columns per wave) on the two host lanes' streams; the chains (gibbsAdvanceKernel), the distributions and the "
-                          "rest of a step are in ms_per_step only")
+        # two kinds of device time in the sampler: the conditionals (gibbsConditionalTileKernel in the first round, gibbsConditionalKernel
+        # behind it: FP64 log-likelihood contractions, their own spans = loglik_ms) and everything else between the sampler's first
+        # and last kernel (gibbsAdvanceKernel: the chains' draws, request offsets, distributions, the host's looks at the progress word:
+        # gibbs_ms - loglik_ms).  The roofline object is that of the conditionals — the kernels with a flop count — and says which
+        # of the two holds more of the sampler's span.
+        chains_ms = max(0.0, stats.get("gibbs_ms", 0.0) - stats["loglik_ms"])
+        search["kernel"] = "gibbsConditionalTileKernel + gibbsConditionalKernel"
+        search["sampler_span_ms_per_step"] = stats.get("gibbs_ms", 0.0) / args.steps
+        search["chains_and_bookkeeping_ms_per_step"] = chains_ms / args.steps
+        search["dominant_by_device_time"] = ("conditionals (gibbsConditionalTileKernel + gibbsConditionalKernel)" if stats["loglik_ms"] >= chains_ms
+                                             else "chains and bookkeeping (gibbsAdvanceKernel, gibbsRequestOffsetsKernel, gibbsDistributionKernel): latency bound, no flop count")
+        search["note"] = ("device time = HIP-event spans of the conditional kernels (one launch per round of the sampler) on the estimator threads' streams, "
+                          "summed over the batches in flight (they overlap); sampler_span = first to last kernel of rpvg_hip_group_gibbs")
         line["roofline"] = search
         line["sampler"] = "device: rpvg_hip_group_gibbs (RPVG_AMD_HOST_GIBBS=1: host-driven lock-step sampler, round 2)"
         line["ms_per_step_outside_conditionals"] = ms_per_step - (stats["loglik_ms"] + stats["build_ms"] + stats["h2d_ms"]) / args.steps
@@ -498,6 +518,11 @@ def run_s3(args, rank, local_rank, world, dist, torch):
             line["roofline_dense_em"] = dense_em_roofline(local_rank)
         except Exception as exc:  # the record is optional; the default workload's line stands on its own
             line["roofline_dense_em"] = dict(error=str(exc))
+        if args.workload == "s3" and args.model == "haplotype-transcripts" and world == 1 and not os.environ.get("RPVG_BENCH_NO_GIBBS_LINE"):
+            try:
+                line["roofline_gibbs"] = gibbs_line(args, local_rank)
+            except Exception as exc:  # noqa: BLE001
+                line["roofline_gibbs"] = dict(error=str(exc))
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_s3(batch, args.model, params, args.cpu_seconds)
     return line
@@ -600,6 +625,45 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
                 h2d_ms_per_batch=up_ms, h2d_bytes_per_batch=bytes_per_batch, h2d_gb_per_s=bytes_per_batch / 1e9 / (up_ms / 1e3),
                 h2d_note="rows of every batch uploaded from page-locked host arrays inside the clock: validation on the host, H2D, "
                          "expansion on the device; overlapped = two resident slots, uploader engine under the previous batch's kernels")
+
+
+def host_bound_line(args, eng_mod, batch, params, local_rank, ranks=8, steps=40):
+    """The pipeline under the host budget ONE rank of an 8-rank node has: every thread the pipeline starts confined to the rank's
+    share of the CPUs the cgroup grants (cpu.max; all hardware threads if it grants everything).  Against the unconfined
+    step it is the weak-scaling efficiency the host side alone allows such a node (predicted; not a multi-GPU measurement)."""
+    from rpvg_amd import hip
+    quota = cpu_quota() or float(os.cpu_count() or 1)
+    share = max(1, int(quota // ranks))
+    allowed = sorted(os.sched_getaffinity(0))
+    mine = set(allowed[:share])
+    row_grp_off32, grp_idx_off32 = batch.offsets32()
+    arrays = [batch.cluster_row_off, batch.cluster_path_off, batch.row_count, batch.row_noise, row_grp_off32, batch.grp_prob,
+              grp_idx_off32, batch.path_idx, batch.path_group_id, batch.path_source_off, batch.source_id]
+    for a in arrays:
+        hip.host_register(a)
+    os.sched_setaffinity(0, mine)  # (threads started from here on inherit it: the pipeline's uploader and estimator threads)
+    try:
+        pipe = eng_mod.Pipeline(args.model, params, local_rank, workers=args.pipeline_workers)
+        try:
+            slots = pipe.workers + 4
+            pipe.prepare_slots(batch, slots)
+            for k in range(2 * slots):
+                pipe.submit(batch, k % slots, compact=True)
+            pipe.wait()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                pipe.submit(batch, k % slots, compact=True)
+            pipe.wait()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+        finally:
+            pipe.close()
+    finally:
+        os.sched_setaffinity(0, set(allowed))
+        for a in arrays:
+            hip.host_unregister(a)
+    return dict(ranks=ranks, node_cpus=quota, cpus_per_rank=share, ms_per_step=ms, steps=steps,
+                note="the headline's pipeline with all of its threads confined (sched_setaffinity) to one rank's share of the node's CPUs: what the "
+                     "host side alone allows a rank of an 8-rank node; efficiency_bound = unconfined ms_per_step / this")
 
 
 def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
@@ -710,6 +774,27 @@ def run_a1(args, rank, local_rank, world, dist, torch):
                 ms_per_step_in_order=[round(x * 1e3, 2) for x in step_s], estimates_equal_estimate_batch=bool(same), prepare_seconds=prepare_s,
                 note="every call flattens its cluster on its own thread; the calls in flight are joined into batches of up to 256 clusters behind "
                      "the interface (PathEstimator::CallCombiner), up to three batches on the GPU at once; rows start on the host, uploads inside")
+
+
+def gibbs_line(args, local_rank, steps=16):
+    """BASELINE.json configs[4] (`-i haplotypes -y 2 --use-hap-gibbs`, 10M reads x 500k paths) inside the default run, so that the
+    driver's record carries it: a short run of the --workload s5 bench as a child process (its own engines, its own memory)."""
+    import subprocess
+    env = dict(os.environ, RPVG_BENCH_NO_SINGLE="1")
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "s5", "--steps", str(steps), "--warmup", "4", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr[-400:])
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    r = d["roofline"]
+    keep = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "evals_per_step", "flops_per_eval", "ms_per_step",
+                              "sampler_span_ms_per_step", "chains_and_bookkeeping_ms_per_step", "dominant_by_device_time", "note") if k in r}
+    keep.update(workload=d["config"]["workload"], value=d["value"], unit_value="read-pairs/s", batch_ms_per_step=d["ms_per_step"], steps=d["steps"],
+                gpu_active_frac=d.get("gpu_active_frac"), host_cpu_ms_per_step=d.get("host_cpu_ms_per_step"), mass_conserved=d.get("mass_conserved"),
+                pipeline=d.get("pipeline", {}).get("workers"),
+                line_note="the configs[4] workload through the same batch pipeline, every batch uploaded inside the clock; python bench.py --workload s5 "
+                          "prints the full line")
+    return keep
 
 
 def dense_em_roofline(local_rank, rows=1000000, paths=2000, its=20):

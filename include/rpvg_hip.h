@@ -514,6 +514,9 @@ typedef struct rpvg_hip_kernel_stats {
     /* length of the union of all timed spans of this context (kernels and copies; a span runs from the first command of
      * a stage to its last on the stage's stream, so this is an upper bound of the time the GPU worked for the context) */
     double busy_ms;
+    /* rpvg_hip_group_gibbs: the span from the sampler's first kernel to its last (chains, request bookkeeping, distributions AND the
+     * conditionals, whose own spans are in loglik_ms: gibbs_ms - loglik_ms is what the chains and their bookkeeping take) */
+    double gibbs_ms;
 } rpvg_hip_kernel_stats;
 
 int rpvg_hip_stats_get(rpvg_hip_ctx * ctx, rpvg_hip_kernel_stats * stats_out);

@@ -1645,7 +1645,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
     // two tiny kernels that would otherwise wait for slots next to that search (0.5 ms before this lane saw its results)
     searchGateLeave(ctx, st);
     scope.reset(new HostScope("bounded search: wait for the kernels"));
-    ok(hipStreamSynchronize(st));
+    ok(waitStream(st));
     if (e == hipSuccess) {
         const uint32_t * counts = static_cast<const uint32_t *>(host_result);
         unsigned long long log_evals = 0;
@@ -1676,7 +1676,7 @@ extern "C" int rpvg_hip_bounded_pair_posteriors(rpvg_hip_ctx * ctx, const rpvg_h
             }
             if (e == hipSuccess) {
                 ok(hipMemcpyAsync(res->block, d_result.ptr + tail_room, total * 16, hipMemcpyDeviceToHost, st));
-                ok(hipStreamSynchronize(st));
+                ok(waitStream(st));
                 pairs = static_cast<const unsigned char *>(res->block);
             }
         }

@@ -386,6 +386,7 @@ int rpvg_hip_ctx::foldSpans() {
                 case FAM_BUILD: stats.build_ms += ms; break;
                 case FAM_H2D: stats.h2d_ms += ms; break;
                 case FAM_COLLAPSE: stats.collapse_ms += ms; break;
+                case FAM_GIBBS: stats.gibbs_ms += ms; break;
                 case FAM_EM_KERNEL:
                     if (s.sub >= 0 && s.sub < RPVG_HIP_EM_KERNELS) stats.em_kernel[s.sub].ms += ms;
                     break;
@@ -393,7 +394,8 @@ int rpvg_hip_ctx::foldSpans() {
             }
             float at = 0;
             // (the per-kernel spans lie inside their call's FAM_EM_SPARSE span: not a second interval)
-            if (s.family != FAM_EM_KERNEL && clock.base && intervals.size() < kMaxIntervals &&
+            // (... and the conditionals' FAM_LOGLIK spans inside their sampler's FAM_GIBBS span)
+            if (s.family != FAM_EM_KERNEL && s.family != FAM_GIBBS && clock.base && intervals.size() < kMaxIntervals &&
                 hipEventElapsedTime(&at, clock.base, s.start) == hipSuccess) {
                 intervals.push_back(TimedInterval{static_cast<double>(at), static_cast<double>(at) + ms, s.family, clock.id});
             }

@@ -338,7 +338,7 @@ int runEmGridProblems(rpvg_hip_ctx * ctx, hipStream_t st, const EmGridProblem * 
             emGridFinishKernel<<<dim3(1), dim3(kGridBlock), 0, st>>>(C, run.d_a.ptr, d.total_mass, d_ctl.ptr, out_abundances, storage.noise_count + p,
                                                                      storage.iterations + p);
             RPVG_HIP_CHECK(hipGetLastError());
-            RPVG_HIP_CHECK(hipStreamSynchronize(st));  // (the buffers of this problem go back to the pool)
+            RPVG_HIP_CHECK(waitStream(st));  // (the buffers of this problem go back to the pool)
             continue;
         }
 

@@ -1576,7 +1576,7 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         if (n_grid > 0) {
             std::vector<EmGridProblem> grid_problems(n_grid);
             RPVG_HIP_CHECK(hipMemcpyAsync(grid_problems.data(), d_grid_problems.ptr, sizeof(EmGridProblem) * n_grid, hipMemcpyDeviceToHost, st));
-            RPVG_HIP_CHECK(hipStreamSynchronize(st));
+            RPVG_HIP_CHECK(waitStream(st));
             EmGridStorage storage;
             storage.prow_off = work.d_prow_off.ptr;
             storage.prow_count = work.d_prow_count.ptr;
@@ -1596,7 +1596,7 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         static const bool debug = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
         if (debug) {  // (synchronises: a measuring aid)
             uint32_t info[6] = {0}, merged = 0, problems = P, counts[3] = {0};
-            RPVG_HIP_CHECK(hipStreamSynchronize(st));
+            RPVG_HIP_CHECK(waitStream(st));
             RPVG_HIP_CHECK(hipMemcpy(info, cw->info.ptr, sizeof(info), hipMemcpyDeviceToHost));
             RPVG_HIP_CHECK(hipMemcpy(&merged, cw->problem_merged.ptr + P, sizeof(merged), hipMemcpyDeviceToHost));
             if (list.d_num_problems) RPVG_HIP_CHECK(hipMemcpy(&problems, list.d_num_problems, sizeof(problems), hipMemcpyDeviceToHost));
@@ -1797,7 +1797,7 @@ int prepareHostProblems(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const 
         std::vector<uint32_t> kept_rows(P), kept_ent(P);
         RPVG_HIP_CHECK(hipMemcpyAsync(kept_rows.data(), out.d_kept_rows, P * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         RPVG_HIP_CHECK(hipMemcpyAsync(kept_ent.data(), out.d_kept_entries, P * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        RPVG_HIP_CHECK(hipStreamSynchronize(st));
+        RPVG_HIP_CHECK(waitStream(st));
         rows_bound = entries_bound = 0;
         for (uint32_t p = 0; p < P; ++p) {
             row_base[p] = rows_bound;
@@ -1864,7 +1864,7 @@ extern "C" int rpvg_hip_em_solve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
 
     scope.reset(new HostScope("em_solve: wait for the kernels + download"));
     RPVG_HIP_CHECK(outputs.fetch(st));
-    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    RPVG_HIP_CHECK(waitStream(st));
     outputs.scatter();
     scope.reset();
     accountEmSolve(ctx, P, problems->col_off, kept_rows.data(), kept_ent.data(), results->iterations);
@@ -1958,6 +1958,6 @@ extern "C" int rpvg_hip_gibbs_read_counts(rpvg_hip_ctx * ctx, const rpvg_hip_bat
     RPVG_HIP_CHECK(hipGetLastError());
     RPVG_HIP_CHECK(d_noise_samples.download(noise_samples, st));
     RPVG_HIP_CHECK(d_abund_samples.download(abundance_samples, st));
-    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    RPVG_HIP_CHECK(waitStream(st));
     return RPVG_HIP_OK;
 }

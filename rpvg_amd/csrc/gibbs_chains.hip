@@ -1200,6 +1200,12 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
 
     const GibbsProblems pr{d_matrix.ptr, d_chains.ptr, d_burn.ptr, d_its.ptr, d_chain_off.ptr, d_col_off.ptr, d_tab_off.ptr, d_log_freq.ptr};
     const GibbsChains ch{d_chain_problem.ptr, d_chain_pos.ptr, d_chain_cur.ptr, d_chain_iter.ptr, d_chain_flag.ptr};
+    const int sampler_span = ctx->spanBegin(FAM_GIBBS);
+    struct SamplerSpan {  // (closed on every way out)
+        rpvg_hip_ctx * ctx;
+        int span;
+        ~SamplerSpan() { ctx->spanEnd(span); }
+    } sampler_span_guard{ctx, sampler_span};
     gibbsStreamKernel<<<dim3(NG), dim3(256), 0, st>>>(d_gen_words.ptr, d_gen_prob_off.ptr, d_gen_prob.ptr, d_stream_off.ptr, pr, groups->mat_cols.ptr, GS,
                                                       d_stream.ptr, ch, d_words.ptr, d_final_state.ptr, d_hdr.ptr);
     RPVG_HIP_CHECK(hipGetLastError());
@@ -1244,7 +1250,7 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     uint32_t chunk = first_rounds;
     while (!finished) {
         if (round + chunk >= kMaxRounds) {  // (a round per column of a flat posterior over thousands of columns: the caller's sampler takes it)
-            RPVG_HIP_CHECK(hipStreamSynchronize(st));
+            RPVG_HIP_CHECK(waitStream(st));
             setError("rpvg_hip_group_gibbs: the chains are not done after %u rounds", round);
             return RPVG_HIP_ERR_UNSUPPORTED;
         }
@@ -1305,7 +1311,7 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
         RPVG_HIP_CHECK(hipGetLastError());
         RPVG_HIP_CHECK(hipMemcpyAsync(&progress->remaining, d_remaining.ptr + (round - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         RPVG_HIP_CHECK(hipMemcpyAsync(&progress->hdr, d_hdr.ptr, sizeof(GibbsHeader), hipMemcpyDeviceToHost, st));
-        RPVG_HIP_CHECK(hipStreamSynchronize(st));
+        RPVG_HIP_CHECK(waitStream(st));
         if (progress->hdr.error) {
             const uint32_t err = progress->hdr.error;
             if (err & kErrDistributions) {
@@ -1347,7 +1353,7 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
     RPVG_HIP_CHECK(hipMemcpyAsync(result->set_off.data(), d_set_off.ptr, (static_cast<size_t>(P) + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     RPVG_HIP_CHECK(hipMemcpyAsync(result->words_consumed.data(), d_words.ptr, static_cast<size_t>(NG) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     RPVG_HIP_CHECK(hipMemcpyAsync(&progress->hdr, d_hdr.ptr, sizeof(GibbsHeader), hipMemcpyDeviceToHost, st));
-    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    RPVG_HIP_CHECK(waitStream(st));
     const uint64_t total_sets = progress->hdr.total_sets;
     RPVG_REQUIRE(total_sets <= out_capacity, "rpvg_hip_group_gibbs: %llu sets in room for %llu", static_cast<unsigned long long>(total_sets),
                  static_cast<unsigned long long>(out_capacity));
@@ -1360,7 +1366,7 @@ extern "C" int rpvg_hip_group_gibbs(rpvg_hip_ctx * ctx, const rpvg_hip_groups * 
         if (progress->hdr.unsorted) {
             RPVG_HIP_CHECK(hipMemcpyAsync(host + 3 * total_sets, out_seq, total_sets * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         }
-        RPVG_HIP_CHECK(hipStreamSynchronize(st));
+        RPVG_HIP_CHECK(waitStream(st));
         if (progress->hdr.unsorted) {  // the few problems with more sets than the collect kernel ranks in LDS
             uint32_t * seq = host + 3 * total_sets;
             std::vector<uint32_t> order, scratch;

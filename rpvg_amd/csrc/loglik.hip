@@ -1146,7 +1146,7 @@ extern "C" int rpvg_hip_group_loglik(rpvg_hip_ctx * ctx, const rpvg_hip_groups *
     ctx->stats.loglik_evals += evals;
     RPVG_HIP_CHECK(hipGetLastError());
     RPVG_HIP_CHECK(d_out.download(out, st));
-    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    RPVG_HIP_CHECK(waitStream(st));
     return groups->buildError(st);  // the matrices were built without a host sync
 }
 
@@ -1213,6 +1213,6 @@ extern "C" int rpvg_hip_group_conditionals(rpvg_hip_ctx * ctx, const rpvg_hip_gr
     ctx->stats.loglik_evals += evals;
     RPVG_HIP_CHECK(hipGetLastError());
     RPVG_HIP_CHECK(d_out.download(out, st));
-    RPVG_HIP_CHECK(hipStreamSynchronize(st));
+    RPVG_HIP_CHECK(waitStream(st));
     return groups->buildError(st);  // the matrices were built without a host sync
 }

@@ -93,7 +93,7 @@ class CKernelStats(C.Structure):
         ("em_iterations_total", C.c_uint64),
         ("search_pairs_possible", C.c_double), ("search_pairs_table", C.c_double), ("search_pairs_kept", C.c_double),
         ("em_kernel", CEmKernelStats * EM_KERNELS),
-        ("collapse_ms", C.c_double), ("busy_ms", C.c_double),
+        ("collapse_ms", C.c_double), ("busy_ms", C.c_double), ("gibbs_ms", C.c_double),
     ]
 
     def as_dict(self):

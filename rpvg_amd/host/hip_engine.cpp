@@ -141,6 +141,7 @@ void HipEngine::stats(const std::vector<const HipEngine *> & engines, rpvg_hip_k
         stats_out->search_pairs_table += lane_stats.search_pairs_table;
         stats_out->search_pairs_kept += lane_stats.search_pairs_kept;
         stats_out->collapse_ms += lane_stats.collapse_ms;
+        stats_out->gibbs_ms += lane_stats.gibbs_ms;
 
         for (int i = 0; i < RPVG_HIP_EM_KERNELS; ++i) {
 
