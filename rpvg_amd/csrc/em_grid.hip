@@ -28,6 +28,8 @@
 
 #include "common.hpp"
 
+#include <atomic>
+
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -75,6 +77,10 @@ __device__ __forceinline__ double rowLanesSum(double v) {
     return v;
 }
 
+// (The accumulators of a workgroup take their additions through ds_add_f64 in whatever order the row slots arrive: the CSR route
+// is reproducible up to the order of those sums — a last-ulp matter, which can move the iteration at which the stop rule fires for
+// a column that sits exactly on the convergence boundary.  The cross-workgroup reduction below has a fixed order; the dense route
+// has no atomics at all.)
 // One streaming pass over the problem's CSR.  LANES lanes share a row (1: a thread per row — short rows, the entries of
 // neighbouring rows are neighbours in memory; 4 / 16 / 64: the lanes stride the row's entries, the row sum by shuffles
 // or DPP), and every row slot walks UNROLL rows at a time: their offsets, counts and noise are loaded together and their
@@ -253,9 +259,14 @@ __global__ __launch_bounds__(kGridBlock) void emGridDenseBuildKernel(const uint3
 template <int LANES, int UNROLL>
 hipError_t launchAccumVariant(const GridAccumArgs & args, const uint32_t grid, const size_t lds, hipStream_t st) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&emGridAccumKernel<LANES, UNROLL>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(lds));
-        if (e != hipSuccess) return e;
+        // (once per variant and size reached, not per launch: this runs every EM iteration)
+        static std::atomic<size_t> granted{0};
+        if (lds > granted.load(std::memory_order_relaxed)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&emGridAccumKernel<LANES, UNROLL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+            granted.store(lds, std::memory_order_relaxed);
+        }
     }
     emGridAccumKernel<LANES, UNROLL><<<dim3(grid), dim3(kGridBlock), lds, st>>>(args);
     return hipSuccess;
@@ -311,16 +322,20 @@ int runEmGridProblems(rpvg_hip_ctx * ctx, hipStream_t st, const EmGridProblem * 
         const double * val = storage.pent_val + d.ent_base;
         double * out_abundances = storage.abundances + d.col_begin;
 
-        if (emGridDenseRoute(C, rows, d.entries)) {
-            const uint64_t ld = (static_cast<uint64_t>(C) + 1) & ~1ull;
-            DeviceBuffer<double> d_matrix;
-            RPVG_HIP_CHECK(d_matrix.alloc(static_cast<size_t>(rows) * ld));
+        const uint64_t dense_ld = (static_cast<uint64_t>(C) + 1) & ~1ull;
+        DeviceBuffer<double> d_matrix;
+        // (the dense copy is the faster route, not a needed one: without the memory for it the problem stays on its CSR)
+        if (emGridDenseRoute(C, rows, d.entries) && d_matrix.alloc(static_cast<size_t>(rows) * dense_ld) == hipSuccess) {
+            const uint64_t ld = dense_ld;
             const int span = ctx->spanBegin(FAM_BUILD, st);
-            RPVG_HIP_CHECK(hipMemsetAsync(d_matrix.ptr, 0, sizeof(double) * rows * ld, st));
+            hipError_t build_error = hipMemsetAsync(d_matrix.ptr, 0, sizeof(double) * rows * ld, st);
             const uint32_t build_grid = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(rows) + 3) / 4, static_cast<uint64_t>(cus) * 16));
-            emGridDenseBuildKernel<<<dim3(std::max(1u, build_grid)), dim3(kGridBlock), 0, st>>>(rows, C, ld, off, nz, col, val, d_matrix.ptr);
-            RPVG_HIP_CHECK(hipGetLastError());
-            ctx->spanEnd(span);
+            if (build_error == hipSuccess) {
+                emGridDenseBuildKernel<<<dim3(std::max(1u, build_grid)), dim3(kGridBlock), 0, st>>>(rows, C, ld, off, nz, col, val, d_matrix.ptr);
+                build_error = hipGetLastError();
+            }
+            ctx->spanEnd(span);  // (closed on the error path too)
+            RPVG_HIP_CHECK(build_error);
             ctx->stats.build_launches += 1;
             DenseEmRun run;
             run.matrix = d_matrix.ptr;

@@ -590,7 +590,9 @@ void NestedPathAbundanceEstimator::estimateClusters(std::vector<PathClusterEstim
             // in the generator's stream depends on how many sets the chains before them found (a discrete distribution
             // over one set draws nothing).  Round j of the batch is transcript j of every cluster that has one — one
             // problem per generator and device call, as with collapsed groups — and its subsets are drawn before round
-            // j + 1 is queued: draw for draw the reference's order, at the price of one device call per round.
+            // j + 1 is queued: draw for draw the reference's order, at the price of one device call per round — as many rounds as the
+            // batch's largest cluster has transcripts, the late rounds with a problem or two each: a batch with one cluster of thousands
+            // of transcripts serialises thousands of small calls (no bound; a caller with such clusters batches them apart).
             size_t max_groups = 0;
 
             for (auto & path_groups: cluster_path_groups) {
@@ -736,6 +738,19 @@ void NestedPathAbundanceEstimator::findPathSourceGroups(GroupPosteriorProblem * 
     static thread_local std::vector<uint32_t> flat_ids, flat_end, first_of_id;
     static thread_local std::vector<uint64_t> source_paths, column_hash;
     static thread_local std::vector<int32_t> table;
+
+    // (a thread keeps what the usual cluster needs; after a very large one the scratch goes back: a 100-thread team would otherwise
+    // hold the peak of every thread for the life of the process)
+    constexpr size_t scratch_kept = size_t(1) << 20;
+
+    if (flat_ids.capacity() > scratch_kept && num_incidences <= scratch_kept / 4) {
+
+        std::vector<uint32_t>().swap(flat_ids);
+        std::vector<uint32_t>().swap(first_of_id);
+        std::vector<uint64_t>().swap(source_paths);
+        std::vector<uint64_t>().swap(column_hash);
+        std::vector<int32_t>().swap(table);
+    }
 
     flat_ids.resize(num_incidences);
     flat_end.resize(paths.size());
@@ -985,6 +1000,11 @@ void NestedPathAbundanceEstimator::mergeSubsetSolutions(std::vector<PathClusterE
 
         static thread_local std::vector<Entry> entries;
         static thread_local std::vector<std::pair<uint32_t, uint32_t> > grouped;  // (group id, position in the subset's list)
+
+        if (entries.capacity() > (size_t(1) << 18)) {  // (after a cluster with a hundred thousand entries: see findPathSourceGroups' scratch)
+
+            std::vector<Entry>().swap(entries);
+        }
 
         entries.clear();
 

@@ -380,8 +380,17 @@ void * rpvg_amd_batch_prepare_synth_dense(void * engine, uint64_t seed, uint64_t
         offsets.cluster_row_off = cluster_row_off;
         offsets.cluster_path_off = cluster_path_off;
 
-        // (every row of the synthetic cluster is one read pair)
+        // (every row of the synthetic cluster is one read pair; the multi-gigabyte batch is freed here until the handle has adopted it)
+        struct BatchGuard {
+
+            rpvg_hip_ctx * ctx;
+            rpvg_hip_batch * batch;
+            ~BatchGuard() { if (batch) rpvg_hip_batch_free(ctx, batch); }
+
+        } batch_guard{hip->ctx(), device_batch};
+
         prepared->device.reset(new DeviceClusterBatch(hip, device_batch, offsets, std::vector<double>(1, static_cast<double>(num_rows))));
+        batch_guard.batch = nullptr;
 
         return guard.release();
 

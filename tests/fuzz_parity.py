@@ -103,9 +103,12 @@ def oracle_in_a_child(model, kw, batch, oracle_threads):
     import subprocess
     child = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_child.py")],
                            input=pickle.dumps((model, kw, batch, oracle_threads), protocol=pickle.HIGHEST_PROTOCOL), capture_output=True)
-    if child.returncode != 0 or not child.stdout:
+    if child.returncode == 0 and child.stdout:
+        return pickle.loads(child.stdout)
+    stderr = child.stderr.decode(errors="replace")
+    if "sum_hap_prob" in stderr and "Assertion" in stderr:  # the one abort that is the reference's own (src/path_abundance_estimator.cpp:748)
         return None
-    return pickle.loads(child.stdout)
+    raise RuntimeError(f"the oracle process failed (exit code {child.returncode}): {stderr[-600:]}")
 
 
 def run_case(eng, case, oracle_threads=32, isolate_oracle=False):
@@ -113,11 +116,15 @@ def run_case(eng, case, oracle_threads=32, isolate_oracle=False):
     params = make_params(**case["kw"])
     if isolate_oracle:
         ref = oracle_in_a_child(case["model"], case["kw"], case["batch"], oracle_threads)
-        if ref is None:
-            return ["skipped: the oracle (the reference's own assertions) aborted on this case"]
     else:
         ref, _ = pyoracle.run(case["model"], params, case["batch"], oracle_threads)
     got, _ = eng.run(case["model"], params, eng.prepare(case["batch"]))
+    if ref is None:
+        # nothing to compare with: the engine still has to run through, conserve the read mass and keep its posteriors in [0, 1]
+        bad = [f"cluster {k}: mass not conserved" for k, g in enumerate(got)
+               if len(g.abundances) and abs(float(np.sum(g.abundances)) + g.noise_count - g.total_count) > 1e-6 * max(1.0, g.total_count)]
+        bad += [f"cluster {k}: posterior outside [0, 1]" for k, g in enumerate(got) if len(g.posteriors) and (g.posteriors.min() < 0 or g.posteriors.max() > 1 + 1e-9)]
+        return bad or ["skipped: the oracle stopped at the reference's own assertion sum_hap_prob <= 1 (src/path_abundance_estimator.cpp:748)"]
     return compare(got, ref)
 
 
@@ -127,6 +134,7 @@ def main():
     only_gibbs = len(sys.argv) > 3 and sys.argv[3] == "gibbs"
     eng = eng_mod.Engine(0)
     failures = 0
+    skipped = 0
     t0 = time.time()
     for i in range(rounds):
         seed = seed0 + i
@@ -136,6 +144,7 @@ def main():
             if problems and problems[0].startswith("skipped"):
                 print(f"{time.time() - t0:6.0f}s [{i:3d}] seed {seed} shape {case['shape']} {case['model']:22s} {case['kw']} "
                       f"clusters {case['batch'].num_clusters} -> {problems[0]}", flush=True)
+                skipped += 1
                 continue
         except Exception as exc:  # noqa: BLE001
             problems = [f"exception: {exc}"]
@@ -145,9 +154,10 @@ def main():
         for p in problems[:5]:
             print("      ", p, flush=True)
         failures += bool(problems)
-    print(f"{rounds} rounds, {failures} with mismatches, {time.time() - t0:.0f} s")
+    print(f"{rounds} rounds, {failures} with mismatches, {skipped} without an oracle (the reference's own assertion), {time.time() - t0:.0f} s")
     eng.close()
-    sys.exit(1 if failures else 0)
+    # (a sweep that mostly skips has compared nothing: one case in two hundred is the rate seen)
+    sys.exit(1 if failures or skipped > max(2, rounds // 20) else 0)
 
 
 if __name__ == "__main__":

@@ -228,3 +228,37 @@ def test_config4_diploid_haplotype_gibbs_10m_reads_follows_the_reference_stream(
         assert g.total_count == r.total_count, k
         if r.total_count > 0 and len(r.posteriors):
             assert abs(g.posteriors.sum() - 1) <= 1e-9, k
+
+
+def test_config3_clusters_sharded_over_a_device_group_at_full_size(engine, config2_batch):
+    """BASELINE.json configs[3]: the configs[2] workload with its 5 000 clusters sharded over the GPUs of a node
+    (rpvg_amd/host/device_group.hpp: clusters bin-packed longest first, one engine and one host thread per entry, final
+    abundance gather + TPM denominator).  A one-GPU box lists its GPU twice: two shards side by side — the bin packing, the
+    per-engine thread budget and the gather see all 5 000 clusters.  Every cluster must get what it gets from one engine
+    on the whole batch (sets, posteriors and EM iteration counts identical; abundances up to the summation order of the EM's
+    LDS atomics), and the gather must return every cluster's abundances in cluster order."""
+    from rpvg_amd import dist as rdist
+    batch = config2_batch
+    params = make_params()
+    whole, _ = engine.run("haplotype-transcripts", params, engine.prepare(batch))
+    group = eng_mod.DeviceGroup([0, 0])
+    try:
+        got, secs = group.run("haplotype-transcripts", params, batch)
+        assert secs > 0 and len(got) == batch.num_clusters
+        for k, (g, w) in enumerate(zip(got, whole)):
+            assert g.path_group_sets == w.path_group_sets, k
+            assert np.array_equal(g.posteriors, w.posteriors), k
+            assert np.allclose(g.abundances, w.abundances, rtol=1e-9, atol=1e-9), k
+            assert g.total_count == w.total_count and abs(g.noise_count - w.noise_count) <= 1e-9 * max(1.0, w.total_count), k
+            assert g.em_iters == w.em_iters and g.em_cols == w.em_cols, k
+        where = group.partition()
+        costs = rdist.cluster_costs(batch)
+        assert [sorted(np.nonzero(where == d)[0].tolist()) for d in range(2)] == rdist.partition_clusters(costs, 2)
+        shares = [float(costs[where == d].sum()) for d in range(2)]
+        assert max(shares) <= 1.02 * (sum(shares) / 2)  # longest-first packing of 5 000 clusters: within 2 % of even
+        flat = np.concatenate([g.abundances for g in got])
+        gathered, tpm_den = group.gather(len(flat))
+        assert np.array_equal(gathered, flat)
+        assert abs(tpm_den - rdist.local_transcript_count(got, batch)) <= 1e-9 * tpm_den
+    finally:
+        group.close()
