@@ -55,7 +55,7 @@ int rpvg_hip_create(int device, rpvg_hip_ctx ** ctx_out);
 int rpvg_hip_create_uploader(int device, rpvg_hip_ctx ** ctx_out);
 /* A context with fewer side streams than rpvg_hip_create's six (1..6), for engines that run whole batches next to each other
  * on one GPU (rpvg_amd/host/batch_pipeline.hpp): the runtime maps all streams of a process onto its hardware queues
- * (GPU_MAX_HW_QUEUES, 16 here), commands of streams that share a queue run in order, and four engines of nine streams
+ * (GPU_MAX_HW_QUEUES, 8 here), commands of streams that share a queue run in order, and four engines of nine streams
  * each put one engine's short kernels behind another's long ones.  The launches that would have had streams of their own
  * follow one another on the streams there are; results are the same. */
 int rpvg_hip_create_with_streams(int device, int side_streams, rpvg_hip_ctx ** ctx_out);

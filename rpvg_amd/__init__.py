@@ -28,12 +28,12 @@ _keep_heap_top()
 
 
 def _ask_for_hardware_queues():
-    """Sixteen hardware queues instead of the HIP runtime's four (the library asks for the same when it is loaded: several
-    batches in flight, an engine of a few streams each; rpvg_amd/csrc/context.hip).  The runtime reads the variable when it
-    starts, so this has to run before the process touches the GPU: import rpvg_amd first.  A value already in the
-    environment is kept."""
+    """Eight hardware queues instead of the HIP runtime's four (the library asks for the same when it is loaded; measured for two host
+    lanes over one batch and for the batch pipeline's four single-lane engines: rpvg_amd/csrc/context.hip).  The runtime reads the
+    variable when it starts, so this has to run before the process touches the GPU: import rpvg_amd first.  A value already in
+    the environment is kept."""
     import os
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 _ask_for_hardware_queues()

@@ -638,6 +638,9 @@ struct rpvg_hip_ctx {
     // joinAux() makes `stream` wait for them.
     hipStream_t aux[kAuxStreams] = {};
     int aux_count = kAuxStreams;  // real side streams: aux[i] for i >= aux_count aliases aux[i % aux_count] (rpvg_hip_create_with_streams)
+    // streams of the EM problems that run over the whole GPU (em_grid.hip: two at a time), made when a solve first has such problems
+    hipStream_t grid_stream[2] = {nullptr, nullptr};
+    hipEvent_t grid_ready = nullptr;
     hipStream_t collapse_stream = nullptr;  // row collapse of the matrices a build leaves behind (highest priority: short kernels next to a search)
     hipStream_t copy_stream = nullptr;  // staged uploads (stagedCopy)
     hipEvent_t copied = nullptr;

@@ -238,10 +238,10 @@ namespace {
 int g_hardware_queues = 4;
 
 __attribute__((constructor)) void askForHardwareQueues() {
-    // (16 since round 5: several batches in flight on one GPU — rpvg_amd/host/batch_pipeline.hpp, one single-lane engine of nine
-    // streams each — run 4.5 ms per configs[2] batch on sixteen queues against 5.4 on twelve and 6.6 on eight; 24 and 32 are
-    // time-sliced and twice as slow; two lanes over one batch measure the same on 8 and 16)
-    (void) setenv("GPU_MAX_HW_QUEUES", "16", 0);  // keeps a value the user has set
+    // (8: two host lanes of nine streams over one batch — 12 and 16 measured equal or slower there — and, since round 5, the batch
+    // pipeline's four single-lane engines of four streams each: 6.0 ms per configs[2] batch on 8 queues, 6.1 on 6, 6.6 on 4, 7.0 on
+    // 10, 5.9 on 12, 8.7 on 16; engines of nine streams each wanted 16 — rpvg_amd/host/batch_pipeline.hpp)
+    (void) setenv("GPU_MAX_HW_QUEUES", "8", 0);  // keeps a value the user has set
     const char * env = std::getenv("GPU_MAX_HW_QUEUES");
     g_hardware_queues = env ? std::max(1, std::atoi(env)) : 4;
 }
@@ -623,6 +623,13 @@ void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
         (void) hipStreamDestroy(ctx->collapse_stream);
     }
     if (ctx->fork_event) (void) hipEventDestroy(ctx->fork_event);
+    for (hipStream_t grid_stream : ctx->grid_stream) {
+        if (grid_stream) {
+            (void) hipStreamSynchronize(grid_stream);
+            (void) hipStreamDestroy(grid_stream);
+        }
+    }
+    if (ctx->grid_ready) (void) hipEventDestroy(ctx->grid_ready);
     searchGateForget(ctx);
     if (ctx->search_done) (void) hipEventDestroy(ctx->search_done);
     bool last = false;

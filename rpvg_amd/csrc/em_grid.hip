@@ -312,6 +312,7 @@ bool emGridDenseRoute(const uint32_t columns, const uint32_t rows, const uint32_
 int runEmGridProblems(rpvg_hip_ctx * ctx, hipStream_t st, const EmGridProblem * problems, const uint32_t count, const EmGridStorage & storage,
                       const uint32_t max_em_its, const double max_rel_em_conv) {
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
+    std::vector<uint32_t> csr_route;  // the problems that stay on their CSR
     for (uint32_t i = 0; i < count; ++i) {
         const EmGridProblem & d = problems[i];
         const uint32_t p = d.problem, C = d.columns, rows = d.rows;
@@ -357,108 +358,173 @@ int runEmGridProblems(rpvg_hip_ctx * ctx, hipStream_t st, const EmGridProblem * 
             continue;
         }
 
-        // ---- CSR route ----
-        const int row_lanes = gridRowLanes(rows, d.entries);
+        csr_route.push_back(i);
+    }
+
+    // ---- CSR route: two problems at a time, each on a stream of its own (a handful of mid-size problems of one solve — em_sparse.hip,
+    // kEmMidGridMax — would otherwise wait for each other: an iteration is two short launches, and most of its time is their boundaries)
+    if (csr_route.empty()) return RPVG_HIP_OK;
+    hipError_t e = hipSuccess;
+    for (int g = 0; g < 2 && e == hipSuccess; ++g) {
+        if (!ctx->grid_stream[g]) e = hipStreamCreateWithFlags(&ctx->grid_stream[g], hipStreamNonBlocking);
+    }
+    if (e == hipSuccess && !ctx->grid_ready) e = hipEventCreateWithFlags(&ctx->grid_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ctx->grid_ready, st);  // (the problems' rows are in place behind what `st` holds so far)
+    for (int g = 0; g < 2 && e == hipSuccess; ++g) e = hipStreamWaitEvent(ctx->grid_stream[g], ctx->grid_ready, 0);
+    RPVG_HIP_CHECK(e);
+
+    struct CsrRun {
+        bool active = false;
+        hipStream_t stream = nullptr;
+        const EmGridProblem * d = nullptr;
+        DeviceBuffer<double> d_a, d_partials;
+        DeviceBuffer<EmGridControl> d_ctl;
+        GridAccumArgs aa;
+        GridUpdateArgs ua;
+        uint32_t grid = 0, update_grid = 0, chunk_its = 0, queued = 0, chunk = 0;
+        int row_lanes = 1, span = -1;
+        size_t lds = 0;
+        EmGridControl * h_ctl = nullptr;  // two pinned slots
+        hipEvent_t looked[2] = {nullptr, nullptr};
+        void release() {
+            for (hipEvent_t & ev : looked) {
+                if (ev) (void) hipEventDestroy(ev);
+                ev = nullptr;
+            }
+            if (h_ctl) pinnedFree(h_ctl);
+            h_ctl = nullptr;
+            d_a.release();
+            d_partials.release();
+            d_ctl.release();
+            active = false;
+        }
+        ~CsrRun() {
+            if (active && stream) (void) hipStreamSynchronize(stream);
+            release();
+        }
+    } runs[2];
+    runs[0].stream = ctx->grid_stream[0];
+    runs[1].stream = ctx->grid_stream[1];
+
+    auto start = [&](CsrRun & r, const EmGridProblem & d) -> hipError_t {
+        const uint32_t p = d.problem, C = d.columns, rows = d.rows;
+        r.d = &d;
+        r.row_lanes = gridRowLanes(rows, d.entries);
         // workgroups: enough to fill the GPU, few enough that the partial vectors (written and read once per iteration,
         // 16 B per column and workgroup) stay below the CSR's own bytes
         const uint64_t csr_bytes = 12ull * d.entries + 20ull * rows;
-        const uint64_t slots = static_cast<uint64_t>(kGridBlock / row_lanes);
+        const uint64_t slots = static_cast<uint64_t>(kGridBlock / r.row_lanes);
         uint64_t blocks = (static_cast<uint64_t>(rows) + slots - 1) / slots;
-        blocks = std::min<uint64_t>(blocks, static_cast<uint64_t>(cus) * (row_lanes == 1 ? 2 : 4));
+        blocks = std::min<uint64_t>(blocks, static_cast<uint64_t>(cus) * (r.row_lanes == 1 ? 2 : 4));
         blocks = std::min<uint64_t>(blocks, std::max<uint64_t>(16, csr_bytes / (16ull * C)));
         if (const char * env = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_GRID_BLOCKS")) blocks = std::max<uint64_t>(1, std::strtoull(env, nullptr, 10));  // A/B knob
         blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, rows));
         const uint32_t rows_per_block = static_cast<uint32_t>((static_cast<uint64_t>(rows) + blocks - 1) / blocks);
-        const uint32_t grid = (rows + rows_per_block - 1) / rows_per_block;
+        r.grid = (rows + rows_per_block - 1) / rows_per_block;
         const uint32_t partial_ld = (C + 63) & ~63u;
-        const size_t lds = sizeof(double) * 2 * static_cast<size_t>(C);
-
-        DeviceBuffer<double> d_a, d_partials;
-        DeviceBuffer<EmGridControl> d_ctl;
-        RPVG_HIP_CHECK(d_a.alloc(C));
-        RPVG_HIP_CHECK(d_partials.alloc(static_cast<size_t>(grid) * partial_ld));
-        RPVG_HIP_CHECK(d_ctl.alloc(1));
-        RPVG_HIP_CHECK(hipMemsetAsync(d_ctl.ptr, 0, sizeof(EmGridControl), st));
+        r.lds = sizeof(double) * 2 * static_cast<size_t>(C);
+        hipError_t err = r.d_a.alloc(C);
+        if (err == hipSuccess) err = r.d_partials.alloc(static_cast<size_t>(r.grid) * partial_ld);
+        if (err == hipSuccess) err = r.d_ctl.alloc(1);
+        if (err == hipSuccess) err = hipMemsetAsync(r.d_ctl.ptr, 0, sizeof(EmGridControl), r.stream);
+        if (err != hipSuccess) return err;
         // src/path_abundance_estimator.cpp:54 — 1 / float(C), widened
-        gridFillKernel<<<dim3((C + 255) / 256), dim3(256), 0, st>>>(d_a.ptr, C, static_cast<double>(1.0f / static_cast<float>(C)));
-
-        GridAccumArgs aa;
-        aa.off = off;
-        aa.cnt = cnt;
-        aa.nz = nz;
-        aa.col = col;
-        aa.val = val;
-        aa.rows = rows;
-        aa.C = C;
-        aa.rows_per_block = rows_per_block;
-        aa.a = d_a.ptr;
-        aa.partials = d_partials.ptr;
-        aa.partial_ld = partial_ld;
-        aa.ctl = d_ctl.ptr;
-        GridUpdateArgs ua;
-        ua.C = C;
-        ua.num_partials = grid;
-        ua.partial_ld = partial_ld;
-        ua.partials = d_partials.ptr;
-        ua.a = d_a.ptr;
-        ua.inv_total = 1.0 / d.total_mass;
-        ua.zero_mass = d.zero_mass;
-        ua.max_rel_em_conv = max_rel_em_conv;
-        ua.max_em_its = max_em_its;
-        ua.ctl = d_ctl.ptr;
-        const uint32_t update_grid = (C + kUpdateColumns - 1) / kUpdateColumns;
-
+        gridFillKernel<<<dim3((C + 255) / 256), dim3(256), 0, r.stream>>>(r.d_a.ptr, C, static_cast<double>(1.0f / static_cast<float>(C)));
+        r.aa.off = storage.prow_off + d.row_base + p;
+        r.aa.cnt = ((d.merged && storage.merged_count) ? storage.merged_count : storage.prow_count) + d.row_base;
+        r.aa.nz = storage.prow_noise + d.row_base;
+        r.aa.col = storage.pent_col + d.ent_base;
+        r.aa.val = storage.pent_val + d.ent_base;
+        r.aa.rows = rows;
+        r.aa.C = C;
+        r.aa.rows_per_block = rows_per_block;
+        r.aa.a = r.d_a.ptr;
+        r.aa.partials = r.d_partials.ptr;
+        r.aa.partial_ld = partial_ld;
+        r.aa.ctl = r.d_ctl.ptr;
+        r.ua.C = C;
+        r.ua.num_partials = r.grid;
+        r.ua.partial_ld = partial_ld;
+        r.ua.partials = r.d_partials.ptr;
+        r.ua.a = r.d_a.ptr;
+        r.ua.inv_total = 1.0 / d.total_mass;
+        r.ua.zero_mass = d.zero_mass;
+        r.ua.max_rel_em_conv = max_rel_em_conv;
+        r.ua.max_em_its = max_em_its;
+        r.ua.ctl = r.d_ctl.ptr;
+        r.update_grid = (C + kUpdateColumns - 1) / kUpdateColumns;
         // Iterations in chunks, two chunks in flight: the control word of chunk k is looked at while chunk k + 1 runs.
         // A short problem's iteration is a few microseconds, a giant one's milliseconds: the chunk holds about half a
         // millisecond of the problem's streaming time at the HBM rate, 4 to 32 iterations.
         const double iteration_us = static_cast<double>(csr_bytes) / 4.0e6 + 8.0;
-        const uint32_t chunk_its = static_cast<uint32_t>(std::min(32.0, std::max(4.0, 500.0 / iteration_us)));
-        EmGridControl * h_ctl = nullptr;  // two pinned slots
-        if (pinnedAlloc(reinterpret_cast<void **>(&h_ctl), 2 * sizeof(EmGridControl)) != hipSuccess) {
-            setError("rpvg_hip_em_solve: out of page-locked host memory");
-            return RPVG_HIP_ERR_ALLOC;
+        r.chunk_its = static_cast<uint32_t>(std::min(32.0, std::max(4.0, 500.0 / iteration_us)));
+        if (pinnedAlloc(reinterpret_cast<void **>(&r.h_ctl), 2 * sizeof(EmGridControl)) != hipSuccess) return hipErrorOutOfMemory;
+        err = hipEventCreateWithFlags(&r.looked[0], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&r.looked[1], hipEventDisableTiming);
+        r.queued = 0;
+        r.chunk = 0;
+        r.span = ctx->spanBegin(FAM_EM_KERNEL, r.stream, RPVG_HIP_EM_KERNELS - 1);
+        r.active = true;
+        return err;
+    };
+    // queues the next chunk of iterations of a run (nothing waits here)
+    auto queueChunk = [&](CsrRun & r) -> hipError_t {
+        const uint32_t n = std::min<uint32_t>(r.chunk_its, max_em_its - r.queued);
+        hipError_t err = hipSuccess;
+        for (uint32_t it = 0; it < n && err == hipSuccess; ++it) {
+            err = launchAccum(r.row_lanes, r.aa, r.grid, r.lds, r.stream);
+            emGridUpdateKernel<<<dim3(r.update_grid), dim3(kUpdateBlock), 0, r.stream>>>(r.ua);
         }
-        hipEvent_t looked[2] = {nullptr, nullptr};
-        auto cleanup = [&]() {
-            for (hipEvent_t ev : looked) if (ev) (void) hipEventDestroy(ev);
-            pinnedFree(h_ctl);
-        };
-        hipError_t e = hipEventCreateWithFlags(&looked[0], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&looked[1], hipEventDisableTiming);
-        uint32_t queued = 0, chunk = 0;
+        r.queued += n;
+        if (err == hipSuccess) err = hipGetLastError();
+        if (err == hipSuccess) err = hipMemcpyAsync(&r.h_ctl[r.chunk & 1], r.d_ctl.ptr, sizeof(EmGridControl), hipMemcpyDeviceToHost, r.stream);
+        if (err == hipSuccess) err = hipEventRecord(r.looked[r.chunk & 1], r.stream);
+        return err;
+    };
+    // looks at the chunk before the one just queued; true: the run has stopped (finish kernel queued, stream waited for, buffers released)
+    auto settle = [&](CsrRun & r, bool & finished) -> hipError_t {
+        hipError_t err = hipSuccess;
         bool done = false;
-        const int span = ctx->spanBegin(FAM_EM_KERNEL, st, RPVG_HIP_EM_KERNELS - 1);
-        while (e == hipSuccess && !done) {
-            const uint32_t n = std::min<uint32_t>(chunk_its, max_em_its - queued);
-            for (uint32_t it = 0; it < n && e == hipSuccess; ++it) {
-                e = launchAccum(row_lanes, aa, grid, lds, st);
-                emGridUpdateKernel<<<dim3(update_grid), dim3(kUpdateBlock), 0, st>>>(ua);
-            }
-            queued += n;
-            if (e == hipSuccess) e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(&h_ctl[chunk & 1], d_ctl.ptr, sizeof(EmGridControl), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipEventRecord(looked[chunk & 1], st);
-            if (e != hipSuccess) break;
-            if (chunk > 0) {  // the chunk before this one
-                e = hipEventSynchronize(looked[(chunk - 1) & 1]);
-                done = e == hipSuccess && h_ctl[(chunk - 1) & 1].done != 0;
-            }
-            if (!done && queued >= max_em_its) {  // the last chunk there can be
-                if (e == hipSuccess) e = hipEventSynchronize(looked[chunk & 1]);
-                done = true;
-            }
-            ++chunk;
+        if (r.chunk > 0) {
+            err = waitEvent(r.looked[(r.chunk - 1) & 1]);
+            done = err == hipSuccess && r.h_ctl[(r.chunk - 1) & 1].done != 0;
         }
-        ctx->spanEnd(span);
-        if (e == hipSuccess) {
-            emGridFinishKernel<<<dim3(1), dim3(kGridBlock), 0, st>>>(C, d_a.ptr, d.total_mass, d_ctl.ptr, out_abundances, storage.noise_count + p,
-                                                                     storage.iterations + p);
-            e = hipGetLastError();
+        if (err == hipSuccess && !done && r.queued >= max_em_its) {  // the last chunk there can be
+            err = waitEvent(r.looked[r.chunk & 1]);
+            done = true;
         }
-        const hipError_t waited = hipStreamSynchronize(st);  // (the buffers of this problem go back to the pool)
-        cleanup();
-        RPVG_HIP_CHECK(e);
-        RPVG_HIP_CHECK(waited);
+        ++r.chunk;
+        finished = done;
+        if (err != hipSuccess || !done) return err;
+        ctx->spanEnd(r.span);
+        const EmGridProblem & d = *r.d;
+        emGridFinishKernel<<<dim3(1), dim3(kGridBlock), 0, r.stream>>>(d.columns, r.d_a.ptr, d.total_mass, r.d_ctl.ptr, storage.abundances + d.col_begin,
+                                                                       storage.noise_count + d.problem, storage.iterations + d.problem);
+        err = hipGetLastError();
+        const hipError_t waited = waitStream(r.stream);  // (the buffers of this problem go back to the pool)
+        r.release();
+        return err != hipSuccess ? err : waited;
+    };
+
+    size_t next = 0;
+    while (e == hipSuccess && (next < csr_route.size() || runs[0].active || runs[1].active)) {
+        for (CsrRun & r : runs) {
+            if (e == hipSuccess && !r.active && next < csr_route.size()) e = start(r, problems[csr_route[next++]]);
+        }
+        for (CsrRun & r : runs) {
+            if (e == hipSuccess && r.active) e = queueChunk(r);
+        }
+        for (CsrRun & r : runs) {
+            bool finished = false;
+            if (e == hipSuccess && r.active) e = settle(r, finished);
+        }
+    }
+    if (e != hipSuccess) {
+        for (CsrRun & r : runs) {
+            if (r.active) (void) hipStreamSynchronize(r.stream);
+        }
+        setError("rpvg_hip_em_solve (problems over the whole GPU): %s", hipGetErrorString(e));
+        return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
     }
     return RPVG_HIP_OK;
 }

@@ -127,6 +127,14 @@ __device__ __forceinline__ void blockExclusiveScanPair(uint32_t & a, uint32_t & 
 constexpr int kEmBins = RPVG_HIP_EM_KERNELS;
 constexpr int kEmGridBin = 11;
 constexpr int kEmWorkBuckets = 32;   // inside a bin the problems are ordered by floor(log2(rows + entries)), large first
+// A FEW mid-size problems — streamed ones (bin 3) of 2^16 rows + entries and more, below the grid threshold — take the grid route
+// too: one workgroup walks such a problem at ~30 us per EM iteration (20 000 rows x 3 entries: 33), the whole GPU at ~8, and a real
+// cluster of that size runs hundreds to thousands of iterations.  Only a few, because the grid takes its problems a handful at
+// a time where the one-workgroup kernels take them all side by side: emOrderKernel moves them when the solve has at most
+// kEmMidGridMax of them (the histogram tells it), and leaves them where they are otherwise.
+constexpr uint32_t kEmMidGridMax = 8;
+constexpr uint32_t kEmMidGridLog2 = 16;  // (a bucket is floor(log2(work + 1)): work + 1 >= 2^16)
+constexpr int kEmStreamedBin = 3;
 constexpr size_t kEmLdsLimit = 156 * 1024;
 constexpr uint32_t kRegColsMax = 32;  // the widest register-resident variant
 
@@ -482,16 +490,35 @@ __global__ __launch_bounds__(256) void fillOffsetsKernel(const FillArgs args) {
 __global__ __launch_bounds__(256) void emOrderKernel(const uint32_t num_problems, const uint32_t * __restrict__ num_problems_dev,
                                                     const uint32_t * __restrict__ prob_bucket, const uint64_t * __restrict__ col_off,
                                                     EmQueues * __restrict__ queues, uint32_t * __restrict__ order,
-                                                    unsigned long long * __restrict__ wide_off, const unsigned long long wide_capacity) {
+                                                    unsigned long long * __restrict__ wide_off, const unsigned long long wide_capacity,
+                                                    const uint32_t mid_grid_allowed) {
     constexpr int kCells = kEmBins * kEmWorkBuckets;
     static_assert(kCells <= 512, "two cells per thread");
     __shared__ uint32_t start[kCells + 1];
     __shared__ uint32_t wave_total[4];
+    __shared__ uint32_t moved_cells;
     const uint32_t P = num_problems_dev ? *num_problems_dev : num_problems;
+    // the few mid-size problems that take the grid route (above): the cells (streamed bin, buckets of 2^16 work units and more)
+    // count as cells of the grid bin — every workgroup reaches the same verdict from the same histogram
+    constexpr uint32_t kMidBuckets = kEmWorkBuckets - kEmMidGridLog2;  // buckets 0 .. kMidBuckets - 1 hold work + 1 >= 2^16
+    if (threadIdx.x == 0) {
+        uint32_t mid = 0;
+        for (uint32_t b = 0; b < kMidBuckets; ++b) mid += queues->histogram[kEmStreamedBin * kEmWorkBuckets + b];
+        moved_cells = (mid_grid_allowed && mid > 0 && mid <= kEmMidGridMax) ? kMidBuckets : 0u;
+    }
+    __syncthreads();
+    const uint32_t moved = moved_cells;
+    auto cellCount = [&](const uint32_t c) -> uint32_t {
+        if (c >= kCells) return 0u;
+        const uint32_t bin = c / kEmWorkBuckets, bucket = c % kEmWorkBuckets;
+        if (bucket < moved && bin == kEmStreamedBin) return 0u;
+        if (bucket < moved && bin == kEmGridBin) return queues->histogram[c] + queues->histogram[kEmStreamedBin * kEmWorkBuckets + bucket];
+        return queues->histogram[c];
+    };
     {
         // exclusive prefix of the histogram: thread t owns cells 2 t and 2 t + 1
         const uint32_t c0 = 2 * threadIdx.x, c1 = c0 + 1;
-        const uint32_t h0 = c0 < kCells ? queues->histogram[c0] : 0u, h1 = c1 < kCells ? queues->histogram[c1] : 0u;
+        const uint32_t h0 = cellCount(c0), h1 = cellCount(c1);
         uint32_t incl = h0 + h1;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -515,7 +542,8 @@ __global__ __launch_bounds__(256) void emOrderKernel(const uint32_t num_problems
     }
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    const uint32_t cell = prob_bucket[p];
+    uint32_t cell = prob_bucket[p];
+    if (cell / kEmWorkBuckets == kEmStreamedBin && cell % kEmWorkBuckets < moved) cell = kEmGridBin * kEmWorkBuckets + cell % kEmWorkBuckets;
     order[start[cell] + atomicAdd(&queues->bucket_cursor[cell], 1u)] = p;
     if (cell / kEmWorkBuckets == 10) {  // abundance + accumulator vectors in global memory
         const unsigned long long need = 2ull * (static_cast<unsigned long long>(col_off[p + 1] - col_off[p]) + 1);
@@ -1376,8 +1404,10 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         RPVG_HIP_CHECK(hipEventCreateWithFlags(&work.filled, hipEventDisableTiming));
         RPVG_HIP_CHECK(hipEventRecord(work.filled, st));
     }
+    // (the few mid-size problems that may take the grid route: only where the grid route exists at all)
+    const bool mid_grid_allowed = rule.grid_min_work > (1ull << kEmMidGridLog2);
     emOrderKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(P, list.d_num_problems, work.d_bucket.ptr, list.d_col_off, queues, work.d_order.ptr,
-                                                              work.d_wide_off.ptr, list.wide_capacity);
+                                                              work.d_wide_off.ptr, list.wide_capacity, mid_grid_allowed ? 1u : 0u);
     RPVG_HIP_CHECK(hipGetLastError());
     ctx->spanEnd(span);
     ctx->stats.build_launches += 1;
@@ -1520,14 +1550,12 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
             RPVG_HIP_CHECK((launchEm<1024, false, true>(args, grid(1), sizeof(double) * (1024 / 64 + 2), s_reg2)));
             ctx->spanEnd(bin_span);
         }
-        // (RPVG_HIP_EM_JOIN_ON_STREAM=1: the context's stream waits for the side streams, not the thread — A/B)
-        static const bool join_on_stream = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_JOIN_ON_STREAM") != nullptr;
-        RPVG_HIP_CHECK(join_on_stream ? ctx->joinAux() : ctx->joinAuxOnHost());
+        // (the side streams are joined behind the problems that run over the whole GPU, below: those start while these kernels run)
         return RPVG_HIP_OK;
     };
     // The grid bin (problems too large for one workgroup, em_grid.hip): the host has to see them.  Only a solve that
     // sits on a cluster large enough to produce one pays for the look (two small copies and their waits).
-    const bool grid_possible = rule.grid_min_work != 0 && list.max_cluster_work >= rule.grid_min_work;
+    const bool grid_possible = rule.grid_min_work != 0 && list.max_cluster_work >= (mid_grid_allowed ? (1ull << kEmMidGridLog2) - 1 : rule.grid_min_work);
     DeviceBuffer<EmGridProblem> d_grid_problems;
     hipEvent_t described = nullptr;
     uint32_t * h_grid_count = nullptr;
@@ -1569,7 +1597,6 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         const int rc = launchVariants(true);
         if (rc != RPVG_HIP_OK) return rc;
     }
-    ctx->spanEnd(span);
     if (grid_possible) {
         RPVG_HIP_CHECK(waitEvent(described));
         const uint32_t n_grid = std::min<uint32_t>(*h_grid_count, P);
@@ -1591,6 +1618,12 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
             if (rc != RPVG_HIP_OK) return rc;
         }
     }
+    {
+        // (RPVG_HIP_EM_JOIN_ON_STREAM=1: the context's stream waits for the side streams, not the thread — A/B)
+        static const bool join_on_stream = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_JOIN_ON_STREAM") != nullptr;
+        RPVG_HIP_CHECK(join_on_stream ? ctx->joinAux() : ctx->joinAuxOnHost());
+    }
+    ctx->spanEnd(span);  // (behind the join: the span of the solve's kernels on all of its streams)
     if (collapse) {
         const CsrCollapseWork * cw = static_cast<const CsrCollapseWork *>(work.collapse.get());
         static const bool debug = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_COLLAPSE_DEBUG") != nullptr;
@@ -1622,9 +1655,17 @@ void accountEmSolve(rpvg_hip_ctx * ctx, const uint32_t P, const uint64_t * col_o
     double bin_bytes[kEmBins] = {};
     uint64_t bin_its[kEmBins] = {}, bin_problems[kEmBins] = {};
     uint32_t bin_slowest[kEmBins] = {};
+    // (emOrderKernel's verdict on the few mid-size problems, repeated)
+    uint32_t mid_problems = 0;
     for (uint32_t p = 0; p < P; ++p) {
         const uint32_t C = static_cast<uint32_t>(col_off[p + 1] - col_off[p]) + 1;
-        const int b = emBinOf(rule, C, kept_rows[p], kept_entries[p]);
+        if (emBinOf(rule, C, kept_rows[p], kept_entries[p]) == kEmStreamedBin && emWorkBucket(kept_rows[p], kept_entries[p]) < kEmWorkBuckets - kEmMidGridLog2) ++mid_problems;
+    }
+    const bool mid_moved = rule.grid_min_work > (1ull << kEmMidGridLog2) && mid_problems > 0 && mid_problems <= kEmMidGridMax;
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t C = static_cast<uint32_t>(col_off[p + 1] - col_off[p]) + 1;
+        int b = emBinOf(rule, C, kept_rows[p], kept_entries[p]);
+        if (mid_moved && b == kEmStreamedBin && emWorkBucket(kept_rows[p], kept_entries[p]) < kEmWorkBuckets - kEmMidGridLog2) b = kEmGridBin;
         // (a problem of the grid bin on the dense route ran em_dense.hip's kernels: emDenseIterate has accounted for it)
         if (b == kEmGridBin && emGridDenseRoute(C, kept_rows[p], kept_entries[p])) {
             bin_problems[b] += 1;

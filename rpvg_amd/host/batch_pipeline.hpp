@@ -13,7 +13,7 @@
 //   `workers`     estimator threads, each with a single-lane engine (nine streams) and an estimator of its own, take the
 //                 resident batches in order and run PathEstimator::estimateBatchSeeded on them.
 // configs[2] of BASELINE.json on one MI355X: 8.6 ms per resident batch one at a time (two host lanes), 6.1 with two such
-// engines, 4.5 with four single-lane engines on sixteen hardware queues (docs/design/host-orchestration.md); with the copy
+// engines, 4.5 with four single-lane engines (docs/design/host-orchestration.md); with the copy
 // of every batch in the loop the PCIe link (54 GB/s, 288 MB per batch) sets the pace.
 // Results are those of the same calls made one after the other: batches do not interact.
 #ifndef RPVG_AMD_BATCH_PIPELINE_HPP
