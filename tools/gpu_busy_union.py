@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Share of wall time during which at least one kernel ran, from a rocprofv3 --kernel-trace csv directory of the pipelined bench
-(several batches in flight: the per-step view of tools/gpu_gaps.py does not apply).  The window is the timed region's: from the
-start of the (K + 1)-th last pairTile2Kernel launch to the end of the last kernel, K = the steps of the run's last loop (default:
-the last 12 searches).  Copies run on the SDMA engines and are not kernels: they are not in the trace.
+(several batches in flight: the per-step view of tools/gpu_gaps.py does not apply).  The window is the pipeline's steady state:
+the K consecutive pairTile2Kernel launches (= batches) that lie closest together, from the start of the first to the start of the
+launch behind them (default K = 12).  Copies run on the SDMA engines and are not kernels: they are not in the trace.
 
     python tools/gpu_busy_union.py <dir> [searches]
 """
@@ -16,9 +16,17 @@ for r in csv.DictReader(open(f)):
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n))
 ev.sort()
 searches = [e for e in ev if e[2].startswith("pairTile2")]
-t0 = searches[-last][0] if len(searches) >= last else ev[0][0]
-t1 = max(e[1] for e in ev)
-ks = [e for e in ev if e[1] > t0]
+# the pipeline's steady state: the `last` consecutive searches that lie closest together (the run also holds resident batches one at
+# a time, warm-ups and a decoded run); the window runs from the start of the first of them to the start of the one behind them
+best = None
+for i in range(0, len(searches) - last):
+    span = searches[i + last][0] - searches[i][0]
+    if best is None or span < best[0]:
+        best = (span, i)
+if best is None:
+    raise SystemExit("fewer searches in the trace than asked for")
+t0, t1 = searches[best[1]][0], searches[best[1] + last][0]
+ks = [(s, min(e, t1), n) for s, e, n in ev if e > t0 and s < t1]
 busy, cur_s, cur_e = 0, None, None
 depth_time = {}
 for s, e, n in ks:

@@ -31,6 +31,7 @@ def main():
     for name in sorted(totals):
         counters = totals[name]
         print(name)
+        print(f"    {'DISPATCHES_PER_PASS':32s} {len(dispatches[name]) / max(1, len(args.dirs)):.6g}")
         for c in sorted(counters):
             print(f"    {c:32s} {counters[c]:.6g}")
 

@@ -23,7 +23,7 @@ for line in open(listing):
         name, value = line.split()
         counters[name] = float(value)
 waves_per_launch = 4 * 6621  # 256-thread workgroups of the S3 batch (bench.py's configs[2] workload: 6 621 (matrix, chunk) items)
-launches = given_launches if given_launches else counters["SQ_WAVES"] / waves_per_launch
+launches = given_launches if given_launches else counters.get("DISPATCHES_PER_PASS") or counters["SQ_WAVES"] / waves_per_launch
 simds, xcds = 256 * 4, 8
 # GRBM_GUI_ACTIVE is summed over the XCDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
 kernel_cycles = counters["GRBM_GUI_ACTIVE"] / xcds
@@ -32,6 +32,6 @@ summary = dict(kernel=kernel, launches=launches, evals_per_launch=evals,
                valu_busy=counters["SQ_INSTS_VALU"] * 4 / (simds * kernel_cycles),
                lds_bank_conflict_share=counters.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, counters.get("SQ_LDS_IDX_ACTIVE", 0.0)),
                kernel_ms_at_2p4_ghz=kernel_cycles / launches / 2.4e6,
-               source=listing, commit=commit, note="rocprofv3 --pmc passes, one host lane (tools/refresh_profiles_r03.sh)")
+               source=listing, commit=commit, note="rocprofv3 --pmc passes, one host lane, every launch a whole batch (tools/refresh_profiles_r05.sh)")
 json.dump(summary, open(out, "w"), indent=1)
 print(json.dumps(summary))

@@ -69,7 +69,7 @@ python tools/pmc_traffic.py --fetch-dir $out/pmc_c2_fetch --write-dir $out/pmc_c
   --command "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --workload c2 --steps 1 --warmup 1 --no-cpu-baseline (two separate passes; 3 estimator calls x 50 EM iterations = 150 launches)" \
   --out $out/pmc_traffic_c2.json > /dev/null
 python tools/pmc_kernels.py $out/pmc_search_1 $out/pmc_search_2 $out/pmc_search_3 $out/pmc_search_4 --kernel pairTile,resolveTable,groupsBuildMask,fillSegments,subsetSelect,subsetMerge,sourceColumns > $out/pmc_s3_throughput_kernels.txt
-(cd $out && python $R/tools/pmc_search_summary.py pmc_s3_throughput_kernels.txt 4573105636 pmc_search_s3.json $commit pairTile2Kernel 0 > /dev/null)
+(cd $out && python $R/tools/pmc_search_summary.py pmc_s3_throughput_kernels.txt 4573105636 pmc_search_s3.json $commit pairTile2Kernel > /dev/null)
 rm -rf $out/pmc_s3_fetch $out/pmc_s3_write $out/pmc_c2_fetch $out/pmc_c2_write $out/pmc_search_?
 echo $commit > $out/COMMIT
 for f in bench_s3_n1 bench_s3_n1_200_steps bench_s3_n1_one_worker bench_s3_n1_two_workers bench_s3_n1_host_source_groups bench_s3_n1_spin_waits bench_c2_n1 bench_s5_n1 bench_rows_n1 bench_e2e_n1 bench_a1_n1_team_64 bench_a1_n1_team_256 bench_a1_n1_team_64_no_combiner bench_s3_n1_profiled; do python - <<PY
