@@ -75,6 +75,12 @@ int hardwareQueues();
 hipError_t waitEvent(hipEvent_t event);
 hipError_t waitStream(hipStream_t stream);
 
+// ---- zeroing device memory in one launch -----------------------------------------------------------
+// hipMemsetAsync of a size or address that is not a multiple of its fill kernel's width becomes up to four fill kernels (head, body,
+// tail), each a dispatch that waits its turn on a busy GPU (eleven per configs[2] batch, 22 us each next to other batches' kernels).
+// One kernel of 4-byte stores instead; ptr and bytes multiples of four (anything else goes to hipMemsetAsync).
+hipError_t zeroAsync(void * ptr, size_t bytes, hipStream_t stream);
+
 // ---- caching device allocator -------------------------------------------------
 // hipMalloc/hipFree cost tens of microseconds to milliseconds each (hipFree also
 // synchronises the device); a step of the hot path needs ~60 scratch arrays whose
@@ -215,7 +221,7 @@ struct UploadPack {
             if (e != hipSuccess) return e;
         }
         if (zero_bytes > 0) {
-            e = hipMemsetAsync(block.ptr + copied_bytes, 0, zero_bytes, stream);
+            e = zeroAsync(block.ptr + copied_bytes, zero_bytes, stream);
             if (e != hipSuccess) return e;
         }
         for (auto & p : pieces) p.bind(block.ptr + p.offset);

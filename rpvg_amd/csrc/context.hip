@@ -279,6 +279,22 @@ hipError_t pollUntilDone(Query query) {
 
 }  // namespace
 
+namespace {
+__global__ void zeroWordsKernel(uint32_t * __restrict__ words, const size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) words[i] = 0u;
+}
+}  // namespace
+
+hipError_t zeroAsync(void * ptr, const size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(ptr) & 3u) || (bytes & 3u)) return hipMemsetAsync(ptr, 0, bytes, stream);
+    const size_t n = bytes / 4;
+    const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>((n + 255) / 256, 2048));
+    zeroWordsKernel<<<dim3(blocks), dim3(256), 0, stream>>>(static_cast<uint32_t *>(ptr), n);
+    return hipGetLastError();
+}
+
 hipError_t waitEvent(hipEvent_t event) {
     const hipError_t e = pollUntilDone([event]() { return hipEventQuery(event); });
     return e == hipErrorNotSupported ? hipEventSynchronize(event) : e;

@@ -1336,7 +1336,7 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     EmQueues * queues = reinterpret_cast<EmQueues *>(work.zeroed_queues ? work.zeroed_queues : work.d_queues.ptr);
 
     int span = ctx->spanBegin(FAM_BUILD);
-    if (!work.zeroed_queues) RPVG_HIP_CHECK(hipMemsetAsync(work.d_queues.ptr, 0, sizeof(EmQueues), st));
+    if (!work.zeroed_queues) RPVG_HIP_CHECK(zeroAsync(work.d_queues.ptr, sizeof(EmQueues), st));
     RPVG_HIP_CHECK(work.d_seg_rows.alloc(list.items_bound));
     RPVG_HIP_CHECK(work.d_seg_entries.alloc(list.items_bound));
     RPVG_HIP_CHECK(work.d_seg_zero.alloc(list.items_bound));

@@ -53,7 +53,8 @@ struct SourceArgs {
     uint32_t * num_col_paths;            // [K]
     uint32_t * max_col_paths;            // [K]
     uint32_t * flags;                    // [0] inconsistent offsets, [1] clusters the arena had no room for
-    uint32_t * big_list;                 // [K] clusters the small workgroups left to the large ones, [K]: their number
+    uint32_t * big_list;                 // [K] clusters the small workgroups left to the large ones
+    uint32_t * big_count;                // their number
 };
 
 __device__ __forceinline__ unsigned long long mixHash(unsigned long long h) {
@@ -76,11 +77,10 @@ __global__ __launch_bounds__(BLOCK) void sourceColumnsKernel(const SourceArgs a)
     __shared__ uint32_t s_scan[kWaves], s_lo[kWaves], s_hi[kWaves];
     __shared__ unsigned long long s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t k = blockIdx.x;
-    if (!SMALL) {
-        if (k >= a.big_list[a.num_clusters]) return;
-        k = a.big_list[k];
-    }
+    // (the large workgroups: a few of them walk the list — five thousand that look at its length and leave took 80 us to dispatch)
+    for (uint32_t turn = blockIdx.x; SMALL ? turn == blockIdx.x : turn < *a.big_count; turn += gridDim.x) {
+    __syncthreads();  // (the LDS of the cluster before)
+    const uint32_t k = SMALL ? turn : a.big_list[turn];
     if (k >= a.num_clusters) return;
     const uint64_t p0 = a.cluster_path_off[k], p1 = a.cluster_path_off[k + 1];
     const uint32_t N = static_cast<uint32_t>(p1 - p0);
@@ -95,11 +95,11 @@ __global__ __launch_bounds__(BLOCK) void sourceColumnsKernel(const SourceArgs a)
     };
     if (i1 < i0 || i1 > a.num_sources || i1 - i0 > 0xfffffffeull) {
         leave(0, 0);
-        return;
+        continue;
     }
     if (i1 == i0 || N == 0) {  // a cluster without haplotype ids: the estimator that needs columns says so
         leave(0, 2);
-        return;
+        continue;
     }
     // 1. the id range
     uint32_t lo = 0xffffffffu, hi = 0;
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(BLOCK) void sourceColumnsKernel(const SourceArgs a)
     unsigned long long * bits = s_bits;
     uint32_t * owner = s_owner, * smin = s_min, * scnt = s_cnt, * group = s_group, * rep = s_rep;
     if (SMALL && !(words <= kLdsWords && H <= kLdsHaplotypes)) {  // (for a large workgroup)
-        if (tid == 0) a.big_list[atomicAdd(&a.big_list[a.num_clusters], 1u)] = k;
-        return;
+        if (tid == 0) a.big_list[atomicAdd(a.big_count, 1u)] = k;
+        continue;
     }
     if (!(words <= kLdsWords && H <= kLdsHaplotypes)) {
         const unsigned long long need = words + (3 * T + 2 * H + 1) / 2;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(BLOCK) void sourceColumnsKernel(const SourceArgs a)
         const unsigned long long base = s_base;
         if (need > a.arena_words || base + need > a.arena_words) {
             leave(0, 1);
-            return;
+            continue;
         }
         bits = a.arena + base;
         owner = reinterpret_cast<uint32_t *>(bits + words);
@@ -254,6 +254,7 @@ __global__ __launch_bounds__(BLOCK) void sourceColumnsKernel(const SourceArgs a)
         for (int w = 1; w < kWaves; ++w) longest_of_all = max(longest_of_all, s_hi[w]);
         a.max_col_paths[k] = longest_of_all;
     }
+    }  // (the next cluster of this workgroup's)
 }
 
 // read count of every cluster: exact in 64-bit integers, one workgroup per cluster
@@ -305,9 +306,9 @@ hipError_t queuePathSourceCopies(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const r
     // scratch of the clusters whose id range or path count outgrows LDS: eight words per incidence, at least 128 MB
     pending.arena_words = std::max<unsigned long long>(1ull << 24, 8ull * S);
     pending.num_sources = S;
-    ok(pending.d_arena.alloc(pending.arena_words + 1));
-    ok(pending.d_sizes.alloc(4 * static_cast<size_t>(K) + 3));  // [sizes 3K | flags 2 | list of the large workgroups K | its length]
-    if (e == hipSuccess && pinnedAlloc(&pending.h_sizes, (3 * static_cast<size_t>(K) + 2) * sizeof(uint32_t)) != hipSuccess) e = hipErrorOutOfMemory;
+    ok(pending.d_arena.alloc(pending.arena_words));
+    ok(pending.d_sizes.alloc(4 * static_cast<size_t>(K) + 8));  // (layout: queuePathSourceKernels)
+    if (e == hipSuccess && pinnedAlloc(&pending.h_sizes, (3 * static_cast<size_t>(K) + 4) * sizeof(uint32_t)) != hipSuccess) e = hipErrorOutOfMemory;
     pending.copied = (e == hipSuccess);
     return e;
 }
@@ -318,9 +319,10 @@ hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSo
     hipStream_t st = ctx->stream;
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
-    ok(hipMemsetAsync(pending.d_arena.ptr + pending.arena_words, 0, sizeof(unsigned long long), st));
-    ok(hipMemsetAsync(pending.d_sizes.ptr + 3 * static_cast<size_t>(K), 0, 2 * sizeof(uint32_t), st));
-    ok(hipMemsetAsync(pending.d_sizes.ptr + 4 * static_cast<size_t>(K) + 2, 0, sizeof(uint32_t), st));  // (the length of the large workgroups' list)
+    // d_sizes: [the arena's cursor, 64 bits | flags 2 | length of the large workgroups' list | - | sizes 3K | that list K]: the first six
+    // words are zeroed by one memset; words 2 .. 6 + 3K come back to the host
+    uint32_t * const words = pending.d_sizes.ptr;
+    ok(zeroAsync(words, 6 * sizeof(uint32_t), st));
     SourceArgs a;
     a.num_clusters = K;
     a.cluster_path_off = b->cluster_path_off.ptr;
@@ -329,21 +331,22 @@ hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSo
     a.num_sources = pending.num_sources;
     a.arena = pending.d_arena.ptr;
     a.arena_words = pending.arena_words;
-    a.arena_cursor = pending.d_arena.ptr + pending.arena_words;
+    a.arena_cursor = reinterpret_cast<unsigned long long *>(words);
     a.col_count = b->src_col_count.ptr;
     a.col_end = b->src_col_end.ptr;
     a.col_path = b->src_col_path.ptr;
-    a.num_cols = pending.d_sizes.ptr;
-    a.num_col_paths = pending.d_sizes.ptr + K;
-    a.max_col_paths = pending.d_sizes.ptr + 2 * static_cast<size_t>(K);
-    a.flags = pending.d_sizes.ptr + 3 * static_cast<size_t>(K);
-    a.big_list = pending.d_sizes.ptr + 3 * static_cast<size_t>(K) + 2;
+    a.flags = words + 2;
+    a.big_count = words + 4;
+    a.num_cols = words + 6;
+    a.num_col_paths = words + 6 + K;
+    a.max_col_paths = words + 6 + 2 * static_cast<size_t>(K);
+    a.big_list = words + 6 + 3 * static_cast<size_t>(K);
     if (e == hipSuccess) {
         sourceColumnsKernel<kSmallBlock, kSmallLdsWords, kSmallLdsHaplotypes, true><<<dim3(K), dim3(kSmallBlock), 0, st>>>(a);
-        sourceColumnsKernel<kBlock, kLdsWords, kLdsHaplotypes, false><<<dim3(K), dim3(kBlock), 0, st>>>(a);
+        sourceColumnsKernel<kBlock, kLdsWords, kLdsHaplotypes, false><<<dim3(std::min<uint32_t>(K, 128)), dim3(kBlock), 0, st>>>(a);
         ok(hipGetLastError());
     }
-    ok(hipMemcpyAsync(pending.h_sizes, pending.d_sizes.ptr, (3 * static_cast<size_t>(K) + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    ok(hipMemcpyAsync(pending.h_sizes, words + 2, (3 * static_cast<size_t>(K) + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     pending.queued = (e == hipSuccess);
     return e;
 }
@@ -351,12 +354,13 @@ hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSo
 int finishPathSources(rpvg_hip_batch * b, PathSourcesPending & pending) {
     if (!pending.queued) return RPVG_HIP_OK;
     const uint32_t K = pending.K;
-    const uint32_t * sizes = static_cast<const uint32_t *>(pending.h_sizes);
-    if (sizes[3 * static_cast<size_t>(K)]) {
+    const uint32_t * flags = static_cast<const uint32_t *>(pending.h_sizes);  // [flags 2 | length of the large list | - | sizes 3K]
+    const uint32_t * sizes = flags + 4;
+    if (flags[0]) {
         setError("rpvg_hip_batch_upload: path_source_off is not a non-decreasing sequence of offsets into source_id");
         return RPVG_HIP_ERR_INVALID;
     }
-    if (sizes[3 * static_cast<size_t>(K) + 1]) {  // id ranges too wide for the scratch: the caller groups on the host
+    if (flags[1]) {  // id ranges too wide for the scratch: the caller groups on the host
         b->src_col_count.release();
         b->src_col_end.release();
         b->src_col_path.release();

@@ -1613,7 +1613,7 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
              * row_item_count = between_count + 1, * mat_list = pair_bytes + num_words + active_words;
     uint8_t * same_prev = tmp->bytes.ptr, * close = same_prev + total_rows, * barrier = close + total_rows;
     uint8_t * active = reinterpret_cast<uint8_t *>(pair_bytes + num_words);
-    ok(hipMemsetAsync(info.ptr, 0, (kInfoWords + num_words + active_words) * sizeof(uint32_t), st));
+    ok(zeroAsync(info.ptr, (kInfoWords + num_words + active_words) * sizeof(uint32_t), st));
     if (!plan) ok(sort(tmp->sort_tmp.ptr));
     PairScanArgs<Arrays> a;
     a.total_rows = total_rows;
@@ -1642,7 +1642,7 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     // 4 096 of them were most of a 60 us kernel).  RPVG_HIP_COLLAPSE_GRID overrides (A/B).
     static const uint32_t small_grid = RPVG_EXPERIMENT_ENV("RPVG_HIP_COLLAPSE_GRID") ? std::max(1, std::atoi(RPVG_EXPERIMENT_ENV("RPVG_HIP_COLLAPSE_GRID"))) : 256;
     if (plan) {
-        ok(hipMemsetAsync(tmp->chunk_count.ptr, 0, sizeof(uint32_t), st));
+        ok(zeroAsync(tmp->chunk_count.ptr, sizeof(uint32_t), st));
         SegmentSortArgs<Arrays> c;
         c.g = arrays;
         c.num_matrices = M;
@@ -1874,7 +1874,7 @@ hipError_t rpvg_hip_detail::queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollap
     ok(work.merged_count.alloc(total_rows));
     ok(work.problem_merged.alloc(P + 1));  // [P]: the number of merged problems
     if (e != hipSuccess) return e;
-    ok(hipMemsetAsync(work.problem_merged.ptr, 0, (P + 1) * sizeof(uint32_t), st));
+    ok(zeroAsync(work.problem_merged.ptr, (P + 1) * sizeof(uint32_t), st));
     CsrArrays arrays;
     arrays.row_base = in.row_base;
     arrays.ent_base = in.ent_base;

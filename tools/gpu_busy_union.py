@@ -13,9 +13,17 @@ f = sorted(glob.glob(d + "/*/*kernel_trace.csv"))[-1]
 ev = []
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-    ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n))
+    ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, r.get("Stream_Id")))
 ev.sort()
-searches = [e for e in ev if e[2].startswith("pairTile2")]
+# (the run's first engine — resident batches, two host lanes, two searches per batch — searches on its two main streams: not the pipeline's)
+first_engine = []
+for e in ev:
+    if e[2].startswith("pairTile2") and e[3] not in first_engine:
+        first_engine.append(e[3])
+    if len(first_engine) == 2:
+        break
+searches = [e for e in ev if e[2].startswith("pairTile2") and e[3] not in first_engine]
+ev = [e[:3] for e in ev]
 # the pipeline's steady state: the `last` consecutive searches that lie closest together (the run also holds resident batches one at
 # a time, warm-ups and a decoded run); the window runs from the start of the first of them to the start of the one behind them
 best = None
