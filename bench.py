@@ -246,6 +246,8 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         base_paths, seed0, gen_kw, config_name = 500000, 5, dict(max_cluster_paths=5000), "configs[4]"
     else:
         params = make_params()
+        if os.environ.get("RPVG_BENCH_MAX_EM_ITS"):  # (experiment: what the EM's iterations cost the step; not a measurement of record)
+            params.max_em_its = int(os.environ["RPVG_BENCH_MAX_EM_ITS"])
         base_paths, seed0, gen_kw, config_name = 200000, 3, {}, "configs[2]"
     K = max(8, int(round(5000 * args.scale)))
     total_paths = max(K, int(round(base_paths * args.scale)))

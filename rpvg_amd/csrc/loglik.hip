@@ -534,6 +534,151 @@ __global__ __launch_bounds__(256) void groupsBuildMaskKernel(const MaskBuildArgs
     }
 }
 
+// ---- matrices of up to 64 columns: the columns of a path as ONE word (round 5) ---------------------------------------------
+//
+// With several batches in flight the GPU is busy throughout, and groupsBuildMaskKernel is a quarter of what its SIMDs issue per
+// configs[2] batch: a cell costs a test of every held entry of the row against the column's set — twice, once for the row sum and
+// once for the value —, four or eight entries whatever the row has, and a set is a load per cell.  The matrices of that batch
+// have up to 64 columns (99 % of its cells), few enough for the incidence the other way round to be a word per PATH: the columns
+// that contain it.  A lane (= a row) then takes its entries one after the other — as many as the wave's longest row has — and
+// adds each entry's probability to the cells whose bit is set in the entry's word, all 64 cells in registers: a bit field
+// extract, two ANDs and an addition per entry and cell (the additions of a cell are those of the other kernels in the same
+// order: entry after entry; an entry outside the column adds + 0.0), no load after the entries', and the cells are still there
+// when the row sum is known.
+constexpr uint32_t kWordMaxColumns = 64;
+constexpr int kWordHeld = 4;   // entries loaded ahead of the loop (3.3 a row on the configs[2] batch; the wave's longest row: 4.4)
+
+// one thread per column: its bit into the word of every path it contains (words zeroed before)
+__global__ void pathColumnWordKernel(const uint32_t num_matrices, const uint64_t num_columns, const uint64_t * __restrict__ group_off,
+                                     const uint64_t * __restrict__ group_path_off, const uint32_t * __restrict__ group_path,
+                                     const uint64_t * __restrict__ num_paths, const uint64_t * __restrict__ word_off,
+                                     unsigned long long * __restrict__ words, uint32_t * __restrict__ error_flag) {
+    const uint64_t column = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (column >= num_columns) return;
+    const uint32_t m = matrixOfColumn(group_off, num_matrices, column);
+    if (word_off[m] == ~0ull) return;  // (a matrix of the other kernels)
+    const unsigned long long bit = 1ull << (column - group_off[m]);
+    for (uint64_t x = group_path_off[column]; x < group_path_off[column + 1]; ++x) {
+        const uint32_t p = group_path[x];
+        if (p >= num_paths[m]) {
+            *error_flag = 1;
+            continue;
+        }
+        if (atomicOr(&words[word_off[m] + p], bit) & bit) *error_flag = 2;  // (the lists of the other kernels would add such a path twice)
+    }
+}
+
+// cells[c] += the entry's probability where bit c of its word is set
+__device__ __forceinline__ void addEntryToCells(double (&cells)[kWordMaxColumns], const uint32_t blocks, const uint64_t word, const double prob) {
+    const int lo = static_cast<int>(static_cast<uint32_t>(word)), hi = static_cast<int>(static_cast<uint32_t>(word >> 32));
+    const int prob_lo = __double2loint(prob), prob_hi = __double2hiint(prob);
+#pragma unroll
+    for (uint32_t b = 0; b < kWordMaxColumns / 8; ++b) {
+        if (b < blocks) {  // (of the wave; a column past the matrix's last has no bit anywhere)
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                const uint32_t c = 8 * b + j;
+                const int all = __builtin_amdgcn_sbfe(c < 32 ? lo : hi, c & 31u, 1);  // 0 or ~0
+                cells[c] += __hiloint2double(prob_hi & all, prob_lo & all);
+            }
+        }
+    }
+}
+
+// A wave per (matrix, 64 rows) item, a lane per row, as groupsBuildMaskKernel; MaskBuildArgs with `masks` = the words of the
+// paths and `mask_off` = the first word of a matrix.
+__global__ __launch_bounds__(256) void groupsBuildWordKernel(const MaskBuildArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (item >= a.num_items) return;
+    const uint32_t m = a.item_matrix[item];
+    const uint64_t R = a.mat_rows[m], r0 = a.mat_row0[m], row_off = a.mat_row_off[m];
+    const uint32_t G = a.mat_cols[m], blocks = (G + 7) / 8;
+    const uint64_t * const words = a.masks + a.mask_off[m];
+    double * const M = a.values + a.mat_val_off[m];
+    const uint64_t i = static_cast<uint64_t>(a.item_chunk[item]) * kMaskRows + lane;
+    const bool valid = i < R;
+    const uint64_t r = valid ? r0 + a.row_perm[row_off + i] : 0;
+    const uint64_t e_begin = valid ? a.row_ent_off[r] : 0, e_end = valid ? a.row_ent_off[r + 1] : 0;
+    const double noise = valid && a.normalise ? a.row_noise[r] : 0.0;
+    const uint32_t n = static_cast<uint32_t>(e_end - e_begin);
+    uint32_t longest = n;
+#pragma unroll
+    for (int offset = 32; offset > 0; offset >>= 1) {
+        const uint32_t other = __shfl_xor(longest, offset);
+        longest = other > longest ? other : longest;
+    }
+    longest = __builtin_amdgcn_readfirstlane(longest);
+
+    uint64_t word[kWordHeld];
+    double prob[kWordHeld];
+#pragma unroll
+    for (int k = 0; k < kWordHeld; ++k) {
+        word[k] = 0;   // (an entry past the row's last: no column)
+        prob[k] = 0.0;
+        if (static_cast<uint32_t>(k) < n) {
+            word[k] = words[a.ent_path[e_begin + k]];
+            prob[k] = a.ent_prob[e_begin + k];
+        }
+    }
+    double cells[kWordMaxColumns];
+#pragma unroll
+    for (uint32_t c = 0; c < kWordMaxColumns; ++c) cells[c] = 0.0;
+#pragma unroll
+    for (int k = 0; k < kWordHeld; ++k) {
+        if (static_cast<uint32_t>(k) < longest) addEntryToCells(cells, blocks, word[k], prob[k]);
+    }
+    for (uint32_t k = kWordHeld; k < longest; ++k) {
+        uint64_t w = 0;
+        double v = 0.0;
+        if (k < n) {
+            w = words[a.ent_path[e_begin + k]];
+            v = a.ent_prob[e_begin + k];
+        }
+        addEntryToCells(cells, blocks, w, v);
+    }
+
+    double rowsum = 0.0;
+    if (a.normalise) {
+#pragma unroll
+        for (uint32_t b = 0; b < kWordMaxColumns / 8; ++b) {
+            if (b < blocks) {
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) rowsum += cells[8 * b + j];  // (in column order; a column past the last adds + 0.0)
+            }
+        }
+    }
+    const double keep = 1 - noise;
+    double key = collapseWeight(G) * noise, mx = 0.0;
+    uint32_t pattern_lo = 0, pattern_hi = 0;
+    double * out = M + i;
+#pragma unroll
+    for (uint32_t c = 0; c < kWordMaxColumns; ++c) {
+        if (c < G) {
+            double value = cells[c];
+            if (a.normalise) {
+                value = (value / rowsum) * keep;
+                if (value != value) value = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
+                key = fma(collapseWeight(c), value, key);
+                if (value != 0.0) {
+                    if (c < 32) pattern_lo |= 1u << (c & 31u); else pattern_hi |= 1u << (c & 31u);
+                }
+            }
+            mx = fmax(mx, value);
+            if (valid) *out = value;
+            out += R;
+        }
+    }
+    if (valid) {
+        a.rowmax[row_off + i] = mx;
+        if (a.normalise && a.collapse_key) {
+            a.collapse_key[row_off + i] = collapseSortKey(m, key, mx);
+            a.collapse_row[row_off + i] = static_cast<uint32_t>(row_off + i);
+            a.collapse_mask[row_off + i] = (static_cast<uint64_t>(pattern_hi) << 32) | pattern_lo;
+        }
+    }
+}
+
 // storage of the matrices groupsBuildKernel accumulates in global memory: one work item = 256 rows of one matrix
 __global__ __launch_bounds__(256) void zeroWideMatricesKernel(const uint32_t * __restrict__ item_matrix, const uint32_t * __restrict__ item_chunk,
                                                               const uint64_t * __restrict__ mat_val_off, const uint64_t * __restrict__ mat_rows,
@@ -756,15 +901,18 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
     std::unique_ptr<HostScope> scope_host(new HostScope("groups_build: host sizes"));
     // host: sizes and offsets only (O(M)); the path -> groups incidence is inverted on the device
     std::vector<uint64_t> val_off(M), row_off(M), row0(M), rows(M), inc_off(M), num_paths(M);
-    std::vector<uint32_t> cols(M), item_matrix, item_chunk, tile_matrix, tile_chunk, mask_matrix, mask_chunk;
-    std::vector<uint64_t> mask_off(M, ~0ull);  // (~0: a matrix of the list kernels)
-    uint64_t val_total = 0, row_total = 0, inc_total = 0, mask_total = 0;
+    std::vector<uint32_t> cols(M), item_matrix, item_chunk, tile_matrix, tile_chunk, mask_matrix, mask_chunk, word_matrix, word_chunk;
+    std::vector<uint64_t> mask_off(M, ~0ull), word_off(M, ~0ull);  // (~0: a matrix of other kernels)
+    uint64_t val_total = 0, row_total = 0, inc_total = 0, mask_total = 0, word_total = 0;
     bool lists_needed = false;  // the path -> columns lists of the tile / global-memory kernels
-    // RPVG_HIP_BUILD_MASKS=1: matrices of up to kMaskMaxColumns columns through groupsBuildMaskKernel instead of the list kernels
-    // (0.84 against 1.05 ms per configs[2] batch standing alone, but 9.71 against 9.65 ms per batch in the two-lane bench: the
-    // list kernels wait, and the other lane's kernels run meanwhile; the mask kernel computes)
+    // Which kernel builds a matrix: up to kWordMaxColumns columns groupsBuildWordKernel, up to kMaskMaxColumns
+    // groupsBuildMaskKernel, the rest the list kernels.  RPVG_HIP_BUILD_MASKS=1: no word kernel, =0: the list kernels for
+    // everything (the three produce the identical values: switches for the tests and for A/B timing — 0.84 (masks) against 1.05 ms
+    // (lists) per configs[2] batch standing alone, but 9.71 against 9.65 ms per batch in round 4's two-lane bench: the list kernels
+    // wait, and the other lane's kernels run meanwhile; with batches in flight the GPU has no such gaps).
     const char * masks_env = std::getenv("RPVG_HIP_BUILD_MASKS");
     const bool build_masks = masks_env ? std::atoi(masks_env) != 0 : true;
+    const bool build_words = masks_env ? std::atoi(masks_env) >= 2 : true;
     for (uint32_t m = 0; m < M; ++m) {
         const uint32_t k = spec->cluster[m];
         if (k >= batch->num_clusters) {
@@ -804,6 +952,15 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
         row_total += R;
         inc_total += N + 1;
         const uint64_t mask_words = (N + 63) / 64;
+        if (build_words && cols[m] <= kWordMaxColumns) {
+            word_off[m] = word_total;
+            word_total += N;
+            for (uint64_t c = 0; c * kMaskRows < R; ++c) {
+                word_matrix.push_back(m);
+                word_chunk.push_back(static_cast<uint32_t>(c));
+            }
+            continue;
+        }
         if (build_masks && cols[m] <= kMaskMaxColumns && mask_words <= kMaskMaxWords) {
             mask_off[m] = mask_total;
             mask_total += cols[m] * mask_words;
@@ -852,7 +1009,8 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
     struct BuildTemporaries {
         DeviceBuffer<uint64_t> inc_off, path_grp_off, group_off, group_path_off, num_paths;
         DeviceBuffer<uint32_t> path_grp, item_matrix, item_chunk, tile_matrix, tile_chunk, group_path, degree, cursor, cluster, mask_matrix, mask_chunk;
-        DeviceBuffer<uint64_t> mask_off, masks, first_path;
+        DeviceBuffer<uint64_t> mask_off, masks, first_path, word_off, path_words;
+        DeviceBuffer<uint32_t> word_matrix, word_chunk;
         DeviceBuffer<uint32_t> column_counts;
         DeviceBuffer<unsigned char> scan_tmp;
     };
@@ -895,6 +1053,12 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
         pack.add(tmp->mask_matrix, mask_matrix.data(), mask_matrix.size());
         pack.add(tmp->mask_chunk, mask_chunk.data(), mask_chunk.size());
         pack.add(tmp->mask_off, mask_off.data(), M);
+    }
+    if (!word_matrix.empty()) {
+        pack.add(tmp->word_matrix, word_matrix.data(), word_matrix.size());
+        pack.add(tmp->word_chunk, word_chunk.data(), word_chunk.size());
+        pack.add(tmp->word_off, word_off.data(), M);
+        pack.addZero(tmp->path_words, word_total);
     }
     std::vector<uint32_t> segment_off;
     if (collapse) {
@@ -965,21 +1129,15 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
                                                            g->mat_fast.ptr, g->mat_mid.ptr,
                                                            kMidMinRows);
         const uint32_t col_blocks = static_cast<uint32_t>((num_columns + 255) / 256);
-        if (!mask_matrix.empty()) {
-            columnMaskKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr, d_group_path.ptr,
-                                                                    d_num_paths.ptr, tmp->mask_off.ptr, tmp->masks.ptr, d_error.ptr);
-            MaskBuildArgs ma;
-            ma.num_items = static_cast<uint32_t>(mask_matrix.size());
-            ma.item_matrix = tmp->mask_matrix.ptr;
-            ma.item_chunk = tmp->mask_chunk.ptr;
+        MaskBuildArgs ma;
+        memset(&ma, 0, sizeof(ma));
+        {
             ma.mat_val_off = g->mat_val_off.ptr;
             ma.mat_row_off = g->mat_row_off.ptr;
             ma.mat_row0 = g->mat_row0.ptr;
             ma.mat_rows = g->mat_rows.ptr;
             ma.mat_cols = g->mat_cols.ptr;
             ma.num_paths = d_num_paths.ptr;
-            ma.mask_off = tmp->mask_off.ptr;
-            ma.masks = tmp->masks.ptr;
             ma.row_ent_off = batch->row_ent_off.ptr;
             ma.ent_path = batch->ent_path.ptr;
             ma.ent_prob = batch->ent_prob.ptr;
@@ -994,7 +1152,27 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
             ma.collapse_key = g->collapse_key.ptr;
             ma.collapse_row = g->collapse_row.ptr;
             ma.collapse_mask = g->collapse_mask.ptr;
+        }
+        if (!mask_matrix.empty()) {
+            columnMaskKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr, d_group_path.ptr,
+                                                                    d_num_paths.ptr, tmp->mask_off.ptr, tmp->masks.ptr, d_error.ptr);
+            ma.num_items = static_cast<uint32_t>(mask_matrix.size());
+            ma.item_matrix = tmp->mask_matrix.ptr;
+            ma.item_chunk = tmp->mask_chunk.ptr;
+            ma.mask_off = tmp->mask_off.ptr;
+            ma.masks = tmp->masks.ptr;
             groupsBuildMaskKernel<<<dim3((ma.num_items + 3) / 4), dim3(256), 0, st>>>(ma);
+        }
+        if (!word_matrix.empty()) {
+            pathColumnWordKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr, d_group_path.ptr,
+                                                                        d_num_paths.ptr, tmp->word_off.ptr,
+                                                                        reinterpret_cast<unsigned long long *>(tmp->path_words.ptr), d_error.ptr);
+            ma.num_items = static_cast<uint32_t>(word_matrix.size());
+            ma.item_matrix = tmp->word_matrix.ptr;
+            ma.item_chunk = tmp->word_chunk.ptr;
+            ma.mask_off = tmp->word_off.ptr;
+            ma.masks = tmp->path_words.ptr;
+            groupsBuildWordKernel<<<dim3((ma.num_items + 3) / 4), dim3(256), 0, st>>>(ma);
         }
         if (lists_needed) {
             incidenceCountKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr,

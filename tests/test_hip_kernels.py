@@ -674,12 +674,14 @@ def test_groups_with_a_path_outside_the_cluster_are_reported_by_the_first_consum
         dg.loglik([0], [[0]], 1.0)
 
 
-def test_groups_with_a_path_listed_twice_are_reported(hip_ctx):
-    """With the columns' paths as bit masks (RPVG_HIP_BUILD_MASKS=1: groupsBuildMaskKernel) a column is a set of paths."""
+@pytest.mark.parametrize("masks", ["2", "1"])
+def test_groups_with_a_path_listed_twice_are_reported(hip_ctx, masks):
+    """With the columns of a path as a word (the default: groupsBuildWordKernel) or the paths of a column as bit masks
+    (RPVG_HIP_BUILD_MASKS=1: groupsBuildMaskKernel) a column is a set of paths."""
     from rpvg_amd import hip
     clusters = small_cases.make_batch_clusters(952, n_clusters=2, with_empty=False)
     dev = hip_ctx.upload(ClusterBatch.from_clusters(clusters))
-    os.environ["RPVG_HIP_BUILD_MASKS"] = "1"
+    os.environ["RPVG_HIP_BUILD_MASKS"] = masks
     try:
         dg = hip_ctx.groups(dev, [0], [[[0], [1, 1]]], False)
         with pytest.raises(hip.EngineError, match="lists a path twice"):
@@ -690,10 +692,11 @@ def test_groups_with_a_path_listed_twice_are_reported(hip_ctx):
 
 @pytest.mark.parametrize("normalise", [True, False])
 def test_matrices_from_path_masks_equal_the_matrices_from_path_lists(hip_ctx, normalise):
-    """groupsBuildMaskKernel (RPVG_HIP_BUILD_MASKS=1: a column's paths as a bit mask, a wave per 64 rows, a lane per row) adds a
-    row's entries in the order groupsBuildTileKernel / groupsBuildKernel (the default) do: the same values to the bit —
-    seen through the log-likelihoods of every column and of pairs.  One word per column, two words (75 paths), more than 64
-    columns (two blocks), a cluster of one row."""
+    """groupsBuildWordKernel (the default up to 64 columns: a path's columns as one word, a wave per 64 rows, a lane per row, the
+    cells in registers) and groupsBuildMaskKernel (RPVG_HIP_BUILD_MASKS=1, and wider matrices: a column's paths as a bit mask)
+    add a row's entries in the order groupsBuildTileKernel / groupsBuildKernel (RPVG_HIP_BUILD_MASKS=0) do: the same values
+    to the bit — seen through the log-likelihoods of every column and of pairs.  One word per column, two words (75 paths),
+    more than 64 columns (two blocks), a cluster of one row, rows of more entries than the word kernel loads ahead."""
     rng = np.random.default_rng(961)
     clusters = small_cases.make_batch_clusters(962, n_clusters=8, with_empty=False)
     clusters.append(small_cases.make_cluster(rng, 3, [30, 25, 20], n_haps=100, n_reads=700))
@@ -709,6 +712,8 @@ def test_matrices_from_path_masks_equal_the_matrices_from_path_lists(hip_ctx, no
             g = [[p] for p in range(len(cl["paths"]))]
         groups.append(g)
     assert max(len(g) for g in groups) > 64 and max(len(cl["paths"]) for cl in clusters) > 64
+    entries = np.diff(batch.grp_idx_off.astype(np.int64)[batch.row_grp_off.astype(np.int64)])
+    assert entries.max() > 4 and sum(1 for g in groups if len(g) <= 64) >= 3
     mats = list(range(len(clusters)))
     requests_m, requests_c = [], []
     for m, g in enumerate(groups):
@@ -716,7 +721,7 @@ def test_matrices_from_path_masks_equal_the_matrices_from_path_lists(hip_ctx, no
             requests_m.append(m)
             requests_c.append([c, (c * 7 + 3) % len(g)])
     results = []
-    for masks in ("1", "0"):
+    for masks in ("2", "1", "0"):
         os.environ["RPVG_HIP_BUILD_MASKS"] = masks
         try:
             dg = hip_ctx.groups(dev, mats, groups, normalise)
@@ -726,7 +731,8 @@ def test_matrices_from_path_masks_equal_the_matrices_from_path_lists(hip_ctx, no
             os.environ.pop("RPVG_HIP_BUILD_MASKS", None)
         results.append((single, pairs))
     assert np.all(np.isfinite(results[0][0])) and np.all(np.isfinite(results[0][1]))
-    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    for other in results[1:]:
+        assert np.array_equal(results[0][0], other[0]) and np.array_equal(results[0][1], other[1])
 
 
 def test_upload_reports_the_first_row_that_breaks_an_invariant(hip_ctx):
