@@ -538,6 +538,25 @@ hipError_t createMainStream(hipStream_t * stream, const bool highest_priority) {
     return hipStreamCreateWithPriority(stream, hipStreamNonBlocking, greatest);
 }
 
+// The runtime maps its streams onto a pool of GPU_MAX_HW_QUEUES hardware queues per priority (least used first), and the
+// commands of streams that share a queue run one after the other.  With several batches in flight (the contexts of few side
+// streams: rpvg_hip_create_with_streams) that is where a batch's time went: the main stream — the chain of dependent kernels
+// from the matrices to the packed results — shared its queue with other contexts' side streams, whose EM kernels run for a
+// millisecond each.  A stream with a CU mask gets a hardware queue of its own, outside the pools; the mask here names every
+// CU.  5.7 -> 5.1-5.2 ms per configs[2] batch with four such contexts; the side or collapse streams as well: 14 and 7 ms —
+// beyond some twenty hardware queues in the process the device time-slices them (GPU_MAX_HW_QUEUES=10: 8 ms).
+// RPVG_HIP_POOLED_MAIN_QUEUE=1: the main stream from the pool, as in the contexts of rpvg_hip_create.
+bool ownQueueForMainStream(const bool uploader, const int side_streams) {
+    static const bool pooled = std::getenv("RPVG_HIP_POOLED_MAIN_QUEUE") != nullptr && std::atoi(std::getenv("RPVG_HIP_POOLED_MAIN_QUEUE")) != 0;
+    return !uploader && side_streams < rpvg_hip_ctx::kAuxStreams && !pooled;
+}
+
+hipError_t createOwnQueueStream(hipStream_t * stream) {
+    uint32_t every_cu[8];  // (256 CUs; bits past the device's last are ignored)
+    for (uint32_t & word : every_cu) word = 0xffffffffu;
+    return hipExtStreamCreateWithCUMask(stream, 8, every_cu);
+}
+
 int createContext(int device, bool uploader, int side_streams, rpvg_hip_ctx ** ctx_out);
 }  // namespace
 
@@ -570,7 +589,7 @@ int createContext(int device, const bool uploader, const int side_streams, rpvg_
     ctx->device = device;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->props, device)) != hipSuccess ||
-        (e = createMainStream(&ctx->stream, uploader)) != hipSuccess) {
+        (e = ownQueueForMainStream(uploader, side_streams) ? createOwnQueueStream(&ctx->stream) : createMainStream(&ctx->stream, uploader)) != hipSuccess) {
         setError("rpvg_hip_create: %s", hipGetErrorString(e));
         delete ctx;
         return RPVG_HIP_ERR_RUNTIME;

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <type_traits>
 
 using namespace rpvg_hip_detail;
 
@@ -612,6 +613,7 @@ __global__ __launch_bounds__(256) void groupsBuildWordKernel(const MaskBuildArgs
 
     uint64_t word[kWordHeld];
     double prob[kWordHeld];
+    bool tiny_entry = false;  // a non-zero entry below 2^-400 (or not a number): see the quotients below
 #pragma unroll
     for (int k = 0; k < kWordHeld; ++k) {
         word[k] = 0;   // (an entry past the row's last: no column)
@@ -619,6 +621,7 @@ __global__ __launch_bounds__(256) void groupsBuildWordKernel(const MaskBuildArgs
         if (static_cast<uint32_t>(k) < n) {
             word[k] = words[a.ent_path[e_begin + k]];
             prob[k] = a.ent_prob[e_begin + k];
+            tiny_entry |= !(prob[k] == 0.0 || prob[k] >= 0x1p-400);
         }
     }
     double cells[kWordMaxColumns];
@@ -634,6 +637,7 @@ __global__ __launch_bounds__(256) void groupsBuildWordKernel(const MaskBuildArgs
         if (k < n) {
             w = words[a.ent_path[e_begin + k]];
             v = a.ent_prob[e_begin + k];
+            tiny_entry |= !(v == 0.0 || v >= 0x1p-400);
         }
         addEntryToCells(cells, blocks, w, v);
     }
@@ -648,25 +652,58 @@ __global__ __launch_bounds__(256) void groupsBuildWordKernel(const MaskBuildArgs
             }
         }
     }
+    // The quotients cell / rowsum.  The division the compiler emits is eleven instructions a cell, six of them on the
+    // denominator alone: its reciprocal (v_rcp_f64, two Newton steps) — once per row here —, then quotient = cell x reciprocal,
+    // remainder = cell - rowsum x quotient, quotient + remainder x reciprocal: the hardware's own sequence, which differs from
+    // this one by the scaling of operands near the ends of the exponent range (v_div_scale / v_div_fmas) and the special cases
+    // of v_div_fixup.  Neither arises while the row sum lies in [2^-400, 2^400] and every non-zero cell is at least 2^-400 (a
+    // cell is a sum of the row's non-negative entries: at least its smallest non-zero one, at most the row sum): such waves —
+    // all of them, in practice — take the three instructions, the others the division.  0 / rowsum is 0 either way, and a row
+    // sum of 0 (all cells 0) gives not-a-number, hence 0, either way.
     const double keep = 1 - noise;
+    constexpr double kSmall = 0x1p-400, kLarge = 0x1p400;
+    const bool plain = __ballot(valid && a.normalise && (!(rowsum == 0.0 || (rowsum >= kSmall && rowsum <= kLarge)) || tiny_entry)) == 0ull;
+    double reciprocal = 0.0;
+    if (plain) {
+        reciprocal = __builtin_amdgcn_rcp(rowsum);
+        reciprocal = fma(reciprocal, fma(-rowsum, reciprocal, 1.0), reciprocal);
+        reciprocal = fma(reciprocal, fma(-rowsum, reciprocal, 1.0), reciprocal);
+    }
     double key = collapseWeight(G) * noise, mx = 0.0;
     uint32_t pattern_lo = 0, pattern_hi = 0;
     double * out = M + i;
+    // eight columns at a time: without a branch between them their quotients overlap
+    auto columns = [&](const uint32_t b, auto all_eight, auto plain_division) {
 #pragma unroll
-    for (uint32_t c = 0; c < kWordMaxColumns; ++c) {
-        if (c < G) {
-            double value = cells[c];
-            if (a.normalise) {
-                value = (value / rowsum) * keep;
-                if (value != value) value = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
-                key = fma(collapseWeight(c), value, key);
-                if (value != 0.0) {
-                    if (c < 32) pattern_lo |= 1u << (c & 31u); else pattern_hi |= 1u << (c & 31u);
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t c = 8 * b + j;
+            if (decltype(all_eight)::value || c < G) {
+                double value = cells[c];
+                if (a.normalise) {
+                    if (decltype(plain_division)::value) {
+                        const double quotient = value * reciprocal;
+                        value = fma(fma(-rowsum, quotient, value), reciprocal, quotient);
+                    } else {
+                        value = value / rowsum;
+                    }
+                    value *= keep;
+                    if (value != value) value = 0.0;  // 0/0 rows -> 0 (src/path_estimator.cpp:162)
+                    key = fma(collapseWeight(c), value, key);
+                    if (c < 32) pattern_lo |= value != 0.0 ? 1u << (c & 31u) : 0u;
+                    else pattern_hi |= value != 0.0 ? 1u << (c & 31u) : 0u;
                 }
+                asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(value));  // (no NaN here: fmax() would quiet both operands first)
+                if (valid) out[static_cast<uint64_t>(j) * R] = value;
             }
-            mx = fmax(mx, value);
-            if (valid) *out = value;
-            out += R;
+        }
+        out += 8 * R;
+    };
+#pragma unroll
+    for (uint32_t b = 0; b < kWordMaxColumns / 8; ++b) {
+        if (8 * b + 8 <= G) {
+            if (plain) columns(b, std::true_type(), std::true_type()); else columns(b, std::true_type(), std::false_type());
+        } else if (8 * b < G) {
+            if (plain) columns(b, std::false_type(), std::true_type()); else columns(b, std::false_type(), std::false_type());
         }
     }
     if (valid) {
