@@ -1015,10 +1015,10 @@ __device__ __forceinline__ void emRegisterProblem(const EmLaunchArgs & args, con
     }
 }
 
+// workgroup `block` of the ones that serve args.bin
 template <int RPL, int COLS>
-__global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) {
-    extern __shared__ __attribute__((aligned(16))) double reg_lds[];
-    if (blockIdx.x >= args.queues->bin_count[args.bin]) return;  // more workgroups than the bin has problems
+__device__ __forceinline__ void emRegisterBin(const EmLaunchArgs & args, const uint32_t block, double * reg_lds) {
+    if (block >= args.queues->bin_count[args.bin]) return;  // more workgroups than the bin has problems
     // (RPVG_HIP_EM_COPIES=0 in the launch arguments: every problem with one copy, A/B and tests)
     for (uint32_t p = nextProblem<64>(args, nullptr); p != UINT32_MAX; p = nextProblem<64>(args, nullptr)) {
         if (RPL == 1 && COLS == 16 && args.register_copies) {
@@ -1033,12 +1033,58 @@ __global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs args) 
     }
 }
 
+// one launch per bin (RPVG_HIP_EM_REGISTER_LAUNCHES=5: A/B, and the per-bin device times of rpvg_hip_kernel_stats)
+template <int RPL, int COLS>
+__global__ __launch_bounds__(64) void emRegisterBinKernel(const EmLaunchArgs args) {
+    extern __shared__ __attribute__((aligned(16))) double reg_lds[];
+    emRegisterBin<RPL, COLS>(args, blockIdx.x, reg_lds);
+}
+
+// The register-resident bins in ONE launch: workgroup b serves bin kRegisterBins[b % variants] as that bin's workgroup
+// b / variants (the variants side by side from the first workgroup on).  A launch lasts as long as its slowest problem iterates
+// — a millisecond per bin on the configs[2] batch, on a few wavefronts —, and launches that share a stream, or, with batches
+// in flight, a hardware queue with other contexts' streams, run one after the other: five bins in five launches were 4.1 ms
+// of queue time per batch, in one launch they are 1.3.
+constexpr uint32_t kRegisterBins[5] = {6, 4, 5, 8, 9};  // <4,16> <1,16> <2,16> <1,32> <2,32>: rpvg_hip_em_kernel_name
+constexpr uint32_t kRegisterKernelIndex = 4;             // the launch's slot in rpvg_hip_kernel_stats::em_kernel
+
+__global__ __launch_bounds__(64) void emRegisterKernel(const EmLaunchArgs launch_args, const uint32_t variants) {
+    extern __shared__ __attribute__((aligned(16))) double reg_lds[];
+    EmLaunchArgs args = launch_args;
+    const uint32_t variant = blockIdx.x % variants, block = blockIdx.x / variants;
+    args.bin = kRegisterBins[variant];
+    switch (variant) {
+        case 0: emRegisterBin<4, 16>(args, block, reg_lds); break;
+        case 1: emRegisterBin<1, 16>(args, block, reg_lds); break;
+        case 2: emRegisterBin<2, 16>(args, block, reg_lds); break;
+        case 3: emRegisterBin<1, 32>(args, block, reg_lds); break;
+        default: emRegisterBin<2, 32>(args, block, reg_lds); break;
+    }
+}
+
 template <int RPL, int COLS>
 hipError_t launchEmRegister(const EmLaunchArgs & args, uint32_t grid, hipStream_t stream) {
     if (grid == 0) return hipSuccess;
     const size_t lds = (64 * RPL * COLS + 2) * sizeof(double);  // the staging tile
-    emRegisterKernel<RPL, COLS><<<dim3(grid), dim3(64), lds, stream>>>(args);
+    emRegisterBinKernel<RPL, COLS><<<dim3(grid), dim3(64), lds, stream>>>(args);
     return hipGetLastError();
+}
+
+// grid_per_bin workgroups for each of the bins (three without problems of more than 16 columns, else five)
+hipError_t launchEmRegisterBins(const EmLaunchArgs & args, const uint32_t grid_per_bin, const bool with_32_columns, hipStream_t stream) {
+    if (grid_per_bin == 0) return hipSuccess;
+    const uint32_t variants = with_32_columns ? 5u : 3u;
+    const size_t lds = (64 * 4 * 16 + 2) * sizeof(double);  // the largest staging tile (4 x 16 = 2 x 32)
+    emRegisterKernel<<<dim3(grid_per_bin * variants), dim3(64), lds, stream>>>(args, variants);
+    return hipGetLastError();
+}
+
+bool oneRegisterLaunch() {
+    static const bool one = []() {
+        const char * env = std::getenv("RPVG_HIP_EM_REGISTER_LAUNCHES");
+        return !(env && std::atoi(env) == 5);
+    }();
+    return one;
 }
 
 
@@ -1510,6 +1556,40 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     // eight hardware queues — hardwareQueues(), context.hip — they get streams of their own; chains of launches that share
     // a stream run one after the other: balanced by the kernels' usual durations).  with_spans: every launch carries its
     // own HIP events on its own stream (rpvg_hip_kernel_stats::em_kernel).
+    // (the default) the register-resident bins in one launch, the others balanced over the side streams by their usual durations:
+    // with six side streams everybody has a stream of its own, with three (the contexts of the batch pipeline) the launch of the
+    // register bins (1.3 ms on the configs[2] batch) and <1024,true> (0.2) share one, <64,true> (0.9) and <256,true> (0.5)
+    // another, and <1024,false> (0.8) and the wide one have the third
+    auto launchVariantsOneRegisterLaunch = [&](auto & timed, int & bin_span) -> int {
+        const bool own_streams = ctx->aux_count >= rpvg_hip_ctx::kAuxStreams;
+        hipStream_t s_register = own_streams ? ctx->aux[3] : ctx->aux[0];
+        hipStream_t s_1024_resident = own_streams ? ctx->aux[4] : ctx->aux[0], s_64 = ctx->aux[1], s_256 = own_streams ? ctx->aux[5] : ctx->aux[1];
+        hipStream_t s_1024 = own_streams ? ctx->aux[0] : ctx->aux[2], s_wide = ctx->aux[2];
+        timed(static_cast<int>(kRegisterKernelIndex), s_register);
+        RPVG_HIP_CHECK(launchEmRegisterBins(args, grid(2), list.max_cols > 16, s_register));
+        ctx->spanEnd(bin_span);
+        timed(2, st);
+        RPVG_HIP_CHECK((launchEm<256, false>(args, grid(1), std::min(streamed_lds_256, kEmLdsLimit), st)));
+        ctx->spanEnd(bin_span);
+        timed(3, s_1024);
+        RPVG_HIP_CHECK((launchEm<1024, false>(args, grid(1), std::min(streamed_lds_1024, kEmLdsLimit), s_1024)));
+        ctx->spanEnd(bin_span);
+        timed(0, s_64);
+        RPVG_HIP_CHECK((launchEm<64, true>(args, grid(2), 8 * 1024, s_64)));
+        ctx->spanEnd(bin_span);
+        timed(1, s_256);
+        RPVG_HIP_CHECK((launchEm<256, true>(args, grid(2), 40 * 1024, s_256)));
+        ctx->spanEnd(bin_span);
+        timed(7, s_1024_resident);
+        RPVG_HIP_CHECK((launchEm<1024, true>(args, grid(1), 152 * 1024, s_1024_resident)));
+        ctx->spanEnd(bin_span);
+        if (wide_possible) {
+            timed(10, s_wide);
+            RPVG_HIP_CHECK((launchEm<1024, false, true>(args, grid(1), sizeof(double) * (1024 / 64 + 2), s_wide)));
+            ctx->spanEnd(bin_span);
+        }
+        return RPVG_HIP_OK;
+    };
     auto launchVariants = [&](const bool with_spans) -> int {
         RPVG_HIP_CHECK(ctx->forkAux());
         int bin_span = -1;
@@ -1518,6 +1598,7 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
             bin_span = with_spans ? ctx->spanBegin(FAM_EM_KERNEL, on, b) : -1;
             return on;
         };
+        if (oneRegisterLaunch()) return launchVariantsOneRegisterLaunch(timed, bin_span);
         RPVG_HIP_CHECK((launchEmRegister<4, 16>(args, grid(2), timed(6, s_reg4))));
         ctx->spanEnd(bin_span);
         RPVG_HIP_CHECK((launchEmRegister<1, 16>(args, grid(2), timed(4, s_reg1))));
@@ -1676,17 +1757,29 @@ void accountEmSolve(rpvg_hip_ctx * ctx, const uint32_t P, const uint64_t * col_o
         bin_problems[b] += 1;
         bin_slowest[b] = std::max(bin_slowest[b], iterations[p]);
     }
+    // (the register-resident bins of one launch are one kernel of the statistics: their problems together, the slowest of all)
+    double slot_bytes[kEmBins] = {};
+    uint64_t slot_its[kEmBins] = {}, slot_problems[kEmBins] = {};
+    uint32_t slot_slowest[kEmBins] = {};
     for (int b = 0; b < kEmBins; ++b) {
-        if (!bin_problems[b]) continue;
+        const bool register_bin = b == 4 || b == 5 || b == 6 || b == 8 || b == 9;
+        const int slot = register_bin && oneRegisterLaunch() ? static_cast<int>(kRegisterKernelIndex) : b;
+        slot_bytes[slot] += bin_bytes[b];
+        slot_its[slot] += bin_its[b];
+        slot_problems[slot] += bin_problems[b];
+        slot_slowest[slot] = std::max(slot_slowest[slot], bin_slowest[b]);
+    }
+    for (int b = 0; b < kEmBins; ++b) {
+        if (!slot_problems[b]) continue;
         rpvg_hip_em_kernel_stats & ks = ctx->stats.em_kernel[b];
         ks.launches += 1;
-        ks.problems += bin_problems[b];
-        ks.iterations += bin_its[b];
-        ks.max_iterations += bin_slowest[b];
-        ks.alg_bytes += bin_bytes[b];
+        ks.problems += slot_problems[b];
+        ks.iterations += slot_its[b];
+        ks.max_iterations += slot_slowest[b];
+        ks.alg_bytes += slot_bytes[b];
         ctx->stats.em_sparse_launches += 1;
-        ctx->stats.em_sparse_alg_bytes += bin_bytes[b];
-        ctx->stats.em_iterations_total += bin_its[b];
+        ctx->stats.em_sparse_alg_bytes += slot_bytes[b];
+        ctx->stats.em_iterations_total += slot_its[b];
     }
 }
 
@@ -1860,10 +1953,13 @@ int prepareHostProblems(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const 
 
 extern "C" const char * rpvg_hip_em_kernel_name(int index) {
     // (the size bins of rpvg_hip_em_solve, in bin order)
+    // (emRegisterKernel: the five register-resident bins — <1,16> <2,16> <4,16> <1,32> <2,32> — in one launch, under the first
+    // one's index; with RPVG_HIP_EM_REGISTER_LAUNCHES=5 every bin has its own launch of emRegisterBinKernel and its own index)
     static const char * const names[RPVG_HIP_EM_KERNELS] = {
         "emSparseKernel<64,true>", "emSparseKernel<256,true>", "emSparseKernel<256,false>", "emSparseKernel<1024,false>",
-        "emRegisterKernel<1,16>", "emRegisterKernel<2,16>", "emRegisterKernel<4,16>", "emSparseKernel<1024,true>",
-        "emRegisterKernel<1,32>", "emRegisterKernel<2,32>", "emSparseKernel<1024,false,WIDE>", "emGridAccumKernel"};
+        "emRegisterBinKernel<1,16>", "emRegisterBinKernel<2,16>", "emRegisterBinKernel<4,16>", "emSparseKernel<1024,true>",
+        "emRegisterBinKernel<1,32>", "emRegisterBinKernel<2,32>", "emSparseKernel<1024,false,WIDE>", "emGridAccumKernel"};
+    if (index == static_cast<int>(kRegisterKernelIndex) && oneRegisterLaunch()) return "emRegisterKernel";
     return (index >= 0 && index < RPVG_HIP_EM_KERNELS) ? names[index] : nullptr;
 }
 
