@@ -638,9 +638,7 @@ def host_bound_line(args, eng_mod, batch, params, local_rank, ranks=8, steps=40)
     share = max(1, int(quota // ranks))
     allowed = sorted(os.sched_getaffinity(0))
     mine = set(allowed[:share])
-    row_grp_off32, grp_idx_off32 = batch.offsets32()
-    arrays = [batch.cluster_row_off, batch.cluster_path_off, batch.row_count, batch.row_noise, row_grp_off32, batch.grp_prob,
-              grp_idx_off32, batch.path_idx, batch.path_group_id, batch.path_source_off, batch.source_id]
+    arrays = copied_arrays(batch)
     for a in arrays:
         hip.host_register(a)
     os.sched_setaffinity(0, mine)  # (threads started from here on inherit it: the pipeline's uploader and estimator threads)
@@ -668,6 +666,14 @@ def host_bound_line(args, eng_mod, batch, params, local_rank, ranks=8, steps=40)
                      "host side alone allows a rank of an 8-rank node; efficiency_bound = unconfined ms_per_step / this")
 
 
+def copied_arrays(batch):
+    """The host arrays of a batch that its copy to the GPU reads (to be page-locked): the two long offset arrays as counts of one
+    byte where they fit, else in 32 bits (include/rpvg_batch.h: what a caller that flattens rows for the GPU writes)."""
+    offsets = batch.counts8() or batch.offsets32()
+    return [batch.cluster_row_off, batch.cluster_path_off, batch.row_count, batch.row_noise, offsets[0], batch.grp_prob,
+            offsets[1], batch.path_idx, batch.path_group_id, batch.path_source_off, batch.source_id]
+
+
 def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
     """K batches through BatchPipeline: submit() K times, wait().  The host arrays are page-locked; every batch is validated,
     copied and expanded on the device inside the clock (and its haplotype columns formed), several batches are in flight, the
@@ -675,10 +681,7 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
     when it stops: ramp-up and drain are inside."""
     import resource
     from rpvg_amd import hip
-    # (the two long offset arrays in their 32-bit form, include/rpvg_batch.h: what a caller that flattens rows for the GPU writes)
-    row_grp_off32, grp_idx_off32 = batch.offsets32()
-    arrays = [batch.cluster_row_off, batch.cluster_path_off, batch.row_count, batch.row_noise, row_grp_off32, batch.grp_prob,
-              grp_idx_off32, batch.path_idx, batch.path_group_id, batch.path_source_off, batch.source_id]
+    arrays = copied_arrays(batch)
     for a in arrays:
         hip.host_register(a)
     pipe = eng_mod.Pipeline(args.model, params, local_rank, workers=args.pipeline_workers)

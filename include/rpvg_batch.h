@@ -52,6 +52,17 @@ typedef struct rpvg_cluster_batch {
      * what paces a pipeline of batches (rpvg_amd/host/batch_pipeline.hpp): whoever flattens rows writes these. */
     const uint32_t * row_grp_off32;    /* [R+1] */
     const uint32_t * grp_idx_off32;    /* [G+1] */
+
+    /* ... or, for the copy to the GPU, as one byte each: the groups of every row and the paths of every group, for a batch
+     * none of whose rows has more than 255 groups and none of whose groups more than 255 paths.  When BOTH are given
+     * rpvg_hip_batch_upload copies them instead of the offset arrays (which it then does not read: they may be NULL) and sums them
+     * up on the device; num_groups / num_entries are their totals (G and NNZ), which the counts must add up to.  Another
+     * 40 MB less of the 230 MB of a configs[2] batch.  Whoever walks a batch on the host reads the offsets: a batch that is
+     * to be sharded, written out or handed to a host estimator keeps them (the accessors below do not look at the counts). */
+    const uint8_t * row_grp_count8;    /* [R] */
+    const uint8_t * grp_idx_count8;    /* [G] */
+    uint64_t num_groups;               /* G   (read with the counts only) */
+    uint64_t num_entries;              /* NNZ (read with the counts only) */
 } rpvg_cluster_batch;
 
 /* The two long offset arrays of a batch in whichever width its owner wrote them. */

@@ -20,6 +20,7 @@ import numpy as np
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
 f64p = C.POINTER(C.c_double)
+u8p = C.POINTER(C.c_uint8)
 
 
 class CClusterBatch(C.Structure):
@@ -40,6 +41,10 @@ class CClusterBatch(C.Structure):
         ("path_effective_length", f64p),
         ("row_grp_off32", u32p),
         ("grp_idx_off32", u32p),
+        ("row_grp_count8", u8p),
+        ("grp_idx_count8", u8p),
+        ("num_groups", C.c_uint64),
+        ("num_entries", C.c_uint64),
     ]
 
 
@@ -150,23 +155,37 @@ class ClusterBatch:
             self._offsets32 = cached
         return cached
 
+    def counts8(self):
+        """The groups of every row and the paths of every group as one byte each (rpvg_cluster_batch::row_grp_count8 /
+        grp_idx_count8), made once and kept; None when a count does not fit."""
+        cached = getattr(self, "_counts8", False)
+        if cached is False:
+            rows, groups = np.diff(self.row_grp_off.astype(np.int64)), np.diff(self.grp_idx_off.astype(np.int64))
+            fits = len(groups) > 0 and int(rows.max(initial=0)) <= 255 and int(groups.max(initial=0)) <= 255
+            cached = (np.ascontiguousarray(rows, dtype=np.uint8), np.ascontiguousarray(groups, dtype=np.uint8)) if fits else None
+            self._counts8 = cached
+        return cached
+
     def as_c(self, compact: bool = False) -> CClusterBatch:
-        """compact: the 32-bit forms of the two long offset arrays instead of the 64-bit ones (a sixth fewer bytes to copy)."""
+        """compact: the 32-bit forms of the two long offset arrays instead of the 64-bit ones (a sixth fewer bytes to copy), and
+        with them, where they fit, the counts of one byte that the copy to the GPU takes instead (a third fewer)."""
         # the returned struct borrows the arrays: keep `self` alive while it is in use
         if compact:
             row32, grp32 = self.offsets32()
+            counts = self.counts8()
+            tail = (_ptr(counts[0], u8p), _ptr(counts[1], u8p), len(self.grp_prob), len(self.path_idx)) if counts else (None, None, 0, 0)
             return CClusterBatch(
                 self.num_clusters, _ptr(self.cluster_row_off, u64p), _ptr(self.cluster_path_off, u64p),
                 _ptr(self.row_count, u32p), _ptr(self.row_noise, f64p), None,
                 _ptr(self.grp_prob, f64p), None, _ptr(self.path_idx, u32p),
                 _ptr(self.path_group_id, u32p), _ptr(self.path_source_count, u32p), _ptr(self.path_source_off, u64p),
-                _ptr(self.source_id, u32p), _ptr(self.path_effective_length, f64p), _ptr(row32, u32p), _ptr(grp32, u32p))
+                _ptr(self.source_id, u32p), _ptr(self.path_effective_length, f64p), _ptr(row32, u32p), _ptr(grp32, u32p), *tail)
         return CClusterBatch(
             self.num_clusters, _ptr(self.cluster_row_off, u64p), _ptr(self.cluster_path_off, u64p),
             _ptr(self.row_count, u32p), _ptr(self.row_noise, f64p), _ptr(self.row_grp_off, u64p),
             _ptr(self.grp_prob, f64p), _ptr(self.grp_idx_off, u64p), _ptr(self.path_idx, u32p),
             _ptr(self.path_group_id, u32p), _ptr(self.path_source_count, u32p), _ptr(self.path_source_off, u64p),
-            _ptr(self.source_id, u32p), _ptr(self.path_effective_length, f64p), None, None)
+            _ptr(self.source_id, u32p), _ptr(self.path_effective_length, f64p), None, None, None, None, 0, 0)
 
     # ---- construction from nested python data (tests, fixtures) -------------
     @staticmethod

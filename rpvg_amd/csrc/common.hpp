@@ -725,6 +725,7 @@ struct rpvg_hip_batch {
         rpvg_hip_detail::DeviceBuffer<uint32_t> d_row_count_u32, d_row_grp_off32, d_grp_idx_off32;
         rpvg_hip_detail::DeviceBuffer<uint64_t> d_row_grp_off, d_grp_idx_off;
         rpvg_hip_detail::DeviceBuffer<double> d_grp_prob;
+        rpvg_hip_detail::DeviceBuffer<uint8_t> d_row_grp_count8, d_grp_idx_count8;  // the count form (include/rpvg_batch.h): summed up into the 32-bit offsets behind the copy
         uint64_t num_groups = 0;
         rpvg_hip_detail::PathSourcesPending path_sources;
     };

@@ -3,6 +3,8 @@
 
 #include "common.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <sys/prctl.h>
 #include <time.h>
 
@@ -764,9 +766,47 @@ extern "C" int rpvg_hip_host_unregister(void * host) {
 
 namespace {
 
-// the two long offset arrays of a host batch, in whichever width the caller wrote them (include/rpvg_batch.h)
-inline uint64_t rowGroupOffset(const rpvg_cluster_batch * hb, const uint64_t r) { return hb->row_grp_off32 ? hb->row_grp_off32[r] : hb->row_grp_off[r]; }
-inline uint64_t groupEntryOffset(const rpvg_cluster_batch * hb, const uint64_t g) { return hb->grp_idx_off32 ? hb->grp_idx_off32[g] : hb->grp_idx_off[g]; }
+// the two long offset arrays of a host batch, in whichever width the caller wrote them (include/rpvg_batch.h); of a batch that
+// came with counts only, by adding them up (the wording of an error message: nothing else reads them here then)
+inline bool countForm(const rpvg_cluster_batch * hb) { return hb->row_grp_count8 != nullptr && hb->grp_idx_count8 != nullptr; }
+inline uint64_t rowGroupOffset(const rpvg_cluster_batch * hb, const uint64_t r) {
+    if (hb->row_grp_off32) return hb->row_grp_off32[r];
+    if (hb->row_grp_off) return hb->row_grp_off[r];
+    uint64_t sum = 0;
+    for (uint64_t i = 0; i < r; ++i) sum += hb->row_grp_count8[i];
+    return sum;
+}
+inline uint64_t groupEntryOffset(const rpvg_cluster_batch * hb, const uint64_t g) {
+    if (hb->grp_idx_off32) return hb->grp_idx_off32[g];
+    if (hb->grp_idx_off) return hb->grp_idx_off[g];
+    uint64_t sum = 0;
+    for (uint64_t i = 0; i < g; ++i) sum += hb->grp_idx_count8[i];
+    return sum;
+}
+
+// counts of one byte -> their running sums in 32 bits: offsets[i] = counts[0] + ... + counts[i - 1], i = 0 .. n
+struct CountAt {
+    const uint8_t * counts;
+    uint64_t n;
+    __host__ __device__ uint32_t operator()(const uint64_t i) const { return i < n ? counts[i] : 0u; }
+};
+
+hipError_t queueOffsetsFromCounts(hipStream_t stream, const uint8_t * counts, const uint64_t n, uint32_t * offsets, DeviceBuffer<unsigned char> & scratch) {
+    hipcub::CountingInputIterator<uint64_t> index(0);
+    hipcub::TransformInputIterator<uint32_t, CountAt, hipcub::CountingInputIterator<uint64_t> > values(index, CountAt{counts, n});
+    size_t bytes = 0;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, values, offsets, static_cast<int>(n + 1), stream);
+    if (e == hipSuccess) e = scratch.alloc(bytes);
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(scratch.ptr, bytes, values, offsets, static_cast<int>(n + 1), stream);
+    return e;
+}
+
+// the entry offset of every cluster's first row
+__global__ void clusterEntryOffsetsKernel(const uint32_t num_clusters, const uint64_t * __restrict__ cluster_row_off, const uint64_t * __restrict__ row_ent_off,
+                                          uint64_t * __restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k <= num_clusters) out[k] = row_ent_off[cluster_row_off[k]];
+}
 
 __global__ void widenOffsetsKernel(const uint64_t n, const uint32_t * __restrict__ narrow, uint64_t * __restrict__ wide) {
     const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
@@ -806,10 +846,13 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
     RPVG_REQUIRE(hb->cluster_row_off && hb->cluster_path_off, "rpvg_hip_batch_upload: cluster offsets are NULL");
     const uint64_t R = hb->cluster_row_off[K];
     const uint64_t P = hb->cluster_path_off[K];
-    RPVG_REQUIRE(R == 0 || (hb->row_count && hb->row_noise && (hb->row_grp_off || hb->row_grp_off32) && (hb->grp_idx_off || hb->grp_idx_off32)),
+    const bool counts = R > 0 && countForm(hb);  // one byte per row and group instead of the offsets (include/rpvg_batch.h)
+    RPVG_REQUIRE(R == 0 || (hb->row_count && hb->row_noise && (counts || ((hb->row_grp_off || hb->row_grp_off32) && (hb->grp_idx_off || hb->grp_idx_off32)))),
                  "rpvg_hip_batch_upload: row arrays are NULL");
-    const uint64_t G = R ? rowGroupOffset(hb, R) : 0;
-    const uint64_t NNZ = G ? groupEntryOffset(hb, G) : 0;
+    RPVG_REQUIRE(!counts || (hb->num_groups < 0xffffffffull && hb->num_entries < 0xffffffffull && hb->num_groups > 0),
+                 "rpvg_hip_batch_upload: counts of one byte come with their totals (num_groups, num_entries: below 2^32 - 1)");
+    const uint64_t G = counts ? hb->num_groups : (R ? rowGroupOffset(hb, R) : 0);
+    const uint64_t NNZ = counts ? hb->num_entries : (G ? groupEntryOffset(hb, G) : 0);
     RPVG_REQUIRE(G == 0 || hb->grp_prob, "rpvg_hip_batch_upload: grp_prob is NULL");
     RPVG_REQUIRE(NNZ == 0 || hb->path_idx, "rpvg_hip_batch_upload: path_idx is NULL");
 
@@ -837,7 +880,7 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
     b->h_cluster_row_off.assign(hb->cluster_row_off, hb->cluster_row_off + K + 1);
     b->h_cluster_path_off.assign(hb->cluster_path_off, hb->cluster_path_off + K + 1);
     b->h_cluster_ent_off.resize(K + 1);
-    for (uint32_t k = 0; k <= K; ++k) {
+    for (uint32_t k = 0; k <= K && !counts; ++k) {  // (with the counts: from the device, behind their sums — uploadFinish)
         const uint64_t r = hb->cluster_row_off[k];
         b->h_cluster_ent_off[k] = R ? groupEntryOffset(hb, rowGroupOffset(hb, r)) : 0;
     }
@@ -856,13 +899,20 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
     const uint64_t zero_off[1] = {0};
     // (the 32-bit forms travel as they are and are widened on the device, behind the copy)
     const bool narrow_offsets = R && G && hb->row_grp_off32 && hb->grp_idx_off32;
-    if (R && hb->row_grp_off32) {
+    if (counts) {
+        ok(up.d_row_grp_count8.upload(hb->row_grp_count8, R, ctx->stream));
+        ok(up.d_grp_idx_count8.upload(hb->grp_idx_count8, G, ctx->stream));
+        ok(up.d_row_grp_off32.alloc(R + 1));
+        ok(up.d_grp_idx_off32.alloc(G + 1));
+    } else if (R && hb->row_grp_off32) {
         ok(up.d_row_grp_off32.upload(hb->row_grp_off32, R + 1, ctx->stream));
         if (!narrow_offsets) ok(up.d_row_grp_off.alloc(R + 1));
     } else {
         ok(up.d_row_grp_off.upload(R ? hb->row_grp_off : zero_off, R + 1, ctx->stream));
     }
-    if (G && hb->grp_idx_off32) {
+    if (counts) {
+        // (both arrays above)
+    } else if (G && hb->grp_idx_off32) {
         ok(up.d_grp_idx_off32.upload(hb->grp_idx_off32, G + 1, ctx->stream));
         if (!narrow_offsets) ok(up.d_grp_idx_off.alloc(G + 1));
     } else {
@@ -876,7 +926,8 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
     // the path side, when the caller handed it in: PathInfo::group_id and source_ids (path_sources.hip)
     if (e == hipSuccess) ok(queuePathSourceCopies(ctx, b, hb, up.path_sources));
     ctx->spanEnd(span);
-    ctx->stats.h2d_bytes += static_cast<double>((K + 1) * 16 + R * 12 + (R + 1) * (hb->row_grp_off32 ? 4 : 8) + (G + 1) * (hb->grp_idx_off32 ? 4 : 8) + G * 8 + NNZ * 4);
+    ctx->stats.h2d_bytes += static_cast<double>((K + 1) * 16 + R * 12 + (counts ? R : (R + 1) * (hb->row_grp_off32 ? 4 : 8)) +
+                                                (counts ? G : (G + 1) * (hb->grp_idx_off32 ? 4 : 8)) + G * 8 + NNZ * 4);
     if (e != hipSuccess) {
         setError("rpvg_hip_batch_upload: %s", hipGetErrorString(e));
         (void) hipStreamSynchronize(ctx->stream);
@@ -913,6 +964,12 @@ static int uploadFinish(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_clust
     DeviceBuffer<unsigned long long> d_first_bad_row;
     if (e == hipSuccess) e = d_first_bad_row.alloc(1);
     if (e == hipSuccess) e = hipMemsetAsync(d_first_bad_row.ptr, 0xFF, sizeof(unsigned long long), ctx->stream);
+    DeviceBuffer<unsigned char> scan_scratch_rows, scan_scratch_groups;
+    const bool counts = up.d_row_grp_count8.ptr != nullptr;
+    if (e == hipSuccess && counts) {  // the offsets the kernels below read: the counts' running sums
+        e = queueOffsetsFromCounts(ctx->stream, up.d_row_grp_count8.ptr, R, up.d_row_grp_off32.ptr, scan_scratch_rows);
+        if (e == hipSuccess) e = queueOffsetsFromCounts(ctx->stream, up.d_grp_idx_count8.ptr, G, up.d_grp_idx_off32.ptr, scan_scratch_groups);
+    }
     if (e == hipSuccess && narrow) {
         if (G > 0) expandGroupsKernel<uint32_t><<<group_grid, dim3(threads), 0, ctx->stream>>>(G, NNZ, up.d_grp_idx_off32.ptr, up.d_grp_prob.ptr, b->ent_prob.ptr);
         rowMetaKernel<uint32_t, uint32_t><<<meta_grid, dim3(threads), 0, ctx->stream>>>(R, G, up.d_row_grp_off32.ptr, up.d_grp_idx_off32.ptr, up.d_row_count_u32.ptr,
@@ -934,17 +991,32 @@ static int uploadFinish(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_clust
     if (e == hipSuccess) e = d_cluster_total.alloc(K);
     if (e == hipSuccess) e = queueClusterTotals(ctx->stream, K, b->cluster_row_off.ptr, up.d_row_count_u32.ptr, d_cluster_total.ptr);
     if (e == hipSuccess) e = queuePathSourceKernels(ctx, b, up.path_sources);
+    DeviceBuffer<uint64_t> d_cluster_ent_off;
+    if (e == hipSuccess && counts) {
+        e = d_cluster_ent_off.alloc(K + 1);
+        if (e == hipSuccess) clusterEntryOffsetsKernel<<<dim3((K + 1 + 255) / 256), dim3(256), 0, ctx->stream>>>(K, b->cluster_row_off.ptr, b->row_ent_off.ptr, d_cluster_ent_off.ptr);
+    }
     ctx->spanEnd(bspan);
     ctx->stats.build_launches += 5;
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&first_bad_row, d_first_bad_row.ptr, sizeof(first_bad_row), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && K > 0) e = hipMemcpyAsync(b->h_cluster_total.data(), d_cluster_total.ptr, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && counts) e = hipMemcpyAsync(b->h_cluster_ent_off.data(), d_cluster_ent_off.ptr, (K + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+    uint32_t count_totals[2] = {0, 0};  // what the counts add up to (against the totals the caller named)
+    if (e == hipSuccess && counts) e = hipMemcpyAsync(&count_totals[0], up.d_row_grp_off32.ptr + R, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && counts) e = hipMemcpyAsync(&count_totals[1], up.d_grp_idx_off32.ptr + G, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = waitStream(ctx->stream);  // temporaries are freed on return
     if (e != hipSuccess) {
         setError("rpvg_hip_batch_upload: %s", hipGetErrorString(e));
         (void) hipStreamSynchronize(ctx->stream);
         delete b;
         return RPVG_HIP_ERR_RUNTIME;
+    }
+    if (counts && (count_totals[0] != G || count_totals[1] != NNZ)) {
+        delete b;
+        setError("rpvg_hip_batch_upload: the counts of the rows' groups and of the groups' paths do not add up to num_groups = %llu and num_entries = %llu",
+                 static_cast<unsigned long long>(G), static_cast<unsigned long long>(NNZ));
+        return RPVG_HIP_ERR_INVALID;
     }
     if (first_bad_row != ~0ull) {  // the message: the host's reading of the offending row's cluster
         delete b;

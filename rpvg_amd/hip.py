@@ -138,11 +138,11 @@ def device_count() -> int:
 
 
 class DeviceBatch:
-    def __init__(self, ctx: "Context", host: ClusterBatch):
+    def __init__(self, ctx: "Context", host: ClusterBatch, compact: bool = False):
         self.ctx = ctx
         self.host = host
         self.handle = C.c_void_p()
-        cb = host.as_c()
+        cb = host.as_c(compact)
         _check(lib().rpvg_hip_batch_upload(ctx.handle, C.byref(cb), C.byref(self.handle)), "rpvg_hip_batch_upload")
 
     def has_source_columns(self) -> bool:
@@ -409,8 +409,9 @@ class Context:
     def synchronize(self):
         _check(lib().rpvg_hip_synchronize(self.handle), "rpvg_hip_synchronize")
 
-    def upload(self, host: ClusterBatch) -> DeviceBatch:
-        return DeviceBatch(self, host)
+    def upload(self, host: ClusterBatch, compact: bool = False) -> DeviceBatch:
+        """compact: the forms of the two long offset arrays made for the copy (ClusterBatch.as_c)."""
+        return DeviceBatch(self, host, compact)
 
     def groups(self, batch: DeviceBatch, clusters, groups, normalise: bool, collapse_precision: float = 0.0) -> DeviceGroups:
         return DeviceGroups(self, batch, clusters, groups, normalise, collapse_precision)

@@ -233,7 +233,7 @@ void HipEngine::check(const int status, const char * what) {
     }
 }
 
-FlatClusterRows::FlatClusterRows() : cluster_row_off(1, 0), cluster_path_off(1, 0), path_source_off(1, 0), row_grp_off(1, 0), grp_idx_off(1, 0) {}
+FlatClusterRows::FlatClusterRows() : cluster_row_off(1, 0), cluster_path_off(1, 0), path_source_off(1, 0), row_grp_off(1, 0), grp_idx_off(1, 0), counts_fit(true) {}
 
 void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & cluster_probs, const std::vector<PathInfo> & paths) {
 
@@ -266,9 +266,13 @@ void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & clus
             grp_prob.emplace_back(path_probs.first);
             path_idx.insert(path_idx.end(), path_probs.second.begin(), path_probs.second.end());
             grp_idx_off.emplace_back(path_idx.size());
+            grp_idx_count.emplace_back(static_cast<uint8_t>(path_probs.second.size()));
+            counts_fit = counts_fit && path_probs.second.size() <= 255;
         }
 
         row_grp_off.emplace_back(grp_prob.size());
+        row_grp_count.emplace_back(static_cast<uint8_t>(probs.pathProbs().size()));
+        counts_fit = counts_fit && probs.pathProbs().size() <= 255;
     }
 
     cluster_row_off.emplace_back(row_count.size());
@@ -298,6 +302,10 @@ void FlatClusterRows::append(const FlatClusterRows & other) {
     appendOffsets(grp_idx_off, other.grp_idx_off);
     appendOffsets(path_source_off, other.path_source_off);
 
+    row_grp_count.insert(row_grp_count.end(), other.row_grp_count.begin(), other.row_grp_count.end());
+    grp_idx_count.insert(grp_idx_count.end(), other.grp_idx_count.begin(), other.grp_idx_count.end());
+    counts_fit = counts_fit && other.counts_fit;
+
     row_count.insert(row_count.end(), other.row_count.begin(), other.row_count.end());
     row_noise.insert(row_noise.end(), other.row_noise.begin(), other.row_noise.end());
     grp_prob.insert(grp_prob.end(), other.grp_prob.begin(), other.grp_prob.end());
@@ -322,6 +330,15 @@ rpvg_cluster_batch FlatClusterRows::view() const {
     batch.grp_idx_off = nullptr;
     batch.grp_idx_off32 = grp_idx_off.data();
     batch.path_idx = path_idx.data();
+
+    // what the copy to the GPU takes instead of the offsets while no row has more than 255 groups and no group more than 255 paths
+    if (counts_fit && !grp_prob.empty()) {
+
+        batch.row_grp_count8 = row_grp_count.data();
+        batch.grp_idx_count8 = grp_idx_count.data();
+        batch.num_groups = grp_prob.size();
+        batch.num_entries = path_idx.size();
+    }
 
     // the PathInfo fields the device reads, when the clusters were added with their paths; the rest of PathInfo stays on the
     // host side of the ABI (PathClusterEstimates::paths)

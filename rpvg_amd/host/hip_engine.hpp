@@ -111,9 +111,12 @@ class FlatClusterRows {
 
     private:
 
-        // (the two long offset arrays in 32 bits: rpvg_cluster_batch::row_grp_off32 / grp_idx_off32 — fewer bytes to copy)
+        // (the two long offset arrays in 32 bits: rpvg_cluster_batch::row_grp_off32 / grp_idx_off32 — and as counts of one byte,
+        // row_grp_count8 / grp_idx_count8, which is what the copy to the GPU takes while they fit: fewer bytes to copy)
         std::vector<uint64_t> cluster_row_off, cluster_path_off, path_source_off;
         std::vector<uint32_t> row_grp_off, grp_idx_off;
+        std::vector<uint8_t> row_grp_count, grp_idx_count;
+        bool counts_fit;
         std::vector<uint32_t> row_count, path_idx, path_group_id, source_id;
         std::vector<double> row_noise, grp_prob;
 };

@@ -272,7 +272,7 @@ std::unique_ptr<DeviceClusterBatch> constructReadPathProbabilities(const DeviceA
     rpvg_hip_batch * batch = nullptr;
     const int status = rpvg_hip_read_rows_to_batch(engine->ctx(), rows, &batch);
 
-    rpvg_cluster_batch rows_view;
+    rpvg_cluster_batch rows_view = {};
     const int view_status = (status == 0) ? rpvg_hip_read_rows_sizes(engine->ctx(), rows, &rows_view) : 0;
 
     std::unique_ptr<DeviceClusterBatch> cluster_batch;

@@ -735,6 +735,62 @@ def test_matrices_from_path_masks_equal_the_matrices_from_path_lists(hip_ctx, no
         assert np.array_equal(results[0][0], other[0]) and np.array_equal(results[0][1], other[1])
 
 
+def test_upload_from_counts_of_one_byte_equals_the_upload_from_offsets(hip_ctx):
+    """rpvg_cluster_batch::row_grp_count8 / grp_idx_count8 (include/rpvg_batch.h): the groups of every row and the paths of every
+    group as one byte each, summed up on the device behind the copy — the same batch as from the offsets (its matrices, through
+    their log-likelihoods, and an EM solve); a count that does not fit sends the offsets; totals that the counts do not add up to
+    are reported."""
+    import ctypes as C
+    from rpvg_amd import hip
+    rng = np.random.default_rng(981)
+    clusters = small_cases.make_batch_clusters(982, n_clusters=12, with_empty=True)
+    clusters.append(small_cases.make_cluster(rng, 2, [9, 7], n_haps=12, n_reads=400))
+    # (groups of several paths: paths that share a probability)
+    clusters.append(dict(paths=[dict(group_id=p // 3, source_count=1, source_ids=[p % 4], effective_length=100.0) for p in range(6)],
+                         rows=[(3, 0.05, [(0.125, [0, 4, 5]), (0.5, [1, 2])]), (1, 0.01, [(0.25, [3])]), (2, 0.5, [(0.0625, [0, 1, 2, 3, 4, 5])])]))
+    batch = ClusterBatch.from_clusters(clusters)
+    assert batch.counts8() is not None and int(np.diff(batch.grp_idx_off.astype(np.int64)).max()) > 1
+    cb = batch.as_c(True)
+    assert bool(cb.row_grp_count8) and cb.num_groups == len(batch.grp_prob) and cb.num_entries == len(batch.path_idx)
+    results = []
+    for compact in (True, False):
+        dev = hip_ctx.upload(batch, compact=compact)
+        try:
+            mats = [k for k, cl in enumerate(clusters) if cl["rows"]]
+            groups = [[[p] for p in range(len(clusters[k]["paths"]))] for k in mats]
+            dg = hip_ctx.groups(dev, mats, groups, False)
+            req_m = [m for m, g in enumerate(groups) for _ in g]
+            req_c = [[c] for g in groups for c in range(len(g))]
+            single = dg.loglik(req_m, req_c, 1.0)
+            abund, noise, total, iters = hip_ctx.em_solve(dev, mats, [list(range(len(clusters[k]["paths"]))) for k in mats])
+            results.append((single, np.concatenate(abund), noise, total, iters, dev.cluster_totals()))
+        finally:
+            dev.free()
+    for x, y in zip(*results):
+        assert np.array_equal(x, y)
+
+    # a group of 300 paths: the counts do not fit, the offsets travel
+    wide = small_cases.make_batch_clusters(983, n_clusters=2, with_empty=False)
+    n = 300
+    wide[0]["paths"] = [dict(group_id=0, source_count=1, source_ids=[p % 7], effective_length=100.0) for p in range(n)]
+    wide[0]["rows"] = [(1, 0.01, [(0.5, list(range(n)))])] + [(2, 0.02, [(0.25, [3, 5]), (0.5, [7])])]
+    wide_batch = ClusterBatch.from_clusters(wide)
+    assert wide_batch.counts8() is None and not bool(wide_batch.as_c(True).row_grp_count8)
+    hip_ctx.upload(wide_batch, compact=True).free()
+
+    # totals that are not the counts' sums
+    cb = batch.as_c(True)
+    cb.row_grp_off32 = None
+    cb.grp_idx_off32 = None
+    cb.num_entries = cb.num_entries - 1
+    handle = C.c_void_p()
+    assert hip.lib().rpvg_hip_batch_upload(hip_ctx.handle, C.byref(cb), C.byref(handle)) != 0
+    assert "do not add up" in hip.lib().rpvg_hip_last_error().decode()
+    cb.num_entries = cb.num_entries + 1
+    assert hip.lib().rpvg_hip_batch_upload(hip_ctx.handle, C.byref(cb), C.byref(handle)) == 0  # (without any offsets)
+    hip.lib().rpvg_hip_batch_free(hip_ctx.handle, handle)
+
+
 def test_upload_reports_the_first_row_that_breaks_an_invariant(hip_ctx):
     """The rows of a batch are checked on the device, behind their copy (validateRowsKernel); the host words the message."""
     from rpvg_amd import hip
