@@ -1422,10 +1422,17 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
     // above did not wait for it, the kernels do.  (Searching the matrices as built and once more the few the collapse
     // replayed was tried: its small kernels then wait for slots next to the search's large one, no gain.)
     const bool side_kernels = M > num_big;  // the sequential kernels on the aux streams
-    ok(groups->waitCollapse(st));
-    if (groups->collapse_done && !searchLaunchesEarly()) {  // (see searchGateEnter: the thread waits, not the stream's queue)
-        HostScope wait_scope("search: wait for the collapse of the matrices");
-        ok(waitEvent(groups->collapse_done));
+    // Matrices whose collapse holds its last stage back (rpvg_hip_groups::held_back_runs), all of them on the table path: the tile
+    // kernel reads them as built, at once — the twenty launches that find the collapse's runs (2 ms of a batch's chain of
+    // kernels, for some hundred rows of three million) run beside it —, and the stage that rewrites rows comes behind both and
+    // adjusts the tile kernel's sums for them.  3.8 against 4.6 ms per configs[2] batch in the pipeline.
+    const bool runs_behind_search = static_cast<bool>(groups->held_back_runs) && pair_tiles && num_big == M;
+    if (!runs_behind_search) {
+        ok(groups->waitCollapse(st));
+        if (groups->collapse_done && !searchLaunchesEarly()) {  // (see searchGateEnter: the thread waits, not the stream's queue)
+            HostScope wait_scope("search: wait for the collapse of the matrices");
+            ok(waitEvent(groups->collapse_done));
+        }
     }
     span = ctx->spanBegin(FAM_LOGLIK);
     searchGateEnter(ctx, st);
@@ -1499,6 +1506,20 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
 #endif
         } else {
             pairTableKernel<<<dim3(((tw.count + 7) / 8) * 8), dim3(256), 0, st>>>(tw);
+        }
+        if (runs_behind_search && e == hipSuccess) {
+            if (groups->collapse_done) {
+                HostScope wait_scope("search: wait for the runs of the matrices' collapse");
+                ok(searchLaunchesEarly() ? hipStreamWaitEvent(st, groups->collapse_done, 0) : waitEvent(groups->collapse_done));
+            }
+            rpvg_hip_groups::SearchSums sums;
+            sums.part_pair = d_part_pair.ptr;
+            sums.part_marginal = d_part_marg.ptr;
+            sums.pair_part_off = d_big_pair_part_off.ptr;
+            sums.col_part_off = d_big_col_part_off.ptr;
+            sums.chunk_rows = chunk_rows;
+            ok(groups->held_back_runs(st, &sums));
+            groups->held_back_runs = nullptr;
         }
 
         ResolveArgs ra;

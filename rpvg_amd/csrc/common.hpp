@@ -782,7 +782,27 @@ struct rpvg_hip_groups {
     // makes its stream wait for it (waitCollapse): what a consumer queues before its kernels — uploads, allocations —
     // does not.
     hipEvent_t built = nullptr, collapse_done = nullptr;
-    hipError_t waitCollapse(hipStream_t stream) const { return collapse_done ? hipStreamWaitEvent(stream, collapse_done, 0) : hipSuccess; }
+    // The last stage of the collapse — the only one that writes the matrices: the rows of a run take the values of its head —
+    // can be held back (matrices built from the batch's own columns, rpvg_hip_groups_build_from_sources): the diploid search then
+    // reads the matrices as built WHILE the stages in front find the runs, and the stage that is left adjusts the search's sums
+    // for the rows it rewrites (bounded_search.hip).  Every other reader gets it queued in front of its own kernels by
+    // waitCollapse().  collapse_done: the stages that were queued.
+    struct SearchSums {               // the per-chunk sums of the table path (pairTile2Kernel)
+        double * part_pair = nullptr;         // [pair_part_off[m] + chunk * G * G + a * G + b], a <= b
+        double * part_marginal = nullptr;     // [col_part_off[m] + chunk * G + a]
+        const uint64_t * pair_part_off = nullptr;
+        const uint64_t * col_part_off = nullptr;
+        uint32_t chunk_rows = 0;
+    };
+    mutable std::function<hipError_t(hipStream_t, const SearchSums *)> held_back_runs;  // empty: nothing held back (any more)
+    hipError_t waitCollapse(hipStream_t stream) const {
+        hipError_t e = collapse_done ? hipStreamWaitEvent(stream, collapse_done, 0) : hipSuccess;
+        if (e == hipSuccess && held_back_runs) {
+            e = held_back_runs(stream, nullptr);
+            held_back_runs = nullptr;
+        }
+        return e;
+    }
     ~rpvg_hip_groups() {
         if (collapse_done) {
             (void) hipEventSynchronize(collapse_done);  // the collapse kernels use the buffers below
@@ -986,7 +1006,8 @@ hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSo
 int finishPathSources(rpvg_hip_batch * b, PathSourcesPending & pending);
 
 // queues the replay of readCollapseProbabilityMatrix on the matrices of `groups` behind their build (row_collapse.hip)
-hipError_t queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups, uint64_t total_rows, double precision, hipStream_t stream);
+// hold_back_runs: everything but the last stage (rpvg_hip_groups::held_back_runs receives that one)
+hipError_t queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups, uint64_t total_rows, double precision, hipStream_t stream, bool hold_back_runs = false);
 }
 
 #endif

@@ -1247,7 +1247,11 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
                 ok(hipStreamWaitEvent(collapse_stream, g->built, 0));
             }
             const int collapse_span = (e == hipSuccess) ? ctx->spanBegin(FAM_COLLAPSE, collapse_stream) : -1;
-            if (e == hipSuccess) ok(queueRowCollapse(ctx, g, row_total, spec->collapse_precision, collapse_stream));
+            // (matrices from the batch's own columns are the diploid search's: it reads them while the collapse finds its runs,
+            // rpvg_hip_groups::held_back_runs; RPVG_HIP_COLLAPSE_BEFORE_SEARCH=1: the whole collapse first, as for everybody else)
+            const char * before_env = std::getenv("RPVG_HIP_COLLAPSE_BEFORE_SEARCH");  // (read per call: the tests take both ways)
+            const bool before_search = before_env != nullptr && std::atoi(before_env) != 0;
+            if (e == hipSuccess) ok(queueRowCollapse(ctx, g, row_total, spec->collapse_precision, collapse_stream, from_sources && !before_search));
             ctx->spanEnd(collapse_span);
             if (e == hipSuccess) ok(hipEventRecord(g->collapse_done, collapse_stream));
         }

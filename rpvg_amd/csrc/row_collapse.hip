@@ -591,6 +591,13 @@ struct ReplayArgs {
     uint32_t * info;
     bool debug;                  // RPVG_HIP_EM_COLLAPSE_DEBUG: slow workgroups of the runs kernel report where their time went
     bool no_lds_tables;          // RPVG_HIP_COLLAPSE_NO_LDS_TABLES (A/B): pair tables read from global memory as in round 3
+    // group matrices whose diploid search ran on the values as built (rpvg_hip_groups::held_back_runs): its sums, to be adjusted
+    // for every row the runs rewrite; part_pair == NULL: nobody has read the matrices yet
+    double * part_pair;
+    double * part_marginal;
+    const uint64_t * pair_part_off;
+    const uint64_t * col_part_off;
+    uint32_t chunk_rows;
 };
 
 // a1. every pair of rows of a small list, one thread each: order and closeness in one pass over the columns.  (A
@@ -905,6 +912,39 @@ __device__ __forceinline__ void finishRuns(const ReplayArgs<MatrixArrays> & a, c
     double * nz = a.g.row_noise + r0;
     double * rm = a.rowmax + r0;
     const uint32_t fast_mid_end = a.mat_mid[m];
+    if (a.part_pair) {
+        // The search has summed count * log(noise + (u_a + u_b) / 2) over the rows as built (pairTile2Kernel: per chunk of rows,
+        // pair of columns a <= b, and column).  A row that takes the values of its head now contributes the head's term with its
+        // own count: the difference goes to the sums of the row's chunk.  One row after the other, the workgroup over the pairs
+        // (every sum has one writer at a time: the result does not depend on the order threads run in); the rows are few.
+        const uint32_t G = mv.G;
+        double * pairs = a.part_pair + a.pair_part_off[m];
+        double * singles = a.part_marginal + a.col_part_off[m];
+        const double * cnt = a.g.row_count + r0;
+        for (uint64_t q = 0; q < n; ++q) {
+            const uint32_t h = head_of[q];
+            if (h == q) continue;  // (uniform)
+            const uint32_t dst = order[q], src = order[h];
+            const double c = cnt[dst], old_noise = nz[dst], new_noise = nz[src];
+            const uint64_t chunk = dst / a.chunk_rows;
+            double * chunk_pairs = pairs + chunk * G * G;
+            double * chunk_singles = singles + chunk * G;
+            for (uint64_t cell = threadIdx.x; cell < static_cast<uint64_t>(G) * G; cell += blockDim.x) {
+                const uint32_t x = static_cast<uint32_t>(cell / G), y = static_cast<uint32_t>(cell % G);
+                if (x > y) continue;
+                const double old_x = M[static_cast<uint64_t>(x) * R + dst], old_y = M[static_cast<uint64_t>(y) * R + dst];
+                const double new_x = M[static_cast<uint64_t>(x) * R + src], new_y = M[static_cast<uint64_t>(y) * R + src];
+                // (the search's own arithmetic: 2 x = (u_a + 2 noise) + u_b)
+                const double before = 0.5 * (fma(2.0, old_noise, old_x) + old_y), after = 0.5 * (fma(2.0, new_noise, new_x) + new_y);
+                if (before != after) chunk_pairs[cell] += c * (log(after) - log(before));
+                if (x == y) {
+                    const double single_before = old_x + old_noise, single_after = new_x + new_noise;
+                    if (single_before != single_after) chunk_singles[x] += c * (log(single_after) - log(single_before));
+                }
+            }
+            __syncthreads();  // (the next row's chunk may be this one's)
+        }
+    }
     uint32_t replaced = 0;
     for (uint64_t q = threadIdx.x >> 6; q < n; q += blockDim.x >> 6) {
         const uint32_t h = head_of[q];
@@ -1542,7 +1582,8 @@ struct SegmentSortPlan {
 template <typename Arrays>
 hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const uint64_t total_rows, const double precision, const uint64_t * key,
                                const uint32_t * row, const uint32_t * segment_begin, const uint32_t * segment_end, const bool segmented, DeviceBuffer<uint32_t> & info, double * rowmax, uint32_t * mat_fast,
-                               uint32_t * mat_mid, CollapseTemporaries * tmp, hipStream_t st, const SegmentSortPlan * plan = nullptr, hipEvent_t sorted = nullptr) {
+                               uint32_t * mat_mid, CollapseTemporaries * tmp, hipStream_t st, const SegmentSortPlan * plan = nullptr, hipEvent_t sorted = nullptr,
+                               std::function<hipError_t(hipStream_t, const rpvg_hip_groups::SearchSums *)> * held_back_runs = nullptr) {
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     // zeroed words: the pair table's byte counter (8 bytes, first: aligned), matrix flags [M], replay list [M] + its
@@ -1732,7 +1773,27 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     collapseRankKernel<Arrays><<<dim3(staged_grid), dim3(256), 0, st>>>(r);
     collapseSortKernel<Arrays><<<dim3(std::min<uint32_t>(M, 32)), dim3(kSortThreads), 0, st>>>(r);
     collapseBetweenKernel<Arrays><<<dim3(2 * staged_grid), dim3(kBetweenThreads), 0, st>>>(r);
-    collapseRunsKernel<Arrays><<<dim3(staged_grid), dim3(256), 0, st>>>(r);
+    r.part_pair = nullptr;
+    r.part_marginal = nullptr;
+    r.pair_part_off = nullptr;
+    r.col_part_off = nullptr;
+    r.chunk_rows = 0;
+    if (held_back_runs) {
+        *held_back_runs = [r](hipStream_t on, const rpvg_hip_groups::SearchSums * sums) {
+            ReplayArgs<Arrays> mine = r;
+            if (sums) {
+                mine.part_pair = sums->part_pair;
+                mine.part_marginal = sums->part_marginal;
+                mine.pair_part_off = sums->pair_part_off;
+                mine.col_part_off = sums->col_part_off;
+                mine.chunk_rows = sums->chunk_rows;
+            }
+            collapseRunsKernel<Arrays><<<dim3(staged_grid), dim3(256), 0, on>>>(mine);
+            return hipGetLastError();
+        };
+    } else {
+        collapseRunsKernel<Arrays><<<dim3(staged_grid), dim3(256), 0, st>>>(r);
+    }
     ok(hipGetLastError());
     return e;
 }
@@ -1822,7 +1883,7 @@ static bool librarySortFor(const char * what) {
 
 // Queues the collapse of the matrices of `g` on `st` behind their build (rpvg_hip_groups_build).
 hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups * g, const uint64_t total_rows, const double precision,
-                                             hipStream_t st) {
+                                             hipStream_t st, const bool hold_back_runs) {
     (void) ctx;
     const uint32_t M = g->num_matrices;
     if (M == 0 || total_rows == 0) return hipSuccess;
@@ -1845,7 +1906,8 @@ hipError_t rpvg_hip_detail::queueRowCollapse(rpvg_hip_ctx * ctx, rpvg_hip_groups
     const bool use_plan = !library_sort && plan.max_segment_rows <= kSortMaxSegmentRows;
     return queueCollapseStages(arrays, M, total_rows, precision, g->collapse_key.ptr, g->collapse_row.ptr, g->collapse_segment_off.ptr,
                                g->collapse_segment_off.ptr + 1, segmented && g->collapse_segment_off.ptr != nullptr, g->collapse_info,
-                               g->rowmax.ptr, g->mat_fast.ptr, g->mat_mid.ptr, tmp.get(), st, use_plan ? &plan : nullptr);
+                               g->rowmax.ptr, g->mat_fast.ptr, g->mat_mid.ptr, tmp.get(), st, use_plan ? &plan : nullptr, nullptr,
+                               hold_back_runs ? &g->held_back_runs : nullptr);
 }
 
 // readCollapseProbabilityMatrix on the rows of every EM problem of a solve (src/path_abundance_estimator.cpp:266,668): queued

@@ -122,6 +122,29 @@ def test_planted_close_rows_match_oracle(engine, seed, kw):
     assert not fuzz_parity.compare(got, ref)
 
 
+def test_runs_behind_the_search_equal_the_collapse_in_front_of_it(engine):
+    """Matrices built from the batch's own columns hold the last stage of their collapse back (rpvg_hip_groups::held_back_runs):
+    the tile kernel of the diploid search reads them as built while the collapse finds its runs, and the stage that rewrites
+    rows adjusts the search's sums for them (row_collapse.hip, finishRuns).  RPVG_HIP_COLLAPSE_BEFORE_SEARCH=1: the whole
+    collapse first.  The same diplotypes, posteriors and abundances either way (the sums differ in their last bits), on the
+    clusters with planted near-equal rows — which the oracle pins (test_planted_close_rows_match_oracle)."""
+    clusters = collapse_cases.make_collapse_clusters(822, n_clusters=12, max_reads=200) + collapse_cases.make_collapse_clusters(4101, n_clusters=4, max_reads=150)
+    batch = ClusterBatch.from_clusters(clusters)
+    prepared = engine.prepare(batch)
+    behind, _ = engine.run("haplotype-transcripts", make_params(), prepared)
+    os.environ["RPVG_HIP_COLLAPSE_BEFORE_SEARCH"] = "1"
+    try:
+        in_front, _ = engine.run("haplotype-transcripts", make_params(), prepared)
+    finally:
+        os.environ.pop("RPVG_HIP_COLLAPSE_BEFORE_SEARCH", None)
+    for k, (b, f) in enumerate(zip(behind, in_front)):
+        bk, fk = b.keyed(), f.keyed()
+        assert set(bk) == set(fk), k
+        for key in fk:
+            assert small_cases.rel_close(bk[key][0], fk[key][0], rel=1e-9) and small_cases.rel_close(bk[key][1], fk[key][1], rel=1e-9), (k, key)
+        assert list(b.em_iters) == list(f.em_iters), k
+
+
 def test_collapsed_rows_reach_the_sequential_search(engine):
     """RPVG_HIP_PAIR_TILES=0: the sequential kernels wait for the collapse on its stream like the tile kernel does."""
     cl = collapse_cases.make_collapse_clusters(823, n_clusters=12, max_reads=200)
