@@ -598,6 +598,8 @@ struct ReplayArgs {
     const uint64_t * pair_part_off;
     const uint64_t * col_part_off;
     uint32_t chunk_rows;
+    uint32_t * rewritten_count;  // [M] rows of the matrix's list that take the values of a head (listRewrittenRows)
+    bool walk_only;              // collapseRunsKernel stops behind the runs (collapseAdjustSumsKernel and collapseRewriteKernel follow)
 };
 
 // a1. every pair of rows of a small list, one thread each: order and closeness in one pass over the columns.  (A
@@ -898,6 +900,121 @@ __global__ __launch_bounds__(kBetweenThreads) void collapseBetweenKernel(const R
     }
 }
 
+// The diploid search has summed count * log(noise + (u_a + u_b) / 2) over the rows AS BUILT (pairTile2Kernel: per chunk of rows,
+// pair of columns a <= b, and column; rpvg_hip_groups::held_back_runs).  A row that takes the values of its head contributes the
+// head's term with its own count: the difference, count * log(after / before), goes to the sums of the row's chunk.  Work item =
+// (matrix with a list, slice of its G x G table of cells): the rewritten rows are staged in LDS some at a time (old and new
+// values: the global loads of a batch of rows in flight together), a thread owns its cells throughout — every sum has one
+// writer and the order of its additions is the list's: the result does not depend on how threads run — and keeps a cell's
+// difference in a register while the rows stay in one chunk (most matrices have one).  The rows are few (some hundred per
+// configs[2] batch) but a matrix may hold most of them: on one workgroup, cell by cell from global memory with two logarithms
+// each, they were 1.5 ms behind the search.
+constexpr uint32_t kAdjustSlices = 16;
+
+__device__ void adjustSearchSums(const ReplayArgs<MatrixArrays> & a, const uint32_t m, const uint32_t slice) {
+    const uint64_t n = a.mat_list[m] & kListSizeMask;
+    const MatrixView mv = viewOf(m, a.g);
+    const uint64_t R = mv.R;
+    const uint64_t r0 = a.g.rowOffset(m);
+    const uint32_t * order = a.order + 2 * r0;
+    const uint32_t * head_of = a.head_of + r0;
+    const double * M = a.g.values + a.g.mat_val_off[m];
+    const double * nz = a.g.row_noise + r0;
+    const uint32_t G = mv.G;
+    constexpr uint32_t kStageDoubles = 4096;
+    constexpr uint32_t kStageRows = 32;
+    __shared__ double stage[kStageDoubles];                      // [row of the batch][old | new][column]
+    __shared__ double stage_noise[2 * kStageRows], stage_count[kStageRows];
+    __shared__ uint32_t stage_chunk[kStageRows];
+    const uint32_t rows_per_stage = G <= kStageDoubles / 2 ? min(kStageRows, kStageDoubles / (2 * G)) : 0u;
+    double * pairs = a.part_pair + a.pair_part_off[m];
+    double * singles = a.part_marginal + a.col_part_off[m];
+    const double * cnt = a.g.row_count + r0;
+    // count * log(after / before): after / before - 1 is tiny for rows within prob_precision of each other unless the values
+    // themselves are — the series then, the logarithm otherwise
+    auto difference = [](const double c, const double before, const double after) {
+        if (before == after) return 0.0;
+        const double x = (after - before) / before;
+        if (fabs(x) < 1e-4) return c * (x * (1.0 - x * (0.5 - x * (1.0 / 3.0 - 0.25 * x))));
+        return c * log1p(x);
+    };
+    // the list positions whose rows are rewritten, in list order (the walk of the runs listed them: runsOfMatrix)
+    const uint32_t * rewritten = a.pair_column + r0;
+    const uint32_t num_rewritten = a.rewritten_count[m];
+    (void) n;
+    for (uint32_t i0 = 0; rows_per_stage && i0 < num_rewritten; i0 += rows_per_stage) {
+        const uint32_t rows = min(rows_per_stage, num_rewritten - i0);
+        __syncthreads();  // (the batch before is done with the LDS)
+        if (threadIdx.x < rows) {
+            const uint64_t q = rewritten[i0 + threadIdx.x];
+            const uint32_t dst = order[q], src = order[head_of[q]];
+            stage_chunk[threadIdx.x] = dst / a.chunk_rows;
+            stage_noise[2 * threadIdx.x] = nz[dst];
+            stage_noise[2 * threadIdx.x + 1] = nz[src];
+            stage_count[threadIdx.x] = cnt[dst];
+        }
+        __syncthreads();
+        for (uint32_t idx = threadIdx.x; idx < rows * G; idx += blockDim.x) {
+            const uint32_t row = idx / G, c = idx % G;
+            const uint64_t q = rewritten[i0 + row];
+            stage[(2 * row) * G + c] = M[static_cast<uint64_t>(c) * R + order[q]];
+            stage[(2 * row + 1) * G + c] = M[static_cast<uint64_t>(c) * R + order[head_of[q]]];
+        }
+        __syncthreads();
+        for (uint64_t cell = static_cast<uint64_t>(slice) * blockDim.x + threadIdx.x; cell < static_cast<uint64_t>(G) * G; cell += static_cast<uint64_t>(kAdjustSlices) * blockDim.x) {
+            const uint32_t x = static_cast<uint32_t>(cell / G), y = static_cast<uint32_t>(cell % G);
+            if (x > y) continue;
+            double sum = 0.0, single_sum = 0.0;
+            uint32_t sum_chunk = kNoRow;
+            auto flush = [&]() {
+                if (sum_chunk == kNoRow) return;
+                if (sum != 0.0) pairs[static_cast<uint64_t>(sum_chunk) * G * G + cell] += sum;
+                if (x == y && single_sum != 0.0) singles[static_cast<uint64_t>(sum_chunk) * G + x] += single_sum;
+                sum = 0.0;
+                single_sum = 0.0;
+            };
+            for (uint32_t row = 0; row < rows; ++row) {
+                const uint32_t chunk = stage_chunk[row];
+                if (chunk != sum_chunk) {
+                    flush();
+                    sum_chunk = chunk;
+                }
+                const double * before_row = stage + (2 * row) * G, * after_row = before_row + G;
+                const double old_noise = stage_noise[2 * row], new_noise = stage_noise[2 * row + 1], c = stage_count[row];
+                // (the search's own arithmetic: 2 x = (u_a + 2 noise) + u_b)
+                sum += difference(c, 0.5 * (fma(2.0, old_noise, before_row[x]) + before_row[y]), 0.5 * (fma(2.0, new_noise, after_row[x]) + after_row[y]));
+                if (x == y) single_sum += difference(c, before_row[x] + old_noise, after_row[x] + new_noise);
+            }
+            flush();
+        }
+    }
+}
+
+// the list positions of matrix m whose rows take the values of their head, in list order, into the scratch of a stage that is
+// done (pair_column), and their number
+__device__ void listRewrittenRows(const ReplayArgs<MatrixArrays> & a, const uint32_t m, const uint64_t n, const uint32_t * head_of) {
+    __shared__ uint32_t rewritten_total, wave_rewritten[4];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t * rewritten = a.pair_column + a.g.rowOffset(m);
+    if (threadIdx.x == 0) rewritten_total = 0;
+    __syncthreads();
+    for (uint64_t q0 = 0; q0 < n; q0 += blockDim.x) {
+        const uint64_t q = q0 + threadIdx.x;
+        const bool mine = q < n && head_of[q] != q;
+        const unsigned long long ballot = __ballot(mine);
+        if (lane == 0) wave_rewritten[threadIdx.x >> 6] = __popcll(ballot);
+        __syncthreads();
+        uint32_t at = rewritten_total + __popcll(ballot & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) at += wave_rewritten[w];
+        if (mine) rewritten[at] = static_cast<uint32_t>(q);
+        __syncthreads();
+        if (threadIdx.x == 0) rewritten_total += wave_rewritten[0] + wave_rewritten[1] + wave_rewritten[2] + wave_rewritten[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.rewritten_count[m] = rewritten_total;
+}
+__device__ void listRewrittenRows(const ReplayArgs<CsrArrays> &, const uint32_t, const uint64_t, const uint32_t *) {}
+
 // What a run does to its rows.  Group matrices: the rows of a run take the values of its head — the consumers are sums over
 // rows of count * log(noise + columns), so "merged into the head" is "takes the values of the head" with the row's own
 // count; a wave per row, its lanes over the columns.
@@ -912,39 +1029,6 @@ __device__ __forceinline__ void finishRuns(const ReplayArgs<MatrixArrays> & a, c
     double * nz = a.g.row_noise + r0;
     double * rm = a.rowmax + r0;
     const uint32_t fast_mid_end = a.mat_mid[m];
-    if (a.part_pair) {
-        // The search has summed count * log(noise + (u_a + u_b) / 2) over the rows as built (pairTile2Kernel: per chunk of rows,
-        // pair of columns a <= b, and column).  A row that takes the values of its head now contributes the head's term with its
-        // own count: the difference goes to the sums of the row's chunk.  One row after the other, the workgroup over the pairs
-        // (every sum has one writer at a time: the result does not depend on the order threads run in); the rows are few.
-        const uint32_t G = mv.G;
-        double * pairs = a.part_pair + a.pair_part_off[m];
-        double * singles = a.part_marginal + a.col_part_off[m];
-        const double * cnt = a.g.row_count + r0;
-        for (uint64_t q = 0; q < n; ++q) {
-            const uint32_t h = head_of[q];
-            if (h == q) continue;  // (uniform)
-            const uint32_t dst = order[q], src = order[h];
-            const double c = cnt[dst], old_noise = nz[dst], new_noise = nz[src];
-            const uint64_t chunk = dst / a.chunk_rows;
-            double * chunk_pairs = pairs + chunk * G * G;
-            double * chunk_singles = singles + chunk * G;
-            for (uint64_t cell = threadIdx.x; cell < static_cast<uint64_t>(G) * G; cell += blockDim.x) {
-                const uint32_t x = static_cast<uint32_t>(cell / G), y = static_cast<uint32_t>(cell % G);
-                if (x > y) continue;
-                const double old_x = M[static_cast<uint64_t>(x) * R + dst], old_y = M[static_cast<uint64_t>(y) * R + dst];
-                const double new_x = M[static_cast<uint64_t>(x) * R + src], new_y = M[static_cast<uint64_t>(y) * R + src];
-                // (the search's own arithmetic: 2 x = (u_a + 2 noise) + u_b)
-                const double before = 0.5 * (fma(2.0, old_noise, old_x) + old_y), after = 0.5 * (fma(2.0, new_noise, new_x) + new_y);
-                if (before != after) chunk_pairs[cell] += c * (log(after) - log(before));
-                if (x == y) {
-                    const double single_before = old_x + old_noise, single_after = new_x + new_noise;
-                    if (single_before != single_after) chunk_singles[x] += c * (log(single_after) - log(single_before));
-                }
-            }
-            __syncthreads();  // (the next row's chunk may be this one's)
-        }
-    }
     uint32_t replaced = 0;
     for (uint64_t q = threadIdx.x >> 6; q < n; q += blockDim.x >> 6) {
         const uint32_t h = head_of[q];
@@ -1098,7 +1182,8 @@ __device__ void runsOfMatrix(const ReplayArgs<Arrays> & a, const uint32_t m) {
         __syncthreads();
         for (uint32_t p = threadIdx.x; p < nn; p += blockDim.x) head_of[p] = lds_head[p];
         __syncthreads();
-        finishRuns(a, m, n, order, head_of, &demote, (encoded & kWholeMatrixBit) != 0);
+        if (a.walk_only) listRewrittenRows(a, m, n, head_of);
+        else finishRuns(a, m, n, order, head_of, &demote, (encoded & kWholeMatrixBit) != 0);
         return;
     }
     for (uint64_t p = threadIdx.x; p < n; p += blockDim.x) {
@@ -1148,7 +1233,8 @@ __device__ void runsOfMatrix(const ReplayArgs<Arrays> & a, const uint32_t m) {
         __syncthreads();
     }
     const long long clock_walked = wall_clock64();
-    finishRuns(a, m, n, order, head_of, &demote, (encoded & kWholeMatrixBit) != 0);
+    if (a.walk_only) listRewrittenRows(a, m, n, head_of);
+    else finishRuns(a, m, n, order, head_of, &demote, (encoded & kWholeMatrixBit) != 0);
     if (a.debug && threadIdx.x == 0 && wall_clock64() - clock_begin > 2000) {
         printf("[runs] matrix %u rows %llu cols %u list %llu tabled %d: walk %lld finish %lld (10 ns)\n", m, static_cast<unsigned long long>(mv.R), mv.G,
                static_cast<unsigned long long>(n), tabled ? 1 : 0, clock_walked - clock_begin, wall_clock64() - clock_walked);
@@ -1242,6 +1328,31 @@ template <typename Arrays>
 __global__ __launch_bounds__(256) void collapseRunsKernel(const ReplayArgs<Arrays> a) {
     const uint32_t num_items = a.replay_list[a.num_matrices];
     for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) runsOfMatrix(a, a.replay_list[item]);
+}
+
+// behind a walk-only collapseRunsKernel: the search's sums ((matrix with a list, slice of its cells) per work item), ...
+__global__ __launch_bounds__(256) void collapseAdjustSumsKernel(const ReplayArgs<MatrixArrays> a) {
+    const uint32_t num_items = a.replay_list[a.num_matrices] * kAdjustSlices;
+    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
+        const uint32_t m = a.replay_list[item / kAdjustSlices];
+        if (a.rewritten_count[m] == 0) continue;  // (uniform)
+        __syncthreads();
+        adjustSearchSums(a, m, item % kAdjustSlices);
+    }
+}
+
+// ... and the values of the heads over their runs
+__global__ __launch_bounds__(256) void collapseRewriteKernel(const ReplayArgs<MatrixArrays> a) {
+    __shared__ uint32_t demote;
+    const uint32_t num_items = a.replay_list[a.num_matrices];
+    for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
+        const uint32_t m = a.replay_list[item];
+        const uint32_t encoded = a.mat_list[m];
+        __syncthreads();
+        if (threadIdx.x == 0) demote = 0;
+        __syncthreads();
+        finishRuns(a, m, encoded & kListSizeMask, a.order + 2 * a.g.rowOffset(m), a.head_of + a.g.rowOffset(m), &demote, (encoded & kWholeMatrixBit) != 0);
+    }
 }
 
 }  // namespace
@@ -1548,7 +1659,16 @@ __global__ __launch_bounds__(256) void collapseUnusedSlotsKernel(const SegmentSo
 
 namespace {
 
+inline void launchAdjustAndRewrite(const ReplayArgs<MatrixArrays> & r, const uint32_t grid, hipStream_t on) {
+    collapseAdjustSumsKernel<<<dim3(grid * 4), dim3(256), 0, on>>>(r);
+    ReplayArgs<MatrixArrays> rewrite = r;
+    rewrite.walk_only = false;
+    collapseRewriteKernel<<<dim3(grid), dim3(256), 0, on>>>(rewrite);
+}
+inline void launchAdjustAndRewrite(const ReplayArgs<CsrArrays> &, const uint32_t, hipStream_t) {}
+
 struct CollapseTemporaries {
+    DeviceBuffer<uint32_t> rewritten_count;
     DeviceBuffer<uint64_t> key_out, pair_pattern;
     DeviceBuffer<uint32_t> row_out, order, head, pair_column, marked_list, pairs, between_items, row_items, list_index;
     DeviceBuffer<uint32_t> stretch;  // stretch starts by position, their running maximum, stretch ends, positions by row: total_rows each
@@ -1778,17 +1898,25 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     r.pair_part_off = nullptr;
     r.col_part_off = nullptr;
     r.chunk_rows = 0;
+    r.rewritten_count = nullptr;
+    r.walk_only = false;
     if (held_back_runs) {
+        ok(tmp->rewritten_count.alloc(M));
+        r.rewritten_count = tmp->rewritten_count.ptr;
         *held_back_runs = [r](hipStream_t on, const rpvg_hip_groups::SearchSums * sums) {
             ReplayArgs<Arrays> mine = r;
-            if (sums) {
+            if (sums) {  // the search has read the matrices as built: the runs, its sums, then the rows
                 mine.part_pair = sums->part_pair;
                 mine.part_marginal = sums->part_marginal;
                 mine.pair_part_off = sums->pair_part_off;
                 mine.col_part_off = sums->col_part_off;
                 mine.chunk_rows = sums->chunk_rows;
+                mine.walk_only = true;
+                collapseRunsKernel<Arrays><<<dim3(staged_grid), dim3(256), 0, on>>>(mine);
+                launchAdjustAndRewrite(mine, staged_grid, on);
+            } else {
+                collapseRunsKernel<Arrays><<<dim3(staged_grid), dim3(256), 0, on>>>(mine);
             }
-            collapseRunsKernel<Arrays><<<dim3(staged_grid), dim3(256), 0, on>>>(mine);
             return hipGetLastError();
         };
     } else {
