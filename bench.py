@@ -414,7 +414,8 @@ def run_s3(args, rank, local_rank, world, dist, torch):
                 traffic = rec["traffic_bytes_per_launch"]
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                     traffic=traffic, kernel=dominant, ms_per_launch=em_ms, algorithmic_bytes_per_launch=em_bytes,
-                    note="dominant EM kernel = the variant with the most device time; ms_per_launch = its own HIP-event span on the "
+                    note="dominant EM kernel = the launch with the most device time (emRegisterKernel: the five register-resident size "
+                         "bins in one launch); ms_per_launch = its own HIP-event span on the "
                          "stream it runs on; algorithmic bytes = sum over its problems of iterations x (12 B/entry + 20 B/row + "
                          "16 B/column); the problems are register/LDS/L2-resident across iterations, so this is effective bandwidth "
                          "(the HBM traffic of the PMC passes is a fraction of the algorithmic bytes) and the kernel's real bound is the "

@@ -8,13 +8,15 @@
 //   submit()      hands over the host arrays of a batch (the caller's, valid until the batch is done) and the containers its
 //                 estimates go to;
 //   one uploader  thread with a context of its own (rpvg_hip_create_uploader: the device's highest stream priority) copies
-//                 the rows and the path side of batch after batch — at most `workers + 1` batches are resident — and forms the
-//                 haplotype columns behind the copy;
-//   `workers`     estimator threads, each with a single-lane engine (nine streams) and an estimator of its own, take the
-//                 resident batches in order and run PathEstimator::estimateBatchSeeded on them.
-// configs[2] of BASELINE.json on one MI355X: 8.6 ms per resident batch one at a time (two host lanes), 6.1 with two such
-// engines, 4.5 with four single-lane engines (docs/design/host-orchestration.md); with the copy
-// of every batch in the loop the PCIe link (54 GB/s, 288 MB per batch) sets the pace.
+//                 the rows and the path side of batch after batch — at most `workers + 2` batches are on the GPU; nothing but
+//                 the copies: the kernels behind them run on the estimating engine (rpvg_hip_batch_upload_begin / _finish);
+//   `workers`     estimator threads, each with a single-lane engine (its main stream on a hardware queue of its own, three
+//                 side streams: rpvg_hip_create_with_streams) and an estimator of its own, take the uploaded batches in order,
+//                 finish their upload (offsets from their counts, expansion, validation, read totals, haplotype columns) and
+//                 run PathEstimator::estimateBatchSeeded on them.
+// configs[2] of BASELINE.json on one MI355X: 8 ms per resident batch one at a time (two host lanes), 4.3-4.8 through the
+// pipeline with every batch copied inside the clock (190 MB per batch at 52 GB/s: 3.7 ms — the PCIe link is the next bound);
+// how it got there: docs/design/history-r05.md.
 // Results are those of the same calls made one after the other: batches do not interact.
 #ifndef RPVG_AMD_BATCH_PIPELINE_HPP
 #define RPVG_AMD_BATCH_PIPELINE_HPP

@@ -26,6 +26,17 @@ RPVG_AMD_PIPELINE_WORKERS=1 timeout 900 python bench.py --steps 60 --no-cpu-base
 RPVG_AMD_PIPELINE_WORKERS=2 timeout 900 python bench.py --steps 60 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_two_workers.json; stamp $out/bench_s3_n1_two_workers.json
 RPVG_AMD_HOST_SOURCE_GROUPS=1 timeout 900 python bench.py --steps 60 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_host_source_groups.json; stamp $out/bench_s3_n1_host_source_groups.json
 RPVG_HIP_SPIN_WAITS=1 timeout 900 python bench.py --steps 60 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_spin_waits.json; stamp $out/bench_s3_n1_spin_waits.json
+# the switches between two correct implementations of the second half of the round (docs/design/history-r05.md), one at a time, no one-batch leg
+ab() {  # name, env...
+  name=$1; shift
+  env "$@" RPVG_BENCH_NO_SINGLE=1 RPVG_BENCH_NO_GIBBS_LINE=1 RPVG_BENCH_NO_HOST_BOUND=1 timeout 900 python bench.py --steps 120 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s3_n1_120_steps_$name.json; stamp $out/bench_s3_n1_120_steps_$name.json
+}
+ab default RPVG_X=1
+ab pooled_main_queue RPVG_HIP_POOLED_MAIN_QUEUE=1
+ab register_bins_in_five_launches RPVG_HIP_EM_REGISTER_LAUNCHES=5
+ab collapse_before_search RPVG_HIP_COLLAPSE_BEFORE_SEARCH=1
+ab mask_build RPVG_HIP_BUILD_MASKS=1
+ab default_again RPVG_X=2
 timeout 900 python bench.py --workload c2 --steps 4 --warmup 1 2>$out/bench_c2.err | tail -1 > $out/bench_c2_n1.json; stamp $out/bench_c2_n1.json
 timeout 900 python bench.py --workload s5 --steps 40 --warmup 6 2>$out/bench_s5.err | tail -1 > $out/bench_s5_n1.json; stamp $out/bench_s5_n1.json
 timeout 900 python bench.py --workload rows --steps 10 --warmup 2 2>$out/bench_rows.err | tail -1 > $out/bench_rows_n1.json; stamp $out/bench_rows_n1.json
@@ -68,11 +79,11 @@ python tools/pmc_traffic.py --fetch-dir $out/pmc_s3_fetch --write-dir $out/pmc_s
 python tools/pmc_traffic.py --fetch-dir $out/pmc_c2_fetch --write-dir $out/pmc_c2_write --kernel emDenseAccum --steps 150 --double-fetch --shape 1000000,2001,2002 --commit $commit \
   --command "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --workload c2 --steps 1 --warmup 1 --no-cpu-baseline (two separate passes; 3 estimator calls x 50 EM iterations = 150 launches)" \
   --out $out/pmc_traffic_c2.json > /dev/null
-python tools/pmc_kernels.py $out/pmc_search_1 $out/pmc_search_2 $out/pmc_search_3 $out/pmc_search_4 --kernel pairTile,resolveTable,groupsBuildMask,fillSegments,subsetSelect,subsetMerge,sourceColumns > $out/pmc_s3_throughput_kernels.txt
+python tools/pmc_kernels.py $out/pmc_search_1 $out/pmc_search_2 $out/pmc_search_3 $out/pmc_search_4 --kernel pairTile,resolveTable,groupsBuild,fillSegments,subsetSelect,subsetMerge,sourceColumns,emRegister,emSparse,collapse,partitionRows,expandGroups,validateRows > $out/pmc_s3_throughput_kernels.txt
 (cd $out && python $R/tools/pmc_search_summary.py pmc_s3_throughput_kernels.txt 4573105636 pmc_search_s3.json $commit pairTile2Kernel > /dev/null)
 rm -rf $out/pmc_s3_fetch $out/pmc_s3_write $out/pmc_c2_fetch $out/pmc_c2_write $out/pmc_search_?
 echo $commit > $out/COMMIT
-for f in bench_s3_n1 bench_s3_n1_200_steps bench_s3_n1_one_worker bench_s3_n1_two_workers bench_s3_n1_host_source_groups bench_s3_n1_spin_waits bench_c2_n1 bench_s5_n1 bench_rows_n1 bench_e2e_n1 bench_a1_n1_team_64 bench_a1_n1_team_256 bench_a1_n1_team_64_no_combiner bench_s3_n1_profiled; do python - <<PY
+for f in bench_s3_n1_120_steps_default bench_s3_n1_120_steps_pooled_main_queue bench_s3_n1_120_steps_register_bins_in_five_launches bench_s3_n1_120_steps_collapse_before_search bench_s3_n1_120_steps_mask_build bench_s3_n1_120_steps_default_again bench_s3_n1 bench_s3_n1_200_steps bench_s3_n1_one_worker bench_s3_n1_two_workers bench_s3_n1_host_source_groups bench_s3_n1_spin_waits bench_c2_n1 bench_s5_n1 bench_rows_n1 bench_e2e_n1 bench_a1_n1_team_64 bench_a1_n1_team_256 bench_a1_n1_team_64_no_combiner bench_s3_n1_profiled; do python - <<PY
 import json
 try:
     d=json.loads(open("$out/$f.json").read())
