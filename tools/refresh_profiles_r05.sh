@@ -54,8 +54,9 @@ prof() {  # name, env + bench args...
 prof s3 --steps 40 --warmup 8
 prof c2 --workload c2 --steps 4 --warmup 1
 prof s5 --workload s5 --steps 10 --warmup 2
-RPVG_BENCH_NO_SINGLE=1 RPVG_BENCH_NO_GIBBS_LINE=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out/prof_tl -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
-python $R/tools/gpu_busy_union.py $out/prof_tl > $out/gpu_busy_s3_pipeline.txt 2>&1; rm -rf $out/prof_tl
+RPVG_BENCH_NO_SINGLE=1 RPVG_BENCH_NO_GIBBS_LINE=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out/prof_tl -- python $R/bench.py --steps 24 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/gpu_busy_union.py $out/prof_tl 16 > $out/gpu_busy_s3_pipeline.txt 2>&1
+python $R/tools/r05_pipe_timeline.py $out/prof_tl 14 25 > $out/kernel_timeline_s3_pipeline.txt 2>&1; rm -rf $out/prof_tl
 RPVG_BENCH_NO_PIPELINE=1 RPVG_BENCH_NO_GIBBS_LINE=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out/prof_tl1 -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 python $R/tools/kernel_timeline.py $out/prof_tl1 15 > $out/kernel_timeline_s3_one_batch.txt 2>&1; rm -rf $out/prof_tl1
 # PMC passes (each in its own run: counter slots; --kernel-trace only).  One host lane, the pipeline only: every launch holds a whole batch.
