@@ -107,6 +107,35 @@ def launch_ranks(n_gpus):
     return subprocess.call(cmd, env=env)
 
 
+NUMA_BINDING = None  # what bind_to_the_gpus_numa_node() did, for the line
+
+
+def bind_to_the_gpus_numa_node(torch, local_rank):
+    """Several ranks on a node: the threads of a rank (its uploader copies 190 MB per batch out of host memory, 40-50 GB/s per rank)
+    on the CPUs of the NUMA node its GPU hangs on, before anything is allocated (first touch puts the batch there too).  Nothing
+    happens when the node cannot be read, has fewer than six of the CPUs the process may use, or RPVG_BENCH_NO_NUMA_BIND is set."""
+    global NUMA_BINDING
+    if os.environ.get("RPVG_BENCH_NO_NUMA_BIND") or not hasattr(os, "sched_setaffinity"):
+        return
+    try:
+        props = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        if node < 0:
+            return
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        mine = set(os.sched_getaffinity(0)) & cpus
+        if len(mine) < 6:
+            return
+        os.sched_setaffinity(0, mine)
+        NUMA_BINDING = dict(gpu=bdf, numa_node=node, cpus=len(mine))
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return
+
+
 def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -114,6 +143,8 @@ def dist_setup(n_gpus):
     if world != n_gpus:
         raise SystemExit(f"bench.py: --gpus {n_gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     import torch
+    if world > 1 and DEVICE == "cuda" and torch.cuda.is_available():
+        bind_to_the_gpus_numa_node(torch, local_rank)
     dist = None
     if world > 1 or os.environ.get("RPVG_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path with one rank
         import torch.distributed as dist_mod
@@ -1133,6 +1164,8 @@ def main():
         pass
     if rank == 0:
         assert line["n_gpus"] == args.gpus, (line["n_gpus"], args.gpus)
+        if NUMA_BINDING is not None:
+            line["numa_binding_rank0"] = NUMA_BINDING
         print(json.dumps(line), flush=True)
 
 

@@ -220,3 +220,28 @@ def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--scale", "0.01"], env=env,
                          capture_output=True, text=True, timeout=120, cwd=root)
     assert out.returncode != 0 and "--gpus 2" in (out.stderr + out.stdout)
+
+
+def test_numa_binding_leaves_the_process_alone_when_it_cannot_be_read(monkeypatch):
+    """bench.py binds a rank of a multi-rank run to the CPUs of its GPU's NUMA node; a GPU whose node cannot be read (no such
+    PCI device here), or a node with too few of the process's CPUs, changes nothing."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class Props:
+        pci_domain_id, pci_bus_id, pci_device_id = 0xfffe, 0xfe, 0x1e
+
+    class Cuda:
+        @staticmethod
+        def get_device_properties(index):
+            return Props()
+
+    class Torch:
+        cuda = Cuda()
+
+    before = os.sched_getaffinity(0)
+    bench.bind_to_the_gpus_numa_node(Torch(), 0)
+    assert os.sched_getaffinity(0) == before and bench.NUMA_BINDING is None
