@@ -793,33 +793,37 @@ def test_upload_from_counts_of_one_byte_equals_the_upload_from_offsets(hip_ctx):
     hip.lib().rpvg_hip_batch_free(hip_ctx.handle, handle)
 
 
-def test_upload_reports_the_first_row_that_breaks_an_invariant(hip_ctx):
-    """The rows of a batch are checked on the device, behind their copy (validateRowsKernel); the host words the message."""
+@pytest.mark.parametrize("compact", [False, True], ids=["offsets", "counts"])
+def test_upload_reports_the_first_row_that_breaks_an_invariant(hip_ctx, compact):
+    """The rows of a batch are checked on the device, behind their copy (validateRowsKernel: over the offsets the caller wrote, or
+    over the running sums of its counts of one byte); the host words the message."""
     from rpvg_amd import hip
     clusters = small_cases.make_batch_clusters(977, n_clusters=4, with_empty=False)
     good = ClusterBatch.from_clusters(clusters)
-    hip_ctx.upload(good)  # nothing to report
+    hip_ctx.upload(good, compact=compact)  # nothing to report
 
     bad = ClusterBatch.from_clusters(clusters)
     last = len(bad.row_noise) - 1
     bad.row_noise[last] = 1.5
     bad.row_noise[last // 2] = 0.0
     with pytest.raises(hip.EngineError, match=r"row %d has noise probability 0 outside \(0, 1\]" % (last // 2)):
-        hip_ctx.upload(bad)
+        hip_ctx.upload(bad, compact=compact)
 
     bad = ClusterBatch.from_clusters(clusters)
-    row = int(bad.cluster_row_off[1])  # first row of the second cluster
+    row = int(bad.cluster_row_off[1]) + 2  # a row of the second cluster
     entry = int(bad.grp_idx_off[int(bad.row_grp_off[row])])
     n_paths = int(bad.cluster_path_off[2] - bad.cluster_path_off[1])
     bad.path_idx[entry] = n_paths
+    bad.path_idx[int(bad.grp_idx_off[int(bad.row_grp_off[row + 3])])] = n_paths + 5  # (not the first)
     with pytest.raises(hip.EngineError, match=r"row %d refers to path %d of a cluster with %d paths" % (row, n_paths, n_paths)):
-        hip_ctx.upload(bad)
+        hip_ctx.upload(bad, compact=compact)
 
-    bad = ClusterBatch.from_clusters(clusters)
-    bad.grp_idx_off[1] = bad.grp_idx_off[-1] + 7
-    with pytest.raises(hip.EngineError, match="inconsistent group or entry offsets"):
-        hip_ctx.upload(bad)
-    hip_ctx.upload(good)  # the context is still usable
+    if not compact:  # (counts cannot contradict each other)
+        bad = ClusterBatch.from_clusters(clusters)
+        bad.grp_idx_off[1] = bad.grp_idx_off[-1] + 7
+        with pytest.raises(hip.EngineError, match="inconsistent group or entry offsets"):
+            hip_ctx.upload(bad)
+    hip_ctx.upload(good, compact=compact)  # the context is still usable
 
 
 def test_em_problem_sets_in_two_passes_when_the_storage_bound_is_over_budget(hip_ctx):
