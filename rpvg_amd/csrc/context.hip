@@ -553,10 +553,16 @@ bool ownQueueForMainStream(const bool uploader, const int side_streams) {
     return !uploader && side_streams < rpvg_hip_ctx::kAuxStreams && !pooled;
 }
 
-hipError_t createOwnQueueStream(hipStream_t * stream) {
-    uint32_t every_cu[8];  // (256 CUs; bits past the device's last are ignored)
+hipError_t createOwnQueueStream(hipStream_t * stream, const int num_cus) {
+    uint32_t every_cu[32];
     for (uint32_t & word : every_cu) word = 0xffffffffu;
-    return hipExtStreamCreateWithCUMask(stream, 8, every_cu);
+    const uint32_t words = static_cast<uint32_t>(std::min(32, std::max(1, (num_cus + 31) / 32)));  // (256 CUs: eight words; bits past the device's last are ignored)
+    hipError_t e = hipExtStreamCreateWithCUMask(stream, words, every_cu);
+    if (e != hipSuccess) {  // (a runtime or a partition mode that does not take the mask: a stream of the pool, as everywhere else)
+        (void) hipGetLastError();
+        e = hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
+    }
+    return e;
 }
 
 int createContext(int device, bool uploader, int side_streams, rpvg_hip_ctx ** ctx_out);
@@ -591,7 +597,7 @@ int createContext(int device, const bool uploader, const int side_streams, rpvg_
     ctx->device = device;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->props, device)) != hipSuccess ||
-        (e = ownQueueForMainStream(uploader, side_streams) ? createOwnQueueStream(&ctx->stream) : createMainStream(&ctx->stream, uploader)) != hipSuccess) {
+        (e = ownQueueForMainStream(uploader, side_streams) ? createOwnQueueStream(&ctx->stream, ctx->props.multiProcessorCount) : createMainStream(&ctx->stream, uploader)) != hipSuccess) {
         setError("rpvg_hip_create: %s", hipGetErrorString(e));
         delete ctx;
         return RPVG_HIP_ERR_RUNTIME;
