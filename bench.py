@@ -492,6 +492,9 @@ def run_s3(args, rank, local_rank, world, dist, torch):
         line["gpu_active_frac"] = (stats["busy_ms"] / args.steps) / ms_per_step
     if h2d is not None:
         line.update(h2d)
+        second = line.get("instrumented_pass")
+        if second and second.get("gpu_active_frac") is not None:  # (the busy union over the wall time of the pass it was taken in)
+            line["gpu_active_frac"] = second["gpu_active_frac"]
     if pipeline_equal is not None:
         line["pipeline_estimates_equal_single_engine"] = bool(pipeline_equal)
     if ENGINE_MODULE != "rpvg_amd.engine":
@@ -600,19 +603,6 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
         barrier_sync(dist, torch)
         import resource
 
-        def thread_cpu():  # CPU seconds (user, system) of every thread of the process so far
-            import glob
-            ticks = os.sysconf("SC_CLK_TCK")
-            out = {}
-            for stat in glob.glob("/proc/self/task/*/stat"):
-                try:
-                    text = open(stat).read()
-                    fields = text[text.rindex(")") + 2:].split()
-                    out[stat.split("/")[4]] = (int(fields[11]) / ticks, int(fields[12]) / ticks)
-                except Exception:  # noqa: BLE001
-                    pass
-            return out
-
         threads0 = thread_cpu() if os.environ.get("RPVG_BENCH_THREAD_CPU") else None
         cpu0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
@@ -624,17 +614,8 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
         barrier_sync(dist, torch)
         overlapped = max_over_ranks(time.perf_counter() - t0, dist, torch)
         cpu1 = resource.getrusage(resource.RUSAGE_SELF)
-        if threads0 is not None:  # who burnt it: CPU time of every thread over the timed region, per step
-            threads1 = thread_cpu()
-            rows = sorted(((sum(threads1[t]) - sum(threads0.get(t, (0.0, 0.0))), threads1[t][0] - threads0.get(t, (0.0, 0.0))[0],
-                            threads1[t][1] - threads0.get(t, (0.0, 0.0))[1], t) for t in threads1), reverse=True)
-            print("thread cpu over the timed region, ms per step (total user sys tid):", file=sys.stderr)
-            for r in rows[:16]:
-                print(f"  {r[0] * 1e3 / args.steps:7.2f} {r[1] * 1e3 / args.steps:7.2f} {r[2] * 1e3 / args.steps:7.2f} {r[3]}", file=sys.stderr)
-            busy = [r for r in rows if r[0] > 0]
-            print(f"  threads {len(rows)}, with CPU time {len(busy)}, sum {sum(r[0] for r in rows) * 1e3 / args.steps:.1f} ms per step "
-                  f"(user {sum(r[1] for r in rows) * 1e3 / args.steps:.1f}, system {sum(r[2] for r in rows) * 1e3 / args.steps:.1f}); "
-                  f"the 16 busiest {sum(r[0] for r in rows[:16]) * 1e3 / args.steps:.1f}", file=sys.stderr)
+        if threads0 is not None:
+            print_thread_cpu(threads0, args.steps)
         host_cpu_ms = ((cpu1.ru_utime - cpu0.ru_utime) + (cpu1.ru_stime - cpu0.ru_stime)) * 1e3 / args.steps
         stats = eng.stats()
         t0 = time.perf_counter()
@@ -698,6 +679,38 @@ def host_bound_line(args, eng_mod, batch, params, local_rank, ranks=8, steps=40)
                      "host side alone allows a rank of an 8-rank node; efficiency_bound = unconfined ms_per_step / this")
 
 
+def thread_cpu():
+    """CPU seconds (user, system) of every thread of the process so far (RPVG_BENCH_THREAD_CPU=1: who burnt the host's time)."""
+    import glob
+    ticks = os.sysconf("SC_CLK_TCK")
+    out = {}
+    for stat in glob.glob("/proc/self/task/*/stat"):
+        try:
+            text = open(stat).read()
+            fields = text[text.rindex(")") + 2:].split()
+            out[stat.split("/")[4]] = (int(fields[11]) / ticks, int(fields[12]) / ticks)
+        except Exception:  # noqa: BLE001
+            pass
+    return out
+
+
+def print_thread_cpu(threads0, steps):
+    threads1 = thread_cpu()
+    rows = sorted(((sum(threads1[t]) - sum(threads0.get(t, (0.0, 0.0))), threads1[t][0] - threads0.get(t, (0.0, 0.0))[0],
+                    threads1[t][1] - threads0.get(t, (0.0, 0.0))[1], t) for t in threads1), reverse=True)
+    print("thread cpu over the timed region, ms per step (total user sys tid):", file=sys.stderr)
+    for r in rows[:16]:
+        try:
+            name = open(f"/proc/self/task/{r[3]}/comm").read().strip()
+        except OSError:
+            name = "?"
+        print(f"  {r[0] * 1e3 / steps:7.2f} {r[1] * 1e3 / steps:7.2f} {r[2] * 1e3 / steps:7.2f} {r[3]} {name}", file=sys.stderr)
+    busy = [r for r in rows if r[0] > 0]
+    print(f"  threads {len(rows)}, with CPU time {len(busy)}, sum {sum(r[0] for r in rows) * 1e3 / steps:.1f} ms per step "
+          f"(user {sum(r[1] for r in rows) * 1e3 / steps:.1f}, system {sum(r[2] for r in rows) * 1e3 / steps:.1f}); "
+          f"the 16 busiest {sum(r[0] for r in rows[:16]) * 1e3 / steps:.1f}", file=sys.stderr)
+
+
 def copied_arrays(batch):
     """The host arrays of a batch that its copy to the GPU reads (to be page-locked): the two long offset arrays as counts of one
     byte where they fit, else in 32 bits (include/rpvg_batch.h: what a caller that flattens rows for the GPU writes)."""
@@ -725,6 +738,7 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
         pipe.wait()
         pipe.reset_stats()
         barrier_sync(dist, torch)
+        threads0 = thread_cpu() if os.environ.get("RPVG_BENCH_THREAD_CPU") else None
         cpu0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         for k in range(args.steps):
@@ -733,6 +747,8 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
         barrier_sync(dist, torch)
         elapsed = max_over_ranks(time.perf_counter() - t0, dist, torch)
         cpu1 = resource.getrusage(resource.RUSAGE_SELF)
+        if threads0 is not None:
+            print_thread_cpu(threads0, args.steps)
         stats = pipe.stats()
         done = pipe.completions()
         workers = pipe.workers
@@ -743,6 +759,45 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
             hip.host_unregister(a)
     host_cpu_ms = ((cpu1.ru_utime - cpu0.ru_utime) + (cpu1.ru_stime - cpu0.ru_stime)) * 1e3 / args.steps
     bytes_per_batch = float(sum(a.nbytes for a in arrays))
+    # The pipeline's contexts time their EM launches only (rpvg_hip_ctx::span_level, context.hip: two events per span are two marker
+    # commands between dependent kernels, and with every kernel family timed a batch takes 0.3-0.6 ms longer).  The per-family
+    # device times, the busy union and the copies' device time of the line come from a second, shorter pass with all of them on.
+    instrumented = stats
+    if stats.get("busy_ms", 0.0) == 0.0 and not os.environ.get("RPVG_HIP_SPANS"):
+        os.environ["RPVG_HIP_SPANS"] = "2"
+        try:
+            for a in arrays:
+                hip.host_register(a)
+            pipe = eng_mod.Pipeline(args.model, params, local_rank, workers=args.pipeline_workers)
+            try:
+                steps2 = max(16, min(args.steps, 48))
+                pipe.prepare_slots(batch, slots)
+                for k in range(2 * slots):
+                    pipe.submit(batch, k % slots, compact=True)
+                pipe.wait()
+                pipe.reset_stats()
+                t2 = time.perf_counter()
+                for k in range(steps2):
+                    pipe.submit(batch, k % slots, compact=True)
+                pipe.wait()
+                instrumented_ms = (time.perf_counter() - t2) / steps2 * 1e3
+                instrumented = pipe.stats()
+                instrumented["steps"] = steps2
+                instrumented["ms_per_step"] = instrumented_ms
+            finally:
+                pipe.close()
+                for a in arrays:
+                    hip.host_unregister(a)
+        finally:
+            os.environ.pop("RPVG_HIP_SPANS", None)
+        # (per step of ITS pass, scaled to the steps of the timed one: what the caller divides by)
+        scale = args.steps / float(instrumented["steps"])
+        for key in ("em_sparse_ms", "em_dense_ms", "loglik_ms", "build_ms", "h2d_ms", "collapse_ms", "busy_ms", "gibbs_ms"):
+            if key in instrumented:
+                stats[key] = instrumented[key] * scale
+        for key in ("upload_copies_ms_per_batch", "upload_kernels_ms_per_batch"):
+            if key in instrumented:
+                stats[key] = instrumented[key]
     up_ms = stats.pop("upload_seconds_per_batch") * 1e3
     up_copies_ms, up_kernels_ms = stats.pop("upload_copies_ms_per_batch", None), stats.pop("upload_kernels_ms_per_batch", None)
     worker_ms = dict(finish_upload=stats.pop("worker_finish_ms_per_batch", None), estimate=stats.pop("worker_estimate_ms_per_batch", None),
@@ -756,7 +811,15 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
                       first_batch_done_ms=float(done[0]) * 1e3, last_batch_done_ms=float(done[-1]) * 1e3,
                       note="time between the completions of consecutive batches inside the timed region (ms_per_step = wall time between the "
                            "barriers / K, ramp-up of the first batch and drain of the last included)")
-    return dict(stats=stats, ms_per_step_with_h2d=elapsed / args.steps * 1e3, ms_per_step_spread=spread, host_cpu_ms_per_step=host_cpu_ms,
+    instrumented_note = None
+    if instrumented is not stats:
+        instrumented_note = dict(steps=instrumented["steps"], ms_per_step=instrumented["ms_per_step"],
+                                 note="a second pass of the pipeline with every kernel family timed (RPVG_HIP_SPANS=2): the source of the line's per-family "
+                                      "device times (`kernels`, `roofline_search`), `gpu_active_frac` and the copies' device time; the timed pass times its EM "
+                                      "launches only (`roofline`, `em_kernels`)")
+        busy_frac = (instrumented.get("busy_ms", 0.0) / instrumented["steps"]) / instrumented["ms_per_step"] if instrumented["ms_per_step"] > 0 else None
+        instrumented_note["gpu_active_frac"] = busy_frac
+    return dict(stats=stats, instrumented_pass=instrumented_note, ms_per_step_with_h2d=elapsed / args.steps * 1e3, ms_per_step_spread=spread, host_cpu_ms_per_step=host_cpu_ms,
                 host_cpu_note="user + system CPU time of the process (uploader, estimator threads, this thread) per step of the timed region, getrusage",
                 pipeline=dict(workers=workers, resident_batches=workers + 1, estimates_slots=slots, worker_ms_per_batch=worker_ms,
                               note="rpvg_amd/host/batch_pipeline.hpp: one uploader thread (context of its own), `workers` estimator threads with a "

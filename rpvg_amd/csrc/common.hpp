@@ -666,6 +666,10 @@ struct rpvg_hip_ctx {
     int allReduceSumF64(double * device_buf, uint64_t n);
     std::vector<rpvg_hip_detail::TimedSpan> spans;
     std::vector<hipStream_t> span_streams;  // the stream of each open span
+    int span_level = 2;                     // which families spanBegin() times (context.hip)
+    int open_spans = 0;                     // begun, not ended
+    void accountSpan(const rpvg_hip_detail::TimedSpan & span, const void * clock_base, uint64_t clock_id);
+    void foldFinishedSpans();
     std::vector<rpvg_hip_detail::TimedInterval> intervals;  // folded spans since the last reset
     rpvg_hip_kernel_stats stats;
 

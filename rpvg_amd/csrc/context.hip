@@ -367,7 +367,17 @@ DeviceClock deviceClock(const int device, hipStream_t stream, const bool renew_i
 }  // namespace
 }  // namespace rpvg_hip_detail
 
+// The spans cost what they record with: two events each, two marker commands in the stream's queue — eighty per configs[2]
+// batch with all of them, between kernels that depend on each other; with several batches in flight that was 0.6 of 4.8 ms per
+// batch.  span_level (rpvg_hip_ctx): 2 every family (the contexts of rpvg_hip_create: one batch at a time, the statistics
+// bench.py and the tools read), 1 the EM launches only (the contexts of rpvg_hip_create_with_streams and rpvg_hip_create_uploader:
+// the batch pipeline — the two events around a batch's copies alone were 0.25 of 3.8 ms per upload), 0 none; RPVG_HIP_SPANS=n when a
+// context is made overrides.
 int rpvg_hip_ctx::spanBegin(int family, hipStream_t on, int sub) {
+    if (span_level <= 0 || (span_level == 1 && family != FAM_EM_KERNEL)) return -1;
+    // a caller that never reads the statistics: the spans that are done are folded now and then (nothing waits: a span still
+    // running stays), once no span is open — handles are positions in the list
+    if (open_spans == 0 && spans.size() >= 1024) foldFinishedSpans();
     TimedSpan s;
     s.family = family;
     s.sub = sub;
@@ -380,50 +390,78 @@ int rpvg_hip_ctx::spanBegin(int family, hipStream_t on, int sub) {
     (void) hipEventRecord(s.start, on);
     spans.push_back(s);
     span_streams.push_back(on);
+    ++open_spans;
     return static_cast<int>(spans.size()) - 1;
 }
 
 void rpvg_hip_ctx::spanEnd(int idx) {
     if (idx < 0) return;
     (void) hipEventRecord(spans[idx].stop, span_streams[idx]);
+    if (open_spans > 0) --open_spans;
+}
+
+// what a finished span adds to the statistics (the caller destroys its events)
+void rpvg_hip_ctx::accountSpan(const rpvg_hip_detail::TimedSpan & s, const void * clock_base, const uint64_t clock_id) {
+    constexpr size_t kMaxIntervals = 1u << 20;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, s.start, s.stop) != hipSuccess) return;
+    switch (s.family) {
+        case FAM_EM_SPARSE: stats.em_sparse_ms += ms; break;
+        case FAM_EM_DENSE: stats.em_dense_ms += ms; break;
+        case FAM_LOGLIK: stats.loglik_ms += ms; break;
+        case FAM_BUILD: stats.build_ms += ms; break;
+        case FAM_H2D: stats.h2d_ms += ms; break;
+        case FAM_COLLAPSE: stats.collapse_ms += ms; break;
+        case FAM_GIBBS: stats.gibbs_ms += ms; break;
+        case FAM_EM_KERNEL:
+            if (s.sub >= 0 && s.sub < RPVG_HIP_EM_KERNELS) stats.em_kernel[s.sub].ms += ms;
+            break;
+        default: break;
+    }
+    float at = 0;
+    // (the per-kernel spans lie inside their call's FAM_EM_SPARSE span: not a second interval)
+    // (... and the conditionals' FAM_LOGLIK spans inside their sampler's FAM_GIBBS span)
+    hipEvent_t base = static_cast<hipEvent_t>(const_cast<void *>(clock_base));
+    if (s.family != FAM_EM_KERNEL && s.family != FAM_GIBBS && base && intervals.size() < kMaxIntervals &&
+        hipEventElapsedTime(&at, base, s.start) == hipSuccess) {
+        intervals.push_back(TimedInterval{static_cast<double>(at), static_cast<double>(at) + ms, s.family, clock_id});
+    }
+}
+
+void rpvg_hip_ctx::foldFinishedSpans() {
+    const DeviceClock clock = deviceClock(device, stream, false);
+    size_t kept = 0;
+    for (size_t i = 0; i < spans.size(); ++i) {
+        if (hipEventQuery(spans[i].stop) == hipSuccess) {
+            accountSpan(spans[i], clock.base, clock.id);
+            (void) hipEventDestroy(spans[i].start);
+            (void) hipEventDestroy(spans[i].stop);
+        } else {
+            (void) hipGetLastError();
+            spans[kept] = spans[i];
+            span_streams[kept] = span_streams[i];
+            ++kept;
+        }
+    }
+    (void) hipGetLastError();
+    spans.resize(kept);
+    span_streams.resize(kept);
 }
 
 int rpvg_hip_ctx::foldSpans() {
     RPVG_HIP_CHECK(hipStreamSynchronize(stream));
     if (collapse_stream) RPVG_HIP_CHECK(hipStreamSynchronize(collapse_stream));
     const DeviceClock clock = deviceClock(device, stream, false);
-    constexpr size_t kMaxIntervals = 1u << 20;
     for (auto & s : spans) {
-        float ms = 0;
         (void) hipEventSynchronize(s.stop);  // spans on side streams
-        if (hipEventElapsedTime(&ms, s.start, s.stop) == hipSuccess) {
-            switch (s.family) {
-                case FAM_EM_SPARSE: stats.em_sparse_ms += ms; break;
-                case FAM_EM_DENSE: stats.em_dense_ms += ms; break;
-                case FAM_LOGLIK: stats.loglik_ms += ms; break;
-                case FAM_BUILD: stats.build_ms += ms; break;
-                case FAM_H2D: stats.h2d_ms += ms; break;
-                case FAM_COLLAPSE: stats.collapse_ms += ms; break;
-                case FAM_GIBBS: stats.gibbs_ms += ms; break;
-                case FAM_EM_KERNEL:
-                    if (s.sub >= 0 && s.sub < RPVG_HIP_EM_KERNELS) stats.em_kernel[s.sub].ms += ms;
-                    break;
-                default: break;
-            }
-            float at = 0;
-            // (the per-kernel spans lie inside their call's FAM_EM_SPARSE span: not a second interval)
-            // (... and the conditionals' FAM_LOGLIK spans inside their sampler's FAM_GIBBS span)
-            if (s.family != FAM_EM_KERNEL && s.family != FAM_GIBBS && clock.base && intervals.size() < kMaxIntervals &&
-                hipEventElapsedTime(&at, clock.base, s.start) == hipSuccess) {
-                intervals.push_back(TimedInterval{static_cast<double>(at), static_cast<double>(at) + ms, s.family, clock.id});
-            }
-        }
+        accountSpan(s, clock.base, clock.id);
         (void) hipGetLastError();
         (void) hipEventDestroy(s.start);
         (void) hipEventDestroy(s.stop);
     }
     spans.clear();
     span_streams.clear();
+    open_spans = 0;
     // union of the intervals on the present clock
     std::vector<std::pair<double, double>> iv;
     for (auto & t : intervals) {
@@ -596,6 +634,10 @@ int createContext(int device, const bool uploader, const int side_streams, rpvg_
     }
     ctx->device = device;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
+    {
+        const char * env = std::getenv("RPVG_HIP_SPANS");  // (read per context)
+        ctx->span_level = env ? std::max(0, std::min(2, std::atoi(env))) : ((uploader || side_streams < rpvg_hip_ctx::kAuxStreams) ? 1 : 2);
+    }
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->props, device)) != hipSuccess ||
         (e = ownQueueForMainStream(uploader, side_streams) ? createOwnQueueStream(&ctx->stream, ctx->props.multiProcessorCount) : createMainStream(&ctx->stream, uploader)) != hipSuccess) {
         setError("rpvg_hip_create: %s", hipGetErrorString(e));
