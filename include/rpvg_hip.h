@@ -92,6 +92,12 @@ void rpvg_hip_batch_free(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch);
  * host_batch is the same caller-owned batch both times (a batch that fails _finish is freed by it). */
 int rpvg_hip_batch_upload_begin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * host_batch, rpvg_hip_batch ** batch_out);
 int rpvg_hip_batch_upload_finish(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch, const rpvg_cluster_batch * host_batch);
+/* ... or the second half itself in two steps: _finish_queue puts the kernels behind the copies on a stream of `ctx` (an uploader's
+ * context: its side stream, next to the copies of the batch after) and returns; _finish_wait, from any thread and without a
+ * context, waits for them and does the host's part — what rpvg_hip_batch_upload_finish does in one call.  A pipeline's uploader
+ * queues, the estimator that takes the batch waits (rpvg_amd/host/batch_pipeline.hpp).  On failure the batch is freed. */
+int rpvg_hip_batch_upload_finish_queue(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch, const rpvg_cluster_batch * host_batch);
+int rpvg_hip_batch_upload_finish_wait(rpvg_hip_batch * batch, const rpvg_cluster_batch * host_batch);
 /* Read count of every cluster of an uploaded batch (the sum of its rows' read counts, exact), added up on the device behind
  * the copy (src/path_abundance_estimator.cpp:44,291,690: `read_counts.sum()`). */
 int rpvg_hip_batch_cluster_totals(const rpvg_hip_batch * batch, double * totals_out, uint32_t num_clusters);

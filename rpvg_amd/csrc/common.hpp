@@ -732,6 +732,21 @@ struct rpvg_hip_batch {
         rpvg_hip_detail::DeviceBuffer<uint8_t> d_row_grp_count8, d_grp_idx_count8;  // the count form (include/rpvg_batch.h): summed up into the 32-bit offsets behind the copy
         uint64_t num_groups = 0;
         rpvg_hip_detail::PathSourcesPending path_sources;
+        // the second half queued (uploadFinishQueue): what its kernels write and what comes back, until the wait
+        rpvg_hip_detail::DeviceBuffer<unsigned long long> d_first_bad_row;
+        rpvg_hip_detail::DeviceBuffer<double> d_cluster_total;
+        rpvg_hip_detail::DeviceBuffer<uint64_t> d_cluster_ent_off;
+        rpvg_hip_detail::DeviceBuffer<unsigned char> scan_scratch_rows, scan_scratch_groups;
+        void * h_results = nullptr;   // page-locked
+        hipEvent_t finished = nullptr;
+        bool counts = false;
+        ~UploadInProgress() {
+            if (finished) {
+                (void) hipEventSynchronize(finished);  // (a batch freed between the two steps: its kernels use the buffers above)
+                (void) hipEventDestroy(finished);
+            }
+            if (h_results) rpvg_hip_detail::pinnedFree(h_results);
+        }
     };
     std::unique_ptr<UploadInProgress> upload;  // null: the batch is complete
 };
@@ -1004,7 +1019,7 @@ hipError_t queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollapseInput & in, dou
 // read count of every cluster (exact integer sums) from the 32-bit counts as uploaded
 hipError_t queueClusterTotals(hipStream_t stream, uint32_t num_clusters, const uint64_t * d_cluster_row_off, const uint32_t * d_row_count_u32, double * d_totals);
 hipError_t queuePathSourceCopies(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_cluster_batch * hb, PathSourcesPending & pending);
-hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSourcesPending & pending);
+hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSourcesPending & pending, hipStream_t stream);
 // RPVG_HIP_OK; RPVG_HIP_ERR_INVALID for inconsistent offsets.  A batch whose id ranges outgrow the scratch set aside for them
 // simply has no source columns (has_source_columns stays false: the caller groups on the host).
 int finishPathSources(rpvg_hip_batch * b, PathSourcesPending & pending);

@@ -986,81 +986,116 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
     return RPVG_HIP_OK;
 }
 
-// (the caller holds no lock; `b` is deleted on failure)
-static int uploadFinish(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_cluster_batch * hb) {
+// The second half of an upload in two steps.  Queue: the kernels behind the copies and the copies of their small results into a
+// page-locked block, on stream `st` of `ctx` (the copies have been waited for: rpvg_hip_batch_upload_begin), an event behind them.
+// Wait: for that event, from any thread, and the host's part (messages, sizes of the haplotype columns).  A pipeline's uploader
+// queues them behind every batch's copies on its side stream and goes on copying; the estimator that takes the batch finds them
+// done, or nearly (rpvg_amd/host/batch_pipeline.hpp).  (the caller holds no lock; `b` is deleted on failure)
+static int uploadFinishQueue(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, hipStream_t st) {
     const uint32_t K = b->num_clusters;
     const uint64_t R = b->num_rows, NNZ = b->num_entries;
-    std::lock_guard<std::mutex> lock(ctx->mutex);
+    // (the context's lock for its main stream — and its statistics — only: on the side stream of an uploader's context a thread of
+    // its own queues these while the uploader queues the next batch's copies)
+    const bool own_stream = st == ctx->stream;
+    std::unique_lock<std::mutex> lock(ctx->mutex, std::defer_lock);
+    if (own_stream) lock.lock();
     hipError_t e = hipSetDevice(ctx->device);
     rpvg_hip_batch::UploadInProgress & up = *b->upload;
     const uint64_t G = up.num_groups;
-    HostScope scope("batch_upload: kernels + wait");
-    const int bspan = ctx->spanBegin(FAM_BUILD);
+    HostScope scope("batch_upload: kernels queued");
+    const int bspan = own_stream ? ctx->spanBegin(FAM_BUILD, st) : -1;
     // both long offset arrays in 32 bits (what a caller that flattens rows for the GPU writes): the kernels read them as they are;
     // one of them only: that one is widened first
     const bool narrow = up.d_row_grp_off32.ptr && up.d_grp_idx_off32.ptr;
     if (e == hipSuccess && !narrow && up.d_row_grp_off32.ptr) {
-        widenOffsetsKernel<<<dim3(static_cast<uint32_t>((R + 1 + 255) / 256)), dim3(256), 0, ctx->stream>>>(R + 1, up.d_row_grp_off32.ptr, up.d_row_grp_off.ptr);
+        widenOffsetsKernel<<<dim3(static_cast<uint32_t>((R + 1 + 255) / 256)), dim3(256), 0, st>>>(R + 1, up.d_row_grp_off32.ptr, up.d_row_grp_off.ptr);
     }
     if (e == hipSuccess && !narrow && up.d_grp_idx_off32.ptr) {
-        widenOffsetsKernel<<<dim3(static_cast<uint32_t>((G + 1 + 255) / 256)), dim3(256), 0, ctx->stream>>>(G + 1, up.d_grp_idx_off32.ptr, up.d_grp_idx_off.ptr);
+        widenOffsetsKernel<<<dim3(static_cast<uint32_t>((G + 1 + 255) / 256)), dim3(256), 0, st>>>(G + 1, up.d_grp_idx_off32.ptr, up.d_grp_idx_off.ptr);
     }
     const uint32_t threads = 256;
     const dim3 group_grid(static_cast<uint32_t>((G + threads - 1) / threads)), meta_grid(static_cast<uint32_t>((R + 1 + threads - 1) / threads)),
         row_grid(static_cast<uint32_t>((R + threads - 1) / threads));
-    unsigned long long first_bad_row = ~0ull;
-    DeviceBuffer<unsigned long long> d_first_bad_row;
-    if (e == hipSuccess) e = d_first_bad_row.alloc(1);
-    if (e == hipSuccess) e = hipMemsetAsync(d_first_bad_row.ptr, 0xFF, sizeof(unsigned long long), ctx->stream);
-    DeviceBuffer<unsigned char> scan_scratch_rows, scan_scratch_groups;
-    const bool counts = up.d_row_grp_count8.ptr != nullptr;
+    if (e == hipSuccess) e = up.d_first_bad_row.alloc(1);
+    if (e == hipSuccess) e = hipMemsetAsync(up.d_first_bad_row.ptr, 0xFF, sizeof(unsigned long long), st);
+    up.counts = up.d_row_grp_count8.ptr != nullptr;
+    const bool counts = up.counts;
     if (e == hipSuccess && counts) {  // the offsets the kernels below read: the counts' running sums
-        e = queueOffsetsFromCounts(ctx->stream, up.d_row_grp_count8.ptr, R, up.d_row_grp_off32.ptr, scan_scratch_rows);
-        if (e == hipSuccess) e = queueOffsetsFromCounts(ctx->stream, up.d_grp_idx_count8.ptr, G, up.d_grp_idx_off32.ptr, scan_scratch_groups);
+        e = queueOffsetsFromCounts(st, up.d_row_grp_count8.ptr, R, up.d_row_grp_off32.ptr, up.scan_scratch_rows);
+        if (e == hipSuccess) e = queueOffsetsFromCounts(st, up.d_grp_idx_count8.ptr, G, up.d_grp_idx_off32.ptr, up.scan_scratch_groups);
     }
     if (e == hipSuccess && narrow) {
-        if (G > 0) expandGroupsKernel<uint32_t><<<group_grid, dim3(threads), 0, ctx->stream>>>(G, NNZ, up.d_grp_idx_off32.ptr, up.d_grp_prob.ptr, b->ent_prob.ptr);
-        rowMetaKernel<uint32_t, uint32_t><<<meta_grid, dim3(threads), 0, ctx->stream>>>(R, G, up.d_row_grp_off32.ptr, up.d_grp_idx_off32.ptr, up.d_row_count_u32.ptr,
-                                                                                         b->row_ent_off.ptr, b->row_count.ptr);
-        if (R > 0) validateRowsKernel<uint32_t, uint32_t><<<row_grid, dim3(threads), 0, ctx->stream>>>(
+        if (G > 0) expandGroupsKernel<uint32_t><<<group_grid, dim3(threads), 0, st>>>(G, NNZ, up.d_grp_idx_off32.ptr, up.d_grp_prob.ptr, b->ent_prob.ptr);
+        rowMetaKernel<uint32_t, uint32_t><<<meta_grid, dim3(threads), 0, st>>>(R, G, up.d_row_grp_off32.ptr, up.d_grp_idx_off32.ptr, up.d_row_count_u32.ptr,
+                                                                                b->row_ent_off.ptr, b->row_count.ptr);
+        if (R > 0) validateRowsKernel<uint32_t, uint32_t><<<row_grid, dim3(threads), 0, st>>>(
             R, G, NNZ, K, b->cluster_row_off.ptr, b->cluster_path_off.ptr, up.d_row_grp_off32.ptr, up.d_grp_idx_off32.ptr, b->row_noise.ptr, b->ent_path.ptr,
-            d_first_bad_row.ptr);
+            up.d_first_bad_row.ptr);
     } else if (e == hipSuccess) {
-        if (G > 0) expandGroupsKernel<uint64_t><<<group_grid, dim3(threads), 0, ctx->stream>>>(G, NNZ, up.d_grp_idx_off.ptr, up.d_grp_prob.ptr, b->ent_prob.ptr);
-        rowMetaKernel<uint64_t, uint64_t><<<meta_grid, dim3(threads), 0, ctx->stream>>>(R, G, up.d_row_grp_off.ptr, up.d_grp_idx_off.ptr, up.d_row_count_u32.ptr,
-                                                                                         b->row_ent_off.ptr, b->row_count.ptr);
-        if (R > 0) validateRowsKernel<uint64_t, uint64_t><<<row_grid, dim3(threads), 0, ctx->stream>>>(
+        if (G > 0) expandGroupsKernel<uint64_t><<<group_grid, dim3(threads), 0, st>>>(G, NNZ, up.d_grp_idx_off.ptr, up.d_grp_prob.ptr, b->ent_prob.ptr);
+        rowMetaKernel<uint64_t, uint64_t><<<meta_grid, dim3(threads), 0, st>>>(R, G, up.d_row_grp_off.ptr, up.d_grp_idx_off.ptr, up.d_row_count_u32.ptr,
+                                                                                b->row_ent_off.ptr, b->row_count.ptr);
+        if (R > 0) validateRowsKernel<uint64_t, uint64_t><<<row_grid, dim3(threads), 0, st>>>(
             R, G, NNZ, K, b->cluster_row_off.ptr, b->cluster_path_off.ptr, up.d_row_grp_off.ptr, up.d_grp_idx_off.ptr, b->row_noise.ptr, b->ent_path.ptr,
-            d_first_bad_row.ptr);
+            up.d_first_bad_row.ptr);
     }
     // read counts per cluster (the host summed three million of them per batch with a team of its own)
-    DeviceBuffer<double> d_cluster_total;
-    b->h_cluster_total.assign(K, 0.0);
-    if (e == hipSuccess) e = d_cluster_total.alloc(K);
-    if (e == hipSuccess) e = queueClusterTotals(ctx->stream, K, b->cluster_row_off.ptr, up.d_row_count_u32.ptr, d_cluster_total.ptr);
-    if (e == hipSuccess) e = queuePathSourceKernels(ctx, b, up.path_sources);
-    DeviceBuffer<uint64_t> d_cluster_ent_off;
+    if (e == hipSuccess) e = up.d_cluster_total.alloc(K);
+    if (e == hipSuccess) e = queueClusterTotals(st, K, b->cluster_row_off.ptr, up.d_row_count_u32.ptr, up.d_cluster_total.ptr);
+    if (e == hipSuccess) e = queuePathSourceKernels(ctx, b, up.path_sources, st);
     if (e == hipSuccess && counts) {
-        e = d_cluster_ent_off.alloc(K + 1);
-        if (e == hipSuccess) clusterEntryOffsetsKernel<<<dim3((K + 1 + 255) / 256), dim3(256), 0, ctx->stream>>>(K, b->cluster_row_off.ptr, b->row_ent_off.ptr, d_cluster_ent_off.ptr);
+        e = up.d_cluster_ent_off.alloc(K + 1);
+        if (e == hipSuccess) clusterEntryOffsetsKernel<<<dim3((K + 1 + 255) / 256), dim3(256), 0, st>>>(K, b->cluster_row_off.ptr, b->row_ent_off.ptr, up.d_cluster_ent_off.ptr);
     }
-    ctx->spanEnd(bspan);
-    ctx->stats.build_launches += 5;
+    if (own_stream) {
+        ctx->spanEnd(bspan);
+        ctx->stats.build_launches += 5;
+    }
     if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&first_bad_row, d_first_bad_row.ptr, sizeof(first_bad_row), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && K > 0) e = hipMemcpyAsync(b->h_cluster_total.data(), d_cluster_total.ptr, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && counts) e = hipMemcpyAsync(b->h_cluster_ent_off.data(), d_cluster_ent_off.ptr, (K + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
-    uint32_t count_totals[2] = {0, 0};  // what the counts add up to (against the totals the caller named)
-    if (e == hipSuccess && counts) e = hipMemcpyAsync(&count_totals[0], up.d_row_grp_off32.ptr + R, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && counts) e = hipMemcpyAsync(&count_totals[1], up.d_grp_idx_off32.ptr + G, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = waitStream(ctx->stream);  // temporaries are freed on return
+    // the small results: [first bad row, 64 bits | the counts' two sums | - | read totals K doubles | entry offsets K + 1]
+    const size_t result_bytes = 16 + 8 * static_cast<size_t>(K) + 8 * (static_cast<size_t>(K) + 1);
+    if (e == hipSuccess) e = pinnedAlloc(&up.h_results, result_bytes);
+    if (e == hipSuccess) {
+        unsigned char * host = static_cast<unsigned char *>(up.h_results);
+        memset(host, 0, 16);
+        e = hipMemcpyAsync(host, up.d_first_bad_row.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && counts) e = hipMemcpyAsync(host + 8, up.d_row_grp_off32.ptr + R, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && counts) e = hipMemcpyAsync(host + 12, up.d_grp_idx_off32.ptr + G, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && K > 0) e = hipMemcpyAsync(host + 16, up.d_cluster_total.ptr, K * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && counts) e = hipMemcpyAsync(host + 16 + 8 * static_cast<size_t>(K), up.d_cluster_ent_off.ptr, (K + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&up.finished, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(up.finished, st);
     if (e != hipSuccess) {
         setError("rpvg_hip_batch_upload: %s", hipGetErrorString(e));
-        (void) hipStreamSynchronize(ctx->stream);
+        (void) hipStreamSynchronize(st);
         delete b;
         return RPVG_HIP_ERR_RUNTIME;
     }
-    if (counts && (count_totals[0] != G || count_totals[1] != NNZ)) {
+    return RPVG_HIP_OK;
+}
+
+static int uploadFinishWait(rpvg_hip_batch * b, const rpvg_cluster_batch * hb) {
+    const uint32_t K = b->num_clusters;
+    const uint64_t NNZ = b->num_entries;
+    rpvg_hip_batch::UploadInProgress & up = *b->upload;
+    const uint64_t G = up.num_groups;
+    HostScope scope("batch_upload: wait for the kernels");
+    const hipError_t e = waitEvent(up.finished);
+    if (e != hipSuccess) {
+        setError("rpvg_hip_batch_upload: %s", hipGetErrorString(e));
+        delete b;
+        return RPVG_HIP_ERR_RUNTIME;
+    }
+    const unsigned char * host = static_cast<const unsigned char *>(up.h_results);
+    unsigned long long first_bad_row = ~0ull;
+    uint32_t count_totals[2] = {0, 0};  // what the counts add up to (against the totals the caller named)
+    memcpy(&first_bad_row, host, sizeof(first_bad_row));
+    memcpy(count_totals, host + 8, sizeof(count_totals));
+    b->h_cluster_total.resize(K);
+    if (K > 0) memcpy(b->h_cluster_total.data(), host + 16, K * sizeof(double));
+    if (up.counts) memcpy(b->h_cluster_ent_off.data(), host + 16 + 8 * static_cast<size_t>(K), (K + 1) * sizeof(uint64_t));
+    if (up.counts && (count_totals[0] != G || count_totals[1] != NNZ)) {
         delete b;
         setError("rpvg_hip_batch_upload: the counts of the rows' groups and of the groups' paths do not add up to num_groups = %llu and num_entries = %llu",
                  static_cast<unsigned long long>(G), static_cast<unsigned long long>(NNZ));
@@ -1088,6 +1123,11 @@ static int uploadFinish(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_clust
     return RPVG_HIP_OK;
 }
 
+static int uploadFinish(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_cluster_batch * hb) {
+    const int rc = uploadFinishQueue(ctx, b, ctx->stream);
+    return rc != RPVG_HIP_OK ? rc : uploadFinishWait(b, hb);
+}
+
 int rpvg_hip_batch_upload(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_hip_batch ** batch_out) {
     rpvg_hip_batch * b = nullptr;
     int rc = uploadBegin(ctx, hb, &b);
@@ -1102,11 +1142,18 @@ int rpvg_hip_batch_upload_begin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * h
     rpvg_hip_batch * b = nullptr;
     const int rc = uploadBegin(ctx, hb, &b);
     if (rc != RPVG_HIP_OK) return rc;
+    // the copies are done: any context of the device may finish the batch.  (An event, waited for without the context's lock:
+    // another thread may queue the kernels behind an earlier batch's copies on this context's side stream meanwhile.)
     hipError_t e = hipSuccess;
+    hipEvent_t copied = nullptr;
     {
         std::lock_guard<std::mutex> lock(ctx->mutex);
-        e = waitStream(ctx->stream);  // the copies are done: any context of the device may finish the batch
+        e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&copied, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(copied, ctx->stream);
     }
+    if (e == hipSuccess) e = waitEvent(copied);
+    if (copied) (void) hipEventDestroy(copied);
     if (e != hipSuccess) {
         setError("rpvg_hip_batch_upload_begin: %s", hipGetErrorString(e));
         delete b;
@@ -1114,6 +1161,21 @@ int rpvg_hip_batch_upload_begin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * h
     }
     *batch_out = b;
     return RPVG_HIP_OK;
+}
+
+int rpvg_hip_batch_upload_finish_queue(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch, const rpvg_cluster_batch * hb) {
+    RPVG_REQUIRE(ctx != nullptr && batch != nullptr && hb != nullptr, "rpvg_hip_batch_upload_finish_queue: NULL argument");
+    RPVG_REQUIRE(batch->upload != nullptr && batch->upload->finished == nullptr, "rpvg_hip_batch_upload_finish_queue: the batch is complete, or queued, already");
+    RPVG_REQUIRE(hb->num_clusters == batch->num_clusters && hb->cluster_row_off && hb->cluster_row_off[hb->num_clusters] == batch->num_rows,
+                 "rpvg_hip_batch_upload_finish_queue: not the host batch the upload began with");
+    // (an uploader's context: its side stream — its main stream carries the next batch's copies)
+    return uploadFinishQueue(ctx, batch, ctx->aux_count > 0 && ctx->aux[0] ? ctx->aux[0] : ctx->stream);
+}
+
+int rpvg_hip_batch_upload_finish_wait(rpvg_hip_batch * batch, const rpvg_cluster_batch * hb) {
+    RPVG_REQUIRE(batch != nullptr && hb != nullptr, "rpvg_hip_batch_upload_finish_wait: NULL argument");
+    RPVG_REQUIRE(batch->upload != nullptr && batch->upload->finished != nullptr, "rpvg_hip_batch_upload_finish_wait: nothing queued for this batch");
+    return uploadFinishWait(batch, hb);
 }
 
 int rpvg_hip_batch_upload_finish(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch, const rpvg_cluster_batch * hb) {

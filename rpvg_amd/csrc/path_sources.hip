@@ -313,10 +313,10 @@ hipError_t queuePathSourceCopies(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const r
     return e;
 }
 
-hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSourcesPending & pending) {
+hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSourcesPending & pending, hipStream_t st) {
+    (void) ctx;
     if (!pending.copied) return hipSuccess;
     const uint32_t K = pending.K;
-    hipStream_t st = ctx->stream;
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     // d_sizes: [the arena's cursor, 64 bits | flags 2 | length of the large workgroups' list | - | sizes 3K | that list K]: the first six

@@ -32,6 +32,7 @@ EXPORTS = [
     "rpvg_hip_nested_subset_em", "rpvg_hip_subset_em_get", "rpvg_hip_subset_em_free",
     "rpvg_hip_batch_cluster_totals", "rpvg_hip_batch_has_source_columns", "rpvg_hip_batch_source_columns_sizes",
     "rpvg_hip_batch_source_columns_get", "rpvg_hip_groups_build_from_sources", "rpvg_hip_batch_upload_begin", "rpvg_hip_batch_upload_finish", "rpvg_hip_create_with_streams",
+    "rpvg_hip_batch_upload_finish_queue", "rpvg_hip_batch_upload_finish_wait",
 ]
 
 COMM_ID_BYTES = 128  # RPVG_HIP_COMM_ID_BYTES

@@ -8,14 +8,16 @@
 //   submit()      hands over the host arrays of a batch (the caller's, valid until the batch is done) and the containers its
 //                 estimates go to;
 //   one uploader  thread with a context of its own (rpvg_hip_create_uploader: the device's highest stream priority) copies
-//                 the rows and the path side of batch after batch — at most `workers + 2` batches are on the GPU; nothing but
-//                 the copies: the kernels behind them run on the estimating engine (rpvg_hip_batch_upload_begin / _finish);
+//                 the rows and the path side of batch after batch — at most `workers + 3` batches are on the GPU; nothing but
+//                 the copies (rpvg_hip_batch_upload_begin);
+//   one more      thread queues the kernels behind a batch's copies — offsets from their counts, expansion, validation, read
+//                 totals, haplotype columns — on the uploader's side stream (rpvg_hip_batch_upload_finish_queue: no context, no
+//                 hardware queue more) while the uploader copies the next batch;
 //   `workers`     estimator threads, each with a single-lane engine (its main stream on a hardware queue of its own, three
-//                 side streams: rpvg_hip_create_with_streams) and an estimator of its own, take the uploaded batches in order,
-//                 finish their upload (offsets from their counts, expansion, validation, read totals, haplotype columns) and
-//                 run PathEstimator::estimateBatchSeeded on them.
-// configs[2] of BASELINE.json on one MI355X: 8 ms per resident batch one at a time (two host lanes), 4.3-4.8 through the
-// pipeline with every batch copied inside the clock (190 MB per batch at 52 GB/s: 3.7 ms — the PCIe link is the next bound);
+//                 side streams: rpvg_hip_create_with_streams) and an estimator of its own, take the batches in order, wait for
+//                 those kernels (rpvg_hip_batch_upload_finish_wait) and run PathEstimator::estimateBatchSeeded.
+// configs[2] of BASELINE.json on one MI355X: 7 ms per resident batch one at a time (two host lanes), 4.1-4.5 through the
+// pipeline with every batch copied inside the clock (190 MB per batch at 53 GB/s: 3.6 ms — the PCIe link is the next bound);
 // how it got there: docs/design/history-r05.md.
 // Results are those of the same calls made one after the other: batches do not interact.
 #ifndef RPVG_AMD_BATCH_PIPELINE_HPP
@@ -86,6 +88,7 @@ class BatchPipeline {
         };
 
         void uploadLoop(const int uploader);
+        void queueLoop();
         void workerLoop(const int worker);
         void fail(std::exception_ptr error);
 
@@ -100,6 +103,7 @@ class BatchPipeline {
         std::condition_variable changed;
 
         std::deque<std::unique_ptr<Job> > to_upload;
+        std::deque<std::unique_ptr<Job> > copied;                         // copied, the kernels behind the copies not yet queued
         std::deque<std::unique_ptr<Job> > resident;                       // uploaded, waiting for a worker
         std::set<const void *> busy_estimates;
 
@@ -114,6 +118,7 @@ class BatchPipeline {
         std::vector<double> completions;
 
         std::vector<std::thread> upload_threads;
+        std::thread queue_thread;
         size_t max_resident;
         std::vector<std::thread> worker_threads;
 };

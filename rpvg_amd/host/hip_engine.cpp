@@ -371,7 +371,7 @@ PipelineWorker & HipEngine::lane(const int lane) {
     return *lane_workers.at(lane - 1);
 }
 
-DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch, const bool finish_later) : hip_engine(engine_in), batch(nullptr), unfinished_host_batch(host_batch), unfinished(finish_later) {
+DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch, const bool finish_later) : hip_engine(engine_in), batch(nullptr), unfinished_host_batch(host_batch), unfinished(finish_later), finish_queued(false) {
 
     assert(hip_engine);
 
@@ -402,6 +402,20 @@ DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, con
     HipEngine::check(rpvg_hip_batch_cluster_totals(batch, total_read_count.data(), host_batch.num_clusters), "rpvg_hip_batch_cluster_totals");
 }
 
+void DeviceClusterBatch::queueFinish() {
+
+    assert(unfinished && batch && !finish_queued);
+
+    ScopedPhase queue_phase("device batch: rpvg_hip_batch_upload_finish_queue");
+
+    rpvg_hip_batch * unfinished_batch = batch;
+    batch = nullptr;  // (a batch that fails is freed by the call)
+
+    HipEngine::check(rpvg_hip_batch_upload_finish_queue(hip_engine->ctx(), unfinished_batch, &unfinished_host_batch), "rpvg_hip_batch_upload_finish_queue");
+    batch = unfinished_batch;
+    finish_queued = true;
+}
+
 void DeviceClusterBatch::finish(std::shared_ptr<HipEngine> engine_in) {
 
     assert(unfinished && batch);
@@ -413,14 +427,22 @@ void DeviceClusterBatch::finish(std::shared_ptr<HipEngine> engine_in) {
     batch = nullptr;  // (a batch that fails its second half is freed by the call)
     unfinished = false;
 
-    HipEngine::check(rpvg_hip_batch_upload_finish(hip_engine->ctx(), unfinished_batch, &unfinished_host_batch), "rpvg_hip_batch_upload_finish");
+    if (finish_queued) {
+
+        HipEngine::check(rpvg_hip_batch_upload_finish_wait(unfinished_batch, &unfinished_host_batch), "rpvg_hip_batch_upload_finish_wait");
+
+    } else {
+
+        HipEngine::check(rpvg_hip_batch_upload_finish(hip_engine->ctx(), unfinished_batch, &unfinished_host_batch), "rpvg_hip_batch_upload_finish");
+    }
+
     batch = unfinished_batch;
 
     total_read_count.resize(num_rows.size());
     HipEngine::check(rpvg_hip_batch_cluster_totals(batch, total_read_count.data(), num_rows.size()), "rpvg_hip_batch_cluster_totals");
 }
 
-DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, rpvg_hip_batch * device_batch, const rpvg_cluster_batch & offsets, const std::vector<double> & total_read_count_in) : hip_engine(engine_in), batch(device_batch), total_read_count(total_read_count_in), unfinished_host_batch(offsets), unfinished(false) {
+DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, rpvg_hip_batch * device_batch, const rpvg_cluster_batch & offsets, const std::vector<double> & total_read_count_in) : hip_engine(engine_in), batch(device_batch), total_read_count(total_read_count_in), unfinished_host_batch(offsets), unfinished(false), finish_queued(false) {
 
     assert(hip_engine);
     assert(batch);

@@ -131,6 +131,10 @@ class DeviceClusterBatch {
         DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch, const bool finish_later = false);
         void finish(std::shared_ptr<HipEngine> engine_in);
 
+        // (between the two) the kernels of the second half queued on the uploading engine's context, behind the copies: finish()
+        // then only waits for them (rpvg_hip_batch_upload_finish_queue / _wait)
+        void queueFinish();
+
         // Adopts a batch that was built on the device (row construction, read_rows.hpp).  `offsets` carries
         // cluster_row_off / cluster_path_off only; total_read_count_in the read count of every cluster.
         DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, rpvg_hip_batch * device_batch, const rpvg_cluster_batch & offsets, const std::vector<double> & total_read_count_in);
@@ -169,6 +173,7 @@ class DeviceClusterBatch {
 
         rpvg_cluster_batch unfinished_host_batch;
         bool unfinished;
+        bool finish_queued;
 };
 
 }

@@ -189,3 +189,52 @@ def test_device_columns_and_merge_equal_the_host_path(monkeypatch):
         assert set(gk) == set(rk)
         for key in rk:
             assert small_cases.rel_close(gk[key][0], rk[key][0], rel=1e-4) and small_cases.rel_close(gk[key][1], rk[key][1], rel=1e-4)
+
+
+@pytest.mark.parametrize("steps", ["begin_finish", "begin_queue_wait"])
+def test_an_upload_in_steps_equals_the_upload_in_one_call(hip_ctx, steps):
+    """rpvg_hip_batch_upload_begin (the copies) + _finish (the kernels behind them, any context of the device), and the second half
+    itself as _finish_queue (no wait: a pipeline's uploader goes on copying) + _finish_wait (from any thread): the same batch as
+    rpvg_hip_batch_upload makes — read totals, haplotype columns, an EM solve — and the same message for a row that breaks an
+    invariant."""
+    import ctypes as C
+    clusters = small_cases.make_batch_clusters(9107, n_clusters=20, with_empty=True)
+    batch = ClusterBatch.from_clusters(clusters)
+    whole = hip_ctx.upload(batch)
+    other = hip.Context(0)
+    try:
+        cb = batch.as_c(True)
+        handle = C.c_void_p()
+        hip._check(hip.lib().rpvg_hip_batch_upload_begin(other.handle, C.byref(cb), C.byref(handle)), "rpvg_hip_batch_upload_begin")
+        if steps == "begin_finish":
+            hip._check(hip.lib().rpvg_hip_batch_upload_finish(hip_ctx.handle, handle, C.byref(cb)), "rpvg_hip_batch_upload_finish")
+        else:
+            hip._check(hip.lib().rpvg_hip_batch_upload_finish_queue(other.handle, handle, C.byref(cb)), "rpvg_hip_batch_upload_finish_queue")
+            hip._check(hip.lib().rpvg_hip_batch_upload_finish_wait(handle, C.byref(cb)), "rpvg_hip_batch_upload_finish_wait")
+        stepped = hip.DeviceBatch.__new__(hip.DeviceBatch)
+        stepped.ctx, stepped.host, stepped.handle = hip_ctx, batch, handle
+        try:
+            assert stepped.has_source_columns() and np.array_equal(stepped.cluster_totals(), whole.cluster_totals())
+            for k in range(batch.num_clusters):
+                assert stepped.source_columns(k) == whole.source_columns(k), k
+            mats = [k for k, cl in enumerate(clusters) if cl["rows"]]
+            columns = [list(range(len(clusters[k]["paths"]))) for k in mats]
+            a = hip_ctx.em_solve(stepped, mats, columns)
+            b = hip_ctx.em_solve(whole, mats, columns)
+            assert np.allclose(np.concatenate(a[0]), np.concatenate(b[0]), rtol=1e-9, atol=1e-12) and np.array_equal(a[3], b[3])
+        finally:
+            stepped.free()
+        bad = ClusterBatch.from_clusters(clusters)
+        bad.row_noise[3] = 0.0
+        cb = bad.as_c(True)
+        hip._check(hip.lib().rpvg_hip_batch_upload_begin(other.handle, C.byref(cb), C.byref(handle)), "rpvg_hip_batch_upload_begin")
+        if steps == "begin_finish":
+            rc = hip.lib().rpvg_hip_batch_upload_finish(hip_ctx.handle, handle, C.byref(cb))
+        else:
+            hip._check(hip.lib().rpvg_hip_batch_upload_finish_queue(other.handle, handle, C.byref(cb)), "rpvg_hip_batch_upload_finish_queue")
+            rc = hip.lib().rpvg_hip_batch_upload_finish_wait(handle, C.byref(cb))
+        assert rc != 0 and "row 3 has noise probability 0" in hip.lib().rpvg_hip_last_error().decode()  # (the batch is freed by the call)
+    finally:
+        whole.free()
+        other.close()
+
