@@ -1903,7 +1903,7 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     if (held_back_runs) {
         ok(tmp->rewritten_count.alloc(M));
         r.rewritten_count = tmp->rewritten_count.ptr;
-        *held_back_runs = [r](hipStream_t on, const rpvg_hip_groups::SearchSums * sums) {
+        *held_back_runs = [=](hipStream_t on, const rpvg_hip_groups::SearchSums * sums) {
             ReplayArgs<Arrays> mine = r;
             if (sums) {  // the search has read the matrices as built: the runs, its sums, then the rows
                 mine.part_pair = sums->part_pair;
