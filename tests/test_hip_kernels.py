@@ -1008,3 +1008,29 @@ def test_device_gibbs_sampler_reports_what_it_does_not_take(hip_ctx):
     assert "matrix 7" in str(invalid.value)
     got, consumed, _, (rounds, conditionals) = dg.gibbs([], 2, [], [], [], [], [], np.zeros((0, 624), np.uint32))
     assert got == [] and len(consumed) == 0 and rounds == 0 and conditionals == 0
+
+
+def test_spans_of_a_caller_that_never_reads_the_statistics_are_folded_on_the_way(hip_ctx):
+    """Every kernel family of a call is bracketed by two HIP events until somebody reads the statistics (context.hip, spanBegin);
+    a context that is never asked folds its finished spans every 1 024 without waiting for anything — their events do not pile up,
+    and what they measured is in the statistics when somebody does ask."""
+    clusters = small_cases.make_batch_clusters(995, n_clusters=3, with_empty=False)
+    batch = ClusterBatch.from_clusters(clusters)
+    dev = hip_ctx.upload(batch)
+    try:
+        mats = list(range(len(clusters)))
+        columns = [list(range(len(cl["paths"]))) for cl in clusters]
+        hip_ctx.reset_stats()
+        first = hip_ctx.em_solve(dev, mats, columns)
+        before = hip_ctx.stats()
+        per_call = before["em_sparse_launches"]
+        assert per_call > 0 and before["em_sparse_ms"] > 0
+        calls = 400  # (several spans per call: the list passes 1 024 more than once)
+        for _ in range(calls):
+            last = hip_ctx.em_solve(dev, mats, columns)
+        after = hip_ctx.stats()
+        assert after["em_sparse_launches"] == per_call * (calls + 1)
+        assert after["em_sparse_ms"] > before["em_sparse_ms"] * calls * 0.2
+        assert np.array_equal(first[3], last[3])
+    finally:
+        dev.free()
