@@ -65,6 +65,34 @@ typedef struct rpvg_cluster_batch {
     uint64_t num_entries;              /* NNZ (read with the counts only) */
 } rpvg_cluster_batch;
 
+/* One cluster as the thread that calls PathEstimator::estimate() for it (src/main.cpp:977) flattens it: the arrays of
+ * rpvg_cluster_batch for a single cluster, offsets local and in 32 bits, all of them inside ONE block of page-locked memory
+ * from rpvg_hip_pinned_alloc (include/rpvg_hip.h) that the GPU reads where it lies.  rpvg_hip_batch_upload_segments takes the
+ * segments of the calls that are in flight at once as one batch: no joined copy on the host, no staging, no copy commands —
+ * one kernel pulls the segments over PCIe and writes the device batch.  Every `*_at` is a byte offset from `base`, a multiple
+ * of 8; the arrays must lie inside [base, base + bytes).  Without paths (has_paths = 0: the batch then carries no haplotype
+ * columns) the three path arrays are not read; all segments of a batch with them, or none. */
+typedef struct rpvg_cluster_segment {
+    const void * base;           /* a block from rpvg_hip_pinned_alloc */
+    uint64_t bytes;              /* of the block that the segment uses */
+    uint32_t num_rows;           /* R   */
+    uint32_t num_groups;         /* G   */
+    uint32_t num_entries;        /* NNZ */
+    uint32_t num_paths;          /* P   */
+    uint32_t num_sources;        /* S   */
+    uint32_t has_paths;
+    uint64_t total_read_count;   /* sum of row_count: the flattening thread adds them up on the way */
+    uint64_t row_count_at;       /* uint32 [R]    readCount()                              */
+    uint64_t row_noise_at;       /* double [R]    noiseProb()                              */
+    uint64_t row_grp_off_at;     /* uint32 [R+1]  groups of every row, from 0              */
+    uint64_t grp_idx_off_at;     /* uint32 [G+1]  paths of every group, from 0             */
+    uint64_t grp_prob_at;        /* double [G]    pathProbs()[g].first                     */
+    uint64_t path_idx_at;        /* uint32 [NNZ]  pathProbs()[g].second, cluster-local     */
+    uint64_t path_group_id_at;   /* uint32 [P]    PathInfo::group_id                       */
+    uint64_t path_source_off_at; /* uint32 [P+1]  source ids of every path, from 0         */
+    uint64_t source_id_at;       /* uint32 [S]    PathInfo::source_ids                     */
+} rpvg_cluster_segment;
+
 /* The two long offset arrays of a batch in whichever width its owner wrote them. */
 static inline uint64_t rpvg_batch_row_group_offset(const rpvg_cluster_batch * batch, uint64_t row) {
     return batch->row_grp_off32 ? batch->row_grp_off32[row] : batch->row_grp_off[row];

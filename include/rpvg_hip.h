@@ -98,6 +98,21 @@ int rpvg_hip_batch_upload_finish(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch, con
  * queues, the estimator that takes the batch waits (rpvg_amd/host/batch_pipeline.hpp).  On failure the batch is freed. */
 int rpvg_hip_batch_upload_finish_queue(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch, const rpvg_cluster_batch * host_batch);
 int rpvg_hip_batch_upload_finish_wait(rpvg_hip_batch * batch, const rpvg_cluster_batch * host_batch);
+/* A batch from the segments its callers flattened (include/rpvg_batch.h, rpvg_cluster_segment): what the reference's per-cluster
+ * loop (src/main.cpp:829,976-977) hands to estimate(), one segment per call in flight, joined on the device.  One kernel reads
+ * the segments from page-locked host memory, expands the (probability, path list) groups, validates rows and offsets and writes
+ * every device array of the batch; the haplotype columns follow as in rpvg_hip_batch_upload.  Returns when the batch is
+ * complete; the segments stay untouched until then.  Same results, entry for entry, as rpvg_hip_batch_upload of the joined
+ * batch.  Page-locked blocks for the segments: rpvg_hip_pinned_alloc (cached by size class; a block's capacity is at least the
+ * bytes asked for) / rpvg_hip_pinned_free. */
+int rpvg_hip_batch_upload_segments(rpvg_hip_ctx * ctx, const rpvg_cluster_segment * segments, uint32_t num_segments, rpvg_hip_batch ** batch_out);
+int rpvg_hip_pinned_alloc(uint64_t bytes, void ** host_out);
+/* How the calling thread waits for the GPU inside the calls of this library from now on: it queries for `microseconds` and then
+ * naps between queries (30 us each).  Default 20: a thread that waits for a millisecond-long batch should not hold a core.  A
+ * thread whose callers are blocked behind it for a few hundred microseconds (the leaders of PathEstimator::estimate()'s call
+ * combiner) asks for more: a nap costs 50-80 us of latency per wait. */
+void rpvg_hip_thread_wait_spin_us(uint32_t microseconds);
+void rpvg_hip_pinned_free(void * host);
 /* Read count of every cluster of an uploaded batch (the sum of its rows' read counts, exact), added up on the device behind
  * the copy (src/path_abundance_estimator.cpp:44,291,690: `read_counts.sum()`). */
 int rpvg_hip_batch_cluster_totals(const rpvg_hip_batch * batch, double * totals_out, uint32_t num_clusters);

@@ -51,9 +51,15 @@ static bool searchLaunchesEarly() {
     return early;
 }
 
-static void searchGateEnter(const rpvg_hip_ctx * ctx, hipStream_t stream) {
+// Searches of fewer than 2^17 matrix rows stay outside: they do not fill the GPU, and the batches of PathEstimator::estimate()'s call
+// combiner — a few dozen small clusters each, three of them on the GPU at once — would otherwise run one after the other with a
+// host wait in between.
+constexpr uint64_t kSearchGateRows = 1ull << 17;
+
+static void searchGateEnter(rpvg_hip_ctx * ctx, hipStream_t stream, const uint64_t matrix_rows) {
     static const bool open_gate = RPVG_EXPERIMENT_ENV("RPVG_HIP_NO_SEARCH_GATE") != nullptr;  // A/B knob
-    if (open_gate) return;
+    ctx->search_gate_held = !open_gate && matrix_rows >= kSearchGateRows;
+    if (!ctx->search_gate_held) return;
     hipEvent_t previous = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_search_gate_mutex);
@@ -66,7 +72,9 @@ static void searchGateEnter(const rpvg_hip_ctx * ctx, hipStream_t stream) {
     if (previous && !searchLaunchesEarly()) (void) waitEvent(previous);
 }
 
-static void searchGateLeave(const rpvg_hip_ctx * ctx, hipStream_t stream) {
+static void searchGateLeave(rpvg_hip_ctx * ctx, hipStream_t stream) {
+    if (!ctx->search_gate_held) return;
+    ctx->search_gate_held = false;
     std::lock_guard<std::mutex> lock(g_search_gate_mutex);
     (void) hipEventRecord(ctx->search_done, stream);
     g_search_gate_owner = ctx;
@@ -1435,7 +1443,7 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
         }
     }
     span = ctx->spanBegin(FAM_LOGLIK);
-    searchGateEnter(ctx, st);
+    searchGateEnter(ctx, st, std::accumulate(groups->h_num_rows.begin(), groups->h_num_rows.end(), uint64_t(0)));
     if (side_kernels) ok(ctx->forkAux());
     if (num_big > 0) {
         TableWork tw;

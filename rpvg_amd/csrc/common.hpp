@@ -100,6 +100,7 @@ void poolTrim(int device);
 // device buffer it filled.  RPVG_HIP_PAGEABLE_UPLOADS=1 restores the direct copies (A/B).
 hipError_t pinnedAlloc(void ** ptr, size_t bytes);
 void pinnedFree(void * ptr);
+size_t pinnedCapacity(const void * ptr);  // of a live block of pinnedAlloc that starts at ptr; 0: not one
 void pinnedTrim();
 bool stagedUploads();
 // An upload does not depend on the kernels queued before it on its stream (it fills a fresh block with host data), but
@@ -628,15 +629,21 @@ struct TimedInterval {
 }  // namespace rpvg_hip_detail
 
 namespace rpvg_hip_detail {
-// what the last rpvg_hip_nested_subset_em on a context needed: the next call reserves by it (subset_em.hip)
+// what the calls of rpvg_hip_nested_subset_em on a context needed, per unit of their input (subsets per matrix, list entries per path,
+// kept rows / entries per row / entry of the call's clusters): the largest of the recent calls, fading — the next call reserves by
+// them whatever its size (the batches of PathEstimator::estimate()'s call combiner differ by orders of magnitude from one to the
+// next); and the exact figures of a call that did not fit, for its second attempt (subset_em.hip)
 struct SubsetEmHints {
-    unsigned long long subsets = 0, list_length = 0, rows = 0, entries = 0;
+    double subsets_per_matrix = 0, list_per_path = 0, rows_per_row = 0, entries_per_entry = 0;
+    bool retry = false;
+    unsigned long long retry_subsets = 0, retry_list_length = 0, retry_rows = 0, retry_entries = 0;
 };
 }  // namespace rpvg_hip_detail
 
 struct rpvg_hip_ctx {
     static constexpr int kAuxStreams = 6;
     rpvg_hip_detail::SubsetEmHints subset_hints;
+    bool search_gate_held = false;  // the search this context has queued takes part in "one search at a time" (bounded_search.hip)
     int device = 0;
     hipStream_t stream = nullptr;
     // Side streams for independent launches of one call (size bins of the batched kernels): their tails
@@ -1020,6 +1027,10 @@ hipError_t queueCsrCollapse(rpvg_hip_ctx * ctx, const CsrCollapseInput & in, dou
 hipError_t queueClusterTotals(hipStream_t stream, uint32_t num_clusters, const uint64_t * d_cluster_row_off, const uint32_t * d_row_count_u32, double * d_totals);
 hipError_t queuePathSourceCopies(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_cluster_batch * hb, PathSourcesPending & pending);
 hipError_t queuePathSourceKernels(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, PathSourcesPending & pending, hipStream_t stream);
+// what queuePathSourceCopies reserves for the kernels (column slots, scratch arena, sizes), for a batch whose path arrays some
+// kernel writes on the device instead of a copy from the host (rpvg_hip_batch_upload_segments): b->path_group_id,
+// pending.d_path_source_off / d_source_id and b->cluster_src_off are allocated, not filled; h_cluster_src_off is the caller's
+hipError_t reservePathSources(rpvg_hip_batch * b, uint32_t num_clusters, uint64_t num_paths, uint64_t num_sources, PathSourcesPending & pending);
 // RPVG_HIP_OK; RPVG_HIP_ERR_INVALID for inconsistent offsets.  A batch whose id ranges outgrow the scratch set aside for them
 // simply has no source columns (has_source_columns stays false: the caller groups on the host).
 int finishPathSources(rpvg_hip_batch * b, PathSourcesPending & pending);

@@ -142,6 +142,12 @@ hipError_t pinnedAlloc(void ** ptr, size_t bytes) {
     return hipSuccess;
 }
 
+size_t pinnedCapacity(const void * ptr) {
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    auto it = g_pinned_live.find(const_cast<void *>(ptr));
+    return it == g_pinned_live.end() ? 0 : it->second;
+}
+
 void pinnedFree(void * ptr) {
     if (!ptr) return;
     std::lock_guard<std::mutex> lock(g_pinned_mutex);
@@ -260,6 +266,9 @@ namespace rpvg_hip_detail {
 
 namespace {
 
+// how long a wait of the calling thread queries before it starts to nap (rpvg_hip_thread_wait_spin_us)
+thread_local uint32_t t_spin_us = 20;
+
 template <typename Query>
 hipError_t pollUntilDone(Query query) {
     static const bool spin = std::getenv("RPVG_HIP_SPIN_WAITS") != nullptr;
@@ -270,10 +279,11 @@ hipError_t pollUntilDone(Query query) {
         slack_set = true;
     }
     const auto begin = std::chrono::steady_clock::now();
+    const auto spin_for = std::chrono::microseconds(t_spin_us);
     while (true) {
         const hipError_t e = query();
         if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - begin < std::chrono::microseconds(20)) continue;
+        if (std::chrono::steady_clock::now() - begin < spin_for) continue;
         timespec nap{0, 30000};
         (void) nanosleep(&nap, nullptr);
     }
@@ -884,6 +894,115 @@ bool validateRow(const rpvg_cluster_batch * hb, const uint32_t k, const uint64_t
 
 }  // namespace
 
+namespace {
+// ---- a batch from its callers' segments (include/rpvg_batch.h, rpvg_cluster_segment) ------------------------------------------
+// What the kernel reads per cluster, in page-locked host memory like the segments themselves: the segment's arrays as pointers and
+// where the cluster starts in every array of the device batch.
+struct SegmentEntry {
+    const uint32_t * row_count;
+    const double * row_noise;
+    const uint32_t * row_grp_off;
+    const uint32_t * grp_idx_off;
+    const double * grp_prob;
+    const uint32_t * path_idx;
+    const uint32_t * path_group_id;
+    const uint32_t * path_source_off;
+    const uint32_t * source_id;
+    uint32_t R, G, NNZ, P, S, pad;
+    uint64_t row_base, ent_base, path_base, src_base;
+};
+
+struct SegmentGatherArgs {
+    const SegmentEntry * table;  // [K], host memory
+    uint32_t num_clusters;
+    uint32_t with_paths;
+    uint64_t * cluster_row_off;
+    uint64_t * cluster_path_off;
+    uint64_t * cluster_src_off;
+    double * row_count;
+    double * row_noise;
+    uint64_t * row_ent_off;
+    uint32_t * ent_path;
+    double * ent_prob;
+    uint32_t * path_group_id;
+    uint64_t * path_source_off;
+    uint32_t * source_id;
+    unsigned long long * first_bad;  // smallest (cluster << 8 | kind) of an invalid segment; ~0: none
+};
+
+constexpr uint32_t kSegmentBadNoise = 1, kSegmentBadPath = 2, kSegmentBadOffsets = 3;
+
+// Workgroups (k, y): cluster k's segment, slice y of its rows, groups, entries, paths and source ids.  Everything a thread reads
+// from a segment is an index it has checked against the segment's own sizes first (the host has checked the arrays against the
+// block): a caller's inconsistent offsets end in an error, not in a wild read.  Reads are 4 or 8 bytes per lane, a wave's next to
+// each other: PCIe reads of 256-512 bytes.
+__global__ __launch_bounds__(256) void segmentsGatherKernel(const SegmentGatherArgs a) {
+    __shared__ SegmentEntry s_entry;
+    const uint32_t k = blockIdx.x;
+    if (threadIdx.x < sizeof(SegmentEntry) / 8) {
+        reinterpret_cast<unsigned long long *>(&s_entry)[threadIdx.x] = reinterpret_cast<const unsigned long long *>(a.table + k)[threadIdx.x];
+    }
+    __syncthreads();
+    const SegmentEntry & s = s_entry;
+    const uint32_t t = blockIdx.y * blockDim.x + threadIdx.x, stride = gridDim.y * blockDim.x;
+    uint32_t bad = 0;
+    for (uint32_t r = t; r < s.R; r += stride) {
+        const double noise = s.row_noise[r];
+        const uint32_t g0 = s.row_grp_off[r], g1 = s.row_grp_off[r + 1];
+        if (!(noise > 0 && noise <= 1)) bad = bad ? bad : kSegmentBadNoise;
+        uint64_t first_entry = 0;
+        if (g0 <= g1 && g1 <= s.G && (r > 0 || g0 == 0) && (r + 1 < s.R || g1 == s.G)) {
+            first_entry = s.grp_idx_off[g0];
+            if (first_entry > s.NNZ) bad = kSegmentBadOffsets;
+        } else {
+            bad = kSegmentBadOffsets;
+        }
+        a.row_count[s.row_base + r] = static_cast<double>(s.row_count[r]);
+        a.row_noise[s.row_base + r] = noise;
+        a.row_ent_off[s.row_base + r] = s.ent_base + first_entry;
+    }
+    for (uint32_t g = t; g < s.G; g += stride) {
+        const uint32_t e0 = s.grp_idx_off[g], e1 = s.grp_idx_off[g + 1];
+        if (e0 <= e1 && e1 <= s.NNZ && (g > 0 || e0 == 0) && (g + 1 < s.G || e1 == s.NNZ)) {
+            const double prob = s.grp_prob[g];
+            for (uint32_t e = e0; e < e1; ++e) a.ent_prob[s.ent_base + e] = prob;
+        } else {
+            bad = kSegmentBadOffsets;
+        }
+    }
+    for (uint32_t e = t; e < s.NNZ; e += stride) {
+        const uint32_t path = s.path_idx[e];
+        if (!(path < s.P)) bad = bad ? bad : kSegmentBadPath;
+        a.ent_path[s.ent_base + e] = path;
+    }
+    if (a.with_paths) {
+        for (uint32_t p = t; p < s.P; p += stride) {
+            const uint32_t s0 = s.path_source_off[p], s1 = s.path_source_off[p + 1];
+            if (!(s0 <= s1 && s1 <= s.S && (p > 0 || s0 == 0) && (p + 1 < s.P || s1 == s.S))) bad = kSegmentBadOffsets;
+            a.path_group_id[s.path_base + p] = s.path_group_id[p];
+            a.path_source_off[s.path_base + p] = s.src_base + s0;
+        }
+        for (uint32_t i = t; i < s.S; i += stride) a.source_id[s.src_base + i] = s.source_id[i];
+    }
+    if (t == 0) {
+        a.cluster_row_off[k] = s.row_base;
+        a.cluster_path_off[k] = s.path_base;
+        a.row_ent_off[s.row_base + s.R] = s.ent_base + s.NNZ;  // (the next cluster's first row writes the same value)
+        if (a.with_paths) {
+            a.cluster_src_off[k] = s.src_base;
+            a.path_source_off[s.path_base + s.P] = s.src_base + s.S;
+        }
+        if (k + 1 == a.num_clusters) {
+            a.cluster_row_off[k + 1] = s.row_base + s.R;
+            a.cluster_path_off[k + 1] = s.path_base + s.P;
+            if (a.with_paths) a.cluster_src_off[k + 1] = s.src_base + s.S;
+        }
+    }
+    if (bad) atomicMin(a.first_bad, (static_cast<unsigned long long>(k) << 8) | bad);
+}
+
+}  // namespace
+
 // The two halves of an upload.  Begin: offsets checked, copies queued on `ctx` (an uploader's stream, usually).  Finish: the
 // kernels behind the copies — expansion of the (probability, path list) groups, row meta data, validation, read totals, the
 // haplotype columns — on any context of the device, and the small results they bring back.
@@ -1184,6 +1303,180 @@ int rpvg_hip_batch_upload_finish(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch, con
     RPVG_REQUIRE(hb->num_clusters == batch->num_clusters && hb->cluster_row_off && hb->cluster_row_off[hb->num_clusters] == batch->num_rows,
                  "rpvg_hip_batch_upload_finish: not the host batch the upload began with");
     return uploadFinish(ctx, batch, hb);
+}
+
+void rpvg_hip_thread_wait_spin_us(uint32_t microseconds) { t_spin_us = microseconds; }
+
+int rpvg_hip_pinned_alloc(uint64_t bytes, void ** host_out) {
+    RPVG_REQUIRE(host_out != nullptr, "rpvg_hip_pinned_alloc: host_out is NULL");
+    *host_out = nullptr;
+    const hipError_t e = pinnedAlloc(host_out, std::max<uint64_t>(bytes, 8));
+    if (e != hipSuccess) {
+        setError("rpvg_hip_pinned_alloc: %llu bytes: %s", static_cast<unsigned long long>(bytes), hipGetErrorString(e));
+        return RPVG_HIP_ERR_ALLOC;
+    }
+    return RPVG_HIP_OK;
+}
+
+void rpvg_hip_pinned_free(void * host) { pinnedFree(host); }
+
+int rpvg_hip_batch_upload_segments(rpvg_hip_ctx * ctx, const rpvg_cluster_segment * segments, uint32_t K, rpvg_hip_batch ** batch_out) {
+    RPVG_REQUIRE(ctx != nullptr && batch_out != nullptr && (segments != nullptr || K == 0), "rpvg_hip_batch_upload_segments: NULL argument");
+    *batch_out = nullptr;
+    std::unique_ptr<HostScope> scope(new HostScope("batch_upload_segments: host checks + table"));
+    const bool with_paths = K > 0 && segments[0].has_paths != 0;
+    uint64_t R = 0, NNZ = 0, P = 0, S = 0, most_work = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+        const rpvg_cluster_segment & g = segments[k];
+        RPVG_REQUIRE(g.base != nullptr && pinnedCapacity(g.base) >= g.bytes, "rpvg_hip_batch_upload_segments: segment %u does not lie in a block of rpvg_hip_pinned_alloc", k);
+        RPVG_REQUIRE((g.has_paths != 0) == with_paths, "rpvg_hip_batch_upload_segments: segment %u: all segments of a batch carry their paths, or none", k);
+        RPVG_REQUIRE(g.num_paths <= 0x7fffffffu, "rpvg_hip_batch_upload_segments: segment %u has too many paths", k);
+        auto inside = [&](const uint64_t at, const uint64_t count, const uint64_t width) { return (at & 7) == 0 && at <= g.bytes && count * width <= g.bytes - at; };
+        bool fits = inside(g.row_count_at, g.num_rows, 4) && inside(g.row_noise_at, g.num_rows, 8) && inside(g.row_grp_off_at, static_cast<uint64_t>(g.num_rows) + 1, 4) &&
+                    inside(g.grp_idx_off_at, static_cast<uint64_t>(g.num_groups) + 1, 4) && inside(g.grp_prob_at, g.num_groups, 8) && inside(g.path_idx_at, g.num_entries, 4);
+        if (with_paths) {
+            fits = fits && inside(g.path_group_id_at, g.num_paths, 4) && inside(g.path_source_off_at, static_cast<uint64_t>(g.num_paths) + 1, 4) && inside(g.source_id_at, g.num_sources, 4);
+        }
+        RPVG_REQUIRE(fits, "rpvg_hip_batch_upload_segments: an array of segment %u is misaligned or outside its block", k);
+        RPVG_REQUIRE(g.num_rows > 0 || (g.num_groups == 0 && g.num_entries == 0), "rpvg_hip_batch_upload_segments: segment %u has groups without rows", k);
+        R += g.num_rows;
+        NNZ += g.num_entries;
+        P += g.num_paths;
+        S += with_paths ? g.num_sources : 0;
+        most_work = std::max<uint64_t>(most_work, std::max<uint64_t>(std::max(g.num_rows, g.num_groups), std::max(g.num_entries, with_paths ? g.num_sources : 0u)));
+    }
+    RPVG_REQUIRE(NNZ < 0xffffffffull, "rpvg_hip_batch_upload_segments: a batch of 2^32 - 1 entries or more");
+
+    std::unique_lock<std::mutex> lock(ctx->mutex);
+    RPVG_HIP_CHECK(hipSetDevice(ctx->device));
+    std::unique_ptr<rpvg_hip_batch> b(new (std::nothrow) rpvg_hip_batch());
+    if (!b) {
+        setError("rpvg_hip_batch_upload_segments: out of host memory");
+        return RPVG_HIP_ERR_ALLOC;
+    }
+    b->num_clusters = K;
+    b->num_rows = R;
+    b->num_entries = NNZ;
+    b->num_paths = P;
+    b->h_cluster_row_off.assign(K + 1, 0);
+    b->h_cluster_path_off.assign(K + 1, 0);
+    b->h_cluster_ent_off.assign(K + 1, 0);
+    b->h_cluster_total.resize(K);
+    if (with_paths) b->h_cluster_src_off.assign(K + 1, 0);
+    b->upload.reset(new rpvg_hip_batch::UploadInProgress());
+    rpvg_hip_batch::UploadInProgress & up = *b->upload;
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    // the table, and behind it the two words that come back (first invalid segment)
+    const size_t table_bytes = std::max<size_t>(K, 1) * sizeof(SegmentEntry);
+    void * h_table = nullptr;
+    if (pinnedAlloc(&h_table, table_bytes + 16) != hipSuccess) {
+        setError("rpvg_hip_batch_upload_segments: out of page-locked host memory");
+        return RPVG_HIP_ERR_ALLOC;
+    }
+    up.h_results = h_table;  // (freed with the upload)
+    SegmentEntry * table = static_cast<SegmentEntry *>(h_table);
+    for (uint32_t k = 0; k < K; ++k) {
+        const rpvg_cluster_segment & g = segments[k];
+        const unsigned char * base = static_cast<const unsigned char *>(g.base);
+        SegmentEntry & t = table[k];
+        t.row_count = reinterpret_cast<const uint32_t *>(base + g.row_count_at);
+        t.row_noise = reinterpret_cast<const double *>(base + g.row_noise_at);
+        t.row_grp_off = reinterpret_cast<const uint32_t *>(base + g.row_grp_off_at);
+        t.grp_idx_off = reinterpret_cast<const uint32_t *>(base + g.grp_idx_off_at);
+        t.grp_prob = reinterpret_cast<const double *>(base + g.grp_prob_at);
+        t.path_idx = reinterpret_cast<const uint32_t *>(base + g.path_idx_at);
+        t.path_group_id = with_paths ? reinterpret_cast<const uint32_t *>(base + g.path_group_id_at) : nullptr;
+        t.path_source_off = with_paths ? reinterpret_cast<const uint32_t *>(base + g.path_source_off_at) : nullptr;
+        t.source_id = with_paths ? reinterpret_cast<const uint32_t *>(base + g.source_id_at) : nullptr;
+        t.R = g.num_rows;
+        t.G = g.num_groups;
+        t.NNZ = g.num_entries;
+        t.P = g.num_paths;
+        t.S = with_paths ? g.num_sources : 0;
+        t.pad = 0;
+        t.row_base = b->h_cluster_row_off[k];
+        t.ent_base = b->h_cluster_ent_off[k];
+        t.path_base = b->h_cluster_path_off[k];
+        t.src_base = with_paths ? b->h_cluster_src_off[k] : 0;
+        b->h_cluster_row_off[k + 1] = t.row_base + t.R;
+        b->h_cluster_ent_off[k + 1] = t.ent_base + t.NNZ;
+        b->h_cluster_path_off[k + 1] = t.path_base + t.P;
+        if (with_paths) b->h_cluster_src_off[k + 1] = t.src_base + t.S;
+        b->h_cluster_total[k] = static_cast<double>(g.total_read_count);
+    }
+    unsigned long long * h_first_bad = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(h_table) + table_bytes);
+    *h_first_bad = ~0ull;
+
+    scope.reset(new HostScope("batch_upload_segments: kernels queued"));
+    ok(b->cluster_row_off.alloc(K + 1));
+    ok(b->cluster_path_off.alloc(K + 1));
+    ok(b->row_count.alloc(R));
+    ok(b->row_noise.alloc(R));
+    ok(b->row_ent_off.alloc(R + 1));
+    ok(b->ent_path.alloc(NNZ));
+    ok(b->ent_prob.alloc(NNZ));
+    ok(up.d_first_bad_row.alloc(1));
+    if (e == hipSuccess && with_paths) ok(reservePathSources(b.get(), K, P, S, up.path_sources));
+    const bool sources = with_paths && up.path_sources.copied;
+    if (e == hipSuccess) ok(hipMemsetAsync(up.d_first_bad_row.ptr, 0xFF, sizeof(unsigned long long), st));
+    const int span = ctx->spanBegin(FAM_BUILD, st);
+    if (e == hipSuccess && K > 0) {
+        SegmentGatherArgs a;
+        a.table = table;
+        a.num_clusters = K;
+        a.with_paths = sources ? 1 : 0;
+        a.cluster_row_off = b->cluster_row_off.ptr;
+        a.cluster_path_off = b->cluster_path_off.ptr;
+        a.cluster_src_off = sources ? b->cluster_src_off.ptr : nullptr;
+        a.row_count = b->row_count.ptr;
+        a.row_noise = b->row_noise.ptr;
+        a.row_ent_off = b->row_ent_off.ptr;
+        a.ent_path = b->ent_path.ptr;
+        a.ent_prob = b->ent_prob.ptr;
+        a.path_group_id = sources ? b->path_group_id.ptr : nullptr;
+        a.path_source_off = sources ? up.path_sources.d_path_source_off.ptr : nullptr;
+        a.source_id = sources ? up.path_sources.d_source_id.ptr : nullptr;
+        a.first_bad = up.d_first_bad_row.ptr;
+        // slices per cluster: four items of the largest cluster's longest array per thread, 64 at the most (a cluster of a million
+        // rows: sixty passes of 16 384 threads)
+        const uint32_t slices = static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(1, (most_work + 1023) / 1024)));
+        segmentsGatherKernel<<<dim3(K, slices), dim3(256), 0, st>>>(a);
+        ok(hipGetLastError());
+    }
+    if (e == hipSuccess && sources) ok(queuePathSourceKernels(ctx, b.get(), up.path_sources, st));
+    ctx->spanEnd(span);
+    ctx->stats.build_launches += sources ? 3 : 1;
+    ctx->stats.h2d_bytes += static_cast<double>(R * 16 + NNZ * 4 + P * 8 + S * 4);  // (what the kernel pulls: no copy command)
+    if (e == hipSuccess) ok(hipMemcpyAsync(h_first_bad, up.d_first_bad_row.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (e == hipSuccess) ok(hipEventCreateWithFlags(&up.finished, hipEventDisableTiming));
+    if (e == hipSuccess) ok(hipEventRecord(up.finished, st));
+    if (e != hipSuccess) {
+        setError("rpvg_hip_batch_upload_segments: %s", hipGetErrorString(e));
+        (void) hipStreamSynchronize(st);
+        return (e == hipErrorOutOfMemory) ? RPVG_HIP_ERR_ALLOC : RPVG_HIP_ERR_RUNTIME;
+    }
+    lock.unlock();
+    scope.reset(new HostScope("batch_upload_segments: wait for the kernels"));
+    e = waitEvent(up.finished);
+    if (e != hipSuccess) {
+        setError("rpvg_hip_batch_upload_segments: %s", hipGetErrorString(e));
+        return RPVG_HIP_ERR_RUNTIME;
+    }
+    if (*h_first_bad != ~0ull) {
+        const unsigned long long k = *h_first_bad >> 8, kind = *h_first_bad & 0xff;
+        setError("rpvg_hip_batch_upload_segments: cluster %llu of the batch: %s", k,
+                 kind == kSegmentBadNoise ? "a row has a noise probability outside (0, 1]"
+                 : kind == kSegmentBadPath ? "a row refers to a path outside its cluster"
+                                           : "inconsistent row, group, entry or source offsets");
+        return RPVG_HIP_ERR_INVALID;
+    }
+    const int sources_rc = finishPathSources(b.get(), up.path_sources);
+    if (sources_rc != RPVG_HIP_OK) return sources_rc;
+    b->upload.reset();
+    *batch_out = b.release();
+    return RPVG_HIP_OK;
 }
 
 void rpvg_hip_batch_free(rpvg_hip_ctx * ctx, rpvg_hip_batch * batch) {

@@ -283,6 +283,22 @@ hipError_t queueClusterTotals(hipStream_t stream, const uint32_t num_clusters, c
     return hipGetLastError();
 }
 
+// the column slots of every cluster (by bounds: as many as it has (haplotype, path) incidences), the scratch of the clusters whose
+// id range or path count outgrows LDS (eight words per incidence, at least 128 MB) and the sizes that come back
+static hipError_t reserveColumnSlots(rpvg_hip_batch * b, const uint32_t K, const uint64_t S, PathSourcesPending & pending) {
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    ok(b->src_col_count.alloc(S));
+    ok(b->src_col_end.alloc(S));
+    ok(b->src_col_path.alloc(S));
+    pending.arena_words = std::max<unsigned long long>(1ull << 24, 8ull * S);
+    pending.num_sources = S;
+    ok(pending.d_arena.alloc(pending.arena_words));
+    ok(pending.d_sizes.alloc(4 * static_cast<size_t>(K) + 8));  // (layout: queuePathSourceKernels)
+    if (e == hipSuccess && pinnedAlloc(&pending.h_sizes, (3 * static_cast<size_t>(K) + 4) * sizeof(uint32_t)) != hipSuccess) e = hipErrorOutOfMemory;
+    return e;
+}
+
 hipError_t queuePathSourceCopies(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const rpvg_cluster_batch * hb, PathSourcesPending & pending) {
     const uint32_t K = hb->num_clusters;
     const uint64_t P = hb->cluster_path_off[K];
@@ -300,15 +316,21 @@ hipError_t queuePathSourceCopies(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const r
     ok(pending.d_source_id.upload(hb->source_id, S, st));
     ok(b->cluster_src_off.upload(b->h_cluster_src_off.data(), K + 1, st));
     ctx->stats.h2d_bytes += static_cast<double>(P * 12 + S * 4 + K * 8);
-    ok(b->src_col_count.alloc(S));
-    ok(b->src_col_end.alloc(S));
-    ok(b->src_col_path.alloc(S));
-    // scratch of the clusters whose id range or path count outgrows LDS: eight words per incidence, at least 128 MB
-    pending.arena_words = std::max<unsigned long long>(1ull << 24, 8ull * S);
-    pending.num_sources = S;
-    ok(pending.d_arena.alloc(pending.arena_words));
-    ok(pending.d_sizes.alloc(4 * static_cast<size_t>(K) + 8));  // (layout: queuePathSourceKernels)
-    if (e == hipSuccess && pinnedAlloc(&pending.h_sizes, (3 * static_cast<size_t>(K) + 4) * sizeof(uint32_t)) != hipSuccess) e = hipErrorOutOfMemory;
+    ok(reserveColumnSlots(b, K, S, pending));
+    pending.copied = (e == hipSuccess);
+    return e;
+}
+
+hipError_t reservePathSources(rpvg_hip_batch * b, const uint32_t K, const uint64_t P, const uint64_t S, PathSourcesPending & pending) {
+    pending.K = K;
+    if (K == 0 || P == 0 || S == 0 || S > 0xfffffff0ull) return hipSuccess;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    ok(b->path_group_id.alloc(P));
+    ok(pending.d_path_source_off.alloc(P + 1));
+    ok(pending.d_source_id.alloc(S));
+    ok(b->cluster_src_off.alloc(K + 1));
+    ok(reserveColumnSlots(b, K, S, pending));
     pending.copied = (e == hipSuccess);
     return e;
 }

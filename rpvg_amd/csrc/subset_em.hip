@@ -777,12 +777,13 @@ struct rpvg_hip_subset_em {
     }
 };
 
-extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_groups * groups,
-                                         const uint32_t * column_counts, double min_rel_likelihood, double min_hap_prob,
-                                         uint32_t max_em_its, double max_rel_em_conv, double collapse_precision,
-                                         rpvg_hip_subset_em ** result_out) {
-    RPVG_REQUIRE(ctx && batch && groups && result_out, "rpvg_hip_nested_subset_em: NULL argument");
-    *result_out = nullptr;
+// One attempt with the capacities the context's hints give.  *did_not_fit: the reserved capacity was too small — the hints now hold
+// what this very call needs and a second attempt fits.
+static int nestedSubsetEmAttempt(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_groups * groups,
+                                 const uint32_t * column_counts, double min_rel_likelihood, double min_hap_prob,
+                                 uint32_t max_em_its, double max_rel_em_conv, double collapse_precision,
+                                 rpvg_hip_subset_em ** result_out, bool * did_not_fit) {
+    *did_not_fit = false;
     RPVG_REQUIRE(min_rel_likelihood > 0, "rpvg_hip_nested_subset_em: min_rel_likelihood must be positive");
     RPVG_REQUIRE(max_em_its > 0, "rpvg_hip_nested_subset_em: max_em_its must be positive");
     RPVG_REQUIRE(groups->batch == batch, "rpvg_hip_nested_subset_em: the matrices were built on another batch");
@@ -834,11 +835,21 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
     // Capacities: what the last call on this context needed, with headroom; a first call plans with eight subsets' worth of
     // every cluster.  A call that does not fit reports what it needed (the next one fits) and is not taken.
     SubsetEmHints & hints = ctx->subset_hints;
-    const unsigned long long cap_subsets = std::min<unsigned long long>(slots, hints.subsets ? hints.subsets + hints.subsets / 4 + 256 : std::max<unsigned long long>(8ull * M, 16384));
-    const unsigned long long cap_length = std::max<unsigned long long>(2 * hints.list_length, std::max<unsigned long long>(8 * lane_paths, 1u << 20));
+    auto planned = [](const double per_unit, const unsigned long long units, const double headroom) {
+        return static_cast<unsigned long long>(std::ceil(per_unit * headroom * static_cast<double>(units)));
+    };
+    unsigned long long cap_subsets = std::min<unsigned long long>(slots, hints.subsets_per_matrix > 0 ? planned(hints.subsets_per_matrix, M, 1.25) + 256 : std::max<unsigned long long>(8ull * M, 16384));
+    unsigned long long cap_length = std::max<unsigned long long>(planned(hints.list_per_path, lane_paths, 2.0), std::max<unsigned long long>(8 * lane_paths, 1u << 20));
+    unsigned long long cap_rows = hints.rows_per_row > 0 ? planned(hints.rows_per_row, lane_rows, 1.25) + 65536 : 8 * lane_rows;
+    unsigned long long cap_entries = hints.entries_per_entry > 0 ? planned(hints.entries_per_entry, lane_entries, 1.25) + 65536 : 8 * lane_entries;
+    if (hints.retry) {  // the second attempt of a call that did not fit: what it reported, exactly
+        cap_subsets = std::min<unsigned long long>(slots, std::max(cap_subsets, hints.retry_subsets + 64));
+        cap_length = std::max(cap_length, hints.retry_list_length + 64);
+        cap_rows = std::max(cap_rows, hints.retry_rows + 64);
+        cap_entries = std::max(cap_entries, hints.retry_entries + 64);
+        hints.retry = false;
+    }
     const unsigned long long cap_columns = cap_length;
-    const unsigned long long cap_rows = hints.rows ? hints.rows + hints.rows / 4 + 65536 : 8 * lane_rows;
-    const unsigned long long cap_entries = hints.entries ? hints.entries + hints.entries / 4 + 65536 : 8 * lane_entries;
     const unsigned long long cap_items = cap_rows / emFillSegmentRows() + cap_subsets;
 
     scope.reset(new HostScope("subset em: search + kernels queued"));
@@ -1095,10 +1106,15 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
     }
     const SubsetHeader got = *h_header;
     pinnedFree(pinned_header);
-    hints.subsets = got.subsets;
-    hints.list_length = got.list_length;
-    hints.rows = got.rows;
-    hints.entries = got.entries;
+    {   // per unit of input, the largest of the recent calls (a call's figure fades by a tenth with every call after it)
+        auto fold = [](double & kept, const unsigned long long needed, const unsigned long long units) {
+            kept = std::max(0.9 * kept, static_cast<double>(needed) / static_cast<double>(std::max<unsigned long long>(units, 1)));
+        };
+        fold(hints.subsets_per_matrix, got.subsets, M);
+        fold(hints.list_per_path, got.list_length, lane_paths);
+        fold(hints.rows_per_row, got.rows, lane_rows);
+        fold(hints.entries_per_entry, got.entries, lane_entries);
+    }
     if (got.build_bad) {
         (void) hipStreamSynchronize(st);
         setError(got.build_bad == 2 ? "rpvg_hip_groups_build: a group lists a path twice" : "rpvg_hip_groups_build: a group refers to a path outside its cluster");
@@ -1108,7 +1124,15 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
     if (got.overflow) {
         (void) hipStreamSynchronize(st);  // (the kernels behind the header saw zero problems)
         setError("rpvg_hip_nested_subset_em: not taken (%llu subsets, %llu rows, %llu entries, %llu selected-diplotype overflows: over the reserved "
-                 "capacity; the next call on this context plans with these figures)", got.subsets, got.rows, got.entries, got.select_overflow);
+                 "capacity)", got.subsets, got.rows, got.entries, got.select_overflow);
+        if (!got.select_overflow) {  // (a matrix that selects more diplotypes than the select kernel holds fits no capacity)
+            hints.retry = true;
+            hints.retry_subsets = got.subsets;
+            hints.retry_list_length = std::max(got.list_length, got.columns);
+            hints.retry_rows = got.rows;
+            hints.retry_entries = got.entries;
+            *did_not_fit = true;
+        }
         return RPVG_HIP_ERR_UNSUPPORTED;
     }
     // exactly what there is: one block, one copy, behind the EM kernels
@@ -1159,6 +1183,27 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
                    reinterpret_cast<const uint32_t *>(host + lay.kept_entries), v.iterations);
     *result_out = res.release();
     return RPVG_HIP_OK;
+}
+
+extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_groups * groups,
+                                         const uint32_t * column_counts, double min_rel_likelihood, double min_hap_prob,
+                                         uint32_t max_em_its, double max_rel_em_conv, double collapse_precision,
+                                         rpvg_hip_subset_em ** result_out) {
+    RPVG_REQUIRE(ctx && batch && groups && result_out, "rpvg_hip_nested_subset_em: NULL argument");
+    *result_out = nullptr;
+    // Capacities are planned from what recent calls needed per unit of input; a call that outgrows them learns what it needs from
+    // its own header and runs again — the search once more, which is cheap next to what the caller would otherwise do (the three
+    // separate calls with the subsets on the host).
+    bool did_not_fit = false;
+    int rc = nestedSubsetEmAttempt(ctx, batch, groups, column_counts, min_rel_likelihood, min_hap_prob, max_em_its, max_rel_em_conv, collapse_precision,
+                                   result_out, &did_not_fit);
+    if (rc == RPVG_HIP_ERR_UNSUPPORTED && did_not_fit) {
+        static const bool trace = std::getenv("RPVG_AMD_TRACE") != nullptr;
+        if (trace) std::fprintf(stderr, "[rpvg_hip trace]   subset em: second attempt (%s)\n", rpvg_hip_last_error());
+        rc = nestedSubsetEmAttempt(ctx, batch, groups, column_counts, min_rel_likelihood, min_hap_prob, max_em_its, max_rel_em_conv, collapse_precision,
+                                   result_out, &did_not_fit);
+    }
+    return rc;
 }
 
 extern "C" int rpvg_hip_subset_em_get(const rpvg_hip_subset_em * result, rpvg_hip_subset_em_view * view_out) {

@@ -33,6 +33,7 @@ EXPORTS = [
     "rpvg_hip_batch_cluster_totals", "rpvg_hip_batch_has_source_columns", "rpvg_hip_batch_source_columns_sizes",
     "rpvg_hip_batch_source_columns_get", "rpvg_hip_groups_build_from_sources", "rpvg_hip_batch_upload_begin", "rpvg_hip_batch_upload_finish", "rpvg_hip_create_with_streams",
     "rpvg_hip_batch_upload_finish_queue", "rpvg_hip_batch_upload_finish_wait",
+    "rpvg_hip_batch_upload_segments", "rpvg_hip_pinned_alloc", "rpvg_hip_pinned_free", "rpvg_hip_thread_wait_spin_us",
 ]
 
 COMM_ID_BYTES = 128  # RPVG_HIP_COMM_ID_BYTES
@@ -138,11 +139,82 @@ def device_count() -> int:
     return n.value if rc == 0 else 0
 
 
+class CClusterSegment(C.Structure):
+    """rpvg_cluster_segment (include/rpvg_batch.h)."""
+    _fields_ = [("base", C.c_void_p), ("bytes", C.c_uint64), ("num_rows", C.c_uint32), ("num_groups", C.c_uint32), ("num_entries", C.c_uint32),
+                ("num_paths", C.c_uint32), ("num_sources", C.c_uint32), ("has_paths", C.c_uint32), ("total_read_count", C.c_uint64),
+                ("row_count_at", C.c_uint64), ("row_noise_at", C.c_uint64), ("row_grp_off_at", C.c_uint64), ("grp_idx_off_at", C.c_uint64),
+                ("grp_prob_at", C.c_uint64), ("path_idx_at", C.c_uint64), ("path_group_id_at", C.c_uint64), ("path_source_off_at", C.c_uint64),
+                ("source_id_at", C.c_uint64)]
+
+
+class PinnedSegments:
+    """The clusters of a ClusterBatch as one rpvg_cluster_segment each, every segment in a page-locked block of its own
+    (rpvg_hip_pinned_alloc) — what the threads of a team calling PathEstimator::estimate() hand to the call combiner."""
+
+    def __init__(self, host: ClusterBatch, with_paths: bool = True):
+        L = lib()
+        L.rpvg_hip_pinned_free.argtypes = [C.c_void_p]
+        K = host.num_clusters
+        self.blocks = []
+        self.segments = (CClusterSegment * max(K, 1))()
+        self.arrays = []  # numpy views of the blocks, per cluster: name -> array (tests corrupt them)
+        for k in range(K):
+            r0, r1 = int(host.cluster_row_off[k]), int(host.cluster_row_off[k + 1])
+            p0, p1 = int(host.cluster_path_off[k]), int(host.cluster_path_off[k + 1])
+            g0, g1 = int(host.row_grp_off[r0]), int(host.row_grp_off[r1])
+            e0, e1 = int(host.grp_idx_off[g0]), int(host.grp_idx_off[g1])
+            s0, s1 = (int(host.path_source_off[p0]), int(host.path_source_off[p1])) if with_paths else (0, 0)
+            pieces = [("row_noise", host.row_noise[r0:r1], np.float64), ("grp_prob", host.grp_prob[g0:g1], np.float64),
+                      ("row_count", host.row_count[r0:r1], np.uint32), ("row_grp_off", host.row_grp_off[r0:r1 + 1] - g0, np.uint32),
+                      ("grp_idx_off", host.grp_idx_off[g0:g1 + 1] - e0, np.uint32), ("path_idx", host.path_idx[e0:e1], np.uint32)]
+            if with_paths:
+                pieces += [("path_group_id", host.path_group_id[p0:p1], np.uint32), ("path_source_off", host.path_source_off[p0:p1 + 1] - s0, np.uint32),
+                           ("source_id", host.source_id[s0:s1], np.uint32)]
+            at, places = 0, {}
+            for name, values, dt in pieces:
+                places[name] = at
+                at += (len(values) * np.dtype(dt).itemsize + 7) & ~7
+            block = C.c_void_p()
+            _check(L.rpvg_hip_pinned_alloc(C.c_uint64(max(at, 8)), C.byref(block)), "rpvg_hip_pinned_alloc")
+            self.blocks.append(block)
+            raw = (C.c_ubyte * max(at, 8)).from_address(block.value)
+            views = {}
+            for name, values, dt in pieces:
+                view = np.frombuffer(raw, dtype=dt, count=len(values), offset=places[name])
+                view[:] = np.asarray(values).astype(dt)
+                views[name] = view
+            self.arrays.append(views)
+            seg = self.segments[k]
+            seg.base, seg.bytes = block.value, max(at, 8)
+            seg.num_rows, seg.num_groups, seg.num_entries, seg.num_paths, seg.num_sources = r1 - r0, g1 - g0, e1 - e0, p1 - p0, s1 - s0
+            seg.has_paths = 1 if with_paths else 0
+            seg.total_read_count = int(host.row_count[r0:r1].astype(np.uint64).sum())
+            for name in places:
+                setattr(seg, name + "_at", places[name])
+        self.count = K
+
+    def free(self):
+        for block in self.blocks:
+            lib().rpvg_hip_pinned_free(block)
+        self.blocks = []
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class DeviceBatch:
-    def __init__(self, ctx: "Context", host: ClusterBatch, compact: bool = False):
+    def __init__(self, ctx: "Context", host: ClusterBatch, compact: bool = False, segments: "PinnedSegments" = None):
         self.ctx = ctx
         self.host = host
         self.handle = C.c_void_p()
+        if segments is not None:
+            _check(lib().rpvg_hip_batch_upload_segments(ctx.handle, segments.segments, C.c_uint32(segments.count), C.byref(self.handle)),
+                   "rpvg_hip_batch_upload_segments")
+            return
         cb = host.as_c(compact)
         _check(lib().rpvg_hip_batch_upload(ctx.handle, C.byref(cb), C.byref(self.handle)), "rpvg_hip_batch_upload")
 
@@ -413,6 +485,10 @@ class Context:
     def upload(self, host: ClusterBatch, compact: bool = False) -> DeviceBatch:
         """compact: the forms of the two long offset arrays made for the copy (ClusterBatch.as_c)."""
         return DeviceBatch(self, host, compact)
+
+    def upload_segments(self, host: ClusterBatch, segments: PinnedSegments) -> DeviceBatch:
+        """The batch from one page-locked segment per cluster (rpvg_hip_batch_upload_segments)."""
+        return DeviceBatch(self, host, segments=segments)
 
     def groups(self, batch: DeviceBatch, clusters, groups, normalise: bool, collapse_precision: float = 0.0) -> DeviceGroups:
         return DeviceGroups(self, batch, clusters, groups, normalise, collapse_precision)

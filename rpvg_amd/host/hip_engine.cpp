@@ -42,6 +42,13 @@ static int defaultHostLanes() {
 
 HipEngine::HipEngine(const int device, const bool uploader, const int host_lanes_in) : context(nullptr), device_id(device), host_lanes(host_lanes_in > 0 ? std::min(host_lanes_in, max_lanes) : defaultHostLanes()) {
 
+    for (auto & lane_context: lane_contexts) {
+
+        lane_context.store(nullptr);
+    }
+
+    lane_workers.reserve(max_lanes - 1);
+
     keepHeapTop();
 
     // an engine that runs whole batches (one lane) stands next to others like it on the GPU (BatchPipeline): few side streams,
@@ -70,7 +77,7 @@ HipEngine::~HipEngine() {
 
     lane_workers.clear();
 
-    for (auto & lane_context: lane_contexts) {
+    for (auto & lane_context: laneContexts()) {
 
         rpvg_hip_destroy(lane_context);
     }
@@ -112,7 +119,8 @@ void HipEngine::stats(const std::vector<const HipEngine *> & engines, rpvg_hip_k
     for (auto & engine: engines) {
 
         contexts.emplace_back(engine->context);
-        contexts.insert(contexts.end(), engine->lane_contexts.begin(), engine->lane_contexts.end());
+        const auto lane_contexts = engine->laneContexts();
+        contexts.insert(contexts.end(), lane_contexts.begin(), lane_contexts.end());
     }
 
     assert(!contexts.empty());
@@ -207,7 +215,7 @@ void HipEngine::resetStats() const {
 
     check(rpvg_hip_stats_reset(context), "rpvg_hip_stats_reset");
 
-    for (auto & lane_context: lane_contexts) {
+    for (auto & lane_context: laneContexts()) {
 
         check(rpvg_hip_stats_reset(lane_context), "rpvg_hip_stats_reset");
     }
@@ -353,6 +361,21 @@ rpvg_cluster_batch FlatClusterRows::view() const {
     return batch;
 }
 
+std::vector<rpvg_hip_ctx *> HipEngine::laneContexts() const {
+
+    std::vector<rpvg_hip_ctx *> contexts;
+
+    for (auto & lane_context: lane_contexts) {
+
+        if (rpvg_hip_ctx * made = lane_context.load(std::memory_order_acquire)) {
+
+            contexts.emplace_back(made);
+        }
+    }
+
+    return contexts;
+}
+
 PipelineWorker & HipEngine::lane(const int lane) {
 
     assert(lane >= 1 && lane < max_lanes);
@@ -364,11 +387,32 @@ PipelineWorker & HipEngine::lane(const int lane) {
         rpvg_hip_ctx * lane_context = nullptr;
         check(rpvg_hip_create(device_id, &lane_context), "rpvg_hip_create");
 
-        lane_contexts.emplace_back(lane_context);
         lane_workers.emplace_back(new PipelineWorker([]() { RetiredContainers::ofThisThread().dropAll(); }));
+        lane_contexts[lane_workers.size() - 1].store(lane_context, std::memory_order_release);
     }
 
     return *lane_workers.at(lane - 1);
+}
+
+int HipEngine::combinerLane(const int slot) {
+
+    assert(slot >= 0 && slot < max_combiner_slots);
+
+    const int lane = max_lanes + slot;
+
+    if (!lane_contexts[lane - 1].load(std::memory_order_acquire)) {
+
+        std::lock_guard<std::mutex> lock(lane_mutex);
+
+        if (!lane_contexts[lane - 1].load(std::memory_order_acquire)) {
+
+            rpvg_hip_ctx * slot_context = nullptr;
+            check(rpvg_hip_create_with_streams(device_id, 3, &slot_context), "rpvg_hip_create_with_streams");
+            lane_contexts[lane - 1].store(slot_context, std::memory_order_release);
+        }
+    }
+
+    return lane;
 }
 
 DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const rpvg_cluster_batch & host_batch, const bool finish_later) : hip_engine(engine_in), batch(nullptr), unfinished_host_batch(host_batch), unfinished(finish_later), finish_queued(false) {
@@ -400,6 +444,155 @@ DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, con
     // a team of its own on the uploading thread)
     total_read_count.resize(host_batch.num_clusters);
     HipEngine::check(rpvg_hip_batch_cluster_totals(batch, total_read_count.data(), host_batch.num_clusters), "rpvg_hip_batch_cluster_totals");
+}
+
+ClusterSegment::ClusterSegment() : block(nullptr), capacity(0), segment() {}
+
+ClusterSegment::~ClusterSegment() {
+
+    rpvg_hip_pinned_free(block);
+}
+
+void ClusterSegment::flatten(const std::vector<ReadPathProbabilities> & cluster_probs, const std::vector<PathInfo> & paths, const bool with_sources) {
+
+    uint64_t num_groups = 0, num_entries = 0, num_sources = 0, total_read_count = 0;
+
+    for (auto & probs: cluster_probs) {
+
+        num_groups += probs.pathProbs().size();
+        total_read_count += probs.readCount();
+
+        for (auto & path_probs: probs.pathProbs()) {
+
+            num_entries += path_probs.second.size();
+        }
+    }
+
+    for (size_t p = 0; with_sources && p < paths.size(); ++p) {
+
+        num_sources += paths[p].source_ids.size();
+    }
+
+    if (cluster_probs.size() >= 0xFFFFFFFFull || num_groups >= 0xFFFFFFFFull || num_entries >= 0xFFFFFFFFull || num_sources >= 0xFFFFFFFFull) {
+
+        throw EngineError("ClusterSegment: a cluster of 2^32 - 1 rows, groups, entries or source ids, or more");
+    }
+
+    const uint64_t R = cluster_probs.size(), G = num_groups, NNZ = num_entries, P = paths.size(), S = num_sources;
+
+    // the arrays one behind the other, each from a multiple of 8 bytes
+    uint64_t at = 0;
+
+    auto place = [&at](const uint64_t count, const uint64_t width) {
+
+        const uint64_t here = at;
+        at += (count * width + 7) & ~7ull;
+        return here;
+    };
+
+    segment = rpvg_cluster_segment();
+    segment.row_noise_at = place(R, 8);
+    segment.grp_prob_at = place(G, 8);
+    segment.row_count_at = place(R, 4);
+    segment.row_grp_off_at = place(R + 1, 4);
+    segment.grp_idx_off_at = place(G + 1, 4);
+    segment.path_idx_at = place(NNZ, 4);
+    segment.path_group_id_at = place(with_sources ? P : 0, 4);
+    segment.path_source_off_at = place(with_sources ? P + 1 : 0, 4);
+    segment.source_id_at = place(S, 4);
+    segment.bytes = std::max<uint64_t>(at, 8);
+
+    if (segment.bytes > capacity) {
+
+        rpvg_hip_pinned_free(block);
+        block = nullptr;
+        capacity = 0;
+
+        const uint64_t wanted = std::max<uint64_t>(segment.bytes + segment.bytes / 4, 1 << 16);
+        HipEngine::check(rpvg_hip_pinned_alloc(wanted, &block), "rpvg_hip_pinned_alloc");
+        capacity = wanted;
+    }
+
+    unsigned char * base = static_cast<unsigned char *>(block);
+
+    double * row_noise = reinterpret_cast<double *>(base + segment.row_noise_at);
+    double * grp_prob = reinterpret_cast<double *>(base + segment.grp_prob_at);
+    uint32_t * row_count = reinterpret_cast<uint32_t *>(base + segment.row_count_at);
+    uint32_t * row_grp_off = reinterpret_cast<uint32_t *>(base + segment.row_grp_off_at);
+    uint32_t * grp_idx_off = reinterpret_cast<uint32_t *>(base + segment.grp_idx_off_at);
+    uint32_t * path_idx = reinterpret_cast<uint32_t *>(base + segment.path_idx_at);
+
+    uint32_t group = 0, entry = 0;
+
+    for (size_t r = 0; r < R; ++r) {
+
+        const ReadPathProbabilities & probs = cluster_probs[r];
+
+        row_count[r] = probs.readCount();
+        row_noise[r] = probs.noiseProb();
+        row_grp_off[r] = group;
+
+        for (auto & path_probs: probs.pathProbs()) {
+
+            grp_prob[group] = path_probs.first;
+            grp_idx_off[group] = entry;
+
+            std::copy(path_probs.second.begin(), path_probs.second.end(), path_idx + entry);
+            entry += path_probs.second.size();
+            ++group;
+        }
+    }
+
+    row_grp_off[R] = group;
+    grp_idx_off[G] = entry;
+
+    uint32_t * path_group_id = reinterpret_cast<uint32_t *>(base + segment.path_group_id_at);
+    uint32_t * path_source_off = reinterpret_cast<uint32_t *>(base + segment.path_source_off_at);
+    uint32_t * source_id = reinterpret_cast<uint32_t *>(base + segment.source_id_at);
+
+    uint32_t source = 0;
+
+    for (size_t p = 0; with_sources && p < P; ++p) {
+
+        path_group_id[p] = paths[p].group_id;
+        path_source_off[p] = source;
+
+        std::copy(paths[p].source_ids.begin(), paths[p].source_ids.end(), source_id + source);
+        source += paths[p].source_ids.size();
+    }
+
+    if (with_sources) {
+
+        path_source_off[P] = source;
+    }
+
+    segment.base = block;
+    segment.num_rows = R;
+    segment.num_groups = G;
+    segment.num_entries = NNZ;
+    segment.num_paths = P;
+    segment.num_sources = S;
+    segment.has_paths = with_sources ? 1 : 0;
+    segment.total_read_count = total_read_count;
+}
+
+DeviceClusterBatch::DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const std::vector<rpvg_cluster_segment> & segments) : hip_engine(engine_in), batch(nullptr), unfinished_host_batch(), unfinished(false), finish_queued(false) {
+
+    assert(hip_engine);
+
+    ScopedPhase upload_phase("device batch: rpvg_hip_batch_upload_segments");
+    HipEngine::check(rpvg_hip_batch_upload_segments(hip_engine->ctx(), segments.data(), segments.size(), &batch), "rpvg_hip_batch_upload_segments");
+
+    num_rows.reserve(segments.size());
+    num_paths.reserve(segments.size());
+    total_read_count.reserve(segments.size());
+
+    for (auto & segment: segments) {
+
+        num_rows.emplace_back(segment.num_rows);
+        num_paths.emplace_back(segment.num_paths);
+        total_read_count.emplace_back(static_cast<double>(segment.total_read_count));
+    }
 }
 
 void DeviceClusterBatch::queueFinish() {

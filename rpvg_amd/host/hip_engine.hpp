@@ -4,8 +4,11 @@
 #ifndef RPVG_AMD_HIP_ENGINE_HPP
 #define RPVG_AMD_HIP_ENGINE_HPP
 
+#include <array>
+#include <atomic>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -45,8 +48,19 @@ class HipEngine {
         // that the kernels of the two lanes run side by side on the GPU.
         rpvg_hip_ctx * ctx() const {
 
+            // (no lock: the slots of lane_contexts never move and a slot is published when its context exists — a combiner leader
+            // creates its context while another leader's batch runs on the one beside it)
             const int lane = currentLane();
-            return (lane > 0 && static_cast<size_t>(lane) <= lane_contexts.size()) ? lane_contexts[lane - 1] : context;
+
+            if (lane > 0 && static_cast<size_t>(lane) <= lane_contexts.size()) {
+
+                if (rpvg_hip_ctx * lane_context = lane_contexts[lane - 1].load(std::memory_order_acquire)) {
+
+                    return lane_context;
+                }
+            }
+
+            return context;
         }
         int device() const { return device_id; }
         int hostLanes() const { return host_lanes; }
@@ -77,6 +91,14 @@ class HipEngine {
 
         static constexpr int max_lanes = 4;
 
+        // Slot `slot` (0 .. max_combiner_slots - 1) of PathEstimator::estimate()'s call combiner: a device context of its own, made on
+        // first use — lean like the engines of a BatchPipeline (three side streams, the main stream on a hardware queue of its own:
+        // chains of short dependent kernels, several of them on the GPU at once).  Returns the lane id a leader sets as its
+        // currentLane() while its batch runs (ctx() then hands out that context).
+        int combinerLane(const int slot);
+
+        static constexpr int max_combiner_slots = 3;
+
     private:
 
         rpvg_hip_ctx * context;
@@ -84,8 +106,11 @@ class HipEngine {
         int host_lanes;
 
         std::mutex lane_mutex;
-        std::vector<rpvg_hip_ctx *> lane_contexts;
-        std::vector<std::unique_ptr<PipelineWorker> > lane_workers;
+        // (lanes 1 .. max_lanes - 1: the host lanes of a batch; behind them the call combiner's slots; a slot is set once, for good)
+        std::array<std::atomic<rpvg_hip_ctx *>, max_lanes - 1 + max_combiner_slots> lane_contexts;
+        std::vector<std::unique_ptr<PipelineWorker> > lane_workers;  // (under lane_mutex)
+
+        std::vector<rpvg_hip_ctx *> laneContexts() const;
 };
 
 // Flat host copy of the rows of K clusters (the arrays rpvg_cluster_batch
@@ -121,10 +146,39 @@ class FlatClusterRows {
         std::vector<double> row_noise, grp_prob;
 };
 
+// One cluster flattened into page-locked memory that the GPU reads where it lies (include/rpvg_batch.h, rpvg_cluster_segment): what
+// a thread that calls PathEstimator::estimate() makes of its cluster before it parks the call (PathEstimator::CallCombiner).  The
+// block is kept and reused from call to call (a thread's next cluster is rarely larger than its last; it grows by size class).
+class ClusterSegment {
+
+    public:
+
+        ClusterSegment();
+        ~ClusterSegment();
+
+        ClusterSegment(const ClusterSegment &) = delete;
+        ClusterSegment & operator=(const ClusterSegment &) = delete;
+
+        // Two passes over the rows: sizes, then the arrays at their final places.  with_sources: the segment carries
+        // PathInfo::group_id and PathInfo::source_ids (the batch then carries its haplotype columns).
+        void flatten(const std::vector<ReadPathProbabilities> & cluster_probs, const std::vector<PathInfo> & paths, const bool with_sources);
+
+        const rpvg_cluster_segment & view() const { return segment; }
+
+    private:
+
+        void * block;
+        uint64_t capacity;
+        rpvg_cluster_segment segment;
+};
+
 // K clusters resident on the GPU.
 class DeviceClusterBatch {
 
     public:
+
+        // From the segments of K callers (rpvg_hip_batch_upload_segments): no joined host copy, no copy commands.
+        DeviceClusterBatch(std::shared_ptr<HipEngine> engine_in, const std::vector<rpvg_cluster_segment> & segments);
 
         // finish_later: only the copies are made here, on engine_in's context (rpvg_hip_batch_upload_begin) — finish() runs the
         // kernels behind them on another engine of the GPU, which owns the batch from then on; host_batch stays valid until then

@@ -694,26 +694,54 @@ void NestedPathAbundanceEstimator::pathGroupPosteriors(std::vector<GroupPosterio
     }
 }
 
-// Paths grouped by group_id (transcript), groups in first-seen order
-// (src/path_abundance_estimator.cpp:473-491).
+// The paths of every transcript (PathInfo::group_id), transcripts in the order their first path appears, a transcript's paths
+// ascending (what src/path_abundance_estimator.cpp:473-491 returns).  Two flat passes instead of a map of vectors grown path by
+// path: the transcripts are numbered in a sorted id list, counted, and every list is written once at its final size.
 std::vector<std::vector<uint32_t> > NestedPathAbundanceEstimator::findPathGroups(const std::vector<PathInfo> & paths) const {
 
-    std::vector<std::vector<uint32_t> > path_groups;
-    std::map<uint32_t, uint32_t> path_group_indexes;
+    const uint32_t num_paths = paths.size();
 
-    for (size_t i = 0; i < paths.size(); ++i) {
+    // distinct transcript ids, ascending; `order_of[k]`: position of id k in first-appearance order
+    std::vector<uint32_t> ids(num_paths);
 
-        auto path_group_indexes_it = path_group_indexes.emplace(paths.at(i).group_id, path_groups.size());
+    for (uint32_t p = 0; p < num_paths; ++p) {
 
-        if (path_group_indexes_it.second) {
-
-            path_groups.emplace_back(std::vector<uint32_t>());
-        }
-
-        path_groups.at(path_group_indexes_it.first->second).emplace_back(i);
+        ids[p] = paths[p].group_id;
     }
 
-    return path_groups;
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+
+    const uint32_t unseen = std::numeric_limits<uint32_t>::max();
+    std::vector<uint32_t> order_of(ids.size(), unseen), transcript_of(num_paths), sizes;
+
+    for (uint32_t p = 0; p < num_paths; ++p) {
+
+        const uint32_t k = std::lower_bound(ids.begin(), ids.end(), paths[p].group_id) - ids.begin();
+
+        if (order_of[k] == unseen) {
+
+            order_of[k] = sizes.size();
+            sizes.emplace_back(0);
+        }
+
+        transcript_of[p] = order_of[k];
+        ++sizes[order_of[k]];
+    }
+
+    std::vector<std::vector<uint32_t> > transcripts(sizes.size());
+
+    for (size_t t = 0; t < transcripts.size(); ++t) {
+
+        transcripts[t].reserve(sizes[t]);
+    }
+
+    for (uint32_t p = 0; p < num_paths; ++p) {
+
+        transcripts[transcript_of[p]].emplace_back(p);
+    }
+
+    return transcripts;
 }
 
 // Haplotypes (source ids) carrying the identical list of paths form one column;
@@ -894,22 +922,31 @@ void NestedPathAbundanceEstimator::findPathSourceGroups(GroupPosteriorProblem * 
     }
 }
 
-// src/path_abundance_estimator.cpp:548-567
+// One diplotype (set of `group_size` columns) of a transcript per requested sample, drawn from the transcript's posteriors — the
+// draws of src/path_abundance_estimator.cpp:548-567, one per sample slot in slot order, from the caller's generator — and the
+// paths its columns stand for (ascending column order) appended to the slot.
 void NestedPathAbundanceEstimator::sampleGroupPathIndices(std::vector<std::vector<uint32_t> > * path_subset_samples, const GroupPosteriors & group_posteriors, const std::vector<uint32_t> & group, std::mt19937 * mt_rng) const {
 
     assert(group_posteriors.group_size == group_size);
-    std::discrete_distribution<uint32_t> path_group_set_sampler(group_posteriors.posteriors.begin(), group_posteriors.posteriors.end());
 
-    for (auto & path_subset_sample: *path_subset_samples) {
+    const std::vector<double> & weights = group_posteriors.posteriors;
+    std::discrete_distribution<uint32_t> draw_set(weights.begin(), weights.end());
 
-        const size_t sampled_set = path_group_set_sampler(*mt_rng);
-        std::vector<uint32_t> path_group_set(group_posteriors.set(sampled_set), group_posteriors.set(sampled_set) + group_size);
+    uint32_t columns[8];
+    assert(group_size <= 8);
 
-        std::sort(path_group_set.begin(), path_group_set.end());
+    for (size_t slot = 0; slot < path_subset_samples->size(); ++slot) {
 
-        for (auto & path_group: path_group_set) {
+        const uint32_t * members = group_posteriors.set(draw_set(*mt_rng));
 
-            path_subset_sample.emplace_back(group.at(path_group));
+        std::copy(members, members + group_size, columns);
+        std::sort(columns, columns + group_size);
+
+        std::vector<uint32_t> & sample = (*path_subset_samples)[slot];
+
+        for (uint32_t j = 0; j < group_size; ++j) {
+
+            sample.emplace_back(group.at(columns[j]));
         }
     }
 }

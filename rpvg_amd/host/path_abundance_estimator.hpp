@@ -88,6 +88,9 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
 
         bool usesRandomNumbers() const { return !infer_collapsed || use_group_post_gibbs || num_gibbs_samples > 0; }
 
+        // (the one-call device path of estimateClusters: collapsed groups, diploid, branch and bound, no read-count samples)
+        bool wantsSourceColumns() const { return infer_collapsed && !use_group_post_gibbs && group_size == 2 && num_gibbs_samples == 0; }
+
         void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs);
 
     private:

@@ -502,7 +502,15 @@ PathEstimator::PathEstimator(const double prob_precision_in, std::shared_ptr<Hip
 void PathEstimator::estimateAlone(PathClusterEstimates * path_cluster_estimates, const std::vector<ReadPathProbabilities> & cluster_probs, std::mt19937 * mt_rng) {
 
     FlatClusterRows rows;
-    rows.addCluster(cluster_probs, path_cluster_estimates->paths);  // (with PathInfo::group_id / source_ids: the device forms the haplotype columns)
+
+    if (wantsSourceColumns()) {
+
+        rows.addCluster(cluster_probs, path_cluster_estimates->paths);  // (with PathInfo::group_id / source_ids: the device forms the haplotype columns)
+
+    } else {
+
+        rows.addCluster(cluster_probs, path_cluster_estimates->paths.size());
+    }
 
     const DeviceClusterBatch cluster_batch(engine, rows.view());
 
@@ -527,20 +535,24 @@ void PathEstimator::estimateAlone(PathClusterEstimates * path_cluster_estimates,
 }
 
 // The reference calls estimate() once per cluster from every thread of an OpenMP team (src/main.cpp:829,976-977:
-// `schedule(dynamic, 1)`).  One cluster is a poor unit of work for a GPU — a chain of some sixty dependent launches whatever
-// its size — so the calls that are in flight at the same time are joined: a caller flattens its cluster (its own work, on
-// its own thread), parks it and sleeps; the first to park leads — it waits for one of three device contexts of the engine
-// to be free and then until 256 clusters are parked, or nobody has arrived for 50 us, or 500 us have passed, takes what is
-// parked as ONE batch through estimateBatch() on that context (up to three batches of a large team are on the GPU at
-// once; while all three are busy the next batch grows), hands every caller its estimates and its advanced generator, and
-// wakes them.
-// Cluster i of a batch is estimated exactly as estimateBatch() estimates it: the results do not depend on who shared the batch.
-// RPVG_AMD_NO_COMBINER=1: every call a batch of one (estimateAlone).  RPVG_AMD_COMBINE_MAX / _QUIET_US / _LINGER_US: the three bounds.
+// `schedule(dynamic, 1)`).  One cluster is a poor unit of work for a GPU — a chain of dependent launches whatever its size —
+// so the calls that are in flight at the same time are joined.  A caller flattens its cluster on its own thread straight into
+// page-locked memory that the GPU reads where it lies (ClusterSegment: a block per thread, kept from call to call), parks the
+// call and sleeps; the first to park leads: it waits for one of three device contexts of the engine to be free and for the
+// batch to be worth taking — 256 clusters parked, or every thread that is inside estimate() has parked and nobody has arrived
+// for 15 us, or nobody has arrived for 50 us, or 500 us have passed since the first — takes what is parked as ONE batch (the
+// segments as they lie: no joined copy, no staging, no copy commands — rpvg_hip_batch_upload_segments) through estimateBatch()
+// on that context (up to three batches of a large team are on the GPU at once; while all three are busy the next batch
+// grows), hands every caller its estimates and its advanced generator, and wakes them.  A lone caller's batch of one leaves at
+// once.  Cluster i of a batch is estimated exactly as estimateBatch() estimates it: the results do not depend on who shared
+// the batch.  A caller without a generator in a batch of callers with one gets a default-seeded one for the call (models that
+// draw nothing never look at it; the reference would have dereferenced its null pointer).
+// RPVG_AMD_NO_COMBINER=1: every call a batch of one (estimateAlone).  RPVG_AMD_COMBINE_MAX / _QUIET_US / _LINGER_US: the bounds.
 class PathEstimator::CallCombiner {
 
     public:
 
-        CallCombiner() : leader_present(false), busy_slots(0) {
+        CallCombiner() : leader_present(false), busy_slots(0), inside(0), parked_in_batches(0) {
 
             auto setting = [](const char * name, const long fallback) {
 
@@ -549,19 +561,32 @@ class PathEstimator::CallCombiner {
             };
 
             max_clusters = setting("RPVG_AMD_COMBINE_MAX", 256);
+            num_slots = static_cast<int>(std::min<long>(HipEngine::max_combiner_slots, setting("RPVG_AMD_COMBINE_SLOTS", HipEngine::max_combiner_slots)));
             quiet = std::chrono::microseconds(setting("RPVG_AMD_COMBINE_QUIET_US", 50));
+            all_parked_quiet = std::chrono::microseconds(setting("RPVG_AMD_COMBINE_ALL_PARKED_US", 15));
             linger = std::chrono::microseconds(setting("RPVG_AMD_COMBINE_LINGER_US", 500));
         }
 
         void call(PathEstimator * owner, PathClusterEstimates * path_cluster_estimates, const std::vector<ReadPathProbabilities> & cluster_probs, std::mt19937 * mt_rng) {
 
-            Parked me;
+            struct Inside {
+
+                std::atomic<int> & count;
+                explicit Inside(std::atomic<int> & count_in) : count(count_in) { ++count; }
+                ~Inside() { --count; }
+
+            } here(inside);
+
+            // (the calling thread's block: a thread has one call in flight)
+            thread_local ClusterSegment segment;
 
             {
                 ScopedPhase phase("combiner: flatten the cluster (callers, summed)");
-                me.rows.addCluster(cluster_probs, path_cluster_estimates->paths);
+                segment.flatten(cluster_probs, path_cluster_estimates->paths, owner->wantsSourceColumns());
             }
 
+            Parked me;
+            me.segment = &segment.view();
             me.estimates = path_cluster_estimates;
             me.rng = mt_rng;
 
@@ -587,14 +612,17 @@ class PathEstimator::CallCombiner {
                 leader_present = true;
 
                 // a batch leaves when a device context is free for it — while all three are busy the parked clusters simply pile up,
-                // so the batches grow with the load — and, a context being free, when enough clusters are parked or nobody has
-                // arrived for a while
+                // so the batches grow with the load — and, a context being free, when it is full, when waiting can bring nobody
+                // (every thread inside estimate() is parked, here or in a batch that is running: at once if that is this thread
+                // alone, after a short pause otherwise — threads that a finished batch has just released are on their way) or
+                // when nobody has arrived for a while
                 while (true) {
 
-                    const bool slot_free = busy_slots != 7;
-                    const auto deadline = std::min(first_arrival + linger, last_arrival + quiet);
+                    const bool slot_free = busy_slots != (1 << num_slots) - 1;
+                    const bool all_parked = static_cast<size_t>(inside.load()) <= staging.size() + parked_in_batches;
+                    const auto deadline = std::min(first_arrival + linger, last_arrival + ((all_parked && parked_in_batches == 0) ? all_parked_quiet : quiet));
 
-                    if (slot_free && (staging.size() >= static_cast<size_t>(max_clusters) || std::chrono::steady_clock::now() >= deadline)) {
+                    if (slot_free && (staging.size() >= static_cast<size_t>(max_clusters) || (all_parked && inside.load() == 1) || std::chrono::steady_clock::now() >= deadline)) {
 
                         break;
                     }
@@ -612,16 +640,17 @@ class PathEstimator::CallCombiner {
                 std::vector<Parked *> batch;
                 batch.swap(staging);
                 leader_present = false;  // (whoever parks next leads the next batch, while this one runs)
+                parked_in_batches += batch.size();
 
-                // one of the three device contexts of the engine that are not the calling threads' own (lanes 1 to 3)
-                int slot = 1;
+                // one of the combiner's device contexts (HipEngine::combinerLane)
+                int slot = 0;
 
-                while (busy_slots & (1 << (slot - 1))) {
+                while (busy_slots & (1 << slot)) {
 
                     ++slot;
                 }
 
-                busy_slots |= 1 << (slot - 1);
+                busy_slots |= 1 << slot;
                 lock.unlock();
 
                 std::exception_ptr error = nullptr;
@@ -636,7 +665,8 @@ class PathEstimator::CallCombiner {
                 }
 
                 lock.lock();
-                busy_slots &= ~(1 << (slot - 1));
+                busy_slots &= ~(1 << slot);
+                parked_in_batches -= batch.size();
 
                 for (auto & parked: batch) {
 
@@ -659,7 +689,7 @@ class PathEstimator::CallCombiner {
 
         struct Parked {
 
-            FlatClusterRows rows;
+            const rpvg_cluster_segment * segment = nullptr;
             PathClusterEstimates * estimates = nullptr;
             std::mt19937 * rng = nullptr;
             bool done = false;
@@ -672,32 +702,38 @@ class PathEstimator::CallCombiner {
             PhaseTrace::add("combiner: number of batches", 1e-3);
             PhaseTrace::add("combiner: clusters in batches", 1e-3 * batch.size());
 
-            std::unique_ptr<ScopedPhase> phase(new ScopedPhase("combiner: join the clusters"));
+            std::unique_ptr<ScopedPhase> phase(new ScopedPhase("combiner: upload"));
 
-            FlatClusterRows rows;
-            bool all_have_generators = true;
+            std::vector<rpvg_cluster_segment> segments;
+            segments.reserve(batch.size());
+
+            bool any_has_generator = false;
 
             for (auto & parked: batch) {
 
-                rows.append(parked->rows);
-                all_have_generators = all_have_generators && parked->rng;
+                segments.emplace_back(*parked->segment);
+                any_has_generator = any_has_generator || parked->rng;
             }
 
-            phase.reset(new ScopedPhase("combiner: upload"));
-
-            // the engine's context for this thread while the batch runs: lane `slot` (a thread that is not in lane 0 runs its
-            // batch on that lane's context, whole: PathEstimator::runInLanes)
-            owner->engine->lane(slot);  // (creates the lane's context on first use)
-
+            // the engine's context for this thread while the batch runs: the slot's (made on first use; a thread that is not in lane 0
+            // runs its batch on its lane's context, whole: PathEstimator::runInLanes)
             struct LaneGuard {
 
                 int previous;
                 explicit LaneGuard(const int lane) : previous(HipEngine::currentLane()) { HipEngine::currentLane() = lane; }
                 ~LaneGuard() { HipEngine::currentLane() = previous; }
 
-            } lane_guard(slot);
+            } lane_guard(owner->engine->combinerLane(slot));
 
-            const DeviceClusterBatch cluster_batch(owner->engine, rows.view());
+            // (up to sixty-four callers sleep behind this thread: its waits for the GPU query instead of napping — three leaders at the most)
+            struct SpinGuard {
+
+                SpinGuard() { rpvg_hip_thread_wait_spin_us(400); }
+                ~SpinGuard() { rpvg_hip_thread_wait_spin_us(20); }
+
+            } spin_guard;
+
+            const DeviceClusterBatch cluster_batch(owner->engine, segments);
 
             phase.reset(new ScopedPhase("combiner: containers in"));
 
@@ -708,9 +744,9 @@ class PathEstimator::CallCombiner {
 
                 batch_estimates[i] = std::move(*batch[i]->estimates);
 
-                if (all_have_generators) {
+                if (any_has_generator) {
 
-                    rngs.emplace_back(*batch[i]->rng);
+                    rngs.emplace_back(batch[i]->rng ? *batch[i]->rng : std::mt19937());
                 }
             }
 
@@ -719,7 +755,7 @@ class PathEstimator::CallCombiner {
 
             try {
 
-                owner->estimateBatch(&batch_estimates, cluster_batch, all_have_generators ? &rngs : nullptr);
+                owner->estimateBatch(&batch_estimates, cluster_batch, any_has_generator ? &rngs : nullptr);
 
             } catch (...) {
 
@@ -732,7 +768,7 @@ class PathEstimator::CallCombiner {
 
                 *batch[i]->estimates = std::move(batch_estimates[i]);
 
-                if (all_have_generators && !error) {
+                if (batch[i]->rng && !error) {
 
                     *batch[i]->rng = rngs[i];
                 }
@@ -751,9 +787,12 @@ class PathEstimator::CallCombiner {
         std::chrono::steady_clock::time_point first_arrival, last_arrival;
         bool leader_present;
         int busy_slots;
+        std::atomic<int> inside;   // threads inside call(): flattening, parked, or leading
+        size_t parked_in_batches;  // of them: in batches that are running (under `mutex`)
 
         long max_clusters;
-        std::chrono::microseconds quiet, linger;
+        int num_slots;
+        std::chrono::microseconds quiet, all_parked_quiet, linger;
 };
 
 void PathEstimator::estimate(PathClusterEstimates * path_cluster_estimates, const std::vector<ReadPathProbabilities> & cluster_probs, std::mt19937 * mt_rng) {

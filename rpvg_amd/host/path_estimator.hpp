@@ -100,6 +100,11 @@ class PathEstimator {
         // `transcripts`, `haplotype-transcripts` and `haplotypes` runs draw none: SURVEY.md F7).
         virtual bool usesRandomNumbers() const { return false; }
 
+        // Whether estimateBatch() reads the haplotype columns of a batch (DeviceClusterBatch::hasSourceColumns: the batch was
+        // uploaded with PathInfo::group_id and PathInfo::source_ids, and the device formed the columns behind the copy) with the
+        // current settings: estimate() ships the paths' ids with a cluster only then.
+        virtual bool wantsSourceColumns() const { return false; }
+
         // Same, seeding cluster i with mt19937(rng_seed + i) as src/main.cpp:976 does.
         void estimateBatchSeeded(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const uint32_t rng_seed);
 
