@@ -77,10 +77,8 @@ __device__ __forceinline__ double rowLanesSum(double v) {
     return v;
 }
 
-// (The accumulators of a workgroup take their additions through ds_add_f64 in whatever order the row slots arrive: the CSR route
-// is reproducible up to the order of those sums — a last-ulp matter, which can move the iteration at which the stop rule fires for
-// a column that sits exactly on the convergence boundary.  The cross-workgroup reduction below has a fixed order; the dense route
-// has no atomics at all.)
+// (The accumulators: one vector per wavefront, added up in wavefront order, and the workgroups' partial vectors in workgroup order
+// below — the CSR route has one order of additions, like the one-workgroup kernels; the dense route has no atomics at all.)
 // One streaming pass over the problem's CSR.  LANES lanes share a row (1: a thread per row — short rows, the entries of
 // neighbouring rows are neighbours in memory; 4 / 16 / 64: the lanes stride the row's entries, the row sum by shuffles
 // or DPP), and every row slot walks UNROLL rows at a time: their offsets, counts and noise are loaded together and their
@@ -91,12 +89,12 @@ __global__ __launch_bounds__(kGridBlock) void emGridAccumKernel(const GridAccumA
     if (args.ctl->done) return;
     extern __shared__ __attribute__((aligned(16))) double grid_lds[];
     const uint32_t C = args.C, noise_col = C - 1;
+    constexpr uint32_t kWaves = kGridBlock / 64;
     double * a = grid_lds;   // [C]
-    double * t = a + C;      // [C]
-    for (uint32_t j = threadIdx.x; j < C; j += kGridBlock) {
-        a[j] = args.a[j];
-        t[j] = 0.0;
-    }
+    double * t = a + C;      // [kWaves x C]: an accumulator vector per wavefront, added up in wavefront order (em_sparse.hip, emSparseProblem)
+    double * tw = t + static_cast<size_t>(threadIdx.x >> 6) * C;
+    for (uint32_t j = threadIdx.x; j < C; j += kGridBlock) a[j] = args.a[j];
+    for (uint32_t j = threadIdx.x; j < kWaves * C; j += kGridBlock) t[j] = 0.0;
     __syncthreads();
     constexpr uint32_t kSlots = kGridBlock / LANES;  // rows the workgroup holds at once
     const uint32_t slot = threadIdx.x / LANES, sl = threadIdx.x % LANES;
@@ -126,16 +124,21 @@ __global__ __launch_bounds__(kGridBlock) void emGridAccumKernel(const GridAccumA
         for (int u = 0; u < UNROLL; ++u) {
             const double w = countOverSum(c[u], rowLanesSum<LANES>(s[u]) + nz[u] * a_noise);  // (no row: count 0, weight 0)
             // (the columns of one row are distinct: the lanes of a row never meet on an accumulator)
-            for (uint32_t e = e0[u] + sl; e < e1[u]; e += LANES) atomicAdd(&t[args.col[e]], w * args.val[e]);
+            for (uint32_t e = e0[u] + sl; e < e1[u]; e += LANES) atomicAdd(&tw[args.col[e]], w * args.val[e]);
             if (sl == 0) tn += w * nz[u];
         }
     }
     // the noise column has no entries: its accumulator takes the per-wave sums of w * noise
     tn = waveSumF64(tn);
-    if ((threadIdx.x & 63) == 0 && tn != 0.0) atomicAdd(&t[noise_col], tn);
+    if ((threadIdx.x & 63) == 0 && tn != 0.0) atomicAdd(&tw[noise_col], tn);
     __syncthreads();
     double * out = args.partials + static_cast<uint64_t>(blockIdx.x) * args.partial_ld;
-    for (uint32_t j = threadIdx.x; j < C; j += kGridBlock) out[j] = t[j];
+    for (uint32_t j = threadIdx.x; j < C; j += kGridBlock) {
+        double tj = t[j];
+#pragma unroll
+        for (uint32_t w = 1; w < kWaves; ++w) tj += t[w * C + j];
+        out[j] = tj;
+    }
 }
 
 struct GridUpdateArgs {
@@ -422,7 +425,7 @@ int runEmGridProblems(rpvg_hip_ctx * ctx, hipStream_t st, const EmGridProblem * 
         const uint32_t rows_per_block = static_cast<uint32_t>((static_cast<uint64_t>(rows) + blocks - 1) / blocks);
         r.grid = (rows + rows_per_block - 1) / rows_per_block;
         const uint32_t partial_ld = (C + 63) & ~63u;
-        r.lds = sizeof(double) * 2 * static_cast<size_t>(C);
+        r.lds = sizeof(double) * (1 + kGridBlock / 64) * static_cast<size_t>(C);
         hipError_t err = r.d_a.alloc(C);
         if (err == hipSuccess) err = r.d_partials.alloc(static_cast<size_t>(r.grid) * partial_ld);
         if (err == hipSuccess) err = r.d_ctl.alloc(1);

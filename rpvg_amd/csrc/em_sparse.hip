@@ -138,12 +138,16 @@ constexpr int kEmStreamedBin = 3;
 constexpr size_t kEmLdsLimit = 156 * 1024;
 constexpr uint32_t kRegColsMax = 32;  // the widest register-resident variant
 
-// LDS bytes of a problem: abundance + accumulator vectors and scratch, plus its CSR when resident
+// LDS bytes of a problem: the abundance vector, one accumulator vector PER WAVEFRONT of the workgroup (the M-step's sums have one
+// order of additions: emSparseProblem) and scratch, plus its CSR when resident
 __host__ __device__ inline size_t emLdsBytes(uint32_t cols, uint32_t rows, uint32_t entries, int block, bool resident) {
-    size_t bytes = sizeof(double) * (2 * static_cast<size_t>(cols) + block / 64 + 2);
+    size_t bytes = sizeof(double) * ((1 + static_cast<size_t>(block) / 64) * cols + block / 64 + 2);
     if (resident) bytes += static_cast<size_t>(rows) * 16 + static_cast<size_t>(entries) * 8 + (static_cast<size_t>(rows) + 1 + entries) * 4 + 8;
     return (bytes + 15) & ~static_cast<size_t>(15);
 }
+
+// the grid route's workgroups (em_grid.hip: four wavefronts): abundances + an accumulator vector per wavefront
+__host__ __device__ inline size_t emGridLdsBytes(const uint32_t cols) { return sizeof(double) * 5 * static_cast<size_t>(cols); }
 
 struct EmBinRule {
     uint32_t use_register_kernel;   // RPVG_HIP_NO_REGISTER_EM=1 clears it
@@ -154,13 +158,16 @@ struct EmBinRule {
 __host__ __device__ inline int emBinOf(const EmBinRule rule, const uint32_t C, const uint32_t rows, const uint32_t entries) {
     const uint64_t work = static_cast<uint64_t>(entries) + rows;
     // (the grid kernels keep the vectors in LDS: the few problems too wide for that stay in bin 10)
-    if (rule.grid_min_work != 0 && work >= rule.grid_min_work && emLdsBytes(C, 0, 0, 1024, false) <= kEmLdsLimit) return kEmGridBin;
+    if (rule.grid_min_work != 0 && work >= rule.grid_min_work && emGridLdsBytes(C) <= kEmLdsLimit) return kEmGridBin;
     if (rule.use_register_kernel && C <= 16 && rows <= 256) return rows <= 64 ? 4 : rows <= 128 ? 5 : 6;
     if (rule.use_register_kernel && C <= kRegColsMax && rows <= 128) return rows <= 64 ? 8 : 9;
     if (emLdsBytes(C, rows, entries, 64, true) <= 8 * 1024) return 0;
     if (emLdsBytes(C, rows, entries, 256, true) <= 40 * 1024) return 1;
     if (emLdsBytes(C, rows, entries, 1024, true) <= 152 * 1024) return 7;
-    if (emLdsBytes(C, 0, 0, 1024, false) > kEmLdsLimit) return 10;
+    // streamed: sixteen wavefronts if their accumulator vectors fit LDS, four if those do (up to ~3 900 columns), else the vectors
+    // in global memory
+    if (emLdsBytes(C, 0, 0, 256, false) > kEmLdsLimit) return 10;
+    if (emLdsBytes(C, 0, 0, 1024, false) > kEmLdsLimit) return 2;
     return work <= rule.streamed_small_work ? 2 : 3;
 }
 
@@ -654,9 +661,16 @@ template <int BLOCK, bool RESIDENT, bool WIDE>
 __device__ __forceinline__ void emSparseProblem(const EmLaunchArgs & args, const uint32_t p, unsigned char * smem_raw) {
     const uint32_t C = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]) + 1;  // + noise
     if (WIDE && args.wide_off[p] + 2ull * C > args.wide_capacity) return;  // (reported through EmQueues::wide_overflow)
+    // The M-step's column sums have ONE order of additions, whatever the wavefronts' timing: every wavefront adds into an
+    // accumulator vector of its own — within a wavefront the additions follow the program and, lanes of one instruction that meet on
+    // a column, the LDS unit's lane order — and the vectors are added up in wavefront order (registers -> LDS slots -> ordered
+    // sum).  Two runs on the same input give the same bits, iteration counts included.  (WIDE — more than ~3 900 columns, the
+    // vectors in global memory — keeps one vector and global atomics: reproducible up to the order of those additions.)
+    constexpr uint32_t kCopies = WIDE ? 1 : BLOCK / 64;
     double * a = WIDE ? args.wide_vectors + args.wide_off[p] : reinterpret_cast<double *>(smem_raw);  // [C] abundances (last = noise)
-    double * t = a + C;                                 // [C] M-step accumulators
-    double * red = WIDE ? reinterpret_cast<double *>(smem_raw) : t + C;  // [BLOCK/64] reduction scratch
+    double * t = a + C;                                 // [kCopies x C] M-step accumulators
+    double * red = WIDE ? reinterpret_cast<double *>(smem_raw) : t + static_cast<size_t>(kCopies) * C;  // [BLOCK/64] reduction scratch
+    double * tw = t + static_cast<size_t>(kCopies == 1 ? 0 : threadIdx.x >> 6) * C;  // this wavefront's
 
     const uint32_t n_rows = args.kept_rows[p];
     const uint64_t rb = args.row_base[p], eb = args.ent_base[p];
@@ -696,7 +710,7 @@ __device__ __forceinline__ void emSparseProblem(const EmLaunchArgs & args, const
     const double a0 = static_cast<double>(1.0f / static_cast<float>(C));
     for (uint32_t j = threadIdx.x; j < C; j += BLOCK) a[j] = a0;
 
-    for (uint32_t j = threadIdx.x; j < C; j += BLOCK) t[j] = 0;
+    for (uint32_t j = threadIdx.x; j < kCopies * C; j += BLOCK) t[j] = 0;
     __syncthreads();  // a[], t[] and (when resident) the problem's CSR are in LDS
 
     const double inv_T = 1.0 / T;
@@ -716,21 +730,27 @@ __device__ __forceinline__ void emSparseProblem(const EmLaunchArgs & args, const
             const double quot = cnt[r] * y;
             // (a row whose count a row collapse moved to its run head takes no part: row_collapse.hip)
             const double w = cnt[r] == 0.0 ? 0.0 : fma(fma(-s, quot, cnt[r]), y, quot);
-            for (uint32_t e = e0; e < e1; ++e) atomicAdd(&t[col[e]], w * val[e]);
+            for (uint32_t e = e0; e < e1; ++e) atomicAdd(&tw[col[e]], w * val[e]);
             tn += w * nz;
         }
         // the noise column has no entries: its accumulator takes the per-wave sums of w * noise
         tn = waveSumF64(tn);
-        if ((threadIdx.x & 63) == 0 && tn != 0.0) atomicAdd(&t[noise_col], tn);
+        if ((threadIdx.x & 63) == 0 && tn != 0.0) atomicAdd(&tw[noise_col], tn);
         __syncthreads();  // all atomics to t[] done, all reads of a[] done
         int viol = 0;
         for (uint32_t j = threadIdx.x; j < C; j += BLOCK) {
             const double aj = a[j];
-            const double an = (j == noise_col) ? (aj * t[j] + Z) * inv_T : (aj * t[j]) * inv_T;
+            double tj = t[j];
+            t[j] = 0;
+#pragma unroll
+            for (uint32_t w = 1; w < kCopies; ++w) {  // (wavefront order)
+                tj += t[w * C + j];
+                t[w * C + j] = 0;
+            }
+            const double an = (j == noise_col) ? (aj * tj + Z) * inv_T : (aj * tj) * inv_T;
             // |an - aj| / an > eps  (src/path_abundance_estimator.cpp:73-75), without the division
             if (an >= kMinEmAbundance && fabs(an - aj) > eps * an) viol = 1;
             a[j] = an;
-            t[j] = 0;
         }
         int any_viol;
         if (BLOCK == 64) {
@@ -1548,7 +1568,7 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     static const double grid_scale = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_GRID_SCALE") ? std::atof(RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_GRID_SCALE")) : 1.0;  // A/B knob
     auto grid = [&](const uint32_t per_cu) { return std::min<uint32_t>(P, std::max<uint32_t>(1, static_cast<uint32_t>(cus * per_cu * grid_scale))); };
     const size_t streamed_lds_256 = emLdsBytes(list.max_cols, 0, 0, 256, false), streamed_lds_1024 = emLdsBytes(list.max_cols, 0, 0, 1024, false);
-    const bool wide_possible = streamed_lds_1024 > kEmLdsLimit;
+    const bool wide_possible = streamed_lds_256 > kEmLdsLimit;
     static const bool few_streams = RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_FEW_STREAMS") != nullptr;  // A/B knob
     const bool many_queues = hardwareQueues() >= 8 && !few_streams;
     hipStream_t s_reg4 = many_queues ? ctx->aux[3] : ctx->aux[0], s_reg1 = many_queues ? ctx->aux[4] : ctx->aux[1], s_reg2 = many_queues ? ctx->aux[5] : ctx->aux[2];
@@ -1840,7 +1860,7 @@ int prepareHostProblems(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const 
         list.max_cluster_paths = std::max<uint32_t>(list.max_cluster_paths, static_cast<uint32_t>(n_paths));
         list.max_cluster_work = std::max<uint64_t>(list.max_cluster_work, (batch->h_cluster_row_off[k + 1] - batch->h_cluster_row_off[k]) +
                                                                               (batch->h_cluster_ent_off[k + 1] - batch->h_cluster_ent_off[k]));
-        if (emLdsBytes(C, 0, 0, 1024, false) > kEmLdsLimit) list.wide_capacity += 2ull * C;
+        if (emLdsBytes(C, 0, 0, 256, false) > kEmLdsLimit) list.wide_capacity += 2ull * C;
         row_base[p] = rows_bound;
         ent_base[p] = entries_bound;
         rows_bound += batch->h_cluster_row_off[k + 1] - batch->h_cluster_row_off[k];

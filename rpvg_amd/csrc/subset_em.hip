@@ -820,7 +820,8 @@ static int nestedSubsetEmAttempt(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
                                                                     (batch->h_cluster_ent_off[k + 1] - batch->h_cluster_ent_off[k]));
     }
     slots = slot_off[M];
-    if (M > 0 && 16ull * (static_cast<uint64_t>(max_paths) + 1) + 18 * 8 > 156 * 1024) {
+    // (em_sparse.hip, emLdsBytes: the streamed kernel of four wavefronts — abundances and an accumulator vector per wavefront)
+    if (M > 0 && 8ull * (5ull * (static_cast<uint64_t>(max_paths) + 1) + 6) > 156 * 1024) {
         setError("rpvg_hip_nested_subset_em: not taken (a cluster with %u paths: EM vectors in global memory)", max_paths);
         return RPVG_HIP_ERR_UNSUPPORTED;
     }
