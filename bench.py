@@ -374,6 +374,11 @@ def run_s3(args, rank, local_rank, world, dist, torch):
             one["note"] = ("the same steps with ONE batch in flight (the headline of rounds 2-4): estimateBatch on two host lanes, the next batch "
                            "uploaded under it from a second resident slot")
             h2d["one_batch_in_flight"] = one
+            if world == 1 and not os.environ.get("RPVG_BENCH_NO_SINGLE_DATASET"):
+                try:
+                    h2d["single_dataset"] = measure_single_dataset(args, eng_mod, batch, params, local_rank)
+                except Exception as exc:  # noqa: BLE001
+                    h2d["single_dataset"] = dict(error=str(exc))
             if world == 1 and args.scale >= 1.0 and not os.environ.get("RPVG_BENCH_NO_HOST_BOUND"):
                 try:
                     bound = host_bound_line(args, eng_mod, batch, params, local_rank)
@@ -388,6 +393,12 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     # driver does before writing rpvg.txt); also fetch one decoded result for a sanity check
     est, _ = eng.run(args.model, params, prepared)
     pipeline_est = h2d.pop("sample_estimates", None) if h2d is not None else None
+    single_dataset = h2d.get("single_dataset") if h2d is not None else None
+    if single_dataset and "estimates" in single_dataset:  # the parts' estimates are the whole batch's, bit for bit
+        parts_est = single_dataset.pop("estimates")
+        single_dataset["equal_whole_batch"] = bool(len(parts_est) == len(est) and all(
+            a.path_group_sets == b.path_group_sets and np.array_equal(a.posteriors, b.posteriors) and np.array_equal(a.abundances, b.abundances)
+            and a.noise_count == b.noise_count and a.em_iters == b.em_iters for a, b in zip(parts_est, est)))
     if pipeline_est is not None:  # the pipeline's batches are the engine's: same estimates, to the bit
         assert len(pipeline_est) == len(est)
         def same(a, b):
@@ -497,6 +508,8 @@ def run_s3(args, rank, local_rank, world, dist, torch):
             line["gpu_active_frac"] = second["gpu_active_frac"]
     if pipeline_equal is not None:
         line["pipeline_estimates_equal_single_engine"] = bool(pipeline_equal)
+    if line.get("single_dataset") and "ms" in line["single_dataset"]:
+        line["single_dataset_ms"] = line["single_dataset"]["ms"]
     if ENGINE_MODULE != "rpvg_amd.engine":
         # a stand-in engine (the CPU test of the launcher and the rank protocol): no metric is claimed
         line.update(metric="none: stand-in engine %s, launcher/protocol self-test only" % ENGINE_MODULE, protocol_value=value, value=None,
@@ -640,6 +653,56 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
                 h2d_ms_per_batch=up_ms, h2d_bytes_per_batch=bytes_per_batch, h2d_gb_per_s=bytes_per_batch / 1e9 / (up_ms / 1e3),
                 h2d_note="rows of every batch uploaded from page-locked host arrays inside the clock: validation on the host, H2D, "
                          "expansion on the device; overlapped = two resident slots, uploader engine under the previous batch's kernels")
+
+
+def dataset_parts(batch, fractions):
+    """The batch's clusters cut into consecutive ranges holding the given fractions of its rows (ClusterRange: no copy of the rows)."""
+    import numpy as np
+    rows = batch.cluster_row_off.astype(np.float64) / max(1.0, float(batch.cluster_row_off[-1]))
+    total = float(sum(fractions))
+    cuts, run = [0], 0.0
+    for f in fractions[:-1]:
+        run += f / total
+        cuts.append(max(cuts[-1] + 1, min(batch.num_clusters - (len(fractions) - len(cuts)), int(np.searchsorted(rows, run)))))
+    cuts.append(batch.num_clusters)
+    return [batch.cluster_range(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+
+def measure_single_dataset(args, eng_mod, batch, params, local_rank, repeats=9):
+    """ONE data set, once: what a real rpvg run hands over — 10 M read pairs in host memory — cut by cluster into parts that go
+    through the batch pipeline one behind the other (the copy of part n + 1 under the kernels of part n, parts on engines of
+    their own), wall clock from the first submit to the last estimate in its host container.  The pipeline is warm (contexts,
+    memory pools), the data is not: every part is copied, validated and expanded inside the clock, and so is the cut itself (views
+    of the caller's arrays and three small offset arrays per part).  Median and minimum of `repeats` passes."""
+    from rpvg_amd import hip
+    fractions = [float(x) for x in os.environ.get("RPVG_BENCH_PARTS", "0.22,0.22,0.2,0.18,0.18").split(",")]
+    arrays = copied_arrays(batch)
+    for a in arrays:
+        hip.host_register(a)
+    pipe = eng_mod.Pipeline(args.model, params, local_rank, workers=args.pipeline_workers)
+    try:
+        parts = dataset_parts(batch, fractions)
+        for slot, part in enumerate(parts):
+            pipe.prepare_slot(slot, part)
+        times = []
+        for rep in range(repeats + 2):
+            t0 = time.perf_counter()
+            cut = dataset_parts(batch, fractions)
+            for slot, part in enumerate(cut):
+                pipe.submit(part, slot, compact=True)
+            pipe.wait()
+            if rep >= 2:
+                times.append((time.perf_counter() - t0) * 1e3)
+        est = [e for slot in range(len(parts)) for e in pipe.result(slot)]
+    finally:
+        pipe.close()
+        for a in arrays:
+            hip.host_unregister(a)
+    times.sort()
+    return dict(ms=times[len(times) // 2], ms_min=times[0], ms_max=times[-1], repeats=repeats, parts=len(parts),
+                rows_per_part=[int(p.num_rows) for p in parts], clusters_per_part=[int(p.num_clusters) for p in parts], estimates=est,
+                note="one cold configs[2] data set (10 M read pairs in page-locked host memory) cut by cluster into parts through the batch pipeline: "
+                     "first submit -> last estimate in its host container, the cut inside; median of the repeats")
 
 
 def host_bound_line(args, eng_mod, batch, params, local_rank, ranks=8, steps=40):

@@ -782,7 +782,7 @@ struct rpvg_hip_subset_em {
 static int nestedSubsetEmAttempt(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_groups * groups,
                                  const uint32_t * column_counts, double min_rel_likelihood, double min_hap_prob,
                                  uint32_t max_em_its, double max_rel_em_conv, double collapse_precision,
-                                 rpvg_hip_subset_em ** result_out, bool * did_not_fit) {
+                                 rpvg_hip_subset_em ** result_out, bool * did_not_fit, PairSearchWork & search, const bool second_attempt) {
     *did_not_fit = false;
     RPVG_REQUIRE(min_rel_likelihood > 0, "rpvg_hip_nested_subset_em: min_rel_likelihood must be positive");
     RPVG_REQUIRE(max_em_its > 0, "rpvg_hip_nested_subset_em: max_em_its must be positive");
@@ -854,14 +854,25 @@ static int nestedSubsetEmAttempt(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     const unsigned long long cap_items = cap_rows / emFillSegmentRows() + cap_subsets;
 
     scope.reset(new HostScope("subset em: search + kernels queued"));
-    PairSearchWork search;
     // with the search's own small arrays (one copy, one memset): the slot offsets; the header and the EM work queues, zeroed
-    search.extra_u64 = slot_off.data();
-    search.extra_u64_count = M + 1;
     const size_t header_room = 256;
-    search.extra_zero_bytes = header_room + emQueuesBytes();
-    int rc = queuePairSearch(ctx, groups, column_counts, min_rel_likelihood, search);
-    if (rc != RPVG_HIP_OK) return rc;
+    int rc = RPVG_HIP_OK;
+    if (!second_attempt) {
+        search.extra_u64 = slot_off.data();
+        search.extra_u64_count = M + 1;
+        search.extra_zero_bytes = header_room + emQueuesBytes();
+        rc = queuePairSearch(ctx, groups, column_counts, min_rel_likelihood, search);
+        if (rc != RPVG_HIP_OK) return rc;
+    } else {
+        // the search is the first attempt's: its pairs are on the device (a second search would meet the matrices with their
+        // collapse's last stage done and leave sums that differ in their last bits — the estimates of a cluster must not depend on
+        // what shared its batch); the header and the EM work queues start from zero again
+        const hipError_t zeroed = zeroAsync(search.d_extra_zero.ptr, search.extra_zero_bytes, st);
+        if (zeroed != hipSuccess) {
+            setError("rpvg_hip_nested_subset_em: %s", hipGetErrorString(zeroed));
+            return RPVG_HIP_ERR_RUNTIME;
+        }
+    }
 
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
@@ -1193,16 +1204,17 @@ extern "C" int rpvg_hip_nested_subset_em(rpvg_hip_ctx * ctx, const rpvg_hip_batc
     RPVG_REQUIRE(ctx && batch && groups && result_out, "rpvg_hip_nested_subset_em: NULL argument");
     *result_out = nullptr;
     // Capacities are planned from what recent calls needed per unit of input; a call that outgrows them learns what it needs from
-    // its own header and runs again — the search once more, which is cheap next to what the caller would otherwise do (the three
-    // separate calls with the subsets on the host).
+    // its own header and selects, expands and solves again — cheap next to what the caller would otherwise do (the three separate
+    // calls with the subsets on the host).
     bool did_not_fit = false;
+    PairSearchWork search;  // (the diploid search runs once: the second attempt selects from the same pairs)
     int rc = nestedSubsetEmAttempt(ctx, batch, groups, column_counts, min_rel_likelihood, min_hap_prob, max_em_its, max_rel_em_conv, collapse_precision,
-                                   result_out, &did_not_fit);
+                                   result_out, &did_not_fit, search, false);
     if (rc == RPVG_HIP_ERR_UNSUPPORTED && did_not_fit) {
         static const bool trace = std::getenv("RPVG_AMD_TRACE") != nullptr;
         if (trace) std::fprintf(stderr, "[rpvg_hip trace]   subset em: second attempt (%s)\n", rpvg_hip_last_error());
         rc = nestedSubsetEmAttempt(ctx, batch, groups, column_counts, min_rel_likelihood, min_hap_prob, max_em_its, max_rel_em_conv, collapse_precision,
-                                   result_out, &did_not_fit);
+                                   result_out, &did_not_fit, search, true);
     }
     return rc;
 }

@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
         L.rpvg_amd_pipeline_workers.argtypes = [C.c_void_p]
         L.rpvg_amd_pipeline_prepare_slots.argtypes = [C.c_void_p, C.POINTER(CClusterBatch), C.c_int]
         L.rpvg_amd_pipeline_submit.argtypes = [C.c_void_p, C.POINTER(CClusterBatch), C.c_int]
+        L.rpvg_amd_pipeline_prepare_slot.argtypes = [C.c_void_p, C.POINTER(CClusterBatch), C.c_int]
         L.rpvg_amd_pipeline_wait.argtypes = [C.c_void_p]
         L.rpvg_amd_pipeline_result.restype = C.c_void_p
         L.rpvg_amd_pipeline_result.argtypes = [C.c_void_p, C.c_int]
@@ -287,8 +288,15 @@ class Pipeline:
         if lib().rpvg_amd_pipeline_prepare_slots(self.handle, C.byref(cb), slots) != 0:
             raise hip.EngineError(f"pipeline prepare failed: {_err()}")
 
-    def submit(self, batch: ClusterBatch, slot: int, compact: bool = False):
-        """compact: hand the batch over with 32-bit offset arrays (ClusterBatch.as_c)."""
+    def prepare_slot(self, slot: int, part):
+        """The containers of one slot for the clusters of `part` (a ClusterBatch or a ClusterRange of one): the parts of one data
+        set go to slots of their own."""
+        cb = part.as_c(True)
+        if lib().rpvg_amd_pipeline_prepare_slot(self.handle, C.byref(cb), slot) != 0:
+            raise hip.EngineError(f"pipeline prepare failed: {_err()}")
+
+    def submit(self, batch, slot: int, compact: bool = False):
+        """compact: hand the batch over with 32-bit offset arrays (ClusterBatch.as_c).  `batch`: a ClusterBatch or a ClusterRange."""
         cb = batch.as_c(compact)
         self._keep.append((batch, cb))
         if lib().rpvg_amd_pipeline_submit(self.handle, C.byref(cb), slot) != 0:

@@ -840,6 +840,39 @@ int rpvg_amd_pipeline_prepare_slots(void * pipeline_handle, const rpvg_cluster_b
     }
 }
 
+// The containers of ONE slot, for the clusters (paths) of `batch` — slots may hold different batches (the parts of one data set,
+// submitted one behind the other); the slots in front of it exist afterwards, empty if they were not prepared.
+int rpvg_amd_pipeline_prepare_slot(void * pipeline_handle, const rpvg_cluster_batch * batch, int slot) {
+
+    try {
+
+        Pipeline * pipeline = static_cast<Pipeline *>(pipeline_handle);
+        pipeline->pipeline->wait();
+
+        const auto paths = unpackPaths(*batch);
+
+        if (pipeline->slots.size() <= static_cast<size_t>(slot)) {
+
+            pipeline->slots.resize(slot + 1);
+        }
+
+        auto & containers = pipeline->slots.at(slot);
+        containers.assign(paths.size(), PathClusterEstimates());
+
+        for (size_t i = 0; i < paths.size(); ++i) {
+
+            containers.at(i).paths = paths.at(i);
+        }
+
+        return 0;
+
+    } catch (const std::exception & e) {
+
+        last_error = e.what();
+        return -1;
+    }
+}
+
 // Queues one batch (its arrays stay the caller's until rpvg_amd_pipeline_wait returns) with the containers of `slot`.
 int rpvg_amd_pipeline_submit(void * pipeline_handle, const rpvg_cluster_batch * batch, int slot) {
 

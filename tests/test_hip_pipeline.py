@@ -242,3 +242,36 @@ def test_batches_in_flight_equal_one_call_after_the_other(model, kw):
     finally:
         pipe.close()
     del batches
+
+
+@pytest.mark.parametrize("model", ["haplotype-transcripts", "transcripts"])
+def test_parts_of_one_data_set_equal_the_whole_batch(model):
+    """One data set cut by cluster into parts (ClusterBatch.cluster_range: views of the caller's arrays, the long offset arrays as
+    slices of its counts of one byte) that go through the pipeline one behind the other — what bench.py's `single_dataset_ms`
+    times — leaves, cluster for cluster, the estimates of the whole batch in one call: bit for bit."""
+    params = make_params()
+    batch = synth.generate(seed=41, num_clusters=120, total_paths=2600, total_reads=200000)
+    engine = eng_mod.Engine(0)
+    try:
+        whole, _ = engine.run(model, params, engine.prepare(batch))
+    finally:
+        engine.close()
+    cuts = [0, 7, 30, 31, 80, batch.num_clusters]
+    parts = [batch.cluster_range(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert sum(p.num_rows for p in parts) == batch.num_rows
+    pipe = eng_mod.Pipeline(model, params, 0, workers=3)
+    try:
+        for slot, part in enumerate(parts):
+            pipe.prepare_slot(slot, part)
+        for _ in range(2):
+            for slot, part in enumerate(parts):
+                pipe.submit(part, slot, compact=True)
+            pipe.wait()
+            got = [e for slot in range(len(parts)) for e in pipe.result(slot)]
+            assert len(got) == len(whole)
+            for k, (g, e) in enumerate(zip(got, whole)):
+                assert g.path_group_sets == e.path_group_sets, k
+                assert np.array_equal(g.posteriors, e.posteriors) and np.array_equal(g.abundances, e.abundances), k
+                assert g.noise_count == e.noise_count and g.total_count == e.total_count and g.em_iters == e.em_iters, k
+    finally:
+        pipe.close()
