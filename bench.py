@@ -587,7 +587,8 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
     arrays = [batch.cluster_row_off, batch.cluster_path_off, batch.row_count, batch.row_noise, batch.row_grp_off, batch.grp_prob,
               batch.grp_idx_off, batch.path_idx, batch.path_group_id, batch.path_source_off, batch.source_id]
     for a in arrays:
-        hip.host_register(a)
+        if a.nbytes >= PAGE_LOCK_MIN_BYTES:
+            hip.host_register(a)
     uploader = eng_mod.Engine(local_rank, uploader=True)
     slots = [prepared, eng.prepare(batch)]
     try:
@@ -640,7 +641,8 @@ def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank
         slots[1].free()
         uploader.close()
         for a in arrays:
-            hip.host_unregister(a)
+            if a.nbytes >= PAGE_LOCK_MIN_BYTES:
+                hip.host_unregister(a)
     bytes_per_batch = float(sum(a.nbytes for a in arrays))
     up_ms = 1e3 * sum(upload_s) / max(1, len(upload_s))
     ordered = sorted(step_ms)
@@ -675,10 +677,11 @@ def measure_single_dataset(args, eng_mod, batch, params, local_rank, repeats=9):
     memory pools), the data is not: every part is copied, validated and expanded inside the clock, and so is the cut itself (views
     of the caller's arrays and three small offset arrays per part).  Median and minimum of `repeats` passes."""
     from rpvg_amd import hip
-    fractions = [float(x) for x in os.environ.get("RPVG_BENCH_PARTS", "0.22,0.22,0.2,0.18,0.18").split(",")]
+    fractions = [float(x) for x in os.environ.get("RPVG_BENCH_PARTS", "0.5,0.5").split(",")]
     arrays = copied_arrays(batch)
     for a in arrays:
-        hip.host_register(a)
+        if a.nbytes >= PAGE_LOCK_MIN_BYTES:
+            hip.host_register(a)
     pipe = eng_mod.Pipeline(args.model, params, local_rank, workers=args.pipeline_workers)
     try:
         parts = dataset_parts(batch, fractions)
@@ -689,7 +692,7 @@ def measure_single_dataset(args, eng_mod, batch, params, local_rank, repeats=9):
             t0 = time.perf_counter()
             cut = dataset_parts(batch, fractions)
             for slot, part in enumerate(cut):
-                pipe.submit(part, slot, compact=True)
+                pipe.submit(part, slot, compact=True, narrow=NARROW_UPLOADS)
             pipe.wait()
             if rep >= 2:
                 times.append((time.perf_counter() - t0) * 1e3)
@@ -697,7 +700,8 @@ def measure_single_dataset(args, eng_mod, batch, params, local_rank, repeats=9):
     finally:
         pipe.close()
         for a in arrays:
-            hip.host_unregister(a)
+            if a.nbytes >= PAGE_LOCK_MIN_BYTES:
+                hip.host_unregister(a)
     times.sort()
     return dict(ms=times[len(times) // 2], ms_min=times[0], ms_max=times[-1], repeats=repeats, parts=len(parts),
                 rows_per_part=[int(p.num_rows) for p in parts], clusters_per_part=[int(p.num_clusters) for p in parts], estimates=est,
@@ -716,7 +720,8 @@ def host_bound_line(args, eng_mod, batch, params, local_rank, ranks=8, steps=40)
     mine = set(allowed[:share])
     arrays = copied_arrays(batch)
     for a in arrays:
-        hip.host_register(a)
+        if a.nbytes >= PAGE_LOCK_MIN_BYTES:
+            hip.host_register(a)
     os.sched_setaffinity(0, mine)  # (threads started from here on inherit it: the pipeline's uploader and estimator threads)
     try:
         pipe = eng_mod.Pipeline(args.model, params, local_rank, workers=args.pipeline_workers)
@@ -724,11 +729,11 @@ def host_bound_line(args, eng_mod, batch, params, local_rank, ranks=8, steps=40)
             slots = pipe.workers + 4
             pipe.prepare_slots(batch, slots)
             for k in range(2 * slots):
-                pipe.submit(batch, k % slots, compact=True)
+                pipe.submit(batch, k % slots, compact=True, narrow=NARROW_UPLOADS)
             pipe.wait()
             t0 = time.perf_counter()
             for k in range(steps):
-                pipe.submit(batch, k % slots, compact=True)
+                pipe.submit(batch, k % slots, compact=True, narrow=NARROW_UPLOADS)
             pipe.wait()
             ms = (time.perf_counter() - t0) / steps * 1e3
         finally:
@@ -736,7 +741,8 @@ def host_bound_line(args, eng_mod, batch, params, local_rank, ranks=8, steps=40)
     finally:
         os.sched_setaffinity(0, set(allowed))
         for a in arrays:
-            hip.host_unregister(a)
+            if a.nbytes >= PAGE_LOCK_MIN_BYTES:
+                hip.host_unregister(a)
     return dict(ranks=ranks, node_cpus=quota, cpus_per_rank=share, ms_per_step=ms, steps=steps,
                 note="the headline's pipeline with all of its threads confined (sched_setaffinity) to one rank's share of the node's CPUs: what the "
                      "host side alone allows a rank of an 8-rank node; efficiency_bound = unconfined ms_per_step / this")
@@ -776,10 +782,18 @@ def print_thread_cpu(threads0, steps):
 
 def copied_arrays(batch):
     """The host arrays of a batch that its copy to the GPU reads (to be page-locked): the two long offset arrays as counts of one
-    byte where they fit, else in 32 bits (include/rpvg_batch.h: what a caller that flattens rows for the GPU writes)."""
+    byte where they fit, else in 32 bits, and the 16-bit path indices and source ids and one-byte read counts where those fit
+    (include/rpvg_batch.h: what a caller that flattens rows for the GPU writes)."""
     offsets = batch.counts8() or batch.offsets32()
-    return [batch.cluster_row_off, batch.cluster_path_off, batch.row_count, batch.row_noise, offsets[0], batch.grp_prob,
-            offsets[1], batch.path_idx, batch.path_group_id, batch.path_source_off, batch.source_id]
+    forms = batch.narrow() if NARROW_UPLOADS else {}
+    counts = [forms["row_count8"], forms["row_count_escape_row"], forms["row_count_escape_count"]] if "row_count8" in forms else [batch.row_count]
+    noise = [forms["row_noise16"], forms["row_noise_table"]] if "row_noise16" in forms else [batch.row_noise]
+    return noise + [batch.cluster_row_off, batch.cluster_path_off, offsets[0], batch.grp_prob,
+            offsets[1], forms.get("path_idx16", batch.path_idx), batch.path_group_id, batch.path_source_off, forms.get("source_id16", batch.source_id)] + counts
+
+
+PAGE_LOCK_MIN_BYTES = 1 << 16  # (smaller arrays — the list of the rows whose count does not fit a byte — go through the library's staging block)
+NARROW_UPLOADS = not os.environ.get("RPVG_BENCH_WIDE_UPLOADS")  # (A/B: the 32-bit path indices, source ids and read counts of round 5)
 
 
 def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
@@ -791,13 +805,14 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
     from rpvg_amd import hip
     arrays = copied_arrays(batch)
     for a in arrays:
-        hip.host_register(a)
+        if a.nbytes >= PAGE_LOCK_MIN_BYTES:
+            hip.host_register(a)
     pipe = eng_mod.Pipeline(args.model, params, local_rank, workers=args.pipeline_workers)
     try:
         slots = pipe.workers + 4
         pipe.prepare_slots(batch, slots)
         for k in range(max(args.warmup, 2 * slots)):
-            pipe.submit(batch, k % slots, compact=True)
+            pipe.submit(batch, k % slots, compact=True, narrow=NARROW_UPLOADS)
         pipe.wait()
         pipe.reset_stats()
         barrier_sync(dist, torch)
@@ -805,7 +820,7 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
         cpu0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         for k in range(args.steps):
-            pipe.submit(batch, k % slots, compact=True)
+            pipe.submit(batch, k % slots, compact=True, narrow=NARROW_UPLOADS)
         pipe.wait()
         barrier_sync(dist, torch)
         elapsed = max_over_ranks(time.perf_counter() - t0, dist, torch)
@@ -819,7 +834,8 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
     finally:
         pipe.close()
         for a in arrays:
-            hip.host_unregister(a)
+            if a.nbytes >= PAGE_LOCK_MIN_BYTES:
+                hip.host_unregister(a)
     host_cpu_ms = ((cpu1.ru_utime - cpu0.ru_utime) + (cpu1.ru_stime - cpu0.ru_stime)) * 1e3 / args.steps
     bytes_per_batch = float(sum(a.nbytes for a in arrays))
     # The pipeline's contexts time their EM launches only (rpvg_hip_ctx::span_level, context.hip: two events per span are two marker
@@ -830,18 +846,19 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
         os.environ["RPVG_HIP_SPANS"] = "2"
         try:
             for a in arrays:
-                hip.host_register(a)
+                if a.nbytes >= PAGE_LOCK_MIN_BYTES:
+                    hip.host_register(a)
             pipe = eng_mod.Pipeline(args.model, params, local_rank, workers=args.pipeline_workers)
             try:
                 steps2 = max(16, min(args.steps, 48))
                 pipe.prepare_slots(batch, slots)
                 for k in range(2 * slots):
-                    pipe.submit(batch, k % slots, compact=True)
+                    pipe.submit(batch, k % slots, compact=True, narrow=NARROW_UPLOADS)
                 pipe.wait()
                 pipe.reset_stats()
                 t2 = time.perf_counter()
                 for k in range(steps2):
-                    pipe.submit(batch, k % slots, compact=True)
+                    pipe.submit(batch, k % slots, compact=True, narrow=NARROW_UPLOADS)
                 pipe.wait()
                 instrumented_ms = (time.perf_counter() - t2) / steps2 * 1e3
                 instrumented = pipe.stats()
@@ -850,7 +867,8 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
             finally:
                 pipe.close()
                 for a in arrays:
-                    hip.host_unregister(a)
+                    if a.nbytes >= PAGE_LOCK_MIN_BYTES:
+                        hip.host_unregister(a)
         finally:
             os.environ.pop("RPVG_HIP_SPANS", None)
         # (per step of ITS pass, scaled to the steps of the timed one: what the caller divides by)

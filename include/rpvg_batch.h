@@ -63,6 +63,24 @@ typedef struct rpvg_cluster_batch {
     const uint8_t * grp_idx_count8;    /* [G] */
     uint64_t num_groups;               /* G   (read with the counts only) */
     uint64_t num_entries;              /* NNZ (read with the counts only) */
+
+    /* Narrower forms of three more arrays, again for the copy to the GPU only (rpvg_hip_batch_upload takes each INSTEAD of its
+     * 32-bit array when it is not NULL — that one may then be NULL — and widens it on the device behind the copy; the device batch
+     * is the same either way, to the bit).  Cluster-local path indices in 16 bits: no cluster of the batch has 65 536 paths or
+     * more (src/main.cpp's clusters have up to a few thousand).  Source (haplotype) ids in 16 bits: all ids below 65 536.  Read
+     * counts in one byte: min(count, 255), the rows with a count of 255 or more (ascending) and their counts listed beside.
+     * With the noise table below, configs[2]: 190 -> 136 MB per batch. */
+    const uint16_t * path_idx16;               /* [NNZ] */
+    const uint16_t * source_id16;              /* [S]   */
+    const uint8_t * row_count8;                /* [R]   */
+    const uint32_t * row_count_escape_row;     /* [E]   rows whose row_count8 is 255 */
+    const uint32_t * row_count_escape_count;   /* [E]   their read counts           */
+    uint64_t num_row_count_escapes;            /* E     */
+    /* ... and the noise probabilities as 16-bit indices into the table of their distinct values (they come from mapping qualities:
+     * a few hundred values for millions of rows; at most 65 536): row r has noise row_noise_table[row_noise16[r]], the very double. */
+    const uint16_t * row_noise16;              /* [R]   instead of row_noise */
+    const double * row_noise_table;            /* [T]   */
+    uint64_t num_row_noise_values;             /* T     */
 } rpvg_cluster_batch;
 
 /* One cluster as the thread that calls PathEstimator::estimate() for it (src/main.cpp:977) flattens it: the arrays of

@@ -21,6 +21,7 @@ u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
 f64p = C.POINTER(C.c_double)
 u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
 
 
 class CClusterBatch(C.Structure):
@@ -45,6 +46,15 @@ class CClusterBatch(C.Structure):
         ("grp_idx_count8", u8p),
         ("num_groups", C.c_uint64),
         ("num_entries", C.c_uint64),
+        ("path_idx16", u16p),
+        ("source_id16", u16p),
+        ("row_count8", u8p),
+        ("row_count_escape_row", u32p),
+        ("row_count_escape_count", u32p),
+        ("num_row_count_escapes", C.c_uint64),
+        ("row_noise16", u16p),
+        ("row_noise_table", f64p),
+        ("num_row_noise_values", C.c_uint64),
     ]
 
 
@@ -166,14 +176,49 @@ class ClusterBatch:
             self._counts8 = cached
         return cached
 
-    def as_c(self, compact: bool = False) -> CClusterBatch:
+    def narrow(self):
+        """The narrow forms of three more arrays for the copy to the GPU (rpvg_cluster_batch::path_idx16, source_id16, row_count8 with
+        the list of the rows whose count does not fit a byte), made once and kept: a dict with the arrays that fit."""
+        cached = getattr(self, "_narrow", None)
+        if cached is None:
+            cached = {}
+            paths = np.diff(self.cluster_path_off.astype(np.int64))
+            if len(self.path_idx) and int(paths.max(initial=0)) < 65536:
+                cached["path_idx16"] = np.ascontiguousarray(self.path_idx, dtype=np.uint16)
+            if len(self.source_id) and int(self.source_id.max()) < 65536:
+                cached["source_id16"] = np.ascontiguousarray(self.source_id, dtype=np.uint16)
+            if len(self.row_count):
+                rows = np.flatnonzero(self.row_count >= 255).astype(np.uint32)
+                cached["row_count8"] = np.ascontiguousarray(np.minimum(self.row_count, 255), dtype=np.uint8)
+                cached["row_count_escape_row"] = np.ascontiguousarray(rows)
+                cached["row_count_escape_count"] = np.ascontiguousarray(self.row_count[rows], dtype=np.uint32)
+                table, index = np.unique(self.row_noise, return_inverse=True)
+                if len(table) <= 65536:
+                    cached["row_noise16"] = np.ascontiguousarray(index, dtype=np.uint16)
+                    cached["row_noise_table"] = np.ascontiguousarray(table, dtype=np.float64)
+            self._narrow = cached
+        return cached
+
+    def as_c(self, compact: bool = False, narrow: bool = False) -> CClusterBatch:
         """compact: the 32-bit forms of the two long offset arrays instead of the 64-bit ones (a sixth fewer bytes to copy), and
-        with them, where they fit, the counts of one byte that the copy to the GPU takes instead (a third fewer)."""
+        with them, where they fit, the counts of one byte that the copy to the GPU takes instead (a third fewer).  narrow: also
+        the 16-bit path indices and source ids and the one-byte read counts, where they fit (narrow())."""
         # the returned struct borrows the arrays: keep `self` alive while it is in use
         if compact:
             row32, grp32 = self.offsets32()
             counts = self.counts8()
             tail = (_ptr(counts[0], u8p), _ptr(counts[1], u8p), len(self.grp_prob), len(self.path_idx)) if counts else (None, None, 0, 0)
+            if narrow:
+                forms = self.narrow()
+                tail = tail + (_ptr(forms["path_idx16"], u16p) if "path_idx16" in forms else None,
+                               _ptr(forms["source_id16"], u16p) if "source_id16" in forms else None,
+                               _ptr(forms["row_count8"], u8p) if "row_count8" in forms else None,
+                               _ptr(forms["row_count_escape_row"], u32p) if "row_count8" in forms else None,
+                               _ptr(forms["row_count_escape_count"], u32p) if "row_count8" in forms else None,
+                               len(forms["row_count_escape_row"]) if "row_count8" in forms else 0,
+                               _ptr(forms["row_noise16"], u16p) if "row_noise16" in forms else None,
+                               _ptr(forms["row_noise_table"], f64p) if "row_noise16" in forms else None,
+                               len(forms["row_noise_table"]) if "row_noise16" in forms else 0)
             return CClusterBatch(
                 self.num_clusters, _ptr(self.cluster_row_off, u64p), _ptr(self.cluster_path_off, u64p),
                 _ptr(self.row_count, u32p), _ptr(self.row_noise, f64p), None,
@@ -311,16 +356,44 @@ class ClusterRange:
         self.source_id, self.path_effective_length = parent.source_id[s0:s1], parent.path_effective_length[p0:p1]
         self.num_clusters, self.num_rows = last - first, r1 - r0
         self.total_reads = int(self.row_count.astype(np.uint64).sum())
+        # the parent's narrow forms (ClusterBatch.narrow): slices again, the listed rows moved to the range's numbering
+        self.narrow_forms = {}
+        forms = parent.narrow()
+        if "path_idx16" in forms:
+            self.narrow_forms["path_idx16"] = forms["path_idx16"][e0:e1]
+        if "source_id16" in forms:
+            self.narrow_forms["source_id16"] = forms["source_id16"][s0:s1]
+        if "row_count8" in forms:
+            listed = forms["row_count_escape_row"]
+            a, b = int(np.searchsorted(listed, r0)), int(np.searchsorted(listed, r1))
+            self.narrow_forms["row_count8"] = forms["row_count8"][r0:r1]
+            self.narrow_forms["row_count_escape_row"] = np.ascontiguousarray(listed[a:b] - np.uint32(r0), dtype=np.uint32)
+            self.narrow_forms["row_count_escape_count"] = forms["row_count_escape_count"][a:b]
+        if "row_noise16" in forms:  # (the whole table with every range: a few kilobytes)
+            self.narrow_forms["row_noise16"] = forms["row_noise16"][r0:r1]
+            self.narrow_forms["row_noise_table"] = forms["row_noise_table"]
 
-    def as_c(self, compact: bool = True) -> CClusterBatch:
+    def as_c(self, compact: bool = True, narrow: bool = False) -> CClusterBatch:
         assert compact, "a cluster range has no offset arrays of its own"
+        tail = ()
+        if narrow:
+            forms = self.narrow_forms
+            tail = (_ptr(forms["path_idx16"], u16p) if "path_idx16" in forms else None,
+                    _ptr(forms["source_id16"], u16p) if "source_id16" in forms else None,
+                    _ptr(forms["row_count8"], u8p) if "row_count8" in forms else None,
+                    _ptr(forms["row_count_escape_row"], u32p) if "row_count8" in forms else None,
+                    _ptr(forms["row_count_escape_count"], u32p) if "row_count8" in forms else None,
+                    len(forms["row_count_escape_row"]) if "row_count8" in forms else 0,
+                    _ptr(forms["row_noise16"], u16p) if "row_noise16" in forms else None,
+                    _ptr(forms["row_noise_table"], f64p) if "row_noise16" in forms else None,
+                    len(forms["row_noise_table"]) if "row_noise16" in forms else 0)
         return CClusterBatch(
             self.num_clusters, _ptr(self.cluster_row_off, u64p), _ptr(self.cluster_path_off, u64p),
             _ptr(self.row_count, u32p), _ptr(self.row_noise, f64p), None,
             _ptr(self.grp_prob, f64p), None, _ptr(self.path_idx, u32p),
             _ptr(self.path_group_id, u32p), _ptr(self.path_source_count, u32p), _ptr(self.path_source_off, u64p),
             _ptr(self.source_id, u32p), _ptr(self.path_effective_length, f64p), None, None,
-            _ptr(self.row_grp_count8, u8p), _ptr(self.grp_idx_count8, u8p), len(self.grp_prob), len(self.path_idx))
+            _ptr(self.row_grp_count8, u8p), _ptr(self.grp_idx_count8, u8p), len(self.grp_prob), len(self.path_idx), *tail)
 
 
 @dataclass

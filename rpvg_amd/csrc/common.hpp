@@ -694,8 +694,9 @@ namespace rpvg_hip_detail {
 struct PathSourcesPending {
     DeviceBuffer<uint64_t> d_path_source_off;
     DeviceBuffer<uint32_t> d_source_id, d_sizes;
+    DeviceBuffer<uint16_t> d_source_id16;  // rpvg_cluster_batch::source_id16: widened into d_source_id behind the copy
     DeviceBuffer<unsigned long long> d_arena;
-    unsigned long long arena_words = 0, num_sources = 0;
+    unsigned long long arena_words = 0, num_sources = 0, num_sources_narrow = 0;
     void * h_sizes = nullptr;  // pinned: [num_cols K | col_paths K | max_col_paths K | error, arena overflow]
     uint32_t K = 0;
     bool copied = false, queued = false;
@@ -737,6 +738,11 @@ struct rpvg_hip_batch {
         rpvg_hip_detail::DeviceBuffer<uint64_t> d_row_grp_off, d_grp_idx_off;
         rpvg_hip_detail::DeviceBuffer<double> d_grp_prob;
         rpvg_hip_detail::DeviceBuffer<uint8_t> d_row_grp_count8, d_grp_idx_count8;  // the count form (include/rpvg_batch.h): summed up into the 32-bit offsets behind the copy
+        // the narrow forms (rpvg_cluster_batch::path_idx16 / row_count8 + escapes): widened behind the copy (widenNarrowKernel)
+        rpvg_hip_detail::DeviceBuffer<uint16_t> d_path_idx16, d_row_noise16;
+        rpvg_hip_detail::DeviceBuffer<double> d_row_noise_table;
+        rpvg_hip_detail::DeviceBuffer<uint8_t> d_row_count8;
+        rpvg_hip_detail::DeviceBuffer<uint32_t> d_escape_row, d_escape_count;
         uint64_t num_groups = 0;
         rpvg_hip_detail::PathSourcesPending path_sources;
         // the second half queued (uploadFinishQueue): what its kernels write and what comes back, until the wait

@@ -866,6 +866,25 @@ __global__ void clusterEntryOffsetsKernel(const uint32_t num_clusters, const uin
     if (k <= num_clusters) out[k] = row_ent_off[cluster_row_off[k]];
 }
 
+// the narrow forms of a batch's copy back in 32 bits: path indices, read counts (a count of 255 stands for "listed": escapeRowCountsKernel), source ids
+__global__ __launch_bounds__(256) void widenNarrowKernel(const uint16_t * __restrict__ path16, uint32_t * __restrict__ path32, const uint64_t num_entries,
+                                                         const uint8_t * __restrict__ count8, uint32_t * __restrict__ count32, const uint64_t num_rows,
+                                                         const uint16_t * __restrict__ source16, uint32_t * __restrict__ source32, const uint64_t num_sources,
+                                                         const uint16_t * __restrict__ noise16, const double * __restrict__ noise_table, const uint32_t num_noise_values,
+                                                         double * __restrict__ noise, const uint64_t num_noise_rows) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x, first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    for (uint64_t i = first; i < num_noise_rows; i += stride) noise[i] = noise16[i] < num_noise_values ? noise_table[noise16[i]] : -1.0;
+    for (uint64_t i = first; i < num_entries; i += stride) path32[i] = path16[i];
+    for (uint64_t i = first; i < num_rows; i += stride) count32[i] = count8[i];
+    for (uint64_t i = first; i < num_sources; i += stride) source32[i] = source16[i];
+}
+
+__global__ void escapeRowCountsKernel(const uint32_t * __restrict__ escape_row, const uint32_t * __restrict__ escape_count, const uint64_t num_escapes,
+                                      const uint64_t num_rows, uint32_t * __restrict__ count32) {
+    const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (i < num_escapes && escape_row[i] < num_rows) count32[escape_row[i]] = escape_count[i];
+}
+
 __global__ void widenOffsetsKernel(const uint64_t n, const uint32_t * __restrict__ narrow, uint64_t * __restrict__ wide) {
     const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (i < n) wide[i] = narrow[i];
@@ -876,16 +895,17 @@ constexpr size_t kProblemChars = 256;
 bool validateRow(const rpvg_cluster_batch * hb, const uint32_t k, const uint64_t r, char * message) {
     message[0] = 0;
     const uint64_t n_paths = hb->cluster_path_off[k + 1] - hb->cluster_path_off[k];
-    const double nz = hb->row_noise[r];
+    const double nz = hb->row_noise16 ? (hb->row_noise16[r] < hb->num_row_noise_values ? hb->row_noise_table[hb->row_noise16[r]] : -1.0) : hb->row_noise[r];
     if (!(nz > 0 && nz <= 1)) {
         std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: row %llu has noise probability %g outside (0, 1]",
                       static_cast<unsigned long long>(r), nz);
         return false;
     }
     for (uint64_t e = groupEntryOffset(hb, rowGroupOffset(hb, r)); e < groupEntryOffset(hb, rowGroupOffset(hb, r + 1)); ++e) {
-        if (!(hb->path_idx[e] < n_paths)) {
+        const uint32_t path = hb->path_idx16 ? hb->path_idx16[e] : hb->path_idx[e];
+        if (!(path < n_paths)) {
             std::snprintf(message, kProblemChars, "rpvg_hip_batch_upload: row %llu refers to path %u of a cluster with %llu paths",
-                          static_cast<unsigned long long>(r), hb->path_idx[e], static_cast<unsigned long long>(n_paths));
+                          static_cast<unsigned long long>(r), path, static_cast<unsigned long long>(n_paths));
             return false;
         }
     }
@@ -1014,14 +1034,16 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
     const uint64_t R = hb->cluster_row_off[K];
     const uint64_t P = hb->cluster_path_off[K];
     const bool counts = R > 0 && countForm(hb);  // one byte per row and group instead of the offsets (include/rpvg_batch.h)
-    RPVG_REQUIRE(R == 0 || (hb->row_count && hb->row_noise && (counts || ((hb->row_grp_off || hb->row_grp_off32) && (hb->grp_idx_off || hb->grp_idx_off32)))),
+    RPVG_REQUIRE(R == 0 || ((hb->row_count || hb->row_count8) && (hb->row_noise || (hb->row_noise16 && hb->row_noise_table)) && (counts || ((hb->row_grp_off || hb->row_grp_off32) && (hb->grp_idx_off || hb->grp_idx_off32)))),
                  "rpvg_hip_batch_upload: row arrays are NULL");
     RPVG_REQUIRE(!counts || (hb->num_groups < 0xffffffffull && hb->num_entries < 0xffffffffull && hb->num_groups > 0),
                  "rpvg_hip_batch_upload: counts of one byte come with their totals (num_groups, num_entries: below 2^32 - 1)");
     const uint64_t G = counts ? hb->num_groups : (R ? rowGroupOffset(hb, R) : 0);
     const uint64_t NNZ = counts ? hb->num_entries : (G ? groupEntryOffset(hb, G) : 0);
     RPVG_REQUIRE(G == 0 || hb->grp_prob, "rpvg_hip_batch_upload: grp_prob is NULL");
-    RPVG_REQUIRE(NNZ == 0 || hb->path_idx, "rpvg_hip_batch_upload: path_idx is NULL");
+    RPVG_REQUIRE(NNZ == 0 || hb->path_idx || hb->path_idx16, "rpvg_hip_batch_upload: path_idx is NULL");
+    RPVG_REQUIRE(!hb->row_count8 || hb->num_row_count_escapes == 0 || (hb->row_count_escape_row && hb->row_count_escape_count),
+                 "rpvg_hip_batch_upload: row_count8 comes with the list of the rows whose count does not fit a byte");
 
     std::unique_ptr<HostScope> scope(new HostScope("batch_upload: host checks + offsets"));
     // validation: the cluster offsets here (O(K)); the rows and entries on the device, behind their copy (validateRowsKernel)
@@ -1061,8 +1083,21 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     ok(b->cluster_row_off.upload(hb->cluster_row_off, K + 1, ctx->stream));
     ok(b->cluster_path_off.upload(hb->cluster_path_off, K + 1, ctx->stream));
-    ok(b->row_noise.upload(hb->row_noise, R, ctx->stream));
-    ok(up.d_row_count_u32.upload(hb->row_count, R, ctx->stream));
+    if (hb->row_noise16) {  // (looked up behind the copy: widenNarrowKernel; an index outside the table becomes a noise of -1 and fails the validation)
+        ok(up.d_row_noise16.upload(hb->row_noise16, R, ctx->stream));
+        ok(up.d_row_noise_table.upload(hb->row_noise_table, hb->num_row_noise_values, ctx->stream));
+        ok(b->row_noise.alloc(R));
+    } else {
+        ok(b->row_noise.upload(hb->row_noise, R, ctx->stream));
+    }
+    if (hb->row_count8) {  // (widened behind the copy, the listed rows written over: widenNarrowKernel)
+        ok(up.d_row_count8.upload(hb->row_count8, R, ctx->stream));
+        ok(up.d_escape_row.upload(hb->row_count_escape_row, hb->num_row_count_escapes, ctx->stream));
+        ok(up.d_escape_count.upload(hb->row_count_escape_count, hb->num_row_count_escapes, ctx->stream));
+        ok(up.d_row_count_u32.alloc(R));
+    } else {
+        ok(up.d_row_count_u32.upload(hb->row_count, R, ctx->stream));
+    }
     const uint64_t zero_off[1] = {0};
     // (the 32-bit forms travel as they are and are widened on the device, behind the copy)
     const bool narrow_offsets = R && G && hb->row_grp_off32 && hb->grp_idx_off32;
@@ -1086,15 +1121,21 @@ static int uploadBegin(rpvg_hip_ctx * ctx, const rpvg_cluster_batch * hb, rpvg_h
         ok(up.d_grp_idx_off.upload(G ? hb->grp_idx_off : zero_off, G + 1, ctx->stream));
     }
     ok(up.d_grp_prob.upload(hb->grp_prob, G, ctx->stream));
-    ok(b->ent_path.upload(hb->path_idx, NNZ, ctx->stream));
+    if (hb->path_idx16) {
+        ok(up.d_path_idx16.upload(hb->path_idx16, NNZ, ctx->stream));
+        ok(b->ent_path.alloc(NNZ));
+    } else {
+        ok(b->ent_path.upload(hb->path_idx, NNZ, ctx->stream));
+    }
     ok(b->ent_prob.alloc(NNZ));
     ok(b->row_count.alloc(R));
     ok(b->row_ent_off.alloc(R + 1));
     // the path side, when the caller handed it in: PathInfo::group_id and source_ids (path_sources.hip)
     if (e == hipSuccess) ok(queuePathSourceCopies(ctx, b, hb, up.path_sources));
     ctx->spanEnd(span);
-    ctx->stats.h2d_bytes += static_cast<double>((K + 1) * 16 + R * 12 + (counts ? R : (R + 1) * (hb->row_grp_off32 ? 4 : 8)) +
-                                                (counts ? G : (G + 1) * (hb->grp_idx_off32 ? 4 : 8)) + G * 8 + NNZ * 4);
+    ctx->stats.h2d_bytes += static_cast<double>((K + 1) * 16 + (hb->row_noise16 ? R * 2 + 8 * hb->num_row_noise_values : R * 8) + (hb->row_count8 ? R + 8 * hb->num_row_count_escapes : 4 * R) +
+                                                (counts ? R : (R + 1) * (hb->row_grp_off32 ? 4 : 8)) +
+                                                (counts ? G : (G + 1) * (hb->grp_idx_off32 ? 4 : 8)) + G * 8 + NNZ * (hb->path_idx16 ? 2 : 4));
     if (e != hipSuccess) {
         setError("rpvg_hip_batch_upload: %s", hipGetErrorString(e));
         (void) hipStreamSynchronize(ctx->stream);
@@ -1131,6 +1172,19 @@ static int uploadFinishQueue(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, hipStream_t
     }
     if (e == hipSuccess && !narrow && up.d_grp_idx_off32.ptr) {
         widenOffsetsKernel<<<dim3(static_cast<uint32_t>((G + 1 + 255) / 256)), dim3(256), 0, st>>>(G + 1, up.d_grp_idx_off32.ptr, up.d_grp_idx_off.ptr);
+    }
+    // the narrow forms of the copy (include/rpvg_batch.h): path indices, read counts and source ids back in 32 bits
+    if (e == hipSuccess && (up.d_path_idx16.ptr || up.d_row_count8.ptr || up.path_sources.d_source_id16.ptr || up.d_row_noise16.ptr)) {
+        const uint64_t S16 = up.path_sources.d_source_id16.ptr ? up.path_sources.num_sources_narrow : 0;
+        const uint64_t most = std::max<uint64_t>(std::max<uint64_t>(up.d_path_idx16.ptr ? NNZ : 0, (up.d_row_count8.ptr || up.d_row_noise16.ptr) ? R : 0), S16);
+        widenNarrowKernel<<<dim3(static_cast<uint32_t>(std::min<uint64_t>((most + 1023) / 1024 + 1, 4096))), dim3(256), 0, st>>>(
+            up.d_path_idx16.ptr, b->ent_path.ptr, up.d_path_idx16.ptr ? NNZ : 0, up.d_row_count8.ptr, up.d_row_count_u32.ptr, up.d_row_count8.ptr ? R : 0,
+            up.path_sources.d_source_id16.ptr, up.path_sources.d_source_id.ptr, S16,
+            up.d_row_noise16.ptr, up.d_row_noise_table.ptr, static_cast<uint32_t>(up.d_row_noise_table.count), b->row_noise.ptr, up.d_row_noise16.ptr ? R : 0);
+        if (up.d_escape_row.count) {
+            escapeRowCountsKernel<<<dim3(static_cast<uint32_t>((up.d_escape_row.count + 255) / 256)), dim3(256), 0, st>>>(
+                up.d_escape_row.ptr, up.d_escape_count.ptr, up.d_escape_row.count, R, up.d_row_count_u32.ptr);
+        }
     }
     const uint32_t threads = 256;
     const dim3 group_grid(static_cast<uint32_t>((G + threads - 1) / threads)), meta_grid(static_cast<uint32_t>((R + 1 + threads - 1) / threads)),

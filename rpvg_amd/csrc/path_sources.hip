@@ -305,7 +305,7 @@ hipError_t queuePathSourceCopies(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const r
     pending.K = K;
     if (K == 0 || P == 0 || !hb->path_source_off || !hb->path_group_id) return hipSuccess;
     const uint64_t S = hb->path_source_off[P];
-    if (S == 0 || !hb->source_id || S > 0xfffffff0ull) return hipSuccess;
+    if (S == 0 || !(hb->source_id || hb->source_id16) || S > 0xfffffff0ull) return hipSuccess;
     hipStream_t st = ctx->stream;
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
@@ -313,9 +313,15 @@ hipError_t queuePathSourceCopies(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, const r
     for (uint32_t k = 0; k <= K; ++k) b->h_cluster_src_off[k] = hb->path_source_off[hb->cluster_path_off[k]];
     ok(b->path_group_id.upload(hb->path_group_id, P, st));
     ok(pending.d_path_source_off.upload(hb->path_source_off, P + 1, st));
-    ok(pending.d_source_id.upload(hb->source_id, S, st));
+    if (hb->source_id16) {  // (widened behind the copy: widenSourceIds)
+        ok(pending.d_source_id16.upload(hb->source_id16, S, st));
+        pending.num_sources_narrow = S;
+        ok(pending.d_source_id.alloc(S));
+    } else {
+        ok(pending.d_source_id.upload(hb->source_id, S, st));
+    }
     ok(b->cluster_src_off.upload(b->h_cluster_src_off.data(), K + 1, st));
-    ctx->stats.h2d_bytes += static_cast<double>(P * 12 + S * 4 + K * 8);
+    ctx->stats.h2d_bytes += static_cast<double>(P * 12 + S * (hb->source_id16 ? 2 : 4) + K * 8);
     ok(reserveColumnSlots(b, K, S, pending));
     pending.copied = (e == hipSuccess);
     return e;

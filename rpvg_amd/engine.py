@@ -295,9 +295,10 @@ class Pipeline:
         if lib().rpvg_amd_pipeline_prepare_slot(self.handle, C.byref(cb), slot) != 0:
             raise hip.EngineError(f"pipeline prepare failed: {_err()}")
 
-    def submit(self, batch, slot: int, compact: bool = False):
-        """compact: hand the batch over with 32-bit offset arrays (ClusterBatch.as_c).  `batch`: a ClusterBatch or a ClusterRange."""
-        cb = batch.as_c(compact)
+    def submit(self, batch, slot: int, compact: bool = False, narrow: bool = False):
+        """compact / narrow: the forms of the batch's arrays made for the copy (ClusterBatch.as_c).  `batch`: a ClusterBatch or a
+        ClusterRange."""
+        cb = batch.as_c(compact, narrow) if narrow else batch.as_c(compact)
         self._keep.append((batch, cb))
         if lib().rpvg_amd_pipeline_submit(self.handle, C.byref(cb), slot) != 0:
             raise hip.EngineError(f"pipeline submit failed: {_err()}")

@@ -207,7 +207,7 @@ class PinnedSegments:
 
 
 class DeviceBatch:
-    def __init__(self, ctx: "Context", host: ClusterBatch, compact: bool = False, segments: "PinnedSegments" = None):
+    def __init__(self, ctx: "Context", host: ClusterBatch, compact: bool = False, segments: "PinnedSegments" = None, narrow: bool = False):
         self.ctx = ctx
         self.host = host
         self.handle = C.c_void_p()
@@ -215,7 +215,7 @@ class DeviceBatch:
             _check(lib().rpvg_hip_batch_upload_segments(ctx.handle, segments.segments, C.c_uint32(segments.count), C.byref(self.handle)),
                    "rpvg_hip_batch_upload_segments")
             return
-        cb = host.as_c(compact)
+        cb = host.as_c(compact or narrow, narrow) if narrow else host.as_c(compact)
         _check(lib().rpvg_hip_batch_upload(ctx.handle, C.byref(cb), C.byref(self.handle)), "rpvg_hip_batch_upload")
 
     def has_source_columns(self) -> bool:
@@ -482,9 +482,9 @@ class Context:
     def synchronize(self):
         _check(lib().rpvg_hip_synchronize(self.handle), "rpvg_hip_synchronize")
 
-    def upload(self, host: ClusterBatch, compact: bool = False) -> DeviceBatch:
-        """compact: the forms of the two long offset arrays made for the copy (ClusterBatch.as_c)."""
-        return DeviceBatch(self, host, compact)
+    def upload(self, host: ClusterBatch, compact: bool = False, narrow: bool = False) -> DeviceBatch:
+        """compact / narrow: the forms of the batch's arrays made for the copy (ClusterBatch.as_c)."""
+        return DeviceBatch(self, host, compact, narrow=narrow)
 
     def upload_segments(self, host: ClusterBatch, segments: PinnedSegments) -> DeviceBatch:
         """The batch from one page-locked segment per cluster (rpvg_hip_batch_upload_segments)."""

@@ -768,8 +768,8 @@ def test_upload_from_counts_of_one_byte_equals_the_upload_from_offsets(hip_ctx):
             dev.free()
     (single_a, abund_a, noise_a, total_a, _, totals_a), (single_b, abund_b, noise_b, total_b, _, totals_b) = results
     assert np.array_equal(single_a, single_b) and np.array_equal(total_a, total_b) and np.array_equal(totals_a, totals_b)
-    # (the EM adds its column sums up with LDS atomics: equal up to their order)
-    assert np.allclose(abund_a, abund_b, rtol=1e-9, atol=1e-12) and np.allclose(noise_a, noise_b, rtol=1e-9, atol=1e-12)
+    # (the EM's column sums have one order of additions: em_sparse.hip, emSparseProblem)
+    assert np.array_equal(abund_a, abund_b) and np.array_equal(noise_a, noise_b)
 
     # a group of 300 paths: the counts do not fit, the offsets travel
     wide = small_cases.make_batch_clusters(983, n_clusters=2, with_empty=False)
@@ -1032,5 +1032,63 @@ def test_spans_of_a_caller_that_never_reads_the_statistics_are_folded_on_the_way
         assert after["em_sparse_launches"] == per_call * (calls + 1)
         assert after["em_sparse_ms"] > before["em_sparse_ms"] * calls * 0.2
         assert np.array_equal(first[3], last[3])
+    finally:
+        dev.free()
+
+
+def test_upload_from_the_narrow_forms_equals_the_upload_from_32_bits(hip_ctx):
+    """rpvg_cluster_batch::path_idx16 / source_id16 / row_count8 + the list of the rows whose count does not fit a byte
+    (include/rpvg_batch.h): widened on the device behind the copy — the same batch as from the 32-bit arrays: read totals, haplotype
+    columns, log-likelihoods and EM solutions bit for bit; a cluster of 65 536 paths or an id of 65 536 keeps the 32-bit array."""
+    from rpvg_amd import hip
+    clusters = small_cases.make_batch_clusters(991, n_clusters=20, max_reads=600, with_empty=True)
+    # read counts on both sides of a byte
+    big = clusters[3]["rows"]
+    clusters[3]["rows"] = [(c if i % 5 else 254 + (i % 4) * 300, z, g) for i, (c, z, g) in enumerate(big)]
+    batch = ClusterBatch.from_clusters(clusters)
+    forms = batch.narrow()
+    assert set(forms) == {"path_idx16", "source_id16", "row_count8", "row_count_escape_row", "row_count_escape_count", "row_noise16", "row_noise_table"}
+    assert len(forms["row_count_escape_row"]) > 2 and int(batch.row_count.max()) > 255
+    cb = batch.as_c(True, True)
+    assert bool(cb.path_idx16) and bool(cb.source_id16) and bool(cb.row_count8) and cb.num_row_count_escapes == len(forms["row_count_escape_row"])
+    assert bool(cb.row_noise16) and cb.num_row_noise_values == len(np.unique(batch.row_noise))
+    results = []
+    for narrow in (True, False):
+        dev = hip_ctx.upload(batch, compact=True, narrow=narrow)
+        try:
+            mats = [k for k, cl in enumerate(clusters) if cl["rows"]]
+            groups = [[[p] for p in range(len(clusters[k]["paths"]))] for k in mats]
+            dg = hip_ctx.groups(dev, mats, groups, False)
+            req_m = [m for m, g in enumerate(groups) for _ in g]
+            req_c = [[c] for g in groups for c in range(len(g))]
+            single = dg.loglik(req_m, req_c, 1.0)
+            abund, noise, total, iters = hip_ctx.em_solve(dev, mats, [list(range(len(clusters[k]["paths"]))) for k in mats])
+            columns = [dev.source_columns(k) for k in range(batch.num_clusters)]
+            results.append((single, np.concatenate(abund), noise, total, iters, dev.cluster_totals(), columns))
+        finally:
+            dev.free()
+    a, b = results
+    assert all(np.array_equal(x, y) for x, y in zip(a[:6], b[:6])) and a[6] == b[6]
+    for k in range(batch.num_clusters):
+        r0, r1 = int(batch.cluster_row_off[k]), int(batch.cluster_row_off[k + 1])
+        assert a[5][k] == float(batch.row_count[r0:r1].astype(np.uint64).sum())
+
+    # an index outside the table of noise values is an invalid noise probability
+    forms["row_noise16"][5] = 60000
+    try:
+        with pytest.raises(hip.EngineError, match="noise probability"):
+            hip_ctx.upload(batch, compact=True, narrow=True)
+    finally:
+        forms["row_noise16"][5] = np.searchsorted(forms["row_noise_table"], batch.row_noise[5])
+
+    # an id of 65 536 and up: the source ids stay in 32 bits, the rest narrow
+    fields = {name: getattr(batch, name).copy() for name in ClusterBatch._DTYPES}
+    fields["source_id"] = fields["source_id"] + np.uint32(70000)
+    far = ClusterBatch(**fields)
+    assert "source_id16" not in far.narrow() and "path_idx16" in far.narrow()
+    dev = hip_ctx.upload(far, compact=True, narrow=True)
+    try:
+        assert np.array_equal(dev.cluster_totals(), a[5])
+        assert [dev.source_columns(k)[1] for k in range(far.num_clusters)] == [c[1] for c in a[6]]
     finally:
         dev.free()
