@@ -573,9 +573,37 @@ def run_s3(args, rank, local_rank, world, dist, torch):
                 line["roofline_gibbs"] = gibbs_line(args, local_rank)
             except Exception as exc:  # noqa: BLE001
                 line["roofline_gibbs"] = dict(error=str(exc))
+        if args.workload == "s3" and args.model == "haplotype-transcripts" and world == 1 and not os.environ.get("RPVG_BENCH_NO_DROP_IN_LINE"):
+            try:
+                line["drop_in"] = drop_in_line(args, local_rank)
+            except Exception as exc:  # noqa: BLE001
+                line["drop_in"] = dict(error=str(exc))
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_s3(batch, args.model, params, args.cpu_seconds)
+        cpu_value = line["cpu_baseline"].get("value") if isinstance(line["cpu_baseline"], dict) else None
+        if cpu_value:
+            # (vs_baseline stays null: BASELINE.md holds no published number for this metric — the ratio to the same-run CPU line is its own field)
+            line["vs_cpu_baseline"] = line["value"] / cpu_value if line.get("value") else None
+            if isinstance(line.get("drop_in"), dict) and line["drop_in"].get("value"):
+                line["drop_in"]["vs_cpu_baseline"] = line["drop_in"]["value"] / cpu_value
     return line
+
+
+def drop_in_line(args, local_rank, steps=5, team=64):
+    """The reference's own call pattern inside the default run, so that the driver's record carries it: PathEstimator::estimate() once
+    per cluster from an OpenMP team of 64 threads on the configs[2] workload (src/main.cpp:829,976-977) — a short run of the
+    --workload a1 bench as a child process (its own engine, its own memory)."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "a1", "--team", str(team), "--steps", str(steps), "--warmup", "2",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr[-400:])
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    return dict(value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"], ms_per_step_in_order=d["ms_per_step_in_order"], steps=d["steps"],
+                team_threads=team, estimates_equal_estimate_batch=d["estimates_equal_estimate_batch"], workload=d["config"]["workload"],
+                note="a step = all 5 000 clusters of the configs[2] data set through estimate(), one call per cluster, every caller blocked until its "
+                     "cluster is done; callers flatten their clusters into page-locked segments that the GPU reads in place, the calls in flight are "
+                     "joined into batches (PathEstimator::CallCombiner); python bench.py --workload a1 prints the full line")
 
 
 def measure_with_uploads(args, eng, eng_mod, prepared, batch, params, local_rank, dist, torch):
