@@ -523,6 +523,7 @@ int rpvg_amd_run_team(void * engine, void * prepared_batch, const char * model, 
         std::string first_failure;
 
         const auto start = std::chrono::steady_clock::now();
+        ScopedPhase pass_phase("team: one pass of estimate() calls");
 
         #pragma omp parallel for schedule(dynamic, 1) num_threads(std::max(1, threads))
         for (size_t i = 0; i < estimates.size(); ++i) {
@@ -541,6 +542,8 @@ int rpvg_amd_run_team(void * engine, void * prepared_batch, const char * model, 
                 }
             }
         }
+
+        pass_phase.stop();
 
         if (seconds_out) {
 
