@@ -107,6 +107,20 @@ def test_dense_cluster_takes_the_dense_route(engine, rows, paths):
     assert stats["em_kernel"][GRID]["problems"] == 1 and stats["em_kernel"][GRID]["iterations"] == 0  # (accounted as dense)
 
 
+def test_dense_route_at_50000_rows_by_2000_paths_matches_the_oracle(engine):
+    """The shape of BASELINE.json configs[1] at a twentieth of its rows — 50 000 rows x 2 000 paths, every row touching every
+    path: 10^8 entries — through PathAbundanceEstimator::estimateBatch: compaction, dense copy (emGridDenseBuildKernel), the wide
+    streaming kernel (a row per workgroup) — against the oracle after a fixed budget of iterations (full convergence takes
+    thousands; the oracle walks the dense matrix on one core)."""
+    batch = large_cases.cluster_batch(50000, 2000, 2000, seed=11, noise_only_frac=0.01)
+    params = make_params(max_em_its=10)
+    got, stats = _run(engine, "transcripts", params, batch)
+    ref, _ = pyoracle.run("transcripts", params, batch, 1)
+    _compare(got, ref)
+    assert ref[0].em_iters[0] == 10 and stats["em_dense_launches"] == 10
+    assert stats["em_kernel"][GRID]["problems"] == 1 and stats["em_kernel"][GRID]["iterations"] == 0  # (accounted as dense)
+
+
 def test_large_and_small_clusters_in_one_batch(engine, monkeypatch):
     """The grid bin next to the one-workgroup bins of the same solve."""
     monkeypatch.setenv("RPVG_HIP_EM_GRID_MIN_WORK", "50000")
