@@ -696,8 +696,12 @@ int createContext(int device, const bool uploader, const int side_streams, rpvg_
 
 void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
     if (!ctx) return;
+    const bool trace = std::getenv("RPVG_AMD_TRACE_EXIT") != nullptr;
+#define RPVG_EXIT_STEP(what) do { if (trace) std::fprintf(stderr, "[exit]   rpvg_hip_destroy: %s\n", what); } while (0)
+    RPVG_EXIT_STEP("begin");
     (void) hipSetDevice(ctx->device);
     (void) ctx->foldSpans();
+    RPVG_EXIT_STEP("spans folded");
     (void) rpvg_hip_comm_destroy(ctx);
     if (ctx->stream) forgetCopyStream(ctx->stream);
     for (int i = 0; i < ctx->aux_count; ++i) {
@@ -707,16 +711,26 @@ void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
         (void) hipStreamSynchronize(ctx->copy_stream);
         (void) hipStreamDestroy(ctx->copy_stream);
     }
+    RPVG_EXIT_STEP("copy stream destroyed");
     if (ctx->copied) (void) hipEventDestroy(ctx->copied);
-    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    // Every stream drained, then the pooled streams, and the main stream last: a main stream with a hardware queue of its own
+    // (createOwnQueueStream) destroyed in front of the side streams left hipStreamDestroy of the first side stream hanging in one
+    // process exit of twenty (tools/r06_exit_hang.sh: the reference-shaped factory binary, whose default engine goes at exit).
+    if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < ctx->aux_count; ++i) {
+        if (ctx->aux[i]) (void) hipStreamSynchronize(ctx->aux[i]);
+    }
+    if (ctx->collapse_stream) (void) hipStreamSynchronize(ctx->collapse_stream);
+    RPVG_EXIT_STEP("streams drained");
     for (int i = 0; i < ctx->aux_count; ++i) {  // (the entries behind are aliases)
         if (ctx->aux[i]) (void) hipStreamDestroy(ctx->aux[i]);
+        RPVG_EXIT_STEP("a side stream destroyed");
         if (ctx->join_event[i]) (void) hipEventDestroy(ctx->join_event[i]);
     }
-    if (ctx->collapse_stream) {
-        (void) hipStreamSynchronize(ctx->collapse_stream);
-        (void) hipStreamDestroy(ctx->collapse_stream);
-    }
+    if (ctx->collapse_stream) (void) hipStreamDestroy(ctx->collapse_stream);
+    RPVG_EXIT_STEP("side and collapse streams destroyed");
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    RPVG_EXIT_STEP("main stream destroyed");
     if (ctx->fork_event) (void) hipEventDestroy(ctx->fork_event);
     for (hipStream_t grid_stream : ctx->grid_stream) {
         if (grid_stream) {
@@ -732,16 +746,21 @@ void rpvg_hip_destroy(rpvg_hip_ctx * ctx) {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         last = (--g_device_contexts[ctx->device] <= 0);
     }
+    RPVG_EXIT_STEP("events destroyed");
     if (last) {
         poolTrim(ctx->device);
+        RPVG_EXIT_STEP("pool trimmed");
         bool any = false;
         {
             std::lock_guard<std::mutex> lock(g_pool_mutex);
             for (auto & kv : g_device_contexts) any = any || kv.second > 0;
         }
         if (!any) pinnedTrim();
+        RPVG_EXIT_STEP("pinned blocks trimmed");
     }
     delete ctx;
+    RPVG_EXIT_STEP("done");
+#undef RPVG_EXIT_STEP
 }
 
 const char * rpvg_hip_last_error(void) { return g_last_error; }

@@ -1666,6 +1666,13 @@ inline void launchAdjustAndRewrite(const ReplayArgs<MatrixArrays> & r, const uin
     collapseRewriteKernel<<<dim3(grid), dim3(256), 0, on>>>(rewrite);
 }
 inline void launchAdjustAndRewrite(const ReplayArgs<CsrArrays> &, const uint32_t, hipStream_t) {}
+// the rows of the runs take their heads' values, behind a walk-only collapseRunsKernel (no search has read the matrices as built)
+inline void launchRewrite(const ReplayArgs<MatrixArrays> & r, const uint32_t grid, hipStream_t on) {
+    ReplayArgs<MatrixArrays> rewrite = r;
+    rewrite.walk_only = false;
+    collapseRewriteKernel<<<dim3(grid), dim3(256), 0, on>>>(rewrite);
+}
+inline void launchRewrite(const ReplayArgs<CsrArrays> &, const uint32_t, hipStream_t) {}
 
 struct CollapseTemporaries {
     DeviceBuffer<uint32_t> rewritten_count;
@@ -1901,21 +1908,25 @@ hipError_t queueCollapseStages(const Arrays & arrays, const uint32_t M, const ui
     r.rewritten_count = nullptr;
     r.walk_only = false;
     if (held_back_runs) {
+        // The walk over the runs writes nothing a reader of the matrices sees (the heads of the list positions, the list of the
+        // rows that will take their head's values): it runs here, on the collapse's stream, beside the search — one matrix of a
+        // configs[2] batch walks for 0.8 ms, which stood behind the tile kernel on the search's stream (round 5) — and what is
+        // held back is the adjustment of the search's sums and the rewrite of the rows.
         ok(tmp->rewritten_count.alloc(M));
         r.rewritten_count = tmp->rewritten_count.ptr;
+        r.walk_only = true;
+        collapseRunsKernel<Arrays><<<dim3(staged_grid), dim3(256), 0, st>>>(r);
         *held_back_runs = [=](hipStream_t on, const rpvg_hip_groups::SearchSums * sums) {
             ReplayArgs<Arrays> mine = r;
-            if (sums) {  // the search has read the matrices as built: the runs, its sums, then the rows
+            if (sums) {  // the search has read the matrices as built: its sums, then the rows
                 mine.part_pair = sums->part_pair;
                 mine.part_marginal = sums->part_marginal;
                 mine.pair_part_off = sums->pair_part_off;
                 mine.col_part_off = sums->col_part_off;
                 mine.chunk_rows = sums->chunk_rows;
-                mine.walk_only = true;
-                collapseRunsKernel<Arrays><<<dim3(staged_grid), dim3(256), 0, on>>>(mine);
                 launchAdjustAndRewrite(mine, staged_grid, on);
             } else {
-                collapseRunsKernel<Arrays><<<dim3(staged_grid), dim3(256), 0, on>>>(mine);
+                launchRewrite(mine, staged_grid, on);
             }
             return hipGetLastError();
         };

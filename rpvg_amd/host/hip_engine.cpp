@@ -1,4 +1,6 @@
 #include "hip_engine.hpp"
+
+#include <cstdio>
 #include "trace.hpp"
 
 #include <algorithm>
@@ -75,14 +77,20 @@ HipEngine::HipEngine(const int device, const bool uploader, const int host_lanes
 
 HipEngine::~HipEngine() {
 
+    const bool trace = std::getenv("RPVG_AMD_TRACE_EXIT") != nullptr;
+    if (trace) std::fprintf(stderr, "[exit] ~HipEngine begins\n");
+
     lane_workers.clear();
+    if (trace) std::fprintf(stderr, "[exit] lane workers joined\n");
 
     for (auto & lane_context: laneContexts()) {
 
         rpvg_hip_destroy(lane_context);
+        if (trace) std::fprintf(stderr, "[exit] a lane context destroyed\n");
     }
 
     rpvg_hip_destroy(context);
+    if (trace) std::fprintf(stderr, "[exit] ~HipEngine done\n");
 }
 
 std::shared_ptr<HipEngine> HipEngine::processDefault() {

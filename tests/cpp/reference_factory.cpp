@@ -4,6 +4,7 @@
 // (no GPU needed to compile and link); run with a model name on a GPU box it estimates one small cluster through the
 // reference-shaped estimate() call (src/main.cpp:976-977) and prints the abundances.
 #include <cassert>
+#include <cstdlib>
 #include <iostream>
 #include <random>
 #include <string>
@@ -74,6 +75,7 @@ int main(int argc, char * argv[]) {
 
     mt19937 mt_rng(0);
     path_estimator->estimate(&estimates, cluster_probs, &mt_rng);
+    if (getenv("RPVG_AMD_TRACE_EXIT")) cerr << "[exit] estimate() returned" << endl;
 
     cout << inference_model << " total " << estimates.total_count << " noise " << estimates.noise_count << " abundances";
 
