@@ -41,13 +41,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 FP64_VALU_PEAK_TFLOPS = 78.6  # FP64 vector rate = half the 157 TF FP32 vector rate (MI355X_MICROARCH.md)
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def load_pmc(name):
     """A PMC summary of profiles/<round>/ (separate rocprofv3 --pmc passes, tools/refresh_profiles_r03.sh): static
     records of the tree of the refresh — the commit they were taken on is part of the record."""
     path = os.path.join(ROOT, "profiles", PROFILE_ROUND, name)
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r05", name)  # (the round before: the record names its commit)
     if not os.path.exists(path):
         return None
     try:

@@ -118,7 +118,11 @@ def run_case(eng, case, oracle_threads=32, isolate_oracle=False):
         ref = oracle_in_a_child(case["model"], case["kw"], case["batch"], oracle_threads)
     else:
         ref, _ = pyoracle.run(case["model"], params, case["batch"], oracle_threads)
-    got, _ = eng.run(case["model"], params, eng.prepare(case["batch"]))
+    team = int(os.environ.get("RPVG_FUZZ_TEAM", "0"))
+    if team > 0:  # the drop-in path: PathEstimator::estimate() once per cluster from an OpenMP team (the call combiner, page-locked segments)
+        got, _ = eng.run_team(case["model"], params, eng.prepare(case["batch"], per_cluster=True), team)
+    else:
+        got, _ = eng.run(case["model"], params, eng.prepare(case["batch"]))
     if ref is None:
         # nothing to compare with: the engine still has to run through, conserve the read mass and keep its posteriors in [0, 1]
         bad = [f"cluster {k}: mass not conserved" for k, g in enumerate(got)
