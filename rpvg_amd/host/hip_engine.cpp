@@ -1,6 +1,7 @@
 #include "hip_engine.hpp"
 
 #include <cstdio>
+#include <cstring>
 #include "trace.hpp"
 
 #include <algorithm>
@@ -249,7 +250,33 @@ void HipEngine::check(const int status, const char * what) {
     }
 }
 
-FlatClusterRows::FlatClusterRows() : cluster_row_off(1, 0), cluster_path_off(1, 0), path_source_off(1, 0), row_grp_off(1, 0), grp_idx_off(1, 0), counts_fit(true) {}
+FlatClusterRows::FlatClusterRows() : cluster_row_off(1, 0), cluster_path_off(1, 0), path_source_off(1, 0), row_grp_off(1, 0), grp_idx_off(1, 0), counts_fit(true), paths_fit16(true), sources_fit16(true), noise_fits16(true) {}
+
+uint16_t FlatClusterRows::noiseIndex(const double noise) {
+
+    uint64_t bits;
+    static_assert(sizeof(bits) == sizeof(noise), "a double is 64 bits");
+    std::memcpy(&bits, &noise, sizeof(bits));
+
+    auto noise_index_it = noise_index.find(bits);
+
+    if (noise_index_it != noise_index.end()) {
+
+        return noise_index_it->second;
+    }
+
+    if (row_noise_table.size() >= 65536) {
+
+        noise_fits16 = false;
+        return 0;
+    }
+
+    const uint16_t index = row_noise_table.size();
+    row_noise_table.emplace_back(noise);
+    noise_index.emplace(bits, index);
+
+    return index;
+}
 
 void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & cluster_probs, const std::vector<PathInfo> & paths) {
 
@@ -260,6 +287,12 @@ void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & clus
         path_group_id.emplace_back(path.group_id);
         source_id.insert(source_id.end(), path.source_ids.begin(), path.source_ids.end());
         path_source_off.emplace_back(source_id.size());
+
+        for (auto & id: path.source_ids) {
+
+            sources_fit16 = sources_fit16 && id < 65536;
+            source_id16.emplace_back(static_cast<uint16_t>(id));
+        }
     }
 
     addCluster(cluster_probs, paths.size());
@@ -274,13 +307,31 @@ void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & clus
             throw EngineError("FlatClusterRows: a batch of more than 2^32 - 1 entries");
         }
 
+        if (probs.readCount() >= 255) {
+
+            row_count_escape_row.emplace_back(row_count.size());
+            row_count_escape_count.emplace_back(probs.readCount());
+        }
+
+        row_count8.emplace_back(static_cast<uint8_t>(std::min<uint32_t>(probs.readCount(), 255)));
         row_count.emplace_back(probs.readCount());
         row_noise.emplace_back(probs.noiseProb());
+
+        if (noise_fits16) {
+
+            row_noise16.emplace_back(noiseIndex(probs.noiseProb()));
+        }
 
         for (auto & path_probs: probs.pathProbs()) {
 
             grp_prob.emplace_back(path_probs.first);
             path_idx.insert(path_idx.end(), path_probs.second.begin(), path_probs.second.end());
+
+            for (auto & path: path_probs.second) {
+
+                path_idx16.emplace_back(static_cast<uint16_t>(path));
+            }
+
             grp_idx_off.emplace_back(path_idx.size());
             grp_idx_count.emplace_back(static_cast<uint8_t>(path_probs.second.size()));
             counts_fit = counts_fit && path_probs.second.size() <= 255;
@@ -290,6 +341,8 @@ void FlatClusterRows::addCluster(const std::vector<ReadPathProbabilities> & clus
         row_grp_count.emplace_back(static_cast<uint8_t>(probs.pathProbs().size()));
         counts_fit = counts_fit && probs.pathProbs().size() <= 255;
     }
+
+    paths_fit16 = paths_fit16 && num_paths < 65536;
 
     cluster_row_off.emplace_back(row_count.size());
     cluster_path_off.emplace_back(cluster_path_off.back() + num_paths);
@@ -321,6 +374,27 @@ void FlatClusterRows::append(const FlatClusterRows & other) {
     row_grp_count.insert(row_grp_count.end(), other.row_grp_count.begin(), other.row_grp_count.end());
     grp_idx_count.insert(grp_idx_count.end(), other.grp_idx_count.begin(), other.grp_idx_count.end());
     counts_fit = counts_fit && other.counts_fit;
+
+    {
+        const uint32_t first_row = row_count.size();
+
+        for (size_t i = 0; i < other.row_count_escape_row.size(); ++i) {
+
+            row_count_escape_row.emplace_back(first_row + other.row_count_escape_row[i]);
+            row_count_escape_count.emplace_back(other.row_count_escape_count[i]);
+        }
+
+        row_count8.insert(row_count8.end(), other.row_count8.begin(), other.row_count8.end());
+        path_idx16.insert(path_idx16.end(), other.path_idx16.begin(), other.path_idx16.end());
+        source_id16.insert(source_id16.end(), other.source_id16.begin(), other.source_id16.end());
+        paths_fit16 = paths_fit16 && other.paths_fit16;
+        sources_fit16 = sources_fit16 && other.sources_fit16;
+
+        for (size_t r = 0; noise_fits16 && r < other.row_noise.size(); ++r) {  // (the other's indices point into the other's table)
+
+            row_noise16.emplace_back(noiseIndex(other.row_noise[r]));
+        }
+    }
 
     row_count.insert(row_count.end(), other.row_count.begin(), other.row_count.end());
     row_noise.insert(row_noise.end(), other.row_noise.begin(), other.row_noise.end());
@@ -356,6 +430,27 @@ rpvg_cluster_batch FlatClusterRows::view() const {
         batch.num_entries = path_idx.size();
     }
 
+    // the narrow forms, for the copy to the GPU, while they fit (the 32-bit arrays stay: whoever walks the batch on the host reads them)
+    if (paths_fit16 && !path_idx.empty()) {
+
+        batch.path_idx16 = path_idx16.data();
+    }
+
+    if (!row_count.empty() && row_count.size() < 0xFFFFFFFFull) {
+
+        batch.row_count8 = row_count8.data();
+        batch.row_count_escape_row = row_count_escape_row.data();
+        batch.row_count_escape_count = row_count_escape_count.data();
+        batch.num_row_count_escapes = row_count_escape_row.size();
+    }
+
+    if (noise_fits16 && row_noise16.size() == row_noise.size() && !row_noise.empty()) {
+
+        batch.row_noise16 = row_noise16.data();
+        batch.row_noise_table = row_noise_table.data();
+        batch.num_row_noise_values = row_noise_table.size();
+    }
+
     // the PathInfo fields the device reads, when the clusters were added with their paths; the rest of PathInfo stays on the
     // host side of the ABI (PathClusterEstimates::paths)
     const bool with_paths = !path_group_id.empty() && path_group_id.size() == cluster_path_off.back();
@@ -364,6 +459,7 @@ rpvg_cluster_batch FlatClusterRows::view() const {
     batch.path_source_count = nullptr;
     batch.path_source_off = with_paths ? path_source_off.data() : nullptr;
     batch.source_id = with_paths ? source_id.data() : nullptr;
+    batch.source_id16 = (with_paths && sources_fit16 && !source_id.empty()) ? source_id16.data() : nullptr;
     batch.path_effective_length = nullptr;
 
     return batch;

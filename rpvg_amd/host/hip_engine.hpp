@@ -11,6 +11,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/rpvg_hip.h"
@@ -144,6 +145,18 @@ class FlatClusterRows {
         bool counts_fit;
         std::vector<uint32_t> row_count, path_idx, path_group_id, source_id;
         std::vector<double> row_noise, grp_prob;
+
+        // the narrow forms of include/rpvg_batch.h, written next to the 32-bit arrays while they fit (the copy to the GPU takes them
+        // instead): cluster-local path indices and source ids in 16 bits, read counts in one byte with the list of the rows that
+        // need more, noise probabilities as indices into the table of their distinct values
+        std::vector<uint16_t> path_idx16, source_id16, row_noise16;
+        std::vector<uint8_t> row_count8;
+        std::vector<uint32_t> row_count_escape_row, row_count_escape_count;
+        std::vector<double> row_noise_table;
+        std::unordered_map<uint64_t, uint16_t> noise_index;  // bits of a noise probability -> its place in the table
+        bool paths_fit16, sources_fit16, noise_fits16;
+
+        uint16_t noiseIndex(const double noise);
 };
 
 // One cluster flattened into page-locked memory that the GPU reads where it lies (include/rpvg_batch.h, rpvg_cluster_segment): what
