@@ -48,8 +48,8 @@ void setError(const char * fmt, ...);
 // Four rounds of measurements left some forty environment switches behind — alternative launch orders, stream layouts, grid
 // sizes, kernels with parts of their work skipped for timing (docs/design/knobs.md).  Several change results or skip work; none
 // belongs in a library somebody links.  The shipped build does not read them: the macro is a null pointer there and the
-// names are not in the binary.  `make -C rpvg_amd/csrc experiments` builds librpvg_hip_experiments.so, which does
-// (-DRPVG_HIP_EXPERIMENTS; RPVG_HIP_LIBRARY=<path> makes the Python harness load it: tools/).
+// names are not in the binary.  `make -C rpvg_amd/csrc clean all EXPERIMENTS=1` builds librpvg_hip.so with them
+// (-DRPVG_HIP_EXPERIMENTS: in place, for tools/ — rebuild without the variable afterwards).
 #ifdef RPVG_HIP_EXPERIMENTS
 #define RPVG_EXPERIMENT_ENV(name) std::getenv(name)
 #else

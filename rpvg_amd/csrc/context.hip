@@ -1182,7 +1182,17 @@ static int uploadFinishQueue(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, hipStream_t
     rpvg_hip_batch::UploadInProgress & up = *b->upload;
     const uint64_t G = up.num_groups;
     HostScope scope("batch_upload: kernels queued");
-    const int bspan = own_stream ? ctx->spanBegin(FAM_BUILD, st) : -1;
+    // (on an uploader's side stream the span is opened and closed under a short hold of the context's lock, and only by a context
+    // that times every kernel family — RPVG_HIP_SPANS=2, bench.py's instrumented pass: the thread that queues these stands behind
+    // the uploader's copies for it)
+    const bool side_span = !own_stream && ctx->span_level >= 2;
+    int bspan = -1;
+    if (own_stream) {
+        bspan = ctx->spanBegin(FAM_BUILD, st);
+    } else if (side_span) {
+        std::lock_guard<std::mutex> span_lock(ctx->mutex);
+        bspan = ctx->spanBegin(FAM_BUILD, st);
+    }
     // both long offset arrays in 32 bits (what a caller that flattens rows for the GPU writes): the kernels read them as they are;
     // one of them only: that one is widened first
     const bool narrow = up.d_row_grp_off32.ptr && up.d_grp_idx_off32.ptr;
@@ -1240,6 +1250,10 @@ static int uploadFinishQueue(rpvg_hip_ctx * ctx, rpvg_hip_batch * b, hipStream_t
         if (e == hipSuccess) clusterEntryOffsetsKernel<<<dim3((K + 1 + 255) / 256), dim3(256), 0, st>>>(K, b->cluster_row_off.ptr, b->row_ent_off.ptr, up.d_cluster_ent_off.ptr);
     }
     if (own_stream) {
+        ctx->spanEnd(bspan);
+        ctx->stats.build_launches += 5;
+    } else if (side_span) {
+        std::lock_guard<std::mutex> span_lock(ctx->mutex);
         ctx->spanEnd(bspan);
         ctx->stats.build_launches += 5;
     }

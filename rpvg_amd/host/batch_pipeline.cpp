@@ -140,18 +140,23 @@ void BatchPipeline::wait() {
     }
 }
 
-void BatchPipeline::fail(std::exception_ptr error) {
+std::vector<std::unique_ptr<BatchPipeline::Job> > BatchPipeline::fail(std::exception_ptr error) {
 
-    // (mutex held) the batches that have not started are dropped: their containers stay as they are
+    // (mutex held) the batches that have not started are dropped: their containers stay as they are.  Only the bookkeeping
+    // happens here: freeing a device batch takes its context's lock and waits for its copies, and every thread of the pipeline
+    // would stand behind this mutex meanwhile.
     if (!first_error) {
 
         first_error = error;
     }
 
+    std::vector<std::unique_ptr<Job> > dropped;
+
     for (auto & job: to_upload) {
 
         busy_estimates.erase(job->estimates);
         --num_unfinished;
+        dropped.emplace_back(std::move(job));
     }
 
     to_upload.clear();
@@ -161,6 +166,7 @@ void BatchPipeline::fail(std::exception_ptr error) {
         busy_estimates.erase(job->estimates);
         --num_unfinished;
         --num_resident;
+        dropped.emplace_back(std::move(job));
     }
 
     copied.clear();
@@ -170,9 +176,12 @@ void BatchPipeline::fail(std::exception_ptr error) {
         busy_estimates.erase(job->estimates);
         --num_unfinished;
         --num_resident;
+        dropped.emplace_back(std::move(job));
     }
 
     resident.clear();
+
+    return dropped;
 }
 
 void BatchPipeline::uploadLoop(const int uploader) {
@@ -216,6 +225,8 @@ void BatchPipeline::uploadLoop(const int uploader) {
 
         const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
 
+        std::vector<std::unique_ptr<Job> > dropped;  // (destroyed behind the block: without the mutex)
+
         {
             std::lock_guard<std::mutex> lock(mutex);
 
@@ -224,7 +235,7 @@ void BatchPipeline::uploadLoop(const int uploader) {
                 busy_estimates.erase(job->estimates);
                 --num_unfinished;
                 --num_resident;
-                fail(error);
+                dropped = fail(error);
 
             } else if (first_error) {  // (a batch failed meanwhile: this one is dropped like those behind it)
 
@@ -280,6 +291,8 @@ void BatchPipeline::queueLoop() {
             error = std::current_exception();
         }
 
+        std::vector<std::unique_ptr<Job> > dropped;  // (destroyed behind the block: without the mutex)
+
         {
             std::lock_guard<std::mutex> lock(mutex);
 
@@ -291,7 +304,7 @@ void BatchPipeline::queueLoop() {
 
                 if (error) {
 
-                    fail(error);
+                    dropped = fail(error);
                 }
 
             } else {
@@ -357,6 +370,8 @@ void BatchPipeline::workerLoop(const int worker) {
         job->device_batch.reset();
         const auto done_at = std::chrono::steady_clock::now();
 
+        std::vector<std::unique_ptr<Job> > dropped;  // (destroyed behind the block: without the mutex)
+
         {
             std::lock_guard<std::mutex> lock(mutex);
 
@@ -370,7 +385,7 @@ void BatchPipeline::workerLoop(const int worker) {
 
             if (error) {
 
-                fail(error);
+                dropped = fail(error);
             }
         }
 

@@ -90,7 +90,10 @@ class BatchPipeline {
         void uploadLoop(const int uploader);
         void queueLoop();
         void workerLoop(const int worker);
-        void fail(std::exception_ptr error);
+        // (mutex held) records the error and takes the batches that have not started out of the queues: the counters are settled
+        // here, the jobs — device batches whose destruction waits for their copies — are the caller's to destroy once it has let
+        // go of the mutex
+        std::vector<std::unique_ptr<Job> > fail(std::exception_ptr error);
 
         const int device;
         const std::string model;
