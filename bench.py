@@ -376,7 +376,9 @@ def run_s3(args, rank, local_rank, world, dist, torch):
             one["note"] = ("the same steps with ONE batch in flight (the headline of rounds 2-4): estimateBatch on two host lanes, the next batch "
                            "uploaded under it from a second resident slot")
             h2d["one_batch_in_flight"] = one
-            if world == 1 and not os.environ.get("RPVG_BENCH_NO_SINGLE_DATASET"):
+            # (the configs[2] line only: a model that draws random numbers gives cluster i of a SUBMITTED batch the generator mt19937(rng_seed + i),
+            # src/main.cpp:976 — the parts of a data set then draw from other generators than the whole)
+            if world == 1 and args.workload == "s3" and args.model == "haplotype-transcripts" and not os.environ.get("RPVG_BENCH_NO_SINGLE_DATASET"):
                 try:
                     h2d["single_dataset"] = measure_single_dataset(args, eng_mod, batch, params, local_rank)
                 except Exception as exc:  # noqa: BLE001
@@ -531,6 +533,18 @@ def run_s3(args, rank, local_rank, world, dist, torch):
                   ms_per_step=ll_ms / args.steps,
                   note="device time = HIP-event spans of the log-likelihood kernels on their streams (the spans of the two host lanes "
                        "overlap each other and the EM kernels); VALU utilisation and instructions per evaluation: profiles/ PMC passes")
+    if stats.get("search_tile_launches"):
+        # the kernel the evaluations belong to, by its own HIP-event spans (the instrumented pass): what `frac` is computed from —
+        # 2 flop x evaluations per launch / its mean duration; the family's spans above also hold the kernels behind it and overlap
+        # between the batches in flight
+        tile_ms = stats["search_tile_ms"] / stats["search_tile_launches"]
+        evals_per_launch = (evals / args.steps) / max(1e-9, stats["search_tile_launches"] / args.steps)
+        tile_tflops = (2.0 * evals_per_launch / 1e12) / (tile_ms / 1e3) if tile_ms > 0 else 0.0
+        search.update(frac_over_family_spans=search["frac"], achieved_over_family_spans=search["achieved"], achieved=tile_tflops,
+                      frac=tile_tflops / FP64_VALU_PEAK_TFLOPS, kernel_ms_per_launch=tile_ms, kernel_launches_per_step=stats["search_tile_launches"] / args.steps,
+                      frac_note="achieved / frac = 2 flop x row-pair evaluations of a launch / the mean duration of pairTile2Kernel by its own HIP events "
+                                "(rpvg_hip_kernel_stats::search_tile_ms); *_over_family_spans = the same evaluations over the spans of the whole "
+                                "log-likelihood family (tile kernel, the collapse's held-back stage, resolveTableKernel), which overlap between batches in flight")
     if stats.get("search_pairs_possible"):
         search.update(pairs_possible_per_step=stats["search_pairs_possible"] / args.steps, pairs_kept_per_step=stats["search_pairs_kept"] / args.steps,
                       pairs_evaluated_exhaustively_per_step=stats["search_pairs_table"] / args.steps,
@@ -903,7 +917,7 @@ def measure_pipeline(args, eng_mod, batch, params, local_rank, dist, torch):
             os.environ.pop("RPVG_HIP_SPANS", None)
         # (per step of ITS pass, scaled to the steps of the timed one: what the caller divides by)
         scale = args.steps / float(instrumented["steps"])
-        for key in ("em_sparse_ms", "em_dense_ms", "loglik_ms", "build_ms", "h2d_ms", "collapse_ms", "busy_ms", "gibbs_ms"):
+        for key in ("em_sparse_ms", "em_dense_ms", "loglik_ms", "build_ms", "h2d_ms", "collapse_ms", "busy_ms", "gibbs_ms", "search_tile_ms", "search_tile_launches"):
             if key in instrumented:
                 stats[key] = instrumented[key] * scale
         for key in ("upload_copies_ms_per_batch", "upload_kernels_ms_per_batch"):

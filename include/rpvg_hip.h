@@ -538,6 +538,10 @@ typedef struct rpvg_hip_kernel_stats {
     /* rpvg_hip_group_gibbs: the span from the sampler's first kernel to its last (chains, request bookkeeping, distributions AND the
      * conditionals, whose own spans are in loglik_ms: gibbs_ms - loglik_ms is what the chains and their bookkeeping take) */
     double gibbs_ms;
+    /* pairTile2Kernel alone (round 6): its own HIP-event spans on the stream it runs on and its launches — the kernel the row-pair
+     * evaluations of loglik_evals belong to on the diploid search's table path (loglik_ms also holds the kernels behind it, and the
+     * spans of batches in flight overlap); timed by contexts that time every kernel family (RPVG_HIP_SPANS=2) */
+    double search_tile_ms;    uint64_t search_tile_launches;
 } rpvg_hip_kernel_stats;
 
 int rpvg_hip_stats_get(rpvg_hip_ctx * ctx, rpvg_hip_kernel_stats * stats_out);

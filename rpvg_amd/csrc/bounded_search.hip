@@ -1505,7 +1505,9 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
             // the matrices' collapse — the matrices it leaves alone as soon as its first stages have told them apart, the others when
             // it is done — 10.4 against 9.9 ms: the second pass's grid of mostly empty workgroups, and the replay's small kernels next
             // to the lane's own tile kernel.)
+            const int tile_span = ctx->spanBegin(FAM_TILE, st);  // (the kernel alone: rpvg_hip_kernel_stats::search_tile_ms)
             pairTile2Kernel<<<dim3(pw.count), dim3(kTileBlock), tile_lds_bytes, st>>>(pw);
+            ctx->spanEnd(tile_span);
 #ifdef RPVG_HIP_EXPERIMENTS
             // (RPVG_HIP_PAIR_REPEAT=n: the same launch n more times — what a batch pays per millisecond of this kernel)
             for (int k = RPVG_EXPERIMENT_ENV("RPVG_HIP_PAIR_REPEAT") ? std::atoi(RPVG_EXPERIMENT_ENV("RPVG_HIP_PAIR_REPEAT")) : 0; k > 0; --k) {

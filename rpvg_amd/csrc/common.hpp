@@ -611,7 +611,7 @@ __device__ __forceinline__ uint32_t blockExclusiveSum(const uint32_t v, uint32_t
 }
 
 // ---- kernel-family timing ---------------------------------------------------
-enum KernelFamily { FAM_EM_SPARSE = 0, FAM_EM_DENSE, FAM_LOGLIK, FAM_BUILD, FAM_H2D, FAM_COLLAPSE, FAM_EM_KERNEL, FAM_GIBBS, FAM_COUNT };
+enum KernelFamily { FAM_EM_SPARSE = 0, FAM_EM_DENSE, FAM_LOGLIK, FAM_BUILD, FAM_H2D, FAM_COLLAPSE, FAM_EM_KERNEL, FAM_GIBBS, FAM_TILE, FAM_COUNT };
 
 struct TimedSpan {
     hipEvent_t start, stop;

@@ -423,6 +423,7 @@ void rpvg_hip_ctx::accountSpan(const rpvg_hip_detail::TimedSpan & s, const void 
         case FAM_H2D: stats.h2d_ms += ms; break;
         case FAM_COLLAPSE: stats.collapse_ms += ms; break;
         case FAM_GIBBS: stats.gibbs_ms += ms; break;
+        case FAM_TILE: stats.search_tile_ms += ms; stats.search_tile_launches += 1; break;
         case FAM_EM_KERNEL:
             if (s.sub >= 0 && s.sub < RPVG_HIP_EM_KERNELS) stats.em_kernel[s.sub].ms += ms;
             break;

@@ -96,6 +96,7 @@ class CKernelStats(C.Structure):
         ("search_pairs_possible", C.c_double), ("search_pairs_table", C.c_double), ("search_pairs_kept", C.c_double),
         ("em_kernel", CEmKernelStats * EM_KERNELS),
         ("collapse_ms", C.c_double), ("busy_ms", C.c_double), ("gibbs_ms", C.c_double),
+        ("search_tile_ms", C.c_double), ("search_tile_launches", C.c_uint64),
     ]
 
     def as_dict(self):

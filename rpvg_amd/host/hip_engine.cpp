@@ -159,6 +159,8 @@ void HipEngine::stats(const std::vector<const HipEngine *> & engines, rpvg_hip_k
         stats_out->search_pairs_kept += lane_stats.search_pairs_kept;
         stats_out->collapse_ms += lane_stats.collapse_ms;
         stats_out->gibbs_ms += lane_stats.gibbs_ms;
+        stats_out->search_tile_ms += lane_stats.search_tile_ms;
+        stats_out->search_tile_launches += lane_stats.search_tile_launches;
 
         for (int i = 0; i < RPVG_HIP_EM_KERNELS; ++i) {
 
