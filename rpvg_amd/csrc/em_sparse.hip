@@ -1386,6 +1386,7 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     hipStream_t st = ctx->stream;
     const uint32_t P = list.P_bound;
     const EmBinRule rule = emBinRule();
+    std::unique_ptr<HostScope> stage_scope(new HostScope("em_solve: allocations + fill queued"));
     RPVG_HIP_CHECK(work.d_prow_off.alloc(list.rows_capacity + P));
     RPVG_HIP_CHECK(work.d_prow_count.alloc(list.rows_capacity));
     RPVG_HIP_CHECK(work.d_prow_noise.alloc(list.rows_capacity));
@@ -1503,7 +1504,9 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         in.max_rows_bound = std::min<uint64_t>(list.max_cluster_work, list.rows_capacity);  // (rows + entries of the largest cluster: a bound of its rows)
         const int collapse_span = ctx->spanBegin(FAM_COLLAPSE, ctx->collapse_stream);
         RPVG_HIP_CHECK(hipEventCreateWithFlags(&work.collapse_sorted, hipEventDisableTiming));
+        stage_scope.reset(new HostScope("em_solve: the problems' collapse queued"));
         RPVG_HIP_CHECK(queueCsrCollapse(ctx, in, collapse_precision, *cw, ctx->collapse_stream, work.collapse_sorted));
+        stage_scope.reset(new HostScope("em_solve: EM launches, grid problems, join"));
         ctx->spanEnd(collapse_span);
         RPVG_HIP_CHECK(hipEventRecord(work.collapsed, ctx->collapse_stream));
     }

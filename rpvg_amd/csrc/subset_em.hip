@@ -941,6 +941,7 @@ static int nestedSubsetEmAttempt(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     MatrixTotals * totals = reinterpret_cast<MatrixTotals *>(d_totals.ptr);
     MatrixTotals * bases = reinterpret_cast<MatrixTotals *>(d_bases.ptr);
 
+    std::unique_ptr<HostScope> part_scope(new HostScope("subset em: select + offsets + expand queued"));
     int span = ctx->spanBegin(FAM_BUILD);
     SelectArgs sa;
     sa.num_matrices = M;
@@ -1028,6 +1029,7 @@ static int nestedSubsetEmAttempt(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     // the next search (another lane's) may start: what follows are this lane's EM problems
     leavePairSearch(ctx);
 
+    part_scope.reset();
     EmProblemList list;
     list.P_bound = static_cast<uint32_t>(std::min<unsigned long long>(cap_subsets, 0xfffffffeull));
     list.d_num_problems = &header->num_problems;
@@ -1058,6 +1060,7 @@ static int nestedSubsetEmAttempt(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
             return rc;
         }
     }
+    part_scope.reset(new HostScope("subset em: merge + pack queued"));
     static_assert(sizeof(SubsetHeader) <= 192, "the merge's flag word sits behind the header");
     uint32_t * d_merge_bad = reinterpret_cast<uint32_t *>(search.d_extra_zero.ptr + 192);
     if (merge_here && e == hipSuccess) {
@@ -1107,6 +1110,7 @@ static int nestedSubsetEmAttempt(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batc
     packResultsKernel<<<dim3(256), dim3(256), 0, st>>>(pa);
     ok(hipGetLastError());
 
+    part_scope.reset();
     scope.reset(new HostScope("subset em: header"));
     if (e == hipSuccess) ok(waitEvent(header_here));
     (void) hipEventDestroy(header_here);
