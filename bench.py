@@ -579,6 +579,16 @@ def run_s3(args, rank, local_rank, world, dist, torch):
     else:
         search["kernel"] = "pairTile2Kernel + resolveTableKernel"
         line["roofline_search"] = search
+    # the engines of this process go before the lines that other processes measure (configs[4], the drop-in path): their contexts hold
+    # streams, hardware queues and resident batches on the GPU the children are timed on
+    try:
+        prepared.free()
+        for other, other_prepared in others:
+            other_prepared.free()
+            other.close()
+        eng.close()
+    except Exception:  # noqa: BLE001  (a stand-in engine without these)
+        pass
     if args.scale >= 1.0 and not s5 and DEVICE == "cuda":
         try:
             line["roofline_dense_em"] = dense_em_roofline(local_rank)
