@@ -98,7 +98,7 @@ class HipEngine {
         // currentLane() while its batch runs (ctx() then hands out that context).
         int combinerLane(const int slot);
 
-        static constexpr int max_combiner_slots = 3;
+        static constexpr int max_combiner_slots = 6;
 
     private:
 

@@ -561,7 +561,7 @@ class PathEstimator::CallCombiner {
             };
 
             max_clusters = setting("RPVG_AMD_COMBINE_MAX", 256);
-            num_slots = static_cast<int>(std::min<long>(HipEngine::max_combiner_slots, setting("RPVG_AMD_COMBINE_SLOTS", HipEngine::max_combiner_slots)));
+            num_slots = static_cast<int>(std::min<long>(HipEngine::max_combiner_slots, setting("RPVG_AMD_COMBINE_SLOTS", 3)));
             quiet = std::chrono::microseconds(setting("RPVG_AMD_COMBINE_QUIET_US", 50));
             all_parked_quiet = std::chrono::microseconds(setting("RPVG_AMD_COMBINE_ALL_PARKED_US", 15));
             linger = std::chrono::microseconds(setting("RPVG_AMD_COMBINE_LINGER_US", 500));
