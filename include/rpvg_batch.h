@@ -109,6 +109,18 @@ typedef struct rpvg_cluster_segment {
     uint64_t path_group_id_at;   /* uint32 [P]    PathInfo::group_id                       */
     uint64_t path_source_off_at; /* uint32 [P+1]  source ids of every path, from 0         */
     uint64_t source_id_at;       /* uint32 [S]    PathInfo::source_ids                     */
+    /* The haplotype columns of the cluster, formed by the caller (findPathSourceGroups, src/path_abundance_estimator.cpp:493-546:
+     * the reference does this per cluster on the calling thread too): haplotypes with the identical path list are one column, its
+     * multiplicity their number, columns in ascending order of their smallest haplotype id, a column's paths ascending.  With
+     * them (has_columns = 1: all segments of a batch, or none) the upload forms no columns on the device and waits for nothing
+     * but its own kernel; path_source_off / source_id are not read then (path_group_id is). */
+    uint32_t has_columns;
+    uint32_t num_columns;        /* C                                                       */
+    uint32_t num_column_paths;   /* L = sum of the columns' list lengths (>= C)             */
+    uint32_t max_column_paths;   /* the longest list                                        */
+    uint64_t col_count_at;       /* uint32 [C]    haplotypes that carry the column's list   */
+    uint64_t col_end_at;         /* uint32 [C]    end of the column's list in col_path      */
+    uint64_t col_path_at;        /* uint32 [L]    the lists, one behind the other           */
 } rpvg_cluster_segment;
 
 /* The two long offset arrays of a batch in whichever width its owner wrote them. */

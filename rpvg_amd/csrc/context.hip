@@ -948,7 +948,10 @@ struct SegmentEntry {
     const uint32_t * path_group_id;
     const uint32_t * path_source_off;
     const uint32_t * source_id;
-    uint32_t R, G, NNZ, P, S, pad;
+    const uint32_t * col_count;  // the caller's haplotype columns (rpvg_cluster_segment::has_columns), else null
+    const uint32_t * col_end;
+    const uint32_t * col_path;
+    uint32_t R, G, NNZ, P, S, C;  // (with columns S is their total list length L: the cluster's slots in the column arrays)
     uint64_t row_base, ent_base, path_base, src_base;
 };
 
@@ -967,6 +970,10 @@ struct SegmentGatherArgs {
     uint32_t * path_group_id;
     uint64_t * path_source_off;
     uint32_t * source_id;
+    uint32_t with_columns;           // the segments carry their haplotype columns: src_col_* are written here
+    uint32_t * src_col_count;
+    uint32_t * src_col_end;
+    uint32_t * src_col_path;
     unsigned long long * first_bad;  // smallest (cluster << 8 | kind) of an invalid segment; ~0: none
 };
 
@@ -1015,7 +1022,21 @@ __global__ __launch_bounds__(256) void segmentsGatherKernel(const SegmentGatherA
         if (!(path < s.P)) bad = bad ? bad : kSegmentBadPath;
         a.ent_path[s.ent_base + e] = path;
     }
-    if (a.with_paths) {
+    if (a.with_columns) {
+        // the caller's columns into the cluster's slots (src_base: the lists' total lengths of the clusters before it)
+        for (uint32_t p = t; p < s.P; p += stride) a.path_group_id[s.path_base + p] = s.path_group_id[p];
+        for (uint32_t c = t; c < s.C; c += stride) {
+            const uint32_t begin = c ? s.col_end[c - 1] : 0u, end = s.col_end[c];
+            if (!(begin < end && end <= s.S && (c + 1 < s.C || end == s.S)) || s.col_count[c] == 0) bad = kSegmentBadOffsets;
+            a.src_col_count[s.src_base + c] = s.col_count[c];
+            a.src_col_end[s.src_base + c] = end;
+        }
+        for (uint32_t i = t; i < s.S; i += stride) {
+            const uint32_t path = s.col_path[i];
+            if (!(path < s.P)) bad = bad ? bad : kSegmentBadPath;
+            a.src_col_path[s.src_base + i] = path;
+        }
+    } else if (a.with_paths) {
         for (uint32_t p = t; p < s.P; p += stride) {
             const uint32_t s0 = s.path_source_off[p], s1 = s.path_source_off[p + 1];
             if (!(s0 <= s1 && s1 <= s.S && (p > 0 || s0 == 0) && (p + 1 < s.P || s1 == s.S))) bad = kSegmentBadOffsets;
@@ -1028,14 +1049,12 @@ __global__ __launch_bounds__(256) void segmentsGatherKernel(const SegmentGatherA
         a.cluster_row_off[k] = s.row_base;
         a.cluster_path_off[k] = s.path_base;
         a.row_ent_off[s.row_base + s.R] = s.ent_base + s.NNZ;  // (the next cluster's first row writes the same value)
-        if (a.with_paths) {
-            a.cluster_src_off[k] = s.src_base;
-            a.path_source_off[s.path_base + s.P] = s.src_base + s.S;
-        }
+        if (a.with_paths || a.with_columns) a.cluster_src_off[k] = s.src_base;
+        if (a.with_paths && !a.with_columns) a.path_source_off[s.path_base + s.P] = s.src_base + s.S;
         if (k + 1 == a.num_clusters) {
             a.cluster_row_off[k + 1] = s.row_base + s.R;
             a.cluster_path_off[k + 1] = s.path_base + s.P;
-            if (a.with_paths) a.cluster_src_off[k + 1] = s.src_base + s.S;
+            if (a.with_paths || a.with_columns) a.cluster_src_off[k + 1] = s.src_base + s.S;
         }
     }
     if (bad) atomicMin(a.first_bad, (static_cast<unsigned long long>(k) << 8) | bad);
@@ -1412,12 +1431,14 @@ int rpvg_hip_batch_upload_segments(rpvg_hip_ctx * ctx, const rpvg_cluster_segmen
     RPVG_REQUIRE(ctx != nullptr && batch_out != nullptr && (segments != nullptr || K == 0), "rpvg_hip_batch_upload_segments: NULL argument");
     *batch_out = nullptr;
     std::unique_ptr<HostScope> scope(new HostScope("batch_upload_segments: host checks + table"));
-    const bool with_paths = K > 0 && segments[0].has_paths != 0;
+    const bool with_columns = K > 0 && segments[0].has_columns != 0;
+    const bool with_paths = K > 0 && segments[0].has_paths != 0 && !with_columns;
     uint64_t R = 0, NNZ = 0, P = 0, S = 0, most_work = 0;
     for (uint32_t k = 0; k < K; ++k) {
         const rpvg_cluster_segment & g = segments[k];
         RPVG_REQUIRE(g.base != nullptr && pinnedCapacity(g.base) >= g.bytes, "rpvg_hip_batch_upload_segments: segment %u does not lie in a block of rpvg_hip_pinned_alloc", k);
-        RPVG_REQUIRE((g.has_paths != 0) == with_paths, "rpvg_hip_batch_upload_segments: segment %u: all segments of a batch carry their paths, or none", k);
+        RPVG_REQUIRE((g.has_columns != 0) == with_columns, "rpvg_hip_batch_upload_segments: segment %u: all segments of a batch carry their haplotype columns, or none", k);
+        RPVG_REQUIRE(with_columns || (g.has_paths != 0) == with_paths, "rpvg_hip_batch_upload_segments: segment %u: all segments of a batch carry their paths, or none", k);
         RPVG_REQUIRE(g.num_paths <= 0x7fffffffu, "rpvg_hip_batch_upload_segments: segment %u has too many paths", k);
         auto inside = [&](const uint64_t at, const uint64_t count, const uint64_t width) { return (at & 7) == 0 && at <= g.bytes && count * width <= g.bytes - at; };
         bool fits = inside(g.row_count_at, g.num_rows, 4) && inside(g.row_noise_at, g.num_rows, 8) && inside(g.row_grp_off_at, static_cast<uint64_t>(g.num_rows) + 1, 4) &&
@@ -1425,13 +1446,19 @@ int rpvg_hip_batch_upload_segments(rpvg_hip_ctx * ctx, const rpvg_cluster_segmen
         if (with_paths) {
             fits = fits && inside(g.path_group_id_at, g.num_paths, 4) && inside(g.path_source_off_at, static_cast<uint64_t>(g.num_paths) + 1, 4) && inside(g.source_id_at, g.num_sources, 4);
         }
+        if (with_columns) {
+            fits = fits && inside(g.path_group_id_at, g.num_paths, 4) && inside(g.col_count_at, g.num_columns, 4) && inside(g.col_end_at, g.num_columns, 4) &&
+                   inside(g.col_path_at, g.num_column_paths, 4) && g.num_columns <= g.num_column_paths && g.max_column_paths <= g.num_column_paths &&
+                   (g.num_columns > 0) == (g.num_column_paths > 0);
+        }
         RPVG_REQUIRE(fits, "rpvg_hip_batch_upload_segments: an array of segment %u is misaligned or outside its block", k);
         RPVG_REQUIRE(g.num_rows > 0 || (g.num_groups == 0 && g.num_entries == 0), "rpvg_hip_batch_upload_segments: segment %u has groups without rows", k);
         R += g.num_rows;
         NNZ += g.num_entries;
         P += g.num_paths;
-        S += with_paths ? g.num_sources : 0;
-        most_work = std::max<uint64_t>(most_work, std::max<uint64_t>(std::max(g.num_rows, g.num_groups), std::max(g.num_entries, with_paths ? g.num_sources : 0u)));
+        const uint32_t slots = with_columns ? g.num_column_paths : (with_paths ? g.num_sources : 0u);
+        S += slots;
+        most_work = std::max<uint64_t>(most_work, std::max<uint64_t>(std::max(g.num_rows, g.num_groups), std::max(g.num_entries, slots)));
     }
     RPVG_REQUIRE(NNZ < 0xffffffffull, "rpvg_hip_batch_upload_segments: a batch of 2^32 - 1 entries or more");
 
@@ -1450,7 +1477,12 @@ int rpvg_hip_batch_upload_segments(rpvg_hip_ctx * ctx, const rpvg_cluster_segmen
     b->h_cluster_path_off.assign(K + 1, 0);
     b->h_cluster_ent_off.assign(K + 1, 0);
     b->h_cluster_total.resize(K);
-    if (with_paths) b->h_cluster_src_off.assign(K + 1, 0);
+    if (with_paths || with_columns) b->h_cluster_src_off.assign(K + 1, 0);
+    if (with_columns) {
+        b->h_src_num_cols.resize(K);
+        b->h_src_col_paths.resize(K);
+        b->h_src_max_col_paths.resize(K);
+    }
     b->upload.reset(new rpvg_hip_batch::UploadInProgress());
     rpvg_hip_batch::UploadInProgress & up = *b->upload;
     hipStream_t st = ctx->stream;
@@ -1475,23 +1507,31 @@ int rpvg_hip_batch_upload_segments(rpvg_hip_ctx * ctx, const rpvg_cluster_segmen
         t.grp_idx_off = reinterpret_cast<const uint32_t *>(base + g.grp_idx_off_at);
         t.grp_prob = reinterpret_cast<const double *>(base + g.grp_prob_at);
         t.path_idx = reinterpret_cast<const uint32_t *>(base + g.path_idx_at);
-        t.path_group_id = with_paths ? reinterpret_cast<const uint32_t *>(base + g.path_group_id_at) : nullptr;
+        t.path_group_id = (with_paths || with_columns) ? reinterpret_cast<const uint32_t *>(base + g.path_group_id_at) : nullptr;
+        t.col_count = with_columns ? reinterpret_cast<const uint32_t *>(base + g.col_count_at) : nullptr;
+        t.col_end = with_columns ? reinterpret_cast<const uint32_t *>(base + g.col_end_at) : nullptr;
+        t.col_path = with_columns ? reinterpret_cast<const uint32_t *>(base + g.col_path_at) : nullptr;
         t.path_source_off = with_paths ? reinterpret_cast<const uint32_t *>(base + g.path_source_off_at) : nullptr;
         t.source_id = with_paths ? reinterpret_cast<const uint32_t *>(base + g.source_id_at) : nullptr;
         t.R = g.num_rows;
         t.G = g.num_groups;
         t.NNZ = g.num_entries;
         t.P = g.num_paths;
-        t.S = with_paths ? g.num_sources : 0;
-        t.pad = 0;
+        t.S = with_columns ? g.num_column_paths : (with_paths ? g.num_sources : 0);
+        t.C = with_columns ? g.num_columns : 0;
         t.row_base = b->h_cluster_row_off[k];
         t.ent_base = b->h_cluster_ent_off[k];
         t.path_base = b->h_cluster_path_off[k];
-        t.src_base = with_paths ? b->h_cluster_src_off[k] : 0;
+        t.src_base = (with_paths || with_columns) ? b->h_cluster_src_off[k] : 0;
         b->h_cluster_row_off[k + 1] = t.row_base + t.R;
         b->h_cluster_ent_off[k + 1] = t.ent_base + t.NNZ;
         b->h_cluster_path_off[k + 1] = t.path_base + t.P;
-        if (with_paths) b->h_cluster_src_off[k + 1] = t.src_base + t.S;
+        if (with_paths || with_columns) b->h_cluster_src_off[k + 1] = t.src_base + t.S;
+        if (with_columns) {
+            b->h_src_num_cols[k] = g.num_columns;
+            b->h_src_col_paths[k] = g.num_column_paths;
+            b->h_src_max_col_paths[k] = g.max_column_paths;
+        }
         b->h_cluster_total[k] = static_cast<double>(g.total_read_count);
     }
     unsigned long long * h_first_bad = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(h_table) + table_bytes);
@@ -1508,6 +1548,14 @@ int rpvg_hip_batch_upload_segments(rpvg_hip_ctx * ctx, const rpvg_cluster_segmen
     ok(up.d_first_bad_row.alloc(1));
     if (e == hipSuccess && with_paths) ok(reservePathSources(b.get(), K, P, S, up.path_sources));
     const bool sources = with_paths && up.path_sources.copied;
+    const bool columns = with_columns && P > 0 && S > 0;
+    if (e == hipSuccess && columns) {  // the columns come with the segments: their slots, nothing to form
+        ok(b->path_group_id.alloc(P));
+        ok(b->cluster_src_off.alloc(K + 1));
+        ok(b->src_col_count.alloc(S));
+        ok(b->src_col_end.alloc(S));
+        ok(b->src_col_path.alloc(S));
+    }
     if (e == hipSuccess) ok(hipMemsetAsync(up.d_first_bad_row.ptr, 0xFF, sizeof(unsigned long long), st));
     const int span = ctx->spanBegin(FAM_BUILD, st);
     if (e == hipSuccess && K > 0) {
@@ -1517,13 +1565,17 @@ int rpvg_hip_batch_upload_segments(rpvg_hip_ctx * ctx, const rpvg_cluster_segmen
         a.with_paths = sources ? 1 : 0;
         a.cluster_row_off = b->cluster_row_off.ptr;
         a.cluster_path_off = b->cluster_path_off.ptr;
-        a.cluster_src_off = sources ? b->cluster_src_off.ptr : nullptr;
+        a.cluster_src_off = (sources || columns) ? b->cluster_src_off.ptr : nullptr;
+        a.with_columns = columns ? 1 : 0;
+        a.src_col_count = columns ? b->src_col_count.ptr : nullptr;
+        a.src_col_end = columns ? b->src_col_end.ptr : nullptr;
+        a.src_col_path = columns ? b->src_col_path.ptr : nullptr;
         a.row_count = b->row_count.ptr;
         a.row_noise = b->row_noise.ptr;
         a.row_ent_off = b->row_ent_off.ptr;
         a.ent_path = b->ent_path.ptr;
         a.ent_prob = b->ent_prob.ptr;
-        a.path_group_id = sources ? b->path_group_id.ptr : nullptr;
+        a.path_group_id = (sources || columns) ? b->path_group_id.ptr : nullptr;
         a.path_source_off = sources ? up.path_sources.d_path_source_off.ptr : nullptr;
         a.source_id = sources ? up.path_sources.d_source_id.ptr : nullptr;
         a.first_bad = up.d_first_bad_row.ptr;
@@ -1556,12 +1608,13 @@ int rpvg_hip_batch_upload_segments(rpvg_hip_ctx * ctx, const rpvg_cluster_segmen
         const unsigned long long k = *h_first_bad >> 8, kind = *h_first_bad & 0xff;
         setError("rpvg_hip_batch_upload_segments: cluster %llu of the batch: %s", k,
                  kind == kSegmentBadNoise ? "a row has a noise probability outside (0, 1]"
-                 : kind == kSegmentBadPath ? "a row refers to a path outside its cluster"
+                 : kind == kSegmentBadPath ? "a row or a haplotype column refers to a path outside its cluster"
                                            : "inconsistent row, group, entry or source offsets");
         return RPVG_HIP_ERR_INVALID;
     }
     const int sources_rc = finishPathSources(b.get(), up.path_sources);
     if (sources_rc != RPVG_HIP_OK) return sources_rc;
+    if (columns) b->has_source_columns = true;
     b->upload.reset();
     *batch_out = b.release();
     return RPVG_HIP_OK;

@@ -146,14 +146,17 @@ class CClusterSegment(C.Structure):
                 ("num_paths", C.c_uint32), ("num_sources", C.c_uint32), ("has_paths", C.c_uint32), ("total_read_count", C.c_uint64),
                 ("row_count_at", C.c_uint64), ("row_noise_at", C.c_uint64), ("row_grp_off_at", C.c_uint64), ("grp_idx_off_at", C.c_uint64),
                 ("grp_prob_at", C.c_uint64), ("path_idx_at", C.c_uint64), ("path_group_id_at", C.c_uint64), ("path_source_off_at", C.c_uint64),
-                ("source_id_at", C.c_uint64)]
+                ("source_id_at", C.c_uint64), ("has_columns", C.c_uint32), ("num_columns", C.c_uint32), ("num_column_paths", C.c_uint32),
+                ("max_column_paths", C.c_uint32), ("col_count_at", C.c_uint64), ("col_end_at", C.c_uint64), ("col_path_at", C.c_uint64)]
 
 
 class PinnedSegments:
     """The clusters of a ClusterBatch as one rpvg_cluster_segment each, every segment in a page-locked block of its own
     (rpvg_hip_pinned_alloc) — what the threads of a team calling PathEstimator::estimate() hand to the call combiner."""
 
-    def __init__(self, host: ClusterBatch, with_paths: bool = True):
+    def __init__(self, host: ClusterBatch, with_paths: bool = True, columns=None):
+        """columns: per cluster (multiplicities, [path list of every column]) — the caller's own haplotype columns
+        (rpvg_cluster_segment::has_columns); the source ids then stay behind."""
         L = lib()
         L.rpvg_hip_pinned_free.argtypes = [C.c_void_p]
         K = host.num_clusters
@@ -169,7 +172,13 @@ class PinnedSegments:
             pieces = [("row_noise", host.row_noise[r0:r1], np.float64), ("grp_prob", host.grp_prob[g0:g1], np.float64),
                       ("row_count", host.row_count[r0:r1], np.uint32), ("row_grp_off", host.row_grp_off[r0:r1 + 1] - g0, np.uint32),
                       ("grp_idx_off", host.grp_idx_off[g0:g1 + 1] - e0, np.uint32), ("path_idx", host.path_idx[e0:e1], np.uint32)]
-            if with_paths:
+            if columns is not None:
+                counts, lists = columns[k]
+                ends = np.cumsum([len(x) for x in lists]).astype(np.uint32) if lists else np.zeros(0, dtype=np.uint32)
+                flat = np.array([p for x in lists for p in x], dtype=np.uint32)
+                pieces += [("path_group_id", host.path_group_id[p0:p1], np.uint32), ("col_count", np.array(counts, dtype=np.uint32), np.uint32),
+                           ("col_end", ends, np.uint32), ("col_path", flat, np.uint32)]
+            elif with_paths:
                 pieces += [("path_group_id", host.path_group_id[p0:p1], np.uint32), ("path_source_off", host.path_source_off[p0:p1 + 1] - s0, np.uint32),
                            ("source_id", host.source_id[s0:s1], np.uint32)]
             at, places = 0, {}
@@ -189,7 +198,12 @@ class PinnedSegments:
             seg = self.segments[k]
             seg.base, seg.bytes = block.value, max(at, 8)
             seg.num_rows, seg.num_groups, seg.num_entries, seg.num_paths, seg.num_sources = r1 - r0, g1 - g0, e1 - e0, p1 - p0, s1 - s0
-            seg.has_paths = 1 if with_paths else 0
+            seg.has_paths = 1 if (with_paths and columns is None) else 0
+            if columns is not None:
+                counts, lists = columns[k]
+                seg.has_columns, seg.num_columns, seg.num_column_paths = 1, len(counts), sum(len(x) for x in lists)
+                seg.max_column_paths = max([len(x) for x in lists], default=0)
+                seg.num_sources = 0
             seg.total_read_count = int(host.row_count[r0:r1].astype(np.uint64).sum())
             for name in places:
                 setattr(seg, name + "_at", places[name])

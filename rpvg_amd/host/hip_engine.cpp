@@ -559,7 +559,9 @@ ClusterSegment::~ClusterSegment() {
     rpvg_hip_pinned_free(block);
 }
 
-void ClusterSegment::flatten(const std::vector<ReadPathProbabilities> & cluster_probs, const std::vector<PathInfo> & paths, const bool with_sources) {
+void ClusterSegment::flatten(const std::vector<ReadPathProbabilities> & cluster_probs, const std::vector<PathInfo> & paths, const bool with_sources_in, const Columns * columns) {
+
+    const bool with_sources = with_sources_in && !columns;  // (the columns stand for the ids)
 
     uint64_t num_groups = 0, num_entries = 0, num_sources = 0, total_read_count = 0;
 
@@ -603,9 +605,14 @@ void ClusterSegment::flatten(const std::vector<ReadPathProbabilities> & cluster_
     segment.row_grp_off_at = place(R + 1, 4);
     segment.grp_idx_off_at = place(G + 1, 4);
     segment.path_idx_at = place(NNZ, 4);
-    segment.path_group_id_at = place(with_sources ? P : 0, 4);
+    const uint64_t num_columns = columns ? columns->num : 0, num_column_paths = columns ? columns->path_off[columns->num] : 0;
+
+    segment.path_group_id_at = place((with_sources || columns) ? P : 0, 4);
     segment.path_source_off_at = place(with_sources ? P + 1 : 0, 4);
     segment.source_id_at = place(S, 4);
+    segment.col_count_at = place(num_columns, 4);
+    segment.col_end_at = place(num_columns, 4);
+    segment.col_path_at = place(num_column_paths, 4);
     segment.bytes = std::max<uint64_t>(at, 8);
 
     if (segment.bytes > capacity) {
@@ -670,6 +677,32 @@ void ClusterSegment::flatten(const std::vector<ReadPathProbabilities> & cluster_
     if (with_sources) {
 
         path_source_off[P] = source;
+    }
+
+    if (columns) {
+
+        for (size_t p = 0; p < P; ++p) {
+
+            path_group_id[p] = paths[p].group_id;
+        }
+
+        uint32_t * col_count = reinterpret_cast<uint32_t *>(base + segment.col_count_at);
+        uint32_t * col_end = reinterpret_cast<uint32_t *>(base + segment.col_end_at);
+        uint32_t longest = 0;
+
+        for (uint32_t c = 0; c < columns->num; ++c) {
+
+            col_count[c] = columns->counts[c];
+            col_end[c] = columns->path_off[c + 1];
+            longest = std::max(longest, columns->path_off[c + 1] - columns->path_off[c]);
+        }
+
+        std::copy(columns->paths, columns->paths + num_column_paths, reinterpret_cast<uint32_t *>(base + segment.col_path_at));
+
+        segment.has_columns = 1;
+        segment.num_columns = columns->num;
+        segment.num_column_paths = num_column_paths;
+        segment.max_column_paths = longest;
     }
 
     segment.base = block;

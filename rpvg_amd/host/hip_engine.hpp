@@ -172,9 +172,20 @@ class ClusterSegment {
         ClusterSegment(const ClusterSegment &) = delete;
         ClusterSegment & operator=(const ClusterSegment &) = delete;
 
+        // The haplotype columns of a cluster as its caller formed them (findPathSourceGroups): multiplicities, list offsets
+        // [num + 1], the lists.
+        struct Columns {
+
+            uint32_t num;
+            const uint32_t * counts;
+            const uint32_t * path_off;
+            const uint32_t * paths;
+        };
+
         // Two passes over the rows: sizes, then the arrays at their final places.  with_sources: the segment carries
-        // PathInfo::group_id and PathInfo::source_ids (the batch then carries its haplotype columns).
-        void flatten(const std::vector<ReadPathProbabilities> & cluster_probs, const std::vector<PathInfo> & paths, const bool with_sources);
+        // PathInfo::group_id and PathInfo::source_ids (the device forms the haplotype columns behind the upload) — or, with
+        // `columns`, PathInfo::group_id and the columns themselves (the upload then forms nothing and waits for nothing but its kernel).
+        void flatten(const std::vector<ReadPathProbabilities> & cluster_probs, const std::vector<PathInfo> & paths, const bool with_sources, const Columns * columns = nullptr);
 
         const rpvg_cluster_segment & view() const { return segment; }
 

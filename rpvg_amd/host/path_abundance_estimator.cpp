@@ -748,6 +748,17 @@ std::vector<std::vector<uint32_t> > NestedPathAbundanceEstimator::findPathGroups
 // its multiplicity is the number of such haplotypes
 // (src/path_abundance_estimator.cpp:493-546).  Columns come out in ascending
 // order of their smallest source id (the reference's order is that of its hash map).
+bool NestedPathAbundanceEstimator::sourceColumnsOf(GroupPosteriorProblem * columns, const std::vector<PathInfo> & paths) const {
+
+    if (!wantsSourceColumns()) {
+
+        return false;
+    }
+
+    findPathSourceGroups(columns, paths);
+    return columns->numColumns() > 0;  // (paths without source ids: the batch's own error message)
+}
+
 void NestedPathAbundanceEstimator::findPathSourceGroups(GroupPosteriorProblem * problem, const std::vector<PathInfo> & paths) const {
 
     // (source id, path) incidences as one key each, grouped by source id with the paths of an id ascending.

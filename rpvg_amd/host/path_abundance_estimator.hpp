@@ -91,6 +91,8 @@ class NestedPathAbundanceEstimator : public PathAbundanceEstimator {
         // (the one-call device path of estimateClusters: collapsed groups, diploid, branch and bound, no read-count samples)
         bool wantsSourceColumns() const { return infer_collapsed && !use_group_post_gibbs && group_size == 2 && num_gibbs_samples == 0; }
 
+        bool sourceColumnsOf(GroupPosteriorProblem * columns, const std::vector<PathInfo> & paths) const;
+
         void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs);
 
     private:

@@ -2,6 +2,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <limits>
+
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <chrono>
 #include <thread>
 #include <cstdio>
@@ -582,7 +587,25 @@ class PathEstimator::CallCombiner {
 
             {
                 ScopedPhase phase("combiner: flatten the cluster (callers, summed)");
-                segment.flatten(cluster_probs, path_cluster_estimates->paths, owner->wantsSourceColumns());
+
+                // (the haplotype columns on this thread, as the reference forms them per cluster: the batch's upload then waits for
+                // nothing but its own kernel — RPVG_AMD_DEVICE_SOURCE_COLUMNS=1: the ids travel and the device forms them, A/B)
+                static const bool device_columns = std::getenv("RPVG_AMD_DEVICE_SOURCE_COLUMNS") != nullptr;
+                thread_local GroupPosteriorProblem columns;
+
+                columns.column_path_off.clear();
+                columns.column_path.clear();
+                columns.column_counts.clear();
+
+                if (!device_columns && owner->sourceColumnsOf(&columns, path_cluster_estimates->paths)) {
+
+                    const ClusterSegment::Columns formed = {columns.numColumns(), columns.column_counts.data(), columns.column_path_off.data(), columns.column_path.data()};
+                    segment.flatten(cluster_probs, path_cluster_estimates->paths, true, &formed);
+
+                } else {
+
+                    segment.flatten(cluster_probs, path_cluster_estimates->paths, owner->wantsSourceColumns());
+                }
             }
 
             Parked me;
@@ -605,7 +628,21 @@ class PathEstimator::CallCombiner {
             if (leader_present) {
 
                 arrived.notify_all();
-                finished.wait(lock, [&] { return me.done; });
+                lock.unlock();
+
+                // (no mutex on the way out: sixty-odd callers woken at once would queue for it one by one — every caller watches its
+                // own flag and sleeps on the combiner's generation word, which a finished batch bumps once for all of them)
+                while (!me.done.load(std::memory_order_acquire)) {
+
+                    const uint32_t seen = generation.load(std::memory_order_acquire);
+
+                    if (me.done.load(std::memory_order_acquire)) {
+
+                        break;
+                    }
+
+                    syscall(SYS_futex, reinterpret_cast<uint32_t *>(&generation), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+                }
 
             } else {
 
@@ -668,15 +705,17 @@ class PathEstimator::CallCombiner {
                 busy_slots &= ~(1 << slot);
                 parked_in_batches -= batch.size();
 
-                for (auto & parked: batch) {
-
-                    parked->error = error;
-                    parked->done = true;
-                }
-
                 lock.unlock();
                 arrived.notify_all();
-                finished.notify_all();
+
+                for (auto & parked: batch) {  // (a caller is gone, and its Parked with it, as soon as it sees its flag)
+
+                    parked->error = error;
+                    parked->done.store(true, std::memory_order_release);
+                }
+
+                generation.fetch_add(1, std::memory_order_release);
+                syscall(SYS_futex, reinterpret_cast<uint32_t *>(&generation), FUTEX_WAKE_PRIVATE, std::numeric_limits<int>::max(), nullptr, nullptr, 0);
             }
 
             if (me.error) {
@@ -692,7 +731,7 @@ class PathEstimator::CallCombiner {
             const rpvg_cluster_segment * segment = nullptr;
             PathClusterEstimates * estimates = nullptr;
             std::mt19937 * rng = nullptr;
-            bool done = false;
+            std::atomic<bool> done{false};
             std::exception_ptr error = nullptr;
         };
 
@@ -781,7 +820,8 @@ class PathEstimator::CallCombiner {
         }
 
         std::mutex mutex;
-        std::condition_variable arrived, finished;
+        std::condition_variable arrived;
+        std::atomic<uint32_t> generation{0};  // bumped by every finished batch: what the parked callers sleep on (futex)
 
         std::vector<Parked *> staging;
         std::chrono::steady_clock::time_point first_arrival, last_arrival;

@@ -105,6 +105,11 @@ class PathEstimator {
         // current settings: estimate() ships the paths' ids with a cluster only then.
         virtual bool wantsSourceColumns() const { return false; }
 
+        // The haplotype columns of a cluster's paths (findPathSourceGroups, src/path_abundance_estimator.cpp:493-546) for an
+        // estimator that wantsSourceColumns(): estimate() forms them on the calling thread, as the reference does, and ships them
+        // with the cluster — the upload of the calls' batch then waits for nothing but its own kernel.  False: not formed.
+        virtual bool sourceColumnsOf(GroupPosteriorProblem * columns, const std::vector<PathInfo> & paths) const { (void) columns; (void) paths; return false; }
+
         // Same, seeding cluster i with mt19937(rng_seed + i) as src/main.cpp:976 does.
         void estimateBatchSeeded(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, const uint32_t rng_seed);
 

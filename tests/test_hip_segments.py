@@ -44,6 +44,43 @@ def test_segments_equal_the_joined_upload(hip_ctx, with_paths):
         segments.free()
 
 
+def test_segments_with_the_callers_columns_equal_the_device_columns(hip_ctx):
+    """rpvg_cluster_segment::has_columns: the haplotype columns formed by the caller (findPathSourceGroups on the calling thread,
+    as the reference does) travel with the segment instead of the source ids — the batch holds the columns the device would have
+    formed, and an inconsistent column list or a path outside the cluster is refused."""
+    from tests.test_hip_path_sources import host_columns
+    clusters = small_cases.make_batch_clusters(9303, n_clusters=30, max_reads=500, with_empty=True)
+    batch = ClusterBatch.from_clusters(clusters)
+    columns = [host_columns(batch, k) for k in range(batch.num_clusters)]
+    segments = hip.PinnedSegments(batch, columns=columns)
+    joined = hip_ctx.upload(batch)
+    pulled = hip_ctx.upload_segments(batch, segments)
+    try:
+        assert pulled.has_source_columns()
+        assert np.array_equal(pulled.cluster_totals(), joined.cluster_totals())
+        for k in range(batch.num_clusters):
+            assert pulled.source_columns(k) == joined.source_columns(k) == columns[k], k
+        a, b = solve_all(hip_ctx, pulled, batch), solve_all(hip_ctx, joined, batch)
+        assert np.array_equal(a[3], b[3]) and all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
+    finally:
+        pulled.free()
+        joined.free()
+    k = next(k for k in range(batch.num_clusters) if len(columns[k][0]) > 1)
+    for fault, expect in (("end", "inconsistent"), ("path", "refers to a path outside its cluster")):
+        views = segments.arrays[k]
+        saved = {name: views[name].copy() for name in ("col_end", "col_path")}
+        if fault == "end":
+            views["col_end"][0] = views["col_end"][-1] + 5
+        else:
+            views["col_path"][0] = 10 ** 6
+        with pytest.raises(hip.EngineError) as err:
+            hip_ctx.upload_segments(batch, segments)
+        assert f"cluster {k} of the batch" in str(err.value) and expect in str(err.value), str(err.value)
+        for name in saved:
+            views[name][:] = saved[name]
+    segments.free()
+
+
 def test_a_large_cluster_takes_several_slices(hip_ctx):
     """One cluster of tens of thousands of rows next to small ones: the kernel's slices walk it."""
     from rpvg_amd import synth
@@ -79,7 +116,7 @@ def test_invalid_segments_are_refused(hip_ctx, fault):
         expect = "cluster 5 of the batch: a row has a noise probability"
     elif fault == "path":
         views["path_idx"][0] = 10000
-        expect = "cluster 5 of the batch: a row refers to a path outside its cluster"
+        expect = "cluster 5 of the batch: a row or a haplotype column refers to a path outside its cluster"
     elif fault == "row_offsets":
         views["row_grp_off"][2] = views["row_grp_off"][-1] + 7
         expect = "cluster 5 of the batch: inconsistent"
