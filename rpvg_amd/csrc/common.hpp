@@ -884,6 +884,22 @@ struct EmOutputs {  // device arrays, [P] unless noted
     double * d_total;           // read count of the problem's cluster
 };
 
+// A problem of the grid bin whose dense row-major matrix (em_grid.hip, the dense route) is written by the compaction itself
+// — straight from the cluster's rows, no CSR in between (em_sparse.hip, fillSegmentsKernel<true>): BASELINE.json configs[1].
+struct EmFusedDense {
+    uint32_t problem, pad;
+    double * matrix;
+    uint64_t ld;
+};
+constexpr int kEmMaxFusedDense = 4;
+constexpr uint32_t kEmDenseMaxCols = 2048;   // em_dense.hip: a row in the registers of one workgroup
+// the dense matrix is the smaller representation (8 B per cell against 12 B per entry + 20 B per row) and a row is narrow enough
+__host__ __device__ inline bool emDenseRule(const uint32_t columns, const uint32_t rows, const uint32_t entries) {
+    if (columns > kEmDenseMaxCols || columns < 2) return false;
+    const uint64_t ld = (static_cast<uint64_t>(columns) + 1) & ~1ull;
+    return 8ull * rows * ld <= 12ull * entries + 20ull * rows;
+}
+
 struct EmSolveWork {  // scratch of one solve: lives until its kernels are done
     DeviceBuffer<uint32_t> d_prow_off, d_pent_col, d_bucket, d_order, d_seg_rows, d_seg_entries;
     DeviceBuffer<double> d_prow_count, d_prow_noise, d_pent_val, d_zero, d_wide_vectors, d_seg_zero, d_seg_total;
@@ -893,6 +909,10 @@ struct EmSolveWork {  // scratch of one solve: lives until its kernels are done
     // row collapse of the problems (row_collapse.hip) and the second EM pass over the problems it merged rows in
     std::shared_ptr<void> collapse;
     DeviceBuffer<unsigned char> d_queues_merged;
+    // dense matrices the compaction wrote itself (queueEmSolve)
+    DeviceBuffer<double> fused_matrix[kEmMaxFusedDense];
+    EmFusedDense fused[kEmMaxFusedDense];
+    uint32_t num_fused = 0;
     hipEvent_t filled = nullptr, collapsed = nullptr, collapse_sorted = nullptr;
     ~EmSolveWork() {
         if (filled) (void) hipEventDestroy(filled);
@@ -936,6 +956,8 @@ struct EmGridStorage {
     double * abundances;
     double * noise_count;
     uint32_t * iterations;
+    const EmFusedDense * fused = nullptr;  // problems whose dense matrix exists already
+    uint32_t num_fused = 0;
 };
 
 // rows + entries from which a problem leaves the one-workgroup kernels (RPVG_HIP_EM_GRID_MIN_WORK; 0: never)

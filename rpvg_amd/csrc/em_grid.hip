@@ -41,7 +41,6 @@ namespace {
 constexpr double kMinEmAbundance = 1e-8;   // src/path_abundance_estimator.cpp:11
 constexpr uint32_t kMinEmConvIts = 10;     // src/path_abundance_estimator.cpp:10
 constexpr int kGridBlock = 256;
-constexpr uint32_t kDenseMaxCols = 2048;   // em_dense.hip: a row in the registers of one workgroup
 
 struct GridAccumArgs {
     const uint32_t * off;    // [rows + 1] entry offsets of the problem's rows (relative to col / val)
@@ -307,9 +306,7 @@ uint64_t emGridMinWork() {
 
 bool emGridDenseRoute(const uint32_t columns, const uint32_t rows, const uint32_t entries) {
     if (RPVG_EXPERIMENT_ENV("RPVG_HIP_EM_GRID_NO_DENSE")) return false;  // A/B knob
-    if (columns > kDenseMaxCols || columns < 2) return false;
-    const uint64_t ld = (static_cast<uint64_t>(columns) + 1) & ~1ull;
-    return 8ull * rows * ld <= 12ull * entries + 20ull * rows;
+    return emDenseRule(columns, rows, entries);
 }
 
 int runEmGridProblems(rpvg_hip_ctx * ctx, hipStream_t st, const EmGridProblem * problems, const uint32_t count, const EmGridStorage & storage,
@@ -328,21 +325,27 @@ int runEmGridProblems(rpvg_hip_ctx * ctx, hipStream_t st, const EmGridProblem * 
 
         const uint64_t dense_ld = (static_cast<uint64_t>(C) + 1) & ~1ull;
         DeviceBuffer<double> d_matrix;
+        const double * prebuilt = nullptr;  // (the compaction wrote the matrix itself: em_sparse.hip, the fused build)
+        for (uint32_t f = 0; f < storage.num_fused; ++f) {
+            if (storage.fused[f].problem == p && storage.fused[f].ld == dense_ld) prebuilt = storage.fused[f].matrix;
+        }
         // (the dense copy is the faster route, not a needed one: without the memory for it the problem stays on its CSR)
-        if (emGridDenseRoute(C, rows, d.entries) && d_matrix.alloc(static_cast<size_t>(rows) * dense_ld) == hipSuccess) {
+        if (prebuilt || (emGridDenseRoute(C, rows, d.entries) && d_matrix.alloc(static_cast<size_t>(rows) * dense_ld) == hipSuccess)) {
             const uint64_t ld = dense_ld;
-            const int span = ctx->spanBegin(FAM_BUILD, st);
-            hipError_t build_error = hipMemsetAsync(d_matrix.ptr, 0, sizeof(double) * rows * ld, st);
-            const uint32_t build_grid = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(rows) + 3) / 4, static_cast<uint64_t>(cus) * 16));
-            if (build_error == hipSuccess) {
-                emGridDenseBuildKernel<<<dim3(std::max(1u, build_grid)), dim3(kGridBlock), 0, st>>>(rows, C, ld, off, nz, col, val, d_matrix.ptr);
-                build_error = hipGetLastError();
+            if (!prebuilt) {
+                const int span = ctx->spanBegin(FAM_BUILD, st);
+                hipError_t build_error = hipMemsetAsync(d_matrix.ptr, 0, sizeof(double) * rows * ld, st);
+                const uint32_t build_grid = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(rows) + 3) / 4, static_cast<uint64_t>(cus) * 16));
+                if (build_error == hipSuccess) {
+                    emGridDenseBuildKernel<<<dim3(std::max(1u, build_grid)), dim3(kGridBlock), 0, st>>>(rows, C, ld, off, nz, col, val, d_matrix.ptr);
+                    build_error = hipGetLastError();
+                }
+                ctx->spanEnd(span);  // (closed on the error path too)
+                RPVG_HIP_CHECK(build_error);
+                ctx->stats.build_launches += 1;
             }
-            ctx->spanEnd(span);  // (closed on the error path too)
-            RPVG_HIP_CHECK(build_error);
-            ctx->stats.build_launches += 1;
             DenseEmRun run;
-            run.matrix = d_matrix.ptr;
+            run.matrix = prebuilt ? prebuilt : d_matrix.ptr;
             run.num_rows = rows;
             run.num_cols = C;
             run.ld = ld;

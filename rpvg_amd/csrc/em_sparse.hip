@@ -253,7 +253,16 @@ struct FillArgs {
     EmBinRule rule;
     uint32_t lds_map_paths;                // capacity of the LDS map of this launch (0: bisection for every problem)
     uint32_t long_row_scratch;             // the launch carries kFillLongRowLds bytes of LDS behind the map: clusters of long rows take a wavefront per row
+    // problems whose rows are written as a dense row-major matrix instead of a CSR (the fused build: queueEmSolve)
+    uint32_t num_fused;
+    EmFusedDense fused[kEmMaxFusedDense];
 };
+
+// whether the rows of cluster k take a wavefront each in fillSegmentsKernel
+__device__ inline bool fillLongRows(const FillArgs & args, const uint32_t k) {
+    const uint64_t c0 = args.cluster_row_off[k], c1 = args.cluster_row_off[k + 1];
+    return args.long_row_scratch && args.row_ent_off[c1] - args.row_ent_off[c0] >= kFillLongRowEntries * (c1 - c0);
+}
 
 template <bool WRITE>
 __global__ __launch_bounds__(256) void fillSegmentsKernel(const FillArgs args) {
@@ -265,14 +274,22 @@ __global__ __launch_bounds__(256) void fillSegmentsKernel(const FillArgs args) {
     uint32_t mapped_problem = UINT32_MAX;
     for (uint32_t item = blockIdx.x; item < num_items; item += gridDim.x) {
         const uint32_t p = args.item_problem[item];
+        if (WRITE) {  // (the rows of these problems go straight into their dense matrices: fillDenseRowsKernel)
+            bool fused = false;
+            for (uint32_t f = 0; f < args.num_fused; ++f) fused = fused || args.fused[f].problem == p;
+            if (fused) continue;
+        }
         const uint32_t segment = static_cast<uint32_t>(item - args.seg_first[p]);
         const uint32_t k = args.prob_cluster[p];
         const uint32_t n_paths = static_cast<uint32_t>(args.cluster_path_off[k + 1] - args.cluster_path_off[k]);
         const uint32_t * cols = args.col_path + args.col_off[p];
         const uint32_t n_cols = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]);
         const bool use_map = n_paths <= args.lds_map_paths;
+        // every path of the cluster is a column (the `transcripts` model: one problem per cluster over all of its paths — the column
+        // list is ascending and without repeats, so as long as the cluster it is 0, 1, 2, ...): no map, and every entry is kept
+        const bool identity = n_cols == n_paths;
         __syncthreads();  // (the previous item is done with the map and the scratch)
-        if (use_map && mapped_problem != p) {
+        if (use_map && !identity && mapped_problem != p) {
             for (uint32_t i = threadIdx.x; i < n_paths; i += BLOCK) lds_map[i] = -1;
             __syncthreads();
             for (uint32_t c = threadIdx.x; c < n_cols; c += BLOCK) lds_map[cols[c]] = static_cast<int32_t>(c);
@@ -280,6 +297,7 @@ __global__ __launch_bounds__(256) void fillSegmentsKernel(const FillArgs args) {
             mapped_problem = p;
         }
         auto column_of = [&](const uint32_t path) -> int32_t {
+            if (identity) return static_cast<int32_t>(path);
             if (use_map) return lds_map[path];
             uint32_t lo = 0, hi = n_cols;  // first column whose path is not below `path`
             while (lo < hi) {
@@ -296,7 +314,7 @@ __global__ __launch_bounds__(256) void fillSegmentsKernel(const FillArgs args) {
         uint32_t * off = WRITE ? args.prow_off + rb + p : nullptr;
         uint32_t run_rows = WRITE ? args.seg_rows[item] : 0, run_ent = WRITE ? args.seg_entries[item] : 0;  // (starts, by now)
         double z = 0, t = 0;  // read counts of the rows without a selected path / of all rows
-        if (args.long_row_scratch && args.row_ent_off[c1] - args.row_ent_off[c0] >= kFillLongRowEntries * (c1 - c0)) {
+        if (fillLongRows(args, k)) {
             // A cluster of long rows (the 2 000-path rows of BASELINE.json configs[1]): a wavefront per row, its lanes striding the
             // row's entries — 512-byte requests — instead of a thread walking 2 000 entries 24 KB from its neighbour's (0.2 s for
             // the 1 M x 2 000 cluster, as long as eighty EM iterations over it).  Kept entries of a row and, for the write, its
@@ -312,13 +330,20 @@ __global__ __launch_bounds__(256) void fillSegmentsKernel(const FillArgs args) {
                 const uint64_t e0 = args.row_ent_off[r], e1 = args.row_ent_off[r + 1];
                 uint32_t n = 0;
                 double sum = 0;
-                for (uint64_t e = e0 + lane; e < e1; e += 64) {
-                    if (column_of(args.ent_path[e]) >= 0) {
-                        ++n;
-                        sum += args.ent_prob[e];
+                if (identity) {
+                    n = static_cast<uint32_t>(e1 - e0);
+                    if (WRITE) {
+                        for (uint64_t e = e0 + lane; e < e1; e += 64) sum += args.ent_prob[e];
                     }
+                } else {
+                    for (uint64_t e = e0 + lane; e < e1; e += 64) {
+                        if (column_of(args.ent_path[e]) >= 0) {
+                            ++n;
+                            sum += args.ent_prob[e];
+                        }
+                    }
+                    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
                 }
-                for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
                 if (WRITE) sum = waveSumF64(sum);
                 if (lane == 0) {
                     row_n[i] = n;
@@ -453,7 +478,7 @@ template <bool WRITE>
 hipError_t launchFillSegments(FillArgs & fa, const uint32_t grid, const uint64_t max_cluster_work, hipStream_t st) {
     static const bool never = RPVG_EXPERIMENT_ENV("RPVG_HIP_FILL_THREAD_ROWS") != nullptr;  // A/B knob
     fa.long_row_scratch = (!never && max_cluster_work >= (1ull << 18)) ? 1u : 0u;
-    fa.lds_map_paths = (fa.lds_map_paths + 1) & ~1u;  // (the scratch behind the map holds doubles)
+    fa.lds_map_paths = (fa.lds_map_paths + 3) & ~3u;  // (the scratch behind the map holds doubles, and fillDenseRowsKernel moves 16 bytes at a time)
     const size_t lds = fa.lds_map_paths * sizeof(int32_t) + (fa.long_row_scratch ? kFillLongRowLds : 0);
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fillSegmentsKernel<WRITE>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -461,6 +486,149 @@ hipError_t launchFillSegments(FillArgs & fa, const uint32_t grid, const uint64_t
     }
     fillSegmentsKernel<WRITE><<<dim3(grid), dim3(256), lds, st>>>(fa);
     return hipSuccess;
+}
+
+// The fused build: the rows of problem args.fused[blockIdx.y] from its cluster straight into its dense row-major matrix — what
+// fillSegmentsKernel<true> and emGridDenseBuildKernel (em_grid.hip) do in two steps with the compacted CSR and a zeroed matrix
+// between them, with the same arithmetic in the same order (row sum: a lane's entries in ascending order, then waveSumF64;
+// value = (P / rowsum) * (1 - noise)), so the matrix is the same to the bit.  A workgroup takes segments of the cluster's rows,
+// a wavefront a row at a time: the row's entries are loaded (at most 64 x kDenseRowCache: into registers, read once; longer
+// rows: read twice), an image of the matrix row in LDS is zeroed meanwhile, the kept entries go to their columns of the image
+// and the noise term behind the last path, and the image leaves in 16-byte stores, one behind the other.  12 B read per entry,
+// 8 B written per cell, nothing written twice (zeros and values to the matrix itself: 4.1 TB/s of algorithmic bytes; the zeros
+// reached HBM).
+constexpr int kDenseRowCache = 32;
+constexpr size_t kFillDenseLds = kFillSegmentRows * 2 * sizeof(uint32_t);   // + an image of a row per wavefront
+
+__global__ __launch_bounds__(256) void fillDenseRowsKernel(const FillArgs args) {
+    constexpr int BLOCK = 256;
+    extern __shared__ __attribute__((aligned(16))) int32_t lds_map[];
+    __shared__ uint32_t scratch[2 * (BLOCK / 64)];
+    const EmFusedDense fd = args.fused[blockIdx.y];
+    const uint32_t p = fd.problem;
+    const uint32_t k = args.prob_cluster[p];
+    const uint32_t n_paths = static_cast<uint32_t>(args.cluster_path_off[k + 1] - args.cluster_path_off[k]);
+    const uint32_t * cols = args.col_path + args.col_off[p];
+    const uint32_t n_cols = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]);
+    const bool identity = n_cols == n_paths;  // (fillSegmentsKernel)
+    const bool use_map = !identity && n_paths <= args.lds_map_paths;
+    uint32_t * row_n = reinterpret_cast<uint32_t *>(lds_map + args.lds_map_paths);  // [kFillSegmentRows] kept entries of a row
+    uint32_t * row_slot = row_n + kFillSegmentRows;                                 // its place among the segment's kept rows
+    double * image = reinterpret_cast<double *>(row_slot + kFillSegmentRows) + (threadIdx.x >> 6) * fd.ld;  // [ld] of this wavefront
+    if (use_map) {
+        for (uint32_t i = threadIdx.x; i < n_paths; i += BLOCK) lds_map[i] = -1;
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < n_cols; c += BLOCK) lds_map[cols[c]] = static_cast<int32_t>(c);
+    }
+    auto column_of = [&](const uint32_t path) -> int32_t {
+        if (identity) return static_cast<int32_t>(path);
+        if (use_map) return lds_map[path];
+        uint32_t lo = 0, hi = n_cols;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cols[mid] < path) lo = mid + 1;
+            else hi = mid;
+        }
+        return (lo < n_cols && cols[lo] == path) ? static_cast<int32_t>(lo) : -1;
+    };
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t c0 = args.cluster_row_off[k], c1 = args.cluster_row_off[k + 1];
+    const uint64_t rb = args.row_base[p];
+    for (uint64_t item = args.seg_first[p] + blockIdx.x; item < args.seg_first[p + 1]; item += gridDim.x) {
+        const uint32_t segment = static_cast<uint32_t>(item - args.seg_first[p]);
+        const uint64_t r0 = c0 + static_cast<uint64_t>(segment) * kFillSegmentRows, r1 = min(c1, r0 + kFillSegmentRows);
+        const uint32_t seg_n = static_cast<uint32_t>(r1 - r0);
+        const uint32_t run_rows = args.seg_rows[item];  // (the segment's first row among the problem's kept rows: fillOffsetsKernel)
+        __syncthreads();  // (the map is complete; the previous segment is done with the scratch)
+        for (uint32_t i = wave; i < seg_n; i += BLOCK / 64) {
+            const uint64_t e0 = args.row_ent_off[r0 + i], e1 = args.row_ent_off[r0 + i + 1];
+            uint32_t n = static_cast<uint32_t>(e1 - e0);
+            if (!identity) {
+                n = 0;
+                for (uint64_t e = e0 + lane; e < e1; e += 64) n += column_of(args.ent_path[e]) >= 0 ? 1u : 0u;
+                for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
+            }
+            if (lane == 0) row_n[i] = n;
+        }
+        __syncthreads();
+        constexpr uint32_t kPer = kFillSegmentRows / BLOCK;
+        uint32_t slots = 0, unused = 0, tot_rows, tot_unused;
+        for (uint32_t j = 0; j < kPer; ++j) {
+            const uint32_t i = threadIdx.x * kPer + j;
+            slots += (i < seg_n && row_n[i]) ? 1u : 0u;
+        }
+        uint32_t slot0 = slots;
+        blockExclusiveScanPair<BLOCK>(slot0, unused, tot_rows, tot_unused, scratch);
+        for (uint32_t j = 0; j < kPer; ++j) {
+            const uint32_t i = threadIdx.x * kPer + j;
+            if (i >= seg_n) break;
+            row_slot[i] = slot0;
+            slot0 += row_n[i] ? 1u : 0u;
+        }
+        __syncthreads();
+        for (uint32_t i = wave; i < seg_n; i += BLOCK / 64) {
+            if (!row_n[i]) continue;
+            const uint64_t r = r0 + i;
+            const uint32_t my_row = run_rows + row_slot[i];
+            const double nz = args.row_noise[r];
+            if (lane == 0) {
+                args.prow_count[rb + my_row] = args.row_count[r];
+                args.prow_noise[rb + my_row] = nz;
+            }
+            const double keep = 1 - nz;
+            const uint64_t e0 = args.row_ent_off[r], e1 = args.row_ent_off[r + 1];
+            double * out = fd.matrix + static_cast<uint64_t>(my_row) * fd.ld;
+            // (a wavefront's LDS instructions execute in order: zeros, values, the read — the compiler keeps the order of accesses
+            // that may touch the same words)
+            for (uint32_t j = 2 * lane; j < fd.ld; j += 128) *reinterpret_cast<double2 *>(image + j) = double2{0.0, 0.0};
+            if (e1 - e0 <= 64ull * kDenseRowCache) {
+                int32_t col[kDenseRowCache];
+                double val[kDenseRowCache];
+                const uint32_t len = static_cast<uint32_t>(e1 - e0);
+#pragma unroll
+                for (int j = 0; j < kDenseRowCache; ++j) {
+                    const uint32_t at = lane + 64u * j;
+                    col[j] = -1;
+                    val[j] = 0.0;
+                    if (64u * j < len && at < len) {
+                        col[j] = static_cast<int32_t>(args.ent_path[e0 + at]);
+                        val[j] = args.ent_prob[e0 + at];
+                    }
+                }
+                double sum = 0;
+#pragma unroll
+                for (int j = 0; j < kDenseRowCache; ++j) {
+                    if (64u * j < len) {
+                        if (col[j] >= 0) col[j] = column_of(static_cast<uint32_t>(col[j]));
+                        if (col[j] >= 0) sum += val[j];
+                    }
+                }
+                const double rowsum = waveSumF64(sum);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < kDenseRowCache; ++j) {
+                    // addNoiseAndNormalizeProbabilityMatrix: (P / rowsum) * (1 - noise), two roundings
+                    if (64u * j < len && col[j] >= 0) image[col[j]] = (val[j] / rowsum) * keep;
+                }
+            } else {
+                double sum = 0;
+                for (uint64_t e = e0 + lane; e < e1; e += 64) {
+                    if (column_of(args.ent_path[e]) >= 0) sum += args.ent_prob[e];
+                }
+                const double rowsum = waveSumF64(sum);
+                __builtin_amdgcn_wave_barrier();
+                for (uint64_t e = e0 + lane; e < e1; e += 64) {
+                    const int32_t c = column_of(args.ent_path[e]);
+                    if (c >= 0) image[c] = (args.ent_prob[e] / rowsum) * keep;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) image[n_cols] = nz;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = 2 * lane; j < fd.ld; j += 128) *reinterpret_cast<double2 *>(out + j) = *reinterpret_cast<const double2 *>(image + j);
+            __builtin_amdgcn_wave_barrier();  // (the next row's zeros stay behind these reads)
+        }
+    }
 }
 
 // per problem: the counts of its segments become their starts; totals, terminal offset, size bin
@@ -489,6 +657,27 @@ __global__ __launch_bounds__(256) void fillOffsetsKernel(const FillArgs args) {
     args.kept_entries[p] = entries;
     args.zero_mass[p] = z;
     args.total_mass[p] = t;
+}
+
+// The problems of the grid bin that take the dense route (em_grid.hip) and sit on a cluster of long rows: the host gives each a
+// matrix and the compaction writes their rows into it — at most kEmMaxFusedDense of them, whichever come first (the others take
+// the CSR and the copy: the same matrix either way).
+struct DenseCandidate {
+    uint32_t problem, rows, columns, entries;
+};
+struct DenseCandidates {
+    uint32_t count, pad;
+    DenseCandidate list[kEmMaxFusedDense];
+};
+__global__ __launch_bounds__(256) void denseCandidatesKernel(const FillArgs args, DenseCandidates * __restrict__ out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (args.num_problems_dev ? *args.num_problems_dev : args.num_problems)) return;
+    if (args.prob_bucket[p] / kEmWorkBuckets != static_cast<uint32_t>(kEmGridBin)) return;
+    const uint32_t columns = static_cast<uint32_t>(args.col_off[p + 1] - args.col_off[p]) + 1;
+    const uint32_t rows = args.kept_rows[p], entries = args.kept_entries[p];
+    if (!emDenseRule(columns, rows, entries) || !fillLongRows(args, args.prob_cluster[p])) return;
+    const uint32_t at = atomicAdd(&out->count, 1u);
+    if (at < static_cast<uint32_t>(kEmMaxFusedDense)) out->list[at] = DenseCandidate{p, rows, columns, entries};
 }
 
 // ---- 3. the work queues ------------------------------------------------------------
@@ -1386,6 +1575,13 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     hipStream_t st = ctx->stream;
     const uint32_t P = list.P_bound;
     const EmBinRule rule = emBinRule();
+    static const bool no_em_collapse = RPVG_EXPERIMENT_ENV("RPVG_HIP_NO_EM_COLLAPSE") != nullptr;
+    const bool collapse = collapse_precision > 0 && !no_em_collapse && !RPVG_EXPERIMENT_ENV("RPVG_HIP_NO_COLLAPSE") && list.rows_capacity > 0;
+    // (the few mid-size problems that may take the grid route: only where the grid route exists at all)
+    const bool mid_grid_allowed = rule.grid_min_work > (1ull << kEmMidGridLog2);
+    // The grid bin (problems too large for one workgroup, em_grid.hip): the host has to see them.  Only a solve that
+    // sits on a cluster large enough to produce one pays for the look (two small copies and their waits).
+    const bool grid_possible = rule.grid_min_work != 0 && list.max_cluster_work >= (mid_grid_allowed ? (1ull << kEmMidGridLog2) - 1 : rule.grid_min_work);
     std::unique_ptr<HostScope> stage_scope(new HostScope("em_solve: allocations + fill queued"));
     RPVG_HIP_CHECK(work.d_prow_off.alloc(list.rows_capacity + P));
     RPVG_HIP_CHECK(work.d_prow_count.alloc(list.rows_capacity));
@@ -1444,11 +1640,64 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     fa.queues = queues;
     fa.rule = rule;
     fa.lds_map_paths = std::min<uint32_t>(list.max_cluster_paths, kLdsMapPaths);
+    fa.num_fused = 0;
     // (the segment kernels walk the items with a grid of a few workgroups per CU: an item is at most 1 024 rows)
     const uint32_t fill_grid = std::min<uint32_t>(list.items_bound, static_cast<uint32_t>(ctx->props.multiProcessorCount) * 8);
     RPVG_HIP_CHECK(launchFillSegments<false>(fa, fill_grid, list.max_cluster_work, st));
     fillOffsetsKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(fa);
+    // The fused build: a problem of the grid bin that will be solved on a dense matrix (em_grid.hip) gets it from the compaction
+    // itself — rows -> matrix, 12 B read per entry and 8 B written per cell, against rows -> CSR -> zeroed matrix -> matrix (the
+    // 1 M x 2 000 cluster of BASELINE.json configs[1]: 36 ms of a 160 ms call).  The host has to see the counts for it (one small
+    // copy and its wait, only in a solve that sits on a cluster large enough for the grid bin); a solve whose problems are
+    // collapsed (row_collapse.hip reads the CSR) keeps the CSR.  RPVG_HIP_NO_FUSED_DENSE=1: never (read per call; the tests take both).
+    if (grid_possible && !collapse && !fill_only && !std::getenv("RPVG_HIP_NO_FUSED_DENSE")) {
+        DeviceBuffer<DenseCandidates> d_candidates;
+        DenseCandidates * h_candidates = nullptr;
+        RPVG_HIP_CHECK(d_candidates.alloc(1));
+        if (pinnedAlloc(reinterpret_cast<void **>(&h_candidates), sizeof(DenseCandidates)) != hipSuccess) {
+            setError("rpvg_hip_em_solve: out of page-locked host memory");
+            return RPVG_HIP_ERR_ALLOC;
+        }
+        struct PinnedGuard {
+            void * p;
+            ~PinnedGuard() { pinnedFree(p); }
+        } pinned_guard{h_candidates};
+        RPVG_HIP_CHECK(zeroAsync(d_candidates.ptr, sizeof(DenseCandidates), st));
+        denseCandidatesKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(fa, d_candidates.ptr);
+        RPVG_HIP_CHECK(hipGetLastError());
+        RPVG_HIP_CHECK(hipMemcpyAsync(h_candidates, d_candidates.ptr, sizeof(DenseCandidates), hipMemcpyDeviceToHost, st));
+        {
+            HostScope wait_scope("em_solve: the counts of the large problems");
+            RPVG_HIP_CHECK(waitStream(st));
+        }
+        const uint32_t n = std::min<uint32_t>(h_candidates->count, kEmMaxFusedDense);
+        for (uint32_t i = 0; i < n; ++i) {
+            const DenseCandidate & c = h_candidates->list[i];
+            if (!emGridDenseRoute(c.columns, c.rows, c.entries)) continue;
+            const uint64_t ld = (static_cast<uint64_t>(c.columns) + 1) & ~1ull;
+            DeviceBuffer<double> & m = work.fused_matrix[work.num_fused];
+            // (without the memory for it the problem takes the CSR, and the grid route decides again)
+            if (m.alloc(static_cast<size_t>(c.rows) * ld) != hipSuccess) {
+                (void) hipGetLastError();
+                continue;
+            }
+            work.fused[work.num_fused] = EmFusedDense{c.problem, 0u, m.ptr, ld};
+            fa.fused[work.num_fused] = work.fused[work.num_fused];
+            ++work.num_fused;
+        }
+        fa.num_fused = work.num_fused;
+    }
     RPVG_HIP_CHECK(launchFillSegments<true>(fa, fill_grid, list.max_cluster_work, st));
+    if (fa.num_fused > 0) {
+        uint64_t widest = 0;
+        for (uint32_t f = 0; f < fa.num_fused; ++f) widest = std::max(widest, fa.fused[f].ld);
+        const size_t lds = fa.lds_map_paths * sizeof(int32_t) + kFillDenseLds + 4 * widest * sizeof(double);
+        if (lds > 64 * 1024) RPVG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fillDenseRowsKernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        const uint32_t dense_grid = std::min<uint32_t>(list.items_bound, static_cast<uint32_t>(ctx->props.multiProcessorCount) * 4);
+        fillDenseRowsKernel<<<dim3(dense_grid, fa.num_fused), dim3(256), lds, st>>>(fa);
+        RPVG_HIP_CHECK(hipGetLastError());
+        ctx->stats.build_launches += 1;
+    }
     RPVG_HIP_CHECK(hipGetLastError());
     ctx->stats.build_launches += 3;
     if (fill_only) {
@@ -1460,8 +1709,6 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
     // version solved every problem next to the collapse and the merged ones a second time: on the configs[2] batch the
     // largest problems were the merged ones, the second pass took as long as the first, and the collapse's forty launches
     // took 2.6 ms in between the persistent EM kernels against 1.5 ms without them.)
-    static const bool no_em_collapse = RPVG_EXPERIMENT_ENV("RPVG_HIP_NO_EM_COLLAPSE") != nullptr;
-    const bool collapse = collapse_precision > 0 && !no_em_collapse && !RPVG_EXPERIMENT_ENV("RPVG_HIP_NO_COLLAPSE") && list.rows_capacity > 0;
     // (the collapse indexes rows with 32 bits and matrices with 20; the callers' memory budgets keep a solve far below both —
     // a solve that is not gets an error rather than results without the collapse)
     RPVG_REQUIRE(!collapse || (list.rows_capacity <= 0x7fffffffull && P + 1 < kCollapseMaxMatrices),
@@ -1471,8 +1718,6 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         RPVG_HIP_CHECK(hipEventCreateWithFlags(&work.filled, hipEventDisableTiming));
         RPVG_HIP_CHECK(hipEventRecord(work.filled, st));
     }
-    // (the few mid-size problems that may take the grid route: only where the grid route exists at all)
-    const bool mid_grid_allowed = rule.grid_min_work > (1ull << kEmMidGridLog2);
     emOrderKernel<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(P, list.d_num_problems, work.d_bucket.ptr, list.d_col_off, queues, work.d_order.ptr,
                                                               work.d_wide_off.ptr, list.wide_capacity, mid_grid_allowed ? 1u : 0u);
     RPVG_HIP_CHECK(hipGetLastError());
@@ -1657,9 +1902,6 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
         // (the side streams are joined behind the problems that run over the whole GPU, below: those start while these kernels run)
         return RPVG_HIP_OK;
     };
-    // The grid bin (problems too large for one workgroup, em_grid.hip): the host has to see them.  Only a solve that
-    // sits on a cluster large enough to produce one pays for the look (two small copies and their waits).
-    const bool grid_possible = rule.grid_min_work != 0 && list.max_cluster_work >= (mid_grid_allowed ? (1ull << kEmMidGridLog2) - 1 : rule.grid_min_work);
     DeviceBuffer<EmGridProblem> d_grid_problems;
     hipEvent_t described = nullptr;
     uint32_t * h_grid_count = nullptr;
@@ -1718,6 +1960,8 @@ int queueEmSolve(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const EmProbl
             storage.abundances = out.d_abundances;
             storage.noise_count = out.d_noise_count;
             storage.iterations = out.d_iterations;
+            storage.fused = work.fused;
+            storage.num_fused = work.num_fused;
             const int rc = runEmGridProblems(ctx, st, grid_problems.data(), n_grid, storage, max_em_its, max_rel_em_conv);
             if (rc != RPVG_HIP_OK) return rc;
         }

@@ -121,6 +121,44 @@ def test_dense_route_at_50000_rows_by_2000_paths_matches_the_oracle(engine):
     assert stats["em_kernel"][GRID]["problems"] == 1 and stats["em_kernel"][GRID]["iterations"] == 0  # (accounted as dense)
 
 
+def test_fused_dense_build_equals_the_csr_and_the_copy(monkeypatch):
+    """A problem of the dense route gets its matrix from the compaction itself (em_sparse.hip, the fused build; RPVG_HIP_NO_FUSED_DENSE=1:
+    compacted CSR, zeroed matrix, copy): the same matrix, so the same abundances bit for bit — for a problem over every path of its
+    cluster (the `transcripts` model: no column map, no reading of path indices to count), for one over a part of the paths (rows
+    that touch none of them drop out, the others keep only their selected entries) and for several in one solve."""
+    from rpvg_amd.batch import ClusterBatch
+    rng = np.random.default_rng(3)
+    parts = [large_cases.cluster_batch(3000, 300, 300, seed=21, noise_only_frac=0.02), large_cases.cluster_batch(4000, 400, 300, seed=22, noise_only_frac=0.01),
+             ClusterBatch.from_clusters(small_cases.make_batch_clusters(78, n_clusters=6))]
+    batch = ClusterBatch.concat(parts)
+    all0, all1 = list(range(300)), list(range(400))
+    part0 = sorted(int(x) for x in rng.choice(300, size=170, replace=False))
+    part1 = sorted(int(x) for x in rng.choice(400, size=220, replace=False))
+    problems = [(0, all0), (0, part0), (1, all1), (1, part1), (2, list(range(int(batch.cluster_path_off[3] - batch.cluster_path_off[2]))))]
+    ctx = hip.Context(0)
+    dev = ctx.upload(batch)
+    try:
+        out = {}
+        for fused in (True, False):
+            if fused:
+                monkeypatch.delenv("RPVG_HIP_NO_FUSED_DENSE", raising=False)
+            else:
+                monkeypatch.setenv("RPVG_HIP_NO_FUSED_DENSE", "1")
+            ctx.reset_stats()
+            out[fused] = ctx.em_solve(dev, [k for k, _ in problems], [c for _, c in problems], max_em_its=25)
+            out[fused] += (ctx.stats(),)
+        a, b = out[True], out[False]
+        assert a[4]["em_dense_launches"] == b[4]["em_dense_launches"] == 100     # four problems on the dense route, 25 iterations each
+        assert b[4]["build_launches"] - a[4]["build_launches"] == 3             # ... four copy kernels against one launch that writes the four matrices
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        for x, y in zip(a[0], b[0]):
+            assert np.array_equal(x, y)
+        assert all(x.sum() > 0 for x in a[0])
+    finally:
+        dev.free()
+        ctx.close()
+
+
 def test_large_and_small_clusters_in_one_batch(engine, monkeypatch):
     """The grid bin next to the one-workgroup bins of the same solve."""
     monkeypatch.setenv("RPVG_HIP_EM_GRID_MIN_WORK", "50000")
