@@ -1313,11 +1313,16 @@ int queuePairSearch(rpvg_hip_ctx * ctx, const rpvg_hip_groups * groups, const ui
                 uint32_t key = 1;
                 while (key < G) key <<= 1;
                 Bucket & b = buckets[key];
-                const uint32_t tiles = tileCount(G), S = tileSlices(G), passes = (tiles + kTileBlock - 1) / kTileBlock;
+                const uint32_t tiles = tileCount(G);
                 b.matrices += 1;
                 b.rows += R;
                 b.evals += R * (0.5 * G * (G + 1));
-                b.lane_rows += R / S * passes * kTileBlock;   // rows a lane walks x lanes of the workgroup
+                // rows a lane walks x lanes of the workgroup, summed over the matrix's work items (planTileRanges: an item's lanes walk
+                // 1 / slices of the rows each) — until round 6 this line priced round 2's kernel, one item per chunk with
+                // tileSlices(G) slices: 0.58 for 64 columns, where the ranges of pairTile2Kernel reach 1.00
+                std::vector<std::pair<uint32_t, uint32_t> > ranges;
+                planTileRanges(tiles, &ranges);
+                for (auto & range : ranges) b.lane_rows += R / (kTileBlock / range.second) * kTileBlock;
                 b.slot_rows += R * tiles * 16;
             }
             for (auto & kv : buckets) {

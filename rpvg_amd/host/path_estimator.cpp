@@ -4,6 +4,8 @@
 #include <atomic>
 #include <limits>
 
+#include <cstring>
+#include <type_traits>
 #include <linux/futex.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -52,8 +54,15 @@ class GroupMatrices {
                 first_path[i + 1] = first_path[i] + problems[i].column_path.size();
             }
 
-            std::vector<uint64_t> group_path_off(group_off.back() + 1, 0);
-            std::vector<uint32_t> group_path(first_path.back());
+            // (kept by the calling thread from call to call, as the generator words of the device sampler below)
+            // (through references: inside the parallel region below the thread_local names would be the team threads' own)
+            thread_local std::vector<uint64_t> kept_group_path_off;
+            thread_local std::vector<uint32_t> kept_group_path;
+            std::vector<uint64_t> & group_path_off = kept_group_path_off;
+            std::vector<uint32_t> & group_path = kept_group_path;
+            group_path_off.resize(group_off.back() + 1);
+            group_path_off[0] = 0;
+            group_path.resize(first_path.back());
 
             #pragma omp parallel for schedule(static, 1) num_threads(hostThreads())
             for (size_t i = 0; i < problems.size(); ++i) {
@@ -1052,13 +1061,33 @@ std::vector<double> PathEstimator::calcPathLogFrequences(const std::vector<uint3
     const uint32_t count_sum = std::accumulate(path_counts.begin(), path_counts.end(), 0u);
     assert(count_sum > 0);
 
-    std::vector<double> path_log_freqs;
-    path_log_freqs.reserve(path_counts.size());
+    std::vector<double> path_log_freqs(path_counts.size());
 
-    for (auto & count: path_counts) {
+    // (most columns of a cluster carry one of a few small counts: the logarithm of a count is taken once — the same
+    // division and the same logarithm as for every column by itself)
+    constexpr uint32_t memo_size = 64;
+    double memo[memo_size];
+    uint64_t memo_set = 0;
 
+    for (size_t i = 0; i < path_counts.size(); ++i) {
+
+        const uint32_t count = path_counts[i];
         assert(count > 0);
-        path_log_freqs.emplace_back(std::log(count / static_cast<double>(count_sum)));
+
+        if (count < memo_size) {
+
+            if (!((memo_set >> count) & 1u)) {
+
+                memo[count] = std::log(count / static_cast<double>(count_sum));
+                memo_set |= uint64_t(1) << count;
+            }
+
+            path_log_freqs[i] = memo[count];
+
+        } else {
+
+            path_log_freqs[i] = std::log(count / static_cast<double>(count_sum));
+        }
     }
 
     return path_log_freqs;
@@ -1296,6 +1325,146 @@ struct GeneratorStateWords {
     }
 };
 
+// What rpvg_hip_group_gibbs wants of a generator — its next 624 outputs — and what it hands back — the state to go on from —
+// without a copy of the generator, 624 calls and a seed(): straight from and to the engine's state array.  libstdc++ keeps a
+// std::mt19937 as its 624 state words (in uint_fast32_t) followed by the position of the next one, and nothing else; that is
+// not something the standard promises, so the first use draws the same words both ways from a probe generator and the raw
+// route is only taken when they agree (and the sizes match at compile time) — otherwise, and with RPVG_AMD_PORTABLE_GENERATORS=1,
+// the portable route below it.  5 000 generators per configs[4] batch: 15 ms of CPU time per batch against 2.
+struct GeneratorLayout {
+
+    std::mt19937::result_type x[std::mt19937::state_size];
+    size_t p;
+};
+
+inline uint32_t temperWord(uint32_t y) {
+
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+inline uint32_t twistWords(const uint32_t upper, const uint32_t lower) {
+
+    const uint32_t y = (upper & 0x80000000u) | (lower & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// the next 624 outputs of a generator whose state words are x and whose next word is x[p] (p == 624: none left)
+inline void nextOutputsFromState(const std::mt19937::result_type * x, const size_t p, uint32_t * out) {
+
+    constexpr size_t n = std::mt19937::state_size, m = 397;
+
+    for (size_t i = p; i < n; ++i) {
+
+        out[i - p] = temperWord(static_cast<uint32_t>(x[i]));
+    }
+
+    // ... and the first p words of the next state: word k from the old words k, k + 1 and k + 397 — for k >= 227 the latter is
+    // the NEW word k - 227 (the generator refills its array in place)
+    uint32_t fresh[n];
+
+    for (size_t k = 0; k < p && k < n - m; ++k) {
+
+        fresh[k] = static_cast<uint32_t>(x[k + m]) ^ twistWords(static_cast<uint32_t>(x[k]), static_cast<uint32_t>(x[k + 1]));
+    }
+
+    for (size_t k = n - m; k < p; ++k) {
+
+        const uint32_t lower = (k + 1 < n) ? static_cast<uint32_t>(x[k + 1]) : fresh[0];
+        fresh[k] = fresh[k - (n - m)] ^ twistWords(static_cast<uint32_t>(x[k]), lower);
+    }
+
+    for (size_t k = 0; k < p; ++k) {
+
+        out[n - p + k] = temperWord(fresh[k]);
+    }
+}
+
+bool rawGeneratorAccess() {
+
+    static const bool usable = []() {
+
+        if (sizeof(GeneratorLayout) != sizeof(std::mt19937) || !std::is_trivially_copyable<std::mt19937>::value || std::getenv("RPVG_AMD_PORTABLE_GENERATORS")) {
+
+            return false;
+        }
+
+        for (const size_t advance: {0u, 1u, 227u, 623u, 624u, 1000u}) {
+
+            std::mt19937 probe(20240229u + advance);
+            probe.discard(advance);
+
+            GeneratorLayout layout;
+            std::memcpy(&layout, &probe, sizeof(layout));
+
+            if (layout.p > std::mt19937::state_size) {
+
+                return false;
+            }
+
+            uint32_t raw[std::mt19937::state_size];
+            nextOutputsFromState(layout.x, layout.p, raw);
+
+            for (size_t w = 0; w < std::mt19937::state_size; ++w) {
+
+                if (raw[w] != probe()) {
+
+                    return false;
+                }
+            }
+        }
+
+        return true;
+    }();
+
+    return usable;
+}
+
+// the next 624 outputs of a generator, which stays where it is
+void nextGeneratorOutputs(const std::mt19937 & generator, uint32_t * out) {
+
+    if (rawGeneratorAccess()) {
+
+        GeneratorLayout layout;  // (a copy of the bytes: 5 KB, and nothing the compiler's view of the generator's type could object to)
+        std::memcpy(&layout, &generator, sizeof(layout));
+        nextOutputsFromState(layout.x, layout.p, out);
+
+    } else {
+
+        std::mt19937 ahead = generator;
+
+        for (size_t w = 0; w < std::mt19937::state_size; ++w) {
+
+            out[w] = ahead();
+        }
+    }
+}
+
+// a generator whose last 624 outputs were the tempered `words`: it goes on behind them
+void setGeneratorBehind(std::mt19937 * generator, const uint32_t * words) {
+
+    if (rawGeneratorAccess()) {
+
+        GeneratorLayout layout;
+
+        for (size_t w = 0; w < std::mt19937::state_size; ++w) {
+
+            layout.x[w] = words[w];
+        }
+
+        layout.p = std::mt19937::state_size;
+        std::memcpy(static_cast<void *>(generator), &layout, sizeof(layout));
+
+    } else {
+
+        GeneratorStateWords state_words(words);
+        generator->seed(state_words);
+    }
+}
+
 // The sampler of src/path_estimator.cpp:475-589 in one device call: the generators' next 624 outputs go in (their
 // untempered values are the generators' states), the sampled sets come out in the reference's order, and every generator
 // is moved past the words its chains took.  False when the device call does not take the input (the distributions of the
@@ -1353,8 +1522,15 @@ bool estimatePathGroupPosteriorsGibbsOnDevice(std::vector<GroupPosteriors> * gro
         column_off[i + 1] = column_off[i] + problems[i].numColumns();
     }
 
-    std::vector<double> log_freqs(column_off.back());
-    std::vector<uint32_t> generator_words(generators.size() * std::mt19937::state_size);
+    // (megabytes per call — 12.5 MB of generator words for a configs[4] batch — kept by the calling lane thread from call to call:
+    // fresh from the allocator every call they are mapped, faulted in page by page and unmapped again, 5 ms of system time)
+    // (through references: inside the parallel regions below the thread_local names would be the team threads' own)
+    thread_local std::vector<double> kept_log_freqs;
+    thread_local std::vector<uint32_t> kept_generator_words;
+    std::vector<double> & log_freqs = kept_log_freqs;
+    std::vector<uint32_t> & generator_words = kept_generator_words;
+    log_freqs.resize(column_off.back());
+    generator_words.resize(generators.size() * std::mt19937::state_size);
 
     ScopedPhase words_phase("gibbs: chain lengths, log frequencies, generator words");
 
@@ -1379,12 +1555,7 @@ bool estimatePathGroupPosteriorsGibbsOnDevice(std::vector<GroupPosteriors> * gro
         #pragma omp for schedule(dynamic, 16)
         for (size_t g = 0; g < generators.size(); ++g) {
 
-            std::mt19937 ahead = *generators[g];
-
-            for (size_t w = 0; w < std::mt19937::state_size; ++w) {
-
-                generator_words[g * std::mt19937::state_size + w] = ahead();
-            }
+            nextGeneratorOutputs(*generators[g], generator_words.data() + g * std::mt19937::state_size);
         }
     }
 
@@ -1436,8 +1607,7 @@ bool estimatePathGroupPosteriorsGibbsOnDevice(std::vector<GroupPosteriors> * gro
 
             if (view.words_consumed[g] >= std::mt19937::state_size) {
 
-                GeneratorStateWords state_words(view.generator_state + g * std::mt19937::state_size);
-                generators[g]->seed(state_words);
+                setGeneratorBehind(generators[g], view.generator_state + g * std::mt19937::state_size);
 
             } else {
 
@@ -1476,6 +1646,64 @@ bool estimatePathGroupPosteriorsGibbsOnDevice(std::vector<GroupPosteriors> * gro
     return true;
 }
 
+}
+
+int PathEstimator::generatorStateSelfTest(const uint32_t rounds) {
+
+    if (!rawGeneratorAccess()) {
+
+        return 0;
+    }
+
+    std::mt19937 positions(7);
+
+    for (uint32_t round = 0; round < rounds; ++round) {
+
+        std::mt19937 generator(1000 + round);
+        generator.discard(positions() % 3000);
+
+        std::mt19937 reference = generator;
+        GeneratorLayout before, after;
+        std::memcpy(&before, &generator, sizeof(before));
+        const size_t position = before.p;
+
+        std::vector<uint32_t> next(std::mt19937::state_size), states(std::mt19937::state_size);
+        nextGeneratorOutputs(generator, next.data());
+
+        if (generator != reference) {
+
+            return -1;
+        }
+
+        for (size_t w = 0; w < std::mt19937::state_size; ++w) {
+
+            if (next[w] != reference()) {
+
+                return -1;
+            }
+        }
+
+        // the device hands back the untempered values of the last 624 words taken (gibbs_chains.hip), in the order they were
+        // taken: the words of the old array from its position on, then the first words of the refilled one
+        std::memcpy(&after, &reference, sizeof(after));
+
+        for (size_t w = 0; w < std::mt19937::state_size; ++w) {
+
+            states[w] = static_cast<uint32_t>(position + w < std::mt19937::state_size ? before.x[position + w] : after.x[position + w - std::mt19937::state_size]);
+        }
+
+        setGeneratorBehind(&generator, states.data());
+
+        for (size_t w = 0; w < 2 * std::mt19937::state_size; ++w) {
+
+            if (generator() != reference()) {
+
+                return -1;
+            }
+        }
+    }
+
+    return 1;
 }
 
 void PathEstimator::estimatePathGroupPosteriorsGibbs(std::vector<GroupPosteriors> * group_posteriors, const DeviceClusterBatch & cluster_batch, const std::vector<GroupPosteriorProblem> & problems, const uint32_t group_size, const bool normalise, const std::vector<std::mt19937 *> & rngs) const {

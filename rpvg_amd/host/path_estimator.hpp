@@ -64,6 +64,25 @@ struct GroupPosteriorProblem {
         column_counts.emplace_back(count);
     }
 
+    // columns 0 .. n-1, column j = path j alone (the raw path posteriors: src/path_posterior_estimator.cpp:9-31) — three
+    // allocations instead of 3 n appends
+    template <typename CountOf>
+    void singlePathColumns(const uint32_t n, CountOf count_of) {
+
+        column_path_off.resize(static_cast<size_t>(n) + 1);
+        column_path.resize(n);
+        column_counts.resize(n);
+
+        for (uint32_t j = 0; j < n; ++j) {
+
+            column_path_off[j] = j;
+            column_path[j] = j;
+            column_counts[j] = count_of(j);
+        }
+
+        column_path_off[n] = n;
+    }
+
     const uint32_t * columnBegin(const uint32_t column) const { return column_path.data() + column_path_off[column]; }
     const uint32_t * columnEnd(const uint32_t column) const { return column_path.data() + column_path_off[column + 1]; }
 };
@@ -95,6 +114,12 @@ class PathEstimator {
         // every cluster i of the device batch; cluster i draws from rngs->at(i)
         // (rngs may be null for models that consume no random numbers).
         virtual void estimateBatch(std::vector<PathClusterEstimates> * path_cluster_estimates, const DeviceClusterBatch & cluster_batch, std::vector<std::mt19937> * rngs) = 0;
+
+        // The host side of the device sampler reads and writes the state of the callers' std::mt19937 directly where the
+        // library's layout allows it (path_estimator.cpp, GeneratorLayout).  1: it does, and `rounds` generators at random
+        // positions gave the same next 624 outputs and went on with the same words as through the standard's interface;
+        // 0: the portable route is in use; -1: a mismatch (which the first use would have turned into the portable route).
+        static int generatorStateSelfTest(uint32_t rounds);
 
         // Whether estimateBatch() draws random numbers with the current settings (the reference's default
         // `transcripts`, `haplotype-transcripts` and `haplotypes` runs draw none: SURVEY.md F7).
@@ -180,6 +205,7 @@ class PathEstimator {
 
         // src/path_estimator.cpp:315-330
         static std::vector<double> calcPathLogFrequences(const std::vector<uint32_t> & path_counts);
+
 
     private:
 

@@ -47,10 +47,7 @@ std::vector<GroupPosteriorProblem> PathPosteriorEstimator::rawPathProblems(const
         auto & problem = problems[p];
         const auto & paths = path_cluster_estimates.at(problem.cluster).paths;
 
-        for (uint32_t j = 0; j < paths.size(); ++j) {
-
-            problem.addColumn(&j, &j + 1, paths.at(j).source_count);
-        }
+        problem.singlePathColumns(paths.size(), [&](const uint32_t j) { return paths[j].source_count; });
     }
 
     return problems;

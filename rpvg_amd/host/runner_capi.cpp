@@ -246,6 +246,12 @@ int rpvg_amd_host_threads() {
     return rpvg_amd::hostThreads();
 }
 
+// PathEstimator::generatorStateSelfTest (path_estimator.hpp): how the host side of the device sampler reaches the generators' states
+int rpvg_amd_generator_state_check(uint32_t rounds) {
+
+    return rpvg_amd::PathEstimator::generatorStateSelfTest(rounds);
+}
+
 // Uploads the batch to the GPU.  keep_rows != 0 also keeps ReadPathProbabilities
 // objects of every cluster for the per-cluster estimate() mode.
 void * rpvg_amd_batch_prepare(void * engine, const rpvg_cluster_batch * batch, int keep_rows) {

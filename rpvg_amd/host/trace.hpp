@@ -14,6 +14,7 @@
 #include <string>
 
 #include <omp.h>
+#include <time.h>
 
 #include "experiments.hpp"
 
@@ -96,6 +97,22 @@ class PhaseTrace {
             totals()[phase] += seconds;
         }
 
+        // RPVG_AMD_TRACE_CPU (with RPVG_AMD_TRACE): next to a phase's wall time the CPU time the WHOLE PROCESS spent while it was
+        // open ("<phase> [process CPU]": the phase's own threads, its OpenMP team — spinning included — and whoever else ran;
+        // meaningful with one call in flight)
+        static bool cpu() {
+
+            static const bool on = enabled() && (std::getenv("RPVG_AMD_TRACE_CPU") != nullptr);
+            return on;
+        }
+
+        static double processCpuSeconds() {
+
+            timespec ts;
+            clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
+            return static_cast<double>(ts.tv_sec) + 1e-9 * static_cast<double>(ts.tv_nsec);
+        }
+
         // RPVG_AMD_TIMELINE: every phase with its start and end (ms since the first phase of the process)
         // and the OpenMP-independent id of the host thread that ran it — who waited for whom.
         static bool timeline() {
@@ -140,7 +157,7 @@ class ScopedPhase {
 
     public:
 
-        explicit ScopedPhase(const char * name_in) : name(name_in), start(std::chrono::steady_clock::now()) {}
+        explicit ScopedPhase(const char * name_in) : name(name_in), start(std::chrono::steady_clock::now()), cpu_start(PhaseTrace::cpu() ? PhaseTrace::processCpuSeconds() : 0.0) {}
 
         ~ScopedPhase() {
 
@@ -153,6 +170,11 @@ class ScopedPhase {
             if (!stopped && PhaseTrace::enabled()) {
 
                 PhaseTrace::add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count());
+
+                if (PhaseTrace::cpu()) {
+
+                    PhaseTrace::add(std::string(name) + " [process CPU]", PhaseTrace::processCpuSeconds() - cpu_start);
+                }
             }
 
             if (!stopped && PhaseTrace::timeline()) {
@@ -167,6 +189,7 @@ class ScopedPhase {
 
         const char * name;
         const std::chrono::steady_clock::time_point start;
+        const double cpu_start;
         bool stopped = false;
 };
 

@@ -185,6 +185,22 @@ def test_restated_random_streams_equal_libstdcxx():
     assert subprocess.run([binary], capture_output=True, text=True, check=True).stdout.strip() == "ok"
 
 
+def test_generator_states_read_and_written_in_place_equal_the_standard_interface():
+    """The host side of the device sampler takes a generator's next 624 outputs from its state array and sets the state it goes
+    on from (path_estimator.cpp, GeneratorLayout) instead of copying the generator, calling it 624 times and seeding it: the same
+    words both ways on this libstdc++ (300 generators at random positions), and the portable route when asked for."""
+    import subprocess
+    import sys
+    from rpvg_amd import engine
+    lib = engine.lib()
+    lib.rpvg_amd_generator_state_check.restype = C.c_int
+    assert lib.rpvg_amd_generator_state_check(C.c_uint32(300)) == 1
+    code = "import ctypes as C; from rpvg_amd import engine; L = engine.lib(); L.rpvg_amd_generator_state_check.restype = C.c_int; print(L.rpvg_amd_generator_state_check(C.c_uint32(5)))"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, env=dict(os.environ, RPVG_AMD_PORTABLE_GENERATORS="1"),
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.stdout.strip().splitlines()[-1] == "0"
+
+
 @pytest.mark.gpu
 def test_restated_random_streams_equal_the_gpu_box_libstdcxx():
     """The same check on the GPU box, against the libstdc++ the host library there is built with and runs on: the device
