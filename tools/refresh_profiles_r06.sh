@@ -34,9 +34,14 @@ for parts in 1 0.5,0.5 0.34,0.33,0.33; do
 done
 timeout 900 python bench.py --workload c2 --steps 4 --warmup 1 2>$out/bench_c2.err | tail -1 > $out/bench_c2_n1.json; stamp $out/bench_c2_n1.json
 timeout 900 python bench.py --workload s5 --steps 40 --warmup 6 2>$out/bench_s5.err | tail -1 > $out/bench_s5_n1.json; stamp $out/bench_s5_n1.json
+RPVG_HIP_NO_FUSED_DENSE=1 timeout 900 python bench.py --workload c2 --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_c2_n1_two_step_build.json; stamp $out/bench_c2_n1_two_step_build.json
+RPVG_AMD_PORTABLE_GENERATORS=1 RPVG_BENCH_NO_HOST_BOUND=1 RPVG_BENCH_NO_SINGLE=1 timeout 900 python bench.py --workload s5 --steps 40 --warmup 6 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_s5_n1_portable_generators.json; stamp $out/bench_s5_n1_portable_generators.json
+(echo "# tree $commit: configs[4], one resident batch, estimateBatch one call at a time on ONE host lane, OMP_WAIT_POLICY=passive (tools/s5_host_profile.py)"; OMP_WAIT_POLICY=passive RPVG_AMD_SINGLE_LANE=1 RPVG_AMD_TRACE=1 RPVG_AMD_TRACE_CPU=1 timeout 600 python tools/s5_host_profile.py 12) > $out/s5_host_cpu_by_phase.txt 2>/dev/null
+(echo "# the same with libgomp's default wait policy"; RPVG_AMD_SINGLE_LANE=1 timeout 600 python tools/s5_host_profile.py 12 | head -1) >> $out/s5_host_cpu_by_phase.txt 2>/dev/null
 # the drop-in path: teams of 64 and 256, the combiner's slots, every call alone
 for t in 64 256; do timeout 900 python bench.py --workload a1 --team $t --steps 8 2>/dev/null | tail -1 > $out/bench_a1_n1_team_$t.json; stamp $out/bench_a1_n1_team_$t.json; done
 RPVG_AMD_COMBINE_SLOTS=1 timeout 900 python bench.py --workload a1 --team 64 --steps 8 2>/dev/null | tail -1 > $out/bench_a1_n1_team_64_one_slot.json; stamp $out/bench_a1_n1_team_64_one_slot.json
+RPVG_AMD_DEVICE_SOURCE_COLUMNS=1 timeout 900 python bench.py --workload a1 --team 64 --steps 8 2>/dev/null | tail -1 > $out/bench_a1_n1_team_64_device_columns.json; stamp $out/bench_a1_n1_team_64_device_columns.json
 RPVG_AMD_NO_COMBINER=1 timeout 900 python bench.py --workload a1 --team 64 --steps 1 --warmup 1 2>/dev/null | tail -1 > $out/bench_a1_n1_team_64_no_combiner.json; stamp $out/bench_a1_n1_team_64_no_combiner.json
 RPVG_AMD_TRACE=1 timeout 600 python bench.py --workload a1 --team 64 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/a1_phase_totals.txt
 RPVG_AMD_TIMELINE=1 timeout 600 python bench.py --workload a1 --team 64 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 > /dev/null | grep "^\[timeline\]" | grep -v "flatten the cluster" > $out/a1_host_timeline.txt
@@ -77,7 +82,7 @@ timeout 1500 python -m tests.fuzz_parity 200 61000 > $out/general_200_from_61000
 timeout 900 python -m tests.fuzz_parity 60 62000 gibbs > $out/gibbs_60_from_62000.txt 2>&1
 RPVG_FUZZ_TEAM=12 timeout 1500 python -m tests.fuzz_parity 150 63000 > $out/general_150_from_63000_through_estimate_team_of_12.txt 2>&1
 echo $commit > $out/COMMIT
-for f in bench_s3_n1 bench_s3_n1_200_steps bench_s3_n1_120_steps_default bench_s3_n1_120_steps_wide_uploads bench_s3_n1_120_steps_default_again bench_c2_n1 bench_s5_n1 bench_a1_n1_team_64 bench_a1_n1_team_256 bench_a1_n1_team_64_one_slot bench_a1_n1_team_64_no_combiner bench_s3_n1_profiled bench_a1_n1_profiled; do python - <<PY
+for f in bench_c2_n1_two_step_build bench_s5_n1_portable_generators bench_a1_n1_team_64_device_columns bench_s3_n1 bench_s3_n1_200_steps bench_s3_n1_120_steps_default bench_s3_n1_120_steps_wide_uploads bench_s3_n1_120_steps_default_again bench_c2_n1 bench_s5_n1 bench_a1_n1_team_64 bench_a1_n1_team_256 bench_a1_n1_team_64_one_slot bench_a1_n1_team_64_no_combiner bench_s3_n1_profiled bench_a1_n1_profiled; do python - <<PY
 import json
 try:
     d=json.loads(open("$out/$f.json").read())

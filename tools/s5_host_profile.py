@@ -3,11 +3,16 @@
 batch, estimateBatch a few times ONE AT A TIME, every phase of the host layer with its wall time and the CPU time the whole process
 spent meanwhile (RPVG_AMD_TRACE=1 RPVG_AMD_TRACE_CPU=1: teams of OpenMP threads included).
 
-    RPVG_AMD_TRACE=1 RPVG_AMD_TRACE_CPU=1 python tools/s5_host_profile.py [steps] 2> trace.txt
+    OMP_WAIT_POLICY=passive RPVG_AMD_SINGLE_LANE=1 RPVG_AMD_TRACE=1 RPVG_AMD_TRACE_CPU=1 python tools/s5_host_profile.py [steps]
+
+(one host lane: the phases do not overlap each other; the library's trace lines are collected from stderr and printed as one table)
 """
+import collections
 import os
+import re
 import resource
 import sys
+import tempfile
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,12 +42,35 @@ def main():
     prep = eng.prepare(batch)
     for _ in range(2):
         eng.run_raw("haplotypes", params, prep)
+    tracing = bool(os.environ.get("RPVG_AMD_TRACE"))
+    if tracing:  # (the library writes its trace to the process's stderr: into a file for the timed calls)
+        sys.stderr.flush()
+        saved, capture = os.dup(2), tempfile.TemporaryFile(mode="w+b")
+        os.dup2(capture.fileno(), 2)
     th0 = thread_cpu()
     r0, t0 = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
     for _ in range(steps):
         eng.run_raw("haplotypes", params, prep)
     r1, t1 = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
     cpu = (r1.ru_utime + r1.ru_stime) - (r0.ru_utime + r0.ru_stime)
+    if tracing:
+        os.dup2(saved, 2)
+        capture.seek(0)
+        tot, cnt = collections.defaultdict(float), collections.Counter()
+        for line in capture.read().decode(errors="replace").splitlines():
+            m = re.match(r"\[rpvg_amd trace\] (.*?)\s+([\d.]+) ms$", line.rstrip())
+            if m:
+                tot[m.group(1).strip()] += float(m.group(2))
+                cnt[m.group(1).strip()] += 1
+            m = re.match(r"\[rpvg_hip trace\]\s+(.*?)\s+([\d.]+) ms$", line.rstrip())
+            if m:
+                tot["  library: " + m.group(1).strip()] += float(m.group(2))
+                cnt["  library: " + m.group(1).strip()] += 1
+        names = [k for k in tot if not k.endswith("[process CPU]")]
+        print("phase                                                                      ms per call: wall   process CPU meanwhile")
+        for k in sorted(names, key=lambda x: -tot.get(x + " [process CPU]", 0.0)):
+            c = tot.get(k + " [process CPU]")
+            print(f"{k:72s} {tot[k] / steps:8.2f}  " + (f"{c / steps:8.2f}" if c is not None else "       -"))
     print(f"{steps} calls: {1e3 * (t1 - t0) / steps:.2f} ms of wall time and {1e3 * cpu / steps:.2f} ms of CPU time per call")
     th1 = thread_cpu()
     rows = sorted(((th1[t][0] - th0.get(t, (0, 0))[0], th1[t][1] - th0.get(t, (0, 0))[1], t, th1[t][2]) for t in th1), key=lambda r: -(r[0] + r[1]))
