@@ -604,20 +604,27 @@ def run_s3(args, rank, local_rank, world, dist, torch):
                 line["drop_in"] = drop_in_line(args, local_rank)
             except Exception as exc:  # noqa: BLE001
                 line["drop_in"] = dict(error=str(exc))
+            # ... and with a team of 256 (the reference's -t): the callers are blocked on the GPU, not computing, so the calls in flight —
+            # and with them the clusters per batch — are the team's size, not the host's cores (tools/r06_a1_teams.sh: 64 ... 512)
+            try:
+                line["drop_in_team_256"] = drop_in_line(args, local_rank, team=256)
+            except Exception as exc:  # noqa: BLE001
+                line["drop_in_team_256"] = dict(error=str(exc))
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_s3(batch, args.model, params, args.cpu_seconds)
         cpu_value = line["cpu_baseline"].get("value") if isinstance(line["cpu_baseline"], dict) else None
         if cpu_value:
             # (vs_baseline stays null: BASELINE.md holds no published number for this metric — the ratio to the same-run CPU line is its own field)
             line["vs_cpu_baseline"] = line["value"] / cpu_value if line.get("value") else None
-            if isinstance(line.get("drop_in"), dict) and line["drop_in"].get("value"):
-                line["drop_in"]["vs_cpu_baseline"] = line["drop_in"]["value"] / cpu_value
+            for key in ("drop_in", "drop_in_team_256"):
+                if isinstance(line.get(key), dict) and line[key].get("value"):
+                    line[key]["vs_cpu_baseline"] = line[key]["value"] / cpu_value
     return line
 
 
 def drop_in_line(args, local_rank, steps=5, team=64):
     """The reference's own call pattern inside the default run, so that the driver's record carries it: PathEstimator::estimate() once
-    per cluster from an OpenMP team of 64 threads on the configs[2] workload (src/main.cpp:829,976-977) — a short run of the
+    per cluster from an OpenMP team of `team` threads on the configs[2] workload (src/main.cpp:829,976-977) — a short run of the
     --workload a1 bench as a child process (its own engine, its own memory)."""
     import subprocess
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "a1", "--team", str(team), "--steps", str(steps), "--warmup", "2",
