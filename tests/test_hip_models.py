@@ -509,3 +509,18 @@ def test_team_of_threads_calling_estimate_equals_the_batch(engine, model, kw, th
     if not kw:
         ref, _ = pyoracle.run(model, params, batch, 4)
         _compare(team, ref)
+
+
+def test_a_team_larger_than_a_batch_may_be(engine):
+    """More callers than the combiner joins into one batch (256) and many more than the host has cores — the configuration that
+    serves estimate() best, its callers being asleep while their batch runs (profiles/r06/a1_by_team_size.txt): 320 threads over
+    700 clusters, the estimates of every cluster those of estimateBatch() on all of them."""
+    clusters = small_cases.make_batch_clusters(6500, n_clusters=700, with_empty=True)
+    batch = ClusterBatch.from_clusters(clusters)
+    params = make_params()
+    whole, _ = engine.run("haplotype-transcripts", params, engine.prepare(batch))
+    team, _ = engine.run_team("haplotype-transcripts", params, engine.prepare(batch, per_cluster=True), 320)
+    for k, (t, w) in enumerate(zip(team, whole)):
+        assert t.path_group_sets == w.path_group_sets, k
+        assert np.array_equal(t.posteriors, w.posteriors) and np.array_equal(t.abundances, w.abundances), k
+        assert t.noise_count == w.noise_count and t.total_count == w.total_count and t.em_iters == w.em_iters, k
