@@ -1262,7 +1262,7 @@ def run_c2(args, rank, local_rank, world, dist, torch):
     else:
         # Through the estimator class: the cluster is a resident batch (its rows generated on the device), and
         # PathAbundanceEstimator::estimateBatch -> rpvg_hip_em_solve sends its one EM problem to the dense route of the
-        # whole-GPU EM (rpvg_amd/csrc/em_grid.hip): compaction + normalisation of the rows, dense copy, `its` iterations.
+        # whole-GPU EM (rpvg_amd/csrc/em_grid.hip): the rows normalised straight into the dense matrix (fillDenseRowsKernel; RPVG_HIP_NO_FUSED_DENSE=1: compacted CSR, then a dense copy), `its` iterations.
         from rpvg_amd import engine as eng_mod
         from rpvg_amd.batch import make_params
         r0, R, total = 0, R_all, float(R_all)
@@ -1318,7 +1318,7 @@ def run_c2(args, rank, local_rank, world, dist, torch):
         em_iterations_per_step=int(done), mass_conserved=bool(abs(ab.sum() + noise - total) <= 1e-6 * total),
         step_breakdown_ms=dict(streaming_passes=stats["em_dense_ms"] / args.steps, build_and_compaction=stats["build_ms"] / args.steps,
                                note="streaming_passes = HIP-event spans of the iterations' streaming-pass launches; build_and_compaction = the "
-                                    "spans of the kernels in front of them (row compaction + normalisation, dense copy); the rest of a step is "
+                                    "spans of the kernels in front of them (the rows counted and normalised straight into the dense matrix: fillDenseRowsKernel); the rest of a step is "
                                     "the reduce / update / control launches and the host's waits between chunks of iterations"))
     if not args.no_cpu_baseline:
         # reference-shaped CPU EM on a row sample of the same matrix, one core (a single cluster is serial
