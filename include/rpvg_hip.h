@@ -250,6 +250,13 @@ int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, cons
 int rpvg_hip_groups_build_from_sources(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t num_matrices,
                                        const uint32_t * clusters, int32_t normalise, double collapse_precision,
                                        rpvg_hip_groups ** groups_out);
+/* The matrices whose column c is path c of the cluster alone — the raw path posteriors of PathPosteriorEstimator /
+ * PathGroupPosteriorEstimator (src/path_posterior_estimator.cpp:9-31, 35-71: one group per path) — for the listed clusters: the
+ * same matrices as rpvg_hip_groups_build with one single-entry list per path, without the lists crossing the ABI (configs[4]:
+ * 500 000 of them per batch, flattened, copied and uploaded every call). */
+int rpvg_hip_groups_build_single_paths(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t num_matrices,
+                                       const uint32_t * clusters, int32_t normalise, double collapse_precision,
+                                       rpvg_hip_groups ** groups_out);
 void rpvg_hip_groups_free(rpvg_hip_ctx * ctx, rpvg_hip_groups * groups);
 /* What the row collapse of these matrices did (waits for their build; any output may be NULL): matrices that held
  * rows within collapse_precision of each other but not equal up to rounding, whose runs were therefore replayed as

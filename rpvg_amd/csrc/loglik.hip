@@ -873,8 +873,22 @@ __global__ __launch_bounds__(256) void gatherSourceColumnsKernel(const uint32_t 
     for (uint32_t x = threadIdx.x; x < L; x += 256) group_path[p0 + x] = src_col_path[slot0 + x];
 }
 
+// column c of a matrix = path c of its cluster, alone (rpvg_hip_groups_build_single_paths)
+__global__ __launch_bounds__(256) void singlePathColumnsKernel(const uint32_t num_matrices, const uint64_t * __restrict__ group_off,
+                                                               uint64_t * __restrict__ group_path_off, uint32_t * __restrict__ group_path) {
+    const uint32_t m = blockIdx.x;
+    if (m >= num_matrices) return;
+    const uint64_t g0 = group_off[m];
+    const uint32_t G = static_cast<uint32_t>(group_off[m + 1] - g0);
+    if (threadIdx.x == 0 && m == 0) group_path_off[0] = 0;
+    for (uint32_t c = threadIdx.x; c < G; c += 256) {
+        group_path_off[g0 + c + 1] = g0 + c + 1;
+        group_path[g0 + c] = c;
+    }
+}
+
 static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec, bool from_sources,
-                       rpvg_hip_groups ** groups_out);
+                       rpvg_hip_groups ** groups_out, bool single_paths = false);
 
 extern "C" int rpvg_hip_groups_build(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec,
                                      rpvg_hip_groups ** groups_out) {
@@ -917,8 +931,29 @@ extern "C" int rpvg_hip_groups_build_from_sources(rpvg_hip_ctx * ctx, const rpvg
     return buildGroups(ctx, batch, &spec, true, groups_out);
 }
 
+extern "C" int rpvg_hip_groups_build_single_paths(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, uint32_t num_matrices, const uint32_t * clusters,
+                                                  int32_t normalise, double collapse_precision, rpvg_hip_groups ** groups_out) {
+    RPVG_REQUIRE(ctx && batch && groups_out && (clusters || num_matrices == 0), "rpvg_hip_groups_build_single_paths: NULL argument");
+    *groups_out = nullptr;
+    std::vector<uint64_t> group_off(num_matrices + 1, 0);
+    for (uint32_t m = 0; m < num_matrices; ++m) {
+        RPVG_REQUIRE(clusters[m] < batch->num_clusters, "rpvg_hip_groups_build_single_paths: matrix %u refers to cluster %u of %u", m, clusters[m],
+                     batch->num_clusters);
+        group_off[m + 1] = group_off[m] + (batch->h_cluster_path_off[clusters[m] + 1] - batch->h_cluster_path_off[clusters[m]]);
+    }
+    rpvg_hip_group_spec spec;
+    spec.num_matrices = num_matrices;
+    spec.cluster = clusters;
+    spec.group_off = group_off.data();
+    spec.group_path_off = group_off.data();  // (per MATRIX, as from the batch's columns: a column is one list entry)
+    spec.group_path = nullptr;
+    spec.normalise = normalise;
+    spec.collapse_precision = collapse_precision;
+    return buildGroups(ctx, batch, &spec, false, groups_out, true);
+}
+
 static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const rpvg_hip_group_spec * spec, const bool from_sources,
-                       rpvg_hip_groups ** groups_out) {
+                       rpvg_hip_groups ** groups_out, const bool single_paths) {
     const uint32_t M = spec->num_matrices;
     RPVG_REQUIRE(spec->collapse_precision >= 0 && spec->collapse_precision < 1, "rpvg_hip_groups_build: collapse_precision outside [0, 1)");
     RPVG_REQUIRE(spec->collapse_precision == 0 || spec->normalise,
@@ -975,6 +1010,7 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
         {
             uint64_t longest = 0;
             if (from_sources) longest = batch->h_src_max_col_paths[k];
+            else if (single_paths) longest = 1;
             else for (uint64_t c = g0; c < g1; ++c) longest = std::max<uint64_t>(longest, spec->group_path_off[c + 1] - spec->group_path_off[c]);
             g->h_max_col_paths.push_back(static_cast<uint32_t>(std::min<uint64_t>(longest, 0xffffffffu)));
             g->h_num_paths.push_back(static_cast<uint32_t>(N));
@@ -1035,7 +1071,7 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
         return RPVG_HIP_OK;
     }
     const uint64_t num_columns = spec->group_off[M];
-    const uint64_t num_incidences = from_sources ? spec->group_path_off[M] : spec->group_path_off[num_columns];
+    const uint64_t num_incidences = (from_sources || single_paths) ? spec->group_path_off[M] : spec->group_path_off[num_columns];
 
     scope_host.reset();
     HostScope scope_dev("groups_build: upload + kernels + sync");
@@ -1074,6 +1110,8 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
     pack.add(d_group_off, spec->group_off, M + 1);
     if (from_sources) {
         pack.add(tmp->first_path, spec->group_path_off, M + 1);
+    } else if (single_paths) {
+        // (nothing: the lists are written on the device)
     } else {
         pack.add(d_group_path_off, spec->group_path_off, num_columns + 1);
         pack.add(d_group_path, spec->group_path, num_incidences);
@@ -1124,6 +1162,14 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
             ok(hipGetLastError());
         }
         g->d_column_counts = tmp->column_counts.ptr;
+    }
+    if (single_paths) {
+        ok(d_group_path_off.alloc(num_columns + 1));
+        ok(d_group_path.alloc(num_incidences));
+        if (e == hipSuccess) {
+            singlePathColumnsKernel<<<dim3(M), dim3(256), 0, st>>>(M, d_group_off.ptr, d_group_path_off.ptr, d_group_path.ptr);
+            ok(hipGetLastError());
+        }
     }
     g->d_group_off = d_group_off.ptr;
     g->d_group_path_off = d_group_path_off.ptr;

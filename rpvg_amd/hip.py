@@ -31,7 +31,7 @@ EXPORTS = [
     "rpvg_hip_read_rows_view", "rpvg_hip_read_rows_sizes", "rpvg_hip_read_rows_free", "rpvg_hip_path_clusters", "rpvg_hip_debug_log",
     "rpvg_hip_nested_subset_em", "rpvg_hip_subset_em_get", "rpvg_hip_subset_em_free",
     "rpvg_hip_batch_cluster_totals", "rpvg_hip_batch_has_source_columns", "rpvg_hip_batch_source_columns_sizes",
-    "rpvg_hip_batch_source_columns_get", "rpvg_hip_groups_build_from_sources", "rpvg_hip_batch_upload_begin", "rpvg_hip_batch_upload_finish", "rpvg_hip_create_with_streams",
+    "rpvg_hip_batch_source_columns_get", "rpvg_hip_groups_build_from_sources", "rpvg_hip_groups_build_single_paths", "rpvg_hip_batch_upload_begin", "rpvg_hip_batch_upload_finish", "rpvg_hip_create_with_streams",
     "rpvg_hip_batch_upload_finish_queue", "rpvg_hip_batch_upload_finish_wait",
     "rpvg_hip_batch_upload_segments", "rpvg_hip_pinned_alloc", "rpvg_hip_pinned_free", "rpvg_hip_thread_wait_spin_us",
 ]
@@ -351,6 +351,12 @@ class DeviceGroups:
         self.ctx = ctx
         self.batch = batch
         cl = np.ascontiguousarray(clusters, dtype=np.uint32)
+        if groups is None:  # column c of a matrix = path c of its cluster alone: rpvg_hip_groups_build_single_paths
+            self.handle = C.c_void_p()
+            _check(lib().rpvg_hip_groups_build_single_paths(ctx.handle, batch.handle, C.c_uint32(len(cl)), C.c_void_p(cl.ctypes.data),
+                                                            C.c_int32(1 if normalise else 0), C.c_double(float(collapse_precision)),
+                                                            C.byref(self.handle)), "rpvg_hip_groups_build_single_paths")
+            return
         goff, gpoff, gp = [0], [0], []
         for cols in groups:
             for paths in cols:

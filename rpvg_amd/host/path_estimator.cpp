@@ -42,6 +42,28 @@ class GroupMatrices {
 
             ScopedPhase phase("posteriors: group matrices build");
 
+            // every problem a list of single-path columns (the raw path posteriors): no list is flattened or copied
+            bool all_single_paths = !problems.empty();
+
+            for (auto & problem: problems) {
+
+                all_single_paths = all_single_paths && problem.single_paths;
+            }
+
+            if (all_single_paths) {
+
+                std::vector<uint32_t> clusters(problems.size());
+
+                for (size_t i = 0; i < problems.size(); ++i) {
+
+                    clusters[i] = problems[i].cluster;
+                    assert(problems[i].numColumns() == cluster_batch.numPaths(problems[i].cluster));
+                }
+
+                HipEngine::check(rpvg_hip_groups_build_single_paths(engine->ctx(), cluster_batch.handle(), clusters.size(), clusters.data(), normalise, normalise ? prob_precision : 0.0, &groups), "rpvg_hip_groups_build_single_paths");
+                return;
+            }
+
             // flat spec arrays: offsets per problem first (cheap, serial), then every problem copies its columns (the
             // incidences of a batch are megabytes, and the GPU waits for this on the first lane)
             std::vector<uint32_t> clusters(problems.size());
@@ -51,7 +73,7 @@ class GroupMatrices {
             for (size_t i = 0; i < problems.size(); ++i) {
 
                 group_off[i + 1] = group_off[i] + problems[i].numColumns();
-                first_path[i + 1] = first_path[i] + problems[i].column_path.size();
+                first_path[i + 1] = first_path[i] + (problems[i].single_paths ? problems[i].numColumns() : problems[i].column_path.size());
             }
 
             // (kept by the calling thread from call to call, as the generator words of the device sampler below)
@@ -69,6 +91,17 @@ class GroupMatrices {
 
                 const auto & problem = problems[i];
                 clusters[i] = problem.cluster;
+
+                if (problem.single_paths) {  // (among problems with lists: the implied ones written out)
+
+                    for (uint32_t column = 1; column <= problem.numColumns(); ++column) {
+
+                        group_path_off[group_off[i] + column] = first_path[i] + column;
+                        group_path[first_path[i] + column - 1] = column - 1;
+                    }
+
+                    continue;
+                }
 
                 for (uint32_t column = 1; column <= problem.numColumns(); ++column) {
 

@@ -64,23 +64,43 @@ struct GroupPosteriorProblem {
         column_counts.emplace_back(count);
     }
 
-    // columns 0 .. n-1, column j = path j alone (the raw path posteriors: src/path_posterior_estimator.cpp:9-31) — three
-    // allocations instead of 3 n appends
+    // columns 0 .. n-1, column j = path j alone (the raw path posteriors: src/path_posterior_estimator.cpp:9-31): only the
+    // counts are kept — the lists 0 | 1 | 2 ... are implied (single_paths), the device writes them itself
+    // (rpvg_hip_groups_build_single_paths), and nothing on the host walks the lists of such a problem
+    bool single_paths = false;
+
     template <typename CountOf>
     void singlePathColumns(const uint32_t n, CountOf count_of) {
 
-        column_path_off.resize(static_cast<size_t>(n) + 1);
-        column_path.resize(n);
+        single_paths = true;
+        column_path_off.clear();
+        column_path.clear();
         column_counts.resize(n);
 
         for (uint32_t j = 0; j < n; ++j) {
 
-            column_path_off[j] = j;
-            column_path[j] = j;
             column_counts[j] = count_of(j);
         }
+    }
 
-        column_path_off[n] = n;
+    // the implied lists written out (a caller that mixes such problems with others)
+    void materialiseSinglePaths() {
+
+        if (single_paths) {
+
+            const uint32_t n = column_counts.size();
+            column_path_off.resize(static_cast<size_t>(n) + 1);
+            column_path.resize(n);
+
+            for (uint32_t j = 0; j < n; ++j) {
+
+                column_path_off[j] = j;
+                column_path[j] = j;
+            }
+
+            column_path_off[n] = n;
+            single_paths = false;
+        }
     }
 
     const uint32_t * columnBegin(const uint32_t column) const { return column_path.data() + column_path_off[column]; }

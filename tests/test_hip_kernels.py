@@ -439,6 +439,33 @@ def test_group_conditionals_equal_member_list_requests(hip_ctx, width):
     assert small_cases.rel_close(got[0], want0, rel=1e-11, floor=1e-9)
 
 
+@pytest.mark.parametrize("normalise", [False, True])
+def test_single_path_matrices_equal_the_matrices_of_listed_single_path_columns(hip_ctx, normalise):
+    """rpvg_hip_groups_build_single_paths: the matrices of the raw path posteriors (src/path_posterior_estimator.cpp:9-31, 35-71: a
+    group per path) without their column lists crossing the ABI — the same log-likelihoods and conditionals, bit for bit, as from
+    rpvg_hip_groups_build with one single-entry list per path; clusters of a few and of thousands of paths, listed twice and out of order."""
+    from rpvg_amd import synth
+    small = ClusterBatch.from_clusters(small_cases.make_batch_clusters(505, n_clusters=9, with_empty=False))
+    wide = synth.generate(seed=12, num_clusters=3, total_paths=3000, total_reads=6000, max_cluster_paths=2500)
+    batch = ClusterBatch.concat([small, wide])
+    dev = hip_ctx.upload(batch)
+    mats = [k for k in range(batch.num_clusters) if batch.cluster_row_off[k + 1] > batch.cluster_row_off[k]]
+    mats = mats[::-1] + mats[:2]
+    num_cols = [int(batch.cluster_path_off[k + 1] - batch.cluster_path_off[k]) for k in mats]
+    listed = hip_ctx.groups(dev, mats, [[[p] for p in range(n)] for n in num_cols], normalise)
+    implied = hip_ctx.groups(dev, mats, None, normalise)
+    rng = np.random.default_rng(5)
+    req_m = [int(m) for m in rng.integers(0, len(mats), size=40)]
+    pairs = [[int(rng.integers(0, num_cols[m])), int(rng.integers(0, num_cols[m]))] for m in req_m]
+    assert np.array_equal(listed.loglik(req_m, pairs, 2.0), implied.loglik(req_m, pairs, 2.0))
+    singles = [[p[0]] for p in pairs]
+    assert np.array_equal(listed.loglik(req_m, singles, 1.0), implied.loglik(req_m, singles, 1.0))
+    others = [[p[0]] for p in pairs]
+    for a, b in zip(listed.conditionals(req_m, others, 2, 2.0, num_cols), implied.conditionals(req_m, others, 2, 2.0, num_cols)):
+        assert np.array_equal(a, b)
+    dev.free()
+
+
 def test_stats_report_kernel_time(hip_ctx):
     clusters = small_cases.make_batch_clusters(9, n_clusters=4, with_empty=False)
     dev = hip_ctx.upload(ClusterBatch.from_clusters(clusters))
