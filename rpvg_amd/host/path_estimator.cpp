@@ -1567,7 +1567,7 @@ bool estimatePathGroupPosteriorsGibbsOnDevice(std::vector<GroupPosteriors> * gro
 
     ScopedPhase words_phase("gibbs: chain lengths, log frequencies, generator words");
 
-    #pragma omp parallel num_threads(hostThreads())
+    #pragma omp parallel num_threads(shortLoopThreads())
     {
         #pragma omp for schedule(dynamic, 16) nowait
         for (size_t i = 0; i < num_problems; ++i) {
@@ -1632,7 +1632,7 @@ bool estimatePathGroupPosteriorsGibbsOnDevice(std::vector<GroupPosteriors> * gro
 
     ScopedPhase results_phase("gibbs: generators moved on, posteriors");
 
-    #pragma omp parallel num_threads(hostThreads())
+    #pragma omp parallel num_threads(shortLoopThreads())
     {
         // the generators end where the reference's sampler leaves them
         #pragma omp for schedule(dynamic, 16) nowait

@@ -41,7 +41,7 @@ std::vector<GroupPosteriorProblem> PathPosteriorEstimator::rawPathProblems(const
         problems.back().cluster = i;
     }
 
-    #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
+    #pragma omp parallel for schedule(dynamic, 16) num_threads(shortLoopThreads())
     for (size_t p = 0; p < problems.size(); ++p) {
 
         auto & problem = problems[p];
@@ -95,7 +95,7 @@ void PathGroupPosteriorEstimator::estimateBatch(std::vector<PathClusterEstimates
     {
         ScopedPhase phase("posteriors: reset estimates");
 
-        #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
+        #pragma omp parallel for schedule(dynamic, 16) num_threads(shortLoopThreads())
         for (size_t i = 0; i < path_cluster_estimates->size(); ++i) {
 
             (*path_cluster_estimates)[i].resetEstimates(0, 0);
@@ -137,7 +137,7 @@ void PathGroupPosteriorEstimator::estimateClusters(std::vector<PathClusterEstima
 
     ScopedPhase pack_phase("posteriors: fill estimates");
 
-    #pragma omp parallel for schedule(dynamic, 16) num_threads(hostThreads())
+    #pragma omp parallel for schedule(dynamic, 16) num_threads(shortLoopThreads())
     for (size_t i = 0; i < problems.size(); ++i) {
 
         auto & estimates = path_cluster_estimates->at(problems.at(i).cluster);

@@ -81,6 +81,15 @@ inline int hostThreads() {
     return threads;
 }
 
+// The team of a loop that is over in a fraction of a millisecond whatever its size (filling a few thousand small containers, 5 000
+// generator states): waking a whole team for it costs more CPU time than the loop.  A quarter of the team, at least two threads:
+// configs[4] through the pipeline (four estimator threads, eight host threads each), five such loops per batch — 41-46 ms of CPU per
+// batch with the whole teams, 33-36 with two threads each, 29 with one, the step unchanged (12.1-13.4 / 12.6-12.7 / 13.1 ms).
+inline int shortLoopThreads() {
+
+    return std::min(hostThreads(), std::max(2, hostThreads() / 4));
+}
+
 class PhaseTrace {
 
     public:
