@@ -53,9 +53,15 @@ def load_pmc(name):
     if not os.path.exists(path):
         return None
     try:
-        return json.load(open(path))
+        record = json.load(open(path))
     except (OSError, ValueError):
         return None
+    if isinstance(record, dict):  # (where the record lies, whatever it says of itself)
+        made_by = str(record.get("source", "rocprofv3 --pmc passes"))
+        if "(" in made_by and made_by.endswith(")"):
+            made_by = made_by[made_by.rindex("(") + 1:-1]
+        record["source"] = os.path.relpath(path, ROOT) + " (" + made_by + ")"
+    return record
 
 
 def parse_args():
