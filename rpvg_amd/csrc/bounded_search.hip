@@ -590,7 +590,8 @@ struct PairTileWork {
     double * part_pair;
     unsigned long long * log_evals;
 #ifdef RPVG_HIP_EXPERIMENTS
-    uint32_t debug_skip;  // timing experiments (RPVG_HIP_PAIR_DEBUG): 1 no count-1 rows, 2 no mid rows, 4 no other rows, 8 no marginals
+    uint32_t debug_skip;  // timing experiments (RPVG_HIP_PAIR_DEBUG): 1 no count-1 rows, 2 no mid rows, 4 no other rows, 8 no marginals, 16 no loads,
+                          // 32 no epilogue, 64 the prologue alone, 128 the dispatch of the grid alone
 #endif
 };
 
@@ -743,6 +744,7 @@ __device__ __forceinline__ void pairTile2Item(const PairTileWork & w, double * c
     };
 
     const uint32_t blocks = (n + sub_rows - 1) / sub_rows;
+    if (RPVG_PAIR_DEBUG_SKIP(w) & 64u) return;  // (timing: the prologue alone)
     if (RPVG_PAIR_DEBUG_SKIP(w) & 16u) {  // (timing without the loads: finite values everywhere)
         for (uint32_t i = threadIdx.x; i < 2 * kTile2BufferDoubles; i += kTileBlock) tile_lds[i] = 0.25;
     }
@@ -846,6 +848,7 @@ __device__ __forceinline__ void pairTile2Item(const PairTileWork & w, double * c
     }
     // The sums of a chunk: one per pair and column.  Slices add theirs up in LDS, in the order of the slices (the staged rows
     // are done with, no load is in flight), so that the resolving workgroup reads one part per chunk.
+    if (RPVG_PAIR_DEBUG_SKIP(w) & 32u) return;  // (timing: without the epilogue)
     double * const out_pairs = w.part_pair + w.pair_part_off[m] + static_cast<uint64_t>(chunk) * G * G;
     double * const out_columns = w.part_marginal + w.col_part_off[m] + static_cast<uint64_t>(chunk) * G;
     double * const sums = tile_lds;         // [S][tcount][16], then
@@ -906,6 +909,7 @@ __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(3)))
     if (item >= w.count) return;
     const uint32_t m = w.item_matrix[item], chunk = w.item_chunk[item];
     const uint32_t t0 = w.item_tiles[item] & 0xffffu, tcount = (w.item_tiles[item] >> 16) + 1;  // tiles [t0, t0 + tcount)
+    if (RPVG_PAIR_DEBUG_SKIP(w) & 128u) return;  // (timing: the dispatch of the grid alone)
     loadLogTable(lt);  // visible after the first barrier of the item
     const uint32_t T = tileColumns(w.mat_cols[m]);
     const uint32_t c_lo = 4 * tileRowOfTile(t0, T), ncols = 4 * T - c_lo;  // columns the item's tiles touch: [c_lo, 4 T)
