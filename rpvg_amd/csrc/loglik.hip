@@ -535,6 +535,33 @@ __global__ __launch_bounds__(256) void groupsBuildMaskKernel(const MaskBuildArgs
     }
 }
 
+// ---- every column one path of its own, values as they are (rpvg_hip_groups_build_single_paths without normalisation: the raw path
+// posteriors of configs[4]) ------------------------------------------------------------------------------------------------------
+// The general kernels ask, cell by cell, which entries of the row lie in the column's set: columns x entries bit tests per row, for
+// matrices of up to thousands of columns (groupsBuildMaskKernel: 5.1 ms per lane of a configs[4] batch, a sixth of the batch's kernel
+// time).  Here a cell is an entry or nothing: the lane zeroes its row column after column (the lanes of a wave write 64 neighbouring
+// doubles of a column) and stores its entries where they belong — the same values, the same row maxima.  A wave per (matrix, 64 rows).
+__global__ __launch_bounds__(256) void groupsBuildSinglePathKernel(const MaskBuildArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (item >= a.num_items) return;
+    const uint32_t m = a.item_matrix[item];
+    const uint64_t R = a.mat_rows[m], r0 = a.mat_row0[m], row_off = a.mat_row_off[m];
+    const uint32_t G = a.mat_cols[m];
+    double * const M = a.values + a.mat_val_off[m];
+    const uint64_t i = static_cast<uint64_t>(a.item_chunk[item]) * kMaskRows + lane;
+    if (i >= R) return;
+    const uint64_t r = r0 + a.row_perm[row_off + i];
+    for (uint32_t c = 0; c < G; ++c) M[static_cast<uint64_t>(c) * R + i] = 0.0;
+    double mx = 0.0;
+    for (uint64_t e = a.row_ent_off[r]; e < a.row_ent_off[r + 1]; ++e) {  // (behind the zeros of the same lane)
+        const double value = a.ent_prob[e];
+        M[static_cast<uint64_t>(a.ent_path[e]) * R + i] = value;
+        mx = fmax(mx, value);
+    }
+    a.rowmax[row_off + i] = mx;
+}
+
 // ---- matrices of up to 64 columns: the columns of a path as ONE word (round 5) ---------------------------------------------
 //
 // With several batches in flight the GPU is busy throughout, and groupsBuildMaskKernel is a quarter of what its SIMDs issue per
@@ -985,6 +1012,8 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
     const char * masks_env = std::getenv("RPVG_HIP_BUILD_MASKS");
     const bool build_masks = masks_env ? std::atoi(masks_env) != 0 : true;
     const bool build_words = masks_env ? std::atoi(masks_env) >= 2 : true;
+    // single-path columns, values as they are: one kernel for every width (RPVG_HIP_NO_DIRECT_BUILD=1: the general kernels — the tests take both)
+    const bool direct = single_paths && !spec->normalise && !std::getenv("RPVG_HIP_NO_DIRECT_BUILD");
     for (uint32_t m = 0; m < M; ++m) {
         const uint32_t k = spec->cluster[m];
         if (k >= batch->num_clusters) {
@@ -1025,6 +1054,13 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
         row_total += R;
         inc_total += N + 1;
         const uint64_t mask_words = (N + 63) / 64;
+        if (direct) {  // (groupsBuildSinglePathKernel: the items of the mask kernel, no masks)
+            for (uint64_t c = 0; c * kMaskRows < R; ++c) {
+                mask_matrix.push_back(m);
+                mask_chunk.push_back(static_cast<uint32_t>(c));
+            }
+            continue;
+        }
         if (build_words && cols[m] <= kWordMaxColumns) {
             word_off[m] = word_total;
             word_total += N;
@@ -1236,7 +1272,12 @@ static int buildGroups(rpvg_hip_ctx * ctx, const rpvg_hip_batch * batch, const r
             ma.collapse_row = g->collapse_row.ptr;
             ma.collapse_mask = g->collapse_mask.ptr;
         }
-        if (!mask_matrix.empty()) {
+        if (!mask_matrix.empty() && direct) {
+            ma.num_items = static_cast<uint32_t>(mask_matrix.size());
+            ma.item_matrix = tmp->mask_matrix.ptr;
+            ma.item_chunk = tmp->mask_chunk.ptr;
+            groupsBuildSinglePathKernel<<<dim3((ma.num_items + 3) / 4), dim3(256), 0, st>>>(ma);
+        } else if (!mask_matrix.empty()) {
             columnMaskKernel<<<dim3(col_blocks), dim3(256), 0, st>>>(M, num_columns, d_group_off.ptr, d_group_path_off.ptr, d_group_path.ptr,
                                                                     d_num_paths.ptr, tmp->mask_off.ptr, tmp->masks.ptr, d_error.ptr);
             ma.num_items = static_cast<uint32_t>(mask_matrix.size());

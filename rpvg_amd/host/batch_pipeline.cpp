@@ -9,15 +9,18 @@
 
 namespace rpvg_amd {
 
-static int defaultWorkers() {
+// Four batches side by side; six where the posteriors are sampled (--use-hap-gibbs): the device sampler is driven in chunks of rounds
+// with a look at its progress between them, and a batch spends more of its time waiting for that than the EM models' batches do
+// (configs[4]: 10.1 against 11.6-11.8 ms per batch, 16.4 with eight; configs[2]: 4.3-4.5 with four, five or six).
+static int defaultWorkers(const rpvg_params & params) {
 
     const char * env = std::getenv("RPVG_AMD_PIPELINE_WORKERS");
-    return env ? std::max(1, std::min(8, std::atoi(env))) : 4;
+    return env ? std::max(1, std::min(8, std::atoi(env))) : (params.use_hap_gibbs ? 6 : 4);
 }
 
 BatchPipeline::BatchPipeline(const int device_in, const std::string & model_in, const rpvg_params & params_in, const int workers) : device(device_in), model(model_in), params(params_in), num_resident(0), num_unfinished(0), stopping(false), first_error(nullptr), upload_seconds(0), finish_seconds(0), estimate_seconds(0), wait_for_batch_seconds(0), upload_batches(0), stats_epoch(std::chrono::steady_clock::now()) {
 
-    const int num_workers = workers > 0 ? std::min(workers, 8) : defaultWorkers();
+    const int num_workers = workers > 0 ? std::min(workers, 8) : defaultWorkers(params_in);
 
     // (engines first, on the calling thread: a failure — no GPU — is the constructor's)
     // (two uploaders: the copies of one batch run while the other's kernels, wait and bookkeeping do — the link stays busy)

@@ -45,7 +45,7 @@ class BatchPipeline {
 
     public:
 
-        // workers: batches estimated side by side; 0 = the default (RPVG_AMD_PIPELINE_WORKERS, else 4)
+        // workers: batches estimated side by side; 0 = the default (RPVG_AMD_PIPELINE_WORKERS, else 4 — 6 with --use-hap-gibbs)
         BatchPipeline(const int device, const std::string & model, const rpvg_params & params, const int workers = 0);
         ~BatchPipeline();
 
