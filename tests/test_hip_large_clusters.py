@@ -134,7 +134,10 @@ def test_fused_dense_build_equals_the_csr_and_the_copy(monkeypatch):
     all0, all1 = list(range(300)), list(range(400))
     part0 = sorted(int(x) for x in rng.choice(300, size=170, replace=False))
     part1 = sorted(int(x) for x in rng.choice(400, size=220, replace=False))
-    problems = [(0, all0), (0, part0), (1, all1), (1, part1), (2, list(range(int(batch.cluster_path_off[3] - batch.cluster_path_off[2]))))]
+    part2 = sorted(int(x) for x in rng.choice(300, size=200, replace=False))
+    part3 = sorted(int(x) for x in rng.choice(400, size=260, replace=False))
+    # (six problems of the dense route: four get their matrices from the compaction, the other two the two-step way, in one solve)
+    problems = [(0, all0), (0, part0), (1, all1), (1, part1), (0, part2), (1, part3), (2, list(range(int(batch.cluster_path_off[3] - batch.cluster_path_off[2]))))]
     ctx = hip.Context(0)
     dev = ctx.upload(batch)
     try:
@@ -148,8 +151,8 @@ def test_fused_dense_build_equals_the_csr_and_the_copy(monkeypatch):
             out[fused] = ctx.em_solve(dev, [k for k, _ in problems], [c for _, c in problems], max_em_its=25)
             out[fused] += (ctx.stats(),)
         a, b = out[True], out[False]
-        assert a[4]["em_dense_launches"] == b[4]["em_dense_launches"] == 100     # four problems on the dense route, 25 iterations each
-        assert b[4]["build_launches"] - a[4]["build_launches"] == 3             # ... four copy kernels against one launch that writes the four matrices
+        assert a[4]["em_dense_launches"] == b[4]["em_dense_launches"] == 150     # six problems on the dense route, 25 iterations each
+        assert b[4]["build_launches"] - a[4]["build_launches"] == 3             # ... six copy kernels against two and the launch that writes four matrices
         assert np.array_equal(a[3], b[3]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         for x, y in zip(a[0], b[0]):
             assert np.array_equal(x, y)
